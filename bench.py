@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — the driver's measurement contract.
+
+  python bench.py --gpus N --steps K --warmup W          (N = 1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Metric (BASELINE.json): Mvoxels/s of TSDF integrate (voxel read-modify-write
+visits per second), config "Chisel TSDF 5 cm / 5 m, 640x480 RGB-D" on a seeded
+synthetic room.  One *step* = one call of
+plvs_hip_tsdf_chisel_integrate_batch_dev over a batch of `--batch` keyframes
+(76 800 camera-frame points each) that are already resident in HBM.
+
+Multi-GPU (N > 1): the voxel-chunk hash is sharded, owner(chunk) =
+ChunkHasher(id) mod N; every rank holds the same clouds, applies only the
+visits of its own chunks, and the per-step lists of updated chunk ids are
+all-gathered over RCCL.  Total work is fixed as N grows -> "strong" scaling.
+
+The JSON line also carries the front-end pieces measured so far (Hamming k=2
+matching) under "frontend", `roofline` (algorithmic bytes of SURVEY §8d over
+the measured GPU time of the integrate pipeline) and `cpu_baseline` (the CPU
+oracle timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=25, help="keyframes per step")
+    ap.add_argument("--resolution", type=float, default=0.05)
+    ap.add_argument("--max-depth", type=float, default=5.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-frontend", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from plvs_amd import _lib
+    from plvs_amd.synth_scene import make_keyframes
+    from plvs_amd.tsdf import TsdfChisel
+
+    # ---------------------------------------------------------------- inputs
+    n_poses = 100                                    # 100 poses, 3.6 deg yaw step
+    total_steps = args.warmup + args.steps
+    kfs = make_keyframes(n_poses, max_depth=args.max_depth, seed=0)
+    batches = []
+    for s in range(total_steps):
+        sel = [kfs[(s * args.batch + j) % n_poses] for j in range(args.batch)]
+        xyz = torch.from_numpy(np.concatenate([k["xyz"] for k in sel])).cuda()
+        rgb = torch.from_numpy(np.concatenate([k["rgb"] for k in sel])).cuda()
+        kfid = torch.from_numpy(np.concatenate([k["kfid"] for k in sel]).astype(np.int32)).cuda()
+        Twc = torch.from_numpy(np.stack([k["Twc"] for k in sel])).cuda()
+        offsets = np.cumsum([0] + [k["xyz"].shape[0] for k in sel]).astype(np.int32)
+        batches.append((xyz, rgb, kfid, offsets, Twc))
+
+    tsdf = TsdfChisel(args.resolution, max_chunks=16384, shard_rank=rank, shard_count=world)
+    upd_cap = 8192
+    d_upd = torch.zeros((upd_cap, 3), dtype=torch.int32, device="cuda")
+    d_cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    if world > 1:
+        g_upd = [torch.zeros_like(d_upd) for _ in range(world)]
+        g_cnt = [torch.zeros_like(d_cnt) for _ in range(world)]
+
+    def step(b):
+        xyz, rgb, kfid, offsets, Twc = b
+        tsdf.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
+        st = tsdf.last_stats()
+        if world > 1:      # the path's one real exchange: updated block lists
+            n = tsdf.updated_chunk_ids_dev(d_upd)
+            d_cnt.fill_(min(n, upd_cap))
+            dist.all_gather(g_cnt, d_cnt)
+            dist.all_gather(g_upd, d_upd)
+        return st
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        step(batches[s])
+    tsdf.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    visits = 0
+    points = 0
+    for s in range(args.warmup, total_steps):
+        st = step(batches[s])
+        visits += st["visits"]
+        points += st["points"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stage_ms, calls = tsdf.stage_ms()
+    tsdf.set_profiling(False)
+
+    # max over ranks of the elapsed time, sum over ranks of the visits
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        v = torch.tensor([visits], dtype=torch.int64, device="cuda")
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        visits_total = int(v.item())
+    else:
+        visits_total = visits
+
+    result = None
+    if rank == 0:
+        mvox = visits_total / elapsed / 1e6
+        # ------------------------------------------------------------ roofline
+        # Algorithmic bytes: 32 B per voxel visit (16 B read + 16 B
+        # written of logical payload) + 28 B per point, for what THIS rank applied.
+        alg_bytes = 32.0 * visits + 28.0 * points
+        gpu_ms = sum(stage_ms.values())
+        dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None
+        achieved = alg_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else 0.0
+        roofline = {
+            "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(achieved / 8000.0, 5), "traffic": None,
+            "kernel": "tsdf_chisel integrate pipeline (" + ", ".join(stage_ms) + ")",
+            "ms_per_launch": round(gpu_ms / max(calls, 1), 4),
+            "stage_ms_per_launch": {k: round(v / max(calls, 1), 4) for k, v in stage_ms.items()},
+            "dominant_stage": dominant,
+            "algorithmic_bytes_per_launch": alg_bytes / max(calls, 1),
+        }
+        result = {
+            "metric": "Mvoxels/sec TSDF integrate (chisel 5 cm / 5 m, 640x480 RGB-D)",
+            "value": round(mvox, 2), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[2] stand-in: synthetic room 6x4x3 m, camera circle r=1 m, "
+                                   "Chisel TSDF 5 cm / 5 m, 76800-point keyframes",
+                       "resolution": args.resolution, "max_depth": args.max_depth,
+                       "keyframes_per_step": args.batch, "points_per_step": int(points // args.steps),
+                       "visits_per_step": int(visits_total // args.steps),
+                       "parallelism": f"chunk-hash shard x{world}"},
+            "roofline": roofline,
+        }
+
+    # ------------------------------------------------- front end (N = 1 only)
+    if rank == 0 and world == 1 and not args.no_frontend:
+        from plvs_amd.matcher import knn2_raw
+        rng = np.random.default_rng(1)
+        q = torch.from_numpy(rng.integers(0, 256, (2000, 32), dtype=np.uint8)).cuda()
+        t = torch.from_numpy(rng.integers(0, 256, (2000, 32), dtype=np.uint8)).cuda()
+        fe = {}
+        for name, rule in (("orb_bf_2000x2000", _lib.TIE_LOWEST_INDEX), ("lbd_mih_2000x2000", _lib.TIE_MIH)):
+            for _ in range(5):
+                knn2_raw(q, t, None, rule)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                knn2_raw(q, t, None, rule)
+            e1.record()
+            torch.cuda.synchronize()
+            fe[name + "_us"] = round(e0.elapsed_time(e1) / 50 * 1e3, 2)
+        result["frontend"] = {"hamming_knn2": fe, "note": "ORB/LBD extraction kernels not timed yet"}
+
+    # -------------------------------------------------- CPU baseline (rank 0)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from tests import oracle_lib
+        oracle = oracle_lib.load()
+        ora = oracle.chisel(args.resolution)
+        nb = 400
+        t0 = time.perf_counter()
+        cv = 0
+        for k in (kfs[i % n_poses] for i in range(nb)):
+            ora.integrate(k["xyz"], k["rgb"], k["kfid"], k["Twc"])
+            cv += ora.last_visits()
+        ct = time.perf_counter() - t0
+        result["cpu_baseline"] = {
+            "value": round(cv / ct / 1e6, 3), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/tsdf_chisel.c (sequential, as the reference loop is) on the first {nb} "
+                      f"keyframes of the same stream, {ct:.1f} s, host has {os.cpu_count()} cores",
+        }
+
+    if rank == 0:
+        print(json.dumps(result))
+    tsdf.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

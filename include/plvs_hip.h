@@ -1,0 +1,190 @@
+/*
+ * plvs_hip.h — C ABI of the MI355X (gfx950) hot path for PLVS.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ types, no
+ * torch types.  Every entry point replaces one reference call site (cited as
+ * file:line relative to the PLVS tree).  All functions return an int status
+ * (PLVS_OK == 0, < 0 on error), never throw, and write only into
+ * caller-provided memory.  One handle per logical instance; handles are
+ * thread-compatible (no shared mutable globals).
+ *
+ * Two flavours per operation:
+ *   - plain      : host pointers in/out, synchronous (what PLVS' CPU code
+ *                  hands over today);
+ *   - `_dev`     : device pointers in/out + a hipStream_t (passed as void*),
+ *                  asynchronous on that stream (inputs already resident in
+ *                  HBM — what bench.py times).
+ */
+#ifndef PLVS_HIP_H_
+#define PLVS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status */
+#define PLVS_OK 0
+#define PLVS_ERR_INVALID_ARG (-1)
+#define PLVS_ERR_HIP (-2)         /* a HIP runtime call failed; see plvs_hip_last_error */
+#define PLVS_ERR_NO_DEVICE (-3)
+#define PLVS_ERR_CAPACITY (-4)    /* a fixed-capacity device structure overflowed */
+#define PLVS_ERR_EMPTY (-5)       /* empty input where the reference bails out */
+
+/* Human-readable description of the last error on the calling thread. */
+const char* plvs_hip_last_error(void);
+/* ABI version of this header (bumped on incompatible change). */
+int plvs_hip_abi_version(void);
+int plvs_hip_device_count(int* count);
+int plvs_hip_set_device(int device);
+/* hipDeviceSynchronize on the current device. */
+int plvs_hip_synchronize(void);
+
+/* Thin device-memory helpers so that a host (C++/cgo/ctypes) caller can keep
+ * inputs resident without linking HIP itself. */
+int plvs_hip_malloc(void** dptr, size_t bytes);
+int plvs_hip_free(void* dptr);
+int plvs_hip_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int plvs_hip_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int plvs_hip_memset(void* dst, int value, size_t bytes);
+
+/* ------------------------------------------------------- Hamming k=2 search
+ * Exact 2-nearest-neighbour search in Hamming space over 256-bit (32-byte)
+ * descriptors; every query is compared against the whole train set.
+ *
+ * Replaces:
+ *   - BinaryDescriptorMatcher::knnMatch(query, train, matches, k=2, mask, compact)
+ *       Thirdparty/line_descriptor/src/binary_descriptor_matcher_custom.cpp:258-336
+ *       (called from LineMatcher::ComputeDescriptorMatches, src/LineMatcher.cc:2572)
+ *       -> tie_rule = PLVS_TIE_MIH
+ *   - cv::BFMatcher(NORM_HAMMING).knnMatch(k=2)  (Frame::BFmatcher, src/Frame.cc:118, 2977)
+ *       -> tie_rule = PLVS_TIE_LOWEST_INDEX
+ *   - the distance itself is ORBmatcher::DescriptorDistance, src/ORBmatcher.cc:2198-2225
+ *
+ * query  : nq x 32 bytes, row-major.  train : nt x 32 bytes.
+ * qmask  : NULL or nq bytes; qmask[i]==0 means "skip query i" (the
+ *          reference's Qx1 mask): its outputs are set to -1.
+ * idx    : nq x 2 int32, train index of best / second best (-1 if absent).
+ * dist   : nq x 2 int32, Hamming distances 0..256 (-1 if absent).
+ *
+ * Tie rule among equal distances:
+ *   PLVS_TIE_LOWEST_INDEX  lowest train index first.
+ *   PLVS_TIE_MIH           the discovery order of the reference's
+ *                          multi-index-hash search (Mihasher(256,32)::query,
+ *                          binary_descriptor_matcher_custom.cpp:633-752):
+ *                          (min per-byte distance s, first byte k reaching it,
+ *                          enumeration rank of that byte's xor pattern,
+ *                          train index).
+ * Errors: nq==0 or nt==0 -> PLVS_ERR_EMPTY (reference prints and returns,
+ * :263-267), outputs untouched.
+ */
+#define PLVS_TIE_LOWEST_INDEX 0
+#define PLVS_TIE_MIH 1
+
+int plvs_hip_hamming_knn2(const uint8_t* query, int nq, const uint8_t* train, int nt,
+                          const uint8_t* qmask, int tie_rule, int32_t* idx, int32_t* dist);
+int plvs_hip_hamming_knn2_dev(const uint8_t* d_query, int nq, const uint8_t* d_train, int nt,
+                              const uint8_t* d_qmask, int tie_rule, int32_t* d_idx,
+                              int32_t* d_dist, void* stream);
+
+/* --------------------------------------------------------- TSDF (open_chisel)
+ * Chunked (16^3) spatially hashed TSDF with per-point ray integration.
+ *
+ * Replaces:
+ *   PointCloudMapChisel::InsertCloud            src/PointCloudMapChisel.cc:76-98
+ *    -> ChiselServer::SetPointCloud             Thirdparty/chisel_server/src/ChiselServer.cpp:561
+ *    -> ChiselServer::IntegrateLastPointCloud   ChiselServer.cpp:664
+ *    -> chisel::Chisel::IntegratePointCloudWidthDepth (point-cloud part)
+ *                                               Thirdparty/open_chisel/src/Chisel.cpp:442-585
+ *   with chisel::Raycast                        open_chisel/src/geometry/Raycast.cpp:65-182
+ *        DistVoxel::Integrate / ColorVoxel::IntegrateSimple
+ *                                               include/open_chisel/DistVoxel.h:91, ColorVoxel.h:91
+ *
+ * Voxel payload (logical 16 B): {f32 sdf (init 99999), f32 weight (0 =
+ * unknown), u32 kfid, u8 r,g,b,colour-weight}.  Chunks are 16x16x16 voxels,
+ * linear id (z*16+y)*16+x (Chunk.h:90-93).
+ */
+typedef struct plvs_tsdf_chisel_params {
+  float resolution;      /* voxel edge in metres (PointCloudMapping.resolution)            */
+  float trunc_quad;      /* QuadraticTruncator coefficients, ChiselServer.cpp:56-59:       */
+  float trunc_linear;    /*   0.0019, -0.00152, 0.001504, scale 6.0                         */
+  float trunc_const;
+  float trunc_scale;
+  float weight;          /* ConstantWeighter weight (1), ChiselServer.cpp:60               */
+  int32_t max_chunks;    /* capacity of the device chunk pool (64 KiB of HBM each)         */
+  int32_t shard_rank;    /* multi-GPU sharding: this instance only owns chunks with        */
+  int32_t shard_count;   /*   (ChunkHasher(id) mod shard_count) == shard_rank; 0/1 = all   */
+} plvs_tsdf_chisel_params;
+
+typedef struct plvs_tsdf_chisel plvs_tsdf_chisel;
+
+/* Fills *p with the constants PLVS uses (ChiselServer.cpp:50-69,
+ * PointCloudMapChisel.cc:46-61) for the given resolution. */
+int plvs_hip_tsdf_chisel_default_params(float resolution, plvs_tsdf_chisel_params* p);
+int plvs_hip_tsdf_chisel_create(const plvs_tsdf_chisel_params* p, plvs_tsdf_chisel** out);
+int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h);
+/* Drops every chunk (PointCloudMap::Clear). */
+int plvs_hip_tsdf_chisel_clear(plvs_tsdf_chisel* h);
+
+/* Integrate one camera-frame cloud.  Twc is the 3x4 row-major camera pose
+ * [R|t] (Sophus::SE3f Twc of InsertCloud).  xyz: n x 3 f32 camera-frame
+ * points in cloud order; rgb: n x 3 u8, the r,g,b members of the pcl point;
+ * kfid: n u32.  Points with z < 0.01 are skipped (Chisel.cpp:475).  Host
+ * pointers; synchronous. */
+int plvs_hip_tsdf_chisel_integrate(plvs_tsdf_chisel* h, const float* xyz, const uint8_t* rgb,
+                                   const uint32_t* kfid, int n, const float* Twc);
+
+/* Batched, device-resident form: `nclouds` clouds integrated in order, cloud c
+ * being points [offsets[c], offsets[c+1]) of the concatenated device arrays,
+ * with pose d_Twc[12*c .. 12*c+11].  `offsets` is a host array of nclouds+1
+ * ints.  Result is identical to nclouds successive calls of the function
+ * above.  Asynchronous on `stream` except for one device->host read of the
+ * visit count. */
+int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d_xyz,
+                                             const uint8_t* d_rgb, const uint32_t* d_kfid,
+                                             const int32_t* offsets, int nclouds,
+                                             const float* d_Twc, void* stream);
+
+/* Counters of the last integrate call: voxel read-modify-write visits applied
+ * (the "Mvoxels" unit of the metric), points consumed, chunks newly created,
+ * chunks updated. */
+typedef struct plvs_tsdf_stats {
+  int64_t visits;
+  int64_t points;
+  int32_t new_chunks;
+  int32_t updated_chunks;
+} plvs_tsdf_stats;
+int plvs_hip_tsdf_chisel_last_stats(plvs_tsdf_chisel* h, plvs_tsdf_stats* s);
+
+/* Optional per-stage timing with HIP events recorded on the caller's stream
+ * (what bench.py uses for the live roofline figure).  Enabling resets the
+ * accumulators.  stage_ms returns the milliseconds accumulated per pipeline
+ * stage and the number of integrate calls they cover. */
+int plvs_hip_tsdf_chisel_set_profiling(plvs_tsdf_chisel* h, int enable);
+int plvs_hip_tsdf_chisel_stage_ms(plvs_tsdf_chisel* h, double* ms, int cap, int* nstages,
+                                  int64_t* calls);
+const char* plvs_hip_tsdf_chisel_stage_name(int i);
+
+int plvs_hip_tsdf_chisel_num_chunks(plvs_tsdf_chisel* h, int* n);
+/* Chunk ids (x,y,z int32 triples) of all chunks, in pool-slot order. */
+int plvs_hip_tsdf_chisel_chunk_ids(plvs_tsdf_chisel* h, int32_t* ids_xyz, int cap, int* n);
+/* Chunk ids updated by the last integrate call (the "updated block list"
+ * that is all-gathered across GPUs; also the mesh-dirty seed set of
+ * Chisel.cpp:553-572). */
+int plvs_hip_tsdf_chisel_updated_chunk_ids(plvs_tsdf_chisel* h, int32_t* ids_xyz, int cap, int* n);
+/* Same list written to a device buffer (cap triples), asynchronous on `stream`:
+ * the payload of the cross-GPU all-gather. */
+int plvs_hip_tsdf_chisel_updated_chunk_ids_dev(plvs_tsdf_chisel* h, int32_t* d_ids_xyz, int cap,
+                                               int* n, void* stream);
+/* Download one chunk: 4096 entries each of sdf, weight, kfid and rgbw
+ * (r | g<<8 | b<<16 | colour-weight<<24).  Returns PLVS_ERR_INVALID_ARG if
+ * the chunk does not exist. */
+int plvs_hip_tsdf_chisel_download_chunk(plvs_tsdf_chisel* h, int cx, int cy, int cz, float* sdf,
+                                        float* weight, uint32_t* kfid, uint32_t* rgbw);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLVS_HIP_H_ */

@@ -1,0 +1,219 @@
+/*
+ * oracle/hamming.c — CPU restatement of the reference's Hamming matching.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under plvs_amd/ may call into this file;
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load it
+ * (as the checker / the timed CPU baseline).
+ *
+ * Parity status: UNPINNED by the reference (it ships no test or golden vector
+ * for this path).  Analytically pinned instead: the distance is
+ * a popcount, and the k-NN result is checked in tests/ against an independent
+ * numpy brute force on (distance) and against the tie rules stated below.
+ *
+ * Follows (paths relative to the PLVS tree):
+ *   src/ORBmatcher.cc:2198-2225              ORBmatcher::DescriptorDistance
+ *   Thirdparty/line_descriptor/src/bitops_custom.hpp:91-104   match()
+ *   Thirdparty/line_descriptor/src/binary_descriptor_matcher_custom.cpp
+ *        :258-336  BinaryDescriptorMatcher::knnMatch (pair-of-images form)
+ *        :107-122  checkKDistances
+ *        :596-629  Mihasher::batchquery
+ *        :633-752  Mihasher::query
+ *        :755-790  Mihasher::Mihasher(B=256, m=32)
+ *        :800-820  Mihasher::populate
+ *        :852-973  SparseHashtable / BucketGroup (bucket = insertion order)
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:2198): four 64-bit words,
+ * SWAR popcount (the non-__POPCNT__ branch, bit-identical to popcnt). */
+int oracle_descriptor_distance(const uint8_t* a, const uint8_t* b) {
+  uint64_t dist = 0;
+  for (int i = 0; i < 4; i++) {
+    uint64_t pa, pb;
+    memcpy(&pa, a + 8 * i, 8);
+    memcpy(&pb, b + 8 * i, 8);
+    uint64_t v = pa ^ pb;
+    v = v - ((v >> 1) & (uint64_t) ~(uint64_t)0 / 3);
+    v = (v & (uint64_t) ~(uint64_t)0 / 15 * 3) + ((v >> 2) & (uint64_t) ~(uint64_t)0 / 15 * 3);
+    v = (v + (v >> 4)) & (uint64_t) ~(uint64_t)0 / 255 * 15;
+    dist += (uint64_t)(v * ((uint64_t) ~(uint64_t)0 / 255)) >> (sizeof(uint64_t) - 1) * 8;
+  }
+  return (int)dist;
+}
+
+/* cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) contract (src/Frame.cc:2977):
+ * exact distances, ties resolved towards the lowest train index (stable
+ * selection over ascending train order).  OpenCV itself is not in the tree;
+ * this is the documented behaviour, restated. */
+void oracle_knn2_bf(const uint8_t* q, int nq, const uint8_t* t, int nt, const uint8_t* qmask,
+                    int32_t* idx, int32_t* dist) {
+  for (int i = 0; i < nq; i++) {
+    int b1 = -1, b2 = -1, d1 = 1 << 30, d2 = 1 << 30;
+    if (!qmask || qmask[i]) {
+      for (int j = 0; j < nt; j++) {
+        int d = oracle_descriptor_distance(q + 32 * (size_t)i, t + 32 * (size_t)j);
+        if (d < d1) {
+          d2 = d1; b2 = b1; d1 = d; b1 = j;
+        } else if (d < d2) {
+          d2 = d; b2 = j;
+        }
+      }
+    }
+    idx[2 * i] = b1; dist[2 * i] = b1 < 0 ? -1 : d1;
+    idx[2 * i + 1] = b2; dist[2 * i + 1] = b2 < 0 ? -1 : d2;
+  }
+}
+
+/* ---------------------------------------------------------------- Mihasher
+ * B = 256 bits, m = 32 substrings -> b = ceil(256/32) = 8 bits each,
+ * mplus = 256 - 32*7 = 32 (all substrings have 8 bits), D = 256, d = ceil(D/m) = 8
+ * (binary_descriptor_matcher_custom.cpp:755-790).  split() (bitops_custom.hpp:107-133)
+ * with b = 8 makes substring k exactly byte k of the code.
+ */
+enum { MIH_B = 256, MIH_M = 32, MIH_BITS = 8, MIH_D = 256, MIH_SMALLD = 8 };
+
+typedef struct {
+  int n;                 /* number of train codes */
+  const uint8_t* codes;  /* n x 32 */
+  /* H[k]: 256 buckets per substring; bucket (k, v) = train indices whose byte k
+   * equals v, in insertion order = ascending index (BucketGroup::insert appends
+   * at the end of the bucket's sub-array, :916-941; populate inserts i = 0..N-1). */
+  int32_t* start; /* [32][257] CSR offsets */
+  int32_t* items; /* [32][n] */
+} mih_t;
+
+static void mih_populate(mih_t* mh, const uint8_t* codes, int n) {
+  mh->n = n;
+  mh->codes = codes;
+  mh->start = (int32_t*)calloc((size_t)MIH_M * 257, sizeof(int32_t));
+  mh->items = (int32_t*)malloc((size_t)MIH_M * (size_t)(n > 0 ? n : 1) * sizeof(int32_t));
+  for (int k = 0; k < MIH_M; k++) {
+    int32_t* st = mh->start + (size_t)k * 257;
+    for (int i = 0; i < n; i++) st[codes[(size_t)i * 32 + k] + 1]++;
+    for (int v = 0; v < 256; v++) st[v + 1] += st[v];
+    int32_t fill[256];
+    memcpy(fill, st, sizeof(fill));
+    for (int i = 0; i < n; i++) mh->items[(size_t)k * n + fill[codes[(size_t)i * 32 + k]]++] = i;
+  }
+}
+
+static void mih_free(mih_t* mh) {
+  free(mh->start);
+  free(mh->items);
+}
+
+/* bitops_custom.hpp:91-104 match(): popcount over the 32 bytes. */
+static int mih_match(const uint8_t* p, const uint8_t* q) {
+  int out = 0;
+  for (int i = 0; i < 32; i += 4) {
+    uint32_t a, b;
+    memcpy(&a, p + i, 4);
+    memcpy(&b, q + i, 4);
+    out += __builtin_popcount(a ^ b);
+  }
+  return out;
+}
+
+/* Mihasher::query (:633-752).  results: K entries (index+1, 0 = none);
+ * numres: 257 counters of candidates seen per exact distance. */
+static void mih_query(const mih_t* mh, int K, const uint8_t* query, uint32_t* results,
+                      uint32_t* numres, uint8_t* seen, uint32_t* res) {
+  const uint32_t maxres = K ? (uint32_t)K : (uint32_t)mh->n;
+  uint32_t n = 0;
+  int power[MIH_BITS + 3];
+  memset(seen, 0, (size_t)mh->n);                       /* counter->erase() */
+  memset(numres, 0, (MIH_B + 1) * sizeof(uint32_t));
+  memset(res, 0, (size_t)K * (MIH_D + 1) * sizeof(uint32_t));
+
+  for (int s = 0; s <= MIH_SMALLD && n < maxres; s++) {
+    for (int k = 0; k < MIH_M; k++) {
+      const int curb = MIH_BITS; /* k < mplus for every k */
+      const uint64_t chunk = query[k];
+      /* enumerate every bit-string with s ones among curb bits (:664-728) */
+      uint64_t bitstr = 0;
+      for (int i = 0; i < s; i++) power[i] = i;
+      power[s] = curb + 1;
+      int bit = s - 1;
+      for (;;) {
+        if (bit != -1) {
+          bitstr ^= (power[bit] == bit) ? (uint64_t)1 << power[bit]
+                                        : (uint64_t)3 << (power[bit] - 1);
+          power[bit]++;
+          bit--;
+        } else {
+          /* bucket lookup H[k].query(chunk ^ bitstr) */
+          const uint64_t v = chunk ^ bitstr;
+          const int32_t* st = mh->start + (size_t)k * 257;
+          const int32_t* arr = mh->items + (size_t)k * mh->n + st[v];
+          const int size = st[v + 1] - st[v];
+          for (int c = 0; c < size; c++) {
+            const uint32_t index = (uint32_t)arr[c];
+            if (!seen[index]) {
+              seen[index] = 1;
+              const int hammd = mih_match(mh->codes + (size_t)index * 32, query);
+              if (hammd <= MIH_D && numres[hammd] < maxres)
+                res[(size_t)hammd * K + numres[hammd]] = index + 1;
+              numres[hammd]++;
+            }
+          }
+          while (++bit < s && power[bit] == power[bit + 1] - 1) {
+            bitstr ^= (uint64_t)1 << (power[bit] - 1);
+            power[bit] = bit;
+          }
+          if (bit == s) break;
+        }
+      }
+      /* :731  n = n + numres[s*m + k]; the reference indexes past B for s = 8,
+       * k > 0 (only reachable when fewer than K codes exist) — read as 0 here. */
+      const int h = s * MIH_M + k;
+      n += (h <= MIH_B) ? numres[h] : 0u;
+      if (n >= maxres) break;
+    }
+  }
+  n = 0;
+  for (int s = 0; s <= MIH_D && (int)n < K; s++)
+    for (int c = 0; c < (int)numres[s] && (int)n < K; c++) results[n++] = res[(size_t)s * K + c];
+  for (; (int)n < K; n++) results[n] = 0; /* reference leaves these uninitialised */
+}
+
+/* BinaryDescriptorMatcher::knnMatch(query, train, matches, k=2, mask, compact)
+ * (:258-336).  Output rows of masked-out queries are -1 (the caller drops them
+ * when compactResult is requested).  When fewer than 2 train codes exist the
+ * reference reads uninitialised memory; here the missing entries are -1. */
+void oracle_knn2_mih(const uint8_t* q, int nq, const uint8_t* t, int nt, const uint8_t* qmask,
+                     int32_t* idx, int32_t* dist) {
+  const int K = 2;
+  mih_t mh;
+  mih_populate(&mh, t, nt);
+  uint32_t* results = (uint32_t*)malloc((size_t)K * (size_t)nq * sizeof(uint32_t));
+  uint32_t* numres = (uint32_t*)malloc((size_t)(MIH_B + 1) * (size_t)nq * sizeof(uint32_t));
+  uint8_t* seen = (uint8_t*)malloc((size_t)(nt > 0 ? nt : 1));
+  uint32_t* res = (uint32_t*)malloc((size_t)K * (MIH_D + 1) * sizeof(uint32_t));
+  for (int i = 0; i < nq; i++) /* batchquery (:596-629) */
+    mih_query(&mh, K, q + (size_t)i * 32, results + (size_t)K * i,
+              numres + (size_t)(MIH_B + 1) * i, seen, res);
+  for (int i = 0; i < nq; i++) {
+    if (qmask && qmask[i] == 0) {
+      idx[2 * i] = idx[2 * i + 1] = -1;
+      dist[2 * i] = dist[2 * i + 1] = -1;
+      continue;
+    }
+    /* checkKDistances (:107-122): the k smallest distances from the histogram */
+    int kd[2] = {-1, -1}, found = 0;
+    const uint32_t* nr = numres + (size_t)(MIH_B + 1) * i;
+    for (int j = 0; j <= MIH_B && found < K; j++)
+      for (uint32_t c = 0; c < nr[j] && found < K; c++) kd[found++] = j;
+    for (int j = 0; j < K; j++) {
+      const uint32_t r = results[(size_t)K * i + j];
+      idx[2 * i + j] = r ? (int32_t)r - 1 : -1;
+      dist[2 * i + j] = r ? kd[j] : -1;
+    }
+  }
+  free(results);
+  free(numres);
+  free(seen);
+  free(res);
+  mih_free(&mh);
+}

@@ -1,0 +1,359 @@
+/*
+ * oracle/tsdf_chisel.c — CPU restatement of the open_chisel point-cloud
+ * integrate that sits behind PointCloudMapChisel::InsertCloud.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under plvs_amd/ may call into this file;
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load it.
+ *
+ * Parity status: UNPINNED by the reference — open_chisel ships no tests and no
+ * golden vectors, and the reference itself cannot be compiled
+ * here (needs Eigen3 + PCL, both absent).  The arithmetic below therefore
+ * restates the reference's expressions *including the evaluation order Eigen
+ * 3.3 gives them* (3-vector reductions are evaluated as a0 + (a1 + a2); an
+ * Affine transform applied to a point is t + R*p; Transform::inverse() of an
+ * Affine transform uses the cofactor inverse), and the C-library overloads
+ * g++ picks for the unqualified calls (fmod / sqrt resolve to the double
+ * versions).  Compiled with -ffp-contract=off so no FMA contraction changes a
+ * rounding.
+ *
+ * Follows (paths relative to the PLVS tree):
+ *   src/PointCloudMapChisel.cc:76-98                  InsertCloud (pose -> chisel::Transform)
+ *   Thirdparty/chisel_server/src/ChiselServer.cpp:50-69, 105-108, 561-586, 664-700
+ *   Thirdparty/chisel_server/include/chisel_server/Conversions.h:97-127   colours = u8 * (1/255)
+ *   Thirdparty/open_chisel/src/Chisel.cpp:442-585     IntegratePointCloudWidthDepth (cloud part)
+ *   Thirdparty/open_chisel/src/geometry/Raycast.cpp:6-30, 65-182
+ *   Thirdparty/open_chisel/include/open_chisel/ChunkManager.h:42-54, 161-206
+ *   Thirdparty/open_chisel/src/ChunkManager.cpp:68, 89-93
+ *   Thirdparty/open_chisel/src/Chunk.cpp:34-50, 96-105 ; include/open_chisel/Chunk.h:85-118
+ *   Thirdparty/open_chisel/include/open_chisel/DistVoxel.h:91-99 ; src/DistVoxel.cpp:27-35
+ *   Thirdparty/open_chisel/include/open_chisel/ColorVoxel.h:91-110
+ *   Thirdparty/open_chisel/include/open_chisel/truncation/QuadraticTruncator.h:45-50
+ *   Thirdparty/open_chisel/include/open_chisel/weighting/ConstantWeighter.h:43-46
+ */
+#include <limits.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define CHUNK_VOX 4096
+#define RAY_STEP_GUARD (1 << 16) /* the reference loop is unbounded; never reached on finite input */
+
+typedef struct {
+  int32_t id[3];
+  int used;
+  float* sdf;     /* DistVoxel::sdf, init 99999 */
+  float* weight;  /* DistVoxel::weight, init 0  */
+  uint32_t* kfid; /* DistVoxel::kfid, init 0    */
+  uint32_t* rgbw; /* ColorVoxel r | g<<8 | b<<16 | weight<<24, init 0 */
+} chunk_t;
+
+typedef struct oracle_chisel {
+  float resolution;
+  float tq, tl, tc, ts; /* QuadraticTruncator */
+  float weight;         /* ConstantWeighter */
+  float half_voxel;     /* ChunkManager.cpp:68  res * 0.5f */
+  float rounding;       /* ChunkManager.cpp:91  1.0f / (16 * res) */
+  chunk_t* tab;
+  size_t cap, count;
+  int shard_rank, shard_count;
+  int64_t last_visits;
+  int32_t last_new, last_updated;
+} oracle_chisel;
+
+/* ChunkHasher (ChunkManager.h:42-54): size_t arithmetic on the int coordinates. */
+static size_t chunk_hash(const int32_t id[3]) {
+  return ((size_t)(int64_t)id[0] * 73856093u) ^ ((size_t)(int64_t)id[1] * 19349663u) ^
+         ((size_t)(int64_t)id[2] * 83492791u);
+}
+
+static chunk_t* tab_find(chunk_t* tab, size_t cap, const int32_t id[3], int* found) {
+  size_t h = chunk_hash(id) & (cap - 1);
+  for (;;) {
+    chunk_t* c = &tab[h];
+    if (!c->used) { *found = 0; return c; }
+    if (c->id[0] == id[0] && c->id[1] == id[1] && c->id[2] == id[2]) { *found = 1; return c; }
+    h = (h + 1) & (cap - 1);
+  }
+}
+
+static void tab_grow(oracle_chisel* o) {
+  size_t ncap = o->cap * 2;
+  chunk_t* nt = (chunk_t*)calloc(ncap, sizeof(chunk_t));
+  for (size_t i = 0; i < o->cap; i++)
+    if (o->tab[i].used) {
+      int f;
+      *tab_find(nt, ncap, o->tab[i].id, &f) = o->tab[i];
+    }
+  free(o->tab);
+  o->tab = nt;
+  o->cap = ncap;
+}
+
+/* Chunk::Chunk (Chunk.cpp:34-50) + DistVoxel()/ColorVoxel() defaults. */
+static chunk_t* chunk_create(oracle_chisel* o, const int32_t id[3]) {
+  if ((o->count + 1) * 2 > o->cap) tab_grow(o);
+  int f;
+  chunk_t* c = tab_find(o->tab, o->cap, id, &f);
+  memcpy(c->id, id, sizeof(c->id));
+  c->used = 1;
+  c->sdf = (float*)malloc(CHUNK_VOX * sizeof(float));
+  c->weight = (float*)calloc(CHUNK_VOX, sizeof(float));
+  c->kfid = (uint32_t*)calloc(CHUNK_VOX, sizeof(uint32_t));
+  c->rgbw = (uint32_t*)calloc(CHUNK_VOX, sizeof(uint32_t));
+  for (int i = 0; i < CHUNK_VOX; i++) c->sdf[i] = 99999.0f;
+  o->count++;
+  return c;
+}
+
+oracle_chisel* oracle_chisel_create(float resolution, float tq, float tl, float tc, float ts,
+                                    float weight, int shard_rank, int shard_count) {
+  oracle_chisel* o = (oracle_chisel*)calloc(1, sizeof(*o));
+  o->resolution = resolution;
+  o->tq = tq; o->tl = tl; o->tc = tc; o->ts = ts;
+  o->weight = weight;
+  o->half_voxel = resolution * 0.5f;
+  o->rounding = 1.0f / ((float)16 * resolution);
+  o->cap = 1024;
+  o->tab = (chunk_t*)calloc(o->cap, sizeof(chunk_t));
+  o->shard_rank = shard_rank;
+  o->shard_count = shard_count;
+  return o;
+}
+
+void oracle_chisel_clear(oracle_chisel* o) {
+  for (size_t i = 0; i < o->cap; i++)
+    if (o->tab[i].used) {
+      free(o->tab[i].sdf); free(o->tab[i].weight); free(o->tab[i].kfid); free(o->tab[i].rgbw);
+    }
+  memset(o->tab, 0, o->cap * sizeof(chunk_t));
+  o->count = 0;
+}
+
+void oracle_chisel_destroy(oracle_chisel* o) {
+  if (!o) return;
+  oracle_chisel_clear(o);
+  free(o->tab);
+  free(o);
+}
+
+/* ---- small float helpers in Eigen's evaluation order ---------------------- */
+static float sum3(float a, float b, float c) { return a + (b + c); } /* redux of 3: a0 + (a1 + a2) */
+static float sqnorm3(const float v[3]) { return sum3(v[0] * v[0], v[1] * v[1], v[2] * v[2]); }
+
+/* Affine3f * Vector3f  ->  t + R p, R p row-wise as a 3-term reduction. */
+static void xform(const float R[9], const float t[3], const float p[3], float out[3]) {
+  for (int i = 0; i < 3; i++)
+    out[i] = t[i] + sum3(R[3 * i + 0] * p[0], R[3 * i + 1] * p[1], R[3 * i + 2] * p[2]);
+}
+
+static float cof(const float m[9], int i, int j) {
+  const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return m[3 * i1 + j1] * m[3 * i2 + j2] - m[3 * i1 + j2] * m[3 * i2 + j1];
+}
+
+/* Transform<float,3,Affine>::inverse(): cofactor inverse of the linear part,
+ * translation = (-Rinv) * t  (Chisel.cpp:451 `cameraPose.inverse()`). */
+void oracle_affine_inverse(const float R[9], const float t[3], float Ri[9], float ti[3]) {
+  const float c00 = cof(R, 0, 0), c10 = cof(R, 1, 0), c20 = cof(R, 2, 0);
+  const float det = sum3(c00 * R[0], c10 * R[3], c20 * R[6]);
+  const float invdet = 1.0f / det;
+  Ri[0] = c00 * invdet; Ri[1] = c10 * invdet; Ri[2] = c20 * invdet;
+  Ri[3] = cof(R, 0, 1) * invdet; Ri[4] = cof(R, 1, 1) * invdet; Ri[5] = cof(R, 2, 1) * invdet;
+  Ri[6] = cof(R, 0, 2) * invdet; Ri[7] = cof(R, 1, 2) * invdet; Ri[8] = cof(R, 2, 2) * invdet;
+  for (int i = 0; i < 3; i++)
+    ti[i] = sum3((-Ri[3 * i + 0]) * t[0], (-Ri[3 * i + 1]) * t[1], (-Ri[3 * i + 2]) * t[2]);
+}
+
+/* Raycast.cpp:12-15 mod(): unqualified fmod on floats -> the double overload. */
+static float rc_mod(float value, float modulus) {
+  return (float)fmod(fmod((double)value, (double)modulus) + (double)modulus, (double)modulus);
+}
+/* Raycast.cpp:17-30 */
+static float rc_intbound(float s, float ds) {
+  if (ds < 0) return rc_intbound(-s, -ds);
+  s = rc_mod(s, 1);
+  return (1 - s) / ds;
+}
+static int rc_signum(int x) { return (x > 0) ? 1 : ((x < 0) ? -1 : 0); }
+
+typedef void (*visit_fn)(void* ctx, int x, int y, int z);
+
+/* chisel::Raycast (Raycast.cpp:65-182); min/max are -/+INT_MAX at the call site
+ * (Chisel.cpp:452-453). */
+static void raycast(const float start[3], const float end[3], visit_fn fn, void* ctx) {
+  int x = (int)floorf(start[0]), y = (int)floorf(start[1]), z = (int)floorf(start[2]);
+  const int endX = (int)floorf(end[0]), endY = (int)floorf(end[1]), endZ = (int)floorf(end[2]);
+  const float direction[3] = {end[0] - start[0], end[1] - start[1], end[2] - start[2]};
+  const float maxDist = sqnorm3(direction);
+  const float dx = (float)(endX - x), dy = (float)(endY - y), dz = (float)(endZ - z);
+  const int stepX = rc_signum((int)dx), stepY = rc_signum((int)dy), stepZ = rc_signum((int)dz);
+  float tMaxX = rc_intbound(start[0], dx), tMaxY = rc_intbound(start[1], dy),
+        tMaxZ = rc_intbound(start[2], dz);
+  const float tDeltaX = ((float)stepX) / dx, tDeltaY = ((float)stepY) / dy,
+              tDeltaZ = ((float)stepZ) / dz;
+  if (stepX == 0 && stepY == 0 && stepZ == 0) return;
+  const int lo = -INT_MAX, hi = INT_MAX;
+  for (int guard = 0; guard < RAY_STEP_GUARD; guard++) {
+    if (x >= lo && x < hi && y >= lo && y < hi && z >= lo && z < hi) {
+      fn(ctx, x, y, z);
+      const float d[3] = {(float)x - start[0], (float)y - start[1], (float)z - start[2]};
+      if (sqnorm3(d) > maxDist) return;
+    }
+    if (x == endX && y == endY && z == endZ) break;
+    if (tMaxX < tMaxY) {
+      if (tMaxX < tMaxZ) { x += stepX; tMaxX += tDeltaX; }
+      else               { z += stepZ; tMaxZ += tDeltaZ; }
+    } else {
+      if (tMaxY < tMaxZ) { y += stepY; tMaxY += tDeltaY; }
+      else               { z += stepZ; tMaxZ += tDeltaZ; }
+    }
+  }
+}
+
+typedef struct {
+  oracle_chisel* o;
+  const float* Ri; const float* ti; /* inverse pose */
+  float depth, truncation;
+  uint8_t r, g, b;
+  uint32_t kfid;
+  chunk_t* last; /* small lookup cache, no semantic effect */
+  int64_t visits;
+  int32_t newc, updc;
+} visit_ctx;
+
+static int owned(const oracle_chisel* o, const int32_t id[3]) {
+  if (o->shard_count <= 1) return 1;
+  return (int)(chunk_hash(id) % (size_t)o->shard_count) == o->shard_rank;
+}
+
+/* Body of the per-voxel loop, Chisel.cpp:503-549. */
+static void visit(void* vctx, int vx, int vy, int vz) {
+  visit_ctx* c = (visit_ctx*)vctx;
+  oracle_chisel* o = c->o;
+  /* ChunkManager::GetCentroid (ChunkManager.h:203-206) */
+  const float center[3] = {(float)vx * o->resolution + o->half_voxel,
+                           (float)vy * o->resolution + o->half_voxel,
+                           (float)vz * o->resolution + o->half_voxel};
+  /* GetIDAt (ChunkManager.h:192-201) */
+  const int32_t id[3] = {(int32_t)floorf(center[0] * o->rounding),
+                         (int32_t)floorf(center[1] * o->rounding),
+                         (int32_t)floorf(center[2] * o->rounding)};
+  if (!owned(o, id)) return; /* multi-GPU shard filter (not in the reference) */
+  /* Chunk::GetLocalVoxelIDFromGlobal + IsCoordValid(VoxelID) (Chunk.cpp:96-105, Chunk.h:90-118) */
+  const int lx = vx - id[0] * 16, ly = vy - id[1] * 16, lz = vz - id[2] * 16;
+  const int vid = (lz * 16 + ly) * 16 + lx;
+  if (!(vid >= 0 && vid < CHUNK_VOX)) return;
+
+  float cc[3];
+  xform(c->Ri, c->ti, center, cc);                         /* inversePose * center  :525 */
+  const float length = sqrtf(sqnorm3(cc));                 /* :526 */
+  const float u = length * (c->depth / cc[2] - 1);         /* :527 */
+  const float weight = o->weight / (2.0f * c->truncation); /* ConstantWeighter.h:45 */
+  if (!(fabs((double)u) < (double)c->truncation)) return;  /* :531 */
+
+  /* A chunk created by GetOrCreateChunkAt but never updated is garbage-collected
+   * at the end of the call (:574-583), so creation can be deferred to the first
+   * update without changing the resulting map. */
+  chunk_t* ch = c->last;
+  if (!ch || ch->id[0] != id[0] || ch->id[1] != id[1] || ch->id[2] != id[2]) {
+    int found;
+    ch = tab_find(o->tab, o->cap, id, &found);
+    if (!found) { ch = chunk_create(o, id); c->newc++; }
+    c->last = ch;
+  }
+  /* DistVoxel::Integrate (DistVoxel.h:91-99) */
+  const float oldSDF = ch->sdf[vid], oldWeight = ch->weight[vid];
+  ch->sdf[vid] = (oldWeight * oldSDF + weight * u) / (weight + oldWeight);
+  ch->weight[vid] = oldWeight + weight;
+  ch->kfid[vid] = c->kfid; /* SetKfid, USE_KFID_INTEGRATION 0 */
+  /* ColorVoxel::IntegrateSimple(r,g,b,1) (ColorVoxel.h:91-110) */
+  uint32_t p = ch->rgbw[vid];
+  uint8_t red = p & 255, green = (p >> 8) & 255, blue = (p >> 16) & 255, cw = p >> 24;
+  const uint8_t wu = 1;
+  if (!(cw >= 255 - wu)) {
+    const float inv = 1.f / (float)(wu + cw);
+    red = (uint8_t)((float)(cw * red + wu * c->r) * inv);
+    green = (uint8_t)((float)(cw * green + wu * c->g) * inv);
+    blue = (uint8_t)((float)(cw * blue + wu * c->b) * inv);
+    cw = (uint8_t)(cw + wu);
+    ch->rgbw[vid] = (uint32_t)red | ((uint32_t)green << 8) | ((uint32_t)blue << 16) | ((uint32_t)cw << 24);
+  }
+  c->visits++;
+}
+
+/* Chisel::IntegratePointCloudWidthDepth, point-cloud part (Chisel.cpp:442-585).
+ * Twc: 3x4 row-major [R|t]. */
+void oracle_chisel_integrate(oracle_chisel* o, const float* xyz, const uint8_t* rgb,
+                             const uint32_t* kfid, int n, const float* Twc) {
+  float R[9], t[3], Ri[9], ti[3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) R[3 * i + j] = Twc[4 * i + j];
+    t[i] = Twc[4 * i + 3];
+  }
+  oracle_affine_inverse(R, t, Ri, ti);
+  const float resolution = o->resolution;
+  const float roundToVoxel = 1.0f / resolution;                             /* :444 */
+  const float diag = (float)(2.0 * sqrt((double)3.0f) * (double)resolution); /* :447 */
+  const float byteToFloat = 1.0f / 255.0f;                                  /* Conversions.h:107 */
+  visit_ctx c;
+  memset(&c, 0, sizeof(c));
+  c.o = o; c.Ri = Ri; c.ti = ti;
+  const size_t before = o->count;
+  /* updated-chunk count: chunks whose any voxel passed; tracked through a per-call mark */
+  for (int i = 0; i < n; i++) {
+    const float* point = xyz + 3 * (size_t)i;
+    float worldPoint[3];
+    xform(R, t, point, worldPoint);                                         /* :472 */
+    const float depth = point[2];
+    if (depth < 0.01f) continue;                                            /* :475 */
+    float v[3] = {worldPoint[0] - t[0], worldPoint[1] - t[1], worldPoint[2] - t[2]};
+    const float z2 = sqnorm3(v);
+    float dir[3] = {v[0], v[1], v[2]};
+    if (z2 > 0.0f) {                                                        /* normalized() */
+      const float nrm = sqrtf(z2);
+      dir[0] = v[0] / nrm; dir[1] = v[1] / nrm; dir[2] = v[2] / nrm;
+    }
+    const float trunc_q = (o->tq * depth * depth + o->tl * depth + o->tc) * o->ts; /* QuadraticTruncator.h:49 */
+    const float truncation = trunc_q > diag ? trunc_q : diag;               /* std::max, :479 */
+    float start[3], end[3];
+    for (int k = 0; k < 3; k++) {
+      const float swp = worldPoint[k] * roundToVoxel;                       /* :482 */
+      const float sdt = dir[k] * truncation * roundToVoxel;                 /* :483 */
+      start[k] = swp - sdt;                                                 /* :486 */
+      end[k] = swp + sdt;                                                   /* :488 */
+    }
+    c.depth = depth; c.truncation = truncation;
+    /* Conversions.h:118-121 then Chisel.cpp:536 */
+    c.r = (uint8_t)(((float)rgb[3 * (size_t)i + 0] * byteToFloat) * 255.0f);
+    c.g = (uint8_t)(((float)rgb[3 * (size_t)i + 1] * byteToFloat) * 255.0f);
+    c.b = (uint8_t)(((float)rgb[3 * (size_t)i + 2] * byteToFloat) * 255.0f);
+    c.kfid = kfid ? kfid[i] : 0;
+    raycast(start, end, visit, &c);
+  }
+  o->last_visits = c.visits;
+  o->last_new = (int32_t)(o->count - before);
+}
+
+int64_t oracle_chisel_last_visits(const oracle_chisel* o) { return o->last_visits; }
+int oracle_chisel_last_new_chunks(const oracle_chisel* o) { return o->last_new; }
+int oracle_chisel_num_chunks(const oracle_chisel* o) { return (int)o->count; }
+
+void oracle_chisel_chunk_ids(const oracle_chisel* o, int32_t* ids) {
+  size_t k = 0;
+  for (size_t i = 0; i < o->cap; i++)
+    if (o->tab[i].used) { memcpy(ids + 3 * k, o->tab[i].id, 3 * sizeof(int32_t)); k++; }
+}
+
+int oracle_chisel_get_chunk(const oracle_chisel* o, int cx, int cy, int cz, float* sdf,
+                            float* weight, uint32_t* kfid, uint32_t* rgbw) {
+  const int32_t id[3] = {cx, cy, cz};
+  int found;
+  chunk_t* c = tab_find(o->tab, o->cap, id, &found);
+  if (!found) return 0;
+  memcpy(sdf, c->sdf, CHUNK_VOX * sizeof(float));
+  memcpy(weight, c->weight, CHUNK_VOX * sizeof(float));
+  memcpy(kfid, c->kfid, CHUNK_VOX * sizeof(uint32_t));
+  memcpy(rgbw, c->rgbw, CHUNK_VOX * sizeof(uint32_t));
+  return 1;
+}

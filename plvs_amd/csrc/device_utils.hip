@@ -1,0 +1,239 @@
+// Device-wide exclusive scan and stable LSD radix sort (internal primitives).
+//
+// Both are written for 64-lane wavefronts: wave-level prefix sums use
+// __shfl_up over 64 lanes, and the radix scatter ranks equal digits inside a
+// wavefront with eight __ballot masks (a "match-any" over the 8-bit digit),
+// which is what keeps the sort stable without any per-item atomics.
+#include "device_utils.hpp"
+
+namespace plvs {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+
+// ------------------------------------------------------------------ scan
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kThreads * kScanItems;  // 2048
+
+// Exclusive prefix of v over the 256 threads of the block; *total = block sum.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total,
+                                                         uint32_t* lds /* >= kWaves words */) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) lds[wid] = x;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) {
+    const uint32_t s = lds[w];
+    if (w < wid) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + x - v;
+}
+
+__global__ __launch_bounds__(kThreads) void scan_tile_sums(const uint32_t* __restrict__ in, size_t n,
+                                                           uint32_t* __restrict__ sums) {
+  __shared__ uint32_t lds[kWaves];
+  const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanItems;
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i)
+    if (base + i < n) s += in[base + i];
+  uint32_t tot;
+  (void)block_exclusive_scan(s, &tot, lds);
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+// Single block: exclusive scan of sums[0..nb) in place, grand total to *total.
+__global__ __launch_bounds__(kThreads) void scan_sums(uint32_t* __restrict__ sums, size_t nb,
+                                                      uint32_t* __restrict__ total) {
+  __shared__ uint32_t lds[kWaves];
+  uint32_t carry = 0;
+  for (size_t start = 0; start < nb; start += kScanTile) {
+    const size_t base = start + (size_t)threadIdx.x * kScanItems;
+    uint32_t v[kScanItems];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+      v[i] = (base + i < nb) ? sums[base + i] : 0u;
+      s += v[i];
+    }
+    uint32_t tot;
+    uint32_t ex = block_exclusive_scan(s, &tot, lds) + carry;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+      if (base + i < nb) sums[base + i] = ex;
+      ex += v[i];
+    }
+    carry += tot;
+  }
+  if (threadIdx.x == 0 && total != nullptr) *total = carry;
+}
+
+__global__ __launch_bounds__(kThreads) void scan_tile_apply(const uint32_t* __restrict__ in,
+                                                            uint32_t* __restrict__ out, size_t n,
+                                                            const uint32_t* __restrict__ sums) {
+  __shared__ uint32_t lds[kWaves];
+  const size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanItems;
+  uint32_t v[kScanItems];
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) {
+    v[i] = (base + i < n) ? in[base + i] : 0u;
+    s += v[i];
+  }
+  uint32_t tot;
+  uint32_t ex = block_exclusive_scan(s, &tot, lds) + sums[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) {
+    if (base + i < n) out[base + i] = ex;
+    ex += v[i];
+  }
+}
+
+// ------------------------------------------------------------ radix sort
+constexpr int kRadixBits = 8;
+constexpr int kRadix = 1 << kRadixBits;
+constexpr int kSortItems = 16;                       // per thread
+constexpr int kSortTile = kThreads * kSortItems;     // 4096 keys per block
+constexpr int kWaveSpan = 64 * kSortItems;           // 1024 consecutive keys per wave
+
+// hist[d * nb + b] = number of keys of tile b whose digit is d.
+__global__ __launch_bounds__(kThreads) void radix_hist(const uint32_t* __restrict__ keys, size_t n,
+                                                       int shift, uint32_t mask, size_t nb,
+                                                       uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[kRadix];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const size_t tile = (size_t)blockIdx.x * kSortTile;
+#pragma unroll 4
+  for (int it = 0; it < kSortItems; ++it) {
+    const size_t i = tile + (size_t)it * kThreads + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  hist[(size_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kThreads) void radix_scatter(
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n, int shift,
+    uint32_t mask, size_t nb, const uint32_t* __restrict__ hist_scanned) {
+  // wave_hist[w][d]: running count of digit d inside wave w's 1024-key span,
+  // later turned into the wave's exclusive base inside the tile.
+  __shared__ uint32_t wave_hist[kWaves][kRadix];
+  __shared__ uint32_t gbase[kRadix];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int w = 0; w < kWaves; ++w) wave_hist[w][threadIdx.x] = 0;
+  gbase[threadIdx.x] = hist_scanned[(size_t)threadIdx.x * nb + blockIdx.x];
+  __syncthreads();
+
+  const size_t span = (size_t)blockIdx.x * kSortTile + (size_t)wid * kWaveSpan;
+  uint32_t k[kSortItems], v[kSortItems], rank[kSortItems];
+  volatile uint32_t* my_hist = wave_hist[wid];
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int it = 0; it < kSortItems; ++it) {
+    const size_t i = span + (size_t)it * 64 + lane;
+    const bool valid = i < n;
+    k[it] = valid ? keys_in[i] : 0u;
+    v[it] = valid ? vals_in[i] : 0u;
+    const uint32_t d = (k[it] >> shift) & mask;
+    // lanes holding the same digit (and a valid key)
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < kRadixBits; ++b) {
+      const unsigned long long bal = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
+    const uint32_t cnt = (uint32_t)__popcll(peers);
+    uint32_t base = 0;
+    if (valid) base = my_hist[d];
+    rank[it] = base + before;
+    // the lowest peer publishes the new running count; LDS ops of one wave
+    // execute in order, so every peer has read `base` before this store lands.
+    if (valid && before == 0) my_hist[d] = base + cnt;
+  }
+  __syncthreads();
+  // exclusive prefix over the waves, per digit (thread d owns digit d)
+  {
+    uint32_t run = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+      const uint32_t c = wave_hist[w][threadIdx.x];
+      wave_hist[w][threadIdx.x] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < kSortItems; ++it) {
+    const size_t i = span + (size_t)it * 64 + lane;
+    if (i < n) {
+      const uint32_t d = (k[it] >> shift) & mask;
+      const size_t pos = (size_t)gbase[d] + wave_hist[wid][d] + rank[it];
+      keys_out[pos] = k[it];
+      vals_out[pos] = v[it];
+    }
+  }
+}
+
+}  // namespace
+
+size_t scan_scratch_words(size_t n) { return (n + kScanTile - 1) / kScanTile + 1; }
+
+hipError_t exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total,
+                              uint32_t* scratch, hipStream_t stream) {
+  if (n == 0) {
+    if (total) return hipMemsetAsync(total, 0, sizeof(uint32_t), stream);
+    return hipSuccess;
+  }
+  const size_t nb = (n + kScanTile - 1) / kScanTile;
+  hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)nb), dim3(kThreads), 0, stream, in, n, scratch);
+  hipLaunchKernelGGL(scan_sums, dim3(1), dim3(kThreads), 0, stream, scratch, nb, total);
+  hipLaunchKernelGGL(scan_tile_apply, dim3((unsigned)nb), dim3(kThreads), 0, stream, in, out, n,
+                     scratch);
+  return hipGetLastError();
+}
+
+size_t radix_scratch_words(size_t n) {
+  const size_t nb = (n + kSortTile - 1) / kSortTile;
+  return (size_t)kRadix * nb + scan_scratch_words((size_t)kRadix * nb);
+}
+
+hipError_t radix_sort_pairs(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1,
+                            size_t n, int bit_lo, int bit_hi, uint32_t* scratch,
+                            hipStream_t stream, bool* result_in_second) {
+  *result_in_second = false;
+  if (n == 0 || bit_hi <= bit_lo) return hipSuccess;
+  const size_t nb = (n + kSortTile - 1) / kSortTile;
+  uint32_t* hist = scratch;
+  uint32_t* scan_scratch = scratch + (size_t)kRadix * nb;
+  uint32_t *ki = keys0, *vi = vals0, *ko = keys1, *vo = vals1;
+  for (int shift = bit_lo; shift < bit_hi; shift += kRadixBits) {
+    const int bits = (bit_hi - shift) < kRadixBits ? (bit_hi - shift) : kRadixBits;
+    const uint32_t mask = (1u << bits) - 1u;
+    hipLaunchKernelGGL(radix_hist, dim3((unsigned)nb), dim3(kThreads), 0, stream, ki, n, shift,
+                       mask, nb, hist);
+    hipError_t e = exclusive_scan_u32(hist, hist, (size_t)kRadix * nb, nullptr, scan_scratch, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(radix_scatter, dim3((unsigned)nb), dim3(kThreads), 0, stream, ki, vi, ko, vo,
+                       n, shift, mask, nb, hist);
+    uint32_t* t = ki; ki = ko; ko = t;
+    t = vi; vi = vo; vo = t;
+    *result_in_second = !*result_in_second;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace plvs

@@ -1,0 +1,27 @@
+// Device-wide primitives used by the hot-path kernels: exclusive scan and a
+// stable LSD radix sort of (key, value) pairs.  Internal C++ API (not part of
+// the C ABI).  All calls are asynchronous on `stream`.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace plvs {
+
+// Scratch requirement (in uint32 words) of exclusive_scan_u32 for n items.
+size_t scan_scratch_words(size_t n);
+// out[i] = sum(in[0..i)); *total (device word, may be null) = sum(in[0..n)).
+// in == out is allowed.
+hipError_t exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint32_t* total,
+                              uint32_t* scratch, hipStream_t stream);
+
+// Scratch requirement (uint32 words) of radix_sort_pairs for n items.
+size_t radix_scratch_words(size_t n);
+// Stable sort of n (key,val) pairs by key bits [bit_lo, bit_hi).  Ping-pongs
+// between (keys0,vals0) and (keys1,vals1); *result_in_second tells where the
+// sorted data ended up.  n is a host value.
+hipError_t radix_sort_pairs(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1,
+                            size_t n, int bit_lo, int bit_hi, uint32_t* scratch,
+                            hipStream_t stream, bool* result_in_second);
+
+}  // namespace plvs

@@ -1,0 +1,234 @@
+// Per-ray and per-voxel arithmetic of the open_chisel point-cloud integrate,
+// shared by every TSDF kernel (and compilable on the host for unit checks of
+// the device logic).  Evaluation order is part of the contract: results must
+// round exactly like Chisel.cpp / Raycast.cpp built against Eigen 3.3 (3-term
+// reductions are a0 + (a1 + a2); an affine transform of a point is t + R p),
+// and the translation unit is built with -ffp-contract=off.
+//
+// Reference: Thirdparty/open_chisel/src/Chisel.cpp:442-550,
+//            Thirdparty/open_chisel/src/geometry/Raycast.cpp:6-182,
+//            include/open_chisel/ChunkManager.h:42-54, 192-206.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define PLVS_HD __host__ __device__ __forceinline__
+#else
+#define PLVS_HD inline
+#endif
+
+namespace plvs {
+namespace chisel {
+
+constexpr int kChunkVox = 4096;        // 16^3 voxels, id = (z*16+y)*16+x  (Chunk.h:90-93)
+constexpr int kRayStepGuard = 1 << 16; // the reference loop is unbounded
+
+struct Pose {        // one per cloud
+  float R[9], t[3];  // camera -> world (Twc)
+  float Ri[9], ti[3];// Transform::inverse() of it
+};
+
+struct Params {
+  float resolution, round_to_voxel, half_voxel, rounding, diag;
+  float tq, tl, tc, ts, weight;
+  int shard_rank, shard_count;
+};
+
+PLVS_HD float sum3(float a, float b, float c) { return a + (b + c); }
+PLVS_HD float sqnorm3(float a, float b, float c) { return sum3(a * a, b * b, c * c); }
+
+PLVS_HD void xform(const float* R, const float* t, float px, float py, float pz, float* out) {
+  out[0] = t[0] + sum3(R[0] * px, R[1] * py, R[2] * pz);
+  out[1] = t[1] + sum3(R[3] * px, R[4] * py, R[5] * pz);
+  out[2] = t[2] + sum3(R[6] * px, R[7] * py, R[8] * pz);
+}
+
+PLVS_HD float cof3(const float* m, int i, int j) {
+  const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return m[3 * i1 + j1] * m[3 * i2 + j2] - m[3 * i1 + j2] * m[3 * i2 + j1];
+}
+
+// Eigen Transform<float,3,Affine>::inverse(): cofactor inverse, t' = (-R^-1) t.
+PLVS_HD void make_pose(const float* Twc /*3x4 row-major*/, Pose* p) {
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) p->R[3 * i + j] = Twc[4 * i + j];
+    p->t[i] = Twc[4 * i + 3];
+  }
+  const float* R = p->R;
+  const float c00 = cof3(R, 0, 0), c10 = cof3(R, 1, 0), c20 = cof3(R, 2, 0);
+  const float det = sum3(c00 * R[0], c10 * R[3], c20 * R[6]);
+  const float invdet = 1.0f / det;
+  float* Ri = p->Ri;
+  Ri[0] = c00 * invdet; Ri[1] = c10 * invdet; Ri[2] = c20 * invdet;
+  Ri[3] = cof3(R, 0, 1) * invdet; Ri[4] = cof3(R, 1, 1) * invdet; Ri[5] = cof3(R, 2, 1) * invdet;
+  Ri[6] = cof3(R, 0, 2) * invdet; Ri[7] = cof3(R, 1, 2) * invdet; Ri[8] = cof3(R, 2, 2) * invdet;
+  for (int i = 0; i < 3; ++i)
+    p->ti[i] = sum3((-Ri[3 * i + 0]) * p->t[0], (-Ri[3 * i + 1]) * p->t[1], (-Ri[3 * i + 2]) * p->t[2]);
+}
+
+// Raycast.cpp:12-15: fmod(fmod(v,1)+1, 1) evaluated in double (the unqualified
+// call picks the double overload), returned as float.  fmod(a,1) == a - trunc(a)
+// exactly for the magnitudes involved, which keeps this off the slow ocml fmod.
+PLVS_HD float rc_mod1(float value) {
+  double r = (double)value;
+  r = r - trunc(r);
+  r = r + 1.0;
+  r = r - trunc(r);
+  return (float)r;
+}
+// Raycast.cpp:17-30
+PLVS_HD float rc_intbound(float s, float ds) {
+  if (ds < 0) { s = -s; ds = -ds; }
+  s = rc_mod1(s);
+  return (1 - s) / ds;
+}
+PLVS_HD int rc_signum(int x) { return (x > 0) ? 1 : ((x < 0) ? -1 : 0); }
+
+// QuadraticTruncator::GetTruncationDistance floored by 2*sqrt(3)*res (Chisel.cpp:479).
+PLVS_HD float truncation_of(const Params& P, float depth) {
+  const float q = (P.tq * depth * depth + P.tl * depth + P.tc) * P.ts;
+  return q > P.diag ? q : P.diag;
+}
+
+// Everything a ray needs (Chisel.cpp:472-488).
+struct Ray {
+  float start[3], end[3];
+  float depth, truncation;
+};
+
+PLVS_HD bool make_ray(const Params& P, const Pose& pose, float px, float py, float pz, Ray* r) {
+  if (pz < 0.01f) return false;  // Chisel.cpp:475
+  float w[3];
+  xform(pose.R, pose.t, px, py, pz, w);
+  const float v0 = w[0] - pose.t[0], v1 = w[1] - pose.t[1], v2 = w[2] - pose.t[2];
+  const float z2 = sqnorm3(v0, v1, v2);
+  float d0 = v0, d1 = v1, d2 = v2;
+  if (z2 > 0.0f) {
+    const float nrm = sqrtf(z2);
+    d0 = v0 / nrm; d1 = v1 / nrm; d2 = v2 / nrm;
+  }
+  const float tr = truncation_of(P, pz);
+  const float d[3] = {d0, d1, d2};
+  for (int k = 0; k < 3; ++k) {
+    const float swp = w[k] * P.round_to_voxel;
+    const float sdt = d[k] * tr * P.round_to_voxel;
+    r->start[k] = swp - sdt;
+    r->end[k] = swp + sdt;
+  }
+  r->depth = pz;
+  r->truncation = tr;
+  return true;
+}
+
+// ChunkHasher (ChunkManager.h:42-54), size_t arithmetic; used only for sharding.
+PLVS_HD uint64_t chunk_hash(int x, int y, int z) {
+  return ((uint64_t)(int64_t)x * 73856093ull) ^ ((uint64_t)(int64_t)y * 19349663ull) ^
+         ((uint64_t)(int64_t)z * 83492791ull);
+}
+
+// What one raycast voxel resolves to (Chisel.cpp:505-531).
+struct Visit {
+  int cx, cy, cz;  // chunk id
+  int vid;         // voxel id inside the chunk
+  float u;         // signed distance along the ray
+};
+
+PLVS_HD float signed_dist(const Pose& pose, float depth, float c0, float c1, float c2) {
+  float cc[3];
+  xform(pose.Ri, pose.ti, c0, c1, c2, cc);
+  const float length = sqrtf(sqnorm3(cc[0], cc[1], cc[2]));
+  return length * (depth / cc[2] - 1);
+}
+
+// Returns true when the voxel takes an update (owned, valid local id, |u| < truncation).
+PLVS_HD bool resolve_visit(const Params& P, const Pose& pose, const Ray& ray, int vx, int vy, int vz,
+                           Visit* v) {
+  const float c0 = (float)vx * P.resolution + P.half_voxel;
+  const float c1 = (float)vy * P.resolution + P.half_voxel;
+  const float c2 = (float)vz * P.resolution + P.half_voxel;
+  v->cx = (int)floorf(c0 * P.rounding);
+  v->cy = (int)floorf(c1 * P.rounding);
+  v->cz = (int)floorf(c2 * P.rounding);
+  if (P.shard_count > 1 &&
+      (int)(chunk_hash(v->cx, v->cy, v->cz) % (uint64_t)P.shard_count) != P.shard_rank)
+    return false;
+  const int lx = vx - v->cx * 16, ly = vy - v->cy * 16, lz = vz - v->cz * 16;
+  v->vid = (lz * 16 + ly) * 16 + lx;
+  if (!(v->vid >= 0 && v->vid < kChunkVox)) return false;
+  v->u = signed_dist(pose, ray.depth, c0, c1, c2);
+  return fabsf(v->u) < ray.truncation;
+}
+
+// chisel::Raycast as a resumable cursor (Raycast.cpp:65-182).
+struct RayCursor {
+  int x, y, z, endX, endY, endZ, stepX, stepY, stepZ;
+  float tMaxX, tMaxY, tMaxZ, tDeltaX, tDeltaY, tDeltaZ, maxDist;
+  float sx, sy, sz;
+  int guard;
+  bool done;
+};
+
+PLVS_HD void ray_begin(const Ray& r, RayCursor* c) {
+  c->sx = r.start[0]; c->sy = r.start[1]; c->sz = r.start[2];
+  c->x = (int)floorf(r.start[0]); c->y = (int)floorf(r.start[1]); c->z = (int)floorf(r.start[2]);
+  c->endX = (int)floorf(r.end[0]); c->endY = (int)floorf(r.end[1]); c->endZ = (int)floorf(r.end[2]);
+  c->maxDist = sqnorm3(r.end[0] - r.start[0], r.end[1] - r.start[1], r.end[2] - r.start[2]);
+  const float dx = (float)(c->endX - c->x), dy = (float)(c->endY - c->y), dz = (float)(c->endZ - c->z);
+  c->stepX = rc_signum((int)dx); c->stepY = rc_signum((int)dy); c->stepZ = rc_signum((int)dz);
+  c->tMaxX = rc_intbound(r.start[0], dx);
+  c->tMaxY = rc_intbound(r.start[1], dy);
+  c->tMaxZ = rc_intbound(r.start[2], dz);
+  c->tDeltaX = ((float)c->stepX) / dx;
+  c->tDeltaY = ((float)c->stepY) / dy;
+  c->tDeltaZ = ((float)c->stepZ) / dz;
+  c->guard = 0;
+  c->done = (c->stepX == 0 && c->stepY == 0 && c->stepZ == 0);
+}
+
+// Emits the current voxel into (vx,vy,vz) and advances; false when the ray is exhausted.
+PLVS_HD bool ray_next(RayCursor* c, int* vx, int* vy, int* vz) {
+  if (c->done) return false;
+  *vx = c->x; *vy = c->y; *vz = c->z;
+  // (the reference's bounds test against -/+INT_MAX only rejects INT_MAX itself)
+  const float d = sqnorm3((float)c->x - c->sx, (float)c->y - c->sy, (float)c->z - c->sz);
+  if (d > c->maxDist) { c->done = true; return true; }
+  if (c->x == c->endX && c->y == c->endY && c->z == c->endZ) { c->done = true; return true; }
+  if (c->tMaxX < c->tMaxY) {
+    if (c->tMaxX < c->tMaxZ) { c->x += c->stepX; c->tMaxX += c->tDeltaX; }
+    else                     { c->z += c->stepZ; c->tMaxZ += c->tDeltaZ; }
+  } else {
+    if (c->tMaxY < c->tMaxZ) { c->y += c->stepY; c->tMaxY += c->tDeltaY; }
+    else                     { c->z += c->stepZ; c->tMaxZ += c->tDeltaZ; }
+  }
+  if (++c->guard >= kRayStepGuard) c->done = true;
+  return true;
+}
+
+// DistVoxel::Integrate + SetKfid + ColorVoxel::IntegrateSimple(r,g,b,1)
+// (DistVoxel.h:91-99, ColorVoxel.h:91-110).
+PLVS_HD void apply_update(float& sdf, float& w, uint32_t& kfid, uint32_t& rgbw, float u, float wu,
+                          uint32_t new_kfid, uint32_t r, uint32_t g, uint32_t b) {
+  const float oldSDF = sdf, oldW = w;
+  sdf = (oldW * oldSDF + wu * u) / (wu + oldW);
+  w = oldW + wu;
+  kfid = new_kfid;
+  uint32_t red = rgbw & 255u, green = (rgbw >> 8) & 255u, blue = (rgbw >> 16) & 255u, cw = rgbw >> 24;
+  if (!(cw >= 254u)) {
+    const float inv = 1.f / (float)(1u + cw);
+    red = (uint32_t)(uint8_t)((float)(cw * red + r) * inv);
+    green = (uint32_t)(uint8_t)((float)(cw * green + g) * inv);
+    blue = (uint32_t)(uint8_t)((float)(cw * blue + b) * inv);
+    cw += 1u;
+    rgbw = red | (green << 8) | (blue << 16) | (cw << 24);
+  }
+}
+
+// Conversions.h:118-121 (u8 * 1/255) followed by Chisel.cpp:536 ((uint8_t)(c * 255.0f)).
+PLVS_HD uint32_t colour_roundtrip(uint32_t c) {
+  const float byteToFloat = 1.0f / 255.0f;
+  return (uint32_t)(uint8_t)(((float)c * byteToFloat) * 255.0f);
+}
+
+}  // namespace chisel
+}  // namespace plvs

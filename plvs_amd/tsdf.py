@@ -1,0 +1,150 @@
+"""Host-side mirror of PLVS's chisel volumetric back end.
+
+  PointCloudMapChisel.InsertCloud(cloud_camera, Twc, max_range)
+      <-> PLVS2::PointCloudMapChisel<PointT>::InsertCloud  (src/PointCloudMapChisel.cc:76-98)
+          -> ChiselServer::SetPointCloud / IntegrateLastPointCloud
+             (Thirdparty/chisel_server/src/ChiselServer.cpp:561, 664)
+          -> chisel::Chisel::IntegratePointCloudWidthDepth
+             (Thirdparty/open_chisel/src/Chisel.cpp:442-585)
+  Clear() <-> PointCloudMap::Clear ; GetChunk/ChunkIds give the map back.
+
+All compute happens in libplvs_hip.so; this file only marshals arguments.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class TsdfChisel:
+    """Thin RAII wrapper of the plvs_hip_tsdf_chisel_* C ABI."""
+
+    def __init__(self, resolution, max_chunks=None, shard_rank=0, shard_count=1):
+        p = _lib.TsdfChiselParams()
+        _lib.check(_lib.lib.plvs_hip_tsdf_chisel_default_params(ctypes.c_float(resolution), ctypes.byref(p)))
+        if max_chunks is not None:
+            p.max_chunks = int(max_chunks)
+        p.shard_rank, p.shard_count = int(shard_rank), int(shard_count)
+        self.params = p
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.lib.plvs_hip_tsdf_chisel_create(ctypes.byref(p), ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            _lib.lib.plvs_hip_tsdf_chisel_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clear(self):
+        _lib.check(_lib.lib.plvs_hip_tsdf_chisel_clear(self._h))
+
+    def integrate(self, xyz, rgb, kfid, Twc):
+        """Host flavour: numpy arrays in camera frame + 3x4 pose."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(-1, 3)
+        kfid = None if kfid is None else np.ascontiguousarray(kfid, dtype=np.uint32)
+        Twc = np.ascontiguousarray(Twc, dtype=np.float32).reshape(3, 4)
+        _lib.check(_lib.lib.plvs_hip_tsdf_chisel_integrate(
+            self._h, _lib.np_ptr(xyz), _lib.np_ptr(rgb), _lib.np_ptr(kfid), xyz.shape[0], _lib.np_ptr(Twc)))
+
+    def integrate_batch_dev(self, d_xyz, d_rgb, d_kfid, offsets, d_Twc):
+        """Device flavour: concatenated clouds resident in HBM (torch tensors),
+        `offsets` a host int32 array of nclouds+1, d_Twc [nclouds,3,4] f32."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        _lib.check(_lib.lib.plvs_hip_tsdf_chisel_integrate_batch_dev(
+            self._h, _lib.t_ptr(d_xyz), _lib.t_ptr(d_rgb), _lib.t_ptr(d_kfid), _lib.np_ptr(offsets),
+            offsets.shape[0] - 1, _lib.t_ptr(d_Twc), _lib.current_stream_ptr()))
+
+    def last_stats(self):
+        s = _lib.TsdfStats()
+        _lib.check(_lib.lib.plvs_hip_tsdf_chisel_last_stats(self._h, ctypes.byref(s)))
+        return dict(visits=s.visits, points=s.points, new_chunks=s.new_chunks,
+                    updated_chunks=s.updated_chunks)
+
+    def set_profiling(self, enable=True):
+        _lib.check(_lib.lib.plvs_hip_tsdf_chisel_set_profiling(self._h, int(bool(enable))))
+
+    def stage_ms(self):
+        """{stage name: accumulated ms}, number of integrate calls covered."""
+        ms = (ctypes.c_double * 16)()
+        n = ctypes.c_int()
+        calls = ctypes.c_int64()
+        _lib.check(_lib.lib.plvs_hip_tsdf_chisel_stage_ms(self._h, ms, 16, ctypes.byref(n), ctypes.byref(calls)))
+        names = [_lib.lib.plvs_hip_tsdf_chisel_stage_name(i).decode() for i in range(n.value)]
+        return {names[i]: ms[i] for i in range(n.value)}, calls.value
+
+    def updated_chunk_ids_dev(self, d_ids):
+        """Writes the updated-chunk id triples into the torch int32 tensor d_ids
+        [cap,3]; returns the number of updated chunks."""
+        n = ctypes.c_int()
+        _lib.check(_lib.lib.plvs_hip_tsdf_chisel_updated_chunk_ids_dev(
+            self._h, _lib.t_ptr(d_ids), d_ids.shape[0], ctypes.byref(n), _lib.current_stream_ptr()))
+        return n.value
+
+    def num_chunks(self):
+        n = ctypes.c_int()
+        _lib.check(_lib.lib.plvs_hip_tsdf_chisel_num_chunks(self._h, ctypes.byref(n)))
+        return n.value
+
+    def chunk_ids(self):
+        n = self.num_chunks()
+        ids = np.zeros((max(n, 1), 3), dtype=np.int32)
+        m = ctypes.c_int()
+        _lib.check(_lib.lib.plvs_hip_tsdf_chisel_chunk_ids(self._h, _lib.np_ptr(ids), n, ctypes.byref(m)))
+        return ids[:n]
+
+    def updated_chunk_ids(self):
+        m = ctypes.c_int()
+        _lib.check(_lib.lib.plvs_hip_tsdf_chisel_updated_chunk_ids(self._h, None, 0, ctypes.byref(m)))
+        ids = np.zeros((max(m.value, 1), 3), dtype=np.int32)
+        _lib.check(_lib.lib.plvs_hip_tsdf_chisel_updated_chunk_ids(self._h, _lib.np_ptr(ids), m.value, ctypes.byref(m)))
+        return ids[:m.value]
+
+    def get_chunk(self, cx, cy, cz):
+        sdf = np.empty(4096, np.float32)
+        w = np.empty(4096, np.float32)
+        kf = np.empty(4096, np.uint32)
+        col = np.empty(4096, np.uint32)
+        _lib.check(_lib.lib.plvs_hip_tsdf_chisel_download_chunk(
+            self._h, int(cx), int(cy), int(cz), _lib.np_ptr(sdf), _lib.np_ptr(w), _lib.np_ptr(kf), _lib.np_ptr(col)))
+        return sdf, w, kf, col
+
+
+class PointCloudMapChisel:
+    """Same surface as PLVS2::PointCloudMapChisel for the integrate path."""
+
+    def __init__(self, resolution, min_depth=0.1, max_depth=5.0, use_carving=False, max_chunks=None):
+        if use_carving:
+            raise NotImplementedError("depth carving (InsertCloudWithDepth) is not on the accelerated path yet")
+        self.resolution = resolution
+        self.min_depth, self.max_depth = min_depth, max_depth
+        self._tsdf = TsdfChisel(resolution, max_chunks=max_chunks)
+
+    def InsertCloud(self, cloud_camera, Twc, max_range=None):
+        """cloud_camera: dict/obj with xyz [n,3] f32, rgb [n,3] u8 (r,g,b members of
+        the pcl point), kfid [n] u32.  Twc: 3x4 (or 4x4) camera pose."""
+        print("PointCloudMapChisel<PointT>::InsertCloud()")
+        Twc = np.asarray(Twc, dtype=np.float32)[:3, :4]
+        self._tsdf.integrate(cloud_camera["xyz"], cloud_camera["rgb"], cloud_camera.get("kfid"), Twc)
+
+    def InsertData(self, pData):
+        """PointCloudMapInput dispatch (src/PointCloudMapChisel.cc:192-225): only the
+        point-cloud input type is handled; anything else terminates the reference."""
+        t = pData.get("type", "kPointCloud")
+        if t != "kPointCloud":
+            raise SystemExit(-1)
+        self.InsertCloud(pData["pPointCloud"], pData["Twc"], pData.get("maxRange", self.max_depth))
+
+    def Clear(self):
+        self._tsdf.clear()
+
+    @property
+    def tsdf(self):
+        return self._tsdf

@@ -1,0 +1,214 @@
+"""Chisel TSDF integrate: oracle self-checks + device arithmetic on the host (CPU),
+HIP path vs oracle (GPU).
+
+Bar: the HIP path is BIT-EXACT against the oracle for sdf, weight, kfid and the
+u8 colours (the north-star only asks for a float tolerance on sdf/weight; the
+device path keeps the reference's per-voxel update order, so no tolerance is
+needed: TOL = 0).
+"""
+import numpy as np
+import pytest
+
+from tests.plvs_amd_synth import make_keyframes, TUM1
+
+TOL = 0.0  # absolute tolerance on sdf / weight (bit-exact)
+
+
+def small_cam(scale=4):
+    c = dict(TUM1)
+    for k in ("fx", "fy", "cx", "cy"):
+        c[k] = c[k] / scale
+    c["width"] //= scale
+    c["height"] //= scale
+    return c
+
+
+def compare_maps(a, b, tol=TOL):
+    ia = {tuple(x) for x in a.chunk_ids()}
+    ib = {tuple(x) for x in b.chunk_ids()}
+    assert ia == ib, f"chunk sets differ: {len(ia)} vs {len(ib)}, only-a {sorted(ia - ib)[:5]}, only-b {sorted(ib - ia)[:5]}"
+    for cid in sorted(ia):
+        ca, cb = a.get_chunk(*cid), b.get_chunk(*cid)
+        if tol == 0.0:
+            assert np.array_equal(ca[0].view(np.uint32), cb[0].view(np.uint32)), f"sdf differs in chunk {cid}"
+            assert np.array_equal(ca[1].view(np.uint32), cb[1].view(np.uint32)), f"weight differs in chunk {cid}"
+        else:
+            assert np.allclose(ca[0], cb[0], rtol=0, atol=tol)
+            assert np.allclose(ca[1], cb[1], rtol=0, atol=tol)
+        assert np.array_equal(ca[2], cb[2]), f"kfid differs in chunk {cid}"
+        assert np.array_equal(ca[3], cb[3]), f"colour differs in chunk {cid}"
+    return len(ia)
+
+
+# ------------------------------------------------------------------ CPU
+def test_oracle_single_point_known_answer(oracle):
+    """One point straight ahead at 0.8 m, identity pose, 5 cm voxels: the ray runs
+    along +z through voxel column (0,0,*), straddling the chunk boundary at
+    0.8 m; every updated voxel (centre c) holds sdf = |c| * (0.8 / c_z - 1)."""
+    m = oracle.chisel(0.05)
+    Twc = np.eye(4, dtype=np.float32)[:3]
+    m.integrate(np.array([[0.0, 0.0, 0.8]], np.float32), np.array([[255, 128, 0]], np.uint8),
+                np.array([7], np.uint32), Twc)
+    tr = max(6 * (0.0019 * 0.64 - 0.00152 * 0.8 + 0.001504), 2 * np.sqrt(3) * 0.05)
+    assert m.last_visits() in (6, 7, 8)
+    assert m.num_chunks() == 2          # z voxels 12..19 straddle chunk z=0 / z=1 (0.8 m)
+    seen = 0
+    for cid in m.chunk_ids():
+        sdf, w, kf, col = m.get_chunk(*cid)
+        idx = np.nonzero(w > 0)[0]
+        for vid in idx:
+            lz = vid >> 8
+            cz = (cid[2] * 16 + lz) * 0.05 + 0.025
+            cx = 0.025
+            expect = np.sqrt(cx * cx * 2 + cz * cz) * (0.8 / cz - 1.0)
+            assert abs(sdf[vid] - expect) < 1e-5
+            assert abs(sdf[vid]) < tr
+            assert abs(w[vid] - 1.0 / (2 * tr)) < 1e-5
+            assert kf[vid] == 7
+            assert col[vid] == (255 | (128 << 8) | (0 << 16) | (1 << 24))
+            seen += 1
+    assert seen == m.last_visits()
+
+
+def test_oracle_skips_near_points_and_empty(oracle):
+    m = oracle.chisel(0.05)
+    Twc = np.eye(4, dtype=np.float32)[:3]
+    m.integrate(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint8), np.zeros(0, np.uint32), Twc)
+    assert m.num_chunks() == 0
+    m.integrate(np.array([[0, 0, 0.005], [0, 0, -1.0]], np.float32), np.zeros((2, 3), np.uint8),
+                np.zeros(2, np.uint32), Twc)
+    assert m.num_chunks() == 0 and m.last_visits() == 0
+
+
+def test_oracle_colour_weight_saturates(oracle):
+    """ColorVoxel weight stops at 254 while the distance weight keeps growing."""
+    m = oracle.chisel(0.05)
+    Twc = np.eye(4, dtype=np.float32)[:3]
+    n = 300
+    xyz = np.tile(np.array([[0.01, 0.01, 1.0]], np.float32), (n, 1))
+    rgb = np.tile(np.array([[200, 100, 50]], np.uint8), (n, 1))
+    m.integrate(xyz, rgb, np.arange(n, dtype=np.uint32), Twc)
+    tot = 0
+    for cid in m.chunk_ids():
+        sdf, w, kf, col = m.get_chunk(*cid)
+        for vid in np.nonzero(w > 0)[0]:
+            assert (col[vid] >> 24) == 254
+            assert kf[vid] == n - 1
+            tot += 1
+    assert tot * n == m.last_visits()
+
+
+@pytest.mark.parametrize("res,nkf", [(0.05, 3), (0.02, 2), (0.10, 3)])
+def test_device_arithmetic_on_host_matches_oracle(oracle, res, nkf):
+    """tsdf_chisel_core.hpp (what the kernels run) compiled with g++ and driven
+    sequentially must reproduce the oracle bit for bit."""
+    from tests import oracle_lib
+    host = oracle_lib._ChiselLike(oracle_lib.load_hostcore(), "hostcore", res)
+    ora = oracle.chisel(res)
+    for kf in make_keyframes(nkf, cam=small_cam(4), seed=3):
+        ora.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+        host.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+        assert ora.last_visits() == host.last_visits() > 0
+    assert compare_maps(ora, host) > 3
+
+
+def test_oracle_shards_partition_the_map(oracle):
+    """Owner(chunk) = ChunkHasher(id) mod N: the shards are disjoint and their
+    union is the unsharded map, voxel for voxel."""
+    kfs = make_keyframes(2, cam=small_cam(4), seed=5)
+    full = oracle.chisel(0.05)
+    shards = [oracle.chisel(0.05, shard_rank=r, shard_count=3) for r in range(3)]
+    for kf in kfs:
+        for m in [full] + shards:
+            m.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+    ids = [set(map(tuple, s.chunk_ids())) for s in shards]
+    assert not (ids[0] & ids[1]) and not (ids[0] & ids[2]) and not (ids[1] & ids[2])
+    assert ids[0] | ids[1] | ids[2] == set(map(tuple, full.chunk_ids()))
+    for s in shards:
+        for cid in s.chunk_ids():
+            a, b = s.get_chunk(*cid), full.get_chunk(*cid)
+            assert all(np.array_equal(x.view(np.uint32), y.view(np.uint32)) for x, y in zip(a, b))
+
+
+# ------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("res,nkf,scale", [(0.05, 4, 4), (0.02, 2, 4), (0.10, 3, 2), (0.05, 2, 1)])
+def test_hip_matches_oracle_bit_exact(oracle, res, nkf, scale):
+    from plvs_amd.tsdf import TsdfChisel
+    ora = oracle.chisel(res)
+    dev = TsdfChisel(res, max_chunks=4096)
+    for kf in make_keyframes(nkf, cam=small_cam(scale), seed=11):
+        ora.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+        dev.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+        st = dev.last_stats()
+        assert st["visits"] == ora.last_visits()
+        assert st["points"] == kf["xyz"].shape[0]
+    assert compare_maps(ora, dev) > 3
+    dev.close()
+
+
+@pytest.mark.gpu
+def test_hip_batch_equals_sequential_and_oracle(oracle):
+    """integrate_batch_dev over K clouds == K single calls == oracle."""
+    import torch
+    from plvs_amd.tsdf import TsdfChisel
+    kfs = make_keyframes(5, cam=small_cam(2), seed=13)
+    ora = oracle.chisel(0.05)
+    for kf in kfs:
+        ora.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+    dev = TsdfChisel(0.05, max_chunks=4096)
+    xyz = torch.from_numpy(np.concatenate([k["xyz"] for k in kfs])).cuda()
+    rgb = torch.from_numpy(np.concatenate([k["rgb"] for k in kfs])).cuda()
+    kfid = torch.from_numpy(np.concatenate([k["kfid"] for k in kfs]).astype(np.int32)).cuda()
+    Twc = torch.from_numpy(np.stack([k["Twc"] for k in kfs])).cuda()
+    offsets = np.cumsum([0] + [k["xyz"].shape[0] for k in kfs]).astype(np.int32)
+    dev.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
+    torch.cuda.synchronize()
+    assert dev.last_stats()["points"] == offsets[-1]
+    compare_maps(ora, dev)
+    upd = set(map(tuple, dev.updated_chunk_ids()))
+    assert upd == set(map(tuple, dev.chunk_ids()))     # first call: every chunk is new and updated
+    dev.close()
+
+
+@pytest.mark.gpu
+def test_hip_edge_cases(oracle):
+    from plvs_amd import _lib
+    from plvs_amd.tsdf import TsdfChisel
+    dev = TsdfChisel(0.05, max_chunks=64)
+    Twc = np.eye(4, dtype=np.float32)[:3]
+    dev.integrate(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint8), np.zeros(0, np.uint32), Twc)
+    assert dev.num_chunks() == 0
+    dev.integrate(np.array([[0, 0, 0.005], [0, 0, -1.0]], np.float32), np.zeros((2, 3), np.uint8),
+                  np.zeros(2, np.uint32), Twc)
+    assert dev.num_chunks() == 0 and dev.last_stats()["visits"] == 0
+    # colour-weight saturation + many updates of the same voxels in one call
+    n = 300
+    xyz = np.tile(np.array([[0.01, 0.01, 1.0]], np.float32), (n, 1))
+    rgb = np.tile(np.array([[200, 100, 50]], np.uint8), (n, 1))
+    ora = oracle.chisel(0.05)
+    ora.integrate(xyz, rgb, np.arange(n, dtype=np.uint32), Twc)
+    dev.integrate(xyz, rgb, np.arange(n, dtype=np.uint32), Twc)
+    compare_maps(ora, dev)
+    # clear, then pool overflow must fail loudly
+    dev.clear()
+    assert dev.num_chunks() == 0
+    big = make_keyframes(1, seed=1)[0]
+    with pytest.raises(_lib.PlvsHipError) as e:
+        dev.integrate(big["xyz"], big["rgb"], big["kfid"], big["Twc"])
+    assert e.value.code == _lib.PLVS_ERR_CAPACITY
+    dev.close()
+
+
+@pytest.mark.gpu
+def test_hip_shards_match_oracle_shards(oracle):
+    from plvs_amd.tsdf import TsdfChisel
+    kfs = make_keyframes(2, cam=small_cam(2), seed=17)
+    for rank in range(2):
+        ora = oracle.chisel(0.05, shard_rank=rank, shard_count=2)
+        dev = TsdfChisel(0.05, max_chunks=4096, shard_rank=rank, shard_count=2)
+        for kf in kfs:
+            ora.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+            dev.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+        compare_maps(ora, dev)
+        dev.close()
