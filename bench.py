@@ -104,10 +104,14 @@ def main():
     t0 = time.perf_counter()
     visits = 0
     points = 0
+    max_run = 0
+    voxels = 0
     for s in range(args.warmup, total_steps):
         st = step(batches[s])
         visits += st["visits"]
         points += st["points"]
+        max_run = max(max_run, st["max_run"])
+        voxels += st["voxels"]
     barrier()
     elapsed = time.perf_counter() - t0
     stage_ms, calls = tsdf.stage_ms()
@@ -154,6 +158,7 @@ def main():
                        "resolution": args.resolution, "max_depth": args.max_depth,
                        "keyframes_per_step": args.batch, "points_per_step": int(points // args.steps),
                        "visits_per_step": int(visits_total // args.steps),
+                       "voxels_per_step": int(voxels // args.steps), "longest_voxel_run": int(max_run),
                        "parallelism": f"chunk-hash shard x{world}"},
             "roofline": roofline,
         }

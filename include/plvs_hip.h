@@ -149,12 +149,15 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
 
 /* Counters of the last integrate call: voxel read-modify-write visits applied
  * (the "Mvoxels" unit of the metric), points consumed, chunks newly created,
- * chunks updated. */
+ * chunks updated, distinct voxels updated, longest per-voxel update run. */
 typedef struct plvs_tsdf_stats {
   int64_t visits;
   int64_t points;
   int32_t new_chunks;
   int32_t updated_chunks;
+  int32_t voxels;    /* distinct voxels updated                                            */
+  int32_t max_run;   /* most updates any single voxel took (its updates are inherently     */
+                     /* sequential: the serial-latency floor of the call)                  */
 } plvs_tsdf_stats;
 int plvs_hip_tsdf_chisel_last_stats(plvs_tsdf_chisel* h, plvs_tsdf_stats* s);
 

@@ -51,6 +51,8 @@ class TsdfStats(ctypes.Structure):
         ("points", ctypes.c_int64),
         ("new_chunks", ctypes.c_int32),
         ("updated_chunks", ctypes.c_int32),
+        ("voxels", ctypes.c_int32),
+        ("max_run", ctypes.c_int32),
     ]
 
 

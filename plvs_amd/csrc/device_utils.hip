@@ -101,40 +101,48 @@ __global__ __launch_bounds__(kThreads) void scan_tile_apply(const uint32_t* __re
 }
 
 // ------------------------------------------------------------ radix sort
-constexpr int kRadixBits = 8;
-constexpr int kRadix = 1 << kRadixBits;
+constexpr int kMaxRadixBits = 11;
 constexpr int kSortItems = 16;                       // per thread
 constexpr int kSortTile = kThreads * kSortItems;     // 4096 keys per block
 constexpr int kWaveSpan = 64 * kSortItems;           // 1024 consecutive keys per wave
 
 // hist[d * nb + b] = number of keys of tile b whose digit is d.
+template <int kBits>
 __global__ __launch_bounds__(kThreads) void radix_hist(const uint32_t* __restrict__ keys, size_t n,
-                                                       int shift, uint32_t mask, size_t nb,
+                                                       int shift, size_t nb,
                                                        uint32_t* __restrict__ hist) {
+  constexpr int kRadix = 1 << kBits;
+  constexpr uint32_t kMask = kRadix - 1;
   __shared__ uint32_t h[kRadix];
-  h[threadIdx.x] = 0;
+  for (int d = threadIdx.x; d < kRadix; d += kThreads) h[d] = 0;
   __syncthreads();
   const size_t tile = (size_t)blockIdx.x * kSortTile;
 #pragma unroll 4
   for (int it = 0; it < kSortItems; ++it) {
     const size_t i = tile + (size_t)it * kThreads + threadIdx.x;
-    if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & kMask], 1u);
   }
   __syncthreads();
-  hist[(size_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+  for (int d = threadIdx.x; d < kRadix; d += kThreads) hist[(size_t)d * nb + blockIdx.x] = h[d];
 }
 
+template <int kBits>
 __global__ __launch_bounds__(kThreads) void radix_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n, int shift,
-    uint32_t mask, size_t nb, const uint32_t* __restrict__ hist_scanned) {
+    size_t nb, const uint32_t* __restrict__ hist_scanned) {
+  constexpr int kRadix = 1 << kBits;
+  constexpr uint32_t kMask = kRadix - 1;
   // wave_hist[w][d]: running count of digit d inside wave w's 1024-key span,
   // later turned into the wave's exclusive base inside the tile.
   __shared__ uint32_t wave_hist[kWaves][kRadix];
   __shared__ uint32_t gbase[kRadix];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (int w = 0; w < kWaves; ++w) wave_hist[w][threadIdx.x] = 0;
-  gbase[threadIdx.x] = hist_scanned[(size_t)threadIdx.x * nb + blockIdx.x];
+  for (int d = threadIdx.x; d < kRadix; d += kThreads) {
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) wave_hist[w][d] = 0;
+    gbase[d] = hist_scanned[(size_t)d * nb + blockIdx.x];
+  }
   __syncthreads();
 
   const size_t span = (size_t)blockIdx.x * kSortTile + (size_t)wid * kWaveSpan;
@@ -147,11 +155,11 @@ __global__ __launch_bounds__(kThreads) void radix_scatter(
     const bool valid = i < n;
     k[it] = valid ? keys_in[i] : 0u;
     v[it] = valid ? vals_in[i] : 0u;
-    const uint32_t d = (k[it] >> shift) & mask;
+    const uint32_t d = (k[it] >> shift) & kMask;
     // lanes holding the same digit (and a valid key)
     unsigned long long peers = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < kRadixBits; ++b) {
+    for (int b = 0; b < kBits; ++b) {
       const unsigned long long bal = __ballot((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? bal : ~bal;
     }
@@ -165,13 +173,13 @@ __global__ __launch_bounds__(kThreads) void radix_scatter(
     if (valid && before == 0) my_hist[d] = base + cnt;
   }
   __syncthreads();
-  // exclusive prefix over the waves, per digit (thread d owns digit d)
-  {
+  // exclusive prefix over the waves, per digit
+  for (int d = threadIdx.x; d < kRadix; d += kThreads) {
     uint32_t run = 0;
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) {
-      const uint32_t c = wave_hist[w][threadIdx.x];
-      wave_hist[w][threadIdx.x] = run;
+      const uint32_t c = wave_hist[w][d];
+      wave_hist[w][d] = run;
       run += c;
     }
   }
@@ -180,12 +188,26 @@ __global__ __launch_bounds__(kThreads) void radix_scatter(
   for (int it = 0; it < kSortItems; ++it) {
     const size_t i = span + (size_t)it * 64 + lane;
     if (i < n) {
-      const uint32_t d = (k[it] >> shift) & mask;
+      const uint32_t d = (k[it] >> shift) & kMask;
       const size_t pos = (size_t)gbase[d] + wave_hist[wid][d] + rank[it];
       keys_out[pos] = k[it];
       vals_out[pos] = v[it];
     }
   }
+}
+
+template <int kBits>
+hipError_t radix_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, size_t n,
+                      int shift, size_t nb, uint32_t* hist, uint32_t* scan_scratch,
+                      hipStream_t stream) {
+  constexpr size_t kRadix = (size_t)1 << kBits;
+  hipLaunchKernelGGL(radix_hist<kBits>, dim3((unsigned)nb), dim3(kThreads), 0, stream, ki, n, shift,
+                     nb, hist);
+  hipError_t e = exclusive_scan_u32(hist, hist, kRadix * nb, nullptr, scan_scratch, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(radix_scatter<kBits>, dim3((unsigned)nb), dim3(kThreads), 0, stream, ki, vi, ko,
+                     vo, n, shift, nb, hist);
+  return hipGetLastError();
 }
 
 }  // namespace
@@ -208,7 +230,8 @@ hipError_t exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint3
 
 size_t radix_scratch_words(size_t n) {
   const size_t nb = (n + kSortTile - 1) / kSortTile;
-  return (size_t)kRadix * nb + scan_scratch_words((size_t)kRadix * nb);
+  const size_t radix = (size_t)1 << kMaxRadixBits;
+  return radix * nb + scan_scratch_words(radix * nb);
 }
 
 hipError_t radix_sort_pairs(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1,
@@ -218,22 +241,29 @@ hipError_t radix_sort_pairs(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, u
   if (n == 0 || bit_hi <= bit_lo) return hipSuccess;
   const size_t nb = (n + kSortTile - 1) / kSortTile;
   uint32_t* hist = scratch;
-  uint32_t* scan_scratch = scratch + (size_t)kRadix * nb;
+  uint32_t* scan_scratch = scratch + ((size_t)1 << kMaxRadixBits) * nb;
+  // fewest passes with digits of at most kMaxRadixBits bits, bits spread evenly
+  // (a stray high bit of the key inside the last digit is harmless: callers
+  // guarantee keys < 2^bit_hi)
+  const int total = bit_hi - bit_lo;
+  const int passes = (total + kMaxRadixBits - 1) / kMaxRadixBits;
+  int bits = (total + passes - 1) / passes;
+  if (bits < 8) bits = 8;
   uint32_t *ki = keys0, *vi = vals0, *ko = keys1, *vo = vals1;
-  for (int shift = bit_lo; shift < bit_hi; shift += kRadixBits) {
-    const int bits = (bit_hi - shift) < kRadixBits ? (bit_hi - shift) : kRadixBits;
-    const uint32_t mask = (1u << bits) - 1u;
-    hipLaunchKernelGGL(radix_hist, dim3((unsigned)nb), dim3(kThreads), 0, stream, ki, n, shift,
-                       mask, nb, hist);
-    hipError_t e = exclusive_scan_u32(hist, hist, (size_t)kRadix * nb, nullptr, scan_scratch, stream);
+  for (int p = 0, shift = bit_lo; p < passes; ++p, shift += bits) {
+    hipError_t e;
+    switch (bits) {
+      case 8: e = radix_pass<8>(ki, vi, ko, vo, n, shift, nb, hist, scan_scratch, stream); break;
+      case 9: e = radix_pass<9>(ki, vi, ko, vo, n, shift, nb, hist, scan_scratch, stream); break;
+      case 10: e = radix_pass<10>(ki, vi, ko, vo, n, shift, nb, hist, scan_scratch, stream); break;
+      default: e = radix_pass<11>(ki, vi, ko, vo, n, shift, nb, hist, scan_scratch, stream); break;
+    }
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(radix_scatter, dim3((unsigned)nb), dim3(kThreads), 0, stream, ki, vi, ko, vo,
-                       n, shift, mask, nb, hist);
     uint32_t* t = ki; ki = ko; ko = t;
     t = vi; vi = vo; vo = t;
     *result_in_second = !*result_in_second;
   }
-  return hipGetLastError();
+  return hipSuccess;
 }
 
 }  // namespace plvs

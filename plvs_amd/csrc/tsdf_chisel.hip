@@ -20,9 +20,12 @@
 //   3. ray_fill    the same walk writes (voxel key, point index) records at
 //                  those offsets, i.e. globally sorted by point.
 //   4. radix sort  stable by voxel key -> per voxel, records in point order.
-//   5. apply       one thread per voxel run re-derives u / weight / colour from
-//                  the point and applies the run sequentially in registers:
-//                  each voxel is read and written once per call.
+//   5. expand      one thread per sorted record derives the update operands
+//                  (w_u*u, w_u) from the point — everything that is not order
+//                  dependent — and compacts the run heads.
+//   6. chain       one thread per voxel run folds its records sequentially in
+//                  registers (the f32 weighted mean and the truncating u8
+//                  colour mean): each voxel is read and written once per call.
 // Results are bit-identical to the sequential CPU loop.
 #include "common.hpp"
 #include "device_utils.hpp"
@@ -38,7 +41,7 @@ constexpr int kCoordBias = 1 << 20;  // chunk ids must lie in [-2^20, 2^20)
 
 constexpr int kNumStages = 6;
 const char* const kStageNames[kNumStages] = {"ray_count", "scan", "ray_fill", "radix_sort",
-                                             "find_heads", "apply_runs"};
+                                             "expand_records", "chain_runs"};
 
 enum ErrBits : uint32_t {
   kErrPoolFull = 1u,
@@ -60,6 +63,7 @@ struct Counters {           // device-side, read back once per call
   uint32_t err;
   uint32_t num_heads;
   uint32_t num_updated;
+  uint32_t max_run;
 };
 
 __device__ __forceinline__ bool pack_chunk(int x, int y, int z, unsigned long long* key) {
@@ -188,82 +192,185 @@ __global__ __launch_bounds__(256) void ray_pass(
   if (!kFill) counts[i] = n;
 }
 
-// Marks the first record of every voxel run (and of every chunk run).
-__global__ __launch_bounds__(256) void find_heads(const uint32_t* __restrict__ keys, uint32_t n,
-                                                  uint32_t* __restrict__ heads,
-                                                  uint32_t* __restrict__ updated_slots,
-                                                  Counters* __restrict__ ctr) {
+// Per sorted record: the update operands the sequential chain needs, computed
+// fully in parallel, plus the compaction of run heads / updated chunks.
+//   rec[r].x = w_u * u        the rounded product DistVoxel::Integrate adds
+//   rec[r].y = +-w_u          ConstantWeighter weight of the record's point;
+//                             negative on the LAST record of a voxel run
+//   rec_c[r] = r | g<<8 | b<<16 of the point (after the reference's u8->f32->u8 trip)
+constexpr int kExpandThreads = 1024;
+__global__ __launch_bounds__(kExpandThreads) void expand_records(
+    Params P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ pts, uint32_t n,
+    const float* __restrict__ xyz, const uint8_t* __restrict__ rgb,
+    const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses,
+    const int32_t* __restrict__ slot_ids, float2* __restrict__ rec, uint32_t* __restrict__ rec_c,
+    uint32_t* __restrict__ heads, uint32_t* __restrict__ updated_slots,
+    Counters* __restrict__ ctr) {
+  __shared__ uint32_t wave_cnt[2][kExpandThreads / 64];
+  __shared__ uint32_t block_base[2];
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   bool head = false, chead = false;
   uint32_t key = 0;
   if (r < n) {
     key = keys[r];
     const uint32_t prev = r ? keys[r - 1] : ~key;
+    const uint32_t next = (r + 1 < n) ? keys[r + 1] : ~key;
     head = (r == 0) || (key != prev);
     chead = (r == 0) || ((key >> 12) != (prev >> 12));
-  }
-  unsigned long long m = __ballot(head);
-  if (m) {
-    uint32_t base = 0;
-    const int leader = __ffsll((long long)m) - 1;
-    if (lane == leader) base = atomicAdd(&ctr->num_heads, (uint32_t)__popcll(m));
-    base = __shfl(base, leader, 64);
-    if (head) heads[base + (uint32_t)__popcll(m & lt)] = r;
-  }
-  m = __ballot(chead);
-  if (m) {
-    uint32_t base = 0;
-    const int leader = __ffsll((long long)m) - 1;
-    if (lane == leader) base = atomicAdd(&ctr->num_updated, (uint32_t)__popcll(m));
-    base = __shfl(base, leader, 64);
-    if (chead) updated_slots[base + (uint32_t)__popcll(m & lt)] = key >> 12;
-  }
-}
-
-// One thread per voxel run: apply the run's updates in point order.
-__global__ __launch_bounds__(256) void apply_runs(
-    Params P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ pts, uint32_t nrec,
-    const uint32_t* __restrict__ heads, const Counters* __restrict__ ctr,
-    const float* __restrict__ xyz, const uint8_t* __restrict__ rgb,
-    const uint32_t* __restrict__ kfid, const int32_t* __restrict__ offsets, int nclouds,
-    const Pose* __restrict__ poses, const int32_t* __restrict__ slot_ids, float* __restrict__ sdf,
-    float* __restrict__ weight, uint32_t* __restrict__ vkfid, uint32_t* __restrict__ rgbw) {
-  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-  if (h >= ctr->num_heads) return;
-  uint32_t r = heads[h];
-  const uint32_t key = keys[r];
-  const uint32_t slot = key >> 12, vid = key & 4095u;
-  const int lx = vid & 15, ly = (vid >> 4) & 15, lz = vid >> 8;
-  const int vx = slot_ids[3 * slot + 0] * 16 + lx, vy = slot_ids[3 * slot + 1] * 16 + ly,
-            vz = slot_ids[3 * slot + 2] * 16 + lz;
-  const float c0 = (float)vx * P.resolution + P.half_voxel;
-  const float c1 = (float)vy * P.resolution + P.half_voxel;
-  const float c2 = (float)vz * P.resolution + P.half_voxel;
-  const size_t a = (size_t)key;  // slot*4096 + vid
-  float s = sdf[a], w = weight[a];
-  uint32_t kf = vkfid[a], col = rgbw[a];
-  int cloud = -1, cbeg = 0, cend = 0;
-  Pose pose;
-  for (; r < nrec && keys[r] == key; ++r) {
     const int p = (int)pts[r];
-    if (cloud < 0 || p < cbeg || p >= cend) {
-      cloud = cloud_of(offsets, nclouds, p);
-      cbeg = offsets[cloud];
-      cend = offsets[cloud + 1];
-      pose = poses[cloud];
-    }
+    const uint32_t slot = key >> 12, vid = key & 4095u;
+    const int vx = slot_ids[3 * slot + 0] * 16 + (int)(vid & 15u);
+    const int vy = slot_ids[3 * slot + 1] * 16 + (int)((vid >> 4) & 15u);
+    const int vz = slot_ids[3 * slot + 2] * 16 + (int)(vid >> 8);
+    const float c0 = (float)vx * P.resolution + P.half_voxel;
+    const float c1 = (float)vy * P.resolution + P.half_voxel;
+    const float c2 = (float)vz * P.resolution + P.half_voxel;
+    const Pose& pose = poses[cloud_of(offsets, nclouds, p)];
     const float depth = xyz[3 * (size_t)p + 2];
     const float tr = truncation_of(P, depth);
     const float u = signed_dist(pose, depth, c0, c1, c2);
     const float wu = P.weight / (2.0f * tr);
-    apply_update(s, w, kf, col, u, wu, kfid ? kfid[p] : 0u, colour_roundtrip(rgb[3 * (size_t)p + 0]),
-                 colour_roundtrip(rgb[3 * (size_t)p + 1]), colour_roundtrip(rgb[3 * (size_t)p + 2]));
+    rec[r] = make_float2(wu * u, (key != next) ? -wu : wu);
+    rec_c[r] = colour_roundtrip(rgb[3 * (size_t)p + 0]) | (colour_roundtrip(rgb[3 * (size_t)p + 1]) << 8) |
+               (colour_roundtrip(rgb[3 * (size_t)p + 2]) << 16);
+  }
+  // block-aggregated, order-free compaction of the two head lists
+  const unsigned long long mh = __ballot(head), mc = __ballot(chead);
+  if (lane == 0) {
+    wave_cnt[0][wid] = (uint32_t)__popcll(mh);
+    wave_cnt[1][wid] = (uint32_t)__popcll(mc);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    uint32_t tot = 0;
+    for (int w = 0; w < kExpandThreads / 64; ++w) {
+      const uint32_t c = wave_cnt[threadIdx.x][w];
+      wave_cnt[threadIdx.x][w] = tot;
+      tot += c;
+    }
+    block_base[threadIdx.x] =
+        tot ? atomicAdd(threadIdx.x == 0 ? &ctr->num_heads : &ctr->num_updated, tot) : 0u;
+  }
+  __syncthreads();
+  if (head) heads[block_base[0] + wave_cnt[0][wid] + (uint32_t)__popcll(mh & lt)] = r;
+  if (chead) updated_slots[block_base[1] + wave_cnt[1][wid] + (uint32_t)__popcll(mc & lt)] = key >> 12;
+}
+
+// One thread per voxel run: the order-dependent part only.  The operands of a
+// run are contiguous and independent of the running value, so they are
+// software-pipelined kChainDepth batches of kChainBatch records ahead of the
+// dependent mul/add/div chain; the negative weight marks the run's last record.
+// A batch without an end marker is folded branch-free.
+constexpr int kChainBatch = 8;
+constexpr int kChainDepth = 4;
+
+struct ChainBatch {
+  float2 v[kChainBatch];
+};
+
+__device__ __forceinline__ void chain_load(const float2* __restrict__ rec, uint32_t r, uint32_t nrec,
+                                           ChainBatch& b) {
+#pragma unroll
+  for (int j = 0; j < kChainBatch; ++j) {
+    const uint32_t rr = r + (uint32_t)j;
+    b.v[j] = rec[rr < nrec ? rr : nrec - 1];  // clamped reads past the run end are never used
+  }
+}
+
+// Returns true when the run ended inside this batch (`last` = its last record).
+__device__ __forceinline__ bool chain_step(const ChainBatch& b, uint32_t r, float& s, float& w,
+                                           uint32_t& last) {
+  uint32_t signs = 0;
+#pragma unroll
+  for (int j = 0; j < kChainBatch; ++j) signs |= __float_as_uint(b.v[j].y);
+  if (!(signs >> 31)) {  // common case: the whole batch belongs to the run
+#pragma unroll
+    for (int j = 0; j < kChainBatch; ++j) dist_update(s, w, b.v[j].x, b.v[j].y);
+    return false;
+  }
+#pragma unroll
+  for (int j = 0; j < kChainBatch; ++j) {
+    dist_update(s, w, b.v[j].x, fabsf(b.v[j].y));
+    if (b.v[j].y < 0.0f) {
+      last = r + (uint32_t)j;
+      return true;
+    }
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(256) void chain_runs(
+    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ pts, uint32_t nrec,
+    const float2* __restrict__ rec, const uint32_t* __restrict__ heads,
+    Counters* __restrict__ ctr, const uint32_t* __restrict__ kfid, float* __restrict__ sdf,
+    float* __restrict__ weight, uint32_t* __restrict__ vkfid) {
+  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= ctr->num_heads) return;
+  uint32_t r = heads[h];
+  const uint32_t r0 = r;
+  const size_t a = (size_t)keys[r];  // slot*4096 + vid
+  ChainBatch b0, b1, b2, b3;
+  static_assert(kChainDepth == 4, "ring below is written for four batches in flight");
+  chain_load(rec, r, nrec, b0);
+  chain_load(rec, r + kChainBatch, nrec, b1);
+  chain_load(rec, r + 2 * kChainBatch, nrec, b2);
+  chain_load(rec, r + 3 * kChainBatch, nrec, b3);
+  float s = sdf[a], w = weight[a];
+  uint32_t last = r;
+  for (;;) {
+    if (chain_step(b0, r, s, w, last)) break;
+    chain_load(rec, r + 4 * kChainBatch, nrec, b0);
+    if (chain_step(b1, r + kChainBatch, s, w, last)) break;
+    chain_load(rec, r + 5 * kChainBatch, nrec, b1);
+    if (chain_step(b2, r + 2 * kChainBatch, s, w, last)) break;
+    chain_load(rec, r + 6 * kChainBatch, nrec, b2);
+    if (chain_step(b3, r + 3 * kChainBatch, s, w, last)) break;
+    chain_load(rec, r + 7 * kChainBatch, nrec, b3);
+    r += 4 * kChainBatch;
   }
   sdf[a] = s;
   weight[a] = w;
-  vkfid[a] = kf;
+  vkfid[a] = kfid ? kfid[pts[last]] : 0u;  // SetKfid: the last update wins
+  // longest run of the call = the serial-latency floor of this stage (reported in the stats)
+  const uint32_t len = last - r0 + 1u;
+  if (len > ctr->max_run) atomicMax(&ctr->max_run, len);  // stale reads only cost extra atomics
+}
+
+// The truncating u8 colour mean of ColorVoxel::IntegrateSimple: order
+// dependent, but frozen for good once the colour weight reaches 254, so a run
+// contributes at most (254 - weight) steps.  One thread per voxel run.
+__global__ __launch_bounds__(256) void chain_colours(
+    const uint32_t* __restrict__ keys, uint32_t nrec, const float2* __restrict__ rec,
+    const uint32_t* __restrict__ rec_c, const uint32_t* __restrict__ heads,
+    const Counters* __restrict__ ctr, uint32_t* __restrict__ rgbw) {
+  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= ctr->num_heads) return;
+  uint32_t r = heads[h];
+  const size_t a = (size_t)keys[r];
+  uint32_t col = rgbw[a];
+  if ((col >> 24) >= 254u) return;
+  for (;;) {
+    uint32_t c[4];
+    float y[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t rr = (r + j < nrec) ? r + j : nrec - 1;
+      c[j] = rec_c[rr];
+      y[j] = rec[rr].y;
+    }
+    bool done = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!done) {
+        colour_update(col, c[j] & 255u, (c[j] >> 8) & 255u, (c[j] >> 16) & 255u);
+        done = (y[j] < 0.0f) || ((col >> 24) >= 254u);
+      }
+    }
+    if (done) break;
+    r += 4;
+  }
   rgbw[a] = col;
 }
 
@@ -283,6 +390,8 @@ struct plvs_tsdf_chisel {
   bool poisoned = false;
   // per-call scratch
   DevBuf<uint32_t> counts, keys0, keys1, pts0, pts1, heads, updated, scratch;
+  DevBuf<float2> rec;
+  DevBuf<uint32_t> rec_c;
   DevBuf<Pose> poses;
   DevBuf<int32_t> offsets;
   // host-flavour staging
@@ -387,6 +496,7 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   for (int i = 0; i <= kNumStages; ++i)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   h->counts.release(); h->keys0.release(); h->keys1.release(); h->pts0.release(); h->pts1.release();
+  h->rec.release(); h->rec_c.release();
   h->heads.release(); h->updated.release(); h->scratch.release(); h->poses.release();
   h->offsets.release(); h->st_xyz.release(); h->st_Twc.release(); h->st_rgb.release();
   h->st_kfid.release();
@@ -442,7 +552,7 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
                      h->poses.p);
   // reset the per-call counters, keep num_chunks
   PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->total_visits, 0, sizeof(uint32_t), s));
-  PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->err, 0, 3 * sizeof(uint32_t), s));
+  PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->err, 0, 4 * sizeof(uint32_t), s));
 
 #define STAGE_MARK(i) \
   do { if (h->profiling) PLVS_HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
@@ -477,6 +587,8 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   PLVS_HIP_TRY(h->pts0.reserve(V));
   PLVS_HIP_TRY(h->pts1.reserve(V));
   PLVS_HIP_TRY(h->heads.reserve(V));
+  PLVS_HIP_TRY(h->rec.reserve(V));
+  PLVS_HIP_TRY(h->rec_c.reserve(V));
   PLVS_HIP_TRY(h->updated.reserve((size_t)h->num_chunks + 1));
   PLVS_HIP_TRY(h->scratch.reserve(radix_scratch_words(V)));
   float ms_a[2] = {0.f, 0.f};
@@ -497,15 +609,17 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   const uint32_t* keys = second ? h->keys1.p : h->keys0.p;
   const uint32_t* pts = second ? h->pts1.p : h->pts0.p;
   STAGE_MARK(4);
-  hipLaunchKernelGGL(find_heads, dim3(ceil_div(V, 256)), dim3(256), 0, s, keys, V, h->heads.p,
-                     h->updated.p, h->d_ctr);
+  hipLaunchKernelGGL(expand_records, dim3(ceil_div(V, kExpandThreads)), dim3(kExpandThreads), 0, s,
+                     h->P, keys, pts, V, d_xyz, d_rgb, h->offsets.p, nclouds, h->poses.p,
+                     h->dir.slot_ids, h->rec.p, h->rec_c.p, h->heads.p, h->updated.p, h->d_ctr);
   PLVS_KERNEL_CHECK();
   STAGE_MARK(5);
   // one thread per voxel run; launched over V (upper bound of the run count),
   // surplus threads exit on the device-side head count.
-  hipLaunchKernelGGL(apply_runs, dim3(ceil_div(V, 256)), dim3(256), 0, s, h->P, keys, pts, V,
-                     h->heads.p, h->d_ctr, d_xyz, d_rgb, d_kfid, h->offsets.p, nclouds, h->poses.p,
-                     h->dir.slot_ids, h->sdf, h->weight, h->kfid, h->rgbw);
+  hipLaunchKernelGGL(chain_runs, dim3(ceil_div(V, 256)), dim3(256), 0, s, keys, pts, V, h->rec.p,
+                     h->heads.p, h->d_ctr, d_kfid, h->sdf, h->weight, h->kfid);
+  hipLaunchKernelGGL(chain_colours, dim3(ceil_div(V, 256)), dim3(256), 0, s, keys, V, h->rec.p,
+                     h->rec_c.p, h->heads.p, h->d_ctr, h->rgbw);
   PLVS_KERNEL_CHECK();
   STAGE_MARK(6);
 #undef STAGE_MARK
@@ -527,6 +641,8 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
     return PLVS_ERR_CAPACITY;
   }
   h->stats.updated_chunks = (int32_t)h->h_ctr->num_updated;
+  h->stats.voxels = (int32_t)h->h_ctr->num_heads;
+  h->stats.max_run = (int32_t)h->h_ctr->max_run;
   h->last_updated = h->h_ctr->num_updated;
   return PLVS_OK;
 }

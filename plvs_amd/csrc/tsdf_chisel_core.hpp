@@ -205,23 +205,31 @@ PLVS_HD bool ray_next(RayCursor* c, int* vx, int* vy, int* vz) {
   return true;
 }
 
-// DistVoxel::Integrate + SetKfid + ColorVoxel::IntegrateSimple(r,g,b,1)
-// (DistVoxel.h:91-99, ColorVoxel.h:91-110).
+// DistVoxel::Integrate (DistVoxel.h:91-99) with the product w_u*u already rounded.
+PLVS_HD void dist_update(float& sdf, float& w, float wu_times_u, float wu) {
+  const float oldSDF = sdf, oldW = w;
+  sdf = (oldW * oldSDF + wu_times_u) / (wu + oldW);
+  w = oldW + wu;
+}
+
+// ColorVoxel::IntegrateSimple(r,g,b,1) (ColorVoxel.h:91-110) on the packed
+// r | g<<8 | b<<16 | weight<<24 word; a no-op once the weight reaches 254.
+PLVS_HD void colour_update(uint32_t& rgbw, uint32_t r, uint32_t g, uint32_t b) {
+  const uint32_t cw = rgbw >> 24;
+  if (cw >= 254u) return;
+  const float inv = 1.f / (float)(1u + cw);
+  const uint32_t red = (uint32_t)(uint8_t)((float)(cw * (rgbw & 255u) + r) * inv);
+  const uint32_t green = (uint32_t)(uint8_t)((float)(cw * ((rgbw >> 8) & 255u) + g) * inv);
+  const uint32_t blue = (uint32_t)(uint8_t)((float)(cw * ((rgbw >> 16) & 255u) + b) * inv);
+  rgbw = red | (green << 8) | (blue << 16) | ((cw + 1u) << 24);
+}
+
+// DistVoxel::Integrate + SetKfid + ColorVoxel::IntegrateSimple for one visit.
 PLVS_HD void apply_update(float& sdf, float& w, uint32_t& kfid, uint32_t& rgbw, float u, float wu,
                           uint32_t new_kfid, uint32_t r, uint32_t g, uint32_t b) {
-  const float oldSDF = sdf, oldW = w;
-  sdf = (oldW * oldSDF + wu * u) / (wu + oldW);
-  w = oldW + wu;
+  dist_update(sdf, w, wu * u, wu);
   kfid = new_kfid;
-  uint32_t red = rgbw & 255u, green = (rgbw >> 8) & 255u, blue = (rgbw >> 16) & 255u, cw = rgbw >> 24;
-  if (!(cw >= 254u)) {
-    const float inv = 1.f / (float)(1u + cw);
-    red = (uint32_t)(uint8_t)((float)(cw * red + r) * inv);
-    green = (uint32_t)(uint8_t)((float)(cw * green + g) * inv);
-    blue = (uint32_t)(uint8_t)((float)(cw * blue + b) * inv);
-    cw += 1u;
-    rgbw = red | (green << 8) | (blue << 16) | (cw << 24);
-  }
+  colour_update(rgbw, r, g, b);
 }
 
 // Conversions.h:118-121 (u8 * 1/255) followed by Chisel.cpp:536 ((uint8_t)(c * 255.0f)).

@@ -49,8 +49,10 @@ def make_keyframes(n_keyframes=100, cam=None, room_size=(6.0, 4.0, 3.0), step=2,
     rng = np.random.default_rng(seed)
     half = np.array(room_size, dtype=np.float64) / 2.0
     room = (-half, half)
-    spheres = [(np.array([1.5, 0.3, 0.2]), 0.4), (np.array([-1.2, -0.5, -0.3]), 0.4),
-               (np.array([0.2, 1.0, 0.4]), 0.4)]
+    # three spheres r = 0.4 m, all >= 0.9 m from the camera path (an RGB-D sensor of
+    # the Kinect/Xtion class has no returns below ~0.5 m; TUM fr1/fr3 depth is 0.5-4 m)
+    spheres = [(np.array([2.3, 0.5, 0.2]), 0.4), (np.array([-2.3, -0.4, -0.3]), 0.4),
+               (np.array([-2.0, 1.3, 0.4]), 0.4)]
     out = []
     for k in range(first, first + n_keyframes):
         yaw = np.deg2rad(3.6 * k)

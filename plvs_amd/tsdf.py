@@ -66,7 +66,7 @@ class TsdfChisel:
         s = _lib.TsdfStats()
         _lib.check(_lib.lib.plvs_hip_tsdf_chisel_last_stats(self._h, ctypes.byref(s)))
         return dict(visits=s.visits, points=s.points, new_chunks=s.new_chunks,
-                    updated_chunks=s.updated_chunks)
+                    updated_chunks=s.updated_chunks, voxels=s.voxels, max_run=s.max_run)
 
     def set_profiling(self, enable=True):
         _lib.check(_lib.lib.plvs_hip_tsdf_chisel_set_profiling(self._h, int(bool(enable))))

@@ -1,0 +1,43 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): GPU parity tests, smoke, bench, rocprof stats + PMC.
+# Every stage has its own timeout and log under gpurun_out/.  Usage:
+#   bash scripts/gpu_check.sh [tag] [stages]     stages: subset of "test smoke bench prof pmc"
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+TAG="${1:-run}"
+STAGES="${2:-test smoke bench prof pmc}"
+O="gpurun_out/$TAG"
+mkdir -p "$O"
+export TMPDIR=/tmp
+R="$PWD"
+echo "start $(date +%T)" > "$O/stages.log"
+if [[ "$STAGES" == *test* ]]; then
+  ( timeout 420 python -m pytest tests -m gpu -x -q 2>&1 | tail -60 ) > "$O/pytest_gpu.log" 2>&1
+  echo "pytest done $(date +%T)" >> "$O/stages.log"
+fi
+if [[ "$STAGES" == *smoke* ]]; then
+  ( timeout 180 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -20 ) > "$O/smoke.log" 2>&1
+  echo "smoke done $(date +%T)" >> "$O/stages.log"
+fi
+if [[ "$STAGES" == *bench* ]]; then
+  ( timeout 300 python bench.py 2>&1 | tail -20 ) > "$O/bench.log" 2>&1
+  echo "bench done $(date +%T)" >> "$O/stages.log"
+fi
+if [[ "$STAGES" == *sweep* ]]; then
+  for B in 1 5 10 50 100; do
+    ( timeout 200 python bench.py --batch $B --no-cpu-baseline --no-frontend 2>&1 | tail -1 ) >> "$O/sweep.log" 2>&1
+  done
+  echo "sweep done $(date +%T)" >> "$O/stages.log"
+fi
+if [[ "$STAGES" == *prof* ]]; then
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof" -o r -- python "$R/bench.py" --no-cpu-baseline 2>&1 | tail -5 ) > "$O/rocprof.log" 2>&1
+  echo "rocprof done $(date +%T)" >> "$O/stages.log"
+fi
+if [[ "$STAGES" == *pmc* ]]; then
+  for C in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$R/$O/pmc_$C" -o r -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-frontend 2>&1 | tail -5 ) > "$O/pmc_$C.log" 2>&1
+  done
+  echo "pmc done $(date +%T)" >> "$O/stages.log"
+fi
+find "$O" -type f | head -40
+cat "$O/stages.log"
+for f in pytest_gpu smoke bench sweep rocprof; do [ -f "$O/$f.log" ] && tail -4 "$O/$f.log"; done

@@ -175,7 +175,7 @@ def test_hip_batch_equals_sequential_and_oracle(oracle):
 def test_hip_edge_cases(oracle):
     from plvs_amd import _lib
     from plvs_amd.tsdf import TsdfChisel
-    dev = TsdfChisel(0.05, max_chunks=64)
+    dev = TsdfChisel(0.05, max_chunks=8)
     Twc = np.eye(4, dtype=np.float32)[:3]
     dev.integrate(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint8), np.zeros(0, np.uint32), Twc)
     assert dev.num_chunks() == 0
