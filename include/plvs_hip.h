@@ -89,6 +89,65 @@ int plvs_hip_hamming_knn2_dev(const uint8_t* d_query, int nq, const uint8_t* d_t
                               const uint8_t* d_qmask, int tie_rule, int32_t* d_idx,
                               int32_t* d_dist, void* stream);
 
+/* ------------------------------------------------------------ ORB extraction
+ * Replaces ORBextractor (include/ORBextractor.h:68-170, src/ORBextractor.cc):
+ *   ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)   :446
+ *   int ORBextractor::operator()(image, mask [ignored], keypoints, descriptors,
+ *                                vLappingArea)                                          :1245
+ * called from Frame::ExtractORB (src/Frame.cc:806-813).  CPU-build semantics
+ * (the `#ifndef USE_CUDA` branches): 8-bit bilinear pyramid, cv::FAST per 35-px
+ * cell with the two-threshold rule, quadtree distribution, intensity-centroid
+ * angle, 7x7 sigma-2 blur, 256-bit rBRIEF.
+ *
+ * plvs_keypoint is cv::KeyPoint field for field (pt.x, pt.y, size, angle,
+ * response, octave, class_id = -1), 28 bytes.
+ */
+typedef struct plvs_keypoint {
+  float x, y;
+  float size;
+  float angle;
+  float response;
+  int32_t octave;
+  int32_t class_id;
+} plvs_keypoint;
+
+typedef struct plvs_orb plvs_orb;
+
+int plvs_hip_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
+                        int min_th_fast, plvs_orb** out);
+int plvs_hip_orb_destroy(plvs_orb* h);
+/* Getters of ORBextractor.h:90-113. */
+int plvs_hip_orb_get_levels(plvs_orb* h);
+float plvs_hip_orb_get_scale_factor(plvs_orb* h);
+int plvs_hip_orb_get_scale_tables(plvs_orb* h, float* scale, float* inv_scale, float* sigma2,
+                                  float* inv_sigma2);
+int plvs_hip_orb_features_per_level(plvs_orb* h, int* out);
+
+/* operator().  image: h rows of `stride` bytes, CV_8UC1.  (lap0, lap1) is
+ * vLappingArea: keypoints with lap0 <= x <= lap1 are packed from the back
+ * (ORBextractor.cc:1357-1378).  kps / desc hold `cap` entries (desc 32 bytes
+ * each).  *n = number of keypoints found (nothing is written if n > cap),
+ * *mono_index = the reference's return value.  Empty image -> PLVS_ERR_EMPTY
+ * and *mono_index = -1 (the reference returns -1). */
+int plvs_hip_orb_extract(plvs_orb* h, const uint8_t* image, int w, int hh, int stride, int lap0,
+                         int lap1, plvs_keypoint* kps, uint8_t* desc, int cap, int* n,
+                         int* mono_index);
+/* Same with the image already resident in device memory (it must be complete,
+ * i.e. the producing stream synchronised, on entry).  Outputs are host arrays:
+ * the keypoints feed PLVS's host-side tracking. */
+int plvs_hip_orb_extract_dev(plvs_orb* h, const uint8_t* d_image, int w, int hh, int stride,
+                             int lap0, int lap1, plvs_keypoint* kps, uint8_t* desc, int cap, int* n,
+                             int* mono_index);
+/* Wall-clock split of the last call, ms: [0] pyramid+FAST+cells, [1] host
+ * quadtree, [2] orientation, [3] cos/sin + descriptors, [4] packing. */
+int plvs_hip_orb_last_stage_ms(plvs_orb* h, double* ms, int cap);
+/* Parity / debug accessors for the last call: pyramid level (mvImagePyramid /
+ * mvImagePyramidFiltered), FAST candidates per level (x, y, response relative
+ * to the detection region, the vToDistributeKeys of ORBextractor.cc:879). */
+int plvs_hip_orb_level_size(plvs_orb* h, int level, int* w, int* hh);
+int plvs_hip_orb_download_level(plvs_orb* h, int level, int blurred, uint8_t* out);
+int plvs_hip_orb_last_candidates(plvs_orb* h, int level, float* xyr, int cap, int* n);
+
 /* --------------------------------------------------------- TSDF (open_chisel)
  * Chunked (16^3) spatially hashed TSDF with per-point ray integration.
  *

@@ -6,5 +6,8 @@ compute is in plvs_amd/lib/libplvs_hip.so (hand-written HIP for gfx950).
 """
 from . import _lib  # noqa: F401  (raises if the HIP library is missing)
 from .matcher import BinaryDescriptorMatcher, BFMatcherHamming, DMatch  # noqa: F401
+from .orb import ORBextractor  # noqa: F401
+from .tsdf import PointCloudMapChisel, TsdfChisel  # noqa: F401
 
-__all__ = ["BinaryDescriptorMatcher", "BFMatcherHamming", "DMatch"]
+__all__ = ["BinaryDescriptorMatcher", "BFMatcherHamming", "DMatch", "ORBextractor",
+           "PointCloudMapChisel", "TsdfChisel"]

@@ -39,6 +39,41 @@ class Oracle:
         b = np.ascontiguousarray(b, dtype=np.uint8)
         return self.lib.oracle_descriptor_distance(_ptr(a), _ptr(b))
 
+    # ------------------------------------------------------------ ORB
+    def orb(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        return OracleOrb(self.lib, nfeatures, scale_factor, nlevels, ini_th, min_th)
+
+    def resize_linear(self, img, dw, dh):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        out = np.empty((dh, dw), np.uint8)
+        self.lib.oracle_resize_linear_u8(_ptr(img), img.shape[1], img.shape[0], _ptr(out), dw, dh)
+        return out
+
+    def gaussian_blur(self, img, ksize, sigma):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        out = np.empty_like(img)
+        self.lib.oracle_gaussian_blur_u8.argtypes = [_vp, _i, _i, _i, ctypes.c_double, _vp]
+        self.lib.oracle_gaussian_blur_u8(_ptr(img), img.shape[1], img.shape[0], ksize, sigma, _ptr(out))
+        return out
+
+    def gaussian_kernel_q8(self, n, sigma):
+        out = np.zeros(n, np.int32)
+        self.lib.oracle_gaussian_kernel_q8.argtypes = [_i, ctypes.c_double, _vp]
+        self.lib.oracle_gaussian_kernel_q8(n, sigma, _ptr(out))
+        return out
+
+    def fast_atan2(self, y, x):
+        self.lib.oracle_fast_atan2.restype = _f
+        self.lib.oracle_fast_atan2.argtypes = [_f, _f]
+        return self.lib.oracle_fast_atan2(y, x)
+
+    def fast(self, img, threshold, nonmax=True):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        cap = img.size
+        out = np.zeros((cap, 3), np.float32)
+        n = self.lib.oracle_fast(_ptr(img), img.shape[1], img.shape[1], img.shape[0], threshold, int(nonmax), _ptr(out), cap)
+        return out[:n]
+
     # ------------------------------------------------------------ TSDF
     def chisel(self, resolution, **kw):
         return _ChiselLike(self.lib, "oracle_chisel", resolution, **kw)
@@ -54,6 +89,81 @@ class Oracle:
         f = self.lib.oracle_knn2_mih if mih else self.lib.oracle_knn2_bf
         f(_ptr(q), nq, _ptr(t), nt, _ptr(qmask), _ptr(idx), _ptr(dist))
         return idx, dist
+
+
+KP_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.float32), ("angle", np.float32),
+                     ("response", np.float32), ("octave", np.int32), ("class_id", np.int32)])
+
+
+class OracleOrb:
+    def __init__(self, lib, nfeatures, scale_factor, nlevels, ini_th, min_th):
+        self.lib = lib
+        self.nlevels = nlevels
+        lib.oracle_orb_create.restype = _vp
+        lib.oracle_orb_create.argtypes = [_i, _f, _i, _i, _i]
+        lib.oracle_orb_destroy.argtypes = [_vp]
+        lib.oracle_orb_extract.argtypes = [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]
+        lib.oracle_orb_features_per_level.argtypes = [_vp, _vp]
+        lib.oracle_orb_umax.argtypes = [_vp, _vp]
+        lib.oracle_orb_level_size.argtypes = [_vp, _i, _vp, _vp]
+        lib.oracle_orb_get_level.argtypes = [_vp, _i, _i, _vp]
+        lib.oracle_orb_num_candidates.argtypes = [_vp, _i]
+        lib.oracle_orb_get_candidates.argtypes = [_vp, _i, _vp]
+        self.h = _vp(lib.oracle_orb_create(nfeatures, scale_factor, nlevels, ini_th, min_th))
+        self.cap = nfeatures * 2 + 64
+
+    def __del__(self):
+        if self.h:
+            self.lib.oracle_orb_destroy(self.h)
+            self.h = None
+
+    def features_per_level(self):
+        out = np.zeros(self.nlevels, np.int32)
+        self.lib.oracle_orb_features_per_level(self.h, _ptr(out))
+        return out
+
+    def umax(self):
+        out = np.zeros(16, np.int32)
+        self.lib.oracle_orb_umax(self.h, _ptr(out))
+        return out
+
+    def extract(self, img, lap=(0, 0)):
+        """-> (monoIndex, keypoints structured array, descriptors [n,32])"""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        kps = np.zeros(self.cap, KP_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n = ctypes.c_int()
+        h, w = img.shape if img.ndim == 2 else (0, 0)
+        mono = self.lib.oracle_orb_extract(self.h, _ptr(img), w, h, w, lap[0], lap[1], _ptr(kps), _ptr(desc),
+                                           self.cap, ctypes.byref(n))
+        assert n.value <= self.cap
+        return mono, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def level(self, level, blurred=False):
+        w, h = ctypes.c_int(), ctypes.c_int()
+        self.lib.oracle_orb_level_size(self.h, level, ctypes.byref(w), ctypes.byref(h))
+        out = np.zeros((h.value, w.value), np.uint8)
+        self.lib.oracle_orb_get_level(self.h, level, int(blurred), _ptr(out))
+        return out
+
+    def candidates(self, level):
+        n = self.lib.oracle_orb_num_candidates(self.h, level)
+        out = np.zeros((max(n, 1), 3), np.float32)
+        self.lib.oracle_orb_get_candidates(self.h, level, _ptr(out))
+        return out[:n]
+
+
+def read_pgm(path):
+    with open(path, "rb") as f:
+        data = f.read()
+    parts = data.split(None, 4)
+    assert parts[0] == b"P5" and int(parts[3]) == 255
+    w, h = int(parts[1]), int(parts[2])
+    return np.frombuffer(data, np.uint8, w * h, len(data) - w * h).reshape(h, w).copy()
+
+
+def golden(name):
+    return read_pgm(os.path.join(ROOT, "tests", "golden", name))
 
 
 class _ChiselLike:
@@ -125,8 +235,21 @@ def load_hostcore():
     return ctypes.CDLL(HOSTCORE_SO)
 
 
+def load_hostorb():
+    """Host (g++) build of plvs_amd/csrc/orb_octree.hpp (the product's quadtree)."""
+    so = os.path.join(HOSTCORE_DIR, "libhostorb.so")
+    src = os.path.join(HOSTCORE_DIR, "orb_host.cpp")
+    hdr = os.path.join(ROOT, "plvs_amd", "csrc", "orb_octree.hpp")
+    if not os.path.exists(so) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(so):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", src, "-o", so], check=True)
+    lib = ctypes.CDLL(so)
+    lib.hostorb_distribute.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _i]
+    return lib
+
+
 def load():
-    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR)
+            if f.endswith((".c", ".h", ".cpp", ".hpp", ".inc"))]
     if not os.path.exists(ORACLE_SO) or any(
             os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs):
         build()
