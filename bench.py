@@ -181,7 +181,33 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             fe[name + "_us"] = round(e0.elapsed_time(e1) / 50 * 1e3, 2)
-        result["frontend"] = {"hamming_knn2": fe, "note": "ORB/LBD extraction kernels not timed yet"}
+        # ORB(2000) extraction on a 640x480 frame resident in HBM (configs[1] front end)
+        from plvs_amd.orb import ORBextractor
+        from tests.oracle_lib import golden
+        frames = [torch.from_numpy(golden(n)).cuda() for n in ("aloe_640x480.pgm", "aloe_640x480_shift.pgm",
+                                                                "cones_640x480.pgm")]
+        ext = ORBextractor(2000, 1.2, 8, 20, 7)
+        for i in range(6):
+            ext(frames[i % 3])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nrep, nk = 30, 0
+        stage = {}
+        for i in range(nrep):
+            mono, kps, desc = ext(frames[i % 3])
+            nk += len(kps)
+            for k, v in ext.stage_ms().items():
+                stage[k] = stage.get(k, 0.0) + v
+        orb_ms = (time.perf_counter() - t0) / nrep * 1e3
+        ext.close()
+        result["frontend"] = {
+            "hamming_knn2": fe,
+            "orb_extract_2000_640x480_ms": round(orb_ms, 3),
+            "orb_keypoints_per_frame": nk // nrep,
+            "orb_stage_ms": {k: round(v / nrep, 3) for k, v in stage.items()},
+            "frames_per_s_orb_plus_match": round(1e3 / (orb_ms + fe["orb_bf_2000x2000_us"] * 1e-3), 1),
+            "note": "line extraction (EDLines/LBD) not on the device yet; its kNN matcher is (lbd_mih)",
+        }
 
     # -------------------------------------------------- CPU baseline (rank 0)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -246,6 +246,57 @@ int plvs_hip_tsdf_chisel_updated_chunk_ids_dev(plvs_tsdf_chisel* h, int32_t* d_i
 int plvs_hip_tsdf_chisel_download_chunk(plvs_tsdf_chisel* h, int cx, int cy, int cz, float* sdf,
                                         float* weight, uint32_t* kfid, uint32_t* rgbw);
 
+/* ------------------------------------------------------------- TSDF (voxblox)
+ * Block-hashed (16^3) TSDF layer with per-point ray-cast integration.
+ *
+ * Replaces:
+ *   PointCloudMapVoxblox::InsertCloud        src/PointCloudMapVoxblox.cc:81-99
+ *    -> TsdfServer::insertPointCloud         Thirdparty/voxblox_server/src/tsdf_server.cc:476-555
+ *    -> SimpleTsdfIntegrator::integratePointCloud
+ *                                            Thirdparty/voxblox/src/integrator/tsdf_integrator.cc:266-327
+ *   with RayCaster (integrator_utils.cc:137-235) and updateTsdfVoxel (:173-232).
+ * Voxel payload 12 B: {f32 distance, f32 weight, u8 r,g,b,a} (core/voxel.h:12-18).
+ *
+ * Integration method: "simple" in the single-thread visiting order of the
+ * reference (ThreadSafeIndex mixed order).  "merged" iterates a
+ * std::unordered_map and "fast" (PLVS's YAML default) is racy by design
+ * (tsdf_integrator.cc:505-569): neither has a reproducible result, see DESIGN.md.
+ */
+typedef struct plvs_tsdf_voxblox_params {
+  float voxel_size;        /* tsdf_voxel_size (PointCloudMapping.resolution)                  */
+  float truncation;        /* default_truncation_distance, 0.1  (PointCloudMapVoxblox.cc:57)  */
+  float max_weight;        /* 10000                                                     (:58) */
+  float min_ray_length;    /* 0.1                                                       (:60) */
+  float max_ray_length;    /* 5.0                                                       (:61) */
+  int32_t voxel_carving;   /* PointCloudMapping.useCarving                              (:59) */
+  int32_t max_blocks;      /* capacity of the device block pool (48 KiB of HBM each)          */
+  int32_t shard_rank;      /* multi-GPU: owner(block) = three-prime hash(id) mod shard_count  */
+  int32_t shard_count;
+} plvs_tsdf_voxblox_params;
+
+typedef struct plvs_tsdf_voxblox plvs_tsdf_voxblox;
+
+int plvs_hip_tsdf_voxblox_default_params(float voxel_size, int use_carving,
+                                         plvs_tsdf_voxblox_params* p);
+int plvs_hip_tsdf_voxblox_create(const plvs_tsdf_voxblox_params* p, plvs_tsdf_voxblox** out);
+int plvs_hip_tsdf_voxblox_destroy(plvs_tsdf_voxblox* h);
+int plvs_hip_tsdf_voxblox_clear(plvs_tsdf_voxblox* h);
+/* xyz: n x 3 f32 camera-frame points (must be finite: PLVS's generator only
+ * emits valid depths; PLVS_ERR_INVALID_ARG otherwise); rgba: n x 4 u8, the
+ * r,g,b,a members of the pcl point; Twc 3x4 row-major. */
+int plvs_hip_tsdf_voxblox_integrate(plvs_tsdf_voxblox* h, const float* xyz, const uint8_t* rgba,
+                                    int n, const float* Twc);
+int plvs_hip_tsdf_voxblox_integrate_batch_dev(plvs_tsdf_voxblox* h, const float* d_xyz,
+                                              const uint8_t* d_rgba, const int32_t* offsets,
+                                              int nclouds, const float* d_Twc, void* stream);
+int plvs_hip_tsdf_voxblox_last_stats(plvs_tsdf_voxblox* h, plvs_tsdf_stats* s);
+int plvs_hip_tsdf_voxblox_num_blocks(plvs_tsdf_voxblox* h, int* n);
+int plvs_hip_tsdf_voxblox_block_ids(plvs_tsdf_voxblox* h, int32_t* ids_xyz, int cap, int* n);
+int plvs_hip_tsdf_voxblox_updated_block_ids_dev(plvs_tsdf_voxblox* h, int32_t* d_ids_xyz, int cap,
+                                                int* n, void* stream);
+int plvs_hip_tsdf_voxblox_download_block(plvs_tsdf_voxblox* h, int bx, int by, int bz,
+                                         float* distance, float* weight, uint32_t* rgba);
+
 #ifdef __cplusplus
 }
 #endif

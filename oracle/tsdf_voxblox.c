@@ -1,0 +1,323 @@
+/*
+ * oracle/tsdf_voxblox.c — CPU restatement of the voxblox TSDF integrate that
+ * sits behind PointCloudMapVoxblox::InsertCloud ("simple" integrator, one
+ * thread: the deterministic order of the reference).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under plvs_amd/ may call into this file.
+ *
+ * Parity status: UNPINNED by the reference.  voxblox's gtests never call
+ * integratePointCloud and are disabled in the build; the
+ * library cannot be compiled here (Eigen3, glog, protobuf, minkindr absent).
+ * Known deviation of this restatement: the reference turns the pose matrix into
+ * a kindr quaternion and rotates points with it (T_G_C * p); here the point is
+ * rotated with the rotation matrix itself (R p + t).  Both are f32; results can
+ * differ in the last ulp of point_G.  The multi-threaded reference is itself
+ * order-nondeterministic (per-voxel mutexes, ThreadSafeIndex); the oracle is the
+ * integrator_threads = 1 schedule.  The "fast" integrator (PLVS's YAML default)
+ * is racy by design (tsdf_integrator.cc:505-569) and has no deterministic
+ * reference; "simple" is the parity target.
+ *
+ * Follows (paths relative to the PLVS tree):
+ *   src/PointCloudMapVoxblox.cc:48-99                      config + InsertCloud
+ *   Thirdparty/voxblox_server/src/tsdf_server.cc:476-530   insertPointCloud (finite filter, colours)
+ *   Thirdparty/voxblox/src/integrator/tsdf_integrator.cc
+ *        :9-31    constructor (inverse sizes, allow_clear needs carving)
+ *        :85-103  isPointValid        :114-157 allocateStorageAndGetVoxelPtr
+ *        :173-232 updateTsdfVoxel     :240-253 computeDistance
+ *        :255-264 getVoxelWeight      :266-327 SimpleTsdfIntegrator
+ *   Thirdparty/voxblox/src/integrator/integrator_utils.cc
+ *        :11-44   ThreadSafeIndex (mixed visiting order)
+ *        :137-235 RayCaster
+ *   Thirdparty/voxblox/include/voxblox/core/common.h:95-125 (Color::blendTwoColors),
+ *        :140-222 (grid helpers, kEpsilon, signum) ; core/voxel.h:12-18 ; core/block_hash.h:15-26
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define VPS 16
+#define BLOCK_VOX 4096
+
+typedef struct {
+  int32_t id[3];
+  int used;
+  float* distance; /* TsdfVoxel::distance, init 0 */
+  float* weight;   /* TsdfVoxel::weight, init 0   */
+  uint32_t* rgba;  /* Color r | g<<8 | b<<16 | a<<24, init 0 */
+} vblock_t;
+
+typedef struct oracle_voxblox {
+  float voxel_size, voxel_size_inv, voxels_per_side_inv;
+  float truncation, max_weight, min_ray, max_ray;
+  int carving, allow_clear, use_const_weight, use_weight_dropoff;
+  vblock_t* tab;
+  size_t cap, count;
+  int shard_rank, shard_count;
+  int64_t last_visits;
+} oracle_voxblox;
+
+static size_t vb_hash(const int32_t id[3]) {
+  /* AnyIndexHash (block_hash.h:21-24) */
+  return ((size_t)(unsigned int)id[0] * 73856093u) ^ ((size_t)(int64_t)id[1] * 19349663u) ^
+         ((size_t)(int64_t)id[2] * 83492791u);
+}
+/* sharding uses the same three-prime hash as the chisel path (sign-extended x) so
+ * that one owner function serves both back ends */
+static size_t owner_hash(const int32_t id[3]) {
+  return ((size_t)(int64_t)id[0] * 73856093u) ^ ((size_t)(int64_t)id[1] * 19349663u) ^
+         ((size_t)(int64_t)id[2] * 83492791u);
+}
+
+static vblock_t* vtab_find(vblock_t* tab, size_t cap, const int32_t id[3], int* found) {
+  size_t h = vb_hash(id) & (cap - 1);
+  for (;;) {
+    vblock_t* c = &tab[h];
+    if (!c->used) { *found = 0; return c; }
+    if (c->id[0] == id[0] && c->id[1] == id[1] && c->id[2] == id[2]) { *found = 1; return c; }
+    h = (h + 1) & (cap - 1);
+  }
+}
+
+static void vtab_grow(oracle_voxblox* o) {
+  size_t ncap = o->cap * 2;
+  vblock_t* nt = (vblock_t*)calloc(ncap, sizeof(vblock_t));
+  for (size_t i = 0; i < o->cap; i++)
+    if (o->tab[i].used) {
+      int f;
+      *vtab_find(nt, ncap, o->tab[i].id, &f) = o->tab[i];
+    }
+  free(o->tab);
+  o->tab = nt;
+  o->cap = ncap;
+}
+
+static vblock_t* vblock_get(oracle_voxblox* o, const int32_t id[3]) {
+  int found;
+  vblock_t* b = vtab_find(o->tab, o->cap, id, &found);
+  if (found) return b;
+  if ((o->count + 1) * 2 > o->cap) {
+    vtab_grow(o);
+    b = vtab_find(o->tab, o->cap, id, &found);
+  }
+  memcpy(b->id, id, sizeof(b->id));
+  b->used = 1;
+  b->distance = (float*)calloc(BLOCK_VOX, sizeof(float));
+  b->weight = (float*)calloc(BLOCK_VOX, sizeof(float));
+  b->rgba = (uint32_t*)calloc(BLOCK_VOX, sizeof(uint32_t));
+  o->count++;
+  return b;
+}
+
+/* PointCloudMapVoxblox.cc:52-71 passes truncation 0.1, max_weight 1e4, ray length
+ * 0.1..5, weight drop-off on, constant weight off, allow_clear on. */
+oracle_voxblox* oracle_voxblox_create(float voxel_size, float truncation, float max_weight,
+                                      float min_ray, float max_ray, int carving, int shard_rank,
+                                      int shard_count) {
+  oracle_voxblox* o = (oracle_voxblox*)calloc(1, sizeof(*o));
+  o->voxel_size = voxel_size;
+  o->voxel_size_inv = (float)(1.0 / voxel_size);        /* tsdf_integrator.cc:17 */
+  o->voxels_per_side_inv = (float)(1.0 / VPS);          /* :19 */
+  o->truncation = truncation;
+  o->max_weight = max_weight;
+  o->min_ray = min_ray;
+  o->max_ray = max_ray;
+  o->carving = carving;
+  o->allow_clear = carving ? 1 : 0;                     /* :26-28 */
+  o->use_const_weight = 0;
+  o->use_weight_dropoff = 1;
+  o->cap = 1024;
+  o->tab = (vblock_t*)calloc(o->cap, sizeof(vblock_t));
+  o->shard_rank = shard_rank;
+  o->shard_count = shard_count;
+  return o;
+}
+
+void oracle_voxblox_clear(oracle_voxblox* o) {
+  for (size_t i = 0; i < o->cap; i++)
+    if (o->tab[i].used) { free(o->tab[i].distance); free(o->tab[i].weight); free(o->tab[i].rgba); }
+  memset(o->tab, 0, o->cap * sizeof(vblock_t));
+  o->count = 0;
+}
+
+void oracle_voxblox_destroy(oracle_voxblox* o) {
+  if (!o) return;
+  oracle_voxblox_clear(o);
+  free(o->tab);
+  free(o);
+}
+
+static float sum3(float a, float b, float c) { return a + (b + c); }
+static float norm3(const float v[3]) { return sqrtf(sum3(v[0] * v[0], v[1] * v[1], v[2] * v[2])); }
+static int vb_signum(float x) { return (x == 0) ? 0 : x < 0 ? -1 : 1; }
+
+/* ThreadSafeIndex::getMixedIndex (integrator_utils.cc:33-44), step_size_ = 1024 */
+static size_t mixed_index(size_t base_idx, size_t number_of_points) {
+  const size_t step = 1024, groups = number_of_points / step;
+  if (groups * step <= base_idx) return base_idx;
+  return (base_idx % groups) * step + base_idx / groups;
+}
+
+/* Color::blendTwoColors (common.h:106-124) on the packed word. */
+static uint32_t blend(uint32_t c1, float w1, uint32_t c2, float w2) {
+  const float total = w1 + w2;
+  w1 /= total;
+  w2 /= total;
+  uint32_t out = 0;
+  for (int k = 0; k < 4; k++) {
+    const uint8_t a = (uint8_t)(c1 >> (8 * k)), b = (uint8_t)(c2 >> (8 * k));
+    out |= (uint32_t)(uint8_t)round((double)(a * w1 + b * w2)) << (8 * k);
+  }
+  return out;
+}
+
+/* updateTsdfVoxel (tsdf_integrator.cc:173-232) */
+static void update_voxel(const oracle_voxblox* o, const float origin[3], const float pG[3],
+                         const int32_t g[3], uint32_t color, float weight, float* distance,
+                         float* vweight, uint32_t* vcolor) {
+  const float center[3] = {((float)g[0] + 0.5f) * o->voxel_size, ((float)g[1] + 0.5f) * o->voxel_size,
+                           ((float)g[2] + 0.5f) * o->voxel_size};
+  /* computeDistance (:240-253) */
+  const float vvo[3] = {center[0] - origin[0], center[1] - origin[1], center[2] - origin[2]};
+  const float vpo[3] = {pG[0] - origin[0], pG[1] - origin[1], pG[2] - origin[2]};
+  const float dist_G = norm3(vpo);
+  const float dist_G_V = sum3(vvo[0] * vpo[0], vvo[1] * vpo[1], vvo[2] * vpo[2]) / dist_G;
+  const float sdf = dist_G - dist_G_V;
+  float updated_weight = weight;
+  const float dropoff_epsilon = o->voxel_size;
+  if (o->use_weight_dropoff && sdf < -dropoff_epsilon) {
+    updated_weight = weight * (o->truncation + sdf) / (o->truncation - dropoff_epsilon);
+    updated_weight = (updated_weight < 0.0f) ? 0.0f : updated_weight; /* std::max(uw, 0.0f) */
+  }
+  const float new_weight = *vweight + updated_weight;
+  if (new_weight < 1e-6f) return;
+  const float new_sdf = (sdf * updated_weight + *distance * *vweight) / new_weight;
+  if (fabsf(sdf) < o->truncation) *vcolor = blend(*vcolor, *vweight, color, updated_weight);
+  /* std::min(trunc, x) = (x < trunc) ? x : trunc ; std::max(-trunc, x) = (-trunc < x) ? x : -trunc */
+  *distance = (new_sdf > 0.0) ? ((new_sdf < o->truncation) ? new_sdf : o->truncation)
+                              : ((-o->truncation < new_sdf) ? new_sdf : -o->truncation);
+  *vweight = (new_weight < o->max_weight) ? new_weight : o->max_weight;
+}
+
+/* SimpleTsdfIntegrator::integratePointCloud with integrator_threads = 1.
+ * Twc: 3x4 row-major [R|t]; rgba: n x 4 u8 (r,g,b,a members of the pcl point). */
+void oracle_voxblox_integrate(oracle_voxblox* o, const float* xyz, const uint8_t* rgba, int n,
+                              const float* Twc) {
+  float R[9], t[3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) R[3 * i + j] = Twc[4 * i + j];
+    t[i] = Twc[4 * i + 3];
+  }
+  /* tsdf_server.cc:509-527: drop non-finite points, keep order */
+  int* keep = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  size_t m = 0;
+  for (int i = 0; i < n; i++)
+    if (isfinite(xyz[3 * i]) && isfinite(xyz[3 * i + 1]) && isfinite(xyz[3 * i + 2])) keep[m++] = i;
+  int64_t visits = 0;
+  vblock_t* last_block = NULL;
+  int32_t last_bid[3] = {0, 0, 0};
+  for (size_t seq = 0; seq < m; seq++) {
+    const int pi = keep[mixed_index(seq, m)];
+    const float* pC = xyz + 3 * (size_t)pi;
+    uint32_t color;
+    memcpy(&color, rgba + 4 * (size_t)pi, 4);
+    /* isPointValid (:85-103), freespace_points = false */
+    const float ray_distance = norm3(pC);
+    int is_clearing;
+    if (ray_distance < o->min_ray) continue;
+    else if (ray_distance > o->max_ray) {
+      if (o->allow_clear) is_clearing = 1;
+      else continue;
+    } else
+      is_clearing = 0;
+    const float* origin = t;
+    float pG[3];
+    for (int k = 0; k < 3; k++) pG[k] = sum3(R[3 * k] * pC[0], R[3 * k + 1] * pC[1], R[3 * k + 2] * pC[2]) + t[k];
+    /* RayCaster ctor (integrator_utils.cc:137-173) */
+    const float d[3] = {pG[0] - origin[0], pG[1] - origin[1], pG[2] - origin[2]};
+    const float dn = norm3(d);
+    float unit[3] = {d[0], d[1], d[2]};
+    if (sum3(d[0] * d[0], d[1] * d[1], d[2] * d[2]) > 0.0f) { unit[0] = d[0] / dn; unit[1] = d[1] / dn; unit[2] = d[2] / dn; }
+    float ray_start[3], ray_end[3];
+    if (is_clearing) {
+      float ray_length = dn;
+      float tmp = ray_length - o->truncation;
+      tmp = (tmp < 0.0f) ? 0.0f : tmp;                       /* std::max(x, 0) */
+      ray_length = (o->max_ray < tmp) ? o->max_ray : tmp;    /* std::min(x, max_ray) */
+      for (int k = 0; k < 3; k++) {
+        ray_end[k] = origin[k] + unit[k] * ray_length;
+        ray_start[k] = o->carving ? origin[k] : ray_end[k];
+      }
+    } else {
+      for (int k = 0; k < 3; k++) {
+        ray_end[k] = pG[k] + unit[k] * o->truncation;
+        ray_start[k] = o->carving ? origin[k] : (pG[k] - unit[k] * o->truncation);
+      }
+    }
+    float ss[3], es[3];
+    for (int k = 0; k < 3; k++) { ss[k] = ray_start[k] * o->voxel_size_inv; es[k] = ray_end[k] * o->voxel_size_inv; }
+    /* setupRayCaster (:196-235) */
+    int32_t cur[3], endi[3], sgn[3];
+    float t_next[3], t_step[3];
+    int steps = 0;
+    for (int k = 0; k < 3; k++) {
+      cur[k] = (int32_t)floorf(ss[k] + 1e-6f);
+      endi[k] = (int32_t)floorf(es[k] + 1e-6f);
+      steps += abs(endi[k] - cur[k]);
+      const float rs = es[k] - ss[k];
+      sgn[k] = vb_signum(rs);
+      const float corrected = (float)(sgn[k] > 0 ? sgn[k] : 0);
+      const float shifted = ss[k] - (float)cur[k];
+      const float dist = corrected - shifted;
+      t_next[k] = dist / rs;          /* the `abs(x) < 0.0 ? 2.0 :` guards can never fire */
+      t_step[k] = (float)sgn[k] / rs;
+    }
+    const float weight = o->use_const_weight ? 1.0f : (fabsf(pC[2]) > 1e-6f ? 1.0f / (pC[2] * pC[2]) : 0.0f);
+    /* nextRayIndex (:180-194): emits ray_length_in_steps + 1 voxels */
+    for (int step = 0; step <= steps; step++) {
+      const int32_t g[3] = {cur[0], cur[1], cur[2]};
+      int mi = 0; /* Eigen minCoeff(&idx): first coefficient, replaced only by a strictly smaller one */
+      if (t_next[1] < t_next[mi]) mi = 1;
+      if (t_next[2] < t_next[mi]) mi = 2;
+      cur[mi] += sgn[mi];
+      t_next[mi] += t_step[mi];
+      /* allocateStorageAndGetVoxelPtr (:114-157) */
+      const int32_t bid[3] = {(int32_t)floorf((float)g[0] * o->voxels_per_side_inv),
+                              (int32_t)floorf((float)g[1] * o->voxels_per_side_inv),
+                              (int32_t)floorf((float)g[2] * o->voxels_per_side_inv)};
+      if (o->shard_count > 1 && (int)(owner_hash(bid) % (size_t)o->shard_count) != o->shard_rank) continue;
+      if (!last_block || last_bid[0] != bid[0] || last_bid[1] != bid[1] || last_bid[2] != bid[2]) {
+        last_block = vblock_get(o, bid); /* may rehash: never keep a pointer across another lookup */
+        memcpy(last_bid, bid, sizeof(last_bid));
+      }
+      const uint32_t off = 1u << 31;
+      const int lx = (int)(((uint32_t)g[0] + off) & 15u), ly = (int)(((uint32_t)g[1] + off) & 15u),
+                lz = (int)(((uint32_t)g[2] + off) & 15u);
+      const int vid = lx + VPS * (ly + lz * VPS);
+      update_voxel(o, origin, pG, g, color, weight, &last_block->distance[vid], &last_block->weight[vid],
+                   &last_block->rgba[vid]);
+      visits++;
+    }
+  }
+  free(keep);
+  o->last_visits = visits;
+}
+
+int64_t oracle_voxblox_last_visits(const oracle_voxblox* o) { return o->last_visits; }
+int oracle_voxblox_num_chunks(const oracle_voxblox* o) { return (int)o->count; }
+void oracle_voxblox_chunk_ids(const oracle_voxblox* o, int32_t* ids) {
+  size_t k = 0;
+  for (size_t i = 0; i < o->cap; i++)
+    if (o->tab[i].used) { memcpy(ids + 3 * k, o->tab[i].id, 3 * sizeof(int32_t)); k++; }
+}
+int oracle_voxblox_get_chunk(const oracle_voxblox* o, int cx, int cy, int cz, float* distance,
+                             float* weight, uint32_t* rgba) {
+  const int32_t id[3] = {cx, cy, cz};
+  int found;
+  vblock_t* b = vtab_find(o->tab, o->cap, id, &found);
+  if (!found) return 0;
+  memcpy(distance, b->distance, BLOCK_VOX * sizeof(float));
+  memcpy(weight, b->weight, BLOCK_VOX * sizeof(float));
+  memcpy(rgba, b->rgba, BLOCK_VOX * sizeof(uint32_t));
+  return 1;
+}

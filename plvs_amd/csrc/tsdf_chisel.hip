@@ -30,32 +30,17 @@
 #include "common.hpp"
 #include "device_utils.hpp"
 #include "tsdf_chisel_core.hpp"
+#include "tsdf_directory.hpp"
 
 using namespace plvs;
 using namespace plvs::chisel;
+using namespace plvs::tsdf;
 
 namespace {
-
-constexpr unsigned long long kEmptyKey = ~0ull;
-constexpr int kCoordBias = 1 << 20;  // chunk ids must lie in [-2^20, 2^20)
 
 constexpr int kNumStages = 6;
 const char* const kStageNames[kNumStages] = {"ray_count", "scan", "ray_fill", "radix_sort",
                                              "expand_records", "chain_runs"};
-
-enum ErrBits : uint32_t {
-  kErrPoolFull = 1u,
-  kErrCoordRange = 2u,
-  kErrDirectoryMiss = 4u,
-};
-
-struct Directory {
-  unsigned long long* keys;  // packed chunk id or kEmptyKey
-  int32_t* slots;            // pool slot of the entry
-  int32_t* slot_ids;         // slot -> chunk id (3 ints)
-  uint32_t mask;             // capacity - 1
-  int32_t max_chunks;
-};
 
 struct Counters {           // device-side, read back once per call
   uint32_t total_visits;
@@ -65,74 +50,6 @@ struct Counters {           // device-side, read back once per call
   uint32_t num_updated;
   uint32_t max_run;
 };
-
-__device__ __forceinline__ bool pack_chunk(int x, int y, int z, unsigned long long* key) {
-  const unsigned ux = (unsigned)(x + kCoordBias), uy = (unsigned)(y + kCoordBias),
-                 uz = (unsigned)(z + kCoordBias);
-  if ((ux | uy | uz) >> 21) return false;
-  *key = ((unsigned long long)ux << 42) | ((unsigned long long)uy << 21) | (unsigned long long)uz;
-  return true;
-}
-
-__device__ __forceinline__ uint32_t dir_hash(int x, int y, int z, uint32_t mask) {
-  return (uint32_t)chunk_hash(x, y, z) & mask;
-}
-
-// Insert-if-absent; the slot of a freshly inserted chunk becomes visible to
-// other threads only after the kernel boundary (the count pass never needs it).
-__device__ void dir_insert(const Directory& d, int x, int y, int z, Counters* ctr) {
-  unsigned long long key;
-  if (!pack_chunk(x, y, z, &key)) {
-    atomicOr(&ctr->err, kErrCoordRange);
-    return;
-  }
-  uint32_t h = dir_hash(x, y, z, d.mask);
-  for (uint32_t probe = 0; probe <= d.mask; ++probe) {
-    unsigned long long cur = d.keys[h];
-    if (cur == key) return;
-    if (cur == kEmptyKey) {
-      cur = atomicCAS(&d.keys[h], kEmptyKey, key);
-      if (cur == kEmptyKey) {
-        const int slot = atomicAdd(&ctr->num_chunks, 1);
-        if (slot < d.max_chunks) {
-          d.slots[h] = slot;
-          d.slot_ids[3 * slot + 0] = x;
-          d.slot_ids[3 * slot + 1] = y;
-          d.slot_ids[3 * slot + 2] = z;
-        } else {
-          atomicOr(&ctr->err, kErrPoolFull);
-        }
-        return;
-      }
-      if (cur == key) return;
-    }
-    h = (h + 1) & d.mask;
-  }
-  atomicOr(&ctr->err, kErrPoolFull);
-}
-
-__device__ int dir_find(const Directory& d, int x, int y, int z) {
-  unsigned long long key;
-  if (!pack_chunk(x, y, z, &key)) return -1;
-  uint32_t h = dir_hash(x, y, z, d.mask);
-  for (uint32_t probe = 0; probe <= d.mask; ++probe) {
-    const unsigned long long cur = d.keys[h];
-    if (cur == key) return d.slots[h];
-    if (cur == kEmptyKey) return -1;
-    h = (h + 1) & d.mask;
-  }
-  return -1;
-}
-
-// cloud index of global point i: largest c with offsets[c] <= i.
-__device__ __forceinline__ int cloud_of(const int32_t* __restrict__ offsets, int nclouds, int i) {
-  int lo = 0, hi = nclouds - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (offsets[mid] <= i) lo = mid; else hi = mid - 1;
-  }
-  return lo;
-}
 
 __global__ void pose_prep(const float* __restrict__ Twc, int nclouds, Pose* __restrict__ poses) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -175,7 +92,7 @@ __global__ __launch_bounds__(256) void ray_pass(
           lslot = dir_find(dir, lcx, lcy, lcz);
           if (lslot < 0) atomicOr(&ctr->err, kErrDirectoryMiss);
         } else {
-          dir_insert(dir, lcx, lcy, lcz, ctr);
+          dir_insert(dir, lcx, lcy, lcz, &ctr->num_chunks, &ctr->err);
           // the float chunk lookup (GetIDAt) and the integer voxel grid only
           // disagree ~100 km from the origin; fail loudly instead of diverging
           if (((vx - lcx * 16) | (vy - lcy * 16) | (vz - lcz * 16)) & ~15)
@@ -452,7 +369,7 @@ int plvs_hip_tsdf_chisel_create(const plvs_tsdf_chisel_params* p, plvs_tsdf_chis
   uint32_t cap = 1024;
   while (cap < 2u * (uint32_t)p->max_chunks) cap <<= 1;
   h->dir.mask = cap - 1;
-  h->dir.max_chunks = p->max_chunks;
+  h->dir.max_blocks = p->max_chunks;
   const size_t nvox = (size_t)p->max_chunks * kChunkVox;
 #define CREATE_TRY(call)                                                        \
   do {                                                                          \

@@ -1,0 +1,103 @@
+// Device-resident directory of 16^3 voxel blocks shared by the TSDF back ends:
+// an open-addressing hash from the packed 3x21-bit block id to the slot of the
+// block in the voxel pool, plus the inverse table slot -> id.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace plvs {
+namespace tsdf {
+
+constexpr unsigned long long kEmptyKey = ~0ull;
+constexpr int kCoordBias = 1 << 20;  // block ids must lie in [-2^20, 2^20)
+
+enum ErrBits : uint32_t {
+  kErrPoolFull = 1u,
+  kErrCoordRange = 2u,
+  kErrDirectoryMiss = 4u,
+};
+
+struct Directory {
+  unsigned long long* keys;  // packed block id or kEmptyKey
+  int32_t* slots;            // pool slot of the entry
+  int32_t* slot_ids;         // slot -> block id (3 ints)
+  uint32_t mask;             // capacity - 1
+  int32_t max_blocks;
+};
+
+__device__ __forceinline__ bool pack_block(int x, int y, int z, unsigned long long* key) {
+  const unsigned ux = (unsigned)(x + kCoordBias), uy = (unsigned)(y + kCoordBias),
+                 uz = (unsigned)(z + kCoordBias);
+  if ((ux | uy | uz) >> 21) return false;
+  *key = ((unsigned long long)ux << 42) | ((unsigned long long)uy << 21) | (unsigned long long)uz;
+  return true;
+}
+
+// The spatial hash both references use for their block maps (ChunkHasher,
+// open_chisel ChunkManager.h:42-54; AnyIndexHash, voxblox block_hash.h:15-26).
+__device__ __forceinline__ uint32_t dir_hash(int x, int y, int z, uint32_t mask) {
+  const uint64_t h = ((uint64_t)(int64_t)x * 73856093ull) ^ ((uint64_t)(int64_t)y * 19349663ull) ^
+                     ((uint64_t)(int64_t)z * 83492791ull);
+  return (uint32_t)h & mask;
+}
+
+// Insert-if-absent; the slot of a freshly inserted block becomes visible to
+// other threads only after the kernel boundary (the count pass never needs it).
+__device__ inline void dir_insert(const Directory& d, int x, int y, int z, int32_t* num_blocks,
+                                  uint32_t* err) {
+  unsigned long long key;
+  if (!pack_block(x, y, z, &key)) {
+    atomicOr(err, kErrCoordRange);
+    return;
+  }
+  uint32_t h = dir_hash(x, y, z, d.mask);
+  for (uint32_t probe = 0; probe <= d.mask; ++probe) {
+    unsigned long long cur = d.keys[h];
+    if (cur == key) return;
+    if (cur == kEmptyKey) {
+      cur = atomicCAS(&d.keys[h], kEmptyKey, key);
+      if (cur == kEmptyKey) {
+        const int slot = atomicAdd(num_blocks, 1);
+        if (slot < d.max_blocks) {
+          d.slots[h] = slot;
+          d.slot_ids[3 * slot + 0] = x;
+          d.slot_ids[3 * slot + 1] = y;
+          d.slot_ids[3 * slot + 2] = z;
+        } else {
+          atomicOr(err, kErrPoolFull);
+        }
+        return;
+      }
+      if (cur == key) return;
+    }
+    h = (h + 1) & d.mask;
+  }
+  atomicOr(err, kErrPoolFull);
+}
+
+__device__ inline int dir_find(const Directory& d, int x, int y, int z) {
+  unsigned long long key;
+  if (!pack_block(x, y, z, &key)) return -1;
+  uint32_t h = dir_hash(x, y, z, d.mask);
+  for (uint32_t probe = 0; probe <= d.mask; ++probe) {
+    const unsigned long long cur = d.keys[h];
+    if (cur == key) return d.slots[h];
+    if (cur == kEmptyKey) return -1;
+    h = (h + 1) & d.mask;
+  }
+  return -1;
+}
+
+// cloud index of global point i: largest c with offsets[c] <= i.
+__device__ __forceinline__ int cloud_of(const int32_t* __restrict__ offsets, int nclouds, int i) {
+  int lo = 0, hi = nclouds - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (offsets[mid] <= i) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+}  // namespace tsdf
+}  // namespace plvs

@@ -1,0 +1,538 @@
+// TSDF integrate for the voxblox back end (PointCloudMapVoxblox::InsertCloud ->
+// TsdfServer::insertPointCloud -> SimpleTsdfIntegrator::integratePointCloud).
+//
+// Same device pipeline as the chisel path (tsdf_chisel.hip): count -> scan ->
+// fill -> stable radix sort by voxel -> expand (order-independent operands) ->
+// chain (one thread folds each voxel's records in the reference's visiting
+// order).  The visiting order is voxblox's ThreadSafeIndex "mixed" order; a
+// record's sequence number is the position of its point in that order, so the
+// single-thread schedule of the reference is reproduced exactly.
+//
+// HBM layout: three planes distance / weight / rgba of max_blocks*4096 dwords
+// (12 B per voxel, 48 KiB per block, voxel.h:12-18), the shared block directory
+// (tsdf_directory.hpp), and per call one (u32 key, u32 sequence) pair plus
+// 12 B of operands per voxel visit.
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "tsdf_directory.hpp"
+#include "tsdf_voxblox_core.hpp"
+
+using namespace plvs;
+using namespace plvs::tsdf;
+using namespace plvs::vbx;
+
+namespace {
+
+constexpr uint32_t kErrNonFinite = 8u;
+constexpr int kMaxRaySteps = 1 << 16;
+
+struct VCounters {
+  uint32_t total_visits;
+  int32_t num_blocks;
+  uint32_t err;
+  uint32_t num_heads;
+  uint32_t num_updated;
+  uint32_t max_run;
+};
+
+__device__ __forceinline__ PoseRt load_pose(const float* __restrict__ Twc, int c) {
+  PoseRt p;
+  const float* T = Twc + 12 * c;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) p.R[3 * i + j] = T[4 * i + j];
+    p.t[i] = T[4 * i + 3];
+  }
+  return p;
+}
+
+// Which point does sequence position i of the batch denote?
+__device__ __forceinline__ int point_of_seq(const int32_t* __restrict__ offsets, int nclouds, int i,
+                                            int* cloud) {
+  const int c = cloud_of(offsets, nclouds, i);
+  const int beg = offsets[c], cnt = offsets[c + 1] - beg;
+  *cloud = c;
+  return beg + (int)mixed_index((uint32_t)(i - beg), (uint32_t)cnt);
+}
+
+template <bool kFill>
+__global__ __launch_bounds__(256) void vb_ray_pass(
+    Params P, const float* __restrict__ xyz, int npoints, const int32_t* __restrict__ offsets,
+    int nclouds, const float* __restrict__ Twc, Directory dir, VCounters* __restrict__ ctr,
+    uint32_t* __restrict__ counts, uint32_t* __restrict__ rec_keys, uint32_t* __restrict__ rec_seq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npoints) return;
+  int cloud;
+  const int p = point_of_seq(offsets, nclouds, i, &cloud);
+  const float px = xyz[3 * (size_t)p], py = xyz[3 * (size_t)p + 1], pz = xyz[3 * (size_t)p + 2];
+  uint32_t n = 0;
+  if (!(isfinite(px) && isfinite(py) && isfinite(pz))) {
+    // the reference filters such points out BEFORE the mixed order is formed;
+    // PLVS's cloud generator never emits them, so refuse instead of diverging
+    if (!kFill) atomicOr(&ctr->err, kErrNonFinite);
+  } else {
+    const PoseRt pose = load_pose(Twc, cloud);
+    Ray ray;
+    if (make_ray(P, pose, px, py, pz, &ray)) {
+      const uint32_t out = kFill ? counts[i] : 0u;
+      int lb[3] = {0, 0, 0}, lslot = -1;
+      bool have_last = false;
+      const int steps = ray.steps < kMaxRaySteps ? ray.steps : kMaxRaySteps;
+      for (int s = 0; s <= steps; ++s) {
+        int g[3], b[3], vid;
+        ray_step(&ray, g);
+        if (!block_of(P, g, b, &vid)) continue;
+        if (!have_last || b[0] != lb[0] || b[1] != lb[1] || b[2] != lb[2]) {
+          lb[0] = b[0]; lb[1] = b[1]; lb[2] = b[2];
+          have_last = true;
+          if (kFill) {
+            lslot = dir_find(dir, b[0], b[1], b[2]);
+            if (lslot < 0) atomicOr(&ctr->err, kErrDirectoryMiss);
+          } else {
+            dir_insert(dir, b[0], b[1], b[2], &ctr->num_blocks, &ctr->err);
+            if (((g[0] - b[0] * 16) | (g[1] - b[1] * 16) | (g[2] - b[2] * 16)) & ~15)
+              atomicOr(&ctr->err, kErrCoordRange);  // float block lookup left the integer grid
+          }
+        }
+        if (kFill && lslot >= 0) {
+          rec_keys[out + n] = (uint32_t)lslot * (uint32_t)kBlockVox + (uint32_t)vid;
+          rec_seq[out + n] = (uint32_t)i;
+        }
+        ++n;
+      }
+    }
+  }
+  if (!kFill) counts[i] = n;
+}
+
+constexpr int kExpandThreads = 1024;
+__global__ __launch_bounds__(kExpandThreads) void vb_expand(
+    Params P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ seqs, uint32_t n,
+    const float* __restrict__ xyz, const uint32_t* __restrict__ rgba,
+    const int32_t* __restrict__ offsets, int nclouds, const float* __restrict__ Twc,
+    const int32_t* __restrict__ slot_ids, float2* __restrict__ rec, uint32_t* __restrict__ rec_c,
+    uint32_t* __restrict__ heads, uint32_t* __restrict__ updated_slots,
+    VCounters* __restrict__ ctr) {
+  __shared__ uint32_t wave_cnt[2][kExpandThreads / 64];
+  __shared__ uint32_t block_base[2];
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  bool head = false, chead = false;
+  uint32_t key = 0;
+  if (r < n) {
+    key = keys[r];
+    const uint32_t prev = r ? keys[r - 1] : ~key;
+    const uint32_t next = (r + 1 < n) ? keys[r + 1] : ~key;
+    head = (r == 0) || (key != prev);
+    chead = (r == 0) || ((key >> 12) != (prev >> 12));
+    int cloud;
+    const int p = point_of_seq(offsets, nclouds, (int)seqs[r], &cloud);
+    const PoseRt pose = load_pose(Twc, cloud);
+    const float px = xyz[3 * (size_t)p], py = xyz[3 * (size_t)p + 1], pz = xyz[3 * (size_t)p + 2];
+    float pG[3];
+    for (int k = 0; k < 3; ++k)
+      pG[k] = vsum3(pose.R[3 * k] * px, pose.R[3 * k + 1] * py, pose.R[3 * k + 2] * pz) + pose.t[k];
+    const float weight = fabsf(pz) > 1e-6f ? 1.0f / (pz * pz) : 0.0f;
+    const uint32_t slot = key >> 12, vid = key & 4095u;
+    const int g[3] = {slot_ids[3 * slot + 0] * 16 + (int)(vid & 15u),
+                      slot_ids[3 * slot + 1] * 16 + (int)((vid >> 4) & 15u),
+                      slot_ids[3 * slot + 2] * 16 + (int)(vid >> 8)};
+    float sdf, uw;
+    visit_operands(P, pose.t, pG, g, weight, &sdf, &uw);
+    // uw >= 0: its sign bit marks the LAST record of the voxel run
+    rec[r] = make_float2(sdf, (key != next) ? -uw : uw);
+    rec_c[r] = rgba[p];
+  }
+  const unsigned long long mh = __ballot(head), mc = __ballot(chead);
+  if (lane == 0) {
+    wave_cnt[0][wid] = (uint32_t)__popcll(mh);
+    wave_cnt[1][wid] = (uint32_t)__popcll(mc);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    uint32_t tot = 0;
+    for (int w = 0; w < kExpandThreads / 64; ++w) {
+      const uint32_t c = wave_cnt[threadIdx.x][w];
+      wave_cnt[threadIdx.x][w] = tot;
+      tot += c;
+    }
+    block_base[threadIdx.x] =
+        tot ? atomicAdd(threadIdx.x == 0 ? &ctr->num_heads : &ctr->num_updated, tot) : 0u;
+  }
+  __syncthreads();
+  if (head) heads[block_base[0] + wave_cnt[0][wid] + (uint32_t)__popcll(mh & lt)] = r;
+  if (chead) updated_slots[block_base[1] + wave_cnt[1][wid] + (uint32_t)__popcll(mc & lt)] = key >> 12;
+}
+
+constexpr int kChainBatch = 8;
+struct VBatch {
+  float2 v[kChainBatch];
+  uint32_t c[kChainBatch];
+};
+__device__ __forceinline__ void vb_load(const float2* __restrict__ rec, const uint32_t* __restrict__ rec_c,
+                                        uint32_t r, uint32_t nrec, VBatch& b) {
+#pragma unroll
+  for (int j = 0; j < kChainBatch; ++j) {
+    const uint32_t rr = r + (uint32_t)j;
+    const uint32_t cl = rr < nrec ? rr : nrec - 1;
+    b.v[j] = rec[cl];
+    b.c[j] = rec_c[cl];
+  }
+}
+__device__ __forceinline__ bool vb_step(const Params& P, const VBatch& b, uint32_t r, float& D, float& W,
+                                        uint32_t& C, uint32_t& last) {
+#pragma unroll
+  for (int j = 0; j < kChainBatch; ++j) {
+    voxel_fold(P, D, W, C, b.v[j].x, fabsf(b.v[j].y), b.c[j]);
+    if (__float_as_uint(b.v[j].y) >> 31) {
+      last = r + (uint32_t)j;
+      return true;
+    }
+  }
+  return false;
+}
+
+// One thread per voxel run folds the records in visiting order.
+__global__ __launch_bounds__(256) void vb_chain(Params P, const uint32_t* __restrict__ keys,
+                                                uint32_t nrec, const float2* __restrict__ rec,
+                                                const uint32_t* __restrict__ rec_c,
+                                                const uint32_t* __restrict__ heads,
+                                                VCounters* __restrict__ ctr, float* __restrict__ dist,
+                                                float* __restrict__ weight, uint32_t* __restrict__ rgba) {
+  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= ctr->num_heads) return;
+  uint32_t r = heads[h];
+  const uint32_t r0 = r;
+  const size_t a = (size_t)keys[r];
+  VBatch b0, b1;
+  vb_load(rec, rec_c, r, nrec, b0);
+  vb_load(rec, rec_c, r + kChainBatch, nrec, b1);
+  float D = dist[a], W = weight[a];
+  uint32_t C = rgba[a];
+  uint32_t last = r;
+  for (;;) {
+    if (vb_step(P, b0, r, D, W, C, last)) break;
+    vb_load(rec, rec_c, r + 2 * kChainBatch, nrec, b0);
+    if (vb_step(P, b1, r + kChainBatch, D, W, C, last)) break;
+    vb_load(rec, rec_c, r + 3 * kChainBatch, nrec, b1);
+    r += 2 * kChainBatch;
+  }
+  dist[a] = D;
+  weight[a] = W;
+  rgba[a] = C;
+  const uint32_t len = last - r0 + 1u;
+  if (len > ctr->max_run) atomicMax(&ctr->max_run, len);
+}
+
+__global__ void vb_gather_slot_ids(const uint32_t* __restrict__ slots, int n,
+                                   const int32_t* __restrict__ slot_ids, int32_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint32_t s = slots[i];
+    out[3 * i] = slot_ids[3 * s];
+    out[3 * i + 1] = slot_ids[3 * s + 1];
+    out[3 * i + 2] = slot_ids[3 * s + 2];
+  }
+}
+
+}  // namespace
+
+struct plvs_tsdf_voxblox {
+  plvs_tsdf_voxblox_params prm;
+  Params P;
+  Directory dir;
+  float* dist = nullptr;
+  float* weight = nullptr;
+  uint32_t* rgba = nullptr;
+  VCounters* d_ctr = nullptr;
+  VCounters* h_ctr = nullptr;
+  int num_blocks = 0;
+  bool poisoned = false;
+  DevBuf<uint32_t> counts, keys0, keys1, seq0, seq1, heads, updated, scratch, rec_c;
+  DevBuf<float2> rec;
+  DevBuf<int32_t> offsets;
+  DevBuf<float> st_xyz, st_Twc;
+  DevBuf<uint32_t> st_rgba;
+  plvs_tsdf_stats stats{};
+  uint32_t last_updated = 0;
+};
+
+static int vb_read_counters(plvs_tsdf_voxblox* h, hipStream_t s) {
+  PLVS_HIP_TRY(hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(VCounters), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  return PLVS_OK;
+}
+
+extern "C" {
+
+int plvs_hip_tsdf_voxblox_default_params(float voxel_size, int use_carving,
+                                         plvs_tsdf_voxblox_params* p) {
+  PLVS_REQUIRE(p, "params is null");
+  PLVS_REQUIRE(voxel_size > 0.0f, "voxel_size must be positive");
+  p->voxel_size = voxel_size;        // tsdf_voxel_size = PointCloudMapping.resolution
+  p->truncation = 0.1f;              // src/PointCloudMapVoxblox.cc:57
+  p->max_weight = 10000.0f;          // :58
+  p->min_ray_length = 0.1f;          // :60
+  p->max_ray_length = 5.0f;          // :61
+  p->voxel_carving = use_carving ? 1 : 0;  // :59
+  p->max_blocks = 32768;             // 1.5 GiB of voxel pool
+  p->shard_rank = 0;
+  p->shard_count = 1;
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_voxblox_destroy(plvs_tsdf_voxblox* h) {
+  if (!h) return PLVS_OK;
+  (void)hipFree(h->dir.keys); (void)hipFree(h->dir.slots); (void)hipFree(h->dir.slot_ids);
+  (void)hipFree(h->dist); (void)hipFree(h->weight); (void)hipFree(h->rgba); (void)hipFree(h->d_ctr);
+  if (h->h_ctr) (void)hipHostFree(h->h_ctr);
+  h->counts.release(); h->keys0.release(); h->keys1.release(); h->seq0.release(); h->seq1.release();
+  h->heads.release(); h->updated.release(); h->scratch.release(); h->rec_c.release(); h->rec.release();
+  h->offsets.release(); h->st_xyz.release(); h->st_Twc.release(); h->st_rgba.release();
+  delete h;
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_voxblox_clear(plvs_tsdf_voxblox* h) {
+  PLVS_REQUIRE(h, "null handle");
+  const size_t cap = (size_t)h->dir.mask + 1;
+  const size_t nvox = (size_t)h->prm.max_blocks * kBlockVox;
+  PLVS_HIP_TRY(hipMemset(h->dir.keys, 0xFF, cap * sizeof(unsigned long long)));
+  PLVS_HIP_TRY(hipMemset(h->dir.slots, 0xFF, cap * sizeof(int32_t)));
+  PLVS_HIP_TRY(hipMemset(h->dist, 0, nvox * sizeof(float)));     // TsdfVoxel defaults: 0, 0, Color()
+  PLVS_HIP_TRY(hipMemset(h->weight, 0, nvox * sizeof(float)));
+  PLVS_HIP_TRY(hipMemset(h->rgba, 0, nvox * sizeof(uint32_t)));
+  PLVS_HIP_TRY(hipMemset(h->d_ctr, 0, sizeof(VCounters)));
+  PLVS_HIP_TRY(hipDeviceSynchronize());
+  h->num_blocks = 0;
+  h->poisoned = false;
+  h->stats = plvs_tsdf_stats{};
+  h->last_updated = 0;
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_voxblox_create(const plvs_tsdf_voxblox_params* p, plvs_tsdf_voxblox** out) {
+  PLVS_REQUIRE(p && out, "null argument");
+  PLVS_REQUIRE(p->voxel_size > 0.0f, "voxel_size must be positive");
+  PLVS_REQUIRE(p->max_blocks > 0 && p->max_blocks <= (1 << 20), "max_blocks must be in (0, 2^20]");
+  PLVS_REQUIRE(p->shard_count <= 1 || (p->shard_rank >= 0 && p->shard_rank < p->shard_count),
+               "shard_rank out of range");
+  plvs_tsdf_voxblox* h = new plvs_tsdf_voxblox();
+  h->prm = *p;
+  Params& P = h->P;
+  P.voxel_size = p->voxel_size;
+  P.voxel_size_inv = (float)(1.0 / p->voxel_size);  // tsdf_integrator.cc:17
+  P.vps_inv = (float)(1.0 / 16);                    // :19
+  P.truncation = p->truncation;
+  P.max_weight = p->max_weight;
+  P.min_ray = p->min_ray_length;
+  P.max_ray = p->max_ray_length;
+  P.carving = p->voxel_carving ? 1 : 0;
+  P.allow_clear = P.carving;  // allow_clear = true in PLVS, but it needs carving (:26-28)
+  P.shard_rank = p->shard_rank;
+  P.shard_count = p->shard_count < 1 ? 1 : p->shard_count;
+  uint32_t cap = 1024;
+  while (cap < 2u * (uint32_t)p->max_blocks) cap <<= 1;
+  h->dir.mask = cap - 1;
+  h->dir.max_blocks = p->max_blocks;
+  const size_t nvox = (size_t)p->max_blocks * kBlockVox;
+#define VB_TRY(call)                                                            \
+  do {                                                                          \
+    hipError_t _e = (call);                                                     \
+    if (_e != hipSuccess) {                                                     \
+      plvs::set_error("%s failed: %s", #call, hipGetErrorString(_e));          \
+      plvs_hip_tsdf_voxblox_destroy(h);                                         \
+      return PLVS_ERR_HIP;                                                      \
+    }                                                                           \
+  } while (0)
+  VB_TRY(hipMalloc((void**)&h->dir.keys, (size_t)cap * sizeof(unsigned long long)));
+  VB_TRY(hipMalloc((void**)&h->dir.slots, (size_t)cap * sizeof(int32_t)));
+  VB_TRY(hipMalloc((void**)&h->dir.slot_ids, (size_t)p->max_blocks * 3 * sizeof(int32_t)));
+  VB_TRY(hipMalloc((void**)&h->dist, nvox * sizeof(float)));
+  VB_TRY(hipMalloc((void**)&h->weight, nvox * sizeof(float)));
+  VB_TRY(hipMalloc((void**)&h->rgba, nvox * sizeof(uint32_t)));
+  VB_TRY(hipMalloc((void**)&h->d_ctr, sizeof(VCounters)));
+  VB_TRY(hipHostMalloc((void**)&h->h_ctr, sizeof(VCounters)));
+#undef VB_TRY
+  *out = h;
+  int rc = plvs_hip_tsdf_voxblox_clear(h);
+  if (rc != PLVS_OK) {
+    plvs_hip_tsdf_voxblox_destroy(h);
+    *out = nullptr;
+  }
+  return rc;
+}
+
+int plvs_hip_tsdf_voxblox_integrate_batch_dev(plvs_tsdf_voxblox* h, const float* d_xyz,
+                                              const uint8_t* d_rgba, const int32_t* offsets,
+                                              int nclouds, const float* d_Twc, void* stream) {
+  PLVS_REQUIRE(h, "null handle");
+  PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
+  PLVS_REQUIRE(offsets && nclouds >= 0, "bad offsets");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  h->stats = plvs_tsdf_stats{};
+  h->last_updated = 0;
+  if (nclouds == 0) return PLVS_OK;
+  const int n = offsets[nclouds] - offsets[0];
+  PLVS_REQUIRE(offsets[0] == 0 && n >= 0, "offsets must start at 0 and be non-decreasing");
+  for (int c = 0; c < nclouds; ++c) PLVS_REQUIRE(offsets[c + 1] >= offsets[c], "offsets must be non-decreasing");
+  h->stats.points = n;
+  if (n == 0) return PLVS_OK;
+  PLVS_REQUIRE(d_xyz && d_rgba && d_Twc, "null device pointer");
+  PLVS_REQUIRE((reinterpret_cast<uintptr_t>(d_rgba) & 3) == 0, "rgba must be 4-byte aligned");
+  const uint32_t* d_col = reinterpret_cast<const uint32_t*>(d_rgba);
+
+  PLVS_HIP_TRY(h->offsets.reserve((size_t)nclouds + 1));
+  PLVS_HIP_TRY(h->counts.reserve((size_t)n));
+  PLVS_HIP_TRY(h->scratch.reserve(scan_scratch_words((size_t)n)));
+  PLVS_HIP_TRY(hipMemcpyAsync(h->offsets.p, offsets, ((size_t)nclouds + 1) * sizeof(int32_t),
+                              hipMemcpyHostToDevice, s));
+  PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->total_visits, 0, sizeof(uint32_t), s));
+  PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->err, 0, 4 * sizeof(uint32_t), s));
+  const dim3 rgrid(ceil_div((size_t)n, 256)), rblock(256);
+  hipLaunchKernelGGL(vb_ray_pass<false>, rgrid, rblock, 0, s, h->P, d_xyz, n, h->offsets.p, nclouds,
+                     d_Twc, h->dir, h->d_ctr, h->counts.p, (uint32_t*)nullptr, (uint32_t*)nullptr);
+  PLVS_KERNEL_CHECK();
+  PLVS_HIP_TRY(exclusive_scan_u32(h->counts.p, h->counts.p, (size_t)n, &h->d_ctr->total_visits,
+                                  h->scratch.p, s));
+  int rc = vb_read_counters(h, s);
+  if (rc != PLVS_OK) return rc;
+  if (h->h_ctr->err) {
+    h->poisoned = true;
+    plvs::set_error("tsdf_voxblox integrate: %s%s%s",
+                    (h->h_ctr->err & kErrPoolFull) ? "block pool full (raise max_blocks) " : "",
+                    (h->h_ctr->err & kErrCoordRange) ? "block id outside +-2^20 " : "",
+                    (h->h_ctr->err & kErrNonFinite) ? "non-finite point in the cloud " : "");
+    return (h->h_ctr->err & kErrNonFinite) ? PLVS_ERR_INVALID_ARG : PLVS_ERR_CAPACITY;
+  }
+  const uint32_t V = h->h_ctr->total_visits;
+  const int before = h->num_blocks;
+  h->num_blocks = h->h_ctr->num_blocks;
+  h->stats.visits = V;
+  h->stats.new_chunks = h->num_blocks - before;
+  if (V == 0) return PLVS_OK;
+  PLVS_HIP_TRY(h->keys0.reserve(V));
+  PLVS_HIP_TRY(h->keys1.reserve(V));
+  PLVS_HIP_TRY(h->seq0.reserve(V));
+  PLVS_HIP_TRY(h->seq1.reserve(V));
+  PLVS_HIP_TRY(h->heads.reserve(V));
+  PLVS_HIP_TRY(h->rec.reserve(V));
+  PLVS_HIP_TRY(h->rec_c.reserve(V));
+  PLVS_HIP_TRY(h->updated.reserve((size_t)h->num_blocks + 1));
+  PLVS_HIP_TRY(h->scratch.reserve(radix_scratch_words(V)));
+  hipLaunchKernelGGL(vb_ray_pass<true>, rgrid, rblock, 0, s, h->P, d_xyz, n, h->offsets.p, nclouds,
+                     d_Twc, h->dir, h->d_ctr, h->counts.p, h->keys0.p, h->seq0.p);
+  PLVS_KERNEL_CHECK();
+  int key_bits = 12;
+  while ((1ll << (key_bits - 12)) < (long long)h->num_blocks) ++key_bits;
+  bool second = false;
+  PLVS_HIP_TRY(radix_sort_pairs(h->keys0.p, h->seq0.p, h->keys1.p, h->seq1.p, V, 0, key_bits,
+                                h->scratch.p, s, &second));
+  const uint32_t* keys = second ? h->keys1.p : h->keys0.p;
+  const uint32_t* seqs = second ? h->seq1.p : h->seq0.p;
+  hipLaunchKernelGGL(vb_expand, dim3(ceil_div(V, kExpandThreads)), dim3(kExpandThreads), 0, s, h->P,
+                     keys, seqs, V, d_xyz, d_col, h->offsets.p, nclouds, d_Twc, h->dir.slot_ids,
+                     h->rec.p, h->rec_c.p, h->heads.p, h->updated.p, h->d_ctr);
+  PLVS_KERNEL_CHECK();
+  hipLaunchKernelGGL(vb_chain, dim3(ceil_div(V, 256)), dim3(256), 0, s, h->P, keys, V, h->rec.p,
+                     h->rec_c.p, h->heads.p, h->d_ctr, h->dist, h->weight, h->rgba);
+  PLVS_KERNEL_CHECK();
+  rc = vb_read_counters(h, s);
+  if (rc != PLVS_OK) return rc;
+  if (h->h_ctr->err) {
+    h->poisoned = true;
+    plvs::set_error("tsdf_voxblox integrate: internal directory miss (err=%u)", h->h_ctr->err);
+    return PLVS_ERR_CAPACITY;
+  }
+  h->stats.updated_chunks = (int32_t)h->h_ctr->num_updated;
+  h->stats.voxels = (int32_t)h->h_ctr->num_heads;
+  h->stats.max_run = (int32_t)h->h_ctr->max_run;
+  h->last_updated = h->h_ctr->num_updated;
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_voxblox_integrate(plvs_tsdf_voxblox* h, const float* xyz, const uint8_t* rgba,
+                                    int n, const float* Twc) {
+  PLVS_REQUIRE(h, "null handle");
+  PLVS_REQUIRE(n >= 0 && Twc, "bad arguments");
+  if (n == 0) {
+    h->stats = plvs_tsdf_stats{};
+    h->last_updated = 0;
+    return PLVS_OK;
+  }
+  PLVS_REQUIRE(xyz && rgba, "null cloud pointer");
+  PLVS_HIP_TRY(h->st_xyz.reserve((size_t)n * 3));
+  PLVS_HIP_TRY(h->st_rgba.reserve((size_t)n));
+  PLVS_HIP_TRY(h->st_Twc.reserve(12));
+  PLVS_HIP_TRY(hipMemcpy(h->st_xyz.p, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(h->st_rgba.p, rgba, (size_t)n * 4, hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(h->st_Twc.p, Twc, 12 * sizeof(float), hipMemcpyHostToDevice));
+  const int32_t offsets[2] = {0, n};
+  int rc = plvs_hip_tsdf_voxblox_integrate_batch_dev(
+      h, h->st_xyz.p, reinterpret_cast<const uint8_t*>(h->st_rgba.p), offsets, 1, h->st_Twc.p, nullptr);
+  if (rc != PLVS_OK) return rc;
+  PLVS_HIP_TRY(hipDeviceSynchronize());
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_voxblox_last_stats(plvs_tsdf_voxblox* h, plvs_tsdf_stats* s) {
+  PLVS_REQUIRE(h && s, "null argument");
+  *s = h->stats;
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_voxblox_num_blocks(plvs_tsdf_voxblox* h, int* n) {
+  PLVS_REQUIRE(h && n, "null argument");
+  *n = h->num_blocks;
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_voxblox_block_ids(plvs_tsdf_voxblox* h, int32_t* ids_xyz, int cap, int* n) {
+  PLVS_REQUIRE(h && n, "null argument");
+  *n = h->num_blocks;
+  const int m = h->num_blocks < cap ? h->num_blocks : cap;
+  if (m > 0) {
+    PLVS_REQUIRE(ids_xyz, "null output");
+    PLVS_HIP_TRY(hipMemcpy(ids_xyz, h->dir.slot_ids, (size_t)m * 3 * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_voxblox_updated_block_ids_dev(plvs_tsdf_voxblox* h, int32_t* d_ids_xyz, int cap,
+                                                int* n, void* stream) {
+  PLVS_REQUIRE(h && n, "null argument");
+  *n = (int)h->last_updated;
+  const int m = (int)h->last_updated < cap ? (int)h->last_updated : cap;
+  if (m <= 0) return PLVS_OK;
+  PLVS_REQUIRE(d_ids_xyz, "null output");
+  hipLaunchKernelGGL(vb_gather_slot_ids, dim3(ceil_div((size_t)m, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), h->updated.p, m, h->dir.slot_ids, d_ids_xyz);
+  PLVS_KERNEL_CHECK();
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_voxblox_download_block(plvs_tsdf_voxblox* h, int bx, int by, int bz,
+                                         float* distance, float* weight, uint32_t* rgba) {
+  PLVS_REQUIRE(h && distance && weight && rgba, "null argument");
+  int32_t* all = new int32_t[(size_t)(h->num_blocks > 0 ? h->num_blocks : 1) * 3];
+  hipError_t e = hipSuccess;
+  if (h->num_blocks > 0)
+    e = hipMemcpy(all, h->dir.slot_ids, (size_t)h->num_blocks * 3 * sizeof(int32_t), hipMemcpyDeviceToHost);
+  int slot = -1;
+  if (e == hipSuccess)
+    for (int i = 0; i < h->num_blocks; ++i)
+      if (all[3 * i] == bx && all[3 * i + 1] == by && all[3 * i + 2] == bz) { slot = i; break; }
+  delete[] all;
+  PLVS_HIP_TRY(e);
+  if (slot < 0) {
+    plvs::set_error("block (%d,%d,%d) does not exist", bx, by, bz);
+    return PLVS_ERR_INVALID_ARG;
+  }
+  const size_t off = (size_t)slot * kBlockVox;
+  PLVS_HIP_TRY(hipMemcpy(distance, h->dist + off, kBlockVox * sizeof(float), hipMemcpyDeviceToHost));
+  PLVS_HIP_TRY(hipMemcpy(weight, h->weight + off, kBlockVox * sizeof(float), hipMemcpyDeviceToHost));
+  PLVS_HIP_TRY(hipMemcpy(rgba, h->rgba + off, kBlockVox * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return PLVS_OK;
+}
+
+}  // extern "C"

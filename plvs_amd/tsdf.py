@@ -117,6 +117,127 @@ class TsdfChisel:
         return sdf, w, kf, col
 
 
+class VoxbloxParams(ctypes.Structure):
+    _fields_ = [("voxel_size", ctypes.c_float), ("truncation", ctypes.c_float), ("max_weight", ctypes.c_float),
+                ("min_ray_length", ctypes.c_float), ("max_ray_length", ctypes.c_float),
+                ("voxel_carving", ctypes.c_int32), ("max_blocks", ctypes.c_int32),
+                ("shard_rank", ctypes.c_int32), ("shard_count", ctypes.c_int32)]
+
+
+_L = _lib.lib
+_vp, _i = ctypes.c_void_p, ctypes.c_int
+_L.plvs_hip_tsdf_voxblox_default_params.argtypes = [ctypes.c_float, _i, ctypes.POINTER(VoxbloxParams)]
+_L.plvs_hip_tsdf_voxblox_create.argtypes = [ctypes.POINTER(VoxbloxParams), ctypes.POINTER(_vp)]
+_L.plvs_hip_tsdf_voxblox_destroy.argtypes = [_vp]
+_L.plvs_hip_tsdf_voxblox_clear.argtypes = [_vp]
+_L.plvs_hip_tsdf_voxblox_integrate.argtypes = [_vp, _vp, _vp, _i, _vp]
+_L.plvs_hip_tsdf_voxblox_integrate_batch_dev.argtypes = [_vp, _vp, _vp, _vp, _i, _vp, _vp]
+_L.plvs_hip_tsdf_voxblox_last_stats.argtypes = [_vp, ctypes.POINTER(_lib.TsdfStats)]
+_L.plvs_hip_tsdf_voxblox_num_blocks.argtypes = [_vp, ctypes.POINTER(_i)]
+_L.plvs_hip_tsdf_voxblox_block_ids.argtypes = [_vp, _vp, _i, ctypes.POINTER(_i)]
+_L.plvs_hip_tsdf_voxblox_updated_block_ids_dev.argtypes = [_vp, _vp, _i, ctypes.POINTER(_i), _vp]
+_L.plvs_hip_tsdf_voxblox_download_block.argtypes = [_vp, _i, _i, _i, _vp, _vp, _vp]
+
+
+class TsdfVoxblox:
+    """Thin RAII wrapper of the plvs_hip_tsdf_voxblox_* C ABI."""
+
+    def __init__(self, voxel_size, use_carving=False, max_blocks=None, shard_rank=0, shard_count=1,
+                 max_ray_length=None):
+        p = VoxbloxParams()
+        _lib.check(_L.plvs_hip_tsdf_voxblox_default_params(ctypes.c_float(voxel_size), int(use_carving), ctypes.byref(p)))
+        if max_blocks is not None:
+            p.max_blocks = int(max_blocks)
+        if max_ray_length is not None:
+            p.max_ray_length = float(max_ray_length)
+        p.shard_rank, p.shard_count = int(shard_rank), int(shard_count)
+        self.params = p
+        self._h = _vp()
+        _lib.check(_L.plvs_hip_tsdf_voxblox_create(ctypes.byref(p), ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _L.plvs_hip_tsdf_voxblox_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clear(self):
+        _lib.check(_L.plvs_hip_tsdf_voxblox_clear(self._h))
+
+    def integrate(self, xyz, rgba, Twc):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8).reshape(-1, 4)
+        Twc = np.ascontiguousarray(Twc, dtype=np.float32).reshape(3, 4)
+        _lib.check(_L.plvs_hip_tsdf_voxblox_integrate(self._h, _lib.np_ptr(xyz), _lib.np_ptr(rgba), xyz.shape[0],
+                                                      _lib.np_ptr(Twc)))
+
+    def integrate_batch_dev(self, d_xyz, d_rgba, offsets, d_Twc):
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        _lib.check(_L.plvs_hip_tsdf_voxblox_integrate_batch_dev(
+            self._h, _lib.t_ptr(d_xyz), _lib.t_ptr(d_rgba), _lib.np_ptr(offsets), offsets.shape[0] - 1,
+            _lib.t_ptr(d_Twc), _lib.current_stream_ptr()))
+
+    def last_stats(self):
+        s = _lib.TsdfStats()
+        _lib.check(_L.plvs_hip_tsdf_voxblox_last_stats(self._h, ctypes.byref(s)))
+        return dict(visits=s.visits, points=s.points, new_chunks=s.new_chunks,
+                    updated_chunks=s.updated_chunks, voxels=s.voxels, max_run=s.max_run)
+
+    def num_chunks(self):
+        n = _i()
+        _lib.check(_L.plvs_hip_tsdf_voxblox_num_blocks(self._h, ctypes.byref(n)))
+        return n.value
+
+    def chunk_ids(self):
+        n = self.num_chunks()
+        ids = np.zeros((max(n, 1), 3), dtype=np.int32)
+        m = _i()
+        _lib.check(_L.plvs_hip_tsdf_voxblox_block_ids(self._h, _lib.np_ptr(ids), n, ctypes.byref(m)))
+        return ids[:n]
+
+    def updated_chunk_ids_dev(self, d_ids):
+        n = _i()
+        _lib.check(_L.plvs_hip_tsdf_voxblox_updated_block_ids_dev(
+            self._h, _lib.t_ptr(d_ids), d_ids.shape[0], ctypes.byref(n), _lib.current_stream_ptr()))
+        return n.value
+
+    def get_chunk(self, bx, by, bz):
+        d = np.empty(4096, np.float32)
+        w = np.empty(4096, np.float32)
+        c = np.empty(4096, np.uint32)
+        _lib.check(_L.plvs_hip_tsdf_voxblox_download_block(self._h, int(bx), int(by), int(bz), _lib.np_ptr(d),
+                                                           _lib.np_ptr(w), _lib.np_ptr(c)))
+        return d, w, c
+
+
+class PointCloudMapVoxblox:
+    """Same surface as PLVS2::PointCloudMapVoxblox for the integrate path
+    (src/PointCloudMapVoxblox.cc:48-99)."""
+    skIntegrationMethod = "simple"   # the reference ships "fast", which is racy by design
+
+    def __init__(self, resolution, use_carving=False, max_blocks=None):
+        if self.skIntegrationMethod != "simple":
+            raise NotImplementedError("only the deterministic 'simple' integrator is on the accelerated path")
+        self._tsdf = TsdfVoxblox(resolution, use_carving, max_blocks)
+
+    def InsertCloud(self, cloud_camera, Twc, max_range=None):
+        print("PointCloudMapVoxblox<PointT>::InsertCloud()")
+        Twc = np.asarray(Twc, dtype=np.float32)[:3, :4]
+        self._tsdf.integrate(cloud_camera["xyz"], cloud_camera["rgba"], Twc)
+
+    def Clear(self):
+        self._tsdf.clear()
+
+    @property
+    def tsdf(self):
+        return self._tsdf
+
+
 class PointCloudMapChisel:
     """Same surface as PLVS2::PointCloudMapChisel for the integrate path."""
 

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../plvs_amd/csrc/tsdf_chisel_core.hpp"
+#include "../../plvs_amd/csrc/tsdf_voxblox_core.hpp"
 
 using namespace plvs::chisel;
 
@@ -95,6 +96,78 @@ int hostcore_get_chunk(HostMap* m, int cx, int cy, int cz, float* sdf, float* w,
   memcpy(w, it->second.w.data(), kChunkVox * 4);
   memcpy(kfid, it->second.kfid.data(), kChunkVox * 4);
   memcpy(rgbw, it->second.rgbw.data(), kChunkVox * 4);
+  return 1;
+}
+}
+
+// ---------------------------------------------------------------- voxblox
+struct HostVBlock {
+  std::vector<float> d, w;
+  std::vector<uint32_t> c;
+  HostVBlock() : d(plvs::vbx::kBlockVox, 0.0f), w(plvs::vbx::kBlockVox, 0.0f), c(plvs::vbx::kBlockVox, 0) {}
+};
+struct HostVMap {
+  plvs::vbx::Params P;
+  std::map<std::tuple<int, int, int>, HostVBlock> blocks;
+  long long visits = 0;
+};
+
+extern "C" {
+HostVMap* hostvbx_create(float voxel_size, float truncation, float max_weight, float min_ray,
+                         float max_ray, int carving, int shard_rank, int shard_count) {
+  HostVMap* m = new HostVMap();
+  plvs::vbx::Params& P = m->P;
+  P.voxel_size = voxel_size;
+  P.voxel_size_inv = (float)(1.0 / voxel_size);
+  P.vps_inv = (float)(1.0 / 16);
+  P.truncation = truncation; P.max_weight = max_weight; P.min_ray = min_ray; P.max_ray = max_ray;
+  P.carving = carving ? 1 : 0; P.allow_clear = P.carving;
+  P.shard_rank = shard_rank; P.shard_count = shard_count < 1 ? 1 : shard_count;
+  return m;
+}
+void hostvbx_destroy(HostVMap* m) { delete m; }
+void hostvbx_integrate(HostVMap* m, const float* xyz, const uint8_t* rgba, int n, const float* Twc) {
+  namespace vbx = plvs::vbx;
+  using vbx::mixed_index; using vbx::make_ray; using vbx::ray_step; using vbx::block_of;
+  using vbx::visit_operands; using vbx::voxel_fold;
+  vbx::PoseRt pose;
+  for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) pose.R[3 * i + j] = Twc[4 * i + j]; pose.t[i] = Twc[4 * i + 3]; }
+  m->visits = 0;
+  for (int seq = 0; seq < n; ++seq) {
+    const int p = (int)mixed_index((uint32_t)seq, (uint32_t)n);
+    vbx::Ray ray;
+    if (!make_ray(m->P, pose, xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2], &ray)) continue;
+    uint32_t colour;
+    memcpy(&colour, rgba + 4 * (size_t)p, 4);
+    for (int s = 0; s <= ray.steps; ++s) {
+      int g[3], b[3], vid;
+      ray_step(&ray, g);
+      if (!block_of(m->P, g, b, &vid)) continue;
+      HostVBlock& blk = m->blocks[std::make_tuple(b[0], b[1], b[2])];
+      // what vb_expand recomputes from (voxel, point)
+      const int gg[3] = {b[0] * 16 + (vid & 15), b[1] * 16 + ((vid >> 4) & 15), b[2] * 16 + (vid >> 8)};
+      float sdf, uw;
+      visit_operands(m->P, pose.t, ray.pG, gg, ray.weight, &sdf, &uw);
+      voxel_fold(m->P, blk.d[vid], blk.w[vid], blk.c[vid], sdf, uw, colour);
+      m->visits++;
+    }
+  }
+}
+long long hostvbx_last_visits(HostVMap* m) { return m->visits; }
+int hostvbx_num_chunks(HostVMap* m) { return (int)m->blocks.size(); }
+void hostvbx_chunk_ids(HostVMap* m, int32_t* ids) {
+  int k = 0;
+  for (auto& kv : m->blocks) {
+    ids[3 * k] = std::get<0>(kv.first); ids[3 * k + 1] = std::get<1>(kv.first); ids[3 * k + 2] = std::get<2>(kv.first);
+    ++k;
+  }
+}
+int hostvbx_get_chunk(HostVMap* m, int bx, int by, int bz, float* d, float* w, uint32_t* c) {
+  auto it = m->blocks.find(std::make_tuple(bx, by, bz));
+  if (it == m->blocks.end()) return 0;
+  memcpy(d, it->second.d.data(), plvs::vbx::kBlockVox * 4);
+  memcpy(w, it->second.w.data(), plvs::vbx::kBlockVox * 4);
+  memcpy(c, it->second.c.data(), plvs::vbx::kBlockVox * 4);
   return 1;
 }
 }

@@ -78,6 +78,9 @@ class Oracle:
     def chisel(self, resolution, **kw):
         return _ChiselLike(self.lib, "oracle_chisel", resolution, **kw)
 
+    def voxblox(self, voxel_size, **kw):
+        return _VoxbloxLike(self.lib, "oracle_voxblox", voxel_size, **kw)
+
     def knn2(self, q, t, qmask=None, mih=True):
         q = np.ascontiguousarray(q, dtype=np.uint8)
         t = np.ascontiguousarray(t, dtype=np.uint8)
@@ -221,6 +224,55 @@ class _ChiselLike:
         return (sdf, w, kf, col) if ok else None
 
 
+class _VoxbloxLike:
+    """Oracle voxblox map / host build of the voxblox device arithmetic."""
+
+    def __init__(self, lib, prefix, voxel_size, truncation=0.1, max_weight=10000.0, min_ray=0.1, max_ray=5.0,
+                 carving=False, shard_rank=0, shard_count=1):
+        self.lib, self.p = lib, prefix
+        g = lambda n: getattr(lib, prefix + n)
+        g("_create").restype = _vp
+        g("_create").argtypes = [_f] * 5 + [_i, _i, _i]
+        g("_destroy").argtypes = [_vp]
+        g("_integrate").argtypes = [_vp, _vp, _vp, _i, _vp]
+        g("_last_visits").restype = ctypes.c_longlong
+        g("_last_visits").argtypes = [_vp]
+        g("_num_chunks").argtypes = [_vp]
+        g("_chunk_ids").argtypes = [_vp, _vp]
+        g("_get_chunk").argtypes = [_vp, _i, _i, _i, _vp, _vp, _vp]
+        self.h = _vp(g("_create")(voxel_size, truncation, max_weight, min_ray, max_ray, int(carving), shard_rank, shard_count))
+
+    def __del__(self):
+        if self.h:
+            getattr(self.lib, self.p + "_destroy")(self.h)
+            self.h = None
+
+    def integrate(self, xyz, rgba, Twc):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        Twc = np.ascontiguousarray(Twc, dtype=np.float32).reshape(3, 4)
+        getattr(self.lib, self.p + "_integrate")(self.h, _ptr(xyz), _ptr(rgba), xyz.shape[0], _ptr(Twc))
+
+    def last_visits(self):
+        return int(getattr(self.lib, self.p + "_last_visits")(self.h))
+
+    def num_chunks(self):
+        return getattr(self.lib, self.p + "_num_chunks")(self.h)
+
+    def chunk_ids(self):
+        n = self.num_chunks()
+        ids = np.zeros((max(n, 1), 3), dtype=np.int32)
+        getattr(self.lib, self.p + "_chunk_ids")(self.h, _ptr(ids))
+        return ids[:n]
+
+    def get_chunk(self, bx, by, bz):
+        d = np.empty(4096, np.float32)
+        w = np.empty(4096, np.float32)
+        c = np.empty(4096, np.uint32)
+        ok = getattr(self.lib, self.p + "_get_chunk")(self.h, int(bx), int(by), int(bz), _ptr(d), _ptr(w), _ptr(c))
+        return (d, w, c) if ok else None
+
+
 HOSTCORE_DIR = os.path.join(ROOT, "tests", "host")
 HOSTCORE_SO = os.path.join(HOSTCORE_DIR, "libhostcore.so")
 
@@ -230,7 +282,8 @@ def load_hostcore():
     kernels execute — for CPU-side agreement checks against the oracle."""
     src = os.path.join(HOSTCORE_DIR, "tsdf_core_host.cpp")
     hdr = os.path.join(ROOT, "plvs_amd", "csrc", "tsdf_chisel_core.hpp")
-    if not os.path.exists(HOSTCORE_SO) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(HOSTCORE_SO):
+    hdr2 = os.path.join(ROOT, "plvs_amd", "csrc", "tsdf_voxblox_core.hpp")
+    if not os.path.exists(HOSTCORE_SO) or max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(hdr2)) > os.path.getmtime(HOSTCORE_SO):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", src, "-o", HOSTCORE_SO], check=True)
     return ctypes.CDLL(HOSTCORE_SO)
 
