@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=25, help="keyframes per step")
     ap.add_argument("--resolution", type=float, default=0.05)
     ap.add_argument("--max-depth", type=float, default=5.0)
+    ap.add_argument("--backend", choices=["chisel", "voxblox"], default="chisel",
+                    help="chisel = configs[2] (5 cm / 5 m); voxblox = configs[3] stand-in (2 cm / 8 m room)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frontend", action="store_true")
     return ap.parse_args()
@@ -53,43 +55,57 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from plvs_amd import _lib
     from plvs_amd.synth_scene import make_keyframes
-    from plvs_amd.tsdf import TsdfChisel
+    from plvs_amd.shard import allgather_block_lists
+    from plvs_amd.tsdf import TsdfChisel, TsdfVoxblox
 
     # ---------------------------------------------------------------- inputs
     n_poses = 100                                    # 100 poses, 3.6 deg yaw step
     total_steps = args.warmup + args.steps
-    kfs = make_keyframes(n_poses, max_depth=args.max_depth, seed=0)
+    vbx = args.backend == "voxblox"
+    if vbx:                      # 2 cm voxels, 16x12x3 m room, depths to 8 m
+        if args.resolution == 0.05:
+            args.resolution = 0.02
+        if args.max_depth == 5.0:
+            args.max_depth = 8.0
+        kfs = make_keyframes(n_poses, room_size=(16.0, 12.0, 3.0), max_depth=args.max_depth, seed=0)
+        for k in kfs:
+            k["rgba"] = np.concatenate([k["rgb"], np.full((k["rgb"].shape[0], 1), 255, np.uint8)], axis=1)
+    else:
+        kfs = make_keyframes(n_poses, max_depth=args.max_depth, seed=0)
     batches = []
     for s in range(total_steps):
         sel = [kfs[(s * args.batch + j) % n_poses] for j in range(args.batch)]
         xyz = torch.from_numpy(np.concatenate([k["xyz"] for k in sel])).cuda()
-        rgb = torch.from_numpy(np.concatenate([k["rgb"] for k in sel])).cuda()
+        rgb = torch.from_numpy(np.concatenate([k["rgba" if vbx else "rgb"] for k in sel])).cuda()
         kfid = torch.from_numpy(np.concatenate([k["kfid"] for k in sel]).astype(np.int32)).cuda()
         Twc = torch.from_numpy(np.stack([k["Twc"] for k in sel])).cuda()
         offsets = np.cumsum([0] + [k["xyz"].shape[0] for k in sel]).astype(np.int32)
         batches.append((xyz, rgb, kfid, offsets, Twc))
 
-    tsdf = TsdfChisel(args.resolution, max_chunks=16384, shard_rank=rank, shard_count=world)
+    if vbx:
+        tsdf = TsdfVoxblox(args.resolution, max_blocks=65536, shard_rank=rank, shard_count=world)
+    else:
+        tsdf = TsdfChisel(args.resolution, max_chunks=16384, shard_rank=rank, shard_count=world)
     upd_cap = 8192
     d_upd = torch.zeros((upd_cap, 3), dtype=torch.int32, device="cuda")
-    d_cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
-    if world > 1:
-        g_upd = [torch.zeros_like(d_upd) for _ in range(world)]
-        g_cnt = [torch.zeros_like(d_cnt) for _ in range(world)]
+    gathered_blocks = [0]
 
     def step(b):
         xyz, rgb, kfid, offsets, Twc = b
-        tsdf.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
+        if vbx:
+            tsdf.integrate_batch_dev(xyz, rgb, offsets, Twc)
+        else:
+            tsdf.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
         st = tsdf.last_stats()
-        if world > 1:      # the path's one real exchange: updated block lists
+        if world > 1:      # the path's one real exchange: updated block lists, over RCCL
             n = tsdf.updated_chunk_ids_dev(d_upd)
-            d_cnt.fill_(min(n, upd_cap))
-            dist.all_gather(g_cnt, d_cnt)
-            dist.all_gather(g_upd, d_upd)
+            lists = allgather_block_lists(d_upd, n, upd_cap)
+            gathered_blocks[0] += sum(int(l.shape[0]) for l in lists)
         return st
 
     def barrier():
@@ -99,7 +115,8 @@ def main():
 
     for s in range(args.warmup):
         step(batches[s])
-    tsdf.set_profiling(True)
+    if not vbx:
+        tsdf.set_profiling(True)
     barrier()
     t0 = time.perf_counter()
     visits = 0
@@ -114,8 +131,11 @@ def main():
         voxels += st["voxels"]
     barrier()
     elapsed = time.perf_counter() - t0
-    stage_ms, calls = tsdf.stage_ms()
-    tsdf.set_profiling(False)
+    if vbx:
+        stage_ms, calls = {}, args.steps
+    else:
+        stage_ms, calls = tsdf.stage_ms()
+        tsdf.set_profiling(False)
 
     # max over ranks of the elapsed time, sum over ranks of the visits
     if world > 1:
@@ -134,27 +154,30 @@ def main():
         # ------------------------------------------------------------ roofline
         # Algorithmic bytes: 32 B per voxel visit (16 B read + 16 B
         # written of logical payload) + 28 B per point, for what THIS rank applied.
-        alg_bytes = 32.0 * visits + 28.0 * points
-        gpu_ms = sum(stage_ms.values())
+        alg_bytes = (24.0 * visits + 16.0 * points) if vbx else (32.0 * visits + 28.0 * points)
+        gpu_ms = sum(stage_ms.values()) if stage_ms else elapsed * 1e3
         dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None
         achieved = alg_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else 0.0
         roofline = {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
             "frac": round(achieved / 8000.0, 5), "traffic": None,
-            "kernel": "tsdf_chisel integrate pipeline (" + ", ".join(stage_ms) + ")",
+            "kernel": f"tsdf_{args.backend} integrate pipeline (" + (", ".join(stage_ms) or "wall clock of the call") + ")",
             "ms_per_launch": round(gpu_ms / max(calls, 1), 4),
             "stage_ms_per_launch": {k: round(v / max(calls, 1), 4) for k, v in stage_ms.items()},
             "dominant_stage": dominant,
             "algorithmic_bytes_per_launch": alg_bytes / max(calls, 1),
         }
         result = {
-            "metric": "Mvoxels/sec TSDF integrate (chisel 5 cm / 5 m, 640x480 RGB-D)",
+            "metric": ("Mvoxels/sec TSDF integrate (voxblox simple 2 cm / 8 m, 640x480 RGB-D)" if vbx else
+                       "Mvoxels/sec TSDF integrate (chisel 5 cm / 5 m, 640x480 RGB-D)"),
             "value": round(mvox, 2), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[2] stand-in: synthetic room 6x4x3 m, camera circle r=1 m, "
-                                   "Chisel TSDF 5 cm / 5 m, 76800-point keyframes",
+            "config": {"workload": ("configs[3] stand-in: synthetic room 16x12x3 m, camera circle r=1 m, Voxblox "
+                                    "simple TSDF 2 cm, max ray 5 m (wrapper constant), 76800-point keyframes" if vbx else
+                                    "configs[2] stand-in: synthetic room 6x4x3 m, camera circle r=1 m, "
+                                    "Chisel TSDF 5 cm / 5 m, 76800-point keyframes"),
                        "resolution": args.resolution, "max_depth": args.max_depth,
                        "keyframes_per_step": args.batch, "points_per_step": int(points // args.steps),
                        "visits_per_step": int(visits_total // args.steps),
@@ -213,17 +236,20 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from tests import oracle_lib
         oracle = oracle_lib.load()
-        ora = oracle.chisel(args.resolution)
+        ora = oracle.voxblox(args.resolution) if vbx else oracle.chisel(args.resolution)
         nb = 400
         t0 = time.perf_counter()
         cv = 0
         for k in (kfs[i % n_poses] for i in range(nb)):
-            ora.integrate(k["xyz"], k["rgb"], k["kfid"], k["Twc"])
+            if vbx:
+                ora.integrate(k["xyz"], k["rgba"], k["Twc"])
+            else:
+                ora.integrate(k["xyz"], k["rgb"], k["kfid"], k["Twc"])
             cv += ora.last_visits()
         ct = time.perf_counter() - t0
         result["cpu_baseline"] = {
             "value": round(cv / ct / 1e6, 3), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
-            "sample": f"oracle/tsdf_chisel.c (sequential, as the reference loop is) on the first {nb} "
+            "sample": f"oracle/tsdf_{args.backend}.c (sequential / integrator_threads=1) on the first {nb} "
                       f"keyframes of the same stream, {ct:.1f} s, host has {os.cpu_count()} cores",
         }
 

@@ -1,0 +1,44 @@
+"""Multi-GPU sharding of the voxel-block hash (new design — the
+reference is single-process).
+
+owner(block) = three-prime spatial hash(block id) mod world_size, the very hash
+both reference back ends key their block maps with (ChunkHasher,
+open_chisel ChunkManager.h:42-54; AnyIndexHash, voxblox block_hash.h:15-26).
+Every rank receives the same clouds, ray-casts all points and applies only the
+visits of the blocks it owns (plvs_tsdf_*_params.shard_rank / shard_count), so
+a voxel's updates stay in reference order on its single owner.  The one
+exchange step of the path is the all-gather of the per-call lists of updated
+block ids (what every rank needs to maintain the global block directory and to
+schedule meshing); it runs over torch.distributed — RCCL/xGMI on GPUs ("nccl"),
+gloo in the CPU tests.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+_P1, _P2, _P3 = np.uint64(73856093), np.uint64(19349663), np.uint64(83492791)
+
+
+def owner_of(ids_xyz, world_size):
+    """Owner rank of each block id ([k,3] int array), same function as the kernels."""
+    ids = np.asarray(ids_xyz, dtype=np.int64).reshape(-1, 3).astype(np.uint64)   # sign-extended like size_t
+    with np.errstate(over="ignore"):
+        h = (ids[:, 0] * _P1) ^ (ids[:, 1] * _P2) ^ (ids[:, 2] * _P3)
+    return (h % np.uint64(world_size)).astype(np.int64)
+
+
+def allgather_block_lists(local_ids, count, cap, group=None):
+    """All-gather variable-length block-id lists.
+
+    local_ids: int32 tensor [cap, 3] (cpu for gloo, cuda for nccl) whose first
+    `count` rows are valid.  Returns a list (one per rank) of int32 tensors
+    [n_r, 3] on the same device.  Two fixed-size collectives: counts, then the
+    padded lists (a few KB: latency-bound on xGMI, so one fused pair per call)."""
+    world = dist.get_world_size(group)
+    dev = local_ids.device
+    cnt = torch.tensor([min(int(count), cap)], dtype=torch.int32, device=dev)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    lists = [torch.zeros_like(local_ids) for _ in range(world)]
+    dist.all_gather(cnts, cnt, group=group)
+    dist.all_gather(lists, local_ids, group=group)
+    return [lists[r][: int(cnts[r].item())] for r in range(world)]

@@ -22,6 +22,10 @@ if [[ "$STAGES" == *bench* ]]; then
   ( timeout 300 python bench.py 2>&1 | tail -20 ) > "$O/bench.log" 2>&1
   echo "bench done $(date +%T)" >> "$O/stages.log"
 fi
+if [[ "$STAGES" == *vbx* ]]; then
+  ( timeout 300 python bench.py --backend voxblox --no-frontend 2>&1 | tail -5 ) > "$O/bench_voxblox.log" 2>&1
+  echo "bench voxblox done $(date +%T)" >> "$O/stages.log"
+fi
 if [[ "$STAGES" == *sweep* ]]; then
   for B in 1 5 10 50 100; do
     ( timeout 200 python bench.py --batch $B --no-cpu-baseline --no-frontend 2>&1 | tail -1 ) >> "$O/sweep.log" 2>&1
@@ -40,4 +44,4 @@ if [[ "$STAGES" == *pmc* ]]; then
 fi
 find "$O" -type f | head -40
 cat "$O/stages.log"
-for f in pytest_gpu smoke bench sweep rocprof; do [ -f "$O/$f.log" ] && tail -4 "$O/$f.log"; done
+for f in pytest_gpu smoke bench bench_voxblox sweep rocprof; do [ -f "$O/$f.log" ] && tail -4 "$O/$f.log"; done

@@ -1,0 +1,90 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the block-list exchange, with the
+CPU oracle standing in for each rank's shard of the map.
+
+Checks: the owner function used by the host equals the one compiled into the
+oracle/kernels (disjoint shards whose union is the unsharded map), and the
+all-gather returns every rank's updated-block list to every rank."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from plvs_amd.shard import allgather_block_lists, owner_of
+    from tests import oracle_lib
+    from tests.plvs_amd_synth import make_keyframes, TUM1
+    cam = dict(TUM1)
+    for k in ("fx", "fy", "cx", "cy"):
+        cam[k] /= 4
+    cam["width"] //= 4
+    cam["height"] //= 4
+    oracle = oracle_lib.load()
+    shard = oracle.chisel(0.05, shard_rank=rank, shard_count=world)
+    seen = []
+    cap = 512
+    for kf in make_keyframes(2, cam=cam, seed=5):
+        before = {tuple(x) for x in shard.chunk_ids()}
+        shard.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+        new = sorted({tuple(x) for x in shard.chunk_ids()} - before)
+        buf = torch.zeros((cap, 3), dtype=torch.int32)
+        if new:
+            buf[: len(new)] = torch.tensor(new, dtype=torch.int32)
+        lists = allgather_block_lists(buf, len(new), cap)
+        assert len(lists) == world
+        assert [tuple(x) for x in lists[rank].tolist()] == new
+        for r, l in enumerate(lists):
+            if len(l):
+                assert np.all(owner_of(l.numpy(), world) == r)      # host owner fn == kernel/oracle owner fn
+        seen.append([[tuple(x) for x in l.tolist()] for l in lists])
+    q.put((rank, seen, sorted(tuple(x) for x in shard.chunk_ids())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_block_list_exchange():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, seen0, ids0), (r1, seen1, ids1) = out
+    assert seen0 == seen1                                  # every rank saw the same gathered lists
+    assert not (set(ids0) & set(ids1))                     # shards are disjoint
+    sys.path.insert(0, ROOT)
+    from tests import oracle_lib
+    from tests.plvs_amd_synth import make_keyframes, TUM1
+    cam = dict(TUM1)
+    for k in ("fx", "fy", "cx", "cy"):
+        cam[k] /= 4
+    cam["width"] //= 4
+    cam["height"] //= 4
+    full = oracle_lib.load().chisel(0.05)
+    for kf in make_keyframes(2, cam=cam, seed=5):
+        full.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+    assert set(ids0) | set(ids1) == {tuple(x) for x in full.chunk_ids()}
+    gathered = {t for step in seen0 for l in step for t in l}
+    assert gathered == set(ids0) | set(ids1)               # the exchange announced every new block
