@@ -148,6 +148,56 @@ int plvs_hip_orb_level_size(plvs_orb* h, int level, int* w, int* hh);
 int plvs_hip_orb_download_level(plvs_orb* h, int level, int blurred, uint8_t* out);
 int plvs_hip_orb_last_candidates(plvs_orb* h, int level, float* xyr, int cap, int* n);
 
+/* ----------------------------------------------------------- Line extraction
+ * Replaces LineExtractor (include/LineExtractor.h:48-83, src/LineExtractor.cc):
+ *   LineExtractor::LineExtractor(numLinefeatures, LSDOptions&)                :104-145
+ *   void LineExtractor::operator()(image, keylines, descriptors)             :150, 199-289
+ * called from Frame::ExtractLSD (src/Frame.cc:815-837), for the default
+ * configuration (Line.LSD.on = 0: EDLines detector of
+ * Thirdparty/line_descriptor/src/binary_descriptor_custom.cpp, LBD descriptor,
+ * Line.pyramidPrecomputation = 0).  The per-pixel maps and the LBD descriptors
+ * are computed on the device; anchor linking, line fitting / validation and the
+ * octave grouping are sequential and run on host threads inside the library.
+ *
+ * plvs_keyline is cv::line_descriptor_c::KeyLine field for field
+ * (descriptor_custom.hpp:104-172), 68 bytes.
+ */
+typedef struct plvs_keyline {
+  float angle;
+  int32_t class_id;
+  int32_t octave;
+  float pt_x, pt_y;
+  float response;
+  float size;
+  float startPointX, startPointY, endPointX, endPointY;
+  float sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY;
+  float lineLength;
+  int32_t numOfPixels;
+} plvs_keyline;
+
+typedef struct plvs_lines plvs_lines;
+
+/* nfeatures = Line.nfeatures (0 keeps all), nlevels = Line.nLevels, scale_factor =
+ * Line.scaleFactor, min_line_length = Line.minLineLength (relative to the image
+ * size), line_fit_err_threshold = LSDOptions::lineFitErrThreshold (1.6). */
+int plvs_hip_lines_create(int nfeatures, int nlevels, float scale_factor, double min_line_length,
+                          double line_fit_err_threshold, plvs_lines** out);
+int plvs_hip_lines_destroy(plvs_lines* h);
+/* keylines / desc hold `cap` entries (desc 32 bytes each); *n = number of lines
+ * (nothing is written if n > cap).  No lines -> *n = 0 (the reference prints
+ * "no lines!" and returns).  Empty image -> PLVS_ERR_EMPTY. */
+int plvs_hip_lines_extract(plvs_lines* h, const uint8_t* image, int w, int hh, int stride,
+                           plvs_keyline* keylines, uint8_t* desc, int cap, int* n);
+int plvs_hip_lines_extract_dev(plvs_lines* h, const uint8_t* d_image, int w, int hh, int stride,
+                               plvs_keyline* keylines, uint8_t* desc, int cap, int* n);
+/* ms of the last call: [0] device maps + D2H, [1] host linking/fitting/grouping, [2] LBD. */
+int plvs_hip_lines_last_stage_ms(plvs_lines* h, double* ms, int cap);
+/* Parity accessors of the last call: which = 0 blurred octave image (u8), 1 dx,
+ * 2 dy (s16), 3 packed map (u16: bits 0-8 gradient/4, bit 15 = |dx| < |dy|). */
+int plvs_hip_lines_octave_size(plvs_lines* h, int octave, int* w, int* hh);
+int plvs_hip_lines_download_map(plvs_lines* h, int octave, int which, void* out);
+int plvs_hip_lines_num_in_octave(plvs_lines* h, int octave);
+
 /* --------------------------------------------------------- TSDF (open_chisel)
  * Chunked (16^3) spatially hashed TSDF with per-point ray integration.
  *

@@ -40,12 +40,13 @@ inline int border_reflect101(int p, int len) {
   return p;
 }
 
-/* cv::resize(src, dst, dsize, 0, 0, INTER_LINEAR) for CV_8UC1
- * (resize.cpp: resizeGeneric_ with HResizeLinear<uchar,int,short,2048> and
- * VResizeLinear<uchar,int,short,FixedPtCast<int,uchar,22>>). */
-inline void resize_linear_u8(const Image& src, Image& dst) {
+/* cv::resize(..., INTER_LINEAR) for CV_8UC1 (resize.cpp: resizeGeneric_ with
+ * HResizeLinear<uchar,int,short,2048> and VResizeLinear<uchar,int,short,
+ * FixedPtCast<int,uchar,22>>).  Two call forms:
+ *   dsize given  (ORB pyramid): inv_scale = dsize / ssize
+ *   fx, fy given (line pyramid): dsize = saturate_cast<int>(ssize * f), inv_scale = f */
+inline void resize_linear_u8_impl(const Image& src, Image& dst, double inv_scale_x, double inv_scale_y) {
   const int sw = src.w, sh = src.h, dw = dst.w, dh = dst.h;
-  const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
   const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
   const int ONE = 2048;
   std::vector<int> xofs(dw), yofs(dh);
@@ -92,6 +93,31 @@ inline void resize_linear_u8(const Image& src, Image& dst) {
     for (int x = 0; x < dw; x++) {
       const int v = (((b0 * (r0[x] >> 4)) >> 16) + ((b1 * (r1[x] >> 4)) >> 16) + 2) >> 2;
       D[x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+    }
+  }
+}
+
+inline void resize_linear_u8(const Image& src, Image& dst) {
+  resize_linear_u8_impl(src, dst, (double)dst.w / src.w, (double)dst.h / src.h);
+}
+inline void resize_linear_u8_factor(const Image& src, Image& dst, double fx, double fy) {
+  dst = Image(cv_round(src.w * fx), cv_round(src.h * fy));
+  resize_linear_u8_impl(src, dst, fx, fy);
+}
+
+/* cv::Sobel(src, dst, CV_16S, dx, dy, 3) with the default BORDER_REFLECT_101: exact integers. */
+inline void sobel3_s16(const Image& src, std::vector<short>& dxo, std::vector<short>& dyo) {
+  const int w = src.w, h = src.h;
+  dxo.assign((size_t)w * h, 0);
+  dyo.assign((size_t)w * h, 0);
+  for (int y = 0; y < h; y++) {
+    const uint8_t* r0 = src.row(border_reflect101(y - 1, h));
+    const uint8_t* r1 = src.row(y);
+    const uint8_t* r2 = src.row(border_reflect101(y + 1, h));
+    for (int x = 0; x < w; x++) {
+      const int xm = border_reflect101(x - 1, w), xp = border_reflect101(x + 1, w);
+      dxo[(size_t)y * w + x] = (short)((r0[xp] - r0[xm]) + 2 * (r1[xp] - r1[xm]) + (r2[xp] - r2[xm]));
+      dyo[(size_t)y * w + x] = (short)((r2[xm] + 2 * r2[x] + r2[xp]) - (r0[xm] + 2 * r0[x] + r0[xp]));
     }
   }
 }

@@ -1,0 +1,956 @@
+/*
+ * oracle/lines.cpp — CPU restatement of PLVS's line front end: EDLines detection
+ * and LBD description as driven by LineExtractor (default configuration:
+ * Line.LSD.on = 0, Line.pyramidPrecomputation = 0).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under plvs_amd/ may call into this file.
+ *
+ * Parity status: UNPINNED by the reference (no tests / stored outputs; OpenCV is
+ * not in the tree — see cv_primitives.hpp for the restated primitives).
+ *
+ * Follows (paths relative to the PLVS tree):
+ *   src/LineExtractor.cc:85-92, 104-145, 199-289       LineExtractor ctor, detectLineFeatures
+ *   Thirdparty/line_descriptor/src/binary_descriptor_custom.cpp
+ *     :74-107    combinations            :119-128  EDLineParam defaults
+ *     :236-277   BinaryDescriptor ctor (gaussCoefL_/gaussCoefG_)
+ *     :438-449   binaryConversion        :504-555  detectImpl (KeyLine fill)
+ *     :614-779   computeImpl             :781-1149 OctaveKeyLines
+ *     :1151-1488 computeLBD              :1540-1575 EDLineDetector ctor / InitEDLine_
+ *     :1604-2407 EdgeDrawing             :2409-2654 EDline (fit / extend)
+ *     :2656-2815 LeastSquaresLineFit_    :2817-2898 LineValidation_
+ *     :2900-2924 EDline(image) salience
+ *   Thirdparty/line_descriptor/include/line_descriptor/descriptor_custom.hpp
+ *     :104-172 KeyLine, :640-845 nfa / log_gamma
+ * Overload notes (they decide float vs double arithmetic): inside namespace cv,
+ * unqualified sqrt / exp / pow / log / abs resolve to the std:: overloads pulled
+ * in by opencv2/core/cvstd.hpp (float in -> float out); cos, sin, atan2, fabs,
+ * round, log10 resolve to the global C (double) functions.
+ */
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <utility>
+#include <vector>
+
+#include "cv_primitives.hpp"
+
+using namespace ocv;
+
+namespace {
+
+const int NUM_OF_BANDS = 9;
+enum { Horizontal = 255, Vertical = 0 };
+enum { UpDir = 1, RightDir = 2, DownDir = 3, LeftDir = 4 };
+const int TryTime = 6, SkipEdgePoint = 2;
+
+const int combinations[32][2] = {
+    {0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {0, 6}, {1, 2}, {1, 3}, {1, 4}, {1, 5}, {1, 6},
+    {2, 3}, {2, 4}, {2, 5}, {2, 6}, {2, 7}, {2, 8}, {3, 4}, {3, 5}, {3, 6}, {3, 7}, {3, 8},
+    {4, 5}, {4, 6}, {4, 7}, {4, 8}, {5, 6}, {5, 7}, {5, 8}, {6, 7}, {6, 8}, {7, 8}};
+
+/* -------------------------------------------------------------- nfa (:640-845) */
+bool double_equal(double a, double b) {
+  if (a == b) return true;
+  const double abs_diff = fabs(a - b), aa = fabs(a), bb = fabs(b);
+  double abs_max = aa > bb ? aa : bb;
+  if (abs_max < DBL_MIN) abs_max = DBL_MIN;
+  return (abs_diff / abs_max) <= (100.0 * DBL_EPSILON);
+}
+double log_gamma_lanczos(double x) {
+  static const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705,
+                              1168.92649479, 83.8676043424, 2.50662827511};
+  double a = (x + 0.5) * log(x + 5.5) - (x + 5.5);
+  double b = 0.0;
+  for (int n = 0; n < 7; n++) {
+    a -= log(x + (double)n);
+    b += q[n] * pow(x, (double)n);
+  }
+  return a + log(b);
+}
+double log_gamma_windschitl(double x) {
+  return 0.918938533204673 + (x - 0.5) * log(x) - x +
+         0.5 * x * log(x * std::sinh(1 / x) + 1 / (810.0 * pow(x, 6.0)));
+}
+double log_gamma(double x) { return x > 15.0 ? log_gamma_windschitl(x) : log_gamma_lanczos(x); }
+
+double nfa(int n, int k, double p, double logNT) {
+  const double tolerance = 0.1, MLN10 = 2.30258509299404568402;
+  if (n == 0 || k == 0) return -logNT;
+  if (n == k) return -logNT - (double)n * log10(p);
+  const double p_term = p / (1.0 - p);
+  const double log1term = log_gamma((double)n + 1.0) - log_gamma((double)k + 1.0) -
+                          log_gamma((double)(n - k) + 1.0) + (double)k * log(p) +
+                          (double)(n - k) * log(1.0 - p);
+  double term = exp(log1term);
+  if (double_equal(term, 0.0)) {
+    if ((double)k > (double)n * p) return -log1term / MLN10 - logNT;
+    return -logNT;
+  }
+  double bin_tail = term;
+  for (int i = k + 1; i <= n; i++) {
+    const double bin_term = (double)(n - i + 1) / (double)i;
+    const double mult_term = bin_term * p_term;
+    term *= mult_term;
+    bin_tail += term;
+    if (bin_term < 1.0) {
+      const double err = term * ((1.0 - pow(mult_term, (double)(n - i + 1))) / (1.0 - mult_term) - 1.0);
+      if (err < tolerance * fabs(-log10(bin_tail) - logNT) * bin_tail) break;
+    }
+  }
+  return -log10(bin_tail) - logNT;
+}
+
+/* cv::Mat_<float> product A(2xn) * B(nx1 or nx2 as rows^T): OpenCV's gemm
+ * accumulates each output in double and stores float. */
+float dotf(const float* a, const float* b, int n) {
+  double s = 0;
+  for (int i = 0; i < n; i++) s += (double)a[i] * (double)b[i];
+  return (float)s;
+}
+
+struct EdgeChains { std::vector<unsigned> xCors, yCors, sId; unsigned numOfEdges = 0; };
+struct LineChains { std::vector<unsigned> xCors, yCors, sId; unsigned numOfLines = 0; };
+
+/* ------------------------------------------------------ EDLineDetector */
+struct EDLineDetector {
+  /* EDLineParam defaults (:119-128), lineFitErrThreshold from LSDOptions (1.6) */
+  short gradienThreshold_ = 80;
+  unsigned char anchorThreshold_ = 8;
+  unsigned scanIntervals_ = 2;
+  int minLineLen_ = 15;
+  double lineFitErrThreshold_ = 1.6;
+  unsigned imageWidth = 0, imageHeight = 0;
+  std::vector<short> dxImg_, dyImg_, gImgWO_, gImg_;
+  std::vector<unsigned char> dirImg_, edgeImage_;
+  LineChains lines_;
+  std::vector<std::vector<double>> lineEquations_;
+  std::vector<std::vector<float>> lineEndpoints_;
+  std::vector<float> lineDirection_, lineSalience_;
+  float ATA[4] = {0, 0, 0, 0}, ATV[2] = {0, 0};
+  double logNT_ = 0;
+
+  /* :1604-2407 */
+  int EdgeDrawing(const Image& image, EdgeChains& edgeChains) {
+    imageWidth = image.w;
+    imageHeight = image.h;
+    const unsigned pixelNum = imageWidth * imageHeight;
+    const unsigned edgePixelArraySize = pixelNum / 5;
+    const unsigned maxNumOfEdge = edgePixelArraySize / 20;
+    sobel3_s16(image, dxImg_, dyImg_);
+    gImg_.assign(pixelNum, 0);
+    gImgWO_.assign(pixelNum, 0);
+    dirImg_.assign(pixelNum, 0);
+    for (unsigned i = 0; i < pixelNum; i++) {
+      const int ax = std::abs((int)dxImg_[i]), ay = std::abs((int)dyImg_[i]);
+      const int sum = ax + ay;
+      const int thr = sum > gradienThreshold_ + 1 ? sum : 0;          /* THRESH_TOZERO at 81 */
+      gImg_[i] = saturate_short(cv_round(thr * 0.25));                /* MatExpr / 4 */
+      gImgWO_[i] = saturate_short(cv_round(sum * 0.25));
+      dirImg_[i] = ax < ay ? 255 : 0;                                 /* compare CMP_LT */
+    }
+    const short* pgImg = gImg_.data();
+    const unsigned char* pdirImg = dirImg_.data();
+    std::vector<unsigned> pAnchorX_(edgePixelArraySize, 0), pAnchorY_(edgePixelArraySize, 0);
+    unsigned anchorsSize = 0;
+    int indexInArray;
+    unsigned char gValue1, gValue2, gValue3;
+    for (unsigned w = 1; w < imageWidth - 1; w = w + scanIntervals_) {
+      for (unsigned h = 1; h < imageHeight - 1; h = h + scanIntervals_) {
+        indexInArray = h * imageWidth + w;
+        bool anchor;
+        if (pdirImg[indexInArray] == Horizontal)
+          anchor = pgImg[indexInArray] >= pgImg[indexInArray - imageWidth] + anchorThreshold_ &&
+                   pgImg[indexInArray] >= pgImg[indexInArray + imageWidth] + anchorThreshold_;
+        else
+          anchor = pgImg[indexInArray] >= pgImg[indexInArray - 1] + anchorThreshold_ &&
+                   pgImg[indexInArray] >= pgImg[indexInArray + 1] + anchorThreshold_;
+        if (anchor) {
+          if (anchorsSize >= edgePixelArraySize) return -1; /* the reference overruns its buffer here */
+          pAnchorX_[anchorsSize] = w;
+          pAnchorY_[anchorsSize++] = h;
+        }
+      }
+    }
+    edgeImage_.assign(pixelNum, 0);
+    unsigned char* pEdgeImg = edgeImage_.data();
+    std::vector<unsigned> pFirstPartEdgeX_(edgePixelArraySize, 0), pFirstPartEdgeY_(edgePixelArraySize, 0),
+        pSecondPartEdgeX_(edgePixelArraySize, 0), pSecondPartEdgeY_(edgePixelArraySize, 0),
+        pFirstPartEdgeS_(maxNumOfEdge + 2, 0), pSecondPartEdgeS_(maxNumOfEdge + 2, 0);
+    unsigned offsetPFirst = 0, offsetPSecond = 0, offsetPS = 0;
+    unsigned x, y, lastX = 0, lastY = 0;
+    unsigned char lastDirection, shouldGoDirection;
+    int edgeLenFirst, edgeLenSecond;
+
+    /* One smart-routing walk (the reference spells it out four times, :1737-2330):
+     * starts at (x, y) with `lastDirection`, appends to the given part arrays. */
+    auto walk = [&](std::vector<unsigned>& px, std::vector<unsigned>& py, unsigned& offset) -> bool {
+      while (pgImg[indexInArray] > 0 && !pEdgeImg[indexInArray]) {
+        pEdgeImg[indexInArray] = 1;
+        if (offset >= edgePixelArraySize) return false;
+        px[offset] = x;
+        py[offset++] = y;
+        shouldGoDirection = 0;
+        if (pdirImg[indexInArray] == Horizontal) {
+          if (lastDirection == UpDir || lastDirection == DownDir)
+            shouldGoDirection = (x > lastX) ? RightDir : LeftDir;
+          lastX = x;
+          lastY = y;
+          if (lastDirection == RightDir || shouldGoDirection == RightDir) {
+            if (x == imageWidth - 1 || y == 0 || y == imageHeight - 1) break;
+            gValue1 = (unsigned char)pgImg[indexInArray - imageWidth + 1];
+            gValue2 = (unsigned char)pgImg[indexInArray + 1];
+            gValue3 = (unsigned char)pgImg[indexInArray + imageWidth + 1];
+            if (gValue1 >= gValue2 && gValue1 >= gValue3) { x = x + 1; y = y - 1; }
+            else if (gValue3 >= gValue2 && gValue3 >= gValue1) { x = x + 1; y = y + 1; }
+            else { x = x + 1; }
+            lastDirection = RightDir;
+          } else if (lastDirection == LeftDir || shouldGoDirection == LeftDir) {
+            if (x == 0 || y == 0 || y == imageHeight - 1) break;
+            gValue1 = (unsigned char)pgImg[indexInArray - imageWidth - 1];
+            gValue2 = (unsigned char)pgImg[indexInArray - 1];
+            gValue3 = (unsigned char)pgImg[indexInArray + imageWidth - 1];
+            if (gValue1 >= gValue2 && gValue1 >= gValue3) { x = x - 1; y = y - 1; }
+            else if (gValue3 >= gValue2 && gValue3 >= gValue1) { x = x - 1; y = y + 1; }
+            else { x = x - 1; }
+            lastDirection = LeftDir;
+          }
+        } else {
+          if (lastDirection == RightDir || lastDirection == LeftDir)
+            shouldGoDirection = (y > lastY) ? DownDir : UpDir;
+          lastX = x;
+          lastY = y;
+          if (lastDirection == DownDir || shouldGoDirection == DownDir) {
+            if (x == 0 || x == imageWidth - 1 || y == imageHeight - 1) break;
+            gValue1 = (unsigned char)pgImg[indexInArray + imageWidth + 1];
+            gValue2 = (unsigned char)pgImg[indexInArray + imageWidth];
+            gValue3 = (unsigned char)pgImg[indexInArray + imageWidth - 1];
+            if (gValue1 >= gValue2 && gValue1 >= gValue3) { x = x + 1; y = y + 1; }
+            else if (gValue3 >= gValue2 && gValue3 >= gValue1) { x = x - 1; y = y + 1; }
+            else { y = y + 1; }
+            lastDirection = DownDir;
+          } else if (lastDirection == UpDir || shouldGoDirection == UpDir) {
+            if (x == 0 || x == imageWidth - 1 || y == 0) break;
+            gValue1 = (unsigned char)pgImg[indexInArray - imageWidth + 1];
+            gValue2 = (unsigned char)pgImg[indexInArray - imageWidth];
+            gValue3 = (unsigned char)pgImg[indexInArray - imageWidth - 1];
+            if (gValue1 >= gValue2 && gValue1 >= gValue3) { x = x + 1; y = y - 1; }
+            else if (gValue3 >= gValue2 && gValue3 >= gValue1) { x = x - 1; y = y - 1; }
+            else { y = y - 1; }
+            lastDirection = UpDir;
+          }
+        }
+        indexInArray = y * imageWidth + x;
+      }
+      return true;
+    };
+
+    for (unsigned i = 0; i < anchorsSize; i++) {
+      x = pAnchorX_[i];
+      y = pAnchorY_[i];
+      indexInArray = y * imageWidth + x;
+      if (pEdgeImg[indexInArray]) continue;
+      if (offsetPS >= maxNumOfEdge) return -1;
+      pFirstPartEdgeS_[offsetPS] = offsetPFirst;
+      const bool horizontalAnchor = pdirImg[indexInArray] == Horizontal;
+      lastDirection = horizontalAnchor ? RightDir : DownDir;
+      if (!walk(pFirstPartEdgeX_, pFirstPartEdgeY_, offsetPFirst)) return -1;
+      x = pAnchorX_[i];
+      y = pAnchorY_[i];
+      indexInArray = y * imageWidth + x;
+      pEdgeImg[indexInArray] = 0;
+      lastDirection = horizontalAnchor ? LeftDir : UpDir;
+      pSecondPartEdgeS_[offsetPS] = offsetPSecond;
+      if (!walk(pSecondPartEdgeX_, pSecondPartEdgeY_, offsetPSecond)) return -1;
+      edgeLenFirst = offsetPFirst - pFirstPartEdgeS_[offsetPS];
+      edgeLenSecond = offsetPSecond - pSecondPartEdgeS_[offsetPS];
+      if (edgeLenFirst + edgeLenSecond < minLineLen_ + 1) {
+        offsetPFirst = pFirstPartEdgeS_[offsetPS];
+        offsetPSecond = pSecondPartEdgeS_[offsetPS];
+      } else {
+        offsetPS++;
+      }
+    }
+    pFirstPartEdgeS_[offsetPS] = offsetPFirst;
+    pSecondPartEdgeS_[offsetPS] = offsetPSecond;
+    if (!(offsetPFirst && offsetPSecond)) return -1; /* "lines not found" */
+    int tempID;
+    edgeChains.xCors.assign(offsetPFirst + offsetPSecond, 0);
+    edgeChains.yCors.assign(offsetPFirst + offsetPSecond, 0);
+    edgeChains.sId.assign(offsetPS + 1, 0);
+    unsigned indexInCors = 0, numOfEdges = 0;
+    for (unsigned edgeId = 0; edgeId < offsetPS; edgeId++) {
+      edgeChains.sId[numOfEdges++] = indexInCors;
+      indexInArray = pFirstPartEdgeS_[edgeId];
+      offsetPFirst = pFirstPartEdgeS_[edgeId + 1];
+      for (tempID = offsetPFirst - 1; tempID >= indexInArray; tempID--) {
+        edgeChains.xCors[indexInCors] = pFirstPartEdgeX_[tempID];
+        edgeChains.yCors[indexInCors++] = pFirstPartEdgeY_[tempID];
+      }
+      indexInArray = pSecondPartEdgeS_[edgeId];
+      offsetPSecond = pSecondPartEdgeS_[edgeId + 1];
+      for (tempID = indexInArray + 1; tempID < (int)offsetPSecond; tempID++) {
+        edgeChains.xCors[indexInCors] = pSecondPartEdgeX_[tempID];
+        edgeChains.yCors[indexInCors++] = pSecondPartEdgeY_[tempID];
+      }
+    }
+    edgeChains.sId[numOfEdges] = indexInCors;
+    edgeChains.numOfEdges = numOfEdges;
+    return 1;
+  }
+
+  /* :2656-2734: initial fit over minLineLen_ pixels */
+  double LeastSquaresLineFit_(const unsigned* xCors, const unsigned* yCors, unsigned offsetS,
+                              std::vector<double>& lineEquation) {
+    const bool horiz = dirImg_[yCors[offsetS] * imageWidth + xCors[offsetS]] == Horizontal;
+    std::vector<float> row0(minLineLen_), ones(minLineLen_, 1.0f), vec(minLineLen_);
+    unsigned offset = offsetS;
+    for (int i = 0; i < minLineLen_; i++) {
+      row0[i] = (float)(horiz ? xCors[offsetS] : yCors[offsetS]);
+      vec[i] = (float)(horiz ? yCors[offsetS] : xCors[offsetS]);
+      offsetS++;
+    }
+    ATA[0] = dotf(row0.data(), row0.data(), minLineLen_);
+    ATA[1] = dotf(row0.data(), ones.data(), minLineLen_);
+    ATA[2] = dotf(ones.data(), row0.data(), minLineLen_);
+    ATA[3] = dotf(ones.data(), ones.data(), minLineLen_);
+    ATV[0] = dotf(row0.data(), vec.data(), minLineLen_);
+    ATV[1] = dotf(ones.data(), vec.data(), minLineLen_);
+    double coef = 1.0 / (double(ATA[0]) * double(ATA[3]) - double(ATA[1]) * double(ATA[2]));
+    lineEquation[0] = coef * (double(ATA[3]) * double(ATV[0]) - double(ATA[1]) * double(ATV[1]));
+    lineEquation[1] = coef * (double(ATA[0]) * double(ATV[1]) - double(ATA[2]) * double(ATV[0]));
+    double fitError = 0;
+    for (int i = 0; i < minLineLen_; i++) {
+      if (horiz) coef = double(yCors[offset]) - double(xCors[offset]) * lineEquation[0] - lineEquation[1];
+      else coef = double(xCors[offset]) - double(yCors[offset]) * lineEquation[0] - lineEquation[1];
+      offset++;
+      fitError += coef * coef;
+    }
+    return sqrt(fitError);
+  }
+
+  /* :2736-2815: incremental re-fit with the newly added pixels */
+  double LeastSquaresLineFit_(const unsigned* xCors, const unsigned* yCors, unsigned offsetS,
+                              unsigned newOffsetS, unsigned offsetE, std::vector<double>& lineEquation) {
+    const int length = offsetE - offsetS, newLength = offsetE - newOffsetS;
+    if (length <= 0 || newLength <= 0) return -1;
+    const bool horiz = dirImg_[yCors[offsetS] * imageWidth + xCors[offsetS]] == Horizontal;
+    std::vector<float> row0(newLength), ones(newLength, 1.0f), vec(newLength);
+    for (int i = 0; i < newLength; i++) {
+      row0[i] = (float)(horiz ? xCors[newOffsetS] : yCors[newOffsetS]);
+      vec[i] = (float)(horiz ? yCors[newOffsetS] : xCors[newOffsetS]);
+      newOffsetS++;
+    }
+    const float t[4] = {dotf(row0.data(), row0.data(), newLength), dotf(row0.data(), ones.data(), newLength),
+                        dotf(ones.data(), row0.data(), newLength), dotf(ones.data(), ones.data(), newLength)};
+    const float v[2] = {dotf(row0.data(), vec.data(), newLength), dotf(ones.data(), vec.data(), newLength)};
+    for (int i = 0; i < 4; i++) ATA[i] = ATA[i] + t[i];   /* Mat_<float> + Mat_<float> */
+    for (int i = 0; i < 2; i++) ATV[i] = ATV[i] + v[i];
+    const double coef = 1.0 / (double(ATA[0]) * double(ATA[3]) - double(ATA[1]) * double(ATA[2]));
+    lineEquation[0] = coef * (double(ATA[3]) * double(ATV[0]) - double(ATA[1]) * double(ATV[1]));
+    lineEquation[1] = coef * (double(ATA[0]) * double(ATV[1]) - double(ATA[2]) * double(ATV[0]));
+    return 0;
+  }
+
+  /* :2817-2898 */
+  bool LineValidation_(const unsigned* xCors, const unsigned* yCors, unsigned offsetS, unsigned offsetE,
+                       std::vector<double>& lineEquation, float& direction) {
+    const int n = offsetE - offsetS;
+    int meanGradientX = 0, meanGradientY = 0;
+    double dx, dy;
+    std::vector<double> pointDirection;
+    for (int i = 0; i < n; i++) {
+      const int index = yCors[offsetS] * imageWidth + xCors[offsetS];
+      offsetS++;
+      meanGradientX += dxImg_[index];
+      meanGradientY += dyImg_[index];
+      dx = (double)dxImg_[index];
+      dy = (double)dyImg_[index];
+      pointDirection.push_back(atan2(-dx, dy));
+    }
+    dx = fabs(lineEquation[1]);
+    dy = fabs(lineEquation[0]);
+    if (meanGradientX == 0 && meanGradientY == 0) return false;
+    if (meanGradientX > 0 && meanGradientY >= 0) direction = (float)atan2(-dy, dx);
+    if (meanGradientX <= 0 && meanGradientY > 0) direction = (float)atan2(dy, dx);
+    if (meanGradientX < 0 && meanGradientY <= 0) direction = (float)atan2(dy, -dx);
+    if (meanGradientX >= 0 && meanGradientY < 0) direction = (float)atan2(-dy, -dx);
+    if (fabs(direction) < 0.15 || M_PI - fabs(direction) < 0.15) {
+      if (fabs(lineEquation[2]) < 10 || fabs(imageHeight - fabs(lineEquation[2])) < 10) return false;
+    }
+    if (fabs(fabs(direction) - M_PI * 0.5) < 0.15) {
+      if (fabs(lineEquation[2]) < 10 || fabs(imageWidth - fabs(lineEquation[2])) < 10) return false;
+    }
+    int k = 0;
+    for (int i = 0; i < n; i++) {
+      const double disDirection = fabs(direction - pointDirection[i]);
+      if (fabs(2 * M_PI - disDirection) < 0.392699 || disDirection < 0.392699) k++;
+    }
+    return nfa(n, k, 0.125, logNT_) > 0;
+  }
+
+  /* :2409-2654 */
+  int EDline(const Image& image, LineChains& lines) {
+    EdgeChains edges;
+    if (EdgeDrawing(image, edges) != 1) return -1;
+    unsigned linePixelID = edges.sId[edges.numOfEdges];
+    lines.xCors.assign(linePixelID, 0);
+    lines.yCors.assign(linePixelID, 0);
+    lines.sId.assign(5 * edges.numOfEdges, 0);
+    const unsigned* pEdgeXCors = edges.xCors.data();
+    const unsigned* pEdgeYCors = edges.yCors.data();
+    const unsigned* pEdgeSID = edges.sId.data();
+    unsigned* pLineXCors = lines.xCors.data();
+    unsigned* pLineYCors = lines.yCors.data();
+    logNT_ = 2.0 * (log10((double)imageWidth) + log10((double)imageHeight));
+    double lineFitErr = 0;
+    std::vector<double> lineEquation(2, 0);
+    lineEquations_.clear();
+    lineEndpoints_.clear();
+    lineDirection_.clear();
+    const unsigned char* pdirImg = dirImg_.data();
+    unsigned numOfLines = 0, newOffsetS = 0, offsetInEdgeArrayS, offsetInEdgeArrayE, offsetInLineArray = 0;
+    float direction = 0;
+    for (unsigned edgeID = 0; edgeID < edges.numOfEdges; edgeID++) {
+      offsetInEdgeArrayS = pEdgeSID[edgeID];
+      offsetInEdgeArrayE = pEdgeSID[edgeID + 1];
+      while (offsetInEdgeArrayE > offsetInEdgeArrayS + minLineLen_) {
+        while (offsetInEdgeArrayE > offsetInEdgeArrayS + minLineLen_) {
+          lineFitErr = LeastSquaresLineFit_(pEdgeXCors, pEdgeYCors, offsetInEdgeArrayS, lineEquation);
+          if (lineFitErr <= lineFitErrThreshold_) break;
+          offsetInEdgeArrayS += SkipEdgePoint;
+        }
+        if (lineFitErr > lineFitErrThreshold_) break;
+        if (numOfLines >= lines.sId.size()) lines.sId.push_back(0);
+        lines.sId[numOfLines] = offsetInLineArray;
+        double coef1 = 0, pointToLineDis;
+        bool bExtended = true, bFirstTry = true;
+        int numOfOutlier, tryTimes = 0;
+        const bool horiz = pdirImg[pEdgeYCors[offsetInEdgeArrayS] * imageWidth + pEdgeXCors[offsetInEdgeArrayS]] == Horizontal;
+        while (bExtended) {
+          tryTimes++;
+          if (bFirstTry) {
+            bFirstTry = false;
+            for (int i = 0; i < minLineLen_; i++) {
+              pLineXCors[offsetInLineArray] = pEdgeXCors[offsetInEdgeArrayS];
+              pLineYCors[offsetInLineArray++] = pEdgeYCors[offsetInEdgeArrayS++];
+            }
+          } else {
+            lineFitErr = LeastSquaresLineFit_(pLineXCors, pLineYCors, lines.sId[numOfLines], newOffsetS,
+                                              offsetInLineArray, lineEquation);
+          }
+          coef1 = horiz ? 1 / sqrt(lineEquation[0] * lineEquation[0] + 1)
+                        : 1 / sqrt(1 + lineEquation[0] * lineEquation[0]);
+          numOfOutlier = 0;
+          newOffsetS = offsetInLineArray;
+          while (offsetInEdgeArrayE > offsetInEdgeArrayS) {
+            if (horiz)
+              pointToLineDis = fabs(lineEquation[0] * pEdgeXCors[offsetInEdgeArrayS] - pEdgeYCors[offsetInEdgeArrayS] + lineEquation[1]) * coef1;
+            else
+              pointToLineDis = fabs(pEdgeXCors[offsetInEdgeArrayS] - lineEquation[0] * pEdgeYCors[offsetInEdgeArrayS] - lineEquation[1]) * coef1;
+            pLineXCors[offsetInLineArray] = pEdgeXCors[offsetInEdgeArrayS];
+            pLineYCors[offsetInLineArray++] = pEdgeYCors[offsetInEdgeArrayS++];
+            if (pointToLineDis > lineFitErrThreshold_) {
+              numOfOutlier++;
+              if (numOfOutlier > 3) break;
+            } else {
+              numOfOutlier = 0;
+            }
+          }
+          offsetInLineArray -= numOfOutlier;
+          offsetInEdgeArrayS -= numOfOutlier;
+          if (offsetInLineArray - newOffsetS > 0 && tryTimes < TryTime) {
+          } else {
+            bExtended = false;
+          }
+        }
+        std::vector<double> lineEqu(3, 0);
+        if (horiz) {
+          lineEqu[0] = lineEquation[0] * coef1;
+          lineEqu[1] = -1 * coef1;
+          lineEqu[2] = lineEquation[1] * coef1;
+        } else {
+          lineEqu[0] = 1 * coef1;
+          lineEqu[1] = -lineEquation[0] * coef1;
+          lineEqu[2] = -lineEquation[1] * coef1;
+        }
+        if (LineValidation_(pLineXCors, pLineYCors, lines.sId[numOfLines], offsetInLineArray, lineEqu, direction)) {
+          lineEquations_.push_back(lineEqu);
+          std::vector<float> lineEndP(4, 0);
+          const double a1 = lineEqu[1] * lineEqu[1], a2 = lineEqu[0] * lineEqu[0], a3 = lineEqu[0] * lineEqu[1],
+                       a4 = lineEqu[2] * lineEqu[0], a5 = lineEqu[2] * lineEqu[1];
+          unsigned Px = pLineXCors[lines.sId[numOfLines]], Py = pLineYCors[lines.sId[numOfLines]];
+          lineEndP[0] = (float)(a1 * Px - a3 * Py - a4);
+          lineEndP[1] = (float)(a2 * Py - a3 * Px - a5);
+          Px = pLineXCors[offsetInLineArray - 1];
+          Py = pLineYCors[offsetInLineArray - 1];
+          lineEndP[2] = (float)(a1 * Px - a3 * Py - a4);
+          lineEndP[3] = (float)(a2 * Py - a3 * Px - a5);
+          lineEndpoints_.push_back(lineEndP);
+          lineDirection_.push_back(direction);
+          numOfLines++;
+        } else {
+          offsetInLineArray = lines.sId[numOfLines];
+        }
+        if (numOfLines >= lines.sId.size()) lines.sId.push_back(offsetInLineArray);
+      }
+    }
+    if (numOfLines >= lines.sId.size()) lines.sId.push_back(0);
+    lines.sId[numOfLines] = offsetInLineArray;
+    lines.numOfLines = numOfLines;
+    return 1;
+  }
+
+  /* :2900-2924 (salience: the reference sums BYTES of the s16 gImgWO_ buffer; it
+   * never reaches the outputs used by PLVS, so it is not reproduced) */
+  int EDline(const Image& image) {
+    if (EDline(image, lines_) != 1) {
+      lines_.numOfLines = 0;
+      return -1;
+    }
+    lineSalience_.assign(lines_.numOfLines, 0.f);
+    return 1;
+  }
+};
+
+struct OctaveSingleLine {
+  float startPointX, startPointY, endPointX, endPointY;
+  float sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY;
+  float direction, salience, lineLength;
+  unsigned numOfPixels, octaveCount;
+  std::vector<float> descriptor;
+};
+
+struct KeyLine {  /* descriptor_custom.hpp:104-172, 68 bytes */
+  float angle;
+  int class_id, octave;
+  float pt_x, pt_y, response, size;
+  float startPointX, startPointY, endPointX, endPointY;
+  float sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY;
+  float lineLength;
+  int numOfPixels;
+};
+
+struct OctaveLine { unsigned octaveCount, lineIDInOctave, lineIDInScaleLineVec; float lineLength; };
+
+struct LineExtractorOracle {
+  int nfeatures, numOfOctave_;
+  float scaleFactor_;
+  double min_length;
+  const int widthOfBand_ = 7, ksize_ = 5;
+  std::vector<EDLineDetector> edLineVec_;
+  std::vector<std::pair<int, int>> images_sizes; /* (width, height) per octave */
+  std::vector<double> gaussCoefL_, gaussCoefG_;
+  std::vector<Image> octaveBlur;                 /* kept for stage-by-stage tests */
+
+  LineExtractorOracle(int nf, int nlevels, float scale, double minlen, double fitErr)
+      : nfeatures(nf), numOfOctave_(nlevels), scaleFactor_(scale), min_length(minlen) {
+    edLineVec_.resize(numOfOctave_);
+    for (auto& e : edLineVec_) e.lineFitErrThreshold_ = fitErr;
+    images_sizes.resize(numOfOctave_);
+    /* :248-274 — note the INTEGER divisions in u and sigma */
+    gaussCoefL_.resize(widthOfBand_ * 3);
+    double u = (widthOfBand_ * 3 - 1) / 2;
+    double sigma = (widthOfBand_ * 2 + 1) / 2;
+    double invsigma2 = -1 / (2 * sigma * sigma);
+    for (int i = 0; i < widthOfBand_ * 3; i++) {
+      const double dis = i - u;
+      gaussCoefL_[i] = exp(dis * dis * invsigma2);
+    }
+    gaussCoefG_.resize(NUM_OF_BANDS * widthOfBand_);
+    u = (NUM_OF_BANDS * widthOfBand_ - 1) / 2;
+    sigma = u;
+    invsigma2 = -1 / (2 * sigma * sigma);
+    for (int i = 0; i < NUM_OF_BANDS * widthOfBand_; i++) {
+      const double dis = i - u;
+      gaussCoefG_[i] = exp(dis * dis * invsigma2);
+    }
+  }
+
+  /* :781-1149 */
+  int OctaveKeyLines(Image image, std::vector<std::vector<OctaveSingleLine>>& keyLines) {
+    unsigned numOfFinalLine = 0;
+    float preSigma2 = (float)std::pow(0.5, 2);
+    const float sigma0 = 1.0;
+    float curSigma2 = (float)std::pow(sigma0, 2);
+    const double factor = scaleFactor_;
+    const double factor2 = factor * factor;
+    octaveBlur.clear();
+    for (int octaveCount = 0; octaveCount < numOfOctave_; octaveCount++) {
+      Image blur;
+      const float increaseSigma = std::sqrt(curSigma2 - preSigma2);
+      gaussian_blur_u8(image, blur, ksize_, increaseSigma);
+      images_sizes[octaveCount] = std::make_pair(blur.w, blur.h);
+      octaveBlur.push_back(blur);
+      if (edLineVec_[octaveCount].EDline(blur) == 1) numOfFinalLine += edLineVec_[octaveCount].lines_.numOfLines;
+      resize_linear_u8_factor(blur, image, (1.f / factor), (1.f / factor));
+      preSigma2 = curSigma2;
+      curSigma2 = (float)(curSigma2 * factor2);
+    }
+    std::vector<OctaveLine> octaveLines(numOfFinalLine);
+    numOfFinalLine = 0;
+    unsigned lineIDInScaleLineVec = 0;
+    float dx, dy;
+    for (unsigned lineCurId = 0; lineCurId < edLineVec_[0].lines_.numOfLines; lineCurId++) {
+      octaveLines[numOfFinalLine].octaveCount = 0;
+      octaveLines[numOfFinalLine].lineIDInOctave = lineCurId;
+      octaveLines[numOfFinalLine].lineIDInScaleLineVec = lineIDInScaleLineVec;
+      dx = (float)fabs(edLineVec_[0].lineEndpoints_[lineCurId][0] - edLineVec_[0].lineEndpoints_[lineCurId][2]);
+      dy = (float)fabs(edLineVec_[0].lineEndpoints_[lineCurId][1] - edLineVec_[0].lineEndpoints_[lineCurId][3]);
+      octaveLines[numOfFinalLine].lineLength = std::sqrt(dx * dx + dy * dy);
+      numOfFinalLine++;
+      lineIDInScaleLineVec++;
+    }
+    std::vector<float> scale(numOfOctave_);
+    scale[0] = 1;
+    for (int o = 1; o < numOfOctave_; o++) scale[o] = (float)(factor * scale[o - 1]);
+    float rho1, rho2, tempValue, direction, diffNear, length;
+    unsigned octaveID, lineIDInOctave;
+    if (numOfOctave_ > 1) {
+      const double twoPI = 2 * M_PI;
+      unsigned closeLineID = 0;
+      float endPointDis, minEndPointDis, minLocalDis, maxLocalDis;
+      float lp0, lp1, lp2, lp3, np0, np1, np2, np3;
+      for (int octaveCount = 1; octaveCount < numOfOctave_; octaveCount++) {
+        EDLineDetector& cur = edLineVec_[octaveCount];
+        for (unsigned lineCurId = 0; lineCurId < cur.lines_.numOfLines; lineCurId++) {
+          rho1 = (float)(scale[octaveCount] * fabs(cur.lineEquations_[lineCurId][2]));
+          tempValue = (float)(rho1 * 0.0152);
+          float diffNearThreshold = (tempValue > 6) ? (tempValue) : 6;
+          diffNearThreshold = (diffNearThreshold < 12) ? diffNearThreshold : 12;
+          dx = (float)fabs(cur.lineEndpoints_[lineCurId][0] - cur.lineEndpoints_[lineCurId][2]);
+          dy = (float)fabs(cur.lineEndpoints_[lineCurId][1] - cur.lineEndpoints_[lineCurId][3]);
+          length = scale[octaveCount] * std::sqrt(dx * dx + dy * dy);
+          minEndPointDis = 12;
+          for (unsigned lineNextId = 0; lineNextId < numOfFinalLine; lineNextId++) {
+            octaveID = octaveLines[lineNextId].octaveCount;
+            if ((int)octaveID == octaveCount) break;
+            lineIDInOctave = octaveLines[lineNextId].lineIDInOctave;
+            EDLineDetector& oth = edLineVec_[octaveID];
+            direction = (float)fabs(cur.lineDirection_[lineCurId] - oth.lineDirection_[lineIDInOctave]);
+            if (direction > 0.1745 && (twoPI - direction > 0.1745)) continue;
+            rho2 = (float)(scale[octaveID] * fabs(oth.lineEquations_[lineIDInOctave][2]));
+            diffNear = (float)fabs(rho1 - rho2);
+            if (diffNear > diffNearThreshold) continue;
+            lp0 = scale[octaveCount] * cur.lineEndpoints_[lineCurId][0];
+            lp1 = scale[octaveCount] * cur.lineEndpoints_[lineCurId][1];
+            lp2 = scale[octaveCount] * cur.lineEndpoints_[lineCurId][2];
+            lp3 = scale[octaveCount] * cur.lineEndpoints_[lineCurId][3];
+            np0 = scale[octaveID] * oth.lineEndpoints_[lineIDInOctave][0];
+            np1 = scale[octaveID] * oth.lineEndpoints_[lineIDInOctave][1];
+            np2 = scale[octaveID] * oth.lineEndpoints_[lineIDInOctave][2];
+            np3 = scale[octaveID] * oth.lineEndpoints_[lineIDInOctave][3];
+            dx = lp0 - np0; dy = lp1 - np1;
+            endPointDis = std::sqrt(dx * dx + dy * dy);
+            minLocalDis = endPointDis;
+            maxLocalDis = endPointDis;
+            dx = lp2 - np2; dy = lp3 - np3;
+            endPointDis = std::sqrt(dx * dx + dy * dy);
+            minLocalDis = (endPointDis < minLocalDis) ? endPointDis : minLocalDis;
+            maxLocalDis = (endPointDis > maxLocalDis) ? endPointDis : maxLocalDis;
+            dx = lp0 - np2; dy = lp1 - np3;
+            endPointDis = std::sqrt(dx * dx + dy * dy);
+            minLocalDis = (endPointDis < minLocalDis) ? endPointDis : minLocalDis;
+            maxLocalDis = (endPointDis > maxLocalDis) ? endPointDis : maxLocalDis;
+            dx = lp2 - np0; dy = lp3 - np1;
+            endPointDis = std::sqrt(dx * dx + dy * dy);
+            minLocalDis = (endPointDis < minLocalDis) ? endPointDis : minLocalDis;
+            maxLocalDis = (endPointDis > maxLocalDis) ? endPointDis : maxLocalDis;
+            if ((maxLocalDis < 0.8 * (length + octaveLines[lineNextId].lineLength)) && (minLocalDis < minEndPointDis)) {
+              minEndPointDis = minLocalDis;
+              closeLineID = lineNextId;
+            }
+          }
+          if (minEndPointDis < 12) {
+            octaveLines[numOfFinalLine].lineIDInScaleLineVec = octaveLines[closeLineID].lineIDInScaleLineVec;
+          } else {
+            octaveLines[numOfFinalLine].lineIDInScaleLineVec = lineIDInScaleLineVec;
+            lineIDInScaleLineVec++;
+          }
+          octaveLines[numOfFinalLine].octaveCount = octaveCount;
+          octaveLines[numOfFinalLine].lineIDInOctave = lineCurId;
+          octaveLines[numOfFinalLine].lineLength = length;
+          numOfFinalLine++;
+        }
+      }
+    }
+    keyLines.clear();
+    keyLines.resize(lineIDInScaleLineVec);
+    float s1, e1, s2, e2;
+    bool shouldChange;
+    for (unsigned lineID = 0; lineID < numOfFinalLine; lineID++) {
+      OctaveSingleLine singleLine;
+      lineIDInOctave = octaveLines[lineID].lineIDInOctave;
+      octaveID = octaveLines[lineID].octaveCount;
+      EDLineDetector& ed = edLineVec_[octaveID];
+      direction = ed.lineDirection_[lineIDInOctave];
+      singleLine.octaveCount = octaveID;
+      singleLine.direction = direction;
+      singleLine.lineLength = octaveLines[lineID].lineLength;
+      singleLine.salience = ed.lineSalience_[lineIDInOctave];
+      singleLine.numOfPixels = ed.lines_.sId[lineIDInOctave + 1] - ed.lines_.sId[lineIDInOctave];
+      shouldChange = false;
+      s1 = ed.lineEndpoints_[lineIDInOctave][0];
+      s2 = ed.lineEndpoints_[lineIDInOctave][1];
+      e1 = ed.lineEndpoints_[lineIDInOctave][2];
+      e2 = ed.lineEndpoints_[lineIDInOctave][3];
+      dx = e1 - s1;
+      dy = e2 - s2;
+      if (direction >= -0.75 * M_PI && direction < -0.25 * M_PI) { if (dy > 0) shouldChange = true; }
+      if (direction >= -0.25 * M_PI && direction < 0.25 * M_PI) { if (dx < 0) shouldChange = true; }
+      if (direction >= 0.25 * M_PI && direction < 0.75 * M_PI) { if (dy < 0) shouldChange = true; }
+      if ((direction >= 0.75 * M_PI && direction < M_PI) || (direction >= -M_PI && direction < -0.75 * M_PI)) { if (dx > 0) shouldChange = true; }
+      tempValue = scale[octaveID];
+      if (shouldChange) {
+        singleLine.sPointInOctaveX = e1; singleLine.sPointInOctaveY = e2;
+        singleLine.ePointInOctaveX = s1; singleLine.ePointInOctaveY = s2;
+        singleLine.startPointX = tempValue * e1; singleLine.startPointY = tempValue * e2;
+        singleLine.endPointX = tempValue * s1; singleLine.endPointY = tempValue * s2;
+      } else {
+        singleLine.sPointInOctaveX = s1; singleLine.sPointInOctaveY = s2;
+        singleLine.ePointInOctaveX = e1; singleLine.ePointInOctaveY = e2;
+        singleLine.startPointX = tempValue * s1; singleLine.startPointY = tempValue * s2;
+        singleLine.endPointX = tempValue * e1; singleLine.endPointY = tempValue * e2;
+      }
+      keyLines[octaveLines[lineID].lineIDInScaleLineVec].push_back(singleLine);
+    }
+    return (int)numOfFinalLine;
+  }
+
+  /* :504-555 */
+  void detect(const Image& image, std::vector<KeyLine>& keylines) {
+    std::vector<std::vector<OctaveSingleLine>> sl;
+    OctaveKeyLines(image, sl);
+    keylines.clear();
+    for (int i = 0; i < (int)sl.size(); i++)
+      for (size_t j = 0; j < sl[i].size(); j++) {
+        const OctaveSingleLine& osl = sl[i][j];
+        KeyLine kl;
+        kl.startPointX = osl.startPointX; kl.startPointY = osl.startPointY;
+        kl.endPointX = osl.endPointX; kl.endPointY = osl.endPointY;
+        kl.sPointInOctaveX = osl.sPointInOctaveX; kl.sPointInOctaveY = osl.sPointInOctaveY;
+        kl.ePointInOctaveX = osl.ePointInOctaveX; kl.ePointInOctaveY = osl.ePointInOctaveY;
+        kl.lineLength = osl.lineLength;
+        kl.numOfPixels = osl.numOfPixels;
+        kl.angle = osl.direction;
+        kl.class_id = i;
+        kl.octave = osl.octaveCount;
+        kl.size = (osl.endPointX - osl.startPointX) * (osl.endPointY - osl.startPointY);
+        kl.response = osl.lineLength / std::max(images_sizes[osl.octaveCount].first, images_sizes[osl.octaveCount].second);
+        kl.pt_x = (osl.endPointX + osl.startPointX) / 2;
+        kl.pt_y = (osl.endPointY + osl.startPointY) / 2;
+        keylines.push_back(kl);
+      }
+  }
+
+  /* :1151-1488 for one line */
+  void computeLBD_one(const KeyLine& kl, uint8_t* out32) {
+    const short heightOfLSP = (short)(widthOfBand_ * NUM_OF_BANDS);
+    const short descriptor_size = NUM_OF_BANDS * 8;
+    float pgdLBandSum[NUM_OF_BANDS] = {0}, ngdLBandSum[NUM_OF_BANDS] = {0}, pgdL2BandSum[NUM_OF_BANDS] = {0},
+          ngdL2BandSum[NUM_OF_BANDS] = {0}, pgdOBandSum[NUM_OF_BANDS] = {0}, ngdOBandSum[NUM_OF_BANDS] = {0},
+          pgdO2BandSum[NUM_OF_BANDS] = {0}, ngdO2BandSum[NUM_OF_BANDS] = {0};
+    const short halfHeight = (heightOfLSP - 1) / 2;
+    const short octaveCount = (short)kl.octave;
+    const EDLineDetector& ed = edLineVec_[octaveCount];
+    const short* pdxImg = ed.dxImg_.data();
+    const short* pdyImg = ed.dyImg_.data();
+    const short realWidth = (short)ed.imageWidth;
+    const short imageWidth = realWidth - 1;
+    const short imageHeight = (short)(ed.imageHeight - 1);
+    const short lengthOfLSP = (short)kl.numOfPixels;
+    const short halfWidth = (lengthOfLSP - 1) / 2;
+    const float lineMiddlePointX = (float)(0.5 * (kl.sPointInOctaveX + kl.ePointInOctaveX));
+    const float lineMiddlePointY = (float)(0.5 * (kl.sPointInOctaveY + kl.ePointInOctaveY));
+    float dL[2], dO[2];
+    dL[0] = (float)cos((double)kl.angle);
+    dL[1] = (float)sin((double)kl.angle);
+    dO[0] = -dL[1];
+    dO[1] = dL[0];
+    float sCorX0 = -dL[0] * halfWidth + dL[1] * halfHeight + lineMiddlePointX;
+    float sCorY0 = -dL[1] * halfWidth - dL[0] * halfHeight + lineMiddlePointY;
+    for (short hID = 0; hID < heightOfLSP; hID++) {
+      float sCorX = sCorX0, sCorY = sCorY0;
+      float pgdLRowSum = 0, ngdLRowSum = 0, pgdORowSum = 0, ngdORowSum = 0;
+      for (short wID = 0; wID < lengthOfLSP; wID++) {
+        short tempCor = (short)round((double)sCorX);
+        const short xCor = (tempCor < 0) ? 0 : (tempCor > imageWidth) ? imageWidth : tempCor;
+        tempCor = (short)round((double)sCorY);
+        const short yCor = (tempCor < 0) ? 0 : (tempCor > imageHeight) ? imageHeight : tempCor;
+        const short dx = pdxImg[yCor * realWidth + xCor], dy = pdyImg[yCor * realWidth + xCor];
+        const float gDL = dx * dL[0] + dy * dL[1];
+        const float gDO = dx * dO[0] + dy * dO[1];
+        if (gDL > 0) pgdLRowSum += gDL; else ngdLRowSum -= gDL;
+        if (gDO > 0) pgdORowSum += gDO; else ngdORowSum -= gDO;
+        sCorX += dL[0];
+        sCorY += dL[1];
+      }
+      sCorX0 -= dL[1];
+      sCorY0 += dL[0];
+      float coefInGaussion = (float)gaussCoefG_[hID];
+      pgdLRowSum = coefInGaussion * pgdLRowSum;
+      ngdLRowSum = coefInGaussion * ngdLRowSum;
+      const float pgdL2RowSum = pgdLRowSum * pgdLRowSum, ngdL2RowSum = ngdLRowSum * ngdLRowSum;
+      pgdORowSum = coefInGaussion * pgdORowSum;
+      ngdORowSum = coefInGaussion * ngdORowSum;
+      const float pgdO2RowSum = pgdORowSum * pgdORowSum, ngdO2RowSum = ngdORowSum * ngdORowSum;
+      auto add = [&](short bandID, float c) {
+        pgdLBandSum[bandID] += c * pgdLRowSum;
+        ngdLBandSum[bandID] += c * ngdLRowSum;
+        pgdL2BandSum[bandID] += c * c * pgdL2RowSum;
+        ngdL2BandSum[bandID] += c * c * ngdL2RowSum;
+        pgdOBandSum[bandID] += c * pgdORowSum;
+        ngdOBandSum[bandID] += c * ngdORowSum;
+        pgdO2BandSum[bandID] += c * c * pgdO2RowSum;
+        ngdO2BandSum[bandID] += c * c * ngdO2RowSum;
+      };
+      short bandID = (short)(hID / widthOfBand_);
+      add(bandID, (float)(gaussCoefL_[hID % widthOfBand_ + widthOfBand_]));
+      bandID--;
+      if (bandID >= 0) add(bandID, (float)(gaussCoefL_[hID % widthOfBand_ + 2 * widthOfBand_]));
+      bandID = bandID + 2;
+      if (bandID < NUM_OF_BANDS) add(bandID, (float)(gaussCoefL_[hID % widthOfBand_]));
+    }
+    float desVec[NUM_OF_BANDS * 8];
+    const float invN2 = (float)(1.0 / (widthOfBand_ * 2.0));
+    const float invN3 = (float)(1.0 / (widthOfBand_ * 3.0));
+    float invN, temp;
+    for (short bandID = 0; bandID < NUM_OF_BANDS; bandID++) {
+      invN = (bandID == 0 || bandID == NUM_OF_BANDS - 1) ? invN2 : invN3;
+      const short desID = bandID * 8;
+      temp = pgdLBandSum[bandID] * invN;
+      desVec[desID] = temp;
+      desVec[desID + 4] = std::sqrt(pgdL2BandSum[bandID] * invN - temp * temp);
+      temp = ngdLBandSum[bandID] * invN;
+      desVec[desID + 1] = temp;
+      desVec[desID + 5] = std::sqrt(ngdL2BandSum[bandID] * invN - temp * temp);
+      temp = pgdOBandSum[bandID] * invN;
+      desVec[desID + 2] = temp;
+      desVec[desID + 6] = std::sqrt(pgdO2BandSum[bandID] * invN - temp * temp);
+      temp = ngdOBandSum[bandID] * invN;
+      desVec[desID + 3] = temp;
+      desVec[desID + 7] = std::sqrt(ngdO2BandSum[bandID] * invN - temp * temp);
+    }
+    float tempM = 0, tempS = 0;
+    for (int base = 0; base < NUM_OF_BANDS; ++base) {
+      const int i = base * 8;
+      tempM += desVec[i] * desVec[i];
+      tempM += desVec[i + 1] * desVec[i + 1];
+      tempM += desVec[i + 2] * desVec[i + 2];
+      tempM += desVec[i + 3] * desVec[i + 3];
+      tempS += desVec[i + 4] * desVec[i + 4];
+      tempS += desVec[i + 5] * desVec[i + 5];
+      tempS += desVec[i + 6] * desVec[i + 6];
+      tempS += desVec[i + 7] * desVec[i + 7];
+    }
+    tempM = 1 / std::sqrt(tempM);
+    tempS = 1 / std::sqrt(tempS);
+    for (int base = 0; base < NUM_OF_BANDS; ++base) {
+      const int i = base * 8;
+      for (int j = 0; j < 4; j++) desVec[i + j] = desVec[i + j] * tempM;
+      for (int j = 4; j < 8; j++) desVec[i + j] = desVec[i + j] * tempS;
+    }
+    for (short i = 0; i < descriptor_size; i++)
+      if (desVec[i] > 0.4) desVec[i] = (float)0.4;
+    temp = 0;
+    for (short i = 0; i < descriptor_size; i++) temp += desVec[i] * desVec[i];
+    temp = 1.f / std::sqrt(temp);
+    for (short i = 0; i < descriptor_size; i++) desVec[i] = desVec[i] * temp;
+    /* computeImpl :752-758 + binaryConversion :438-449 */
+    for (int comb = 0; comb < 32; comb++) {
+      const float* f1 = &desVec[8 * combinations[comb][0]];
+      const float* f2 = &desVec[8 * combinations[comb][1]];
+      uint8_t result = 0;
+      for (int i = 0; i < 8; i++)
+        if (f1[i] > f2[i]) result += (uint8_t)(1 << i);
+      out32[comb] = result;
+    }
+  }
+
+  /* LineExtractor::detectLineFeatures (src/LineExtractor.cc:199-289) */
+  void extract(const Image& img, std::vector<KeyLine>& lines, std::vector<uint8_t>& descriptors) {
+    detect(img, lines);
+    if ((int)lines.size() > nfeatures && nfeatures != 0) {
+      std::sort(lines.begin(), lines.end(), [](const KeyLine& a, const KeyLine& b) { return a.response > b.response; });
+      lines.resize(nfeatures);
+    }
+    const int kBorderThreshold = 5;
+    const int minX = kBorderThreshold, maxX = img.w - kBorderThreshold, minY = kBorderThreshold, maxY = img.h - kBorderThreshold;
+    lines.erase(std::remove_if(lines.begin(), lines.end(),
+                               [&](const KeyLine& l) {
+                                 return ((l.startPointX < minX) && (l.endPointX < minX)) ||
+                                        ((l.startPointX > maxX) && (l.endPointX > maxX)) ||
+                                        ((l.startPointY < minY) && (l.endPointY < minY)) ||
+                                        ((l.startPointY > maxY) && (l.endPointY > maxY));
+                               }),
+                lines.end());
+    bool bCutForMinLength = false;
+    int iCut = 0;
+    for (size_t i = 0, iEnd = lines.size(); i < iEnd; i++) {
+      lines[i].class_id = (int)i;
+      if (lines[i].response < min_length) {
+        iCut = (int)i;
+        bCutForMinLength = true;
+        break;
+      }
+    }
+    if (bCutForMinLength) {
+      if (iCut > 0) lines.resize(iCut);
+      else lines.clear();
+    }
+    descriptors.assign(lines.size() * 32, 0);
+    for (size_t i = 0; i < lines.size(); i++) computeLBD_one(lines[i], &descriptors[i * 32]);
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+void* oracle_lines_create(int nfeatures, int nlevels, float scale, double min_length, double fit_err) {
+  return new LineExtractorOracle(nfeatures, nlevels, scale, min_length, fit_err);
+}
+void oracle_lines_destroy(void* h) { delete (LineExtractorOracle*)h; }
+
+/* keylines: cap entries of 68 bytes (the KeyLine layout); desc: cap x 32.  Returns the line count. */
+int oracle_lines_extract(void* h, const uint8_t* img, int w, int hh, int stride, void* keylines,
+                         uint8_t* desc, int cap) {
+  LineExtractorOracle* e = (LineExtractorOracle*)h;
+  Image im(w, hh);
+  for (int y = 0; y < hh; y++) memcpy(im.row(y), img + (size_t)y * stride, w);
+  std::vector<KeyLine> lines;
+  std::vector<uint8_t> d;
+  e->extract(im, lines, d);
+  static_assert(sizeof(KeyLine) == 68, "KeyLine must be 68 bytes");
+  if ((int)lines.size() <= cap) {
+    if (!lines.empty()) memcpy(keylines, lines.data(), lines.size() * sizeof(KeyLine));
+    if (!d.empty()) memcpy(desc, d.data(), d.size());
+  }
+  return (int)lines.size();
+}
+
+/* stage accessors for the last extract */
+int oracle_lines_octave_size(void* h, int octave, int* w, int* hh) {
+  LineExtractorOracle* e = (LineExtractorOracle*)h;
+  *w = e->images_sizes[octave].first;
+  *hh = e->images_sizes[octave].second;
+  return 0;
+}
+/* which: 0 blurred image (u8), 1 dx, 2 dy, 3 gImg (s16), 4 dirImg (u8) */
+void oracle_lines_get_map(void* h, int octave, int which, void* out) {
+  LineExtractorOracle* e = (LineExtractorOracle*)h;
+  const EDLineDetector& ed = e->edLineVec_[octave];
+  switch (which) {
+    case 0: memcpy(out, e->octaveBlur[octave].d.data(), e->octaveBlur[octave].d.size()); break;
+    case 1: memcpy(out, ed.dxImg_.data(), ed.dxImg_.size() * 2); break;
+    case 2: memcpy(out, ed.dyImg_.data(), ed.dyImg_.size() * 2); break;
+    case 3: memcpy(out, ed.gImg_.data(), ed.gImg_.size() * 2); break;
+    case 4: memcpy(out, ed.dirImg_.data(), ed.dirImg_.size()); break;
+  }
+}
+int oracle_lines_num_in_octave(void* h, int octave) {
+  return (int)((LineExtractorOracle*)h)->edLineVec_[octave].lines_.numOfLines;
+}
+
+}  // extern "C"

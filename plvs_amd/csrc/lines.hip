@@ -1,0 +1,603 @@
+// Line front end: EDLines detection + LBD description as driven by
+// LineExtractor::operator() (src/LineExtractor.cc:150, 199-289; Line.LSD.on = 0,
+// Line.pyramidPrecomputation = 0).
+//
+// Split of the work (SURVEY.md §7 "hard parts"):
+//   device  lines_blur5        5x5 Gaussian, exact 8.8 fixed point, sigma per octave (:787-815)
+//           lines_sobel_grad   3x3 Sobel (s16) + |dx|+|dy| thresholded at 81, /4 with
+//                              round-half-even, direction bit (:1642-1654), packed u16
+//           lines_resize       cv::resize(fx = fy = 1/scale, INTER_LINEAR) (:840)
+//           lbd_kernel         one 64-lane wavefront per line: lane = one of the 63 rows of
+//                              the line support region, walked pixel by pixel with the
+//                              reference's float accumulators; 9 lanes then fold the
+//                              rows into the band statistics in row order; lane 0
+//                              normalises and emits the 256-bit descriptor (:1151-1488, :438-449)
+//   host    lines_host.hpp     anchor linking, line fitting / validation, octave grouping,
+//                              selection — order dependent, one thread per octave
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <thread>
+#include <vector>
+
+#include "common.hpp"
+#include "lines_host.hpp"
+
+using namespace plvs;
+using namespace plvs::lines;
+
+namespace {
+
+constexpr int kBands = 9, kBandWidth = 7, kRows = kBands * kBandWidth;  // 63
+constexpr int kMaxOctaves = 8;
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+  return p;
+}
+
+struct Q5 { int w[5]; };
+
+// exact 2-D fixed-point Gaussian: (sum_y w_y sum_x w_x p + 2^15) >> 16
+__global__ __launch_bounds__(256) void lines_blur5(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                   int w, int h, Q5 k) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  uint32_t acc = 0;
+#pragma unroll
+  for (int j = -2; j <= 2; ++j) {
+    const uint8_t* r = src + (size_t)reflect101(y + j, h) * w;
+    uint32_t rowv = 0;
+#pragma unroll
+    for (int i = -2; i <= 2; ++i) rowv += (uint32_t)k.w[i + 2] * r[reflect101(x + i, w)];
+    acc += (uint32_t)k.w[j + 2] * rowv;
+  }
+  dst[(size_t)y * w + x] = (uint8_t)((acc + (1u << 15)) >> 16);
+}
+
+__device__ __forceinline__ int round_half_even_quarter(int v) {
+  // cvRound(v * 0.25) for a non-negative integer v
+  const int q = v >> 2, r = v & 3;
+  return q + ((r > 2) || (r == 2 && (q & 1)));
+}
+
+__global__ __launch_bounds__(256) void lines_sobel_grad(const uint8_t* __restrict__ img, int w, int h,
+                                                        int16_t* __restrict__ dxo, int16_t* __restrict__ dyo,
+                                                        uint16_t* __restrict__ gd, int grad_threshold) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  const uint8_t* r0 = img + (size_t)reflect101(y - 1, h) * w;
+  const uint8_t* r1 = img + (size_t)y * w;
+  const uint8_t* r2 = img + (size_t)reflect101(y + 1, h) * w;
+  const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+  const int dx = (r0[xp] - r0[xm]) + 2 * (r1[xp] - r1[xm]) + (r2[xp] - r2[xm]);
+  const int dy = (r2[xm] + 2 * r2[x] + r2[xp]) - (r0[xm] + 2 * r0[x] + r0[xp]);
+  const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy;
+  const int sum = ax + ay;
+  const int g = round_half_even_quarter(sum > grad_threshold + 1 ? sum : 0);  // THRESH_TOZERO then / 4
+  const size_t i = (size_t)y * w + x;
+  dxo[i] = (int16_t)dx;
+  dyo[i] = (int16_t)dy;
+  gd[i] = (uint16_t)(g | (ax < ay ? 0x8000 : 0));
+}
+
+__global__ __launch_bounds__(256) void lines_resize(const uint8_t* __restrict__ src, int sw,
+                                                    uint8_t* __restrict__ dst, int dw, int dh,
+                                                    const int* __restrict__ xofs, const short* __restrict__ alpha,
+                                                    const int* __restrict__ yofs, const short* __restrict__ beta) {
+  const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (dx >= dw || dy >= dh) return;
+  const int sx0 = xofs[2 * dx], sx1 = xofs[2 * dx + 1], a0 = alpha[2 * dx], a1 = alpha[2 * dx + 1];
+  const int sy0 = yofs[2 * dy], sy1 = yofs[2 * dy + 1], b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
+  const uint8_t* r0 = src + (size_t)sy0 * sw;
+  const uint8_t* r1 = src + (size_t)sy1 * sw;
+  const int h0 = r0[sx0] * a0 + r0[sx1] * a1, h1 = r1[sx0] * a0 + r1[sx1] * a1;
+  const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+  dst[(size_t)dy * dw + dx] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+}
+
+struct LbdLine {   // per selected line, prepared on the host
+  int octave, num_pixels;
+  float dL0, dL1;          // (float)cos / sin of the line direction (double libm on the host)
+  float s0x, s0y;          // sCorX0 / sCorY0 of row 0
+};
+
+struct LbdOctave {
+  const int16_t* dx;
+  const int16_t* dy;
+  int w, h;
+};
+
+struct LbdTables {
+  float g[kRows];          // (float)gaussCoefG_[hID]
+  float l[3 * kBandWidth]; // (float)gaussCoefL_[i]
+  LbdOctave oct[kMaxOctaves];
+};
+
+__constant__ int c_comb[32][2] = {
+    {0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {0, 6}, {1, 2}, {1, 3}, {1, 4}, {1, 5}, {1, 6},
+    {2, 3}, {2, 4}, {2, 5}, {2, 6}, {2, 7}, {2, 8}, {3, 4}, {3, 5}, {3, 6}, {3, 7}, {3, 8},
+    {4, 5}, {4, 6}, {4, 7}, {4, 8}, {5, 6}, {5, 7}, {5, 8}, {6, 7}, {6, 8}, {7, 8}};
+
+__global__ __launch_bounds__(64) void lbd_kernel(const LbdLine* __restrict__ lines, LbdTables T,
+                                                 uint8_t* __restrict__ desc) {
+  __shared__ float rows[kRows][8];   // per row: pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2
+  __shared__ float band[kBands][8];
+  const LbdLine L = lines[blockIdx.x];
+  const LbdOctave O = T.oct[L.octave];
+  const int hID = threadIdx.x;
+  if (hID < kRows) {
+    const float dL0 = L.dL0, dL1 = L.dL1, dO0 = -L.dL1, dO1 = L.dL0;
+    // row start: sCorX0 -= dL[1], sCorY0 += dL[0] once per preceding row (sequential f32)
+    float sx0 = L.s0x, sy0 = L.s0y;
+    for (int r = 0; r < hID; ++r) { sx0 -= dL1; sy0 += dL0; }
+    float sx = sx0, sy = sy0;
+    float pL = 0, nL = 0, pO = 0, nO = 0;
+    const short maxx = (short)(O.w - 1), maxy = (short)(O.h - 1);
+    for (int wID = 0; wID < L.num_pixels; ++wID) {
+      short t = (short)roundf(sx);
+      const short xc = (t < 0) ? (short)0 : (t > maxx) ? maxx : t;
+      t = (short)roundf(sy);
+      const short yc = (t < 0) ? (short)0 : (t > maxy) ? maxy : t;
+      const short dx = O.dx[yc * O.w + xc], dy = O.dy[yc * O.w + xc];
+      const float gDL = dx * dL0 + dy * dL1;
+      const float gDO = dx * dO0 + dy * dO1;
+      if (gDL > 0) pL += gDL; else nL -= gDL;
+      if (gDO > 0) pO += gDO; else nO -= gDO;
+      sx += dL0;
+      sy += dL1;
+    }
+    const float cg = T.g[hID];
+    pL = cg * pL; nL = cg * nL; pO = cg * pO; nO = cg * nO;
+    rows[hID][0] = pL; rows[hID][1] = nL; rows[hID][2] = pL * pL; rows[hID][3] = nL * nL;
+    rows[hID][4] = pO; rows[hID][5] = nO; rows[hID][6] = pO * pO; rows[hID][7] = nO * nO;
+  }
+  __syncthreads();
+  if (threadIdx.x < kBands) {
+    // band b receives, in row order: rows of band b-1 (weight l[r%7]), of band b
+    // (l[r%7 + 7]) and of band b+1 (l[r%7 + 14])
+    const int b = threadIdx.x;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = 0; r < kRows; ++r) {
+      const int rb = r / kBandWidth;
+      float c;
+      if (rb == b - 1) c = T.l[r % kBandWidth];
+      else if (rb == b) c = T.l[r % kBandWidth + kBandWidth];
+      else if (rb == b + 1) c = T.l[r % kBandWidth + 2 * kBandWidth];
+      else continue;
+      acc[0] += c * rows[r][0];
+      acc[1] += c * rows[r][1];
+      acc[2] += c * c * rows[r][2];
+      acc[3] += c * c * rows[r][3];
+      acc[4] += c * rows[r][4];
+      acc[5] += c * rows[r][5];
+      acc[6] += c * c * rows[r][6];
+      acc[7] += c * c * rows[r][7];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) band[b][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float d[kBands * 8];
+    const float invN2 = (float)(1.0 / (kBandWidth * 2.0)), invN3 = (float)(1.0 / (kBandWidth * 3.0));
+    for (int b = 0; b < kBands; ++b) {
+      const float invN = (b == 0 || b == kBands - 1) ? invN2 : invN3;
+      float t = band[b][0] * invN;
+      d[b * 8 + 0] = t; d[b * 8 + 4] = sqrtf(band[b][2] * invN - t * t);
+      t = band[b][1] * invN;
+      d[b * 8 + 1] = t; d[b * 8 + 5] = sqrtf(band[b][3] * invN - t * t);
+      t = band[b][4] * invN;
+      d[b * 8 + 2] = t; d[b * 8 + 6] = sqrtf(band[b][6] * invN - t * t);
+      t = band[b][5] * invN;
+      d[b * 8 + 3] = t; d[b * 8 + 7] = sqrtf(band[b][7] * invN - t * t);
+    }
+    float tM = 0, tS = 0;
+    for (int b = 0; b < kBands; ++b) {
+      const float* p = &d[b * 8];
+      tM += p[0] * p[0]; tM += p[1] * p[1]; tM += p[2] * p[2]; tM += p[3] * p[3];
+      tS += p[4] * p[4]; tS += p[5] * p[5]; tS += p[6] * p[6]; tS += p[7] * p[7];
+    }
+    tM = 1 / sqrtf(tM);
+    tS = 1 / sqrtf(tS);
+    for (int b = 0; b < kBands; ++b)
+      for (int k = 0; k < 8; ++k) d[b * 8 + k] = d[b * 8 + k] * (k < 4 ? tM : tS);
+    for (int i = 0; i < kBands * 8; ++i)
+      if ((double)d[i] > 0.4) d[i] = (float)0.4;
+    float t = 0;
+    for (int i = 0; i < kBands * 8; ++i) t += d[i] * d[i];
+    t = 1.f / sqrtf(t);
+    for (int i = 0; i < kBands * 8; ++i) d[i] = d[i] * t;
+    uint8_t* out = desc + (size_t)blockIdx.x * 32;
+    for (int c = 0; c < 32; ++c) {
+      const float* f1 = &d[8 * c_comb[c][0]];
+      const float* f2 = &d[8 * c_comb[c][1]];
+      unsigned v = 0;
+      for (int i = 0; i < 8; ++i)
+        if (f1[i] > f2[i]) v += 1u << i;
+      out[c] = (uint8_t)v;
+    }
+  }
+}
+
+inline int cvr(double v) { return (int)lrint(v); }
+inline int cvrf(float v) { return (int)lrintf(v); }
+inline int cvfloor(double v) { int i = (int)v; return i - (i > v); }
+
+// getGaussianKernel bit-exact fixed point, 8 fractional bits (smooth.dispatch.cpp)
+Q5 gaussian_q8_5(double sigma) {
+  double k[5], sum = 0;
+  const double s2 = -0.5 / (sigma * sigma);
+  for (int i = 0; i < 5; ++i) { const double x = i - 2.0; k[i] = std::exp(s2 * x * x); sum += k[i]; }
+  for (int i = 0; i < 5; ++i) k[i] /= sum;
+  Q5 q;
+  double err = 0;
+  long long s = 0;
+  for (int i = 0; i < 2; ++i) {
+    const double adj = k[i] * 256.0 + err;
+    const long long v0 = (long long)lrint(adj);
+    err = adj - (double)v0;
+    q.w[i] = q.w[4 - i] = (int)v0;
+    s += v0;
+  }
+  q.w[2] = (int)(256 - 2 * s);
+  return q;
+}
+
+// cv::resize tap tables with an explicit inverse scale (fx = fy given, dsize empty)
+void resize_taps_factor(int ssize, int dsize, double inv_scale, std::vector<int>& ofs, std::vector<short>& coef, bool is_x) {
+  const double scale = 1. / inv_scale;
+  ofs.resize(2 * dsize);
+  coef.resize(2 * dsize);
+  for (int d = 0; d < dsize; ++d) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = cvfloor(f);
+    f -= s;
+    int s0, s1;
+    if (is_x) {
+      if (s < 0) { f = 0; s = 0; }
+      if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+      s0 = s;
+      s1 = s + 1 < ssize ? s + 1 : ssize - 1;
+    } else {
+      s0 = s < 0 ? 0 : (s >= ssize ? ssize - 1 : s);
+      s1 = s + 1 < 0 ? 0 : (s + 1 >= ssize ? ssize - 1 : s + 1);
+    }
+    ofs[2 * d] = s0;
+    ofs[2 * d + 1] = s1;
+    auto sat = [](int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); };
+    coef[2 * d] = sat(cvrf((1.f - f) * 2048));
+    coef[2 * d + 1] = sat(cvrf(f * 2048));
+  }
+}
+
+double now_ms() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+}  // namespace
+
+struct plvs_lines {
+  int nfeatures, nlevels;
+  float scale;
+  double min_length;
+  EdParams ed;
+  float gaussG[kRows], gaussL[3 * kBandWidth];
+  // geometry of the current image size
+  int img_w = 0, img_h = 0;
+  std::vector<std::pair<int, int>> sizes;      // (w, h) per octave
+  std::vector<Q5> kernels;
+  std::vector<uint8_t*> d_img, d_blur;         // octave input / blurred
+  std::vector<int16_t*> d_dx, d_dy;
+  std::vector<uint16_t*> d_gd;
+  std::vector<int*> d_xofs, d_yofs;
+  std::vector<short*> d_alpha, d_beta;
+  std::vector<int16_t*> h_dx, h_dy;            // pinned
+  std::vector<uint16_t*> h_gd;
+  uint8_t* h_img = nullptr;
+  LbdLine* d_lines = nullptr;
+  LbdLine* h_lines = nullptr;
+  uint8_t* d_desc = nullptr;
+  uint8_t* h_desc = nullptr;
+  int line_cap = 0;
+  hipStream_t stream = nullptr;
+  std::vector<OctaveDetector> det;
+  double last_ms[4] = {};
+};
+
+namespace {
+
+void lines_free_geometry(plvs_lines* o) {
+  for (auto p : o->d_img) (void)hipFree(p);
+  for (auto p : o->d_blur) (void)hipFree(p);
+  for (auto p : o->d_dx) (void)hipFree(p);
+  for (auto p : o->d_dy) (void)hipFree(p);
+  for (auto p : o->d_gd) (void)hipFree(p);
+  for (auto p : o->d_xofs) (void)hipFree(p);
+  for (auto p : o->d_yofs) (void)hipFree(p);
+  for (auto p : o->d_alpha) (void)hipFree(p);
+  for (auto p : o->d_beta) (void)hipFree(p);
+  for (auto p : o->h_dx) if (p) (void)hipHostFree(p);
+  for (auto p : o->h_dy) if (p) (void)hipHostFree(p);
+  for (auto p : o->h_gd) if (p) (void)hipHostFree(p);
+  if (o->h_img) (void)hipHostFree(o->h_img);
+  o->d_img.clear(); o->d_blur.clear(); o->d_dx.clear(); o->d_dy.clear(); o->d_gd.clear();
+  o->d_xofs.clear(); o->d_yofs.clear(); o->d_alpha.clear(); o->d_beta.clear();
+  o->h_dx.clear(); o->h_dy.clear(); o->h_gd.clear();
+  o->h_img = nullptr;
+  o->img_w = o->img_h = 0;
+}
+
+int lines_build_geometry(plvs_lines* o, int w, int h) {
+  lines_free_geometry(o);
+  const int n = o->nlevels;
+  o->sizes.assign(n, {0, 0});
+  o->kernels.resize(n);
+  o->d_img.assign(n, nullptr); o->d_blur.assign(n, nullptr); o->d_dx.assign(n, nullptr);
+  o->d_dy.assign(n, nullptr); o->d_gd.assign(n, nullptr);
+  o->d_xofs.assign(n, nullptr); o->d_yofs.assign(n, nullptr); o->d_alpha.assign(n, nullptr); o->d_beta.assign(n, nullptr);
+  o->h_dx.assign(n, nullptr); o->h_dy.assign(n, nullptr); o->h_gd.assign(n, nullptr);
+  // OctaveKeyLines :785-846: sigma schedule and octave sizes
+  float preSigma2 = (float)std::pow(0.5, 2);
+  float curSigma2 = (float)std::pow(1.0f, 2);
+  const double factor = o->scale, factor2 = factor * factor;
+  const double inv = (1.f / factor);
+  int cw = w, ch = h;
+  for (int i = 0; i < n; ++i) {
+    if (cw < 8 || ch < 8) {
+      plvs::set_error("lines: octave %d of a %dx%d image is too small", i, w, h);
+      return PLVS_ERR_INVALID_ARG;
+    }
+    o->sizes[i] = {cw, ch};
+    const float increaseSigma = std::sqrt(curSigma2 - preSigma2);
+    o->kernels[i] = gaussian_q8_5(increaseSigma);
+    const size_t px = (size_t)cw * ch;
+    PLVS_HIP_TRY(hipMalloc((void**)&o->d_img[i], px));
+    PLVS_HIP_TRY(hipMalloc((void**)&o->d_blur[i], px));
+    PLVS_HIP_TRY(hipMalloc((void**)&o->d_dx[i], px * 2));
+    PLVS_HIP_TRY(hipMalloc((void**)&o->d_dy[i], px * 2));
+    PLVS_HIP_TRY(hipMalloc((void**)&o->d_gd[i], px * 2));
+    PLVS_HIP_TRY(hipHostMalloc((void**)&o->h_dx[i], px * 2));
+    PLVS_HIP_TRY(hipHostMalloc((void**)&o->h_dy[i], px * 2));
+    PLVS_HIP_TRY(hipHostMalloc((void**)&o->h_gd[i], px * 2));
+    const int nw = cvr(cw * inv), nh = cvr(ch * inv);   // dsize = saturate_cast<int>(ssize * f)
+    if (i + 1 < n) {
+      std::vector<int> xo, yo;
+      std::vector<short> al, be;
+      resize_taps_factor(cw, nw, inv, xo, al, true);
+      resize_taps_factor(ch, nh, inv, yo, be, false);
+      PLVS_HIP_TRY(hipMalloc((void**)&o->d_xofs[i], xo.size() * sizeof(int)));
+      PLVS_HIP_TRY(hipMalloc((void**)&o->d_yofs[i], yo.size() * sizeof(int)));
+      PLVS_HIP_TRY(hipMalloc((void**)&o->d_alpha[i], al.size() * sizeof(short)));
+      PLVS_HIP_TRY(hipMalloc((void**)&o->d_beta[i], be.size() * sizeof(short)));
+      PLVS_HIP_TRY(hipMemcpy(o->d_xofs[i], xo.data(), xo.size() * sizeof(int), hipMemcpyHostToDevice));
+      PLVS_HIP_TRY(hipMemcpy(o->d_yofs[i], yo.data(), yo.size() * sizeof(int), hipMemcpyHostToDevice));
+      PLVS_HIP_TRY(hipMemcpy(o->d_alpha[i], al.data(), al.size() * sizeof(short), hipMemcpyHostToDevice));
+      PLVS_HIP_TRY(hipMemcpy(o->d_beta[i], be.data(), be.size() * sizeof(short), hipMemcpyHostToDevice));
+    }
+    cw = nw; ch = nh;
+    preSigma2 = curSigma2;
+    curSigma2 = (float)(curSigma2 * factor2);
+  }
+  PLVS_HIP_TRY(hipHostMalloc((void**)&o->h_img, (size_t)w * h));
+  o->img_w = w;
+  o->img_h = h;
+  return PLVS_OK;
+}
+
+int lines_extract_body(plvs_lines* o, plvs_keyline* keylines, uint8_t* desc, int cap, int* n_out) {
+  hipStream_t s = o->stream;
+  const int n = o->nlevels;
+  const double t0 = now_ms();
+  for (int i = 0; i < n; ++i) {
+    const int w = o->sizes[i].first, h = o->sizes[i].second;
+    const dim3 grid((w + 63) / 64, (h + 3) / 4), block(256);
+    hipLaunchKernelGGL(lines_blur5, grid, block, 0, s, o->d_img[i], o->d_blur[i], w, h, o->kernels[i]);
+    hipLaunchKernelGGL(lines_sobel_grad, grid, block, 0, s, o->d_blur[i], w, h, o->d_dx[i], o->d_dy[i],
+                       o->d_gd[i], 80);
+    const size_t px = (size_t)w * h;
+    PLVS_HIP_TRY(hipMemcpyAsync(o->h_gd[i], o->d_gd[i], px * 2, hipMemcpyDeviceToHost, s));
+    PLVS_HIP_TRY(hipMemcpyAsync(o->h_dx[i], o->d_dx[i], px * 2, hipMemcpyDeviceToHost, s));
+    PLVS_HIP_TRY(hipMemcpyAsync(o->h_dy[i], o->d_dy[i], px * 2, hipMemcpyDeviceToHost, s));
+    if (i + 1 < n) {
+      const int nw = o->sizes[i + 1].first, nh = o->sizes[i + 1].second;
+      hipLaunchKernelGGL(lines_resize, dim3((nw + 63) / 64, (nh + 3) / 4), block, 0, s, o->d_blur[i], w,
+                         o->d_img[i + 1], nw, nh, o->d_xofs[i], o->d_alpha[i], o->d_yofs[i], o->d_beta[i]);
+    }
+  }
+  PLVS_KERNEL_CHECK();
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  const double t1 = now_ms();
+  // ---- host: one thread per octave
+  o->det.resize(n);
+  std::vector<char> ok(n, 0);
+  {
+    auto work = [&](int i) {
+      OctaveMaps m;
+      m.w = o->sizes[i].first; m.h = o->sizes[i].second;
+      m.gd = o->h_gd[i]; m.dx = o->h_dx[i]; m.dy = o->h_dy[i];
+      ok[i] = o->det[i].run(m, o->ed) ? 1 : 0;
+      if (!ok[i]) o->det[i].segments.clear();   // "failure: lines extraction on octave i": no lines from it
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < n; ++i) th.emplace_back(work, i);
+    work(0);
+    for (auto& t : th) t.join();
+  }
+  std::vector<KeyLine> kl = group_and_flatten(o->det, o->sizes, o->scale);
+  select_lines(kl, o->nfeatures, o->img_w, o->img_h, o->min_length);
+  const double t2 = now_ms();
+  const int nl = (int)kl.size();
+  *n_out = nl;
+  if (nl == 0) {
+    // "LineExtractor::detectLineFeatures() - no lines!" : empty outputs
+    return PLVS_OK;
+  }
+  if (nl > o->line_cap) {
+    plvs::set_error("lines: %d lines exceed the internal capacity %d", nl, o->line_cap);
+    return PLVS_ERR_CAPACITY;
+  }
+  // ---- LBD on the device
+  const short halfHeight = (kRows - 1) / 2;
+  for (int i = 0; i < nl; ++i) {
+    const KeyLine& k = kl[i];
+    LbdLine& L = o->h_lines[i];
+    L.octave = k.octave;
+    L.num_pixels = (short)k.numOfPixels;
+    const short halfWidth = (short)(((short)k.numOfPixels - 1) / 2);
+    const float midx = (float)(0.5 * (k.sPointInOctaveX + k.ePointInOctaveX));
+    const float midy = (float)(0.5 * (k.sPointInOctaveY + k.ePointInOctaveY));
+    L.dL0 = (float)cos((double)k.angle);
+    L.dL1 = (float)sin((double)k.angle);
+    L.s0x = -L.dL0 * halfWidth + L.dL1 * halfHeight + midx;
+    L.s0y = -L.dL1 * halfWidth - L.dL0 * halfHeight + midy;
+  }
+  LbdTables T;
+  for (int i = 0; i < kRows; ++i) T.g[i] = o->gaussG[i];
+  for (int i = 0; i < 3 * kBandWidth; ++i) T.l[i] = o->gaussL[i];
+  for (int i = 0; i < kMaxOctaves; ++i) T.oct[i] = LbdOctave{nullptr, nullptr, 0, 0};
+  for (int i = 0; i < n; ++i) T.oct[i] = LbdOctave{o->d_dx[i], o->d_dy[i], o->sizes[i].first, o->sizes[i].second};
+  PLVS_HIP_TRY(hipMemcpyAsync(o->d_lines, o->h_lines, sizeof(LbdLine) * nl, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(lbd_kernel, dim3(nl), dim3(64), 0, s, o->d_lines, T, o->d_desc);
+  PLVS_KERNEL_CHECK();
+  PLVS_HIP_TRY(hipMemcpyAsync(o->h_desc, o->d_desc, (size_t)32 * nl, hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  if (nl <= cap) {
+    static_assert(sizeof(KeyLine) == sizeof(plvs_keyline), "KeyLine layout");
+    memcpy(keylines, kl.data(), sizeof(KeyLine) * nl);
+    memcpy(desc, o->h_desc, (size_t)32 * nl);
+  }
+  const double t3 = now_ms();
+  o->last_ms[0] = t1 - t0;   // device maps + D2H
+  o->last_ms[1] = t2 - t1;   // host linking / fitting / grouping
+  o->last_ms[2] = t3 - t2;   // LBD
+  return PLVS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int plvs_hip_lines_create(int nfeatures, int nlevels, float scale_factor, double min_line_length,
+                          double line_fit_err_threshold, plvs_lines** out) {
+  PLVS_REQUIRE(out, "null output");
+  PLVS_REQUIRE(nfeatures >= 0 && nlevels >= 1 && nlevels <= kMaxOctaves && scale_factor > 1.0f,
+               "bad line extractor parameters");
+  plvs_lines* o = new plvs_lines();
+  o->nfeatures = nfeatures;
+  o->nlevels = nlevels;
+  o->scale = scale_factor;
+  o->min_length = min_line_length;
+  o->ed.fit_err_threshold = line_fit_err_threshold;
+  // BinaryDescriptor ctor :248-274 (note the integer divisions)
+  {
+    double u = (kBandWidth * 3 - 1) / 2;
+    double sigma = (kBandWidth * 2 + 1) / 2;
+    double inv = -1 / (2 * sigma * sigma);
+    for (int i = 0; i < kBandWidth * 3; ++i) { const double d = i - u; o->gaussL[i] = (float)exp(d * d * inv); }
+    u = (kBands * kBandWidth - 1) / 2;
+    sigma = u;
+    inv = -1 / (2 * sigma * sigma);
+    for (int i = 0; i < kRows; ++i) { const double d = i - u; o->gaussG[i] = (float)exp(d * d * inv); }
+  }
+  o->line_cap = 4096;
+#define LN_TRY(call)                                                       \
+  do {                                                                     \
+    hipError_t _e = (call);                                                \
+    if (_e != hipSuccess) {                                                \
+      plvs::set_error("%s failed: %s", #call, hipGetErrorString(_e));     \
+      plvs_hip_lines_destroy(o);                                           \
+      return PLVS_ERR_HIP;                                                 \
+    }                                                                      \
+  } while (0)
+  LN_TRY(hipStreamCreate(&o->stream));
+  LN_TRY(hipMalloc((void**)&o->d_lines, sizeof(LbdLine) * o->line_cap));
+  LN_TRY(hipHostMalloc((void**)&o->h_lines, sizeof(LbdLine) * o->line_cap));
+  LN_TRY(hipMalloc((void**)&o->d_desc, (size_t)32 * o->line_cap));
+  LN_TRY(hipHostMalloc((void**)&o->h_desc, (size_t)32 * o->line_cap));
+#undef LN_TRY
+  *out = o;
+  return PLVS_OK;
+}
+
+int plvs_hip_lines_destroy(plvs_lines* o) {
+  if (!o) return PLVS_OK;
+  lines_free_geometry(o);
+  (void)hipFree(o->d_lines);
+  (void)hipFree(o->d_desc);
+  if (o->h_lines) (void)hipHostFree(o->h_lines);
+  if (o->h_desc) (void)hipHostFree(o->h_desc);
+  if (o->stream) (void)hipStreamDestroy(o->stream);
+  delete o;
+  return PLVS_OK;
+}
+
+int plvs_hip_lines_extract(plvs_lines* o, const uint8_t* image, int w, int h, int stride,
+                           plvs_keyline* keylines, uint8_t* desc, int cap, int* n) {
+  PLVS_REQUIRE(o && n, "null argument");
+  *n = 0;
+  if (!image || w <= 0 || h <= 0) {
+    plvs::set_error("lines: empty image");
+    return PLVS_ERR_EMPTY;
+  }
+  PLVS_REQUIRE(stride >= w, "stride smaller than width");
+  PLVS_REQUIRE(w < 32768 && h < 32768, "image too large");
+  if (w != o->img_w || h != o->img_h) {
+    int rc = lines_build_geometry(o, w, h);
+    if (rc != PLVS_OK) return rc;
+  }
+  for (int y = 0; y < h; ++y) memcpy(o->h_img + (size_t)y * w, image + (size_t)y * stride, w);
+  PLVS_HIP_TRY(hipMemcpyAsync(o->d_img[0], o->h_img, (size_t)w * h, hipMemcpyHostToDevice, o->stream));
+  return lines_extract_body(o, keylines, desc, cap, n);
+}
+
+int plvs_hip_lines_extract_dev(plvs_lines* o, const uint8_t* d_image, int w, int h, int stride,
+                               plvs_keyline* keylines, uint8_t* desc, int cap, int* n) {
+  PLVS_REQUIRE(o && n, "null argument");
+  *n = 0;
+  if (!d_image || w <= 0 || h <= 0) {
+    plvs::set_error("lines: empty image");
+    return PLVS_ERR_EMPTY;
+  }
+  PLVS_REQUIRE(stride >= w, "stride smaller than width");
+  PLVS_REQUIRE(w < 32768 && h < 32768, "image too large");
+  if (w != o->img_w || h != o->img_h) {
+    int rc = lines_build_geometry(o, w, h);
+    if (rc != PLVS_OK) return rc;
+  }
+  PLVS_HIP_TRY(hipMemcpy2DAsync(o->d_img[0], w, d_image, stride, w, h, hipMemcpyDeviceToDevice, o->stream));
+  return lines_extract_body(o, keylines, desc, cap, n);
+}
+
+int plvs_hip_lines_last_stage_ms(plvs_lines* o, double* ms, int cap) {
+  PLVS_REQUIRE(o && ms, "null argument");
+  for (int i = 0; i < 3 && i < cap; ++i) ms[i] = o->last_ms[i];
+  return PLVS_OK;
+}
+
+// Parity accessors: which = 0 blurred octave image (u8), 1 dx, 2 dy (s16), 3 packed
+// gradient/direction map (u16), of the last call.
+int plvs_hip_lines_octave_size(plvs_lines* o, int octave, int* w, int* h) {
+  PLVS_REQUIRE(o && w && h && octave >= 0 && octave < o->nlevels && o->img_w > 0, "bad argument");
+  *w = o->sizes[octave].first;
+  *h = o->sizes[octave].second;
+  return PLVS_OK;
+}
+int plvs_hip_lines_download_map(plvs_lines* o, int octave, int which, void* out) {
+  PLVS_REQUIRE(o && out && octave >= 0 && octave < o->nlevels && o->img_w > 0, "bad argument");
+  const size_t px = (size_t)o->sizes[octave].first * o->sizes[octave].second;
+  const void* src = which == 0 ? (const void*)o->d_blur[octave]
+                    : which == 1 ? (const void*)o->d_dx[octave]
+                    : which == 2 ? (const void*)o->d_dy[octave] : (const void*)o->d_gd[octave];
+  PLVS_HIP_TRY(hipMemcpy(out, src, which == 0 ? px : px * 2, hipMemcpyDeviceToHost));
+  return PLVS_OK;
+}
+int plvs_hip_lines_num_in_octave(plvs_lines* o, int octave) {
+  if (!o || octave < 0 || octave >= (int)o->det.size()) return 0;
+  return (int)o->det[octave].segments.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,490 @@
+// Host-side (sequential, order-dependent) stages of the EDLines detector.
+//
+// EdgeDrawing's smart routing (binary_descriptor_custom.cpp:1698-2349) consumes
+// anchors in scan order and marks pixels as it walks, the incremental
+// least-squares line fit (:2409-2654, :2656-2815) extends segments pixel by
+// pixel with float accumulators, and the Helmholtz validation (:2817-2898, nfa
+// descriptor_custom.hpp:763-845) closes each segment: none of it is data
+// parallel, all of it is cheap.  The device produces the per-pixel maps
+// (blur, Sobel, gradient magnitude / direction); this header turns them into
+// line segments, octave by octave (one host thread per octave), then groups
+// the segments across octaves (:903-1149) and flattens them to KeyLines (:504-555).
+#pragma once
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <utility>
+#include <vector>
+
+namespace plvs {
+namespace lines {
+
+// ---------------------------------------------------------------- NFA
+inline bool nearly_equal(double a, double b) {
+  if (a == b) return true;
+  const double diff = fabs(a - b), aa = fabs(a), bb = fabs(b);
+  double m = aa > bb ? aa : bb;
+  if (m < DBL_MIN) m = DBL_MIN;
+  return (diff / m) <= (100.0 * DBL_EPSILON);
+}
+inline double lgamma_lanczos(double x) {
+  static const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705,
+                              1168.92649479, 83.8676043424, 2.50662827511};
+  double a = (x + 0.5) * log(x + 5.5) - (x + 5.5), b = 0.0;
+  for (int n = 0; n < 7; ++n) {
+    a -= log(x + (double)n);
+    b += q[n] * pow(x, (double)n);
+  }
+  return a + log(b);
+}
+inline double lgamma_windschitl(double x) {
+  return 0.918938533204673 + (x - 0.5) * log(x) - x +
+         0.5 * x * log(x * std::sinh(1 / x) + 1 / (810.0 * pow(x, 6.0)));
+}
+inline double lgamma_any(double x) { return x > 15.0 ? lgamma_windschitl(x) : lgamma_lanczos(x); }
+
+// -log10(NFA) of k aligned points among n, p = 1/8
+inline double nfa(int n, int k, double p, double logNT) {
+  if (n == 0 || k == 0) return -logNT;
+  if (n == k) return -logNT - (double)n * log10(p);
+  const double p_term = p / (1.0 - p);
+  const double log1term = lgamma_any((double)n + 1.0) - lgamma_any((double)k + 1.0) -
+                          lgamma_any((double)(n - k) + 1.0) + (double)k * log(p) +
+                          (double)(n - k) * log(1.0 - p);
+  double term = exp(log1term);
+  if (nearly_equal(term, 0.0)) {
+    if ((double)k > (double)n * p) return -log1term / 2.30258509299404568402 - logNT;
+    return -logNT;
+  }
+  double tail = term;
+  for (int i = k + 1; i <= n; ++i) {
+    const double bin_term = (double)(n - i + 1) / (double)i;
+    const double mult_term = bin_term * p_term;
+    term *= mult_term;
+    tail += term;
+    if (bin_term < 1.0) {
+      const double err = term * ((1.0 - pow(mult_term, (double)(n - i + 1))) / (1.0 - mult_term) - 1.0);
+      if (err < 0.1 * fabs(-log10(tail) - logNT) * tail) break;
+    }
+  }
+  return -log10(tail) - logNT;
+}
+
+// ------------------------------------------------------------ per octave
+struct Segment {              // one validated line segment of an octave
+  double eq[3];               // w1 x + w2 y + w3 = 0, w1^2 + w2^2 = 1
+  float ep[4];                // endpoints (x0, y0, x1, y1)
+  float direction;
+  int num_pixels;
+};
+
+struct OctaveMaps {           // what the device hands over for one octave
+  int w = 0, h = 0;
+  const uint16_t* gd = nullptr;   // bits 0..8: gradient magnitude / 4 (0 below threshold), bit 15: |dx| < |dy|
+  const int16_t* dx = nullptr;    // Sobel derivatives (for the validation)
+  const int16_t* dy = nullptr;
+};
+
+struct EdParams {
+  int anchor_threshold = 8, scan_interval = 2, min_line_len = 15;
+  double fit_err_threshold = 1.6;
+};
+
+class OctaveDetector {
+ public:
+  std::vector<Segment> segments;
+
+  // returns false on the reference's failure paths ("lines not found", buffer overrun)
+  bool run(const OctaveMaps& m, const EdParams& prm) {
+    segments.clear();
+    W = m.w; H = m.h; maps = m; P = prm;
+    return draw_edges() && fit_lines();
+  }
+
+ private:
+  int W = 0, H = 0;
+  OctaveMaps maps;
+  EdParams P;
+  std::vector<uint16_t> cx, cy;       // edge chains, pixel by pixel
+  std::vector<uint32_t> cstart;       // chain c = [cstart[c], cstart[c+1])
+  float ata[4] = {0, 0, 0, 0}, atv[2] = {0, 0};
+  double logNT = 0;
+
+  int g(int idx) const { return maps.gd[idx] & 0x1ff; }
+  bool horizontal(int idx) const { return (maps.gd[idx] & 0x8000u) != 0; }
+
+  // ---- EdgeDrawing: anchors (column-major scan) + smart routing
+  bool draw_edges() {
+    const size_t npix = (size_t)W * H;
+    const size_t cap = npix / 5, max_edges = cap / 20;
+    std::vector<uint16_t> ax, ay;
+    for (int x = 1; x < W - 1; x += P.scan_interval)
+      for (int y = 1; y < H - 1; y += P.scan_interval) {
+        const int i = y * W + x, gi = g(i);
+        const bool a = horizontal(i) ? (gi >= g(i - W) + P.anchor_threshold && gi >= g(i + W) + P.anchor_threshold)
+                                     : (gi >= g(i - 1) + P.anchor_threshold && gi >= g(i + 1) + P.anchor_threshold);
+        if (a) {
+          if (ax.size() >= cap) return false;
+          ax.push_back((uint16_t)x);
+          ay.push_back((uint16_t)y);
+        }
+      }
+    std::vector<uint8_t> used(npix, 0);
+    // the two halves of every edge, as the reference stores them
+    std::vector<uint16_t> fx, fy, sx, sy;
+    std::vector<uint32_t> fstart, sstart;
+    enum { kUp = 1, kRight = 2, kDown = 3, kLeft = 4 };
+    // candidate moves per heading: {diag1, straight, diag3} as (dx, dy)
+    static const int mv[5][3][2] = {{{0, 0}, {0, 0}, {0, 0}},
+                                    {{1, -1}, {0, -1}, {-1, -1}},   // up
+                                    {{1, -1}, {1, 0}, {1, 1}},      // right
+                                    {{1, 1}, {0, 1}, {-1, 1}},      // down
+                                    {{-1, -1}, {-1, 0}, {-1, 1}}};  // left
+    int lastX = 0, lastY = 0;   // persists across walks, as in the reference
+    auto at_border = [&](int heading, int x, int y) {
+      switch (heading) {
+        case kRight: return x == W - 1 || y == 0 || y == H - 1;
+        case kLeft: return x == 0 || y == 0 || y == H - 1;
+        case kDown: return x == 0 || x == W - 1 || y == H - 1;
+        default: return x == 0 || x == W - 1 || y == 0;
+      }
+    };
+    auto walk = [&](int x, int y, int heading, std::vector<uint16_t>& ox, std::vector<uint16_t>& oy) -> bool {
+      int idx = y * W + x;
+      while (g(idx) > 0 && !used[idx]) {
+        used[idx] = 1;
+        if (ox.size() >= cap) return false;
+        ox.push_back((uint16_t)x);
+        oy.push_back((uint16_t)y);
+        int want = 0;
+        int go = 0;
+        if (horizontal(idx)) {
+          if (heading == kUp || heading == kDown) want = (x > lastX) ? kRight : kLeft;
+          lastX = x; lastY = y;
+          if (heading == kRight || want == kRight) go = kRight;
+          else if (heading == kLeft || want == kLeft) go = kLeft;
+        } else {
+          if (heading == kRight || heading == kLeft) want = (y > lastY) ? kDown : kUp;
+          lastX = x; lastY = y;
+          if (heading == kDown || want == kDown) go = kDown;
+          else if (heading == kUp || want == kUp) go = kUp;
+        }
+        if (go) {
+          if (at_border(go, x, y)) break;
+          // the reference compares the neighbours' magnitudes truncated to 8 bits
+          const int g1 = g((y + mv[go][0][1]) * W + x + mv[go][0][0]) & 0xff;
+          const int g2 = g((y + mv[go][1][1]) * W + x + mv[go][1][0]) & 0xff;
+          const int g3 = g((y + mv[go][2][1]) * W + x + mv[go][2][0]) & 0xff;
+          const int pick = (g1 >= g2 && g1 >= g3) ? 0 : ((g3 >= g2 && g3 >= g1) ? 2 : 1);
+          x += mv[go][pick][0];
+          y += mv[go][pick][1];
+          heading = go;
+        }
+        idx = y * W + x;
+      }
+      return true;
+    };
+    for (size_t a = 0; a < ax.size(); ++a) {
+      const int x = ax[a], y = ay[a], idx = y * W + x;
+      if (used[idx]) continue;
+      if (fstart.size() >= max_edges) return false;
+      const size_t f0 = fx.size(), s0 = sx.size();
+      const bool hor = horizontal(idx);
+      if (!walk(x, y, hor ? kRight : kDown, fx, fy)) return false;
+      used[idx] = 0;   // the anchor is walked again as the head of the second half
+      if (!walk(x, y, hor ? kLeft : kUp, sx, sy)) return false;
+      if ((int)(fx.size() - f0) + (int)(sx.size() - s0) < P.min_line_len + 1) {
+        fx.resize(f0); fy.resize(f0); sx.resize(s0); sy.resize(s0);   // short edge: dropped (pixels stay marked)
+      } else {
+        fstart.push_back((uint32_t)f0);
+        sstart.push_back((uint32_t)s0);
+      }
+    }
+    if (fx.empty() || sx.empty()) return false;   // "Edge drawing Error: lines not found"
+    fstart.push_back((uint32_t)fx.size());
+    sstart.push_back((uint32_t)sx.size());
+    cx.clear(); cy.clear(); cstart.clear();
+    for (size_t e = 0; e + 1 < fstart.size(); ++e) {
+      cstart.push_back((uint32_t)cx.size());
+      for (int i = (int)fstart[e + 1] - 1; i >= (int)fstart[e]; --i) { cx.push_back(fx[i]); cy.push_back(fy[i]); }
+      for (uint32_t i = sstart[e] + 1; i < sstart[e + 1]; ++i) { cx.push_back(sx[i]); cy.push_back(sy[i]); }
+    }
+    cstart.push_back((uint32_t)cx.size());
+    return true;
+  }
+
+  // cv::Mat_<float> products: accumulate in double, store float
+  static float dot(const float* a, const float* b, int n) {
+    double s = 0;
+    for (int i = 0; i < n; ++i) s += (double)a[i] * (double)b[i];
+    return (float)s;
+  }
+  void solve(double eq[2]) const {
+    const double c = 1.0 / (double(ata[0]) * double(ata[3]) - double(ata[1]) * double(ata[2]));
+    eq[0] = c * (double(ata[3]) * double(atv[0]) - double(ata[1]) * double(atv[1]));
+    eq[1] = c * (double(ata[0]) * double(atv[1]) - double(ata[2]) * double(atv[0]));
+  }
+  // accumulate the normal equations over pixels [b, e) of (px, py); `fresh` restarts them
+  void accumulate(const uint16_t* px, const uint16_t* py, size_t b, size_t e, bool hor, bool fresh) {
+    const int n = (int)(e - b);
+    std::vector<float> u(n), one(n, 1.0f), v(n);
+    for (int i = 0; i < n; ++i) {
+      u[i] = (float)(hor ? px[b + i] : py[b + i]);
+      v[i] = (float)(hor ? py[b + i] : px[b + i]);
+    }
+    const float t[4] = {dot(u.data(), u.data(), n), dot(u.data(), one.data(), n), dot(one.data(), u.data(), n),
+                        dot(one.data(), one.data(), n)};
+    const float r[2] = {dot(u.data(), v.data(), n), dot(one.data(), v.data(), n)};
+    for (int i = 0; i < 4; ++i) ata[i] = fresh ? t[i] : ata[i] + t[i];
+    for (int i = 0; i < 2; ++i) atv[i] = fresh ? r[i] : atv[i] + r[i];
+  }
+
+  bool validate(const uint16_t* px, const uint16_t* py, size_t b, size_t e, const double eq[3], float* dir_out) {
+    const int n = (int)(e - b);
+    int mgx = 0, mgy = 0;
+    std::vector<double> pdir(n);
+    for (int i = 0; i < n; ++i) {
+      const int idx = py[b + i] * W + px[b + i];
+      mgx += maps.dx[idx];
+      mgy += maps.dy[idx];
+      pdir[i] = atan2(-(double)maps.dx[idx], (double)maps.dy[idx]);
+    }
+    const double dx = fabs(eq[1]), dy = fabs(eq[0]);
+    if (mgx == 0 && mgy == 0) return false;
+    float direction = *dir_out;   // the reference leaves it untouched if no quadrant matches
+    if (mgx > 0 && mgy >= 0) direction = (float)atan2(-dy, dx);
+    if (mgx <= 0 && mgy > 0) direction = (float)atan2(dy, dx);
+    if (mgx < 0 && mgy <= 0) direction = (float)atan2(dy, -dx);
+    if (mgx >= 0 && mgy < 0) direction = (float)atan2(-dy, -dx);
+    *dir_out = direction;
+    if (fabs(direction) < 0.15 || M_PI - fabs(direction) < 0.15)
+      if (fabs(eq[2]) < 10 || fabs((unsigned)H - fabs(eq[2])) < 10) return false;
+    if (fabs(fabs(direction) - M_PI * 0.5) < 0.15)
+      if (fabs(eq[2]) < 10 || fabs((unsigned)W - fabs(eq[2])) < 10) return false;
+    int k = 0;
+    for (int i = 0; i < n; ++i) {
+      const double d = fabs(direction - pdir[i]);
+      if (fabs(2 * M_PI - d) < 0.392699 || d < 0.392699) ++k;
+    }
+    return nfa(n, k, 0.125, logNT) > 0;
+  }
+
+  bool fit_lines() {
+    logNT = 2.0 * (log10((double)(unsigned)W) + log10((double)(unsigned)H));
+    const int L = P.min_line_len;
+    const double thr = P.fit_err_threshold;
+    std::vector<uint16_t> lx(cx.size()), ly(cx.size());   // pixels of accepted / tentative lines
+    size_t lpos = 0;
+    float direction = 0;
+    double eq2[2] = {0, 0};
+    const uint16_t* ex = cx.data();
+    const uint16_t* ey = cy.data();
+    for (size_t c = 0; c + 1 < cstart.size(); ++c) {
+      size_t s = cstart[c];
+      const size_t e = cstart[c + 1];
+      while (e > s + L) {
+        // slide until 15 consecutive pixels fit a line
+        double err = 0;
+        while (e > s + L) {
+          const bool hor0 = horizontal(ey[s] * W + ex[s]);
+          accumulate(ex, ey, s, s + L, hor0, true);
+          solve(eq2);
+          err = 0;
+          for (int i = 0; i < L; ++i) {
+            const double r = hor0 ? double(ey[s + i]) - double(ex[s + i]) * eq2[0] - eq2[1]
+                                  : double(ex[s + i]) - double(ey[s + i]) * eq2[0] - eq2[1];
+            err += r * r;
+          }
+          err = sqrt(err);
+          if (err <= thr) break;
+          s += 2;   // SkipEdgePoint
+        }
+        if (err > thr) break;
+        const size_t lbeg = lpos;
+        const bool hor = horizontal(ey[s] * W + ex[s]);
+        double coef1 = 0;
+        size_t new_from = 0;
+        int tries = 0;
+        bool first = true, extended = true;
+        while (extended) {
+          ++tries;
+          if (first) {
+            first = false;
+            for (int i = 0; i < L; ++i) { lx[lpos] = ex[s]; ly[lpos++] = ey[s++]; }
+          } else if (lpos > new_from) {
+            // re-estimate with the pixels added by the previous try; the fit direction is
+            // re-read from the FIRST pixel of the line, as the reference does
+            const bool horf = horizontal(ly[lbeg] * W + lx[lbeg]);
+            accumulate(lx.data(), ly.data(), new_from, lpos, horf, false);
+            solve(eq2);
+          }
+          coef1 = 1 / sqrt(eq2[0] * eq2[0] + 1);
+          int outliers = 0;
+          new_from = lpos;
+          while (e > s) {
+            const double d = hor ? fabs(eq2[0] * ex[s] - ey[s] + eq2[1]) * coef1
+                                 : fabs(ex[s] - eq2[0] * ey[s] - eq2[1]) * coef1;
+            lx[lpos] = ex[s];
+            ly[lpos++] = ey[s++];
+            if (d > thr) {
+              if (++outliers > 3) break;
+            } else {
+              outliers = 0;
+            }
+          }
+          lpos -= outliers;
+          s -= outliers;
+          if (!(lpos > new_from && tries < 6)) extended = false;   // TryTime
+        }
+        double eq[3];
+        if (hor) { eq[0] = eq2[0] * coef1; eq[1] = -1 * coef1; eq[2] = eq2[1] * coef1; }
+        else { eq[0] = 1 * coef1; eq[1] = -eq2[0] * coef1; eq[2] = -eq2[1] * coef1; }
+        if (validate(lx.data(), ly.data(), lbeg, lpos, eq, &direction)) {
+          Segment sg;
+          sg.eq[0] = eq[0]; sg.eq[1] = eq[1]; sg.eq[2] = eq[2];
+          const double a1 = eq[1] * eq[1], a2 = eq[0] * eq[0], a3 = eq[0] * eq[1], a4 = eq[2] * eq[0], a5 = eq[2] * eq[1];
+          unsigned Px = lx[lbeg], Py = ly[lbeg];
+          sg.ep[0] = (float)(a1 * Px - a3 * Py - a4);
+          sg.ep[1] = (float)(a2 * Py - a3 * Px - a5);
+          Px = lx[lpos - 1]; Py = ly[lpos - 1];
+          sg.ep[2] = (float)(a1 * Px - a3 * Py - a4);
+          sg.ep[3] = (float)(a2 * Py - a3 * Px - a5);
+          sg.direction = direction;
+          sg.num_pixels = (int)(lpos - lbeg);
+          segments.push_back(sg);
+        } else {
+          lpos = lbeg;
+        }
+      }
+    }
+    return true;
+  }
+};
+
+// ------------------------------------------------------------ across octaves
+struct KeyLine {   // cv::line_descriptor_c::KeyLine, 68 bytes (descriptor_custom.hpp:104-172)
+  float angle;
+  int32_t class_id, octave;
+  float pt_x, pt_y, response, size;
+  float startPointX, startPointY, endPointX, endPointY;
+  float sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY;
+  float lineLength;
+  int32_t numOfPixels;
+};
+
+// OctaveKeyLines' grouping (:860-1149) + detectImpl's flattening (:504-555)
+inline std::vector<KeyLine> group_and_flatten(const std::vector<OctaveDetector>& oct,
+                                              const std::vector<std::pair<int, int>>& sizes, double factor) {
+  struct Ref { int octave, id, group; float length; };
+  const int no = (int)oct.size();
+  std::vector<float> scale(no);
+  scale[0] = 1;
+  for (int o = 1; o < no; ++o) scale[o] = (float)(factor * scale[o - 1]);
+  std::vector<Ref> all;
+  int groups = 0;
+  auto seg_len = [](const Segment& s) {
+    const float dx = (float)fabs(s.ep[0] - s.ep[2]), dy = (float)fabs(s.ep[1] - s.ep[3]);
+    return std::sqrt(dx * dx + dy * dy);
+  };
+  for (int i = 0; i < (int)oct[0].segments.size(); ++i) all.push_back(Ref{0, i, groups++, seg_len(oct[0].segments[i])});
+  const double twoPI = 2 * M_PI;
+  for (int o = 1; o < no; ++o) {
+    for (int i = 0; i < (int)oct[o].segments.size(); ++i) {
+      const Segment& cur = oct[o].segments[i];
+      const float rho1 = (float)(scale[o] * fabs(cur.eq[2]));
+      const float tv = (float)(rho1 * 0.0152);
+      float near_thr = (tv > 6) ? tv : 6;
+      near_thr = (near_thr < 12) ? near_thr : 12;
+      const float length = scale[o] * seg_len(cur);
+      float best = 12;
+      int best_ref = 0;
+      for (size_t r = 0; r < all.size(); ++r) {
+        if (all[r].octave == o) break;
+        const Segment& oth = oct[all[r].octave].segments[all[r].id];
+        const float ddir = (float)fabs(cur.direction - oth.direction);
+        if (ddir > 0.1745 && (twoPI - ddir > 0.1745)) continue;
+        const float so = scale[all[r].octave];
+        const float rho2 = (float)(so * fabs(oth.eq[2]));
+        if ((float)fabs(rho1 - rho2) > near_thr) continue;
+        const float lp[4] = {scale[o] * cur.ep[0], scale[o] * cur.ep[1], scale[o] * cur.ep[2], scale[o] * cur.ep[3]};
+        const float np[4] = {so * oth.ep[0], so * oth.ep[1], so * oth.ep[2], so * oth.ep[3]};
+        auto dist = [](float ax, float ay, float bx, float by) {
+          const float dx = ax - bx, dy = ay - by;
+          return std::sqrt(dx * dx + dy * dy);
+        };
+        float d = dist(lp[0], lp[1], np[0], np[1]);
+        float mn = d, mx = d;
+        d = dist(lp[2], lp[3], np[2], np[3]); mn = (d < mn) ? d : mn; mx = (d > mx) ? d : mx;
+        d = dist(lp[0], lp[1], np[2], np[3]); mn = (d < mn) ? d : mn; mx = (d > mx) ? d : mx;
+        d = dist(lp[2], lp[3], np[0], np[1]); mn = (d < mn) ? d : mn; mx = (d > mx) ? d : mx;
+        if ((mx < 0.8 * (length + all[r].length)) && (mn < best)) {
+          best = mn;
+          best_ref = (int)r;
+        }
+      }
+      const int group = (best < 12) ? all[best_ref].group : groups++;
+      all.push_back(Ref{o, i, group, length});
+    }
+  }
+  // ScaleLines: group -> members in discovery order; flattened group by group
+  std::vector<std::vector<int>> members(groups);
+  for (size_t r = 0; r < all.size(); ++r) members[all[r].group].push_back((int)r);
+  std::vector<KeyLine> out;
+  out.reserve(all.size());
+  for (int gidx = 0; gidx < groups; ++gidx)
+    for (int r : members[gidx]) {
+      const Ref& ref = all[r];
+      const Segment& s = oct[ref.octave].segments[ref.id];
+      const float direction = s.direction;
+      const float s1 = s.ep[0], s2 = s.ep[1], e1 = s.ep[2], e2 = s.ep[3];
+      const float dx = e1 - s1, dy = e2 - s2;
+      bool swap = false;
+      if (direction >= -0.75 * M_PI && direction < -0.25 * M_PI && dy > 0) swap = true;
+      if (direction >= -0.25 * M_PI && direction < 0.25 * M_PI && dx < 0) swap = true;
+      if (direction >= 0.25 * M_PI && direction < 0.75 * M_PI && dy < 0) swap = true;
+      if (((direction >= 0.75 * M_PI && direction < M_PI) || (direction >= -M_PI && direction < -0.75 * M_PI)) && dx > 0)
+        swap = true;
+      const float sc = scale[ref.octave];
+      KeyLine k;
+      k.sPointInOctaveX = swap ? e1 : s1; k.sPointInOctaveY = swap ? e2 : s2;
+      k.ePointInOctaveX = swap ? s1 : e1; k.ePointInOctaveY = swap ? s2 : e2;
+      k.startPointX = sc * k.sPointInOctaveX; k.startPointY = sc * k.sPointInOctaveY;
+      k.endPointX = sc * k.ePointInOctaveX; k.endPointY = sc * k.ePointInOctaveY;
+      k.lineLength = ref.length;
+      k.numOfPixels = s.num_pixels;
+      k.angle = direction;
+      k.class_id = gidx;
+      k.octave = ref.octave;
+      k.size = (k.endPointX - k.startPointX) * (k.endPointY - k.startPointY);
+      k.response = k.lineLength / std::max(sizes[ref.octave].first, sizes[ref.octave].second);
+      k.pt_x = (k.endPointX + k.startPointX) / 2;
+      k.pt_y = (k.endPointY + k.startPointY) / 2;
+      out.push_back(k);
+    }
+  return out;
+}
+
+// LineExtractor::detectLineFeatures' selection (src/LineExtractor.cc:229-266)
+inline void select_lines(std::vector<KeyLine>& lines, int nfeatures, int img_w, int img_h, double min_length) {
+  if ((int)lines.size() > nfeatures && nfeatures != 0) {
+    std::sort(lines.begin(), lines.end(), [](const KeyLine& a, const KeyLine& b) { return a.response > b.response; });
+    lines.resize(nfeatures);
+  }
+  const int lo = 5, hx = img_w - 5, hy = img_h - 5;   // kBorderThreshold
+  lines.erase(std::remove_if(lines.begin(), lines.end(),
+                             [&](const KeyLine& l) {
+                               return ((l.startPointX < lo) && (l.endPointX < lo)) || ((l.startPointX > hx) && (l.endPointX > hx)) ||
+                                      ((l.startPointY < lo) && (l.endPointY < lo)) || ((l.startPointY > hy) && (l.endPointY > hy));
+                             }),
+              lines.end());
+  size_t keep = lines.size();
+  for (size_t i = 0; i < lines.size(); ++i) {
+    lines[i].class_id = (int)i;
+    if (lines[i].response < min_length) { keep = i; break; }
+  }
+  lines.resize(keep);
+}
+
+}  // namespace lines
+}  // namespace plvs

@@ -1,0 +1,31 @@
+// Host compile of the product's sequential line stages (plvs_amd/csrc/lines_host.hpp),
+// fed with per-pixel maps supplied by the caller — a CPU-side agreement check
+// against the oracle.  Test infrastructure only.
+#include <cstring>
+#include <vector>
+
+#include "../../plvs_amd/csrc/lines_host.hpp"
+
+using namespace plvs::lines;
+
+// gd/dx/dy: concatenated per-octave maps; sizes: (w,h) pairs.
+extern "C" int hostlines_run(int noct, const int* sizes, const uint16_t* const* gd, const int16_t* const* dx,
+                             const int16_t* const* dy, double scale, int nfeatures, int img_w, int img_h,
+                             double min_length, double fit_err, void* keylines_out, int cap, int* per_octave) {
+  std::vector<OctaveDetector> det(noct);
+  std::vector<std::pair<int, int>> sz(noct);
+  EdParams P;
+  P.fit_err_threshold = fit_err;
+  for (int i = 0; i < noct; ++i) {
+    OctaveMaps m;
+    m.w = sizes[2 * i]; m.h = sizes[2 * i + 1];
+    m.gd = gd[i]; m.dx = dx[i]; m.dy = dy[i];
+    sz[i] = {m.w, m.h};
+    if (!det[i].run(m, P)) det[i].segments.clear();
+    per_octave[i] = (int)det[i].segments.size();
+  }
+  std::vector<KeyLine> kl = group_and_flatten(det, sz, scale);
+  select_lines(kl, nfeatures, img_w, img_h, min_length);
+  if ((int)kl.size() <= cap && !kl.empty()) memcpy(keylines_out, kl.data(), kl.size() * sizeof(KeyLine));
+  return (int)kl.size();
+}

@@ -43,6 +43,9 @@ class Oracle:
     def orb(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
         return OracleOrb(self.lib, nfeatures, scale_factor, nlevels, ini_th, min_th)
 
+    def lines(self, **kw):
+        return OracleLines(self.lib, **kw)
+
     def resize_linear(self, img, dw, dh):
         img = np.ascontiguousarray(img, dtype=np.uint8)
         out = np.empty((dh, dw), np.uint8)
@@ -154,6 +157,54 @@ class OracleOrb:
         out = np.zeros((max(n, 1), 3), np.float32)
         self.lib.oracle_orb_get_candidates(self.h, level, _ptr(out))
         return out[:n]
+
+
+KEYLINE_DTYPE = np.dtype([("angle", np.float32), ("class_id", np.int32), ("octave", np.int32), ("pt_x", np.float32),
+                          ("pt_y", np.float32), ("response", np.float32), ("size", np.float32),
+                          ("startPointX", np.float32), ("startPointY", np.float32), ("endPointX", np.float32),
+                          ("endPointY", np.float32), ("sPointInOctaveX", np.float32), ("sPointInOctaveY", np.float32),
+                          ("ePointInOctaveX", np.float32), ("ePointInOctaveY", np.float32),
+                          ("lineLength", np.float32), ("numOfPixels", np.int32)])
+
+
+class OracleLines:
+    def __init__(self, lib, nfeatures=100, nlevels=3, scale=1.2, min_length=0.02, fit_err=1.6):
+        self.lib, self.nlevels = lib, nlevels
+        lib.oracle_lines_create.restype = _vp
+        lib.oracle_lines_create.argtypes = [_i, _i, _f, ctypes.c_double, ctypes.c_double]
+        lib.oracle_lines_destroy.argtypes = [_vp]
+        lib.oracle_lines_extract.argtypes = [_vp, _vp, _i, _i, _i, _vp, _vp, _i]
+        lib.oracle_lines_octave_size.argtypes = [_vp, _i, _vp, _vp]
+        lib.oracle_lines_get_map.argtypes = [_vp, _i, _i, _vp]
+        lib.oracle_lines_num_in_octave.argtypes = [_vp, _i]
+        self.h = _vp(lib.oracle_lines_create(nfeatures, nlevels, scale, min_length, fit_err))
+        self.cap = 20000
+
+    def __del__(self):
+        if self.h:
+            self.lib.oracle_lines_destroy(self.h)
+            self.h = None
+
+    def extract(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        kl = np.zeros(self.cap, KEYLINE_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n = self.lib.oracle_lines_extract(self.h, _ptr(img), img.shape[1], img.shape[0], img.shape[1], _ptr(kl),
+                                          _ptr(desc), self.cap)
+        assert n <= self.cap
+        return kl[:n].copy(), desc[:n].copy()
+
+    def octave_map(self, octave, which):
+        """which: 'blur' (u8), 'dx', 'dy', 'g' (s16), 'dir' (u8)"""
+        w, h = ctypes.c_int(), ctypes.c_int()
+        self.lib.oracle_lines_octave_size(self.h, octave, ctypes.byref(w), ctypes.byref(h))
+        code = {"blur": 0, "dx": 1, "dy": 2, "g": 3, "dir": 4}[which]
+        out = np.zeros((h.value, w.value), np.uint8 if code in (0, 4) else np.int16)
+        self.lib.oracle_lines_get_map(self.h, octave, code, _ptr(out))
+        return out
+
+    def num_in_octave(self, octave):
+        return self.lib.oracle_lines_num_in_octave(self.h, octave)
 
 
 def read_pgm(path):
@@ -298,6 +349,16 @@ def load_hostorb():
     lib = ctypes.CDLL(so)
     lib.hostorb_distribute.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _i]
     return lib
+
+
+def load_hostlines():
+    """Host (g++) build of plvs_amd/csrc/lines_host.hpp (the product's sequential line stages)."""
+    so = os.path.join(HOSTCORE_DIR, "libhostlines.so")
+    src = os.path.join(HOSTCORE_DIR, "lines_host.cpp")
+    hdr = os.path.join(ROOT, "plvs_amd", "csrc", "lines_host.hpp")
+    if not os.path.exists(so) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(so):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", src, "-o", so], check=True)
+    return ctypes.CDLL(so)
 
 
 def load():
