@@ -16,6 +16,7 @@
 //                              selection — order dependent, one thread per octave
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <thread>
 #include <vector>
@@ -80,6 +81,26 @@ __global__ __launch_bounds__(256) void lines_sobel_grad(const uint8_t* __restric
   dxo[i] = (int16_t)dx;
   dyo[i] = (int16_t)dy;
   gd[i] = (uint16_t)(g | (ax < ay ? 0x8000 : 0));
+}
+
+// Anchor test of EdgeDrawing (:1665-1691) on the stride-2 scan grid, written in scan
+// (column-major) order so that the host consumes it with one linear pass.
+__global__ __launch_bounds__(256) void lines_anchor_flags(const uint16_t* __restrict__ gd, int w, int h,
+                                                          int rows, int cols, int anchor_threshold,
+                                                          uint8_t* __restrict__ flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int c = i / rows, r = i % rows;
+  const int x = 2 * c + 1, y = 2 * r + 1;
+  const int idx = y * w + x;
+  const int v = gd[idx];
+  const int gi = v & 0x1ff;
+  bool a;
+  if (v & 0x8000)
+    a = gi >= (gd[idx - w] & 0x1ff) + anchor_threshold && gi >= (gd[idx + w] & 0x1ff) + anchor_threshold;
+  else
+    a = gi >= (gd[idx - 1] & 0x1ff) + anchor_threshold && gi >= (gd[idx + 1] & 0x1ff) + anchor_threshold;
+  flags[i] = a ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void lines_resize(const uint8_t* __restrict__ src, int sw,
@@ -293,6 +314,7 @@ struct plvs_lines {
   std::vector<uint8_t*> d_img, d_blur;         // octave input / blurred
   std::vector<int16_t*> d_dx, d_dy;
   std::vector<uint16_t*> d_gd;
+  std::vector<uint8_t*> d_anchor, h_anchor;    // scan-order anchor flags (device / pinned host)
   std::vector<int*> d_xofs, d_yofs;
   std::vector<short*> d_alpha, d_beta;
   std::vector<int16_t*> h_dx, h_dy;            // pinned
@@ -316,6 +338,9 @@ void lines_free_geometry(plvs_lines* o) {
   for (auto p : o->d_dx) (void)hipFree(p);
   for (auto p : o->d_dy) (void)hipFree(p);
   for (auto p : o->d_gd) (void)hipFree(p);
+  for (auto p : o->d_anchor) (void)hipFree(p);
+  for (auto p : o->h_anchor) if (p) (void)hipHostFree(p);
+  o->d_anchor.clear(); o->h_anchor.clear();
   for (auto p : o->d_xofs) (void)hipFree(p);
   for (auto p : o->d_yofs) (void)hipFree(p);
   for (auto p : o->d_alpha) (void)hipFree(p);
@@ -340,6 +365,7 @@ int lines_build_geometry(plvs_lines* o, int w, int h) {
   o->d_dy.assign(n, nullptr); o->d_gd.assign(n, nullptr);
   o->d_xofs.assign(n, nullptr); o->d_yofs.assign(n, nullptr); o->d_alpha.assign(n, nullptr); o->d_beta.assign(n, nullptr);
   o->h_dx.assign(n, nullptr); o->h_dy.assign(n, nullptr); o->h_gd.assign(n, nullptr);
+  o->d_anchor.assign(n, nullptr); o->h_anchor.assign(n, nullptr);
   // OctaveKeyLines :785-846: sigma schedule and octave sizes
   float preSigma2 = (float)std::pow(0.5, 2);
   float curSigma2 = (float)std::pow(1.0f, 2);
@@ -363,6 +389,9 @@ int lines_build_geometry(plvs_lines* o, int w, int h) {
     PLVS_HIP_TRY(hipHostMalloc((void**)&o->h_dx[i], px * 2));
     PLVS_HIP_TRY(hipHostMalloc((void**)&o->h_dy[i], px * 2));
     PLVS_HIP_TRY(hipHostMalloc((void**)&o->h_gd[i], px * 2));
+    const size_t na = (size_t)((cw - 1) / 2) * ((ch - 1) / 2) + 1;
+    PLVS_HIP_TRY(hipMalloc((void**)&o->d_anchor[i], na));
+    PLVS_HIP_TRY(hipHostMalloc((void**)&o->h_anchor[i], na));
     const int nw = cvr(cw * inv), nh = cvr(ch * inv);   // dsize = saturate_cast<int>(ssize * f)
     if (i + 1 < n) {
       std::vector<int> xo, yo;
@@ -399,6 +428,12 @@ int lines_extract_body(plvs_lines* o, plvs_keyline* keylines, uint8_t* desc, int
     hipLaunchKernelGGL(lines_sobel_grad, grid, block, 0, s, o->d_blur[i], w, h, o->d_dx[i], o->d_dy[i],
                        o->d_gd[i], 80);
     const size_t px = (size_t)w * h;
+    const int arows = (h - 1) / 2, acols = (w - 1) / 2;
+    if (arows > 0 && acols > 0) {
+      hipLaunchKernelGGL(lines_anchor_flags, dim3((arows * acols + 255) / 256), block, 0, s, o->d_gd[i], w, h,
+                         arows, acols, o->ed.anchor_threshold, o->d_anchor[i]);
+      PLVS_HIP_TRY(hipMemcpyAsync(o->h_anchor[i], o->d_anchor[i], (size_t)arows * acols, hipMemcpyDeviceToHost, s));
+    }
     PLVS_HIP_TRY(hipMemcpyAsync(o->h_gd[i], o->d_gd[i], px * 2, hipMemcpyDeviceToHost, s));
     PLVS_HIP_TRY(hipMemcpyAsync(o->h_dx[i], o->d_dx[i], px * 2, hipMemcpyDeviceToHost, s));
     PLVS_HIP_TRY(hipMemcpyAsync(o->h_dy[i], o->d_dy[i], px * 2, hipMemcpyDeviceToHost, s));
@@ -411,21 +446,59 @@ int lines_extract_body(plvs_lines* o, plvs_keyline* keylines, uint8_t* desc, int
   PLVS_KERNEL_CHECK();
   PLVS_HIP_TRY(hipStreamSynchronize(s));
   const double t1 = now_ms();
-  // ---- host: one thread per octave
+  // ---- host, phase 1: EdgeDrawing (sequential per octave), one thread per octave
   o->det.resize(n);
-  std::vector<char> ok(n, 0);
   {
     auto work = [&](int i) {
       OctaveMaps m;
       m.w = o->sizes[i].first; m.h = o->sizes[i].second;
       m.gd = o->h_gd[i]; m.dx = o->h_dx[i]; m.dy = o->h_dy[i];
-      ok[i] = o->det[i].run(m, o->ed) ? 1 : 0;
-      if (!ok[i]) o->det[i].segments.clear();   // "failure: lines extraction on octave i": no lines from it
+      m.anchors = (m.w >= 3 && m.h >= 3) ? o->h_anchor[i] : nullptr;
+      // on "failure: lines extraction on octave i" the octave contributes no lines
+      (void)o->det[i].prepare(m, o->ed);
     };
     std::vector<std::thread> th;
     for (int i = 1; i < n; ++i) th.emplace_back(work, i);
     work(0);
     for (auto& t : th) t.join();
+  }
+  // ---- host, phase 2: the edge chains are fitted independently -> balanced tasks over a
+  // few threads, results concatenated in chain order (the reference's line order)
+  {
+    struct Task { int octave, c0, c1; std::vector<Segment> out; };
+    std::vector<Task> tasks;
+    size_t total = 0;
+    for (int i = 0; i < n; ++i)
+      for (int c = 0; c < o->det[i].num_chains(); ++c) total += o->det[i].chain_pixels(c);
+    const int kThreads = 6;
+    const size_t per_task = total / (kThreads * 2) + 1;
+    for (int i = 0; i < n; ++i) {
+      int c0 = 0;
+      size_t acc = 0;
+      const int nc = o->det[i].num_chains();
+      for (int c = 0; c < nc; ++c) {
+        acc += o->det[i].chain_pixels(c);
+        if (acc >= per_task || c == nc - 1) {
+          tasks.push_back(Task{i, c0, c + 1, {}});
+          c0 = c + 1;
+          acc = 0;
+        }
+      }
+    }
+    std::atomic<int> next(0);
+    auto worker = [&]() {
+      for (;;) {
+        const int t = next.fetch_add(1);
+        if (t >= (int)tasks.size()) break;
+        o->det[tasks[t].octave].fit_range(tasks[t].c0, tasks[t].c1, tasks[t].out);
+      }
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < kThreads && i < (int)tasks.size(); ++i) th.emplace_back(worker);
+    worker();
+    for (auto& t : th) t.join();
+    for (Task& t : tasks)
+      o->det[t.octave].segments.insert(o->det[t.octave].segments.end(), t.out.begin(), t.out.end());
   }
   std::vector<KeyLine> kl = group_and_flatten(o->det, o->sizes, o->scale);
   select_lines(kl, o->nfeatures, o->img_w, o->img_h, o->min_length);

@@ -10,6 +10,8 @@
 // line segments, octave by octave (one host thread per octave), then groups
 // the segments across octaves (:903-1149) and flattens them to KeyLines (:504-555).
 #pragma once
+#include <time.h>
+
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -84,6 +86,9 @@ struct OctaveMaps {           // what the device hands over for one octave
   const uint16_t* gd = nullptr;   // bits 0..8: gradient magnitude / 4 (0 below threshold), bit 15: |dx| < |dy|
   const int16_t* dx = nullptr;    // Sobel derivatives (for the validation)
   const int16_t* dy = nullptr;
+  // optional: anchor flags of the stride-2 scan grid in scan (column-major) order,
+  // flag[(x-1)/2 * rows + (y-1)/2] for x = 1,3,.. and y = 1,3,.. (rows = number of scanned y)
+  const uint8_t* anchors = nullptr;
 };
 
 struct EdParams {
@@ -91,15 +96,29 @@ struct EdParams {
   double fit_err_threshold = 1.6;
 };
 
+inline double clock_ms() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
 class OctaveDetector {
  public:
   std::vector<Segment> segments;
+  double ms_draw = 0, ms_fit = 0, ms_validate = 0, ms_anchor = 0;   // wall-clock split of the last run
 
   // returns false on the reference's failure paths ("lines not found", buffer overrun)
   bool run(const OctaveMaps& m, const EdParams& prm) {
     segments.clear();
     W = m.w; H = m.h; maps = m; P = prm;
-    return draw_edges() && fit_lines();
+    logNT = 2.0 * (log10((double)(unsigned)W) + log10((double)(unsigned)H));
+    const double t0 = clock_ms();
+    const bool ok1 = draw_edges();
+    const double t1 = clock_ms();
+    const bool ok2 = ok1 && fit_lines();
+    ms_draw = t1 - t0;
+    ms_fit = clock_ms() - t1;
+    return ok2;
   }
 
  private:
@@ -107,32 +126,53 @@ class OctaveDetector {
   OctaveMaps maps;
   EdParams P;
   std::vector<uint16_t> cx, cy;       // edge chains, pixel by pixel
+  std::vector<uint16_t> fx_, fy_, sx_, sy_;   // scratch kept across calls (no reallocation per frame)
+  std::vector<uint8_t> used;
   std::vector<uint32_t> cstart;       // chain c = [cstart[c], cstart[c+1])
-  float ata[4] = {0, 0, 0, 0}, atv[2] = {0, 0};
   double logNT = 0;
+  struct FitState { float ata[4] = {0, 0, 0, 0}, atv[2] = {0, 0}; };
 
   int g(int idx) const { return maps.gd[idx] & 0x1ff; }
   bool horizontal(int idx) const { return (maps.gd[idx] & 0x8000u) != 0; }
 
   // ---- EdgeDrawing: anchors (column-major scan) + smart routing
   bool draw_edges() {
+    const double t_begin = clock_ms();
     const size_t npix = (size_t)W * H;
     const size_t cap = npix / 5, max_edges = cap / 20;
     std::vector<uint16_t> ax, ay;
-    for (int x = 1; x < W - 1; x += P.scan_interval)
-      for (int y = 1; y < H - 1; y += P.scan_interval) {
-        const int i = y * W + x, gi = g(i);
-        const bool a = horizontal(i) ? (gi >= g(i - W) + P.anchor_threshold && gi >= g(i + W) + P.anchor_threshold)
-                                     : (gi >= g(i - 1) + P.anchor_threshold && gi >= g(i + 1) + P.anchor_threshold);
-        if (a) {
-          if (ax.size() >= cap) return false;
-          ax.push_back((uint16_t)x);
-          ay.push_back((uint16_t)y);
+    if (maps.anchors != nullptr && P.scan_interval == 2) {
+      // the device already evaluated the anchor test; its flag map is laid out in
+      // scan order, so this is one linear pass
+      const int rows = (H - 1) / 2, cols = (W - 1) / 2;   // y = 1,3,.. < H-1 ; x = 1,3,.. < W-1
+      const uint8_t* f = maps.anchors;
+      for (int c = 0; c < cols; ++c)
+        for (int r = 0; r < rows; ++r)
+          if (f[(size_t)c * rows + r]) {
+            if (ax.size() >= cap) return false;
+            ax.push_back((uint16_t)(2 * c + 1));
+            ay.push_back((uint16_t)(2 * r + 1));
+          }
+    } else {
+      for (int x = 1; x < W - 1; x += P.scan_interval)
+        for (int y = 1; y < H - 1; y += P.scan_interval) {
+          const int i = y * W + x, gi = g(i);
+          const bool a = horizontal(i) ? (gi >= g(i - W) + P.anchor_threshold && gi >= g(i + W) + P.anchor_threshold)
+                                       : (gi >= g(i - 1) + P.anchor_threshold && gi >= g(i + 1) + P.anchor_threshold);
+          if (a) {
+            if (ax.size() >= cap) return false;
+            ax.push_back((uint16_t)x);
+            ay.push_back((uint16_t)y);
+          }
         }
-      }
-    std::vector<uint8_t> used(npix, 0);
+    }
+    const double ta = clock_ms();
+    used.assign(npix, 0);
     // the two halves of every edge, as the reference stores them
-    std::vector<uint16_t> fx, fy, sx, sy;
+    std::vector<uint16_t>& fx = fx_; std::vector<uint16_t>& fy = fy_;
+    std::vector<uint16_t>& sx = sx_; std::vector<uint16_t>& sy = sy_;
+    fx.clear(); fy.clear(); sx.clear(); sy.clear();
+    fx.reserve(cap / 4); fy.reserve(cap / 4); sx.reserve(cap / 4); sy.reserve(cap / 4);
     std::vector<uint32_t> fstart, sstart;
     enum { kUp = 1, kRight = 2, kDown = 3, kLeft = 4 };
     // candidate moves per heading: {diag1, straight, diag3} as (dx, dy)
@@ -201,6 +241,7 @@ class OctaveDetector {
         sstart.push_back((uint32_t)s0);
       }
     }
+    ms_anchor = ta - t_begin;
     if (fx.empty() || sx.empty()) return false;   // "Edge drawing Error: lines not found"
     fstart.push_back((uint32_t)fx.size());
     sstart.push_back((uint32_t)sx.size());
@@ -214,41 +255,40 @@ class OctaveDetector {
     return true;
   }
 
-  // cv::Mat_<float> products: accumulate in double, store float
-  static float dot(const float* a, const float* b, int n) {
-    double s = 0;
-    for (int i = 0; i < n; ++i) s += (double)a[i] * (double)b[i];
-    return (float)s;
-  }
-  void solve(double eq[2]) const {
+  static void solve(const FitState& F, double eq[2]) {
+    const float* ata = F.ata;
+    const float* atv = F.atv;
     const double c = 1.0 / (double(ata[0]) * double(ata[3]) - double(ata[1]) * double(ata[2]));
     eq[0] = c * (double(ata[3]) * double(atv[0]) - double(ata[1]) * double(atv[1]));
     eq[1] = c * (double(ata[0]) * double(atv[1]) - double(ata[2]) * double(atv[0]));
   }
-  // accumulate the normal equations over pixels [b, e) of (px, py); `fresh` restarts them
-  void accumulate(const uint16_t* px, const uint16_t* py, size_t b, size_t e, bool hor, bool fresh) {
-    const int n = (int)(e - b);
-    std::vector<float> u(n), one(n, 1.0f), v(n);
-    for (int i = 0; i < n; ++i) {
-      u[i] = (float)(hor ? px[b + i] : py[b + i]);
-      v[i] = (float)(hor ? py[b + i] : px[b + i]);
+  // accumulate the normal equations over pixels [b, e) of (px, py); `fresh` restarts them.
+  // cv::Mat_<float> products: every entry is a double-accumulated dot product stored as float.
+  static void accumulate(FitState& F, const uint16_t* px, const uint16_t* py, size_t b, size_t e, bool hor, bool fresh) {
+    float* ata = F.ata;
+    float* atv = F.atv;
+    double suu = 0, su = 0, suv = 0, sv = 0;
+    for (size_t i = b; i < e; ++i) {
+      const double u = (double)(float)(hor ? px[i] : py[i]), v = (double)(float)(hor ? py[i] : px[i]);
+      suu += u * u;
+      su += u * 1.0;
+      suv += u * v;
+      sv += 1.0 * v;
     }
-    const float t[4] = {dot(u.data(), u.data(), n), dot(u.data(), one.data(), n), dot(one.data(), u.data(), n),
-                        dot(one.data(), one.data(), n)};
-    const float r[2] = {dot(u.data(), v.data(), n), dot(one.data(), v.data(), n)};
+    const float n = (float)(double)(e - b);
+    const float t[4] = {(float)suu, (float)su, (float)su, n};
+    const float r[2] = {(float)suv, (float)sv};
     for (int i = 0; i < 4; ++i) ata[i] = fresh ? t[i] : ata[i] + t[i];
     for (int i = 0; i < 2; ++i) atv[i] = fresh ? r[i] : atv[i] + r[i];
   }
 
-  bool validate(const uint16_t* px, const uint16_t* py, size_t b, size_t e, const double eq[3], float* dir_out) {
+  bool validate(const uint16_t* px, const uint16_t* py, size_t b, size_t e, const double eq[3], float* dir_out) const {
     const int n = (int)(e - b);
     int mgx = 0, mgy = 0;
-    std::vector<double> pdir(n);
     for (int i = 0; i < n; ++i) {
       const int idx = py[b + i] * W + px[b + i];
       mgx += maps.dx[idx];
       mgy += maps.dy[idx];
-      pdir[i] = atan2(-(double)maps.dx[idx], (double)maps.dy[idx]);
     }
     const double dx = fabs(eq[1]), dy = fabs(eq[0]);
     if (mgx == 0 && mgy == 0) return false;
@@ -262,25 +302,66 @@ class OctaveDetector {
       if (fabs(eq[2]) < 10 || fabs((unsigned)H - fabs(eq[2])) < 10) return false;
     if (fabs(fabs(direction) - M_PI * 0.5) < 0.15)
       if (fabs(eq[2]) < 10 || fabs((unsigned)W - fabs(eq[2])) < 10) return false;
+    // Count the pixels whose level-line angle atan2(-gx, gy) lies within 0.392699 rad of the
+    // line direction (circular distance).  The reference evaluates atan2 for every pixel;
+    // here the angle between the two directions is bounded through their dot product and
+    // libm's atan2 is only consulted when that bound is within 1e-9 of the threshold, so
+    // the count is identical.
+    const double D = (double)direction, cD = cos(D), sD = sin(D);
+    const double ct = cos(0.392699), lo = ct * (1.0 - 1e-9), hi = ct * (1.0 + 1e-9);
     int k = 0;
     for (int i = 0; i < n; ++i) {
-      const double d = fabs(direction - pdir[i]);
-      if (fabs(2 * M_PI - d) < 0.392699 || d < 0.392699) ++k;
+      const int idx = py[b + i] * W + px[b + i];
+      const double gx = (double)maps.dx[idx], gy = (double)maps.dy[idx];
+      const double nrm = sqrt(gx * gx + gy * gy);
+      const double c = cD * gy - sD * gx;          // |g| * cos(angle between)
+      bool aligned;
+      if (nrm > 0 && c > hi * nrm) aligned = true;
+      else if (nrm > 0 && c < lo * nrm) aligned = false;
+      else {
+        const double d = fabs(direction - atan2(-gx, gy));
+        aligned = fabs(2 * M_PI - d) < 0.392699 || d < 0.392699;
+      }
+      if (aligned) ++k;
     }
     return nfa(n, k, 0.125, logNT) > 0;
   }
 
   bool fit_lines() {
+    fit_range(0, num_chains(), segments);
+    return true;
+  }
+
+ public:
+  int num_chains() const { return cstart.empty() ? 0 : (int)cstart.size() - 1; }
+  size_t chain_pixels(int c) const { return cstart[c + 1] - cstart[c]; }
+  // EdgeDrawing only (the sequential part); the chains can then be fitted in
+  // parallel with fit_range — every chain is fitted independently of the others.
+  bool prepare(const OctaveMaps& m, const EdParams& prm) {
+    segments.clear();
+    W = m.w; H = m.h; maps = m; P = prm;
     logNT = 2.0 * (log10((double)(unsigned)W) + log10((double)(unsigned)H));
+    const double t0 = clock_ms();
+    const bool ok = draw_edges();
+    ms_draw = clock_ms() - t0;
+    if (!ok) { cx.clear(); cy.clear(); cstart.clear(); }
+    return ok;
+  }
+
+  // Line fitting + validation of chains [c0, c1) (EDline :2442-2650), appended to `out`.
+  void fit_range(int c0, int c1, std::vector<Segment>& out) const {
     const int L = P.min_line_len;
     const double thr = P.fit_err_threshold;
-    std::vector<uint16_t> lx(cx.size()), ly(cx.size());   // pixels of accepted / tentative lines
+    if (c1 <= c0) return;
+    const size_t base = cstart[c0];
+    std::vector<uint16_t> lx(cstart[c1] - base), ly(cstart[c1] - base);   // pixels of accepted / tentative lines
     size_t lpos = 0;
     float direction = 0;
     double eq2[2] = {0, 0};
+    FitState F;
     const uint16_t* ex = cx.data();
     const uint16_t* ey = cy.data();
-    for (size_t c = 0; c + 1 < cstart.size(); ++c) {
+    for (int c = c0; c < c1; ++c) {
       size_t s = cstart[c];
       const size_t e = cstart[c + 1];
       while (e > s + L) {
@@ -288,8 +369,8 @@ class OctaveDetector {
         double err = 0;
         while (e > s + L) {
           const bool hor0 = horizontal(ey[s] * W + ex[s]);
-          accumulate(ex, ey, s, s + L, hor0, true);
-          solve(eq2);
+          accumulate(F, ex, ey, s, s + L, hor0, true);
+          solve(F, eq2);
           err = 0;
           for (int i = 0; i < L; ++i) {
             const double r = hor0 ? double(ey[s + i]) - double(ex[s + i]) * eq2[0] - eq2[1]
@@ -316,8 +397,8 @@ class OctaveDetector {
             // re-estimate with the pixels added by the previous try; the fit direction is
             // re-read from the FIRST pixel of the line, as the reference does
             const bool horf = horizontal(ly[lbeg] * W + lx[lbeg]);
-            accumulate(lx.data(), ly.data(), new_from, lpos, horf, false);
-            solve(eq2);
+            accumulate(F, lx.data(), ly.data(), new_from, lpos, horf, false);
+            solve(F, eq2);
           }
           coef1 = 1 / sqrt(eq2[0] * eq2[0] + 1);
           int outliers = 0;
@@ -352,13 +433,12 @@ class OctaveDetector {
           sg.ep[3] = (float)(a2 * Py - a3 * Px - a5);
           sg.direction = direction;
           sg.num_pixels = (int)(lpos - lbeg);
-          segments.push_back(sg);
+          out.push_back(sg);
         } else {
           lpos = lbeg;
         }
       }
     }
-    return true;
   }
 };
 

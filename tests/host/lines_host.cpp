@@ -1,6 +1,8 @@
 // Host compile of the product's sequential line stages (plvs_amd/csrc/lines_host.hpp),
 // fed with per-pixel maps supplied by the caller — a CPU-side agreement check
 // against the oracle.  Test infrastructure only.
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -23,6 +25,8 @@ extern "C" int hostlines_run(int noct, const int* sizes, const uint16_t* const* 
     sz[i] = {m.w, m.h};
     if (!det[i].run(m, P)) det[i].segments.clear();
     per_octave[i] = (int)det[i].segments.size();
+    if (getenv("PLVS_LINES_PROFILE"))
+      fprintf(stderr, "octave %d: draw %.3f ms (anchors %.3f), fit %.3f ms, validate %.3f ms\n", i, det[i].ms_draw, det[i].ms_anchor, det[i].ms_fit, det[i].ms_validate);
   }
   std::vector<KeyLine> kl = group_and_flatten(det, sz, scale);
   select_lines(kl, nfeatures, img_w, img_h, min_length);
