@@ -206,7 +206,7 @@ def main():
             fe[name + "_us"] = round(e0.elapsed_time(e1) / 50 * 1e3, 2)
         # ORB(2000) extraction on a 640x480 frame resident in HBM (configs[1] front end)
         from plvs_amd.orb import ORBextractor
-        from tests.oracle_lib import golden
+        from plvs_amd.pgm import golden_frame as golden
         frames = [torch.from_numpy(golden(n)).cuda() for n in ("aloe_640x480.pgm", "aloe_640x480_shift.pgm",
                                                                 "cones_640x480.pgm")]
         ext = ORBextractor(2000, 1.2, 8, 20, 7)

@@ -190,7 +190,9 @@ int plvs_hip_lines_extract(plvs_lines* h, const uint8_t* image, int w, int hh, i
                            plvs_keyline* keylines, uint8_t* desc, int cap, int* n);
 int plvs_hip_lines_extract_dev(plvs_lines* h, const uint8_t* d_image, int w, int hh, int stride,
                                plvs_keyline* keylines, uint8_t* desc, int cap, int* n);
-/* ms of the last call: [0] device maps + D2H, [1] host linking/fitting/grouping, [2] LBD. */
+/* ms of the last call: [0] device maps + D2H, [1] host linking/fitting/grouping, [2] LBD;
+ * split of [1]: [3] EdgeDrawing of octave 0, [4] tail of the (overlapped) line fitting,
+ * [5] grouping + selection. */
 int plvs_hip_lines_last_stage_ms(plvs_lines* h, double* ms, int cap);
 /* Parity accessors of the last call: which = 0 blurred octave image (u8), 1 dx,
  * 2 dy (s16), 3 packed map (u16: bits 0-8 gradient/4, bit 15 = |dx| < |dy|). */

@@ -327,7 +327,7 @@ struct plvs_lines {
   int line_cap = 0;
   hipStream_t stream = nullptr;
   std::vector<OctaveDetector> det;
-  double last_ms[4] = {};
+  double last_ms[6] = {};
 };
 
 namespace {
@@ -446,10 +446,25 @@ int lines_extract_body(plvs_lines* o, plvs_keyline* keylines, uint8_t* desc, int
   PLVS_KERNEL_CHECK();
   PLVS_HIP_TRY(hipStreamSynchronize(s));
   const double t1 = now_ms();
-  // ---- host, phase 1: EdgeDrawing (sequential per octave), one thread per octave
+  // ---- host: EdgeDrawing is sequential per octave (one routing thread each); every finished
+  // edge chain is fitted independently, so fitting threads consume batches of chains while
+  // the routing is still running.  Results are concatenated in chain order (= the
+  // reference's line order).
   o->det.resize(n);
   {
-    auto work = [&](int i) {
+    constexpr int kBatch = 24;       // chains per fitting task
+    constexpr int kFitThreads = 4;
+    struct OctaveWork {
+      ChainProgress prog;
+      std::atomic<int> next{0};                   // next batch to claim
+      std::vector<std::vector<Segment>> out;      // per batch
+    };
+    std::vector<OctaveWork> work(n);
+    for (int i = 0; i < n; ++i) {
+      o->det[i].progress = &work[i].prog;
+      work[i].out.resize((size_t)o->sizes[i].first * o->sizes[i].second / 100 / kBatch + 2);
+    }
+    auto route = [&](int i) {
       OctaveMaps m;
       m.w = o->sizes[i].first; m.h = o->sizes[i].second;
       m.gd = o->h_gd[i]; m.dx = o->h_dx[i]; m.dy = o->h_dy[i];
@@ -457,52 +472,52 @@ int lines_extract_body(plvs_lines* o, plvs_keyline* keylines, uint8_t* desc, int
       // on "failure: lines extraction on octave i" the octave contributes no lines
       (void)o->det[i].prepare(m, o->ed);
     };
-    std::vector<std::thread> th;
-    for (int i = 1; i < n; ++i) th.emplace_back(work, i);
-    work(0);
-    for (auto& t : th) t.join();
-  }
-  // ---- host, phase 2: the edge chains are fitted independently -> balanced tasks over a
-  // few threads, results concatenated in chain order (the reference's line order)
-  {
-    struct Task { int octave, c0, c1; std::vector<Segment> out; };
-    std::vector<Task> tasks;
-    size_t total = 0;
-    for (int i = 0; i < n; ++i)
-      for (int c = 0; c < o->det[i].num_chains(); ++c) total += o->det[i].chain_pixels(c);
-    const int kThreads = 6;
-    const size_t per_task = total / (kThreads * 2) + 1;
-    for (int i = 0; i < n; ++i) {
-      int c0 = 0;
-      size_t acc = 0;
-      const int nc = o->det[i].num_chains();
-      for (int c = 0; c < nc; ++c) {
-        acc += o->det[i].chain_pixels(c);
-        if (acc >= per_task || c == nc - 1) {
-          tasks.push_back(Task{i, c0, c + 1, {}});
-          c0 = c + 1;
-          acc = 0;
-        }
-      }
-    }
-    std::atomic<int> next(0);
-    auto worker = [&]() {
+    // claims and fits ready batches until every octave is routed and drained
+    auto fit = [&]() {
       for (;;) {
-        const int t = next.fetch_add(1);
-        if (t >= (int)tasks.size()) break;
-        o->det[tasks[t].octave].fit_range(tasks[t].c0, tasks[t].c1, tasks[t].out);
+        bool all_drained = true, did = false;
+        for (int i = 0; i < n; ++i) {
+          OctaveWork& wk = work[i];
+          const int done = wk.prog.done.load(std::memory_order_acquire);
+          const int ready = wk.prog.ready.load(std::memory_order_acquire);
+          int b = wk.next.load(std::memory_order_relaxed);
+          const int c0 = b * kBatch;
+          const bool full = ready >= c0 + kBatch, tail = done && ready > c0;
+          if (full || tail) {
+            all_drained = false;
+            if (wk.next.compare_exchange_strong(b, b + 1)) {
+              const int c1 = full ? c0 + kBatch : ready;
+              o->det[i].fit_range(c0, c1, wk.out[b]);
+              did = true;
+            }
+          } else if (!done) {
+            all_drained = false;
+          }
+        }
+        if (all_drained) break;
+        if (!did) __builtin_ia32_pause();
       }
     };
     std::vector<std::thread> th;
-    for (int i = 1; i < kThreads && i < (int)tasks.size(); ++i) th.emplace_back(worker);
-    worker();
+    for (int i = 1; i < n; ++i) th.emplace_back([&, i]() { route(i); fit(); });
+    for (int i = 0; i < kFitThreads; ++i) th.emplace_back(fit);
+    route(0);
+    fit();
     for (auto& t : th) t.join();
-    for (Task& t : tasks)
-      o->det[t.octave].segments.insert(o->det[t.octave].segments.end(), t.out.begin(), t.out.end());
+    for (int i = 0; i < n; ++i) {
+      o->det[i].progress = nullptr;
+      if (o->det[i].failed) continue;
+      for (auto& v : work[i].out) o->det[i].segments.insert(o->det[i].segments.end(), v.begin(), v.end());
+    }
   }
+  const double t1a = t1 + o->det[0].ms_draw;   // octave 0's routing; fitting overlaps it
+  const double t1b = now_ms();
   std::vector<KeyLine> kl = group_and_flatten(o->det, o->sizes, o->scale);
   select_lines(kl, o->nfeatures, o->img_w, o->img_h, o->min_length);
   const double t2 = now_ms();
+  o->last_ms[3] = t1a - t1;   // EdgeDrawing
+  o->last_ms[4] = t1b - t1a;  // line fitting + validation still running after the routing
+  o->last_ms[5] = t2 - t1b;   // octave grouping + selection
   const int nl = (int)kl.size();
   *n_out = nl;
   if (nl == 0) {
@@ -647,7 +662,7 @@ int plvs_hip_lines_extract_dev(plvs_lines* o, const uint8_t* d_image, int w, int
 
 int plvs_hip_lines_last_stage_ms(plvs_lines* o, double* ms, int cap) {
   PLVS_REQUIRE(o && ms, "null argument");
-  for (int i = 0; i < 3 && i < cap; ++i) ms[i] = o->last_ms[i];
+  for (int i = 0; i < 6 && i < cap; ++i) ms[i] = o->last_ms[i];
   return PLVS_OK;
 }
 

@@ -13,9 +13,11 @@
 #include <time.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <utility>
 #include <vector>
 
@@ -102,10 +104,20 @@ inline double clock_ms() {
   return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
+// Progress of one octave's EdgeDrawing, read by the threads that fit its chains while
+// the routing is still running: chains [0, ready) are complete; done is set at the end.
+struct ChainProgress {
+  std::atomic<int> ready{0};
+  std::atomic<int> done{0};
+};
+
 class OctaveDetector {
  public:
   std::vector<Segment> segments;
-  double ms_draw = 0, ms_fit = 0, ms_validate = 0, ms_anchor = 0;   // wall-clock split of the last run
+  ChainProgress* progress = nullptr;   // optional; set by the caller before prepare()
+  double ms_draw = 0, ms_fit = 0, ms_validate = 0, ms_anchor = 0, ms_route = 0;
+  int n_anchor = 0, n_walked = 0;
+  bool failed = false;   // wall-clock split of the last run
 
   // returns false on the reference's failure paths ("lines not found", buffer overrun)
   bool run(const OctaveMaps& m, const EdParams& prm) {
@@ -127,7 +139,8 @@ class OctaveDetector {
   EdParams P;
   std::vector<uint16_t> cx, cy;       // edge chains, pixel by pixel
   std::vector<uint16_t> fx_, fy_, sx_, sy_;   // scratch kept across calls (no reallocation per frame)
-  std::vector<uint8_t> used;
+  std::vector<uint16_t> wk_;
+  int n_chains = 0;
   std::vector<uint32_t> cstart;       // chain c = [cstart[c], cstart[c+1])
   double logNT = 0;
   struct FitState { float ata[4] = {0, 0, 0, 0}, atv[2] = {0, 0}; };
@@ -167,92 +180,106 @@ class OctaveDetector {
         }
     }
     const double ta = clock_ms();
-    used.assign(npix, 0);
-    // the two halves of every edge, as the reference stores them
-    std::vector<uint16_t>& fx = fx_; std::vector<uint16_t>& fy = fy_;
-    std::vector<uint16_t>& sx = sx_; std::vector<uint16_t>& sy = sy_;
-    fx.clear(); fy.clear(); sx.clear(); sy.clear();
-    fx.reserve(cap / 4); fy.reserve(cap / 4); sx.reserve(cap / 4); sy.reserve(cap / 4);
-    std::vector<uint32_t> fstart, sstart;
+    // working copy of the packed map: bits 0..8 magnitude, bit 15 orientation, bit 14 = visited
+    wk_.resize(npix);
+    memcpy(wk_.data(), maps.gd, npix * sizeof(uint16_t));
+    uint16_t* wk = wk_.data();
+    constexpr uint16_t kUsed = 0x4000, kMag = 0x1ff;
+    // the two halves of every edge, as the reference stores them (capacity = its buffer size)
+    fx_.resize(cap); fy_.resize(cap); sx_.resize(cap); sy_.resize(cap);
+    uint16_t* half_x[2] = {fx_.data(), sx_.data()};
+    uint16_t* half_y[2] = {fy_.data(), sy_.data()};
+    size_t half_n[2] = {0, 0};
     enum { kUp = 1, kRight = 2, kDown = 3, kLeft = 4 };
-    // candidate moves per heading: {diag1, straight, diag3} as (dx, dy)
+    // candidate moves per heading: {diag1, straight, diag3} as (dx, dy) and as index deltas
     static const int mv[5][3][2] = {{{0, 0}, {0, 0}, {0, 0}},
                                     {{1, -1}, {0, -1}, {-1, -1}},   // up
                                     {{1, -1}, {1, 0}, {1, 1}},      // right
                                     {{1, 1}, {0, 1}, {-1, 1}},      // down
                                     {{-1, -1}, {-1, 0}, {-1, 1}}};  // left
+    int dl[5][3];
+    for (int hdg = 0; hdg < 5; ++hdg)
+      for (int k = 0; k < 3; ++k) dl[hdg][k] = mv[hdg][k][1] * W + mv[hdg][k][0];
+    const int Wm1 = W - 1, Hm1 = H - 1;
     int lastX = 0, lastY = 0;   // persists across walks, as in the reference
-    auto at_border = [&](int heading, int x, int y) {
-      switch (heading) {
-        case kRight: return x == W - 1 || y == 0 || y == H - 1;
-        case kLeft: return x == 0 || y == 0 || y == H - 1;
-        case kDown: return x == 0 || x == W - 1 || y == H - 1;
-        default: return x == 0 || x == W - 1 || y == 0;
-      }
-    };
-    auto walk = [&](int x, int y, int heading, std::vector<uint16_t>& ox, std::vector<uint16_t>& oy) -> bool {
+    size_t walked = 0;
+    auto walk = [&](int x, int y, int heading, int half) -> bool {
+      uint16_t* ox = half_x[half];
+      uint16_t* oy = half_y[half];
+      size_t n = half_n[half];
       int idx = y * W + x;
-      while (g(idx) > 0 && !used[idx]) {
-        used[idx] = 1;
-        if (ox.size() >= cap) return false;
-        ox.push_back((uint16_t)x);
-        oy.push_back((uint16_t)y);
-        int want = 0;
-        int go = 0;
-        if (horizontal(idx)) {
-          if (heading == kUp || heading == kDown) want = (x > lastX) ? kRight : kLeft;
-          lastX = x; lastY = y;
-          if (heading == kRight || want == kRight) go = kRight;
-          else if (heading == kLeft || want == kLeft) go = kLeft;
+      uint16_t v = wk[idx];
+      // continue while the magnitude is non-zero and the pixel is unvisited
+      while ((v & kMag) != 0 && (v & kUsed) == 0) {
+        wk[idx] = v | kUsed;
+        if (n >= cap) return false;
+        ox[n] = (uint16_t)x;
+        oy[n++] = (uint16_t)y;
+        int go;
+        if (v & 0x8000u) {   // horizontal edge here
+          if (heading == kUp || heading == kDown) go = (x > lastX) ? kRight : kLeft;
+          else go = heading;
         } else {
-          if (heading == kRight || heading == kLeft) want = (y > lastY) ? kDown : kUp;
-          lastX = x; lastY = y;
-          if (heading == kDown || want == kDown) go = kDown;
-          else if (heading == kUp || want == kUp) go = kUp;
+          if (heading == kRight || heading == kLeft) go = (y > lastY) ? kDown : kUp;
+          else go = heading;
         }
-        if (go) {
-          if (at_border(go, x, y)) break;
-          // the reference compares the neighbours' magnitudes truncated to 8 bits
-          const int g1 = g((y + mv[go][0][1]) * W + x + mv[go][0][0]) & 0xff;
-          const int g2 = g((y + mv[go][1][1]) * W + x + mv[go][1][0]) & 0xff;
-          const int g3 = g((y + mv[go][2][1]) * W + x + mv[go][2][0]) & 0xff;
-          const int pick = (g1 >= g2 && g1 >= g3) ? 0 : ((g3 >= g2 && g3 >= g1) ? 2 : 1);
-          x += mv[go][pick][0];
-          y += mv[go][pick][1];
-          heading = go;
+        lastX = x; lastY = y;
+        // image border in the direction of travel ends the walk
+        bool border;
+        switch (go) {
+          case kRight: border = x == Wm1 || y == 0 || y == Hm1; break;
+          case kLeft: border = x == 0 || y == 0 || y == Hm1; break;
+          case kDown: border = x == 0 || x == Wm1 || y == Hm1; break;
+          default: border = x == 0 || x == Wm1 || y == 0; break;
         }
-        idx = y * W + x;
+        if (border) break;
+        // the reference compares the neighbours' magnitudes truncated to 8 bits
+        const int g1 = wk[idx + dl[go][0]] & 0xff;
+        const int g2 = wk[idx + dl[go][1]] & 0xff;
+        const int g3 = wk[idx + dl[go][2]] & 0xff;
+        const int pick = (g1 >= g2 && g1 >= g3) ? 0 : ((g3 >= g2 && g3 >= g1) ? 2 : 1);
+        x += mv[go][pick][0];
+        y += mv[go][pick][1];
+        idx += dl[go][pick];
+        heading = go;
+        v = wk[idx];
       }
+      walked += n - half_n[half];
+      half_n[half] = n;
       return true;
     };
+    // chains are published edge by edge: cx/cy/cstart never reallocate during the routing
+    cx.resize(2 * cap); cy.resize(2 * cap);
+    cstart.resize(max_edges + 2);
+    n_chains = 0;
+    size_t w = 0;
+    cstart[0] = 0;
+    const uint16_t* fx = half_x[0]; const uint16_t* fy = half_y[0];
+    const uint16_t* sx = half_x[1]; const uint16_t* sy = half_y[1];
     for (size_t a = 0; a < ax.size(); ++a) {
       const int x = ax[a], y = ay[a], idx = y * W + x;
-      if (used[idx]) continue;
-      if (fstart.size() >= max_edges) return false;
-      const size_t f0 = fx.size(), s0 = sx.size();
-      const bool hor = horizontal(idx);
-      if (!walk(x, y, hor ? kRight : kDown, fx, fy)) return false;
-      used[idx] = 0;   // the anchor is walked again as the head of the second half
-      if (!walk(x, y, hor ? kLeft : kUp, sx, sy)) return false;
-      if ((int)(fx.size() - f0) + (int)(sx.size() - s0) < P.min_line_len + 1) {
-        fx.resize(f0); fy.resize(f0); sx.resize(s0); sy.resize(s0);   // short edge: dropped (pixels stay marked)
+      if (wk[idx] & kUsed) continue;
+      if ((size_t)n_chains >= max_edges) return false;
+      const size_t f0 = half_n[0], s0 = half_n[1];
+      const bool hor = (wk[idx] & 0x8000u) != 0;
+      if (!walk(x, y, hor ? kRight : kDown, 0)) return false;
+      wk[idx] &= (uint16_t)~kUsed;   // the anchor is walked again as the head of the second half
+      if (!walk(x, y, hor ? kLeft : kUp, 1)) return false;
+      if ((int)(half_n[0] - f0) + (int)(half_n[1] - s0) < P.min_line_len + 1) {
+        half_n[0] = f0; half_n[1] = s0;   // short edge: dropped (pixels stay marked)
       } else {
-        fstart.push_back((uint32_t)f0);
-        sstart.push_back((uint32_t)s0);
+        // the edge = first half reversed + second half without its head (the anchor)
+        for (size_t i = half_n[0]; i-- > f0;) { cx[w] = fx[i]; cy[w++] = fy[i]; }
+        for (size_t i = s0 + 1; i < half_n[1]; ++i) { cx[w] = sx[i]; cy[w++] = sy[i]; }
+        cstart[++n_chains] = (uint32_t)w;
+        if (progress) progress->ready.store(n_chains, std::memory_order_release);
       }
     }
     ms_anchor = ta - t_begin;
-    if (fx.empty() || sx.empty()) return false;   // "Edge drawing Error: lines not found"
-    fstart.push_back((uint32_t)fx.size());
-    sstart.push_back((uint32_t)sx.size());
-    cx.clear(); cy.clear(); cstart.clear();
-    for (size_t e = 0; e + 1 < fstart.size(); ++e) {
-      cstart.push_back((uint32_t)cx.size());
-      for (int i = (int)fstart[e + 1] - 1; i >= (int)fstart[e]; --i) { cx.push_back(fx[i]); cy.push_back(fy[i]); }
-      for (uint32_t i = sstart[e] + 1; i < sstart[e + 1]; ++i) { cx.push_back(sx[i]); cy.push_back(sy[i]); }
-    }
-    cstart.push_back((uint32_t)cx.size());
-    return true;
+    ms_route = clock_ms() - ta;
+    n_anchor = (int)ax.size();
+    n_walked = (int)walked;
+    return n_chains > 0;   // otherwise "Edge drawing Error: lines not found"
   }
 
   static void solve(const FitState& F, double eq[2]) {
@@ -333,7 +360,8 @@ class OctaveDetector {
   }
 
  public:
-  int num_chains() const { return cstart.empty() ? 0 : (int)cstart.size() - 1; }
+  int num_chains() const { return n_chains; }
+  int max_chains() const { return (int)((size_t)W * H / 100) + 1; }
   size_t chain_pixels(int c) const { return cstart[c + 1] - cstart[c]; }
   // EdgeDrawing only (the sequential part); the chains can then be fitted in
   // parallel with fit_range — every chain is fitted independently of the others.
@@ -344,7 +372,9 @@ class OctaveDetector {
     const double t0 = clock_ms();
     const bool ok = draw_edges();
     ms_draw = clock_ms() - t0;
-    if (!ok) { cx.clear(); cy.clear(); cstart.clear(); }
+    if (!ok) n_chains = 0;
+    failed = !ok;
+    if (progress) progress->done.store(1, std::memory_order_release);
     return ok;
   }
 

@@ -87,9 +87,10 @@ class LineExtractor:
         return self._kl[:n.value].copy(), self._desc[:n.value].copy()
 
     def stage_ms(self):
-        ms = (ctypes.c_double * 4)()
-        _lib.check(L.plvs_hip_lines_last_stage_ms(self._h, ms, 4))
-        return dict(zip(["device_maps", "host_link_fit_group", "lbd"], list(ms)[:3]))
+        ms = (ctypes.c_double * 6)()
+        _lib.check(L.plvs_hip_lines_last_stage_ms(self._h, ms, 6))
+        return dict(zip(["device_maps", "host_link_fit_group", "lbd", "host_edge_drawing",
+                         "host_line_fit", "host_group_select"], list(ms)))
 
     def octave_map(self, octave, which):
         """which: 'blur' (u8), 'dx', 'dy' (s16), 'gd' (u16 packed)"""

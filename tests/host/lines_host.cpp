@@ -26,7 +26,7 @@ extern "C" int hostlines_run(int noct, const int* sizes, const uint16_t* const* 
     if (!det[i].run(m, P)) det[i].segments.clear();
     per_octave[i] = (int)det[i].segments.size();
     if (getenv("PLVS_LINES_PROFILE"))
-      fprintf(stderr, "octave %d: draw %.3f ms (anchors %.3f), fit %.3f ms, validate %.3f ms\n", i, det[i].ms_draw, det[i].ms_anchor, det[i].ms_fit, det[i].ms_validate);
+      fprintf(stderr, "octave %d: draw %.3f ms (anchors %.3f, route %.3f, %d anchors, %d walked, %d chains), fit %.3f ms\n", i, det[i].ms_draw, det[i].ms_anchor, det[i].ms_route, det[i].n_anchor, det[i].n_walked, det[i].num_chains(), det[i].ms_fit);
   }
   std::vector<KeyLine> kl = group_and_flatten(det, sz, scale);
   select_lines(kl, nfeatures, img_w, img_h, min_length);

@@ -207,13 +207,7 @@ class OracleLines:
         return self.lib.oracle_lines_num_in_octave(self.h, octave)
 
 
-def read_pgm(path):
-    with open(path, "rb") as f:
-        data = f.read()
-    parts = data.split(None, 4)
-    assert parts[0] == b"P5" and int(parts[3]) == 255
-    w, h = int(parts[1]), int(parts[2])
-    return np.frombuffer(data, np.uint8, w * h, len(data) - w * h).reshape(h, w).copy()
+from plvs_amd.pgm import read_pgm  # noqa: E402
 
 
 def golden(name):
