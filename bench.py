@@ -237,16 +237,13 @@ def main():
                 lstage[k] = lstage.get(k, 0.0) + v
         lines_ms = (time.perf_counter() - t0) / nrep * 1e3
         # the reference extracts points and lines on two host threads (src/Frame.cc:503-508)
-        import threading
+        from plvs_amd.frame import extract_frame
         ext2 = ORBextractor(2000, 1.2, 8, 20, 7)
         for i in range(4):
-            ext2(frames[i % 3])
+            extract_frame(ext2, lext, frames[i % 3])
         t0 = time.perf_counter()
         for i in range(nrep):
-            th = threading.Thread(target=lext, args=(frames[i % 3],))
-            th.start()
-            mono, kps, desc = ext2(frames[i % 3])
-            th.join()
+            extract_frame(ext2, lext, frames[i % 3])
         both_ms = (time.perf_counter() - t0) / nrep * 1e3
         ext2.close()
         lext.close()

@@ -200,6 +200,17 @@ int plvs_hip_lines_octave_size(plvs_lines* h, int octave, int* w, int* hh);
 int plvs_hip_lines_download_map(plvs_lines* h, int octave, int which, void* out);
 int plvs_hip_lines_num_in_octave(plvs_lines* h, int octave);
 
+/* ------------------------------------------------------------ Frame extraction
+ * Points and lines of one image, extracted concurrently on two host threads
+ * (each extractor drives its own stream), as Frame::Frame does with threadLeft /
+ * threadLines (src/Frame.cc:503-508).  Arguments as in plvs_hip_orb_extract_dev
+ * and plvs_hip_lines_extract_dev; the ORB status is returned first. */
+int plvs_hip_frame_extract_dev(plvs_orb* orb, plvs_lines* lines, const uint8_t* d_image, int w,
+                               int hh, int stride, int lap0, int lap1, plvs_keypoint* kps,
+                               uint8_t* desc, int kp_cap, int* n_kp, int* mono_index,
+                               plvs_keyline* keylines, uint8_t* line_desc, int line_cap,
+                               int* n_lines);
+
 /* --------------------------------------------------------- TSDF (open_chisel)
  * Chunked (16^3) spatially hashed TSDF with per-point ray integration.
  *

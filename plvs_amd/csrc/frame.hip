@@ -1,0 +1,27 @@
+// Frame-level extraction: the ORB extractor and the line extractor of one image run on
+// two host threads, each driving its own stream — what Frame::Frame does with
+// threadLeft / threadLines (reference src/Frame.cc:503-508 mono, :290-330 stereo).
+#include <cstdio>
+#include <thread>
+
+#include "common.hpp"
+
+extern "C" int plvs_hip_frame_extract_dev(plvs_orb* orb, plvs_lines* lines, const uint8_t* d_image, int w,
+                                          int h, int stride, int lap0, int lap1, plvs_keypoint* kps,
+                                          uint8_t* desc, int kp_cap, int* n_kp, int* mono_index,
+                                          plvs_keyline* keylines, uint8_t* line_desc, int line_cap,
+                                          int* n_lines) {
+  PLVS_REQUIRE(orb && lines && n_kp && mono_index && n_lines, "null argument");
+  int rc_lines = PLVS_OK;
+  char lines_error[512] = "";
+  std::thread tl([&]() {
+    rc_lines = plvs_hip_lines_extract_dev(lines, d_image, w, h, stride, keylines, line_desc, line_cap, n_lines);
+    if (rc_lines != PLVS_OK) snprintf(lines_error, sizeof lines_error, "%s", plvs_hip_last_error());   // thread-local
+  });
+  const int rc_orb = plvs_hip_orb_extract_dev(orb, d_image, w, h, stride, lap0, lap1, kps, desc, kp_cap, n_kp,
+                                              mono_index);
+  tl.join();
+  if (rc_orb != PLVS_OK) return rc_orb;
+  if (rc_lines != PLVS_OK) plvs::set_error("%s", lines_error);
+  return rc_lines;
+}

@@ -497,9 +497,24 @@ inline std::vector<KeyLine> group_and_flatten(const std::vector<OctaveDetector>&
     const float dx = (float)fabs(s.ep[0] - s.ep[2]), dy = (float)fabs(s.ep[1] - s.ep[3]);
     return std::sqrt(dx * dx + dy * dy);
   };
-  for (int i = 0; i < (int)oct[0].segments.size(); ++i) all.push_back(Ref{0, i, groups++, seg_len(oct[0].segments[i])});
+  // per already-seen line, in discovery order: what the comparison below reads of it
+  // (direction, scaled distance to the origin, scaled endpoints, scaled length)
+  std::vector<float> a_dir, a_rho, a_len, a_ep;
+  size_t total = 0;
+  for (int o = 0; o < no; ++o) total += oct[o].segments.size();
+  all.reserve(total); a_dir.reserve(total); a_rho.reserve(total); a_len.reserve(total); a_ep.reserve(4 * total);
+  auto remember = [&](int o, int i, int group, float length) {
+    const Segment& sg = oct[o].segments[i];
+    all.push_back(Ref{o, i, group, length});
+    a_dir.push_back(sg.direction);
+    a_rho.push_back((float)(scale[o] * fabs(sg.eq[2])));
+    a_len.push_back(length);
+    for (int k = 0; k < 4; ++k) a_ep.push_back(scale[o] * sg.ep[k]);
+  };
+  for (int i = 0; i < (int)oct[0].segments.size(); ++i) remember(0, i, groups++, seg_len(oct[0].segments[i]));
   const double twoPI = 2 * M_PI;
   for (int o = 1; o < no; ++o) {
+    const size_t lower = all.size();   // lines of the octaves below
     for (int i = 0; i < (int)oct[o].segments.size(); ++i) {
       const Segment& cur = oct[o].segments[i];
       const float rho1 = (float)(scale[o] * fabs(cur.eq[2]));
@@ -507,18 +522,15 @@ inline std::vector<KeyLine> group_and_flatten(const std::vector<OctaveDetector>&
       float near_thr = (tv > 6) ? tv : 6;
       near_thr = (near_thr < 12) ? near_thr : 12;
       const float length = scale[o] * seg_len(cur);
+      const float lp[4] = {scale[o] * cur.ep[0], scale[o] * cur.ep[1], scale[o] * cur.ep[2], scale[o] * cur.ep[3]};
+      const float cdir = cur.direction;
       float best = 12;
       int best_ref = 0;
-      for (size_t r = 0; r < all.size(); ++r) {
-        if (all[r].octave == o) break;
-        const Segment& oth = oct[all[r].octave].segments[all[r].id];
-        const float ddir = (float)fabs(cur.direction - oth.direction);
+      for (size_t r = 0; r < lower; ++r) {
+        const float ddir = (float)fabs(cdir - a_dir[r]);
         if (ddir > 0.1745 && (twoPI - ddir > 0.1745)) continue;
-        const float so = scale[all[r].octave];
-        const float rho2 = (float)(so * fabs(oth.eq[2]));
-        if ((float)fabs(rho1 - rho2) > near_thr) continue;
-        const float lp[4] = {scale[o] * cur.ep[0], scale[o] * cur.ep[1], scale[o] * cur.ep[2], scale[o] * cur.ep[3]};
-        const float np[4] = {so * oth.ep[0], so * oth.ep[1], so * oth.ep[2], so * oth.ep[3]};
+        if ((float)fabs(rho1 - a_rho[r]) > near_thr) continue;
+        const float* np = &a_ep[4 * r];
         auto dist = [](float ax, float ay, float bx, float by) {
           const float dx = ax - bx, dy = ay - by;
           return std::sqrt(dx * dx + dy * dy);
@@ -528,23 +540,27 @@ inline std::vector<KeyLine> group_and_flatten(const std::vector<OctaveDetector>&
         d = dist(lp[2], lp[3], np[2], np[3]); mn = (d < mn) ? d : mn; mx = (d > mx) ? d : mx;
         d = dist(lp[0], lp[1], np[2], np[3]); mn = (d < mn) ? d : mn; mx = (d > mx) ? d : mx;
         d = dist(lp[2], lp[3], np[0], np[1]); mn = (d < mn) ? d : mn; mx = (d > mx) ? d : mx;
-        if ((mx < 0.8 * (length + all[r].length)) && (mn < best)) {
+        if ((mx < 0.8 * (length + a_len[r])) && (mn < best)) {
           best = mn;
           best_ref = (int)r;
         }
       }
-      const int group = (best < 12) ? all[best_ref].group : groups++;
-      all.push_back(Ref{o, i, group, length});
+      remember(o, i, (best < 12) ? all[best_ref].group : groups++, length);
     }
   }
   // ScaleLines: group -> members in discovery order; flattened group by group
-  std::vector<std::vector<int>> members(groups);
-  for (size_t r = 0; r < all.size(); ++r) members[all[r].group].push_back((int)r);
+  std::vector<int> first(groups + 1, 0), order(all.size());   // stable counting sort by group
+  for (const Ref& r : all) ++first[r.group + 1];
+  for (int gidx = 0; gidx < groups; ++gidx) first[gidx + 1] += first[gidx];
+  {
+    std::vector<int> fill(first.begin(), first.end() - 1);
+    for (size_t r = 0; r < all.size(); ++r) order[fill[all[r].group]++] = (int)r;
+  }
   std::vector<KeyLine> out;
   out.reserve(all.size());
   for (int gidx = 0; gidx < groups; ++gidx)
-    for (int r : members[gidx]) {
-      const Ref& ref = all[r];
+    for (int m = first[gidx]; m < first[gidx + 1]; ++m) {
+      const Ref& ref = all[order[m]];
       const Segment& s = oct[ref.octave].segments[ref.id];
       const float direction = s.direction;
       const float s1 = s.ep[0], s2 = s.ep[1], e1 = s.ep[2], e2 = s.ep[3];

@@ -136,3 +136,25 @@ def test_hip_lines_device_input_resize_and_empty(oracle):
     kl0, d0 = dev(flat)
     assert len(kl0) == 0 and d0.shape == (0, 32)
     dev.close()
+
+
+@pytest.mark.gpu
+def test_hip_frame_extract_points_and_lines_together(oracle):
+    """Frame.cc:503-508: ORB and line extraction of one image on two threads — the
+    combined entry point returns exactly what the two extractors return alone."""
+    import torch
+    from plvs_amd.frame import extract_frame
+    from plvs_amd.lines import LineExtractor
+    from plvs_amd.orb import ORBextractor
+    orb, lines = ORBextractor(1000, 1.2, 8, 20, 7), LineExtractor(100)
+    oorb, olines = oracle.orb(1000, 1.2, 8, 20, 7), oracle.lines()
+    for name in IMAGES[:2]:
+        img = golden(name)
+        for _ in range(3):   # repeated calls: the overlapped host threads must not disturb the order
+            mono, kps, desc, kl, ldesc = extract_frame(orb, lines, torch.from_numpy(img).cuda())
+            omono, okps, odesc = oorb.extract(img)
+            okl, oldesc = olines.extract(img)
+            assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
+            assert kl.tobytes() == okl.tobytes() and np.array_equal(ldesc, oldesc)
+    orb.close()
+    lines.close()
