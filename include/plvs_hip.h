@@ -211,6 +211,11 @@ int plvs_hip_frame_extract_dev(plvs_orb* orb, plvs_lines* lines, const uint8_t* 
                                plvs_keyline* keylines, uint8_t* line_desc, int line_cap,
                                int* n_lines);
 
+/* Device self-test backing the TSDF chain kernel: counts the binary32 significands b =
+ * 1.m * 2^exponent for which the kernel's reciprocal (v_rcp_f32 + one Newton step) differs
+ * from the correctly rounded 1/b.  Expected: 0 for every exponent the kernel admits. */
+int plvs_hip_selftest_rcp(int exponent, uint32_t* mismatches);
+
 /* --------------------------------------------------------- TSDF (open_chisel)
  * Chunked (16^3) spatially hashed TSDF with per-point ray integration.
  *

@@ -42,6 +42,10 @@ constexpr int kNumStages = 6;
 const char* const kStageNames[kNumStages] = {"ray_count", "scan", "ray_fill", "radix_sort",
                                              "expand_records", "chain_runs"};
 
+#ifndef PLVS_CHAIN_PROBE
+#define PLVS_CHAIN_PROBE 0
+#endif
+
 struct Counters {           // device-side, read back once per call
   uint32_t total_visits;
   int32_t num_chunks;
@@ -49,6 +53,10 @@ struct Counters {           // device-side, read back once per call
   uint32_t num_heads;
   uint32_t num_updated;
   uint32_t max_run;
+#if PLVS_CHAIN_PROBE
+  uint32_t pad_;
+  unsigned long long probe[6];   // instrumentation build only
+#endif
 };
 
 __global__ void pose_prep(const float* __restrict__ Twc, int nclouds, Pose* __restrict__ poses) {
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_records(
     const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses,
     const int32_t* __restrict__ slot_ids, float2* __restrict__ rec, uint32_t* __restrict__ rec_c,
     uint32_t* __restrict__ heads, uint32_t* __restrict__ updated_slots,
-    Counters* __restrict__ ctr) {
+    Counters* __restrict__ ctr, const uint32_t* __restrict__ kfid, uint32_t* __restrict__ vkfid) {
   __shared__ uint32_t wave_cnt[2][kExpandThreads / 64];
   __shared__ uint32_t block_base[2];
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -150,6 +158,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_records(
     const float u = signed_dist(pose, depth, c0, c1, c2);
     const float wu = P.weight / (2.0f * tr);
     rec[r] = make_float2(wu * u, (key != next) ? -wu : wu);
+    if (key != next) vkfid[key] = kfid ? kfid[p] : 0u;   // SetKfid: the last update of the run wins
     rec_c[r] = colour_roundtrip(rgb[3 * (size_t)p + 0]) | (colour_roundtrip(rgb[3 * (size_t)p + 1]) << 8) |
                (colour_roundtrip(rgb[3 * (size_t)p + 2]) << 16);
   }
@@ -175,84 +184,197 @@ __global__ __launch_bounds__(kExpandThreads) void expand_records(
   if (chead) updated_slots[block_base[1] + wave_cnt[1][wid] + (uint32_t)__popcll(mc & lt)] = key >> 12;
 }
 
-// One thread per voxel run: the order-dependent part only.  The operands of a
-// run are contiguous and independent of the running value, so they are
-// software-pipelined kChainDepth batches of kChainBatch records ahead of the
-// dependent mul/add/div chain; the negative weight marks the run's last record.
-// A batch without an end marker is folded branch-free.
+// The order-dependent part: one thread per voxel run, 64 runs per wave, eight records per
+// run and pass.  A single wave issues about one instruction every four cycles, and the
+// longest run of the call is a serial chain, so the kernel is built to keep the
+// instructions per step low and every wait off that chain:
+//  * Loads: a lane walking its own run touches 64 different cache lines per load
+//    instruction.  Here the wave fetches a pass cooperatively — four lanes read the eight
+//    consecutive records (64 B) of one run, sixteen runs per load instruction — and hands
+//    the records to their lanes through LDS (XOR-swizzled 16-byte units).  Four passes are
+//    in flight in registers; the LDS hop is pipelined one pass deep (four buffers, no
+//    barrier: one wave, and LDS operations of a wave execute in order).
+//  * Arithmetic: w_k = w_{k-1} + wu_k does not depend on the running sdf, so the weights and
+//    their reciprocals of the NEXT pass are computed beside the sdf recurrence of the
+//    current pass; the recurrence itself is dist_update_rcp (mul, add, mul, fma, fma).
+//    v_rcp_f32 plus one Newton step gives the correctly rounded reciprocal for every
+//    binary32 significand on gfx950 (plvs_hip_selftest_rcp checks all 2^23 of them).
+//  * A lane whose pass contains the end of its run (negative weight = last record), or an
+//    operand outside the exact range of the reciprocal form, redoes that pass step by step.
+//    Nothing is loaded there: the keyframe id of the last record is written by
+//    expand_records, the longest run is reduced once per wave.
 constexpr int kChainBatch = 8;
-constexpr int kChainDepth = 4;
+constexpr int kChainSets = 4;
 
-struct ChainBatch {
-  float2 v[kChainBatch];
+__device__ __forceinline__ float rcp_rn(float b) {
+  const float y0 = __builtin_amdgcn_rcpf(b);
+  const float e = fmaf(-b, y0, 1.0f);
+  return fmaf(e, y0, y0);
+}
+
+struct __attribute__((packed, aligned(8))) RecPair {   // two consecutive float2 records
+  float x0, y0, x1, y1;
 };
 
-__device__ __forceinline__ void chain_load(const float2* __restrict__ rec, uint32_t r, uint32_t nrec,
-                                           ChainBatch& b) {
-#pragma unroll
-  for (int j = 0; j < kChainBatch; ++j) {
-    const uint32_t rr = r + (uint32_t)j;
-    b.v[j] = rec[rr < nrec ? rr : nrec - 1];  // clamped reads past the run end are never used
-  }
-}
+// 16-byte unit u (records 2u, 2u+1) of a run inside a staging buffer
+__device__ __forceinline__ int stage_unit(int run, int u) { return run * 4 + ((u ^ (run >> 1)) & 3); }
 
-// Returns true when the run ended inside this batch (`last` = its last record).
-__device__ __forceinline__ bool chain_step(const ChainBatch& b, uint32_t r, float& s, float& w,
-                                           uint32_t& last) {
-  uint32_t signs = 0;
+__global__ __launch_bounds__(64) void chain_runs(
+    const uint32_t* __restrict__ keys, uint32_t nrec, const float2* __restrict__ rec,
+    const uint32_t* __restrict__ heads, Counters* __restrict__ ctr, float* __restrict__ sdf,
+    float* __restrict__ weight) {
+  __shared__ float4 stage[kChainSets][64 * 4];
+  const int l = threadIdx.x;
+  const uint32_t nheads = ctr->num_heads;
+  const uint32_t last_pair = nrec - 1;   // the record buffer holds at least nrec + 1 records
+  // the grid is an upper bound (the run count is only known on the device): surplus waves
+  // leave at once, and a wave takes further groups of 64 runs if the grid was capped
+  for (uint32_t group = blockIdx.x; group * 64u < nheads; group += gridDim.x) {
+    const uint32_t h = group * 64u + (uint32_t)l;
+    bool live = h < nheads;
+    const uint32_t r0 = live ? heads[h] : 0u;
+    const size_t a = live ? (size_t)keys[r0] : 0;   // slot*4096 + vid
+    float s = live ? sdf[a] : 0.0f;
+    float w = live ? weight[a] : 1.0f;
+    uint32_t my_len = 0;
+    // load i serves runs 16 i .. 16 i + 15; this lane fetches records 2q, 2q+1 (q = lane & 3)
+    // of run 16 i + (lane >> 2)
+    uint32_t base[4];
 #pragma unroll
-  for (int j = 0; j < kChainBatch; ++j) signs |= __float_as_uint(b.v[j].y);
-  if (!(signs >> 31)) {  // common case: the whole batch belongs to the run
+    for (int i = 0; i < 4; ++i) base[i] = (uint32_t)__shfl((int)r0, 16 * i + (l >> 2)) + 2u * (uint32_t)(l & 3);
+    const char* const rec_bytes = reinterpret_cast<const char*>(rec);
+
+    RecPair G[kChainSets][4];
+    auto fetch = [&](uint32_t pass, RecPair (&g)[4]) {
 #pragma unroll
-    for (int j = 0; j < kChainBatch; ++j) dist_update(s, w, b.v[j].x, b.v[j].y);
-    return false;
+      for (int i = 0; i < 4; ++i)
+        g[i] = *reinterpret_cast<const RecPair*>(rec_bytes + (min(base[i] + pass * kChainBatch, last_pair) << 3));
+    };
+    auto to_stage = [&](int buf, const RecPair (&g)[4]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        stage[buf][stage_unit(16 * i + (l >> 2), l & 3)] = make_float4(g[i].x0, g[i].y0, g[i].x1, g[i].y1);
+    };
+    auto from_stage = [&](int buf, float4 (&R)[4]) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) R[u] = stage[buf][stage_unit(l, u)];
+    };
+    // weights, reciprocals and end markers of a pass, from the weight the run has before it
+    struct Prepared {
+      float x[kChainBatch], wn[kChainBatch], y[kChainBatch], wu[kChainBatch];
+      bool plain;   // the pass holds the end of the run, or a weight outside the exact range
+    };
+    auto prepare = [&](const float4 (&R)[4], float w_in, Prepared& P) {
+      uint32_t signs = 0;
+      float wk = w_in;
+#pragma unroll
+      for (int k = 0; k < kChainBatch; ++k) {
+        const float4 t = R[k >> 1];
+        P.x[k] = (k & 1) ? t.z : t.x;
+        P.wu[k] = (k & 1) ? t.w : t.y;
+        signs |= __float_as_uint(P.wu[k]);
+        wk = fabsf(P.wu[k]) + wk;
+        P.wn[k] = wk;
+        P.y[k] = rcp_rn(wk);
+      }
+      // the weights grow along the pass: the first and the last bound them all
+      P.plain = ((signs >> 31) != 0) | !(P.wn[0] >= 0x1p-20f) | !(P.wn[kChainBatch - 1] <= 0x1p40f);
+    };
+
+    static_assert(kChainSets == 4, "the rotation below is written for four register sets / buffers");
+    fetch(0, G[0]);
+    fetch(1, G[1]);
+    fetch(2, G[2]);
+    fetch(3, G[3]);
+    to_stage(0, G[0]);
+    fetch(4, G[0]);
+    to_stage(1, G[1]);
+    fetch(5, G[1]);
+    float4 R[4];
+    Prepared cur, nxt;
+    from_stage(0, R);
+    prepare(R, w, cur);
+
+    uint32_t pass = 0;
+    // Pass p: records of pass p+2 go to LDS (and their registers are refilled with pass p+6),
+    // pass p+1 is read from LDS and prepared, the recurrence of pass p runs.
+#define PLVS_CHAIN_PASS(J, CUR, NXT)                                                                      \
+  {                                                                                               \
+    PLVS_PROBE(0)                                                                                 \
+    from_stage(((J) + 1) & 3, R);                                                                 \
+    to_stage(((J) + 2) & 3, G[((J) + 2) & 3]);                                                    \
+    fetch(pass + 2 + kChainSets, G[((J) + 2) & 3]);                                               \
+    PLVS_PROBE(1)                                                                                 \
+    float s_fast = s, w_fast = w, amin = 0x1p0f, amax = 0x1p0f;                                   \
+    _Pragma("unroll") for (int k = 0; k < kChainBatch; ++k)                                       \
+        dist_update_rcp(s_fast, w_fast, CUR.x[k], CUR.wn[k], CUR.y[k], amin, amax);               \
+    PLVS_PROBE(2)                                                                                 \
+    prepare(R, CUR.wn[kChainBatch - 1], NXT);                                                     \
+    PLVS_PROBE(3)                                                                                 \
+    const bool redo = live && (CUR.plain || !(amin >= 0x1p-60f) || !(amax <= 0x1p60f));           \
+    if (__ballot(redo) != 0ull && redo) {                                                         \
+      bool fin = false;                                                                           \
+      _Pragma("unroll") for (int k = 0; k < kChainBatch; ++k) {                                   \
+        if (!fin) {                                                                               \
+          float s2 = s, w2 = w, mn = 0x1p0f, mx = 0x1p0f;                                         \
+          dist_update_rcp(s2, w2, CUR.x[k], CUR.wn[k], CUR.y[k], mn, mx);                         \
+          if ((mn >= 0x1p-60f) && (mx <= 0x1p60f) && (CUR.wn[k] >= 0x1p-20f) &&                   \
+              (CUR.wn[k] <= 0x1p40f)) {                                                           \
+            s = s2;                                                                               \
+            w = w2;                                                                               \
+          } else {                                                                                \
+            dist_update(s, w, CUR.x[k], fabsf(CUR.wu[k]));                                        \
+          }                                                                                       \
+          if (CUR.wu[k] < 0.0f) {                                                                 \
+            fin = true;                                                                           \
+            my_len = pass * kChainBatch + (uint32_t)k + 1u;                                       \
+          }                                                                                       \
+        }                                                                                         \
+      }                                                                                           \
+      if (fin) {                                                                                  \
+        sdf[a] = s;                                                                               \
+        weight[a] = w;                                                                            \
+        live = false;                                                                             \
+      }                                                                                           \
+    } else {                                                                                      \
+      s = s_fast;                                                                                 \
+      w = w_fast;                                                                                 \
+    }                                                                                             \
+    ++pass;                                                                                       \
+    PLVS_PROBE(4)                                                                                 \
+    if (__ballot(live) == 0ull) break;                                                            \
   }
-#pragma unroll
-  for (int j = 0; j < kChainBatch; ++j) {
-    dist_update(s, w, b.v[j].x, fabsf(b.v[j].y));
-    if (b.v[j].y < 0.0f) {
-      last = r + (uint32_t)j;
-      return true;
+#if PLVS_CHAIN_PROBE
+    unsigned long long pt[5] = {0, 0, 0, 0, 0}, pacc[4] = {0, 0, 0, 0};
+    const unsigned long long p_begin = clock64(), p_wall = wall_clock64();
+#define PLVS_PROBE(i)                                                                \
+  __builtin_amdgcn_sched_barrier(0);                                                 \
+  pt[i] = clock64();                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                 \
+  if ((i) > 0) pacc[(i) - 1] += pt[i] - pt[(i) - 1];
+#else
+#define PLVS_PROBE(i)
+#endif
+    for (;;) {
+      PLVS_CHAIN_PASS(0, cur, nxt)
+      PLVS_CHAIN_PASS(1, nxt, cur)
+      PLVS_CHAIN_PASS(2, cur, nxt)
+      PLVS_CHAIN_PASS(3, nxt, cur)
     }
+#undef PLVS_CHAIN_PASS
+#if PLVS_CHAIN_PROBE
+    if (l == 0) {
+      const unsigned long long key = (unsigned long long)pass << 40;
+      atomicMax(&ctr->probe[0], key | (clock64() - p_begin));
+      atomicMax(&ctr->probe[1], key | (wall_clock64() - p_wall));
+      for (int i = 0; i < 4; ++i) atomicMax(&ctr->probe[2 + i], key | pacc[i]);
+    }
+#endif
+    // longest run of the call = the serial-latency floor of this stage (reported in the stats)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) my_len = max(my_len, (uint32_t)__shfl_xor((int)my_len, off));
+    if (l == 0 && my_len > ctr->max_run) atomicMax(&ctr->max_run, my_len);
   }
-  return false;
-}
-
-__global__ __launch_bounds__(256) void chain_runs(
-    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ pts, uint32_t nrec,
-    const float2* __restrict__ rec, const uint32_t* __restrict__ heads,
-    Counters* __restrict__ ctr, const uint32_t* __restrict__ kfid, float* __restrict__ sdf,
-    float* __restrict__ weight, uint32_t* __restrict__ vkfid) {
-  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-  if (h >= ctr->num_heads) return;
-  uint32_t r = heads[h];
-  const uint32_t r0 = r;
-  const size_t a = (size_t)keys[r];  // slot*4096 + vid
-  ChainBatch b0, b1, b2, b3;
-  static_assert(kChainDepth == 4, "ring below is written for four batches in flight");
-  chain_load(rec, r, nrec, b0);
-  chain_load(rec, r + kChainBatch, nrec, b1);
-  chain_load(rec, r + 2 * kChainBatch, nrec, b2);
-  chain_load(rec, r + 3 * kChainBatch, nrec, b3);
-  float s = sdf[a], w = weight[a];
-  uint32_t last = r;
-  for (;;) {
-    if (chain_step(b0, r, s, w, last)) break;
-    chain_load(rec, r + 4 * kChainBatch, nrec, b0);
-    if (chain_step(b1, r + kChainBatch, s, w, last)) break;
-    chain_load(rec, r + 5 * kChainBatch, nrec, b1);
-    if (chain_step(b2, r + 2 * kChainBatch, s, w, last)) break;
-    chain_load(rec, r + 6 * kChainBatch, nrec, b2);
-    if (chain_step(b3, r + 3 * kChainBatch, s, w, last)) break;
-    chain_load(rec, r + 7 * kChainBatch, nrec, b3);
-    r += 4 * kChainBatch;
-  }
-  sdf[a] = s;
-  weight[a] = w;
-  vkfid[a] = kfid ? kfid[pts[last]] : 0u;  // SetKfid: the last update wins
-  // longest run of the call = the serial-latency floor of this stage (reported in the stats)
-  const uint32_t len = last - r0 + 1u;
-  if (len > ctr->max_run) atomicMax(&ctr->max_run, len);  // stale reads only cost extra atomics
 }
 
 // The truncating u8 colour mean of ColorVoxel::IntegrateSimple: order
@@ -291,6 +413,14 @@ __global__ __launch_bounds__(256) void chain_colours(
   rgbw[a] = col;
 }
 
+// Hardware assumption of chain_runs, checked exhaustively: rcp_rn(b) == RN(1/b) for every
+// significand at the given exponent.
+__global__ void selftest_rcp_kernel(int exponent, uint32_t* __restrict__ mismatches) {
+  const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  const float b = __uint_as_float(((uint32_t)(exponent + 127) << 23) | m);
+  if (__float_as_uint(rcp_rn(b)) != __float_as_uint(1.0f / b)) atomicAdd(mismatches, 1u);
+}
+
 }  // namespace
 
 struct plvs_tsdf_chisel {
@@ -317,6 +447,8 @@ struct plvs_tsdf_chisel {
   DevBuf<uint32_t> st_kfid;
   plvs_tsdf_stats stats{};
   uint32_t last_updated = 0;
+  hipStream_t side = nullptr;   // second stream for the colour chain
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // optional per-stage timing (HIP events on the caller's stream)
   bool profiling = false;
   hipEvent_t ev[kNumStages + 1] = {};
@@ -331,6 +463,18 @@ static int read_counters(plvs_tsdf_chisel* h, hipStream_t s) {
 }
 
 extern "C" {
+
+int plvs_hip_selftest_rcp(int exponent, uint32_t* mismatches) {
+  PLVS_REQUIRE(mismatches && exponent > -126 && exponent < 127, "bad argument");
+  uint32_t* d = nullptr;
+  PLVS_HIP_TRY(hipMalloc((void**)&d, sizeof(uint32_t)));
+  PLVS_HIP_TRY(hipMemset(d, 0, sizeof(uint32_t)));
+  hipLaunchKernelGGL(selftest_rcp_kernel, dim3((1u << 23) / 256), dim3(256), 0, nullptr, exponent, d);
+  hipError_t e = hipMemcpy(mismatches, d, sizeof(uint32_t), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  PLVS_HIP_TRY(e);
+  return PLVS_OK;
+}
 
 int plvs_hip_tsdf_chisel_default_params(float resolution, plvs_tsdf_chisel_params* p) {
   PLVS_REQUIRE(p, "params is null");
@@ -389,6 +533,9 @@ int plvs_hip_tsdf_chisel_create(const plvs_tsdf_chisel_params* p, plvs_tsdf_chis
   CREATE_TRY(hipMalloc((void**)&h->rgbw, nvox * sizeof(uint32_t)));
   CREATE_TRY(hipMalloc((void**)&h->d_ctr, sizeof(Counters)));
   CREATE_TRY(hipHostMalloc((void**)&h->h_ctr, sizeof(Counters)));
+  CREATE_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  CREATE_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
 #undef CREATE_TRY
   *out = h;
   int rc = plvs_hip_tsdf_chisel_clear(h);
@@ -410,6 +557,9 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   (void)hipFree(h->rgbw);
   (void)hipFree(h->d_ctr);
   if (h->h_ctr) (void)hipHostFree(h->h_ctr);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->side) (void)hipStreamDestroy(h->side);
   for (int i = 0; i <= kNumStages; ++i)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   h->counts.release(); h->keys0.release(); h->keys1.release(); h->pts0.release(); h->pts1.release();
@@ -498,13 +648,17 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   h->stats.visits = V;
   h->stats.new_chunks = h->num_chunks - chunks_before;
   if (V == 0) return PLVS_OK;
+  if (V >= (1u << 29)) {
+    plvs::set_error("tsdf_chisel integrate: %u voxel visits in one call exceed the 2^29 limit (split the batch)", V);
+    return PLVS_ERR_CAPACITY;
+  }
 
   PLVS_HIP_TRY(h->keys0.reserve(V));
   PLVS_HIP_TRY(h->keys1.reserve(V));
   PLVS_HIP_TRY(h->pts0.reserve(V));
   PLVS_HIP_TRY(h->pts1.reserve(V));
   PLVS_HIP_TRY(h->heads.reserve(V));
-  PLVS_HIP_TRY(h->rec.reserve(V));
+  PLVS_HIP_TRY(h->rec.reserve((size_t)V + 2));   // chain_runs reads record pairs
   PLVS_HIP_TRY(h->rec_c.reserve(V));
   PLVS_HIP_TRY(h->updated.reserve((size_t)h->num_chunks + 1));
   PLVS_HIP_TRY(h->scratch.reserve(radix_scratch_words(V)));
@@ -528,15 +682,24 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   STAGE_MARK(4);
   hipLaunchKernelGGL(expand_records, dim3(ceil_div(V, kExpandThreads)), dim3(kExpandThreads), 0, s,
                      h->P, keys, pts, V, d_xyz, d_rgb, h->offsets.p, nclouds, h->poses.p,
-                     h->dir.slot_ids, h->rec.p, h->rec_c.p, h->heads.p, h->updated.p, h->d_ctr);
+                     h->dir.slot_ids, h->rec.p, h->rec_c.p, h->heads.p, h->updated.p, h->d_ctr, d_kfid,
+                     h->kfid);
   PLVS_KERNEL_CHECK();
   STAGE_MARK(5);
   // one thread per voxel run; launched over V (upper bound of the run count),
   // surplus threads exit on the device-side head count.
-  hipLaunchKernelGGL(chain_runs, dim3(ceil_div(V, 256)), dim3(256), 0, s, keys, pts, V, h->rec.p,
-                     h->heads.p, h->d_ctr, d_kfid, h->sdf, h->weight, h->kfid);
-  hipLaunchKernelGGL(chain_colours, dim3(ceil_div(V, 256)), dim3(256), 0, s, keys, V, h->rec.p,
+  // The colour chain touches only rgbw and the distance chain only sdf/weight/kfid; both are
+  // latency-bound with few waves, so they run side by side on two streams.
+  PLVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
+  PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+  hipLaunchKernelGGL(chain_colours, dim3(ceil_div(V, 256)), dim3(256), 0, h->side, keys, V, h->rec.p,
                      h->rec_c.p, h->heads.p, h->d_ctr, h->rgbw);
+  PLVS_HIP_TRY(hipEventRecord(h->ev_join, h->side));
+  // one thread per voxel run; launched over V (upper bound of the run count), surplus
+  // waves exit on the device-side head count
+  hipLaunchKernelGGL(chain_runs, dim3(std::min<size_t>(ceil_div(V, 64), 16384)), dim3(64), 0, s, keys, V,
+                     h->rec.p, h->heads.p, h->d_ctr, h->sdf, h->weight);
+  PLVS_HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
   PLVS_KERNEL_CHECK();
   STAGE_MARK(6);
 #undef STAGE_MARK
@@ -560,6 +723,15 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   h->stats.updated_chunks = (int32_t)h->h_ctr->num_updated;
   h->stats.voxels = (int32_t)h->h_ctr->num_heads;
   h->stats.max_run = (int32_t)h->h_ctr->max_run;
+#if PLVS_CHAIN_PROBE
+  {
+    const unsigned long long m = (1ull << 40) - 1;
+    const unsigned long long* q = h->h_ctr->probe;
+    fprintf(stderr, "chain probe: passes %llu cycles %llu wall100MHz %llu | stage+fetch %llu chain %llu prepare %llu tail %llu\n",
+            q[0] >> 40, q[0] & m, q[1] & m, q[2] & m, q[3] & m, q[4] & m, q[5] & m);
+    (void)hipMemsetAsync(h->d_ctr->probe, 0, sizeof(h->d_ctr->probe), s);
+  }
+#endif
   h->last_updated = h->h_ctr->num_updated;
   return PLVS_OK;
 }

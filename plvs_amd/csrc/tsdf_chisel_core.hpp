@@ -212,6 +212,30 @@ PLVS_HD void dist_update(float& sdf, float& w, float wu_times_u, float wu) {
   w = oldW + wu;
 }
 
+// dist_update with the division taken off the sdf -> sdf dependency: the divisor
+// (the new weight) does not depend on the running sdf, so y = RN(1/wn) is computed
+// ahead of the chain and the quotient is recovered exactly from it,
+//   q = RN(a*y), r = a - q*wn (exact in one fma), sdf = RN(q + r*y) = RN(a / wn)
+// (the classic correction step of reciprocal-based division: with a correctly
+// rounded reciprocal and no under/overflow in q, r it yields the correctly rounded
+// quotient).  wn = wu + w (== w + wu) and y = RN(1/wn) are passed in; amin / amax collect the
+// range of |a|.  Outside dist_update_rcp_exact's ranges the caller redoes the step(s) with
+// dist_update.
+PLVS_HD void dist_update_rcp(float& sdf, float& w, float wu_times_u, float wn, float y, float& amin,
+                             float& amax) {
+  const float a = w * sdf + wu_times_u;
+  const float q = a * y;
+  const float r = fmaf(-q, wn, a);
+  sdf = fmaf(r, y, q);
+  w = wn;
+  amin = fminf(amin, fabsf(a));
+  amax = fmaxf(amax, fabsf(a));
+}
+// the operand ranges in which dist_update_rcp is exact
+PLVS_HD bool dist_update_rcp_exact(float amin, float amax, float wn_min, float wn_max) {
+  return (amin >= 0x1p-60f) && (amax <= 0x1p60f) && (wn_min >= 0x1p-20f) && (wn_max <= 0x1p40f);
+}
+
 // ColorVoxel::IntegrateSimple(r,g,b,1) (ColorVoxel.h:91-110) on the packed
 // r | g<<8 | b<<16 | weight<<24 word; a no-op once the weight reaches 254.
 PLVS_HD void colour_update(uint32_t& rgbw, uint32_t r, uint32_t g, uint32_t b) {

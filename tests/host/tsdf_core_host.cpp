@@ -23,7 +23,7 @@ struct HostChunk {
 struct HostMap {
   Params P;
   std::map<std::tuple<int, int, int>, HostChunk> chunks;
-  long long visits = 0;
+  long long visits = 0, fallbacks = 0;
 };
 
 extern "C" {
@@ -69,15 +69,29 @@ void hostcore_integrate(HostMap* m, const float* xyz, const uint8_t* rgb, const 
       const float tr = truncation_of(m->P, depth);
       const float u = signed_dist(pose, depth, c0, c1, c2);
       const float wu = m->P.weight / (2.0f * tr);
-      apply_update(c.sdf[v.vid], c.w[v.vid], c.kfid[v.vid], c.rgbw[v.vid], u, wu,
-                   kfid ? kfid[i] : 0u, colour_roundtrip(rgb[3 * i]), colour_roundtrip(rgb[3 * i + 1]),
-                   colour_roundtrip(rgb[3 * i + 2]));
+      // the chain kernel's form of DistVoxel::Integrate: reciprocal form, plain division
+      // when an operand is outside its exact range
+      float s_new = c.sdf[v.vid], w_new = c.w[v.vid];
+      float amin = 1.0f, amax = 1.0f;
+      const float wn = wu + w_new;
+      dist_update_rcp(s_new, w_new, wu * u, wn, 1.0f / wn, amin, amax);
+      if (dist_update_rcp_exact(amin, amax, wn, wn)) {
+        c.sdf[v.vid] = s_new;
+        c.w[v.vid] = w_new;
+      } else {
+        dist_update(c.sdf[v.vid], c.w[v.vid], wu * u, wu);
+        m->fallbacks++;
+      }
+      c.kfid[v.vid] = kfid ? kfid[i] : 0u;
+      colour_update(c.rgbw[v.vid], colour_roundtrip(rgb[3 * i]), colour_roundtrip(rgb[3 * i + 1]),
+                    colour_roundtrip(rgb[3 * i + 2]));
       m->visits++;
     }
   }
 }
 
 long long hostcore_last_visits(HostMap* m) { return m->visits; }
+long long hostcore_fallbacks(HostMap* m) { return m->fallbacks; }
 int hostcore_num_chunks(HostMap* m) { return (int)m->chunks.size(); }
 void hostcore_chunk_ids(HostMap* m, int32_t* ids) {
   int k = 0;
@@ -109,7 +123,7 @@ struct HostVBlock {
 struct HostVMap {
   plvs::vbx::Params P;
   std::map<std::tuple<int, int, int>, HostVBlock> blocks;
-  long long visits = 0;
+  long long visits = 0, fallbacks = 0;
 };
 
 extern "C" {

@@ -212,3 +212,18 @@ def test_hip_shards_match_oracle_shards(oracle):
             dev.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
         compare_maps(ora, dev)
         dev.close()
+
+
+@pytest.mark.gpu
+def test_hip_reciprocal_is_correctly_rounded_for_every_significand():
+    """chain_runs divides through RN(1/w) computed as v_rcp_f32 + one Newton step; the exact
+    quotient recovery needs that reciprocal correctly rounded.  Checked for all 2^23
+    significands at the ends and inside the exponent range the kernel admits (2^-20..2^40)."""
+    import ctypes
+    from plvs_amd import _lib
+    f = _lib.lib.plvs_hip_selftest_rcp
+    f.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    for exponent in (-20, -7, -1, 0, 1, 2, 13, 39):
+        bad = ctypes.c_uint32(12345)
+        _lib.check(f(exponent, ctypes.byref(bad)))
+        assert bad.value == 0, f"exponent {exponent}: {bad.value} significands not correctly rounded"
