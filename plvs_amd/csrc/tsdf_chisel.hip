@@ -7,8 +7,9 @@
 //                   [s*4096, (s+1)*4096) of every plane (64 KiB per chunk).
 //   chunk directory open-addressing hash (2*max_chunks, power of two) from the
 //                   packed 3x21-bit chunk id to the pool slot, plus slot -> id.
-//   per call        one u32 (slot*4096 + voxel) key and one u32 point index per
-//                   voxel visit.
+//   per call        per voxel visit the update operands (w_u*u, w_u: 8 bytes) and the
+//                   colour (4 bytes), written once grouped per tile and once in voxel
+//                   order; per tile-local run of visits to one voxel a 20-byte descriptor.
 //
 // The reference integrates points strictly in order, and both the running
 // weighted mean (f32) and the truncating u8 colour mean are order dependent.
@@ -17,15 +18,17 @@
 //                  the voxels that take an update; first-touch chunks are
 //                  inserted into the directory.
 //   2. scan        exclusive scan of the counts = visit offsets (point order).
-//   3. ray_fill    the same walk writes (voxel key, point index) records at
-//                  those offsets, i.e. globally sorted by point.
-//   4. radix sort  stable by voxel key -> per voxel, records in point order.
-//   5. expand      one thread per sorted record derives the update operands
-//                  (w_u*u, w_u) from the point — everything that is not order
-//                  dependent — and compacts the run heads.
-//   6. chain       one thread per voxel run folds its records sequentially in
-//                  registers (the f32 weighted mean and the truncating u8
-//                  colour mean): each voxel is read and written once per call.
+//   3. ray_tiles   the visit slots are cut into tiles of 4096; a workgroup re-walks the
+//                  rays of its tile, keeps the visits in LDS, groups them by voxel (point
+//                  order inside a group) and writes the update operands (w_u*u, w_u) and
+//                  colours grouped that way, plus one descriptor per group ("run").
+//   4. sort_runs   stable radix sort of the run descriptors by voxel key: per voxel its
+//                  runs in tile (= point) order.  Runs, not visits, are sorted.
+//   5. gather_runs copies the runs into voxel order -> per voxel its records contiguous
+//                  and in point order; compacts voxel heads and updated chunks.
+//   6. chain       one thread per voxel folds its records sequentially in registers (the
+//                  f32 weighted mean; the truncating u8 colour mean on a second stream):
+//                  each voxel is read and written once per call.
 // Results are bit-identical to the sequential CPU loop.
 #include "common.hpp"
 #include "device_utils.hpp"
@@ -39,11 +42,22 @@ using namespace plvs::tsdf;
 namespace {
 
 constexpr int kNumStages = 6;
-const char* const kStageNames[kNumStages] = {"ray_count", "scan", "ray_fill", "radix_sort",
-                                             "expand_records", "chain_runs"};
+const char* const kStageNames[kNumStages] = {"ray_count", "scan", "ray_tiles", "sort_runs",
+                                             "gather_runs", "chain_runs"};
 
 #ifndef PLVS_CHAIN_PROBE
 #define PLVS_CHAIN_PROBE 0
+#endif
+#ifndef PLVS_TILE_PROBE
+#define PLVS_TILE_PROBE 0
+#endif
+#if PLVS_TILE_PROBE
+#define TILE_PROBE(i)                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                           \
+  if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); atomicAdd(&ctr->tprobe[i], now_ - tp_); tp_ = now_; } \
+  __builtin_amdgcn_sched_barrier(0);
+#else
+#define TILE_PROBE(i)
 #endif
 
 struct Counters {           // device-side, read back once per call
@@ -53,9 +67,12 @@ struct Counters {           // device-side, read back once per call
   uint32_t num_heads;
   uint32_t num_updated;
   uint32_t max_run;
+  uint32_t num_desc;
 #if PLVS_CHAIN_PROBE
-  uint32_t pad_;
   unsigned long long probe[6];   // instrumentation build only
+#endif
+#if PLVS_TILE_PROBE
+  unsigned long long tprobe[8];   // instrumentation build only
 #endif
 };
 
@@ -70,25 +87,21 @@ __global__ void pool_init(float* __restrict__ sdf, size_t n) {
   for (size_t j = i; j < n; j += stride) sdf[j] = 99999.0f;
 }
 
-// Pass 1 (kFill == false): count the updating visits of each point and insert
-// first-touch chunks.  Pass 2 (kFill == true): write the visit records.
-template <bool kFill>
-__global__ __launch_bounds__(256) void ray_pass(
+// Stage 1: count the updating visits of each point and insert first-touch chunks.
+__global__ __launch_bounds__(256) void ray_count(
     Params P, const float* __restrict__ xyz, int npoints, const int32_t* __restrict__ offsets,
     int nclouds, const Pose* __restrict__ poses, Directory dir, Counters* __restrict__ ctr,
-    uint32_t* __restrict__ counts /* pass 1 out, pass 2: scanned offsets */,
-    uint32_t* __restrict__ rec_keys, uint32_t* __restrict__ rec_pts) {
+    uint32_t* __restrict__ counts) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npoints) return;
   const Pose pose = poses[cloud_of(offsets, nclouds, i)];
   Ray ray;
   uint32_t n = 0;
   if (make_ray(P, pose, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], &ray)) {
-    const uint32_t out = kFill ? counts[i] : 0u;
     RayCursor cur;
     ray_begin(ray, &cur);
     int vx, vy, vz;
-    int lcx = 0, lcy = 0, lcz = 0, lslot = -1;  // last chunk seen by this ray
+    int lcx = 0, lcy = 0, lcz = 0;  // last chunk seen by this ray
     bool have_last = false;
     while (ray_next(&cur, &vx, &vy, &vz)) {
       Visit v;
@@ -96,92 +109,517 @@ __global__ __launch_bounds__(256) void ray_pass(
       if (!have_last || v.cx != lcx || v.cy != lcy || v.cz != lcz) {
         lcx = v.cx; lcy = v.cy; lcz = v.cz;
         have_last = true;
-        if (kFill) {
-          lslot = dir_find(dir, lcx, lcy, lcz);
-          if (lslot < 0) atomicOr(&ctr->err, kErrDirectoryMiss);
-        } else {
-          dir_insert(dir, lcx, lcy, lcz, &ctr->num_chunks, &ctr->err);
-          // the float chunk lookup (GetIDAt) and the integer voxel grid only
-          // disagree ~100 km from the origin; fail loudly instead of diverging
-          if (((vx - lcx * 16) | (vy - lcy * 16) | (vz - lcz * 16)) & ~15)
-            atomicOr(&ctr->err, kErrCoordRange);
-        }
-      }
-      if (kFill && lslot >= 0) {
-        rec_keys[out + n] = (uint32_t)lslot * (uint32_t)kChunkVox + (uint32_t)v.vid;
-        rec_pts[out + n] = (uint32_t)i;
+        dir_insert(dir, lcx, lcy, lcz, &ctr->num_chunks, &ctr->err);
+        // the float chunk lookup (GetIDAt) and the integer voxel grid only
+        // disagree ~100 km from the origin; fail loudly instead of diverging
+        if (((vx - lcx * 16) | (vy - lcy * 16) | (vz - lcz * 16)) & ~15)
+          atomicOr(&ctr->err, kErrCoordRange);
       }
       ++n;
     }
   }
-  if (!kFill) counts[i] = n;
+  counts[i] = n;
 }
 
-// Per sorted record: the update operands the sequential chain needs, computed
-// fully in parallel, plus the compaction of run heads / updated chunks.
-//   rec[r].x = w_u * u        the rounded product DistVoxel::Integrate adds
-//   rec[r].y = +-w_u          ConstantWeighter weight of the record's point;
-//                             negative on the LAST record of a voxel run
-//   rec_c[r] = r | g<<8 | b<<16 of the point (after the reference's u8->f32->u8 trip)
-constexpr int kExpandThreads = 1024;
-__global__ __launch_bounds__(kExpandThreads) void expand_records(
-    Params P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ pts, uint32_t n,
-    const float* __restrict__ xyz, const uint8_t* __restrict__ rgb,
-    const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses,
-    const int32_t* __restrict__ slot_ids, float2* __restrict__ rec, uint32_t* __restrict__ rec_c,
-    uint32_t* __restrict__ heads, uint32_t* __restrict__ updated_slots,
-    Counters* __restrict__ ctr, const uint32_t* __restrict__ kfid, uint32_t* __restrict__ vkfid) {
-  __shared__ uint32_t wave_cnt[2][kExpandThreads / 64];
+// ------------------------------------------------------------------ tiles
+// Stage 3.  The visit slots of the call (point order, dense: offsets = scan of the counts)
+// are cut into tiles of kTileSlots.  One workgroup per tile re-walks the rays of its points,
+// keeps the tile's visits in LDS, groups them by voxel and writes
+//   * the update operands (w_u*u, w_u) and the colour of every visit, grouped by voxel
+//     and, inside a group, in point order (tile-local "runs"), fully coalesced;
+//   * one descriptor per run: voxel key (slot*4096 + voxel), position, length and the
+//     point of its last visit.
+// Only the descriptors (one per run, not one per visit) go through the global sort.
+//
+// Grouping: an LDS hash table keyed by the voxel key gives every visit the table entry of
+// its voxel; a stable LDS radix sort of (entry, slot) tags by entry (12 bits, two passes)
+// makes the visits of a voxel contiguous and keeps them in slot (= point) order — its cost
+// does not depend on how many visits a voxel collects.  The order of the groups inside
+// a tile is irrelevant: a tile holds at most one run per voxel, and runs of different tiles
+// keep their tile order through the stable global sort.
+//
+// Run descriptors are numbered across tiles by a decoupled look-back over tile_state (tile
+// ids are tickets, so a tile only ever waits for tiles that already started).
+constexpr int kTileSlots = 4096;
+constexpr int kTileThreads = 512;
+constexpr int kTileItems = kTileSlots / kTileThreads;   // per thread in the LDS phases
+constexpr uint32_t kTileEmpty = 0xFFFFFFFFu;
+constexpr int kTileChunkCache = 64;
+constexpr int kTileCloudCache = 64;
+
+__global__ void mark_tiles(const uint32_t* __restrict__ voff /* n + 1 */, int n,
+                           uint32_t* __restrict__ tile_first) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t o = voff[i], e = voff[i + 1];
+  // the point owning the first slot of a tile
+  for (uint32_t t = (o + kTileSlots - 1) / kTileSlots; (unsigned long long)t * kTileSlots < e; ++t) tile_first[t] = (uint32_t)i;
+}
+
+// One pass of a stable LSD radix sort of the kTileSlots tags of a tile in LDS (6-bit digit at
+// `shift`).  Wave w owns the contiguous span [w*512, (w+1)*512); equal digits are ranked inside
+// a wave-row with ballots (lane order = slot order), a running count per (wave, digit) carries
+// over the rows, and one scan over the 8 x 64 counts places the spans.
+constexpr int kTileRadixBits = 6;
+constexpr int kTileRadix = 1 << kTileRadixBits;
+__device__ __forceinline__ void tile_radix_pass(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                int shift, uint32_t (*wave_hist)[kTileRadix], int tid) {
+  constexpr int kWavesT = kTileThreads / 64;
+  const int lane = tid & 63, wid = tid >> 6;
+  wave_hist[wid][lane] = 0;   // 64 digits, 64 lanes
+  __syncthreads();
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  uint32_t v[kTileItems], rank[kTileItems];
+  volatile uint32_t* my_hist = wave_hist[wid];
+#pragma unroll
+  for (int it = 0; it < kTileItems; ++it) {
+    v[it] = src[wid * (kTileItems * 64) + it * 64 + lane];
+    const uint32_t d = (v[it] >> shift) & (kTileRadix - 1);
+    unsigned long long peers = ~0ull;
+#pragma unroll
+    for (int b = 0; b < kTileRadixBits; ++b) {
+      const unsigned long long bal = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
+    const uint32_t base = my_hist[d];
+    rank[it] = base + before;
+    // the lowest peer publishes the new running count; LDS operations of one wave execute in
+    // order, so every peer has read `base` before this store lands
+    if (before == 0) my_hist[d] = base + (uint32_t)__popcll(peers);
+  }
+  __syncthreads();
+  // exclusive scan over (digit, wave) in that order: thread = one (digit, wave) cell
+  {
+    const int d = tid / kWavesT, w = tid % kWavesT;   // 512 cells
+    const uint32_t c = wave_hist[w][d];
+    uint32_t inc = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
+      if (lane >= off) inc += up;
+    }
+    __shared__ uint32_t part[kWavesT];
+    if (lane == 63) part[wid] = inc;
+    __syncthreads();
+    uint32_t basev = 0;
+#pragma unroll
+    for (int q = 0; q < kWavesT; ++q) basev += (q < wid) ? part[q] : 0u;
+    wave_hist[w][d] = basev + inc - c;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < kTileItems; ++it) {
+    const uint32_t d = (v[it] >> shift) & (kTileRadix - 1);
+    dst[wave_hist[wid][d] + rank[it]] = v[it];
+  }
+  __syncthreads();
+}
+
+// dir_find through a small per-tile cache in LDS (a tile meets a handful of chunks, every ray
+// of it asks for them again).  An entry whose slot is still pending, or a full cache, falls
+// back to the directory.
+__device__ __forceinline__ int tile_find_chunk(const Directory& dir, unsigned long long* ckey, int32_t* cslot,
+                                               int x, int y, int z) {
+  unsigned long long key;
+  if (!pack_block(x, y, z, &key)) return -1;
+  uint32_t h = dir_hash(x, y, z, kTileChunkCache - 1);
+  for (int probe = 0; probe < kTileChunkCache; ++probe) {
+    unsigned long long cur = ckey[h];
+    if (cur == kEmptyKey) {
+      const int slot = dir_find(dir, x, y, z);
+      cur = atomicCAS(&ckey[h], kEmptyKey, key);
+      if (cur == kEmptyKey) {
+        cslot[h] = slot;
+        return slot;
+      }
+      if (cur == key) return slot;
+    } else if (cur == key) {
+      const int slot = cslot[h];
+      return slot != -2 ? slot : dir_find(dir, x, y, z);
+    }
+    h = (h + 1) & (kTileChunkCache - 1);
+  }
+  return dir_find(dir, x, y, z);
+}
+
+struct TileOut {
+  float2* rec_t;        // [V] operands, tile-grouped
+  uint32_t* recc_t;     // [V] colours, tile-grouped
+  uint32_t* dkey;       // run descriptors: voxel key,
+  uint4* desc;          // (position in rec_t, length, point of the last visit, -)
+  uint32_t* didx;       // identity, the value array of the sort
+};
+
+__device__ __forceinline__ unsigned long long ld_state(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_state(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(kTileThreads) void ray_tiles(
+    Params P, const float* __restrict__ xyz, const uint8_t* __restrict__ rgb, int npoints,
+    const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
+    Counters* __restrict__ ctr, const uint32_t* __restrict__ voff, uint32_t V,
+    const uint32_t* __restrict__ tile_first, uint32_t ntiles, uint32_t* __restrict__ ticket,
+    unsigned long long* __restrict__ tile_state, TileOut out) {
+  __shared__ uint32_t skey[kTileSlots];     // voxel key of the visit in slot s
+  __shared__ float su[kTileSlots];          // its signed distance u
+  __shared__ uint16_t spt[kTileSlots];      // its point, relative to the tile's first point
+  __shared__ uint32_t bufA[kTileSlots];     // tags: group table entry << 12 | slot; sorted in place
+  __shared__ uint32_t bufB[kTileSlots];     // the group hash table, then the sort's second buffer, then run heads
+  __shared__ uint32_t wave_hist[kTileThreads / 64][kTileRadix];
+  uint32_t* const gtab = bufB;              // representative slot of the voxel hashed to this entry
+  __shared__ uint32_t wsum[kTileThreads / 64];
+  __shared__ uint32_t sh_tile, sh_base;
+  __shared__ unsigned long long ckey[kTileChunkCache];   // chunk id -> pool slot, the chunks this tile meets
+  __shared__ int32_t cslot[kTileChunkCache];
+  __shared__ int32_t cl_off[kTileCloudCache + 1];          // cloud offsets around the tile
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+
+#if PLVS_TILE_PROBE
+  unsigned long long tp_ = clock64();
+#endif
+  if (tid == 0) {
+    sh_tile = atomicAdd(ticket, 1u);
+  }
+#pragma unroll
+  for (int k = 0; k < kTileItems; ++k) gtab[tid + k * kTileThreads] = kTileEmpty;
+  if (tid < kTileChunkCache) {
+    ckey[tid] = kEmptyKey;
+    cslot[tid] = -2;
+  }
+  __syncthreads();
+  const uint32_t t = sh_tile;
+  const uint32_t slot0 = t * kTileSlots;
+  const uint32_t n = min((uint32_t)kTileSlots, V - slot0);
+  const uint32_t first = tile_first[t];
+  const uint32_t last = (t + 1 < ntiles) ? tile_first[t + 1] : (uint32_t)(npoints - 1);
+
+  TILE_PROBE(0)
+  // the clouds the tile's points belong to: offsets of up to kTileCloudCache of them in LDS
+  const int cloud0 = cloud_of(offsets, nclouds, (int)first);
+  const int ncl = min(nclouds - cloud0, kTileCloudCache);
+  if (tid <= ncl) cl_off[tid] = offsets[cloud0 + tid];
+  __syncthreads();
+
+  // ---- phase 1: the visits of this tile, in slot (= point, then ray) order
+  for (uint32_t i = first + tid; i <= last; i += kTileThreads) {
+    const uint32_t o = voff[i], e = voff[i + 1];
+    if (e == o || e <= slot0 || o >= slot0 + n) continue;
+    const uint32_t n_lo = (o < slot0) ? slot0 - o : 0u;       // visits before it belong to the previous tile
+    const uint32_t n_hi = min(e, slot0 + n) - o;              // visits from it on to the next one
+    int cl = 0;
+    while (cl + 1 < ncl && (int)i >= cl_off[cl + 1]) ++cl;
+    if ((int)i >= cl_off[ncl]) cl = cloud_of(offsets, nclouds, (int)i) - cloud0;   // beyond the cached clouds
+    const Pose pose = poses[cloud0 + cl];
+    Ray ray;
+    if (!make_ray(P, pose, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], &ray)) continue;
+    RayCursor cur;
+    ray_begin(ray, &cur);
+    int vx, vy, vz;
+    int lcx = 0, lcy = 0, lcz = 0, lslot = -1;
+    bool have_last = false;
+    uint32_t nv = 0;
+    while (nv < n_hi && ray_next(&cur, &vx, &vy, &vz)) {
+      Visit v;
+      if (!resolve_visit(P, pose, ray, vx, vy, vz, &v)) continue;
+      if (nv >= n_lo) {
+        if (!have_last || v.cx != lcx || v.cy != lcy || v.cz != lcz) {
+          lcx = v.cx; lcy = v.cy; lcz = v.cz;
+          have_last = true;
+          lslot = tile_find_chunk(dir, ckey, cslot, lcx, lcy, lcz);
+          if (lslot < 0) atomicOr(&ctr->err, kErrDirectoryMiss);
+        }
+        const uint32_t s = o + nv - slot0;
+        skey[s] = (uint32_t)max(lslot, 0) * (uint32_t)kChunkVox + (uint32_t)v.vid;
+        su[s] = v.u;
+        spt[s] = (uint16_t)(i - first);
+      }
+      ++nv;
+    }
+    if (nv < n_hi) atomicOr(&ctr->err, kErrDirectoryMiss);   // the count pass saw more visits: cannot happen
+  }
+  __syncthreads();
+
+  TILE_PROBE(1)
+  // ---- phase 2: group by voxel key.  The hash table gives every voxel of the tile one entry;
+  // a visit is tagged with the entry of its voxel.
+#pragma unroll
+  for (int k = 0; k < kTileItems; ++k) {
+    const uint32_t s = tid + k * kTileThreads;
+    uint32_t tag = kTileEmpty;   // beyond the tile's last slot: sorts behind everything
+    if (s < n) {
+      const uint32_t key = skey[s];
+      uint32_t h = (key * 2654435761u) >> 20;
+      for (;;) {
+        uint32_t e = gtab[h];
+        if (e == kTileEmpty) {
+          e = atomicCAS(&gtab[h], kTileEmpty, s);   // s: the entry's representative visit
+          if (e == kTileEmpty) break;
+        }
+        if (skey[e] == key) break;
+        h = (h + 1) & (kTileSlots - 1);
+      }
+      tag = (h << 12) | s;
+    }
+    bufA[s] = tag;
+  }
+  __syncthreads();
+
+  TILE_PROBE(2)
+  // ---- phase 3: stable LSD radix sort of the tags by table entry (2 x 6 bits): visits of one
+  // voxel end up contiguous and in slot (= point) order.  bufB overlays the hash table.
+  tile_radix_pass(bufA, bufB, 12, wave_hist, tid);
+  tile_radix_pass(bufB, bufA, 18, wave_hist, tid);
+
+  TILE_PROBE(3)
+  // ---- phase 4: group heads: positions hp[g] of the runs, their number
+  uint32_t acc = 0;
+  uint32_t flags = 0;
+#pragma unroll
+  for (int k = 0; k < kTileItems; ++k) {
+    const uint32_t j = tid * kTileItems + k;   // this thread's contiguous positions
+    const uint32_t cur = bufA[j];
+    const uint32_t prev = j ? bufA[j - 1] : kTileEmpty;
+    const bool head = j < n && (j == 0 || (cur >> 12) != (prev >> 12));
+    flags |= head ? (1u << k) : 0u;
+    acc += head ? 1u : 0u;
+  }
+  uint32_t inc = acc;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
+    if (lane >= off) inc += up;
+  }
+  if (lane == 63) wsum[wid] = inc;
+  __syncthreads();
+  uint32_t wbase = 0, ngroups = 0;
+#pragma unroll
+  for (int w = 0; w < kTileThreads / 64; ++w) {
+    const uint32_t v = wsum[w];
+    if (w < wid) wbase += v;
+    ngroups += v;
+  }
+  uint16_t* const hp = reinterpret_cast<uint16_t*>(bufB);   // (the sorted tags are in bufA)
+  {
+    uint32_t g = wbase + inc - acc;
+#pragma unroll
+    for (int k = 0; k < kTileItems; ++k)
+      if (flags & (1u << k)) hp[g++] = (uint16_t)(tid * kTileItems + k);
+  }
+  if (tid == 0) hp[ngroups] = (uint16_t)n;
+  // publish this tile's run count for the tiles behind it
+  if (tid == 0 && t > 0) st_state(&tile_state[t], (1ull << 62) | ngroups);
+  __syncthreads();   // hp complete
+
+  TILE_PROBE(5)
+  // ---- phase 5: operands out, in sorted order
+#pragma unroll
+  for (int k = 0; k < kTileItems; ++k) {
+    const uint32_t j = tid + k * kTileThreads;
+    if (j < n) {
+      const uint32_t s = bufA[j] & 0xFFFu;
+      const size_t p = (size_t)first + spt[s];
+      const float tr = truncation_of(P, xyz[3 * p + 2]);
+      const float wu = P.weight / (2.0f * tr);
+      out.rec_t[slot0 + j] = make_float2(wu * su[s], wu);
+      out.recc_t[slot0 + j] = colour_roundtrip(rgb[3 * p + 0]) | (colour_roundtrip(rgb[3 * p + 1]) << 8) |
+                              (colour_roundtrip(rgb[3 * p + 2]) << 16);
+    }
+  }
+
+  // the tile's place in the run numbering: wave 0, decoupled look-back over 64 predecessors
+  // at a time (they published their counts a phase ago)
+  if (wid == 0) {
+    unsigned long long base = 0;
+    if (t > 0) {
+      for (long long hi = (long long)t - 1; hi >= 0; hi -= 64) {
+        const long long p = hi - lane;   // lane 0 = nearest predecessor
+        unsigned long long st = 2ull << 62;   // before the first tile: an empty prefix
+        if (p >= 0) {
+          do { st = ld_state(&tile_state[p]); } while ((st >> 62) == 0);
+        }
+        const unsigned long long is_prefix = __ballot((st >> 62) == 2);
+        const int stop = __ffsll((long long)is_prefix) - 1;   // nearest tile with a known prefix
+        unsigned long long v = (stop < 0 || lane <= stop) ? (st & ((1ull << 62) - 1)) : 0ull;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += (unsigned long long)__shfl_xor((long long)v, off);
+        base += v;
+        if (stop >= 0) break;
+      }
+    }
+    if (lane == 0) {
+      st_state(&tile_state[t], (2ull << 62) | (base + ngroups));
+      sh_base = (uint32_t)base;
+      if (t + 1 == ntiles) ctr->num_desc = (uint32_t)(base + ngroups);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 6: run descriptors out
+  const uint32_t dbase = sh_base;
+  for (uint32_t g = tid; g < ngroups; g += kTileThreads) {
+    const uint32_t p0 = hp[g], p1 = hp[g + 1];
+    const uint32_t d = dbase + g;
+    out.dkey[d] = skey[bufA[p0] & 0xFFFu];
+    out.desc[d] = make_uint4(slot0 + p0, p1 - p0, first + spt[bufA[p1 - 1] & 0xFFFu], 0u);
+    out.didx[d] = d;
+  }
+  TILE_PROBE(6)
+}
+
+// counts of the runs in sorted order (input of the scan that places them)
+__global__ void run_counts(const uint32_t* __restrict__ sorted_idx, const uint4* __restrict__ desc,
+                           uint32_t nd, uint32_t* __restrict__ cnts) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < nd) cnts[j] = desc[sorted_idx[j]].y;
+}
+
+// the run holding the first record of every block of kGatherSpan output records
+constexpr int kGatherThreads = 256;
+constexpr int kGatherSpan = 2048;
+__global__ void mark_blocks(const uint32_t* __restrict__ dst, uint32_t nd, uint32_t V,
+                            uint32_t* __restrict__ block_first) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nd) return;
+  const uint32_t a = dst[j], e = (j + 1 < nd) ? dst[j + 1] : V;
+  for (uint32_t b = (a + kGatherSpan - 1) / kGatherSpan; (unsigned long long)b * kGatherSpan < e; ++b) block_first[b] = j;
+}
+
+// Stage 5.  Runs in voxel order (stable: tile order inside a voxel) -> the records of
+// every voxel contiguous and in point order, which is what the chain kernels walk:
+//   rec[r]   = (w_u * u, +-w_u)   negative on the LAST record of a voxel
+//   rec_c[r] = r | g<<8 | b<<16
+// Output-centric: a block owns kGatherSpan consecutive output records, so its stores are
+// fully coalesced; the runs that cover the span are looked up once (their first positions
+// are marked in LDS and a max-scan hands every output record its run), the loads follow the
+// runs (contiguous pieces of a tile).  Also compacts the voxel heads (first record + key)
+// and the updated chunks, and sets the keyframe id of the voxel (SetKfid: the last update
+// of the call wins).
+__global__ __launch_bounds__(kGatherThreads) void gather_runs(
+    const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ sorted_idx, uint32_t nd,
+    const uint4* __restrict__ desc, const uint32_t* __restrict__ dst,
+    const uint32_t* __restrict__ block_first, uint32_t nblocks, uint32_t V,
+    const float2* __restrict__ rec_t, const uint32_t* __restrict__ recc_t, float2* __restrict__ rec,
+    uint32_t* __restrict__ rec_c, uint32_t* __restrict__ heads, uint32_t* __restrict__ head_keys,
+    uint32_t* __restrict__ updated_slots, Counters* __restrict__ ctr,
+    const uint32_t* __restrict__ kfid, uint32_t* __restrict__ vkfid) {
+  constexpr int kItems = kGatherSpan / kGatherThreads;   // 8
+  constexpr int kMaxRuns = kGatherSpan + 1;
+  __shared__ uint16_t id[kGatherSpan];          // run (local index + 1) of every output record
+  __shared__ uint32_t delta[kMaxRuns + 3];      // source position - output position of the run
+  __shared__ uint32_t endl[kMaxRuns + 3];       // end of the run | bit 31: it closes its voxel
+  __shared__ uint32_t wtot[kGatherThreads / 64];
   __shared__ uint32_t block_base[2];
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  bool head = false, chead = false;
-  uint32_t key = 0;
-  if (r < n) {
-    key = keys[r];
-    const uint32_t prev = r ? keys[r - 1] : ~key;
-    const uint32_t next = (r + 1 < n) ? keys[r + 1] : ~key;
-    head = (r == 0) || (key != prev);
-    chead = (r == 0) || ((key >> 12) != (prev >> 12));
-    const int p = (int)pts[r];
-    const uint32_t slot = key >> 12, vid = key & 4095u;
-    const int vx = slot_ids[3 * slot + 0] * 16 + (int)(vid & 15u);
-    const int vy = slot_ids[3 * slot + 1] * 16 + (int)((vid >> 4) & 15u);
-    const int vz = slot_ids[3 * slot + 2] * 16 + (int)(vid >> 8);
-    const float c0 = (float)vx * P.resolution + P.half_voxel;
-    const float c1 = (float)vy * P.resolution + P.half_voxel;
-    const float c2 = (float)vz * P.resolution + P.half_voxel;
-    const Pose& pose = poses[cloud_of(offsets, nclouds, p)];
-    const float depth = xyz[3 * (size_t)p + 2];
-    const float tr = truncation_of(P, depth);
-    const float u = signed_dist(pose, depth, c0, c1, c2);
-    const float wu = P.weight / (2.0f * tr);
-    rec[r] = make_float2(wu * u, (key != next) ? -wu : wu);
-    if (key != next) vkfid[key] = kfid ? kfid[p] : 0u;   // SetKfid: the last update of the run wins
-    rec_c[r] = colour_roundtrip(rgb[3 * (size_t)p + 0]) | (colour_roundtrip(rgb[3 * (size_t)p + 1]) << 8) |
-               (colour_roundtrip(rgb[3 * (size_t)p + 2]) << 16);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t b = blockIdx.x;
+  const uint32_t B0 = b * kGatherSpan;
+  const uint32_t nrec = min((uint32_t)kGatherSpan, V - B0);
+  const uint32_t j_lo = block_first[b];
+  const uint32_t j_hi = (b + 1 < nblocks) ? block_first[b + 1] : nd - 1;
+  const uint32_t nruns = j_hi - j_lo + 1;
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) id[tid + k * kGatherThreads] = 0;
+  __syncthreads();
+
+  // ---- the runs of the span; the ones that start here also do the per-voxel bookkeeping
+  uint32_t my_heads = 0;   // heads | chunk heads << 16 among this thread's runs
+  for (uint32_t jl = tid; jl < nruns; jl += kGatherThreads) {
+    const uint32_t j = j_lo + jl;
+    const uint32_t key = skeys[j];
+    const uint32_t next = (j + 1 < nd) ? skeys[j + 1] : ~key;
+    const uint4 d = desc[sorted_idx[j]];
+    const uint32_t a = dst[j];
+    const bool closes = key != next;
+    delta[jl] = d.x - a;
+    endl[jl] = (a + d.y) | (closes ? 0x80000000u : 0u);
+    if (a < B0 + nrec) id[max(a, B0) - B0] = (uint16_t)(jl + 1);
+    if (a >= B0 && a < B0 + nrec) {
+      const uint32_t prev = j ? skeys[j - 1] : ~key;
+      my_heads += (key != prev) ? 1u : 0u;
+      my_heads += (j == 0 || (key >> 12) != (prev >> 12)) ? (1u << 16) : 0u;
+      if (closes) vkfid[key] = kfid ? kfid[d.z] : 0u;
+    }
   }
   // block-aggregated, order-free compaction of the two head lists
-  const unsigned long long mh = __ballot(head), mc = __ballot(chead);
-  if (lane == 0) {
-    wave_cnt[0][wid] = (uint32_t)__popcll(mh);
-    wave_cnt[1][wid] = (uint32_t)__popcll(mc);
+  uint32_t inc = my_heads;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
+    if (lane >= off) inc += up;
   }
+  if (lane == 63) wtot[wid] = inc;
+  __syncthreads();   // also: id / delta / endl complete
+  uint32_t wbase = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kGatherThreads / 64; ++w) {
+    const uint32_t v = wtot[w];
+    if (w < wid) wbase += v;
+    total += v;
+  }
+  if (tid < 2) {
+    const uint32_t c = tid == 0 ? (total & 0xFFFFu) : (total >> 16);
+    block_base[tid] = c ? atomicAdd(tid == 0 ? &ctr->num_heads : &ctr->num_updated, c) : 0u;
+  }
+  // ---- every output record learns its run: inclusive max-scan of the marks
+  uint32_t loc[kItems], run_max = 0;
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    run_max = max(run_max, (uint32_t)id[tid * kItems + k]);
+    loc[k] = run_max;
+  }
+  uint32_t sc = run_max;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)sc, off);
+    if (lane >= off) sc = max(sc, up);
+  }
+  __syncthreads();   // block_base written; wtot free again
+  if (lane == 63) wtot[wid] = sc;
   __syncthreads();
-  if (threadIdx.x < 2) {
-    uint32_t tot = 0;
-    for (int w = 0; w < kExpandThreads / 64; ++w) {
-      const uint32_t c = wave_cnt[threadIdx.x][w];
-      wave_cnt[threadIdx.x][w] = tot;
-      tot += c;
+  uint32_t before = 0;
+#pragma unroll
+  for (int w = 0; w < kGatherThreads / 64; ++w) before = (w < wid) ? max(before, wtot[w]) : before;
+  const uint32_t up1 = (uint32_t)__shfl_up((int)sc, 1);
+  before = max(before, lane ? up1 : 0u);
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) id[tid * kItems + k] = (uint16_t)max(loc[k], before);
+  // head lists
+  {
+    const uint32_t excl = wbase + inc - my_heads;
+    uint32_t at_h = block_base[0] + (excl & 0xFFFFu), at_c = block_base[1] + (excl >> 16);
+    for (uint32_t jl = tid; jl < nruns; jl += kGatherThreads) {
+      const uint32_t j = j_lo + jl;
+      const uint32_t a = dst[j];
+      if (a >= B0 && a < B0 + nrec) {
+        const uint32_t key = skeys[j];
+        const uint32_t prev = j ? skeys[j - 1] : ~key;
+        if (key != prev) {
+          heads[at_h] = a;
+          head_keys[at_h++] = key;
+        }
+        if (j == 0 || (key >> 12) != (prev >> 12)) updated_slots[at_c++] = key >> 12;
+      }
     }
-    block_base[threadIdx.x] =
-        tot ? atomicAdd(threadIdx.x == 0 ? &ctr->num_heads : &ctr->num_updated, tot) : 0u;
   }
   __syncthreads();
-  if (head) heads[block_base[0] + wave_cnt[0][wid] + (uint32_t)__popcll(mh & lt)] = r;
-  if (chead) updated_slots[block_base[1] + wave_cnt[1][wid] + (uint32_t)__popcll(mc & lt)] = key >> 12;
+  // ---- copy
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    const uint32_t q = tid + k * kGatherThreads;
+    if (q < nrec) {
+      const uint32_t jl = (uint32_t)id[q] - 1u;
+      const uint32_t r = B0 + q;
+      const uint32_t src = r + delta[jl];
+      const uint32_t e = endl[jl];
+      float2 v = rec_t[src];
+      if ((e >> 31) && (e & 0x7FFFFFFFu) == r + 1) v.y = -v.y;
+      rec[r] = v;
+      rec_c[r] = recc_t[src];
+    }
+  }
 }
 
 // The order-dependent part: one thread per voxel run, 64 runs per wave, eight records per
@@ -201,8 +639,8 @@ __global__ __launch_bounds__(kExpandThreads) void expand_records(
 //    binary32 significand on gfx950 (plvs_hip_selftest_rcp checks all 2^23 of them).
 //  * A lane whose pass contains the end of its run (negative weight = last record), or an
 //    operand outside the exact range of the reciprocal form, redoes that pass step by step.
-//    Nothing is loaded there: the keyframe id of the last record is written by
-//    expand_records, the longest run is reduced once per wave.
+//    Nothing is loaded there: the keyframe id of the voxel is written by gather_runs,
+//    the longest run is reduced once per wave.
 constexpr int kChainBatch = 8;
 constexpr int kChainSets = 4;
 
@@ -220,7 +658,7 @@ struct __attribute__((packed, aligned(8))) RecPair {   // two consecutive float2
 __device__ __forceinline__ int stage_unit(int run, int u) { return run * 4 + ((u ^ (run >> 1)) & 3); }
 
 __global__ __launch_bounds__(64) void chain_runs(
-    const uint32_t* __restrict__ keys, uint32_t nrec, const float2* __restrict__ rec,
+    const uint32_t* __restrict__ head_keys, uint32_t nrec, const float2* __restrict__ rec,
     const uint32_t* __restrict__ heads, Counters* __restrict__ ctr, float* __restrict__ sdf,
     float* __restrict__ weight) {
   __shared__ float4 stage[kChainSets][64 * 4];
@@ -233,7 +671,7 @@ __global__ __launch_bounds__(64) void chain_runs(
     const uint32_t h = group * 64u + (uint32_t)l;
     bool live = h < nheads;
     const uint32_t r0 = live ? heads[h] : 0u;
-    const size_t a = live ? (size_t)keys[r0] : 0;   // slot*4096 + vid
+    const size_t a = live ? (size_t)head_keys[h] : 0;   // slot*4096 + vid
     float s = live ? sdf[a] : 0.0f;
     float w = live ? weight[a] : 1.0f;
     uint32_t my_len = 0;
@@ -381,36 +819,37 @@ __global__ __launch_bounds__(64) void chain_runs(
 // dependent, but frozen for good once the colour weight reaches 254, so a run
 // contributes at most (254 - weight) steps.  One thread per voxel run.
 __global__ __launch_bounds__(256) void chain_colours(
-    const uint32_t* __restrict__ keys, uint32_t nrec, const float2* __restrict__ rec,
+    const uint32_t* __restrict__ head_keys, uint32_t nrec, const float2* __restrict__ rec,
     const uint32_t* __restrict__ rec_c, const uint32_t* __restrict__ heads,
     const Counters* __restrict__ ctr, uint32_t* __restrict__ rgbw) {
-  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-  if (h >= ctr->num_heads) return;
-  uint32_t r = heads[h];
-  const size_t a = (size_t)keys[r];
-  uint32_t col = rgbw[a];
-  if ((col >> 24) >= 254u) return;
-  for (;;) {
-    uint32_t c[4];
-    float y[4];
+  const uint32_t nheads = ctr->num_heads;
+  for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nheads; h += gridDim.x * blockDim.x) {
+    uint32_t r = heads[h];
+    const size_t a = (size_t)head_keys[h];
+    uint32_t col = rgbw[a];
+    if ((col >> 24) >= 254u) continue;
+    for (;;) {
+      uint32_t c[4];
+      float y[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t rr = (r + j < nrec) ? r + j : nrec - 1;
-      c[j] = rec_c[rr];
-      y[j] = rec[rr].y;
-    }
-    bool done = false;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (!done) {
-        colour_update(col, c[j] & 255u, (c[j] >> 8) & 255u, (c[j] >> 16) & 255u);
-        done = (y[j] < 0.0f) || ((col >> 24) >= 254u);
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t rr = (r + j < nrec) ? r + j : nrec - 1;
+        c[j] = rec_c[rr];
+        y[j] = rec[rr].y;
       }
+      bool done = false;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (!done) {
+          colour_update(col, c[j] & 255u, (c[j] >> 8) & 255u, (c[j] >> 16) & 255u);
+          done = (y[j] < 0.0f) || ((col >> 24) >= 254u);
+        }
+      }
+      if (done) break;
+      r += 4;
     }
-    if (done) break;
-    r += 4;
+    rgbw[a] = col;
   }
-  rgbw[a] = col;
 }
 
 // Hardware assumption of chain_runs, checked exhaustively: rcp_rn(b) == RN(1/b) for every
@@ -436,9 +875,13 @@ struct plvs_tsdf_chisel {
   int num_chunks = 0;         // host mirror
   bool poisoned = false;
   // per-call scratch
-  DevBuf<uint32_t> counts, keys0, keys1, pts0, pts1, heads, updated, scratch;
-  DevBuf<float2> rec;
-  DevBuf<uint32_t> rec_c;
+  DevBuf<uint32_t> counts, heads, head_keys, updated, scratch;
+  DevBuf<float2> rec, rec_t;         // operands in voxel order / grouped per tile
+  DevBuf<uint32_t> rec_c, recc_t;    // colours, same two orders
+  DevBuf<uint32_t> dkey0, dkey1, didx0, didx1, run_cnt, run_dst;   // run descriptors
+  DevBuf<uint4> desc;
+  DevBuf<uint32_t> tile_first, block_first;
+  DevBuf<unsigned long long> tile_state;   // [0]: ticket, [1..]: look-back state per tile
   DevBuf<Pose> poses;
   DevBuf<int32_t> offsets;
   // host-flavour staging
@@ -562,8 +1005,11 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   if (h->side) (void)hipStreamDestroy(h->side);
   for (int i = 0; i <= kNumStages; ++i)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
-  h->counts.release(); h->keys0.release(); h->keys1.release(); h->pts0.release(); h->pts1.release();
-  h->rec.release(); h->rec_c.release();
+  h->counts.release(); h->head_keys.release();
+  h->rec.release(); h->rec_c.release(); h->rec_t.release(); h->recc_t.release();
+  h->dkey0.release(); h->dkey1.release(); h->didx0.release(); h->didx1.release();
+  h->desc.release(); h->run_cnt.release(); h->run_dst.release();
+  h->tile_first.release(); h->block_first.release(); h->tile_state.release();
   h->heads.release(); h->updated.release(); h->scratch.release(); h->poses.release();
   h->offsets.release(); h->st_xyz.release(); h->st_Twc.release(); h->st_rgb.release();
   h->st_kfid.release();
@@ -611,7 +1057,7 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
 
   PLVS_HIP_TRY(h->offsets.reserve((size_t)nclouds + 1));
   PLVS_HIP_TRY(h->poses.reserve((size_t)nclouds));
-  PLVS_HIP_TRY(h->counts.reserve((size_t)n));
+  PLVS_HIP_TRY(h->counts.reserve((size_t)n + 1));
   PLVS_HIP_TRY(h->scratch.reserve(scan_scratch_words((size_t)n)));
   PLVS_HIP_TRY(hipMemcpyAsync(h->offsets.p, offsets, ((size_t)nclouds + 1) * sizeof(int32_t),
                               hipMemcpyHostToDevice, s));
@@ -619,19 +1065,20 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
                      h->poses.p);
   // reset the per-call counters, keep num_chunks
   PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->total_visits, 0, sizeof(uint32_t), s));
-  PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->err, 0, 4 * sizeof(uint32_t), s));
+  PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->err, 0, 5 * sizeof(uint32_t), s));
 
 #define STAGE_MARK(i) \
   do { if (h->profiling) PLVS_HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
-  const dim3 rgrid(ceil_div((size_t)n, 256)), rblock(256);
   STAGE_MARK(0);
-  hipLaunchKernelGGL(ray_pass<false>, rgrid, rblock, 0, s, h->P, d_xyz, n, h->offsets.p, nclouds,
-                     h->poses.p, h->dir, h->d_ctr, h->counts.p, (uint32_t*)nullptr,
-                     (uint32_t*)nullptr);
+  hipLaunchKernelGGL(ray_count, dim3(ceil_div((size_t)n, 256)), dim3(256), 0, s, h->P, d_xyz, n,
+                     h->offsets.p, nclouds, h->poses.p, h->dir, h->d_ctr, h->counts.p);
   PLVS_KERNEL_CHECK();
   STAGE_MARK(1);
+  // counts -> visit offsets (n + 1 entries: the total closes the list)
   PLVS_HIP_TRY(exclusive_scan_u32(h->counts.p, h->counts.p, (size_t)n, &h->d_ctr->total_visits,
                                   h->scratch.p, s));
+  PLVS_HIP_TRY(hipMemcpyAsync(h->counts.p + n, &h->d_ctr->total_visits, sizeof(uint32_t),
+                              hipMemcpyDeviceToDevice, s));
   STAGE_MARK(2);
   int rc = read_counters(h, s);
   if (rc != PLVS_OK) return rc;
@@ -653,52 +1100,82 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
     return PLVS_ERR_CAPACITY;
   }
 
-  PLVS_HIP_TRY(h->keys0.reserve(V));
-  PLVS_HIP_TRY(h->keys1.reserve(V));
-  PLVS_HIP_TRY(h->pts0.reserve(V));
-  PLVS_HIP_TRY(h->pts1.reserve(V));
-  PLVS_HIP_TRY(h->heads.reserve(V));
+  const uint32_t ntiles = ceil_div(V, kTileSlots);
+  PLVS_HIP_TRY(h->rec_t.reserve(V));
+  PLVS_HIP_TRY(h->recc_t.reserve(V));
   PLVS_HIP_TRY(h->rec.reserve((size_t)V + 2));   // chain_runs reads record pairs
   PLVS_HIP_TRY(h->rec_c.reserve(V));
+  PLVS_HIP_TRY(h->heads.reserve(V));
+  PLVS_HIP_TRY(h->head_keys.reserve(V));
+  PLVS_HIP_TRY(h->dkey0.reserve(V));
+  PLVS_HIP_TRY(h->didx0.reserve(V));
+  PLVS_HIP_TRY(h->desc.reserve(V));
+  PLVS_HIP_TRY(h->tile_first.reserve(ntiles));
+  PLVS_HIP_TRY(h->block_first.reserve(ceil_div(V, kGatherSpan)));
+  PLVS_HIP_TRY(h->tile_state.reserve((size_t)ntiles + 1));
   PLVS_HIP_TRY(h->updated.reserve((size_t)h->num_chunks + 1));
-  PLVS_HIP_TRY(h->scratch.reserve(radix_scratch_words(V)));
   float ms_a[2] = {0.f, 0.f};
   if (h->profiling) {  // stages 0,1 are complete (the counter read synchronised)
     PLVS_HIP_TRY(hipEventElapsedTime(&ms_a[0], h->ev[0], h->ev[1]));
     PLVS_HIP_TRY(hipEventElapsedTime(&ms_a[1], h->ev[1], h->ev[2]));
   }
   STAGE_MARK(2);
-  hipLaunchKernelGGL(ray_pass<true>, rgrid, rblock, 0, s, h->P, d_xyz, n, h->offsets.p, nclouds,
-                     h->poses.p, h->dir, h->d_ctr, h->counts.p, h->keys0.p, h->pts0.p);
+  PLVS_HIP_TRY(hipMemsetAsync(h->tile_state.p, 0, ((size_t)ntiles + 1) * sizeof(unsigned long long), s));
+  hipLaunchKernelGGL(mark_tiles, dim3(ceil_div((size_t)n, 256)), dim3(256), 0, s, h->counts.p, n,
+                     h->tile_first.p);
+  {
+    TileOut out{h->rec_t.p, h->recc_t.p, h->dkey0.p, h->desc.p, h->didx0.p};
+    hipLaunchKernelGGL(ray_tiles, dim3(ntiles), dim3(kTileThreads), 0, s, h->P, d_xyz, d_rgb, n,
+                       h->offsets.p, nclouds, h->poses.p, h->dir, h->d_ctr, h->counts.p, V,
+                       h->tile_first.p, ntiles, reinterpret_cast<uint32_t*>(h->tile_state.p),
+                       h->tile_state.p + 1, out);
+  }
   PLVS_KERNEL_CHECK();
+  STAGE_MARK(3);
+  rc = read_counters(h, s);   // the number of runs sizes the sort
+  if (rc != PLVS_OK) return rc;
+  if (h->h_ctr->err) {
+    h->poisoned = true;
+    plvs::set_error("tsdf_chisel integrate: internal directory miss (err=%u)", h->h_ctr->err);
+    return PLVS_ERR_CAPACITY;
+  }
+  const uint32_t D = h->h_ctr->num_desc;
+  float ms_b = 0.f;
+  if (h->profiling) PLVS_HIP_TRY(hipEventElapsedTime(&ms_b, h->ev[2], h->ev[3]));
+  PLVS_HIP_TRY(h->dkey1.reserve(D));
+  PLVS_HIP_TRY(h->didx1.reserve(D));
+  PLVS_HIP_TRY(h->run_cnt.reserve(D));
+  PLVS_HIP_TRY(h->run_dst.reserve(D));
+  PLVS_HIP_TRY(h->scratch.reserve(radix_scratch_words(D)));
   STAGE_MARK(3);
   int key_bits = 12;
   while ((1ll << (key_bits - 12)) < (long long)h->num_chunks) ++key_bits;
   bool second = false;
-  PLVS_HIP_TRY(radix_sort_pairs(h->keys0.p, h->pts0.p, h->keys1.p, h->pts1.p, V, 0, key_bits,
+  PLVS_HIP_TRY(radix_sort_pairs(h->dkey0.p, h->didx0.p, h->dkey1.p, h->didx1.p, D, 0, key_bits,
                                 h->scratch.p, s, &second));
-  const uint32_t* keys = second ? h->keys1.p : h->keys0.p;
-  const uint32_t* pts = second ? h->pts1.p : h->pts0.p;
+  const uint32_t* skeys = second ? h->dkey1.p : h->dkey0.p;
+  const uint32_t* sidx = second ? h->didx1.p : h->didx0.p;
   STAGE_MARK(4);
-  hipLaunchKernelGGL(expand_records, dim3(ceil_div(V, kExpandThreads)), dim3(kExpandThreads), 0, s,
-                     h->P, keys, pts, V, d_xyz, d_rgb, h->offsets.p, nclouds, h->poses.p,
-                     h->dir.slot_ids, h->rec.p, h->rec_c.p, h->heads.p, h->updated.p, h->d_ctr, d_kfid,
-                     h->kfid);
+  hipLaunchKernelGGL(run_counts, dim3(ceil_div(D, 256)), dim3(256), 0, s, sidx, h->desc.p, D, h->run_cnt.p);
+  PLVS_HIP_TRY(exclusive_scan_u32(h->run_cnt.p, h->run_dst.p, D, nullptr, h->scratch.p, s));
+  const uint32_t nblocks = ceil_div(V, kGatherSpan);
+  hipLaunchKernelGGL(mark_blocks, dim3(ceil_div(D, 256)), dim3(256), 0, s, h->run_dst.p, D, V, h->block_first.p);
+  hipLaunchKernelGGL(gather_runs, dim3(nblocks), dim3(kGatherThreads), 0, s, skeys, sidx, D, h->desc.p,
+                     h->run_dst.p, h->block_first.p, nblocks, V, h->rec_t.p, h->recc_t.p, h->rec.p,
+                     h->rec_c.p, h->heads.p, h->head_keys.p, h->updated.p, h->d_ctr, d_kfid, h->kfid);
   PLVS_KERNEL_CHECK();
   STAGE_MARK(5);
-  // one thread per voxel run; launched over V (upper bound of the run count),
-  // surplus threads exit on the device-side head count.
-  // The colour chain touches only rgbw and the distance chain only sdf/weight/kfid; both are
+  // The colour chain touches only rgbw and the distance chain only sdf/weight; both are
   // latency-bound with few waves, so they run side by side on two streams.
   PLVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
   PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-  hipLaunchKernelGGL(chain_colours, dim3(ceil_div(V, 256)), dim3(256), 0, h->side, keys, V, h->rec.p,
-                     h->rec_c.p, h->heads.p, h->d_ctr, h->rgbw);
+  hipLaunchKernelGGL(chain_colours, dim3(std::min<size_t>(ceil_div(D, 256), 2048)), dim3(256), 0, h->side,
+                     h->head_keys.p, V, h->rec.p, h->rec_c.p, h->heads.p, h->d_ctr, h->rgbw);
   PLVS_HIP_TRY(hipEventRecord(h->ev_join, h->side));
-  // one thread per voxel run; launched over V (upper bound of the run count), surplus
-  // waves exit on the device-side head count
-  hipLaunchKernelGGL(chain_runs, dim3(std::min<size_t>(ceil_div(V, 64), 16384)), dim3(64), 0, s, keys, V,
-                     h->rec.p, h->heads.p, h->d_ctr, h->sdf, h->weight);
+  // one thread per voxel; the grid is an upper bound of the voxel count, surplus waves exit
+  // on the device-side count
+  hipLaunchKernelGGL(chain_runs, dim3(std::min<size_t>(ceil_div(D, 64), 16384)), dim3(64), 0, s,
+                     h->head_keys.p, V, h->rec.p, h->heads.p, h->d_ctr, h->sdf, h->weight);
   PLVS_HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
   PLVS_KERNEL_CHECK();
   STAGE_MARK(6);
@@ -708,7 +1185,8 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   if (h->profiling) {
     h->stage_ms[0] += ms_a[0];
     h->stage_ms[1] += ms_a[1];
-    for (int i = 2; i < kNumStages; ++i) {
+    h->stage_ms[2] += ms_b;
+    for (int i = 3; i < kNumStages; ++i) {
       float ms = 0.f;
       PLVS_HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
       h->stage_ms[i] += ms;
@@ -723,6 +1201,14 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   h->stats.updated_chunks = (int32_t)h->h_ctr->num_updated;
   h->stats.voxels = (int32_t)h->h_ctr->num_heads;
   h->stats.max_run = (int32_t)h->h_ctr->max_run;
+#if PLVS_TILE_PROBE
+  {
+    const unsigned long long* q = h->h_ctr->tprobe;
+    fprintf(stderr, "tile probe (cycles/tile): setup %llu raycast %llu group %llu radix %llu heads+lookback %llu out %llu | tiles %u runs %u\n",
+            q[0] / ntiles, q[1] / ntiles, q[2] / ntiles, q[3] / ntiles, q[5] / ntiles, q[6] / ntiles, ntiles, D);
+    (void)hipMemsetAsync(h->d_ctr->tprobe, 0, sizeof(h->d_ctr->tprobe), s);
+  }
+#endif
 #if PLVS_CHAIN_PROBE
   {
     const unsigned long long m = (1ull << 40) - 1;
