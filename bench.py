@@ -167,6 +167,16 @@ def main():
             "dominant_stage": dominant,
             "algorithmic_bytes_per_launch": alg_bytes / max(calls, 1),
         }
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
+        # runs of this same command; scripts/pmc_traffic.py) committed under profiles/
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                           f"r01_pmc_traffic_{args.backend}.json")
+        if world == 1 and args.batch == 25 and os.path.exists(pmc):
+            with open(pmc) as f:
+                t = json.load(f)
+            roofline["traffic"] = t["traffic"]
+            roofline["traffic_source"] = ("profiles/" + os.path.basename(pmc) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                          "passes of this command, FETCH_SIZE x2 (gfx950) + WRITE_SIZE, per launch")
         result = {
             "metric": ("Mvoxels/sec TSDF integrate (voxblox simple 2 cm / 8 m, 640x480 RGB-D)" if vbx else
                        "Mvoxels/sec TSDF integrate (chisel 5 cm / 5 m, 640x480 RGB-D)"),

@@ -126,10 +126,10 @@ __global__ __launch_bounds__(kThreads) void radix_hist(const uint32_t* __restric
   for (int d = threadIdx.x; d < kRadix; d += kThreads) hist[(size_t)d * nb + blockIdx.x] = h[d];
 }
 
-template <int kBits>
+template <int kBits, typename TV>
 __global__ __launch_bounds__(kThreads) void radix_scatter(
-    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n, int shift,
+    const uint32_t* __restrict__ keys_in, const TV* __restrict__ vals_in,
+    uint32_t* __restrict__ keys_out, TV* __restrict__ vals_out, size_t n, int shift,
     size_t nb, const uint32_t* __restrict__ hist_scanned) {
   constexpr int kRadix = 1 << kBits;
   constexpr uint32_t kMask = kRadix - 1;
@@ -146,7 +146,8 @@ __global__ __launch_bounds__(kThreads) void radix_scatter(
   __syncthreads();
 
   const size_t span = (size_t)blockIdx.x * kSortTile + (size_t)wid * kWaveSpan;
-  uint32_t k[kSortItems], v[kSortItems], rank[kSortItems];
+  uint32_t k[kSortItems], rank[kSortItems];
+  TV v[kSortItems];
   volatile uint32_t* my_hist = wave_hist[wid];
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(kThreads) void radix_scatter(
     const size_t i = span + (size_t)it * 64 + lane;
     const bool valid = i < n;
     k[it] = valid ? keys_in[i] : 0u;
-    v[it] = valid ? vals_in[i] : 0u;
+    v[it] = valid ? vals_in[i] : TV(0);
     const uint32_t d = (k[it] >> shift) & kMask;
     // lanes holding the same digit (and a valid key)
     unsigned long long peers = __ballot(valid);
@@ -196,8 +197,8 @@ __global__ __launch_bounds__(kThreads) void radix_scatter(
   }
 }
 
-template <int kBits>
-hipError_t radix_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, size_t n,
+template <int kBits, typename TV>
+hipError_t radix_pass(const uint32_t* ki, const TV* vi, uint32_t* ko, TV* vo, size_t n,
                       int shift, size_t nb, uint32_t* hist, uint32_t* scan_scratch,
                       hipStream_t stream) {
   constexpr size_t kRadix = (size_t)1 << kBits;
@@ -205,7 +206,7 @@ hipError_t radix_pass(const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint
                      nb, hist);
   hipError_t e = exclusive_scan_u32(hist, hist, kRadix * nb, nullptr, scan_scratch, stream);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(radix_scatter<kBits>, dim3((unsigned)nb), dim3(kThreads), 0, stream, ki, vi, ko,
+  hipLaunchKernelGGL((radix_scatter<kBits, TV>), dim3((unsigned)nb), dim3(kThreads), 0, stream, ki, vi, ko,
                      vo, n, shift, nb, hist);
   return hipGetLastError();
 }
@@ -234,7 +235,8 @@ size_t radix_scratch_words(size_t n) {
   return radix * nb + scan_scratch_words(radix * nb);
 }
 
-hipError_t radix_sort_pairs(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1,
+template <typename TV>
+static hipError_t radix_sort_impl(uint32_t* keys0, TV* vals0, uint32_t* keys1, TV* vals1,
                             size_t n, int bit_lo, int bit_hi, uint32_t* scratch,
                             hipStream_t stream, bool* result_in_second) {
   *result_in_second = false;
@@ -249,21 +251,36 @@ hipError_t radix_sort_pairs(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, u
   const int passes = (total + kMaxRadixBits - 1) / kMaxRadixBits;
   int bits = (total + passes - 1) / passes;
   if (bits < 8) bits = 8;
-  uint32_t *ki = keys0, *vi = vals0, *ko = keys1, *vo = vals1;
+  uint32_t *ki = keys0, *ko = keys1;
+  TV *vi = vals0, *vo = vals1;
   for (int p = 0, shift = bit_lo; p < passes; ++p, shift += bits) {
     hipError_t e;
     switch (bits) {
-      case 8: e = radix_pass<8>(ki, vi, ko, vo, n, shift, nb, hist, scan_scratch, stream); break;
-      case 9: e = radix_pass<9>(ki, vi, ko, vo, n, shift, nb, hist, scan_scratch, stream); break;
-      case 10: e = radix_pass<10>(ki, vi, ko, vo, n, shift, nb, hist, scan_scratch, stream); break;
-      default: e = radix_pass<11>(ki, vi, ko, vo, n, shift, nb, hist, scan_scratch, stream); break;
+      case 8: e = radix_pass<8, TV>(ki, vi, ko, vo, n, shift, nb, hist, scan_scratch, stream); break;
+      case 9: e = radix_pass<9, TV>(ki, vi, ko, vo, n, shift, nb, hist, scan_scratch, stream); break;
+      case 10: e = radix_pass<10, TV>(ki, vi, ko, vo, n, shift, nb, hist, scan_scratch, stream); break;
+      default: e = radix_pass<11, TV>(ki, vi, ko, vo, n, shift, nb, hist, scan_scratch, stream); break;
     }
     if (e != hipSuccess) return e;
     uint32_t* t = ki; ki = ko; ko = t;
-    t = vi; vi = vo; vo = t;
+    TV* tv = vi; vi = vo; vo = tv;
     *result_in_second = !*result_in_second;
   }
   return hipSuccess;
+}
+
+hipError_t radix_sort_pairs(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1,
+                            size_t n, int bit_lo, int bit_hi, uint32_t* scratch,
+                            hipStream_t stream, bool* result_in_second) {
+  return radix_sort_impl<uint32_t>(keys0, vals0, keys1, vals1, n, bit_lo, bit_hi, scratch, stream,
+                                   result_in_second);
+}
+
+hipError_t radix_sort_pairs_u64(uint32_t* keys0, unsigned long long* vals0, uint32_t* keys1,
+                                unsigned long long* vals1, size_t n, int bit_lo, int bit_hi,
+                                uint32_t* scratch, hipStream_t stream, bool* result_in_second) {
+  return radix_sort_impl<unsigned long long>(keys0, vals0, keys1, vals1, n, bit_lo, bit_hi, scratch,
+                                             stream, result_in_second);
 }
 
 }  // namespace plvs

@@ -24,4 +24,9 @@ hipError_t radix_sort_pairs(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, u
                             size_t n, int bit_lo, int bit_hi, uint32_t* scratch,
                             hipStream_t stream, bool* result_in_second);
 
+// Same with 64-bit values.
+hipError_t radix_sort_pairs_u64(uint32_t* keys0, unsigned long long* vals0, uint32_t* keys1,
+                                unsigned long long* vals1, size_t n, int bit_lo, int bit_hi,
+                                uint32_t* scratch, hipStream_t stream, bool* result_in_second);
+
 }  // namespace plvs

@@ -248,7 +248,7 @@ struct TileOut {
   uint32_t* recc_t;     // [V] colours, tile-grouped
   uint32_t* dkey;       // run descriptors: voxel key,
   uint4* desc;          // (position in rec_t, length, point of the last visit, -)
-  uint32_t* didx;       // identity, the value array of the sort
+  unsigned long long* didx;   // value array of the sort: descriptor index | length << 32
 };
 
 __device__ __forceinline__ unsigned long long ld_state(const unsigned long long* p) {
@@ -465,16 +465,16 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
     const uint32_t d = dbase + g;
     out.dkey[d] = skey[bufA[p0] & 0xFFFu];
     out.desc[d] = make_uint4(slot0 + p0, p1 - p0, first + spt[bufA[p1 - 1] & 0xFFFu], 0u);
-    out.didx[d] = d;
+    out.didx[d] = (unsigned long long)d | ((unsigned long long)(p1 - p0) << 32);
   }
   TILE_PROBE(6)
 }
 
-// counts of the runs in sorted order (input of the scan that places them)
-__global__ void run_counts(const uint32_t* __restrict__ sorted_idx, const uint4* __restrict__ desc,
-                           uint32_t nd, uint32_t* __restrict__ cnts) {
+// lengths of the runs in sorted order (input of the scan that places them)
+__global__ void run_counts(const unsigned long long* __restrict__ sorted_val, uint32_t nd,
+                           uint32_t* __restrict__ cnts) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < nd) cnts[j] = desc[sorted_idx[j]].y;
+  if (j < nd) cnts[j] = (uint32_t)(sorted_val[j] >> 32);
 }
 
 // the run holding the first record of every block of kGatherSpan output records
@@ -499,7 +499,7 @@ __global__ void mark_blocks(const uint32_t* __restrict__ dst, uint32_t nd, uint3
 // and the updated chunks, and sets the keyframe id of the voxel (SetKfid: the last update
 // of the call wins).
 __global__ __launch_bounds__(kGatherThreads) void gather_runs(
-    const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ sorted_idx, uint32_t nd,
+    const uint32_t* __restrict__ skeys, const unsigned long long* __restrict__ sorted_val, uint32_t nd,
     const uint4* __restrict__ desc, const uint32_t* __restrict__ dst,
     const uint32_t* __restrict__ block_first, uint32_t nblocks, uint32_t V,
     const float2* __restrict__ rec_t, const uint32_t* __restrict__ recc_t, float2* __restrict__ rec,
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(kGatherThreads) void gather_runs(
     const uint32_t j = j_lo + jl;
     const uint32_t key = skeys[j];
     const uint32_t next = (j + 1 < nd) ? skeys[j + 1] : ~key;
-    const uint4 d = desc[sorted_idx[j]];
+    const uint4 d = desc[(uint32_t)sorted_val[j]];
     const uint32_t a = dst[j];
     const bool closes = key != next;
     delta[jl] = d.x - a;
@@ -878,7 +878,8 @@ struct plvs_tsdf_chisel {
   DevBuf<uint32_t> counts, heads, head_keys, updated, scratch;
   DevBuf<float2> rec, rec_t;         // operands in voxel order / grouped per tile
   DevBuf<uint32_t> rec_c, recc_t;    // colours, same two orders
-  DevBuf<uint32_t> dkey0, dkey1, didx0, didx1, run_cnt, run_dst;   // run descriptors
+  DevBuf<uint32_t> dkey0, dkey1, run_cnt, run_dst;   // run descriptors
+  DevBuf<unsigned long long> didx0, didx1;
   DevBuf<uint4> desc;
   DevBuf<uint32_t> tile_first, block_first;
   DevBuf<unsigned long long> tile_state;   // [0]: ticket, [1..]: look-back state per tile
@@ -1151,12 +1152,12 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   int key_bits = 12;
   while ((1ll << (key_bits - 12)) < (long long)h->num_chunks) ++key_bits;
   bool second = false;
-  PLVS_HIP_TRY(radix_sort_pairs(h->dkey0.p, h->didx0.p, h->dkey1.p, h->didx1.p, D, 0, key_bits,
+  PLVS_HIP_TRY(radix_sort_pairs_u64(h->dkey0.p, h->didx0.p, h->dkey1.p, h->didx1.p, D, 0, key_bits,
                                 h->scratch.p, s, &second));
   const uint32_t* skeys = second ? h->dkey1.p : h->dkey0.p;
-  const uint32_t* sidx = second ? h->didx1.p : h->didx0.p;
+  const unsigned long long* sidx = second ? h->didx1.p : h->didx0.p;
   STAGE_MARK(4);
-  hipLaunchKernelGGL(run_counts, dim3(ceil_div(D, 256)), dim3(256), 0, s, sidx, h->desc.p, D, h->run_cnt.p);
+  hipLaunchKernelGGL(run_counts, dim3(ceil_div(D, 256)), dim3(256), 0, s, sidx, D, h->run_cnt.p);
   PLVS_HIP_TRY(exclusive_scan_u32(h->run_cnt.p, h->run_dst.p, D, nullptr, h->scratch.p, s));
   const uint32_t nblocks = ceil_div(V, kGatherSpan);
   hipLaunchKernelGGL(mark_blocks, dim3(ceil_div(D, 256)), dim3(256), 0, s, h->run_dst.p, D, V, h->block_first.p);
