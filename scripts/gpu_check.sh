@@ -45,3 +45,7 @@ fi
 find "$O" -type f | head -40
 cat "$O/stages.log"
 for f in pytest_gpu smoke bench bench_voxblox sweep rocprof; do [ -f "$O/$f.log" ] && tail -4 "$O/$f.log"; done
+if [[ "$STAGES" == *clk* ]]; then
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d "$R/$O/pmc_clk" -o r -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-frontend 2>&1 | tail -5 ) > "$O/pmc_clk.log" 2>&1
+  echo "clk done $(date +%T)" >> "$O/stages.log"
+fi
