@@ -247,8 +247,8 @@ struct TileOut {
   float2* rec_t;        // [V] operands, tile-grouped
   uint32_t* recc_t;     // [V] colours, tile-grouped
   uint32_t* dkey;       // run descriptors: voxel key,
-  uint4* desc;          // (position in rec_t, length, point of the last visit, -)
-  unsigned long long* didx;   // value array of the sort: descriptor index | length << 32
+  unsigned long long* dval;   // value array of the sort: position in rec_t | length << 32,
+  uint32_t* last_pt;    // [V], sparse: at a run's position, the point of its last visit
 };
 
 __device__ __forceinline__ unsigned long long ld_state(const unsigned long long* p) {
@@ -464,8 +464,8 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
     const uint32_t p0 = hp[g], p1 = hp[g + 1];
     const uint32_t d = dbase + g;
     out.dkey[d] = skey[bufA[p0] & 0xFFFu];
-    out.desc[d] = make_uint4(slot0 + p0, p1 - p0, first + spt[bufA[p1 - 1] & 0xFFFu], 0u);
-    out.didx[d] = (unsigned long long)d | ((unsigned long long)(p1 - p0) << 32);
+    out.dval[d] = (unsigned long long)(slot0 + p0) | ((unsigned long long)(p1 - p0) << 32);
+    out.last_pt[slot0 + p0] = first + spt[bufA[p1 - 1] & 0xFFFu];
   }
   TILE_PROBE(6)
 }
@@ -500,7 +500,7 @@ __global__ void mark_blocks(const uint32_t* __restrict__ dst, uint32_t nd, uint3
 // of the call wins).
 __global__ __launch_bounds__(kGatherThreads) void gather_runs(
     const uint32_t* __restrict__ skeys, const unsigned long long* __restrict__ sorted_val, uint32_t nd,
-    const uint4* __restrict__ desc, const uint32_t* __restrict__ dst,
+    const uint32_t* __restrict__ last_pt, const uint32_t* __restrict__ dst,
     const uint32_t* __restrict__ block_first, uint32_t nblocks, uint32_t V,
     const float2* __restrict__ rec_t, const uint32_t* __restrict__ recc_t, float2* __restrict__ rec,
     uint32_t* __restrict__ rec_c, uint32_t* __restrict__ heads, uint32_t* __restrict__ head_keys,
@@ -530,17 +530,18 @@ __global__ __launch_bounds__(kGatherThreads) void gather_runs(
     const uint32_t j = j_lo + jl;
     const uint32_t key = skeys[j];
     const uint32_t next = (j + 1 < nd) ? skeys[j + 1] : ~key;
-    const uint4 d = desc[(uint32_t)sorted_val[j]];
+    const unsigned long long d = sorted_val[j];
+    const uint32_t from = (uint32_t)d, len = (uint32_t)(d >> 32);
     const uint32_t a = dst[j];
     const bool closes = key != next;
-    delta[jl] = d.x - a;
-    endl[jl] = (a + d.y) | (closes ? 0x80000000u : 0u);
+    delta[jl] = from - a;
+    endl[jl] = (a + len) | (closes ? 0x80000000u : 0u);
     if (a < B0 + nrec) id[max(a, B0) - B0] = (uint16_t)(jl + 1);
     if (a >= B0 && a < B0 + nrec) {
       const uint32_t prev = j ? skeys[j - 1] : ~key;
       my_heads += (key != prev) ? 1u : 0u;
       my_heads += (j == 0 || (key >> 12) != (prev >> 12)) ? (1u << 16) : 0u;
-      if (closes) vkfid[key] = kfid ? kfid[d.z] : 0u;
+      if (closes) vkfid[key] = kfid ? kfid[last_pt[from]] : 0u;
     }
   }
   // block-aggregated, order-free compaction of the two head lists
@@ -878,9 +879,8 @@ struct plvs_tsdf_chisel {
   DevBuf<uint32_t> counts, heads, head_keys, updated, scratch;
   DevBuf<float2> rec, rec_t;         // operands in voxel order / grouped per tile
   DevBuf<uint32_t> rec_c, recc_t;    // colours, same two orders
-  DevBuf<uint32_t> dkey0, dkey1, run_cnt, run_dst;   // run descriptors
+  DevBuf<uint32_t> dkey0, dkey1, run_cnt, run_dst, last_pt;   // run descriptors
   DevBuf<unsigned long long> didx0, didx1;
-  DevBuf<uint4> desc;
   DevBuf<uint32_t> tile_first, block_first;
   DevBuf<unsigned long long> tile_state;   // [0]: ticket, [1..]: look-back state per tile
   DevBuf<Pose> poses;
@@ -1009,7 +1009,7 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   h->counts.release(); h->head_keys.release();
   h->rec.release(); h->rec_c.release(); h->rec_t.release(); h->recc_t.release();
   h->dkey0.release(); h->dkey1.release(); h->didx0.release(); h->didx1.release();
-  h->desc.release(); h->run_cnt.release(); h->run_dst.release();
+  h->last_pt.release(); h->run_cnt.release(); h->run_dst.release();
   h->tile_first.release(); h->block_first.release(); h->tile_state.release();
   h->heads.release(); h->updated.release(); h->scratch.release(); h->poses.release();
   h->offsets.release(); h->st_xyz.release(); h->st_Twc.release(); h->st_rgb.release();
@@ -1110,7 +1110,7 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   PLVS_HIP_TRY(h->head_keys.reserve(V));
   PLVS_HIP_TRY(h->dkey0.reserve(V));
   PLVS_HIP_TRY(h->didx0.reserve(V));
-  PLVS_HIP_TRY(h->desc.reserve(V));
+  PLVS_HIP_TRY(h->last_pt.reserve(V));
   PLVS_HIP_TRY(h->tile_first.reserve(ntiles));
   PLVS_HIP_TRY(h->block_first.reserve(ceil_div(V, kGatherSpan)));
   PLVS_HIP_TRY(h->tile_state.reserve((size_t)ntiles + 1));
@@ -1125,7 +1125,7 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   hipLaunchKernelGGL(mark_tiles, dim3(ceil_div((size_t)n, 256)), dim3(256), 0, s, h->counts.p, n,
                      h->tile_first.p);
   {
-    TileOut out{h->rec_t.p, h->recc_t.p, h->dkey0.p, h->desc.p, h->didx0.p};
+    TileOut out{h->rec_t.p, h->recc_t.p, h->dkey0.p, h->didx0.p, h->last_pt.p};
     hipLaunchKernelGGL(ray_tiles, dim3(ntiles), dim3(kTileThreads), 0, s, h->P, d_xyz, d_rgb, n,
                        h->offsets.p, nclouds, h->poses.p, h->dir, h->d_ctr, h->counts.p, V,
                        h->tile_first.p, ntiles, reinterpret_cast<uint32_t*>(h->tile_state.p),
@@ -1161,7 +1161,7 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   PLVS_HIP_TRY(exclusive_scan_u32(h->run_cnt.p, h->run_dst.p, D, nullptr, h->scratch.p, s));
   const uint32_t nblocks = ceil_div(V, kGatherSpan);
   hipLaunchKernelGGL(mark_blocks, dim3(ceil_div(D, 256)), dim3(256), 0, s, h->run_dst.p, D, V, h->block_first.p);
-  hipLaunchKernelGGL(gather_runs, dim3(nblocks), dim3(kGatherThreads), 0, s, skeys, sidx, D, h->desc.p,
+  hipLaunchKernelGGL(gather_runs, dim3(nblocks), dim3(kGatherThreads), 0, s, skeys, sidx, D, h->last_pt.p,
                      h->run_dst.p, h->block_first.p, nblocks, V, h->rec_t.p, h->recc_t.p, h->rec.p,
                      h->rec_c.p, h->heads.p, h->head_keys.p, h->updated.p, h->d_ctr, d_kfid, h->kfid);
   PLVS_KERNEL_CHECK();
