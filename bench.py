@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--max-depth", type=float, default=5.0)
     ap.add_argument("--backend", choices=["chisel", "voxblox"], default="chisel",
                     help="chisel = configs[2] (5 cm / 5 m); voxblox = configs[3] stand-in (2 cm / 8 m room)")
+    ap.add_argument("--order-free", action="store_true",
+                    help="chisel: sum the visits of a call per voxel and apply them in one update (sdf / weight within "
+                         "the float tolerance stated in tests/test_tsdf_chisel.py; kfid, colour exact)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frontend", action="store_true")
     return ap.parse_args()
@@ -90,7 +93,8 @@ def main():
     if vbx:
         tsdf = TsdfVoxblox(args.resolution, max_blocks=65536, shard_rank=rank, shard_count=world)
     else:
-        tsdf = TsdfChisel(args.resolution, max_chunks=16384, shard_rank=rank, shard_count=world)
+        tsdf = TsdfChisel(args.resolution, max_chunks=16384, shard_rank=rank, shard_count=world,
+                          order_free=args.order_free)
     upd_cap = 8192
     d_upd = torch.zeros((upd_cap, 3), dtype=torch.int32, device="cuda")
     gathered_blocks = [0]

@@ -243,6 +243,11 @@ typedef struct plvs_tsdf_chisel_params {
   int32_t max_chunks;    /* capacity of the device chunk pool (64 KiB of HBM each)         */
   int32_t shard_rank;    /* multi-GPU sharding: this instance only owns chunks with        */
   int32_t shard_count;   /*   (ChunkHasher(id) mod shard_count) == shard_rank; 0/1 = all   */
+  int32_t order_free;    /* 0 (default): every voxel update applied in the reference's order,
+                          *   results bit-identical to the CPU loop.  1: the visits of a call
+                          *   are summed per voxel and applied in one update — sdf / weight
+                          *   within float rounding of the reference (tolerance in
+                          *   tests/test_tsdf_chisel.py), kfid and colour still exact.       */
 } plvs_tsdf_chisel_params;
 
 typedef struct plvs_tsdf_chisel plvs_tsdf_chisel;

@@ -42,6 +42,7 @@ class TsdfChiselParams(ctypes.Structure):
         ("max_chunks", ctypes.c_int32),
         ("shard_rank", ctypes.c_int32),
         ("shard_count", ctypes.c_int32),
+        ("order_free", ctypes.c_int32),
     ]
 
 

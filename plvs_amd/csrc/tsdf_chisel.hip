@@ -249,6 +249,10 @@ struct TileOut {
   uint32_t* dkey;       // run descriptors: voxel key,
   unsigned long long* dval;   // value array of the sort: position in rec_t | length << 32,
   uint32_t* last_pt;    // [V], sparse: at a run's position, the point of its last visit
+  // order-free mode: one partial sum per run instead of the operands of every visit
+  float2* psum;         // [V], sparse, at the run's position: (sum of w_u * u, sum of w_u), point order
+                        // (dval and last_pt as in the ordered mode; colours in recc_t for the
+                        // voxels whose colour weight is still below 254)
 };
 
 __device__ __forceinline__ unsigned long long ld_state(const unsigned long long* p) {
@@ -258,12 +262,13 @@ __device__ __forceinline__ void st_state(unsigned long long* p, unsigned long lo
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+template <bool kOrderFree>
 __global__ __launch_bounds__(kTileThreads) void ray_tiles(
     Params P, const float* __restrict__ xyz, const uint8_t* __restrict__ rgb, int npoints,
     const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
     Counters* __restrict__ ctr, const uint32_t* __restrict__ voff, uint32_t V,
     const uint32_t* __restrict__ tile_first, uint32_t ntiles, uint32_t* __restrict__ ticket,
-    unsigned long long* __restrict__ tile_state, TileOut out) {
+    unsigned long long* __restrict__ tile_state, const uint32_t* __restrict__ rgbw, TileOut out) {
   __shared__ uint32_t skey[kTileSlots];     // voxel key of the visit in slot s
   __shared__ float su[kTileSlots];          // its signed distance u
   __shared__ uint16_t spt[kTileSlots];      // its point, relative to the tile's first point
@@ -415,6 +420,102 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
   __syncthreads();   // hp complete
 
   TILE_PROBE(5)
+  if constexpr (kOrderFree) {
+    // ---- phase 5 (order-free mode): one partial sum per run, summed in point order (the
+    // result is deterministic).  The colour stays exact: the reference's truncating mean only
+    // ever uses the first 254 visits of a voxel, so the colours of the visits are kept (in
+    // point order, as in the ordered mode) for the voxels whose colour weight is below 254 at
+    // the start of the call, and for those only.
+    __shared__ uint32_t saturated[kTileSlots / 32];   // per group-table entry: colour frozen
+    if (tid < kTileSlots / 32) saturated[tid] = 0;
+    uint32_t g_key[kTileItems], g_last[kTileItems];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < kTileItems; ++m) {
+      const uint32_t g = tid + m * kTileThreads;
+      g_key[m] = 0; g_last[m] = 0;
+      if (g < ngroups) {
+        const uint32_t tag = bufA[hp[g]];
+        g_key[m] = skey[tag & 0xFFFu];
+        g_last[m] = first + spt[bufA[hp[g + 1] - 1] & 0xFFFu];
+        if ((rgbw[g_key[m]] >> 24) >= 254u) atomicOr(&saturated[tag >> 17], 1u << ((tag >> 12) & 31u));
+      }
+    }
+    __syncthreads();
+    float v_wuu[kTileItems], v_wu[kTileItems];
+#pragma unroll
+    for (int k = 0; k < kTileItems; ++k) {
+      const uint32_t j = tid + k * kTileThreads;
+      v_wuu[k] = 0.f; v_wu[k] = 0.f;
+      if (j < n) {
+        const uint32_t tag = bufA[j];
+        const uint32_t s = tag & 0xFFFu;
+        const size_t p = (size_t)first + spt[s];
+        const float tr = truncation_of(P, xyz[3 * p + 2]);
+        const float wu = P.weight / (2.0f * tr);
+        v_wuu[k] = wu * su[s];
+        v_wu[k] = wu;
+        if (!((saturated[tag >> 17] >> ((tag >> 12) & 31u)) & 1u))
+          out.recc_t[slot0 + j] = colour_roundtrip(rgb[3 * p + 0]) | (colour_roundtrip(rgb[3 * p + 1]) << 8) |
+                                  (colour_roundtrip(rgb[3 * p + 2]) << 16);
+      }
+    }
+    __syncthreads();   // su / skey are free now: they take the per-position operands
+    float* const a_wuu = su;
+    float* const a_wu = reinterpret_cast<float*>(skey);
+#pragma unroll
+    for (int k = 0; k < kTileItems; ++k) {
+      const uint32_t j = tid + k * kTileThreads;
+      a_wuu[j] = v_wuu[k];
+      a_wu[j] = v_wu[k];
+    }
+  // the tile's place in the run numbering: wave 0, decoupled look-back over 64 predecessors
+  // at a time (they published their counts a phase ago)
+  if (wid == 0) {
+    unsigned long long base = 0;
+    if (t > 0) {
+      for (long long hi = (long long)t - 1; hi >= 0; hi -= 64) {
+        const long long p = hi - lane;   // lane 0 = nearest predecessor
+        unsigned long long st = 2ull << 62;   // before the first tile: an empty prefix
+        if (p >= 0) {
+          do { st = ld_state(&tile_state[p]); } while ((st >> 62) == 0);
+        }
+        const unsigned long long is_prefix = __ballot((st >> 62) == 2);
+        const int stop = __ffsll((long long)is_prefix) - 1;   // nearest tile with a known prefix
+        unsigned long long v = (stop < 0 || lane <= stop) ? (st & ((1ull << 62) - 1)) : 0ull;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += (unsigned long long)__shfl_xor((long long)v, off);
+        base += v;
+        if (stop >= 0) break;
+      }
+    }
+    if (lane == 0) {
+      st_state(&tile_state[t], (2ull << 62) | (base + ngroups));
+      sh_base = (uint32_t)base;
+      if (t + 1 == ntiles) ctr->num_desc = (uint32_t)(base + ngroups);
+    }
+  }
+  __syncthreads();
+    __syncthreads();
+    const uint32_t dbase = sh_base;
+#pragma unroll
+    for (int m = 0; m < kTileItems; ++m) {
+      const uint32_t g = tid + m * kTileThreads;
+      if (g < ngroups) {
+        const uint32_t p0 = hp[g], p1 = hp[g + 1];
+        float s_wuu = 0.f, s_wu = 0.f;
+        for (uint32_t j = p0; j < p1; ++j) {
+          s_wuu += a_wuu[j];
+          s_wu += a_wu[j];
+        }
+        const uint32_t d = dbase + g;
+        out.dkey[d] = g_key[m];
+        out.dval[d] = (unsigned long long)(slot0 + p0) | ((unsigned long long)(p1 - p0) << 32);
+        out.psum[slot0 + p0] = make_float2(s_wuu, s_wu);
+        out.last_pt[slot0 + p0] = g_last[m];
+      }
+    }
+  } else {
   // ---- phase 5: operands out, in sorted order
 #pragma unroll
   for (int k = 0; k < kTileItems; ++k) {
@@ -467,6 +568,7 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
     out.dval[d] = (unsigned long long)(slot0 + p0) | ((unsigned long long)(p1 - p0) << 32);
     out.last_pt[slot0 + p0] = first + spt[bufA[p1 - 1] & 0xFFFu];
   }
+  }
   TILE_PROBE(6)
 }
 
@@ -495,24 +597,20 @@ __global__ void mark_blocks(const uint32_t* __restrict__ dst, uint32_t nd, uint3
 // Output-centric: a block owns kGatherSpan consecutive output records, so its stores are
 // fully coalesced; the runs that cover the span are looked up once (their first positions
 // are marked in LDS and a max-scan hands every output record its run), the loads follow the
-// runs (contiguous pieces of a tile).  Also compacts the voxel heads (first record + key)
-// and the updated chunks, and sets the keyframe id of the voxel (SetKfid: the last update
-// of the call wins).
+// runs (contiguous pieces of a tile).  Also sets the keyframe id of the voxel (SetKfid: the
+// last update of the call wins).  The voxel list itself comes from voxel_heads.
 __global__ __launch_bounds__(kGatherThreads) void gather_runs(
     const uint32_t* __restrict__ skeys, const unsigned long long* __restrict__ sorted_val, uint32_t nd,
     const uint32_t* __restrict__ last_pt, const uint32_t* __restrict__ dst,
     const uint32_t* __restrict__ block_first, uint32_t nblocks, uint32_t V,
     const float2* __restrict__ rec_t, const uint32_t* __restrict__ recc_t, float2* __restrict__ rec,
-    uint32_t* __restrict__ rec_c, uint32_t* __restrict__ heads, uint32_t* __restrict__ head_keys,
-    uint32_t* __restrict__ updated_slots, Counters* __restrict__ ctr,
-    const uint32_t* __restrict__ kfid, uint32_t* __restrict__ vkfid) {
+    uint32_t* __restrict__ rec_c, const uint32_t* __restrict__ kfid, uint32_t* __restrict__ vkfid) {
   constexpr int kItems = kGatherSpan / kGatherThreads;   // 8
   constexpr int kMaxRuns = kGatherSpan + 1;
   __shared__ uint16_t id[kGatherSpan];          // run (local index + 1) of every output record
   __shared__ uint32_t delta[kMaxRuns + 3];      // source position - output position of the run
   __shared__ uint32_t endl[kMaxRuns + 3];       // end of the run | bit 31: it closes its voxel
   __shared__ uint32_t wtot[kGatherThreads / 64];
-  __shared__ uint32_t block_base[2];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint32_t b = blockIdx.x;
   const uint32_t B0 = b * kGatherSpan;
@@ -524,8 +622,7 @@ __global__ __launch_bounds__(kGatherThreads) void gather_runs(
   for (int k = 0; k < kItems; ++k) id[tid + k * kGatherThreads] = 0;
   __syncthreads();
 
-  // ---- the runs of the span; the ones that start here also do the per-voxel bookkeeping
-  uint32_t my_heads = 0;   // heads | chunk heads << 16 among this thread's runs
+  // ---- the runs of the span; the run that closes a voxel also sets its keyframe id
   for (uint32_t jl = tid; jl < nruns; jl += kGatherThreads) {
     const uint32_t j = j_lo + jl;
     const uint32_t key = skeys[j];
@@ -537,33 +634,9 @@ __global__ __launch_bounds__(kGatherThreads) void gather_runs(
     delta[jl] = from - a;
     endl[jl] = (a + len) | (closes ? 0x80000000u : 0u);
     if (a < B0 + nrec) id[max(a, B0) - B0] = (uint16_t)(jl + 1);
-    if (a >= B0 && a < B0 + nrec) {
-      const uint32_t prev = j ? skeys[j - 1] : ~key;
-      my_heads += (key != prev) ? 1u : 0u;
-      my_heads += (j == 0 || (key >> 12) != (prev >> 12)) ? (1u << 16) : 0u;
-      if (closes) vkfid[key] = kfid ? kfid[last_pt[from]] : 0u;
-    }
+    if (closes && a >= B0 && a < B0 + nrec) vkfid[key] = kfid ? kfid[last_pt[from]] : 0u;
   }
-  // block-aggregated, order-free compaction of the two head lists
-  uint32_t inc = my_heads;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
-    if (lane >= off) inc += up;
-  }
-  if (lane == 63) wtot[wid] = inc;
-  __syncthreads();   // also: id / delta / endl complete
-  uint32_t wbase = 0, total = 0;
-#pragma unroll
-  for (int w = 0; w < kGatherThreads / 64; ++w) {
-    const uint32_t v = wtot[w];
-    if (w < wid) wbase += v;
-    total += v;
-  }
-  if (tid < 2) {
-    const uint32_t c = tid == 0 ? (total & 0xFFFFu) : (total >> 16);
-    block_base[tid] = c ? atomicAdd(tid == 0 ? &ctr->num_heads : &ctr->num_updated, c) : 0u;
-  }
+  __syncthreads();   // id / delta / endl complete
   // ---- every output record learns its run: inclusive max-scan of the marks
   uint32_t loc[kItems], run_max = 0;
 #pragma unroll
@@ -577,7 +650,6 @@ __global__ __launch_bounds__(kGatherThreads) void gather_runs(
     const uint32_t up = (uint32_t)__shfl_up((int)sc, off);
     if (lane >= off) sc = max(sc, up);
   }
-  __syncthreads();   // block_base written; wtot free again
   if (lane == 63) wtot[wid] = sc;
   __syncthreads();
   uint32_t before = 0;
@@ -587,24 +659,6 @@ __global__ __launch_bounds__(kGatherThreads) void gather_runs(
   before = max(before, lane ? up1 : 0u);
 #pragma unroll
   for (int k = 0; k < kItems; ++k) id[tid * kItems + k] = (uint16_t)max(loc[k], before);
-  // head lists
-  {
-    const uint32_t excl = wbase + inc - my_heads;
-    uint32_t at_h = block_base[0] + (excl & 0xFFFFu), at_c = block_base[1] + (excl >> 16);
-    for (uint32_t jl = tid; jl < nruns; jl += kGatherThreads) {
-      const uint32_t j = j_lo + jl;
-      const uint32_t a = dst[j];
-      if (a >= B0 && a < B0 + nrec) {
-        const uint32_t key = skeys[j];
-        const uint32_t prev = j ? skeys[j - 1] : ~key;
-        if (key != prev) {
-          heads[at_h] = a;
-          head_keys[at_h++] = key;
-        }
-        if (j == 0 || (key >> 12) != (prev >> 12)) updated_slots[at_c++] = key >> 12;
-      }
-    }
-  }
   __syncthreads();
   // ---- copy
 #pragma unroll
@@ -620,6 +674,205 @@ __global__ __launch_bounds__(kGatherThreads) void gather_runs(
       rec[r] = v;
       rec_c[r] = recc_t[src];
     }
+  }
+}
+
+// Order-free mode, last stage.  After the stable sort the partial sums of a voxel (one per
+// run) are contiguous and in tile = point order.
+//   voxel_heads   compacts the first run of every voxel (and the updated chunks).
+//   reduce_sums   one wave per voxel adds its partial sums (lane-local, then a fixed xor
+//                 tree: deterministic) and applies them in ONE update,
+//                     sdf <- (W * sdf + sum w_u u) / (W + sum w_u),  W <- W + sum w_u
+//                 which is the reference's running weighted mean up to float rounding (the
+//                 reference rounds after every visit).  kfid is exact (last visit in point
+//                 order).
+//   fold_colours  one thread per voxel whose colour weight is below 254: the truncating u8
+//                 mean is folded visit by visit over the kept colours, exactly as the
+//                 reference does, until the weight reaches 254 (at most 254 steps in the life
+//                 of a voxel).  Runs beside reduce_sums on a second stream.
+constexpr int kHeadTiles = 16;   // 4096 runs per block: few same-address atomics
+__global__ __launch_bounds__(256) void voxel_heads(
+    const uint32_t* __restrict__ skeys, uint32_t nd, uint32_t* __restrict__ vj0,
+    uint32_t* __restrict__ updated_slots, Counters* __restrict__ ctr) {
+  __shared__ uint32_t wtot[4];
+  __shared__ uint32_t block_base[2];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const uint32_t first = blockIdx.x * (256 * kHeadTiles) + threadIdx.x * kHeadTiles;   // this thread's runs
+  uint32_t hmask = 0, cmask = 0;
+#pragma unroll
+  for (int k = 0; k < kHeadTiles; ++k) {
+    const uint32_t j = first + k;
+    if (j < nd) {
+      const uint32_t key = skeys[j];
+      const uint32_t prev = j ? skeys[j - 1] : ~key;
+      hmask |= (key != prev) ? (1u << k) : 0u;
+      cmask |= (j == 0 || (key >> 12) != (prev >> 12)) ? (1u << k) : 0u;
+    }
+  }
+  const uint32_t mine = (uint32_t)__popc(hmask) | ((uint32_t)__popc(cmask) << 16);
+  uint32_t inc = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
+    if (lane >= off) inc += up;
+  }
+  if (lane == 63) wtot[wid] = inc;
+  __syncthreads();
+  uint32_t wbase = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const uint32_t v = wtot[w];
+    if (w < wid) wbase += v;
+    total += v;
+  }
+  if (threadIdx.x < 2) {
+    const uint32_t c = threadIdx.x == 0 ? (total & 0xFFFFu) : (total >> 16);
+    block_base[threadIdx.x] = c ? atomicAdd(threadIdx.x == 0 ? &ctr->num_heads : &ctr->num_updated, c) : 0u;
+  }
+  __syncthreads();
+  const uint32_t excl = wbase + inc - mine;
+  uint32_t at_h = block_base[0] + (excl & 0xFFFFu), at_c = block_base[1] + (excl >> 16);
+#pragma unroll
+  for (int k = 0; k < kHeadTiles; ++k) {
+    if (hmask & (1u << k)) vj0[at_h++] = first + k;
+    if (cmask & (1u << k)) updated_slots[at_c++] = skeys[first + k] >> 12;
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_sums(
+    const uint32_t* __restrict__ skeys, const unsigned long long* __restrict__ sval, uint32_t nd,
+    const uint32_t* __restrict__ vj0, const float2* __restrict__ psum, const uint32_t* __restrict__ last_pt,
+    const uint32_t* __restrict__ kfid, float* __restrict__ sdf, float* __restrict__ weight,
+    uint32_t* __restrict__ vkfid, Counters* __restrict__ ctr) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t nvox = ctr->num_heads;
+  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+  for (uint32_t v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); v < nvox; v += nwaves) {
+    const uint32_t j0 = vj0[v];
+    const uint32_t key = skeys[j0];
+    float m = 0.f, wsum = 0.f;
+    uint32_t cnt = 0, last_at = 0;
+    for (uint32_t base = j0;; base += 64) {
+      const uint32_t jj = base + lane;
+      const bool mine = jj < nd && skeys[jj] == key;
+      if (mine) {
+        const unsigned long long d = sval[jj];
+        const float2 ps = psum[(uint32_t)d];
+        m += ps.x;
+        wsum += ps.y;
+        cnt += (uint32_t)(d >> 32);
+        last_at = (uint32_t)d;
+      }
+      const unsigned long long got = __ballot(mine);
+      if (got != ~0ull) {
+        // the voxel's last run sits in the highest lane of this (partial) pass, or in lane 63 of
+        // the previous one
+        const int top = got ? 63 - __clzll((long long)got) : 63;
+        last_at = (uint32_t)__shfl((int)last_at, top);
+        break;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      m += __shfl_xor(m, off);
+      wsum += __shfl_xor(wsum, off);
+      cnt += (uint32_t)__shfl_xor((int)cnt, off);
+    }
+    if (lane == 0) {
+      const float W = weight[key], S = sdf[key];
+      const float wn = W + wsum;
+      sdf[key] = (W * S + m) / wn;
+      weight[key] = wn;
+      vkfid[key] = kfid ? kfid[last_pt[last_at]] : 0u;
+      // most visits of one voxel in the call (what the ordered mode reports as its longest chain)
+      if (cnt > ctr->max_run) atomicMax(&ctr->max_run, cnt);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void fold_colours(
+    const uint32_t* __restrict__ skeys, const unsigned long long* __restrict__ sval, uint32_t nd,
+    const uint32_t* __restrict__ vj0, const uint32_t* __restrict__ recc_t, uint32_t* __restrict__ rgbw,
+    const Counters* __restrict__ ctr) {
+  // 1 / (1 + weight), the factor of ColorVoxel::IntegrateSimple, for every weight it can see
+  __shared__ float inv_tab[256];
+  inv_tab[threadIdx.x] = 1.f / (float)(1u + (uint32_t)threadIdx.x);
+  __syncthreads();
+  const uint32_t nvox = ctr->num_heads;
+  for (uint32_t v0 = blockIdx.x * blockDim.x; v0 < nvox; v0 += gridDim.x * blockDim.x) {
+    const uint32_t v = v0 + threadIdx.x;
+    uint32_t key = 0, col = 254u << 24, jj = 0;
+    if (v < nvox) {
+      jj = vj0[v];
+      key = skeys[jj];
+      col = rgbw[key];
+    }
+    const bool fresh = v < nvox && (col >> 24) < 254u;
+    // one flat loop for the whole wave: a lane takes up to eight visits of its current run per
+    // turn and moves to its next run when that one is used up.  The loads run a turn ahead of
+    // the fold (colours) and two turns ahead (run descriptors): the fold is cheap, the latency
+    // of a load per visit is not.
+    struct Piece { uint32_t at, n; bool ok; };   // up to eight visits of one run
+    auto next_piece = [&](Piece cur, uint32_t& run, uint32_t& run_left, unsigned long long& ahead, bool& ahead_ok) {
+      // what follows `cur`: the rest of its run, else the first piece of the next run
+      Piece nx;
+      if (run_left > 8) {
+        run_left -= 8;
+        nx.at = cur.at + 8;
+        nx.n = min(run_left, 8u);
+        nx.ok = cur.ok;
+      } else {
+        nx.ok = cur.ok && ahead_ok;
+        nx.at = (uint32_t)ahead;
+        run_left = (uint32_t)(ahead >> 32);
+        nx.n = min(run_left, 8u);
+        // and the descriptor after that
+        ++run;
+        const uint32_t jn = run + 1;
+        ahead_ok = nx.ok && jn < nd && skeys[jn] == key;
+        ahead = ahead_ok ? sval[jn] : 0ull;
+      }
+      return nx;
+    };
+    uint32_t run = jj, run_left = 0;
+    unsigned long long ahead = 0ull;
+    bool ahead_ok = false;
+    Piece cur{0u, 0u, fresh};
+    if (fresh) {
+      const unsigned long long d = sval[jj];
+      cur.at = (uint32_t)d;
+      run_left = (uint32_t)(d >> 32);
+      cur.n = min(run_left, 8u);
+      ahead_ok = jj + 1 < nd && skeys[jj + 1] == key;
+      ahead = ahead_ok ? sval[jj + 1] : 0ull;
+    }
+    uint32_t c[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) c[e] = cur.ok ? recc_t[cur.at + min((uint32_t)e, cur.n - 1)] : 0u;
+    while (__ballot(cur.ok) != 0ull) {
+      const Piece nx = next_piece(cur, run, run_left, ahead, ahead_ok);
+      uint32_t cn[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cn[e] = nx.ok ? recc_t[nx.at + min((uint32_t)e, nx.n - 1)] : 0u;
+      if (cur.ok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t cw = col >> 24;
+          if ((uint32_t)e < cur.n && cw < 254u) {   // ColorVoxel::IntegrateSimple, visit by visit
+            const float inv = inv_tab[cw];
+            const uint32_t red = (uint32_t)(uint8_t)((float)(cw * (col & 255u) + (c[e] & 255u)) * inv);
+            const uint32_t green = (uint32_t)(uint8_t)((float)(cw * ((col >> 8) & 255u) + ((c[e] >> 8) & 255u)) * inv);
+            const uint32_t blue = (uint32_t)(uint8_t)((float)(cw * ((col >> 16) & 255u) + ((c[e] >> 16) & 255u)) * inv);
+            col = red | (green << 8) | (blue << 16) | ((cw + 1u) << 24);
+          }
+        }
+      }
+      cur = nx;
+      if ((col >> 24) >= 254u) cur.ok = false;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) c[e] = cn[e];
+    }
+    if (fresh) rgbw[key] = col;
   }
 }
 
@@ -659,8 +912,8 @@ struct __attribute__((packed, aligned(8))) RecPair {   // two consecutive float2
 __device__ __forceinline__ int stage_unit(int run, int u) { return run * 4 + ((u ^ (run >> 1)) & 3); }
 
 __global__ __launch_bounds__(64) void chain_runs(
-    const uint32_t* __restrict__ head_keys, uint32_t nrec, const float2* __restrict__ rec,
-    const uint32_t* __restrict__ heads, Counters* __restrict__ ctr, float* __restrict__ sdf,
+    const uint32_t* __restrict__ vj0, const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ dst,
+    uint32_t nrec, const float2* __restrict__ rec, Counters* __restrict__ ctr, float* __restrict__ sdf,
     float* __restrict__ weight) {
   __shared__ float4 stage[kChainSets][64 * 4];
   const int l = threadIdx.x;
@@ -671,8 +924,9 @@ __global__ __launch_bounds__(64) void chain_runs(
   for (uint32_t group = blockIdx.x; group * 64u < nheads; group += gridDim.x) {
     const uint32_t h = group * 64u + (uint32_t)l;
     bool live = h < nheads;
-    const uint32_t r0 = live ? heads[h] : 0u;
-    const size_t a = live ? (size_t)head_keys[h] : 0;   // slot*4096 + vid
+    const uint32_t j0 = live ? vj0[h] : 0u;            // first run of the voxel
+    const uint32_t r0 = live ? dst[j0] : 0u;           // its first record
+    const size_t a = live ? (size_t)skeys[j0] : 0;     // slot*4096 + vid
     float s = live ? sdf[a] : 0.0f;
     float w = live ? weight[a] : 1.0f;
     uint32_t my_len = 0;
@@ -820,13 +1074,14 @@ __global__ __launch_bounds__(64) void chain_runs(
 // dependent, but frozen for good once the colour weight reaches 254, so a run
 // contributes at most (254 - weight) steps.  One thread per voxel run.
 __global__ __launch_bounds__(256) void chain_colours(
-    const uint32_t* __restrict__ head_keys, uint32_t nrec, const float2* __restrict__ rec,
-    const uint32_t* __restrict__ rec_c, const uint32_t* __restrict__ heads,
+    const uint32_t* __restrict__ vj0, const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ dst,
+    uint32_t nrec, const float2* __restrict__ rec, const uint32_t* __restrict__ rec_c,
     const Counters* __restrict__ ctr, uint32_t* __restrict__ rgbw) {
   const uint32_t nheads = ctr->num_heads;
   for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nheads; h += gridDim.x * blockDim.x) {
-    uint32_t r = heads[h];
-    const size_t a = (size_t)head_keys[h];
+    const uint32_t j0 = vj0[h];
+    uint32_t r = dst[j0];
+    const size_t a = (size_t)skeys[j0];
     uint32_t col = rgbw[a];
     if ((col >> 24) >= 254u) continue;
     for (;;) {
@@ -876,12 +1131,13 @@ struct plvs_tsdf_chisel {
   int num_chunks = 0;         // host mirror
   bool poisoned = false;
   // per-call scratch
-  DevBuf<uint32_t> counts, heads, head_keys, updated, scratch;
+  DevBuf<uint32_t> counts, heads, updated, scratch;
   DevBuf<float2> rec, rec_t;         // operands in voxel order / grouped per tile
   DevBuf<uint32_t> rec_c, recc_t;    // colours, same two orders
   DevBuf<uint32_t> dkey0, dkey1, run_cnt, run_dst, last_pt;   // run descriptors
   DevBuf<unsigned long long> didx0, didx1;
   DevBuf<uint32_t> tile_first, block_first;
+  DevBuf<float2> psum;   // order-free mode: partial sums per run
   DevBuf<unsigned long long> tile_state;   // [0]: ticket, [1..]: look-back state per tile
   DevBuf<Pose> poses;
   DevBuf<int32_t> offsets;
@@ -932,6 +1188,7 @@ int plvs_hip_tsdf_chisel_default_params(float resolution, plvs_tsdf_chisel_param
   p->max_chunks = 32768;        // 2 GiB of voxel pool
   p->shard_rank = 0;
   p->shard_count = 1;
+  p->order_free = 0;
   return PLVS_OK;
 }
 
@@ -1006,11 +1263,12 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   if (h->side) (void)hipStreamDestroy(h->side);
   for (int i = 0; i <= kNumStages; ++i)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
-  h->counts.release(); h->head_keys.release();
+  h->counts.release();
   h->rec.release(); h->rec_c.release(); h->rec_t.release(); h->recc_t.release();
   h->dkey0.release(); h->dkey1.release(); h->didx0.release(); h->didx1.release();
   h->last_pt.release(); h->run_cnt.release(); h->run_dst.release();
   h->tile_first.release(); h->block_first.release(); h->tile_state.release();
+  h->psum.release();
   h->heads.release(); h->updated.release(); h->scratch.release(); h->poses.release();
   h->offsets.release(); h->st_xyz.release(); h->st_Twc.release(); h->st_rgb.release();
   h->st_kfid.release();
@@ -1102,19 +1360,25 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   }
 
   const uint32_t ntiles = ceil_div(V, kTileSlots);
-  PLVS_HIP_TRY(h->rec_t.reserve(V));
-  PLVS_HIP_TRY(h->recc_t.reserve(V));
-  PLVS_HIP_TRY(h->rec.reserve((size_t)V + 2));   // chain_runs reads record pairs
-  PLVS_HIP_TRY(h->rec_c.reserve(V));
-  PLVS_HIP_TRY(h->heads.reserve(V));
-  PLVS_HIP_TRY(h->head_keys.reserve(V));
+  const bool order_free = h->prm.order_free != 0;
   PLVS_HIP_TRY(h->dkey0.reserve(V));
-  PLVS_HIP_TRY(h->didx0.reserve(V));
-  PLVS_HIP_TRY(h->last_pt.reserve(V));
   PLVS_HIP_TRY(h->tile_first.reserve(ntiles));
-  PLVS_HIP_TRY(h->block_first.reserve(ceil_div(V, kGatherSpan)));
   PLVS_HIP_TRY(h->tile_state.reserve((size_t)ntiles + 1));
   PLVS_HIP_TRY(h->updated.reserve((size_t)h->num_chunks + 1));
+  if (order_free) {
+    PLVS_HIP_TRY(h->psum.reserve(V));
+    PLVS_HIP_TRY(h->recc_t.reserve(V));
+    PLVS_HIP_TRY(h->didx0.reserve(V));
+    PLVS_HIP_TRY(h->last_pt.reserve(V));
+  } else {
+    PLVS_HIP_TRY(h->rec_t.reserve(V));
+    PLVS_HIP_TRY(h->recc_t.reserve(V));
+    PLVS_HIP_TRY(h->rec.reserve((size_t)V + 2));   // chain_runs reads record pairs
+    PLVS_HIP_TRY(h->rec_c.reserve(V));
+    PLVS_HIP_TRY(h->didx0.reserve(V));
+    PLVS_HIP_TRY(h->last_pt.reserve(V));
+    PLVS_HIP_TRY(h->block_first.reserve(ceil_div(V, kGatherSpan)));
+  }
   float ms_a[2] = {0.f, 0.f};
   if (h->profiling) {  // stages 0,1 are complete (the counter read synchronised)
     PLVS_HIP_TRY(hipEventElapsedTime(&ms_a[0], h->ev[0], h->ev[1]));
@@ -1125,11 +1389,18 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   hipLaunchKernelGGL(mark_tiles, dim3(ceil_div((size_t)n, 256)), dim3(256), 0, s, h->counts.p, n,
                      h->tile_first.p);
   {
-    TileOut out{h->rec_t.p, h->recc_t.p, h->dkey0.p, h->didx0.p, h->last_pt.p};
-    hipLaunchKernelGGL(ray_tiles, dim3(ntiles), dim3(kTileThreads), 0, s, h->P, d_xyz, d_rgb, n,
-                       h->offsets.p, nclouds, h->poses.p, h->dir, h->d_ctr, h->counts.p, V,
-                       h->tile_first.p, ntiles, reinterpret_cast<uint32_t*>(h->tile_state.p),
-                       h->tile_state.p + 1, out);
+    TileOut out{h->rec_t.p, h->recc_t.p, h->dkey0.p, h->didx0.p, h->last_pt.p,
+                h->psum.p};
+    if (order_free)
+      hipLaunchKernelGGL(ray_tiles<true>, dim3(ntiles), dim3(kTileThreads), 0, s, h->P, d_xyz, d_rgb, n,
+                         h->offsets.p, nclouds, h->poses.p, h->dir, h->d_ctr, h->counts.p, V,
+                         h->tile_first.p, ntiles, reinterpret_cast<uint32_t*>(h->tile_state.p),
+                         h->tile_state.p + 1, h->rgbw, out);
+    else
+      hipLaunchKernelGGL(ray_tiles<false>, dim3(ntiles), dim3(kTileThreads), 0, s, h->P, d_xyz, d_rgb, n,
+                         h->offsets.p, nclouds, h->poses.p, h->dir, h->d_ctr, h->counts.p, V,
+                         h->tile_first.p, ntiles, reinterpret_cast<uint32_t*>(h->tile_state.p),
+                         h->tile_state.p + 1, h->rgbw, out);
   }
   PLVS_KERNEL_CHECK();
   STAGE_MARK(3);
@@ -1144,42 +1415,69 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   float ms_b = 0.f;
   if (h->profiling) PLVS_HIP_TRY(hipEventElapsedTime(&ms_b, h->ev[2], h->ev[3]));
   PLVS_HIP_TRY(h->dkey1.reserve(D));
-  PLVS_HIP_TRY(h->didx1.reserve(D));
-  PLVS_HIP_TRY(h->run_cnt.reserve(D));
-  PLVS_HIP_TRY(h->run_dst.reserve(D));
   PLVS_HIP_TRY(h->scratch.reserve(radix_scratch_words(D)));
-  STAGE_MARK(3);
   int key_bits = 12;
   while ((1ll << (key_bits - 12)) < (long long)h->num_chunks) ++key_bits;
   bool second = false;
-  PLVS_HIP_TRY(radix_sort_pairs_u64(h->dkey0.p, h->didx0.p, h->dkey1.p, h->didx1.p, D, 0, key_bits,
-                                h->scratch.p, s, &second));
-  const uint32_t* skeys = second ? h->dkey1.p : h->dkey0.p;
-  const unsigned long long* sidx = second ? h->didx1.p : h->didx0.p;
-  STAGE_MARK(4);
-  hipLaunchKernelGGL(run_counts, dim3(ceil_div(D, 256)), dim3(256), 0, s, sidx, D, h->run_cnt.p);
-  PLVS_HIP_TRY(exclusive_scan_u32(h->run_cnt.p, h->run_dst.p, D, nullptr, h->scratch.p, s));
-  const uint32_t nblocks = ceil_div(V, kGatherSpan);
-  hipLaunchKernelGGL(mark_blocks, dim3(ceil_div(D, 256)), dim3(256), 0, s, h->run_dst.p, D, V, h->block_first.p);
-  hipLaunchKernelGGL(gather_runs, dim3(nblocks), dim3(kGatherThreads), 0, s, skeys, sidx, D, h->last_pt.p,
-                     h->run_dst.p, h->block_first.p, nblocks, V, h->rec_t.p, h->recc_t.p, h->rec.p,
-                     h->rec_c.p, h->heads.p, h->head_keys.p, h->updated.p, h->d_ctr, d_kfid, h->kfid);
-  PLVS_KERNEL_CHECK();
-  STAGE_MARK(5);
-  // The colour chain touches only rgbw and the distance chain only sdf/weight; both are
-  // latency-bound with few waves, so they run side by side on two streams.
-  PLVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
-  PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-  hipLaunchKernelGGL(chain_colours, dim3(std::min<size_t>(ceil_div(D, 256), 2048)), dim3(256), 0, h->side,
-                     h->head_keys.p, V, h->rec.p, h->rec_c.p, h->heads.p, h->d_ctr, h->rgbw);
-  PLVS_HIP_TRY(hipEventRecord(h->ev_join, h->side));
-  // one thread per voxel; the grid is an upper bound of the voxel count, surplus waves exit
-  // on the device-side count
-  hipLaunchKernelGGL(chain_runs, dim3(std::min<size_t>(ceil_div(D, 64), 16384)), dim3(64), 0, s,
-                     h->head_keys.p, V, h->rec.p, h->heads.p, h->d_ctr, h->sdf, h->weight);
-  PLVS_HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
-  PLVS_KERNEL_CHECK();
-  STAGE_MARK(6);
+  if (order_free) {
+    PLVS_HIP_TRY(h->didx1.reserve(D));
+    STAGE_MARK(3);
+    PLVS_HIP_TRY(radix_sort_pairs_u64(h->dkey0.p, h->didx0.p, h->dkey1.p, h->didx1.p, D, 0, key_bits,
+                                      h->scratch.p, s, &second));
+    STAGE_MARK(4);
+    const uint32_t* skeys = second ? h->dkey1.p : h->dkey0.p;
+    const unsigned long long* sval = second ? h->didx1.p : h->didx0.p;
+    PLVS_HIP_TRY(h->heads.reserve(D));
+    hipLaunchKernelGGL(voxel_heads, dim3(ceil_div(D, 256 * kHeadTiles)), dim3(256), 0, s, skeys, D, h->heads.p,
+                       h->updated.p, h->d_ctr);
+    PLVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
+    PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    hipLaunchKernelGGL(fold_colours, dim3(std::min<size_t>(ceil_div(D, 256), 1024)), dim3(256), 0, h->side,
+                       skeys, sval, D, h->heads.p, h->recc_t.p, h->rgbw, h->d_ctr);
+    PLVS_HIP_TRY(hipEventRecord(h->ev_join, h->side));
+    hipLaunchKernelGGL(reduce_sums, dim3(std::min<size_t>(ceil_div(D, 4), 8192)), dim3(256), 0, s, skeys, sval,
+                       D, h->heads.p, h->psum.p, h->last_pt.p, d_kfid, h->sdf, h->weight, h->kfid, h->d_ctr);
+    PLVS_HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+    PLVS_KERNEL_CHECK();
+    STAGE_MARK(5);
+    STAGE_MARK(6);
+  } else {
+    PLVS_HIP_TRY(h->didx1.reserve(D));
+    PLVS_HIP_TRY(h->run_cnt.reserve(D));
+    PLVS_HIP_TRY(h->run_dst.reserve(D));
+    STAGE_MARK(3);
+    PLVS_HIP_TRY(radix_sort_pairs_u64(h->dkey0.p, h->didx0.p, h->dkey1.p, h->didx1.p, D, 0, key_bits,
+                                  h->scratch.p, s, &second));
+    const uint32_t* skeys = second ? h->dkey1.p : h->dkey0.p;
+    const unsigned long long* sidx = second ? h->didx1.p : h->didx0.p;
+    STAGE_MARK(4);
+    hipLaunchKernelGGL(run_counts, dim3(ceil_div(D, 256)), dim3(256), 0, s, sidx, D, h->run_cnt.p);
+    PLVS_HIP_TRY(exclusive_scan_u32(h->run_cnt.p, h->run_dst.p, D, nullptr, h->scratch.p, s));
+    const uint32_t nblocks = ceil_div(V, kGatherSpan);
+    hipLaunchKernelGGL(mark_blocks, dim3(ceil_div(D, 256)), dim3(256), 0, s, h->run_dst.p, D, V, h->block_first.p);
+    hipLaunchKernelGGL(gather_runs, dim3(nblocks), dim3(kGatherThreads), 0, s, skeys, sidx, D, h->last_pt.p,
+                       h->run_dst.p, h->block_first.p, nblocks, V, h->rec_t.p, h->recc_t.p, h->rec.p,
+                       h->rec_c.p, d_kfid, h->kfid);
+    PLVS_HIP_TRY(h->heads.reserve(D));
+    hipLaunchKernelGGL(voxel_heads, dim3(ceil_div(D, 256 * kHeadTiles)), dim3(256), 0, s, skeys, D, h->heads.p,
+                       h->updated.p, h->d_ctr);
+    PLVS_KERNEL_CHECK();
+    STAGE_MARK(5);
+    // The colour chain touches only rgbw and the distance chain only sdf/weight; both are
+    // latency-bound with few waves, so they run side by side on two streams.
+    PLVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
+    PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    hipLaunchKernelGGL(chain_colours, dim3(std::min<size_t>(ceil_div(D, 256), 2048)), dim3(256), 0, h->side,
+                       h->heads.p, skeys, h->run_dst.p, V, h->rec.p, h->rec_c.p, h->d_ctr, h->rgbw);
+    PLVS_HIP_TRY(hipEventRecord(h->ev_join, h->side));
+    // one thread per voxel; the grid is an upper bound of the voxel count, surplus waves exit
+    // on the device-side count
+    hipLaunchKernelGGL(chain_runs, dim3(std::min<size_t>(ceil_div(D, 64), 16384)), dim3(64), 0, s,
+                       h->heads.p, skeys, h->run_dst.p, V, h->rec.p, h->d_ctr, h->sdf, h->weight);
+    PLVS_HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+    PLVS_KERNEL_CHECK();
+    STAGE_MARK(6);
+  }
 #undef STAGE_MARK
   rc = read_counters(h, s);
   if (rc != PLVS_OK) return rc;

@@ -21,12 +21,16 @@ from . import _lib
 class TsdfChisel:
     """Thin RAII wrapper of the plvs_hip_tsdf_chisel_* C ABI."""
 
-    def __init__(self, resolution, max_chunks=None, shard_rank=0, shard_count=1):
+    def __init__(self, resolution, max_chunks=None, shard_rank=0, shard_count=1, order_free=False):
+        """order_free=False: bit-identical to the reference's sequential loop.  True: the visits
+        of a call are summed per voxel and applied at once (float-rounding tolerance on sdf /
+        weight; kfid and colour stay exact)."""
         p = _lib.TsdfChiselParams()
         _lib.check(_lib.lib.plvs_hip_tsdf_chisel_default_params(ctypes.c_float(resolution), ctypes.byref(p)))
         if max_chunks is not None:
             p.max_chunks = int(max_chunks)
         p.shard_rank, p.shard_count = int(shard_rank), int(shard_count)
+        p.order_free = 1 if order_free else 0
         self.params = p
         self._h = ctypes.c_void_p()
         _lib.check(_lib.lib.plvs_hip_tsdf_chisel_create(ctypes.byref(p), ctypes.byref(self._h)))

@@ -19,7 +19,7 @@ if [[ "$STAGES" == *smoke* ]]; then
   echo "smoke done $(date +%T)" >> "$O/stages.log"
 fi
 if [[ "$STAGES" == *bench* ]]; then
-  ( timeout 300 python bench.py 2>&1 | tail -20 ) > "$O/bench.log" 2>&1
+  ( timeout 300 python bench.py $BENCH_ARGS 2>&1 | tail -20 ) > "$O/bench.log" 2>&1
   echo "bench done $(date +%T)" >> "$O/stages.log"
 fi
 if [[ "$STAGES" == *vbx* ]]; then
@@ -33,7 +33,7 @@ if [[ "$STAGES" == *sweep* ]]; then
   echo "sweep done $(date +%T)" >> "$O/stages.log"
 fi
 if [[ "$STAGES" == *prof* ]]; then
-  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof" -o r -- python "$R/bench.py" --no-cpu-baseline 2>&1 | tail -5 ) > "$O/rocprof.log" 2>&1
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof" -o r -- python "$R/bench.py" --no-cpu-baseline $BENCH_ARGS 2>&1 | tail -5 ) > "$O/rocprof.log" 2>&1
   echo "rocprof done $(date +%T)" >> "$O/stages.log"
 fi
 if [[ "$STAGES" == *pmc* ]]; then

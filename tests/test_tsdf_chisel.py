@@ -227,3 +227,51 @@ def test_hip_reciprocal_is_correctly_rounded_for_every_significand():
         bad = ctypes.c_uint32(12345)
         _lib.check(f(exponent, ctypes.byref(bad)))
         assert bad.value == 0, f"exponent {exponent}: {bad.value} significands not correctly rounded"
+
+
+# Order-free mode (plvs_tsdf_chisel_params.order_free = 1): BASELINE's north star asks for the TSDF
+# sdf / weights "within a stated float tolerance" of the reference.  The tolerance, stated here:
+ORDER_FREE_SDF_ATOL = 5e-6        # metres; |sdf| < 0.3 m, so this is a few float ulps
+ORDER_FREE_WEIGHT_RTOL = 2e-5    # relative
+ORDER_FREE_COLOUR_ATOL = 0        # the colour (truncating u8 mean, frozen at weight 254) stays exact
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 3])
+def test_hip_order_free_mode_is_within_the_stated_tolerance(oracle, batch):
+    import torch
+    from plvs_amd.tsdf import TsdfChisel
+    kfs = make_keyframes(6, cam=small_cam(2), seed=21)
+    ora = oracle.chisel(0.05)
+    dev = TsdfChisel(0.05, max_chunks=4096, order_free=True)
+    for b0 in range(0, len(kfs), batch):
+        part = kfs[b0:b0 + batch]
+        for kf in part:
+            ora.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+        xyz = torch.from_numpy(np.concatenate([k["xyz"] for k in part])).cuda()
+        rgb = torch.from_numpy(np.concatenate([k["rgb"] for k in part])).cuda()
+        kfid = torch.from_numpy(np.concatenate([k["kfid"] for k in part]).astype(np.int32)).cuda()
+        Twc = torch.from_numpy(np.stack([k["Twc"] for k in part])).cuda()
+        offsets = np.cumsum([0] + [k["xyz"].shape[0] for k in part]).astype(np.int32)
+        dev.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
+        torch.cuda.synchronize()
+        assert dev.last_stats()["visits"] > 0
+    ia = {tuple(x) for x in ora.chunk_ids()}
+    assert ia == {tuple(x) for x in dev.chunk_ids()}
+    worst = [0.0, 0.0, 0]
+    for cid in sorted(ia):
+        a, b = ora.get_chunk(*cid), dev.get_chunk(*cid)
+        known = a[1] > 0
+        assert np.array_equal(known, b[1] > 0), "the sets of observed voxels differ"
+        assert np.array_equal(a[2], b[2]), "kfid must be exact"
+        if not known.any():
+            continue
+        worst[0] = max(worst[0], float(np.abs(a[0][known] - b[0][known]).max()))
+        worst[1] = max(worst[1], float((np.abs(a[1][known] - b[1][known]) / a[1][known]).max()))
+        ca, cb = a[3][known], b[3][known]
+        assert np.array_equal(np.minimum(ca >> 24, 254), np.minimum(cb >> 24, 254)), "colour weights differ"
+        for sh in (0, 8, 16):
+            worst[2] = max(worst[2], int(np.abs(((ca >> sh) & 255).astype(int) - ((cb >> sh) & 255).astype(int)).max()))
+    print("order-free deviations: sdf %.3g m, weight %.3g rel, colour %d levels" % tuple(worst))
+    assert worst[0] <= ORDER_FREE_SDF_ATOL and worst[1] <= ORDER_FREE_WEIGHT_RTOL and worst[2] <= ORDER_FREE_COLOUR_ATOL
+    dev.close()
