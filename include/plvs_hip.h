@@ -148,6 +148,49 @@ int plvs_hip_orb_level_size(plvs_orb* h, int level, int* w, int* hh);
 int plvs_hip_orb_download_level(plvs_orb* h, int level, int blurred, uint8_t* out);
 int plvs_hip_orb_last_candidates(plvs_orb* h, int level, float* xyr, int cap, int* n);
 
+/* ------------------------------------------------- ORB search by projection
+ * ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th,
+ * bFarPoints, thFarPoints) (src/ORBmatcher.cc:71-244) for monocular / RGB-D frames
+ * (F.Nleft == -1), called from Tracking::SearchLocalPoints.  The views list what the
+ * function reads of F and of the map points; all arrays are host memory. */
+typedef struct plvs_frame_view {
+  int32_t n;                    /* F.N                                               */
+  const float* x;               /* F.mvKeysUn[i].pt.x / .y                           */
+  const float* y;
+  const int32_t* octave;        /* F.mvKeysUn[i].octave                              */
+  const float* u_right;         /* F.mvuRight[i] (<= 0: none)                        */
+  const uint8_t* desc;          /* F.mDescriptors, n x 32                            */
+  float min_x, min_y;           /* F.mnMinX, F.mnMinY                                */
+  float grid_w_inv, grid_h_inv; /* F.mfGridElementWidthInv / HeightInv (64 x 48)     */
+  const float* scale_factors;   /* F.mvScaleFactors                                  */
+} plvs_frame_view;
+
+typedef struct plvs_mappoint_view {
+  int32_t m;
+  const uint8_t* track_in_view; /* pMP->mbTrackInView                                */
+  const uint8_t* bad;           /* pMP->isBad()                                      */
+  const float* proj_x;          /* pMP->mTrackProjX / Y / XR                         */
+  const float* proj_y;
+  const float* proj_xr;
+  const float* view_cos;        /* pMP->mTrackViewCos                                */
+  const float* track_depth;     /* pMP->mTrackDepth                                  */
+  const int32_t* level;         /* pMP->mnTrackScaleLevel                            */
+  const uint8_t* desc;          /* pMP->GetDescriptor(), m x 32                      */
+  const uint8_t* has_obs;       /* pMP->Observations() > 0; NULL = all               */
+} plvs_mappoint_view;
+
+/* occupied[i] != 0: keypoint i already holds a map point with observations (NULL = none).
+ * assigned[i] (n entries, out): index of the map point given to keypoint i, or -1
+ * (the caller stores F.mvpMapPoints[i] = vpMapPoints[assigned[i]]).  *nmatches = the
+ * reference's return value. */
+int plvs_hip_orb_search_by_projection(const plvs_frame_view* F, const plvs_mappoint_view* M, float th,
+                                      int far_points, float th_far, float nn_ratio,
+                                      const uint8_t* occupied, int32_t* assigned, int* nmatches);
+/* The batched primitive under it: dist[p] = DescriptorDistance(query[pair_q[p]],
+ * train[pair_t[p]]) (src/ORBmatcher.cc:2198-2225) for arbitrary candidate lists. */
+int plvs_hip_hamming_pairs(const uint8_t* query, int nq, const uint8_t* train, int nt,
+                           const int32_t* pair_q, const int32_t* pair_t, int npairs, int32_t* dist);
+
 /* ----------------------------------------------------------- Line extraction
  * Replaces LineExtractor (include/LineExtractor.h:48-83, src/LineExtractor.cc):
  *   LineExtractor::LineExtractor(numLinefeatures, LSDOptions&)                :104-145

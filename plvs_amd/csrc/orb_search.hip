@@ -1,0 +1,183 @@
+// ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints)
+// (reference src/ORBmatcher.cc:71-244) for monocular / RGB-D frames, replaced at the
+// search-function level: the Hamming distances of every (map point, candidate
+// keypoint) pair are computed in one batched launch; the parts that are sequential by
+// definition — the candidate windows on the 64x48 frame grid (Frame::GetFeaturesInArea,
+// src/Frame.cc:1231-1303) and the greedy best / second-best assignment, in which a keypoint
+// claimed by an earlier map point is skipped by the later ones — stay on the host, in the
+// reference's order.
+#include <cmath>
+#include <vector>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int kGridCols = 64;   // FRAME_GRID_COLS, include/Frame.h:68
+constexpr int kGridRows = 48;   // FRAME_GRID_ROWS, include/Frame.h:67
+constexpr int kThHigh = 100;    // ORBmatcher::TH_HIGH, src/ORBmatcher.cc:57
+
+// dist[p] = ORBmatcher::DescriptorDistance(query[pair_q[p]], train[pair_t[p]]) (src/ORBmatcher.cc:2198)
+__global__ __launch_bounds__(256) void hamming_pairs_kernel(const uint4* __restrict__ query,
+                                                            const uint4* __restrict__ train,
+                                                            const int32_t* __restrict__ pair_q,
+                                                            const int32_t* __restrict__ pair_t, int npairs,
+                                                            int32_t* __restrict__ dist) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npairs) return;
+  const uint4 a0 = query[2 * pair_q[p]], a1 = query[2 * pair_q[p] + 1];
+  const uint4 b0 = train[2 * pair_t[p]], b1 = train[2 * pair_t[p] + 1];
+  dist[p] = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+            __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+}  // namespace
+
+extern "C" {
+
+int plvs_hip_hamming_pairs(const uint8_t* query, int nq, const uint8_t* train, int nt, const int32_t* pair_q,
+                           const int32_t* pair_t, int npairs, int32_t* dist) {
+  PLVS_REQUIRE(nq >= 0 && nt >= 0 && npairs >= 0, "negative size");
+  if (npairs == 0) return PLVS_OK;
+  PLVS_REQUIRE(query && train && pair_q && pair_t && dist, "null argument");
+  for (int p = 0; p < npairs; ++p)
+    PLVS_REQUIRE(pair_q[p] >= 0 && pair_q[p] < nq && pair_t[p] >= 0 && pair_t[p] < nt, "pair index out of range");
+  plvs::DevBuf<uint8_t> dq, dt;
+  plvs::DevBuf<int32_t> dpq, dpt, dd;
+  hipError_t e = hipSuccess;
+  auto fail = [&](hipError_t err, const char* what) {
+    plvs::set_error("%s failed: %s", what, hipGetErrorString(err));
+    dq.release(); dt.release(); dpq.release(); dpt.release(); dd.release();
+    return PLVS_ERR_HIP;
+  };
+  if ((e = dq.reserve((size_t)nq * 32)) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = dt.reserve((size_t)nt * 32)) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = dpq.reserve(npairs)) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = dpt.reserve(npairs)) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = dd.reserve(npairs)) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = hipMemcpy(dq.p, query, (size_t)nq * 32, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
+  if ((e = hipMemcpy(dt.p, train, (size_t)nt * 32, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
+  if ((e = hipMemcpy(dpq.p, pair_q, sizeof(int32_t) * npairs, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
+  if ((e = hipMemcpy(dpt.p, pair_t, sizeof(int32_t) * npairs, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
+  hipLaunchKernelGGL(hamming_pairs_kernel, dim3(plvs::ceil_div(npairs, 256)), dim3(256), 0, nullptr,
+                     reinterpret_cast<const uint4*>(dq.p), reinterpret_cast<const uint4*>(dt.p), dpq.p, dpt.p,
+                     npairs, dd.p);
+  if ((e = hipGetLastError()) != hipSuccess) return fail(e, "hamming_pairs_kernel");
+  if ((e = hipMemcpy(dist, dd.p, sizeof(int32_t) * npairs, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "hipMemcpy");
+  dq.release(); dt.release(); dpq.release(); dpt.release(); dd.release();
+  return PLVS_OK;
+}
+
+int plvs_hip_orb_search_by_projection(const plvs_frame_view* F, const plvs_mappoint_view* M, float th,
+                                      int far_points, float th_far, float nn_ratio, const uint8_t* occupied,
+                                      int32_t* assigned, int* nmatches) {
+  PLVS_REQUIRE(F && M && assigned && nmatches, "null argument");
+  PLVS_REQUIRE(F->n >= 0 && M->m >= 0, "negative size");
+  *nmatches = 0;
+  for (int i = 0; i < F->n; ++i) assigned[i] = -1;
+  if (F->n == 0 || M->m == 0) return PLVS_OK;
+  PLVS_REQUIRE(F->x && F->y && F->octave && F->u_right && F->desc && F->scale_factors, "null frame array");
+  PLVS_REQUIRE(M->track_in_view && M->bad && M->proj_x && M->proj_y && M->proj_xr && M->view_cos &&
+                   M->track_depth && M->level && M->desc,
+               "null map-point array");
+  // ---- Frame::AssignFeaturesToGrid (src/Frame.cc:717-752): cell lists in keypoint order
+  std::vector<int> cell(F->n), start(kGridCols * kGridRows + 1, 0), members(F->n);
+  for (int i = 0; i < F->n; ++i) {
+    const int px = (int)std::round((F->x[i] - F->min_x) * F->grid_w_inv);   // PosInGrid, :1305-1316
+    const int py = (int)std::round((F->y[i] - F->min_y) * F->grid_h_inv);
+    cell[i] = (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) ? -1 : px * kGridRows + py;
+    if (cell[i] >= 0) ++start[cell[i] + 1];
+  }
+  for (int c = 0; c < kGridCols * kGridRows; ++c) start[c + 1] += start[c];
+  {
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    for (int i = 0; i < F->n; ++i)
+      if (cell[i] >= 0) members[fill[cell[i]]++] = i;
+  }
+  // ---- candidate windows (GetFeaturesInArea) of every map point the reference would process,
+  // in the reference's order; everything but the "already claimed" test is decided here
+  struct Query { int k; float r_scaled; int first, count; };
+  std::vector<Query> queries;
+  std::vector<int32_t> pair_q, pair_t;
+  const bool factor = th != 1.0f;
+  for (int k = 0; k < M->m; ++k) {
+    if (!M->track_in_view[k]) continue;
+    if (far_points && M->track_depth[k] > th_far) continue;
+    if (M->bad[k]) continue;
+    const int level = M->level[k];
+    PLVS_REQUIRE(level >= 0, "negative predicted level");
+    float r = ((double)M->view_cos[k] > 0.998) ? 2.5f : 4.0f;   // RadiusByViewingCos, :246-252
+    if (factor) r *= th;
+    const float x = M->proj_x[k], y = M->proj_y[k], rr = r * F->scale_factors[level];
+    const int min_level = level - 1, max_level = level;
+    int c0 = (int)std::floor((x - F->min_x - rr) * F->grid_w_inv);
+    if (c0 < 0) c0 = 0;
+    if (c0 >= kGridCols) continue;
+    int c1 = (int)std::ceil((x - F->min_x + rr) * F->grid_w_inv);
+    if (c1 > kGridCols - 1) c1 = kGridCols - 1;
+    if (c1 < 0) continue;
+    int r0 = (int)std::floor((y - F->min_y - rr) * F->grid_h_inv);
+    if (r0 < 0) r0 = 0;
+    if (r0 >= kGridRows) continue;
+    int r1 = (int)std::ceil((y - F->min_y + rr) * F->grid_h_inv);
+    if (r1 > kGridRows - 1) r1 = kGridRows - 1;
+    if (r1 < 0) continue;
+    const bool check_levels = (min_level > 0) || (max_level >= 0);
+    Query q{k, rr, (int)pair_q.size(), 0};
+    for (int ix = c0; ix <= c1; ++ix)
+      for (int iy = r0; iy <= r1; ++iy) {
+        const int c = ix * kGridRows + iy;
+        for (int m = start[c]; m < start[c + 1]; ++m) {
+          const int idx = members[m];
+          if (check_levels && (F->octave[idx] < min_level || F->octave[idx] > max_level)) continue;
+          const float dx = F->x[idx] - x, dy = F->y[idx] - y;
+          if (!(std::fabs(dx) < rr && std::fabs(dy) < rr)) continue;
+          if (F->u_right[idx] > 0) {   // stereo coordinate must agree (RGB-D / stereo frames)
+            const float er = std::fabs(M->proj_xr[k] - F->u_right[idx]);
+            if (er > rr) continue;
+          }
+          pair_q.push_back(k);
+          pair_t.push_back(idx);
+        }
+      }
+    q.count = (int)pair_q.size() - q.first;
+    if (q.count) queries.push_back(q);
+  }
+  // ---- all distances in one launch
+  std::vector<int32_t> dist(pair_q.size());
+  int rc = plvs_hip_hamming_pairs(M->desc, M->m, F->desc, F->n, pair_q.data(), pair_t.data(), (int)pair_q.size(),
+                                  dist.data());
+  if (rc != PLVS_OK) return rc;
+  // ---- greedy assignment in map-point order (:106-163)
+  std::vector<uint8_t> blocked(F->n);
+  for (int i = 0; i < F->n; ++i) blocked[i] = occupied ? occupied[i] : 0;
+  int n = 0;
+  for (const Query& q : queries) {
+    int best = 256, best2 = 256, best_level = -1, best_level2 = -1, best_idx = -1;
+    for (int p = q.first; p < q.first + q.count; ++p) {
+      const int idx = pair_t[p];
+      if (blocked[idx]) continue;   // F.mvpMapPoints[idx] && Observations() > 0
+      const int d = dist[p];
+      if (d < best) {
+        best2 = best; best = d;
+        best_level2 = best_level; best_level = F->octave[idx];
+        best_idx = idx;
+      } else if (d < best2) {
+        best_level2 = F->octave[idx];
+        best2 = d;
+      }
+    }
+    if (best <= kThHigh) {
+      if (best_level == best_level2 && (float)best > nn_ratio * (float)best2) continue;
+      if (best_level != best_level2 || (float)best <= nn_ratio * (float)best2) {
+        assigned[best_idx] = q.k;
+        blocked[best_idx] = M->has_obs ? M->has_obs[q.k] : 1;
+        ++n;
+      }
+    }
+  }
+  *nmatches = n;
+  return PLVS_OK;
+}
+
+}  // extern "C"

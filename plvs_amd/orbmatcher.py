@@ -1,0 +1,103 @@
+"""Host-side mirror of PLVS2::ORBmatcher for the search functions that run through
+libplvs_hip.so (reference include/ORBmatcher.h, src/ORBmatcher.cc).
+
+    matcher = ORBmatcher(nnratio=0.8, checkOri=True)
+    nmatches, assigned = matcher.SearchByProjection(F, vpMapPoints, th, bFarPoints, thFarPoints)
+
+`F` and `vpMapPoints` are FrameView / MapPointView: the arrays the reference function reads of
+its Frame and MapPoint objects.  `assigned[i]` is the index (into vpMapPoints) of the map
+point given to keypoint i, or -1 — what the reference writes into F.mvpMapPoints.
+"""
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+
+_vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+
+
+class _FrameViewC(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("x", _vp), ("y", _vp), ("octave", _vp), ("u_right", _vp), ("desc", _vp),
+                ("min_x", _f), ("min_y", _f), ("grid_w_inv", _f), ("grid_h_inv", _f), ("scale_factors", _vp)]
+
+
+class _MapPointViewC(ctypes.Structure):
+    _fields_ = [("m", ctypes.c_int32), ("track_in_view", _vp), ("bad", _vp), ("proj_x", _vp), ("proj_y", _vp),
+                ("proj_xr", _vp), ("view_cos", _vp), ("track_depth", _vp), ("level", _vp), ("desc", _vp),
+                ("has_obs", _vp)]
+
+
+@dataclass
+class FrameView:
+    x: np.ndarray               # mvKeysUn[i].pt.x
+    y: np.ndarray
+    octave: np.ndarray          # mvKeysUn[i].octave
+    u_right: np.ndarray         # mvuRight[i]
+    desc: np.ndarray            # mDescriptors [n,32]
+    min_x: float                # mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv
+    min_y: float
+    grid_w_inv: float
+    grid_h_inv: float
+    scale_factors: np.ndarray   # mvScaleFactors
+
+    def as_c(self):
+        self._keep = [np.ascontiguousarray(self.x, np.float32), np.ascontiguousarray(self.y, np.float32),
+                      np.ascontiguousarray(self.octave, np.int32), np.ascontiguousarray(self.u_right, np.float32),
+                      np.ascontiguousarray(self.desc, np.uint8), np.ascontiguousarray(self.scale_factors, np.float32)]
+        k = self._keep
+        return _FrameViewC(len(k[0]), _lib.np_ptr(k[0]), _lib.np_ptr(k[1]), _lib.np_ptr(k[2]), _lib.np_ptr(k[3]),
+                           _lib.np_ptr(k[4]), self.min_x, self.min_y, self.grid_w_inv, self.grid_h_inv,
+                           _lib.np_ptr(k[5]))
+
+
+@dataclass
+class MapPointView:
+    track_in_view: np.ndarray   # mbTrackInView
+    bad: np.ndarray             # isBad()
+    proj_x: np.ndarray          # mTrackProjX / Y / XR
+    proj_y: np.ndarray
+    proj_xr: np.ndarray
+    view_cos: np.ndarray        # mTrackViewCos
+    track_depth: np.ndarray     # mTrackDepth
+    level: np.ndarray           # mnTrackScaleLevel
+    desc: np.ndarray            # GetDescriptor() [m,32]
+    has_obs: np.ndarray = None  # Observations() > 0 (None: all)
+
+    def as_c(self):
+        u8 = lambda a: np.ascontiguousarray(a, np.uint8)
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        self._keep = [u8(self.track_in_view), u8(self.bad), f32(self.proj_x), f32(self.proj_y), f32(self.proj_xr),
+                      f32(self.view_cos), f32(self.track_depth), np.ascontiguousarray(self.level, np.int32),
+                      u8(self.desc), None if self.has_obs is None else u8(self.has_obs)]
+        k = self._keep
+        return _MapPointViewC(len(k[0]), *[_lib.np_ptr(a) for a in k])
+
+
+class ORBmatcher:
+    TH_LOW, TH_HIGH, HISTO_LENGTH = 50, 100, 12
+
+    def __init__(self, nnratio=0.6, checkOri=True):
+        self.mfNNratio, self.mbCheckOrientation = float(nnratio), bool(checkOri)
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        a = np.ascontiguousarray(a, np.uint8).reshape(1, 32)
+        b = np.ascontiguousarray(b, np.uint8).reshape(1, 32)
+        d = np.zeros(1, np.int32)
+        z = np.zeros(1, np.int32)
+        _lib.check(_lib.lib.plvs_hip_hamming_pairs(_lib.np_ptr(a), 1, _lib.np_ptr(b), 1, _lib.np_ptr(z), _lib.np_ptr(z),
+                                                   1, _lib.np_ptr(d)))
+        return int(d[0])
+
+    def SearchByProjection(self, F, vpMapPoints, th=1.0, bFarPoints=False, thFarPoints=50.0, occupied=None):
+        fc, mc = F.as_c(), vpMapPoints.as_c()
+        assigned = np.full(fc.n, -7, np.int32)
+        occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+        n = _i()
+        f = _lib.lib.plvs_hip_orb_search_by_projection
+        f.argtypes = [_vp, _vp, _f, _i, _f, _f, _vp, _vp, _vp]
+        _lib.check(f(ctypes.byref(fc), ctypes.byref(mc), th, int(bFarPoints), thFarPoints, self.mfNNratio,
+                     _lib.np_ptr(occ), _lib.np_ptr(assigned), ctypes.byref(n)))
+        return n.value, assigned
