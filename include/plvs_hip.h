@@ -243,6 +243,19 @@ int plvs_hip_lines_octave_size(plvs_lines* h, int octave, int* w, int* hh);
 int plvs_hip_lines_download_map(plvs_lines* h, int octave, int which, void* out);
 int plvs_hip_lines_num_in_octave(plvs_lines* h, int octave);
 
+/* LineMatcher::SearchByKnn(Frame& CurrentFrame, const Frame& LastFrame)
+ * (src/LineMatcher.cc:303-447), single-camera frames.  Last frame = query side:
+ * LBD descriptors (n_last x 32), valid_last[i] = LastFrame.mvpMapLines[i] &&
+ * !LastFrame.mvbLineOutlier[i], angle_last[i] = mvKeyLinesUn[i].angle (radians); current
+ * frame = train side.  assigned[t] (n_cur entries, out) = index of the last-frame line
+ * whose map line goes to current line t (CurrentFrame.mvpMapLines[t] =
+ * LastFrame.mvpMapLines[assigned[t]]) or -1; *nmatches = the reference's return value.
+ * nn_ratio / check_orientation are the LineMatcher constructor arguments. */
+int plvs_hip_lines_search_by_knn(const uint8_t* desc_last, int n_last, const uint8_t* valid_last,
+                                 const float* angle_last, const uint8_t* desc_cur, int n_cur,
+                                 const float* angle_cur, float nn_ratio, int check_orientation,
+                                 int32_t* assigned, int* nmatches);
+
 /* ------------------------------------------------------------ Frame extraction
  * Points and lines of one image, extracted concurrently on two host threads
  * (each extractor drives its own stream), as Frame::Frame does with threadLeft /
