@@ -186,6 +186,28 @@ typedef struct plvs_mappoint_view {
 int plvs_hip_orb_search_by_projection(const plvs_frame_view* F, const plvs_mappoint_view* M, float th,
                                       int far_points, float th_far, float nn_ratio,
                                       const uint8_t* occupied, int32_t* assigned, int* nmatches);
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono)
+ * (src/ORBmatcher.cc:1774-1993), single-camera frames; called by Tracking::TrackWithMotionModel.
+ * The projection of the last frame's map points (Tcw * x3Dw, mpCamera->project) is the
+ * caller's: u, v, 1/z per last-frame keypoint. */
+typedef struct plvs_lastframe_view {
+  int32_t n;                    /* LastFrame.N                                        */
+  const uint8_t* valid;         /* LastFrame.mvpMapPoints[i] && !mvbOutlier[i]        */
+  const float* u;               /* uv(0), uv(1) of the map point in the current frame  */
+  const float* v;
+  const float* invz;            /* 1.0 / x3Dc(2)                                      */
+  const int32_t* octave;        /* LastFrame.mvKeys[i].octave                         */
+  const float* angle;           /* LastFrame.mvKeysUn[i].angle (degrees)              */
+  const uint8_t* desc;          /* pMP->GetDescriptor(), n x 32                       */
+  const uint8_t* has_obs;       /* pMP->Observations() > 0; NULL = all                */
+} plvs_lastframe_view;
+/* cur_angle[i] = CurrentFrame.mvKeysUn[i].angle; max_x / max_y = mnMaxX / mnMaxY; mbf =
+ * CurrentFrame.mbf; forward / backward = bForward / bBackward (:1795-1796).  assigned[i2]
+ * (out) = index of the last-frame keypoint whose map point goes to current keypoint i2. */
+int plvs_hip_orb_search_by_projection_ff(const plvs_frame_view* F, const float* cur_angle, float max_x,
+                                         float max_y, float mbf, const plvs_lastframe_view* L, float th,
+                                         int forward, int backward, int check_orientation,
+                                         const uint8_t* occupied, int32_t* assigned, int* nmatches);
 /* The batched primitive under it: dist[p] = DescriptorDistance(query[pair_q[p]],
  * train[pair_t[p]]) (src/ORBmatcher.cc:2198-2225) for arbitrary candidate lists. */
 int plvs_hip_hamming_pairs(const uint8_t* query, int nq, const uint8_t* train, int nt,

@@ -1,5 +1,6 @@
 // ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints)
-// (reference src/ORBmatcher.cc:71-244) for monocular / RGB-D frames, replaced at the
+// (reference src/ORBmatcher.cc:71-244) and SearchByProjection(CurrentFrame, LastFrame, th, bMono)
+// (:1774-1993) for monocular / RGB-D frames, replaced at the
 // search-function level: the Hamming distances of every (map point, candidate
 // keypoint) pair are computed in one batched launch; the parts that are sequential by
 // definition — the candidate windows on the 64x48 frame grid (Frame::GetFeaturesInArea,
@@ -16,6 +17,7 @@ namespace {
 constexpr int kGridCols = 64;   // FRAME_GRID_COLS, include/Frame.h:68
 constexpr int kGridRows = 48;   // FRAME_GRID_ROWS, include/Frame.h:67
 constexpr int kThHigh = 100;    // ORBmatcher::TH_HIGH, src/ORBmatcher.cc:57
+constexpr int kHistoLength = 12; // ORBmatcher::HISTO_LENGTH, :61
 
 // dist[p] = ORBmatcher::DescriptorDistance(query[pair_q[p]], train[pair_t[p]]) (src/ORBmatcher.cc:2198)
 __global__ __launch_bounds__(256) void hamming_pairs_kernel(const uint4* __restrict__ query,
@@ -29,6 +31,66 @@ __global__ __launch_bounds__(256) void hamming_pairs_kernel(const uint4* __restr
   const uint4 b0 = train[2 * pair_t[p]], b1 = train[2 * pair_t[p] + 1];
   dist[p] = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
             __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// Frame::AssignFeaturesToGrid (src/Frame.cc:717-752): cell lists in keypoint order
+struct FrameGrid {
+  std::vector<int> start, members;
+  explicit FrameGrid(const plvs_frame_view* F) : start(kGridCols * kGridRows + 1, 0), members(F->n) {
+    std::vector<int> cell(F->n);
+    for (int i = 0; i < F->n; ++i) {
+      const int px = (int)std::round((F->x[i] - F->min_x) * F->grid_w_inv);   // PosInGrid, :1305-1316
+      const int py = (int)std::round((F->y[i] - F->min_y) * F->grid_h_inv);
+      cell[i] = (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) ? -1 : px * kGridRows + py;
+      if (cell[i] >= 0) ++start[cell[i] + 1];
+    }
+    for (int c = 0; c < kGridCols * kGridRows; ++c) start[c + 1] += start[c];
+    std::vector<int> fill(start.begin(), start.end() - 1);
+    for (int i = 0; i < F->n; ++i)
+      if (cell[i] >= 0) members[fill[cell[i]]++] = i;
+  }
+  // Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel) (src/Frame.cc:1231-1303), appended to `out`
+  // in the reference's order (defaults: minLevel = -1, maxLevel = kMaxInt, include/Frame.h:173)
+  template <typename Fn>
+  void for_each_in_area(const plvs_frame_view* F, float x, float y, float r, int min_level, int max_level, Fn&& fn) const {
+    int c0 = (int)std::floor((x - F->min_x - r) * F->grid_w_inv);
+    if (c0 < 0) c0 = 0;
+    if (c0 >= kGridCols) return;
+    int c1 = (int)std::ceil((x - F->min_x + r) * F->grid_w_inv);
+    if (c1 > kGridCols - 1) c1 = kGridCols - 1;
+    if (c1 < 0) return;
+    int r0 = (int)std::floor((y - F->min_y - r) * F->grid_h_inv);
+    if (r0 < 0) r0 = 0;
+    if (r0 >= kGridRows) return;
+    int r1 = (int)std::ceil((y - F->min_y + r) * F->grid_h_inv);
+    if (r1 > kGridRows - 1) r1 = kGridRows - 1;
+    if (r1 < 0) return;
+    const bool check_levels = (min_level > 0) || (max_level >= 0);
+    for (int ix = c0; ix <= c1; ++ix)
+      for (int iy = r0; iy <= r1; ++iy) {
+        const int c = ix * kGridRows + iy;
+        for (int m = start[c]; m < start[c + 1]; ++m) {
+          const int idx = members[m];
+          if (check_levels && (F->octave[idx] < min_level || F->octave[idx] > max_level)) continue;
+          const float dx = F->x[idx] - x, dy = F->y[idx] - y;
+          if (std::fabs(dx) < r && std::fabs(dy) < r) fn(idx);
+        }
+      }
+  }
+};
+
+// ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:2123-2170) on bin counts
+void three_maxima(const int* count, int L, int& ind1, int& ind2, int& ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  ind1 = ind2 = ind3 = -1;
+  for (int i = 0; i < L; ++i) {
+    const int s = count[i];
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+    else if (s > max3) { max3 = s; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
 }
 
 }  // namespace
@@ -80,20 +142,7 @@ int plvs_hip_orb_search_by_projection(const plvs_frame_view* F, const plvs_mappo
   PLVS_REQUIRE(M->track_in_view && M->bad && M->proj_x && M->proj_y && M->proj_xr && M->view_cos &&
                    M->track_depth && M->level && M->desc,
                "null map-point array");
-  // ---- Frame::AssignFeaturesToGrid (src/Frame.cc:717-752): cell lists in keypoint order
-  std::vector<int> cell(F->n), start(kGridCols * kGridRows + 1, 0), members(F->n);
-  for (int i = 0; i < F->n; ++i) {
-    const int px = (int)std::round((F->x[i] - F->min_x) * F->grid_w_inv);   // PosInGrid, :1305-1316
-    const int py = (int)std::round((F->y[i] - F->min_y) * F->grid_h_inv);
-    cell[i] = (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) ? -1 : px * kGridRows + py;
-    if (cell[i] >= 0) ++start[cell[i] + 1];
-  }
-  for (int c = 0; c < kGridCols * kGridRows; ++c) start[c + 1] += start[c];
-  {
-    std::vector<int> fill(start.begin(), start.end() - 1);
-    for (int i = 0; i < F->n; ++i)
-      if (cell[i] >= 0) members[fill[cell[i]]++] = i;
-  }
+  const FrameGrid grid(F);
   // ---- candidate windows (GetFeaturesInArea) of every map point the reference would process,
   // in the reference's order; everything but the "already claimed" test is decided here
   struct Query { int k; float r_scaled; int first, count; };
@@ -109,37 +158,15 @@ int plvs_hip_orb_search_by_projection(const plvs_frame_view* F, const plvs_mappo
     float r = ((double)M->view_cos[k] > 0.998) ? 2.5f : 4.0f;   // RadiusByViewingCos, :246-252
     if (factor) r *= th;
     const float x = M->proj_x[k], y = M->proj_y[k], rr = r * F->scale_factors[level];
-    const int min_level = level - 1, max_level = level;
-    int c0 = (int)std::floor((x - F->min_x - rr) * F->grid_w_inv);
-    if (c0 < 0) c0 = 0;
-    if (c0 >= kGridCols) continue;
-    int c1 = (int)std::ceil((x - F->min_x + rr) * F->grid_w_inv);
-    if (c1 > kGridCols - 1) c1 = kGridCols - 1;
-    if (c1 < 0) continue;
-    int r0 = (int)std::floor((y - F->min_y - rr) * F->grid_h_inv);
-    if (r0 < 0) r0 = 0;
-    if (r0 >= kGridRows) continue;
-    int r1 = (int)std::ceil((y - F->min_y + rr) * F->grid_h_inv);
-    if (r1 > kGridRows - 1) r1 = kGridRows - 1;
-    if (r1 < 0) continue;
-    const bool check_levels = (min_level > 0) || (max_level >= 0);
     Query q{k, rr, (int)pair_q.size(), 0};
-    for (int ix = c0; ix <= c1; ++ix)
-      for (int iy = r0; iy <= r1; ++iy) {
-        const int c = ix * kGridRows + iy;
-        for (int m = start[c]; m < start[c + 1]; ++m) {
-          const int idx = members[m];
-          if (check_levels && (F->octave[idx] < min_level || F->octave[idx] > max_level)) continue;
-          const float dx = F->x[idx] - x, dy = F->y[idx] - y;
-          if (!(std::fabs(dx) < rr && std::fabs(dy) < rr)) continue;
-          if (F->u_right[idx] > 0) {   // stereo coordinate must agree (RGB-D / stereo frames)
-            const float er = std::fabs(M->proj_xr[k] - F->u_right[idx]);
-            if (er > rr) continue;
-          }
-          pair_q.push_back(k);
-          pair_t.push_back(idx);
-        }
+    grid.for_each_in_area(F, x, y, rr, level - 1, level, [&](int idx) {
+      if (F->u_right[idx] > 0) {   // stereo coordinate must agree (RGB-D / stereo frames)
+        const float er = std::fabs(M->proj_xr[k] - F->u_right[idx]);
+        if (er > rr) return;
       }
+      pair_q.push_back(k);
+      pair_t.push_back(idx);
+    });
     q.count = (int)pair_q.size() - q.first;
     if (q.count) queries.push_back(q);
   }
@@ -175,6 +202,92 @@ int plvs_hip_orb_search_by_projection(const plvs_frame_view* F, const plvs_mappo
         ++n;
       }
     }
+  }
+  *nmatches = n;
+  return PLVS_OK;
+}
+
+int plvs_hip_orb_search_by_projection_ff(const plvs_frame_view* F, const float* cur_angle, float max_x, float max_y,
+                                         float mbf, const plvs_lastframe_view* L, float th, int forward,
+                                         int backward, int check_orientation, const uint8_t* occupied,
+                                         int32_t* assigned, int* nmatches) {
+  PLVS_REQUIRE(F && L && assigned && nmatches, "null argument");
+  PLVS_REQUIRE(F->n >= 0 && L->n >= 0, "negative size");
+  *nmatches = 0;
+  for (int i = 0; i < F->n; ++i) assigned[i] = -1;
+  if (F->n == 0 || L->n == 0) return PLVS_OK;
+  PLVS_REQUIRE(F->x && F->y && F->octave && F->u_right && F->desc && F->scale_factors && cur_angle,
+               "null frame array");
+  PLVS_REQUIRE(L->valid && L->u && L->v && L->invz && L->octave && L->angle && L->desc, "null last-frame array");
+  const FrameGrid grid(F);
+  struct Query { int i; int first, count; };
+  std::vector<Query> queries;
+  std::vector<int32_t> pair_q, pair_t;
+  for (int i = 0; i < L->n; ++i) {
+    if (!L->valid[i]) continue;
+    const float invzc = L->invz[i];
+    if (invzc < 0) continue;
+    const float u = L->u[i], v = L->v[i];
+    if (u < F->min_x || u > max_x) continue;
+    if (v < F->min_y || v > max_y) continue;
+    const int oct = L->octave[i];
+    PLVS_REQUIRE(oct >= 0, "negative octave");
+    const float radius = th * F->scale_factors[oct];   // :1826
+    const int min_level = forward ? oct : (backward ? 0 : oct - 1);
+    const int max_level = forward ? 2147483647 : (backward ? oct : oct + 1);
+    Query q{i, (int)pair_q.size(), 0};
+    grid.for_each_in_area(F, u, v, radius, min_level, max_level, [&](int i2) {
+      if (F->u_right[i2] > 0) {
+        const float ur = u - mbf * invzc;
+        const float er = std::fabs(ur - F->u_right[i2]);
+        if (er > radius) return;
+      }
+      pair_q.push_back(i);
+      pair_t.push_back(i2);
+    });
+    q.count = (int)pair_q.size() - q.first;
+    if (q.count) queries.push_back(q);
+  }
+  std::vector<int32_t> dist(pair_q.size());
+  int rc = plvs_hip_hamming_pairs(L->desc, L->n, F->desc, F->n, pair_q.data(), pair_t.data(), (int)pair_q.size(),
+                                  dist.data());
+  if (rc != PLVS_OK) return rc;
+  std::vector<uint8_t> blocked(F->n);
+  for (int i = 0; i < F->n; ++i) blocked[i] = occupied ? occupied[i] : 0;
+  std::vector<int> hist_item, hist_bin;   // rotHist: what was pushed, in order (duplicates possible)
+  const float factor = kHistoLength / 360.0f;
+  int n = 0;
+  for (const Query& q : queries) {
+    int best = 256, best_idx = -1;
+    for (int p = q.first; p < q.first + q.count; ++p) {
+      const int i2 = pair_t[p];
+      if (blocked[i2]) continue;   // CurrentFrame.mvpMapPoints[i2] && Observations() > 0
+      if (dist[p] < best) { best = dist[p]; best_idx = i2; }
+    }
+    if (best <= kThHigh) {
+      assigned[best_idx] = q.i;
+      blocked[best_idx] = L->has_obs ? L->has_obs[q.i] : 1;
+      ++n;
+      if (check_orientation) {
+        float rot = L->angle[q.i] - cur_angle[best_idx];
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)std::round(rot * factor);
+        if (bin == kHistoLength) bin = 0;
+        hist_item.push_back(best_idx);
+        hist_bin.push_back(bin);
+      }
+    }
+  }
+  if (check_orientation) {
+    int count[kHistoLength] = {0};
+    for (int b : hist_bin) ++count[b];
+    int ind1, ind2, ind3;
+    three_maxima(count, kHistoLength, ind1, ind2, ind3);
+    for (size_t k = 0; k < hist_bin.size(); ++k)
+      if (hist_bin[k] != ind1 && hist_bin[k] != ind2 && hist_bin[k] != ind3) {
+        assigned[hist_item[k]] = -1;
+        --n;
+      }
   }
   *nmatches = n;
   return PLVS_OK;

@@ -101,3 +101,47 @@ class ORBmatcher:
         _lib.check(f(ctypes.byref(fc), ctypes.byref(mc), th, int(bFarPoints), thFarPoints, self.mfNNratio,
                      _lib.np_ptr(occ), _lib.np_ptr(assigned), ctypes.byref(n)))
         return n.value, assigned
+
+
+class _LastFrameViewC(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("valid", _vp), ("u", _vp), ("v", _vp), ("invz", _vp), ("octave", _vp),
+                ("angle", _vp), ("desc", _vp), ("has_obs", _vp)]
+
+
+@dataclass
+class LastFrameView:
+    valid: np.ndarray     # LastFrame.mvpMapPoints[i] && !LastFrame.mvbOutlier[i]
+    u: np.ndarray         # projection of the map point into the current frame
+    v: np.ndarray
+    invz: np.ndarray      # 1 / depth in the current camera
+    octave: np.ndarray    # LastFrame.mvKeys[i].octave
+    angle: np.ndarray     # LastFrame.mvKeysUn[i].angle
+    desc: np.ndarray      # pMP->GetDescriptor() [n,32]
+    has_obs: np.ndarray = None
+
+    def as_c(self):
+        u8 = lambda a: np.ascontiguousarray(a, np.uint8)
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        self._keep = [u8(self.valid), f32(self.u), f32(self.v), f32(self.invz),
+                      np.ascontiguousarray(self.octave, np.int32), f32(self.angle), u8(self.desc),
+                      None if self.has_obs is None else u8(self.has_obs)]
+        k = self._keep
+        return _LastFrameViewC(len(k[0]), *[_lib.np_ptr(a) for a in k])
+
+
+def _search_ff(self, CurrentFrame, cur_angle, max_x, max_y, mbf, LastFrame, th, bForward=False, bBackward=False,
+               occupied=None):
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (src/ORBmatcher.cc:1774)."""
+    fc, lc = CurrentFrame.as_c(), LastFrame.as_c()
+    ang = np.ascontiguousarray(cur_angle, np.float32)
+    assigned = np.full(fc.n, -7, np.int32)
+    occ = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+    n = _i()
+    f = _lib.lib.plvs_hip_orb_search_by_projection_ff
+    f.argtypes = [_vp, _vp, _f, _f, _f, _vp, _f, _i, _i, _i, _vp, _vp, _vp]
+    _lib.check(f(ctypes.byref(fc), _lib.np_ptr(ang), max_x, max_y, mbf, ctypes.byref(lc), th, int(bForward),
+                 int(bBackward), int(self.mbCheckOrientation), _lib.np_ptr(occ), _lib.np_ptr(assigned), ctypes.byref(n)))
+    return n.value, assigned
+
+
+ORBmatcher.SearchByProjectionLastFrame = _search_ff

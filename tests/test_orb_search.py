@@ -124,3 +124,76 @@ def test_hip_hamming_pairs_and_edge_cases(oracle):
     rc = _lib.lib.plvs_hip_hamming_pairs(_lib.np_ptr(q), 50, _lib.np_ptr(t), 70, _lib.np_ptr(bad), _lib.np_ptr(bad), 1,
                                          _lib.np_ptr(d))
     assert rc != 0
+
+
+# ------------------------------------------------------------------ frame to frame (M2)
+def make_ff_case(seed, n=1500, w=640, h=480):
+    from plvs_amd.orbmatcher import LastFrameView
+    F, _, occ = make_case(seed, n=n, m=1)
+    rng = np.random.default_rng(seed + 100)
+    cur_angle = rng.uniform(0, 360, n).astype(np.float32)
+    nl = 1200
+    src = rng.integers(0, n, nl)
+    desc = F.desc[src].copy()
+    desc ^= (rng.integers(0, 256, (nl, 32), dtype=np.uint8) & rng.integers(0, 256, (nl, 32), dtype=np.uint8)
+             & rng.integers(0, 256, (nl, 32), dtype=np.uint8))
+    u = (F.x[src] + rng.normal(0, 4.0, nl)).astype(np.float32)
+    v = (F.y[src] + rng.normal(0, 4.0, nl)).astype(np.float32)
+    far = rng.random(nl) < 0.05
+    u[far] += 2000                                   # projections outside the image bounds
+    invz = rng.uniform(-0.05, 1.0, nl).astype(np.float32)   # a few behind the camera
+    ang = (cur_angle[src] + 20 + rng.normal(0, 6, nl)).astype(np.float32)
+    wild = rng.random(nl) < 0.2
+    ang[wild] = rng.uniform(0, 360, int(wild.sum()))
+    L = LastFrameView(valid=(rng.random(nl) < 0.8), u=u, v=v, invz=invz,
+                      octave=np.clip(F.octave[src] + rng.integers(-1, 2, nl), 0, 7), angle=ang, desc=desc,
+                      has_obs=(rng.random(nl) < 0.97))
+    return F, cur_angle, float(w), float(h), 40.0, L, occ
+
+
+def oracle_search_ff(lib, F, cur_angle, max_x, max_y, mbf, L, th, fwd, bwd, check, occ):
+    fc, lc = F.as_c(), L.as_c()
+    assigned = np.full(fc.n, -7, np.int32)
+    f = lib.oracle_orb_search_by_projection_ff
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p,
+                  ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    n = f(ctypes.byref(fc), p(cur_angle), max_x, max_y, mbf, ctypes.byref(lc), th, fwd, bwd, check, p(occ), p(assigned))
+    return n, assigned
+
+
+def test_oracle_search_last_frame_properties(oracle):
+    F, ang, mx, my, mbf, L, occ = make_ff_case(2)
+    n0, a0 = oracle_search_ff(oracle.lib, F, ang, mx, my, mbf, L, 15.0, 0, 0, 0, occ)
+    got = np.nonzero(a0 >= 0)[0]
+    assert n0 >= len(got) > 100
+    for i2 in got:
+        i = a0[i2]
+        assert L.valid[i] and L.invz[i] >= 0 and 0 <= L.u[i] <= mx and 0 <= L.v[i] <= my and not occ[i2]
+        r = 15.0 * F.scale_factors[L.octave[i]]
+        assert abs(F.x[i2] - L.u[i]) < r and abs(F.y[i2] - L.v[i]) < r
+        assert L.octave[i] - 1 <= F.octave[i2] <= L.octave[i] + 1
+        assert oracle.descriptor_distance(L.desc[i], F.desc[i2]) <= 100
+    # the rotation check only removes matches; forward / backward restrict the octave band
+    n1, a1 = oracle_search_ff(oracle.lib, F, ang, mx, my, mbf, L, 15.0, 0, 0, 1, occ)
+    assert n1 < n0 and set(np.nonzero(a1 >= 0)[0]) <= set(got)
+    nf, af = oracle_search_ff(oracle.lib, F, ang, mx, my, mbf, L, 15.0, 1, 0, 0, occ)
+    for i2 in np.nonzero(af >= 0)[0]:
+        assert F.octave[i2] >= L.octave[af[i2]]
+    nb, ab = oracle_search_ff(oracle.lib, F, ang, mx, my, mbf, L, 15.0, 0, 1, 0, occ)
+    for i2 in np.nonzero(ab >= 0)[0]:
+        assert F.octave[i2] <= L.octave[ab[i2]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,th,fwd,bwd,check", [(1, 15.0, 0, 0, 1), (2, 7.0, 0, 0, 1), (3, 15.0, 1, 0, 1),
+                                                   (4, 30.0, 0, 1, 0)])
+def test_hip_search_last_frame_matches_oracle(oracle, seed, th, fwd, bwd, check):
+    from plvs_amd.orbmatcher import ORBmatcher
+    F, ang, mx, my, mbf, L, occ = make_ff_case(seed)
+    want_n, want = oracle_search_ff(oracle.lib, F, ang, mx, my, mbf, L, th, fwd, bwd, check, occ)
+    got_n, got = ORBmatcher(0.9, bool(check)).SearchByProjectionLastFrame(F, ang, mx, my, mbf, L, th, bool(fwd),
+                                                                         bool(bwd), occupied=occ)
+    assert got_n == want_n > 30
+    assert np.array_equal(got, want)
