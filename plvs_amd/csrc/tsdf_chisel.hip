@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
   __shared__ unsigned long long ckey[kTileChunkCache];   // chunk id -> pool slot, the chunks this tile meets
   __shared__ int32_t cslot[kTileChunkCache];
   __shared__ int32_t cl_off[kTileCloudCache + 1];          // cloud offsets around the tile
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x;
 
 #if PLVS_TILE_PROBE
   unsigned long long tp_ = clock64();

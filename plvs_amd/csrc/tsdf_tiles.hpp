@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kGatherThreads) void gather_runs(
     delta[jl] = from - a;
     endl[jl] = (a + len) | (closes ? 0x80000000u : 0u);
     if (a < B0 + nrec) id[max(a, B0) - B0] = (uint16_t)(jl + 1);
-    if (closes && a >= B0 && a < B0 + nrec) vkfid[key] = kfid ? kfid[last_pt[from]] : 0u;
+    if (vkfid != nullptr && closes && a >= B0 && a < B0 + nrec) vkfid[key] = kfid ? kfid[last_pt[from]] : 0u;
   }
   __syncthreads();   // id / delta / endl complete
   // ---- every output record learns its run: inclusive max-scan of the marks
