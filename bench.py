@@ -221,7 +221,7 @@ def main():
             "stage_ms_per_launch": {n: round(v / max(c2, 1), 4) for n, v in zip(names2, list(sm2.values())[:5])},
             "what": "plvs_tsdf_chisel_params.order_free = 1: the visits of a call are summed per voxel (per tile in "
                     "LDS, then per voxel) and applied in one update; no per-visit chain",
-            "parity": "sdf within 5e-6 m, weight within 2e-5 relative of the reference (measured 6.7e-7 m, "
+            "parity": "sdf within 2e-5 m, weight within 5e-5 relative of the reference (measured 6.7e-7 m, "
                       "4.5e-6); kfid and colour bit-exact (tests/test_tsdf_chisel.py); the headline `value` is the "
                       "bit-exact ordered mode",
         }
