@@ -426,6 +426,8 @@ __global__ __launch_bounds__(256) void fold_colours(
   __shared__ float inv_tab[256];
   inv_tab[threadIdx.x] = 1.f / (float)(1u + (uint32_t)threadIdx.x);
   __syncthreads();
+  constexpr int kTurn = 16;   // visits per turn
+  constexpr int kRuns = 8;    // run descriptors looked at per turn
   const uint32_t nvox = ctr->num_heads;
   for (uint32_t v0 = blockIdx.x * blockDim.x; v0 < nvox; v0 += gridDim.x * blockDim.x) {
     const uint32_t v = v0 + threadIdx.x;
@@ -436,57 +438,70 @@ __global__ __launch_bounds__(256) void fold_colours(
       col = rgbw[key];
     }
     const bool fresh = v < nvox && (col >> 24) < 254u;
-    // one flat loop for the whole wave: a lane takes up to eight visits of its current run per
-    // turn and moves to its next run when that one is used up.  The loads run a turn ahead of
-    // the fold (colours) and two turns ahead (run descriptors): the fold is cheap, the latency
-    // of a load per visit is not.
-    struct Piece { uint32_t at, n; bool ok; };   // up to eight visits of one run
-    auto next_piece = [&](Piece cur, uint32_t& run, uint32_t& run_left, unsigned long long& ahead, bool& ahead_ok) {
-      // what follows `cur`: the rest of its run, else the first piece of the next run
-      Piece nx;
-      if (run_left > 8) {
-        run_left -= 8;
-        nx.at = cur.at + 8;
-        nx.n = min(run_left, 8u);
-        nx.ok = cur.ok;
-      } else {
-        nx.ok = cur.ok && ahead_ok;
-        nx.at = (uint32_t)ahead;
-        run_left = (uint32_t)(ahead >> 32);
-        nx.n = min(run_left, 8u);
-        // and the descriptor after that
-        ++run;
-        const uint32_t jn = run + 1;
-        ahead_ok = nx.ok && jn < nd && skeys[jn] == key;
-        ahead = ahead_ok ? sval[jn] : 0ull;
-      }
-      return nx;
-    };
-    uint32_t run = jj, run_left = 0;
-    unsigned long long ahead = 0ull;
-    bool ahead_ok = false;
-    Piece cur{0u, 0u, fresh};
-    if (fresh) {
-      const unsigned long long d = sval[jj];
-      cur.at = (uint32_t)d;
-      run_left = (uint32_t)(d >> 32);
-      cur.n = min(run_left, 8u);
-      ahead_ok = jj + 1 < nd && skeys[jj + 1] == key;
-      ahead = ahead_ok ? sval[jj + 1] : 0ull;
+    // One flat loop for the whole wave.  A turn takes up to kTurn visits, across up to kRuns
+    // consecutive runs of the voxel (runs are short: ~10 visits); the run descriptors of the next
+    // turn are requested while the colours of this one are in flight — the fold is cheap, the
+    // latency of a load per visit is not.
+    bool active = fresh;
+    uint32_t pos = 0;   // visits of run jj already folded
+    unsigned long long d[kRuns];
+    uint32_t dk[kRuns];
+#pragma unroll
+    for (int q = 0; q < kRuns; ++q) {
+      const uint32_t jq = min(jj + q, nd - 1);
+      d[q] = active ? sval[jq] : 0ull;
+      dk[q] = active ? skeys[jq] : ~key;
     }
-    uint32_t c[8];
+    while (__ballot(active) != 0ull) {
+      // the runs at hand: which of them belong to the voxel, where each starts in the turn's
+      // visit sequence (prefix of the remaining lengths)
+      uint32_t start[kRuns + 1];   // visit index (within the turn's sequence) at which run q begins
+      uint32_t nvalid = 0;          // leading runs of the voxel among the descriptors
+      start[0] = 0;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) c[e] = cur.ok ? recc_t[cur.at + min((uint32_t)e, cur.n - 1)] : 0u;
-    while (__ballot(cur.ok) != 0ull) {
-      const Piece nx = next_piece(cur, run, run_left, ahead, ahead_ok);
-      uint32_t cn[8];
+      for (int q = 0; q < kRuns; ++q) {
+        const bool mine = nvalid == (uint32_t)q && (jj + q < nd) && dk[q] == key;
+        nvalid += mine ? 1u : 0u;
+        const uint32_t len = mine ? (uint32_t)(d[q] >> 32) - (q == 0 ? pos : 0u) : 0u;
+        start[q + 1] = start[q] + len;
+      }
+      const bool voxel_ends = nvalid < (uint32_t)kRuns;   // the voxel's runs end within the descriptors at hand
+      const uint32_t avail = start[kRuns];
+      const uint32_t taken = min(avail, (uint32_t)kTurn);
+      // addresses of this turn's visits
+      uint32_t addr[kTurn];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) cn[e] = nx.ok ? recc_t[nx.at + min((uint32_t)e, nx.n - 1)] : 0u;
-      if (cur.ok) {
+      for (int e = 0; e < kTurn; ++e) {
+        uint32_t a0 = (uint32_t)d[0] + pos + (uint32_t)e;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int q = 1; q < kRuns; ++q) a0 = ((uint32_t)e >= start[q]) ? (uint32_t)d[q] + ((uint32_t)e - start[q]) : a0;
+        addr[e] = a0;
+      }
+      // where the turn stops: the run holding visit number `taken` (or past the last one)
+      uint32_t run = 0;
+#pragma unroll
+      for (int q = 1; q <= kRuns; ++q) run += (taken >= start[q]) ? 1u : 0u;   // runs fully consumed
+      const uint32_t p = (run < (uint32_t)kRuns) ? taken - start[run] + (run == 0 ? pos : 0u) : 0u;
+      uint32_t c[kTurn];
+#pragma unroll
+      for (int e = 0; e < kTurn; ++e) c[e] = (active && (uint32_t)e < taken) ? recc_t[addr[e]] : 0u;
+      // where the next turn starts, and its descriptors
+      // (run / p after the loop: p may equal the count of run `run`; the skip at the top handles it)
+      const uint32_t jj_next = jj + min(run, (uint32_t)kRuns);
+      const uint32_t pos_next = (run < (uint32_t)kRuns) ? p : 0u;
+      unsigned long long dn[kRuns];
+      uint32_t dkn[kRuns];
+#pragma unroll
+      for (int q = 0; q < kRuns; ++q) {
+        const uint32_t jq = min(jj_next + q, nd - 1);
+        dn[q] = active ? sval[jq] : 0ull;
+        dkn[q] = active && (jj_next + q < nd) ? skeys[jq] : ~key;
+      }
+      if (active) {
+#pragma unroll
+        for (int e = 0; e < kTurn; ++e) {
           const uint32_t cw = col >> 24;
-          if ((uint32_t)e < cur.n && cw < 254u) {   // ColorVoxel::IntegrateSimple, visit by visit
+          if ((uint32_t)e < taken && cw < 254u) {   // ColorVoxel::IntegrateSimple, visit by visit
             const float inv = inv_tab[cw];
             const uint32_t red = (uint32_t)(uint8_t)((float)(cw * (col & 255u) + (c[e] & 255u)) * inv);
             const uint32_t green = (uint32_t)(uint8_t)((float)(cw * ((col >> 8) & 255u) + ((c[e] >> 8) & 255u)) * inv);
@@ -494,11 +509,12 @@ __global__ __launch_bounds__(256) void fold_colours(
             col = red | (green << 8) | (blue << 16) | ((cw + 1u) << 24);
           }
         }
+        if ((col >> 24) >= 254u || (voxel_ends && taken == avail) || taken == 0) active = false;
       }
-      cur = nx;
-      if ((col >> 24) >= 254u) cur.ok = false;
+      jj = jj_next;
+      pos = pos_next;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) c[e] = cn[e];
+      for (int q = 0; q < kRuns; ++q) { d[q] = dn[q]; dk[q] = dkn[q]; }
     }
     if (fresh) rgbw[key] = col;
   }
@@ -1058,14 +1074,12 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
     PLVS_HIP_TRY(h->heads.reserve(D));
     hipLaunchKernelGGL(voxel_heads, dim3(ceil_div(D, 256 * kHeadTiles)), dim3(256), 0, s, skeys, D, h->heads.p,
                        h->updated.p, h->d_ctr);
-    PLVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
-    PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    hipLaunchKernelGGL(fold_colours, dim3(std::min<size_t>(ceil_div(D, 256), 1024)), dim3(256), 0, h->side,
-                       skeys, sval, D, h->heads.p, h->recc_t.p, h->rgbw, h->d_ctr);
-    PLVS_HIP_TRY(hipEventRecord(h->ev_join, h->side));
+    // (the two kernels are NOT overlapped on two streams: measured, they slow each other down by
+    // more than the shorter one takes)
     hipLaunchKernelGGL(reduce_sums, dim3(std::min<size_t>(ceil_div(D, 4), 8192)), dim3(256), 0, s, skeys, sval,
                        D, h->heads.p, h->psum.p, h->last_pt.p, d_kfid, h->sdf, h->weight, h->kfid, h->d_ctr);
-    PLVS_HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+    hipLaunchKernelGGL(fold_colours, dim3(std::min<size_t>(ceil_div(D, 256), 1024)), dim3(256), 0, s,
+                       skeys, sval, D, h->heads.p, h->recc_t.p, h->rgbw, h->d_ctr);
     PLVS_KERNEL_CHECK();
     STAGE_MARK(5);
     STAGE_MARK(6);
