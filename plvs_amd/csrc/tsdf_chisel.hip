@@ -714,44 +714,6 @@ __global__ __launch_bounds__(64) void chain_runs(
   }
 }
 
-// The truncating u8 colour mean of ColorVoxel::IntegrateSimple: order
-// dependent, but frozen for good once the colour weight reaches 254, so a run
-// contributes at most (254 - weight) steps.  One thread per voxel run.
-__global__ __launch_bounds__(256) void chain_colours(
-    const uint32_t* __restrict__ vj0, const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ dst,
-    uint32_t nrec, const float2* __restrict__ rec, const uint32_t* __restrict__ rec_c,
-    const Counters* __restrict__ ctr, uint32_t* __restrict__ rgbw) {
-  const uint32_t nheads = ctr->num_heads;
-  for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nheads; h += gridDim.x * blockDim.x) {
-    const uint32_t j0 = vj0[h];
-    uint32_t r = dst[j0];
-    const size_t a = (size_t)skeys[j0];
-    uint32_t col = rgbw[a];
-    if ((col >> 24) >= 254u) continue;
-    for (;;) {
-      uint32_t c[4];
-      float y[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t rr = (r + j < nrec) ? r + j : nrec - 1;
-        c[j] = rec_c[rr];
-        y[j] = rec[rr].y;
-      }
-      bool done = false;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (!done) {
-          colour_update(col, c[j] & 255u, (c[j] >> 8) & 255u, (c[j] >> 16) & 255u);
-          done = (y[j] < 0.0f) || ((col >> 24) >= 254u);
-        }
-      }
-      if (done) break;
-      r += 4;
-    }
-    rgbw[a] = col;
-  }
-}
-
 // Hardware assumption of chain_runs, checked exhaustively: rcp_rn(b) == RN(1/b) for every
 // significand at the given exponent.
 __global__ void selftest_rcp_kernel(int exponent, uint32_t* __restrict__ mismatches) {
@@ -777,7 +739,7 @@ struct plvs_tsdf_chisel {
   // per-call scratch
   DevBuf<uint32_t> counts, heads, updated, scratch;
   DevBuf<float2> rec, rec_t;         // operands in voxel order / grouped per tile
-  DevBuf<uint32_t> rec_c, recc_t;    // colours, same two orders
+  DevBuf<uint32_t> recc_t;           // colours, grouped per tile (folded through the sorted runs)
   DevBuf<uint32_t> dkey0, dkey1, run_cnt, run_dst, last_pt;   // run descriptors
   DevBuf<unsigned long long> didx0, didx1;
   DevBuf<uint32_t> tile_first, block_first;
@@ -908,7 +870,7 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   for (int i = 0; i <= kNumStages; ++i)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   h->counts.release();
-  h->rec.release(); h->rec_c.release(); h->rec_t.release(); h->recc_t.release();
+  h->rec.release(); h->rec_t.release(); h->recc_t.release();
   h->dkey0.release(); h->dkey1.release(); h->didx0.release(); h->didx1.release();
   h->last_pt.release(); h->run_cnt.release(); h->run_dst.release();
   h->tile_first.release(); h->block_first.release(); h->tile_state.release();
@@ -1018,7 +980,6 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
     PLVS_HIP_TRY(h->rec_t.reserve(V));
     PLVS_HIP_TRY(h->recc_t.reserve(V));
     PLVS_HIP_TRY(h->rec.reserve((size_t)V + 2));   // chain_runs reads record pairs
-    PLVS_HIP_TRY(h->rec_c.reserve(V));
     PLVS_HIP_TRY(h->didx0.reserve(V));
     PLVS_HIP_TRY(h->last_pt.reserve(V));
     PLVS_HIP_TRY(h->block_first.reserve(ceil_div(V, kGatherSpan)));
@@ -1093,25 +1054,26 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
     const uint32_t* skeys = second ? h->dkey1.p : h->dkey0.p;
     const unsigned long long* sidx = second ? h->didx1.p : h->didx0.p;
     STAGE_MARK(4);
+    PLVS_HIP_TRY(h->heads.reserve(D));
+    hipLaunchKernelGGL(voxel_heads, dim3(ceil_div(D, 256 * kHeadTiles)), dim3(256), 0, s, skeys, D, h->heads.p,
+                       h->updated.p, h->d_ctr);
+    // The colour fold (truncating u8 mean, exact: fold_colours) reads the tile-ordered colours through
+    // the sorted runs and touches only rgbw, so it runs on a second stream beside the gather; the
+    // distance chain then has the machine to itself.
+    PLVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
+    PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    hipLaunchKernelGGL(fold_colours, dim3(std::min<size_t>(ceil_div(D, 256), 1024)), dim3(256), 0, h->side,
+                       skeys, sidx, D, h->heads.p, h->recc_t.p, h->rgbw, h->d_ctr);
+    PLVS_HIP_TRY(hipEventRecord(h->ev_join, h->side));
     hipLaunchKernelGGL(run_counts, dim3(ceil_div(D, 256)), dim3(256), 0, s, sidx, D, h->run_cnt.p);
     PLVS_HIP_TRY(exclusive_scan_u32(h->run_cnt.p, h->run_dst.p, D, nullptr, h->scratch.p, s));
     const uint32_t nblocks = ceil_div(V, kGatherSpan);
     hipLaunchKernelGGL(mark_blocks, dim3(ceil_div(D, 256)), dim3(256), 0, s, h->run_dst.p, D, V, h->block_first.p);
     hipLaunchKernelGGL(gather_runs, dim3(nblocks), dim3(kGatherThreads), 0, s, skeys, sidx, D, h->last_pt.p,
                        h->run_dst.p, h->block_first.p, nblocks, V, h->rec_t.p, h->recc_t.p, h->rec.p,
-                       h->rec_c.p, d_kfid, h->kfid);
-    PLVS_HIP_TRY(h->heads.reserve(D));
-    hipLaunchKernelGGL(voxel_heads, dim3(ceil_div(D, 256 * kHeadTiles)), dim3(256), 0, s, skeys, D, h->heads.p,
-                       h->updated.p, h->d_ctr);
+                       (uint32_t*)nullptr, d_kfid, h->kfid);
     PLVS_KERNEL_CHECK();
     STAGE_MARK(5);
-    // The colour chain touches only rgbw and the distance chain only sdf/weight; both are
-    // latency-bound with few waves, so they run side by side on two streams.
-    PLVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
-    PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    hipLaunchKernelGGL(chain_colours, dim3(std::min<size_t>(ceil_div(D, 256), 2048)), dim3(256), 0, h->side,
-                       h->heads.p, skeys, h->run_dst.p, V, h->rec.p, h->rec_c.p, h->d_ctr, h->rgbw);
-    PLVS_HIP_TRY(hipEventRecord(h->ev_join, h->side));
     // one thread per voxel; the grid is an upper bound of the voxel count, surplus waves exit
     // on the device-side count
     hipLaunchKernelGGL(chain_runs, dim3(std::min<size_t>(ceil_div(D, 64), 16384)), dim3(64), 0, s,

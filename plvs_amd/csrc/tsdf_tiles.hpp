@@ -259,7 +259,7 @@ __global__ void mark_blocks(const uint32_t* __restrict__ dst, uint32_t nd, uint3
 // Stage 5.  Runs in voxel order (stable: tile order inside a voxel) -> the records of
 // every voxel contiguous and in point order, which is what the chain kernels walk:
 //   rec[r]   = (w_u * u, +-w_u)   negative on the LAST record of a voxel
-//   rec_c[r] = r | g<<8 | b<<16
+//   rec_c[r] = r | g<<8 | b<<16   (only if the caller wants the colours in voxel order too)
 // Output-centric: a block owns kGatherSpan consecutive output records, so its stores are
 // fully coalesced; the runs that cover the span are looked up once (their first positions
 // are marked in LDS and a max-scan hands every output record its run), the loads follow the
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kGatherThreads) void gather_runs(
       float2 v = rec_t[src];
       if ((e >> 31) && (e & 0x7FFFFFFFu) == r + 1) v.y = -v.y;
       rec[r] = v;
-      rec_c[r] = recc_t[src];
+      if (rec_c != nullptr) rec_c[r] = recc_t[src];
     }
   }
 }
