@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--order-free", action="store_true",
                     help="chisel: sum the visits of a call per voxel and apply them in one update (sdf / weight within "
                          "the float tolerance stated in tests/test_tsdf_chisel.py; kfid, colour exact)")
+    ap.add_argument("--no-order-free-leg", action="store_true", help="skip the extra order-free measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frontend", action="store_true")
     return ap.parse_args()
@@ -201,7 +202,7 @@ def main():
         }
 
     # ------------------------------------------------- order-free mode, same stream (N = 1 only)
-    if rank == 0 and world == 1 and not vbx and not args.order_free:
+    if rank == 0 and world == 1 and not vbx and not args.order_free and not args.no_order_free_leg:
         t2 = TsdfChisel(args.resolution, max_chunks=16384, order_free=True)
         for s in range(args.warmup):
             t2.integrate_batch_dev(*[batches[s][i] for i in (0, 1, 2, 3, 4)])

@@ -38,7 +38,7 @@ if [[ "$STAGES" == *prof* ]]; then
 fi
 if [[ "$STAGES" == *pmc* ]]; then
   for C in FETCH_SIZE WRITE_SIZE; do
-    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$R/$O/pmc_$C" -o r -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-frontend 2>&1 | tail -5 ) > "$O/pmc_$C.log" 2>&1
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$R/$O/pmc_$C" -o r -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-frontend --no-order-free-leg $BENCH_ARGS 2>&1 | tail -5 ) > "$O/pmc_$C.log" 2>&1
   done
   echo "pmc done $(date +%T)" >> "$O/stages.log"
 fi
