@@ -397,6 +397,24 @@ int plvs_hip_tsdf_chisel_updated_chunk_ids_dev(plvs_tsdf_chisel* h, int32_t* d_i
 int plvs_hip_tsdf_chisel_download_chunk(plvs_tsdf_chisel* h, int cx, int cy, int cz, float* sdf,
                                         float* weight, uint32_t* kfid, uint32_t* rgbw);
 
+/* Depth-image carving, the first part of Chisel::IntegratePointCloudWidthDepth when the
+ * integrator has carving enabled (Chisel.cpp:394-438; PointCloudMapping.useCarving, off in the
+ * shipped settings): every existing chunk on the camera-frustum list goes through
+ * ProjectionIntegrator::CarveWithDepth (ProjectionIntegrator.h:271-338) — known voxels more than
+ * truncation + carving_dist in front of the measured depth, with sdf < 1e-5, are Reset().  Call it
+ * before the integrate of the same keyframe, as the reference does.  depth: height rows of
+ * width floats, NaN = no measurement; fx..cy: the depth camera's intrinsics; near / far:
+ * ChiselServer's plane distances (0.05 / 5.0); Twc 3x4 row-major (host memory in both flavours);
+ * carving_dist: 0.05 in PLVS.  *carved_chunks = "carved in N chunks"; afterwards
+ * plvs_hip_tsdf_chisel_updated_chunk_ids[_dev] lists them (meshesToUpdate). */
+int plvs_hip_tsdf_chisel_carve(plvs_tsdf_chisel* h, const float* depth, int width, int height, float fx,
+                               float fy, float cx, float cy, float near_dist, float far_dist,
+                               const float* Twc, float carving_dist, int* carved_chunks);
+int plvs_hip_tsdf_chisel_carve_dev(plvs_tsdf_chisel* h, const float* d_depth, int width, int height,
+                                   float fx, float fy, float cx, float cy, float near_dist,
+                                   float far_dist, const float* Twc, float carving_dist, void* stream,
+                                   int* carved_chunks);
+
 /* ------------------------------------------------------------- TSDF (voxblox)
  * Block-hashed (16^3) TSDF layer with per-point ray-cast integration.
  *

@@ -357,3 +357,148 @@ int oracle_chisel_get_chunk(const oracle_chisel* o, int cx, int cy, int cz, floa
   memcpy(rgbw, c->rgbw, CHUNK_VOX * sizeof(uint32_t));
   return 1;
 }
+
+/* ------------------------------------------------------------------ carving
+ * Chisel::IntegratePointCloudWidthDepth, the part before the point cloud (Chisel.cpp:394-438):
+ * PinholeCamera::SetupFrustum (PinholeCamera.cpp:55-59) -> Frustum::SetFromParams /
+ * SetFromVectors (Frustum.cpp:150-196) -> ChunkManager::GetChunkIDsIntersecting(frustum)
+ * (ChunkManager.cpp:241-271, Frustum::Intersects Frustum.cpp:40-78, Plane(a,b,c) Plane.cpp:46-54)
+ * -> ProjectionIntegrator::CarveWithDepth (ProjectionIntegrator.h:271-338) for every
+ * existing chunk of the list.  Restated literally, including what looks unintended in the
+ * reference: SetupFrustum passes fy for fx, Plane keeps the distance of the UNnormalised
+ * normal, and Intersects accepts a box as soon as ONE plane has its far vertex in front.
+ * atan2 / tan resolve to the double overloads (unqualified calls on floats without
+ * <math.h>'s C++ wrappers); Eigen reductions of three terms are a0 + (a1 + a2). */
+typedef struct { float n[3]; float d; } plane_t;
+
+static void vsub(const float a[3], const float b[3], float o[3]) { for (int i = 0; i < 3; i++) o[i] = a[i] - b[i]; }
+static float vdot(const float a[3], const float b[3]) { return sum3(a[0] * b[0], a[1] * b[1], a[2] * b[2]); }
+
+static plane_t plane_from(const float a[3], const float b[3], const float c[3]) {
+  float ab[3], ac[3], cr[3];
+  vsub(b, a, ab);
+  vsub(c, a, ac);
+  cr[0] = ab[1] * ac[2] - ab[2] * ac[1];
+  cr[1] = ab[2] * ac[0] - ab[0] * ac[2];
+  cr[2] = ab[0] * ac[1] - ab[1] * ac[0];
+  plane_t p;
+  const float z = sqnorm3(cr);
+  for (int i = 0; i < 3; i++) p.n[i] = (z > 0.0f) ? cr[i] / sqrtf(z) : cr[i];   /* Eigen normalized() */
+  p.d = -vdot(cr, a);
+  return p;
+}
+
+/* planes[6] = far, near, top, bottom, left, right (the order Intersects walks them);
+ * lo / hi = ComputeBoundingBox of the 8 corners. */
+static void chisel_frustum(const float R[9], const float t[3], float near_d, float far_d, float fy, float cy,
+                           float width, float height, plane_t planes[6], float lo[3], float hi[3]) {
+  float right[3], up[3], fwd[3];
+  for (int i = 0; i < 3; i++) { right[i] = R[3 * i + 0]; up[i] = -R[3 * i + 1]; fwd[i] = R[3 * i + 2]; }
+  const float fx = fy;                                            /* SetupFrustum hands fy twice */
+  const float aspect = (fx * width) / (fy * height);
+  const float fov = (float)(atan2((double)cy, (double)fy) + atan2((double)(height - cy), (double)fy));
+  const float tang = (float)tan((double)(fov / 2));
+  const float hf = tang * far_d, wf = hf * aspect, hn = tang * near_d, wn = hn * aspect;
+  float fc[3], nc[3], c[8][3];
+  for (int i = 0; i < 3; i++) { fc[i] = t[i] + fwd[i] * far_d; nc[i] = t[i] + fwd[i] * near_d; }
+  float *ftl = c[0], *ftr = c[1], *fbl = c[2], *fbr = c[3], *nbr = c[4], *ntl = c[5], *ntr = c[6], *nbl = c[7];
+  for (int i = 0; i < 3; i++) {
+    ftl[i] = fc[i] + (up[i] * hf) - (right[i] * wf);
+    ftr[i] = fc[i] + (up[i] * hf) + (right[i] * wf);
+    fbl[i] = fc[i] - (up[i] * hf) - (right[i] * wf);
+    fbr[i] = fc[i] - (up[i] * hf) + (right[i] * wf);
+    ntl[i] = nc[i] + (up[i] * hn) - (right[i] * wn);
+    ntr[i] = nc[i] + (up[i] * hn) + (right[i] * wn);
+    nbl[i] = nc[i] - (up[i] * hn) - (right[i] * wn);
+    nbr[i] = nc[i] - (up[i] * hn) + (right[i] * wn);
+  }
+  planes[0] = plane_from(ftr, ftl, fbr);   /* far */
+  planes[1] = plane_from(nbl, ntl, nbr);   /* near */
+  planes[2] = plane_from(ntl, ftl, ntr);   /* top */
+  planes[3] = plane_from(nbr, fbl, nbl);   /* bottom */
+  planes[4] = plane_from(ftl, ntl, fbl);   /* left */
+  planes[5] = plane_from(ntr, ftr, nbr);   /* right */
+  for (int i = 0; i < 3; i++) { lo[i] = 3.402823466e+38f; hi[i] = -3.402823466e+38f; }
+  for (int k = 0; k < 8; k++)
+    for (int i = 0; i < 3; i++) {
+      lo[i] = (c[k][i] < lo[i]) ? c[k][i] : lo[i];   /* std::min<float>(tempMin, corner) */
+      hi[i] = (hi[i] < c[k][i]) ? c[k][i] : hi[i];   /* std::max<float>(tempMax, corner) */
+    }
+}
+
+static int frustum_intersects(const plane_t planes[6], const float bmin[3], const float bmax[3]) {
+  for (int p = 0; p < 6; p++) {
+    float v[3];
+    for (int i = 0; i < 3; i++) v[i] = (planes[p].n[i] < 0.0f) ? bmin[i] : bmax[i];
+    if (vdot(v, planes[p].n) + planes[p].d > 0.0f) return 1;
+  }
+  return 0;
+}
+
+/* depth: height rows of width floats (NaN = no measurement).  Returns the number of carved chunks
+ * ("carved in N chunks"); ids of those chunks to carved_ids (3 ints each) if not NULL. */
+int oracle_chisel_carve(oracle_chisel* o, const float* depth, int width, int height, float fx, float fy, float cx,
+                        float cy, float near_d, float far_d, const float* Twc, float carving_dist,
+                        int32_t* carved_ids) {
+  float R[9], t[3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) R[3 * i + j] = Twc[4 * i + j];
+    t[i] = Twc[4 * i + 3];
+  }
+  plane_t planes[6];
+  float lo[3], hi[3];
+  chisel_frustum(R, t, near_d, far_d, fy, cy, (float)width, (float)height, planes, lo, hi);
+  const float res = o->resolution;
+  const float diag = (float)(2.0 * sqrt((double)3.0f) * (double)res);
+  int32_t min_id[3], max_id[3];
+  for (int i = 0; i < 3; i++) {                     /* GetIDAt, ChunkManager.h:192-198 */
+    min_id[i] = (int32_t)floorf(lo[i] * o->rounding);
+    max_id[i] = (int32_t)floorf(hi[i] * o->rounding) + 1;
+  }
+  int carved = 0;
+  for (int x = min_id[0] - 1; x <= max_id[0] + 1; x++)
+    for (int y = min_id[1] - 1; y <= max_id[1] + 1; y++)
+      for (int z = min_id[2] - 1; z <= max_id[2] + 1; z++) {
+        const float bmin[3] = {(float)(x * 16) * res, (float)(y * 16) * res, (float)(z * 16) * res};
+        const float bmax[3] = {bmin[0] + 16.0f * res, bmin[1] + 16.0f * res, bmin[2] + 16.0f * res};
+        if (!frustum_intersects(planes, bmin, bmax)) continue;
+        const int32_t id[3] = {x, y, z};
+        int found = 0;
+        chunk_t* ch = tab_find(o->tab, o->cap, id, &found);
+        if (!found) continue;
+        /* ---- CarveWithDepth */
+        const float origin[3] = {(float)(16 * x) * res, (float)(16 * y) * res, (float)(16 * z) * res};   /* Chunk.cpp:48 */
+        int updated = 0;
+        for (int i = 0; i < CHUNK_VOX; i++) {
+          if ((double)ch->weight[i] <= 1e-15) continue;
+          const int lx = i & 15, ly = (i >> 4) & 15, lz = i >> 8;
+          const float cen[3] = {((float)lx * res + o->half_voxel) + origin[0],        /* centroids[i] + origin */
+                                ((float)ly * res + o->half_voxel) + origin[1],
+                                ((float)lz * res + o->half_voxel) + origin[2]};
+          float dv[3], pc[3];
+          vsub(cen, t, dv);
+          for (int r = 0; r < 3; r++) pc[r] = sum3(R[0 + r] * dv[0], R[3 + r] * dv[1], R[6 + r] * dv[2]);   /* Rcw = R^T */
+          const float inv_z = 1.0f / pc[2];
+          const float u = fx * pc[0] * inv_z + cx, v = fy * pc[1] * inv_z + cy;
+          if (pc[2] < 0 || !(u >= 0 && v >= 0 && u < (float)width && v < (float)height)) continue;
+          const float d = depth[(size_t)(int)v * (size_t)width + (size_t)(int)u];
+          if (isnan(d)) continue;
+          const float q = (o->tq * d * d + o->tl * d + o->tc) * o->ts;
+          const float trunc = q > diag ? q : diag;      /* std::max(truncator(depth), diag) */
+          const float surface = d - pc[2];
+          if (surface > trunc + carving_dist) {
+            if ((double)ch->sdf[i] < 1e-5) {
+              ch->sdf[i] = 99999.0f;                    /* DistVoxel::Reset */
+              ch->weight[i] = 0.0f;
+              ch->kfid[i] = 0;
+              updated = 1;
+            }
+          }
+        }
+        if (updated) {
+          if (carved_ids) { carved_ids[3 * carved] = x; carved_ids[3 * carved + 1] = y; carved_ids[3 * carved + 2] = z; }
+          carved++;
+        }
+      }
+  return carved;
+}

@@ -714,6 +714,81 @@ __global__ __launch_bounds__(64) void chain_runs(
   }
 }
 
+// ------------------------------------------------------------------ carving (T7)
+// Chisel::IntegratePointCloudWidthDepth, the part before the point cloud (Chisel.cpp:394-438):
+// every existing chunk the camera frustum "intersects" (ChunkManager::GetChunkIDsIntersecting,
+// ChunkManager.cpp:241-271 + Frustum::Intersects, Frustum.cpp:40-78) goes through
+// ProjectionIntegrator::CarveWithDepth (ProjectionIntegrator.h:271-338): a known voxel whose
+// centre projects onto the depth image, lies more than truncation + carvingDist in front of
+// the measured surface and has sdf < 1e-5 is Reset().  Block-centric and order free: one
+// thread per voxel of every allocated chunk.  The frustum (six planes, bounding box) is built
+// on the host exactly as the reference does (carve_frustum below).
+struct CarveCamera {
+  float R[9], t[3];            // camera -> world
+  float fx, fy, cx, cy;
+  float width, height;         // as floats (IsPointOnImage compares float coordinates with them)
+  int iwidth;
+  float plane_n[6][3], plane_d[6];   // far, near, top, bottom, left, right
+  int lo[3], hi[3];            // candidate chunk ids, inclusive (minID - 1 .. maxID + 1)
+  float carving_dist;
+};
+
+__global__ __launch_bounds__(256) void carve_chunks(Params P, CarveCamera C, const float* __restrict__ depth,
+                                                    const int32_t* __restrict__ slot_ids, int num_chunks,
+                                                    float* __restrict__ sdf, float* __restrict__ weight,
+                                                    uint32_t* __restrict__ vkfid, uint32_t* __restrict__ carved) {
+  const int slot = blockIdx.x >> 4;   // 16 blocks of 256 voxels per chunk
+  if (slot >= num_chunks) return;
+  const int id[3] = {slot_ids[3 * slot], slot_ids[3 * slot + 1], slot_ids[3 * slot + 2]};
+  // ---- is the chunk on the reference's list?
+  for (int k = 0; k < 3; ++k)
+    if (id[k] < C.lo[k] || id[k] > C.hi[k]) return;
+  const float bmin[3] = {(float)(id[0] * 16) * P.resolution, (float)(id[1] * 16) * P.resolution,
+                         (float)(id[2] * 16) * P.resolution};
+  const float ext = 16.0f * P.resolution;
+  bool hit = false;
+  for (int p = 0; p < 6 && !hit; ++p) {
+    float v[3];
+    for (int k = 0; k < 3; ++k) v[k] = (C.plane_n[p][k] < 0.0f) ? bmin[k] : bmin[k] + ext;
+    hit = sum3(v[0] * C.plane_n[p][0], v[1] * C.plane_n[p][1], v[2] * C.plane_n[p][2]) + C.plane_d[p] > 0.0f;
+  }
+  if (!hit) return;
+  // ---- CarveWithDepth for this thread's voxel
+  const int i = ((blockIdx.x & 15) << 8) | threadIdx.x;
+  const size_t a = (size_t)slot * kChunkVox + (size_t)i;
+  bool updated = false;
+  if (!((double)weight[a] <= 1e-15)) {
+    const int lx = i & 15, ly = (i >> 4) & 15, lz = i >> 8;
+    const float cen[3] = {((float)lx * P.resolution + P.half_voxel) + bmin[0],
+                          ((float)ly * P.resolution + P.half_voxel) + bmin[1],
+                          ((float)lz * P.resolution + P.half_voxel) + bmin[2]};
+    const float d0 = cen[0] - C.t[0], d1 = cen[1] - C.t[1], d2 = cen[2] - C.t[2];
+    float pc[3];
+    for (int r = 0; r < 3; ++r) pc[r] = sum3(C.R[r] * d0, C.R[3 + r] * d1, C.R[6 + r] * d2);   // Rcw = R^T
+    const float inv_z = 1.0f / pc[2];
+    const float u = C.fx * pc[0] * inv_z + C.cx, v = C.fy * pc[1] * inv_z + C.cy;
+    if (!(pc[2] < 0) && (u >= 0 && v >= 0 && u < C.width && v < C.height)) {
+      const float d = depth[(size_t)(int)v * (size_t)C.iwidth + (size_t)(int)u];
+      if (!isnan(d)) {
+        const float trunc = truncation_of(P, d);
+        if (d - pc[2] > trunc + C.carving_dist && (double)sdf[a] < 1e-5) {
+          sdf[a] = 99999.0f;   // DistVoxel::Reset
+          weight[a] = 0.0f;
+          vkfid[a] = 0u;
+          updated = true;
+        }
+      }
+    }
+  }
+  if (__syncthreads_or(updated) && threadIdx.x == 0) carved[slot] = 1u;
+}
+
+__global__ void carve_collect(const uint32_t* __restrict__ carved, int num_chunks, uint32_t* __restrict__ list,
+                              Counters* __restrict__ ctr) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < num_chunks && carved[s]) list[atomicAdd(&ctr->num_updated, 1u)] = (uint32_t)s;
+}
+
 // Hardware assumption of chain_runs, checked exhaustively: rcp_rn(b) == RN(1/b) for every
 // significand at the given exponent.
 __global__ void selftest_rcp_kernel(int exponent, uint32_t* __restrict__ mismatches) {
@@ -1277,3 +1352,114 @@ int plvs_hip_tsdf_chisel_download_chunk(plvs_tsdf_chisel* h, int cx, int cy, int
 }
 
 }  // extern "C"
+
+// PinholeCamera::SetupFrustum -> Frustum::SetFromParams / SetFromVectors (PinholeCamera.cpp:55-59,
+// Frustum.cpp:150-196), Plane(a, b, c) (Plane.cpp:46-54), Frustum::ComputeBoundingBox (:100-125),
+// ChunkManager::GetChunkIDsIntersecting's id range (ChunkManager.cpp:248-257).  Literal, including
+// fy handed over for fx, the plane distance of the unnormalised normal, and the double atan2 / tan.
+static void carve_frustum(const Params& P, const float* Twc, float near_d, float far_d, float fy, float cy,
+                          float width, float height, CarveCamera* C) {
+  auto s3 = [](float a, float b, float c) { return a + (b + c); };
+  float R[9], t[3];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) R[3 * i + j] = Twc[4 * i + j];
+    t[i] = Twc[4 * i + 3];
+  }
+  float right[3], up[3], fwd[3];
+  for (int i = 0; i < 3; ++i) { right[i] = R[3 * i]; up[i] = -R[3 * i + 1]; fwd[i] = R[3 * i + 2]; }
+  const float fx = fy;
+  const float aspect = (fx * width) / (fy * height);
+  const float fov = (float)(atan2((double)cy, (double)fy) + atan2((double)(height - cy), (double)fy));
+  const float tang = (float)tan((double)(fov / 2));
+  const float hf = tang * far_d, wf = hf * aspect, hn = tang * near_d, wn = hn * aspect;
+  float fc[3], nc[3], c[8][3];
+  for (int i = 0; i < 3; ++i) { fc[i] = t[i] + fwd[i] * far_d; nc[i] = t[i] + fwd[i] * near_d; }
+  float *ftl = c[0], *ftr = c[1], *fbl = c[2], *fbr = c[3], *nbr = c[4], *ntl = c[5], *ntr = c[6], *nbl = c[7];
+  for (int i = 0; i < 3; ++i) {
+    ftl[i] = fc[i] + (up[i] * hf) - (right[i] * wf);
+    ftr[i] = fc[i] + (up[i] * hf) + (right[i] * wf);
+    fbl[i] = fc[i] - (up[i] * hf) - (right[i] * wf);
+    fbr[i] = fc[i] - (up[i] * hf) + (right[i] * wf);
+    ntl[i] = nc[i] + (up[i] * hn) - (right[i] * wn);
+    ntr[i] = nc[i] + (up[i] * hn) + (right[i] * wn);
+    nbl[i] = nc[i] - (up[i] * hn) - (right[i] * wn);
+    nbr[i] = nc[i] - (up[i] * hn) + (right[i] * wn);
+  }
+  auto plane = [&](int k, const float* a, const float* b, const float* cc) {
+    float ab[3], ac[3], cr[3];
+    for (int i = 0; i < 3; ++i) { ab[i] = b[i] - a[i]; ac[i] = cc[i] - a[i]; }
+    cr[0] = ab[1] * ac[2] - ab[2] * ac[1];
+    cr[1] = ab[2] * ac[0] - ab[0] * ac[2];
+    cr[2] = ab[0] * ac[1] - ab[1] * ac[0];
+    const float z = s3(cr[0] * cr[0], cr[1] * cr[1], cr[2] * cr[2]);
+    for (int i = 0; i < 3; ++i) C->plane_n[k][i] = (z > 0.0f) ? cr[i] / std::sqrt(z) : cr[i];
+    C->plane_d[k] = -s3(cr[0] * a[0], cr[1] * a[1], cr[2] * a[2]);
+  };
+  plane(0, ftr, ftl, fbr);   // far
+  plane(1, nbl, ntl, nbr);   // near
+  plane(2, ntl, ftl, ntr);   // top
+  plane(3, nbr, fbl, nbl);   // bottom
+  plane(4, ftl, ntl, fbl);   // left
+  plane(5, ntr, ftr, nbr);   // right
+  float lo[3], hi[3];
+  for (int i = 0; i < 3; ++i) { lo[i] = 3.402823466e+38f; hi[i] = -3.402823466e+38f; }
+  for (int k = 0; k < 8; ++k)
+    for (int i = 0; i < 3; ++i) {
+      lo[i] = (c[k][i] < lo[i]) ? c[k][i] : lo[i];
+      hi[i] = (hi[i] < c[k][i]) ? c[k][i] : hi[i];
+    }
+  for (int i = 0; i < 3; ++i) {   // GetIDAt(min) - 1 .. GetIDAt(max) + 1 + 1
+    C->lo[i] = (int)std::floor(lo[i] * P.rounding) - 1;
+    C->hi[i] = (int)std::floor(hi[i] * P.rounding) + 1 + 1;
+    for (int j = 0; j < 3; ++j) C->R[3 * i + j] = R[3 * i + j];
+    C->t[i] = t[i];
+  }
+}
+
+extern "C" int plvs_hip_tsdf_chisel_carve_dev(plvs_tsdf_chisel* h, const float* d_depth, int width, int height,
+                                              float fx, float fy, float cx, float cy, float near_dist,
+                                              float far_dist, const float* Twc, float carving_dist, void* stream,
+                                              int* carved_chunks) {
+  PLVS_REQUIRE(h && Twc && carved_chunks, "null argument");
+  PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
+  PLVS_REQUIRE(width > 0 && height > 0, "empty depth image");
+  *carved_chunks = 0;
+  h->stats = plvs_tsdf_stats{};
+  h->last_updated = 0;
+  if (h->num_chunks == 0) return PLVS_OK;
+  PLVS_REQUIRE(d_depth, "null depth image");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  CarveCamera C;
+  carve_frustum(h->P, Twc, near_dist, far_dist, fy, cy, (float)width, (float)height, &C);
+  C.fx = fx; C.fy = fy; C.cx = cx; C.cy = cy;
+  C.width = (float)width; C.height = (float)height; C.iwidth = width;
+  C.carving_dist = carving_dist;
+  PLVS_HIP_TRY(h->scratch.reserve((size_t)h->num_chunks));
+  PLVS_HIP_TRY(h->updated.reserve((size_t)h->num_chunks + 1));
+  PLVS_HIP_TRY(hipMemsetAsync(h->scratch.p, 0, (size_t)h->num_chunks * sizeof(uint32_t), s));
+  PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->num_updated, 0, sizeof(uint32_t), s));
+  hipLaunchKernelGGL(carve_chunks, dim3((unsigned)h->num_chunks * 16u), dim3(256), 0, s, h->P, C, d_depth,
+                     h->dir.slot_ids, h->num_chunks, h->sdf, h->weight, h->kfid, h->scratch.p);
+  hipLaunchKernelGGL(carve_collect, dim3(ceil_div((size_t)h->num_chunks, 256)), dim3(256), 0, s, h->scratch.p,
+                     h->num_chunks, h->updated.p, h->d_ctr);
+  PLVS_KERNEL_CHECK();
+  int rc = read_counters(h, s);
+  if (rc != PLVS_OK) return rc;
+  h->last_updated = h->h_ctr->num_updated;   // updated_chunk_ids now lists the carved chunks (meshesToUpdate)
+  h->stats.updated_chunks = (int32_t)h->last_updated;
+  *carved_chunks = (int)h->last_updated;
+  return PLVS_OK;
+}
+
+extern "C" int plvs_hip_tsdf_chisel_carve(plvs_tsdf_chisel* h, const float* depth, int width, int height, float fx,
+                                          float fy, float cx, float cy, float near_dist, float far_dist,
+                                          const float* Twc, float carving_dist, int* carved_chunks) {
+  PLVS_REQUIRE(h && depth && width > 0 && height > 0, "bad arguments");
+  PLVS_HIP_TRY(h->st_xyz.reserve((size_t)width * height));
+  PLVS_HIP_TRY(hipMemcpy(h->st_xyz.p, depth, (size_t)width * height * sizeof(float), hipMemcpyHostToDevice));
+  int rc = plvs_hip_tsdf_chisel_carve_dev(h, h->st_xyz.p, width, height, fx, fy, cx, cy, near_dist, far_dist, Twc,
+                                          carving_dist, nullptr, carved_chunks);
+  if (rc != PLVS_OK) return rc;
+  PLVS_HIP_TRY(hipDeviceSynchronize());
+  return PLVS_OK;
+}

@@ -58,6 +58,19 @@ class TsdfChisel:
         _lib.check(_lib.lib.plvs_hip_tsdf_chisel_integrate(
             self._h, _lib.np_ptr(xyz), _lib.np_ptr(rgb), _lib.np_ptr(kfid), xyz.shape[0], _lib.np_ptr(Twc)))
 
+    def carve(self, depth, fx, fy, cx, cy, Twc, near=0.05, far=5.0, carving_dist=0.05):
+        """Depth-image carving (Chisel.cpp:394-438 / ProjectionIntegrator::CarveWithDepth); depth is a
+        float32 image (NaN = no measurement).  Returns the number of carved chunks."""
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        Twc = np.ascontiguousarray(Twc, dtype=np.float32).reshape(3, 4)
+        n = ctypes.c_int()
+        f = _lib.lib.plvs_hip_tsdf_chisel_carve
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_float] * 6 + \
+                     [ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p]
+        _lib.check(f(self._h, _lib.np_ptr(depth), depth.shape[1], depth.shape[0], fx, fy, cx, cy, near, far,
+                     _lib.np_ptr(Twc), carving_dist, ctypes.byref(n)))
+        return n.value
+
     def integrate_batch_dev(self, d_xyz, d_rgb, d_kfid, offsets, d_Twc):
         """Device flavour: concatenated clouds resident in HBM (torch tensors),
         `offsets` a host int32 array of nclouds+1, d_Twc [nclouds,3,4] f32."""

@@ -233,6 +233,18 @@ class _ChiselLike:
         f(lib, prefix + "_get_chunk").argtypes = [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]
         self.h = _vp(f(lib, prefix + "_create")(resolution, tq, tl, tc, ts, weight, shard_rank, shard_count))
 
+    def carve(self, depth, fx, fy, cx, cy, Twc, near=0.05, far=5.0, carving_dist=0.05):
+        """-> (number of carved chunks, their ids)  (oracle only)"""
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        Twc = np.ascontiguousarray(Twc, dtype=np.float32).reshape(3, 4)
+        f = getattr(self.lib, self.p + "_carve")
+        f.restype = _i
+        f.argtypes = [_vp, _vp, _i, _i] + [_f] * 6 + [_vp, _f, _vp]
+        ids = np.zeros((max(self.num_chunks(), 1), 3), np.int32)
+        n = f(self.h, _ptr(depth), depth.shape[1], depth.shape[0], fx, fy, cx, cy, near, far, _ptr(Twc), carving_dist,
+              _ptr(ids))
+        return n, ids[:n]
+
     def close(self):
         if self.h:
             getattr(self.lib, self.p + "_destroy")(self.h)

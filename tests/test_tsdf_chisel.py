@@ -333,3 +333,69 @@ def test_hip_degenerate_clouds_match_oracle(oracle, order_free):
     else:
         assert compare_maps(ora, dev) > 50
     dev.close()
+
+
+# ------------------------------------------------------------------ carving (T7)
+def _depth_image(cam, kind, seed=0):
+    h, w = cam["height"], cam["width"]
+    rng = np.random.default_rng(seed)
+    if kind == "far":          # everything measured far away: whatever was mapped in front is carved
+        d = np.full((h, w), 4.2, np.float32)
+    elif kind == "mixed":      # some pixels far, some close (nothing to carve there), some without a measurement
+        d = rng.uniform(0.4, 4.8, (h, w)).astype(np.float32)
+        d[rng.random((h, w)) < 0.15] = np.nan
+    else:                      # "near": the surface moved closer: nothing in front of it
+        d = np.full((h, w), 0.3, np.float32)
+    return d
+
+
+def test_oracle_carving_properties(oracle):
+    cam = small_cam(4)
+    kfs = make_keyframes(4, cam=cam, seed=31)
+    m = oracle.chisel(0.05)
+    for kf in kfs:
+        m.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+    before = {tuple(c): m.get_chunk(*c) for c in m.chunk_ids()}
+    known_before = sum(int((v[1] > 0).sum()) for v in before.values())
+    # a surface right in front of the camera: no voxel is more than truncation + 0.05 in front of it
+    n_near, _ = m.carve(_depth_image(cam, "near"), cam["fx"], cam["fy"], cam["cx"], cam["cy"], kfs[0]["Twc"])
+    assert n_near == 0
+    n_far, ids = m.carve(_depth_image(cam, "far"), cam["fx"], cam["fy"], cam["cx"], cam["cy"], kfs[0]["Twc"])
+    assert n_far == len(ids) > 0
+    after = {tuple(c): m.get_chunk(*c) for c in m.chunk_ids()}
+    assert set(after) == set(before)                 # carving never creates or drops chunks
+    known_after = sum(int((v[1] > 0).sum()) for v in after.values())
+    assert known_after < known_before
+    touched = {tuple(i) for i in ids}
+    for cid, (sdf, w, kf, col) in after.items():
+        b = before[cid]
+        changed = (w != b[1])
+        assert changed.any() == (cid in touched)
+        # a carved voxel is reset: sdf 99999, weight 0, kfid 0, colour untouched; only voxels with sdf < 1e-5 go
+        assert np.all(sdf[changed] == 99999.0) and np.all(w[changed] == 0) and np.all(kf[changed] == 0)
+        assert np.all(b[0][changed] < 1e-5) and np.array_equal(col, b[3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["far", "mixed", "near"])
+def test_hip_carving_matches_oracle(oracle, kind):
+    from plvs_amd.tsdf import TsdfChisel
+    cam = small_cam(2)
+    kfs = make_keyframes(5, cam=cam, seed=33)
+    ora = oracle.chisel(0.05)
+    dev = TsdfChisel(0.05, max_chunks=4096)
+    for kf in kfs:
+        ora.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+        dev.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+    for step, pose in enumerate((kfs[1]["Twc"], kfs[4]["Twc"])):
+        depth = _depth_image(cam, kind, seed=step)
+        want_n, want_ids = ora.carve(depth, cam["fx"], cam["fy"], cam["cx"], cam["cy"], pose)
+        got_n = dev.carve(depth, cam["fx"], cam["fy"], cam["cx"], cam["cy"], pose)
+        assert got_n == want_n
+        assert {tuple(i) for i in dev.updated_chunk_ids()} == {tuple(i) for i in want_ids}
+        compare_maps(ora, dev)
+    # integrating on top of a carved map still agrees
+    ora.integrate(kfs[2]["xyz"], kfs[2]["rgb"], kfs[2]["kfid"], kfs[2]["Twc"])
+    dev.integrate(kfs[2]["xyz"], kfs[2]["rgb"], kfs[2]["kfid"], kfs[2]["Twc"])
+    compare_maps(ora, dev)
+    dev.close()
