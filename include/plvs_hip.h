@@ -415,6 +415,65 @@ int plvs_hip_tsdf_chisel_carve_dev(plvs_tsdf_chisel* h, const float* d_depth, in
                                    float far_dist, const float* Twc, float carving_dist, void* stream,
                                    int* carved_chunks);
 
+/* ------------------------------------------------- depth image -> cloud (T0)
+ * Replaces PointCloudMapping::GeneratePointCloudInCameraFrameBGRA
+ * src/PointCloudMapping.cc:929-1031 (caller IntegratePointCloudKeyframe path,
+ * :660-677 via GeneratePointCloudInCameraFrame :1228) for the shipped build:
+ * pcl::PointSurfelSegment with normals, EigthNeighborhoodIndicesFast,
+ * Segmentation.on 0, filterDepth.on 0.  Every grid pixel (m, n), m and n
+ * multiples of `step` (PointCloudMapping.downSampleStep, 2), with
+ * min_depth < d < max_depth (double limits, PointCloudMapTypes.h:59-60)
+ * becomes one point, in row-major grid order: p = (gx*d, gy*d, d), the
+ * r, g, b members take the image's B, G, R bytes (:978-980), normals are the
+ * area-weighted cross products of the up/left/down/right neighbours in
+ * double (:1007-1030), label 0.                                            */
+
+/* pcl::PointSurfelSegment (include/PointSurfelSegment.h:63-94), 48 bytes. */
+typedef struct plvs_point_surfel {
+  float x, y, z;
+  uint32_t kfid;
+  float normal_x, normal_y, normal_z, normal_pad;
+  uint8_t b, g, r, a;
+  float depth;
+  uint32_t label, label_confidence;
+} plvs_point_surfel;
+
+typedef struct plvs_cloudgen plvs_cloudgen;
+
+/* Rows of matCamGridPoints_ actually used: ceil(w/step) * ceil(h/step). */
+int plvs_hip_cloudgen_num_grid_points(int width, int height, int step);
+/* InitCamGridPoints (src/PointCloudMapping.cc:796-905) for an undistorted,
+ * unrectified camera (mDistCoef[0] == 0): grid[2*ii] = (n - cx)/fx,
+ * grid[2*ii+1] = (m - cy)/fy.  Host function, no GPU.  A PLVS build with
+ * distortion hands over its own matCamGridPoints_ instead. */
+int plvs_hip_cloudgen_grid_points(int width, int height, int step, double fx, double fy, double cx,
+                                  double cy, float* grid);
+/* grid_points: host, num_grid_points x 2 f32 = matCamGridPoints_ after
+ * InitCamGridPoints (computed once per camera there too). */
+int plvs_hip_cloudgen_create(int width, int height, int step, const float* grid_points,
+                             plvs_cloudgen** out);
+int plvs_hip_cloudgen_destroy(plvs_cloudgen* h);
+/* Host flavour: depth (f32, pitch in floats) and colour (BGR u8, pitch in
+ * bytes) are host images; out receives *n records (capacity >=
+ * num_grid_points); pixel_to_point (height x width int32, -1 = no point) may
+ * be NULL.  Synchronous. */
+int plvs_hip_cloudgen_generate(plvs_cloudgen* h, const float* depth, int depth_pitch,
+                               const uint8_t* bgr, int bgr_pitch, double min_depth, double max_depth,
+                               uint32_t kfid, plvs_point_surfel* out, int capacity,
+                               int32_t* pixel_to_point, int* n);
+/* Device flavour: images resident in HBM; writes the arrays the TSDF entry
+ * points consume (d_xyz n x 3; d_rgb n x 3 for chisel and/or d_rgba n x 4 for
+ * voxblox; d_kfid n) plus optional d_normals (n x 3), d_point_depth (n),
+ * d_pixel_to_point; every output except d_xyz may be NULL.  The point count
+ * goes to *d_count (device, may be NULL) and, if n != NULL, to *n after a
+ * stream synchronise (the batch integrate needs host offsets). */
+int plvs_hip_cloudgen_generate_dev(plvs_cloudgen* h, const float* d_depth, int depth_pitch,
+                                   const uint8_t* d_bgr, int bgr_pitch, double min_depth,
+                                   double max_depth, uint32_t kfid, float* d_xyz, uint8_t* d_rgb,
+                                   uint8_t* d_rgba, uint32_t* d_kfid, float* d_normals,
+                                   float* d_point_depth, int32_t* d_pixel_to_point, int* d_count,
+                                   void* stream, int* n);
+
 /* ------------------------------------------------------------- TSDF (voxblox)
  * Block-hashed (16^3) TSDF layer with per-point ray-cast integration.
  *

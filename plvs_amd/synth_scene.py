@@ -79,3 +79,35 @@ def make_keyframes(n_keyframes=100, cam=None, room_size=(6.0, 4.0, 3.0), step=2,
                         kfid=np.full(xyz.shape[0], k, dtype=np.uint32),
                         Twc=np.ascontiguousarray(Twc)))
     return out
+
+
+def make_rgbd_frames(n_frames=2, cam=None, room_size=(6.0, 4.0, 3.0), seed=0, holes=True, first=0):
+    """Full-resolution inputs of GeneratePointCloudInCameraFrameBGRA: a list of dicts
+    {depth f32[h,w], bgr u8[h,w,3], Twc f32[3,4]}.  `holes` adds what a real sensor produces:
+    zero (no return), NaN and out-of-range patches."""
+    cam = cam or TUM1
+    rng = np.random.default_rng(seed)
+    half = np.array(room_size, dtype=np.float64) / 2.0
+    spheres = [(np.array([2.3, 0.5, 0.2]), 0.4), (np.array([-2.3, -0.4, -0.3]), 0.4),
+               (np.array([-2.0, 1.3, 0.4]), 0.4)]
+    out = []
+    for k in range(first, first + n_frames):
+        yaw = np.deg2rad(3.6 * k)
+        pos = np.array([np.cos(yaw), np.sin(yaw), 0.1 * np.sin(2 * yaw)])
+        fwd = np.array([np.cos(yaw), np.sin(yaw), 0.0])
+        right = np.array([np.sin(yaw), -np.cos(yaw), 0.0])
+        R = np.stack([right, np.cross(fwd, right), fwd], axis=1)
+        _, _, depth = _render_depth(R, pos, cam, (-half, half), spheres, 1)
+        depth = depth + rng.standard_normal(depth.shape) * (0.0012 + 0.0019 * (depth - 0.4) ** 2)
+        d32 = depth.astype(np.float32)
+        h, w = d32.shape
+        if holes:
+            for _ in range(12):
+                y0, x0 = int(rng.integers(0, h - 40)), int(rng.integers(0, w - 40))
+                hh, ww = int(rng.integers(3, 40)), int(rng.integers(3, 40))
+                d32[y0:y0 + hh, x0:x0 + ww] = (0.0, np.nan, 25.0)[int(rng.integers(0, 3))]
+            d32[rng.random(d32.shape) < 0.02] = 0.0
+        bgr = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        Twc = np.concatenate([R, pos[:, None]], axis=1).astype(np.float32)
+        out.append(dict(depth=np.ascontiguousarray(d32), bgr=bgr, Twc=np.ascontiguousarray(Twc)))
+    return out

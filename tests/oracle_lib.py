@@ -84,6 +84,37 @@ class Oracle:
     def voxblox(self, voxel_size, **kw):
         return _VoxbloxLike(self.lib, "oracle_voxblox", voxel_size, **kw)
 
+    # ------------------------------------------------------------ depth -> cloud (T0)
+    def cam_grid_points(self, width, height, step, fx, fy, cx, cy):
+        ngrid = ((width + step - 1) // step) * ((height + step - 1) // step)
+        grid = np.zeros((ngrid, 2), np.float32)
+        d = ctypes.c_double
+        self.lib.oracle_cam_grid_points.argtypes = [_i, _i, _i, d, d, d, d, _vp]
+        self.lib.oracle_cam_grid_points.restype = None
+        self.lib.oracle_cam_grid_points(width, height, step, fx, fy, cx, cy, _ptr(grid))
+        return grid
+
+    def cloudgen(self, depth, bgr, grid, step, min_depth, max_depth, kfid, depth_pitch=None, bgr_pitch=None,
+                 width=None, height=None):
+        """-> (records [n] SURFEL_DTYPE, pixel_to_point [h, w] int32)."""
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        height = height or depth.shape[0]
+        width = width or depth.shape[1]
+        depth_pitch = depth_pitch or depth.shape[1]
+        bgr_pitch = bgr_pitch or bgr.shape[1] * 3
+        grid = np.ascontiguousarray(grid, dtype=np.float32)
+        ngrid = ((width + step - 1) // step) * ((height + step - 1) // step)
+        out = np.zeros(max(ngrid, 1), SURFEL_DTYPE)
+        p2p = np.zeros((height, width), np.int32)
+        d = ctypes.c_double
+        f = self.lib.oracle_cloudgen
+        f.argtypes = [_vp, _i, _vp, _i, _i, _i, _i, _vp, d, d, ctypes.c_uint32, _vp, _vp]
+        f.restype = _i
+        n = f(_ptr(depth), depth_pitch, _ptr(bgr), bgr_pitch, width, height, step, _ptr(grid), min_depth, max_depth,
+              kfid, _ptr(out), _ptr(p2p))
+        return out[:n], p2p
+
     def knn2(self, q, t, qmask=None, mih=True):
         q = np.ascontiguousarray(q, dtype=np.uint8)
         t = np.ascontiguousarray(t, dtype=np.uint8)
@@ -96,6 +127,10 @@ class Oracle:
         f(_ptr(q), nq, _ptr(t), nt, _ptr(qmask), _ptr(idx), _ptr(dist))
         return idx, dist
 
+
+SURFEL_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("kfid", "<u4"), ("normal", "<f4", (3,)),
+                         ("normal_pad", "<f4"), ("b", "u1"), ("g", "u1"), ("r", "u1"), ("a", "u1"),
+                         ("depth", "<f4"), ("label", "<u4"), ("label_confidence", "<u4")])
 
 KP_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.float32), ("angle", np.float32),
                      ("response", np.float32), ("octave", np.int32), ("class_id", np.int32)])

@@ -8,5 +8,6 @@ _spec = importlib.util.spec_from_file_location("plvs_amd_synth_scene", _p)
 _m = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(_m)
 make_keyframes = _m.make_keyframes
+make_rgbd_frames = _m.make_rgbd_frames
 TUM1 = _m.TUM1
 KITTI = _m.KITTI
