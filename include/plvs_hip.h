@@ -415,6 +415,23 @@ int plvs_hip_tsdf_chisel_carve_dev(plvs_tsdf_chisel* h, const float* d_depth, in
                                    float far_dist, const float* Twc, float carving_dist, void* stream,
                                    int* carved_chunks);
 
+/* ------------------------------------------------- sparse stereo matching (M5)
+ * Replaces Frame::ComputeStereoMatches src/Frame.cc:1780-1975 (caller: the
+ * stereo Frame constructor, after the two ExtractORB threads joined).  The two
+ * extractors must have processed the current rectified pair: their device
+ * pyramids (mvImagePyramid) are read in place.  keys / desc are the packed
+ * outputs of plvs_hip_orb_extract (mvKeys / mDescriptors, mvKeysRight /
+ * mDescriptorsRight); mb = baseline in metres, mbf = fx * baseline.
+ * u_right / depth: n_left floats = mvuRight / mvDepth (-1 = no match), after
+ * the 1.5 * 1.4 * median cut.  *n_matched (nullable) = keypoints with depth. */
+typedef struct plvs_stereo plvs_stereo;
+int plvs_hip_stereo_create(plvs_orb* left, plvs_orb* right, plvs_stereo** out);
+int plvs_hip_stereo_destroy(plvs_stereo* s);
+int plvs_hip_stereo_matches(plvs_stereo* s, const plvs_keypoint* keys_left, const uint8_t* desc_left,
+                            int n_left, const plvs_keypoint* keys_right, const uint8_t* desc_right,
+                            int n_right, float mb, float mbf, float* u_right, float* depth,
+                            int* n_matched);
+
 /* ------------------------------------------------- depth image -> cloud (T0)
  * Replaces PointCloudMapping::GeneratePointCloudInCameraFrameBGRA
  * src/PointCloudMapping.cc:929-1031 (caller IntegratePointCloudKeyframe path,

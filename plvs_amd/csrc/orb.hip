@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "orb_internal.hpp"
 #include "orb_octree.hpp"
 
 using namespace plvs;
@@ -952,3 +953,23 @@ int plvs_hip_orb_last_candidates(plvs_orb* o, int level, float* xyr, int cap, in
 }
 
 }  // extern "C"
+
+namespace plvs {
+
+bool orb_pyramid_view(const plvs_orb* o, OrbPyramidView* v) {
+  if (o == nullptr || v == nullptr || o->img_w <= 0 || o->d_pyr == nullptr) return false;
+  if (o->nlevels > kMaxOrbLevels) return false;
+  v->nlevels = o->nlevels;
+  for (int l = 0; l < o->nlevels; ++l) {
+    const LevelDev& L = o->levels[l];
+    v->level[l] = o->d_pyr + L.off;
+    v->w[l] = L.w;
+    v->h[l] = L.h;
+    v->pitch[l] = L.pitch;
+    v->scale[l] = o->scale[l];
+    v->inv_scale[l] = o->inv_scale[l];
+  }
+  return true;
+}
+
+}  // namespace plvs

@@ -40,7 +40,8 @@ def write_pgm(path, img):
 if __name__ == "__main__":
     os.makedirs(DST, exist_ok=True)
     crops = [("aloe_left", 640, 480, 64, 32, "aloe_640x480"), ("aloe_left", 640, 480, 67, 34, "aloe_640x480_shift"),
-             ("cones_left", 640, 480, 128, 96, "cones_640x480"), ("urban1_left", 1241, 376, 40, 8, "urban1_1241x376")]
+             ("cones_left", 640, 480, 128, 96, "cones_640x480"), ("urban1_left", 1241, 376, 40, 8, "urban1_1241x376"),
+             ("urban1_right", 1241, 376, 40, 8, "urban1_right_1241x376")]  # rectified pair for M5
     for name, w, h, x0, y0, out in crops:
         img = read_pgm(os.path.join(SRC, name + ".pgm"))
         write_pgm(os.path.join(DST, out + ".pgm"), img[y0:y0 + h, x0:x0 + w])

@@ -84,6 +84,35 @@ class Oracle:
     def voxblox(self, voxel_size, **kw):
         return _VoxbloxLike(self.lib, "oracle_voxblox", voxel_size, **kw)
 
+    # ------------------------------------------------------------ stereo (M5)
+    def stereo_matches(self, keys_left, desc_left, keys_right, desc_right, pyr_left, pyr_right, scale, inv_scale,
+                       mb, mbf):
+        """pyr_*: lists of level images (mvImagePyramid).  -> (uRight, depth, score, kept)."""
+        kl = np.ascontiguousarray(keys_left, dtype=KP_DTYPE)
+        kr = np.ascontiguousarray(keys_right, dtype=KP_DTYPE)
+        dl = np.ascontiguousarray(desc_left, dtype=np.uint8)
+        dr = np.ascontiguousarray(desc_right, dtype=np.uint8)
+        pl = [np.ascontiguousarray(a, dtype=np.uint8) for a in pyr_left]
+        pr = [np.ascontiguousarray(a, dtype=np.uint8) for a in pyr_right]
+        nl = len(pl)
+        lw = np.array([a.shape[1] for a in pl], np.int32)
+        lh = np.array([a.shape[0] for a in pl], np.int32)
+        assert all(a.shape == b.shape for a, b in zip(pl, pr))
+        arr_l = (ctypes.c_void_p * nl)(*[a.ctypes.data for a in pl])
+        arr_r = (ctypes.c_void_p * nl)(*[a.ctypes.data for a in pr])
+        sc = np.ascontiguousarray(scale, dtype=np.float32)
+        isc = np.ascontiguousarray(inv_scale, dtype=np.float32)
+        u = np.zeros(max(kl.shape[0], 1), np.float32)
+        d = np.zeros(max(kl.shape[0], 1), np.float32)
+        score = np.zeros(max(kl.shape[0], 1), np.int32)
+        f = self.lib.oracle_stereo_matches
+        f.restype = _i
+        f.argtypes = [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp]
+        kept = f(_ptr(kl), _ptr(dl), kl.shape[0], _ptr(kr), _ptr(dr), kr.shape[0], arr_l, arr_r, _ptr(lw), _ptr(lh), nl,
+                 _ptr(sc), _ptr(isc), mb, mbf, _ptr(u), _ptr(d), _ptr(score))
+        n = kl.shape[0]
+        return u[:n], d[:n], score[:n], kept
+
     # ------------------------------------------------------------ depth -> cloud (T0)
     def cam_grid_points(self, width, height, step, fx, fy, cx, cy):
         ngrid = ((width + step - 1) // step) * ((height + step - 1) // step)
