@@ -208,6 +208,27 @@ int plvs_hip_orb_search_by_projection_ff(const plvs_frame_view* F, const float* 
                                          float max_y, float mbf, const plvs_lastframe_view* L, float th,
                                          int forward, int backward, int check_orientation,
                                          const uint8_t* occupied, int32_t* assigned, int* nmatches);
+/* ORBmatcher::SearchByBoW(KeyFramePtr& pKF, Frame& F, vpMapPointMatches)
+ * (src/ORBmatcher.cc:300-507), single-camera frames; called by
+ * Tracking::TrackReferenceKeyFrame and Relocalization.  A DBoW2::FeatureVector
+ * (std::map<NodeId, std::vector<unsigned>>) is handed over as its in-order
+ * traversal: node ids ascending, offsets (nnodes + 1) into the concatenated
+ * feature-index lists. */
+typedef struct plvs_featvec_view {
+  int32_t nnodes;
+  const uint32_t* node_id;
+  const int32_t* offset;
+  const uint32_t* index;
+} plvs_featvec_view;
+/* kf_valid[i] = vpMapPointsKF[i] && !isBad(); kf_angle = pKF->mvKeysUn[i].angle,
+ * f_angle = F.mvKeys[i].angle (degrees; only read when check_orientation);
+ * nn_ratio = mfNNratio.  assigned[iF] (out, f_n) = key-frame keypoint whose map
+ * point goes to frame keypoint iF, or -1; *nmatches = the return value. */
+int plvs_hip_orb_search_by_bow(const plvs_featvec_view* kf_vec, const uint8_t* kf_desc, int kf_n,
+                               const uint8_t* kf_valid, const float* kf_angle,
+                               const plvs_featvec_view* f_vec, const uint8_t* f_desc, int f_n,
+                               const float* f_angle, float nn_ratio, int check_orientation,
+                               int32_t* assigned, int* nmatches);
 /* The batched primitive under it: dist[p] = DescriptorDistance(query[pair_q[p]],
  * train[pair_t[p]]) (src/ORBmatcher.cc:2198-2225) for arbitrary candidate lists. */
 int plvs_hip_hamming_pairs(const uint8_t* query, int nq, const uint8_t* train, int nt,
@@ -277,6 +298,27 @@ int plvs_hip_lines_search_by_knn(const uint8_t* desc_last, int n_last, const uin
                                  const float* angle_last, const uint8_t* desc_cur, int n_cur,
                                  const float* angle_cur, float nn_ratio, int check_orientation,
                                  int32_t* assigned, int* nmatches);
+
+/* LineMatcher::SearchByKnn(KeyFramePtr& pKF, const Frame& F, vpMapLineMatches)
+ * (src/LineMatcher.cc:156-301), called by Tracking::TrackReferenceKeyFrame: key frame =
+ * query side (valid_kf[i] = vpMapLinesKF[i] && !isBad()), frame = train side; a match needs
+ * distance <= TH_LOW (60).  assigned[t] (n_f entries) = key-frame line whose map line goes
+ * to frame line t, or -1. */
+int plvs_hip_lines_search_by_knn_kf(const uint8_t* desc_kf, int n_kf, const uint8_t* valid_kf,
+                                    const float* angle_kf, const uint8_t* desc_f, int n_f,
+                                    const float* angle_f, float nn_ratio, int check_orientation,
+                                    int32_t* assigned, int* nmatches);
+/* LineMatcher::SearchStereoMatchesByKnn(frame, vMatches, vValidMatches, descriptorDist)
+ * (src/LineMatcher.cc:454-586): left lines = query, right lines = train; angle / octave of
+ * mvKeyLinesUn / mvKeyLinesRightUn.  Outputs = vMatches (queryIdx, trainIdx, distance) and
+ * vValidMatches in the reference's order, *n_out entries (cap >= n_right always suffices);
+ * *nmatches = the return value (valid entries). */
+int plvs_hip_lines_search_stereo_by_knn(const uint8_t* desc_left, int n_left, const float* angle_left,
+                                        const int32_t* octave_left, const uint8_t* desc_right, int n_right,
+                                        const float* angle_right, const int32_t* octave_right, float nn_ratio,
+                                        int check_orientation, int descriptor_dist, int32_t* match_query,
+                                        int32_t* match_train, float* match_distance, uint8_t* match_valid,
+                                        int cap, int* n_out, int* nmatches);
 
 /* ------------------------------------------------------------ Frame extraction
  * Points and lines of one image, extracted concurrently on two host threads

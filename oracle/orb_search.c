@@ -13,6 +13,7 @@
 #define GRID_COLS 64   /* FRAME_GRID_COLS, include/Frame.h:68 */
 #define GRID_ROWS 48   /* FRAME_GRID_ROWS, include/Frame.h:67 */
 #define TH_HIGH 100    /* src/ORBmatcher.cc:57 */
+#define TH_LOW 50      /* :58 */
 
 extern int oracle_descriptor_distance(const uint8_t* a, const uint8_t* b);
 
@@ -282,5 +283,96 @@ int oracle_orb_search_by_projection_ff(const frame_view* F, const float* cur_ang
       }
   }
   free(start); free(members); free(cand); free(blocked); free(hist_items); free(hist_bin);
+  return nmatches;
+}
+
+/* ---- ORBmatcher::SearchByBoW(KeyFramePtr& pKF, Frame& F, vpMapPointMatches), src/ORBmatcher.cc:300-507
+ * (SURVEY §8 row M4), single-camera frames (F.Nleft == -1 branch, :351-374).
+ *
+ * DBoW2::FeatureVector is a std::map<NodeId, std::vector<unsigned int>>: here its in-order
+ * traversal — node ids ascending, offsets (nnodes + 1) into the concatenated index lists.  The
+ * two-iterator walk with lower_bound (:321-489) visits exactly the common node ids in ascending
+ * order.  kf_valid[i] = vpMapPointsKF[i] && !isBad() (:338-344); angles are kp.angle of
+ * pKF->mvKeysUn and F.mvKeys (:415-427).  assigned[iF] (out, f_n entries) = the key-frame
+ * keypoint whose map point F keypoint iF receives, or -1.  Returns nmatches. */
+typedef struct {
+  int32_t nnodes;
+  const uint32_t* node_id;
+  const int32_t* offset;
+  const uint32_t* index;
+} featvec_view;
+
+int oracle_orb_search_by_bow(const featvec_view* KV, const uint8_t* kf_desc, int kf_n, const uint8_t* kf_valid,
+                             const float* kf_angle, const featvec_view* FV, const uint8_t* f_desc, int f_n,
+                             const float* f_angle, float nn_ratio, int check_orientation, int32_t* assigned) {
+  (void)kf_n;
+  for (int i = 0; i < f_n; ++i) assigned[i] = -1;
+  int* hist_items = (int*)malloc(sizeof(int) * (size_t)(f_n > 0 ? f_n : 1));
+  int* hist_bin = (int*)malloc(sizeof(int) * (size_t)(f_n > 0 ? f_n : 1));
+  int nhist = 0, nmatches = 0;
+  const float factor = 12 / 360.0f;                                    /* :313-315 */
+  int a = 0, b = 0;
+  while (a < KV->nnodes && b < FV->nnodes) {                           /* :327 */
+    if (KV->node_id[a] == FV->node_id[b]) {
+      for (int ik = KV->offset[a]; ik < KV->offset[a + 1]; ++ik) {     /* :334 */
+        const unsigned realIdxKF = KV->index[ik];
+        if (!kf_valid[realIdxKF]) continue;
+        const uint8_t* dKF = kf_desc + 32 * (size_t)realIdxKF;
+        int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+        for (int jf = FV->offset[b]; jf < FV->offset[b + 1]; ++jf) {   /* :357 */
+          const unsigned realIdxF = FV->index[jf];
+          if (assigned[realIdxF] >= 0) continue;                       /* vpMapPointMatches[realIdxF] */
+          const int dist = oracle_descriptor_distance(dKF, f_desc + 32 * (size_t)realIdxF);
+          if (dist < bestDist1) {
+            bestDist2 = bestDist1;
+            bestDist1 = dist;
+            bestIdxF = (int)realIdxF;
+          } else if (dist < bestDist2) {
+            bestDist2 = dist;
+          }
+        }
+        if (bestDist1 <= TH_LOW) {                                     /* :407 */
+          if ((float)bestDist1 < nn_ratio * (float)bestDist2) {
+            assigned[bestIdxF] = (int32_t)realIdxKF;
+            if (check_orientation) {
+              float rot = kf_angle[realIdxKF] - f_angle[bestIdxF];
+              if (rot < 0.0) rot += 360.0f;
+              int bin = (int)roundf(rot * factor);
+              if (bin == 12) bin = 0;
+              hist_items[nhist] = bestIdxF;
+              hist_bin[nhist++] = bin;
+            }
+            nmatches++;
+          }
+        }
+      }
+      a++;
+      b++;
+    } else if (KV->node_id[a] < FV->node_id[b]) {
+      while (a < KV->nnodes && KV->node_id[a] < FV->node_id[b]) a++;   /* lower_bound */
+    } else {
+      while (b < FV->nnodes && FV->node_id[b] < KV->node_id[a]) b++;
+    }
+  }
+  if (check_orientation) {                                              /* :491-507 */
+    int count[12] = {0};
+    for (int k = 0; k < nhist; ++k) count[hist_bin[k]]++;
+    int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+    for (int c = 0; c < 12; ++c) {
+      const int s = count[c];
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = c; }
+      else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = c; }
+      else if (s > max3) { max3 = s; ind3 = c; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+    for (int k = 0; k < nhist; ++k)
+      if (hist_bin[k] != ind1 && hist_bin[k] != ind2 && hist_bin[k] != ind3) {
+        assigned[hist_items[k]] = -1;
+        nmatches--;
+      }
+  }
+  free(hist_items);
+  free(hist_bin);
   return nmatches;
 }

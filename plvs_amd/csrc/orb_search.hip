@@ -17,6 +17,7 @@ namespace {
 constexpr int kGridCols = 64;   // FRAME_GRID_COLS, include/Frame.h:68
 constexpr int kGridRows = 48;   // FRAME_GRID_ROWS, include/Frame.h:67
 constexpr int kThHigh = 100;    // ORBmatcher::TH_HIGH, src/ORBmatcher.cc:57
+constexpr int kThLow = 50;      // ORBmatcher::TH_LOW, :58
 constexpr int kHistoLength = 12; // ORBmatcher::HISTO_LENGTH, :61
 
 // dist[p] = ORBmatcher::DescriptorDistance(query[pair_q[p]], train[pair_t[p]]) (src/ORBmatcher.cc:2198)
@@ -281,6 +282,108 @@ int plvs_hip_orb_search_by_projection_ff(const plvs_frame_view* F, const float* 
   if (check_orientation) {
     int count[kHistoLength] = {0};
     for (int b : hist_bin) ++count[b];
+    int ind1, ind2, ind3;
+    three_maxima(count, kHistoLength, ind1, ind2, ind3);
+    for (size_t k = 0; k < hist_bin.size(); ++k)
+      if (hist_bin[k] != ind1 && hist_bin[k] != ind2 && hist_bin[k] != ind3) {
+        assigned[hist_item[k]] = -1;
+        --n;
+      }
+  }
+  *nmatches = n;
+  return PLVS_OK;
+}
+
+int plvs_hip_orb_search_by_bow(const plvs_featvec_view* KV, const uint8_t* kf_desc, int kf_n,
+                               const uint8_t* kf_valid, const float* kf_angle, const plvs_featvec_view* FV,
+                               const uint8_t* f_desc, int f_n, const float* f_angle, float nn_ratio,
+                               int check_orientation, int32_t* assigned, int* nmatches) {
+  PLVS_REQUIRE(KV && FV && nmatches, "null argument");
+  PLVS_REQUIRE(kf_n >= 0 && f_n >= 0 && KV->nnodes >= 0 && FV->nnodes >= 0, "negative size");
+  PLVS_REQUIRE(f_n == 0 || assigned, "assigned is null");
+  *nmatches = 0;
+  for (int i = 0; i < f_n; ++i) assigned[i] = -1;
+  if (kf_n == 0 || f_n == 0 || KV->nnodes == 0 || FV->nnodes == 0) return PLVS_OK;
+  PLVS_REQUIRE(KV->node_id && KV->offset && KV->index && FV->node_id && FV->offset && FV->index,
+               "null feature-vector array");
+  PLVS_REQUIRE(kf_desc && kf_valid && f_desc, "null descriptor / validity array");
+  PLVS_REQUIRE(!check_orientation || (kf_angle && f_angle), "angles needed for the orientation check");
+  for (int a = 0; a < KV->nnodes; ++a) {
+    PLVS_REQUIRE(KV->offset[a] <= KV->offset[a + 1], "key-frame offsets not monotone");
+    PLVS_REQUIRE(a == 0 || KV->node_id[a - 1] < KV->node_id[a], "key-frame node ids must ascend (std::map order)");
+  }
+  for (int b = 0; b < FV->nnodes; ++b) {
+    PLVS_REQUIRE(FV->offset[b] <= FV->offset[b + 1], "frame offsets not monotone");
+    PLVS_REQUIRE(b == 0 || FV->node_id[b - 1] < FV->node_id[b], "frame node ids must ascend (std::map order)");
+  }
+  for (int k = KV->offset[0]; k < KV->offset[KV->nnodes]; ++k)
+    PLVS_REQUIRE(KV->index[k] < (uint32_t)kf_n, "key-frame feature index out of range");
+  for (int k = FV->offset[0]; k < FV->offset[FV->nnodes]; ++k)
+    PLVS_REQUIRE(FV->index[k] < (uint32_t)f_n, "frame feature index out of range");
+
+  // Every (key-frame feature, frame feature) pair of every common vocabulary node, in the
+  // reference's visiting order; one launch for all distances, then the greedy pass on the host.
+  struct Query { int kf; int first, count; };
+  std::vector<Query> queries;
+  std::vector<int32_t> pair_q, pair_t;
+  int a = 0, b = 0;
+  while (a < KV->nnodes && b < FV->nnodes) {   // the lower_bound walk of :327-489
+    if (KV->node_id[a] == FV->node_id[b]) {
+      for (int ik = KV->offset[a]; ik < KV->offset[a + 1]; ++ik) {
+        const int real_kf = (int)KV->index[ik];
+        if (!kf_valid[real_kf]) continue;   // !pMP || pMP->isBad()
+        Query q{real_kf, (int)pair_q.size(), FV->offset[b + 1] - FV->offset[b]};
+        for (int jf = FV->offset[b]; jf < FV->offset[b + 1]; ++jf) {
+          pair_q.push_back(real_kf);
+          pair_t.push_back((int32_t)FV->index[jf]);
+        }
+        if (q.count) queries.push_back(q);
+      }
+      ++a;
+      ++b;
+    } else if (KV->node_id[a] < FV->node_id[b]) {
+      ++a;
+    } else {
+      ++b;
+    }
+  }
+  std::vector<int32_t> dist(pair_q.size());
+  int rc = plvs_hip_hamming_pairs(kf_desc, kf_n, f_desc, f_n, pair_q.data(), pair_t.data(), (int)pair_q.size(),
+                                  dist.data());
+  if (rc != PLVS_OK) return rc;
+  std::vector<int> hist_item, hist_bin;
+  const float factor = kHistoLength / 360.0f;   // USE_NEW_HISTOGRAM_FACTOR, :52, :313
+  int n = 0;
+  for (const Query& q : queries) {
+    int best1 = 256, best_idx = -1, best2 = 256;
+    for (int p = q.first; p < q.first + q.count; ++p) {
+      const int i_f = pair_t[p];
+      if (assigned[i_f] >= 0) continue;   // vpMapPointMatches[realIdxF]
+      const int d = dist[p];
+      if (d < best1) {
+        best2 = best1;
+        best1 = d;
+        best_idx = i_f;
+      } else if (d < best2) {
+        best2 = d;
+      }
+    }
+    if (best1 <= kThLow && (float)best1 < nn_ratio * (float)best2) {
+      assigned[best_idx] = q.kf;
+      ++n;
+      if (check_orientation) {
+        float rot = kf_angle[q.kf] - f_angle[best_idx];
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)std::round(rot * factor);
+        if (bin == kHistoLength) bin = 0;
+        hist_item.push_back(best_idx);
+        hist_bin.push_back(bin);
+      }
+    }
+  }
+  if (check_orientation) {
+    int count[kHistoLength] = {0};
+    for (int bn : hist_bin) ++count[bn];
     int ind1, ind2, ind3;
     three_maxima(count, kHistoLength, ind1, ind2, ind3);
     for (size_t k = 0; k < hist_bin.size(); ++k)

@@ -145,3 +145,45 @@ def _search_ff(self, CurrentFrame, cur_angle, max_x, max_y, mbf, LastFrame, th, 
 
 
 ORBmatcher.SearchByProjectionLastFrame = _search_ff
+
+
+class _FeatVecC(ctypes.Structure):
+    _fields_ = [("nnodes", ctypes.c_int32), ("node_id", _vp), ("offset", _vp), ("index", _vp)]
+
+
+class FeatureVector:
+    """DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned int>>) from a {node id: [feature
+    indices]} mapping; traversed in ascending node id like the std::map."""
+
+    def __init__(self, nodes):
+        ids = sorted(nodes)
+        self.node_id = np.array(ids, np.uint32)
+        lens = [len(nodes[k]) for k in ids]
+        self.offset = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        self.index = (np.concatenate([np.asarray(nodes[k], np.uint32) for k in ids]) if ids
+                      else np.zeros(0, np.uint32)).astype(np.uint32)
+
+    def as_c(self):
+        return _FeatVecC(len(self.node_id), _lib.np_ptr(self.node_id), _lib.np_ptr(self.offset), _lib.np_ptr(self.index))
+
+
+def _search_bow(self, kf_featvec, kf_desc, kf_valid, kf_angle, f_featvec, f_desc, f_angle):
+    """ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) (src/ORBmatcher.cc:300).  kf_valid[i]: the key frame's
+    keypoint i holds a good map point.  -> (nmatches, assigned [F.N]: key-frame keypoint index or -1)."""
+    kd = np.ascontiguousarray(kf_desc, np.uint8).reshape(-1, 32)
+    fd = np.ascontiguousarray(f_desc, np.uint8).reshape(-1, 32)
+    kv = np.ascontiguousarray(kf_valid, np.uint8)
+    ka = np.ascontiguousarray(kf_angle, np.float32)
+    fa = np.ascontiguousarray(f_angle, np.float32)
+    assigned = np.full(fd.shape[0], -7, np.int32)
+    kc, fc = kf_featvec.as_c(), f_featvec.as_c()
+    n = _i()
+    f = _lib.lib.plvs_hip_orb_search_by_bow
+    f.argtypes = [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _vp, _vp]
+    _lib.check(f(ctypes.byref(kc), _lib.np_ptr(kd), kd.shape[0], _lib.np_ptr(kv), _lib.np_ptr(ka), ctypes.byref(fc),
+                 _lib.np_ptr(fd), fd.shape[0], _lib.np_ptr(fa), self.mfNNratio, int(self.mbCheckOrientation),
+                 _lib.np_ptr(assigned), ctypes.byref(n)))
+    return n.value, assigned
+
+
+ORBmatcher.SearchByBoW = _search_bow

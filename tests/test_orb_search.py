@@ -197,3 +197,93 @@ def test_hip_search_last_frame_matches_oracle(oracle, seed, th, fwd, bwd, check)
                                                                          bool(bwd), occupied=occ)
     assert got_n == want_n > 30
     assert np.array_equal(got, want)
+
+
+# ----------------------------------------------------------------- SearchByBoW (M4)
+def make_bow_case(seed, nk=1800, nf=2000, nodes=90):
+    """A key frame and a frame re-observing it: descriptors a few bits apart, the vocabulary node a
+    function of the clean descriptor so that most true pairs share a node; some land elsewhere."""
+    from plvs_amd.orbmatcher import FeatureVector
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, (nk, 32), dtype=np.uint8)
+    node_of = (base[:, 0].astype(np.int64) * 7 + base[:, 1]) % nodes * 3 + 10      # sparse, unordered ids
+    kf_desc = base.copy()
+    src = rng.integers(0, nk, nf)
+    f_desc = base[src].copy()
+    flips = rng.integers(0, 256, (nf, 32), dtype=np.uint8) & rng.integers(0, 256, (nf, 32), dtype=np.uint8) \
+        & rng.integers(0, 256, (nf, 32), dtype=np.uint8)
+    f_desc ^= flips                                                               # ~32 bits: around TH_LOW
+    exact = rng.random(nf) < 0.3
+    f_desc[exact] = base[src[exact]]                                              # exact copies -> ties at 0
+    f_node = node_of[src].copy()
+    stray = rng.random(nf) < 0.1
+    f_node[stray] = rng.integers(0, nodes, int(stray.sum())) * 3 + 10 + rng.integers(0, 2, int(stray.sum()))
+    kf_nodes, f_nodes = {}, {}
+    for i in rng.permutation(nk):
+        kf_nodes.setdefault(int(node_of[i]), []).append(int(i))
+    for i in rng.permutation(nf):
+        f_nodes.setdefault(int(f_node[i]), []).append(int(i))
+    kf_valid = (rng.random(nk) < 0.8).astype(np.uint8)
+    kf_angle = rng.uniform(0, 360, nk).astype(np.float32)
+    f_angle = (kf_angle[src] + np.where(rng.random(nf) < 0.8, 25.0, rng.uniform(0, 360, nf))
+               + rng.normal(0, 4.0, nf)).astype(np.float32) % np.float32(360.0)
+    return FeatureVector(kf_nodes), kf_desc, kf_valid, kf_angle, FeatureVector(f_nodes), f_desc, f_angle
+
+
+def oracle_search_bow(lib, KV, kd, kv, ka, FV, fd, fa, ratio, check):
+    assigned = np.full(fd.shape[0], -7, np.int32)
+    f = lib.oracle_orb_search_by_bow
+    f.restype = ctypes.c_int
+    vp = ctypes.c_void_p
+    f.argtypes = [vp, vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp, ctypes.c_float, ctypes.c_int, vp]
+    kc, fc = KV.as_c(), FV.as_c()
+    p = lambda a: a.ctypes.data_as(vp)
+    n = f(ctypes.byref(kc), p(kd), kd.shape[0], p(kv), p(ka), ctypes.byref(fc), p(fd), fd.shape[0], p(fa), ratio,
+          check, p(assigned))
+    return n, assigned
+
+
+def test_oracle_search_by_bow_properties(oracle):
+    KV, kd, kv, ka, FV, fd, fa = make_bow_case(1)
+    n0, a0 = oracle_search_bow(oracle.lib, KV, kd, kv, ka, FV, fd, fa, 0.7, 0)
+    got = np.nonzero(a0 >= 0)[0]
+    assert n0 == len(got) > 300
+    node_kf = {int(i): int(KV.node_id[a]) for a in range(len(KV.node_id))
+               for i in KV.index[KV.offset[a]:KV.offset[a + 1]]}
+    node_f = {int(i): int(FV.node_id[a]) for a in range(len(FV.node_id))
+              for i in FV.index[FV.offset[a]:FV.offset[a + 1]]}
+    assert len(set(a0[got])) == len(got)                       # a key-frame keypoint is visited once
+    for i_f in got:
+        k = int(a0[i_f])
+        assert kv[k] and node_kf[k] == node_f[int(i_f)]
+        assert oracle.descriptor_distance(kd[k], fd[i_f]) <= 50
+    # a stricter ratio or the rotation check only removes matches
+    n1, a1 = oracle_search_bow(oracle.lib, KV, kd, kv, ka, FV, fd, fa, 0.5, 0)
+    assert n1 < n0
+    n2, a2 = oracle_search_bow(oracle.lib, KV, kd, kv, ka, FV, fd, fa, 0.7, 1)
+    assert 0 < n2 < n0 and set(np.nonzero(a2 >= 0)[0]) <= set(got)
+    # no common node -> nothing
+    from plvs_amd.orbmatcher import FeatureVector
+    n3, a3 = oracle_search_bow(oracle.lib, FeatureVector({1: [0, 1]}), kd, kv, ka, FeatureVector({2: [0, 1]}), fd, fa,
+                               0.7, 1)
+    assert n3 == 0 and (a3 == -1).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,ratio,check", [(1, 0.7, 1), (2, 0.7, 0), (3, 0.9, 1), (4, 0.5, 1)])
+def test_hip_search_by_bow_matches_oracle(oracle, seed, ratio, check):
+    from plvs_amd import _lib
+    from plvs_amd.orbmatcher import FeatureVector, ORBmatcher
+    KV, kd, kv, ka, FV, fd, fa = make_bow_case(seed)
+    want_n, want = oracle_search_bow(oracle.lib, KV, kd, kv, ka, FV, fd, fa, ratio, check)
+    got_n, got = ORBmatcher(ratio, bool(check)).SearchByBoW(KV, kd, kv, ka, FV, fd, fa)
+    assert got_n == want_n > 100
+    assert np.array_equal(got, want)
+    # empty sides, disjoint vocabularies, malformed vectors
+    m = ORBmatcher(ratio, bool(check))
+    n, a = m.SearchByBoW(KV, kd, kv, ka, FeatureVector({}), fd, fa)
+    assert n == 0 and (a == -1).all()
+    n, a = m.SearchByBoW(FeatureVector({5: [0]}), kd, kv, ka, FeatureVector({6: [0]}), fd, fa)
+    assert n == 0 and (a == -1).all()
+    with pytest.raises(_lib.PlvsHipError):
+        m.SearchByBoW(FeatureVector({5: [kd.shape[0]]}), kd, kv, ka, FV, fd, fa)      # index out of range
