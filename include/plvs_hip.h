@@ -276,6 +276,15 @@ int plvs_hip_lines_extract(plvs_lines* h, const uint8_t* image, int w, int hh, i
                            plvs_keyline* keylines, uint8_t* desc, int cap, int* n);
 int plvs_hip_lines_extract_dev(plvs_lines* h, const uint8_t* d_image, int w, int hh, int stride,
                                plvs_keyline* keylines, uint8_t* desc, int cap, int* n);
+/* LineExtractor::SetGaussianPyramid (include/LineExtractor.h:83, src/LineExtractor.cc:170) as used by
+ * Frame::PrecomputeGaussianPyramid (src/Frame.cc:841-865) when Line.pyramidPrecomputation is on
+ * (USE_UNFILTERED_PYRAMID_FOR_LINES 1): octave i of the line detector is level i of `orb`'s
+ * unblurred pyramid — read in place on the device — instead of the detector's own blur -> resize
+ * chain; the number of octaves becomes min(own, orb levels) and the scale factor the extractor's
+ * (BinaryDescriptor::setGaussianPyramid, binary_descriptor_custom.cpp:1491-1533, border 0).
+ * `orb` must have processed the same image before plvs_hip_lines_extract[_dev] is called
+ * (plvs_hip_frame_extract_dev orders the two itself).  orb = NULL restores the own pyramid. */
+int plvs_hip_lines_set_gaussian_pyramid(plvs_lines* h, plvs_orb* orb);
 /* ms of the last call: [0] device maps + D2H, [1] host linking/fitting/grouping, [2] LBD;
  * split of [1]: [3] EdgeDrawing of octave 0, [4] tail of the (overlapped) line fitting,
  * [5] grouping + selection. */

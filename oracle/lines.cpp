@@ -543,6 +543,8 @@ struct LineExtractorOracle {
   std::vector<std::pair<int, int>> images_sizes; /* (width, height) per octave */
   std::vector<double> gaussCoefL_, gaussCoefG_;
   std::vector<Image> octaveBlur;                 /* kept for stage-by-stage tests */
+  std::vector<Image> octaveImages;               /* setGaussianPyramid, :1491-1533 (border 0) */
+  bool bSetGaussianPyramid = false;
 
   LineExtractorOracle(int nf, int nlevels, float scale, double minlen, double fitErr)
       : nfeatures(nf), numOfOctave_(nlevels), scaleFactor_(scale), min_length(minlen) {
@@ -580,11 +582,12 @@ struct LineExtractorOracle {
     for (int octaveCount = 0; octaveCount < numOfOctave_; octaveCount++) {
       Image blur;
       const float increaseSigma = std::sqrt(curSigma2 - preSigma2);
+      if (bSetGaussianPyramid) image = octaveImages[octaveCount];             /* :805-808 */
       gaussian_blur_u8(image, blur, ksize_, increaseSigma);
       images_sizes[octaveCount] = std::make_pair(blur.w, blur.h);
       octaveBlur.push_back(blur);
       if (edLineVec_[octaveCount].EDline(blur) == 1) numOfFinalLine += edLineVec_[octaveCount].lines_.numOfLines;
-      resize_linear_u8_factor(blur, image, (1.f / factor), (1.f / factor));
+      if (!bSetGaussianPyramid) resize_linear_u8_factor(blur, image, (1.f / factor), (1.f / factor));   /* :836 */
       preSigma2 = curSigma2;
       curSigma2 = (float)(curSigma2 * factor2);
     }
@@ -912,6 +915,25 @@ void* oracle_lines_create(int nfeatures, int nlevels, float scale, double min_le
   return new LineExtractorOracle(nfeatures, nlevels, scale, min_length, fit_err);
 }
 void oracle_lines_destroy(void* h) { delete (LineExtractorOracle*)h; }
+
+/* LineExtractor::SetGaussianPyramid -> BinaryDescriptor::setGaussianPyramid (:1491-1533) with border
+ * 0, as Frame::PrecomputeGaussianPyramid calls it (src/Frame.cc:848): levels = ORBextractor::
+ * mvImagePyramid (tightly packed here), num_octaves = LineExtractor::GetLevels(), scale =
+ * ORBextractor::GetScaleFactor().  npyr = 0 clears it. */
+void oracle_lines_set_pyramid(void* h, const uint8_t* const* levels, const int* w, const int* hh, int npyr,
+                              int num_octaves, float scale) {
+  LineExtractorOracle* e = (LineExtractorOracle*)h;
+  e->octaveImages.clear();
+  e->bSetGaussianPyramid = npyr > 0;
+  if (npyr <= 0) return;
+  e->numOfOctave_ = std::min(num_octaves, std::min(e->numOfOctave_, npyr));
+  e->scaleFactor_ = scale;
+  for (int i = 0; i < npyr; i++) {
+    Image im(w[i], hh[i]);
+    for (int y = 0; y < hh[i]; y++) memcpy(im.row(y), levels[i] + (size_t)y * w[i], w[i]);
+    e->octaveImages.push_back(im);
+  }
+}
 
 /* keylines: cap entries of 68 bytes (the KeyLine layout); desc: cap x 32.  Returns the line count. */
 int oracle_lines_extract(void* h, const uint8_t* img, int w, int hh, int stride, void* keylines,

@@ -1,10 +1,13 @@
 // Frame-level extraction: the ORB extractor and the line extractor of one image run on
 // two host threads, each driving its own stream — what Frame::Frame does with
 // threadLeft / threadLines (reference src/Frame.cc:503-508 mono, :290-330 stereo).
+#include <atomic>
 #include <cstdio>
+#include <future>
 #include <thread>
 
 #include "common.hpp"
+#include "orb_internal.hpp"
 
 extern "C" int plvs_hip_frame_extract_dev(plvs_orb* orb, plvs_lines* lines, const uint8_t* d_image, int w,
                                           int h, int stride, int lap0, int lap1, plvs_keypoint* kps,
@@ -14,12 +17,29 @@ extern "C" int plvs_hip_frame_extract_dev(plvs_orb* orb, plvs_lines* lines, cons
   PLVS_REQUIRE(orb && lines && n_kp && mono_index && n_lines, "null argument");
   int rc_lines = PLVS_OK;
   char lines_error[512] = "";
+  // Line.pyramidPrecomputation (Frame::PrecomputeGaussianPyramid, src/Frame.cc:841-865): the line
+  // extractor reads the ORB pyramid.  The reference builds it before starting the two threads;
+  // here the line thread starts as soon as the ORB thread has enqueued the pyramid kernels and
+  // orders its device work after them through the extractor's event.
+  const bool shared = plvs::lines_shared_orb(lines) == orb;
+  std::promise<void> pyramid_enqueued;
+  std::future<void> pyramid_ready = pyramid_enqueued.get_future();
+  std::atomic<bool> fired{false};
+  auto fire = [&]() {
+    if (!fired.exchange(true)) pyramid_enqueued.set_value();
+  };
+  if (shared) plvs::orb_set_pyramid_hook(orb, fire);
   std::thread tl([&]() {
+    if (shared) pyramid_ready.wait();
     rc_lines = plvs_hip_lines_extract_dev(lines, d_image, w, h, stride, keylines, line_desc, line_cap, n_lines);
     if (rc_lines != PLVS_OK) snprintf(lines_error, sizeof lines_error, "%s", plvs_hip_last_error());   // thread-local
   });
   const int rc_orb = plvs_hip_orb_extract_dev(orb, d_image, w, h, stride, lap0, lap1, kps, desc, kp_cap, n_kp,
                                               mono_index);
+  if (shared) {
+    plvs::orb_set_pyramid_hook(orb, nullptr);
+    fire();   // the extractor returned before reaching its pyramid (error paths)
+  }
   tl.join();
   if (rc_orb != PLVS_OK) return rc_orb;
   if (rc_lines != PLVS_OK) plvs::set_error("%s", lines_error);

@@ -16,6 +16,7 @@
 //                              selection — order dependent, one thread per octave
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <thread>
@@ -23,6 +24,7 @@
 
 #include "common.hpp"
 #include "lines_host.hpp"
+#include "orb_internal.hpp"
 
 using namespace plvs;
 using namespace plvs::lines;
@@ -304,6 +306,10 @@ double now_ms() {
 struct plvs_lines {
   int nfeatures, nlevels;
   float scale;
+  int nlevels_cfg = 0;            // the constructor's values; nlevels / scale follow the shared
+  float scale_cfg = 0.f;          // pyramid while one is set (BinaryDescriptor::setGaussianPyramid)
+  plvs_orb* shared = nullptr;     // ORB extractor whose device pyramid feeds the octaves, or null
+  bool geometry_shared = false;   // what the current geometry was built for
   double min_length;
   EdParams ed;
   float gaussG[kRows], gaussL[3 * kBandWidth];
@@ -356,8 +362,19 @@ void lines_free_geometry(plvs_lines* o) {
   o->img_w = o->img_h = 0;
 }
 
-int lines_build_geometry(plvs_lines* o, int w, int h) {
+// `view` non-null: octave i is level i of a shared ORB pyramid (OctaveKeyLines :805-808, no
+// resize between octaves, :836); otherwise the extractor's own blur -> resize chain.
+int lines_build_geometry(plvs_lines* o, int w, int h, const plvs::OrbPyramidView* view = nullptr) {
   lines_free_geometry(o);
+  if (view != nullptr) {
+    // BinaryDescriptor::setGaussianPyramid :1497-1498
+    o->nlevels = std::min(o->nlevels_cfg, view->nlevels);
+    o->scale = view->scale[1 < view->nlevels ? 1 : 0];   // ORBextractor::GetScaleFactor(): mvScaleFactor[1]
+  } else {
+    o->nlevels = o->nlevels_cfg;
+    o->scale = o->scale_cfg;
+  }
+  o->geometry_shared = view != nullptr;
   const int n = o->nlevels;
   o->sizes.assign(n, {0, 0});
   o->kernels.resize(n);
@@ -373,6 +390,10 @@ int lines_build_geometry(plvs_lines* o, int w, int h) {
   const double inv = (1.f / factor);
   int cw = w, ch = h;
   for (int i = 0; i < n; ++i) {
+    if (view != nullptr) {
+      cw = view->w[i];
+      ch = view->h[i];
+    }
     if (cw < 8 || ch < 8) {
       plvs::set_error("lines: octave %d of a %dx%d image is too small", i, w, h);
       return PLVS_ERR_INVALID_ARG;
@@ -393,7 +414,7 @@ int lines_build_geometry(plvs_lines* o, int w, int h) {
     PLVS_HIP_TRY(hipMalloc((void**)&o->d_anchor[i], na));
     PLVS_HIP_TRY(hipHostMalloc((void**)&o->h_anchor[i], na));
     const int nw = cvr(cw * inv), nh = cvr(ch * inv);   // dsize = saturate_cast<int>(ssize * f)
-    if (i + 1 < n) {
+    if (i + 1 < n && view == nullptr) {
       std::vector<int> xo, yo;
       std::vector<short> al, be;
       resize_taps_factor(cw, nw, inv, xo, al, true);
@@ -437,7 +458,7 @@ int lines_extract_body(plvs_lines* o, plvs_keyline* keylines, uint8_t* desc, int
     PLVS_HIP_TRY(hipMemcpyAsync(o->h_gd[i], o->d_gd[i], px * 2, hipMemcpyDeviceToHost, s));
     PLVS_HIP_TRY(hipMemcpyAsync(o->h_dx[i], o->d_dx[i], px * 2, hipMemcpyDeviceToHost, s));
     PLVS_HIP_TRY(hipMemcpyAsync(o->h_dy[i], o->d_dy[i], px * 2, hipMemcpyDeviceToHost, s));
-    if (i + 1 < n) {
+    if (i + 1 < n && !o->geometry_shared) {
       const int nw = o->sizes[i + 1].first, nh = o->sizes[i + 1].second;
       hipLaunchKernelGGL(lines_resize, dim3((nw + 63) / 64, (nh + 3) / 4), block, 0, s, o->d_blur[i], w,
                          o->d_img[i + 1], nw, nh, o->d_xofs[i], o->d_alpha[i], o->d_yofs[i], o->d_beta[i]);
@@ -567,6 +588,35 @@ int lines_extract_body(plvs_lines* o, plvs_keyline* keylines, uint8_t* desc, int
 
 }  // namespace
 
+namespace {
+
+// Octave inputs from the shared ORB pyramid (Frame::PrecomputeGaussianPyramid, src/Frame.cc:841-865,
+// USE_UNFILTERED_PYRAMID_FOR_LINES: the unblurred levels).  The copies are ordered after the
+// extractor's pyramid kernels through its event; nothing leaves the device.
+int lines_load_shared(plvs_lines* o, int w, int h) {
+  plvs::OrbPyramidView v;
+  if (!plvs::orb_pyramid_view(o->shared, &v)) {
+    plvs::set_error("lines: the shared ORB extractor holds no pyramid yet");
+    return PLVS_ERR_INVALID_ARG;
+  }
+  PLVS_REQUIRE(v.w[0] == w && v.h[0] == h, "image size differs from the shared pyramid's level 0");
+  bool rebuild = !o->geometry_shared || w != o->img_w || h != o->img_h ||
+                 o->nlevels != std::min(o->nlevels_cfg, v.nlevels);
+  for (int i = 0; !rebuild && i < o->nlevels; ++i)
+    rebuild = o->sizes[i].first != v.w[i] || o->sizes[i].second != v.h[i];
+  if (rebuild) {
+    const int rc = lines_build_geometry(o, w, h, &v);
+    if (rc != PLVS_OK) return rc;
+  }
+  PLVS_HIP_TRY(hipStreamWaitEvent(o->stream, plvs::orb_pyramid_event(o->shared), 0));
+  for (int i = 0; i < o->nlevels; ++i)
+    PLVS_HIP_TRY(hipMemcpy2DAsync(o->d_img[i], v.w[i], v.level[i], v.pitch[i], v.w[i], v.h[i],
+                                  hipMemcpyDeviceToDevice, o->stream));
+  return PLVS_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int plvs_hip_lines_create(int nfeatures, int nlevels, float scale_factor, double min_line_length,
@@ -576,8 +626,8 @@ int plvs_hip_lines_create(int nfeatures, int nlevels, float scale_factor, double
                "bad line extractor parameters");
   plvs_lines* o = new plvs_lines();
   o->nfeatures = nfeatures;
-  o->nlevels = nlevels;
-  o->scale = scale_factor;
+  o->nlevels = o->nlevels_cfg = nlevels;
+  o->scale = o->scale_cfg = scale_factor;
   o->min_length = min_line_length;
   o->ed.fit_err_threshold = line_fit_err_threshold;
   // BinaryDescriptor ctor :248-274 (note the integer divisions)
@@ -633,7 +683,11 @@ int plvs_hip_lines_extract(plvs_lines* o, const uint8_t* image, int w, int h, in
   }
   PLVS_REQUIRE(stride >= w, "stride smaller than width");
   PLVS_REQUIRE(w < 32768 && h < 32768, "image too large");
-  if (w != o->img_w || h != o->img_h) {
+  if (o->shared != nullptr) {
+    const int rc = lines_load_shared(o, w, h);
+    return rc != PLVS_OK ? rc : lines_extract_body(o, keylines, desc, cap, n);
+  }
+  if (w != o->img_w || h != o->img_h || o->geometry_shared) {
     int rc = lines_build_geometry(o, w, h);
     if (rc != PLVS_OK) return rc;
   }
@@ -652,12 +706,22 @@ int plvs_hip_lines_extract_dev(plvs_lines* o, const uint8_t* d_image, int w, int
   }
   PLVS_REQUIRE(stride >= w, "stride smaller than width");
   PLVS_REQUIRE(w < 32768 && h < 32768, "image too large");
-  if (w != o->img_w || h != o->img_h) {
+  if (o->shared != nullptr) {
+    const int rc = lines_load_shared(o, w, h);
+    return rc != PLVS_OK ? rc : lines_extract_body(o, keylines, desc, cap, n);
+  }
+  if (w != o->img_w || h != o->img_h || o->geometry_shared) {
     int rc = lines_build_geometry(o, w, h);
     if (rc != PLVS_OK) return rc;
   }
   PLVS_HIP_TRY(hipMemcpy2DAsync(o->d_img[0], w, d_image, stride, w, h, hipMemcpyDeviceToDevice, o->stream));
   return lines_extract_body(o, keylines, desc, cap, n);
+}
+
+int plvs_hip_lines_set_gaussian_pyramid(plvs_lines* o, plvs_orb* orb) {
+  PLVS_REQUIRE(o, "null handle");
+  o->shared = orb;
+  return PLVS_OK;
 }
 
 int plvs_hip_lines_last_stage_ms(plvs_lines* o, double* ms, int cap) {
@@ -689,3 +753,7 @@ int plvs_hip_lines_num_in_octave(plvs_lines* o, int octave) {
 }
 
 }  // extern "C"
+
+namespace plvs {
+plvs_orb* lines_shared_orb(const plvs_lines* o) { return o ? o->shared : nullptr; }
+}  // namespace plvs

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -457,6 +458,7 @@ struct plvs_orb {
   uint8_t* h_desc = nullptr;
   hipStream_t stream = nullptr, stream2 = nullptr;
   hipEvent_t ev_pyr = nullptr;
+  std::function<void()> pyramid_hook;   // see orb_internal.hpp
   // stage timing of the last call (ms): gpu segments by events, host by clock
   double last_ms[8] = {};
 };
@@ -739,6 +741,11 @@ static int orb_extract_body(plvs_orb* o, int lap0, int lap1, plvs_keypoint* kps,
                        o->d_xofs[l], o->d_alpha[l], o->d_yofs[l], o->d_beta[l]);
   }
   PLVS_HIP_TRY(hipEventRecord(o->ev_pyr, s));
+  if (o->pyramid_hook) {
+    std::function<void()> hook = std::move(o->pyramid_hook);
+    o->pyramid_hook = nullptr;
+    hook();
+  }
   hipLaunchKernelGGL(fast_score_map, dim3(o->total_tiles), dim3(256), 0, s, o->d_levels, nl, o->d_pyr,
                      o->d_score, o->min_th);
   uint32_t total = 0;
@@ -955,6 +962,11 @@ int plvs_hip_orb_last_candidates(plvs_orb* o, int level, float* xyr, int cap, in
 }  // extern "C"
 
 namespace plvs {
+
+hipEvent_t orb_pyramid_event(const plvs_orb* o) { return o ? o->ev_pyr : nullptr; }
+void orb_set_pyramid_hook(plvs_orb* o, std::function<void()> hook) {
+  if (o) o->pyramid_hook = std::move(hook);
+}
 
 bool orb_pyramid_view(const plvs_orb* o, OrbPyramidView* v) {
   if (o == nullptr || v == nullptr || o->img_w <= 0 || o->d_pyr == nullptr) return false;

@@ -86,6 +86,13 @@ class LineExtractor:
             print("LineExtractor::detectLineFeatures() - no lines! **********")
         return self._kl[:n.value].copy(), self._desc[:n.value].copy()
 
+    def SetGaussianPyramid(self, orb_extractor):
+        """LineExtractor::SetGaussianPyramid as Frame::PrecomputeGaussianPyramid uses it (src/Frame.cc:848):
+        the octaves become the levels of `orb_extractor`'s device pyramid; None restores the own chain."""
+        self._shared = orb_extractor                       # keep the handle alive
+        L.plvs_hip_lines_set_gaussian_pyramid.argtypes = [_vp, _vp]
+        _lib.check(L.plvs_hip_lines_set_gaussian_pyramid(self._h, orb_extractor._h if orb_extractor else None))
+
     def stage_ms(self):
         ms = (ctypes.c_double * 6)()
         _lib.check(L.plvs_hip_lines_last_stage_ms(self._h, ms, 6))

@@ -258,6 +258,24 @@ class OracleLines:
         assert n <= self.cap
         return kl[:n].copy(), desc[:n].copy()
 
+    def set_pyramid(self, levels, num_octaves, scale):
+        """LineExtractor::SetGaussianPyramid(pyramid, numOctaves, scale) with border 0; levels = list of
+        level images (ORBextractor::mvImagePyramid); [] clears it."""
+        lv = [np.ascontiguousarray(a, dtype=np.uint8) for a in levels]
+        n = len(lv)
+        ptrs = (ctypes.c_void_p * max(n, 1))(*[a.ctypes.data for a in lv])
+        w = np.array([a.shape[1] for a in lv] or [0], np.int32)
+        h = np.array([a.shape[0] for a in lv] or [0], np.int32)
+        f = self.lib.oracle_lines_set_pyramid
+        f.restype = None
+        f.argtypes = [_vp, _vp, _vp, _vp, _i, _i, _f]
+        f(self.h, ptrs, _ptr(w), _ptr(h), n, num_octaves, scale)
+
+    def octave_size(self, octave):
+        w, h = ctypes.c_int(), ctypes.c_int()
+        self.lib.oracle_lines_octave_size(self.h, octave, ctypes.byref(w), ctypes.byref(h))
+        return w.value, h.value
+
     def octave_map(self, octave, which):
         """which: 'blur' (u8), 'dx', 'dy', 'g' (s16), 'dir' (u8)"""
         w, h = ctypes.c_int(), ctypes.c_int()

@@ -158,3 +158,71 @@ def test_hip_frame_extract_points_and_lines_together(oracle):
             assert kl.tobytes() == okl.tobytes() and np.array_equal(ldesc, oldesc)
     orb.close()
     lines.close()
+
+
+# ------------------------------------------------------------------ shared ORB pyramid (O9)
+def _oracle_shared(oracle, img, nfeatures=1000):
+    oorb = oracle.orb(nfeatures, 1.2, 8, 20, 7)
+    out = oorb.extract(img)
+    ol = oracle.lines()
+    ol.set_pyramid([oorb.level(l) for l in range(8)], 3, 1.2)
+    return out, ol
+
+
+def test_oracle_lines_on_a_shared_pyramid(oracle):
+    """Line.pyramidPrecomputation: octave i = ORB level i (cvRound sizes, unblurred), no resize chain."""
+    img = golden(IMAGES[0])
+    _, ol = _oracle_shared(oracle, img)
+    kl, desc = ol.extract(img)
+    own_kl, _ = oracle.lines().extract(img)
+    assert 20 < len(kl) <= 100 and desc.shape == (len(kl), 32)
+    assert ol.octave_size(0) == (640, 480) and ol.octave_size(1) == (533, 400) and ol.octave_size(2) == (444, 333)
+    # octave 0 is the same image either way; the higher octaves differ (resized from the unblurred level)
+    k0, o0 = kl[kl["octave"] == 0], own_kl[own_kl["octave"] == 0]
+    assert len(k0) > 5 and len(o0) > 5
+    assert kl.tobytes() != own_kl.tobytes()
+
+
+@pytest.mark.gpu
+def test_hip_lines_on_a_shared_pyramid_match_oracle(oracle):
+    import torch
+    from plvs_amd.frame import extract_frame
+    from plvs_amd.lines import LineExtractor
+    from plvs_amd.orb import ORBextractor
+    orb, lines = ORBextractor(1000, 1.2, 8, 20, 7), LineExtractor(100)
+    lines.SetGaussianPyramid(orb)
+    for name in IMAGES[:3]:
+        img = golden(name)
+        (omono, okps, odesc), ol = _oracle_shared(oracle, img)
+        okl, oldesc = ol.extract(img)
+        # sequential: extractor first, then the lines on its pyramid
+        orb(img)
+        kl, ldesc = lines(img)
+        assert kl.tobytes() == okl.tobytes() and np.array_equal(ldesc, oldesc)
+        for o in range(3):
+            assert np.array_equal(lines.octave_map(o, "blur"), ol.octave_map(o, "blur"))
+        # concurrent: the frame-level entry point orders the two through the pyramid event
+        for _ in range(3):
+            mono, kps, desc, kl, ldesc = extract_frame(orb, lines, torch.from_numpy(img).cuda())
+            assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
+            assert kl.tobytes() == okl.tobytes() and np.array_equal(ldesc, oldesc)
+    # a different image size rebuilds both geometries
+    small = golden(IMAGES[0])[:300, :400].copy()
+    (_, _, _), ol = _oracle_shared(oracle, small)
+    okl, oldesc = ol.extract(small)
+    mono, kps, desc, kl, ldesc = extract_frame(orb, lines, torch.from_numpy(small).cuda())
+    assert kl.tobytes() == okl.tobytes() and np.array_equal(ldesc, oldesc)
+    # back to the extractor's own pyramid
+    lines.SetGaussianPyramid(None)
+    img = golden(IMAGES[0])
+    okl, oldesc = oracle.lines().extract(img)
+    kl, ldesc = lines(img)
+    assert kl.tobytes() == okl.tobytes() and np.array_equal(ldesc, oldesc)
+    # sharing with an extractor that has not seen an image is an error, not a fallback
+    from plvs_amd import _lib
+    fresh = ORBextractor(500, 1.2, 8, 20, 7)
+    lines.SetGaussianPyramid(fresh)
+    with pytest.raises(_lib.PlvsHipError):
+        lines(img)
+    lines.close()
+    orb.close()
