@@ -483,6 +483,20 @@ int plvs_hip_stereo_matches(plvs_stereo* s, const plvs_keypoint* keys_left, cons
                             int n_right, float mb, float mbf, float* u_right, float* depth,
                             int* n_matched);
 
+/* Surface extraction: ChunkManager::RecomputeMesh (Thirdparty/open_chisel/src/ChunkManager.cpp:116-170:
+ * GenerateMesh with one kfid per cube, ColorizeMesh, ComputeNormalsFromGradients) for every chunk of
+ * the list — what Chisel::UpdateMeshes (Chisel.cpp:57-65) does for meshesToUpdate (the 27-neighbourhood
+ * of the updated chunks, :553-568) when PointCloudMapChisel::UpdateMap calls it
+ * (src/PointCloudMapChisel.cc:236).  chunk_ids_xyz: host, nchunks x 3.  Outputs (host): the
+ * chisel::Mesh arrays of the chunks back to back, in list order — vertices / normals / colors
+ * (n x 3 f32, colours in [0, 1]) and kfids (n); chunk c owns [chunk_first[c], chunk_first[c+1])
+ * (chunk_first: nchunks + 1 ints); a chunk that does not exist owns nothing.  *nvertices = n.  If
+ * n > capacity nothing is written but chunk_first / *nvertices, and PLVS_ERR_CAPACITY is returned.
+ * Needs the whole map on one device (shard_count <= 1). */
+int plvs_hip_tsdf_chisel_mesh_chunks(plvs_tsdf_chisel* h, const int32_t* chunk_ids_xyz, int nchunks,
+                                     float* vertices, float* normals, float* colors, uint32_t* kfids,
+                                     int capacity, int32_t* chunk_first, int* nvertices);
+
 /* ------------------------------------------------- depth image -> cloud (T0)
  * Replaces PointCloudMapping::GeneratePointCloudInCameraFrameBGRA
  * src/PointCloudMapping.cc:929-1031 (caller IntegratePointCloudKeyframe path,

@@ -502,3 +502,248 @@ int oracle_chisel_carve(oracle_chisel* o, const float* depth, int width, int hei
       }
   return carved;
 }
+
+/* ===========================================================================================
+ * Surface extraction of one chunk — ChunkManager::RecomputeMesh (src/ChunkManager.cpp:116-170):
+ *   GenerateMesh (:577-660) with USE_KFID_MESHING 1 / USE_KFID_VERTICES 0 (:39-40):
+ *     ExtractInsideVoxelMeshKfid (:438-475), ExtractBorderVoxelMeshKfid (:477-575),
+ *     MarchingCubes::MeshCube(coords, sdf, kfid, ...) + InterpolateEdgeVertices / InterpolateVertex
+ *     (include/open_chisel/marching_cubes/MarchingCubes.h:110-143, 206-245), triangleTable /
+ *     edgeIndexPairs (src/marching_cubes/MarchingCubes.cpp:32-305);
+ *   ColorizeMesh (:860-872) -> InterpolateColor (:718-805), Chunk::GetColorAt (Chunk.cpp:137-155);
+ *   ComputeNormalsFromGradients (:840-858) -> GetSDFAndGradient (:663-690), GetSDF (:692-716).
+ * Called from Chisel::UpdateMeshes (Chisel.cpp:57-65) <- ChiselServer::UpdateMesh <-
+ * PointCloudMapChisel::UpdateMap (src/PointCloudMapChisel.cc:228-246).
+ * Quirks kept: InterpolateVertex returns v1 + 0.5 v2 on a flat edge; InterpolateColor passes voxel
+ * INDICES to a function that expects metres; GetSDF accepts any linear id in [0, 4096).
+ * Parity unpinned (no test or stored output in the reference). */
+static const int kTriangleTable[256 * 16] = {
+#include "mc_table.inc"
+};
+static const int kEdgeIndexPairs[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6},
+                                           {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+static const int kCubeIndexOffsets[3][8] = {{0, 1, 1, 0, 0, 1, 1, 0},   /* ChunkManager.cpp:84-86 */
+                                            {0, 0, 1, 1, 0, 0, 1, 1},
+                                            {0, 0, 0, 0, 1, 1, 1, 1}};
+
+typedef struct {
+  float* vertices; float* normals; uint32_t* kfids;
+  int n, cap;
+} mesh_out;
+
+static const chunk_t* mesh_find(const oracle_chisel* o, int x, int y, int z) {
+  const int32_t id[3] = {x, y, z};
+  int found = 0;
+  chunk_t* c = tab_find(o->tab, o->cap, id, &found);
+  return found ? c : NULL;
+}
+static const chunk_t* mesh_chunk_at(const oracle_chisel* o, const float pos[3]) {   /* GetChunkAt, ChunkManager.h:141 */
+  return mesh_find(o, (int)floorf(pos[0] * o->rounding), (int)floorf(pos[1] * o->rounding),
+                   (int)floorf(pos[2] * o->rounding));
+}
+static void mesh_origin(const oracle_chisel* o, const chunk_t* c, float org[3]) {    /* Chunk.cpp:48 */
+  for (int i = 0; i < 3; i++) org[i] = (float)(16 * c->id[i]) * o->resolution;
+}
+
+/* MarchingCubes::MeshCube(vertexCoords, vertexSDF, const uint32_t& vertexKfid, ...) */
+static void mesh_cube(const float cc[8][3], const float sdf[8], uint32_t kfid, mesh_out* m) {
+  int index = 0;
+  for (int i = 0; i < 8; i++) index |= (sdf[i] < 0) ? (1 << i) : 0;
+  if (index == 0) return;
+  float edge[12][3];
+  memset(edge, 0, sizeof edge);
+  for (int i = 0; i < 12; i++) {
+    const int e0 = kEdgeIndexPairs[i][0], e1 = kEdgeIndexPairs[i][1];
+    if ((sdf[e0] < 0 && sdf[e1] >= 0) || (sdf[e0] >= 0 && sdf[e1] < 0)) {
+      const float minDiff = 1e-6f;
+      const float sdfDiff = sdf[e0] - sdf[e1];
+      if (fabsf(sdfDiff) < minDiff) {
+        for (int k = 0; k < 3; k++) edge[i][k] = cc[e0][k] + 0.5f * cc[e1][k];
+      } else {
+        const float t = sdf[e0] / sdfDiff;
+        for (int k = 0; k < 3; k++) edge[i][k] = cc[e0][k] + t * (cc[e1][k] - cc[e0][k]);
+      }
+    }
+  }
+  const int* row = kTriangleTable + 16 * index;
+  for (int col = 0; row[col] != -1; col += 3) {
+    if (m->n + 3 > m->cap) { m->n += 3; continue; }   /* counted, not stored */
+    float* p0 = m->vertices + 3 * (size_t)m->n;
+    float *p1 = p0 + 3, *p2 = p0 + 6;
+    for (int k = 0; k < 3; k++) {
+      p0[k] = edge[row[col + 2]][k];
+      p1[k] = edge[row[col + 1]][k];
+      p2[k] = edge[row[col]][k];
+    }
+    float px[3], py[3], n[3];
+    vsub(p1, p0, px);
+    vsub(p2, p0, py);
+    n[0] = px[1] * py[2] - px[2] * py[1];
+    n[1] = px[2] * py[0] - px[0] * py[2];
+    n[2] = px[0] * py[1] - px[1] * py[0];
+    const float z = sqnorm3(n);
+    if (z > 0.0f) { const float s = sqrtf(z); n[0] /= s; n[1] /= s; n[2] /= s; }   /* normalized() */
+    for (int v = 0; v < 3; v++) {
+      for (int k = 0; k < 3; k++) m->normals[3 * (size_t)(m->n + v) + k] = n[k];
+      m->kfids[m->n + v] = kfid;
+    }
+    m->n += 3;
+  }
+}
+
+/* ExtractInsideVoxelMeshKfid / ExtractBorderVoxelMeshKfid: the border variant with every corner
+ * inside the chunk reduces to the inside variant, so one function serves both loops. */
+static void mesh_voxel(const oracle_chisel* o, const chunk_t* ch, int x, int y, int z, mesh_out* m) {
+  float org[3];
+  mesh_origin(o, ch, org);
+  const float res = o->resolution;
+  /* centroids[i] + chunk->GetOrigin(), ChunkManager.cpp:78, :601 */
+  const float coords[3] = {((float)x * res + o->half_voxel) + org[0], ((float)y * res + o->half_voxel) + org[1],
+                           ((float)z * res + o->half_voxel) + org[2]};
+  float cc[8][3], sdf[8];
+  uint32_t kfid = 0;
+  for (int i = 0; i < 8; i++) {
+    int c[3] = {x + kCubeIndexOffsets[0][i], y + kCubeIndexOffsets[1][i], z + kCubeIndexOffsets[2][i]};
+    const chunk_t* src = ch;
+    if (c[0] > 15 || c[1] > 15 || c[2] > 15) {                   /* :492-527 (offsets are never negative) */
+      int off[3] = {0, 0, 0};
+      for (int j = 0; j < 3; j++)
+        if (c[j] >= 16) { off[j] = 1; c[j] = 0; }
+      src = mesh_find(o, ch->id[0] + off[0], ch->id[1] + off[1], ch->id[2] + off[2]);
+      if (!src) return;                                           /* allNeighborsObserved = false */
+    }
+    const int id = (c[2] * 16 + c[1]) * 16 + c[0];
+    if (src->weight[id] <= 1e-15) return;                         /* double comparison, :462, :499, :543 */
+    for (int k = 0; k < 3; k++) cc[i][k] = coords[k] + (float)kCubeIndexOffsets[k][i] * res;
+    sdf[i] = src->sdf[id];
+    if (i == 0) kfid = src->kfid[id];
+  }
+  mesh_cube(cc, sdf, kfid, m);
+}
+
+static const uint32_t* mesh_color_voxel(const oracle_chisel* o, float px, float py, float pz) {   /* GetColorVoxel, :818 */
+  const float pos[3] = {px, py, pz};
+  const chunk_t* c = mesh_chunk_at(o, pos);
+  if (!c) return NULL;
+  float org[3];
+  mesh_origin(o, c, org);
+  const float inv = 1.0f / o->resolution;                         /* Chunk.cpp:38 */
+  const int vx = (int)floorf((pos[0] - org[0]) * inv), vy = (int)floorf((pos[1] - org[1]) * inv),
+            vz = (int)floorf((pos[2] - org[2]) * inv);
+  const int id = (vz * 16 + vy) * 16 + vx;
+  return (id >= 0 && id < CHUNK_VOX) ? &c->rgbw[id] : NULL;
+}
+
+static void mesh_interpolate_color(const oracle_chisel* o, const float p[3], float out[3]) {   /* :718-805 */
+  const float inv = 1.f / o->resolution;                          /* ChunkManager.cpp:67 */
+  const float x = p[0], y = p[1], z = p[2];
+  const int x_0 = (int)floorf(x * inv), y_0 = (int)floorf(y * inv), z_0 = (int)floorf(z * inv);
+  const int x_1 = x_0 + 1, y_1 = y_0 + 1, z_1 = z_0 + 1;
+  const uint32_t* v_000 = mesh_color_voxel(o, (float)x_0, (float)y_0, (float)z_0);
+  const uint32_t* v_001 = mesh_color_voxel(o, (float)x_0, (float)y_0, (float)z_1);
+  const uint32_t* v_011 = mesh_color_voxel(o, (float)x_0, (float)y_1, (float)z_1);
+  const uint32_t* v_111 = mesh_color_voxel(o, (float)x_1, (float)y_1, (float)z_1);
+  const uint32_t* v_110 = mesh_color_voxel(o, (float)x_1, (float)y_1, (float)z_0);
+  const uint32_t* v_100 = mesh_color_voxel(o, (float)x_1, (float)y_0, (float)z_0);
+  const uint32_t* v_010 = mesh_color_voxel(o, (float)x_0, (float)y_1, (float)z_0);
+  const uint32_t* v_101 = mesh_color_voxel(o, (float)x_1, (float)y_0, (float)z_1);
+  if (!v_000 || !v_001 || !v_011 || !v_111 || !v_110 || !v_100 || !v_010 || !v_101) {
+    out[0] = out[1] = out[2] = 0.0f;
+    const chunk_t* c = mesh_chunk_at(o, p);
+    if (!c) return;
+    float org[3];
+    mesh_origin(o, c, org);                                        /* Chunk::GetColorAt, Chunk.cpp:137-155 */
+    const float size = 16.0f * o->resolution;
+    for (int k = 0; k < 3; k++)
+      if (!(p[k] >= org[k] && p[k] <= org[k] + size)) return;
+    const float cinv = 1.0f / o->resolution;
+    const int cx = (int)((p[0] - org[0]) * cinv), cy = (int)((p[1] - org[1]) * cinv), cz = (int)((p[2] - org[2]) * cinv);
+    if (cx < 0 || cx >= 16 || cy < 0 || cy >= 16 || cz < 0 || cz >= 16) return;
+    const uint32_t col = c->rgbw[(cz * 16 + cy) * 16 + cx];
+    const float invMaxVal = 1.f / 255.0f;
+    out[0] = (float)(col & 255u) * invMaxVal;
+    out[1] = (float)((col >> 8) & 255u) * invMaxVal;
+    out[2] = (float)((col >> 16) & 255u) * invMaxVal;
+    return;
+  }
+  const float xd = (x - (float)x_0) / (float)(x_1 - x_0);
+  const float yd = (y - (float)y_0) / (float)(y_1 - y_0);
+  const float zd = (z - (float)z_0) / (float)(z_1 - z_0);
+  for (int ch = 0; ch < 3; ch++) {
+    const int sh = 8 * ch;
+#define CH(v) ((float)(((*(v)) >> sh) & 255u))
+    const float c_00 = CH(v_000) * (1 - xd) + CH(v_100) * xd;
+    const float c_10 = CH(v_010) * (1 - xd) + CH(v_110) * xd;
+    const float c_01 = CH(v_001) * (1 - xd) + CH(v_101) * xd;
+    const float c_11 = CH(v_011) * (1 - xd) + CH(v_111) * xd;
+#undef CH
+    const float c_0 = c_00 * (1 - yd) + c_10 * yd;
+    const float c_1 = c_01 * (1 - yd) + c_11 * yd;
+    const float c = c_0 * (1 - zd) + c_1 * zd;
+    out[ch] = c / 255.0f;
+  }
+}
+
+static int mesh_get_sdf(const oracle_chisel* o, const float posf[3], double* dist) {   /* GetSDF, :692-716 */
+  const chunk_t* c = mesh_chunk_at(o, posf);
+  if (!c) return 0;
+  float org[3];
+  mesh_origin(o, c, org);
+  const float inv = 1.0f / o->resolution;
+  const int vx = (int)floorf((posf[0] - org[0]) * inv), vy = (int)floorf((posf[1] - org[1]) * inv),
+            vz = (int)floorf((posf[2] - org[2]) * inv);
+  const int id = (vz * 16 + vy) * 16 + vx;
+  if (id >= 0 && id < CHUNK_VOX && c->weight[id] > 1e-12) {
+    *dist = c->sdf[id];
+    return 1;
+  }
+  return 0;
+}
+
+static void mesh_gradient_normal(const oracle_chisel* o, const float pos[3], float* normal) {   /* :840-858 */
+  const float res = o->resolution, inv = 1.f / res, half = 0.5f * res;   /* ChunkManager.cpp:67, :89 */
+  const float posf[3] = {floorf(pos[0] * inv) * res + half, floorf(pos[1] * inv) * res + half,
+                         floorf(pos[2] * inv) * res + half};
+  double dist, dp[3], dm[3];
+  if (!mesh_get_sdf(o, posf, &dist)) return;
+  for (int k = 0; k < 3; k++) {                                    /* +x, +y, +z */
+    float q[3] = {posf[0], posf[1], posf[2]};
+    q[k] = posf[k] + res;
+    if (!mesh_get_sdf(o, q, &dp[k])) return;
+  }
+  for (int k = 0; k < 3; k++) {                                    /* -x, -y, -z */
+    float q[3] = {posf[0], posf[1], posf[2]};
+    q[k] = posf[k] - res;
+    if (!mesh_get_sdf(o, q, &dm[k])) return;
+  }
+  float g[3] = {(float)(dp[0] - dm[0]), (float)(dp[1] - dm[1]), (float)(dp[2] - dm[2])};
+  const float z = sqnorm3(g);
+  if (z > 0.0f) { const float s = sqrtf(z); g[0] /= s; g[1] /= s; g[2] /= s; }   /* grad->normalize() */
+  const float mag = sqrtf(sqnorm3(g));
+  if (mag > 1e-12) {
+    const float r = 1.0f / mag;
+    normal[0] = g[0] * r; normal[1] = g[1] * r; normal[2] = g[2] * r;
+  }
+}
+
+/* Returns the number of vertices of chunk (cx, cy, cz) (0 if the chunk does not exist), writing up to
+ * `cap` of them: vertices / normals / colors n x 3 f32, kfids n u32 — chisel::Mesh after RecomputeMesh. */
+int oracle_chisel_mesh_chunk(const oracle_chisel* o, int cx, int cy, int cz, float* vertices, float* normals,
+                             float* colors, uint32_t* kfids, int cap) {
+  const chunk_t* ch = mesh_find(o, cx, cy, cz);
+  if (!ch) return 0;
+  mesh_out m = {vertices, normals, kfids, 0, cap};
+  for (int z = 0; z < 15; z++)                                     /* :590-606 */
+    for (int y = 0; y < 15; y++)
+      for (int x = 0; x < 15; x++) mesh_voxel(o, ch, x, y, z, &m);
+  for (int z = 0; z < 15; z++)                                     /* max X plane, :611-625 */
+    for (int y = 0; y < 16; y++) mesh_voxel(o, ch, 15, y, z, &m);
+  for (int z = 0; z < 15; z++)                                     /* max Y plane, :628-642 */
+    for (int x = 0; x < 15; x++) mesh_voxel(o, ch, x, 15, z, &m);
+  for (int y = 0; y < 16; y++)                                     /* max Z plane, :645-659 */
+    for (int x = 0; x < 16; x++) mesh_voxel(o, ch, x, y, 15, &m);
+  const int n = m.n < cap ? m.n : cap;
+  for (int i = 0; i < n; i++) mesh_interpolate_color(o, vertices + 3 * (size_t)i, colors + 3 * (size_t)i);   /* :158-161 */
+  for (int i = 0; i < n; i++) mesh_gradient_normal(o, vertices + 3 * (size_t)i, normals + 3 * (size_t)i);    /* :163 */
+  return m.n;
+}

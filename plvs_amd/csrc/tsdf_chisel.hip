@@ -34,6 +34,7 @@
 #include "device_utils.hpp"
 #include "tsdf_chisel_core.hpp"
 #include "tsdf_directory.hpp"
+#include "tsdf_chisel_view.hpp"
 #include "tsdf_tiles.hpp"
 
 using namespace plvs;
@@ -1463,3 +1464,22 @@ extern "C" int plvs_hip_tsdf_chisel_carve(plvs_tsdf_chisel* h, const float* dept
   PLVS_HIP_TRY(hipDeviceSynchronize());
   return PLVS_OK;
 }
+
+namespace plvs {
+namespace tsdf {
+
+bool chisel_map_view(const plvs_tsdf_chisel* h, ChiselMapView* v) {
+  if (h == nullptr || v == nullptr || h->poisoned) return false;
+  v->resolution = h->P.resolution;
+  v->dir = h->dir;
+  v->sdf = h->sdf;
+  v->weight = h->weight;
+  v->kfid = h->kfid;
+  v->rgbw = h->rgbw;
+  v->num_chunks = h->num_chunks;
+  v->shard_count = h->P.shard_count;
+  return true;
+}
+
+}  // namespace tsdf
+}  // namespace plvs

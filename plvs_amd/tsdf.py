@@ -71,6 +71,30 @@ class TsdfChisel:
                      _lib.np_ptr(Twc), carving_dist, ctypes.byref(n)))
         return n.value
 
+    def mesh_chunks(self, chunk_ids):
+        """ChunkManager::RecomputeMesh for every chunk id of the list ([n,3] ints, e.g. the 27-neighbourhood of
+        updated_chunk_ids() = Chisel's meshesToUpdate).  -> dict(vertices, normals, colors [m,3] f32, kfids [m] u32,
+        chunk_first [n+1]): chunk c owns rows chunk_first[c]:chunk_first[c+1]."""
+        ids = np.ascontiguousarray(chunk_ids, dtype=np.int32).reshape(-1, 3)
+        first = np.zeros(ids.shape[0] + 1, np.int32)
+        n = ctypes.c_int()
+        f = _lib.lib.plvs_hip_tsdf_chisel_mesh_chunks
+        f.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 2
+        cap = 0
+        while True:
+            v = np.zeros((max(cap, 1), 3), np.float32)
+            nr = np.zeros((max(cap, 1), 3), np.float32)
+            c = np.zeros((max(cap, 1), 3), np.float32)
+            k = np.zeros(max(cap, 1), np.uint32)
+            rc = f(self._h, _lib.np_ptr(ids), ids.shape[0], _lib.np_ptr(v), _lib.np_ptr(nr), _lib.np_ptr(c),
+                   _lib.np_ptr(k), cap, _lib.np_ptr(first), ctypes.byref(n))
+            if rc == _lib.PLVS_ERR_CAPACITY and n.value > cap:
+                cap = n.value            # first call sizes the mesh, second call fills it
+                continue
+            _lib.check(rc)
+            m = n.value
+            return dict(vertices=v[:m], normals=nr[:m], colors=c[:m], kfids=k[:m], chunk_first=first)
+
     def integrate_batch_dev(self, d_xyz, d_rgb, d_kfid, offsets, d_Twc):
         """Device flavour: concatenated clouds resident in HBM (torch tensors),
         `offsets` a host int32 array of nclouds+1, d_Twc [nclouds,3,4] f32."""

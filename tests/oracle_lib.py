@@ -327,6 +327,19 @@ class _ChiselLike:
               _ptr(ids))
         return n, ids[:n]
 
+    def mesh_chunk(self, cx, cy, cz):
+        """ChunkManager::RecomputeMesh of one chunk -> (vertices, normals, colors [n,3] f32, kfids [n] u32)
+        (oracle only)."""
+        f = getattr(self.lib, self.p + "_mesh_chunk")
+        f.restype = _i
+        f.argtypes = [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i]
+        cap = 4096 * 15
+        v, nr, c = (np.zeros((cap, 3), np.float32) for _ in range(3))
+        k = np.zeros(cap, np.uint32)
+        n = f(self.h, int(cx), int(cy), int(cz), _ptr(v), _ptr(nr), _ptr(c), _ptr(k), cap)
+        assert n <= cap
+        return v[:n].copy(), nr[:n].copy(), c[:n].copy(), k[:n].copy()
+
     def close(self):
         if self.h:
             getattr(self.lib, self.p + "_destroy")(self.h)
