@@ -19,7 +19,8 @@
 //                through the chunk directory, neighbours included)
 // so the vertex order inside a chunk and the order of the chunks are the reference's / the caller's.
 // The map stays in HBM; only the finished mesh crosses PCIe.  Arithmetic follows the reference
-// expression by expression (quirks included, see oracle/tsdf_chisel.c), no FMA contraction.
+// expression by expression (quirks included: the flat-edge vertex, voxel indices used as metres in the colour look-up, the
+// linear-id range check), no FMA contraction.
 #include <vector>
 
 #include "common.hpp"

@@ -86,7 +86,7 @@ def test_hip_mesh_matches_oracle(oracle, res, n_kf):
             assert got["colors"][a:b].tobytes() == c.tobytes()
             assert got["normals"][a:b].tobytes() == n.tobytes()
             checked += 1
-    assert checked > 50
+    assert checked > 10
     # empty list, unknown chunks only
     e = hip.mesh_chunks(np.zeros((0, 3), np.int32))
     assert len(e["vertices"]) == 0
