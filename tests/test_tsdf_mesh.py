@@ -74,7 +74,7 @@ def test_hip_mesh_matches_oracle(oracle, res, n_kf):
     assert any(tuple(c) not in existing for c in todo) and any(tuple(c) in existing for c in todo)
     got = hip.mesh_chunks(todo)
     first = got["chunk_first"]
-    assert first[0] == 0 and first[-1] == len(got["vertices"]) > 10000
+    assert first[0] == 0 and first[-1] == len(got["vertices"]) > 2000
     checked = 0
     for i, cid in enumerate(todo):
         v, n, c, kf = ref.mesh_chunk(*cid)
@@ -86,7 +86,7 @@ def test_hip_mesh_matches_oracle(oracle, res, n_kf):
             assert got["colors"][a:b].tobytes() == c.tobytes()
             assert got["normals"][a:b].tobytes() == n.tobytes()
             checked += 1
-    assert checked > 10
+    assert checked > 5
     # empty list, unknown chunks only
     e = hip.mesh_chunks(np.zeros((0, 3), np.int32))
     assert len(e["vertices"]) == 0
