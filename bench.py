@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=25, help="keyframes per step")
+    ap.add_argument("--batch", type=int, default=100,
+                    help="keyframes per step (default: the whole 100-pose sequence of SURVEY §8d in one launch)")
     ap.add_argument("--resolution", type=float, default=0.05)
     ap.add_argument("--max-depth", type=float, default=5.0)
     ap.add_argument("--backend", choices=["chisel", "voxblox"], default="chisel",
@@ -176,7 +177,7 @@ def main():
         # runs of this same command; scripts/pmc_traffic.py) committed under profiles/
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
                            f"r01_pmc_traffic_{args.backend}.json")
-        if world == 1 and args.batch == 25 and os.path.exists(pmc):
+        if world == 1 and args.batch == 100 and os.path.exists(pmc):
             with open(pmc) as f:
                 t = json.load(f)
             roofline["traffic"] = t["traffic"]

@@ -16,7 +16,8 @@ import sys
 from collections import defaultdict
 
 PIPELINE = ("pose_prep", "ray_count", "scan_tile_sums", "scan_sums", "scan_tile_apply", "mark_tiles", "ray_tiles",
-            "radix_hist", "radix_scatter", "run_counts", "mark_blocks", "gather_runs", "chain_runs", "chain_colours")
+            "radix_hist", "radix_scatter", "voxel_heads", "fold_colours", "reduce_sums", "run_counts", "mark_blocks",
+            "gather_runs", "chain_runs")
 
 
 def short(n):
