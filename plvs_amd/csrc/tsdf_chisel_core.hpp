@@ -187,21 +187,27 @@ PLVS_HD void ray_begin(const Ray& r, RayCursor* c) {
 }
 
 // Emits the current voxel into (vx,vy,vz) and advances; false when the ray is exhausted.
+// Straight-line form of the loop body of Raycast.cpp:115-180 (selects instead of the if / else
+// ladder: on the GPU the ladder costs more exec-mask bookkeeping than arithmetic); the
+// comparisons, their order and the one addition per step are the reference's.
 PLVS_HD bool ray_next(RayCursor* c, int* vx, int* vy, int* vz) {
   if (c->done) return false;
   *vx = c->x; *vy = c->y; *vz = c->z;
   // (the reference's bounds test against -/+INT_MAX only rejects INT_MAX itself)
   const float d = sqnorm3((float)c->x - c->sx, (float)c->y - c->sy, (float)c->z - c->sz);
-  if (d > c->maxDist) { c->done = true; return true; }
-  if (c->x == c->endX && c->y == c->endY && c->z == c->endZ) { c->done = true; return true; }
-  if (c->tMaxX < c->tMaxY) {
-    if (c->tMaxX < c->tMaxZ) { c->x += c->stepX; c->tMaxX += c->tDeltaX; }
-    else                     { c->z += c->stepZ; c->tMaxZ += c->tDeltaZ; }
-  } else {
-    if (c->tMaxY < c->tMaxZ) { c->y += c->stepY; c->tMaxY += c->tDeltaY; }
-    else                     { c->z += c->stepZ; c->tMaxZ += c->tDeltaZ; }
-  }
-  if (++c->guard >= kRayStepGuard) c->done = true;
+  const bool stop = (d > c->maxDist) | ((c->x == c->endX) & (c->y == c->endY) & (c->z == c->endZ));
+  const bool x_lt_y = c->tMaxX < c->tMaxY;
+  const bool use_x = x_lt_y & (c->tMaxX < c->tMaxZ);
+  const bool use_y = (!x_lt_y) & (c->tMaxY < c->tMaxZ);
+  const bool go_x = use_x & !stop, go_y = use_y & !stop, go_z = !(use_x | use_y) & !stop;
+  c->x += go_x ? c->stepX : 0;
+  c->y += go_y ? c->stepY : 0;
+  c->z += go_z ? c->stepZ : 0;
+  c->tMaxX = go_x ? c->tMaxX + c->tDeltaX : c->tMaxX;
+  c->tMaxY = go_y ? c->tMaxY + c->tDeltaY : c->tMaxY;
+  c->tMaxZ = go_z ? c->tMaxZ + c->tDeltaZ : c->tMaxZ;
+  c->guard += stop ? 0 : 1;
+  c->done = stop | (c->guard >= kRayStepGuard);
   return true;
 }
 
