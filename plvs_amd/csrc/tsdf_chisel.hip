@@ -99,7 +99,14 @@ __global__ __launch_bounds__(256) void ray_count(
   const Pose pose = poses[cloud_of(offsets, nclouds, i)];
   Ray ray;
   uint32_t n = 0;
-  if (make_ray(P, pose, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], &ray)) {
+  bool walk = make_ray(P, pose, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], &ray);
+  if (walk && !ray_in_coord_range(ray)) {
+    // beyond the range in which the integer chunk addressing equals the reference's float
+    // lookup: fail loudly instead of diverging
+    atomicOr(&ctr->err, kErrCoordRange);
+    walk = false;
+  }
+  if (walk) {
     RayCursor cur;
     ray_begin(ray, &cur);
     int vx, vy, vz;
@@ -112,10 +119,6 @@ __global__ __launch_bounds__(256) void ray_count(
         lcx = v.cx; lcy = v.cy; lcz = v.cz;
         have_last = true;
         dir_insert(dir, lcx, lcy, lcz, &ctr->num_chunks, &ctr->err);
-        // the float chunk lookup (GetIDAt) and the integer voxel grid only
-        // disagree ~100 km from the origin; fail loudly instead of diverging
-        if (((vx - lcx * 16) | (vy - lcy * 16) | (vz - lcz * 16)) & ~15)
-          atomicOr(&ctr->err, kErrCoordRange);
       }
       ++n;
     }
@@ -1027,7 +1030,7 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
     h->poisoned = true;
     plvs::set_error("tsdf_chisel integrate: %s%s",
                     (h->h_ctr->err & kErrPoolFull) ? "chunk pool full (raise max_chunks) " : "",
-                    (h->h_ctr->err & kErrCoordRange) ? "chunk id outside +-2^20 " : "");
+                    (h->h_ctr->err & kErrCoordRange) ? "voxel coordinates beyond +-2^20 (outside the supported map extent) " : "");
     return PLVS_ERR_CAPACITY;
   }
   const uint32_t V = h->h_ctr->total_visits;

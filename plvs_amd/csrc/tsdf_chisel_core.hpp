@@ -141,21 +141,34 @@ PLVS_HD float signed_dist(const Pose& pose, float depth, float c0, float c1, flo
   return length * (depth / cc[2] - 1);
 }
 
-// Returns true when the voxel takes an update (owned, valid local id, |u| < truncation).
+// |voxel coordinate| below which the reference's float chunk lookup (GetIDAt on the voxel centre,
+// ChunkManager.h:192-198: floor(((v * res + res/2)) * (1 / (16 res)))) provably equals the integer
+// v >> 4: the exact value (v + 0.5) / 16 is at least 1/32 away from every integer and the three
+// roundings perturb it by less than 2^-22 relative, i.e. by less than 1/32 while |v| < 2^21.  Rays
+// that leave this range (50 km at 5 cm) make the call fail with kErrCoordRange instead of diverging.
+constexpr float kVoxelCoordLimit = 1048576.0f - 128.0f;   // the walk can overshoot a ray's ends by a few voxels
+
+PLVS_HD bool ray_in_coord_range(const Ray& r) {
+  bool ok = true;
+  for (int k = 0; k < 3; ++k)
+    ok = ok && (fabsf(r.start[k]) < kVoxelCoordLimit) && (fabsf(r.end[k]) < kVoxelCoordLimit);
+  return ok;
+}
+
+// Returns true when the voxel takes an update (owned, |u| < truncation).  Chunk id and local voxel
+// id come from the integer voxel coordinates (see kVoxelCoordLimit).
 PLVS_HD bool resolve_visit(const Params& P, const Pose& pose, const Ray& ray, int vx, int vy, int vz,
                            Visit* v) {
-  const float c0 = (float)vx * P.resolution + P.half_voxel;
-  const float c1 = (float)vy * P.resolution + P.half_voxel;
-  const float c2 = (float)vz * P.resolution + P.half_voxel;
-  v->cx = (int)floorf(c0 * P.rounding);
-  v->cy = (int)floorf(c1 * P.rounding);
-  v->cz = (int)floorf(c2 * P.rounding);
+  v->cx = vx >> 4;
+  v->cy = vy >> 4;
+  v->cz = vz >> 4;
   if (P.shard_count > 1 &&
       (int)(chunk_hash(v->cx, v->cy, v->cz) % (uint64_t)P.shard_count) != P.shard_rank)
     return false;
-  const int lx = vx - v->cx * 16, ly = vy - v->cy * 16, lz = vz - v->cz * 16;
-  v->vid = (lz * 16 + ly) * 16 + lx;
-  if (!(v->vid >= 0 && v->vid < kChunkVox)) return false;
+  v->vid = ((vz & 15) * 16 + (vy & 15)) * 16 + (vx & 15);
+  const float c0 = (float)vx * P.resolution + P.half_voxel;
+  const float c1 = (float)vy * P.resolution + P.half_voxel;
+  const float c2 = (float)vz * P.resolution + P.half_voxel;
   v->u = signed_dist(pose, ray.depth, c0, c1, c2);
   return fabsf(v->u) < ray.truncation;
 }

@@ -201,6 +201,31 @@ def test_hip_edge_cases(oracle):
 
 
 @pytest.mark.gpu
+def test_hip_far_from_the_origin(oracle):
+    """Chunk ids come from the integer voxel coordinates; that equals the reference's float lookup while
+    |voxel| < 2^20 (proof in tsdf_chisel_core.hpp).  40 km out (800 000 voxels at 5 cm) must still be exact,
+    60 km must be refused, not silently different."""
+    from plvs_amd import _lib
+    from plvs_amd.tsdf import TsdfChisel
+    kf = make_keyframes(1, seed=2)[0]
+    for shift, ok in ((np.array([40000.0, -39000.0, 38000.0], np.float32), True),
+                      (np.array([60000.0, 0.0, 0.0], np.float32), False)):
+        Twc = kf["Twc"].copy()
+        Twc[:, 3] += shift
+        dev = TsdfChisel(0.05)
+        if ok:
+            ora = oracle.chisel(0.05)
+            ora.integrate(kf["xyz"][::7], kf["rgb"][::7], kf["kfid"][::7], Twc)
+            dev.integrate(kf["xyz"][::7], kf["rgb"][::7], kf["kfid"][::7], Twc)
+            compare_maps(ora, dev)
+            assert np.abs(np.asarray(dev.chunk_ids())).max() > 40000
+        else:
+            with pytest.raises(_lib.PlvsHipError):
+                dev.integrate(kf["xyz"][::7], kf["rgb"][::7], kf["kfid"][::7], Twc)
+        dev.close()
+
+
+@pytest.mark.gpu
 def test_hip_shards_match_oracle_shards(oracle):
     from plvs_amd.tsdf import TsdfChisel
     kfs = make_keyframes(2, cam=small_cam(2), seed=17)
