@@ -108,13 +108,14 @@ __global__ __launch_bounds__(256) void ray_count(
   }
   if (walk) {
     RayCursor cur;
+    OwnerCache owner;
     ray_begin(ray, &cur);
     int vx, vy, vz;
     int lcx = 0, lcy = 0, lcz = 0;  // last chunk seen by this ray
     bool have_last = false;
     while (ray_next(&cur, &vx, &vy, &vz)) {
       Visit v;
-      if (!resolve_visit(P, pose, ray, vx, vy, vz, &v)) continue;
+      if (!resolve_visit(P, pose, ray, vx, vy, vz, &v, &owner)) continue;
       if (!have_last || v.cx != lcx || v.cy != lcy || v.cz != lcz) {
         lcx = v.cx; lcy = v.cy; lcz = v.cz;
         have_last = true;
@@ -217,6 +218,7 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
     Ray ray;
     if (!make_ray(P, pose, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], &ray)) continue;
     RayCursor cur;
+    OwnerCache owner;
     ray_begin(ray, &cur);
     int vx, vy, vz;
     int lcx = 0, lcy = 0, lcz = 0, lslot = -1;
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
     uint32_t nv = 0;
     while (nv < n_hi && ray_next(&cur, &vx, &vy, &vz)) {
       Visit v;
-      if (!resolve_visit(P, pose, ray, vx, vy, vz, &v)) continue;
+      if (!resolve_visit(P, pose, ray, vx, vy, vz, &v, &owner)) continue;
       if (nv >= n_lo) {
         if (!have_last || v.cx != lcx || v.cy != lcy || v.cz != lcz) {
           lcx = v.cx; lcy = v.cy; lcz = v.cz;

@@ -9,6 +9,7 @@
 //            Thirdparty/open_chisel/src/geometry/Raycast.cpp:6-182,
 //            include/open_chisel/ChunkManager.h:42-54, 192-206.
 #pragma once
+#include <climits>
 #include <cmath>
 #include <cstdint>
 
@@ -127,6 +128,30 @@ PLVS_HD uint64_t chunk_hash(int x, int y, int z) {
          ((uint64_t)(int64_t)z * 83492791ull);
 }
 
+// hash % count without a 64-bit division (count is the number of GPUs: small, usually a power of two).
+PLVS_HD int shard_of(uint64_t h, int count) {
+  const uint32_t c = (uint32_t)count;
+  if ((c & (c - 1u)) == 0u) return (int)((uint32_t)h & (c - 1u));
+  const uint32_t hi = (uint32_t)(h >> 32) % c, lo = (uint32_t)h % c;
+  const uint32_t two32 = ((0xFFFFFFFFu % c) + 1u) % c;   // 2^32 mod c
+  return (int)(((unsigned long long)hi * two32 + lo) % c);
+}
+
+// Ownership of the chunk a walk is in, re-evaluated only when the chunk changes (a ray crosses one or
+// two chunk boundaries in a dozen steps).
+struct OwnerCache {
+  int cx = INT_MIN, cy = 0, cz = 0;
+  bool owned = false;
+};
+PLVS_HD bool chunk_owned(const Params& P, int cx, int cy, int cz, OwnerCache* oc) {
+  if (P.shard_count <= 1) return true;
+  if (cx != oc->cx || cy != oc->cy || cz != oc->cz) {
+    oc->cx = cx; oc->cy = cy; oc->cz = cz;
+    oc->owned = shard_of(chunk_hash(cx, cy, cz), P.shard_count) == P.shard_rank;
+  }
+  return oc->owned;
+}
+
 // What one raycast voxel resolves to (Chisel.cpp:505-531).
 struct Visit {
   int cx, cy, cz;  // chunk id
@@ -158,13 +183,11 @@ PLVS_HD bool ray_in_coord_range(const Ray& r) {
 // Returns true when the voxel takes an update (owned, |u| < truncation).  Chunk id and local voxel
 // id come from the integer voxel coordinates (see kVoxelCoordLimit).
 PLVS_HD bool resolve_visit(const Params& P, const Pose& pose, const Ray& ray, int vx, int vy, int vz,
-                           Visit* v) {
+                           Visit* v, OwnerCache* oc) {
   v->cx = vx >> 4;
   v->cy = vy >> 4;
   v->cz = vz >> 4;
-  if (P.shard_count > 1 &&
-      (int)(chunk_hash(v->cx, v->cy, v->cz) % (uint64_t)P.shard_count) != P.shard_rank)
-    return false;
+  if (!chunk_owned(P, v->cx, v->cy, v->cz, oc)) return false;
   v->vid = ((vz & 15) * 16 + (vy & 15)) * 16 + (vx & 15);
   const float c0 = (float)vx * P.resolution + P.half_voxel;
   const float c1 = (float)vy * P.resolution + P.half_voxel;

@@ -54,11 +54,12 @@ void hostcore_integrate(HostMap* m, const float* xyz, const uint8_t* rgb, const 
     Ray ray;
     if (!make_ray(m->P, pose, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], &ray)) continue;
     RayCursor cur;
+    OwnerCache owner;
     ray_begin(ray, &cur);
     int vx, vy, vz;
     while (ray_next(&cur, &vx, &vy, &vz)) {
       Visit v;
-      if (!resolve_visit(m->P, pose, ray, vx, vy, vz, &v)) continue;
+      if (!resolve_visit(m->P, pose, ray, vx, vy, vz, &v, &owner)) continue;
       HostChunk& c = m->chunks[std::make_tuple(v.cx, v.cy, v.cz)];
       // what apply_runs recomputes from (voxel, point)
       const int lx = v.vid & 15, ly = (v.vid >> 4) & 15, lz = v.vid >> 8;

@@ -229,9 +229,9 @@ def test_hip_far_from_the_origin(oracle):
 def test_hip_shards_match_oracle_shards(oracle):
     from plvs_amd.tsdf import TsdfChisel
     kfs = make_keyframes(2, cam=small_cam(2), seed=17)
-    for rank in range(2):
-        ora = oracle.chisel(0.05, shard_rank=rank, shard_count=2)
-        dev = TsdfChisel(0.05, max_chunks=4096, shard_rank=rank, shard_count=2)
+    for rank, count in ((0, 2), (1, 2), (2, 3), (5, 8)):     # power-of-two and general owner arithmetic
+        ora = oracle.chisel(0.05, shard_rank=rank, shard_count=count)
+        dev = TsdfChisel(0.05, max_chunks=4096, shard_rank=rank, shard_count=count)
         for kf in kfs:
             ora.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
             dev.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
