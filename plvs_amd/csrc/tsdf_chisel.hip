@@ -146,6 +146,19 @@ __global__ __launch_bounds__(256) void ray_count(
 //
 // Run descriptors are numbered across tiles by a decoupled look-back over tile_state (tile
 // ids are tickets, so a tile only ever waits for tiles that already started).
+// The point (global index) whose ray produced the visit in slot s of the tile.
+__device__ __forceinline__ uint32_t tile_point_of(bool wide, const uint32_t* __restrict__ voff, uint32_t first,
+                                                  uint32_t last, uint32_t slot0, const uint16_t* spt, uint32_t s) {
+  if (!wide) return first + spt[s];
+  const uint32_t g = slot0 + s;          // the visit's global number: voff[i] <= g < voff[i + 1]
+  uint32_t lo = first, hi = last + 1;    // voff[lo] <= g < voff[hi]
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (voff[mid] <= g) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
 struct TileOut {
   float2* rec_t;        // [V] operands, tile-grouped
   uint32_t* recc_t;     // [V] colours, tile-grouped
@@ -205,10 +218,52 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
   if (tid <= ncl) cl_off[tid] = offsets[cloud0 + tid];
   __syncthreads();
 
-  // ---- phase 1: the visits of this tile, in slot (= point, then ray) order
-  for (uint32_t i = first + tid; i <= last; i += kTileThreads) {
+  // ---- phase 1a: the points of [first, last] that have visits in this tile, compacted (any order:
+  // a visit's slot comes from voff).  On a shard most points of the range have none — their chunks
+  // belong to other ranks, whole keyframes can look at chunks of other ranks only — and a wave
+  // would otherwise walk 64 rays for the few lanes that do.  Stretches without visits are jumped
+  // over by bisection on voff (uniform control flow).
+  uint32_t* const tile_rays = bufA;   // free until phase 2; a tile holds <= kTileSlots such points
+  if (tid == 0) sh_base = 0;
+  __syncthreads();
+  for (uint32_t base = first; base <= last;) {
+    const uint32_t vb = voff[base];
+    if (vb >= slot0 + n) break;                          // the rest belongs to later tiles
+    const uint32_t end = min(base + (uint32_t)kTileThreads, last + 1);
+    if (voff[end] == vb) {                               // nothing in [base, end)
+      uint32_t lo = end, hi = last + 1;                  // voff[lo] == vb throughout
+      if (voff[hi] == vb) break;
+      while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (voff[mid] > vb) hi = mid; else lo = mid;
+      }
+      base = lo;                                         // point lo is the next one with visits
+      continue;
+    }
+    const uint32_t i = base + tid;
+    bool has = false;
+    if (i < end) {
+      const uint32_t o = voff[i], e = voff[i + 1];
+      has = !(e == o || e <= slot0 || o >= slot0 + n);
+    }
+    const unsigned long long m = __ballot(has);
+    uint32_t wbase = 0;
+    if ((tid & 63) == 0 && m != 0ull) wbase = atomicAdd(&sh_base, (uint32_t)__popcll(m));
+    wbase = __shfl(wbase, 0);
+    if (has) tile_rays[wbase + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = i;
+    base = end;
+  }
+  __syncthreads();
+  const uint32_t nrays = sh_base;
+  // spt holds a point relative to `first` in 16 bits; a tile that spans more (long stretches
+  // without visits) recovers the point of a visit from voff instead (tile_point_of)
+  const bool wide = (last - first) > 0xFFFFu;
+  __syncthreads();   // sh_base is reused by the look-back
+
+  // ---- phase 1b: the visits of this tile, in slot (= point, then ray) order
+  for (uint32_t r = tid; r < nrays; r += kTileThreads) {
+    const uint32_t i = tile_rays[r];
     const uint32_t o = voff[i], e = voff[i + 1];
-    if (e == o || e <= slot0 || o >= slot0 + n) continue;
     const uint32_t n_lo = (o < slot0) ? slot0 - o : 0u;       // visits before it belong to the previous tile
     const uint32_t n_hi = min(e, slot0 + n) - o;              // visits from it on to the next one
     int cl = 0;
@@ -273,7 +328,7 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
       if (g < ngroups) {
         const uint32_t tag = bufA[hp[g]];
         g_key[m] = skey[tag & 0xFFFu];
-        g_last[m] = first + spt[bufA[hp[g + 1] - 1] & 0xFFFu];
+        g_last[m] = tile_point_of(wide, voff, first, last, slot0, spt, bufA[hp[g + 1] - 1] & 0xFFFu);
         if ((rgbw[g_key[m]] >> 24) >= 254u) atomicOr(&saturated[tag >> 17], 1u << ((tag >> 12) & 31u));
       }
     }
@@ -286,7 +341,7 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
       if (j < n) {
         const uint32_t tag = bufA[j];
         const uint32_t s = tag & 0xFFFu;
-        const size_t p = (size_t)first + spt[s];
+        const size_t p = tile_point_of(wide, voff, first, last, slot0, spt, s);
         const float tr = truncation_of(P, xyz[3 * p + 2]);
         const float wu = P.weight / (2.0f * tr);
         v_wuu[k] = wu * su[s];
@@ -334,7 +389,7 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
     const uint32_t j = tid + k * kTileThreads;
     if (j < n) {
       const uint32_t s = bufA[j] & 0xFFFu;
-      const size_t p = (size_t)first + spt[s];
+      const size_t p = tile_point_of(wide, voff, first, last, slot0, spt, s);
       const float tr = truncation_of(P, xyz[3 * p + 2]);
       const float wu = P.weight / (2.0f * tr);
       out.rec_t[slot0 + j] = make_float2(wu * su[s], wu);
@@ -354,7 +409,7 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
     const uint32_t d = dbase + g;
     out.dkey[d] = skey[bufA[p0] & 0xFFFu];
     out.dval[d] = (unsigned long long)(slot0 + p0) | ((unsigned long long)(p1 - p0) << 32);
-    out.last_pt[slot0 + p0] = first + spt[bufA[p1 - 1] & 0xFFFu];
+    out.last_pt[slot0 + p0] = tile_point_of(wide, voff, first, last, slot0, spt, bufA[p1 - 1] & 0xFFFu);
   }
   }
   TILE_PROBE(6)

@@ -360,6 +360,49 @@ def test_hip_degenerate_clouds_match_oracle(oracle, order_free):
     dev.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("order_free,shards", [(False, 1), (True, 1), (False, 16)])
+def test_hip_long_stretches_without_visits(oracle, order_free, shards):
+    """A tile whose visits come from points more than 2^16 apart (skipped points in between: z < 0.01, or —
+    on a shard — whole keyframes that only see other ranks' chunks): the per-visit point index no longer
+    fits the 16-bit tile-relative form and is recovered from the offsets."""
+    from plvs_amd.tsdf import TsdfChisel
+    kf = make_keyframes(2, cam=small_cam(2), seed=23)
+    a, b = kf[0], kf[1]
+    na, nb = 1500, 900
+    hole = 70000 if shards == 1 else 3000
+    skip = np.tile(np.array([[0.1, 0.1, 0.001]], np.float32), (hole, 1))          # z < 0.01: no ray
+    xyz = np.concatenate([a["xyz"][:na], skip, a["xyz"][na:na + nb], skip, a["xyz"][na + nb:na + 2 * nb]])
+    rgb = np.concatenate([a["rgb"][:na], np.zeros((hole, 3), np.uint8), a["rgb"][na:na + nb],
+                          np.zeros((hole, 3), np.uint8), a["rgb"][na + nb:na + 2 * nb]])
+    kfid = np.arange(xyz.shape[0], dtype=np.uint32)                                 # kfid = point index: exposes a wrong point
+    for rank in ((0,) if shards == 1 else (0, 15)):     # rank 15 of 16 owns ~500 visits per copy: tiles ~70 000 points wide
+        ora = oracle.chisel(0.05, shard_rank=rank, shard_count=shards)
+        dev = TsdfChisel(0.05, max_chunks=4096, shard_rank=rank, shard_count=shards, order_free=order_free)
+        if shards > 1:
+            # many repetitions of the cloud: a rank's 4096-visit tiles stretch over several copies
+            reps = 40
+            xyz_r, rgb_r = np.tile(xyz, (reps, 1)), np.tile(rgb, (reps, 1))
+            kfid_r = np.arange(xyz_r.shape[0], dtype=np.uint32)
+            ora.integrate(xyz_r, rgb_r, kfid_r, a["Twc"])
+            dev.integrate(xyz_r, rgb_r, kfid_r, a["Twc"])
+        else:
+            ora.integrate(xyz, rgb, kfid, a["Twc"])
+            dev.integrate(xyz, rgb, kfid, a["Twc"])
+        ora.integrate(b["xyz"], b["rgb"], b["kfid"], b["Twc"])
+        dev.integrate(b["xyz"], b["rgb"], b["kfid"], b["Twc"])
+        if order_free:
+            for cid in {tuple(x) for x in ora.chunk_ids()}:
+                p, q = ora.get_chunk(*cid), dev.get_chunk(*cid)
+                known = p[1] > 0
+                assert np.array_equal(known, q[1] > 0) and np.array_equal(p[2], q[2]) and np.array_equal(p[3], q[3])
+                if known.any():
+                    assert np.abs(p[0][known] - q[0][known]).max() <= ORDER_FREE_SDF_ATOL
+        else:
+            assert compare_maps(ora, dev) > 5
+        dev.close()
+
+
 # ------------------------------------------------------------------ carving (T7)
 def _depth_image(cam, kind, seed=0):
     h, w = cam["height"], cam["width"]
