@@ -399,7 +399,7 @@ def test_hip_long_stretches_without_visits(oracle, order_free, shards):
                 if known.any():
                     assert np.abs(p[0][known] - q[0][known]).max() <= ORDER_FREE_SDF_ATOL
         else:
-            assert compare_maps(ora, dev) > 5
+            assert compare_maps(ora, dev) >= 1      # a 1/16 shard of this small scene is one or two chunks
         dev.close()
 
 
