@@ -222,6 +222,24 @@ PLVS_HD void ray_begin(const Ray& r, RayCursor* c) {
   c->done = (c->stepX == 0 && c->stepY == 0 && c->stepZ == 0);
 }
 
+// Sharded maps: can the walk that starts at `c` emit a voxel of a chunk this rank owns?  Conservative
+// and cheap (no walk).  Along an axis the walk only moves in the direction of its step; every emitted
+// voxel but the last is within sqrt(maxDist) of the start point (the loop's own stop test) and the
+// last is one step further, so an axis advances at most L = ceil(sqrt(maxDist)) + 1 voxels (+1 below
+// for the rounding of the square root).  That box covers at most a few chunks.
+PLVS_HD bool walk_may_touch_owned(const Params& P, const RayCursor& c) {
+  const int L = (int)ceilf(sqrtf(c.maxDist)) + 2;
+  const int x1 = c.x + c.stepX * L, y1 = c.y + c.stepY * L, z1 = c.z + c.stepZ * L;
+  const int cx0 = (c.x < x1 ? c.x : x1) >> 4, cx1 = (c.x < x1 ? x1 : c.x) >> 4;
+  const int cy0 = (c.y < y1 ? c.y : y1) >> 4, cy1 = (c.y < y1 ? y1 : c.y) >> 4;
+  const int cz0 = (c.z < z1 ? c.z : z1) >> 4, cz1 = (c.z < z1 ? z1 : c.z) >> 4;
+  for (int cz = cz0; cz <= cz1; ++cz)
+    for (int cy = cy0; cy <= cy1; ++cy)
+      for (int cx = cx0; cx <= cx1; ++cx)
+        if (shard_of(chunk_hash(cx, cy, cz), P.shard_count) == P.shard_rank) return true;
+  return false;
+}
+
 // Emits the current voxel into (vx,vy,vz) and advances; false when the ray is exhausted.
 // Straight-line form of the loop body of Raycast.cpp:115-180 (selects instead of the if / else
 // ladder: on the GPU the ladder costs more exec-mask bookkeeping than arithmetic); the
