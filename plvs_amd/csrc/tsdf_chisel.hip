@@ -116,15 +116,17 @@ __global__ __launch_bounds__(256) void ray_count(
     int vx, vy, vz;
     int lcx = 0, lcy = 0, lcz = 0;  // last chunk seen by this ray
     bool have_last = false;
+    // one DDA step per trip for every lane (an early `continue` on rejected steps makes the compiler
+    // nest a skip loop in which the lanes of a wave wait for each other's rejected stretches)
     while (ray_next(&cur, &vx, &vy, &vz)) {
       Visit v;
-      if (!resolve_visit(P, pose, ray, vx, vy, vz, &v, &owner)) continue;
-      if (!have_last || v.cx != lcx || v.cy != lcy || v.cz != lcz) {
+      const bool ok = resolve_visit(P, pose, ray, vx, vy, vz, &v, &owner);
+      if (ok && (!have_last || v.cx != lcx || v.cy != lcy || v.cz != lcz)) {
         lcx = v.cx; lcy = v.cy; lcz = v.cz;
         have_last = true;
         dir_insert(dir, lcx, lcy, lcz, &ctr->num_chunks, &ctr->err);
       }
-      ++n;
+      n += ok ? 1u : 0u;
     }
   }
   counts[i] = n;
@@ -284,8 +286,8 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
     uint32_t nv = 0;
     while (nv < n_hi && ray_next(&cur, &vx, &vy, &vz)) {
       Visit v;
-      if (!resolve_visit(P, pose, ray, vx, vy, vz, &v, &owner)) continue;
-      if (nv >= n_lo) {
+      const bool ok = resolve_visit(P, pose, ray, vx, vy, vz, &v, &owner);   // no early continue: see ray_count
+      if (ok && nv >= n_lo) {
         if (!have_last || v.cx != lcx || v.cy != lcy || v.cz != lcz) {
           lcx = v.cx; lcy = v.cy; lcz = v.cz;
           have_last = true;
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
         su[s] = v.u;
         spt[s] = (uint16_t)(i - first);
       }
-      ++nv;
+      nv += ok ? 1u : 0u;
     }
     if (nv < n_hi) atomicOr(&ctr->err, kErrDirectoryMiss);   // the count pass saw more visits: cannot happen
   }
