@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256) void vb_ray_pass(
       for (int s = 0; s <= steps; ++s) {
         int g[3], b[3], vid;
         ray_step(&ray, g);
-        if (!block_of(P, g, b, &vid)) continue;
-        if (!have_last || b[0] != lb[0] || b[1] != lb[1] || b[2] != lb[2]) {
+        const bool ok = block_of(P, g, b, &vid);   // no early continue: every lane takes one step per trip
+        if (ok && (!have_last || b[0] != lb[0] || b[1] != lb[1] || b[2] != lb[2])) {
           lb[0] = b[0]; lb[1] = b[1]; lb[2] = b[2];
           have_last = true;
           if (kFill) {
@@ -93,11 +93,11 @@ __global__ __launch_bounds__(256) void vb_ray_pass(
               atomicOr(&ctr->err, kErrCoordRange);  // float block lookup left the integer grid
           }
         }
-        if (kFill && lslot >= 0) {
+        if (ok && kFill && lslot >= 0) {
           rec_keys[out + n] = (uint32_t)lslot * (uint32_t)kBlockVox + (uint32_t)vid;
           rec_seq[out + n] = (uint32_t)i;
         }
-        ++n;
+        n += ok ? 1u : 0u;
       }
     }
   }

@@ -116,13 +116,22 @@ PLVS_HD uint64_t owner_hash(int x, int y, int z) {
          ((uint64_t)(int64_t)z * 83492791ull);
 }
 
+// hash % count without a 64-bit division (count = number of GPUs: small, usually a power of two).
+PLVS_HD int shard_of(uint64_t h, int count) {
+  const uint32_t c = (uint32_t)count;
+  if ((c & (c - 1u)) == 0u) return (int)((uint32_t)h & (c - 1u));
+  const uint32_t hi = (uint32_t)(h >> 32) % c, lo = (uint32_t)h % c;
+  const uint32_t two32 = ((0xFFFFFFFFu % c) + 1u) % c;   // 2^32 mod c
+  return (int)(((unsigned long long)hi * two32 + lo) % c);
+}
+
 // getBlockIndexFromGlobalVoxelIndex + getLocalFromGlobalVoxelIndex.  Returns false
 // when the block belongs to another shard.
 PLVS_HD bool block_of(const Params& P, const int g[3], int b[3], int* vid) {
   b[0] = (int)floorf((float)g[0] * P.vps_inv);
   b[1] = (int)floorf((float)g[1] * P.vps_inv);
   b[2] = (int)floorf((float)g[2] * P.vps_inv);
-  if (P.shard_count > 1 && (int)(owner_hash(b[0], b[1], b[2]) % (uint64_t)P.shard_count) != P.shard_rank)
+  if (P.shard_count > 1 && shard_of(owner_hash(b[0], b[1], b[2]), P.shard_count) != P.shard_rank)
     return false;
   const uint32_t off = 1u << 31;
   const int lx = (int)(((uint32_t)g[0] + off) & 15u), ly = (int)(((uint32_t)g[1] + off) & 15u),
