@@ -124,7 +124,7 @@ def test_hip_batch_shards_and_errors(oracle):
     rgba = torch.from_numpy(np.concatenate([rgba_of(k) for k in kfs])).cuda()
     Twc = torch.from_numpy(np.stack([k["Twc"] for k in kfs])).cuda()
     offsets = np.cumsum([0] + [k["xyz"].shape[0] for k in kfs]).astype(np.int32)
-    for rank, count in ((0, 1), (0, 2), (1, 2)):
+    for rank, count in ((0, 1), (0, 2), (1, 2), (2, 3)):
         ora = oracle.voxblox(0.05, shard_rank=rank, shard_count=count)
         for k in kfs:
             ora.integrate(k["xyz"], rgba_of(k), k["Twc"])
