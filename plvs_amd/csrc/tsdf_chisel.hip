@@ -89,34 +89,16 @@ __global__ void pool_init(float* __restrict__ sdf, size_t n) {
   for (size_t j = i; j < n; j += stride) sdf[j] = 99999.0f;
 }
 
-// What the count pass learns about a ray, kept so that the tile pass replays the walk instead of
-// repeating its arithmetic (voxel centre -> camera frame, IEEE sqrt and divide per step): the start
-// voxel, the axis advanced after every emitted voxel, which emitted voxels take an update, and the
-// signed distance u of those.  Rays that emit more than kWalkLogSteps voxels are flagged and
-// re-walked by the tile pass as before.
-constexpr int kWalkLogSteps = 32;
-constexpr uint32_t kWalkNoReplay = 1u << 31;
-constexpr int kWalkBias = 1 << 20;   // voxel coordinates lie in (-2^20, 2^20): kVoxelCoordLimit
-struct WalkLog {
-  unsigned long long* start;   // (x + bias) | (y + bias) << 21 | (z + bias) << 42
-  unsigned long long* axes;    // 2 bits per emitted voxel: the axis advanced after it (3 = none)
-  uint32_t* accept;            // bit j: the j-th emitted voxel takes an update
-  uint32_t* meta;              // emitted voxels (bits 0-7) | step < 0 on x, y, z (bits 8-10) | kWalkNoReplay
-  float* u;                    // u of the a-th accepted voxel of point i at u[a * npoints + i]
-};
-
 // Stage 1: count the updating visits of each point and insert first-touch chunks.
 __global__ __launch_bounds__(256) void ray_count(
     Params P, const float* __restrict__ xyz, int npoints, const int32_t* __restrict__ offsets,
     int nclouds, const Pose* __restrict__ poses, Directory dir, Counters* __restrict__ ctr,
-    uint32_t* __restrict__ counts, WalkLog wlog) {
+    uint32_t* __restrict__ counts) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npoints) return;
   const Pose pose = poses[cloud_of(offsets, nclouds, i)];
   Ray ray;
   uint32_t n = 0;
-  unsigned long long w_start = 0, w_axes = 0;
-  uint32_t w_accept = 0, w_meta = 0;
   bool walk = make_ray(P, pose, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], &ray);
   if (walk && !ray_in_coord_range(ray)) {
     // beyond the range in which the integer chunk addressing equals the reference's float
@@ -131,16 +113,12 @@ __global__ __launch_bounds__(256) void ray_count(
     // on a shard most rays cannot reach a chunk of this rank: skip their walk (with two ranks
     // nearly every ray still can, the test would only cost)
     if (P.shard_count > 2 && !walk_may_touch_owned(P, cur)) cur.done = true;
-    int vx, vy, vz, axis;
+    int vx, vy, vz;
     int lcx = 0, lcy = 0, lcz = 0;  // last chunk seen by this ray
     bool have_last = false;
-    w_start = (unsigned long long)(uint32_t)(cur.x + kWalkBias) | ((unsigned long long)(uint32_t)(cur.y + kWalkBias) << 21) |
-              ((unsigned long long)(uint32_t)(cur.z + kWalkBias) << 42);
-    w_meta = (cur.stepX < 0 ? 0x100u : 0u) | (cur.stepY < 0 ? 0x200u : 0u) | (cur.stepZ < 0 ? 0x400u : 0u);
-    uint32_t emitted = 0;
     // one DDA step per trip for every lane (an early `continue` on rejected steps makes the compiler
     // nest a skip loop in which the lanes of a wave wait for each other's rejected stretches)
-    while (ray_next(&cur, &vx, &vy, &vz, &axis)) {
+    while (ray_next(&cur, &vx, &vy, &vz)) {
       Visit v;
       const bool ok = resolve_visit(P, pose, ray, vx, vy, vz, &v, &owner);
       if (ok && (!have_last || v.cx != lcx || v.cy != lcy || v.cz != lcz)) {
@@ -148,23 +126,10 @@ __global__ __launch_bounds__(256) void ray_count(
         have_last = true;
         dir_insert(dir, lcx, lcy, lcz, &ctr->num_chunks, &ctr->err);
       }
-      if (emitted < (uint32_t)kWalkLogSteps) {
-        w_axes |= (unsigned long long)axis << (2 * emitted);
-        w_accept |= (ok ? 1u : 0u) << emitted;
-        if (ok) wlog.u[(size_t)n * (size_t)npoints + (size_t)i] = v.u;
-      }
       n += ok ? 1u : 0u;
-      ++emitted;
     }
-    w_meta |= (emitted > (uint32_t)kWalkLogSteps) ? kWalkNoReplay : emitted;
   }
   counts[i] = n;
-  if (n != 0) {   // rays without visits are never looked at again
-    wlog.start[i] = w_start;
-    wlog.axes[i] = w_axes;
-    wlog.accept[i] = w_accept;
-    wlog.meta[i] = w_meta;
-  }
 }
 
 // ------------------------------------------------------------------ tiles
@@ -217,8 +182,7 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
     const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
     Counters* __restrict__ ctr, const uint32_t* __restrict__ voff, uint32_t V,
     const uint32_t* __restrict__ tile_first, uint32_t ntiles, uint32_t* __restrict__ ticket,
-    unsigned long long* __restrict__ tile_state, const uint32_t* __restrict__ rgbw, TileOut out,
-    WalkLog wlog) {
+    unsigned long long* __restrict__ tile_state, const uint32_t* __restrict__ rgbw, TileOut out) {
   __shared__ uint32_t skey[kTileSlots];     // voxel key of the visit in slot s
   __shared__ float su[kTileSlots];          // its signed distance u
   __shared__ uint16_t spt[kTileSlots];      // its point, relative to the tile's first point
@@ -307,42 +271,6 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
     const uint32_t o = voff[i], e = voff[i + 1];
     const uint32_t n_lo = (o < slot0) ? slot0 - o : 0u;       // visits before it belong to the previous tile
     const uint32_t n_hi = min(e, slot0 + n) - o;              // visits from it on to the next one
-    const uint32_t meta = wlog.meta[i];
-    if (!(meta & kWalkNoReplay)) {
-      // replay the walk the count pass logged: integer steps only, u read back
-      const unsigned long long st = wlog.start[i], ax = wlog.axes[i];
-      const uint32_t acc = wlog.accept[i];
-      int x = (int)(uint32_t)(st & 0x1FFFFFull) - kWalkBias, y = (int)(uint32_t)((st >> 21) & 0x1FFFFFull) - kWalkBias,
-          z = (int)(uint32_t)((st >> 42) & 0x1FFFFFull) - kWalkBias;
-      const int sx = (meta & 0x100u) ? -1 : 1, sy = (meta & 0x200u) ? -1 : 1, sz = (meta & 0x400u) ? -1 : 1;
-      const uint32_t emitted = meta & 0xFFu;
-      int lcx = 0, lcy = 0, lcz = 0, lslot = -1;
-      bool have_last = false;
-      uint32_t a = 0;
-      for (uint32_t j = 0; j < emitted && a < n_hi; ++j) {
-        const bool ok = (acc >> j) & 1u;
-        if (ok && a >= n_lo) {
-          const int cx = x >> 4, cy = y >> 4, cz = z >> 4;
-          if (!have_last || cx != lcx || cy != lcy || cz != lcz) {
-            lcx = cx; lcy = cy; lcz = cz;
-            have_last = true;
-            lslot = tile_find_chunk(dir, ckey, cslot, lcx, lcy, lcz);
-            if (lslot < 0) atomicOr(&ctr->err, kErrDirectoryMiss);
-          }
-          const uint32_t s = o + a - slot0;
-          skey[s] = (uint32_t)max(lslot, 0) * (uint32_t)kChunkVox + (uint32_t)(((z & 15) * 16 + (y & 15)) * 16 + (x & 15));
-          su[s] = wlog.u[(size_t)a * (size_t)npoints + (size_t)i];
-          spt[s] = (uint16_t)(i - first);
-        }
-        a += ok ? 1u : 0u;
-        const uint32_t axj = (uint32_t)(ax >> (2 * j)) & 3u;
-        x += (axj == 0u) ? sx : 0;
-        y += (axj == 1u) ? sy : 0;
-        z += (axj == 2u) ? sz : 0;
-      }
-      if (a < n_hi) atomicOr(&ctr->err, kErrDirectoryMiss);   // the log holds fewer visits than the count: cannot happen
-      continue;
-    }
     int cl = 0;
     while (cl + 1 < ncl && (int)i >= cl_off[cl + 1]) ++cl;
     if ((int)i >= cl_off[ncl]) cl = cloud_of(offsets, nclouds, (int)i) - cloud0;   // beyond the cached clouds
@@ -959,10 +887,6 @@ struct plvs_tsdf_chisel {
   DevBuf<float2> psum;   // order-free mode: partial sums per run
   DevBuf<unsigned long long> tile_state;   // [0]: ticket, [1..]: look-back state per tile
   DevBuf<Pose> poses;
-  // the walk log of the count pass (replayed by the tile pass)
-  DevBuf<unsigned long long> wl_start, wl_axes;
-  DevBuf<uint32_t> wl_accept, wl_meta;
-  DevBuf<float> wl_u;
   DevBuf<int32_t> offsets;
   // host-flavour staging
   DevBuf<float> st_xyz, st_Twc;
@@ -1095,7 +1019,6 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   h->heads.release(); h->updated.release(); h->scratch.release(); h->poses.release();
   h->offsets.release(); h->st_xyz.release(); h->st_Twc.release(); h->st_rgb.release();
   h->st_kfid.release();
-  h->wl_start.release(); h->wl_axes.release(); h->wl_accept.release(); h->wl_meta.release(); h->wl_u.release();
   delete h;
   return PLVS_OK;
 }
@@ -1153,14 +1076,8 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
 #define STAGE_MARK(i) \
   do { if (h->profiling) PLVS_HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
   STAGE_MARK(0);
-  PLVS_HIP_TRY(h->wl_start.reserve((size_t)n));
-  PLVS_HIP_TRY(h->wl_axes.reserve((size_t)n));
-  PLVS_HIP_TRY(h->wl_accept.reserve((size_t)n));
-  PLVS_HIP_TRY(h->wl_meta.reserve((size_t)n));
-  PLVS_HIP_TRY(h->wl_u.reserve((size_t)n * kWalkLogSteps));
-  const WalkLog wlog{h->wl_start.p, h->wl_axes.p, h->wl_accept.p, h->wl_meta.p, h->wl_u.p};
   hipLaunchKernelGGL(ray_count, dim3(ceil_div((size_t)n, 256)), dim3(256), 0, s, h->P, d_xyz, n,
-                     h->offsets.p, nclouds, h->poses.p, h->dir, h->d_ctr, h->counts.p, wlog);
+                     h->offsets.p, nclouds, h->poses.p, h->dir, h->d_ctr, h->counts.p);
   PLVS_KERNEL_CHECK();
   STAGE_MARK(1);
   // counts -> visit offsets (n + 1 entries: the total closes the list)
@@ -1224,12 +1141,12 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
       hipLaunchKernelGGL(ray_tiles<true>, dim3(ntiles), dim3(kTileThreads), 0, s, h->P, d_xyz, d_rgb, n,
                          h->offsets.p, nclouds, h->poses.p, h->dir, h->d_ctr, h->counts.p, V,
                          h->tile_first.p, ntiles, reinterpret_cast<uint32_t*>(h->tile_state.p),
-                         h->tile_state.p + 1, h->rgbw, out, wlog);
+                         h->tile_state.p + 1, h->rgbw, out);
     else
       hipLaunchKernelGGL(ray_tiles<false>, dim3(ntiles), dim3(kTileThreads), 0, s, h->P, d_xyz, d_rgb, n,
                          h->offsets.p, nclouds, h->poses.p, h->dir, h->d_ctr, h->counts.p, V,
                          h->tile_first.p, ntiles, reinterpret_cast<uint32_t*>(h->tile_state.p),
-                         h->tile_state.p + 1, h->rgbw, out, wlog);
+                         h->tile_state.p + 1, h->rgbw, out);
   }
   PLVS_KERNEL_CHECK();
   STAGE_MARK(3);

@@ -244,9 +244,7 @@ PLVS_HD bool walk_may_touch_owned(const Params& P, const RayCursor& c) {
 // Straight-line form of the loop body of Raycast.cpp:115-180 (selects instead of the if / else
 // ladder: on the GPU the ladder costs more exec-mask bookkeeping than arithmetic); the
 // comparisons, their order and the one addition per step are the reference's.
-// *axis (optional): the axis the walk advanced along after emitting this voxel (0, 1, 2), 3 = none
-// (the emitted voxel is the last one).
-PLVS_HD bool ray_next(RayCursor* c, int* vx, int* vy, int* vz, int* axis = nullptr) {
+PLVS_HD bool ray_next(RayCursor* c, int* vx, int* vy, int* vz) {
   if (c->done) return false;
   *vx = c->x; *vy = c->y; *vz = c->z;
   // (the reference's bounds test against -/+INT_MAX only rejects INT_MAX itself)
@@ -264,7 +262,6 @@ PLVS_HD bool ray_next(RayCursor* c, int* vx, int* vy, int* vz, int* axis = nullp
   c->tMaxZ = go_z ? c->tMaxZ + c->tDeltaZ : c->tMaxZ;
   c->guard += stop ? 0 : 1;
   c->done = stop | (c->guard >= kRayStepGuard);
-  if (axis != nullptr) *axis = go_x ? 0 : (go_y ? 1 : (go_z ? 2 : 3));
   return true;
 }
 
