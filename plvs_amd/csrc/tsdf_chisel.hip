@@ -151,20 +151,9 @@ __global__ __launch_bounds__(256) void ray_count(
 //
 // Run descriptors are numbered across tiles by a decoupled look-back over tile_state (tile
 // ids are tickets, so a tile only ever waits for tiles that already started).
-// The point (global index) whose ray produced the visit in slot s of the tile.
-__device__ __forceinline__ uint32_t tile_point_of(bool wide, const uint32_t* __restrict__ voff, uint32_t first,
-                                                  uint32_t last, uint32_t slot0, const uint16_t* spt, uint32_t s) {
-  if (!wide) return first + spt[s];
-  const uint32_t g = slot0 + s;          // the visit's global number: voff[i] <= g < voff[i + 1]
-  uint32_t lo = first, hi = last + 1;    // voff[lo] <= g < voff[hi]
-  while (hi - lo > 1) {
-    const uint32_t mid = lo + (hi - lo) / 2;
-    if (voff[mid] <= g) lo = mid; else hi = mid;
-  }
-  return lo;
-}
-
 struct TileOut {
+  float2* vis;          // [V] per visit, in slot order: (u, point index as bits) — kept out of LDS so that
+                        // three tiles fit a CU
   float2* rec_t;        // [V] operands, tile-grouped
   uint32_t* recc_t;     // [V] colours, tile-grouped
   uint32_t* dkey;       // run descriptors: voxel key,
@@ -177,15 +166,13 @@ struct TileOut {
 };
 
 template <bool kOrderFree>
-__global__ __launch_bounds__(kTileThreads) void ray_tiles(
+__global__ __launch_bounds__(kTileThreads, 6) void ray_tiles(
     Params P, const float* __restrict__ xyz, const uint8_t* __restrict__ rgb, int npoints,
     const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
     Counters* __restrict__ ctr, const uint32_t* __restrict__ voff, uint32_t V,
     const uint32_t* __restrict__ tile_first, uint32_t ntiles, uint32_t* __restrict__ ticket,
     unsigned long long* __restrict__ tile_state, const uint32_t* __restrict__ rgbw, TileOut out) {
   __shared__ uint32_t skey[kTileSlots];     // voxel key of the visit in slot s
-  __shared__ float su[kTileSlots];          // its signed distance u
-  __shared__ uint16_t spt[kTileSlots];      // its point, relative to the tile's first point
   __shared__ uint32_t bufA[kTileSlots];     // tags: group table entry << 12 | slot; sorted in place
   __shared__ uint32_t bufB[kTileSlots];     // the group hash table, then the sort's second buffer, then run heads
   __shared__ uint32_t wave_hist[kTileThreads / 64][kTileRadix];
@@ -260,9 +247,6 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
   }
   __syncthreads();
   const uint32_t nrays = sh_base;
-  // spt holds a point relative to `first` in 16 bits; a tile that spans more (long stretches
-  // without visits) recovers the point of a visit from voff instead (tile_point_of)
-  const bool wide = (last - first) > 0xFFFFu;
   __syncthreads();   // sh_base is reused by the look-back
 
   // ---- phase 1b: the visits of this tile, in slot (= point, then ray) order
@@ -296,8 +280,7 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
         }
         const uint32_t s = o + nv - slot0;
         skey[s] = (uint32_t)max(lslot, 0) * (uint32_t)kChunkVox + (uint32_t)v.vid;
-        su[s] = v.u;
-        spt[s] = (uint16_t)(i - first);
+        out.vis[slot0 + s] = make_float2(v.u, __uint_as_float(i));
       }
       nv += ok ? 1u : 0u;
     }
@@ -333,7 +316,7 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
       if (g < ngroups) {
         const uint32_t tag = bufA[hp[g]];
         g_key[m] = skey[tag & 0xFFFu];
-        g_last[m] = tile_point_of(wide, voff, first, last, slot0, spt, bufA[hp[g + 1] - 1] & 0xFFFu);
+        g_last[m] = __float_as_uint(out.vis[slot0 + (bufA[hp[g + 1] - 1] & 0xFFFu)].y);
         if ((rgbw[g_key[m]] >> 24) >= 254u) atomicOr(&saturated[tag >> 17], 1u << ((tag >> 12) & 31u));
       }
     }
@@ -346,18 +329,19 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
       if (j < n) {
         const uint32_t tag = bufA[j];
         const uint32_t s = tag & 0xFFFu;
-        const size_t p = tile_point_of(wide, voff, first, last, slot0, spt, s);
+        const float2 vv = out.vis[slot0 + s];
+        const size_t p = __float_as_uint(vv.y);
         const float tr = truncation_of(P, xyz[3 * p + 2]);
         const float wu = P.weight / (2.0f * tr);
-        v_wuu[k] = wu * su[s];
+        v_wuu[k] = wu * vv.x;
         v_wu[k] = wu;
         if (!((saturated[tag >> 17] >> ((tag >> 12) & 31u)) & 1u))
           out.recc_t[slot0 + j] = colour_roundtrip(rgb[3 * p + 0]) | (colour_roundtrip(rgb[3 * p + 1]) << 8) |
                                   (colour_roundtrip(rgb[3 * p + 2]) << 16);
       }
     }
-    __syncthreads();   // su / skey are free now: they take the per-position operands
-    float* const a_wuu = su;
+    __syncthreads();   // the tags (bufA) and skey are free now: they take the per-position operands
+    float* const a_wuu = reinterpret_cast<float*>(bufA);
     float* const a_wu = reinterpret_cast<float*>(skey);
 #pragma unroll
     for (int k = 0; k < kTileItems; ++k) {
@@ -394,10 +378,11 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
     const uint32_t j = tid + k * kTileThreads;
     if (j < n) {
       const uint32_t s = bufA[j] & 0xFFFu;
-      const size_t p = tile_point_of(wide, voff, first, last, slot0, spt, s);
+      const float2 vv = out.vis[slot0 + s];
+      const size_t p = __float_as_uint(vv.y);
       const float tr = truncation_of(P, xyz[3 * p + 2]);
       const float wu = P.weight / (2.0f * tr);
-      out.rec_t[slot0 + j] = make_float2(wu * su[s], wu);
+      out.rec_t[slot0 + j] = make_float2(wu * vv.x, wu);
       out.recc_t[slot0 + j] = colour_roundtrip(rgb[3 * p + 0]) | (colour_roundtrip(rgb[3 * p + 1]) << 8) |
                               (colour_roundtrip(rgb[3 * p + 2]) << 16);
     }
@@ -414,7 +399,7 @@ __global__ __launch_bounds__(kTileThreads) void ray_tiles(
     const uint32_t d = dbase + g;
     out.dkey[d] = skey[bufA[p0] & 0xFFFu];
     out.dval[d] = (unsigned long long)(slot0 + p0) | ((unsigned long long)(p1 - p0) << 32);
-    out.last_pt[slot0 + p0] = tile_point_of(wide, voff, first, last, slot0, spt, bufA[p1 - 1] & 0xFFFu);
+    out.last_pt[slot0 + p0] = __float_as_uint(out.vis[slot0 + (bufA[p1 - 1] & 0xFFFu)].y);
   }
   }
   TILE_PROBE(6)
@@ -1114,6 +1099,7 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   PLVS_HIP_TRY(h->updated.reserve((size_t)h->num_chunks + 1));
   if (order_free) {
     PLVS_HIP_TRY(h->psum.reserve(V));
+    PLVS_HIP_TRY(h->rec_t.reserve(V));    // order-free mode: the per-visit (u, point) array of the tile pass
     PLVS_HIP_TRY(h->recc_t.reserve(V));
     PLVS_HIP_TRY(h->didx0.reserve(V));
     PLVS_HIP_TRY(h->last_pt.reserve(V));
@@ -1135,7 +1121,8 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   hipLaunchKernelGGL(mark_tiles, dim3(ceil_div((size_t)n, 256)), dim3(256), 0, s, h->counts.p, n,
                      h->tile_first.p);
   {
-    TileOut out{h->rec_t.p, h->recc_t.p, h->dkey0.p, h->didx0.p, h->last_pt.p,
+    // per-visit (u, point): the buffer the gather fills later (ordered) / the unused operand buffer (order-free)
+    TileOut out{order_free ? h->rec_t.p : h->rec.p, h->rec_t.p, h->recc_t.p, h->dkey0.p, h->didx0.p, h->last_pt.p,
                 h->psum.p};
     if (order_free)
       hipLaunchKernelGGL(ray_tiles<true>, dim3(ntiles), dim3(kTileThreads), 0, s, h->P, d_xyz, d_rgb, n,
