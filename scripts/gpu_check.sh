@@ -27,7 +27,7 @@ if [[ "$STAGES" == *vbx* ]]; then
   echo "bench voxblox done $(date +%T)" >> "$O/stages.log"
 fi
 if [[ "$STAGES" == *sweep* ]]; then
-  for B in 1 5 10 50 100; do
+  for B in 1 5 10 25 50 100; do
     ( timeout 200 python bench.py --batch $B --no-cpu-baseline --no-frontend 2>&1 | tail -1 ) >> "$O/sweep.log" 2>&1
   done
   echo "sweep done $(date +%T)" >> "$O/stages.log"
