@@ -106,13 +106,13 @@ __global__ __launch_bounds__(256) void ray_count(
     atomicOr(&ctr->err, kErrCoordRange);
     walk = false;
   }
+  // on a shard most rays cannot reach a chunk of this rank: skip their set-up and walk (with two
+  // ranks nearly every ray still can, the test would only cost)
+  if (walk && P.shard_count > 2 && !walk_may_touch_owned(P, ray)) walk = false;
   if (walk) {
     RayCursor cur;
     OwnerCache owner;
     ray_begin(ray, &cur);
-    // on a shard most rays cannot reach a chunk of this rank: skip their walk (with two ranks
-    // nearly every ray still can, the test would only cost)
-    if (P.shard_count > 2 && !walk_may_touch_owned(P, cur)) cur.done = true;
     int vx, vy, vz;
     int lcx = 0, lcy = 0, lcz = 0;  // last chunk seen by this ray
     bool have_last = false;

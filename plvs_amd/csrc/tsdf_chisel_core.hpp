@@ -227,12 +227,17 @@ PLVS_HD void ray_begin(const Ray& r, RayCursor* c) {
 // voxel but the last is within sqrt(maxDist) of the start point (the loop's own stop test) and the
 // last is one step further, so an axis advances at most L = ceil(sqrt(maxDist)) + 1 voxels (+1 below
 // for the rounding of the square root).  That box covers at most a few chunks.
-PLVS_HD bool walk_may_touch_owned(const Params& P, const RayCursor& c) {
-  const int L = (int)ceilf(sqrtf(c.maxDist)) + 2;
-  const int x1 = c.x + c.stepX * L, y1 = c.y + c.stepY * L, z1 = c.z + c.stepZ * L;
-  const int cx0 = (c.x < x1 ? c.x : x1) >> 4, cx1 = (c.x < x1 ? x1 : c.x) >> 4;
-  const int cy0 = (c.y < y1 ? c.y : y1) >> 4, cy1 = (c.y < y1 ? y1 : c.y) >> 4;
-  const int cz0 = (c.z < z1 ? c.z : z1) >> 4, cz1 = (c.z < z1 ? z1 : c.z) >> 4;
+PLVS_HD bool walk_may_touch_owned(const Params& P, const Ray& r) {
+  // start voxel, step signs and stop distance exactly as ray_begin derives them (without its divisions)
+  const int x = (int)floorf(r.start[0]), y = (int)floorf(r.start[1]), z = (int)floorf(r.start[2]);
+  const int sx = rc_signum((int)floorf(r.end[0]) - x), sy = rc_signum((int)floorf(r.end[1]) - y),
+            sz = rc_signum((int)floorf(r.end[2]) - z);
+  const float maxDist = sqnorm3(r.end[0] - r.start[0], r.end[1] - r.start[1], r.end[2] - r.start[2]);
+  const int L = (int)ceilf(sqrtf(maxDist)) + 2;
+  const int x1 = x + sx * L, y1 = y + sy * L, z1 = z + sz * L;
+  const int cx0 = (x < x1 ? x : x1) >> 4, cx1 = (x < x1 ? x1 : x) >> 4;
+  const int cy0 = (y < y1 ? y : y1) >> 4, cy1 = (y < y1 ? y1 : y) >> 4;
+  const int cz0 = (z < z1 ? z : z1) >> 4, cz1 = (z < z1 ? z1 : z) >> 4;
   for (int cz = cz0; cz <= cz1; ++cz)
     for (int cy = cy0; cy <= cy1; ++cy)
       for (int cx = cx0; cx <= cx1; ++cx)
