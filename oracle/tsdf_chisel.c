@@ -747,3 +747,17 @@ int oracle_chisel_mesh_chunk(const oracle_chisel* o, int cx, int cy, int cz, flo
   for (int i = 0; i < n; i++) mesh_gradient_normal(o, vertices + 3 * (size_t)i, normals + 3 * (size_t)i);    /* :163 */
   return m.n;
 }
+
+/* Test hook (no counterpart in the reference): overwrite / create one chunk with given voxel payloads, so
+ * that the meshing restatement can be checked on analytic distance fields. */
+void oracle_chisel_set_chunk(oracle_chisel* o, int cx, int cy, int cz, const float* sdf, const float* weight,
+                             const uint32_t* kfid, const uint32_t* rgbw) {
+  const int32_t id[3] = {cx, cy, cz};
+  int found = 0;
+  chunk_t* c = tab_find(o->tab, o->cap, id, &found);
+  if (!found) c = chunk_create(o, id);
+  memcpy(c->sdf, sdf, CHUNK_VOX * sizeof(float));
+  memcpy(c->weight, weight, CHUNK_VOX * sizeof(float));
+  memcpy(c->kfid, kfid, CHUNK_VOX * sizeof(uint32_t));
+  memcpy(c->rgbw, rgbw, CHUNK_VOX * sizeof(uint32_t));
+}

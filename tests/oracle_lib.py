@@ -327,6 +327,15 @@ class _ChiselLike:
               _ptr(ids))
         return n, ids[:n]
 
+    def set_chunk(self, cx, cy, cz, sdf, weight, kfid, rgbw):
+        """Test hook: overwrite / create a chunk (4096 voxels, id = (z * 16 + y) * 16 + x)  (oracle only)."""
+        f = getattr(self.lib, self.p + "_set_chunk")
+        f.restype = None
+        f.argtypes = [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]
+        a = [np.ascontiguousarray(sdf, np.float32).reshape(4096), np.ascontiguousarray(weight, np.float32).reshape(4096),
+             np.ascontiguousarray(kfid, np.uint32).reshape(4096), np.ascontiguousarray(rgbw, np.uint32).reshape(4096)]
+        f(self.h, int(cx), int(cy), int(cz), *[_ptr(x) for x in a])
+
     def mesh_chunk(self, cx, cy, cz):
         """ChunkManager::RecomputeMesh of one chunk -> (vertices, normals, colors [n,3] f32, kfids [n] u32)
         (oracle only)."""

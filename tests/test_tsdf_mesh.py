@@ -45,6 +45,61 @@ def test_oracle_mesh_lies_on_the_scene_surface(oracle):
     assert len(m.mesh_chunk(1000, 1000, 1000)[0]) == 0
 
 
+def test_oracle_mesh_of_an_analytic_sphere(oracle):
+    """The meshing restatement on a distance field with a known answer: a sphere of radius 0.55 m sampled
+    into a 2 x 2 x 2 block of chunks (res 0.05).  The extracted surface must be the sphere: vertices on it,
+    closed, consistently oriented (every directed edge has its reverse exactly once), genus 0, normals
+    radial and pointing along the gradient, colours interpolated from the stored voxel colours."""
+    res, r = 0.05, 0.55
+    centre = np.array([0.8, 0.8, 0.8])
+    m = oracle.chisel(res)
+    idx = np.arange(16)
+    for cx in range(2):
+        for cy in range(2):
+            for cz in range(2):
+                X, Y, Z = np.meshgrid(idx + 16 * cx, idx + 16 * cy, idx + 16 * cz, indexing="ij")   # [x, y, z]
+                pts = np.stack([X, Y, Z], -1) * res + res / 2
+                sdf = np.linalg.norm(pts - centre, axis=-1) - r                         # > 0 outside
+                # voxel id = (z * 16 + y) * 16 + x  -> array indexed [z, y, x]
+                sdf_zyx = np.transpose(sdf, (2, 1, 0)).astype(np.float32)
+                rgbw = np.full(4096, 200 | (100 << 8) | (50 << 16) | (254 << 24), np.uint32)
+                m.set_chunk(cx, cy, cz, sdf_zyx, np.ones(4096, np.float32), np.full(4096, 9, np.uint32), rgbw)
+    V, N, C, K = [], [], [], []
+    for cx in range(2):
+        for cy in range(2):
+            for cz in range(2):
+                v, n, c, k = m.mesh_chunk(cx, cy, cz)
+                V.append(v); N.append(n); C.append(c); K.append(k)
+    v, n, c, k = np.concatenate(V), np.concatenate(N), np.concatenate(C), np.concatenate(K)
+    assert len(v) % 3 == 0 and len(v) > 3000 and (k == 9).all()
+    # on the sphere (linear interpolation of a distance field: second-order error)
+    d = np.linalg.norm(v.astype(np.float64) - centre, axis=1)
+    assert np.abs(d - r).max() < 0.15 * res
+    # closed and consistently oriented
+    key = np.round(v.astype(np.float64) / (res * 1e-3)).astype(np.int64)
+    _, vid = np.unique(key, axis=0, return_inverse=True)
+    tri = vid.reshape(-1, 3)
+    tri = tri[(tri[:, 0] != tri[:, 1]) & (tri[:, 1] != tri[:, 2]) & (tri[:, 0] != tri[:, 2])]     # degenerate slivers
+    edges = np.concatenate([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]])
+    fwd = {}
+    for a, b in edges:
+        fwd[(a, b)] = fwd.get((a, b), 0) + 1
+    assert all(cnt == 1 for cnt in fwd.values()), "a directed edge is used twice: inconsistent orientation"
+    assert all((b, a) in fwd for (a, b) in fwd), "the surface is not closed"
+    nv, ne, nf = len(np.unique(tri)), len(fwd) // 2, len(tri)
+    assert nv - ne + nf == 2, "Euler characteristic of a sphere"
+    # triangle winding (p1 - p0) x (p2 - p0) and the stored gradient normal agree with the outward radial direction
+    p = v.reshape(-1, 3, 3).astype(np.float64)
+    geo = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+    radial = p.mean(axis=1) - centre
+    keep = np.linalg.norm(geo, axis=1) > 1e-9
+    assert (np.einsum("ij,ij->i", geo[keep], radial[keep]) > 0).all()
+    rad_v = (v - centre) / np.linalg.norm(v - centre, axis=1, keepdims=True)
+    assert (np.einsum("ij,ij->i", n.astype(np.float64), rad_v) > 0.9).all()
+    # colours: every voxel stores (200, 100, 50); the look-up quirk falls back to the nearest voxel -> exact
+    assert np.allclose(c, np.array([200, 100, 50]) / 255.0, atol=1e-6)
+
+
 def _neighbourhood(ids):
     s = set()
     for cid in ids:
