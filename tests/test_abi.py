@@ -42,3 +42,22 @@ def test_product_package_has_no_oracle_dependency():
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "liboracle" not in txt and "oracle_lib" not in txt and "oracle/" not in txt, \
                     f"{os.path.join(dirpath, f)} references the oracle"
+
+
+def test_header_is_plain_c_and_links():
+    """The boundary is a C ABI: the header must compile as C99 (and C++11) with no other include path, and a C
+    program calling it must link against the library (no torch / C++ types in the signatures)."""
+    import subprocess
+    import tempfile
+    src = '#include "plvs_hip.h"\nint main(void) { return plvs_hip_abi_version() == 1 ? 0 : 1; }\n'
+    inc = os.path.join(ROOT, "include")
+    lib_dir = os.path.join(ROOT, "plvs_amd", "lib")
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "abi.c")
+        open(c, "w").write(src)
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-c", c, "-o",
+                        os.path.join(d, "abi_c.o")], check=True)
+        subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-I", inc, "-x", "c++", "-c", c, "-o",
+                        os.path.join(d, "abi_cpp.o")], check=True)
+        subprocess.run(["gcc", os.path.join(d, "abi_c.o"), "-L", lib_dir, "-l:libplvs_hip.so",
+                        "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", os.path.join(d, "abi")], check=True)
