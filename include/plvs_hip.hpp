@@ -1,0 +1,405 @@
+// C++ host-side mirror of the PLVS interfaces that the hot path hides behind (header only, C++14).
+//
+// plvs_hip.h is the boundary (C ABI).  This header is what a PLVS translation unit includes to keep
+// its own class names, argument meaning and error behaviour while the arithmetic runs in
+// libplvs_hip.so.  The reference classes take cv::Mat / pcl::PointCloud / Sophus::SE3f; OpenCV,
+// PCL, Eigen and Sophus are not part of this repository, so the mirror takes the plain views of
+// those types defined below (same memory layout as the originals: a PLVS build passes
+// mat.data / mat.step, cloud.points.data(), Twc.matrix3x4().data() — see INTEGRATION.md).
+//
+//   PLVS2hip::ORBextractor              include/ORBextractor.h:76-113, src/ORBextractor.cc:446, :1245
+//   PLVS2hip::LineExtractor             include/LineExtractor.h:48-83, src/LineExtractor.cc:150, :170
+//   PLVS2hip::BinaryDescriptorMatcher   binary_descriptor_matcher_custom.cpp:258
+//   PLVS2hip::ORBmatcher                include/ORBmatcher.h:64 (DescriptorDistance)
+//   PLVS2hip::ComputeStereoMatches      src/Frame.cc:1780
+//   PLVS2hip::PointCloudGenerator       src/PointCloudMapping.cc:796, :929
+//   PLVS2hip::PointCloudMapChisel       include/PointCloudMapChisel.h:61, src/PointCloudMapChisel.cc:76-246
+//   PLVS2hip::PointCloudMapVoxblox      include/PointCloudMapVoxblox.h:54, src/PointCloudMapVoxblox.cc:81
+//
+// Errors of the library surface as std::runtime_error carrying plvs_hip_last_error(); there is no
+// CPU fallback anywhere.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "plvs_hip.h"
+
+namespace PLVS2hip {
+
+inline void check(int rc) {
+  if (rc != PLVS_OK) throw std::runtime_error(std::string("plvs_hip: ") + plvs_hip_last_error());
+}
+
+// ---- views of the reference's argument types
+struct Image8U {      // cv::Mat of type CV_8UC1 (or CV_8UC3 for colour): rows, cols, step, data
+  int rows = 0, cols = 0;
+  size_t step = 0;
+  const uint8_t* data = nullptr;
+  bool empty() const { return data == nullptr || rows <= 0 || cols <= 0; }
+};
+struct Image32F {     // cv::Mat of type CV_32FC1 (depth)
+  int rows = 0, cols = 0;
+  size_t step = 0;    // bytes, like cv::Mat::step
+  const float* data = nullptr;
+};
+using KeyPoint = plvs_keypoint;             // cv::KeyPoint, field for field
+using KeyLine = plvs_keyline;               // cv::line_descriptor_c::KeyLine
+using PointSurfelSegment = plvs_point_surfel;   // pcl::PointSurfelSegment, 48 bytes
+struct DMatch {                             // cv::DMatch
+  int queryIdx = -1, trainIdx = -1, imgIdx = 0;
+  float distance = 0.f;
+};
+struct SE3f {                               // Sophus::SE3f as the 3x4 row-major [R|t] the integrators read
+  float m[12];
+};
+
+// ------------------------------------------------------------------------------------ ORB
+class ORBextractor {
+ public:
+  ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST) : nfeatures_(nfeatures) {
+    check(plvs_hip_orb_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, &h_));
+  }
+  ~ORBextractor() { plvs_hip_orb_destroy(h_); }
+  ORBextractor(const ORBextractor&) = delete;
+  ORBextractor& operator=(const ORBextractor&) = delete;
+
+  // int operator()(InputArray image, InputArray mask /*ignored*/, vector<KeyPoint>&, OutputArray descriptors,
+  //                vector<int>& vLappingArea): returns monoIndex, -1 on an empty image (ORBextractor.cc:1254).
+  int operator()(const Image8U& image, std::vector<KeyPoint>& keypoints, std::vector<uint8_t>& descriptors,
+                 const std::vector<int>& vLappingArea = {0, 0}) {
+    keypoints.clear();
+    descriptors.clear();
+    if (image.empty()) return -1;
+    int cap = 2 * nfeatures_ + 1024, n = 0, mono = 0;
+    for (;;) {
+      keypoints.resize((size_t)cap);
+      descriptors.resize((size_t)cap * 32);
+      const int lap0 = vLappingArea.size() > 0 ? vLappingArea[0] : 0, lap1 = vLappingArea.size() > 1 ? vLappingArea[1] : 0;
+      const int rc = plvs_hip_orb_extract(h_, image.data, image.cols, image.rows, (int)image.step, lap0, lap1,
+                                          keypoints.data(), descriptors.data(), cap, &n, &mono);
+      if (rc == PLVS_ERR_EMPTY) { keypoints.clear(); descriptors.clear(); return -1; }
+      check(rc);
+      if (n > cap) { cap = n; continue; }   // nothing was written: call again with room for n
+      break;
+    }
+    keypoints.resize((size_t)n);
+    descriptors.resize((size_t)n * 32);
+    return mono;
+  }
+  int GetLevels() { return plvs_hip_orb_get_levels(h_); }
+  float GetScaleFactor() { return plvs_hip_orb_get_scale_factor(h_); }
+  std::vector<float> GetScaleFactors() { return table(0); }
+  std::vector<float> GetInverseScaleFactors() { return table(1); }
+  std::vector<float> GetScaleSigmaSquares() { return table(2); }
+  std::vector<float> GetInverseScaleSigmaSquares() { return table(3); }
+  plvs_orb* handle() { return h_; }
+
+ private:
+  std::vector<float> table(int which) {
+    const int n = GetLevels();
+    std::vector<float> t[4];
+    for (auto& v : t) v.resize((size_t)n);
+    check(plvs_hip_orb_get_scale_tables(h_, t[0].data(), t[1].data(), t[2].data(), t[3].data()));
+    return t[which];
+  }
+  plvs_orb* h_ = nullptr;
+  int nfeatures_;
+};
+
+// ------------------------------------------------------------------------------------ lines
+struct LSDOptions {   // the fields of LSDDetectorC::LSDOptions the EDLines path reads (LineExtractor.cc:104-145)
+  int numOctaves = 3;
+  float scale = 1.2f;
+  double min_length = 0.02;
+  double lineFitErrThreshold = 1.6;
+};
+
+class LineExtractor {
+ public:
+  LineExtractor(int numLinefeatures, const LSDOptions& opts = LSDOptions()) {
+    check(plvs_hip_lines_create(numLinefeatures, opts.numOctaves, opts.scale, opts.min_length, opts.lineFitErrThreshold, &h_));
+  }
+  ~LineExtractor() { plvs_hip_lines_destroy(h_); }
+  LineExtractor(const LineExtractor&) = delete;
+  LineExtractor& operator=(const LineExtractor&) = delete;
+
+  // void operator()(const cv::Mat& image, std::vector<KeyLine>& keylines, cv::Mat& descriptors): empty outputs
+  // (after "no lines!") when nothing is found, LineExtractor.cc:269-273.
+  void operator()(const Image8U& image, std::vector<KeyLine>& keylines, std::vector<uint8_t>& descriptors) {
+    int cap = 4096, n = 0;
+    keylines.resize((size_t)cap);
+    descriptors.resize((size_t)cap * 32);
+    check(plvs_hip_lines_extract(h_, image.data, image.cols, image.rows, (int)image.step, keylines.data(),
+                                 descriptors.data(), cap, &n));
+    keylines.resize((size_t)n);
+    descriptors.resize((size_t)n * 32);
+  }
+  // SetGaussianPyramid(mpORBextractor->mvImagePyramid, levels, scale) of Frame::PrecomputeGaussianPyramid: the
+  // pyramid stays on the device, so the extractor itself is handed over (nullptr = own pyramid again).
+  void SetGaussianPyramid(ORBextractor* orb) { check(plvs_hip_lines_set_gaussian_pyramid(h_, orb ? orb->handle() : nullptr)); }
+  plvs_lines* handle() { return h_; }
+
+ private:
+  plvs_lines* h_ = nullptr;
+};
+
+// ------------------------------------------------------------------------------------ matching
+class BinaryDescriptorMatcher {
+ public:
+  // knnMatch(query, train, matches, k, mask, compactResult), k = 2 as LineMatcher calls it; query / train are
+  // N x 32 byte rows.  Masked-out queries give an empty entry, dropped when compactResult.
+  void knnMatch(const uint8_t* query, int nq, const uint8_t* train, int nt, std::vector<std::vector<DMatch>>& matches,
+                int k = 2, const uint8_t* mask = nullptr, bool compactResult = false) const {
+    matches.clear();
+    if (k != 2) throw std::invalid_argument("BinaryDescriptorMatcher::knnMatch: only k = 2 is on the accelerated path");
+    if (nq <= 0 || nt <= 0) return;   // "empty query or train descriptors", :263-266
+    std::vector<int32_t> idx((size_t)2 * nq), dist((size_t)2 * nq);
+    check(plvs_hip_hamming_knn2(query, nq, train, nt, mask, PLVS_TIE_MIH, idx.data(), dist.data()));
+    for (int q = 0; q < nq; ++q) {
+      std::vector<DMatch> row;
+      for (int j = 0; j < 2; ++j)
+        if (idx[2 * q + j] >= 0) {
+          DMatch m;
+          m.queryIdx = q;
+          m.trainIdx = idx[2 * q + j];
+          m.distance = (float)dist[2 * q + j];
+          row.push_back(m);
+        }
+      if (!(compactResult && (mask != nullptr && mask[q] == 0))) matches.push_back(row);
+    }
+  }
+};
+
+struct ORBmatcher {
+  static constexpr int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 12;
+  static int DescriptorDistance(const uint8_t* a, const uint8_t* b) {
+    const int32_t z = 0;
+    int32_t d = 0;
+    check(plvs_hip_hamming_pairs(a, 1, b, 1, &z, &z, 1, &d));
+    return d;
+  }
+};
+
+// Frame::ComputeStereoMatches: mvuRight / mvDepth of the left keypoints (-1 = none).
+inline void ComputeStereoMatches(ORBextractor& left, ORBextractor& right, const std::vector<KeyPoint>& mvKeys,
+                                 const std::vector<uint8_t>& mDescriptors, const std::vector<KeyPoint>& mvKeysRight,
+                                 const std::vector<uint8_t>& mDescriptorsRight, float mb, float mbf,
+                                 std::vector<float>& mvuRight, std::vector<float>& mvDepth) {
+  plvs_stereo* s = nullptr;
+  check(plvs_hip_stereo_create(left.handle(), right.handle(), &s));
+  mvuRight.assign(mvKeys.size(), -1.0f);
+  mvDepth.assign(mvKeys.size(), -1.0f);
+  int n = 0;
+  const int rc = plvs_hip_stereo_matches(s, mvKeys.data(), mDescriptors.data(), (int)mvKeys.size(), mvKeysRight.data(),
+                                         mDescriptorsRight.data(), (int)mvKeysRight.size(), mb, mbf, mvuRight.data(),
+                                         mvDepth.data(), &n);
+  plvs_hip_stereo_destroy(s);
+  check(rc);
+}
+
+// ------------------------------------------------------------------------------------ depth -> cloud
+class PointCloudGenerator {   // PointCloudMapping::InitCamGridPoints + GeneratePointCloudInCameraFrameBGRA
+ public:
+  // matCamGridPoints: N x 2 floats after InitCamGridPoints, or empty for an undistorted camera (computed here)
+  PointCloudGenerator(int width, int height, int downsampleStep, double fx, double fy, double cx, double cy,
+                      double minDepth, double maxDepth, std::vector<float> matCamGridPoints = {})
+      : w_(width), h_img_(height), min_(minDepth), max_(maxDepth) {
+    ngrid_ = plvs_hip_cloudgen_num_grid_points(width, height, downsampleStep);
+    if (matCamGridPoints.empty()) {
+      matCamGridPoints.resize((size_t)2 * ngrid_);
+      check(plvs_hip_cloudgen_grid_points(width, height, downsampleStep, fx, fy, cx, cy, matCamGridPoints.data()));
+    }
+    check(plvs_hip_cloudgen_create(width, height, downsampleStep, matCamGridPoints.data(), &h_));
+  }
+  ~PointCloudGenerator() { plvs_hip_cloudgen_destroy(h_); }
+  PointCloudGenerator(const PointCloudGenerator&) = delete;
+  PointCloudGenerator& operator=(const PointCloudGenerator&) = delete;
+
+  std::vector<PointSurfelSegment> GeneratePointCloudInCameraFrameBGRA(uint32_t kfid, const Image8U& color,
+                                                                      const Image32F& depth,
+                                                                      std::vector<int32_t>* pixelToPointIndex = nullptr) {
+    std::vector<PointSurfelSegment> cloud((size_t)ngrid_);
+    if (pixelToPointIndex) pixelToPointIndex->resize((size_t)w_ * h_img_);
+    int n = 0;
+    check(plvs_hip_cloudgen_generate(h_, depth.data, (int)(depth.step / sizeof(float)), color.data, (int)color.step, min_,
+                                     max_, kfid, cloud.data(), ngrid_, pixelToPointIndex ? pixelToPointIndex->data() : nullptr,
+                                     &n));
+    cloud.resize((size_t)n);
+    return cloud;
+  }
+
+ private:
+  plvs_cloudgen* h_ = nullptr;
+  int w_, h_img_, ngrid_ = 0;
+  double min_, max_;
+};
+
+// ------------------------------------------------------------------------------------ chisel map
+struct Mesh {   // chisel::Mesh after RecomputeMesh
+  std::vector<float> vertices, normals, colors;   // n x 3
+  std::vector<uint32_t> kfids;
+};
+
+class PointCloudMapChisel {
+ public:
+  using ChunkID = std::tuple<int, int, int>;
+  explicit PointCloudMapChisel(float resolution, bool useCarving = false, float carvingDist = 0.05f,
+                               float nearPlaneDist = 0.05f, float farPlaneDist = 5.0f)
+      : useCarving_(useCarving), carvingDist_(carvingDist), near_(nearPlaneDist), far_(farPlaneDist) {
+    plvs_tsdf_chisel_params p;
+    check(plvs_hip_tsdf_chisel_default_params(resolution, &p));
+    check(plvs_hip_tsdf_chisel_create(&p, &h_));
+  }
+  ~PointCloudMapChisel() { plvs_hip_tsdf_chisel_destroy(h_); }
+  PointCloudMapChisel(const PointCloudMapChisel&) = delete;
+  PointCloudMapChisel& operator=(const PointCloudMapChisel&) = delete;
+
+  // InsertCloud(cloud_camera, Twc, max_range): SetPointCloud + IntegrateLastPointCloud (PointCloudMapChisel.cc:76-98)
+  void InsertCloud(const std::vector<PointSurfelSegment>& cloud_camera, const SE3f& Twc, double /*max_range*/ = 0) {
+    const size_t n = cloud_camera.size();
+    xyz_.resize(3 * n);
+    rgb_.resize(3 * n);
+    kfid_.resize(n);
+    for (size_t i = 0; i < n; ++i) {   // PclPointCloudToChisel: position, the r, g, b members, kfid
+      const PointSurfelSegment& p = cloud_camera[i];
+      xyz_[3 * i] = p.x; xyz_[3 * i + 1] = p.y; xyz_[3 * i + 2] = p.z;
+      rgb_[3 * i] = p.r; rgb_[3 * i + 1] = p.g; rgb_[3 * i + 2] = p.b;
+      kfid_[i] = p.kfid;
+    }
+    check(plvs_hip_tsdf_chisel_integrate(h_, xyz_.data(), rgb_.data(), kfid_.data(), (int)n, Twc.m));
+    MarkUpdated();
+  }
+  // InsertCloudWithDepth: carving of the depth image's frustum first when useCarving (Chisel.cpp:394-438)
+  void InsertCloudWithDepth(const std::vector<PointSurfelSegment>& cloud_camera, const SE3f& Twc, const Image32F& depthImage,
+                            float fx, float fy, float cx, float cy, double max_range = 0) {
+    if (useCarving_) {
+      if (depthImage.step != (size_t)depthImage.cols * sizeof(float))
+        throw std::invalid_argument("InsertCloudWithDepth: the depth image must be continuous");
+      int carved = 0;
+      check(plvs_hip_tsdf_chisel_carve(h_, depthImage.data, depthImage.cols, depthImage.rows, fx, fy, cx, cy, near_, far_,
+                                       Twc.m, carvingDist_, &carved));
+    }
+    InsertCloud(cloud_camera, Twc, max_range);
+  }
+  // UpdateMap: UpdateMesh (meshes of the 27-neighbourhood of every chunk updated since the last call,
+  // Chisel.cpp:553-568) + GetPointCloud (ChiselServer.cpp:971-1068).  Returns the cloud size.
+  int UpdateMap() {
+    std::vector<int32_t> ids;
+    for (const ChunkID& c : meshesToUpdate_) { ids.push_back(std::get<0>(c)); ids.push_back(std::get<1>(c)); ids.push_back(std::get<2>(c)); }
+    const int nch = (int)meshesToUpdate_.size();
+    if (nch > 0) {
+      std::vector<int32_t> first((size_t)nch + 1);
+      std::vector<float> V, N, C;
+      std::vector<uint32_t> K;
+      int nv = 0;
+      int rc = plvs_hip_tsdf_chisel_mesh_chunks(h_, ids.data(), nch, nullptr, nullptr, nullptr, nullptr, 0, first.data(), &nv);
+      if (rc == PLVS_ERR_CAPACITY) {
+        V.resize((size_t)3 * nv); N.resize((size_t)3 * nv); C.resize((size_t)3 * nv); K.resize((size_t)nv);
+        rc = plvs_hip_tsdf_chisel_mesh_chunks(h_, ids.data(), nch, V.data(), N.data(), C.data(), K.data(), nv, first.data(), &nv);
+      }
+      check(rc);
+      int c = 0;
+      for (const ChunkID& id : meshesToUpdate_) {
+        const int a = first[(size_t)c], b = first[(size_t)c + 1];
+        ++c;
+        if (a == b) continue;   // RecomputeMesh stores non-empty meshes only (ChunkManager.cpp:165-167)
+        Mesh& m = allMeshes_[id];
+        m.vertices.assign(V.begin() + 3 * a, V.begin() + 3 * b);
+        m.normals.assign(N.begin() + 3 * a, N.begin() + 3 * b);
+        m.colors.assign(C.begin() + 3 * a, C.begin() + 3 * b);
+        m.kfids.assign(K.begin() + a, K.begin() + b);
+      }
+      meshesToUpdate_.clear();
+    }
+    pointCloud_.clear();
+    for (const auto& kv : allMeshes_) {   // the reference walks an unordered_map: its order is unspecified, this one is by id
+      const Mesh& m = kv.second;
+      for (size_t i = 0; i < m.kfids.size(); ++i) {
+        PointSurfelSegment p;
+        std::memset(&p, 0, sizeof p);
+        p.x = m.vertices[3 * i]; p.y = m.vertices[3 * i + 1]; p.z = m.vertices[3 * i + 2];
+        p.r = (uint8_t)(m.colors[3 * i] * 255);          // point.r = meshCol[0]*255, ChiselServer.cpp:1023-1025
+        p.g = (uint8_t)(m.colors[3 * i + 1] * 255);
+        p.b = (uint8_t)(m.colors[3 * i + 2] * 255);
+        p.normal_x = m.normals[3 * i]; p.normal_y = m.normals[3 * i + 1]; p.normal_z = m.normals[3 * i + 2];
+        p.kfid = m.kfids[i];
+        pointCloud_.push_back(p);
+      }
+    }
+    return (int)pointCloud_.size();
+  }
+  void Clear() {
+    check(plvs_hip_tsdf_chisel_clear(h_));
+    meshesToUpdate_.clear();
+    allMeshes_.clear();
+    pointCloud_.clear();
+  }
+  const std::vector<PointSurfelSegment>& GetPointCloud() const { return pointCloud_; }
+  const std::map<ChunkID, Mesh>& GetAllMeshes() const { return allMeshes_; }
+  plvs_tsdf_chisel* handle() { return h_; }
+
+ private:
+  void MarkUpdated() {
+    int n = 0;
+    check(plvs_hip_tsdf_chisel_updated_chunk_ids(h_, nullptr, 0, &n));
+    std::vector<int32_t> ids((size_t)3 * (n > 0 ? n : 1));
+    if (n > 0) check(plvs_hip_tsdf_chisel_updated_chunk_ids(h_, ids.data(), n, &n));
+    for (int i = 0; i < n; ++i)
+      for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dz = -1; dz <= 1; ++dz)
+            meshesToUpdate_.insert(ChunkID(ids[3 * i] + dx, ids[3 * i + 1] + dy, ids[3 * i + 2] + dz));
+  }
+  plvs_tsdf_chisel* h_ = nullptr;
+  bool useCarving_;
+  float carvingDist_, near_, far_;
+  std::vector<float> xyz_;
+  std::vector<uint8_t> rgb_;
+  std::vector<uint32_t> kfid_;
+  std::set<ChunkID> meshesToUpdate_;
+  std::map<ChunkID, Mesh> allMeshes_;
+  std::vector<PointSurfelSegment> pointCloud_;
+};
+
+// ------------------------------------------------------------------------------------ voxblox map
+class PointCloudMapVoxblox {
+ public:
+  explicit PointCloudMapVoxblox(float voxelSize, bool useCarving = false) {
+    plvs_tsdf_voxblox_params p;
+    check(plvs_hip_tsdf_voxblox_default_params(voxelSize, useCarving ? 1 : 0, &p));
+    check(plvs_hip_tsdf_voxblox_create(&p, &h_));
+  }
+  ~PointCloudMapVoxblox() { plvs_hip_tsdf_voxblox_destroy(h_); }
+  PointCloudMapVoxblox(const PointCloudMapVoxblox&) = delete;
+  PointCloudMapVoxblox& operator=(const PointCloudMapVoxblox&) = delete;
+
+  // InsertCloud: pcl cloud -> voxblox Pointcloud / Colors (r, g, b, a members) -> integratePointCloud
+  // (PointCloudMapVoxblox.cc:81-99)
+  void InsertCloud(const std::vector<PointSurfelSegment>& cloud_camera, const SE3f& Twc, double /*max_range*/ = 0) {
+    const size_t n = cloud_camera.size();
+    xyz_.resize(3 * n);
+    rgba_.resize(4 * n);
+    for (size_t i = 0; i < n; ++i) {
+      const PointSurfelSegment& p = cloud_camera[i];
+      xyz_[3 * i] = p.x; xyz_[3 * i + 1] = p.y; xyz_[3 * i + 2] = p.z;
+      rgba_[4 * i] = p.r; rgba_[4 * i + 1] = p.g; rgba_[4 * i + 2] = p.b; rgba_[4 * i + 3] = p.a;
+    }
+    check(plvs_hip_tsdf_voxblox_integrate(h_, xyz_.data(), rgba_.data(), (int)n, Twc.m));
+  }
+  void Clear() { check(plvs_hip_tsdf_voxblox_clear(h_)); }
+  int NumBlocks() { int n = 0; check(plvs_hip_tsdf_voxblox_num_blocks(h_, &n)); return n; }
+  plvs_tsdf_voxblox* handle() { return h_; }
+
+ private:
+  plvs_tsdf_voxblox* h_ = nullptr;
+  std::vector<float> xyz_;
+  std::vector<uint8_t> rgba_;
+};
+
+}  // namespace PLVS2hip

@@ -282,12 +282,15 @@ class PointCloudMapVoxblox:
 class PointCloudMapChisel:
     """Same surface as PLVS2::PointCloudMapChisel for the integrate path."""
 
-    def __init__(self, resolution, min_depth=0.1, max_depth=5.0, use_carving=False, max_chunks=None):
-        if use_carving:
-            raise NotImplementedError("depth carving (InsertCloudWithDepth) is not on the accelerated path yet")
+    def __init__(self, resolution, min_depth=0.1, max_depth=5.0, use_carving=False, max_chunks=None,
+                 carving_dist=0.05, near_plane_dist=0.05, far_plane_dist=5.0):
         self.resolution = resolution
         self.min_depth, self.max_depth = min_depth, max_depth
+        self.use_carving, self.carving_dist = use_carving, carving_dist
+        self.near_plane_dist, self.far_plane_dist = near_plane_dist, far_plane_dist
         self._tsdf = TsdfChisel(resolution, max_chunks=max_chunks)
+        self._meshes_to_update = set()       # Chisel::meshesToUpdate
+        self.all_meshes = {}                 # chunk id -> dict(vertices, normals, colors, kfids)
 
     def InsertCloud(self, cloud_camera, Twc, max_range=None):
         """cloud_camera: dict/obj with xyz [n,3] f32, rgb [n,3] u8 (r,g,b members of
@@ -295,6 +298,49 @@ class PointCloudMapChisel:
         print("PointCloudMapChisel<PointT>::InsertCloud()")
         Twc = np.asarray(Twc, dtype=np.float32)[:3, :4]
         self._tsdf.integrate(cloud_camera["xyz"], cloud_camera["rgb"], cloud_camera.get("kfid"), Twc)
+        for c in self._tsdf.updated_chunk_ids():          # Chisel.cpp:553-568
+            for dx in (-1, 0, 1):
+                for dy in (-1, 0, 1):
+                    for dz in (-1, 0, 1):
+                        self._meshes_to_update.add((int(c[0]) + dx, int(c[1]) + dy, int(c[2]) + dz))
+
+    def InsertCloudWithDepth(self, cloud_camera, Twc, depthImage, fx, fy, cx, cy, max_range=None):
+        """src/PointCloudMapChisel.cc:100-133: with useCarving the depth image's frustum is carved first
+        (Chisel.cpp:394-438), then the cloud is integrated."""
+        Twc = np.asarray(Twc, dtype=np.float32)[:3, :4]
+        if self.use_carving:
+            self._tsdf.carve(depthImage, fx, fy, cx, cy, Twc, near=self.near_plane_dist, far=self.far_plane_dist,
+                             carving_dist=self.carving_dist)
+        self.InsertCloud(cloud_camera, Twc, max_range)
+
+    def UpdateMap(self):
+        """UpdateMesh + GetPointCloud (src/PointCloudMapChisel.cc:228-246): -> the output cloud as a structured
+        array (x, y, z, normal, r, g, b, kfid), meshes walked in chunk-id order."""
+        todo = sorted(self._meshes_to_update)
+        if todo:
+            m = self._tsdf.mesh_chunks(np.array(todo, np.int32))
+            first = m["chunk_first"]
+            for i, cid in enumerate(todo):
+                a, b = int(first[i]), int(first[i + 1])
+                if b > a:
+                    self.all_meshes[cid] = dict(vertices=m["vertices"][a:b].copy(), normals=m["normals"][a:b].copy(),
+                                                colors=m["colors"][a:b].copy(), kfids=m["kfids"][a:b].copy())
+            self._meshes_to_update.clear()
+        from .cloudgen import POINT_SURFEL
+        n = sum(len(v["kfids"]) for v in self.all_meshes.values())
+        cloud = np.zeros(n, POINT_SURFEL)
+        o = 0
+        for cid in sorted(self.all_meshes):
+            v = self.all_meshes[cid]
+            k = len(v["kfids"])
+            c = cloud[o:o + k]
+            c["x"], c["y"], c["z"] = v["vertices"][:, 0], v["vertices"][:, 1], v["vertices"][:, 2]
+            c["normal"] = v["normals"]
+            col = (v["colors"] * np.float32(255)).astype(np.uint8)          # point.r = meshCol[0]*255
+            c["r"], c["g"], c["b"] = col[:, 0], col[:, 1], col[:, 2]
+            c["kfid"] = v["kfids"]
+            o += k
+        return cloud
 
     def InsertData(self, pData):
         """PointCloudMapInput dispatch (src/PointCloudMapChisel.cc:192-225): only the
@@ -306,6 +352,8 @@ class PointCloudMapChisel:
 
     def Clear(self):
         self._tsdf.clear()
+        self._meshes_to_update.clear()
+        self.all_meshes.clear()
 
     @property
     def tsdf(self):

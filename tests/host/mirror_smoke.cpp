@@ -1,0 +1,135 @@
+// Exercises include/plvs_hip.hpp (the C++ mirror of the PLVS interfaces) end to end, prints one line per
+// result (sizes + FNV-1a hashes) and dumps the raw arrays into <out_dir>; tests/test_cpp_mirror.py compares
+// them with the same calls made through the Python mirror (which the parity tests pin against the oracle).
+// Usage: mirror_smoke <left.pgm> <right.pgm> <out_dir>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "plvs_hip.hpp"
+
+using namespace PLVS2hip;
+
+static uint64_t fnv(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
+  const uint8_t* b = static_cast<const uint8_t*>(p);
+  for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+static std::string g_out;
+static void dump(const char* name, const void* p, size_t n) {
+  std::ofstream f(g_out + "/" + name + ".bin", std::ios::binary);
+  f.write(static_cast<const char*>(p), (std::streamsize)n);
+}
+
+static std::vector<uint8_t> read_pgm(const char* path, int* w, int* h) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) { std::fprintf(stderr, "cannot open %s\n", path); std::exit(2); }
+  std::string magic;
+  int maxv;
+  f >> magic >> *w >> *h >> maxv;
+  f.get();
+  std::vector<uint8_t> img((size_t)*w * *h);
+  f.read(reinterpret_cast<char*>(img.data()), (std::streamsize)img.size());
+  return img;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 4) return 2;
+  g_out = argv[3];
+  int w, h, w2, h2;
+  std::vector<uint8_t> left = read_pgm(argv[1], &w, &h), right = read_pgm(argv[2], &w2, &h2);
+  Image8U il{h, w, (size_t)w, left.data()}, ir{h2, w2, (size_t)w2, right.data()};
+
+  // ---- ORB on both images, stereo matches
+  ORBextractor exl(2000, 1.2f, 8, 20, 7), exr(2000, 1.2f, 8, 20, 7);
+  std::vector<KeyPoint> kl, kr;
+  std::vector<uint8_t> dl, dr;
+  const int mono = exl(il, kl, dl);
+  exr(ir, kr, dr);
+  std::printf("orb_left %d %d %016llx %016llx\n", mono, (int)kl.size(), (unsigned long long)fnv(kl.data(), kl.size() * sizeof(KeyPoint)),
+              (unsigned long long)fnv(dl.data(), dl.size()));
+  dump("orb_keys", kl.data(), kl.size() * sizeof(KeyPoint));
+  dump("orb_desc", dl.data(), dl.size());
+  std::vector<float> uR, depth;
+  ComputeStereoMatches(exl, exr, kl, dl, kr, dr, 386.1448f / 718.856f, 386.1448f, uR, depth);
+  std::printf("stereo %016llx %016llx\n", (unsigned long long)fnv(uR.data(), uR.size() * 4), (unsigned long long)fnv(depth.data(), depth.size() * 4));
+  dump("stereo_uright", uR.data(), uR.size() * 4);
+  dump("stereo_depth", depth.data(), depth.size() * 4);
+  Image8U none;
+  std::vector<KeyPoint> ke;
+  std::vector<uint8_t> de;
+  std::printf("orb_empty %d %d\n", exl(none, ke, de), (int)ke.size());
+
+  // ---- lines on the left image, LBD k-NN left vs right lines
+  LineExtractor lx(100), lx2(100);
+  std::vector<KeyLine> ll, lr;
+  std::vector<uint8_t> ldl, ldr;
+  lx(il, ll, ldl);
+  lx2(ir, lr, ldr);
+  std::printf("lines %d %016llx %016llx\n", (int)ll.size(), (unsigned long long)fnv(ll.data(), ll.size() * sizeof(KeyLine)),
+              (unsigned long long)fnv(ldl.data(), ldl.size()));
+  dump("lines_keys", ll.data(), ll.size() * sizeof(KeyLine));
+  dump("lines_desc", ldl.data(), ldl.size());
+  BinaryDescriptorMatcher bdm;
+  std::vector<std::vector<DMatch>> matches;
+  bdm.knnMatch(ldl.data(), (int)ll.size(), ldr.data(), (int)lr.size(), matches);
+  uint64_t hm = 1469598103934665603ull;
+  std::vector<int32_t> flat;
+  for (const auto& row : matches)
+    for (const DMatch& m : row) {
+      hm = fnv(&m.queryIdx, 4, hm); hm = fnv(&m.trainIdx, 4, hm); hm = fnv(&m.distance, 4, hm);
+      flat.push_back(m.queryIdx); flat.push_back(m.trainIdx); flat.push_back((int32_t)m.distance);
+    }
+  dump("knn", flat.data(), flat.size() * 4);
+  std::printf("knn %d %016llx %d\n", (int)matches.size(), (unsigned long long)hm,
+              ORBmatcher::DescriptorDistance(dl.data(), dl.data() + 32));
+
+  // ---- depth -> cloud -> chisel map (with carving) -> meshes -> output cloud; voxblox beside it
+  const int W = 320, H = 240;
+  const double fx = 258.65, fy = 258.23, cx = 159.3, cy = 127.6;
+  std::vector<float> dimg((size_t)W * H);
+  std::vector<uint8_t> cimg((size_t)W * H * 3);
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      dimg[(size_t)y * W + x] = 1.5f + 0.002f * (float)x + 0.3f * std::sin(0.05f * (float)y);
+      for (int c = 0; c < 3; ++c) cimg[((size_t)y * W + x) * 3 + c] = (uint8_t)((x * 3 + y * 5 + c * 40) & 255);
+    }
+  for (int y = 40; y < 60; ++y)
+    for (int x = 100; x < 140; ++x) dimg[(size_t)y * W + x] = 0.0f;   // a hole
+  PointCloudGenerator gen(W, H, 2, fx, fy, cx, cy, 0.1, 5.0);
+  Image8U ci{H, W, (size_t)W * 3, cimg.data()};
+  Image32F di{H, W, (size_t)W * sizeof(float), dimg.data()};
+  std::vector<int32_t> p2p;
+  std::vector<PointSurfelSegment> cloud = gen.GeneratePointCloudInCameraFrameBGRA(7, ci, di, &p2p);
+  std::printf("cloud %d %016llx %016llx\n", (int)cloud.size(), (unsigned long long)fnv(cloud.data(), cloud.size() * sizeof(PointSurfelSegment)),
+              (unsigned long long)fnv(p2p.data(), p2p.size() * 4));
+  dump("cloud", cloud.data(), cloud.size() * sizeof(PointSurfelSegment));
+  dump("p2p", p2p.data(), p2p.size() * 4);
+  dump("depth_img", dimg.data(), dimg.size() * 4);
+  dump("color_img", cimg.data(), cimg.size());
+  SE3f Twc = {{1, 0, 0, 0.1f, 0, 1, 0, -0.2f, 0, 0, 1, 0.05f}};
+  PointCloudMapChisel map(0.05f, true);
+  map.InsertCloudWithDepth(cloud, Twc, di, (float)fx, (float)fy, (float)cx, (float)cy);
+  Twc.m[3] += 0.03f;
+  map.InsertCloudWithDepth(cloud, Twc, di, (float)fx, (float)fy, (float)cx, (float)cy);
+  const int npts = map.UpdateMap();
+  uint64_t hv = 1469598103934665603ull;
+  for (const auto& kv : map.GetAllMeshes()) {
+    hv = fnv(kv.second.vertices.data(), kv.second.vertices.size() * 4, hv);
+    hv = fnv(kv.second.normals.data(), kv.second.normals.size() * 4, hv);
+    hv = fnv(kv.second.colors.data(), kv.second.colors.size() * 4, hv);
+    hv = fnv(kv.second.kfids.data(), kv.second.kfids.size() * 4, hv);
+  }
+  dump("map_cloud", map.GetPointCloud().data(), map.GetPointCloud().size() * sizeof(PointSurfelSegment));
+  std::printf("chisel %d %d %016llx\n", npts, (int)map.GetAllMeshes().size(), (unsigned long long)hv);
+  PointCloudMapVoxblox vmap(0.05f);
+  vmap.InsertCloud(cloud, Twc);
+  std::printf("voxblox %d\n", vmap.NumBlocks());
+  map.Clear();
+  std::printf("cleared %d\n", map.UpdateMap());
+  return 0;
+}

@@ -1,0 +1,92 @@
+"""include/plvs_hip.hpp — the C++ host-side mirror of the PLVS interfaces (ORBextractor, LineExtractor,
+BinaryDescriptorMatcher, ComputeStereoMatches, PointCloudGenerator, PointCloudMapChisel / Voxblox): it must
+compile against nothing but the C ABI, and a C++ program using it must produce byte for byte what the Python
+mirror produces through the same library (the Python path is what the parity tests pin against the oracle)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "host", "mirror_smoke.cpp")
+
+
+def build(out):
+    lib_dir = os.path.join(ROOT, "plvs_amd", "lib")
+    subprocess.run(["g++", "-std=c++14", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), SRC,
+                    "-L", lib_dir, "-l:libplvs_hip.so", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", out],
+                   check=True)
+
+
+def test_cpp_mirror_compiles_against_the_c_abi_only(tmp_path):
+    build(str(tmp_path / "mirror_smoke"))
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_matches_python_mirror(tmp_path):
+    from plvs_amd import cloudgen
+    from plvs_amd.lines import LineExtractor
+    from plvs_amd.matcher import BinaryDescriptorMatcher
+    from plvs_amd.orb import ORBextractor
+    from plvs_amd.orbmatcher import ORBmatcher
+    from plvs_amd.stereo import StereoMatcher
+    from plvs_amd.tsdf import PointCloudMapChisel, TsdfVoxblox
+    from tests.oracle_lib import golden
+    exe = str(tmp_path / "mirror_smoke")
+    build(exe)
+    out = tmp_path / "out"
+    out.mkdir()
+    gold = os.path.join(ROOT, "tests", "golden")
+    r = subprocess.run([exe, os.path.join(gold, "urban1_1241x376.pgm"), os.path.join(gold, "urban1_right_1241x376.pgm"),
+                        str(out)], check=True, capture_output=True, text=True)
+    lines_out = {l.split()[0]: l.split()[1:] for l in r.stdout.splitlines() if l and not l.startswith("PointCloudMap")}
+    load = lambda name, dt: np.fromfile(str(out / (name + ".bin")), dtype=dt)
+
+    left, right = golden("urban1_1241x376.pgm"), golden("urban1_right_1241x376.pgm")
+    exl, exr = ORBextractor(2000, 1.2, 8, 20, 7), ORBextractor(2000, 1.2, 8, 20, 7)
+    mono, kl, dl = exl(left)
+    _, kr, dr = exr(right)
+    assert int(lines_out["orb_left"][0]) == mono and int(lines_out["orb_left"][1]) == len(kl)
+    assert load("orb_keys", np.uint8).tobytes() == kl.tobytes() and load("orb_desc", np.uint8).tobytes() == dl.tobytes()
+    assert lines_out["orb_empty"] == ["-1", "0"]                       # empty image: -1, no keypoints
+    mb, mbf = np.float32(386.1448) / np.float32(718.856), np.float32(386.1448)
+    u, z = StereoMatcher(exl, exr).ComputeStereoMatches(kl, dl, kr, dr, mb, mbf)
+    assert load("stereo_uright", np.float32).tobytes() == u.tobytes()
+    assert load("stereo_depth", np.float32).tobytes() == z.tobytes()
+
+    lx, lx2 = LineExtractor(100), LineExtractor(100)
+    ll, ldl = lx(left)
+    lr, ldr = lx2(right)
+    assert int(lines_out["lines"][0]) == len(ll)
+    assert load("lines_keys", np.uint8).tobytes() == ll.tobytes() and load("lines_desc", np.uint8).tobytes() == ldl.tobytes()
+    matches = []
+    BinaryDescriptorMatcher().knnMatch(ldl, ldr, matches, k=2)
+    flat = np.array([[m.queryIdx, m.trainIdx, int(m.distance)] for row in matches for m in row], np.int32).reshape(-1)
+    assert int(lines_out["knn"][0]) == len(matches) and np.array_equal(load("knn", np.int32), flat)
+    assert int(lines_out["knn"][2]) == ORBmatcher.DescriptorDistance(dl[0], dl[1])
+
+    W, H = 320, 240
+    fx, fy, cx, cy = 258.65, 258.23, 159.3, 127.6
+    depth = load("depth_img", np.float32).reshape(H, W)
+    color = load("color_img", np.uint8).reshape(H, W, 3)
+    gen = cloudgen.PointCloudGenerator(W, H, cloudgen.InitCamGridPoints(W, H, 2, fx, fy, cx, cy), step=2, min_depth=0.1,
+                                       max_depth=5.0)
+    cloud, p2p = gen.GeneratePointCloudInCameraFrameBGRA(color, depth, 7)
+    assert load("cloud", np.uint8).tobytes() == cloud.tobytes() and np.array_equal(load("p2p", np.int32).reshape(H, W), p2p)
+
+    Twc = np.array([[1, 0, 0, 0.1], [0, 1, 0, -0.2], [0, 0, 1, 0.05]], np.float32)
+    pc = dict(xyz=np.stack([cloud["x"], cloud["y"], cloud["z"]], -1), rgb=np.stack([cloud["r"], cloud["g"], cloud["b"]], -1),
+              kfid=cloud["kfid"])
+    m = PointCloudMapChisel(0.05, use_carving=True)
+    m.InsertCloudWithDepth(pc, Twc, depth, np.float32(fx), np.float32(fy), np.float32(cx), np.float32(cy))
+    Twc2 = Twc.copy()
+    Twc2[0, 3] += np.float32(0.03)
+    m.InsertCloudWithDepth(pc, Twc2, depth, np.float32(fx), np.float32(fy), np.float32(cx), np.float32(cy))
+    mc = m.UpdateMap()
+    assert int(lines_out["chisel"][0]) == len(mc) > 1000 and int(lines_out["chisel"][1]) == len(m.all_meshes)
+    assert load("map_cloud", np.uint8).tobytes() == mc.tobytes()
+    v = TsdfVoxblox(0.05)
+    v.integrate(pc["xyz"], np.concatenate([pc["rgb"], np.zeros((len(cloud), 1), np.uint8)], 1), Twc2)
+    assert int(lines_out["voxblox"][0]) == v.num_chunks()
+    assert lines_out["cleared"] == ["0"]
