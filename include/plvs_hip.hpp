@@ -10,7 +10,8 @@
 //   PLVS2hip::ORBextractor              include/ORBextractor.h:76-113, src/ORBextractor.cc:446, :1245
 //   PLVS2hip::LineExtractor             include/LineExtractor.h:48-83, src/LineExtractor.cc:150, :170
 //   PLVS2hip::BinaryDescriptorMatcher   binary_descriptor_matcher_custom.cpp:258
-//   PLVS2hip::ORBmatcher                include/ORBmatcher.h:64 (DescriptorDistance)
+//   PLVS2hip::ORBmatcher                include/ORBmatcher.h (DescriptorDistance, SearchByProjection x2, SearchByBoW)
+//   PLVS2hip::LineMatcher               src/LineMatcher.cc:156, :303, :454
 //   PLVS2hip::ComputeStereoMatches      src/Frame.cc:1780
 //   PLVS2hip::PointCloudGenerator       src/PointCloudMapping.cc:796, :929
 //   PLVS2hip::PointCloudMapChisel       include/PointCloudMapChisel.h:61, src/PointCloudMapChisel.cc:76-246
@@ -176,14 +177,101 @@ class BinaryDescriptorMatcher {
   }
 };
 
-struct ORBmatcher {
+// The search functions take the arrays the reference functions read of their Frame / MapPoint / KeyFrame
+// objects (plvs_frame_view, plvs_mappoint_view, plvs_lastframe_view, plvs_featvec_view of plvs_hip.h) and
+// return the reference's return value; `assigned[i]` is what the reference stores per keypoint (an index
+// into the other side, -1 = none) — the caller maps it back to its MapPoint* / MapLine*.
+class ORBmatcher {
+ public:
   static constexpr int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 12;
+  explicit ORBmatcher(float nnratio = 0.6f, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
   static int DescriptorDistance(const uint8_t* a, const uint8_t* b) {
     const int32_t z = 0;
     int32_t d = 0;
     check(plvs_hip_hamming_pairs(a, 1, b, 1, &z, &z, 1, &d));
     return d;
   }
+  // SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th, bFarPoints, thFarPoints), ORBmatcher.cc:71
+  int SearchByProjection(const plvs_frame_view& F, const plvs_mappoint_view& vpMapPoints, float th, bool bFarPoints,
+                         float thFarPoints, const uint8_t* occupied, std::vector<int32_t>& assigned) const {
+    assigned.assign((size_t)F.n, -1);
+    int n = 0;
+    check(plvs_hip_orb_search_by_projection(&F, &vpMapPoints, th, bFarPoints ? 1 : 0, thFarPoints, mfNNratio, occupied,
+                                            assigned.data(), &n));
+    return n;
+  }
+  // SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono), ORBmatcher.cc:1774
+  int SearchByProjection(const plvs_frame_view& CurrentFrame, const float* curAngles, float mnMaxX, float mnMaxY, float mbf,
+                         const plvs_lastframe_view& LastFrame, float th, bool bForward, bool bBackward,
+                         const uint8_t* occupied, std::vector<int32_t>& assigned) const {
+    assigned.assign((size_t)CurrentFrame.n, -1);
+    int n = 0;
+    check(plvs_hip_orb_search_by_projection_ff(&CurrentFrame, curAngles, mnMaxX, mnMaxY, mbf, &LastFrame, th, bForward ? 1 : 0,
+                                               bBackward ? 1 : 0, mbCheckOrientation ? 1 : 0, occupied, assigned.data(), &n));
+    return n;
+  }
+  // SearchByBoW(KeyFramePtr& pKF, Frame& F, vpMapPointMatches), ORBmatcher.cc:300
+  int SearchByBoW(const plvs_featvec_view& kfFeatVec, const uint8_t* kfDescriptors, int kfN, const uint8_t* kfValid,
+                  const float* kfAngles, const plvs_featvec_view& fFeatVec, const uint8_t* fDescriptors, int fN,
+                  const float* fAngles, std::vector<int32_t>& assigned) const {
+    assigned.assign((size_t)fN, -1);
+    int n = 0;
+    check(plvs_hip_orb_search_by_bow(&kfFeatVec, kfDescriptors, kfN, kfValid, kfAngles, &fFeatVec, fDescriptors, fN, fAngles,
+                                     mfNNratio, mbCheckOrientation ? 1 : 0, assigned.data(), &n));
+    return n;
+  }
+  float mfNNratio;
+  bool mbCheckOrientation;
+};
+
+class LineMatcher {
+ public:
+  static constexpr int TH_HIGH = 110, TH_LOW = 60, TH_LOW_STEREO = 50, HISTO_LENGTH = 12;   // LineMatcher.cc:87-90
+  explicit LineMatcher(float nnratio = 0.6f, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+  // SearchByKnn(Frame& CurrentFrame, const Frame& LastFrame), LineMatcher.cc:303
+  int SearchByKnn(const uint8_t* descLast, int nLast, const uint8_t* validLast, const float* angleLast,
+                  const uint8_t* descCur, int nCur, const float* angleCur, std::vector<int32_t>& assigned) const {
+    assigned.assign((size_t)nCur, -1);
+    int n = 0;
+    check(plvs_hip_lines_search_by_knn(descLast, nLast, validLast, angleLast, descCur, nCur, angleCur, mfNNratio,
+                                       mbCheckOrientation ? 1 : 0, assigned.data(), &n));
+    return n;
+  }
+  // SearchByKnn(KeyFramePtr& pKF, const Frame& F, vpMapLineMatches), LineMatcher.cc:156
+  int SearchByKnnKF(const uint8_t* descKF, int nKF, const uint8_t* validKF, const float* angleKF, const uint8_t* descF,
+                    int nF, const float* angleF, std::vector<int32_t>& assigned) const {
+    assigned.assign((size_t)nF, -1);
+    int n = 0;
+    check(plvs_hip_lines_search_by_knn_kf(descKF, nKF, validKF, angleKF, descF, nF, angleF, mfNNratio,
+                                          mbCheckOrientation ? 1 : 0, assigned.data(), &n));
+    return n;
+  }
+  // SearchStereoMatchesByKnn(frame, vMatches, vValidMatches, descriptorDist), LineMatcher.cc:454
+  int SearchStereoMatchesByKnn(const uint8_t* descLeft, int nLeft, const float* angleLeft, const int32_t* octaveLeft,
+                               const uint8_t* descRight, int nRight, const float* angleRight, const int32_t* octaveRight,
+                               std::vector<DMatch>& vMatches, std::vector<bool>& vValidMatches,
+                               int descriptorDist = TH_LOW_STEREO) const {
+    const int cap = nRight > 0 ? nRight : 1;
+    std::vector<int32_t> q((size_t)cap), t((size_t)cap);
+    std::vector<float> d((size_t)cap);
+    std::vector<uint8_t> v((size_t)cap);
+    int k = 0, n = 0;
+    check(plvs_hip_lines_search_stereo_by_knn(descLeft, nLeft, angleLeft, octaveLeft, descRight, nRight, angleRight,
+                                              octaveRight, mfNNratio, mbCheckOrientation ? 1 : 0, descriptorDist, q.data(),
+                                              t.data(), d.data(), v.data(), cap, &k, &n));
+    vMatches.clear();
+    vValidMatches.clear();
+    for (int i = 0; i < k; ++i) {
+      DMatch m;
+      m.queryIdx = q[(size_t)i]; m.trainIdx = t[(size_t)i]; m.distance = d[(size_t)i];
+      vMatches.push_back(m);
+      vValidMatches.push_back(v[(size_t)i] != 0);
+    }
+    return n;
+  }
+  float mfNNratio;
+  bool mbCheckOrientation;
 };
 
 // Frame::ComputeStereoMatches: mvuRight / mvDepth of the left keypoints (-1 = none).

@@ -88,6 +88,51 @@ int main(int argc, char** argv) {
   std::printf("knn %d %016llx %d\n", (int)matches.size(), (unsigned long long)hm,
               ORBmatcher::DescriptorDistance(dl.data(), dl.data() + 32));
 
+  // ---- the search functions: lines left (query) vs right (train); ORB BoW search with the vocabulary node = first
+  // descriptor byte (a stand-in for DBoW2's FeatureVector)
+  {
+    std::vector<uint8_t> valid(ll.size(), 1);
+    std::vector<float> al(ll.size()), ar(lr.size());
+    std::vector<int32_t> ol(ll.size()), orr(lr.size());
+    for (size_t i = 0; i < ll.size(); ++i) { al[i] = ll[i].angle; ol[i] = ll[i].octave; if (i % 7 == 3) valid[i] = 0; }
+    for (size_t i = 0; i < lr.size(); ++i) { ar[i] = lr[i].angle; orr[i] = lr[i].octave; }
+    LineMatcher lm(0.8f, true);
+    std::vector<int32_t> a1, a2;
+    const int n1 = lm.SearchByKnn(ldl.data(), (int)ll.size(), valid.data(), al.data(), ldr.data(), (int)lr.size(), ar.data(), a1);
+    const int n2 = lm.SearchByKnnKF(ldl.data(), (int)ll.size(), valid.data(), al.data(), ldr.data(), (int)lr.size(), ar.data(), a2);
+    std::vector<DMatch> vm;
+    std::vector<bool> vv;
+    const int n3 = lm.SearchStereoMatchesByKnn(ldl.data(), (int)ll.size(), al.data(), ol.data(), ldr.data(), (int)lr.size(),
+                                               ar.data(), orr.data(), vm, vv);
+    std::vector<int32_t> sflat;
+    for (size_t i = 0; i < vm.size(); ++i) { sflat.push_back(vm[i].queryIdx); sflat.push_back(vm[i].trainIdx); sflat.push_back((int32_t)vm[i].distance); sflat.push_back(vv[i] ? 1 : 0); }
+    std::printf("line_search %d %d %d %d\n", n1, n2, n3, (int)vm.size());
+    dump("line_ff", a1.data(), a1.size() * 4);
+    dump("line_kf", a2.data(), a2.size() * 4);
+    dump("line_stereo", sflat.data(), sflat.size() * 4);
+
+    auto featvec = [](const std::vector<uint8_t>& desc, std::vector<uint32_t>& ids, std::vector<int32_t>& off, std::vector<uint32_t>& idx) {
+      std::map<uint32_t, std::vector<uint32_t>> fv;
+      for (size_t i = 0; i < desc.size() / 32; ++i) fv[desc[32 * i] >> 2].push_back((uint32_t)i);
+      off.push_back(0);
+      for (const auto& kv : fv) { ids.push_back(kv.first); idx.insert(idx.end(), kv.second.begin(), kv.second.end()); off.push_back((int32_t)idx.size()); }
+    };
+    std::vector<uint32_t> kid, kidx, fid, fidx;
+    std::vector<int32_t> koff, foff;
+    featvec(dl, kid, koff, kidx);
+    featvec(dr, fid, foff, fidx);
+    plvs_featvec_view kv{(int32_t)kid.size(), kid.data(), koff.data(), kidx.data()}, fv{(int32_t)fid.size(), fid.data(), foff.data(), fidx.data()};
+    std::vector<uint8_t> kvalid(kl.size(), 1);
+    std::vector<float> ka(kl.size()), fa(kr.size());
+    for (size_t i = 0; i < kl.size(); ++i) ka[i] = kl[i].angle;
+    for (size_t i = 0; i < kr.size(); ++i) fa[i] = kr[i].angle;
+    std::vector<int32_t> ab;
+    const int nb = ORBmatcher(0.7f, true).SearchByBoW(kv, dl.data(), (int)kl.size(), kvalid.data(), ka.data(), fv, dr.data(),
+                                                     (int)kr.size(), fa.data(), ab);
+    std::printf("bow %d\n", nb);
+    dump("bow", ab.data(), ab.size() * 4);
+  }
+
   // ---- depth -> cloud -> chisel map (with carving) -> meshes -> output cloud; voxblox beside it
   const int W = 320, H = 240;
   const double fx = 258.65, fy = 258.23, cx = 159.3, cy = 127.6;

@@ -66,6 +66,29 @@ def test_cpp_mirror_matches_python_mirror(tmp_path):
     assert int(lines_out["knn"][0]) == len(matches) and np.array_equal(load("knn", np.int32), flat)
     assert int(lines_out["knn"][2]) == ORBmatcher.DescriptorDistance(dl[0], dl[1])
 
+    # the search functions through both mirrors
+    from plvs_amd.linematcher import LineMatcher
+    from plvs_amd.orbmatcher import FeatureVector
+    valid = np.ones(len(ll), np.uint8)
+    valid[3::7] = 0
+    lm = LineMatcher(0.8, True)
+    n1, a1 = lm.SearchByKnnLastFrame(ldl, valid, ll["angle"], ldr, lr["angle"])
+    n2, a2 = lm.SearchByKnn(ldl, valid, ll["angle"], ldr, lr["angle"])
+    n3, sm, sv = lm.SearchStereoMatchesByKnn(ldl, ll["angle"], ll["octave"], ldr, lr["angle"], lr["octave"])
+    assert [int(x) for x in lines_out["line_search"]] == [n1, n2, n3, len(sm)] and n1 > 5
+    assert np.array_equal(load("line_ff", np.int32), a1) and np.array_equal(load("line_kf", np.int32), a2)
+    sflat = np.stack([sm["queryIdx"], sm["trainIdx"], sm["distance"].astype(np.int32), sv.astype(np.int32)], -1).reshape(-1)
+    assert np.array_equal(load("line_stereo", np.int32), sflat)
+
+    def featvec(desc):
+        nodes = {}
+        for i, b in enumerate(desc[:, 0] >> 2):
+            nodes.setdefault(int(b), []).append(i)
+        return FeatureVector(nodes)
+    nb, ab = ORBmatcher(0.7, True).SearchByBoW(featvec(dl), dl, np.ones(len(kl), np.uint8), kl["angle"], featvec(dr), dr,
+                                               kr["angle"])
+    assert int(lines_out["bow"][0]) == nb > 50 and np.array_equal(load("bow", np.int32), ab)
+
     W, H = 320, 240
     fx, fy, cx, cy = 258.65, 258.23, 159.3, 127.6
     depth = load("depth_img", np.float32).reshape(H, W)
