@@ -497,6 +497,26 @@ int plvs_hip_tsdf_chisel_mesh_chunks(plvs_tsdf_chisel* h, const int32_t* chunk_i
                                      float* vertices, float* normals, float* colors, uint32_t* kfids,
                                      int capacity, int32_t* chunk_first, int* nvertices);
 
+/* ------------------------------------------------- dense stereo (semi-global matching)
+ * Replaces sgm::StereoSGM as PointCloudKeyFrame::ProcessStereoLibsgm uses it
+ * (src/PointCloudKeyFrame.cc:435-481): StereoSGM(width, height, 64, 8, 8, HOST2HOST) with
+ * Parameters(P1 = 10, P2 = 120, uniqueness = 0.95f) (Thirdparty/libsgm/include/libsgm.h:62-88),
+ * execute(left, right, dst) (src/stereo_sgm.cpp:133-181): census, 8-path aggregation,
+ * winner-takes-all + uniqueness, 3x3 median, left-right check.  Images are width x height u8,
+ * tightly packed; the disparity is u8, 0 = invalid (PLVS: depth = bf / disparity). */
+typedef struct plvs_sgm plvs_sgm;
+int plvs_hip_sgm_create(int width, int height, int disparity_size, int p1, int p2, float uniqueness,
+                        plvs_sgm** out);
+int plvs_hip_sgm_destroy(plvs_sgm* s);
+/* Host images in, host disparity out; synchronous (EXECUTE_INOUT_HOST2HOST). */
+int plvs_hip_sgm_execute(plvs_sgm* s, const uint8_t* left, const uint8_t* right, uint8_t* disparity);
+/* Device images / disparity (EXECUTE_INOUT_CUDA2CUDA); asynchronous on `stream`. */
+int plvs_hip_sgm_execute_dev(plvs_sgm* s, const uint8_t* d_left, const uint8_t* d_right,
+                             uint8_t* d_disparity, void* stream);
+/* Parity accessors of the last call: which = 0 / 1 census left / right (u32 per pixel), 2 summed path
+ * costs (u16, width * height * 64), 3 / 4 raw left / right disparity, 5 / 6 after the median (u8). */
+int plvs_hip_sgm_download(plvs_sgm* s, int which, void* out);
+
 /* ------------------------------------------------- depth image -> cloud (T0)
  * Replaces PointCloudMapping::GeneratePointCloudInCameraFrameBGRA
  * src/PointCloudMapping.cc:929-1031 (caller IntegratePointCloudKeyframe path,

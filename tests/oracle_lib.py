@@ -84,6 +84,26 @@ class Oracle:
     def voxblox(self, voxel_size, **kw):
         return _VoxbloxLike(self.lib, "oracle_voxblox", voxel_size, **kw)
 
+    # ------------------------------------------------------------ dense stereo (libsgm)
+    def sgm(self, left, right, p1=10, p2=120, uniqueness=0.95, stages=False):
+        """-> disparity [h, w] u8, or (disparity, dict of stage arrays) with stages=True."""
+        left = np.ascontiguousarray(left, dtype=np.uint8)
+        right = np.ascontiguousarray(right, dtype=np.uint8)
+        h, w = left.shape
+        disp = np.zeros((h, w), np.uint8)
+        st = {}
+        if stages:
+            st = dict(census_left=np.zeros((h, w), np.uint32), census_right=np.zeros((h, w), np.uint32),
+                      cost_sum=np.zeros((h, w, 64), np.uint16), raw_left=np.zeros((h, w), np.uint8),
+                      raw_right=np.zeros((h, w), np.uint8), median_left=np.zeros((h, w), np.uint8),
+                      median_right=np.zeros((h, w), np.uint8))
+        f = self.lib.oracle_sgm
+        f.restype = None
+        f.argtypes = [_vp, _vp, _i, _i, _i, _i, _f] + [_vp] * 8
+        order = ["census_left", "census_right", "cost_sum", "raw_left", "raw_right", "median_left", "median_right"]
+        f(_ptr(left), _ptr(right), w, h, p1, p2, uniqueness, _ptr(disp), *[_ptr(st[k]) if stages else None for k in order])
+        return (disp, st) if stages else disp
+
     # ------------------------------------------------------------ stereo (M5)
     def stereo_matches(self, keys_left, desc_left, keys_right, desc_right, pyr_left, pyr_right, scale, inv_scale,
                        mb, mbf):
