@@ -48,10 +48,23 @@ __global__ __launch_bounds__(256) void sgm_census(const uint8_t* __restrict__ sr
   dst[(size_t)y * w + x] = f;
 }
 
+// Wave-wide minimum, the same value in every lane: four DPP steps fold each row of 16 lanes (xor 1, xor 2,
+// mirror of 8, mirror of 16), the four row results are read as scalars.  No LDS crossbar traffic on the
+// recurrence's critical path.
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
-  return v;
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false));   // row_half_mirror
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false));   // row_mirror
+  return min(min((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+             min((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+}
+// the value of lane d - 1 / d + 1 (lane 0 / 63 keep their own: the callers do not use it there)
+__device__ __forceinline__ uint32_t lane_prev(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);   // wave_shr:1
+}
+__device__ __forceinline__ uint32_t lane_next(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false);   // wave_shl:1
 }
 
 // One path per wave.  DX, DY: direction; path id -> where it enters the image.
@@ -96,7 +109,7 @@ __global__ __launch_bounds__(256) void sgm_path(const uint32_t* __restrict__ lef
       const uint32_t cost = (uint32_t)__popc(fl[k] ^ fr[k]);
       // DynamicProgramming::update
       uint32_t out = min(dp - last_min, p2);
-      const uint32_t prev = (uint32_t)__shfl_up((int)dp, 1), next = (uint32_t)__shfl_down((int)dp, 1);
+      const uint32_t prev = lane_prev(dp), next = lane_next(dp);
       if (lane != 0) out = min(out, prev - last_min + p1);
       if (lane != kDisp - 1) out = min(out, next - last_min + p1);
       dp = out + cost;
