@@ -315,6 +315,24 @@ def main():
             "hamming_knn2": fe,
             "note": "match = one brute-force 2000x2000 ORB k-NN + one 100x100 LBD k-NN per frame",
         }
+        # configs[4] (KITTI stereo): dense disparity by semi-global matching on a 1240x376 pair resident in HBM
+        from plvs_amd.sgm import StereoSGM
+        sl = torch.from_numpy(np.ascontiguousarray(golden("urban1_1241x376.pgm")[:, :1240])).cuda()
+        sr = torch.from_numpy(np.ascontiguousarray(golden("urban1_right_1241x376.pgm")[:, :1240])).cuda()
+        sgm = StereoSGM(1240, 376)
+        sd = torch.zeros((376, 1240), dtype=torch.uint8, device="cuda")
+        for _ in range(3):
+            sgm.execute_dev(sl, sr, sd)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            sgm.execute_dev(sl, sr, sd)
+        e1.record()
+        torch.cuda.synchronize()
+        result["frontend"]["dense_stereo_sgm"] = {
+            "ms_per_pair": round(e0.elapsed_time(e1) / 20, 3), "size": "1240x376, 64 disparities, 8 paths",
+            "valid_fraction": round(float((sd > 0).float().mean()), 3)}
 
     # -------------------------------------------------- CPU baseline (rank 0)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -13,6 +13,7 @@
 //   PLVS2hip::ORBmatcher                include/ORBmatcher.h (DescriptorDistance, SearchByProjection x2, SearchByBoW)
 //   PLVS2hip::LineMatcher               src/LineMatcher.cc:156, :303, :454
 //   PLVS2hip::ComputeStereoMatches      src/Frame.cc:1780
+//   PLVS2hip::StereoSGM                 Thirdparty/libsgm/include/libsgm.h:57 (as src/PointCloudKeyFrame.cc:435 uses it)
 //   PLVS2hip::PointCloudGenerator       src/PointCloudMapping.cc:796, :929
 //   PLVS2hip::PointCloudMapChisel       include/PointCloudMapChisel.h:61, src/PointCloudMapChisel.cc:76-246
 //   PLVS2hip::PointCloudMapVoxblox      include/PointCloudMapVoxblox.h:54, src/PointCloudMapVoxblox.cc:81
@@ -290,6 +291,34 @@ inline void ComputeStereoMatches(ORBextractor& left, ORBextractor& right, const 
   plvs_hip_stereo_destroy(s);
   check(rc);
 }
+
+// ------------------------------------------------------------------------------------ dense stereo
+// sgm::StereoSGM (Thirdparty/libsgm/include/libsgm.h:57-110) for 8-bit images and an 8-bit disparity, the way
+// PointCloudKeyFrame::ProcessStereoLibsgm constructs it; execute() is EXECUTE_INOUT_HOST2HOST.
+class StereoSGM {
+ public:
+  struct Parameters {
+    int P1, P2;
+    float uniqueness;
+    Parameters(int P1 = 10, int P2 = 120, float uniqueness = 0.95f) : P1(P1), P2(P2), uniqueness(uniqueness) {}
+  };
+  StereoSGM(int width, int height, int disparity_size, int input_depth_bits = 8, int output_depth_bits = 8,
+            const Parameters& param = Parameters()) {
+    if (input_depth_bits != 8 || output_depth_bits != 8) throw std::logic_error("depth bits must be 8 on the accelerated path");
+    if (disparity_size != 64 && disparity_size != 128) throw std::logic_error("disparity size must be 64 or 128");
+    check(plvs_hip_sgm_create(width, height, disparity_size, param.P1, param.P2, param.uniqueness, &h_));
+  }
+  ~StereoSGM() { plvs_hip_sgm_destroy(h_); }
+  StereoSGM(const StereoSGM&) = delete;
+  StereoSGM& operator=(const StereoSGM&) = delete;
+  void execute(const void* left_pixels, const void* right_pixels, void* dst) {
+    check(plvs_hip_sgm_execute(h_, static_cast<const uint8_t*>(left_pixels), static_cast<const uint8_t*>(right_pixels),
+                               static_cast<uint8_t*>(dst)));
+  }
+
+ private:
+  plvs_sgm* h_ = nullptr;
+};
 
 // ------------------------------------------------------------------------------------ depth -> cloud
 class PointCloudGenerator {   // PointCloudMapping::InitCamGridPoints + GeneratePointCloudInCameraFrameBGRA

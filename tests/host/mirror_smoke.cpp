@@ -133,6 +133,19 @@ int main(int argc, char** argv) {
     dump("bow", ab.data(), ab.size() * 4);
   }
 
+  // ---- dense stereo on the same pair (width cropped to 1240)
+  {
+    const int sw = 1240;
+    std::vector<uint8_t> cl((size_t)sw * h), cr((size_t)sw * h), disp((size_t)sw * h);
+    for (int y = 0; y < h; ++y) { std::memcpy(&cl[(size_t)y * sw], &left[(size_t)y * w], sw); std::memcpy(&cr[(size_t)y * sw], &right[(size_t)y * w], sw); }
+    StereoSGM sgm(sw, h, 64);
+    sgm.execute(cl.data(), cr.data(), disp.data());
+    size_t valid = 0;
+    for (uint8_t d : disp) valid += d > 0;
+    std::printf("sgm %d %016llx\n", (int)valid, (unsigned long long)fnv(disp.data(), disp.size()));
+    dump("sgm", disp.data(), disp.size());
+  }
+
   // ---- depth -> cloud -> chisel map (with carving) -> meshes -> output cloud; voxblox beside it
   const int W = 320, H = 240;
   const double fx = 258.65, fy = 258.23, cx = 159.3, cy = 127.6;

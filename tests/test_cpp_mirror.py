@@ -89,6 +89,10 @@ def test_cpp_mirror_matches_python_mirror(tmp_path):
                                                kr["angle"])
     assert int(lines_out["bow"][0]) == nb > 50 and np.array_equal(load("bow", np.int32), ab)
 
+    from plvs_amd.sgm import StereoSGM
+    disp = StereoSGM(1240, 376).execute(left[:, :1240], right[:, :1240])
+    assert int(lines_out["sgm"][0]) == int((disp > 0).sum()) and load("sgm", np.uint8).tobytes() == disp.tobytes()
+
     W, H = 320, 240
     fx, fy, cx, cy = 258.65, 258.23, 159.3, 127.6
     depth = load("depth_img", np.float32).reshape(H, W)
