@@ -82,30 +82,35 @@ __global__ __launch_bounds__(256) void sgm_path(const uint32_t* __restrict__ lef
   else { npaths = w + h - 1; nsteps = h; }
   if (path >= npaths) return;
   uint32_t dp = 0, last_min = 0;   // DynamicProgramming(): a path starts from zero costs
-  for (int i0 = 0; i0 < nsteps; i0 += kBatch) {
-    uint32_t fl[kBatch], fr[kBatch];
-    int px[kBatch], py[kBatch];
-    bool in[kBatch];
+  // position of step i on this path
+  auto pos = [&](int i, int* x, int* y) {
+    if (DY == 0) { *y = path; *x = DX > 0 ? i : w - 1 - i; }
+    else if (DX == 0) { *x = path; *y = DY > 0 ? i : h - 1 - i; }
+    else { *y = DY > 0 ? i : h - 1 - i; *x = (DX > 0 ? path - (h - 1) : path) + i * DX; }
+  };
+  // features of the kBatch steps from i0 on: the left one (the wave's pixel) and right[x - d] per lane
+  auto fetch = [&](int i0, uint32_t (&fl)[kBatch], uint32_t (&fr)[kBatch]) {
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
-      const int i = i0 + k;
       int x, y;
-      if (DY == 0) { y = path; x = DX > 0 ? i : w - 1 - i; }
-      else if (DX == 0) { x = path; y = DY > 0 ? i : h - 1 - i; }
-      else { y = DY > 0 ? i : h - 1 - i; x = (DX > 0 ? path - (h - 1) : path) + i * DX; }
-      px[k] = x;
-      py[k] = y;
-      in[k] = i < nsteps && x >= 0 && x < w;
+      pos(i0 + k, &x, &y);
       fl[k] = 0;
       fr[k] = 0;
-      if (in[k]) {
+      if (i0 + k < nsteps && x >= 0 && x < w) {
         fl[k] = left[(size_t)y * w + x];
         if (x - lane >= 0) fr[k] = right[(size_t)y * w + (x - lane)];   // beyond the left border: feature 0
       }
     }
+  };
+  uint32_t fl[kBatch], fr[kBatch], nl[kBatch], nr[kBatch];
+  fetch(0, fl, fr);
+  for (int i0 = 0; i0 < nsteps; i0 += kBatch) {
+    fetch(i0 + kBatch, nl, nr);   // the next batch is in flight while this one runs through the recurrence
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
-      if (!in[k]) continue;   // uniform: the position is the wave's
+      int x, y;
+      pos(i0 + k, &x, &y);
+      if (!(i0 + k < nsteps && x >= 0 && x < w)) continue;   // uniform: the position is the wave's
       const uint32_t cost = (uint32_t)__popc(fl[k] ^ fr[k]);
       // DynamicProgramming::update
       uint32_t out = min(dp - last_min, p2);
@@ -114,7 +119,12 @@ __global__ __launch_bounds__(256) void sgm_path(const uint32_t* __restrict__ lef
       if (lane != kDisp - 1) out = min(out, next - last_min + p1);
       dp = out + cost;
       last_min = wave_min_u32(dp);
-      dest[((size_t)py[k] * w + px[k]) * kDisp + lane] = (uint8_t)dp;
+      dest[((size_t)y * w + x) * kDisp + lane] = (uint8_t)dp;
+    }
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      fl[k] = nl[k];
+      fr[k] = nr[k];
     }
   }
 }
