@@ -872,6 +872,8 @@ struct plvs_tsdf_chisel {
   DevBuf<float2> psum;   // order-free mode: partial sums per run
   DevBuf<unsigned long long> tile_state;   // [0]: ticket, [1..]: look-back state per tile
   DevBuf<Pose> poses;
+  void* ext = nullptr;                 // see ChiselMapView::ext
+  void (*ext_free)(void*) = nullptr;
   DevBuf<int32_t> offsets;
   // host-flavour staging
   DevBuf<float> st_xyz, st_Twc;
@@ -981,6 +983,7 @@ int plvs_hip_tsdf_chisel_create(const plvs_tsdf_chisel_params* p, plvs_tsdf_chis
 
 int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   if (!h) return PLVS_OK;
+  if (h->ext != nullptr && h->ext_free != nullptr) h->ext_free(h->ext);
   (void)hipFree(h->dir.keys);
   (void)hipFree(h->dir.slots);
   (void)hipFree(h->dir.slot_ids);
@@ -1520,7 +1523,7 @@ extern "C" int plvs_hip_tsdf_chisel_carve(plvs_tsdf_chisel* h, const float* dept
 namespace plvs {
 namespace tsdf {
 
-bool chisel_map_view(const plvs_tsdf_chisel* h, ChiselMapView* v) {
+bool chisel_map_view(plvs_tsdf_chisel* h, ChiselMapView* v) {
   if (h == nullptr || v == nullptr || h->poisoned) return false;
   v->resolution = h->P.resolution;
   v->dir = h->dir;
@@ -1530,6 +1533,8 @@ bool chisel_map_view(const plvs_tsdf_chisel* h, ChiselMapView* v) {
   v->rgbw = h->rgbw;
   v->num_chunks = h->num_chunks;
   v->shard_count = h->P.shard_count;
+  v->ext = &h->ext;
+  v->ext_free = &h->ext_free;
   return true;
 }
 

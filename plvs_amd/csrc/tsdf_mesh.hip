@@ -377,6 +377,20 @@ __global__ __launch_bounds__(kMeshThreads) void mesh_shade(ChiselMapView m, uint
   }
 }
 
+// Scratch of the meshing calls, kept with the map (ChiselMapView::ext) so that a call per keyframe does not
+// allocate: the buffers only grow.
+struct MeshScratch {
+  plvs::DevBuf<int32_t> ids, slots;
+  plvs::DevBuf<uint32_t> counts, first, scan, total, kfids;
+  plvs::DevBuf<float> vertices, normals, colors;
+  static void destroy(void* p) {
+    MeshScratch* s = static_cast<MeshScratch*>(p);
+    s->ids.release(); s->slots.release(); s->counts.release(); s->first.release(); s->scan.release();
+    s->total.release(); s->kfids.release(); s->vertices.release(); s->normals.release(); s->colors.release();
+    delete s;
+  }
+};
+
 }  // namespace
 
 extern "C" int plvs_hip_tsdf_chisel_mesh_chunks(plvs_tsdf_chisel* h, const int32_t* chunk_ids_xyz, int nchunks,
@@ -397,80 +411,52 @@ extern "C" int plvs_hip_tsdf_chisel_mesh_chunks(plvs_tsdf_chisel* h, const int32
   }
   PLVS_REQUIRE(m.shard_count <= 1, "meshing needs the whole map on one device (neighbour chunks of other shards are missing)");
 
+  if (*m.ext == nullptr) {
+    *m.ext = new MeshScratch();
+    *m.ext_free = &MeshScratch::destroy;
+  }
+  MeshScratch& sc = *static_cast<MeshScratch*>(*m.ext);
   const size_t nvox = (size_t)nchunks * kChunkVox;
-  int32_t *d_ids = nullptr, *d_slots = nullptr;
-  uint32_t *d_counts = nullptr, *d_first = nullptr, *d_scratch = nullptr, *d_total = nullptr, *d_kfids = nullptr;
-  float *d_vertices = nullptr, *d_normals = nullptr, *d_colors = nullptr;
-  int rc = PLVS_OK;
+  hipStream_t s = nullptr;   // the map's calls are synchronous on return; the default stream orders after them
+  PLVS_HIP_TRY(sc.ids.reserve(3 * (size_t)nchunks));
+  PLVS_HIP_TRY(sc.slots.reserve((size_t)nchunks));
+  PLVS_HIP_TRY(sc.counts.reserve(nvox));
+  PLVS_HIP_TRY(sc.first.reserve(nvox));
+  PLVS_HIP_TRY(sc.scan.reserve(plvs::scan_scratch_words(nvox)));
+  PLVS_HIP_TRY(sc.total.reserve(1));
+  PLVS_HIP_TRY(hipMemcpyAsync(sc.ids.p, chunk_ids_xyz, sizeof(int32_t) * 3 * (size_t)nchunks, hipMemcpyHostToDevice, s));
+  mesh_slots<<<plvs::ceil_div((size_t)nchunks, 256), 256, 0, s>>>(m, sc.ids.p, nchunks, sc.slots.p);
+  mesh_count<<<plvs::ceil_div(nvox, kMeshThreads), kMeshThreads, 0, s>>>(m, sc.ids.p, sc.slots.p, nchunks, sc.counts.p);
+  PLVS_KERNEL_CHECK();
+  PLVS_HIP_TRY(plvs::exclusive_scan_u32(sc.counts.p, sc.first.p, nvox, sc.total.p, sc.scan.p, s));
   uint32_t total = 0;
   std::vector<uint32_t> firsts((size_t)nchunks);
-#define MESH_TRY(call)                                                                     \
-  do {                                                                                     \
-    hipError_t _e = (call);                                                                \
-    if (_e != hipSuccess) {                                                                \
-      plvs::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
-      rc = PLVS_ERR_HIP;                                                                   \
-      goto done;                                                                           \
-    }                                                                                      \
-  } while (0)
-  {
-    hipStream_t s = nullptr;   // the map's calls are synchronous on return; the default stream orders after them
-    MESH_TRY(hipMalloc((void**)&d_ids, sizeof(int32_t) * 3 * (size_t)nchunks));
-    MESH_TRY(hipMalloc((void**)&d_slots, sizeof(int32_t) * (size_t)nchunks));
-    MESH_TRY(hipMalloc((void**)&d_counts, sizeof(uint32_t) * nvox));
-    MESH_TRY(hipMalloc((void**)&d_first, sizeof(uint32_t) * nvox));
-    MESH_TRY(hipMalloc((void**)&d_scratch, sizeof(uint32_t) * plvs::scan_scratch_words(nvox)));
-    MESH_TRY(hipMalloc((void**)&d_total, sizeof(uint32_t)));
-    MESH_TRY(hipMemcpyAsync(d_ids, chunk_ids_xyz, sizeof(int32_t) * 3 * (size_t)nchunks, hipMemcpyHostToDevice, s));
-    mesh_slots<<<plvs::ceil_div((size_t)nchunks, 256), 256, 0, s>>>(m, d_ids, nchunks, d_slots);
-    mesh_count<<<plvs::ceil_div(nvox, kMeshThreads), kMeshThreads, 0, s>>>(m, d_ids, d_slots, nchunks, d_counts);
-    MESH_TRY(hipGetLastError());
-    MESH_TRY(plvs::exclusive_scan_u32(d_counts, d_first, nvox, d_total, d_scratch, s));
-    MESH_TRY(hipMemcpyAsync(&total, d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    MESH_TRY(hipMemcpy2DAsync(firsts.data(), sizeof(uint32_t), d_first, sizeof(uint32_t) * kChunkVox, sizeof(uint32_t),
-                              (size_t)nchunks, hipMemcpyDeviceToHost, s));
-    MESH_TRY(hipStreamSynchronize(s));
-    *nvertices = (int)total;
-    for (int c = 0; c < nchunks; ++c) chunk_first[c] = (int32_t)firsts[(size_t)c];
-    chunk_first[nchunks] = (int32_t)total;
-    if (total > (uint32_t)capacity) {
-      plvs::set_error("mesh_chunks: %u vertices exceed the capacity %d (call again with room for *nvertices)", total,
-                      capacity);
-      rc = PLVS_ERR_CAPACITY;
-      goto done;
-    }
-    if (total == 0) goto done;
-    if (!(vertices && normals && colors && kfids)) {
-      plvs::set_error("invalid argument: null output array");
-      rc = PLVS_ERR_INVALID_ARG;
-      goto done;
-    }
-    MESH_TRY(hipMalloc((void**)&d_vertices, sizeof(float) * 3 * (size_t)total));
-    MESH_TRY(hipMalloc((void**)&d_normals, sizeof(float) * 3 * (size_t)total));
-    MESH_TRY(hipMalloc((void**)&d_colors, sizeof(float) * 3 * (size_t)total));
-    MESH_TRY(hipMalloc((void**)&d_kfids, sizeof(uint32_t) * (size_t)total));
-    mesh_emit<<<plvs::ceil_div(nvox, kMeshThreads), kMeshThreads, 0, s>>>(m, d_ids, d_slots, nchunks, d_first, total,
-                                                                         d_vertices, d_normals, d_kfids);
-    mesh_shade<<<plvs::ceil_div((size_t)total, kMeshThreads), kMeshThreads, 0, s>>>(m, total, d_vertices, d_normals,
-                                                                                   d_colors);
-    MESH_TRY(hipGetLastError());
-    MESH_TRY(hipMemcpyAsync(vertices, d_vertices, sizeof(float) * 3 * (size_t)total, hipMemcpyDeviceToHost, s));
-    MESH_TRY(hipMemcpyAsync(normals, d_normals, sizeof(float) * 3 * (size_t)total, hipMemcpyDeviceToHost, s));
-    MESH_TRY(hipMemcpyAsync(colors, d_colors, sizeof(float) * 3 * (size_t)total, hipMemcpyDeviceToHost, s));
-    MESH_TRY(hipMemcpyAsync(kfids, d_kfids, sizeof(uint32_t) * (size_t)total, hipMemcpyDeviceToHost, s));
-    MESH_TRY(hipStreamSynchronize(s));
+  PLVS_HIP_TRY(hipMemcpyAsync(&total, sc.total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipMemcpy2DAsync(firsts.data(), sizeof(uint32_t), sc.first.p, sizeof(uint32_t) * kChunkVox, sizeof(uint32_t),
+                                (size_t)nchunks, hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  *nvertices = (int)total;
+  for (int c = 0; c < nchunks; ++c) chunk_first[c] = (int32_t)firsts[(size_t)c];
+  chunk_first[nchunks] = (int32_t)total;
+  if (total > (uint32_t)capacity) {
+    plvs::set_error("mesh_chunks: %u vertices exceed the capacity %d (call again with room for *nvertices)", total, capacity);
+    return PLVS_ERR_CAPACITY;
   }
-done:
-#undef MESH_TRY
-  (void)hipFree(d_ids);
-  (void)hipFree(d_slots);
-  (void)hipFree(d_counts);
-  (void)hipFree(d_first);
-  (void)hipFree(d_scratch);
-  (void)hipFree(d_total);
-  (void)hipFree(d_vertices);
-  (void)hipFree(d_normals);
-  (void)hipFree(d_colors);
-  (void)hipFree(d_kfids);
-  return rc;
+  if (total == 0) return PLVS_OK;
+  PLVS_REQUIRE(vertices && normals && colors && kfids, "null output array");
+  PLVS_HIP_TRY(sc.vertices.reserve(3 * (size_t)total));
+  PLVS_HIP_TRY(sc.normals.reserve(3 * (size_t)total));
+  PLVS_HIP_TRY(sc.colors.reserve(3 * (size_t)total));
+  PLVS_HIP_TRY(sc.kfids.reserve((size_t)total));
+  mesh_emit<<<plvs::ceil_div(nvox, kMeshThreads), kMeshThreads, 0, s>>>(m, sc.ids.p, sc.slots.p, nchunks, sc.first.p, total,
+                                                                       sc.vertices.p, sc.normals.p, sc.kfids.p);
+  mesh_shade<<<plvs::ceil_div((size_t)total, kMeshThreads), kMeshThreads, 0, s>>>(m, total, sc.vertices.p, sc.normals.p,
+                                                                                 sc.colors.p);
+  PLVS_KERNEL_CHECK();
+  PLVS_HIP_TRY(hipMemcpyAsync(vertices, sc.vertices.p, sizeof(float) * 3 * (size_t)total, hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipMemcpyAsync(normals, sc.normals.p, sizeof(float) * 3 * (size_t)total, hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipMemcpyAsync(colors, sc.colors.p, sizeof(float) * 3 * (size_t)total, hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipMemcpyAsync(kfids, sc.kfids.p, sizeof(uint32_t) * (size_t)total, hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  return PLVS_OK;
 }
