@@ -224,6 +224,8 @@ struct plvs_sgm {
   int w = 0, h = 0, p1 = 10, p2 = 120;
   float uniqueness = 0.95f;
   hipStream_t stream = nullptr;
+  hipStream_t path_stream[kPaths] = {};   // the eight path passes are independent: they run side by side
+  hipEvent_t ev_census = nullptr, ev_path[kPaths] = {};
   uint8_t *d_left = nullptr, *d_right = nullptr, *d_cost = nullptr, *d_dl = nullptr, *d_dr = nullptr, *d_ml = nullptr,
           *d_mr = nullptr, *d_out = nullptr;
   uint32_t *d_cl = nullptr, *d_cr = nullptr;
@@ -238,6 +240,11 @@ int plvs_hip_sgm_destroy(plvs_sgm* s) {
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (s->stream) (void)hipStreamDestroy(s->stream);
+  for (int i = 0; i < kPaths; ++i) {
+    if (s->path_stream[i]) (void)hipStreamDestroy(s->path_stream[i]);
+    if (s->ev_path[i]) (void)hipEventDestroy(s->ev_path[i]);
+  }
+  if (s->ev_census) (void)hipEventDestroy(s->ev_census);
   delete s;
   return PLVS_OK;
 }
@@ -255,6 +262,11 @@ int plvs_hip_sgm_create(int width, int height, int disparity_size, int p1, int p
   s->uniqueness = uniqueness;
   const size_t n = (size_t)width * height;
   hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+  for (int i = 0; i < kPaths && e == hipSuccess; ++i) {
+    e = hipStreamCreateWithFlags(&s->path_stream[i], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_path[i], hipEventDisableTiming);
+  }
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_census, hipEventDisableTiming);
   auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
   alloc((void**)&s->d_left, n);
   alloc((void**)&s->d_right, n);
@@ -288,15 +300,24 @@ int plvs_hip_sgm_execute_dev(plvs_sgm* s, const uint8_t* d_left, const uint8_t* 
   sgm_census<<<grid2d, block, 0, st>>>(d_right, w, h, s->d_cr);
   const uint32_t p1 = (uint32_t)s->p1, p2 = (uint32_t)s->p2;
   const unsigned gv = plvs::ceil_div((size_t)w, 4), gh = plvs::ceil_div((size_t)h, 4), go = plvs::ceil_div((size_t)(w + h - 1), 4);
-  sgm_path<0, 1><<<gv, block, 0, st>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 0 * step);
-  sgm_path<0, -1><<<gv, block, 0, st>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 1 * step);
-  sgm_path<1, 0><<<gh, block, 0, st>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 2 * step);
-  sgm_path<-1, 0><<<gh, block, 0, st>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 3 * step);
-  sgm_path<1, 1><<<go, block, 0, st>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 4 * step);
-  sgm_path<-1, 1><<<go, block, 0, st>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 5 * step);
-  sgm_path<-1, -1><<<go, block, 0, st>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 6 * step);
-  sgm_path<1, -1><<<go, block, 0, st>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 7 * step);
+  // A path pass is a chain of dependent steps with at most a wave or two per SIMD: alone it leaves the machine
+  // idle.  The eight passes write disjoint volumes, so they run on eight streams between two events (libsgm
+  // does the same, path_aggregation.cu:56-83) and hide each other's latency.
+  PLVS_HIP_TRY(hipEventRecord(s->ev_census, st));
+  for (int i = 0; i < kPaths; ++i) PLVS_HIP_TRY(hipStreamWaitEvent(s->path_stream[i], s->ev_census, 0));
+  sgm_path<0, 1><<<gv, block, 0, s->path_stream[0]>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 0 * step);
+  sgm_path<0, -1><<<gv, block, 0, s->path_stream[1]>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 1 * step);
+  sgm_path<1, 0><<<gh, block, 0, s->path_stream[2]>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 2 * step);
+  sgm_path<-1, 0><<<gh, block, 0, s->path_stream[3]>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 3 * step);
+  sgm_path<1, 1><<<go, block, 0, s->path_stream[4]>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 4 * step);
+  sgm_path<-1, 1><<<go, block, 0, s->path_stream[5]>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 5 * step);
+  sgm_path<-1, -1><<<go, block, 0, s->path_stream[6]>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 6 * step);
+  sgm_path<1, -1><<<go, block, 0, s->path_stream[7]>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 7 * step);
   PLVS_KERNEL_CHECK();
+  for (int i = 0; i < kPaths; ++i) {
+    PLVS_HIP_TRY(hipEventRecord(s->ev_path[i], s->path_stream[i]));
+    PLVS_HIP_TRY(hipStreamWaitEvent(st, s->ev_path[i], 0));
+  }
   const unsigned gw = (unsigned)std::min<size_t>(plvs::ceil_div(n, 4), 65536);
   sgm_wta_left<<<gw, block, 0, st>>>(s->d_cost, (int)n, s->uniqueness, s->d_sum, s->d_dl);
   sgm_wta_right<<<gw, block, 0, st>>>(s->d_sum, w, h, s->uniqueness, s->d_dr);
