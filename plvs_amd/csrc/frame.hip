@@ -29,7 +29,14 @@ extern "C" int plvs_hip_frame_extract_dev(plvs_orb* orb, plvs_lines* lines, cons
     if (!fired.exchange(true)) pyramid_enqueued.set_value();
   };
   if (shared) plvs::orb_set_pyramid_hook(orb, fire);
+  int device = 0;
+  PLVS_HIP_TRY(hipGetDevice(&device));   // the current device is per thread: the line thread inherits the caller's
   std::thread tl([&]() {
+    if (hipSetDevice(device) != hipSuccess) {
+      rc_lines = PLVS_ERR_HIP;
+      snprintf(lines_error, sizeof lines_error, "frame: hipSetDevice(%d) failed on the line thread", device);
+      return;
+    }
     if (shared) pyramid_ready.wait();
     rc_lines = plvs_hip_lines_extract_dev(lines, d_image, w, h, stride, keylines, line_desc, line_cap, n_lines);
     if (rc_lines != PLVS_OK) snprintf(lines_error, sizeof lines_error, "%s", plvs_hip_last_error());   // thread-local
