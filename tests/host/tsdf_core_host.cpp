@@ -115,6 +115,56 @@ int hostcore_get_chunk(HostMap* m, int cx, int cy, int cz, float* sdf, float* w,
 }
 }
 
+// ---------------------------------------------------------------- sharding checks
+extern "C" {
+
+int hostcore_shard_of(unsigned long long h, int count) { return shard_of((uint64_t)h, count); }
+
+// For every point: does the cheap cull agree with the walk?  Returns the number of rays whose walk
+// emits a visit this rank owns although walk_may_touch_owned said it could not (must be 0);
+// *culled = rays the cull rejects, *owned_rays = rays with at least one owned visit.
+long long hostcore_cull_violations(HostMap* m, const float* xyz, int n, const float* Twc, long long* culled,
+                                   long long* owned_rays) {
+  Pose pose;
+  make_pose(Twc, &pose);
+  long long bad = 0;
+  *culled = 0;
+  *owned_rays = 0;
+  for (int i = 0; i < n; ++i) {
+    Ray ray;
+    if (!make_ray(m->P, pose, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], &ray)) continue;
+    if (!ray_in_coord_range(ray)) continue;
+    const bool may = walk_may_touch_owned(m->P, ray);
+    RayCursor cur;
+    OwnerCache owner;
+    ray_begin(ray, &cur);
+    int vx, vy, vz;
+    bool any = false;
+    while (ray_next(&cur, &vx, &vy, &vz)) {
+      Visit v;
+      any = resolve_visit(m->P, pose, ray, vx, vy, vz, &v, &owner) || any;
+    }
+    *culled += may ? 0 : 1;
+    *owned_rays += any ? 1 : 0;
+    bad += (any && !may) ? 1 : 0;
+  }
+  return bad;
+}
+
+// The reference's float chunk lookup (ChunkManager.h:192-198 on the voxel centre, Chisel.cpp:505-511)
+// against the integer form the kernels use; returns the number of coordinates where they differ.
+long long hostcore_chunk_id_mismatches(float resolution, const int32_t* v, int n) {
+  const float half = resolution * 0.5f, rounding = 1.0f / ((float)16 * resolution);
+  long long bad = 0;
+  for (int i = 0; i < n; ++i) {
+    const float centre = (float)v[i] * resolution + half;
+    const int ref = (int)std::floor(centre * rounding);
+    bad += (ref != (v[i] >> 4)) ? 1 : 0;
+  }
+  return bad;
+}
+}
+
 // ---------------------------------------------------------------- voxblox
 struct HostVBlock {
   std::vector<float> d, w;

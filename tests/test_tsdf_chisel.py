@@ -467,3 +467,69 @@ def test_hip_carving_matches_oracle(oracle, kind):
     dev.integrate(kfs[2]["xyz"], kfs[2]["rgb"], kfs[2]["kfid"], kfs[2]["Twc"])
     compare_maps(ora, dev)
     dev.close()
+
+
+def test_shard_of_is_hash_mod_count():
+    """shard_of (32-bit arithmetic, mask for powers of two) == ChunkHasher(id) % N in size_t arithmetic."""
+    import ctypes
+    from tests import oracle_lib
+    lib = oracle_lib.load_hostcore()
+    lib.hostcore_shard_of.argtypes = [ctypes.c_ulonglong, ctypes.c_int]
+    rng = np.random.default_rng(11)
+    hs = [0, 1, 2**32 - 1, 2**32, 2**64 - 1, 2**63, 73856093 * 5 ^ 19349663 * 7] + \
+        [int(x) for x in rng.integers(0, 2**64, 4000, dtype=np.uint64)]
+    for count in (1, 2, 3, 4, 5, 6, 7, 8, 12, 16, 31, 64, 1000, 65521):
+        for h in hs:
+            assert lib.hostcore_shard_of(h, count) == h % count, (h, count)
+
+
+@pytest.mark.parametrize("count", [3, 4, 8, 16])
+def test_shard_cull_never_drops_an_owned_visit(count):
+    """walk_may_touch_owned (the cull ahead of the walk on sharded maps) is conservative: no ray with a
+    visit this rank owns is culled — and it does cull a useful share of the others."""
+    import ctypes
+    from tests import oracle_lib
+    lib = oracle_lib.load_hostcore()
+    lib.hostcore_cull_violations.restype = ctypes.c_longlong
+    kfs = make_keyframes(3, cam=small_cam(4), seed=9)
+    # far from the origin too: negative coordinates, large hashes
+    far = np.array([-1234.56, 789.01, -33.3], np.float32)
+    culled_total = owned_total = 0
+    for rank in range(count):
+        host = oracle_lib._ChiselLike(lib, "hostcore", 0.05, shard_rank=rank, shard_count=count)
+        for kf in kfs:
+            for shift in (None, far):
+                Twc = kf["Twc"].copy()
+                if shift is not None:
+                    Twc[:, 3] += shift
+                culled = ctypes.c_longlong(0)
+                owned = ctypes.c_longlong(0)
+                xyz = np.ascontiguousarray(kf["xyz"], np.float32)
+                bad = lib.hostcore_cull_violations(host.h, xyz.ctypes.data_as(ctypes.c_void_p),
+                                                   ctypes.c_int(xyz.shape[0]),
+                                                   np.ascontiguousarray(Twc, np.float32).ctypes.data_as(ctypes.c_void_p),
+                                                   ctypes.byref(culled), ctypes.byref(owned))
+                assert bad == 0
+                culled_total += culled.value
+                owned_total += owned.value
+    assert owned_total > 0
+    if count >= 8:
+        assert culled_total > 0
+
+
+def test_integer_chunk_ids_equal_the_float_lookup():
+    """v >> 4 == floor((v * res + res / 2) * (1 / (16 res))) for every |v| the kernels accept
+    (kVoxelCoordLimit): dense near the chunk boundaries, where a rounding slip would show."""
+    import ctypes
+    from tests import oracle_lib
+    lib = oracle_lib.load_hostcore()
+    lib.hostcore_chunk_id_mismatches.restype = ctypes.c_longlong
+    lim = 1048576 - 128
+    rng = np.random.default_rng(4)
+    edges = (rng.integers(-lim // 16, lim // 16, 200000)[:, None] * 16 + np.array([-1, 0, 1, 15, 16])[None, :]).ravel()
+    v = np.concatenate([np.arange(-70000, 70000), edges, rng.integers(-lim + 1, lim, 500000),
+                        np.arange(lim - 5000, lim), np.arange(-lim + 1, -lim + 5000)]).astype(np.int32)
+    v = np.ascontiguousarray(v[np.abs(v) < lim])
+    for res in (0.05, 0.02, 0.10, 0.04, 0.0123, 0.25):
+        bad = lib.hostcore_chunk_id_mismatches(ctypes.c_float(res), v.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(v.size))
+        assert bad == 0, res
