@@ -282,12 +282,12 @@ def main():
         # the reference extracts points and lines on two host threads (src/Frame.cc:503-508)
         from plvs_amd.frame import extract_frame
         ext2 = ORBextractor(2000, 1.2, 8, 20, 7)
-        for i in range(4):
+        for i in range(8):
             extract_frame(ext2, lext, frames[i % 3])
         t0 = time.perf_counter()
-        for i in range(nrep):
+        for i in range(2 * nrep):
             extract_frame(ext2, lext, frames[i % 3])
-        both_ms = (time.perf_counter() - t0) / nrep * 1e3
+        both_ms = (time.perf_counter() - t0) / (2 * nrep) * 1e3
         ext2.close()
         lext.close()
         match_ms = (fe["orb_bf_2000x2000_us"] + fe["lbd_mih_2000x2000_us"] * 0.0) * 1e-3

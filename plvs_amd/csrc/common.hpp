@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/plvs_hip.h"
@@ -72,5 +73,13 @@ struct DevBuf {
 };
 
 static inline unsigned ceil_div(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+// Integer tuning knob from the environment (host thread counts), clamped to [lo, hi].
+static inline int env_int(const char* name, int dflt, int lo, int hi) {
+  const char* v = getenv(name);
+  if (!v || !*v) return dflt;
+  const long x = strtol(v, nullptr, 10);
+  return (int)(x < lo ? lo : (x > hi ? hi : x));
+}
 
 }  // namespace plvs

@@ -474,7 +474,9 @@ int lines_extract_body(plvs_lines* o, plvs_keyline* keylines, uint8_t* desc, int
   o->det.resize(n);
   {
     constexpr int kBatch = 24;       // chains per fitting task
-    constexpr int kFitThreads = 4;
+    // extra fitting threads beside the routing ones, and whether an idle one yields its core instead of spinning
+    const int kFitThreads = plvs::env_int("PLVS_HIP_LINES_FIT_THREADS", 2, 0, 16);
+    const bool idle_yield = plvs::env_int("PLVS_HIP_LINES_FIT_YIELD", 0, 0, 1) != 0;
     struct OctaveWork {
       ChainProgress prog;
       std::atomic<int> next{0};                   // next batch to claim
@@ -516,7 +518,9 @@ int lines_extract_body(plvs_lines* o, plvs_keyline* keylines, uint8_t* desc, int
           }
         }
         if (all_drained) break;
-        if (!did) __builtin_ia32_pause();
+        if (!did) {
+          if (idle_yield) std::this_thread::yield(); else __builtin_ia32_pause();
+        }
       }
     };
     std::vector<std::thread> th;

@@ -22,6 +22,7 @@
 //   describe_kernel   256-bit rBRIEF, 32 lanes per keypoint
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <functional>
 #include <thread>
@@ -776,7 +777,8 @@ static int orb_extract_body(plvs_orb* o, int lap0, int lap1, plvs_keypoint* kps,
   PLVS_HIP_TRY(hipStreamSynchronize(s));
   const double t1 = now_ms();
 
-  // ---- host: quadtree distribution, one thread per level (:1001-1003)
+  // ---- host: quadtree distribution, the levels in parallel (:1001-1003 runs one thread per level; three
+  // threads are as fast here — scripts/experiments/frontend_threads.txt — and start sooner)
   std::vector<std::vector<Cand>> selected(nl);
   {
     std::vector<uint32_t> start(nl + 1, 0);
@@ -794,9 +796,23 @@ static int orb_extract_body(plvs_orb* o, int lap0, int lap1, plvs_keypoint* kps,
       selected[l] = distribute_quadtree(cands, kMinBorder, L.w - kEdgeThreshold + 3, kMinBorder,
                                         L.h - kEdgeThreshold + 3, o->features_per_level[l]);
     };
+    // the levels are dealt to nt threads (the caller is one of them), largest first to the least loaded
+    const int nt = plvs::env_int("PLVS_HIP_ORB_TREE_THREADS", std::min(nl, 3), 1, nl);
+    std::vector<int> order(nl);
+    for (int l = 0; l < nl; ++l) order[l] = l;
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int a, int b) { return o->h_level_counts[a] > o->h_level_counts[b]; });
+    std::vector<std::vector<int>> share(nt);
+    std::vector<uint64_t> load(nt, 0);
+    for (int l : order) {
+      const int k = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+      share[k].push_back(l);
+      load[k] += o->h_level_counts[l] + 1u;
+    }
+    auto run = [&](int k) { for (int l : share[k]) work(l); };
     std::vector<std::thread> th;
-    for (int l = 1; l < nl; ++l) th.emplace_back(work, l);
-    work(0);
+    for (int k = 1; k < nt; ++k) th.emplace_back(run, k);
+    run(0);
     for (auto& t : th) t.join();
   }
   int nk = 0;
