@@ -26,6 +26,7 @@ namespace {
 constexpr int kDisp = 64;
 constexpr int kPaths = 8;
 constexpr int kBatch = 8;   // path steps whose loads are in flight together
+constexpr int kSideStreams = 3;   // the path passes are spread over the call's stream and three more (see execute)
 
 __global__ __launch_bounds__(256) void sgm_census(const uint8_t* __restrict__ src, int w, int h,
                                                   uint32_t* __restrict__ dst) {
@@ -52,19 +53,19 @@ __global__ __launch_bounds__(256) void sgm_census(const uint8_t* __restrict__ sr
 // mirror of 8, mirror of 16), the four row results are read as scalars.  No LDS crossbar traffic on the
 // recurrence's critical path.
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false));   // row_half_mirror
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false));   // row_mirror
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, true));   // row_half_mirror
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, true));   // row_mirror
   return min(min((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
              min((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
 }
 // the value of lane d - 1 / d + 1 (lane 0 / 63 keep their own: the callers do not use it there)
 __device__ __forceinline__ uint32_t lane_prev(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);   // wave_shr:1
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, true);   // wave_shr:1
 }
 __device__ __forceinline__ uint32_t lane_next(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false);   // wave_shl:1
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, true);   // wave_shl:1
 }
 
 // One path per wave.  DX, DY: direction; path id -> where it enters the image.
@@ -103,23 +104,43 @@ __global__ __launch_bounds__(256) void sgm_path(const uint32_t* __restrict__ lef
     }
   };
   uint32_t fl[kBatch], fr[kBatch], nl[kBatch], nr[kBatch];
+  uint32_t done[kBatch];   // costs of the previous batch, stored at the start of the next one
+  bool done_ok[kBatch];
+#pragma unroll
+  for (int k = 0; k < kBatch; ++k) { done[k] = 0; done_ok[k] = false; }
   fetch(0, fl, fr);
-  for (int i0 = 0; i0 < nsteps; i0 += kBatch) {
+  // Loads and stores share one in-order counter (vmcnt).  Within a batch the order is: stores of the previous
+  // batch, loads of the next one, then eight steps of pure register work — so the only wait is for loads that
+  // have had a whole batch to arrive, never for a store.  The first batch is waited for here, outside the loop.
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  for (int i0 = 0; i0 < nsteps + kBatch; i0 += kBatch) {
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      if (done_ok[k]) {
+        int x, y;
+        pos(i0 - kBatch + k, &x, &y);
+        dest[((size_t)y * w + x) * kDisp + lane] = (uint8_t)done[k];
+      }
+    }
+    if (i0 >= nsteps) break;
     fetch(i0 + kBatch, nl, nr);   // the next batch is in flight while this one runs through the recurrence
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
       int x, y;
       pos(i0 + k, &x, &y);
-      if (!(i0 + k < nsteps && x >= 0 && x < w)) continue;   // uniform: the position is the wave's
+      const bool valid = i0 + k < nsteps && x >= 0 && x < w;   // uniform: the position is the wave's
       const uint32_t cost = (uint32_t)__popc(fl[k] ^ fr[k]);
       // DynamicProgramming::update
       uint32_t out = min(dp - last_min, p2);
       const uint32_t prev = lane_prev(dp), next = lane_next(dp);
       if (lane != 0) out = min(out, prev - last_min + p1);
       if (lane != kDisp - 1) out = min(out, next - last_min + p1);
-      dp = out + cost;
-      last_min = wave_min_u32(dp);
-      dest[((size_t)y * w + x) * kDisp + lane] = (uint8_t)dp;
+      const uint32_t ndp = out + cost;
+      const uint32_t nmin = wave_min_u32(ndp);
+      dp = valid ? ndp : dp;
+      last_min = valid ? nmin : last_min;
+      done[k] = ndp;
+      done_ok[k] = valid;
     }
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
@@ -224,8 +245,8 @@ struct plvs_sgm {
   int w = 0, h = 0, p1 = 10, p2 = 120;
   float uniqueness = 0.95f;
   hipStream_t stream = nullptr;
-  hipStream_t path_stream[kPaths] = {};   // the eight path passes are independent: they run side by side
-  hipEvent_t ev_census = nullptr, ev_path[kPaths] = {};
+  hipStream_t path_stream[kSideStreams] = {};   // the eight path passes are independent: they run side by side
+  hipEvent_t ev_census = nullptr, ev_path[kSideStreams] = {};
   uint8_t *d_left = nullptr, *d_right = nullptr, *d_cost = nullptr, *d_dl = nullptr, *d_dr = nullptr, *d_ml = nullptr,
           *d_mr = nullptr, *d_out = nullptr;
   uint32_t *d_cl = nullptr, *d_cr = nullptr;
@@ -240,7 +261,7 @@ int plvs_hip_sgm_destroy(plvs_sgm* s) {
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (s->stream) (void)hipStreamDestroy(s->stream);
-  for (int i = 0; i < kPaths; ++i) {
+  for (int i = 0; i < kSideStreams; ++i) {
     if (s->path_stream[i]) (void)hipStreamDestroy(s->path_stream[i]);
     if (s->ev_path[i]) (void)hipEventDestroy(s->ev_path[i]);
   }
@@ -262,7 +283,7 @@ int plvs_hip_sgm_create(int width, int height, int disparity_size, int p1, int p
   s->uniqueness = uniqueness;
   const size_t n = (size_t)width * height;
   hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
-  for (int i = 0; i < kPaths && e == hipSuccess; ++i) {
+  for (int i = 0; i < kSideStreams && e == hipSuccess; ++i) {
     e = hipStreamCreateWithFlags(&s->path_stream[i], hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_path[i], hipEventDisableTiming);
   }
@@ -301,20 +322,24 @@ int plvs_hip_sgm_execute_dev(plvs_sgm* s, const uint8_t* d_left, const uint8_t* 
   const uint32_t p1 = (uint32_t)s->p1, p2 = (uint32_t)s->p2;
   const unsigned gv = plvs::ceil_div((size_t)w, 4), gh = plvs::ceil_div((size_t)h, 4), go = plvs::ceil_div((size_t)(w + h - 1), 4);
   // A path pass is a chain of dependent steps with at most a wave or two per SIMD: alone it leaves the machine
-  // idle.  The eight passes write disjoint volumes, so they run on eight streams between two events (libsgm
-  // does the same, path_aggregation.cu:56-83) and hide each other's latency.
+  // idle.  The eight passes write disjoint volumes, so they run side by side (libsgm does the same,
+  // path_aggregation.cu:56-83) — on FOUR streams, because the runtime feeds the device through four hardware
+  // queues and streams beyond that share one (measured with eight: a queue got both 1240-step horizontal passes
+  // and a third pass, 605 of the stage's 616 us).  The passes are dealt by their measured lengths: the longest
+  // horizontal pass alone on the call's own stream, the other three streams about equal.
   PLVS_HIP_TRY(hipEventRecord(s->ev_census, st));
-  for (int i = 0; i < kPaths; ++i) PLVS_HIP_TRY(hipStreamWaitEvent(s->path_stream[i], s->ev_census, 0));
-  sgm_path<0, 1><<<gv, block, 0, s->path_stream[0]>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 0 * step);
-  sgm_path<0, -1><<<gv, block, 0, s->path_stream[1]>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 1 * step);
-  sgm_path<1, 0><<<gh, block, 0, s->path_stream[2]>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 2 * step);
-  sgm_path<-1, 0><<<gh, block, 0, s->path_stream[3]>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 3 * step);
-  sgm_path<1, 1><<<go, block, 0, s->path_stream[4]>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 4 * step);
-  sgm_path<-1, 1><<<go, block, 0, s->path_stream[5]>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 5 * step);
-  sgm_path<-1, -1><<<go, block, 0, s->path_stream[6]>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 6 * step);
-  sgm_path<1, -1><<<go, block, 0, s->path_stream[7]>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 7 * step);
+  for (int i = 0; i < kSideStreams; ++i) PLVS_HIP_TRY(hipStreamWaitEvent(s->path_stream[i], s->ev_census, 0));
+  hipStream_t q1 = s->path_stream[0], q2 = s->path_stream[1], q3 = s->path_stream[2];
+  sgm_path<-1, 0><<<gh, block, 0, st>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 3 * step);
+  sgm_path<1, 0><<<gh, block, 0, q1>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 2 * step);
+  sgm_path<-1, 1><<<go, block, 0, q2>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 5 * step);
+  sgm_path<0, -1><<<gv, block, 0, q3>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 1 * step);
+  sgm_path<1, -1><<<go, block, 0, q1>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 7 * step);
+  sgm_path<1, 1><<<go, block, 0, q2>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 4 * step);
+  sgm_path<0, 1><<<gv, block, 0, q3>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 0 * step);
+  sgm_path<-1, -1><<<go, block, 0, q3>>>(s->d_cl, s->d_cr, w, h, p1, p2, s->d_cost + 6 * step);
   PLVS_KERNEL_CHECK();
-  for (int i = 0; i < kPaths; ++i) {
+  for (int i = 0; i < kSideStreams; ++i) {
     PLVS_HIP_TRY(hipEventRecord(s->ev_path[i], s->path_stream[i]));
     PLVS_HIP_TRY(hipStreamWaitEvent(st, s->ev_path[i], 0));
   }
