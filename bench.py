@@ -15,10 +15,13 @@ ChunkHasher(id) mod N; every rank holds the same clouds, applies only the
 visits of its own chunks, and the per-step lists of updated chunk ids are
 all-gathered over RCCL.  Total work is fixed as N grows -> "strong" scaling.
 
-The JSON line also carries the front-end pieces measured so far (Hamming k=2
-matching) under "frontend", `roofline` (algorithmic bytes of SURVEY §8d over
-the measured GPU time of the integrate pipeline) and `cpu_baseline` (the CPU
-oracle timed on this box's host cores on a bounded sample).
+The JSON line also carries `roofline` (algorithmic bytes of SURVEY §8d over the
+measured GPU time of the integrate pipeline, per-stage times from HIP events on
+the library's own stream, HBM traffic from the committed PMC passes),
+`cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded
+sample), the order-free mode's figure, and under "frontend" the per-frame front
+end (ORB 2000, EDLines + LBD, both extractions on two threads, Hamming k = 2,
+SGM dense stereo) — N = 1 only.
 """
 import argparse
 import json
