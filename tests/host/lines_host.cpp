@@ -33,3 +33,34 @@ extern "C" int hostlines_run(int noct, const int* sizes, const uint16_t* const* 
   if ((int)kl.size() <= cap && !kl.empty()) memcpy(keylines_out, kl.data(), kl.size() * sizeof(KeyLine));
   return (int)kl.size();
 }
+
+// Timing of the host stages (test infrastructure): `reps` runs, ms per run of
+// [0] EdgeDrawing octave 0, [1] all octaves' EdgeDrawing, [2] fitting, [3] grouping, [4] selection.
+extern "C" void hostlines_bench(int noct, const int* sizes, const uint16_t* const* gd, const int16_t* const* dx,
+                                const int16_t* const* dy, double scale, int nfeatures, int img_w, int img_h,
+                                double min_length, double fit_err, int reps, double* ms) {
+  std::vector<OctaveDetector> det(noct);
+  std::vector<std::pair<int, int>> sz(noct);
+  EdParams P;
+  P.fit_err_threshold = fit_err;
+  for (int k = 0; k < 5; ++k) ms[k] = 0;
+  for (int r = 0; r < reps; ++r) {
+    for (int i = 0; i < noct; ++i) {
+      OctaveMaps m;
+      m.w = sizes[2 * i]; m.h = sizes[2 * i + 1];
+      m.gd = gd[i]; m.dx = dx[i]; m.dy = dy[i];
+      sz[i] = {m.w, m.h};
+      det[i].run(m, P);
+      if (i == 0) ms[0] += det[i].ms_draw;
+      ms[1] += det[i].ms_draw;
+      ms[2] += det[i].ms_fit;
+    }
+    const double t0 = clock_ms();
+    std::vector<KeyLine> kl = group_and_flatten(det, sz, scale);
+    const double t1 = clock_ms();
+    select_lines(kl, nfeatures, img_w, img_h, min_length);
+    ms[3] += t1 - t0;
+    ms[4] += clock_ms() - t1;
+  }
+  for (int k = 0; k < 5; ++k) ms[k] /= reps;
+}
