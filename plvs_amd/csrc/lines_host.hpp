@@ -161,13 +161,24 @@ class OctaveDetector {
       // scan order, so this is one linear pass
       const int rows = (H - 1) / 2, cols = (W - 1) / 2;   // y = 1,3,.. < H-1 ; x = 1,3,.. < W-1
       const uint8_t* f = maps.anchors;
-      for (int c = 0; c < cols; ++c)
-        for (int r = 0; r < rows; ++r)
-          if (f[(size_t)c * rows + r]) {
-            if (ax.size() >= cap) return false;
-            ax.push_back((uint16_t)(2 * c + 1));
-            ay.push_back((uint16_t)(2 * r + 1));
-          }
+      const size_t nflags = (size_t)rows * cols;           // flat index = c * rows + r: already the scan order
+      auto take = [&](size_t i) -> bool {
+        if (ax.size() >= cap) return false;
+        const size_t c = i / (size_t)rows;
+        ax.push_back((uint16_t)(2 * c + 1));
+        ay.push_back((uint16_t)(2 * (i - c * rows) + 1));
+        return true;
+      };
+      size_t i = 0;
+      for (; i + 8 <= nflags; i += 8) {                    // anchors are sparse: eight flags per test
+        uint64_t wd;
+        memcpy(&wd, f + i, 8);
+        if (wd == 0) continue;
+        for (size_t k = 0; k < 8; ++k)
+          if (f[i + k] && !take(i + k)) return false;
+      }
+      for (; i < nflags; ++i)
+        if (f[i] && !take(i)) return false;
     } else {
       for (int x = 1; x < W - 1; x += P.scan_interval)
         for (int y = 1; y < H - 1; y += P.scan_interval) {

@@ -10,6 +10,22 @@
 
 using namespace plvs::lines;
 
+// The anchor flag map the device kernel would produce (same test, laid out in scan order).
+static void make_flags(OctaveMaps& m, const EdParams& P, std::vector<uint8_t>& flags) {
+  if (m.w < 3 || m.h < 3) return;
+  const int rows = (m.h - 1) / 2, cols = (m.w - 1) / 2;
+  flags.assign((size_t)rows * cols, 0);
+  auto g = [&](int idx) { return (int)(m.gd[idx] & 0x1ff); };
+  for (int c = 0; c < cols; ++c)
+    for (int r = 0; r < rows; ++r) {
+      const int x = 2 * c + 1, y = 2 * r + 1, idx = y * m.w + x, gi = g(idx), t = P.anchor_threshold;
+      const bool hor = (m.gd[idx] & 0x8000u) != 0;
+      flags[(size_t)c * rows + r] = hor ? (gi >= g(idx - m.w) + t && gi >= g(idx + m.w) + t)
+                                        : (gi >= g(idx - 1) + t && gi >= g(idx + 1) + t);
+    }
+  m.anchors = flags.data();
+}
+
 // gd/dx/dy: concatenated per-octave maps; sizes: (w,h) pairs.
 extern "C" int hostlines_run(int noct, const int* sizes, const uint16_t* const* gd, const int16_t* const* dx,
                              const int16_t* const* dy, double scale, int nfeatures, int img_w, int img_h,
@@ -23,6 +39,10 @@ extern "C" int hostlines_run(int noct, const int* sizes, const uint16_t* const* 
     m.w = sizes[2 * i]; m.h = sizes[2 * i + 1];
     m.gd = gd[i]; m.dx = dx[i]; m.dy = dy[i];
     sz[i] = {m.w, m.h};
+    // PLVS_HOSTLINES_FLAGS=1: hand over the anchor flag map the device kernel would produce (same test, laid
+    // out in scan order), so that the flag-consuming path of draw_edges is covered on the CPU too
+    std::vector<uint8_t> flags;
+    if (getenv("PLVS_HOSTLINES_FLAGS")) make_flags(m, P, flags);
     if (!det[i].run(m, P)) det[i].segments.clear();
     per_octave[i] = (int)det[i].segments.size();
     if (getenv("PLVS_LINES_PROFILE"))
@@ -44,12 +64,18 @@ extern "C" void hostlines_bench(int noct, const int* sizes, const uint16_t* cons
   EdParams P;
   P.fit_err_threshold = fit_err;
   for (int k = 0; k < 5; ++k) ms[k] = 0;
+  std::vector<std::vector<uint8_t>> flags(noct);
+  std::vector<OctaveMaps> maps(noct);
+  for (int i = 0; i < noct; ++i) {
+    OctaveMaps& m = maps[i];
+    m.w = sizes[2 * i]; m.h = sizes[2 * i + 1];
+    m.gd = gd[i]; m.dx = dx[i]; m.dy = dy[i];
+    sz[i] = {m.w, m.h};
+    if (getenv("PLVS_HOSTLINES_FLAGS")) make_flags(m, P, flags[i]);
+  }
   for (int r = 0; r < reps; ++r) {
     for (int i = 0; i < noct; ++i) {
-      OctaveMaps m;
-      m.w = sizes[2 * i]; m.h = sizes[2 * i + 1];
-      m.gd = gd[i]; m.dx = dx[i]; m.dy = dy[i];
-      sz[i] = {m.w, m.h};
+      const OctaveMaps& m = maps[i];
       det[i].run(m, P);
       if (i == 0) ms[0] += det[i].ms_draw;
       ms[1] += det[i].ms_draw;

@@ -4,6 +4,7 @@ stages vs the oracle (CPU); full HIP + host path vs oracle, stage by stage (GPU)
 Bar: bit-exact KeyLine fields (compared as raw 68-byte records) and descriptor bits.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -86,6 +87,13 @@ def test_product_host_stages_match_oracle(oracle, name):
     assert list(per) == [ora.num_in_octave(o) for o in range(3)]
     assert len(kl) == len(okl) > 10
     assert kl.tobytes() == okl.tobytes()
+    # the same with the anchor test taken from a flag map, as the device hands it over
+    os.environ["PLVS_HOSTLINES_FLAGS"] = "1"
+    try:
+        kl_f, per_f = _run_hostlines(lib, ora, img)
+    finally:
+        del os.environ["PLVS_HOSTLINES_FLAGS"]
+    assert list(per_f) == list(per) and kl_f.tobytes() == okl.tobytes()
     # nfeatures = 0: no sort, so the min-length cut falls at the first short line in
     # detection order (the reference's behaviour, src/LineExtractor.cc:229-266)
     ora_all = oracle.lines(nfeatures=0)
