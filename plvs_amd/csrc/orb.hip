@@ -433,6 +433,7 @@ struct plvs_orb {
   float scale_factor;
   std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
   std::vector<int> features_per_level;
+  std::vector<plvs::orb::QuadTree> tree_scratch;   // per level: node array and key pool of the quadtree, kept across frames
   int umax[kHalfPatch + 1];
   // geometry for the current image size
   int img_w = 0, img_h = 0;
@@ -651,6 +652,7 @@ int plvs_hip_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_
   }
   // features per level (:481-493)
   o->features_per_level.resize(nlevels);
+  o->tree_scratch.resize(nlevels);
   const float factor = 1.0f / scale_factor;
   float desired = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
   int sum = 0;
@@ -794,7 +796,7 @@ static int orb_extract_body(plvs_orb* o, int lap0, int lap1, plvs_keypoint* kps,
         cands[i] = Cand{(float)(wd & 0xfffu), (float)((wd >> 12) & 0xfffu), (float)(wd >> 24)};
       }
       selected[l] = distribute_quadtree(cands, kMinBorder, L.w - kEdgeThreshold + 3, kMinBorder,
-                                        L.h - kEdgeThreshold + 3, o->features_per_level[l]);
+                                        L.h - kEdgeThreshold + 3, o->features_per_level[l], &o->tree_scratch[l]);
     };
     // the levels are dealt to nt threads (the caller is one of them), largest first to the least loaded
     const int nt = plvs::env_int("PLVS_HIP_ORB_TREE_THREADS", std::min(nl, 3), 1, nl);
