@@ -349,9 +349,9 @@ __global__ __launch_bounds__(kTileThreads, 6) void ray_tiles(
       a_wuu[j] = v_wuu[k];
       a_wu[j] = v_wu[k];
     }
-  // the tile's place in the run numbering (decoupled look-back, wave 0)
-  tile_lookback(t, ngroups, ntiles, tile_state, &sh_base, &ctr->num_desc, tid);
-  __syncthreads();
+    // the tile's place in the run numbering (decoupled look-back, wave 0)
+    tile_lookback(t, ngroups, ntiles, tile_state, &sh_base, &ctr->num_desc, tid);
+    __syncthreads();
     __syncthreads();
     const uint32_t dbase = sh_base;
 #pragma unroll
