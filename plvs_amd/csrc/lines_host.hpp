@@ -409,10 +409,27 @@ class OctaveDetector {
       const size_t e = cstart[c + 1];
       while (e > s + L) {
         // slide until 15 consecutive pixels fit a line
+        // The window's sums are sums of integers below 2^53: exact in the reference's double accumulators in
+        // any order, so they are carried along the slide (two pixels out, two in) instead of re-added.
         double err = 0;
+        int64_t wx = 0, wy = 0, wxx = 0, wyy = 0, wxy = 0;
+        size_t wbeg = s, wend = s;   // the sums cover [wbeg, wend)
         while (e > s + L) {
           const bool hor0 = horizontal(ey[s] * W + ex[s]);
-          accumulate(F, ex, ey, s, s + L, hor0, true);
+          for (; wbeg < s; ++wbeg) {
+            const int64_t x = ex[wbeg], y = ey[wbeg];
+            wx -= x; wy -= y; wxx -= x * x; wyy -= y * y; wxy -= x * y;
+          }
+          for (; wend < s + L; ++wend) {
+            const int64_t x = ex[wend], y = ey[wend];
+            wx += x; wy += y; wxx += x * x; wyy += y * y; wxy += x * y;
+          }
+          {
+            const double suu = (double)(hor0 ? wxx : wyy), su = (double)(hor0 ? wx : wy), suv = (double)wxy,
+                         sv = (double)(hor0 ? wy : wx);
+            F.ata[0] = (float)suu; F.ata[1] = (float)su; F.ata[2] = (float)su; F.ata[3] = (float)(double)L;
+            F.atv[0] = (float)suv; F.atv[1] = (float)sv;
+          }
           solve(F, eq2);
           err = 0;
           for (int i = 0; i < L; ++i) {
