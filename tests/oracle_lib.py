@@ -455,7 +455,21 @@ class _VoxbloxLike:
 
 
 HOSTCORE_DIR = os.path.join(ROOT, "tests", "host")
-HOSTCORE_SO = os.path.join(HOSTCORE_DIR, "libhostcore.so")
+
+
+ROCM_CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def _host_build(stem, src, hdrs):
+    """Builds a host harness on demand.  PLVS_HOST_CXX=rocm-clang compiles it with the compiler and
+    optimisation level the product's host code is built with (hipcc's clang, -O3) instead of g++ -O2."""
+    if os.environ.get("PLVS_HOST_CXX") == "rocm-clang":
+        cxx, opt, so = ROCM_CLANG, "-O3", os.path.join(HOSTCORE_DIR, stem + "_clang.so")
+    else:
+        cxx, opt, so = "g++", "-O2", os.path.join(HOSTCORE_DIR, stem + ".so")
+    if not os.path.exists(so) or max(os.path.getmtime(f) for f in [src] + hdrs) > os.path.getmtime(so):
+        subprocess.run([cxx, opt, "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", src, "-o", so], check=True)
+    return so
 
 
 def load_hostcore():
@@ -464,31 +478,23 @@ def load_hostcore():
     src = os.path.join(HOSTCORE_DIR, "tsdf_core_host.cpp")
     hdr = os.path.join(ROOT, "plvs_amd", "csrc", "tsdf_chisel_core.hpp")
     hdr2 = os.path.join(ROOT, "plvs_amd", "csrc", "tsdf_voxblox_core.hpp")
-    if not os.path.exists(HOSTCORE_SO) or max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(hdr2)) > os.path.getmtime(HOSTCORE_SO):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", src, "-o", HOSTCORE_SO], check=True)
-    return ctypes.CDLL(HOSTCORE_SO)
+    return ctypes.CDLL(_host_build("libhostcore", src, [hdr, hdr2]))
 
 
 def load_hostorb():
     """Host (g++) build of plvs_amd/csrc/orb_octree.hpp (the product's quadtree)."""
-    so = os.path.join(HOSTCORE_DIR, "libhostorb.so")
     src = os.path.join(HOSTCORE_DIR, "orb_host.cpp")
     hdr = os.path.join(ROOT, "plvs_amd", "csrc", "orb_octree.hpp")
-    if not os.path.exists(so) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(so):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", src, "-o", so], check=True)
-    lib = ctypes.CDLL(so)
+    lib = ctypes.CDLL(_host_build("libhostorb", src, [hdr]))
     lib.hostorb_distribute.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _i]
     return lib
 
 
 def load_hostlines():
     """Host (g++) build of plvs_amd/csrc/lines_host.hpp (the product's sequential line stages)."""
-    so = os.path.join(HOSTCORE_DIR, "libhostlines.so")
     src = os.path.join(HOSTCORE_DIR, "lines_host.cpp")
     hdr = os.path.join(ROOT, "plvs_amd", "csrc", "lines_host.hpp")
-    if not os.path.exists(so) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(so):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", src, "-o", so], check=True)
-    return ctypes.CDLL(so)
+    return ctypes.CDLL(_host_build("libhostlines", src, [hdr]))
 
 
 def load():

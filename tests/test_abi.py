@@ -61,3 +61,24 @@ def test_header_is_plain_c_and_links():
                         os.path.join(d, "abi_cpp.o")], check=True)
         subprocess.run(["gcc", os.path.join(d, "abi_c.o"), "-L", lib_dir, "-l:libplvs_hip.so",
                         "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", os.path.join(d, "abi")], check=True)
+
+
+def test_host_stages_under_the_product_compiler():
+    """The product's host code (quadtree, line stages, TSDF arithmetic header) is compiled by hipcc's clang at
+    -O3; the CPU agreement checks use g++ -O2 by default.  Run them once more on harnesses built with that clang."""
+    import subprocess
+    import sys
+    import pytest
+    from tests import oracle_lib
+    if not os.path.exists(oracle_lib.ROCM_CLANG):
+        pytest.skip("no ROCm clang here")
+    env = dict(os.environ, PLVS_HOST_CXX="rocm-clang")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider",
+                        "tests/test_lines.py::test_product_host_stages_match_oracle",
+                        "tests/test_orb.py::test_product_quadtree_on_host_matches_oracle",
+                        "tests/test_tsdf_chisel.py::test_device_arithmetic_on_host_matches_oracle",
+                        "tests/test_tsdf_chisel.py::test_shard_cull_never_drops_an_owned_visit",
+                        "tests/test_tsdf_voxblox.py", "-m", "not gpu"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
