@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: world_size-2 gloo run of the block-list exchange, with the
+"""N > 1 path on CPU: world_size 2 and 3 gloo runs of the block-list exchange, with the
 CPU oracle standing in for each rank's shard of the map.
 
 Checks: the owner function used by the host equals the one compiled into the
@@ -59,8 +59,8 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_block_list_exchange():
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])      # 3: the owner function's non-power-of-two path
+def test_gloo_block_list_exchange(world):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -71,9 +71,12 @@ def test_two_rank_gloo_block_list_exchange():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, seen0, ids0), (r1, seen1, ids1) = out
-    assert seen0 == seen1                                  # every rank saw the same gathered lists
-    assert not (set(ids0) & set(ids1))                     # shards are disjoint
+    seen = [o[1] for o in out]
+    ids = [set(o[2]) for o in out]
+    assert all(s == seen[0] for s in seen)                 # every rank saw the same gathered lists
+    for a in range(world):
+        for b in range(a + 1, world):
+            assert not (ids[a] & ids[b])                   # shards are disjoint
     sys.path.insert(0, ROOT)
     from tests import oracle_lib
     from tests.plvs_amd_synth import make_keyframes, TUM1
@@ -85,6 +88,7 @@ def test_two_rank_gloo_block_list_exchange():
     full = oracle_lib.load().chisel(0.05)
     for kf in make_keyframes(2, cam=cam, seed=5):
         full.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
-    assert set(ids0) | set(ids1) == {tuple(x) for x in full.chunk_ids()}
-    gathered = {t for step in seen0 for l in step for t in l}
-    assert gathered == set(ids0) | set(ids1)               # the exchange announced every new block
+    union = set().union(*ids)
+    assert union == {tuple(x) for x in full.chunk_ids()}
+    gathered = {t for step in seen[0] for l in step for t in l}
+    assert gathered == union                               # the exchange announced every new block
