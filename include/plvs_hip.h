@@ -430,6 +430,8 @@ int plvs_hip_tsdf_chisel_set_profiling(plvs_tsdf_chisel* h, int enable);
 int plvs_hip_tsdf_chisel_stage_ms(plvs_tsdf_chisel* h, double* ms, int cap, int* nstages,
                                   int64_t* calls);
 const char* plvs_hip_tsdf_chisel_stage_name(int i);
+/* Stage names of the pipeline the handle last ran (they differ between the ordered and the order-free mode). */
+const char* plvs_hip_tsdf_chisel_stage_name_of(plvs_tsdf_chisel* h, int i);
 
 int plvs_hip_tsdf_chisel_num_chunks(plvs_tsdf_chisel* h, int* n);
 /* Chunk ids (x,y,z int32 triples) of all chunks, in pool-slot order. */

@@ -97,6 +97,8 @@ lib.plvs_hip_tsdf_chisel_set_profiling.argtypes = [_vp, _i]
 lib.plvs_hip_tsdf_chisel_stage_ms.argtypes = [_vp, _vp, _i, _ip, ctypes.POINTER(ctypes.c_int64)]
 lib.plvs_hip_tsdf_chisel_stage_name.argtypes = [_i]
 lib.plvs_hip_tsdf_chisel_stage_name.restype = ctypes.c_char_p
+lib.plvs_hip_tsdf_chisel_stage_name_of.argtypes = [_vp, _i]
+lib.plvs_hip_tsdf_chisel_stage_name_of.restype = ctypes.c_char_p
 lib.plvs_hip_tsdf_chisel_updated_chunk_ids_dev.argtypes = [_vp, _vp, _i, _ip, _vp]
 lib.plvs_hip_tsdf_chisel_num_chunks.argtypes = [_vp, _ip]
 lib.plvs_hip_tsdf_chisel_chunk_ids.argtypes = [_vp, _vp, _i, _ip]

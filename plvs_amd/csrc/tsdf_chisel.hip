@@ -36,6 +36,7 @@
 #include "tsdf_directory.hpp"
 #include "tsdf_chisel_view.hpp"
 #include "tsdf_tiles.hpp"
+#include "tsdf_walk.hpp"
 
 using namespace plvs;
 using namespace plvs::chisel;
@@ -881,6 +882,16 @@ struct plvs_tsdf_chisel {
   DevBuf<uint32_t> st_kfid;
   plvs_tsdf_stats stats{};
   uint32_t last_updated = 0;
+  // single-walk pipeline (tsdf_walk.hpp)
+  WalkCounters* d_wctr = nullptr;   // [2]: the call's counters, the colour pass's voxel list
+  WalkCounters* h_wctr = nullptr;   // pinned
+  DevBuf<uint4> w_rec, w_seg, w_sorted_seg;
+  DevBuf<uint32_t> w_chunk_nseg, w_chunk_off, w_chunk_fill, w_active_off, w_masks, w_dummy, w_seg_cnt, w_tile_visits;
+  DevBuf<uint8_t> w_cold;
+  DevBuf<uint32_t> w_runkey, w_run_cnt, w_val0, w_val1;   // runs: per-tile regions of 2^run_r1_log2 slots
+  uint32_t run_r1_log2 = 6;
+  float scale_u = 1.f, scale_w = 1.f;   // fixed-point scales of the order-free accumulators (powers of two)
+  int stage_set = 0;                    // which pipeline the stage times belong to
   hipStream_t side = nullptr;   // second stream for the colour chain
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // optional per-stage timing (HIP events on the caller's stream)
@@ -893,6 +904,161 @@ struct plvs_tsdf_chisel {
 static int read_counters(plvs_tsdf_chisel* h, hipStream_t s) {
   PLVS_HIP_TRY(hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
   PLVS_HIP_TRY(hipStreamSynchronize(s));
+  return PLVS_OK;
+}
+
+// ------------------------------------------------------------------ single-walk pipeline (tsdf_walk.hpp)
+constexpr int kWalkStages = 4;
+const char* const kWalkStageNames[kWalkStages] = {"walk_tiles", "sort_segments", "apply_chunks", "fold_colours"};
+const char* const kRunStageNames[kNumStages] = {"walk_runs", "sort_runs", "place_runs", "expand_runs", "chain_runs",
+                                                "-"};
+
+static int read_walk_counters(plvs_tsdf_chisel* h, hipStream_t s) {
+  PLVS_HIP_TRY(hipMemcpyAsync(h->h_wctr, h->d_wctr, 2 * sizeof(WalkCounters), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  return PLVS_OK;
+}
+
+static int walk_fail(plvs_tsdf_chisel* h, uint32_t err) {
+  h->poisoned = true;
+  plvs::set_error("tsdf_chisel integrate: %s%s(err=%u)",
+                  (err & kErrPoolFull) ? "chunk pool full (raise max_chunks) " : "",
+                  (err & kErrCoordRange) ? "voxel coordinates beyond +-2^20 (outside the supported map extent) " : "", err);
+  return PLVS_ERR_CAPACITY;
+}
+
+// Stable sort of the D runs walk_tiles left in the per-tile regions by voxel key: per voxel its runs
+// in tile (= point) order; the value carried is the run's slot (tile = slot >> r1_log2, mask at slot * 8).
+static int sort_runs(plvs_tsdf_chisel* h, uint32_t D, uint32_t ntiles, hipStream_t s, const uint32_t** skeys,
+                     const uint32_t** sval) {
+  const size_t nslots = (size_t)ntiles << h->run_r1_log2;
+  PLVS_HIP_TRY(h->dkey0.reserve(D));
+  PLVS_HIP_TRY(h->dkey1.reserve(D));
+  PLVS_HIP_TRY(h->w_val0.reserve(D));
+  PLVS_HIP_TRY(h->w_val1.reserve(D));
+  PLVS_HIP_TRY(h->scratch.reserve(radix_scratch_words(nslots)));
+  int key_bits = 12;
+  while ((1ll << (key_bits - 12)) < (long long)h->num_chunks) ++key_bits;
+  bool second = false;
+  PLVS_HIP_TRY(radix_sort_sparse_u32(h->w_runkey.p, h->w_run_cnt.p, h->run_r1_log2, nslots, D, h->dkey0.p, h->w_val0.p,
+                                     h->dkey1.p, h->w_val1.p, 0, key_bits, h->scratch.p, s, &second));
+  *skeys = second ? h->dkey1.p : h->dkey0.p;
+  *sval = second ? h->w_val1.p : h->w_val0.p;
+  return PLVS_OK;
+}
+
+// Order-free mode: walk_tiles -> segment sort -> apply_chunks (+ the colour fold when the call met voxels
+// whose colour weight is below 254).
+static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uint8_t* d_rgb, const uint32_t* d_kfid,
+                              int n, int nclouds, hipStream_t s) {
+  const uint32_t ntiles = ceil_div((size_t)n, kWalkRays);
+  const int max_chunks = h->prm.max_chunks;
+  PLVS_HIP_TRY(h->tile_state.reserve((size_t)ntiles + 1));
+  PLVS_HIP_TRY(h->w_chunk_nseg.reserve((size_t)max_chunks));
+  PLVS_HIP_TRY(h->w_chunk_off.reserve((size_t)max_chunks + 1));
+  PLVS_HIP_TRY(h->w_chunk_fill.reserve((size_t)max_chunks));
+  PLVS_HIP_TRY(h->w_active_off.reserve((size_t)max_chunks + 1));
+  PLVS_HIP_TRY(h->updated.reserve((size_t)max_chunks + 1));
+  PLVS_HIP_TRY(h->w_seg_cnt.reserve(ntiles));
+  PLVS_HIP_TRY(h->w_tile_visits.reserve(ntiles));
+  // every tile owns kWalkLimit records / kWalkChunks segments; the spill area behind them grows on demand
+  const size_t rec_own = (size_t)ntiles * kWalkLimit, seg_own = (size_t)ntiles * kWalkChunks;
+  if (rec_own + (1 << 16) >= 0xFFFFFFFFull) {
+    plvs::set_error("tsdf_chisel integrate: %d points in one call exceed the record index range (split the batch)", n);
+    return PLVS_ERR_CAPACITY;
+  }
+  size_t rec_spill = std::max<size_t>(h->w_rec.cap > rec_own ? h->w_rec.cap - rec_own : 0, (size_t)1 << 16);
+  size_t seg_spill = std::max<size_t>(h->w_seg.cap / 2 > seg_own ? h->w_seg.cap / 2 - seg_own : 0, (size_t)1 << 12);
+  PLVS_HIP_TRY(h->w_run_cnt.reserve(ntiles));
+  h->stage_set = 1;
+  const int chunks_before = h->num_chunks;
+#define STAGE_MARK(i) \
+  do { if (h->profiling) PLVS_HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
+  for (int attempt = 0;; ++attempt) {
+    PLVS_HIP_TRY(h->w_rec.reserve(rec_own + rec_spill));
+    PLVS_HIP_TRY(h->w_seg.reserve(2 * (seg_own + seg_spill)));
+    PLVS_HIP_TRY(h->w_sorted_seg.reserve(h->w_seg.cap));
+    PLVS_HIP_TRY(h->w_runkey.reserve((size_t)ntiles << h->run_r1_log2));
+    PLVS_HIP_TRY(h->w_masks.reserve(((size_t)ntiles << h->run_r1_log2) * 8));
+    PLVS_HIP_TRY(hipMemsetAsync(h->d_wctr, 0, 2 * sizeof(WalkCounters), s));
+    PLVS_HIP_TRY(hipMemsetAsync(h->w_chunk_nseg.p, 0, (size_t)max_chunks * sizeof(uint32_t), s));
+    STAGE_MARK(0);
+    AccOut out{h->w_rec.p, (uint32_t)std::min<size_t>(rec_own + rec_spill, 0xFFFFFFFFu), h->w_seg.p,
+               (uint32_t)std::min<size_t>(seg_own + seg_spill, 0xFFFFFFFFu), h->w_seg_cnt.p, h->w_tile_visits.p};
+    RunOut runs{h->w_runkey.p, h->w_masks.p, h->w_run_cnt.p, h->run_r1_log2};
+    hipLaunchKernelGGL(walk_tiles<false>, dim3(ntiles), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
+                       h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw, out, runs,
+                       plvs::env_int("PLVS_WALK_EXP", 0, 0, 255));
+    STAGE_MARK(1);
+    const unsigned seg_blocks = ceil_div(seg_own + seg_spill, kSegSpan);
+    hipLaunchKernelGGL(seg_pass<false>, dim3(seg_blocks), dim3(256), 0, s, h->w_seg.p, out.seg_cap, ntiles,
+                       h->w_seg_cnt.p, h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p,
+                       h->d_wctr);
+    hipLaunchKernelGGL(seg_scan, dim3(1), dim3(1024), 0, s, h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p,
+                       h->updated.p, h->w_active_off.p, h->d_wctr, &h->d_ctr->num_chunks, max_chunks,
+                       h->w_tile_visits.p, h->w_run_cnt.p, ntiles);
+    hipLaunchKernelGGL(seg_pass<true>, dim3(seg_blocks), dim3(256), 0, s, h->w_seg.p, out.seg_cap, ntiles,
+                       h->w_seg_cnt.p, h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p,
+                       h->d_wctr);
+    STAGE_MARK(2);
+    hipLaunchKernelGGL(apply_chunks, dim3(4096), dim3(kApplyThreads), 0, s, h->w_sorted_seg.p, h->updated.p,
+                       h->w_active_off.p, h->w_rec.p, 1.0 / (double)h->scale_u, 1.0 / (double)h->scale_w, d_kfid, h->sdf,
+                       h->weight, h->kfid, h->d_wctr);
+    PLVS_KERNEL_CHECK();
+    STAGE_MARK(3);
+    int rc = read_walk_counters(h, s);
+    if (rc != PLVS_OK) return rc;
+    const uint32_t err = h->h_wctr->err;
+    if (err & ~kErrScratch) return walk_fail(h, err);
+    if (err & kErrScratch) {   // the map is untouched (apply_chunks left at once): grow and repeat
+      if (attempt >= 8) return walk_fail(h, err);
+      rec_spill = std::max<size_t>(rec_spill, (size_t)h->h_wctr->rec_top * 2);
+      seg_spill = std::max<size_t>(seg_spill, (size_t)h->h_wctr->seg_top * 2);
+      while ((1u << h->run_r1_log2) < h->h_wctr->run_need) ++h->run_r1_log2;
+      if (((size_t)ntiles << h->run_r1_log2) >= 0xFFFFFFFFull) return walk_fail(h, err);
+      continue;
+    }
+    break;
+  }
+  const WalkCounters& c = *h->h_wctr;
+  h->num_chunks = h->h_ctr->num_chunks;
+  h->stats.visits = (int64_t)c.total_visits;
+  h->stats.new_chunks = h->num_chunks - chunks_before;
+  h->stats.updated_chunks = (int32_t)c.num_updated;
+  h->stats.voxels = (int32_t)c.num_heads;
+  h->stats.max_run = (int32_t)c.max_run;
+  h->last_updated = c.num_updated;
+  float ms[3] = {0.f, 0.f, 0.f};
+  if (h->profiling)
+    for (int i = 0; i < 3; ++i) PLVS_HIP_TRY(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+  float ms_colour = 0.f;
+  const uint32_t D = c.num_desc;
+  if (D > 0) {
+    // ---- colour fold: the truncating u8 mean is order dependent -> through the sorted runs of the
+    // voxels whose colour weight is below 254
+    STAGE_MARK(4);
+    const uint32_t* skeys = nullptr;
+    const uint32_t* sval = nullptr;
+    int rc = sort_runs(h, D, ntiles, s, &skeys, &sval);
+    if (rc != PLVS_OK) return rc;
+    PLVS_HIP_TRY(h->heads.reserve(D));
+    PLVS_HIP_TRY(h->w_dummy.reserve((size_t)max_chunks + 1));
+    hipLaunchKernelGGL(voxel_heads, dim3(ceil_div(D, 256 * kHeadTiles)), dim3(256), 0, s, skeys, D, h->heads.p,
+                       h->w_dummy.p, h->d_wctr + 1);
+    hipLaunchKernelGGL(fold_colours_masks, dim3(std::min<size_t>(ceil_div(D, 256), 2048)), dim3(256), 0, s, skeys,
+                       sval, D, h->run_r1_log2, h->heads.p, h->w_masks.p, d_rgb, h->rgbw, &h->d_wctr[1].num_heads);
+    PLVS_KERNEL_CHECK();
+    STAGE_MARK(5);
+    PLVS_HIP_TRY(hipStreamSynchronize(s));
+    if (h->profiling) PLVS_HIP_TRY(hipEventElapsedTime(&ms_colour, h->ev[4], h->ev[5]));
+  }
+#undef STAGE_MARK
+  if (h->profiling) {
+    for (int i = 0; i < 3; ++i) h->stage_ms[i] += ms[i];
+    h->stage_ms[3] += ms_colour;
+    h->prof_calls++;
+  }
   return PLVS_OK;
 }
 
@@ -968,6 +1134,16 @@ int plvs_hip_tsdf_chisel_create(const plvs_tsdf_chisel_params* p, plvs_tsdf_chis
   CREATE_TRY(hipMalloc((void**)&h->rgbw, nvox * sizeof(uint32_t)));
   CREATE_TRY(hipMalloc((void**)&h->d_ctr, sizeof(Counters)));
   CREATE_TRY(hipHostMalloc((void**)&h->h_ctr, sizeof(Counters)));
+  CREATE_TRY(hipMalloc((void**)&h->d_wctr, 2 * sizeof(WalkCounters)));
+  CREATE_TRY(hipHostMalloc((void**)&h->h_wctr, 2 * sizeof(WalkCounters)));
+  {
+    // Fixed-point scales of the order-free accumulators: a tile adds at most kWalkRays terms per voxel,
+    // |w_u u| < weight / 2 and w_u <= weight / (2 diag); the largest powers of two that keep a tile's
+    // sums inside 31 bits (one bit of headroom).
+    const double wu_max = (double)p->weight / (2.0 * (double)P.diag), wuu_max = 0.5 * (double)p->weight;
+    h->scale_u = (float)std::exp2(std::floor(std::log2(1073741824.0 / (kWalkRays * wuu_max))));
+    h->scale_w = (float)std::exp2(std::floor(std::log2(1073741824.0 / (kWalkRays * wu_max))));
+  }
   CREATE_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
   CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   CREATE_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
@@ -993,6 +1169,12 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   (void)hipFree(h->rgbw);
   (void)hipFree(h->d_ctr);
   if (h->h_ctr) (void)hipHostFree(h->h_ctr);
+  (void)hipFree(h->d_wctr);
+  if (h->h_wctr) (void)hipHostFree(h->h_wctr);
+  h->w_rec.release(); h->w_seg.release(); h->w_sorted_seg.release(); h->w_chunk_nseg.release();
+  h->w_chunk_off.release(); h->w_chunk_fill.release(); h->w_active_off.release(); h->w_masks.release();
+  h->w_dummy.release(); h->w_cold.release(); h->w_runkey.release(); h->w_run_cnt.release(); h->w_val0.release();
+  h->w_val1.release(); h->w_seg_cnt.release(); h->w_tile_visits.release();
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->side) (void)hipStreamDestroy(h->side);
@@ -1060,6 +1242,9 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   // reset the per-call counters, keep num_chunks
   PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->total_visits, 0, sizeof(uint32_t), s));
   PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->err, 0, 5 * sizeof(uint32_t), s));
+
+  if (h->prm.order_free != 0) return integrate_walk_acc(h, d_xyz, d_rgb, d_kfid, n, nclouds, s);
+  h->stage_set = 0;
 
 #define STAGE_MARK(i) \
   do { if (h->profiling) PLVS_HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
@@ -1299,7 +1484,7 @@ int plvs_hip_tsdf_chisel_set_profiling(plvs_tsdf_chisel* h, int enable) {
 int plvs_hip_tsdf_chisel_stage_ms(plvs_tsdf_chisel* h, double* ms, int cap, int* nstages,
                                   int64_t* calls) {
   PLVS_REQUIRE(h && nstages, "null argument");
-  *nstages = kNumStages;
+  *nstages = h->stage_set == 1 ? kWalkStages : kNumStages;
   if (calls) *calls = h->prof_calls;
   for (int i = 0; i < kNumStages && i < cap; ++i) ms[i] = h->stage_ms[i];
   return PLVS_OK;
@@ -1307,6 +1492,13 @@ int plvs_hip_tsdf_chisel_stage_ms(plvs_tsdf_chisel* h, double* ms, int cap, int*
 
 const char* plvs_hip_tsdf_chisel_stage_name(int i) {
   return (i >= 0 && i < kNumStages) ? kStageNames[i] : "";
+}
+
+const char* plvs_hip_tsdf_chisel_stage_name_of(plvs_tsdf_chisel* h, int i) {
+  if (h == nullptr || i < 0) return "";
+  if (h->stage_set == 1) return i < kWalkStages ? kWalkStageNames[i] : "";
+  if (h->stage_set == 2) return i < kNumStages ? kRunStageNames[i] : "";
+  return i < kNumStages ? kStageNames[i] : "";
 }
 
 __global__ void gather_slot_ids(const uint32_t* __restrict__ slots, int n,

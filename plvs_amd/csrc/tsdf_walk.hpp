@@ -1,0 +1,939 @@
+// The single-walk integrate of the open_chisel back end (included by tsdf_chisel.hip).
+//
+// One workgroup = one tile of kWalkRays consecutive points.  Every thread walks the
+// Amanatides-Woo ray of its point ONCE (tsdf_chisel_core.hpp: the reference's arithmetic, bit for
+// bit) and the visits of the tile meet in an LDS hash table keyed by the voxel coordinates:
+//
+//   walk_acc    (order-free mode)  an entry accumulates sum(w_u * u), sum(w_u), the visit count and
+//               the last visiting ray of its voxel — in FIXED POINT, so the sums do not depend on
+//               the order in which the lanes arrive (deterministic, order-free).  At the end of the
+//               tile the entries are resolved to pool slots (first-touch chunks are inserted here),
+//               grouped by chunk and written as 16-byte records into (tile, chunk) segments.
+//               No global memory is touched inside the ray loop.
+//   seg_scan / seg_scatter        counting sort of the segment descriptors by chunk.
+//   apply_chunks                  "LDS-staged blocks": a workgroup owns a slab of one chunk, adds the
+//               chunk's records into 64-bit LDS accumulators and applies ONE update per voxel,
+//                   sdf <- (W * sdf + sum w_u u) / (W + sum w_u),   W <- W + sum w_u,
+//               kfid <- kfid of the last visiting point.
+//
+//   walk_runs   the order-preserving form: an entry keeps the BIT MASK of the tile's rays that visit
+//               its voxel (a ray visits a voxel at most once, so ray order = point order = the
+//               reference's update order).  One run descriptor + 32-byte mask per (tile, voxel)
+//               leaves the tile, numbered across tiles by a decoupled look-back.  The ordered mode
+//               emits every voxel; the order-free mode runs it only over the tiles that met a voxel
+//               whose colour weight is still below 254 and emits only those voxels (the truncating
+//               u8 colour mean is order dependent and must stay exact).
+//   expand_runs (ordered mode)    recomputes (w_u * u, w_u) of every visit from (point, voxel) —
+//               the walk is only needed to know WHICH voxels a ray visits — straight into voxel
+//               order for chain_runs.
+//   fold_colours_masks            ColorVoxel::IntegrateSimple visit by visit through the sorted runs.
+//
+// A tile whose visits do not fit the table is cut in halves (ray ranges), a single ray that does
+// not fit is cut into windows of visits; both are rare and only cost a re-walk.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "tsdf_chisel_core.hpp"
+#include "tsdf_directory.hpp"
+#include "tsdf_tiles.hpp"
+
+namespace {
+
+using namespace plvs::chisel;
+using plvs::tsdf::cloud_of;
+using plvs::tsdf::kCoordBias;
+using plvs::tsdf::kErrCoordRange;
+using plvs::tsdf::kErrPoolFull;
+
+constexpr int kWalkRays = 256;                  // rays (= threads) per tile
+constexpr int kWalkEntries = 1024;              // LDS hash table entries
+constexpr int kWalkLimit = kWalkEntries * 3 / 4;   // entries a (sub-)tile may use
+constexpr int kWalkWindow = kWalkLimit / 2;     // visits per window of a single over-long ray
+constexpr int kWalkChunks = 64;                 // per-tile chunk cache
+constexpr unsigned long long kVoxEmpty = ~0ull;
+constexpr uint32_t kErrScratch = 8u;            // record / segment / run buffers too small: the host grows them and retries
+
+struct WalkCounters {           // device-side, read back once per call
+  unsigned long long total_visits;
+  uint32_t err;
+  uint32_t num_heads;           // voxels updated by the call
+  uint32_t num_updated;         // chunks updated by the call
+  uint32_t max_run;             // most visits of one voxel in the call
+  uint32_t num_desc;            // runs of the call (sum of the per-tile counts)
+  uint32_t run_need;            // most run slots a tile asked for (when they did not fit)
+  uint32_t rec_top, seg_top;    // records / segments written (walk_acc)
+  uint32_t ncold;               // tiles that met a voxel with colour weight < 254
+  uint32_t split_tiles;         // tiles that had to be cut (table overflow)
+  uint32_t ticket, ticket2;     // tile tickets of walk_acc / walk_runs
+};
+
+__device__ __forceinline__ unsigned long long pack_voxel(int x, int y, int z) {
+  return ((unsigned long long)(unsigned)(z + kCoordBias) << 42) | ((unsigned long long)(unsigned)(y + kCoordBias) << 21) |
+         (unsigned long long)(unsigned)(x + kCoordBias);
+}
+__device__ __forceinline__ void unpack_voxel(unsigned long long k, int* x, int* y, int* z) {
+  *x = (int)(k & 0x1FFFFFu) - kCoordBias;
+  *y = (int)((k >> 21) & 0x1FFFFFu) - kCoordBias;
+  *z = (int)((k >> 42) & 0x1FFFFFu) - kCoordBias;
+}
+__device__ __forceinline__ uint32_t voxel_hash(int x, int y, int z) {
+  // the voxels of a tile lie in a small box: x + 2^10 y + 2^20 z is unique there
+  const uint32_t k = (uint32_t)x + ((uint32_t)y << 10) + ((uint32_t)z << 20);
+  return (k * 2654435761u) >> (32 - 10);
+}
+static_assert(kWalkEntries == 1024, "voxel_hash yields 10 bits");
+
+// Find-or-insert with the slot returned; usable by concurrent workgroups of ONE kernel: a block that
+// another workgroup is just inserting is waited for (its slot arrives a few instructions after its key).
+__device__ inline int dir_find_or_insert(const Directory& d, int x, int y, int z, int32_t* num_blocks,
+                                         uint32_t* err) {
+  unsigned long long key;
+  if (!pack_block(x, y, z, &key)) {
+    atomicOr(err, kErrCoordRange);
+    return -1;
+  }
+  uint32_t h = dir_hash(x, y, z, d.mask);
+  for (uint32_t probe = 0; probe <= d.mask; ++probe) {
+    unsigned long long cur = __hip_atomic_load(&d.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == kEmptyKey) {
+      cur = atomicCAS(&d.keys[h], kEmptyKey, key);
+      if (cur == kEmptyKey) {
+        const int slot = atomicAdd(num_blocks, 1);
+        if (slot < d.max_blocks) {
+          d.slot_ids[3 * slot + 0] = x;
+          d.slot_ids[3 * slot + 1] = y;
+          d.slot_ids[3 * slot + 2] = z;
+          __hip_atomic_store(&d.slots[h], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return slot;
+        }
+        atomicOr(err, kErrPoolFull);
+        __hip_atomic_store(&d.slots[h], -2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return -1;
+      }
+    }
+    if (cur == key) {
+      int slot;
+      int spins = 0;
+      do {
+        slot = __hip_atomic_load(&d.slots[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } while (slot == -1 && ++spins < (1 << 22));
+      return slot >= 0 ? slot : -1;
+    }
+    h = (h + 1) & d.mask;
+  }
+  atomicOr(err, kErrPoolFull);
+  return -1;
+}
+
+// ------------------------------------------------------------------ the walk of one (sub-)tile
+constexpr int kLogLen = 19;                      // visits per ray kept in the tile's visit log
+constexpr int kSlabs = 8;                        // a chunk is applied in slabs of kSlabVox voxels
+constexpr int kSlabVox = kChunkVox / kSlabs;
+
+struct SubTile {          // rays [lo, hi) of the tile, visits [vlo, vhi) of each ray
+  uint16_t lo, hi;
+  uint32_t vlo, vhi;
+};
+
+struct WalkShared {       // LDS state of walk_tiles
+  unsigned long long ekey[kWalkEntries];
+  unsigned long long ckey[kWalkChunks];        // chunk cache: packed chunk id,
+  int32_t cslot[kWalkChunks];                  //   pool slot,
+  uint32_t ccnt[kWalkChunks * kSlabs];         //   entries of the (sub-)tile per (chunk, slab),
+  uint16_t cbase[kWalkChunks * kSlabs];        //   first record of the group, relative to the flush's first record
+  uint32_t rbase;                              // first record of the flush
+  SubTile stack[24];
+  int sp;
+  uint32_t nent;          // entries in use
+  uint32_t overflow;      // the table is full: the (sub-)tile is cut
+  uint32_t wsum[kWalkRays / 64];
+  uint32_t base;          // look-back result
+};
+
+// Entry of the voxel in the table (inserted if absent); -1 when the table is full.
+__device__ __forceinline__ int table_find_or_insert(WalkShared& S, int vx, int vy, int vz) {
+  const unsigned long long key = pack_voxel(vx, vy, vz);
+  uint32_t h = voxel_hash(vx, vy, vz);
+  for (int probe = 0; probe < kWalkEntries; ++probe) {
+    unsigned long long cur = S.ekey[h];
+    if (cur == key) return (int)h;
+    if (cur == kVoxEmpty) {
+      if (*(volatile uint32_t*)&S.overflow) return -1;
+      cur = atomicCAS(&S.ekey[h], kVoxEmpty, key);
+      if (cur == kVoxEmpty) {
+        if (atomicAdd(&S.nent, 1u) >= (uint32_t)kWalkLimit) S.overflow = 1u;   // this insert still stands
+        return (int)h;
+      }
+      if (cur == key) return (int)h;
+    }
+    h = (h + 1) & (kWalkEntries - 1);
+  }
+  S.overflow = 1u;
+  return -1;
+}
+// Entry of a voxel that is known to be in the table.
+__device__ __forceinline__ int table_find(const WalkShared& S, int vx, int vy, int vz) {
+  const unsigned long long key = pack_voxel(vx, vy, vz);
+  uint32_t h = voxel_hash(vx, vy, vz);
+  for (int probe = 0; probe < kWalkEntries; ++probe) {
+    if (S.ekey[h] == key) return (int)h;
+    h = (h + 1) & (kWalkEntries - 1);
+  }
+  return -1;
+}
+
+// Walks the ray inside the window [vlo, vhi) of its visits; on_visit(k, vx, vy, vz, u), k = index of
+// the visit inside the window, returns false to abandon the walk (table overflow).  Returns the number
+// of accepted visits seen up to the point where the walk stopped (at most vhi).
+template <class OnVisit>
+__device__ __forceinline__ uint32_t walk_one(const Params& P, const Pose& pose, const Ray& ray, uint32_t vlo,
+                                             uint32_t vhi, OnVisit&& on_visit) {
+  RayCursor cur;
+  OwnerCache owner;
+  ray_begin(ray, &cur);
+  int vx, vy, vz;
+  uint32_t nv = 0;
+  bool go = true;
+  while (go && nv < vhi && ray_next(&cur, &vx, &vy, &vz)) {
+    Visit v;
+    const bool ok = resolve_visit(P, pose, ray, vx, vy, vz, &v, &owner);   // no early continue (see ray_count)
+    if (ok && nv >= vlo) go = on_visit(nv - vlo, vx, vy, vz, v.u);
+    nv += ok ? 1u : 0u;
+  }
+  return nv;
+}
+
+// Pose and ray of point i; false if the point casts no ray (or lies outside the supported extent).
+__device__ __forceinline__ bool tile_ray(const Params& P, const float* __restrict__ xyz,
+                                         const int32_t* __restrict__ offsets, int nclouds,
+                                         const Pose* __restrict__ poses, uint32_t i, Pose* pose, Ray* ray,
+                                         uint32_t* err) {
+  *pose = poses[cloud_of(offsets, nclouds, (int)i)];
+  if (!make_ray(P, *pose, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], ray)) return false;
+  if (!ray_in_coord_range(*ray)) {
+    atomicOr(err, kErrCoordRange);
+    return false;
+  }
+  if (P.shard_count > 2 && !walk_may_touch_owned(P, *ray)) return false;
+  return true;
+}
+
+__device__ __forceinline__ void subtile_reset(WalkShared& S, int tid) {
+#pragma unroll
+  for (int k = 0; k < kWalkEntries / kWalkRays; ++k) S.ekey[tid + k * kWalkRays] = kVoxEmpty;
+  if (tid < kWalkChunks) {
+    S.ckey[tid] = kEmptyKey;
+    S.cslot[tid] = -1;
+  }
+#pragma unroll
+  for (int k = 0; k < kWalkChunks * kSlabs / kWalkRays; ++k) S.ccnt[tid + k * kWalkRays] = 0;
+  if (tid == 0) {
+    S.nent = 0;
+    S.overflow = 0;
+  }
+}
+
+// After an overflow: cut the (sub-)tile (thread 0).  Rays first; a single ray is cut into windows of its
+// visits (a window of kWalkWindow visits always fits).
+__device__ __forceinline__ void subtile_split(WalkShared& S, const SubTile st) {
+  if (st.hi - st.lo > 1) {
+    const uint16_t mid = (uint16_t)((st.lo + st.hi) / 2);
+    S.stack[S.sp++] = SubTile{mid, st.hi, st.vlo, st.vhi};
+    S.stack[S.sp++] = SubTile{st.lo, mid, st.vlo, st.vhi};   // processed first: sub-tiles stay in point order
+  } else {
+    const uint32_t a = st.vlo, b = (st.vhi == 0xFFFFFFFFu) ? a + 2u * kWalkWindow : st.vhi;
+    const uint32_t mid = (st.vhi == 0xFFFFFFFFu) ? a + kWalkWindow : a + (b - a) / 2;
+    S.stack[S.sp++] = SubTile{st.lo, st.hi, mid, st.vhi};
+    S.stack[S.sp++] = SubTile{st.lo, st.hi, a, mid};
+  }
+}
+
+// Cache index of a chunk among the (sub-)tile's chunks; -1: the cache is full.
+__device__ __forceinline__ int chunk_cache_insert(WalkShared& S, int cx, int cy, int cz) {
+  unsigned long long key;
+  if (!pack_block(cx, cy, cz, &key)) return -1;
+  uint32_t h = dir_hash(cx, cy, cz, kWalkChunks - 1);
+  for (int probe = 0; probe < kWalkChunks; ++probe) {
+    unsigned long long cur = S.ckey[h];
+    if (cur == kEmptyKey) cur = atomicCAS(&S.ckey[h], kEmptyKey, key);
+    if (cur == kEmptyKey || cur == key) return (int)h;
+    h = (h + 1) & (kWalkChunks - 1);
+  }
+  return -1;
+}
+
+// ------------------------------------------------------------------ walk_tiles
+// Output layout of the order-free records: tile t owns records [t * kWalkLimit, (t + 1) * kWalkLimit)
+// and segment descriptors [t * kWalkChunks, ...) for its first flush — no allocation, no same-address
+// atomics (a returning device-scope atomic on one word costs ~11 ns: 30 000 tiles queueing for one
+// counter would take longer than the walk).  Further flushes of a tile that had to be cut, and entries
+// beyond the chunk cache, go to a spill area behind the per-tile regions through two counters (rare).
+// A segment = the records of one (tile, chunk), grouped by slab; its descriptor is two uint4:
+//   {slot, first record, records, 0}, {first record of slab 0..7 inside the segment, 8 x u16}.
+struct AccOut {
+  uint4* rec;                // {vid | count << 12, last point, sum w_u*u (fixed), sum w_u (fixed)}
+  uint32_t rec_cap;          // ntiles * kWalkLimit + spill
+  uint4* seg;                // two per segment
+  uint32_t seg_cap;          // ntiles * kWalkChunks + spill (in segments)
+  uint32_t* seg_cnt;         // [ntiles] segments in the tile's own region
+  uint32_t* tile_visits;     // [ntiles]
+};
+// Runs: one descriptor + 256-bit ray mask per (tile, voxel) that needs its visits in order.
+// Tile t owns run slots [t << r1_log2, (t + 1) << r1_log2) and fills them from the front, in the order
+// of its flushes (= point order); run_cnt[t] = how many.  No numbering across tiles: the stable sort by
+// voxel key reads this sparse layout directly (radix_sort_sparse_u32) and carries the slot index, from
+// which the tile (slot >> r1_log2) and the mask follow.  A tile that needs more slots reports how many
+// (run_need) and the host repeats the call with larger regions.
+struct RunOut {
+  uint32_t* dkey;                 // [ntiles << r1_log2] voxel key (slot * 4096 + voxel)
+  uint32_t* masks;                // [(ntiles << r1_log2) * 8] rays of the tile that visit the voxel, bit r = ray r
+  uint32_t* run_cnt;              // [ntiles]
+  uint32_t r1_log2;
+};
+
+template <bool kOrdered>
+struct WalkCfg {
+  static constexpr int kMaskCap = kOrdered ? kWalkLimit : 512;   // masks built per round (LDS)
+};
+
+__device__ __forceinline__ uint4 pack_suboffsets(const uint32_t* o) {
+  return make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
+}
+
+// kOrdered = false: order-free accumulation (records) + runs of the voxels whose colour weight is below 254.
+// kOrdered = true: runs of every voxel, no records.
+template <bool kOrdered>
+__global__ __launch_bounds__(kWalkRays) void walk_tiles(
+    Params P, float scale_u, float scale_w, const float* __restrict__ xyz, int npoints,
+    const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
+    int32_t* __restrict__ num_chunks, WalkCounters* __restrict__ ctr, const uint32_t* __restrict__ rgbw, AccOut out,
+    RunOut runs, int exp) {
+  constexpr int kMaskCap = WalkCfg<kOrdered>::kMaskCap;
+  constexpr int kPer = kWalkEntries / kWalkRays;
+  __shared__ WalkShared S;
+  __shared__ uint32_t raw[kMaskCap * 8];              // accumulators during the walk, ray masks afterwards
+  __shared__ uint16_t vlog[kLogLen * kWalkRays];      // entry of visit k of ray r at [k * kWalkRays + r]
+  __shared__ uint16_t e_midx[kWalkEntries];           // mask index of the entry (0xFFFF: none)
+  int32_t* const e_wuu = reinterpret_cast<int32_t*>(raw);                                 // sum of w_u * u, fixed point
+  unsigned long long* const e_wc = reinterpret_cast<unsigned long long*>(raw + kWalkEntries);   // visits << 32 | sum of w_u
+  uint32_t* const e_last = raw + 3 * kWalkEntries;                                        // last visiting ray
+  static_assert(kMaskCap * 8 >= 4 * kWalkEntries, "the accumulators overlay the mask area");
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // Tiles are numbered in point order by blockIdx: workgroups are dispatched in that order, so the
+  // look-back below only ever waits for tiles that are already running.
+  const uint32_t tile = blockIdx.x, ntiles = gridDim.x;
+  if (tid == 0) {
+    S.stack[0] = SubTile{0, (uint16_t)kWalkRays, 0u, 0xFFFFFFFFu};
+    S.sp = 1;
+  }
+  const uint32_t i = tile * kWalkRays + (uint32_t)tid;
+  Pose pose;
+  Ray ray;
+  const bool has_ray = i < (uint32_t)npoints && tile_ray(P, xyz, offsets, nclouds, poses, i, &pose, &ray, &ctr->err);
+  const float wu = has_ray ? P.weight / (2.0f * ray.truncation) : 0.0f;
+  const uint32_t q_w = (uint32_t)__float2int_rn(wu * scale_w);
+  uint32_t my_visits = 0;
+  bool was_split = false;
+  int flushes = 0;
+  uint32_t emitted = 0;
+
+  while (true) {
+    __syncthreads();
+    if (S.sp == 0) break;
+    const SubTile st = S.stack[S.sp - 1];
+    __syncthreads();
+    if (tid == 0) --S.sp;
+    subtile_reset(S, tid);
+    if (!kOrdered) {
+#pragma unroll
+      for (int k = 0; k < 4 * kPer; ++k) raw[tid + k * kWalkRays] = 0u;
+    }
+    __syncthreads();
+    uint32_t nv = 0;
+    const bool walks = has_ray && tid >= st.lo && tid < st.hi;
+    if (walks) {
+      nv = walk_one(P, pose, ray, st.vlo, st.vhi, [&](uint32_t k, int vx, int vy, int vz, float u) {
+        if (exp & 2) return true;
+        const int e = table_find_or_insert(S, vx, vy, vz);
+        if (e < 0) return false;
+        if (k < (uint32_t)kLogLen) vlog[k * kWalkRays + tid] = (uint16_t)e;
+        if (exp & 1) return true;
+        if (!kOrdered) {
+          atomicAdd(&e_wuu[e], __float2int_rn((wu * u) * scale_u));
+          atomicAdd(&e_wc[e], (1ull << 32) | (unsigned long long)q_w);
+          atomicMax(&e_last[e], (uint32_t)tid);
+        }
+        return true;
+      });
+    }
+    __syncthreads();
+    const bool overflowed = S.overflow != 0;
+    __syncthreads();
+    if (overflowed) {
+      was_split = true;
+      if (tid == 0) subtile_split(S, st);
+      continue;
+    }
+    const uint32_t nmine = nv > st.vlo ? nv - st.vlo : 0u;   // this ray's visits in the (sub-)tile
+    my_visits += nmine;
+    if (exp & 4) continue;
+
+    // ---- entries -> chunks -> pool slots
+    int ci[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const unsigned long long key = S.ekey[tid + k * kWalkRays];
+      ci[k] = -2;
+      if (key != kVoxEmpty) {
+        int vx, vy, vz;
+        unpack_voxel(key, &vx, &vy, &vz);
+        ci[k] = chunk_cache_insert(S, vx >> 4, vy >> 4, vz >> 4);
+      }
+    }
+    __syncthreads();
+    if (tid < kWalkChunks && S.ckey[tid] != kEmptyKey) {
+      const unsigned long long ck = S.ckey[tid];
+      S.cslot[tid] = dir_find_or_insert(dir, (int)((ck >> 42) & 0x1FFFFFu) - kCoordBias,
+                                        (int)((ck >> 21) & 0x1FFFFFu) - kCoordBias, (int)(ck & 0x1FFFFFu) - kCoordBias,
+                                        num_chunks, &ctr->err);
+    }
+    __syncthreads();
+    uint32_t rank[kPer], vkey[kPer];
+    int slot_of[kPer];
+    uint32_t need = 0, nneed = 0;   // entries of this thread that leave the tile as runs
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      rank[k] = 0;
+      vkey[k] = 0;
+      slot_of[k] = -1;
+      if (ci[k] == -2) continue;
+      const unsigned long long key = S.ekey[tid + k * kWalkRays];
+      int vx, vy, vz;
+      unpack_voxel(key, &vx, &vy, &vz);
+      const uint32_t vid = (uint32_t)(((vz & 15) * 16 + (vy & 15)) * 16 + (vx & 15));
+      if (ci[k] >= 0) {
+        slot_of[k] = S.cslot[ci[k]];
+        if (!kOrdered && slot_of[k] >= 0) rank[k] = atomicAdd(&S.ccnt[ci[k] * kSlabs + (int)(vid / kSlabVox)], 1u);
+      } else {
+        slot_of[k] = dir_find_or_insert(dir, vx >> 4, vy >> 4, vz >> 4, num_chunks, &ctr->err);
+      }
+      if (slot_of[k] >= 0) {
+        vkey[k] = (uint32_t)slot_of[k] * (uint32_t)kChunkVox + vid;
+        if (!(exp & 8) && (kOrdered || (rgbw[vkey[k]] >> 24) < 254u)) {
+          need |= 1u << k;
+          ++nneed;
+        }
+      }
+    }
+    __syncthreads();
+    if (!kOrdered) {
+      // ---- records: wave 0 places the (chunk, slab) groups (the tile's own region on its first flush)
+      if (tid < 64) {
+        uint32_t sub[kSlabs], c = 0;
+#pragma unroll
+        for (int s = 0; s < kSlabs; ++s) {
+          sub[s] = c;
+          c += S.ccnt[tid * kSlabs + s];
+        }
+        uint32_t inc = c, sinc = c ? 1u : 0u;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t up = (uint32_t)__shfl_up((int)inc, off), sup = (uint32_t)__shfl_up((int)sinc, off);
+          if (tid >= off) { inc += up; sinc += sup; }
+        }
+        const uint32_t tot = (uint32_t)__shfl((int)inc, 63), stot = (uint32_t)__shfl((int)sinc, 63);
+        uint32_t rbase = tile * (uint32_t)kWalkLimit, sbase = tile * (uint32_t)kWalkChunks;
+        if (flushes > 0) {
+          if (tid == 0 && tot) {
+            rbase = ntiles * (uint32_t)kWalkLimit + atomicAdd(&ctr->rec_top, tot);
+            sbase = ntiles * (uint32_t)kWalkChunks + atomicAdd(&ctr->seg_top, stot);
+            if (rbase + tot > out.rec_cap || sbase + stot > out.seg_cap) atomicOr(&ctr->err, kErrScratch);
+          }
+          rbase = (uint32_t)__shfl((int)rbase, 0);
+          sbase = (uint32_t)__shfl((int)sbase, 0);
+        } else if (tid == 0) {
+          out.seg_cnt[tile] = stot;
+        }
+        if (tid == 0) S.rbase = rbase;
+#pragma unroll
+        for (int s = 0; s < kSlabs; ++s) S.cbase[tid * kSlabs + s] = (uint16_t)(inc - c + sub[s]);
+        if (c) {
+          const uint32_t sg = sbase + sinc - 1u;
+          if (sg < out.seg_cap) {
+            out.seg[2 * (size_t)sg] = make_uint4((uint32_t)S.cslot[tid], rbase + inc - c, c, 0u);
+            out.seg[2 * (size_t)sg + 1] = pack_suboffsets(sub);
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        if (slot_of[k] < 0) continue;
+        const int e = tid + k * kWalkRays;
+        const uint32_t vid = vkey[k] % (uint32_t)kChunkVox;
+        const unsigned long long wc = e_wc[e];
+        const uint4 r = make_uint4(vid | ((uint32_t)(wc >> 32) << 12), tile * kWalkRays + e_last[e], (uint32_t)e_wuu[e],
+                                   (uint32_t)wc);
+        uint32_t at;
+        if (ci[k] >= 0) {
+          at = S.rbase + S.cbase[ci[k] * kSlabs + (int)(vid / kSlabVox)] + rank[k];
+        } else {   // beyond the chunk cache (scattered clouds): a segment of its own in the spill area
+          at = ntiles * (uint32_t)kWalkLimit + atomicAdd(&ctr->rec_top, 1u);
+          const uint32_t sg = ntiles * (uint32_t)kWalkChunks + atomicAdd(&ctr->seg_top, 1u);
+          if (at >= out.rec_cap || sg >= out.seg_cap) {
+            atomicOr(&ctr->err, kErrScratch);
+          } else {
+            uint32_t sub[kSlabs];
+#pragma unroll
+            for (int s = 0; s < kSlabs; ++s) sub[s] = (uint32_t)s > vid / kSlabVox ? 1u : 0u;
+            out.seg[2 * (size_t)sg] = make_uint4((uint32_t)slot_of[k], at, 1u, 0u);
+            out.seg[2 * (size_t)sg + 1] = pack_suboffsets(sub);
+          }
+        }
+        if (at < out.rec_cap) out.rec[at] = r;
+      }
+    }
+
+    // ---- runs: number the entries that need one
+    uint32_t inc = nneed;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
+      if (lane >= off) inc += up;
+    }
+    if (lane == 63) S.wsum[wid] = inc;
+    __syncthreads();   // (also: the records are out, the accumulator area is free)
+    uint32_t wbase = 0, nruns = 0;
+#pragma unroll
+    for (int w = 0; w < kWalkRays / 64; ++w) {
+      const uint32_t v = S.wsum[w];
+      if (w < wid) wbase += v;
+      nruns += v;
+    }
+    {
+      uint32_t m = wbase + inc - nneed;
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) e_midx[tid + k * kWalkRays] = (need & (1u << k)) ? (uint16_t)m++ : (uint16_t)0xFFFFu;
+    }
+    // the runs go to the tile's own slots, behind those of its earlier flushes
+    const bool fits = emitted + nruns <= (1u << runs.r1_log2);
+    if (!fits && tid == 0) {
+      atomicOr(&ctr->err, kErrScratch);
+      atomicMax(&ctr->run_need, emitted + nruns);
+    }
+    for (uint32_t r0 = 0; fits && r0 < nruns; r0 += kMaskCap) {
+      __syncthreads();   // e_midx complete / the previous round's masks are out
+#pragma unroll
+      for (int k = 0; k < kMaskCap * 8 / kWalkRays; ++k) raw[tid + k * kWalkRays] = 0u;
+      __syncthreads();
+      if (walks && nmine) {
+        const uint32_t logged = min(nmine, (uint32_t)kLogLen);
+        for (uint32_t k = 0; k < logged; ++k) {
+          const uint32_t m = (uint32_t)e_midx[vlog[k * kWalkRays + tid]] - r0;   // 0xFFFF - r0 stays out of range
+          if (m < (uint32_t)kMaskCap) atomicOr(&raw[m * 8 + (tid >> 5)], 1u << (tid & 31));
+        }
+        if (nmine > (uint32_t)kLogLen) {   // the log is full: the rest of the ray is walked again
+          walk_one(P, pose, ray, st.vlo, st.vhi, [&](uint32_t k, int vx, int vy, int vz, float) {
+            if (k >= (uint32_t)kLogLen) {
+              const int e = table_find(S, vx, vy, vz);
+              const uint32_t m = e >= 0 ? (uint32_t)e_midx[e] - r0 : 0xFFFFFFFFu;
+              if (m < (uint32_t)kMaskCap) atomicOr(&raw[m * 8 + (tid >> 5)], 1u << (tid & 31));
+            }
+            return true;
+          });
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        const uint32_t m = (uint32_t)e_midx[tid + k * kWalkRays];
+        if (m == 0xFFFFu || m < r0 || m >= r0 + (uint32_t)kMaskCap) continue;
+        const size_t d = ((size_t)tile << runs.r1_log2) + emitted + m;
+        runs.dkey[d] = vkey[k];
+        const uint32_t* mk = raw + (m - r0) * 8;
+        uint4* dst = reinterpret_cast<uint4*>(runs.masks + d * 8);
+        dst[0] = make_uint4(mk[0], mk[1], mk[2], mk[3]);
+        dst[1] = make_uint4(mk[4], mk[5], mk[6], mk[7]);
+      }
+    }
+    emitted += nruns;
+    ++flushes;
+  }
+
+  // ---- tile epilogue: run and visit counts
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) my_visits += (uint32_t)__shfl_xor((int)my_visits, off);
+  __syncthreads();
+  if (lane == 0) S.wsum[wid] = my_visits;
+  __syncthreads();
+  if (tid == 0) {
+    runs.run_cnt[tile] = min(emitted, 1u << runs.r1_log2);
+    uint32_t v = 0;
+    for (int w = 0; w < kWalkRays / 64; ++w) v += S.wsum[w];
+    out.tile_visits[tile] = v;
+    if (!kOrdered && flushes == 0) out.seg_cnt[tile] = 0;
+    if (was_split) atomicAdd(&ctr->split_tiles, 1u);
+  }
+}
+
+// ------------------------------------------------------------------ segments -> chunk order
+// Counting sort of the segment descriptors by chunk.  A workgroup takes kSegSpan descriptor slots
+// (segments of neighbouring tiles: a handful of chunks), counts them per chunk in an LDS table and
+// goes to the global per-chunk counters once per (workgroup, chunk): seg_pass<false> counts,
+// seg_scan scans (and lists the updated chunks, sums the per-tile visit counts), seg_pass<true> places.
+constexpr int kSegSpan = 1024;     // descriptor slots per workgroup (16 tiles)
+constexpr int kSegTable = 512;
+template <bool kScatter>
+__global__ __launch_bounds__(256) void seg_pass(const uint4* __restrict__ seg, uint32_t seg_cap, uint32_t ntiles,
+                                                const uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ chunk_nseg,
+                                                const uint32_t* __restrict__ chunk_off, uint32_t* __restrict__ chunk_fill,
+                                                uint4* __restrict__ sorted, const WalkCounters* __restrict__ ctr) {
+  __shared__ uint32_t hkey[kSegTable], hcnt[kSegTable], hbase[kSegTable];
+  const int tid = threadIdx.x;
+  const uint32_t own = ntiles * (uint32_t)kWalkChunks;
+  const uint32_t n = min(own + ctr->seg_top, seg_cap);
+  for (int k = tid; k < kSegTable; k += 256) {
+    hkey[k] = 0xFFFFFFFFu;
+    hcnt[k] = 0;
+  }
+  __syncthreads();
+  constexpr int kPer = kSegSpan / 256;
+  int ent[kPer];
+  uint32_t rnk[kPer], slot[kPer];
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) {
+    const uint32_t j = blockIdx.x * (uint32_t)kSegSpan + (uint32_t)(q * 256 + tid);
+    ent[q] = -2;   // no segment here
+    if (j >= n || (j < own && (j % kWalkChunks) >= seg_cnt[j / kWalkChunks])) continue;
+    slot[q] = seg[2 * (size_t)j].x;
+    uint32_t h = (slot[q] * 2654435761u) >> (32 - 9);
+    ent[q] = -1;   // table full: straight to the global counters
+    for (int probe = 0; probe < kSegTable; ++probe) {
+      uint32_t cur = hkey[h];
+      if (cur == 0xFFFFFFFFu) cur = atomicCAS(&hkey[h], 0xFFFFFFFFu, slot[q]);
+      if (cur == 0xFFFFFFFFu || cur == slot[q]) {
+        ent[q] = (int)h;
+        break;
+      }
+      h = (h + 1) & (kSegTable - 1);
+    }
+    if (ent[q] >= 0) rnk[q] = atomicAdd(&hcnt[ent[q]], 1u);
+  }
+  __syncthreads();
+  for (int k = tid; k < kSegTable; k += 256) {
+    if (hkey[k] == 0xFFFFFFFFu) continue;
+    if (kScatter) hbase[k] = chunk_off[hkey[k]] + atomicAdd(&chunk_fill[hkey[k]], hcnt[k]);
+    else atomicAdd(&chunk_nseg[hkey[k]], hcnt[k]);
+  }
+  if (kScatter) __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) {
+    if (ent[q] == -2) continue;
+    const uint32_t j = blockIdx.x * (uint32_t)kSegSpan + (uint32_t)(q * 256 + tid);
+    if (kScatter) {
+      const uint32_t at = ent[q] >= 0 ? hbase[ent[q]] + rnk[q] : chunk_off[slot[q]] + atomicAdd(&chunk_fill[slot[q]], 1u);
+      sorted[2 * (size_t)at] = seg[2 * (size_t)j];
+      sorted[2 * (size_t)at + 1] = seg[2 * (size_t)j + 1];
+    } else if (ent[q] == -1) {
+      atomicAdd(&chunk_nseg[slot[q]], 1u);
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void seg_scan(const uint32_t* __restrict__ chunk_nseg, uint32_t* __restrict__ chunk_off,
+                                                 uint32_t* __restrict__ chunk_fill, uint32_t* __restrict__ active,
+                                                 uint32_t* __restrict__ active_off, WalkCounters* __restrict__ ctr,
+                                                 const int32_t* __restrict__ num_chunks, int max_chunks,
+                                                 const uint32_t* __restrict__ tile_visits,
+                                                 const uint32_t* __restrict__ run_cnt, uint32_t ntiles) {
+  __shared__ uint32_t wsum[16], wact[16];
+  __shared__ uint32_t carry, acarry;
+  __shared__ unsigned long long vsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int n = min(*num_chunks, max_chunks);
+  if (tid == 0) { carry = 0; acarry = 0; }
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int s = base + tid;
+    const uint32_t c = s < n ? chunk_nseg[s] : 0u;
+    const uint32_t a = c ? 1u : 0u;
+    uint32_t inc = c, ainc = a;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)inc, off), aup = (uint32_t)__shfl_up((int)ainc, off);
+      if (lane >= off) { inc += up; ainc += aup; }
+    }
+    if (lane == 63) { wsum[wid] = inc; wact[wid] = ainc; }
+    __syncthreads();
+    uint32_t wb = carry, ab = acarry, tot = 0, atot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      if (w < wid) { wb += wsum[w]; ab += wact[w]; }
+      tot += wsum[w];
+      atot += wact[w];
+    }
+    if (s < n) {
+      chunk_off[s] = wb + inc - c;
+      chunk_fill[s] = 0;
+      if (c) {
+        active[ab + ainc - 1u] = (uint32_t)s;
+        active_off[ab + ainc - 1u] = wb + inc - c;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) { carry += tot; acarry += atot; }
+    __syncthreads();
+  }
+  unsigned long long v = 0, nr = 0;
+  for (uint32_t t = tid; t < ntiles; t += 1024) {
+    v += tile_visits[t];
+    nr += run_cnt[t];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    v += (unsigned long long)__shfl_xor((long long)v, off);
+    nr += (unsigned long long)__shfl_xor((long long)nr, off);
+  }
+  __shared__ unsigned long long rsum[16];
+  if (lane == 0) { vsum[wid] = v; rsum[wid] = nr; }
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long tot = 0, rtot = 0;
+    for (int w = 0; w < 16; ++w) { tot += vsum[w]; rtot += rsum[w]; }
+    ctr->total_visits = tot;
+    ctr->num_desc = (uint32_t)rtot;
+    ctr->num_updated = acarry;
+    active_off[acarry] = carry;
+  }
+}
+
+// The apply stage ("LDS-staged blocks").  Work item = (updated chunk, slab of kSlabVox voxels): the
+// records of the slab — contiguous inside every segment of the chunk — are added into LDS accumulators
+// (64-bit fixed point: the result does not depend on the order of the records), then every visited
+// voxel of the slab takes ONE update.  Sixteen lanes share a segment, four segments per group are in
+// flight together.
+constexpr int kApplyThreads = 512;
+__global__ __launch_bounds__(kApplyThreads) void apply_chunks(
+    const uint4* __restrict__ sorted_seg, const uint32_t* __restrict__ active, const uint32_t* __restrict__ active_off,
+    const uint4* __restrict__ rec, double inv_scale_u, double inv_scale_w, const uint32_t* __restrict__ kfid_of_point,
+    float* __restrict__ sdf, float* __restrict__ weight, uint32_t* __restrict__ vkfid, WalkCounters* __restrict__ ctr) {
+  __shared__ long long a_wuu[kSlabVox];
+  __shared__ unsigned long long a_w[kSlabVox];
+  __shared__ uint32_t a_last[kSlabVox], a_cnt[kSlabVox];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int grp = tid >> 4, gl = tid & 15;
+  constexpr int kGroups = kApplyThreads / 16, kFly = 4;
+  if (ctr->err) return;   // the walk ran out of scratch: the host grows it and repeats the call, the map stays as it was
+  const uint32_t nitems = ctr->num_updated * kSlabs;
+  uint32_t voxels = 0, longest = 0;
+  auto add = [&](const uint4 q) {
+    const uint32_t v = (q.x & 0xFFFu) % kSlabVox;
+    atomicAdd((unsigned long long*)&a_wuu[v], (unsigned long long)(long long)(int32_t)q.z);
+    atomicAdd(&a_w[v], (unsigned long long)q.w);
+    atomicMax(&a_last[v], q.y);
+    atomicAdd(&a_cnt[v], q.x >> 12);
+  };
+  for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const uint32_t a = item / kSlabs, slab = item % kSlabs;
+    for (int v = tid; v < kSlabVox; v += kApplyThreads) {
+      a_wuu[v] = 0;
+      a_w[v] = 0;
+      a_last[v] = 0;
+      a_cnt[v] = 0;
+    }
+    __syncthreads();
+    const uint32_t s0 = active_off[a], s1 = active_off[a + 1];
+    for (uint32_t sb = s0 + (uint32_t)grp * kFly; sb < s1; sb += kGroups * kFly) {
+      uint32_t lo[kFly], hi[kFly];
+      uint4 q[kFly];
+#pragma unroll
+      for (int j = 0; j < kFly; ++j) {
+        lo[j] = hi[j] = 0;
+        if (sb + j < s1) {
+          const uint4 d0 = sorted_seg[2 * (size_t)(sb + j)], d1 = sorted_seg[2 * (size_t)(sb + j) + 1];
+          const uint32_t w[4] = {d1.x, d1.y, d1.z, d1.w};
+          const uint32_t o = (w[slab >> 1] >> ((slab & 1) * 16)) & 0xFFFFu;
+          const uint32_t e = slab + 1 < kSlabs ? (w[(slab + 1) >> 1] >> (((slab + 1) & 1) * 16)) & 0xFFFFu : d0.z;
+          lo[j] = d0.y + o;
+          hi[j] = d0.y + e;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kFly; ++j)
+        if (lo[j] + gl < hi[j]) q[j] = rec[lo[j] + gl];
+#pragma unroll
+      for (int j = 0; j < kFly; ++j) {
+        if (lo[j] + gl < hi[j]) add(q[j]);
+        for (uint32_t r = lo[j] + 16u + gl; r < hi[j]; r += 16) add(rec[r]);
+      }
+    }
+    __syncthreads();
+    const size_t pool0 = (size_t)active[a] * kChunkVox + (size_t)slab * kSlabVox;
+    for (int v = tid; v < kSlabVox; v += kApplyThreads) {
+      const uint32_t c = a_cnt[v];
+      if (c) {
+        const float m = (float)((double)a_wuu[v] * inv_scale_u), ws = (float)((double)a_w[v] * inv_scale_w);
+        const float W = weight[pool0 + v], Sd = sdf[pool0 + v];
+        const float wn = W + ws;
+        sdf[pool0 + v] = (W * Sd + m) / wn;
+        weight[pool0 + v] = wn;
+        vkfid[pool0 + v] = kfid_of_point ? kfid_of_point[a_last[v]] : 0u;
+        ++voxels;
+        longest = max(longest, c);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    voxels += (uint32_t)__shfl_xor((int)voxels, off);
+    longest = max(longest, (uint32_t)__shfl_xor((int)longest, off));
+  }
+  if (lane == 0 && voxels) {
+    atomicAdd(&ctr->num_heads, voxels);
+    atomicMax(&ctr->max_run, longest);
+  }
+}
+
+// sum of the per-tile visit counts (ordered mode: the order-free mode sums them in seg_scan)
+__global__ __launch_bounds__(1024) void sum_tile_visits(const uint32_t* __restrict__ tile_visits,
+                                                        const uint32_t* __restrict__ run_cnt, uint32_t ntiles,
+                                                        WalkCounters* __restrict__ ctr) {
+  __shared__ unsigned long long vsum[16], rsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  unsigned long long v = 0, nr = 0;
+  for (uint32_t t = tid; t < ntiles; t += 1024) {
+    v += tile_visits[t];
+    nr += run_cnt[t];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    v += (unsigned long long)__shfl_xor((long long)v, off);
+    nr += (unsigned long long)__shfl_xor((long long)nr, off);
+  }
+  if (lane == 0) { vsum[wid] = v; rsum[wid] = nr; }
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long tot = 0, rtot = 0;
+    for (int w = 0; w < 16; ++w) { tot += vsum[w]; rtot += rsum[w]; }
+    ctr->total_visits = tot;
+    ctr->num_desc = (uint32_t)rtot;
+  }
+}
+
+// visits of every run in sorted order (input of the scan that places them in voxel order)
+__global__ void mask_counts(const uint32_t* __restrict__ sorted_val, uint32_t nd,
+                            const uint32_t* __restrict__ masks, uint32_t* __restrict__ cnts) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nd) return;
+  const uint4* m = reinterpret_cast<const uint4*>(masks + (size_t)sorted_val[j] * 8);
+  const uint4 a = m[0], b = m[1];
+  cnts[j] = (uint32_t)(__popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) +
+                       __popc(b.w));
+}
+
+// Ordered mode: the update operands of every visit, in voxel order (what chain_runs folds).  One
+// thread per run: for every ray of the mask (ascending = point order) the signed distance of the
+// voxel centre along the ray is recomputed exactly as the walk computed it.
+//   rec[r] = (w_u * u, +-w_u), negative on the LAST record of a voxel; kfid of the voxel = its last visit's.
+__global__ __launch_bounds__(256) void expand_runs(
+    Params P, const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ sorted_val, uint32_t nd,
+    uint32_t r1_log2, const uint32_t* __restrict__ masks, const uint32_t* __restrict__ dst, const float* __restrict__ xyz,
+    const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses,
+    const int32_t* __restrict__ slot_ids, const uint32_t* __restrict__ kfid_of_point, float2* __restrict__ rec,
+    uint32_t* __restrict__ vkfid) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nd) return;
+  const uint32_t key = skeys[j];
+  const bool closes = (j + 1 >= nd) || skeys[j + 1] != key;
+  const uint32_t val = sorted_val[j];
+  const uint32_t* m = masks + (size_t)val * 8;
+  const uint32_t p0 = (val >> r1_log2) * (uint32_t)kWalkRays;
+  const uint32_t slot = key / kChunkVox, vid = key % kChunkVox;
+  const int vx = slot_ids[3 * slot] * 16 + (int)(vid & 15), vy = slot_ids[3 * slot + 1] * 16 + (int)((vid >> 4) & 15),
+            vz = slot_ids[3 * slot + 2] * 16 + (int)(vid >> 8);
+  const float c0 = (float)vx * P.resolution + P.half_voxel, c1 = (float)vy * P.resolution + P.half_voxel,
+              c2 = (float)vz * P.resolution + P.half_voxel;
+  uint32_t r = dst[j];
+  uint32_t last_p = 0;
+  int cl = cloud_of(offsets, nclouds, (int)p0);
+  Pose pose = poses[cl];
+  int cl_end = offsets[cl + 1];
+#pragma unroll 1
+  for (int w = 0; w < kWalkRays / 32; ++w) {
+    uint32_t bits = m[w];
+    while (bits) {
+      const int b = __ffs((int)bits) - 1;
+      bits &= bits - 1u;
+      const uint32_t p = p0 + (uint32_t)(w * 32 + b);
+      if ((int)p >= cl_end) {
+        cl = cloud_of(offsets, nclouds, (int)p);
+        pose = poses[cl];
+        cl_end = offsets[cl + 1];
+      }
+      const float depth = xyz[3 * (size_t)p + 2];
+      const float tr = truncation_of(P, depth);
+      const float wu = P.weight / (2.0f * tr);
+      const float u = signed_dist(pose, depth, c0, c1, c2);
+      rec[r++] = make_float2(wu * u, wu);
+      last_p = p;
+    }
+  }
+  if (closes) {
+    rec[r - 1].y = -rec[r - 1].y;
+    vkfid[key] = kfid_of_point ? kfid_of_point[last_p] : 0u;
+  }
+}
+
+// ColorVoxel::IntegrateSimple visit by visit, for the voxels whose colour weight is below 254: one
+// thread per voxel walks its runs (sorted: tile order = point order), the rays of a mask in ascending
+// order, until the weight reaches 254 (at most 254 steps in the life of a voxel).
+__global__ __launch_bounds__(256) void fold_colours_masks(
+    const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ sorted_val, uint32_t nd, uint32_t r1_log2,
+    const uint32_t* __restrict__ vj0, const uint32_t* __restrict__ masks, const uint8_t* __restrict__ rgb,
+    uint32_t* __restrict__ rgbw, const uint32_t* __restrict__ num_heads) {
+  const uint32_t nvox = *num_heads;
+  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += gridDim.x * blockDim.x) {
+    uint32_t j = vj0[v];
+    const uint32_t key = skeys[j];
+    uint32_t col = rgbw[key];
+    if ((col >> 24) >= 254u) continue;
+    for (; j < nd && skeys[j] == key && (col >> 24) < 254u; ++j) {
+      const uint32_t val = sorted_val[j];
+      const uint4* m4 = reinterpret_cast<const uint4*>(masks + (size_t)val * 8);
+      const uint4 a = m4[0], b = m4[1];
+      const uint32_t m[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      const uint32_t p0 = (val >> r1_log2) * (uint32_t)kWalkRays;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        uint32_t bits = m[w];
+        while (bits && (col >> 24) < 254u) {
+          // up to four visits at a time: their colours are independent loads
+          uint32_t c[4];
+          int n = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            c[q] = 0;
+            if (bits) {
+              const int bpos = __ffs((int)bits) - 1;
+              bits &= bits - 1u;
+              const size_t p = (size_t)p0 + (size_t)(w * 32 + bpos);
+              c[q] = (uint32_t)rgb[3 * p] | ((uint32_t)rgb[3 * p + 1] << 8) | ((uint32_t)rgb[3 * p + 2] << 16);
+              n = q + 1;
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q < n)
+              colour_update(col, colour_roundtrip(c[q] & 255u), colour_roundtrip((c[q] >> 8) & 255u),
+                            colour_roundtrip((c[q] >> 16) & 255u));
+        }
+      }
+    }
+    rgbw[key] = col;
+  }
+}
+
+}  // namespace

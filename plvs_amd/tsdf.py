@@ -118,7 +118,7 @@ class TsdfChisel:
         n = ctypes.c_int()
         calls = ctypes.c_int64()
         _lib.check(_lib.lib.plvs_hip_tsdf_chisel_stage_ms(self._h, ms, 16, ctypes.byref(n), ctypes.byref(calls)))
-        names = [_lib.lib.plvs_hip_tsdf_chisel_stage_name(i).decode() for i in range(n.value)]
+        names = [_lib.lib.plvs_hip_tsdf_chisel_stage_name_of(self._h, i).decode() for i in range(n.value)]
         return {names[i]: ms[i] for i in range(n.value)}, calls.value
 
     def updated_chunk_ids_dev(self, d_ids):
