@@ -107,21 +107,10 @@ constexpr int kSortTile = kThreads * kSortItems;     // 4096 keys per block
 constexpr int kWaveSpan = 64 * kSortItems;           // 1024 consecutive keys per wave
 
 // hist[d * nb + b] = number of keys of tile b whose digit is d.
-// Sparse input (first pass of radix_sort_sparse_u32): the items sit in regions of 2^r1_log2 slots, region
-// t holding sparse_cnt[t] of them at its start; slot i is an item iff (i mod 2^r1) < sparse_cnt[i >> r1].
-__device__ __forceinline__ bool radix_valid(size_t i, size_t n, const uint32_t* __restrict__ sparse_cnt,
-                                            uint32_t r1_log2) {
-  if (i >= n) return false;
-  if (sparse_cnt == nullptr) return true;
-  return (uint32_t)(i & (((size_t)1 << r1_log2) - 1)) < sparse_cnt[i >> r1_log2];
-}
-
 template <int kBits>
 __global__ __launch_bounds__(kThreads) void radix_hist(const uint32_t* __restrict__ keys, size_t n,
                                                        int shift, size_t nb,
-                                                       uint32_t* __restrict__ hist,
-                                                       const uint32_t* __restrict__ sparse_cnt = nullptr,
-                                                       uint32_t r1_log2 = 0) {
+                                                       uint32_t* __restrict__ hist) {
   constexpr int kRadix = 1 << kBits;
   constexpr uint32_t kMask = kRadix - 1;
   __shared__ uint32_t h[kRadix];
@@ -131,7 +120,7 @@ __global__ __launch_bounds__(kThreads) void radix_hist(const uint32_t* __restric
 #pragma unroll 4
   for (int it = 0; it < kSortItems; ++it) {
     const size_t i = tile + (size_t)it * kThreads + threadIdx.x;
-    if (radix_valid(i, n, sparse_cnt, r1_log2)) atomicAdd(&h[(keys[i] >> shift) & kMask], 1u);
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & kMask], 1u);
   }
   __syncthreads();
   for (int d = threadIdx.x; d < kRadix; d += kThreads) hist[(size_t)d * nb + blockIdx.x] = h[d];
@@ -141,8 +130,7 @@ template <int kBits, typename TV>
 __global__ __launch_bounds__(kThreads) void radix_scatter(
     const uint32_t* __restrict__ keys_in, const TV* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, TV* __restrict__ vals_out, size_t n, int shift,
-    size_t nb, const uint32_t* __restrict__ hist_scanned, const uint32_t* __restrict__ sparse_cnt = nullptr,
-    uint32_t r1_log2 = 0) {
+    size_t nb, const uint32_t* __restrict__ hist_scanned) {
   constexpr int kRadix = 1 << kBits;
   constexpr uint32_t kMask = kRadix - 1;
   // wave_hist[w][d]: running count of digit d inside wave w's 1024-key span,
@@ -165,9 +153,9 @@ __global__ __launch_bounds__(kThreads) void radix_scatter(
 #pragma unroll
   for (int it = 0; it < kSortItems; ++it) {
     const size_t i = span + (size_t)it * 64 + lane;
-    const bool valid = radix_valid(i, n, sparse_cnt, r1_log2);
+    const bool valid = i < n;
     k[it] = valid ? keys_in[i] : 0u;
-    v[it] = valid ? (sparse_cnt != nullptr ? (TV)i : vals_in[i]) : TV(0);
+    v[it] = valid ? vals_in[i] : TV(0);
     const uint32_t d = (k[it] >> shift) & kMask;
     // lanes holding the same digit (and a valid key)
     unsigned long long peers = __ballot(valid);
@@ -200,7 +188,7 @@ __global__ __launch_bounds__(kThreads) void radix_scatter(
 #pragma unroll
   for (int it = 0; it < kSortItems; ++it) {
     const size_t i = span + (size_t)it * 64 + lane;
-    if (radix_valid(i, n, sparse_cnt, r1_log2)) {
+    if (i < n) {
       const uint32_t d = (k[it] >> shift) & kMask;
       const size_t pos = (size_t)gbase[d] + wave_hist[wid][d] + rank[it];
       keys_out[pos] = k[it];
@@ -212,14 +200,14 @@ __global__ __launch_bounds__(kThreads) void radix_scatter(
 template <int kBits, typename TV>
 hipError_t radix_pass(const uint32_t* ki, const TV* vi, uint32_t* ko, TV* vo, size_t n,
                       int shift, size_t nb, uint32_t* hist, uint32_t* scan_scratch,
-                      hipStream_t stream, const uint32_t* sparse_cnt = nullptr, uint32_t r1_log2 = 0) {
+                      hipStream_t stream) {
   constexpr size_t kRadix = (size_t)1 << kBits;
   hipLaunchKernelGGL(radix_hist<kBits>, dim3((unsigned)nb), dim3(kThreads), 0, stream, ki, n, shift,
-                     nb, hist, sparse_cnt, r1_log2);
+                     nb, hist);
   hipError_t e = exclusive_scan_u32(hist, hist, kRadix * nb, nullptr, scan_scratch, stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((radix_scatter<kBits, TV>), dim3((unsigned)nb), dim3(kThreads), 0, stream, ki, vi, ko,
-                     vo, n, shift, nb, hist, sparse_cnt, r1_log2);
+                     vo, n, shift, nb, hist);
   return hipGetLastError();
 }
 
@@ -277,45 +265,6 @@ static hipError_t radix_sort_impl(uint32_t* keys0, TV* vals0, uint32_t* keys1, T
     uint32_t* t = ki; ki = ko; ko = t;
     TV* tv = vi; vi = vo; vo = tv;
     *result_in_second = !*result_in_second;
-  }
-  return hipSuccess;
-}
-
-hipError_t radix_sort_sparse_u32(const uint32_t* keys_sparse, const uint32_t* sparse_cnt, uint32_t r1_log2,
-                                 size_t nslots, size_t n, uint32_t* keys0, uint32_t* vals0, uint32_t* keys1,
-                                 uint32_t* vals1, int bit_lo, int bit_hi, uint32_t* scratch, hipStream_t stream,
-                                 bool* result_in_second) {
-  *result_in_second = false;
-  if (n == 0 || nslots == 0) return hipSuccess;
-  if (bit_hi <= bit_lo) bit_hi = bit_lo + 1;   // at least the compacting pass
-  const size_t nb_sparse = (nslots + kSortTile - 1) / kSortTile, nb = (n + kSortTile - 1) / kSortTile;
-  uint32_t* hist = scratch;
-  uint32_t* scan_scratch = scratch + ((size_t)1 << kMaxRadixBits) * nb_sparse;
-  const int total = bit_hi - bit_lo;
-  const int passes = (total + kMaxRadixBits - 1) / kMaxRadixBits;
-  int bits = (total + passes - 1) / passes;
-  if (bits < 8) bits = 8;
-  const uint32_t* ki = keys_sparse;
-  const uint32_t* vi = nullptr;
-  uint32_t *ko = keys0, *vo = vals0;
-  for (int p = 0, shift = bit_lo; p < passes; ++p, shift += bits) {
-    const size_t items = p == 0 ? nslots : n, blocks = p == 0 ? nb_sparse : nb;
-    const uint32_t* sc = p == 0 ? sparse_cnt : nullptr;
-    hipError_t e;
-    switch (bits) {
-      case 8: e = radix_pass<8, uint32_t>(ki, vi, ko, vo, items, shift, blocks, hist, scan_scratch, stream, sc, r1_log2); break;
-      case 9: e = radix_pass<9, uint32_t>(ki, vi, ko, vo, items, shift, blocks, hist, scan_scratch, stream, sc, r1_log2); break;
-      case 10: e = radix_pass<10, uint32_t>(ki, vi, ko, vo, items, shift, blocks, hist, scan_scratch, stream, sc, r1_log2); break;
-      default: e = radix_pass<11, uint32_t>(ki, vi, ko, vo, items, shift, blocks, hist, scan_scratch, stream, sc, r1_log2); break;
-    }
-    if (e != hipSuccess) return e;
-    // output of pass p is the input of pass p + 1; the buffers alternate between (keys0, vals0) and (keys1, vals1)
-    ki = ko;
-    vi = vo;
-    const bool out_is_first = (ko == keys0);
-    ko = out_is_first ? keys1 : keys0;
-    vo = out_is_first ? vals1 : vals0;
-    *result_in_second = !out_is_first;
   }
   return hipSuccess;
 }

@@ -24,15 +24,6 @@ hipError_t radix_sort_pairs(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, u
                             size_t n, int bit_lo, int bit_hi, uint32_t* scratch,
                             hipStream_t stream, bool* result_in_second);
 
-// Stable sort of items that sit in regions of 2^r1_log2 slots (region t holds sparse_cnt[t] of them at its
-// start; nslots slots in all, n items in all — a host value).  The first pass reads the sparse layout and
-// writes (key, slot index) pairs densely; the result is in (keys0, vals0) or (keys1, vals1).  Scratch:
-// radix_scratch_words(nslots).
-hipError_t radix_sort_sparse_u32(const uint32_t* keys_sparse, const uint32_t* sparse_cnt, uint32_t r1_log2,
-                                 size_t nslots, size_t n, uint32_t* keys0, uint32_t* vals0, uint32_t* keys1,
-                                 uint32_t* vals1, int bit_lo, int bit_hi, uint32_t* scratch, hipStream_t stream,
-                                 bool* result_in_second);
-
 // Same with 64-bit values.
 hipError_t radix_sort_pairs_u64(uint32_t* keys0, unsigned long long* vals0, uint32_t* keys1,
                                 unsigned long long* vals1, size_t n, int bit_lo, int bit_hi,

@@ -888,7 +888,7 @@ struct plvs_tsdf_chisel {
   DevBuf<uint4> w_rec, w_seg, w_sorted_seg;
   DevBuf<uint32_t> w_chunk_nseg, w_chunk_off, w_chunk_fill, w_active_off, w_masks, w_dummy, w_seg_cnt, w_tile_visits;
   DevBuf<uint8_t> w_cold;
-  DevBuf<uint32_t> w_runkey, w_run_cnt, w_val0, w_val1;   // runs: per-tile regions of 2^run_r1_log2 slots
+  DevBuf<uint32_t> w_runkey, w_run_cnt, w_run_off, w_val0, w_val1;   // runs: per-tile regions of 2^run_r1_log2 slots
   uint32_t run_r1_log2 = 6;
   float scale_u = 1.f, scale_w = 1.f;   // fixed-point scales of the order-free accumulators (powers of two)
   int stage_set = 0;                    // which pipeline the stage times belong to
@@ -932,17 +932,20 @@ static int walk_fail(plvs_tsdf_chisel* h, uint32_t err) {
 // in tile (= point) order; the value carried is the run's slot (tile = slot >> r1_log2, mask at slot * 8).
 static int sort_runs(plvs_tsdf_chisel* h, uint32_t D, uint32_t ntiles, hipStream_t s, const uint32_t** skeys,
                      const uint32_t** sval) {
-  const size_t nslots = (size_t)ntiles << h->run_r1_log2;
   PLVS_HIP_TRY(h->dkey0.reserve(D));
   PLVS_HIP_TRY(h->dkey1.reserve(D));
   PLVS_HIP_TRY(h->w_val0.reserve(D));
   PLVS_HIP_TRY(h->w_val1.reserve(D));
-  PLVS_HIP_TRY(h->scratch.reserve(radix_scratch_words(nslots)));
+  PLVS_HIP_TRY(h->w_run_off.reserve((size_t)ntiles + 1));
+  PLVS_HIP_TRY(h->scratch.reserve(std::max(radix_scratch_words(D), scan_scratch_words(ntiles))));
+  PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, ntiles, nullptr, h->scratch.p, s));
+  hipLaunchKernelGGL(compact_runs, dim3(ceil_div(ntiles, 4)), dim3(256), 0, s, h->w_runkey.p, h->w_run_cnt.p,
+                     h->w_run_off.p, ntiles, h->run_r1_log2, h->dkey0.p, h->w_val0.p);
   int key_bits = 12;
   while ((1ll << (key_bits - 12)) < (long long)h->num_chunks) ++key_bits;
   bool second = false;
-  PLVS_HIP_TRY(radix_sort_sparse_u32(h->w_runkey.p, h->w_run_cnt.p, h->run_r1_log2, nslots, D, h->dkey0.p, h->w_val0.p,
-                                     h->dkey1.p, h->w_val1.p, 0, key_bits, h->scratch.p, s, &second));
+  PLVS_HIP_TRY(radix_sort_pairs(h->dkey0.p, h->w_val0.p, h->dkey1.p, h->w_val1.p, D, 0, key_bits, h->scratch.p, s,
+                                &second));
   *skeys = second ? h->dkey1.p : h->dkey0.p;
   *sval = second ? h->w_val1.p : h->w_val0.p;
   return PLVS_OK;
@@ -980,7 +983,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     PLVS_HIP_TRY(h->w_seg.reserve(2 * (seg_own + seg_spill)));
     PLVS_HIP_TRY(h->w_sorted_seg.reserve(h->w_seg.cap));
     PLVS_HIP_TRY(h->w_runkey.reserve((size_t)ntiles << h->run_r1_log2));
-    PLVS_HIP_TRY(h->w_masks.reserve(((size_t)ntiles << h->run_r1_log2) * 8));
+    PLVS_HIP_TRY(h->w_masks.reserve(((size_t)ntiles << h->run_r1_log2) * kMaskWords));
     PLVS_HIP_TRY(hipMemsetAsync(h->d_wctr, 0, 2 * sizeof(WalkCounters), s));
     PLVS_HIP_TRY(hipMemsetAsync(h->w_chunk_nseg.p, 0, (size_t)max_chunks * sizeof(uint32_t), s));
     STAGE_MARK(0);
@@ -1022,6 +1025,13 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     break;
   }
   const WalkCounters& c = *h->h_wctr;
+#if PLVS_WALK_PROBE
+  {
+    const double w = (double)ceil_div(ntiles, 16) * 4;
+    fprintf(stderr, "walk probe (cycles per wave): setup %.0f walk %.0f barrier %.0f resolve %.0f records %.0f runs %.0f\n",
+            c.probe[0] / w, c.probe[1] / w, c.probe[2] / w, c.probe[3] / w, c.probe[4] / w, c.probe[5] / w);
+  }
+#endif
   h->num_chunks = h->h_ctr->num_chunks;
   h->stats.visits = (int64_t)c.total_visits;
   h->stats.new_chunks = h->num_chunks - chunks_before;
@@ -1046,7 +1056,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     PLVS_HIP_TRY(h->w_dummy.reserve((size_t)max_chunks + 1));
     hipLaunchKernelGGL(voxel_heads, dim3(ceil_div(D, 256 * kHeadTiles)), dim3(256), 0, s, skeys, D, h->heads.p,
                        h->w_dummy.p, h->d_wctr + 1);
-    hipLaunchKernelGGL(fold_colours_masks, dim3(std::min<size_t>(ceil_div(D, 256), 2048)), dim3(256), 0, s, skeys,
+    hipLaunchKernelGGL(fold_colours_masks, dim3(std::min<size_t>(ceil_div(D, kFoldWaves), 8192)), dim3(64 * kFoldWaves), 0, s, skeys,
                        sval, D, h->run_r1_log2, h->heads.p, h->w_masks.p, d_rgb, h->rgbw, &h->d_wctr[1].num_heads);
     PLVS_KERNEL_CHECK();
     STAGE_MARK(5);
@@ -1173,7 +1183,7 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   if (h->h_wctr) (void)hipHostFree(h->h_wctr);
   h->w_rec.release(); h->w_seg.release(); h->w_sorted_seg.release(); h->w_chunk_nseg.release();
   h->w_chunk_off.release(); h->w_chunk_fill.release(); h->w_active_off.release(); h->w_masks.release();
-  h->w_dummy.release(); h->w_cold.release(); h->w_runkey.release(); h->w_run_cnt.release(); h->w_val0.release();
+  h->w_dummy.release(); h->w_cold.release(); h->w_runkey.release(); h->w_run_cnt.release(); h->w_run_off.release(); h->w_val0.release();
   h->w_val1.release(); h->w_seg_cnt.release(); h->w_tile_visits.release();
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);

@@ -47,12 +47,28 @@ using plvs::tsdf::kCoordBias;
 using plvs::tsdf::kErrCoordRange;
 using plvs::tsdf::kErrPoolFull;
 
-constexpr int kWalkRays = 256;                  // rays (= threads) per tile
+constexpr int kWalkRays = 512;                  // rays (= threads) per tile
+constexpr int kMaskWords = kWalkRays / 32;      // a run's ray mask
 constexpr int kWalkEntries = 1024;              // LDS hash table entries
 constexpr int kWalkLimit = kWalkEntries * 3 / 4;   // entries a (sub-)tile may use
 constexpr int kWalkWindow = kWalkLimit / 2;     // visits per window of a single over-long ray
 constexpr int kWalkChunks = 64;                 // per-tile chunk cache
 constexpr unsigned long long kVoxEmpty = ~0ull;
+#ifndef PLVS_WALK_PROBE
+#define PLVS_WALK_PROBE 0
+#endif
+#if PLVS_WALK_PROBE
+#define WALK_PROBE(i)                                                                                   \
+  __builtin_amdgcn_sched_barrier(0);                                                                    \
+  if ((threadIdx.x & 63) == 0 && (blockIdx.x & 15) == 0) {                                              \
+    const unsigned long long now_ = clock64();                                                          \
+    atomicAdd(&ctr->probe[i], now_ - tp_);                                                              \
+    tp_ = now_;                                                                                         \
+  }                                                                                                     \
+  __builtin_amdgcn_sched_barrier(0);
+#else
+#define WALK_PROBE(i)
+#endif
 constexpr uint32_t kErrScratch = 8u;            // record / segment / run buffers too small: the host grows them and retries
 
 struct WalkCounters {           // device-side, read back once per call
@@ -66,7 +82,10 @@ struct WalkCounters {           // device-side, read back once per call
   uint32_t rec_top, seg_top;    // records / segments written (walk_acc)
   uint32_t ncold;               // tiles that met a voxel with colour weight < 254
   uint32_t split_tiles;         // tiles that had to be cut (table overflow)
-  uint32_t ticket, ticket2;     // tile tickets of walk_acc / walk_runs
+  uint32_t ticket, ticket2;     // (unused)
+#if PLVS_WALK_PROBE
+  unsigned long long probe[8];  // instrumentation build only
+#endif
 };
 
 __device__ __forceinline__ unsigned long long pack_voxel(int x, int y, int z) {
@@ -96,7 +115,14 @@ __device__ inline int dir_find_or_insert(const Directory& d, int x, int y, int z
   }
   uint32_t h = dir_hash(x, y, z, d.mask);
   for (uint32_t probe = 0; probe <= d.mask; ++probe) {
-    unsigned long long cur = __hip_atomic_load(&d.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // plain (cached) loads first: a block inserted by an earlier kernel is found without leaving the L2; a
+    // stale line can only look emptier than the truth, and then the agent-scope path below decides
+    unsigned long long cur = d.keys[h];
+    if (cur == key) {
+      const int cached = d.slots[h];
+      if (cached >= 0) return cached;
+    }
+    cur = __hip_atomic_load(&d.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cur == kEmptyKey) {
       cur = atomicCAS(&d.keys[h], kEmptyKey, key);
       if (cur == kEmptyKey) {
@@ -128,13 +154,14 @@ __device__ inline int dir_find_or_insert(const Directory& d, int x, int y, int z
 }
 
 // ------------------------------------------------------------------ the walk of one (sub-)tile
-constexpr int kLogLen = 19;                      // visits per ray kept in the tile's visit log
+constexpr int kLogLen = 16;                      // visits per ray kept in the tile's visit log
 constexpr int kSlabs = 8;                        // a chunk is applied in slabs of kSlabVox voxels
 constexpr int kSlabVox = kChunkVox / kSlabs;
 
-struct SubTile {          // rays [lo, hi) of the tile, visits [vlo, vhi) of each ray
+struct SubTile {          // rays [lo, hi) of the tile — all of one cloud —, visits [vlo, vhi) of each ray
   uint16_t lo, hi;
   uint32_t vlo, vhi;
+  int32_t cloud;
 };
 
 struct WalkShared {       // LDS state of walk_tiles
@@ -144,12 +171,12 @@ struct WalkShared {       // LDS state of walk_tiles
   uint32_t ccnt[kWalkChunks * kSlabs];         //   entries of the (sub-)tile per (chunk, slab),
   uint16_t cbase[kWalkChunks * kSlabs];        //   first record of the group, relative to the flush's first record
   uint32_t rbase;                              // first record of the flush
-  SubTile stack[24];
+  SubTile stack[12];   // depth: 8 halvings of the ray range + the windows of one ray
   int sp;
   uint32_t nent;          // entries in use
   uint32_t overflow;      // the table is full: the (sub-)tile is cut
   uint32_t wsum[kWalkRays / 64];
-  uint32_t base;          // look-back result
+  uint32_t next, nrays;   // rays of the tile not yet handed out as sub-tiles / rays of the tile
 };
 
 // Entry of the voxel in the table (inserted if absent); -1 when the table is full.
@@ -160,7 +187,7 @@ __device__ __forceinline__ int table_find_or_insert(WalkShared& S, int vx, int v
     unsigned long long cur = S.ekey[h];
     if (cur == key) return (int)h;
     if (cur == kVoxEmpty) {
-      if (*(volatile uint32_t*)&S.overflow) return -1;
+      if (__hip_atomic_load(&S.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return -1;   // (an LDS read)
       cur = atomicCAS(&S.ekey[h], kVoxEmpty, key);
       if (cur == kVoxEmpty) {
         if (atomicAdd(&S.nent, 1u) >= (uint32_t)kWalkLimit) S.overflow = 1u;   // this insert still stands
@@ -205,13 +232,11 @@ __device__ __forceinline__ uint32_t walk_one(const Params& P, const Pose& pose, 
   return nv;
 }
 
-// Pose and ray of point i; false if the point casts no ray (or lies outside the supported extent).
-__device__ __forceinline__ bool tile_ray(const Params& P, const float* __restrict__ xyz,
-                                         const int32_t* __restrict__ offsets, int nclouds,
-                                         const Pose* __restrict__ poses, uint32_t i, Pose* pose, Ray* ray,
-                                         uint32_t* err) {
-  *pose = poses[cloud_of(offsets, nclouds, (int)i)];
-  if (!make_ray(P, *pose, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], ray)) return false;
+// Ray of point i under the pose of its cloud; false if the point casts no ray (or lies outside the
+// supported extent).
+__device__ __forceinline__ bool tile_ray(const Params& P, const float* __restrict__ xyz, const Pose& pose, uint32_t i,
+                                         Ray* ray, uint32_t* err) {
+  if (!make_ray(P, pose, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], ray)) return false;
   if (!ray_in_coord_range(*ray)) {
     atomicOr(err, kErrCoordRange);
     return false;
@@ -240,13 +265,13 @@ __device__ __forceinline__ void subtile_reset(WalkShared& S, int tid) {
 __device__ __forceinline__ void subtile_split(WalkShared& S, const SubTile st) {
   if (st.hi - st.lo > 1) {
     const uint16_t mid = (uint16_t)((st.lo + st.hi) / 2);
-    S.stack[S.sp++] = SubTile{mid, st.hi, st.vlo, st.vhi};
-    S.stack[S.sp++] = SubTile{st.lo, mid, st.vlo, st.vhi};   // processed first: sub-tiles stay in point order
+    S.stack[S.sp++] = SubTile{mid, st.hi, st.vlo, st.vhi, st.cloud};
+    S.stack[S.sp++] = SubTile{st.lo, mid, st.vlo, st.vhi, st.cloud};   // processed first: sub-tiles stay in point order
   } else {
     const uint32_t a = st.vlo, b = (st.vhi == 0xFFFFFFFFu) ? a + 2u * kWalkWindow : st.vhi;
     const uint32_t mid = (st.vhi == 0xFFFFFFFFu) ? a + kWalkWindow : a + (b - a) / 2;
-    S.stack[S.sp++] = SubTile{st.lo, st.hi, mid, st.vhi};
-    S.stack[S.sp++] = SubTile{st.lo, st.hi, a, mid};
+    S.stack[S.sp++] = SubTile{st.lo, st.hi, mid, st.vhi, st.cloud};
+    S.stack[S.sp++] = SubTile{st.lo, st.hi, a, mid, st.cloud};
   }
 }
 
@@ -282,20 +307,20 @@ struct AccOut {
 };
 // Runs: one descriptor + 256-bit ray mask per (tile, voxel) that needs its visits in order.
 // Tile t owns run slots [t << r1_log2, (t + 1) << r1_log2) and fills them from the front, in the order
-// of its flushes (= point order); run_cnt[t] = how many.  No numbering across tiles: the stable sort by
-// voxel key reads this sparse layout directly (radix_sort_sparse_u32) and carries the slot index, from
-// which the tile (slot >> r1_log2) and the mask follow.  A tile that needs more slots reports how many
+// of its flushes (= point order); run_cnt[t] = how many.  No numbering across tiles inside the kernel
+// (a look-back made every tile wait for its slowest neighbour): compact_runs lists (key, slot) densely
+// in tile order for the stable sort by voxel key; the tile (slot >> r1_log2) and the mask follow from the slot.  A tile that needs more slots reports how many
 // (run_need) and the host repeats the call with larger regions.
 struct RunOut {
   uint32_t* dkey;                 // [ntiles << r1_log2] voxel key (slot * 4096 + voxel)
-  uint32_t* masks;                // [(ntiles << r1_log2) * 8] rays of the tile that visit the voxel, bit r = ray r
+  uint32_t* masks;                // [(ntiles << r1_log2) * kMaskWords] rays of the tile that visit the voxel, bit r = ray r
   uint32_t* run_cnt;              // [ntiles]
   uint32_t r1_log2;
 };
 
 template <bool kOrdered>
 struct WalkCfg {
-  static constexpr int kMaskCap = kOrdered ? kWalkLimit : 512;   // masks built per round (LDS)
+  static constexpr int kMaskCap = 256;   // masks built per round (LDS)
 };
 
 __device__ __forceinline__ uint4 pack_suboffsets(const uint32_t* o) {
@@ -305,7 +330,7 @@ __device__ __forceinline__ uint4 pack_suboffsets(const uint32_t* o) {
 // kOrdered = false: order-free accumulation (records) + runs of the voxels whose colour weight is below 254.
 // kOrdered = true: runs of every voxel, no records.
 template <bool kOrdered>
-__global__ __launch_bounds__(kWalkRays) void walk_tiles(
+__global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
     Params P, float scale_u, float scale_w, const float* __restrict__ xyz, int npoints,
     const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
     int32_t* __restrict__ num_chunks, WalkCounters* __restrict__ ctr, const uint32_t* __restrict__ rgbw, AccOut out,
@@ -313,33 +338,42 @@ __global__ __launch_bounds__(kWalkRays) void walk_tiles(
   constexpr int kMaskCap = WalkCfg<kOrdered>::kMaskCap;
   constexpr int kPer = kWalkEntries / kWalkRays;
   __shared__ WalkShared S;
-  __shared__ uint32_t raw[kMaskCap * 8];              // accumulators during the walk, ray masks afterwards
-  __shared__ uint16_t vlog[kLogLen * kWalkRays];      // entry of visit k of ray r at [k * kWalkRays + r]
+  __shared__ uint32_t raw[kMaskCap * kMaskWords];              // accumulators during the walk, ray masks afterwards
+  __shared__ uint32_t vlog[kLogLen / 2 * kWalkRays];   // entries of visits 2k, 2k+1 of ray r at [k * kWalkRays + r] (lo, hi)
   __shared__ uint16_t e_midx[kWalkEntries];           // mask index of the entry (0xFFFF: none)
   int32_t* const e_wuu = reinterpret_cast<int32_t*>(raw);                                 // sum of w_u * u, fixed point
   unsigned long long* const e_wc = reinterpret_cast<unsigned long long*>(raw + kWalkEntries);   // visits << 32 | sum of w_u
   uint32_t* const e_last = raw + 3 * kWalkEntries;                                        // last visiting ray
-  static_assert(kMaskCap * 8 >= 4 * kWalkEntries, "the accumulators overlay the mask area");
+  static_assert(kMaskCap * kMaskWords >= 4 * kWalkEntries, "the accumulators overlay the mask area");
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   // Tiles are numbered in point order by blockIdx: workgroups are dispatched in that order, so the
   // look-back below only ever waits for tiles that are already running.
   const uint32_t tile = blockIdx.x, ntiles = gridDim.x;
+  const uint32_t first = tile * kWalkRays;
   if (tid == 0) {
-    S.stack[0] = SubTile{0, (uint16_t)kWalkRays, 0u, 0xFFFFFFFFu};
-    S.sp = 1;
+    S.sp = 0;
+    S.next = 0;
+    S.nrays = min((uint32_t)kWalkRays, (uint32_t)npoints - first);
   }
-  const uint32_t i = tile * kWalkRays + (uint32_t)tid;
-  Pose pose;
-  Ray ray;
-  const bool has_ray = i < (uint32_t)npoints && tile_ray(P, xyz, offsets, nclouds, poses, i, &pose, &ray, &ctr->err);
-  const float wu = has_ray ? P.weight / (2.0f * ray.truncation) : 0.0f;
-  const uint32_t q_w = (uint32_t)__float2int_rn(wu * scale_w);
+  const uint32_t i = first + (uint32_t)tid;
   uint32_t my_visits = 0;
   bool was_split = false;
   int flushes = 0;
   uint32_t emitted = 0;
+#if PLVS_WALK_PROBE
+  unsigned long long tp_ = clock64();
+#endif
 
   while (true) {
+    __syncthreads();
+    // A sub-tile holds rays of ONE cloud, so that its pose is uniform (scalar registers); the tile hands
+    // out its rays cloud by cloud (nearly every tile lies inside one cloud).
+    if (tid == 0 && S.sp == 0 && S.next < S.nrays) {
+      const int c = cloud_of(offsets, nclouds, (int)(first + S.next));
+      const uint32_t end = min((uint32_t)(offsets[c + 1] - (int32_t)first), S.nrays);
+      S.stack[S.sp++] = SubTile{(uint16_t)S.next, (uint16_t)end, 0u, 0xFFFFFFFFu, c};
+      S.next = end;
+    }
     __syncthreads();
     if (S.sp == 0) break;
     const SubTile st = S.stack[S.sp - 1];
@@ -350,15 +384,23 @@ __global__ __launch_bounds__(kWalkRays) void walk_tiles(
 #pragma unroll
       for (int k = 0; k < 4 * kPer; ++k) raw[tid + k * kWalkRays] = 0u;
     }
+    const Pose pose = poses[__builtin_amdgcn_readfirstlane(st.cloud)];
+    Ray ray;
+    const bool walks = tid >= st.lo && tid < st.hi && tile_ray(P, xyz, pose, i, &ray, &ctr->err);
+    const float wu = walks ? P.weight / (2.0f * ray.truncation) : 0.0f;
+    const uint32_t q_w = (uint32_t)__float2int_rn(wu * scale_w);
     __syncthreads();
-    uint32_t nv = 0;
-    const bool walks = has_ray && tid >= st.lo && tid < st.hi;
+    WALK_PROBE(0)
+    uint32_t nv = 0, log_lo = 0;
     if (walks) {
       nv = walk_one(P, pose, ray, st.vlo, st.vhi, [&](uint32_t k, int vx, int vy, int vz, float u) {
         if (exp & 2) return true;
         const int e = table_find_or_insert(S, vx, vy, vz);
         if (e < 0) return false;
-        if (k < (uint32_t)kLogLen) vlog[k * kWalkRays + tid] = (uint16_t)e;
+        if (k < (uint32_t)kLogLen) {   // two entries per dword, written once per pair
+          if (k & 1u) vlog[(k >> 1) * kWalkRays + tid] = log_lo | ((uint32_t)e << 16);
+          else log_lo = (uint32_t)e;
+        }
         if (exp & 1) return true;
         if (!kOrdered) {
           atomicAdd(&e_wuu[e], __float2int_rn((wu * u) * scale_u));
@@ -368,7 +410,9 @@ __global__ __launch_bounds__(kWalkRays) void walk_tiles(
         return true;
       });
     }
+    WALK_PROBE(1)
     __syncthreads();
+    WALK_PROBE(2)
     const bool overflowed = S.overflow != 0;
     __syncthreads();
     if (overflowed) {
@@ -377,6 +421,7 @@ __global__ __launch_bounds__(kWalkRays) void walk_tiles(
       continue;
     }
     const uint32_t nmine = nv > st.vlo ? nv - st.vlo : 0u;   // this ray's visits in the (sub-)tile
+    if ((nmine & 1u) && nmine <= (uint32_t)kLogLen) vlog[(nmine >> 1) * kWalkRays + tid] = log_lo;   // the odd last one
     my_visits += nmine;
     if (exp & 4) continue;
 
@@ -428,6 +473,7 @@ __global__ __launch_bounds__(kWalkRays) void walk_tiles(
       }
     }
     __syncthreads();
+    WALK_PROBE(3)
     if (!kOrdered) {
       // ---- records: wave 0 places the (chunk, slab) groups (the tile's own region on its first flush)
       if (tid < 64) {
@@ -496,6 +542,7 @@ __global__ __launch_bounds__(kWalkRays) void walk_tiles(
       }
     }
 
+    WALK_PROBE(4)
     // ---- runs: number the entries that need one
     uint32_t inc = nneed;
 #pragma unroll
@@ -526,20 +573,21 @@ __global__ __launch_bounds__(kWalkRays) void walk_tiles(
     for (uint32_t r0 = 0; fits && r0 < nruns; r0 += kMaskCap) {
       __syncthreads();   // e_midx complete / the previous round's masks are out
 #pragma unroll
-      for (int k = 0; k < kMaskCap * 8 / kWalkRays; ++k) raw[tid + k * kWalkRays] = 0u;
+      for (int k = 0; k < kMaskCap * kMaskWords / kWalkRays; ++k) raw[tid + k * kWalkRays] = 0u;
       __syncthreads();
       if (walks && nmine) {
         const uint32_t logged = min(nmine, (uint32_t)kLogLen);
         for (uint32_t k = 0; k < logged; ++k) {
-          const uint32_t m = (uint32_t)e_midx[vlog[k * kWalkRays + tid]] - r0;   // 0xFFFF - r0 stays out of range
-          if (m < (uint32_t)kMaskCap) atomicOr(&raw[m * 8 + (tid >> 5)], 1u << (tid & 31));
+          const uint32_t e = (vlog[(k >> 1) * kWalkRays + tid] >> ((k & 1u) * 16)) & 0xFFFFu;
+          const uint32_t m = (uint32_t)e_midx[e] - r0;   // 0xFFFF - r0 stays out of range
+          if (m < (uint32_t)kMaskCap) atomicOr(&raw[m * kMaskWords + (tid >> 5)], 1u << (tid & 31));
         }
         if (nmine > (uint32_t)kLogLen) {   // the log is full: the rest of the ray is walked again
           walk_one(P, pose, ray, st.vlo, st.vhi, [&](uint32_t k, int vx, int vy, int vz, float) {
             if (k >= (uint32_t)kLogLen) {
               const int e = table_find(S, vx, vy, vz);
               const uint32_t m = e >= 0 ? (uint32_t)e_midx[e] - r0 : 0xFFFFFFFFu;
-              if (m < (uint32_t)kMaskCap) atomicOr(&raw[m * 8 + (tid >> 5)], 1u << (tid & 31));
+              if (m < (uint32_t)kMaskCap) atomicOr(&raw[m * kMaskWords + (tid >> 5)], 1u << (tid & 31));
             }
             return true;
           });
@@ -552,14 +600,15 @@ __global__ __launch_bounds__(kWalkRays) void walk_tiles(
         if (m == 0xFFFFu || m < r0 || m >= r0 + (uint32_t)kMaskCap) continue;
         const size_t d = ((size_t)tile << runs.r1_log2) + emitted + m;
         runs.dkey[d] = vkey[k];
-        const uint32_t* mk = raw + (m - r0) * 8;
-        uint4* dst = reinterpret_cast<uint4*>(runs.masks + d * 8);
-        dst[0] = make_uint4(mk[0], mk[1], mk[2], mk[3]);
-        dst[1] = make_uint4(mk[4], mk[5], mk[6], mk[7]);
+        const uint32_t* mk = raw + (m - r0) * kMaskWords;
+        uint4* dst = reinterpret_cast<uint4*>(runs.masks + d * kMaskWords);
+#pragma unroll
+        for (int q = 0; q < kMaskWords / 4; ++q) dst[q] = make_uint4(mk[4 * q], mk[4 * q + 1], mk[4 * q + 2], mk[4 * q + 3]);
       }
     }
     emitted += nruns;
     ++flushes;
+    WALK_PROBE(5)
   }
 
   // ---- tile epilogue: run and visit counts
@@ -828,10 +877,14 @@ __global__ void mask_counts(const uint32_t* __restrict__ sorted_val, uint32_t nd
                             const uint32_t* __restrict__ masks, uint32_t* __restrict__ cnts) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nd) return;
-  const uint4* m = reinterpret_cast<const uint4*>(masks + (size_t)sorted_val[j] * 8);
-  const uint4 a = m[0], b = m[1];
-  cnts[j] = (uint32_t)(__popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) +
-                       __popc(b.w));
+  const uint4* m = reinterpret_cast<const uint4*>(masks + (size_t)sorted_val[j] * kMaskWords);
+  uint32_t c = 0;
+#pragma unroll
+  for (int q = 0; q < kMaskWords / 4; ++q) {
+    const uint4 a = m[q];
+    c += (uint32_t)(__popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w));
+  }
+  cnts[j] = c;
 }
 
 // Ordered mode: the update operands of every visit, in voxel order (what chain_runs folds).  One
@@ -849,7 +902,7 @@ __global__ __launch_bounds__(256) void expand_runs(
   const uint32_t key = skeys[j];
   const bool closes = (j + 1 >= nd) || skeys[j + 1] != key;
   const uint32_t val = sorted_val[j];
-  const uint32_t* m = masks + (size_t)val * 8;
+  const uint32_t* m = masks + (size_t)val * kMaskWords;
   const uint32_t p0 = (val >> r1_log2) * (uint32_t)kWalkRays;
   const uint32_t slot = key / kChunkVox, vid = key % kChunkVox;
   const int vx = slot_ids[3 * slot] * 16 + (int)(vid & 15), vy = slot_ids[3 * slot + 1] * 16 + (int)((vid >> 4) & 15),
@@ -887,52 +940,94 @@ __global__ __launch_bounds__(256) void expand_runs(
   }
 }
 
-// ColorVoxel::IntegrateSimple visit by visit, for the voxels whose colour weight is below 254: one
-// thread per voxel walks its runs (sorted: tile order = point order), the rays of a mask in ascending
-// order, until the weight reaches 254 (at most 254 steps in the life of a voxel).
-__global__ __launch_bounds__(256) void fold_colours_masks(
+// Runs of the per-tile regions -> dense (key, slot) pairs in tile order (the input of the stable sort
+// by voxel key).  One wave per tile.
+__global__ __launch_bounds__(256) void compact_runs(const uint32_t* __restrict__ runkey, const uint32_t* __restrict__ run_cnt,
+                                                    const uint32_t* __restrict__ run_off, uint32_t ntiles,
+                                                    uint32_t r1_log2, uint32_t* __restrict__ dkey,
+                                                    uint32_t* __restrict__ dval) {
+  const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (t >= ntiles) return;
+  const uint32_t n = run_cnt[t], o = run_off[t], base = t << r1_log2;
+  for (uint32_t k = threadIdx.x & 63; k < n; k += 64) {
+    dkey[o + k] = runkey[base + k];
+    dval[o + k] = base + k;
+  }
+}
+
+// ColorVoxel::IntegrateSimple visit by visit, for the voxels whose colour weight is below 254.  One
+// wave per voxel: the lanes take its runs (sorted: tile order = point order) 64 at a time, place the
+// colours of their visits — the rays of a mask in ascending order — in LDS at the visit's rank, and three
+// lanes fold the red, green and blue sequences (the weight is common) until the weight reaches 254: at
+// most 254 steps in the life of a voxel, none once it is there.
+constexpr int kFoldWaves = 4;
+__global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
     const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ sorted_val, uint32_t nd, uint32_t r1_log2,
     const uint32_t* __restrict__ vj0, const uint32_t* __restrict__ masks, const uint8_t* __restrict__ rgb,
     uint32_t* __restrict__ rgbw, const uint32_t* __restrict__ num_heads) {
+  __shared__ uint32_t stage[kFoldWaves][256];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const uint32_t nvox = *num_heads;
-  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += gridDim.x * blockDim.x) {
-    uint32_t j = vj0[v];
-    const uint32_t key = skeys[j];
-    uint32_t col = rgbw[key];
-    if ((col >> 24) >= 254u) continue;
-    for (; j < nd && skeys[j] == key && (col >> 24) < 254u; ++j) {
-      const uint32_t val = sorted_val[j];
-      const uint4* m4 = reinterpret_cast<const uint4*>(masks + (size_t)val * 8);
-      const uint4 a = m4[0], b = m4[1];
-      const uint32_t m[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-      const uint32_t p0 = (val >> r1_log2) * (uint32_t)kWalkRays;
+  const uint32_t nwaves = gridDim.x * kFoldWaves;
+  for (uint32_t v = blockIdx.x * kFoldWaves + wid; v < nvox; v += nwaves) {
+    const uint32_t j0 = vj0[v];
+    const uint32_t key = skeys[j0];
+    const uint32_t col0 = rgbw[key];
+    const uint32_t cw0 = col0 >> 24;
+    if (cw0 >= 254u) continue;
+    const uint32_t need = 254u - cw0;   // visits that still count
+    uint32_t have = 0;                  // visits staged so far
+    for (uint32_t jb = j0; have < need; jb += 64) {
+      const uint32_t j = jb + (uint32_t)lane;
+      const bool mine = j < nd && skeys[j] == key;
+      uint32_t m[kMaskWords];
 #pragma unroll
-      for (int w = 0; w < 8; ++w) {
+      for (int w = 0; w < kMaskWords; ++w) m[w] = 0;
+      uint32_t p0 = 0, cnt = 0;
+      if (mine) {
+        const uint32_t val = sorted_val[j];
+        const uint4* m4 = reinterpret_cast<const uint4*>(masks + (size_t)val * kMaskWords);
+#pragma unroll
+        for (int q = 0; q < kMaskWords / 4; ++q) {
+          const uint4 a = m4[q];
+          m[4 * q] = a.x; m[4 * q + 1] = a.y; m[4 * q + 2] = a.z; m[4 * q + 3] = a.w;
+        }
+        p0 = (val >> r1_log2) * (uint32_t)kWalkRays;
+#pragma unroll
+        for (int w = 0; w < kMaskWords; ++w) cnt += (uint32_t)__popc(m[w]);
+      }
+      uint32_t inc = cnt;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
+        if (lane >= off) inc += up;
+      }
+      uint32_t at = have + inc - cnt;
+#pragma unroll
+      for (int w = 0; w < kMaskWords; ++w) {
         uint32_t bits = m[w];
-        while (bits && (col >> 24) < 254u) {
-          // up to four visits at a time: their colours are independent loads
-          uint32_t c[4];
-          int n = 0;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            c[q] = 0;
-            if (bits) {
-              const int bpos = __ffs((int)bits) - 1;
-              bits &= bits - 1u;
-              const size_t p = (size_t)p0 + (size_t)(w * 32 + bpos);
-              c[q] = (uint32_t)rgb[3 * p] | ((uint32_t)rgb[3 * p + 1] << 8) | ((uint32_t)rgb[3 * p + 2] << 16);
-              n = q + 1;
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (q < n)
-              colour_update(col, colour_roundtrip(c[q] & 255u), colour_roundtrip((c[q] >> 8) & 255u),
-                            colour_roundtrip((c[q] >> 16) & 255u));
+        while (bits && at < need) {
+          const int bpos = __ffs((int)bits) - 1;
+          bits &= bits - 1u;
+          const size_t p = (size_t)p0 + (size_t)(w * 32 + bpos);
+          stage[wid][at++] = (uint32_t)rgb[3 * p] | ((uint32_t)rgb[3 * p + 1] << 8) | ((uint32_t)rgb[3 * p + 2] << 16);
         }
       }
+      have += (uint32_t)__shfl((int)inc, 63);
+      if (__ballot(mine) != ~0ull) break;   // the voxel's runs end inside this batch
     }
-    rgbw[key] = col;
+    const uint32_t steps = min(have, need);
+    // lanes 0..2 fold one channel each (ColorVoxel::IntegrateSimple: (uint8)((float)(w * old + new) * (1 / (w + 1))))
+    uint32_t ch = (col0 >> (8 * (lane & 3))) & 255u;
+    if (lane < 3) {
+      for (uint32_t k = 0; k < steps; ++k) {
+        const uint32_t cw = cw0 + k;
+        const uint32_t x = colour_roundtrip((stage[wid][k] >> (8 * lane)) & 255u);
+        ch = (uint32_t)(uint8_t)((float)(cw * ch + x) * (1.f / (float)(1u + cw)));
+      }
+    }
+    const uint32_t r = (uint32_t)__shfl((int)ch, 0), g = (uint32_t)__shfl((int)ch, 1), bl = (uint32_t)__shfl((int)ch, 2);
+    if (lane == 0) rgbw[key] = r | (g << 8) | (bl << 16) | ((cw0 + steps) << 24);
   }
 }
 
