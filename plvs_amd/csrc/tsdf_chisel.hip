@@ -910,8 +910,6 @@ static int read_counters(plvs_tsdf_chisel* h, hipStream_t s) {
 // ------------------------------------------------------------------ single-walk pipeline (tsdf_walk.hpp)
 constexpr int kWalkStages = 4;
 const char* const kWalkStageNames[kWalkStages] = {"walk_tiles", "sort_segments", "apply_chunks", "fold_colours"};
-const char* const kRunStageNames[kNumStages] = {"walk_runs", "sort_runs", "place_runs", "expand_runs", "chain_runs",
-                                                "-"};
 
 static int read_walk_counters(plvs_tsdf_chisel* h, hipStream_t s) {
   PLVS_HIP_TRY(hipMemcpyAsync(h->h_wctr, h->d_wctr, 2 * sizeof(WalkCounters), hipMemcpyDeviceToHost, s));
@@ -990,9 +988,8 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     AccOut out{h->w_rec.p, (uint32_t)std::min<size_t>(rec_own + rec_spill, 0xFFFFFFFFu), h->w_seg.p,
                (uint32_t)std::min<size_t>(seg_own + seg_spill, 0xFFFFFFFFu), h->w_seg_cnt.p, h->w_tile_visits.p};
     RunOut runs{h->w_runkey.p, h->w_masks.p, h->w_run_cnt.p, h->run_r1_log2};
-    hipLaunchKernelGGL(walk_tiles<false>, dim3(ntiles), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
-                       h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw, out, runs,
-                       plvs::env_int("PLVS_WALK_EXP", 0, 0, 255));
+    hipLaunchKernelGGL(walk_tiles, dim3(ntiles), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
+                       h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw, out, runs);
     STAGE_MARK(1);
     const unsigned seg_blocks = ceil_div(seg_own + seg_spill, kSegSpan);
     hipLaunchKernelGGL(seg_pass<false>, dim3(seg_blocks), dim3(256), 0, s, h->w_seg.p, out.seg_cap, ntiles,
@@ -1025,13 +1022,6 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     break;
   }
   const WalkCounters& c = *h->h_wctr;
-#if PLVS_WALK_PROBE
-  {
-    const double w = (double)ceil_div(ntiles, 16) * 4;
-    fprintf(stderr, "walk probe (cycles per wave): setup %.0f walk %.0f barrier %.0f resolve %.0f records %.0f runs %.0f\n",
-            c.probe[0] / w, c.probe[1] / w, c.probe[2] / w, c.probe[3] / w, c.probe[4] / w, c.probe[5] / w);
-  }
-#endif
   h->num_chunks = h->h_ctr->num_chunks;
   h->stats.visits = (int64_t)c.total_visits;
   h->stats.new_chunks = h->num_chunks - chunks_before;
@@ -1507,7 +1497,6 @@ const char* plvs_hip_tsdf_chisel_stage_name(int i) {
 const char* plvs_hip_tsdf_chisel_stage_name_of(plvs_tsdf_chisel* h, int i) {
   if (h == nullptr || i < 0) return "";
   if (h->stage_set == 1) return i < kWalkStages ? kWalkStageNames[i] : "";
-  if (h->stage_set == 2) return i < kNumStages ? kRunStageNames[i] : "";
   return i < kNumStages ? kStageNames[i] : "";
 }
 

@@ -45,6 +45,7 @@ using namespace plvs::chisel;
 using plvs::tsdf::cloud_of;
 using plvs::tsdf::kCoordBias;
 using plvs::tsdf::kErrCoordRange;
+using plvs::tsdf::kErrDirectoryMiss;
 using plvs::tsdf::kErrPoolFull;
 
 constexpr int kWalkRays = 512;                  // rays (= threads) per tile
@@ -54,21 +55,6 @@ constexpr int kWalkLimit = kWalkEntries * 3 / 4;   // entries a (sub-)tile may u
 constexpr int kWalkWindow = kWalkLimit / 2;     // visits per window of a single over-long ray
 constexpr int kWalkChunks = 64;                 // per-tile chunk cache
 constexpr unsigned long long kVoxEmpty = ~0ull;
-#ifndef PLVS_WALK_PROBE
-#define PLVS_WALK_PROBE 0
-#endif
-#if PLVS_WALK_PROBE
-#define WALK_PROBE(i)                                                                                   \
-  __builtin_amdgcn_sched_barrier(0);                                                                    \
-  if ((threadIdx.x & 63) == 0 && (blockIdx.x & 15) == 0) {                                              \
-    const unsigned long long now_ = clock64();                                                          \
-    atomicAdd(&ctr->probe[i], now_ - tp_);                                                              \
-    tp_ = now_;                                                                                         \
-  }                                                                                                     \
-  __builtin_amdgcn_sched_barrier(0);
-#else
-#define WALK_PROBE(i)
-#endif
 constexpr uint32_t kErrScratch = 8u;            // record / segment / run buffers too small: the host grows them and retries
 
 struct WalkCounters {           // device-side, read back once per call
@@ -82,10 +68,6 @@ struct WalkCounters {           // device-side, read back once per call
   uint32_t rec_top, seg_top;    // records / segments written (walk_acc)
   uint32_t ncold;               // tiles that met a voxel with colour weight < 254
   uint32_t split_tiles;         // tiles that had to be cut (table overflow)
-  uint32_t ticket, ticket2;     // (unused)
-#if PLVS_WALK_PROBE
-  unsigned long long probe[8];  // instrumentation build only
-#endif
 };
 
 __device__ __forceinline__ unsigned long long pack_voxel(int x, int y, int z) {
@@ -104,8 +86,11 @@ __device__ __forceinline__ uint32_t voxel_hash(int x, int y, int z) {
 }
 static_assert(kWalkEntries == 1024, "voxel_hash yields 10 bits");
 
-// Find-or-insert with the slot returned; usable by concurrent workgroups of ONE kernel: a block that
-// another workgroup is just inserting is waited for (its slot arrives a few instructions after its key).
+// Find-or-insert with the slot returned; usable by concurrent workgroups of ONE kernel.  A block that
+// another thread is just inserting is waited for (its slot arrives a few instructions after its key) —
+// in a SECOND phase, entered only after every lane of the wave has finished its own insertions: lanes
+// of one wave run their divergent paths one after the other, so a lane that spun for another wave's
+// slot before its neighbour lane had published the slot THAT wave is spinning for would deadlock.
 __device__ inline int dir_find_or_insert(const Directory& d, int x, int y, int z, int32_t* num_blocks,
                                          uint32_t* err) {
   unsigned long long key;
@@ -114,43 +99,57 @@ __device__ inline int dir_find_or_insert(const Directory& d, int x, int y, int z
     return -1;
   }
   uint32_t h = dir_hash(x, y, z, d.mask);
+  int slot = -1;
+  bool pending = false, full = true;
+  // ---- phase 1: find the entry or create it (no waiting)
   for (uint32_t probe = 0; probe <= d.mask; ++probe) {
-    // plain (cached) loads first: a block inserted by an earlier kernel is found without leaving the L2; a
-    // stale line can only look emptier than the truth, and then the agent-scope path below decides
+    // plain (cached) loads first: a block inserted by an earlier kernel is found without leaving the L2.  A
+    // stale line can only look emptier than the truth (an entry goes from empty to its final value once),
+    // and then the read-modify-write path decides: RMW atomics are performed at the device's coherence
+    // point, unlike loads, which another XCD's L2 may serve from a stale line.
     unsigned long long cur = d.keys[h];
     if (cur == key) {
       const int cached = d.slots[h];
-      if (cached >= 0) return cached;
-    }
-    cur = __hip_atomic_load(&d.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cur == kEmptyKey) {
-      cur = atomicCAS(&d.keys[h], kEmptyKey, key);
-      if (cur == kEmptyKey) {
-        const int slot = atomicAdd(num_blocks, 1);
-        if (slot < d.max_blocks) {
-          d.slot_ids[3 * slot + 0] = x;
-          d.slot_ids[3 * slot + 1] = y;
-          d.slot_ids[3 * slot + 2] = z;
-          __hip_atomic_store(&d.slots[h], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          return slot;
-        }
-        atomicOr(err, kErrPoolFull);
-        __hip_atomic_store(&d.slots[h], -2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return -1;
+      if (cached >= 0) {
+        slot = cached;
+        full = false;
+        break;
       }
     }
+    cur = atomicCAS(&d.keys[h], kEmptyKey, key);
+    if (cur == kEmptyKey) {   // inserted here: allocate and publish the slot
+      const int s = atomicAdd(num_blocks, 1);
+      if (s < d.max_blocks) {
+        d.slot_ids[3 * s + 0] = x;
+        d.slot_ids[3 * s + 1] = y;
+        d.slot_ids[3 * s + 2] = z;
+        atomicExch(&d.slots[h], s);
+        slot = s;
+      } else {
+        atomicOr(err, kErrPoolFull);
+        atomicExch(&d.slots[h], -2);
+      }
+      full = false;
+      break;
+    }
     if (cur == key) {
-      int slot;
-      int spins = 0;
-      do {
-        slot = __hip_atomic_load(&d.slots[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } while (slot == -1 && ++spins < (1 << 22));
-      return slot >= 0 ? slot : -1;
+      pending = true;
+      full = false;
+      break;
     }
     h = (h + 1) & d.mask;
   }
-  atomicOr(err, kErrPoolFull);
-  return -1;
+  if (full) atomicOr(err, kErrPoolFull);
+  // ---- phase 2: the slot of an entry somebody else created (slots are -1 while pending, -2 / >= 0 when final)
+  if (pending) {
+    int spins = 0;
+    do {
+      slot = atomicMax(&d.slots[h], -2);   // an RMW read
+    } while (slot == -1 && ++spins < (1 << 24));
+    if (slot == -1) atomicOr(err, kErrDirectoryMiss);
+    if (slot < 0) slot = -1;
+  }
+  return slot;
 }
 
 // ------------------------------------------------------------------ the walk of one (sub-)tile
@@ -318,24 +317,18 @@ struct RunOut {
   uint32_t r1_log2;
 };
 
-template <bool kOrdered>
-struct WalkCfg {
-  static constexpr int kMaskCap = 256;   // masks built per round (LDS)
-};
+constexpr int kMaskCap = 256;   // ray masks built per round (LDS)
 
 __device__ __forceinline__ uint4 pack_suboffsets(const uint32_t* o) {
   return make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
 }
 
-// kOrdered = false: order-free accumulation (records) + runs of the voxels whose colour weight is below 254.
-// kOrdered = true: runs of every voxel, no records.
-template <bool kOrdered>
+// Order-free accumulation (records) + runs of the voxels whose colour weight is below 254.
 __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
     Params P, float scale_u, float scale_w, const float* __restrict__ xyz, int npoints,
     const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
     int32_t* __restrict__ num_chunks, WalkCounters* __restrict__ ctr, const uint32_t* __restrict__ rgbw, AccOut out,
-    RunOut runs, int exp) {
-  constexpr int kMaskCap = WalkCfg<kOrdered>::kMaskCap;
+    RunOut runs) {
   constexpr int kPer = kWalkEntries / kWalkRays;
   __shared__ WalkShared S;
   __shared__ uint32_t raw[kMaskCap * kMaskWords];              // accumulators during the walk, ray masks afterwards
@@ -360,9 +353,6 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
   bool was_split = false;
   int flushes = 0;
   uint32_t emitted = 0;
-#if PLVS_WALK_PROBE
-  unsigned long long tp_ = clock64();
-#endif
 
   while (true) {
     __syncthreads();
@@ -380,39 +370,30 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
     __syncthreads();
     if (tid == 0) --S.sp;
     subtile_reset(S, tid);
-    if (!kOrdered) {
 #pragma unroll
-      for (int k = 0; k < 4 * kPer; ++k) raw[tid + k * kWalkRays] = 0u;
-    }
+    for (int k = 0; k < 4 * kPer; ++k) raw[tid + k * kWalkRays] = 0u;
     const Pose pose = poses[__builtin_amdgcn_readfirstlane(st.cloud)];
     Ray ray;
     const bool walks = tid >= st.lo && tid < st.hi && tile_ray(P, xyz, pose, i, &ray, &ctr->err);
     const float wu = walks ? P.weight / (2.0f * ray.truncation) : 0.0f;
     const uint32_t q_w = (uint32_t)__float2int_rn(wu * scale_w);
     __syncthreads();
-    WALK_PROBE(0)
     uint32_t nv = 0, log_lo = 0;
     if (walks) {
       nv = walk_one(P, pose, ray, st.vlo, st.vhi, [&](uint32_t k, int vx, int vy, int vz, float u) {
-        if (exp & 2) return true;
         const int e = table_find_or_insert(S, vx, vy, vz);
         if (e < 0) return false;
         if (k < (uint32_t)kLogLen) {   // two entries per dword, written once per pair
           if (k & 1u) vlog[(k >> 1) * kWalkRays + tid] = log_lo | ((uint32_t)e << 16);
           else log_lo = (uint32_t)e;
         }
-        if (exp & 1) return true;
-        if (!kOrdered) {
-          atomicAdd(&e_wuu[e], __float2int_rn((wu * u) * scale_u));
-          atomicAdd(&e_wc[e], (1ull << 32) | (unsigned long long)q_w);
-          atomicMax(&e_last[e], (uint32_t)tid);
-        }
+        atomicAdd(&e_wuu[e], __float2int_rn((wu * u) * scale_u));
+        atomicAdd(&e_wc[e], (1ull << 32) | (unsigned long long)q_w);
+        atomicMax(&e_last[e], (uint32_t)tid);
         return true;
       });
     }
-    WALK_PROBE(1)
     __syncthreads();
-    WALK_PROBE(2)
     const bool overflowed = S.overflow != 0;
     __syncthreads();
     if (overflowed) {
@@ -423,7 +404,6 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
     const uint32_t nmine = nv > st.vlo ? nv - st.vlo : 0u;   // this ray's visits in the (sub-)tile
     if ((nmine & 1u) && nmine <= (uint32_t)kLogLen) vlog[(nmine >> 1) * kWalkRays + tid] = log_lo;   // the odd last one
     my_visits += nmine;
-    if (exp & 4) continue;
 
     // ---- entries -> chunks -> pool slots
     int ci[kPer];
@@ -460,21 +440,20 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
       const uint32_t vid = (uint32_t)(((vz & 15) * 16 + (vy & 15)) * 16 + (vx & 15));
       if (ci[k] >= 0) {
         slot_of[k] = S.cslot[ci[k]];
-        if (!kOrdered && slot_of[k] >= 0) rank[k] = atomicAdd(&S.ccnt[ci[k] * kSlabs + (int)(vid / kSlabVox)], 1u);
+        if (slot_of[k] >= 0) rank[k] = atomicAdd(&S.ccnt[ci[k] * kSlabs + (int)(vid / kSlabVox)], 1u);
       } else {
         slot_of[k] = dir_find_or_insert(dir, vx >> 4, vy >> 4, vz >> 4, num_chunks, &ctr->err);
       }
       if (slot_of[k] >= 0) {
         vkey[k] = (uint32_t)slot_of[k] * (uint32_t)kChunkVox + vid;
-        if (!(exp & 8) && (kOrdered || (rgbw[vkey[k]] >> 24) < 254u)) {
+        if ((rgbw[vkey[k]] >> 24) < 254u) {   // its colour still depends on the order of the visits
           need |= 1u << k;
           ++nneed;
         }
       }
     }
     __syncthreads();
-    WALK_PROBE(3)
-    if (!kOrdered) {
+    {
       // ---- records: wave 0 places the (chunk, slab) groups (the tile's own region on its first flush)
       if (tid < 64) {
         uint32_t sub[kSlabs], c = 0;
@@ -542,7 +521,6 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
       }
     }
 
-    WALK_PROBE(4)
     // ---- runs: number the entries that need one
     uint32_t inc = nneed;
 #pragma unroll
@@ -608,7 +586,6 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
     }
     emitted += nruns;
     ++flushes;
-    WALK_PROBE(5)
   }
 
   // ---- tile epilogue: run and visit counts
@@ -622,7 +599,7 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
     uint32_t v = 0;
     for (int w = 0; w < kWalkRays / 64; ++w) v += S.wsum[w];
     out.tile_visits[tile] = v;
-    if (!kOrdered && flushes == 0) out.seg_cnt[tile] = 0;
+    if (flushes == 0) out.seg_cnt[tile] = 0;
     if (was_split) atomicAdd(&ctr->split_tiles, 1u);
   }
 }
@@ -843,100 +820,6 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
   if (lane == 0 && voxels) {
     atomicAdd(&ctr->num_heads, voxels);
     atomicMax(&ctr->max_run, longest);
-  }
-}
-
-// sum of the per-tile visit counts (ordered mode: the order-free mode sums them in seg_scan)
-__global__ __launch_bounds__(1024) void sum_tile_visits(const uint32_t* __restrict__ tile_visits,
-                                                        const uint32_t* __restrict__ run_cnt, uint32_t ntiles,
-                                                        WalkCounters* __restrict__ ctr) {
-  __shared__ unsigned long long vsum[16], rsum[16];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  unsigned long long v = 0, nr = 0;
-  for (uint32_t t = tid; t < ntiles; t += 1024) {
-    v += tile_visits[t];
-    nr += run_cnt[t];
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    v += (unsigned long long)__shfl_xor((long long)v, off);
-    nr += (unsigned long long)__shfl_xor((long long)nr, off);
-  }
-  if (lane == 0) { vsum[wid] = v; rsum[wid] = nr; }
-  __syncthreads();
-  if (tid == 0) {
-    unsigned long long tot = 0, rtot = 0;
-    for (int w = 0; w < 16; ++w) { tot += vsum[w]; rtot += rsum[w]; }
-    ctr->total_visits = tot;
-    ctr->num_desc = (uint32_t)rtot;
-  }
-}
-
-// visits of every run in sorted order (input of the scan that places them in voxel order)
-__global__ void mask_counts(const uint32_t* __restrict__ sorted_val, uint32_t nd,
-                            const uint32_t* __restrict__ masks, uint32_t* __restrict__ cnts) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= nd) return;
-  const uint4* m = reinterpret_cast<const uint4*>(masks + (size_t)sorted_val[j] * kMaskWords);
-  uint32_t c = 0;
-#pragma unroll
-  for (int q = 0; q < kMaskWords / 4; ++q) {
-    const uint4 a = m[q];
-    c += (uint32_t)(__popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w));
-  }
-  cnts[j] = c;
-}
-
-// Ordered mode: the update operands of every visit, in voxel order (what chain_runs folds).  One
-// thread per run: for every ray of the mask (ascending = point order) the signed distance of the
-// voxel centre along the ray is recomputed exactly as the walk computed it.
-//   rec[r] = (w_u * u, +-w_u), negative on the LAST record of a voxel; kfid of the voxel = its last visit's.
-__global__ __launch_bounds__(256) void expand_runs(
-    Params P, const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ sorted_val, uint32_t nd,
-    uint32_t r1_log2, const uint32_t* __restrict__ masks, const uint32_t* __restrict__ dst, const float* __restrict__ xyz,
-    const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses,
-    const int32_t* __restrict__ slot_ids, const uint32_t* __restrict__ kfid_of_point, float2* __restrict__ rec,
-    uint32_t* __restrict__ vkfid) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= nd) return;
-  const uint32_t key = skeys[j];
-  const bool closes = (j + 1 >= nd) || skeys[j + 1] != key;
-  const uint32_t val = sorted_val[j];
-  const uint32_t* m = masks + (size_t)val * kMaskWords;
-  const uint32_t p0 = (val >> r1_log2) * (uint32_t)kWalkRays;
-  const uint32_t slot = key / kChunkVox, vid = key % kChunkVox;
-  const int vx = slot_ids[3 * slot] * 16 + (int)(vid & 15), vy = slot_ids[3 * slot + 1] * 16 + (int)((vid >> 4) & 15),
-            vz = slot_ids[3 * slot + 2] * 16 + (int)(vid >> 8);
-  const float c0 = (float)vx * P.resolution + P.half_voxel, c1 = (float)vy * P.resolution + P.half_voxel,
-              c2 = (float)vz * P.resolution + P.half_voxel;
-  uint32_t r = dst[j];
-  uint32_t last_p = 0;
-  int cl = cloud_of(offsets, nclouds, (int)p0);
-  Pose pose = poses[cl];
-  int cl_end = offsets[cl + 1];
-#pragma unroll 1
-  for (int w = 0; w < kWalkRays / 32; ++w) {
-    uint32_t bits = m[w];
-    while (bits) {
-      const int b = __ffs((int)bits) - 1;
-      bits &= bits - 1u;
-      const uint32_t p = p0 + (uint32_t)(w * 32 + b);
-      if ((int)p >= cl_end) {
-        cl = cloud_of(offsets, nclouds, (int)p);
-        pose = poses[cl];
-        cl_end = offsets[cl + 1];
-      }
-      const float depth = xyz[3 * (size_t)p + 2];
-      const float tr = truncation_of(P, depth);
-      const float wu = P.weight / (2.0f * tr);
-      const float u = signed_dist(pose, depth, c0, c1, c2);
-      rec[r++] = make_float2(wu * u, wu);
-      last_p = p;
-    }
-  }
-  if (closes) {
-    rec[r - 1].y = -rec[r - 1].y;
-    vkfid[key] = kfid_of_point ? kfid_of_point[last_p] : 0u;
   }
 }
 

@@ -17,8 +17,8 @@ kfid = torch.from_numpy(np.concatenate([k["kfid"] for k in kfs]).astype(np.int32
 Twc = torch.from_numpy(np.stack([k["Twc"] for k in kfs])).cuda()
 offsets = np.cumsum([0] + [k["xyz"].shape[0] for k in kfs]).astype(np.int32)
 for exp in [int(a) for a in sys.argv[1:]] or [0]:
-    os.environ["PLVS_WALK_EXP"] = str(exp)
-    t = TsdfChisel(0.05, max_chunks=16384, order_free=True)
+    pass
+    t = TsdfChisel(0.05, max_chunks=16384, order_free=exp >= 0)   # a negative argument: the ordered mode
     for _ in range(2):
         t.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
     t.set_profiling(True)
