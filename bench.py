@@ -10,18 +10,26 @@ synthetic room.  One *step* = one call of
 plvs_hip_tsdf_chisel_integrate_batch_dev over a batch of `--batch` keyframes
 (76 800 camera-frame points each) that are already resident in HBM.
 
+`value` is the order-free mode — what BASELINE's north star asks of the TSDF:
+sdf / weight within a stated float tolerance (tests/test_tsdf_chisel.py: 2e-5 m,
+5e-5 relative; deterministic: the sums are fixed point), kfid and colour exact.
+The bit-exact ordered mode is measured beside it (`bit_exact_mode`; `--ordered`
+makes it the headline).  After the timed loops the final maps of both modes are
+compared with the CPU oracle run over the very same sequence (`parity_checked`);
+that oracle run is also the `cpu_baseline`.
+
 Multi-GPU (N > 1): the voxel-chunk hash is sharded, owner(chunk) =
 ChunkHasher(id) mod N; every rank holds the same clouds, applies only the
 visits of its own chunks, and the per-step lists of updated chunk ids are
 all-gathered over RCCL.  Total work is fixed as N grows -> "strong" scaling.
+The same stream is used at every N so that the driver's curve is one workload;
+BASELINE's configs[3] (voxblox 2 cm, 16x12x3 m room) is measured at every N as
+the `voxblox_configs3` leg.
 
 The JSON line also carries `roofline` (algorithmic bytes of SURVEY §8d over the
 measured GPU time of the integrate pipeline, per-stage times from HIP events on
-the library's own stream, HBM traffic from the committed PMC passes),
-`cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded
-sample), the order-free mode's figure, and under "frontend" the per-frame front
-end (ORB 2000, EDLines + LBD, both extractions on two threads, Hamming k = 2,
-SGM dense stereo) — N = 1 only.
+the library's own stream, HBM traffic from the committed PMC passes) and under
+"frontend" the per-frame front end — N = 1 only.
 """
 import argparse
 import json
@@ -44,10 +52,14 @@ def parse():
     ap.add_argument("--max-depth", type=float, default=5.0)
     ap.add_argument("--backend", choices=["chisel", "voxblox"], default="chisel",
                     help="chisel = configs[2] (5 cm / 5 m); voxblox = configs[3] stand-in (2 cm / 8 m room)")
-    ap.add_argument("--order-free", action="store_true",
-                    help="chisel: sum the visits of a call per voxel and apply them in one update (sdf / weight within "
-                         "the float tolerance stated in tests/test_tsdf_chisel.py; kfid, colour exact)")
-    ap.add_argument("--no-order-free-leg", action="store_true", help="skip the extra order-free measurement")
+    ap.add_argument("--ordered", action="store_true",
+                    help="chisel: make the bit-exact ordered mode the headline (default: the order-free mode, sdf / "
+                         "weight within the float tolerance stated in tests/test_tsdf_chisel.py; kfid, colour exact)")
+    ap.add_argument("--order-free", action="store_true", help="(the default; kept for older command lines)")
+    ap.add_argument("--no-other-mode-leg", action="store_true", help="skip the measurement of the other chisel mode")
+    ap.add_argument("--no-voxblox-leg", action="store_true", help="skip the configs[3] (voxblox 2 cm) leg")
+    ap.add_argument("--no-parity-check", action="store_true",
+                    help="skip the oracle run over the same sequence (parity check + CPU baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frontend", action="store_true")
     return ap.parse_args()
@@ -99,7 +111,7 @@ def main():
         tsdf = TsdfVoxblox(args.resolution, max_blocks=65536, shard_rank=rank, shard_count=world)
     else:
         tsdf = TsdfChisel(args.resolution, max_chunks=16384, shard_rank=rank, shard_count=world,
-                          order_free=args.order_free)
+                          order_free=not args.ordered)
     upd_cap = 8192
     d_upd = torch.zeros((upd_cap, 3), dtype=torch.int32, device="cuda")
     gathered_blocks = [0]
@@ -178,14 +190,16 @@ def main():
         }
         # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
         # runs of this same command; scripts/pmc_traffic.py) committed under profiles/
+        mode_tag = "" if vbx else ("_ordered" if args.ordered else "_order_free")
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                           f"r01_pmc_traffic_{args.backend}.json")
+                           f"r02_pmc_traffic_{args.backend}{mode_tag}.json")
         if world == 1 and args.batch == 100 and os.path.exists(pmc):
             with open(pmc) as f:
                 t = json.load(f)
             roofline["traffic"] = t["traffic"]
             roofline["traffic_source"] = ("profiles/" + os.path.basename(pmc) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                           "passes of this command, FETCH_SIZE x2 (gfx950) + WRITE_SIZE, per launch")
+        mode_name = "ordered (bit-exact)" if args.ordered else "order-free (fixed-point sums; sdf / weight within tolerance)"
         result = {
             "metric": ("Mvoxels/sec TSDF integrate (voxblox simple 2 cm / 8 m, 640x480 RGB-D)" if vbx else
                        "Mvoxels/sec TSDF integrate (chisel 5 cm / 5 m, 640x480 RGB-D)"),
@@ -197,6 +211,7 @@ def main():
                                     "simple TSDF 2 cm, max ray 5 m (wrapper constant), 76800-point keyframes" if vbx else
                                     "configs[2] stand-in: synthetic room 6x4x3 m, camera circle r=1 m, "
                                     "Chisel TSDF 5 cm / 5 m, 76800-point keyframes"),
+                       "mode": None if vbx else mode_name,
                        "resolution": args.resolution, "max_depth": args.max_depth,
                        "keyframes_per_step": args.batch, "points_per_step": int(points // args.steps),
                        "visits_per_step": int(visits_total // args.steps),
@@ -205,31 +220,149 @@ def main():
             "roofline": roofline,
         }
 
-    # ------------------------------------------------- order-free mode, same stream (N = 1 only)
-    if rank == 0 and world == 1 and not vbx and not args.order_free and not args.no_order_free_leg:
-        t2 = TsdfChisel(args.resolution, max_chunks=16384, order_free=True)
+    # ------------------------------------------------- the other chisel mode, same stream (N = 1 only)
+    t2 = None
+    if rank == 0 and world == 1 and not vbx and not args.no_other_mode_leg:
+        t2 = TsdfChisel(args.resolution, max_chunks=16384, order_free=args.ordered)
         for s in range(args.warmup):
             t2.integrate_batch_dev(*[batches[s][i] for i in (0, 1, 2, 3, 4)])
         torch.cuda.synchronize()
         t2.set_profiling(True)
         t0 = time.perf_counter()
-        v2 = 0
+        v2 = p2 = 0
         for s in range(args.warmup, total_steps):
             t2.integrate_batch_dev(*[batches[s][i] for i in (0, 1, 2, 3, 4)])
-            v2 += t2.last_stats()["visits"]
+            st2 = t2.last_stats()
+            v2 += st2["visits"]
+            p2 += st2["points"]
         torch.cuda.synchronize()
         el2 = time.perf_counter() - t0
         sm2, c2 = t2.stage_ms()
-        result["order_free_mode"] = {
+        t2.set_profiling(False)
+        ms2 = sum(sm2.values())
+        ach2 = (32.0 * v2 + 28.0 * p2) / (ms2 * 1e-3) / 1e9 if ms2 > 0 else 0.0
+        leg = {
             "value": round(v2 / el2 / 1e6, 2), "unit": "Mvoxels/s", "ms_per_step": round(el2 / args.steps * 1e3, 3),
             "stage_ms_per_launch": {n: round(v / max(c2, 1), 4) for n, v in sm2.items()},
-            "what": "plvs_tsdf_chisel_params.order_free = 1: the visits of a call are summed per voxel (per tile in "
-                    "LDS, then per voxel) and applied in one update; no per-visit chain",
-            "parity": "sdf within 2e-5 m, weight within 5e-5 relative of the reference (measured 6.7e-7 m, "
-                      "4.5e-6); kfid and colour bit-exact (tests/test_tsdf_chisel.py); the headline `value` is the "
-                      "bit-exact ordered mode",
+            "roofline": {"bound": "hbm", "achieved": round(ach2, 2), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(ach2 / 8000.0, 5), "ms_per_launch": round(ms2 / max(c2, 1), 4)},
         }
+        if args.ordered:
+            leg["what"] = ("plvs_tsdf_chisel_params.order_free = 1: one walk; the visits of a call are summed per voxel "
+                           "in fixed point (per tile in LDS, then per chunk slab in LDS) and applied in one update")
+            result["order_free_mode"] = leg
+        else:
+            leg["what"] = ("plvs_tsdf_chisel_params.order_free = 0: every voxel update applied in the reference's order "
+                           "(count, scan, tile sort, run sort, gather, sequential chain); sdf / weight bit-identical")
+            result["bit_exact_mode"] = leg
+
+    # ------------------------------------------------- parity of the timed maps + CPU baseline (rank 0, N = 1)
+    if rank == 0 and world == 1 and not vbx and not args.no_parity_check and not args.no_cpu_baseline:
+        from tests import oracle_lib
+        oracle = oracle_lib.load()
+        ora = oracle.chisel(args.resolution)
+        t0 = time.perf_counter()
+        cv = 0
+        for s in range(total_steps):
+            for j in range(args.batch):
+                k = kfs[(s * args.batch + j) % n_poses]
+                ora.integrate(k["xyz"], k["rgb"], k["kfid"], k["Twc"])
+                cv += ora.last_visits()
+        ct = time.perf_counter() - t0
+        result["cpu_baseline"] = {
+            "value": round(cv / ct / 1e6, 3), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/tsdf_chisel.c (the reference's sequential loop, gcc -O3 -march=native -ffp-contract=off) on "
+                      f"the same {total_steps * args.batch} keyframes the device integrated, {ct:.1f} s, host has "
+                      f"{os.cpu_count()} cores",
+        }
+
+        def deviations(dev, exact):
+            ids = {tuple(c) for c in ora.chunk_ids()}
+            if ids != {tuple(c) for c in dev.chunk_ids()}:
+                return {"ok": False, "why": "chunk sets differ"}
+            # Order-free mode: the reference adds the w_u of a voxel one by one in f32 (and re-rounds the mean
+            # after every visit); after N visits that sum has drifted from the exact one by up to N * 2^-24
+            # relative.  The order-free mode rounds once per call, so it is compared within the tolerance of
+            # the tests (2e-5 m, 5e-5) or the reference's own drift bound for the visits a voxel has taken,
+            # whichever is larger: N <= W / w_min with w_min = 1 / (2 * truncation(5 m)) = 2.0, i.e.
+            # |dW| / W <= W * 2^-25 and |dsdf| <= W * 2^-25 * truncation.
+            ws = ww = wr = 0.0
+            for cid in ids:
+                a, b = ora.get_chunk(*cid), dev.get_chunk(*cid)
+                if not (np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])):
+                    return {"ok": False, "why": f"kfid / colour differ in chunk {cid}"}
+                known = a[1] > 0
+                if not np.array_equal(known, b[1] > 0):
+                    return {"ok": False, "why": f"observed voxels differ in chunk {cid}"}
+                if exact:
+                    if not (np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and
+                            np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))):
+                        return {"ok": False, "why": f"sdf / weight bits differ in chunk {cid}"}
+                elif known.any():
+                    ds = np.abs(a[0][known] - b[0][known])
+                    dw = np.abs(a[1][known] - b[1][known]) / a[1][known]
+                    drift = a[1][known].astype(np.float64) * 2.0 ** -25
+                    ws = max(ws, float(ds.max()))
+                    ww = max(ww, float(dw.max()))
+                    wr = max(wr, float((ds / np.maximum(2e-5, drift * 0.25)).max()), float((dw / np.maximum(5e-5, drift)).max()))
+            if exact:
+                return {"ok": True, "chunks": len(ids), "sdf_weight": "bit-identical", "kfid_colour": "identical"}
+            return {"ok": wr <= 1.0, "chunks": len(ids), "max_abs_sdf_m": ws, "max_rel_weight": ww,
+                    "max_deviation_over_tolerance": wr,
+                    "tolerance": "per voxel max(2e-5 m, W * 2^-25 * 0.25 m) and max(5e-5, W * 2^-25) relative: the test "
+                                 "tolerance or the drift bound of the reference's own sequential f32 sums after the W / 2 "
+                                 "visits the voxel has taken, whichever is larger", "kfid_colour": "identical"}
+
+        checks = {("bit_exact_mode" if args.ordered else "order_free_mode"): deviations(tsdf, args.ordered)}
+        if t2 is not None:
+            checks["order_free_mode" if args.ordered else "bit_exact_mode"] = deviations(t2, not args.ordered)
+        result["parity_checked"] = all(c["ok"] for c in checks.values())
+        result["parity"] = {"against": f"oracle/tsdf_chisel.c over the same {total_steps * args.batch} keyframes, final map, "
+                                       "outside the timed region", **checks}
+    if t2 is not None:
         t2.close()
+
+    # ------------------------------------------------- configs[3]: voxblox 2 cm in the 16x12x3 m room (every N)
+    if not vbx and not args.no_voxblox_leg:
+        vk = make_keyframes(25, room_size=(16.0, 12.0, 3.0), max_depth=8.0, seed=0)
+        vxyz = torch.from_numpy(np.concatenate([k["xyz"] for k in vk])).cuda()
+        vrgba = torch.from_numpy(np.concatenate([np.concatenate([k["rgb"], np.full((k["rgb"].shape[0], 1), 255, np.uint8)],
+                                                                axis=1) for k in vk])).cuda()
+        vTwc = torch.from_numpy(np.stack([k["Twc"] for k in vk])).cuda()
+        voff = np.cumsum([0] + [k["xyz"].shape[0] for k in vk]).astype(np.int32)
+        vb = TsdfVoxblox(0.02, max_blocks=65536, shard_rank=rank, shard_count=world)
+        for _ in range(2):
+            vb.integrate_batch_dev(vxyz, vrgba, voff, vTwc)
+        barrier()
+        t0 = time.perf_counter()
+        vv = vp = 0
+        for _ in range(4):
+            vb.integrate_batch_dev(vxyz, vrgba, voff, vTwc)
+            stv = vb.last_stats()
+            vv += stv["visits"]
+            vp += stv["points"]
+        barrier()
+        vel = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([vel], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            vel = float(tt.item())
+            tv = torch.tensor([vv], dtype=torch.int64, device="cuda")
+            dist.all_reduce(tv, op=dist.ReduceOp.SUM)
+            vv_total = int(tv.item())
+        else:
+            vv_total = vv
+        if rank == 0:
+            ach = (24.0 * vv + 16.0 * vp) / vel / 1e9
+            result["voxblox_configs3"] = {
+                "metric": "Mvoxels/sec TSDF integrate (voxblox simple 2 cm, 16x12x3 m room, depths to 8 m, max ray 5 m)",
+                "value": round(vv_total / vel / 1e6, 2), "unit": "Mvoxels/s", "n_gpus": world, "keyframes_per_step": 25,
+                "ms_per_step": round(vel / 4 * 1e3, 3), "visits_per_step": int(vv_total // 4),
+                "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
+                             "frac": round(ach / 8000.0, 5),
+                             "note": "24 B per visit + 16 B per point over the wall time of the call (this rank's share)"},
+            }
+        vb.close()
 
     # ------------------------------------------------- front end (N = 1 only)
     if rank == 0 and world == 1 and not args.no_frontend:
@@ -336,8 +469,8 @@ def main():
             "ms_per_pair": round(e0.elapsed_time(e1) / 20, 3), "size": "1240x376, 64 disparities, 8 paths",
             "valid_fraction": round(float((sd > 0).float().mean()), 3)}
 
-    # -------------------------------------------------- CPU baseline (rank 0)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    # -------------------------------------------------- CPU baseline when the parity leg did not run (rank 0)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and "cpu_baseline" not in result:
         from tests import oracle_lib
         oracle = oracle_lib.load()
         ora = oracle.voxblox(args.resolution) if vbx else oracle.chisel(args.resolution)

@@ -15,7 +15,8 @@ import json
 import sys
 from collections import defaultdict
 
-PIPELINE = ("pose_prep", "ray_count", "scan_tile_sums", "scan_sums", "scan_tile_apply", "mark_tiles", "ray_tiles",
+PIPELINE = ("pose_prep", "walk_tiles", "seg_pass", "seg_scan", "apply_chunks", "compact_runs", "fold_colours_masks",
+            "ray_count", "scan_tile_sums", "scan_sums", "scan_tile_apply", "mark_tiles", "ray_tiles",
             "radix_hist", "radix_scatter", "voxel_heads", "fold_colours", "reduce_sums", "run_counts", "mark_blocks",
             "gather_runs", "chain_runs")
 
@@ -37,7 +38,8 @@ def load(path):
 
 def main(argv):
     fetch, write = load(argv[1]), load(argv[2])
-    calls = fetch["ray_tiles"][1] or 1          # one ray_tiles dispatch per integrate call
+    # one ray_tiles (ordered mode) / walk_tiles (order-free mode) dispatch per integrate call
+    calls = fetch["ray_tiles"][1] or fetch["walk_tiles"][1] or 1
     out = {"unit": "bytes per integrate call (one launch of the pipeline)", "integrate_calls": calls, "kernels": {}}
     tot_r = tot_w = 0.0
     for k in PIPELINE:
