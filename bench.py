@@ -112,7 +112,7 @@ def main():
     else:
         tsdf = TsdfChisel(args.resolution, max_chunks=16384, shard_rank=rank, shard_count=world,
                           order_free=not args.ordered)
-    upd_cap = 8192
+    upd_cap = 16384          # = max_chunks: an updated-chunk list always fits
     d_upd = torch.zeros((upd_cap, 3), dtype=torch.int32, device="cuda")
     gathered_blocks = [0]
 

@@ -401,6 +401,12 @@ class PointCloudMapChisel {
       int carved = 0;
       check(plvs_hip_tsdf_chisel_carve(h_, depthImage.data, depthImage.cols, depthImage.rows, fx, fy, cx, cy, near_, far_,
                                        Twc.m, carvingDist_, &carved));
+      if (carved > 0) {   // meshesToUpdate[chunkID] = true for every carved chunk, the chunk alone (Chisel.cpp:432)
+        std::vector<int32_t> ids((size_t)3 * carved);
+        int n = 0;
+        check(plvs_hip_tsdf_chisel_updated_chunk_ids(h_, ids.data(), carved, &n));
+        for (int i = 0; i < n && i < carved; ++i) meshesToUpdate_.insert(ChunkID(ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]));
+      }
     }
     InsertCloud(cloud_camera, Twc, max_range);
   }
@@ -425,7 +431,13 @@ class PointCloudMapChisel {
       for (const ChunkID& id : meshesToUpdate_) {
         const int a = first[(size_t)c], b = first[(size_t)c + 1];
         ++c;
-        if (a == b) continue;   // RecomputeMesh stores non-empty meshes only (ChunkManager.cpp:165-167)
+        if (a == b) {
+          // RecomputeMesh stores non-empty meshes only (ChunkManager.cpp:165-167) — but it re-uses the mesh object
+          // already in allMeshes and GenerateMesh clears it first (:581): an existing mesh becomes empty in place
+          auto it = allMeshes_.find(id);
+          if (it != allMeshes_.end()) { it->second.vertices.clear(); it->second.normals.clear(); it->second.colors.clear(); it->second.kfids.clear(); }
+          continue;
+        }
         Mesh& m = allMeshes_[id];
         m.vertices.assign(V.begin() + 3 * a, V.begin() + 3 * b);
         m.normals.assign(N.begin() + 3 * a, N.begin() + 3 * b);

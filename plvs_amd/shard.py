@@ -36,7 +36,11 @@ def allgather_block_lists(local_ids, count, cap, group=None):
     padded lists (a few KB: latency-bound on xGMI, so one fused pair per call)."""
     world = dist.get_world_size(group)
     dev = local_ids.device
-    cnt = torch.tensor([min(int(count), cap)], dtype=torch.int32, device=dev)
+    if int(count) > cap or cap > local_ids.shape[0]:
+        # a clamped list would silently drop block ids from every other rank's directory
+        raise ValueError(f"allgather_block_lists: {count} updated blocks do not fit the {cap}-row buffer "
+                         f"(size it to the map's block capacity)")
+    cnt = torch.tensor([int(count)], dtype=torch.int32, device=dev)
     cnts = [torch.zeros_like(cnt) for _ in range(world)]
     lists = [torch.zeros_like(local_ids) for _ in range(world)]
     dist.all_gather(cnts, cnt, group=group)

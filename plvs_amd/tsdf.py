@@ -309,8 +309,11 @@ class PointCloudMapChisel:
         (Chisel.cpp:394-438), then the cloud is integrated."""
         Twc = np.asarray(Twc, dtype=np.float32)[:3, :4]
         if self.use_carving:
-            self._tsdf.carve(depthImage, fx, fy, cx, cy, Twc, near=self.near_plane_dist, far=self.far_plane_dist,
-                             carving_dist=self.carving_dist)
+            n = self._tsdf.carve(depthImage, fx, fy, cx, cy, Twc, near=self.near_plane_dist, far=self.far_plane_dist,
+                                 carving_dist=self.carving_dist)
+            if n:      # meshesToUpdate[chunkID] = true for every carved chunk, the chunk alone (Chisel.cpp:432)
+                for c in self._tsdf.updated_chunk_ids():
+                    self._meshes_to_update.add((int(c[0]), int(c[1]), int(c[2])))
         self.InsertCloud(cloud_camera, Twc, max_range)
 
     def UpdateMap(self):
@@ -325,6 +328,12 @@ class PointCloudMapChisel:
                 if b > a:
                     self.all_meshes[cid] = dict(vertices=m["vertices"][a:b].copy(), normals=m["normals"][a:b].copy(),
                                                 colors=m["colors"][a:b].copy(), kfids=m["kfids"][a:b].copy())
+                elif cid in self.all_meshes:
+                    # RecomputeMesh re-uses the mesh object already in allMeshes and GenerateMesh clears it first
+                    # (ChunkManager.cpp:581): a chunk whose surface is gone (carved / reset) keeps an EMPTY mesh
+                    e = self.all_meshes[cid]
+                    self.all_meshes[cid] = dict(vertices=e["vertices"][:0], normals=e["normals"][:0],
+                                                colors=e["colors"][:0], kfids=e["kfids"][:0])
             self._meshes_to_update.clear()
         from .cloudgen import POINT_SURFEL
         n = sum(len(v["kfids"]) for v in self.all_meshes.values())

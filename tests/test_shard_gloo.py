@@ -28,7 +28,13 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from plvs_amd.shard import allgather_block_lists, owner_of
+    # plvs_amd/shard.py needs numpy + torch only: loaded by path, so that a box without the HIP library (the
+    # package import loads it) still runs this CPU test
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("plvs_amd_shard", os.path.join(ROOT, "plvs_amd", "shard.py"))
+    shard_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shard_mod)
+    allgather_block_lists, owner_of = shard_mod.allgather_block_lists, shard_mod.owner_of
     from tests import oracle_lib
     from tests.plvs_amd_synth import make_keyframes, TUM1
     cam = dict(TUM1)
