@@ -329,6 +329,45 @@ int plvs_hip_lines_search_stereo_by_knn(const uint8_t* desc_left, int n_left, co
                                         int32_t* match_train, float* match_distance, uint8_t* match_valid,
                                         int cap, int* n_out, int* nmatches);
 
+/* LineMatcher::SearchByProjection — the guided line searches Tracking runs on every frame
+ * (single-camera frames: NlinesLeft == -1, no mpCamera2).  The view lists what they read of the frame;
+ * the projection of the map lines into it (LineProjection::ProjectLineWithCheck, MapLine::mTrackProj*)
+ * is the caller's, as in the point searches.  All arrays are host memory. */
+typedef struct plvs_line_frame_view {
+  int32_t n;                          /* F.Nlines                                                  */
+  const plvs_keyline* keylines_un;    /* F.mvKeyLinesUn                                            */
+  const uint8_t* descriptors;         /* F.mLineDescriptors, n x 32                                */
+  const float* u_right_start;         /* F.mvuRightLineStart / End (< 0: none); NULL = empty       */
+  const float* u_right_end;
+  float bf;                           /* F.mbf                                                     */
+  int32_t n_levels;                   /* entries of the two tables below                           */
+  const float* line_scale_factors;    /* F.mvLineScaleFactors                                      */
+  const float* line_inv_level_sigma2; /* F.mvLineInvLevelSigma2                                    */
+  float max_diag;                     /* Frame::mnMaxDiag (the (theta, d) grid spans [-diag, diag]) */
+} plvs_line_frame_view;
+/* LineMatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, bLargerSearch, bMono)
+ * (src/LineMatcher.cc:837-1230), called by Tracking::TrackWithMotionModel (src/Tracking.cc:3653).
+ * Per last-frame line i: valid[i] = mvpMapLines[i] && !mvbLineOutlier[i] && ProjectLineWithCheck
+ * succeeded; proj[6 i ..] = uS, vS, uE, vE, invSz, invEz of the projection; octave[i] / angle[i] of
+ * LastFrame.mvKeyLinesUn[i]; desc = pML->GetDescriptor() (n_last x 32); has_obs[i] =
+ * pML->Observations() > 0 (NULL = all).  occupied[i2] != 0: current line i2 already holds a map line
+ * with observations (NULL = none).  direction: 0, 1 = bForward, 2 = bBackward (:860-861).
+ * assigned[i2] (out, F->n entries) = last-frame line whose map line goes to current line i2, or -1;
+ * *nmatches = the reference's return value. */
+int plvs_hip_lines_search_by_projection_ff(const plvs_line_frame_view* F, const uint8_t* occupied, int n_last,
+                                           const uint8_t* valid, const float* proj, const int32_t* octave,
+                                           const float* angle, const uint8_t* desc, const uint8_t* has_obs,
+                                           int larger_search, int direction, float nn_ratio, int check_orientation,
+                                           int32_t* assigned, int* nmatches);
+/* LineMatcher::SearchByProjection(Frame& F, const std::vector<MapLinePtr>&, bLargerSearch)
+ * (src/LineMatcher.cc:1286-1560, left image), called by Tracking::SearchLocalLines (:4576).  Per map
+ * line m: in_view[m] = mbTrackInView && !isBad(); proj[6 m ..] = mTrackProjStartX, StartY, EndX, EndY,
+ * 1 / mTrackStartDepth, 1 / mTrackEndDepth; level[m] = mnTrackScaleLevel. */
+int plvs_hip_lines_search_by_projection(const plvs_line_frame_view* F, const uint8_t* occupied, int n_map,
+                                        const uint8_t* in_view, const float* proj, const int32_t* level,
+                                        const uint8_t* desc, const uint8_t* has_obs, int larger_search,
+                                        float nn_ratio, int32_t* assigned, int* nmatches);
+
 /* ------------------------------------------------------------ Frame extraction
  * Points and lines of one image, extracted concurrently on two host threads
  * (each extractor drives its own stream), as Frame::Frame does with threadLeft /

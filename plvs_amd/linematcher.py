@@ -19,8 +19,65 @@ def _f32(a):
     return np.ascontiguousarray(a, np.float32)
 
 
+class LineFrameView(ctypes.Structure):
+    """plvs_line_frame_view (include/plvs_hip.h): what the guided line searches read of a Frame."""
+    _fields_ = [("n", ctypes.c_int32), ("keylines_un", _vp), ("descriptors", _vp), ("u_right_start", _vp),
+                ("u_right_end", _vp), ("bf", _f), ("n_levels", ctypes.c_int32), ("line_scale_factors", _vp),
+                ("line_inv_level_sigma2", _vp), ("max_diag", _f)]
+
+
+def line_frame_view(keylines_un, descriptors, scale_factors, inv_level_sigma2, max_diag, u_right_start=None,
+                    u_right_end=None, bf=0.0):
+    """-> (view, keep-alive tuple).  keylines_un: structured array with the KeyLine layout (68 bytes)."""
+    kl = np.ascontiguousarray(keylines_un)
+    assert kl.dtype.itemsize == 68
+    d = _u8(descriptors).reshape(-1, 32)
+    sf, s2 = _f32(scale_factors), _f32(inv_level_sigma2)
+    us = None if u_right_start is None else _f32(u_right_start)
+    ue = None if u_right_end is None else _f32(u_right_end)
+    v = LineFrameView(kl.shape[0], _lib.np_ptr(kl), _lib.np_ptr(d), _lib.np_ptr(us), _lib.np_ptr(ue), float(bf),
+                      sf.shape[0], _lib.np_ptr(sf), _lib.np_ptr(s2), float(max_diag))
+    return v, (kl, d, sf, s2, us, ue)
+
+
 class LineMatcher:
     TH_HIGH, TH_LOW, TH_LOW_STEREO, HISTO_LENGTH = 110, 60, 50, 12     # src/LineMatcher.cc:87-90
+
+    def SearchByProjectionLastFrame(self, view, valid, proj, octave, angle, desc, occupied=None, has_obs=None,
+                                    bLargerSearch=False, direction=0):
+        """SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, bLargerSearch, bMono),
+        src/LineMatcher.cc:837.  proj [n_last, 6] = uS, vS, uE, vE, invSz, invEz of the last frame's map lines
+        in the current frame.  -> (nmatches, assigned [Nlines]: last-frame line index or -1)."""
+        F, keep = view
+        va, pr = _u8(valid), _f32(proj).reshape(-1, 6)
+        oc, an, de = np.ascontiguousarray(octave, np.int32), _f32(angle), _u8(desc).reshape(-1, 32)
+        occ = None if occupied is None else _u8(occupied)
+        ho = None if has_obs is None else _u8(has_obs)
+        assigned = np.full(max(F.n, 1), -7, np.int32)
+        n = _i()
+        f = _lib.lib.plvs_hip_lines_search_by_projection_ff
+        f.argtypes = [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp]
+        _lib.check(f(ctypes.byref(F), _lib.np_ptr(occ), va.shape[0], _lib.np_ptr(va), _lib.np_ptr(pr), _lib.np_ptr(oc),
+                     _lib.np_ptr(an), _lib.np_ptr(de), _lib.np_ptr(ho), int(bLargerSearch), int(direction),
+                     self.mfNNratio, int(self.mbCheckOrientation), _lib.np_ptr(assigned), ctypes.byref(n)))
+        return n.value, assigned[:F.n]
+
+    def SearchByProjection(self, view, in_view, proj, level, desc, occupied=None, has_obs=None, bLargerSearch=False):
+        """SearchByProjection(Frame& F, const std::vector<MapLinePtr>&, bLargerSearch), src/LineMatcher.cc:1286.
+        -> (nmatches, assigned [Nlines]: map-line index or -1)."""
+        F, keep = view
+        iv, pr = _u8(in_view), _f32(proj).reshape(-1, 6)
+        lv, de = np.ascontiguousarray(level, np.int32), _u8(desc).reshape(-1, 32)
+        occ = None if occupied is None else _u8(occupied)
+        ho = None if has_obs is None else _u8(has_obs)
+        assigned = np.full(max(F.n, 1), -7, np.int32)
+        n = _i()
+        f = _lib.lib.plvs_hip_lines_search_by_projection
+        f.argtypes = [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp]
+        _lib.check(f(ctypes.byref(F), _lib.np_ptr(occ), iv.shape[0], _lib.np_ptr(iv), _lib.np_ptr(pr), _lib.np_ptr(lv),
+                     _lib.np_ptr(de), _lib.np_ptr(ho), int(bLargerSearch), self.mfNNratio, _lib.np_ptr(assigned),
+                     ctypes.byref(n)))
+        return n.value, assigned[:F.n]
 
     def __init__(self, nnratio=0.6, checkOri=True):
         self.mfNNratio, self.mbCheckOrientation = float(nnratio), bool(checkOri)
