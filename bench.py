@@ -450,6 +450,81 @@ def main():
             "hamming_knn2": fe,
             "note": "match = one brute-force 2000x2000 ORB k-NN + one 100x100 LBD k-NN per frame",
         }
+        # ---- every search function at the working sizes (host flavour: what PLVS's Tracking would call), beside
+        # the CPU restatement of the same call.  2000 keypoints x 1500 map points, 300 x 250 lines.
+        try:
+            from plvs_amd.linematcher import LineMatcher, line_frame_view
+            from plvs_amd.orbmatcher import ORBmatcher
+            from tests import oracle_lib
+            from tests import test_line_proj_search as tlp
+            from tests import test_line_search as tls
+            from tests import test_orb_search as tos
+            ora = oracle_lib.load()
+
+            def per_call_us(fn, reps=30):
+                fn()
+                fn()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                return round((time.perf_counter() - t0) / reps * 1e6, 1)
+
+            mt = {}
+            F, M, occ = tos.make_case(1, n=2000, m=1500)
+            om = ORBmatcher(0.8, True)
+            mt["orb_search_by_projection_mappoints"] = {
+                "hip_us": per_call_us(lambda: om.SearchByProjection(F, M, 1.0, False, 40.0, occupied=occ)),
+                "cpu_us": per_call_us(lambda: tos.oracle_search(ora.lib, F, M, 1.0, False, 40.0, 0.8, occ), 10)}
+            F2, ang, mx, my, mbf, L, occ2 = tos.make_ff_case(1, n=2000)
+            om2 = ORBmatcher(0.9, True)
+            mt["orb_search_by_projection_lastframe"] = {
+                "hip_us": per_call_us(lambda: om2.SearchByProjectionLastFrame(F2, ang, mx, my, mbf, L, 15.0, False, False,
+                                                                              occupied=occ2)),
+                "cpu_us": per_call_us(lambda: tos.oracle_search_ff(ora.lib, F2, ang, mx, my, mbf, L, 15.0, 0, 0, 1, occ2), 10)}
+            KV, kd, kv, ka, FV, fd, fa = tos.make_bow_case(1, nk=2000, nf=2000)
+            om3 = ORBmatcher(0.7, True)
+            mt["orb_search_by_bow"] = {
+                "hip_us": per_call_us(lambda: om3.SearchByBoW(KV, kd, kv, ka, FV, fd, fa)),
+                "cpu_us": per_call_us(lambda: tos.oracle_search_bow(ora.lib, KV, kd, kv, ka, FV, fd, fa, 0.7, 1), 10)}
+            lc = tls.make_case(1, n_last=250, n_cur=300)
+            lm = LineMatcher(0.8, True)
+            mt["lines_search_by_knn_keyframe"] = {
+                "hip_us": per_call_us(lambda: lm.SearchByKnn(lc[0], lc[1], lc[2], lc[3], lc[4])),
+                "cpu_us": per_call_us(lambda: tls.run(tls.oracle_fn(ora), lc, 0.8, True), 10)}
+            pc = tlp.make_case(1, n_cur=300, n_last=250)
+            view = line_frame_view(pc["kl"], pc["desc"], tlp.SCALE, tlp.INV_SIGMA2, tlp.MAX_DIAG)
+            mt["lines_search_by_projection_lastframe"] = {
+                "hip_us": per_call_us(lambda: lm.SearchByProjectionLastFrame(view, pc["valid"], pc["proj"], pc["octave"],
+                                                                              pc["angle"], pc["ldesc"],
+                                                                              occupied=pc["occupied"], has_obs=pc["has_obs"])),
+                "cpu_us": per_call_us(lambda: tlp.oracle_ff(ora, pc, False, 0, 0.8, True), 10)}
+            mt["lines_search_by_projection_maplines"] = {
+                "hip_us": per_call_us(lambda: lm.SearchByProjection(view, pc["valid"], pc["proj"], pc["octave"], pc["ldesc"],
+                                                                    occupied=pc["occupied"], has_obs=pc["has_obs"])),
+                "cpu_us": per_call_us(lambda: tlp.oracle_map(ora, pc, False, 0.8), 10)}
+            mt["note"] = ("host flavours (inputs in host memory, one staged copy in and out per call) on synthetic frames of "
+                          "the working size; cpu_us = oracle/*.c (the reference's loop, one core), both through ctypes")
+            result["frontend"]["search_functions"] = mt
+            # ---- CPU baseline of the extraction: the reference's two threads (src/Frame.cc:503-508)
+            import threading
+            host_frames = [f.cpu().numpy() for f in frames]
+            o_orb, o_lines = ora.orb(2000, 1.2, 8, 20, 7), ora.lines()
+            t0 = time.perf_counter()
+            ncpu = 6
+            for i in range(ncpu):
+                img = host_frames[i % 3]
+                th_ = [threading.Thread(target=o_orb.extract, args=(img,)), threading.Thread(target=o_lines.extract, args=(img,))]
+                for t_ in th_:
+                    t_.start()
+                for t_ in th_:
+                    t_.join()
+            cpu_ms = (time.perf_counter() - t0) / ncpu * 1e3
+            result["frontend"]["cpu_baseline"] = {
+                "value": round(1e3 / cpu_ms, 2), "unit": "frames/s", "ms_per_frame": round(cpu_ms, 2), "cores": 2,
+                "kind": "port", "sample": f"oracle/orb.cpp || oracle/lines.cpp on two threads, {ncpu} frames (extraction "
+                                          f"only), host has {os.cpu_count()} cores"}
+        except Exception as e:      # the timing harness must not take the benchmark line down
+            result["frontend"]["search_functions"] = {"error": repr(e)}
         # configs[4] (KITTI stereo): dense disparity by semi-global matching on a 1240x376 pair resident in HBM
         from plvs_amd.sgm import StereoSGM
         sl = torch.from_numpy(np.ascontiguousarray(golden("urban1_1241x376.pgm")[:, :1240])).cuda()

@@ -41,6 +41,9 @@ int plvs_hip_device_count(int* count);
 int plvs_hip_set_device(int device);
 /* hipDeviceSynchronize on the current device. */
 int plvs_hip_synchronize(void);
+/* Frees the calling thread's staging buffers (pinned host + device block + stream) that the host
+ * flavours of the small matcher calls keep between calls. */
+int plvs_hip_release_thread_buffers(void);
 
 /* Thin device-memory helpers so that a host (C++/cgo/ctypes) caller can keep
  * inputs resident without linking HIP itself. */

@@ -72,6 +72,21 @@ struct DevBuf {
   }
 };
 
+// Per-thread staging for the host flavours of small calls (k-NN / candidate distances of a few hundred
+// descriptors): one pinned host block, one device block and a stream, kept between calls — a call is
+// one host-to-device copy, the kernel, one device-to-host copy and one stream wait instead of a
+// hipMalloc / hipFree / blocking pageable copy per array.  Released by plvs_hip_release_thread_buffers()
+// (or never: a thread that exits leaves a few hundred KB behind).
+struct HostStage {
+  char* pinned = nullptr;
+  char* dev = nullptr;
+  size_t cap = 0;
+  hipStream_t stream = nullptr;
+  hipError_t reserve(size_t bytes);
+  void release();
+};
+HostStage& thread_stage();
+
 static inline unsigned ceil_div(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 // Integer tuning knob from the environment (host thread counts), clamped to [lo, hi].

@@ -153,43 +153,27 @@ int plvs_hip_hamming_knn2(const uint8_t* query, int nq, const uint8_t* train, in
     return PLVS_ERR_EMPTY;
   }
   PLVS_REQUIRE(query && train && idx && dist, "null descriptor or output pointer");
-  uint8_t *dq = nullptr, *dt = nullptr, *dm = nullptr;
-  int32_t *di = nullptr, *dd = nullptr;
-  int rc = PLVS_OK;
-  auto cleanup = [&]() {
-    (void)hipFree(dq);
-    (void)hipFree(dt);
-    (void)hipFree(dm);
-    (void)hipFree(di);
-    (void)hipFree(dd);
-  };
-#define TRY_OR_CLEAN(call)                                                  \
-  do {                                                                      \
-    hipError_t _e = (call);                                                 \
-    if (_e != hipSuccess) {                                                 \
-      plvs::set_error("%s failed: %s", #call, hipGetErrorString(_e));      \
-      cleanup();                                                            \
-      return PLVS_ERR_HIP;                                                  \
-    }                                                                       \
-  } while (0)
-  TRY_OR_CLEAN(hipMalloc((void**)&dq, (size_t)nq * 32));
-  TRY_OR_CLEAN(hipMalloc((void**)&dt, (size_t)nt * 32));
-  TRY_OR_CLEAN(hipMalloc((void**)&di, (size_t)nq * 2 * sizeof(int32_t)));
-  TRY_OR_CLEAN(hipMalloc((void**)&dd, (size_t)nq * 2 * sizeof(int32_t)));
-  TRY_OR_CLEAN(hipMemcpy(dq, query, (size_t)nq * 32, hipMemcpyHostToDevice));
-  TRY_OR_CLEAN(hipMemcpy(dt, train, (size_t)nt * 32, hipMemcpyHostToDevice));
-  if (qmask) {
-    TRY_OR_CLEAN(hipMalloc((void**)&dm, (size_t)nq));
-    TRY_OR_CLEAN(hipMemcpy(dm, qmask, (size_t)nq, hipMemcpyHostToDevice));
-  }
-  rc = plvs_hip_hamming_knn2_dev(dq, nq, dt, nt, dm, tie_rule, di, dd, nullptr);
-  if (rc == PLVS_OK) {
-    TRY_OR_CLEAN(hipMemcpy(idx, di, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
-    TRY_OR_CLEAN(hipMemcpy(dist, dd, (size_t)nq * 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
-  }
-#undef TRY_OR_CLEAN
-  cleanup();
-  return rc;
+  // one staged block: [query | train | mask] in, [idx | dist] out (16-byte aligned pieces)
+  auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t o_q = 0, o_t = o_q + up16((size_t)nq * 32), o_m = o_t + up16((size_t)nt * 32),
+               o_i = o_m + up16(qmask ? (size_t)nq : 0), o_d = o_i + up16((size_t)nq * 2 * sizeof(int32_t)),
+               total = o_d + up16((size_t)nq * 2 * sizeof(int32_t));
+  plvs::HostStage& st = plvs::thread_stage();
+  PLVS_HIP_TRY(st.reserve(total));
+  memcpy(st.pinned + o_q, query, (size_t)nq * 32);
+  memcpy(st.pinned + o_t, train, (size_t)nt * 32);
+  if (qmask) memcpy(st.pinned + o_m, qmask, (size_t)nq);
+  PLVS_HIP_TRY(hipMemcpyAsync(st.dev, st.pinned, o_i, hipMemcpyHostToDevice, st.stream));
+  const int rc = plvs_hip_hamming_knn2_dev(reinterpret_cast<uint8_t*>(st.dev + o_q), nq, reinterpret_cast<uint8_t*>(st.dev + o_t),
+                                           nt, qmask ? reinterpret_cast<uint8_t*>(st.dev + o_m) : nullptr, tie_rule,
+                                           reinterpret_cast<int32_t*>(st.dev + o_i), reinterpret_cast<int32_t*>(st.dev + o_d),
+                                           st.stream);
+  if (rc != PLVS_OK) return rc;
+  PLVS_HIP_TRY(hipMemcpyAsync(st.pinned + o_i, st.dev + o_i, total - o_i, hipMemcpyDeviceToHost, st.stream));
+  PLVS_HIP_TRY(hipStreamSynchronize(st.stream));
+  memcpy(idx, st.pinned + o_i, (size_t)nq * 2 * sizeof(int32_t));
+  memcpy(dist, st.pinned + o_d, (size_t)nq * 2 * sizeof(int32_t));
+  return PLVS_OK;
 }
 
 }  // extern "C"

@@ -105,29 +105,26 @@ int plvs_hip_hamming_pairs(const uint8_t* query, int nq, const uint8_t* train, i
   PLVS_REQUIRE(query && train && pair_q && pair_t && dist, "null argument");
   for (int p = 0; p < npairs; ++p)
     PLVS_REQUIRE(pair_q[p] >= 0 && pair_q[p] < nq && pair_t[p] >= 0 && pair_t[p] < nt, "pair index out of range");
-  plvs::DevBuf<uint8_t> dq, dt;
-  plvs::DevBuf<int32_t> dpq, dpt, dd;
-  hipError_t e = hipSuccess;
-  auto fail = [&](hipError_t err, const char* what) {
-    plvs::set_error("%s failed: %s", what, hipGetErrorString(err));
-    dq.release(); dt.release(); dpq.release(); dpt.release(); dd.release();
-    return PLVS_ERR_HIP;
-  };
-  if ((e = dq.reserve((size_t)nq * 32)) != hipSuccess) return fail(e, "hipMalloc");
-  if ((e = dt.reserve((size_t)nt * 32)) != hipSuccess) return fail(e, "hipMalloc");
-  if ((e = dpq.reserve(npairs)) != hipSuccess) return fail(e, "hipMalloc");
-  if ((e = dpt.reserve(npairs)) != hipSuccess) return fail(e, "hipMalloc");
-  if ((e = dd.reserve(npairs)) != hipSuccess) return fail(e, "hipMalloc");
-  if ((e = hipMemcpy(dq.p, query, (size_t)nq * 32, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
-  if ((e = hipMemcpy(dt.p, train, (size_t)nt * 32, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
-  if ((e = hipMemcpy(dpq.p, pair_q, sizeof(int32_t) * npairs, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
-  if ((e = hipMemcpy(dpt.p, pair_t, sizeof(int32_t) * npairs, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
-  hipLaunchKernelGGL(hamming_pairs_kernel, dim3(plvs::ceil_div(npairs, 256)), dim3(256), 0, nullptr,
-                     reinterpret_cast<const uint4*>(dq.p), reinterpret_cast<const uint4*>(dt.p), dpq.p, dpt.p,
-                     npairs, dd.p);
-  if ((e = hipGetLastError()) != hipSuccess) return fail(e, "hamming_pairs_kernel");
-  if ((e = hipMemcpy(dist, dd.p, sizeof(int32_t) * npairs, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "hipMemcpy");
-  dq.release(); dt.release(); dpq.release(); dpt.release(); dd.release();
+  // one staged block: [query | train | pair_q | pair_t] in, [dist] out
+  auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t o_q = 0, o_t = o_q + up16((size_t)nq * 32), o_pq = o_t + up16((size_t)nt * 32),
+               o_pt = o_pq + up16(sizeof(int32_t) * (size_t)npairs), o_d = o_pt + up16(sizeof(int32_t) * (size_t)npairs),
+               total = o_d + up16(sizeof(int32_t) * (size_t)npairs);
+  plvs::HostStage& st = plvs::thread_stage();
+  PLVS_HIP_TRY(st.reserve(total));
+  memcpy(st.pinned + o_q, query, (size_t)nq * 32);
+  memcpy(st.pinned + o_t, train, (size_t)nt * 32);
+  memcpy(st.pinned + o_pq, pair_q, sizeof(int32_t) * (size_t)npairs);
+  memcpy(st.pinned + o_pt, pair_t, sizeof(int32_t) * (size_t)npairs);
+  PLVS_HIP_TRY(hipMemcpyAsync(st.dev, st.pinned, o_d, hipMemcpyHostToDevice, st.stream));
+  hipLaunchKernelGGL(hamming_pairs_kernel, dim3(plvs::ceil_div(npairs, 256)), dim3(256), 0, st.stream,
+                     reinterpret_cast<const uint4*>(st.dev + o_q), reinterpret_cast<const uint4*>(st.dev + o_t),
+                     reinterpret_cast<const int32_t*>(st.dev + o_pq), reinterpret_cast<const int32_t*>(st.dev + o_pt), npairs,
+                     reinterpret_cast<int32_t*>(st.dev + o_d));
+  PLVS_KERNEL_CHECK();
+  PLVS_HIP_TRY(hipMemcpyAsync(st.pinned + o_d, st.dev + o_d, sizeof(int32_t) * (size_t)npairs, hipMemcpyDeviceToHost, st.stream));
+  PLVS_HIP_TRY(hipStreamSynchronize(st.stream));
+  memcpy(dist, st.pinned + o_d, sizeof(int32_t) * (size_t)npairs);
   return PLVS_OK;
 }
 

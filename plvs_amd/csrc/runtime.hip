@@ -15,9 +15,47 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+hipError_t HostStage::reserve(size_t bytes) {
+  if (stream == nullptr) {
+    hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+  }
+  if (bytes <= cap) return hipSuccess;
+  const size_t want = bytes + bytes / 2 + 4096;
+  if (pinned) (void)hipHostFree(pinned);
+  if (dev) (void)hipFree(dev);
+  pinned = dev = nullptr;
+  cap = 0;
+  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&pinned), want);
+  if (e != hipSuccess) return e;
+  e = hipMalloc(reinterpret_cast<void**>(&dev), want);
+  if (e != hipSuccess) return e;
+  cap = want;
+  return hipSuccess;
+}
+
+void HostStage::release() {
+  if (pinned) (void)hipHostFree(pinned);
+  if (dev) (void)hipFree(dev);
+  if (stream) (void)hipStreamDestroy(stream);
+  pinned = dev = nullptr;
+  stream = nullptr;
+  cap = 0;
+}
+
+HostStage& thread_stage() {
+  static thread_local HostStage stage;   // no destructor on purpose: thread exit may come after the runtime's
+  return stage;
+}
+
 }  // namespace plvs
 
 extern "C" {
+
+int plvs_hip_release_thread_buffers(void) {
+  plvs::thread_stage().release();
+  return PLVS_OK;
+}
 
 const char* plvs_hip_last_error(void) { return plvs::last_error_buf(); }
 
