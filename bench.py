@@ -80,7 +80,7 @@ def main():
 
     from plvs_amd import _lib
     from plvs_amd.synth_scene import make_keyframes
-    from plvs_amd.shard import allgather_block_lists
+    from plvs_amd.shard import BlockDirectory, allgather_block_lists
     from plvs_amd.tsdf import TsdfChisel, TsdfVoxblox
 
     # ---------------------------------------------------------------- inputs
@@ -115,6 +115,7 @@ def main():
     upd_cap = 16384          # = max_chunks: an updated-chunk list always fits
     d_upd = torch.zeros((upd_cap, 3), dtype=torch.int32, device="cuda")
     gathered_blocks = [0]
+    gdir = BlockDirectory(16384) if world > 1 else None      # every rank's copy of the global block -> owner table
 
     def step(b):
         xyz, rgb, kfid, offsets, Twc = b
@@ -125,8 +126,9 @@ def main():
         st = tsdf.last_stats()
         if world > 1:      # the path's one real exchange: updated block lists, over RCCL
             n = tsdf.updated_chunk_ids_dev(d_upd)
-            lists = allgather_block_lists(d_upd, n, upd_cap)
-            gathered_blocks[0] += sum(int(l.shape[0]) for l in lists)
+            all_ids, counts = allgather_block_lists(d_upd, n, upd_cap, padded=True)
+            gdir.merge(all_ids, counts)
+            gathered_blocks[0] += 1
         return st
 
     def barrier():
@@ -216,7 +218,8 @@ def main():
                        "keyframes_per_step": args.batch, "points_per_step": int(points // args.steps),
                        "visits_per_step": int(visits_total // args.steps),
                        "voxels_per_step": int(voxels // args.steps), "longest_voxel_run": int(max_run),
-                       "parallelism": f"chunk-hash shard x{world}"},
+                       "parallelism": f"chunk-hash shard x{world}",
+                       "global_directory_blocks": (gdir.count() if gdir is not None else None)},
             "roofline": roofline,
         }
 

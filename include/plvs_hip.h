@@ -510,6 +510,28 @@ int plvs_hip_tsdf_chisel_carve_dev(plvs_tsdf_chisel* h, const float* d_depth, in
                                    float far_dist, const float* Twc, float carving_dist, void* stream,
                                    int* carved_chunks);
 
+/* ------------------------------------------- multi-GPU: the block-list exchange
+ * The sharded TSDF path (shard_rank / shard_count of either back end; owner(block) =
+ * three-prime hash(block id) mod N, ChunkManager.h:42-54 / block_hash.h:15-26) has ONE
+ * exchange step: every rank contributes the ids of the blocks its last integrate call
+ * updated (plvs_hip_tsdf_*_updated_*_ids_dev) and receives everybody's, over RCCL / xGMI
+ * (two fixed-size ncclAllGather: counts, padded lists).  rccl_comm is the caller's
+ * ncclComm_t (one process per GPU); RCCL is resolved at run time, the library has no
+ * link-time dependency on it.  d_all_ids: [world * cap * 3], d_all_counts: [world]. */
+int plvs_hip_tsdf_exchange_block_lists(void* rccl_comm, const int32_t* d_local_ids, int local_count, int cap,
+                                       int32_t* d_all_ids, int32_t* d_all_counts, void* stream);
+int plvs_hip_rccl_world_size(void* rccl_comm, int* world);
+/* The global block directory a rank keeps from the gathered lists: block id -> owner rank
+ * (which blocks exist on which GPU: what the host needs to schedule meshing and to route
+ * queries).  merge is asynchronous on `stream`; count / list synchronise. */
+typedef struct plvs_block_directory plvs_block_directory;
+int plvs_hip_block_directory_create(int max_blocks, plvs_block_directory** out);
+int plvs_hip_block_directory_destroy(plvs_block_directory* d);
+int plvs_hip_block_directory_merge(plvs_block_directory* d, const int32_t* d_all_ids, const int32_t* d_counts, int world,
+                                   int cap, void* stream);
+int plvs_hip_block_directory_count(plvs_block_directory* d, int* n);
+int plvs_hip_block_directory_list(plvs_block_directory* d, int32_t* ids_xyz, int32_t* owners, int cap, int* n);
+
 /* ------------------------------------------------- sparse stereo matching (M5)
  * Replaces Frame::ComputeStereoMatches src/Frame.cc:1780-1975 (caller: the
  * stereo Frame constructor, after the two ExtractORB threads joined).  The two

@@ -1,0 +1,208 @@
+// The one exchange step of the sharded TSDF path, behind the C ABI (BASELINE north star: "RCCL all-gather
+// of updated block lists over xGMI"): every rank contributes the ids of the blocks its
+// last integrate call updated, every rank receives all lists and folds them into its copy of the GLOBAL
+// block directory (block id -> owner rank) — what a C++ PLVS host needs to know which blocks exist on which
+// GPU and to schedule meshing.  New design: the reference is single-process.
+//
+// RCCL is resolved at run time (the symbols of the process if RCCL is already loaded — e.g. by torch —,
+// librccl.so.1 otherwise): the library carries no link-time dependency on it.
+#include <dlfcn.h>
+
+#include "common.hpp"
+#include "tsdf_directory.hpp"
+
+namespace {
+
+using plvs::tsdf::kEmptyKey;
+using plvs::tsdf::pack_block;
+
+// the three RCCL entry points used (rccl.h: ncclResult_t = int, ncclInt32 = 2)
+using AllGatherFn = int (*)(const void*, void*, size_t, int, void*, hipStream_t);
+using CommCountFn = int (*)(void*, int*);
+using ErrStrFn = const char* (*)(int);
+struct Rccl {
+  AllGatherFn all_gather = nullptr;
+  CommCountFn comm_count = nullptr, comm_rank = nullptr;
+  ErrStrFn err = nullptr;
+};
+
+const Rccl* rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    void* h = RTLD_DEFAULT;
+    if (dlsym(h, "ncclAllGather") == nullptr) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (h == nullptr) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (h != nullptr) {
+      r.all_gather = reinterpret_cast<AllGatherFn>(dlsym(h, "ncclAllGather"));
+      r.comm_count = reinterpret_cast<CommCountFn>(dlsym(h, "ncclCommCount"));
+      r.comm_rank = reinterpret_cast<CommCountFn>(dlsym(h, "ncclCommUserRank"));
+      r.err = reinterpret_cast<ErrStrFn>(dlsym(h, "ncclGetErrorString"));
+    }
+  }
+  return (r.all_gather && r.comm_count && r.comm_rank) ? &r : nullptr;
+}
+
+// Global directory: open addressing, packed block id -> owner rank.
+__global__ void directory_merge(const int32_t* __restrict__ all_ids, const int32_t* __restrict__ counts, int world,
+                                int cap, unsigned long long* __restrict__ keys, int32_t* __restrict__ owner,
+                                uint32_t mask, uint32_t* __restrict__ nblocks, uint32_t* __restrict__ err) {
+  const int r = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= world || i >= min(counts[r], cap)) return;
+  const int32_t* id = all_ids + ((size_t)r * cap + i) * 3;
+  unsigned long long key;
+  if (!pack_block(id[0], id[1], id[2], &key)) {
+    atomicOr(err, plvs::tsdf::kErrCoordRange);
+    return;
+  }
+  uint32_t h = plvs::tsdf::dir_hash(id[0], id[1], id[2], mask);
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
+    const unsigned long long cur = atomicCAS(&keys[h], kEmptyKey, key);
+    if (cur == kEmptyKey) {
+      owner[h] = r;
+      atomicAdd(nblocks, 1u);
+      return;
+    }
+    if (cur == key) return;
+    h = (h + 1) & mask;
+  }
+  atomicOr(err, plvs::tsdf::kErrPoolFull);
+}
+
+__global__ void directory_list(const unsigned long long* __restrict__ keys, const int32_t* __restrict__ owner, uint32_t capacity,
+                               int32_t* __restrict__ ids, int32_t* __restrict__ owners, int cap_out,
+                               uint32_t* __restrict__ n) {
+  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= capacity || keys[h] == kEmptyKey) return;
+  const uint32_t at = atomicAdd(n, 1u);
+  if ((int)at >= cap_out) return;
+  const unsigned long long k = keys[h];
+  ids[3 * at + 0] = (int)((k >> 42) & 0x1FFFFFu) - plvs::tsdf::kCoordBias;
+  ids[3 * at + 1] = (int)((k >> 21) & 0x1FFFFFu) - plvs::tsdf::kCoordBias;
+  ids[3 * at + 2] = (int)(k & 0x1FFFFFu) - plvs::tsdf::kCoordBias;
+  owners[at] = owner[h];
+}
+
+}  // namespace
+
+struct plvs_block_directory {
+  unsigned long long* keys = nullptr;
+  int32_t* owner = nullptr;
+  uint32_t* ctr = nullptr;   // [0] blocks, [1] error bits, [2] list cursor
+  uint32_t mask = 0;
+};
+
+extern "C" {
+
+int plvs_hip_block_directory_create(int max_blocks, plvs_block_directory** out) {
+  PLVS_REQUIRE(out && max_blocks > 0 && max_blocks <= (1 << 24), "bad arguments");
+  plvs_block_directory* d = new plvs_block_directory();
+  uint32_t cap = 1024;
+  while (cap < 2u * (uint32_t)max_blocks) cap <<= 1;
+  d->mask = cap - 1;
+  if (hipMalloc((void**)&d->keys, (size_t)cap * 8) != hipSuccess || hipMalloc((void**)&d->owner, (size_t)cap * 4) != hipSuccess ||
+      hipMalloc((void**)&d->ctr, 3 * sizeof(uint32_t)) != hipSuccess) {
+    plvs::set_error("block directory: out of device memory");
+    (void)hipFree(d->keys); (void)hipFree(d->owner); (void)hipFree(d->ctr);
+    delete d;
+    return PLVS_ERR_HIP;
+  }
+  PLVS_HIP_TRY(hipMemset(d->keys, 0xFF, (size_t)cap * 8));
+  PLVS_HIP_TRY(hipMemset(d->ctr, 0, 3 * sizeof(uint32_t)));
+  *out = d;
+  return PLVS_OK;
+}
+
+int plvs_hip_block_directory_destroy(plvs_block_directory* d) {
+  if (!d) return PLVS_OK;
+  (void)hipFree(d->keys); (void)hipFree(d->owner); (void)hipFree(d->ctr);
+  delete d;
+  return PLVS_OK;
+}
+
+int plvs_hip_block_directory_merge(plvs_block_directory* d, const int32_t* d_all_ids, const int32_t* d_counts, int world,
+                                   int cap, void* stream) {
+  PLVS_REQUIRE(d && d_all_ids && d_counts && world > 0 && cap > 0, "bad arguments");
+  hipLaunchKernelGGL(directory_merge, dim3(plvs::ceil_div((size_t)cap, 256), (unsigned)world), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), d_all_ids, d_counts, world, cap, d->keys, d->owner, d->mask, d->ctr,
+                     d->ctr + 1);
+  PLVS_KERNEL_CHECK();
+  return PLVS_OK;
+}
+
+int plvs_hip_block_directory_count(plvs_block_directory* d, int* n) {
+  PLVS_REQUIRE(d && n, "null argument");
+  uint32_t c[2] = {0, 0};
+  PLVS_HIP_TRY(hipMemcpy(c, d->ctr, sizeof(c), hipMemcpyDeviceToHost));
+  if (c[1]) {
+    plvs::set_error("block directory: %s", (c[1] & plvs::tsdf::kErrPoolFull) ? "full" : "block id out of range");
+    return PLVS_ERR_CAPACITY;
+  }
+  *n = (int)c[0];
+  return PLVS_OK;
+}
+
+int plvs_hip_block_directory_list(plvs_block_directory* d, int32_t* ids_xyz, int32_t* owners, int cap, int* n) {
+  PLVS_REQUIRE(d && n && cap >= 0 && (cap == 0 || (ids_xyz && owners)), "bad arguments");
+  int32_t *di = nullptr, *dow = nullptr;
+  PLVS_HIP_TRY(hipMemset(d->ctr + 2, 0, sizeof(uint32_t)));
+  PLVS_HIP_TRY(hipMalloc((void**)&di, (size_t)(cap > 0 ? cap : 1) * 3 * sizeof(int32_t)));
+  PLVS_HIP_TRY(hipMalloc((void**)&dow, (size_t)(cap > 0 ? cap : 1) * sizeof(int32_t)));
+  hipLaunchKernelGGL(directory_list, dim3(plvs::ceil_div((size_t)d->mask + 1, 256)), dim3(256), 0, nullptr, d->keys, d->owner,
+                     d->mask + 1, di, dow, cap, d->ctr + 2);
+  uint32_t got = 0;
+  hipError_t e = hipMemcpy(&got, d->ctr + 2, sizeof(uint32_t), hipMemcpyDeviceToHost);
+  const int m = (int)got < cap ? (int)got : cap;
+  if (e == hipSuccess && m > 0) e = hipMemcpy(ids_xyz, di, (size_t)m * 3 * sizeof(int32_t), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && m > 0) e = hipMemcpy(owners, dow, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost);
+  (void)hipFree(di);
+  (void)hipFree(dow);
+  PLVS_HIP_TRY(e);
+  *n = (int)got;
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_exchange_block_lists(void* rccl_comm, const int32_t* d_local_ids, int local_count, int cap,
+                                       int32_t* d_all_ids, int32_t* d_all_counts, void* stream) {
+  PLVS_REQUIRE(rccl_comm && d_local_ids && d_all_ids && d_all_counts && cap > 0, "bad arguments");
+  PLVS_REQUIRE(local_count >= 0 && local_count <= cap, "the local list does not fit the per-rank capacity");
+  const Rccl* r = rccl();
+  if (r == nullptr) {
+    plvs::set_error("RCCL is not available in this process (ncclAllGather / librccl.so.1 not found)");
+    return PLVS_ERR_NO_DEVICE;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // two fixed-size collectives: the counts, then the padded lists (a few KB per rank: latency-bound on xGMI)
+  int rank = 0;
+  if (r->comm_rank(rccl_comm, &rank) != 0) {
+    plvs::set_error("ncclCommUserRank failed");
+    return PLVS_ERR_HIP;
+  }
+  const int32_t count = local_count;   // in place: this rank's slot of the gathered counts
+  PLVS_HIP_TRY(hipMemcpyAsync(d_all_counts + rank, &count, sizeof(int32_t), hipMemcpyHostToDevice, s));
+  int rc = r->all_gather(d_all_counts + rank, d_all_counts, 1, /*ncclInt32*/ 2, rccl_comm, s);
+  if (rc == 0) rc = r->all_gather(d_local_ids, d_all_ids, (size_t)cap * 3, /*ncclInt32*/ 2, rccl_comm, s);
+  if (rc != 0) {
+    plvs::set_error("ncclAllGather failed: %s", r->err ? r->err(rc) : "?");
+    return PLVS_ERR_HIP;
+  }
+  return PLVS_OK;
+}
+
+int plvs_hip_rccl_world_size(void* rccl_comm, int* world) {
+  PLVS_REQUIRE(rccl_comm && world, "null argument");
+  const Rccl* r = rccl();
+  if (r == nullptr) {
+    plvs::set_error("RCCL is not available in this process");
+    return PLVS_ERR_NO_DEVICE;
+  }
+  if (r->comm_count(rccl_comm, world) != 0) {
+    plvs::set_error("ncclCommCount failed");
+    return PLVS_ERR_HIP;
+  }
+  return PLVS_OK;
+}
+
+}  // extern "C"

@@ -27,7 +27,7 @@ def owner_of(ids_xyz, world_size):
     return (h % np.uint64(world_size)).astype(np.int64)
 
 
-def allgather_block_lists(local_ids, count, cap, group=None):
+def allgather_block_lists(local_ids, count, cap, group=None, padded=False):
     """All-gather variable-length block-id lists.
 
     local_ids: int32 tensor [cap, 3] (cpu for gloo, cuda for nccl) whose first
@@ -45,4 +45,39 @@ def allgather_block_lists(local_ids, count, cap, group=None):
     lists = [torch.zeros_like(local_ids) for _ in range(world)]
     dist.all_gather(cnts, cnt, group=group)
     dist.all_gather(lists, local_ids, group=group)
+    if padded:      # the layout plvs_hip_block_directory_merge reads: [world, cap, 3] ids + [world] counts
+        return torch.stack(lists).contiguous(), torch.cat(cnts).contiguous()
     return [lists[r][: int(cnts[r].item())] for r in range(world)]
+
+
+class BlockDirectory:
+    """plvs_block_directory (include/plvs_hip.h): the global block id -> owner rank table a rank keeps from the
+    gathered lists.  Imports the HIP library on first use (this module itself needs numpy + torch only)."""
+
+    def __init__(self, max_blocks):
+        import ctypes
+        from . import _lib
+        self._lib, self._ct = _lib, ctypes
+        self._h = ctypes.c_void_p()
+        _lib.lib.plvs_hip_block_directory_create.argtypes = [ctypes.c_int, ctypes.c_void_p]
+        _lib.check(_lib.lib.plvs_hip_block_directory_create(int(max_blocks), ctypes.byref(self._h)))
+
+    def merge(self, all_ids, counts):
+        ct, lib = self._ct, self._lib
+        f = lib.lib.plvs_hip_block_directory_merge
+        f.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p]
+        lib.check(f(self._h, lib.t_ptr(all_ids), lib.t_ptr(counts), all_ids.shape[0], all_ids.shape[1],
+                    lib.current_stream_ptr()))
+
+    def count(self):
+        n = self._ct.c_int()
+        f = self._lib.lib.plvs_hip_block_directory_count
+        f.argtypes = [self._ct.c_void_p, self._ct.c_void_p]
+        self._lib.check(f(self._h, self._ct.byref(n)))
+        return n.value
+
+    def close(self):
+        if self._h:
+            self._lib.lib.plvs_hip_block_directory_destroy.argtypes = [self._ct.c_void_p]
+            self._lib.lib.plvs_hip_block_directory_destroy(self._h)
+            self._h = None
