@@ -29,7 +29,9 @@
 //   6. chain       one thread per voxel folds its records sequentially in registers (the
 //                  f32 weighted mean; the truncating u8 colour mean on a second stream):
 //                  each voxel is read and written once per call.
-// Results are bit-identical to the sequential CPU loop.
+// Results are bit-identical to the sequential CPU loop.  This is the ordered mode (order_free = 0); the
+// order-free mode (sdf / weight within a stated float tolerance, kfid and colour exact) is the single-walk
+// pipeline of tsdf_walk.hpp.
 #include "common.hpp"
 #include "device_utils.hpp"
 #include "tsdf_chisel_core.hpp"
@@ -160,13 +162,8 @@ struct TileOut {
   uint32_t* dkey;       // run descriptors: voxel key,
   unsigned long long* dval;   // value array of the sort: position in rec_t | length << 32,
   uint32_t* last_pt;    // [V], sparse: at a run's position, the point of its last visit
-  // order-free mode: one partial sum per run instead of the operands of every visit
-  float2* psum;         // [V], sparse, at the run's position: (sum of w_u * u, sum of w_u), point order
-                        // (dval and last_pt as in the ordered mode; colours in recc_t for the
-                        // voxels whose colour weight is still below 254)
 };
 
-template <bool kOrderFree>
 __global__ __launch_bounds__(kTileThreads, 6) void ray_tiles(
     Params P, const float* __restrict__ xyz, const uint8_t* __restrict__ rgb, int npoints,
     const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
@@ -300,79 +297,6 @@ __global__ __launch_bounds__(kTileThreads, 6) void ray_tiles(
   __syncthreads();   // hp complete
 
   TILE_PROBE(5)
-  if constexpr (kOrderFree) {
-    // ---- phase 5 (order-free mode): one partial sum per run, summed in point order (the
-    // result is deterministic).  The colour stays exact: the reference's truncating mean only
-    // ever uses the first 254 visits of a voxel, so the colours of the visits are kept (in
-    // point order, as in the ordered mode) for the voxels whose colour weight is below 254 at
-    // the start of the call, and for those only.
-    __shared__ uint32_t saturated[kTileSlots / 32];   // per group-table entry: colour frozen
-    if (tid < kTileSlots / 32) saturated[tid] = 0;
-    uint32_t g_key[kTileItems], g_last[kTileItems];
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < kTileItems; ++m) {
-      const uint32_t g = tid + m * kTileThreads;
-      g_key[m] = 0; g_last[m] = 0;
-      if (g < ngroups) {
-        const uint32_t tag = bufA[hp[g]];
-        g_key[m] = skey[tag & 0xFFFu];
-        g_last[m] = __float_as_uint(out.vis[slot0 + (bufA[hp[g + 1] - 1] & 0xFFFu)].y);
-        if ((rgbw[g_key[m]] >> 24) >= 254u) atomicOr(&saturated[tag >> 17], 1u << ((tag >> 12) & 31u));
-      }
-    }
-    __syncthreads();
-    float v_wuu[kTileItems], v_wu[kTileItems];
-#pragma unroll
-    for (int k = 0; k < kTileItems; ++k) {
-      const uint32_t j = tid + k * kTileThreads;
-      v_wuu[k] = 0.f; v_wu[k] = 0.f;
-      if (j < n) {
-        const uint32_t tag = bufA[j];
-        const uint32_t s = tag & 0xFFFu;
-        const float2 vv = out.vis[slot0 + s];
-        const size_t p = __float_as_uint(vv.y);
-        const float tr = truncation_of(P, xyz[3 * p + 2]);
-        const float wu = P.weight / (2.0f * tr);
-        v_wuu[k] = wu * vv.x;
-        v_wu[k] = wu;
-        if (!((saturated[tag >> 17] >> ((tag >> 12) & 31u)) & 1u))
-          out.recc_t[slot0 + j] = colour_roundtrip(rgb[3 * p + 0]) | (colour_roundtrip(rgb[3 * p + 1]) << 8) |
-                                  (colour_roundtrip(rgb[3 * p + 2]) << 16);
-      }
-    }
-    __syncthreads();   // the tags (bufA) and skey are free now: they take the per-position operands
-    float* const a_wuu = reinterpret_cast<float*>(bufA);
-    float* const a_wu = reinterpret_cast<float*>(skey);
-#pragma unroll
-    for (int k = 0; k < kTileItems; ++k) {
-      const uint32_t j = tid + k * kTileThreads;
-      a_wuu[j] = v_wuu[k];
-      a_wu[j] = v_wu[k];
-    }
-    // the tile's place in the run numbering (decoupled look-back, wave 0)
-    tile_lookback(t, ngroups, ntiles, tile_state, &sh_base, &ctr->num_desc, tid);
-    __syncthreads();
-    __syncthreads();
-    const uint32_t dbase = sh_base;
-#pragma unroll
-    for (int m = 0; m < kTileItems; ++m) {
-      const uint32_t g = tid + m * kTileThreads;
-      if (g < ngroups) {
-        const uint32_t p0 = hp[g], p1 = hp[g + 1];
-        float s_wuu = 0.f, s_wu = 0.f;
-        for (uint32_t j = p0; j < p1; ++j) {
-          s_wuu += a_wuu[j];
-          s_wu += a_wu[j];
-        }
-        const uint32_t d = dbase + g;
-        out.dkey[d] = g_key[m];
-        out.dval[d] = (unsigned long long)(slot0 + p0) | ((unsigned long long)(p1 - p0) << 32);
-        out.psum[slot0 + p0] = make_float2(s_wuu, s_wu);
-        out.last_pt[slot0 + p0] = g_last[m];
-      }
-    }
-  } else {
   // ---- phase 5: operands out, in sorted order
 #pragma unroll
   for (int k = 0; k < kTileItems; ++k) {
@@ -402,74 +326,12 @@ __global__ __launch_bounds__(kTileThreads, 6) void ray_tiles(
     out.dval[d] = (unsigned long long)(slot0 + p0) | ((unsigned long long)(p1 - p0) << 32);
     out.last_pt[slot0 + p0] = __float_as_uint(out.vis[slot0 + (bufA[p1 - 1] & 0xFFFu)].y);
   }
-  }
   TILE_PROBE(6)
 }
 
-// Order-free mode, last stage.  After the stable sort the partial sums of a voxel (one per
-// run) are contiguous and in tile = point order.
-//   voxel_heads   compacts the first run of every voxel (and the updated chunks).
-//   reduce_sums   one wave per voxel adds its partial sums (lane-local, then a fixed xor
-//                 tree: deterministic) and applies them in ONE update,
-//                     sdf <- (W * sdf + sum w_u u) / (W + sum w_u),  W <- W + sum w_u
-//                 which is the reference's running weighted mean up to float rounding (the
-//                 reference rounds after every visit).  kfid is exact (last visit in point
-//                 order).
-//   fold_colours  one thread per voxel whose colour weight is below 254: the truncating u8
-//                 mean is folded visit by visit over the kept colours, exactly as the
-//                 reference does, until the weight reaches 254 (at most 254 steps in the life
-//                 of a voxel).  Runs beside reduce_sums on a second stream.
-__global__ __launch_bounds__(256) void reduce_sums(
-    const uint32_t* __restrict__ skeys, const unsigned long long* __restrict__ sval, uint32_t nd,
-    const uint32_t* __restrict__ vj0, const float2* __restrict__ psum, const uint32_t* __restrict__ last_pt,
-    const uint32_t* __restrict__ kfid, float* __restrict__ sdf, float* __restrict__ weight,
-    uint32_t* __restrict__ vkfid, Counters* __restrict__ ctr) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t nvox = ctr->num_heads;
-  const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
-  for (uint32_t v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); v < nvox; v += nwaves) {
-    const uint32_t j0 = vj0[v];
-    const uint32_t key = skeys[j0];
-    float m = 0.f, wsum = 0.f;
-    uint32_t cnt = 0, last_at = 0;
-    for (uint32_t base = j0;; base += 64) {
-      const uint32_t jj = base + lane;
-      const bool mine = jj < nd && skeys[jj] == key;
-      if (mine) {
-        const unsigned long long d = sval[jj];
-        const float2 ps = psum[(uint32_t)d];
-        m += ps.x;
-        wsum += ps.y;
-        cnt += (uint32_t)(d >> 32);
-        last_at = (uint32_t)d;
-      }
-      const unsigned long long got = __ballot(mine);
-      if (got != ~0ull) {
-        // the voxel's last run sits in the highest lane of this (partial) pass, or in lane 63 of
-        // the previous one
-        const int top = got ? 63 - __clzll((long long)got) : 63;
-        last_at = (uint32_t)__shfl((int)last_at, top);
-        break;
-      }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      m += __shfl_xor(m, off);
-      wsum += __shfl_xor(wsum, off);
-      cnt += (uint32_t)__shfl_xor((int)cnt, off);
-    }
-    if (lane == 0) {
-      const float W = weight[key], S = sdf[key];
-      const float wn = W + wsum;
-      sdf[key] = (W * S + m) / wn;
-      weight[key] = wn;
-      vkfid[key] = kfid ? kfid[last_pt[last_at]] : 0u;
-      // most visits of one voxel in the call (what the ordered mode reports as its longest chain)
-      if (cnt > ctr->max_run) atomicMax(&ctr->max_run, cnt);
-    }
-  }
-}
-
+// The truncating u8 colour mean of the ordered mode: one thread per voxel whose colour weight is below
+// 254 folds its visits one by one through the sorted runs, exactly as the reference does, until the
+// weight reaches 254 (at most 254 steps in the life of a voxel).
 __global__ __launch_bounds__(256) void fold_colours(
     const uint32_t* __restrict__ skeys, const unsigned long long* __restrict__ sval, uint32_t nd,
     const uint32_t* __restrict__ vj0, const uint32_t* __restrict__ recc_t, uint32_t* __restrict__ rgbw,
@@ -870,7 +732,6 @@ struct plvs_tsdf_chisel {
   DevBuf<uint32_t> dkey0, dkey1, run_cnt, run_dst, last_pt;   // run descriptors
   DevBuf<unsigned long long> didx0, didx1;
   DevBuf<uint32_t> tile_first, block_first;
-  DevBuf<float2> psum;   // order-free mode: partial sums per run
   DevBuf<unsigned long long> tile_state;   // [0]: ticket, [1..]: look-back state per tile
   DevBuf<Pose> poses;
   void* ext = nullptr;                 // see ChiselMapView::ext
@@ -1185,7 +1046,6 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   h->dkey0.release(); h->dkey1.release(); h->didx0.release(); h->didx1.release();
   h->last_pt.release(); h->run_cnt.release(); h->run_dst.release();
   h->tile_first.release(); h->block_first.release(); h->tile_state.release();
-  h->psum.release();
   h->heads.release(); h->updated.release(); h->scratch.release(); h->poses.release();
   h->offsets.release(); h->st_xyz.release(); h->st_Twc.release(); h->st_rgb.release();
   h->st_kfid.release();
@@ -1280,25 +1140,16 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   }
 
   const uint32_t ntiles = ceil_div(V, kTileSlots);
-  const bool order_free = h->prm.order_free != 0;
   PLVS_HIP_TRY(h->dkey0.reserve(V));
   PLVS_HIP_TRY(h->tile_first.reserve(ntiles));
   PLVS_HIP_TRY(h->tile_state.reserve((size_t)ntiles + 1));
   PLVS_HIP_TRY(h->updated.reserve((size_t)h->num_chunks + 1));
-  if (order_free) {
-    PLVS_HIP_TRY(h->psum.reserve(V));
-    PLVS_HIP_TRY(h->rec_t.reserve(V));    // order-free mode: the per-visit (u, point) array of the tile pass
-    PLVS_HIP_TRY(h->recc_t.reserve(V));
-    PLVS_HIP_TRY(h->didx0.reserve(V));
-    PLVS_HIP_TRY(h->last_pt.reserve(V));
-  } else {
-    PLVS_HIP_TRY(h->rec_t.reserve(V));
-    PLVS_HIP_TRY(h->recc_t.reserve(V));
-    PLVS_HIP_TRY(h->rec.reserve((size_t)V + 2));   // chain_runs reads record pairs
-    PLVS_HIP_TRY(h->didx0.reserve(V));
-    PLVS_HIP_TRY(h->last_pt.reserve(V));
-    PLVS_HIP_TRY(h->block_first.reserve(ceil_div(V, kGatherSpan)));
-  }
+  PLVS_HIP_TRY(h->rec_t.reserve(V));
+  PLVS_HIP_TRY(h->recc_t.reserve(V));
+  PLVS_HIP_TRY(h->rec.reserve((size_t)V + 2));   // chain_runs reads record pairs
+  PLVS_HIP_TRY(h->didx0.reserve(V));
+  PLVS_HIP_TRY(h->last_pt.reserve(V));
+  PLVS_HIP_TRY(h->block_first.reserve(ceil_div(V, kGatherSpan)));
   float ms_a[2] = {0.f, 0.f};
   if (h->profiling) {  // stages 0,1 are complete (the counter read synchronised)
     PLVS_HIP_TRY(hipEventElapsedTime(&ms_a[0], h->ev[0], h->ev[1]));
@@ -1309,19 +1160,11 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   hipLaunchKernelGGL(mark_tiles, dim3(ceil_div((size_t)n, 256)), dim3(256), 0, s, h->counts.p, n,
                      h->tile_first.p);
   {
-    // per-visit (u, point): the buffer the gather fills later (ordered) / the unused operand buffer (order-free)
-    TileOut out{order_free ? h->rec_t.p : h->rec.p, h->rec_t.p, h->recc_t.p, h->dkey0.p, h->didx0.p, h->last_pt.p,
-                h->psum.p};
-    if (order_free)
-      hipLaunchKernelGGL(ray_tiles<true>, dim3(ntiles), dim3(kTileThreads), 0, s, h->P, d_xyz, d_rgb, n,
-                         h->offsets.p, nclouds, h->poses.p, h->dir, h->d_ctr, h->counts.p, V,
-                         h->tile_first.p, ntiles, reinterpret_cast<uint32_t*>(h->tile_state.p),
-                         h->tile_state.p + 1, h->rgbw, out);
-    else
-      hipLaunchKernelGGL(ray_tiles<false>, dim3(ntiles), dim3(kTileThreads), 0, s, h->P, d_xyz, d_rgb, n,
-                         h->offsets.p, nclouds, h->poses.p, h->dir, h->d_ctr, h->counts.p, V,
-                         h->tile_first.p, ntiles, reinterpret_cast<uint32_t*>(h->tile_state.p),
-                         h->tile_state.p + 1, h->rgbw, out);
+    // per-visit (u, point): in the buffer the gather fills later
+    TileOut out{h->rec.p, h->rec_t.p, h->recc_t.p, h->dkey0.p, h->didx0.p, h->last_pt.p};
+    hipLaunchKernelGGL(ray_tiles, dim3(ntiles), dim3(kTileThreads), 0, s, h->P, d_xyz, d_rgb, n, h->offsets.p, nclouds,
+                       h->poses.p, h->dir, h->d_ctr, h->counts.p, V, h->tile_first.p, ntiles,
+                       reinterpret_cast<uint32_t*>(h->tile_state.p), h->tile_state.p + 1, h->rgbw, out);
   }
   PLVS_KERNEL_CHECK();
   STAGE_MARK(3);
@@ -1340,27 +1183,7 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   int key_bits = 12;
   while ((1ll << (key_bits - 12)) < (long long)h->num_chunks) ++key_bits;
   bool second = false;
-  if (order_free) {
-    PLVS_HIP_TRY(h->didx1.reserve(D));
-    STAGE_MARK(3);
-    PLVS_HIP_TRY(radix_sort_pairs_u64(h->dkey0.p, h->didx0.p, h->dkey1.p, h->didx1.p, D, 0, key_bits,
-                                      h->scratch.p, s, &second));
-    STAGE_MARK(4);
-    const uint32_t* skeys = second ? h->dkey1.p : h->dkey0.p;
-    const unsigned long long* sval = second ? h->didx1.p : h->didx0.p;
-    PLVS_HIP_TRY(h->heads.reserve(D));
-    hipLaunchKernelGGL(voxel_heads, dim3(ceil_div(D, 256 * kHeadTiles)), dim3(256), 0, s, skeys, D, h->heads.p,
-                       h->updated.p, h->d_ctr);
-    // (the two kernels are NOT overlapped on two streams: measured, they slow each other down by
-    // more than the shorter one takes)
-    hipLaunchKernelGGL(reduce_sums, dim3(std::min<size_t>(ceil_div(D, 4), 8192)), dim3(256), 0, s, skeys, sval,
-                       D, h->heads.p, h->psum.p, h->last_pt.p, d_kfid, h->sdf, h->weight, h->kfid, h->d_ctr);
-    hipLaunchKernelGGL(fold_colours, dim3(std::min<size_t>(ceil_div(D, 256), 1024)), dim3(256), 0, s,
-                       skeys, sval, D, h->heads.p, h->recc_t.p, h->rgbw, h->d_ctr);
-    PLVS_KERNEL_CHECK();
-    STAGE_MARK(5);
-    STAGE_MARK(6);
-  } else {
+  {
     PLVS_HIP_TRY(h->didx1.reserve(D));
     PLVS_HIP_TRY(h->run_cnt.reserve(D));
     PLVS_HIP_TRY(h->run_dst.reserve(D));

@@ -1,35 +1,34 @@
-// The single-walk integrate of the open_chisel back end (included by tsdf_chisel.hip).
+// The single-walk integrate of the open_chisel back end: the order-free mode
+// (plvs_tsdf_chisel_params.order_free = 1; included by tsdf_chisel.hip).
 //
-// One workgroup = one tile of kWalkRays consecutive points.  Every thread walks the
-// Amanatides-Woo ray of its point ONCE (tsdf_chisel_core.hpp: the reference's arithmetic, bit for
-// bit) and the visits of the tile meet in an LDS hash table keyed by the voxel coordinates:
+// One workgroup = one tile of kWalkRays consecutive points.  Every thread walks the Amanatides-Woo ray
+// of its point ONCE (tsdf_chisel_core.hpp: the reference's arithmetic, bit for bit) and the visits of the
+// tile meet in an LDS hash table keyed by the voxel coordinates:
 //
-//   walk_acc    (order-free mode)  an entry accumulates sum(w_u * u), sum(w_u), the visit count and
-//               the last visiting ray of its voxel — in FIXED POINT, so the sums do not depend on
-//               the order in which the lanes arrive (deterministic, order-free).  At the end of the
-//               tile the entries are resolved to pool slots (first-touch chunks are inserted here),
-//               grouped by chunk and written as 16-byte records into (tile, chunk) segments.
-//               No global memory is touched inside the ray loop.
-//   seg_scan / seg_scatter        counting sort of the segment descriptors by chunk.
+//   walk_tiles  an entry accumulates sum(w_u * u), sum(w_u), the visit count and the last visiting ray of
+//               its voxel — in FIXED POINT, so the sums do not depend on the order in which the lanes
+//               arrive (deterministic, order-free).  No global memory is touched inside the ray loop.
+//               At the end of the tile the entries are resolved to pool slots (first-touch chunks are
+//               inserted here), grouped by (chunk, slab) and written as 16-byte records into the tile's
+//               own record region; one segment descriptor per (tile, chunk).
+//               The u8 colour mean of the reference truncates after every visit and freezes at weight
+//               254: it stays EXACT.  Every ray logs the entries it visited (LDS); for the entries whose
+//               voxel is still below 254 the log is turned into the BIT MASK of the tile's rays that
+//               visit the voxel — a ray visits a voxel at most once, so ray order = point order = the
+//               reference's update order — and one run (voxel key + mask) leaves the tile.
+//   seg_pass / seg_scan           counting sort of the segment descriptors by chunk (LDS-aggregated).
 //   apply_chunks                  "LDS-staged blocks": a workgroup owns a slab of one chunk, adds the
-//               chunk's records into 64-bit LDS accumulators and applies ONE update per voxel,
+//               slab's records into 64-bit LDS accumulators and applies ONE update per voxel,
 //                   sdf <- (W * sdf + sum w_u u) / (W + sum w_u),   W <- W + sum w_u,
 //               kfid <- kfid of the last visiting point.
+//   compact_runs, stable radix sort by voxel key, voxel_heads, fold_colours_masks
+//               ColorVoxel::IntegrateSimple visit by visit through the sorted runs of the voxels below
+//               weight 254 (a wave per voxel; nothing once a map has saturated).
 //
-//   walk_runs   the order-preserving form: an entry keeps the BIT MASK of the tile's rays that visit
-//               its voxel (a ray visits a voxel at most once, so ray order = point order = the
-//               reference's update order).  One run descriptor + 32-byte mask per (tile, voxel)
-//               leaves the tile, numbered across tiles by a decoupled look-back.  The ordered mode
-//               emits every voxel; the order-free mode runs it only over the tiles that met a voxel
-//               whose colour weight is still below 254 and emits only those voxels (the truncating
-//               u8 colour mean is order dependent and must stay exact).
-//   expand_runs (ordered mode)    recomputes (w_u * u, w_u) of every visit from (point, voxel) —
-//               the walk is only needed to know WHICH voxels a ray visits — straight into voxel
-//               order for chain_runs.
-//   fold_colours_masks            ColorVoxel::IntegrateSimple visit by visit through the sorted runs.
-//
-// A tile whose visits do not fit the table is cut in halves (ray ranges), a single ray that does
-// not fit is cut into windows of visits; both are rare and only cost a re-walk.
+// A tile whose visits do not fit the table is cut in halves (ray ranges), a single ray that does not fit
+// is cut into windows of visits; both are rare and only cost a re-walk.  Nothing in the pipeline queues
+// on one global counter: a returning device-scope atomic on one word costs ~11 ns, and 15 000 tiles
+// taking a ticket, a record range and a run range each used to cost more than the walk itself.
 #pragma once
 #include <hip/hip_runtime.h>
 
