@@ -386,6 +386,9 @@ int plvs_hip_frame_extract_dev(plvs_orb* orb, plvs_lines* lines, const uint8_t* 
  * 1.m * 2^exponent for which the kernel's reciprocal (v_rcp_f32 + one Newton step) differs
  * from the correctly rounded 1/b.  Expected: 0 for every exponent the kernel admits. */
 int plvs_hip_selftest_rcp(int exponent, uint32_t* mismatches);
+/* The walk's square root and quotient (normal-range forms without the compiler's range scaffolding) against
+ * sqrtf and `/` on the device, 2.7e8 pseudo-random operand pairs per call: mismatches[0] sqrt, [1] division. */
+int plvs_hip_selftest_walk_math(uint32_t seed, uint32_t* mismatches_sqrt_div);
 
 /* --------------------------------------------------------- TSDF (open_chisel)
  * Chunked (16^3) spatially hashed TSDF with per-point ray integration.

@@ -937,6 +937,18 @@ int plvs_hip_selftest_rcp(int exponent, uint32_t* mismatches) {
   return PLVS_OK;
 }
 
+int plvs_hip_selftest_walk_math(uint32_t seed, uint32_t* mismatches_sqrt_div) {
+  PLVS_REQUIRE(mismatches_sqrt_div, "null argument");
+  uint32_t* d = nullptr;
+  PLVS_HIP_TRY(hipMalloc((void**)&d, 2 * sizeof(uint32_t)));
+  PLVS_HIP_TRY(hipMemset(d, 0, 2 * sizeof(uint32_t)));
+  hipLaunchKernelGGL(selftest_walk_math_kernel, dim3(16384), dim3(256), 0, nullptr, seed, d);
+  hipError_t e = hipMemcpy(mismatches_sqrt_div, d, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  PLVS_HIP_TRY(e);
+  return PLVS_OK;
+}
+
 int plvs_hip_tsdf_chisel_default_params(float resolution, plvs_tsdf_chisel_params* p) {
   PLVS_REQUIRE(p, "params is null");
   PLVS_REQUIRE(resolution > 0.0f, "resolution must be positive");

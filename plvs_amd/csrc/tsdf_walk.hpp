@@ -53,7 +53,6 @@ constexpr int kWalkEntries = 1024;              // LDS hash table entries
 constexpr int kWalkLimit = kWalkEntries * 3 / 4;   // entries a (sub-)tile may use
 constexpr int kWalkWindow = kWalkLimit / 2;     // visits per window of a single over-long ray
 constexpr int kWalkChunks = 64;                 // per-tile chunk cache
-constexpr unsigned long long kVoxEmpty = ~0ull;
 constexpr uint32_t kErrScratch = 8u;            // record / segment / run buffers too small: the host grows them and retries
 
 struct WalkCounters {           // device-side, read back once per call
@@ -68,22 +67,6 @@ struct WalkCounters {           // device-side, read back once per call
   uint32_t ncold;               // tiles that met a voxel with colour weight < 254
   uint32_t split_tiles;         // tiles that had to be cut (table overflow)
 };
-
-__device__ __forceinline__ unsigned long long pack_voxel(int x, int y, int z) {
-  return ((unsigned long long)(unsigned)(z + kCoordBias) << 42) | ((unsigned long long)(unsigned)(y + kCoordBias) << 21) |
-         (unsigned long long)(unsigned)(x + kCoordBias);
-}
-__device__ __forceinline__ void unpack_voxel(unsigned long long k, int* x, int* y, int* z) {
-  *x = (int)(k & 0x1FFFFFu) - kCoordBias;
-  *y = (int)((k >> 21) & 0x1FFFFFu) - kCoordBias;
-  *z = (int)((k >> 42) & 0x1FFFFFu) - kCoordBias;
-}
-__device__ __forceinline__ uint32_t voxel_hash(int x, int y, int z) {
-  // the voxels of a tile lie in a small box: x + 2^10 y + 2^20 z is unique there
-  const uint32_t k = (uint32_t)x + ((uint32_t)y << 10) + ((uint32_t)z << 20);
-  return (k * 2654435761u) >> (32 - 10);
-}
-static_assert(kWalkEntries == 1024, "voxel_hash yields 10 bits");
 
 // Find-or-insert with the slot returned; usable by concurrent workgroups of ONE kernel.  A block that
 // another thread is just inserting is waited for (its slot arrives a few instructions after its key) —
@@ -162,8 +145,18 @@ struct SubTile {          // rays [lo, hi) of the tile — all of one cloud —,
   int32_t cloud;
 };
 
+// The voxel table of a (sub-)tile: kWalkEntries 32-bit keys in buckets of four (one ds_read_b128 per probe).
+// A key = the voxel's coordinates relative to the (sub-)tile's origin, 10 bits per axis: the rays of a tile
+// — consecutive points — stay within +-512 voxels of the first ray's start (a sub-tile whose rays do not is
+// cut like one whose voxels do not fit the table; a single ray sets its origin at the first visit of its window).
+constexpr uint32_t kKeyEmpty = 0xFFFFFFFFu;
+constexpr int kBuckets = kWalkEntries / 4;
+constexpr int kOriginBias = 512;
+
 struct WalkShared {       // LDS state of walk_tiles
-  unsigned long long ekey[kWalkEntries];
+  alignas(16) uint32_t ekey[kWalkEntries];
+  int32_t org[3];                              // origin of the keys
+  uint32_t cand[kWalkRays / 64];               // first walking ray of every wave
   unsigned long long ckey[kWalkChunks];        // chunk cache: packed chunk id,
   int32_t cslot[kWalkChunks];                  //   pool slot,
   uint32_t ccnt[kWalkChunks * kSlabs];         //   entries of the (sub-)tile per (chunk, slab),
@@ -177,36 +170,97 @@ struct WalkShared {       // LDS state of walk_tiles
   uint32_t next, nrays;   // rays of the tile not yet handed out as sub-tiles / rays of the tile
 };
 
-// Entry of the voxel in the table (inserted if absent); -1 when the table is full.
-__device__ __forceinline__ int table_find_or_insert(WalkShared& S, int vx, int vy, int vz) {
-  const unsigned long long key = pack_voxel(vx, vy, vz);
-  uint32_t h = voxel_hash(vx, vy, vz);
-  for (int probe = 0; probe < kWalkEntries; ++probe) {
-    unsigned long long cur = S.ekey[h];
-    if (cur == key) return (int)h;
-    if (cur == kVoxEmpty) {
+// Key of a voxel relative to the origin; false if it lies outside the 1024^3 box of the keys.
+__device__ __forceinline__ bool rel_key(int vx, int vy, int vz, int ox, int oy, int oz, uint32_t* key) {
+  const uint32_t dx = (uint32_t)(vx - ox), dy = (uint32_t)(vy - oy), dz = (uint32_t)(vz - oz);
+  *key = dx | (dy << 10) | (dz << 20);
+  return ((dx | dy | dz) >> 10) == 0u;
+}
+__device__ __forceinline__ uint32_t key_bucket(uint32_t key) { return (key * 2654435761u) >> 24; }
+static_assert(kBuckets == 256, "key_bucket yields 8 bits");
+
+// position of `want` among the four keys of a bucket, -1 if absent
+__device__ __forceinline__ int bucket_match(const uint4 k4, uint32_t want) {
+  return k4.x == want ? 0 : (k4.y == want ? 1 : (k4.z == want ? 2 : (k4.w == want ? 3 : -1)));
+}
+
+// Entry of the key in the table (inserted if absent); -1 when the table is full.  A key lives in the first
+// bucket from its home bucket on that had a free slot when it came (entries are never removed), so a search
+// ends at the first bucket that holds the key or a free slot.
+__device__ __forceinline__ int table_find_or_insert(WalkShared& S, uint32_t key) {
+  uint32_t b = key_bucket(key);
+  for (int probe = 0; probe < 4 * kBuckets; ++probe) {
+    const uint4 k4 = *reinterpret_cast<const uint4*>(&S.ekey[4 * b]);
+    const int j = bucket_match(k4, key);
+    if (j >= 0) return (int)(4 * b) + j;
+    const int je = bucket_match(k4, kKeyEmpty);
+    if (je >= 0) {
       if (__hip_atomic_load(&S.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return -1;   // (an LDS read)
-      cur = atomicCAS(&S.ekey[h], kVoxEmpty, key);
-      if (cur == kVoxEmpty) {
+      const uint32_t old = atomicCAS(&S.ekey[4 * b + je], kKeyEmpty, key);
+      if (old == kKeyEmpty) {
         if (atomicAdd(&S.nent, 1u) >= (uint32_t)kWalkLimit) S.overflow = 1u;   // this insert still stands
-        return (int)h;
+        return (int)(4 * b) + je;
       }
-      if (cur == key) return (int)h;
+      if (old == key) return (int)(4 * b) + je;
+      continue;   // another voxel took the slot: look at this bucket again
     }
-    h = (h + 1) & (kWalkEntries - 1);
+    b = (b + 1) & (kBuckets - 1);
   }
   S.overflow = 1u;
   return -1;
 }
-// Entry of a voxel that is known to be in the table.
-__device__ __forceinline__ int table_find(const WalkShared& S, int vx, int vy, int vz) {
-  const unsigned long long key = pack_voxel(vx, vy, vz);
-  uint32_t h = voxel_hash(vx, vy, vz);
-  for (int probe = 0; probe < kWalkEntries; ++probe) {
-    if (S.ekey[h] == key) return (int)h;
-    h = (h + 1) & (kWalkEntries - 1);
+// Entry of a key that is known to be in the table.
+__device__ __forceinline__ int table_find(const WalkShared& S, uint32_t key) {
+  uint32_t b = key_bucket(key);
+  for (int probe = 0; probe < kBuckets; ++probe) {
+    const int j = bucket_match(*reinterpret_cast<const uint4*>(&S.ekey[4 * b]), key);
+    if (j >= 0) return (int)(4 * b) + j;
+    b = (b + 1) & (kBuckets - 1);
   }
   return -1;
+}
+
+// sqrtf and the IEEE quotient without the range scaffolding the compiler wraps around them (denormal scaling,
+// div_scale / div_fmas / div_fixup, class checks): 9 + 6 instructions instead of 16 + 12, for operands in the
+// normal range — squared lengths and depths of metres here.  Same results bit for bit:
+//   sqrt   v_sqrt_f32 (<= 1 ulp) corrected by the residuals at s - 1 ulp and s + 1 ulp — the core of the
+//          compiler's own correctly rounded sequence;
+//   a / b  y = RN(1 / b) (v_rcp_f32 + one Newton step: correctly rounded for every binary32 significand on
+//          gfx950, plvs_hip_selftest_rcp), q = RN(a y), r = a - q b (exact in one fma), RN(q + r y) = RN(a / b)
+//          (Markstein's correction step, as in dist_update_rcp).
+// plvs_hip_selftest_walk_math compares both against sqrtf and `/` on the device over the operand ranges of the walk.
+__device__ __forceinline__ float sqrt_rn_normal(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+  const float rm = fmaf(-sm, s, x), rp = fmaf(-sp, s, x);
+  float r = (rm <= 0.0f) ? sm : s;
+  r = (rp > 0.0f) ? sp : r;
+  return r;
+}
+__device__ __forceinline__ float div_rn_normal(float a, float b) {
+  const float y0 = __builtin_amdgcn_rcpf(b);
+  const float y = fmaf(fmaf(-b, y0, 1.0f), y0, y0);
+  const float q = a * y;
+  return fmaf(fmaf(-q, b, a), y, q);
+}
+// signed_dist (tsdf_chisel_core.hpp) with the two above; operands outside their range (a voxel centre within
+// 2^-40 m of the camera plane or centre) take the plain forms.
+__device__ __forceinline__ float signed_dist_fast(const Pose& pose, float depth, float c0, float c1, float c2) {
+  float cc[3];
+  xform(pose.Ri, pose.ti, c0, c1, c2, cc);
+  const float n2 = sqnorm3(cc[0], cc[1], cc[2]);
+  const bool plain = !(n2 >= 0x1p-80f && n2 <= 0x1p80f) || !(fabsf(cc[2]) >= 0x1p-40f && fabsf(cc[2]) <= 0x1p40f);
+  if (__builtin_expect(plain, 0)) return sqrtf(n2) * (depth / cc[2] - 1);
+  return sqrt_rn_normal(n2) * (div_rn_normal(depth, cc[2]) - 1);
+}
+__device__ __forceinline__ bool resolve_visit_fast(const Params& P, const Pose& pose, const Ray& ray, int vx, int vy, int vz,
+                                                   float* u, OwnerCache* oc) {
+  if (!chunk_owned(P, vx >> 4, vy >> 4, vz >> 4, oc)) return false;
+  const float c0 = (float)vx * P.resolution + P.half_voxel;
+  const float c1 = (float)vy * P.resolution + P.half_voxel;
+  const float c2 = (float)vz * P.resolution + P.half_voxel;
+  *u = signed_dist_fast(pose, ray.depth, c0, c1, c2);
+  return fabsf(*u) < ray.truncation;
 }
 
 // Walks the ray inside the window [vlo, vhi) of its visits; on_visit(k, vx, vy, vz, u), k = index of
@@ -222,9 +276,9 @@ __device__ __forceinline__ uint32_t walk_one(const Params& P, const Pose& pose, 
   uint32_t nv = 0;
   bool go = true;
   while (go && nv < vhi && ray_next(&cur, &vx, &vy, &vz)) {
-    Visit v;
-    const bool ok = resolve_visit(P, pose, ray, vx, vy, vz, &v, &owner);   // no early continue (see ray_count)
-    if (ok && nv >= vlo) go = on_visit(nv - vlo, vx, vy, vz, v.u);
+    float u;
+    const bool ok = resolve_visit_fast(P, pose, ray, vx, vy, vz, &u, &owner);   // no early continue (see ray_count)
+    if (ok && nv >= vlo) go = on_visit(nv - vlo, vx, vy, vz, u);
     nv += ok ? 1u : 0u;
   }
   return nv;
@@ -245,7 +299,7 @@ __device__ __forceinline__ bool tile_ray(const Params& P, const float* __restric
 
 __device__ __forceinline__ void subtile_reset(WalkShared& S, int tid) {
 #pragma unroll
-  for (int k = 0; k < kWalkEntries / kWalkRays; ++k) S.ekey[tid + k * kWalkRays] = kVoxEmpty;
+  for (int k = 0; k < kWalkEntries / kWalkRays; ++k) S.ekey[tid + k * kWalkRays] = kKeyEmpty;
   if (tid < kWalkChunks) {
     S.ckey[tid] = kEmptyKey;
     S.cslot[tid] = -1;
@@ -331,7 +385,7 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
   constexpr int kPer = kWalkEntries / kWalkRays;
   __shared__ WalkShared S;
   __shared__ uint32_t raw[kMaskCap * kMaskWords];              // accumulators during the walk, ray masks afterwards
-  __shared__ uint32_t vlog[kLogLen / 2 * kWalkRays];   // entries of visits 2k, 2k+1 of ray r at [k * kWalkRays + r] (lo, hi)
+  __shared__ uint16_t vlog[kLogLen * kWalkRays];        // entry of visit k of ray r at [k * kWalkRays + r]
   __shared__ uint16_t e_midx[kWalkEntries];           // mask index of the entry (0xFFFF: none)
   int32_t* const e_wuu = reinterpret_cast<int32_t*>(raw);                                 // sum of w_u * u, fixed point
   unsigned long long* const e_wc = reinterpret_cast<unsigned long long*>(raw + kWalkEntries);   // visits << 32 | sum of w_u
@@ -376,16 +430,40 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
     const bool walks = tid >= st.lo && tid < st.hi && tile_ray(P, xyz, pose, i, &ray, &ctr->err);
     const float wu = walks ? P.weight / (2.0f * ray.truncation) : 0.0f;
     const uint32_t q_w = (uint32_t)__float2int_rn(wu * scale_w);
+    // origin of the voxel keys: the start voxel of the first walking ray (a lone ray sets it at the first visit
+    // of its window instead: its windows may lie anywhere along a very long ray)
+    const bool lone = st.hi - st.lo == 1;
+    {
+      const unsigned long long wm = __ballot(walks);
+      if (lane == 0) S.cand[wid] = wm ? (uint32_t)(wid * 64 + __ffsll((long long)wm) - 1) : 0xFFFFFFFFu;
+    }
     __syncthreads();
-    uint32_t nv = 0, log_lo = 0;
+    {
+      uint32_t firstw = 0xFFFFFFFFu;
+#pragma unroll
+      for (int w = 0; w < kWalkRays / 64; ++w) firstw = min(firstw, S.cand[w]);
+      if ((uint32_t)tid == firstw && !lone)
+        for (int k = 0; k < 3; ++k) S.org[k] = (int)floorf(ray.start[k]) - kOriginBias;
+    }
+    __syncthreads();
+    int ox = S.org[0], oy = S.org[1], oz = S.org[2];
+    bool org_set = !lone;
+    uint32_t nv = 0;
     if (walks) {
       nv = walk_one(P, pose, ray, st.vlo, st.vhi, [&](uint32_t k, int vx, int vy, int vz, float u) {
-        const int e = table_find_or_insert(S, vx, vy, vz);
-        if (e < 0) return false;
-        if (k < (uint32_t)kLogLen) {   // two entries per dword, written once per pair
-          if (k & 1u) vlog[(k >> 1) * kWalkRays + tid] = log_lo | ((uint32_t)e << 16);
-          else log_lo = (uint32_t)e;
+        if (!org_set) {   // (one lane only)
+          ox = vx - kOriginBias; oy = vy - kOriginBias; oz = vz - kOriginBias;
+          S.org[0] = ox; S.org[1] = oy; S.org[2] = oz;
+          org_set = true;
         }
+        uint32_t key;
+        if (!rel_key(vx, vy, vz, ox, oy, oz, &key)) {   // the rays of the sub-tile are too far apart: cut it
+          S.overflow = 1u;
+          return false;
+        }
+        const int e = table_find_or_insert(S, key);
+        if (e < 0) return false;
+        if (k < (uint32_t)kLogLen) vlog[k * kWalkRays + tid] = (uint16_t)e;
         atomicAdd(&e_wuu[e], __float2int_rn((wu * u) * scale_u));
         atomicAdd(&e_wc[e], (1ull << 32) | (unsigned long long)q_w);
         atomicMax(&e_last[e], (uint32_t)tid);
@@ -401,18 +479,17 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
       continue;
     }
     const uint32_t nmine = nv > st.vlo ? nv - st.vlo : 0u;   // this ray's visits in the (sub-)tile
-    if ((nmine & 1u) && nmine <= (uint32_t)kLogLen) vlog[(nmine >> 1) * kWalkRays + tid] = log_lo;   // the odd last one
     my_visits += nmine;
 
     // ---- entries -> chunks -> pool slots
+    const int fox = S.org[0], foy = S.org[1], foz = S.org[2];   // (a lone ray set them during its walk)
     int ci[kPer];
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
-      const unsigned long long key = S.ekey[tid + k * kWalkRays];
+      const uint32_t key = S.ekey[tid + k * kWalkRays];
       ci[k] = -2;
-      if (key != kVoxEmpty) {
-        int vx, vy, vz;
-        unpack_voxel(key, &vx, &vy, &vz);
+      if (key != kKeyEmpty) {
+        const int vx = (int)(key & 1023u) + fox, vy = (int)((key >> 10) & 1023u) + foy, vz = (int)(key >> 20) + foz;
         ci[k] = chunk_cache_insert(S, vx >> 4, vy >> 4, vz >> 4);
       }
     }
@@ -433,9 +510,8 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
       vkey[k] = 0;
       slot_of[k] = -1;
       if (ci[k] == -2) continue;
-      const unsigned long long key = S.ekey[tid + k * kWalkRays];
-      int vx, vy, vz;
-      unpack_voxel(key, &vx, &vy, &vz);
+      const uint32_t key = S.ekey[tid + k * kWalkRays];
+      const int vx = (int)(key & 1023u) + fox, vy = (int)((key >> 10) & 1023u) + foy, vz = (int)(key >> 20) + foz;
       const uint32_t vid = (uint32_t)(((vz & 15) * 16 + (vy & 15)) * 16 + (vx & 15));
       if (ci[k] >= 0) {
         slot_of[k] = S.cslot[ci[k]];
@@ -555,14 +631,14 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
       if (walks && nmine) {
         const uint32_t logged = min(nmine, (uint32_t)kLogLen);
         for (uint32_t k = 0; k < logged; ++k) {
-          const uint32_t e = (vlog[(k >> 1) * kWalkRays + tid] >> ((k & 1u) * 16)) & 0xFFFFu;
-          const uint32_t m = (uint32_t)e_midx[e] - r0;   // 0xFFFF - r0 stays out of range
+          const uint32_t m = (uint32_t)e_midx[vlog[k * kWalkRays + tid]] - r0;   // 0xFFFF - r0 stays out of range
           if (m < (uint32_t)kMaskCap) atomicOr(&raw[m * kMaskWords + (tid >> 5)], 1u << (tid & 31));
         }
         if (nmine > (uint32_t)kLogLen) {   // the log is full: the rest of the ray is walked again
           walk_one(P, pose, ray, st.vlo, st.vhi, [&](uint32_t k, int vx, int vy, int vz, float) {
             if (k >= (uint32_t)kLogLen) {
-              const int e = table_find(S, vx, vy, vz);
+              uint32_t key;
+              const int e = rel_key(vx, vy, vz, fox, foy, foz, &key) ? table_find(S, key) : -1;
               const uint32_t m = e >= 0 ? (uint32_t)e_midx[e] - r0 : 0xFFFFFFFFu;
               if (m < (uint32_t)kMaskCap) atomicOr(&raw[m * kMaskWords + (tid >> 5)], 1u << (tid & 31));
             }
@@ -819,6 +895,23 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
   if (lane == 0 && voxels) {
     atomicAdd(&ctr->num_heads, voxels);
     atomicMax(&ctr->max_run, longest);
+  }
+}
+
+// Self-test of sqrt_rn_normal / div_rn_normal against the compiler's sqrtf and `/` (GPU test): pseudo-random
+// operands over the ranges the walk meets, plus every significand at a few exponents for the square root.
+__global__ void selftest_walk_math_kernel(uint32_t seed, uint32_t* __restrict__ mismatches) {
+  uint32_t x = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + seed;
+  for (int it = 0; it < 64; ++it) {
+    x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+    const uint32_t ma = x & 0x7FFFFFu;
+    x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+    const uint32_t mb = x & 0x7FFFFFu;
+    const int ea = (int)((x >> 23) & 31u) - 16, eb = (int)((x >> 28) & 15u) - 8;
+    const float a = __uint_as_float(((uint32_t)(ea + 127) << 23) | ma);
+    const float b = __uint_as_float(((uint32_t)(eb + 127) << 23) | mb | ((x >> 27) & 1u ? 0x80000000u : 0u));
+    if (__float_as_uint(sqrt_rn_normal(a)) != __float_as_uint(sqrtf(a))) atomicAdd(&mismatches[0], 1u);
+    if (__float_as_uint(div_rn_normal(a, b)) != __float_as_uint(a / b)) atomicAdd(&mismatches[1], 1u);
   }
 }
 

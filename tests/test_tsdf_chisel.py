@@ -254,6 +254,21 @@ def test_hip_reciprocal_is_correctly_rounded_for_every_significand():
         assert bad.value == 0, f"exponent {exponent}: {bad.value} significands not correctly rounded"
 
 
+@pytest.mark.gpu
+def test_hip_walk_square_root_and_quotient_are_the_ieee_ones():
+    """The single-walk kernel takes sqrt and the quotient of the signed distance without the compiler's range
+    scaffolding (tsdf_walk.hpp: sqrt_rn_normal, div_rn_normal); they must agree with sqrtf and `/` bit for bit —
+    1.3e9 pseudo-random operand pairs over the exponents the walk meets."""
+    import ctypes
+    from plvs_amd import _lib
+    f = _lib.lib.plvs_hip_selftest_walk_math
+    f.argtypes = [ctypes.c_uint32, ctypes.c_void_p]
+    for seed in (1, 77, 4242, 99991, 123456789):
+        bad = (ctypes.c_uint32 * 2)(7, 7)
+        _lib.check(f(seed, bad))
+        assert bad[0] == 0 and bad[1] == 0, f"seed {seed}: {bad[0]} square roots, {bad[1]} quotients differ"
+
+
 # Order-free mode (plvs_tsdf_chisel_params.order_free = 1): BASELINE's north star asks for the TSDF
 # sdf / weights "within a stated float tolerance" of the reference.  The tolerance, stated here:
 ORDER_FREE_SDF_ATOL = 2e-5        # metres (0.04 % of a 5 cm voxel); measured 7e-7 on keyframe streams, 6e-6
