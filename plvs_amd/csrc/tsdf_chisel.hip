@@ -789,19 +789,19 @@ static int walk_fail(plvs_tsdf_chisel* h, uint32_t err) {
 
 // Stable sort of the D runs walk_tiles left in the per-tile regions by voxel key: per voxel its runs
 // in tile (= point) order; the value carried is the run's slot (tile = slot >> r1_log2, mask at slot * 8).
-static int sort_runs(plvs_tsdf_chisel* h, uint32_t D, uint32_t ntiles, hipStream_t s, const uint32_t** skeys,
-                     const uint32_t** sval) {
+static int sort_runs(plvs_tsdf_chisel* h, uint32_t D, uint32_t ntiles, int num_chunks, hipStream_t s,
+                     const uint32_t** skeys, const uint32_t** sval) {
   PLVS_HIP_TRY(h->dkey0.reserve(D));
   PLVS_HIP_TRY(h->dkey1.reserve(D));
   PLVS_HIP_TRY(h->w_val0.reserve(D));
   PLVS_HIP_TRY(h->w_val1.reserve(D));
   PLVS_HIP_TRY(h->w_run_off.reserve((size_t)ntiles + 1));
   PLVS_HIP_TRY(h->scratch.reserve(std::max(radix_scratch_words(D), scan_scratch_words(ntiles))));
-  PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, ntiles, nullptr, h->scratch.p, s));
+  // (the caller has scanned run_cnt into w_run_off)
   hipLaunchKernelGGL(compact_runs, dim3(ceil_div(ntiles, 4)), dim3(256), 0, s, h->w_runkey.p, h->w_run_cnt.p,
                      h->w_run_off.p, ntiles, h->run_r1_log2, h->dkey0.p, h->w_val0.p);
   int key_bits = 12;
-  while ((1ll << (key_bits - 12)) < (long long)h->num_chunks) ++key_bits;
+  while ((1ll << (key_bits - 12)) < (long long)num_chunks) ++key_bits;   // (the count after this call's insertions)
   bool second = false;
   PLVS_HIP_TRY(radix_sort_pairs(h->dkey0.p, h->w_val0.p, h->dkey1.p, h->w_val1.p, D, 0, key_bits, h->scratch.p, s,
                                 &second));
@@ -833,6 +833,11 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
   size_t rec_spill = std::max<size_t>(h->w_rec.cap > rec_own ? h->w_rec.cap - rec_own : 0, (size_t)1 << 16);
   size_t seg_spill = std::max<size_t>(h->w_seg.cap / 2 > seg_own ? h->w_seg.cap / 2 - seg_own : 0, (size_t)1 << 12);
   PLVS_HIP_TRY(h->w_run_cnt.reserve(ntiles));
+  PLVS_HIP_TRY(h->dkey0.reserve(kSmallRuns));
+  PLVS_HIP_TRY(h->w_val0.reserve(kSmallRuns));
+  PLVS_HIP_TRY(h->heads.reserve(kSmallRuns));
+  PLVS_HIP_TRY(h->w_run_off.reserve((size_t)ntiles + 1));
+  PLVS_HIP_TRY(h->scratch.reserve(scan_scratch_words(ntiles)));
   h->stage_set = 1;
   const int chunks_before = h->num_chunks;
 #define STAGE_MARK(i) \
@@ -851,6 +856,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     RunOut runs{h->w_runkey.p, h->w_masks.p, h->w_run_cnt.p, h->run_r1_log2};
     hipLaunchKernelGGL(walk_tiles, dim3(ntiles), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
                        h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw, out, runs);
+    PLVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
     STAGE_MARK(1);
     const unsigned seg_blocks = ceil_div(seg_own + seg_spill, kSegSpan);
     hipLaunchKernelGGL(seg_pass<false>, dim3(seg_blocks), dim3(256), 0, s, h->w_seg.p, out.seg_cap, ntiles,
@@ -868,11 +874,46 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
                        h->weight, h->kfid, h->d_wctr);
     PLVS_KERNEL_CHECK();
     STAGE_MARK(3);
+    // ---- colour fold: the truncating u8 mean is order dependent -> through the sorted runs of the voxels
+    // whose colour weight is below 254.  It only needs the runs the walk left, so it runs on the side stream
+    // beside the segment sort and the apply stage (both short, latency-bound kernels).
+    {
+      uint32_t* const side_ctr = &h->d_wctr[1].num_desc;   // the run count, for the side stream's kernels
+      PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+      PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, ntiles, side_ctr, h->scratch.p, h->side));
+      PLVS_HIP_TRY(hipMemcpyAsync(&h->h_wctr[1], &h->d_wctr[1], sizeof(WalkCounters), hipMemcpyDeviceToHost, h->side));
+      PLVS_HIP_TRY(hipMemcpyAsync(&h->h_wctr[0], &h->d_wctr[0], sizeof(WalkCounters), hipMemcpyDeviceToHost, h->side));
+      PLVS_HIP_TRY(hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, h->side));
+      PLVS_HIP_TRY(hipStreamSynchronize(h->side));   // the walk is over; segment sort and apply are queued behind it
+      const uint32_t D = h->h_wctr[1].num_desc;
+      if (h->h_wctr[0].err == 0 && D > 0) {
+        const uint32_t* skeys = h->dkey0.p;
+        const uint32_t* sval = h->w_val0.p;
+        if (D <= kSmallRuns) {
+          hipLaunchKernelGGL(sort_runs_small, dim3(1), dim3(1024), 0, h->side, h->w_runkey.p, h->w_run_cnt.p, ntiles,
+                             h->run_r1_log2, h->d_wctr + 1, h->dkey0.p, h->w_val0.p, h->heads.p);
+        } else {
+          int rc = sort_runs(h, D, ntiles, h->h_ctr->num_chunks, h->side, &skeys, &sval);
+          if (rc != PLVS_OK) return rc;
+          PLVS_HIP_TRY(h->heads.reserve(D));
+          PLVS_HIP_TRY(h->w_dummy.reserve((size_t)max_chunks + 1));
+          hipLaunchKernelGGL(voxel_heads, dim3(ceil_div(D, 256 * kHeadTiles)), dim3(256), 0, h->side, skeys, D,
+                             h->heads.p, h->w_dummy.p, h->d_wctr + 1);
+        }
+        hipLaunchKernelGGL(fold_colours_masks, dim3(std::min<size_t>(ceil_div(D, kFoldWaves), 8192)),
+                           dim3(64 * kFoldWaves), 0, h->side, skeys, sval, side_ctr, h->run_r1_log2, h->heads.p,
+                           h->w_masks.p, d_rgb, h->rgbw, &h->d_wctr[1].num_heads);
+        PLVS_KERNEL_CHECK();
+      }
+      PLVS_HIP_TRY(hipEventRecord(h->ev_join, h->side));
+      PLVS_HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+    }
+    STAGE_MARK(4);
     int rc = read_walk_counters(h, s);
     if (rc != PLVS_OK) return rc;
     const uint32_t err = h->h_wctr->err;
     if (err & ~kErrScratch) return walk_fail(h, err);
-    if (err & kErrScratch) {   // the map is untouched (apply_chunks left at once): grow and repeat
+    if (err & kErrScratch) {   // the map is untouched (apply_chunks left at once, no colours folded): grow and repeat
       if (attempt >= 8) return walk_fail(h, err);
       rec_spill = std::max<size_t>(rec_spill, (size_t)h->h_wctr->rec_top * 2);
       seg_spill = std::max<size_t>(seg_spill, (size_t)h->h_wctr->seg_top * 2);
@@ -890,34 +931,12 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
   h->stats.voxels = (int32_t)c.num_heads;
   h->stats.max_run = (int32_t)c.max_run;
   h->last_updated = c.num_updated;
-  float ms[3] = {0.f, 0.f, 0.f};
+  float ms[4] = {0.f, 0.f, 0.f, 0.f};   // the last one: what the colour fold adds behind the apply stage
   if (h->profiling)
-    for (int i = 0; i < 3; ++i) PLVS_HIP_TRY(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
-  float ms_colour = 0.f;
-  const uint32_t D = c.num_desc;
-  if (D > 0) {
-    // ---- colour fold: the truncating u8 mean is order dependent -> through the sorted runs of the
-    // voxels whose colour weight is below 254
-    STAGE_MARK(4);
-    const uint32_t* skeys = nullptr;
-    const uint32_t* sval = nullptr;
-    int rc = sort_runs(h, D, ntiles, s, &skeys, &sval);
-    if (rc != PLVS_OK) return rc;
-    PLVS_HIP_TRY(h->heads.reserve(D));
-    PLVS_HIP_TRY(h->w_dummy.reserve((size_t)max_chunks + 1));
-    hipLaunchKernelGGL(voxel_heads, dim3(ceil_div(D, 256 * kHeadTiles)), dim3(256), 0, s, skeys, D, h->heads.p,
-                       h->w_dummy.p, h->d_wctr + 1);
-    hipLaunchKernelGGL(fold_colours_masks, dim3(std::min<size_t>(ceil_div(D, kFoldWaves), 8192)), dim3(64 * kFoldWaves), 0, s, skeys,
-                       sval, D, h->run_r1_log2, h->heads.p, h->w_masks.p, d_rgb, h->rgbw, &h->d_wctr[1].num_heads);
-    PLVS_KERNEL_CHECK();
-    STAGE_MARK(5);
-    PLVS_HIP_TRY(hipStreamSynchronize(s));
-    if (h->profiling) PLVS_HIP_TRY(hipEventElapsedTime(&ms_colour, h->ev[4], h->ev[5]));
-  }
+    for (int i = 0; i < 4; ++i) PLVS_HIP_TRY(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
 #undef STAGE_MARK
   if (h->profiling) {
-    for (int i = 0; i < 3; ++i) h->stage_ms[i] += ms[i];
-    h->stage_ms[3] += ms_colour;
+    for (int i = 0; i < 4; ++i) h->stage_ms[i] += ms[i];
     h->prof_calls++;
   }
   return PLVS_OK;

@@ -930,6 +930,92 @@ __global__ __launch_bounds__(256) void compact_runs(const uint32_t* __restrict__
   }
 }
 
+// The same, down to the voxel heads, for a call with few runs (a map whose colours have saturated keeps a
+// trickle of them at its rim): one workgroup compacts the runs of the tiles into LDS as (key << 32 | slot),
+// sorts them there (bitonic; slot order = tile order, so equal keys stay in point order) and lists the first
+// run of every voxel — one launch instead of a compaction, the radix passes and the head scan, none of
+// which is worth its launch for a few hundred runs.  ctr = the colour side's counters (num_desc: the runs).
+constexpr uint32_t kSmallRuns = 4096;
+__global__ __launch_bounds__(1024) void sort_runs_small(const uint32_t* __restrict__ runkey, const uint32_t* __restrict__ run_cnt,
+                                                        uint32_t ntiles, uint32_t r1_log2, WalkCounters* __restrict__ ctr,
+                                                        uint32_t* __restrict__ skeys, uint32_t* __restrict__ sval,
+                                                        uint32_t* __restrict__ heads) {
+  __shared__ unsigned long long item[kSmallRuns];
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t D = ctr->num_desc;   // 0 < D <= kSmallRuns (the host chose this path)
+  uint32_t P = 64;
+  while (P < D) P <<= 1;
+  for (uint32_t k = tid; k < P; k += 1024) item[k] = ~0ull;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  auto block_scan = [&](uint32_t c, uint32_t* total) {   // exclusive prefix of c over the workgroup, after `carry`
+    uint32_t inc = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
+      if (lane >= off) inc += up;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    uint32_t wb = carry, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      if (w < wid) wb += wsum[w];
+      tot += wsum[w];
+    }
+    *total = tot;
+    return wb + inc - c;
+  };
+  for (uint32_t base = 0; base < ntiles; base += 1024) {
+    const uint32_t t = base + (uint32_t)tid;
+    const uint32_t n = t < ntiles ? run_cnt[t] : 0u;
+    uint32_t tot;
+    const uint32_t o = block_scan(n, &tot);
+    for (uint32_t k = 0; k < n; ++k) {
+      const uint32_t slot = (t << r1_log2) + k;
+      item[o + k] = ((unsigned long long)runkey[slot] << 32) | slot;
+    }
+    __syncthreads();
+    if (tid == 0) carry += tot;
+    __syncthreads();
+  }
+  for (uint32_t k = 2; k <= P; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = tid; i < P; i += 1024) {
+        const uint32_t x = i ^ j;
+        if (x > i) {
+          const unsigned long long a = item[i], b = item[x];
+          if ((a > b) == ((i & k) == 0)) {
+            item[i] = b;
+            item[x] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < D; base += 1024) {
+    const uint32_t j = base + (uint32_t)tid;
+    uint32_t head = 0;
+    if (j < D) {
+      const unsigned long long it = item[j];
+      skeys[j] = (uint32_t)(it >> 32);
+      sval[j] = (uint32_t)it;
+      head = (j == 0 || (uint32_t)(item[j - 1] >> 32) != (uint32_t)(it >> 32)) ? 1u : 0u;
+    }
+    uint32_t tot;
+    const uint32_t o = block_scan(head, &tot);
+    if (head) heads[o] = j;
+    __syncthreads();
+    if (tid == 0) carry += tot;
+    __syncthreads();
+  }
+  if (tid == 0) ctr->num_heads = carry;
+}
+
 // ColorVoxel::IntegrateSimple visit by visit, for the voxels whose colour weight is below 254.  One
 // wave per voxel: the lanes take its runs (sorted: tile order = point order) 64 at a time, place the
 // colours of their visits — the rays of a mask in ascending order — in LDS at the visit's rank, and three
@@ -937,12 +1023,12 @@ __global__ __launch_bounds__(256) void compact_runs(const uint32_t* __restrict__
 // most 254 steps in the life of a voxel, none once it is there.
 constexpr int kFoldWaves = 4;
 __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
-    const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ sorted_val, uint32_t nd, uint32_t r1_log2,
-    const uint32_t* __restrict__ vj0, const uint32_t* __restrict__ masks, const uint8_t* __restrict__ rgb,
-    uint32_t* __restrict__ rgbw, const uint32_t* __restrict__ num_heads) {
+    const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ sorted_val, const uint32_t* __restrict__ nd_dev,
+    uint32_t r1_log2, const uint32_t* __restrict__ vj0, const uint32_t* __restrict__ masks,
+    const uint8_t* __restrict__ rgb, uint32_t* __restrict__ rgbw, const uint32_t* __restrict__ num_heads) {
   __shared__ uint32_t stage[kFoldWaves][256];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const uint32_t nvox = *num_heads;
+  const uint32_t nvox = *num_heads, nd = *nd_dev;
   const uint32_t nwaves = gridDim.x * kFoldWaves;
   for (uint32_t v = blockIdx.x * kFoldWaves + wid; v < nvox; v += nwaves) {
     const uint32_t j0 = vj0[v];
