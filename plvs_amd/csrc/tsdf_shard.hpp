@@ -1,0 +1,239 @@
+// Ray-sharded multi-GPU integrate of the open_chisel back end (order-free mode; included by tsdf_chisel.hip
+// after tsdf_walk.hpp).  New design: the reference is a single process.
+//
+// The map is sharded by chunk (owner = three-prime ChunkHasher mod N, ChunkManager.h:42-54), the WORK by
+// tile of the point stream: rank r walks the tiles t = r (mod N) of every call — its share of the rays,
+// whatever chunks they cross — and the partial sums it collects for a chunk travel to the chunk's owner:
+//
+//   shard_walk    walk_tiles<acc> over the rank's tiles into a per-call scratch directory, segment sort;
+//                 per chunk its owner and record total (shard_chunk_totals), per destination the place of
+//                 every chunk in the send buffers (shard_plan) -> send counts
+//   shard_pack    segment descriptors (chunk id instead of slot, record offsets relative to the destination's
+//                 block) and records, grouped by destination, into the caller's send buffers (shard_pack_segments)
+//   (exchange)    ONE all-to-all of the two buffers — RCCL send/recv behind plvs_hip_tsdf_chisel_integrate_sharded,
+//                 torch.distributed in the Python mirror, device copies between virtual ranks in the tests
+//   shard_apply   received descriptors -> slots of the owner's directory (shard_translate, first-touch chunks are
+//                 inserted here), the segment sort and apply_chunks of the single-device path on the received
+//                 records.  The sums are integers: the result is bit-identical to the single-device order-free
+//                 integrate whatever N is.
+//                 Colours (the truncating u8 mean is order dependent below weight 254): apply_chunks marks the
+//                 tiles that touched a voxel of this owner still below 254; the owner walks those tiles itself
+//                 (walk_tiles<runs>, visits filtered to its chunks) and folds the runs as the single-device path
+//                 does.  Nothing to do once a region's colours have saturated.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "tsdf_walk.hpp"
+
+namespace {
+
+// Per updated chunk of the call (index a in `active`): its owner and the records of its segments.
+__global__ __launch_bounds__(256) void shard_chunk_totals(const uint4* __restrict__ sorted_seg,
+                                                          const uint32_t* __restrict__ active,
+                                                          const uint32_t* __restrict__ active_off,
+                                                          const int32_t* __restrict__ slot_ids, int nranks,
+                                                          const WalkCounters* __restrict__ ctr,
+                                                          uint32_t* __restrict__ nrec, uint32_t* __restrict__ owner) {
+  __shared__ uint32_t wsum[4];
+  if (ctr->err) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t n = ctr->num_updated;
+  for (uint32_t a = blockIdx.x; a < n; a += gridDim.x) {
+    const uint32_t s0 = active_off[a], s1 = active_off[a + 1];
+    uint32_t c = 0;
+    for (uint32_t j = s0 + (uint32_t)tid; j < s1; j += 256) c += sorted_seg[2 * (size_t)j].z;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off);
+    if (lane == 0) wsum[wid] = c;
+    __syncthreads();
+    if (tid == 0) {
+      const int32_t* id = slot_ids + 3 * (size_t)active[a];
+      nrec[a] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+      owner[a] = (uint32_t)shard_of(chunk_hash(id[0], id[1], id[2]), nranks);
+    }
+    __syncthreads();
+  }
+}
+
+// Places of the chunks in the send buffers: destination by destination, chunks in `active` order.
+// counts[2p], counts[2p+1] = segments and records for rank p; obase = the same as running offsets.
+__global__ __launch_bounds__(1024) void shard_plan(const uint32_t* __restrict__ active_off, const uint32_t* __restrict__ nrec,
+                                                   const uint32_t* __restrict__ owner, int nranks,
+                                                   const WalkCounters* __restrict__ ctr, uint32_t* __restrict__ seg_dst,
+                                                   uint32_t* __restrict__ rec_dst, long long* __restrict__ counts,
+                                                   uint32_t* __restrict__ obase) {
+  __shared__ uint32_t wsum_s[16], wsum_r[16];
+  __shared__ uint32_t carry_s, carry_r;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t n = ctr->err ? 0u : ctr->num_updated;
+  if (tid == 0) { carry_s = 0; carry_r = 0; }
+  __syncthreads();
+  for (int p = 0; p < nranks; ++p) {
+    const uint32_t base_s = carry_s, base_r = carry_r;
+    __syncthreads();
+    if (tid == 0) { obase[2 * p] = base_s; obase[2 * p + 1] = base_r; }
+    for (uint32_t b = 0; b < n; b += 1024) {
+      const uint32_t a = b + (uint32_t)tid;
+      const bool mine = a < n && owner[a] == (uint32_t)p;
+      const uint32_t cs = mine ? active_off[a + 1] - active_off[a] : 0u, cr = mine ? nrec[a] : 0u;
+      uint32_t is = cs, ir = cr;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t us = (uint32_t)__shfl_up((int)is, off), ur = (uint32_t)__shfl_up((int)ir, off);
+        if (lane >= off) { is += us; ir += ur; }
+      }
+      if (lane == 63) { wsum_s[wid] = is; wsum_r[wid] = ir; }
+      __syncthreads();
+      uint32_t ws = carry_s, wr = carry_r, ts = 0, tr = 0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) {
+        if (w < wid) { ws += wsum_s[w]; wr += wsum_r[w]; }
+        ts += wsum_s[w];
+        tr += wsum_r[w];
+      }
+      if (mine) {
+        seg_dst[a] = ws + is - cs;
+        rec_dst[a] = wr + ir - cr;
+      }
+      __syncthreads();
+      if (tid == 0) { carry_s += ts; carry_r += tr; }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      counts[2 * p] = (long long)(carry_s - base_s);
+      counts[2 * p + 1] = (long long)(carry_r - base_r);
+    }
+    __syncthreads();
+  }
+}
+
+// The wire form of a segment descriptor (two uint4):
+//   {chunk key low, first record relative to the destination's record block, chunk key high, tile},
+//   {slab offsets 1..7 as in the local form, the record count in the 16 bits of offset 0 (always 0)}.
+// Workgroup per chunk; the records of a segment are copied by a wave (contiguous 16-byte items).
+__global__ __launch_bounds__(256) void shard_pack_segments(
+    const uint4* __restrict__ sorted_seg, const uint4* __restrict__ rec, const uint32_t* __restrict__ active,
+    const uint32_t* __restrict__ active_off, const int32_t* __restrict__ slot_ids, const uint32_t* __restrict__ owner,
+    const uint32_t* __restrict__ seg_dst, const uint32_t* __restrict__ rec_dst, const uint32_t* __restrict__ obase,
+    const WalkCounters* __restrict__ ctr, uint4* __restrict__ seg_out, uint4* __restrict__ rec_out) {
+  __shared__ uint32_t src[256], dst[256], cnt[256], wsum[4];
+  __shared__ uint32_t run;
+  if (ctr->err) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t n = ctr->num_updated;
+  for (uint32_t a = blockIdx.x; a < n; a += gridDim.x) {
+    const uint32_t s0 = active_off[a], s1 = active_off[a + 1];
+    const int32_t* id = slot_ids + 3 * (size_t)active[a];
+    unsigned long long key = 0;
+    pack_block(id[0], id[1], id[2], &key);   // (in range: the walk packed it before)
+    const uint32_t rel = obase[2 * owner[a] + 1];
+    if (tid == 0) run = rec_dst[a];
+    __syncthreads();
+    for (uint32_t b = s0; b < s1; b += 256) {
+      const uint32_t j = b + (uint32_t)tid;
+      uint4 d0 = make_uint4(0, 0, 0, 0), d1 = make_uint4(0, 0, 0, 0);
+      if (j < s1) {
+        d0 = sorted_seg[2 * (size_t)j];
+        d1 = sorted_seg[2 * (size_t)j + 1];
+      }
+      const uint32_t c = d0.z;
+      uint32_t inc = c;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
+        if (lane >= off) inc += up;
+      }
+      if (lane == 63) wsum[wid] = inc;
+      __syncthreads();
+      uint32_t wb = run, tot = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        if (w < wid) wb += wsum[w];
+        tot += wsum[w];
+      }
+      const uint32_t at = wb + inc - c;
+      src[tid] = d0.y;
+      dst[tid] = at;
+      cnt[tid] = c;
+      if (j < s1) {
+        const size_t o = (size_t)seg_dst[a] + (j - s0);
+        seg_out[2 * o] = make_uint4((uint32_t)key, at - rel, (uint32_t)(key >> 32), d0.w);
+        seg_out[2 * o + 1] = make_uint4(d1.x | c, d1.y, d1.z, d1.w);
+      }
+      __syncthreads();
+      const uint32_t nb = min(256u, s1 - b);
+      for (uint32_t i = (uint32_t)wid; i < nb; i += 4) {
+        const uint32_t sc = src[i], ds = dst[i], cc = cnt[i];
+        for (uint32_t r = (uint32_t)lane; r < cc; r += 64) rec_out[(size_t)ds + r] = rec[(size_t)sc + r];
+      }
+      __syncthreads();
+      if (tid == 0) run += tot;
+      __syncthreads();
+    }
+  }
+}
+
+// Received descriptors (grouped by source rank; src_off[q], src_off[nranks + 1 + q] = first segment / first
+// record of source q's block) -> the local form, with the chunk's slot in the owner's directory (first-touch
+// chunks are inserted) and record offsets into the whole receive buffer.
+__global__ __launch_bounds__(256) void shard_translate(const uint4* __restrict__ seg_in, uint32_t total,
+                                                       const uint32_t* __restrict__ src_off, int nranks, Directory dir,
+                                                       int32_t* __restrict__ num_chunks, uint32_t* __restrict__ err,
+                                                       uint4* __restrict__ seg_out) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= total) return;
+  int q = 0;
+  while (q + 1 < nranks && src_off[q + 1] <= j) ++q;
+  const uint4 d0 = seg_in[2 * (size_t)j], d1 = seg_in[2 * (size_t)j + 1];
+  const unsigned long long key = (unsigned long long)d0.x | ((unsigned long long)d0.z << 32);
+  const int x = (int)((key >> 42) & 0x1FFFFFu) - kCoordBias, y = (int)((key >> 21) & 0x1FFFFFu) - kCoordBias,
+            z = (int)(key & 0x1FFFFFu) - kCoordBias;
+  const int slot = dir_find_or_insert(dir, x, y, z, num_chunks, err);
+  uint32_t c = d1.x & 0xFFFFu;
+  if (slot < 0) c = 0;   // (err is set: apply_chunks leaves at once, the host reports it)
+  seg_out[2 * (size_t)j] = make_uint4(slot < 0 ? 0u : (uint32_t)slot, d0.y + src_off[nranks + 1 + q], c, d0.w);
+  seg_out[2 * (size_t)j + 1] = make_uint4(d1.x & 0xFFFF0000u, d1.y, d1.z, d1.w);
+}
+
+// Bitmap of marked tiles -> ascending list (one workgroup).
+__global__ __launch_bounds__(1024) void shard_list_tiles(const uint32_t* __restrict__ marks, uint32_t nwords,
+                                                         uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t b = 0; b < nwords; b += 1024) {
+    const uint32_t w = b + (uint32_t)tid;
+    uint32_t bits = w < nwords ? marks[w] : 0u;
+    const uint32_t c = (uint32_t)__popc(bits);
+    uint32_t inc = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
+      if (lane >= off) inc += up;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    uint32_t at = carry, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (k < wid) at += wsum[k];
+      tot += wsum[k];
+    }
+    at += inc - c;
+    while (bits) {
+      const int bpos = __ffs((int)bits) - 1;
+      bits &= bits - 1u;
+      list[at++] = w * 32u + (uint32_t)bpos;
+    }
+    __syncthreads();
+    if (tid == 0) carry += tot;
+    __syncthreads();
+  }
+  if (tid == 0) *count = carry;
+}
+
+}  // namespace

@@ -376,12 +376,24 @@ __device__ __forceinline__ uint4 pack_suboffsets(const uint32_t* o) {
   return make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
 }
 
-// Order-free accumulation (records) + runs of the voxels whose colour weight is below 254.
+// Which tile of the point stream a workgroup takes: its block index itself (the whole stream on one device),
+// every stride-th tile (a rank of the ray-sharded multi-GPU integrate) or an entry of an ascending list (the
+// tiles an owner re-walks for the colours).  The output regions are indexed by the block ("local tile").
+struct TileMap {
+  const uint32_t* list;
+  uint32_t stride, first;
+  __device__ __host__ uint32_t tile_of(uint32_t local) const { return list ? list[local] : local * stride + first; }
+};
+
+// Order-free accumulation (kAcc: records + segments) and/or the runs of the voxels whose colour weight is
+// below 254 (kRuns).  Both: the single-device integrate; kAcc alone: a rank's share of the rays in the
+// ray-sharded integrate (dir = the call's scratch directory); kRuns alone: the owner's colour walk.
+template <bool kAcc, bool kRuns>
 __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
     Params P, float scale_u, float scale_w, const float* __restrict__ xyz, int npoints,
     const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
     int32_t* __restrict__ num_chunks, WalkCounters* __restrict__ ctr, const uint32_t* __restrict__ rgbw, AccOut out,
-    RunOut runs) {
+    RunOut runs, TileMap tmap) {
   constexpr int kPer = kWalkEntries / kWalkRays;
   __shared__ WalkShared S;
   __shared__ uint32_t raw[kMaskCap * kMaskWords];              // accumulators during the walk, ray masks afterwards
@@ -394,8 +406,9 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   // Tiles are numbered in point order by blockIdx: workgroups are dispatched in that order, so the
   // look-back below only ever waits for tiles that are already running.
-  const uint32_t tile = blockIdx.x, ntiles = gridDim.x;
-  const uint32_t first = tile * kWalkRays;
+  const uint32_t tile = blockIdx.x, ntiles = gridDim.x;   // the local tile: output regions
+  const uint32_t gtile = tmap.tile_of(tile);             // its place in the point stream
+  const uint32_t first = gtile * kWalkRays;
   if (tid == 0) {
     S.sp = 0;
     S.next = 0;
@@ -463,10 +476,12 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
         }
         const int e = table_find_or_insert(S, key);
         if (e < 0) return false;
-        if (k < (uint32_t)kLogLen) vlog[k * kWalkRays + tid] = (uint16_t)e;
-        atomicAdd(&e_wuu[e], __float2int_rn((wu * u) * scale_u));
-        atomicAdd(&e_wc[e], (1ull << 32) | (unsigned long long)q_w);
-        atomicMax(&e_last[e], (uint32_t)tid);
+        if (kRuns && k < (uint32_t)kLogLen) vlog[k * kWalkRays + tid] = (uint16_t)e;
+        if (kAcc) {
+          atomicAdd(&e_wuu[e], __float2int_rn((wu * u) * scale_u));
+          atomicAdd(&e_wc[e], (1ull << 32) | (unsigned long long)q_w);
+          atomicMax(&e_last[e], (uint32_t)tid);
+        }
         return true;
       });
     }
@@ -521,14 +536,14 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
       }
       if (slot_of[k] >= 0) {
         vkey[k] = (uint32_t)slot_of[k] * (uint32_t)kChunkVox + vid;
-        if ((rgbw[vkey[k]] >> 24) < 254u) {   // its colour still depends on the order of the visits
+        if (kRuns && (rgbw[vkey[k]] >> 24) < 254u) {   // its colour still depends on the order of the visits
           need |= 1u << k;
           ++nneed;
         }
       }
     }
     __syncthreads();
-    {
+    if (kAcc) {
       // ---- records: wave 0 places the (chunk, slab) groups (the tile's own region on its first flush)
       if (tid < 64) {
         uint32_t sub[kSlabs], c = 0;
@@ -562,7 +577,7 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
         if (c) {
           const uint32_t sg = sbase + sinc - 1u;
           if (sg < out.seg_cap) {
-            out.seg[2 * (size_t)sg] = make_uint4((uint32_t)S.cslot[tid], rbase + inc - c, c, 0u);
+            out.seg[2 * (size_t)sg] = make_uint4((uint32_t)S.cslot[tid], rbase + inc - c, c, gtile);
             out.seg[2 * (size_t)sg + 1] = pack_suboffsets(sub);
           }
         }
@@ -574,7 +589,7 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
         const int e = tid + k * kWalkRays;
         const uint32_t vid = vkey[k] % (uint32_t)kChunkVox;
         const unsigned long long wc = e_wc[e];
-        const uint4 r = make_uint4(vid | ((uint32_t)(wc >> 32) << 12), tile * kWalkRays + e_last[e], (uint32_t)e_wuu[e],
+        const uint4 r = make_uint4(vid | ((uint32_t)(wc >> 32) << 12), gtile * kWalkRays + e_last[e], (uint32_t)e_wuu[e],
                                    (uint32_t)wc);
         uint32_t at;
         if (ci[k] >= 0) {
@@ -588,7 +603,7 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
             uint32_t sub[kSlabs];
 #pragma unroll
             for (int s = 0; s < kSlabs; ++s) sub[s] = (uint32_t)s > vid / kSlabVox ? 1u : 0u;
-            out.seg[2 * (size_t)sg] = make_uint4((uint32_t)slot_of[k], at, 1u, 0u);
+            out.seg[2 * (size_t)sg] = make_uint4((uint32_t)slot_of[k], at, 1u, gtile);
             out.seg[2 * (size_t)sg + 1] = pack_suboffsets(sub);
           }
         }
@@ -596,6 +611,8 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
       }
     }
 
+    ++flushes;
+    if (!kRuns) continue;   // (the loop head's barrier lets the records leave before the table is reset)
     // ---- runs: number the entries that need one
     uint32_t inc = nneed;
 #pragma unroll
@@ -660,7 +677,6 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
       }
     }
     emitted += nruns;
-    ++flushes;
   }
 
   // ---- tile epilogue: run and visit counts
@@ -670,11 +686,13 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
   if (lane == 0) S.wsum[wid] = my_visits;
   __syncthreads();
   if (tid == 0) {
-    runs.run_cnt[tile] = min(emitted, 1u << runs.r1_log2);
-    uint32_t v = 0;
-    for (int w = 0; w < kWalkRays / 64; ++w) v += S.wsum[w];
-    out.tile_visits[tile] = v;
-    if (flushes == 0) out.seg_cnt[tile] = 0;
+    if (kRuns) runs.run_cnt[tile] = min(emitted, 1u << runs.r1_log2);
+    if (kAcc) {
+      uint32_t v = 0;
+      for (int w = 0; w < kWalkRays / 64; ++w) v += S.wsum[w];
+      out.tile_visits[tile] = v;
+      if (flushes == 0) out.seg_cnt[tile] = 0;
+    }
     if (was_split) atomicAdd(&ctr->split_tiles, 1u);
   }
 }
@@ -790,7 +808,7 @@ __global__ __launch_bounds__(1024) void seg_scan(const uint32_t* __restrict__ ch
   unsigned long long v = 0, nr = 0;
   for (uint32_t t = tid; t < ntiles; t += 1024) {
     v += tile_visits[t];
-    nr += run_cnt[t];
+    nr += run_cnt ? run_cnt[t] : 0u;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -819,10 +837,14 @@ constexpr int kApplyThreads = 512;
 __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
     const uint4* __restrict__ sorted_seg, const uint32_t* __restrict__ active, const uint32_t* __restrict__ active_off,
     const uint4* __restrict__ rec, double inv_scale_u, double inv_scale_w, const uint32_t* __restrict__ kfid_of_point,
-    float* __restrict__ sdf, float* __restrict__ weight, uint32_t* __restrict__ vkfid, WalkCounters* __restrict__ ctr) {
+    float* __restrict__ sdf, float* __restrict__ weight, uint32_t* __restrict__ vkfid, WalkCounters* __restrict__ ctr,
+    const uint32_t* __restrict__ rgbw, uint32_t* __restrict__ tile_marks) {
+  // tile_marks (ray-sharded integrate only): bitmap of the tiles that visited a voxel whose colour weight is
+  // still below 254 — the tiles the owner walks again for the colour runs.
   __shared__ long long a_wuu[kSlabVox];
   __shared__ unsigned long long a_w[kSlabVox];
   __shared__ uint32_t a_last[kSlabVox], a_cnt[kSlabVox];
+  __shared__ uint32_t any_cold;
   const int tid = threadIdx.x, lane = tid & 63;
   const int grp = tid >> 4, gl = tid & 15;
   constexpr int kGroups = kApplyThreads / 16, kFly = 4;
@@ -844,6 +866,7 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
       a_last[v] = 0;
       a_cnt[v] = 0;
     }
+    if (tid == 0) any_cold = 0;
     __syncthreads();
     const uint32_t s0 = active_off[a], s1 = active_off[a + 1];
     for (uint32_t sb = s0 + (uint32_t)grp * kFly; sb < s1; sb += kGroups * kFly) {
@@ -883,9 +906,31 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
         vkfid[pool0 + v] = kfid_of_point ? kfid_of_point[a_last[v]] : 0u;
         ++voxels;
         longest = max(longest, c);
+        if (tile_marks && (rgbw[pool0 + v] >> 24) < 254u) {
+          a_cnt[v] = 0x80000000u;
+          any_cold = 1u;
+        }
       }
     }
     __syncthreads();
+    uint32_t cold_any = 0;
+    if (tile_marks) {
+      cold_any = any_cold;
+      __syncthreads();   // (everybody has read the flag before the next item resets it)
+    }
+    if (cold_any) {   // second look at the slab's records: which tiles brought the cold voxels
+      for (uint32_t sb = s0 + (uint32_t)grp; sb < s1; sb += kGroups) {
+        const uint4 d0 = sorted_seg[2 * (size_t)sb], d1 = sorted_seg[2 * (size_t)sb + 1];
+        const uint32_t w[4] = {d1.x, d1.y, d1.z, d1.w};
+        const uint32_t o = (w[slab >> 1] >> ((slab & 1) * 16)) & 0xFFFFu;
+        const uint32_t e = slab + 1 < kSlabs ? (w[(slab + 1) >> 1] >> (((slab + 1) & 1) * 16)) & 0xFFFFu : d0.z;
+        bool cold = false;
+        for (uint32_t r = d0.y + o + gl; r < d0.y + e; r += 16)
+          cold |= (a_cnt[(rec[r].x & 0xFFFu) % kSlabVox] & 0x80000000u) != 0u;
+        if (cold) atomicOr(&tile_marks[d0.w >> 5], 1u << (d0.w & 31u));
+      }
+      __syncthreads();
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -1025,7 +1070,7 @@ constexpr int kFoldWaves = 4;
 __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
     const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ sorted_val, const uint32_t* __restrict__ nd_dev,
     uint32_t r1_log2, const uint32_t* __restrict__ vj0, const uint32_t* __restrict__ masks,
-    const uint8_t* __restrict__ rgb, uint32_t* __restrict__ rgbw, const uint32_t* __restrict__ num_heads) {
+    const uint8_t* __restrict__ rgb, uint32_t* __restrict__ rgbw, const uint32_t* __restrict__ num_heads, TileMap tmap) {
   __shared__ uint32_t stage[kFoldWaves][256];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const uint32_t nvox = *num_heads, nd = *nd_dev;
@@ -1053,7 +1098,7 @@ __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
           const uint4 a = m4[q];
           m[4 * q] = a.x; m[4 * q + 1] = a.y; m[4 * q + 2] = a.z; m[4 * q + 3] = a.w;
         }
-        p0 = (val >> r1_log2) * (uint32_t)kWalkRays;
+        p0 = tmap.tile_of(val >> r1_log2) * (uint32_t)kWalkRays;
 #pragma unroll
         for (int w = 0; w < kMaskWords; ++w) cnt += (uint32_t)__popc(m[w]);
       }

@@ -50,6 +50,29 @@ def allgather_block_lists(local_ids, count, cap, group=None, padded=False):
     return [lists[r][: int(cnts[r].item())] for r in range(world)]
 
 
+def exchange_segments(send_seg, send_rec, send_counts, group=None):
+    """The all-to-all of the ray-sharded integrate (TsdfChisel.shard_walk / shard_pack / shard_apply).
+
+    send_seg [S, 8] / send_rec [R, 4] int32 tensors grouped by destination rank in rank order, send_counts
+    [world, 2] (segments, records per destination).  Returns (recv_seg, recv_rec, recv_counts) grouped by
+    source rank.  Three collectives: the counts, then the two payloads (all_to_all_single with split sizes —
+    RCCL send/recv pairs over xGMI on GPUs, gloo in the CPU tests)."""
+    world = dist.get_world_size(group)
+    dev = send_seg.device
+    sc = torch.as_tensor(np.ascontiguousarray(send_counts, dtype=np.int64).reshape(world, 2)).to(dev)
+    rc = torch.zeros_like(sc)
+    dist.all_to_all_single(rc, sc, group=group)
+    recv_counts = rc.cpu().numpy()
+    send_counts = np.asarray(send_counts, dtype=np.int64).reshape(world, 2)
+    recv_seg = torch.zeros((int(recv_counts[:, 0].sum()), 8), dtype=send_seg.dtype, device=dev)
+    recv_rec = torch.zeros((int(recv_counts[:, 1].sum()), 4), dtype=send_rec.dtype, device=dev)
+    dist.all_to_all_single(recv_seg, send_seg, output_split_sizes=[int(c) for c in recv_counts[:, 0]],
+                           input_split_sizes=[int(c) for c in send_counts[:, 0]], group=group)
+    dist.all_to_all_single(recv_rec, send_rec, output_split_sizes=[int(c) for c in recv_counts[:, 1]],
+                           input_split_sizes=[int(c) for c in send_counts[:, 1]], group=group)
+    return recv_seg, recv_rec, recv_counts
+
+
 class BlockDirectory:
     """plvs_block_directory (include/plvs_hip.h): the global block id -> owner rank table a rank keeps from the
     gathered lists.  Imports the HIP library on first use (this module itself needs numpy + torch only)."""

@@ -103,6 +103,34 @@ class TsdfChisel:
             self._h, _lib.t_ptr(d_xyz), _lib.t_ptr(d_rgb), _lib.t_ptr(d_kfid), _lib.np_ptr(offsets),
             offsets.shape[0] - 1, _lib.t_ptr(d_Twc), _lib.current_stream_ptr()))
 
+    # ---- ray-sharded multi-GPU integrate (order_free, shard_count > 1): walk -> pack -> exchange -> apply
+    def shard_walk(self, d_xyz, offsets, d_Twc):
+        """Phase 1: this rank walks its tiles of the point stream (tile t belongs to rank t % shard_count).
+        Returns the int64 array [shard_count, 2] of (segments, records) bound for every rank."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        counts = np.zeros((self.params.shard_count, 2), np.int64)
+        f = _lib.lib.plvs_hip_tsdf_chisel_shard_walk
+        f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 3
+        _lib.check(f(self._h, _lib.t_ptr(d_xyz), _lib.np_ptr(offsets), offsets.shape[0] - 1, _lib.t_ptr(d_Twc),
+                     _lib.np_ptr(counts), _lib.current_stream_ptr()))
+        return counts
+
+    def shard_pack(self, d_seg, d_rec):
+        """Phase 2: fills the send buffers (torch int32 tensors [sum segments, 8] and [sum records, 4]), grouped
+        by destination rank in rank order."""
+        f = _lib.lib.plvs_hip_tsdf_chisel_shard_pack
+        f.argtypes = [ctypes.c_void_p] * 4
+        _lib.check(f(self._h, _lib.t_ptr(d_seg), _lib.t_ptr(d_rec), _lib.current_stream_ptr()))
+
+    def shard_apply(self, d_seg, d_rec, recv_counts, d_xyz, d_rgb, d_kfid):
+        """Phase 3: the received buffers (grouped by source rank in rank order; recv_counts [shard_count, 2]) are
+        applied to this rank's chunks; colours of voxels below weight 254 through a walk of the marked tiles."""
+        recv_counts = np.ascontiguousarray(recv_counts, dtype=np.int64)
+        f = _lib.lib.plvs_hip_tsdf_chisel_shard_apply
+        f.argtypes = [ctypes.c_void_p] * 8
+        _lib.check(f(self._h, _lib.t_ptr(d_seg), _lib.t_ptr(d_rec), _lib.np_ptr(recv_counts), _lib.t_ptr(d_xyz),
+                     _lib.t_ptr(d_rgb), _lib.t_ptr(d_kfid), _lib.current_stream_ptr()))
+
     def last_stats(self):
         s = _lib.TsdfStats()
         _lib.check(_lib.lib.plvs_hip_tsdf_chisel_last_stats(self._h, ctypes.byref(s)))
