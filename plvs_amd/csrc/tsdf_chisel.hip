@@ -757,9 +757,11 @@ struct plvs_tsdf_chisel {
   float scale_u = 1.f, scale_w = 1.f;   // fixed-point scales of the order-free accumulators (powers of two)
   int stage_set = 0;                    // which pipeline the stage times belong to
   // ray-sharded multi-GPU integrate (tsdf_shard.hpp)
-  Directory xdir{};                  // the call's scratch directory: every chunk the rank's tiles touch
+  Directory xdir{};                  // the walk directory: every chunk the rank's tiles have crossed (ids only)
   int32_t* d_xcount = nullptr;
-  DevBuf<uint32_t> sh_nrec, sh_owner, sh_seg_dst, sh_rec_dst, sh_obase, sh_src_off, sh_marks, sh_tiles;
+  uint32_t* x_sat = nullptr;         //   + one bit per voxel: its owner has reported the colour saturated
+  DevBuf<uint32_t> sh_nrec, sh_owner, sh_slot_owner, sh_seg_dst, sh_rec_dst, sh_obase, sh_src_off, sh_run_ctr, sh_vkey, sh_sat;
+  uint32_t sh_nt = 0, sh_runs = 0, sh_nsat = 0;
   DevBuf<long long> sh_counts;
   long long* h_sh_counts = nullptr;  // pinned
   int sh_n = 0, sh_nclouds = 0;      // the call in flight (shard_walk -> shard_pack -> shard_apply)
@@ -868,8 +870,8 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
                (uint32_t)std::min<size_t>(seg_own + seg_spill, 0xFFFFFFFFu), h->w_seg_cnt.p, h->w_tile_visits.p};
     RunOut runs{h->w_runkey.p, h->w_masks.p, h->w_run_cnt.p, h->run_r1_log2};
     hipLaunchKernelGGL((walk_tiles<true, true>), dim3(ntiles), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
-                       h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw, out, runs,
-                       TileMap{nullptr, 1u, 0u});
+                       h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
+                       (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u});
     PLVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
     STAGE_MARK(1);
     const unsigned seg_blocks = ceil_div(seg_own + seg_spill, kSegSpan);
@@ -885,7 +887,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     STAGE_MARK(2);
     hipLaunchKernelGGL(apply_chunks, dim3(4096), dim3(kApplyThreads), 0, s, h->w_sorted_seg.p, h->updated.p,
                        h->w_active_off.p, h->w_rec.p, 1.0 / (double)h->scale_u, 1.0 / (double)h->scale_w, d_kfid, h->sdf,
-                       h->weight, h->kfid, h->d_wctr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+                       h->weight, h->kfid, h->d_wctr);
     PLVS_KERNEL_CHECK();
     STAGE_MARK(3);
     // ---- colour fold: the truncating u8 mean is order dependent -> through the sorted runs of the voxels
@@ -915,8 +917,9 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
                              h->heads.p, h->w_dummy.p, h->d_wctr + 1);
         }
         hipLaunchKernelGGL(fold_colours_masks, dim3(std::min<size_t>(ceil_div(D, kFoldWaves), 8192)),
-                           dim3(64 * kFoldWaves), 0, h->side, skeys, sval, side_ctr, h->run_r1_log2, h->heads.p,
-                           h->w_masks.p, d_rgb, h->rgbw, &h->d_wctr[1].num_heads, TileMap{nullptr, 1u, 0u});
+                           dim3(64 * kFoldWaves), 0, h->side, skeys, sval, side_ctr,
+                           RunSrc{h->w_masks.p, (uint32_t)kMaskWords, h->run_r1_log2, TileMap{1u, 0u}}, h->heads.p, d_rgb,
+                           h->rgbw, &h->d_wctr[1].num_heads, (uint32_t*)nullptr, (uint32_t*)nullptr);
         PLVS_KERNEL_CHECK();
       }
       PLVS_HIP_TRY(hipEventRecord(h->ev_join, h->side));
@@ -1081,13 +1084,15 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   (void)hipFree(h->xdir.slots);
   (void)hipFree(h->xdir.slot_ids);
   (void)hipFree(h->d_xcount);
+  (void)hipFree(h->x_sat);
   if (h->h_sh_counts) (void)hipHostFree(h->h_sh_counts);
   h->w_rec.release(); h->w_seg.release(); h->w_sorted_seg.release(); h->w_chunk_nseg.release();
   h->w_chunk_off.release(); h->w_chunk_fill.release(); h->w_active_off.release(); h->w_masks.release();
   h->w_dummy.release(); h->w_cold.release(); h->w_runkey.release(); h->w_run_cnt.release(); h->w_run_off.release(); h->w_val0.release();
   h->w_val1.release(); h->w_seg_cnt.release(); h->w_tile_visits.release();
   h->sh_nrec.release(); h->sh_owner.release(); h->sh_seg_dst.release(); h->sh_rec_dst.release(); h->sh_obase.release();
-  h->sh_src_off.release(); h->sh_marks.release(); h->sh_tiles.release(); h->sh_counts.release();
+  h->sh_src_off.release(); h->sh_slot_owner.release(); h->sh_run_ctr.release(); h->sh_vkey.release(); h->sh_sat.release();
+  h->sh_counts.release();
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->side) (void)hipStreamDestroy(h->side);
@@ -1105,8 +1110,14 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   return PLVS_OK;
 }
 
+static int shard_state_clear(plvs_tsdf_chisel* h);
+
 int plvs_hip_tsdf_chisel_clear(plvs_tsdf_chisel* h) {
   PLVS_REQUIRE(h, "null handle");
+  {
+    int rc = shard_state_clear(h);   // (the walk directory of the ray-sharded integrate, if in use)
+    if (rc != PLVS_OK) return rc;
+  }
   const size_t cap = (size_t)h->dir.mask + 1;
   const size_t nvox = (size_t)h->prm.max_chunks * kChunkVox;
   PLVS_HIP_TRY(hipMemset(h->dir.keys, 0xFF, cap * sizeof(unsigned long long)));
@@ -1610,16 +1621,34 @@ bool chisel_map_view(plvs_tsdf_chisel* h, ChiselMapView* v) {
 // ------------------------------------------------------------------ ray-sharded integrate (tsdf_shard.hpp)
 static int shard_state_init(plvs_tsdf_chisel* h) {
   if (h->xdir.keys) return PLVS_OK;
-  const size_t cap = (size_t)h->dir.mask + 1;
-  h->xdir = h->dir;
-  h->xdir.keys = nullptr;
-  h->xdir.slots = nullptr;
-  h->xdir.slot_ids = nullptr;
+  // the walk directory: every chunk of the whole map may pass through it (ids + 512 B of bits each)
+  const size_t xmax = std::min<size_t>((size_t)h->prm.max_chunks * (size_t)h->prm.shard_count, (size_t)1 << 22);
+  size_t cap = 1024;
+  while (cap < 2 * xmax) cap <<= 1;
+  h->xdir.mask = (uint32_t)(cap - 1);
+  h->xdir.max_blocks = (int32_t)xmax;
   PLVS_HIP_TRY(hipMalloc((void**)&h->xdir.keys, cap * sizeof(unsigned long long)));
   PLVS_HIP_TRY(hipMalloc((void**)&h->xdir.slots, cap * sizeof(int32_t)));
-  PLVS_HIP_TRY(hipMalloc((void**)&h->xdir.slot_ids, (size_t)h->prm.max_chunks * 3 * sizeof(int32_t)));
-  PLVS_HIP_TRY(hipMalloc((void**)&h->d_xcount, sizeof(int32_t)));
-  PLVS_HIP_TRY(hipHostMalloc((void**)&h->h_sh_counts, (size_t)2 * h->prm.shard_count * sizeof(long long)));
+  PLVS_HIP_TRY(hipMalloc((void**)&h->xdir.slot_ids, xmax * 3 * sizeof(int32_t)));
+  PLVS_HIP_TRY(hipMalloc((void**)&h->x_sat, xmax * (kChunkVox / 32) * sizeof(uint32_t)));
+  PLVS_HIP_TRY(hipMalloc((void**)&h->d_xcount, 4 * sizeof(int32_t)));   // [0] chunks, [1] error bits, [2] saturated this call
+  PLVS_HIP_TRY(hipHostMalloc((void**)&h->h_sh_counts, (size_t)3 * h->prm.shard_count * sizeof(long long)));
+  PLVS_HIP_TRY(hipMemset(h->xdir.keys, 0xFF, cap * sizeof(unsigned long long)));
+  PLVS_HIP_TRY(hipMemset(h->xdir.slots, 0xFF, cap * sizeof(int32_t)));
+  PLVS_HIP_TRY(hipMemset(h->x_sat, 0, xmax * (kChunkVox / 32) * sizeof(uint32_t)));
+  PLVS_HIP_TRY(hipMemset(h->d_xcount, 0, 4 * sizeof(int32_t)));
+  return PLVS_OK;
+}
+
+static int shard_state_clear(plvs_tsdf_chisel* h) {
+  if (!h->xdir.keys) return PLVS_OK;
+  const size_t cap = (size_t)h->xdir.mask + 1;
+  PLVS_HIP_TRY(hipMemset(h->xdir.keys, 0xFF, cap * sizeof(unsigned long long)));
+  PLVS_HIP_TRY(hipMemset(h->xdir.slots, 0xFF, cap * sizeof(int32_t)));
+  PLVS_HIP_TRY(hipMemset(h->x_sat, 0, (size_t)h->xdir.max_blocks * (kChunkVox / 32) * sizeof(uint32_t)));
+  PLVS_HIP_TRY(hipMemset(h->d_xcount, 0, 4 * sizeof(int32_t)));
+  h->sh_phase = 0;
+  h->sh_nsat = 0;
   return PLVS_OK;
 }
 
@@ -1629,11 +1658,12 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
                                     const float* d_Twc, int64_t* send_counts, void* stream) {
   PLVS_REQUIRE(h && send_counts, "null argument");
   PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
-  PLVS_REQUIRE(h->prm.order_free != 0 && h->prm.shard_count > 1, "the ray-sharded integrate needs order_free = 1 and shard_count > 1");
+  PLVS_REQUIRE(h->prm.order_free != 0 && h->prm.shard_count > 1 && h->prm.shard_count <= 64,
+               "the ray-sharded integrate needs order_free = 1 and 2 <= shard_count <= 64");
   PLVS_REQUIRE(offsets && nclouds >= 0, "bad offsets");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int N = h->prm.shard_count, rank = h->prm.shard_rank;
-  for (int p = 0; p < 2 * N; ++p) send_counts[p] = 0;
+  for (int p = 0; p < 3 * N; ++p) send_counts[p] = 0;
   h->sh_stats = plvs_tsdf_stats{};
   h->sh_phase = 0;
   const int n = nclouds > 0 ? offsets[nclouds] - offsets[0] : 0;
@@ -1641,80 +1671,85 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
   for (int c = 0; c < nclouds; ++c) PLVS_REQUIRE(offsets[c + 1] >= offsets[c], "offsets must be non-decreasing");
   int rc = shard_state_init(h);
   if (rc != PLVS_OK) return rc;
-  for (int p = 0; p < 2 * N; ++p) h->h_sh_counts[p] = 0;
+  for (int p = 0; p < 3 * N; ++p) h->h_sh_counts[p] = 0;
   h->sh_n = n;
   h->sh_nclouds = nclouds;
   h->sh_ntiles = (uint32_t)ceil_div((size_t)n, kWalkRays);
+  h->sh_nt = 0;
+  h->sh_runs = 0;
   h->sh_stats.points = n;
   h->sh_phase = 1;
   const uint32_t nt = h->sh_ntiles > (uint32_t)rank ? (h->sh_ntiles - (uint32_t)rank + (uint32_t)N - 1u) / (uint32_t)N : 0u;
-  if (n == 0) return PLVS_OK;
+  if (nt == 0) return PLVS_OK;
   PLVS_REQUIRE(d_xyz && d_Twc, "null device pointer");
-  const int max_chunks = h->prm.max_chunks;
-  // (every rank: an owner's colour walk needs the poses even when the rank itself has no tile to walk)
+  h->sh_nt = nt;
+  const size_t xmax = (size_t)h->xdir.max_blocks;
   PLVS_HIP_TRY(h->offsets.reserve((size_t)nclouds + 1));
   PLVS_HIP_TRY(h->poses.reserve((size_t)nclouds));
   PLVS_HIP_TRY(hipMemcpyAsync(h->offsets.p, offsets, ((size_t)nclouds + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(pose_prep, dim3(ceil_div((size_t)nclouds, 64)), dim3(64), 0, s, d_Twc, nclouds, h->poses.p);
-  if (nt == 0) {
-    PLVS_HIP_TRY(hipStreamSynchronize(s));   // (offsets is a host array of the caller)
-    return PLVS_OK;
-  }
-  PLVS_HIP_TRY(h->w_chunk_nseg.reserve((size_t)max_chunks));
-  PLVS_HIP_TRY(h->w_chunk_off.reserve((size_t)max_chunks + 1));
-  PLVS_HIP_TRY(h->w_chunk_fill.reserve((size_t)max_chunks));
-  PLVS_HIP_TRY(h->w_active_off.reserve((size_t)max_chunks + 1));
-  PLVS_HIP_TRY(h->updated.reserve((size_t)max_chunks + 1));
+  PLVS_HIP_TRY(h->w_chunk_nseg.reserve(xmax));
+  PLVS_HIP_TRY(h->w_chunk_off.reserve(xmax + 1));
+  PLVS_HIP_TRY(h->w_chunk_fill.reserve(xmax));
+  PLVS_HIP_TRY(h->w_active_off.reserve(xmax + 1));
+  PLVS_HIP_TRY(h->updated.reserve(xmax + 1));
   PLVS_HIP_TRY(h->w_seg_cnt.reserve(nt));
   PLVS_HIP_TRY(h->w_tile_visits.reserve(nt));
-  PLVS_HIP_TRY(h->sh_nrec.reserve((size_t)max_chunks));
-  PLVS_HIP_TRY(h->sh_owner.reserve((size_t)max_chunks));
-  PLVS_HIP_TRY(h->sh_seg_dst.reserve((size_t)max_chunks));
-  PLVS_HIP_TRY(h->sh_rec_dst.reserve((size_t)max_chunks));
+  PLVS_HIP_TRY(h->w_run_cnt.reserve(nt));
+  PLVS_HIP_TRY(h->w_run_off.reserve((size_t)nt + 1));
+  PLVS_HIP_TRY(h->sh_nrec.reserve(xmax));
+  PLVS_HIP_TRY(h->sh_owner.reserve(xmax));
+  PLVS_HIP_TRY(h->sh_slot_owner.reserve(xmax));
+  PLVS_HIP_TRY(h->sh_seg_dst.reserve(xmax));
+  PLVS_HIP_TRY(h->sh_rec_dst.reserve(xmax));
   PLVS_HIP_TRY(h->sh_obase.reserve((size_t)2 * N));
-  PLVS_HIP_TRY(h->sh_counts.reserve((size_t)2 * N));
+  PLVS_HIP_TRY(h->sh_run_ctr.reserve((size_t)3 * 64));   // counts, bases, fill cursors per destination
+  PLVS_HIP_TRY(h->sh_counts.reserve((size_t)3 * N));
   const size_t rec_own = (size_t)nt * kWalkLimit, seg_own = (size_t)nt * kWalkChunks;
   size_t rec_spill = std::max<size_t>(h->w_rec.cap > rec_own ? h->w_rec.cap - rec_own : 0, (size_t)1 << 16);
   size_t seg_spill = std::max<size_t>(h->w_seg.cap / 2 > seg_own ? h->w_seg.cap / 2 - seg_own : 0, (size_t)1 << 12);
   Params Pw = h->P;       // this rank walks its tiles through every chunk they cross
   Pw.shard_count = 1;
   Pw.shard_rank = 0;
-  const size_t cap = (size_t)h->xdir.mask + 1;
+  const TileMap tmap{(uint32_t)N, (uint32_t)rank};
+  uint32_t* const xerr = reinterpret_cast<uint32_t*>(h->d_xcount + 1);
   for (int attempt = 0;; ++attempt) {
     PLVS_HIP_TRY(h->w_rec.reserve(rec_own + rec_spill));
     PLVS_HIP_TRY(h->w_seg.reserve(2 * (seg_own + seg_spill)));
     PLVS_HIP_TRY(h->w_sorted_seg.reserve(h->w_seg.cap));
-    PLVS_HIP_TRY(hipMemsetAsync(h->xdir.keys, 0xFF, cap * sizeof(unsigned long long), s));
-    PLVS_HIP_TRY(hipMemsetAsync(h->xdir.slots, 0xFF, cap * sizeof(int32_t), s));
-    PLVS_HIP_TRY(hipMemsetAsync(h->d_xcount, 0, sizeof(int32_t), s));
+    PLVS_HIP_TRY(h->w_runkey.reserve((size_t)nt << h->run_r1_log2));
+    PLVS_HIP_TRY(h->w_masks.reserve(((size_t)nt << h->run_r1_log2) * kMaskWords));
+    PLVS_HIP_TRY(h->scratch.reserve(scan_scratch_words(nt)));
     PLVS_HIP_TRY(hipMemsetAsync(h->d_wctr, 0, 2 * sizeof(WalkCounters), s));
-    PLVS_HIP_TRY(hipMemsetAsync(h->w_chunk_nseg.p, 0, (size_t)max_chunks * sizeof(uint32_t), s));
+    PLVS_HIP_TRY(hipMemsetAsync(h->w_chunk_nseg.p, 0, xmax * sizeof(uint32_t), s));
+    PLVS_HIP_TRY(hipMemsetAsync(h->sh_run_ctr.p, 0, 3 * 64 * sizeof(uint32_t), s));
     AccOut out{h->w_rec.p, (uint32_t)std::min<size_t>(rec_own + rec_spill, 0xFFFFFFFFu), h->w_seg.p,
                (uint32_t)std::min<size_t>(seg_own + seg_spill, 0xFFFFFFFFu), h->w_seg_cnt.p, h->w_tile_visits.p};
-    RunOut runs{nullptr, nullptr, nullptr, 0u};
-    hipLaunchKernelGGL((walk_tiles<true, false>), dim3(nt), dim3(kWalkRays), 0, s, Pw, h->scale_u, h->scale_w, d_xyz, n,
-                       h->offsets.p, nclouds, h->poses.p, h->xdir, h->d_xcount, h->d_wctr, (const uint32_t*)nullptr, out,
-                       runs, TileMap{nullptr, (uint32_t)N, (uint32_t)rank});
+    RunOut runs{h->w_runkey.p, h->w_masks.p, h->w_run_cnt.p, h->run_r1_log2};
+    // (a chunk entered by an attempt that has to be repeated stays in the walk directory: harmless)
+    hipLaunchKernelGGL((walk_tiles<true, true>), dim3(nt), dim3(kWalkRays), 0, s, Pw, h->scale_u, h->scale_w, d_xyz, n,
+                       h->offsets.p, nclouds, h->poses.p, h->xdir, h->d_xcount, h->d_wctr, (const uint32_t*)nullptr,
+                       (const uint32_t*)h->x_sat, out, runs, tmap);
     const unsigned seg_blocks = ceil_div(seg_own + seg_spill, kSegSpan);
     hipLaunchKernelGGL(seg_pass<false>, dim3(seg_blocks), dim3(256), 0, s, h->w_seg.p, out.seg_cap, nt, h->w_seg_cnt.p,
                        h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p, h->d_wctr);
     hipLaunchKernelGGL(seg_scan, dim3(1), dim3(1024), 0, s, h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p,
-                       h->updated.p, h->w_active_off.p, h->d_wctr, h->d_xcount, max_chunks, h->w_tile_visits.p,
-                       (const uint32_t*)nullptr, nt);
+                       h->updated.p, h->w_active_off.p, h->d_wctr, h->d_xcount, (int)xmax, h->w_tile_visits.p,
+                       h->w_run_cnt.p, nt);
     hipLaunchKernelGGL(seg_pass<true>, dim3(seg_blocks), dim3(256), 0, s, h->w_seg.p, out.seg_cap, nt, h->w_seg_cnt.p,
                        h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p, h->d_wctr);
     hipLaunchKernelGGL(shard_chunk_totals, dim3(1024), dim3(256), 0, s, h->w_sorted_seg.p, h->updated.p,
-                       h->w_active_off.p, h->xdir.slot_ids, N, h->d_wctr, h->sh_nrec.p, h->sh_owner.p);
-    hipLaunchKernelGGL(shard_plan, dim3(1), dim3(1024), 0, s, h->w_active_off.p, h->sh_nrec.p, h->sh_owner.p, N,
-                       h->d_wctr, h->sh_seg_dst.p, h->sh_rec_dst.p, h->sh_counts.p, h->sh_obase.p);
+                       h->w_active_off.p, h->xdir.slot_ids, N, h->d_wctr, h->sh_nrec.p, h->sh_owner.p, h->sh_slot_owner.p);
     PLVS_KERNEL_CHECK();
-    PLVS_HIP_TRY(hipMemcpyAsync(h->h_sh_counts, h->sh_counts.p, (size_t)2 * N * sizeof(long long), hipMemcpyDeviceToHost, s));
+    // the runs, densely, in tile order (seg_scan has left their number in num_desc)
+    PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, nt, nullptr, h->scratch.p, s));
     PLVS_HIP_TRY(hipMemcpyAsync(h->h_wctr, h->d_wctr, sizeof(WalkCounters), hipMemcpyDeviceToHost, s));
+    PLVS_HIP_TRY(hipMemcpyAsync(h->h_ctr, h->d_xcount, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     PLVS_HIP_TRY(hipStreamSynchronize(s));
     const uint32_t err = h->h_wctr->err;
     if (err & kErrPoolFull) {
       h->poisoned = true;
-      plvs::set_error("tsdf_chisel shard_walk: one call touches more chunks than max_chunks (the scratch directory is full)");
+      plvs::set_error("tsdf_chisel shard_walk: the walk directory is full (max_chunks x shard_count chunks)");
       return PLVS_ERR_CAPACITY;
     }
     if (err & ~kErrScratch) return walk_fail(h, err);
@@ -1722,63 +1757,88 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
       if (attempt >= 8) return walk_fail(h, err);
       rec_spill = std::max<size_t>(rec_spill, (size_t)h->h_wctr->rec_top * 2);
       seg_spill = std::max<size_t>(seg_spill, (size_t)h->h_wctr->seg_top * 2);
+      while ((1u << h->run_r1_log2) < h->h_wctr->run_need) ++h->run_r1_log2;
+      if (((size_t)nt << h->run_r1_log2) >= 0xFFFFFFFFull) return walk_fail(h, err);
       continue;
     }
     break;
   }
-  for (int p = 0; p < 2 * N; ++p) send_counts[p] = (int64_t)h->h_sh_counts[p];
+  const uint32_t D = h->h_wctr->num_desc;
+  h->sh_runs = D;
+  uint32_t* const rc_counts = h->sh_run_ctr.p;
+  if (D > 0) {
+    PLVS_HIP_TRY(h->dkey0.reserve(D));
+    PLVS_HIP_TRY(h->w_val0.reserve(D));
+    hipLaunchKernelGGL(compact_runs, dim3(ceil_div(nt, 4)), dim3(256), 0, s, h->w_runkey.p, h->w_run_cnt.p,
+                       h->w_run_off.p, nt, h->run_r1_log2, h->dkey0.p, h->w_val0.p);
+    hipLaunchKernelGGL(shard_run_count, dim3(256), dim3(256), 0, s, h->dkey0.p, &h->d_wctr[0].num_desc,
+                       h->sh_slot_owner.p, N, rc_counts);
+  }
+  hipLaunchKernelGGL(shard_plan, dim3(1), dim3(1024), 0, s, h->w_active_off.p, h->sh_nrec.p, h->sh_owner.p, N,
+                     h->d_wctr, h->sh_seg_dst.p, h->sh_rec_dst.p, h->sh_counts.p, h->sh_obase.p, rc_counts,
+                     rc_counts + 64, rc_counts + 128);
+  PLVS_KERNEL_CHECK();
+  PLVS_HIP_TRY(hipMemcpyAsync(h->h_sh_counts, h->sh_counts.p, (size_t)3 * N * sizeof(long long), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  (void)xerr;
+  for (int p = 0; p < 3 * N; ++p) send_counts[p] = (int64_t)h->h_sh_counts[p];
   h->sh_stats.visits = (int64_t)h->h_wctr->total_visits;
   return PLVS_OK;
 }
 
-int plvs_hip_tsdf_chisel_shard_pack(plvs_tsdf_chisel* h, void* d_seg_dst, void* d_rec_dst, void* stream) {
+int plvs_hip_tsdf_chisel_shard_pack(plvs_tsdf_chisel* h, void* d_seg_dst, void* d_rec_dst, void* d_run_dst, void* stream) {
   PLVS_REQUIRE(h, "null handle");
   PLVS_REQUIRE(h->sh_phase == 1, "shard_pack follows shard_walk");
   hipStream_t s = static_cast<hipStream_t>(stream);
   h->sh_phase = 2;
   long long nseg = 0;
-  for (int p = 0; p < h->prm.shard_count; ++p) nseg += h->h_sh_counts ? h->h_sh_counts[2 * p] : 0;
+  for (int p = 0; p < h->prm.shard_count; ++p) nseg += h->h_sh_counts ? h->h_sh_counts[3 * p] : 0;
   if (nseg == 0) return PLVS_OK;
-  PLVS_REQUIRE(d_seg_dst && d_rec_dst, "null send buffer");
+  PLVS_REQUIRE(d_seg_dst && d_rec_dst && (h->sh_runs == 0 || d_run_dst), "null send buffer");
   hipLaunchKernelGGL(shard_pack_segments, dim3(2048), dim3(256), 0, s, h->w_sorted_seg.p, h->w_rec.p, h->updated.p,
                      h->w_active_off.p, h->xdir.slot_ids, h->sh_owner.p, h->sh_seg_dst.p, h->sh_rec_dst.p, h->sh_obase.p,
                      h->d_wctr, static_cast<uint4*>(d_seg_dst), static_cast<uint4*>(d_rec_dst));
+  if (h->sh_runs > 0)
+    hipLaunchKernelGGL(shard_run_pack, dim3(std::min<size_t>(ceil_div((size_t)h->sh_runs, kRunSpan), 4096)), dim3(256), 0, s,
+                       h->dkey0.p, h->w_val0.p, &h->d_wctr[0].num_desc, h->w_masks.p, h->run_r1_log2,
+                       TileMap{(uint32_t)h->prm.shard_count, (uint32_t)h->prm.shard_rank}, h->xdir.slot_ids,
+                       h->sh_slot_owner.p, h->sh_run_ctr.p + 64, h->sh_run_ctr.p + 128, static_cast<uint32_t*>(d_run_dst));
   PLVS_KERNEL_CHECK();
   return PLVS_OK;
 }
 
 int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src, const void* d_rec_src,
-                                     const int64_t* recv_counts, const float* d_xyz, const uint8_t* d_rgb,
+                                     const void* d_run_src, const int64_t* recv_counts, const uint8_t* d_rgb,
                                      const uint32_t* d_kfid, void* stream) {
   PLVS_REQUIRE(h && recv_counts, "null argument");
   PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
   PLVS_REQUIRE(h->sh_phase == 2, "shard_apply follows shard_pack");
   hipStream_t s = static_cast<hipStream_t>(stream);
   h->sh_phase = 0;
+  h->sh_nsat = 0;
   const int N = h->prm.shard_count;
   const int max_chunks = h->prm.max_chunks;
   std::vector<uint32_t> src_off(2 * ((size_t)N + 1));
-  size_t tseg = 0, trec = 0;
+  size_t tseg = 0, trec = 0, trun = 0;
   for (int q = 0; q < N; ++q) {
-    PLVS_REQUIRE(recv_counts[2 * q] >= 0 && recv_counts[2 * q + 1] >= 0, "negative receive count");
+    PLVS_REQUIRE(recv_counts[3 * q] >= 0 && recv_counts[3 * q + 1] >= 0 && recv_counts[3 * q + 2] >= 0, "negative receive count");
     src_off[q] = (uint32_t)tseg;
     src_off[N + 1 + q] = (uint32_t)trec;
-    tseg += (size_t)recv_counts[2 * q];
-    trec += (size_t)recv_counts[2 * q + 1];
+    tseg += (size_t)recv_counts[3 * q];
+    trec += (size_t)recv_counts[3 * q + 1];
+    trun += (size_t)recv_counts[3 * q + 2];
   }
   src_off[N] = (uint32_t)tseg;
   src_off[2 * N + 1] = (uint32_t)trec;
-  PLVS_REQUIRE(tseg < 0x7FFFFFFFull && trec < 0xFFFFFFFFull, "receive buffers beyond the index range (split the batch)");
+  PLVS_REQUIRE(tseg < 0x7FFFFFFFull && trec < 0xFFFFFFFFull && trun < 0x7FFFFFFFull,
+               "receive buffers beyond the index range (split the batch)");
   h->stats = h->sh_stats;
   h->last_updated = 0;
   h->stage_set = 1;
   if (tseg == 0) return PLVS_OK;
-  PLVS_REQUIRE(d_seg_src && d_rec_src && d_xyz && d_rgb, "null device pointer");
+  PLVS_REQUIRE(d_seg_src && d_rec_src && d_rgb && (trun == 0 || d_run_src), "null device pointer");
   const uint32_t total = (uint32_t)tseg;
-  const uint32_t nwords = (uint32_t)ceil_div((size_t)h->sh_ntiles, 32);
   PLVS_HIP_TRY(h->sh_src_off.reserve(src_off.size()));
-  PLVS_HIP_TRY(h->sh_marks.reserve((size_t)nwords + 1));
-  PLVS_HIP_TRY(h->sh_tiles.reserve((size_t)h->sh_ntiles + 1));
   PLVS_HIP_TRY(h->w_seg.reserve(2 * (size_t)total));
   PLVS_HIP_TRY(h->w_sorted_seg.reserve(2 * (size_t)total));
   PLVS_HIP_TRY(h->w_chunk_nseg.reserve((size_t)max_chunks));
@@ -1793,7 +1853,7 @@ int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src,
   PLVS_HIP_TRY(hipMemsetAsync(h->d_wctr, 0, 2 * sizeof(WalkCounters), s));
   PLVS_HIP_TRY(hipMemcpyAsync(&h->d_wctr[0].seg_top, &total, sizeof(uint32_t), hipMemcpyHostToDevice, s));
   PLVS_HIP_TRY(hipMemsetAsync(h->w_chunk_nseg.p, 0, (size_t)max_chunks * sizeof(uint32_t), s));
-  PLVS_HIP_TRY(hipMemsetAsync(h->sh_marks.p, 0, ((size_t)nwords + 1) * sizeof(uint32_t), s));
+  PLVS_HIP_TRY(hipMemsetAsync(h->d_xcount + 2, 0, sizeof(int32_t), s));
 #define STAGE_MARK(i) \
   do { if (h->profiling) PLVS_HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
   STAGE_MARK(0);
@@ -1812,69 +1872,61 @@ int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src,
   STAGE_MARK(2);
   hipLaunchKernelGGL(apply_chunks, dim3(4096), dim3(kApplyThreads), 0, s, h->w_sorted_seg.p, h->updated.p,
                      h->w_active_off.p, static_cast<const uint4*>(d_rec_src), 1.0 / (double)h->scale_u,
-                     1.0 / (double)h->scale_w, d_kfid, h->sdf, h->weight, h->kfid, h->d_wctr, (const uint32_t*)h->rgbw,
-                     h->sh_marks.p);
-  hipLaunchKernelGGL(shard_list_tiles, dim3(1), dim3(1024), 0, s, h->sh_marks.p, nwords, h->sh_tiles.p,
-                     &h->d_wctr[0].ncold);
+                     1.0 / (double)h->scale_w, d_kfid, h->sdf, h->weight, h->kfid, h->d_wctr);
   PLVS_KERNEL_CHECK();
   STAGE_MARK(3);
+  // ---- colours: the received runs, by (voxel, tile)
+  if (trun > 0) {
+    const uint32_t R = (uint32_t)trun;
+    const uint32_t* runs = static_cast<const uint32_t*>(d_run_src);
+    PLVS_HIP_TRY(h->dkey0.reserve(R));
+    PLVS_HIP_TRY(h->dkey1.reserve(R));
+    PLVS_HIP_TRY(h->w_val0.reserve(R));
+    PLVS_HIP_TRY(h->w_val1.reserve(R));
+    PLVS_HIP_TRY(h->sh_vkey.reserve(R));
+    PLVS_HIP_TRY(h->heads.reserve(R));
+    PLVS_HIP_TRY(h->sh_sat.reserve(R));
+    PLVS_HIP_TRY(h->w_dummy.reserve((size_t)max_chunks + 1));
+    PLVS_HIP_TRY(h->scratch.reserve(radix_scratch_words(R)));
+    uint32_t* const err = &h->d_wctr[0].err;
+    hipLaunchKernelGGL(shard_run_translate, dim3(ceil_div((size_t)R, 256)), dim3(256), 0, s, runs, R, h->dir, err,
+                       h->sh_vkey.p, h->dkey0.p, h->w_val0.p);
+    int tile_bits = 1;
+    while ((1ull << tile_bits) < (unsigned long long)h->sh_ntiles) ++tile_bits;
+    bool second = false;
+    PLVS_HIP_TRY(radix_sort_pairs(h->dkey0.p, h->w_val0.p, h->dkey1.p, h->w_val1.p, R, 0, tile_bits, h->scratch.p, s, &second));
+    uint32_t* order = second ? h->w_val1.p : h->w_val0.p;
+    uint32_t* other = second ? h->w_val0.p : h->w_val1.p;
+    uint32_t* k_in = second ? h->dkey0.p : h->dkey1.p;   // the key buffer the tile sort has left free
+    uint32_t* k_out = second ? h->dkey1.p : h->dkey0.p;
+    hipLaunchKernelGGL(shard_gather_keys, dim3(ceil_div((size_t)R, 256)), dim3(256), 0, s, h->sh_vkey.p, order, R, k_in);
+    // the chunk count after this call's insertions bounds the voxel keys; it is read below with the counters, so
+    // take the pool capacity as the bound here
+    int key_bits = 12;
+    while ((1ll << (key_bits - 12)) < (long long)max_chunks) ++key_bits;
+    PLVS_HIP_TRY(radix_sort_pairs(k_in, order, k_out, other, R, 0, key_bits, h->scratch.p, s, &second));
+    const uint32_t* skeys = second ? k_out : k_in;
+    const uint32_t* sval = second ? other : order;
+    PLVS_HIP_TRY(hipMemcpyAsync(&h->d_wctr[1].num_desc, &R, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(voxel_heads, dim3(ceil_div(R, 256 * kHeadTiles)), dim3(256), 0, s, skeys, R, h->heads.p,
+                       h->w_dummy.p, h->d_wctr + 1);
+    hipLaunchKernelGGL(fold_colours_masks, dim3(std::min<size_t>(ceil_div(R, kFoldWaves), 8192)), dim3(64 * kFoldWaves), 0, s,
+                       skeys, sval, &h->d_wctr[1].num_desc, RunSrc{runs, kWireRun, 0u, TileMap{1u, 0u}}, h->heads.p, d_rgb,
+                       h->rgbw, &h->d_wctr[1].num_heads, h->sh_sat.p, reinterpret_cast<uint32_t*>(h->d_xcount + 2));
+    PLVS_KERNEL_CHECK();
+  }
+  STAGE_MARK(4);
+  PLVS_HIP_TRY(hipMemcpyAsync(h->h_sh_counts, h->d_xcount + 2, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   int rc = read_walk_counters(h, s);
   if (rc != PLVS_OK) return rc;
   if (h->h_wctr->err) return walk_fail(h, h->h_wctr->err);
-  const uint32_t ncold = h->h_wctr->ncold;
+  h->sh_nsat = (uint32_t)(*reinterpret_cast<int32_t*>(h->h_sh_counts));
   h->num_chunks = h->h_ctr->num_chunks;
   h->stats.new_chunks = h->num_chunks - chunks_before;
   h->stats.updated_chunks = (int32_t)h->h_wctr->num_updated;
   h->stats.voxels = (int32_t)h->h_wctr->num_heads;
   h->stats.max_run = (int32_t)h->h_wctr->max_run;
   h->last_updated = h->h_wctr->num_updated;
-  // ---- colours: the owner walks the marked tiles itself (visits filtered to its chunks) for their runs
-  if (ncold > 0) {
-    PLVS_HIP_TRY(h->w_run_cnt.reserve(ncold));
-    PLVS_HIP_TRY(h->w_run_off.reserve((size_t)ncold + 1));
-    PLVS_HIP_TRY(h->scratch.reserve(scan_scratch_words(ncold)));
-    const TileMap tmap{h->sh_tiles.p, 1u, 0u};
-    for (int attempt = 0;; ++attempt) {
-      PLVS_HIP_TRY(h->w_runkey.reserve((size_t)ncold << h->run_r1_log2));
-      PLVS_HIP_TRY(h->w_masks.reserve(((size_t)ncold << h->run_r1_log2) * kMaskWords));
-      PLVS_HIP_TRY(hipMemsetAsync(h->d_wctr, 0, 2 * sizeof(WalkCounters), s));
-      AccOut out{nullptr, 0u, nullptr, 0u, nullptr, nullptr};
-      RunOut runs{h->w_runkey.p, h->w_masks.p, h->w_run_cnt.p, h->run_r1_log2};
-      hipLaunchKernelGGL((walk_tiles<false, true>), dim3(ncold), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w,
-                         d_xyz, h->sh_n, h->offsets.p, h->sh_nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr,
-                         h->rgbw, out, runs, tmap);
-      PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, ncold, &h->d_wctr[1].num_desc, h->scratch.p, s));
-      PLVS_KERNEL_CHECK();
-      rc = read_walk_counters(h, s);
-      if (rc != PLVS_OK) return rc;
-      const uint32_t err = h->h_wctr->err;
-      if (err & ~kErrScratch) return walk_fail(h, err);
-      if (err & kErrScratch) {
-        if (attempt >= 8) return walk_fail(h, err);
-        while ((1u << h->run_r1_log2) < h->h_wctr->run_need) ++h->run_r1_log2;
-        if (((size_t)ncold << h->run_r1_log2) >= 0xFFFFFFFFull) return walk_fail(h, err);
-        continue;
-      }
-      break;
-    }
-    const uint32_t D = h->h_wctr[1].num_desc;
-    if (D > 0) {
-      const uint32_t* skeys = nullptr;
-      const uint32_t* sval = nullptr;
-      rc = sort_runs(h, D, ncold, h->h_ctr->num_chunks, s, &skeys, &sval);
-      if (rc != PLVS_OK) return rc;
-      PLVS_HIP_TRY(h->heads.reserve(D));
-      PLVS_HIP_TRY(h->w_dummy.reserve((size_t)max_chunks + 1));
-      hipLaunchKernelGGL(voxel_heads, dim3(ceil_div(D, 256 * kHeadTiles)), dim3(256), 0, s, skeys, D, h->heads.p,
-                         h->w_dummy.p, h->d_wctr + 1);
-      hipLaunchKernelGGL(fold_colours_masks, dim3(std::min<size_t>(ceil_div(D, kFoldWaves), 8192)), dim3(64 * kFoldWaves), 0,
-                         s, skeys, sval, &h->d_wctr[1].num_desc, h->run_r1_log2, h->heads.p, h->w_masks.p, d_rgb, h->rgbw,
-                         &h->d_wctr[1].num_heads, tmap);
-      PLVS_KERNEL_CHECK();
-    }
-  }
-  STAGE_MARK(4);
-  PLVS_HIP_TRY(hipStreamSynchronize(s));
   if (h->profiling) {
     for (int i = 0; i < 4; ++i) {
       float ms = 0.f;
@@ -1884,6 +1936,36 @@ int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src,
     h->prof_calls++;
   }
 #undef STAGE_MARK
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_chisel_shard_saturated(plvs_tsdf_chisel* h, int32_t* d_voxels, int cap, int* n, void* stream) {
+  PLVS_REQUIRE(h && n, "null argument");
+  *n = (int)h->sh_nsat;
+  if (h->sh_nsat == 0) return PLVS_OK;
+  if (cap < (int)h->sh_nsat) {
+    plvs::set_error("shard_saturated: %u voxels, room for %d", h->sh_nsat, cap);
+    return PLVS_ERR_CAPACITY;
+  }
+  PLVS_REQUIRE(d_voxels, "null output");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(shard_saturated_ids, dim3(ceil_div((size_t)h->sh_nsat, 256)), dim3(256), 0, s, h->sh_sat.p, h->sh_nsat,
+                     h->dir.slot_ids, d_voxels);
+  PLVS_KERNEL_CHECK();
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_chisel_shard_note_saturated(plvs_tsdf_chisel* h, const int32_t* d_voxels, int n, void* stream) {
+  PLVS_REQUIRE(h && n >= 0, "bad argument");
+  PLVS_REQUIRE(h->prm.order_free != 0 && h->prm.shard_count > 1, "not a ray-sharded map");
+  if (n == 0) return PLVS_OK;
+  PLVS_REQUIRE(d_voxels, "null list");
+  int rc = shard_state_init(h);
+  if (rc != PLVS_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(shard_note_saturated, dim3(ceil_div((size_t)n, 256)), dim3(256), 0, s, d_voxels, (uint32_t)n, h->xdir,
+                     h->d_xcount, reinterpret_cast<uint32_t*>(h->d_xcount + 1), h->x_sat);
+  PLVS_KERNEL_CHECK();
   return PLVS_OK;
 }
 

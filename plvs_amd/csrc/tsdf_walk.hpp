@@ -376,24 +376,24 @@ __device__ __forceinline__ uint4 pack_suboffsets(const uint32_t* o) {
   return make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
 }
 
-// Which tile of the point stream a workgroup takes: its block index itself (the whole stream on one device),
-// every stride-th tile (a rank of the ray-sharded multi-GPU integrate) or an entry of an ascending list (the
-// tiles an owner re-walks for the colours).  The output regions are indexed by the block ("local tile").
+// Which tile of the point stream a workgroup takes: its block index itself (the whole stream on one device) or
+// every stride-th tile (a rank of the ray-sharded multi-GPU integrate).  The output regions are indexed by the
+// block ("local tile").
 struct TileMap {
-  const uint32_t* list;
   uint32_t stride, first;
-  __device__ __host__ uint32_t tile_of(uint32_t local) const { return list ? list[local] : local * stride + first; }
+  __device__ __host__ uint32_t tile_of(uint32_t local) const { return local * stride + first; }
 };
 
-// Order-free accumulation (kAcc: records + segments) and/or the runs of the voxels whose colour weight is
-// below 254 (kRuns).  Both: the single-device integrate; kAcc alone: a rank's share of the rays in the
-// ray-sharded integrate (dir = the call's scratch directory); kRuns alone: the owner's colour walk.
+// Order-free accumulation (records + segments) and the runs of the voxels whose colour weight is below 254.
+// `sat` = nullptr: the single-device integrate, the colour weight is read from rgbw.  Otherwise a rank's share
+// of the rays in the ray-sharded integrate: dir = the rank's directory of every chunk it has walked through,
+// sat = its bitmap of the voxels their owners have reported saturated (4096 bits per directory slot).
 template <bool kAcc, bool kRuns>
 __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
     Params P, float scale_u, float scale_w, const float* __restrict__ xyz, int npoints,
     const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
-    int32_t* __restrict__ num_chunks, WalkCounters* __restrict__ ctr, const uint32_t* __restrict__ rgbw, AccOut out,
-    RunOut runs, TileMap tmap) {
+    int32_t* __restrict__ num_chunks, WalkCounters* __restrict__ ctr, const uint32_t* __restrict__ rgbw,
+    const uint32_t* __restrict__ sat, AccOut out, RunOut runs, TileMap tmap) {
   constexpr int kPer = kWalkEntries / kWalkRays;
   __shared__ WalkShared S;
   __shared__ uint32_t raw[kMaskCap * kMaskWords];              // accumulators during the walk, ray masks afterwards
@@ -536,7 +536,8 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
       }
       if (slot_of[k] >= 0) {
         vkey[k] = (uint32_t)slot_of[k] * (uint32_t)kChunkVox + vid;
-        if (kRuns && (rgbw[vkey[k]] >> 24) < 254u) {   // its colour still depends on the order of the visits
+        const bool cold = sat ? ((sat[vkey[k] >> 5] >> (vkey[k] & 31u)) & 1u) == 0u : (rgbw[vkey[k]] >> 24) < 254u;
+        if (kRuns && cold) {   // its colour still depends on the order of the visits
           need |= 1u << k;
           ++nneed;
         }
@@ -837,14 +838,10 @@ constexpr int kApplyThreads = 512;
 __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
     const uint4* __restrict__ sorted_seg, const uint32_t* __restrict__ active, const uint32_t* __restrict__ active_off,
     const uint4* __restrict__ rec, double inv_scale_u, double inv_scale_w, const uint32_t* __restrict__ kfid_of_point,
-    float* __restrict__ sdf, float* __restrict__ weight, uint32_t* __restrict__ vkfid, WalkCounters* __restrict__ ctr,
-    const uint32_t* __restrict__ rgbw, uint32_t* __restrict__ tile_marks) {
-  // tile_marks (ray-sharded integrate only): bitmap of the tiles that visited a voxel whose colour weight is
-  // still below 254 — the tiles the owner walks again for the colour runs.
+    float* __restrict__ sdf, float* __restrict__ weight, uint32_t* __restrict__ vkfid, WalkCounters* __restrict__ ctr) {
   __shared__ long long a_wuu[kSlabVox];
   __shared__ unsigned long long a_w[kSlabVox];
   __shared__ uint32_t a_last[kSlabVox], a_cnt[kSlabVox];
-  __shared__ uint32_t any_cold;
   const int tid = threadIdx.x, lane = tid & 63;
   const int grp = tid >> 4, gl = tid & 15;
   constexpr int kGroups = kApplyThreads / 16, kFly = 4;
@@ -866,7 +863,6 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
       a_last[v] = 0;
       a_cnt[v] = 0;
     }
-    if (tid == 0) any_cold = 0;
     __syncthreads();
     const uint32_t s0 = active_off[a], s1 = active_off[a + 1];
     for (uint32_t sb = s0 + (uint32_t)grp * kFly; sb < s1; sb += kGroups * kFly) {
@@ -906,31 +902,9 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
         vkfid[pool0 + v] = kfid_of_point ? kfid_of_point[a_last[v]] : 0u;
         ++voxels;
         longest = max(longest, c);
-        if (tile_marks && (rgbw[pool0 + v] >> 24) < 254u) {
-          a_cnt[v] = 0x80000000u;
-          any_cold = 1u;
-        }
       }
     }
     __syncthreads();
-    uint32_t cold_any = 0;
-    if (tile_marks) {
-      cold_any = any_cold;
-      __syncthreads();   // (everybody has read the flag before the next item resets it)
-    }
-    if (cold_any) {   // second look at the slab's records: which tiles brought the cold voxels
-      for (uint32_t sb = s0 + (uint32_t)grp; sb < s1; sb += kGroups) {
-        const uint4 d0 = sorted_seg[2 * (size_t)sb], d1 = sorted_seg[2 * (size_t)sb + 1];
-        const uint32_t w[4] = {d1.x, d1.y, d1.z, d1.w};
-        const uint32_t o = (w[slab >> 1] >> ((slab & 1) * 16)) & 0xFFFFu;
-        const uint32_t e = slab + 1 < kSlabs ? (w[(slab + 1) >> 1] >> (((slab + 1) & 1) * 16)) & 0xFFFFu : d0.z;
-        bool cold = false;
-        for (uint32_t r = d0.y + o + gl; r < d0.y + e; r += 16)
-          cold |= (a_cnt[(rec[r].x & 0xFFFu) % kSlabVox] & 0x80000000u) != 0u;
-        if (cold) atomicOr(&tile_marks[d0.w >> 5], 1u << (d0.w & 31u));
-      }
-      __syncthreads();
-    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -1067,10 +1041,20 @@ __global__ __launch_bounds__(1024) void sort_runs_small(const uint32_t* __restri
 // lanes fold the red, green and blue sequences (the weight is common) until the weight reaches 254: at
 // most 254 steps in the life of a voxel, none once it is there.
 constexpr int kFoldWaves = 4;
+// Where the fold finds run `val`: the per-tile regions of the walk (words = kMaskWords: the mask at
+// base + val * words, the tile from the slot number) or the runs an owner received in the ray-sharded integrate
+// (words = kWireRun: {chunk key, voxel, tile, mask}).
+constexpr uint32_t kWireRun = 4 + kMaskWords;
+struct RunSrc {
+  const uint32_t* base;
+  uint32_t words, r1_log2;
+  TileMap tmap;
+};
 __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
     const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ sorted_val, const uint32_t* __restrict__ nd_dev,
-    uint32_t r1_log2, const uint32_t* __restrict__ vj0, const uint32_t* __restrict__ masks,
-    const uint8_t* __restrict__ rgb, uint32_t* __restrict__ rgbw, const uint32_t* __restrict__ num_heads, TileMap tmap) {
+    RunSrc src, const uint32_t* __restrict__ vj0, const uint8_t* __restrict__ rgb, uint32_t* __restrict__ rgbw,
+    const uint32_t* __restrict__ num_heads, uint32_t* __restrict__ sat_list, uint32_t* __restrict__ sat_count) {
+  // sat_list (ray-sharded integrate): the voxels whose colour weight reaches 254 in this call
   __shared__ uint32_t stage[kFoldWaves][256];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const uint32_t nvox = *num_heads, nd = *nd_dev;
@@ -1092,13 +1076,14 @@ __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
       uint32_t p0 = 0, cnt = 0;
       if (mine) {
         const uint32_t val = sorted_val[j];
-        const uint4* m4 = reinterpret_cast<const uint4*>(masks + (size_t)val * kMaskWords);
+        const uint32_t* run = src.base + (size_t)val * src.words;
+        const uint4* m4 = reinterpret_cast<const uint4*>(run + (src.words - kMaskWords));
 #pragma unroll
         for (int q = 0; q < kMaskWords / 4; ++q) {
           const uint4 a = m4[q];
           m[4 * q] = a.x; m[4 * q + 1] = a.y; m[4 * q + 2] = a.z; m[4 * q + 3] = a.w;
         }
-        p0 = tmap.tile_of(val >> r1_log2) * (uint32_t)kWalkRays;
+        p0 = (src.words == kWireRun ? run[3] : src.tmap.tile_of(val >> src.r1_log2)) * (uint32_t)kWalkRays;
 #pragma unroll
         for (int w = 0; w < kMaskWords; ++w) cnt += (uint32_t)__popc(m[w]);
       }
@@ -1133,7 +1118,10 @@ __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
       }
     }
     const uint32_t r = (uint32_t)__shfl((int)ch, 0), g = (uint32_t)__shfl((int)ch, 1), bl = (uint32_t)__shfl((int)ch, 2);
-    if (lane == 0) rgbw[key] = r | (g << 8) | (bl << 16) | ((cw0 + steps) << 24);
+    if (lane == 0) {
+      rgbw[key] = r | (g << 8) | (bl << 16) | ((cw0 + steps) << 24);
+      if (sat_list && cw0 + steps >= 254u) sat_list[atomicAdd(sat_count, 1u)] = key;
+    }
   }
 }
 

@@ -50,27 +50,56 @@ def allgather_block_lists(local_ids, count, cap, group=None, padded=False):
     return [lists[r][: int(cnts[r].item())] for r in range(world)]
 
 
-def exchange_segments(send_seg, send_rec, send_counts, group=None):
+def exchange_segments(send_seg, send_rec, send_run, send_counts, group=None):
     """The all-to-all of the ray-sharded integrate (TsdfChisel.shard_walk / shard_pack / shard_apply).
 
-    send_seg [S, 8] / send_rec [R, 4] int32 tensors grouped by destination rank in rank order, send_counts
-    [world, 2] (segments, records per destination).  Returns (recv_seg, recv_rec, recv_counts) grouped by
-    source rank.  Three collectives: the counts, then the two payloads (all_to_all_single with split sizes —
-    RCCL send/recv pairs over xGMI on GPUs, gloo in the CPU tests)."""
+    send_seg [S, 8], send_rec [R, 4], send_run [U, 20] int32 tensors grouped by destination rank in rank order,
+    send_counts [world, 3] (segments, records, runs per destination).  Returns (recv_seg, recv_rec, recv_run,
+    recv_counts) grouped by source rank.  Four collectives: the counts, then the three payloads
+    (all_to_all_single with split sizes — RCCL send/recv pairs over xGMI on GPUs, gloo in the CPU tests)."""
     world = dist.get_world_size(group)
     dev = send_seg.device
-    sc = torch.as_tensor(np.ascontiguousarray(send_counts, dtype=np.int64).reshape(world, 2)).to(dev)
+    send_counts = np.ascontiguousarray(send_counts, dtype=np.int64).reshape(world, 3)
+    sc = torch.from_numpy(send_counts.copy()).to(dev)
     rc = torch.zeros_like(sc)
     dist.all_to_all_single(rc, sc, group=group)
     recv_counts = rc.cpu().numpy()
-    send_counts = np.asarray(send_counts, dtype=np.int64).reshape(world, 2)
-    recv_seg = torch.zeros((int(recv_counts[:, 0].sum()), 8), dtype=send_seg.dtype, device=dev)
-    recv_rec = torch.zeros((int(recv_counts[:, 1].sum()), 4), dtype=send_rec.dtype, device=dev)
-    dist.all_to_all_single(recv_seg, send_seg, output_split_sizes=[int(c) for c in recv_counts[:, 0]],
-                           input_split_sizes=[int(c) for c in send_counts[:, 0]], group=group)
-    dist.all_to_all_single(recv_rec, send_rec, output_split_sizes=[int(c) for c in recv_counts[:, 1]],
-                           input_split_sizes=[int(c) for c in send_counts[:, 1]], group=group)
-    return recv_seg, recv_rec, recv_counts
+    out = []
+    for k, (buf, width) in enumerate(((send_seg, 8), (send_rec, 4), (send_run, 20))):
+        recv = torch.zeros((int(recv_counts[:, k].sum()), width), dtype=buf.dtype, device=dev)
+        dist.all_to_all_single(recv, buf.reshape(-1, width), output_split_sizes=[int(c) for c in recv_counts[:, k]],
+                               input_split_sizes=[int(c) for c in send_counts[:, k]], group=group)
+        out.append(recv)
+    return out[0], out[1], out[2], recv_counts
+
+
+def sharded_integrate(tsdf, d_xyz, d_rgb, d_kfid, offsets, d_Twc, group=None):
+    """One ray-sharded integrate call of this rank's TsdfChisel (every rank calls it with the same clouds)."""
+    world = dist.get_world_size(group)
+    counts = tsdf.shard_walk(d_xyz, offsets, d_Twc)
+    dev = d_xyz.device
+    seg = torch.zeros((int(counts[:, 0].sum()), 8), dtype=torch.int32, device=dev)
+    rec = torch.zeros((int(counts[:, 1].sum()), 4), dtype=torch.int32, device=dev)
+    run = torch.zeros((int(counts[:, 2].sum()), 20), dtype=torch.int32, device=dev)
+    tsdf.shard_pack(seg, rec, run)
+    rseg, rrec, rrun, rcounts = exchange_segments(seg, rec, run, counts, group)
+    tsdf.shard_apply(rseg, rrec, rrun, rcounts, d_rgb, d_kfid)
+    # voxels whose colour saturated in this call: every rank stops sending their runs
+    sat = tsdf.shard_saturated()
+    n = torch.tensor([sat.shape[0]], dtype=torch.int64, device=dev)
+    ns = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(ns, n, group=group)
+    cap = max(int(x.item()) for x in ns)
+    if cap > 0:
+        pad = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
+        pad[: sat.shape[0]] = sat
+        lists = [torch.zeros_like(pad) for _ in range(world)]
+        dist.all_gather(lists, pad, group=group)
+        for r in range(world):
+            k = int(ns[r].item())
+            if k:
+                tsdf.shard_note_saturated(lists[r][:k].contiguous())
+    return counts
 
 
 class BlockDirectory:

@@ -106,30 +106,49 @@ class TsdfChisel:
     # ---- ray-sharded multi-GPU integrate (order_free, shard_count > 1): walk -> pack -> exchange -> apply
     def shard_walk(self, d_xyz, offsets, d_Twc):
         """Phase 1: this rank walks its tiles of the point stream (tile t belongs to rank t % shard_count).
-        Returns the int64 array [shard_count, 2] of (segments, records) bound for every rank."""
+        Returns the int64 array [shard_count, 3] of (segments, records, colour runs) bound for every rank."""
         offsets = np.ascontiguousarray(offsets, dtype=np.int32)
-        counts = np.zeros((self.params.shard_count, 2), np.int64)
+        counts = np.zeros((self.params.shard_count, 3), np.int64)
         f = _lib.lib.plvs_hip_tsdf_chisel_shard_walk
         f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 3
         _lib.check(f(self._h, _lib.t_ptr(d_xyz), _lib.np_ptr(offsets), offsets.shape[0] - 1, _lib.t_ptr(d_Twc),
                      _lib.np_ptr(counts), _lib.current_stream_ptr()))
         return counts
 
-    def shard_pack(self, d_seg, d_rec):
-        """Phase 2: fills the send buffers (torch int32 tensors [sum segments, 8] and [sum records, 4]), grouped
-        by destination rank in rank order."""
+    def shard_pack(self, d_seg, d_rec, d_run):
+        """Phase 2: fills the send buffers (torch int32 tensors [segments, 8], [records, 4] and [runs, 20]),
+        each grouped by destination rank in rank order."""
         f = _lib.lib.plvs_hip_tsdf_chisel_shard_pack
-        f.argtypes = [ctypes.c_void_p] * 4
-        _lib.check(f(self._h, _lib.t_ptr(d_seg), _lib.t_ptr(d_rec), _lib.current_stream_ptr()))
+        f.argtypes = [ctypes.c_void_p] * 5
+        _lib.check(f(self._h, _lib.t_ptr(d_seg), _lib.t_ptr(d_rec), _lib.t_ptr(d_run), _lib.current_stream_ptr()))
 
-    def shard_apply(self, d_seg, d_rec, recv_counts, d_xyz, d_rgb, d_kfid):
-        """Phase 3: the received buffers (grouped by source rank in rank order; recv_counts [shard_count, 2]) are
-        applied to this rank's chunks; colours of voxels below weight 254 through a walk of the marked tiles."""
+    def shard_apply(self, d_seg, d_rec, d_run, recv_counts, d_rgb, d_kfid):
+        """Phase 3: the received buffers (grouped by source rank in rank order; recv_counts [shard_count, 3]) are
+        applied to this rank's chunks, colours through the received runs."""
         recv_counts = np.ascontiguousarray(recv_counts, dtype=np.int64)
         f = _lib.lib.plvs_hip_tsdf_chisel_shard_apply
         f.argtypes = [ctypes.c_void_p] * 8
-        _lib.check(f(self._h, _lib.t_ptr(d_seg), _lib.t_ptr(d_rec), _lib.np_ptr(recv_counts), _lib.t_ptr(d_xyz),
+        _lib.check(f(self._h, _lib.t_ptr(d_seg), _lib.t_ptr(d_rec), _lib.t_ptr(d_run), _lib.np_ptr(recv_counts),
                      _lib.t_ptr(d_rgb), _lib.t_ptr(d_kfid), _lib.current_stream_ptr()))
+
+    def shard_saturated(self):
+        """Voxels of this rank whose colour weight reached 254 in the last shard_apply: int32 tensor [n, 4]
+        (chunk x, y, z, voxel) on the device — to be all-gathered and noted on every rank."""
+        n = ctypes.c_int()
+        f = _lib.lib.plvs_hip_tsdf_chisel_shard_saturated
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        rc = f(self._h, None, 0, ctypes.byref(n), _lib.current_stream_ptr())
+        if rc == _lib.PLVS_OK:
+            return torch.zeros((0, 4), dtype=torch.int32, device="cuda")
+        out = torch.zeros((n.value, 4), dtype=torch.int32, device="cuda")
+        _lib.check(f(self._h, _lib.t_ptr(out), n.value, ctypes.byref(n), _lib.current_stream_ptr()))
+        return out
+
+    def shard_note_saturated(self, d_voxels):
+        """Notes voxels other ranks (or this one) reported saturated: this rank's walks stop sending their runs."""
+        f = _lib.lib.plvs_hip_tsdf_chisel_shard_note_saturated
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        _lib.check(f(self._h, _lib.t_ptr(d_voxels), int(d_voxels.shape[0]), _lib.current_stream_ptr()))
 
     def last_stats(self):
         s = _lib.TsdfStats()

@@ -1,33 +1,76 @@
 #!/usr/bin/env python3
-"""Per-rank GPU time of the sharded chisel integrate, emulated on ONE device: rank 0 of N = 1, 2, 4, 8
-on the bench's 100-keyframe batch (no collective).  The driver measures the real multi-GPU runs; this
-shows what a rank computes."""
-import time
+"""Per-rank GPU time of the ray-sharded chisel integrate (order-free mode), emulated on ONE device with
+virtual ranks: N handles step through the bench's 100-keyframe batches, the all-to-all is done with tensor
+slices (not timed: the driver measures the real multi-GPU runs).  Printed per N: the slowest rank's time in
+shard_walk, shard_pack and shard_apply (HIP events around each phase), the bytes a rank sends, and what the
+single-device integrate takes on the same batches."""
+import sys
 
 import numpy as np
 import torch
 
-from plvs_amd.synth_scene import make_keyframes
-from plvs_amd.tsdf import TsdfChisel
+sys.path.insert(0, __file__.rsplit("/", 3)[0])
+from plvs_amd.synth_scene import make_keyframes  # noqa: E402
+from plvs_amd.tsdf import TsdfChisel  # noqa: E402
+from tests.test_shard_rays import virtual_all_to_all  # noqa: E402
 
-kfs = make_keyframes(100, max_depth=5.0, seed=0)
-xyz = torch.from_numpy(np.concatenate([k["xyz"] for k in kfs])).cuda()
-rgb = torch.from_numpy(np.concatenate([k["rgb"] for k in kfs])).cuda()
-kfid = torch.from_numpy(np.concatenate([k["kfid"] for k in kfs]).astype(np.int32)).cuda()
-Twc = torch.from_numpy(np.stack([k["Twc"] for k in kfs])).cuda()
-offsets = np.cumsum([0] + [k["xyz"].shape[0] for k in kfs]).astype(np.int32)
-for n in (1, 2, 4, 8):
-    t = TsdfChisel(0.05, max_chunks=16384, shard_rank=0, shard_count=n)
-    for _ in range(2):
-        t.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
-    t.set_profiling(True)
+STEPS = 4
+kfs = make_keyframes(100 * STEPS, max_depth=5.0, seed=0)
+
+
+def batch(i):
+    part = kfs[100 * i:100 * (i + 1)]
+    xyz = torch.from_numpy(np.concatenate([k["xyz"] for k in part])).cuda()
+    rgb = torch.from_numpy(np.concatenate([k["rgb"] for k in part])).cuda()
+    kfid = torch.from_numpy(np.concatenate([k["kfid"] for k in part]).astype(np.int32)).cuda()
+    Twc = torch.from_numpy(np.stack([k["Twc"] for k in part])).cuda()
+    offsets = np.cumsum([0] + [k["xyz"].shape[0] for k in part]).astype(np.int32)
+    return xyz, rgb, kfid, offsets, Twc
+
+
+def timed(fn):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    out = fn()
+    b.record()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(5):
-        t.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 5
-    st, calls = t.stage_ms()
-    print(n, "ranks: %.3f ms per step on rank 0, visits %d" % (dt * 1e3, t.last_stats()["visits"]),
-          {k: round(v / max(calls, 1), 3) for k, v in st.items()})
-    t.close()
+    return out, a.elapsed_time(b)
+
+
+batches = [batch(i) for i in range(STEPS)]
+single = TsdfChisel(0.05, max_chunks=16384, order_free=True)
+t1 = []
+for xyz, rgb, kfid, offsets, Twc in batches:
+    _, ms = timed(lambda: single.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc))
+    t1.append(ms)
+print("single device: %.3f ms per batch (last %d of %d)" % (np.mean(t1[1:]), STEPS - 1, STEPS))
+single.close()
+for world in [int(a) for a in sys.argv[1:]] or [2, 4, 8]:
+    ranks = [TsdfChisel(0.05, max_chunks=16384, shard_rank=r, shard_count=world, order_free=True) for r in range(world)]
+    per_step = []
+    for xyz, rgb, kfid, offsets, Twc in batches:
+        tw, tp, ta, sent = [], [], [], []
+        counts, segs, recs = [], [], []
+        for t in ranks:
+            c, ms = timed(lambda: t.shard_walk(xyz, offsets, Twc))
+            counts.append(c)
+            tw.append(ms)
+        for t, c in zip(ranks, counts):
+            seg = torch.zeros((int(c[:, 0].sum()), 8), dtype=torch.int32, device="cuda")
+            rec = torch.zeros((int(c[:, 1].sum()), 4), dtype=torch.int32, device="cuda")
+            _, ms = timed(lambda: t.shard_pack(seg, rec))
+            tp.append(ms)
+            segs.append(seg)
+            recs.append(rec)
+            r = ranks.index(t)
+            sent.append(32 * (c[:, 0].sum() - c[r, 0]) + 16 * (c[:, 1].sum() - c[r, 1]))
+        for t, (seg, rec, rc) in zip(ranks, virtual_all_to_all(counts, segs, recs)):
+            _, ms = timed(lambda: t.shard_apply(seg, rec, rc, xyz, rgb, kfid))
+            ta.append(ms)
+        per_step.append((max(tw), max(tp), max(ta), max(sent), [t.last_stats()["visits"] for t in ranks]))
+    w, p, a, sent, visits = (np.mean([s[k] for s in per_step[1:]]) if k < 4 else per_step[-1][4] for k in range(5))
+    print("N=%d: slowest rank walk %.3f + pack %.3f + apply %.3f = %.3f ms per batch (speed-up of the compute %.2fx), "
+          "%.1f MB sent per rank, visits per rank %d..%d"
+          % (world, w, p, a, w + p + a, np.mean(t1[1:]) / (w + p + a), sent / 1e6, min(visits), max(visits)))
+    for t in ranks:
+        t.close()

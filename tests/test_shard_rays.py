@@ -19,34 +19,42 @@ def _batch(kfs):
     return xyz, rgb, kfid, offsets, Twc
 
 
-def virtual_all_to_all(counts, segs, recs):
-    """counts[src][dst] = (segments, records); buffers grouped by destination -> per destination, grouped by source."""
+WIDTHS = (8, 4, 20)   # int32 words of a segment descriptor, a record, a colour run
+
+
+def virtual_all_to_all(counts, bufs):
+    """counts[src][dst] = (segments, records, runs); bufs[src] = the three send buffers grouped by destination
+    -> per destination the three receive buffers grouped by source, and its receive counts."""
     world = len(counts)
     out = []
     for dst in range(world):
-        ps, pr, rc = [], [], np.zeros((world, 2), np.int64)
+        parts, rc = [[], [], []], np.zeros((world, 3), np.int64)
         for src in range(world):
-            so, ro = counts[src][:dst].sum(axis=0)
-            ns, nr = counts[src][dst]
-            ps.append(segs[src][so:so + ns])
-            pr.append(recs[src][ro:ro + nr])
-            rc[src] = (ns, nr)
-        out.append((torch.cat(ps).contiguous(), torch.cat(pr).contiguous(), rc))
+            off = counts[src][:dst].sum(axis=0)
+            rc[src] = counts[src][dst]
+            for k in range(3):
+                parts[k].append(bufs[src][k][off[k]:off[k] + rc[src][k]])
+        out.append(tuple(torch.cat(p).contiguous() for p in parts) + (rc,))
     return out
+
+
+def send_buffers(t, c):
+    bufs = tuple(torch.zeros((int(c[:, k].sum()), w), dtype=torch.int32, device="cuda") for k, w in enumerate(WIDTHS))
+    t.shard_pack(*bufs)
+    return bufs
 
 
 def sharded_step(ranks, xyz, rgb, kfid, offsets, Twc):
     counts = [t.shard_walk(xyz, offsets, Twc) for t in ranks]
-    segs, recs = [], []
-    for t, c in zip(ranks, counts):
-        seg = torch.zeros((int(c[:, 0].sum()), 8), dtype=torch.int32, device="cuda")
-        rec = torch.zeros((int(c[:, 1].sum()), 4), dtype=torch.int32, device="cuda")
-        t.shard_pack(seg, rec)
-        segs.append(seg)
-        recs.append(rec)
+    bufs = [send_buffers(t, c) for t, c in zip(ranks, counts)]
     torch.cuda.synchronize()
-    for t, (seg, rec, rc) in zip(ranks, virtual_all_to_all(counts, segs, recs)):
-        t.shard_apply(seg, rec, rc, xyz, rgb, kfid)
+    for t, (seg, rec, run, rc) in zip(ranks, virtual_all_to_all(counts, bufs)):
+        t.shard_apply(seg, rec, run, rc, rgb, kfid)
+    sat = [t.shard_saturated() for t in ranks]   # the all-gather of the newly saturated voxels
+    for t in ranks:
+        for lst in sat:
+            if lst.shape[0]:
+                t.shard_note_saturated(lst)
     torch.cuda.synchronize()
     return counts
 
@@ -55,15 +63,17 @@ def sharded_step(ranks, xyz, rgb, kfid, offsets, Twc):
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_hip_ray_sharded_integrate_equals_the_single_device_map(world):
     from plvs_amd.tsdf import TsdfChisel
-    kfs = make_keyframes(8, max_depth=5.0, seed=3)
+    kfs = make_keyframes(12, max_depth=5.0, seed=3)
     single = TsdfChisel(0.05, max_chunks=4096, order_free=True)
     ranks = [TsdfChisel(0.05, max_chunks=4096, shard_rank=r, shard_count=world, order_free=True) for r in range(world)]
     walked = 0
-    for b0 in range(0, len(kfs), 3):   # batches of 3, 3 and 2 keyframes: later calls meet half-saturated colours
-        xyz, rgb, kfid, offsets, Twc = _batch(kfs[b0:b0 + 3])
+    runs_sent = []
+    for b0 in range(0, len(kfs), 5):   # batches of 5, 5 and 2 keyframes: later calls meet half-saturated colours
+        xyz, rgb, kfid, offsets, Twc = _batch(kfs[b0:b0 + 5])
         single.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
         want_visits = single.last_stats()["visits"]
-        sharded_step(ranks, xyz, rgb, kfid, offsets, Twc)
+        counts = sharded_step(ranks, xyz, rgb, kfid, offsets, Twc)
+        runs_sent.append(int(sum(c[:, 2].sum() for c in counts)))
         assert sum(t.last_stats()["visits"] for t in ranks) == want_visits, "every visit is walked by exactly one rank"
         walked += want_visits
     assert walked > 0
@@ -80,6 +90,9 @@ def test_hip_ray_sharded_integrate_equals_the_single_device_map(world):
         for name, x, y in zip(("sdf", "weight", "kfid", "colour"), a, b):
             assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x,
                                   y.view(np.uint32) if y.dtype == np.float32 else y), f"{name} of chunk {cid} differs"
+    saturated = sum(int(((single.get_chunk(*cid)[3] >> 24) >= 254).sum()) for cid in ids)
+    assert saturated > 0, "the scene must drive some colours to saturation for the test to cover the feedback"
+    assert runs_sent[1] < runs_sent[0], "walkers stop sending the runs of voxels reported saturated"
     for t in ranks + [single]:
         t.close()
 
@@ -110,8 +123,8 @@ def test_hip_ray_sharded_integrate_with_more_ranks_than_tiles_and_empty_calls():
     for t in ranks:
         c = t.shard_walk(xyz[:0], e, Twc[:0])
         assert c.sum() == 0
-        t.shard_pack(torch.zeros((0, 8), dtype=torch.int32, device="cuda"), torch.zeros((0, 4), dtype=torch.int32, device="cuda"))
-        t.shard_apply(torch.zeros((0, 8), dtype=torch.int32, device="cuda"), torch.zeros((0, 4), dtype=torch.int32, device="cuda"),
-                      np.zeros((world, 2), np.int64), xyz[:0], rgb[:0], kfid[:0])
+        empty = tuple(torch.zeros((0, w), dtype=torch.int32, device="cuda") for w in WIDTHS)
+        t.shard_pack(*empty)
+        t.shard_apply(*empty, np.zeros((world, 3), np.int64), rgb[:0], kfid[:0])
     for t in ranks + [single]:
         t.close()
