@@ -19,10 +19,14 @@ compared with the CPU oracle run over the very same sequence (`parity_checked`);
 that oracle run is also the `cpu_baseline`.
 
 Multi-GPU (N > 1): the voxel-chunk hash is sharded, owner(chunk) =
-ChunkHasher(id) mod N; every rank holds the same clouds, applies only the
-visits of its own chunks, and the per-step lists of updated chunk ids are
-all-gathered over RCCL.  Total work is fixed as N grows -> "strong" scaling.
-The same stream is used at every N so that the driver's curve is one workload;
+ChunkHasher(id) mod N, and the RAYS are sharded by tile of the point stream
+(plvs_amd/csrc/tsdf_shard.hpp): rank r walks tiles t = r (mod N), its partial
+sums and colour runs travel to the chunk owners in one all-to-all per step, the
+per-step lists of updated chunk ids and of newly colour-saturated voxels are
+all-gathered — all over RCCL.  The union of the shards is bit-identical to the
+single-GPU order-free map (tests/test_shard_rays.py).  Weak scaling: a step
+carries --batch keyframes per GPU (--strong keeps the step fixed).  The ordered
+mode and the voxblox back end keep the chunk-hash shard with replicated walks;
 BASELINE's configs[3] (voxblox 2 cm, 16x12x3 m room) is measured at every N as
 the `voxblox_configs3` leg.
 
@@ -58,6 +62,8 @@ def parse():
     ap.add_argument("--order-free", action="store_true", help="(the default; kept for older command lines)")
     ap.add_argument("--no-other-mode-leg", action="store_true", help="skip the measurement of the other chisel mode")
     ap.add_argument("--no-voxblox-leg", action="store_true", help="skip the configs[3] (voxblox 2 cm) leg")
+    ap.add_argument("--strong", action="store_true",
+                    help="N > 1: keep the step at --batch keyframes (default: --batch keyframes per GPU, weak scaling)")
     ap.add_argument("--no-parity-check", action="store_true",
                     help="skip the oracle run over the same sequence (parity check + CPU baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -80,7 +86,7 @@ def main():
 
     from plvs_amd import _lib
     from plvs_amd.synth_scene import make_keyframes
-    from plvs_amd.shard import BlockDirectory, allgather_block_lists
+    from plvs_amd.shard import BlockDirectory, allgather_block_lists, sharded_integrate
     from plvs_amd.tsdf import TsdfChisel, TsdfVoxblox
 
     # ---------------------------------------------------------------- inputs
@@ -97,9 +103,15 @@ def main():
             k["rgba"] = np.concatenate([k["rgb"], np.full((k["rgb"].shape[0], 1), 255, np.uint8)], axis=1)
     else:
         kfs = make_keyframes(n_poses, max_depth=args.max_depth, seed=0)
+    # N > 1 (chisel, order-free): the ray-sharded integrate — rank r walks every N-th tile of the step's point
+    # stream and sends what it collected to the chunk owners.  Weak scaling by default: a step carries --batch
+    # keyframes PER GPU (a longer stretch of the stream, e.g. a map rebuild), so every rank's share of the rays
+    # stays what one GPU walks at N = 1.
+    ray_sharded = world > 1 and not vbx and not args.ordered
+    step_kfs = args.batch * (world if (ray_sharded and not args.strong) else 1)
     batches = []
     for s in range(total_steps):
-        sel = [kfs[(s * args.batch + j) % n_poses] for j in range(args.batch)]
+        sel = [kfs[(s * step_kfs + j) % n_poses] for j in range(step_kfs)]
         xyz = torch.from_numpy(np.concatenate([k["xyz"] for k in sel])).cuda()
         rgb = torch.from_numpy(np.concatenate([k["rgba" if vbx else "rgb"] for k in sel])).cuda()
         kfid = torch.from_numpy(np.concatenate([k["kfid"] for k in sel]).astype(np.int32)).cuda()
@@ -121,6 +133,8 @@ def main():
         xyz, rgb, kfid, offsets, Twc = b
         if vbx:
             tsdf.integrate_batch_dev(xyz, rgb, offsets, Twc)
+        elif ray_sharded:
+            sharded_integrate(tsdf, xyz, rgb, kfid, offsets, Twc)
         else:
             tsdf.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
         st = tsdf.last_stats()
@@ -207,7 +221,8 @@ def main():
                        "Mvoxels/sec TSDF integrate (chisel 5 cm / 5 m, 640x480 RGB-D)"),
             "value": round(mvox, 2), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak" if (ray_sharded and not args.strong) else "strong",
+            "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": ("configs[3] stand-in: synthetic room 16x12x3 m, camera circle r=1 m, Voxblox "
                                     "simple TSDF 2 cm, max ray 5 m (wrapper constant), 76800-point keyframes" if vbx else
@@ -215,10 +230,12 @@ def main():
                                     "Chisel TSDF 5 cm / 5 m, 76800-point keyframes"),
                        "mode": None if vbx else mode_name,
                        "resolution": args.resolution, "max_depth": args.max_depth,
-                       "keyframes_per_step": args.batch, "points_per_step": int(points // args.steps),
+                       "keyframes_per_step": step_kfs, "points_per_step": int(points // args.steps),
                        "visits_per_step": int(visits_total // args.steps),
                        "voxels_per_step": int(voxels // args.steps), "longest_voxel_run": int(max_run),
-                       "parallelism": f"chunk-hash shard x{world}",
+                       "parallelism": (f"ray-sharded x{world}: rank r walks tiles t = r (mod {world}), partial sums and "
+                                       f"colour runs go to the chunk owners (three-prime hash mod {world}) in one "
+                                       "all-to-all per step" if ray_sharded else f"chunk-hash shard x{world}"),
                        "global_directory_blocks": (gdir.count() if gdir is not None else None)},
             "roofline": roofline,
         }

@@ -513,6 +513,40 @@ int plvs_hip_tsdf_chisel_carve_dev(plvs_tsdf_chisel* h, const float* d_depth, in
                                    float far_dist, const float* Twc, float carving_dist, void* stream,
                                    int* carved_chunks);
 
+/* ------------------------------------------- multi-GPU: the ray-sharded integrate (chisel, order_free = 1)
+ * New design (the reference is one process): the MAP is sharded by chunk (shard_rank / shard_count, owner =
+ * ChunkHasher(id) mod N, ChunkManager.h:42-54), the WORK by tile of the point stream — rank r walks the tiles
+ * t = r (mod N) of 512 consecutive points of every call, through whatever chunks their rays cross, and sends
+ * what it collected to the chunk owners.  Every rank is given the same clouds.  One call =
+ *   shard_walk    this rank's tiles; send_counts[3 * N] = {segments, records, colour runs} per destination
+ *   shard_pack    the three send buffers, each grouped by destination in rank order:
+ *                 segments 32 B, records 16 B, runs 80 B per item (sizes from send_counts)
+ *   all-to-all    counts, then the three buffers (the caller's transport; ..._integrate_sharded does it over RCCL)
+ *   shard_apply   the three receive buffers grouped by source in rank order, recv_counts[3 * N]
+ *   shard_saturated / all-gather / shard_note_saturated
+ *                 the voxels whose colour weight reached 254 in the call: walkers stop sending their runs
+ *                 (late knowledge only costs surplus runs).
+ * The partial sums are integers: the union of the shards is bit-identical to the single-device order_free map
+ * for every N (tests/test_shard_rays.py).  shard_count = 1 is allowed (the rank sends to itself).  Each rank
+ * also keeps a walk directory (ids + 512 B of bits per chunk it has walked through, up to max_chunks x
+ * shard_count chunks); the voxel data stay with the owner.  InsertCloud equivalent: Chisel.cpp:442-585. */
+int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, const int32_t* offsets, int nclouds,
+                                    const float* d_Twc, int64_t* send_counts, void* stream);
+int plvs_hip_tsdf_chisel_shard_pack(plvs_tsdf_chisel* h, void* d_seg_dst, void* d_rec_dst, void* d_run_dst,
+                                    void* stream);
+int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src, const void* d_rec_src,
+                                     const void* d_run_src, const int64_t* recv_counts, const uint8_t* d_rgb,
+                                     const uint32_t* d_kfid, void* stream);
+/* *n = voxels that saturated in the last shard_apply; written to d_voxels as {chunk x, y, z, voxel} int32
+ * quadruples when cap >= *n (PLVS_ERR_CAPACITY otherwise: call once with cap 0 for the count). */
+int plvs_hip_tsdf_chisel_shard_saturated(plvs_tsdf_chisel* h, int32_t* d_voxels, int cap, int* n, void* stream);
+int plvs_hip_tsdf_chisel_shard_note_saturated(plvs_tsdf_chisel* h, const int32_t* d_voxels, int n, void* stream);
+/* All of the above with the exchanges over RCCL (grouped ncclSend / ncclRecv, ncclAllGather); rccl_comm is the
+ * caller's ncclComm_t, one process per GPU, its size and rank those of the map's shard_count / shard_rank. */
+int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm, const float* d_xyz,
+                                           const uint8_t* d_rgb, const uint32_t* d_kfid, const int32_t* offsets,
+                                           int nclouds, const float* d_Twc, void* stream);
+
 /* ------------------------------------------- multi-GPU: the block-list exchange
  * The sharded TSDF path (shard_rank / shard_count of either back end; owner(block) =
  * three-prime hash(block id) mod N, ChunkManager.h:42-54 / block_hash.h:15-26) has ONE

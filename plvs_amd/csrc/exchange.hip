@@ -16,12 +16,18 @@ namespace {
 using plvs::tsdf::kEmptyKey;
 using plvs::tsdf::pack_block;
 
-// the three RCCL entry points used (rccl.h: ncclResult_t = int, ncclInt32 = 2)
+// the RCCL entry points used (rccl.h: ncclResult_t = int, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4)
 using AllGatherFn = int (*)(const void*, void*, size_t, int, void*, hipStream_t);
+using SendFn = int (*)(const void*, size_t, int, int, void*, hipStream_t);
+using RecvFn = int (*)(void*, size_t, int, int, void*, hipStream_t);
+using GroupFn = int (*)();
 using CommCountFn = int (*)(void*, int*);
 using ErrStrFn = const char* (*)(int);
 struct Rccl {
   AllGatherFn all_gather = nullptr;
+  SendFn send = nullptr;
+  RecvFn recv = nullptr;
+  GroupFn group_start = nullptr, group_end = nullptr;
   CommCountFn comm_count = nullptr, comm_rank = nullptr;
   ErrStrFn err = nullptr;
 };
@@ -39,6 +45,10 @@ const Rccl* rccl() {
       r.comm_count = reinterpret_cast<CommCountFn>(dlsym(h, "ncclCommCount"));
       r.comm_rank = reinterpret_cast<CommCountFn>(dlsym(h, "ncclCommUserRank"));
       r.err = reinterpret_cast<ErrStrFn>(dlsym(h, "ncclGetErrorString"));
+      r.send = reinterpret_cast<SendFn>(dlsym(h, "ncclSend"));
+      r.recv = reinterpret_cast<RecvFn>(dlsym(h, "ncclRecv"));
+      r.group_start = reinterpret_cast<GroupFn>(dlsym(h, "ncclGroupStart"));
+      r.group_end = reinterpret_cast<GroupFn>(dlsym(h, "ncclGroupEnd"));
     }
   }
   return (r.all_gather && r.comm_count && r.comm_rank) ? &r : nullptr;
@@ -188,6 +198,110 @@ int plvs_hip_tsdf_exchange_block_lists(void* rccl_comm, const int32_t* d_local_i
     plvs::set_error("ncclAllGather failed: %s", r->err ? r->err(rc) : "?");
     return PLVS_ERR_HIP;
   }
+  return PLVS_OK;
+}
+
+// The ray-sharded integrate with its exchanges over RCCL (tsdf_shard.hpp): shard_walk, the all-to-all of the
+// counts, shard_pack, the all-to-all of segments / records / runs (grouped ncclSend / ncclRecv pairs, uint32
+// words), shard_apply, and the all-gather of the voxels whose colour saturated in the call.
+int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm, const float* d_xyz, const uint8_t* d_rgb,
+                                           const uint32_t* d_kfid, const int32_t* offsets, int nclouds, const float* d_Twc,
+                                           void* stream) {
+  PLVS_REQUIRE(h && rccl_comm, "null argument");
+  const Rccl* r = rccl();
+  if (r == nullptr || !r->send || !r->recv || !r->group_start || !r->group_end) {
+    plvs::set_error("RCCL is not available in this process (ncclSend / ncclRecv / librccl.so.1 not found)");
+    return PLVS_ERR_NO_DEVICE;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int world = 0, rank = 0;
+  if (r->comm_count(rccl_comm, &world) != 0 || r->comm_rank(rccl_comm, &rank) != 0 || world < 1 || world > 64) {
+    plvs::set_error("bad RCCL communicator (1..64 ranks)");
+    return PLVS_ERR_INVALID_ARG;
+  }
+  struct Scratch {   // grow-only device buffers of this thread
+    plvs::DevBuf<long long> cnt;
+    plvs::DevBuf<uint32_t> send[3], recv[3];
+    plvs::DevBuf<int32_t> sat, all_sat, nsat;
+  };
+  static thread_local Scratch B;
+  constexpr size_t kWords[3] = {8, 4, 20};   // uint32 words of a segment descriptor, a record, a run
+  int64_t sc[3 * 64], rcv[3 * 64];
+  int rc = plvs_hip_tsdf_chisel_shard_walk(h, d_xyz, offsets, nclouds, d_Twc, sc, stream);
+  if (rc != PLVS_OK) return rc;
+#define RCCL_TRY(call)                                                      \
+  do {                                                                      \
+    const int e_ = (call);                                                  \
+    if (e_ != 0) {                                                          \
+      plvs::set_error("%s failed: %s", #call, r->err ? r->err(e_) : "?");   \
+      return PLVS_ERR_HIP;                                                  \
+    }                                                                       \
+  } while (0)
+  // ---- counts
+  PLVS_HIP_TRY(B.cnt.reserve((size_t)6 * world));
+  PLVS_HIP_TRY(hipMemcpyAsync(B.cnt.p, sc, (size_t)3 * world * sizeof(long long), hipMemcpyHostToDevice, s));
+  RCCL_TRY(r->group_start());
+  for (int p = 0; p < world; ++p) {
+    RCCL_TRY(r->send(B.cnt.p + 3 * p, 3, /*ncclInt64*/ 4, p, rccl_comm, s));
+    RCCL_TRY(r->recv(B.cnt.p + 3 * world + 3 * p, 3, /*ncclInt64*/ 4, p, rccl_comm, s));
+  }
+  RCCL_TRY(r->group_end());
+  PLVS_HIP_TRY(hipMemcpyAsync(rcv, B.cnt.p + 3 * world, (size_t)3 * world * sizeof(long long), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  // ---- payloads
+  size_t stot[3] = {0, 0, 0}, rtot[3] = {0, 0, 0};
+  for (int p = 0; p < world; ++p)
+    for (int k = 0; k < 3; ++k) {
+      stot[k] += (size_t)sc[3 * p + k];
+      rtot[k] += (size_t)rcv[3 * p + k];
+    }
+  for (int k = 0; k < 3; ++k) {
+    PLVS_HIP_TRY(B.send[k].reserve(stot[k] * kWords[k] + 4));
+    PLVS_HIP_TRY(B.recv[k].reserve(rtot[k] * kWords[k] + 4));
+  }
+  rc = plvs_hip_tsdf_chisel_shard_pack(h, B.send[0].p, B.send[1].p, B.send[2].p, stream);
+  if (rc != PLVS_OK) return rc;
+  RCCL_TRY(r->group_start());
+  {
+    size_t so[3] = {0, 0, 0}, ro[3] = {0, 0, 0};
+    for (int p = 0; p < world; ++p)
+      for (int k = 0; k < 3; ++k) {
+        const size_t ns = (size_t)sc[3 * p + k] * kWords[k], nr = (size_t)rcv[3 * p + k] * kWords[k];
+        if (ns) RCCL_TRY(r->send(B.send[k].p + so[k], ns, /*ncclUint32*/ 3, p, rccl_comm, s));
+        if (nr) RCCL_TRY(r->recv(B.recv[k].p + ro[k], nr, /*ncclUint32*/ 3, p, rccl_comm, s));
+        so[k] += ns;
+        ro[k] += nr;
+      }
+  }
+  RCCL_TRY(r->group_end());
+  rc = plvs_hip_tsdf_chisel_shard_apply(h, B.recv[0].p, B.recv[1].p, B.recv[2].p, rcv, d_rgb, d_kfid, stream);
+  if (rc != PLVS_OK) return rc;
+  // ---- voxels whose colour saturated: every rank notes every list
+  int nsat = 0;
+  rc = plvs_hip_tsdf_chisel_shard_saturated(h, nullptr, 0, &nsat, stream);
+  if (rc != PLVS_OK && rc != PLVS_ERR_CAPACITY) return rc;
+  PLVS_HIP_TRY(B.nsat.reserve((size_t)world + 1));
+  PLVS_HIP_TRY(hipMemcpyAsync(B.nsat.p + rank, &nsat, sizeof(int32_t), hipMemcpyHostToDevice, s));
+  RCCL_TRY(r->all_gather(B.nsat.p + rank, B.nsat.p, 1, /*ncclInt32*/ 2, rccl_comm, s));
+  int32_t all_n[64];
+  PLVS_HIP_TRY(hipMemcpyAsync(all_n, B.nsat.p, (size_t)world * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  int cap = 0;
+  for (int p = 0; p < world; ++p) cap = all_n[p] > cap ? all_n[p] : cap;
+  if (cap > 0) {
+    PLVS_HIP_TRY(B.sat.reserve((size_t)cap * 4));
+    PLVS_HIP_TRY(B.all_sat.reserve((size_t)cap * 4 * world));
+    if (nsat > 0) {
+      rc = plvs_hip_tsdf_chisel_shard_saturated(h, B.sat.p, cap, &nsat, stream);
+      if (rc != PLVS_OK) return rc;
+    }
+    RCCL_TRY(r->all_gather(B.sat.p, B.all_sat.p, (size_t)cap * 4, /*ncclInt32*/ 2, rccl_comm, s));
+    for (int p = 0; p < world; ++p) {
+      rc = plvs_hip_tsdf_chisel_shard_note_saturated(h, B.all_sat.p + (size_t)p * cap * 4, all_n[p], stream);
+      if (rc != PLVS_OK) return rc;
+    }
+  }
+#undef RCCL_TRY
   return PLVS_OK;
 }
 

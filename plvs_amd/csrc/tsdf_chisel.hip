@@ -760,7 +760,7 @@ struct plvs_tsdf_chisel {
   Directory xdir{};                  // the walk directory: every chunk the rank's tiles have crossed (ids only)
   int32_t* d_xcount = nullptr;
   uint32_t* x_sat = nullptr;         //   + one bit per voxel: its owner has reported the colour saturated
-  DevBuf<uint32_t> sh_nrec, sh_owner, sh_slot_owner, sh_seg_dst, sh_rec_dst, sh_obase, sh_src_off, sh_run_ctr, sh_vkey, sh_sat;
+  DevBuf<uint32_t> sh_seg_pre, sh_nrec, sh_owner, sh_slot_owner, sh_seg_dst, sh_rec_dst, sh_obase, sh_src_off, sh_run_ctr, sh_vkey, sh_sat;
   uint32_t sh_nt = 0, sh_runs = 0, sh_nsat = 0;
   DevBuf<long long> sh_counts;
   long long* h_sh_counts = nullptr;  // pinned
@@ -1091,7 +1091,7 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   h->w_dummy.release(); h->w_cold.release(); h->w_runkey.release(); h->w_run_cnt.release(); h->w_run_off.release(); h->w_val0.release();
   h->w_val1.release(); h->w_seg_cnt.release(); h->w_tile_visits.release();
   h->sh_nrec.release(); h->sh_owner.release(); h->sh_seg_dst.release(); h->sh_rec_dst.release(); h->sh_obase.release();
-  h->sh_src_off.release(); h->sh_slot_owner.release(); h->sh_run_ctr.release(); h->sh_vkey.release(); h->sh_sat.release();
+  h->sh_seg_pre.release(); h->sh_src_off.release(); h->sh_slot_owner.release(); h->sh_run_ctr.release(); h->sh_vkey.release(); h->sh_sat.release();
   h->sh_counts.release();
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -1622,7 +1622,7 @@ bool chisel_map_view(plvs_tsdf_chisel* h, ChiselMapView* v) {
 static int shard_state_init(plvs_tsdf_chisel* h) {
   if (h->xdir.keys) return PLVS_OK;
   // the walk directory: every chunk of the whole map may pass through it (ids + 512 B of bits each)
-  const size_t xmax = std::min<size_t>((size_t)h->prm.max_chunks * (size_t)h->prm.shard_count, (size_t)1 << 22);
+  const size_t xmax = std::min<size_t>((size_t)h->prm.max_chunks * (size_t)std::max(1, h->prm.shard_count), (size_t)1 << 22);
   size_t cap = 1024;
   while (cap < 2 * xmax) cap <<= 1;
   h->xdir.mask = (uint32_t)(cap - 1);
@@ -1632,7 +1632,7 @@ static int shard_state_init(plvs_tsdf_chisel* h) {
   PLVS_HIP_TRY(hipMalloc((void**)&h->xdir.slot_ids, xmax * 3 * sizeof(int32_t)));
   PLVS_HIP_TRY(hipMalloc((void**)&h->x_sat, xmax * (kChunkVox / 32) * sizeof(uint32_t)));
   PLVS_HIP_TRY(hipMalloc((void**)&h->d_xcount, 4 * sizeof(int32_t)));   // [0] chunks, [1] error bits, [2] saturated this call
-  PLVS_HIP_TRY(hipHostMalloc((void**)&h->h_sh_counts, (size_t)3 * h->prm.shard_count * sizeof(long long)));
+  PLVS_HIP_TRY(hipHostMalloc((void**)&h->h_sh_counts, (size_t)3 * std::max(1, h->prm.shard_count) * sizeof(long long)));
   PLVS_HIP_TRY(hipMemset(h->xdir.keys, 0xFF, cap * sizeof(unsigned long long)));
   PLVS_HIP_TRY(hipMemset(h->xdir.slots, 0xFF, cap * sizeof(int32_t)));
   PLVS_HIP_TRY(hipMemset(h->x_sat, 0, xmax * (kChunkVox / 32) * sizeof(uint32_t)));
@@ -1658,11 +1658,11 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
                                     const float* d_Twc, int64_t* send_counts, void* stream) {
   PLVS_REQUIRE(h && send_counts, "null argument");
   PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
-  PLVS_REQUIRE(h->prm.order_free != 0 && h->prm.shard_count > 1 && h->prm.shard_count <= 64,
-               "the ray-sharded integrate needs order_free = 1 and 2 <= shard_count <= 64");
+  PLVS_REQUIRE(h->prm.order_free != 0 && h->prm.shard_count >= 1 && h->prm.shard_count <= 64,
+               "the ray-sharded integrate needs order_free = 1 and 1 <= shard_count <= 64");
   PLVS_REQUIRE(offsets && nclouds >= 0, "bad offsets");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int N = h->prm.shard_count, rank = h->prm.shard_rank;
+  const int N = std::max(1, h->prm.shard_count), rank = N > 1 ? h->prm.shard_rank : 0;
   for (int p = 0; p < 3 * N; ++p) send_counts[p] = 0;
   h->sh_stats = plvs_tsdf_stats{};
   h->sh_phase = 0;
@@ -1712,13 +1712,15 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
   Pw.shard_count = 1;
   Pw.shard_rank = 0;
   const TileMap tmap{(uint32_t)N, (uint32_t)rank};
-  uint32_t* const xerr = reinterpret_cast<uint32_t*>(h->d_xcount + 1);
   for (int attempt = 0;; ++attempt) {
     PLVS_HIP_TRY(h->w_rec.reserve(rec_own + rec_spill));
     PLVS_HIP_TRY(h->w_seg.reserve(2 * (seg_own + seg_spill)));
     PLVS_HIP_TRY(h->w_sorted_seg.reserve(h->w_seg.cap));
+    PLVS_HIP_TRY(h->sh_seg_pre.reserve(h->w_seg.cap / 2 + 1));
     PLVS_HIP_TRY(h->w_runkey.reserve((size_t)nt << h->run_r1_log2));
     PLVS_HIP_TRY(h->w_masks.reserve(((size_t)nt << h->run_r1_log2) * kMaskWords));
+    PLVS_HIP_TRY(h->dkey0.reserve((size_t)nt << h->run_r1_log2));   // (all a call's runs, whatever their number)
+    PLVS_HIP_TRY(h->w_val0.reserve((size_t)nt << h->run_r1_log2));
     PLVS_HIP_TRY(h->scratch.reserve(scan_scratch_words(nt)));
     PLVS_HIP_TRY(hipMemsetAsync(h->d_wctr, 0, 2 * sizeof(WalkCounters), s));
     PLVS_HIP_TRY(hipMemsetAsync(h->w_chunk_nseg.p, 0, xmax * sizeof(uint32_t), s));
@@ -1739,12 +1741,20 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
     hipLaunchKernelGGL(seg_pass<true>, dim3(seg_blocks), dim3(256), 0, s, h->w_seg.p, out.seg_cap, nt, h->w_seg_cnt.p,
                        h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p, h->d_wctr);
     hipLaunchKernelGGL(shard_chunk_totals, dim3(1024), dim3(256), 0, s, h->w_sorted_seg.p, h->updated.p,
-                       h->w_active_off.p, h->xdir.slot_ids, N, h->d_wctr, h->sh_nrec.p, h->sh_owner.p, h->sh_slot_owner.p);
-    PLVS_KERNEL_CHECK();
-    // the runs, densely, in tile order (seg_scan has left their number in num_desc)
+                       h->w_active_off.p, h->xdir.slot_ids, N, h->d_wctr, h->sh_nrec.p, h->sh_owner.p, h->sh_slot_owner.p,
+                       h->sh_seg_pre.p);
+    // the runs, densely, in tile order (seg_scan has left their number in num_desc), counted per destination
     PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, nt, nullptr, h->scratch.p, s));
+    hipLaunchKernelGGL(compact_runs, dim3(ceil_div(nt, 4)), dim3(256), 0, s, h->w_runkey.p, h->w_run_cnt.p,
+                       h->w_run_off.p, nt, h->run_r1_log2, h->dkey0.p, h->w_val0.p);
+    hipLaunchKernelGGL(shard_run_count, dim3(256), dim3(256), 0, s, h->dkey0.p, &h->d_wctr[0].num_desc,
+                       h->sh_slot_owner.p, N, h->sh_run_ctr.p);
+    hipLaunchKernelGGL(shard_plan, dim3(1), dim3(1024), 0, s, h->w_active_off.p, h->sh_nrec.p, h->sh_owner.p, N,
+                       h->d_wctr, h->sh_seg_dst.p, h->sh_rec_dst.p, h->sh_counts.p, h->sh_obase.p, h->sh_run_ctr.p,
+                       h->sh_run_ctr.p + 64, h->sh_run_ctr.p + 128);
+    PLVS_KERNEL_CHECK();
+    PLVS_HIP_TRY(hipMemcpyAsync(h->h_sh_counts, h->sh_counts.p, (size_t)3 * N * sizeof(long long), hipMemcpyDeviceToHost, s));
     PLVS_HIP_TRY(hipMemcpyAsync(h->h_wctr, h->d_wctr, sizeof(WalkCounters), hipMemcpyDeviceToHost, s));
-    PLVS_HIP_TRY(hipMemcpyAsync(h->h_ctr, h->d_xcount, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     PLVS_HIP_TRY(hipStreamSynchronize(s));
     const uint32_t err = h->h_wctr->err;
     if (err & kErrPoolFull) {
@@ -1763,24 +1773,7 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
     }
     break;
   }
-  const uint32_t D = h->h_wctr->num_desc;
-  h->sh_runs = D;
-  uint32_t* const rc_counts = h->sh_run_ctr.p;
-  if (D > 0) {
-    PLVS_HIP_TRY(h->dkey0.reserve(D));
-    PLVS_HIP_TRY(h->w_val0.reserve(D));
-    hipLaunchKernelGGL(compact_runs, dim3(ceil_div(nt, 4)), dim3(256), 0, s, h->w_runkey.p, h->w_run_cnt.p,
-                       h->w_run_off.p, nt, h->run_r1_log2, h->dkey0.p, h->w_val0.p);
-    hipLaunchKernelGGL(shard_run_count, dim3(256), dim3(256), 0, s, h->dkey0.p, &h->d_wctr[0].num_desc,
-                       h->sh_slot_owner.p, N, rc_counts);
-  }
-  hipLaunchKernelGGL(shard_plan, dim3(1), dim3(1024), 0, s, h->w_active_off.p, h->sh_nrec.p, h->sh_owner.p, N,
-                     h->d_wctr, h->sh_seg_dst.p, h->sh_rec_dst.p, h->sh_counts.p, h->sh_obase.p, rc_counts,
-                     rc_counts + 64, rc_counts + 128);
-  PLVS_KERNEL_CHECK();
-  PLVS_HIP_TRY(hipMemcpyAsync(h->h_sh_counts, h->sh_counts.p, (size_t)3 * N * sizeof(long long), hipMemcpyDeviceToHost, s));
-  PLVS_HIP_TRY(hipStreamSynchronize(s));
-  (void)xerr;
+  h->sh_runs = h->h_wctr->num_desc;
   for (int p = 0; p < 3 * N; ++p) send_counts[p] = (int64_t)h->h_sh_counts[p];
   h->sh_stats.visits = (int64_t)h->h_wctr->total_visits;
   return PLVS_OK;
@@ -1792,16 +1785,17 @@ int plvs_hip_tsdf_chisel_shard_pack(plvs_tsdf_chisel* h, void* d_seg_dst, void* 
   hipStream_t s = static_cast<hipStream_t>(stream);
   h->sh_phase = 2;
   long long nseg = 0;
-  for (int p = 0; p < h->prm.shard_count; ++p) nseg += h->h_sh_counts ? h->h_sh_counts[3 * p] : 0;
+  for (int p = 0; p < std::max(1, h->prm.shard_count); ++p) nseg += h->h_sh_counts ? h->h_sh_counts[3 * p] : 0;
   if (nseg == 0) return PLVS_OK;
   PLVS_REQUIRE(d_seg_dst && d_rec_dst && (h->sh_runs == 0 || d_run_dst), "null send buffer");
-  hipLaunchKernelGGL(shard_pack_segments, dim3(2048), dim3(256), 0, s, h->w_sorted_seg.p, h->w_rec.p, h->updated.p,
-                     h->w_active_off.p, h->xdir.slot_ids, h->sh_owner.p, h->sh_seg_dst.p, h->sh_rec_dst.p, h->sh_obase.p,
-                     h->d_wctr, static_cast<uint4*>(d_seg_dst), static_cast<uint4*>(d_rec_dst));
+  hipLaunchKernelGGL(shard_pack_segments, dim3((unsigned)std::min<long long>(ceil_div((size_t)nseg, 256), 4096)), dim3(256), 0, s, h->w_sorted_seg.p, h->w_rec.p, h->updated.p,
+                     h->w_active_off.p, h->xdir.slot_ids, h->sh_owner.p, h->sh_seg_dst.p, h->sh_rec_dst.p, h->sh_seg_pre.p,
+                     h->sh_obase.p, h->d_wctr, static_cast<uint4*>(d_seg_dst), static_cast<uint4*>(d_rec_dst));
   if (h->sh_runs > 0)
     hipLaunchKernelGGL(shard_run_pack, dim3(std::min<size_t>(ceil_div((size_t)h->sh_runs, kRunSpan), 4096)), dim3(256), 0, s,
                        h->dkey0.p, h->w_val0.p, &h->d_wctr[0].num_desc, h->w_masks.p, h->run_r1_log2,
-                       TileMap{(uint32_t)h->prm.shard_count, (uint32_t)h->prm.shard_rank}, h->xdir.slot_ids,
+                       TileMap{(uint32_t)std::max(1, h->prm.shard_count), h->prm.shard_count > 1 ? (uint32_t)h->prm.shard_rank : 0u},
+                       h->xdir.slot_ids,
                        h->sh_slot_owner.p, h->sh_run_ctr.p + 64, h->sh_run_ctr.p + 128, static_cast<uint32_t*>(d_run_dst));
   PLVS_KERNEL_CHECK();
   return PLVS_OK;
@@ -1816,7 +1810,7 @@ int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src,
   hipStream_t s = static_cast<hipStream_t>(stream);
   h->sh_phase = 0;
   h->sh_nsat = 0;
-  const int N = h->prm.shard_count;
+  const int N = std::max(1, h->prm.shard_count);
   const int max_chunks = h->prm.max_chunks;
   std::vector<uint32_t> src_off(2 * ((size_t)N + 1));
   size_t tseg = 0, trec = 0, trun = 0;
@@ -1957,7 +1951,7 @@ int plvs_hip_tsdf_chisel_shard_saturated(plvs_tsdf_chisel* h, int32_t* d_voxels,
 
 int plvs_hip_tsdf_chisel_shard_note_saturated(plvs_tsdf_chisel* h, const int32_t* d_voxels, int n, void* stream) {
   PLVS_REQUIRE(h && n >= 0, "bad argument");
-  PLVS_REQUIRE(h->prm.order_free != 0 && h->prm.shard_count > 1, "not a ray-sharded map");
+  PLVS_REQUIRE(h->prm.order_free != 0 && h->prm.shard_count >= 1, "not a ray-sharded map");
   if (n == 0) return PLVS_OK;
   PLVS_REQUIRE(d_voxels, "null list");
   int rc = shard_state_init(h);

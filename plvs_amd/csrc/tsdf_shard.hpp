@@ -32,29 +32,49 @@
 
 namespace {
 
-// Per updated chunk of the call (index a in `active`): its owner and the records of its segments.
+// Per updated chunk of the call (index a in `active`): its owner, the records of its segments and, per segment,
+// the records of the chunk's earlier segments (seg_pre).
 __global__ __launch_bounds__(256) void shard_chunk_totals(const uint4* __restrict__ sorted_seg,
                                                           const uint32_t* __restrict__ active,
                                                           const uint32_t* __restrict__ active_off,
                                                           const int32_t* __restrict__ slot_ids, int nranks,
                                                           const WalkCounters* __restrict__ ctr,
                                                           uint32_t* __restrict__ nrec, uint32_t* __restrict__ owner,
-                                                          uint32_t* __restrict__ slot_owner) {
+                                                          uint32_t* __restrict__ slot_owner, uint32_t* __restrict__ seg_pre) {
   __shared__ uint32_t wsum[4];
+  __shared__ uint32_t run;
   if (ctr->err) return;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint32_t n = ctr->num_updated;
   for (uint32_t a = blockIdx.x; a < n; a += gridDim.x) {
     const uint32_t s0 = active_off[a], s1 = active_off[a + 1];
-    uint32_t c = 0;
-    for (uint32_t j = s0 + (uint32_t)tid; j < s1; j += 256) c += sorted_seg[2 * (size_t)j].z;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off);
-    if (lane == 0) wsum[wid] = c;
+    if (tid == 0) run = 0;
     __syncthreads();
+    for (uint32_t b = s0; b < s1; b += 256) {
+      const uint32_t j = b + (uint32_t)tid;
+      const uint32_t c = j < s1 ? sorted_seg[2 * (size_t)j].z : 0u;
+      uint32_t inc = c;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
+        if (lane >= off) inc += up;
+      }
+      if (lane == 63) wsum[wid] = inc;
+      __syncthreads();
+      uint32_t wb = run, tot = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        if (w < wid) wb += wsum[w];
+        tot += wsum[w];
+      }
+      if (j < s1) seg_pre[j] = wb + inc - c;
+      __syncthreads();
+      if (tid == 0) run += tot;
+      __syncthreads();
+    }
     if (tid == 0) {
       const int32_t* id = slot_ids + 3 * (size_t)active[a];
-      nrec[a] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+      nrec[a] = run;
       owner[a] = (uint32_t)shard_of(chunk_hash(id[0], id[1], id[2]), nranks);
       slot_owner[active[a]] = owner[a];
     }
@@ -129,65 +149,45 @@ __global__ __launch_bounds__(1024) void shard_plan(const uint32_t* __restrict__ 
 // The wire form of a segment descriptor (two uint4):
 //   {chunk key low, first record relative to the destination's record block, chunk key high, tile},
 //   {slab offsets 1..7 as in the local form, the record count in the 16 bits of offset 0 (always 0)}.
-// Workgroup per chunk; the records of a segment are copied by a wave (contiguous 16-byte items).
+// A lane per segment for the descriptors, then the wave copies the records of its 64 segments one after the
+// other (contiguous 16-byte items).
 __global__ __launch_bounds__(256) void shard_pack_segments(
     const uint4* __restrict__ sorted_seg, const uint4* __restrict__ rec, const uint32_t* __restrict__ active,
     const uint32_t* __restrict__ active_off, const int32_t* __restrict__ slot_ids, const uint32_t* __restrict__ owner,
-    const uint32_t* __restrict__ seg_dst, const uint32_t* __restrict__ rec_dst, const uint32_t* __restrict__ obase,
-    const WalkCounters* __restrict__ ctr, uint4* __restrict__ seg_out, uint4* __restrict__ rec_out) {
-  __shared__ uint32_t src[256], dst[256], cnt[256], wsum[4];
-  __shared__ uint32_t run;
+    const uint32_t* __restrict__ seg_dst, const uint32_t* __restrict__ rec_dst, const uint32_t* __restrict__ seg_pre,
+    const uint32_t* __restrict__ obase, const WalkCounters* __restrict__ ctr, uint4* __restrict__ seg_out,
+    uint4* __restrict__ rec_out) {
   if (ctr->err) return;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lane = threadIdx.x & 63;
   const uint32_t n = ctr->num_updated;
-  for (uint32_t a = blockIdx.x; a < n; a += gridDim.x) {
-    const uint32_t s0 = active_off[a], s1 = active_off[a + 1];
-    const int32_t* id = slot_ids + 3 * (size_t)active[a];
-    unsigned long long key = 0;
-    pack_block(id[0], id[1], id[2], &key);   // (in range: the walk packed it before)
-    const uint32_t rel = obase[2 * owner[a] + 1];
-    if (tid == 0) run = rec_dst[a];
-    __syncthreads();
-    for (uint32_t b = s0; b < s1; b += 256) {
-      const uint32_t j = b + (uint32_t)tid;
-      uint4 d0 = make_uint4(0, 0, 0, 0), d1 = make_uint4(0, 0, 0, 0);
-      if (j < s1) {
-        d0 = sorted_seg[2 * (size_t)j];
-        d1 = sorted_seg[2 * (size_t)j + 1];
+  const uint32_t total = active_off[n];
+  const uint32_t nwaves = gridDim.x * 4u;
+  for (uint32_t w0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u; w0 < total; w0 += nwaves * 64u) {
+    const uint32_t j = w0 + (uint32_t)lane;
+    uint32_t sc = 0, ds = 0, cc = 0;
+    if (j < total) {
+      uint32_t lo = 0, hi = n - 1;   // the chunk of segment j: the last a with active_off[a] <= j
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (active_off[mid] <= j) lo = mid; else hi = mid - 1;
       }
-      const uint32_t c = d0.z;
-      uint32_t inc = c;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
-        if (lane >= off) inc += up;
-      }
-      if (lane == 63) wsum[wid] = inc;
-      __syncthreads();
-      uint32_t wb = run, tot = 0;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        if (w < wid) wb += wsum[w];
-        tot += wsum[w];
-      }
-      const uint32_t at = wb + inc - c;
-      src[tid] = d0.y;
-      dst[tid] = at;
-      cnt[tid] = c;
-      if (j < s1) {
-        const size_t o = (size_t)seg_dst[a] + (j - s0);
-        seg_out[2 * o] = make_uint4((uint32_t)key, at - rel, (uint32_t)(key >> 32), d0.w);
-        seg_out[2 * o + 1] = make_uint4(d1.x | c, d1.y, d1.z, d1.w);
-      }
-      __syncthreads();
-      const uint32_t nb = min(256u, s1 - b);
-      for (uint32_t i = (uint32_t)wid; i < nb; i += 4) {
-        const uint32_t sc = src[i], ds = dst[i], cc = cnt[i];
-        for (uint32_t r = (uint32_t)lane; r < cc; r += 64) rec_out[(size_t)ds + r] = rec[(size_t)sc + r];
-      }
-      __syncthreads();
-      if (tid == 0) run += tot;
-      __syncthreads();
+      const uint32_t a = lo;
+      const uint4 d0 = sorted_seg[2 * (size_t)j], d1 = sorted_seg[2 * (size_t)j + 1];
+      const int32_t* id = slot_ids + 3 * (size_t)active[a];
+      unsigned long long key = 0;
+      pack_block(id[0], id[1], id[2], &key);   // (in range: the walk packed it before)
+      sc = d0.y;
+      cc = d0.z;
+      ds = rec_dst[a] + seg_pre[j];
+      const size_t o = (size_t)seg_dst[a] + (j - active_off[a]);
+      seg_out[2 * o] = make_uint4((uint32_t)key, ds - obase[2 * owner[a] + 1], (uint32_t)(key >> 32), d0.w);
+      seg_out[2 * o + 1] = make_uint4(d1.x | cc, d1.y, d1.z, d1.w);
+    }
+    for (int i = 0; i < 64; ++i) {
+      const uint32_t c = (uint32_t)__shfl((int)cc, i);
+      if (c == 0) continue;
+      const uint32_t s = (uint32_t)__shfl((int)sc, i), d = (uint32_t)__shfl((int)ds, i);
+      for (uint32_t r = (uint32_t)lane; r < c; r += 64) rec_out[(size_t)d + r] = rec[(size_t)s + r];
     }
   }
 }

@@ -12,7 +12,7 @@ import torch
 sys.path.insert(0, __file__.rsplit("/", 3)[0])
 from plvs_amd.synth_scene import make_keyframes  # noqa: E402
 from plvs_amd.tsdf import TsdfChisel  # noqa: E402
-from tests.test_shard_rays import virtual_all_to_all  # noqa: E402
+from tests.test_shard_rays import WIDTHS, send_buffers, virtual_all_to_all  # noqa: E402
 
 STEPS = 4
 kfs = make_keyframes(100 * STEPS, max_depth=5.0, seed=0)
@@ -50,23 +50,24 @@ for world in [int(a) for a in sys.argv[1:]] or [2, 4, 8]:
     per_step = []
     for xyz, rgb, kfid, offsets, Twc in batches:
         tw, tp, ta, sent = [], [], [], []
-        counts, segs, recs = [], [], []
+        counts, bufs = [], []
         for t in ranks:
             c, ms = timed(lambda: t.shard_walk(xyz, offsets, Twc))
             counts.append(c)
             tw.append(ms)
-        for t, c in zip(ranks, counts):
-            seg = torch.zeros((int(c[:, 0].sum()), 8), dtype=torch.int32, device="cuda")
-            rec = torch.zeros((int(c[:, 1].sum()), 4), dtype=torch.int32, device="cuda")
-            _, ms = timed(lambda: t.shard_pack(seg, rec))
+        for r, (t, c) in enumerate(zip(ranks, counts)):
+            b, ms = timed(lambda: send_buffers(t, c))
             tp.append(ms)
-            segs.append(seg)
-            recs.append(rec)
-            r = ranks.index(t)
-            sent.append(32 * (c[:, 0].sum() - c[r, 0]) + 16 * (c[:, 1].sum() - c[r, 1]))
-        for t, (seg, rec, rc) in zip(ranks, virtual_all_to_all(counts, segs, recs)):
-            _, ms = timed(lambda: t.shard_apply(seg, rec, rc, xyz, rgb, kfid))
+            bufs.append(b)
+            sent.append(sum(4 * WIDTHS[k] * (c[:, k].sum() - c[r, k]) for k in range(3)))
+        for t, (seg, rec, run, rc) in zip(ranks, virtual_all_to_all(counts, bufs)):
+            _, ms = timed(lambda: t.shard_apply(seg, rec, run, rc, rgb, kfid))
             ta.append(ms)
+        sat = [t.shard_saturated() for t in ranks]
+        for t in ranks:
+            for lst in sat:
+                if lst.shape[0]:
+                    t.shard_note_saturated(lst)
         per_step.append((max(tw), max(tp), max(ta), max(sent), [t.last_stats()["visits"] for t in ranks]))
     w, p, a, sent, visits = (np.mean([s[k] for s in per_step[1:]]) if k < 4 else per_step[-1][4] for k in range(5))
     print("N=%d: slowest rank walk %.3f + pack %.3f + apply %.3f = %.3f ms per batch (speed-up of the compute %.2fx), "

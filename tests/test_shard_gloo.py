@@ -98,3 +98,52 @@ def test_gloo_block_list_exchange(world):
     assert union == {tuple(x) for x in full.chunk_ids()}
     gathered = {t for step in seen[0] for l in step for t in l}
     assert gathered == union                               # the exchange announced every new block
+
+
+def _worker_segments(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("plvs_amd_shard", os.path.join(ROOT, "plvs_amd", "shard.py"))
+    shard_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shard_mod)
+    # rank `src` sends to rank `dst`: (src + 2 dst) segments, (3 src + dst) records, (src * dst) runs, every item
+    # stamped with (src, dst, index) so that the receiver can tell where each row comes from
+    counts = np.array([[rank + 2 * d, 3 * rank + d, rank * d] for d in range(world)], np.int64)
+    bufs = []
+    for k, width in enumerate((8, 4, 20)):
+        rows = []
+        for d in range(world):
+            for i in range(counts[d, k]):
+                rows.append([rank, d, i, k] + [7] * (width - 4))
+        bufs.append(torch.tensor(rows, dtype=torch.int32).reshape(-1, width))
+    seg, rec, run, rc = shard_mod.exchange_segments(bufs[0], bufs[1], bufs[2], counts)
+    ok = True
+    for k, (got, width) in enumerate(((seg, 8), (rec, 4), (run, 20))):
+        want = []
+        for src in range(world):
+            n = [src + 2 * rank, 3 * src + rank, src * rank][k]
+            ok &= int(rc[src, k]) == n
+            want += [[src, rank, i, k] + [7] * (width - 4) for i in range(n)]
+        ok &= got.tolist() == want
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_segment_exchange_of_the_ray_sharded_integrate(world):
+    """plvs_amd.shard.exchange_segments: counts + three all_to_all_single with split sizes (empty splits included)."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_segments, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out == [(r, True) for r in range(world)]

@@ -128,3 +128,63 @@ def test_hip_ray_sharded_integrate_with_more_ranks_than_tiles_and_empty_calls():
         t.shard_apply(*empty, np.zeros((world, 3), np.int64), rgb[:0], kfid[:0])
     for t in ranks + [single]:
         t.close()
+
+
+@pytest.mark.gpu
+def test_hip_ray_sharded_integrate_through_torch_distributed_and_rccl_at_world_one():
+    """The two real transports with one rank (a rank sends to itself): plvs_amd.shard.sharded_integrate over
+    torch.distributed ("nccl" = RCCL) and plvs_hip_tsdf_chisel_integrate_sharded over an ncclComm_t of its own."""
+    import ctypes
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from plvs_amd import _lib
+    from plvs_amd.shard import sharded_integrate
+    from plvs_amd.tsdf import TsdfChisel
+    kfs = make_keyframes(6, max_depth=5.0, seed=7)
+    single = TsdfChisel(0.05, max_chunks=2048, order_free=True)
+    via_torch = TsdfChisel(0.05, max_chunks=2048, order_free=True)
+    via_rccl = TsdfChisel(0.05, max_chunks=2048, order_free=True)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    rccl = ctypes.CDLL("librccl.so.1", mode=ctypes.RTLD_GLOBAL)
+    uid = (ctypes.c_char * 128)()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+
+    class _Uid(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    rccl.ncclCommInitRank.argtypes = [ctypes.c_void_p, ctypes.c_int, _Uid, ctypes.c_int]
+    u = _Uid()
+    ctypes.memmove(ctypes.byref(u), uid, 128)
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, u, 0) == 0
+    f = _lib.lib.plvs_hip_tsdf_chisel_integrate_sharded
+    f.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] + [ctypes.c_void_p] * 2
+    try:
+        for b0 in range(0, len(kfs), 3):
+            xyz, rgb, kfid, offsets, Twc = _batch(kfs[b0:b0 + 3])
+            single.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
+            sharded_integrate(via_torch, xyz, rgb, kfid, offsets, Twc)
+            _lib.check(f(via_rccl._h, comm, _lib.t_ptr(xyz), _lib.t_ptr(rgb), _lib.t_ptr(kfid), _lib.np_ptr(offsets),
+                         offsets.shape[0] - 1, _lib.t_ptr(Twc), _lib.current_stream_ptr()))
+            torch.cuda.synchronize()
+            assert via_torch.last_stats()["visits"] == single.last_stats()["visits"] == via_rccl.last_stats()["visits"]
+        ids = sorted(tuple(x) for x in single.chunk_ids())
+        for other in (via_torch, via_rccl):
+            assert sorted(tuple(x) for x in other.chunk_ids()) == ids
+            for cid in ids:
+                for x, y in zip(single.get_chunk(*cid), other.get_chunk(*cid)):
+                    assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x,
+                                          y.view(np.uint32) if y.dtype == np.float32 else y)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
+        dist.destroy_process_group()
+        for t in (single, via_torch, via_rccl):
+            t.close()
