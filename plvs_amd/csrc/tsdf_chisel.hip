@@ -1788,7 +1788,7 @@ int plvs_hip_tsdf_chisel_shard_pack(plvs_tsdf_chisel* h, void* d_seg_dst, void* 
   for (int p = 0; p < std::max(1, h->prm.shard_count); ++p) nseg += h->h_sh_counts ? h->h_sh_counts[3 * p] : 0;
   if (nseg == 0) return PLVS_OK;
   PLVS_REQUIRE(d_seg_dst && d_rec_dst && (h->sh_runs == 0 || d_run_dst), "null send buffer");
-  hipLaunchKernelGGL(shard_pack_segments, dim3((unsigned)std::min<long long>(ceil_div((size_t)nseg, 256), 4096)), dim3(256), 0, s, h->w_sorted_seg.p, h->w_rec.p, h->updated.p,
+  hipLaunchKernelGGL(shard_pack_segments, dim3((unsigned)std::min<long long>(ceil_div((size_t)nseg, 4), 8192)), dim3(256), 0, s, h->w_sorted_seg.p, h->w_rec.p, h->updated.p,
                      h->w_active_off.p, h->xdir.slot_ids, h->sh_owner.p, h->sh_seg_dst.p, h->sh_rec_dst.p, h->sh_seg_pre.p,
                      h->sh_obase.p, h->d_wctr, static_cast<uint4*>(d_seg_dst), static_cast<uint4*>(d_rec_dst));
   if (h->sh_runs > 0)

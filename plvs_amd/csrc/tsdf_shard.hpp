@@ -149,8 +149,7 @@ __global__ __launch_bounds__(1024) void shard_plan(const uint32_t* __restrict__ 
 // The wire form of a segment descriptor (two uint4):
 //   {chunk key low, first record relative to the destination's record block, chunk key high, tile},
 //   {slab offsets 1..7 as in the local form, the record count in the 16 bits of offset 0 (always 0)}.
-// A lane per segment for the descriptors, then the wave copies the records of its 64 segments one after the
-// other (contiguous 16-byte items).
+// A wave per segment: its lanes copy the records (contiguous 16-byte items), lane 0 writes the descriptor.
 __global__ __launch_bounds__(256) void shard_pack_segments(
     const uint4* __restrict__ sorted_seg, const uint4* __restrict__ rec, const uint32_t* __restrict__ active,
     const uint32_t* __restrict__ active_off, const int32_t* __restrict__ slot_ids, const uint32_t* __restrict__ owner,
@@ -162,33 +161,25 @@ __global__ __launch_bounds__(256) void shard_pack_segments(
   const uint32_t n = ctr->num_updated;
   const uint32_t total = active_off[n];
   const uint32_t nwaves = gridDim.x * 4u;
-  for (uint32_t w0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u; w0 < total; w0 += nwaves * 64u) {
-    const uint32_t j = w0 + (uint32_t)lane;
-    uint32_t sc = 0, ds = 0, cc = 0;
-    if (j < total) {
-      uint32_t lo = 0, hi = n - 1;   // the chunk of segment j: the last a with active_off[a] <= j
-      while (lo < hi) {
-        const uint32_t mid = (lo + hi + 1) >> 1;
-        if (active_off[mid] <= j) lo = mid; else hi = mid - 1;
-      }
-      const uint32_t a = lo;
-      const uint4 d0 = sorted_seg[2 * (size_t)j], d1 = sorted_seg[2 * (size_t)j + 1];
+  for (uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6); j < total; j += nwaves) {
+    uint32_t lo = 0, hi = n - 1;   // the chunk of segment j: the last a with active_off[a] <= j
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi + 1) >> 1;
+      if (active_off[mid] <= j) lo = mid; else hi = mid - 1;
+    }
+    const uint32_t a = lo;
+    const uint4 d0 = sorted_seg[2 * (size_t)j];
+    const uint32_t ds = rec_dst[a] + seg_pre[j];
+    if (lane == 0) {
+      const uint4 d1 = sorted_seg[2 * (size_t)j + 1];
       const int32_t* id = slot_ids + 3 * (size_t)active[a];
       unsigned long long key = 0;
       pack_block(id[0], id[1], id[2], &key);   // (in range: the walk packed it before)
-      sc = d0.y;
-      cc = d0.z;
-      ds = rec_dst[a] + seg_pre[j];
       const size_t o = (size_t)seg_dst[a] + (j - active_off[a]);
       seg_out[2 * o] = make_uint4((uint32_t)key, ds - obase[2 * owner[a] + 1], (uint32_t)(key >> 32), d0.w);
-      seg_out[2 * o + 1] = make_uint4(d1.x | cc, d1.y, d1.z, d1.w);
+      seg_out[2 * o + 1] = make_uint4(d1.x | d0.z, d1.y, d1.z, d1.w);
     }
-    for (int i = 0; i < 64; ++i) {
-      const uint32_t c = (uint32_t)__shfl((int)cc, i);
-      if (c == 0) continue;
-      const uint32_t s = (uint32_t)__shfl((int)sc, i), d = (uint32_t)__shfl((int)ds, i);
-      for (uint32_t r = (uint32_t)lane; r < c; r += 64) rec_out[(size_t)d + r] = rec[(size_t)s + r];
-    }
+    for (uint32_t r = (uint32_t)lane; r < d0.z; r += 64) rec_out[(size_t)ds + r] = rec[(size_t)d0.y + r];
   }
 }
 
