@@ -1748,7 +1748,7 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
     hipLaunchKernelGGL(compact_runs, dim3(ceil_div(nt, 4)), dim3(256), 0, s, h->w_runkey.p, h->w_run_cnt.p,
                        h->w_run_off.p, nt, h->run_r1_log2, h->dkey0.p, h->w_val0.p);
     hipLaunchKernelGGL(shard_run_count, dim3(256), dim3(256), 0, s, h->dkey0.p, &h->d_wctr[0].num_desc,
-                       h->sh_slot_owner.p, N, h->sh_run_ctr.p);
+                       h->sh_slot_owner.p, N, h->sh_run_ctr.p, h->d_wctr);
     hipLaunchKernelGGL(shard_plan, dim3(1), dim3(1024), 0, s, h->w_active_off.p, h->sh_nrec.p, h->sh_owner.p, N,
                        h->d_wctr, h->sh_seg_dst.p, h->sh_rec_dst.p, h->sh_counts.p, h->sh_obase.p, h->sh_run_ctr.p,
                        h->sh_run_ctr.p + 64, h->sh_run_ctr.p + 128);

@@ -209,8 +209,9 @@ __global__ __launch_bounds__(256) void shard_translate(const uint4* __restrict__
 // Runs per destination (dkey = dense run keys in local tile order, slot * 4096 + voxel of the walk directory).
 __global__ __launch_bounds__(256) void shard_run_count(const uint32_t* __restrict__ dkey, const uint32_t* __restrict__ nd_dev,
                                                        const uint32_t* __restrict__ slot_owner, int nranks,
-                                                       uint32_t* __restrict__ run_counts) {
+                                                       uint32_t* __restrict__ run_counts, const WalkCounters* __restrict__ ctr) {
   __shared__ uint32_t hist[64];
+  if (ctr->err) return;   // (a walk that ran out of room leaves unwritten run slots behind: the host repeats the call)
   if (threadIdx.x < 64) hist[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t nd = *nd_dev;
