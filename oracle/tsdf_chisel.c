@@ -5,15 +5,21 @@
  * TEST INFRASTRUCTURE ONLY.  Nothing under plvs_amd/ may call into this file;
  * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load it.
  *
- * Parity status: UNPINNED by the reference — open_chisel ships no tests and no
- * golden vectors, and the reference itself cannot be compiled
- * here (needs Eigen3 + PCL, both absent).  The arithmetic below therefore
- * restates the reference's expressions *including the evaluation order Eigen
- * 3.3 gives them* (3-vector reductions are evaluated as a0 + (a1 + a2); an
- * Affine transform applied to a point is t + R*p; Transform::inverse() of an
- * Affine transform uses the cofactor inverse), and the C-library overloads
- * g++ picks for the unqualified calls (fmod / sqrt resolve to the double
- * versions).  Compiled with -ffp-contract=off so no FMA contraction changes a
+ * Parity status: PARTLY PINNED by the reference's own sources.  open_chisel ships no tests and no golden
+ * vectors and the whole library cannot be compiled here (Eigen3 + PCL absent), but the
+ * self-contained pieces of the path compile UNMODIFIED against a minimal Eigen stand-in
+ * (oracle/ref/ -> oracle/_ref/libchisel_ref.so): Raycast.cpp (traversal order, tie rules, stop test),
+ * DistVoxel::Integrate, ColorVoxel::IntegrateSimple, QuadraticTruncator, ConstantWeighter.
+ * tests/test_oracle_pinned.py checks raycast(), dist_integrate(), colour_integrate_simple(),
+ * quadratic_truncation() and constant_weight() below — the very functions the integrate loop calls —
+ * against them bit for bit (40 000 rays incl. boundary starts, axis-aligned, diagonal, zero-length and
+ * 400-voxel rays; update sequences through colour saturation).
+ * NOT pinned (restated by reading): the loop glue of Chisel.cpp:442-585 — pose inverse, ray end points, the
+ * signed distance of :525-527, chunk hashing / creation order — and the evaluation order Eigen 3.3 gives
+ * these expressions (3-vector reductions are evaluated as a0 + (a1 + a2); an Affine transform applied to a
+ * point is t + R*p; Transform::inverse() of an Affine transform uses the cofactor inverse; the stand-in
+ * encodes the same reading), and the C-library overloads g++ picks for the unqualified calls (fmod / sqrt
+ * resolve to the double versions).  Compiled with -ffp-contract=off so no FMA contraction changes a
  * rounding.
  *
  * Follows (paths relative to the PLVS tree):
@@ -222,6 +228,31 @@ typedef struct {
   int32_t newc, updc;
 } visit_ctx;
 
+/* DistVoxel::Integrate (DistVoxel.h:91-99) */
+static void dist_integrate(float* sdf, float* w, float distUpdate, float weightUpdate) {
+  const float oldSDF = *sdf, oldWeight = *w;
+  *sdf = (oldWeight * oldSDF + weightUpdate * distUpdate) / (weightUpdate + oldWeight);
+  *w = oldWeight + weightUpdate;
+}
+
+/* ColorVoxel::IntegrateSimple (ColorVoxel.h:91-110) on r | g << 8 | b << 16 | weight << 24 */
+static uint32_t colour_integrate_simple(uint32_t p, uint8_t r, uint8_t g, uint8_t b, uint8_t wu) {
+  uint8_t red = p & 255, green = (p >> 8) & 255, blue = (p >> 16) & 255, cw = p >> 24;
+  if (cw >= 255 - wu) return p;
+  const float inv = 1.f / (float)(wu + cw);
+  red = (uint8_t)((float)(cw * red + wu * r) * inv);
+  green = (uint8_t)((float)(cw * green + wu * g) * inv);
+  blue = (uint8_t)((float)(cw * blue + wu * b) * inv);
+  cw = (uint8_t)(cw + wu);
+  return (uint32_t)red | ((uint32_t)green << 8) | ((uint32_t)blue << 16) | ((uint32_t)cw << 24);
+}
+
+/* QuadraticTruncator::GetTruncationDistance (QuadraticTruncator.h:49), ConstantWeighter::GetWeight (ConstantWeighter.h:45) */
+static float quadratic_truncation(float q, float l, float c, float s, float reading) {
+  return (q * reading * reading + l * reading + c) * s;
+}
+static float constant_weight(float weight, float truncation) { return weight / (2.0f * truncation); }
+
 static int owned(const oracle_chisel* o, const int32_t id[3]) {
   if (o->shard_count <= 1) return 1;
   return (int)(chunk_hash(id) % (size_t)o->shard_count) == o->shard_rank;
@@ -249,7 +280,7 @@ static void visit(void* vctx, int vx, int vy, int vz) {
   xform(c->Ri, c->ti, center, cc);                         /* inversePose * center  :525 */
   const float length = sqrtf(sqnorm3(cc));                 /* :526 */
   const float u = length * (c->depth / cc[2] - 1);         /* :527 */
-  const float weight = o->weight / (2.0f * c->truncation); /* ConstantWeighter.h:45 */
+  const float weight = constant_weight(o->weight, c->truncation);
   if (!(fabs((double)u) < (double)c->truncation)) return;  /* :531 */
 
   /* A chunk created by GetOrCreateChunkAt but never updated is garbage-collected
@@ -262,23 +293,9 @@ static void visit(void* vctx, int vx, int vy, int vz) {
     if (!found) { ch = chunk_create(o, id); c->newc++; }
     c->last = ch;
   }
-  /* DistVoxel::Integrate (DistVoxel.h:91-99) */
-  const float oldSDF = ch->sdf[vid], oldWeight = ch->weight[vid];
-  ch->sdf[vid] = (oldWeight * oldSDF + weight * u) / (weight + oldWeight);
-  ch->weight[vid] = oldWeight + weight;
+  dist_integrate(&ch->sdf[vid], &ch->weight[vid], u, weight);
   ch->kfid[vid] = c->kfid; /* SetKfid, USE_KFID_INTEGRATION 0 */
-  /* ColorVoxel::IntegrateSimple(r,g,b,1) (ColorVoxel.h:91-110) */
-  uint32_t p = ch->rgbw[vid];
-  uint8_t red = p & 255, green = (p >> 8) & 255, blue = (p >> 16) & 255, cw = p >> 24;
-  const uint8_t wu = 1;
-  if (!(cw >= 255 - wu)) {
-    const float inv = 1.f / (float)(wu + cw);
-    red = (uint8_t)((float)(cw * red + wu * c->r) * inv);
-    green = (uint8_t)((float)(cw * green + wu * c->g) * inv);
-    blue = (uint8_t)((float)(cw * blue + wu * c->b) * inv);
-    cw = (uint8_t)(cw + wu);
-    ch->rgbw[vid] = (uint32_t)red | ((uint32_t)green << 8) | ((uint32_t)blue << 16) | ((uint32_t)cw << 24);
-  }
+  ch->rgbw[vid] = colour_integrate_simple(ch->rgbw[vid], c->r, c->g, c->b, 1);
   c->visits++;
 }
 
@@ -314,7 +331,7 @@ void oracle_chisel_integrate(oracle_chisel* o, const float* xyz, const uint8_t* 
       const float nrm = sqrtf(z2);
       dir[0] = v[0] / nrm; dir[1] = v[1] / nrm; dir[2] = v[2] / nrm;
     }
-    const float trunc_q = (o->tq * depth * depth + o->tl * depth + o->tc) * o->ts; /* QuadraticTruncator.h:49 */
+    const float trunc_q = quadratic_truncation(o->tq, o->tl, o->tc, o->ts, depth);
     const float truncation = trunc_q > diag ? trunc_q : diag;               /* std::max, :479 */
     float start[3], end[3];
     for (int k = 0; k < 3; k++) {
@@ -761,3 +778,28 @@ void oracle_chisel_set_chunk(oracle_chisel* o, int cx, int cy, int cz, const flo
   memcpy(c->kfid, kfid, CHUNK_VOX * sizeof(uint32_t));
   memcpy(c->rgbw, rgbw, CHUNK_VOX * sizeof(uint32_t));
 }
+
+/* ---- the pieces above, one by one, for tests/test_oracle_pinned.py: checked there against the reference's own
+ * Raycast.cpp / DistVoxel.h / ColorVoxel.h / QuadraticTruncator.h / ConstantWeighter.h compiled into
+ * oracle/_ref/libchisel_ref.so (oracle/ref/). */
+typedef struct { int32_t* out; int cap, n; } rc_list;
+static void rc_collect(void* ctx, int x, int y, int z) {
+  rc_list* l = (rc_list*)ctx;
+  if (l->n < l->cap) { l->out[3 * l->n] = x; l->out[3 * l->n + 1] = y; l->out[3 * l->n + 2] = z; }
+  l->n++;
+}
+int oracle_chisel_raycast(const float* start, const float* end, int32_t* out, int cap) {
+  rc_list l = {out, cap, 0};
+  raycast(start, end, rc_collect, &l);
+  return l.n;
+}
+void oracle_chisel_dist_integrate(float* sdf, float* weight, float dist_update, float weight_update) {
+  dist_integrate(sdf, weight, dist_update, weight_update);
+}
+void oracle_chisel_colour_integrate_simple(uint8_t* rgbw, uint8_t r, uint8_t g, uint8_t b, uint8_t weight_update) {
+  const uint32_t p = colour_integrate_simple((uint32_t)rgbw[0] | ((uint32_t)rgbw[1] << 8) | ((uint32_t)rgbw[2] << 16) |
+                                             ((uint32_t)rgbw[3] << 24), r, g, b, weight_update);
+  rgbw[0] = p & 255; rgbw[1] = (p >> 8) & 255; rgbw[2] = (p >> 16) & 255; rgbw[3] = p >> 24;
+}
+float oracle_chisel_truncation(float q, float l, float c, float s, float reading) { return quadratic_truncation(q, l, c, s, reading); }
+float oracle_chisel_weight(float weight, float surface_dist, float truncation) { (void)surface_dist; return constant_weight(weight, truncation); }

@@ -1,0 +1,125 @@
+"""The chisel oracle pinned by the reference's OWN sources: oracle/_ref/libchisel_ref.so is open_chisel's
+Raycast.cpp, DistVoxel, ColorVoxel, QuadraticTruncator and ConstantWeighter compiled unmodified from
+/root/reference against a minimal Eigen stand-in (oracle/ref/).  The restatement in oracle/tsdf_chisel.c must agree
+with them bit for bit on random and adversarial inputs: traversal order, tie rules and stop test of the ray cast,
+the voxel update arithmetic, the truncation and weight formulas.
+
+The .so is built in the container that has the reference tree (oracle/ref/Makefile, __graft_entry__.build()) and
+travels with the snapshot; without it the test is skipped (nothing here reads /root/reference at run time)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "libchisel_ref.so")
+ORA = os.path.join(ROOT, "oracle", "liboracle.so")
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(ORA)),
+                                reason="oracle/_ref/libchisel_ref.so (built where /root/reference exists) not present")
+
+
+def _libs():
+    ref, ora = ctypes.CDLL(REF), ctypes.CDLL(ORA)
+    f3 = ctypes.c_float * 3
+    for lib, name in ((ref, "ref_chisel_raycast"), (ora, "oracle_chisel_raycast")):
+        fn = getattr(lib, name)
+        fn.argtypes = [f3, f3, ctypes.c_void_p, ctypes.c_int]
+        fn.restype = ctypes.c_int
+    for lib, pre in ((ref, "ref_chisel_"), (ora, "oracle_chisel_")):
+        getattr(lib, pre + "dist_integrate").argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float]
+        getattr(lib, pre + "colour_integrate_simple").argtypes = [ctypes.c_void_p] + [ctypes.c_uint8] * 4
+        t = getattr(lib, pre + "truncation")
+        t.argtypes, t.restype = [ctypes.c_float] * 5, ctypes.c_float
+        w = getattr(lib, pre + "weight")
+        w.argtypes, w.restype = [ctypes.c_float] * 3, ctypes.c_float
+    return ref, ora, f3
+
+
+def _rays(rng, n):
+    """Segments like the integrate loop casts (a few to a few hundred voxels long), plus the awkward ones: starts
+    and ends on voxel boundaries (ties between tMax values), axis-aligned and diagonal directions, zero length."""
+    start = rng.uniform(-40, 40, (n, 3)).astype(np.float32)
+    length = rng.uniform(0.0, 30.0, (n, 1)).astype(np.float32)
+    length[-n // 20:] = rng.uniform(100.0, 400.0, (n // 20, 1)).astype(np.float32)   # carving-length rays
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-6)
+    end = (start + d * length).astype(np.float32)
+    k = n // 8
+    start[:k] = np.round(start[:k])                          # integer starts: intbound's s == floor(s) branch
+    end[k:2 * k] = np.round(end[k:2 * k])
+    axis = rng.integers(0, 3, 2 * k)
+    for i in range(2 * k, 3 * k):                            # axis-aligned
+        e = start[i].copy()
+        e[axis[i - 2 * k]] += np.float32(rng.uniform(-20, 20))
+        end[i] = e
+    for i in range(3 * k, 4 * k):                            # exact diagonals from integer + 0.5: every tMax ties
+        s = np.round(start[i]) + np.float32(0.5)
+        m = np.float32(rng.integers(1, 12))
+        sg = rng.choice(np.array([-1.0, 1.0], np.float32), 3)
+        start[i], end[i] = s, s + sg * m
+    end[4 * k:4 * k + 50] = start[4 * k:4 * k + 50]          # zero length
+    start[4 * k + 50:4 * k + 100] *= np.float32(1e-3)        # tiny coordinates around the origin (negative floors)
+    end[4 * k + 50:4 * k + 100] = start[4 * k + 50:4 * k + 100] + np.float32(0.25) * d[4 * k + 50:4 * k + 100]
+    return start, end
+
+
+def test_raycast_restatement_equals_the_reference_source():
+    ref, ora, f3 = _libs()
+    rng = np.random.default_rng(20260925)
+    start, end = _rays(rng, 40000)
+    cap = 4096
+    a, b = np.zeros((cap, 3), np.int32), np.zeros((cap, 3), np.int32)
+    total = longest = 0
+    for s, e in zip(start, end):
+        na = ref.ref_chisel_raycast(f3(*s), f3(*e), a.ctypes.data, cap)
+        nb = ora.oracle_chisel_raycast(f3(*s), f3(*e), b.ctypes.data, cap)
+        assert na == nb, (s, e, na, nb)
+        assert na <= cap
+        assert np.array_equal(a[:na], b[:nb]), (s, e)
+        total += na
+        longest = max(longest, na)
+    assert total > 400000 and longest > 300         # the sample did exercise long walks
+
+
+def test_voxel_updates_truncation_and_weight_equal_the_reference_source():
+    ref, ora, _ = _libs()
+    rng = np.random.default_rng(7)
+    # DistVoxel::Integrate: running means as the integrate loop produces them, and raw random operands
+    for trial in range(200):
+        sa, wa = np.float32(99999.0), np.float32(0.0)          # DistVoxel's initial state
+        sb, wb = np.float32(99999.0), np.float32(0.0)
+        ra, rb = (np.array([x], np.float32) for x in (sa, sb))
+        qa, qb = (np.array([x], np.float32) for x in (wa, wb))
+        for _ in range(300):
+            u = np.float32(rng.uniform(-0.6, 0.6))
+            w = np.float32(rng.uniform(0.5, 12.0))
+            ref.ref_chisel_dist_integrate(ra.ctypes.data, qa.ctypes.data, u, w)
+            ora.oracle_chisel_dist_integrate(rb.ctypes.data, qb.ctypes.data, u, w)
+            assert ra.view(np.uint32)[0] == rb.view(np.uint32)[0] and qa.view(np.uint32)[0] == qb.view(np.uint32)[0]
+    # ColorVoxel::IntegrateSimple: every weight 0..255 against random colours, and long sequences through saturation
+    for cw in range(256):
+        for _ in range(40):
+            p = np.array(list(rng.integers(0, 256, 3)) + [cw], np.uint8)
+            q = p.copy()
+            r, g, b = (int(x) for x in rng.integers(0, 256, 3))
+            ref.ref_chisel_colour_integrate_simple(p.ctypes.data, r, g, b, 1)
+            ora.oracle_chisel_colour_integrate_simple(q.ctypes.data, r, g, b, 1)
+            assert np.array_equal(p, q), (cw, r, g, b)
+    p, q = np.zeros(4, np.uint8), np.zeros(4, np.uint8)
+    for _ in range(600):
+        r, g, b = (int(x) for x in rng.integers(0, 256, 3))
+        ref.ref_chisel_colour_integrate_simple(p.ctypes.data, r, g, b, 1)
+        ora.oracle_chisel_colour_integrate_simple(q.ctypes.data, r, g, b, 1)
+        assert np.array_equal(p, q)
+    assert p[3] == 254                                  # frozen one short of 255, as the reference's test leaves it
+    # QuadraticTruncator with PLVS's constants (ChiselServer.cpp:56-59) and random ones; ConstantWeighter
+    for reading in np.concatenate([np.linspace(0.0, 12.0, 5000), rng.uniform(0, 100, 5000)]).astype(np.float32):
+        for q_, l_, c_, s_ in ((0.0019, -0.00152, 0.001504, 6.0), tuple(rng.uniform(-1, 1, 4))):
+            x = ref.ref_chisel_truncation(q_, l_, c_, s_, reading)
+            y = ora.oracle_chisel_truncation(q_, l_, c_, s_, reading)
+            assert np.float32(x).view(np.uint32) == np.float32(y).view(np.uint32)
+        t = np.float32(rng.uniform(0.05, 2.0))
+        assert np.float32(ref.ref_chisel_weight(1.0, 0.0, t)).view(np.uint32) == \
+            np.float32(ora.oracle_chisel_weight(1.0, 0.0, t)).view(np.uint32)
