@@ -248,6 +248,32 @@ class LineMatcher {
                                           mbCheckOrientation ? 1 : 0, assigned.data(), &n));
     return n;
   }
+  // SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, bLargerSearch, bMono), LineMatcher.cc:837 — the
+  // per-frame line match of Tracking::TrackWithMotionModel.  The caller hands over the projections of the last
+  // frame's map lines into the current frame (see plvs_hip_lines_search_by_projection_ff); direction: 0, 1 forward,
+  // 2 backward.  assigned[i2] = last-frame line whose map line the current line i2 takes, -1 = none.
+  int SearchByProjection(const plvs_line_frame_view& CurrentFrame, const uint8_t* occupied, int nLast, const uint8_t* valid,
+                         const float* proj, const int32_t* octave, const float* angle, const uint8_t* desc,
+                         const uint8_t* hasObservations, bool bLargerSearch, int direction,
+                         std::vector<int32_t>& assigned) const {
+    assigned.assign((size_t)CurrentFrame.n, -1);
+    int n = 0;
+    check(plvs_hip_lines_search_by_projection_ff(&CurrentFrame, occupied, nLast, valid, proj, octave, angle, desc,
+                                                 hasObservations, bLargerSearch ? 1 : 0, direction, mfNNratio,
+                                                 mbCheckOrientation ? 1 : 0, assigned.data(), &n));
+    return n;
+  }
+  // SearchByProjection(Frame& F, const std::vector<MapLinePtr>& vpMapLines, bLargerSearch), LineMatcher.cc:1286 —
+  // Tracking::SearchLocalLines.  assigned[i2] = map line the frame line i2 takes, -1 = none.
+  int SearchByProjection(const plvs_line_frame_view& F, const uint8_t* occupied, int nMapLines, const uint8_t* inView,
+                         const float* proj, const int32_t* level, const uint8_t* desc, const uint8_t* hasObservations,
+                         bool bLargerSearch, std::vector<int32_t>& assigned) const {
+    assigned.assign((size_t)F.n, -1);
+    int n = 0;
+    check(plvs_hip_lines_search_by_projection(&F, occupied, nMapLines, inView, proj, level, desc, hasObservations,
+                                              bLargerSearch ? 1 : 0, mfNNratio, assigned.data(), &n));
+    return n;
+  }
   // SearchStereoMatchesByKnn(frame, vMatches, vValidMatches, descriptorDist), LineMatcher.cc:454
   int SearchStereoMatchesByKnn(const uint8_t* descLeft, int nLeft, const float* angleLeft, const int32_t* octaveLeft,
                                const uint8_t* descRight, int nRight, const float* angleRight, const int32_t* octaveRight,
