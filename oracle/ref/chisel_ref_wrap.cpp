@@ -17,7 +17,25 @@
 #include <open_chisel/truncation/QuadraticTruncator.h>
 #include <open_chisel/weighting/ConstantWeighter.h>
 
+// Chisel.cpp:447, `const float diag = 2.0f * sqrt(3.0f) * resolution;`, as that translation unit sees it: inside
+// namespace chisel, after <open_chisel/Chisel.h> (Eigen: <cmath>, never <math.h>), <iostream>, <vector>,
+// <unordered_map>.  With only <cmath> in the include chain the unqualified call finds the C library's
+// ::sqrt(double) — libstdc++ adds the float overload to the global namespace only when <math.h> itself is
+// included — so the product is formed in double and rounded once; oracle/tsdf_chisel.c assumes exactly that.
+#include <iostream>
+#include <unordered_map>
+#include <vector>
+namespace chisel {
+static_assert(sizeof(sqrt(3.0f)) == sizeof(double), "unqualified sqrt(3.0f) binds to ::sqrt(double) here");
+static float truncation_floor(float resolution) {
+  const float diag = 2.0f * sqrt(3.0f) * resolution;
+  return diag;
+}
+}  // namespace chisel
+
 extern "C" {
+
+float ref_chisel_diag(float resolution) { return chisel::truncation_floor(resolution); }
 
 // Raycast(start, end, minVal, maxVal, &voxels) with the bounds Chisel.cpp:447-448 passes; returns the number of
 // voxels (the first `cap` are written to out as x, y, z).

@@ -801,5 +801,6 @@ void oracle_chisel_colour_integrate_simple(uint8_t* rgbw, uint8_t r, uint8_t g, 
                                              ((uint32_t)rgbw[3] << 24), r, g, b, weight_update);
   rgbw[0] = p & 255; rgbw[1] = (p >> 8) & 255; rgbw[2] = (p >> 16) & 255; rgbw[3] = p >> 24;
 }
+float oracle_chisel_diag(float resolution) { return (float)(2.0 * sqrt((double)3.0f) * (double)resolution); }   /* as oracle_chisel_integrate computes it */
 float oracle_chisel_truncation(float q, float l, float c, float s, float reading) { return quadratic_truncation(q, l, c, s, reading); }
 float oracle_chisel_weight(float weight, float surface_dist, float truncation) { (void)surface_dist; return constant_weight(weight, truncation); }

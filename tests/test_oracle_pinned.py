@@ -34,6 +34,8 @@ def _libs():
         t.argtypes, t.restype = [ctypes.c_float] * 5, ctypes.c_float
         w = getattr(lib, pre + "weight")
         w.argtypes, w.restype = [ctypes.c_float] * 3, ctypes.c_float
+        dg = getattr(lib, pre + "diag")
+        dg.argtypes, dg.restype = [ctypes.c_float], ctypes.c_float
     return ref, ora, f3
 
 
@@ -123,3 +125,13 @@ def test_voxel_updates_truncation_and_weight_equal_the_reference_source():
         t = np.float32(rng.uniform(0.05, 2.0))
         assert np.float32(ref.ref_chisel_weight(1.0, 0.0, t)).view(np.uint32) == \
             np.float32(ora.oracle_chisel_weight(1.0, 0.0, t)).view(np.uint32)
+
+
+def test_truncation_floor_binds_sqrt_as_the_reference_translation_unit_does():
+    """Chisel.cpp:447 `2.0f * sqrt(3.0f) * resolution`: double sqrt, one rounding (static_assert in
+    oracle/ref/chisel_ref_wrap.cpp); the oracle's diag must be that value for every resolution PLVS may use."""
+    ref, ora, _ = _libs()
+    rng = np.random.default_rng(3)
+    for res in np.concatenate([np.array([0.005, 0.01, 0.015, 0.02, 0.025, 0.03, 0.04, 0.05, 0.1, 0.2], np.float32),
+                               rng.uniform(0.001, 0.5, 20000).astype(np.float32)]):
+        assert np.float32(ref.ref_chisel_diag(res)).view(np.uint32) == np.float32(ora.oracle_chisel_diag(res)).view(np.uint32)
