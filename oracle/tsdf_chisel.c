@@ -804,3 +804,7 @@ void oracle_chisel_colour_integrate_simple(uint8_t* rgbw, uint8_t r, uint8_t g, 
 float oracle_chisel_diag(float resolution) { return (float)(2.0 * sqrt((double)3.0f) * (double)resolution); }   /* as oracle_chisel_integrate computes it */
 float oracle_chisel_truncation(float q, float l, float c, float s, float reading) { return quadratic_truncation(q, l, c, s, reading); }
 float oracle_chisel_weight(float weight, float surface_dist, float truncation) { (void)surface_dist; return constant_weight(weight, truncation); }
+void oracle_chisel_mc_tables(int* triangle_table, int* edge_index_pairs) {
+  memcpy(triangle_table, kTriangleTable, sizeof(kTriangleTable));
+  memcpy(edge_index_pairs, kEdgeIndexPairs, sizeof(kEdgeIndexPairs));
+}

@@ -135,3 +135,21 @@ def test_truncation_floor_binds_sqrt_as_the_reference_translation_unit_does():
     for res in np.concatenate([np.array([0.005, 0.01, 0.015, 0.02, 0.025, 0.03, 0.04, 0.05, 0.1, 0.2], np.float32),
                                rng.uniform(0.001, 0.5, 20000).astype(np.float32)]):
         assert np.float32(ref.ref_chisel_diag(res)).view(np.uint32) == np.float32(ora.oracle_chisel_diag(res)).view(np.uint32)
+
+
+def test_marching_cubes_tables_are_the_reference_sources():
+    """The triangle table and the edge index pairs the oracle (and, through the committed table, the HIP mesher)
+    use against the ones MarchingCubes.cpp defines."""
+    ref, ora = ctypes.CDLL(REF), ctypes.CDLL(ORA)
+    a, b = np.zeros(4096, np.int32), np.zeros(4096, np.int32)
+    ea, eb = np.zeros(24, np.int32), np.zeros(24, np.int32)
+    ref.ref_chisel_mc_tables(a.ctypes.data_as(ctypes.c_void_p), ea.ctypes.data_as(ctypes.c_void_p))
+    ora.oracle_chisel_mc_tables(b.ctypes.data_as(ctypes.c_void_p), eb.ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(a, b) and np.array_equal(ea, eb)
+    assert (a.reshape(256, 16)[:, -1] == -1).all() and a.max() == 11
+    # the product's copy of the table (plvs_amd/csrc/mc_table.inc, compiled into tsdf_mesh.hip) holds the same numbers
+    import re
+    text = open(os.path.join(ROOT, "plvs_amd", "csrc", "mc_table.inc")).read()
+    text = "\n".join(l for l in text.splitlines() if not l.lstrip().startswith("//"))
+    nums = np.array([int(x) for x in re.findall(r"-?\d+", text)], np.int32)
+    assert np.array_equal(nums, a)
