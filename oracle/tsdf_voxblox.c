@@ -7,11 +7,9 @@
  *
  * Parity status: UNPINNED by the reference.  voxblox's gtests never call
  * integratePointCloud and are disabled in the build; the
- * library cannot be compiled here (Eigen3, glog, protobuf, minkindr absent).
- * Known deviation of this restatement: the reference turns the pose matrix into
- * a kindr quaternion and rotates points with it (T_G_C * p); here the point is
- * rotated with the rotation matrix itself (R p + t).  Both are f32; results can
- * differ in the last ulp of point_G.  The multi-threaded reference is itself
+ * library cannot be compiled here (Eigen3, glog, protobuf absent).
+ * The pose goes through kindr's quaternion as in the reference (quat_from_matrix / quat_transform below, restated
+ * from minkindr — present in the tree — and Eigen 3.3's Quaternion.h, which is not).  The multi-threaded reference is itself
  * order-nondeterministic (per-voxel mutexes, ThreadSafeIndex); the oracle is the
  * integrator_threads = 1 schedule.  The "fast" integrator (PLVS's YAML default)
  * is racy by design (tsdf_integrator.cc:505-569) and has no deterministic
@@ -199,6 +197,44 @@ static void update_voxel(const oracle_voxblox* o, const float origin[3], const f
   *vweight = (new_weight < o->max_weight) ? new_weight : o->max_weight;
 }
 
+/* T_G_C = kindr::minimal::QuatTransformationTemplate<float>(Twc.matrix()) (tsdf_server.cc:484-486): the rotation
+ * block becomes an Eigen::Quaternionf (minkindr/.../quat-transformation-inl.h:72-75, rotation-quaternion-inl.h:112-116),
+ * by Eigen 3.3's matrix -> quaternion assignment (Eigen/src/Geometry/Quaternion.h, quaternionbase_assign_impl<Other,3,3>:
+ * Shoemake's algorithm).  q = {w, x, y, z}. */
+static void quat_from_matrix(const float m[9], float q[4]) {
+  const float tr = m[0] + (m[4] + m[8]);   /* trace() = diagonal().sum(): the length-3 unrolled redux a0 + (a1 + a2) */
+  if (tr > 0.0f) {
+    float s = sqrtf(tr + 1.0f);
+    q[0] = 0.5f * s;
+    s = 0.5f / s;
+    q[1] = (m[7] - m[5]) * s;                                 /* (m21 - m12) */
+    q[2] = (m[2] - m[6]) * s;                                 /* (m02 - m20) */
+    q[3] = (m[3] - m[1]) * s;                                 /* (m10 - m01) */
+  } else {
+    int i = 0;
+    if (m[4] > m[0]) i = 1;
+    if (m[8] > m[4 * i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    float s = sqrtf(m[4 * i] - m[4 * j] - m[4 * k] + 1.0f);
+    q[1 + i] = 0.5f * s;
+    s = 0.5f / s;
+    q[0] = (m[3 * k + j] - m[3 * j + k]) * s;
+    q[1 + j] = (m[3 * j + i] + m[3 * i + j]) * s;
+    q[1 + k] = (m[3 * k + i] + m[3 * i + k]) * s;
+  }
+}
+
+/* T * p = q.rotate(p) + t (quat-transformation-inl.h:159-162; rotate = Eigen's Quaternion * Vector3,
+ * QuaternionBase::_transformVector: uv = 2 (q.vec x v);  v + w uv + q.vec x uv, evaluated coefficient-wise as
+ * (v + w * uv) + cross). */
+static void quat_transform(const float q[4], const float t[3], const float v[3], float out[3]) {
+  const float w = q[0], x = q[1], y = q[2], z = q[3];
+  float uv[3] = {y * v[2] - z * v[1], z * v[0] - x * v[2], x * v[1] - y * v[0]};
+  uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+  const float c[3] = {y * uv[2] - z * uv[1], z * uv[0] - x * uv[2], x * uv[1] - y * uv[0]};
+  for (int k = 0; k < 3; k++) out[k] = ((v[k] + w * uv[k]) + c[k]) + t[k];
+}
+
 /* SimpleTsdfIntegrator::integratePointCloud with integrator_threads = 1.
  * Twc: 3x4 row-major [R|t]; rgba: n x 4 u8 (r,g,b,a members of the pcl point). */
 void oracle_voxblox_integrate(oracle_voxblox* o, const float* xyz, const uint8_t* rgba, int n,
@@ -208,6 +244,8 @@ void oracle_voxblox_integrate(oracle_voxblox* o, const float* xyz, const uint8_t
     for (int j = 0; j < 3; j++) R[3 * i + j] = Twc[4 * i + j];
     t[i] = Twc[4 * i + 3];
   }
+  float q[4];
+  quat_from_matrix(R, q);
   /* tsdf_server.cc:509-527: drop non-finite points, keep order */
   int* keep = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
   size_t m = 0;
@@ -232,7 +270,7 @@ void oracle_voxblox_integrate(oracle_voxblox* o, const float* xyz, const uint8_t
       is_clearing = 0;
     const float* origin = t;
     float pG[3];
-    for (int k = 0; k < 3; k++) pG[k] = sum3(R[3 * k] * pC[0], R[3 * k + 1] * pC[1], R[3 * k + 2] * pC[2]) + t[k];
+    quat_transform(q, t, pC, pG);                            /* T_G_C * point_C (tsdf_integrator.cc:289) */
     /* RayCaster ctor (integrator_utils.cc:137-173) */
     const float d[3] = {pG[0] - origin[0], pG[1] - origin[1], pG[2] - origin[2]};
     const float dn = norm3(d);
@@ -320,4 +358,16 @@ int oracle_voxblox_get_chunk(const oracle_voxblox* o, int cx, int cy, int cz, fl
   memcpy(weight, b->weight, BLOCK_VOX * sizeof(float));
   memcpy(rgba, b->rgba, BLOCK_VOX * sizeof(uint32_t));
   return 1;
+}
+
+/* T_G_C * point_C alone (tests/test_tsdf_voxblox.py checks it against R p + t on rotations that take every branch
+ * of quat_from_matrix). */
+void oracle_voxblox_transform(const float* Twc, const float* p, float* out) {
+  float R[9], t[3], q[4];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) R[3 * i + j] = Twc[4 * i + j];
+    t[i] = Twc[4 * i + 3];
+  }
+  quat_from_matrix(R, q);
+  quat_transform(q, t, p, out);
 }

@@ -42,6 +42,7 @@ __device__ __forceinline__ PoseRt load_pose(const float* __restrict__ Twc, int c
     for (int j = 0; j < 3; ++j) p.R[3 * i + j] = T[4 * i + j];
     p.t[i] = T[4 * i + 3];
   }
+  quat_from_matrix(p.R, p.q);
   return p;
 }
 
@@ -130,8 +131,7 @@ __global__ __launch_bounds__(kExpandThreads) void vb_expand(
     const PoseRt pose = load_pose(Twc, cloud);
     const float px = xyz[3 * (size_t)p], py = xyz[3 * (size_t)p + 1], pz = xyz[3 * (size_t)p + 2];
     float pG[3];
-    for (int k = 0; k < 3; ++k)
-      pG[k] = vsum3(pose.R[3 * k] * px, pose.R[3 * k + 1] * py, pose.R[3 * k + 2] * pz) + pose.t[k];
+    quat_transform(pose, px, py, pz, pG);
     const float weight = fabsf(pz) > 1e-6f ? 1.0f / (pz * pz) : 0.0f;
     const uint32_t slot = key >> 12, vid = key & 4095u;
     const int g[3] = {slot_ids[3 * slot + 0] * 16 + (int)(vid & 15u),

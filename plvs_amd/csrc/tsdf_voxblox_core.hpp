@@ -32,7 +32,47 @@ struct Params {
 
 struct PoseRt {
   float R[9], t[3];
+  float q[4];   // w, x, y, z: the rotation as the reference's kindr transformation holds it
 };
+
+// Eigen 3.3's rotation matrix -> quaternion assignment (Quaternion.h, quaternionbase_assign_impl<Other,3,3>), which
+// kindr::minimal::QuatTransformationTemplate(TransformationMatrix) runs on the pose (tsdf_server.cc:484-486).
+PLVS_HD void quat_from_matrix(const float m[9], float q[4]) {
+  const float tr = m[0] + (m[4] + m[8]);
+  if (tr > 0.0f) {
+    float s = sqrtf(tr + 1.0f);
+    q[0] = 0.5f * s;
+    s = 0.5f / s;
+    q[1] = (m[7] - m[5]) * s;
+    q[2] = (m[2] - m[6]) * s;
+    q[3] = (m[3] - m[1]) * s;
+  } else {
+    int i = 0;
+    if (m[4] > m[0]) i = 1;
+    if (m[8] > m[4 * i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    float s = sqrtf(m[4 * i] - m[4 * j] - m[4 * k] + 1.0f);
+    float v[3];
+    v[i] = 0.5f * s;
+    s = 0.5f / s;
+    q[0] = (m[3 * k + j] - m[3 * j + k]) * s;
+    v[j] = (m[3 * j + i] + m[3 * i + j]) * s;
+    v[k] = (m[3 * k + i] + m[3 * i + k]) * s;
+    q[1] = v[0]; q[2] = v[1]; q[3] = v[2];
+  }
+}
+
+// T_G_C * point_C = q.rotate(p) + t (minkindr quat-transformation-inl.h:159-162; Eigen's
+// QuaternionBase::_transformVector: uv = 2 (q.vec x v); (v + w uv) + q.vec x uv).
+PLVS_HD void quat_transform(const PoseRt& pose, float vx, float vy, float vz, float out[3]) {
+  const float w = pose.q[0], x = pose.q[1], y = pose.q[2], z = pose.q[3];
+  float u0 = y * vz - z * vy, u1 = z * vx - x * vz, u2 = x * vy - y * vx;
+  u0 += u0; u1 += u1; u2 += u2;
+  const float c0 = y * u2 - z * u1, c1 = z * u0 - x * u2, c2 = x * u1 - y * u0;
+  out[0] = ((vx + w * u0) + c0) + pose.t[0];
+  out[1] = ((vy + w * u1) + c1) + pose.t[1];
+  out[2] = ((vz + w * u2) + c2) + pose.t[2];
+}
 
 PLVS_HD float vsum3(float a, float b, float c) { return a + (b + c); }
 
@@ -61,8 +101,7 @@ PLVS_HD bool make_ray(const Params& P, const PoseRt& pose, float px, float py, f
   } else
     clearing = false;
   const float* o = pose.t;
-  for (int k = 0; k < 3; ++k)
-    r->pG[k] = vsum3(pose.R[3 * k] * px, pose.R[3 * k + 1] * py, pose.R[3 * k + 2] * pz) + pose.t[k];
+  quat_transform(pose, px, py, pz, r->pG);
   const float d0 = r->pG[0] - o[0], d1 = r->pG[1] - o[1], d2 = r->pG[2] - o[2];
   const float z2 = vsum3(d0 * d0, d1 * d1, d2 * d2);
   const float dn = sqrtf(z2);

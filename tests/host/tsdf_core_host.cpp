@@ -197,6 +197,7 @@ void hostvbx_integrate(HostVMap* m, const float* xyz, const uint8_t* rgba, int n
   using vbx::visit_operands; using vbx::voxel_fold;
   vbx::PoseRt pose;
   for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) pose.R[3 * i + j] = Twc[4 * i + j]; pose.t[i] = Twc[4 * i + 3]; }
+  vbx::quat_from_matrix(pose.R, pose.q);   // as load_pose (tsdf_voxblox.hip) does
   m->visits = 0;
   for (int seq = 0; seq < n; ++seq) {
     const int p = (int)mixed_index((uint32_t)seq, (uint32_t)n);

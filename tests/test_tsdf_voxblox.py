@@ -140,3 +140,34 @@ def test_hip_batch_shards_and_errors(oracle):
         dev.integrate(bad, rgba_of(kfs[0]), kfs[0]["Twc"])
     assert e.value.code == _lib.PLVS_ERR_INVALID_ARG
     dev.close()
+
+
+def test_oracle_pose_goes_through_the_kindr_quaternion():
+    """T_G_C * p as the reference forms it (rotation matrix -> Eigen quaternion -> q.rotate(p) + t) agrees with
+    R p + t to float rounding for rotations that take each of the four branches of the matrix -> quaternion step."""
+    import ctypes
+    import os
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "liboracle.so"))
+    rng = np.random.default_rng(11)
+
+    def rot(axis, ang):
+        a = np.asarray(axis, np.float64) / np.linalg.norm(axis)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+    cases = [rot(rng.normal(size=3), rng.uniform(-1, 1)) for _ in range(50)]           # trace > 0
+    for ax in np.eye(3):                                                               # near-half turns: the three
+        cases += [rot(ax + 0.05 * rng.normal(size=3), np.pi - e) for e in (0.0, 1e-3, 0.2)]   # diagonal branches
+    seen = set()
+    for R in cases:
+        tr = np.trace(R)
+        seen.add("w" if tr > 0 else "xyz"[int(np.argmax(np.diag(R)))])
+        Twc = np.concatenate([R, rng.uniform(-3, 3, (3, 1))], axis=1).astype(np.float32)
+        for _ in range(20):
+            p = rng.uniform(-6, 6, 3).astype(np.float32)
+            out = np.zeros(3, np.float32)
+            lib.oracle_voxblox_transform(Twc.ctypes.data_as(ctypes.c_void_p), p.ctypes.data_as(ctypes.c_void_p),
+                                         out.ctypes.data_as(ctypes.c_void_p))
+            want = Twc[:, :3].astype(np.float64) @ p.astype(np.float64) + Twc[:, 3]
+            assert np.abs(out - want).max() < 2e-5, (R, p, out, want)
+    assert seen == {"w", "x", "y", "z"}
