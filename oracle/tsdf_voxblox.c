@@ -5,9 +5,17 @@
  *
  * TEST INFRASTRUCTURE ONLY.  Nothing under plvs_amd/ may call into this file.
  *
- * Parity status: UNPINNED by the reference.  voxblox's gtests never call
- * integratePointCloud and are disabled in the build; the
- * library cannot be compiled here (Eigen3, glog, protobuf absent).
+ * Parity status: PARTLY PINNED by the reference's own sources.  voxblox's gtests never call
+ * integratePointCloud and are disabled in the build; the library as a whole cannot be compiled
+ * here (Eigen3, glog, protobuf absent), but integrator_utils.cc and the inline helpers of common.h /
+ * block_hash.h compile UNMODIFIED against stand-ins for Eigen, glog and kindr's type names
+ * (oracle/ref/vbx_shim -> oracle/_ref/libvoxblox_ref.so).  tests/test_oracle_pinned.py checks vb_ray_setup /
+ * vb_ray_next (RayCaster: ray end points for normal and clearing rays with carving on and off, setupRayCaster,
+ * nextRayIndex; 30 000 rays), mixed_index (ThreadSafeIndex with its bit-reversal table), blend
+ * (Color::blendTwoColors), block_index / local_index and the block hash below — the functions the integrate loop
+ * calls — against them bit for bit.  NOT pinned (restated by reading): updateTsdfVoxel / computeDistance /
+ * getVoxelWeight (tsdf_integrator.cc needs Layer / Block, which need protobuf), the point filter, the pose
+ * conversion below, and Eigen's evaluation order, which the stand-in encodes as this file does.
  * The pose goes through kindr's quaternion as in the reference (quat_from_matrix / quat_transform below, restated
  * from minkindr — present in the tree — and Eigen 3.3's Quaternion.h, which is not).  The multi-threaded reference is itself
  * order-nondeterministic (per-voxel mutexes, ThreadSafeIndex); the oracle is the
@@ -197,6 +205,72 @@ static void update_voxel(const oracle_voxblox* o, const float origin[3], const f
   *vweight = (new_weight < o->max_weight) ? new_weight : o->max_weight;
 }
 
+/* RayCaster (integrator_utils.cc:137-235): the constructor SimpleTsdfIntegrator uses + setupRayCaster, nextRayIndex. */
+typedef struct {
+  int32_t cur[3], sgn[3];
+  float t_next[3], t_step[3];
+  int steps; /* ray_length_in_steps_: the ray emits steps + 1 voxels */
+} vb_ray;
+
+static void vb_ray_setup(const float origin[3], const float pG[3], int is_clearing, int carving, float max_ray,
+                         float voxel_size_inv, float truncation, vb_ray* r) {
+  const float d[3] = {pG[0] - origin[0], pG[1] - origin[1], pG[2] - origin[2]};
+  const float dn = norm3(d);
+  float unit[3] = {d[0], d[1], d[2]};
+  if (sum3(d[0] * d[0], d[1] * d[1], d[2] * d[2]) > 0.0f) { unit[0] = d[0] / dn; unit[1] = d[1] / dn; unit[2] = d[2] / dn; }
+  float ray_start[3], ray_end[3];
+  if (is_clearing) {
+    float ray_length = dn;
+    float tmp = ray_length - truncation;
+    tmp = (tmp < 0.0f) ? 0.0f : tmp;                     /* std::max(x, 0) */
+    ray_length = (max_ray < tmp) ? max_ray : tmp;        /* std::min(x, max_ray) */
+    for (int k = 0; k < 3; k++) {
+      ray_end[k] = origin[k] + unit[k] * ray_length;
+      ray_start[k] = carving ? origin[k] : ray_end[k];
+    }
+  } else {
+    for (int k = 0; k < 3; k++) {
+      ray_end[k] = pG[k] + unit[k] * truncation;
+      ray_start[k] = carving ? origin[k] : (pG[k] - unit[k] * truncation);
+    }
+  }
+  float ss[3], es[3];
+  for (int k = 0; k < 3; k++) { ss[k] = ray_start[k] * voxel_size_inv; es[k] = ray_end[k] * voxel_size_inv; }
+  /* setupRayCaster (:196-235) */
+  int32_t endi[3];
+  r->steps = 0;
+  for (int k = 0; k < 3; k++) {
+    r->cur[k] = (int32_t)floorf(ss[k] + 1e-6f);          /* getGridIndexFromPoint (common.h:147-151) */
+    endi[k] = (int32_t)floorf(es[k] + 1e-6f);
+    r->steps += abs(endi[k] - r->cur[k]);
+    const float rs = es[k] - ss[k];
+    r->sgn[k] = vb_signum(rs);
+    const float corrected = (float)(r->sgn[k] > 0 ? r->sgn[k] : 0);
+    const float shifted = ss[k] - (float)r->cur[k];
+    const float dist = corrected - shifted;
+    r->t_next[k] = dist / rs;          /* the `abs(x) < 0.0 ? 2.0 :` guards can never fire */
+    r->t_step[k] = (float)r->sgn[k] / rs;
+  }
+}
+
+static void vb_ray_next(vb_ray* r, int32_t g[3]) {
+  g[0] = r->cur[0]; g[1] = r->cur[1]; g[2] = r->cur[2];
+  int mi = 0; /* Eigen minCoeff(&idx): first coefficient, replaced only by a strictly smaller one */
+  if (r->t_next[1] < r->t_next[mi]) mi = 1;
+  if (r->t_next[2] < r->t_next[mi]) mi = 2;
+  r->cur[mi] += r->sgn[mi];
+  r->t_next[mi] += r->t_step[mi];
+}
+
+/* getBlockIndexFromGlobalVoxelIndex (common.h:175-186), getLocalFromGlobalVoxelIndex (:190-198), 16 voxels per side */
+static void block_index(const int32_t g[3], float voxels_per_side_inv, int32_t bid[3]) {
+  for (int k = 0; k < 3; k++) bid[k] = (int32_t)floorf((float)g[k] * voxels_per_side_inv);
+}
+static void local_index(const int32_t g[3], int32_t l[3]) {
+  const uint32_t off = 1u << 31;
+  for (int k = 0; k < 3; k++) l[k] = (int32_t)(((uint32_t)g[k] + off) & 15u);
+}
+
 /* T_G_C = kindr::minimal::QuatTransformationTemplate<float>(Twc.matrix()) (tsdf_server.cc:484-486): the rotation
  * block becomes an Eigen::Quaternionf (minkindr/.../quat-transformation-inl.h:72-75, rotation-quaternion-inl.h:112-116),
  * by Eigen 3.3's matrix -> quaternion assignment (Eigen/src/Geometry/Quaternion.h, quaternionbase_assign_impl<Other,3,3>:
@@ -271,67 +345,24 @@ void oracle_voxblox_integrate(oracle_voxblox* o, const float* xyz, const uint8_t
     const float* origin = t;
     float pG[3];
     quat_transform(q, t, pC, pG);                            /* T_G_C * point_C (tsdf_integrator.cc:289) */
-    /* RayCaster ctor (integrator_utils.cc:137-173) */
-    const float d[3] = {pG[0] - origin[0], pG[1] - origin[1], pG[2] - origin[2]};
-    const float dn = norm3(d);
-    float unit[3] = {d[0], d[1], d[2]};
-    if (sum3(d[0] * d[0], d[1] * d[1], d[2] * d[2]) > 0.0f) { unit[0] = d[0] / dn; unit[1] = d[1] / dn; unit[2] = d[2] / dn; }
-    float ray_start[3], ray_end[3];
-    if (is_clearing) {
-      float ray_length = dn;
-      float tmp = ray_length - o->truncation;
-      tmp = (tmp < 0.0f) ? 0.0f : tmp;                       /* std::max(x, 0) */
-      ray_length = (o->max_ray < tmp) ? o->max_ray : tmp;    /* std::min(x, max_ray) */
-      for (int k = 0; k < 3; k++) {
-        ray_end[k] = origin[k] + unit[k] * ray_length;
-        ray_start[k] = o->carving ? origin[k] : ray_end[k];
-      }
-    } else {
-      for (int k = 0; k < 3; k++) {
-        ray_end[k] = pG[k] + unit[k] * o->truncation;
-        ray_start[k] = o->carving ? origin[k] : (pG[k] - unit[k] * o->truncation);
-      }
-    }
-    float ss[3], es[3];
-    for (int k = 0; k < 3; k++) { ss[k] = ray_start[k] * o->voxel_size_inv; es[k] = ray_end[k] * o->voxel_size_inv; }
-    /* setupRayCaster (:196-235) */
-    int32_t cur[3], endi[3], sgn[3];
-    float t_next[3], t_step[3];
-    int steps = 0;
-    for (int k = 0; k < 3; k++) {
-      cur[k] = (int32_t)floorf(ss[k] + 1e-6f);
-      endi[k] = (int32_t)floorf(es[k] + 1e-6f);
-      steps += abs(endi[k] - cur[k]);
-      const float rs = es[k] - ss[k];
-      sgn[k] = vb_signum(rs);
-      const float corrected = (float)(sgn[k] > 0 ? sgn[k] : 0);
-      const float shifted = ss[k] - (float)cur[k];
-      const float dist = corrected - shifted;
-      t_next[k] = dist / rs;          /* the `abs(x) < 0.0 ? 2.0 :` guards can never fire */
-      t_step[k] = (float)sgn[k] / rs;
-    }
+    vb_ray ray;
+    vb_ray_setup(origin, pG, is_clearing, o->carving, o->max_ray, o->voxel_size_inv, o->truncation, &ray);
     const float weight = o->use_const_weight ? 1.0f : (fabsf(pC[2]) > 1e-6f ? 1.0f / (pC[2] * pC[2]) : 0.0f);
     /* nextRayIndex (:180-194): emits ray_length_in_steps + 1 voxels */
-    for (int step = 0; step <= steps; step++) {
-      const int32_t g[3] = {cur[0], cur[1], cur[2]};
-      int mi = 0; /* Eigen minCoeff(&idx): first coefficient, replaced only by a strictly smaller one */
-      if (t_next[1] < t_next[mi]) mi = 1;
-      if (t_next[2] < t_next[mi]) mi = 2;
-      cur[mi] += sgn[mi];
-      t_next[mi] += t_step[mi];
+    for (int step = 0; step <= ray.steps; step++) {
+      int32_t g[3];
+      vb_ray_next(&ray, g);
       /* allocateStorageAndGetVoxelPtr (:114-157) */
-      const int32_t bid[3] = {(int32_t)floorf((float)g[0] * o->voxels_per_side_inv),
-                              (int32_t)floorf((float)g[1] * o->voxels_per_side_inv),
-                              (int32_t)floorf((float)g[2] * o->voxels_per_side_inv)};
+      int32_t bid[3];
+      block_index(g, o->voxels_per_side_inv, bid);
       if (o->shard_count > 1 && (int)(owner_hash(bid) % (size_t)o->shard_count) != o->shard_rank) continue;
       if (!last_block || last_bid[0] != bid[0] || last_bid[1] != bid[1] || last_bid[2] != bid[2]) {
         last_block = vblock_get(o, bid); /* may rehash: never keep a pointer across another lookup */
         memcpy(last_bid, bid, sizeof(last_bid));
       }
-      const uint32_t off = 1u << 31;
-      const int lx = (int)(((uint32_t)g[0] + off) & 15u), ly = (int)(((uint32_t)g[1] + off) & 15u),
-                lz = (int)(((uint32_t)g[2] + off) & 15u);
-      const int vid = lx + VPS * (ly + lz * VPS);
+      int32_t l[3];
+      local_index(g, l);
+      const int vid = l[0] + VPS * (l[1] + l[2] * VPS);
       update_voxel(o, origin, pG, g, color, weight, &last_block->distance[vid], &last_block->weight[vid],
                    &last_block->rgba[vid]);
       visits++;
@@ -370,4 +401,27 @@ void oracle_voxblox_transform(const float* Twc, const float* p, float* out) {
   }
   quat_from_matrix(R, q);
   quat_transform(q, t, p, out);
+}
+
+/* ---- the pieces above one by one, for tests/test_oracle_pinned.py: checked there against voxblox's own
+ * integrator_utils.cc / common.h / block_hash.h compiled into oracle/_ref/libvoxblox_ref.so (oracle/ref/). */
+int oracle_voxblox_raycast(const float* origin, const float* point_G, int is_clearing, int carving, float max_ray,
+                           float voxel_size_inv, float truncation, int32_t* out, int cap) {
+  vb_ray r;
+  vb_ray_setup(origin, point_G, is_clearing, carving, max_ray, voxel_size_inv, truncation, &r);
+  for (int s = 0; s <= r.steps; s++) {
+    int32_t g[3];
+    vb_ray_next(&r, g);
+    if (s < cap) { out[3 * s] = g[0]; out[3 * s + 1] = g[1]; out[3 * s + 2] = g[2]; }
+  }
+  return r.steps + 1;
+}
+void oracle_voxblox_mixed_order(int n, int64_t* out) {
+  for (int i = 0; i < n; i++) out[i] = (int64_t)mixed_index((size_t)i, (size_t)n);
+}
+uint32_t oracle_voxblox_blend(uint32_t c1, float w1, uint32_t c2, float w2) { return blend(c1, w1, c2, w2); }
+void oracle_voxblox_indices(const int32_t* g, int32_t* block, int32_t* local, uint64_t* hash) {
+  block_index(g, (float)(1.0 / VPS), block);
+  local_index(g, local);
+  *hash = (uint64_t)vb_hash(block);
 }

@@ -153,3 +153,78 @@ def test_marching_cubes_tables_are_the_reference_sources():
     text = "\n".join(l for l in text.splitlines() if not l.lstrip().startswith("//"))
     nums = np.array([int(x) for x in re.findall(r"-?\d+", text)], np.int32)
     assert np.array_equal(nums, a)
+
+
+# ---------------------------------------------------------------- voxblox
+VREF = os.path.join(ROOT, "oracle", "_ref", "libvoxblox_ref.so")
+needs_vref = pytest.mark.skipif(not os.path.exists(VREF), reason="oracle/_ref/libvoxblox_ref.so not present")
+
+
+def _vlibs():
+    ref, ora = ctypes.CDLL(VREF), ctypes.CDLL(ORA)
+    f3 = ctypes.c_float * 3
+    for lib, pre in ((ref, "ref_voxblox_"), (ora, "oracle_voxblox_")):
+        rc = getattr(lib, pre + "raycast")
+        rc.argtypes = [f3, f3, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_int]
+        rc.restype = ctypes.c_int
+        getattr(lib, pre + "mixed_order").argtypes = [ctypes.c_int, ctypes.c_void_p]
+        bl = getattr(lib, pre + "blend")
+        bl.argtypes, bl.restype = [ctypes.c_uint32, ctypes.c_float, ctypes.c_uint32, ctypes.c_float], ctypes.c_uint32
+        getattr(lib, pre + "indices").argtypes = [ctypes.c_void_p] * 4
+    return ref, ora, f3
+
+
+@needs_vref
+def test_voxblox_raycaster_restatement_equals_the_reference_source():
+    """RayCaster's constructor (ray end points for normal and clearing rays, carving on and off), setupRayCaster
+    and nextRayIndex of integrator_utils.cc against vb_ray_setup / vb_ray_next of oracle/tsdf_voxblox.c."""
+    ref, ora, f3 = _vlibs()
+    rng = np.random.default_rng(99)
+    cap = 4096
+    a, b = np.zeros((cap, 3), np.int32), np.zeros((cap, 3), np.int32)
+    total = 0
+    for i in range(30000):
+        origin = rng.uniform(-5, 5, 3).astype(np.float32)
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        if i % 7 == 0:                               # axis-aligned rays: two t_to_next_boundary are infinite
+            d = np.eye(3)[rng.integers(0, 3)] * rng.choice([-1.0, 1.0])
+        point = (origin + d * rng.uniform(0.1, 9.0)).astype(np.float32)
+        if i % 11 == 0:                              # points on voxel boundaries
+            point = np.round(point * 10) / np.float32(10)
+        if i % 501 == 0:
+            point = origin.copy()                    # zero-length ray
+        vs = float(rng.choice([0.02, 0.05, 0.1]))
+        vsi = np.float32(1.0 / vs)                   # static_cast<FloatingPoint>(1.0 / voxel_size)
+        clearing, carving = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        na = ref.ref_voxblox_raycast(f3(*origin), f3(*point), clearing, carving, 5.0, vsi, 0.1, a.ctypes.data, cap)
+        nb = ora.oracle_voxblox_raycast(f3(*origin), f3(*point), clearing, carving, 5.0, vsi, 0.1, b.ctypes.data, cap)
+        assert na == nb, (origin, point, vs, clearing, carving, na, nb)
+        assert np.array_equal(a[:min(na, cap)], b[:min(nb, cap)]), (origin, point, vs, clearing, carving)
+        total += na
+    assert total > 500000
+
+
+@needs_vref
+def test_voxblox_point_order_colour_blend_and_indices_equal_the_reference_source():
+    ref, ora, _ = _vlibs()
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 1023, 1024, 1025, 2048, 5000, 76800, 307200):      # ThreadSafeIndex: groups of 1024 + a tail
+        a, b = np.zeros(n, np.int64), np.zeros(n, np.int64)
+        ref.ref_voxblox_mixed_order(n, a.ctypes.data)
+        ora.oracle_voxblox_mixed_order(n, b.ctypes.data)
+        assert np.array_equal(a, b)
+        assert np.array_equal(np.sort(a), np.arange(n))
+    for _ in range(200000):                                              # Color::blendTwoColors
+        c1, c2 = (int(x) for x in rng.integers(0, 2 ** 32, 2, dtype=np.uint64))
+        w1 = np.float32(rng.choice([0.0, rng.uniform(0, 50), rng.uniform(0, 1e4)]))
+        w2 = np.float32(rng.uniform(1e-4, 100))
+        assert ref.ref_voxblox_blend(c1, w1, c2, w2) == ora.oracle_voxblox_blend(c1, w1, c2, w2), (c1, w1, c2, w2)
+    g = np.zeros(3, np.int32)                                            # block / local voxel index, block hash
+    ba, la, bb, lb = (np.zeros(3, np.int32) for _ in range(4))
+    ha, hb = np.zeros(1, np.uint64), np.zeros(1, np.uint64)
+    for _ in range(100000):
+        g[:] = rng.integers(-70000, 70000, 3) if rng.random() < 0.9 else rng.integers(-40, 40, 3)
+        ref.ref_voxblox_indices(g.ctypes.data, ba.ctypes.data, la.ctypes.data, ha.ctypes.data)
+        ora.oracle_voxblox_indices(g.ctypes.data, bb.ctypes.data, lb.ctypes.data, hb.ctypes.data)
+        assert np.array_equal(ba, bb) and np.array_equal(la, lb) and ha[0] == hb[0], g
