@@ -467,6 +467,10 @@ typedef struct plvs_tsdf_stats {
 } plvs_tsdf_stats;
 int plvs_hip_tsdf_chisel_last_stats(plvs_tsdf_chisel* h, plvs_tsdf_stats* s);
 
+/* Tuning knob of the order_free apply stage: a chunk that collects more than `min_segments` (tile, chunk) segments in
+ * a call is applied in parts of `part_segments` segments (defaults 2048 / 256); results do not depend on it. */
+int plvs_hip_tsdf_chisel_set_apply_parts(plvs_tsdf_chisel* h, int part_segments, int min_segments);
+
 /* Optional per-stage timing with HIP events recorded on the caller's stream
  * (what bench.py uses for the live roofline figure).  Enabling resets the
  * accumulators.  stage_ms returns the milliseconds accumulated per pipeline

@@ -752,6 +752,12 @@ struct plvs_tsdf_chisel {
   DevBuf<uint4> w_rec, w_seg, w_sorted_seg;
   DevBuf<uint32_t> w_chunk_nseg, w_chunk_off, w_chunk_fill, w_active_off, w_masks, w_dummy, w_seg_cnt, w_tile_visits;
   DevBuf<uint8_t> w_cold;
+  DevBuf<uint32_t> w_part_off, w_multi_idx;          // apply stage: parts of the updated chunks
+  DevBuf<long long> pa_wuu;                          //   accumulators of the chunks applied in parts (zero between calls)
+  DevBuf<unsigned long long> pa_w;
+  DevBuf<uint32_t> pa_last, pa_cnt, pa_done;
+  uint32_t multi_cap = 0;
+  uint32_t part_segs = kPartSegs, part_min = kPartMin;   // (plvs_hip_tsdf_chisel_set_apply_parts)
   DevBuf<uint32_t> w_runkey, w_run_cnt, w_run_off, w_val0, w_val1;   // runs: per-tile regions of 2^run_r1_log2 slots
   uint32_t run_r1_log2 = 6;
   float scale_u = 1.f, scale_w = 1.f;   // fixed-point scales of the order-free accumulators (powers of two)
@@ -825,6 +831,26 @@ static int sort_runs(plvs_tsdf_chisel* h, uint32_t D, uint32_t ntiles, int num_c
   return PLVS_OK;
 }
 
+// Accumulators for `chunks` chunks applied in parts (apply_chunks leaves them zero).
+static int ensure_part_acc(plvs_tsdf_chisel* h, uint32_t chunks) {
+  if (chunks <= h->multi_cap) return PLVS_OK;
+  const size_t nv = (size_t)chunks * kChunkVox, nd = (size_t)chunks * kSlabs;
+  h->pa_wuu.release(); h->pa_w.release(); h->pa_last.release(); h->pa_cnt.release(); h->pa_done.release();
+  h->multi_cap = 0;
+  PLVS_HIP_TRY(h->pa_wuu.reserve(nv));
+  PLVS_HIP_TRY(h->pa_w.reserve(nv));
+  PLVS_HIP_TRY(h->pa_last.reserve(nv));
+  PLVS_HIP_TRY(h->pa_cnt.reserve(nv));
+  PLVS_HIP_TRY(h->pa_done.reserve(nd));
+  PLVS_HIP_TRY(hipMemset(h->pa_wuu.p, 0, nv * sizeof(long long)));
+  PLVS_HIP_TRY(hipMemset(h->pa_w.p, 0, nv * sizeof(unsigned long long)));
+  PLVS_HIP_TRY(hipMemset(h->pa_last.p, 0, nv * sizeof(uint32_t)));
+  PLVS_HIP_TRY(hipMemset(h->pa_cnt.p, 0, nv * sizeof(uint32_t)));
+  PLVS_HIP_TRY(hipMemset(h->pa_done.p, 0, nd * sizeof(uint32_t)));
+  h->multi_cap = chunks;
+  return PLVS_OK;
+}
+
 // Order-free mode: walk_tiles -> segment sort -> apply_chunks (+ the colour fold when the call met voxels
 // whose colour weight is below 254).
 static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uint8_t* d_rgb, const uint32_t* d_kfid,
@@ -848,6 +874,12 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
   size_t rec_spill = std::max<size_t>(h->w_rec.cap > rec_own ? h->w_rec.cap - rec_own : 0, (size_t)1 << 16);
   size_t seg_spill = std::max<size_t>(h->w_seg.cap / 2 > seg_own ? h->w_seg.cap / 2 - seg_own : 0, (size_t)1 << 12);
   PLVS_HIP_TRY(h->w_run_cnt.reserve(ntiles));
+  PLVS_HIP_TRY(h->w_part_off.reserve((size_t)max_chunks + 1));
+  PLVS_HIP_TRY(h->w_multi_idx.reserve((size_t)max_chunks + 1));
+  {
+    int rc = ensure_part_acc(h, std::min<uint32_t>((uint32_t)max_chunks, 64u));
+    if (rc != PLVS_OK) return rc;
+  }
   PLVS_HIP_TRY(h->dkey0.reserve(kSmallRuns));
   PLVS_HIP_TRY(h->w_val0.reserve(kSmallRuns));
   PLVS_HIP_TRY(h->heads.reserve(kSmallRuns));
@@ -880,14 +912,16 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
                        h->d_wctr);
     hipLaunchKernelGGL(seg_scan, dim3(1), dim3(1024), 0, s, h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p,
                        h->updated.p, h->w_active_off.p, h->d_wctr, &h->d_ctr->num_chunks, max_chunks,
-                       h->w_tile_visits.p, h->w_run_cnt.p, ntiles);
+                       h->w_tile_visits.p, h->w_run_cnt.p, ntiles, h->w_part_off.p, h->w_multi_idx.p, h->multi_cap,
+                       h->part_segs, h->part_min);
     hipLaunchKernelGGL(seg_pass<true>, dim3(seg_blocks), dim3(256), 0, s, h->w_seg.p, out.seg_cap, ntiles,
                        h->w_seg_cnt.p, h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p,
                        h->d_wctr);
     STAGE_MARK(2);
     hipLaunchKernelGGL(apply_chunks, dim3(4096), dim3(kApplyThreads), 0, s, h->w_sorted_seg.p, h->updated.p,
-                       h->w_active_off.p, h->w_rec.p, 1.0 / (double)h->scale_u, 1.0 / (double)h->scale_w, d_kfid, h->sdf,
-                       h->weight, h->kfid, h->d_wctr);
+                       h->w_active_off.p, h->w_part_off.p, h->w_multi_idx.p, h->part_segs,
+                       PartAcc{h->pa_wuu.p, h->pa_w.p, h->pa_last.p, h->pa_cnt.p, h->pa_done.p}, h->w_rec.p,
+                       1.0 / (double)h->scale_u, 1.0 / (double)h->scale_w, d_kfid, h->sdf, h->weight, h->kfid, h->d_wctr);
     PLVS_KERNEL_CHECK();
     STAGE_MARK(3);
     // ---- colour fold: the truncating u8 mean is order dependent -> through the sorted runs of the voxels
@@ -948,6 +982,10 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
   h->stats.voxels = (int32_t)c.num_heads;
   h->stats.max_run = (int32_t)c.max_run;
   h->last_updated = c.num_updated;
+  if (c.num_multi > h->multi_cap) {   // more busy chunks than part accumulators: provide them for the next call
+    int rc = ensure_part_acc(h, std::min<uint32_t>((uint32_t)max_chunks, c.num_multi + c.num_multi / 2));
+    if (rc != PLVS_OK) return rc;
+  }
   float ms[4] = {0.f, 0.f, 0.f, 0.f};   // the last one: what the colour fold adds behind the apply stage
   if (h->profiling)
     for (int i = 0; i < 4; ++i) PLVS_HIP_TRY(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
@@ -1089,7 +1127,8 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   h->w_rec.release(); h->w_seg.release(); h->w_sorted_seg.release(); h->w_chunk_nseg.release();
   h->w_chunk_off.release(); h->w_chunk_fill.release(); h->w_active_off.release(); h->w_masks.release();
   h->w_dummy.release(); h->w_cold.release(); h->w_runkey.release(); h->w_run_cnt.release(); h->w_run_off.release(); h->w_val0.release();
-  h->w_val1.release(); h->w_seg_cnt.release(); h->w_tile_visits.release();
+  h->w_val1.release(); h->w_seg_cnt.release(); h->w_tile_visits.release(); h->w_part_off.release(); h->w_multi_idx.release();
+  h->pa_wuu.release(); h->pa_w.release(); h->pa_last.release(); h->pa_cnt.release(); h->pa_done.release();
   h->sh_nrec.release(); h->sh_owner.release(); h->sh_seg_dst.release(); h->sh_rec_dst.release(); h->sh_obase.release();
   h->sh_seg_pre.release(); h->sh_src_off.release(); h->sh_slot_owner.release(); h->sh_run_ctr.release(); h->sh_vkey.release(); h->sh_sat.release();
   h->sh_counts.release();
@@ -1354,6 +1393,13 @@ int plvs_hip_tsdf_chisel_integrate(plvs_tsdf_chisel* h, const float* xyz, const 
                                                     h->st_Twc.p, nullptr);
   if (rc != PLVS_OK) return rc;
   PLVS_HIP_TRY(hipDeviceSynchronize());
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_chisel_set_apply_parts(plvs_tsdf_chisel* h, int part_segments, int min_segments) {
+  PLVS_REQUIRE(h && part_segments >= 1 && min_segments >= 1, "bad argument");
+  h->part_segs = (uint32_t)part_segments;
+  h->part_min = (uint32_t)min_segments;
   return PLVS_OK;
 }
 
@@ -1697,6 +1743,8 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
   PLVS_HIP_TRY(h->w_tile_visits.reserve(nt));
   PLVS_HIP_TRY(h->w_run_cnt.reserve(nt));
   PLVS_HIP_TRY(h->w_run_off.reserve((size_t)nt + 1));
+  PLVS_HIP_TRY(h->w_part_off.reserve(xmax + 1));
+  PLVS_HIP_TRY(h->w_multi_idx.reserve(xmax + 1));
   PLVS_HIP_TRY(h->sh_nrec.reserve(xmax));
   PLVS_HIP_TRY(h->sh_owner.reserve(xmax));
   PLVS_HIP_TRY(h->sh_slot_owner.reserve(xmax));
@@ -1737,7 +1785,7 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
                        h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p, h->d_wctr);
     hipLaunchKernelGGL(seg_scan, dim3(1), dim3(1024), 0, s, h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p,
                        h->updated.p, h->w_active_off.p, h->d_wctr, h->d_xcount, (int)xmax, h->w_tile_visits.p,
-                       h->w_run_cnt.p, nt);
+                       h->w_run_cnt.p, nt, h->w_part_off.p, h->w_multi_idx.p, 0u, h->part_segs, h->part_min);
     hipLaunchKernelGGL(seg_pass<true>, dim3(seg_blocks), dim3(256), 0, s, h->w_seg.p, out.seg_cap, nt, h->w_seg_cnt.p,
                        h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p, h->d_wctr);
     hipLaunchKernelGGL(shard_chunk_totals, dim3(1024), dim3(256), 0, s, h->w_sorted_seg.p, h->updated.p,
@@ -1840,6 +1888,13 @@ int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src,
   PLVS_HIP_TRY(h->w_chunk_fill.reserve((size_t)max_chunks));
   PLVS_HIP_TRY(h->w_active_off.reserve((size_t)max_chunks + 1));
   PLVS_HIP_TRY(h->updated.reserve((size_t)max_chunks + 1));
+  PLVS_HIP_TRY(h->w_part_off.reserve((size_t)max_chunks + 1));
+  PLVS_HIP_TRY(h->w_multi_idx.reserve((size_t)max_chunks + 1));
+  {
+    // every chunk applied in parts has more than kPartMin segments: the received total bounds their number
+    int rc = ensure_part_acc(h, std::min<uint32_t>((uint32_t)max_chunks, total / std::max(1u, h->part_min) + 1u));
+    if (rc != PLVS_OK) return rc;
+  }
   const int chunks_before = h->num_chunks;
   PLVS_HIP_TRY(hipMemcpyAsync(h->sh_src_off.p, src_off.data(), src_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
   PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->total_visits, 0, sizeof(uint32_t), s));
@@ -1860,13 +1915,16 @@ int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src,
                      h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p, h->d_wctr);
   hipLaunchKernelGGL(seg_scan, dim3(1), dim3(1024), 0, s, h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p,
                      h->updated.p, h->w_active_off.p, h->d_wctr, &h->d_ctr->num_chunks, max_chunks,
-                     (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
+                     (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, h->w_part_off.p, h->w_multi_idx.p, h->multi_cap,
+                     h->part_segs, h->part_min);
   hipLaunchKernelGGL(seg_pass<true>, dim3(seg_blocks), dim3(256), 0, s, h->w_seg.p, total, 0u, (const uint32_t*)nullptr,
                      h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p, h->d_wctr);
   STAGE_MARK(2);
   hipLaunchKernelGGL(apply_chunks, dim3(4096), dim3(kApplyThreads), 0, s, h->w_sorted_seg.p, h->updated.p,
-                     h->w_active_off.p, static_cast<const uint4*>(d_rec_src), 1.0 / (double)h->scale_u,
-                     1.0 / (double)h->scale_w, d_kfid, h->sdf, h->weight, h->kfid, h->d_wctr);
+                     h->w_active_off.p, h->w_part_off.p, h->w_multi_idx.p, h->part_segs,
+                     PartAcc{h->pa_wuu.p, h->pa_w.p, h->pa_last.p, h->pa_cnt.p, h->pa_done.p},
+                     static_cast<const uint4*>(d_rec_src), 1.0 / (double)h->scale_u, 1.0 / (double)h->scale_w, d_kfid,
+                     h->sdf, h->weight, h->kfid, h->d_wctr);
   PLVS_KERNEL_CHECK();
   STAGE_MARK(3);
   // ---- colours: the received runs, by (voxel, tile)

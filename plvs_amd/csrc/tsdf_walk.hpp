@@ -66,6 +66,8 @@ struct WalkCounters {           // device-side, read back once per call
   uint32_t rec_top, seg_top;    // records / segments written (walk_acc)
   uint32_t ncold;               // tiles that met a voxel with colour weight < 254
   uint32_t split_tiles;         // tiles that had to be cut (table overflow)
+  uint32_t num_parts;           // apply stage: sum over the updated chunks of their parts
+  uint32_t num_multi;           //   chunks applied in more than one part
 };
 
 // Find-or-insert with the slot returned; usable by concurrent workgroups of ONE kernel.  A block that
@@ -704,6 +706,8 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
 // goes to the global per-chunk counters once per (workgroup, chunk): seg_pass<false> counts,
 // seg_scan scans (and lists the updated chunks, sums the per-tile visit counts), seg_pass<true> places.
 constexpr int kSegSpan = 1024;     // descriptor slots per workgroup (16 tiles)
+constexpr uint32_t kPartSegs = 256;   // segments of a busy chunk one work item of the apply stage takes (default)
+constexpr uint32_t kPartMin = 2048;   // a chunk with more segments than this is applied in parts (default)
 constexpr int kSegTable = 512;
 template <bool kScatter>
 __global__ __launch_bounds__(256) void seg_pass(const uint4* __restrict__ seg, uint32_t seg_cap, uint32_t ntiles,
@@ -767,43 +771,73 @@ __global__ __launch_bounds__(1024) void seg_scan(const uint32_t* __restrict__ ch
                                                  uint32_t* __restrict__ active_off, WalkCounters* __restrict__ ctr,
                                                  const int32_t* __restrict__ num_chunks, int max_chunks,
                                                  const uint32_t* __restrict__ tile_visits,
-                                                 const uint32_t* __restrict__ run_cnt, uint32_t ntiles) {
-  __shared__ uint32_t wsum[16], wact[16];
-  __shared__ uint32_t carry, acarry;
+                                                 const uint32_t* __restrict__ run_cnt, uint32_t ntiles,
+                                                 uint32_t* __restrict__ part_off, uint32_t* __restrict__ multi_idx,
+                                                 uint32_t multi_cap, uint32_t part_segs, uint32_t part_min) {
+  // part_off / multi_idx (per updated chunk, in `active` order): the chunk's first part in the apply stage's
+  // item list (a part = part_segs segments of a chunk with more than part_min of them) and its index among the
+  // chunks applied in parts
+  __shared__ uint32_t wsum[16], wact[16], wprt[16], wmul[16];
+  __shared__ uint32_t carry, acarry, pcarry, mcarry;
   __shared__ unsigned long long vsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int n = min(*num_chunks, max_chunks);
-  if (tid == 0) { carry = 0; acarry = 0; }
+  if (tid == 0) { carry = 0; acarry = 0; pcarry = 0; mcarry = 0; }
   __syncthreads();
   for (int base = 0; base < n; base += 1024) {
     const int s = base + tid;
     const uint32_t c = s < n ? chunk_nseg[s] : 0u;
     const uint32_t a = c ? 1u : 0u;
-    uint32_t inc = c, ainc = a;
+    const uint32_t m = c > part_min ? 1u : 0u;
+    uint32_t inc = c, ainc = a, minc = m;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const uint32_t up = (uint32_t)__shfl_up((int)inc, off), aup = (uint32_t)__shfl_up((int)ainc, off);
-      if (lane >= off) { inc += up; ainc += aup; }
+      const uint32_t mup = (uint32_t)__shfl_up((int)minc, off);
+      if (lane >= off) { inc += up; ainc += aup; minc += mup; }
     }
-    if (lane == 63) { wsum[wid] = inc; wact[wid] = ainc; }
+    if (lane == 63) { wsum[wid] = inc; wact[wid] = ainc; wmul[wid] = minc; }
     __syncthreads();
-    uint32_t wb = carry, ab = acarry, tot = 0, atot = 0;
+    uint32_t wb = carry, ab = acarry, mb = mcarry, tot = 0, atot = 0, mtot = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) {
-      if (w < wid) { wb += wsum[w]; ab += wact[w]; }
+      if (w < wid) { wb += wsum[w]; ab += wact[w]; mb += wmul[w]; }
       tot += wsum[w];
       atot += wact[w];
+      mtot += wmul[w];
+    }
+    // a busy chunk beyond the accumulators the host has provided is applied in one part (slower, never wrong);
+    // the host sees num_multi and provides more for the next call
+    const uint32_t midx = mb + minc - 1u;
+    const bool multi = m && midx < multi_cap;
+    const uint32_t np = multi ? (c + part_segs - 1u) / part_segs : a;
+    uint32_t pinc = np;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t pup = (uint32_t)__shfl_up((int)pinc, off);
+      if (lane >= off) pinc += pup;
+    }
+    if (lane == 63) wprt[wid] = pinc;
+    __syncthreads();
+    uint32_t pb = pcarry, ptot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      if (w < wid) pb += wprt[w];
+      ptot += wprt[w];
     }
     if (s < n) {
       chunk_off[s] = wb + inc - c;
       chunk_fill[s] = 0;
       if (c) {
-        active[ab + ainc - 1u] = (uint32_t)s;
-        active_off[ab + ainc - 1u] = wb + inc - c;
+        const uint32_t at = ab + ainc - 1u;
+        active[at] = (uint32_t)s;
+        active_off[at] = wb + inc - c;
+        part_off[at] = pb + pinc - np;
+        multi_idx[at] = multi ? midx : 0xFFFFFFFFu;
       }
     }
     __syncthreads();
-    if (tid == 0) { carry += tot; acarry += atot; }
+    if (tid == 0) { carry += tot; acarry += atot; pcarry += ptot; mcarry += mtot; }
     __syncthreads();
   }
   unsigned long long v = 0, nr = 0;
@@ -826,27 +860,39 @@ __global__ __launch_bounds__(1024) void seg_scan(const uint32_t* __restrict__ ch
     ctr->num_desc = (uint32_t)rtot;
     ctr->num_updated = acarry;
     active_off[acarry] = carry;
+    part_off[acarry] = pcarry;
+    ctr->num_parts = pcarry;
+    ctr->num_multi = mcarry;
   }
 }
 
-// The apply stage ("LDS-staged blocks").  Work item = (updated chunk, slab of kSlabVox voxels): the
-// records of the slab — contiguous inside every segment of the chunk — are added into LDS accumulators
-// (64-bit fixed point: the result does not depend on the order of the records), then every visited
-// voxel of the slab takes ONE update.  Sixteen lanes share a segment, four segments per group are in
-// flight together.
+// The apply stage ("LDS-staged blocks").  Work item = (updated chunk, part, slab of kSlabVox voxels): the records of
+// the slab — contiguous inside every segment — are added into LDS accumulators (64-bit fixed point: the result does
+// not depend on the order of the records).  A chunk normally is one part and takes its updates at once, ONE per
+// visited voxel.  A chunk with more than part_min segments (an owner of the ray-sharded integrate collects the
+// segments of every rank; a long batch over a small scene) is cut into parts of part_segs segments: the parts add
+// their sums to the chunk's accumulators in global memory, the part that finishes last applies the update and leaves
+// the accumulators zero for the next call.  Sixteen lanes share a segment, four segments per group are in flight.
+struct PartAcc {           // per (chunk applied in parts, voxel); `done` per (such chunk, slab)
+  long long* wuu;
+  unsigned long long* w;
+  uint32_t *last, *cnt, *done;
+};
 constexpr int kApplyThreads = 512;
 __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
     const uint4* __restrict__ sorted_seg, const uint32_t* __restrict__ active, const uint32_t* __restrict__ active_off,
+    const uint32_t* __restrict__ part_off, const uint32_t* __restrict__ multi_idx, uint32_t part_segs, PartAcc acc,
     const uint4* __restrict__ rec, double inv_scale_u, double inv_scale_w, const uint32_t* __restrict__ kfid_of_point,
     float* __restrict__ sdf, float* __restrict__ weight, uint32_t* __restrict__ vkfid, WalkCounters* __restrict__ ctr) {
   __shared__ long long a_wuu[kSlabVox];
   __shared__ unsigned long long a_w[kSlabVox];
   __shared__ uint32_t a_last[kSlabVox], a_cnt[kSlabVox];
+  __shared__ uint32_t is_last;
   const int tid = threadIdx.x, lane = tid & 63;
   const int grp = tid >> 4, gl = tid & 15;
   constexpr int kGroups = kApplyThreads / 16, kFly = 4;
   if (ctr->err) return;   // the walk ran out of scratch: the host grows it and repeats the call, the map stays as it was
-  const uint32_t nitems = ctr->num_updated * kSlabs;
+  const uint32_t nchunks = ctr->num_updated, nitems = ctr->num_parts * kSlabs;
   uint32_t voxels = 0, longest = 0;
   auto add = [&](const uint4 q) {
     const uint32_t v = (q.x & 0xFFFu) % kSlabVox;
@@ -856,7 +902,13 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
     atomicAdd(&a_cnt[v], q.x >> 12);
   };
   for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const uint32_t a = item / kSlabs, slab = item % kSlabs;
+    const uint32_t pi = item / kSlabs, slab = item % kSlabs;
+    uint32_t lo = 0, hi = nchunks - 1;   // the chunk of part pi: the last a with part_off[a] <= pi
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi + 1) >> 1;
+      if (part_off[mid] <= pi) lo = mid; else hi = mid - 1;
+    }
+    const uint32_t a = lo, nparts = part_off[a + 1] - part_off[a];
     for (int v = tid; v < kSlabVox; v += kApplyThreads) {
       a_wuu[v] = 0;
       a_w[v] = 0;
@@ -864,44 +916,78 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
       a_cnt[v] = 0;
     }
     __syncthreads();
-    const uint32_t s0 = active_off[a], s1 = active_off[a + 1];
+    const uint32_t s0 = active_off[a] + (pi - part_off[a]) * part_segs;
+    const uint32_t s1 = nparts > 1 ? min(active_off[a + 1], s0 + part_segs) : active_off[a + 1];
     for (uint32_t sb = s0 + (uint32_t)grp * kFly; sb < s1; sb += kGroups * kFly) {
-      uint32_t lo[kFly], hi[kFly];
+      uint32_t lo_r[kFly], hi_r[kFly];
       uint4 q[kFly];
 #pragma unroll
       for (int j = 0; j < kFly; ++j) {
-        lo[j] = hi[j] = 0;
+        lo_r[j] = hi_r[j] = 0;
         if (sb + j < s1) {
           const uint4 d0 = sorted_seg[2 * (size_t)(sb + j)], d1 = sorted_seg[2 * (size_t)(sb + j) + 1];
           const uint32_t w[4] = {d1.x, d1.y, d1.z, d1.w};
           const uint32_t o = (w[slab >> 1] >> ((slab & 1) * 16)) & 0xFFFFu;
           const uint32_t e = slab + 1 < kSlabs ? (w[(slab + 1) >> 1] >> (((slab + 1) & 1) * 16)) & 0xFFFFu : d0.z;
-          lo[j] = d0.y + o;
-          hi[j] = d0.y + e;
+          lo_r[j] = d0.y + o;
+          hi_r[j] = d0.y + e;
         }
       }
 #pragma unroll
       for (int j = 0; j < kFly; ++j)
-        if (lo[j] + gl < hi[j]) q[j] = rec[lo[j] + gl];
+        if (lo_r[j] + gl < hi_r[j]) q[j] = rec[lo_r[j] + gl];
 #pragma unroll
       for (int j = 0; j < kFly; ++j) {
-        if (lo[j] + gl < hi[j]) add(q[j]);
-        for (uint32_t r = lo[j] + 16u + gl; r < hi[j]; r += 16) add(rec[r]);
+        if (lo_r[j] + gl < hi_r[j]) add(q[j]);
+        for (uint32_t r = lo_r[j] + 16u + gl; r < hi_r[j]; r += 16) add(rec[r]);
       }
     }
     __syncthreads();
     const size_t pool0 = (size_t)active[a] * kChunkVox + (size_t)slab * kSlabVox;
-    for (int v = tid; v < kSlabVox; v += kApplyThreads) {
-      const uint32_t c = a_cnt[v];
-      if (c) {
-        const float m = (float)((double)a_wuu[v] * inv_scale_u), ws = (float)((double)a_w[v] * inv_scale_w);
-        const float W = weight[pool0 + v], Sd = sdf[pool0 + v];
-        const float wn = W + ws;
-        sdf[pool0 + v] = (W * Sd + m) / wn;
-        weight[pool0 + v] = wn;
-        vkfid[pool0 + v] = kfid_of_point ? kfid_of_point[a_last[v]] : 0u;
-        ++voxels;
-        longest = max(longest, c);
+    bool apply = true;
+    if (nparts > 1) {
+      // ---- this part's sums join the chunk's; the last part to arrive applies them.  Returning atomics: once their
+      // results are back they have been performed, so the ticket below is taken after them without a release fence
+      // (which would write the whole L2 back).
+      const size_t g0 = ((size_t)multi_idx[a] * kSlabs + slab) * kSlabVox;
+      uint32_t seen = 0;
+      for (int v = tid; v < kSlabVox; v += kApplyThreads) {
+        if (a_cnt[v] == 0) continue;
+        seen += (uint32_t)atomicAdd((unsigned long long*)&acc.wuu[g0 + v], (unsigned long long)a_wuu[v]);
+        seen += (uint32_t)atomicAdd(&acc.w[g0 + v], a_w[v]);
+        seen += atomicMax(&acc.last[g0 + v], a_last[v]);
+        seen += atomicAdd(&acc.cnt[g0 + v], a_cnt[v]);
+      }
+      if (seen == 0x9E3779B9u) a_last[tid % kSlabVox] = seen;   // (keeps the results alive; never the point)
+      __syncthreads();
+      if (tid == 0) is_last = atomicAdd(&acc.done[(size_t)multi_idx[a] * kSlabs + slab], 1u) == nparts - 1u ? 1u : 0u;
+      __syncthreads();
+      apply = is_last != 0u;
+      if (apply) {   // (read-modify-write reads: performed where the other parts' atomics were)
+        for (int v = tid; v < kSlabVox; v += kApplyThreads) {
+          a_cnt[v] = atomicExch(&acc.cnt[g0 + v], 0u);
+          if (a_cnt[v]) {
+            a_wuu[v] = (long long)atomicExch((unsigned long long*)&acc.wuu[g0 + v], 0ull);
+            a_w[v] = atomicExch(&acc.w[g0 + v], 0ull);
+            a_last[v] = atomicExch(&acc.last[g0 + v], 0u);
+          }
+        }
+        if (tid == 0) atomicExch(&acc.done[(size_t)multi_idx[a] * kSlabs + slab], 0u);
+      }
+    }
+    if (apply) {
+      for (int v = tid; v < kSlabVox; v += kApplyThreads) {
+        const uint32_t c = a_cnt[v];
+        if (c) {
+          const float m = (float)((double)a_wuu[v] * inv_scale_u), ws = (float)((double)a_w[v] * inv_scale_w);
+          const float W = weight[pool0 + v], Sd = sdf[pool0 + v];
+          const float wn = W + ws;
+          sdf[pool0 + v] = (W * Sd + m) / wn;
+          weight[pool0 + v] = wn;
+          vkfid[pool0 + v] = kfid_of_point ? kfid_of_point[a_last[v]] : 0u;
+          ++voxels;
+          longest = max(longest, c);
+        }
       }
     }
     __syncthreads();

@@ -156,6 +156,13 @@ class TsdfChisel:
         return dict(visits=s.visits, points=s.points, new_chunks=s.new_chunks,
                     updated_chunks=s.updated_chunks, voxels=s.voxels, max_run=s.max_run)
 
+    def set_apply_parts(self, part_segments, min_segments):
+        """Tuning knob of the order-free apply stage (results do not depend on it): chunks with more than
+        `min_segments` segments in a call are applied in parts of `part_segments`."""
+        f = _lib.lib.plvs_hip_tsdf_chisel_set_apply_parts
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        _lib.check(f(self._h, int(part_segments), int(min_segments)))
+
     def set_profiling(self, enable=True):
         _lib.check(_lib.lib.plvs_hip_tsdf_chisel_set_profiling(self._h, int(bool(enable))))
 

@@ -14,12 +14,16 @@ from plvs_amd.synth_scene import make_keyframes  # noqa: E402
 from plvs_amd.tsdf import TsdfChisel  # noqa: E402
 from tests.test_shard_rays import WIDTHS, send_buffers, virtual_all_to_all  # noqa: E402
 
-STEPS = 4
-kfs = make_keyframes(100 * STEPS, max_depth=5.0, seed=0)
+STEPS = 3
+WEAK = "--weak" in sys.argv          # a step carries 100 keyframes per rank (bench.py's default at N > 1)
+WORLDS = [int(a) for a in sys.argv[1:] if not a.startswith("-")] or [2, 4, 8]
+PER_STEP = 100 * (max(WORLDS) if WEAK else 1)
+poses = make_keyframes(100, max_depth=5.0, seed=0)
+kfs = [poses[i % 100] for i in range(PER_STEP * STEPS)]
 
 
 def batch(i):
-    part = kfs[100 * i:100 * (i + 1)]
+    part = kfs[PER_STEP * i:PER_STEP * (i + 1)]
     xyz = torch.from_numpy(np.concatenate([k["xyz"] for k in part])).cuda()
     rgb = torch.from_numpy(np.concatenate([k["rgb"] for k in part])).cuda()
     kfid = torch.from_numpy(np.concatenate([k["kfid"] for k in part]).astype(np.int32)).cuda()
@@ -43,9 +47,9 @@ t1 = []
 for xyz, rgb, kfid, offsets, Twc in batches:
     _, ms = timed(lambda: single.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc))
     t1.append(ms)
-print("single device: %.3f ms per batch (last %d of %d)" % (np.mean(t1[1:]), STEPS - 1, STEPS))
+print("single device: %.3f ms per batch of %d keyframes (last %d of %d)" % (np.mean(t1[1:]), PER_STEP, STEPS - 1, STEPS))
 single.close()
-for world in [int(a) for a in sys.argv[1:]] or [2, 4, 8]:
+for world in WORLDS:
     ranks = [TsdfChisel(0.05, max_chunks=16384, shard_rank=r, shard_count=world, order_free=True) for r in range(world)]
     per_step = []
     for xyz, rgb, kfid, offsets, Twc in batches:

@@ -188,3 +188,39 @@ def test_hip_ray_sharded_integrate_through_torch_distributed_and_rccl_at_world_o
         dist.destroy_process_group()
         for t in (single, via_torch, via_rccl):
             t.close()
+
+
+@pytest.mark.gpu
+def test_hip_order_free_apply_in_parts_gives_the_same_map():
+    """A busy chunk is applied in parts (sums through global accumulators, the last part applies): forced here with
+    tiny thresholds, on one device and on the owners of a ray-sharded map; every variant must be bit-identical."""
+    from plvs_amd.tsdf import TsdfChisel
+    kfs = make_keyframes(6, max_depth=5.0, seed=9)
+    plain = TsdfChisel(0.05, max_chunks=2048, order_free=True)
+    parts = TsdfChisel(0.05, max_chunks=2048, order_free=True)
+    parts.set_apply_parts(8, 16)          # nearly every chunk has more than 16 segments: few accumulator sets at first
+    world = 3
+    ranks = [TsdfChisel(0.05, max_chunks=2048, shard_rank=r, shard_count=world, order_free=True) for r in range(world)]
+    for t in ranks:
+        t.set_apply_parts(4, 8)
+    for b0 in range(0, len(kfs), 2):
+        xyz, rgb, kfid, offsets, Twc = _batch(kfs[b0:b0 + 2])
+        plain.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
+        parts.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
+        sharded_step(ranks, xyz, rgb, kfid, offsets, Twc)
+        assert parts.last_stats() == plain.last_stats()
+    ids = sorted(tuple(x) for x in plain.chunk_ids())
+    assert sorted(tuple(x) for x in parts.chunk_ids()) == ids
+    owner = {}
+    for r, t in enumerate(ranks):
+        for cid in (tuple(x) for x in t.chunk_ids()):
+            owner[cid] = t
+    assert sorted(owner) == ids
+    for cid in ids:
+        a = plain.get_chunk(*cid)
+        for other in (parts.get_chunk(*cid), owner[cid].get_chunk(*cid)):
+            for x, y in zip(a, other):
+                assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x,
+                                      y.view(np.uint32) if y.dtype == np.float32 else y), cid
+    for t in ranks + [plain, parts]:
+        t.close()
