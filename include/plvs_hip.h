@@ -522,9 +522,10 @@ int plvs_hip_tsdf_chisel_carve_dev(plvs_tsdf_chisel* h, const float* d_depth, in
  * ChunkHasher(id) mod N, ChunkManager.h:42-54), the WORK by tile of the point stream — rank r walks the tiles
  * t = r (mod N) of 512 consecutive points of every call, through whatever chunks their rays cross, and sends
  * what it collected to the chunk owners.  Every rank is given the same clouds.  One call =
- *   shard_walk    this rank's tiles; send_counts[3 * N] = {segments, records, colour runs} per destination
+ *   shard_walk    this rank's tiles, then its own aggregation: one sum per touched voxel;
+ *                 send_counts[3 * N] = {descriptors, voxel sums, colour runs} per destination
  *   shard_pack    the three send buffers, each grouped by destination in rank order:
- *                 segments 32 B, records 16 B, runs 80 B per item (sizes from send_counts)
+ *                 descriptors 32 B (one per chunk and slab of 512 voxels), sums 32 B, runs 80 B per item
  *   all-to-all    counts, then the three buffers (the caller's transport; ..._integrate_sharded does it over RCCL)
  *   shard_apply   the three receive buffers grouped by source in rank order, recv_counts[3 * N]
  *   shard_saturated / all-gather / shard_note_saturated

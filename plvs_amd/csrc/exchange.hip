@@ -202,7 +202,7 @@ int plvs_hip_tsdf_exchange_block_lists(void* rccl_comm, const int32_t* d_local_i
 }
 
 // The ray-sharded integrate with its exchanges over RCCL (tsdf_shard.hpp): shard_walk, the all-to-all of the
-// counts, shard_pack, the all-to-all of segments / records / runs (grouped ncclSend / ncclRecv pairs, uint32
+// counts, shard_pack, the all-to-all of descriptors / voxel sums / runs (grouped ncclSend / ncclRecv pairs, uint32
 // words), shard_apply, and the all-gather of the voxels whose colour saturated in the call.
 int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm, const float* d_xyz, const uint8_t* d_rgb,
                                            const uint32_t* d_kfid, const int32_t* offsets, int nclouds, const float* d_Twc,
@@ -225,7 +225,7 @@ int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm,
     plvs::DevBuf<int32_t> sat, all_sat, nsat;
   };
   static thread_local Scratch B;
-  constexpr size_t kWords[3] = {8, 4, 20};   // uint32 words of a segment descriptor, a record, a run
+  constexpr size_t kWords[3] = {8, 8, 20};   // uint32 words of a descriptor, a voxel sum, a run
   int64_t sc[3 * 64], rcv[3 * 64];
   int rc = plvs_hip_tsdf_chisel_shard_walk(h, d_xyz, offsets, nclouds, d_Twc, sc, stream);
   if (rc != PLVS_OK) return rc;

@@ -766,7 +766,10 @@ struct plvs_tsdf_chisel {
   Directory xdir{};                  // the walk directory: every chunk the rank's tiles have crossed (ids only)
   int32_t* d_xcount = nullptr;
   uint32_t* x_sat = nullptr;         //   + one bit per voxel: its owner has reported the colour saturated
-  DevBuf<uint32_t> sh_seg_pre, sh_nrec, sh_owner, sh_slot_owner, sh_seg_dst, sh_rec_dst, sh_obase, sh_src_off, sh_run_ctr, sh_vkey, sh_sat;
+  DevBuf<uint32_t> sh_ctl;
+  uint32_t* h_sh_ctl = nullptr;      // pinned [320]
+  DevBuf<uint4> sh_seg_reg, sh_rec_reg;
+  DevBuf<uint32_t> sh_nrec, sh_owner, sh_slot_owner, sh_seg_dst, sh_rec_dst, sh_obase, sh_src_off, sh_run_ctr, sh_vkey, sh_sat;
   uint32_t sh_nt = 0, sh_runs = 0, sh_nsat = 0;
   DevBuf<long long> sh_counts;
   long long* h_sh_counts = nullptr;  // pinned
@@ -918,10 +921,11 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
                        h->w_seg_cnt.p, h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p,
                        h->d_wctr);
     STAGE_MARK(2);
-    hipLaunchKernelGGL(apply_chunks, dim3(4096), dim3(kApplyThreads), 0, s, h->w_sorted_seg.p, h->updated.p,
+    hipLaunchKernelGGL((apply_chunks<false, false>), dim3(4096), dim3(kApplyThreads), 0, s, h->w_sorted_seg.p, h->updated.p,
                        h->w_active_off.p, h->w_part_off.p, h->w_multi_idx.p, h->part_segs,
                        PartAcc{h->pa_wuu.p, h->pa_w.p, h->pa_last.p, h->pa_cnt.p, h->pa_done.p}, h->w_rec.p,
-                       1.0 / (double)h->scale_u, 1.0 / (double)h->scale_w, d_kfid, h->sdf, h->weight, h->kfid, h->d_wctr);
+                       1.0 / (double)h->scale_u, 1.0 / (double)h->scale_w, d_kfid, h->sdf, h->weight, h->kfid, h->d_wctr,
+                       EmitOut{});
     PLVS_KERNEL_CHECK();
     STAGE_MARK(3);
     // ---- colour fold: the truncating u8 mean is order dependent -> through the sorted runs of the voxels
@@ -1124,13 +1128,14 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   (void)hipFree(h->d_xcount);
   (void)hipFree(h->x_sat);
   if (h->h_sh_counts) (void)hipHostFree(h->h_sh_counts);
+  if (h->h_sh_ctl) (void)hipHostFree(h->h_sh_ctl);
   h->w_rec.release(); h->w_seg.release(); h->w_sorted_seg.release(); h->w_chunk_nseg.release();
   h->w_chunk_off.release(); h->w_chunk_fill.release(); h->w_active_off.release(); h->w_masks.release();
   h->w_dummy.release(); h->w_cold.release(); h->w_runkey.release(); h->w_run_cnt.release(); h->w_run_off.release(); h->w_val0.release();
   h->w_val1.release(); h->w_seg_cnt.release(); h->w_tile_visits.release(); h->w_part_off.release(); h->w_multi_idx.release();
   h->pa_wuu.release(); h->pa_w.release(); h->pa_last.release(); h->pa_cnt.release(); h->pa_done.release();
   h->sh_nrec.release(); h->sh_owner.release(); h->sh_seg_dst.release(); h->sh_rec_dst.release(); h->sh_obase.release();
-  h->sh_seg_pre.release(); h->sh_src_off.release(); h->sh_slot_owner.release(); h->sh_run_ctr.release(); h->sh_vkey.release(); h->sh_sat.release();
+  h->sh_ctl.release(); h->sh_seg_reg.release(); h->sh_rec_reg.release(); h->sh_src_off.release(); h->sh_slot_owner.release(); h->sh_run_ctr.release(); h->sh_vkey.release(); h->sh_sat.release();
   h->sh_counts.release();
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -1678,7 +1683,8 @@ static int shard_state_init(plvs_tsdf_chisel* h) {
   PLVS_HIP_TRY(hipMalloc((void**)&h->xdir.slot_ids, xmax * 3 * sizeof(int32_t)));
   PLVS_HIP_TRY(hipMalloc((void**)&h->x_sat, xmax * (kChunkVox / 32) * sizeof(uint32_t)));
   PLVS_HIP_TRY(hipMalloc((void**)&h->d_xcount, 4 * sizeof(int32_t)));   // [0] chunks, [1] error bits, [2] saturated this call
-  PLVS_HIP_TRY(hipHostMalloc((void**)&h->h_sh_counts, (size_t)3 * std::max(1, h->prm.shard_count) * sizeof(long long)));
+  PLVS_HIP_TRY(hipHostMalloc((void**)&h->h_sh_counts, ((size_t)3 * 64 + 2) * sizeof(long long)));
+  PLVS_HIP_TRY(hipHostMalloc((void**)&h->h_sh_ctl, 320 * sizeof(uint32_t)));
   PLVS_HIP_TRY(hipMemset(h->xdir.keys, 0xFF, cap * sizeof(unsigned long long)));
   PLVS_HIP_TRY(hipMemset(h->xdir.slots, 0xFF, cap * sizeof(int32_t)));
   PLVS_HIP_TRY(hipMemset(h->x_sat, 0, xmax * (kChunkVox / 32) * sizeof(uint32_t)));
@@ -1748,11 +1754,12 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
   PLVS_HIP_TRY(h->sh_nrec.reserve(xmax));
   PLVS_HIP_TRY(h->sh_owner.reserve(xmax));
   PLVS_HIP_TRY(h->sh_slot_owner.reserve(xmax));
-  PLVS_HIP_TRY(h->sh_seg_dst.reserve(xmax));
-  PLVS_HIP_TRY(h->sh_rec_dst.reserve(xmax));
-  PLVS_HIP_TRY(h->sh_obase.reserve((size_t)2 * N));
   PLVS_HIP_TRY(h->sh_run_ctr.reserve((size_t)3 * 64));   // counts, bases, fill cursors per destination
-  PLVS_HIP_TRY(h->sh_counts.reserve((size_t)3 * N));
+  PLVS_HIP_TRY(h->sh_ctl.reserve(256 + 2));              // regions, fill cursors, region totals
+  {
+    int rc2 = ensure_part_acc(h, (uint32_t)std::min<size_t>(xmax, 64));
+    if (rc2 != PLVS_OK) return rc2;
+  }
   const size_t rec_own = (size_t)nt * kWalkLimit, seg_own = (size_t)nt * kWalkChunks;
   size_t rec_spill = std::max<size_t>(h->w_rec.cap > rec_own ? h->w_rec.cap - rec_own : 0, (size_t)1 << 16);
   size_t seg_spill = std::max<size_t>(h->w_seg.cap / 2 > seg_own ? h->w_seg.cap / 2 - seg_own : 0, (size_t)1 << 12);
@@ -1764,7 +1771,6 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
     PLVS_HIP_TRY(h->w_rec.reserve(rec_own + rec_spill));
     PLVS_HIP_TRY(h->w_seg.reserve(2 * (seg_own + seg_spill)));
     PLVS_HIP_TRY(h->w_sorted_seg.reserve(h->w_seg.cap));
-    PLVS_HIP_TRY(h->sh_seg_pre.reserve(h->w_seg.cap / 2 + 1));
     PLVS_HIP_TRY(h->w_runkey.reserve((size_t)nt << h->run_r1_log2));
     PLVS_HIP_TRY(h->w_masks.reserve(((size_t)nt << h->run_r1_log2) * kMaskWords));
     PLVS_HIP_TRY(h->dkey0.reserve((size_t)nt << h->run_r1_log2));   // (all a call's runs, whatever their number)
@@ -1785,23 +1791,24 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
                        h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p, h->d_wctr);
     hipLaunchKernelGGL(seg_scan, dim3(1), dim3(1024), 0, s, h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p,
                        h->updated.p, h->w_active_off.p, h->d_wctr, h->d_xcount, (int)xmax, h->w_tile_visits.p,
-                       h->w_run_cnt.p, nt, h->w_part_off.p, h->w_multi_idx.p, 0u, h->part_segs, h->part_min);
+                       h->w_run_cnt.p, nt, h->w_part_off.p, h->w_multi_idx.p, h->multi_cap, h->part_segs, h->part_min);
     hipLaunchKernelGGL(seg_pass<true>, dim3(seg_blocks), dim3(256), 0, s, h->w_seg.p, out.seg_cap, nt, h->w_seg_cnt.p,
                        h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p, h->d_wctr);
     hipLaunchKernelGGL(shard_chunk_totals, dim3(1024), dim3(256), 0, s, h->w_sorted_seg.p, h->updated.p,
-                       h->w_active_off.p, h->xdir.slot_ids, N, h->d_wctr, h->sh_nrec.p, h->sh_owner.p, h->sh_slot_owner.p,
-                       h->sh_seg_pre.p);
+                       h->w_active_off.p, h->xdir.slot_ids, N, h->d_wctr, h->sh_nrec.p, h->sh_owner.p, h->sh_slot_owner.p);
+    hipLaunchKernelGGL(shard_plan, dim3(1), dim3(1024), 0, s, h->sh_nrec.p, h->sh_owner.p, N, h->d_wctr, h->sh_ctl.p,
+                       h->sh_ctl.p + 256);
     // the runs, densely, in tile order (seg_scan has left their number in num_desc), counted per destination
     PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, nt, nullptr, h->scratch.p, s));
     hipLaunchKernelGGL(compact_runs, dim3(ceil_div(nt, 4)), dim3(256), 0, s, h->w_runkey.p, h->w_run_cnt.p,
                        h->w_run_off.p, nt, h->run_r1_log2, h->dkey0.p, h->w_val0.p);
     hipLaunchKernelGGL(shard_run_count, dim3(256), dim3(256), 0, s, h->dkey0.p, &h->d_wctr[0].num_desc,
                        h->sh_slot_owner.p, N, h->sh_run_ctr.p, h->d_wctr);
-    hipLaunchKernelGGL(shard_plan, dim3(1), dim3(1024), 0, s, h->w_active_off.p, h->sh_nrec.p, h->sh_owner.p, N,
-                       h->d_wctr, h->sh_seg_dst.p, h->sh_rec_dst.p, h->sh_counts.p, h->sh_obase.p, h->sh_run_ctr.p,
-                       h->sh_run_ctr.p + 64, h->sh_run_ctr.p + 128);
+    hipLaunchKernelGGL(shard_run_plan, dim3(1), dim3(64), 0, s, h->sh_run_ctr.p, N, h->d_wctr);
     PLVS_KERNEL_CHECK();
-    PLVS_HIP_TRY(hipMemcpyAsync(h->h_sh_counts, h->sh_counts.p, (size_t)3 * N * sizeof(long long), hipMemcpyDeviceToHost, s));
+    // sizes of the send regions (and whether the walk has to be repeated)
+    uint32_t* const h_plan = reinterpret_cast<uint32_t*>(h->h_sh_counts + 3 * 64);
+    PLVS_HIP_TRY(hipMemcpyAsync(h_plan, h->sh_ctl.p + 256, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     PLVS_HIP_TRY(hipMemcpyAsync(h->h_wctr, h->d_wctr, sizeof(WalkCounters), hipMemcpyDeviceToHost, s));
     PLVS_HIP_TRY(hipStreamSynchronize(s));
     const uint32_t err = h->h_wctr->err;
@@ -1819,7 +1826,30 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
       if (((size_t)nt << h->run_r1_log2) >= 0xFFFFFFFFull) return walk_fail(h, err);
       continue;
     }
+    // ---- this rank's own aggregation: one sum per touched voxel into the owner's send region
+    PLVS_HIP_TRY(h->sh_seg_reg.reserve(2 * (size_t)h_plan[0] + 2));
+    PLVS_HIP_TRY(h->sh_rec_reg.reserve(2 * (size_t)h_plan[1] + 2));
+    uint32_t* const ctl = h->sh_ctl.p;
+    hipLaunchKernelGGL((apply_chunks<false, true>), dim3(4096), dim3(kApplyThreads), 0, s, h->w_sorted_seg.p, h->updated.p,
+                       h->w_active_off.p, h->w_part_off.p, h->w_multi_idx.p, h->part_segs,
+                       PartAcc{h->pa_wuu.p, h->pa_w.p, h->pa_last.p, h->pa_cnt.p, h->pa_done.p}, h->w_rec.p, 0.0, 0.0,
+                       (const uint32_t*)nullptr, (float*)nullptr, (float*)nullptr, (uint32_t*)nullptr, h->d_wctr,
+                       EmitOut{h->xdir.slot_ids, h->sh_owner.p, ctl, ctl + 64, ctl + 128, ctl + 192, h->sh_seg_reg.p,
+                               h->sh_rec_reg.p});
+    PLVS_KERNEL_CHECK();
+    PLVS_HIP_TRY(hipMemcpyAsync(h->h_sh_ctl, h->sh_ctl.p, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    PLVS_HIP_TRY(hipMemcpyAsync(h->h_sh_ctl + 256, h->sh_run_ctr.p, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    PLVS_HIP_TRY(hipStreamSynchronize(s));
     break;
+  }
+  for (int p = 0; p < N; ++p) {
+    h->h_sh_counts[3 * p] = (long long)h->h_sh_ctl[128 + p];
+    h->h_sh_counts[3 * p + 1] = (long long)h->h_sh_ctl[192 + p];
+    h->h_sh_counts[3 * p + 2] = (long long)h->h_sh_ctl[256 + p];
+  }
+  if (h->h_wctr->num_multi > h->multi_cap) {
+    rc = ensure_part_acc(h, (uint32_t)std::min<size_t>(xmax, (size_t)h->h_wctr->num_multi + h->h_wctr->num_multi / 2));
+    if (rc != PLVS_OK) return rc;
   }
   h->sh_runs = h->h_wctr->num_desc;
   for (int p = 0; p < 3 * N; ++p) send_counts[p] = (int64_t)h->h_sh_counts[p];
@@ -1832,13 +1862,21 @@ int plvs_hip_tsdf_chisel_shard_pack(plvs_tsdf_chisel* h, void* d_seg_dst, void* 
   PLVS_REQUIRE(h->sh_phase == 1, "shard_pack follows shard_walk");
   hipStream_t s = static_cast<hipStream_t>(stream);
   h->sh_phase = 2;
+  const int N = std::max(1, h->prm.shard_count);
   long long nseg = 0;
-  for (int p = 0; p < std::max(1, h->prm.shard_count); ++p) nseg += h->h_sh_counts ? h->h_sh_counts[3 * p] : 0;
+  for (int p = 0; p < N; ++p) nseg += h->h_sh_counts ? h->h_sh_counts[3 * p] : 0;
   if (nseg == 0) return PLVS_OK;
   PLVS_REQUIRE(d_seg_dst && d_rec_dst && (h->sh_runs == 0 || d_run_dst), "null send buffer");
-  hipLaunchKernelGGL(shard_pack_segments, dim3((unsigned)std::min<long long>(ceil_div((size_t)nseg, 4), 8192)), dim3(256), 0, s, h->w_sorted_seg.p, h->w_rec.p, h->updated.p,
-                     h->w_active_off.p, h->xdir.slot_ids, h->sh_owner.p, h->sh_seg_dst.p, h->sh_rec_dst.p, h->sh_seg_pre.p,
-                     h->sh_obase.p, h->d_wctr, static_cast<uint4*>(d_seg_dst), static_cast<uint4*>(d_rec_dst));
+  uint32_t dst_off[128] = {};
+  for (int p = 1; p < N; ++p) {
+    dst_off[p] = dst_off[p - 1] + (uint32_t)h->h_sh_counts[3 * (p - 1)];
+    dst_off[64 + p] = dst_off[64 + p - 1] + (uint32_t)h->h_sh_counts[3 * (p - 1) + 1];
+  }
+  PLVS_HIP_TRY(h->sh_src_off.reserve(128));
+  PLVS_HIP_TRY(hipMemcpyAsync(h->sh_src_off.p, dst_off, sizeof(dst_off), hipMemcpyHostToDevice, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));   // (dst_off is on this stack)
+  hipLaunchKernelGGL(shard_copy_regions, dim3(512), dim3(256), 0, s, h->sh_seg_reg.p, h->sh_rec_reg.p, h->sh_ctl.p,
+                     h->sh_src_off.p, N, static_cast<uint4*>(d_seg_dst), static_cast<uint4*>(d_rec_dst));
   if (h->sh_runs > 0)
     hipLaunchKernelGGL(shard_run_pack, dim3(std::min<size_t>(ceil_div((size_t)h->sh_runs, kRunSpan), 4096)), dim3(256), 0, s,
                        h->dkey0.p, h->w_val0.p, &h->d_wctr[0].num_desc, h->w_masks.p, h->run_r1_log2,
@@ -1920,11 +1958,11 @@ int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src,
   hipLaunchKernelGGL(seg_pass<true>, dim3(seg_blocks), dim3(256), 0, s, h->w_seg.p, total, 0u, (const uint32_t*)nullptr,
                      h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p, h->d_wctr);
   STAGE_MARK(2);
-  hipLaunchKernelGGL(apply_chunks, dim3(4096), dim3(kApplyThreads), 0, s, h->w_sorted_seg.p, h->updated.p,
+  hipLaunchKernelGGL((apply_chunks<true, false>), dim3(4096), dim3(kApplyThreads), 0, s, h->w_sorted_seg.p, h->updated.p,
                      h->w_active_off.p, h->w_part_off.p, h->w_multi_idx.p, h->part_segs,
                      PartAcc{h->pa_wuu.p, h->pa_w.p, h->pa_last.p, h->pa_cnt.p, h->pa_done.p},
                      static_cast<const uint4*>(d_rec_src), 1.0 / (double)h->scale_u, 1.0 / (double)h->scale_w, d_kfid,
-                     h->sdf, h->weight, h->kfid, h->d_wctr);
+                     h->sdf, h->weight, h->kfid, h->d_wctr, EmitOut{});
   PLVS_KERNEL_CHECK();
   STAGE_MARK(3);
   // ---- colours: the received runs, by (voxel, tile)

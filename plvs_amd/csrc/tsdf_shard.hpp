@@ -6,16 +6,18 @@
 // whatever chunks they cross — and what it collects for a chunk travels to the chunk's owner:
 //
 //   shard_walk    walk_tiles over the rank's tiles into the rank's WALK DIRECTORY (every chunk the rank has ever
-//                 walked through: ids + one bit per voxel "colour saturated", no voxel data), segment sort;
-//                 per chunk its owner and record total (shard_chunk_totals), per destination the runs
-//                 (shard_run_count) and the place of every chunk in the send buffers (shard_plan) -> send counts
-//   shard_pack    segment descriptors (chunk id instead of slot, record offsets relative to the destination's
-//                 block), records and colour runs, grouped by destination, into the caller's send buffers
+//                 walked through: ids + one bit per voxel "colour saturated", no voxel data), segment sort, then the
+//                 rank's OWN aggregation: apply_chunks<emit> adds the records of every (chunk, slab) in LDS and
+//                 leaves one 32-byte sum per touched voxel + one descriptor per (chunk, slab) in the send region of
+//                 the chunk's owner (shard_chunk_totals / shard_plan size the regions) -> send counts.  A voxel seen
+//                 from a thousand tiles of this rank travels once.
+//   shard_pack    the used parts of the regions and the colour runs, grouped by destination, into the caller's
+//                 send buffers
 //   (exchange)    ONE all-to-all of the three buffers — RCCL send/recv behind plvs_hip_tsdf_chisel_integrate_sharded,
 //                 torch.distributed in the Python mirror, device copies between virtual ranks in the tests
 //   shard_apply   received descriptors -> slots of the owner's directory (shard_translate, first-touch chunks are
 //                 inserted here), the segment sort and apply_chunks of the single-device path on the received
-//                 records.  The sums are integers: the result is bit-identical to the single-device order-free
+//                 sums (N per voxel at most).  The sums are integers: the result is bit-identical to the single-device order-free
 //                 integrate whatever N is.
 //                 Colours (the truncating u8 mean is order dependent below weight 254): the received runs
 //                 (voxel, tile, ray mask) are sorted by (voxel, tile) and folded as on a single device.  A walker
@@ -32,49 +34,29 @@
 
 namespace {
 
-// Per updated chunk of the call (index a in `active`): its owner, the records of its segments and, per segment,
-// the records of the chunk's earlier segments (seg_pre).
+// Per updated chunk of the call (index a in `active`): its owner and the records of its segments.
 __global__ __launch_bounds__(256) void shard_chunk_totals(const uint4* __restrict__ sorted_seg,
                                                           const uint32_t* __restrict__ active,
                                                           const uint32_t* __restrict__ active_off,
                                                           const int32_t* __restrict__ slot_ids, int nranks,
                                                           const WalkCounters* __restrict__ ctr,
                                                           uint32_t* __restrict__ nrec, uint32_t* __restrict__ owner,
-                                                          uint32_t* __restrict__ slot_owner, uint32_t* __restrict__ seg_pre) {
+                                                          uint32_t* __restrict__ slot_owner) {
   __shared__ uint32_t wsum[4];
-  __shared__ uint32_t run;
   if (ctr->err) return;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint32_t n = ctr->num_updated;
   for (uint32_t a = blockIdx.x; a < n; a += gridDim.x) {
     const uint32_t s0 = active_off[a], s1 = active_off[a + 1];
-    if (tid == 0) run = 0;
+    uint32_t c = 0;
+    for (uint32_t j = s0 + (uint32_t)tid; j < s1; j += 256) c += sorted_seg[2 * (size_t)j].z;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off);
+    if (lane == 0) wsum[wid] = c;
     __syncthreads();
-    for (uint32_t b = s0; b < s1; b += 256) {
-      const uint32_t j = b + (uint32_t)tid;
-      const uint32_t c = j < s1 ? sorted_seg[2 * (size_t)j].z : 0u;
-      uint32_t inc = c;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
-        if (lane >= off) inc += up;
-      }
-      if (lane == 63) wsum[wid] = inc;
-      __syncthreads();
-      uint32_t wb = run, tot = 0;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        if (w < wid) wb += wsum[w];
-        tot += wsum[w];
-      }
-      if (j < s1) seg_pre[j] = wb + inc - c;
-      __syncthreads();
-      if (tid == 0) run += tot;
-      __syncthreads();
-    }
     if (tid == 0) {
       const int32_t* id = slot_ids + 3 * (size_t)active[a];
-      nrec[a] = run;
+      nrec[a] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
       owner[a] = (uint32_t)shard_of(chunk_hash(id[0], id[1], id[2]), nranks);
       slot_owner[active[a]] = owner[a];
     }
@@ -82,107 +64,56 @@ __global__ __launch_bounds__(256) void shard_chunk_totals(const uint4* __restric
   }
 }
 
-// Places of the chunks in the send buffers: destination by destination, chunks in `active` order.
-// counts[3p .. 3p+2] = segments, records and runs for rank p; obase[2p], [2p+1] = the first two as running
-// offsets, run_base[p] = the third.
-__global__ __launch_bounds__(1024) void shard_plan(const uint32_t* __restrict__ active_off, const uint32_t* __restrict__ nrec,
-                                                   const uint32_t* __restrict__ owner, int nranks,
-                                                   const WalkCounters* __restrict__ ctr, uint32_t* __restrict__ seg_dst,
-                                                   uint32_t* __restrict__ rec_dst, long long* __restrict__ counts,
-                                                   uint32_t* __restrict__ obase, const uint32_t* __restrict__ run_counts,
-                                                   uint32_t* __restrict__ run_base, uint32_t* __restrict__ run_fill) {
-  __shared__ uint32_t wsum_s[16], wsum_r[16];
-  __shared__ uint32_t carry_s, carry_r;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const uint32_t n = ctr->err ? 0u : ctr->num_updated;
-  if (tid == 0) { carry_s = 0; carry_r = 0; }
+// Send regions: destination p gets room for 8 descriptors and min(4096, records) sums per chunk it owns among the
+// call's chunks (a chunk has 4096 voxels; it cannot have more touched voxels than records).  plan[0], plan[1] = the
+// two totals, seg_region / rec_region[p] = the first descriptor / sum of p's region; the fill cursors are zeroed.
+// ctl = {seg_region[64], rec_region[64], seg_fill[64], rec_fill[64]}.
+__global__ __launch_bounds__(1024) void shard_plan(const uint32_t* __restrict__ nrec, const uint32_t* __restrict__ owner,
+                                                   int nranks, const WalkCounters* __restrict__ ctr,
+                                                   uint32_t* __restrict__ ctl, uint32_t* __restrict__ plan) {
+  __shared__ uint32_t segs[64], recs[64];
+  const int tid = threadIdx.x;
+  if (tid < 64) { segs[tid] = 0; recs[tid] = 0; }
   __syncthreads();
-  for (int p = 0; p < nranks; ++p) {
-    const uint32_t base_s = carry_s, base_r = carry_r;
-    __syncthreads();
-    if (tid == 0) { obase[2 * p] = base_s; obase[2 * p + 1] = base_r; }
-    for (uint32_t b = 0; b < n; b += 1024) {
-      const uint32_t a = b + (uint32_t)tid;
-      const bool mine = a < n && owner[a] == (uint32_t)p;
-      const uint32_t cs = mine ? active_off[a + 1] - active_off[a] : 0u, cr = mine ? nrec[a] : 0u;
-      uint32_t is = cs, ir = cr;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t us = (uint32_t)__shfl_up((int)is, off), ur = (uint32_t)__shfl_up((int)ir, off);
-        if (lane >= off) { is += us; ir += ur; }
-      }
-      if (lane == 63) { wsum_s[wid] = is; wsum_r[wid] = ir; }
-      __syncthreads();
-      uint32_t ws = carry_s, wr = carry_r, ts = 0, tr = 0;
-#pragma unroll
-      for (int w = 0; w < 16; ++w) {
-        if (w < wid) { ws += wsum_s[w]; wr += wsum_r[w]; }
-        ts += wsum_s[w];
-        tr += wsum_r[w];
-      }
-      if (mine) {
-        seg_dst[a] = ws + is - cs;
-        rec_dst[a] = wr + ir - cr;
-      }
-      __syncthreads();
-      if (tid == 0) { carry_s += ts; carry_r += tr; }
-      __syncthreads();
-    }
-    if (tid == 0) {
-      counts[3 * p] = (long long)(carry_s - base_s);
-      counts[3 * p + 1] = (long long)(carry_r - base_r);
-    }
-    __syncthreads();
+  const uint32_t n = ctr->err ? 0u : ctr->num_updated;
+  for (uint32_t a = (uint32_t)tid; a < n; a += 1024) {
+    atomicAdd(&segs[owner[a]], (uint32_t)kSlabs);
+    atomicAdd(&recs[owner[a]], min(nrec[a], (uint32_t)kChunkVox));
   }
+  __syncthreads();
   if (tid == 0) {
-    uint32_t b = 0;
-    for (int p = 0; p < nranks; ++p) {
-      const uint32_t c = ctr->err ? 0u : run_counts[p];
-      run_base[p] = b;
-      run_fill[p] = 0;
-      counts[3 * p + 2] = (long long)c;
-      b += c;
+    uint32_t bs = 0, br = 0;
+    for (int p = 0; p < 64; ++p) {
+      ctl[p] = bs;
+      ctl[64 + p] = br;
+      ctl[128 + p] = 0;
+      ctl[192 + p] = 0;
+      if (p < nranks) { bs += segs[p]; br += recs[p]; }
     }
+    plan[0] = bs;
+    plan[1] = br;
   }
 }
 
-// The wire form of a segment descriptor (two uint4):
-//   {chunk key low, first record relative to the destination's record block, chunk key high, tile},
-//   {slab offsets 1..7 as in the local form, the record count in the 16 bits of offset 0 (always 0)}.
-// A wave per segment: its lanes copy the records (contiguous 16-byte items), lane 0 writes the descriptor.
-__global__ __launch_bounds__(256) void shard_pack_segments(
-    const uint4* __restrict__ sorted_seg, const uint4* __restrict__ rec, const uint32_t* __restrict__ active,
-    const uint32_t* __restrict__ active_off, const int32_t* __restrict__ slot_ids, const uint32_t* __restrict__ owner,
-    const uint32_t* __restrict__ seg_dst, const uint32_t* __restrict__ rec_dst, const uint32_t* __restrict__ seg_pre,
-    const uint32_t* __restrict__ obase, const WalkCounters* __restrict__ ctr, uint4* __restrict__ seg_out,
-    uint4* __restrict__ rec_out) {
-  if (ctr->err) return;
-  const int lane = threadIdx.x & 63;
-  const uint32_t n = ctr->num_updated;
-  const uint32_t total = active_off[n];
-  const uint32_t nwaves = gridDim.x * 4u;
-  for (uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6); j < total; j += nwaves) {
-    uint32_t lo = 0, hi = n - 1;   // the chunk of segment j: the last a with active_off[a] <= j
-    while (lo < hi) {
-      const uint32_t mid = (lo + hi + 1) >> 1;
-      if (active_off[mid] <= j) lo = mid; else hi = mid - 1;
-    }
-    const uint32_t a = lo;
-    const uint4 d0 = sorted_seg[2 * (size_t)j];
-    const uint32_t ds = rec_dst[a] + seg_pre[j];
-    if (lane == 0) {
-      const uint4 d1 = sorted_seg[2 * (size_t)j + 1];
-      const int32_t* id = slot_ids + 3 * (size_t)active[a];
-      unsigned long long key = 0;
-      pack_block(id[0], id[1], id[2], &key);   // (in range: the walk packed it before)
-      const size_t o = (size_t)seg_dst[a] + (j - active_off[a]);
-      seg_out[2 * o] = make_uint4((uint32_t)key, ds - obase[2 * owner[a] + 1], (uint32_t)(key >> 32), d0.w);
-      seg_out[2 * o + 1] = make_uint4(d1.x | d0.z, d1.y, d1.z, d1.w);
-    }
-    for (uint32_t r = (uint32_t)lane; r < d0.z; r += 64) rec_out[(size_t)ds + r] = rec[(size_t)d0.y + r];
+// The used part of every send region -> the caller's buffers, destination after destination
+// (ctl as above; dst_off[p], dst_off[64 + p] = where p's descriptors / sums start there).
+__global__ __launch_bounds__(256) void shard_copy_regions(const uint4* __restrict__ seg_reg, const uint4* __restrict__ rec_reg,
+                                                          const uint32_t* __restrict__ ctl, const uint32_t* __restrict__ dst_off,
+                                                          int nranks, uint4* __restrict__ seg_out, uint4* __restrict__ rec_out) {
+  for (int p = 0; p < nranks; ++p) {
+    const uint32_t ns = 2u * ctl[128 + p], nr = 2u * ctl[192 + p];   // in uint4 (two per descriptor / per sum)
+    const uint4* ss = seg_reg + 2 * (size_t)ctl[p];
+    const uint4* rs = rec_reg + 2 * (size_t)ctl[64 + p];
+    uint4* sd = seg_out + 2 * (size_t)dst_off[p];
+    uint4* rd = rec_out + 2 * (size_t)dst_off[64 + p];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < ns; i += gridDim.x * 256u) sd[i] = ss[i];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nr; i += gridDim.x * 256u) rd[i] = rs[i];
   }
 }
 
+// The wire form of a segment descriptor (two uint4), written by apply_chunks<emit>:
+//   {chunk key low, first sum relative to the destination's block, chunk key high, slab},
+//   {slab offsets as in the local form — all the sums lie in ONE slab —, the count in the 16 bits of offset 0}.
 // Received descriptors (grouped by source rank; src_off[q], src_off[nranks + 1 + q] = first segment / first
 // record of source q's block) -> the local form, with the chunk's slot in the owner's directory (first-touch
 // chunks are inserted) and record offsets into the whole receive buffer.
@@ -219,6 +150,18 @@ __global__ __launch_bounds__(256) void shard_run_count(const uint32_t* __restric
     atomicAdd(&hist[slot_owner[dkey[j] >> 12]], 1u);
   __syncthreads();
   if ((int)threadIdx.x < nranks && hist[threadIdx.x]) atomicAdd(&run_counts[threadIdx.x], hist[threadIdx.x]);
+}
+
+// Bases of the destinations' runs in the send buffer (rc = {counts[64], bases[64], fill cursors[64]}).
+__global__ void shard_run_plan(uint32_t* __restrict__ rc, int nranks, const WalkCounters* __restrict__ ctr) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint32_t b = 0;
+  for (int p = 0; p < 64; ++p) {
+    if (ctr->err || p >= nranks) rc[p] = 0;
+    rc[64 + p] = b;
+    rc[128 + p] = 0;
+    b += rc[p];
+  }
 }
 
 // Wire form of a run, kWireRun words: {chunk key low, chunk key high, voxel, tile, ray mask}.  The runs of a

@@ -878,12 +878,28 @@ struct PartAcc {           // per (chunk applied in parts, voxel); `done` per (s
   unsigned long long* w;
   uint32_t *last, *cnt, *done;
 };
+// kWide: the records are the 32-byte per-voxel sums a rank of the ray-sharded integrate sends to a chunk's owner,
+//   {voxel | count << 12, last point, sum w_u*u (64 bit)}, {sum w_u (64 bit), 0, 0}.
+// kEmit (a rank's own aggregation before the exchange): instead of updating the voxels, the sums of the slab's touched
+//   voxels leave as wide records + one descriptor (chunk id, slab) in the send region of the chunk's owner.
+struct EmitOut {
+  const int32_t* slot_ids;      // walk directory: slot -> chunk id
+  const uint32_t* owner;        // [active index] destination rank of the chunk
+  const uint32_t* seg_region;   // [rank] first descriptor / first record of the rank's send region,
+  const uint32_t* rec_region;
+  uint32_t* seg_fill;           // [rank] descriptors / records written so far
+  uint32_t* rec_fill;
+  uint4* seg_out;
+  uint4* rec_out;
+};
 constexpr int kApplyThreads = 512;
+template <bool kWide, bool kEmit>
 __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
     const uint4* __restrict__ sorted_seg, const uint32_t* __restrict__ active, const uint32_t* __restrict__ active_off,
     const uint32_t* __restrict__ part_off, const uint32_t* __restrict__ multi_idx, uint32_t part_segs, PartAcc acc,
     const uint4* __restrict__ rec, double inv_scale_u, double inv_scale_w, const uint32_t* __restrict__ kfid_of_point,
-    float* __restrict__ sdf, float* __restrict__ weight, uint32_t* __restrict__ vkfid, WalkCounters* __restrict__ ctr) {
+    float* __restrict__ sdf, float* __restrict__ weight, uint32_t* __restrict__ vkfid, WalkCounters* __restrict__ ctr,
+    EmitOut emit) {
   __shared__ long long a_wuu[kSlabVox];
   __shared__ unsigned long long a_w[kSlabVox];
   __shared__ uint32_t a_last[kSlabVox], a_cnt[kSlabVox];
@@ -894,12 +910,28 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
   if (ctr->err) return;   // the walk ran out of scratch: the host grows it and repeats the call, the map stays as it was
   const uint32_t nchunks = ctr->num_updated, nitems = ctr->num_parts * kSlabs;
   uint32_t voxels = 0, longest = 0;
-  auto add = [&](const uint4 q) {
-    const uint32_t v = (q.x & 0xFFFu) % kSlabVox;
-    atomicAdd((unsigned long long*)&a_wuu[v], (unsigned long long)(long long)(int32_t)q.z);
-    atomicAdd(&a_w[v], (unsigned long long)q.w);
-    atomicMax(&a_last[v], q.y);
-    atomicAdd(&a_cnt[v], q.x >> 12);
+  struct Rec { uint4 a, b; };
+  auto load = [&](uint32_t r) {   // record r of the call
+    Rec q;
+    if (kWide) {
+      q.a = rec[2 * (size_t)r];
+      q.b = rec[2 * (size_t)r + 1];
+    } else {
+      q.a = rec[r];
+      q.b = make_uint4(0u, 0u, 0u, 0u);
+    }
+    return q;
+  };
+  auto add = [&](const Rec& q) {
+    const unsigned long long wuu = kWide ? ((unsigned long long)q.a.z | ((unsigned long long)q.a.w << 32))
+                                         : (unsigned long long)(long long)(int32_t)q.a.z;
+    const unsigned long long w = kWide ? ((unsigned long long)q.b.x | ((unsigned long long)q.b.y << 32))
+                                       : (unsigned long long)q.a.w;
+    const uint32_t v = (q.a.x & 0xFFFu) % kSlabVox;
+    atomicAdd((unsigned long long*)&a_wuu[v], wuu);
+    atomicAdd(&a_w[v], w);
+    atomicMax(&a_last[v], q.a.y);
+    atomicAdd(&a_cnt[v], q.a.x >> 12);
   };
   for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
     const uint32_t pi = item / kSlabs, slab = item % kSlabs;
@@ -920,7 +952,6 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
     const uint32_t s1 = nparts > 1 ? min(active_off[a + 1], s0 + part_segs) : active_off[a + 1];
     for (uint32_t sb = s0 + (uint32_t)grp * kFly; sb < s1; sb += kGroups * kFly) {
       uint32_t lo_r[kFly], hi_r[kFly];
-      uint4 q[kFly];
 #pragma unroll
       for (int j = 0; j < kFly; ++j) {
         lo_r[j] = hi_r[j] = 0;
@@ -933,13 +964,14 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
           hi_r[j] = d0.y + e;
         }
       }
+      Rec q[kFly];
 #pragma unroll
       for (int j = 0; j < kFly; ++j)
-        if (lo_r[j] + gl < hi_r[j]) q[j] = rec[lo_r[j] + gl];
+        if (lo_r[j] + gl < hi_r[j]) q[j] = load(lo_r[j] + gl);
 #pragma unroll
       for (int j = 0; j < kFly; ++j) {
         if (lo_r[j] + gl < hi_r[j]) add(q[j]);
-        for (uint32_t r = lo_r[j] + 16u + gl; r < hi_r[j]; r += 16) add(rec[r]);
+        for (uint32_t r = lo_r[j] + 16u + gl; r < hi_r[j]; r += 16) add(load(r));
       }
     }
     __syncthreads();
@@ -975,7 +1007,45 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
         if (tid == 0) atomicExch(&acc.done[(size_t)multi_idx[a] * kSlabs + slab], 0u);
       }
     }
-    if (apply) {
+    if (apply && kEmit) {
+      // ---- the slab's sums leave for the chunk's owner: one wide record per touched voxel, one descriptor
+      static_assert(kSlabVox == kApplyThreads, "a thread per voxel of the slab");
+      const uint32_t c = a_cnt[tid];
+      const unsigned long long touched = __ballot(c != 0u);
+      __shared__ uint32_t wtot[kApplyThreads / 64];
+      __shared__ uint32_t ebase;
+      if (lane == 0) wtot[tid >> 6] = (uint32_t)__popcll(touched);
+      __syncthreads();
+      uint32_t before = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < kApplyThreads / 64; ++w) {
+        if (w < (tid >> 6)) before += wtot[w];
+        total += wtot[w];
+      }
+      const uint32_t p = emit.owner[a];
+      if (tid == 0 && total) {
+        ebase = atomicAdd(&emit.rec_fill[p], total);
+        const uint32_t sg = emit.seg_region[p] + atomicAdd(&emit.seg_fill[p], 1u);
+        const int32_t* id = emit.slot_ids + 3 * (size_t)active[a];
+        unsigned long long key = 0;
+        pack_block(id[0], id[1], id[2], &key);
+        uint32_t sub[kSlabs];
+#pragma unroll
+        for (int k = 0; k < kSlabs; ++k) sub[k] = (uint32_t)k > slab ? total : 0u;
+        const uint4 so = pack_suboffsets(sub);
+        emit.seg_out[2 * (size_t)sg] = make_uint4((uint32_t)key, ebase, (uint32_t)(key >> 32), slab);
+        emit.seg_out[2 * (size_t)sg + 1] = make_uint4(so.x | total, so.y, so.z, so.w);   // (offset 0 is 0: its bits carry the count)
+      }
+      __syncthreads();
+      if (c) {
+        const uint32_t at = emit.rec_region[p] + ebase + before + (uint32_t)__popcll(touched & ((1ull << lane) - 1ull));
+        const unsigned long long wuu = (unsigned long long)a_wuu[tid], w = a_w[tid];
+        emit.rec_out[2 * (size_t)at] = make_uint4((slab * (uint32_t)kSlabVox + (uint32_t)tid) | (c << 12), a_last[tid],
+                                                   (uint32_t)wuu, (uint32_t)(wuu >> 32));
+        emit.rec_out[2 * (size_t)at + 1] = make_uint4((uint32_t)w, (uint32_t)(w >> 32), 0u, 0u);
+        ++voxels;
+      }
+    } else if (apply) {
       for (int v = tid; v < kSlabVox; v += kApplyThreads) {
         const uint32_t c = a_cnt[v];
         if (c) {

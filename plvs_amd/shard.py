@@ -53,8 +53,8 @@ def allgather_block_lists(local_ids, count, cap, group=None, padded=False):
 def exchange_segments(send_seg, send_rec, send_run, send_counts, group=None):
     """The all-to-all of the ray-sharded integrate (TsdfChisel.shard_walk / shard_pack / shard_apply).
 
-    send_seg [S, 8], send_rec [R, 4], send_run [U, 20] int32 tensors grouped by destination rank in rank order,
-    send_counts [world, 3] (segments, records, runs per destination).  Returns (recv_seg, recv_rec, recv_run,
+    send_seg [S, 8], send_rec [R, 8], send_run [U, 20] int32 tensors grouped by destination rank in rank order,
+    send_counts [world, 3] (descriptors, voxel sums, runs per destination).  Returns (recv_seg, recv_rec, recv_run,
     recv_counts) grouped by source rank.  Four collectives: the counts, then the three payloads
     (all_to_all_single with split sizes — RCCL send/recv pairs over xGMI on GPUs, gloo in the CPU tests)."""
     world = dist.get_world_size(group)
@@ -65,7 +65,7 @@ def exchange_segments(send_seg, send_rec, send_run, send_counts, group=None):
     dist.all_to_all_single(rc, sc, group=group)
     recv_counts = rc.cpu().numpy()
     out = []
-    for k, (buf, width) in enumerate(((send_seg, 8), (send_rec, 4), (send_run, 20))):
+    for k, (buf, width) in enumerate(((send_seg, 8), (send_rec, 8), (send_run, 20))):
         recv = torch.zeros((int(recv_counts[:, k].sum()), width), dtype=buf.dtype, device=dev)
         dist.all_to_all_single(recv, buf.reshape(-1, width), output_split_sizes=[int(c) for c in recv_counts[:, k]],
                                input_split_sizes=[int(c) for c in send_counts[:, k]], group=group)
@@ -79,7 +79,7 @@ def sharded_integrate(tsdf, d_xyz, d_rgb, d_kfid, offsets, d_Twc, group=None):
     counts = tsdf.shard_walk(d_xyz, offsets, d_Twc)
     dev = d_xyz.device
     seg = torch.zeros((int(counts[:, 0].sum()), 8), dtype=torch.int32, device=dev)
-    rec = torch.zeros((int(counts[:, 1].sum()), 4), dtype=torch.int32, device=dev)
+    rec = torch.zeros((int(counts[:, 1].sum()), 8), dtype=torch.int32, device=dev)
     run = torch.zeros((int(counts[:, 2].sum()), 20), dtype=torch.int32, device=dev)
     tsdf.shard_pack(seg, rec, run)
     rseg, rrec, rrun, rcounts = exchange_segments(seg, rec, run, counts, group)

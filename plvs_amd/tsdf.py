@@ -106,7 +106,7 @@ class TsdfChisel:
     # ---- ray-sharded multi-GPU integrate (order_free, shard_count > 1): walk -> pack -> exchange -> apply
     def shard_walk(self, d_xyz, offsets, d_Twc):
         """Phase 1: this rank walks its tiles of the point stream (tile t belongs to rank t % shard_count).
-        Returns the int64 array [shard_count, 3] of (segments, records, colour runs) bound for every rank."""
+        Returns the int64 array [shard_count, 3] of (descriptors, voxel sums, colour runs) bound for every rank."""
         offsets = np.ascontiguousarray(offsets, dtype=np.int32)
         counts = np.zeros((self.params.shard_count, 3), np.int64)
         f = _lib.lib.plvs_hip_tsdf_chisel_shard_walk
@@ -116,7 +116,7 @@ class TsdfChisel:
         return counts
 
     def shard_pack(self, d_seg, d_rec, d_run):
-        """Phase 2: fills the send buffers (torch int32 tensors [segments, 8], [records, 4] and [runs, 20]),
+        """Phase 2: fills the send buffers (torch int32 tensors [descriptors, 8], [sums, 8] and [runs, 20]),
         each grouped by destination rank in rank order."""
         f = _lib.lib.plvs_hip_tsdf_chisel_shard_pack
         f.argtypes = [ctypes.c_void_p] * 5

@@ -113,7 +113,7 @@ def _worker_segments(rank, world, port, q):
     # stamped with (src, dst, index) so that the receiver can tell where each row comes from
     counts = np.array([[rank + 2 * d, 3 * rank + d, rank * d] for d in range(world)], np.int64)
     bufs = []
-    for k, width in enumerate((8, 4, 20)):
+    for k, width in enumerate((8, 8, 20)):
         rows = []
         for d in range(world):
             for i in range(counts[d, k]):
@@ -121,7 +121,7 @@ def _worker_segments(rank, world, port, q):
         bufs.append(torch.tensor(rows, dtype=torch.int32).reshape(-1, width))
     seg, rec, run, rc = shard_mod.exchange_segments(bufs[0], bufs[1], bufs[2], counts)
     ok = True
-    for k, (got, width) in enumerate(((seg, 8), (rec, 4), (run, 20))):
+    for k, (got, width) in enumerate(((seg, 8), (rec, 8), (run, 20))):
         want = []
         for src in range(world):
             n = [src + 2 * rank, 3 * src + rank, src * rank][k]

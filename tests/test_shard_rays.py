@@ -19,7 +19,7 @@ def _batch(kfs):
     return xyz, rgb, kfid, offsets, Twc
 
 
-WIDTHS = (8, 4, 20)   # int32 words of a segment descriptor, a record, a colour run
+WIDTHS = (8, 8, 20)   # int32 words of a descriptor, a voxel sum, a colour run
 
 
 def virtual_all_to_all(counts, bufs):
