@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--order-free", action="store_true", help="(the default; kept for older command lines)")
     ap.add_argument("--no-other-mode-leg", action="store_true", help="skip the measurement of the other chisel mode")
     ap.add_argument("--no-voxblox-leg", action="store_true", help="skip the configs[3] (voxblox 2 cm) leg")
+    ap.add_argument("--sharded-at-one", action="store_true",
+                    help="N = 1: run the step through the multi-GPU code path (a process group of one rank), to exercise it")
     ap.add_argument("--strong", action="store_true",
                     help="N > 1: keep the step at --batch keyframes (default: --batch keyframes per GPU, weak scaling)")
     ap.add_argument("--no-parity-check", action="store_true",
@@ -79,10 +81,12 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    multi = world > 1 or args.sharded_at_one
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
 
     from plvs_amd import _lib
     from plvs_amd.synth_scene import make_keyframes
@@ -107,7 +111,7 @@ def main():
     # stream and sends what it collected to the chunk owners.  Weak scaling by default: a step carries --batch
     # keyframes PER GPU (a longer stretch of the stream, e.g. a map rebuild), so every rank's share of the rays
     # stays what one GPU walks at N = 1.
-    ray_sharded = world > 1 and not vbx and not args.ordered
+    ray_sharded = multi and not vbx and not args.ordered
     step_kfs = args.batch * (world if (ray_sharded and not args.strong) else 1)
     batches = []
     for s in range(total_steps):
@@ -127,7 +131,7 @@ def main():
     upd_cap = 16384          # = max_chunks: an updated-chunk list always fits
     d_upd = torch.zeros((upd_cap, 3), dtype=torch.int32, device="cuda")
     gathered_blocks = [0]
-    gdir = BlockDirectory(16384) if world > 1 else None      # every rank's copy of the global block -> owner table
+    gdir = BlockDirectory(16384) if multi else None      # every rank's copy of the global block -> owner table
 
     def step(b):
         xyz, rgb, kfid, offsets, Twc = b
@@ -138,7 +142,7 @@ def main():
         else:
             tsdf.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
         st = tsdf.last_stats()
-        if world > 1:      # the path's one real exchange: updated block lists, over RCCL
+        if multi:      # the updated block lists, over RCCL
             n = tsdf.updated_chunk_ids_dev(d_upd)
             all_ids, counts = allgather_block_lists(d_upd, n, upd_cap, padded=True)
             gdir.merge(all_ids, counts)
@@ -146,7 +150,7 @@ def main():
         return st
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -168,14 +172,16 @@ def main():
         voxels += st["voxels"]
     barrier()
     elapsed = time.perf_counter() - t0
-    if vbx:
+    if vbx or ray_sharded:   # (the sharded step is three library calls around the exchanges: the wall clock is its time)
         stage_ms, calls = {}, args.steps
+        if not vbx:
+            tsdf.set_profiling(False)
     else:
         stage_ms, calls = tsdf.stage_ms()
         tsdf.set_profiling(False)
 
     # max over ranks of the elapsed time, sum over ranks of the visits
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -209,7 +215,7 @@ def main():
         mode_tag = "" if vbx else ("_ordered" if args.ordered else "_order_free")
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
                            f"r02_pmc_traffic_{args.backend}{mode_tag}.json")
-        if world == 1 and args.batch == 100 and os.path.exists(pmc):
+        if world == 1 and not multi and args.batch == 100 and os.path.exists(pmc):
             with open(pmc) as f:
                 t = json.load(f)
             roofline["traffic"] = t["traffic"]
@@ -363,7 +369,7 @@ def main():
             vp += stv["points"]
         barrier()
         vel = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             tt = torch.tensor([vel], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             vel = float(tt.item())
@@ -588,7 +594,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     tsdf.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
