@@ -1729,8 +1729,13 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
   h->sh_ntiles = (uint32_t)ceil_div((size_t)n, kWalkRays);
   h->sh_nt = 0;
   h->sh_runs = 0;
-  h->sh_stats.points = n;
   h->sh_phase = 1;
+  {   // the points of this rank's tiles
+    int64_t own = 0;
+    for (uint32_t t = (uint32_t)rank; t < h->sh_ntiles; t += (uint32_t)N)
+      own += std::min<int64_t>(kWalkRays, (int64_t)n - (int64_t)t * kWalkRays);
+    h->sh_stats.points = own;
+  }
   const uint32_t nt = h->sh_ntiles > (uint32_t)rank ? (h->sh_ntiles - (uint32_t)rank + (uint32_t)N - 1u) / (uint32_t)N : 0u;
   if (nt == 0) return PLVS_OK;
   PLVS_REQUIRE(d_xyz && d_Twc, "null device pointer");
