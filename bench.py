@@ -451,7 +451,6 @@ def main():
         both_ms = (time.perf_counter() - t0) / (2 * nrep) * 1e3
         ext2.close()
         lext.close()
-        match_ms = (fe["orb_bf_2000x2000_us"] + fe["lbd_mih_2000x2000_us"] * 0.0) * 1e-3
         # LBD k-NN at the real size (100 x 100 lines)
         q100 = torch.from_numpy(rng.integers(0, 256, (100, 32), dtype=np.uint8)).cuda()
         for _ in range(5):
@@ -528,6 +527,40 @@ def main():
                 "hip_us": per_call_us(lambda: lm.SearchByProjection(view, pc["valid"], pc["proj"], pc["octave"], pc["ldesc"],
                                                                     occupied=pc["occupied"], has_obs=pc["has_obs"])),
                 "cpu_us": per_call_us(lambda: tlp.oracle_map(ora, pc, False, 0.8), 10)}
+            # ---- the tracking step on REAL extractor output: frame upload, ORB + lines of aloe_shift, and
+            # ORBmatcher::SearchByProjection(CurrentFrame, LastFrame) of its keypoints against the previous frame's
+            # (aloe: the same scene cropped 3 px / 2 px further left / up, so a last-frame keypoint at (x, y) projects
+            # to (x - 3, y - 2); every last-frame keypoint stands for a map point 2 m away)
+            from plvs_amd.orbmatcher import FrameView, LastFrameView
+            ext3, lext3 = ORBextractor(2000, 1.2, 8, 20, 7), LineExtractor(100)
+            scale = np.asarray(ext3.GetScaleFactors(), np.float32)
+            pinned = [torch.from_numpy(golden(n)).pin_memory() for n in ("aloe_640x480.pgm", "aloe_640x480_shift.pgm")]
+            _, k0, d0 = ext3(pinned[0].cuda())
+            last = LastFrameView(valid=np.ones(len(k0), np.uint8), u=k0["x"] - 3.0, v=k0["y"] - 2.0,
+                                 invz=np.full(len(k0), 0.5, np.float32), octave=k0["octave"], angle=k0["angle"], desc=d0)
+            om4 = ORBmatcher(0.9, True)
+
+            def track_once():
+                img = pinned[1].cuda(non_blocking=True)
+                _, k1, d1, _, _ = extract_frame(ext3, lext3, img)
+                cur = FrameView(k1["x"], k1["y"], k1["octave"], np.full(len(k1), -1.0, np.float32), d1, 0.0, 0.0,
+                                64.0 / 640.0, 48.0 / 480.0, scale)
+                return om4.SearchByProjectionLastFrame(cur, k1["angle"], 640.0, 480.0, 40.0, last, 15.0), cur, k1
+
+            (nm, _), cur, k1 = track_once()
+            real_us = per_call_us(lambda: track_once(), 30)
+            match_us = per_call_us(lambda: om4.SearchByProjectionLastFrame(cur, k1["angle"], 640.0, 480.0, 40.0, last, 15.0), 30)
+            cpu_match_us = per_call_us(lambda: tos.oracle_search_ff(ora.lib, cur, np.ascontiguousarray(k1["angle"], np.float32),
+                                                                   640.0, 480.0, 40.0, last, 15.0, 0, 0, 1,
+                                                                   np.zeros(len(k1), np.uint8)), 10)
+            ext3.close()
+            lext3.close()
+            result["frontend"]["real_pair_tracking_step"] = {
+                "what": "pinned host frame -> HBM, ORB 2000 || EDLines/LBD 100x3, SearchByProjection(CurrentFrame, LastFrame) "
+                        "of aloe_shift against aloe's keypoints (host flavour)",
+                "ms_per_frame": round(real_us * 1e-3, 3), "search_by_projection_us": match_us,
+                "search_by_projection_cpu_us": cpu_match_us, "matches": int(nm),
+                "keypoints": [int(len(k0)), int(len(k1))]}
             mt["note"] = ("host flavours (inputs in host memory, one staged copy in and out per call) on synthetic frames of "
                           "the working size; cpu_us = oracle/*.c (the reference's loop, one core), both through ctypes")
             result["frontend"]["search_functions"] = mt
