@@ -36,7 +36,11 @@ __global__ __launch_bounds__(256) void hamming_pairs_kernel(const uint4* __restr
 
 // Frame::AssignFeaturesToGrid (src/Frame.cc:717-752): cell lists in keypoint order
 struct FrameGrid {
-  std::vector<int> start, members;
+  // mGrid as one array in the reference's enumeration order — column ix, row iy, insertion order inside the cell —
+  // with the fields the window test reads next to the index: a window is one contiguous range per column.
+  struct Member { float x, y; int octave, idx; };
+  std::vector<int> start;
+  std::vector<Member> members;
   explicit FrameGrid(const plvs_frame_view* F) : start(kGridCols * kGridRows + 1, 0), members(F->n) {
     std::vector<int> cell(F->n);
     for (int i = 0; i < F->n; ++i) {
@@ -48,7 +52,7 @@ struct FrameGrid {
     for (int c = 0; c < kGridCols * kGridRows; ++c) start[c + 1] += start[c];
     std::vector<int> fill(start.begin(), start.end() - 1);
     for (int i = 0; i < F->n; ++i)
-      if (cell[i] >= 0) members[fill[cell[i]]++] = i;
+      if (cell[i] >= 0) members[fill[cell[i]]++] = Member{F->x[i], F->y[i], F->octave[i], i};
   }
   // Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel) (src/Frame.cc:1231-1303), appended to `out`
   // in the reference's order (defaults: minLevel = -1, maxLevel = kMaxInt, include/Frame.h:173)
@@ -67,16 +71,15 @@ struct FrameGrid {
     if (r1 > kGridRows - 1) r1 = kGridRows - 1;
     if (r1 < 0) return;
     const bool check_levels = (min_level > 0) || (max_level >= 0);
-    for (int ix = c0; ix <= c1; ++ix)
-      for (int iy = r0; iy <= r1; ++iy) {
-        const int c = ix * kGridRows + iy;
-        for (int m = start[c]; m < start[c + 1]; ++m) {
-          const int idx = members[m];
-          if (check_levels && (F->octave[idx] < min_level || F->octave[idx] > max_level)) continue;
-          const float dx = F->x[idx] - x, dy = F->y[idx] - y;
-          if (std::fabs(dx) < r && std::fabs(dy) < r) fn(idx);
-        }
+    for (int ix = c0; ix <= c1; ++ix) {
+      const Member* m = members.data() + start[ix * kGridRows + r0];
+      const Member* const end = members.data() + start[ix * kGridRows + r1 + 1];   // rows r0 .. r1 of the column
+      for (; m < end; ++m) {
+        if (check_levels && (m->octave < min_level || m->octave > max_level)) continue;
+        const float dx = m->x - x, dy = m->y - y;
+        if (std::fabs(dx) < r && std::fabs(dy) < r) fn(m->idx);
       }
+    }
   }
 };
 
@@ -221,6 +224,9 @@ int plvs_hip_orb_search_by_projection_ff(const plvs_frame_view* F, const float* 
   struct Query { int i; int first, count; };
   std::vector<Query> queries;
   std::vector<int32_t> pair_q, pair_t;
+  queries.reserve((size_t)L->n);
+  pair_q.reserve((size_t)L->n * 16);
+  pair_t.reserve((size_t)L->n * 16);
   for (int i = 0; i < L->n; ++i) {
     if (!L->valid[i]) continue;
     const float invzc = L->invz[i];
