@@ -83,6 +83,156 @@ struct FrameGrid {
   }
 };
 
+// Frame::GetFeaturesInArea + the stereo gate + the Hamming distance of every candidate, on the device: a wave per
+// query walks the query's grid window in the reference's order — column after column, each column's rows one
+// contiguous range of the CSR members —, and the accepted candidates leave as (index, distance) in that order (ballot
+// compaction keeps it).  Two passes over the window: count, reserve the query's output range, emit.
+struct WinQuery {
+  float u, v, r, ur;            // window centre, radius, predicted right coordinate
+  int min_level, max_level;     // inclusive; tested only when check_levels
+  int src;                      // descriptor row of the query
+  int check_levels;
+};
+struct WinFrame {
+  const FrameGrid::Member* members;
+  const int* start;
+  const float* u_right;
+  const uint4* desc;            // two uint4 per keypoint
+  float min_x, min_y, grid_w_inv, grid_h_inv;
+};
+__global__ __launch_bounds__(256) void orb_window_candidates(const WinQuery* __restrict__ queries, int nq, WinFrame F,
+                                                             const uint4* __restrict__ qdesc, uint32_t* __restrict__ cursor,
+                                                             int32_t* __restrict__ q_first, int32_t* __restrict__ q_count,
+                                                             int2* __restrict__ out, uint32_t out_cap) {
+  const int lane = threadIdx.x & 63;
+  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= nq) return;
+  const WinQuery q = queries[qi];
+  int c0 = (int)floorf((q.u - F.min_x - q.r) * F.grid_w_inv);
+  int c1 = (int)ceilf((q.u - F.min_x + q.r) * F.grid_w_inv);
+  int r0 = (int)floorf((q.v - F.min_y - q.r) * F.grid_h_inv);
+  int r1 = (int)ceilf((q.v - F.min_y + q.r) * F.grid_h_inv);
+  bool empty = c0 >= kGridCols || c1 < 0 || r0 >= kGridRows || r1 < 0;
+  c0 = max(c0, 0); c1 = min(c1, kGridCols - 1); r0 = max(r0, 0); r1 = min(r1, kGridRows - 1);
+  auto accept = [&](const FrameGrid::Member& m) {
+    if (q.check_levels && (m.octave < q.min_level || m.octave > q.max_level)) return false;
+    const float dx = m.x - q.u, dy = m.y - q.v;
+    if (!(fabsf(dx) < q.r && fabsf(dy) < q.r)) return false;
+    const float ur = F.u_right[m.idx];
+    if (ur > 0) {
+      const float er = fabsf(q.ur - ur);
+      if (er > q.r) return false;
+    }
+    return true;
+  };
+  uint32_t total = 0;
+  if (!empty)
+    for (int ix = c0; ix <= c1; ++ix) {
+      const int s = F.start[ix * kGridRows + r0], e = F.start[ix * kGridRows + r1 + 1];
+      for (int b = s; b < e; b += 64) {
+        const bool ok = b + lane < e && accept(F.members[b + lane]);
+        total += (uint32_t)__popcll(__ballot(ok));
+      }
+    }
+  uint32_t first = 0;
+  if (lane == 0) {
+    first = total ? atomicAdd(cursor, total) : 0u;
+    q_first[qi] = (int32_t)first;
+    q_count[qi] = (int32_t)total;
+  }
+  first = (uint32_t)__shfl((int)first, 0);
+  if (total == 0 || first + total > out_cap) return;   // (the host sees cursor > out_cap and repeats with more room)
+  const uint4 qa = qdesc[2 * (size_t)q.src], qb = qdesc[2 * (size_t)q.src + 1];
+  uint32_t at = first;
+  for (int ix = c0; ix <= c1; ++ix) {
+    const int s = F.start[ix * kGridRows + r0], e = F.start[ix * kGridRows + r1 + 1];
+    for (int b = s; b < e; b += 64) {
+      FrameGrid::Member m{};
+      bool ok = false;
+      if (b + lane < e) {
+        m = F.members[b + lane];
+        ok = accept(m);
+      }
+      const unsigned long long mask = __ballot(ok);
+      if (ok) {
+        const uint4 ta = F.desc[2 * (size_t)m.idx], tb = F.desc[2 * (size_t)m.idx + 1];
+        const int d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
+                      __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+        out[at + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = make_int2(m.idx, d);
+      }
+      at += (uint32_t)__popcll(mask);
+    }
+  }
+}
+
+// The windows of `wq` on frame F (orb_window_candidates): per query k the accepted candidates pair_t / dist
+// [q_at[k], q_at[k] + q_n[k]) in the reference's enumeration order.  qdesc: the queries' descriptor rows (n_qdesc x 32).
+int window_candidates(const plvs_frame_view* F, const FrameGrid& grid, const std::vector<WinQuery>& wq, const uint8_t* qdesc,
+                      int n_qdesc, std::vector<int32_t>& q_at, std::vector<int32_t>& q_n, std::vector<int32_t>& pair_t,
+                      std::vector<int32_t>& dist) {
+  const int nq = (int)wq.size();
+  q_at.assign((size_t)nq, 0);
+  q_n.assign((size_t)nq, 0);
+  pair_t.clear();
+  dist.clear();
+  if (nq == 0) return PLVS_OK;
+  auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t nm = grid.members.size();
+  plvs::HostStage& st = plvs::thread_stage();
+  size_t out_cap = (size_t)nq * 32 + 4096;
+  for (int attempt = 0;; ++attempt) {
+    const size_t o_wq = 0, o_mem = o_wq + up16(sizeof(WinQuery) * (size_t)nq), o_start = o_mem + up16(sizeof(FrameGrid::Member) * nm),
+                 o_ur = o_start + up16(sizeof(int) * grid.start.size()), o_fd = o_ur + up16(sizeof(float) * (size_t)F->n),
+                 o_qd = o_fd + up16((size_t)F->n * 32), o_cur = o_qd + up16((size_t)n_qdesc * 32), o_first = o_cur + 16,
+                 o_count = o_first + up16(sizeof(int32_t) * (size_t)nq), o_out = o_count + up16(sizeof(int32_t) * (size_t)nq),
+                 total = o_out + up16(sizeof(int2) * out_cap);
+    PLVS_HIP_TRY(st.reserve(total));
+    memcpy(st.pinned + o_wq, wq.data(), sizeof(WinQuery) * (size_t)nq);
+    memcpy(st.pinned + o_mem, grid.members.data(), sizeof(FrameGrid::Member) * nm);
+    memcpy(st.pinned + o_start, grid.start.data(), sizeof(int) * grid.start.size());
+    memcpy(st.pinned + o_ur, F->u_right, sizeof(float) * (size_t)F->n);
+    memcpy(st.pinned + o_fd, F->desc, (size_t)F->n * 32);
+    memcpy(st.pinned + o_qd, qdesc, (size_t)n_qdesc * 32);
+    memset(st.pinned + o_cur, 0, 16);
+    PLVS_HIP_TRY(hipMemcpyAsync(st.dev, st.pinned, o_first, hipMemcpyHostToDevice, st.stream));
+    const WinFrame wf{reinterpret_cast<const FrameGrid::Member*>(st.dev + o_mem), reinterpret_cast<const int*>(st.dev + o_start),
+                      reinterpret_cast<const float*>(st.dev + o_ur), reinterpret_cast<const uint4*>(st.dev + o_fd),
+                      F->min_x, F->min_y, F->grid_w_inv, F->grid_h_inv};
+    hipLaunchKernelGGL(orb_window_candidates, dim3(plvs::ceil_div((size_t)nq, 4)), dim3(256), 0, st.stream,
+                       reinterpret_cast<const WinQuery*>(st.dev + o_wq), nq, wf, reinterpret_cast<const uint4*>(st.dev + o_qd),
+                       reinterpret_cast<uint32_t*>(st.dev + o_cur), reinterpret_cast<int32_t*>(st.dev + o_first),
+                       reinterpret_cast<int32_t*>(st.dev + o_count), reinterpret_cast<int2*>(st.dev + o_out), (uint32_t)out_cap);
+    PLVS_KERNEL_CHECK();
+    PLVS_HIP_TRY(hipMemcpyAsync(st.pinned + o_cur, st.dev + o_cur, o_out - o_cur, hipMemcpyDeviceToHost, st.stream));
+    PLVS_HIP_TRY(hipStreamSynchronize(st.stream));
+    const uint32_t found = *reinterpret_cast<const uint32_t*>(st.pinned + o_cur);
+    if (found > out_cap) {   // more candidates than room: once more with what is needed
+      PLVS_REQUIRE(attempt == 0, "candidate count changed between two identical launches");
+      out_cap = (size_t)found + 64;
+      continue;
+    }
+    PLVS_HIP_TRY(hipMemcpyAsync(st.pinned + o_out, st.dev + o_out, sizeof(int2) * (size_t)found, hipMemcpyDeviceToHost, st.stream));
+    PLVS_HIP_TRY(hipStreamSynchronize(st.stream));
+    const int32_t* qf = reinterpret_cast<const int32_t*>(st.pinned + o_first);
+    const int32_t* qc = reinterpret_cast<const int32_t*>(st.pinned + o_count);
+    const int2* rec = reinterpret_cast<const int2*>(st.pinned + o_out);
+    pair_t.resize(found);
+    dist.resize(found);
+    // (the ranges were reserved in the order the waves arrived: copied here query after query)
+    uint32_t at = 0;
+    for (int k = 0; k < nq; ++k) {
+      q_at[k] = (int32_t)at;
+      q_n[k] = qc[k];
+      for (int c = 0; c < qc[k]; ++c) {
+        pair_t[at + c] = rec[qf[k] + c].x;
+        dist[at + c] = rec[qf[k] + c].y;
+      }
+      at += (uint32_t)qc[k];
+    }
+    return PLVS_OK;
+  }
+}
+
 // ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:2123-2170) on bin counts
 void three_maxima(const int* count, int L, int& ind1, int& ind2, int& ind3) {
   int max1 = 0, max2 = 0, max3 = 0;
@@ -147,8 +297,8 @@ int plvs_hip_orb_search_by_projection(const plvs_frame_view* F, const plvs_mappo
   // ---- candidate windows (GetFeaturesInArea) of every map point the reference would process,
   // in the reference's order; everything but the "already claimed" test is decided here
   struct Query { int k; float r_scaled; int first, count; };
-  std::vector<Query> queries;
-  std::vector<int32_t> pair_q, pair_t;
+  std::vector<WinQuery> wq;
+  wq.reserve((size_t)M->m);
   const bool factor = th != 1.0f;
   for (int k = 0; k < M->m; ++k) {
     if (!M->track_in_view[k]) continue;
@@ -158,24 +308,17 @@ int plvs_hip_orb_search_by_projection(const plvs_frame_view* F, const plvs_mappo
     PLVS_REQUIRE(level >= 0, "negative predicted level");
     float r = ((double)M->view_cos[k] > 0.998) ? 2.5f : 4.0f;   // RadiusByViewingCos, :246-252
     if (factor) r *= th;
-    const float x = M->proj_x[k], y = M->proj_y[k], rr = r * F->scale_factors[level];
-    Query q{k, rr, (int)pair_q.size(), 0};
-    grid.for_each_in_area(F, x, y, rr, level - 1, level, [&](int idx) {
-      if (F->u_right[idx] > 0) {   // stereo coordinate must agree (RGB-D / stereo frames)
-        const float er = std::fabs(M->proj_xr[k] - F->u_right[idx]);
-        if (er > rr) return;
-      }
-      pair_q.push_back(k);
-      pair_t.push_back(idx);
-    });
-    q.count = (int)pair_q.size() - q.first;
-    if (q.count) queries.push_back(q);
+    const float rr = r * F->scale_factors[level];
+    // GetFeaturesInArea(x, y, rr, level - 1, level); a keypoint with a stereo coordinate must agree with the
+    // point's predicted one within rr (RGB-D / stereo frames)
+    wq.push_back(WinQuery{M->proj_x[k], M->proj_y[k], rr, M->proj_xr[k], level - 1, level, k, (level - 1 > 0 || level >= 0) ? 1 : 0});
   }
-  // ---- all distances in one launch
-  std::vector<int32_t> dist(pair_q.size());
-  int rc = plvs_hip_hamming_pairs(M->desc, M->m, F->desc, F->n, pair_q.data(), pair_t.data(), (int)pair_q.size(),
-                                  dist.data());
+  std::vector<Query> queries;
+  std::vector<int32_t> pair_t, dist, q_at, q_n;
+  int rc = window_candidates(F, grid, wq, M->desc, M->m, q_at, q_n, pair_t, dist);
   if (rc != PLVS_OK) return rc;
+  for (size_t k = 0; k < wq.size(); ++k)
+    if (q_n[k]) queries.push_back(Query{wq[k].src, wq[k].r, q_at[k], q_n[k]});
   // ---- greedy assignment in map-point order (:106-163)
   std::vector<uint8_t> blocked(F->n);
   for (int i = 0; i < F->n; ++i) blocked[i] = occupied ? occupied[i] : 0;
@@ -221,12 +364,11 @@ int plvs_hip_orb_search_by_projection_ff(const plvs_frame_view* F, const float* 
                "null frame array");
   PLVS_REQUIRE(L->valid && L->u && L->v && L->invz && L->octave && L->angle && L->desc, "null last-frame array");
   const FrameGrid grid(F);
+  // ---- the queries the reference would run (:1800-1840), then their windows and distances on the device
   struct Query { int i; int first, count; };
-  std::vector<Query> queries;
-  std::vector<int32_t> pair_q, pair_t;
-  queries.reserve((size_t)L->n);
-  pair_q.reserve((size_t)L->n * 16);
-  pair_t.reserve((size_t)L->n * 16);
+  std::vector<WinQuery> wq;
+  std::vector<int> wq_src;
+  wq.reserve((size_t)L->n);
   for (int i = 0; i < L->n; ++i) {
     if (!L->valid[i]) continue;
     const float invzc = L->invz[i];
@@ -239,23 +381,14 @@ int plvs_hip_orb_search_by_projection_ff(const plvs_frame_view* F, const float* 
     const float radius = th * F->scale_factors[oct];   // :1826
     const int min_level = forward ? oct : (backward ? 0 : oct - 1);
     const int max_level = forward ? 2147483647 : (backward ? oct : oct + 1);
-    Query q{i, (int)pair_q.size(), 0};
-    grid.for_each_in_area(F, u, v, radius, min_level, max_level, [&](int i2) {
-      if (F->u_right[i2] > 0) {
-        const float ur = u - mbf * invzc;
-        const float er = std::fabs(ur - F->u_right[i2]);
-        if (er > radius) return;
-      }
-      pair_q.push_back(i);
-      pair_t.push_back(i2);
-    });
-    q.count = (int)pair_q.size() - q.first;
-    if (q.count) queries.push_back(q);
+    wq.push_back(WinQuery{u, v, radius, u - mbf * invzc, min_level, max_level, i, (min_level > 0 || max_level >= 0) ? 1 : 0});
   }
-  std::vector<int32_t> dist(pair_q.size());
-  int rc = plvs_hip_hamming_pairs(L->desc, L->n, F->desc, F->n, pair_q.data(), pair_t.data(), (int)pair_q.size(),
-                                  dist.data());
+  std::vector<Query> queries;
+  std::vector<int32_t> pair_t, dist, q_at, q_n;
+  int rc = window_candidates(F, grid, wq, L->desc, L->n, q_at, q_n, pair_t, dist);
   if (rc != PLVS_OK) return rc;
+  for (size_t k = 0; k < wq.size(); ++k)
+    if (q_n[k]) queries.push_back(Query{wq[k].src, q_at[k], q_n[k]});
   std::vector<uint8_t> blocked(F->n);
   for (int i = 0; i < F->n; ++i) blocked[i] = occupied ? occupied[i] : 0;
   std::vector<int> hist_item, hist_bin;   // rotHist: what was pushed, in order (duplicates possible)
