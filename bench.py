@@ -535,16 +535,24 @@ def main():
             ext3, lext3 = ORBextractor(2000, 1.2, 8, 20, 7), LineExtractor(100)
             scale = np.asarray(ext3.GetScaleFactors(), np.float32)
             pinned = [torch.from_numpy(golden(n)).pin_memory() for n in ("aloe_640x480.pgm", "aloe_640x480_shift.pgm")]
-            _, k0, d0 = ext3(pinned[0].cuda())
+            _, k0, d0, l0, ld0 = extract_frame(ext3, lext3, pinned[0].cuda())
+            # last frame's lines as map lines projected into the current frame (same 3 px / 2 px shift, 2 m away)
+            lproj = np.stack([l0["startPointX"] - 3.0, l0["startPointY"] - 2.0, l0["endPointX"] - 3.0, l0["endPointY"] - 2.0,
+                              np.full(len(l0), 0.5), np.full(len(l0), 0.5)], axis=1).astype(np.float32)
+            lvalid = np.ones(len(l0), np.uint8)
+            lm4 = LineMatcher(0.8, True)
             last = LastFrameView(valid=np.ones(len(k0), np.uint8), u=k0["x"] - 3.0, v=k0["y"] - 2.0,
                                  invz=np.full(len(k0), 0.5, np.float32), octave=k0["octave"], angle=k0["angle"], desc=d0)
             om4 = ORBmatcher(0.9, True)
 
             def track_once():
                 img = pinned[1].cuda(non_blocking=True)
-                _, k1, d1, _, _ = extract_frame(ext3, lext3, img)
+                _, k1, d1, l1, ld1 = extract_frame(ext3, lext3, img)
                 cur = FrameView(k1["x"], k1["y"], k1["octave"], np.full(len(k1), -1.0, np.float32), d1, 0.0, 0.0,
                                 64.0 / 640.0, 48.0 / 480.0, scale)
+                lview = line_frame_view(l1, ld1, tlp.SCALE, tlp.INV_SIGMA2, tlp.MAX_DIAG)
+                nl_, _ = lm4.SearchByProjectionLastFrame(lview, lvalid, lproj, l0["octave"], l0["angle"], ld0)
+                track_once.line_matches = nl_
                 return om4.SearchByProjectionLastFrame(cur, k1["angle"], 640.0, 480.0, 40.0, last, 15.0), cur, k1
 
             (nm, _), cur, k1 = track_once()
@@ -556,10 +564,12 @@ def main():
             ext3.close()
             lext3.close()
             result["frontend"]["real_pair_tracking_step"] = {
-                "what": "pinned host frame -> HBM, ORB 2000 || EDLines/LBD 100x3, SearchByProjection(CurrentFrame, LastFrame) "
-                        "of aloe_shift against aloe's keypoints (host flavour)",
+                "what": "pinned host frame -> HBM, ORB 2000 || EDLines/LBD 100x3, ORBmatcher and LineMatcher "
+                        "SearchByProjection(CurrentFrame, LastFrame) of aloe_shift against aloe's keypoints and lines "
+                        "(host flavours)",
                 "ms_per_frame": round(real_us * 1e-3, 3), "search_by_projection_us": match_us,
                 "search_by_projection_cpu_us": cpu_match_us, "matches": int(nm),
+                "line_matches": int(getattr(track_once, "line_matches", -1)),
                 "keypoints": [int(len(k0)), int(len(k1))]}
             mt["note"] = ("host flavours (inputs in host memory, one staged copy in and out per call) on synthetic frames of "
                           "the working size; cpu_us = oracle/*.c (the reference's loop, one core), both through ctypes")

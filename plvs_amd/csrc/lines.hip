@@ -332,6 +332,7 @@ struct plvs_lines {
   uint8_t* h_desc = nullptr;
   int line_cap = 0;
   hipStream_t stream = nullptr;
+  std::vector<hipEvent_t> ev_maps;             // octave i's maps have landed in the pinned buffers
   std::vector<OctaveDetector> det;
   double last_ms[6] = {};
 };
@@ -383,6 +384,11 @@ int lines_build_geometry(plvs_lines* o, int w, int h, const plvs::OrbPyramidView
   o->d_xofs.assign(n, nullptr); o->d_yofs.assign(n, nullptr); o->d_alpha.assign(n, nullptr); o->d_beta.assign(n, nullptr);
   o->h_dx.assign(n, nullptr); o->h_dy.assign(n, nullptr); o->h_gd.assign(n, nullptr);
   o->d_anchor.assign(n, nullptr); o->h_anchor.assign(n, nullptr);
+  while ((int)o->ev_maps.size() < n) {
+    hipEvent_t e = nullptr;
+    PLVS_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    o->ev_maps.push_back(e);
+  }
   // OctaveKeyLines :785-846: sigma schedule and octave sizes
   float preSigma2 = (float)std::pow(0.5, 2);
   float curSigma2 = (float)std::pow(1.0f, 2);
@@ -458,6 +464,7 @@ int lines_extract_body(plvs_lines* o, plvs_keyline* keylines, uint8_t* desc, int
     PLVS_HIP_TRY(hipMemcpyAsync(o->h_gd[i], o->d_gd[i], px * 2, hipMemcpyDeviceToHost, s));
     PLVS_HIP_TRY(hipMemcpyAsync(o->h_dx[i], o->d_dx[i], px * 2, hipMemcpyDeviceToHost, s));
     PLVS_HIP_TRY(hipMemcpyAsync(o->h_dy[i], o->d_dy[i], px * 2, hipMemcpyDeviceToHost, s));
+    PLVS_HIP_TRY(hipEventRecord(o->ev_maps[i], s));
     if (i + 1 < n && !o->geometry_shared) {
       const int nw = o->sizes[i + 1].first, nh = o->sizes[i + 1].second;
       hipLaunchKernelGGL(lines_resize, dim3((nw + 63) / 64, (nh + 3) / 4), block, 0, s, o->d_blur[i], w,
@@ -465,7 +472,9 @@ int lines_extract_body(plvs_lines* o, plvs_keyline* keylines, uint8_t* desc, int
     }
   }
   PLVS_KERNEL_CHECK();
-  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  // every octave is routed as soon as ITS maps have landed (the routing of octave 0 — the long pole of the host
+  // stage — starts while the smaller octaves are still being computed and copied)
+  PLVS_HIP_TRY(hipEventSynchronize(o->ev_maps[0]));
   const double t1 = now_ms();
   // ---- host: EdgeDrawing is sequential per octave (one routing thread each); every finished
   // edge chain is fitted independently, so fitting threads consume batches of chains while
@@ -488,6 +497,11 @@ int lines_extract_body(plvs_lines* o, plvs_keyline* keylines, uint8_t* desc, int
       work[i].out.resize((size_t)o->sizes[i].first * o->sizes[i].second / 100 / kBatch + 2);
     }
     auto route = [&](int i) {
+      if (i > 0 && hipEventSynchronize(o->ev_maps[i]) != hipSuccess) {
+        o->det[i].failed = true;
+        work[i].prog.done.store(1, std::memory_order_release);
+        return;
+      }
       OctaveMaps m;
       m.w = o->sizes[i].first; m.h = o->sizes[i].second;
       m.gd = o->h_gd[i]; m.dx = o->h_dx[i]; m.dy = o->h_dy[i];
@@ -672,6 +686,7 @@ int plvs_hip_lines_destroy(plvs_lines* o) {
   (void)hipFree(o->d_desc);
   if (o->h_lines) (void)hipHostFree(o->h_lines);
   if (o->h_desc) (void)hipHostFree(o->h_desc);
+  for (hipEvent_t e : o->ev_maps) (void)hipEventDestroy(e);
   if (o->stream) (void)hipStreamDestroy(o->stream);
   delete o;
   return PLVS_OK;
