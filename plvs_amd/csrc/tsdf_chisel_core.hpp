@@ -254,11 +254,12 @@ PLVS_HD bool ray_next(RayCursor* c, int* vx, int* vy, int* vz) {
   *vx = c->x; *vy = c->y; *vz = c->z;
   // (the reference's bounds test against -/+INT_MAX only rejects INT_MAX itself)
   const float d = sqnorm3((float)c->x - c->sx, (float)c->y - c->sy, (float)c->z - c->sz);
-  const bool stop = (d > c->maxDist) | ((c->x == c->endX) & (c->y == c->endY) & (c->z == c->endZ));
-  const bool x_lt_y = c->tMaxX < c->tMaxY;
-  const bool use_x = x_lt_y & (c->tMaxX < c->tMaxZ);
-  const bool use_y = (!x_lt_y) & (c->tMaxY < c->tMaxZ);
-  const bool go_x = use_x & !stop, go_y = use_y & !stop, go_z = !(use_x | use_y) & !stop;
+  const bool stop = (d > c->maxDist) || ((c->x == c->endX) && (c->y == c->endY) && (c->z == c->endZ));
+  const bool x_lt_y = c->tMaxX < c->tMaxY, x_lt_z = c->tMaxX < c->tMaxZ, y_lt_z = c->tMaxY < c->tMaxZ;
+  // (lane-mask logic: pure comparisons, no side effects — the compiler keeps them as mask operations)
+  const bool go_x = !stop && x_lt_y && x_lt_z;
+  const bool go_y = !stop && !x_lt_y && y_lt_z;
+  const bool go_z = !stop && ((x_lt_y && !x_lt_z) || (!x_lt_y && !y_lt_z));
   c->x += go_x ? c->stepX : 0;
   c->y += go_y ? c->stepY : 0;
   c->z += go_z ? c->stepZ : 0;
