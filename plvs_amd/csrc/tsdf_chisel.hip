@@ -751,7 +751,6 @@ struct plvs_tsdf_chisel {
   WalkCounters* h_wctr = nullptr;   // pinned
   DevBuf<uint4> w_rec, w_seg, w_sorted_seg;
   DevBuf<uint32_t> w_chunk_nseg, w_chunk_off, w_chunk_fill, w_active_off, w_masks, w_dummy, w_seg_cnt, w_tile_visits;
-  DevBuf<uint8_t> w_cold;
   DevBuf<uint32_t> w_part_off, w_multi_idx;          // apply stage: parts of the updated chunks
   DevBuf<long long> pa_wuu;                          //   accumulators of the chunks applied in parts (zero between calls)
   DevBuf<unsigned long long> pa_w;
@@ -769,9 +768,8 @@ struct plvs_tsdf_chisel {
   DevBuf<uint32_t> sh_ctl;
   uint32_t* h_sh_ctl = nullptr;      // pinned [320]
   DevBuf<uint4> sh_seg_reg, sh_rec_reg;
-  DevBuf<uint32_t> sh_nrec, sh_owner, sh_slot_owner, sh_seg_dst, sh_rec_dst, sh_obase, sh_src_off, sh_run_ctr, sh_vkey, sh_sat;
+  DevBuf<uint32_t> sh_nrec, sh_owner, sh_slot_owner, sh_src_off, sh_run_ctr, sh_vkey, sh_sat;
   uint32_t sh_nt = 0, sh_runs = 0, sh_nsat = 0;
-  DevBuf<long long> sh_counts;
   long long* h_sh_counts = nullptr;  // pinned
   int sh_n = 0, sh_nclouds = 0;      // the call in flight (shard_walk -> shard_pack -> shard_apply)
   uint32_t sh_ntiles = 0;            // tiles of the whole point stream
@@ -1131,12 +1129,11 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   if (h->h_sh_ctl) (void)hipHostFree(h->h_sh_ctl);
   h->w_rec.release(); h->w_seg.release(); h->w_sorted_seg.release(); h->w_chunk_nseg.release();
   h->w_chunk_off.release(); h->w_chunk_fill.release(); h->w_active_off.release(); h->w_masks.release();
-  h->w_dummy.release(); h->w_cold.release(); h->w_runkey.release(); h->w_run_cnt.release(); h->w_run_off.release(); h->w_val0.release();
+  h->w_dummy.release(); h->w_runkey.release(); h->w_run_cnt.release(); h->w_run_off.release(); h->w_val0.release();
   h->w_val1.release(); h->w_seg_cnt.release(); h->w_tile_visits.release(); h->w_part_off.release(); h->w_multi_idx.release();
   h->pa_wuu.release(); h->pa_w.release(); h->pa_last.release(); h->pa_cnt.release(); h->pa_done.release();
-  h->sh_nrec.release(); h->sh_owner.release(); h->sh_seg_dst.release(); h->sh_rec_dst.release(); h->sh_obase.release();
+  h->sh_nrec.release(); h->sh_owner.release();
   h->sh_ctl.release(); h->sh_seg_reg.release(); h->sh_rec_reg.release(); h->sh_src_off.release(); h->sh_slot_owner.release(); h->sh_run_ctr.release(); h->sh_vkey.release(); h->sh_sat.release();
-  h->sh_counts.release();
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->side) (void)hipStreamDestroy(h->side);

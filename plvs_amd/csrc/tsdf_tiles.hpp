@@ -238,38 +238,6 @@ __device__ __forceinline__ void tile_lookback(uint32_t t, uint32_t ngroups, uint
   }
 }
 
-// The two halves of tile_lookback for kernels that publish their inclusive prefix themselves (a tile
-// that emits in several rounds only knows its total at the end):
-//   tile_lookback_publish   status 1: the tile's own count is known, the tiles behind it can sum it;
-//   tile_lookback_base      waits for / sums the predecessors -> *sh_base (exclusive prefix).
-__device__ __forceinline__ void tile_lookback_publish(uint32_t t, uint32_t n, unsigned long long* __restrict__ tile_state,
-                                                      int tid) {
-  if (tid == 0) st_state(&tile_state[t], (1ull << 62) | n);
-}
-__device__ __forceinline__ void tile_lookback_base(uint32_t t, unsigned long long* __restrict__ tile_state,
-                                                   uint32_t* sh_base, int tid) {
-  const int lane = tid & 63;
-  if ((tid >> 6) != 0) return;
-  unsigned long long base = 0;
-  if (t > 0) {
-    for (long long hi = (long long)t - 1; hi >= 0; hi -= 64) {
-      const long long p = hi - lane;
-      unsigned long long st = 2ull << 62;
-      if (p >= 0) {
-        do { st = ld_state(&tile_state[p]); } while ((st >> 62) == 0);
-      }
-      const unsigned long long is_prefix = __ballot((st >> 62) == 2);
-      const int stop = __ffsll((long long)is_prefix) - 1;
-      unsigned long long v = (stop < 0 || lane <= stop) ? (st & ((1ull << 62) - 1)) : 0ull;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += (unsigned long long)__shfl_xor((long long)v, off);
-      base += v;
-      if (stop >= 0) break;
-    }
-  }
-  if (lane == 0) *sh_base = (uint32_t)base;
-}
-
 // lengths of the runs in sorted order (input of the scan that places them)
 __global__ void run_counts(const unsigned long long* __restrict__ sorted_val, uint32_t nd,
                            uint32_t* __restrict__ cnts) {
