@@ -89,6 +89,44 @@ __global__ void pose_prep(const float* __restrict__ Twc, int nclouds, Pose* __re
   if (c < nclouds) make_pose(Twc + 12 * c, &poses[c]);
 }
 
+// The order-free call's whole prologue in one launch: poses, the cloud offsets (read from the pinned host copy),
+// zeroed counters and per-chunk segment counts.  (Seven small commands — copy, kernel, five fills — cost 40 us of
+// queueing in front of a 55 us walk of one keyframe.)
+__global__ void walk_prologue(const float* __restrict__ Twc, int nclouds, Pose* __restrict__ poses,
+                              const int32_t* __restrict__ host_offsets, int32_t* __restrict__ offsets,
+                              WalkCounters* __restrict__ wctr, Counters* __restrict__ ctr, uint32_t* __restrict__ chunk_nseg,
+                              int nseg) {
+  const int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  for (int c = i0; c < nclouds; c += stride) make_pose(Twc + 12 * c, &poses[c]);
+  for (int c = i0; c <= nclouds; c += stride) offsets[c] = host_offsets[c];
+  for (int k = i0; k < nseg; k += stride) chunk_nseg[k] = 0u;
+  uint32_t* w = reinterpret_cast<uint32_t*>(wctr);
+  for (int k = i0; k < (int)(2 * sizeof(WalkCounters) / sizeof(uint32_t)); k += stride) w[k] = 0u;
+  if (i0 == 0) {   // reset the per-call counters, keep num_chunks
+    ctr->total_visits = 0;
+    ctr->err = 0;
+    ctr->num_heads = 0;
+    ctr->num_updated = 0;
+    ctr->max_run = 0;
+    ctr->num_desc = 0;
+  }
+}
+
+// Counters -> their pinned host copies by a kernel's stores: a small device-to-host copy command costs tens of
+// microseconds of queueing, a store through the host-mapped pointer a few.
+__global__ void publish_counters(const WalkCounters* __restrict__ wctr, const Counters* __restrict__ ctr,
+                                 WalkCounters* __restrict__ host_wctr, Counters* __restrict__ host_ctr) {
+  const uint32_t* a = reinterpret_cast<const uint32_t*>(wctr);
+  uint32_t* b = reinterpret_cast<uint32_t*>(host_wctr);
+  for (int k = threadIdx.x; k < (int)(2 * sizeof(WalkCounters) / sizeof(uint32_t)); k += blockDim.x) b[k] = a[k];
+  if (ctr) {
+    const uint32_t* c = reinterpret_cast<const uint32_t*>(ctr);
+    uint32_t* d = reinterpret_cast<uint32_t*>(host_ctr);
+    for (int k = threadIdx.x; k < (int)(sizeof(Counters) / sizeof(uint32_t)); k += blockDim.x) d[k] = c[k];
+  }
+  __threadfence_system();
+}
+
 __global__ void pool_init(float* __restrict__ sdf, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -758,6 +796,8 @@ struct plvs_tsdf_chisel {
   uint32_t multi_cap = 0;
   uint32_t part_segs = kPartSegs, part_min = kPartMin;   // (plvs_hip_tsdf_chisel_set_apply_parts)
   DevBuf<uint32_t> w_runkey, w_run_cnt, w_run_off, w_val0, w_val1;   // runs: per-tile regions of 2^run_r1_log2 slots
+  int32_t* h_offsets = nullptr;      // pinned copy of the call's cloud offsets
+  size_t h_offsets_cap = 0;
   uint32_t run_r1_log2 = 6;
   float scale_u = 1.f, scale_w = 1.f;   // fixed-point scales of the order-free accumulators (powers of two)
   int stage_set = 0;                    // which pipeline the stage times belong to
@@ -795,8 +835,8 @@ constexpr int kWalkStages = 4;
 const char* const kWalkStageNames[kWalkStages] = {"walk_tiles", "sort_segments", "apply_chunks", "fold_colours"};
 
 static int read_walk_counters(plvs_tsdf_chisel* h, hipStream_t s) {
-  PLVS_HIP_TRY(hipMemcpyAsync(h->h_wctr, h->d_wctr, 2 * sizeof(WalkCounters), hipMemcpyDeviceToHost, s));
-  PLVS_HIP_TRY(hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(publish_counters, dim3(1), dim3(64), 0, s, h->d_wctr, h->d_ctr, h->h_wctr, h->h_ctr);
+  PLVS_KERNEL_CHECK();
   PLVS_HIP_TRY(hipStreamSynchronize(s));
   return PLVS_OK;
 }
@@ -855,9 +895,17 @@ static int ensure_part_acc(plvs_tsdf_chisel* h, uint32_t chunks) {
 // Order-free mode: walk_tiles -> segment sort -> apply_chunks (+ the colour fold when the call met voxels
 // whose colour weight is below 254).
 static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uint8_t* d_rgb, const uint32_t* d_kfid,
-                              int n, int nclouds, hipStream_t s) {
+                              int n, int nclouds, const int32_t* offsets, const float* d_Twc, hipStream_t s) {
   const uint32_t ntiles = ceil_div((size_t)n, kWalkRays);
   const int max_chunks = h->prm.max_chunks;
+  if (h->h_offsets_cap < (size_t)nclouds + 1) {   // pinned copy of the offsets: the prologue kernel reads it
+    if (h->h_offsets) (void)hipHostFree(h->h_offsets);
+    h->h_offsets = nullptr;
+    h->h_offsets_cap = 0;
+    PLVS_HIP_TRY(hipHostMalloc((void**)&h->h_offsets, ((size_t)nclouds + 1 + 64) * sizeof(int32_t)));
+    h->h_offsets_cap = (size_t)nclouds + 1 + 64;
+  }
+  memcpy(h->h_offsets, offsets, ((size_t)nclouds + 1) * sizeof(int32_t));
   PLVS_HIP_TRY(h->tile_state.reserve((size_t)ntiles + 1));
   PLVS_HIP_TRY(h->w_chunk_nseg.reserve((size_t)max_chunks));
   PLVS_HIP_TRY(h->w_chunk_off.reserve((size_t)max_chunks + 1));
@@ -896,8 +944,9 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     PLVS_HIP_TRY(h->w_sorted_seg.reserve(h->w_seg.cap));
     PLVS_HIP_TRY(h->w_runkey.reserve((size_t)ntiles << h->run_r1_log2));
     PLVS_HIP_TRY(h->w_masks.reserve(((size_t)ntiles << h->run_r1_log2) * kMaskWords));
-    PLVS_HIP_TRY(hipMemsetAsync(h->d_wctr, 0, 2 * sizeof(WalkCounters), s));
-    PLVS_HIP_TRY(hipMemsetAsync(h->w_chunk_nseg.p, 0, (size_t)max_chunks * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(walk_prologue, dim3(ceil_div((size_t)std::max(max_chunks, nclouds + 1), 256)), dim3(256), 0, s, d_Twc,
+                       nclouds, h->poses.p, (const int32_t*)h->h_offsets, h->offsets.p, h->d_wctr, h->d_ctr, h->w_chunk_nseg.p,
+                       max_chunks);
     STAGE_MARK(0);
     AccOut out{h->w_rec.p, (uint32_t)std::min<size_t>(rec_own + rec_spill, 0xFFFFFFFFu), h->w_seg.p,
                (uint32_t)std::min<size_t>(seg_own + seg_spill, 0xFFFFFFFFu), h->w_seg_cnt.p, h->w_tile_visits.p};
@@ -932,31 +981,31 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     {
       uint32_t* const side_ctr = &h->d_wctr[1].num_desc;   // the run count, for the side stream's kernels
       PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-      PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, ntiles, side_ctr, h->scratch.p, h->side));
-      PLVS_HIP_TRY(hipMemcpyAsync(&h->h_wctr[1], &h->d_wctr[1], sizeof(WalkCounters), hipMemcpyDeviceToHost, h->side));
-      PLVS_HIP_TRY(hipMemcpyAsync(&h->h_wctr[0], &h->d_wctr[0], sizeof(WalkCounters), hipMemcpyDeviceToHost, h->side));
-      PLVS_HIP_TRY(hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, h->side));
-      PLVS_HIP_TRY(hipStreamSynchronize(h->side));   // the walk is over; segment sort and apply are queued behind it
-      const uint32_t D = h->h_wctr[1].num_desc;
-      if (h->h_wctr[0].err == 0 && D > 0) {
-        const uint32_t* skeys = h->dkey0.p;
-        const uint32_t* sval = h->w_val0.p;
-        if (D <= kSmallRuns) {
-          hipLaunchKernelGGL(sort_runs_small, dim3(1), dim3(1024), 0, h->side, h->w_runkey.p, h->w_run_cnt.p, ntiles,
-                             h->run_r1_log2, h->d_wctr + 1, h->dkey0.p, h->w_val0.p, h->heads.p);
-        } else {
-          int rc = sort_runs(h, D, ntiles, h->h_ctr->num_chunks, h->side, &skeys, &sval);
-          if (rc != PLVS_OK) return rc;
-          PLVS_HIP_TRY(h->heads.reserve(D));
-          PLVS_HIP_TRY(h->w_dummy.reserve((size_t)max_chunks + 1));
-          hipLaunchKernelGGL(voxel_heads, dim3(ceil_div(D, 256 * kHeadTiles)), dim3(256), 0, h->side, skeys, D,
-                             h->heads.p, h->w_dummy.p, h->d_wctr + 1);
+      {
+        PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, ntiles, side_ctr, h->scratch.p, h->side));
+        hipLaunchKernelGGL(publish_counters, dim3(1), dim3(64), 0, h->side, h->d_wctr, h->d_ctr, h->h_wctr, h->h_ctr);
+        PLVS_HIP_TRY(hipStreamSynchronize(h->side));   // the walk is over; segment sort and apply are queued behind it
+        const uint32_t D = h->h_wctr[1].num_desc;
+        if (h->h_wctr[0].err == 0 && D > 0) {
+          const uint32_t* skeys = h->dkey0.p;
+          const uint32_t* sval = h->w_val0.p;
+          if (D <= kSmallRuns) {
+            hipLaunchKernelGGL(sort_runs_small, dim3(1), dim3(1024), 0, h->side, h->w_runkey.p, h->w_run_cnt.p, ntiles,
+                               h->run_r1_log2, h->d_wctr + 1, h->dkey0.p, h->w_val0.p, h->heads.p);
+          } else {
+            int rc = sort_runs(h, D, ntiles, h->h_ctr->num_chunks, h->side, &skeys, &sval);
+            if (rc != PLVS_OK) return rc;
+            PLVS_HIP_TRY(h->heads.reserve(D));
+            PLVS_HIP_TRY(h->w_dummy.reserve((size_t)max_chunks + 1));
+            hipLaunchKernelGGL(voxel_heads, dim3(ceil_div(D, 256 * kHeadTiles)), dim3(256), 0, h->side, skeys, D,
+                               h->heads.p, h->w_dummy.p, h->d_wctr + 1);
+          }
+          hipLaunchKernelGGL(fold_colours_masks, dim3(std::min<size_t>(ceil_div(D, kFoldWaves), 8192)),
+                             dim3(64 * kFoldWaves), 0, h->side, skeys, sval, side_ctr,
+                             RunSrc{h->w_masks.p, (uint32_t)kMaskWords, h->run_r1_log2, TileMap{1u, 0u}}, h->heads.p, d_rgb,
+                             h->rgbw, &h->d_wctr[1].num_heads, (uint32_t*)nullptr, (uint32_t*)nullptr);
+          PLVS_KERNEL_CHECK();
         }
-        hipLaunchKernelGGL(fold_colours_masks, dim3(std::min<size_t>(ceil_div(D, kFoldWaves), 8192)),
-                           dim3(64 * kFoldWaves), 0, h->side, skeys, sval, side_ctr,
-                           RunSrc{h->w_masks.p, (uint32_t)kMaskWords, h->run_r1_log2, TileMap{1u, 0u}}, h->heads.p, d_rgb,
-                           h->rgbw, &h->d_wctr[1].num_heads, (uint32_t*)nullptr, (uint32_t*)nullptr);
-        PLVS_KERNEL_CHECK();
       }
       PLVS_HIP_TRY(hipEventRecord(h->ev_join, h->side));
       PLVS_HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
@@ -1120,6 +1169,7 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   if (h->h_ctr) (void)hipHostFree(h->h_ctr);
   (void)hipFree(h->d_wctr);
   if (h->h_wctr) (void)hipHostFree(h->h_wctr);
+  if (h->h_offsets) (void)hipHostFree(h->h_offsets);
   (void)hipFree(h->xdir.keys);
   (void)hipFree(h->xdir.slots);
   (void)hipFree(h->xdir.slot_ids);
@@ -1197,6 +1247,7 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
 
   PLVS_HIP_TRY(h->offsets.reserve((size_t)nclouds + 1));
   PLVS_HIP_TRY(h->poses.reserve((size_t)nclouds));
+  if (h->prm.order_free != 0) return integrate_walk_acc(h, d_xyz, d_rgb, d_kfid, n, nclouds, offsets, d_Twc, s);
   PLVS_HIP_TRY(h->counts.reserve((size_t)n + 1));
   PLVS_HIP_TRY(h->scratch.reserve(scan_scratch_words((size_t)n)));
   PLVS_HIP_TRY(hipMemcpyAsync(h->offsets.p, offsets, ((size_t)nclouds + 1) * sizeof(int32_t),
@@ -1207,7 +1258,6 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->total_visits, 0, sizeof(uint32_t), s));
   PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->err, 0, 5 * sizeof(uint32_t), s));
 
-  if (h->prm.order_free != 0) return integrate_walk_acc(h, d_xyz, d_rgb, d_kfid, n, nclouds, s);
   h->stage_set = 0;
 
 #define STAGE_MARK(i) \
