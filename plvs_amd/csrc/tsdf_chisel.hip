@@ -116,14 +116,25 @@ __global__ void walk_prologue(const float* __restrict__ Twc, int nclouds, Pose* 
 // microseconds of queueing, a store through the host-mapped pointer a few.
 __global__ void publish_counters(const WalkCounters* __restrict__ wctr, const Counters* __restrict__ ctr,
                                  WalkCounters* __restrict__ host_wctr, Counters* __restrict__ host_ctr) {
-  const uint32_t* a = reinterpret_cast<const uint32_t*>(wctr);
-  uint32_t* b = reinterpret_cast<uint32_t*>(host_wctr);
-  for (int k = threadIdx.x; k < (int)(2 * sizeof(WalkCounters) / sizeof(uint32_t)); k += blockDim.x) b[k] = a[k];
+  if (wctr) {
+    const uint32_t* a = reinterpret_cast<const uint32_t*>(wctr);
+    uint32_t* b = reinterpret_cast<uint32_t*>(host_wctr);
+    for (int k = threadIdx.x; k < (int)(2 * sizeof(WalkCounters) / sizeof(uint32_t)); k += blockDim.x) b[k] = a[k];
+  }
   if (ctr) {
     const uint32_t* c = reinterpret_cast<const uint32_t*>(ctr);
     uint32_t* d = reinterpret_cast<uint32_t*>(host_ctr);
     for (int k = threadIdx.x; k < (int)(sizeof(Counters) / sizeof(uint32_t)); k += blockDim.x) d[k] = c[k];
   }
+  __threadfence_system();
+}
+
+// ... and any few words the same way (up to three ranges per launch).
+__global__ void publish_words(const uint32_t* __restrict__ a, uint32_t* __restrict__ ha, int na, const uint32_t* __restrict__ b,
+                              uint32_t* __restrict__ hb, int nb, const uint32_t* __restrict__ c, uint32_t* __restrict__ hc, int nc) {
+  for (int k = threadIdx.x; k < na; k += blockDim.x) ha[k] = a[k];
+  for (int k = threadIdx.x; k < nb; k += blockDim.x) hb[k] = b[k];
+  for (int k = threadIdx.x; k < nc; k += blockDim.x) hc[k] = c[k];
   __threadfence_system();
 }
 
@@ -825,7 +836,9 @@ struct plvs_tsdf_chisel {
 };
 
 static int read_counters(plvs_tsdf_chisel* h, hipStream_t s) {
-  PLVS_HIP_TRY(hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(publish_counters, dim3(1), dim3(64), 0, s, (const WalkCounters*)nullptr, h->d_ctr, (WalkCounters*)nullptr,
+                     h->h_ctr);
+  PLVS_KERNEL_CHECK();
   PLVS_HIP_TRY(hipStreamSynchronize(s));
   return PLVS_OK;
 }
@@ -1860,8 +1873,10 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
     PLVS_KERNEL_CHECK();
     // sizes of the send regions (and whether the walk has to be repeated)
     uint32_t* const h_plan = reinterpret_cast<uint32_t*>(h->h_sh_counts + 3 * 64);
-    PLVS_HIP_TRY(hipMemcpyAsync(h_plan, h->sh_ctl.p + 256, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    PLVS_HIP_TRY(hipMemcpyAsync(h->h_wctr, h->d_wctr, sizeof(WalkCounters), hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(publish_words, dim3(1), dim3(64), 0, s, (const uint32_t*)(h->sh_ctl.p + 256), h_plan, 2,
+                       reinterpret_cast<const uint32_t*>(h->d_wctr), reinterpret_cast<uint32_t*>(h->h_wctr),
+                       (int)(sizeof(WalkCounters) / sizeof(uint32_t)), (const uint32_t*)nullptr, (uint32_t*)nullptr, 0);
+    PLVS_KERNEL_CHECK();
     PLVS_HIP_TRY(hipStreamSynchronize(s));
     const uint32_t err = h->h_wctr->err;
     if (err & kErrPoolFull) {
@@ -1889,8 +1904,9 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
                        EmitOut{h->xdir.slot_ids, h->sh_owner.p, ctl, ctl + 64, ctl + 128, ctl + 192, h->sh_seg_reg.p,
                                h->sh_rec_reg.p});
     PLVS_KERNEL_CHECK();
-    PLVS_HIP_TRY(hipMemcpyAsync(h->h_sh_ctl, h->sh_ctl.p, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    PLVS_HIP_TRY(hipMemcpyAsync(h->h_sh_ctl + 256, h->sh_run_ctr.p, 64 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(publish_words, dim3(1), dim3(256), 0, s, (const uint32_t*)h->sh_ctl.p, h->h_sh_ctl, 256,
+                       (const uint32_t*)h->sh_run_ctr.p, h->h_sh_ctl + 256, 64, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0);
+    PLVS_KERNEL_CHECK();
     PLVS_HIP_TRY(hipStreamSynchronize(s));
     break;
   }
@@ -2058,7 +2074,9 @@ int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src,
     PLVS_KERNEL_CHECK();
   }
   STAGE_MARK(4);
-  PLVS_HIP_TRY(hipMemcpyAsync(h->h_sh_counts, h->d_xcount + 2, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  hipLaunchKernelGGL(publish_words, dim3(1), dim3(64), 0, s, reinterpret_cast<const uint32_t*>(h->d_xcount + 2),
+                     reinterpret_cast<uint32_t*>(h->h_sh_counts), 1, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0,
+                     (const uint32_t*)nullptr, (uint32_t*)nullptr, 0);
   int rc = read_walk_counters(h, s);
   if (rc != PLVS_OK) return rc;
   if (h->h_wctr->err) return walk_fail(h, h->h_wctr->err);

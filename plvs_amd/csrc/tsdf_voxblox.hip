@@ -35,6 +35,13 @@ struct VCounters {
   uint32_t max_run;
 };
 
+__global__ void vb_publish_counters(const VCounters* __restrict__ ctr, VCounters* __restrict__ host_ctr) {
+  const uint32_t* a = reinterpret_cast<const uint32_t*>(ctr);
+  uint32_t* b = reinterpret_cast<uint32_t*>(host_ctr);
+  for (int k = threadIdx.x; k < (int)(sizeof(VCounters) / sizeof(uint32_t)); k += blockDim.x) b[k] = a[k];
+  __threadfence_system();
+}
+
 __device__ __forceinline__ PoseRt load_pose(const float* __restrict__ Twc, int c) {
   PoseRt p;
   const float* T = Twc + 12 * c;
@@ -258,7 +265,9 @@ struct plvs_tsdf_voxblox {
 };
 
 static int vb_read_counters(plvs_tsdf_voxblox* h, hipStream_t s) {
-  PLVS_HIP_TRY(hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(VCounters), hipMemcpyDeviceToHost, s));
+  // (published by a kernel's stores into the pinned copy: a small copy command costs tens of microseconds of queueing)
+  hipLaunchKernelGGL(vb_publish_counters, dim3(1), dim3(64), 0, s, h->d_ctr, h->h_ctr);
+  PLVS_KERNEL_CHECK();
   PLVS_HIP_TRY(hipStreamSynchronize(s));
   return PLVS_OK;
 }
