@@ -730,10 +730,29 @@ int plvs_hip_tsdf_voxblox_integrate_batch_dev(plvs_tsdf_voxblox* h, const float*
 int plvs_hip_tsdf_voxblox_last_stats(plvs_tsdf_voxblox* h, plvs_tsdf_stats* s);
 int plvs_hip_tsdf_voxblox_num_blocks(plvs_tsdf_voxblox* h, int* n);
 int plvs_hip_tsdf_voxblox_block_ids(plvs_tsdf_voxblox* h, int32_t* ids_xyz, int cap, int* n);
+/* The blocks the last integrate call visited (Block::updated() = true, tsdf_integrator.cc:151): host / device list. */
+int plvs_hip_tsdf_voxblox_updated_block_ids(plvs_tsdf_voxblox* h, int32_t* ids_xyz, int cap, int* n);
 int plvs_hip_tsdf_voxblox_updated_block_ids_dev(plvs_tsdf_voxblox* h, int32_t* d_ids_xyz, int cap,
                                                 int* n, void* stream);
 int plvs_hip_tsdf_voxblox_download_block(plvs_tsdf_voxblox* h, int bx, int by, int bz,
                                          float* distance, float* weight, uint32_t* rgba);
+
+/* Surface extraction: MeshIntegrator<TsdfVoxel>::updateMeshForBlock
+ * (Thirdparty/voxblox/include/voxblox/mesh/mesh_integrator.h:231-251: extractBlockMesh :165-229 with
+ * MarchingCubes::meshCube mesh/marching_cubes.h:66-102, updateMeshColor :348-368; min_weight 1e-4, use_color)
+ * for every block of the list — what TsdfServer::updateMesh (Thirdparty/voxblox_server/src/tsdf_server.cc:775-787)
+ * runs on the blocks integrated into since the last call (generateMesh(only_mesh_updated_blocks = true,
+ * clear_updated_flag = true), mesh_integrator.h:111-139) when PointCloudMapVoxblox::UpdateMap calls it
+ * (src/PointCloudMapVoxblox.cc:168).  block_ids_xyz: host, nblocks x 3 (the caller accumulates
+ * plvs_hip_tsdf_voxblox_updated_block_ids_dev over its integrate calls, as Block::updated() does).
+ * Outputs (host): the voxblox::Mesh arrays of the blocks back to back, in list order — vertices / normals
+ * (n x 3 f32; three consecutive vertices are one triangle, Mesh::indices is 0 .. n-1) and colors (n x 4 u8:
+ * Color r, g, b, a); block c owns [block_first[c], block_first[c+1]) (block_first: nblocks + 1 ints); a block
+ * that does not exist owns nothing.  *nvertices = n.  If n > capacity nothing is written but block_first /
+ * *nvertices, and PLVS_ERR_CAPACITY is returned.  Needs the whole map on one device (shard_count <= 1). */
+int plvs_hip_tsdf_voxblox_mesh_blocks(plvs_tsdf_voxblox* h, const int32_t* block_ids_xyz, int nblocks,
+                                      float* vertices, float* normals, uint8_t* colors_rgba, int capacity,
+                                      int32_t* block_first, int* nvertices);
 
 #ifdef __cplusplus
 }

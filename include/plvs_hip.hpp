@@ -523,8 +523,14 @@ class PointCloudMapChisel {
 };
 
 // ------------------------------------------------------------------------------------ voxblox map
+struct VoxbloxMesh {   // voxblox::Mesh after updateMeshForBlock (three consecutive vertices = one triangle)
+  std::vector<float> vertices, normals;   // n x 3
+  std::vector<uint8_t> colors;            // n x 4: Color r, g, b, a
+};
+
 class PointCloudMapVoxblox {
  public:
+  using BlockID = std::tuple<int, int, int>;
   explicit PointCloudMapVoxblox(float voxelSize, bool useCarving = false) {
     plvs_tsdf_voxblox_params p;
     check(plvs_hip_tsdf_voxblox_default_params(voxelSize, useCarving ? 1 : 0, &p));
@@ -546,15 +552,79 @@ class PointCloudMapVoxblox {
       rgba_[4 * i] = p.r; rgba_[4 * i + 1] = p.g; rgba_[4 * i + 2] = p.b; rgba_[4 * i + 3] = p.a;
     }
     check(plvs_hip_tsdf_voxblox_integrate(h_, xyz_.data(), rgba_.data(), (int)n, Twc.m));
+    // every block the integrator touched has updated() set (tsdf_integrator.cc:151) until the next updateMesh
+    int nu = 0;
+    check(plvs_hip_tsdf_voxblox_updated_block_ids(h_, nullptr, 0, &nu));
+    std::vector<int32_t> ids((size_t)3 * (nu > 0 ? nu : 1));
+    if (nu > 0) check(plvs_hip_tsdf_voxblox_updated_block_ids(h_, ids.data(), nu, &nu));
+    for (int i = 0; i < nu; ++i) updated_.insert(BlockID(ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]));
   }
-  void Clear() { check(plvs_hip_tsdf_voxblox_clear(h_)); }
+  // UpdateMap: TsdfServer::updateMesh (generateMesh(only_mesh_updated_blocks, clear_updated_flag), tsdf_server.cc:775-787)
+  // + getMeshAsPointcloud (voxblox_ros/mesh_vis.h:272-318, ColorMode::kColor)  (src/PointCloudMapVoxblox.cc:160-179).
+  // Returns the cloud size.
+  int UpdateMap() {
+    const int nb = (int)updated_.size();
+    if (nb > 0) {
+      std::vector<int32_t> ids;
+      for (const BlockID& b : updated_) { ids.push_back(std::get<0>(b)); ids.push_back(std::get<1>(b)); ids.push_back(std::get<2>(b)); }
+      std::vector<int32_t> first((size_t)nb + 1);
+      std::vector<float> V, N;
+      std::vector<uint8_t> C;
+      int nv = 0;
+      int rc = plvs_hip_tsdf_voxblox_mesh_blocks(h_, ids.data(), nb, nullptr, nullptr, nullptr, 0, first.data(), &nv);
+      if (rc == PLVS_ERR_CAPACITY) {
+        V.resize((size_t)3 * nv); N.resize((size_t)3 * nv); C.resize((size_t)4 * nv);
+        rc = plvs_hip_tsdf_voxblox_mesh_blocks(h_, ids.data(), nb, V.data(), N.data(), C.data(), nv, first.data(), &nv);
+      }
+      check(rc);
+      int c = 0;
+      for (const BlockID& id : updated_) {   // allocateMeshPtrByIndex + mesh->clear(): an updated block always owns a mesh
+        const int a = first[(size_t)c], b = first[(size_t)c + 1];
+        ++c;
+        VoxbloxMesh& m = meshLayer_[id];
+        m.vertices.assign(V.begin() + 3 * a, V.begin() + 3 * b);
+        m.normals.assign(N.begin() + 3 * a, N.begin() + 3 * b);
+        m.colors.assign(C.begin() + 4 * a, C.begin() + 4 * b);
+      }
+      updated_.clear();
+    }
+    pointCloud_.clear();
+    for (const auto& kv : meshLayer_) {   // the reference walks an unordered_map: its order is unspecified, this one is by id
+      const VoxbloxMesh& m = kv.second;
+      for (size_t i = 0; i < m.vertices.size() / 3; ++i) {
+        PointSurfelSegment p;
+        std::memset(&p, 0, sizeof p);
+        p.x = m.vertices[3 * i]; p.y = m.vertices[3 * i + 1]; p.z = m.vertices[3 * i + 2];
+        p.r = CloudColour(m.colors[4 * i]); p.g = CloudColour(m.colors[4 * i + 1]); p.b = CloudColour(m.colors[4 * i + 2]);
+        p.normal_x = m.normals[3 * i]; p.normal_y = m.normals[3 * i + 1]; p.normal_z = m.normals[3 * i + 2];
+        pointCloud_.push_back(p);
+      }
+    }
+    return (int)pointCloud_.size();
+  }
+  void Clear() {
+    check(plvs_hip_tsdf_voxblox_clear(h_));
+    updated_.clear();
+    meshLayer_.clear();
+    pointCloud_.clear();
+  }
   int NumBlocks() { int n = 0; check(plvs_hip_tsdf_voxblox_num_blocks(h_, &n)); return n; }
+  const std::vector<PointSurfelSegment>& GetPointCloud() const { return pointCloud_; }
+  const std::map<BlockID, VoxbloxMesh>& GetMeshLayer() const { return meshLayer_; }
   plvs_tsdf_voxblox* handle() { return h_; }
 
  private:
+  // colorVoxbloxToMsg then colorMsgToVoxblox (voxblox_ros/conversions.h:44-60): through a float in [0, 1] and back
+  static uint8_t CloudColour(uint8_t c) {
+    const float msg = (float)(c / 255.0);
+    return (uint8_t)(msg * 255.0);
+  }
   plvs_tsdf_voxblox* h_ = nullptr;
   std::vector<float> xyz_;
   std::vector<uint8_t> rgba_;
+  std::set<BlockID> updated_;
+  std::map<BlockID, VoxbloxMesh> meshLayer_;
+  std::vector<PointSurfelSegment> pointCloud_;
 };
 
 }  // namespace PLVS2hip

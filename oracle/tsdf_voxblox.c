@@ -425,3 +425,173 @@ void oracle_voxblox_indices(const int32_t* g, int32_t* block, int32_t* local, ui
   local_index(g, local);
   *hash = (uint64_t)vb_hash(block);
 }
+
+/* ---------------------------------------------------------------- surface extraction
+ * MeshIntegrator<TsdfVoxel>::updateMeshForBlock (Thirdparty/voxblox/include/voxblox/mesh/mesh_integrator.h:231-251)
+ * as TsdfServer::updateMesh (Thirdparty/voxblox_server/src/tsdf_server.cc:775-787) runs it on every block whose
+ * updated() flag is set, PointCloudMapVoxblox::UpdateMap (src/PointCloudMapVoxblox.cc:160-179):
+ *   extractBlockMesh            :165-229   the walk over the block: 15^3 interior (x outer, z inner), then the
+ *                                          max-X (z, y), max-Y (z, x < 15) and max-Z (y < 15, x < 15) planes
+ *   extractMeshInsideBlock / OnBorder  :253-346   the eight corners (neighbour blocks in +x/+y/+z), getSdfIfValid
+ *                                          (utils/meshing_utils.h:15-23: weight <= min_weight is unobserved)
+ *   MarchingCubes::meshCube     mesh/marching_cubes.h:66-102 (vertices col+2, col+1, col; flat triangle normal),
+ *                               interpolateEdgeVertices :117-134, interpolateVertex :138-153
+ *   updateMeshColor             :348-368   nearest voxel of THIS block (computeVoxelIndexFromCoordinates clamps
+ *                                          into the block, core/block.h:60-70, so the neighbour branch is dead)
+ * Block geometry: origin = index * block_size (layer.h:122-126, common.h:186-191), voxel centre =
+ * origin + (index + 0.5) * voxel_size with the sum and product in double (common.h:179-184).
+ * The marching-cubes table is the one open_chisel uses (mc_table.inc); tests/test_oracle_pinned.py compares it,
+ * the edge pairs and meshCube itself with voxblox's marching_cubes.{h,cc} compiled into oracle/_ref.
+ * Parity of the block walk, the corner gathering and the colour look-up: restated by reading (they need Layer /
+ * Block, which need protobuf). */
+static const int kVbTriangleTable[256 * 16] = {
+#include "mc_table.inc"
+};
+static const int kVbEdgeIndexPairs[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6},
+                                             {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+static const int kVbCubeIndexOffsets[3][8] = {{0, 1, 1, 0, 0, 1, 1, 0},   /* mesh_integrator.h:100-102 */
+                                              {0, 0, 1, 1, 0, 0, 1, 1},
+                                              {0, 0, 0, 0, 1, 1, 1, 1}};
+#define VB_MESH_MIN_WEIGHT 1e-4f   /* MeshIntegratorConfig::min_weight, mesh_integrator.h:49 (tsdf_server.cc:323-328 keeps it) */
+
+typedef struct {
+  float* vertices; float* normals;
+  int n, cap;
+} vb_mesh_out;
+
+static void vb_mesh_cube(const float cc[8][3], const float sdf[8], vb_mesh_out* m) {
+  int index = 0;
+  for (int i = 0; i < 8; i++) index |= (sdf[i] < 0) ? (1 << i) : 0;
+  if (index == 0) return;
+  float edge[12][3];
+  memset(edge, 0, sizeof edge);
+  for (int i = 0; i < 12; i++) {
+    const int e0 = kVbEdgeIndexPairs[i][0], e1 = kVbEdgeIndexPairs[i][1];
+    if ((sdf[e0] < 0 && sdf[e1] >= 0) || (sdf[e0] >= 0 && sdf[e1] < 0)) {
+      const float diff = sdf[e0] - sdf[e1];
+      if (fabsf(diff) >= 1e-6f) {
+        const float t = sdf[e0] / diff;
+        for (int k = 0; k < 3; k++) edge[i][k] = cc[e0][k] + t * (cc[e1][k] - cc[e0][k]);
+      } else {
+        for (int k = 0; k < 3; k++) edge[i][k] = 0.5f * (cc[e0][k] + cc[e1][k]);
+      }
+    }
+  }
+  const int* row = kVbTriangleTable + 16 * index;
+  for (int col = 0; row[col] != -1; col += 3) {
+    if (m->n + 3 > m->cap) { m->n += 3; continue; }   /* counted, not stored */
+    float* p0 = m->vertices + 3 * (size_t)m->n;
+    float *p1 = p0 + 3, *p2 = p0 + 6;
+    for (int k = 0; k < 3; k++) {
+      p0[k] = edge[row[col + 2]][k];
+      p1[k] = edge[row[col + 1]][k];
+      p2[k] = edge[row[col]][k];
+    }
+    const float px[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+    const float py[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+    float n[3] = {px[1] * py[2] - px[2] * py[1], px[2] * py[0] - px[0] * py[2], px[0] * py[1] - px[1] * py[0]};
+    const float z = sum3(n[0] * n[0], n[1] * n[1], n[2] * n[2]);
+    if (z > 0.0f) { const float s = sqrtf(z); n[0] /= s; n[1] /= s; n[2] /= s; }   /* normalized() */
+    for (int v = 0; v < 3; v++)
+      for (int k = 0; k < 3; k++) m->normals[3 * (size_t)(m->n + v) + k] = n[k];
+    m->n += 3;
+  }
+}
+
+static const vblock_t* vb_mesh_find(const oracle_voxblox* o, int x, int y, int z) {
+  const int32_t id[3] = {x, y, z};
+  int found = 0;
+  vblock_t* b = vtab_find(o->tab, o->cap, id, &found);
+  return found ? b : NULL;
+}
+
+static void vb_block_origin(const oracle_voxblox* o, const vblock_t* b, float org[3]) {
+  const float block_size = o->voxel_size * (float)VPS;   /* layer.h:34 */
+  for (int k = 0; k < 3; k++) org[k] = (float)b->id[k] * block_size;
+}
+
+static void vb_mesh_voxel(const oracle_voxblox* o, const vblock_t* blk, int x, int y, int z, vb_mesh_out* m) {
+  float org[3], coords[3];
+  vb_block_origin(o, blk, org);
+  const int v[3] = {x, y, z};
+  for (int k = 0; k < 3; k++) coords[k] = org[k] + (float)(((double)(float)v[k] + 0.5) * (double)o->voxel_size);
+  float cc[8][3], sdf[8];
+  for (int i = 0; i < 8; i++) {
+    int c[3] = {x + kVbCubeIndexOffsets[0][i], y + kVbCubeIndexOffsets[1][i], z + kVbCubeIndexOffsets[2][i]};
+    const vblock_t* src = blk;
+    if (c[0] >= VPS || c[1] >= VPS || c[2] >= VPS) {   /* :303-337 (offsets are never negative) */
+      int off[3] = {0, 0, 0};
+      for (int j = 0; j < 3; j++)
+        if (c[j] >= VPS) { off[j] = 1; c[j] -= VPS; }
+      src = vb_mesh_find(o, blk->id[0] + off[0], blk->id[1] + off[1], blk->id[2] + off[2]);
+      if (!src) return;
+    }
+    const int id = c[0] + VPS * (c[1] + c[2] * VPS);
+    if (src->weight[id] <= VB_MESH_MIN_WEIGHT) return;
+    sdf[i] = src->distance[id];
+    for (int k = 0; k < 3; k++) cc[i][k] = coords[k] + (float)kVbCubeIndexOffsets[k][i] * o->voxel_size;
+  }
+  vb_mesh_cube(cc, sdf, m);
+}
+
+/* voxblox::Mesh of block (bx, by, bz) after updateMeshForBlock: vertices / normals n x 3 f32, colors n x 4 u8
+ * (r, g, b, a).  Returns n (0 for a block that does not exist), writing at most `cap` vertices. */
+int oracle_voxblox_mesh_block(const oracle_voxblox* o, int bx, int by, int bz, float* vertices, float* normals,
+                              uint8_t* colors, int cap) {
+  const vblock_t* blk = vb_mesh_find(o, bx, by, bz);
+  if (!blk) return 0;
+  vb_mesh_out m = {vertices, normals, 0, cap};
+  for (int x = 0; x < VPS - 1; x++)
+    for (int y = 0; y < VPS - 1; y++)
+      for (int z = 0; z < VPS - 1; z++) vb_mesh_voxel(o, blk, x, y, z, &m);
+  for (int z = 0; z < VPS; z++)                                   /* max X plane */
+    for (int y = 0; y < VPS; y++) vb_mesh_voxel(o, blk, VPS - 1, y, z, &m);
+  for (int z = 0; z < VPS; z++)                                   /* max Y plane */
+    for (int x = 0; x < VPS - 1; x++) vb_mesh_voxel(o, blk, x, VPS - 1, z, &m);
+  for (int y = 0; y < VPS - 1; y++)                               /* max Z plane */
+    for (int x = 0; x < VPS - 1; x++) vb_mesh_voxel(o, blk, x, y, VPS - 1, &m);
+  const int n = m.n < cap ? m.n : cap;
+  float org[3];
+  vb_block_origin(o, blk, org);
+  for (int i = 0; i < n; i++) {                                   /* updateMeshColor */
+    int idx[3];
+    for (int k = 0; k < 3; k++) {
+      int g = (int)floorf((vertices[3 * (size_t)i + k] - org[k]) * o->voxel_size_inv + 1e-6f);
+      idx[k] = g < 0 ? 0 : (g > VPS - 1 ? VPS - 1 : g);
+    }
+    const int id = idx[0] + VPS * (idx[1] + idx[2] * VPS);
+    uint32_t c = 0;                                               /* Color(): r = g = b = a = 0 */
+    if (!(blk->weight[id] <= VB_MESH_MIN_WEIGHT)) c = blk->rgba[id];
+    for (int k = 0; k < 4; k++) colors[4 * (size_t)i + k] = (uint8_t)(c >> (8 * k));
+  }
+  return m.n;
+}
+
+/* getMeshAsPointcloud (voxblox_ros/tsdf_server.h:84-87 -> mesh_vis.h:272-318, ColorMode::kColor): every colour
+ * channel goes through a float in [0, 1] and back (conversions.h:44-60). */
+uint8_t oracle_voxblox_cloud_colour(uint8_t c) {
+  const float msg = (float)((double)c / 255.0);
+  return (uint8_t)((double)msg * 255.0);
+}
+
+/* Test hooks (no counterpart in the reference): one cube through meshCube; overwrite / create one block. */
+int oracle_voxblox_mesh_cube(const float* corner_coords /* 8 x 3 */, const float* corner_sdf, float* vertices,
+                             float* normals) {
+  float cc[8][3];
+  memcpy(cc, corner_coords, sizeof cc);
+  vb_mesh_out m = {vertices, normals, 0, 15};
+  vb_mesh_cube(cc, corner_sdf, &m);
+  return m.n;
+}
+void oracle_voxblox_mc_tables(int* triangle_table, int* edge_index_pairs) {
+  memcpy(triangle_table, kVbTriangleTable, sizeof(kVbTriangleTable));
+  memcpy(edge_index_pairs, kVbEdgeIndexPairs, sizeof(kVbEdgeIndexPairs));
+}
+void oracle_voxblox_set_block(oracle_voxblox* o, int bx, int by, int bz, const float* distance, const float* weight,
+                              const uint32_t* rgba) {
+  const int32_t id[3] = {bx, by, bz};
+  vblock_t* b = vblock_get(o, id);
+  memcpy(b->distance, distance, BLOCK_VOX * sizeof(float));
+  memcpy(b->weight, weight, BLOCK_VOX * sizeof(float));
+  memcpy(b->rgba, rgba, BLOCK_VOX * sizeof(uint32_t));
+}

@@ -12,10 +12,14 @@
 // (12 B per voxel, 48 KiB per block, voxel.h:12-18), the shared block directory
 // (tsdf_directory.hpp), and per call one (u32 key, u32 sequence) pair plus
 // 12 B of operands per voxel visit.
+#include <cstring>
+#include <vector>
+
 #include "common.hpp"
 #include "device_utils.hpp"
 #include "tsdf_directory.hpp"
 #include "tsdf_voxblox_core.hpp"
+#include "tsdf_voxblox_view.hpp"
 
 using namespace plvs;
 using namespace plvs::tsdf;
@@ -262,7 +266,30 @@ struct plvs_tsdf_voxblox {
   DevBuf<uint32_t> st_rgba;
   plvs_tsdf_stats stats{};
   uint32_t last_updated = 0;
+  void* ext = nullptr;                 // meshing scratch (tsdf_voxblox_mesh.hip), freed with the map
+  void (*ext_free)(void*) = nullptr;
 };
+
+namespace plvs {
+namespace vbx {
+
+bool voxblox_map_view(plvs_tsdf_voxblox* h, VoxbloxMapView* v) {
+  if (h == nullptr || v == nullptr || h->poisoned) return false;
+  v->voxel_size = h->P.voxel_size;
+  v->voxel_size_inv = h->P.voxel_size_inv;
+  v->dir = h->dir;
+  v->distance = h->dist;
+  v->weight = h->weight;
+  v->rgba = h->rgba;
+  v->num_blocks = h->num_blocks;
+  v->shard_count = h->P.shard_count;
+  v->ext = &h->ext;
+  v->ext_free = &h->ext_free;
+  return true;
+}
+
+}  // namespace vbx
+}  // namespace plvs
 
 static int vb_read_counters(plvs_tsdf_voxblox* h, hipStream_t s) {
   // (published by a kernel's stores into the pinned copy: a small copy command costs tens of microseconds of queueing)
@@ -292,6 +319,7 @@ int plvs_hip_tsdf_voxblox_default_params(float voxel_size, int use_carving,
 
 int plvs_hip_tsdf_voxblox_destroy(plvs_tsdf_voxblox* h) {
   if (!h) return PLVS_OK;
+  if (h->ext && h->ext_free) h->ext_free(h->ext);
   (void)hipFree(h->dir.keys); (void)hipFree(h->dir.slots); (void)hipFree(h->dir.slot_ids);
   (void)hipFree(h->dist); (void)hipFree(h->weight); (void)hipFree(h->rgba); (void)hipFree(h->d_ctr);
   if (h->h_ctr) (void)hipHostFree(h->h_ctr);
@@ -517,6 +545,21 @@ int plvs_hip_tsdf_voxblox_updated_block_ids_dev(plvs_tsdf_voxblox* h, int32_t* d
   hipLaunchKernelGGL(vb_gather_slot_ids, dim3(ceil_div((size_t)m, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), h->updated.p, m, h->dir.slot_ids, d_ids_xyz);
   PLVS_KERNEL_CHECK();
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_voxblox_updated_block_ids(plvs_tsdf_voxblox* h, int32_t* ids_xyz, int cap, int* n) {
+  PLVS_REQUIRE(h && n, "null argument");
+  *n = (int)h->last_updated;
+  const int m = (int)h->last_updated < cap ? (int)h->last_updated : cap;
+  if (m <= 0) return PLVS_OK;
+  PLVS_REQUIRE(ids_xyz, "null output");
+  // small lists: resolve slot -> id on the host
+  std::vector<uint32_t> slots(h->last_updated);
+  std::vector<int32_t> all((size_t)h->num_blocks * 3);
+  PLVS_HIP_TRY(hipMemcpy(slots.data(), h->updated.p, slots.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  PLVS_HIP_TRY(hipMemcpy(all.data(), h->dir.slot_ids, all.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  for (int i = 0; i < m; ++i) memcpy(ids_xyz + 3 * i, all.data() + 3 * (size_t)slots[(size_t)i], 3 * sizeof(int32_t));
   return PLVS_OK;
 }
 

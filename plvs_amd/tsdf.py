@@ -301,6 +301,38 @@ class TsdfVoxblox:
             self._h, _lib.t_ptr(d_ids), d_ids.shape[0], ctypes.byref(n), _lib.current_stream_ptr()))
         return n.value
 
+    def updated_chunk_ids(self):
+        """[n,3] ids of the blocks the last integrate call visited (Block::updated())."""
+        n = _i()
+        f = _L.plvs_hip_tsdf_voxblox_updated_block_ids
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        _lib.check(f(self._h, None, 0, ctypes.byref(n)))
+        ids = np.zeros((max(n.value, 1), 3), np.int32)
+        _lib.check(f(self._h, _lib.np_ptr(ids), n.value, ctypes.byref(n)))
+        return ids[:n.value]
+
+    def mesh_blocks(self, block_ids):
+        """MeshIntegrator::updateMeshForBlock for every block id of the list ([n,3] ints).  -> dict(vertices, normals
+        [m,3] f32, colors [m,4] u8 (r, g, b, a), block_first [n+1]): block c owns rows block_first[c]:block_first[c+1]."""
+        ids = np.ascontiguousarray(block_ids, dtype=np.int32).reshape(-1, 3)
+        first = np.zeros(ids.shape[0] + 1, np.int32)
+        n = ctypes.c_int()
+        f = _L.plvs_hip_tsdf_voxblox_mesh_blocks
+        f.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 2
+        cap = 0
+        while True:
+            v = np.zeros((max(cap, 1), 3), np.float32)
+            nr = np.zeros((max(cap, 1), 3), np.float32)
+            c = np.zeros((max(cap, 1), 4), np.uint8)
+            rc = f(self._h, _lib.np_ptr(ids), ids.shape[0], _lib.np_ptr(v), _lib.np_ptr(nr), _lib.np_ptr(c), cap,
+                   _lib.np_ptr(first), ctypes.byref(n))
+            if rc == _lib.PLVS_ERR_CAPACITY and n.value > cap:
+                cap = n.value            # first call sizes the mesh, second call fills it
+                continue
+            _lib.check(rc)
+            m = n.value
+            return dict(vertices=v[:m], normals=nr[:m], colors=c[:m], block_first=first)
+
     def get_chunk(self, bx, by, bz):
         d = np.empty(4096, np.float32)
         w = np.empty(4096, np.float32)
@@ -319,14 +351,55 @@ class PointCloudMapVoxblox:
         if self.skIntegrationMethod != "simple":
             raise NotImplementedError("only the deterministic 'simple' integrator is on the accelerated path")
         self._tsdf = TsdfVoxblox(resolution, use_carving, max_blocks)
+        self._updated = set()        # the blocks whose updated() flag is set
+        self.mesh_layer = {}         # block id -> dict(vertices, normals, colors): voxblox::MeshLayer
 
     def InsertCloud(self, cloud_camera, Twc, max_range=None):
         print("PointCloudMapVoxblox<PointT>::InsertCloud()")
         Twc = np.asarray(Twc, dtype=np.float32)[:3, :4]
         self._tsdf.integrate(cloud_camera["xyz"], cloud_camera["rgba"], Twc)
+        for b in self._tsdf.updated_chunk_ids():          # tsdf_integrator.cc:151
+            self._updated.add((int(b[0]), int(b[1]), int(b[2])))
+
+    # colorVoxbloxToMsg / colorMsgToVoxblox (voxblox_ros/conversions.h:44-60): a channel goes through a float in [0, 1]
+    _CLOUD_COLOUR = ((np.arange(256) / 255.0).astype(np.float32).astype(np.float64) * 255.0).astype(np.uint8)
+
+    def UpdateMap(self):
+        """updateMesh (generateMesh(only_mesh_updated_blocks, clear_updated_flag), tsdf_server.cc:775-787) +
+        getMeshAsPointcloud (voxblox_ros/mesh_vis.h:272-318, ColorMode::kColor)  (src/PointCloudMapVoxblox.cc:160-179).
+        -> the output cloud as a structured array (x, y, z, normal, r, g, b), meshes walked in block-id order (the
+        reference walks its hash map)."""
+        todo = sorted(self._updated)
+        if todo:
+            m = self._tsdf.mesh_blocks(np.array(todo, np.int32))
+            first = m["block_first"]
+            for i, bid in enumerate(todo):
+                a, b = int(first[i]), int(first[i + 1])
+                # allocateMeshPtrByIndex + mesh->clear(): an updated block always owns a (possibly empty) mesh
+                self.mesh_layer[bid] = dict(vertices=m["vertices"][a:b].copy(), normals=m["normals"][a:b].copy(),
+                                            colors=m["colors"][a:b].copy())
+            self._updated.clear()
+        from .cloudgen import POINT_SURFEL
+        n = sum(len(v["vertices"]) for v in self.mesh_layer.values())
+        cloud = np.zeros(n, POINT_SURFEL)
+        o = 0
+        for bid in sorted(self.mesh_layer):
+            v = self.mesh_layer[bid]
+            k = len(v["vertices"])
+            if not k:
+                continue
+            cloud["x"][o:o + k], cloud["y"][o:o + k], cloud["z"][o:o + k] = v["vertices"].T
+            cloud["normal"][o:o + k] = v["normals"]
+            rgb = self._CLOUD_COLOUR[v["colors"][:, :3]]
+            cloud["r"][o:o + k], cloud["g"][o:o + k], cloud["b"][o:o + k] = rgb.T
+            o += k
+        self.point_cloud = cloud
+        return cloud
 
     def Clear(self):
         self._tsdf.clear()
+        self._updated.clear()
+        self.mesh_layer.clear()
 
     @property
     def tsdf(self):

@@ -186,7 +186,11 @@ int main(int argc, char** argv) {
   std::printf("chisel %d %d %016llx\n", npts, (int)map.GetAllMeshes().size(), (unsigned long long)hv);
   PointCloudMapVoxblox vmap(0.05f);
   vmap.InsertCloud(cloud, Twc);
-  std::printf("voxblox %d\n", vmap.NumBlocks());
+  Twc.m[3] -= 0.03f;
+  vmap.InsertCloud(cloud, Twc);
+  const int vpts = vmap.UpdateMap();
+  dump("vmap_cloud", vmap.GetPointCloud().data(), vmap.GetPointCloud().size() * sizeof(PointSurfelSegment));
+  std::printf("voxblox %d %d %d\n", vmap.NumBlocks(), vpts, (int)vmap.GetMeshLayer().size());
   map.Clear();
   std::printf("cleared %d\n", map.UpdateMap());
   return 0;

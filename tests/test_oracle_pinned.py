@@ -228,3 +228,48 @@ def test_voxblox_point_order_colour_blend_and_indices_equal_the_reference_source
         ref.ref_voxblox_indices(g.ctypes.data, ba.ctypes.data, la.ctypes.data, ha.ctypes.data)
         ora.oracle_voxblox_indices(g.ctypes.data, bb.ctypes.data, lb.ctypes.data, hb.ctypes.data)
         assert np.array_equal(ba, bb) and np.array_equal(la, lb) and ha[0] == hb[0], g
+
+
+@needs_vref
+def test_voxblox_marching_cubes_equal_the_reference_source():
+    """MarchingCubes::meshCube of voxblox's mesh/marching_cubes.h (vertex configuration, edge interpolation with its
+    small-difference midpoint, the col+2 / col+1 / col vertex order, the flat triangle normal) and the tables of
+    src/mesh/marching_cubes.cc against vb_mesh_cube and the tables of oracle/tsdf_voxblox.c — every one of the 256
+    corner configurations, distances with exact zeros, near-equal pairs and values of very different size."""
+    ref, ora = ctypes.CDLL(VREF), ctypes.CDLL(ORA)
+    a, b = np.zeros(4096, np.int32), np.zeros(4096, np.int32)
+    ea, eb = np.zeros(24, np.int32), np.zeros(24, np.int32)
+    ref.ref_voxblox_mc_tables(a.ctypes.data_as(ctypes.c_void_p), ea.ctypes.data_as(ctypes.c_void_p))
+    ora.oracle_voxblox_mc_tables(b.ctypes.data_as(ctypes.c_void_p), eb.ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(a, b) and np.array_equal(ea, eb)
+    for lib, name in ((ref, "ref_voxblox_mesh_cube"), (ora, "oracle_voxblox_mesh_cube")):
+        getattr(lib, name).argtypes = [ctypes.c_void_p] * 4
+        getattr(lib, name).restype = ctypes.c_int
+    rng = np.random.default_rng(17)
+    offs = np.array([[0, 1, 1, 0, 0, 1, 1, 0], [0, 0, 1, 1, 0, 0, 1, 1], [0, 0, 0, 0, 1, 1, 1, 1]], np.float32).T   # 8 x 3
+    va, na, vb, nb = (np.zeros((15, 3), np.float32) for _ in range(4))
+    seen, total = set(), 0
+    for it in range(40000):
+        vs = np.float32(rng.choice([0.02, 0.05, 0.1]))
+        base = (rng.integers(-200, 200, 3).astype(np.float32) + np.float32(0.5)) * vs
+        coords = np.ascontiguousarray(base + offs * vs, np.float32)
+        cfg = it % 256 if it < 2560 else int(rng.integers(0, 256))
+        sign = np.array([-1.0 if (cfg >> i) & 1 else 1.0 for i in range(8)], np.float32)
+        mag = rng.uniform(0.0, 0.1, 8).astype(np.float32)
+        kind = it % 5
+        if kind == 1:
+            mag[rng.integers(0, 8, 3)] = 0.0                   # exact zeros (>= 0: outside)
+        elif kind == 2:
+            mag[:] = np.float32(rng.uniform(1e-8, 6e-7))       # |sdf1 - sdf2| around the 1e-6 midpoint switch
+            mag += rng.uniform(0, 3e-7, 8).astype(np.float32)
+        elif kind == 3:
+            mag *= np.float32(10.0) ** rng.integers(-6, 1, 8).astype(np.float32)
+        sdf = np.ascontiguousarray(sign * mag, np.float32)
+        n1 = ref.ref_voxblox_mesh_cube(coords.ctypes.data, sdf.ctypes.data, va.ctypes.data, na.ctypes.data)
+        n2 = ora.oracle_voxblox_mesh_cube(coords.ctypes.data, sdf.ctypes.data, vb.ctypes.data, nb.ctypes.data)
+        assert n1 == n2 and n1 % 3 == 0, (cfg, sdf)
+        assert va[:n1].tobytes() == vb[:n1].tobytes(), (cfg, sdf, coords)
+        assert na[:n1].tobytes() == nb[:n1].tobytes(), (cfg, sdf, coords)
+        seen.add(int(sum(1 << i for i in range(8) if sdf[i] < 0)))
+        total += n1
+    assert len(seen) == 256 and total > 200000
