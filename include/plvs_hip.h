@@ -32,6 +32,7 @@ extern "C" {
 #define PLVS_ERR_NO_DEVICE (-3)
 #define PLVS_ERR_CAPACITY (-4)    /* a fixed-capacity device structure overflowed */
 #define PLVS_ERR_EMPTY (-5)       /* empty input where the reference bails out */
+#define PLVS_ERR_HALO (-6)        /* sharded map: chunks of other ranks are needed first (plvs_hip_tsdf_chisel_halo_*) */
 
 /* Human-readable description of the last error on the calling thread. */
 const char* plvs_hip_last_error(void);
@@ -600,10 +601,46 @@ int plvs_hip_stereo_matches(plvs_stereo* s, const plvs_keypoint* keys_left, cons
  * (n x 3 f32, colours in [0, 1]) and kfids (n); chunk c owns [chunk_first[c], chunk_first[c+1])
  * (chunk_first: nchunks + 1 ints); a chunk that does not exist owns nothing.  *nvertices = n.  If
  * n > capacity nothing is written but chunk_first / *nvertices, and PLVS_ERR_CAPACITY is returned.
- * Needs the whole map on one device (shard_count <= 1). */
+ * Sharded map (shard_count > 1): the list holds chunks of THIS rank (another rank's chunk owns nothing); the
+ * cubes on a chunk's +x / +y / +z faces, the colour interpolation and the gradient normals read neighbour chunks
+ * that live on other ranks.  A call that met a foreign chunk it does not hold returns PLVS_ERR_HALO; the caller
+ * fetches the chunks plvs_hip_tsdf_chisel_halo_missing lists from their owners (halo_export there, halo_import
+ * here) and calls again — until no rank misses anything (two or three rounds: new vertices can reach further
+ * chunks).  The result is then the single-device mesh of the chunk, byte for byte. */
 int plvs_hip_tsdf_chisel_mesh_chunks(plvs_tsdf_chisel* h, const int32_t* chunk_ids_xyz, int nchunks,
                                      float* vertices, float* normals, float* colors, uint32_t* kfids,
                                      int capacity, int32_t* chunk_first, int* nvertices);
+
+/* Halo of a sharded map, for meshing (see plvs_hip_tsdf_chisel_mesh_chunks).
+ *   halo_missing  the chunk ids (host, n x 3) the last mesh_chunks call looked for on other ranks and did not hold;
+ *                 PLVS_ERR_CAPACITY with *n set if cap is too small.
+ *   halo_lookup   owner side: d_found[i] = 1 if this rank has the i-th of the n requested ids (device, n x 3), else 0.
+ *   halo_export   owner side: the found chunks' four planes (sdf, weight, kfid, rgbw: 4096 words each = one payload
+ *                 row of 16384 words), packed in request order into d_payload (rows = number of found flags set;
+ *                 may be null when none is).
+ *   halo_import   requester side: the ids it asked for, the found flags and the nfound payload rows received from
+ *                 the owners become ghost chunks (read-only copies in free slots of the pool); "found = 0" is
+ *                 remembered as "exists nowhere".  PLVS_ERR_CAPACITY if the pool has fewer than nfound free slots.
+ *                 All three are asynchronous on `stream`.
+ *   halo_clear    drops every ghost (also done by the next integrate / shard_apply / clear call).
+ * The exchange itself is halo_gather below, or the caller's own all-to-all (plvs_amd/shard.py: gather_mesh_halo over
+ * torch.distributed). */
+/*   mesh_probe    the stages of mesh_chunks on the device only (no outputs, no capacity): *nmissing = the foreign
+ *                 chunks the list's meshes reach for and this rank does not hold (0: mesh_chunks will succeed).
+ *   halo_gather   the whole exchange over an RCCL communicator (ncclComm_t), collective: every rank calls it with
+ *                 its own list (possibly empty); rounds of mesh_probe, requests to the owners (ncclSend / ncclRecv),
+ *                 halo_lookup / halo_export there, halo_import here, until no rank misses anything.  *fetched = chunks imported.
+ *                 Afterwards mesh_chunks(the same list) is a local call. */
+int plvs_hip_tsdf_chisel_mesh_probe(plvs_tsdf_chisel* h, const int32_t* chunk_ids_xyz, int nchunks, int* nmissing);
+int plvs_hip_tsdf_chisel_halo_gather(plvs_tsdf_chisel* h, void* rccl_comm, const int32_t* chunk_ids_xyz, int nchunks,
+                                     int* fetched, void* stream);
+int plvs_hip_tsdf_chisel_halo_missing(plvs_tsdf_chisel* h, int32_t* ids_xyz, int cap, int* n);
+int plvs_hip_tsdf_chisel_halo_lookup(plvs_tsdf_chisel* h, const int32_t* d_ids_xyz, int n, uint32_t* d_found, void* stream);
+int plvs_hip_tsdf_chisel_halo_export(plvs_tsdf_chisel* h, const int32_t* d_ids_xyz, const uint32_t* d_found, int n,
+                                     uint32_t* d_payload, void* stream);
+int plvs_hip_tsdf_chisel_halo_import(plvs_tsdf_chisel* h, const int32_t* d_ids_xyz, const uint32_t* d_found,
+                                     const uint32_t* d_payload, int n, int nfound, void* stream);
+int plvs_hip_tsdf_chisel_halo_clear(plvs_tsdf_chisel* h);
 
 /* ------------------------------------------------- dense stereo (semi-global matching)
  * Replaces sgm::StereoSGM as PointCloudKeyFrame::ProcessStereoLibsgm uses it

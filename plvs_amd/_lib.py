@@ -20,6 +20,7 @@ PLVS_ERR_HIP = -2
 PLVS_ERR_NO_DEVICE = -3
 PLVS_ERR_CAPACITY = -4
 PLVS_ERR_EMPTY = -5
+PLVS_ERR_HALO = -6
 
 TIE_LOWEST_INDEX = 0
 TIE_MIH = 1

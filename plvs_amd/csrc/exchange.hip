@@ -8,7 +8,10 @@
 // librccl.so.1 otherwise): the library carries no link-time dependency on it.
 #include <dlfcn.h>
 
+#include <vector>
+
 #include "common.hpp"
+#include "tsdf_chisel_core.hpp"
 #include "tsdf_directory.hpp"
 
 namespace {
@@ -303,6 +306,164 @@ int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm,
   }
 #undef RCCL_TRY
   return PLVS_OK;
+}
+
+// The meshing halo of a sharded chisel map over RCCL (include/plvs_hip.h: halo_gather): rounds of
+//   mesh_probe -> all-gather of the miss counts -> requests to the owners -> halo_export there -> answers back ->
+//   halo_import here
+// until no rank misses anything.  A chunk travels as 64 KiB (four planes of 4096 words).
+int plvs_hip_tsdf_chisel_halo_gather(plvs_tsdf_chisel* h, void* rccl_comm, const int32_t* chunk_ids_xyz, int nchunks,
+                                     int* fetched, void* stream) {
+  PLVS_REQUIRE(h && rccl_comm && fetched, "null argument");
+  *fetched = 0;
+  const Rccl* r = rccl();
+  if (r == nullptr || !r->send || !r->recv || !r->group_start || !r->group_end) {
+    plvs::set_error("RCCL is not available in this process (ncclSend / ncclRecv / librccl.so.1 not found)");
+    return PLVS_ERR_NO_DEVICE;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int world = 0, rank = 0;
+  if (r->comm_count(rccl_comm, &world) != 0 || r->comm_rank(rccl_comm, &rank) != 0 || world < 1 || world > 64) {
+    plvs::set_error("bad RCCL communicator (1..64 ranks)");
+    return PLVS_ERR_INVALID_ARG;
+  }
+  constexpr size_t kHaloWords = 4 * 4096;
+  struct Scratch {   // grow-only device buffers of this thread
+    plvs::DevBuf<int32_t> cnt, req_ids, got_ids;
+    plvs::DevBuf<uint32_t> got_found, got_payload, back_found, back_payload;
+  };
+  static thread_local Scratch B;
+#define RCCL_TRY(call)                                                      \
+  do {                                                                      \
+    const int e_ = (call);                                                  \
+    if (e_ != 0) {                                                          \
+      plvs::set_error("%s failed: %s", #call, r->err ? r->err(e_) : "?");   \
+      return PLVS_ERR_HIP;                                                  \
+    }                                                                       \
+  } while (0)
+  PLVS_HIP_TRY(B.cnt.reserve((size_t)4 * world + 4));
+  for (int round = 0; round < 8; ++round) {
+    int nmiss = 0;
+    int rc = plvs_hip_tsdf_chisel_mesh_probe(h, chunk_ids_xyz, nchunks, &nmiss);
+    if (rc != PLVS_OK) return rc;
+    // does anybody miss anything?
+    int32_t all_miss[64];
+    PLVS_HIP_TRY(hipMemcpyAsync(B.cnt.p + rank, &nmiss, sizeof(int32_t), hipMemcpyHostToDevice, s));
+    RCCL_TRY(r->all_gather(B.cnt.p + rank, B.cnt.p, 1, /*ncclInt32*/ 2, rccl_comm, s));
+    PLVS_HIP_TRY(hipMemcpyAsync(all_miss, B.cnt.p, (size_t)world * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    PLVS_HIP_TRY(hipStreamSynchronize(s));
+    int any = 0;
+    for (int p = 0; p < world; ++p) any |= all_miss[p];
+    if (any == 0) {
+      return PLVS_OK;
+    }
+    // this rank's requests, grouped by owner
+    std::vector<int32_t> miss((size_t)3 * (nmiss > 0 ? nmiss : 1)), req((size_t)3 * (nmiss > 0 ? nmiss : 1));
+    if (nmiss > 0) {
+      int got_n = 0;
+      rc = plvs_hip_tsdf_chisel_halo_missing(h, miss.data(), nmiss, &got_n);
+      if (rc != PLVS_OK) return rc;
+      nmiss = got_n;
+    }
+    int32_t req_cnt[64] = {0}, got_cnt[64] = {0}, at[64];
+    std::vector<int> owner((size_t)(nmiss > 0 ? nmiss : 1));
+    for (int i = 0; i < nmiss; ++i) {
+      owner[(size_t)i] = plvs::chisel::shard_of(plvs::chisel::chunk_hash(miss[3 * i], miss[3 * i + 1], miss[3 * i + 2]), world);
+      ++req_cnt[owner[(size_t)i]];
+    }
+    at[0] = 0;
+    for (int p = 1; p < world; ++p) at[p] = at[p - 1] + req_cnt[p - 1];
+    for (int i = 0; i < nmiss; ++i) {
+      const int o = at[owner[(size_t)i]]++;
+      req[3 * (size_t)o] = miss[3 * i];
+      req[3 * (size_t)o + 1] = miss[3 * i + 1];
+      req[3 * (size_t)o + 2] = miss[3 * i + 2];
+    }
+    // ---- request counts
+    int32_t* d_req_cnt = B.cnt.p + world;
+    int32_t* d_got_cnt = B.cnt.p + 2 * world;
+    PLVS_HIP_TRY(hipMemcpyAsync(d_req_cnt, req_cnt, (size_t)world * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    RCCL_TRY(r->group_start());
+    for (int p = 0; p < world; ++p) {
+      RCCL_TRY(r->send(d_req_cnt + p, 1, /*ncclInt32*/ 2, p, rccl_comm, s));
+      RCCL_TRY(r->recv(d_got_cnt + p, 1, /*ncclInt32*/ 2, p, rccl_comm, s));
+    }
+    RCCL_TRY(r->group_end());
+    PLVS_HIP_TRY(hipMemcpyAsync(got_cnt, d_got_cnt, (size_t)world * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    PLVS_HIP_TRY(hipStreamSynchronize(s));
+    size_t ngot = 0;
+    for (int p = 0; p < world; ++p) ngot += (size_t)got_cnt[p];
+    // ---- the ids
+    PLVS_HIP_TRY(B.req_ids.reserve(3 * (size_t)nmiss + 4));
+    PLVS_HIP_TRY(B.got_ids.reserve(3 * ngot + 4));
+    if (nmiss > 0)
+      PLVS_HIP_TRY(hipMemcpyAsync(B.req_ids.p, req.data(), (size_t)3 * nmiss * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    RCCL_TRY(r->group_start());
+    {
+      size_t so = 0, ro = 0;
+      for (int p = 0; p < world; ++p) {
+        if (req_cnt[p]) RCCL_TRY(r->send(B.req_ids.p + 3 * so, (size_t)3 * req_cnt[p], /*ncclInt32*/ 2, p, rccl_comm, s));
+        if (got_cnt[p]) RCCL_TRY(r->recv(B.got_ids.p + 3 * ro, (size_t)3 * got_cnt[p], /*ncclInt32*/ 2, p, rccl_comm, s));
+        so += (size_t)req_cnt[p];
+        ro += (size_t)got_cnt[p];
+      }
+    }
+    RCCL_TRY(r->group_end());
+    // ---- owners look the ids up; the flags travel the reverse way, then one payload row per chunk that exists
+    PLVS_HIP_TRY(B.got_found.reserve(ngot + 4));
+    PLVS_HIP_TRY(B.back_found.reserve((size_t)nmiss + 4));
+    rc = plvs_hip_tsdf_chisel_halo_lookup(h, B.got_ids.p, (int)ngot, B.got_found.p, stream);
+    if (rc != PLVS_OK) return rc;
+    RCCL_TRY(r->group_start());
+    {
+      size_t so = 0, ro = 0;
+      for (int p = 0; p < world; ++p) {
+        if (got_cnt[p]) RCCL_TRY(r->send(B.got_found.p + so, (size_t)got_cnt[p], /*ncclUint32*/ 3, p, rccl_comm, s));
+        if (req_cnt[p]) RCCL_TRY(r->recv(B.back_found.p + ro, (size_t)req_cnt[p], /*ncclUint32*/ 3, p, rccl_comm, s));
+        so += (size_t)got_cnt[p];
+        ro += (size_t)req_cnt[p];
+      }
+    }
+    RCCL_TRY(r->group_end());
+    std::vector<uint32_t> got_found(ngot + 1), back_found((size_t)nmiss + 1);
+    if (ngot) PLVS_HIP_TRY(hipMemcpyAsync(got_found.data(), B.got_found.p, ngot * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (nmiss) PLVS_HIP_TRY(hipMemcpyAsync(back_found.data(), B.back_found.p, (size_t)nmiss * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    PLVS_HIP_TRY(hipStreamSynchronize(s));
+    size_t send_rows[64] = {0}, recv_rows[64] = {0}, nsend = 0, nrecv = 0;
+    {
+      size_t so = 0, ro = 0;
+      for (int p = 0; p < world; ++p) {
+        for (int i = 0; i < got_cnt[p]; ++i) send_rows[p] += got_found[so + (size_t)i] ? 1 : 0;
+        for (int i = 0; i < req_cnt[p]; ++i) recv_rows[p] += back_found[ro + (size_t)i] ? 1 : 0;
+        so += (size_t)got_cnt[p];
+        ro += (size_t)req_cnt[p];
+        nsend += send_rows[p];
+        nrecv += recv_rows[p];
+      }
+    }
+    PLVS_HIP_TRY(B.got_payload.reserve(nsend * kHaloWords + 4));
+    PLVS_HIP_TRY(B.back_payload.reserve(nrecv * kHaloWords + 4));
+    rc = plvs_hip_tsdf_chisel_halo_export(h, B.got_ids.p, B.got_found.p, (int)ngot, B.got_payload.p, stream);
+    if (rc != PLVS_OK) return rc;
+    RCCL_TRY(r->group_start());
+    {
+      size_t so = 0, ro = 0;
+      for (int p = 0; p < world; ++p) {
+        if (send_rows[p]) RCCL_TRY(r->send(B.got_payload.p + so * kHaloWords, send_rows[p] * kHaloWords, /*ncclUint32*/ 3, p, rccl_comm, s));
+        if (recv_rows[p]) RCCL_TRY(r->recv(B.back_payload.p + ro * kHaloWords, recv_rows[p] * kHaloWords, /*ncclUint32*/ 3, p, rccl_comm, s));
+        so += send_rows[p];
+        ro += recv_rows[p];
+      }
+    }
+    RCCL_TRY(r->group_end());
+    rc = plvs_hip_tsdf_chisel_halo_import(h, B.req_ids.p, B.back_found.p, B.back_payload.p, nmiss, (int)nrecv, stream);
+    if (rc != PLVS_OK) return rc;
+    PLVS_HIP_TRY(hipStreamSynchronize(s));   // (the next probe runs on the default stream)
+    *fetched += (int)nrecv;
+  }
+#undef RCCL_TRY
+  plvs::set_error("halo_gather: the halo did not settle in 8 rounds");
+  return PLVS_ERR_CAPACITY;
 }
 
 int plvs_hip_rccl_world_size(void* rccl_comm, int* world) {

@@ -788,6 +788,15 @@ struct plvs_tsdf_chisel {
   DevBuf<Pose> poses;
   void* ext = nullptr;                 // see ChiselMapView::ext
   void (*ext_free)(void*) = nullptr;
+  // halo of a sharded map (meshing): ghost copies of other ranks' chunks in the pool slots past num_chunks
+  Directory gdir{};                    // id -> ghost slot / kGhostAbsent (allocated by the first import)
+  int ghost_count = 0;                 // ghost chunks (pool slots taken) since the last halo_clear
+  long long ghost_entries = 0;         //   and directory entries ("absent" answers included)
+  DevBuf<uint32_t> halo_row;           // payload row of each request (prefix of the found flags)
+  unsigned long long* miss_keys = nullptr;   // the chunks the last meshing pass looked for and did not have
+  int32_t* miss_ids = nullptr;
+  uint32_t* miss_count = nullptr;
+  uint32_t miss_cap = 0, miss_mask = 0;
   DevBuf<int32_t> offsets;
   // host-flavour staging
   DevBuf<float> st_xyz, st_Twc;
@@ -1183,6 +1192,11 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   (void)hipFree(h->d_wctr);
   if (h->h_wctr) (void)hipHostFree(h->h_wctr);
   if (h->h_offsets) (void)hipHostFree(h->h_offsets);
+  (void)hipFree(h->gdir.keys);
+  (void)hipFree(h->gdir.slots);
+  (void)hipFree(h->miss_keys);
+  (void)hipFree(h->miss_ids);
+  (void)hipFree(h->miss_count);
   (void)hipFree(h->xdir.keys);
   (void)hipFree(h->xdir.slots);
   (void)hipFree(h->xdir.slot_ids);
@@ -1195,7 +1209,7 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   h->w_dummy.release(); h->w_runkey.release(); h->w_run_cnt.release(); h->w_run_off.release(); h->w_val0.release();
   h->w_val1.release(); h->w_seg_cnt.release(); h->w_tile_visits.release(); h->w_part_off.release(); h->w_multi_idx.release();
   h->pa_wuu.release(); h->pa_w.release(); h->pa_last.release(); h->pa_cnt.release(); h->pa_done.release();
-  h->sh_nrec.release(); h->sh_owner.release();
+  h->sh_nrec.release(); h->sh_owner.release(); h->halo_row.release();
   h->sh_ctl.release(); h->sh_seg_reg.release(); h->sh_rec_reg.release(); h->sh_src_off.release(); h->sh_slot_owner.release(); h->sh_run_ctr.release(); h->sh_vkey.release(); h->sh_sat.release();
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -1215,9 +1229,14 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
 }
 
 static int shard_state_clear(plvs_tsdf_chisel* h);
+static int halo_drop(plvs_tsdf_chisel* h, hipStream_t s);
 
 int plvs_hip_tsdf_chisel_clear(plvs_tsdf_chisel* h) {
   PLVS_REQUIRE(h, "null handle");
+  {
+    int rc = halo_drop(h, nullptr);
+    if (rc != PLVS_OK) return rc;
+  }
   {
     int rc = shard_state_clear(h);   // (the walk directory of the ray-sharded integrate, if in use)
     if (rc != PLVS_OK) return rc;
@@ -1257,6 +1276,10 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   h->stats.points = n;
   if (n == 0) return PLVS_OK;
   PLVS_REQUIRE(d_xyz && d_rgb && d_Twc, "null device pointer");
+  {
+    int rc = halo_drop(h, s);   // new chunks go into the pool slots a meshing halo may still occupy
+    if (rc != PLVS_OK) return rc;
+  }
 
   PLVS_HIP_TRY(h->offsets.reserve((size_t)nclouds + 1));
   PLVS_HIP_TRY(h->poses.reserve((size_t)nclouds));
@@ -1721,13 +1744,267 @@ bool chisel_map_view(plvs_tsdf_chisel* h, ChiselMapView* v) {
   v->rgbw = h->rgbw;
   v->num_chunks = h->num_chunks;
   v->shard_count = h->P.shard_count;
+  v->shard_rank = h->P.shard_rank;
   v->ext = &h->ext;
   v->ext_free = &h->ext_free;
+  if (h->P.shard_count > 1) {
+    if (h->miss_keys == nullptr) {
+      // every chunk of the whole map could be asked for: as many entries as the walk directory may hold
+      const size_t want = std::min<size_t>((size_t)h->prm.max_chunks * (size_t)h->P.shard_count, (size_t)1 << 22);
+      size_t cap = 1024;
+      while (cap < 2 * want) cap <<= 1;
+      if (hipMalloc(&h->miss_keys, cap * sizeof(unsigned long long)) != hipSuccess) return false;
+      if (hipMalloc(&h->miss_ids, want * 3 * sizeof(int32_t)) != hipSuccess) return false;
+      if (hipMalloc(&h->miss_count, sizeof(uint32_t)) != hipSuccess) return false;
+      h->miss_cap = (uint32_t)want;
+      h->miss_mask = (uint32_t)(cap - 1);
+    }
+    if (hipMemsetAsync(h->miss_keys, 0xFF, ((size_t)h->miss_mask + 1) * sizeof(unsigned long long), nullptr) != hipSuccess) return false;
+    if (hipMemsetAsync(h->miss_count, 0, sizeof(uint32_t), nullptr) != hipSuccess) return false;
+    v->ghost = h->gdir;
+    v->miss_keys = h->miss_keys;
+    v->miss_mask = h->miss_mask;
+    v->miss_ids = h->miss_ids;
+    v->miss_count = h->miss_count;
+    v->miss_cap = h->miss_cap;
+  }
   return true;
 }
 
 }  // namespace tsdf
 }  // namespace plvs
+
+// ------------------------------------------------------------------ halo of a sharded map (meshing)
+namespace {
+
+constexpr int kHaloWords = 4 * kChunkVox;   // a chunk on the wire: sdf, weight, kfid, rgbw planes
+
+// Which of the requested chunks this rank has.
+__global__ void halo_lookup_chunks(Directory dir, const int32_t* __restrict__ ids, int n, uint32_t* __restrict__ found) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) found[i] = dir_find(dir, ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]) >= 0 ? 1u : 0u;
+}
+
+// row[i] = number of found chunks before request i (one workgroup; request lists are a few thousand long).
+__global__ __launch_bounds__(1024) void halo_rows(const uint32_t* __restrict__ found, int n, uint32_t* __restrict__ row) {
+  __shared__ uint32_t s_part[1024];
+  const int per = (n + 1023) / 1024;
+  const int lo = min((int)threadIdx.x * per, n), hi = min(lo + per, n);
+  uint32_t sum = 0;
+  for (int i = lo; i < hi; ++i) sum += found[i] ? 1u : 0u;
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const uint32_t add = threadIdx.x >= (unsigned)d ? s_part[threadIdx.x - d] : 0u;
+    __syncthreads();
+    s_part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  uint32_t run = s_part[threadIdx.x] - sum;
+  for (int i = lo; i < hi; ++i) {
+    row[i] = run;
+    run += found[i] ? 1u : 0u;
+  }
+}
+
+// The found chunks' planes, one payload row (kHaloWords) each, in request order.
+__global__ __launch_bounds__(256) void halo_export_chunks(Directory dir, const float* __restrict__ sdf,
+                                                          const float* __restrict__ weight, const uint32_t* __restrict__ kfid,
+                                                          const uint32_t* __restrict__ rgbw, const int32_t* __restrict__ ids,
+                                                          const uint32_t* __restrict__ found, const uint32_t* __restrict__ row,
+                                                          uint32_t* __restrict__ payload) {
+  const int i = blockIdx.x;
+  if (!found[i]) return;
+  __shared__ int s_slot;
+  if (threadIdx.x == 0) s_slot = dir_find(dir, ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]);
+  __syncthreads();
+  const int slot = s_slot;
+  if (slot < 0) return;
+  const size_t src = (size_t)slot * kChunkVox;
+  uint4* dst = reinterpret_cast<uint4*>(payload + (size_t)row[i] * kHaloWords);
+  const uint4* p0 = reinterpret_cast<const uint4*>(sdf + src);
+  const uint4* p1 = reinterpret_cast<const uint4*>(weight + src);
+  const uint4* p2 = reinterpret_cast<const uint4*>(kfid + src);
+  const uint4* p3 = reinterpret_cast<const uint4*>(rgbw + src);
+  for (int v = threadIdx.x; v < kChunkVox / 4; v += 256) {
+    dst[v] = p0[v];
+    dst[kChunkVox / 4 + v] = p1[v];
+    dst[2 * (kChunkVox / 4) + v] = p2[v];
+    dst[3 * (kChunkVox / 4) + v] = p3[v];
+  }
+}
+
+// id -> ghost slot (base + its payload row), or kGhostAbsent for a chunk its owner does not have; an id already
+// present keeps its entry.
+__global__ void halo_insert(Directory g, const int32_t* __restrict__ ids, const uint32_t* __restrict__ found,
+                            const uint32_t* __restrict__ row, int n, int base, uint32_t* __restrict__ err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = ids[3 * i], y = ids[3 * i + 1], z = ids[3 * i + 2];
+  unsigned long long key;
+  if (!pack_block(x, y, z, &key)) {
+    atomicOr(err, kErrCoordRange);
+    return;
+  }
+  uint32_t hsh = dir_hash(x, y, z, g.mask);
+  for (uint32_t probe = 0; probe <= g.mask; ++probe) {
+    unsigned long long cur = g.keys[hsh];
+    if (cur == key) return;
+    if (cur == kEmptyKey) {
+      cur = atomicCAS(&g.keys[hsh], kEmptyKey, key);
+      if (cur == kEmptyKey) {
+        g.slots[hsh] = found[i] ? base + (int)row[i] : plvs::tsdf::kGhostAbsent;
+        return;
+      }
+      if (cur == key) return;
+    }
+    hsh = (hsh + 1) & g.mask;
+  }
+  atomicOr(err, kErrPoolFull);
+}
+
+__global__ __launch_bounds__(256) void halo_import_chunks(float* __restrict__ sdf, float* __restrict__ weight,
+                                                          uint32_t* __restrict__ kfid, uint32_t* __restrict__ rgbw,
+                                                          const uint32_t* __restrict__ found, const uint32_t* __restrict__ row,
+                                                          const uint32_t* __restrict__ payload, int base) {
+  const int i = blockIdx.x;
+  if (!found[i]) return;
+  const size_t dst = (size_t)(base + (int)row[i]) * kChunkVox;
+  const uint4* src = reinterpret_cast<const uint4*>(payload + (size_t)row[i] * kHaloWords);
+  uint4* p0 = reinterpret_cast<uint4*>(sdf + dst);
+  uint4* p1 = reinterpret_cast<uint4*>(weight + dst);
+  uint4* p2 = reinterpret_cast<uint4*>(kfid + dst);
+  uint4* p3 = reinterpret_cast<uint4*>(rgbw + dst);
+  for (int v = threadIdx.x; v < kChunkVox / 4; v += 256) {
+    p0[v] = src[v];
+    p1[v] = src[kChunkVox / 4 + v];
+    p2[v] = src[2 * (kChunkVox / 4) + v];
+    p3[v] = src[3 * (kChunkVox / 4) + v];
+  }
+}
+
+// Ghost slots back to the state of a never-used pool slot (clear() leaves sdf 99999, everything else 0).
+__global__ __launch_bounds__(256) void halo_reset_slots(float* __restrict__ sdf, float* __restrict__ weight,
+                                                        uint32_t* __restrict__ kfid, uint32_t* __restrict__ rgbw, int base) {
+  const size_t at = (size_t)(base + blockIdx.x) * kChunkVox;
+  for (int v = threadIdx.x; v < kChunkVox; v += 256) {
+    sdf[at + v] = 99999.0f;
+    weight[at + v] = 0.f;
+    kfid[at + v] = 0u;
+    rgbw[at + v] = 0u;
+  }
+}
+
+}  // namespace
+
+// Drops the ghosts (the integrate calls allocate new chunks in the slots they occupy).
+static int halo_drop(plvs_tsdf_chisel* h, hipStream_t s) {
+  if (h->ghost_entries == 0) return PLVS_OK;
+  if (h->ghost_count > 0) {
+    hipLaunchKernelGGL(halo_reset_slots, dim3((unsigned)h->ghost_count), dim3(256), 0, s, h->sdf, h->weight, h->kfid, h->rgbw,
+                       h->num_chunks);
+    PLVS_KERNEL_CHECK();
+  }
+  PLVS_HIP_TRY(hipMemsetAsync(h->gdir.keys, 0xFF, ((size_t)h->gdir.mask + 1) * sizeof(unsigned long long), s));
+  h->ghost_count = 0;
+  h->ghost_entries = 0;
+  return PLVS_OK;
+}
+
+extern "C" {
+
+int plvs_hip_tsdf_chisel_halo_missing(plvs_tsdf_chisel* h, int32_t* ids_xyz, int cap, int* n) {
+  PLVS_REQUIRE(h && n, "null argument");
+  *n = 0;
+  if (h->miss_count == nullptr) return PLVS_OK;
+  uint32_t cnt = 0;
+  PLVS_HIP_TRY(hipMemcpy(&cnt, h->miss_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (cnt > h->miss_cap) {
+    plvs::set_error("halo_missing: %u missing chunks exceed the list capacity %u", cnt, h->miss_cap);
+    return PLVS_ERR_CAPACITY;
+  }
+  *n = (int)cnt;
+  if (cnt == 0) return PLVS_OK;
+  if ((int)cnt > cap) return PLVS_ERR_CAPACITY;
+  PLVS_REQUIRE(ids_xyz, "null output");
+  PLVS_HIP_TRY(hipMemcpy(ids_xyz, h->miss_ids, (size_t)cnt * 3 * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_chisel_halo_lookup(plvs_tsdf_chisel* h, const int32_t* d_ids_xyz, int n, uint32_t* d_found, void* stream) {
+  PLVS_REQUIRE(h && !h->poisoned, "unusable handle");
+  PLVS_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return PLVS_OK;
+  PLVS_REQUIRE(d_ids_xyz && d_found, "null argument");
+  hipLaunchKernelGGL(halo_lookup_chunks, dim3(ceil_div((size_t)n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), h->dir,
+                     d_ids_xyz, n, d_found);
+  PLVS_KERNEL_CHECK();
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_chisel_halo_export(plvs_tsdf_chisel* h, const int32_t* d_ids_xyz, const uint32_t* d_found, int n,
+                                     uint32_t* d_payload, void* stream) {
+  PLVS_REQUIRE(h && !h->poisoned, "unusable handle");
+  PLVS_REQUIRE(n >= 0, "negative size");
+  if (n == 0 || d_payload == nullptr) return PLVS_OK;   // (no payload buffer: the caller saw no flag set)
+  PLVS_REQUIRE(d_ids_xyz && d_found, "null argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  PLVS_HIP_TRY(h->halo_row.reserve((size_t)n));
+  hipLaunchKernelGGL(halo_rows, dim3(1), dim3(1024), 0, s, d_found, n, h->halo_row.p);
+  hipLaunchKernelGGL(halo_export_chunks, dim3((unsigned)n), dim3(256), 0, s, h->dir, h->sdf, h->weight, h->kfid, h->rgbw,
+                     d_ids_xyz, d_found, h->halo_row.p, d_payload);
+  PLVS_KERNEL_CHECK();
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_chisel_halo_import(plvs_tsdf_chisel* h, const int32_t* d_ids_xyz, const uint32_t* d_found,
+                                     const uint32_t* d_payload, int n, int nfound, void* stream) {
+  PLVS_REQUIRE(h && !h->poisoned, "unusable handle");
+  PLVS_REQUIRE(n >= 0 && nfound >= 0 && nfound <= n, "bad sizes");
+  if (n == 0) return PLVS_OK;
+  PLVS_REQUIRE(d_ids_xyz && d_found && (nfound == 0 || d_payload), "null argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if ((long long)h->num_chunks + h->ghost_count + nfound > (long long)h->prm.max_chunks) {
+    plvs::set_error("halo_import: %d own + %d ghost + %d new chunks exceed the pool (%d)", h->num_chunks, h->ghost_count, nfound,
+                    h->prm.max_chunks);
+    return PLVS_ERR_CAPACITY;
+  }
+  if (h->gdir.keys == nullptr) {
+    // entries are foreign chunks that exist (at most the pool's worth) and ids that exist nowhere (the colour look-up's
+    // reach: a few thousand per call) — sized like the miss set, which bounds what one handle can ever ask for
+    size_t cap = (size_t)h->miss_mask + 1;
+    if (cap < 1024) cap = 1024;
+    while (cap < 2 * (size_t)h->prm.max_chunks) cap <<= 1;
+    PLVS_HIP_TRY(hipMalloc(&h->gdir.keys, cap * sizeof(unsigned long long)));
+    PLVS_HIP_TRY(hipMalloc(&h->gdir.slots, cap * sizeof(int32_t)));
+    h->gdir.slot_ids = nullptr;
+    h->gdir.mask = (uint32_t)(cap - 1);
+    h->gdir.max_blocks = h->prm.max_chunks;
+    PLVS_HIP_TRY(hipMemsetAsync(h->gdir.keys, 0xFF, cap * sizeof(unsigned long long), s));
+  }
+  const int base = h->num_chunks + h->ghost_count;
+  PLVS_HIP_TRY(h->halo_row.reserve((size_t)n));
+  hipLaunchKernelGGL(halo_rows, dim3(1), dim3(1024), 0, s, d_found, n, h->halo_row.p);
+  hipLaunchKernelGGL(halo_insert, dim3(ceil_div((size_t)n, 256)), dim3(256), 0, s, h->gdir, d_ids_xyz, d_found, h->halo_row.p, n,
+                     base, &h->d_ctr->err);
+  if (nfound > 0)
+    hipLaunchKernelGGL(halo_import_chunks, dim3((unsigned)n), dim3(256), 0, s, h->sdf, h->weight, h->kfid, h->rgbw, d_found,
+                       h->halo_row.p, d_payload, base);
+  PLVS_KERNEL_CHECK();
+  h->ghost_count += nfound;
+  h->ghost_entries += n;
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_chisel_halo_clear(plvs_tsdf_chisel* h) {
+  PLVS_REQUIRE(h, "null handle");
+  int rc = halo_drop(h, nullptr);
+  if (rc != PLVS_OK) return rc;
+  PLVS_HIP_TRY(hipStreamSynchronize(nullptr));
+  return PLVS_OK;
+}
+
+}  // extern "C"
 
 // ------------------------------------------------------------------ ray-sharded integrate (tsdf_shard.hpp)
 static int shard_state_init(plvs_tsdf_chisel* h) {
@@ -1962,6 +2239,10 @@ int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src,
   PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
   PLVS_REQUIRE(h->sh_phase == 2, "shard_apply follows shard_pack");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  {
+    int rc = halo_drop(h, s);   // first-touch chunks go into the pool slots a meshing halo may still occupy
+    if (rc != PLVS_OK) return rc;
+  }
   h->sh_phase = 0;
   h->sh_nsat = 0;
   const int N = std::max(1, h->prm.shard_count);

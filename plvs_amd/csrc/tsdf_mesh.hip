@@ -25,6 +25,7 @@
 
 #include "common.hpp"
 #include "device_utils.hpp"
+#include "tsdf_chisel_core.hpp"
 #include "tsdf_chisel_view.hpp"
 
 namespace {
@@ -70,6 +71,41 @@ __device__ __forceinline__ void walk_voxel(int k, int* x, int* y, int* z) {
   }
 }
 
+// Chunk id -> pool slot.  On a sharded map a chunk of another rank is looked for among the imported ghosts; one that
+// has not been brought in yet is noted in the miss set (the caller fetches it and meshes again).
+__device__ __forceinline__ int find_chunk(const ChiselMapView& m, int cx, int cy, int cz) {
+  const int s = dir_find(m.dir, cx, cy, cz);
+  if (s >= 0 || m.shard_count <= 1) return s;
+  if (plvs::chisel::shard_of(plvs::chisel::chunk_hash(cx, cy, cz), m.shard_count) == m.shard_rank) return -1;
+  if (m.ghost.keys != nullptr) {
+    const int g = dir_find(m.ghost, cx, cy, cz);
+    if (g >= 0) return g;
+    if (g == plvs::tsdf::kGhostAbsent) return -1;
+  }
+  unsigned long long key;
+  if (!plvs::tsdf::pack_block(cx, cy, cz, &key)) return -1;
+  uint32_t hsh = plvs::tsdf::dir_hash(cx, cy, cz, m.miss_mask);
+  for (uint32_t probe = 0; probe <= m.miss_mask; ++probe) {
+    unsigned long long cur = m.miss_keys[hsh];
+    if (cur == key) break;
+    if (cur == plvs::tsdf::kEmptyKey) {
+      cur = atomicCAS(&m.miss_keys[hsh], plvs::tsdf::kEmptyKey, key);
+      if (cur == plvs::tsdf::kEmptyKey) {
+        const uint32_t at = atomicAdd(m.miss_count, 1u);
+        if (at < m.miss_cap) {
+          m.miss_ids[3 * at] = cx;
+          m.miss_ids[3 * at + 1] = cy;
+          m.miss_ids[3 * at + 2] = cz;
+        }
+        break;
+      }
+      if (cur == key) break;
+    }
+    hsh = (hsh + 1) & m.miss_mask;
+  }
+  return -1;
+}
+
 struct Cube {
   float sdf[8];
   uint32_t kfid;
@@ -102,7 +138,7 @@ __device__ __forceinline__ void load_cube(const ChiselMapView& m, int slot, int 
       for (int j = 1; j < 8; ++j)
         if (j == which) cached = nslot[j];
       if (cached == -2) {
-        cached = dir_find(m.dir, cx + ox, cy + oy, cz + oz);
+        cached = find_chunk(m, cx + ox, cy + oy, cz + oz);
 #pragma unroll
         for (int j = 1; j < 8; ++j)
           if (j == which) nslot[j] = cached;
@@ -248,7 +284,7 @@ __global__ __launch_bounds__(kMeshThreads) void mesh_emit(ChiselMapView m, const
 __device__ __forceinline__ long voxel_at(const ChiselMapView& m, float px, float py, float pz, float rounding,
                                          float inv) {
   const int cx = (int)floorf(px * rounding), cy = (int)floorf(py * rounding), cz = (int)floorf(pz * rounding);
-  const int slot = dir_find(m.dir, cx, cy, cz);
+  const int slot = find_chunk(m, cx, cy, cz);
   if (slot < 0) return -1;
   const float res = m.resolution;
   const int vx = (int)floorf((px - (float)(16 * cx) * res) * inv);
@@ -299,7 +335,7 @@ __global__ __launch_bounds__(kMeshThreads) void mesh_shade(ChiselMapView m, uint
     if (!all) {
       // chunk->GetColorAt(colorPos), Chunk.cpp:137-155
       const int cx = (int)floorf(x * rounding), cy = (int)floorf(y * rounding), cz = (int)floorf(z * rounding);
-      const int slot = dir_find(m.dir, cx, cy, cz);
+      const int slot = find_chunk(m, cx, cy, cz);
       if (slot >= 0) {
         const float ox = (float)(16 * cx) * res, oy = (float)(16 * cy) * res, oz = (float)(16 * cz) * res;
         const float size = 16.0f * res;
@@ -393,23 +429,24 @@ struct MeshScratch {
 
 }  // namespace
 
-extern "C" int plvs_hip_tsdf_chisel_mesh_chunks(plvs_tsdf_chisel* h, const int32_t* chunk_ids_xyz, int nchunks,
-                                                float* vertices, float* normals, float* colors, uint32_t* kfids,
-                                                int capacity, int32_t* chunk_first, int* nvertices) {
+// probe: run every stage on the device and report only how many foreign chunks were missed (no host outputs, no
+// capacity limit) — what settles the halo of a sharded map before the sizing and the filling call.
+static int mesh_run(plvs_tsdf_chisel* h, const int32_t* chunk_ids_xyz, int nchunks, float* vertices, float* normals,
+                    float* colors, uint32_t* kfids, int capacity, int32_t* chunk_first, int* nvertices, bool probe,
+                    uint32_t* missing_out) {
   PLVS_REQUIRE(h != nullptr && nvertices != nullptr, "null handle / nvertices");
   PLVS_REQUIRE(nchunks >= 0 && capacity >= 0, "negative size");
   *nvertices = 0;
   if (chunk_first != nullptr)
     for (int c = 0; c <= nchunks; ++c) chunk_first[c] = 0;
-  if (nchunks == 0) return PLVS_OK;
-  PLVS_REQUIRE(chunk_ids_xyz != nullptr && chunk_first != nullptr, "null chunk list / chunk_first");
-  PLVS_REQUIRE(nchunks <= (1 << 18), "too many chunks in one call");
   ChiselMapView m;
-  if (!plvs::tsdf::chisel_map_view(h, &m)) {
+  if (!plvs::tsdf::chisel_map_view(h, &m)) {   // (also empties the miss set of a sharded map)
     plvs::set_error("mesh_chunks: the map handle is unusable");
     return PLVS_ERR_INVALID_ARG;
   }
-  PLVS_REQUIRE(m.shard_count <= 1, "meshing needs the whole map on one device (neighbour chunks of other shards are missing)");
+  if (nchunks == 0) return PLVS_OK;
+  PLVS_REQUIRE(chunk_ids_xyz != nullptr && chunk_first != nullptr, "null chunk list / chunk_first");
+  PLVS_REQUIRE(nchunks <= (1 << 18), "too many chunks in one call");
 
   if (*m.ext == nullptr) {
     *m.ext = new MeshScratch();
@@ -429,21 +466,27 @@ extern "C" int plvs_hip_tsdf_chisel_mesh_chunks(plvs_tsdf_chisel* h, const int32
   mesh_count<<<plvs::ceil_div(nvox, kMeshThreads), kMeshThreads, 0, s>>>(m, sc.ids.p, sc.slots.p, nchunks, sc.counts.p);
   PLVS_KERNEL_CHECK();
   PLVS_HIP_TRY(plvs::exclusive_scan_u32(sc.counts.p, sc.first.p, nvox, sc.total.p, sc.scan.p, s));
-  uint32_t total = 0;
+  uint32_t total = 0, missing = 0;
   std::vector<uint32_t> firsts((size_t)nchunks);
   PLVS_HIP_TRY(hipMemcpyAsync(&total, sc.total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  if (m.miss_count != nullptr) PLVS_HIP_TRY(hipMemcpyAsync(&missing, m.miss_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   PLVS_HIP_TRY(hipMemcpy2DAsync(firsts.data(), sizeof(uint32_t), sc.first.p, sizeof(uint32_t) * kChunkVox, sizeof(uint32_t),
                                 (size_t)nchunks, hipMemcpyDeviceToHost, s));
   PLVS_HIP_TRY(hipStreamSynchronize(s));
   *nvertices = (int)total;
   for (int c = 0; c < nchunks; ++c) chunk_first[c] = (int32_t)firsts[(size_t)c];
   chunk_first[nchunks] = (int32_t)total;
-  if (total > (uint32_t)capacity) {
+  if (missing_out != nullptr) *missing_out = missing;
+  if (missing > 0) {
+    plvs::set_error("mesh_chunks: %u chunks of other ranks are needed (plvs_hip_tsdf_chisel_halo_missing lists them)", missing);
+    return PLVS_ERR_HALO;
+  }
+  if (!probe && total > (uint32_t)capacity) {
     plvs::set_error("mesh_chunks: %u vertices exceed the capacity %d (call again with room for *nvertices)", total, capacity);
     return PLVS_ERR_CAPACITY;
   }
   if (total == 0) return PLVS_OK;
-  PLVS_REQUIRE(vertices && normals && colors && kfids, "null output array");
+  PLVS_REQUIRE(probe || (vertices && normals && colors && kfids), "null output array");
   PLVS_HIP_TRY(sc.vertices.reserve(3 * (size_t)total));
   PLVS_HIP_TRY(sc.normals.reserve(3 * (size_t)total));
   PLVS_HIP_TRY(sc.colors.reserve(3 * (size_t)total));
@@ -453,10 +496,37 @@ extern "C" int plvs_hip_tsdf_chisel_mesh_chunks(plvs_tsdf_chisel* h, const int32
   mesh_shade<<<plvs::ceil_div((size_t)total, kMeshThreads), kMeshThreads, 0, s>>>(m, total, sc.vertices.p, sc.normals.p,
                                                                                  sc.colors.p);
   PLVS_KERNEL_CHECK();
-  PLVS_HIP_TRY(hipMemcpyAsync(vertices, sc.vertices.p, sizeof(float) * 3 * (size_t)total, hipMemcpyDeviceToHost, s));
-  PLVS_HIP_TRY(hipMemcpyAsync(normals, sc.normals.p, sizeof(float) * 3 * (size_t)total, hipMemcpyDeviceToHost, s));
-  PLVS_HIP_TRY(hipMemcpyAsync(colors, sc.colors.p, sizeof(float) * 3 * (size_t)total, hipMemcpyDeviceToHost, s));
-  PLVS_HIP_TRY(hipMemcpyAsync(kfids, sc.kfids.p, sizeof(uint32_t) * (size_t)total, hipMemcpyDeviceToHost, s));
+  if (!probe) {
+    PLVS_HIP_TRY(hipMemcpyAsync(vertices, sc.vertices.p, sizeof(float) * 3 * (size_t)total, hipMemcpyDeviceToHost, s));
+    PLVS_HIP_TRY(hipMemcpyAsync(normals, sc.normals.p, sizeof(float) * 3 * (size_t)total, hipMemcpyDeviceToHost, s));
+    PLVS_HIP_TRY(hipMemcpyAsync(colors, sc.colors.p, sizeof(float) * 3 * (size_t)total, hipMemcpyDeviceToHost, s));
+    PLVS_HIP_TRY(hipMemcpyAsync(kfids, sc.kfids.p, sizeof(uint32_t) * (size_t)total, hipMemcpyDeviceToHost, s));
+  }
+  if (m.miss_count != nullptr) PLVS_HIP_TRY(hipMemcpyAsync(&missing, m.miss_count, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   PLVS_HIP_TRY(hipStreamSynchronize(s));
+  if (missing_out != nullptr) *missing_out = missing;
+  if (missing > 0) {   // the colour / gradient look-ups of the new vertices reached chunks that are not here yet
+    plvs::set_error("mesh_chunks: %u chunks of other ranks are needed (plvs_hip_tsdf_chisel_halo_missing lists them)", missing);
+    return PLVS_ERR_HALO;
+  }
   return PLVS_OK;
+}
+
+extern "C" int plvs_hip_tsdf_chisel_mesh_chunks(plvs_tsdf_chisel* h, const int32_t* chunk_ids_xyz, int nchunks,
+                                                float* vertices, float* normals, float* colors, uint32_t* kfids,
+                                                int capacity, int32_t* chunk_first, int* nvertices) {
+  return mesh_run(h, chunk_ids_xyz, nchunks, vertices, normals, colors, kfids, capacity, chunk_first, nvertices, false,
+                  nullptr);
+}
+
+extern "C" int plvs_hip_tsdf_chisel_mesh_probe(plvs_tsdf_chisel* h, const int32_t* chunk_ids_xyz, int nchunks,
+                                               int* nmissing) {
+  PLVS_REQUIRE(nmissing != nullptr, "null nmissing");
+  *nmissing = 0;
+  std::vector<int32_t> first((size_t)(nchunks > 0 ? nchunks : 0) + 1);
+  int nv = 0;
+  uint32_t missing = 0;
+  const int rc = mesh_run(h, chunk_ids_xyz, nchunks, nullptr, nullptr, nullptr, nullptr, 0, first.data(), &nv, true, &missing);
+  *nmissing = (int)missing;
+  return rc == PLVS_ERR_HALO ? PLVS_OK : rc;
 }

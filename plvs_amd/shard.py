@@ -102,6 +102,77 @@ def sharded_integrate(tsdf, d_xyz, d_rgb, d_kfid, offsets, d_Twc, group=None):
     return counts
 
 
+def _all_to_all_rows(send, send_counts, group):
+    """send [sum, w] grouped by destination rank, send_counts [world] -> (recv grouped by source, recv_counts)."""
+    world = dist.get_world_size(group)
+    sc = torch.tensor([int(c) for c in send_counts], dtype=torch.int64, device=send.device)
+    rc = torch.zeros_like(sc)
+    dist.all_to_all_single(rc, sc, group=group)
+    rcl = [int(c) for c in rc.cpu()]
+    recv = torch.zeros((sum(rcl),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+    dist.all_to_all_single(recv, send, output_split_sizes=rcl, input_split_sizes=[int(c) for c in send_counts], group=group)
+    assert len(rcl) == world
+    return recv, rcl
+
+
+def halo_round(tsdf, missing, world, rank, exchange):
+    """One round of the meshing halo: route the chunk ids this rank misses to their owners, let the owners pack the
+    chunks (TsdfChisel.halo_export), bring the answers home (halo_import).  `exchange(send, send_counts) -> (recv,
+    recv_counts)` is the all-to-all (torch.distributed here, tensor slices in the single-device tests)."""
+    dev = getattr(tsdf, "device", None) or torch.device("cuda", torch.cuda.current_device())
+    own = owner_of(missing, world) if len(missing) else np.zeros(0, np.int64)
+    assert not (own == rank).any()
+    order = np.argsort(own, kind="stable")
+    req = torch.from_numpy(np.ascontiguousarray(missing[order], np.int32)).to(dev).reshape(-1, 3)
+    req_counts = [int((own == q).sum()) for q in range(world)]
+    got, got_counts = exchange(req, req_counts)                       # the ids other ranks ask this one for
+    found = torch.zeros((got.shape[0],), dtype=torch.int32, device=dev)
+    tsdf.halo_lookup(got.contiguous(), found)
+    back_found, back_counts = exchange(found.reshape(-1, 1), got_counts)   # answers travel the reverse way, same grouping
+    assert back_counts == req_counts
+    back_found = back_found.reshape(-1).contiguous()
+    # one payload row per chunk that exists: the owner's rows are in request order, so a requester's rows are a slice
+    fh, bh = found.cpu().numpy(), back_found.cpu().numpy()
+    send_rows = [int(x.sum()) for x in np.split(fh, np.cumsum(got_counts)[:-1])]
+    payload = torch.empty((int(fh.sum()), tsdf.HALO_WORDS), dtype=torch.int32, device=dev)
+    tsdf.halo_export(got.contiguous(), found, payload)
+    back_payload, recv_rows = exchange(payload, send_rows)
+    assert recv_rows == [int(x.sum()) for x in np.split(bh, np.cumsum(req_counts)[:-1])]
+    tsdf.halo_import(req, back_found, back_payload.contiguous())
+    return int(bh.sum())
+
+
+def gather_mesh_halo(tsdf, chunk_ids, group=None, max_rounds=8):
+    """Brings in the chunks of other ranks that meshing THIS rank's `chunk_ids` reads (cube faces, colour
+    interpolation, gradient normals): probe, fetch what the pass reached for, probe again — until no rank misses
+    anything.  Collective: every rank calls it with its own list (possibly empty).  -> chunks fetched.
+    (plvs_hip_tsdf_chisel_halo_gather is the same loop behind the C ABI over an ncclComm_t.)"""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = getattr(tsdf, "device", None) or torch.device("cuda", torch.cuda.current_device())
+    fetched = 0
+    settled = False                          # (a rank that is done keeps serving the others' requests)
+    for _ in range(max_rounds):
+        missing = np.zeros((0, 3), np.int32)
+        if not settled:
+            if tsdf.mesh_probe(chunk_ids) > 0:
+                missing = tsdf.halo_missing()
+            else:
+                settled = True
+        flag = torch.tensor([len(missing)], dtype=torch.int64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if int(flag.item()) == 0:
+            return fetched
+        fetched += halo_round(tsdf, missing, world, rank, lambda send, counts: _all_to_all_rows(send, counts, group))
+    raise RuntimeError("gather_mesh_halo: the halo did not settle")
+
+
+def sharded_mesh_chunks(tsdf, chunk_ids, group=None):
+    """ChunkManager::RecomputeMesh of THIS rank's chunks in `chunk_ids` on a sharded map: the single-device mesh of
+    each chunk, byte for byte.  Every rank calls it.  -> (TsdfChisel.mesh_chunks dict, chunks fetched)."""
+    fetched = gather_mesh_halo(tsdf, chunk_ids, group)
+    return tsdf.mesh_chunks(chunk_ids), fetched
+
+
 class BlockDirectory:
     """plvs_block_directory (include/plvs_hip.h): the global block id -> owner rank table a rank keeps from the
     gathered lists.  Imports the HIP library on first use (this module itself needs numpy + torch only)."""

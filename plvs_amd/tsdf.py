@@ -71,10 +71,11 @@ class TsdfChisel:
                      _lib.np_ptr(Twc), carving_dist, ctypes.byref(n)))
         return n.value
 
-    def mesh_chunks(self, chunk_ids):
+    def mesh_chunks(self, chunk_ids, halo_ok=False):
         """ChunkManager::RecomputeMesh for every chunk id of the list ([n,3] ints, e.g. the 27-neighbourhood of
         updated_chunk_ids() = Chisel's meshesToUpdate).  -> dict(vertices, normals, colors [m,3] f32, kfids [m] u32,
-        chunk_first [n+1]): chunk c owns rows chunk_first[c]:chunk_first[c+1]."""
+        chunk_first [n+1]): chunk c owns rows chunk_first[c]:chunk_first[c+1].  Sharded map: None (with halo_ok) when
+        chunks of other ranks are needed first — halo_missing() lists them (plvs_amd.shard.sharded_mesh_chunks)."""
         ids = np.ascontiguousarray(chunk_ids, dtype=np.int32).reshape(-1, 3)
         first = np.zeros(ids.shape[0] + 1, np.int32)
         n = ctypes.c_int()
@@ -91,9 +92,70 @@ class TsdfChisel:
             if rc == _lib.PLVS_ERR_CAPACITY and n.value > cap:
                 cap = n.value            # first call sizes the mesh, second call fills it
                 continue
+            if rc == _lib.PLVS_ERR_HALO and halo_ok:
+                return None
             _lib.check(rc)
             m = n.value
             return dict(vertices=v[:m], normals=nr[:m], colors=c[:m], kfids=k[:m], chunk_first=first)
+
+    # ---- halo of a sharded map, for meshing (include/plvs_hip.h: plvs_hip_tsdf_chisel_halo_*)
+    HALO_WORDS = 4 * 4096     # a chunk on the wire: sdf, weight, kfid, rgbw planes
+
+    def mesh_probe(self, chunk_ids):
+        """The stages of mesh_chunks on the device only -> the number of foreign chunks the list's meshes reach for and
+        this rank does not hold (halo_missing() lists them); 0: mesh_chunks will succeed."""
+        ids = np.ascontiguousarray(chunk_ids, dtype=np.int32).reshape(-1, 3)
+        f = _lib.lib.plvs_hip_tsdf_chisel_mesh_probe
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        n = ctypes.c_int()
+        _lib.check(f(self._h, _lib.np_ptr(ids), ids.shape[0], ctypes.byref(n)))
+        return n.value
+
+    def halo_gather(self, comm, chunk_ids):
+        """The whole halo exchange behind the C ABI over an ncclComm_t (collective) -> chunks imported."""
+        ids = np.ascontiguousarray(chunk_ids, dtype=np.int32).reshape(-1, 3)
+        f = _lib.lib.plvs_hip_tsdf_chisel_halo_gather
+        f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        n = ctypes.c_int()
+        _lib.check(f(self._h, comm, _lib.np_ptr(ids), ids.shape[0], ctypes.byref(n), _lib.current_stream_ptr()))
+        return n.value
+
+    def halo_missing(self):
+        """[k,3] int32: the chunks of other ranks the last mesh_chunks call looked for and did not hold."""
+        f = _lib.lib.plvs_hip_tsdf_chisel_halo_missing
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        n = ctypes.c_int()
+        rc = f(self._h, None, 0, ctypes.byref(n))
+        if rc != _lib.PLVS_ERR_CAPACITY:
+            _lib.check(rc)
+        ids = np.zeros((max(n.value, 1), 3), np.int32)
+        if n.value:
+            _lib.check(f(self._h, _lib.np_ptr(ids), n.value, ctypes.byref(n)))
+        return ids[:n.value]
+
+    def halo_lookup(self, d_ids, d_found):
+        """Owner side: d_ids [n,3] int32 (cuda) -> d_found [n] int32 (1: this rank has the chunk)."""
+        f = _lib.lib.plvs_hip_tsdf_chisel_halo_lookup
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        _lib.check(f(self._h, _lib.t_ptr(d_ids), int(d_ids.shape[0]), _lib.t_ptr(d_found), _lib.current_stream_ptr()))
+
+    def halo_export(self, d_ids, d_found, d_payload):
+        """Owner side: the found chunks, one row of HALO_WORDS int32 each, in request order -> d_payload [nfound, ...]."""
+        f = _lib.lib.plvs_hip_tsdf_chisel_halo_export
+        f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        _lib.check(f(self._h, _lib.t_ptr(d_ids), _lib.t_ptr(d_found), int(d_ids.shape[0]), _lib.t_ptr(d_payload),
+                     _lib.current_stream_ptr()))
+
+    def halo_import(self, d_ids, d_found, d_payload):
+        """Requester side: the ids asked for, the owners' found flags, the payload rows of the found ones."""
+        f = _lib.lib.plvs_hip_tsdf_chisel_halo_import
+        f.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        _lib.check(f(self._h, _lib.t_ptr(d_ids), _lib.t_ptr(d_found), _lib.t_ptr(d_payload), int(d_ids.shape[0]),
+                     int(d_payload.shape[0]), _lib.current_stream_ptr()))
+
+    def halo_clear(self):
+        _lib.lib.plvs_hip_tsdf_chisel_halo_clear.argtypes = [ctypes.c_void_p]
+        _lib.check(_lib.lib.plvs_hip_tsdf_chisel_halo_clear(self._h))
 
     def integrate_batch_dev(self, d_xyz, d_rgb, d_kfid, offsets, d_Twc):
         """Device flavour: concatenated clouds resident in HBM (torch tensors),

@@ -147,3 +147,140 @@ def test_gloo_segment_exchange_of_the_ray_sharded_integrate(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert out == [(r, True) for r in range(world)]
+
+
+class _FakeShard:
+    """Stands in for a rank's TsdfChisel in the meshing-halo protocol (CPU tensors): the map is a line of chunks
+    (i, 0, 0), i < n, hash-sharded like the real one; "meshing" chunk i needs chunk i + 1, and — once that one is
+    here and its payload is odd — chunk i + 2 as well (new vertices reaching further: a second round).  Chunks past
+    the end of the line do not exist anywhere."""
+    HALO_WORDS = 8
+    device = torch.device("cpu")
+
+    def __init__(self, rank, world, n, owner_of):
+        self.rank, self.world, self.n = rank, world, n
+        ids = np.array([[i, 0, 0] for i in range(n)], np.int32)
+        self.owner = {i: int(o) for i, o in enumerate(owner_of(ids, world))}
+        self.own = {i: self.payload_of(i) for i in range(n) if self.owner[i] == rank}
+        self.ghost, self.absent, self.missing = {}, set(), []
+
+    @staticmethod
+    def payload_of(i):
+        return [(i * 7 + 3) % 11] + [i] * 7
+
+    def _get(self, i, miss):
+        if i in self.own:
+            return self.own[i]
+        if i in self.ghost:
+            return self.ghost[i]
+        owner = self.owner.get(i)
+        if owner is None:                 # beyond the line: owned by nobody this rank knows; ask the hash owner
+            if i in self.absent:
+                return None
+            miss.add(i)
+            return None
+        if owner == self.rank or i in self.absent:
+            return None
+        miss.add(i)
+        return None
+
+    def mesh_chunks(self, chunk_ids, halo_ok=False):
+        miss, out = set(), {}
+        for c in chunk_ids:
+            i = int(c[0])
+            if i not in self.own:
+                continue
+            acc = list(self.own[i])
+            nb = self._get(i + 1, miss)
+            if nb is not None:
+                acc.append(nb[0])
+                if nb[0] % 2 == 1:
+                    nb2 = self._get(i + 2, miss)
+                    if nb2 is not None:
+                        acc.append(nb2[0])
+            out[i] = acc
+        self.missing = sorted(miss)
+        return None if self.missing else out
+
+    def mesh_probe(self, chunk_ids):
+        self.mesh_chunks(chunk_ids)
+        return len(self.missing)
+
+    def halo_missing(self):
+        return np.array([[i, 0, 0] for i in self.missing], np.int32).reshape(-1, 3)
+
+    def halo_lookup(self, d_ids, found):
+        for k, c in enumerate(d_ids.tolist()):
+            found[k] = 1 if c[0] in self.own else 0
+
+    def halo_export(self, d_ids, found, payload):
+        row = 0
+        for k, c in enumerate(d_ids.tolist()):
+            if int(found[k]):
+                payload[row] = torch.tensor(self.own[c[0]], dtype=torch.int32)
+                row += 1
+        assert row == payload.shape[0]
+
+    def halo_import(self, d_ids, found, payload):
+        row = 0
+        for k, c in enumerate(d_ids.tolist()):
+            if int(found[k]):
+                self.ghost[c[0]] = payload[row].tolist()
+                row += 1
+            else:
+                self.absent.add(c[0])
+        assert row == payload.shape[0]
+
+
+def _worker_halo(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("plvs_amd_shard", os.path.join(ROOT, "plvs_amd", "shard.py"))
+    shard_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shard_mod)
+    n = 23
+    fake = _FakeShard(rank, world, n, shard_mod.owner_of)
+    fake.owner[n] = int(shard_mod.owner_of(np.array([[n, 0, 0]]), world)[0])        # ids past the end: asked of the
+    fake.owner[n + 1] = int(shard_mod.owner_of(np.array([[n + 1, 0, 0]]), world)[0])  # rank the hash names, "absent"
+    mine = np.array([[i, 0, 0] for i in sorted(fake.own)], np.int32).reshape(-1, 3)
+    got, fetched = shard_mod.sharded_mesh_chunks(fake, mine)
+    q.put((rank, got, fetched, sorted(fake.ghost), sorted(fake.absent)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_meshing_halo_rounds(world):
+    """plvs_amd.shard.sharded_mesh_chunks / halo_round over gloo with a stand-in map: requests reach the owners,
+    answers (found and not found) come back to the asker in the asker's order, a second round fetches what the first
+    round's chunks made reachable, ranks that are done keep serving, and the result equals the unsharded one."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_halo, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = 23
+    pay = _FakeShard.payload_of
+    want = {}
+    for i in range(n):
+        acc = list(pay(i))
+        if i + 1 < n:
+            acc.append(pay(i + 1)[0])
+            if pay(i + 1)[0] % 2 == 1 and i + 2 < n:
+                acc.append(pay(i + 2)[0])
+        want[i] = acc
+    merged = {}
+    for rank, got, fetched, ghosts, absent in out:
+        assert not (set(got) & set(merged))
+        merged.update(got)
+        assert fetched == len(ghosts)
+    assert merged == want
+    assert any(o[2] > 0 for o in out) and any(o[4] for o in out), "chunks were fetched, and some were reported absent"

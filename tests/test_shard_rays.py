@@ -182,6 +182,16 @@ def test_hip_ray_sharded_integrate_through_torch_distributed_and_rccl_at_world_o
                 for x, y in zip(single.get_chunk(*cid), other.get_chunk(*cid)):
                     assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x,
                                           y.view(np.uint32) if y.dtype == np.float32 else y)
+        # meshing through the same two transports (one rank: nothing is foreign, the collectives still run)
+        from plvs_amd.shard import sharded_mesh_chunks
+        todo = np.array(ids, np.int32)
+        want = single.mesh_chunks(todo)
+        got, fetched = sharded_mesh_chunks(via_torch, todo)
+        assert fetched == 0 and via_rccl.halo_gather(comm, todo) == 0
+        got2 = via_rccl.mesh_chunks(todo)
+        for name in ("vertices", "normals", "colors", "kfids", "chunk_first"):
+            assert want[name].tobytes() == got[name].tobytes() == got2[name].tobytes(), name
+        assert len(want["vertices"]) > 5000
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)
@@ -223,4 +233,107 @@ def test_hip_order_free_apply_in_parts_gives_the_same_map():
                 assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x,
                                       y.view(np.uint32) if y.dtype == np.float32 else y), cid
     for t in ranks + [plain, parts]:
+        t.close()
+
+
+def _nbhd27(ids):
+    s = set()
+    for c in ids:
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dz in (-1, 0, 1):
+                    s.add((int(c[0]) + dx, int(c[1]) + dy, int(c[2]) + dz))
+    return sorted(s)
+
+
+def virtual_halo_round(ranks, missing):
+    """The meshing halo between virtual ranks: every rank's missing ids go to their owners' halo_export, the answers
+    into the asker's halo_import (what plvs_amd.shard.halo_round does over a process group).  -> chunks moved."""
+    world, moved = len(ranks), 0
+    for r, t in enumerate(ranks):
+        if not len(missing[r]):
+            continue
+        own = owner_of(missing[r], world)
+        assert not (own == r).any(), "a rank never misses a chunk of its own"
+        for q in range(world):
+            ids = np.ascontiguousarray(missing[r][own == q], np.int32)
+            if not len(ids):
+                continue
+            d_ids = torch.from_numpy(ids).cuda()
+            found = torch.zeros(len(ids), dtype=torch.int32, device="cuda")
+            ranks[q].halo_lookup(d_ids, found)
+            nfound = int(found.sum().item())
+            payload = torch.empty((nfound, t.HALO_WORDS), dtype=torch.int32, device="cuda")
+            ranks[q].halo_export(d_ids, found, payload)
+            t.halo_import(d_ids, found, payload)
+            moved += nfound
+    torch.cuda.synchronize()
+    return moved
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 5])
+def test_hip_sharded_meshes_equal_the_single_device_meshes(world):
+    """Meshing a sharded map: each rank meshes ITS chunks of meshesToUpdate, fetching the neighbour chunks the cubes,
+    the colour interpolation and the gradient normals read from their owners, in rounds, until nobody misses
+    anything.  Every chunk's mesh must be the single-device one byte for byte; the halo goes away with the next
+    integrate call and leaves the pool as it was."""
+    from plvs_amd.tsdf import TsdfChisel
+    kfs = make_keyframes(7, max_depth=5.0, seed=3)
+    single = TsdfChisel(0.05, max_chunks=4096, order_free=True)
+    ranks = [TsdfChisel(0.05, max_chunks=4096, shard_rank=r, shard_count=world, order_free=True) for r in range(world)]
+    for phase, (b0, b1) in enumerate(((0, 5), (5, 7))):
+        xyz, rgb, kfid, offsets, Twc = _batch(kfs[b0:b1])
+        single.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
+        sharded_step(ranks, xyz, rgb, kfid, offsets, Twc)
+        updated = [tuple(int(v) for v in c) for t in ranks for c in t.updated_chunk_ids()]
+        assert sorted(updated) == sorted(tuple(int(v) for v in c) for c in single.updated_chunk_ids())
+        todo = np.array(_nbhd27(updated), np.int32)                       # Chisel::meshesToUpdate
+        own = owner_of(todo, world)
+        mine = [np.ascontiguousarray(todo[own == r]) for r in range(world)]
+        before = [t.num_chunks() for t in ranks]
+        rounds, moved = 0, 0
+        assert ranks[0].mesh_chunks(mine[0], halo_ok=True) is None, "the first pass reaches for other ranks' chunks"
+        while True:
+            missing = [t.halo_missing() if t.mesh_probe(mine[r]) else np.zeros((0, 3), np.int32) for r, t in enumerate(ranks)]
+            if not any(len(m) for m in missing):
+                break
+            rounds += 1
+            assert rounds <= 4, "the halo settles in a few rounds"
+            moved += virtual_halo_round(ranks, missing)
+        assert rounds >= 1 and moved > 0
+        result = [t.mesh_chunks(mine[r]) for r, t in enumerate(ranks)]
+        want = single.mesh_chunks(todo)
+        wf = want["chunk_first"]
+        pos = {tuple(int(v) for v in c): i for i, c in enumerate(todo)}
+        total = 0
+        for r in range(world):
+            gf = result[r]["chunk_first"]
+            for j, c in enumerate(mine[r]):
+                i = pos[tuple(int(v) for v in c)]
+                a, b, a2, b2 = int(wf[i]), int(wf[i + 1]), int(gf[j]), int(gf[j + 1])
+                assert b - a == b2 - a2, (c, b - a, b2 - a2)
+                for name in ("vertices", "normals", "colors", "kfids"):
+                    assert want[name][a:b].tobytes() == result[r][name][a2:b2].tobytes(), (name, c)
+                total += b - a
+        assert total == len(want["vertices"]) > 8000
+        # a rank asked for another rank's chunk owns nothing for it
+        foreign = np.ascontiguousarray(todo[own == 1][:3])
+        m0 = ranks[0].mesh_chunks(foreign, halo_ok=True)
+        assert m0 is not None and len(m0["vertices"]) == 0
+        assert [t.num_chunks() for t in ranks] == before, "ghosts are not chunks of the map"
+        if phase == 0:
+            continue            # the next integrate call drops the halo and re-uses its pool slots
+        for t in ranks:
+            t.halo_clear()
+    # after the halo is gone the shards still hold exactly the single-device map
+    ids = {tuple(x) for x in single.chunk_ids()}
+    for t in ranks:
+        for cid in (tuple(x) for x in t.chunk_ids()):
+            a, b = single.get_chunk(*cid), t.get_chunk(*cid)
+            assert all(np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x,
+                                      y.view(np.uint32) if y.dtype == np.float32 else y) for x, y in zip(a, b)), cid
+            ids.discard(cid)
+    assert not ids
+    for t in ranks + [single]:
         t.close()
