@@ -454,6 +454,19 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
                                              const int32_t* offsets, int nclouds,
                                              const float* d_Twc, void* stream);
 
+/* A cloud WITH NORMALS, as PointCloudMapChisel::LoadMap feeds the saved map through
+ * (src/PointCloudMapChisel.cc:527-546 -> ChiselServer::IntegrateWorldPointCloud, ChiselServer.cpp:587-615, Twc =
+ * identity there -> Chisel::IntegrateWorldPointCloudWithNormals, Chisel.cpp:238-376): every point casts the
+ * segment point -/+ 4 voxels along its normal (n x 3 f32, normalised here as there), u = (centre - point) . normal,
+ * truncation 4 * resolution, no depth test, no carving, ColorVoxel::Integrate (not IntegrateSimple).  Runs the
+ * ordered pipeline on any handle (bit-exact); the updated-chunk list is set as by the integrate calls.  Host
+ * pointers and synchronous / device pointers and asynchronous on `stream` as above. */
+int plvs_hip_tsdf_chisel_integrate_world_normals(plvs_tsdf_chisel* h, const float* xyz, const uint8_t* rgb,
+                                                 const uint32_t* kfid, const float* normals, int n, const float* Twc);
+int plvs_hip_tsdf_chisel_integrate_world_normals_dev(plvs_tsdf_chisel* h, const float* d_xyz, const uint8_t* d_rgb,
+                                                     const uint32_t* d_kfid, const float* d_normals, int n,
+                                                     const float* d_Twc, void* stream);
+
 /* Counters of the last integrate call: voxel read-modify-write visits applied
  * (the "Mvoxels" unit of the metric), points consumed, chunks newly created,
  * chunks updated, distinct voxels updated, longest per-voxel update run. */

@@ -489,6 +489,25 @@ class PointCloudMapChisel {
     }
     return (int)pointCloud_.size();
   }
+  // LoadMap once PointCloudMap::LoadMap has read the saved cloud (src/PointCloudMapChisel.cc:527-546):
+  // ChiselServer::IntegrateWorldPointCloud(cloud, identity) — every point along its normal
+  // (Chisel::IntegrateWorldPointCloudWithNormals) — then UpdateMap.
+  int LoadMap(const std::vector<PointSurfelSegment>& cloud) {
+    const size_t n = cloud.size();
+    xyz_.resize(3 * n); rgb_.resize(3 * n); kfid_.resize(n);
+    std::vector<float> nrm(3 * n);
+    for (size_t i = 0; i < n; ++i) {
+      const PointSurfelSegment& p = cloud[i];
+      xyz_[3 * i] = p.x; xyz_[3 * i + 1] = p.y; xyz_[3 * i + 2] = p.z;
+      rgb_[3 * i] = p.r; rgb_[3 * i + 1] = p.g; rgb_[3 * i + 2] = p.b;
+      nrm[3 * i] = p.normal_x; nrm[3 * i + 1] = p.normal_y; nrm[3 * i + 2] = p.normal_z;
+      kfid_[i] = p.kfid;
+    }
+    const float identity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    check(plvs_hip_tsdf_chisel_integrate_world_normals(h_, xyz_.data(), rgb_.data(), kfid_.data(), nrm.data(), (int)n, identity));
+    MarkUpdated();
+    return UpdateMap();
+  }
   void Clear() {
     check(plvs_hip_tsdf_chisel_clear(h_));
     meshesToUpdate_.clear();

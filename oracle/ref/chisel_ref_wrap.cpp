@@ -76,6 +76,20 @@ void ref_chisel_colour_integrate_simple(uint8_t* rgbw, uint8_t r, uint8_t g, uin
   rgbw[3] = v.GetWeight();
 }
 
+// ColorVoxel::Integrate (the flavour IntegrateWorldPointCloudWithNormals calls) on a voxel holding rgbw[0..3].
+void ref_chisel_colour_integrate(uint8_t* rgbw, uint8_t r, uint8_t g, uint8_t b, uint8_t weight_update) {
+  chisel::ColorVoxel v;
+  v.SetRed(rgbw[0]);
+  v.SetGreen(rgbw[1]);
+  v.SetBlue(rgbw[2]);
+  v.SetWeight(rgbw[3]);
+  v.Integrate(r, g, b, weight_update);
+  rgbw[0] = v.GetRed();
+  rgbw[1] = v.GetGreen();
+  rgbw[2] = v.GetBlue();
+  rgbw[3] = v.GetWeight();
+}
+
 float ref_chisel_truncation(float quadratic, float linear, float constant, float scale, float reading) {
   return chisel::QuadraticTruncator(quadratic, linear, constant, scale).GetTruncationDistance(reading);
 }

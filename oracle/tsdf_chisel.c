@@ -221,6 +221,7 @@ typedef struct {
   oracle_chisel* o;
   const float* Ri; const float* ti; /* inverse pose */
   float depth, truncation;
+  const float* wp; const float* dir; /* non-null: the normals flavour (world point, unit normal) */
   uint8_t r, g, b;
   uint32_t kfid;
   chunk_t* last; /* small lookup cache, no semantic effect */
@@ -243,6 +244,24 @@ static uint32_t colour_integrate_simple(uint32_t p, uint8_t r, uint8_t g, uint8_
   red = (uint8_t)((float)(cw * red + wu * r) * inv);
   green = (uint8_t)((float)(cw * green + wu * g) * inv);
   blue = (uint8_t)((float)(cw * blue + wu * b) * inv);
+  cw = (uint8_t)(cw + wu);
+  return (uint32_t)red | ((uint32_t)green << 8) | ((uint32_t)blue << 16) | ((uint32_t)cw << 24);
+}
+
+/* ColorVoxel::Integrate (ColorVoxel.h:68-89): the flavour IntegrateWorldPointCloudWithNormals calls — a true
+ * division and Saturate where IntegrateSimple multiplies by a rounded reciprocal. */
+static uint32_t colour_integrate(uint32_t p, uint8_t r, uint8_t g, uint8_t b, uint8_t wu) {
+  uint8_t red = p & 255, green = (p >> 8) & 255, blue = (p >> 16) & 255, cw = p >> 24;
+  if (cw >= 255 - wu) return p;
+  const float den = (float)(wu + cw);
+  const uint8_t in[3] = {r, g, b};
+  uint8_t* ch[3] = {&red, &green, &blue};
+  for (int k = 0; k < 3; k++) {
+    float v = ((float)cw * (float)*ch[k] + (float)(wu * in[k])) / den;
+    v = v > 0.0f ? v : 0.0f;            /* Saturate: std::min(std::max(value, 0.0f), 255.0f) */
+    v = v < 255.0f ? v : 255.0f;
+    *ch[k] = (uint8_t)v;
+  }
   cw = (uint8_t)(cw + wu);
   return (uint32_t)red | ((uint32_t)green << 8) | ((uint32_t)blue << 16) | ((uint32_t)cw << 24);
 }
@@ -276,10 +295,16 @@ static void visit(void* vctx, int vx, int vy, int vz) {
   const int vid = (lz * 16 + ly) * 16 + lx;
   if (!(vid >= 0 && vid < CHUNK_VOX)) return;
 
-  float cc[3];
-  xform(c->Ri, c->ti, center, cc);                         /* inversePose * center  :525 */
-  const float length = sqrtf(sqnorm3(cc));                 /* :526 */
-  const float u = length * (c->depth / cc[2] - 1);         /* :527 */
+  float u;
+  if (c->dir) {                                            /* IntegrateWorldPointCloudWithNormals, Chisel.cpp:329 */
+    const float d[3] = {center[0] - c->wp[0], center[1] - c->wp[1], center[2] - c->wp[2]};
+    u = d[0] * c->dir[0] + (d[1] * c->dir[1] + d[2] * c->dir[2]);   /* (center - worldPoint).dot(dir) */
+  } else {
+    float cc[3];
+    xform(c->Ri, c->ti, center, cc);                       /* inversePose * center  :525 */
+    const float length = sqrtf(sqnorm3(cc));               /* :526 */
+    u = length * (c->depth / cc[2] - 1);                   /* :527 */
+  }
   const float weight = constant_weight(o->weight, c->truncation);
   if (!(fabs((double)u) < (double)c->truncation)) return;  /* :531 */
 
@@ -295,7 +320,8 @@ static void visit(void* vctx, int vx, int vy, int vz) {
   }
   dist_integrate(&ch->sdf[vid], &ch->weight[vid], u, weight);
   ch->kfid[vid] = c->kfid; /* SetKfid, USE_KFID_INTEGRATION 0 */
-  ch->rgbw[vid] = colour_integrate_simple(ch->rgbw[vid], c->r, c->g, c->b, 1);
+  ch->rgbw[vid] = c->dir ? colour_integrate(ch->rgbw[vid], c->r, c->g, c->b, 1)          /* :338 */
+                         : colour_integrate_simple(ch->rgbw[vid], c->r, c->g, c->b, 1);  /* :536 */
   c->visits++;
 }
 
@@ -343,6 +369,56 @@ void oracle_chisel_integrate(oracle_chisel* o, const float* xyz, const uint8_t* 
     c.depth = depth; c.truncation = truncation;
     /* Conversions.h:118-121 then Chisel.cpp:536 */
     c.r = (uint8_t)(((float)rgb[3 * (size_t)i + 0] * byteToFloat) * 255.0f);
+    c.g = (uint8_t)(((float)rgb[3 * (size_t)i + 1] * byteToFloat) * 255.0f);
+    c.b = (uint8_t)(((float)rgb[3 * (size_t)i + 2] * byteToFloat) * 255.0f);
+    c.kfid = kfid ? kfid[i] : 0;
+    raycast(start, end, visit, &c);
+  }
+  o->last_visits = c.visits;
+  o->last_new = (int32_t)(o->count - before);
+}
+
+/* Chisel::IntegrateWorldPointCloudWithNormals (Chisel.cpp:238-376), what PointCloudMapChisel::LoadMap feeds the
+ * saved map cloud through (src/PointCloudMapChisel.cc:527-546 -> ChiselServer::IntegrateWorldPointCloud,
+ * ChiselServer.cpp:587-615; Twc = identity there): every point casts the segment point -/+ 4 voxels along its
+ * NORMAL, u = (centre - point) . normal, constant truncation 4 * resolution, no depth test, no carving,
+ * ColorVoxel::Integrate.  normals: n x 3.  Restated by reading; ColorVoxel::Integrate is pinned
+ * (tests/test_oracle_pinned.py). */
+void oracle_chisel_integrate_world_normals(oracle_chisel* o, const float* xyz, const uint8_t* rgb, const uint32_t* kfid,
+                                           const float* normals, int n, const float* Twc) {
+  float R[9], t[3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) R[3 * i + j] = Twc[4 * i + j];
+    t[i] = Twc[4 * i + 3];
+  }
+  const float resolution = o->resolution;
+  const float roundToVoxel = 1.0f / resolution;                             /* :244 */
+  const float truncation = 4 * resolution;                                  /* :266 */
+  const float byteToFloat = 1.0f / 255.0f;                                  /* Conversions.h:158 */
+  visit_ctx c;
+  memset(&c, 0, sizeof(c));
+  c.o = o;
+  const size_t before = o->count;
+  for (int i = 0; i < n; i++) {
+    float worldPoint[3];
+    xform(R, t, xyz + 3 * (size_t)i, worldPoint);                           /* :276 */
+    const float* nrm = normals + 3 * (size_t)i;
+    const float z2 = sqnorm3(nrm);
+    float dir[3] = {nrm[0], nrm[1], nrm[2]};
+    if (z2 > 0.0f) {                                                        /* normalized(), :282 */
+      const float l = sqrtf(z2);
+      dir[0] = nrm[0] / l; dir[1] = nrm[1] / l; dir[2] = nrm[2] / l;
+    }
+    float start[3], end[3];
+    for (int k = 0; k < 3; k++) {
+      const float swp = worldPoint[k] * roundToVoxel;                       /* :288 */
+      const float sdt = dir[k] * truncation * roundToVoxel;                 /* :289 */
+      start[k] = swp - sdt;                                                 /* :291 */
+      end[k] = swp + sdt;                                                   /* :293 */
+    }
+    c.truncation = truncation;
+    c.wp = worldPoint; c.dir = dir;
+    c.r = (uint8_t)(((float)rgb[3 * (size_t)i + 0] * byteToFloat) * 255.0f);   /* Conversions.h:177-179, Chisel.cpp:338 */
     c.g = (uint8_t)(((float)rgb[3 * (size_t)i + 1] * byteToFloat) * 255.0f);
     c.b = (uint8_t)(((float)rgb[3 * (size_t)i + 2] * byteToFloat) * 255.0f);
     c.kfid = kfid ? kfid[i] : 0;
@@ -799,6 +875,11 @@ void oracle_chisel_dist_integrate(float* sdf, float* weight, float dist_update, 
 void oracle_chisel_colour_integrate_simple(uint8_t* rgbw, uint8_t r, uint8_t g, uint8_t b, uint8_t weight_update) {
   const uint32_t p = colour_integrate_simple((uint32_t)rgbw[0] | ((uint32_t)rgbw[1] << 8) | ((uint32_t)rgbw[2] << 16) |
                                              ((uint32_t)rgbw[3] << 24), r, g, b, weight_update);
+  rgbw[0] = p & 255; rgbw[1] = (p >> 8) & 255; rgbw[2] = (p >> 16) & 255; rgbw[3] = p >> 24;
+}
+void oracle_chisel_colour_integrate(uint8_t* rgbw, uint8_t r, uint8_t g, uint8_t b, uint8_t weight_update) {
+  const uint32_t p = colour_integrate((uint32_t)rgbw[0] | ((uint32_t)rgbw[1] << 8) | ((uint32_t)rgbw[2] << 16) |
+                                      ((uint32_t)rgbw[3] << 24), r, g, b, weight_update);
   rgbw[0] = p & 255; rgbw[1] = (p >> 8) & 255; rgbw[2] = (p >> 16) & 255; rgbw[3] = p >> 24;
 }
 float oracle_chisel_diag(float resolution) { return (float)(2.0 * sqrt((double)3.0f) * (double)resolution); }   /* as oracle_chisel_integrate computes it */

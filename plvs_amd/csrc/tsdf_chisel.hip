@@ -145,16 +145,24 @@ __global__ void pool_init(float* __restrict__ sdf, size_t n) {
 }
 
 // Stage 1: count the updating visits of each point and insert first-touch chunks.
+// kNormals: the world-cloud-with-normals flavour (make_ray_normal / resolve_visit_normal), `normals` n x 3.
+template <bool kNormals>
 __global__ __launch_bounds__(256) void ray_count(
-    Params P, const float* __restrict__ xyz, int npoints, const int32_t* __restrict__ offsets,
-    int nclouds, const Pose* __restrict__ poses, Directory dir, Counters* __restrict__ ctr,
-    uint32_t* __restrict__ counts) {
+    Params P, const float* __restrict__ xyz, const float* __restrict__ normals, int npoints,
+    const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
+    Counters* __restrict__ ctr, uint32_t* __restrict__ counts) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npoints) return;
   const Pose pose = poses[cloud_of(offsets, nclouds, i)];
   Ray ray;
+  RayN aux;
   uint32_t n = 0;
-  bool walk = make_ray(P, pose, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], &ray);
+  bool walk = true;
+  if (kNormals)
+    make_ray_normal(P, pose, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], normals[3 * (size_t)i],
+                    normals[3 * (size_t)i + 1], normals[3 * (size_t)i + 2], &ray, &aux);
+  else
+    walk = make_ray(P, pose, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], &ray);
   if (walk && !ray_in_coord_range(ray)) {
     // beyond the range in which the integer chunk addressing equals the reference's float
     // lookup: fail loudly instead of diverging
@@ -175,7 +183,8 @@ __global__ __launch_bounds__(256) void ray_count(
     // nest a skip loop in which the lanes of a wave wait for each other's rejected stretches)
     while (ray_next(&cur, &vx, &vy, &vz)) {
       Visit v;
-      const bool ok = resolve_visit(P, pose, ray, vx, vy, vz, &v, &owner);
+      const bool ok = kNormals ? resolve_visit_normal(P, aux, ray, vx, vy, vz, &v, &owner)
+                               : resolve_visit(P, pose, ray, vx, vy, vz, &v, &owner);
       if (ok && (!have_last || v.cx != lcx || v.cy != lcy || v.cz != lcz)) {
         lcx = v.cx; lcy = v.cy; lcz = v.cz;
         have_last = true;
@@ -216,8 +225,9 @@ struct TileOut {
   uint32_t* last_pt;    // [V], sparse: at a run's position, the point of its last visit
 };
 
+template <bool kNormals>
 __global__ __launch_bounds__(kTileThreads, 6) void ray_tiles(
-    Params P, const float* __restrict__ xyz, const uint8_t* __restrict__ rgb, int npoints,
+    Params P, const float* __restrict__ xyz, const float* __restrict__ normals, const uint8_t* __restrict__ rgb, int npoints,
     const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
     Counters* __restrict__ ctr, const uint32_t* __restrict__ voff, uint32_t V,
     const uint32_t* __restrict__ tile_first, uint32_t ntiles, uint32_t* __restrict__ ticket,
@@ -310,7 +320,12 @@ __global__ __launch_bounds__(kTileThreads, 6) void ray_tiles(
     if ((int)i >= cl_off[ncl]) cl = cloud_of(offsets, nclouds, (int)i) - cloud0;   // beyond the cached clouds
     const Pose pose = poses[cloud0 + cl];
     Ray ray;
-    if (!make_ray(P, pose, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], &ray)) continue;
+    RayN aux;
+    if (kNormals)
+      make_ray_normal(P, pose, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], normals[3 * (size_t)i],
+                      normals[3 * (size_t)i + 1], normals[3 * (size_t)i + 2], &ray, &aux);
+    else if (!make_ray(P, pose, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], &ray))
+      continue;
     RayCursor cur;
     OwnerCache owner;
     ray_begin(ray, &cur);
@@ -320,7 +335,8 @@ __global__ __launch_bounds__(kTileThreads, 6) void ray_tiles(
     uint32_t nv = 0;
     while (nv < n_hi && ray_next(&cur, &vx, &vy, &vz)) {
       Visit v;
-      const bool ok = resolve_visit(P, pose, ray, vx, vy, vz, &v, &owner);   // no early continue: see ray_count
+      const bool ok = kNormals ? resolve_visit_normal(P, aux, ray, vx, vy, vz, &v, &owner)
+                               : resolve_visit(P, pose, ray, vx, vy, vz, &v, &owner);   // no early continue: see ray_count
       if (ok && nv >= n_lo) {
         if (!have_last || v.cx != lcx || v.cy != lcy || v.cz != lcz) {
           lcx = v.cx; lcy = v.cy; lcz = v.cz;
@@ -357,7 +373,7 @@ __global__ __launch_bounds__(kTileThreads, 6) void ray_tiles(
       const uint32_t s = bufA[j] & 0xFFFu;
       const float2 vv = out.vis[slot0 + s];
       const size_t p = __float_as_uint(vv.y);
-      const float tr = truncation_of(P, xyz[3 * p + 2]);
+      const float tr = kNormals ? 4 * P.resolution : truncation_of(P, xyz[3 * p + 2]);
       const float wu = P.weight / (2.0f * tr);
       out.rec_t[slot0 + j] = make_float2(wu * vv.x, wu);
       out.recc_t[slot0 + j] = colour_roundtrip(rgb[3 * p + 0]) | (colour_roundtrip(rgb[3 * p + 1]) << 8) |
@@ -384,6 +400,8 @@ __global__ __launch_bounds__(kTileThreads, 6) void ray_tiles(
 // The truncating u8 colour mean of the ordered mode: one thread per voxel whose colour weight is below
 // 254 folds its visits one by one through the sorted runs, exactly as the reference does, until the
 // weight reaches 254 (at most 254 steps in the life of a voxel).
+// kDivide: ColorVoxel::Integrate (a true division; the world-cloud-with-normals flavour) instead of IntegrateSimple.
+template <bool kDivide>
 __global__ __launch_bounds__(256) void fold_colours(
     const uint32_t* __restrict__ skeys, const unsigned long long* __restrict__ sval, uint32_t nd,
     const uint32_t* __restrict__ vj0, const uint32_t* __restrict__ recc_t, uint32_t* __restrict__ rgbw,
@@ -468,10 +486,18 @@ __global__ __launch_bounds__(256) void fold_colours(
         for (int e = 0; e < kTurn; ++e) {
           const uint32_t cw = col >> 24;
           if ((uint32_t)e < taken && cw < 254u) {   // ColorVoxel::IntegrateSimple, visit by visit
-            const float inv = inv_tab[cw];
-            const uint32_t red = (uint32_t)(uint8_t)((float)(cw * (col & 255u) + (c[e] & 255u)) * inv);
-            const uint32_t green = (uint32_t)(uint8_t)((float)(cw * ((col >> 8) & 255u) + ((c[e] >> 8) & 255u)) * inv);
-            const uint32_t blue = (uint32_t)(uint8_t)((float)(cw * ((col >> 16) & 255u) + ((c[e] >> 16) & 255u)) * inv);
+            uint32_t red, green, blue;
+            if (kDivide) {   // ColorVoxel::Integrate (ColorVoxel.h:68-89); Saturate cannot bind: a mean of bytes
+              const float den = (float)(cw + 1u);
+              red = (uint32_t)(uint8_t)((float)(cw * (col & 255u) + (c[e] & 255u)) / den);
+              green = (uint32_t)(uint8_t)((float)(cw * ((col >> 8) & 255u) + ((c[e] >> 8) & 255u)) / den);
+              blue = (uint32_t)(uint8_t)((float)(cw * ((col >> 16) & 255u) + ((c[e] >> 16) & 255u)) / den);
+            } else {
+              const float inv = inv_tab[cw];
+              red = (uint32_t)(uint8_t)((float)(cw * (col & 255u) + (c[e] & 255u)) * inv);
+              green = (uint32_t)(uint8_t)((float)(cw * ((col >> 8) & 255u) + ((c[e] >> 8) & 255u)) * inv);
+              blue = (uint32_t)(uint8_t)((float)(cw * ((col >> 16) & 255u) + ((c[e] >> 16) & 255u)) * inv);
+            }
             col = red | (green << 8) | (blue << 16) | ((cw + 1u) << 24);
           }
         }
@@ -1259,10 +1285,13 @@ int plvs_hip_tsdf_chisel_clear(plvs_tsdf_chisel* h) {
   return PLVS_OK;
 }
 
-int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d_xyz,
-                                             const uint8_t* d_rgb, const uint32_t* d_kfid,
-                                             const int32_t* offsets, int nclouds,
-                                             const float* d_Twc, void* stream) {
+}  // extern "C"
+
+// d_normals != nullptr: the world-cloud-with-normals flavour (Chisel::IntegrateWorldPointCloudWithNormals), always
+// through the ordered pipeline.
+static int integrate_batch_impl(plvs_tsdf_chisel* h, const float* d_xyz, const uint8_t* d_rgb, const uint32_t* d_kfid,
+                                const int32_t* offsets, int nclouds, const float* d_Twc, void* stream,
+                                const float* d_normals) {
   PLVS_REQUIRE(h, "null handle");
   PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
   PLVS_REQUIRE(offsets && nclouds >= 0, "bad offsets");
@@ -1283,7 +1312,7 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
 
   PLVS_HIP_TRY(h->offsets.reserve((size_t)nclouds + 1));
   PLVS_HIP_TRY(h->poses.reserve((size_t)nclouds));
-  if (h->prm.order_free != 0) return integrate_walk_acc(h, d_xyz, d_rgb, d_kfid, n, nclouds, offsets, d_Twc, s);
+  if (h->prm.order_free != 0 && d_normals == nullptr) return integrate_walk_acc(h, d_xyz, d_rgb, d_kfid, n, nclouds, offsets, d_Twc, s);
   PLVS_HIP_TRY(h->counts.reserve((size_t)n + 1));
   PLVS_HIP_TRY(h->scratch.reserve(scan_scratch_words((size_t)n)));
   PLVS_HIP_TRY(hipMemcpyAsync(h->offsets.p, offsets, ((size_t)nclouds + 1) * sizeof(int32_t),
@@ -1299,8 +1328,12 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
 #define STAGE_MARK(i) \
   do { if (h->profiling) PLVS_HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
   STAGE_MARK(0);
-  hipLaunchKernelGGL(ray_count, dim3(ceil_div((size_t)n, 256)), dim3(256), 0, s, h->P, d_xyz, n,
-                     h->offsets.p, nclouds, h->poses.p, h->dir, h->d_ctr, h->counts.p);
+  if (d_normals != nullptr)
+    hipLaunchKernelGGL(ray_count<true>, dim3(ceil_div((size_t)n, 256)), dim3(256), 0, s, h->P, d_xyz, d_normals, n,
+                       h->offsets.p, nclouds, h->poses.p, h->dir, h->d_ctr, h->counts.p);
+  else
+    hipLaunchKernelGGL(ray_count<false>, dim3(ceil_div((size_t)n, 256)), dim3(256), 0, s, h->P, d_xyz, d_normals, n,
+                       h->offsets.p, nclouds, h->poses.p, h->dir, h->d_ctr, h->counts.p);
   PLVS_KERNEL_CHECK();
   STAGE_MARK(1);
   // counts -> visit offsets (n + 1 entries: the total closes the list)
@@ -1352,9 +1385,14 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
   {
     // per-visit (u, point): in the buffer the gather fills later
     TileOut out{h->rec.p, h->rec_t.p, h->recc_t.p, h->dkey0.p, h->didx0.p, h->last_pt.p};
-    hipLaunchKernelGGL(ray_tiles, dim3(ntiles), dim3(kTileThreads), 0, s, h->P, d_xyz, d_rgb, n, h->offsets.p, nclouds,
-                       h->poses.p, h->dir, h->d_ctr, h->counts.p, V, h->tile_first.p, ntiles,
-                       reinterpret_cast<uint32_t*>(h->tile_state.p), h->tile_state.p + 1, h->rgbw, out);
+    if (d_normals != nullptr)
+      hipLaunchKernelGGL(ray_tiles<true>, dim3(ntiles), dim3(kTileThreads), 0, s, h->P, d_xyz, d_normals, d_rgb, n,
+                         h->offsets.p, nclouds, h->poses.p, h->dir, h->d_ctr, h->counts.p, V, h->tile_first.p, ntiles,
+                         reinterpret_cast<uint32_t*>(h->tile_state.p), h->tile_state.p + 1, h->rgbw, out);
+    else
+      hipLaunchKernelGGL(ray_tiles<false>, dim3(ntiles), dim3(kTileThreads), 0, s, h->P, d_xyz, d_normals, d_rgb, n,
+                         h->offsets.p, nclouds, h->poses.p, h->dir, h->d_ctr, h->counts.p, V, h->tile_first.p, ntiles,
+                         reinterpret_cast<uint32_t*>(h->tile_state.p), h->tile_state.p + 1, h->rgbw, out);
   }
   PLVS_KERNEL_CHECK();
   STAGE_MARK(3);
@@ -1391,8 +1429,12 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
     // distance chain then has the machine to itself.
     PLVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
     PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    hipLaunchKernelGGL(fold_colours, dim3(std::min<size_t>(ceil_div(D, 256), 1024)), dim3(256), 0, h->side,
-                       skeys, sidx, D, h->heads.p, h->recc_t.p, h->rgbw, h->d_ctr);
+    if (d_normals != nullptr)
+      hipLaunchKernelGGL(fold_colours<true>, dim3(std::min<size_t>(ceil_div(D, 256), 1024)), dim3(256), 0, h->side,
+                         skeys, sidx, D, h->heads.p, h->recc_t.p, h->rgbw, h->d_ctr);
+    else
+      hipLaunchKernelGGL(fold_colours<false>, dim3(std::min<size_t>(ceil_div(D, 256), 1024)), dim3(256), 0, h->side,
+                         skeys, sidx, D, h->heads.p, h->recc_t.p, h->rgbw, h->d_ctr);
     PLVS_HIP_TRY(hipEventRecord(h->ev_join, h->side));
     hipLaunchKernelGGL(run_counts, dim3(ceil_div(D, 256)), dim3(256), 0, s, sidx, D, h->run_cnt.p);
     PLVS_HIP_TRY(exclusive_scan_u32(h->run_cnt.p, h->run_dst.p, D, nullptr, h->scratch.p, s));
@@ -1452,6 +1494,52 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
 #endif
   h->last_updated = h->h_ctr->num_updated;
   return PLVS_OK;
+}
+
+extern "C" {
+
+int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d_xyz,
+                                             const uint8_t* d_rgb, const uint32_t* d_kfid,
+                                             const int32_t* offsets, int nclouds,
+                                             const float* d_Twc, void* stream) {
+  return integrate_batch_impl(h, d_xyz, d_rgb, d_kfid, offsets, nclouds, d_Twc, stream, nullptr);
+}
+
+int plvs_hip_tsdf_chisel_integrate_world_normals_dev(plvs_tsdf_chisel* h, const float* d_xyz, const uint8_t* d_rgb,
+                                                     const uint32_t* d_kfid, const float* d_normals, int n,
+                                                     const float* d_Twc, void* stream) {
+  PLVS_REQUIRE(h && n >= 0, "bad arguments");
+  PLVS_REQUIRE(n == 0 || d_normals, "null normals");
+  PLVS_REQUIRE(std::max(1, h->prm.shard_count) == 1 || h->prm.order_free == 0,
+               "a ray-sharded (order_free) map takes the world cloud on the rank that owns each chunk: use an ordered sharded handle");
+  const int32_t offsets[2] = {0, n};
+  return integrate_batch_impl(h, d_xyz, d_rgb, d_kfid, offsets, 1, d_Twc, stream, d_normals);
+}
+
+int plvs_hip_tsdf_chisel_integrate_world_normals(plvs_tsdf_chisel* h, const float* xyz, const uint8_t* rgb,
+                                                 const uint32_t* kfid, const float* normals, int n, const float* Twc) {
+  PLVS_REQUIRE(h, "null handle");
+  PLVS_REQUIRE(n >= 0 && Twc, "bad arguments");
+  h->stats = plvs_tsdf_stats{};
+  h->last_updated = 0;
+  if (n == 0) return PLVS_OK;
+  PLVS_REQUIRE(xyz && rgb && normals, "null input");
+  DevBuf<float> st_n;
+  PLVS_HIP_TRY(h->st_xyz.reserve((size_t)n * 3));
+  PLVS_HIP_TRY(h->st_rgb.reserve((size_t)n * 3));
+  PLVS_HIP_TRY(h->st_Twc.reserve(12));
+  PLVS_HIP_TRY(st_n.reserve((size_t)n * 3));
+  if (kfid) PLVS_HIP_TRY(h->st_kfid.reserve((size_t)n));
+  PLVS_HIP_TRY(hipMemcpy(h->st_xyz.p, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(h->st_rgb.p, rgb, (size_t)n * 3, hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(st_n.p, normals, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(h->st_Twc.p, Twc, 12 * sizeof(float), hipMemcpyHostToDevice));
+  if (kfid) PLVS_HIP_TRY(hipMemcpy(h->st_kfid.p, kfid, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  const int rc = plvs_hip_tsdf_chisel_integrate_world_normals_dev(h, h->st_xyz.p, h->st_rgb.p, kfid ? h->st_kfid.p : nullptr,
+                                                                  st_n.p, n, h->st_Twc.p, nullptr);
+  (void)hipDeviceSynchronize();
+  st_n.release();
+  return rc;
 }
 
 int plvs_hip_tsdf_chisel_integrate(plvs_tsdf_chisel* h, const float* xyz, const uint8_t* rgb,

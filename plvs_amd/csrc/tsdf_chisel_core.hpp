@@ -122,6 +122,33 @@ PLVS_HD bool make_ray(const Params& P, const Pose& pose, float px, float py, flo
   return true;
 }
 
+// The "world cloud with normals" flavour (Chisel::IntegrateWorldPointCloudWithNormals, Chisel.cpp:238-376: what
+// PointCloudMapChisel::LoadMap integrates the saved map through): the segment point -/+ 4 voxels along the point's
+// normal, no depth test, constant truncation.
+struct RayN {
+  float wp[3], dir[3];   // world point, unit normal
+};
+
+PLVS_HD void make_ray_normal(const Params& P, const Pose& pose, float px, float py, float pz, float nx, float ny,
+                             float nz, Ray* r, RayN* a) {
+  xform(pose.R, pose.t, px, py, pz, a->wp);                 // cameraPose * point, :276
+  const float z2 = sqnorm3(nx, ny, nz);
+  a->dir[0] = nx; a->dir[1] = ny; a->dir[2] = nz;
+  if (z2 > 0.0f) {                                          // normal.normalized(), :282
+    const float nrm = sqrtf(z2);
+    a->dir[0] = nx / nrm; a->dir[1] = ny / nrm; a->dir[2] = nz / nrm;
+  }
+  const float tr = 4 * P.resolution;                        // :266
+  for (int k = 0; k < 3; ++k) {
+    const float swp = a->wp[k] * P.round_to_voxel;          // :288
+    const float sdt = a->dir[k] * tr * P.round_to_voxel;    // :289
+    r->start[k] = swp - sdt;
+    r->end[k] = swp + sdt;
+  }
+  r->depth = 0.f;
+  r->truncation = tr;
+}
+
 // ChunkHasher (ChunkManager.h:42-54), size_t arithmetic; used only for sharding.
 PLVS_HD uint64_t chunk_hash(int x, int y, int z) {
   return ((uint64_t)(int64_t)x * 73856093ull) ^ ((uint64_t)(int64_t)y * 19349663ull) ^
@@ -193,6 +220,21 @@ PLVS_HD bool resolve_visit(const Params& P, const Pose& pose, const Ray& ray, in
   const float c1 = (float)vy * P.resolution + P.half_voxel;
   const float c2 = (float)vz * P.resolution + P.half_voxel;
   v->u = signed_dist(pose, ray.depth, c0, c1, c2);
+  return fabsf(v->u) < ray.truncation;
+}
+
+// The same for the normals flavour: u = (centre - worldPoint) . dir (Chisel.cpp:329).
+PLVS_HD bool resolve_visit_normal(const Params& P, const RayN& a, const Ray& ray, int vx, int vy, int vz, Visit* v,
+                                  OwnerCache* oc) {
+  v->cx = vx >> 4;
+  v->cy = vy >> 4;
+  v->cz = vz >> 4;
+  if (!chunk_owned(P, v->cx, v->cy, v->cz, oc)) return false;
+  v->vid = ((vz & 15) * 16 + (vy & 15)) * 16 + (vx & 15);
+  const float c0 = (float)vx * P.resolution + P.half_voxel;
+  const float c1 = (float)vy * P.resolution + P.half_voxel;
+  const float c2 = (float)vz * P.resolution + P.half_voxel;
+  v->u = sum3((c0 - a.wp[0]) * a.dir[0], (c1 - a.wp[1]) * a.dir[1], (c2 - a.wp[2]) * a.dir[2]);
   return fabsf(v->u) < ray.truncation;
 }
 

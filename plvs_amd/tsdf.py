@@ -157,6 +157,18 @@ class TsdfChisel:
         _lib.lib.plvs_hip_tsdf_chisel_halo_clear.argtypes = [ctypes.c_void_p]
         _lib.check(_lib.lib.plvs_hip_tsdf_chisel_halo_clear(self._h))
 
+    def integrate_world_normals(self, xyz, rgb, kfid, normals, Twc=None):
+        """Chisel::IntegrateWorldPointCloudWithNormals (the LoadMap path): a cloud with normals, Twc identity by default."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(-1, 3)
+        normals = np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+        kfid = None if kfid is None else np.ascontiguousarray(kfid, dtype=np.uint32)
+        Twc = np.ascontiguousarray(np.eye(4, dtype=np.float32)[:3] if Twc is None else Twc, dtype=np.float32).reshape(3, 4)
+        f = _lib.lib.plvs_hip_tsdf_chisel_integrate_world_normals
+        f.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int, ctypes.c_void_p]
+        _lib.check(f(self._h, _lib.np_ptr(xyz), _lib.np_ptr(rgb), _lib.np_ptr(kfid), _lib.np_ptr(normals), xyz.shape[0],
+                     _lib.np_ptr(Twc)))
+
     def integrate_batch_dev(self, d_xyz, d_rgb, d_kfid, offsets, d_Twc):
         """Device flavour: concatenated clouds resident in HBM (torch tensors),
         `offsets` a host int32 array of nclouds+1, d_Twc [nclouds,3,4] f32."""
@@ -539,6 +551,24 @@ class PointCloudMapChisel:
             c["kfid"] = v["kfids"]
             o += k
         return cloud
+
+    def LoadMap(self, cloud):
+        """LoadMap once PointCloudMap::LoadMap has read the saved cloud (src/PointCloudMapChisel.cc:527-546):
+        ChiselServer::IntegrateWorldPointCloud(cloud, identity) — every point along its normal — then UpdateMap.
+        cloud: structured POINT_SURFEL array (or a dict with xyz, rgb, kfid, normal)."""
+        if isinstance(cloud, dict):
+            xyz, rgb, kfid, nrm = cloud["xyz"], cloud["rgb"], cloud.get("kfid"), cloud["normal"]
+        else:
+            xyz = np.stack([cloud["x"], cloud["y"], cloud["z"]], -1)
+            rgb = np.stack([cloud["r"], cloud["g"], cloud["b"]], -1)
+            kfid, nrm = cloud["kfid"], cloud["normal"]
+        self._tsdf.integrate_world_normals(xyz, rgb, kfid, nrm)
+        for c in self._tsdf.updated_chunk_ids():          # Chisel.cpp:349-365
+            for dx in (-1, 0, 1):
+                for dy in (-1, 0, 1):
+                    for dz in (-1, 0, 1):
+                        self._meshes_to_update.add((int(c[0]) + dx, int(c[1]) + dy, int(c[2]) + dz))
+        return self.UpdateMap()
 
     def InsertData(self, pData):
         """PointCloudMapInput dispatch (src/PointCloudMapChisel.cc:192-225): only the

@@ -191,6 +191,12 @@ int main(int argc, char** argv) {
   const int vpts = vmap.UpdateMap();
   dump("vmap_cloud", vmap.GetPointCloud().data(), vmap.GetPointCloud().size() * sizeof(PointSurfelSegment));
   std::printf("voxblox %d %d %d\n", vmap.NumBlocks(), vpts, (int)vmap.GetMeshLayer().size());
+  {   // LoadMap: the chisel map's own output cloud back into an empty map, along its normals
+    PointCloudMapChisel again(0.05f);
+    const int lpts = again.LoadMap(map.GetPointCloud());
+    dump("loaded_cloud", again.GetPointCloud().data(), again.GetPointCloud().size() * sizeof(PointSurfelSegment));
+    std::printf("loadmap %d %d\n", lpts, (int)again.GetAllMeshes().size());
+  }
   map.Clear();
   std::printf("cleared %d\n", map.UpdateMap());
   return 0;

@@ -384,6 +384,18 @@ class _ChiselLike:
         Twc = np.ascontiguousarray(Twc, dtype=np.float32).reshape(3, 4)
         getattr(self.lib, self.p + "_integrate")(self.h, _ptr(xyz), _ptr(rgb), _ptr(kfid), xyz.shape[0], _ptr(Twc))
 
+    def integrate_world_normals(self, xyz, rgb, kfid, normals, Twc=None):
+        """Chisel::IntegrateWorldPointCloudWithNormals (oracle only)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        normals = np.ascontiguousarray(normals, dtype=np.float32)
+        kfid = None if kfid is None else np.ascontiguousarray(kfid, dtype=np.uint32)
+        Twc = np.ascontiguousarray(np.eye(4, dtype=np.float32)[:3] if Twc is None else Twc, dtype=np.float32).reshape(3, 4)
+        f = getattr(self.lib, self.p + "_integrate_world_normals")
+        f.restype = None
+        f.argtypes = [_vp] * 5 + [_i, _vp]
+        f(self.h, _ptr(xyz), _ptr(rgb), _ptr(kfid), _ptr(normals), xyz.shape[0], _ptr(Twc))
+
     def last_visits(self):
         return int(getattr(self.lib, self.p + "_last_visits")(self.h))
 

@@ -113,6 +113,10 @@ def test_cpp_mirror_matches_python_mirror(tmp_path):
     mc = m.UpdateMap()
     assert int(lines_out["chisel"][0]) == len(mc) > 1000 and int(lines_out["chisel"][1]) == len(m.all_meshes)
     assert load("map_cloud", np.uint8).tobytes() == mc.tobytes()
+    again = PointCloudMapChisel(0.05)
+    lc = again.LoadMap(mc)
+    assert int(lines_out["loadmap"][0]) == len(lc) > 500 and int(lines_out["loadmap"][1]) == len(again.all_meshes)
+    assert load("loaded_cloud", np.uint8).tobytes() == lc.tobytes()
     from plvs_amd.tsdf import PointCloudMapVoxblox
     v = PointCloudMapVoxblox(0.05)
     vc = dict(xyz=pc["xyz"], rgba=np.stack([cloud["r"], cloud["g"], cloud["b"], cloud["a"]], -1))

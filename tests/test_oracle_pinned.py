@@ -116,6 +116,23 @@ def test_voxel_updates_truncation_and_weight_equal_the_reference_source():
         ora.oracle_chisel_colour_integrate_simple(q.ctypes.data, r, g, b, 1)
         assert np.array_equal(p, q)
     assert p[3] == 254                                  # frozen one short of 255, as the reference's test leaves it
+    # ColorVoxel::Integrate (division + Saturate: IntegrateWorldPointCloudWithNormals' flavour) — exhaustively over
+    # weight x old x new for one channel, then the three channels together; and it is NOT IntegrateSimple
+    differs = 0
+    for name in ("colour_integrate",):
+        getattr(ref, "ref_chisel_" + name).argtypes = [ctypes.c_void_p] + [ctypes.c_uint8] * 4
+        getattr(ora, "oracle_chisel_" + name).argtypes = [ctypes.c_void_p] + [ctypes.c_uint8] * 4
+    for cw in range(256):
+        for old in range(0, 256, 3):
+            for new in range(0, 256, 5):
+                p = np.array([old, 255 - old, (old * 7) & 255, cw], np.uint8)
+                q, q2 = p.copy(), p.copy()
+                ref.ref_chisel_colour_integrate(p.ctypes.data, new, (new * 3) & 255, 255 - new, 1)
+                ora.oracle_chisel_colour_integrate(q.ctypes.data, new, (new * 3) & 255, 255 - new, 1)
+                assert np.array_equal(p, q), (cw, old, new)
+                ora.oracle_chisel_colour_integrate_simple(q2.ctypes.data, new, (new * 3) & 255, 255 - new, 1)
+                differs += int(not np.array_equal(q, q2))
+    assert differs > 0, "the two colour updates round differently somewhere (else one restatement would do)"
     # QuadraticTruncator with PLVS's constants (ChiselServer.cpp:56-59) and random ones; ConstantWeighter
     for reading in np.concatenate([np.linspace(0.0, 12.0, 5000), rng.uniform(0, 100, 5000)]).astype(np.float32):
         for q_, l_, c_, s_ in ((0.0019, -0.00152, 0.001504, 6.0), tuple(rng.uniform(-1, 1, 4))):
