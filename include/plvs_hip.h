@@ -777,6 +777,14 @@ int plvs_hip_tsdf_voxblox_integrate(plvs_tsdf_voxblox* h, const float* xyz, cons
 int plvs_hip_tsdf_voxblox_integrate_batch_dev(plvs_tsdf_voxblox* h, const float* d_xyz,
                                               const uint8_t* d_rgba, const int32_t* offsets,
                                               int nclouds, const float* d_Twc, void* stream);
+/* A cloud WITH NORMALS, as PointCloudMapVoxblox::LoadMap feeds the saved cloud through
+ * (src/PointCloudMapVoxblox.cc:233-258 -> TsdfServer::insertWorldPointCloud, tsdf_server.cc:577-660, T = identity
+ * there -> TsdfIntegratorBase::integrateWorlPointCloud, tsdf_integrator.cc:35-82): points in cloud order, each
+ * casting point + normal * truncation -> point - normal * truncation (normals n x 3 f32, normalised here as
+ * there), weight 1, ray_start in the sensor origin's place; no ray-length test.  Host pointers; synchronous.
+ * Non-finite points are refused (the reference drops them). */
+int plvs_hip_tsdf_voxblox_integrate_world_normals(plvs_tsdf_voxblox* h, const float* xyz, const uint8_t* rgba,
+                                                  const float* normals, int n, const float* Twc);
 int plvs_hip_tsdf_voxblox_last_stats(plvs_tsdf_voxblox* h, plvs_tsdf_stats* s);
 int plvs_hip_tsdf_voxblox_num_blocks(plvs_tsdf_voxblox* h, int* n);
 int plvs_hip_tsdf_voxblox_block_ids(plvs_tsdf_voxblox* h, int32_t* ids_xyz, int cap, int* n);

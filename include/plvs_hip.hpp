@@ -571,12 +571,25 @@ class PointCloudMapVoxblox {
       rgba_[4 * i] = p.r; rgba_[4 * i + 1] = p.g; rgba_[4 * i + 2] = p.b; rgba_[4 * i + 3] = p.a;
     }
     check(plvs_hip_tsdf_voxblox_integrate(h_, xyz_.data(), rgba_.data(), (int)n, Twc.m));
-    // every block the integrator touched has updated() set (tsdf_integrator.cc:151) until the next updateMesh
-    int nu = 0;
-    check(plvs_hip_tsdf_voxblox_updated_block_ids(h_, nullptr, 0, &nu));
-    std::vector<int32_t> ids((size_t)3 * (nu > 0 ? nu : 1));
-    if (nu > 0) check(plvs_hip_tsdf_voxblox_updated_block_ids(h_, ids.data(), nu, &nu));
-    for (int i = 0; i < nu; ++i) updated_.insert(BlockID(ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]));
+    MarkUpdated();
+  }
+  // LoadMap of a saved cloud once PointCloudMap::LoadMap has read it (src/PointCloudMapVoxblox.cc:233-258):
+  // TsdfServer::insertWorldPointCloud(cloud, identity) — every point along its normal — then UpdateMap.
+  int LoadMap(const std::vector<PointSurfelSegment>& cloud) {
+    const size_t n = cloud.size();
+    xyz_.resize(3 * n);
+    rgba_.resize(4 * n);
+    std::vector<float> nrm(3 * n);
+    for (size_t i = 0; i < n; ++i) {
+      const PointSurfelSegment& p = cloud[i];
+      xyz_[3 * i] = p.x; xyz_[3 * i + 1] = p.y; xyz_[3 * i + 2] = p.z;
+      rgba_[4 * i] = p.r; rgba_[4 * i + 1] = p.g; rgba_[4 * i + 2] = p.b; rgba_[4 * i + 3] = p.a;
+      nrm[3 * i] = p.normal_x; nrm[3 * i + 1] = p.normal_y; nrm[3 * i + 2] = p.normal_z;
+    }
+    const float identity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    check(plvs_hip_tsdf_voxblox_integrate_world_normals(h_, xyz_.data(), rgba_.data(), nrm.data(), (int)n, identity));
+    MarkUpdated();
+    return UpdateMap();
   }
   // UpdateMap: TsdfServer::updateMesh (generateMesh(only_mesh_updated_blocks, clear_updated_flag), tsdf_server.cc:775-787)
   // + getMeshAsPointcloud (voxblox_ros/mesh_vis.h:272-318, ColorMode::kColor)  (src/PointCloudMapVoxblox.cc:160-179).
@@ -633,6 +646,14 @@ class PointCloudMapVoxblox {
   plvs_tsdf_voxblox* handle() { return h_; }
 
  private:
+  // every block the integrator touched has updated() set (tsdf_integrator.cc:151) until the next updateMesh
+  void MarkUpdated() {
+    int nu = 0;
+    check(plvs_hip_tsdf_voxblox_updated_block_ids(h_, nullptr, 0, &nu));
+    std::vector<int32_t> ids((size_t)3 * (nu > 0 ? nu : 1));
+    if (nu > 0) check(plvs_hip_tsdf_voxblox_updated_block_ids(h_, ids.data(), nu, &nu));
+    for (int i = 0; i < nu; ++i) updated_.insert(BlockID(ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]));
+  }
   // colorVoxbloxToMsg then colorMsgToVoxblox (voxblox_ros/conversions.h:44-60): through a float in [0, 1] and back
   static uint8_t CloudColour(uint8_t c) {
     const float msg = (float)(c / 255.0);

@@ -212,6 +212,8 @@ typedef struct {
   int steps; /* ray_length_in_steps_: the ray emits steps + 1 voxels */
 } vb_ray;
 
+static void vb_ray_setup_scaled(const float ss[3], const float es[3], vb_ray* r);
+
 static void vb_ray_setup(const float origin[3], const float pG[3], int is_clearing, int carving, float max_ray,
                          float voxel_size_inv, float truncation, vb_ray* r) {
   const float d[3] = {pG[0] - origin[0], pG[1] - origin[1], pG[2] - origin[2]};
@@ -236,7 +238,11 @@ static void vb_ray_setup(const float origin[3], const float pG[3], int is_cleari
   }
   float ss[3], es[3];
   for (int k = 0; k < 3; k++) { ss[k] = ray_start[k] * voxel_size_inv; es[k] = ray_end[k] * voxel_size_inv; }
-  /* setupRayCaster (:196-235) */
+  vb_ray_setup_scaled(ss, es, r);
+}
+
+/* setupRayCaster (:196-235); also RayCaster(start_scaled, end_scaled) (:169-173) */
+static void vb_ray_setup_scaled(const float ss[3], const float es[3], vb_ray* r) {
   int32_t endi[3];
   r->steps = 0;
   for (int k = 0; k < 3; k++) {
@@ -369,6 +375,66 @@ void oracle_voxblox_integrate(oracle_voxblox* o, const float* xyz, const uint8_t
     }
   }
   free(keep);
+  o->last_visits = visits;
+}
+
+/* TsdfIntegratorBase::integrateWorlPointCloud (tsdf_integrator.cc:35-82), what PointCloudMapVoxblox::LoadMap feeds the
+ * saved cloud through (src/PointCloudMapVoxblox.cc:233-258 -> TsdfServer::insertWorldPointCloud, tsdf_server.cc:577-660,
+ * T = identity there): points in CLOUD order (no ThreadSafeIndex), each casting point + normal * truncation ->
+ * point - normal * truncation, every voxel updated with weight 1 and ray_start in the role of the sensor origin.  No
+ * isPointValid test.  The normal goes through T_G_C * normal_C — the full transformation, translation included, as the
+ * reference writes it.  normals: n x 3.  Restated by reading (RayCaster, blend, indices are the pinned pieces). */
+void oracle_voxblox_integrate_world_normals(oracle_voxblox* o, const float* xyz, const uint8_t* rgba, const float* normals,
+                                            int n, const float* Twc) {
+  float R[9], t[3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) R[3 * i + j] = Twc[4 * i + j];
+    t[i] = Twc[4 * i + 3];
+  }
+  float q[4];
+  quat_from_matrix(R, q);
+  int64_t visits = 0;
+  vblock_t* last_block = NULL;
+  int32_t last_bid[3] = {0, 0, 0};
+  for (int pi = 0; pi < n; pi++) {
+    const float* pC = xyz + 3 * (size_t)pi;
+    if (!(isfinite(pC[0]) && isfinite(pC[1]) && isfinite(pC[2]))) continue;   /* tsdf_server.cc:617-622 */
+    uint32_t color;
+    memcpy(&color, rgba + 4 * (size_t)pi, 4);
+    const float* nC = normals + 3 * (size_t)pi;
+    float nn[3] = {nC[0], nC[1], nC[2]};
+    const float z2 = sum3(nC[0] * nC[0], nC[1] * nC[1], nC[2] * nC[2]);
+    if (z2 > 0.0f) { const float l = sqrtf(z2); nn[0] = nC[0] / l; nn[1] = nC[1] / l; nn[2] = nC[2] / l; }   /* :44 */
+    float pG[3], nG[3];
+    quat_transform(q, t, pC, pG);                              /* :47 */
+    quat_transform(q, t, nn, nG);                              /* :48 */
+    float ray_start[3], ray_end[3], ss[3], es[3];
+    for (int k = 0; k < 3; k++) {
+      ray_start[k] = pG[k] + nG[k] * o->truncation;            /* :52 */
+      ray_end[k] = pG[k] - nG[k] * o->truncation;              /* :53 */
+      ss[k] = ray_start[k] * o->voxel_size_inv;                /* :55-56 */
+      es[k] = ray_end[k] * o->voxel_size_inv;
+    }
+    vb_ray ray;
+    vb_ray_setup_scaled(ss, es, &ray);                         /* RayCaster(start_scaled, end_scaled), :62 */
+    for (int step = 0; step <= ray.steps; step++) {
+      int32_t g[3];
+      vb_ray_next(&ray, g);
+      int32_t bid[3];
+      block_index(g, o->voxels_per_side_inv, bid);
+      if (o->shard_count > 1 && (int)(owner_hash(bid) % (size_t)o->shard_count) != o->shard_rank) continue;
+      if (!last_block || last_bid[0] != bid[0] || last_bid[1] != bid[1] || last_bid[2] != bid[2]) {
+        last_block = vblock_get(o, bid);
+        memcpy(last_bid, bid, sizeof(last_bid));
+      }
+      int32_t l[3];
+      local_index(g, l);
+      const int vid = l[0] + VPS * (l[1] + l[2] * VPS);
+      update_voxel(o, ray_start, pG, g, color, 1.0f, &last_block->distance[vid], &last_block->weight[vid],
+                   &last_block->rgba[vid]);                    /* :78 */
+      visits++;
+    }
+  }
   o->last_visits = visits;
 }
 

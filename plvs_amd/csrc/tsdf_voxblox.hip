@@ -66,15 +66,17 @@ __device__ __forceinline__ int point_of_seq(const int32_t* __restrict__ offsets,
   return beg + (int)mixed_index((uint32_t)(i - beg), (uint32_t)cnt);
 }
 
-template <bool kFill>
+// kWorld: the world-cloud-with-normals flavour (make_ray_world): cloud order, no validity test; `normals` n x 3.
+template <bool kFill, bool kWorld>
 __global__ __launch_bounds__(256) void vb_ray_pass(
-    Params P, const float* __restrict__ xyz, int npoints, const int32_t* __restrict__ offsets,
-    int nclouds, const float* __restrict__ Twc, Directory dir, VCounters* __restrict__ ctr,
-    uint32_t* __restrict__ counts, uint32_t* __restrict__ rec_keys, uint32_t* __restrict__ rec_seq) {
+    Params P, const float* __restrict__ xyz, const float* __restrict__ normals, int npoints,
+    const int32_t* __restrict__ offsets, int nclouds, const float* __restrict__ Twc, Directory dir,
+    VCounters* __restrict__ ctr, uint32_t* __restrict__ counts, uint32_t* __restrict__ rec_keys,
+    uint32_t* __restrict__ rec_seq) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npoints) return;
-  int cloud;
-  const int p = point_of_seq(offsets, nclouds, i, &cloud);
+  int cloud = 0;
+  const int p = kWorld ? i : point_of_seq(offsets, nclouds, i, &cloud);
   const float px = xyz[3 * (size_t)p], py = xyz[3 * (size_t)p + 1], pz = xyz[3 * (size_t)p + 2];
   uint32_t n = 0;
   if (!(isfinite(px) && isfinite(py) && isfinite(pz))) {
@@ -84,7 +86,14 @@ __global__ __launch_bounds__(256) void vb_ray_pass(
   } else {
     const PoseRt pose = load_pose(Twc, cloud);
     Ray ray;
-    if (make_ray(P, pose, px, py, pz, &ray)) {
+    bool walk = true;
+    if (kWorld) {
+      float rs[3];
+      make_ray_world(P, pose, px, py, pz, normals[3 * (size_t)p], normals[3 * (size_t)p + 1], normals[3 * (size_t)p + 2], &ray, rs);
+    } else {
+      walk = make_ray(P, pose, px, py, pz, &ray);
+    }
+    if (walk) {
       const uint32_t out = kFill ? counts[i] : 0u;
       int lb[3] = {0, 0, 0}, lslot = -1;
       bool have_last = false;
@@ -117,9 +126,10 @@ __global__ __launch_bounds__(256) void vb_ray_pass(
 }
 
 constexpr int kExpandThreads = 1024;
+template <bool kWorld>
 __global__ __launch_bounds__(kExpandThreads) void vb_expand(
     Params P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ seqs, uint32_t n,
-    const float* __restrict__ xyz, const uint32_t* __restrict__ rgba,
+    const float* __restrict__ xyz, const float* __restrict__ normals, const uint32_t* __restrict__ rgba,
     const int32_t* __restrict__ offsets, int nclouds, const float* __restrict__ Twc,
     const int32_t* __restrict__ slot_ids, float2* __restrict__ rec, uint32_t* __restrict__ rec_c,
     uint32_t* __restrict__ heads, uint32_t* __restrict__ updated_slots,
@@ -137,19 +147,26 @@ __global__ __launch_bounds__(kExpandThreads) void vb_expand(
     const uint32_t next = (r + 1 < n) ? keys[r + 1] : ~key;
     head = (r == 0) || (key != prev);
     chead = (r == 0) || ((key >> 12) != (prev >> 12));
-    int cloud;
-    const int p = point_of_seq(offsets, nclouds, (int)seqs[r], &cloud);
+    int cloud = 0;
+    const int p = kWorld ? (int)seqs[r] : point_of_seq(offsets, nclouds, (int)seqs[r], &cloud);
     const PoseRt pose = load_pose(Twc, cloud);
     const float px = xyz[3 * (size_t)p], py = xyz[3 * (size_t)p + 1], pz = xyz[3 * (size_t)p + 2];
-    float pG[3];
-    quat_transform(pose, px, py, pz, pG);
-    const float weight = fabsf(pz) > 1e-6f ? 1.0f / (pz * pz) : 0.0f;
     const uint32_t slot = key >> 12, vid = key & 4095u;
     const int g[3] = {slot_ids[3 * slot + 0] * 16 + (int)(vid & 15u),
                       slot_ids[3 * slot + 1] * 16 + (int)((vid >> 4) & 15u),
                       slot_ids[3 * slot + 2] * 16 + (int)(vid >> 8)};
     float sdf, uw;
-    visit_operands(P, pose.t, pG, g, weight, &sdf, &uw);
+    if (kWorld) {   // updateTsdfVoxel(ray_start, point_G, ..., weight 1), tsdf_integrator.cc:78
+      Ray ray;
+      float rs[3];
+      make_ray_world(P, pose, px, py, pz, normals[3 * (size_t)p], normals[3 * (size_t)p + 1], normals[3 * (size_t)p + 2], &ray, rs);
+      visit_operands(P, rs, ray.pG, g, 1.0f, &sdf, &uw);
+    } else {
+      float pG[3];
+      quat_transform(pose, px, py, pz, pG);
+      const float weight = fabsf(pz) > 1e-6f ? 1.0f / (pz * pz) : 0.0f;
+      visit_operands(P, pose.t, pG, g, weight, &sdf, &uw);
+    }
     // uw >= 0: its sign bit marks the LAST record of the voxel run
     rec[r] = make_float2(sdf, (key != next) ? -uw : uw);
     rec_c[r] = rgba[p];
@@ -400,9 +417,11 @@ int plvs_hip_tsdf_voxblox_create(const plvs_tsdf_voxblox_params* p, plvs_tsdf_vo
   return rc;
 }
 
-int plvs_hip_tsdf_voxblox_integrate_batch_dev(plvs_tsdf_voxblox* h, const float* d_xyz,
-                                              const uint8_t* d_rgba, const int32_t* offsets,
-                                              int nclouds, const float* d_Twc, void* stream) {
+}  // extern "C"
+
+// d_normals != nullptr: the world-cloud-with-normals flavour (integrateWorlPointCloud), one cloud.
+static int vb_integrate_impl(plvs_tsdf_voxblox* h, const float* d_xyz, const uint8_t* d_rgba, const int32_t* offsets,
+                             int nclouds, const float* d_Twc, void* stream, const float* d_normals) {
   PLVS_REQUIRE(h, "null handle");
   PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
   PLVS_REQUIRE(offsets && nclouds >= 0, "bad offsets");
@@ -427,8 +446,12 @@ int plvs_hip_tsdf_voxblox_integrate_batch_dev(plvs_tsdf_voxblox* h, const float*
   PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->total_visits, 0, sizeof(uint32_t), s));
   PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->err, 0, 4 * sizeof(uint32_t), s));
   const dim3 rgrid(ceil_div((size_t)n, 256)), rblock(256);
-  hipLaunchKernelGGL(vb_ray_pass<false>, rgrid, rblock, 0, s, h->P, d_xyz, n, h->offsets.p, nclouds,
-                     d_Twc, h->dir, h->d_ctr, h->counts.p, (uint32_t*)nullptr, (uint32_t*)nullptr);
+  if (d_normals != nullptr)
+    hipLaunchKernelGGL((vb_ray_pass<false, true>), rgrid, rblock, 0, s, h->P, d_xyz, d_normals, n, h->offsets.p, nclouds,
+                       d_Twc, h->dir, h->d_ctr, h->counts.p, (uint32_t*)nullptr, (uint32_t*)nullptr);
+  else
+    hipLaunchKernelGGL((vb_ray_pass<false, false>), rgrid, rblock, 0, s, h->P, d_xyz, d_normals, n, h->offsets.p, nclouds,
+                       d_Twc, h->dir, h->d_ctr, h->counts.p, (uint32_t*)nullptr, (uint32_t*)nullptr);
   PLVS_KERNEL_CHECK();
   PLVS_HIP_TRY(exclusive_scan_u32(h->counts.p, h->counts.p, (size_t)n, &h->d_ctr->total_visits,
                                   h->scratch.p, s));
@@ -457,8 +480,12 @@ int plvs_hip_tsdf_voxblox_integrate_batch_dev(plvs_tsdf_voxblox* h, const float*
   PLVS_HIP_TRY(h->rec_c.reserve(V));
   PLVS_HIP_TRY(h->updated.reserve((size_t)h->num_blocks + 1));
   PLVS_HIP_TRY(h->scratch.reserve(radix_scratch_words(V)));
-  hipLaunchKernelGGL(vb_ray_pass<true>, rgrid, rblock, 0, s, h->P, d_xyz, n, h->offsets.p, nclouds,
-                     d_Twc, h->dir, h->d_ctr, h->counts.p, h->keys0.p, h->seq0.p);
+  if (d_normals != nullptr)
+    hipLaunchKernelGGL((vb_ray_pass<true, true>), rgrid, rblock, 0, s, h->P, d_xyz, d_normals, n, h->offsets.p, nclouds,
+                       d_Twc, h->dir, h->d_ctr, h->counts.p, h->keys0.p, h->seq0.p);
+  else
+    hipLaunchKernelGGL((vb_ray_pass<true, false>), rgrid, rblock, 0, s, h->P, d_xyz, d_normals, n, h->offsets.p, nclouds,
+                       d_Twc, h->dir, h->d_ctr, h->counts.p, h->keys0.p, h->seq0.p);
   PLVS_KERNEL_CHECK();
   int key_bits = 12;
   while ((1ll << (key_bits - 12)) < (long long)h->num_blocks) ++key_bits;
@@ -467,9 +494,14 @@ int plvs_hip_tsdf_voxblox_integrate_batch_dev(plvs_tsdf_voxblox* h, const float*
                                 h->scratch.p, s, &second));
   const uint32_t* keys = second ? h->keys1.p : h->keys0.p;
   const uint32_t* seqs = second ? h->seq1.p : h->seq0.p;
-  hipLaunchKernelGGL(vb_expand, dim3(ceil_div(V, kExpandThreads)), dim3(kExpandThreads), 0, s, h->P,
-                     keys, seqs, V, d_xyz, d_col, h->offsets.p, nclouds, d_Twc, h->dir.slot_ids,
-                     h->rec.p, h->rec_c.p, h->heads.p, h->updated.p, h->d_ctr);
+  if (d_normals != nullptr)
+    hipLaunchKernelGGL(vb_expand<true>, dim3(ceil_div(V, kExpandThreads)), dim3(kExpandThreads), 0, s, h->P,
+                       keys, seqs, V, d_xyz, d_normals, d_col, h->offsets.p, nclouds, d_Twc, h->dir.slot_ids,
+                       h->rec.p, h->rec_c.p, h->heads.p, h->updated.p, h->d_ctr);
+  else
+    hipLaunchKernelGGL(vb_expand<false>, dim3(ceil_div(V, kExpandThreads)), dim3(kExpandThreads), 0, s, h->P,
+                       keys, seqs, V, d_xyz, d_normals, d_col, h->offsets.p, nclouds, d_Twc, h->dir.slot_ids,
+                       h->rec.p, h->rec_c.p, h->heads.p, h->updated.p, h->d_ctr);
   PLVS_KERNEL_CHECK();
   hipLaunchKernelGGL(vb_chain, dim3(ceil_div(V, 256)), dim3(256), 0, s, h->P, keys, V, h->rec.p,
                      h->rec_c.p, h->heads.p, h->d_ctr, h->dist, h->weight, h->rgba);
@@ -486,6 +518,41 @@ int plvs_hip_tsdf_voxblox_integrate_batch_dev(plvs_tsdf_voxblox* h, const float*
   h->stats.max_run = (int32_t)h->h_ctr->max_run;
   h->last_updated = h->h_ctr->num_updated;
   return PLVS_OK;
+}
+
+extern "C" {
+
+int plvs_hip_tsdf_voxblox_integrate_batch_dev(plvs_tsdf_voxblox* h, const float* d_xyz,
+                                              const uint8_t* d_rgba, const int32_t* offsets,
+                                              int nclouds, const float* d_Twc, void* stream) {
+  return vb_integrate_impl(h, d_xyz, d_rgba, offsets, nclouds, d_Twc, stream, nullptr);
+}
+
+int plvs_hip_tsdf_voxblox_integrate_world_normals(plvs_tsdf_voxblox* h, const float* xyz, const uint8_t* rgba,
+                                                  const float* normals, int n, const float* Twc) {
+  PLVS_REQUIRE(h, "null handle");
+  PLVS_REQUIRE(n >= 0 && Twc, "bad arguments");
+  if (n == 0) {
+    h->stats = plvs_tsdf_stats{};
+    h->last_updated = 0;
+    return PLVS_OK;
+  }
+  PLVS_REQUIRE(xyz && rgba && normals, "null cloud pointer");
+  DevBuf<float> st_n;
+  PLVS_HIP_TRY(h->st_xyz.reserve((size_t)n * 3));
+  PLVS_HIP_TRY(h->st_rgba.reserve((size_t)n));
+  PLVS_HIP_TRY(h->st_Twc.reserve(12));
+  PLVS_HIP_TRY(st_n.reserve((size_t)n * 3));
+  PLVS_HIP_TRY(hipMemcpy(h->st_xyz.p, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(h->st_rgba.p, rgba, (size_t)n * 4, hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(st_n.p, normals, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(h->st_Twc.p, Twc, 12 * sizeof(float), hipMemcpyHostToDevice));
+  const int32_t offsets[2] = {0, n};
+  const int rc = vb_integrate_impl(h, h->st_xyz.p, reinterpret_cast<const uint8_t*>(h->st_rgba.p), offsets, 1, h->st_Twc.p,
+                                   nullptr, st_n.p);
+  (void)hipDeviceSynchronize();
+  st_n.release();
+  return rc;
 }
 
 int plvs_hip_tsdf_voxblox_integrate(plvs_tsdf_voxblox* h, const float* xyz, const uint8_t* rgba,

@@ -140,6 +140,39 @@ PLVS_HD bool make_ray(const Params& P, const PoseRt& pose, float px, float py, f
   return true;
 }
 
+// The world-cloud-with-normals flavour (TsdfIntegratorBase::integrateWorlPointCloud, tsdf_integrator.cc:35-82: what
+// PointCloudMapVoxblox::LoadMap integrates the saved cloud through): the ray point + n * truncation ->
+// point - n * truncation with n = T_G_C * normalized(normal) (the full transformation, as written there), through
+// RayCaster(start_scaled, end_scaled); ray_start takes the sensor origin's place in updateTsdfVoxel, weight 1.
+PLVS_HD void make_ray_world(const Params& P, const PoseRt& pose, float px, float py, float pz, float nx, float ny,
+                            float nz, Ray* r, float ray_start[3]) {
+  const float z2 = vsum3(nx * nx, ny * ny, nz * nz);
+  if (z2 > 0.0f) {
+    const float l = sqrtf(z2);
+    nx /= l; ny /= l; nz /= l;
+  }
+  float nG[3];
+  quat_transform(pose, px, py, pz, r->pG);
+  quat_transform(pose, nx, ny, nz, nG);
+  r->steps = 0;
+  for (int k = 0; k < 3; ++k) {
+    ray_start[k] = r->pG[k] + nG[k] * P.truncation;
+    const float re = r->pG[k] - nG[k] * P.truncation;
+    const float ss = ray_start[k] * P.voxel_size_inv, es = re * P.voxel_size_inv;
+    r->cur[k] = (int)floorf(ss + 1e-6f);
+    const int endk = (int)floorf(es + 1e-6f);
+    const int dk = endk - r->cur[k];
+    r->steps += dk < 0 ? -dk : dk;
+    const float ray = es - ss;
+    r->sgn[k] = (ray == 0) ? 0 : (ray < 0 ? -1 : 1);
+    const float corrected = (float)(r->sgn[k] > 0 ? r->sgn[k] : 0);
+    const float shifted = ss - (float)r->cur[k];
+    r->t_next[k] = (corrected - shifted) / ray;
+    r->t_step[k] = (float)r->sgn[k] / ray;
+  }
+  r->weight = 1.0f;
+}
+
 // RayCaster::nextRayIndex: returns the current voxel and advances.
 PLVS_HD void ray_step(Ray* r, int g[3]) {
   g[0] = r->cur[0]; g[1] = r->cur[1]; g[2] = r->cur[2];

@@ -345,6 +345,16 @@ class TsdfVoxblox:
         _lib.check(_L.plvs_hip_tsdf_voxblox_integrate(self._h, _lib.np_ptr(xyz), _lib.np_ptr(rgba), xyz.shape[0],
                                                       _lib.np_ptr(Twc)))
 
+    def integrate_world_normals(self, xyz, rgba, normals, Twc=None):
+        """TsdfIntegratorBase::integrateWorlPointCloud (the LoadMap path): a cloud with normals, T identity by default."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8).reshape(-1, 4)
+        normals = np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+        Twc = np.ascontiguousarray(np.eye(4, dtype=np.float32)[:3] if Twc is None else Twc, dtype=np.float32).reshape(3, 4)
+        f = _L.plvs_hip_tsdf_voxblox_integrate_world_normals
+        f.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p]
+        _lib.check(f(self._h, _lib.np_ptr(xyz), _lib.np_ptr(rgba), _lib.np_ptr(normals), xyz.shape[0], _lib.np_ptr(Twc)))
+
     def integrate_batch_dev(self, d_xyz, d_rgba, offsets, d_Twc):
         offsets = np.ascontiguousarray(offsets, dtype=np.int32)
         _lib.check(_L.plvs_hip_tsdf_voxblox_integrate_batch_dev(
@@ -434,6 +444,17 @@ class PointCloudMapVoxblox:
         self._tsdf.integrate(cloud_camera["xyz"], cloud_camera["rgba"], Twc)
         for b in self._tsdf.updated_chunk_ids():          # tsdf_integrator.cc:151
             self._updated.add((int(b[0]), int(b[1]), int(b[2])))
+
+    def LoadMap(self, cloud):
+        """LoadMap of a saved cloud once PointCloudMap::LoadMap has read it (src/PointCloudMapVoxblox.cc:233-258):
+        TsdfServer::insertWorldPointCloud(cloud, identity) — every point along its normal — then UpdateMap.  (The
+        `.proto` volume file of TsdfServer::loadMap is protobuf I/O on the host: not mirrored.)"""
+        xyz = np.stack([cloud["x"], cloud["y"], cloud["z"]], -1)
+        rgba = np.stack([cloud["r"], cloud["g"], cloud["b"], cloud["a"]], -1)
+        self._tsdf.integrate_world_normals(xyz, rgba, cloud["normal"])
+        for b in self._tsdf.updated_chunk_ids():
+            self._updated.add((int(b[0]), int(b[1]), int(b[2])))
+        return self.UpdateMap()
 
     # colorVoxbloxToMsg / colorMsgToVoxblox (voxblox_ros/conversions.h:44-60): a channel goes through a float in [0, 1]
     _CLOUD_COLOUR = ((np.arange(256) / 255.0).astype(np.float32).astype(np.float64) * 255.0).astype(np.uint8)

@@ -446,6 +446,17 @@ class _VoxbloxLike:
         Twc = np.ascontiguousarray(Twc, dtype=np.float32).reshape(3, 4)
         getattr(self.lib, self.p + "_integrate")(self.h, _ptr(xyz), _ptr(rgba), xyz.shape[0], _ptr(Twc))
 
+    def integrate_world_normals(self, xyz, rgba, normals, Twc=None):
+        """TsdfIntegratorBase::integrateWorlPointCloud (oracle only)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        normals = np.ascontiguousarray(normals, dtype=np.float32)
+        Twc = np.ascontiguousarray(np.eye(4, dtype=np.float32)[:3] if Twc is None else Twc, dtype=np.float32).reshape(3, 4)
+        f = getattr(self.lib, self.p + "_integrate_world_normals")
+        f.restype = None
+        f.argtypes = [_vp] * 4 + [_i, _vp]
+        f(self.h, _ptr(xyz), _ptr(rgba), _ptr(normals), xyz.shape[0], _ptr(Twc))
+
     def last_visits(self):
         return int(getattr(self.lib, self.p + "_last_visits")(self.h))
 

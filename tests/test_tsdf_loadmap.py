@@ -131,3 +131,70 @@ def test_save_load_round_trip_through_the_mirror(oracle):
     cells = key(saved)
     grown = {(a + dx, b + dy, c + dz) for (a, b, c) in cells for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1)}
     assert len(key(reloaded) - grown) < 0.01 * len(key(reloaded))
+
+
+# ---------------------------------------------------------------- voxblox
+def test_oracle_voxblox_world_normals_properties(oracle):
+    vs, trunc = 0.05, 0.1
+    m = oracle.voxblox(vs)
+    xyz, rgb, _, nrm = surface_cloud(3000, 5, vs)
+    keep = np.linalg.norm(nrm, axis=1) > 0                        # (a zero normal makes 0 / 0 distances: separate case)
+    xyz, rgb, nrm = xyz[keep], rgb[keep], nrm[keep]
+    rgba = np.concatenate([rgb, np.full((len(rgb), 1), 255, np.uint8)], 1)
+    m.integrate_world_normals(xyz, rgba, nrm)
+    # a ray of 2 * truncation = 4 voxels: 4 to 8 voxels per point, every one updated with weight 1 (no drop-off in
+    # front of the surface; behind it the drop-off scales the weight down)
+    assert 3.5 * len(xyz) < m.last_visits() < 8.5 * len(xyz)
+    for bid in m.chunk_ids():
+        d, w, c = m.get_chunk(*bid)
+        hit = w > 0
+        assert (np.abs(d[hit]) <= np.float32(trunc)).all()
+    # the camera-ray flavour drops points closer than min_ray_length; this one has no such test
+    near = (np.linalg.norm(xyz, axis=1) < 2.0).sum()
+    assert near > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("vs,n", [(0.05, 30000), (0.10, 20000), (0.02, 10000)])
+def test_hip_voxblox_world_normals_matches_oracle(oracle, vs, n):
+    from plvs_amd.tsdf import TsdfVoxblox
+    ref, hip = oracle.voxblox(vs), TsdfVoxblox(vs, max_blocks=65536)
+    for k in make_keyframes(2, seed=4):                           # onto a map with camera-ray history
+        rgba = np.concatenate([k["rgb"], np.full((len(k["rgb"]), 1), 255, np.uint8)], 1)
+        ref.integrate(k["xyz"], rgba, k["Twc"])
+        hip.integrate(k["xyz"], rgba, k["Twc"])
+    T = np.array([[0.0, -1.0, 0.0, 0.3], [1.0, 0.0, 0.0, -0.2], [0.0, 0.0, 1.0, 0.1]], np.float32)
+    for seed, pose in ((1, None), (2, T), (3, None)):
+        xyz, rgb, _, nrm = surface_cloud(n, seed, vs)             # zero normals included: NaN distances, handled alike
+        rgba = np.concatenate([rgb, np.full((len(rgb), 1), 200, np.uint8)], 1)
+        ref.integrate_world_normals(xyz, rgba, nrm, pose)
+        hip.integrate_world_normals(xyz, rgba, nrm, pose)
+        assert hip.last_stats()["visits"] == ref.last_visits()
+    ids = sorted(tuple(int(v) for v in b) for b in ref.chunk_ids())
+    assert ids == sorted(tuple(int(v) for v in b) for b in hip.chunk_ids())
+    for bid in ids:
+        for name, x, y in zip(("distance", "weight", "colour"), ref.get_chunk(*bid), hip.get_chunk(*bid)):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (name, bid)
+    hip.close()
+
+
+@pytest.mark.gpu
+def test_voxblox_save_load_round_trip_through_the_mirror(oracle):
+    from plvs_amd.tsdf import PointCloudMapVoxblox
+    pm = PointCloudMapVoxblox(0.05)
+    for k in make_keyframes(3, seed=6):
+        rgba = np.concatenate([k["rgb"], np.full((len(k["rgb"]), 1), 255, np.uint8)], 1)
+        pm.InsertCloud(dict(xyz=k["xyz"], rgba=rgba), k["Twc"])
+    saved = pm.UpdateMap()
+    assert len(saved) > 8000
+    fresh = PointCloudMapVoxblox(0.05)
+    reloaded = fresh.LoadMap(saved)
+    ref = oracle.voxblox(0.05)
+    ref.integrate_world_normals(np.stack([saved["x"], saved["y"], saved["z"]], -1),
+                                np.stack([saved["r"], saved["g"], saved["b"], saved["a"]], -1), saved["normal"])
+    ids = sorted(tuple(int(v) for v in b) for b in ref.chunk_ids())
+    assert ids == sorted(tuple(int(v) for v in b) for b in fresh.tsdf.chunk_ids())
+    for bid in ids:
+        for x, y in zip(ref.get_chunk(*bid), fresh.tsdf.get_chunk(*bid)):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), bid
+    assert len(reloaded) > 0.3 * len(saved)
