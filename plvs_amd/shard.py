@@ -32,22 +32,26 @@ def allgather_block_lists(local_ids, count, cap, group=None, padded=False):
 
     local_ids: int32 tensor [cap, 3] (cpu for gloo, cuda for nccl) whose first
     `count` rows are valid.  Returns a list (one per rank) of int32 tensors
-    [n_r, 3] on the same device.  Two fixed-size collectives: counts, then the
-    padded lists (a few KB: latency-bound on xGMI, so one fused pair per call)."""
+    [n_r, 3] on the same device.  ONE fixed-size collective: every rank contributes its
+    padded list with the count in a row of its own behind it (small messages are
+    latency-bound on xGMI: a second collective for the counts would double the cost)."""
     world = dist.get_world_size(group)
     dev = local_ids.device
     if int(count) > cap or cap > local_ids.shape[0]:
         # a clamped list would silently drop block ids from every other rank's directory
         raise ValueError(f"allgather_block_lists: {count} updated blocks do not fit the {cap}-row buffer "
                          f"(size it to the map's block capacity)")
-    cnt = torch.tensor([int(count)], dtype=torch.int32, device=dev)
-    cnts = [torch.zeros_like(cnt) for _ in range(world)]
-    lists = [torch.zeros_like(local_ids) for _ in range(world)]
-    dist.all_gather(cnts, cnt, group=group)
-    dist.all_gather(lists, local_ids, group=group)
-    if padded:      # the layout plvs_hip_block_directory_merge reads: [world, cap, 3] ids + [world] counts
-        return torch.stack(lists).contiguous(), torch.cat(cnts).contiguous()
-    return [lists[r][: int(cnts[r].item())] for r in range(world)]
+    mine = torch.empty((cap + 1, 3), dtype=torch.int32, device=dev)
+    mine[:cap] = local_ids[:cap]
+    mine[cap] = torch.tensor([int(count), 0, 0], dtype=torch.int32)
+    flat = torch.empty((world * (cap + 1), 3), dtype=torch.int32, device=dev)   # (the concatenated form: gloo takes no other)
+    dist.all_gather_into_tensor(flat, mine, group=group)
+    gathered = flat.view(world, cap + 1, 3)
+    counts = gathered[:, cap, 0].contiguous()
+    if padded:      # the layout plvs_hip_block_directory_merge reads: [world, rows, 3] ids + [world] counts
+        return gathered, counts
+    c = counts.cpu()
+    return [gathered[r, : int(c[r])] for r in range(world)]
 
 
 def exchange_segments(send_seg, send_rec, send_run, send_counts, group=None):
@@ -55,22 +59,42 @@ def exchange_segments(send_seg, send_rec, send_run, send_counts, group=None):
 
     send_seg [S, 8], send_rec [R, 8], send_run [U, 20] int32 tensors grouped by destination rank in rank order,
     send_counts [world, 3] (descriptors, voxel sums, runs per destination).  Returns (recv_seg, recv_rec, recv_run,
-    recv_counts) grouped by source rank.  Four collectives: the counts, then the three payloads
-    (all_to_all_single with split sizes — RCCL send/recv pairs over xGMI on GPUs, gloo in the CPU tests)."""
-    world = dist.get_world_size(group)
+    recv_counts) grouped by source rank.  Two collectives: the counts, then ONE group of point-to-point
+    operations carrying the three payloads of every pair of ranks (RCCL: a single grouped launch of ncclSend /
+    ncclRecv pairs over xGMI — what an all-to-all is made of; gloo in the CPU tests); a rank's messages to itself
+    are copies."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = send_seg.device
     send_counts = np.ascontiguousarray(send_counts, dtype=np.int64).reshape(world, 3)
     sc = torch.from_numpy(send_counts.copy()).to(dev)
     rc = torch.zeros_like(sc)
     dist.all_to_all_single(rc, sc, group=group)
     recv_counts = rc.cpu().numpy()
-    out = []
-    for k, (buf, width) in enumerate(((send_seg, 8), (send_rec, 8), (send_run, 20))):
-        recv = torch.zeros((int(recv_counts[:, k].sum()), width), dtype=buf.dtype, device=dev)
-        dist.all_to_all_single(recv, buf.reshape(-1, width), output_split_sizes=[int(c) for c in recv_counts[:, k]],
-                               input_split_sizes=[int(c) for c in send_counts[:, k]], group=group)
-        out.append(recv)
-    return out[0], out[1], out[2], recv_counts
+    send = [send_seg.reshape(-1, 8), send_rec.reshape(-1, 8), send_run.reshape(-1, 20)]
+    recv = [torch.empty((int(recv_counts[:, k].sum()), w), dtype=send[k].dtype, device=dev) for k, w in enumerate((8, 8, 20))]
+    so, ro, ops = [0, 0, 0], [0, 0, 0], []
+    for p in range(world):
+        for k in range(3):
+            ns, nr = int(send_counts[p, k]), int(recv_counts[p, k])
+            if p == rank:
+                assert ns == nr
+                if ns:
+                    recv[k][ro[k]:ro[k] + nr].copy_(send[k][so[k]:so[k] + ns])
+            else:       # both sides skip an empty message: the pairing of sends and receives stays in step
+                peer = p if group is None else dist.get_global_rank(group, p)
+                if ns:
+                    ops.append(dist.P2POp(dist.isend, send[k][so[k]:so[k] + ns], peer, group))
+                if nr:
+                    ops.append(dist.P2POp(dist.irecv, recv[k][ro[k]:ro[k] + nr], peer, group))
+            so[k] += ns
+            ro[k] += nr
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return recv[0], recv[1], recv[2], recv_counts
+
+
+SAT_ROWS = 65536      # newly saturated voxels a rank reports per step (16 B each); a longer list waits for the next step
 
 
 def sharded_integrate(tsdf, d_xyz, d_rgb, d_kfid, offsets, d_Twc, group=None):
@@ -78,27 +102,32 @@ def sharded_integrate(tsdf, d_xyz, d_rgb, d_kfid, offsets, d_Twc, group=None):
     world = dist.get_world_size(group)
     counts = tsdf.shard_walk(d_xyz, offsets, d_Twc)
     dev = d_xyz.device
-    seg = torch.zeros((int(counts[:, 0].sum()), 8), dtype=torch.int32, device=dev)
-    rec = torch.zeros((int(counts[:, 1].sum()), 8), dtype=torch.int32, device=dev)
-    run = torch.zeros((int(counts[:, 2].sum()), 20), dtype=torch.int32, device=dev)
+    seg = torch.empty((int(counts[:, 0].sum()), 8), dtype=torch.int32, device=dev)    # (shard_pack fills every row)
+    rec = torch.empty((int(counts[:, 1].sum()), 8), dtype=torch.int32, device=dev)
+    run = torch.empty((int(counts[:, 2].sum()), 20), dtype=torch.int32, device=dev)
     tsdf.shard_pack(seg, rec, run)
     rseg, rrec, rrun, rcounts = exchange_segments(seg, rec, run, counts, group)
     tsdf.shard_apply(rseg, rrec, rrun, rcounts, d_rgb, d_kfid)
-    # voxels whose colour saturated in this call: every rank stops sending their runs
+    # voxels whose colour saturated in this call: every rank stops sending their runs.  One fixed-size all-gather
+    # (list + its length in a last row); the list is advisory — a run sent for a saturated voxel is a no-op at its
+    # owner — so what does not fit waits for the next step.
     sat = tsdf.shard_saturated()
-    n = torch.tensor([sat.shape[0]], dtype=torch.int64, device=dev)
-    ns = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(ns, n, group=group)
-    cap = max(int(x.item()) for x in ns)
-    if cap > 0:
-        pad = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
-        pad[: sat.shape[0]] = sat
-        lists = [torch.zeros_like(pad) for _ in range(world)]
-        dist.all_gather(lists, pad, group=group)
-        for r in range(world):
-            k = int(ns[r].item())
-            if k:
-                tsdf.shard_note_saturated(lists[r][:k].contiguous())
+    backlog = getattr(tsdf, "_sat_backlog", None)
+    if backlog is not None and backlog.shape[0]:
+        sat = torch.cat([backlog, sat])
+    k = min(int(sat.shape[0]), SAT_ROWS)
+    tsdf._sat_backlog = sat[k:].clone() if sat.shape[0] > k else None
+    mine = torch.empty((SAT_ROWS + 1, 4), dtype=torch.int32, device=dev)       # (rows past k are never read)
+    if k:
+        mine[:k] = sat[:k]
+    mine[SAT_ROWS] = torch.tensor([k, 0, 0, 0], dtype=torch.int32)
+    flat = torch.empty((world * (SAT_ROWS + 1), 4), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(flat, mine, group=group)
+    gathered = flat.view(world, SAT_ROWS + 1, 4)
+    ks = gathered[:, SAT_ROWS, 0].cpu()
+    for r in range(world):
+        if int(ks[r]):
+            tsdf.shard_note_saturated(gathered[r, : int(ks[r])])
     return counts
 
 
