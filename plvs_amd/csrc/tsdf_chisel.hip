@@ -1837,8 +1837,10 @@ bool chisel_map_view(plvs_tsdf_chisel* h, ChiselMapView* v) {
   v->ext_free = &h->ext_free;
   if (h->P.shard_count > 1) {
     if (h->miss_keys == nullptr) {
-      // every chunk of the whole map could be asked for: as many entries as the walk directory may hold
-      const size_t want = std::min<size_t>((size_t)h->prm.max_chunks * (size_t)h->P.shard_count, (size_t)1 << 22);
+      // every chunk of the whole map could be asked for, and many ids that exist nowhere (InterpolateColor's look-ups at
+      // voxel indices used as metres reach ~20 chunk widths: thousands of distinct ids per call): at least 2^18 entries
+      const size_t want = std::max<size_t>(std::min<size_t>((size_t)h->prm.max_chunks * (size_t)h->P.shard_count, (size_t)1 << 22),
+                                           (size_t)1 << 18);
       size_t cap = 1024;
       while (cap < 2 * want) cap <<= 1;
       if (hipMalloc(&h->miss_keys, cap * sizeof(unsigned long long)) != hipSuccess) return false;
@@ -2059,16 +2061,19 @@ int plvs_hip_tsdf_chisel_halo_import(plvs_tsdf_chisel* h, const int32_t* d_ids_x
   }
   if (h->gdir.keys == nullptr) {
     // entries are foreign chunks that exist (at most the pool's worth) and ids that exist nowhere (the colour look-up's
-    // reach: a few thousand per call) — sized like the miss set, which bounds what one handle can ever ask for
-    size_t cap = (size_t)h->miss_mask + 1;
-    if (cap < 1024) cap = 1024;
-    while (cap < 2 * (size_t)h->prm.max_chunks) cap <<= 1;
+    // reach: thousands per call), kept until the next integrate call: twice the miss set's table
+    size_t cap = 2 * std::max<size_t>((size_t)h->miss_mask + 1, (size_t)1 << 19);
+    while (cap < 4 * (size_t)h->prm.max_chunks) cap <<= 1;
     PLVS_HIP_TRY(hipMalloc(&h->gdir.keys, cap * sizeof(unsigned long long)));
     PLVS_HIP_TRY(hipMalloc(&h->gdir.slots, cap * sizeof(int32_t)));
     h->gdir.slot_ids = nullptr;
     h->gdir.mask = (uint32_t)(cap - 1);
     h->gdir.max_blocks = h->prm.max_chunks;
     PLVS_HIP_TRY(hipMemsetAsync(h->gdir.keys, 0xFF, cap * sizeof(unsigned long long), s));
+  }
+  if ((size_t)h->ghost_entries + (size_t)n > ((size_t)h->gdir.mask + 1) / 2) {
+    plvs::set_error("halo_import: %lld + %d entries exceed the ghost directory (halo_clear drops them)", h->ghost_entries, n);
+    return PLVS_ERR_CAPACITY;
   }
   const int base = h->num_chunks + h->ghost_count;
   PLVS_HIP_TRY(h->halo_row.reserve((size_t)n));
