@@ -807,10 +807,30 @@ int plvs_hip_tsdf_voxblox_download_block(plvs_tsdf_voxblox* h, int bx, int by, i
  * (n x 3 f32; three consecutive vertices are one triangle, Mesh::indices is 0 .. n-1) and colors (n x 4 u8:
  * Color r, g, b, a); block c owns [block_first[c], block_first[c+1]) (block_first: nblocks + 1 ints); a block
  * that does not exist owns nothing.  *nvertices = n.  If n > capacity nothing is written but block_first /
- * *nvertices, and PLVS_ERR_CAPACITY is returned.  Needs the whole map on one device (shard_count <= 1). */
+ * *nvertices, and PLVS_ERR_CAPACITY is returned.  Sharded map (shard_count > 1): the list holds blocks of THIS rank
+ * (another rank's block owns nothing); the cubes on a block's +x / +y / +z faces read up to seven neighbour blocks,
+ * which the caller brings in first from their owners (plvs_hip_tsdf_voxblox_halo_* below; a neighbour that was not
+ * brought in counts as non-existent). */
 int plvs_hip_tsdf_voxblox_mesh_blocks(plvs_tsdf_voxblox* h, const int32_t* block_ids_xyz, int nblocks,
                                       float* vertices, float* normals, uint8_t* colors_rgba, int capacity,
                                       int32_t* block_first, int* nvertices);
+
+/* Halo of a sharded voxblox map, for meshing.  The ids to fetch are known on the host: the seven +x / +y / +z
+ * neighbours of every block to mesh that another rank owns (three-prime block hash mod shard_count).
+ *   halo_lookup   owner side: d_found[i] = 1 if this rank has the i-th of the n requested ids (device, n x 3).
+ *   halo_export   owner side: the found blocks' three planes (distance, weight, rgba: 4096 words each = one payload
+ *                 row of 12288 words), packed in request order (rows = number of flags set; may be null when none is).
+ *   halo_import   requester side: ids / found flags / nfound payload rows become ghost blocks (read-only copies in
+ *                 free pool slots).  PLVS_ERR_CAPACITY if the pool has fewer than nfound free slots.
+ *   halo_clear    drops every ghost (also done by the next integrate / clear call).
+ * All asynchronous on `stream` but halo_clear.  plvs_amd/shard.py: sharded_mesh_blocks runs the exchange over
+ * torch.distributed. */
+int plvs_hip_tsdf_voxblox_halo_lookup(plvs_tsdf_voxblox* h, const int32_t* d_ids_xyz, int n, uint32_t* d_found, void* stream);
+int plvs_hip_tsdf_voxblox_halo_export(plvs_tsdf_voxblox* h, const int32_t* d_ids_xyz, const uint32_t* d_found, int n,
+                                      uint32_t* d_payload, void* stream);
+int plvs_hip_tsdf_voxblox_halo_import(plvs_tsdf_voxblox* h, const int32_t* d_ids_xyz, const uint32_t* d_found,
+                                      const uint32_t* d_payload, int n, int nfound, void* stream);
+int plvs_hip_tsdf_voxblox_halo_clear(plvs_tsdf_voxblox* h);
 
 #ifdef __cplusplus
 }

@@ -285,6 +285,10 @@ struct plvs_tsdf_voxblox {
   uint32_t last_updated = 0;
   void* ext = nullptr;                 // meshing scratch (tsdf_voxblox_mesh.hip), freed with the map
   void (*ext_free)(void*) = nullptr;
+  // halo of a sharded map (meshing): ghost copies of other ranks' blocks in the pool slots past num_blocks
+  Directory gdir{};
+  int ghost_count = 0;
+  DevBuf<uint32_t> halo_row;
 };
 
 namespace plvs {
@@ -300,6 +304,7 @@ bool voxblox_map_view(plvs_tsdf_voxblox* h, VoxbloxMapView* v) {
   v->rgba = h->rgba;
   v->num_blocks = h->num_blocks;
   v->shard_count = h->P.shard_count;
+  v->ghost = h->gdir;
   v->ext = &h->ext;
   v->ext_free = &h->ext_free;
   return true;
@@ -337,6 +342,8 @@ int plvs_hip_tsdf_voxblox_default_params(float voxel_size, int use_carving,
 int plvs_hip_tsdf_voxblox_destroy(plvs_tsdf_voxblox* h) {
   if (!h) return PLVS_OK;
   if (h->ext && h->ext_free) h->ext_free(h->ext);
+  (void)hipFree(h->gdir.keys); (void)hipFree(h->gdir.slots);
+  h->halo_row.release();
   (void)hipFree(h->dir.keys); (void)hipFree(h->dir.slots); (void)hipFree(h->dir.slot_ids);
   (void)hipFree(h->dist); (void)hipFree(h->weight); (void)hipFree(h->rgba); (void)hipFree(h->d_ctr);
   if (h->h_ctr) (void)hipHostFree(h->h_ctr);
@@ -349,6 +356,8 @@ int plvs_hip_tsdf_voxblox_destroy(plvs_tsdf_voxblox* h) {
 
 int plvs_hip_tsdf_voxblox_clear(plvs_tsdf_voxblox* h) {
   PLVS_REQUIRE(h, "null handle");
+  if (h->gdir.keys != nullptr) PLVS_HIP_TRY(hipMemset(h->gdir.keys, 0xFF, ((size_t)h->gdir.mask + 1) * sizeof(unsigned long long)));
+  h->ghost_count = 0;
   const size_t cap = (size_t)h->dir.mask + 1;
   const size_t nvox = (size_t)h->prm.max_blocks * kBlockVox;
   PLVS_HIP_TRY(hipMemset(h->dir.keys, 0xFF, cap * sizeof(unsigned long long)));
@@ -419,6 +428,193 @@ int plvs_hip_tsdf_voxblox_create(const plvs_tsdf_voxblox_params* p, plvs_tsdf_vo
 
 }  // extern "C"
 
+// ------------------------------------------------------------------ halo of a sharded map (meshing)
+// A block's mesh reads its +x / +y / +z neighbour blocks (mesh_integrator.h:299-337), which block-hash sharding
+// puts on other ranks: the caller asks their owners for them (the ids are known on the host: the seven neighbours of
+// every block it meshes), the owners answer with found flags and one payload row per block that exists (three planes
+// of 4096 words: distance, weight, rgba), the rows become ghost blocks past num_blocks until the next integrate call.
+namespace {
+
+constexpr int kVbHaloWords = 3 * kBlockVox;
+
+__global__ void vb_halo_lookup(Directory dir, const int32_t* __restrict__ ids, int n, uint32_t* __restrict__ found) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) found[i] = dir_find(dir, ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]) >= 0 ? 1u : 0u;
+}
+
+// row[i] = number of found blocks before request i (one workgroup).
+__global__ __launch_bounds__(1024) void vb_halo_rows(const uint32_t* __restrict__ found, int n, uint32_t* __restrict__ row) {
+  __shared__ uint32_t s_part[1024];
+  const int per = (n + 1023) / 1024;
+  const int lo = min((int)threadIdx.x * per, n), hi = min(lo + per, n);
+  uint32_t sum = 0;
+  for (int i = lo; i < hi; ++i) sum += found[i] ? 1u : 0u;
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const uint32_t add = threadIdx.x >= (unsigned)d ? s_part[threadIdx.x - d] : 0u;
+    __syncthreads();
+    s_part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  uint32_t run = s_part[threadIdx.x] - sum;
+  for (int i = lo; i < hi; ++i) {
+    row[i] = run;
+    run += found[i] ? 1u : 0u;
+  }
+}
+
+__global__ __launch_bounds__(256) void vb_halo_export(Directory dir, const float* __restrict__ dist,
+                                                      const float* __restrict__ weight, const uint32_t* __restrict__ rgba,
+                                                      const int32_t* __restrict__ ids, const uint32_t* __restrict__ found,
+                                                      const uint32_t* __restrict__ row, uint32_t* __restrict__ payload) {
+  const int i = blockIdx.x;
+  if (!found[i]) return;
+  __shared__ int s_slot;
+  if (threadIdx.x == 0) s_slot = dir_find(dir, ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]);
+  __syncthreads();
+  const int slot = s_slot;
+  if (slot < 0) return;
+  const size_t src = (size_t)slot * kBlockVox;
+  uint4* dst = reinterpret_cast<uint4*>(payload + (size_t)row[i] * kVbHaloWords);
+  const uint4* p0 = reinterpret_cast<const uint4*>(dist + src);
+  const uint4* p1 = reinterpret_cast<const uint4*>(weight + src);
+  const uint4* p2 = reinterpret_cast<const uint4*>(rgba + src);
+  for (int v = threadIdx.x; v < kBlockVox / 4; v += 256) {
+    dst[v] = p0[v];
+    dst[kBlockVox / 4 + v] = p1[v];
+    dst[2 * (kBlockVox / 4) + v] = p2[v];
+  }
+}
+
+// id -> ghost slot (base + payload row); a block nobody has gets no entry (the look-up then says "does not exist").
+__global__ void vb_halo_insert(Directory g, const int32_t* __restrict__ ids, const uint32_t* __restrict__ found,
+                               const uint32_t* __restrict__ row, int n, int base) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !found[i]) return;
+  const int x = ids[3 * i], y = ids[3 * i + 1], z = ids[3 * i + 2];
+  unsigned long long key;
+  if (!pack_block(x, y, z, &key)) return;
+  uint32_t hsh = dir_hash(x, y, z, g.mask);
+  for (uint32_t probe = 0; probe <= g.mask; ++probe) {
+    unsigned long long cur = g.keys[hsh];
+    if (cur == key) return;
+    if (cur == kEmptyKey) {
+      cur = atomicCAS(&g.keys[hsh], kEmptyKey, key);
+      if (cur == kEmptyKey) {
+        g.slots[hsh] = base + (int)row[i];
+        return;
+      }
+      if (cur == key) return;
+    }
+    hsh = (hsh + 1) & g.mask;
+  }
+}
+
+__global__ __launch_bounds__(256) void vb_halo_import(float* __restrict__ dist, float* __restrict__ weight,
+                                                      uint32_t* __restrict__ rgba, const uint32_t* __restrict__ found,
+                                                      const uint32_t* __restrict__ row, const uint32_t* __restrict__ payload,
+                                                      int base) {
+  const int i = blockIdx.x;
+  if (!found[i]) return;
+  const size_t dst = (size_t)(base + (int)row[i]) * kBlockVox;
+  const uint4* src = reinterpret_cast<const uint4*>(payload + (size_t)row[i] * kVbHaloWords);
+  uint4* p0 = reinterpret_cast<uint4*>(dist + dst);
+  uint4* p1 = reinterpret_cast<uint4*>(weight + dst);
+  uint4* p2 = reinterpret_cast<uint4*>(rgba + dst);
+  for (int v = threadIdx.x; v < kBlockVox / 4; v += 256) {
+    p0[v] = src[v];
+    p1[v] = src[kBlockVox / 4 + v];
+    p2[v] = src[2 * (kBlockVox / 4) + v];
+  }
+}
+
+}  // namespace
+
+// Drops the ghosts: the integrate calls allocate new blocks in the slots they occupy (never-used slots are all zero).
+static int vb_halo_drop(plvs_tsdf_voxblox* h, hipStream_t s) {
+  if (h->ghost_count == 0) return PLVS_OK;
+  const size_t at = (size_t)h->num_blocks * kBlockVox, len = (size_t)h->ghost_count * kBlockVox;
+  PLVS_HIP_TRY(hipMemsetAsync(h->dist + at, 0, len * sizeof(float), s));
+  PLVS_HIP_TRY(hipMemsetAsync(h->weight + at, 0, len * sizeof(float), s));
+  PLVS_HIP_TRY(hipMemsetAsync(h->rgba + at, 0, len * sizeof(uint32_t), s));
+  PLVS_HIP_TRY(hipMemsetAsync(h->gdir.keys, 0xFF, ((size_t)h->gdir.mask + 1) * sizeof(unsigned long long), s));
+  h->ghost_count = 0;
+  return PLVS_OK;
+}
+
+extern "C" {
+
+int plvs_hip_tsdf_voxblox_halo_lookup(plvs_tsdf_voxblox* h, const int32_t* d_ids_xyz, int n, uint32_t* d_found, void* stream) {
+  PLVS_REQUIRE(h && !h->poisoned, "unusable handle");
+  PLVS_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return PLVS_OK;
+  PLVS_REQUIRE(d_ids_xyz && d_found, "null argument");
+  hipLaunchKernelGGL(vb_halo_lookup, dim3(ceil_div((size_t)n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), h->dir,
+                     d_ids_xyz, n, d_found);
+  PLVS_KERNEL_CHECK();
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_voxblox_halo_export(plvs_tsdf_voxblox* h, const int32_t* d_ids_xyz, const uint32_t* d_found, int n,
+                                      uint32_t* d_payload, void* stream) {
+  PLVS_REQUIRE(h && !h->poisoned, "unusable handle");
+  PLVS_REQUIRE(n >= 0, "negative size");
+  if (n == 0 || d_payload == nullptr) return PLVS_OK;   // (no payload buffer: the caller saw no flag set)
+  PLVS_REQUIRE(d_ids_xyz && d_found, "null argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  PLVS_HIP_TRY(h->halo_row.reserve((size_t)n));
+  hipLaunchKernelGGL(vb_halo_rows, dim3(1), dim3(1024), 0, s, d_found, n, h->halo_row.p);
+  hipLaunchKernelGGL(vb_halo_export, dim3((unsigned)n), dim3(256), 0, s, h->dir, h->dist, h->weight, h->rgba, d_ids_xyz,
+                     d_found, h->halo_row.p, d_payload);
+  PLVS_KERNEL_CHECK();
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_voxblox_halo_import(plvs_tsdf_voxblox* h, const int32_t* d_ids_xyz, const uint32_t* d_found,
+                                      const uint32_t* d_payload, int n, int nfound, void* stream) {
+  PLVS_REQUIRE(h && !h->poisoned, "unusable handle");
+  PLVS_REQUIRE(n >= 0 && nfound >= 0 && nfound <= n, "bad sizes");
+  if (n == 0 || nfound == 0) return PLVS_OK;
+  PLVS_REQUIRE(d_ids_xyz && d_found && d_payload, "null argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if ((long long)h->num_blocks + h->ghost_count + nfound > (long long)h->prm.max_blocks) {
+    plvs::set_error("halo_import: %d own + %d ghost + %d new blocks exceed the pool (%d)", h->num_blocks, h->ghost_count, nfound,
+                    h->prm.max_blocks);
+    return PLVS_ERR_CAPACITY;
+  }
+  if (h->gdir.keys == nullptr) {
+    size_t cap = 1024;
+    while (cap < 2 * (size_t)h->prm.max_blocks) cap <<= 1;
+    PLVS_HIP_TRY(hipMalloc(&h->gdir.keys, cap * sizeof(unsigned long long)));
+    PLVS_HIP_TRY(hipMalloc(&h->gdir.slots, cap * sizeof(int32_t)));
+    h->gdir.slot_ids = nullptr;
+    h->gdir.mask = (uint32_t)(cap - 1);
+    h->gdir.max_blocks = h->prm.max_blocks;
+    PLVS_HIP_TRY(hipMemsetAsync(h->gdir.keys, 0xFF, cap * sizeof(unsigned long long), s));
+  }
+  const int base = h->num_blocks + h->ghost_count;
+  PLVS_HIP_TRY(h->halo_row.reserve((size_t)n));
+  hipLaunchKernelGGL(vb_halo_rows, dim3(1), dim3(1024), 0, s, d_found, n, h->halo_row.p);
+  hipLaunchKernelGGL(vb_halo_insert, dim3(ceil_div((size_t)n, 256)), dim3(256), 0, s, h->gdir, d_ids_xyz, d_found, h->halo_row.p, n,
+                     base);
+  hipLaunchKernelGGL(vb_halo_import, dim3((unsigned)n), dim3(256), 0, s, h->dist, h->weight, h->rgba, d_found, h->halo_row.p,
+                     d_payload, base);
+  PLVS_KERNEL_CHECK();
+  h->ghost_count += nfound;
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_voxblox_halo_clear(plvs_tsdf_voxblox* h) {
+  PLVS_REQUIRE(h, "null handle");
+  int rc = vb_halo_drop(h, nullptr);
+  if (rc != PLVS_OK) return rc;
+  PLVS_HIP_TRY(hipStreamSynchronize(nullptr));
+  return PLVS_OK;
+}
+
+}  // extern "C"
+
 // d_normals != nullptr: the world-cloud-with-normals flavour (integrateWorlPointCloud), one cloud.
 static int vb_integrate_impl(plvs_tsdf_voxblox* h, const float* d_xyz, const uint8_t* d_rgba, const int32_t* offsets,
                              int nclouds, const float* d_Twc, void* stream, const float* d_normals) {
@@ -436,6 +632,10 @@ static int vb_integrate_impl(plvs_tsdf_voxblox* h, const float* d_xyz, const uin
   if (n == 0) return PLVS_OK;
   PLVS_REQUIRE(d_xyz && d_rgba && d_Twc, "null device pointer");
   PLVS_REQUIRE((reinterpret_cast<uintptr_t>(d_rgba) & 3) == 0, "rgba must be 4-byte aligned");
+  {
+    int rc = vb_halo_drop(h, s);   // new blocks go into the pool slots a meshing halo may still occupy
+    if (rc != PLVS_OK) return rc;
+  }
   const uint32_t* d_col = reinterpret_cast<const uint32_t*>(d_rgba);
 
   PLVS_HIP_TRY(h->offsets.reserve((size_t)nclouds + 1));

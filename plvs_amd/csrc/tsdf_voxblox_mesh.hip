@@ -74,6 +74,13 @@ struct Cube {
   int index;   // vertex configuration; 0 = nothing to emit (also: an unobserved corner)
 };
 
+// Block id -> pool slot: the rank's own blocks, then the ghosts of a sharded map's halo.
+__device__ __forceinline__ int find_block(const VoxbloxMapView& m, int bx, int by, int bz) {
+  const int s = dir_find(m.dir, bx, by, bz);
+  if (s >= 0 || m.ghost.keys == nullptr) return s;
+  return dir_find(m.ghost, bx, by, bz);
+}
+
 __device__ __forceinline__ void load_cube(const VoxbloxMapView& m, int slot, int bx, int by, int bz, int x, int y,
                                           int z, Cube* c) {
   c->index = 0;
@@ -97,7 +104,7 @@ __device__ __forceinline__ void load_cube(const VoxbloxMapView& m, int slot, int
       for (int j = 1; j < 8; ++j)
         if (j == which) cached = nslot[j];
       if (cached == -2) {
-        cached = dir_find(m.dir, bx + ox, by + oy, bz + oz);
+        cached = find_block(m, bx + ox, by + oy, bz + oz);
 #pragma unroll
         for (int j = 1; j < 8; ++j)
           if (j == which) nslot[j] = cached;
@@ -279,7 +286,6 @@ extern "C" int plvs_hip_tsdf_voxblox_mesh_blocks(plvs_tsdf_voxblox* h, const int
     plvs::set_error("mesh_blocks: the map handle is unusable");
     return PLVS_ERR_INVALID_ARG;
   }
-  PLVS_REQUIRE(m.shard_count <= 1, "meshing needs the whole map on one device (neighbour blocks of other shards are missing)");
 
   if (*m.ext == nullptr) {
     *m.ext = new MeshScratch();

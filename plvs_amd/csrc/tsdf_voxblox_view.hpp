@@ -20,6 +20,9 @@ struct VoxbloxMapView {
   const uint32_t* rgba = nullptr;   // r | g << 8 | b << 16 | a << 24
   int num_blocks = 0;
   int shard_count = 1;
+  // sharded maps: copies of other ranks' blocks brought in for meshing (plvs_hip_tsdf_voxblox_halo_*): id -> pool slot
+  // past num_blocks; keys null until a halo has been imported
+  plvs::tsdf::Directory ghost{};
   // state another translation unit keeps with the map (the meshing scratch buffers): *ext is freed with
   // (*ext_free)(*ext) when the map is destroyed
   void** ext = nullptr;

@@ -202,6 +202,27 @@ def sharded_mesh_chunks(tsdf, chunk_ids, group=None):
     return tsdf.mesh_chunks(chunk_ids), fetched
 
 
+def voxblox_halo_ids(block_ids, world, rank):
+    """The blocks of other ranks a voxblox mesh of `block_ids` reads: the seven +x / +y / +z neighbours
+    (mesh_integrator.h:299-337) that this rank does not own, without duplicates.  [k, 3] int32."""
+    ids = np.asarray(block_ids, dtype=np.int64).reshape(-1, 3)
+    if not len(ids):
+        return np.zeros((0, 3), np.int32)
+    offs = np.array([[dx, dy, dz] for dz in (0, 1) for dy in (0, 1) for dx in (0, 1)][1:], np.int64)
+    nb = np.unique((ids[:, None, :] + offs[None, :, :]).reshape(-1, 3), axis=0)
+    return np.ascontiguousarray(nb[owner_of(nb, world) != rank], np.int32)
+
+
+def sharded_mesh_blocks(tsdf, block_ids, group=None):
+    """MeshIntegrator::updateMeshForBlock of THIS rank's blocks in `block_ids` on a sharded voxblox map: fetch the
+    neighbour blocks the border cubes read from their owners (one round: the ids are known), then mesh.  Every rank
+    calls it (with its own list, possibly empty).  -> (TsdfVoxblox.mesh_blocks dict, blocks fetched)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    need = voxblox_halo_ids(block_ids, world, rank)
+    fetched = halo_round(tsdf, need, world, rank, lambda send, counts: _all_to_all_rows(send, counts, group))
+    return tsdf.mesh_blocks(block_ids), fetched
+
+
 class BlockDirectory:
     """plvs_block_directory (include/plvs_hip.h): the global block id -> owner rank table a rank keeps from the
     gathered lists.  Imports the HIP library on first use (this module itself needs numpy + torch only)."""

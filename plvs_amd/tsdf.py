@@ -417,6 +417,30 @@ class TsdfVoxblox:
             m = n.value
             return dict(vertices=v[:m], normals=nr[:m], colors=c[:m], block_first=first)
 
+    # ---- halo of a sharded map, for meshing (include/plvs_hip.h: plvs_hip_tsdf_voxblox_halo_*)
+    HALO_WORDS = 3 * 4096     # a block on the wire: distance, weight, rgba planes
+
+    def halo_lookup(self, d_ids, d_found):
+        f = _L.plvs_hip_tsdf_voxblox_halo_lookup
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        _lib.check(f(self._h, _lib.t_ptr(d_ids), int(d_ids.shape[0]), _lib.t_ptr(d_found), _lib.current_stream_ptr()))
+
+    def halo_export(self, d_ids, d_found, d_payload):
+        f = _L.plvs_hip_tsdf_voxblox_halo_export
+        f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        _lib.check(f(self._h, _lib.t_ptr(d_ids), _lib.t_ptr(d_found), int(d_ids.shape[0]), _lib.t_ptr(d_payload),
+                     _lib.current_stream_ptr()))
+
+    def halo_import(self, d_ids, d_found, d_payload):
+        f = _L.plvs_hip_tsdf_voxblox_halo_import
+        f.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        _lib.check(f(self._h, _lib.t_ptr(d_ids), _lib.t_ptr(d_found), _lib.t_ptr(d_payload), int(d_ids.shape[0]),
+                     int(d_payload.shape[0]), _lib.current_stream_ptr()))
+
+    def halo_clear(self):
+        _L.plvs_hip_tsdf_voxblox_halo_clear.argtypes = [ctypes.c_void_p]
+        _lib.check(_L.plvs_hip_tsdf_voxblox_halo_clear(self._h))
+
     def get_chunk(self, bx, by, bz):
         d = np.empty(4096, np.float32)
         w = np.empty(4096, np.float32)

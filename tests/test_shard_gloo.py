@@ -284,3 +284,29 @@ def test_gloo_meshing_halo_rounds(world):
         assert fetched == len(ghosts)
     assert merged == want
     assert any(o[2] > 0 for o in out) and any(o[4] for o in out), "chunks were fetched, and some were reported absent"
+
+
+def test_voxblox_halo_ids_are_the_foreign_forward_neighbours():
+    """plvs_amd.shard.voxblox_halo_ids: exactly the +x / +y / +z neighbours (seven per block) owned by other ranks,
+    once each."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("plvs_amd_shard", os.path.join(ROOT, "plvs_amd", "shard.py"))
+    shard_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shard_mod)
+    rng = np.random.default_rng(3)
+    ids = np.unique(rng.integers(-6, 6, (200, 3)), axis=0).astype(np.int32)
+    for world in (2, 3, 8):
+        for rank in range(world):
+            mine = ids[shard_mod.owner_of(ids, world) == rank]
+            need = shard_mod.voxblox_halo_ids(mine, world, rank)
+            want = set()
+            for b in mine:
+                for dx in (0, 1):
+                    for dy in (0, 1):
+                        for dz in (0, 1):
+                            if dx or dy or dz:
+                                n = (int(b[0]) + dx, int(b[1]) + dy, int(b[2]) + dz)
+                                if shard_mod.owner_of(np.array([n]), world)[0] != rank:
+                                    want.add(n)
+            assert len(need) == len(want) and set(map(tuple, need.tolist())) == want
+    assert shard_mod.voxblox_halo_ids(np.zeros((0, 3), np.int32), 4, 0).shape == (0, 3)

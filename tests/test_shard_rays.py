@@ -192,6 +192,17 @@ def test_hip_ray_sharded_integrate_through_torch_distributed_and_rccl_at_world_o
         for name in ("vertices", "normals", "colors", "kfids", "chunk_first"):
             assert want[name].tobytes() == got[name].tobytes() == got2[name].tobytes(), name
         assert len(want["vertices"]) > 5000
+        # and a voxblox map through sharded_mesh_blocks (one rank: no neighbour is foreign, the collectives still run)
+        from plvs_amd.shard import sharded_mesh_blocks
+        from plvs_amd.tsdf import TsdfVoxblox
+        vb = TsdfVoxblox(0.05)
+        k0 = kfs[0]
+        vb.integrate(k0["xyz"], np.concatenate([k0["rgb"], np.full((len(k0["rgb"]), 1), 255, np.uint8)], 1), k0["Twc"])
+        bids = np.ascontiguousarray(vb.chunk_ids(), np.int32)
+        a, fetched = sharded_mesh_blocks(vb, bids)
+        b = vb.mesh_blocks(bids)
+        assert fetched == 0 and all(a[n].tobytes() == b[n].tobytes() for n in ("vertices", "normals", "colors", "block_first"))
+        vb.close()
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)

@@ -224,3 +224,70 @@ def test_update_map_mirror_accumulates_updated_blocks(oracle):
     assert n == len(cloud) > 5000
     pm.Clear()
     assert len(pm.UpdateMap()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 5])
+def test_hip_sharded_voxblox_meshes_equal_the_single_device_meshes(oracle, world):
+    """A block-hash sharded voxblox map (every rank walks every ray and keeps the blocks it owns): each rank meshes
+    ITS blocks after fetching the +x / +y / +z neighbour blocks other ranks own (halo_lookup / export / import, here
+    between virtual ranks on one device).  Every block's mesh must be the single-device one byte for byte; the halo
+    goes away with the next integrate call and leaves the pool as it was."""
+    import torch
+    from plvs_amd.shard import owner_of, voxblox_halo_ids
+    from plvs_amd.tsdf import TsdfVoxblox
+    vs = 0.05
+    single = TsdfVoxblox(vs, max_blocks=8192)
+    ranks = [TsdfVoxblox(vs, max_blocks=8192, shard_rank=r, shard_count=world) for r in range(world)]
+    kfs = make_keyframes(4, seed=2)
+    for phase, part in enumerate((kfs[:3], kfs[3:])):
+        for k in part:
+            for t in [single] + ranks:
+                t.integrate(k["xyz"], rgba_of(k), k["Twc"])
+        ids = np.array(sorted(tuple(int(v) for v in b) for b in single.chunk_ids()), np.int32)
+        own = owner_of(ids, world)
+        want = single.mesh_blocks(ids)
+        wf = want["block_first"]
+        total, moved = 0, 0
+        for r, t in enumerate(ranks):
+            mine = np.ascontiguousarray(ids[own == r])
+            assert sorted(map(tuple, mine.tolist())) == sorted(tuple(int(v) for v in b) for b in t.chunk_ids())
+            before = t.num_chunks()
+            need = voxblox_halo_ids(mine, world, r)
+            assert len(need) and (owner_of(need, world) != r).all()
+            for q in range(world):                                   # the exchange, between virtual ranks
+                ask = np.ascontiguousarray(need[owner_of(need, world) == q])
+                if not len(ask):
+                    continue
+                d_ids = torch.from_numpy(ask).cuda()
+                found = torch.zeros(len(ask), dtype=torch.int32, device="cuda")
+                ranks[q].halo_lookup(d_ids, found)
+                payload = torch.empty((int(found.sum().item()), t.HALO_WORDS), dtype=torch.int32, device="cuda")
+                ranks[q].halo_export(d_ids, found, payload)
+                t.halo_import(d_ids, found, payload)
+                moved += payload.shape[0]
+            got = t.mesh_blocks(mine)
+            gf = got["block_first"]
+            pos = {tuple(int(v) for v in b): i for i, b in enumerate(ids)}
+            for j, b in enumerate(mine):
+                i = pos[tuple(int(v) for v in b)]
+                a, e, a2, e2 = int(wf[i]), int(wf[i + 1]), int(gf[j]), int(gf[j + 1])
+                assert e - a == e2 - a2, (b, e - a, e2 - a2)
+                for name, w in (("vertices", 1), ("normals", 1), ("colors", 1)):
+                    assert want[name][a:e].tobytes() == got[name][a2:e2].tobytes(), (name, b)
+                total += e - a
+            assert t.num_chunks() == before, "ghosts are not blocks of the map"
+            if phase == 1:
+                t.halo_clear()
+        assert total == len(want["vertices"]) > 5000 and moved > 0
+        # without the halo a border cube that reaches into another rank's block is dropped: the halo matters
+        if phase == 1:
+            bare = sum(len(t.mesh_blocks(np.ascontiguousarray(ids[own == r]))["vertices"]) for r, t in enumerate(ranks))
+            assert bare < total
+    # the shards still hold exactly the single-device map
+    for r, t in enumerate(ranks):
+        for b in t.chunk_ids():
+            for x, y in zip(single.get_chunk(*b), t.get_chunk(*b)):
+                assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), b
+    for t in ranks + [single]:
+        t.close()
