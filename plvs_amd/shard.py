@@ -94,7 +94,7 @@ def exchange_segments(send_seg, send_rec, send_run, send_counts, group=None):
     return recv[0], recv[1], recv[2], recv_counts
 
 
-SAT_ROWS = 65536      # newly saturated voxels a rank reports per step (16 B each); a longer list waits for the next step
+SAT_ROWS = 16384      # newly saturated voxels a rank reports per step (16 B each: a 256 KiB message); a longer list waits for the next step
 
 
 def sharded_integrate(tsdf, d_xyz, d_rgb, d_kfid, offsets, d_Twc, group=None):
