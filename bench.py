@@ -114,14 +114,18 @@ def main():
     ray_sharded = multi and not vbx and not args.ordered
     step_kfs = args.batch * (world if (ray_sharded and not args.strong) else 1)
     batches = []
+    built = {}     # steps that carry the same key frames share one copy in HBM (at N x 100 key frames per step all do)
     for s in range(total_steps):
-        sel = [kfs[(s * step_kfs + j) % n_poses] for j in range(step_kfs)]
-        xyz = torch.from_numpy(np.concatenate([k["xyz"] for k in sel])).cuda()
-        rgb = torch.from_numpy(np.concatenate([k["rgba" if vbx else "rgb"] for k in sel])).cuda()
-        kfid = torch.from_numpy(np.concatenate([k["kfid"] for k in sel]).astype(np.int32)).cuda()
-        Twc = torch.from_numpy(np.stack([k["Twc"] for k in sel])).cuda()
-        offsets = np.cumsum([0] + [k["xyz"].shape[0] for k in sel]).astype(np.int32)
-        batches.append((xyz, rgb, kfid, offsets, Twc))
+        first = (s * step_kfs) % n_poses
+        if first not in built:
+            sel = [kfs[(first + j) % n_poses] for j in range(step_kfs)]
+            xyz = torch.from_numpy(np.concatenate([k["xyz"] for k in sel])).cuda()
+            rgb = torch.from_numpy(np.concatenate([k["rgba" if vbx else "rgb"] for k in sel])).cuda()
+            kfid = torch.from_numpy(np.concatenate([k["kfid"] for k in sel]).astype(np.int32)).cuda()
+            Twc = torch.from_numpy(np.stack([k["Twc"] for k in sel])).cuda()
+            offsets = np.cumsum([0] + [k["xyz"].shape[0] for k in sel]).astype(np.int32)
+            built[first] = (xyz, rgb, kfid, offsets, Twc)
+        batches.append(built[first])
 
     if vbx:
         tsdf = TsdfVoxblox(args.resolution, max_blocks=65536, shard_rank=rank, shard_count=world)
