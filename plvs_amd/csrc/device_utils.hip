@@ -100,6 +100,53 @@ __global__ __launch_bounds__(kThreads) void scan_tile_apply(const uint32_t* __re
   }
 }
 
+// Short inputs: one workgroup of 1024 threads walks the array in spans of 8192 with a running carry — one launch
+// instead of three (a dependent launch costs more than such a span takes).
+constexpr int kSingleThreads = 1024;
+constexpr int kSingleSpan = kSingleThreads * kScanItems;   // 8192
+constexpr size_t kSingleMax = 6 * (size_t)kSingleSpan;      // 49152 elements
+
+__global__ __launch_bounds__(kSingleThreads) void scan_single(const uint32_t* in, uint32_t* out,   // (in == out is allowed)
+                                                              size_t n, uint32_t* __restrict__ total) {
+  __shared__ uint32_t wsum[kSingleThreads / 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t carry = 0;
+  for (size_t start = 0; start < n; start += kSingleSpan) {
+    const size_t base = start + (size_t)threadIdx.x * kScanItems;
+    uint32_t v[kScanItems];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+      v[i] = (base + i < n) ? in[base + i] : 0u;
+      s += v[i];
+    }
+    uint32_t x = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wid] = x;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kSingleThreads / 64; ++w) {
+      const uint32_t t = wsum[w];
+      if (w < wid) wbase += t;
+      tot += t;
+    }
+    __syncthreads();   // wsum is rewritten by the next span
+    uint32_t ex = carry + wbase + x - s;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+      if (base + i < n) out[base + i] = ex;
+      ex += v[i];
+    }
+    carry += tot;
+  }
+  if (threadIdx.x == 0 && total != nullptr) *total = carry;
+}
+
 // ------------------------------------------------------------ radix sort
 constexpr int kMaxRadixBits = 11;
 constexpr int kSortItems = 16;                       // per thread
@@ -220,6 +267,10 @@ hipError_t exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint3
   if (n == 0) {
     if (total) return hipMemsetAsync(total, 0, sizeof(uint32_t), stream);
     return hipSuccess;
+  }
+  if (n <= kSingleMax) {
+    hipLaunchKernelGGL(scan_single, dim3(1), dim3(kSingleThreads), 0, stream, in, out, n, total);
+    return hipGetLastError();
   }
   const size_t nb = (n + kScanTile - 1) / kScanTile;
   hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)nb), dim3(kThreads), 0, stream, in, n, scratch);
