@@ -825,7 +825,7 @@ struct plvs_tsdf_chisel {
   uint32_t miss_cap = 0, miss_mask = 0;
   DevBuf<int32_t> offsets;
   // host-flavour staging
-  DevBuf<float> st_xyz, st_Twc;
+  DevBuf<float> st_xyz, st_Twc, st_nrm;
   DevBuf<uint8_t> st_rgb;
   DevBuf<uint32_t> st_kfid;
   plvs_tsdf_stats stats{};
@@ -1248,7 +1248,7 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   h->last_pt.release(); h->run_cnt.release(); h->run_dst.release();
   h->tile_first.release(); h->block_first.release(); h->tile_state.release();
   h->heads.release(); h->updated.release(); h->scratch.release(); h->poses.release();
-  h->offsets.release(); h->st_xyz.release(); h->st_Twc.release(); h->st_rgb.release();
+  h->offsets.release(); h->st_xyz.release(); h->st_Twc.release(); h->st_nrm.release(); h->st_rgb.release();
   h->st_kfid.release();
   delete h;
   return PLVS_OK;
@@ -1524,21 +1524,19 @@ int plvs_hip_tsdf_chisel_integrate_world_normals(plvs_tsdf_chisel* h, const floa
   h->last_updated = 0;
   if (n == 0) return PLVS_OK;
   PLVS_REQUIRE(xyz && rgb && normals, "null input");
-  DevBuf<float> st_n;
   PLVS_HIP_TRY(h->st_xyz.reserve((size_t)n * 3));
   PLVS_HIP_TRY(h->st_rgb.reserve((size_t)n * 3));
   PLVS_HIP_TRY(h->st_Twc.reserve(12));
-  PLVS_HIP_TRY(st_n.reserve((size_t)n * 3));
+  PLVS_HIP_TRY(h->st_nrm.reserve((size_t)n * 3));
   if (kfid) PLVS_HIP_TRY(h->st_kfid.reserve((size_t)n));
   PLVS_HIP_TRY(hipMemcpy(h->st_xyz.p, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
   PLVS_HIP_TRY(hipMemcpy(h->st_rgb.p, rgb, (size_t)n * 3, hipMemcpyHostToDevice));
-  PLVS_HIP_TRY(hipMemcpy(st_n.p, normals, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(h->st_nrm.p, normals, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
   PLVS_HIP_TRY(hipMemcpy(h->st_Twc.p, Twc, 12 * sizeof(float), hipMemcpyHostToDevice));
   if (kfid) PLVS_HIP_TRY(hipMemcpy(h->st_kfid.p, kfid, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
   const int rc = plvs_hip_tsdf_chisel_integrate_world_normals_dev(h, h->st_xyz.p, h->st_rgb.p, kfid ? h->st_kfid.p : nullptr,
-                                                                  st_n.p, n, h->st_Twc.p, nullptr);
+                                                                  h->st_nrm.p, n, h->st_Twc.p, nullptr);
   (void)hipDeviceSynchronize();
-  st_n.release();
   return rc;
 }
 

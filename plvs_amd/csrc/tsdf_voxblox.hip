@@ -279,7 +279,7 @@ struct plvs_tsdf_voxblox {
   DevBuf<uint32_t> counts, keys0, keys1, seq0, seq1, heads, updated, scratch, rec_c;
   DevBuf<float2> rec;
   DevBuf<int32_t> offsets;
-  DevBuf<float> st_xyz, st_Twc;
+  DevBuf<float> st_xyz, st_Twc, st_nrm;
   DevBuf<uint32_t> st_rgba;
   plvs_tsdf_stats stats{};
   uint32_t last_updated = 0;
@@ -349,7 +349,7 @@ int plvs_hip_tsdf_voxblox_destroy(plvs_tsdf_voxblox* h) {
   if (h->h_ctr) (void)hipHostFree(h->h_ctr);
   h->counts.release(); h->keys0.release(); h->keys1.release(); h->seq0.release(); h->seq1.release();
   h->heads.release(); h->updated.release(); h->scratch.release(); h->rec_c.release(); h->rec.release();
-  h->offsets.release(); h->st_xyz.release(); h->st_Twc.release(); h->st_rgba.release();
+  h->offsets.release(); h->st_xyz.release(); h->st_Twc.release(); h->st_nrm.release(); h->st_rgba.release();
   delete h;
   return PLVS_OK;
 }
@@ -738,20 +738,18 @@ int plvs_hip_tsdf_voxblox_integrate_world_normals(plvs_tsdf_voxblox* h, const fl
     return PLVS_OK;
   }
   PLVS_REQUIRE(xyz && rgba && normals, "null cloud pointer");
-  DevBuf<float> st_n;
   PLVS_HIP_TRY(h->st_xyz.reserve((size_t)n * 3));
   PLVS_HIP_TRY(h->st_rgba.reserve((size_t)n));
   PLVS_HIP_TRY(h->st_Twc.reserve(12));
-  PLVS_HIP_TRY(st_n.reserve((size_t)n * 3));
+  PLVS_HIP_TRY(h->st_nrm.reserve((size_t)n * 3));
   PLVS_HIP_TRY(hipMemcpy(h->st_xyz.p, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
   PLVS_HIP_TRY(hipMemcpy(h->st_rgba.p, rgba, (size_t)n * 4, hipMemcpyHostToDevice));
-  PLVS_HIP_TRY(hipMemcpy(st_n.p, normals, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(h->st_nrm.p, normals, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
   PLVS_HIP_TRY(hipMemcpy(h->st_Twc.p, Twc, 12 * sizeof(float), hipMemcpyHostToDevice));
   const int32_t offsets[2] = {0, n};
   const int rc = vb_integrate_impl(h, h->st_xyz.p, reinterpret_cast<const uint8_t*>(h->st_rgba.p), offsets, 1, h->st_Twc.p,
-                                   nullptr, st_n.p);
+                                   nullptr, h->st_nrm.p);
   (void)hipDeviceSynchronize();
-  st_n.release();
   return rc;
 }
 
