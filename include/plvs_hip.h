@@ -624,6 +624,12 @@ int plvs_hip_tsdf_chisel_mesh_chunks(plvs_tsdf_chisel* h, const int32_t* chunk_i
                                      float* vertices, float* normals, float* colors, uint32_t* kfids,
                                      int capacity, int32_t* chunk_first, int* nvertices);
 
+/* Creates or REPLACES one chunk with the given voxel planes (host, 4096 each, id = (z * 16 + y) * 16 + x): the
+ * counterpart of download_chunk (a volume snapshot coming back; the reference itself has no volume file for chisel),
+ * and what lets tests put analytic distance fields on the device. */
+int plvs_hip_tsdf_chisel_upload_chunk(plvs_tsdf_chisel* h, int cx, int cy, int cz, const float* sdf, const float* weight,
+                                      const uint32_t* kfid, const uint32_t* rgbw);
+
 /* Halo of a sharded map, for meshing (see plvs_hip_tsdf_chisel_mesh_chunks).
  *   halo_missing  the chunk ids (host, n x 3) the last mesh_chunks call looked for on other ranks and did not hold;
  *                 PLVS_ERR_CAPACITY with *n set if cap is too small.
@@ -814,6 +820,13 @@ int plvs_hip_tsdf_voxblox_download_block(plvs_tsdf_voxblox* h, int bx, int by, i
 int plvs_hip_tsdf_voxblox_mesh_blocks(plvs_tsdf_voxblox* h, const int32_t* block_ids_xyz, int nblocks,
                                       float* vertices, float* normals, uint8_t* colors_rgba, int capacity,
                                       int32_t* block_first, int* nvertices);
+
+/* Creates or REPLACES one block with the given voxel planes (host, 4096 each, index x + 16 * (y + 16 * z)) — the
+ * device side of TsdfServer::loadMap (tsdf_server.cc:865-872: io::LoadBlocksFromFile with
+ * BlockMergingStrategy::kReplace, core/layer_inl.h:195-197) once the `.proto` file has been read on the host;
+ * download_block is the device side of saveMap (:859-863).  The caller marks the block updated (layer_inl.h:215). */
+int plvs_hip_tsdf_voxblox_upload_block(plvs_tsdf_voxblox* h, int bx, int by, int bz, const float* distance,
+                                       const float* weight, const uint32_t* rgba);
 
 /* Halo of a sharded voxblox map, for meshing.  The ids to fetch are known on the host: the seven +x / +y / +z
  * neighbours of every block to mesh that another rank owns (three-prime block hash mod shard_count).

@@ -641,6 +641,37 @@ class PointCloudMapVoxblox {
     pointCloud_.clear();
   }
   int NumBlocks() { int n = 0; check(plvs_hip_tsdf_voxblox_num_blocks(h_, &n)); return n; }
+  // The device side of TsdfServer::saveMap / loadMap (tsdf_server.cc:859-872): every block's voxel planes out of /
+  // into HBM; the `.proto` serialisation of a StoredBlock stays with the reference's protobuf code.  A loaded block
+  // replaces / creates its block and is marked updated (BlockMergingStrategy::kReplace, core/layer_inl.h:195-197, :215).
+  struct StoredBlock {
+    BlockID id;
+    std::vector<float> distance, weight;   // 4096 each, index x + 16 * (y + 16 * z)
+    std::vector<uint32_t> rgba;
+  };
+  std::vector<StoredBlock> SaveLayer() {
+    const int n = NumBlocks();
+    std::vector<int32_t> ids((size_t)3 * (n > 0 ? n : 1));
+    int m = 0;
+    check(plvs_hip_tsdf_voxblox_block_ids(h_, ids.data(), n, &m));
+    std::vector<StoredBlock> out((size_t)n);
+    for (int i = 0; i < n; ++i) {
+      StoredBlock& b = out[(size_t)i];
+      b.id = BlockID(ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]);
+      b.distance.resize(4096); b.weight.resize(4096); b.rgba.resize(4096);
+      check(plvs_hip_tsdf_voxblox_download_block(h_, ids[3 * i], ids[3 * i + 1], ids[3 * i + 2], b.distance.data(), b.weight.data(),
+                                                 b.rgba.data()));
+    }
+    return out;
+  }
+  bool LoadLayer(const std::vector<StoredBlock>& blocks) {
+    for (const StoredBlock& b : blocks) {
+      check(plvs_hip_tsdf_voxblox_upload_block(h_, std::get<0>(b.id), std::get<1>(b.id), std::get<2>(b.id), b.distance.data(),
+                                               b.weight.data(), b.rgba.data()));
+      updated_.insert(b.id);
+    }
+    return true;
+  }
   const std::vector<PointSurfelSegment>& GetPointCloud() const { return pointCloud_; }
   const std::map<BlockID, VoxbloxMesh>& GetMeshLayer() const { return meshLayer_; }
   plvs_tsdf_voxblox* handle() { return h_; }

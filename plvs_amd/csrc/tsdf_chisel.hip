@@ -1862,6 +1862,12 @@ bool chisel_map_view(plvs_tsdf_chisel* h, ChiselMapView* v) {
 }  // namespace tsdf
 }  // namespace plvs
 
+// One chunk id -> its pool slot, created if absent (plvs_hip_tsdf_chisel_upload_chunk).
+__global__ void chunk_slot_of(Directory dir, int x, int y, int z, int32_t* __restrict__ num_chunks, uint32_t* __restrict__ err,
+                              int32_t* __restrict__ slot_out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *slot_out = dir_find_or_insert(dir, x, y, z, num_chunks, err);
+}
+
 // ------------------------------------------------------------------ halo of a sharded map (meshing)
 namespace {
 
@@ -2000,6 +2006,38 @@ static int halo_drop(plvs_tsdf_chisel* h, hipStream_t s) {
 }
 
 extern "C" {
+
+// Creates or REPLACES one chunk with the given voxel planes (host, 4096 each, id = (z * 16 + y) * 16 + x): the way a
+// volume saved with download_chunk comes back, and what lets tests put analytic distance fields on the device.
+int plvs_hip_tsdf_chisel_upload_chunk(plvs_tsdf_chisel* h, int cx, int cy, int cz, const float* sdf, const float* weight,
+                                      const uint32_t* kfid, const uint32_t* rgbw) {
+  PLVS_REQUIRE(h && sdf && weight && kfid && rgbw, "null argument");
+  PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
+  if (std::max(1, h->prm.shard_count) > 1)
+    PLVS_REQUIRE(shard_of(chunk_hash(cx, cy, cz), h->prm.shard_count) == h->prm.shard_rank, "the chunk belongs to another rank");
+  int rc = halo_drop(h, nullptr);
+  if (rc != PLVS_OK) return rc;
+  PLVS_HIP_TRY(hipMemset(&h->d_ctr->err, 0, sizeof(uint32_t)));
+  int32_t* d_slot = reinterpret_cast<int32_t*>(&h->d_ctr->total_visits);   // (a counter no call is using now)
+  hipLaunchKernelGGL(chunk_slot_of, dim3(1), dim3(64), 0, nullptr, h->dir, cx, cy, cz, &h->d_ctr->num_chunks, &h->d_ctr->err,
+                     d_slot);
+  PLVS_KERNEL_CHECK();
+  rc = read_counters(h, nullptr);
+  if (rc != PLVS_OK) return rc;
+  if (h->h_ctr->err) {
+    h->poisoned = true;
+    plvs::set_error("upload_chunk: %s", (h->h_ctr->err & kErrPoolFull) ? "chunk pool full (raise max_chunks)" : "chunk id out of range");
+    return PLVS_ERR_CAPACITY;
+  }
+  const int slot = (int)h->h_ctr->total_visits;
+  h->num_chunks = h->h_ctr->num_chunks;
+  const size_t off = (size_t)slot * kChunkVox;
+  PLVS_HIP_TRY(hipMemcpy(h->sdf + off, sdf, kChunkVox * sizeof(float), hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(h->weight + off, weight, kChunkVox * sizeof(float), hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(h->kfid + off, kfid, kChunkVox * sizeof(uint32_t), hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(h->rgbw + off, rgbw, kChunkVox * sizeof(uint32_t), hipMemcpyHostToDevice));
+  return PLVS_OK;
+}
 
 int plvs_hip_tsdf_chisel_halo_missing(plvs_tsdf_chisel* h, int32_t* ids_xyz, int cap, int* n) {
   PLVS_REQUIRE(h && n, "null argument");

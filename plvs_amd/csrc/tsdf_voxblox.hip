@@ -428,6 +428,15 @@ int plvs_hip_tsdf_voxblox_create(const plvs_tsdf_voxblox_params* p, plvs_tsdf_vo
 
 }  // extern "C"
 
+namespace {
+// One block id -> its pool slot, created if absent (plvs_hip_tsdf_voxblox_upload_block).
+__global__ void vb_block_slot_of(Directory dir, int x, int y, int z, VCounters* __restrict__ ctr, int32_t* __restrict__ slot_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  dir_insert(dir, x, y, z, &ctr->num_blocks, &ctr->err);
+  *slot_out = dir_find(dir, x, y, z);
+}
+}  // namespace
+
 // ------------------------------------------------------------------ halo of a sharded map (meshing)
 // A block's mesh reads its +x / +y / +z neighbour blocks (mesh_integrator.h:299-337), which block-hash sharding
 // puts on other ranks: the caller asks their owners for them (the ids are known on the host: the seven neighbours of
@@ -544,6 +553,39 @@ static int vb_halo_drop(plvs_tsdf_voxblox* h, hipStream_t s) {
 }
 
 extern "C" {
+
+// Creates or REPLACES one block with the given voxel planes (host, 4096 each, index x + 16 * (y + 16 * z)): what
+// Layer::addBlockFromProto does with BlockMergingStrategy::kReplace for every block of a saved layer
+// (TsdfServer::loadMap, tsdf_server.cc:865-872 -> io::LoadBlocksFromFile; core/layer_inl.h:195-197, :215) once the
+// protobuf has been read on the host.  The caller marks the block updated, as layer_inl.h:215 does.
+int plvs_hip_tsdf_voxblox_upload_block(plvs_tsdf_voxblox* h, int bx, int by, int bz, const float* distance, const float* weight,
+                                       const uint32_t* rgba) {
+  PLVS_REQUIRE(h && distance && weight && rgba, "null argument");
+  PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
+  if (h->P.shard_count > 1)
+    PLVS_REQUIRE(shard_of(owner_hash(bx, by, bz), h->P.shard_count) == h->P.shard_rank, "the block belongs to another rank");
+  int rc = vb_halo_drop(h, nullptr);
+  if (rc != PLVS_OK) return rc;
+  PLVS_HIP_TRY(hipMemset(&h->d_ctr->err, 0, sizeof(uint32_t)));
+  int32_t* d_slot = reinterpret_cast<int32_t*>(&h->d_ctr->total_visits);   // (a counter no call is using now)
+  hipLaunchKernelGGL(vb_block_slot_of, dim3(1), dim3(64), 0, nullptr, h->dir, bx, by, bz, h->d_ctr, d_slot);
+  PLVS_KERNEL_CHECK();
+  rc = vb_read_counters(h, nullptr);
+  if (rc != PLVS_OK) return rc;
+  if (h->h_ctr->err) {
+    h->poisoned = true;
+    plvs::set_error("upload_block: %s", (h->h_ctr->err & kErrPoolFull) ? "block pool full (raise max_blocks)" : "block id out of range");
+    return PLVS_ERR_CAPACITY;
+  }
+  const int slot = (int)h->h_ctr->total_visits;
+  PLVS_REQUIRE(slot >= 0, "internal: the block was not inserted");
+  h->num_blocks = h->h_ctr->num_blocks;
+  const size_t off = (size_t)slot * kBlockVox;
+  PLVS_HIP_TRY(hipMemcpy(h->dist + off, distance, kBlockVox * sizeof(float), hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(h->weight + off, weight, kBlockVox * sizeof(float), hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(h->rgba + off, rgba, kBlockVox * sizeof(uint32_t), hipMemcpyHostToDevice));
+  return PLVS_OK;
+}
 
 int plvs_hip_tsdf_voxblox_halo_lookup(plvs_tsdf_voxblox* h, const int32_t* d_ids_xyz, int n, uint32_t* d_found, void* stream) {
   PLVS_REQUIRE(h && !h->poisoned, "unusable handle");

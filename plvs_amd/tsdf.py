@@ -98,6 +98,14 @@ class TsdfChisel:
             m = n.value
             return dict(vertices=v[:m], normals=nr[:m], colors=c[:m], kfids=k[:m], chunk_first=first)
 
+    def set_chunk(self, cx, cy, cz, sdf, weight, kfid, rgbw):
+        """Creates or replaces one chunk (4096 voxels, id = (z * 16 + y) * 16 + x): the counterpart of get_chunk."""
+        a = [np.ascontiguousarray(sdf, np.float32).reshape(4096), np.ascontiguousarray(weight, np.float32).reshape(4096),
+             np.ascontiguousarray(kfid, np.uint32).reshape(4096), np.ascontiguousarray(rgbw, np.uint32).reshape(4096)]
+        f = _lib.lib.plvs_hip_tsdf_chisel_upload_chunk
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4
+        _lib.check(f(self._h, int(cx), int(cy), int(cz), *[_lib.np_ptr(x) for x in a]))
+
     # ---- halo of a sharded map, for meshing (include/plvs_hip.h: plvs_hip_tsdf_chisel_halo_*)
     HALO_WORDS = 4 * 4096     # a chunk on the wire: sdf, weight, kfid, rgbw planes
 
@@ -417,6 +425,14 @@ class TsdfVoxblox:
             m = n.value
             return dict(vertices=v[:m], normals=nr[:m], colors=c[:m], block_first=first)
 
+    def set_chunk(self, bx, by, bz, distance, weight, rgba):
+        """Creates or replaces one block (4096 voxels, index x + 16 * (y + 16 * z)): Layer::addBlockFromProto(kReplace)."""
+        a = [np.ascontiguousarray(distance, np.float32).reshape(4096), np.ascontiguousarray(weight, np.float32).reshape(4096),
+             np.ascontiguousarray(rgba, np.uint32).reshape(4096)]
+        f = _L.plvs_hip_tsdf_voxblox_upload_block
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3
+        _lib.check(f(self._h, int(bx), int(by), int(bz), *[_lib.np_ptr(x) for x in a]))
+
     # ---- halo of a sharded map, for meshing (include/plvs_hip.h: plvs_hip_tsdf_voxblox_halo_*)
     HALO_WORDS = 3 * 4096     # a block on the wire: distance, weight, rgba planes
 
@@ -479,6 +495,20 @@ class PointCloudMapVoxblox:
         for b in self._tsdf.updated_chunk_ids():
             self._updated.add((int(b[0]), int(b[1]), int(b[2])))
         return self.UpdateMap()
+
+    def SaveLayer(self):
+        """TsdfServer::saveMap's device side (tsdf_server.cc:859-863, io::SaveLayer): every block's voxel planes, as
+        {block id: (distance, weight, rgba)} — the `.proto` serialisation itself stays with the reference's protobuf code."""
+        return {tuple(int(v) for v in b): self._tsdf.get_chunk(*b) for b in self._tsdf.chunk_ids()}
+
+    def LoadLayer(self, blocks):
+        """TsdfServer::loadMap's device side (tsdf_server.cc:865-872: LoadBlocksFromFile with kReplace): every stored block
+        replaces / creates its block and is marked updated (core/layer_inl.h:195-197, :215).  No UpdateMap: the reference's
+        `.proto` branch of LoadMap does not call it either (src/PointCloudMapVoxblox.cc:237-241)."""
+        for bid, (d, w, c) in blocks.items():
+            self._tsdf.set_chunk(bid[0], bid[1], bid[2], d, w, c)
+            self._updated.add((int(bid[0]), int(bid[1]), int(bid[2])))
+        return True
 
     # colorVoxbloxToMsg / colorMsgToVoxblox (voxblox_ros/conversions.h:44-60): a channel goes through a float in [0, 1]
     _CLOUD_COLOUR = ((np.arange(256) / 255.0).astype(np.float32).astype(np.float64) * 255.0).astype(np.uint8)

@@ -191,6 +191,14 @@ int main(int argc, char** argv) {
   const int vpts = vmap.UpdateMap();
   dump("vmap_cloud", vmap.GetPointCloud().data(), vmap.GetPointCloud().size() * sizeof(PointSurfelSegment));
   std::printf("voxblox %d %d %d\n", vmap.NumBlocks(), vpts, (int)vmap.GetMeshLayer().size());
+  {   // saveMap / loadMap of the layer: into an empty map, meshed there
+    PointCloudMapVoxblox vcopy(0.05f);
+    vcopy.LoadLayer(vmap.SaveLayer());
+    const int cpts = vcopy.UpdateMap();
+    std::printf("voxblox_layer %d %d %d\n", vcopy.NumBlocks(), cpts,
+                (int)(cpts == vpts && std::memcmp(vcopy.GetPointCloud().data(), vmap.GetPointCloud().data(),
+                                                  (size_t)vpts * sizeof(PointSurfelSegment)) == 0));
+  }
   {   // LoadMap: the chisel map's own output cloud back into an empty map, along its normals
     PointCloudMapChisel again(0.05f);
     const int lpts = again.LoadMap(map.GetPointCloud());

@@ -128,4 +128,6 @@ def test_cpp_mirror_matches_python_mirror(tmp_path):
     assert int(lines_out["voxblox"][0]) == v.tsdf.num_chunks()
     assert int(lines_out["voxblox"][1]) == len(vcloud) > 1000 and int(lines_out["voxblox"][2]) == len(v.mesh_layer)
     assert load("vmap_cloud", np.uint8).tobytes() == vcloud.tobytes()
+    # the layer saved and loaded into an empty map meshes to the same cloud
+    assert lines_out["voxblox_layer"] == [lines_out["voxblox"][0], lines_out["voxblox"][1], "1"]
     assert lines_out["cleared"] == ["0"]

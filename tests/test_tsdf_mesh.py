@@ -165,3 +165,49 @@ def test_hip_mesh_capacity_is_reported():
     rc = f(hip._h, _lib.np_ptr(ids), len(ids), _lib.np_ptr(buf), _lib.np_ptr(buf.copy()), _lib.np_ptr(buf.copy()),
            _lib.np_ptr(np.zeros(8, np.uint32)), 8, _lib.np_ptr(first), ctypes.byref(n))
     assert rc == _lib.PLVS_ERR_CAPACITY and n.value > 8 and first[-1] == n.value and (buf == 0).all()
+
+
+@pytest.mark.gpu
+def test_hip_mesh_of_an_analytic_sphere_through_upload_chunk(oracle):
+    """Chunks uploaded through the C ABI: the analytic sphere of the oracle test plus exact zeros, unobserved voxels
+    and random colours / kfids, meshed on the device byte for byte as the oracle meshes it (cube configurations, flat
+    edges and colour look-ups an integrated room never produces)."""
+    from plvs_amd.tsdf import TsdfChisel
+    res, r = 0.05, 0.55
+    centre = np.array([0.8, 0.8, 0.8])
+    ref, hip = oracle.chisel(res), TsdfChisel(res, max_chunks=64)
+    idx = np.arange(16)
+    rng = np.random.default_rng(8)
+    ids = []
+    for cx in range(2):
+        for cy in range(2):
+            for cz in range(2):
+                X, Y, Z = np.meshgrid(idx + 16 * cx, idx + 16 * cy, idx + 16 * cz, indexing="ij")
+                pts = np.stack([X, Y, Z], -1) * res + res / 2
+                sdf = np.transpose(np.linalg.norm(pts - centre, axis=-1) - r, (2, 1, 0)).astype(np.float32).reshape(-1)
+                sdf[rng.integers(0, 4096, 40)] = 0.0
+                flat = rng.integers(0, 4095, 30)                                 # neighbours closer than 1e-6: the flat-edge vertex
+                sdf[flat + 1] = -sdf[flat] + np.float32(3e-7) * np.sign(sdf[flat])
+                w = np.ones(4096, np.float32)
+                w[rng.integers(0, 4096, 60)] = 0.0
+                kfid = rng.integers(0, 1000, 4096).astype(np.uint32)
+                rgbw = rng.integers(0, 2 ** 32, 4096, dtype=np.uint64).astype(np.uint32)
+                ref.set_chunk(cx, cy, cz, sdf, w, kfid, rgbw)
+                hip.set_chunk(cx, cy, cz, sdf, w, kfid, rgbw)
+                ids.append((cx, cy, cz))
+    assert hip.num_chunks() == 8
+    for cid in ids:                                                              # what went up comes back down
+        for x, y in zip(ref.get_chunk(*cid), hip.get_chunk(*cid)):
+            assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y)
+    todo = _neighbourhood(ids)
+    m = hip.mesh_chunks(np.array(todo, np.int32))
+    first, total = m["chunk_first"], 0
+    for i, cid in enumerate(todo):
+        v, n, c, k = ref.mesh_chunk(*cid)
+        a, b = int(first[i]), int(first[i + 1])
+        assert b - a == len(v), (cid, b - a, len(v))
+        assert m["vertices"][a:b].tobytes() == v.tobytes() and m["normals"][a:b].tobytes() == n.tobytes(), cid
+        assert m["colors"][a:b].tobytes() == c.tobytes() and m["kfids"][a:b].tobytes() == k.tobytes(), cid
+        total += len(v)
+    assert total > 3000
+    hip.close()

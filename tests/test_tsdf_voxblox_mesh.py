@@ -291,3 +291,53 @@ def test_hip_sharded_voxblox_meshes_equal_the_single_device_meshes(oracle, world
                 assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), b
     for t in ranks + [single]:
         t.close()
+
+
+@pytest.mark.gpu
+def test_hip_mesh_of_an_analytic_sphere_through_upload_block(oracle):
+    """Blocks uploaded through the C ABI (the device side of TsdfServer::loadMap): the analytic sphere of the oracle
+    test, meshed on the device, byte for byte the oracle's mesh — cube configurations an integrated room never
+    produces — and a layer saved from one map and loaded into another gives the same meshes."""
+    from plvs_amd.tsdf import PointCloudMapVoxblox, TsdfVoxblox
+    vs, r = 0.05, 0.55
+    centre = np.array([0.8, 0.8, 0.8])
+    ref, hip = oracle.voxblox(vs), TsdfVoxblox(vs, max_blocks=64)
+    idx = np.arange(16)
+    rng = np.random.default_rng(4)
+    ids = []
+    for bx in range(2):
+        for by in range(2):
+            for bz in range(2):
+                X, Y, Z = np.meshgrid(idx + 16 * bx, idx + 16 * by, idx + 16 * bz, indexing="ij")
+                pts = np.stack([X, Y, Z], -1) * vs + vs / 2
+                sdf = np.transpose(np.linalg.norm(pts - centre, axis=-1) - r, (2, 1, 0)).astype(np.float32).reshape(-1)
+                sdf[rng.integers(0, 4096, 40)] = 0.0                         # exact zeros: "outside" by the >= 0 rule
+                w = np.ones(4096, np.float32)
+                w[rng.integers(0, 4096, 60)] = np.float32(1e-4)              # unobserved voxels (weight <= min_weight)
+                rgba = rng.integers(0, 2 ** 32, 4096, dtype=np.uint64).astype(np.uint32)
+                set_block(ref, bx, by, bz, sdf, w, rgba)
+                hip.set_chunk(bx, by, bz, sdf, w, rgba)
+                ids.append((bx, by, bz))
+    hip.set_chunk(1, 1, 1, *ref.get_chunk(1, 1, 1))                          # replacing a block is idempotent
+    assert hip.num_chunks() == 8
+    m = hip.mesh_blocks(np.array(ids, np.int32))
+    first, total = m["block_first"], 0
+    for i, bid in enumerate(ids):
+        v, n, c = mesh_block(ref, *bid)
+        a, b = int(first[i]), int(first[i + 1])
+        assert b - a == len(v) and m["vertices"][a:b].tobytes() == v.tobytes(), bid
+        assert m["normals"][a:b].tobytes() == n.tobytes() and m["colors"][a:b].tobytes() == c.tobytes(), bid
+        total += len(v)
+    assert total > 3000
+    # save -> load through the mirror
+    src = PointCloudMapVoxblox(vs, max_blocks=64)
+    for bid in ids:
+        src.tsdf.set_chunk(*bid, *hip.get_chunk(*bid))
+    layer = src.SaveLayer()
+    dst = PointCloudMapVoxblox(vs, max_blocks=64)
+    assert dst.LoadLayer(layer) and dst.tsdf.num_chunks() == 8
+    cloud = dst.UpdateMap()                                                   # every loaded block is marked updated
+    assert len(cloud) == total
+    got = dst.tsdf.mesh_blocks(np.array(ids, np.int32))
+    assert got["vertices"].tobytes() == m["vertices"].tobytes() and got["colors"].tobytes() == m["colors"].tobytes()
+    hip.close()
