@@ -783,6 +783,18 @@ int plvs_hip_tsdf_voxblox_integrate(plvs_tsdf_voxblox* h, const float* xyz, cons
 int plvs_hip_tsdf_voxblox_integrate_batch_dev(plvs_tsdf_voxblox* h, const float* d_xyz,
                                               const uint8_t* d_rgba, const int32_t* offsets,
                                               int nclouds, const float* d_Twc, void* stream);
+/* The "merged" integration method (PointCloudMapping.voxbloxIntegrationMethod: "merged"):
+ * MergedTsdfIntegrator::integratePointCloud (Thirdparty/voxblox/src/integrator/tsdf_integrator.cc:329-492) with
+ * integrator_threads = 1 and enable_anti_grazing off (src/PointCloudMapVoxblox.cc:67): the points that end in the
+ * same voxel are folded into one weighted point and colour and cast as ONE ray (clearing rays: the first point of
+ * their voxel); the bundles are integrated in the iteration order of the reference's
+ * std::unordered_map<AnyIndex, ..., AnyIndexHash> filled in the mixed visiting order.  That order is produced on the
+ * host by filling the same container (libstdc++'s, with the reference's hash) in the same sequence — it is the one
+ * host step; validity / end voxel per point, the fold of each bundle, the rays and the voxel updates run on the
+ * device.  Host pointers; synchronous.  Same arguments as plvs_hip_tsdf_voxblox_integrate. */
+int plvs_hip_tsdf_voxblox_integrate_merged(plvs_tsdf_voxblox* h, const float* xyz, const uint8_t* rgba, int n,
+                                           const float* Twc);
+
 /* A cloud WITH NORMALS, as PointCloudMapVoxblox::LoadMap feeds the saved cloud through
  * (src/PointCloudMapVoxblox.cc:233-258 -> TsdfServer::insertWorldPointCloud, tsdf_server.cc:577-660, T = identity
  * there -> TsdfIntegratorBase::integrateWorlPointCloud, tsdf_integrator.cc:35-82): points in cloud order, each

@@ -550,7 +550,12 @@ struct VoxbloxMesh {   // voxblox::Mesh after updateMeshForBlock (three consecut
 class PointCloudMapVoxblox {
  public:
   using BlockID = std::tuple<int, int, int>;
-  explicit PointCloudMapVoxblox(float voxelSize, bool useCarving = false) {
+  // integrationMethod: PointCloudMapping.voxbloxIntegrationMethod (src/PointCloudMapVoxblox.cc:44, :74) — "simple" and
+  // "merged" are on the accelerated path (one-thread schedules of the reference); "fast" is racy by design and refused.
+  explicit PointCloudMapVoxblox(float voxelSize, bool useCarving = false, const std::string& integrationMethod = "simple")
+      : merged_(integrationMethod == "merged") {
+    if (integrationMethod != "simple" && integrationMethod != "merged")
+      throw std::runtime_error("plvs_hip: voxblox integration method '" + integrationMethod + "' is not on the accelerated path");
     plvs_tsdf_voxblox_params p;
     check(plvs_hip_tsdf_voxblox_default_params(voxelSize, useCarving ? 1 : 0, &p));
     check(plvs_hip_tsdf_voxblox_create(&p, &h_));
@@ -570,7 +575,8 @@ class PointCloudMapVoxblox {
       xyz_[3 * i] = p.x; xyz_[3 * i + 1] = p.y; xyz_[3 * i + 2] = p.z;
       rgba_[4 * i] = p.r; rgba_[4 * i + 1] = p.g; rgba_[4 * i + 2] = p.b; rgba_[4 * i + 3] = p.a;
     }
-    check(plvs_hip_tsdf_voxblox_integrate(h_, xyz_.data(), rgba_.data(), (int)n, Twc.m));
+    if (merged_) check(plvs_hip_tsdf_voxblox_integrate_merged(h_, xyz_.data(), rgba_.data(), (int)n, Twc.m));
+    else check(plvs_hip_tsdf_voxblox_integrate(h_, xyz_.data(), rgba_.data(), (int)n, Twc.m));
     MarkUpdated();
   }
   // LoadMap of a saved cloud once PointCloudMap::LoadMap has read it (src/PointCloudMapVoxblox.cc:233-258):
@@ -691,6 +697,7 @@ class PointCloudMapVoxblox {
     return (uint8_t)(msg * 255.0);
   }
   plvs_tsdf_voxblox* h_ = nullptr;
+  bool merged_ = false;
   std::vector<float> xyz_;
   std::vector<uint8_t> rgba_;
   std::set<BlockID> updated_;

@@ -64,4 +64,18 @@ void ref_voxblox_indices(const int32_t* g, int32_t* block, int32_t* local, uint6
   *hash = (uint64_t)voxblox::AnyIndexHash()(b);
 }
 
+// The order in which the reference's own map type — AnyIndexHashMapType<T>::type, what MergedTsdfIntegrator::bundleRays
+// fills and integrateVoxels walks (tsdf_integrator.cc:337-341, :448-470) — hands back keys inserted in the given
+// sequence (operator[] semantics).  order_out: first-insertion positions of the distinct keys, in iteration order.
+int ref_voxblox_bundle_order(const int32_t* g, int n, int32_t* order_out) {
+  voxblox::AnyIndexHashMapType<int32_t>::type m;
+  for (int i = 0; i < n; ++i) {
+    const voxblox::AnyIndex k(g[3 * i], g[3 * i + 1], g[3 * i + 2]);
+    if (m.find(k) == m.end()) m[k] = i;
+  }
+  int c = 0;
+  for (const auto& kv : m) order_out[c++] = kv.second;
+  return c;
+}
+
 }  // extern "C"

@@ -378,6 +378,73 @@ void oracle_voxblox_integrate(oracle_voxblox* o, const float* xyz, const uint8_t
   o->last_visits = visits;
 }
 
+/* ---- MergedTsdfIntegrator (tsdf_integrator.cc:329-492), integrator_threads = 1.  The bundling — points grouped by
+ * the voxel they end in, in the iteration order of the reference's std::unordered_map — is oracle/tsdf_voxblox_merged.cpp
+ * (it IS a std::unordered_map with the reference's hash); the pieces it needs from this file: */
+
+/* isPointValid (:85-103), freespace_points = false: 0 = skipped, 1 = normal ray, 2 = clearing ray */
+int oracle_voxblox_point_kind(const oracle_voxblox* o, const float* pC) {
+  const float ray_distance = norm3(pC);
+  if (ray_distance < o->min_ray) return 0;
+  if (ray_distance > o->max_ray) return o->allow_clear ? 2 : 0;
+  return 1;
+}
+
+/* getGridIndexFromPoint(T_G_C * point_C, voxel_size_inv) (:372-374; common.h:152-157) */
+void oracle_voxblox_point_voxel(const oracle_voxblox* o, const float* Twc, const float* pC, int32_t* g) {
+  float R[9], t[3], q[4], pG[3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) R[3 * i + j] = Twc[4 * i + j];
+    t[i] = Twc[4 * i + 3];
+  }
+  quat_from_matrix(R, q);
+  quat_transform(q, t, pC, pG);
+  for (int k = 0; k < 3; k++) g[k] = (int32_t)floorf(pG[k] * o->voxel_size_inv + 1e-6f);
+}
+
+/* getVoxelWeight (:255-264), use_const_weight = false */
+float oracle_voxblox_point_weight(const float* pC) { return fabsf(pC[2]) > 1e-6f ? 1.0f / (pC[2] * pC[2]) : 0.0f; }
+
+/* The ray part of integrateVoxel (:418-446) for n merged bundles, in the given order: RayCaster(origin,
+ * T_G_C * merged_point_C, clearing_ray, ...) and updateTsdfVoxel with the merged colour and weight.  enable_anti_grazing
+ * is off (src/PointCloudMapVoxblox.cc:67). */
+void oracle_voxblox_integrate_bundles(oracle_voxblox* o, const float* merged_C, const uint32_t* colours, const float* weights,
+                                      const uint8_t* clearing, int n, const float* Twc) {
+  float R[9], t[3], q[4];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) R[3 * i + j] = Twc[4 * i + j];
+    t[i] = Twc[4 * i + 3];
+  }
+  quat_from_matrix(R, q);
+  int64_t visits = 0;
+  vblock_t* last_block = NULL;
+  int32_t last_bid[3] = {0, 0, 0};
+  for (int b = 0; b < n; b++) {
+    float pG[3];
+    quat_transform(q, t, merged_C + 3 * (size_t)b, pG);
+    vb_ray ray;
+    vb_ray_setup(t, pG, clearing[b] != 0, o->carving, o->max_ray, o->voxel_size_inv, o->truncation, &ray);
+    for (int step = 0; step <= ray.steps; step++) {
+      int32_t g[3];
+      vb_ray_next(&ray, g);
+      int32_t bid[3];
+      block_index(g, o->voxels_per_side_inv, bid);
+      if (o->shard_count > 1 && (int)(owner_hash(bid) % (size_t)o->shard_count) != o->shard_rank) continue;
+      if (!last_block || last_bid[0] != bid[0] || last_bid[1] != bid[1] || last_bid[2] != bid[2]) {
+        last_block = vblock_get(o, bid);
+        memcpy(last_bid, bid, sizeof(last_bid));
+      }
+      int32_t l[3];
+      local_index(g, l);
+      const int vid = l[0] + VPS * (l[1] + l[2] * VPS);
+      update_voxel(o, t, pG, g, colours[b], weights[b], &last_block->distance[vid], &last_block->weight[vid],
+                   &last_block->rgba[vid]);
+      visits++;
+    }
+  }
+  o->last_visits = visits;
+}
+
 /* TsdfIntegratorBase::integrateWorlPointCloud (tsdf_integrator.cc:35-82), what PointCloudMapVoxblox::LoadMap feeds the
  * saved cloud through (src/PointCloudMapVoxblox.cc:233-258 -> TsdfServer::insertWorldPointCloud, tsdf_server.cc:577-660,
  * T = identity there): points in CLOUD order (no ThreadSafeIndex), each casting point + normal * truncation ->

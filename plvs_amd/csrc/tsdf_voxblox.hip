@@ -13,6 +13,7 @@
 // (tsdf_directory.hpp), and per call one (u32 key, u32 sequence) pair plus
 // 12 B of operands per voxel visit.
 #include <cstring>
+#include <unordered_map>
 #include <vector>
 
 #include "common.hpp"
@@ -66,17 +67,22 @@ __device__ __forceinline__ int point_of_seq(const int32_t* __restrict__ offsets,
   return beg + (int)mixed_index((uint32_t)(i - beg), (uint32_t)cnt);
 }
 
-// kWorld: the world-cloud-with-normals flavour (make_ray_world): cloud order, no validity test; `normals` n x 3.
-template <bool kFill, bool kWorld>
+// The flavours of the ray passes.  kSimple: camera rays in the mixed visiting order.  kWorld: the
+// world-cloud-with-normals flavour (make_ray_world): cloud order, no validity test; `aux` = normals, n x 3.  kMerged:
+// MergedTsdfIntegrator's bundles in their integration order (make_ray_merged): xyz = merged points, `aux` = merged
+// weights (n), `clr` = the bundles' clearing flags.
+enum VbMode { kSimple = 0, kWorld = 1, kMerged = 2 };
+
+template <bool kFill, int kMode>
 __global__ __launch_bounds__(256) void vb_ray_pass(
-    Params P, const float* __restrict__ xyz, const float* __restrict__ normals, int npoints,
+    Params P, const float* __restrict__ xyz, const float* __restrict__ aux, const uint8_t* __restrict__ clr, int npoints,
     const int32_t* __restrict__ offsets, int nclouds, const float* __restrict__ Twc, Directory dir,
     VCounters* __restrict__ ctr, uint32_t* __restrict__ counts, uint32_t* __restrict__ rec_keys,
     uint32_t* __restrict__ rec_seq) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npoints) return;
   int cloud = 0;
-  const int p = kWorld ? i : point_of_seq(offsets, nclouds, i, &cloud);
+  const int p = kMode != kSimple ? i : point_of_seq(offsets, nclouds, i, &cloud);
   const float px = xyz[3 * (size_t)p], py = xyz[3 * (size_t)p + 1], pz = xyz[3 * (size_t)p + 2];
   uint32_t n = 0;
   if (!(isfinite(px) && isfinite(py) && isfinite(pz))) {
@@ -87,9 +93,11 @@ __global__ __launch_bounds__(256) void vb_ray_pass(
     const PoseRt pose = load_pose(Twc, cloud);
     Ray ray;
     bool walk = true;
-    if (kWorld) {
+    if (kMode == kWorld) {
       float rs[3];
-      make_ray_world(P, pose, px, py, pz, normals[3 * (size_t)p], normals[3 * (size_t)p + 1], normals[3 * (size_t)p + 2], &ray, rs);
+      make_ray_world(P, pose, px, py, pz, aux[3 * (size_t)p], aux[3 * (size_t)p + 1], aux[3 * (size_t)p + 2], &ray, rs);
+    } else if (kMode == kMerged) {
+      make_ray_merged(P, pose, px, py, pz, clr[p] != 0, &ray);
     } else {
       walk = make_ray(P, pose, px, py, pz, &ray);
     }
@@ -125,11 +133,71 @@ __global__ __launch_bounds__(256) void vb_ray_pass(
   if (!kFill) counts[i] = n;
 }
 
+// MergedTsdfIntegrator::bundleRays, the per-point part (tsdf_integrator.cc:361-386): isPointValid -> kind (0 skipped,
+// 1 normal, 2 clearing) and the voxel T_G_C * point_C ends in.  The grouping itself needs the reference's hash map and
+// is done on the host (plvs_hip_tsdf_voxblox_integrate_merged).
+__global__ __launch_bounds__(256) void vb_merge_keys(Params P, const float* __restrict__ xyz, int n,
+                                                     const float* __restrict__ Twc, VCounters* __restrict__ ctr,
+                                                     uint8_t* __restrict__ kind, int32_t* __restrict__ g) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float px = xyz[3 * (size_t)i], py = xyz[3 * (size_t)i + 1], pz = xyz[3 * (size_t)i + 2];
+  uint8_t k = 0;
+  int v[3] = {0, 0, 0};
+  if (!(isfinite(px) && isfinite(py) && isfinite(pz))) {
+    atomicOr(&ctr->err, kErrNonFinite);
+  } else {
+    const float ray_distance = sqrtf(vsum3(px * px, py * py, pz * pz));
+    if (ray_distance < P.min_ray) k = 0;
+    else if (ray_distance > P.max_ray) k = P.allow_clear ? 2 : 0;
+    else k = 1;
+    if (k) {
+      const PoseRt pose = load_pose(Twc, 0);
+      float pG[3];
+      quat_transform(pose, px, py, pz, pG);
+      for (int c = 0; c < 3; ++c) v[c] = (int)floorf(pG[c] * P.voxel_size_inv + 1e-6f);
+    }
+  }
+  kind[i] = k;
+  g[3 * (size_t)i] = v[0];
+  g[3 * (size_t)i + 1] = v[1];
+  g[3 * (size_t)i + 2] = v[2];
+}
+
+// integrateVoxel's fold of a bundle's points into one (tsdf_integrator.cc:404-416), one thread per bundle: the
+// recurrence is short (a handful of points per voxel) and sequential in float.
+__global__ __launch_bounds__(256) void vb_merge_bundles(const float* __restrict__ xyz, const uint32_t* __restrict__ rgba,
+                                                        const uint32_t* __restrict__ first, const uint32_t* __restrict__ pts,
+                                                        const uint8_t* __restrict__ clr, int nb, float* __restrict__ mxyz,
+                                                        uint32_t* __restrict__ mcol, float* __restrict__ mw) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  uint32_t colour = 0;   // Color()
+  float m0 = 0.f, m1 = 0.f, m2 = 0.f, W = 0.f;
+  const uint32_t end = clr[b] ? first[b] + 1u : first[b + 1];   // only the first point of a clearing bundle
+  for (uint32_t j = first[b]; j < end; ++j) {
+    const size_t p = pts[j];
+    const float px = xyz[3 * p], py = xyz[3 * p + 1], pz = xyz[3 * p + 2];
+    const float w = fabsf(pz) > 1e-6f ? 1.0f / (pz * pz) : 0.0f;   // getVoxelWeight
+    const float tot = W + w;
+    m0 = (m0 * W + px * w) / tot;
+    m1 = (m1 * W + py * w) / tot;
+    m2 = (m2 * W + pz * w) / tot;
+    colour = blend_colours(colour, W, rgba[p], w);
+    W += w;
+  }
+  mxyz[3 * (size_t)b] = m0;
+  mxyz[3 * (size_t)b + 1] = m1;
+  mxyz[3 * (size_t)b + 2] = m2;
+  mcol[b] = colour;
+  mw[b] = W;
+}
+
 constexpr int kExpandThreads = 1024;
-template <bool kWorld>
+template <int kMode>
 __global__ __launch_bounds__(kExpandThreads) void vb_expand(
     Params P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ seqs, uint32_t n,
-    const float* __restrict__ xyz, const float* __restrict__ normals, const uint32_t* __restrict__ rgba,
+    const float* __restrict__ xyz, const float* __restrict__ aux, const uint32_t* __restrict__ rgba,
     const int32_t* __restrict__ offsets, int nclouds, const float* __restrict__ Twc,
     const int32_t* __restrict__ slot_ids, float2* __restrict__ rec, uint32_t* __restrict__ rec_c,
     uint32_t* __restrict__ heads, uint32_t* __restrict__ updated_slots,
@@ -148,7 +216,7 @@ __global__ __launch_bounds__(kExpandThreads) void vb_expand(
     head = (r == 0) || (key != prev);
     chead = (r == 0) || ((key >> 12) != (prev >> 12));
     int cloud = 0;
-    const int p = kWorld ? (int)seqs[r] : point_of_seq(offsets, nclouds, (int)seqs[r], &cloud);
+    const int p = kMode != kSimple ? (int)seqs[r] : point_of_seq(offsets, nclouds, (int)seqs[r], &cloud);
     const PoseRt pose = load_pose(Twc, cloud);
     const float px = xyz[3 * (size_t)p], py = xyz[3 * (size_t)p + 1], pz = xyz[3 * (size_t)p + 2];
     const uint32_t slot = key >> 12, vid = key & 4095u;
@@ -156,11 +224,15 @@ __global__ __launch_bounds__(kExpandThreads) void vb_expand(
                       slot_ids[3 * slot + 1] * 16 + (int)((vid >> 4) & 15u),
                       slot_ids[3 * slot + 2] * 16 + (int)(vid >> 8)};
     float sdf, uw;
-    if (kWorld) {   // updateTsdfVoxel(ray_start, point_G, ..., weight 1), tsdf_integrator.cc:78
+    if (kMode == kWorld) {   // updateTsdfVoxel(ray_start, point_G, ..., weight 1), tsdf_integrator.cc:78
       Ray ray;
       float rs[3];
-      make_ray_world(P, pose, px, py, pz, normals[3 * (size_t)p], normals[3 * (size_t)p + 1], normals[3 * (size_t)p + 2], &ray, rs);
+      make_ray_world(P, pose, px, py, pz, aux[3 * (size_t)p], aux[3 * (size_t)p + 1], aux[3 * (size_t)p + 2], &ray, rs);
       visit_operands(P, rs, ray.pG, g, 1.0f, &sdf, &uw);
+    } else if (kMode == kMerged) {   // updateTsdfVoxel(origin, merged_point_G, ..., merged_color, merged_weight), :443
+      float pG[3];
+      quat_transform(pose, px, py, pz, pG);
+      visit_operands(P, pose.t, pG, g, aux[p], &sdf, &uw);
     } else {
       float pG[3];
       quat_transform(pose, px, py, pz, pG);
@@ -281,6 +353,11 @@ struct plvs_tsdf_voxblox {
   DevBuf<int32_t> offsets;
   DevBuf<float> st_xyz, st_Twc, st_nrm;
   DevBuf<uint32_t> st_rgba;
+  // merged integrator: per-point kinds / end voxels, the bundles (CSR) and their merged points
+  DevBuf<uint8_t> mg_kind, mg_clr;
+  DevBuf<int32_t> mg_g;
+  DevBuf<uint32_t> mg_first, mg_pts, mg_col;
+  DevBuf<float> mg_xyz, mg_w;
   plvs_tsdf_stats stats{};
   uint32_t last_updated = 0;
   void* ext = nullptr;                 // meshing scratch (tsdf_voxblox_mesh.hip), freed with the map
@@ -350,6 +427,8 @@ int plvs_hip_tsdf_voxblox_destroy(plvs_tsdf_voxblox* h) {
   h->counts.release(); h->keys0.release(); h->keys1.release(); h->seq0.release(); h->seq1.release();
   h->heads.release(); h->updated.release(); h->scratch.release(); h->rec_c.release(); h->rec.release();
   h->offsets.release(); h->st_xyz.release(); h->st_Twc.release(); h->st_nrm.release(); h->st_rgba.release();
+  h->mg_kind.release(); h->mg_clr.release(); h->mg_g.release(); h->mg_first.release(); h->mg_pts.release(); h->mg_col.release();
+  h->mg_xyz.release(); h->mg_w.release();
   delete h;
   return PLVS_OK;
 }
@@ -657,9 +736,11 @@ int plvs_hip_tsdf_voxblox_halo_clear(plvs_tsdf_voxblox* h) {
 
 }  // extern "C"
 
-// d_normals != nullptr: the world-cloud-with-normals flavour (integrateWorlPointCloud), one cloud.
+// mode kWorld: the world-cloud-with-normals flavour (integrateWorlPointCloud), d_aux = normals; mode kMerged:
+// MergedTsdfIntegrator's bundles, d_aux = merged weights, d_clr = clearing flags.  Both: one cloud.
 static int vb_integrate_impl(plvs_tsdf_voxblox* h, const float* d_xyz, const uint8_t* d_rgba, const int32_t* offsets,
-                             int nclouds, const float* d_Twc, void* stream, const float* d_normals) {
+                             int nclouds, const float* d_Twc, void* stream, int mode, const float* d_aux,
+                             const uint8_t* d_clr) {
   PLVS_REQUIRE(h, "null handle");
   PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
   PLVS_REQUIRE(offsets && nclouds >= 0, "bad offsets");
@@ -688,12 +769,12 @@ static int vb_integrate_impl(plvs_tsdf_voxblox* h, const float* d_xyz, const uin
   PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->total_visits, 0, sizeof(uint32_t), s));
   PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->err, 0, 4 * sizeof(uint32_t), s));
   const dim3 rgrid(ceil_div((size_t)n, 256)), rblock(256);
-  if (d_normals != nullptr)
-    hipLaunchKernelGGL((vb_ray_pass<false, true>), rgrid, rblock, 0, s, h->P, d_xyz, d_normals, n, h->offsets.p, nclouds,
-                       d_Twc, h->dir, h->d_ctr, h->counts.p, (uint32_t*)nullptr, (uint32_t*)nullptr);
-  else
-    hipLaunchKernelGGL((vb_ray_pass<false, false>), rgrid, rblock, 0, s, h->P, d_xyz, d_normals, n, h->offsets.p, nclouds,
-                       d_Twc, h->dir, h->d_ctr, h->counts.p, (uint32_t*)nullptr, (uint32_t*)nullptr);
+#define VB_RAY_PASS(FILL, MODE, K, Q)                                                                                    \
+  hipLaunchKernelGGL((vb_ray_pass<FILL, MODE>), rgrid, rblock, 0, s, h->P, d_xyz, d_aux, d_clr, n, h->offsets.p, nclouds, \
+                     d_Twc, h->dir, h->d_ctr, h->counts.p, K, Q)
+  if (mode == kWorld) VB_RAY_PASS(false, kWorld, (uint32_t*)nullptr, (uint32_t*)nullptr);
+  else if (mode == kMerged) VB_RAY_PASS(false, kMerged, (uint32_t*)nullptr, (uint32_t*)nullptr);
+  else VB_RAY_PASS(false, kSimple, (uint32_t*)nullptr, (uint32_t*)nullptr);
   PLVS_KERNEL_CHECK();
   PLVS_HIP_TRY(exclusive_scan_u32(h->counts.p, h->counts.p, (size_t)n, &h->d_ctr->total_visits,
                                   h->scratch.p, s));
@@ -722,12 +803,10 @@ static int vb_integrate_impl(plvs_tsdf_voxblox* h, const float* d_xyz, const uin
   PLVS_HIP_TRY(h->rec_c.reserve(V));
   PLVS_HIP_TRY(h->updated.reserve((size_t)h->num_blocks + 1));
   PLVS_HIP_TRY(h->scratch.reserve(radix_scratch_words(V)));
-  if (d_normals != nullptr)
-    hipLaunchKernelGGL((vb_ray_pass<true, true>), rgrid, rblock, 0, s, h->P, d_xyz, d_normals, n, h->offsets.p, nclouds,
-                       d_Twc, h->dir, h->d_ctr, h->counts.p, h->keys0.p, h->seq0.p);
-  else
-    hipLaunchKernelGGL((vb_ray_pass<true, false>), rgrid, rblock, 0, s, h->P, d_xyz, d_normals, n, h->offsets.p, nclouds,
-                       d_Twc, h->dir, h->d_ctr, h->counts.p, h->keys0.p, h->seq0.p);
+  if (mode == kWorld) VB_RAY_PASS(true, kWorld, h->keys0.p, h->seq0.p);
+  else if (mode == kMerged) VB_RAY_PASS(true, kMerged, h->keys0.p, h->seq0.p);
+  else VB_RAY_PASS(true, kSimple, h->keys0.p, h->seq0.p);
+#undef VB_RAY_PASS
   PLVS_KERNEL_CHECK();
   int key_bits = 12;
   while ((1ll << (key_bits - 12)) < (long long)h->num_blocks) ++key_bits;
@@ -736,14 +815,14 @@ static int vb_integrate_impl(plvs_tsdf_voxblox* h, const float* d_xyz, const uin
                                 h->scratch.p, s, &second));
   const uint32_t* keys = second ? h->keys1.p : h->keys0.p;
   const uint32_t* seqs = second ? h->seq1.p : h->seq0.p;
-  if (d_normals != nullptr)
-    hipLaunchKernelGGL(vb_expand<true>, dim3(ceil_div(V, kExpandThreads)), dim3(kExpandThreads), 0, s, h->P,
-                       keys, seqs, V, d_xyz, d_normals, d_col, h->offsets.p, nclouds, d_Twc, h->dir.slot_ids,
-                       h->rec.p, h->rec_c.p, h->heads.p, h->updated.p, h->d_ctr);
-  else
-    hipLaunchKernelGGL(vb_expand<false>, dim3(ceil_div(V, kExpandThreads)), dim3(kExpandThreads), 0, s, h->P,
-                       keys, seqs, V, d_xyz, d_normals, d_col, h->offsets.p, nclouds, d_Twc, h->dir.slot_ids,
-                       h->rec.p, h->rec_c.p, h->heads.p, h->updated.p, h->d_ctr);
+#define VB_EXPAND(MODE)                                                                                             \
+  hipLaunchKernelGGL(vb_expand<MODE>, dim3(ceil_div(V, kExpandThreads)), dim3(kExpandThreads), 0, s, h->P, keys, seqs, V, \
+                     d_xyz, d_aux, d_col, h->offsets.p, nclouds, d_Twc, h->dir.slot_ids, h->rec.p, h->rec_c.p,           \
+                     h->heads.p, h->updated.p, h->d_ctr)
+  if (mode == kWorld) VB_EXPAND(kWorld);
+  else if (mode == kMerged) VB_EXPAND(kMerged);
+  else VB_EXPAND(kSimple);
+#undef VB_EXPAND
   PLVS_KERNEL_CHECK();
   hipLaunchKernelGGL(vb_chain, dim3(ceil_div(V, 256)), dim3(256), 0, s, h->P, keys, V, h->rec.p,
                      h->rec_c.p, h->heads.p, h->d_ctr, h->dist, h->weight, h->rgba);
@@ -767,7 +846,7 @@ extern "C" {
 int plvs_hip_tsdf_voxblox_integrate_batch_dev(plvs_tsdf_voxblox* h, const float* d_xyz,
                                               const uint8_t* d_rgba, const int32_t* offsets,
                                               int nclouds, const float* d_Twc, void* stream) {
-  return vb_integrate_impl(h, d_xyz, d_rgba, offsets, nclouds, d_Twc, stream, nullptr);
+  return vb_integrate_impl(h, d_xyz, d_rgba, offsets, nclouds, d_Twc, stream, kSimple, nullptr, nullptr);
 }
 
 int plvs_hip_tsdf_voxblox_integrate_world_normals(plvs_tsdf_voxblox* h, const float* xyz, const uint8_t* rgba,
@@ -790,8 +869,97 @@ int plvs_hip_tsdf_voxblox_integrate_world_normals(plvs_tsdf_voxblox* h, const fl
   PLVS_HIP_TRY(hipMemcpy(h->st_Twc.p, Twc, 12 * sizeof(float), hipMemcpyHostToDevice));
   const int32_t offsets[2] = {0, n};
   const int rc = vb_integrate_impl(h, h->st_xyz.p, reinterpret_cast<const uint8_t*>(h->st_rgba.p), offsets, 1, h->st_Twc.p,
-                                   nullptr, h->st_nrm.p);
+                                   nullptr, kWorld, h->st_nrm.p, nullptr);
   (void)hipDeviceSynchronize();
+  return rc;
+}
+
+int plvs_hip_tsdf_voxblox_integrate_merged(plvs_tsdf_voxblox* h, const float* xyz, const uint8_t* rgba, int n,
+                                           const float* Twc) {
+  PLVS_REQUIRE(h, "null handle");
+  PLVS_REQUIRE(n >= 0 && Twc, "bad arguments");
+  PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
+  h->stats = plvs_tsdf_stats{};
+  h->last_updated = 0;
+  if (n == 0) return PLVS_OK;
+  PLVS_REQUIRE(xyz && rgba, "null cloud pointer");
+  hipStream_t s = nullptr;
+  PLVS_HIP_TRY(h->st_xyz.reserve((size_t)n * 3));
+  PLVS_HIP_TRY(h->st_rgba.reserve((size_t)n));
+  PLVS_HIP_TRY(h->st_Twc.reserve(12));
+  PLVS_HIP_TRY(h->mg_kind.reserve((size_t)n));
+  PLVS_HIP_TRY(h->mg_g.reserve((size_t)n * 3));
+  PLVS_HIP_TRY(hipMemcpy(h->st_xyz.p, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(h->st_rgba.p, rgba, (size_t)n * 4, hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(h->st_Twc.p, Twc, 12 * sizeof(float), hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->err, 0, sizeof(uint32_t), s));
+  hipLaunchKernelGGL(vb_merge_keys, dim3(ceil_div((size_t)n, 256)), dim3(256), 0, s, h->P, h->st_xyz.p, n, h->st_Twc.p, h->d_ctr,
+                     h->mg_kind.p, h->mg_g.p);
+  PLVS_KERNEL_CHECK();
+  std::vector<uint8_t> kind((size_t)n);
+  std::vector<int32_t> g((size_t)n * 3);
+  PLVS_HIP_TRY(hipMemcpy(kind.data(), h->mg_kind.p, (size_t)n, hipMemcpyDeviceToHost));
+  PLVS_HIP_TRY(hipMemcpy(g.data(), h->mg_g.p, (size_t)n * 3 * sizeof(int32_t), hipMemcpyDeviceToHost));
+  int rc = vb_read_counters(h, s);
+  if (rc != PLVS_OK) return rc;
+  if (h->h_ctr->err & kErrNonFinite) {
+    plvs::set_error("tsdf_voxblox integrate_merged: non-finite point in the cloud");
+    return PLVS_ERR_INVALID_ARG;
+  }
+  // bundleRays (tsdf_integrator.cc:361-386): points in the mixed visiting order into voxel_map / clear_map.  The
+  // integration order of the bundles is the iteration order of those maps (integrateVoxels, :448-470: begin(), ++it) —
+  // AnyIndexHashMapType = std::unordered_map with AnyIndexHash (core/block_hash.h:15-34) — so the host fills the
+  // same container with the same hash in the same sequence and walks it; nothing is computed here but that order.
+  struct Key {
+    int32_t v[3];
+    bool operator==(const Key& o) const { return v[0] == o.v[0] && v[1] == o.v[1] && v[2] == o.v[2]; }
+  };
+  struct KeyHash {
+    std::size_t operator()(const Key& k) const {
+      return (static_cast<unsigned int>(k.v[0]) * std::size_t(73856093) ^ k.v[1] * std::size_t(19349663) ^
+              k.v[2] * std::size_t(83492791));
+    }
+  };
+  using BundleMap = std::unordered_map<Key, std::vector<uint32_t>, KeyHash>;
+  BundleMap voxel_map, clear_map;
+  for (uint32_t sq = 0; sq < (uint32_t)n; ++sq) {
+    const uint32_t p = mixed_index(sq, (uint32_t)n);
+    if (kind[p] == 0) continue;
+    const Key k{{g[3 * (size_t)p], g[3 * (size_t)p + 1], g[3 * (size_t)p + 2]}};
+    (kind[p] == 2 ? clear_map : voxel_map)[k].push_back(p);
+  }
+  const size_t nb = voxel_map.size() + clear_map.size();
+  h->stats.points = n;
+  if (nb == 0) return PLVS_OK;
+  std::vector<uint32_t> first(nb + 1), pts;
+  std::vector<uint8_t> clr(nb);
+  pts.reserve((size_t)n);
+  size_t b = 0;
+  for (int pass = 0; pass < 2; ++pass)
+    for (const auto& kv : (pass ? clear_map : voxel_map)) {
+      first[b] = (uint32_t)pts.size();
+      clr[b] = (uint8_t)pass;
+      pts.insert(pts.end(), kv.second.begin(), kv.second.end());
+      ++b;
+    }
+  first[nb] = (uint32_t)pts.size();
+  PLVS_HIP_TRY(h->mg_first.reserve(nb + 1));
+  PLVS_HIP_TRY(h->mg_pts.reserve(pts.size()));
+  PLVS_HIP_TRY(h->mg_clr.reserve(nb));
+  PLVS_HIP_TRY(h->mg_xyz.reserve(3 * nb));
+  PLVS_HIP_TRY(h->mg_col.reserve(nb));
+  PLVS_HIP_TRY(h->mg_w.reserve(nb));
+  PLVS_HIP_TRY(hipMemcpy(h->mg_first.p, first.data(), (nb + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(h->mg_pts.p, pts.data(), pts.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(h->mg_clr.p, clr.data(), nb, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(vb_merge_bundles, dim3(ceil_div(nb, 256)), dim3(256), 0, s, h->st_xyz.p, h->st_rgba.p, h->mg_first.p,
+                     h->mg_pts.p, h->mg_clr.p, (int)nb, h->mg_xyz.p, h->mg_col.p, h->mg_w.p);
+  PLVS_KERNEL_CHECK();
+  const int32_t offsets[2] = {0, (int32_t)nb};
+  rc = vb_integrate_impl(h, h->mg_xyz.p, reinterpret_cast<const uint8_t*>(h->mg_col.p), offsets, 1, h->st_Twc.p, nullptr, kMerged,
+                         h->mg_w.p, h->mg_clr.p);
+  (void)hipDeviceSynchronize();
+  h->stats.points = n;
   return rc;
 }
 

@@ -90,6 +90,8 @@ struct Ray {
   float weight;               // getVoxelWeight(point_C)
 };
 
+PLVS_HD void ray_setup(const Params& P, const PoseRt& pose, bool clearing, Ray* r);
+
 // isPointValid + RayCaster set-up.  Returns false when the point is skipped.
 PLVS_HD bool make_ray(const Params& P, const PoseRt& pose, float px, float py, float pz, Ray* r) {
   const float ray_distance = sqrtf(vsum3(px * px, py * py, pz * pz));
@@ -100,8 +102,23 @@ PLVS_HD bool make_ray(const Params& P, const PoseRt& pose, float px, float py, f
     clearing = true;
   } else
     clearing = false;
-  const float* o = pose.t;
   quat_transform(pose, px, py, pz, r->pG);
+  ray_setup(P, pose, clearing, r);
+  r->weight = fabsf(pz) > 1e-6f ? 1.0f / (pz * pz) : 0.0f;  // use_const_weight = false
+  return true;
+}
+
+// MergedTsdfIntegrator::integrateVoxel's ray (tsdf_integrator.cc:418-424): RayCaster(origin, T_G_C * merged_point_C,
+// clearing_ray, ...) with the clearing flag of the bundle — no validity test of its own (bundleRays made it per point).
+PLVS_HD void make_ray_merged(const Params& P, const PoseRt& pose, float px, float py, float pz, bool clearing, Ray* r) {
+  quat_transform(pose, px, py, pz, r->pG);
+  ray_setup(P, pose, clearing, r);
+  r->weight = 0.0f;   // (the bundle's merged weight is an input of its own)
+}
+
+// RayCaster's constructor from origin and r->pG (integrator_utils.cc:137-167) + setupRayCaster (:196-235).
+PLVS_HD void ray_setup(const Params& P, const PoseRt& pose, bool clearing, Ray* r) {
+  const float* o = pose.t;
   const float d0 = r->pG[0] - o[0], d1 = r->pG[1] - o[1], d2 = r->pG[2] - o[2];
   const float z2 = vsum3(d0 * d0, d1 * d1, d2 * d2);
   const float dn = sqrtf(z2);
@@ -136,8 +153,6 @@ PLVS_HD bool make_ray(const Params& P, const PoseRt& pose, float px, float py, f
     r->t_next[k] = (corrected - shifted) / ray;
     r->t_step[k] = (float)r->sgn[k] / ray;
   }
-  r->weight = fabsf(pz) > 1e-6f ? 1.0f / (pz * pz) : 0.0f;  // use_const_weight = false
-  return true;
 }
 
 // The world-cloud-with-normals flavour (TsdfIntegratorBase::integrateWorlPointCloud, tsdf_integrator.cc:35-82: what

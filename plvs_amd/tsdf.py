@@ -353,6 +353,15 @@ class TsdfVoxblox:
         _lib.check(_L.plvs_hip_tsdf_voxblox_integrate(self._h, _lib.np_ptr(xyz), _lib.np_ptr(rgba), xyz.shape[0],
                                                       _lib.np_ptr(Twc)))
 
+    def integrate_merged(self, xyz, rgba, Twc):
+        """MergedTsdfIntegrator::integratePointCloud (integration method "merged", one thread)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8).reshape(-1, 4)
+        Twc = np.ascontiguousarray(Twc, dtype=np.float32).reshape(3, 4)
+        f = _L.plvs_hip_tsdf_voxblox_integrate_merged
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        _lib.check(f(self._h, _lib.np_ptr(xyz), _lib.np_ptr(rgba), xyz.shape[0], _lib.np_ptr(Twc)))
+
     def integrate_world_normals(self, xyz, rgba, normals, Twc=None):
         """TsdfIntegratorBase::integrateWorlPointCloud (the LoadMap path): a cloud with normals, T identity by default."""
         xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
@@ -472,8 +481,8 @@ class PointCloudMapVoxblox:
     skIntegrationMethod = "simple"   # the reference ships "fast", which is racy by design
 
     def __init__(self, resolution, use_carving=False, max_blocks=None):
-        if self.skIntegrationMethod != "simple":
-            raise NotImplementedError("only the deterministic 'simple' integrator is on the accelerated path")
+        if self.skIntegrationMethod not in ("simple", "merged"):
+            raise NotImplementedError("'fast' is racy by design (DESIGN.md §6): 'simple' and 'merged' are on the accelerated path")
         self._tsdf = TsdfVoxblox(resolution, use_carving, max_blocks)
         self._updated = set()        # the blocks whose updated() flag is set
         self.mesh_layer = {}         # block id -> dict(vertices, normals, colors): voxblox::MeshLayer
@@ -481,7 +490,10 @@ class PointCloudMapVoxblox:
     def InsertCloud(self, cloud_camera, Twc, max_range=None):
         print("PointCloudMapVoxblox<PointT>::InsertCloud()")
         Twc = np.asarray(Twc, dtype=np.float32)[:3, :4]
-        self._tsdf.integrate(cloud_camera["xyz"], cloud_camera["rgba"], Twc)
+        if self.skIntegrationMethod == "merged":
+            self._tsdf.integrate_merged(cloud_camera["xyz"], cloud_camera["rgba"], Twc)
+        else:
+            self._tsdf.integrate(cloud_camera["xyz"], cloud_camera["rgba"], Twc)
         for b in self._tsdf.updated_chunk_ids():          # tsdf_integrator.cc:151
             self._updated.add((int(b[0]), int(b[1]), int(b[2])))
 

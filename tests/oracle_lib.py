@@ -446,6 +446,19 @@ class _VoxbloxLike:
         Twc = np.ascontiguousarray(Twc, dtype=np.float32).reshape(3, 4)
         getattr(self.lib, self.p + "_integrate")(self.h, _ptr(xyz), _ptr(rgba), xyz.shape[0], _ptr(Twc))
 
+    def integrate_merged(self, xyz, rgba, Twc):
+        """MergedTsdfIntegrator::integratePointCloud (oracle only) -> (number of bundles, first point of each)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        Twc = np.ascontiguousarray(Twc, dtype=np.float32).reshape(3, 4)
+        f = getattr(self.lib, self.p + "_integrate_merged")
+        f.restype = None
+        f.argtypes = [_vp, _vp, _vp, _i, _vp, _vp, _vp]
+        nb = _i()
+        firsts = np.zeros(max(xyz.shape[0], 1), np.int32)
+        f(self.h, _ptr(xyz), _ptr(rgba), xyz.shape[0], _ptr(Twc), ctypes.byref(nb), _ptr(firsts))
+        return nb.value, firsts[:nb.value]
+
     def integrate_world_normals(self, xyz, rgba, normals, Twc=None):
         """TsdfIntegratorBase::integrateWorlPointCloud (oracle only)."""
         xyz = np.ascontiguousarray(xyz, dtype=np.float32)

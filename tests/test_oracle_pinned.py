@@ -290,3 +290,30 @@ def test_voxblox_marching_cubes_equal_the_reference_source():
         seen.add(int(sum(1 << i for i in range(8) if sdf[i] < 0)))
         total += n1
     assert len(seen) == 256 and total > 200000
+
+
+@needs_vref
+def test_voxblox_bundle_order_is_the_reference_maps_iteration_order():
+    """MergedTsdfIntegrator integrates its bundles in the iteration order of an AnyIndexHashMapType map.  The oracle
+    (and, with the same code, the product's host side) builds a std::unordered_map with the reference's hash over a
+    plain key type; here the reference's OWN container type (core/block_hash.h, compiled against the Eigen stand-in)
+    is filled with the same sequences — voxel indices as a cloud produces them, with repeats, negative coordinates,
+    sizes that cross many rehashes — and must iterate identically."""
+    ref, ora = ctypes.CDLL(VREF), ctypes.CDLL(ORA)
+    for lib, name in ((ref, "ref_voxblox_bundle_order"), (ora, "oracle_voxblox_bundle_order")):
+        getattr(lib, name).argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        getattr(lib, name).restype = ctypes.c_int
+    rng = np.random.default_rng(23)
+    for n in (1, 2, 7, 13, 14, 100, 1000, 5000, 76800, 300000):
+        spread = max(3, int(round(n ** (1 / 3) * 1.5)))
+        g = rng.integers(-spread, spread, (n, 3)).astype(np.int32)                 # ~ n / 4 distinct voxels, many repeats
+        if n > 1000:                                                                # a surface-like sheet with large offsets
+            g[:, 2] = (g[:, 0] // 3 + 40000).astype(np.int32)
+        g = np.ascontiguousarray(g)
+        a, b = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        na = ref.ref_voxblox_bundle_order(g.ctypes.data, n, a.ctypes.data)
+        nb = ora.oracle_voxblox_bundle_order(g.ctypes.data, n, b.ctypes.data)
+        assert na == nb == len(np.unique(g, axis=0))
+        assert np.array_equal(a[:na], b[:nb]), n
+        if n >= 1000:
+            assert not np.array_equal(a[:na], np.sort(a[:na])), "the map does not iterate in insertion order"
