@@ -47,7 +47,7 @@ __global__ void vb_publish_counters(const VCounters* __restrict__ ctr, VCounters
   __threadfence_system();
 }
 
-__device__ __forceinline__ PoseRt load_pose(const float* __restrict__ Twc, int c) {
+__device__ __forceinline__ PoseRt make_pose(const float* __restrict__ Twc, int c) {
   PoseRt p;
   const float* T = Twc + 12 * c;
   for (int i = 0; i < 3; ++i) {
@@ -57,6 +57,15 @@ __device__ __forceinline__ PoseRt load_pose(const float* __restrict__ Twc, int c
   quat_from_matrix(p.R, p.q);
   return p;
 }
+
+// The poses of a call with their quaternions, once per cloud (the kernels used to redo the conversion — a square root
+// and a division — for every point and every voxel visit).
+__global__ void vb_pose_prep(const float* __restrict__ Twc, int nclouds, PoseRt* __restrict__ poses) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < nclouds) poses[c] = make_pose(Twc, c);
+}
+
+__device__ __forceinline__ PoseRt load_pose(const PoseRt* __restrict__ poses, int c) { return poses[c]; }
 
 // Which point does sequence position i of the batch denote?
 __device__ __forceinline__ int point_of_seq(const int32_t* __restrict__ offsets, int nclouds, int i,
@@ -76,7 +85,7 @@ enum VbMode { kSimple = 0, kWorld = 1, kMerged = 2 };
 template <bool kFill, int kMode>
 __global__ __launch_bounds__(256) void vb_ray_pass(
     Params P, const float* __restrict__ xyz, const float* __restrict__ aux, const uint8_t* __restrict__ clr, int npoints,
-    const int32_t* __restrict__ offsets, int nclouds, const float* __restrict__ Twc, Directory dir,
+    const int32_t* __restrict__ offsets, int nclouds, const PoseRt* __restrict__ Twc, Directory dir,
     VCounters* __restrict__ ctr, uint32_t* __restrict__ counts, uint32_t* __restrict__ rec_keys,
     uint32_t* __restrict__ rec_seq) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(256) void vb_ray_pass(
 // 1 normal, 2 clearing) and the voxel T_G_C * point_C ends in.  The grouping itself needs the reference's hash map and
 // is done on the host (plvs_hip_tsdf_voxblox_integrate_merged).
 __global__ __launch_bounds__(256) void vb_merge_keys(Params P, const float* __restrict__ xyz, int n,
-                                                     const float* __restrict__ Twc, VCounters* __restrict__ ctr,
+                                                     const PoseRt* __restrict__ Twc, VCounters* __restrict__ ctr,
                                                      uint8_t* __restrict__ kind, int32_t* __restrict__ g) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -198,7 +207,7 @@ template <int kMode>
 __global__ __launch_bounds__(kExpandThreads) void vb_expand(
     Params P, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ seqs, uint32_t n,
     const float* __restrict__ xyz, const float* __restrict__ aux, const uint32_t* __restrict__ rgba,
-    const int32_t* __restrict__ offsets, int nclouds, const float* __restrict__ Twc,
+    const int32_t* __restrict__ offsets, int nclouds, const PoseRt* __restrict__ Twc,
     const int32_t* __restrict__ slot_ids, float2* __restrict__ rec, uint32_t* __restrict__ rec_c,
     uint32_t* __restrict__ heads, uint32_t* __restrict__ updated_slots,
     VCounters* __restrict__ ctr) {
@@ -353,6 +362,7 @@ struct plvs_tsdf_voxblox {
   DevBuf<int32_t> offsets;
   DevBuf<float> st_xyz, st_Twc, st_nrm;
   DevBuf<uint32_t> st_rgba;
+  DevBuf<PoseRt> poses;
   // merged integrator: per-point kinds / end voxels, the bundles (CSR) and their merged points
   DevBuf<uint8_t> mg_kind, mg_clr;
   DevBuf<int32_t> mg_g;
@@ -428,7 +438,7 @@ int plvs_hip_tsdf_voxblox_destroy(plvs_tsdf_voxblox* h) {
   h->heads.release(); h->updated.release(); h->scratch.release(); h->rec_c.release(); h->rec.release();
   h->offsets.release(); h->st_xyz.release(); h->st_Twc.release(); h->st_nrm.release(); h->st_rgba.release();
   h->mg_kind.release(); h->mg_clr.release(); h->mg_g.release(); h->mg_first.release(); h->mg_pts.release(); h->mg_col.release();
-  h->mg_xyz.release(); h->mg_w.release();
+  h->mg_xyz.release(); h->mg_w.release(); h->poses.release();
   delete h;
   return PLVS_OK;
 }
@@ -768,10 +778,13 @@ static int vb_integrate_impl(plvs_tsdf_voxblox* h, const float* d_xyz, const uin
                               hipMemcpyHostToDevice, s));
   PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->total_visits, 0, sizeof(uint32_t), s));
   PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->err, 0, 4 * sizeof(uint32_t), s));
+  PLVS_HIP_TRY(h->poses.reserve((size_t)nclouds));
+  hipLaunchKernelGGL(vb_pose_prep, dim3(ceil_div((size_t)nclouds, 64)), dim3(64), 0, s, d_Twc, nclouds, h->poses.p);
+  const PoseRt* const d_poses = h->poses.p;
   const dim3 rgrid(ceil_div((size_t)n, 256)), rblock(256);
 #define VB_RAY_PASS(FILL, MODE, K, Q)                                                                                    \
   hipLaunchKernelGGL((vb_ray_pass<FILL, MODE>), rgrid, rblock, 0, s, h->P, d_xyz, d_aux, d_clr, n, h->offsets.p, nclouds, \
-                     d_Twc, h->dir, h->d_ctr, h->counts.p, K, Q)
+                     d_poses, h->dir, h->d_ctr, h->counts.p, K, Q)
   if (mode == kWorld) VB_RAY_PASS(false, kWorld, (uint32_t*)nullptr, (uint32_t*)nullptr);
   else if (mode == kMerged) VB_RAY_PASS(false, kMerged, (uint32_t*)nullptr, (uint32_t*)nullptr);
   else VB_RAY_PASS(false, kSimple, (uint32_t*)nullptr, (uint32_t*)nullptr);
@@ -817,7 +830,7 @@ static int vb_integrate_impl(plvs_tsdf_voxblox* h, const float* d_xyz, const uin
   const uint32_t* seqs = second ? h->seq1.p : h->seq0.p;
 #define VB_EXPAND(MODE)                                                                                             \
   hipLaunchKernelGGL(vb_expand<MODE>, dim3(ceil_div(V, kExpandThreads)), dim3(kExpandThreads), 0, s, h->P, keys, seqs, V, \
-                     d_xyz, d_aux, d_col, h->offsets.p, nclouds, d_Twc, h->dir.slot_ids, h->rec.p, h->rec_c.p,           \
+                     d_xyz, d_aux, d_col, h->offsets.p, nclouds, d_poses, h->dir.slot_ids, h->rec.p, h->rec_c.p,         \
                      h->heads.p, h->updated.p, h->d_ctr)
   if (mode == kWorld) VB_EXPAND(kWorld);
   else if (mode == kMerged) VB_EXPAND(kMerged);
@@ -893,7 +906,9 @@ int plvs_hip_tsdf_voxblox_integrate_merged(plvs_tsdf_voxblox* h, const float* xy
   PLVS_HIP_TRY(hipMemcpy(h->st_rgba.p, rgba, (size_t)n * 4, hipMemcpyHostToDevice));
   PLVS_HIP_TRY(hipMemcpy(h->st_Twc.p, Twc, 12 * sizeof(float), hipMemcpyHostToDevice));
   PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->err, 0, sizeof(uint32_t), s));
-  hipLaunchKernelGGL(vb_merge_keys, dim3(ceil_div((size_t)n, 256)), dim3(256), 0, s, h->P, h->st_xyz.p, n, h->st_Twc.p, h->d_ctr,
+  PLVS_HIP_TRY(h->poses.reserve(1));
+  hipLaunchKernelGGL(vb_pose_prep, dim3(1), dim3(64), 0, s, h->st_Twc.p, 1, h->poses.p);
+  hipLaunchKernelGGL(vb_merge_keys, dim3(ceil_div((size_t)n, 256)), dim3(256), 0, s, h->P, h->st_xyz.p, n, h->poses.p, h->d_ctr,
                      h->mg_kind.p, h->mg_g.p);
   PLVS_KERNEL_CHECK();
   std::vector<uint8_t> kind((size_t)n);
