@@ -856,6 +856,11 @@ int plvs_hip_tsdf_voxblox_halo_export(plvs_tsdf_voxblox* h, const int32_t* d_ids
 int plvs_hip_tsdf_voxblox_halo_import(plvs_tsdf_voxblox* h, const int32_t* d_ids_xyz, const uint32_t* d_found,
                                       const uint32_t* d_payload, int n, int nfound, void* stream);
 int plvs_hip_tsdf_voxblox_halo_clear(plvs_tsdf_voxblox* h);
+/* The exchange over an RCCL communicator (ncclComm_t), collective: every rank calls it with the blocks it is about
+ * to mesh (possibly none); one round of requests / flags / payload rows (ncclSend / ncclRecv groups).  *fetched =
+ * blocks imported.  Afterwards mesh_blocks(the same list) is a local call. */
+int plvs_hip_tsdf_voxblox_halo_gather(plvs_tsdf_voxblox* h, void* rccl_comm, const int32_t* block_ids_xyz, int nblocks,
+                                      int* fetched, void* stream);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,8 @@
 // librccl.so.1 otherwise): the library carries no link-time dependency on it.
 #include <dlfcn.h>
 
+#include <algorithm>
+#include <array>
 #include <vector>
 
 #include "common.hpp"
@@ -308,31 +310,29 @@ int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm,
   return PLVS_OK;
 }
 
-// The meshing halo of a sharded chisel map over RCCL (include/plvs_hip.h: halo_gather): rounds of
-//   mesh_probe -> all-gather of the miss counts -> requests to the owners -> halo_export there -> answers back ->
-//   halo_import here
-// until no rank misses anything.  A chunk travels as 64 KiB (four planes of 4096 words).
-int plvs_hip_tsdf_chisel_halo_gather(plvs_tsdf_chisel* h, void* rccl_comm, const int32_t* chunk_ids_xyz, int nchunks,
-                                     int* fetched, void* stream) {
-  PLVS_REQUIRE(h && rccl_comm && fetched, "null argument");
-  *fetched = 0;
-  const Rccl* r = rccl();
-  if (r == nullptr || !r->send || !r->recv || !r->group_start || !r->group_end) {
-    plvs::set_error("RCCL is not available in this process (ncclSend / ncclRecv / librccl.so.1 not found)");
-    return PLVS_ERR_NO_DEVICE;
-  }
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  int world = 0, rank = 0;
-  if (r->comm_count(rccl_comm, &world) != 0 || r->comm_rank(rccl_comm, &rank) != 0 || world < 1 || world > 64) {
-    plvs::set_error("bad RCCL communicator (1..64 ranks)");
-    return PLVS_ERR_INVALID_ARG;
-  }
-  constexpr size_t kHaloWords = 4 * 4096;
-  struct Scratch {   // grow-only device buffers of this thread
-    plvs::DevBuf<int32_t> cnt, req_ids, got_ids;
-    plvs::DevBuf<uint32_t> got_found, got_payload, back_found, back_payload;
-  };
-  static thread_local Scratch B;
+}  // extern "C"
+
+namespace {
+
+// One round of a meshing halo over RCCL, shared by the two back ends: this rank's requests (host ids, any order) go to
+// their owners (three-prime hash mod world), the owners look them up, the found flags travel back, then one payload row
+// per block that exists; the answers are imported here.  Grouped ncclSend / ncclRecv for every step.
+struct HaloOps {
+  void* map;
+  size_t words;   // uint32 words of a block on the wire
+  int (*lookup)(void* map, const int32_t* d_ids, int n, uint32_t* d_found, void* stream);
+  int (*pack)(void* map, const int32_t* d_ids, const uint32_t* d_found, int n, uint32_t* d_payload, void* stream);
+  int (*import)(void* map, const int32_t* d_ids, const uint32_t* d_found, const uint32_t* d_payload, int n, int nfound,
+                void* stream);
+};
+
+struct HaloScratch {   // grow-only device buffers of the calling thread
+  plvs::DevBuf<int32_t> cnt, req_ids, got_ids;
+  plvs::DevBuf<uint32_t> got_found, got_payload, back_found, back_payload;
+};
+
+int halo_round(const Rccl* r, void* comm, int world, hipStream_t s, HaloScratch& B, const HaloOps& ops,
+               const std::vector<int32_t>& miss, int* imported) {
 #define RCCL_TRY(call)                                                      \
   do {                                                                      \
     const int e_ = (call);                                                  \
@@ -341,129 +341,220 @@ int plvs_hip_tsdf_chisel_halo_gather(plvs_tsdf_chisel* h, void* rccl_comm, const
       return PLVS_ERR_HIP;                                                  \
     }                                                                       \
   } while (0)
+  void* const stream = static_cast<void*>(s);
+  const int nmiss = (int)(miss.size() / 3);
+  *imported = 0;
+  PLVS_HIP_TRY(B.cnt.reserve((size_t)4 * world + 4));
+  std::vector<int32_t> req((size_t)3 * (nmiss > 0 ? nmiss : 1));
+  int32_t req_cnt[64] = {0}, got_cnt[64] = {0}, at[64];
+  std::vector<int> owner((size_t)(nmiss > 0 ? nmiss : 1));
+  for (int i = 0; i < nmiss; ++i) {
+    owner[(size_t)i] = plvs::chisel::shard_of(plvs::chisel::chunk_hash(miss[3 * i], miss[3 * i + 1], miss[3 * i + 2]), world);
+    ++req_cnt[owner[(size_t)i]];
+  }
+  at[0] = 0;
+  for (int p = 1; p < world; ++p) at[p] = at[p - 1] + req_cnt[p - 1];
+  for (int i = 0; i < nmiss; ++i) {
+    const int o = at[owner[(size_t)i]]++;
+    req[3 * (size_t)o] = miss[3 * i];
+    req[3 * (size_t)o + 1] = miss[3 * i + 1];
+    req[3 * (size_t)o + 2] = miss[3 * i + 2];
+  }
+  // ---- request counts
+  int32_t* d_req_cnt = B.cnt.p + world;
+  int32_t* d_got_cnt = B.cnt.p + 2 * world;
+  PLVS_HIP_TRY(hipMemcpyAsync(d_req_cnt, req_cnt, (size_t)world * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  RCCL_TRY(r->group_start());
+  for (int p = 0; p < world; ++p) {
+    RCCL_TRY(r->send(d_req_cnt + p, 1, /*ncclInt32*/ 2, p, comm, s));
+    RCCL_TRY(r->recv(d_got_cnt + p, 1, /*ncclInt32*/ 2, p, comm, s));
+  }
+  RCCL_TRY(r->group_end());
+  PLVS_HIP_TRY(hipMemcpyAsync(got_cnt, d_got_cnt, (size_t)world * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  size_t ngot = 0;
+  for (int p = 0; p < world; ++p) ngot += (size_t)got_cnt[p];
+  // ---- the ids
+  PLVS_HIP_TRY(B.req_ids.reserve(3 * (size_t)nmiss + 4));
+  PLVS_HIP_TRY(B.got_ids.reserve(3 * ngot + 4));
+  if (nmiss > 0)
+    PLVS_HIP_TRY(hipMemcpyAsync(B.req_ids.p, req.data(), (size_t)3 * nmiss * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  RCCL_TRY(r->group_start());
+  {
+    size_t so = 0, ro = 0;
+    for (int p = 0; p < world; ++p) {
+      if (req_cnt[p]) RCCL_TRY(r->send(B.req_ids.p + 3 * so, (size_t)3 * req_cnt[p], /*ncclInt32*/ 2, p, comm, s));
+      if (got_cnt[p]) RCCL_TRY(r->recv(B.got_ids.p + 3 * ro, (size_t)3 * got_cnt[p], /*ncclInt32*/ 2, p, comm, s));
+      so += (size_t)req_cnt[p];
+      ro += (size_t)got_cnt[p];
+    }
+  }
+  RCCL_TRY(r->group_end());
+  // ---- owners look the ids up; the flags travel the reverse way, then one payload row per block that exists
+  PLVS_HIP_TRY(B.got_found.reserve(ngot + 4));
+  PLVS_HIP_TRY(B.back_found.reserve((size_t)nmiss + 4));
+  int rc = ops.lookup(ops.map, B.got_ids.p, (int)ngot, B.got_found.p, stream);
+  if (rc != PLVS_OK) return rc;
+  RCCL_TRY(r->group_start());
+  {
+    size_t so = 0, ro = 0;
+    for (int p = 0; p < world; ++p) {
+      if (got_cnt[p]) RCCL_TRY(r->send(B.got_found.p + so, (size_t)got_cnt[p], /*ncclUint32*/ 3, p, comm, s));
+      if (req_cnt[p]) RCCL_TRY(r->recv(B.back_found.p + ro, (size_t)req_cnt[p], /*ncclUint32*/ 3, p, comm, s));
+      so += (size_t)got_cnt[p];
+      ro += (size_t)req_cnt[p];
+    }
+  }
+  RCCL_TRY(r->group_end());
+  std::vector<uint32_t> got_found(ngot + 1), back_found((size_t)nmiss + 1);
+  if (ngot) PLVS_HIP_TRY(hipMemcpyAsync(got_found.data(), B.got_found.p, ngot * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  if (nmiss) PLVS_HIP_TRY(hipMemcpyAsync(back_found.data(), B.back_found.p, (size_t)nmiss * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  size_t send_rows[64] = {0}, recv_rows[64] = {0}, nsend = 0, nrecv = 0;
+  {
+    size_t so = 0, ro = 0;
+    for (int p = 0; p < world; ++p) {
+      for (int i = 0; i < got_cnt[p]; ++i) send_rows[p] += got_found[so + (size_t)i] ? 1 : 0;
+      for (int i = 0; i < req_cnt[p]; ++i) recv_rows[p] += back_found[ro + (size_t)i] ? 1 : 0;
+      so += (size_t)got_cnt[p];
+      ro += (size_t)req_cnt[p];
+      nsend += send_rows[p];
+      nrecv += recv_rows[p];
+    }
+  }
+  PLVS_HIP_TRY(B.got_payload.reserve(nsend * ops.words + 4));
+  PLVS_HIP_TRY(B.back_payload.reserve(nrecv * ops.words + 4));
+  rc = ops.pack(ops.map, B.got_ids.p, B.got_found.p, (int)ngot, B.got_payload.p, stream);
+  if (rc != PLVS_OK) return rc;
+  RCCL_TRY(r->group_start());
+  {
+    size_t so = 0, ro = 0;
+    for (int p = 0; p < world; ++p) {
+      if (send_rows[p]) RCCL_TRY(r->send(B.got_payload.p + so * ops.words, send_rows[p] * ops.words, /*ncclUint32*/ 3, p, comm, s));
+      if (recv_rows[p]) RCCL_TRY(r->recv(B.back_payload.p + ro * ops.words, recv_rows[p] * ops.words, /*ncclUint32*/ 3, p, comm, s));
+      so += send_rows[p];
+      ro += recv_rows[p];
+    }
+  }
+  RCCL_TRY(r->group_end());
+  rc = ops.import(ops.map, B.req_ids.p, B.back_found.p, B.back_payload.p, nmiss, (int)nrecv, stream);
+  if (rc != PLVS_OK) return rc;
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  *imported = (int)nrecv;
+  return PLVS_OK;
+#undef RCCL_TRY
+}
+
+int halo_comm(void* rccl_comm, const Rccl** r_out, int* world, int* rank) {
+  const Rccl* r = rccl();
+  if (r == nullptr || !r->send || !r->recv || !r->group_start || !r->group_end) {
+    plvs::set_error("RCCL is not available in this process (ncclSend / ncclRecv / librccl.so.1 not found)");
+    return PLVS_ERR_NO_DEVICE;
+  }
+  if (r->comm_count(rccl_comm, world) != 0 || r->comm_rank(rccl_comm, rank) != 0 || *world < 1 || *world > 64) {
+    plvs::set_error("bad RCCL communicator (1..64 ranks)");
+    return PLVS_ERR_INVALID_ARG;
+  }
+  *r_out = r;
+  return PLVS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// The meshing halo of a sharded chisel map over RCCL (include/plvs_hip.h: halo_gather): rounds of
+//   mesh_probe -> all-gather of the miss counts -> halo_round (requests to the owners, answers back, import)
+// until no rank misses anything.  A chunk travels as 64 KiB (four planes of 4096 words).
+int plvs_hip_tsdf_chisel_halo_gather(plvs_tsdf_chisel* h, void* rccl_comm, const int32_t* chunk_ids_xyz, int nchunks,
+                                     int* fetched, void* stream) {
+  PLVS_REQUIRE(h && rccl_comm && fetched, "null argument");
+  *fetched = 0;
+  const Rccl* r = nullptr;
+  int world = 0, rank = 0;
+  int rc = halo_comm(rccl_comm, &r, &world, &rank);
+  if (rc != PLVS_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  static thread_local HaloScratch B;
+  const HaloOps ops{h, (size_t)4 * 4096,
+                    [](void* m, const int32_t* ids, int n, uint32_t* f, void* st) {
+                      return plvs_hip_tsdf_chisel_halo_lookup(static_cast<plvs_tsdf_chisel*>(m), ids, n, f, st);
+                    },
+                    [](void* m, const int32_t* ids, const uint32_t* f, int n, uint32_t* p, void* st) {
+                      return plvs_hip_tsdf_chisel_halo_export(static_cast<plvs_tsdf_chisel*>(m), ids, f, n, p, st);
+                    },
+                    [](void* m, const int32_t* ids, const uint32_t* f, const uint32_t* p, int n, int nf, void* st) {
+                      return plvs_hip_tsdf_chisel_halo_import(static_cast<plvs_tsdf_chisel*>(m), ids, f, p, n, nf, st);
+                    }};
   PLVS_HIP_TRY(B.cnt.reserve((size_t)4 * world + 4));
   for (int round = 0; round < 8; ++round) {
     int nmiss = 0;
-    int rc = plvs_hip_tsdf_chisel_mesh_probe(h, chunk_ids_xyz, nchunks, &nmiss);
+    rc = plvs_hip_tsdf_chisel_mesh_probe(h, chunk_ids_xyz, nchunks, &nmiss);
     if (rc != PLVS_OK) return rc;
     // does anybody miss anything?
     int32_t all_miss[64];
     PLVS_HIP_TRY(hipMemcpyAsync(B.cnt.p + rank, &nmiss, sizeof(int32_t), hipMemcpyHostToDevice, s));
-    RCCL_TRY(r->all_gather(B.cnt.p + rank, B.cnt.p, 1, /*ncclInt32*/ 2, rccl_comm, s));
+    if (r->all_gather(B.cnt.p + rank, B.cnt.p, 1, /*ncclInt32*/ 2, rccl_comm, s) != 0) {
+      plvs::set_error("ncclAllGather failed");
+      return PLVS_ERR_HIP;
+    }
     PLVS_HIP_TRY(hipMemcpyAsync(all_miss, B.cnt.p, (size_t)world * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     PLVS_HIP_TRY(hipStreamSynchronize(s));
     int any = 0;
     for (int p = 0; p < world; ++p) any |= all_miss[p];
-    if (any == 0) {
-      return PLVS_OK;
-    }
-    // this rank's requests, grouped by owner
-    std::vector<int32_t> miss((size_t)3 * (nmiss > 0 ? nmiss : 1)), req((size_t)3 * (nmiss > 0 ? nmiss : 1));
+    if (any == 0) return PLVS_OK;
+    std::vector<int32_t> miss((size_t)3 * (nmiss > 0 ? nmiss : 0));
     if (nmiss > 0) {
       int got_n = 0;
       rc = plvs_hip_tsdf_chisel_halo_missing(h, miss.data(), nmiss, &got_n);
       if (rc != PLVS_OK) return rc;
-      nmiss = got_n;
+      miss.resize((size_t)3 * got_n);
     }
-    int32_t req_cnt[64] = {0}, got_cnt[64] = {0}, at[64];
-    std::vector<int> owner((size_t)(nmiss > 0 ? nmiss : 1));
-    for (int i = 0; i < nmiss; ++i) {
-      owner[(size_t)i] = plvs::chisel::shard_of(plvs::chisel::chunk_hash(miss[3 * i], miss[3 * i + 1], miss[3 * i + 2]), world);
-      ++req_cnt[owner[(size_t)i]];
-    }
-    at[0] = 0;
-    for (int p = 1; p < world; ++p) at[p] = at[p - 1] + req_cnt[p - 1];
-    for (int i = 0; i < nmiss; ++i) {
-      const int o = at[owner[(size_t)i]]++;
-      req[3 * (size_t)o] = miss[3 * i];
-      req[3 * (size_t)o + 1] = miss[3 * i + 1];
-      req[3 * (size_t)o + 2] = miss[3 * i + 2];
-    }
-    // ---- request counts
-    int32_t* d_req_cnt = B.cnt.p + world;
-    int32_t* d_got_cnt = B.cnt.p + 2 * world;
-    PLVS_HIP_TRY(hipMemcpyAsync(d_req_cnt, req_cnt, (size_t)world * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    RCCL_TRY(r->group_start());
-    for (int p = 0; p < world; ++p) {
-      RCCL_TRY(r->send(d_req_cnt + p, 1, /*ncclInt32*/ 2, p, rccl_comm, s));
-      RCCL_TRY(r->recv(d_got_cnt + p, 1, /*ncclInt32*/ 2, p, rccl_comm, s));
-    }
-    RCCL_TRY(r->group_end());
-    PLVS_HIP_TRY(hipMemcpyAsync(got_cnt, d_got_cnt, (size_t)world * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    PLVS_HIP_TRY(hipStreamSynchronize(s));
-    size_t ngot = 0;
-    for (int p = 0; p < world; ++p) ngot += (size_t)got_cnt[p];
-    // ---- the ids
-    PLVS_HIP_TRY(B.req_ids.reserve(3 * (size_t)nmiss + 4));
-    PLVS_HIP_TRY(B.got_ids.reserve(3 * ngot + 4));
-    if (nmiss > 0)
-      PLVS_HIP_TRY(hipMemcpyAsync(B.req_ids.p, req.data(), (size_t)3 * nmiss * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    RCCL_TRY(r->group_start());
-    {
-      size_t so = 0, ro = 0;
-      for (int p = 0; p < world; ++p) {
-        if (req_cnt[p]) RCCL_TRY(r->send(B.req_ids.p + 3 * so, (size_t)3 * req_cnt[p], /*ncclInt32*/ 2, p, rccl_comm, s));
-        if (got_cnt[p]) RCCL_TRY(r->recv(B.got_ids.p + 3 * ro, (size_t)3 * got_cnt[p], /*ncclInt32*/ 2, p, rccl_comm, s));
-        so += (size_t)req_cnt[p];
-        ro += (size_t)got_cnt[p];
-      }
-    }
-    RCCL_TRY(r->group_end());
-    // ---- owners look the ids up; the flags travel the reverse way, then one payload row per chunk that exists
-    PLVS_HIP_TRY(B.got_found.reserve(ngot + 4));
-    PLVS_HIP_TRY(B.back_found.reserve((size_t)nmiss + 4));
-    rc = plvs_hip_tsdf_chisel_halo_lookup(h, B.got_ids.p, (int)ngot, B.got_found.p, stream);
+    int imported = 0;
+    rc = halo_round(r, rccl_comm, world, s, B, ops, miss, &imported);
     if (rc != PLVS_OK) return rc;
-    RCCL_TRY(r->group_start());
-    {
-      size_t so = 0, ro = 0;
-      for (int p = 0; p < world; ++p) {
-        if (got_cnt[p]) RCCL_TRY(r->send(B.got_found.p + so, (size_t)got_cnt[p], /*ncclUint32*/ 3, p, rccl_comm, s));
-        if (req_cnt[p]) RCCL_TRY(r->recv(B.back_found.p + ro, (size_t)req_cnt[p], /*ncclUint32*/ 3, p, rccl_comm, s));
-        so += (size_t)got_cnt[p];
-        ro += (size_t)req_cnt[p];
-      }
-    }
-    RCCL_TRY(r->group_end());
-    std::vector<uint32_t> got_found(ngot + 1), back_found((size_t)nmiss + 1);
-    if (ngot) PLVS_HIP_TRY(hipMemcpyAsync(got_found.data(), B.got_found.p, ngot * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    if (nmiss) PLVS_HIP_TRY(hipMemcpyAsync(back_found.data(), B.back_found.p, (size_t)nmiss * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    PLVS_HIP_TRY(hipStreamSynchronize(s));
-    size_t send_rows[64] = {0}, recv_rows[64] = {0}, nsend = 0, nrecv = 0;
-    {
-      size_t so = 0, ro = 0;
-      for (int p = 0; p < world; ++p) {
-        for (int i = 0; i < got_cnt[p]; ++i) send_rows[p] += got_found[so + (size_t)i] ? 1 : 0;
-        for (int i = 0; i < req_cnt[p]; ++i) recv_rows[p] += back_found[ro + (size_t)i] ? 1 : 0;
-        so += (size_t)got_cnt[p];
-        ro += (size_t)req_cnt[p];
-        nsend += send_rows[p];
-        nrecv += recv_rows[p];
-      }
-    }
-    PLVS_HIP_TRY(B.got_payload.reserve(nsend * kHaloWords + 4));
-    PLVS_HIP_TRY(B.back_payload.reserve(nrecv * kHaloWords + 4));
-    rc = plvs_hip_tsdf_chisel_halo_export(h, B.got_ids.p, B.got_found.p, (int)ngot, B.got_payload.p, stream);
-    if (rc != PLVS_OK) return rc;
-    RCCL_TRY(r->group_start());
-    {
-      size_t so = 0, ro = 0;
-      for (int p = 0; p < world; ++p) {
-        if (send_rows[p]) RCCL_TRY(r->send(B.got_payload.p + so * kHaloWords, send_rows[p] * kHaloWords, /*ncclUint32*/ 3, p, rccl_comm, s));
-        if (recv_rows[p]) RCCL_TRY(r->recv(B.back_payload.p + ro * kHaloWords, recv_rows[p] * kHaloWords, /*ncclUint32*/ 3, p, rccl_comm, s));
-        so += send_rows[p];
-        ro += recv_rows[p];
-      }
-    }
-    RCCL_TRY(r->group_end());
-    rc = plvs_hip_tsdf_chisel_halo_import(h, B.req_ids.p, B.back_found.p, B.back_payload.p, nmiss, (int)nrecv, stream);
-    if (rc != PLVS_OK) return rc;
-    PLVS_HIP_TRY(hipStreamSynchronize(s));   // (the next probe runs on the default stream)
-    *fetched += (int)nrecv;
+    *fetched += imported;
   }
-#undef RCCL_TRY
   plvs::set_error("halo_gather: the halo did not settle in 8 rounds");
   return PLVS_ERR_CAPACITY;
+}
+
+// The meshing halo of a block-sharded voxblox map over RCCL: the blocks to fetch are known (the seven +x / +y / +z
+// neighbours of every block of the list that another rank owns), so it is ONE halo_round.  A block travels as 48 KiB.
+int plvs_hip_tsdf_voxblox_halo_gather(plvs_tsdf_voxblox* h, void* rccl_comm, const int32_t* block_ids_xyz, int nblocks,
+                                      int* fetched, void* stream) {
+  PLVS_REQUIRE(h && rccl_comm && fetched && nblocks >= 0 && (nblocks == 0 || block_ids_xyz), "bad arguments");
+  *fetched = 0;
+  const Rccl* r = nullptr;
+  int world = 0, rank = 0;
+  int rc = halo_comm(rccl_comm, &r, &world, &rank);
+  if (rc != PLVS_OK) return rc;
+  static thread_local HaloScratch B;
+  const HaloOps ops{h, (size_t)3 * 4096,
+                    [](void* m, const int32_t* ids, int n, uint32_t* f, void* st) {
+                      return plvs_hip_tsdf_voxblox_halo_lookup(static_cast<plvs_tsdf_voxblox*>(m), ids, n, f, st);
+                    },
+                    [](void* m, const int32_t* ids, const uint32_t* f, int n, uint32_t* p, void* st) {
+                      return plvs_hip_tsdf_voxblox_halo_export(static_cast<plvs_tsdf_voxblox*>(m), ids, f, n, p, st);
+                    },
+                    [](void* m, const int32_t* ids, const uint32_t* f, const uint32_t* p, int n, int nf, void* st) {
+                      return plvs_hip_tsdf_voxblox_halo_import(static_cast<plvs_tsdf_voxblox*>(m), ids, f, p, n, nf, st);
+                    }};
+  // the foreign forward neighbours, once each
+  std::vector<std::array<int32_t, 3>> need;
+  need.reserve((size_t)nblocks * 7);
+  for (int i = 0; i < nblocks; ++i)
+    for (int d = 1; d < 8; ++d) {
+      const std::array<int32_t, 3> nb = {block_ids_xyz[3 * i] + (d & 1), block_ids_xyz[3 * i + 1] + ((d >> 1) & 1),
+                                         block_ids_xyz[3 * i + 2] + ((d >> 2) & 1)};
+      if (plvs::chisel::shard_of(plvs::chisel::chunk_hash(nb[0], nb[1], nb[2]), world) != rank) need.push_back(nb);
+    }
+  std::sort(need.begin(), need.end());
+  need.erase(std::unique(need.begin(), need.end()), need.end());
+  std::vector<int32_t> miss;
+  miss.reserve(need.size() * 3);
+  for (const auto& nb : need) miss.insert(miss.end(), nb.begin(), nb.end());
+  return halo_round(r, rccl_comm, world, static_cast<hipStream_t>(stream), B, ops, miss, fetched);
 }
 
 int plvs_hip_rccl_world_size(void* rccl_comm, int* world) {

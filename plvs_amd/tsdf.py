@@ -462,6 +462,15 @@ class TsdfVoxblox:
         _lib.check(f(self._h, _lib.t_ptr(d_ids), _lib.t_ptr(d_found), _lib.t_ptr(d_payload), int(d_ids.shape[0]),
                      int(d_payload.shape[0]), _lib.current_stream_ptr()))
 
+    def halo_gather(self, comm, block_ids):
+        """The halo exchange behind the C ABI over an ncclComm_t (collective) -> blocks imported."""
+        ids = np.ascontiguousarray(block_ids, dtype=np.int32).reshape(-1, 3)
+        f = _L.plvs_hip_tsdf_voxblox_halo_gather
+        f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        n = ctypes.c_int()
+        _lib.check(f(self._h, comm, _lib.np_ptr(ids), ids.shape[0], ctypes.byref(n), _lib.current_stream_ptr()))
+        return n.value
+
     def halo_clear(self):
         _L.plvs_hip_tsdf_voxblox_halo_clear.argtypes = [ctypes.c_void_p]
         _lib.check(_L.plvs_hip_tsdf_voxblox_halo_clear(self._h))

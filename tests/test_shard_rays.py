@@ -202,6 +202,7 @@ def test_hip_ray_sharded_integrate_through_torch_distributed_and_rccl_at_world_o
         a, fetched = sharded_mesh_blocks(vb, bids)
         b = vb.mesh_blocks(bids)
         assert fetched == 0 and all(a[n].tobytes() == b[n].tobytes() for n in ("vertices", "normals", "colors", "block_first"))
+        assert vb.halo_gather(comm, bids) == 0          # the same exchange behind the C ABI over the ncclComm_t
         vb.close()
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
