@@ -1,0 +1,109 @@
+// C entry points over voxblox's OWN integrators — src/integrator/tsdf_integrator.cc (TsdfIntegratorBase::updateTsdfVoxel,
+// computeDistance, getVoxelWeight, isPointValid, allocateStorageAndGetVoxelPtr, integrateWorlPointCloud; the Simple and
+// the Merged integrator) with Layer / Block from core/*.h — compiled where they lie under /root/reference against the
+// stand-ins of oracle/ref/vbx_shim (Eigen, glog, kindr, protobuf names) -> oracle/_ref/libvoxblox_ref.so.
+// tests/test_oracle_pinned.py runs whole clouds through these and through oracle/tsdf_voxblox.c /
+// tsdf_voxblox_merged.cpp and compares every voxel of every block bit for bit.
+// The pose arrives as (quaternion, position): the conversion from the pose matrix is not part of what is pinned here
+// (vbx_shim/kindr/minimal/quat-transformation.h).  integrator_threads = 1.
+// TEST INFRASTRUCTURE ONLY: nothing under plvs_amd/ may call into this file.
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "voxblox/core/layer.h"
+#include "voxblox/core/voxel.h"
+#include "voxblox/integrator/tsdf_integrator.h"
+
+namespace {
+struct RefMap {
+  std::unique_ptr<voxblox::Layer<voxblox::TsdfVoxel>> layer;
+  std::unique_ptr<voxblox::TsdfIntegratorBase> integrator;
+};
+}  // namespace
+
+extern "C" {
+
+// The configuration src/PointCloudMapVoxblox.cc:52-71 builds; method: "simple" or "merged".
+void* ref_voxblox_create(float voxel_size, float truncation, float max_weight, float min_ray, float max_ray, int carving,
+                         const char* method) {
+  RefMap* m = new RefMap();
+  m->layer.reset(new voxblox::Layer<voxblox::TsdfVoxel>(voxel_size, 16u));
+  voxblox::TsdfIntegratorBase::Config c;
+  c.default_truncation_distance = truncation;
+  c.max_weight = max_weight;
+  c.voxel_carving_enabled = carving != 0;
+  c.min_ray_length_m = min_ray;
+  c.max_ray_length_m = max_ray;
+  c.use_const_weight = false;
+  c.allow_clear = true;
+  c.use_weight_dropoff = true;
+  c.use_sparsity_compensation_factor = false;
+  c.sparsity_compensation_factor = 1.0f;
+  c.enable_anti_grazing = false;
+  c.integrator_threads = 1;
+  if (std::string(method) == "merged") m->integrator.reset(new voxblox::MergedTsdfIntegrator(c, m->layer.get()));
+  else m->integrator.reset(new voxblox::SimpleTsdfIntegrator(c, m->layer.get()));
+  return m;
+}
+
+void ref_voxblox_destroy(void* h) { delete static_cast<RefMap*>(h); }
+
+static void to_cloud(const float* xyz, const uint8_t* rgba, int n, voxblox::Pointcloud* pts, voxblox::Colors* cols) {
+  pts->reserve((size_t)n);
+  cols->reserve((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    pts->push_back(voxblox::Point(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
+    cols->push_back(voxblox::Color(rgba[4 * i], rgba[4 * i + 1], rgba[4 * i + 2], rgba[4 * i + 3]));
+  }
+}
+
+void ref_voxblox_integrate(void* h, const float* quat_wxyz, const float* position, const float* xyz, const uint8_t* rgba, int n) {
+  RefMap* m = static_cast<RefMap*>(h);
+  voxblox::Pointcloud pts;
+  voxblox::Colors cols;
+  to_cloud(xyz, rgba, n, &pts, &cols);
+  const voxblox::Transformation T(quat_wxyz, position);
+  m->integrator->integratePointCloud(T, pts, cols, false);
+}
+
+void ref_voxblox_integrate_world(void* h, const float* quat_wxyz, const float* position, const float* xyz, const uint8_t* rgba,
+                                 const float* normals, int n) {
+  RefMap* m = static_cast<RefMap*>(h);
+  voxblox::Pointcloud pts;
+  voxblox::Colors cols;
+  to_cloud(xyz, rgba, n, &pts, &cols);
+  voxblox::Normals nrm;
+  nrm.reserve((size_t)n);
+  for (int i = 0; i < n; ++i) nrm.push_back(voxblox::Point(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]));
+  const voxblox::Transformation T(quat_wxyz, position);
+  m->integrator->integrateWorlPointCloud(T, pts, cols, nrm);
+}
+
+int ref_voxblox_num_blocks(void* h) { return (int)static_cast<RefMap*>(h)->layer->getNumberOfAllocatedBlocks(); }
+
+void ref_voxblox_block_ids(void* h, int32_t* ids) {
+  voxblox::BlockIndexList list;
+  static_cast<RefMap*>(h)->layer->getAllAllocatedBlocks(&list);
+  size_t k = 0;
+  for (const voxblox::BlockIndex& b : list) {
+    ids[3 * k] = b.x(); ids[3 * k + 1] = b.y(); ids[3 * k + 2] = b.z();
+    ++k;
+  }
+}
+
+int ref_voxblox_get_block(void* h, int bx, int by, int bz, float* distance, float* weight, uint32_t* rgba) {
+  voxblox::Block<voxblox::TsdfVoxel>::ConstPtr b =
+      static_cast<RefMap*>(h)->layer->getBlockPtrByIndex(voxblox::BlockIndex(bx, by, bz));
+  if (!b) return 0;
+  for (size_t i = 0; i < b->num_voxels(); ++i) {
+    const voxblox::TsdfVoxel& v = b->getVoxelByLinearIndex(i);
+    distance[i] = v.distance;
+    weight[i] = v.weight;
+    rgba[i] = (uint32_t)v.color.r | ((uint32_t)v.color.g << 8) | ((uint32_t)v.color.b << 16) | ((uint32_t)v.color.a << 24);
+  }
+  return 1;
+}
+
+}  // extern "C"

@@ -5,17 +5,24 @@
  *
  * TEST INFRASTRUCTURE ONLY.  Nothing under plvs_amd/ may call into this file.
  *
- * Parity status: PARTLY PINNED by the reference's own sources.  voxblox's gtests never call
- * integratePointCloud and are disabled in the build; the library as a whole cannot be compiled
- * here (Eigen3, glog, protobuf absent), but integrator_utils.cc and the inline helpers of common.h /
- * block_hash.h compile UNMODIFIED against stand-ins for Eigen, glog and kindr's type names
- * (oracle/ref/vbx_shim -> oracle/_ref/libvoxblox_ref.so).  tests/test_oracle_pinned.py checks vb_ray_setup /
- * vb_ray_next (RayCaster: ray end points for normal and clearing rays with carving on and off, setupRayCaster,
- * nextRayIndex; 30 000 rays), mixed_index (ThreadSafeIndex with its bit-reversal table), blend
- * (Color::blendTwoColors), block_index / local_index and the block hash below — the functions the integrate loop
- * calls — against them bit for bit.  NOT pinned (restated by reading): updateTsdfVoxel / computeDistance /
- * getVoxelWeight (tsdf_integrator.cc needs Layer / Block, which need protobuf), the point filter, the pose
- * conversion below, and Eigen's evaluation order, which the stand-in encodes as this file does.
+ * Parity status: PINNED by the reference's own sources, end to end but for the pose conversion.  voxblox's gtests
+ * never call integratePointCloud and are disabled in the build, and the library as a whole cannot be
+ * built here (Eigen3, glog, protobuf, kindr absent) — but its integrator sources compile UNMODIFIED against small
+ * stand-ins for those headers (oracle/ref/vbx_shim -> oracle/_ref/libvoxblox_ref.so): src/integrator/tsdf_integrator.cc
+ * (TsdfIntegratorBase::updateTsdfVoxel / computeDistance / getVoxelWeight / isPointValid /
+ * allocateStorageAndGetVoxelPtr / integrateWorlPointCloud, SimpleTsdfIntegrator, MergedTsdfIntegrator) with Layer and
+ * Block from core/*.h, src/integrator/integrator_utils.cc (RayCaster, ThreadSafeIndex), mesh/marching_cubes.{h,cc}.
+ * tests/test_oracle_pinned.py runs WHOLE CLOUDS (three key frames, 5 and 10 cm, carving off / on with points beyond
+ * the 5 m ray limit; posed world clouds with un-normalised and zero normals) through the reference's Simple and Merged
+ * integrators and integrateWorlPointCloud and through this file (+ tsdf_voxblox_merged.cpp) and compares every voxel
+ * of every block bit for bit; the pieces (ray caster, visiting order, colour blend, indices, hash, map iteration
+ * order, meshCube) are also compared one by one.  What the stand-ins encode rather than pin: Eigen's evaluation order
+ * for sums of three, and the pose — the kindr stand-in applies a quaternion it is handed (computed by
+ * quat_from_matrix below, restated from minkindr + Eigen 3.3's Quaternion.h), it does not convert the matrix.
+ * One behaviour of the reference is NOT reproduced: integrateWorlPointCloud never calls updateLayerWithStoredBlocks,
+ * so the blocks it creates stay in the integrator's temp_block_map_ and join the layer only with the next
+ * integratePointCloud call (PointCloudMapVoxblox::LoadMap's UpdateMap therefore meshes none of them); here, and on the
+ * device, they are in the map at once — the voxel payloads are identical.
  * The pose goes through kindr's quaternion as in the reference (quat_from_matrix / quat_transform below, restated
  * from minkindr — present in the tree — and Eigen 3.3's Quaternion.h, which is not).  The multi-threaded reference is itself
  * order-nondeterministic (per-voxel mutexes, ThreadSafeIndex); the oracle is the
@@ -534,6 +541,15 @@ void oracle_voxblox_transform(const float* Twc, const float* p, float* out) {
   }
   quat_from_matrix(R, q);
   quat_transform(q, t, p, out);
+}
+
+/* The pose as the kindr transformation holds it: (w, x, y, z) of quat_from_matrix — handed to the reference's own
+ * integrators compiled into oracle/_ref (their kindr stand-in takes the quaternion, not the matrix). */
+void oracle_voxblox_pose_quat(const float* Twc, float* q_wxyz) {
+  float R[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) R[3 * i + j] = Twc[4 * i + j];
+  quat_from_matrix(R, q_wxyz);
 }
 
 /* ---- the pieces above one by one, for tests/test_oracle_pinned.py: checked there against voxblox's own

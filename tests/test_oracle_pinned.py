@@ -317,3 +317,112 @@ def test_voxblox_bundle_order_is_the_reference_maps_iteration_order():
         assert np.array_equal(a[:na], b[:nb]), n
         if n >= 1000:
             assert not np.array_equal(a[:na], np.sort(a[:na])), "the map does not iterate in insertion order"
+
+
+# ---------------------------------------------------------------- voxblox: the integrators themselves
+def _ref_map(ref, vs, carving, method):
+    ref.ref_voxblox_create.restype = ctypes.c_void_p
+    ref.ref_voxblox_create.argtypes = [ctypes.c_float] * 5 + [ctypes.c_int, ctypes.c_char_p]
+    return ctypes.c_void_p(ref.ref_voxblox_create(vs, 0.1, 10000.0, 0.1, 5.0, int(carving), method.encode()))
+
+
+def _ref_blocks(ref, h):
+    ref.ref_voxblox_num_blocks.argtypes = [ctypes.c_void_p]
+    ref.ref_voxblox_block_ids.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    ref.ref_voxblox_get_block.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3
+    n = ref.ref_voxblox_num_blocks(h)
+    ids = np.zeros((max(n, 1), 3), np.int32)
+    ref.ref_voxblox_block_ids(h, ids.ctypes.data)
+    out = {}
+    for b in ids[:n]:
+        d, w, c = np.zeros(4096, np.float32), np.zeros(4096, np.float32), np.zeros(4096, np.uint32)
+        assert ref.ref_voxblox_get_block(h, int(b[0]), int(b[1]), int(b[2]), d.ctypes.data, w.ctypes.data, c.ctypes.data)
+        out[tuple(int(v) for v in b)] = (d, w, c)
+    return out
+
+
+@needs_vref
+@pytest.mark.parametrize("method,vs,carving,far", [("simple", 0.05, False, False), ("simple", 0.10, True, True),
+                                                    ("merged", 0.05, False, False), ("merged", 0.10, True, True)])
+def test_voxblox_integrators_equal_the_reference_sources(method, vs, carving, far):
+    """Whole clouds through voxblox's OWN SimpleTsdfIntegrator / MergedTsdfIntegrator (tsdf_integrator.cc with Layer /
+    Block, compiled unmodified against the stand-ins) and through the restatement: every voxel of every block bit for
+    bit — updateTsdfVoxel, computeDistance, getVoxelWeight with the drop-off, isPointValid, clearing rays, the mixed
+    visiting order, the merged bundles and their hash-map order, block allocation."""
+    from tests import oracle_lib
+    from tests.plvs_amd_synth import make_keyframes
+    ref = ctypes.CDLL(VREF)
+    oracle = oracle_lib.load()
+    ref.ref_voxblox_integrate.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int]
+    ref.ref_voxblox_destroy.argtypes = [ctypes.c_void_p]
+    oracle.lib.oracle_voxblox_pose_quat.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    h = _ref_map(ref, vs, carving, method)
+    ora = oracle.voxblox(vs, carving=carving)
+    kfs = make_keyframes(3, max_depth=8.0, room_size=(16.0, 12.0, 3.0), seed=11) if far else make_keyframes(3, seed=11)
+    for k in kfs:
+        xyz = np.ascontiguousarray(k["xyz"][::2], np.float32)
+        rgba = np.ascontiguousarray(np.concatenate([k["rgb"][::2], np.full((len(xyz), 1), 255, np.uint8)], 1))
+        Twc = np.ascontiguousarray(k["Twc"], np.float32).reshape(3, 4)
+        q = np.zeros(4, np.float32)
+        oracle.lib.oracle_voxblox_pose_quat(Twc.ctypes.data, q.ctypes.data)
+        t = np.ascontiguousarray(Twc[:, 3])
+        ref.ref_voxblox_integrate(h, q.ctypes.data, t.ctypes.data, xyz.ctypes.data, rgba.ctypes.data, len(xyz))
+        (ora.integrate_merged if method == "merged" else ora.integrate)(xyz, rgba, Twc)
+    want = _ref_blocks(ref, h)
+    got = {tuple(int(v) for v in b): ora.get_chunk(*b) for b in ora.chunk_ids()}
+    assert set(got) == set(want) and len(want) > 20
+    for bid, planes in want.items():
+        for name, x, y in zip(("distance", "weight", "colour"), planes, got[bid]):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (name, bid)
+    ref.ref_voxblox_destroy(h)
+
+
+@needs_vref
+def test_voxblox_world_cloud_integrate_equals_the_reference_source():
+    """TsdfIntegratorBase::integrateWorlPointCloud (the LoadMap path) of the reference against the restatement: posed
+    clouds with un-normalised and zero normals, onto a map that already holds camera-ray integrations."""
+    from tests import oracle_lib
+    from tests.plvs_amd_synth import make_keyframes
+    from tests.test_tsdf_loadmap import surface_cloud
+    ref = ctypes.CDLL(VREF)
+    oracle = oracle_lib.load()
+    ref.ref_voxblox_integrate.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int]
+    ref.ref_voxblox_integrate_world.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int]
+    ref.ref_voxblox_destroy.argtypes = [ctypes.c_void_p]
+    oracle.lib.oracle_voxblox_pose_quat.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    vs = 0.05
+    h = _ref_map(ref, vs, False, "simple")
+    ora = oracle.voxblox(vs)
+
+    def pose(Twc):
+        Twc = np.ascontiguousarray(Twc, np.float32).reshape(3, 4)
+        q = np.zeros(4, np.float32)
+        oracle.lib.oracle_voxblox_pose_quat(Twc.ctypes.data, q.ctypes.data)
+        return Twc, q, np.ascontiguousarray(Twc[:, 3])
+
+    k = make_keyframes(1, seed=4)[0]
+    xyz = np.ascontiguousarray(k["xyz"][::2], np.float32)
+    rgba = np.ascontiguousarray(np.concatenate([k["rgb"][::2], np.full((len(xyz), 1), 255, np.uint8)], 1))
+    Twc, q, t = pose(k["Twc"])
+    ref.ref_voxblox_integrate(h, q.ctypes.data, t.ctypes.data, xyz.ctypes.data, rgba.ctypes.data, len(xyz))
+    ora.integrate(xyz, rgba, Twc)
+    T2 = np.array([[0.0, -1.0, 0.0, 0.3], [1.0, 0.0, 0.0, -0.2], [0.0, 0.0, 1.0, 0.1]], np.float32)
+    for seed, P in ((1, np.eye(4, dtype=np.float32)[:3]), (2, T2)):
+        xyz, rgb, _, nrm = surface_cloud(20000, seed, vs)
+        rgba = np.ascontiguousarray(np.concatenate([rgb, np.full((len(rgb), 1), 200, np.uint8)], 1))
+        Twc, q, t = pose(P)
+        ref.ref_voxblox_integrate_world(h, q.ctypes.data, t.ctypes.data, xyz.ctypes.data, rgba.ctypes.data, nrm.ctypes.data, len(xyz))
+        ora.integrate_world_normals(xyz, rgba, nrm, Twc)
+    # integrateWorlPointCloud leaves the blocks it creates in the integrator's temp_block_map_ — it never calls
+    # updateLayerWithStoredBlocks (tsdf_integrator.cc:35-82 vs :288) — so they join the layer with the NEXT
+    # integratePointCloud call; an empty cloud does it.  (The restatement and the device path insert them at once: §6.)
+    before_flush = len(_ref_blocks(ref, h))
+    ref.ref_voxblox_integrate(h, q.ctypes.data, t.ctypes.data, xyz.ctypes.data, rgba.ctypes.data, 0)
+    want = _ref_blocks(ref, h)
+    assert before_flush < len(want)
+    got = {tuple(int(v) for v in b): ora.get_chunk(*b) for b in ora.chunk_ids()}
+    assert set(got) == set(want) and len(want) > 50
+    for bid, planes in want.items():
+        for name, x, y in zip(("distance", "weight", "colour"), planes, got[bid]):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (name, bid)
+    ref.ref_voxblox_destroy(h)
