@@ -1,6 +1,6 @@
 // C entry points over voxblox's OWN integrators — src/integrator/tsdf_integrator.cc (TsdfIntegratorBase::updateTsdfVoxel,
 // computeDistance, getVoxelWeight, isPointValid, allocateStorageAndGetVoxelPtr, integrateWorlPointCloud; the Simple and
-// the Merged integrator) with Layer / Block from core/*.h — compiled where they lie under /root/reference against the
+// the Merged integrator; mesh/mesh_integrator.h: MeshIntegrator::updateMeshForBlock) with Layer / Block from core/*.h — compiled where they lie under /root/reference against the
 // stand-ins of oracle/ref/vbx_shim (Eigen, glog, kindr, protobuf names) -> oracle/_ref/libvoxblox_ref.so.
 // tests/test_oracle_pinned.py runs whole clouds through these and through oracle/tsdf_voxblox.c /
 // tsdf_voxblox_merged.cpp and compares every voxel of every block bit for bit.
@@ -15,6 +15,8 @@
 #include "voxblox/core/layer.h"
 #include "voxblox/core/voxel.h"
 #include "voxblox/integrator/tsdf_integrator.h"
+#include "voxblox/mesh/mesh_integrator.h"
+#include "voxblox/mesh/mesh_layer.h"
 
 namespace {
 struct RefMap {
@@ -104,6 +106,33 @@ int ref_voxblox_get_block(void* h, int bx, int by, int bz, float* distance, floa
     rgba[i] = (uint32_t)v.color.r | ((uint32_t)v.color.g << 8) | ((uint32_t)v.color.b << 16) | ((uint32_t)v.color.a << 24);
   }
   return 1;
+}
+
+// MeshIntegrator<TsdfVoxel>::updateMeshForBlock (mesh/mesh_integrator.h:231-251; min_weight 1e-4, use_color, as
+// TsdfServer builds it) on one block of the map: vertices / normals n x 3, colors n x 4 (r, g, b, a).  Returns n
+// (writes at most `cap` vertices).
+int ref_voxblox_mesh_block(void* h, int bx, int by, int bz, float* vertices, float* normals, uint8_t* colors, int cap) {
+  RefMap* m = static_cast<RefMap*>(h);
+  voxblox::MeshIntegratorConfig config;
+  config.integrator_threads = 1;
+  voxblox::MeshLayer mesh_layer(m->layer->block_size());
+  voxblox::MeshIntegrator<voxblox::TsdfVoxel> integrator(config, m->layer.get(), &mesh_layer);
+  const voxblox::BlockIndex idx(bx, by, bz);
+  if (!m->layer->hasBlock(idx)) return 0;
+  voxblox::Mesh::Ptr mesh = mesh_layer.allocateMeshPtrByIndex(idx);
+  integrator.updateMeshForBlock(idx);
+  const int n = (int)mesh->vertices.size();
+  for (int i = 0; i < n && i < cap; ++i) {
+    for (int k = 0; k < 3; ++k) {
+      vertices[3 * i + k] = mesh->vertices[i][k];
+      normals[3 * i + k] = mesh->normals[i][k];
+    }
+    colors[4 * i] = mesh->colors[i].r;
+    colors[4 * i + 1] = mesh->colors[i].g;
+    colors[4 * i + 2] = mesh->colors[i].b;
+    colors[4 * i + 3] = mesh->colors[i].a;
+  }
+  return n;
 }
 
 }  // extern "C"

@@ -591,8 +591,9 @@ void oracle_voxblox_indices(const int32_t* g, int32_t* block, int32_t* local, ui
  * origin + (index + 0.5) * voxel_size with the sum and product in double (common.h:179-184).
  * The marching-cubes table is the one open_chisel uses (mc_table.inc); tests/test_oracle_pinned.py compares it,
  * the edge pairs and meshCube itself with voxblox's marching_cubes.{h,cc} compiled into oracle/_ref.
- * Parity of the block walk, the corner gathering and the colour look-up: restated by reading (they need Layer /
- * Block, which need protobuf). */
+ * Pinned: the reference's own MeshIntegrator::updateMeshForBlock (mesh_integrator.h with Layer / Block / Mesh, compiled
+ * into oracle/_ref against the stand-ins) on maps its SimpleTsdfIntegrator built, against oracle_voxblox_mesh_block on
+ * the oracle's copy — every block's vertices, normals and colours byte for byte (tests/test_oracle_pinned.py). */
 static const int kVbTriangleTable[256 * 16] = {
 #include "mc_table.inc"
 };

@@ -426,3 +426,45 @@ def test_voxblox_world_cloud_integrate_equals_the_reference_source():
         for name, x, y in zip(("distance", "weight", "colour"), planes, got[bid]):
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (name, bid)
     ref.ref_voxblox_destroy(h)
+
+
+@needs_vref
+def test_voxblox_mesh_integrator_equals_the_reference_source():
+    """MeshIntegrator<TsdfVoxel>::updateMeshForBlock of the reference (mesh/mesh_integrator.h with Layer / Block / Mesh,
+    compiled unmodified) on a map its own SimpleTsdfIntegrator built, against oracle_voxblox_mesh_block on the oracle's
+    copy of that map: the walk over the block, the corner gathering through neighbour blocks, unobserved corners,
+    meshCube, the colour look-up — vertices, normals and colours of every block, byte for byte."""
+    from tests import oracle_lib
+    from tests.plvs_amd_synth import make_keyframes
+    from tests.test_tsdf_voxblox_mesh import mesh_block
+    ref = ctypes.CDLL(VREF)
+    oracle = oracle_lib.load()
+    ref.ref_voxblox_integrate.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int]
+    ref.ref_voxblox_mesh_block.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3 + [ctypes.c_int]
+    ref.ref_voxblox_destroy.argtypes = [ctypes.c_void_p]
+    oracle.lib.oracle_voxblox_pose_quat.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    total = 0
+    for vs in (0.05, 0.10):
+        h = _ref_map(ref, vs, False, "simple")
+        ora = oracle.voxblox(vs)
+        for k in make_keyframes(3, seed=13):
+            xyz = np.ascontiguousarray(k["xyz"][::2], np.float32)
+            rgba = np.ascontiguousarray(np.concatenate([k["rgb"][::2], np.full((len(xyz), 1), 255, np.uint8)], 1))
+            Twc = np.ascontiguousarray(k["Twc"], np.float32).reshape(3, 4)
+            q = np.zeros(4, np.float32)
+            oracle.lib.oracle_voxblox_pose_quat(Twc.ctypes.data, q.ctypes.data)
+            t = np.ascontiguousarray(Twc[:, 3])
+            ref.ref_voxblox_integrate(h, q.ctypes.data, t.ctypes.data, xyz.ctypes.data, rgba.ctypes.data, len(xyz))
+            ora.integrate(xyz, rgba, Twc)
+        cap = 4096 * 15
+        v, n = np.zeros((cap, 3), np.float32), np.zeros((cap, 3), np.float32)
+        c = np.zeros((cap, 4), np.uint8)
+        for bid in ora.chunk_ids():
+            nv = ref.ref_voxblox_mesh_block(h, int(bid[0]), int(bid[1]), int(bid[2]), v.ctypes.data, n.ctypes.data, c.ctypes.data, cap)
+            ov, on, oc = mesh_block(ora, *bid)
+            assert nv == len(ov), (vs, bid, nv, len(ov))
+            assert v[:nv].tobytes() == ov.tobytes() and n[:nv].tobytes() == on.tobytes() and c[:nv].tobytes() == oc.tobytes(), (vs, bid)
+            total += nv
+        assert ref.ref_voxblox_mesh_block(h, 999, 999, 999, v.ctypes.data, n.ctypes.data, c.ctypes.data, cap) == 0
+        ref.ref_voxblox_destroy(h)
+    assert total > 15000
