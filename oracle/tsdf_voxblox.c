@@ -11,7 +11,7 @@
  * stand-ins for those headers (oracle/ref/vbx_shim -> oracle/_ref/libvoxblox_ref.so): src/integrator/tsdf_integrator.cc
  * (TsdfIntegratorBase::updateTsdfVoxel / computeDistance / getVoxelWeight / isPointValid /
  * allocateStorageAndGetVoxelPtr / integrateWorlPointCloud, SimpleTsdfIntegrator, MergedTsdfIntegrator) with Layer and
- * Block from core/*.h, src/integrator/integrator_utils.cc (RayCaster, ThreadSafeIndex), mesh/marching_cubes.{h,cc}.
+ * Block from the core headers, src/integrator/integrator_utils.cc (RayCaster, ThreadSafeIndex), mesh/marching_cubes.{h,cc}.
  * tests/test_oracle_pinned.py runs WHOLE CLOUDS (three key frames, 5 and 10 cm, carving off / on with points beyond
  * the 5 m ray limit; posed world clouds with un-normalised and zero normals) through the reference's Simple and Merged
  * integrators and integrateWorlPointCloud and through this file (+ tsdf_voxblox_merged.cpp) and compares every voxel
