@@ -5,22 +5,28 @@
  * TEST INFRASTRUCTURE ONLY.  Nothing under plvs_amd/ may call into this file;
  * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load it.
  *
- * Parity status: PARTLY PINNED by the reference's own sources.  open_chisel ships no tests and no golden
- * vectors and the whole library cannot be compiled here (Eigen3 + PCL absent), but the
- * self-contained pieces of the path compile UNMODIFIED against a minimal Eigen stand-in
- * (oracle/ref/ -> oracle/_ref/libchisel_ref.so): Raycast.cpp (traversal order, tie rules, stop test),
- * DistVoxel::Integrate, ColorVoxel::IntegrateSimple, QuadraticTruncator, ConstantWeighter.
- * tests/test_oracle_pinned.py checks raycast(), dist_integrate(), colour_integrate_simple(),
- * quadratic_truncation() and constant_weight() below — the very functions the integrate loop calls —
- * against them bit for bit (40 000 rays incl. boundary starts, axis-aligned, diagonal, zero-length and
- * 400-voxel rays; update sequences through colour saturation).
- * NOT pinned (restated by reading): the loop glue of Chisel.cpp:442-585 — pose inverse, ray end points, the
- * signed distance of :525-527, chunk hashing / creation order — and the evaluation order Eigen 3.3 gives
- * these expressions (3-vector reductions are evaluated as a0 + (a1 + a2); an Affine transform applied to a
- * point is t + R*p; Transform::inverse() of an Affine transform uses the cofactor inverse; the stand-in
- * encodes the same reading), and the C-library overloads g++ picks for the unqualified calls (fmod / sqrt
- * resolve to the double versions).  Compiled with -ffp-contract=off so no FMA contraction changes a
- * rounding.
+ * Parity status: PINNED END TO END by the reference's own sources.  open_chisel ships no tests and no golden
+ * vectors, and the real Eigen3 / PCL are absent here, but ALL SIXTEEN sources under
+ * Thirdparty/open_chisel/src compile UNMODIFIED against an Eigen stand-in (oracle/ref/eigen_full/: fixed-size
+ * vectors, 3x3 / 4x4 matrices, the affine Transform, Quaternion) into oracle/_ref/libchisel_full_ref.so.
+ * tests/test_oracle_pinned_chisel_map.py drives chisel::Chisel there as ChiselServer does — several key frames
+ * through IntegratePointCloudWidthDepth at three resolutions, the same with carving by depth images,
+ * IntegrateWorldPointCloudWithNormals on posed clouds, UpdateMeshes — and compares EVERY voxel of every chunk
+ * (sdf, weight, kfid, colour, colour weight) and every mesh vertex / normal / colour / kfid of every chunk with
+ * this file's results, bit for bit.  Chunk creation / garbage collection, the frustum and CarveWithDepth, the
+ * loop glue of Chisel.cpp:442-585 and ChunkManager::RecomputeMesh therefore come from the reference's source.
+ * The pieces are also pinned one by one (oracle/_ref/libchisel_ref.so, tests/test_oracle_pinned.py):
+ * Raycast.cpp on 40 000 rays incl. boundary starts, axis-aligned, diagonal, zero-length and 400-voxel rays;
+ * DistVoxel::Integrate, ColorVoxel::Integrate / IntegrateSimple through saturation; QuadraticTruncator,
+ * ConstantWeighter; the marching-cubes tables.
+ * What the stand-in ENCODES rather than takes from Eigen, and so remains a reading (of Eigen 3.3, not of the
+ * reference): the evaluation order of fixed-size expressions (3-vector reductions are a0 + (a1 + a2); an Affine
+ * transform applied to a point is R*p + t, each row of R*p one such reduction; Transform::inverse() of an Affine
+ * transform uses the cofactor inverse of the linear part).  The C-library overloads g++ picks for the
+ * unqualified calls (fmod / sqrt resolve to the double versions) ARE the reference's, since its translation
+ * units are what is compiled.  Not compiled: chisel_server (needs PCL); the handful of its lines on this path
+ * (integrator set-up, colour bytes * 1/255) are repeated in oracle/ref/chisel_full_ref_wrap.cpp with citations.
+ * Compiled with -ffp-contract=off so no FMA contraction changes a rounding.
  *
  * Follows (paths relative to the PLVS tree):
  *   src/PointCloudMapChisel.cc:76-98                  InsertCloud (pose -> chisel::Transform)
@@ -382,8 +388,8 @@ void oracle_chisel_integrate(oracle_chisel* o, const float* xyz, const uint8_t* 
  * saved map cloud through (src/PointCloudMapChisel.cc:527-546 -> ChiselServer::IntegrateWorldPointCloud,
  * ChiselServer.cpp:587-615; Twc = identity there): every point casts the segment point -/+ 4 voxels along its
  * NORMAL, u = (centre - point) . normal, constant truncation 4 * resolution, no depth test, no carving,
- * ColorVoxel::Integrate.  normals: n x 3.  Restated by reading; ColorVoxel::Integrate is pinned
- * (tests/test_oracle_pinned.py). */
+ * ColorVoxel::Integrate.  normals: n x 3.  Pinned against the compiled Chisel.cpp
+ * (tests/test_oracle_pinned_chisel_map.py). */
 void oracle_chisel_integrate_world_normals(oracle_chisel* o, const float* xyz, const uint8_t* rgb, const uint32_t* kfid,
                                            const float* normals, int n, const float* Twc) {
   float R[9], t[3];
@@ -609,7 +615,8 @@ int oracle_chisel_carve(oracle_chisel* o, const float* depth, int width, int hei
  * PointCloudMapChisel::UpdateMap (src/PointCloudMapChisel.cc:228-246).
  * Quirks kept: InterpolateVertex returns v1 + 0.5 v2 on a flat edge; InterpolateColor passes voxel
  * INDICES to a function that expects metres; GetSDF accepts any linear id in [0, 4096).
- * Parity unpinned (no test or stored output in the reference). */
+ * Pinned: ChunkManager.cpp compiled into oracle/_ref/libchisel_full_ref.so gives the same meshes bit for bit
+ * (tests/test_oracle_pinned_chisel_map.py). */
 static const int kTriangleTable[256 * 16] = {
 #include "mc_table.inc"
 };
