@@ -156,4 +156,19 @@ int ref_chisel_full_mesh_chunk(void* p, int cx, int cy, int cz, float* vertices,
   return n;
 }
 
+// Chisel::Deform (Chisel.cpp:588-591 -> ChunkManager::Deform): kfids n, Rt n x 12 floats (R row-major, then t), as
+// PointCloudMapChisel::OnMapChange fills the MapKfidRt.
+void ref_chisel_full_deform(void* p, const uint32_t* kfids, const float* Rt, int n) {
+  chisel::MapKfidRt map;
+  for (int i = 0; i < n; ++i) {
+    chisel::TransformRt T;
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) T.R(r, c) = Rt[12 * i + 3 * r + c];
+      T.t(r) = Rt[12 * i + 9 + r];
+    }
+    map[kfids[i]] = T;
+  }
+  static_cast<FullRef*>(p)->map->Deform(map);
+}
+
 }  // extern "C"

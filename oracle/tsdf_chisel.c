@@ -71,6 +71,12 @@ typedef struct oracle_chisel {
   int shard_rank, shard_count;
   int64_t last_visits;
   int32_t last_new, last_updated;
+  /* every raycast voxel's chunk id, in visiting order (GetOrCreateChunkAt is called for each, Chisel.cpp:505):
+   * what oracle/tsdf_chisel_deform.cpp needs to keep the reference's std::unordered_map order */
+  void (*visit_hook)(void* ctx, const int32_t id[3]);
+  void* visit_hook_ctx;
+  int32_t hook_last[3];
+  int hook_has_last;
 } oracle_chisel;
 
 /* ChunkHasher (ChunkManager.h:42-54): size_t arithmetic on the int coordinates. */
@@ -295,6 +301,11 @@ static void visit(void* vctx, int vx, int vy, int vz) {
   const int32_t id[3] = {(int32_t)floorf(center[0] * o->rounding),
                          (int32_t)floorf(center[1] * o->rounding),
                          (int32_t)floorf(center[2] * o->rounding)};
+  if (o->visit_hook && !(o->hook_has_last && o->hook_last[0] == id[0] && o->hook_last[1] == id[1] && o->hook_last[2] == id[2])) {
+    o->visit_hook(o->visit_hook_ctx, id);   /* (repeats of one id in a row are dropped: the hook only looks the id up) */
+    memcpy(o->hook_last, id, sizeof(id));
+    o->hook_has_last = 1;
+  }
   if (!owned(o, id)) return; /* multi-GPU shard filter (not in the reference) */
   /* Chunk::GetLocalVoxelIDFromGlobal + IsCoordValid(VoxelID) (Chunk.cpp:96-105, Chunk.h:90-118) */
   const int lx = vx - id[0] * 16, ly = vy - id[1] * 16, lz = vz - id[2] * 16;
@@ -347,6 +358,7 @@ void oracle_chisel_integrate(oracle_chisel* o, const float* xyz, const uint8_t* 
   const float byteToFloat = 1.0f / 255.0f;                                  /* Conversions.h:107 */
   visit_ctx c;
   memset(&c, 0, sizeof(c));
+  o->hook_has_last = 0;
   c.o = o; c.Ri = Ri; c.ti = ti;
   const size_t before = o->count;
   /* updated-chunk count: chunks whose any voxel passed; tracked through a per-call mark */
@@ -403,6 +415,7 @@ void oracle_chisel_integrate_world_normals(oracle_chisel* o, const float* xyz, c
   const float byteToFloat = 1.0f / 255.0f;                                  /* Conversions.h:158 */
   visit_ctx c;
   memset(&c, 0, sizeof(c));
+  o->hook_has_last = 0;
   c.o = o;
   const size_t before = o->count;
   for (int i = 0; i < n; i++) {
@@ -860,6 +873,106 @@ void oracle_chisel_set_chunk(oracle_chisel* o, int cx, int cy, int cz, const flo
   memcpy(c->weight, weight, CHUNK_VOX * sizeof(float));
   memcpy(c->kfid, kfid, CHUNK_VOX * sizeof(uint32_t));
   memcpy(c->rgbw, rgbw, CHUNK_VOX * sizeof(uint32_t));
+}
+
+/* ===========================================================================================
+ * ChunkManager::Deform, the chunk part (src/ChunkManager.cpp:918-1017), behind Chisel::Deform (Chisel.cpp:588-591) <-
+ * ChiselServer::Deform (ChiselServer.cpp:617-621) <- PointCloudMapChisel::OnMapChange (src/PointCloudMapChisel.cc):
+ * every known voxel (weight > 1e-15) whose kfid has an entry in the deformation map moves to
+ * newPos = R * centre + t; the first voxel to land in a new voxel is copied, later ones are merged with
+ * DistVoxel::Integrate(sdf, weight), SetKfid and ColorVoxel::Integrate(r, g, b, 1).  Old chunks are walked in the
+ * iteration order of the reference's std::unordered_map `chunks`, which the CALLER supplies as `order` (n_order ids;
+ * oracle/tsdf_chisel_deform.cpp keeps the real container); voxels of a chunk in id order.  new_order receives the ids
+ * of the new chunks in the order the reference inserts them into `newChunks` (first claim).
+ * The new chunk comes from floor(newPos * 1/(16 res)) and the voxel from floor(newPos * 1/res) - 16 * chunk: two
+ * roundings that can disagree by one voxel at a chunk face.  The reference then indexes with the linear id
+ * (z * 16 + y) * 16 + x of the out-of-range local coordinates: inside [0, 4096) that is a (wrong but well-defined)
+ * voxel and is reproduced; outside it is undefined behaviour in the reference — skipped here and counted in
+ * stats[1].  stats[0] = voxels discarded because their kfid has no transformation ("num discarded voxels").
+ * Rt: n_map x 12 floats (R row-major, then t); kfids strictly increasing.  Pinned against the compiled
+ * ChunkManager.cpp (tests/test_oracle_pinned_chisel_map.py). */
+int oracle_chisel_deform(oracle_chisel* o, const int32_t* order, int n_order, const uint32_t* kfids, const float* Rt,
+                         int n_map, int32_t* new_order, int new_cap, int64_t* stats) {
+  oracle_chisel nw = *o;
+  nw.cap = 1024; nw.count = 0;
+  nw.tab = (chunk_t*)calloc(nw.cap, sizeof(chunk_t));
+  const float res = o->resolution, inv_res = 1.f / res;          /* ChunkManager.cpp:67 */
+  int n_new = 0;
+  int64_t discarded = 0, undefined = 0;
+  for (int c = 0; c < n_order; c++) {
+    const int32_t* cid = order + 3 * (size_t)c;
+    int found = 0;
+    chunk_t* ch = tab_find(o->tab, o->cap, cid, &found);
+    if (!found) continue;                                        /* (a caller error; the order lists existing chunks) */
+    const float origin[3] = {(float)(16 * cid[0]) * res, (float)(16 * cid[1]) * res, (float)(16 * cid[2]) * res};
+    for (int v = 0; v < CHUNK_VOX; v++) {
+      if ((double)ch->weight[v] <= 1e-15) continue;              /* :953 */
+      const uint32_t kf = ch->kfid[v];
+      int lo = 0, hi = n_map - 1, at = -1;
+      while (lo <= hi) { const int mid = (lo + hi) / 2; if (kfids[mid] == kf) { at = mid; break; } if (kfids[mid] < kf) lo = mid + 1; else hi = mid - 1; }
+      if (at < 0) { discarded++; continue; }                     /* :960-966 */
+      const float* R = Rt + 12 * (size_t)at;
+      const int lx = v & 15, ly = (v >> 4) & 15, lz = v >> 8;
+      const float pos[3] = {((float)lx * res + o->half_voxel) + origin[0],       /* centroids[voxelID] + origin  :972 */
+                            ((float)ly * res + o->half_voxel) + origin[1],
+                            ((float)lz * res + o->half_voxel) + origin[2]};
+      float np[3];
+      xform(R, R + 9, pos, np);                                  /* Rt.R * pos + Rt.t  :973 */
+      const int32_t nid[3] = {(int32_t)floorf(np[0] * o->rounding), (int32_t)floorf(np[1] * o->rounding),
+                              (int32_t)floorf(np[2] * o->rounding)};             /* GetIDAt  :977 */
+      const int gx = (int)floorf(np[0] * inv_res), gy = (int)floorf(np[1] * inv_res), gz = (int)floorf(np[2] * inv_res);
+      const int nx = gx - nid[0] * 16, ny = gy - nid[1] * 16, nz = gz - nid[2] * 16;   /* Chunk.cpp:101-105 */
+      const int nv = (nz * 16 + ny) * 16 + nx;                   /* Chunk.h:90-93 */
+      int f2 = 0;
+      chunk_t* nc = tab_find(nw.tab, nw.cap, nid, &f2);
+      if (!f2) {                                                 /* :981-990 (the chunk is created before the voxel is indexed) */
+        nc = chunk_create(&nw, nid);
+        if (n_new < new_cap) memcpy(new_order + 3 * (size_t)n_new, nid, sizeof(nid));
+        n_new++;
+      }
+      if (nv < 0 || nv >= CHUNK_VOX) { undefined++; continue; }
+      if ((double)nc->weight[nv] <= 1e-15) {                     /* :998-1003 */
+        nc->sdf[nv] = ch->sdf[v]; nc->weight[nv] = ch->weight[v]; nc->kfid[nv] = kf; nc->rgbw[nv] = ch->rgbw[v];
+      } else {                                                   /* :1004-1011 */
+        dist_integrate(&nc->sdf[nv], &nc->weight[nv], ch->sdf[v], ch->weight[v]);
+        nc->kfid[nv] = kf;
+        const uint32_t p = ch->rgbw[v];
+        nc->rgbw[nv] = colour_integrate(nc->rgbw[nv], (uint8_t)p, (uint8_t)(p >> 8), (uint8_t)(p >> 16), 1);
+      }
+    }
+  }
+  oracle_chisel_clear(o);
+  free(o->tab);
+  o->tab = nw.tab; o->cap = nw.cap; o->count = nw.count;         /* chunks.swap(newChunks)  :1015 */
+  if (stats) { stats[0] = discarded; stats[1] = undefined; }
+  return n_new;
+}
+
+/* The mesh part of ChunkManager::Deform (:1020-1051): vertex = R * vertex + t, normal = R * normal for the vertices
+ * whose kfid has a transformation; the others stay. */
+void oracle_chisel_deform_mesh(float* vertices, float* normals, const uint32_t* vkfid, int n, const uint32_t* kfids,
+                               const float* Rt, int n_map) {
+  for (int i = 0; i < n; i++) {
+    int lo = 0, hi = n_map - 1, at = -1;
+    while (lo <= hi) { const int mid = (lo + hi) / 2; if (kfids[mid] == vkfid[i]) { at = mid; break; } if (kfids[mid] < vkfid[i]) lo = mid + 1; else hi = mid - 1; }
+    if (at < 0) continue;
+    const float* R = Rt + 12 * (size_t)at;
+    float v[3], nr[3];
+    xform(R, R + 9, vertices + 3 * (size_t)i, v);
+    for (int k = 0; k < 3; k++) nr[k] = sum3(R[3 * k] * normals[3 * (size_t)i], R[3 * k + 1] * normals[3 * (size_t)i + 1], R[3 * k + 2] * normals[3 * (size_t)i + 2]);
+    memcpy(vertices + 3 * (size_t)i, v, sizeof(v));
+    memcpy(normals + 3 * (size_t)i, nr, sizeof(nr));
+  }
+}
+
+void oracle_chisel_set_visit_hook(oracle_chisel* o, void (*hook)(void*, const int32_t*), void* ctx) {
+  o->visit_hook = hook; o->visit_hook_ctx = ctx; o->hook_has_last = 0;
+}
+int oracle_chisel_has_chunk(const oracle_chisel* o, int cx, int cy, int cz) {
+  const int32_t id[3] = {cx, cy, cz};
+  int found = 0;
+  tab_find(o->tab, o->cap, id, &found);
+  return found;
 }
 
 /* ---- the pieces above, one by one, for tests/test_oracle_pinned.py: checked there against the reference's own

@@ -371,6 +371,10 @@ class _ChiselLike:
 
     def close(self):
         if self.h:
+            if getattr(self, "ordered", None):
+                self.lib.oracle_chisel_ordered_detach.argtypes = [_vp]
+                self.lib.oracle_chisel_ordered_detach(self.ordered)
+                self.ordered = None
             getattr(self.lib, self.p + "_destroy")(self.h)
             self.h = None
 
@@ -398,6 +402,48 @@ class _ChiselLike:
 
     def last_visits(self):
         return int(getattr(self.lib, self.p + "_last_visits")(self.h))
+
+    # ---- Chisel::Deform (oracle only): the reference's chunk-map order is kept beside the map
+    def track_order(self):
+        """Attach the std::unordered_map shadow (oracle/tsdf_chisel_deform.cpp) to this (still empty) map; from here on
+        call end_call() after every integrate."""
+        f = self.lib.oracle_chisel_ordered_attach
+        f.restype, f.argtypes = _vp, [_vp]
+        self.ordered = _vp(f(self.h))
+        self.lib.oracle_chisel_ordered_end_call.argtypes = [_vp]
+        self.lib.oracle_chisel_ordered_size.argtypes = [_vp]
+        self.lib.oracle_chisel_ordered_order.argtypes = [_vp, _vp]
+        self.lib.oracle_chisel_ordered_deform.argtypes = [_vp, _vp, _vp, _i, _vp]
+        return self
+
+    def end_call(self):
+        self.lib.oracle_chisel_ordered_end_call(self.ordered)
+
+    def chunk_order(self):
+        n = self.lib.oracle_chisel_ordered_size(self.ordered)
+        ids = np.zeros((max(n, 1), 3), np.int32)
+        self.lib.oracle_chisel_ordered_order(self.ordered, _ptr(ids))
+        return ids[:n]
+
+    def deform(self, kfids, Rt):
+        """kfids [n] strictly increasing, Rt [n, 12] (R row-major, t) -> (new chunk count, discarded, undefined)"""
+        kfids = np.ascontiguousarray(kfids, np.uint32)
+        Rt = np.ascontiguousarray(Rt, np.float32).reshape(len(kfids), 12)
+        assert np.all(np.diff(kfids.astype(np.int64)) > 0)
+        stats = np.zeros(2, np.int64)
+        n = self.lib.oracle_chisel_ordered_deform(self.ordered, _ptr(kfids), _ptr(Rt), len(kfids), _ptr(stats))
+        return n, int(stats[0]), int(stats[1])
+
+    def deform_mesh(self, vertices, normals, vkfid, kfids, Rt):
+        v = np.ascontiguousarray(vertices, np.float32).copy()
+        nr = np.ascontiguousarray(normals, np.float32).copy()
+        vk = np.ascontiguousarray(vkfid, np.uint32)
+        kfids = np.ascontiguousarray(kfids, np.uint32)
+        Rt = np.ascontiguousarray(Rt, np.float32).reshape(len(kfids), 12)
+        f = self.lib.oracle_chisel_deform_mesh
+        f.restype, f.argtypes = None, [_vp, _vp, _vp, _i, _vp, _vp, _i]
+        f(_ptr(v), _ptr(nr), _ptr(vk), len(vk), _ptr(kfids), _ptr(Rt), len(kfids))
+        return v, nr
 
     def num_chunks(self):
         return getattr(self.lib, self.p + "_num_chunks")(self.h)
@@ -472,6 +518,48 @@ class _VoxbloxLike:
 
     def last_visits(self):
         return int(getattr(self.lib, self.p + "_last_visits")(self.h))
+
+    # ---- Chisel::Deform (oracle only): the reference's chunk-map order is kept beside the map
+    def track_order(self):
+        """Attach the std::unordered_map shadow (oracle/tsdf_chisel_deform.cpp) to this (still empty) map; from here on
+        call end_call() after every integrate."""
+        f = self.lib.oracle_chisel_ordered_attach
+        f.restype, f.argtypes = _vp, [_vp]
+        self.ordered = _vp(f(self.h))
+        self.lib.oracle_chisel_ordered_end_call.argtypes = [_vp]
+        self.lib.oracle_chisel_ordered_size.argtypes = [_vp]
+        self.lib.oracle_chisel_ordered_order.argtypes = [_vp, _vp]
+        self.lib.oracle_chisel_ordered_deform.argtypes = [_vp, _vp, _vp, _i, _vp]
+        return self
+
+    def end_call(self):
+        self.lib.oracle_chisel_ordered_end_call(self.ordered)
+
+    def chunk_order(self):
+        n = self.lib.oracle_chisel_ordered_size(self.ordered)
+        ids = np.zeros((max(n, 1), 3), np.int32)
+        self.lib.oracle_chisel_ordered_order(self.ordered, _ptr(ids))
+        return ids[:n]
+
+    def deform(self, kfids, Rt):
+        """kfids [n] strictly increasing, Rt [n, 12] (R row-major, t) -> (new chunk count, discarded, undefined)"""
+        kfids = np.ascontiguousarray(kfids, np.uint32)
+        Rt = np.ascontiguousarray(Rt, np.float32).reshape(len(kfids), 12)
+        assert np.all(np.diff(kfids.astype(np.int64)) > 0)
+        stats = np.zeros(2, np.int64)
+        n = self.lib.oracle_chisel_ordered_deform(self.ordered, _ptr(kfids), _ptr(Rt), len(kfids), _ptr(stats))
+        return n, int(stats[0]), int(stats[1])
+
+    def deform_mesh(self, vertices, normals, vkfid, kfids, Rt):
+        v = np.ascontiguousarray(vertices, np.float32).copy()
+        nr = np.ascontiguousarray(normals, np.float32).copy()
+        vk = np.ascontiguousarray(vkfid, np.uint32)
+        kfids = np.ascontiguousarray(kfids, np.uint32)
+        Rt = np.ascontiguousarray(Rt, np.float32).reshape(len(kfids), 12)
+        f = self.lib.oracle_chisel_deform_mesh
+        f.restype, f.argtypes = None, [_vp, _vp, _vp, _i, _vp, _vp, _i]
+        f(_ptr(v), _ptr(nr), _ptr(vk), len(vk), _ptr(kfids), _ptr(Rt), len(kfids))
+        return v, nr
 
     def num_chunks(self):
         return getattr(self.lib, self.p + "_num_chunks")(self.h)

@@ -45,6 +45,7 @@ class RefChisel:
         lib.ref_chisel_full_get_chunk.argtypes = [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]
         lib.ref_chisel_full_update_meshes.argtypes = [_vp]
         lib.ref_chisel_full_mesh_chunk.argtypes = [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i]
+        lib.ref_chisel_full_deform.argtypes = [_vp, _vp, _vp, _i]
         self.cam = cam
         self.h = _vp(lib.ref_chisel_full_create(resolution, *TRUNC, weight, int(carving), carving_dist, cam["fx"],
                                                 cam["fy"], cam["cx"], cam["cy"], cam["width"], cam["height"], near,
@@ -91,6 +92,11 @@ class RefChisel:
                np.empty(4096, np.uint32))
         ok = self.lib.ref_chisel_full_get_chunk(self.h, int(cx), int(cy), int(cz), *[_ptr(a) for a in out])
         return out if ok else None
+
+    def deform(self, kfids, Rt):
+        kfids = np.ascontiguousarray(kfids, np.uint32)
+        Rt = np.ascontiguousarray(Rt, np.float32).reshape(len(kfids), 12)
+        self.lib.ref_chisel_full_deform(self.h, _ptr(kfids), _ptr(Rt), len(kfids))
 
     def update_meshes(self):
         self.lib.ref_chisel_full_update_meshes(self.h)
@@ -206,4 +212,85 @@ def test_chunk_meshes_equal_the_reference_library(oracle):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{name} differ in chunk {cid}"
         total += len(want[0])
     assert total > 3000
+    ref.close()
+
+
+def small_motions(kfids, seed, rot=0.03, shift=0.08):
+    """One rigid correction per key frame, as a pose-graph optimisation hands them to OnMapChange: a rotation of a
+    few degrees and a shift of a few voxels.  -> [n, 12] (R row-major, then t)"""
+    rng = np.random.default_rng(seed)
+    out = np.zeros((len(kfids), 12), np.float32)
+    for i in range(len(kfids)):
+        w = rng.normal(scale=rot, size=3)
+        th = np.linalg.norm(w)
+        k = w / max(th, 1e-12)
+        K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+        out[i, :9] = R.astype(np.float32).reshape(9)
+        out[i, 9:] = rng.normal(scale=shift, size=3).astype(np.float32)
+    return out
+
+
+@pytest.mark.parametrize("res,drop", [(0.05, False), (0.05, True), (0.1, False)])
+def test_deform_equals_the_reference_library(oracle, res, drop):
+    """Chisel::Deform after several key frames: the oracle walks the old chunks in the order of a std::unordered_map
+    fed with the reference's insert / erase history; colliding voxels then merge in the reference's sequence.  Then
+    the map is integrated into and deformed AGAIN (the order of the swapped-in container), and meshed."""
+    cam = small_cam(4)
+    kfs = make_keyframes(5, cam=cam, seed=61)
+    ref, ora = RefChisel(res, cam), oracle.chisel(res).track_order()
+
+    def both(kf):
+        ref.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+        ora.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+        ora.end_call()
+
+    for kf in kfs[:4]:
+        both(kf)
+    assert [tuple(c) for c in ora.chunk_order()] == [tuple(c) for c in ref.chunk_ids()]   # the container's order itself
+    kfids = np.unique(np.concatenate([kf["kfid"] for kf in kfs]))
+    if drop:
+        kfids = kfids[1:]                                    # voxels of one key frame have no transformation: discarded
+    Rt = small_motions(kfids, seed=7)
+    n_new, discarded, undefined = ora.deform(kfids, Rt)
+    assert undefined == 0                                    # (the reference would index out of bounds there)
+    assert (discarded > 0) == drop
+    ref.deform(kfids, Rt)
+    assert [tuple(c) for c in ora.chunk_order()] == [tuple(c) for c in ref.chunk_ids()]
+    assert maps_identical(ref, ora) == n_new > 8
+    both(kfs[4])
+    both(kfs[0])
+    assert [tuple(c) for c in ora.chunk_order()] == [tuple(c) for c in ref.chunk_ids()]
+    Rt2 = small_motions(kfids, seed=9, rot=0.2, shift=0.5)   # a large correction: many voxels collide
+    _, _, undefined = ora.deform(kfids, Rt2)
+    assert undefined == 0
+    ref.deform(kfids, Rt2)
+    maps_identical(ref, ora)
+    ref.close()
+
+
+def test_deform_moves_the_stored_meshes_as_the_reference_library_does(oracle):
+    cam = small_cam(4)
+    ref, ora = RefChisel(0.05, cam), oracle.chisel(0.05).track_order()
+    for kf in make_keyframes(3, cam=cam, seed=67):
+        ref.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+        ora.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+        ora.end_call()
+    ref.update_meshes()
+    ids = sorted(tuple(int(v) for v in c) for c in ora.chunk_ids())
+    before = {cid: ora.mesh_chunk(*cid) for cid in ids}
+    kfids = np.array([0, 2], np.uint32)                      # key frame 1's vertices stay where they are
+    Rt = small_motions(kfids, seed=11, rot=0.1, shift=0.3)
+    ref.deform(kfids, Rt)
+    total = moved = 0
+    for cid in ids:
+        v, nr, col, kf = before[cid]
+        want_v, want_n, want_c, want_k = ref.mesh_chunk(*cid)
+        got_v, got_n = ora.deform_mesh(v, nr, kf, kfids, Rt)
+        assert np.array_equal(got_v.view(np.uint32), want_v.view(np.uint32)), f"vertices differ in chunk {cid}"
+        assert np.array_equal(got_n.view(np.uint32), want_n.view(np.uint32)), f"normals differ in chunk {cid}"
+        assert np.array_equal(col, want_c) and np.array_equal(kf, want_k)
+        total += len(v)
+        moved += int((got_v != v).any(axis=1).sum())
+    assert 0 < moved < total
     ref.close()
