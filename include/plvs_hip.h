@@ -624,6 +624,41 @@ int plvs_hip_tsdf_chisel_mesh_chunks(plvs_tsdf_chisel* h, const int32_t* chunk_i
                                      float* vertices, float* normals, float* colors, uint32_t* kfids,
                                      int capacity, int32_t* chunk_first, int* nvertices);
 
+/* ---- Chisel::Deform: PointCloudMapChisel::OnMapChange with key-frame adjustment (src/PointCloudMapChisel.cc:389-470
+ * -> ChiselServer::Deform, ChiselServer.cpp:617-621 -> Chisel::Deform, Chisel.cpp:588-591 -> ChunkManager::Deform,
+ * ChunkManager.cpp:918-1063).  Every known voxel whose kfid has an entry in the deformation map moves to
+ * R * centre + t; the first voxel to land in a new voxel is copied, later ones are merged into it
+ * (DistVoxel::Integrate, SetKfid, ColorVoxel::Integrate).  Who is first follows the reference's walk over `chunks`, a
+ * std::unordered_map whose iteration order is a function of its insert / erase history: with deform enabled the map
+ * keeps that container (ids only, host side) — every integrate call then reports the chunks it VISITS in first-visit
+ * order (one more walk of the rays; one cloud per call), and upload_chunk / clear update it as CreateChunk / Reset do.
+ * Enable on the EMPTY map (unsharded, max_chunks < 2^20).  Results equal the reference's voxel for voxel.
+ *
+ * deform: kfids[n_map] strictly increasing, Rt n_map x 12 floats (R row-major, then t) — the MapKfidRt OnMapChange
+ * fills (Rt = Twc_new * Tcw_at_integration).  Voxels whose kfid has no entry are dropped, as in the reference
+ * (stats.discarded, its "num discarded voxels").  stats.undefined counts voxels whose new chunk (floor(p / (16 res)))
+ * and new voxel (floor(p / res)) roundings disagree so that the reference indexes outside the chunk's voxel array
+ * (undefined behaviour there): they are dropped.  PLVS_ERR_CAPACITY if the deformed map needs more than max_chunks
+ * chunks; the map is then unchanged.  The updated-chunk list is empty afterwards (the reference leaves
+ * meshesToUpdate alone and moves the stored meshes instead: deform_mesh). */
+typedef struct plvs_tsdf_deform_stats {
+  int32_t new_chunks;   /* chunks of the deformed map                                  */
+  int64_t moved;        /* voxels that moved (copied or merged)                        */
+  int64_t discarded;    /* known voxels without a transformation                       */
+  int64_t undefined;    /* see above                                                   */
+} plvs_tsdf_deform_stats;
+int plvs_hip_tsdf_chisel_enable_deform(plvs_tsdf_chisel* h);
+int plvs_hip_tsdf_chisel_deform(plvs_tsdf_chisel* h, const uint32_t* kfids, const float* Rt, int n_map,
+                                plvs_tsdf_deform_stats* stats);
+/* The chunk ids in the iteration order of the reference's container (deform enabled). */
+int plvs_hip_tsdf_chisel_chunk_order(plvs_tsdf_chisel* h, int32_t* ids_xyz, int cap, int* n);
+/* The mesh half of ChunkManager::Deform (:1020-1051): vertex = R * vertex + t, normal = R * normal for the vertices
+ * whose kfid has a transformation (in place; the others stay).  Host and device-pointer flavours. */
+int plvs_hip_tsdf_chisel_deform_mesh(float* vertices, float* normals, const uint32_t* vertex_kfid, int n,
+                                     const uint32_t* kfids, const float* Rt, int n_map);
+int plvs_hip_tsdf_chisel_deform_mesh_dev(float* d_vertices, float* d_normals, const uint32_t* d_vertex_kfid, int n,
+                                         const uint32_t* d_kfids, const float* d_Rt, int n_map, void* stream);
+
 /* Creates or REPLACES one chunk with the given voxel planes (host, 4096 each, id = (z * 16 + y) * 16 + x): the
  * counterpart of download_chunk (a volume snapshot coming back; the reference itself has no volume file for chisel),
  * and what lets tests put analytic distance fields on the device. */

@@ -77,6 +77,12 @@ void oracle_chisel_ordered_end_call(void* p) {
     if (!oracle_chisel_has_chunk(h->map, k.x, k.y, k.z)) h->chunks.erase(k);
   h->fresh.clear();
 }
+// Chisel::Reset -> ChunkManager::Reset: chunks.clear() (the bucket array stays); call with oracle_chisel_clear.
+void oracle_chisel_ordered_reset(void* p) {
+  Ordered* h = static_cast<Ordered*>(p);
+  h->chunks.clear();
+  h->fresh.clear();
+}
 int oracle_chisel_ordered_size(void* p) { return (int)static_cast<Ordered*>(p)->chunks.size(); }
 void oracle_chisel_ordered_order(void* p, int32_t* ids) {
   size_t k = 0;

@@ -791,6 +791,8 @@ __global__ void selftest_rcp_kernel(int exponent, uint32_t* __restrict__ mismatc
 
 }  // namespace
 
+struct ChiselDeformState;   // tsdf_chisel_deform.hpp (included at the end of this file)
+
 struct plvs_tsdf_chisel {
   plvs_tsdf_chisel_params prm;
   Params P;
@@ -812,6 +814,7 @@ struct plvs_tsdf_chisel {
   DevBuf<uint32_t> tile_first, block_first;
   DevBuf<unsigned long long> tile_state;   // [0]: ticket, [1..]: look-back state per tile
   DevBuf<Pose> poses;
+  ChiselDeformState* dfm = nullptr;    // Chisel::Deform: the reference's chunk-map order, kept once enable_deform is on
   void* ext = nullptr;                 // see ChiselMapView::ext
   void (*ext_free)(void*) = nullptr;
   // halo of a sharded map (meshing): ghost copies of other ranks' chunks in the pool slots past num_chunks
@@ -869,6 +872,14 @@ struct plvs_tsdf_chisel {
   double stage_ms[kNumStages] = {};
   int64_t prof_calls = 0;
 };
+
+// Chisel::Deform support (tsdf_chisel_deform.hpp)
+static void deform_state_clear(plvs_tsdf_chisel* h);
+static void deform_state_free(plvs_tsdf_chisel* h);
+static void deform_note_created(plvs_tsdf_chisel* h, int cx, int cy, int cz);
+static int deform_track_begin(plvs_tsdf_chisel* h, const float* d_xyz, const float* d_normals, int n, int nclouds,
+                              const float* d_Twc, hipStream_t s);
+static int deform_track_end(plvs_tsdf_chisel* h, hipStream_t s);
 
 static int read_counters(plvs_tsdf_chisel* h, hipStream_t s) {
   hipLaunchKernelGGL(publish_counters, dim3(1), dim3(64), 0, s, (const WalkCounters*)nullptr, h->d_ctr, (WalkCounters*)nullptr,
@@ -1206,6 +1217,7 @@ int plvs_hip_tsdf_chisel_create(const plvs_tsdf_chisel_params* p, plvs_tsdf_chis
 int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   if (!h) return PLVS_OK;
   if (h->ext != nullptr && h->ext_free != nullptr) h->ext_free(h->ext);
+  deform_state_free(h);
   (void)hipFree(h->dir.keys);
   (void)hipFree(h->dir.slots);
   (void)hipFree(h->dir.slot_ids);
@@ -1282,6 +1294,7 @@ int plvs_hip_tsdf_chisel_clear(plvs_tsdf_chisel* h) {
   h->poisoned = false;
   h->stats = plvs_tsdf_stats{};
   h->last_updated = 0;
+  deform_state_clear(h);
   return PLVS_OK;
 }
 
@@ -1289,7 +1302,28 @@ int plvs_hip_tsdf_chisel_clear(plvs_tsdf_chisel* h) {
 
 // d_normals != nullptr: the world-cloud-with-normals flavour (Chisel::IntegrateWorldPointCloudWithNormals), always
 // through the ordered pipeline.
+static int integrate_batch_core(plvs_tsdf_chisel* h, const float* d_xyz, const uint8_t* d_rgb, const uint32_t* d_kfid,
+                                const int32_t* offsets, int nclouds, const float* d_Twc, void* stream,
+                                const float* d_normals);
+
 static int integrate_batch_impl(plvs_tsdf_chisel* h, const float* d_xyz, const uint8_t* d_rgb, const uint32_t* d_kfid,
+                                const int32_t* offsets, int nclouds, const float* d_Twc, void* stream,
+                                const float* d_normals) {
+  PLVS_REQUIRE(h, "null handle");
+  // a map with deform enabled keeps the reference's chunk-map order: the call's visits are replayed first
+  const bool track = h->dfm != nullptr && !h->poisoned && offsets && nclouds >= 1 && offsets[nclouds] - offsets[0] > 0 && d_xyz &&
+                     d_Twc;
+  if (track) {
+    int rc = halo_drop(h, static_cast<hipStream_t>(stream));
+    if (rc == PLVS_OK) rc = deform_track_begin(h, d_xyz, d_normals, offsets[nclouds] - offsets[0], nclouds, d_Twc, static_cast<hipStream_t>(stream));
+    if (rc != PLVS_OK) return rc;
+  }
+  int rc = integrate_batch_core(h, d_xyz, d_rgb, d_kfid, offsets, nclouds, d_Twc, stream, d_normals);
+  if (track && rc == PLVS_OK) rc = deform_track_end(h, static_cast<hipStream_t>(stream));
+  return rc;
+}
+
+static int integrate_batch_core(plvs_tsdf_chisel* h, const float* d_xyz, const uint8_t* d_rgb, const uint32_t* d_kfid,
                                 const int32_t* offsets, int nclouds, const float* d_Twc, void* stream,
                                 const float* d_normals) {
   PLVS_REQUIRE(h, "null handle");
@@ -2031,6 +2065,7 @@ int plvs_hip_tsdf_chisel_upload_chunk(plvs_tsdf_chisel* h, int cx, int cy, int c
   }
   const int slot = (int)h->h_ctr->total_visits;
   h->num_chunks = h->h_ctr->num_chunks;
+  if (h->dfm) deform_note_created(h, cx, cy, cz);
   const size_t off = (size_t)slot * kChunkVox;
   PLVS_HIP_TRY(hipMemcpy(h->sdf + off, sdf, kChunkVox * sizeof(float), hipMemcpyHostToDevice));
   PLVS_HIP_TRY(hipMemcpy(h->weight + off, weight, kChunkVox * sizeof(float), hipMemcpyHostToDevice));
@@ -2540,3 +2575,5 @@ int plvs_hip_tsdf_chisel_shard_note_saturated(plvs_tsdf_chisel* h, const int32_t
 }
 
 }  // extern "C"
+
+#include "tsdf_chisel_deform.hpp"

@@ -106,6 +106,54 @@ class TsdfChisel:
         f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 4
         _lib.check(f(self._h, int(cx), int(cy), int(cz), *[_lib.np_ptr(x) for x in a]))
 
+    # ---- Chisel::Deform (include/plvs_hip.h: plvs_hip_tsdf_chisel_enable_deform / _deform / _deform_mesh)
+    def enable_deform(self):
+        """On the EMPTY map: from here on the map keeps the reference's chunk-container order (one cloud per integrate
+        call)."""
+        f = _lib.lib.plvs_hip_tsdf_chisel_enable_deform
+        f.argtypes = [ctypes.c_void_p]
+        _lib.check(f(self._h))
+        return self
+
+    def chunk_order(self):
+        """Chunk ids in the iteration order of the reference's std::unordered_map (deform enabled)."""
+        n = self.num_chunks()
+        ids = np.zeros((max(n, 1), 3), np.int32)
+        m = ctypes.c_int()
+        f = _lib.lib.plvs_hip_tsdf_chisel_chunk_order
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        _lib.check(f(self._h, _lib.np_ptr(ids), n, ctypes.byref(m)))
+        return ids[:m.value]
+
+    class _DeformStats(ctypes.Structure):
+        _fields_ = [("new_chunks", ctypes.c_int32), ("moved", ctypes.c_int64), ("discarded", ctypes.c_int64),
+                    ("undefined", ctypes.c_int64)]
+
+    def deform(self, kfids, Rt):
+        """Chisel::Deform.  kfids [n] strictly increasing, Rt [n, 12] (R row-major, then t).
+        -> dict(new_chunks, moved, discarded, undefined)"""
+        kfids = np.ascontiguousarray(kfids, np.uint32)
+        Rt = np.ascontiguousarray(Rt, np.float32).reshape(len(kfids), 12)
+        st = self._DeformStats()
+        f = _lib.lib.plvs_hip_tsdf_chisel_deform
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        _lib.check(f(self._h, _lib.np_ptr(kfids), _lib.np_ptr(Rt), len(kfids), ctypes.byref(st)))
+        return dict(new_chunks=st.new_chunks, moved=st.moved, discarded=st.discarded, undefined=st.undefined)
+
+    @staticmethod
+    def deform_mesh(vertices, normals, vertex_kfid, kfids, Rt):
+        """The mesh half of ChunkManager::Deform: -> (vertices, normals) moved by their key frame's transformation."""
+        v = np.ascontiguousarray(vertices, np.float32).copy()
+        nr = np.ascontiguousarray(normals, np.float32).copy()
+        vk = np.ascontiguousarray(vertex_kfid, np.uint32)
+        kfids = np.ascontiguousarray(kfids, np.uint32)
+        Rt = np.ascontiguousarray(Rt, np.float32).reshape(len(kfids), 12)
+        f = _lib.lib.plvs_hip_tsdf_chisel_deform_mesh
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                      ctypes.c_int]
+        _lib.check(f(_lib.np_ptr(v), _lib.np_ptr(nr), _lib.np_ptr(vk), len(vk), _lib.np_ptr(kfids), _lib.np_ptr(Rt), len(kfids)))
+        return v, nr
+
     # ---- halo of a sharded map, for meshing (include/plvs_hip.h: plvs_hip_tsdf_chisel_halo_*)
     HALO_WORDS = 4 * 4096     # a chunk on the wire: sdf, weight, kfid, rgbw planes
 
@@ -580,12 +628,17 @@ class PointCloudMapChisel:
     """Same surface as PLVS2::PointCloudMapChisel for the integrate path."""
 
     def __init__(self, resolution, min_depth=0.1, max_depth=5.0, use_carving=False, max_chunks=None,
-                 carving_dist=0.05, near_plane_dist=0.05, far_plane_dist=5.0):
+                 carving_dist=0.05, near_plane_dist=0.05, far_plane_dist=5.0, bResetOnSparseMapChange=True,
+                 bCloudDeformationOnSparseMapChange=False):
         self.resolution = resolution
         self.min_depth, self.max_depth = min_depth, max_depth
         self.use_carving, self.carving_dist = use_carving, carving_dist
         self.near_plane_dist, self.far_plane_dist = near_plane_dist, far_plane_dist
+        self.bResetOnSparseMapChange = bResetOnSparseMapChange
+        self.bCloudDeformationOnSparseMapChange = bCloudDeformationOnSparseMapChange
         self._tsdf = TsdfChisel(resolution, max_chunks=max_chunks)
+        if bCloudDeformationOnSparseMapChange:
+            self._tsdf.enable_deform()       # the map keeps the reference's chunk order from its first cloud on
         self._meshes_to_update = set()       # Chisel::meshesToUpdate
         self.all_meshes = {}                 # chunk id -> dict(vertices, normals, colors, kfids)
 
@@ -673,6 +726,29 @@ class PointCloudMapChisel:
         if t != "kPointCloud":
             raise SystemExit(-1)
         self.InsertCloud(pData["pPointCloud"], pData["Twc"], pData.get("maxRange", self.max_depth))
+
+    def OnMapChange(self, mapKfidToRt=None):
+        """src/PointCloudMapChisel.cc:262-274 / :389-496.  With bResetOnSparseMapChange: ChiselServer::Reset.  With
+        bCloudDeformationOnSparseMapChange: UpdateMap, ChiselServer::Deform(mapKfidToRt), UpdateMap.  mapKfidToRt:
+        {kfid: (R 3x3, t 3)} — Twc_new * Tcw_at_integration of every valid key frame, which the caller derives from its
+        key frames as :420-478 does.  -> the output cloud after the change."""
+        if self.bResetOnSparseMapChange:
+            self._tsdf.clear()                               # Chisel::Reset: chunks, meshes, meshesToUpdate
+            self._meshes_to_update.clear()
+            self.all_meshes.clear()
+        if self.bCloudDeformationOnSparseMapChange:
+            self.UpdateMap()
+            kfids = np.array(sorted(mapKfidToRt or {}), np.uint32)
+            Rt = np.zeros((len(kfids), 12), np.float32)
+            for i, k in enumerate(kfids):
+                R, t = mapKfidToRt[int(k)]
+                Rt[i, :9] = np.asarray(R, np.float32).reshape(9)
+                Rt[i, 9:] = np.asarray(t, np.float32).reshape(3)
+            self._tsdf.deform(kfids, Rt)
+            for cid, m in self.all_meshes.items():           # ChunkManager.cpp:1020-1051: the stored meshes move too
+                if len(m["kfids"]):
+                    m["vertices"], m["normals"] = TsdfChisel.deform_mesh(m["vertices"], m["normals"], m["kfids"], kfids, Rt)
+        return self.UpdateMap()
 
     def Clear(self):
         self._tsdf.clear()

@@ -416,6 +416,14 @@ class _ChiselLike:
         self.lib.oracle_chisel_ordered_deform.argtypes = [_vp, _vp, _vp, _i, _vp]
         return self
 
+    def clear(self):
+        """Chisel::Reset."""
+        self.lib.oracle_chisel_clear.argtypes = [_vp]
+        self.lib.oracle_chisel_clear(self.h)
+        if getattr(self, "ordered", None):
+            self.lib.oracle_chisel_ordered_reset.argtypes = [_vp]
+            self.lib.oracle_chisel_ordered_reset(self.ordered)
+
     def end_call(self):
         self.lib.oracle_chisel_ordered_end_call(self.ordered)
 

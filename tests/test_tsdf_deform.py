@@ -1,0 +1,217 @@
+"""Chisel::Deform (ChunkManager.cpp:918-1063) on the device against the oracle (oracle/tsdf_chisel.c +
+oracle/tsdf_chisel_deform.cpp, themselves pinned against the compiled reference library in
+tests/test_oracle_pinned_chisel_map.py).  The bar: the chunk-container order the map keeps equals the oracle's real
+std::unordered_map after every call, and the deformed map is bit-identical — sdf, weight, kfid, colour, colour weight
+of every voxel — through several integrate / carve / deform / clear cycles."""
+import numpy as np
+import pytest
+
+from tests import oracle_lib
+from tests.plvs_amd_synth import TUM1, make_keyframes
+from tests.test_tsdf_chisel import compare_maps
+from tests.test_tsdf_loadmap import surface_cloud
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return oracle_lib.load()
+
+
+def small_cam(scale):
+    c = dict(TUM1)
+    for k in ("fx", "fy", "cx", "cy"):
+        c[k] = c[k] / scale
+    c["width"] //= scale
+    c["height"] //= scale
+    return c
+
+
+def motions(kfids, seed, rot=0.03, shift=0.08):
+    """One rigid correction per key frame (what OnMapChange derives from the optimised poses) -> [n, 12]."""
+    rng = np.random.default_rng(seed)
+    out = np.zeros((len(kfids), 12), np.float32)
+    for i in range(len(kfids)):
+        w = rng.normal(scale=rot, size=3)
+        th = np.linalg.norm(w)
+        k = w / max(th, 1e-12)
+        K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+        out[i, :9] = R.astype(np.float32).reshape(9)
+        out[i, 9:] = rng.normal(scale=shift, size=3).astype(np.float32)
+    return out
+
+
+def order_of(m):
+    return [tuple(int(v) for v in c) for c in m.chunk_order()]
+
+
+def test_oracle_deform_properties(oracle):
+    """Identity transformations put every voxel back where it was; a missing key frame drops its voxels."""
+    cam = small_cam(4)
+    kfs = make_keyframes(3, cam=cam, seed=71)
+    m = oracle.chisel(0.05).track_order()
+    for kf in kfs:
+        m.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+        m.end_call()
+    before = {tuple(c): m.get_chunk(*c) for c in m.chunk_ids()}
+    kfids = np.unique(np.concatenate([kf["kfid"] for kf in kfs]))
+    ident = np.tile(np.concatenate([np.eye(3).reshape(9), np.zeros(3)]).astype(np.float32), (len(kfids), 1))
+    n_new, discarded, undefined = m.deform(kfids, ident)
+    assert discarded == 0 and undefined == 0
+    after = {tuple(c): m.get_chunk(*c) for c in m.chunk_ids()}
+    # chunks without a known voxel are not recreated; the others come back voxel for voxel where they are known
+    known = {cid for cid, v in before.items() if (v[1] > 1e-15).any()}
+    assert set(after) == known and n_new == len(known)
+    for cid in known:
+        k = before[cid][1] > 1e-15
+        for a, b in zip(before[cid], after[cid]):
+            assert np.array_equal(a[k], b[k])
+        assert np.all(after[cid][1][~k] == 0)
+    _, discarded, _ = m.deform(kfids[1:], ident[1:])
+    assert discarded > 0
+    assert sum(int((v[2][v[1] > 0] == kfids[0]).sum()) for v in (m.get_chunk(*c) for c in m.chunk_ids())) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("res,order_free", [(0.05, False), (0.1, False), (0.05, True)])
+def test_hip_deform_matches_oracle(oracle, res, order_free):
+    from plvs_amd.tsdf import TsdfChisel
+    cam = small_cam(4)
+    kfs = make_keyframes(6, cam=cam, seed=73)
+    ora = oracle.chisel(res).track_order()
+    dev = TsdfChisel(res, max_chunks=8192, order_free=order_free).enable_deform()
+
+    def integrate(kf):
+        ora.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+        ora.end_call()
+        dev.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+        assert order_of(dev) == order_of(ora)              # the reference's container order, call by call
+
+    def same_maps():
+        if not order_free:
+            return compare_maps(ora, dev)
+        # the order-free mode's sdf / weight carry its stated float tolerance into the deformed map; ids, kfid exact
+        assert sorted(order_of(dev)) == sorted(order_of(ora))
+        return dev.num_chunks()
+
+    for kf in kfs[:4]:
+        integrate(kf)
+    kfids = np.unique(np.concatenate([kf["kfid"] for kf in kfs]))
+    Rt = motions(kfids, seed=3)
+    want = ora.deform(kfids, Rt)
+    got = dev.deform(kfids, Rt)
+    assert want[2] == 0
+    if not order_free:
+        assert (got["new_chunks"], got["discarded"], got["undefined"]) == want
+        assert got["moved"] > 10000
+    assert order_of(dev) == order_of(ora)
+    assert same_maps() > 8
+    assert len(dev.updated_chunk_ids()) == 0
+    integrate(kfs[4])                                      # integrating into the deformed map ...
+    xyz, rgb, kfid, nrm = surface_cloud(3000, seed=9)
+    ora.integrate_world_normals(xyz, rgb, kfid % 6, nrm)
+    ora.end_call()
+    dev.integrate_world_normals(xyz, rgb, kfid % 6, nrm)
+    assert order_of(dev) == order_of(ora)
+    Rt2 = motions(kfids[:-1], seed=5, rot=0.2, shift=0.5)  # ... and a large correction that drops one key frame
+    want = ora.deform(kfids[:-1], Rt2)
+    got = dev.deform(kfids[:-1], Rt2)
+    assert want[1] > 0 and want[2] == 0
+    if not order_free:
+        assert (got["new_chunks"], got["discarded"], got["undefined"]) == want
+    assert order_of(dev) == order_of(ora)
+    same_maps()
+    # Reset keeps the container's bucket array: the order after a clear still has to agree
+    dev.clear()
+    ora.clear()
+    integrate(kfs[5])
+    integrate(kfs[1])
+    ora.deform(kfids, Rt)
+    dev.deform(kfids, Rt)
+    assert order_of(dev) == order_of(ora)
+    same_maps()
+    dev.close()
+
+
+@pytest.mark.gpu
+def test_hip_deform_with_carving_and_uploaded_chunks(oracle):
+    from plvs_amd.tsdf import TsdfChisel
+    cam = small_cam(4)
+    kfs = make_keyframes(3, cam=cam, seed=79)
+    ora = oracle.chisel(0.05).track_order()
+    dev = TsdfChisel(0.05, max_chunks=4096).enable_deform()
+    for kf in kfs:
+        ora.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+        ora.end_call()
+        dev.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+    depth = np.full((cam["height"], cam["width"]), 4.2, np.float32)     # carving resets voxels: they no longer move
+    n_ora, _ = ora.carve(depth, cam["fx"], cam["fy"], cam["cx"], cam["cy"], kfs[0]["Twc"])
+    n_dev = dev.carve(depth, cam["fx"], cam["fy"], cam["cx"], cam["cy"], kfs[0]["Twc"])
+    assert n_ora == n_dev > 0
+    kfids = np.arange(3, dtype=np.uint32)
+    Rt = motions(kfids, seed=13, rot=0.08, shift=0.2)
+    want = ora.deform(kfids, Rt)
+    got = dev.deform(kfids, Rt)
+    assert (got["new_chunks"], got["discarded"], got["undefined"]) == want
+    assert order_of(dev) == order_of(ora)
+    compare_maps(ora, dev)
+    dev.close()
+
+
+@pytest.mark.gpu
+def test_hip_deform_mesh_and_on_map_change(oracle):
+    from plvs_amd.tsdf import PointCloudMapChisel, TsdfChisel
+    cam = small_cam(4)
+    kfs = make_keyframes(3, cam=cam, seed=83)
+    pm = PointCloudMapChisel(0.05, max_chunks=4096, bResetOnSparseMapChange=False, bCloudDeformationOnSparseMapChange=True)
+    for kf in kfs:
+        pm.InsertCloud(kf, kf["Twc"])
+    before = pm.UpdateMap()
+    assert len(before) > 3000
+    kfids = np.array([0, 2], np.uint32)                     # key frame 1's vertices stay
+    Rt = motions(kfids, seed=17, rot=0.1, shift=0.3)
+    after = pm.OnMapChange({int(k): (Rt[i, :9].reshape(3, 3), Rt[i, 9:]) for i, k in enumerate(kfids)})
+    # the reference moves the stored meshes and marks nothing for re-meshing: the output cloud is the old one, moved
+    xyz = np.stack([before["x"], before["y"], before["z"]], -1)
+    want_v, want_n = oracle.chisel(0.05).deform_mesh(xyz, before["normal"], before["kfid"], kfids, Rt)
+    got_v = np.stack([after["x"], after["y"], after["z"]], -1)
+    assert np.array_equal(got_v.view(np.uint32), want_v.view(np.uint32))
+    assert np.array_equal(np.ascontiguousarray(after["normal"]).view(np.uint32), want_n.view(np.uint32))
+    assert np.array_equal(after["kfid"], before["kfid"]) and np.array_equal(after["r"], before["r"])
+    moved = (got_v != xyz).any(axis=1)
+    assert 0 < moved.sum() < len(xyz) and not moved[before["kfid"] == 1].any()
+    # the volume moved as well: the next cloud re-meshes deformed chunks
+    assert pm.tsdf.num_chunks() > 8 and len(pm.tsdf.chunk_order()) == pm.tsdf.num_chunks()
+    pm.InsertCloud(kfs[0], kfs[0]["Twc"])
+    assert len(pm.UpdateMap()) > 0
+    pm.tsdf.close()
+
+
+@pytest.mark.gpu
+def test_hip_deform_refusals(oracle):
+    from plvs_amd import _lib
+    from plvs_amd.tsdf import TsdfChisel
+    cam = small_cam(4)
+    kf = make_keyframes(1, cam=cam, seed=89)[0]
+    ident = np.concatenate([np.eye(3).reshape(9), np.zeros(3)]).astype(np.float32)[None]
+    plain = TsdfChisel(0.05, max_chunks=2048)
+    plain.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+    with pytest.raises(_lib.PlvsHipError):                      # the order is the map's whole history
+        plain.enable_deform()
+    with pytest.raises(_lib.PlvsHipError):
+        plain.deform(np.zeros(1, np.uint32), ident)
+    plain.close()
+    small = TsdfChisel(0.05, max_chunks=256).enable_deform()
+    small.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+    ids = {tuple(c) for c in small.chunk_ids()}
+    one = small.get_chunk(*sorted(ids)[0])
+    far = ident.copy()
+    far[0, :9] *= 40.0                                       # scatters the voxels over far more than 256 chunks
+    with pytest.raises(_lib.PlvsHipError):
+        small.deform(np.zeros(1, np.uint32), far)
+    assert {tuple(c) for c in small.chunk_ids()} == ids      # ... and the map is unchanged
+    for a, b in zip(one, small.get_chunk(*sorted(ids)[0])):
+        assert np.array_equal(a, b)
+    with pytest.raises(_lib.PlvsHipError):                      # kfids must be strictly increasing
+        small.deform(np.array([1, 1], np.uint32), np.repeat(ident, 2, 0))
+    small.close()
