@@ -392,12 +392,17 @@ struct Mesh {   // chisel::Mesh after RecomputeMesh
 class PointCloudMapChisel {
  public:
   using ChunkID = std::tuple<int, int, int>;
+  // bCloudDeformationOnSparseMapChange: the map keeps the reference's chunk order from its first cloud on, so that
+  // OnMapChange can deform it as Chisel::Deform does (plvs_hip_tsdf_chisel_enable_deform)
   explicit PointCloudMapChisel(float resolution, bool useCarving = false, float carvingDist = 0.05f,
-                               float nearPlaneDist = 0.05f, float farPlaneDist = 5.0f)
-      : useCarving_(useCarving), carvingDist_(carvingDist), near_(nearPlaneDist), far_(farPlaneDist) {
+                               float nearPlaneDist = 0.05f, float farPlaneDist = 5.0f, bool bResetOnSparseMapChange = true,
+                               bool bCloudDeformationOnSparseMapChange = false)
+      : useCarving_(useCarving), carvingDist_(carvingDist), near_(nearPlaneDist), far_(farPlaneDist),
+        resetOnChange_(bResetOnSparseMapChange), deformOnChange_(bCloudDeformationOnSparseMapChange) {
     plvs_tsdf_chisel_params p;
     check(plvs_hip_tsdf_chisel_default_params(resolution, &p));
     check(plvs_hip_tsdf_chisel_create(&p, &h_));
+    if (deformOnChange_) check(plvs_hip_tsdf_chisel_enable_deform(h_));
   }
   ~PointCloudMapChisel() { plvs_hip_tsdf_chisel_destroy(h_); }
   PointCloudMapChisel(const PointCloudMapChisel&) = delete;
@@ -514,6 +519,28 @@ class PointCloudMapChisel {
     allMeshes_.clear();
     pointCloud_.clear();
   }
+  // OnMapChange (src/PointCloudMapChisel.cc:262-274, :389-496).  mapKfidToRt: kfid -> Twc_new * Tcw_at_integration
+  // (12 floats: R row-major, then t) for every valid key frame, which the caller derives from its key frames as
+  // :420-478 does.  Reset, or UpdateMap + Chisel::Deform (volume and stored meshes) + UpdateMap.
+  struct Rt12 { float v[12]; };
+  int OnMapChange(const std::map<uint32_t, Rt12>& mapKfidToRt = {}) {
+    if (resetOnChange_) { check(plvs_hip_tsdf_chisel_clear(h_)); meshesToUpdate_.clear(); allMeshes_.clear(); }
+    if (deformOnChange_) {
+      UpdateMap();
+      std::vector<uint32_t> kf;
+      std::vector<float> rt;
+      for (const auto& e : mapKfidToRt) { kf.push_back(e.first); rt.insert(rt.end(), e.second.v, e.second.v + 12); }
+      plvs_tsdf_deform_stats st;
+      check(plvs_hip_tsdf_chisel_deform(h_, kf.data(), rt.data(), (int)kf.size(), &st));
+      for (auto& kv : allMeshes_) {   // ChunkManager.cpp:1020-1051
+        Mesh& m = kv.second;
+        if (!m.kfids.empty())
+          check(plvs_hip_tsdf_chisel_deform_mesh(m.vertices.data(), m.normals.data(), m.kfids.data(), (int)m.kfids.size(), kf.data(),
+                                                 rt.data(), (int)kf.size()));
+      }
+    }
+    return UpdateMap();
+  }
   const std::vector<PointSurfelSegment>& GetPointCloud() const { return pointCloud_; }
   const std::map<ChunkID, Mesh>& GetAllMeshes() const { return allMeshes_; }
   plvs_tsdf_chisel* handle() { return h_; }
@@ -533,6 +560,7 @@ class PointCloudMapChisel {
   plvs_tsdf_chisel* h_ = nullptr;
   bool useCarving_;
   float carvingDist_, near_, far_;
+  bool resetOnChange_ = true, deformOnChange_ = false;
   std::vector<float> xyz_;
   std::vector<uint8_t> rgb_;
   std::vector<uint32_t> kfid_;

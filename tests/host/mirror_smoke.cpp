@@ -205,6 +205,20 @@ int main(int argc, char** argv) {
     dump("loaded_cloud", again.GetPointCloud().data(), again.GetPointCloud().size() * sizeof(PointSurfelSegment));
     std::printf("loadmap %d %d\n", lpts, (int)again.GetAllMeshes().size());
   }
+  {   // OnMapChange with cloud deformation: the volume and the stored meshes move with their key frame (kfid 7 here)
+    PointCloudMapChisel dmap(0.05f, false, 0.05f, 0.05f, 5.0f, /*reset*/ false, /*deform*/ true);
+    SE3f T = {{1, 0, 0, 0.1f, 0, 1, 0, -0.2f, 0, 0, 1, 0.05f}};
+    dmap.InsertCloud(cloud, T);
+    dmap.UpdateMap();
+    std::map<uint32_t, PointCloudMapChisel::Rt12> rt;
+    rt[7] = PointCloudMapChisel::Rt12{{0.9998f, -0.02f, 0.f, 0.02f, 0.9998f, 0.f, 0.f, 0.f, 1.f, 0.04f, -0.03f, 0.11f}};
+    const int dpts = dmap.OnMapChange(rt);
+    dump("deformed_cloud", dmap.GetPointCloud().data(), dmap.GetPointCloud().size() * sizeof(PointSurfelSegment));
+    dmap.InsertCloud(cloud, T);   // the deformed volume takes the next cloud
+    const int dpts2 = dmap.UpdateMap();
+    dump("deformed_cloud2", dmap.GetPointCloud().data(), dmap.GetPointCloud().size() * sizeof(PointSurfelSegment));
+    std::printf("deform %d %d\n", dpts, dpts2);
+  }
   map.Clear();
   std::printf("cleared %d\n", map.UpdateMap());
   return 0;

@@ -130,4 +130,16 @@ def test_cpp_mirror_matches_python_mirror(tmp_path):
     assert load("vmap_cloud", np.uint8).tobytes() == vcloud.tobytes()
     # the layer saved and loaded into an empty map meshes to the same cloud
     assert lines_out["voxblox_layer"] == [lines_out["voxblox"][0], lines_out["voxblox"][1], "1"]
+    # OnMapChange with cloud deformation, C++ mirror against the python mirror (both over the C ABI)
+    dm = PointCloudMapChisel(0.05, bResetOnSparseMapChange=False, bCloudDeformationOnSparseMapChange=True)
+    dm.InsertCloud(pc, Twc)
+    dm.UpdateMap()
+    R = np.array([[0.9998, -0.02, 0.0], [0.02, 0.9998, 0.0], [0.0, 0.0, 1.0]], np.float32)
+    dc = dm.OnMapChange({7: (R, np.array([0.04, -0.03, 0.11], np.float32))})
+    assert int(lines_out["deform"][0]) == len(dc) > 1000
+    assert load("deformed_cloud", np.uint8).tobytes() == dc.tobytes()
+    dm.InsertCloud(pc, Twc)
+    dc2 = dm.UpdateMap()
+    assert int(lines_out["deform"][1]) == len(dc2) > 1000
+    assert load("deformed_cloud2", np.uint8).tobytes() == dc2.tobytes()
     assert lines_out["cleared"] == ["0"]
