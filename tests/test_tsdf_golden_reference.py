@@ -110,3 +110,73 @@ def test_hip_reproduces_the_reference_built_maps(golden, carving):
     got = check(a, golden, carving)
     assert got[-1]["chunks"] > 8
     a.m.close()
+
+
+# ------------------------------------------------------------------ voxblox
+from tests import voxblox_golden_scenario as V   # noqa: E402
+
+VGOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "voxblox_reference_digests.json")
+
+
+@pytest.fixture(scope="module")
+def vgolden():
+    with open(VGOLDEN) as f:
+        g = json.load(f)
+    assert V.inputs_digest() == g["inputs"], "the synthetic inputs changed: regenerate with scripts/make_voxblox_golden.py"
+    return g
+
+
+class VoxbloxOracleAdapter:
+    def __init__(self, case):
+        self.m = oracle_lib.load().voxblox(case["vs"], carving=case["carving"])
+        self.merged = case["method"] == "merged"
+
+    def integrate(self, xyz, rgba, Twc):
+        (self.m.integrate_merged if self.merged else self.m.integrate)(xyz, rgba, Twc)
+
+    def world(self, xyz, rgba, nrm, Twc):
+        self.m.integrate_world_normals(xyz, rgba, nrm, Twc)
+
+    def block_ids(self):
+        return self.m.chunk_ids()
+
+    def get_block(self, bx, by, bz):
+        return self.m.get_chunk(bx, by, bz)
+
+    def mesh_block(self, bx, by, bz):
+        from tests.test_tsdf_voxblox_mesh import mesh_block
+        return mesh_block(self.m, bx, by, bz)
+
+
+class VoxbloxDeviceAdapter(VoxbloxOracleAdapter):
+    def __init__(self, case):
+        from plvs_amd.tsdf import TsdfVoxblox
+        self.m = TsdfVoxblox(case["vs"], use_carving=case["carving"], max_blocks=8192)
+        self.merged = case["method"] == "merged"
+        self._mesh = None
+
+    def mesh_block(self, bx, by, bz):
+        if self._mesh is None:
+            ids = sorted(tuple(int(v) for v in b) for b in self.m.chunk_ids())
+            r = self.m.mesh_blocks(np.array(ids, np.int32))
+            first = r["block_first"]
+            self._mesh = {b: tuple(r[k][int(first[i]):int(first[i + 1])] for k in ("vertices", "normals", "colors"))
+                          for i, b in enumerate(ids)}
+        return self._mesh[(bx, by, bz)]
+
+
+def vcheck(make_adapter, g):
+    got = V.run(make_adapter)
+    assert [r["case"] for r in got] == [r["case"] for r in g["cases"]]
+    for a, b in zip(got, g["cases"]):
+        assert a == b, f"case '{a['case']}' differs from the reference's layer / mesh: {a} vs {b}"
+        assert a["chunks"] > 20 and a["vertices"] > 5000
+
+
+def test_oracle_reproduces_the_reference_built_voxblox_layers(vgolden):
+    vcheck(VoxbloxOracleAdapter, vgolden)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_the_reference_built_voxblox_layers(vgolden):
+    vcheck(VoxbloxDeviceAdapter, vgolden)
