@@ -48,8 +48,8 @@ import torch.distributed as dist
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=100,
                     help="keyframes per step (default: the whole 100-pose sequence of SURVEY §8d in one launch)")
     ap.add_argument("--resolution", type=float, default=0.05)
