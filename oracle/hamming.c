@@ -5,10 +5,13 @@
  * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load it
  * (as the checker / the timed CPU baseline).
  *
- * Parity status: UNPINNED by the reference (it ships no test or golden vector
- * for this path).  Analytically pinned instead: the distance is
- * a popcount, and the k-NN result is checked in tests/ against an independent
- * numpy brute force on (distance) and against the tie rules stated below.
+ * Parity status: the LBD k-NN (oracle_knn2_mih) is PINNED by the reference's own source: the matcher file
+ * binary_descriptor_matcher_custom.cpp compiles unmodified against an OpenCV stand-in (oracle/ref/cv_shim ->
+ * oracle/_ref/liblbd_matcher_ref.so) and tests/test_oracle_pinned.py compares BinaryDescriptorMatcher::knnMatch(k = 2)
+ * with this file on random and clustered codes (many equidistant neighbours, duplicates, exact copies, query masks,
+ * nt = 2): indices and distances of both neighbours of every query.  The brute-force ORB k-NN (oracle_knn2_bf, what
+ * cv::BFMatcher does) stays analytically pinned — the distance is a popcount, and the result is checked against an
+ * independent numpy brute force with the lowest-index tie rule (OpenCV itself is absent here).
  *
  * Follows (paths relative to the PLVS tree):
  *   src/ORBmatcher.cc:2198-2225              ORBmatcher::DescriptorDistance

@@ -1,0 +1,2 @@
+// (see cvshim.hpp)
+#include "cvshim.hpp"

@@ -468,3 +468,47 @@ def test_voxblox_mesh_integrator_equals_the_reference_source():
         assert ref.ref_voxblox_mesh_block(h, 999, 999, 999, v.ctypes.data, n.ctypes.data, c.ctypes.data, cap) == 0
         ref.ref_voxblox_destroy(h)
     assert total > 15000
+
+
+# ------------------------------------------------------------------ LBD matcher (multi-index hashing k-NN)
+LREF = os.path.join(ROOT, "oracle", "_ref", "liblbd_matcher_ref.so")
+needs_lref = pytest.mark.skipif(not os.path.exists(LREF), reason="oracle/_ref/liblbd_matcher_ref.so not present")
+
+
+def _codes(rng, n, clustered):
+    """LBD-like 256-bit codes: random, or few cluster centres with a few flipped bits (many equidistant neighbours:
+    the case where WHICH of them the hash search reports is decided by its probing order)."""
+    if not clustered:
+        return rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    centres = rng.integers(0, 256, (max(n // 12, 1), 32), dtype=np.uint8)
+    out = centres[rng.integers(0, len(centres), n)].copy()
+    for i in range(n):
+        for b in rng.integers(0, 256, rng.integers(0, 4)):
+            out[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    return out
+
+
+@needs_lref
+@pytest.mark.parametrize("nq,nt,seed,clustered", [(100, 100, 1, False), (300, 200, 2, True), (64, 1000, 3, True),
+                                                  (500, 37, 4, False), (7, 2, 5, False), (200, 300, 6, True)])
+def test_lbd_mih_knn_restatement_equals_the_reference_source(nq, nt, seed, clustered):
+    """BinaryDescriptorMatcher::knnMatch(k = 2) -> Mihasher populate / batchquery / query of the reference, compiled
+    unmodified, against oracle_knn2_mih: indices (incl. the choice among equidistant train lines, duplicates and exact
+    copies of the query) and distances of both neighbours of every query, with and without a query mask."""
+    from tests import oracle_lib
+    ref = ctypes.CDLL(LREF)
+    ref.ref_lbd_knn2.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3
+    oracle = oracle_lib.load()
+    rng = np.random.default_rng(seed)
+    t = _codes(rng, nt, clustered)
+    q = _codes(rng, nq, clustered)
+    q[::5] = t[rng.integers(0, nt, len(q[::5]))]            # exact copies: distance 0, often shared by several train rows
+    for mask in (None, (rng.random(nq) < 0.7).astype(np.uint8)):
+        idx = np.full((nq, 2), -7, np.int32)
+        dist = np.full((nq, 2), -7, np.int32)
+        ref.ref_lbd_knn2(q.ctypes.data, nq, t.ctypes.data, nt, None if mask is None else mask.ctypes.data, idx.ctypes.data,
+                         dist.ctypes.data)
+        oidx, odist = oracle.knn2(q, t, mask, mih=True)
+        assert np.array_equal(idx, oidx), np.argwhere(idx != oidx)[:5]
+        assert np.array_equal(dist, odist)
+        assert (idx[mask.astype(bool) if mask is not None else slice(None)] >= 0).all()
