@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libplvs_hip.so")
+# (PLVS_HIP_LIB: a developer build of the same library, e.g. one with kernel phase clocks)
+LIB_PATH = os.environ.get("PLVS_HIP_LIB") or os.path.join(_HERE, "lib", "libplvs_hip.so")
 
 PLVS_OK = 0
 PLVS_ERR_INVALID_ARG = -1

@@ -1121,6 +1121,18 @@ int plvs_hip_selftest_rcp(int exponent, uint32_t* mismatches) {
   return PLVS_OK;
 }
 
+#ifdef PLVS_WALK_PROF
+// developer build only (make PROF=1): the phase clocks of walk_tiles, summed over the tiles since the last reset
+int plvs_hip_debug_walk_prof(unsigned long long* out16, int reset) {
+  if (out16) PLVS_HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_walk_prof), 16 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[16] = {};
+    PLVS_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_walk_prof), z, sizeof z));
+  }
+  return PLVS_OK;
+}
+#endif
+
 int plvs_hip_selftest_walk_math(uint32_t seed, uint32_t* mismatches_sqrt_div) {
   PLVS_REQUIRE(mismatches_sqrt_div, "null argument");
   uint32_t* d = nullptr;

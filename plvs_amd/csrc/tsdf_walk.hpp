@@ -55,6 +55,33 @@ constexpr int kWalkWindow = kWalkLimit / 2;     // visits per window of a single
 constexpr int kWalkChunks = 64;                 // per-tile chunk cache
 constexpr uint32_t kErrScratch = 8u;            // record / segment / run buffers too small: the host grows them and retries
 
+// Phase clocks of walk_tiles (a developer build: make PROF=1 -> libplvs_hip_prof.so; thread 0 of a tile adds the shader
+// cycles between the tile's barriers to g_walk_prof[phase]).  Compiled out of the product library.
+#ifndef PLVS_WALK_EXP
+#define PLVS_WALK_EXP 0     // timing experiments (developer builds; results are wrong with any bit set)
+#endif
+#ifdef PLVS_WALK_PROF
+__device__ unsigned long long g_walk_prof[16];
+#define WALK_PROF_BEGIN()                                         \
+  long long prof_t = (long long)clock64();                        \
+  unsigned long long prof_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define WALK_PROF(k)                                               \
+  do {                                                             \
+    const long long now = (long long)clock64();                    \
+    prof_acc[k] += (unsigned long long)(now - prof_t);             \
+    prof_t = now;                                                  \
+  } while (0)
+#define WALK_PROF_END()                                            \
+  do {                                                             \
+    if (threadIdx.x == 0)                                          \
+      for (int k = 0; k < 9; ++k) atomicAdd(&g_walk_prof[k], prof_acc[k]); \
+  } while (0)
+#else
+#define WALK_PROF_BEGIN() do {} while (0)
+#define WALK_PROF(k) do {} while (0)
+#define WALK_PROF_END() do {} while (0)
+#endif
+
 struct WalkCounters {           // device-side, read back once per call
   unsigned long long total_visits;
   uint32_t err;
@@ -181,14 +208,20 @@ __device__ __forceinline__ bool rel_key(int vx, int vy, int vz, int ox, int oy, 
 __device__ __forceinline__ uint32_t key_bucket(uint32_t key) { return (key * 2654435761u) >> 24; }
 static_assert(kBuckets == 256, "key_bucket yields 8 bits");
 
-// position of `want` among the four keys of a bucket, -1 if absent
+// position of `want` among the four keys of a bucket, -1 if absent.  All four comparisons feed the result, so the
+// bucket is ONE ds_read_b128 (a short-circuit form makes the compiler read the first key alone and branch).
 __device__ __forceinline__ int bucket_match(const uint4 k4, uint32_t want) {
-  return k4.x == want ? 0 : (k4.y == want ? 1 : (k4.z == want ? 2 : (k4.w == want ? 3 : -1)));
+  const bool c0 = k4.x == want, c1 = k4.y == want, c2 = k4.z == want, c3 = k4.w == want;
+  const int j = c3 ? 3 : (c2 ? 2 : (c1 ? 1 : 0));
+  return (c0 | c1 | c2 | c3) ? j : -1;
 }
 
 // Entry of the key in the table (inserted if absent); -1 when the table is full.  A key lives in the first
 // bucket from its home bucket on that had a free slot when it came (entries are never removed), so a search
-// ends at the first bucket that holds the key or a free slot.
+// ends at the first bucket that holds the key or a free slot.  ONE LDS round trip for a key that is there, two for
+// a first touch (the bucket, the compare-and-swap): every wave step of the walk has a few lanes on this path and
+// the step is as slow as its slowest lane.  Entries are not counted here — the flush counts them (entries beyond
+// kWalkLimit: the (sub-)tile is cut, as when the table is full).
 __device__ __forceinline__ int table_find_or_insert(WalkShared& S, uint32_t key) {
   uint32_t b = key_bucket(key);
   for (int probe = 0; probe < 4 * kBuckets; ++probe) {
@@ -197,13 +230,8 @@ __device__ __forceinline__ int table_find_or_insert(WalkShared& S, uint32_t key)
     if (j >= 0) return (int)(4 * b) + j;
     const int je = bucket_match(k4, kKeyEmpty);
     if (je >= 0) {
-      if (__hip_atomic_load(&S.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return -1;   // (an LDS read)
       const uint32_t old = atomicCAS(&S.ekey[4 * b + je], kKeyEmpty, key);
-      if (old == kKeyEmpty) {
-        if (atomicAdd(&S.nent, 1u) >= (uint32_t)kWalkLimit) S.overflow = 1u;   // this insert still stands
-        return (int)(4 * b) + je;
-      }
-      if (old == key) return (int)(4 * b) + je;
+      if (old == kKeyEmpty || old == key) return (int)(4 * b) + je;
       continue;   // another voxel took the slot: look at this bucket again
     }
     b = (b + 1) & (kBuckets - 1);
@@ -252,6 +280,9 @@ __device__ __forceinline__ float signed_dist_fast(const Pose& pose, float depth,
   xform(pose.Ri, pose.ti, c0, c1, c2, cc);
   const float n2 = sqnorm3(cc[0], cc[1], cc[2]);
   const bool plain = !(n2 >= 0x1p-80f && n2 <= 0x1p80f) || !(fabsf(cc[2]) >= 0x1p-40f && fabsf(cc[2]) <= 0x1p40f);
+#if (PLVS_WALK_EXP & 4)   // (timing experiment: raw v_sqrt / v_rcp, no correction steps)
+  return __builtin_amdgcn_sqrtf(n2) * (depth * __builtin_amdgcn_rcpf(cc[2]) - 1);
+#endif
   if (__builtin_expect(plain, 0)) return sqrtf(n2) * (depth / cc[2] - 1);
   return sqrt_rn_normal(n2) * (div_rn_normal(depth, cc[2]) - 1);
 }
@@ -282,6 +313,115 @@ __device__ __forceinline__ uint32_t walk_one(const Params& P, const Pose& pose, 
     const bool ok = resolve_visit_fast(P, pose, ray, vx, vy, vz, &u, &owner);   // no early continue (see ray_count)
     if (ok && nv >= vlo) go = on_visit(nv - vlo, vx, vy, vz, u);
     nv += ok ? 1u : 0u;
+  }
+  return nv;
+}
+
+// ------------------------------------------------------------------ the lean walk (the common case of walk_tiles)
+// The same voxels, the same membership test |u| < truncation as walk_one + resolve_visit_fast — with ~half the instructions
+// per voxel step:
+//  * the position is carried as three floats (exact integers) and as the packed table key itself (one add per step:
+//    +-1, +-1 << 10 or +-1 << 20), so a step has no int -> float conversions, no key packing and no range test — the
+//    ray's whole box (start voxel +- its length) is checked against the key box once, before the walk;
+//  * TWO-TIER u: the reference's u = |c_c| (z / c_c.z - 1) needs a correctly rounded square root and quotient and the
+//    reference's own rounding sequence of the camera transform only where it DECIDES something, i.e. where |u| is
+//    within the error bound of the truncation distance.  Everywhere else (all but ~1 voxel step in 10^3) the voxel takes
+//    u from 9 fused multiply-adds (voxel index -> camera frame in one affine map), v_sqrt_f32 and v_rcp_f32 raw:
+//        |u_lean - u_reference| <= band  (walk_band: 2^-17 of the coordinate magnitudes involved, ~30x the bound
+//    derived in DESIGN.md §4.1; plvs_hip_selftest_walk_lean measures the actual maximum on the device),
+//    so |u_lean| < tau - band  =>  inside,  |u_lean| >= tau + band  =>  outside, and in between the exact form decides.
+//    The order-free sums are toleranced (fixed point, 2^-22 m), the membership is not: it stays the reference's.
+// The DDA state (tMax, tDelta, the distance test against maxDist, the tie rules) is the reference's, bit for bit.
+struct LeanPose {           // voxel index -> camera frame: c_c = A v + b (A = Ri * resolution, b = ti + Ri * half voxel)
+  float A[9], b[3];
+};
+__device__ __forceinline__ void lean_pose(const Params& P, const Pose& pose, LeanPose* L) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) L->A[k] = pose.Ri[k] * P.resolution;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    L->b[k] = fmaf(pose.Ri[3 * k], P.half_voxel, fmaf(pose.Ri[3 * k + 1], P.half_voxel, fmaf(pose.Ri[3 * k + 2], P.half_voxel, pose.ti[k])));
+}
+// u of voxel (fx, fy, fz) (floats holding integers) by the lean form
+__device__ __forceinline__ float lean_u(const LeanPose& L, float depth, float fx, float fy, float fz) {
+  const float c0 = fmaf(L.A[0], fx, fmaf(L.A[1], fy, fmaf(L.A[2], fz, L.b[0])));
+  const float c1 = fmaf(L.A[3], fx, fmaf(L.A[4], fy, fmaf(L.A[5], fz, L.b[1])));
+  const float c2 = fmaf(L.A[6], fx, fmaf(L.A[7], fy, fmaf(L.A[8], fz, L.b[2])));
+  const float n2 = fmaf(c0, c0, fmaf(c1, c1, c2 * c2));
+  return __builtin_amdgcn_sqrtf(n2) * ((depth - c2) * __builtin_amdgcn_rcpf(c2));
+}
+// the band around the truncation distance inside which the exact form decides (see above); start = the ray's start in
+// voxel units, reach = how far (in voxels) the walk can get from it
+// and obl2 = (|p| / p.z)^2 of the camera-frame point (du / dc_c grows with the obliquity of the ray)
+__device__ __forceinline__ float walk_band(const Params& P, const Pose& pose, const Ray& ray, float reach, float obl2) {
+  const float ext = (fmaxf(fmaxf(fabsf(ray.start[0]), fabsf(ray.start[1])), fabsf(ray.start[2])) + reach) * P.resolution;
+  const float m = fabsf(pose.ti[0]) + fabsf(pose.ti[1]) + fabsf(pose.ti[2]) + 3.0f * ext + ray.depth + 1.0f;
+  return m * fmaxf(obl2, 1.0f) * 0x1p-19f;
+}
+
+template <bool kAcc, bool kRuns>
+__device__ __forceinline__ uint32_t walk_lean(const Params& P, const Pose& pose, const LeanPose& L, const Ray& ray,
+                                              WalkShared& S, int ox, int oy, int oz, int tid, float obl2, float wu_scaled,
+                                              uint32_t q_w, int32_t* e_wuu, unsigned long long* e_wc, uint32_t* e_last, uint16_t* vlog) {
+  RayCursor cur;
+  ray_begin(ray, &cur);
+  if (cur.done) return 0u;   // start voxel == end voxel: Raycast.cpp emits nothing
+  // ---- the ray's box against the key box (every emitted voxel lies within `reach` of the start voxel on each axis)
+  const int reach = (int)(__builtin_amdgcn_sqrtf(cur.maxDist)) + 3;
+  const int rx = cur.x - ox, ry = cur.y - oy, rz = cur.z - oz;
+  if (min(min(rx, ry), rz) - reach < 0 || max(max(rx, ry), rz) + reach > 1023) {
+    S.overflow = 1u;   // the rays of the sub-tile are too far apart: it is cut (a lone ray takes the general walk)
+    return 0u;
+  }
+  uint32_t key = (uint32_t)rx | ((uint32_t)ry << 10) | ((uint32_t)rz << 20);
+  const uint32_t endkey = (uint32_t)(cur.endX - ox) | ((uint32_t)(cur.endY - oy) << 10) | ((uint32_t)(cur.endZ - oz) << 20);
+  const uint32_t kx = (uint32_t)cur.stepX, ky = (uint32_t)cur.stepY << 10, kz = (uint32_t)cur.stepZ << 20;
+  float fx = (float)cur.x, fy = (float)cur.y, fz = (float)cur.z;
+  const float sfx = (float)cur.stepX, sfy = (float)cur.stepY, sfz = (float)cur.stepZ;
+  float tmx = cur.tMaxX, tmy = cur.tMaxY, tmz = cur.tMaxZ;
+  // an axis that never steps has tDelta = 0 / 0; it is never added in the reference (its tMax is +inf), here it is
+  // multiplied by a zero mask: keep it finite
+  const float tdx = cur.stepX ? cur.tDeltaX : 0.0f, tdy = cur.stepY ? cur.tDeltaY : 0.0f, tdz = cur.stepZ ? cur.tDeltaZ : 0.0f;
+  const float band = walk_band(P, pose, ray, (float)reach, obl2);
+  const float tau_in = ray.truncation - band, tau_out = ray.truncation + band;
+  uint32_t nv = 0;
+  for (int guard = 0; guard < kRayStepGuard; ++guard) {   // (the reference loop is unbounded)
+    // ---- Raycast.cpp:115-129 at the current voxel
+    const float d = sqnorm3(fx - cur.sx, fy - cur.sy, fz - cur.sz);
+    const bool stop = (d > cur.maxDist) || (key == endkey);
+    // ---- Chisel.cpp:525-531: does the voxel take the update?
+    float u = lean_u(L, ray.depth, fx, fy, fz);
+    const float au = fabsf(u);
+    bool in = au < tau_in;
+    if (__builtin_expect(!in && au < tau_out, 0)) {   // too close to call: the reference's own arithmetic
+      const float c0 = fx * P.resolution + P.half_voxel, c1 = fy * P.resolution + P.half_voxel,
+                  c2 = fz * P.resolution + P.half_voxel;
+      u = signed_dist_fast(pose, ray.depth, c0, c1, c2);
+      in = fabsf(u) < ray.truncation;
+    }
+    if (in) {
+      const int e = table_find_or_insert(S, key);
+      if (__builtin_expect(e < 0, 0)) break;   // the table is full: the (sub-)tile is cut
+      if (kRuns && nv < (uint32_t)kLogLen) vlog[nv * kWalkRays + tid] = (uint16_t)e;
+      if (kAcc) {
+        atomicAdd(&e_wuu[e], __float2int_rn(wu_scaled * u));
+        atomicAdd(&e_wc[e], (1ull << 32) | (unsigned long long)q_w);
+        atomicMax(&e_last[e], (uint32_t)tid);
+      }
+      ++nv;
+    }
+    if (stop) break;
+    // ---- Raycast.cpp:131-180: the axis with the smallest tMax steps (the reference's comparisons and tie rules)
+    const bool x_lt_y = tmx < tmy, x_lt_z = tmx < tmz, y_lt_z = tmy < tmz;
+    const bool go_x = x_lt_y && x_lt_z, go_y = !x_lt_y && y_lt_z;
+    const float mx = go_x ? 1.0f : 0.0f, my = go_y ? 1.0f : 0.0f, mz = (go_x || go_y) ? 0.0f : 1.0f;
+    fx = fmaf(mx, sfx, fx);      // (exact: integers)
+    fy = fmaf(my, sfy, fy);
+    fz = fmaf(mz, sfz, fz);
+    tmx = fmaf(mx, tdx, tmx);    // RN(tMax + tDelta) on the stepping axis, unchanged on the others
+    tmy = fmaf(my, tdy, tmy);
+    tmz = fmaf(mz, tdz, tmz);
+    key += go_x ? kx : (go_y ? ky : kz);
   }
   return nv;
 }
@@ -421,6 +561,7 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
   bool was_split = false;
   int flushes = 0;
   uint32_t emitted = 0;
+  WALK_PROF_BEGIN();
 
   while (true) {
     __syncthreads();
@@ -464,7 +605,19 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
     int ox = S.org[0], oy = S.org[1], oz = S.org[2];
     bool org_set = !lone;
     uint32_t nv = 0;
-    if (walks) {
+    WALK_PROF(0);   // sub-tile set-up: table reset, ray of the point, key origin
+    // the lean walk: whole rays of a sub-tile of several rays on an unsharded map (everything but the re-walks
+    // of a ray that did not fit the table and the owner-filtered walk of a sharded handle)
+    const bool lean = !lone && st.vlo == 0u && st.vhi == 0xFFFFFFFFu && P.shard_count <= 1 && !(PLVS_WALK_EXP & 512);
+    if (lean) {
+      if (walks && !(PLVS_WALK_EXP & 32)) {
+        LeanPose LP;
+        lean_pose(P, pose, &LP);
+        const float px = xyz[3 * (size_t)i], py = xyz[3 * (size_t)i + 1], pz = xyz[3 * (size_t)i + 2];
+        const float obl2 = (px * px + py * py + pz * pz) / (pz * pz);
+        nv = walk_lean<kAcc, kRuns>(P, pose, LP, ray, S, ox, oy, oz, tid, obl2, wu * scale_u, q_w, e_wuu, e_wc, e_last, vlog);
+      }
+    } else if (walks && !(PLVS_WALK_EXP & 32)) {   // (bit 32, timing experiment: set-up and flush only)
       nv = walk_one(P, pose, ray, st.vlo, st.vhi, [&](uint32_t k, int vx, int vy, int vz, float u) {
         if (!org_set) {   // (one lane only)
           ox = vx - kOriginBias; oy = vy - kOriginBias; oz = vz - kOriginBias;
@@ -476,19 +629,45 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
           S.overflow = 1u;
           return false;
         }
+#if (PLVS_WALK_EXP & 2)   // (timing experiment: no table)
+        const int e = (int)(key_bucket(key) * 4u + (key & 3u));
+        S.ekey[e] = key;
+#else
         const int e = table_find_or_insert(S, key);
         if (e < 0) return false;
+#endif
+#if !(PLVS_WALK_EXP & 8)   // (timing experiment: no visit log)
         if (kRuns && k < (uint32_t)kLogLen) vlog[k * kWalkRays + tid] = (uint16_t)e;
+#endif
+#if (PLVS_WALK_EXP & 1)   // (timing experiment: plain stores instead of the three atomics)
+        if (kAcc) {
+          e_wuu[e] = __float2int_rn((wu * u) * scale_u);
+          e_wc[e] = (1ull << 32) | (unsigned long long)q_w;
+          e_last[e] = (uint32_t)tid;
+        }
+#else
         if (kAcc) {
           atomicAdd(&e_wuu[e], __float2int_rn((wu * u) * scale_u));
           atomicAdd(&e_wc[e], (1ull << 32) | (unsigned long long)q_w);
           atomicMax(&e_last[e], (uint32_t)tid);
         }
+#endif
         return true;
       });
     }
+    WALK_PROF(1);   // thread 0's own walk
     __syncthreads();
-    const bool overflowed = S.overflow != 0;
+    WALK_PROF(2);   // ... and the wait for the tile's longest ray
+    {   // entries in use (nobody counts them during the walk)
+      uint32_t mine = 0;
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) mine += S.ekey[tid + k * kWalkRays] != kKeyEmpty ? 1u : 0u;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) mine += (uint32_t)__shfl_xor((int)mine, off);
+      if (lane == 0 && mine) atomicAdd(&S.nent, mine);
+    }
+    __syncthreads();
+    const bool overflowed = S.overflow != 0 || S.nent > (uint32_t)kWalkLimit;
     __syncthreads();
     if (overflowed) {
       was_split = true;
@@ -497,6 +676,10 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
     }
     const uint32_t nmine = nv > st.vlo ? nv - st.vlo : 0u;   // this ray's visits in the (sub-)tile
     my_visits += nmine;
+#if (PLVS_WALK_EXP & 16)   // (timing experiment: no flush)
+    ++flushes;
+    continue;
+#endif
 
     // ---- entries -> chunks -> pool slots
     const int fox = S.org[0], foy = S.org[1], foz = S.org[2];   // (a lone ray set them during its walk)
@@ -511,13 +694,19 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
       }
     }
     __syncthreads();
+    WALK_PROF(3);   // entries -> chunk cache
     if (tid < kWalkChunks && S.ckey[tid] != kEmptyKey) {
       const unsigned long long ck = S.ckey[tid];
+#if (PLVS_WALK_EXP & 256)   // (timing experiment: no directory look-up)
+      S.cslot[tid] = tid;
+#else
       S.cslot[tid] = dir_find_or_insert(dir, (int)((ck >> 42) & 0x1FFFFFu) - kCoordBias,
                                         (int)((ck >> 21) & 0x1FFFFFu) - kCoordBias, (int)(ck & 0x1FFFFFu) - kCoordBias,
                                         num_chunks, &ctr->err);
+#endif
     }
     __syncthreads();
+    WALK_PROF(4);   // chunk cache -> directory
     uint32_t rank[kPer], vkey[kPer];
     int slot_of[kPer];
     uint32_t need = 0, nneed = 0;   // entries of this thread that leave the tile as runs
@@ -538,7 +727,11 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
       }
       if (slot_of[k] >= 0) {
         vkey[k] = (uint32_t)slot_of[k] * (uint32_t)kChunkVox + vid;
+#if (PLVS_WALK_EXP & 128)   // (timing experiment: no colour-weight loads)
+        const bool cold = false;
+#else
         const bool cold = sat ? ((sat[vkey[k] >> 5] >> (vkey[k] & 31u)) & 1u) == 0u : (rgbw[vkey[k]] >> 24) < 254u;
+#endif
         if (kRuns && cold) {   // its colour still depends on the order of the visits
           need |= 1u << k;
           ++nneed;
@@ -546,6 +739,7 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
       }
     }
     __syncthreads();
+    WALK_PROF(5);   // ranks, colour weights
     if (kAcc) {
       // ---- records: wave 0 places the (chunk, slab) groups (the tile's own region on its first flush)
       if (tid < 64) {
@@ -615,7 +809,8 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
     }
 
     ++flushes;
-    if (!kRuns) continue;   // (the loop head's barrier lets the records leave before the table is reset)
+    WALK_PROF(6);   // records
+    if (!kRuns || (PLVS_WALK_EXP & 64)) continue;   // (bit 64, timing experiment: no runs)   // (the loop head's barrier lets the records leave before the table is reset)
     // ---- runs: number the entries that need one
     uint32_t inc = nneed;
 #pragma unroll
@@ -680,6 +875,7 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
       }
     }
     emitted += nruns;
+    WALK_PROF(7);   // runs
   }
 
   // ---- tile epilogue: run and visit counts
@@ -698,6 +894,8 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
     }
     if (was_split) atomicAdd(&ctr->split_tiles, 1u);
   }
+  WALK_PROF(8);     // epilogue
+  WALK_PROF_END();
 }
 
 // ------------------------------------------------------------------ segments -> chunk order
