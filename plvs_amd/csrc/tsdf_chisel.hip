@@ -837,7 +837,7 @@ struct plvs_tsdf_chisel {
   WalkCounters* d_wctr = nullptr;   // [2]: the call's counters, the colour pass's voxel list
   WalkCounters* h_wctr = nullptr;   // pinned
   DevBuf<uint4> w_rec, w_seg, w_sorted_seg;
-  DevBuf<uint32_t> w_chunk_nseg, w_chunk_off, w_chunk_fill, w_active_off, w_masks, w_dummy, w_seg_cnt, w_tile_visits;
+  DevBuf<uint32_t> w_chunk_nseg, w_chunk_off, w_chunk_fill, w_active_off, w_masks, w_dummy, w_seg_cnt, w_tile_visits, w_deferred;
   DevBuf<uint32_t> w_part_off, w_multi_idx;          // apply stage: parts of the updated chunks
   DevBuf<long long> pa_wuu;                          //   accumulators of the chunks applied in parts (zero between calls)
   DevBuf<unsigned long long> pa_w;
@@ -891,6 +891,7 @@ static int read_counters(plvs_tsdf_chisel* h, hipStream_t s) {
 
 // ------------------------------------------------------------------ single-walk pipeline (tsdf_walk.hpp)
 constexpr int kWalkStages = 4;
+constexpr unsigned kDeferGrid = 240;   // workgroups of the general walk over the deferred tiles (it loops over the list)
 const char* const kWalkStageNames[kWalkStages] = {"walk_tiles", "sort_segments", "apply_chunks", "fold_colours"};
 
 static int read_walk_counters(plvs_tsdf_chisel* h, hipStream_t s) {
@@ -973,6 +974,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
   PLVS_HIP_TRY(h->updated.reserve((size_t)max_chunks + 1));
   PLVS_HIP_TRY(h->w_seg_cnt.reserve(ntiles));
   PLVS_HIP_TRY(h->w_tile_visits.reserve(ntiles));
+  PLVS_HIP_TRY(h->w_deferred.reserve(ntiles));
   // every tile owns kWalkLimit records / kWalkChunks segments; the spill area behind them grows on demand
   const size_t rec_own = (size_t)ntiles * kWalkLimit, seg_own = (size_t)ntiles * kWalkChunks;
   if (rec_own + (1 << 16) >= 0xFFFFFFFFull) {
@@ -1010,9 +1012,15 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     AccOut out{h->w_rec.p, (uint32_t)std::min<size_t>(rec_own + rec_spill, 0xFFFFFFFFu), h->w_seg.p,
                (uint32_t)std::min<size_t>(seg_own + seg_spill, 0xFFFFFFFFu), h->w_seg_cnt.p, h->w_tile_visits.p};
     RunOut runs{h->w_runkey.p, h->w_masks.p, h->w_run_cnt.p, h->run_r1_log2};
-    hipLaunchKernelGGL((walk_tiles<true, true>), dim3(ntiles), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
+    // the common case of a tile alone in a lean kernel; what it defers (tiles over several clouds, table overflows,
+    // the owner-filtered walk of a sharded handle) is walked by the general kernel from the list
+    hipLaunchKernelGGL(walk_fast, dim3(ntiles), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
                        h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
-                       (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u});
+                       (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u}, h->w_deferred.p);
+    hipLaunchKernelGGL((walk_tiles<true, true>), dim3(kDeferGrid), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
+                       h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
+                       (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u}, (uint32_t)ntiles,
+                       (const uint32_t*)h->w_deferred.p, (const uint32_t*)&h->d_wctr->ndeferred);
     PLVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
     STAGE_MARK(1);
     const unsigned seg_blocks = ceil_div(seg_own + seg_spill, kSegSpan);
@@ -1257,7 +1265,7 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   h->w_rec.release(); h->w_seg.release(); h->w_sorted_seg.release(); h->w_chunk_nseg.release();
   h->w_chunk_off.release(); h->w_chunk_fill.release(); h->w_active_off.release(); h->w_masks.release();
   h->w_dummy.release(); h->w_runkey.release(); h->w_run_cnt.release(); h->w_run_off.release(); h->w_val0.release();
-  h->w_val1.release(); h->w_seg_cnt.release(); h->w_tile_visits.release(); h->w_part_off.release(); h->w_multi_idx.release();
+  h->w_val1.release(); h->w_seg_cnt.release(); h->w_tile_visits.release(); h->w_deferred.release(); h->w_part_off.release(); h->w_multi_idx.release();
   h->pa_wuu.release(); h->pa_w.release(); h->pa_last.release(); h->pa_cnt.release(); h->pa_done.release();
   h->sh_nrec.release(); h->sh_owner.release(); h->halo_row.release();
   h->sh_ctl.release(); h->sh_seg_reg.release(); h->sh_rec_reg.release(); h->sh_src_off.release(); h->sh_slot_owner.release(); h->sh_run_ctr.release(); h->sh_vkey.release(); h->sh_sat.release();
@@ -2265,6 +2273,7 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
   PLVS_HIP_TRY(h->updated.reserve(xmax + 1));
   PLVS_HIP_TRY(h->w_seg_cnt.reserve(nt));
   PLVS_HIP_TRY(h->w_tile_visits.reserve(nt));
+  PLVS_HIP_TRY(h->w_deferred.reserve(nt));
   PLVS_HIP_TRY(h->w_run_cnt.reserve(nt));
   PLVS_HIP_TRY(h->w_run_off.reserve((size_t)nt + 1));
   PLVS_HIP_TRY(h->w_part_off.reserve(xmax + 1));
@@ -2301,9 +2310,13 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
                (uint32_t)std::min<size_t>(seg_own + seg_spill, 0xFFFFFFFFu), h->w_seg_cnt.p, h->w_tile_visits.p};
     RunOut runs{h->w_runkey.p, h->w_masks.p, h->w_run_cnt.p, h->run_r1_log2};
     // (a chunk entered by an attempt that has to be repeated stays in the walk directory: harmless)
-    hipLaunchKernelGGL((walk_tiles<true, true>), dim3(nt), dim3(kWalkRays), 0, s, Pw, h->scale_u, h->scale_w, d_xyz, n,
+    hipLaunchKernelGGL(walk_fast, dim3(nt), dim3(kWalkRays), 0, s, Pw, h->scale_u, h->scale_w, d_xyz, n,
                        h->offsets.p, nclouds, h->poses.p, h->xdir, h->d_xcount, h->d_wctr, (const uint32_t*)nullptr,
-                       (const uint32_t*)h->x_sat, out, runs, tmap);
+                       (const uint32_t*)h->x_sat, out, runs, tmap, h->w_deferred.p);
+    hipLaunchKernelGGL((walk_tiles<true, true>), dim3(kDeferGrid), dim3(kWalkRays), 0, s, Pw, h->scale_u, h->scale_w, d_xyz, n,
+                       h->offsets.p, nclouds, h->poses.p, h->xdir, h->d_xcount, h->d_wctr, (const uint32_t*)nullptr,
+                       (const uint32_t*)h->x_sat, out, runs, tmap, (uint32_t)nt, (const uint32_t*)h->w_deferred.p,
+                       (const uint32_t*)&h->d_wctr->ndeferred);
     const unsigned seg_blocks = ceil_div(seg_own + seg_spill, kSegSpan);
     hipLaunchKernelGGL(seg_pass<false>, dim3(seg_blocks), dim3(256), 0, s, h->w_seg.p, out.seg_cap, nt, h->w_seg_cnt.p,
                        h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p, h->d_wctr);

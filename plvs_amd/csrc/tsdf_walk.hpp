@@ -95,6 +95,7 @@ struct WalkCounters {           // device-side, read back once per call
   uint32_t split_tiles;         // tiles that had to be cut (table overflow)
   uint32_t num_parts;           // apply stage: sum over the updated chunks of their parts
   uint32_t num_multi;           //   chunks applied in more than one part
+  uint32_t ndeferred;           // tiles walk_fast left to walk_tiles (several clouds in the tile, table overflow)
 };
 
 // Find-or-insert with the slot returned; usable by concurrent workgroups of ONE kernel.  A block that
@@ -185,8 +186,10 @@ constexpr int kOriginBias = 512;
 struct WalkShared {       // LDS state of walk_tiles
   alignas(16) uint32_t ekey[kWalkEntries];
   int32_t org[3];                              // origin of the keys
-  uint32_t cand[kWalkRays / 64];               // first walking ray of every wave
-  unsigned long long ckey[kWalkChunks];        // chunk cache: packed chunk id,
+  uint32_t cand[kWalkRays / 64];               // does the wave have a walking ray ...
+  int32_t worg[kWalkRays / 64][3];             // ... and the origin its first one proposes
+  uint32_t run_total, vis_total;               // runs emitted / visits walked by the tile so far
+  uint32_t ccode[kWalkChunks];                 // chunk cache: chunk code (the chunk bits of a voxel key),
   int32_t cslot[kWalkChunks];                  //   pool slot,
   uint32_t ccnt[kWalkChunks * kSlabs];         //   entries of the (sub-)tile per (chunk, slab),
   uint16_t cbase[kWalkChunks * kSlabs];        //   first record of the group, relative to the flush's first record
@@ -204,6 +207,20 @@ __device__ __forceinline__ bool rel_key(int vx, int vy, int vz, int ox, int oy, 
   const uint32_t dx = (uint32_t)(vx - ox), dy = (uint32_t)(vy - oy), dz = (uint32_t)(vz - oz);
   *key = dx | (dy << 10) | (dz << 20);
   return ((dx | dy | dz) >> 10) == 0u;
+}
+// The origin is a multiple of 16 on every axis (origin_of), so a key carries its chunk and its voxel id in fixed bit
+// fields: bits 4..9 of each 10-bit coordinate = the chunk relative to the origin's chunk (the CHUNK CODE: the key with
+// the voxel bits masked away — unique per chunk of the tile), bits 0..3 = the voxel inside the chunk.
+__device__ __forceinline__ int origin_of(int v) { return (v - kOriginBias) & ~15; }
+constexpr uint32_t kChunkCodeMask = 0x3F0FC3F0u;
+__device__ __forceinline__ uint32_t chunk_code(uint32_t key) { return key & kChunkCodeMask; }
+__device__ __forceinline__ uint32_t voxel_in_chunk(uint32_t key) {   // (z * 16 + y) * 16 + x  (Chunk.h:90-93)
+  return (key & 15u) | ((key >> 6) & 0xF0u) | ((key >> 12) & 0xF00u);
+}
+__device__ __forceinline__ void chunk_of_code(uint32_t code, int ox, int oy, int oz, int* cx, int* cy, int* cz) {
+  *cx = (ox >> 4) + (int)((code >> 4) & 63u);
+  *cy = (oy >> 4) + (int)((code >> 14) & 63u);
+  *cz = (oz >> 4) + (int)((code >> 24) & 63u);
 }
 __device__ __forceinline__ uint32_t key_bucket(uint32_t key) { return (key * 2654435761u) >> 24; }
 static_assert(kBuckets == 256, "key_bucket yields 8 bits");
@@ -286,94 +303,116 @@ __device__ __forceinline__ float signed_dist_fast(const Pose& pose, float depth,
   if (__builtin_expect(plain, 0)) return sqrtf(n2) * (depth / cc[2] - 1);
   return sqrt_rn_normal(n2) * (div_rn_normal(depth, cc[2]) - 1);
 }
-__device__ __forceinline__ bool resolve_visit_fast(const Params& P, const Pose& pose, const Ray& ray, int vx, int vy, int vz,
-                                                   float* u, OwnerCache* oc) {
-  if (!chunk_owned(P, vx >> 4, vy >> 4, vz >> 4, oc)) return false;
-  const float c0 = (float)vx * P.resolution + P.half_voxel;
-  const float c1 = (float)vy * P.resolution + P.half_voxel;
-  const float c2 = (float)vz * P.resolution + P.half_voxel;
-  *u = signed_dist_fast(pose, ray.depth, c0, c1, c2);
-  return fabsf(*u) < ray.truncation;
+// ------------------------------------------------------------------ two-tier u and the lean walk
+// TWO-TIER u.  The reference's u = |c_c| (z / c_c.z - 1) needs a correctly rounded square root and quotient and the
+// reference's own rounding sequence of the camera transform only where it DECIDES something, i.e. where |u| is within
+// the error bound of the truncation distance.  Everywhere else (all but ~1 voxel step in 10^3) the voxel takes u from
+// 9 fused multiply-adds (voxel index -> camera frame in one affine map), v_sqrt_f32 and v_rcp_f32 raw:
+//     |u_lean - u_reference| <= band   (lean_ray: 2^-19 of the coordinate magnitudes involved times the squared
+//                                       obliquity of the ray, ~3x the bound derived in DESIGN.md §4.1;
+//                                       plvs_hip_selftest_walk_lean measures the actual maximum on the device),
+// so |u_lean| < tau - band  =>  inside,  |u_lean| >= tau + band  =>  outside, and in between the exact form decides.
+// The order-free sums are toleranced (fixed point, 2^-22 m), the membership is not: it stays the reference's.
+// EVERY walk of the order-free mode takes u this way (the lean walk below and the general walk_one), so a voxel's
+// contribution does not depend on which of the two walked its ray.
+__device__ __forceinline__ float uniform_f(float x) {   // a wave-uniform value -> a scalar register
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
 }
-
-// Walks the ray inside the window [vlo, vhi) of its visits; on_visit(k, vx, vy, vz, u), k = index of
-// the visit inside the window, returns false to abandon the walk (table overflow).  Returns the number
-// of accepted visits seen up to the point where the walk stopped (at most vhi).
-template <class OnVisit>
-__device__ __forceinline__ uint32_t walk_one(const Params& P, const Pose& pose, const Ray& ray, uint32_t vlo,
-                                             uint32_t vhi, OnVisit&& on_visit) {
-  RayCursor cur;
-  OwnerCache owner;
-  ray_begin(ray, &cur);
-  int vx, vy, vz;
-  uint32_t nv = 0;
-  bool go = true;
-  while (go && nv < vhi && ray_next(&cur, &vx, &vy, &vz)) {
-    float u;
-    const bool ok = resolve_visit_fast(P, pose, ray, vx, vy, vz, &u, &owner);   // no early continue (see ray_count)
-    if (ok && nv >= vlo) go = on_visit(nv - vlo, vx, vy, vz, u);
-    nv += ok ? 1u : 0u;
-  }
-  return nv;
-}
-
-// ------------------------------------------------------------------ the lean walk (the common case of walk_tiles)
-// The same voxels, the same membership test |u| < truncation as walk_one + resolve_visit_fast — with ~half the instructions
-// per voxel step:
-//  * the position is carried as three floats (exact integers) and as the packed table key itself (one add per step:
-//    +-1, +-1 << 10 or +-1 << 20), so a step has no int -> float conversions, no key packing and no range test — the
-//    ray's whole box (start voxel +- its length) is checked against the key box once, before the walk;
-//  * TWO-TIER u: the reference's u = |c_c| (z / c_c.z - 1) needs a correctly rounded square root and quotient and the
-//    reference's own rounding sequence of the camera transform only where it DECIDES something, i.e. where |u| is
-//    within the error bound of the truncation distance.  Everywhere else (all but ~1 voxel step in 10^3) the voxel takes
-//    u from 9 fused multiply-adds (voxel index -> camera frame in one affine map), v_sqrt_f32 and v_rcp_f32 raw:
-//        |u_lean - u_reference| <= band  (walk_band: 2^-17 of the coordinate magnitudes involved, ~30x the bound
-//    derived in DESIGN.md §4.1; plvs_hip_selftest_walk_lean measures the actual maximum on the device),
-//    so |u_lean| < tau - band  =>  inside,  |u_lean| >= tau + band  =>  outside, and in between the exact form decides.
-//    The order-free sums are toleranced (fixed point, 2^-22 m), the membership is not: it stays the reference's.
-// The DDA state (tMax, tDelta, the distance test against maxDist, the tie rules) is the reference's, bit for bit.
-struct LeanPose {           // voxel index -> camera frame: c_c = A v + b (A = Ri * resolution, b = ti + Ri * half voxel)
+struct LeanRay {            // voxel index -> camera frame: c_c = A v + b (A = Ri * resolution, b = ti + Ri * half voxel)
   float A[9], b[3];
+  float tau_in, tau_out;    // truncation distance -/+ band
 };
-__device__ __forceinline__ void lean_pose(const Params& P, const Pose& pose, LeanPose* L) {
+__device__ __forceinline__ void lean_ray(const Params& P, const Pose& pose, const Ray& ray, LeanRay* L) {
+  // (the pose is uniform over the sub-tile: the map lives in scalar registers — a VALU instruction takes one of them
+  // as an operand for free, and twelve vector registers stay available to the loop)
 #pragma unroll
-  for (int k = 0; k < 9; ++k) L->A[k] = pose.Ri[k] * P.resolution;
+  for (int k = 0; k < 9; ++k) L->A[k] = uniform_f(pose.Ri[k] * P.resolution);
 #pragma unroll
   for (int k = 0; k < 3; ++k)
-    L->b[k] = fmaf(pose.Ri[3 * k], P.half_voxel, fmaf(pose.Ri[3 * k + 1], P.half_voxel, fmaf(pose.Ri[3 * k + 2], P.half_voxel, pose.ti[k])));
+    L->b[k] = uniform_f(fmaf(pose.Ri[3 * k], P.half_voxel, fmaf(pose.Ri[3 * k + 1], P.half_voxel, fmaf(pose.Ri[3 * k + 2], P.half_voxel, pose.ti[k]))));
+  // the band: coordinate magnitudes the two forms round at (camera position, the ray's ends, its depth) and the
+  // squared obliquity |p|^2 / p.z^2 of the ray (du / dc_c grows with it); all from the ray itself, so that every
+  // walk of the same ray derives the same band
+  const float mx = (ray.start[0] + ray.end[0]) * (0.5f * P.resolution) - pose.t[0];
+  const float my = (ray.start[1] + ray.end[1]) * (0.5f * P.resolution) - pose.t[1];
+  const float mz = (ray.start[2] + ray.end[2]) * (0.5f * P.resolution) - pose.t[2];
+  const float obl2 = fmaxf(sqnorm3(mx, my, mz) / (ray.depth * ray.depth), 1.0f);
+  float ext = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) ext = fmaxf(ext, fmaxf(fabsf(ray.start[k]), fabsf(ray.end[k])));
+  const float m = fabsf(pose.ti[0]) + fabsf(pose.ti[1]) + fabsf(pose.ti[2]) + 3.0f * (ext + 4.0f) * P.resolution + ray.depth + 1.0f;
+  const float band = m * obl2 * 0x1p-19f;
+  L->tau_in = ray.truncation - band;
+  L->tau_out = ray.truncation + band;
 }
 // u of voxel (fx, fy, fz) (floats holding integers) by the lean form
-__device__ __forceinline__ float lean_u(const LeanPose& L, float depth, float fx, float fy, float fz) {
+__device__ __forceinline__ float lean_u(const LeanRay& L, float depth, float fx, float fy, float fz) {
   const float c0 = fmaf(L.A[0], fx, fmaf(L.A[1], fy, fmaf(L.A[2], fz, L.b[0])));
   const float c1 = fmaf(L.A[3], fx, fmaf(L.A[4], fy, fmaf(L.A[5], fz, L.b[1])));
   const float c2 = fmaf(L.A[6], fx, fmaf(L.A[7], fy, fmaf(L.A[8], fz, L.b[2])));
   const float n2 = fmaf(c0, c0, fmaf(c1, c1, c2 * c2));
   return __builtin_amdgcn_sqrtf(n2) * ((depth - c2) * __builtin_amdgcn_rcpf(c2));
 }
-// the band around the truncation distance inside which the exact form decides (see above); start = the ray's start in
-// voxel units, reach = how far (in voxels) the walk can get from it
-// and obl2 = (|p| / p.z)^2 of the camera-frame point (du / dc_c grows with the obliquity of the ray)
-__device__ __forceinline__ float walk_band(const Params& P, const Pose& pose, const Ray& ray, float reach, float obl2) {
-  const float ext = (fmaxf(fmaxf(fabsf(ray.start[0]), fabsf(ray.start[1])), fabsf(ray.start[2])) + reach) * P.resolution;
-  const float m = fabsf(pose.ti[0]) + fabsf(pose.ti[1]) + fabsf(pose.ti[2]) + 3.0f * ext + ray.depth + 1.0f;
-  return m * fmaxf(obl2, 1.0f) * 0x1p-19f;
+// Chisel.cpp:525-531: does voxel (fx, fy, fz) take the update?  *u = its signed distance (lean or exact, see above).
+__device__ __forceinline__ bool two_tier_visit(const Params& P, const Pose& pose, const Ray& ray, const LeanRay& L, float fx,
+                                               float fy, float fz, float* u) {
+  *u = lean_u(L, ray.depth, fx, fy, fz);
+  const float au = fabsf(*u);
+  bool in = au < L.tau_in;
+  if (__builtin_expect(!in && au < L.tau_out, 0)) {   // too close to call: the reference's own arithmetic
+    const float c0 = fx * P.resolution + P.half_voxel, c1 = fy * P.resolution + P.half_voxel,
+                c2 = fz * P.resolution + P.half_voxel;
+    *u = signed_dist_fast(pose, ray.depth, c0, c1, c2);
+    in = fabsf(*u) < ray.truncation;
+  }
+  return in;
 }
 
+// Walks the ray inside the window [vlo, vhi) of its visits; on_visit(k, vx, vy, vz, u), k = index of
+// the visit inside the window, returns false to abandon the walk (table overflow).  Returns the number
+// of accepted visits seen up to the point where the walk stopped (at most vhi).  The general walk: windows of a
+// ray that does not fit the table, the owner filter of a sharded handle, the re-walk behind a full visit log.
+template <class OnVisit>
+__device__ __forceinline__ uint32_t walk_one(const Params& P, const Pose& pose, const Ray& ray, uint32_t vlo,
+                                             uint32_t vhi, OnVisit&& on_visit) {
+  RayCursor cur;
+  OwnerCache owner;
+  LeanRay L;
+  lean_ray(P, pose, ray, &L);
+  ray_begin(ray, &cur);
+  int vx, vy, vz;
+  uint32_t nv = 0;
+  bool go = true;
+  while (go && nv < vhi && ray_next(&cur, &vx, &vy, &vz)) {
+    float u = 0.0f;
+    const bool ok = chunk_owned(P, vx >> 4, vy >> 4, vz >> 4, &owner) &&
+                    two_tier_visit(P, pose, ray, L, (float)vx, (float)vy, (float)vz, &u);
+    if (ok && nv >= vlo) go = on_visit(nv - vlo, vx, vy, vz, u);
+    nv += ok ? 1u : 0u;
+  }
+  return nv;
+}
+
+// The lean walk (the common case of walk_tiles: whole rays of a sub-tile of several rays, no owner filter).  The same
+// voxels in the same order as walk_one — with ~half the instructions per voxel step: the position is carried as three
+// floats (exact integers) and as the packed table key itself (one add per step: +-1, +-1 << 10 or +-1 << 20), so a
+// step has no int -> float conversions, no key packing and no range test — the ray's whole box (start voxel +- its
+// length) is checked against the key box once, before the walk (lean_fits).  The DDA state (tMax, tDelta, the distance
+// test against maxDist, the tie rules) is the reference's, bit for bit.
+__device__ __forceinline__ int lean_reach(const Ray& ray) {   // how far (in voxels, per axis) a walk can get from its start voxel
+  const float maxDist = sqnorm3(ray.end[0] - ray.start[0], ray.end[1] - ray.start[1], ray.end[2] - ray.start[2]);
+  return (int)(__builtin_amdgcn_sqrtf(maxDist)) + 3;
+}
 template <bool kAcc, bool kRuns>
-__device__ __forceinline__ uint32_t walk_lean(const Params& P, const Pose& pose, const LeanPose& L, const Ray& ray,
-                                              WalkShared& S, int ox, int oy, int oz, int tid, float obl2, float wu_scaled,
-                                              uint32_t q_w, int32_t* e_wuu, unsigned long long* e_wc, uint32_t* e_last, uint16_t* vlog) {
+__device__ __forceinline__ uint32_t walk_lean(const Params& P, const Pose& pose, const Ray& ray, WalkShared& S, int ox, int oy,
+                                              int oz, int tid, float wu_scaled, uint32_t q_w, int32_t* e_wuu,
+                                              unsigned long long* e_wc, uint32_t* e_last, uint16_t* vlog) {
   RayCursor cur;
   ray_begin(ray, &cur);
   if (cur.done) return 0u;   // start voxel == end voxel: Raycast.cpp emits nothing
-  // ---- the ray's box against the key box (every emitted voxel lies within `reach` of the start voxel on each axis)
-  const int reach = (int)(__builtin_amdgcn_sqrtf(cur.maxDist)) + 3;
-  const int rx = cur.x - ox, ry = cur.y - oy, rz = cur.z - oz;
-  if (min(min(rx, ry), rz) - reach < 0 || max(max(rx, ry), rz) + reach > 1023) {
-    S.overflow = 1u;   // the rays of the sub-tile are too far apart: it is cut (a lone ray takes the general walk)
-    return 0u;
-  }
-  uint32_t key = (uint32_t)rx | ((uint32_t)ry << 10) | ((uint32_t)rz << 20);
+  LeanRay L;
+  lean_ray(P, pose, ray, &L);
+  uint32_t key = (uint32_t)(cur.x - ox) | ((uint32_t)(cur.y - oy) << 10) | ((uint32_t)(cur.z - oz) << 20);
   const uint32_t endkey = (uint32_t)(cur.endX - ox) | ((uint32_t)(cur.endY - oy) << 10) | ((uint32_t)(cur.endZ - oz) << 20);
   const uint32_t kx = (uint32_t)cur.stepX, ky = (uint32_t)cur.stepY << 10, kz = (uint32_t)cur.stepZ << 20;
   float fx = (float)cur.x, fy = (float)cur.y, fz = (float)cur.z;
@@ -382,24 +421,13 @@ __device__ __forceinline__ uint32_t walk_lean(const Params& P, const Pose& pose,
   // an axis that never steps has tDelta = 0 / 0; it is never added in the reference (its tMax is +inf), here it is
   // multiplied by a zero mask: keep it finite
   const float tdx = cur.stepX ? cur.tDeltaX : 0.0f, tdy = cur.stepY ? cur.tDeltaY : 0.0f, tdz = cur.stepZ ? cur.tDeltaZ : 0.0f;
-  const float band = walk_band(P, pose, ray, (float)reach, obl2);
-  const float tau_in = ray.truncation - band, tau_out = ray.truncation + band;
   uint32_t nv = 0;
   for (int guard = 0; guard < kRayStepGuard; ++guard) {   // (the reference loop is unbounded)
     // ---- Raycast.cpp:115-129 at the current voxel
     const float d = sqnorm3(fx - cur.sx, fy - cur.sy, fz - cur.sz);
     const bool stop = (d > cur.maxDist) || (key == endkey);
-    // ---- Chisel.cpp:525-531: does the voxel take the update?
-    float u = lean_u(L, ray.depth, fx, fy, fz);
-    const float au = fabsf(u);
-    bool in = au < tau_in;
-    if (__builtin_expect(!in && au < tau_out, 0)) {   // too close to call: the reference's own arithmetic
-      const float c0 = fx * P.resolution + P.half_voxel, c1 = fy * P.resolution + P.half_voxel,
-                  c2 = fz * P.resolution + P.half_voxel;
-      u = signed_dist_fast(pose, ray.depth, c0, c1, c2);
-      in = fabsf(u) < ray.truncation;
-    }
-    if (in) {
+    float u;
+    if (two_tier_visit(P, pose, ray, L, fx, fy, fz, &u)) {
       const int e = table_find_or_insert(S, key);
       if (__builtin_expect(e < 0, 0)) break;   // the table is full: the (sub-)tile is cut
       if (kRuns && nv < (uint32_t)kLogLen) vlog[nv * kWalkRays + tid] = (uint16_t)e;
@@ -443,7 +471,7 @@ __device__ __forceinline__ void subtile_reset(WalkShared& S, int tid) {
 #pragma unroll
   for (int k = 0; k < kWalkEntries / kWalkRays; ++k) S.ekey[tid + k * kWalkRays] = kKeyEmpty;
   if (tid < kWalkChunks) {
-    S.ckey[tid] = kEmptyKey;
+    S.ccode[tid] = kKeyEmpty;
     S.cslot[tid] = -1;
   }
 #pragma unroll
@@ -469,19 +497,50 @@ __device__ __forceinline__ void subtile_split(WalkShared& S, const SubTile st) {
   }
 }
 
-// Cache index of a chunk among the (sub-)tile's chunks; -1: the cache is full.
-__device__ __forceinline__ int chunk_cache_insert(WalkShared& S, int cx, int cy, int cz) {
-  unsigned long long key;
-  if (!pack_block(cx, cy, cz, &key)) return -1;
-  uint32_t h = dir_hash(cx, cy, cz, kWalkChunks - 1);
+// Cache index of a chunk (by its code) among the (sub-)tile's chunks; -1: the cache is full.  *won: this call
+// created the entry.
+__device__ __forceinline__ int chunk_cache_insert(WalkShared& S, uint32_t code, bool* won) {
+  uint32_t h = (code * 2654435761u) >> 26;
+  static_assert(kWalkChunks == 64, "the hash yields 6 bits");
+  *won = false;
   for (int probe = 0; probe < kWalkChunks; ++probe) {
-    unsigned long long cur = S.ckey[h];
-    if (cur == kEmptyKey) cur = atomicCAS(&S.ckey[h], kEmptyKey, key);
-    if (cur == kEmptyKey || cur == key) return (int)h;
+    uint32_t cur = S.ccode[h];
+    if (cur == kKeyEmpty) {
+      cur = atomicCAS(&S.ccode[h], kKeyEmpty, code);
+      if (cur == kKeyEmpty) {
+        *won = true;
+        return (int)h;
+      }
+    }
+    if (cur == code) return (int)h;
     h = (h + 1) & (kWalkChunks - 1);
   }
   return -1;
 }
+
+// The home entry of a chunk in the directory, read without waiting: the walk's set-up issues these loads for the
+// chunks its rays start and end in and looks at them only after the rest of the set-up arithmetic, so the flush
+// finds the pool slots of (nearly) all its chunks already in the cache instead of paying two dependent global
+// round trips with seven of the tile's eight waves idle.  A chunk that is not at its home entry, not in the map yet
+// or just being inserted by another tile stays unresolved (-1) and takes dir_find_or_insert in the flush.
+struct DirPeek {
+  unsigned long long want, key;
+  int32_t slot;
+};
+__device__ __forceinline__ DirPeek dir_peek(const Directory& d, int cx, int cy, int cz) {
+  DirPeek p;
+  p.key = kEmptyKey;
+  p.slot = -1;
+  if (!pack_block(cx, cy, cz, &p.want)) {
+    p.want = 0;   // (never equals kEmptyKey)
+    return p;
+  }
+  const uint32_t h = dir_hash(cx, cy, cz, d.mask);
+  p.key = d.keys[h];
+  p.slot = d.slots[h];
+  return p;
+}
+__device__ __forceinline__ int dir_peek_slot(const DirPeek& p) { return (p.key == p.want && p.slot >= 0) ? p.slot : -1; }
 
 // ------------------------------------------------------------------ walk_tiles
 // Output layout of the order-free records: tile t owns records [t * kWalkLimit, (t + 1) * kWalkLimit)
@@ -535,7 +594,8 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
     Params P, float scale_u, float scale_w, const float* __restrict__ xyz, int npoints,
     const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
     int32_t* __restrict__ num_chunks, WalkCounters* __restrict__ ctr, const uint32_t* __restrict__ rgbw,
-    const uint32_t* __restrict__ sat, AccOut out, RunOut runs, TileMap tmap) {
+    const uint32_t* __restrict__ sat, AccOut out, RunOut runs, TileMap tmap, uint32_t ntiles,
+    const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ ntile_list) {
   constexpr int kPer = kWalkEntries / kWalkRays;
   __shared__ WalkShared S;
   __shared__ uint32_t raw[kMaskCap * kMaskWords];              // accumulators during the walk, ray masks afterwards
@@ -546,81 +606,135 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
   uint32_t* const e_last = raw + 3 * kWalkEntries;                                        // last visiting ray
   static_assert(kMaskCap * kMaskWords >= 4 * kWalkEntries, "the accumulators overlay the mask area");
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  // Tiles are numbered in point order by blockIdx: workgroups are dispatched in that order, so the
-  // look-back below only ever waits for tiles that are already running.
-  const uint32_t tile = blockIdx.x, ntiles = gridDim.x;   // the local tile: output regions
+  // the tiles walk_fast deferred (tile_list) — or every tile of the call (tile_list = nullptr: blockIdx is the tile)
+  const uint32_t nlist = tile_list ? min(*ntile_list, ntiles) : ntiles;
+  for (uint32_t lb = blockIdx.x; lb < nlist; lb += gridDim.x) {
+  const uint32_t tile = tile_list ? tile_list[lb] : lb;   // the local tile: output regions
   const uint32_t gtile = tmap.tile_of(tile);             // its place in the point stream
   const uint32_t first = gtile * kWalkRays;
+  __syncthreads();   // (the previous tile of this workgroup is done with the shared state)
+  // Nearly every tile lies inside one cloud and fits its table: ONE sub-tile, known without a word of shared memory.
+  // A barrier costs a tile about a microsecond (the slowest of eight waves, their memory operations drained) — the
+  // common path below has five of them; the sub-tile stack (several clouds in the tile, a table overflow) costs three
+  // more per sub-tile.
+  const uint32_t nrays = min((uint32_t)kWalkRays, (uint32_t)npoints - first);
+  const int cloud0 = cloud_of(offsets, nclouds, (int)first);
+  const bool single = (uint32_t)(offsets[cloud0 + 1] - (int32_t)first) >= nrays;
   if (tid == 0) {
     S.sp = 0;
-    S.next = 0;
-    S.nrays = min((uint32_t)kWalkRays, (uint32_t)npoints - first);
+    S.next = single ? nrays : 0u;
+    S.nrays = nrays;
+    S.run_total = 0;
+    S.vis_total = 0;
   }
   const uint32_t i = first + (uint32_t)tid;
   uint32_t my_visits = 0;
   bool was_split = false;
   int flushes = 0;
-  uint32_t emitted = 0;
+  bool first_pass = true;
   WALK_PROF_BEGIN();
 
   while (true) {
-    __syncthreads();
-    // A sub-tile holds rays of ONE cloud, so that its pose is uniform (scalar registers); the tile hands
-    // out its rays cloud by cloud (nearly every tile lies inside one cloud).
-    if (tid == 0 && S.sp == 0 && S.next < S.nrays) {
-      const int c = cloud_of(offsets, nclouds, (int)(first + S.next));
-      const uint32_t end = min((uint32_t)(offsets[c + 1] - (int32_t)first), S.nrays);
-      S.stack[S.sp++] = SubTile{(uint16_t)S.next, (uint16_t)end, 0u, 0xFFFFFFFFu, c};
-      S.next = end;
+    SubTile st;
+    if (first_pass && single) {
+      st = SubTile{(uint16_t)0, (uint16_t)nrays, 0u, 0xFFFFFFFFu, cloud0};
+    } else {
+      __syncthreads();
+      // A sub-tile holds rays of ONE cloud, so that its pose is uniform (scalar registers); the tile hands
+      // out its rays cloud by cloud.
+      if (tid == 0 && S.sp == 0 && S.next < S.nrays) {
+        const int c = cloud_of(offsets, nclouds, (int)(first + S.next));
+        const uint32_t end = min((uint32_t)(offsets[c + 1] - (int32_t)first), S.nrays);
+        S.stack[S.sp++] = SubTile{(uint16_t)S.next, (uint16_t)end, 0u, 0xFFFFFFFFu, c};
+        S.next = end;
+      }
+      __syncthreads();
+      if (S.sp == 0) break;
+      st = S.stack[S.sp - 1];
+      __syncthreads();
+      if (tid == 0) --S.sp;
     }
-    __syncthreads();
-    if (S.sp == 0) break;
-    const SubTile st = S.stack[S.sp - 1];
-    __syncthreads();
-    if (tid == 0) --S.sp;
+    first_pass = false;
     subtile_reset(S, tid);
 #pragma unroll
     for (int k = 0; k < 4 * kPer; ++k) raw[tid + k * kWalkRays] = 0u;
-    const Pose pose = poses[__builtin_amdgcn_readfirstlane(st.cloud)];
+    const Pose& pose = poses[__builtin_amdgcn_readfirstlane(st.cloud)];   // (scalar loads where it is used)
     Ray ray;
     const bool walks = tid >= st.lo && tid < st.hi && tile_ray(P, xyz, pose, i, &ray, &ctr->err);
     const float wu = walks ? P.weight / (2.0f * ray.truncation) : 0.0f;
+    const float wu_scaled = wu * scale_u;
     const uint32_t q_w = (uint32_t)__float2int_rn(wu * scale_w);
-    // origin of the voxel keys: the start voxel of the first walking ray (a lone ray sets it at the first visit
-    // of its window instead: its windows may lie anywhere along a very long ray)
+    // origin of the voxel keys: below the start voxel of the first walking ray, on a chunk boundary (a lone ray sets
+    // it at the first visit of its window instead: its windows may lie anywhere along a very long ray)
     const bool lone = st.hi - st.lo == 1;
     {
       const unsigned long long wm = __ballot(walks);
-      if (lane == 0) S.cand[wid] = wm ? (uint32_t)(wid * 64 + __ffsll((long long)wm) - 1) : 0xFFFFFFFFu;
+      if (lane == 0) S.cand[wid] = wm ? 1u : 0u;
+      if (wm && lane == __ffsll((long long)wm) - 1)
+        for (int k = 0; k < 3; ++k) S.worg[wid][k] = origin_of((int)floorf(ray.start[k]));
     }
     __syncthreads();
-    {
-      uint32_t firstw = 0xFFFFFFFFu;
+    int ox = 0, oy = 0, oz = 0;
+    if (!lone) {   // the first wave that has a walking ray names the origin (every thread reads the same words)
+      int w0 = 0;
 #pragma unroll
-      for (int w = 0; w < kWalkRays / 64; ++w) firstw = min(firstw, S.cand[w]);
-      if ((uint32_t)tid == firstw && !lone)
-        for (int k = 0; k < 3; ++k) S.org[k] = (int)floorf(ray.start[k]) - kOriginBias;
+      for (int w = kWalkRays / 64 - 1; w >= 0; --w) w0 = S.cand[w] ? w : w0;
+      ox = S.worg[w0][0]; oy = S.worg[w0][1]; oz = S.worg[w0][2];
+      if (tid == 0) { S.org[0] = ox; S.org[1] = oy; S.org[2] = oz; }   // (the flush reads S.org: a lone ray sets it later)
     }
-    __syncthreads();
-    int ox = S.org[0], oy = S.org[1], oz = S.org[2];
     bool org_set = !lone;
     uint32_t nv = 0;
-    WALK_PROF(0);   // sub-tile set-up: table reset, ray of the point, key origin
     // the lean walk: whole rays of a sub-tile of several rays on an unsharded map (everything but the re-walks
     // of a ray that did not fit the table and the owner-filtered walk of a sharded handle)
     const bool lean = !lone && st.vlo == 0u && st.vhi == 0xFFFFFFFFu && P.shard_count <= 1 && !(PLVS_WALK_EXP & 512);
     if (lean) {
-      if (walks && !(PLVS_WALK_EXP & 32)) {
-        LeanPose LP;
-        lean_pose(P, pose, &LP);
-        const float px = xyz[3 * (size_t)i], py = xyz[3 * (size_t)i + 1], pz = xyz[3 * (size_t)i + 2];
-        const float obl2 = (px * px + py * py + pz * pz) / (pz * pz);
-        nv = walk_lean<kAcc, kRuns>(P, pose, LP, ray, S, ox, oy, oz, tid, obl2, wu * scale_u, q_w, e_wuu, e_wc, e_last, vlog);
+      // ---- the chunks the ray starts and ends in -> chunk cache, their directory entries requested (DirPeek) ...
+      bool fits = false, won_s = false, won_e = false;
+      int ci_s = -1, ci_e = -1;
+      uint32_t code_s = kKeyEmpty, code_e = kKeyEmpty;
+      if (walks) {
+        const int reach = lean_reach(ray);
+        const int rx = (int)floorf(ray.start[0]) - ox, ry = (int)floorf(ray.start[1]) - oy, rz = (int)floorf(ray.start[2]) - oz;
+        fits = min(min(rx, ry), rz) - reach >= 0 && max(max(rx, ry), rz) + reach <= 1023;
+        if (fits) {
+          code_s = chunk_code((uint32_t)rx | ((uint32_t)ry << 10) | ((uint32_t)rz << 20));
+          code_e = chunk_code((uint32_t)((int)floorf(ray.end[0]) - ox) | ((uint32_t)((int)floorf(ray.end[1]) - oy) << 10) |
+                              ((uint32_t)((int)floorf(ray.end[2]) - oz) << 20));
+        } else {
+          S.overflow = 1u;   // the rays of the sub-tile are too far apart: it is cut (a lone ray takes the general walk)
+        }
+      }
+      {   // neighbouring rays share their chunks: only the first lane of a run of equal codes goes to the cache
+        const uint32_t prev_s = (uint32_t)__shfl_up((int)code_s, 1), prev_e = (uint32_t)__shfl_up((int)code_e, 1);
+        if (code_s != kKeyEmpty && (lane == 0 || code_s != prev_s)) ci_s = chunk_cache_insert(S, code_s, &won_s);
+        if (code_e != kKeyEmpty && code_e != code_s && (lane == 0 || code_e != prev_e)) ci_e = chunk_cache_insert(S, code_e, &won_e);
+      }
+      DirPeek peek_s, peek_e;
+      peek_s.want = peek_e.want = 0; peek_s.key = peek_e.key = kEmptyKey; peek_s.slot = peek_e.slot = -1;
+      if (won_s) {
+        int cx, cy, cz;
+        chunk_of_code(code_s, ox, oy, oz, &cx, &cy, &cz);
+        peek_s = dir_peek(dir, cx, cy, cz);
+      }
+      if (won_e) {
+        int cx, cy, cz;
+        chunk_of_code(code_e, ox, oy, oz, &cx, &cy, &cz);
+        peek_e = dir_peek(dir, cx, cy, cz);
+      }
+      WALK_PROF(0);   // sub-tile set-up: table reset, ray of the point, key origin
+      // ---- ... the walk (its set-up arithmetic hides the directory's latency; the slots land before the loop)
+      if (fits && !(PLVS_WALK_EXP & 32)) {
+        RayCursor cur;
+        ray_begin(ray, &cur);   // (walk_lean's own ray_begin is this one: common subexpression)
+        if (won_s && dir_peek_slot(peek_s) >= 0) S.cslot[ci_s] = dir_peek_slot(peek_s);
+        if (won_e && dir_peek_slot(peek_e) >= 0) S.cslot[ci_e] = dir_peek_slot(peek_e);
+        nv = walk_lean<kAcc, kRuns>(P, pose, ray, S, ox, oy, oz, tid, wu_scaled, q_w, e_wuu, e_wc, e_last, vlog);
       }
     } else if (walks && !(PLVS_WALK_EXP & 32)) {   // (bit 32, timing experiment: set-up and flush only)
+      WALK_PROF(0);
       nv = walk_one(P, pose, ray, st.vlo, st.vhi, [&](uint32_t k, int vx, int vy, int vz, float u) {
         if (!org_set) {   // (one lane only)
-          ox = vx - kOriginBias; oy = vy - kOriginBias; oz = vz - kOriginBias;
+          ox = origin_of(vx); oy = origin_of(vy); oz = origin_of(vz);
           S.org[0] = ox; S.org[1] = oy; S.org[2] = oz;
           org_set = true;
         }
@@ -629,47 +743,39 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
           S.overflow = 1u;
           return false;
         }
-#if (PLVS_WALK_EXP & 2)   // (timing experiment: no table)
-        const int e = (int)(key_bucket(key) * 4u + (key & 3u));
-        S.ekey[e] = key;
-#else
         const int e = table_find_or_insert(S, key);
         if (e < 0) return false;
-#endif
-#if !(PLVS_WALK_EXP & 8)   // (timing experiment: no visit log)
         if (kRuns && k < (uint32_t)kLogLen) vlog[k * kWalkRays + tid] = (uint16_t)e;
-#endif
-#if (PLVS_WALK_EXP & 1)   // (timing experiment: plain stores instead of the three atomics)
         if (kAcc) {
-          e_wuu[e] = __float2int_rn((wu * u) * scale_u);
-          e_wc[e] = (1ull << 32) | (unsigned long long)q_w;
-          e_last[e] = (uint32_t)tid;
-        }
-#else
-        if (kAcc) {
-          atomicAdd(&e_wuu[e], __float2int_rn((wu * u) * scale_u));
+          atomicAdd(&e_wuu[e], __float2int_rn(wu_scaled * u));
           atomicAdd(&e_wc[e], (1ull << 32) | (unsigned long long)q_w);
           atomicMax(&e_last[e], (uint32_t)tid);
         }
-#endif
         return true;
       });
     }
     WALK_PROF(1);   // thread 0's own walk
+#if (PLVS_WALK_EXP & 2048)
+    __builtin_amdgcn_s_setprio(3);   // the flush: short dependent phases between barriers — ahead of the other tiles' walks
+#endif
     __syncthreads();
     WALK_PROF(2);   // ... and the wait for the tile's longest ray
+    uint32_t ekey[kPer];
     {   // entries in use (nobody counts them during the walk)
       uint32_t mine = 0;
 #pragma unroll
-      for (int k = 0; k < kPer; ++k) mine += S.ekey[tid + k * kWalkRays] != kKeyEmpty ? 1u : 0u;
+      for (int k = 0; k < kPer; ++k) {
+        ekey[k] = S.ekey[tid + k * kWalkRays];
+        mine += ekey[k] != kKeyEmpty ? 1u : 0u;
+      }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) mine += (uint32_t)__shfl_xor((int)mine, off);
       if (lane == 0 && mine) atomicAdd(&S.nent, mine);
     }
     __syncthreads();
     const bool overflowed = S.overflow != 0 || S.nent > (uint32_t)kWalkLimit;
-    __syncthreads();
     if (overflowed) {
+      __syncthreads();   // (everybody has read the flag before the stack changes)
       was_split = true;
       if (tid == 0) subtile_split(S, st);
       continue;
@@ -686,44 +792,54 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
     int ci[kPer];
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
-      const uint32_t key = S.ekey[tid + k * kWalkRays];
       ci[k] = -2;
-      if (key != kKeyEmpty) {
-        const int vx = (int)(key & 1023u) + fox, vy = (int)((key >> 10) & 1023u) + foy, vz = (int)(key >> 20) + foz;
-        ci[k] = chunk_cache_insert(S, vx >> 4, vy >> 4, vz >> 4);
+      if (ekey[k] != kKeyEmpty) {
+        bool won;
+        ci[k] = chunk_cache_insert(S, chunk_code(ekey[k]), &won);
+        // (a chunk joins the map when one of its voxels takes an update — not because a ray started or ended in it)
+        if (ci[k] >= 0 && S.cslot[ci[k]] == -1) S.cslot[ci[k]] = -3;   // wanted, not resolved yet
       }
     }
-    __syncthreads();
+    bool unresolved = false;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) unresolved = unresolved || (ci[k] >= 0 && S.cslot[ci[k]] < 0);
+    // (one barrier: the cache is complete — and is any chunk with entries still without its pool slot?  The lean walk
+    // resolved the chunks its rays start and end in ahead of the loop; what can be left: chunks a ray only passes
+    // through, chunks not at their home entry of the directory, and the first-touch chunks, inserted here)
+    const bool any_unresolved = __syncthreads_or(unresolved ? 1 : 0) != 0;
     WALK_PROF(3);   // entries -> chunk cache
-    if (tid < kWalkChunks && S.ckey[tid] != kEmptyKey) {
-      const unsigned long long ck = S.ckey[tid];
-#if (PLVS_WALK_EXP & 256)   // (timing experiment: no directory look-up)
-      S.cslot[tid] = tid;
-#else
-      S.cslot[tid] = dir_find_or_insert(dir, (int)((ck >> 42) & 0x1FFFFFu) - kCoordBias,
-                                        (int)((ck >> 21) & 0x1FFFFFu) - kCoordBias, (int)(ck & 0x1FFFFFu) - kCoordBias,
-                                        num_chunks, &ctr->err);
-#endif
+    if (any_unresolved) {
+      if (tid < kWalkChunks && S.cslot[tid] == -3) {
+        int cx, cy, cz;
+        chunk_of_code(S.ccode[tid], fox, foy, foz, &cx, &cy, &cz);
+        S.cslot[tid] = dir_find_or_insert(dir, cx, cy, cz, num_chunks, &ctr->err);
+      }
+      __syncthreads();
     }
-    __syncthreads();
     WALK_PROF(4);   // chunk cache -> directory
-    uint32_t rank[kPer], vkey[kPer];
+    uint32_t rank[kPer], vkey[kPer], elast[kPer];
+    unsigned long long ewc[kPer];
     int slot_of[kPer];
     uint32_t need = 0, nneed = 0;   // entries of this thread that leave the tile as runs
+    bool multi = false;             // ... one of them visited by more than one ray
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
       rank[k] = 0;
       vkey[k] = 0;
       slot_of[k] = -1;
+      elast[k] = 0;
+      ewc[k] = 0;
       if (ci[k] == -2) continue;
-      const uint32_t key = S.ekey[tid + k * kWalkRays];
-      const int vx = (int)(key & 1023u) + fox, vy = (int)((key >> 10) & 1023u) + foy, vz = (int)(key >> 20) + foz;
-      const uint32_t vid = (uint32_t)(((vz & 15) * 16 + (vy & 15)) * 16 + (vx & 15));
+      const uint32_t vid = voxel_in_chunk(ekey[k]);
+      ewc[k] = e_wc[tid + k * kWalkRays];
+      elast[k] = e_last[tid + k * kWalkRays];
       if (ci[k] >= 0) {
         slot_of[k] = S.cslot[ci[k]];
         if (slot_of[k] >= 0) rank[k] = atomicAdd(&S.ccnt[ci[k] * kSlabs + (int)(vid / kSlabVox)], 1u);
       } else {
-        slot_of[k] = dir_find_or_insert(dir, vx >> 4, vy >> 4, vz >> 4, num_chunks, &ctr->err);
+        int cx, cy, cz;
+        chunk_of_code(chunk_code(ekey[k]), fox, foy, foz, &cx, &cy, &cz);
+        slot_of[k] = dir_find_or_insert(dir, cx, cy, cz, num_chunks, &ctr->err);
       }
       if (slot_of[k] >= 0) {
         vkey[k] = (uint32_t)slot_of[k] * (uint32_t)kChunkVox + vid;
@@ -735,29 +851,38 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
         if (kRuns && cold) {   // its colour still depends on the order of the visits
           need |= 1u << k;
           ++nneed;
+          multi = multi || (uint32_t)(ewc[k] >> 32) > 1u;
         }
       }
     }
-    __syncthreads();
+    // (one barrier: the ranks are complete, and does any voxel that needs a run have more than one visiting ray?)
+    const bool any_multi = __syncthreads_or(multi ? 1 : 0) != 0;
     WALK_PROF(5);   // ranks, colour weights
     if (kAcc) {
-      // ---- records: wave 0 places the (chunk, slab) groups (the tile's own region on its first flush)
-      if (tid < 64) {
+      // ---- records: the (chunk, slab) groups are placed by a scan over the cache's 64 chunks, one lane per chunk.
+      // First flush of the tile (its own record / segment regions, no allocation): EVERY wave runs the scan and writes
+      // the same table of group bases — a wave reads back its own LDS writes in order, so nobody waits for wave 0
+      // behind a barrier; wave 0 alone writes the segment descriptors.  Later flushes (a tile that was cut) take their
+      // regions from the spill counters: wave 0 scans, the others wait.
+      const bool own_region = flushes == 0;
+      uint32_t rbase = tile * (uint32_t)kWalkLimit;
+      if (own_region || tid < 64) {
+        const int cl = lane;   // the chunk of this lane
         uint32_t sub[kSlabs], c = 0;
 #pragma unroll
         for (int s = 0; s < kSlabs; ++s) {
           sub[s] = c;
-          c += S.ccnt[tid * kSlabs + s];
+          c += S.ccnt[cl * kSlabs + s];
         }
         uint32_t inc = c, sinc = c ? 1u : 0u;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
           const uint32_t up = (uint32_t)__shfl_up((int)inc, off), sup = (uint32_t)__shfl_up((int)sinc, off);
-          if (tid >= off) { inc += up; sinc += sup; }
+          if (lane >= off) { inc += up; sinc += sup; }
         }
         const uint32_t tot = (uint32_t)__shfl((int)inc, 63), stot = (uint32_t)__shfl((int)sinc, 63);
-        uint32_t rbase = tile * (uint32_t)kWalkLimit, sbase = tile * (uint32_t)kWalkChunks;
-        if (flushes > 0) {
+        uint32_t sbase = tile * (uint32_t)kWalkChunks;
+        if (!own_region) {
           if (tid == 0 && tot) {
             rbase = ntiles * (uint32_t)kWalkLimit + atomicAdd(&ctr->rec_top, tot);
             sbase = ntiles * (uint32_t)kWalkChunks + atomicAdd(&ctr->seg_top, stot);
@@ -765,32 +890,34 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
           }
           rbase = (uint32_t)__shfl((int)rbase, 0);
           sbase = (uint32_t)__shfl((int)sbase, 0);
+          if (tid == 0) S.rbase = rbase;
         } else if (tid == 0) {
           out.seg_cnt[tile] = stot;
         }
-        if (tid == 0) S.rbase = rbase;
 #pragma unroll
-        for (int s = 0; s < kSlabs; ++s) S.cbase[tid * kSlabs + s] = (uint16_t)(inc - c + sub[s]);
-        if (c) {
+        for (int s = 0; s < kSlabs; ++s) S.cbase[cl * kSlabs + s] = (uint16_t)(inc - c + sub[s]);
+        if (c && tid < 64) {
           const uint32_t sg = sbase + sinc - 1u;
           if (sg < out.seg_cap) {
-            out.seg[2 * (size_t)sg] = make_uint4((uint32_t)S.cslot[tid], rbase + inc - c, c, gtile);
+            out.seg[2 * (size_t)sg] = make_uint4((uint32_t)S.cslot[cl], rbase + inc - c, c, gtile);
             out.seg[2 * (size_t)sg + 1] = pack_suboffsets(sub);
           }
         }
       }
-      __syncthreads();
+      if (!own_region) {
+        __syncthreads();
+        rbase = S.rbase;
+      }
 #pragma unroll
       for (int k = 0; k < kPer; ++k) {
         if (slot_of[k] < 0) continue;
         const int e = tid + k * kWalkRays;
         const uint32_t vid = vkey[k] % (uint32_t)kChunkVox;
-        const unsigned long long wc = e_wc[e];
-        const uint4 r = make_uint4(vid | ((uint32_t)(wc >> 32) << 12), gtile * kWalkRays + e_last[e], (uint32_t)e_wuu[e],
-                                   (uint32_t)wc);
+        const uint4 r = make_uint4(vid | ((uint32_t)(ewc[k] >> 32) << 12), gtile * kWalkRays + elast[k], (uint32_t)e_wuu[e],
+                                   (uint32_t)ewc[k]);
         uint32_t at;
         if (ci[k] >= 0) {
-          at = S.rbase + S.cbase[ci[k] * kSlabs + (int)(vid / kSlabVox)] + rank[k];
+          at = rbase + S.cbase[ci[k] * kSlabs + (int)(vid / kSlabVox)] + rank[k];
         } else {   // beyond the chunk cache (scattered clouds): a segment of its own in the spill area
           at = ntiles * (uint32_t)kWalkLimit + atomicAdd(&ctr->rec_top, 1u);
           const uint32_t sg = ntiles * (uint32_t)kWalkChunks + atomicAdd(&ctr->seg_top, 1u);
@@ -810,13 +937,47 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
 
     ++flushes;
     WALK_PROF(6);   // records
-    if (!kRuns || (PLVS_WALK_EXP & 64)) continue;   // (bit 64, timing experiment: no runs)   // (the loop head's barrier lets the records leave before the table is reset)
-    // ---- runs: number the entries that need one
+    if (!kRuns || (PLVS_WALK_EXP & 64)) {   // (bit 64, timing experiment: no runs)
+      if (single && !was_split) break;
+      continue;
+    }
+    // ---- runs: number the entries that need one (wave by wave)
     uint32_t inc = nneed;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
       if (lane >= off) inc += up;
+    }
+    const uint32_t wave_runs = (uint32_t)__shfl((int)inc, 63);
+    if (!any_multi) {
+      // every voxel that needs a run has ONE visiting ray — the steady state of a map whose colours have mostly
+      // saturated: what is still below 254 is what few rays reach — and the accumulator named it (e_last): the
+      // mask is that one bit, no pass over the visit logs.  The tile's run slots are handed out wave by wave (the
+      // order of a tile's runs among themselves is immaterial: they are runs of different voxels), no barrier.
+      uint32_t base = 0;
+      if (lane == 0 && wave_runs) base = atomicAdd(&S.run_total, wave_runs);
+      base = (uint32_t)__shfl((int)base, 0);
+      const bool fits_runs = base + wave_runs <= (1u << runs.r1_log2);
+      if (!fits_runs && lane == 0) {
+        atomicOr(&ctr->err, kErrScratch);
+        atomicMax(&ctr->run_need, base + wave_runs);   // (the largest of these is the tile's total)
+      }
+      uint32_t m = base + inc - nneed;
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        if (!(need & (1u << k)) || !fits_runs) continue;
+        const size_t d = ((size_t)tile << runs.r1_log2) + m++;
+        runs.dkey[d] = vkey[k];
+        uint4* dst = reinterpret_cast<uint4*>(runs.masks + d * kMaskWords);
+        const uint32_t word = elast[k] >> 5, bit = 1u << (elast[k] & 31u);
+#pragma unroll
+        for (int q = 0; q < kMaskWords / 4; ++q)
+          dst[q] = make_uint4(word == 4u * q ? bit : 0u, word == 4u * q + 1u ? bit : 0u, word == 4u * q + 2u ? bit : 0u,
+                              word == 4u * q + 3u ? bit : 0u);
+      }
+      WALK_PROF(7);
+      if (single && !was_split) break;
+      continue;
     }
     if (lane == 63) S.wsum[wid] = inc;
     __syncthreads();   // (also: the records are out, the accumulator area is free)
@@ -827,18 +988,19 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
       if (w < wid) wbase += v;
       nruns += v;
     }
+    // the runs go to the tile's own slots, behind those of its earlier flushes
+    const uint32_t emitted = S.run_total;
+    const bool fits_runs = emitted + nruns <= (1u << runs.r1_log2);
+    if (!fits_runs && tid == 0) {
+      atomicOr(&ctr->err, kErrScratch);
+      atomicMax(&ctr->run_need, emitted + nruns);
+    }
     {
       uint32_t m = wbase + inc - nneed;
 #pragma unroll
       for (int k = 0; k < kPer; ++k) e_midx[tid + k * kWalkRays] = (need & (1u << k)) ? (uint16_t)m++ : (uint16_t)0xFFFFu;
     }
-    // the runs go to the tile's own slots, behind those of its earlier flushes
-    const bool fits = emitted + nruns <= (1u << runs.r1_log2);
-    if (!fits && tid == 0) {
-      atomicOr(&ctr->err, kErrScratch);
-      atomicMax(&ctr->run_need, emitted + nruns);
-    }
-    for (uint32_t r0 = 0; fits && r0 < nruns; r0 += kMaskCap) {
+    for (uint32_t r0 = 0; fits_runs && r0 < nruns; r0 += kMaskCap) {
       __syncthreads();   // e_midx complete / the previous round's masks are out
 #pragma unroll
       for (int k = 0; k < kMaskCap * kMaskWords / kWalkRays; ++k) raw[tid + k * kWalkRays] = 0u;
@@ -874,28 +1036,353 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
         for (int q = 0; q < kMaskWords / 4; ++q) dst[q] = make_uint4(mk[4 * q], mk[4 * q + 1], mk[4 * q + 2], mk[4 * q + 3]);
       }
     }
-    emitted += nruns;
+    __syncthreads();   // (everybody has read run_total)
+    if (tid == 0) S.run_total = emitted + nruns;
     WALK_PROF(7);   // runs
+    if (single && !was_split) break;
   }
 
   // ---- tile epilogue: run and visit counts
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) my_visits += (uint32_t)__shfl_xor((int)my_visits, off);
-  __syncthreads();
-  if (lane == 0) S.wsum[wid] = my_visits;
+  if (lane == 0 && my_visits) atomicAdd(&S.vis_total, my_visits);
   __syncthreads();
   if (tid == 0) {
-    if (kRuns) runs.run_cnt[tile] = min(emitted, 1u << runs.r1_log2);
+    if (kRuns) runs.run_cnt[tile] = min(S.run_total, 1u << runs.r1_log2);
     if (kAcc) {
-      uint32_t v = 0;
-      for (int w = 0; w < kWalkRays / 64; ++w) v += S.wsum[w];
-      out.tile_visits[tile] = v;
+      out.tile_visits[tile] = S.vis_total;
       if (flushes == 0) out.seg_cnt[tile] = 0;
     }
     if (was_split) atomicAdd(&ctr->split_tiles, 1u);
   }
   WALK_PROF(8);     // epilogue
   WALK_PROF_END();
+  }   // (tiles of the list)
+}
+
+// ------------------------------------------------------------------ walk_fast: the common case of walk_tiles, alone
+// A tile that lies inside one cloud, whose rays fit the key box and whose voxels fit the table — every tile of a depth
+// camera's clouds but a handful — has ONE sub-tile and ONE flush.  This kernel is that case and nothing else: no
+// sub-tile stack, no windows of a single ray, no spill regions, and so few enough live values that the voxel loop runs
+// out of registers (walk_tiles with every path in one body spilled into its loop), and FIVE barriers per tile instead
+// of eighteen (a barrier costs a tile ~1 us: the slowest of eight waves, their memory operations drained).  A tile
+// that does not qualify is DEFERRED: nothing of it has reached global memory when that is known (records, segments,
+// runs and directory inserts all happen in the flush), its index goes to a list and walk_tiles (the general kernel)
+// walks the list behind this kernel.  Same outputs, same regions, bit for bit the same records either way.
+__global__ __launch_bounds__(kWalkRays, 6) void walk_fast(
+    Params P, float scale_u, float scale_w, const float* __restrict__ xyz, int npoints,
+    const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
+    int32_t* __restrict__ num_chunks, WalkCounters* __restrict__ ctr, const uint32_t* __restrict__ rgbw,
+    const uint32_t* __restrict__ sat, AccOut out, RunOut runs, TileMap tmap, uint32_t* __restrict__ deferred) {
+  constexpr int kPer = kWalkEntries / kWalkRays;
+  __shared__ WalkShared S;
+  __shared__ uint32_t raw[kMaskCap * kMaskWords];              // accumulators during the walk, ray masks afterwards
+  __shared__ uint16_t vlog[kLogLen * kWalkRays];        // entry of visit k of ray r at [k * kWalkRays + r]
+  __shared__ uint16_t e_midx[kWalkEntries];           // mask index of the entry (0xFFFF: none)
+  int32_t* const e_wuu = reinterpret_cast<int32_t*>(raw);                                 // sum of w_u * u, fixed point
+  unsigned long long* const e_wc = reinterpret_cast<unsigned long long*>(raw + kWalkEntries);   // visits << 32 | sum of w_u
+  uint32_t* const e_last = raw + 3 * kWalkEntries;                                        // last visiting ray
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t tile = blockIdx.x;                       // the local tile: output regions
+  const uint32_t gtile = tmap.tile_of(tile);             // its place in the point stream
+  const uint32_t first = gtile * kWalkRays;
+  const uint32_t nrays = min((uint32_t)kWalkRays, (uint32_t)npoints - first);
+  const int cloud = cloud_of(offsets, nclouds, (int)first);
+  bool defer = (uint32_t)(offsets[cloud + 1] - (int32_t)first) < nrays || P.shard_count > 1;   // (uniform)
+  uint32_t nv = 0;
+  bool walks = false;
+  int ox = 0, oy = 0, oz = 0;
+  if (!defer) {
+    subtile_reset(S, tid);
+#pragma unroll
+    for (int k = 0; k < 4 * kPer; ++k) raw[tid + k * kWalkRays] = 0u;
+    if (tid == 0) {
+      S.run_total = 0;
+      S.vis_total = 0;
+    }
+    const Pose& pose = poses[cloud];   // (uniform address: scalar loads where it is used)
+    Ray ray;
+    walks = (uint32_t)tid < nrays && tile_ray(P, xyz, pose, first + (uint32_t)tid, &ray, &ctr->err);
+    const float wu = walks ? P.weight / (2.0f * ray.truncation) : 0.0f;
+    {   // origin of the voxel keys: below the start voxel of the first walking ray, on a chunk boundary
+      const unsigned long long wm = __ballot(walks);
+      if (lane == 0) S.cand[wid] = wm ? 1u : 0u;
+      if (wm && lane == __ffsll((long long)wm) - 1)
+        for (int k = 0; k < 3; ++k) S.worg[wid][k] = origin_of((int)floorf(ray.start[k]));
+    }
+    __syncthreads();                                                                        // ---- barrier 1
+    {
+      int w0 = 0;
+#pragma unroll
+      for (int w = kWalkRays / 64 - 1; w >= 0; --w) w0 = S.cand[w] ? w : w0;
+      ox = S.worg[w0][0]; oy = S.worg[w0][1]; oz = S.worg[w0][2];
+    }
+    // ---- the chunks the ray starts and ends in -> chunk cache, their directory entries requested (DirPeek) ...
+    bool fits = false, won_s = false, won_e = false;
+    int ci_s = -1, ci_e = -1;
+    uint32_t code_s = kKeyEmpty, code_e = kKeyEmpty;
+    if (walks) {
+      const int reach = lean_reach(ray);
+      const int rx = (int)floorf(ray.start[0]) - ox, ry = (int)floorf(ray.start[1]) - oy, rz = (int)floorf(ray.start[2]) - oz;
+      fits = min(min(rx, ry), rz) - reach >= 0 && max(max(rx, ry), rz) + reach <= 1023;
+      if (fits) {
+        code_s = chunk_code((uint32_t)rx | ((uint32_t)ry << 10) | ((uint32_t)rz << 20));
+        code_e = chunk_code((uint32_t)((int)floorf(ray.end[0]) - ox) | ((uint32_t)((int)floorf(ray.end[1]) - oy) << 10) |
+                            ((uint32_t)((int)floorf(ray.end[2]) - oz) << 20));
+      } else {
+        S.overflow = 1u;   // the rays of the tile are too far apart
+      }
+    }
+    {   // neighbouring rays share their chunks: only the first lane of a run of equal codes goes to the cache
+      const uint32_t prev_s = (uint32_t)__shfl_up((int)code_s, 1), prev_e = (uint32_t)__shfl_up((int)code_e, 1);
+      if (code_s != kKeyEmpty && (lane == 0 || code_s != prev_s)) ci_s = chunk_cache_insert(S, code_s, &won_s);
+      if (code_e != kKeyEmpty && code_e != code_s && (lane == 0 || code_e != prev_e)) ci_e = chunk_cache_insert(S, code_e, &won_e);
+    }
+    DirPeek peek_s, peek_e;
+    peek_s.want = peek_e.want = 0; peek_s.key = peek_e.key = kEmptyKey; peek_s.slot = peek_e.slot = -1;
+    if (won_s) {
+      int cx, cy, cz;
+      chunk_of_code(code_s, ox, oy, oz, &cx, &cy, &cz);
+      peek_s = dir_peek(dir, cx, cy, cz);
+    }
+    if (won_e) {
+      int cx, cy, cz;
+      chunk_of_code(code_e, ox, oy, oz, &cx, &cy, &cz);
+      peek_e = dir_peek(dir, cx, cy, cz);
+    }
+    // ---- ... the walk (its set-up arithmetic hides the directory's latency; the slots land before the loop)
+    if (fits) {
+      RayCursor cur;
+      ray_begin(ray, &cur);   // (walk_lean's own ray_begin is this one: common subexpression)
+      if (won_s && dir_peek_slot(peek_s) >= 0) S.cslot[ci_s] = dir_peek_slot(peek_s);
+      if (won_e && dir_peek_slot(peek_e) >= 0) S.cslot[ci_e] = dir_peek_slot(peek_e);
+      nv = walk_lean<true, true>(P, pose, ray, S, ox, oy, oz, tid, wu * scale_u, (uint32_t)__float2int_rn(wu * scale_w), e_wuu,
+                                 e_wc, e_last, vlog);
+    }
+  }
+  uint32_t ekey[kPer];
+  if (!defer) {   // entries in use (nobody counts them during the walk)
+    __syncthreads();                                                                        // ---- barrier 2
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) ekey[k] = S.ekey[tid + k * kWalkRays];
+    static_assert(kPer == 2, "two entries per thread");
+    const uint32_t wave_n = (uint32_t)__popcll(__ballot(ekey[0] != kKeyEmpty)) + (uint32_t)__popcll(__ballot(ekey[1] != kKeyEmpty));
+    if (lane == 0 && wave_n) atomicAdd(&S.nent, wave_n);
+  } else {
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) ekey[k] = kKeyEmpty;
+  }
+  // ---- cache: entries -> chunks; one barrier later everybody knows whether the tile stands
+  int ci[kPer];
+  bool unresolved = false;
+  if (!defer) {
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      ci[k] = -2;
+      if (ekey[k] != kKeyEmpty) {
+        bool won;
+        ci[k] = chunk_cache_insert(S, chunk_code(ekey[k]), &won);
+        // (a chunk joins the map when one of its voxels takes an update — not because a ray started or ended in it)
+        if (ci[k] >= 0 && S.cslot[ci[k]] == -1) S.cslot[ci[k]] = -3;   // wanted, not resolved yet
+        if (ci[k] < 0) S.overflow = 1u;   // more chunks than the cache holds
+        unresolved = unresolved || (ci[k] >= 0 && S.cslot[ci[k]] < 0);
+      }
+    }
+    const bool any_unresolved = __syncthreads_or(unresolved ? 1 : 0) != 0;                  // ---- barrier 3
+    // (a tile whose table overflowed, whose rays did not fit the key box or whose chunks did not fit the cache is
+    // walked by the general kernel: nothing of it has left the workgroup yet)
+    defer = S.overflow != 0 || S.nent > (uint32_t)kWalkLimit;
+    if (!defer && any_unresolved) {
+      if (tid < kWalkChunks && S.cslot[tid] == -3) {
+        int cx, cy, cz;
+        chunk_of_code(S.ccode[tid], ox, oy, oz, &cx, &cy, &cz);
+        S.cslot[tid] = dir_find_or_insert(dir, cx, cy, cz, num_chunks, &ctr->err);
+      }
+      __syncthreads();
+    }
+  }
+  if (defer) {
+    if (tid == 0) {
+      out.seg_cnt[tile] = 0;
+      runs.run_cnt[tile] = 0;
+      out.tile_visits[tile] = 0;
+      deferred[atomicAdd(&ctr->ndeferred, 1u)] = tile;
+    }
+    return;
+  }
+  {   // visits of the tile
+    uint32_t v = nv;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off);
+    if (lane == 0 && v) atomicAdd(&S.vis_total, v);
+  }
+  // ---- ranks inside the (chunk, slab) groups, colour weights
+  uint32_t rank[kPer], vkey[kPer], elast[kPer];
+  unsigned long long ewc[kPer];
+  uint32_t need = 0, nneed = 0;   // entries of this thread that leave the tile as runs
+  bool multi = false;             // ... one of them visited by more than one ray
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    rank[k] = 0;
+    vkey[k] = 0xFFFFFFFFu;        // (no pool slot: the directory is full)
+    elast[k] = 0;
+    ewc[k] = 0;
+    if (ci[k] < 0) continue;
+    const uint32_t vid = voxel_in_chunk(ekey[k]);
+    ewc[k] = e_wc[tid + k * kWalkRays];
+    elast[k] = e_last[tid + k * kWalkRays];
+    const int slot = S.cslot[ci[k]];
+    if (slot < 0) continue;
+    rank[k] = atomicAdd(&S.ccnt[ci[k] * kSlabs + (int)(vid / kSlabVox)], 1u);
+    vkey[k] = (uint32_t)slot * (uint32_t)kChunkVox + vid;
+    const bool cold = sat ? ((sat[vkey[k] >> 5] >> (vkey[k] & 31u)) & 1u) == 0u : (rgbw[vkey[k]] >> 24) < 254u;
+    if (cold) {   // its colour still depends on the order of the visits
+      need |= 1u << k;
+      ++nneed;
+      multi = multi || (uint32_t)(ewc[k] >> 32) > 1u;
+    }
+  }
+  // (one barrier: the ranks are complete, and does any voxel that needs a run have more than one visiting ray?)
+  const bool any_multi = __syncthreads_or(multi ? 1 : 0) != 0;                              // ---- barrier 4
+  // ---- records: the (chunk, slab) groups are placed by a scan over the cache's 64 chunks, one lane per chunk.  EVERY
+  // wave runs the scan and writes the same table of group bases — a wave reads back its own LDS writes in order, so
+  // nobody waits for wave 0 behind a barrier; wave 0 alone writes the segment descriptors.
+  const uint32_t rbase = tile * (uint32_t)kWalkLimit;
+  {
+    uint32_t sub[kSlabs], c = 0;
+#pragma unroll
+    for (int s = 0; s < kSlabs; ++s) {
+      sub[s] = c;
+      c += S.ccnt[lane * kSlabs + s];
+    }
+    uint32_t inc = c, sinc = c ? 1u : 0u;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)inc, off), sup = (uint32_t)__shfl_up((int)sinc, off);
+      if (lane >= off) { inc += up; sinc += sup; }
+    }
+#pragma unroll
+    for (int s = 0; s < kSlabs; ++s) S.cbase[lane * kSlabs + s] = (uint16_t)(inc - c + sub[s]);
+    if (wid == 0) {
+      const uint32_t stot = (uint32_t)__shfl((int)sinc, 63);
+      if (lane == 0) out.seg_cnt[tile] = stot;
+      if (c) {
+        const uint32_t sg = tile * (uint32_t)kWalkChunks + sinc - 1u;
+        out.seg[2 * (size_t)sg] = make_uint4((uint32_t)S.cslot[lane], rbase + inc - c, c, gtile);
+        out.seg[2 * (size_t)sg + 1] = pack_suboffsets(sub);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    if (vkey[k] == 0xFFFFFFFFu) continue;
+    const uint32_t vid = vkey[k] % (uint32_t)kChunkVox;
+    const uint4 r = make_uint4(vid | ((uint32_t)(ewc[k] >> 32) << 12), gtile * kWalkRays + elast[k],
+                               (uint32_t)e_wuu[tid + k * kWalkRays], (uint32_t)ewc[k]);
+    out.rec[rbase + S.cbase[ci[k] * kSlabs + (int)(vid / kSlabVox)] + rank[k]] = r;
+  }
+  // ---- runs: number the entries that need one (wave by wave)
+  uint32_t inc = nneed;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
+    if (lane >= off) inc += up;
+  }
+  const uint32_t wave_runs = (uint32_t)__shfl((int)inc, 63);
+  if (!any_multi) {
+    // every voxel that needs a run has ONE visiting ray — the steady state of a map whose colours have mostly
+    // saturated: what is still below 254 is what few rays reach — and the accumulator named it (e_last): the mask is
+    // that one bit, no pass over the visit logs.  The tile's run slots are handed out wave by wave (the order of a
+    // tile's runs among themselves is immaterial: they are runs of different voxels), no barrier.
+    uint32_t base = 0;
+    if (lane == 0 && wave_runs) base = atomicAdd(&S.run_total, wave_runs);
+    base = (uint32_t)__shfl((int)base, 0);
+    const bool fits_runs = base + wave_runs <= (1u << runs.r1_log2);
+    if (!fits_runs && lane == 0) {
+      atomicOr(&ctr->err, kErrScratch);
+      atomicMax(&ctr->run_need, base + wave_runs);   // (the largest of these is the tile's total)
+    }
+    uint32_t m = base + inc - nneed;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      if (!(need & (1u << k)) || !fits_runs) continue;
+      const size_t d = ((size_t)tile << runs.r1_log2) + m++;
+      runs.dkey[d] = vkey[k];
+      uint4* dst = reinterpret_cast<uint4*>(runs.masks + d * kMaskWords);
+      const uint32_t word = elast[k] >> 5, bit = 1u << (elast[k] & 31u);
+#pragma unroll
+      for (int q = 0; q < kMaskWords / 4; ++q)
+        dst[q] = make_uint4(word == 4u * q ? bit : 0u, word == 4u * q + 1u ? bit : 0u, word == 4u * q + 2u ? bit : 0u,
+                            word == 4u * q + 3u ? bit : 0u);
+    }
+  } else {
+    // the masks come from the visit logs: bit r of a voxel's mask = ray r of the tile visits it
+    if (lane == 63) S.wsum[wid] = inc;
+    __syncthreads();   // (also: the records are out, the accumulator area is free)
+    uint32_t wbase = 0, nruns = 0;
+#pragma unroll
+    for (int w = 0; w < kWalkRays / 64; ++w) {
+      const uint32_t v = S.wsum[w];
+      if (w < wid) wbase += v;
+      nruns += v;
+    }
+    const bool fits_runs = nruns <= (1u << runs.r1_log2);
+    if (!fits_runs && tid == 0) {
+      atomicOr(&ctr->err, kErrScratch);
+      atomicMax(&ctr->run_need, nruns);
+    }
+    {
+      uint32_t m = wbase + inc - nneed;
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) e_midx[tid + k * kWalkRays] = (need & (1u << k)) ? (uint16_t)m++ : (uint16_t)0xFFFFu;
+    }
+    for (uint32_t r0 = 0; fits_runs && r0 < nruns; r0 += kMaskCap) {
+      __syncthreads();   // e_midx complete / the previous round's masks are out
+#pragma unroll
+      for (int k = 0; k < kMaskCap * kMaskWords / kWalkRays; ++k) raw[tid + k * kWalkRays] = 0u;
+      __syncthreads();
+      if (nv) {
+        const uint32_t logged = min(nv, (uint32_t)kLogLen);
+        for (uint32_t k = 0; k < logged; ++k) {
+          const uint32_t m = (uint32_t)e_midx[vlog[k * kWalkRays + tid]] - r0;   // 0xFFFF - r0 stays out of range
+          if (m < (uint32_t)kMaskCap) atomicOr(&raw[m * kMaskWords + (tid >> 5)], 1u << (tid & 31));
+        }
+        if (nv > (uint32_t)kLogLen) {   // the log is full: the rest of the ray is walked again
+          const Pose& pose = poses[cloud];
+          Ray ray;
+          if (tile_ray(P, xyz, pose, first + (uint32_t)tid, &ray, &ctr->err))
+            walk_one(P, pose, ray, 0u, 0xFFFFFFFFu, [&](uint32_t k, int vx, int vy, int vz, float) {
+              if (k >= (uint32_t)kLogLen) {
+                uint32_t key;
+                const int e = rel_key(vx, vy, vz, ox, oy, oz, &key) ? table_find(S, key) : -1;
+                const uint32_t m = e >= 0 ? (uint32_t)e_midx[e] - r0 : 0xFFFFFFFFu;
+                if (m < (uint32_t)kMaskCap) atomicOr(&raw[m * kMaskWords + (tid >> 5)], 1u << (tid & 31));
+              }
+              return true;
+            });
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        const uint32_t m = (uint32_t)e_midx[tid + k * kWalkRays];
+        if (m == 0xFFFFu || m < r0 || m >= r0 + (uint32_t)kMaskCap) continue;
+        const size_t d = ((size_t)tile << runs.r1_log2) + m;
+        runs.dkey[d] = vkey[k];
+        const uint32_t* mk = raw + (m - r0) * kMaskWords;
+        uint4* dst = reinterpret_cast<uint4*>(runs.masks + d * kMaskWords);
+#pragma unroll
+        for (int q = 0; q < kMaskWords / 4; ++q) dst[q] = make_uint4(mk[4 * q], mk[4 * q + 1], mk[4 * q + 2], mk[4 * q + 3]);
+      }
+    }
+    if (tid == 0) S.run_total = nruns;
+  }
+  // ---- tile epilogue: run and visit counts
+  __syncthreads();                                                                          // ---- barrier 5
+  if (tid == 0) {
+    runs.run_cnt[tile] = min(S.run_total, 1u << runs.r1_log2);
+    out.tile_visits[tile] = S.vis_total;
+  }
 }
 
 // ------------------------------------------------------------------ segments -> chunk order
