@@ -291,6 +291,7 @@ def main():
         from tests import oracle_lib
         oracle = oracle_lib.load()
         ora = oracle.chisel(args.resolution)
+        ora.track_exact()   # the exact (double) mean of the same visits beside the reference's f32 running mean
         t0 = time.perf_counter()
         cv = 0
         for s in range(total_steps):
@@ -299,24 +300,59 @@ def main():
                 ora.integrate(k["xyz"], k["rgb"], k["kfid"], k["Twc"])
                 cv += ora.last_visits()
         ct = time.perf_counter() - t0
-        result["cpu_baseline"] = {
+        port = {
             "value": round(cv / ct / 1e6, 3), "unit": "Mvoxels/s", "cores": 1, "kind": "port",
-            "sample": f"oracle/tsdf_chisel.c (the reference's sequential loop, gcc -O3 -march=native -ffp-contract=off) on "
-                      f"the same {total_steps * args.batch} keyframes the device integrated, {ct:.1f} s, host has "
-                      f"{os.cpu_count()} cores",
+            "sample": f"oracle/tsdf_chisel.c (the reference's sequential loop, gcc -O3 -march=x86-64-v3 -ffp-contract=off, "
+                      f"with the exact-mean accumulators of the parity check on) over the same "
+                      f"{total_steps * args.batch} keyframes the device integrated, {ct:.1f} s, host has {os.cpu_count()} cores",
         }
+        result["cpu_baseline"] = port
+        # ... and the reference ITSELF where its compiled library travelled with the snapshot: all of open_chisel built
+        # unmodified with the reference's flags (oracle/ref/Makefile -> oracle/_ref/libchisel_full_ref_o3.so), on a
+        # bounded sample of the same stream (the reference integrates one voxel per unordered_map look-up)
+        ref_so = os.path.join(ROOT, "oracle", "_ref", "libchisel_full_ref_o3.so")
+        if os.path.exists(ref_so):
+            import tests.test_oracle_pinned_chisel_map as pinned
+            pinned.REF = ref_so
+            from plvs_amd.synth_scene import TUM1
+            refmap = pinned.RefChisel(args.resolution, dict(TUM1))
+            nref = min(total_steps * args.batch, 120)
+            for j in range(5):
+                k = kfs[j % n_poses]
+                refmap.integrate(k["xyz"], k["rgb"], k["kfid"], k["Twc"])
+            t0 = time.perf_counter()
+            rv = 0
+            for j in range(nref):
+                k = kfs[(5 + j) % n_poses]
+                refmap.integrate(k["xyz"], k["rgb"], k["kfid"], k["Twc"])
+            rt = time.perf_counter() - t0
+            # (the reference exposes no visit counter: the visits of the same keyframes as the port counted them)
+            probe = oracle.chisel(args.resolution)
+            for j in range(nref):
+                k = kfs[(5 + j) % n_poses]
+                probe.integrate(k["xyz"], k["rgb"], k["kfid"], k["Twc"])
+                rv += probe.last_visits()
+            probe.close()
+            refmap.close()
+            result["cpu_baseline"] = {
+                "value": round(rv / rt / 1e6, 3), "unit": "Mvoxels/s", "cores": 1, "kind": "reference",
+                "sample": f"chisel::Chisel::IntegratePointCloudWidthDepth of the reference's own open_chisel sources (g++ -O3 "
+                          f"-march=x86-64-v3 as its CMakeLists asks, oracle/_ref/libchisel_full_ref_o3.so) over {nref} keyframes "
+                          f"of the same stream after 5 warm-up keyframes, {rt:.1f} s, 1 thread (the reference is sequential), "
+                          f"host has {os.cpu_count()} cores",
+                "port": port,
+            }
 
         def deviations(dev, exact):
             ids = {tuple(c) for c in ora.chunk_ids()}
             if ids != {tuple(c) for c in dev.chunk_ids()}:
                 return {"ok": False, "why": "chunk sets differ"}
-            # Order-free mode: the reference adds the w_u of a voxel one by one in f32 (and re-rounds the mean
-            # after every visit); after N visits that sum has drifted from the exact one by up to N * 2^-24
-            # relative.  The order-free mode rounds once per call, so it is compared within the tolerance of
-            # the tests (2e-5 m, 5e-5) or the reference's own drift bound for the visits a voxel has taken,
-            # whichever is larger: N <= W / w_min with w_min = 1 / (2 * truncation(5 m)) = 2.0, i.e.
-            # |dW| / W <= W * 2^-25 and |dsdf| <= W * 2^-25 * truncation.
-            ws = ww = wr = 0.0
+            # Order-free mode.  Stated tolerance: |dsdf| <= 2e-5 m, |dW| / W <= 5e-5 (tests/test_tsdf_chisel.py) — against
+            # the EXACT mean of the visits, sum(w_u u) / sum(w_u) in double over the reference's own u and membership.
+            # The reference's f32 running mean itself drifts from that mean (every visit re-rounds sdf and W; after N
+            # visits by up to ~N * 2^-24 relative), so after thousands of visits per voxel the distance between the two
+            # f32 results is dominated by the reference's drift: both distances are reported, per voxel maxima.
+            ws = ww = rs = rw = ds_ref = dw_ref = 0.0
             for cid in ids:
                 a, b = ora.get_chunk(*cid), dev.get_chunk(*cid)
                 if not (np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])):
@@ -329,19 +365,21 @@ def main():
                             np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))):
                         return {"ok": False, "why": f"sdf / weight bits differ in chunk {cid}"}
                 elif known.any():
-                    ds = np.abs(a[0][known] - b[0][known])
-                    dw = np.abs(a[1][known] - b[1][known]) / a[1][known]
-                    drift = a[1][known].astype(np.float64) * 2.0 ** -25
-                    ws = max(ws, float(ds.max()))
-                    ww = max(ww, float(dw.max()))
-                    wr = max(wr, float((ds / np.maximum(2e-5, drift * 0.25)).max()), float((dw / np.maximum(5e-5, drift)).max()))
+                    xs, xw = ora.get_chunk_exact(*cid)
+                    ws = max(ws, float(np.abs(b[0][known] - xs[known]).max()))
+                    ww = max(ww, float((np.abs(b[1][known] - xw[known]) / xw[known]).max()))
+                    rs = max(rs, float(np.abs(a[0][known] - xs[known]).max()))
+                    rw = max(rw, float((np.abs(a[1][known] - xw[known]) / xw[known]).max()))
+                    ds_ref = max(ds_ref, float(np.abs(a[0][known] - b[0][known]).max()))
+                    dw_ref = max(dw_ref, float((np.abs(a[1][known] - b[1][known]) / a[1][known]).max()))
             if exact:
                 return {"ok": True, "chunks": len(ids), "sdf_weight": "bit-identical", "kfid_colour": "identical"}
-            return {"ok": wr <= 1.0, "chunks": len(ids), "max_abs_sdf_m": ws, "max_rel_weight": ww,
-                    "max_deviation_over_tolerance": wr,
-                    "tolerance": "per voxel max(2e-5 m, W * 2^-25 * 0.25 m) and max(5e-5, W * 2^-25) relative: the test "
-                                 "tolerance or the drift bound of the reference's own sequential f32 sums after the W / 2 "
-                                 "visits the voxel has taken, whichever is larger", "kfid_colour": "identical"}
+            return {"ok": ws <= 2e-5 and ww <= 5e-5, "chunks": len(ids),
+                    "tolerance": "|dsdf| <= 2e-5 m and |dW| / W <= 5e-5 against the exact (f64) mean of the same visits",
+                    "order_free_vs_exact_mean": {"max_abs_sdf_m": ws, "max_rel_weight": ww},
+                    "reference_f32_vs_exact_mean": {"max_abs_sdf_m": rs, "max_rel_weight": rw},
+                    "order_free_vs_reference_f32": {"max_abs_sdf_m": ds_ref, "max_rel_weight": dw_ref},
+                    "kfid_colour": "identical", "observed_voxels": "identical"}
 
         checks = {("bit_exact_mode" if args.ordered else "order_free_mode"): deviations(tsdf, args.ordered)}
         if t2 is not None:

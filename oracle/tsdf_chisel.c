@@ -58,6 +58,11 @@ typedef struct {
   float* weight;  /* DistVoxel::weight, init 0  */
   uint32_t* kfid; /* DistVoxel::kfid, init 0    */
   uint32_t* rgbw; /* ColorVoxel r | g<<8 | b<<16 | weight<<24, init 0 */
+  /* the EXACT mean of the same visits, kept beside the reference's f32 running mean when oracle_chisel_track_exact is
+   * on: sum of w_u * u and sum of w_u in double (the membership |u| < truncation and every u are the reference's own
+   * f32 values).  A checker of both the reference's sequential f32 drift and the order-free mode's rounding. */
+  double* x_wu;
+  double* x_w;
 } chunk_t;
 
 typedef struct oracle_chisel {
@@ -73,6 +78,7 @@ typedef struct oracle_chisel {
   int32_t last_new, last_updated;
   /* every raycast voxel's chunk id, in visiting order (GetOrCreateChunkAt is called for each, Chisel.cpp:505):
    * what oracle/tsdf_chisel_deform.cpp needs to keep the reference's std::unordered_map order */
+  int track_exact;
   void (*visit_hook)(void* ctx, const int32_t id[3]);
   void* visit_hook_ctx;
   int32_t hook_last[3];
@@ -120,6 +126,11 @@ static chunk_t* chunk_create(oracle_chisel* o, const int32_t id[3]) {
   c->kfid = (uint32_t*)calloc(CHUNK_VOX, sizeof(uint32_t));
   c->rgbw = (uint32_t*)calloc(CHUNK_VOX, sizeof(uint32_t));
   for (int i = 0; i < CHUNK_VOX; i++) c->sdf[i] = 99999.0f;
+  c->x_wu = c->x_w = NULL;
+  if (o->track_exact) {
+    c->x_wu = (double*)calloc(CHUNK_VOX, sizeof(double));
+    c->x_w = (double*)calloc(CHUNK_VOX, sizeof(double));
+  }
   o->count++;
   return c;
 }
@@ -143,6 +154,7 @@ void oracle_chisel_clear(oracle_chisel* o) {
   for (size_t i = 0; i < o->cap; i++)
     if (o->tab[i].used) {
       free(o->tab[i].sdf); free(o->tab[i].weight); free(o->tab[i].kfid); free(o->tab[i].rgbw);
+      free(o->tab[i].x_wu); free(o->tab[i].x_w);
     }
   memset(o->tab, 0, o->cap * sizeof(chunk_t));
   o->count = 0;
@@ -336,6 +348,10 @@ static void visit(void* vctx, int vx, int vy, int vz) {
     c->last = ch;
   }
   dist_integrate(&ch->sdf[vid], &ch->weight[vid], u, weight);
+  if (ch->x_w) {   /* the exact mean of the same visits (products and sums in double) */
+    ch->x_wu[vid] += (double)weight * (double)u;
+    ch->x_w[vid] += (double)weight;
+  }
   ch->kfid[vid] = c->kfid; /* SetKfid, USE_KFID_INTEGRATION 0 */
   ch->rgbw[vid] = c->dir ? colour_integrate(ch->rgbw[vid], c->r, c->g, c->b, 1)          /* :338 */
                          : colour_integrate_simple(ch->rgbw[vid], c->r, c->g, c->b, 1);  /* :536 */
@@ -455,6 +471,23 @@ void oracle_chisel_chunk_ids(const oracle_chisel* o, int32_t* ids) {
   size_t k = 0;
   for (size_t i = 0; i < o->cap; i++)
     if (o->tab[i].used) { memcpy(ids + 3 * k, o->tab[i].id, 3 * sizeof(int32_t)); k++; }
+}
+
+/* Turn the exact (double) accumulators on: for maps that start empty (chunks created afterwards carry them). */
+void oracle_chisel_track_exact(oracle_chisel* o, int on) { o->track_exact = on; }
+
+/* sdf = sum(w_u u) / sum(w_u) and W = sum(w_u) of every voxel of the chunk in double; 0 where the voxel is unknown.
+ * Returns 0 if the chunk does not exist or carries no exact accumulators. */
+int oracle_chisel_get_chunk_exact(const oracle_chisel* o, int cx, int cy, int cz, double* sdf, double* weight) {
+  const int32_t id[3] = {cx, cy, cz};
+  int found;
+  chunk_t* c = tab_find(o->tab, o->cap, id, &found);
+  if (!found || !c->x_w) return 0;
+  for (int i = 0; i < CHUNK_VOX; i++) {
+    weight[i] = c->x_w[i];
+    sdf[i] = c->x_w[i] > 0 ? c->x_wu[i] / c->x_w[i] : 0.0;
+  }
+  return 1;
 }
 
 int oracle_chisel_get_chunk(const oracle_chisel* o, int cx, int cy, int cz, float* sdf,

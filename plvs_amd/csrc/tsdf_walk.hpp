@@ -201,6 +201,19 @@ struct WalkShared {       // LDS state of walk_tiles
   uint32_t wsum[kWalkRays / 64];
   uint32_t next, nrays;   // rays of the tile not yet handed out as sub-tiles / rays of the tile
 };
+struct FastShared {       // LDS state of walk_fast: WalkShared without the sub-tile stack (four tiles per CU: 40 KiB each)
+  alignas(16) uint32_t ekey[kWalkEntries];
+  uint32_t cand[kWalkRays / 64];
+  int32_t worg[kWalkRays / 64][3];
+  uint32_t run_total, vis_total;
+  uint32_t ccode[kWalkChunks];
+  int32_t cslot[kWalkChunks];
+  uint32_t ccnt[kWalkChunks * kSlabs];
+  uint16_t cbase[kWalkChunks * kSlabs];
+  uint32_t nent, overflow;
+  uint32_t wsum[kWalkRays / 64];
+};
+
 
 // Key of a voxel relative to the origin; false if it lies outside the 1024^3 box of the keys.
 __device__ __forceinline__ bool rel_key(int vx, int vy, int vz, int ox, int oy, int oz, uint32_t* key) {
@@ -222,8 +235,32 @@ __device__ __forceinline__ void chunk_of_code(uint32_t code, int ox, int oy, int
   *cy = (oy >> 4) + (int)((code >> 14) & 63u);
   *cz = (oz >> 4) + (int)((code >> 24) & 63u);
 }
-__device__ __forceinline__ uint32_t key_bucket(uint32_t key) { return (key * 2654435761u) >> 24; }
+// The table stores a voxel key MULTIPLIED by an odd constant ("table key", a bijection of the 32-bit words): its top
+// eight bits are the home bucket, and since the walk moves the key by one of three constants per voxel step the
+// table key moves by one of three constants too — the voxel loop carries the table key alone and never multiplies
+// (v_mul_lo_u32 issues at a quarter of the rate of an add).  No voxel key maps to kKeyEmpty (0xF174D0AF would: keys
+// have 30 bits).
+constexpr uint32_t kKeyMul = 2654435761u, kKeyMulInv = 0x0E8B2F51u;
+static_assert((uint32_t)(kKeyMul * kKeyMulInv) == 1u, "inverse of the table-key multiplier");
+__device__ __forceinline__ uint32_t table_key(uint32_t key) { return key * kKeyMul; }
+__device__ __forceinline__ uint32_t voxel_key(uint32_t tkey) { return tkey * kKeyMulInv; }
+__device__ __forceinline__ uint32_t key_bucket(uint32_t tkey) { return tkey >> 24; }
 static_assert(kBuckets == 256, "key_bucket yields 8 bits");
+
+// Inclusive prefix sum over the 64 lanes of a wave by DPP (row shifts inside the rows of 16, then the row broadcasts):
+// six VALU instructions, no LDS traffic (a __shfl_up is a ds_bpermute_b32 through the LDS crossbar).
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+  return x;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x) {   // (a scalar: the last lane of the scan)
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(x), 63);
+}
 
 // position of `want` among the four keys of a bucket, -1 if absent.  All four comparisons feed the result, so the
 // bucket is ONE ds_read_b128 (a short-circuit form makes the compiler read the first key alone and branch).
@@ -239,7 +276,8 @@ __device__ __forceinline__ int bucket_match(const uint4 k4, uint32_t want) {
 // a first touch (the bucket, the compare-and-swap): every wave step of the walk has a few lanes on this path and
 // the step is as slow as its slowest lane.  Entries are not counted here — the flush counts them (entries beyond
 // kWalkLimit: the (sub-)tile is cut, as when the table is full).
-__device__ __forceinline__ int table_find_or_insert(WalkShared& S, uint32_t key) {
+template <class SH>
+__device__ __forceinline__ int table_find_or_insert(SH& S, uint32_t key /* a table key */) {
   uint32_t b = key_bucket(key);
   for (int probe = 0; probe < 4 * kBuckets; ++probe) {
     const uint4 k4 = *reinterpret_cast<const uint4*>(&S.ekey[4 * b]);
@@ -256,8 +294,9 @@ __device__ __forceinline__ int table_find_or_insert(WalkShared& S, uint32_t key)
   S.overflow = 1u;
   return -1;
 }
-// Entry of a key that is known to be in the table.
-__device__ __forceinline__ int table_find(const WalkShared& S, uint32_t key) {
+// Entry of a (table) key that is known to be in the table.
+template <class SH>
+__device__ __forceinline__ int table_find(const SH& S, uint32_t key) {
   uint32_t b = key_bucket(key);
   for (int probe = 0; probe < kBuckets; ++probe) {
     const int j = bucket_match(*reinterpret_cast<const uint4*>(&S.ekey[4 * b]), key);
@@ -403,8 +442,8 @@ __device__ __forceinline__ int lean_reach(const Ray& ray) {   // how far (in vox
   const float maxDist = sqnorm3(ray.end[0] - ray.start[0], ray.end[1] - ray.start[1], ray.end[2] - ray.start[2]);
   return (int)(__builtin_amdgcn_sqrtf(maxDist)) + 3;
 }
-template <bool kAcc, bool kRuns>
-__device__ __forceinline__ uint32_t walk_lean(const Params& P, const Pose& pose, const Ray& ray, WalkShared& S, int ox, int oy,
+template <bool kAcc, bool kRuns, class SH>
+__device__ __forceinline__ uint32_t walk_lean(const Params& P, const Pose& pose, const Ray& ray, SH& S, int ox, int oy,
                                               int oz, int tid, float wu_scaled, uint32_t q_w, int32_t* e_wuu,
                                               unsigned long long* e_wc, uint32_t* e_last, uint16_t* vlog) {
   RayCursor cur;
@@ -412,9 +451,10 @@ __device__ __forceinline__ uint32_t walk_lean(const Params& P, const Pose& pose,
   if (cur.done) return 0u;   // start voxel == end voxel: Raycast.cpp emits nothing
   LeanRay L;
   lean_ray(P, pose, ray, &L);
-  uint32_t key = (uint32_t)(cur.x - ox) | ((uint32_t)(cur.y - oy) << 10) | ((uint32_t)(cur.z - oz) << 20);
-  const uint32_t endkey = (uint32_t)(cur.endX - ox) | ((uint32_t)(cur.endY - oy) << 10) | ((uint32_t)(cur.endZ - oz) << 20);
-  const uint32_t kx = (uint32_t)cur.stepX, ky = (uint32_t)cur.stepY << 10, kz = (uint32_t)cur.stepZ << 20;
+  // (table keys: see key_bucket)
+  uint32_t key = table_key((uint32_t)(cur.x - ox) | ((uint32_t)(cur.y - oy) << 10) | ((uint32_t)(cur.z - oz) << 20));
+  const uint32_t endkey = table_key((uint32_t)(cur.endX - ox) | ((uint32_t)(cur.endY - oy) << 10) | ((uint32_t)(cur.endZ - oz) << 20));
+  const uint32_t kx = table_key((uint32_t)cur.stepX), ky = table_key((uint32_t)cur.stepY << 10), kz = table_key((uint32_t)cur.stepZ << 20);
   float fx = (float)cur.x, fy = (float)cur.y, fz = (float)cur.z;
   const float sfx = (float)cur.stepX, sfy = (float)cur.stepY, sfz = (float)cur.stepZ;
   float tmx = cur.tMaxX, tmy = cur.tMaxY, tmz = cur.tMaxZ;
@@ -467,7 +507,8 @@ __device__ __forceinline__ bool tile_ray(const Params& P, const float* __restric
   return true;
 }
 
-__device__ __forceinline__ void subtile_reset(WalkShared& S, int tid) {
+template <class SH>
+__device__ __forceinline__ void subtile_reset(SH& S, int tid) {
 #pragma unroll
   for (int k = 0; k < kWalkEntries / kWalkRays; ++k) S.ekey[tid + k * kWalkRays] = kKeyEmpty;
   if (tid < kWalkChunks) {
@@ -499,7 +540,8 @@ __device__ __forceinline__ void subtile_split(WalkShared& S, const SubTile st) {
 
 // Cache index of a chunk (by its code) among the (sub-)tile's chunks; -1: the cache is full.  *won: this call
 // created the entry.
-__device__ __forceinline__ int chunk_cache_insert(WalkShared& S, uint32_t code, bool* won) {
+template <class SH>
+__device__ __forceinline__ int chunk_cache_insert(SH& S, uint32_t code, bool* won) {
   uint32_t h = (code * 2654435761u) >> 26;
   static_assert(kWalkChunks == 64, "the hash yields 6 bits");
   *won = false;
@@ -743,7 +785,7 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
           S.overflow = 1u;
           return false;
         }
-        const int e = table_find_or_insert(S, key);
+        const int e = table_find_or_insert(S, table_key(key));
         if (e < 0) return false;
         if (kRuns && k < (uint32_t)kLogLen) vlog[k * kWalkRays + tid] = (uint16_t)e;
         if (kAcc) {
@@ -767,6 +809,7 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
       for (int k = 0; k < kPer; ++k) {
         ekey[k] = S.ekey[tid + k * kWalkRays];
         mine += ekey[k] != kKeyEmpty ? 1u : 0u;
+        if (ekey[k] != kKeyEmpty) ekey[k] = voxel_key(ekey[k]);   // (the table holds table keys)
       }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) mine += (uint32_t)__shfl_xor((int)mine, off);
@@ -1015,7 +1058,7 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
           walk_one(P, pose, ray, st.vlo, st.vhi, [&](uint32_t k, int vx, int vy, int vz, float) {
             if (k >= (uint32_t)kLogLen) {
               uint32_t key;
-              const int e = rel_key(vx, vy, vz, fox, foy, foz, &key) ? table_find(S, key) : -1;
+              const int e = rel_key(vx, vy, vz, fox, foy, foz, &key) ? table_find(S, table_key(key)) : -1;
               const uint32_t m = e >= 0 ? (uint32_t)e_midx[e] - r0 : 0xFFFFFFFFu;
               if (m < (uint32_t)kMaskCap) atomicOr(&raw[m * kMaskWords + (tid >> 5)], 1u << (tid & 31));
             }
@@ -1069,16 +1112,21 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
 // that does not qualify is DEFERRED: nothing of it has reached global memory when that is known (records, segments,
 // runs and directory inserts all happen in the flush), its index goes to a list and walk_tiles (the general kernel)
 // walks the list behind this kernel.  Same outputs, same regions, bit for bit the same records either way.
-__global__ __launch_bounds__(kWalkRays, 6) void walk_fast(
+#ifndef PLVS_WALK_FAST_WAVES
+#define PLVS_WALK_FAST_WAVES 6
+#endif
+__global__ __launch_bounds__(kWalkRays, PLVS_WALK_FAST_WAVES) void walk_fast(
     Params P, float scale_u, float scale_w, const float* __restrict__ xyz, int npoints,
     const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
     int32_t* __restrict__ num_chunks, WalkCounters* __restrict__ ctr, const uint32_t* __restrict__ rgbw,
     const uint32_t* __restrict__ sat, AccOut out, RunOut runs, TileMap tmap, uint32_t* __restrict__ deferred) {
   constexpr int kPer = kWalkEntries / kWalkRays;
-  __shared__ WalkShared S;
+  __shared__ FastShared S;
   __shared__ uint32_t raw[kMaskCap * kMaskWords];              // accumulators during the walk, ray masks afterwards
   __shared__ uint16_t vlog[kLogLen * kWalkRays];        // entry of visit k of ray r at [k * kWalkRays + r]
-  __shared__ uint16_t e_midx[kWalkEntries];           // mask index of the entry (0xFFFF: none)
+  // mask index of the entry (0xFFFF: none) — in the words of the (chunk, slab) counters, dead once the records are out
+  uint16_t* const e_midx = reinterpret_cast<uint16_t*>(S.ccnt);
+  static_assert(sizeof(S.ccnt) >= kWalkEntries * sizeof(uint16_t), "e_midx overlays ccnt");
   int32_t* const e_wuu = reinterpret_cast<int32_t*>(raw);                                 // sum of w_u * u, fixed point
   unsigned long long* const e_wc = reinterpret_cast<unsigned long long*>(raw + kWalkEntries);   // visits << 32 | sum of w_u
   uint32_t* const e_last = raw + 3 * kWalkEntries;                                        // last visiting ray
@@ -1156,15 +1204,24 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_fast(
       ray_begin(ray, &cur);   // (walk_lean's own ray_begin is this one: common subexpression)
       if (won_s && dir_peek_slot(peek_s) >= 0) S.cslot[ci_s] = dir_peek_slot(peek_s);
       if (won_e && dir_peek_slot(peek_e) >= 0) S.cslot[ci_e] = dir_peek_slot(peek_e);
+#if !(PLVS_WALK_EXP & 32)   // (bit 32, timing experiment: no voxel loop)
       nv = walk_lean<true, true>(P, pose, ray, S, ox, oy, oz, tid, wu * scale_u, (uint32_t)__float2int_rn(wu * scale_w), e_wuu,
                                  e_wc, e_last, vlog);
+#endif
     }
   }
+#if (PLVS_WALK_EXP & 16)   // (bit 16, timing experiment: no flush)
+  if (tid == 0) { out.seg_cnt[tile] = 0; runs.run_cnt[tile] = 0; out.tile_visits[tile] = nv; }
+  return;
+#endif
   uint32_t ekey[kPer];
   if (!defer) {   // entries in use (nobody counts them during the walk)
     __syncthreads();                                                                        // ---- barrier 2
 #pragma unroll
-    for (int k = 0; k < kPer; ++k) ekey[k] = S.ekey[tid + k * kWalkRays];
+    for (int k = 0; k < kPer; ++k) {
+      ekey[k] = S.ekey[tid + k * kWalkRays];
+      if (ekey[k] != kKeyEmpty) ekey[k] = voxel_key(ekey[k]);   // (the table holds table keys)
+    }
     static_assert(kPer == 2, "two entries per thread");
     const uint32_t wave_n = (uint32_t)__popcll(__ballot(ekey[0] != kKeyEmpty)) + (uint32_t)__popcll(__ballot(ekey[1] != kKeyEmpty));
     if (lane == 0 && wave_n) atomicAdd(&S.nent, wave_n);
@@ -1211,9 +1268,7 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_fast(
     return;
   }
   {   // visits of the tile
-    uint32_t v = nv;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off);
+    const uint32_t v = wave_sum(nv);
     if (lane == 0 && v) atomicAdd(&S.vis_total, v);
   }
   // ---- ranks inside the (chunk, slab) groups, colour weights
@@ -1255,16 +1310,13 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_fast(
       sub[s] = c;
       c += S.ccnt[lane * kSlabs + s];
     }
-    uint32_t inc = c, sinc = c ? 1u : 0u;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t up = (uint32_t)__shfl_up((int)inc, off), sup = (uint32_t)__shfl_up((int)sinc, off);
-      if (lane >= off) { inc += up; sinc += sup; }
-    }
+    // (records and segments in one scan: a chunk holds at most 1024 entries of the tile)
+    const uint32_t both = wave_scan_incl(c | (c ? 1u << 16 : 0u));
+    const uint32_t inc = both & 0xFFFFu, sinc = both >> 16;
 #pragma unroll
     for (int s = 0; s < kSlabs; ++s) S.cbase[lane * kSlabs + s] = (uint16_t)(inc - c + sub[s]);
     if (wid == 0) {
-      const uint32_t stot = (uint32_t)__shfl((int)sinc, 63);
+      const uint32_t stot = (uint32_t)__builtin_amdgcn_readlane((int)sinc, 63);
       if (lane == 0) out.seg_cnt[tile] = stot;
       if (c) {
         const uint32_t sg = tile * (uint32_t)kWalkChunks + sinc - 1u;
@@ -1282,38 +1334,35 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_fast(
     out.rec[rbase + S.cbase[ci[k] * kSlabs + (int)(vid / kSlabVox)] + rank[k]] = r;
   }
   // ---- runs: number the entries that need one (wave by wave)
-  uint32_t inc = nneed;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
-    if (lane >= off) inc += up;
-  }
-  const uint32_t wave_runs = (uint32_t)__shfl((int)inc, 63);
+  const uint32_t inc = wave_scan_incl(nneed);
+  const uint32_t wave_runs = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
   if (!any_multi) {
     // every voxel that needs a run has ONE visiting ray — the steady state of a map whose colours have mostly
     // saturated: what is still below 254 is what few rays reach — and the accumulator named it (e_last): the mask is
     // that one bit, no pass over the visit logs.  The tile's run slots are handed out wave by wave (the order of a
     // tile's runs among themselves is immaterial: they are runs of different voxels), no barrier.
-    uint32_t base = 0;
-    if (lane == 0 && wave_runs) base = atomicAdd(&S.run_total, wave_runs);
-    base = (uint32_t)__shfl((int)base, 0);
-    const bool fits_runs = base + wave_runs <= (1u << runs.r1_log2);
-    if (!fits_runs && lane == 0) {
-      atomicOr(&ctr->err, kErrScratch);
-      atomicMax(&ctr->run_need, base + wave_runs);   // (the largest of these is the tile's total)
-    }
-    uint32_t m = base + inc - nneed;
+    if (wave_runs) {   // (uniform over the wave)
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&S.run_total, wave_runs);
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      const bool fits_runs = base + wave_runs <= (1u << runs.r1_log2);
+      if (!fits_runs && lane == 0) {
+        atomicOr(&ctr->err, kErrScratch);
+        atomicMax(&ctr->run_need, base + wave_runs);   // (the largest of these is the tile's total)
+      }
+      uint32_t m = base + inc - nneed;
 #pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      if (!(need & (1u << k)) || !fits_runs) continue;
-      const size_t d = ((size_t)tile << runs.r1_log2) + m++;
-      runs.dkey[d] = vkey[k];
-      uint4* dst = reinterpret_cast<uint4*>(runs.masks + d * kMaskWords);
-      const uint32_t word = elast[k] >> 5, bit = 1u << (elast[k] & 31u);
+      for (int k = 0; k < kPer; ++k) {
+        if (!(need & (1u << k)) || !fits_runs) continue;
+        const size_t d = ((size_t)tile << runs.r1_log2) + m++;
+        runs.dkey[d] = vkey[k];
+        uint4* dst = reinterpret_cast<uint4*>(runs.masks + d * kMaskWords);
+        const uint32_t word = elast[k] >> 5, bit = 1u << (elast[k] & 31u);
 #pragma unroll
-      for (int q = 0; q < kMaskWords / 4; ++q)
-        dst[q] = make_uint4(word == 4u * q ? bit : 0u, word == 4u * q + 1u ? bit : 0u, word == 4u * q + 2u ? bit : 0u,
-                            word == 4u * q + 3u ? bit : 0u);
+        for (int q = 0; q < kMaskWords / 4; ++q)
+          dst[q] = make_uint4(word == 4u * q ? bit : 0u, word == 4u * q + 1u ? bit : 0u, word == 4u * q + 2u ? bit : 0u,
+                              word == 4u * q + 3u ? bit : 0u);
+      }
     }
   } else {
     // the masks come from the visit logs: bit r of a voxel's mask = ray r of the tile visits it
@@ -1354,7 +1403,7 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_fast(
             walk_one(P, pose, ray, 0u, 0xFFFFFFFFu, [&](uint32_t k, int vx, int vy, int vz, float) {
               if (k >= (uint32_t)kLogLen) {
                 uint32_t key;
-                const int e = rel_key(vx, vy, vz, ox, oy, oz, &key) ? table_find(S, key) : -1;
+                const int e = rel_key(vx, vy, vz, ox, oy, oz, &key) ? table_find(S, table_key(key)) : -1;
                 const uint32_t m = e >= 0 ? (uint32_t)e_midx[e] - r0 : 0xFFFFFFFFu;
                 if (m < (uint32_t)kMaskCap) atomicOr(&raw[m * kMaskWords + (tid >> 5)], 1u << (tid & 31));
               }

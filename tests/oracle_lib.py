@@ -403,6 +403,23 @@ class _ChiselLike:
     def last_visits(self):
         return int(getattr(self.lib, self.p + "_last_visits")(self.h))
 
+    # ---- the exact (double) mean of the same visits beside the reference's f32 running mean (oracle only)
+    def track_exact(self, on=True):
+        f = getattr(self.lib, self.p + "_track_exact")
+        f.restype = None
+        f.argtypes = [_vp, _i]
+        f(self.h, int(on))
+
+    def get_chunk_exact(self, cx, cy, cz):
+        """-> (sdf, weight) [4096] f64: sum(w_u u) / sum(w_u) and sum(w_u) over the visits the map took (0 where unknown)"""
+        f = getattr(self.lib, self.p + "_get_chunk_exact")
+        f.restype = _i
+        f.argtypes = [_vp, _i, _i, _i, _vp, _vp]
+        sdf, w = np.zeros(4096, np.float64), np.zeros(4096, np.float64)
+        ok = f(self.h, int(cx), int(cy), int(cz), _ptr(sdf), _ptr(w))
+        assert ok, "no exact accumulators for this chunk"
+        return sdf, w
+
     # ---- Chisel::Deform (oracle only): the reference's chunk-map order is kept beside the map
     def track_order(self):
         """Attach the std::unordered_map shadow (oracle/tsdf_chisel_deform.cpp) to this (still empty) map; from here on
