@@ -579,11 +579,15 @@ class PointCloudMapVoxblox {
  public:
   using BlockID = std::tuple<int, int, int>;
   // integrationMethod: PointCloudMapping.voxbloxIntegrationMethod (src/PointCloudMapVoxblox.cc:44, :74) — "simple" and
-  // "merged" are on the accelerated path (one-thread schedules of the reference); "fast" is racy by design and refused.
+  // "merged" are on the accelerated path (one-thread schedules of the reference, bit for bit).  "fast" (the YAML default)
+  // is voxblox's lossy speed-up of "simple" — points whose start voxel was seen are dropped, rays stop after two voxels
+  // some ray of the scan already updated — sequential through two approximate hash sets and racy across its threads:
+  // there is no single result to reproduce.  It is SUBSTITUTED by "simple", the integrator it approximates (every ray
+  // cast in full: the map observes a superset of fast's voxels; INTEGRATION.md §4 has the measured difference).
   explicit PointCloudMapVoxblox(float voxelSize, bool useCarving = false, const std::string& integrationMethod = "simple")
-      : merged_(integrationMethod == "merged") {
-    if (integrationMethod != "simple" && integrationMethod != "merged")
-      throw std::runtime_error("plvs_hip: voxblox integration method '" + integrationMethod + "' is not on the accelerated path");
+      : merged_(integrationMethod == "merged"), fast_substituted_(integrationMethod == "fast") {
+    if (integrationMethod != "simple" && integrationMethod != "merged" && integrationMethod != "fast")
+      throw std::runtime_error("plvs_hip: unknown voxblox integration method '" + integrationMethod + "'");
     plvs_tsdf_voxblox_params p;
     check(plvs_hip_tsdf_voxblox_default_params(voxelSize, useCarving ? 1 : 0, &p));
     check(plvs_hip_tsdf_voxblox_create(&p, &h_));
@@ -726,6 +730,7 @@ class PointCloudMapVoxblox {
   }
   plvs_tsdf_voxblox* h_ = nullptr;
   bool merged_ = false;
+  bool fast_substituted_ = false;   // "fast" was asked for: "simple" runs (see the constructor)
   std::vector<float> xyz_;
   std::vector<uint8_t> rgba_;
   std::set<BlockID> updated_;

@@ -27,7 +27,9 @@ struct RefMap {
 
 extern "C" {
 
-// The configuration src/PointCloudMapVoxblox.cc:52-71 builds; method: "simple" or "merged".
+// The configuration src/PointCloudMapVoxblox.cc:52-71 builds; method: "simple", "merged" or "fast" (PLVS's default,
+// src/PointCloudMapVoxblox.cc:44: FastTsdfIntegrator, tsdf_integrator.cc:505-605 — here with ONE thread, which makes its
+// two approximate hash sets deterministic; scripts/voxblox_fast_vs_simple.py measures what it leaves out of the map).
 void* ref_voxblox_create(float voxel_size, float truncation, float max_weight, float min_ray, float max_ray, int carving,
                          const char* method) {
   RefMap* m = new RefMap();
@@ -45,7 +47,11 @@ void* ref_voxblox_create(float voxel_size, float truncation, float max_weight, f
   c.sparsity_compensation_factor = 1.0f;
   c.enable_anti_grazing = false;
   c.integrator_threads = 1;
-  if (std::string(method) == "merged") m->integrator.reset(new voxblox::MergedTsdfIntegrator(c, m->layer.get()));
+  c.start_voxel_subsampling_factor = 2.0f;   // (fast integrator: src/PointCloudMapVoxblox.cc:67-69)
+  c.max_consecutive_ray_collisions = 2;
+  c.clear_checks_every_n_frames = 1;
+  if (std::string(method) == "fast") m->integrator.reset(new voxblox::FastTsdfIntegrator(c, m->layer.get()));
+  else if (std::string(method) == "merged") m->integrator.reset(new voxblox::MergedTsdfIntegrator(c, m->layer.get()));
   else m->integrator.reset(new voxblox::SimpleTsdfIntegrator(c, m->layer.get()));
   return m;
 }

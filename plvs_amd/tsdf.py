@@ -535,11 +535,13 @@ class TsdfVoxblox:
 class PointCloudMapVoxblox:
     """Same surface as PLVS2::PointCloudMapVoxblox for the integrate path
     (src/PointCloudMapVoxblox.cc:48-99)."""
-    skIntegrationMethod = "simple"   # the reference ships "fast", which is racy by design
+    # "simple" and "merged" reproduce the reference's one-thread schedules bit for bit; "fast" (the reference's YAML
+    # default: a lossy, order-dependent, racy speed-up of "simple") is substituted by "simple" (INTEGRATION.md §4)
+    skIntegrationMethod = "simple"
 
     def __init__(self, resolution, use_carving=False, max_blocks=None):
-        if self.skIntegrationMethod not in ("simple", "merged"):
-            raise NotImplementedError("'fast' is racy by design (DESIGN.md §6): 'simple' and 'merged' are on the accelerated path")
+        if self.skIntegrationMethod not in ("simple", "merged", "fast"):
+            raise ValueError(f"unknown voxblox integration method {self.skIntegrationMethod!r}")
         self._tsdf = TsdfVoxblox(resolution, use_carving, max_blocks)
         self._updated = set()        # the blocks whose updated() flag is set
         self.mesh_layer = {}         # block id -> dict(vertices, normals, colors): voxblox::MeshLayer
