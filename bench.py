@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--no-parity-check", action="store_true",
                     help="skip the oracle run over the same sequence (parity check + CPU baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-realistic-legs", action="store_true", help="skip the first-lap and 5-key-frame-call legs")
     ap.add_argument("--no-frontend", action="store_true")
     return ap.parse_args()
 
@@ -250,6 +251,60 @@ def main():
             "roofline": roofline,
         }
 
+    # ------------------------------------------------- what PLVS runs, not only the steady state (N = 1 only)
+    # The headline step re-integrates the same 100 key frames into a map that has seen them: no chunk is allocated,
+    # nearly every colour has saturated.  Two legs with the rest inside the timed region:
+    #  first_lap    a FRESH map takes the 100 key frames in one call: chunk allocation, directory inserts, a run and a
+    #               colour fold for every voxel (all below weight 254)
+    #  updatemap_5  the same stream in calls of 5 key frames — what PointCloudMapping::UpdateMap hands over
+    #               (src/PointCloudMapping.cc:552) — on a fresh map (first lap) and on the map that lap left (second lap)
+    if rank == 0 and world == 1 and not vbx and not multi and not args.no_realistic_legs:
+        tl = TsdfChisel(args.resolution, max_chunks=16384, order_free=not args.ordered)
+        b0 = batches[0]
+
+        def timed_call(t, b):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            t.integrate_batch_dev(*b)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0, t.last_stats()
+
+        laps = []
+        for rep in range(4):          # (the first repetition also sizes the handle's scratch buffers: dropped)
+            tl.clear()
+            dt, st = timed_call(tl, b0)
+            laps.append((dt, st))
+        dt = float(np.median([x[0] for x in laps[1:]]))
+        st = laps[-1][1]
+        legs = {"first_lap": {
+            "what": "one call of 100 key frames into an EMPTY map (median of 3 calls, each on a cleared map)",
+            "ms_per_call": round(dt * 1e3, 3), "value": round(st["visits"] / dt / 1e6, 2), "unit": "Mvoxels/s",
+            "new_chunks": st["new_chunks"], "voxels": st["voxels"],
+            "roofline_frac": round((32.0 * st["visits"] + 28.0 * st["points"]) / dt / 8e12, 5)}}
+        sel = [kfs[j % n_poses] for j in range(100)]
+        small = []
+        for j0 in range(0, 100, 5):
+            grp = sel[j0:j0 + 5]
+            small.append((torch.from_numpy(np.concatenate([k["xyz"] for k in grp])).cuda(),
+                          torch.from_numpy(np.concatenate([k["rgb"] for k in grp])).cuda(),
+                          torch.from_numpy(np.concatenate([k["kfid"] for k in grp]).astype(np.int32)).cuda(),
+                          np.cumsum([0] + [k["xyz"].shape[0] for k in grp]).astype(np.int32),
+                          torch.from_numpy(np.stack([k["Twc"] for k in grp])).cuda()))
+        for lap_name in ("warm-up", "first_lap", "second_lap"):
+            if lap_name != "second_lap":
+                tl.clear()
+            ts, vs = [], 0
+            for b in small:
+                dtc, stc = timed_call(tl, b)
+                ts.append(dtc)
+                vs += stc["visits"]
+            if lap_name != "warm-up":
+                legs.setdefault("updatemap_5", {"what": "20 calls of 5 key frames each (PointCloudMapping::UpdateMap's batch)"})[lap_name] = {
+                    "ms_per_call_median": round(float(np.median(ts)) * 1e3, 4), "ms_per_call_max": round(max(ts) * 1e3, 4),
+                    "value": round(vs / sum(ts) / 1e6, 2), "unit": "Mvoxels/s"}
+        tl.close()
+        result["realistic_legs"] = legs
+
     # ------------------------------------------------- the other chisel mode, same stream (N = 1 only)
     t2 = None
     if rank == 0 and world == 1 and not vbx and not args.no_other_mode_leg:
@@ -310,7 +365,7 @@ def main():
         # ... and the reference ITSELF where its compiled library travelled with the snapshot: all of open_chisel built
         # unmodified with the reference's flags (oracle/ref/Makefile -> oracle/_ref/libchisel_full_ref_o3.so), on a
         # bounded sample of the same stream (the reference integrates one voxel per unordered_map look-up)
-        ref_so = os.path.join(ROOT, "oracle", "_ref", "libchisel_full_ref_o3.so")
+        ref_so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "_ref", "libchisel_full_ref_o3.so")
         if os.path.exists(ref_so):
             import tests.test_oracle_pinned_chisel_map as pinned
             pinned.REF = ref_so

@@ -1940,78 +1940,116 @@ struct RunSrc {
   uint32_t words, r1_log2;
   TileMap tmap;
 };
+constexpr int kFoldGroup = 8;     // voxels a wave folds together (staging: 8 lanes each; fold: 4 lanes each: r, g, b, idle)
+constexpr int kFoldSteps = 256;   // >= 254: the visits that can still count for a voxel
 __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
     const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ sorted_val, const uint32_t* __restrict__ nd_dev,
     RunSrc src, const uint32_t* __restrict__ vj0, const uint8_t* __restrict__ rgb, uint32_t* __restrict__ rgbw,
     const uint32_t* __restrict__ num_heads, uint32_t* __restrict__ sat_list, uint32_t* __restrict__ sat_count) {
   // sat_list (ray-sharded integrate): the voxels whose colour weight reaches 254 in this call
-  __shared__ uint32_t stage[kFoldWaves][256];
+  // A wave takes kFoldGroup voxels of the head list at a time.
+  //  staging  eight lanes per voxel, one lane per RUN, eight runs of every voxel at a time: the lane reads its run's ray
+  //           mask and writes the colours of its rays — bits ascending = point order — into the stage of its voxel, at
+  //           the place a prefix sum over the voxel's eight lanes gives it (runs of a voxel in tile order: the stable
+  //           sort kept it); only the first 254 - weight visits of a voxel count, a voxel that has them stops reading.
+  //           64 independent mask and colour loads in flight per step.
+  //  fold     four lanes per voxel (r, g, b, -): ColorVoxel::IntegrateSimple visit by visit, 1 / (1 + weight) from a
+  //           table of the 254 quotients the reference's division can produce.
+  // (The first version gave a whole wave to ONE voxel and folded on three of its lanes: the 60 000 voxels of a
+  // 5-key-frame call on a young map took 81 us, nearly all of it the serial chains at 3 / 64 lanes.)
+  __shared__ uint32_t stage[kFoldWaves][kFoldGroup][kFoldSteps];
+  __shared__ float rcp[256];
+  __shared__ uint32_t have[kFoldWaves][kFoldGroup];
+  for (int k = threadIdx.x; k < 256; k += blockDim.x) rcp[k] = 1.f / (float)(1u + (uint32_t)k);
+  __syncthreads();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const uint32_t nvox = *num_heads, nd = *nd_dev;
-  const uint32_t nwaves = gridDim.x * kFoldWaves;
-  for (uint32_t v = blockIdx.x * kFoldWaves + wid; v < nvox; v += nwaves) {
-    const uint32_t j0 = vj0[v];
-    const uint32_t key = skeys[j0];
-    const uint32_t col0 = rgbw[key];
-    const uint32_t cw0 = col0 >> 24;
-    if (cw0 >= 254u) continue;
-    const uint32_t need = 254u - cw0;   // visits that still count
-    uint32_t have = 0;                  // visits staged so far
-    for (uint32_t jb = j0; have < need; jb += 64) {
-      const uint32_t j = jb + (uint32_t)lane;
-      const bool mine = j < nd && skeys[j] == key;
-      uint32_t m[kMaskWords];
+  const uint32_t ngroups = (nvox + kFoldGroup - 1) / kFoldGroup, nwaves = gridDim.x * kFoldWaves;
+  for (uint32_t grp = blockIdx.x * kFoldWaves + wid; grp < ngroups; grp += nwaves) {
+    const uint32_t v0 = grp * kFoldGroup, nv = min((uint32_t)kFoldGroup, nvox - v0);
+    // ---- the group's voxels: lane i < nv holds voxel v0 + i
+    uint32_t my_j0 = nd, my_key = 0, my_col = 0xFF000000u;
+    if ((uint32_t)lane < nv) {
+      my_j0 = vj0[v0 + lane];
+      my_key = skeys[my_j0];
+      my_col = rgbw[my_key];
+    }
+    // ---- staging: lanes 8 v .. 8 v + 7 work on voxel v
+    {
+      const int vl = lane >> 3, sub = lane & 7;
+      const uint32_t j0v = (uint32_t)__shfl((int)my_j0, vl), keyv = (uint32_t)__shfl((int)my_key, vl);
+      const uint32_t cwv = (uint32_t)__shfl((int)my_col, vl) >> 24;
+      const uint32_t needv = cwv >= 254u ? 0u : 254u - cwv;
+      uint32_t havev = 0;
+      bool open = (uint32_t)vl < nv && needv > 0u;
+      for (uint32_t jb = 0; __any(open); jb += 8) {
+        const uint32_t j = j0v + jb + (uint32_t)sub;
+        const bool mine = open && j < nd && skeys[j] == keyv;
+        uint32_t m[kMaskWords];
 #pragma unroll
-      for (int w = 0; w < kMaskWords; ++w) m[w] = 0;
-      uint32_t p0 = 0, cnt = 0;
-      if (mine) {
-        const uint32_t val = sorted_val[j];
-        const uint32_t* run = src.base + (size_t)val * src.words;
-        const uint4* m4 = reinterpret_cast<const uint4*>(run + (src.words - kMaskWords));
+        for (int w = 0; w < kMaskWords; ++w) m[w] = 0;
+        size_t p0 = 0;
+        uint32_t cnt = 0;
+        if (mine) {
+          const uint32_t val = sorted_val[j];
+          const uint32_t* run = src.base + (size_t)val * src.words;
+          const uint4* m4 = reinterpret_cast<const uint4*>(run + (src.words - kMaskWords));
 #pragma unroll
-        for (int q = 0; q < kMaskWords / 4; ++q) {
-          const uint4 a = m4[q];
-          m[4 * q] = a.x; m[4 * q + 1] = a.y; m[4 * q + 2] = a.z; m[4 * q + 3] = a.w;
+          for (int q = 0; q < kMaskWords / 4; ++q) {
+            const uint4 a = m4[q];
+            m[4 * q] = a.x; m[4 * q + 1] = a.y; m[4 * q + 2] = a.z; m[4 * q + 3] = a.w;
+          }
+          p0 = (size_t)(src.words == kWireRun ? run[3] : src.tmap.tile_of(val >> src.r1_log2)) * (size_t)kWalkRays;
+#pragma unroll
+          for (int w = 0; w < kMaskWords; ++w) cnt += (uint32_t)__popc(m[w]);
         }
-        p0 = (src.words == kWireRun ? run[3] : src.tmap.tile_of(val >> src.r1_log2)) * (uint32_t)kWalkRays;
+        uint32_t inc = cnt;   // prefix over the voxel's eight lanes
 #pragma unroll
-        for (int w = 0; w < kMaskWords; ++w) cnt += (uint32_t)__popc(m[w]);
+        for (int d = 1; d < 8; d <<= 1) {
+          const uint32_t up = (uint32_t)__shfl_up((int)inc, d, 8);
+          if (sub >= d) inc += up;
+        }
+        uint32_t at = havev + inc - cnt;
+#pragma unroll
+        for (int w = 0; w < kMaskWords; ++w) {
+          uint32_t bits = m[w];
+          while (bits && at < needv) {
+            const int bpos = __ffs((int)bits) - 1;
+            bits &= bits - 1u;
+            const uint8_t* px = rgb + 3 * (p0 + (size_t)(w * 32 + bpos));
+            stage[wid][vl][at++] = colour_roundtrip(px[0]) | (colour_roundtrip(px[1]) << 8) | (colour_roundtrip(px[2]) << 16);
+          }
+        }
+        havev += (uint32_t)__shfl((int)inc, 7, 8);
+        const uint32_t group_mine = (uint32_t)(__ballot(mine) >> (8 * vl)) & 0xFFu;
+        open = open && group_mine == 0xFFu && havev < needv;   // more runs of this voxel may follow, and they still count
       }
-      uint32_t inc = cnt;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
-        if (lane >= off) inc += up;
-      }
-      uint32_t at = have + inc - cnt;
-#pragma unroll
-      for (int w = 0; w < kMaskWords; ++w) {
-        uint32_t bits = m[w];
-        while (bits && at < need) {
-          const int bpos = __ffs((int)bits) - 1;
-          bits &= bits - 1u;
-          const size_t p = (size_t)p0 + (size_t)(w * 32 + bpos);
-          stage[wid][at++] = (uint32_t)rgb[3 * p] | ((uint32_t)rgb[3 * p + 1] << 8) | ((uint32_t)rgb[3 * p + 2] << 16);
+      if (sub == 0 && vl < kFoldGroup) have[wid][vl] = havev;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- fold: lane = voxel * 4 + channel
+    {
+      const int fv = lane >> 2, fc = lane & 3;
+      const uint32_t col0 = (uint32_t)__shfl((int)my_col, fv);
+      const uint32_t key = (uint32_t)__shfl((int)my_key, fv);
+      const bool active = (uint32_t)fv < nv && fv < kFoldGroup;
+      const uint32_t cw0 = col0 >> 24;
+      const uint32_t steps = (active && cw0 < 254u) ? min(have[wid][fv & (kFoldGroup - 1)], 254u - cw0) : 0u;
+      uint32_t ch = (col0 >> (8 * fc)) & 255u;
+      if (fc < 3) {
+        for (uint32_t k = 0; k < steps; ++k) {
+          const uint32_t cw = cw0 + k;
+          const uint32_t x = (stage[wid][fv & (kFoldGroup - 1)][k] >> (8 * fc)) & 255u;
+          ch = (uint32_t)(uint8_t)((float)(cw * ch + x) * rcp[cw]);
         }
       }
-      have += (uint32_t)__shfl((int)inc, 63);
-      if (__ballot(mine) != ~0ull) break;   // the voxel's runs end inside this batch
-    }
-    const uint32_t steps = min(have, need);
-    // lanes 0..2 fold one channel each (ColorVoxel::IntegrateSimple: (uint8)((float)(w * old + new) * (1 / (w + 1))))
-    uint32_t ch = (col0 >> (8 * (lane & 3))) & 255u;
-    if (lane < 3) {
-      for (uint32_t k = 0; k < steps; ++k) {
-        const uint32_t cw = cw0 + k;
-        const uint32_t x = colour_roundtrip((stage[wid][k] >> (8 * lane)) & 255u);
-        ch = (uint32_t)(uint8_t)((float)(cw * ch + x) * (1.f / (float)(1u + cw)));
+      const uint32_t g = (uint32_t)__shfl_down((int)ch, 1), bl = (uint32_t)__shfl_down((int)ch, 2);
+      if (active && fc == 0 && cw0 < 254u) {
+        rgbw[key] = ch | (g << 8) | (bl << 16) | ((cw0 + steps) << 24);
+        if (sat_list && cw0 + steps >= 254u) sat_list[atomicAdd(sat_count, 1u)] = key;
       }
     }
-    const uint32_t r = (uint32_t)__shfl((int)ch, 0), g = (uint32_t)__shfl((int)ch, 1), bl = (uint32_t)__shfl((int)ch, 2);
-    if (lane == 0) {
-      rgbw[key] = r | (g << 8) | (bl << 16) | ((cw0 + steps) << 24);
-      if (sat_list && cw0 + steps >= 254u) sat_list[atomicAdd(sat_count, 1u)] = key;
-    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 

@@ -33,12 +33,12 @@ if [[ "$STAGES" == *sweep* ]]; then
   echo "sweep done $(date +%T)" >> "$O/stages.log"
 fi
 if [[ "$STAGES" == *prof* ]]; then
-  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof" -o r -- python "$R/bench.py" --no-cpu-baseline --no-frontend $BENCH_ARGS 2>&1 | tail -5 ) > "$O/rocprof.log" 2>&1
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof" -o r -- python "$R/bench.py" --no-cpu-baseline --no-frontend --no-realistic-legs $BENCH_ARGS 2>&1 | tail -5 ) > "$O/rocprof.log" 2>&1
   echo "rocprof done $(date +%T)" >> "$O/stages.log"
 fi
 if [[ "$STAGES" == *pmc* ]]; then
   for C in FETCH_SIZE WRITE_SIZE; do
-    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$R/$O/pmc_$C" -o r -- python "$R/bench.py" --steps 2 --warmup 2 --no-cpu-baseline --no-frontend --no-other-mode-leg --no-voxblox-leg $BENCH_ARGS 2>&1 | tail -5 ) > "$O/pmc_$C.log" 2>&1
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$R/$O/pmc_$C" -o r -- python "$R/bench.py" --steps 2 --warmup 2 --no-cpu-baseline --no-frontend --no-other-mode-leg --no-voxblox-leg --no-realistic-legs $BENCH_ARGS 2>&1 | tail -5 ) > "$O/pmc_$C.log" 2>&1
   done
   echo "pmc done $(date +%T)" >> "$O/stages.log"
 fi

@@ -92,8 +92,17 @@ def test_mirror_runs_the_merged_method(oracle):
     class Fast(PointCloudMapVoxblox):
         skIntegrationMethod = "fast"
 
-    with pytest.raises(NotImplementedError):
-        Fast(0.05)
+    class Unknown(PointCloudMapVoxblox):
+        skIntegrationMethod = "quick"
+
+    with pytest.raises(ValueError):
+        Unknown(0.05)
+    # "fast" (the reference's YAML default) is accepted and runs the integrator it approximates: "simple" 
+    pf, refs = Fast(0.05), oracle.voxblox(0.05)
+    for k in make_keyframes(2, seed=8):
+        pf.InsertCloud(dict(xyz=k["xyz"], rgba=rgba_of(k)), k["Twc"])
+        refs.integrate(k["xyz"], rgba_of(k), k["Twc"])
+    maps_equal(refs, pf.tsdf)
     pm, ref = Merged(0.05), oracle.voxblox(0.05)
     for k in make_keyframes(2, seed=8):
         pm.InsertCloud(dict(xyz=k["xyz"], rgba=rgba_of(k)), k["Twc"])
