@@ -127,6 +127,9 @@ __device__ inline int dir_find_or_insert(const Directory& d, int x, int y, int z
         full = false;
         break;
       }
+    } else if (cur != kEmptyKey) {   // another block's entry (an entry never changes once written): next probe, and
+      h = (h + 1) & d.mask;          // no read-modify-write on a word that thousands of threads pass over
+      continue;
     }
     cur = atomicCAS(&d.keys[h], kEmptyKey, key);
     if (cur == kEmptyKey) {   // inserted here: allocate and publish the slot
@@ -1229,35 +1232,62 @@ __global__ __launch_bounds__(kWalkRays, PLVS_WALK_FAST_WAVES) void walk_fast(
 #pragma unroll
     for (int k = 0; k < kPer; ++k) ekey[k] = kKeyEmpty;
   }
-  // ---- cache: entries -> chunks; one barrier later everybody knows whether the tile stands
+  // ---- entries -> chunks -> pool slots, ranks inside the (chunk, slab) groups, colour weights: no barrier in between.
+  // The chunk cache hands every thread the same index for a chunk whoever inserts it first; nearly every chunk's
+  // slot is already there (the walk's set-up asked the directory for the chunks its rays start and end in); a thread
+  // whose entry lies in a chunk still without one — a chunk a ray only passes through, one not at its home entry of
+  // the directory, a first touch — asks the directory itself (find or insert: a chunk joins the map when one of its
+  // voxels takes an update).  Whether the tile stands at all (table, key box and cache held everything) is only known
+  // at the next barrier: a tile that does not is deferred there — all it has done to global memory by then is to
+  // enter chunks its voxels need anyway.
   int ci[kPer];
-  bool unresolved = false;
+  uint32_t rank[kPer], vkey[kPer], elast[kPer];
+  unsigned long long ewc[kPer];
+  uint32_t need = 0, nneed = 0;   // entries of this thread that leave the tile as runs
+  bool multi = false;             // ... one of them visited by more than one ray
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    ci[k] = -2;
+    rank[k] = 0;
+    vkey[k] = 0xFFFFFFFFu;        // (no entry / no pool slot: the directory is full)
+    elast[k] = 0;
+    ewc[k] = 0;
+  }
   if (!defer) {
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
-      ci[k] = -2;
-      if (ekey[k] != kKeyEmpty) {
-        bool won;
-        ci[k] = chunk_cache_insert(S, chunk_code(ekey[k]), &won);
-        // (a chunk joins the map when one of its voxels takes an update — not because a ray started or ended in it)
-        if (ci[k] >= 0 && S.cslot[ci[k]] == -1) S.cslot[ci[k]] = -3;   // wanted, not resolved yet
-        if (ci[k] < 0) S.overflow = 1u;   // more chunks than the cache holds
-        unresolved = unresolved || (ci[k] >= 0 && S.cslot[ci[k]] < 0);
+      if (ekey[k] == kKeyEmpty) continue;
+      bool won;
+      ci[k] = chunk_cache_insert(S, chunk_code(ekey[k]), &won);
+      if (ci[k] < 0) {
+        S.overflow = 1u;   // more chunks than the cache holds
+        continue;
       }
-    }
-    const bool any_unresolved = __syncthreads_or(unresolved ? 1 : 0) != 0;                  // ---- barrier 3
-    // (a tile whose table overflowed, whose rays did not fit the key box or whose chunks did not fit the cache is
-    // walked by the general kernel: nothing of it has left the workgroup yet)
-    defer = S.overflow != 0 || S.nent > (uint32_t)kWalkLimit;
-    if (!defer && any_unresolved) {
-      if (tid < kWalkChunks && S.cslot[tid] == -3) {
+      const uint32_t vid = voxel_in_chunk(ekey[k]);
+      ewc[k] = e_wc[tid + k * kWalkRays];
+      elast[k] = e_last[tid + k * kWalkRays];
+      int slot = S.cslot[ci[k]];
+      if (slot < 0) {
         int cx, cy, cz;
-        chunk_of_code(S.ccode[tid], ox, oy, oz, &cx, &cy, &cz);
-        S.cslot[tid] = dir_find_or_insert(dir, cx, cy, cz, num_chunks, &ctr->err);
+        chunk_of_code(chunk_code(ekey[k]), ox, oy, oz, &cx, &cy, &cz);
+        slot = dir_find_or_insert(dir, cx, cy, cz, num_chunks, &ctr->err);
+        if (slot >= 0) S.cslot[ci[k]] = slot;
       }
-      __syncthreads();
+      if (slot < 0) continue;
+      rank[k] = atomicAdd(&S.ccnt[ci[k] * kSlabs + (int)(vid / kSlabVox)], 1u);
+      vkey[k] = (uint32_t)slot * (uint32_t)kChunkVox + vid;
+      const bool cold = sat ? ((sat[vkey[k] >> 5] >> (vkey[k] & 31u)) & 1u) == 0u : (rgbw[vkey[k]] >> 24) < 254u;
+      if (cold) {   // its colour still depends on the order of the visits
+        need |= 1u << k;
+        ++nneed;
+        multi = multi || (uint32_t)(ewc[k] >> 32) > 1u;
+      }
     }
   }
+  // (one barrier: the ranks are complete, the tile's entries are counted — and does any voxel that needs a run have
+  // more than one visiting ray?)
+  const bool any_multi = __syncthreads_or(multi ? 1 : 0) != 0;                              // ---- barrier 3
+  if (!defer) defer = S.overflow != 0 || S.nent > (uint32_t)kWalkLimit;
   if (defer) {
     if (tid == 0) {
       out.seg_cnt[tile] = 0;
@@ -1271,34 +1301,6 @@ __global__ __launch_bounds__(kWalkRays, PLVS_WALK_FAST_WAVES) void walk_fast(
     const uint32_t v = wave_sum(nv);
     if (lane == 0 && v) atomicAdd(&S.vis_total, v);
   }
-  // ---- ranks inside the (chunk, slab) groups, colour weights
-  uint32_t rank[kPer], vkey[kPer], elast[kPer];
-  unsigned long long ewc[kPer];
-  uint32_t need = 0, nneed = 0;   // entries of this thread that leave the tile as runs
-  bool multi = false;             // ... one of them visited by more than one ray
-#pragma unroll
-  for (int k = 0; k < kPer; ++k) {
-    rank[k] = 0;
-    vkey[k] = 0xFFFFFFFFu;        // (no pool slot: the directory is full)
-    elast[k] = 0;
-    ewc[k] = 0;
-    if (ci[k] < 0) continue;
-    const uint32_t vid = voxel_in_chunk(ekey[k]);
-    ewc[k] = e_wc[tid + k * kWalkRays];
-    elast[k] = e_last[tid + k * kWalkRays];
-    const int slot = S.cslot[ci[k]];
-    if (slot < 0) continue;
-    rank[k] = atomicAdd(&S.ccnt[ci[k] * kSlabs + (int)(vid / kSlabVox)], 1u);
-    vkey[k] = (uint32_t)slot * (uint32_t)kChunkVox + vid;
-    const bool cold = sat ? ((sat[vkey[k] >> 5] >> (vkey[k] & 31u)) & 1u) == 0u : (rgbw[vkey[k]] >> 24) < 254u;
-    if (cold) {   // its colour still depends on the order of the visits
-      need |= 1u << k;
-      ++nneed;
-      multi = multi || (uint32_t)(ewc[k] >> 32) > 1u;
-    }
-  }
-  // (one barrier: the ranks are complete, and does any voxel that needs a run have more than one visiting ray?)
-  const bool any_multi = __syncthreads_or(multi ? 1 : 0) != 0;                              // ---- barrier 4
   // ---- records: the (chunk, slab) groups are placed by a scan over the cache's 64 chunks, one lane per chunk.  EVERY
   // wave runs the scan and writes the same table of group bases — a wave reads back its own LDS writes in order, so
   // nobody waits for wave 0 behind a barrier; wave 0 alone writes the segment descriptors.
@@ -1427,7 +1429,7 @@ __global__ __launch_bounds__(kWalkRays, PLVS_WALK_FAST_WAVES) void walk_fast(
     if (tid == 0) S.run_total = nruns;
   }
   // ---- tile epilogue: run and visit counts
-  __syncthreads();                                                                          // ---- barrier 5
+  __syncthreads();                                                                          // ---- barrier 4
   if (tid == 0) {
     runs.run_cnt[tile] = min(S.run_total, 1u << runs.r1_log2);
     out.tile_visits[tile] = S.vis_total;
