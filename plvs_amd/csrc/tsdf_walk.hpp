@@ -1168,45 +1168,15 @@ __global__ __launch_bounds__(kWalkRays, PLVS_WALK_FAST_WAVES) void walk_fast(
       for (int w = kWalkRays / 64 - 1; w >= 0; --w) w0 = S.cand[w] ? w : w0;
       ox = S.worg[w0][0]; oy = S.worg[w0][1]; oz = S.worg[w0][2];
     }
-    // ---- the chunks the ray starts and ends in -> chunk cache, their directory entries requested (DirPeek) ...
-    bool fits = false, won_s = false, won_e = false;
-    int ci_s = -1, ci_e = -1;
-    uint32_t code_s = kKeyEmpty, code_e = kKeyEmpty;
+    // ---- does the ray's whole box (start voxel +- its reach) lie inside the key box?
+    bool fits = false;
     if (walks) {
       const int reach = lean_reach(ray);
       const int rx = (int)floorf(ray.start[0]) - ox, ry = (int)floorf(ray.start[1]) - oy, rz = (int)floorf(ray.start[2]) - oz;
       fits = min(min(rx, ry), rz) - reach >= 0 && max(max(rx, ry), rz) + reach <= 1023;
-      if (fits) {
-        code_s = chunk_code((uint32_t)rx | ((uint32_t)ry << 10) | ((uint32_t)rz << 20));
-        code_e = chunk_code((uint32_t)((int)floorf(ray.end[0]) - ox) | ((uint32_t)((int)floorf(ray.end[1]) - oy) << 10) |
-                            ((uint32_t)((int)floorf(ray.end[2]) - oz) << 20));
-      } else {
-        S.overflow = 1u;   // the rays of the tile are too far apart
-      }
+      if (!fits) S.overflow = 1u;   // the rays of the tile are too far apart
     }
-    {   // neighbouring rays share their chunks: only the first lane of a run of equal codes goes to the cache
-      const uint32_t prev_s = (uint32_t)__shfl_up((int)code_s, 1), prev_e = (uint32_t)__shfl_up((int)code_e, 1);
-      if (code_s != kKeyEmpty && (lane == 0 || code_s != prev_s)) ci_s = chunk_cache_insert(S, code_s, &won_s);
-      if (code_e != kKeyEmpty && code_e != code_s && (lane == 0 || code_e != prev_e)) ci_e = chunk_cache_insert(S, code_e, &won_e);
-    }
-    DirPeek peek_s, peek_e;
-    peek_s.want = peek_e.want = 0; peek_s.key = peek_e.key = kEmptyKey; peek_s.slot = peek_e.slot = -1;
-    if (won_s) {
-      int cx, cy, cz;
-      chunk_of_code(code_s, ox, oy, oz, &cx, &cy, &cz);
-      peek_s = dir_peek(dir, cx, cy, cz);
-    }
-    if (won_e) {
-      int cx, cy, cz;
-      chunk_of_code(code_e, ox, oy, oz, &cx, &cy, &cz);
-      peek_e = dir_peek(dir, cx, cy, cz);
-    }
-    // ---- ... the walk (its set-up arithmetic hides the directory's latency; the slots land before the loop)
     if (fits) {
-      RayCursor cur;
-      ray_begin(ray, &cur);   // (walk_lean's own ray_begin is this one: common subexpression)
-      if (won_s && dir_peek_slot(peek_s) >= 0) S.cslot[ci_s] = dir_peek_slot(peek_s);
-      if (won_e && dir_peek_slot(peek_e) >= 0) S.cslot[ci_e] = dir_peek_slot(peek_e);
 #if !(PLVS_WALK_EXP & 32)   // (bit 32, timing experiment: no voxel loop)
       nv = walk_lean<true, true>(P, pose, ray, S, ox, oy, oz, tid, wu * scale_u, (uint32_t)__float2int_rn(wu * scale_w), e_wuu,
                                  e_wc, e_last, vlog);
