@@ -219,7 +219,7 @@ def main():
         # runs of this same command; scripts/pmc_traffic.py) committed under profiles/
         mode_tag = "" if vbx else ("_ordered" if args.ordered else "_order_free")
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                           f"r02_pmc_traffic_{args.backend}{mode_tag}.json")
+                           f"r03_pmc_traffic_{args.backend}{mode_tag}.json")
         if world == 1 and not multi and args.batch == 100 and os.path.exists(pmc):
             with open(pmc) as f:
                 t = json.load(f)

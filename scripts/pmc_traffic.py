@@ -15,7 +15,7 @@ import json
 import sys
 from collections import defaultdict
 
-PIPELINE = ("pose_prep", "walk_tiles", "seg_pass", "seg_scan", "apply_chunks", "compact_runs", "sort_runs_small", "fold_colours_masks",
+PIPELINE = ("pose_prep", "walk_prologue", "walk_fast", "walk_tiles", "seg_pass", "seg_scan", "apply_chunks", "compact_runs", "sort_runs_small", "fold_colours_masks",
             "ray_count", "scan_tile_sums", "scan_sums", "scan_tile_apply", "mark_tiles", "ray_tiles",
             "radix_hist", "radix_scatter", "voxel_heads", "fold_colours", "reduce_sums", "run_counts", "mark_blocks",
             "gather_runs", "chain_runs")
