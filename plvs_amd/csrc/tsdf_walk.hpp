@@ -471,7 +471,23 @@ __device__ __forceinline__ uint32_t walk_lean(const Params& P, const Pose& pose,
     const bool stop = (d > cur.maxDist) || (key == endkey);
     float u;
     if (two_tier_visit(P, pose, ray, L, fx, fy, fz, &u)) {
-      const int e = table_find_or_insert(S, key);
+      // the home bucket first, in straight-line code: the key is there (7 visits in 8) or one of its slots is free and
+      // takes it (nearly all the rest); whatever else — the slot went to another voxel, the bucket is full — is the
+      // general search's business
+      int e;
+      {
+        const uint32_t b = key_bucket(key);
+        const uint4 k4 = *reinterpret_cast<const uint4*>(&S.ekey[4 * b]);
+        const int j = bucket_match(k4, key);
+        if (j >= 0) {
+          e = (int)(4 * b) + j;
+        } else {
+          const int je = bucket_match(k4, kKeyEmpty);
+          uint32_t old = 0u;
+          if (je >= 0) old = atomicCAS(&S.ekey[4 * b + je], kKeyEmpty, key);
+          e = (je >= 0 && (old == kKeyEmpty || old == key)) ? (int)(4 * b) + je : table_find_or_insert(S, key);
+        }
+      }
       if (__builtin_expect(e < 0, 0)) break;   // the table is full: the (sub-)tile is cut
       if (kRuns && nv < (uint32_t)kLogLen) vlog[nv * kWalkRays + tid] = (uint16_t)e;
       if (kAcc) {
