@@ -109,6 +109,10 @@ struct plvs_block_directory {
   uint32_t mask = 0;
 };
 
+namespace {
+__global__ void store_word(int32_t* p, int32_t v) { *p = v; }
+}  // namespace
+
 extern "C" {
 
 int plvs_hip_block_directory_create(int max_blocks, plvs_block_directory** out) {
@@ -195,8 +199,9 @@ int plvs_hip_tsdf_exchange_block_lists(void* rccl_comm, const int32_t* d_local_i
     plvs::set_error("ncclCommUserRank failed");
     return PLVS_ERR_HIP;
   }
-  const int32_t count = local_count;   // in place: this rank's slot of the gathered counts
-  PLVS_HIP_TRY(hipMemcpyAsync(d_all_counts + rank, &count, sizeof(int32_t), hipMemcpyHostToDevice, s));
+  // in place: this rank's slot of the gathered counts (the value travels as a kernel argument: an asynchronous copy
+  // from a stack variable could outlive this function)
+  hipLaunchKernelGGL(store_word, dim3(1), dim3(1), 0, s, d_all_counts + rank, (int32_t)local_count);
   int rc = r->all_gather(d_all_counts + rank, d_all_counts, 1, /*ncclInt32*/ 2, rccl_comm, s);
   if (rc == 0) rc = r->all_gather(d_local_ids, d_all_ids, (size_t)cap * 3, /*ncclInt32*/ 2, rccl_comm, s);
   if (rc != 0) {
@@ -232,8 +237,14 @@ int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm,
   static thread_local Scratch B;
   constexpr size_t kWords[3] = {8, 8, 20};   // uint32 words of a descriptor, a voxel sum, a run
   int64_t sc[3 * 64], rcv[3 * 64];
-  int rc = plvs_hip_tsdf_chisel_shard_walk(h, d_xyz, offsets, nclouds, d_Twc, sc, stream);
-  if (rc != PLVS_OK) return rc;
+  // A rank whose own stage fails must not leave its peers blocked inside a collective: it goes through the
+  // exchanges with nothing to send and says so in its counts (-1), the peers finish the step with what arrived and
+  // every rank returns an error — the failing one its own, the others PLVS_ERR_HALO.
+  int failed = plvs_hip_tsdf_chisel_shard_walk(h, d_xyz, offsets, nclouds, d_Twc, sc, stream);
+  if (failed != PLVS_OK)
+    for (int p = 0; p < world; ++p) sc[3 * p] = -1, sc[3 * p + 1] = 0, sc[3 * p + 2] = 0;
+  int rc = PLVS_OK;
+  bool peer_failed = false;
 #define RCCL_TRY(call)                                                      \
   do {                                                                      \
     const int e_ = (call);                                                  \
@@ -253,6 +264,13 @@ int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm,
   RCCL_TRY(r->group_end());
   PLVS_HIP_TRY(hipMemcpyAsync(rcv, B.cnt.p + 3 * world, (size_t)3 * world * sizeof(long long), hipMemcpyDeviceToHost, s));
   PLVS_HIP_TRY(hipStreamSynchronize(s));
+  for (int p = 0; p < world; ++p) {
+    if (rcv[3 * p] < 0) {
+      peer_failed = peer_failed || p != rank;
+      rcv[3 * p] = rcv[3 * p + 1] = rcv[3 * p + 2] = 0;
+    }
+    if (sc[3 * p] < 0) sc[3 * p] = 0;
+  }
   // ---- payloads
   size_t stot[3] = {0, 0, 0}, rtot[3] = {0, 0, 0};
   for (int p = 0; p < world; ++p)
@@ -264,8 +282,11 @@ int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm,
     PLVS_HIP_TRY(B.send[k].reserve(stot[k] * kWords[k] + 4));
     PLVS_HIP_TRY(B.recv[k].reserve(rtot[k] * kWords[k] + 4));
   }
-  rc = plvs_hip_tsdf_chisel_shard_pack(h, B.send[0].p, B.send[1].p, B.send[2].p, stream);
-  if (rc != PLVS_OK) return rc;
+  if (failed == PLVS_OK) {
+    failed = plvs_hip_tsdf_chisel_shard_pack(h, B.send[0].p, B.send[1].p, B.send[2].p, stream);
+    // (the peers already expect this rank's counts: what goes out after a failed pack is unspecified data of the
+    // announced size; this rank's error return tells the caller the step is void)
+  }
   RCCL_TRY(r->group_start());
   {
     size_t so[3] = {0, 0, 0}, ro[3] = {0, 0, 0};
@@ -279,12 +300,13 @@ int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm,
       }
   }
   RCCL_TRY(r->group_end());
-  rc = plvs_hip_tsdf_chisel_shard_apply(h, B.recv[0].p, B.recv[1].p, B.recv[2].p, rcv, d_rgb, d_kfid, stream);
-  if (rc != PLVS_OK) return rc;
+  if (failed == PLVS_OK) failed = plvs_hip_tsdf_chisel_shard_apply(h, B.recv[0].p, B.recv[1].p, B.recv[2].p, rcv, d_rgb, d_kfid, stream);
   // ---- voxels whose colour saturated: every rank notes every list
   int nsat = 0;
-  rc = plvs_hip_tsdf_chisel_shard_saturated(h, nullptr, 0, &nsat, stream);
-  if (rc != PLVS_OK && rc != PLVS_ERR_CAPACITY) return rc;
+  if (failed == PLVS_OK) {
+    rc = plvs_hip_tsdf_chisel_shard_saturated(h, nullptr, 0, &nsat, stream);
+    if (rc != PLVS_OK && rc != PLVS_ERR_CAPACITY) { failed = rc; nsat = 0; }
+  }
   PLVS_HIP_TRY(B.nsat.reserve((size_t)world + 1));
   PLVS_HIP_TRY(hipMemcpyAsync(B.nsat.p + rank, &nsat, sizeof(int32_t), hipMemcpyHostToDevice, s));
   RCCL_TRY(r->all_gather(B.nsat.p + rank, B.nsat.p, 1, /*ncclInt32*/ 2, rccl_comm, s));
@@ -296,17 +318,17 @@ int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm,
   if (cap > 0) {
     PLVS_HIP_TRY(B.sat.reserve((size_t)cap * 4));
     PLVS_HIP_TRY(B.all_sat.reserve((size_t)cap * 4 * world));
-    if (nsat > 0) {
-      rc = plvs_hip_tsdf_chisel_shard_saturated(h, B.sat.p, cap, &nsat, stream);
-      if (rc != PLVS_OK) return rc;
-    }
+    if (nsat > 0 && failed == PLVS_OK) failed = plvs_hip_tsdf_chisel_shard_saturated(h, B.sat.p, cap, &nsat, stream);
     RCCL_TRY(r->all_gather(B.sat.p, B.all_sat.p, (size_t)cap * 4, /*ncclInt32*/ 2, rccl_comm, s));
-    for (int p = 0; p < world; ++p) {
-      rc = plvs_hip_tsdf_chisel_shard_note_saturated(h, B.all_sat.p + (size_t)p * cap * 4, all_n[p], stream);
-      if (rc != PLVS_OK) return rc;
-    }
+    for (int p = 0; p < world && failed == PLVS_OK; ++p)
+      failed = plvs_hip_tsdf_chisel_shard_note_saturated(h, B.all_sat.p + (size_t)p * cap * 4, all_n[p], stream);
   }
 #undef RCCL_TRY
+  if (failed != PLVS_OK) return failed;
+  if (peer_failed) {
+    plvs::set_error("a peer rank failed in its share of the sharded integrate: the step is void on every rank");
+    return PLVS_ERR_HALO;
+  }
   return PLVS_OK;
 }
 

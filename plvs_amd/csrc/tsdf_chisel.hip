@@ -1836,6 +1836,10 @@ extern "C" int plvs_hip_tsdf_chisel_carve_dev(plvs_tsdf_chisel* h, const float* 
   if (h->num_chunks == 0) return PLVS_OK;
   PLVS_REQUIRE(d_depth, "null depth image");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  {   // carving changes owned voxels: ghost copies of them held for meshing (here or on peer ranks) are stale now
+    int rc = halo_drop(h, s);
+    if (rc != PLVS_OK) return rc;
+  }
   CarveCamera C;
   carve_frustum(h->P, Twc, near_dist, far_dist, fy, cy, (float)width, (float)height, &C);
   C.fx = fx; C.fy = fy; C.cx = cx; C.cy = cy;
@@ -2155,8 +2159,19 @@ int plvs_hip_tsdf_chisel_halo_import(plvs_tsdf_chisel* h, const int32_t* d_ids_x
     // reach: thousands per call), kept until the next integrate call: twice the miss set's table
     size_t cap = 2 * std::max<size_t>((size_t)h->miss_mask + 1, (size_t)1 << 19);
     while (cap < 4 * (size_t)h->prm.max_chunks) cap <<= 1;
-    PLVS_HIP_TRY(hipMalloc(&h->gdir.keys, cap * sizeof(unsigned long long)));
-    PLVS_HIP_TRY(hipMalloc(&h->gdir.slots, cap * sizeof(int32_t)));
+    // (both tables or neither: a half-built ghost directory would be taken for a complete one by the next call)
+    unsigned long long* gkeys = nullptr;
+    int32_t* gslots = nullptr;
+    PLVS_HIP_TRY(hipMalloc(&gkeys, cap * sizeof(unsigned long long)));
+    {
+      const hipError_t e = hipMalloc(&gslots, cap * sizeof(int32_t));
+      if (e != hipSuccess) {
+        (void)hipFree(gkeys);
+        PLVS_HIP_TRY(e);
+      }
+    }
+    h->gdir.keys = gkeys;
+    h->gdir.slots = gslots;
     h->gdir.slot_ids = nullptr;
     h->gdir.mask = (uint32_t)(cap - 1);
     h->gdir.max_blocks = h->prm.max_chunks;
