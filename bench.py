@@ -185,6 +185,44 @@ def main():
         stage_ms, calls = tsdf.stage_ms()
         tsdf.set_profiling(False)
 
+    # ---- N > 1 (ray-sharded): where a step's time goes, and the other scaling leg
+    # phases_ms: three more steps run with a device synchronisation after each phase (walk / pack / exchange / apply /
+    # feedback; max over ranks) — their sum exceeds ms_per_step by the overlap the synchronisations remove.
+    # other_leg: the same job under the OTHER scaling rule (weak: --batch key frames per GPU per step; strong: --batch
+    # key frames per step whatever N), so one run of `bench.py --gpus N` gives both curves.
+    phases_ms, other_leg = None, None
+    if ray_sharded:
+        tim = {}
+        for s in range(3):
+            sharded_integrate(tsdf, *[batches[s % len(batches)][i] for i in (0, 1, 2, 3, 4)], timings=tim)
+        names = ["walk", "pack", "exchange", "apply", "feedback"]
+        t = torch.tensor([tim.get(k, 0.0) / 3.0 for k in names], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        phases_ms = {k: round(float(v), 4) for k, v in zip(names, t.tolist())}
+        if world > 1:
+            other_kfs = args.batch * (1 if not args.strong else world)
+            sel = [kfs[j % n_poses] for j in range(other_kfs)]
+            ob = (torch.from_numpy(np.concatenate([k["xyz"] for k in sel])).cuda(),
+                  torch.from_numpy(np.concatenate([k["rgb"] for k in sel])).cuda(),
+                  torch.from_numpy(np.concatenate([k["kfid"] for k in sel]).astype(np.int32)).cuda(),
+                  np.cumsum([0] + [k["xyz"].shape[0] for k in sel]).astype(np.int32),
+                  torch.from_numpy(np.stack([k["Twc"] for k in sel])).cuda())
+            for s in range(max(args.warmup, 1)):
+                step(ob)
+            barrier()
+            t1 = time.perf_counter()
+            ov = 0
+            for s in range(args.steps):
+                ov += step(ob)["visits"]
+            barrier()
+            t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            v = torch.tensor([ov], dtype=torch.int64, device="cuda")
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            other_leg = {"scaling": "strong" if not args.strong else "weak", "keyframes_per_step": other_kfs,
+                         "value": round(int(v.item()) / float(t.item()) / 1e6, 2), "unit": "Mvoxels/s",
+                         "ms_per_step": round(float(t.item()) / args.steps * 1e3, 3), "steps": args.steps}
+
     # max over ranks of the elapsed time, sum over ranks of the visits
     if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -250,6 +288,10 @@ def main():
                        "global_directory_blocks": (gdir.count() if gdir is not None else None)},
             "roofline": roofline,
         }
+        if phases_ms is not None:
+            result["phases_ms"] = phases_ms
+        if other_leg is not None:
+            result["other_scaling_leg"] = other_leg
 
     # ------------------------------------------------- what PLVS runs, not only the steady state (N = 1 only)
     # The headline step re-integrates the same 100 key frames into a map that has seen them: no chunk is allocated,
@@ -682,8 +724,11 @@ def main():
             import threading
             host_frames = [f.cpu().numpy() for f in frames]
             o_orb, o_lines = ora.orb(2000, 1.2, 8, 20, 7), ora.lines()
+            ncpu = 100
+            for i in range(10):      # warm-up (>= 100 frames after 10 warm-ups)
+                o_orb.extract(host_frames[i % 3])
+                o_lines.extract(host_frames[i % 3])
             t0 = time.perf_counter()
-            ncpu = 6
             for i in range(ncpu):
                 img = host_frames[i % 3]
                 th_ = [threading.Thread(target=o_orb.extract, args=(img,)), threading.Thread(target=o_lines.extract, args=(img,))]
@@ -694,8 +739,8 @@ def main():
             cpu_ms = (time.perf_counter() - t0) / ncpu * 1e3
             result["frontend"]["cpu_baseline"] = {
                 "value": round(1e3 / cpu_ms, 2), "unit": "frames/s", "ms_per_frame": round(cpu_ms, 2), "cores": 2,
-                "kind": "port", "sample": f"oracle/orb.cpp || oracle/lines.cpp on two threads, {ncpu} frames (extraction "
-                                          f"only), host has {os.cpu_count()} cores"}
+                "kind": "port", "sample": f"oracle/orb.cpp || oracle/lines.cpp on two threads, {ncpu} frames after 10 warm-up "
+                                          f"frames (extraction only), host has {os.cpu_count()} cores"}
         except Exception as e:      # the timing harness must not take the benchmark line down
             result["frontend"]["search_functions"] = {"error": repr(e)}
         # configs[4] (KITTI stereo): dense disparity by semi-global matching on a 1240x376 pair resident in HBM

@@ -129,6 +129,23 @@ __global__ void publish_counters(const WalkCounters* __restrict__ wctr, const Co
   __threadfence_system();
 }
 
+// The start of shard_apply in one launch: counters of the call cleared, the received totals in place (what a
+// handful of small memsets / copies would do, each a runtime call of its own).
+__global__ void shard_apply_begin(Counters* ctr, WalkCounters* wctr, int32_t* xcount_sat, uint32_t* __restrict__ chunk_nseg,
+                                  uint32_t max_chunks, uint32_t total_seg, uint32_t total_runs) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint32_t c = i; c < max_chunks; c += gridDim.x * blockDim.x) chunk_nseg[c] = 0u;
+  if (i == 0) {
+    ctr->total_visits = 0u;
+    ctr->err = 0u; ctr->num_heads = 0u; ctr->num_updated = 0u; ctr->max_run = 0u; ctr->num_desc = 0u;
+    wctr[0] = WalkCounters{};
+    wctr[1] = WalkCounters{};
+    wctr[0].seg_top = total_seg;
+    wctr[1].num_desc = total_runs;
+    *xcount_sat = 0;
+  }
+}
+
 // ... and any few words the same way (up to three ranges per launch).
 __global__ void publish_words(const uint32_t* __restrict__ a, uint32_t* __restrict__ ha, int na, const uint32_t* __restrict__ b,
                               uint32_t* __restrict__ hb, int nb, const uint32_t* __restrict__ c, uint32_t* __restrict__ hc, int nc) {
@@ -856,6 +873,7 @@ struct plvs_tsdf_chisel {
   uint32_t* x_sat = nullptr;         //   + one bit per voxel: its owner has reported the colour saturated
   DevBuf<uint32_t> sh_ctl;
   uint32_t* h_sh_ctl = nullptr;      // pinned [320]
+  uint32_t* h_sh_off = nullptr;      // pinned [128 + 132]: region offsets on their way to the device (pack | apply)
   DevBuf<uint4> sh_seg_reg, sh_rec_reg;
   DevBuf<uint32_t> sh_nrec, sh_owner, sh_slot_owner, sh_src_off, sh_run_ctr, sh_vkey, sh_sat;
   uint32_t sh_nt = 0, sh_runs = 0, sh_nsat = 0;
@@ -1262,6 +1280,7 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   (void)hipFree(h->x_sat);
   if (h->h_sh_counts) (void)hipHostFree(h->h_sh_counts);
   if (h->h_sh_ctl) (void)hipHostFree(h->h_sh_ctl);
+  if (h->h_sh_off) (void)hipHostFree(h->h_sh_off);
   h->w_rec.release(); h->w_seg.release(); h->w_sorted_seg.release(); h->w_chunk_nseg.release();
   h->w_chunk_off.release(); h->w_chunk_fill.release(); h->w_active_off.release(); h->w_masks.release();
   h->w_dummy.release(); h->w_runkey.release(); h->w_run_cnt.release(); h->w_run_off.release(); h->w_val0.release();
@@ -2221,6 +2240,7 @@ static int shard_state_init(plvs_tsdf_chisel* h) {
   PLVS_HIP_TRY(hipMalloc((void**)&h->d_xcount, 4 * sizeof(int32_t)));   // [0] chunks, [1] error bits, [2] saturated this call
   PLVS_HIP_TRY(hipHostMalloc((void**)&h->h_sh_counts, ((size_t)3 * 64 + 2) * sizeof(long long)));
   PLVS_HIP_TRY(hipHostMalloc((void**)&h->h_sh_ctl, 320 * sizeof(uint32_t)));
+  PLVS_HIP_TRY(hipHostMalloc((void**)&h->h_sh_off, (128 + 132) * sizeof(uint32_t)));
   PLVS_HIP_TRY(hipMemset(h->xdir.keys, 0xFF, cap * sizeof(unsigned long long)));
   PLVS_HIP_TRY(hipMemset(h->xdir.slots, 0xFF, cap * sizeof(int32_t)));
   PLVS_HIP_TRY(hipMemset(h->x_sat, 0, xmax * (kChunkVox / 32) * sizeof(uint32_t)));
@@ -2416,14 +2436,16 @@ int plvs_hip_tsdf_chisel_shard_pack(plvs_tsdf_chisel* h, void* d_seg_dst, void* 
   for (int p = 0; p < N; ++p) nseg += h->h_sh_counts ? h->h_sh_counts[3 * p] : 0;
   if (nseg == 0) return PLVS_OK;
   PLVS_REQUIRE(d_seg_dst && d_rec_dst && (h->sh_runs == 0 || d_run_dst), "null send buffer");
-  uint32_t dst_off[128] = {};
+  // (pinned staging: the copy is asynchronous and its source outlives this call; the previous step's copies have
+  // executed — shard_apply ends with a synchronisation)
+  uint32_t* const dst_off = h->h_sh_off;
+  for (int p = 0; p < 128; ++p) dst_off[p] = 0;
   for (int p = 1; p < N; ++p) {
     dst_off[p] = dst_off[p - 1] + (uint32_t)h->h_sh_counts[3 * (p - 1)];
     dst_off[64 + p] = dst_off[64 + p - 1] + (uint32_t)h->h_sh_counts[3 * (p - 1) + 1];
   }
-  PLVS_HIP_TRY(h->sh_src_off.reserve(128));
-  PLVS_HIP_TRY(hipMemcpyAsync(h->sh_src_off.p, dst_off, sizeof(dst_off), hipMemcpyHostToDevice, s));
-  PLVS_HIP_TRY(hipStreamSynchronize(s));   // (dst_off is on this stack)
+  PLVS_HIP_TRY(h->sh_src_off.reserve(128 + 132));
+  PLVS_HIP_TRY(hipMemcpyAsync(h->sh_src_off.p, dst_off, 128 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(shard_copy_regions, dim3(512), dim3(256), 0, s, h->sh_seg_reg.p, h->sh_rec_reg.p, h->sh_ctl.p,
                      h->sh_src_off.p, N, static_cast<uint4*>(d_seg_dst), static_cast<uint4*>(d_rec_dst));
   if (h->sh_runs > 0)
@@ -2451,7 +2473,8 @@ int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src,
   h->sh_nsat = 0;
   const int N = std::max(1, h->prm.shard_count);
   const int max_chunks = h->prm.max_chunks;
-  std::vector<uint32_t> src_off(2 * ((size_t)N + 1));
+  PLVS_REQUIRE(h->h_sh_off != nullptr, "shard_apply follows shard_walk");
+  uint32_t* const src_off = h->h_sh_off + 128;   // pinned, 2 (N + 1) <= 130 words
   size_t tseg = 0, trec = 0, trun = 0;
   for (int q = 0; q < N; ++q) {
     PLVS_REQUIRE(recv_counts[3 * q] >= 0 && recv_counts[3 * q + 1] >= 0 && recv_counts[3 * q + 2] >= 0, "negative receive count");
@@ -2471,7 +2494,7 @@ int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src,
   if (tseg == 0) return PLVS_OK;
   PLVS_REQUIRE(d_seg_src && d_rec_src && d_rgb && (trun == 0 || d_run_src), "null device pointer");
   const uint32_t total = (uint32_t)tseg;
-  PLVS_HIP_TRY(h->sh_src_off.reserve(src_off.size()));
+  PLVS_HIP_TRY(h->sh_src_off.reserve(128 + 132));
   PLVS_HIP_TRY(h->w_seg.reserve(2 * (size_t)total));
   PLVS_HIP_TRY(h->w_sorted_seg.reserve(2 * (size_t)total));
   PLVS_HIP_TRY(h->w_chunk_nseg.reserve((size_t)max_chunks));
@@ -2487,19 +2510,16 @@ int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src,
     if (rc != PLVS_OK) return rc;
   }
   const int chunks_before = h->num_chunks;
-  PLVS_HIP_TRY(hipMemcpyAsync(h->sh_src_off.p, src_off.data(), src_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-  PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->total_visits, 0, sizeof(uint32_t), s));
-  PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->err, 0, 5 * sizeof(uint32_t), s));
-  PLVS_HIP_TRY(hipMemsetAsync(h->d_wctr, 0, 2 * sizeof(WalkCounters), s));
-  PLVS_HIP_TRY(hipMemcpyAsync(&h->d_wctr[0].seg_top, &total, sizeof(uint32_t), hipMemcpyHostToDevice, s));
-  PLVS_HIP_TRY(hipMemsetAsync(h->w_chunk_nseg.p, 0, (size_t)max_chunks * sizeof(uint32_t), s));
-  PLVS_HIP_TRY(hipMemsetAsync(h->d_xcount + 2, 0, sizeof(int32_t), s));
+  uint32_t* const d_src_off = h->sh_src_off.p + 128;   // (apart from the words shard_pack's kernels may still be reading)
+  PLVS_HIP_TRY(hipMemcpyAsync(d_src_off, src_off, 2 * ((size_t)N + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(shard_apply_begin, dim3(ceil_div((size_t)max_chunks, 1024)), dim3(256), 0, s, h->d_ctr, h->d_wctr,
+                     h->d_xcount + 2, h->w_chunk_nseg.p, (uint32_t)max_chunks, total, (uint32_t)trun);
 #define STAGE_MARK(i) \
   do { if (h->profiling) PLVS_HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
   STAGE_MARK(0);
   STAGE_MARK(1);   // (the walk ran in shard_walk: its stage time stays 0 here)
   hipLaunchKernelGGL(shard_translate, dim3(ceil_div((size_t)total, 256)), dim3(256), 0, s,
-                     static_cast<const uint4*>(d_seg_src), total, h->sh_src_off.p, N, h->dir, &h->d_ctr->num_chunks,
+                     static_cast<const uint4*>(d_seg_src), total, d_src_off, N, h->dir, &h->d_ctr->num_chunks,
                      &h->d_wctr[0].err, h->w_seg.p);
   const unsigned seg_blocks = ceil_div((size_t)total, kSegSpan);
   hipLaunchKernelGGL(seg_pass<false>, dim3(seg_blocks), dim3(256), 0, s, h->w_seg.p, total, 0u, (const uint32_t*)nullptr,
@@ -2550,7 +2570,6 @@ int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src,
     PLVS_HIP_TRY(radix_sort_pairs(k_in, order, k_out, other, R, 0, key_bits, h->scratch.p, s, &second));
     const uint32_t* skeys = second ? k_out : k_in;
     const uint32_t* sval = second ? other : order;
-    PLVS_HIP_TRY(hipMemcpyAsync(&h->d_wctr[1].num_desc, &R, sizeof(uint32_t), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(voxel_heads, dim3(ceil_div(R, 256 * kHeadTiles)), dim3(256), 0, s, skeys, R, h->heads.p,
                        h->w_dummy.p, h->d_wctr + 1);
     hipLaunchKernelGGL(fold_colours_masks, dim3(std::min<size_t>(ceil_div(R, kFoldWaves), 8192)), dim3(64 * kFoldWaves), 0, s,

@@ -12,6 +12,8 @@ block ids (what every rank needs to maintain the global block directory and to
 schedule meshing); it runs over torch.distributed — RCCL/xGMI on GPUs ("nccl"),
 gloo in the CPU tests.
 """
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -97,17 +99,38 @@ def exchange_segments(send_seg, send_rec, send_run, send_counts, group=None):
 SAT_ROWS = 16384      # newly saturated voxels a rank reports per step (16 B each: a 256 KiB message); a longer list waits for the next step
 
 
-def sharded_integrate(tsdf, d_xyz, d_rgb, d_kfid, offsets, d_Twc, group=None):
-    """One ray-sharded integrate call of this rank's TsdfChisel (every rank calls it with the same clouds)."""
+def sharded_integrate(tsdf, d_xyz, d_rgb, d_kfid, offsets, d_Twc, group=None, timings=None):
+    """One ray-sharded integrate call of this rank's TsdfChisel (every rank calls it with the same clouds).
+
+    timings: a dict -> the call runs with a device synchronisation after every phase and ADDS each phase's wall time
+    (ms) under 'walk', 'pack', 'exchange', 'apply', 'feedback' (a profiled call: slower than a plain one by the
+    overlap the synchronisations remove)."""
     world = dist.get_world_size(group)
-    counts = tsdf.shard_walk(d_xyz, offsets, d_Twc)
     dev = d_xyz.device
+    t_last = [0.0]
+
+    def lap(name):
+        if timings is None:
+            return
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        now = time.perf_counter()
+        if name is not None:
+            timings[name] = timings.get(name, 0.0) + (now - t_last[0]) * 1e3
+        t_last[0] = now
+
+    lap(None)
+    counts = tsdf.shard_walk(d_xyz, offsets, d_Twc)
+    lap("walk")
     seg = torch.empty((int(counts[:, 0].sum()), 8), dtype=torch.int32, device=dev)    # (shard_pack fills every row)
     rec = torch.empty((int(counts[:, 1].sum()), 8), dtype=torch.int32, device=dev)
     run = torch.empty((int(counts[:, 2].sum()), 20), dtype=torch.int32, device=dev)
     tsdf.shard_pack(seg, rec, run)
+    lap("pack")
     rseg, rrec, rrun, rcounts = exchange_segments(seg, rec, run, counts, group)
+    lap("exchange")
     tsdf.shard_apply(rseg, rrec, rrun, rcounts, d_rgb, d_kfid)
+    lap("apply")
     # voxels whose colour saturated in this call: every rank stops sending their runs.  One fixed-size all-gather
     # (list + its length in a last row); the list is advisory — a run sent for a saturated voxel is a no-op at its
     # owner — so what does not fit waits for the next step.
@@ -128,6 +151,7 @@ def sharded_integrate(tsdf, d_xyz, d_rgb, d_kfid, offsets, d_Twc, group=None):
     for r in range(world):
         if int(ks[r]):
             tsdf.shard_note_saturated(gathered[r, : int(ks[r])])
+    lap("feedback")
     return counts
 
 
