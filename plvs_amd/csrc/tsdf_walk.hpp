@@ -98,75 +98,6 @@ struct WalkCounters {           // device-side, read back once per call
   uint32_t ndeferred;           // tiles walk_fast left to walk_tiles (several clouds in the tile, table overflow)
 };
 
-// Find-or-insert with the slot returned; usable by concurrent workgroups of ONE kernel.  A block that
-// another thread is just inserting is waited for (its slot arrives a few instructions after its key) —
-// in a SECOND phase, entered only after every lane of the wave has finished its own insertions: lanes
-// of one wave run their divergent paths one after the other, so a lane that spun for another wave's
-// slot before its neighbour lane had published the slot THAT wave is spinning for would deadlock.
-__device__ inline int dir_find_or_insert(const Directory& d, int x, int y, int z, int32_t* num_blocks,
-                                         uint32_t* err) {
-  unsigned long long key;
-  if (!pack_block(x, y, z, &key)) {
-    atomicOr(err, kErrCoordRange);
-    return -1;
-  }
-  uint32_t h = dir_hash(x, y, z, d.mask);
-  int slot = -1;
-  bool pending = false, full = true;
-  // ---- phase 1: find the entry or create it (no waiting)
-  for (uint32_t probe = 0; probe <= d.mask; ++probe) {
-    // plain (cached) loads first: a block inserted by an earlier kernel is found without leaving the L2.  A
-    // stale line can only look emptier than the truth (an entry goes from empty to its final value once),
-    // and then the read-modify-write path decides: RMW atomics are performed at the device's coherence
-    // point, unlike loads, which another XCD's L2 may serve from a stale line.
-    unsigned long long cur = d.keys[h];
-    if (cur == key) {
-      const int cached = d.slots[h];
-      if (cached >= 0) {
-        slot = cached;
-        full = false;
-        break;
-      }
-    } else if (cur != kEmptyKey) {   // another block's entry (an entry never changes once written): next probe, and
-      h = (h + 1) & d.mask;          // no read-modify-write on a word that thousands of threads pass over
-      continue;
-    }
-    cur = atomicCAS(&d.keys[h], kEmptyKey, key);
-    if (cur == kEmptyKey) {   // inserted here: allocate and publish the slot
-      const int s = atomicAdd(num_blocks, 1);
-      if (s < d.max_blocks) {
-        d.slot_ids[3 * s + 0] = x;
-        d.slot_ids[3 * s + 1] = y;
-        d.slot_ids[3 * s + 2] = z;
-        atomicExch(&d.slots[h], s);
-        slot = s;
-      } else {
-        atomicOr(err, kErrPoolFull);
-        atomicExch(&d.slots[h], -2);
-      }
-      full = false;
-      break;
-    }
-    if (cur == key) {
-      pending = true;
-      full = false;
-      break;
-    }
-    h = (h + 1) & d.mask;
-  }
-  if (full) atomicOr(err, kErrPoolFull);
-  // ---- phase 2: the slot of an entry somebody else created (slots are -1 while pending, -2 / >= 0 when final)
-  if (pending) {
-    int spins = 0;
-    do {
-      slot = atomicMax(&d.slots[h], -2);   // an RMW read
-    } while (slot == -1 && ++spins < (1 << 24));
-    if (slot == -1) atomicOr(err, kErrDirectoryMiss);
-    if (slot < 0) slot = -1;
-  }
-  return slot;
-}
-
 // ------------------------------------------------------------------ the walk of one (sub-)tile
 constexpr int kLogLen = 16;                      // visits per ray kept in the tile's visit log
 constexpr int kSlabs = 8;                        // a chunk is applied in slabs of kSlabVox voxels
