@@ -684,15 +684,22 @@ def main():
                                  invz=np.full(len(k0), 0.5, np.float32), octave=k0["octave"], angle=k0["angle"], desc=d0)
             om4 = ORBmatcher(0.9, True)
 
+            no_uright = np.full(4096, -1.0, np.float32)
+
+            def match_points(k1, d1):      # runs as soon as the points are out, beside the line thread
+                cur = FrameView(k1["x"], k1["y"], k1["octave"], no_uright[:len(k1)], d1, 0.0, 0.0,
+                                64.0 / 640.0, 48.0 / 480.0, scale)
+                return om4.SearchByProjectionLastFrame(cur, k1["angle"], 640.0, 480.0, 40.0, last, 15.0)
+
             def track_once():
                 img = pinned[1].cuda(non_blocking=True)
-                _, k1, d1, l1, ld1 = extract_frame(ext3, lext3, img)
-                cur = FrameView(k1["x"], k1["y"], k1["octave"], np.full(len(k1), -1.0, np.float32), d1, 0.0, 0.0,
-                                64.0 / 640.0, 48.0 / 480.0, scale)
+                _, k1, d1, l1, ld1 = extract_frame(ext3, lext3, img, after_points=match_points)
                 lview = line_frame_view(l1, ld1, tlp.SCALE, tlp.INV_SIGMA2, tlp.MAX_DIAG)
                 nl_, _ = lm4.SearchByProjectionLastFrame(lview, lvalid, lproj, l0["octave"], l0["angle"], ld0)
                 track_once.line_matches = nl_
-                return om4.SearchByProjectionLastFrame(cur, k1["angle"], 640.0, 480.0, 40.0, last, 15.0), cur, k1
+                cur = FrameView(k1["x"], k1["y"], k1["octave"], no_uright[:len(k1)], d1, 0.0, 0.0,
+                                64.0 / 640.0, 48.0 / 480.0, scale)
+                return extract_frame.hook_result, cur, k1
 
             (nm, _), cur, k1 = track_once()
             real_us = per_call_us(lambda: track_once(), 30)
@@ -705,7 +712,8 @@ def main():
             result["frontend"]["real_pair_tracking_step"] = {
                 "what": "pinned host frame -> HBM, ORB 2000 || EDLines/LBD 100x3, ORBmatcher and LineMatcher "
                         "SearchByProjection(CurrentFrame, LastFrame) of aloe_shift against aloe's keypoints and lines "
-                        "(host flavours)",
+                        "(host flavours); the ORB search runs in plvs_hip_frame_extract_dev_hook's after-points hook, "
+                        "beside the line thread",
                 "ms_per_frame": round(real_us * 1e-3, 3), "search_by_projection_us": match_us,
                 "search_by_projection_cpu_us": cpu_match_us, "matches": int(nm),
                 "line_matches": int(getattr(track_once, "line_matches", -1)),

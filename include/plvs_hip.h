@@ -382,6 +382,16 @@ int plvs_hip_frame_extract_dev(plvs_orb* orb, plvs_lines* lines, const uint8_t* 
                                uint8_t* desc, int kp_cap, int* n_kp, int* mono_index,
                                plvs_keyline* keylines, uint8_t* line_desc, int line_cap,
                                int* n_lines);
+/* The same with a hook: after_points(user, orb_status) runs on the calling thread as soon as the points are out
+ * (kps / desc / *n_kp / *mono_index written) while the line thread is still at work — the place for what Tracking does
+ * with the points alone (ORBmatcher::SearchByProjection of TrackWithMotionModel, src/Tracking.cc) when the caller
+ * wants it off the frame's critical path; the reference joins both threads first (src/Frame.cc:507-508) and gets the
+ * same results later. */
+int plvs_hip_frame_extract_dev_hook(plvs_orb* orb, plvs_lines* lines, const uint8_t* d_image, int w,
+                                    int hh, int stride, int lap0, int lap1, plvs_keypoint* kps,
+                                    uint8_t* desc, int kp_cap, int* n_kp, int* mono_index,
+                                    plvs_keyline* keylines, uint8_t* line_desc, int line_cap,
+                                    int* n_lines, void (*after_points)(void* user, int orb_status), void* user);
 
 /* Device self-test backing the TSDF chain kernel: counts the binary32 significands b =
  * 1.m * 2^exponent for which the kernel's reciprocal (v_rcp_f32 + one Newton step) differs

@@ -9,11 +9,10 @@
 #include "common.hpp"
 #include "orb_internal.hpp"
 
-extern "C" int plvs_hip_frame_extract_dev(plvs_orb* orb, plvs_lines* lines, const uint8_t* d_image, int w,
-                                          int h, int stride, int lap0, int lap1, plvs_keypoint* kps,
-                                          uint8_t* desc, int kp_cap, int* n_kp, int* mono_index,
-                                          plvs_keyline* keylines, uint8_t* line_desc, int line_cap,
-                                          int* n_lines) {
+static int frame_extract(plvs_orb* orb, plvs_lines* lines, const uint8_t* d_image, int w, int h, int stride, int lap0,
+                         int lap1, plvs_keypoint* kps, uint8_t* desc, int kp_cap, int* n_kp, int* mono_index,
+                         plvs_keyline* keylines, uint8_t* line_desc, int line_cap, int* n_lines,
+                         void (*after_points)(void*, int), void* user) {
   PLVS_REQUIRE(orb && lines && n_kp && mono_index && n_lines, "null argument");
   int rc_lines = PLVS_OK;
   char lines_error[512] = "";
@@ -47,8 +46,28 @@ extern "C" int plvs_hip_frame_extract_dev(plvs_orb* orb, plvs_lines* lines, cons
     plvs::orb_set_pyramid_hook(orb, nullptr);
     fire();   // the extractor returned before reaching its pyramid (error paths)
   }
+  if (after_points) after_points(user, rc_orb);   // the caller's work on the points, beside the line thread
   tl.join();
   if (rc_orb != PLVS_OK) return rc_orb;
   if (rc_lines != PLVS_OK) plvs::set_error("%s", lines_error);
   return rc_lines;
+}
+
+extern "C" int plvs_hip_frame_extract_dev(plvs_orb* orb, plvs_lines* lines, const uint8_t* d_image, int w,
+                                          int h, int stride, int lap0, int lap1, plvs_keypoint* kps,
+                                          uint8_t* desc, int kp_cap, int* n_kp, int* mono_index,
+                                          plvs_keyline* keylines, uint8_t* line_desc, int line_cap,
+                                          int* n_lines) {
+  return frame_extract(orb, lines, d_image, w, h, stride, lap0, lap1, kps, desc, kp_cap, n_kp, mono_index, keylines,
+                       line_desc, line_cap, n_lines, nullptr, nullptr);
+}
+
+extern "C" int plvs_hip_frame_extract_dev_hook(plvs_orb* orb, plvs_lines* lines, const uint8_t* d_image, int w,
+                                               int h, int stride, int lap0, int lap1, plvs_keypoint* kps,
+                                               uint8_t* desc, int kp_cap, int* n_kp, int* mono_index,
+                                               plvs_keyline* keylines, uint8_t* line_desc, int line_cap,
+                                               int* n_lines, void (*after_points)(void* user, int orb_status),
+                                               void* user) {
+  return frame_extract(orb, lines, d_image, w, h, stride, lap0, lap1, kps, desc, kp_cap, n_kp, mono_index, keylines,
+                       line_desc, line_cap, n_lines, after_points, user);
 }
