@@ -848,6 +848,15 @@ int plvs_hip_tsdf_voxblox_integrate_merged(plvs_tsdf_voxblox* h, const float* xy
  * Non-finite points are refused (the reference drops them). */
 int plvs_hip_tsdf_voxblox_integrate_world_normals(plvs_tsdf_voxblox* h, const float* xyz, const uint8_t* rgba,
                                                   const float* normals, int n, const float* Twc);
+/* TsdfIntegratorBase::integrateWorlPointCloud (tsdf_integrator.cc:35-82) leaves the blocks it creates in the
+ * integrator's temp_block_map_: it never calls updateLayerWithStoredBlocks, so they join the layer only with the next
+ * integratePointCloud call (:306 / :343) — after PointCloudMapVoxblox::LoadMap the map's block list, its meshes and
+ * Block::updated() miss them until a camera cloud arrives.  enable = 1 reproduces that: blocks created by
+ * plvs_hip_tsdf_voxblox_integrate_world_normals stay out of num_blocks / block_ids / download_block /
+ * updated_block_ids / the meshing calls until the next integrate / integrate_batch_dev / integrate_merged (their
+ * voxels accumulate meanwhile, as the reference's do); enable = 0 (default) shows them at once and makes any waiting
+ * blocks visible. */
+int plvs_hip_tsdf_voxblox_set_deferred_world_blocks(plvs_tsdf_voxblox* h, int enable);
 int plvs_hip_tsdf_voxblox_last_stats(plvs_tsdf_voxblox* h, plvs_tsdf_stats* s);
 int plvs_hip_tsdf_voxblox_num_blocks(plvs_tsdf_voxblox* h, int* n);
 int plvs_hip_tsdf_voxblox_block_ids(plvs_tsdf_voxblox* h, int32_t* ids_xyz, int cap, int* n);

@@ -55,6 +55,7 @@
 typedef struct {
   int32_t id[3];
   int used;
+  int pending;     /* created by integrateWorlPointCloud, still in temp_block_map_ (only with defer_world_blocks) */
   float* distance; /* TsdfVoxel::distance, init 0 */
   float* weight;   /* TsdfVoxel::weight, init 0   */
   uint32_t* rgba;  /* Color r | g<<8 | b<<16 | a<<24, init 0 */
@@ -68,6 +69,7 @@ typedef struct oracle_voxblox {
   size_t cap, count;
   int shard_rank, shard_count;
   int64_t last_visits;
+  int defer_world_blocks, in_world_call;
 } oracle_voxblox;
 
 static size_t vb_hash(const int32_t id[3]) {
@@ -105,6 +107,8 @@ static void vtab_grow(oracle_voxblox* o) {
   o->cap = ncap;
 }
 
+static void vb_publish_pending(oracle_voxblox* o);
+
 static vblock_t* vblock_get(oracle_voxblox* o, const int32_t id[3]) {
   int found;
   vblock_t* b = vtab_find(o->tab, o->cap, id, &found);
@@ -115,6 +119,7 @@ static vblock_t* vblock_get(oracle_voxblox* o, const int32_t id[3]) {
   }
   memcpy(b->id, id, sizeof(b->id));
   b->used = 1;
+  b->pending = o->in_world_call && o->defer_world_blocks;
   b->distance = (float*)calloc(BLOCK_VOX, sizeof(float));
   b->weight = (float*)calloc(BLOCK_VOX, sizeof(float));
   b->rgba = (uint32_t*)calloc(BLOCK_VOX, sizeof(uint32_t));
@@ -327,6 +332,7 @@ static void quat_transform(const float q[4], const float t[3], const float v[3],
 void oracle_voxblox_integrate(oracle_voxblox* o, const float* xyz, const uint8_t* rgba, int n,
                               const float* Twc) {
   float R[9], t[3];
+  vb_publish_pending(o);   /* updateLayerWithStoredBlocks, tsdf_integrator.cc:306 */
   for (int i = 0; i < 3; i++) {
     for (int j = 0; j < 3; j++) R[3 * i + j] = Twc[4 * i + j];
     t[i] = Twc[4 * i + 3];
@@ -418,6 +424,7 @@ float oracle_voxblox_point_weight(const float* pC) { return fabsf(pC[2]) > 1e-6f
 void oracle_voxblox_integrate_bundles(oracle_voxblox* o, const float* merged_C, const uint32_t* colours, const float* weights,
                                       const uint8_t* clearing, int n, const float* Twc) {
   float R[9], t[3], q[4];
+  vb_publish_pending(o);   /* updateLayerWithStoredBlocks, tsdf_integrator.cc:343 */
   for (int i = 0; i < 3; i++) {
     for (int j = 0; j < 3; j++) R[3 * i + j] = Twc[4 * i + j];
     t[i] = Twc[4 * i + 3];
@@ -461,6 +468,7 @@ void oracle_voxblox_integrate_bundles(oracle_voxblox* o, const float* merged_C, 
 void oracle_voxblox_integrate_world_normals(oracle_voxblox* o, const float* xyz, const uint8_t* rgba, const float* normals,
                                             int n, const float* Twc) {
   float R[9], t[3];
+  o->in_world_call = 1;
   for (int i = 0; i < 3; i++) {
     for (int j = 0; j < 3; j++) R[3 * i + j] = Twc[4 * i + j];
     t[i] = Twc[4 * i + 3];
@@ -510,21 +518,35 @@ void oracle_voxblox_integrate_world_normals(oracle_voxblox* o, const float* xyz,
     }
   }
   o->last_visits = visits;
+  o->in_world_call = 0;
 }
 
 int64_t oracle_voxblox_last_visits(const oracle_voxblox* o) { return o->last_visits; }
-int oracle_voxblox_num_chunks(const oracle_voxblox* o) { return (int)o->count; }
+/* The layer's blocks: with defer_world_blocks, the ones integrateWorlPointCloud created are not among them until the
+ * next integratePointCloud (updateLayerWithStoredBlocks, tsdf_integrator.cc:306 / :343; never called by :35-82). */
+int oracle_voxblox_num_chunks(const oracle_voxblox* o) {
+  int k = 0;
+  for (size_t i = 0; i < o->cap; i++) k += o->tab[i].used && !o->tab[i].pending;
+  return k;
+}
 void oracle_voxblox_chunk_ids(const oracle_voxblox* o, int32_t* ids) {
   size_t k = 0;
   for (size_t i = 0; i < o->cap; i++)
-    if (o->tab[i].used) { memcpy(ids + 3 * k, o->tab[i].id, 3 * sizeof(int32_t)); k++; }
+    if (o->tab[i].used && !o->tab[i].pending) { memcpy(ids + 3 * k, o->tab[i].id, 3 * sizeof(int32_t)); k++; }
+}
+static void vb_publish_pending(oracle_voxblox* o) {
+  for (size_t i = 0; i < o->cap; i++) o->tab[i].pending = 0;
+}
+void oracle_voxblox_set_deferred_world_blocks(oracle_voxblox* o, int enable) {
+  o->defer_world_blocks = enable != 0;
+  if (!enable) vb_publish_pending(o);
 }
 int oracle_voxblox_get_chunk(const oracle_voxblox* o, int cx, int cy, int cz, float* distance,
                              float* weight, uint32_t* rgba) {
   const int32_t id[3] = {cx, cy, cz};
   int found;
   vblock_t* b = vtab_find(o->tab, o->cap, id, &found);
-  if (!found) return 0;
+  if (!found || b->pending) return 0;
   memcpy(distance, b->distance, BLOCK_VOX * sizeof(float));
   memcpy(weight, b->weight, BLOCK_VOX * sizeof(float));
   memcpy(rgba, b->rgba, BLOCK_VOX * sizeof(uint32_t));
@@ -652,7 +674,7 @@ static const vblock_t* vb_mesh_find(const oracle_voxblox* o, int x, int y, int z
   const int32_t id[3] = {x, y, z};
   int found = 0;
   vblock_t* b = vtab_find(o->tab, o->cap, id, &found);
-  return found ? b : NULL;
+  return found && !b->pending ? b : NULL;
 }
 
 static void vb_block_origin(const oracle_voxblox* o, const vblock_t* b, float org[3]) {

@@ -359,6 +359,36 @@ __global__ __launch_bounds__(256) void vb_chain_chunks(Params P, const uint32_t*
   if (lane == 0 && longest > ctr->max_run) atomicMax(&ctr->max_run, longest);
 }
 
+// The updated-block list without the blocks that have not joined the layer yet (slots >= visible), order kept; one
+// workgroup (the list has a few thousand entries).  *n_out = the new length.
+__global__ __launch_bounds__(1024) void vb_filter_slots(uint32_t* __restrict__ slots, uint32_t n, uint32_t visible,
+                                                        uint32_t* __restrict__ n_out) {
+  __shared__ uint32_t s_cnt[16];
+  __shared__ uint32_t s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) s_base = 0u;
+  __syncthreads();
+  for (uint32_t i0 = 0; i0 < n; i0 += 1024u) {
+    const uint32_t i = i0 + (uint32_t)tid;
+    const uint32_t v = i < n ? slots[i] : 0u;
+    const bool keep = i < n && v < visible;
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) s_cnt[wid] = (uint32_t)__popcll(m);
+    __syncthreads();   // (every slot of this round has been read: compaction only moves entries towards the front)
+    uint32_t at = s_base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wid; ++w) at += s_cnt[w];
+    if (keep) slots[at] = v;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t t = 0;
+      for (int w = 0; w < 16; ++w) t += s_cnt[w];
+      s_base += t;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *n_out = s_base;
+}
+
 __global__ void vb_gather_slot_ids(const uint32_t* __restrict__ slots, int n,
                                    const int32_t* __restrict__ slot_ids, int32_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -382,6 +412,8 @@ struct plvs_tsdf_voxblox {
   VCounters* d_ctr = nullptr;
   VCounters* h_ctr = nullptr;
   int num_blocks = 0;
+  int visible_blocks = 0;              // blocks the layer shows: all, unless world-cloud blocks wait for the next camera-ray call
+  bool defer_world_blocks = false;
   bool poisoned = false;
   DevBuf<uint32_t> counts, keys0, keys1, seq0, seq1, heads, updated, scratch, rec_c;
   DevBuf<float2> rec;
@@ -416,6 +448,7 @@ bool voxblox_map_view(plvs_tsdf_voxblox* h, VoxbloxMapView* v) {
   v->weight = h->weight;
   v->rgba = h->rgba;
   v->num_blocks = h->num_blocks;
+  v->visible_blocks = h->visible_blocks;
   v->shard_count = h->P.shard_count;
   v->ghost = h->gdir;
   v->ext = &h->ext;
@@ -483,6 +516,7 @@ int plvs_hip_tsdf_voxblox_clear(plvs_tsdf_voxblox* h) {
   PLVS_HIP_TRY(hipMemset(h->d_ctr, 0, sizeof(VCounters)));
   PLVS_HIP_TRY(hipDeviceSynchronize());
   h->num_blocks = 0;
+  h->visible_blocks = 0;
   h->poisoned = false;
   h->stats = plvs_tsdf_stats{};
   h->last_updated = 0;
@@ -695,6 +729,7 @@ int plvs_hip_tsdf_voxblox_upload_block(plvs_tsdf_voxblox* h, int bx, int by, int
   const int slot = (int)h->h_ctr->total_visits;
   PLVS_REQUIRE(slot >= 0, "internal: the block was not inserted");
   h->num_blocks = h->h_ctr->num_blocks;
+  h->visible_blocks = h->num_blocks;   // (a block handed to the layer directly: whatever waited joins with it)
   const size_t off = (size_t)slot * kBlockVox;
   PLVS_HIP_TRY(hipMemcpy(h->dist + off, distance, kBlockVox * sizeof(float), hipMemcpyHostToDevice));
   PLVS_HIP_TRY(hipMemcpy(h->weight + off, weight, kBlockVox * sizeof(float), hipMemcpyHostToDevice));
@@ -830,6 +865,9 @@ static int vb_integrate_impl(plvs_tsdf_voxblox* h, const float* d_xyz, const uin
   const uint32_t V = h->h_ctr->total_visits;
   const int before = h->num_blocks;
   h->num_blocks = h->h_ctr->num_blocks;
+  // integratePointCloud starts with updateLayerWithStoredBlocks (tsdf_integrator.cc:306, :343): whatever a world cloud
+  // left waiting joins the layer now; integrateWorlPointCloud itself never calls it (:35-82)
+  if (!(mode == kWorld && h->defer_world_blocks)) h->visible_blocks = h->num_blocks;
   h->stats.visits = V;
   h->stats.new_chunks = h->num_blocks - before;
   if (V == 0) return PLVS_OK;
@@ -877,6 +915,14 @@ static int vb_integrate_impl(plvs_tsdf_voxblox* h, const float* d_xyz, const uin
   h->stats.voxels = (int32_t)h->h_ctr->num_heads;
   h->stats.max_run = (int32_t)h->h_ctr->max_run;
   h->last_updated = h->h_ctr->num_updated;
+  if (h->visible_blocks < h->num_blocks && h->last_updated > 0) {   // Block::updated() of a block outside the layer is not seen
+    hipLaunchKernelGGL(vb_filter_slots, dim3(1), dim3(1024), 0, s, h->updated.p, h->last_updated, (uint32_t)h->visible_blocks,
+                       &h->d_ctr->num_updated);
+    PLVS_KERNEL_CHECK();
+    rc = vb_read_counters(h, s);
+    if (rc != PLVS_OK) return rc;
+    h->last_updated = h->h_ctr->num_updated;
+  }
   return PLVS_OK;
 }
 
@@ -1028,6 +1074,13 @@ int plvs_hip_tsdf_voxblox_integrate(plvs_tsdf_voxblox* h, const float* xyz, cons
   return PLVS_OK;
 }
 
+int plvs_hip_tsdf_voxblox_set_deferred_world_blocks(plvs_tsdf_voxblox* h, int enable) {
+  PLVS_REQUIRE(h, "null handle");
+  h->defer_world_blocks = enable != 0;
+  if (!h->defer_world_blocks) h->visible_blocks = h->num_blocks;
+  return PLVS_OK;
+}
+
 int plvs_hip_tsdf_voxblox_last_stats(plvs_tsdf_voxblox* h, plvs_tsdf_stats* s) {
   PLVS_REQUIRE(h && s, "null argument");
   *s = h->stats;
@@ -1036,14 +1089,14 @@ int plvs_hip_tsdf_voxblox_last_stats(plvs_tsdf_voxblox* h, plvs_tsdf_stats* s) {
 
 int plvs_hip_tsdf_voxblox_num_blocks(plvs_tsdf_voxblox* h, int* n) {
   PLVS_REQUIRE(h && n, "null argument");
-  *n = h->num_blocks;
+  *n = h->visible_blocks;
   return PLVS_OK;
 }
 
 int plvs_hip_tsdf_voxblox_block_ids(plvs_tsdf_voxblox* h, int32_t* ids_xyz, int cap, int* n) {
   PLVS_REQUIRE(h && n, "null argument");
-  *n = h->num_blocks;
-  const int m = h->num_blocks < cap ? h->num_blocks : cap;
+  *n = h->visible_blocks;
+  const int m = h->visible_blocks < cap ? h->visible_blocks : cap;
   if (m > 0) {
     PLVS_REQUIRE(ids_xyz, "null output");
     PLVS_HIP_TRY(hipMemcpy(ids_xyz, h->dir.slot_ids, (size_t)m * 3 * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1088,7 +1141,7 @@ int plvs_hip_tsdf_voxblox_download_block(plvs_tsdf_voxblox* h, int bx, int by, i
     e = hipMemcpy(all, h->dir.slot_ids, (size_t)h->num_blocks * 3 * sizeof(int32_t), hipMemcpyDeviceToHost);
   int slot = -1;
   if (e == hipSuccess)
-    for (int i = 0; i < h->num_blocks; ++i)
+    for (int i = 0; i < h->visible_blocks; ++i)
       if (all[3 * i] == bx && all[3 * i + 1] == by && all[3 * i + 2] == bz) { slot = i; break; }
   delete[] all;
   PLVS_HIP_TRY(e);

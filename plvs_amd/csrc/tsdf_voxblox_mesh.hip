@@ -76,7 +76,8 @@ struct Cube {
 
 // Block id -> pool slot: the rank's own blocks, then the ghosts of a sharded map's halo.
 __device__ __forceinline__ int find_block(const VoxbloxMapView& m, int bx, int by, int bz) {
-  const int s = dir_find(m.dir, bx, by, bz);
+  int s = dir_find(m.dir, bx, by, bz);
+  if (s >= m.visible_blocks) s = -1;   // (a block that has not joined the layer yet)
   if (s >= 0 || m.ghost.keys == nullptr) return s;
   return dir_find(m.ghost, bx, by, bz);
 }
@@ -130,7 +131,10 @@ __device__ __forceinline__ int table_vertices(int index) {
 // Block ids -> pool slots (-1 = the block does not exist: updateMeshForBlock returns with the mesh cleared, :239-243).
 __global__ void vmesh_slots(VoxbloxMapView m, const int32_t* __restrict__ ids, int nblocks, int32_t* __restrict__ slots) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < nblocks) slots[c] = dir_find(m.dir, ids[3 * c], ids[3 * c + 1], ids[3 * c + 2]);
+  if (c < nblocks) {
+    const int s = dir_find(m.dir, ids[3 * c], ids[3 * c + 1], ids[3 * c + 2]);
+    slots[c] = s < m.visible_blocks ? s : -1;
+  }
 }
 
 __global__ __launch_bounds__(kMeshThreads) void vmesh_count(VoxbloxMapView m, const int32_t* __restrict__ ids,

@@ -19,6 +19,7 @@ struct VoxbloxMapView {
   const float* weight = nullptr;
   const uint32_t* rgba = nullptr;   // r | g << 8 | b << 16 | a << 24
   int num_blocks = 0;
+  int visible_blocks = 0;           // own blocks the layer shows (< num_blocks while world-cloud blocks wait: see plvs_hip_tsdf_voxblox_set_deferred_world_blocks)
   int shard_count = 1;
   // sharded maps: copies of other ranks' blocks brought in for meshing (plvs_hip_tsdf_voxblox_halo_*): id -> pool slot
   // past num_blocks; keys null until a halo has been imported

@@ -394,6 +394,13 @@ class TsdfVoxblox:
     def clear(self):
         _lib.check(_L.plvs_hip_tsdf_voxblox_clear(self._h))
 
+    def set_deferred_world_blocks(self, enable):
+        """plvs_hip_tsdf_voxblox_set_deferred_world_blocks: blocks created by integrate_world_normals stay out of the
+        block list / meshes / updated list until the next camera-ray integrate (the reference's behaviour)."""
+        f = _L.plvs_hip_tsdf_voxblox_set_deferred_world_blocks
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        _lib.check(f(self._h, int(enable)))
+
     def integrate(self, xyz, rgba, Twc):
         xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
         rgba = np.ascontiguousarray(rgba, dtype=np.uint8).reshape(-1, 4)

@@ -511,6 +511,12 @@ class _VoxbloxLike:
             getattr(self.lib, self.p + "_destroy")(self.h)
             self.h = None
 
+    def set_deferred_world_blocks(self, enable):
+        """Blocks created by integrate_world_normals join the block list only with the next camera-ray integrate."""
+        f = getattr(self.lib, self.p + "_set_deferred_world_blocks")
+        f.argtypes = [_vp, _i]
+        f(self.h, int(enable))
+
     def integrate(self, xyz, rgba, Twc):
         xyz = np.ascontiguousarray(xyz, dtype=np.float32)
         rgba = np.ascontiguousarray(rgba, dtype=np.uint8)

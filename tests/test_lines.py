@@ -168,6 +168,45 @@ def test_hip_frame_extract_points_and_lines_together(oracle):
     lines.close()
 
 
+@pytest.mark.gpu
+def test_hip_frame_extract_hook_sees_the_points_before_the_lines_are_out(oracle):
+    """plvs_hip_frame_extract_dev_hook: the hook runs once, on the caller's thread, with the finished points — the same
+    points and lines come back as without it; an exception raised inside it reaches the caller after the call."""
+    import threading
+    import torch
+    from plvs_amd.frame import extract_frame
+    from plvs_amd.lines import LineExtractor
+    from plvs_amd.orb import ORBextractor
+    orb, lines = ORBextractor(1000, 1.2, 8, 20, 7), LineExtractor(100)
+    img = golden(IMAGES[0])
+    omono, okps, odesc = oracle.orb(1000, 1.2, 8, 20, 7).extract(img)
+    okl, oldesc = oracle.lines().extract(img)
+    seen = []
+
+    def hook(kps, desc):
+        seen.append((kps.tobytes(), desc.copy(), threading.get_ident()))
+        return len(kps)
+
+    for _ in range(3):
+        mono, kps, desc, kl, ldesc = extract_frame(orb, lines, torch.from_numpy(img).cuda(), after_points=hook)
+        assert extract_frame.hook_result == len(okps)
+        assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
+        assert kl.tobytes() == okl.tobytes() and np.array_equal(ldesc, oldesc)
+    assert len(seen) == 3
+    for b, d, tid in seen:
+        assert b == okps.tobytes() and np.array_equal(d, odesc) and tid == threading.get_ident()
+
+    def bad(kps, desc):
+        raise ValueError("from the hook")
+
+    with pytest.raises(ValueError, match="from the hook"):
+        extract_frame(orb, lines, torch.from_numpy(img).cuda(), after_points=bad)
+    mono, kps, desc, kl, ldesc = extract_frame(orb, lines, torch.from_numpy(img).cuda())   # the extractors are intact
+    assert kps.tobytes() == okps.tobytes() and kl.tobytes() == okl.tobytes()
+    orb.close()
+    lines.close()
+
+
 # ------------------------------------------------------------------ shared ORB pyramid (O9)
 def _oracle_shared(oracle, img, nfeatures=1000):
     oorb = oracle.orb(nfeatures, 1.2, 8, 20, 7)

@@ -429,6 +429,62 @@ def test_voxblox_world_cloud_integrate_equals_the_reference_source():
 
 
 @needs_vref
+def test_voxblox_world_cloud_block_visibility_equals_the_reference_source():
+    """With set_deferred_world_blocks the restatement shows what the reference's layer shows at every point of
+    camera cloud -> world cloud -> world cloud -> camera cloud: the blocks a world cloud creates are absent from the
+    block list (and read as missing) until the next integratePointCloud, their voxels accumulating meanwhile."""
+    from tests import oracle_lib
+    from tests.plvs_amd_synth import make_keyframes
+    from tests.test_tsdf_loadmap import surface_cloud
+    ref = ctypes.CDLL(VREF)
+    oracle = oracle_lib.load()
+    ref.ref_voxblox_integrate.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int]
+    ref.ref_voxblox_integrate_world.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int]
+    ref.ref_voxblox_destroy.argtypes = [ctypes.c_void_p]
+    oracle.lib.oracle_voxblox_pose_quat.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    vs = 0.05
+    h = _ref_map(ref, vs, False, "simple")
+    ora = oracle.voxblox(vs)
+    ora.set_deferred_world_blocks(True)
+
+    def same():
+        want = _ref_blocks(ref, h)
+        got = {tuple(int(v) for v in b): ora.get_chunk(*b) for b in ora.chunk_ids()}
+        assert set(got) == set(want) and ora.num_chunks() == len(want)
+        for bid, planes in want.items():
+            for name, x, y in zip(("distance", "weight", "colour"), planes, got[bid]):
+                assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (name, bid)
+        return len(want)
+
+    def pose(Twc):
+        Twc = np.ascontiguousarray(Twc, np.float32).reshape(3, 4)
+        q = np.zeros(4, np.float32)
+        oracle.lib.oracle_voxblox_pose_quat(Twc.ctypes.data, q.ctypes.data)
+        return Twc, q, np.ascontiguousarray(Twc[:, 3])
+
+    kfs = make_keyframes(2, seed=4)
+    counts = []
+    for step in ("cam0", "world1", "world2", "cam1"):
+        if step.startswith("cam"):
+            k = kfs[int(step[3])]
+            xyz = np.ascontiguousarray(k["xyz"][::2], np.float32)
+            rgba = np.ascontiguousarray(np.concatenate([k["rgb"][::2], np.full((len(xyz), 1), 255, np.uint8)], 1))
+            Twc, q, t = pose(k["Twc"])
+            ref.ref_voxblox_integrate(h, q.ctypes.data, t.ctypes.data, xyz.ctypes.data, rgba.ctypes.data, len(xyz))
+            ora.integrate(xyz, rgba, Twc)
+        else:
+            xyz, rgb, _, nrm = surface_cloud(20000, int(step[5]), vs)
+            rgba = np.ascontiguousarray(np.concatenate([rgb, np.full((len(rgb), 1), 200, np.uint8)], 1))
+            Twc, q, t = pose(np.eye(4, dtype=np.float32)[:3])
+            ref.ref_voxblox_integrate_world(h, q.ctypes.data, t.ctypes.data, xyz.ctypes.data, rgba.ctypes.data, nrm.ctypes.data, len(xyz))
+            ora.integrate_world_normals(xyz, rgba, nrm, Twc)
+        counts.append(same())
+    assert counts[1] == counts[0] or counts[2] <= counts[3]        # (world clouds add nothing visible ...)
+    assert counts[3] > counts[2]                                    # (... until the camera cloud publishes their blocks)
+    ref.ref_voxblox_destroy(h)
+
+
+@needs_vref
 def test_voxblox_mesh_integrator_equals_the_reference_source():
     """MeshIntegrator<TsdfVoxel>::updateMeshForBlock of the reference (mesh/mesh_integrator.h with Layer / Block / Mesh,
     compiled unmodified) on a map its own SimpleTsdfIntegrator built, against oracle_voxblox_mesh_block on the oracle's

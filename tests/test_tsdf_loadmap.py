@@ -198,3 +198,60 @@ def test_voxblox_save_load_round_trip_through_the_mirror(oracle):
         for x, y in zip(ref.get_chunk(*bid), fresh.tsdf.get_chunk(*bid)):
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), bid
     assert len(reloaded) > 0.3 * len(saved)
+
+
+@pytest.mark.gpu
+def test_hip_voxblox_deferred_world_blocks_match_oracle(oracle):
+    """plvs_hip_tsdf_voxblox_set_deferred_world_blocks: at every point of camera cloud -> world cloud -> world cloud ->
+    camera cloud the device map lists the blocks the oracle lists (pinned to the reference's layer by
+    tests/test_oracle_pinned.py), with the same voxels; a waiting block is absent from the updated list and reads as
+    missing; switching the flag off publishes what waits."""
+    from plvs_amd import _lib
+    from plvs_amd.tsdf import TsdfVoxblox
+    vs = 0.05
+    ref, hip = oracle.voxblox(vs), TsdfVoxblox(vs, max_blocks=65536)
+    ref.set_deferred_world_blocks(True)
+    hip.set_deferred_world_blocks(True)
+
+    def same():
+        ids = sorted(tuple(int(v) for v in b) for b in ref.chunk_ids())
+        assert ids == sorted(tuple(int(v) for v in b) for b in hip.chunk_ids())
+        assert hip.num_chunks() == len(ids)
+        for bid in ids:
+            for name, x, y in zip(("distance", "weight", "colour"), ref.get_chunk(*bid), hip.get_chunk(*bid)):
+                assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (name, bid)
+        return set(ids)
+
+    kfs = make_keyframes(2, seed=4)
+    rgba0 = np.concatenate([kfs[0]["rgb"], np.full((len(kfs[0]["rgb"]), 1), 255, np.uint8)], 1)
+    ref.integrate(kfs[0]["xyz"], rgba0, kfs[0]["Twc"])
+    hip.integrate(kfs[0]["xyz"], rgba0, kfs[0]["Twc"])
+    seen0 = same()
+    xyz, rgb, _, nrm = surface_cloud(20000, 1, vs)
+    rgba = np.concatenate([rgb, np.full((len(rgb), 1), 200, np.uint8)], 1)
+    ref.integrate_world_normals(xyz, rgba, nrm)
+    hip.integrate_world_normals(xyz, rgba, nrm)
+    assert hip.last_stats()["visits"] == ref.last_visits()
+    seen1 = same()
+    assert seen1 == seen0                                   # nothing the world cloud created is visible
+    upd = set(tuple(int(v) for v in b) for b in hip.updated_chunk_ids())
+    assert upd <= seen1                                     # (only blocks of the layer report Block::updated())
+    assert hip.last_stats()["new_chunks"] > 0
+    xyz2, rgb2, _, nrm2 = surface_cloud(20000, 2, vs)
+    rgba2 = np.concatenate([rgb2, np.full((len(rgb2), 1), 200, np.uint8)], 1)
+    ref.integrate_world_normals(xyz2, rgba2, nrm2)
+    hip.integrate_world_normals(xyz2, rgba2, nrm2)
+    assert same() == seen0
+    rgba1 = np.concatenate([kfs[1]["rgb"], np.full((len(kfs[1]["rgb"]), 1), 255, np.uint8)], 1)
+    ref.integrate(kfs[1]["xyz"], rgba1, kfs[1]["Twc"])
+    hip.integrate(kfs[1]["xyz"], rgba1, kfs[1]["Twc"])
+    seen3 = same()
+    assert len(seen3) > len(seen0) + 10                     # the camera cloud published them, with both clouds' voxels
+    # the flag off: world-cloud blocks show at once again, and whatever waits is published
+    ref.integrate_world_normals(xyz + np.float32(3.0), rgba, nrm)
+    hip.integrate_world_normals(xyz + np.float32(3.0), rgba, nrm)
+    assert same() == seen3
+    ref.set_deferred_world_blocks(False)
+    hip.set_deferred_world_blocks(False)
+    assert len(same()) > len(seen3)
+    hip.close()
