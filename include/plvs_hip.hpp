@@ -611,6 +611,10 @@ class PointCloudMapVoxblox {
     else check(plvs_hip_tsdf_voxblox_integrate(h_, xyz_.data(), rgba_.data(), (int)n, Twc.m));
     MarkUpdated();
   }
+  // The reference's LoadMap leaves the blocks of the loaded cloud outside the layer until the next InsertCloud
+  // (integrateWorlPointCloud never publishes them: plvs_hip_tsdf_voxblox_set_deferred_world_blocks) — its UpdateMap
+  // meshes none of them.  Off by default (the loaded map shows at once); on = what a PLVS build does today.
+  void SetReferenceLoadMapVisibility(bool on) { check(plvs_hip_tsdf_voxblox_set_deferred_world_blocks(h_, on ? 1 : 0)); }
   // LoadMap of a saved cloud once PointCloudMap::LoadMap has read it (src/PointCloudMapVoxblox.cc:233-258):
   // TsdfServer::insertWorldPointCloud(cloud, identity) — every point along its normal — then UpdateMap.
   int LoadMap(const std::vector<PointSurfelSegment>& cloud) {

@@ -12,6 +12,7 @@
 // (12 B per voxel, 48 KiB per block, voxel.h:12-18), the shared block directory
 // (tsdf_directory.hpp), and per call one (u32 key, u32 sequence) pair plus
 // 12 B of operands per voxel visit.
+#include <algorithm>
 #include <cstring>
 #include <unordered_map>
 #include <vector>
@@ -417,6 +418,7 @@ struct plvs_tsdf_voxblox {
   bool poisoned = false;
   DevBuf<uint32_t> counts, keys0, keys1, seq0, seq1, heads, updated, scratch, rec_c;
   DevBuf<float2> rec;
+  DevBuf<uint32_t> upd_merge;          // (the updated list when waiting world-cloud blocks join it)
   DevBuf<int32_t> offsets;
   DevBuf<float> st_xyz, st_Twc, st_nrm;
   DevBuf<uint32_t> st_rgba;
@@ -494,7 +496,7 @@ int plvs_hip_tsdf_voxblox_destroy(plvs_tsdf_voxblox* h) {
   (void)hipFree(h->dist); (void)hipFree(h->weight); (void)hipFree(h->rgba); (void)hipFree(h->d_ctr);
   if (h->h_ctr) (void)hipHostFree(h->h_ctr);
   h->counts.release(); h->keys0.release(); h->keys1.release(); h->seq0.release(); h->seq1.release();
-  h->heads.release(); h->updated.release(); h->scratch.release(); h->rec_c.release(); h->rec.release();
+  h->heads.release(); h->updated.release(); h->scratch.release(); h->rec_c.release(); h->rec.release(); h->upd_merge.release();
   h->offsets.release(); h->st_xyz.release(); h->st_Twc.release(); h->st_nrm.release(); h->st_rgba.release();
   h->mg_kind.release(); h->mg_clr.release(); h->mg_g.release(); h->mg_first.release(); h->mg_pts.release(); h->mg_col.release();
   h->mg_xyz.release(); h->mg_w.release(); h->poses.release();
@@ -807,6 +809,29 @@ int plvs_hip_tsdf_voxblox_halo_clear(plvs_tsdf_voxblox* h) {
 
 }  // extern "C"
 
+// Blocks a world cloud left waiting (slots [lo, hi)) have just joined the layer with their Block::updated() flags set
+// (integrateWorlPointCloud marks them, tsdf_integrator.cc:76-80): they belong to this call's updated list even if this
+// call's rays did not touch them.  Rare (once after a LoadMap): done on the host.
+static int vb_publish_waiting(plvs_tsdf_voxblox* h, hipStream_t s, int published_lo, int published_hi) {
+  if (published_hi <= published_lo) return PLVS_OK;
+  std::vector<uint32_t> upd(h->last_updated);
+  if (!upd.empty()) PLVS_HIP_TRY(hipMemcpyAsync(upd.data(), h->updated.p, upd.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  std::vector<uint8_t> in((size_t)(published_hi - published_lo), 0);
+  for (uint32_t v : upd)
+    if ((int)v >= published_lo && (int)v < published_hi) in[(size_t)((int)v - published_lo)] = 1;
+  for (int v = published_lo; v < published_hi; ++v)
+    if (!in[(size_t)(v - published_lo)]) upd.push_back((uint32_t)v);
+  std::sort(upd.begin(), upd.end());
+  PLVS_HIP_TRY(h->upd_merge.reserve(upd.size() + 1));
+  PLVS_HIP_TRY(hipMemcpy(h->upd_merge.p, upd.data(), upd.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  std::swap(h->updated.p, h->upd_merge.p);
+  std::swap(h->updated.cap, h->upd_merge.cap);
+  h->last_updated = (uint32_t)upd.size();
+  h->stats.updated_chunks = (int32_t)upd.size();
+  return PLVS_OK;
+}
+
 // mode kWorld: the world-cloud-with-normals flavour (integrateWorlPointCloud), d_aux = normals; mode kMerged:
 // MergedTsdfIntegrator's bundles, d_aux = merged weights, d_clr = clearing flags.  Both: one cloud.
 static int vb_integrate_impl(plvs_tsdf_voxblox* h, const float* d_xyz, const uint8_t* d_rgba, const int32_t* offsets,
@@ -818,12 +843,19 @@ static int vb_integrate_impl(plvs_tsdf_voxblox* h, const float* d_xyz, const uin
   hipStream_t s = static_cast<hipStream_t>(stream);
   h->stats = plvs_tsdf_stats{};
   h->last_updated = 0;
-  if (nclouds == 0) return PLVS_OK;
+  // a camera cloud, even an empty one, starts with updateLayerWithStoredBlocks (tsdf_integrator.cc:306 / :343)
+  auto publish_all = [&]() -> int {
+    if (mode == kWorld) return PLVS_OK;
+    const int lo = h->visible_blocks, hi = h->num_blocks;
+    h->visible_blocks = h->num_blocks;
+    return vb_publish_waiting(h, s, lo, hi);
+  };
+  if (nclouds == 0) return publish_all();
   const int n = offsets[nclouds] - offsets[0];
   PLVS_REQUIRE(offsets[0] == 0 && n >= 0, "offsets must start at 0 and be non-decreasing");
   for (int c = 0; c < nclouds; ++c) PLVS_REQUIRE(offsets[c + 1] >= offsets[c], "offsets must be non-decreasing");
   h->stats.points = n;
-  if (n == 0) return PLVS_OK;
+  if (n == 0) return publish_all();
   PLVS_REQUIRE(d_xyz && d_rgba && d_Twc, "null device pointer");
   PLVS_REQUIRE((reinterpret_cast<uintptr_t>(d_rgba) & 3) == 0, "rgba must be 4-byte aligned");
   {
@@ -867,10 +899,11 @@ static int vb_integrate_impl(plvs_tsdf_voxblox* h, const float* d_xyz, const uin
   h->num_blocks = h->h_ctr->num_blocks;
   // integratePointCloud starts with updateLayerWithStoredBlocks (tsdf_integrator.cc:306, :343): whatever a world cloud
   // left waiting joins the layer now; integrateWorlPointCloud itself never calls it (:35-82)
+  const int published_lo = h->visible_blocks, published_hi = (mode == kWorld && h->defer_world_blocks) ? h->visible_blocks : before;
   if (!(mode == kWorld && h->defer_world_blocks)) h->visible_blocks = h->num_blocks;
   h->stats.visits = V;
   h->stats.new_chunks = h->num_blocks - before;
-  if (V == 0) return PLVS_OK;
+  if (V == 0) return vb_publish_waiting(h, s, published_lo, published_hi);
   PLVS_HIP_TRY(h->keys0.reserve(V));
   PLVS_HIP_TRY(h->keys1.reserve(V));
   PLVS_HIP_TRY(h->seq0.reserve(V));
@@ -915,6 +948,10 @@ static int vb_integrate_impl(plvs_tsdf_voxblox* h, const float* d_xyz, const uin
   h->stats.voxels = (int32_t)h->h_ctr->num_heads;
   h->stats.max_run = (int32_t)h->h_ctr->max_run;
   h->last_updated = h->h_ctr->num_updated;
+  {
+    int rc2 = vb_publish_waiting(h, s, published_lo, published_hi);
+    if (rc2 != PLVS_OK) return rc2;
+  }
   if (h->visible_blocks < h->num_blocks && h->last_updated > 0) {   // Block::updated() of a block outside the layer is not seen
     hipLaunchKernelGGL(vb_filter_slots, dim3(1), dim3(1024), 0, s, h->updated.p, h->last_updated, (uint32_t)h->visible_blocks,
                        &h->d_ctr->num_updated);
@@ -1054,10 +1091,9 @@ int plvs_hip_tsdf_voxblox_integrate(plvs_tsdf_voxblox* h, const float* xyz, cons
                                     int n, const float* Twc) {
   PLVS_REQUIRE(h, "null handle");
   PLVS_REQUIRE(n >= 0 && Twc, "bad arguments");
-  if (n == 0) {
-    h->stats = plvs_tsdf_stats{};
-    h->last_updated = 0;
-    return PLVS_OK;
+  if (n == 0) {   // (an empty cloud still publishes what a world cloud left waiting)
+    const int32_t none[2] = {0, 0};
+    return plvs_hip_tsdf_voxblox_integrate_batch_dev(h, nullptr, nullptr, none, 1, nullptr, nullptr);
   }
   PLVS_REQUIRE(xyz && rgba, "null cloud pointer");
   PLVS_HIP_TRY(h->st_xyz.reserve((size_t)n * 3));

@@ -563,6 +563,11 @@ class PointCloudMapVoxblox:
         for b in self._tsdf.updated_chunk_ids():          # tsdf_integrator.cc:151
             self._updated.add((int(b[0]), int(b[1]), int(b[2])))
 
+    def SetReferenceLoadMapVisibility(self, on):
+        """The reference's LoadMap leaves the loaded cloud's blocks outside the layer until the next InsertCloud
+        (integrateWorlPointCloud never publishes them); on = reproduce that, off (default) = the map shows at once."""
+        self._tsdf.set_deferred_world_blocks(on)
+
     def LoadMap(self, cloud):
         """LoadMap of a saved cloud once PointCloudMap::LoadMap has read it (src/PointCloudMapVoxblox.cc:233-258):
         TsdfServer::insertWorldPointCloud(cloud, identity) — every point along its normal — then UpdateMap.  (The

@@ -247,11 +247,26 @@ def test_hip_voxblox_deferred_world_blocks_match_oracle(oracle):
     hip.integrate(kfs[1]["xyz"], rgba1, kfs[1]["Twc"])
     seen3 = same()
     assert len(seen3) > len(seen0) + 10                     # the camera cloud published them, with both clouds' voxels
+    # ... and they arrive with their updated() flags: the call's updated list holds them whether or not its rays met them
+    upd3 = set(tuple(int(v) for v in b) for b in hip.updated_chunk_ids())
+    assert (seen3 - seen0) <= upd3 and upd3 <= seen3
     # the flag off: world-cloud blocks show at once again, and whatever waits is published
     ref.integrate_world_normals(xyz + np.float32(3.0), rgba, nrm)
     hip.integrate_world_normals(xyz + np.float32(3.0), rgba, nrm)
     assert same() == seen3
     ref.set_deferred_world_blocks(False)
     hip.set_deferred_world_blocks(False)
-    assert len(same()) > len(seen3)
+    seen4 = same()
+    assert len(seen4) > len(seen3)
+    # an EMPTY camera cloud publishes too (integratePointCloud starts with updateLayerWithStoredBlocks)
+    ref.set_deferred_world_blocks(True)
+    hip.set_deferred_world_blocks(True)
+    ref.integrate_world_normals(xyz - np.float32(3.0), rgba, nrm)
+    hip.integrate_world_normals(xyz - np.float32(3.0), rgba, nrm)
+    assert same() == seen4
+    ref.integrate(np.zeros((0, 3), np.float32), np.zeros((0, 4), np.uint8), kfs[1]["Twc"])
+    hip.integrate(np.zeros((0, 3), np.float32), np.zeros((0, 4), np.uint8), kfs[1]["Twc"])
+    seen5 = same()
+    assert len(seen5) > len(seen4)
+    assert set(tuple(int(v) for v in b) for b in hip.updated_chunk_ids()) == seen5 - seen4
     hip.close()
