@@ -191,11 +191,18 @@ PLVS_HD void make_ray_world(const Params& P, const PoseRt& pose, float px, float
 // RayCaster::nextRayIndex: returns the current voxel and advances.
 PLVS_HD void ray_step(Ray* r, int g[3]) {
   g[0] = r->cur[0]; g[1] = r->cur[1]; g[2] = r->cur[2];
-  int mi = 0;  // Eigen minCoeff(&idx): first coefficient unless a later one is strictly smaller
-  if (r->t_next[1] < r->t_next[mi]) mi = 1;
-  if (r->t_next[2] < r->t_next[mi]) mi = 2;
-  r->cur[mi] += r->sgn[mi];
-  r->t_next[mi] += r->t_step[mi];
+  // Eigen minCoeff(&idx): the first coefficient unless a later one is strictly smaller.  Written with selects on
+  // constant indices: an index computed at run time would send the whole Ray to scratch / LDS.
+  const bool y_lt = r->t_next[1] < r->t_next[0];
+  const float m01 = y_lt ? r->t_next[1] : r->t_next[0];
+  const bool z_lt = r->t_next[2] < m01;
+  const bool s0 = !y_lt && !z_lt, s1 = y_lt && !z_lt;
+  r->cur[0] += s0 ? r->sgn[0] : 0;
+  r->cur[1] += s1 ? r->sgn[1] : 0;
+  r->cur[2] += z_lt ? r->sgn[2] : 0;
+  r->t_next[0] = s0 ? r->t_next[0] + r->t_step[0] : r->t_next[0];
+  r->t_next[1] = s1 ? r->t_next[1] + r->t_step[1] : r->t_next[1];
+  r->t_next[2] = z_lt ? r->t_next[2] + r->t_step[2] : r->t_next[2];
 }
 
 PLVS_HD uint64_t owner_hash(int x, int y, int z) {
