@@ -1603,13 +1603,25 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
     __syncthreads();
     const uint32_t s0 = active_off[a] + (pi - part_off[a]) * part_segs;
     const uint32_t s1 = nparts > 1 ? min(active_off[a + 1], s0 + part_segs) : active_off[a + 1];
+    // (the descriptors of the NEXT round are asked for before this round's records: a round is two dependent global
+    // loads — descriptor, then records — and a slab's item runs a dozen rounds)
+    uint4 nd0[kFly], nd1[kFly];
+    auto fetch_desc = [&](uint32_t sb) {
+#pragma unroll
+      for (int j = 0; j < kFly; ++j)
+        if (sb + j < s1) {
+          nd0[j] = sorted_seg[2 * (size_t)(sb + j)];
+          nd1[j] = sorted_seg[2 * (size_t)(sb + j) + 1];
+        }
+    };
+    fetch_desc(s0 + (uint32_t)grp * kFly);
     for (uint32_t sb = s0 + (uint32_t)grp * kFly; sb < s1; sb += kGroups * kFly) {
       uint32_t lo_r[kFly], hi_r[kFly];
 #pragma unroll
       for (int j = 0; j < kFly; ++j) {
         lo_r[j] = hi_r[j] = 0;
         if (sb + j < s1) {
-          const uint4 d0 = sorted_seg[2 * (size_t)(sb + j)], d1 = sorted_seg[2 * (size_t)(sb + j) + 1];
+          const uint4 d0 = nd0[j], d1 = nd1[j];
           const uint32_t w[4] = {d1.x, d1.y, d1.z, d1.w};
           const uint32_t o = (w[slab >> 1] >> ((slab & 1) * 16)) & 0xFFFFu;
           const uint32_t e = slab + 1 < kSlabs ? (w[(slab + 1) >> 1] >> (((slab + 1) & 1) * 16)) & 0xFFFFu : d0.z;
@@ -1621,6 +1633,7 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
 #pragma unroll
       for (int j = 0; j < kFly; ++j)
         if (lo_r[j] + gl < hi_r[j]) q[j] = load(lo_r[j] + gl);
+      fetch_desc(sb + kGroups * kFly);
 #pragma unroll
       for (int j = 0; j < kFly; ++j) {
         if (lo_r[j] + gl < hi_r[j]) add(q[j]);
