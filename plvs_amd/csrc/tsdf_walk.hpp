@@ -1948,15 +1948,42 @@ __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
           while (bits && at < needv) {
             const int bpos = __ffs((int)bits) - 1;
             bits &= bits - 1u;
-            const uint8_t* px = rgb + 3 * (p0 + (size_t)(w * 32 + bpos));
-            stage[wid][vl][at++] = colour_roundtrip(px[0]) | (colour_roundtrip(px[1]) << 8) | (colour_roundtrip(px[2]) << 16);
+            stage[wid][vl][at++] = (uint32_t)(p0 + (size_t)(w * 32 + bpos));   // the visit's point; its colour below
           }
         }
         havev += (uint32_t)__shfl((int)inc, 7, 8);
         const uint32_t group_mine = (uint32_t)(__ballot(mine) >> (8 * vl)) & 0xFFu;
         open = open && group_mine == 0xFFu && havev < needv;   // more runs of this voxel may follow, and they still count
       }
-      if (sub == 0 && vl < kFoldGroup) have[wid][vl] = havev;
+      if (sub == 0 && vl < kFoldGroup) have[wid][vl] = min(havev, needv);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- the colours of the staged visits, all 64 lanes, eight independent slots per lane and round (a lane that
+    // fetched the colour of each of its visits inside the bit loop above paid one memory latency per visit: 0.67 ms
+    // for the first call over a fresh map)
+#pragma unroll
+    for (int c = 0; c < kFoldGroup * kFoldSteps / 64 / 8; ++c) {
+      uint32_t idx[8], colr[8];
+      bool ok[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = c * 8 + u, v = (i * 64) / kFoldSteps, k = (i * 64) % kFoldSteps + lane;
+        ok[u] = (uint32_t)k < have[wid][v];
+        idx[u] = ok[u] ? stage[wid][v][k] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        colr[u] = 0;
+        if (ok[u]) {
+          const uint8_t* px = rgb + 3 * (size_t)idx[u];
+          colr[u] = colour_roundtrip(px[0]) | (colour_roundtrip(px[1]) << 8) | (colour_roundtrip(px[2]) << 16);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = c * 8 + u, v = (i * 64) / kFoldSteps, k = (i * 64) % kFoldSteps + lane;
+        if (ok[u]) stage[wid][v][k] = colr[u];
+      }
     }
     __builtin_amdgcn_wave_barrier();
     // ---- fold: lane = voxel * 4 + channel
