@@ -199,7 +199,7 @@ def main():
         t = torch.tensor([tim.get(k, 0.0) / 3.0 for k in names], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         phases_ms = {k: round(float(v), 4) for k, v in zip(names, t.tolist())}
-        if world > 1:
+        if world > 1 or os.environ.get("PLVS_BENCH_FORCE_OTHER_LEG"):   # (the variable: a one-GPU rehearsal of this branch)
             other_kfs = args.batch * (1 if not args.strong else world)
             sel = [kfs[j % n_poses] for j in range(other_kfs)]
             ob = (torch.from_numpy(np.concatenate([k["xyz"] for k in sel])).cuda(),
