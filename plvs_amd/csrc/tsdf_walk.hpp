@@ -1057,11 +1057,13 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
 // A tile that lies inside one cloud, whose rays fit the key box and whose voxels fit the table — every tile of a depth
 // camera's clouds but a handful — has ONE sub-tile and ONE flush.  This kernel is that case and nothing else: no
 // sub-tile stack, no windows of a single ray, no spill regions, and so few enough live values that the voxel loop runs
-// out of registers (walk_tiles with every path in one body spilled into its loop), and FIVE barriers per tile instead
-// of eighteen (a barrier costs a tile ~1 us: the slowest of eight waves, their memory operations drained).  A tile
-// that does not qualify is DEFERRED: nothing of it has reached global memory when that is known (records, segments,
-// runs and directory inserts all happen in the flush), its index goes to a list and walk_tiles (the general kernel)
-// walks the list behind this kernel.  Same outputs, same regions, bit for bit the same records either way.
+// out of registers (walk_tiles with every path in one body spilled into its loop), and FOUR barriers per tile instead
+// of eighteen (a barrier costs a tile ~1 us: the slowest of eight waves, their memory operations drained): key origin;
+// end of the walk; ranks / entry count / "does a needy voxel have several rays"; counts out.  A tile that does not
+// qualify is DEFERRED: all it has done to global memory when that is known is to enter chunks its voxels need anyway
+// (every entry resolves its own chunk with dir_find_or_insert — no directory phase, no prefetch), no records, segments
+// or runs; its index goes to a list and walk_tiles (the general kernel) walks the list behind this kernel.  Same
+// outputs, same regions, bit for bit the same records either way.
 #ifndef PLVS_WALK_FAST_WAVES
 #define PLVS_WALK_FAST_WAVES 6
 #endif
