@@ -1003,7 +1003,10 @@ int plvs_hip_tsdf_voxblox_integrate_merged(plvs_tsdf_voxblox* h, const float* xy
   PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
   h->stats = plvs_tsdf_stats{};
   h->last_updated = 0;
-  if (n == 0) return PLVS_OK;
+  if (n == 0) {   // (an empty cloud still publishes what a world cloud left waiting, as in the simple flavour)
+    const int32_t none[2] = {0, 0};
+    return plvs_hip_tsdf_voxblox_integrate_batch_dev(h, nullptr, nullptr, none, 1, nullptr, nullptr);
+  }
   PLVS_REQUIRE(xyz && rgba, "null cloud pointer");
   hipStream_t s = nullptr;
   PLVS_HIP_TRY(h->st_xyz.reserve((size_t)n * 3));
@@ -1054,7 +1057,12 @@ int plvs_hip_tsdf_voxblox_integrate_merged(plvs_tsdf_voxblox* h, const float* xy
   }
   const size_t nb = voxel_map.size() + clear_map.size();
   h->stats.points = n;
-  if (nb == 0) return PLVS_OK;
+  if (nb == 0) {   // (every point skipped: nothing to cast, but the call still publishes waiting world-cloud blocks)
+    const int32_t none[2] = {0, 0};
+    const int rc0 = plvs_hip_tsdf_voxblox_integrate_batch_dev(h, nullptr, nullptr, none, 1, nullptr, nullptr);
+    h->stats.points = n;
+    return rc0;
+  }
   std::vector<uint32_t> first(nb + 1), pts;
   std::vector<uint8_t> clr(nb);
   pts.reserve((size_t)n);
