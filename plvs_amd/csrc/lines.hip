@@ -20,6 +20,9 @@
 #include <atomic>
 #include <cmath>
 #include <thread>
+#include <mutex>
+#include <functional>
+#include <condition_variable>
 #include <vector>
 
 #include "common.hpp"
@@ -303,6 +306,64 @@ double now_ms() {
 
 }  // namespace
 
+// The host threads of the line stage (one routing thread per extra octave + the fitting threads), kept between frames:
+// creating them per frame cost the calling thread 15-25 us EACH before it could start routing octave 0.
+class HostPool {
+ public:
+  ~HostPool() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      quit_ = true;
+    }
+    go_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  // job(i) for i in [0, n) on n pool threads; the callable must stay alive until wait() returns
+  void start(int n, const std::function<void(int)>* job) {
+    std::unique_lock<std::mutex> lk(m_);
+    while ((int)th_.size() < n) {
+      const int idx = (int)th_.size();
+      const uint64_t seen = gen_;
+      th_.emplace_back([this, idx, seen]() { worker(idx, seen); });
+    }
+    job_ = job;
+    njobs_ = n;
+    pending_ = n;
+    ++gen_;
+    lk.unlock();
+    go_.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return pending_ == 0; });
+  }
+
+ private:
+  void worker(int idx, uint64_t seen) {
+    for (;;) {
+      const std::function<void(int)>* job;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        go_.wait(lk, [&] { return quit_ || gen_ != seen; });
+        if (quit_) return;
+        seen = gen_;
+        if (idx >= njobs_) continue;
+        job = job_;
+      }
+      (*job)(idx);
+      std::lock_guard<std::mutex> lk(m_);
+      if (--pending_ == 0) done_.notify_all();
+    }
+  }
+  std::mutex m_;
+  std::condition_variable go_, done_;
+  std::vector<std::thread> th_;
+  const std::function<void(int)>* job_ = nullptr;
+  uint64_t gen_ = 0;
+  int njobs_ = 0, pending_ = 0;
+  bool quit_ = false;
+};
+
 struct plvs_lines {
   int nfeatures, nlevels;
   float scale;
@@ -332,9 +393,12 @@ struct plvs_lines {
   uint8_t* h_desc = nullptr;
   int line_cap = 0;
   hipStream_t stream = nullptr;
-  std::vector<hipEvent_t> ev_maps;             // octave i's maps have landed in the pinned buffers
+  hipStream_t copy_stream = nullptr;           // the gradient images go home beside the next octave's kernels
+  std::vector<hipEvent_t> ev_route;            // octave i's packed map and anchor flags have landed (what EdgeDrawing reads)
+  std::vector<hipEvent_t> ev_maps;             // ... and its dx / dy images (what the line fit reads)
   std::vector<OctaveDetector> det;
   double last_ms[6] = {};
+  HostPool pool;
 };
 
 namespace {
@@ -388,6 +452,11 @@ int lines_build_geometry(plvs_lines* o, int w, int h, const plvs::OrbPyramidView
     hipEvent_t e = nullptr;
     PLVS_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     o->ev_maps.push_back(e);
+  }
+  while ((int)o->ev_route.size() < n) {
+    hipEvent_t e = nullptr;
+    PLVS_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    o->ev_route.push_back(e);
   }
   // OctaveKeyLines :785-846: sigma schedule and octave sizes
   float preSigma2 = (float)std::pow(0.5, 2);
@@ -462,9 +531,13 @@ int lines_extract_body(plvs_lines* o, plvs_keyline* keylines, uint8_t* desc, int
       PLVS_HIP_TRY(hipMemcpyAsync(o->h_anchor[i], o->d_anchor[i], (size_t)arows * acols, hipMemcpyDeviceToHost, s));
     }
     PLVS_HIP_TRY(hipMemcpyAsync(o->h_gd[i], o->d_gd[i], px * 2, hipMemcpyDeviceToHost, s));
-    PLVS_HIP_TRY(hipMemcpyAsync(o->h_dx[i], o->d_dx[i], px * 2, hipMemcpyDeviceToHost, s));
-    PLVS_HIP_TRY(hipMemcpyAsync(o->h_dy[i], o->d_dy[i], px * 2, hipMemcpyDeviceToHost, s));
-    PLVS_HIP_TRY(hipEventRecord(o->ev_maps[i], s));
+    PLVS_HIP_TRY(hipEventRecord(o->ev_route[i], s));
+    // the gradient images (two thirds of the bytes) follow on a second stream: EdgeDrawing starts without them, the
+    // next octave's kernels do not queue behind them
+    PLVS_HIP_TRY(hipStreamWaitEvent(o->copy_stream, o->ev_route[i], 0));
+    PLVS_HIP_TRY(hipMemcpyAsync(o->h_dx[i], o->d_dx[i], px * 2, hipMemcpyDeviceToHost, o->copy_stream));
+    PLVS_HIP_TRY(hipMemcpyAsync(o->h_dy[i], o->d_dy[i], px * 2, hipMemcpyDeviceToHost, o->copy_stream));
+    PLVS_HIP_TRY(hipEventRecord(o->ev_maps[i], o->copy_stream));
     if (i + 1 < n && !o->geometry_shared) {
       const int nw = o->sizes[i + 1].first, nh = o->sizes[i + 1].second;
       hipLaunchKernelGGL(lines_resize, dim3((nw + 63) / 64, (nh + 3) / 4), block, 0, s, o->d_blur[i], w,
@@ -474,7 +547,7 @@ int lines_extract_body(plvs_lines* o, plvs_keyline* keylines, uint8_t* desc, int
   PLVS_KERNEL_CHECK();
   // every octave is routed as soon as ITS maps have landed (the routing of octave 0 — the long pole of the host
   // stage — starts while the smaller octaves are still being computed and copied)
-  PLVS_HIP_TRY(hipEventSynchronize(o->ev_maps[0]));
+  PLVS_HIP_TRY(hipEventSynchronize(o->ev_route[0]));
   const double t1 = now_ms();
   // ---- host: EdgeDrawing is sequential per octave (one routing thread each); every finished
   // edge chain is fitted independently, so fitting threads consume batches of chains while
@@ -482,12 +555,13 @@ int lines_extract_body(plvs_lines* o, plvs_keyline* keylines, uint8_t* desc, int
   // reference's line order).
   o->det.resize(n);
   {
-    constexpr int kBatch = 24;       // chains per fitting task
+    constexpr int kBatch = kEdgeChainBatch;   // chains per fitting task (= the routing thread's publishing step)
     // extra fitting threads beside the routing ones, and whether an idle one yields its core instead of spinning
-    const int kFitThreads = plvs::env_int("PLVS_HIP_LINES_FIT_THREADS", 2, 0, 16);
+    const int kFitThreads = plvs::env_int("PLVS_HIP_LINES_FIT_THREADS", 3, 0, 16);
     const bool idle_yield = plvs::env_int("PLVS_HIP_LINES_FIT_YIELD", 0, 0, 1) != 0;
     struct OctaveWork {
       ChainProgress prog;
+      std::atomic<int> grad{0};                   // 1: the octave's dx / dy images are known to have landed; -1: failed
       std::atomic<int> next{0};                   // next batch to claim
       std::vector<std::vector<Segment>> out;      // per batch
     };
@@ -497,7 +571,7 @@ int lines_extract_body(plvs_lines* o, plvs_keyline* keylines, uint8_t* desc, int
       work[i].out.resize((size_t)o->sizes[i].first * o->sizes[i].second / 100 / kBatch + 2);
     }
     auto route = [&](int i) {
-      if (i > 0 && hipEventSynchronize(o->ev_maps[i]) != hipSuccess) {
+      if (i > 0 && hipEventSynchronize(o->ev_route[i]) != hipSuccess) {
         o->det[i].failed = true;
         work[i].prog.done.store(1, std::memory_order_release);
         return;
@@ -524,7 +598,10 @@ int lines_extract_body(plvs_lines* o, plvs_keyline* keylines, uint8_t* desc, int
             all_drained = false;
             if (wk.next.compare_exchange_strong(b, b + 1)) {
               const int c1 = full ? c0 + kBatch : ready;
-              o->det[i].fit_range(c0, c1, wk.out[b]);
+              if (wk.grad.load(std::memory_order_acquire) == 0)   // (the fit reads dx / dy: by now they are nearly always there)
+                wk.grad.store(hipEventSynchronize(o->ev_maps[i]) == hipSuccess ? 1 : -1, std::memory_order_release);
+              if (wk.grad.load(std::memory_order_acquire) > 0) o->det[i].fit_range(c0, c1, wk.out[b]);
+              else o->det[i].failed = true;
               did = true;
             }
           } else if (!done) {
@@ -532,17 +609,24 @@ int lines_extract_body(plvs_lines* o, plvs_keyline* keylines, uint8_t* desc, int
           }
         }
         if (all_drained) break;
-        if (!did) {
-          if (idle_yield) std::this_thread::yield(); else __builtin_ia32_pause();
+        if (!did) {   // nothing ready: leave the progress words alone for a moment
+          if (idle_yield) std::this_thread::yield();
+          else for (int k = 0; k < 64; ++k) __builtin_ia32_pause();
         }
       }
     };
-    std::vector<std::thread> th;
-    for (int i = 1; i < n; ++i) th.emplace_back([&, i]() { route(i); fit(); });
-    for (int i = 0; i < kFitThreads; ++i) th.emplace_back(fit);
+    int device = 0;
+    (void)hipGetDevice(&device);   // (the current device is per thread: the pool's threads take the caller's)
+    const std::function<void(int)> job = [&](int j) {
+      (void)hipSetDevice(device);
+      if (j < n - 1) route(j + 1);
+      fit();
+    };
+    o->pool.start(n - 1 + kFitThreads, &job);
     route(0);
     fit();
-    for (auto& t : th) t.join();
+    o->pool.wait();
+    PLVS_HIP_TRY(hipStreamSynchronize(o->copy_stream));   // (long done; the next frame's kernels overwrite what it read)
     for (int i = 0; i < n; ++i) {
       o->det[i].progress = nullptr;
       if (o->det[i].failed) continue;
@@ -670,6 +754,7 @@ int plvs_hip_lines_create(int nfeatures, int nlevels, float scale_factor, double
     }                                                                      \
   } while (0)
   LN_TRY(hipStreamCreate(&o->stream));
+  LN_TRY(hipStreamCreate(&o->copy_stream));
   LN_TRY(hipMalloc((void**)&o->d_lines, sizeof(LbdLine) * o->line_cap));
   LN_TRY(hipHostMalloc((void**)&o->h_lines, sizeof(LbdLine) * o->line_cap));
   LN_TRY(hipMalloc((void**)&o->d_desc, (size_t)32 * o->line_cap));
@@ -687,6 +772,8 @@ int plvs_hip_lines_destroy(plvs_lines* o) {
   if (o->h_lines) (void)hipHostFree(o->h_lines);
   if (o->h_desc) (void)hipHostFree(o->h_desc);
   for (hipEvent_t e : o->ev_maps) (void)hipEventDestroy(e);
+  for (hipEvent_t e : o->ev_route) (void)hipEventDestroy(e);
+  if (o->copy_stream) (void)hipStreamDestroy(o->copy_stream);
   if (o->stream) (void)hipStreamDestroy(o->stream);
   delete o;
   return PLVS_OK;
