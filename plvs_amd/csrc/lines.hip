@@ -753,8 +753,14 @@ int plvs_hip_lines_create(int nfeatures, int nlevels, float scale_factor, double
       return PLVS_ERR_HIP;                                                 \
     }                                                                      \
   } while (0)
-  LN_TRY(hipStreamCreate(&o->stream));
-  LN_TRY(hipStreamCreate(&o->copy_stream));
+  {
+    // the line stage is the frame's critical path when points and lines are extracted side by side
+    // (plvs_hip_frame_extract_dev): a few short kernels, then a long host stage — its stream goes first on the device
+    int least = 0, greatest = 0;
+    LN_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    LN_TRY(hipStreamCreateWithPriority(&o->stream, hipStreamNonBlocking, greatest));
+    LN_TRY(hipStreamCreateWithPriority(&o->copy_stream, hipStreamNonBlocking, greatest));
+  }
   LN_TRY(hipMalloc((void**)&o->d_lines, sizeof(LbdLine) * o->line_cap));
   LN_TRY(hipHostMalloc((void**)&o->h_lines, sizeof(LbdLine) * o->line_cap));
   LN_TRY(hipMalloc((void**)&o->d_desc, (size_t)32 * o->line_cap));
