@@ -1,5 +1,10 @@
 // Shared host-side plumbing for the HIP translation units of libplvs_hip.so.
 #pragma once
+#include <vector>
+#include <thread>
+#include <mutex>
+#include <functional>
+#include <condition_variable>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -70,6 +75,64 @@ struct DevBuf {
     p = nullptr;
     cap = 0;
   }
+};
+
+// Host helper threads kept between calls (the line stage's routing / fitting threads, the ORB quadtree's level threads):
+// creating them per frame cost the calling thread 15-25 us EACH before it could start its own share.
+class HostPool {
+ public:
+  ~HostPool() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      quit_ = true;
+    }
+    go_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  // job(i) for i in [0, n) on n pool threads; the callable must stay alive until wait() returns
+  void start(int n, const std::function<void(int)>* job) {
+    std::unique_lock<std::mutex> lk(m_);
+    while ((int)th_.size() < n) {
+      const int idx = (int)th_.size();
+      const uint64_t seen = gen_;
+      th_.emplace_back([this, idx, seen]() { worker(idx, seen); });
+    }
+    job_ = job;
+    njobs_ = n;
+    pending_ = n;
+    ++gen_;
+    lk.unlock();
+    go_.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return pending_ == 0; });
+  }
+
+ private:
+  void worker(int idx, uint64_t seen) {
+    for (;;) {
+      const std::function<void(int)>* job;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        go_.wait(lk, [&] { return quit_ || gen_ != seen; });
+        if (quit_) return;
+        seen = gen_;
+        if (idx >= njobs_) continue;
+        job = job_;
+      }
+      (*job)(idx);
+      std::lock_guard<std::mutex> lk(m_);
+      if (--pending_ == 0) done_.notify_all();
+    }
+  }
+  std::mutex m_;
+  std::condition_variable go_, done_;
+  std::vector<std::thread> th_;
+  const std::function<void(int)>* job_ = nullptr;
+  uint64_t gen_ = 0;
+  int njobs_ = 0, pending_ = 0;
+  bool quit_ = false;
 };
 
 // Per-thread staging for the host flavours of small calls (k-NN / candidate distances of a few hundred

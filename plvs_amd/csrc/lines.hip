@@ -306,64 +306,6 @@ double now_ms() {
 
 }  // namespace
 
-// The host threads of the line stage (one routing thread per extra octave + the fitting threads), kept between frames:
-// creating them per frame cost the calling thread 15-25 us EACH before it could start routing octave 0.
-class HostPool {
- public:
-  ~HostPool() {
-    {
-      std::lock_guard<std::mutex> lk(m_);
-      quit_ = true;
-    }
-    go_.notify_all();
-    for (auto& t : th_) t.join();
-  }
-  // job(i) for i in [0, n) on n pool threads; the callable must stay alive until wait() returns
-  void start(int n, const std::function<void(int)>* job) {
-    std::unique_lock<std::mutex> lk(m_);
-    while ((int)th_.size() < n) {
-      const int idx = (int)th_.size();
-      const uint64_t seen = gen_;
-      th_.emplace_back([this, idx, seen]() { worker(idx, seen); });
-    }
-    job_ = job;
-    njobs_ = n;
-    pending_ = n;
-    ++gen_;
-    lk.unlock();
-    go_.notify_all();
-  }
-  void wait() {
-    std::unique_lock<std::mutex> lk(m_);
-    done_.wait(lk, [&] { return pending_ == 0; });
-  }
-
- private:
-  void worker(int idx, uint64_t seen) {
-    for (;;) {
-      const std::function<void(int)>* job;
-      {
-        std::unique_lock<std::mutex> lk(m_);
-        go_.wait(lk, [&] { return quit_ || gen_ != seen; });
-        if (quit_) return;
-        seen = gen_;
-        if (idx >= njobs_) continue;
-        job = job_;
-      }
-      (*job)(idx);
-      std::lock_guard<std::mutex> lk(m_);
-      if (--pending_ == 0) done_.notify_all();
-    }
-  }
-  std::mutex m_;
-  std::condition_variable go_, done_;
-  std::vector<std::thread> th_;
-  const std::function<void(int)>* job_ = nullptr;
-  uint64_t gen_ = 0;
-  int njobs_ = 0, pending_ = 0;
-  bool quit_ = false;
-};
-
 struct plvs_lines {
   int nfeatures, nlevels;
   float scale;
@@ -398,7 +340,7 @@ struct plvs_lines {
   std::vector<hipEvent_t> ev_maps;             // ... and its dx / dy images (what the line fit reads)
   std::vector<OctaveDetector> det;
   double last_ms[6] = {};
-  HostPool pool;
+  plvs::HostPool pool;
 };
 
 namespace {

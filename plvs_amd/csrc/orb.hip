@@ -434,6 +434,7 @@ struct plvs_orb {
   std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
   std::vector<int> features_per_level;
   std::vector<plvs::orb::QuadTree> tree_scratch;   // per level: node array and key pool of the quadtree, kept across frames
+  plvs::HostPool pool;                             // the quadtree's helper threads
   int umax[kHalfPatch + 1];
   // geometry for the current image size
   int img_w = 0, img_h = 0;
@@ -812,10 +813,10 @@ static int orb_extract_body(plvs_orb* o, int lap0, int lap1, plvs_keypoint* kps,
       load[k] += o->h_level_counts[l] + 1u;
     }
     auto run = [&](int k) { for (int l : share[k]) work(l); };
-    std::vector<std::thread> th;
-    for (int k = 1; k < nt; ++k) th.emplace_back(run, k);
+    const std::function<void(int)> job = [&](int j) { run(j + 1); };   // (helper threads kept between frames)
+    o->pool.start(nt - 1, &job);
     run(0);
-    for (auto& t : th) t.join();
+    o->pool.wait();
   }
   int nk = 0;
   for (int l = 0; l < nl; ++l) nk += (int)selected[l].size();
