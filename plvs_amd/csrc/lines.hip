@@ -7,9 +7,10 @@
 //           lines_sobel_grad   3x3 Sobel (s16) + |dx|+|dy| thresholded at 81, /4 with
 //                              round-half-even, direction bit (:1642-1654), packed u16
 //           lines_resize       cv::resize(fx = fy = 1/scale, INTER_LINEAR) (:840)
-//           lbd_kernel         one 64-lane wavefront per line: lane = one of the 63 rows of
-//                              the line support region, walked pixel by pixel with the
-//                              reference's float accumulators; 9 lanes then fold the
+//           lbd_kernel         one workgroup per line: a lane per row of the line support
+//                              region keeps the reference's sequential coordinates and float
+//                              accumulators, all 256 threads gather the gradients of 32
+//                              pixels of every row at a time; 9 lanes then fold the
 //                              rows into the band statistics in row order; lane 0
 //                              normalises and emits the 256-bit descriptor (:1151-1488, :438-449)
 //   host    lines_host.hpp     anchor linking, line fitting / validation, octave grouping,
@@ -146,34 +147,63 @@ __constant__ int c_comb[32][2] = {
     {2, 3}, {2, 4}, {2, 5}, {2, 6}, {2, 7}, {2, 8}, {3, 4}, {3, 5}, {3, 6}, {3, 7}, {3, 8},
     {4, 5}, {4, 6}, {4, 7}, {4, 8}, {5, 6}, {5, 7}, {5, 8}, {6, 7}, {6, 8}, {7, 8}};
 
-__global__ __launch_bounds__(64) void lbd_kernel(const LbdLine* __restrict__ lines, LbdTables T,
-                                                 uint8_t* __restrict__ desc) {
+// One workgroup of 256 per line.  A row of the line support region is a sequential sum over its pixels (float adds in
+// pixel order, as the reference takes them) of gradients gathered at rounded, sequentially accumulated coordinates.
+// The coordinates and the sums stay with the row's lane; the GATHER — two loads per (row, pixel), what a lane per row
+// waited for pixel by pixel: 92 us for 100 lines — is dealt to all 256 threads, kLbdChunk pixels of every row at a time,
+// through LDS.
+constexpr int kLbdThreads = 256;
+constexpr int kLbdChunk = 32;
+__global__ __launch_bounds__(kLbdThreads) void lbd_kernel(const LbdLine* __restrict__ lines, LbdTables T,
+                                                          uint8_t* __restrict__ desc) {
   __shared__ float rows[kRows][8];   // per row: pgdL, ngdL, pgdL2, ngdL2, pgdO, ngdO, pgdO2, ngdO2
   __shared__ float band[kBands][8];
+  __shared__ int s_idx[kRows][kLbdChunk];        // pixel index of (row, pixel of the chunk)
+  __shared__ float s_gl[kRows][kLbdChunk + 1], s_go[kRows][kLbdChunk + 1];
   const LbdLine L = lines[blockIdx.x];
   const LbdOctave O = T.oct[L.octave];
   const int hID = threadIdx.x;
+  const float dL0 = L.dL0, dL1 = L.dL1, dO0 = -L.dL1, dO1 = L.dL0;
+  float sx = 0.f, sy = 0.f, pL = 0, nL = 0, pO = 0, nO = 0;
+  const short maxx = (short)(O.w - 1), maxy = (short)(O.h - 1);
   if (hID < kRows) {
-    const float dL0 = L.dL0, dL1 = L.dL1, dO0 = -L.dL1, dO1 = L.dL0;
     // row start: sCorX0 -= dL[1], sCorY0 += dL[0] once per preceding row (sequential f32)
     float sx0 = L.s0x, sy0 = L.s0y;
     for (int r = 0; r < hID; ++r) { sx0 -= dL1; sy0 += dL0; }
-    float sx = sx0, sy = sy0;
-    float pL = 0, nL = 0, pO = 0, nO = 0;
-    const short maxx = (short)(O.w - 1), maxy = (short)(O.h - 1);
-    for (int wID = 0; wID < L.num_pixels; ++wID) {
-      short t = (short)roundf(sx);
-      const short xc = (t < 0) ? (short)0 : (t > maxx) ? maxx : t;
-      t = (short)roundf(sy);
-      const short yc = (t < 0) ? (short)0 : (t > maxy) ? maxy : t;
-      const short dx = O.dx[yc * O.w + xc], dy = O.dy[yc * O.w + xc];
-      const float gDL = dx * dL0 + dy * dL1;
-      const float gDO = dx * dO0 + dy * dO1;
-      if (gDL > 0) pL += gDL; else nL -= gDL;
-      if (gDO > 0) pO += gDO; else nO -= gDO;
-      sx += dL0;
-      sy += dL1;
+    sx = sx0;
+    sy = sy0;
+  }
+  for (int w0 = 0; w0 < L.num_pixels; w0 += kLbdChunk) {
+    const int nw = min(kLbdChunk, L.num_pixels - w0);
+    if (hID < kRows) {
+      for (int k = 0; k < nw; ++k) {
+        short t = (short)roundf(sx);
+        const short xc = (t < 0) ? (short)0 : (t > maxx) ? maxx : t;
+        t = (short)roundf(sy);
+        const short yc = (t < 0) ? (short)0 : (t > maxy) ? maxy : t;
+        s_idx[hID][k] = yc * O.w + xc;
+        sx += dL0;
+        sy += dL1;
+      }
     }
+    __syncthreads();
+    for (int e = threadIdx.x; e < kRows * nw; e += kLbdThreads) {
+      const int r = e / nw, k = e - r * nw;
+      const int idx = s_idx[r][k];
+      const short dx = O.dx[idx], dy = O.dy[idx];
+      s_gl[r][k] = dx * dL0 + dy * dL1;
+      s_go[r][k] = dx * dO0 + dy * dO1;
+    }
+    __syncthreads();
+    if (hID < kRows) {
+      for (int k = 0; k < nw; ++k) {
+        const float gDL = s_gl[hID][k], gDO = s_go[hID][k];
+        if (gDL > 0) pL += gDL; else nL -= gDL;
+        if (gDO > 0) pO += gDO; else nO -= gDO;
+      }
+    }
+  }
+  if (hID < kRows) {
     const float cg = T.g[hID];
     pL = cg * pL; nL = cg * nL; pO = cg * pO; nO = cg * nO;
     rows[hID][0] = pL; rows[hID][1] = nL; rows[hID][2] = pL * pL; rows[hID][3] = nL * nL;
@@ -614,7 +644,7 @@ int lines_extract_body(plvs_lines* o, plvs_keyline* keylines, uint8_t* desc, int
   for (int i = 0; i < kMaxOctaves; ++i) T.oct[i] = LbdOctave{nullptr, nullptr, 0, 0};
   for (int i = 0; i < n; ++i) T.oct[i] = LbdOctave{o->d_dx[i], o->d_dy[i], o->sizes[i].first, o->sizes[i].second};
   PLVS_HIP_TRY(hipMemcpyAsync(o->d_lines, o->h_lines, sizeof(LbdLine) * nl, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(lbd_kernel, dim3(nl), dim3(64), 0, s, o->d_lines, T, o->d_desc);
+  hipLaunchKernelGGL(lbd_kernel, dim3(nl), dim3(kLbdThreads), 0, s, o->d_lines, T, o->d_desc);
   PLVS_KERNEL_CHECK();
   PLVS_HIP_TRY(hipMemcpyAsync(o->h_desc, o->d_desc, (size_t)32 * nl, hipMemcpyDeviceToHost, s));
   PLVS_HIP_TRY(hipStreamSynchronize(s));
