@@ -685,8 +685,8 @@ int plvs_hip_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_
   } while (0)
   ORB_CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), h_pattern, sizeof(h_pattern)));
   ORB_CREATE_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), o->umax, sizeof(o->umax)));
-  ORB_CREATE_TRY(hipStreamCreate(&o->stream));
-  ORB_CREATE_TRY(hipStreamCreate(&o->stream2));
+  ORB_CREATE_TRY(hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking));
+  ORB_CREATE_TRY(hipStreamCreateWithFlags(&o->stream2, hipStreamNonBlocking));
   ORB_CREATE_TRY(hipEventCreateWithFlags(&o->ev_pyr, hipEventDisableTiming));
   o->kp_cap = nfeatures * 2 + 1024;
   ORB_CREATE_TRY(hipMalloc((void**)&o->d_kps, sizeof(KpDev) * o->kp_cap));
