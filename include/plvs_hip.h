@@ -400,6 +400,11 @@ int plvs_hip_selftest_rcp(int exponent, uint32_t* mismatches);
 /* The walk's square root and quotient (normal-range forms without the compiler's range scaffolding) against
  * sqrtf and `/` on the device, 2.7e8 pseudo-random operand pairs per call: mismatches[0] sqrt, [1] division. */
 int plvs_hip_selftest_walk_math(uint32_t seed, uint32_t* mismatches_sqrt_div);
+/* The device-wide stable radix sort behind the run / record orderings of both TSDF back ends (two scatter paths: wide
+ * digits for short arrays, 8-bit digits reordered in LDS from 2^20 pairs on): n pseudo-random keys below 2^bit_hi with
+ * their positions as values (32-bit, or 64-bit with wide_values), sorted on bits [bit_lo, bit_hi).  mismatches2[0] =
+ * neighbours out of order or equal keys whose positions are not ascending (stability), [1] = pairs torn apart. */
+int plvs_hip_selftest_radix_sort(uint32_t n, int bit_lo, int bit_hi, int wide_values, uint32_t seed, uint32_t* mismatches2);
 
 /* --------------------------------------------------------- TSDF (open_chisel)
  * Chunked (16^3) spatially hashed TSDF with per-point ray integration.

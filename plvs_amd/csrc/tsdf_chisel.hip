@@ -798,6 +798,35 @@ __global__ void carve_collect(const uint32_t* __restrict__ carved, int num_chunk
   if (s < num_chunks && carved[s]) list[atomicAdd(&ctr->num_updated, 1u)] = (uint32_t)s;
 }
 
+// Self-test of the device-wide stable radix sort (device_utils.hip) at sizes on both sides of its two scatter paths:
+// pseudo-random keys below 2^bits (many equal keys when bits is small), values = original positions.
+__global__ void selftest_sort_fill(uint32_t* __restrict__ keys, uint32_t* __restrict__ v32, unsigned long long* __restrict__ v64,
+                                   uint32_t n, int bits, uint32_t seed) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t x = (i + 1u) * 2654435761u + seed;
+  x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+  x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+  keys[i] = bits >= 32 ? x : (x & ((1u << bits) - 1u));
+  if (v32) v32[i] = i;
+  if (v64) v64[i] = ((unsigned long long)~i << 32) | i;
+}
+// mismatches[0]: order / stability violations, [1]: a pair whose key is not the key its value's position held
+__global__ void selftest_sort_check(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ keys,
+                                    const uint32_t* __restrict__ v32, const unsigned long long* __restrict__ v64, uint32_t n,
+                                    int bit_lo, int bit_hi, uint32_t* __restrict__ mismatches) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t mask = (bit_hi - bit_lo >= 32 ? 0xFFFFFFFFu : ((1u << (bit_hi - bit_lo)) - 1u)) << bit_lo;
+  const uint32_t pos = v32 ? v32[i] : (uint32_t)v64[i];
+  if (pos >= n || keys_in[pos] != keys[i] || (v64 && (uint32_t)(v64[i] >> 32) != ~pos)) atomicAdd(&mismatches[1], 1u);
+  if (i + 1 < n) {
+    const uint32_t a = keys[i] & mask, b = keys[i + 1] & mask;
+    const uint32_t pn = v32 ? v32[i + 1] : (uint32_t)v64[i + 1];
+    if (a > b || (a == b && pos >= pn)) atomicAdd(&mismatches[0], 1u);
+  }
+}
+
 // Hardware assumption of chain_runs, checked exhaustively: rcp_rn(b) == RN(1/b) for every
 // significand at the given exponent.
 __global__ void selftest_rcp_kernel(int exponent, uint32_t* __restrict__ mismatches) {
@@ -1143,6 +1172,38 @@ int plvs_hip_selftest_rcp(int exponent, uint32_t* mismatches) {
   hipLaunchKernelGGL(selftest_rcp_kernel, dim3((1u << 23) / 256), dim3(256), 0, nullptr, exponent, d);
   hipError_t e = hipMemcpy(mismatches, d, sizeof(uint32_t), hipMemcpyDeviceToHost);
   (void)hipFree(d);
+  PLVS_HIP_TRY(e);
+  return PLVS_OK;
+}
+
+int plvs_hip_selftest_radix_sort(uint32_t n, int bit_lo, int bit_hi, int wide_values, uint32_t seed, uint32_t* mismatches2) {
+  PLVS_REQUIRE(mismatches2 && n > 0 && bit_lo >= 0 && bit_hi > bit_lo && bit_hi <= 32, "bad argument");
+  plvs::DevBuf<uint32_t> k_in, k0, k1, v0, v1, scratch, bad;
+  plvs::DevBuf<unsigned long long> w0, w1;
+  PLVS_HIP_TRY(k_in.reserve(n));
+  PLVS_HIP_TRY(k0.reserve(n));
+  PLVS_HIP_TRY(k1.reserve(n));
+  if (wide_values) {
+    PLVS_HIP_TRY(w0.reserve(n));
+    PLVS_HIP_TRY(w1.reserve(n));
+  } else {
+    PLVS_HIP_TRY(v0.reserve(n));
+    PLVS_HIP_TRY(v1.reserve(n));
+  }
+  PLVS_HIP_TRY(scratch.reserve(radix_scratch_words(n)));
+  PLVS_HIP_TRY(bad.reserve(2));
+  PLVS_HIP_TRY(hipMemset(bad.p, 0, 2 * sizeof(uint32_t)));
+  const dim3 grid(ceil_div((size_t)n, 256)), block(256);
+  hipLaunchKernelGGL(selftest_sort_fill, grid, block, 0, nullptr, k0.p, v0.p, w0.p, n, bit_hi, seed);
+  PLVS_HIP_TRY(hipMemcpyAsync(k_in.p, k0.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, nullptr));
+  bool second = false;
+  if (wide_values) PLVS_HIP_TRY(radix_sort_pairs_u64(k0.p, w0.p, k1.p, w1.p, n, bit_lo, bit_hi, scratch.p, nullptr, &second));
+  else PLVS_HIP_TRY(radix_sort_pairs(k0.p, v0.p, k1.p, v1.p, n, bit_lo, bit_hi, scratch.p, nullptr, &second));
+  hipLaunchKernelGGL(selftest_sort_check, grid, block, 0, nullptr, k_in.p, second ? k1.p : k0.p,
+                     wide_values ? (const uint32_t*)nullptr : (second ? v1.p : v0.p),
+                     wide_values ? (second ? w1.p : w0.p) : (const unsigned long long*)nullptr, n, bit_lo, bit_hi, bad.p);
+  hipError_t e = hipMemcpy(mismatches2, bad.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost);
+  k_in.release(); k0.release(); k1.release(); v0.release(); v1.release(); w0.release(); w1.release(); scratch.release(); bad.release();
   PLVS_HIP_TRY(e);
   return PLVS_OK;
 }
