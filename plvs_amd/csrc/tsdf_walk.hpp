@@ -1735,9 +1735,23 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
     voxels += (uint32_t)__shfl_xor((int)voxels, off);
     longest = max(longest, (uint32_t)__shfl_xor((int)longest, off));
   }
-  if (lane == 0 && voxels) {
-    atomicAdd(&ctr->num_heads, voxels);
-    atomicMax(&ctr->max_run, longest);
+  // one update of the call's counters per workgroup, and the maximum only when it would move (thousands of waves
+  // bumping the same two words are serviced one after the other at the memory side)
+  __shared__ uint32_t w_vox[kApplyThreads / 64], w_long[kApplyThreads / 64];
+  if (lane == 0) {
+    w_vox[tid >> 6] = voxels;
+    w_long[tid >> 6] = longest;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t v = 0, l = 0;
+#pragma unroll
+    for (int w = 0; w < kApplyThreads / 64; ++w) {
+      v += w_vox[w];
+      l = max(l, w_long[w]);
+    }
+    if (v) atomicAdd(&ctr->num_heads, v);
+    if (l > ctr->max_run) atomicMax(&ctr->max_run, l);
   }
 }
 
