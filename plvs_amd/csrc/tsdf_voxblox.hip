@@ -83,64 +83,96 @@ __device__ __forceinline__ int point_of_seq(const int32_t* __restrict__ offsets,
 // weights (n), `clr` = the bundles' clearing flags.
 enum VbMode { kSimple = 0, kWorld = 1, kMerged = 2 };
 
+// The fill pass stages a wave's records in LDS: the 64 rays of a wave own ONE contiguous range of the record arrays
+// (their counts were scanned in ray order), so the wave writes it with consecutive lanes on consecutive words instead of
+// 64 lanes on 64 short pieces.  A wave whose range exceeds kFillStage records (carving) writes the excess directly.
+constexpr int kFillStage = 1536;
 template <bool kFill, int kMode>
 __global__ __launch_bounds__(256) void vb_ray_pass(
     Params P, const float* __restrict__ xyz, const float* __restrict__ aux, const uint8_t* __restrict__ clr, int npoints,
     const int32_t* __restrict__ offsets, int nclouds, const PoseRt* __restrict__ Twc, Directory dir,
     VCounters* __restrict__ ctr, uint32_t* __restrict__ counts, uint32_t* __restrict__ rec_keys,
     uint32_t* __restrict__ rec_seq) {
+  __shared__ uint32_t s_key[kFill ? 4 : 1][kFill ? kFillStage : 1], s_seq[kFill ? 4 : 1][kFill ? kFillStage : 1];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= npoints) return;
-  int cloud = 0;
-  const int p = kMode != kSimple ? i : point_of_seq(offsets, nclouds, i, &cloud);
-  const float px = xyz[3 * (size_t)p], py = xyz[3 * (size_t)p + 1], pz = xyz[3 * (size_t)p + 2];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const bool valid = i < npoints;
+  if (!kFill && !valid) return;
   uint32_t n = 0;
-  if (!(isfinite(px) && isfinite(py) && isfinite(pz))) {
-    // the reference filters such points out BEFORE the mixed order is formed;
-    // PLVS's cloud generator never emits them, so refuse instead of diverging
-    if (!kFill) atomicOr(&ctr->err, kErrNonFinite);
-  } else {
-    const PoseRt pose = load_pose(Twc, cloud);
-    Ray ray;
-    bool walk = true;
-    if (kMode == kWorld) {
-      float rs[3];
-      make_ray_world(P, pose, px, py, pz, aux[3 * (size_t)p], aux[3 * (size_t)p + 1], aux[3 * (size_t)p + 2], &ray, rs);
-    } else if (kMode == kMerged) {
-      make_ray_merged(P, pose, px, py, pz, clr[p] != 0, &ray);
+  const uint32_t out = (kFill && valid) ? counts[i] : 0u;
+  // (lane 0 of a wave is valid whenever any lane is: the wave's range starts at its first ray's offset)
+  const uint32_t wbase = kFill ? (uint32_t)__builtin_amdgcn_readfirstlane((int)out) : 0u;
+  if (valid) {
+    int cloud = 0;
+    const int p = kMode != kSimple ? i : point_of_seq(offsets, nclouds, i, &cloud);
+    const float px = xyz[3 * (size_t)p], py = xyz[3 * (size_t)p + 1], pz = xyz[3 * (size_t)p + 2];
+    if (!(isfinite(px) && isfinite(py) && isfinite(pz))) {
+      // the reference filters such points out BEFORE the mixed order is formed;
+      // PLVS's cloud generator never emits them, so refuse instead of diverging
+      if (!kFill) atomicOr(&ctr->err, kErrNonFinite);
     } else {
-      walk = make_ray(P, pose, px, py, pz, &ray);
-    }
-    if (walk) {
-      const uint32_t out = kFill ? counts[i] : 0u;
-      int lb[3] = {0, 0, 0}, lslot = -1;
-      bool have_last = false;
-      const int steps = ray.steps < kMaxRaySteps ? ray.steps : kMaxRaySteps;
-      for (int s = 0; s <= steps; ++s) {
-        int g[3], b[3], vid;
-        ray_step(&ray, g);
-        const bool ok = block_of(P, g, b, &vid);   // no early continue: every lane takes one step per trip
-        if (ok && (!have_last || b[0] != lb[0] || b[1] != lb[1] || b[2] != lb[2])) {
-          lb[0] = b[0]; lb[1] = b[1]; lb[2] = b[2];
-          have_last = true;
-          if (kFill) {
-            lslot = dir_find(dir, b[0], b[1], b[2]);
-            if (lslot < 0) atomicOr(&ctr->err, kErrDirectoryMiss);
-          } else {
-            dir_insert(dir, b[0], b[1], b[2], &ctr->num_blocks, &ctr->err);
-            if (((g[0] - b[0] * 16) | (g[1] - b[1] * 16) | (g[2] - b[2] * 16)) & ~15)
-              atomicOr(&ctr->err, kErrCoordRange);  // float block lookup left the integer grid
+      const PoseRt pose = load_pose(Twc, cloud);
+      Ray ray;
+      bool walk = true;
+      if (kMode == kWorld) {
+        float rs[3];
+        make_ray_world(P, pose, px, py, pz, aux[3 * (size_t)p], aux[3 * (size_t)p + 1], aux[3 * (size_t)p + 2], &ray, rs);
+      } else if (kMode == kMerged) {
+        make_ray_merged(P, pose, px, py, pz, clr[p] != 0, &ray);
+      } else {
+        walk = make_ray(P, pose, px, py, pz, &ray);
+      }
+      if (walk) {
+        int lb[3] = {0, 0, 0}, lslot = -1;
+        bool have_last = false;
+        const int steps = ray.steps < kMaxRaySteps ? ray.steps : kMaxRaySteps;
+        for (int s = 0; s <= steps; ++s) {
+          int g[3], b[3], vid;
+          ray_step(&ray, g);
+          const bool ok = block_of(P, g, b, &vid);   // no early continue: every lane takes one step per trip
+          if (ok && (!have_last || b[0] != lb[0] || b[1] != lb[1] || b[2] != lb[2])) {
+            lb[0] = b[0]; lb[1] = b[1]; lb[2] = b[2];
+            have_last = true;
+            if (kFill) {
+              lslot = dir_find(dir, b[0], b[1], b[2]);
+              if (lslot < 0) atomicOr(&ctr->err, kErrDirectoryMiss);
+            } else {
+              dir_insert(dir, b[0], b[1], b[2], &ctr->num_blocks, &ctr->err);
+              if (((g[0] - b[0] * 16) | (g[1] - b[1] * 16) | (g[2] - b[2] * 16)) & ~15)
+                atomicOr(&ctr->err, kErrCoordRange);  // float block lookup left the integer grid
+            }
           }
+          if (ok && kFill) {
+            // (a directory miss is an error the host reports: the record still gets a defined key)
+            const uint32_t key = lslot >= 0 ? (uint32_t)lslot * (uint32_t)kBlockVox + (uint32_t)vid : 0u;
+            const uint32_t at = out + n - wbase;
+            if (at < (uint32_t)kFillStage) {
+              s_key[wid][at] = key;
+              s_seq[wid][at] = (uint32_t)i;
+            } else {
+              rec_keys[out + n] = key;
+              rec_seq[out + n] = (uint32_t)i;
+            }
+          }
+          n += ok ? 1u : 0u;
         }
-        if (ok && kFill && lslot >= 0) {
-          rec_keys[out + n] = (uint32_t)lslot * (uint32_t)kBlockVox + (uint32_t)vid;
-          rec_seq[out + n] = (uint32_t)i;
-        }
-        n += ok ? 1u : 0u;
       }
     }
   }
-  if (!kFill) counts[i] = n;
+  if (!kFill) {
+    counts[i] = n;
+    return;
+  }
+  // the wave's staged records leave in one piece (a wave's LDS operations execute in order: no barrier)
+  uint32_t wend = out + n;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) wend = max(wend, (uint32_t)__shfl_xor((int)wend, off));
+  const uint32_t cnt = min(wend - wbase, (uint32_t)kFillStage);
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t j = (uint32_t)lane; j < cnt; j += 64u) {
+    rec_keys[wbase + j] = s_key[wid][j];
+    rec_seq[wbase + j] = s_seq[wid][j];
+  }
 }
 
 // MergedTsdfIntegrator::bundleRays, the per-point part (tsdf_integrator.cc:361-386): isPointValid -> kind (0 skipped,
