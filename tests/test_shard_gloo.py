@@ -149,6 +149,96 @@ def test_gloo_segment_exchange_of_the_ray_sharded_integrate(world):
     assert out == [(r, True) for r in range(world)]
 
 
+class _FakeIntegrate:
+    """Stands in for a rank's TsdfChisel in plvs_amd.shard.sharded_integrate (CPU tensors): the "walk" produces, for
+    every destination rank d, (rank + 2 d) descriptors, (3 rank + d + 1) voxel sums and (rank * d) runs, every row
+    stamped (source, destination, index, kind); the "apply" keeps what arrived; every rank reports (rank + 1) voxels as
+    saturated after the apply, and a rank notes what the others (and itself) reported."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+        self.applied, self.noted, self.packed = None, [], False
+
+    def _counts(self):
+        return np.array([[self.rank + 2 * d, 3 * self.rank + d + 1, self.rank * d] for d in range(self.world)], np.int64)
+
+    def shard_walk(self, d_xyz, offsets, d_Twc):
+        return self._counts()
+
+    def shard_pack(self, seg, rec, run):
+        for k, buf in enumerate((seg, rec, run)):
+            row = 0
+            for d in range(self.world):
+                for i in range(int(self._counts()[d, k])):
+                    buf[row, :4] = torch.tensor([self.rank, d, i, k], dtype=torch.int32)
+                    buf[row, 4:] = 7
+                    row += 1
+            assert row == buf.shape[0]
+        self.packed = True
+
+    def shard_apply(self, seg, rec, run, counts, d_rgb, d_kfid):
+        assert self.packed
+        self.applied = (seg.clone(), rec.clone(), run.clone(), np.array(counts))
+
+    def shard_saturated(self):
+        return torch.tensor([[self.rank, 0, 0, v] for v in range(self.rank + 1)], dtype=torch.int32).reshape(-1, 4)
+
+    def shard_note_saturated(self, voxels):
+        self.noted.append(voxels.clone())
+
+
+def _worker_sharded_integrate(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("plvs_amd_shard", os.path.join(ROOT, "plvs_amd", "shard.py"))
+    shard_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shard_mod)
+    t = _FakeIntegrate(rank, world)
+    xyz = torch.zeros((4, 3))
+    timings = {}
+    ok = True
+    for step in range(2):      # (the second step also takes the path with the first one's timings present)
+        t.noted, t.packed = [], False
+        counts = shard_mod.sharded_integrate(t, xyz, None, None, np.array([0, 4], np.int32), None, timings=timings)
+        ok &= np.array_equal(counts, t._counts())
+        seg, rec, run, rc = t.applied
+        for k, (got, width) in enumerate(((seg, 8), (rec, 8), (run, 20))):
+            want = []
+            for src in range(world):
+                n = [src + 2 * rank, 3 * src + rank + 1, src * rank][k]
+                ok &= int(rc[src, k]) == n
+                want += [[src, rank, i, k] + [7] * (width - 4) for i in range(n)]
+            ok &= got.tolist() == want
+        # every rank's saturated voxels reached this rank, in rank order
+        noted = [v.tolist() for v in t.noted]
+        ok &= noted == [[[src, 0, 0, v] for v in range(src + 1)] for src in range(world)]
+    ok &= sorted(timings) == ["apply", "exchange", "feedback", "pack", "walk"] and all(v >= 0.0 for v in timings.values())
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_sharded_integrate_orchestration(world):
+    """plvs_amd.shard.sharded_integrate end to end over gloo with a stand-in map: walk -> pack -> the all-to-all of
+    the three buffers -> apply -> the all-gather of the saturated voxels -> note, twice in a row, with the per-phase
+    timings bench.py --gpus N reports."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_sharded_integrate, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out == [(r, True) for r in range(world)]
+
+
 class _FakeShard:
     """Stands in for a rank's TsdfChisel in the meshing-halo protocol (CPU tensors): the map is a line of chunks
     (i, 0, 0), i < n, hash-sharded like the real one; "meshing" chunk i needs chunk i + 1, and — once that one is
