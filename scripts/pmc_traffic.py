@@ -17,7 +17,7 @@ from collections import defaultdict
 
 PIPELINE = ("pose_prep", "walk_prologue", "walk_fast", "walk_tiles", "seg_pass", "seg_scan", "apply_chunks", "compact_runs", "sort_runs_small", "fold_colours_masks",
             "ray_count", "scan_tile_sums", "scan_sums", "scan_tile_apply", "mark_tiles", "ray_tiles",
-            "radix_hist", "radix_scatter", "voxel_heads", "fold_colours", "reduce_sums", "run_counts", "mark_blocks",
+            "radix_hist", "radix_scatter", "radix_scatter_lds", "voxel_heads", "fold_colours", "reduce_sums", "run_counts", "mark_blocks",
             "gather_runs", "chain_runs")
 
 
