@@ -311,82 +311,416 @@ __global__ __launch_bounds__(kExpandThreads) void vb_expand(
 // runs past the chunk's end reads on from global memory; one that started before belongs to the workgroup before).
 // (The first version gave a thread one voxel run and read it at a stride of the run lengths: 12 B per visit in
 // scattered pieces, 0.34 ms for the 11 M visits of a step.)
+//
+// Two ways to fold a run, by its length (round 3):
+//  * SHORT runs (< kLongRun visits, wholly inside the chunk): a lane per run, voxel_fold visit by visit; a lane that
+//    finishes takes the chunk's next short run at once.  In such a wave some lane starts a run in nearly every trip
+//    of the loop, so a visit costs the wave the run-start path too (two global round trips): ≈ 0.6 us.  Fine for a few
+//    visits — but a voxel that every key frame of the call sees has hundreds, and the kernel used to end with such
+//    lanes (0.36 ms for 11 M visits).
+//  * LONG runs (and the run that leaves the chunk): EIGHT lanes per run, eight visits per trip.  What makes a visit
+//    expensive — three IEEE divisions, the byte <-> float conversions of four colour channels — does not depend on
+//    the running distance or colour: the weight sequence W_k = min(W_{k-1} + w_k, max) only needs the records, and
+//    with it the divisor (W_{k-1} + w_k), both blend factors and the product sdf*w of EVERY visit are known up front.
+//    So per trip: the eight lanes take eight records; the weight chain runs through the eight visits (plain running
+//    sums — the 1e-6 floor and the max_weight ceiling are checked afterwards and a trip they act on is redone);
+//    lane g computes visit g's operands — one correctly rounded reciprocal and three exact quotients from it — into
+//    LDS; then the order-dependent part runs with lane 0 carrying the distance (mul, add, the exact-quotient step
+//    mul, fma, fma — dist_update_rcp's form — and a median for the clamp) and lanes 1-4 a colour channel each
+//    (mul, add, round).  A trip of eight visits takes ≈ 1.3 us; nothing in it waits for global memory (the next
+//    trip's records are fetched before the chains start, the voxels of all long runs are staged in LDS up front).
+//    The groups take the chunk's long runs longest first, each the next one as soon as its own ends.
+// Measured (MI355X, 25 key frames per call, 11.2 M visits): 0.36 -> 0.25-0.27 ms, the call 1.10 -> 0.97 ms.  The
+// kernel is now bound by each chunk's longest run (a workgroup lives as long as it: ≈ 25 us on average, two to three
+// times the 8 trips a group averages) at the three workgroups per CU the 45 KB of LDS allow.  Did not help: four
+// lanes per run (slower: twice the trips on the critical run), 128- and 64-thread workgroups, a quarter fewer
+// instructions per trip, a lane-path threshold anywhere from 8 to 128.
+#ifndef PLVS_VB_LONG_RUN
+#define PLVS_VB_LONG_RUN 16
+#endif
 constexpr int kChainChunk = 2048;
-__global__ __launch_bounds__(256) void vb_chain_chunks(Params P, const uint32_t* __restrict__ keys, uint32_t nrec,
-                                                       const float2* __restrict__ rec, const uint32_t* __restrict__ rec_c,
-                                                       VCounters* __restrict__ ctr, float* __restrict__ dist,
-                                                       float* __restrict__ weight, uint32_t* __restrict__ rgba) {
+constexpr int kChainThreads = 256;
+constexpr int kLongRun = PLVS_VB_LONG_RUN;
+constexpr int kG = 8;   // lanes per long run = visits per trip
+constexpr int kChainGroups = kChainThreads / kG;
+constexpr int kMaxLong = kChainChunk / kLongRun + 2;
+
+#ifndef PLVS_VB_PROF
+#define PLVS_VB_PROF 0
+#endif
+#if PLVS_VB_PROF   // developer build: the times (100 MHz ticks) at which every wave passes its stages, read by plvs_hip_debug_chain_prof
+constexpr int kProfWaves = 1 << 16;
+__device__ unsigned long long g_chain_prof[kProfWaves][4];
+#define CHAIN_PROBE(i)                                                                                         \
+  if (lane == 0 && blockIdx.x * (kChainThreads / 64) + wid < kProfWaves)                                       \
+    g_chain_prof[blockIdx.x * (kChainThreads / 64) + wid][i] = wall_clock64();
+#else
+#define CHAIN_PROBE(i)
+#endif
+
+// RN(1/b) for b in [2^-20, 2^40] (tsdf_chisel.hip's rcp_rn: checked for every significand by plvs_hip_selftest_rcp) and
+// RN(a/b) from it (dist_update_rcp's correction step), exact for a = 0 or |a| in [2^-60, 2^60]
+__device__ __forceinline__ float vb_rcp_rn(float b) {
+  const float y0 = __builtin_amdgcn_rcpf(b);
+  const float e = fmaf(-b, y0, 1.0f);
+  return fmaf(e, y0, y0);
+}
+__device__ __forceinline__ float vb_quot(float a, float b, float y) {
+  const float q = a * y;
+  const float r = fmaf(-q, b, a);
+  return fmaf(r, y, q);
+}
+__device__ __forceinline__ bool vb_quot_ok(float a) { return a == 0.0f || (fabsf(a) >= 0x1p-60f && fabsf(a) <= 0x1p60f); }
+
+// record rr of the chunk (LDS), of the records behind it (global) or a terminator beyond the call's last record
+__device__ __forceinline__ void chain_load(const float2* s_rec, const uint32_t* s_col, const float2* __restrict__ rec,
+                                           const uint32_t* __restrict__ rec_c, uint32_t c0, uint32_t n, uint32_t nrec,
+                                           uint32_t rr, float2* v, uint32_t* col) {
+  const uint32_t rl = min(rr, n - 1u);
+  *v = s_rec[rl];
+  *col = s_col[rl];
+  if (rr >= n) {   // (only the run that leaves the chunk gets here)
+    if (c0 + rr < nrec) {
+      *v = rec[c0 + rr];
+      *col = rec_c[c0 + rr];
+    } else {
+      *v = make_float2(0.f, -0.0f);
+      *col = 0u;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kChainThreads) void vb_chain_chunks(
+    Params P, const uint32_t* __restrict__ keys, uint32_t nrec, const float2* __restrict__ rec,
+    const uint32_t* __restrict__ rec_c, VCounters* __restrict__ ctr, float* __restrict__ dist,
+    float* __restrict__ weight, uint32_t* __restrict__ rgba) {
   __shared__ float2 s_rec[kChainChunk];
   __shared__ uint32_t s_col[kChainChunk];
-  __shared__ uint16_t s_head[kChainChunk];
-  __shared__ uint32_t s_nheads;
-  const int tid = threadIdx.x, lane = tid & 63;
+  __shared__ uint16_t s_head[kChainChunk + 2];   // positions of the run heads of the chunk, ascending; then the chunk's end
+  __shared__ uint16_t s_short[kChainChunk];      // the short runs (indices into s_head), any order
+  __shared__ uint16_t s_long[kMaxLong];          // the long ones
+  __shared__ unsigned long long s_mask[kChainChunk / 64];
+  __shared__ uint32_t s_pre[kChainChunk / 64];
+  // the per-visit operands of a trip, the distance lane's and the colour lanes' apart; + 1: the groups of a wave start
+  // in different banks (at a stride of kG * 16 B every group of a quarter-wave would read the same four)
+  __shared__ float4 s_opd[kChainGroups][kG + 1], s_opc[kChainGroups][kG + 1];
+  __shared__ __attribute__((aligned(16))) float s_uw[kChainGroups][kG];
+  __shared__ float4 s_state[kMaxLong];           // a long run's voxel: distance, weight, colour, its index in the pool
+  __shared__ uint32_t s_cls[32];
+  __shared__ uint32_t s_nheads, s_nshort, s_nlong, s_next, s_next_long;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
   const uint32_t c0 = blockIdx.x * (uint32_t)kChainChunk;
   if (c0 >= nrec) return;
   const uint32_t n = min((uint32_t)kChainChunk, nrec - c0);
-  if (tid == 0) s_nheads = 0;
-  __syncthreads();
+  CHAIN_PROBE(0)
+  if (tid < 32) s_cls[tid] = 0;
+  if (tid == 0) {
+    s_nshort = 0;
+    s_nlong = 0;
+    s_next = (uint32_t)kChainThreads;   // the next short run to hand out; the first ones go by thread index
+    s_next_long = (uint32_t)kChainGroups;   // the same for long runs and groups
+  }
+  // ---- the chunk into LDS; its run heads in record order.  All loads of the thread are issued before the first is
+  // used (clamped addresses instead of branches): one memory latency per chunk, not one per round.
+  constexpr int kRounds = kChainChunk / kChainThreads;
+  float2 l_rec[kRounds];
+  uint32_t l_col[kRounds], l_key[kRounds], l_prev[kRounds];
 #pragma unroll
-  for (int k = 0; k < kChainChunk / 256; ++k) {
-    const uint32_t r = (uint32_t)(k * 256 + tid);
+  for (int k = 0; k < kRounds; ++k) {
+    const uint32_t at = c0 + min((uint32_t)(k * kChainThreads + tid), n - 1u);
+    l_rec[k] = rec[at];
+    l_col[k] = rec_c[at];
+    l_key[k] = keys[at];
+    l_prev[k] = keys[max(at, 1u) - 1u];
+  }
+  uint32_t myheads = 0;
+#pragma unroll
+  for (int k = 0; k < kRounds; ++k) {
+    const uint32_t r = (uint32_t)(k * kChainThreads + tid);
     bool head = false;
     if (r < n) {
-      s_rec[r] = rec[c0 + r];
-      s_col[r] = rec_c[c0 + r];
-      const uint32_t key = keys[c0 + r];
-      head = (c0 + r == 0u) || keys[c0 + r - 1u] != key;
+      s_rec[r] = l_rec[k];
+      s_col[r] = l_col[k];
+      head = (c0 + r == 0u) || l_prev[k] != l_key[k];
     }
     const unsigned long long m = __ballot(head);
-    uint32_t base = 0;
-    if (lane == 0 && m) base = atomicAdd(&s_nheads, (uint32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, 0);
-    if (head) s_head[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)r;
+    if (lane == 0) s_mask[k * (kChainThreads / 64) + wid] = m;
+    myheads |= head ? (1u << k) : 0u;
+  }
+  __syncthreads();
+  if (tid < kChainChunk / 64) {   // (32 words: half of wave 0)
+    const uint32_t c = (uint32_t)__popcll(s_mask[tid]);
+    uint32_t incl = c;
+#pragma unroll
+    for (int off = 1; off < kChainChunk / 64; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+      if (tid >= off) incl += up;
+    }
+    s_pre[tid] = incl - c;
+    if (tid == kChainChunk / 64 - 1) s_nheads = incl;
   }
   __syncthreads();
   const uint32_t nheads = s_nheads;
-  // Runs differ in length (ten visits on average, hundreds for the voxels every key frame of the step sees): a lane
-  // that finishes its run takes the next one of the chunk at once (a counter in LDS), so a wave's lanes fold side by
-  // side until the chunk's runs are used up instead of idling behind the wave's longest run.
-  __syncthreads();                 // (everybody has read the count)
-  if (tid == 0) s_nheads = 256u;   // (now: the next run to hand out; the first 256 go by thread index)
-  __syncthreads();
-  uint32_t longest = 0;
-  uint32_t h = (uint32_t)tid, r = 0, r0 = 0;
-  size_t a = 0;
-  float D = 0.f, W = 0.f;
-  uint32_t C = 0;
-  bool have = false;
-  for (;;) {
-    if (!have) {
-      if (h >= nheads) break;
-      r = r0 = s_head[h];
-      a = (size_t)keys[c0 + r0];
-      D = dist[a];
-      W = weight[a];
-      C = rgba[a];
-      have = true;
-    }
-    float2 v;
-    uint32_t col;
-    if (r < n) {
-      v = s_rec[r];
-      col = s_col[r];
-    } else {                       // the run leaves the chunk
-      v = rec[c0 + r];
-      col = rec_c[c0 + r];
-    }
-    voxel_fold(P, D, W, C, v.x, fabsf(v.y), col);
-    if (__float_as_uint(v.y) >> 31) {   // (its sign bit marks the last record of the run)
-      dist[a] = D;
-      weight[a] = W;
-      rgba[a] = C;
-      longest = max(longest, r - r0 + 1u);
-      have = false;
-      h = atomicAdd(&s_nheads, 1u);
-    } else {
-      ++r;
+#pragma unroll
+  for (int k = 0; k < kChainChunk / kChainThreads; ++k) {
+    if ((myheads >> k) & 1u) {
+      const int w = k * (kChainThreads / 64) + wid;
+      s_head[s_pre[w] + (uint32_t)__popcll(s_mask[w] & lt)] = (uint16_t)(k * kChainThreads + tid);
     }
   }
+  if (tid == 0) s_head[nheads] = (uint16_t)n;
+  __syncthreads();
+  // ---- short and long runs.  The chunk's last run is long when it goes on behind the chunk.  The long ones are put
+  // in classes of descending length (a counting sort over trips of eight visits; the run that leaves the chunk first):
+  // the groups take them in that order, so a workgroup does not end with one group on a long run it started last.
+  const bool crossing = !(__float_as_uint(s_rec[n - 1u].y) >> 31);
+  auto run_class = [&](uint32_t h, bool* is_long) -> uint32_t {
+    const uint32_t len = (uint32_t)s_head[h + 1u] - (uint32_t)s_head[h];
+    const bool leaves = crossing && h + 1u == nheads;
+    *is_long = len >= (uint32_t)kLongRun || leaves;
+    return leaves ? 0u : 31u - min((len + 7u) >> 3, 31u);
+  };
+  for (uint32_t base = 0; base < nheads; base += (uint32_t)kChainThreads) {
+    const uint32_t h = base + (uint32_t)tid;
+    bool is_long = false, is_short = false;
+    if (h < nheads) {
+      const uint32_t cls = run_class(h, &is_long);
+      is_short = !is_long;
+      if (is_long) atomicAdd(&s_cls[cls], 1u);
+    }
+    const unsigned long long ms = __ballot(is_short);
+    uint32_t bs = 0;
+    if (lane == 0 && ms) bs = atomicAdd(&s_nshort, (uint32_t)__popcll(ms));
+    bs = (uint32_t)__shfl((int)bs, 0);
+    if (is_short) s_short[bs + (uint32_t)__popcll(ms & lt)] = (uint16_t)h;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    const uint32_t c = s_cls[tid];
+    uint32_t incl = c;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+      if (tid >= off) incl += up;
+    }
+    s_cls[tid] = incl - c;   // (from here on: where the class's next run goes)
+    if (tid == 31) s_nlong = incl;
+  }
+  __syncthreads();
+  for (uint32_t base = 0; base < nheads; base += (uint32_t)kChainThreads) {
+    const uint32_t h = base + (uint32_t)tid;
+    if (h < nheads) {
+      bool is_long;
+      const uint32_t cls = run_class(h, &is_long);
+      if (is_long) s_long[atomicAdd(&s_cls[cls], 1u)] = (uint16_t)h;
+    }
+  }
+  __syncthreads();
+  const uint32_t nshort = s_nshort, nlong = s_nlong;
+  uint32_t longest = 0;
+  // the voxels of the long runs into LDS, all loads side by side (a group that starts a run inside the trip loop below
+  // must not make its wave wait for global memory)
+  for (uint32_t j = (uint32_t)tid; j < nlong; j += (uint32_t)kChainThreads) {
+    const uint32_t a = keys[c0 + s_head[s_long[j]]];
+    s_state[j] = make_float4(dist[a], weight[a], __uint_as_float(rgba[a]), __uint_as_float(a));
+  }
+  CHAIN_PROBE(1)
+  // ---- short runs: a lane per run
+  {
+    uint32_t i = (uint32_t)tid, r = 0;
+    size_t a = 0;
+    float D = 0.f, W = 0.f;
+    uint32_t C = 0;
+    bool have = false;
+    for (;;) {
+      if (!have) {
+        if (i >= nshort) break;
+        const uint32_t h = s_short[i];
+        r = s_head[h];
+        longest = max(longest, (uint32_t)s_head[h + 1u] - r);
+        a = (size_t)keys[c0 + r];
+        D = dist[a];
+        W = weight[a];
+        C = rgba[a];
+        have = true;
+      }
+      const float2 v = s_rec[r];
+      voxel_fold(P, D, W, C, v.x, fabsf(v.y), s_col[r]);
+      if (__float_as_uint(v.y) >> 31) {   // (its sign bit marks the last record of the run)
+        dist[a] = D;
+        weight[a] = W;
+        rgba[a] = C;
+        have = false;
+        i = atomicAdd(&s_next, 1u);
+      } else {
+        ++r;
+      }
+    }
+  }
+  CHAIN_PROBE(2)
+  // ---- long runs: kG lanes per run, kG visits per trip.  Lane 0 of the group carries the distance, lanes 1-4 a colour
+  // channel each.  ONE loop: a group whose run ends takes the
+  // chunk's next long run in the same trip, so the groups of a wave never wait for each other's runs.
+  __syncthreads();   // (s_state complete)
+  const int grp = tid / kG, g = tid % kG;
+  const int sh = 8 * ((g - 1) & 3);   // lanes 1-4 (and, idle, 0 and 5-7): the colour channel
+  {
+    // (the first runs — the longest — dealt round the waves, not eight in a row to each: a workgroup's waves sit on
+    // different SIMDs)
+    constexpr int kGroupsPerWave = 64 / kG, kWaves = kChainThreads / 64;
+    uint32_t j = (uint32_t)((grp % kGroupsPerWave) * kWaves + grp / kGroupsPerWave), r = 0, visits = 0, col = 0;
+    float W = 0.f, X = 0.f, Dx = 0.f;
+    float2 v = make_float2(0.f, 0.f);
+    bool have = false;
+    for (;;) {
+      if (!have) {
+        if (j >= nlong) break;
+        const float4 st = s_state[j];
+        Dx = st.x;                                              // (lane 0's)
+        W = st.y;
+        X = (float)((__float_as_uint(st.z) >> sh) & 255u);      // the lane's colour channel
+        r = s_head[s_long[j]];
+        visits = 0;
+        chain_load(s_rec, s_col, rec, rec_c, c0, n, nrec, r + (uint32_t)g, &v, &col);
+        have = true;
+      }
+      // the visits of this trip: up to the run's last record
+      const unsigned long long bal = __ballot(__float_as_uint(v.y) >> 31);
+      const uint32_t gm = (uint32_t)(bal >> (lane & ~(kG - 1))) & ((1u << kG) - 1u);
+      const int nvalid = gm ? __ffs((int)gm) : kG;
+      const bool done = gm != 0u;
+      const float sdf = v.x, uw = fabsf(v.y);
+      s_uw[grp][g] = uw;
+      float2 vn = make_float2(0.f, 0.f);
+      uint32_t coln = 0;
+      if (!done) chain_load(s_rec, s_col, rec, rec_c, c0, n, nrec, r + (uint32_t)(kG + g), &vn, &coln);
+      __builtin_amdgcn_wave_barrier();
+      // the weight chain: lane g takes the steps of the visits before its own
+      float u[kG];
+#pragma unroll
+      for (int k = 0; k < kG; k += 4)
+        *reinterpret_cast<float4*>(&u[k]) = *reinterpret_cast<const float4*>(&s_uw[grp][k]);
+      // (plain running sums first: the 1e-6 floor and the max_weight ceiling of updateTsdfVoxel almost never act, and a
+      // lane whose own sum is clean knows that the sums before it were)
+      float w_prev = W;
+#pragma unroll
+      for (int k = 0; k < kG - 1; ++k) {
+        const float nwk = w_prev + u[k];
+        w_prev = (k < g) ? nwk : w_prev;
+      }
+      float nw = w_prev + uw;
+      {
+        const unsigned long long balw = __ballot((g < nvalid) && !((nw >= 1e-6f) && (nw < P.max_weight)));
+        if ((((uint32_t)(balw >> (lane & ~(kG - 1)))) & ((1u << kG) - 1u)) != 0u) {
+          w_prev = W;
+          for (int k = 0; k < kG - 1; ++k) {
+            const float nwk = w_prev + u[k];
+            const float stepped = (nwk < 1e-6f) ? w_prev : ((nwk < P.max_weight) ? nwk : P.max_weight);
+            w_prev = (k < g) ? stepped : w_prev;
+          }
+          nw = w_prev + uw;
+        }
+      }
+      const bool skip = (g >= nvalid) || (nw < 1e-6f);
+      const float w_after = skip ? w_prev : ((nw < P.max_weight) ? nw : P.max_weight);
+      W = __shfl(w_after, nvalid - 1, kG);   // (the weight after the trip's last visit)
+      // visit g's operands (blend_colours' total = w1 + w2 is nw): the distance half, the colour half
+      const bool rcp_ok = (nw >= 0x1p-20f) && (nw <= 0x1p40f);
+      const unsigned long long balr = __ballot(!skip && !rcp_ok);
+      bool inexact = (((uint32_t)(balr >> (lane & ~(kG - 1)))) & ((1u << kG) - 1u)) != 0u;
+      {
+        const bool blend = !skip && (fabsf(sdf) < P.truncation);
+        // 1 / nw correctly rounded (v_rcp_f32 and one Newton step: plvs_hip_selftest_rcp), and both blend factors as exact
+        // quotients from it (the same correction step as the distance's); operands outside the exact ranges divide
+        float y = vb_rcp_rn(nw), w1n = vb_quot(w_prev, nw, y), w2n = vb_quot(uw, nw, y);
+        if (!skip && !(rcp_ok && vb_quot_ok(w_prev) && vb_quot_ok(uw))) {   // (a skipped visit's operands are not used)
+          y = 1.0f / nw;
+          w1n = w_prev / nw;
+          w2n = uw / nw;
+        }
+        s_opd[grp][g] = make_float4(skip ? -w_prev : w_prev, sdf * uw, y, nw);
+        s_opc[grp][g] = make_float4(w1n, w2n, __uint_as_float(col), blend ? 1.0f : 0.0f);
+      }
+      __builtin_amdgcn_wave_barrier();
+      float4 opc[kG];
+#pragma unroll
+      for (int k = 0; k < kG; ++k) opc[k] = s_opc[grp][k];
+      // the order-dependent part.  A colour step: round(a*w1 + b*w2) of non-negative operands with w1 + w2 = 1 up to
+      // roundings is an integer in [0, 255] — blend_colours' cast to a byte and back changes nothing.
+      auto colour_steps = [&](float x) {
+#pragma unroll
+        for (int k = 0; k < kG; ++k) {
+          const float b = (float)((__float_as_uint(opc[k].z) >> sh) & 255u);
+          const float t = x * opc[k].x + b * opc[k].y;
+          const float tr = truncf(t);
+          const float nc = tr + (((t - tr) >= 0.5f) ? 1.0f : 0.0f);   // roundf of t >= 0
+          x = (opc[k].w != 0.0f) ? nc : x;
+        }
+        return x;
+      };
+      if (g == 0) {
+        float4 opd[kG];
+#pragma unroll
+        for (int k = 0; k < kG; ++k) opd[k] = s_opd[grp][k];
+        // (the quotient from the reciprocal is exact inside dist_update_rcp_exact's operand ranges; a trip that leaves
+        // them — none does on real data — is redone with the division itself)
+        const float x0 = Dx;
+#pragma unroll
+        for (int k = 0; k < kG; ++k) {
+          const bool skipk = __float_as_uint(opd[k].x) >> 31;
+          const float t = opd[k].y + Dx * fabsf(opd[k].x);   // sdf * w + D * W
+          const float y = opd[k].z, nwk = opd[k].w;
+          const float q = t * y;
+          const float rem = fmaf(-q, nwk, t);
+          const float nd = fmaf(rem, y, q);
+          const float at = fabsf(t);
+          inexact |= !skipk && !(at >= 0x1p-60f && at <= 0x1p60f);
+          // (an exact quotient of in-range operands is finite: the median IS voxel_fold's pair of std::min / std::max)
+          Dx = skipk ? Dx : __builtin_amdgcn_fmed3f(nd, -P.truncation, P.truncation);
+        }
+        if (inexact) {
+          Dx = x0;
+          for (int k = 0; k < kG; ++k) {
+            const float t = opd[k].y + Dx * fabsf(opd[k].x);
+            float nd = t / opd[k].w;
+            nd = (nd > 0.0f) ? ((nd < P.truncation) ? nd : P.truncation) : ((-P.truncation < nd) ? nd : -P.truncation);
+            Dx = (__float_as_uint(opd[k].x) >> 31) ? Dx : nd;
+          }
+        }
+      } else {
+        X = colour_steps(X);
+      }
+      __builtin_amdgcn_wave_barrier();
+      visits += (uint32_t)nvalid;
+      if (done) {
+        const uint32_t cx = (uint32_t)X;
+        const uint32_t C = (uint32_t)__shfl((int)cx, 1, kG) | ((uint32_t)__shfl((int)cx, 2, kG) << 8) |
+                           ((uint32_t)__shfl((int)cx, 3, kG) << 16) | ((uint32_t)__shfl((int)cx, 4, kG) << 24);
+        uint32_t jn = 0;
+        if (g == 0) {
+          s_state[j] = make_float4(Dx, W, __uint_as_float(C), s_state[j].w);
+          jn = atomicAdd(&s_next_long, 1u);
+        }
+        j = (uint32_t)__shfl((int)jn, 0, kG);
+        longest = max(longest, visits);
+        have = false;
+      } else {
+        v = vn;
+        col = coln;
+        r += (uint32_t)kG;
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t j = (uint32_t)tid; j < nlong; j += (uint32_t)kChainThreads) {
+    const float4 st = s_state[j];
+    const size_t a = (size_t)__float_as_uint(st.w);
+    dist[a] = st.x;
+    weight[a] = st.y;
+    rgba[a] = __float_as_uint(st.z);
+  }
+  CHAIN_PROBE(3)
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, off));
   if (lane == 0 && longest > ctr->max_run) atomicMax(&ctr->max_run, longest);
@@ -957,6 +1291,9 @@ static int vb_integrate_impl(plvs_tsdf_voxblox* h, const float* d_xyz, const uin
                                 h->scratch.p, s, &second));
   const uint32_t* keys = second ? h->keys1.p : h->keys0.p;
   const uint32_t* seqs = second ? h->seq1.p : h->seq0.p;
+  // (Folding the records in slices on a second stream while the next slice is expanded was measured in round 3: the two
+  // kernels slow each other down by more than the overlap gains — 1.03-1.13 ms with two slices, 1.08-1.20 with four,
+  // against 0.93-1.03 for one after the other.)
 #define VB_EXPAND(MODE)                                                                                             \
   hipLaunchKernelGGL(vb_expand<MODE>, dim3(ceil_div(V, kExpandThreads)), dim3(kExpandThreads), 0, s, h->P, keys, seqs, V, \
                      d_xyz, d_aux, d_col, h->offsets.p, nclouds, d_poses, h->dir.slot_ids, h->rec.p, h->rec_c.p,         \
@@ -966,7 +1303,7 @@ static int vb_integrate_impl(plvs_tsdf_voxblox* h, const float* d_xyz, const uin
   else VB_EXPAND(kSimple);
 #undef VB_EXPAND
   PLVS_KERNEL_CHECK();
-  hipLaunchKernelGGL(vb_chain_chunks, dim3(ceil_div(V, kChainChunk)), dim3(256), 0, s, h->P, keys, V, h->rec.p,
+  hipLaunchKernelGGL(vb_chain_chunks, dim3(ceil_div(V, kChainChunk)), dim3(kChainThreads), 0, s, h->P, keys, V, h->rec.p,
                      h->rec_c.p, h->d_ctr, h->dist, h->weight, h->rgba);
   PLVS_KERNEL_CHECK();
   rc = vb_read_counters(h, s);
@@ -1233,3 +1570,11 @@ int plvs_hip_tsdf_voxblox_download_block(plvs_tsdf_voxblox* h, int bx, int by, i
 }
 
 }  // extern "C"
+
+#if PLVS_VB_PROF
+extern "C" int plvs_hip_debug_chain_prof(unsigned long long* out, int nwaves) {
+  PLVS_HIP_TRY(hipDeviceSynchronize());
+  PLVS_HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_prof), (size_t)nwaves * 4 * sizeof(unsigned long long)));
+  return PLVS_OK;
+}
+#endif
