@@ -1,0 +1,222 @@
+/* TEST INFRASTRUCTURE ONLY — CPU restatement of the two methods of libelas that the reference's own accelerated
+ * build moves to the GPU (class ElasGPU : public Elas, Thirdparty/libelas-gpu/GPU/elas_gpu.h:41-45):
+ *
+ *   Elas::computeDisparity   Thirdparty/libelas-gpu/CPU/elas.cpp:840-968  (findMatch :739-837,
+ *                            updatePosteriorMinimum :717-737)
+ *   Elas::adaptiveMean       Thirdparty/libelas-gpu/CPU/elas.cpp:1349-1572
+ *
+ * PLVS reaches them through PointCloudKeyFrame::ProcessStereoLibelas (src/PointCloudKeyFrame.cc:335-432) ->
+ * libelas::ElasInterface::process -> Elas::process (elas.cpp:36-159).  Everything else of Elas::process (descriptors,
+ * support matches, Delaunay triangulation, planes, grid, left/right check, speckles, gap interpolation, median) stays
+ * the reference's host code, exactly as in its GPU build.
+ *
+ * Plain C, no SSE: _mm_sad_epu8 of two 16-byte descriptors + the two extracts is the sum of the 16 absolute byte
+ * differences; the 4- / 8-float registers of adaptiveMean are written out slot by slot IN THE REGISTER'S ORDER (the
+ * float sums are not associative).  Pinned: tests/test_elas.py compares both functions with the reference's compiled
+ * methods (oracle/_ref/libelas_ref.so, oracle/ref/elas_ref_wrap.cpp) on the arguments the reference pipeline itself
+ * produces for real stereo pairs.  Nothing under plvs_amd/ may call into this file.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+  int32_t subsampling;   /* Elas::Parameters, elas.h:62-90: the fields the two methods read */
+  int32_t grid_size;
+  int32_t match_texture;
+  float beta, gamma, sigma, sradius;
+} oracle_elas_params;
+
+typedef struct { int32_t u, v, d; } elas_support_pt;                                   /* elas.h:178-183 */
+typedef struct { int32_t c1, c2, c3; float t1a, t1b, t1c, t2a, t2b, t2c; } elas_triangle;   /* elas.h:185-190 */
+
+static int32_t imin(int32_t a, int32_t b) { return a < b ? a : b; }
+static int32_t imax(int32_t a, int32_t b) { return a > b ? a : b; }
+
+/* (uint32_t)(float) assigned to an int32_t (elas.cpp:927-928, :947-948): on x86-64 the conversion goes through the
+ * 64-bit truncation and keeps the low 32 bits, so a negative product comes back as the negative integer */
+static int32_t trunc_u32_as_i32(float x) { return (int32_t)(uint32_t)(int64_t)x; }
+
+static int32_t sad16(const uint8_t* a, const uint8_t* b) {
+  int32_t s = 0;
+  for (int i = 0; i < 16; ++i) s += abs((int32_t)a[i] - (int32_t)b[i]);
+  return s;
+}
+
+/* Elas::findMatch (elas.cpp:739-837) */
+static void find_match(const oracle_elas_params* p, int32_t width, int32_t height, int32_t u, int32_t v, float plane_a, float plane_b,
+                       float plane_c, const int32_t* disparity_grid, const int32_t* grid_dims, const uint8_t* I1_desc,
+                       const uint8_t* I2_desc, const int32_t* P, int32_t plane_radius, int valid, int right_image, float* D) {
+  const int32_t disp_num = grid_dims[0] - 1;
+  const int32_t window_size = 2;
+  const uint32_t d_addr = p->subsampling ? (uint32_t)((v / 2) * (width / 2) + u / 2) : (uint32_t)(v * width + u);
+  if (u < window_size || u >= width - window_size) return;
+  const int32_t line_offset = 16 * width * imax(imin(v, height - 3), 2);
+  const uint8_t* I1_line = (right_image ? I2_desc : I1_desc) + line_offset;
+  const uint8_t* I2_line = (right_image ? I1_desc : I2_desc) + line_offset;
+  const uint8_t* I1_block = I1_line + 16 * u;
+  int32_t sum = 0;
+  for (int i = 0; i < 16; ++i) sum += abs((int32_t)I1_block[i] - 128);
+  if (sum < p->match_texture) return;
+  const int32_t d_plane = (int32_t)(plane_a * (float)u + plane_b * (float)v + plane_c);
+  const int32_t d_plane_min = imax(d_plane - plane_radius, 0);
+  const int32_t d_plane_max = imin(d_plane + plane_radius, disp_num - 1);
+  const int32_t grid_x = (int32_t)floorf((float)u / (float)p->grid_size);
+  const int32_t grid_y = (int32_t)floorf((float)v / (float)p->grid_size);
+  const uint32_t grid_addr = (uint32_t)((grid_y * grid_dims[1] + grid_x) * grid_dims[0]);   /* getAddressOffsetGrid, d = 0 */
+  const int32_t num_grid = disparity_grid[grid_addr];
+  const int32_t* d_grid = disparity_grid + grid_addr + 1;
+  int32_t min_val = 10000, min_d = -1;
+  const int32_t sign = right_image ? 1 : -1;
+  for (int32_t i = 0; i < num_grid; ++i) {
+    const int32_t d_curr = d_grid[i];
+    if (d_curr < d_plane_min || d_curr > d_plane_max) {
+      const int32_t u_warp = u + sign * d_curr;
+      if (u_warp < window_size || u_warp >= width - window_size) continue;
+      const int32_t val = sad16(I1_block, I2_line + 16 * u_warp);
+      if (val < min_val) { min_val = val; min_d = d_curr; }
+    }
+  }
+  for (int32_t d_curr = d_plane_min; d_curr <= d_plane_max; ++d_curr) {
+    const int32_t u_warp = u + sign * d_curr;
+    if (u_warp < window_size || u_warp >= width - window_size) continue;
+    const int32_t val = sad16(I1_block, I2_line + 16 * u_warp) + (valid ? P[abs(d_curr - d_plane)] : 0);
+    if (val < min_val) { min_val = val; min_d = d_curr; }
+  }
+  D[d_addr] = min_d >= 0 ? (float)min_d : -1.0f;
+}
+
+/* Elas::computeDisparity (elas.cpp:840-968) */
+void oracle_elas_compute_disparity(const oracle_elas_params* p, const elas_support_pt* p_support, int32_t n_support,
+                                   const elas_triangle* tri, int32_t n_tri, const int32_t* disparity_grid, const int32_t* grid_dims,
+                                   const uint8_t* I1_desc, const uint8_t* I2_desc, int32_t width, int32_t height, int32_t right_image,
+                                   float* D) {
+  (void)n_support;
+  const int32_t disp_num = grid_dims[0] - 1;
+  const int32_t npix = p->subsampling ? (width / 2) * (height / 2) : width * height;
+  for (int32_t i = 0; i < npix; ++i) D[i] = -10.0f;
+  const float two_sigma_squared = 2 * p->sigma * p->sigma;
+  int32_t* P = (int32_t*)malloc(sizeof(int32_t) * (size_t)(disp_num > 0 ? disp_num : 1));
+  /* (elas.cpp:861-864 under `using namespace std` with <math.h>: exp / log / ceil of float arguments bind to the float
+   * overloads, the whole expression is evaluated in float) */
+  for (int32_t delta_d = 0; delta_d < disp_num; ++delta_d)
+    P[delta_d] = (int32_t)((-logf(p->gamma + expf((float)(-delta_d * delta_d) / two_sigma_squared)) + logf(p->gamma)) / p->beta);
+  const int32_t plane_radius = (int32_t)fmaxf(ceilf(p->sigma * p->sradius), 2.0f);
+  for (int32_t i = 0; i < n_tri; ++i) {
+    float plane_a, plane_b, plane_c, plane_d;
+    if (!right_image) { plane_a = tri[i].t1a; plane_b = tri[i].t1b; plane_c = tri[i].t1c; plane_d = tri[i].t2a; }
+    else              { plane_a = tri[i].t2a; plane_b = tri[i].t2b; plane_c = tri[i].t2c; plane_d = tri[i].t1a; }
+    const int32_t c[3] = {tri[i].c1, tri[i].c2, tri[i].c3};
+    float tri_u[3], tri_v[3];
+    for (int k = 0; k < 3; ++k) {
+      tri_u[k] = right_image ? (float)(p_support[c[k]].u - p_support[c[k]].d) : (float)p_support[c[k]].u;
+      tri_v[k] = (float)p_support[c[k]].v;
+    }
+    for (int j = 0; j < 3; ++j)
+      for (int k = 0; k < j; ++k)
+        if (tri_u[k] > tri_u[j]) {
+          const float tu = tri_u[j]; tri_u[j] = tri_u[k]; tri_u[k] = tu;
+          const float tv = tri_v[j]; tri_v[j] = tri_v[k]; tri_v[k] = tv;
+        }
+    const float A_u = tri_u[0], A_v = tri_v[0], B_u = tri_u[1], B_v = tri_v[1], C_u = tri_u[2], C_v = tri_v[2];
+    float AB_a = 0, AC_a = 0, BC_a = 0;
+    if ((int32_t)A_u != (int32_t)B_u) AB_a = (A_v - B_v) / (A_u - B_u);
+    if ((int32_t)A_u != (int32_t)C_u) AC_a = (A_v - C_v) / (A_u - C_u);
+    if ((int32_t)B_u != (int32_t)C_u) BC_a = (B_v - C_v) / (B_u - C_u);
+    const float AB_b = A_v - AB_a * A_u, AC_b = A_v - AC_a * A_u, BC_b = B_v - BC_a * B_u;
+    const int valid = fabs(plane_a) < 0.7 && fabs(plane_d) < 0.7;
+    for (int part = 0; part < 2; ++part) {
+      const float lo_u = part ? B_u : A_u, hi_u = part ? C_u : B_u, e_a = part ? BC_a : AB_a, e_b = part ? BC_b : AB_b;
+      if ((int32_t)lo_u == (int32_t)hi_u) continue;
+      for (int32_t u = imax((int32_t)lo_u, 0); u < imin((int32_t)hi_u, width); ++u) {
+        if (p->subsampling && u % 2 != 0) continue;
+        const int32_t v_1 = trunc_u32_as_i32(AC_a * (float)u + AC_b);
+        const int32_t v_2 = trunc_u32_as_i32(e_a * (float)u + e_b);
+        for (int32_t v = imin(v_1, v_2); v < imax(v_1, v_2); ++v)
+          if (!p->subsampling || v % 2 == 0)
+            find_match(p, width, height, u, v, plane_a, plane_b, plane_c, disparity_grid, grid_dims, I1_desc, I2_desc, P,
+                       plane_radius, valid, right_image, D);
+      }
+    }
+  }
+  free(P);
+}
+
+/* one output of Elas::adaptiveMean's filters: the window's values by REGISTER SLOT (slot = pixel index mod n), the
+ * weights max(0, 4 - |val - centre|) — with subsampling the "absolute value" is the reference's
+ * _mm_and_ps(x, _mm_set1_ps(0x7FFFFFFF)) (elas.cpp:1379, :1402): the mask is the FLOAT 2147483648.0f = 0x4F000000, so
+ * it keeps four exponent bits and nothing else — summed in the order of the four-lane registers */
+static int mean_of_window(const float* val, int n, float centre, int masked_abs, float* out) {
+  float weight[8], factor[8];
+  for (int s = 0; s < n; ++s) {
+    float w = val[s] - centre;
+    if (masked_abs) {
+      uint32_t b;
+      memcpy(&b, &w, 4);
+      b &= 0x4F000000u;
+      memcpy(&w, &b, 4);
+    } else {
+      const float neg = 0.0f - w;
+      w = (neg > w) ? neg : w;   /* _mm_max_ps(0 - x, x) */
+    }
+    w = 4.0f - w;
+    w = (0.0f > w) ? 0.0f : w;   /* _mm_max_ps(0, x) */
+    weight[s] = w;
+    factor[s] = val[s] * w;
+  }
+  if (n == 8)
+    for (int s = 0; s < 4; ++s) {
+      weight[s] = weight[s] + weight[s + 4];
+      factor[s] = factor[s] + factor[s + 4];
+    }
+  const float weight_sum = weight[0] + weight[1] + weight[2] + weight[3];
+  const float factor_sum = factor[0] + factor[1] + factor[2] + factor[3];
+  if (weight_sum > 0) {
+    const float d = factor_sum / weight_sum;
+    if (d >= 0) {
+      *out = d;
+      return 1;
+    }
+  }
+  return 0;
+}
+
+/* Elas::adaptiveMean (elas.cpp:1349-1572).  width x height: the IMAGE size (D is half of it with subsampling).
+ * The scratch image D_tmp is uninitialised malloc memory in the reference wherever the horizontal pass does not write
+ * (rows 0-2 and the last three, the outermost columns) and the vertical pass reads some of it: 0.0 here, the content
+ * of fresh pages (what a large malloc returns in a fresh process; oracle/ref/elas_ref_wrap.cpp keeps the compiled
+ * reference on such pages). */
+void oracle_elas_adaptive_mean(float* D, int32_t width, int32_t height, int32_t subsampling) {
+  const int32_t W = subsampling ? width / 2 : width, H = subsampling ? height / 2 : height;
+  const size_t n = (size_t)W * (size_t)H;
+  float* D_copy = (float*)malloc(n * sizeof(float));
+  float* D_tmp = (float*)calloc(n, sizeof(float));
+  memcpy(D_copy, D, n * sizeof(float));
+  for (size_t i = 0; i < n; ++i)
+    if (D[i] < 0) { D_copy[i] = -10.0f; D_tmp[i] = -10.0f; }
+  const int taps = subsampling ? 4 : 8, back = subsampling ? 1 : 3;
+  float val[8];
+  /* horizontal: the window ends at u, its output is `back` pixels behind */
+  for (int32_t v = 3; v < H - 3; ++v) {
+    for (int32_t u = 0; u < taps - 1; ++u) val[u] = D_copy[v * W + u];
+    for (int32_t u = taps - 1; u < W; ++u) {
+      const float centre = D_copy[v * W + (u - back)];
+      val[u % taps] = D_copy[v * W + u];
+      float d;
+      if (mean_of_window(val, taps, centre, subsampling, &d)) D_tmp[v * W + (u - back)] = d;
+    }
+  }
+  /* vertical */
+  for (int32_t u = 3; u < W - 3; ++u) {
+    for (int32_t v = 0; v < taps - 1; ++v) val[v] = D_tmp[v * W + u];
+    for (int32_t v = taps - 1; v < H; ++v) {
+      const float centre = D_tmp[(v - back) * W + u];
+      val[v % taps] = D_tmp[v * W + u];
+      float d;
+      if (mean_of_window(val, taps, centre, subsampling, &d)) D[(v - back) * W + u] = d;
+    }
+  }
+  free(D_copy);
+  free(D_tmp);
+}

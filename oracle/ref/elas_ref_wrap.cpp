@@ -11,6 +11,56 @@
 
 #include "elas.h"
 
+// The two methods the reference's own accelerated build overrides (Thirdparty/libelas-gpu/GPU/elas_gpu.h:41-45,
+// class ElasGPU : public Elas): computeDisparity and adaptiveMean.  HookedElas lets a test stand in the same place:
+// a hook receives the arguments the reference pipeline hands over and either calls the reference's own method
+// (ref_elas_base_*: capture of inputs and expected outputs) or fills D itself (the oracle, the HIP path) — the rest of
+// the pipeline stays the reference's compiled code.
+extern "C" {
+struct ref_elas_hooks {
+  // support: n_support x {u, v, d}; tri: n_tri x {c1, c2, c3, t1a, t1b, t1c, t2a, t2b, t2c} (36-byte records)
+  void (*compute_disparity)(void* user, void* call, const int32_t* support, int n_support, const void* tri, int n_tri,
+                            const int32_t* grid, const int32_t* grid_dims, const uint8_t* I1_desc, const uint8_t* I2_desc,
+                            int right_image, float* D);
+  void (*adaptive_mean)(void* user, void* elas, float* D);
+  void* user;
+};
+}
+
+namespace {
+
+struct HookedElas;
+struct DisparityCall {
+  HookedElas* self;
+  std::vector<libelas::Elas::support_pt>* support;
+  std::vector<libelas::Elas::triangle>* tri;
+  int32_t *grid, *grid_dims;
+  uint8_t *d1, *d2;
+  bool right;
+};
+
+struct HookedElas : libelas::Elas {
+  const ref_elas_hooks* hooks;
+  HookedElas(Parameters p, const ref_elas_hooks* h) : libelas::Elas(p), hooks(h) {}
+  void computeDisparity(std::vector<support_pt> p_support, std::vector<triangle> tri, int32_t* disparity_grid, int32_t* grid_dims,
+                        uint8_t* I1_desc, uint8_t* I2_desc, bool right_image, float* D) override {
+    static_assert(sizeof(support_pt) == 12 && sizeof(triangle) == 36, "record layouts handed to the hooks");
+    if (hooks == nullptr || hooks->compute_disparity == nullptr) {
+      libelas::Elas::computeDisparity(p_support, tri, disparity_grid, grid_dims, I1_desc, I2_desc, right_image, D);
+      return;
+    }
+    DisparityCall call{this, &p_support, &tri, disparity_grid, grid_dims, I1_desc, I2_desc, right_image};
+    hooks->compute_disparity(hooks->user, &call, reinterpret_cast<const int32_t*>(p_support.data()), (int)p_support.size(),
+                             tri.data(), (int)tri.size(), disparity_grid, grid_dims, I1_desc, I2_desc, right_image ? 1 : 0, D);
+  }
+  void adaptiveMean(float* D) override {
+    if (hooks == nullptr || hooks->adaptive_mean == nullptr) libelas::Elas::adaptiveMean(D);
+    else hooks->adaptive_mean(hooks->user, this, D);
+  }
+};
+
+}  // namespace
+
 extern "C" {
 
 // Elas::process with the parameters of main_cpu.cpp (the run that produced the stored outputs): Parameters() defaults
@@ -25,6 +75,37 @@ void ref_elas_process(const uint8_t* left, const uint8_t* right, int width, int 
   libelas::Elas elas(param);
   const int32_t dims[3] = {width, height, stride};
   elas.process(const_cast<uint8_t*>(left), const_cast<uint8_t*>(right), D1, D2, dims);
+}
+
+
+// The same with hooks in ElasGPU's two places (either may be null = the reference's own method).
+// (Elas::adaptiveMean reads its scratch image where the horizontal pass never wrote it, findMatch the descriptor images'
+// unwritten borders: elas_zero_malloc.h pins that memory to zero, the content of fresh pages.)
+void ref_elas_process_hooked(const uint8_t* left, const uint8_t* right, int width, int height, int stride, int plvs,
+                             int subsampling, float* D1, float* D2, const ref_elas_hooks* hooks) {
+  libelas::Elas::Parameters param;
+  param.postprocess_only_left = plvs != 0;
+  param.subsampling = subsampling != 0;
+  HookedElas elas(param, hooks);
+  const int32_t dims[3] = {width, height, stride};
+  elas.process(const_cast<uint8_t*>(left), const_cast<uint8_t*>(right), D1, D2, dims);
+}
+
+// From inside a hook: the reference's own computeDisparity / adaptiveMean on the arguments of that call.
+void ref_elas_base_compute_disparity(void* call, float* D) {
+  DisparityCall* c = static_cast<DisparityCall*>(call);
+  c->self->libelas::Elas::computeDisparity(*c->support, *c->tri, c->grid, c->grid_dims, c->d1, c->d2, c->right, D);
+}
+void ref_elas_base_adaptive_mean(void* elas, float* D) { static_cast<HookedElas*>(elas)->libelas::Elas::adaptiveMean(D); }
+
+// Elas::adaptiveMean alone on a disparity image (width x height is the IMAGE size: with subsampling D is half of it).
+void ref_elas_adaptive_mean(float* D, int width, int height, int subsampling) {
+  libelas::Elas::Parameters param;
+  param.subsampling = subsampling != 0;
+  struct Sized : libelas::Elas {
+    Sized(Parameters p, int w, int h) : libelas::Elas(p) { width = w; height = h; }
+  } e(param, width, height);
+  e.adaptiveMean(D);
 }
 
 }  // extern "C"

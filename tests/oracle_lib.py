@@ -104,6 +104,38 @@ class Oracle:
         f(_ptr(left), _ptr(right), w, h, p1, p2, uniqueness, _ptr(disp), *[_ptr(st[k]) if stages else None for k in order])
         return (disp, st) if stages else disp
 
+    # ------------------------------------------------------------ libelas: the two methods its GPU build overrides
+    ELAS_ROBOTICS = dict(grid_size=20, match_texture=1, beta=0.02, gamma=3.0, sigma=1.0, sradius=2.0)   # elas.h:97-121
+
+    def elas_compute_disparity(self, a, **params):
+        """a: the arguments of Elas::computeDisparity as tests/elas_ref.py hands them over -> D float32 [h, w] (halved
+        with subsampling)."""
+        prm = dict(self.ELAS_ROBOTICS, **params)
+
+        class P(ctypes.Structure):
+            _fields_ = [("subsampling", _i), ("grid_size", _i), ("match_texture", _i), ("beta", _f), ("gamma", _f),
+                        ("sigma", _f), ("sradius", _f)]
+        p = P(int(a["subsampling"]), prm["grid_size"], prm["match_texture"], prm["beta"], prm["gamma"], prm["sigma"],
+              prm["sradius"])
+        w, h = a["width"], a["height"]
+        D = np.zeros((h // 2, w // 2) if a["subsampling"] else (h, w), np.float32)
+        f = self.lib.oracle_elas_compute_disparity
+        f.restype = None
+        f.argtypes = [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]
+        sup, tri = np.ascontiguousarray(a["support"]), np.ascontiguousarray(a["tri"])
+        grid, gd = np.ascontiguousarray(a["grid"], np.int32), np.ascontiguousarray(a["grid_dims"], np.int32)
+        f(ctypes.byref(p), _ptr(sup), len(sup), _ptr(tri), len(tri), _ptr(grid), _ptr(gd), _ptr(a["I1_desc"]), _ptr(a["I2_desc"]),
+          w, h, int(a["right_image"]), _ptr(D))
+        return D
+
+    def elas_adaptive_mean(self, D, width, height, subsampling):
+        D = np.ascontiguousarray(D, np.float32).copy()
+        f = self.lib.oracle_elas_adaptive_mean
+        f.restype = None
+        f.argtypes = [_vp, _i, _i, _i]
+        f(_ptr(D), width, height, int(subsampling))
+        return D
+
     # ------------------------------------------------------------ stereo (M5)
     def stereo_matches(self, keys_left, desc_left, keys_right, desc_right, pyr_left, pyr_right, scale, inv_scale,
                        mb, mbf):

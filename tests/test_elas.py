@@ -1,0 +1,110 @@
+"""libelas: the two methods the reference's own GPU build overrides (class ElasGPU : public Elas,
+Thirdparty/libelas-gpu/GPU/elas_gpu.h:41-45) — Elas::computeDisparity (CPU/elas.cpp:840-968) and Elas::adaptiveMean
+(:1349-1572) — as PointCloudKeyFrame::ProcessStereoLibelas reaches them (src/PointCloudKeyFrame.cc:335-432).
+
+The reference's CPU sources run here compiled unmodified (oracle/_ref/libelas_ref.so) with hooks in ElasGPU's two places
+(tests/elas_ref.py): the arguments are the ones the reference pipeline itself produces for a real stereo pair
+(tests/golden/urban1*: the tree's own input, cropped).  CPU tests pin oracle/elas.c against the compiled methods; GPU tests
+put the HIP path through the C ABI against the oracle, and INTO the reference pipeline against the pure reference run.
+Where oracle/_ref is absent the committed capture tests/golden/elas_capture.npz stands in (scripts/make_elas_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import elas_ref
+from plvs_amd.pgm import read_pgm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+needs_ref = pytest.mark.skipif(not elas_ref.available(), reason="needs oracle/_ref/libelas_ref.so (built where /root/reference is)")
+
+
+def pair(width=None, height=None):
+    left = read_pgm(os.path.join(GOLDEN, "urban1_1241x376.pgm"))
+    right = read_pgm(os.path.join(GOLDEN, "urban1_right_1241x376.pgm"))
+    h, w = left.shape
+    width, height = width or w, height or h
+    return np.ascontiguousarray(left[:height, :width]), np.ascontiguousarray(right[:height, :width])
+
+
+def golden_capture():
+    z = np.load(os.path.join(GOLDEN, "elas_capture.npz"))
+    calls = []
+    for i in range(int(z["n_disparity_calls"])):
+        calls.append({k: z[f"d{i}_{k}"] for k in ("support", "tri", "grid", "grid_dims", "D")})
+        calls[-1]["I1_desc"], calls[-1]["I2_desc"] = z["I1_desc"], z["I2_desc"]
+        calls[-1]["support"] = np.ascontiguousarray(calls[-1]["support"]).view(elas_ref.SUPPORT).reshape(-1)
+        calls[-1]["tri"] = np.ascontiguousarray(calls[-1]["tri"]).view(elas_ref.TRIANGLE).reshape(-1)
+        for k in ("right_image", "width", "height", "subsampling"):
+            calls[-1][k] = int(z[f"d{i}_{k}"])
+    means = [dict(D_in=z[f"m{i}_D_in"], D_out=z[f"m{i}_D_out"], width=int(z[f"m{i}_width"]), height=int(z[f"m{i}_height"]),
+                  subsampling=int(z[f"m{i}_subsampling"])) for i in range(int(z["n_mean_calls"]))]
+    return calls, means
+
+
+# ------------------------------------------------------------------ the oracle against the reference's compiled methods
+@needs_ref
+@pytest.mark.parametrize("subsampling", [False, True])
+@pytest.mark.parametrize("size", [(1241, 376), (640, 300), (333, 201)])
+def test_oracle_compute_disparity_and_adaptive_mean_equal_the_reference_source(oracle, subsampling, size):
+    left, right = pair(*size)
+    disp_calls, mean_calls, _ = elas_ref.capture(left, right, subsampling=subsampling, plvs=False)
+    assert len(disp_calls) == 2 and len(mean_calls) == 2      # left and right image; both post-processed
+    for a in disp_calls:
+        got = oracle.elas_compute_disparity(a)
+        assert np.array_equal(got.reshape(-1).view(np.uint32), a["D"].view(np.uint32)), f"right_image={a['right_image']}"
+        assert (a["D"] >= 0).mean() > 0.3                      # a real disparity map, not an empty one
+    for m in mean_calls:
+        got = oracle.elas_adaptive_mean(m["D_in"], m["width"], m["height"], m["subsampling"])
+        assert np.array_equal(got.reshape(-1).view(np.uint32), m["D_out"].view(np.uint32))
+        assert not np.array_equal(m["D_in"], m["D_out"])
+
+
+@needs_ref
+@pytest.mark.parametrize("subsampling", [False, True])
+def test_reference_pipeline_with_the_oracle_in_elasgpus_place_equals_the_reference(oracle, subsampling):
+    left, right = pair(800, 376)
+    want = elas_ref.reference(left, right, subsampling=subsampling, plvs=True)     # PLVS: postprocess_only_left
+    got = elas_ref.run_with(left, right, oracle.elas_compute_disparity, oracle.elas_adaptive_mean, subsampling=subsampling,
+                            plvs=True)
+    for g, w in zip(got, want):
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
+    assert (want[0] >= 0).mean() > 0.3
+
+
+@needs_ref
+def test_adaptive_mean_alone_on_synthetic_maps_equals_the_reference_source(oracle):
+    """Ramps, steps of 2 / 4 / 8 / 16 levels (the exponent classes of the subsampling branch's mask), invalid islands,
+    borders: Elas::adaptiveMean alone.  (Maps of at least 32 KB: the reference reads its scratch image where it never
+    wrote it — column 3 at full resolution, rows 0-2 — and only a block that large is fresh zero pages under the
+    wrapper's mmap threshold; smaller ones come back from the heap with whatever the process left there.)"""
+    import ctypes
+    lib = ctypes.CDLL(elas_ref.REF)
+    lib.ref_elas_adaptive_mean.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    rng = np.random.default_rng(5)
+    for sub in (0, 1):
+        for (w, h) in ((128, 80), (131, 77), (200, 45)):
+            w, h = (2 * w + 1, 2 * h) if sub else (w, h)
+            W, H = (w // 2, h // 2) if sub else (w, h)
+            D = (np.linspace(0, 60, W)[None, :] + np.linspace(0, 9, H)[:, None]).astype(np.float32)
+            D += rng.choice([0, 0, 0, 2, 4, 8, 16, 33.5], size=D.shape).astype(np.float32)
+            D[rng.random(D.shape) < 0.15] = -1.0
+            D[H // 3:H // 3 + 3, W // 4:W // 2] = -10.0
+            want = D.copy()
+            lib.ref_elas_adaptive_mean(want.ctypes.data, w, h, sub)
+            got = oracle.elas_adaptive_mean(D, w, h, sub)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (sub, w, h)
+
+
+def test_oracle_reproduces_the_committed_capture_of_the_reference(oracle):
+    """Runs everywhere: the arguments and results of the reference's methods on a 256 x 128 crop, captured by
+    scripts/make_elas_golden.py from the compiled reference."""
+    calls, means = golden_capture()
+    assert len(calls) == 2 and len(means) == 2 and {m["subsampling"] for m in means} == {0, 1}
+    for a in calls:
+        got = oracle.elas_compute_disparity(a)
+        assert np.array_equal(got.reshape(-1).view(np.uint32), a["D"].reshape(-1).view(np.uint32))
+    for m in means:
+        got = oracle.elas_adaptive_mean(m["D_in"], m["width"], m["height"], m["subsampling"])
+        assert np.array_equal(got.reshape(-1).view(np.uint32), m["D_out"].reshape(-1).view(np.uint32))
