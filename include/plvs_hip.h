@@ -711,6 +711,43 @@ int plvs_hip_tsdf_chisel_halo_import(plvs_tsdf_chisel* h, const int32_t* d_ids_x
                                      const uint32_t* d_payload, int n, int nfound, void* stream);
 int plvs_hip_tsdf_chisel_halo_clear(plvs_tsdf_chisel* h);
 
+/* ------------------------------------------------- dense stereo (libelas: the part its GPU build moves to the device)
+ * Replaces the two methods the reference's own accelerated build overrides — class ElasGPU : public Elas,
+ * Thirdparty/libelas-gpu/GPU/elas_gpu.h:41-45:
+ *   computeDisparity   Elas::computeDisparity, Thirdparty/libelas-gpu/CPU/elas.cpp:840-968 (findMatch :739-837)
+ *   adaptiveMean       Elas::adaptiveMean,     Thirdparty/libelas-gpu/CPU/elas.cpp:1349-1572
+ * as PointCloudKeyFrame::ProcessStereoLibelas reaches them (src/PointCloudKeyFrame.cc:335-432 ->
+ * libelas::ElasInterface::process -> Elas::process, elas.cpp:36-159).  Descriptors, support matches, the Delaunay
+ * triangulation, planes, grid, left/right check, speckle removal and gap interpolation stay the caller's host code, as in
+ * that build.  All pointers are HOST pointers (the reference's call sites hand over host memory); results are bit-identical
+ * to the CPU methods.
+ *   params            the fields of Elas::Parameters (elas.h:62-90) the two methods read
+ *   compute_disparity support: n_support x {u, v, d} (Elas::support_pt); tri: n_tri x 36-byte Elas::triangle records
+ *                     {c1, c2, c3, t1a, t1b, t1c, t2a, t2b, t2c}; disparity_grid / grid_dims as Elas::createGrid leaves
+ *                     them; I1_desc / I2_desc: Descriptor::I_desc, 16 * width * height bytes each — pass both with the
+ *                     first call of an image pair and NULL with the second (the right image's): the staged copies are
+ *                     reused.  D: width x height floats (width/2 x height/2 with subsampling), -10 where no triangle
+ *                     reaches, -1 where no candidate matched.
+ *   adaptive_mean     D in place; width x height is the IMAGE size (D is half of it with subsampling).  Where the
+ *                     reference reads scratch memory it never wrote (column 3 and the first / last three rows of its
+ *                     D_tmp) the value is 0.0, the content of fresh pages. */
+typedef struct plvs_elas plvs_elas;
+typedef struct {
+  int32_t subsampling;   /* Parameters::subsampling (PLVS: skDownsampleStep even) */
+  int32_t grid_size;     /* 20 */
+  int32_t match_texture; /* 1 (ROBOTICS) */
+  float beta;            /* 0.02 */
+  float gamma;           /* 3 */
+  float sigma;           /* 1 */
+  float sradius;         /* 2 */
+} plvs_elas_params;
+int plvs_hip_elas_create(const plvs_elas_params* params, plvs_elas** out);
+int plvs_hip_elas_destroy(plvs_elas* e);
+int plvs_hip_elas_compute_disparity(plvs_elas* e, const int32_t* support, int n_support, const void* tri, int n_tri,
+                                    const int32_t* disparity_grid, const int32_t* grid_dims, const uint8_t* I1_desc,
+                                    const uint8_t* I2_desc, int width, int height, int right_image, float* D);
+int plvs_hip_elas_adaptive_mean(plvs_elas* e, float* D, int width, int height);
+
 /* ------------------------------------------------- dense stereo (semi-global matching)
  * Replaces sgm::StereoSGM as PointCloudKeyFrame::ProcessStereoLibsgm uses it
  * (src/PointCloudKeyFrame.cc:435-481): StereoSGM(width, height, 64, 8, 8, HOST2HOST) with

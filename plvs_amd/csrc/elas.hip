@@ -1,0 +1,373 @@
+// libelas on the device: the two methods the reference's own accelerated build overrides —
+//   ElasGPU::computeDisparity, ElasGPU::adaptiveMean   (Thirdparty/libelas-gpu/GPU/elas_gpu.h:41-45),
+// i.e. Elas::computeDisparity (CPU/elas.cpp:840-968 with findMatch :739-837) and Elas::adaptiveMean (:1349-1572),
+// reached from PointCloudKeyFrame::ProcessStereoLibelas (src/PointCloudKeyFrame.cc:335-432) through
+// libelas::ElasInterface::process.  Everything else of Elas::process stays the caller's host code, as in that build.
+//
+// computeDisparity rasterises the triangles one after the other and lets later ones overwrite earlier ones on shared
+// pixels; whether a pixel is written at all depends on the pixel alone (its column and texture), the value on the plane
+// of the LAST triangle that covers it.  So: (1) elas_owner — a wave per triangle walks the triangle's columns exactly as
+// the reference does (same float expressions, same float -> integer conversions) and leaves max(triangle index) per
+// pixel; (2) elas_match — a thread per pixel runs findMatch against its owner's plane: the grid candidates, then the
+// plane's disparity range with the prior, 16-byte descriptor SADs (v_sad_u8).  adaptiveMean's two filter passes have
+// a fixed window per output pixel: a thread per pixel, the window's values summed in the order the reference's
+// four-lane registers impose (slot = pixel index mod 4 / 8).
+#include <cmath>
+#include <vector>
+
+#include "common.hpp"
+
+namespace {
+
+using plvs::ceil_div;
+
+struct Support { int32_t u, v, d; };                                                   // Elas::support_pt, elas.h:178-183
+struct Triangle { int32_t c1, c2, c3; float t1a, t1b, t1c, t2a, t2b, t2c; };           // Elas::triangle, elas.h:185-190
+static_assert(sizeof(Support) == 12 && sizeof(Triangle) == 36, "record layouts of the C ABI");
+
+struct MatchParams {
+  int32_t width, height, subsampling, right_image;
+  int32_t grid_size, match_texture, plane_radius, disp_num;
+  int32_t grid_w, grid_stride;   // grid_dims[1], grid_dims[0]
+};
+
+// (uint32_t)(float) stored into an int32_t (elas.cpp:927-928, :947-948) as x86-64 evaluates it: the 64-bit truncation's
+// low word — a negative product comes back as the negative integer, not as 0
+__device__ __forceinline__ int32_t trunc_u32_as_i32(float x) { return (int32_t)(uint32_t)(long long)x; }
+
+// the triangle as computeDisparity sees it: sorted corners, the three edge lines, the plane and its validity
+struct TriSetup {
+  float A_u, B_u, C_u;
+  float AB_a, AB_b, AC_a, AC_b, BC_a, BC_b;
+  float plane_a, plane_b, plane_c;
+  bool valid;
+};
+
+__device__ __forceinline__ TriSetup tri_setup(const Triangle& t, const Support* __restrict__ sup, bool right_image) {
+  TriSetup s;
+  float plane_d;
+  if (!right_image) { s.plane_a = t.t1a; s.plane_b = t.t1b; s.plane_c = t.t1c; plane_d = t.t2a; }
+  else              { s.plane_a = t.t2a; s.plane_b = t.t2b; s.plane_c = t.t2c; plane_d = t.t1a; }
+  const Support p1 = sup[t.c1], p2 = sup[t.c2], p3 = sup[t.c3];
+  float u0 = right_image ? (float)(p1.u - p1.d) : (float)p1.u, v0 = (float)p1.v;
+  float u1 = right_image ? (float)(p2.u - p2.d) : (float)p2.u, v1 = (float)p2.v;
+  float u2 = right_image ? (float)(p3.u - p3.d) : (float)p3.u, v2 = (float)p3.v;
+  // (the reference's exchange sort over j = 0..2, k < j: compares (0,1), then (0,2), then (1,2))
+#define SWAP_IF(ua, va, ub, vb) if (ua > ub) { const float tu = ub; ub = ua; ua = tu; const float tv = vb; vb = va; va = tv; }
+  SWAP_IF(u0, v0, u1, v1)
+  SWAP_IF(u0, v0, u2, v2)
+  SWAP_IF(u1, v1, u2, v2)
+#undef SWAP_IF
+  s.A_u = u0; s.B_u = u1; s.C_u = u2;
+  s.AB_a = 0.f; s.AC_a = 0.f; s.BC_a = 0.f;
+  if ((int32_t)u0 != (int32_t)u1) s.AB_a = (v0 - v1) / (u0 - u1);
+  if ((int32_t)u0 != (int32_t)u2) s.AC_a = (v0 - v2) / (u0 - u2);
+  if ((int32_t)u1 != (int32_t)u2) s.BC_a = (v1 - v2) / (u1 - u2);
+  s.AB_b = v0 - s.AB_a * u0;
+  s.AC_b = v0 - s.AC_a * u0;
+  s.BC_b = v1 - s.BC_a * u1;
+  s.valid = fabs((double)s.plane_a) < 0.7 && fabs((double)plane_d) < 0.7;
+  return s;
+}
+
+// (1) the last triangle over every pixel: owner[pixel] = index + 1.  One wave per triangle, a lane per column.
+__global__ __launch_bounds__(64) void elas_owner(MatchParams P, const Triangle* __restrict__ tri, int ntri,
+                                                 const Support* __restrict__ sup, uint32_t* __restrict__ owner) {
+  const int i = blockIdx.x;
+  if (i >= ntri) return;
+  const TriSetup s = tri_setup(tri[i], sup, P.right_image != 0);
+  const int ow = P.subsampling ? P.width / 2 : P.width;
+  for (int part = 0; part < 2; ++part) {
+    const float lo_u = part ? s.B_u : s.A_u, hi_u = part ? s.C_u : s.B_u;
+    const float e_a = part ? s.BC_a : s.AB_a, e_b = part ? s.BC_b : s.AB_b;
+    if ((int32_t)lo_u == (int32_t)hi_u) continue;
+    const int u_begin = max((int32_t)lo_u, 0), u_end = min((int32_t)hi_u, P.width);
+    for (int u = u_begin + (int)threadIdx.x; u < u_end; u += 64) {
+      if (P.subsampling && (u % 2) != 0) continue;
+      if (u < 2 || u >= P.width - 2) continue;   // (findMatch returns before it writes: elas.cpp:753-754)
+      const int32_t v_1 = trunc_u32_as_i32(s.AC_a * (float)u + s.AC_b);
+      const int32_t v_2 = trunc_u32_as_i32(e_a * (float)u + e_b);
+      // (rows outside the image would be writes outside D in the reference: its triangles never produce them)
+      const int v_begin = max(min(v_1, v_2), 0), v_end = min(max(v_1, v_2), P.height);
+      for (int v = v_begin; v < v_end; ++v)
+        if (!P.subsampling || (v % 2) == 0) {
+          const size_t at = P.subsampling ? (size_t)(v / 2) * ow + u / 2 : (size_t)v * ow + u;
+          atomicMax(&owner[at], (uint32_t)i + 1u);
+        }
+    }
+  }
+}
+
+__device__ __forceinline__ int32_t sad16(const uint4 a, const uint4 b) {
+  uint32_t s = __builtin_amdgcn_sad_u8(a.x, b.x, 0u);
+  s = __builtin_amdgcn_sad_u8(a.y, b.y, s);
+  s = __builtin_amdgcn_sad_u8(a.z, b.z, s);
+  return (int32_t)__builtin_amdgcn_sad_u8(a.w, b.w, s);
+}
+
+// (2) Elas::findMatch for every pixel some triangle covers
+__global__ __launch_bounds__(256) void elas_match(MatchParams P, const Triangle* __restrict__ tri, const Support* __restrict__ sup,
+                                                  const uint32_t* __restrict__ owner, const int32_t* __restrict__ grid,
+                                                  const int32_t* __restrict__ prior, const uint4* __restrict__ desc1,
+                                                  const uint4* __restrict__ desc2, float* __restrict__ D) {
+  const int ow = P.subsampling ? P.width / 2 : P.width, oh = P.subsampling ? P.height / 2 : P.height;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= ow || y >= oh) return;
+  const size_t at = (size_t)y * ow + x;
+  float out = -10.0f;   // (computeDisparity's initial value: no triangle, a column at the border, too little texture)
+  const uint32_t own = owner[at];
+  const int u = P.subsampling ? 2 * x : x, v = P.subsampling ? 2 * y : y;
+  const int window_size = 2;
+  if (own != 0u && !(u < window_size || u >= P.width - window_size)) {
+    const TriSetup s = tri_setup(tri[own - 1u], sup, P.right_image != 0);
+    const size_t line = (size_t)P.width * (size_t)max(min(v, P.height - 3), 2);
+    const uint4* I1_line = (P.right_image ? desc2 : desc1) + line;
+    const uint4* I2_line = (P.right_image ? desc1 : desc2) + line;
+    const uint4 block = I1_line[u];
+    const int32_t texture = sad16(block, make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u));
+    if (texture >= P.match_texture) {
+      const int32_t d_plane = (int32_t)(s.plane_a * (float)u + s.plane_b * (float)v + s.plane_c);
+      const int32_t d_plane_min = max(d_plane - P.plane_radius, 0);
+      const int32_t d_plane_max = min(d_plane + P.plane_radius, P.disp_num - 1);
+      const int32_t grid_x = (int32_t)floorf((float)u / (float)P.grid_size);
+      const int32_t grid_y = (int32_t)floorf((float)v / (float)P.grid_size);
+      const int32_t* cell = grid + (size_t)(grid_y * P.grid_w + grid_x) * (size_t)P.grid_stride;
+      const int32_t num_grid = cell[0];
+      int32_t min_val = 10000, min_d = -1;
+      const int32_t sign = P.right_image ? 1 : -1;
+      for (int32_t k = 0; k < num_grid; ++k) {
+        const int32_t d_curr = cell[1 + k];
+        if (d_curr < d_plane_min || d_curr > d_plane_max) {
+          const int32_t u_warp = u + sign * d_curr;
+          if (u_warp < window_size || u_warp >= P.width - window_size) continue;
+          const int32_t val = sad16(block, I2_line[u_warp]);
+          if (val < min_val) { min_val = val; min_d = d_curr; }
+        }
+      }
+      for (int32_t d_curr = d_plane_min; d_curr <= d_plane_max; ++d_curr) {
+        const int32_t u_warp = u + sign * d_curr;
+        if (u_warp < window_size || u_warp >= P.width - window_size) continue;
+        const int32_t val = sad16(block, I2_line[u_warp]) + (s.valid ? prior[abs(d_curr - d_plane)] : 0);
+        if (val < min_val) { min_val = val; min_d = d_curr; }
+      }
+      out = min_d >= 0 ? (float)min_d : -1.0f;
+    }
+  }
+  D[at] = out;
+}
+
+// ------------------------------------------------------------------ adaptiveMean
+// one output of either pass (elas.cpp:1389-1411, :1467-1503): `val` by register slot; the "absolute value" of the
+// subsampling branch is the reference's and-mask with the FLOAT 2147483648.0f = 0x4F000000 (elas.cpp:1379)
+template <int kTaps>
+__device__ __forceinline__ bool mean_of_window(const float* val, float centre, float* out) {
+  float weight[kTaps], factor[kTaps];
+#pragma unroll
+  for (int s = 0; s < kTaps; ++s) {
+    float w = val[s] - centre;
+    if (kTaps == 4) {
+      w = __uint_as_float(__float_as_uint(w) & 0x4F000000u);
+    } else {
+      const float neg = 0.0f - w;
+      w = (neg > w) ? neg : w;
+    }
+    w = 4.0f - w;
+    w = (0.0f > w) ? 0.0f : w;
+    weight[s] = w;
+    factor[s] = val[s] * w;
+  }
+  if (kTaps == 8) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      weight[s] = weight[s] + weight[s + 4];
+      factor[s] = factor[s] + factor[s + 4];
+    }
+  }
+  const float weight_sum = weight[0] + weight[1] + weight[2] + weight[3];
+  const float factor_sum = factor[0] + factor[1] + factor[2] + factor[3];
+  if (weight_sum > 0) {
+    const float d = factor_sum / weight_sum;
+    if (d >= 0) {
+      *out = d;
+      return true;
+    }
+  }
+  return false;
+}
+
+// D -> D_copy (negatives -> -10) and the initial D_tmp (-10 there, 0 elsewhere: the reference leaves D_tmp's valid pixels
+// unwritten until the horizontal pass; where that pass never writes, the vertical one reads what malloc returned —
+// zero pages in a fresh process, the value oracle/ref/elas_zero_malloc.h pins the compiled reference to)
+__global__ void mean_prepare(const float* __restrict__ D, size_t n, float* __restrict__ D_copy, float* __restrict__ D_tmp) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float d = D[i];
+  D_copy[i] = d < 0 ? -10.0f : d;
+  D_tmp[i] = d < 0 ? -10.0f : 0.0f;
+}
+
+// kVertical = false: D_copy -> D_tmp along rows; true: D_tmp -> D along columns.  The window ends `back` pixels behind
+// its last pixel's output: window = [c + back - kTaps + 1, c + back] for the output at c.
+template <int kTaps, bool kVertical>
+__global__ __launch_bounds__(256) void mean_pass(const float* __restrict__ src, float* __restrict__ dst, int W, int H) {
+  constexpr int back = kTaps == 4 ? 1 : 3;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= W || y >= H) return;
+  const int c = kVertical ? y : x, len = kVertical ? H : W;
+  // the other coordinate's range (elas.cpp:1383 / :1413: rows 3 .. H-4 for the horizontal pass, columns 3 .. W-4 for the vertical)
+  if (kVertical ? (x < 3 || x >= W - 3) : (y < 3 || y >= H - 3)) return;
+  const int last = c + back;                       // the loop index (u or v) at which this output is produced
+  if (last < kTaps - 1 || last >= len) return;
+  float val[kTaps];
+#pragma unroll
+  for (int k = 0; k < kTaps; ++k) {
+    const int i = last - k;                        // a pixel of the window ...
+    const float vk = kVertical ? src[(size_t)i * W + x] : src[(size_t)y * W + i];
+    // ... sits in slot i mod kTaps; write through a select chain (kTaps is 4 or 8: no dynamic indexing)
+#pragma unroll
+    for (int s = 0; s < kTaps; ++s)
+      if ((i % kTaps) == s) val[s] = vk;
+  }
+  const float centre = kVertical ? src[(size_t)c * W + x] : src[(size_t)y * W + c];
+  float d;
+  if (mean_of_window<kTaps>(val, centre, &d)) dst[kVertical ? (size_t)c * W + x : (size_t)y * W + c] = d;
+}
+
+}  // namespace
+
+struct plvs_elas {
+  plvs_elas_params prm;
+  hipStream_t stream = nullptr;
+  plvs::DevBuf<uint8_t> desc1, desc2;
+  plvs::DevBuf<Support> support;
+  plvs::DevBuf<Triangle> tri;
+  plvs::DevBuf<int32_t> grid, prior;
+  plvs::DevBuf<uint32_t> owner;
+  plvs::DevBuf<float> D, D_copy, D_tmp;
+  int desc_width = 0, desc_height = 0;   // the staged descriptor images' size (0: none)
+};
+
+extern "C" {
+
+int plvs_hip_elas_create(const plvs_elas_params* p, plvs_elas** out) {
+  PLVS_REQUIRE(p && out, "null argument");
+  PLVS_REQUIRE(p->grid_size > 0 && p->beta != 0.0f && p->sigma > 0.0f, "grid_size, beta, sigma");
+  plvs_elas* h = new plvs_elas();
+  h->prm = *p;
+  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete h;
+    plvs::set_error("hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));
+    return PLVS_ERR_HIP;
+  }
+  *out = h;
+  return PLVS_OK;
+}
+
+int plvs_hip_elas_destroy(plvs_elas* h) {
+  if (!h) return PLVS_OK;
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  h->desc1.release(); h->desc2.release(); h->support.release(); h->tri.release(); h->grid.release(); h->prior.release();
+  h->owner.release(); h->D.release(); h->D_copy.release(); h->D_tmp.release();
+  delete h;
+  return PLVS_OK;
+}
+
+int plvs_hip_elas_compute_disparity(plvs_elas* h, const int32_t* support, int n_support, const void* tri, int n_tri,
+                                    const int32_t* disparity_grid, const int32_t* grid_dims, const uint8_t* I1_desc,
+                                    const uint8_t* I2_desc, int width, int height, int right_image, float* D) {
+  PLVS_REQUIRE(h && grid_dims && D, "null argument");
+  PLVS_REQUIRE(width >= 8 && height >= 8, "image size");
+  PLVS_REQUIRE(n_support >= 0 && n_tri >= 0 && (n_tri == 0 || (support && tri)), "support points / triangles");
+  PLVS_REQUIRE(grid_dims[0] >= 2 && grid_dims[1] > 0 && grid_dims[2] > 0 && disparity_grid, "disparity grid");
+  PLVS_REQUIRE((I1_desc == nullptr) == (I2_desc == nullptr), "both descriptor images or neither");
+  PLVS_REQUIRE(I1_desc != nullptr || (h->desc_width == width && h->desc_height == height),
+               "no descriptor images staged for this size (pass them with the first call of a pair)");
+  PLVS_REQUIRE((int64_t)grid_dims[1] * h->prm.grid_size >= width && (int64_t)grid_dims[2] * h->prm.grid_size >= height,
+               "the disparity grid does not cover the image");
+  const Support* hs = reinterpret_cast<const Support*>(support);
+  const Triangle* ht = static_cast<const Triangle*>(tri);
+  for (int i = 0; i < n_tri; ++i)
+    PLVS_REQUIRE(ht[i].c1 >= 0 && ht[i].c1 < n_support && ht[i].c2 >= 0 && ht[i].c2 < n_support && ht[i].c3 >= 0 &&
+                     ht[i].c3 < n_support, "triangle corner outside the support points");
+  hipStream_t s = h->stream;
+  const bool sub = h->prm.subsampling != 0;
+  const int ow = sub ? width / 2 : width, oh = sub ? height / 2 : height;
+  const size_t npix = (size_t)ow * oh, desc_bytes = (size_t)16 * width * height;
+  const size_t ngrid = (size_t)grid_dims[0] * grid_dims[1] * grid_dims[2];
+  const int disp_num = grid_dims[0] - 1;
+  // the prior table and the plane radius on the host, in the reference's float arithmetic (elas.cpp:861-865: exp / log /
+  // ceil of floats under `using namespace std`)
+  std::vector<int32_t> P((size_t)disp_num);
+  const float two_sigma_squared = 2 * h->prm.sigma * h->prm.sigma;
+  for (int32_t delta_d = 0; delta_d < disp_num; ++delta_d)
+    P[(size_t)delta_d] = (int32_t)((-std::log(h->prm.gamma + std::exp((float)(-delta_d * delta_d) / two_sigma_squared)) +
+                                    std::log(h->prm.gamma)) / h->prm.beta);
+  MatchParams mp;
+  mp.width = width; mp.height = height; mp.subsampling = sub; mp.right_image = right_image != 0;
+  mp.grid_size = h->prm.grid_size; mp.match_texture = h->prm.match_texture;
+  mp.plane_radius = (int32_t)std::max(std::ceil(h->prm.sigma * h->prm.sradius), 2.0f);
+  mp.disp_num = disp_num; mp.grid_w = grid_dims[1]; mp.grid_stride = grid_dims[0];
+
+  PLVS_HIP_TRY(h->support.reserve((size_t)std::max(n_support, 1)));
+  PLVS_HIP_TRY(h->tri.reserve((size_t)std::max(n_tri, 1)));
+  PLVS_HIP_TRY(h->grid.reserve(ngrid));
+  PLVS_HIP_TRY(h->prior.reserve((size_t)disp_num));
+  PLVS_HIP_TRY(h->owner.reserve(npix));
+  PLVS_HIP_TRY(h->D.reserve(npix));
+  if (I1_desc != nullptr) {
+    PLVS_HIP_TRY(h->desc1.reserve(desc_bytes));
+    PLVS_HIP_TRY(h->desc2.reserve(desc_bytes));
+    h->desc_width = h->desc_height = 0;
+    PLVS_HIP_TRY(hipMemcpyAsync(h->desc1.p, I1_desc, desc_bytes, hipMemcpyHostToDevice, s));
+    PLVS_HIP_TRY(hipMemcpyAsync(h->desc2.p, I2_desc, desc_bytes, hipMemcpyHostToDevice, s));
+  }
+  if (n_support) PLVS_HIP_TRY(hipMemcpyAsync(h->support.p, hs, (size_t)n_support * sizeof(Support), hipMemcpyHostToDevice, s));
+  if (n_tri) PLVS_HIP_TRY(hipMemcpyAsync(h->tri.p, ht, (size_t)n_tri * sizeof(Triangle), hipMemcpyHostToDevice, s));
+  PLVS_HIP_TRY(hipMemcpyAsync(h->grid.p, disparity_grid, ngrid * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  PLVS_HIP_TRY(hipMemcpyAsync(h->prior.p, P.data(), (size_t)disp_num * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  PLVS_HIP_TRY(hipMemsetAsync(h->owner.p, 0, npix * sizeof(uint32_t), s));
+  if (n_tri) {
+    hipLaunchKernelGGL(elas_owner, dim3((unsigned)n_tri), dim3(64), 0, s, mp, h->tri.p, n_tri, h->support.p, h->owner.p);
+    PLVS_KERNEL_CHECK();
+  }
+  hipLaunchKernelGGL(elas_match, dim3(ceil_div((size_t)ow, 256), (unsigned)oh), dim3(256), 0, s, mp, h->tri.p, h->support.p,
+                     h->owner.p, h->grid.p, h->prior.p, reinterpret_cast<const uint4*>(h->desc1.p),
+                     reinterpret_cast<const uint4*>(h->desc2.p), h->D.p);
+  PLVS_KERNEL_CHECK();
+  PLVS_HIP_TRY(hipMemcpyAsync(D, h->D.p, npix * sizeof(float), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  if (I1_desc != nullptr) {
+    h->desc_width = width;
+    h->desc_height = height;
+  }
+  return PLVS_OK;
+}
+
+int plvs_hip_elas_adaptive_mean(plvs_elas* h, float* D, int width, int height) {
+  PLVS_REQUIRE(h && D, "null argument");
+  PLVS_REQUIRE(width >= 2 && height >= 2, "image size");
+  hipStream_t s = h->stream;
+  const bool sub = h->prm.subsampling != 0;
+  const int W = sub ? width / 2 : width, H = sub ? height / 2 : height;
+  const size_t n = (size_t)W * H;
+  PLVS_HIP_TRY(h->D.reserve(n));
+  PLVS_HIP_TRY(h->D_copy.reserve(n));
+  PLVS_HIP_TRY(h->D_tmp.reserve(n));
+  PLVS_HIP_TRY(hipMemcpyAsync(h->D.p, D, n * sizeof(float), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(mean_prepare, dim3(ceil_div(n, 256)), dim3(256), 0, s, h->D.p, n, h->D_copy.p, h->D_tmp.p);
+  const dim3 grid(ceil_div((size_t)W, 256), (unsigned)H), block(256);
+  if (sub) {
+    hipLaunchKernelGGL((mean_pass<4, false>), grid, block, 0, s, h->D_copy.p, h->D_tmp.p, W, H);
+    hipLaunchKernelGGL((mean_pass<4, true>), grid, block, 0, s, h->D_tmp.p, h->D.p, W, H);
+  } else {
+    hipLaunchKernelGGL((mean_pass<8, false>), grid, block, 0, s, h->D_copy.p, h->D_tmp.p, W, H);
+    hipLaunchKernelGGL((mean_pass<8, true>), grid, block, 0, s, h->D_tmp.p, h->D.p, W, H);
+  }
+  PLVS_KERNEL_CHECK();
+  PLVS_HIP_TRY(hipMemcpyAsync(D, h->D.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  return PLVS_OK;
+}
+
+}  // extern "C"

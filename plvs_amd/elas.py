@@ -1,0 +1,92 @@
+"""Host-side mirror of libelas::ElasGPU (Thirdparty/libelas-gpu/GPU/elas_gpu.h:29-47): the two methods of libelas::Elas the
+reference's accelerated build overrides — computeDisparity and adaptiveMean — as PointCloudKeyFrame::ProcessStereoLibelas
+reaches them (src/PointCloudKeyFrame.cc:335-432).  Same argument meaning as the reference's methods; the rest of
+Elas::process (descriptors, support matches, triangulation, planes, grid, left/right check, speckles, gaps) is the
+caller's.  The arithmetic runs in libplvs_hip.so; there is no CPU fallback."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+_vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+L = _lib.lib
+
+SUPPORT_PT = np.dtype([("u", np.int32), ("v", np.int32), ("d", np.int32)])                     # Elas::support_pt
+TRIANGLE = np.dtype([("c1", np.int32), ("c2", np.int32), ("c3", np.int32), ("t1a", np.float32), ("t1b", np.float32),
+                     ("t1c", np.float32), ("t2a", np.float32), ("t2b", np.float32), ("t2c", np.float32)])   # Elas::triangle
+
+
+class _Params(ctypes.Structure):
+    _fields_ = [("subsampling", ctypes.c_int32), ("grid_size", ctypes.c_int32), ("match_texture", ctypes.c_int32),
+                ("beta", _f), ("gamma", _f), ("sigma", _f), ("sradius", _f)]
+
+
+L.plvs_hip_elas_create.argtypes = [ctypes.POINTER(_Params), ctypes.POINTER(_vp)]
+L.plvs_hip_elas_destroy.argtypes = [_vp]
+L.plvs_hip_elas_compute_disparity.argtypes = [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]
+L.plvs_hip_elas_adaptive_mean.argtypes = [_vp, _vp, _i, _i]
+
+
+class ElasGPU:
+    class Parameters:
+        """The fields of Elas::Parameters (elas.h:62-90) the two methods read; defaults: the ROBOTICS setting (:97-121)
+        PLVS starts from, `subsampling` as PLVS sets it (PointCloudMapping::skDownsampleStep even)."""
+
+        def __init__(self, subsampling=False, grid_size=20, match_texture=1, beta=0.02, gamma=3.0, sigma=1.0, sradius=2.0):
+            self.subsampling, self.grid_size, self.match_texture = bool(subsampling), int(grid_size), int(match_texture)
+            self.beta, self.gamma, self.sigma, self.sradius = float(beta), float(gamma), float(sigma), float(sradius)
+
+    def __init__(self, param=None):
+        self.param = param or ElasGPU.Parameters()
+        p = _Params(int(self.param.subsampling), self.param.grid_size, self.param.match_texture, self.param.beta,
+                    self.param.gamma, self.param.sigma, self.param.sradius)
+        self._h = _vp()
+        _lib.check(L.plvs_hip_elas_create(ctypes.byref(p), ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.plvs_hip_elas_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _out_shape(self, width, height):
+        return (height // 2, width // 2) if self.param.subsampling else (height, width)
+
+    def computeDisparity(self, p_support, tri, disparity_grid, grid_dims, I1_desc, I2_desc, right_image, width, height):
+        """p_support: SUPPORT_PT records, tri: TRIANGLE records, disparity_grid / grid_dims as Elas::createGrid leaves them,
+        I*_desc: Descriptor::I_desc (16 * width * height bytes; both None = the pair staged by the previous call)
+        -> D float32 (-10: no triangle, -1: no match)."""
+        sup = np.ascontiguousarray(p_support, dtype=SUPPORT_PT)
+        tri = np.ascontiguousarray(tri, dtype=TRIANGLE)
+        grid = np.ascontiguousarray(disparity_grid, dtype=np.int32)
+        gd = np.ascontiguousarray(grid_dims, dtype=np.int32)
+        if gd.size != 3 or grid.size < int(gd[0]) * int(gd[1]) * int(gd[2]):
+            raise ValueError("disparity_grid is smaller than grid_dims says")
+        if (I1_desc is None) != (I2_desc is None):
+            raise ValueError("both descriptor images or neither")
+        d1 = d2 = None
+        if I1_desc is not None:
+            d1 = np.ascontiguousarray(I1_desc, dtype=np.uint8)
+            d2 = np.ascontiguousarray(I2_desc, dtype=np.uint8)
+            if d1.size != 16 * width * height or d2.size != d1.size:
+                raise ValueError("a descriptor image has 16 * width * height bytes")
+        D = np.empty(self._out_shape(width, height), np.float32)
+        _lib.check(L.plvs_hip_elas_compute_disparity(self._h, _lib.np_ptr(sup), len(sup), _lib.np_ptr(tri), len(tri),
+                                                     _lib.np_ptr(grid), _lib.np_ptr(gd), None if d1 is None else _lib.np_ptr(d1),
+                                                     None if d2 is None else _lib.np_ptr(d2), int(width), int(height),
+                                                     int(bool(right_image)), _lib.np_ptr(D)))
+        return D
+
+    def adaptiveMean(self, D, width, height):
+        """D (the disparity map of a width x height image; half of it with subsampling) -> the filtered map."""
+        D = np.ascontiguousarray(D, dtype=np.float32).copy()
+        if D.size != int(np.prod(self._out_shape(width, height))):
+            raise ValueError("D does not have the size of the disparity map")
+        _lib.check(L.plvs_hip_elas_adaptive_mean(self._h, _lib.np_ptr(D), int(width), int(height)))
+        return D

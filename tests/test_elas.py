@@ -108,3 +108,81 @@ def test_oracle_reproduces_the_committed_capture_of_the_reference(oracle):
     for m in means:
         got = oracle.elas_adaptive_mean(m["D_in"], m["width"], m["height"], m["subsampling"])
         assert np.array_equal(got.reshape(-1).view(np.uint32), m["D_out"].reshape(-1).view(np.uint32))
+
+
+# ------------------------------------------------------------------ the HIP path, through the C ABI
+def _hip_disparity(e):
+    def f(a):
+        return e.computeDisparity(a["support"], a["tri"], a["grid"], a["grid_dims"], a["I1_desc"], a["I2_desc"], a["right_image"],
+                                  a["width"], a["height"])
+    return f
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_the_committed_capture_of_the_reference():
+    from plvs_amd.elas import ElasGPU
+    calls, means = golden_capture()
+    e = ElasGPU()
+    for a in calls:
+        got = _hip_disparity(e)(a)
+        assert np.array_equal(got.reshape(-1).view(np.uint32), a["D"].reshape(-1).view(np.uint32)), a["right_image"]
+    # the second image of a pair on the descriptors the first call staged
+    a = dict(calls[1], I1_desc=None, I2_desc=None)
+    assert np.array_equal(_hip_disparity(e)(a).reshape(-1).view(np.uint32), calls[1]["D"].reshape(-1).view(np.uint32))
+    for m in means:
+        em = ElasGPU(ElasGPU.Parameters(subsampling=bool(m["subsampling"])))
+        got = em.adaptiveMean(m["D_in"], m["width"], m["height"])
+        assert np.array_equal(got.reshape(-1).view(np.uint32), m["D_out"].reshape(-1).view(np.uint32)), m["subsampling"]
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("subsampling", [False, True])
+@pytest.mark.parametrize("size", [(1241, 376), (640, 300), (333, 201)])
+def test_hip_equals_oracle_and_reference_on_the_reference_pipelines_own_arguments(oracle, subsampling, size):
+    from plvs_amd.elas import ElasGPU
+    left, right = pair(*size)
+    disp_calls, mean_calls, _ = elas_ref.capture(left, right, subsampling=subsampling, plvs=False)
+    e = ElasGPU(ElasGPU.Parameters(subsampling=subsampling))
+    for a in disp_calls:
+        got = _hip_disparity(e)(a)
+        assert np.array_equal(got.reshape(-1).view(np.uint32), a["D"].view(np.uint32)), f"right_image={a['right_image']}"
+        assert np.array_equal(got.view(np.uint32), oracle.elas_compute_disparity(a).view(np.uint32))
+    for m in mean_calls:
+        got = e.adaptiveMean(m["D_in"], m["width"], m["height"])
+        assert np.array_equal(got.reshape(-1).view(np.uint32), m["D_out"].view(np.uint32))
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("subsampling", [False, True])
+def test_reference_pipeline_with_the_hip_path_in_elasgpus_place_equals_the_reference(subsampling):
+    """What a PLVS built against this library runs: Elas::process with computeDisparity and adaptiveMean on the device."""
+    from plvs_amd.elas import ElasGPU
+    left, right = pair()
+    want = elas_ref.reference(left, right, subsampling=subsampling, plvs=True)
+    e = ElasGPU(ElasGPU.Parameters(subsampling=subsampling))
+    got = elas_ref.run_with(left, right, _hip_disparity(e), lambda D, w, h, sub: e.adaptiveMean(D, w, h), subsampling=subsampling,
+                            plvs=True)
+    for g, w in zip(got, want):
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
+    assert (want[0] >= 0).mean() > 0.3
+
+
+@pytest.mark.gpu
+def test_hip_elas_rejects_bad_arguments():
+    from plvs_amd import _lib
+    from plvs_amd.elas import ElasGPU
+    calls, _ = golden_capture()
+    a = calls[0]
+    e = ElasGPU()
+    with pytest.raises(_lib.PlvsHipError):      # no descriptors staged yet
+        e.computeDisparity(a["support"], a["tri"], a["grid"], a["grid_dims"], None, None, 0, a["width"], a["height"])
+    bad = a["tri"].copy()
+    bad["c2"][0] = len(a["support"])
+    with pytest.raises(_lib.PlvsHipError):      # a corner that is no support point
+        e.computeDisparity(a["support"], bad, a["grid"], a["grid_dims"], a["I1_desc"], a["I2_desc"], 0, a["width"], a["height"])
+    # no triangles: nothing is matched
+    D = e.computeDisparity(a["support"], a["tri"][:0], a["grid"], a["grid_dims"], a["I1_desc"], a["I2_desc"], 0, a["width"],
+                           a["height"])
+    assert np.all(D == -10.0)
