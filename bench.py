@@ -770,6 +770,60 @@ def main():
             "ms_per_pair": round(e0.elapsed_time(e1) / 20, 3), "size": "1240x376, 64 disparities, 8 paths",
             "valid_fraction": round(float((sd > 0).float().mean()), 3)}
 
+        # dense disparity by libelas: the two methods its GPU build overrides, on the arguments the reference's own
+        # pipeline produces for that pair (oracle/_ref/libelas_ref.so: test infrastructure, the CPU baseline of this leg)
+        try:
+            from tests import elas_ref
+            if not elas_ref.available():
+                raise RuntimeError("oracle/_ref/libelas_ref.so is not built here")
+            from plvs_amd.elas import ElasGPU
+            el, er = golden("urban1_1241x376.pgm"), golden("urban1_right_1241x376.pgm")
+            leg = {}
+            for sub in (False, True):
+                t0 = time.perf_counter()
+                dcalls, mcalls, _ = elas_ref.capture(el, er, subsampling=sub, plvs=True)
+                whole_ms = (time.perf_counter() - t0) * 1e3
+                eg = ElasGPU(ElasGPU.Parameters(subsampling=sub))
+
+                def hip_pair():
+                    out = []
+                    for i, a in enumerate(dcalls):
+                        out.append(eg.computeDisparity(a["support"], a["tri"], a["grid"], a["grid_dims"], a["I1_desc"] if i == 0 else None,
+                                                       a["I2_desc"] if i == 0 else None, a["right_image"], a["width"], a["height"]))
+                    out.append(eg.adaptiveMean(mcalls[0]["D_in"], mcalls[0]["width"], mcalls[0]["height"]))
+                    return out
+                got = hip_pair()
+                same = all(np.array_equal(g.reshape(-1).view(np.uint32), w.reshape(-1).view(np.uint32))
+                           for g, w in zip(got, [c["D"] for c in dcalls] + [mcalls[0]["D_out"]]))
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    hip_pair()
+                hip_ms = (time.perf_counter() - t0) / 10 * 1e3
+                # the reference's compiled methods on the same arguments (timed inside the hooks)
+                cpu = {"disparity": 0.0, "mean": 0.0}
+
+                def t_disp(a, D):
+                    t = time.perf_counter()
+                    a["lib"].ref_elas_base_compute_disparity(a["call"], D.ctypes.data)
+                    cpu["disparity"] += time.perf_counter() - t
+
+                def t_mean(a, D):
+                    t = time.perf_counter()
+                    a["lib"].ref_elas_base_adaptive_mean(a["elas"], D.ctypes.data)
+                    cpu["mean"] += time.perf_counter() - t
+                elas_ref._run(el, er, sub, True, t_disp, t_mean)
+                leg["subsampling" if sub else "full_resolution"] = {
+                    "hip_ms_per_pair": round(hip_ms, 3), "cpu_ms_per_pair": round((cpu["disparity"] + cpu["mean"]) * 1e3, 3),
+                    "cpu_compute_disparity_ms": round(cpu["disparity"] * 1e3, 3), "cpu_adaptive_mean_ms": round(cpu["mean"] * 1e3, 3),
+                    "bit_identical": bool(same), "reference_pipeline_ms": round(whole_ms, 1)}
+            leg["what"] = ("Elas::computeDisparity (left + right image) + Elas::adaptiveMean (left) of the 1241x376 pair — the part "
+                           "ElasGPU moves to the device; host flavours (descriptor images, triangles and grid uploaded per pair, "
+                           "disparity maps read back); cpu = the reference's compiled methods, 1 thread; reference_pipeline_ms = "
+                           "the whole Elas::process on the CPU for scale (under the capture hooks)")
+            result["frontend"]["dense_stereo_elas"] = leg
+        except Exception as e:
+            result["frontend"]["dense_stereo_elas"] = {"skipped": repr(e)}
+
     # -------------------------------------------------- CPU baseline when the parity leg did not run (rank 0)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and "cpu_baseline" not in result:
         from tests import oracle_lib

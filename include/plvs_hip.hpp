@@ -346,6 +346,55 @@ class StereoSGM {
   plvs_sgm* h_ = nullptr;
 };
 
+// libelas::ElasGPU (Thirdparty/libelas-gpu/GPU/elas_gpu.h:29-47) without the inheritance: the two methods of
+// libelas::Elas it overrides.  In a PLVS tree the class is the reference's own —
+//     class ElasGPU : public Elas { ... computeDisparity(...) override; adaptiveMean(float* D) override; };
+// — with these two bodies (INTEGRATION.md shows it); here the reference's types are spelled out so that the header
+// stands alone.  support_pt / triangle have the layout of Elas::support_pt / Elas::triangle (elas.h:178-190).
+class ElasGPU {
+ public:
+  struct support_pt { int32_t u, v, d; };
+  struct triangle { int32_t c1, c2, c3; float t1a, t1b, t1c, t2a, t2b, t2c; };
+  struct Parameters {   // the fields of Elas::Parameters the two methods read; defaults: ROBOTICS (elas.h:97-121)
+    bool subsampling;
+    int32_t grid_size, match_texture;
+    float beta, gamma, sigma, sradius;
+    Parameters() : subsampling(false), grid_size(20), match_texture(1), beta(0.02f), gamma(3), sigma(1), sradius(2) {}
+  };
+  explicit ElasGPU(const Parameters& param = Parameters()) : param(param) {
+    plvs_elas_params p{param.subsampling ? 1 : 0, param.grid_size, param.match_texture, param.beta, param.gamma, param.sigma,
+                       param.sradius};
+    check(plvs_hip_elas_create(&p, &h_));
+  }
+  ~ElasGPU() { plvs_hip_elas_destroy(h_); }
+  ElasGPU(const ElasGPU&) = delete;
+  ElasGPU& operator=(const ElasGPU&) = delete;
+  // Elas::process sets width / height before it calls the two methods (elas.cpp:39-40); here the caller does.
+  int32_t width = 0, height = 0;
+  Parameters param;
+
+  // Elas::computeDisparity's arguments.  The descriptor images are uploaded with the left image's call and reused by
+  // the right image's (Elas::process calls the two back to back on the same pair, elas.cpp:113-114).
+  void computeDisparity(const std::vector<support_pt>& p_support, const std::vector<triangle>& tri, const int32_t* disparity_grid,
+                        const int32_t* grid_dims, const uint8_t* I1_desc, const uint8_t* I2_desc, bool right_image, float* D) {
+    static_assert(sizeof(support_pt) == 12 && sizeof(triangle) == 36, "record layouts of the C ABI");
+    const bool staged = right_image && I1_desc == staged_1_ && I2_desc == staged_2_ && staged_w_ == width && staged_h_ == height;
+    check(plvs_hip_elas_compute_disparity(h_, reinterpret_cast<const int32_t*>(p_support.data()), (int)p_support.size(), tri.data(),
+                                          (int)tri.size(), disparity_grid, grid_dims, staged ? nullptr : I1_desc,
+                                          staged ? nullptr : I2_desc, width, height, right_image ? 1 : 0, D));
+    staged_1_ = right_image ? nullptr : I1_desc;   // (only a left-image call vouches for the staged pair)
+    staged_2_ = right_image ? nullptr : I2_desc;
+    staged_w_ = width;
+    staged_h_ = height;
+  }
+  void adaptiveMean(float* D) { check(plvs_hip_elas_adaptive_mean(h_, D, width, height)); }
+
+ private:
+  plvs_elas* h_ = nullptr;
+  const uint8_t *staged_1_ = nullptr, *staged_2_ = nullptr;
+  int32_t staged_w_ = 0, staged_h_ = 0;
+};
+
 // ------------------------------------------------------------------------------------ depth -> cloud
 class PointCloudGenerator {   // PointCloudMapping::InitCamGridPoints + GeneratePointCloudInCameraFrameBGRA
  public:

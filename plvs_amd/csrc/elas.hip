@@ -197,7 +197,7 @@ __device__ __forceinline__ bool mean_of_window(const float* val, float centre, f
 
 // D -> D_copy (negatives -> -10) and the initial D_tmp (-10 there, 0 elsewhere: the reference leaves D_tmp's valid pixels
 // unwritten until the horizontal pass; where that pass never writes, the vertical one reads what malloc returned —
-// zero pages in a fresh process, the value oracle/ref/elas_zero_malloc.h pins the compiled reference to)
+// zero pages in a fresh process, the value the parity tests pin the compiled reference to)
 __global__ void mean_prepare(const float* __restrict__ D, size_t n, float* __restrict__ D_copy, float* __restrict__ D_tmp) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
