@@ -6,6 +6,7 @@
 // committed as fixtures where small) and checks the disparities against the outputs the reference STORES in its tree
 // (Thirdparty/libelas-gpu/GPU_test/2016_12_06_cpu/*_disp.pgm) — the one golden vector the reference holds for this path.
 // TEST INFRASTRUCTURE ONLY: nothing under plvs_amd/ may call into this file.
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 
@@ -46,17 +47,37 @@ struct HookedElas : libelas::Elas {
                         uint8_t* I1_desc, uint8_t* I2_desc, bool right_image, float* D) override {
     static_assert(sizeof(support_pt) == 12 && sizeof(triangle) == 36, "record layouts handed to the hooks");
     if (hooks == nullptr || hooks->compute_disparity == nullptr) {
+      Timed t(this, 4);
       libelas::Elas::computeDisparity(p_support, tri, disparity_grid, grid_dims, I1_desc, I2_desc, right_image, D);
       return;
     }
+    Timed t(this, 4);
     DisparityCall call{this, &p_support, &tri, disparity_grid, grid_dims, I1_desc, I2_desc, right_image};
     hooks->compute_disparity(hooks->user, &call, reinterpret_cast<const int32_t*>(p_support.data()), (int)p_support.size(),
                              tri.data(), (int)tri.size(), disparity_grid, grid_dims, I1_desc, I2_desc, right_image ? 1 : 0, D);
   }
   void adaptiveMean(float* D) override {
+    Timed t(this, 9);
     if (hooks == nullptr || hooks->adaptive_mean == nullptr) libelas::Elas::adaptiveMean(D);
     else hooks->adaptive_mean(hooks->user, this, D);
   }
+  // where Elas::process spends its time: seconds per virtual stage of the last run (ref_elas_stage_seconds)
+  double seconds[12] = {};
+  struct Timed {
+    HookedElas* e;
+    int i;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    Timed(HookedElas* e, int i) : e(e), i(i) {}
+    ~Timed() { e->seconds[i] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+  };
+  std::vector<support_pt> computeSupportMatches(uint8_t* a, uint8_t* b) override { Timed t(this, 0); return libelas::Elas::computeSupportMatches(a, b); }
+  std::vector<triangle> computeDelaunayTriangulation(std::vector<support_pt> p, int32_t r) override { Timed t(this, 1); return libelas::Elas::computeDelaunayTriangulation(p, r); }
+  void computeDisparityPlanes(std::vector<support_pt> p, std::vector<triangle>& tr, int32_t r) override { Timed t(this, 2); libelas::Elas::computeDisparityPlanes(p, tr, r); }
+  void createGrid(std::vector<support_pt> p, int32_t* g, int32_t* gd, bool r) override { Timed t(this, 3); libelas::Elas::createGrid(p, g, gd, r); }
+  void leftRightConsistencyCheck(float* D1, float* D2) override { Timed t(this, 5); libelas::Elas::leftRightConsistencyCheck(D1, D2); }
+  void removeSmallSegments(float* D) override { Timed t(this, 6); libelas::Elas::removeSmallSegments(D); }
+  void gapInterpolation(float* D) override { Timed t(this, 7); libelas::Elas::gapInterpolation(D); }
+  void median(float* D) override { Timed t(this, 8); libelas::Elas::median(D); }
 };
 
 }  // namespace
@@ -89,6 +110,23 @@ void ref_elas_process_hooked(const uint8_t* left, const uint8_t* right, int widt
   HookedElas elas(param, hooks);
   const int32_t dims[3] = {width, height, stride};
   elas.process(const_cast<uint8_t*>(left), const_cast<uint8_t*>(right), D1, D2, dims);
+}
+
+// Where Elas::process spends its time: the pipeline once more, seconds per stage — 0 support matches, 1 triangulation
+// (both images), 2 planes, 3 grid, 4 computeDisparity, 5 left/right check, 6 speckles, 7 gaps, 8 median, 9 adaptiveMean,
+// 10 the whole of process (the remainder is the two Descriptor constructions).
+void ref_elas_stage_seconds(const uint8_t* left, const uint8_t* right, int width, int height, int stride, int plvs,
+                            int subsampling, double* seconds11) {
+  libelas::Elas::Parameters param;
+  param.postprocess_only_left = plvs != 0;
+  param.subsampling = subsampling != 0;
+  HookedElas elas(param, nullptr);
+  std::vector<float> D1((size_t)width * height), D2((size_t)width * height);
+  const int32_t dims[3] = {width, height, stride};
+  const auto t0 = std::chrono::steady_clock::now();
+  elas.process(const_cast<uint8_t*>(left), const_cast<uint8_t*>(right), D1.data(), D2.data(), dims);
+  elas.seconds[10] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  for (int i = 0; i < 11; ++i) seconds11[i] = elas.seconds[i];
 }
 
 // From inside a hook: the reference's own computeDisparity / adaptiveMean on the arguments of that call.
