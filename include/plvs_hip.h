@@ -740,6 +740,12 @@ typedef struct {
   float gamma;           /* 3 */
   float sigma;           /* 1 */
   float sradius;         /* 2 */
+  /* support_candidates only: */
+  int32_t disp_min, disp_max;    /* 0, 255 */
+  int32_t candidate_stepsize;    /* 5 */
+  int32_t support_texture;       /* 10 */
+  int32_t lr_threshold;          /* 2 */
+  float support_threshold;       /* 0.85 (ROBOTICS) */
 } plvs_elas_params;
 int plvs_hip_elas_create(const plvs_elas_params* params, plvs_elas** out);
 int plvs_hip_elas_destroy(plvs_elas* e);
@@ -747,6 +753,15 @@ int plvs_hip_elas_compute_disparity(plvs_elas* e, const int32_t* support, int n_
                                     const int32_t* disparity_grid, const int32_t* grid_dims, const uint8_t* I1_desc,
                                     const uint8_t* I2_desc, int width, int height, int right_image, float* D);
 int plvs_hip_elas_adaptive_mean(plvs_elas* e, float* D, int width, int height);
+/* One step further than ElasGPU: the candidate loop of Elas::computeSupportMatches (elas.cpp:434-456 with
+ * computeMatchingDisparity :296-410) — for every point of the regular grid the disparity of the best forward match that
+ * the backward match confirms, -1 otherwise.  D_can: D_can_width x D_can_height int16 with the counts of elas.cpp:425-428
+ * (ceil(width / step) x ceil(height / step), step = candidate_stepsize, + 1 if odd with subsampling); row 0 and column 0
+ * come back 0 as the reference's calloc leaves them.  The caller goes on with the reference's own
+ * removeInconsistentSupportPoints / removeRedundantSupportPoints / addCornerSupportPoints on this grid.  The descriptor
+ * images stay staged: the compute_disparity calls of the same pair pass NULL. */
+int plvs_hip_elas_support_candidates(plvs_elas* e, const uint8_t* I1_desc, const uint8_t* I2_desc, int width, int height,
+                                     int16_t* D_can);
 
 /* ------------------------------------------------- dense stereo (semi-global matching)
  * Replaces sgm::StereoSGM as PointCloudKeyFrame::ProcessStereoLibsgm uses it

@@ -359,11 +359,16 @@ class ElasGPU {
     bool subsampling;
     int32_t grid_size, match_texture;
     float beta, gamma, sigma, sradius;
-    Parameters() : subsampling(false), grid_size(20), match_texture(1), beta(0.02f), gamma(3), sigma(1), sradius(2) {}
+    int32_t disp_min, disp_max, candidate_stepsize, support_texture, lr_threshold;   // supportCandidates only
+    float support_threshold;
+    Parameters()
+        : subsampling(false), grid_size(20), match_texture(1), beta(0.02f), gamma(3), sigma(1), sradius(2), disp_min(0),
+          disp_max(255), candidate_stepsize(5), support_texture(10), lr_threshold(2), support_threshold(0.85f) {}
   };
   explicit ElasGPU(const Parameters& param = Parameters()) : param(param) {
     plvs_elas_params p{param.subsampling ? 1 : 0, param.grid_size, param.match_texture, param.beta, param.gamma, param.sigma,
-                       param.sradius};
+                       param.sradius, param.disp_min, param.disp_max, param.candidate_stepsize, param.support_texture,
+                       param.lr_threshold, param.support_threshold};
     check(plvs_hip_elas_create(&p, &h_));
   }
   ~ElasGPU() { plvs_hip_elas_destroy(h_); }
@@ -378,21 +383,34 @@ class ElasGPU {
   void computeDisparity(const std::vector<support_pt>& p_support, const std::vector<triangle>& tri, const int32_t* disparity_grid,
                         const int32_t* grid_dims, const uint8_t* I1_desc, const uint8_t* I2_desc, bool right_image, float* D) {
     static_assert(sizeof(support_pt) == 12 && sizeof(triangle) == 36, "record layouts of the C ABI");
-    const bool staged = right_image && I1_desc == staged_1_ && I2_desc == staged_2_ && staged_w_ == width && staged_h_ == height;
+    const bool staged = (right_image || staged_by_support_) && I1_desc == staged_1_ && I2_desc == staged_2_ && staged_w_ == width &&
+                        staged_h_ == height;
     check(plvs_hip_elas_compute_disparity(h_, reinterpret_cast<const int32_t*>(p_support.data()), (int)p_support.size(), tri.data(),
                                           (int)tri.size(), disparity_grid, grid_dims, staged ? nullptr : I1_desc,
                                           staged ? nullptr : I2_desc, width, height, right_image ? 1 : 0, D));
-    staged_1_ = right_image ? nullptr : I1_desc;   // (only a left-image call vouches for the staged pair)
+    staged_by_support_ = staged_by_support_ && !right_image;   // (the pair supportCandidates staged serves its two calls)
+    staged_1_ = right_image ? nullptr : I1_desc;       // (only a left-image call vouches for the staged pair)
     staged_2_ = right_image ? nullptr : I2_desc;
     staged_w_ = width;
     staged_h_ = height;
   }
   void adaptiveMean(float* D) { check(plvs_hip_elas_adaptive_mean(h_, D, width, height)); }
+  // The candidate loop of Elas::computeSupportMatches (elas.cpp:434-456): D_can as that function allocates it
+  // (D_can_width x D_can_height int16); the reference's filters follow on the host.  Stages the descriptor pair.
+  void supportCandidates(const uint8_t* I1_desc, const uint8_t* I2_desc, int16_t* D_can) {
+    check(plvs_hip_elas_support_candidates(h_, I1_desc, I2_desc, width, height, D_can));
+    staged_1_ = I1_desc;
+    staged_2_ = I2_desc;
+    staged_w_ = width;
+    staged_h_ = height;
+    staged_by_support_ = true;
+  }
 
  private:
   plvs_elas* h_ = nullptr;
   const uint8_t *staged_1_ = nullptr, *staged_2_ = nullptr;
   int32_t staged_w_ = 0, staged_h_ = 0;
+  bool staged_by_support_ = false;
 };
 
 // ------------------------------------------------------------------------------------ depth -> cloud

@@ -220,3 +220,75 @@ void oracle_elas_adaptive_mean(float* D, int32_t width, int32_t height, int32_t 
   free(D_copy);
   free(D_tmp);
 }
+
+/* ------------------------------------------------------------------ the candidate grid of Elas::computeSupportMatches
+ * (elas.cpp:416-489, computeMatchingDisparity :296-410): for every point of the regular grid the forward match in the
+ * other image, confirmed by the backward match from there.  What follows in computeSupportMatches —
+ * removeInconsistentSupportPoints, removeRedundantSupportPoints, the conversion to a vector, addCornerSupportPoints —
+ * works on this small grid and stays the reference's host code. */
+typedef struct {
+  int32_t subsampling, candidate_stepsize, disp_min, disp_max, support_texture, lr_threshold;
+  float support_threshold;
+} oracle_elas_support_params;
+
+static int16_t matching_disparity(const oracle_elas_support_params* p, int32_t width, int32_t height, int32_t u, int32_t v,
+                                  const uint8_t* I1_desc, const uint8_t* I2_desc, int right_image) {
+  const int32_t u_step = 2, v_step = 2, window_size = 3;
+  const int32_t off[4] = {-16 * u_step - 16 * width * v_step, +16 * u_step - 16 * width * v_step,
+                          -16 * u_step + 16 * width * v_step, +16 * u_step + 16 * width * v_step};
+  if (!(u >= window_size + u_step && u <= width - window_size - 1 - u_step && v >= window_size + v_step &&
+        v <= height - window_size - 1 - v_step))
+    return -1;
+  const int32_t line_offset = 16 * width * v;
+  const uint8_t* I1_line = (right_image ? I2_desc : I1_desc) + line_offset;
+  const uint8_t* I2_line = (right_image ? I1_desc : I2_desc) + line_offset;
+  const uint8_t* I1_block = I1_line + 16 * u;
+  int32_t sum = 0;
+  for (int i = 0; i < 16; ++i) sum += abs((int32_t)I1_block[i] - 128);
+  if (sum < p->support_texture) return -1;
+  int16_t min_1_E = 32767, min_1_d = -1, min_2_E = 32767, min_2_d = -1;
+  const int32_t disp_min_valid = imax(p->disp_min, 0);
+  const int32_t disp_max_valid = right_image ? imin(p->disp_max, width - u - window_size - u_step)
+                                             : imin(p->disp_max, u - window_size - u_step);
+  if (disp_max_valid - disp_min_valid < 10) return -1;
+  for (int16_t d = (int16_t)disp_min_valid; d <= disp_max_valid; ++d) {
+    const int32_t u_warp = right_image ? u + d : u - d;
+    const uint8_t* I2_block = I2_line + 16 * u_warp;
+    sum = 0;
+    for (int k = 0; k < 4; ++k) sum += sad16(I1_block + off[k], I2_block + off[k]);
+    if (sum < min_1_E) {
+      min_2_E = min_1_E;
+      min_2_d = min_1_d;
+      min_1_E = (int16_t)sum;
+      min_1_d = d;
+    } else if (sum < min_2_E) {
+      min_2_E = (int16_t)sum;
+      min_2_d = d;
+    }
+  }
+  if (min_1_d >= 0 && min_2_d >= 0 && (float)min_1_E < p->support_threshold * (float)min_2_E) return min_1_d;
+  return -1;
+}
+
+/* D_can: D_can_width x D_can_height int16 (the counts of elas.cpp:425-428), zero-initialised by the caller as the
+ * reference's calloc leaves it: row 0 and column 0 are never written. */
+void oracle_elas_support_candidates(const oracle_elas_support_params* p, const uint8_t* I1_desc, const uint8_t* I2_desc,
+                                    int32_t width, int32_t height, int16_t* D_can) {
+  int32_t step = p->candidate_stepsize;
+  if (p->subsampling) step += step % 2;
+  int32_t W = 0, H = 0;
+  for (int32_t u = 0; u < width; u += step) ++W;
+  for (int32_t v = 0; v < height; v += step) ++H;
+  for (int32_t u_can = 1; u_can < W; ++u_can) {
+    const int32_t u = u_can * step;
+    for (int32_t v_can = 1; v_can < H; ++v_can) {
+      const int32_t v = v_can * step;
+      D_can[v_can * W + u_can] = -1;
+      const int16_t d = matching_disparity(p, width, height, u, v, I1_desc, I2_desc, 0);
+      if (d >= 0) {
+        const int16_t d2 = matching_disparity(p, width, height, u - d, v, I1_desc, I2_desc, 1);
+        if (d2 >= 0 && abs(d - d2) <= p->lr_threshold) D_can[v_can * W + u_can] = d;
+      }
+    }
+  }
+}

@@ -25,6 +25,10 @@ struct ref_elas_hooks {
                             int right_image, float* D);
   void (*adaptive_mean)(void* user, void* elas, float* D);
   void* user;
+  // (not one of ElasGPU's: the candidate grid inside Elas::computeSupportMatches, elas.cpp:434-456.  D_can arrives
+  // zeroed, D_can_width x D_can_height; the reference's own filters and the conversion to support points follow.)
+  void (*support_candidates)(void* user, const uint8_t* I1_desc, const uint8_t* I2_desc, int16_t* D_can, int D_can_width,
+                             int D_can_height);
 };
 }
 
@@ -70,7 +74,28 @@ struct HookedElas : libelas::Elas {
     Timed(HookedElas* e, int i) : e(e), i(i) {}
     ~Timed() { e->seconds[i] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
   };
-  std::vector<support_pt> computeSupportMatches(uint8_t* a, uint8_t* b) override { Timed t(this, 0); return libelas::Elas::computeSupportMatches(a, b); }
+  std::vector<support_pt> computeSupportMatches(uint8_t* a, uint8_t* b) override {
+    Timed t(this, 0);
+    if (hooks == nullptr || hooks->support_candidates == nullptr) return libelas::Elas::computeSupportMatches(a, b);
+    // elas.cpp:416-489 around the candidate loop (:434-456), which the hook runs
+    int32_t step = param.candidate_stepsize;
+    if (param.subsampling) step += step % 2;
+    int32_t W = 0, H = 0;
+    for (int32_t u = 0; u < width; u += step) W++;
+    for (int32_t v = 0; v < height; v += step) H++;
+    int16_t* D_can = (int16_t*)calloc(W * H, sizeof(int16_t));
+    hooks->support_candidates(hooks->user, a, b, D_can, W, H);
+    removeInconsistentSupportPoints(D_can, W, H);
+    removeRedundantSupportPoints(D_can, W, H, 5, 1, true);
+    removeRedundantSupportPoints(D_can, W, H, 5, 1, false);
+    std::vector<support_pt> p_support;
+    for (int32_t u_can = 1; u_can < W; u_can++)
+      for (int32_t v_can = 1; v_can < H; v_can++)
+        if (D_can[v_can * W + u_can] >= 0) p_support.push_back(support_pt(u_can * step, v_can * step, D_can[v_can * W + u_can]));
+    if (param.add_corners) addCornerSupportPoints(p_support);
+    free(D_can);
+    return p_support;
+  }
   std::vector<triangle> computeDelaunayTriangulation(std::vector<support_pt> p, int32_t r) override { Timed t(this, 1); return libelas::Elas::computeDelaunayTriangulation(p, r); }
   void computeDisparityPlanes(std::vector<support_pt> p, std::vector<triangle>& tr, int32_t r) override { Timed t(this, 2); libelas::Elas::computeDisparityPlanes(p, tr, r); }
   void createGrid(std::vector<support_pt> p, int32_t* g, int32_t* gd, bool r) override { Timed t(this, 3); libelas::Elas::createGrid(p, g, gd, r); }

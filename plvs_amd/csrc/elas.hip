@@ -156,6 +156,74 @@ __global__ __launch_bounds__(256) void elas_match(MatchParams P, const Triangle*
   D[at] = out;
 }
 
+// ------------------------------------------------------------------ the candidate grid of computeSupportMatches
+// Elas::computeMatchingDisparity (elas.cpp:296-410) for one grid point: the energy of a disparity is the SAD of four
+// descriptors around the point (two columns / two rows away); the best disparity must beat the second smallest energy by
+// the support ratio.  A wave per candidate, a lane per disparity: the sequential "best and second best" of the reference
+// is the lexicographic minimum of (energy, disparity) and the second smallest energy of all — both order-free.
+struct SupportParams {
+  int32_t width, height, step, can_w, can_h;
+  int32_t disp_min, disp_max, support_texture, lr_threshold;
+  float support_threshold;
+};
+
+__device__ __forceinline__ int matching_disparity(const SupportParams& P, int u, int v, const uint4* __restrict__ desc1,
+                                                  const uint4* __restrict__ desc2, bool right_image, int lane) {
+  const int u_step = 2, v_step = 2, window_size = 3;
+  if (!(u >= window_size + u_step && u <= P.width - window_size - 1 - u_step && v >= window_size + v_step &&
+        v <= P.height - window_size - 1 - v_step))
+    return -1;
+  const uint4* I1_line = (right_image ? desc2 : desc1) + (size_t)P.width * v;
+  const uint4* I2_line = (right_image ? desc1 : desc2) + (size_t)P.width * v;
+  const int32_t texture = sad16(I1_line[u], make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u));
+  if (texture < P.support_texture) return -1;
+  const int disp_min_valid = max(P.disp_min, 0);
+  const int disp_max_valid = right_image ? min(P.disp_max, P.width - u - window_size - u_step)
+                                         : min(P.disp_max, u - window_size - u_step);
+  if (disp_max_valid - disp_min_valid < 10) return -1;
+  const ptrdiff_t row = (ptrdiff_t)P.width * v_step;
+  const uint4 b0 = I1_line[u - u_step - row], b1 = I1_line[u + u_step - row], b2 = I1_line[u - u_step + row],
+              b3 = I1_line[u + u_step + row];
+  int32_t e1 = 32767, d1 = 0x7FFFFFFF, e2 = 32767;   // this lane's best (energy, disparity) and second smallest energy
+  for (int d = disp_min_valid + lane; d <= disp_max_valid; d += 64) {
+    const int u_warp = right_image ? u + d : u - d;
+    const int32_t sum = sad16(b0, I2_line[u_warp - u_step - row]) + sad16(b1, I2_line[u_warp + u_step - row]) +
+                        sad16(b2, I2_line[u_warp - u_step + row]) + sad16(b3, I2_line[u_warp + u_step + row]);
+    if (sum < e1) {          // (a lane meets its disparities in ascending order: the reference's own update)
+      e2 = e1;
+      e1 = sum;
+      d1 = d;
+    } else if (sum < e2) {
+      e2 = sum;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int32_t oe1 = __shfl_xor(e1, off), od1 = __shfl_xor(d1, off), oe2 = __shfl_xor(e2, off);
+    const bool other_wins = oe1 < e1 || (oe1 == e1 && od1 < d1);
+    const int32_t loser = other_wins ? e1 : oe1;
+    e2 = min(min(e2, oe2), loser);
+    e1 = other_wins ? oe1 : e1;
+    d1 = other_wins ? od1 : d1;
+  }
+  // (at least eleven disparities were tried: a second best always exists)
+  return ((float)e1 < P.support_threshold * (float)e2) ? d1 : -1;
+}
+
+__global__ __launch_bounds__(64) void elas_support_candidates(SupportParams P, const uint4* __restrict__ desc1,
+                                                              const uint4* __restrict__ desc2, int16_t* __restrict__ D_can) {
+  const int u_can = 1 + (int)blockIdx.x, v_can = 1 + (int)blockIdx.y, lane = threadIdx.x;
+  if (u_can >= P.can_w || v_can >= P.can_h) return;
+  const int u = u_can * P.step, v = v_can * P.step;
+  int out = -1;
+  const int d = matching_disparity(P, u, v, desc1, desc2, false, lane);   // (wave-uniform)
+  if (d >= 0) {
+    const int d2 = matching_disparity(P, u - d, v, desc1, desc2, true, lane);
+    if (d2 >= 0 && abs(d - d2) <= P.lr_threshold) out = d;
+  }
+  if (lane == 0) D_can[(size_t)v_can * P.can_w + u_can] = (int16_t)out;
+}
+
 // ------------------------------------------------------------------ adaptiveMean
 // one output of either pass (elas.cpp:1389-1411, :1467-1503): `val` by register slot; the "absolute value" of the
 // subsampling branch is the reference's and-mask with the FLOAT 2147483648.0f = 0x4F000000 (elas.cpp:1379)
@@ -244,6 +312,7 @@ struct plvs_elas {
   plvs::DevBuf<int32_t> grid, prior;
   plvs::DevBuf<uint32_t> owner;
   plvs::DevBuf<float> D, D_copy, D_tmp;
+  plvs::DevBuf<int16_t> D_can;
   int desc_width = 0, desc_height = 0;   // the staged descriptor images' size (0: none)
 };
 
@@ -268,8 +337,41 @@ int plvs_hip_elas_destroy(plvs_elas* h) {
   if (!h) return PLVS_OK;
   if (h->stream) (void)hipStreamDestroy(h->stream);
   h->desc1.release(); h->desc2.release(); h->support.release(); h->tri.release(); h->grid.release(); h->prior.release();
-  h->owner.release(); h->D.release(); h->D_copy.release(); h->D_tmp.release();
+  h->owner.release(); h->D.release(); h->D_copy.release(); h->D_tmp.release(); h->D_can.release();
   delete h;
+  return PLVS_OK;
+}
+
+int plvs_hip_elas_support_candidates(plvs_elas* h, const uint8_t* I1_desc, const uint8_t* I2_desc, int width, int height,
+                                     int16_t* D_can) {
+  PLVS_REQUIRE(h && I1_desc && I2_desc && D_can, "null argument");
+  PLVS_REQUIRE(width >= 16 && height >= 16, "image size");
+  PLVS_REQUIRE(h->prm.candidate_stepsize > 0 && h->prm.disp_max >= h->prm.disp_min && h->prm.disp_max < 32767, "support parameters");
+  hipStream_t s = h->stream;
+  SupportParams sp;
+  sp.width = width; sp.height = height;
+  sp.step = h->prm.candidate_stepsize + (h->prm.subsampling ? h->prm.candidate_stepsize % 2 : 0);   // elas.cpp:420-422
+  sp.can_w = (width + sp.step - 1) / sp.step;
+  sp.can_h = (height + sp.step - 1) / sp.step;
+  sp.disp_min = h->prm.disp_min; sp.disp_max = h->prm.disp_max; sp.support_texture = h->prm.support_texture;
+  sp.lr_threshold = h->prm.lr_threshold; sp.support_threshold = h->prm.support_threshold;
+  const size_t desc_bytes = (size_t)16 * width * height, ncan = (size_t)sp.can_w * sp.can_h;
+  PLVS_HIP_TRY(h->desc1.reserve(desc_bytes));
+  PLVS_HIP_TRY(h->desc2.reserve(desc_bytes));
+  PLVS_HIP_TRY(h->D_can.reserve(ncan));
+  h->desc_width = h->desc_height = 0;
+  PLVS_HIP_TRY(hipMemcpyAsync(h->desc1.p, I1_desc, desc_bytes, hipMemcpyHostToDevice, s));
+  PLVS_HIP_TRY(hipMemcpyAsync(h->desc2.p, I2_desc, desc_bytes, hipMemcpyHostToDevice, s));
+  PLVS_HIP_TRY(hipMemsetAsync(h->D_can.p, 0, ncan * sizeof(int16_t), s));   // (row 0 / column 0: calloc's zeros, elas.cpp:429)
+  if (sp.can_w > 1 && sp.can_h > 1) {
+    hipLaunchKernelGGL(elas_support_candidates, dim3((unsigned)(sp.can_w - 1), (unsigned)(sp.can_h - 1)), dim3(64), 0, s, sp,
+                       reinterpret_cast<const uint4*>(h->desc1.p), reinterpret_cast<const uint4*>(h->desc2.p), h->D_can.p);
+    PLVS_KERNEL_CHECK();
+  }
+  PLVS_HIP_TRY(hipMemcpyAsync(D_can, h->D_can.p, ncan * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  h->desc_width = width;     // (the pair stays staged for the compute_disparity calls that follow)
+  h->desc_height = height;
   return PLVS_OK;
 }
 

@@ -19,13 +19,16 @@ TRIANGLE = np.dtype([("c1", np.int32), ("c2", np.int32), ("c3", np.int32), ("t1a
 
 class _Params(ctypes.Structure):
     _fields_ = [("subsampling", ctypes.c_int32), ("grid_size", ctypes.c_int32), ("match_texture", ctypes.c_int32),
-                ("beta", _f), ("gamma", _f), ("sigma", _f), ("sradius", _f)]
+                ("beta", _f), ("gamma", _f), ("sigma", _f), ("sradius", _f),
+                ("disp_min", ctypes.c_int32), ("disp_max", ctypes.c_int32), ("candidate_stepsize", ctypes.c_int32),
+                ("support_texture", ctypes.c_int32), ("lr_threshold", ctypes.c_int32), ("support_threshold", _f)]
 
 
 L.plvs_hip_elas_create.argtypes = [ctypes.POINTER(_Params), ctypes.POINTER(_vp)]
 L.plvs_hip_elas_destroy.argtypes = [_vp]
 L.plvs_hip_elas_compute_disparity.argtypes = [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]
 L.plvs_hip_elas_adaptive_mean.argtypes = [_vp, _vp, _i, _i]
+L.plvs_hip_elas_support_candidates.argtypes = [_vp, _vp, _vp, _i, _i, _vp]
 
 
 class ElasGPU:
@@ -33,14 +36,19 @@ class ElasGPU:
         """The fields of Elas::Parameters (elas.h:62-90) the two methods read; defaults: the ROBOTICS setting (:97-121)
         PLVS starts from, `subsampling` as PLVS sets it (PointCloudMapping::skDownsampleStep even)."""
 
-        def __init__(self, subsampling=False, grid_size=20, match_texture=1, beta=0.02, gamma=3.0, sigma=1.0, sradius=2.0):
+        def __init__(self, subsampling=False, grid_size=20, match_texture=1, beta=0.02, gamma=3.0, sigma=1.0, sradius=2.0,
+                     disp_min=0, disp_max=255, candidate_stepsize=5, support_texture=10, lr_threshold=2, support_threshold=0.85):
             self.subsampling, self.grid_size, self.match_texture = bool(subsampling), int(grid_size), int(match_texture)
             self.beta, self.gamma, self.sigma, self.sradius = float(beta), float(gamma), float(sigma), float(sradius)
+            self.disp_min, self.disp_max, self.candidate_stepsize = int(disp_min), int(disp_max), int(candidate_stepsize)
+            self.support_texture, self.lr_threshold = int(support_texture), int(lr_threshold)
+            self.support_threshold = float(support_threshold)
 
     def __init__(self, param=None):
         self.param = param or ElasGPU.Parameters()
-        p = _Params(int(self.param.subsampling), self.param.grid_size, self.param.match_texture, self.param.beta,
-                    self.param.gamma, self.param.sigma, self.param.sradius)
+        q = self.param
+        p = _Params(int(q.subsampling), q.grid_size, q.match_texture, q.beta, q.gamma, q.sigma, q.sradius, q.disp_min, q.disp_max,
+                    q.candidate_stepsize, q.support_texture, q.lr_threshold, q.support_threshold)
         self._h = _vp()
         _lib.check(L.plvs_hip_elas_create(ctypes.byref(p), ctypes.byref(self._h)))
 
@@ -82,6 +90,26 @@ class ElasGPU:
                                                      None if d2 is None else _lib.np_ptr(d2), int(width), int(height),
                                                      int(bool(right_image)), _lib.np_ptr(D)))
         return D
+
+    def candidateGrid(self, width, height):
+        """(D_can_width, D_can_height, step) of Elas::computeSupportMatches (elas.cpp:420-428)."""
+        step = self.param.candidate_stepsize + (self.param.candidate_stepsize % 2 if self.param.subsampling else 0)
+        return -(-width // step), -(-height // step), step
+
+    def supportCandidates(self, I1_desc, I2_desc, width, height):
+        """The candidate loop of Elas::computeSupportMatches (elas.cpp:434-456) -> D_can int16 [D_can_height, D_can_width]:
+        the confirmed disparity of every grid point or -1 (row / column 0: 0).  The reference's filters
+        (removeInconsistentSupportPoints, removeRedundantSupportPoints, addCornerSupportPoints) follow on the host.  The
+        descriptor images stay staged for the computeDisparity calls of the pair (pass None there)."""
+        d1 = np.ascontiguousarray(I1_desc, dtype=np.uint8)
+        d2 = np.ascontiguousarray(I2_desc, dtype=np.uint8)
+        if d1.size != 16 * width * height or d2.size != d1.size:
+            raise ValueError("a descriptor image has 16 * width * height bytes")
+        cw, ch, _ = self.candidateGrid(width, height)
+        D_can = np.empty((ch, cw), np.int16)
+        _lib.check(L.plvs_hip_elas_support_candidates(self._h, _lib.np_ptr(d1), _lib.np_ptr(d2), int(width), int(height),
+                                                      _lib.np_ptr(D_can)))
+        return D_can
 
     def adaptiveMean(self, D, width, height):
         """D (the disparity map of a width x height image; half of it with subsampling) -> the filtered map."""

@@ -21,10 +21,11 @@ assert SUPPORT.itemsize == 12 and TRIANGLE.itemsize == 36
 _DISP = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
 _MEAN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+_CAND = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
 
 
 class _Hooks(ctypes.Structure):
-    _fields_ = [("compute_disparity", _DISP), ("adaptive_mean", _MEAN), ("user", ctypes.c_void_p)]
+    _fields_ = [("compute_disparity", _DISP), ("adaptive_mean", _MEAN), ("user", ctypes.c_void_p), ("support_candidates", _CAND)]
 
 
 def available():
@@ -46,8 +47,9 @@ def _view(ptr, dtype, count):
     return np.frombuffer(buf, dtype=dtype, count=count)
 
 
-def _run(left, right, subsampling, plvs, on_disparity, on_mean):
-    """on_disparity(call: dict, D: float32 view to fill) / on_mean(elas handle, D view); either None = the reference's."""
+def _run(left, right, subsampling, plvs, on_disparity, on_mean, on_candidates=None):
+    """on_disparity(call: dict, D: float32 view to fill) / on_mean(elas handle, D view) / on_candidates(dict, D_can int16 view
+    [H, W], zeroed); any of them None = the reference's own code."""
     lib = _lib()
     h, w = left.shape
     oh, ow = (h // 2, w // 2) if subsampling else (h, w)
@@ -71,7 +73,15 @@ def _run(left, right, subsampling, plvs, on_disparity, on_mean):
         except Exception as e:  # noqa: BLE001
             errors.append(e)
 
-    hooks = _Hooks(_DISP(disp) if on_disparity else _DISP(), _MEAN(mean) if on_mean else _MEAN(), None)
+    def cand(user, i1, i2, D_can, cw, ch):
+        try:
+            on_candidates(dict(I1_desc=_view(i1, np.uint8, 16 * w * h).copy(), I2_desc=_view(i2, np.uint8, 16 * w * h).copy(),
+                               width=w, height=h, subsampling=int(subsampling)), _view(D_can, np.int16, cw * ch).reshape(ch, cw))
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    hooks = _Hooks(_DISP(disp) if on_disparity else _DISP(), _MEAN(mean) if on_mean else _MEAN(), None,
+                   _CAND(cand) if on_candidates else _CAND())
     left, right = np.ascontiguousarray(left), np.ascontiguousarray(right)
     lib.ref_elas_process_hooked(left.ctypes.data, right.ctypes.data, w, h, w, int(plvs), int(subsampling), d1.ctypes.data,
                                 d2.ctypes.data, ctypes.byref(hooks))
@@ -105,13 +115,20 @@ def capture(left, right, subsampling=False, plvs=True):
     return disp_calls, mean_calls, out
 
 
-def run_with(left, right, compute_disparity, adaptive_mean, subsampling=False, plvs=True):
+def run_with(left, right, compute_disparity, adaptive_mean, subsampling=False, plvs=True, support_candidates=None):
     """The reference pipeline with compute_disparity(args) -> D and adaptive_mean(D_in, width, height, subsampling) -> D
-    in ElasGPU's two places."""
+    in ElasGPU's two places (None = the reference's own) and, optionally, support_candidates(args) -> D_can [H, W] int16 as
+    the candidate loop of Elas::computeSupportMatches."""
     def on_disparity(args, D):
         D[:] = compute_disparity({k: v for k, v in args.items() if k not in ("call", "lib")}).reshape(-1)
 
     def on_mean(args, D):
         D[:] = adaptive_mean(D.copy(), args["width"], args["height"], args["subsampling"]).reshape(-1)
 
-    return _run(left, right, subsampling, plvs, on_disparity, on_mean)
+    def on_candidates(args, D_can):
+        got = support_candidates(args)
+        assert got.shape == D_can.shape, (got.shape, D_can.shape)
+        D_can[:] = got
+
+    return _run(left, right, subsampling, plvs, on_disparity if compute_disparity else None, on_mean if adaptive_mean else None,
+                on_candidates if support_candidates else None)

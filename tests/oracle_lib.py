@@ -128,6 +128,32 @@ class Oracle:
           w, h, int(a["right_image"]), _ptr(D))
         return D
 
+    ELAS_SUPPORT_ROBOTICS = dict(candidate_stepsize=5, disp_min=0, disp_max=255, support_texture=10, lr_threshold=2,
+                                 support_threshold=0.85)                                                 # elas.h:97-121
+
+    @staticmethod
+    def elas_candidate_grid(width, height, subsampling, candidate_stepsize=5):
+        step = candidate_stepsize + (candidate_stepsize % 2 if subsampling else 0)        # elas.cpp:420-428
+        return len(range(0, width, step)), len(range(0, height, step)), step
+
+    def elas_support_candidates(self, a, **params):
+        """The candidate loop of Elas::computeSupportMatches -> D_can int16 [D_can_height, D_can_width] (row / column 0: 0)."""
+        prm = dict(self.ELAS_SUPPORT_ROBOTICS, **params)
+
+        class P(ctypes.Structure):
+            _fields_ = [("subsampling", _i), ("candidate_stepsize", _i), ("disp_min", _i), ("disp_max", _i),
+                        ("support_texture", _i), ("lr_threshold", _i), ("support_threshold", _f)]
+        p = P(int(a["subsampling"]), prm["candidate_stepsize"], prm["disp_min"], prm["disp_max"], prm["support_texture"],
+              prm["lr_threshold"], prm["support_threshold"])
+        w, h = a["width"], a["height"]
+        cw, ch, _ = self.elas_candidate_grid(w, h, a["subsampling"], prm["candidate_stepsize"])
+        D_can = np.zeros((ch, cw), np.int16)
+        f = self.lib.oracle_elas_support_candidates
+        f.restype = None
+        f.argtypes = [_vp, _vp, _vp, _i, _i, _vp]
+        f(ctypes.byref(p), _ptr(a["I1_desc"]), _ptr(a["I2_desc"]), w, h, _ptr(D_can))
+        return D_can
+
     def elas_adaptive_mean(self, D, width, height, subsampling):
         D = np.ascontiguousarray(D, np.float32).copy()
         f = self.lib.oracle_elas_adaptive_mean

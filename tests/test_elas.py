@@ -74,6 +74,29 @@ def test_reference_pipeline_with_the_oracle_in_elasgpus_place_equals_the_referen
 
 
 @needs_ref
+@pytest.mark.parametrize("subsampling", [False, True])
+@pytest.mark.parametrize("size", [(1241, 376), (640, 300)])
+def test_reference_pipeline_with_the_oracles_candidate_grid_gives_the_references_support_points(oracle, subsampling, size):
+    """The candidate loop of Elas::computeSupportMatches (elas.cpp:434-456) replaced by the oracle's, the reference's own
+    filters after it: the support points and triangles the pipeline then hands to computeDisparity are the reference's."""
+    left, right = pair(*size)
+    want_calls, _, want = elas_ref.capture(left, right, subsampling=subsampling, plvs=True)
+    got_calls = []
+
+    def record(a):
+        got_calls.append(a)
+        return oracle.elas_compute_disparity(a)
+    got = elas_ref.run_with(left, right, record, oracle.elas_adaptive_mean, subsampling=subsampling, plvs=True,
+                            support_candidates=oracle.elas_support_candidates)
+    assert len(got_calls) == 2
+    for g, w in zip(got_calls, want_calls):
+        assert len(w["support"]) > 100
+        assert np.array_equal(g["support"], w["support"]) and np.array_equal(g["tri"], w["tri"])
+    for g, w in zip(got, want):
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
+
+
+@needs_ref
 def test_adaptive_mean_alone_on_synthetic_maps_equals_the_reference_source(oracle):
     """Ramps, steps of 2 / 4 / 8 / 16 levels (the exponent classes of the subsampling branch's mask), invalid islands,
     borders: Elas::adaptiveMean alone.  (Maps of at least 32 KB: the reference reads its scratch image where it never
@@ -186,3 +209,33 @@ def test_hip_elas_rejects_bad_arguments():
     D = e.computeDisparity(a["support"], a["tri"][:0], a["grid"], a["grid_dims"], a["I1_desc"], a["I2_desc"], 0, a["width"],
                            a["height"])
     assert np.all(D == -10.0)
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("subsampling", [False, True])
+@pytest.mark.parametrize("size", [(1241, 376), (640, 300), (333, 201)])
+def test_hip_candidate_grid_equals_oracle_and_feeds_the_reference_pipeline(oracle, subsampling, size):
+    """Elas::computeSupportMatches' candidate loop on the device: equal to the oracle's grid point by point; and the
+    reference pipeline with that loop, computeDisparity and adaptiveMean all on the device gives the reference's maps."""
+    from plvs_amd.elas import ElasGPU
+    left, right = pair(*size)
+    e = ElasGPU(ElasGPU.Parameters(subsampling=subsampling))
+    grids = []
+
+    def candidates(a):
+        got = e.supportCandidates(a["I1_desc"], a["I2_desc"], a["width"], a["height"])
+        want = oracle.elas_support_candidates(a)
+        assert np.array_equal(got, want), f"{int((got != want).sum())} grid points differ"
+        grids.append(got)
+        return got
+
+    def disparity(a):        # the pair is staged by supportCandidates
+        return e.computeDisparity(a["support"], a["tri"], a["grid"], a["grid_dims"], None, None, a["right_image"], a["width"],
+                                  a["height"])
+    want = elas_ref.reference(left, right, subsampling=subsampling, plvs=True)
+    got = elas_ref.run_with(left, right, disparity, lambda D, w, h, sub: e.adaptiveMean(D, w, h), subsampling=subsampling,
+                            plvs=True, support_candidates=candidates)
+    assert len(grids) == 1 and (grids[0] >= 0).sum() > 50
+    for g, w in zip(got, want):
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
