@@ -368,13 +368,15 @@ class TsdfVoxblox:
     """Thin RAII wrapper of the plvs_hip_tsdf_voxblox_* C ABI."""
 
     def __init__(self, voxel_size, use_carving=False, max_blocks=None, shard_rank=0, shard_count=1,
-                 max_ray_length=None):
+                 max_ray_length=None, max_weight=None):
         p = VoxbloxParams()
         _lib.check(_L.plvs_hip_tsdf_voxblox_default_params(ctypes.c_float(voxel_size), int(use_carving), ctypes.byref(p)))
         if max_blocks is not None:
             p.max_blocks = int(max_blocks)
         if max_ray_length is not None:
             p.max_ray_length = float(max_ray_length)
+        if max_weight is not None:          # TsdfIntegratorBase::Config::max_weight (10000 unless the caller says otherwise)
+            p.max_weight = float(max_weight)
         p.shard_rank, p.shard_count = int(shard_rank), int(shard_count)
         self.params = p
         self._h = _vp()

@@ -115,6 +115,41 @@ def test_hip_matches_oracle_bit_exact(oracle, res, nkf, scale, carving):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("max_weight", [10000.0, 2.5, 0.3])
+def test_hip_long_voxel_runs_weight_ceiling_and_weight_floor_match_oracle(oracle, max_weight):
+    """The fold's eight-lane path (voxel runs of 16 visits and more) and its exceptions: many key frames from one pose
+    in ONE call give every surface voxel a run of dozens to hundreds of visits, some running past the fold's 2048-record
+    chunks; a small max_weight makes updateTsdfVoxel's weight ceiling act inside nearly every trip of eight visits; points
+    two kilometres away (clearing rays of weight 1/z^2 = 2.5e-7) meet its 1e-6 floor on fresh voxels."""
+    import torch
+    from plvs_amd.tsdf import TsdfVoxblox
+    kfs = make_keyframes(2, cam=small_cam(2), seed=29)
+    kfs = [kfs[0]] * 5 + [kfs[1]] * 4                      # the same views again and again: long runs, in order
+    far = kfs[0]["xyz"][::7].copy()
+    far *= (2000.0 / np.maximum(np.abs(far[:, 2:3]), 1e-3))   # the same directions, z = 2 km
+    clouds = [np.concatenate([k["xyz"], far]) if i % 3 == 0 else k["xyz"] for i, k in enumerate(kfs)]
+    cols = [np.concatenate([rgba_of(k), rgba_of(kfs[0])[::7]]) if i % 3 == 0 else rgba_of(k) for i, k in enumerate(kfs)]
+    ora = oracle.voxblox(0.10, carving=True, max_weight=max_weight)
+    for c, col, k in zip(clouds, cols, kfs):
+        ora.integrate(c, col, k["Twc"])
+    dev = TsdfVoxblox(0.10, use_carving=True, max_blocks=8192, max_weight=max_weight)
+    xyz = torch.from_numpy(np.concatenate(clouds)).cuda()
+    rgba = torch.from_numpy(np.concatenate(cols)).cuda()
+    Twc = torch.from_numpy(np.stack([k["Twc"] for k in kfs])).cuda()
+    offsets = np.cumsum([0] + [c.shape[0] for c in clouds]).astype(np.int32)
+    dev.integrate_batch_dev(xyz, rgba, offsets, Twc)
+    torch.cuda.synchronize()
+    st = dev.last_stats()
+    assert st["max_run"] > 2048 // 4 and st["visits"] > 40 * 2048      # runs of hundreds of visits, dozens of chunks
+    assert compare(ora, dev) > 3
+    # and a second call on the populated map (voxels that start from their stored state)
+    ora.integrate(clouds[0], cols[0], kfs[0]["Twc"])
+    dev.integrate(clouds[0], cols[0], kfs[0]["Twc"])
+    compare(ora, dev)
+    dev.close()
+
+
+@pytest.mark.gpu
 def test_hip_batch_shards_and_errors(oracle):
     import torch
     from plvs_amd import _lib
