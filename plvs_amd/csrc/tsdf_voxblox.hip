@@ -332,7 +332,7 @@ __global__ __launch_bounds__(kExpandThreads) void vb_expand(
 //    The groups take the chunk's long runs longest first, each the next one as soon as its own ends.
 // Measured (MI355X, 25 key frames per call, 11.2 M visits): 0.36 -> 0.25-0.27 ms, the call 1.10 -> 0.97 ms.  The
 // kernel is now bound by each chunk's longest run (a workgroup lives as long as it: ≈ 25 us on average, two to three
-// times the 8 trips a group averages) at the three workgroups per CU the 45 KB of LDS allow.  Did not help: four
+// times the 8 trips a group averages) at the four workgroups per CU its 40.8 KB of LDS allow (three at 45 KB: + 5 %).  Did not help: four
 // lanes per run (slower: twice the trips on the critical run), 128- and 64-thread workgroups, a quarter fewer
 // instructions per trip, a lane-path threshold anywhere from 8 to 128.
 #ifndef PLVS_VB_LONG_RUN
@@ -397,13 +397,17 @@ __global__ __launch_bounds__(kChainThreads) void vb_chain_chunks(
   __shared__ float2 s_rec[kChainChunk];
   __shared__ uint32_t s_col[kChainChunk];
   __shared__ uint16_t s_head[kChainChunk + 2];   // positions of the run heads of the chunk, ascending; then the chunk's end
-  __shared__ uint16_t s_short[kChainChunk];      // the short runs (indices into s_head), any order
   __shared__ uint16_t s_long[kMaxLong];          // the long ones
   __shared__ unsigned long long s_mask[kChainChunk / 64];
   __shared__ uint32_t s_pre[kChainChunk / 64];
   // the per-visit operands of a trip, the distance lane's and the colour lanes' apart; + 1: the groups of a wave start
   // in different banks (at a stride of kG * 16 B every group of a quarter-wave would read the same four)
-  __shared__ float4 s_opd[kChainGroups][kG + 1], s_opc[kChainGroups][kG + 1];
+  // (40.8 KB in all: four workgroups per CU.  The short runs' list lies over the distance operands — it is dead before the
+  // long loop's first trip, a barrier between — and the operand rows are unpadded: the bank conflicts of the groups'
+  // broadcast reads cost 1 %, the fourth workgroup gains 5 % of the call.  Chunks of 1536 / 1024 records: slower.)
+  __shared__ float4 s_opd[kChainGroups][kG], s_opc[kChainGroups][kG];
+  static_assert(sizeof(s_opd) >= kChainChunk * sizeof(uint16_t), "the short runs' list lies over the distance operands");
+  uint16_t* const s_short = reinterpret_cast<uint16_t*>(&s_opd[0][0]);   // the short runs (indices into s_head), any order
   __shared__ __attribute__((aligned(16))) float s_uw[kChainGroups][kG];
   __shared__ float4 s_state[kMaxLong];           // a long run's voxel: distance, weight, colour, its index in the pool
   __shared__ uint32_t s_cls[32];
