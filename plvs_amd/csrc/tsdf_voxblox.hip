@@ -400,8 +400,7 @@ __global__ __launch_bounds__(kChainThreads) void vb_chain_chunks(
   __shared__ uint16_t s_long[kMaxLong];          // the long ones
   __shared__ unsigned long long s_mask[kChainChunk / 64];
   __shared__ uint32_t s_pre[kChainChunk / 64];
-  // the per-visit operands of a trip, the distance lane's and the colour lanes' apart; + 1: the groups of a wave start
-  // in different banks (at a stride of kG * 16 B every group of a quarter-wave would read the same four)
+  // the per-visit operands of a trip, the distance lane's and the colour lanes' apart
   // (40.8 KB in all: four workgroups per CU.  The short runs' list lies over the distance operands — it is dead before the
   // long loop's first trip, a barrier between — and the operand rows are unpadded: the bank conflicts of the groups'
   // broadcast reads cost 1 %, the fourth workgroup gains 5 % of the call.  Chunks of 1536 / 1024 records: slower.)
