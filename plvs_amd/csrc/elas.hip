@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void elas_match(MatchParams P, const Triangle*
       const int32_t grid_x = (int32_t)floorf((float)u / (float)P.grid_size);
       const int32_t grid_y = (int32_t)floorf((float)v / (float)P.grid_size);
       const int32_t* cell = grid + (size_t)(grid_y * P.grid_w + grid_x) * (size_t)P.grid_stride;
-      const int32_t num_grid = cell[0];
+      const int32_t num_grid = min(cell[0], P.grid_stride - 1);   // (createGrid never writes more; a corrupt count stays inside the cell)
       int32_t min_val = 10000, min_d = -1;
       const int32_t sign = P.right_image ? 1 : -1;
       for (int32_t k = 0; k < num_grid; ++k) {

@@ -38,6 +38,20 @@ for sub in (False, True):
         for k in ("width", "height", "subsampling"):
             out[f"m{nm}_{k}"] = np.int32(m[k])
         nm += 1
+# the candidate grid of computeSupportMatches for the stored descriptor pair: the reference keeps it in a local variable,
+# so the stored grid is the oracle's — AFTER checking that the reference pipeline fed with it hands computeDisparity the
+# very support points and triangles of the pure reference run (the capture above)
+from tests import oracle_lib  # noqa: E402
+ora = oracle_lib.load()
+grids = []
+seen = []
+elas_ref.run_with(left, right, lambda a: (seen.append(a), ora.elas_compute_disparity(a))[1], ora.elas_adaptive_mean,
+                  subsampling=False, plvs=True,
+                  support_candidates=lambda a: (grids.append(ora.elas_support_candidates(a)), grids[-1])[1])
+ref_calls, _, _ = elas_ref.capture(left, right, subsampling=False, plvs=True)
+assert len(grids) == 1 and all(np.array_equal(g["support"], w["support"]) and np.array_equal(g["tri"], w["tri"])
+                               for g, w in zip(seen, ref_calls))
+out["D_can"] = grids[0]
 out["n_disparity_calls"], out["n_mean_calls"] = np.int32(nd), np.int32(nm)
 path = os.path.join(ROOT, "tests", "golden", "elas_capture.npz")
 np.savez_compressed(path, **out)

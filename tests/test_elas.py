@@ -131,6 +131,8 @@ def test_oracle_reproduces_the_committed_capture_of_the_reference(oracle):
     for m in means:
         got = oracle.elas_adaptive_mean(m["D_in"], m["width"], m["height"], m["subsampling"])
         assert np.array_equal(got.reshape(-1).view(np.uint32), m["D_out"].reshape(-1).view(np.uint32))
+    want = np.load(os.path.join(GOLDEN, "elas_capture.npz"))["D_can"]      # (checked against the reference pipeline when stored)
+    assert np.array_equal(oracle.elas_support_candidates(calls[0]), want) and (want >= 0).sum() > 20
 
 
 # ------------------------------------------------------------------ the HIP path, through the C ABI
@@ -152,6 +154,13 @@ def test_hip_reproduces_the_committed_capture_of_the_reference():
     # the second image of a pair on the descriptors the first call staged
     a = dict(calls[1], I1_desc=None, I2_desc=None)
     assert np.array_equal(_hip_disparity(e)(a).reshape(-1).view(np.uint32), calls[1]["D"].reshape(-1).view(np.uint32))
+    # the candidate grid of computeSupportMatches, and both images on the pair IT staged
+    want = np.load(os.path.join(GOLDEN, "elas_capture.npz"))["D_can"]
+    e2 = ElasGPU()
+    assert np.array_equal(e2.supportCandidates(calls[0]["I1_desc"], calls[0]["I2_desc"], calls[0]["width"], calls[0]["height"]), want)
+    for c in calls:
+        got = _hip_disparity(e2)(dict(c, I1_desc=None, I2_desc=None))
+        assert np.array_equal(got.reshape(-1).view(np.uint32), c["D"].reshape(-1).view(np.uint32))
     for m in means:
         em = ElasGPU(ElasGPU.Parameters(subsampling=bool(m["subsampling"])))
         got = em.adaptiveMean(m["D_in"], m["width"], m["height"])
