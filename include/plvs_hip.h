@@ -744,8 +744,13 @@ typedef struct {
   int32_t disp_min, disp_max;    /* 0, 255 */
   int32_t candidate_stepsize;    /* 5 */
   int32_t support_texture;       /* 10 */
-  int32_t lr_threshold;          /* 2 */
+  int32_t lr_threshold;          /* 2 (also left_right_check) */
   float support_threshold;       /* 0.85 (ROBOTICS) */
+  /* the post-processing entry points only: */
+  float speckle_sim_threshold;   /* 1 */
+  int32_t speckle_size;          /* 200 */
+  int32_t ipol_gap_width;        /* 3 (ROBOTICS), 5000 (MIDDLEBURY) */
+  int32_t add_corners;           /* 0 (ROBOTICS), 1 (MIDDLEBURY) */
 } plvs_elas_params;
 int plvs_hip_elas_create(const plvs_elas_params* params, plvs_elas** out);
 int plvs_hip_elas_destroy(plvs_elas* e);
@@ -762,6 +767,14 @@ int plvs_hip_elas_adaptive_mean(plvs_elas* e, float* D, int width, int height);
  * images stay staged: the compute_disparity calls of the same pair pass NULL. */
 int plvs_hip_elas_support_candidates(plvs_elas* e, const uint8_t* I1_desc, const uint8_t* I2_desc, int width, int height,
                                      int16_t* D_can);
+/* The post-processing between computeDisparity and adaptiveMean, also virtual in Elas: leftRightConsistencyCheck
+ * (elas.cpp:971-1040; both maps in place), removeSmallSegments (:1043-1160), gapInterpolation (:1163-1347).  width x height
+ * is the IMAGE size (the maps are half of it with subsampling).  remove_small_segments expects what the left/right check
+ * leaves — every invalid pixel at -10 — and a similarity threshold below 10: the reference's segments are then the
+ * connected components of a symmetric relation, which is what the device computes. */
+int plvs_hip_elas_left_right_check(plvs_elas* e, float* D1, float* D2, int width, int height);
+int plvs_hip_elas_remove_small_segments(plvs_elas* e, float* D, int width, int height);
+int plvs_hip_elas_gap_interpolation(plvs_elas* e, float* D, int width, int height);
 
 /* ------------------------------------------------- dense stereo (semi-global matching)
  * Replaces sgm::StereoSGM as PointCloudKeyFrame::ProcessStereoLibsgm uses it

@@ -359,16 +359,21 @@ class ElasGPU {
     bool subsampling;
     int32_t grid_size, match_texture;
     float beta, gamma, sigma, sradius;
-    int32_t disp_min, disp_max, candidate_stepsize, support_texture, lr_threshold;   // supportCandidates only
+    int32_t disp_min, disp_max, candidate_stepsize, support_texture, lr_threshold;   // supportCandidates (lr_threshold: the check too)
     float support_threshold;
+    float speckle_sim_threshold;                                                      // the post-processing methods
+    int32_t speckle_size, ipol_gap_width;
+    bool add_corners;
     Parameters()
         : subsampling(false), grid_size(20), match_texture(1), beta(0.02f), gamma(3), sigma(1), sradius(2), disp_min(0),
-          disp_max(255), candidate_stepsize(5), support_texture(10), lr_threshold(2), support_threshold(0.85f) {}
+          disp_max(255), candidate_stepsize(5), support_texture(10), lr_threshold(2), support_threshold(0.85f),
+          speckle_sim_threshold(1), speckle_size(200), ipol_gap_width(3), add_corners(false) {}
   };
   explicit ElasGPU(const Parameters& param = Parameters()) : param(param) {
     plvs_elas_params p{param.subsampling ? 1 : 0, param.grid_size, param.match_texture, param.beta, param.gamma, param.sigma,
                        param.sradius, param.disp_min, param.disp_max, param.candidate_stepsize, param.support_texture,
-                       param.lr_threshold, param.support_threshold};
+                       param.lr_threshold, param.support_threshold, param.speckle_sim_threshold, param.speckle_size,
+                       param.ipol_gap_width, param.add_corners ? 1 : 0};
     check(plvs_hip_elas_create(&p, &h_));
   }
   ~ElasGPU() { plvs_hip_elas_destroy(h_); }
@@ -395,6 +400,10 @@ class ElasGPU {
     staged_h_ = height;
   }
   void adaptiveMean(float* D) { check(plvs_hip_elas_adaptive_mean(h_, D, width, height)); }
+  // the other virtual post-processing methods of Elas (elas.cpp:971-1347), in place
+  void leftRightConsistencyCheck(float* D1, float* D2) { check(plvs_hip_elas_left_right_check(h_, D1, D2, width, height)); }
+  void removeSmallSegments(float* D) { check(plvs_hip_elas_remove_small_segments(h_, D, width, height)); }
+  void gapInterpolation(float* D) { check(plvs_hip_elas_gap_interpolation(h_, D, width, height)); }
   // The candidate loop of Elas::computeSupportMatches (elas.cpp:434-456): D_can as that function allocates it
   // (D_can_width x D_can_height int16); the reference's filters follow on the host.  Stages the descriptor pair.
   void supportCandidates(const uint8_t* I1_desc, const uint8_t* I2_desc, int16_t* D_can) {

@@ -292,3 +292,117 @@ void oracle_elas_support_candidates(const oracle_elas_support_params* p, const u
     }
   }
 }
+
+/* ------------------------------------------------------------------ the post-processing between computeDisparity and
+ * adaptiveMean: Elas::leftRightConsistencyCheck (elas.cpp:971-1040), Elas::removeSmallSegments (:1043-1160),
+ * Elas::gapInterpolation (:1163-1347).  W x H below is the DISPARITY MAP's size (half the image's with subsampling). */
+
+/* both maps against each other; invalid = -10 */
+void oracle_elas_left_right_check(float* D1, float* D2, int32_t W, int32_t H, int32_t subsampling, int32_t lr_threshold) {
+  const size_t n = (size_t)W * H;
+  float* c1 = (float*)malloc(n * sizeof(float));
+  float* c2 = (float*)malloc(n * sizeof(float));
+  memcpy(c1, D1, n * sizeof(float));
+  memcpy(c2, D2, n * sizeof(float));
+  for (int32_t u = 0; u < W; ++u)
+    for (int32_t v = 0; v < H; ++v) {
+      const size_t addr = (size_t)v * W + u;
+      const float d1 = c1[addr], d2 = c2[addr];
+      const float u_warp_1 = subsampling ? (float)u - d1 / 2 : (float)u - d1;
+      const float u_warp_2 = subsampling ? (float)u + d2 / 2 : (float)u + d2;
+      if (d1 >= 0 && u_warp_1 >= 0 && u_warp_1 < W) {
+        if (fabs(c2[(size_t)v * W + (int32_t)u_warp_1] - d1) > lr_threshold) D1[addr] = -10;
+      } else {
+        D1[addr] = -10;
+      }
+      if (d2 >= 0 && u_warp_2 >= 0 && u_warp_2 < W) {
+        if (fabs(c1[(size_t)v * W + (int32_t)u_warp_2] - d2) > lr_threshold) D2[addr] = -10;
+      } else {
+        D2[addr] = -10;
+      }
+    }
+  free(c1);
+  free(c2);
+}
+
+/* segments of 4-connected pixels whose neighbouring disparities differ by at most speckle_sim_threshold, grown in the
+ * reference's order; segments smaller than the speckle size are invalidated.  speckle_size: Parameters::speckle_size
+ * (the reference shrinks it to sqrt(size) * 2 with subsampling, elas.cpp:1051). */
+void oracle_elas_remove_small_segments(float* D, int32_t W, int32_t H, int32_t subsampling, int32_t speckle_size,
+                                       float speckle_sim_threshold) {
+  int32_t D_speckle_size = speckle_size;
+  if (subsampling) D_speckle_size = (int32_t)(sqrtf((float)speckle_size) * 2);
+  const size_t n = (size_t)W * H;
+  int32_t* done = (int32_t*)calloc(n, sizeof(int32_t));
+  int32_t* list_u = (int32_t*)calloc(n, sizeof(int32_t));
+  int32_t* list_v = (int32_t*)calloc(n, sizeof(int32_t));
+  for (int32_t u = 0; u < W; ++u)
+    for (int32_t v = 0; v < H; ++v) {
+      if (done[(size_t)v * W + u] != 0) continue;
+      list_u[0] = u;
+      list_v[0] = v;
+      int32_t count = 1, curr = 0;
+      while (curr < count) {
+        const int32_t uc = list_u[curr], vc = list_v[curr];
+        const size_t addr_curr = (size_t)vc * W + uc;
+        const int32_t nu[4] = {uc - 1, uc + 1, uc, uc}, nv[4] = {vc, vc, vc - 1, vc + 1};
+        for (int i = 0; i < 4; ++i) {
+          if (nu[i] >= 0 && nv[i] >= 0 && nu[i] < W && nv[i] < H) {
+            const size_t addr_n = (size_t)nv[i] * W + nu[i];
+            if (done[addr_n] == 0 && D[addr_n] >= 0 && fabs(D[addr_curr] - D[addr_n]) <= speckle_sim_threshold) {
+              list_u[count] = nu[i];
+              list_v[count] = nv[i];
+              ++count;
+              done[addr_n] = 1;
+            }
+          }
+        }
+        ++curr;
+        done[addr_curr] = 1;
+      }
+      if (count < D_speckle_size)
+        for (int32_t i = 0; i < count; ++i) D[(size_t)list_v[i] * W + list_u[i]] = -10;
+    }
+  free(done);
+  free(list_u);
+  free(list_v);
+}
+
+/* one line of gapInterpolation: D[0], D[stride], ... D[(len-1) * stride] */
+static void gap_line(float* D, int32_t len, size_t stride, int32_t gap_width, int32_t add_corners) {
+  const float discon_threshold = 3.0f;
+  int32_t count = 0;
+  for (int32_t i = 0; i < len; ++i) {
+    if (D[(size_t)i * stride] >= 0) {
+      if (count >= 1 && count <= gap_width) {
+        const int32_t first = i - count, last = i - 1;
+        if (first > 0 && last < len - 1) {
+          const float d1 = D[(size_t)(first - 1) * stride], d2 = D[(size_t)(last + 1) * stride];
+          const float d_ipol = (fabs(d1 - d2) < discon_threshold) ? (d1 + d2) / 2 : (d1 < d2 ? d1 : d2);   /* std::min(d1, d2) */
+          for (int32_t k = first; k <= last; ++k) D[(size_t)k * stride] = d_ipol;
+        }
+      }
+      count = 0;
+    } else {
+      ++count;
+    }
+  }
+  if (add_corners) {
+    for (int32_t i = 0; i < len; ++i)
+      if (D[(size_t)i * stride] >= 0) {
+        for (int32_t k = imax(i - gap_width, 0); k < i; ++k) D[(size_t)k * stride] = D[(size_t)i * stride];
+        break;
+      }
+    for (int32_t i = len - 1; i >= 0; --i)
+      if (D[(size_t)i * stride] >= 0) {
+        for (int32_t k = i; k <= imin(i + gap_width, len - 1); ++k) D[(size_t)k * stride] = D[(size_t)i * stride];
+        break;
+      }
+  }
+}
+
+void oracle_elas_gap_interpolation(float* D, int32_t W, int32_t H, int32_t subsampling, int32_t ipol_gap_width, int32_t add_corners) {
+  const int32_t gap = subsampling ? ipol_gap_width / 2 + 1 : ipol_gap_width;
+  for (int32_t v = 0; v < H; ++v) gap_line(D + (size_t)v * W, W, 1, gap, add_corners);
+  for (int32_t u = 0; u < W; ++u) gap_line(D + u, H, (size_t)W, gap, add_corners);
+}

@@ -29,6 +29,10 @@ struct ref_elas_hooks {
   // zeroed, D_can_width x D_can_height; the reference's own filters and the conversion to support points follow.)
   void (*support_candidates)(void* user, const uint8_t* I1_desc, const uint8_t* I2_desc, int16_t* D_can, int D_can_width,
                              int D_can_height);
+  // (the post-processing between computeDisparity and adaptiveMean, in place of the reference's own methods)
+  void (*left_right_check)(void* user, float* D1, float* D2);
+  void (*remove_small_segments)(void* user, float* D);
+  void (*gap_interpolation)(void* user, float* D);
 };
 }
 
@@ -99,9 +103,21 @@ struct HookedElas : libelas::Elas {
   std::vector<triangle> computeDelaunayTriangulation(std::vector<support_pt> p, int32_t r) override { Timed t(this, 1); return libelas::Elas::computeDelaunayTriangulation(p, r); }
   void computeDisparityPlanes(std::vector<support_pt> p, std::vector<triangle>& tr, int32_t r) override { Timed t(this, 2); libelas::Elas::computeDisparityPlanes(p, tr, r); }
   void createGrid(std::vector<support_pt> p, int32_t* g, int32_t* gd, bool r) override { Timed t(this, 3); libelas::Elas::createGrid(p, g, gd, r); }
-  void leftRightConsistencyCheck(float* D1, float* D2) override { Timed t(this, 5); libelas::Elas::leftRightConsistencyCheck(D1, D2); }
-  void removeSmallSegments(float* D) override { Timed t(this, 6); libelas::Elas::removeSmallSegments(D); }
-  void gapInterpolation(float* D) override { Timed t(this, 7); libelas::Elas::gapInterpolation(D); }
+  void leftRightConsistencyCheck(float* D1, float* D2) override {
+    Timed t(this, 5);
+    if (hooks && hooks->left_right_check) hooks->left_right_check(hooks->user, D1, D2);
+    else libelas::Elas::leftRightConsistencyCheck(D1, D2);
+  }
+  void removeSmallSegments(float* D) override {
+    Timed t(this, 6);
+    if (hooks && hooks->remove_small_segments) hooks->remove_small_segments(hooks->user, D);
+    else libelas::Elas::removeSmallSegments(D);
+  }
+  void gapInterpolation(float* D) override {
+    Timed t(this, 7);
+    if (hooks && hooks->gap_interpolation) hooks->gap_interpolation(hooks->user, D);
+    else libelas::Elas::gapInterpolation(D);
+  }
   void median(float* D) override { Timed t(this, 8); libelas::Elas::median(D); }
 };
 
@@ -129,8 +145,9 @@ void ref_elas_process(const uint8_t* left, const uint8_t* right, int width, int 
 // unwritten borders: elas_zero_malloc.h pins that memory to zero, the content of fresh pages.)
 void ref_elas_process_hooked(const uint8_t* left, const uint8_t* right, int width, int height, int stride, int plvs,
                              int subsampling, float* D1, float* D2, const ref_elas_hooks* hooks) {
-  libelas::Elas::Parameters param;
-  param.postprocess_only_left = plvs != 0;
+  // plvs: bit 0 = postprocess_only_left (PLVS), bit 1 = the MIDDLEBURY parameter set (add_corners, wider gaps, no texture floor)
+  libelas::Elas::Parameters param((plvs & 2) ? libelas::Elas::MIDDLEBURY : libelas::Elas::ROBOTICS);
+  param.postprocess_only_left = (plvs & 1) != 0;
   param.subsampling = subsampling != 0;
   HookedElas elas(param, hooks);
   const int32_t dims[3] = {width, height, stride};

@@ -301,6 +301,127 @@ __global__ __launch_bounds__(256) void mean_pass(const float* __restrict__ src, 
   if (mean_of_window<kTaps>(val, centre, &d)) dst[kVertical ? (size_t)c * W + x : (size_t)y * W + c] = d;
 }
 
+// ------------------------------------------------------------------ the post-processing between computeDisparity and
+// adaptiveMean (elas.cpp:971-1347); W x H is the disparity map's size
+// Elas::leftRightConsistencyCheck: every pixel of either map against the other map at its warped column
+__global__ __launch_bounds__(256) void lr_check(const float* __restrict__ in1, const float* __restrict__ in2, float* __restrict__ out1,
+                                                float* __restrict__ out2, int W, int H, int subsampling, int lr_threshold) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+  if (u >= W || v >= H) return;
+  const size_t addr = (size_t)v * W + u;
+  const float d1 = in1[addr], d2 = in2[addr];
+  const float u_warp_1 = subsampling ? (float)u - d1 / 2 : (float)u - d1;
+  const float u_warp_2 = subsampling ? (float)u + d2 / 2 : (float)u + d2;
+  float o1 = -10.0f, o2 = -10.0f;
+  if (d1 >= 0 && u_warp_1 >= 0 && u_warp_1 < W && !(fabsf(in2[(size_t)v * W + (int32_t)u_warp_1] - d1) > (float)lr_threshold)) o1 = d1;
+  if (d2 >= 0 && u_warp_2 >= 0 && u_warp_2 < W && !(fabsf(in1[(size_t)v * W + (int32_t)u_warp_2] - d2) > (float)lr_threshold)) o2 = d2;
+  out1[addr] = o1;
+  out2[addr] = o2;
+}
+
+// Elas::removeSmallSegments: the reference grows 4-connected segments of valid pixels whose neighbouring disparities differ
+// by at most the similarity threshold and invalidates the small ones.  With every invalid pixel at -10 (as the left/right
+// check leaves them) and a threshold below 10 the segments are the connected components of a symmetric relation: a
+// union-find over the right / lower neighbour pairs gives the same partition whatever the order.
+__device__ __forceinline__ uint32_t seg_find(const uint32_t* parent, uint32_t x) {
+  uint32_t p = parent[x];
+  while (p != x) {
+    x = p;
+    p = parent[x];
+  }
+  return x;
+}
+__device__ __forceinline__ void seg_union(uint32_t* parent, uint32_t a, uint32_t b) {
+  for (;;) {
+    a = seg_find(parent, a);
+    b = seg_find(parent, b);
+    if (a == b) return;
+    if (a < b) { const uint32_t t = a; a = b; b = t; }
+    const uint32_t old = atomicMin(&parent[a], b);   // (a was a root: hang it under the smaller root)
+    if (old == a) return;
+    a = old;                                         // (somebody moved it meanwhile: go on from there)
+  }
+}
+__global__ void seg_init(uint32_t* __restrict__ parent, uint32_t* __restrict__ size, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    parent[i] = (uint32_t)i;
+    size[i] = 0u;
+  }
+}
+__global__ __launch_bounds__(256) void seg_link(const float* __restrict__ D, uint32_t* __restrict__ parent, int W, int H, float sim) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+  if (u >= W || v >= H) return;
+  const size_t at = (size_t)v * W + u;
+  const float d = D[at];
+  if (!(d >= 0)) return;
+  if (u + 1 < W) {
+    const float r = D[at + 1];
+    if (r >= 0 && fabsf(d - r) <= sim) seg_union(parent, (uint32_t)at, (uint32_t)at + 1u);
+  }
+  if (v + 1 < H) {
+    const float b = D[at + W];
+    if (b >= 0 && fabsf(d - b) <= sim) seg_union(parent, (uint32_t)at, (uint32_t)(at + W));
+  }
+}
+__global__ void seg_count(const float* __restrict__ D, uint32_t* __restrict__ parent, uint32_t* __restrict__ size, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !(D[i] >= 0)) return;
+  const uint32_t root = seg_find(parent, (uint32_t)i);
+  parent[i] = root;   // (only shortens this pixel's own path: the roots are final after seg_link)
+  atomicAdd(&size[root], 1u);
+}
+__global__ void seg_apply(float* __restrict__ D, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ size, size_t n,
+                          uint32_t speckle) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t count = (D[i] >= 0) ? size[parent[i]] : 1u;   // (an invalid pixel is a segment of its own)
+  if (count < speckle) D[i] = -10.0f;
+}
+
+// Elas::gapInterpolation: one line (a row, then a column) at a time, exactly as the reference walks it
+__device__ void gap_line(float* D, int len, size_t stride, int gap_width, bool add_corners) {
+  const float discon_threshold = 3.0f;
+  int count = 0;
+  for (int i = 0; i < len; ++i) {
+    if (D[(size_t)i * stride] >= 0) {
+      if (count >= 1 && count <= gap_width) {
+        const int first = i - count, last = i - 1;
+        if (first > 0 && last < len - 1) {
+          const float d1 = D[(size_t)(first - 1) * stride], d2 = D[(size_t)(last + 1) * stride];
+          const float d_ipol = (fabsf(d1 - d2) < discon_threshold) ? (d1 + d2) / 2 : ((d2 < d1) ? d2 : d1);
+          for (int k = first; k <= last; ++k) D[(size_t)k * stride] = d_ipol;
+        }
+      }
+      count = 0;
+    } else {
+      ++count;
+    }
+  }
+  if (add_corners) {
+    for (int i = 0; i < len; ++i)
+      if (D[(size_t)i * stride] >= 0) {
+        const float d = D[(size_t)i * stride];
+        for (int k = max(i - gap_width, 0); k < i; ++k) D[(size_t)k * stride] = d;
+        break;
+      }
+    for (int i = len - 1; i >= 0; --i)
+      if (D[(size_t)i * stride] >= 0) {
+        const float d = D[(size_t)i * stride];
+        for (int k = i; k <= min(i + gap_width, len - 1); ++k) D[(size_t)k * stride] = d;
+        break;
+      }
+  }
+}
+__global__ void gap_rows(float* __restrict__ D, int W, int H, int gap_width, int add_corners) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < H) gap_line(D + (size_t)v * W, W, 1, gap_width, add_corners != 0);
+}
+__global__ void gap_cols(float* __restrict__ D, int W, int H, int gap_width, int add_corners) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < W) gap_line(D + u, H, (size_t)W, gap_width, add_corners != 0);
+}
+
 }  // namespace
 
 struct plvs_elas {
@@ -313,6 +434,7 @@ struct plvs_elas {
   plvs::DevBuf<uint32_t> owner;
   plvs::DevBuf<float> D, D_copy, D_tmp;
   plvs::DevBuf<int16_t> D_can;
+  plvs::DevBuf<uint32_t> seg_parent, seg_size;
   int desc_width = 0, desc_height = 0;   // the staged descriptor images' size (0: none)
 };
 
@@ -337,7 +459,7 @@ int plvs_hip_elas_destroy(plvs_elas* h) {
   if (!h) return PLVS_OK;
   if (h->stream) (void)hipStreamDestroy(h->stream);
   h->desc1.release(); h->desc2.release(); h->support.release(); h->tri.release(); h->grid.release(); h->prior.release();
-  h->owner.release(); h->D.release(); h->D_copy.release(); h->D_tmp.release(); h->D_can.release();
+  h->owner.release(); h->D.release(); h->D_copy.release(); h->D_tmp.release(); h->D_can.release(); h->seg_parent.release(); h->seg_size.release();
   delete h;
   return PLVS_OK;
 }
@@ -466,6 +588,73 @@ int plvs_hip_elas_adaptive_mean(plvs_elas* h, float* D, int width, int height) {
     hipLaunchKernelGGL((mean_pass<8, false>), grid, block, 0, s, h->D_copy.p, h->D_tmp.p, W, H);
     hipLaunchKernelGGL((mean_pass<8, true>), grid, block, 0, s, h->D_tmp.p, h->D.p, W, H);
   }
+  PLVS_KERNEL_CHECK();
+  PLVS_HIP_TRY(hipMemcpyAsync(D, h->D.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  return PLVS_OK;
+}
+
+int plvs_hip_elas_left_right_check(plvs_elas* h, float* D1, float* D2, int width, int height) {
+  PLVS_REQUIRE(h && D1 && D2, "null argument");
+  PLVS_REQUIRE(width >= 2 && height >= 2, "image size");
+  hipStream_t s = h->stream;
+  const bool sub = h->prm.subsampling != 0;
+  const int W = sub ? width / 2 : width, H = sub ? height / 2 : height;
+  const size_t n = (size_t)W * H;
+  PLVS_HIP_TRY(h->D.reserve(n));
+  PLVS_HIP_TRY(h->D_copy.reserve(n));
+  PLVS_HIP_TRY(h->D_tmp.reserve(2 * n));
+  PLVS_HIP_TRY(hipMemcpyAsync(h->D.p, D1, n * sizeof(float), hipMemcpyHostToDevice, s));
+  PLVS_HIP_TRY(hipMemcpyAsync(h->D_copy.p, D2, n * sizeof(float), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(lr_check, dim3(ceil_div((size_t)W, 256), (unsigned)H), dim3(256), 0, s, h->D.p, h->D_copy.p, h->D_tmp.p,
+                     h->D_tmp.p + n, W, H, sub ? 1 : 0, h->prm.lr_threshold);
+  PLVS_KERNEL_CHECK();
+  PLVS_HIP_TRY(hipMemcpyAsync(D1, h->D_tmp.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipMemcpyAsync(D2, h->D_tmp.p + n, n * sizeof(float), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  return PLVS_OK;
+}
+
+int plvs_hip_elas_remove_small_segments(plvs_elas* h, float* D, int width, int height) {
+  PLVS_REQUIRE(h && D, "null argument");
+  PLVS_REQUIRE(width >= 2 && height >= 2, "image size");
+  PLVS_REQUIRE(h->prm.speckle_sim_threshold >= 0.0f && h->prm.speckle_sim_threshold < 10.0f,
+               "speckle_sim_threshold must stay below the distance of the invalid marker (-10) to a valid disparity");
+  hipStream_t s = h->stream;
+  const bool sub = h->prm.subsampling != 0;
+  const int W = sub ? width / 2 : width, H = sub ? height / 2 : height;
+  const size_t n = (size_t)W * H;
+  PLVS_REQUIRE(n < 0xFFFFFFFFull, "image size");
+  int32_t speckle = h->prm.speckle_size;
+  if (sub) speckle = (int32_t)(std::sqrt((float)h->prm.speckle_size) * 2);   // elas.cpp:1051
+  PLVS_HIP_TRY(h->D.reserve(n));
+  PLVS_HIP_TRY(h->seg_parent.reserve(n));
+  PLVS_HIP_TRY(h->seg_size.reserve(n));
+  PLVS_HIP_TRY(hipMemcpyAsync(h->D.p, D, n * sizeof(float), hipMemcpyHostToDevice, s));
+  const dim3 grid2(ceil_div((size_t)W, 256), (unsigned)H), block(256);
+  hipLaunchKernelGGL(seg_init, dim3(ceil_div(n, 256)), block, 0, s, h->seg_parent.p, h->seg_size.p, n);
+  hipLaunchKernelGGL(seg_link, grid2, block, 0, s, h->D.p, h->seg_parent.p, W, H, h->prm.speckle_sim_threshold);
+  hipLaunchKernelGGL(seg_count, dim3(ceil_div(n, 256)), block, 0, s, h->D.p, h->seg_parent.p, h->seg_size.p, n);
+  hipLaunchKernelGGL(seg_apply, dim3(ceil_div(n, 256)), block, 0, s, h->D.p, h->seg_parent.p, h->seg_size.p, n,
+                     (uint32_t)std::max(speckle, 0));
+  PLVS_KERNEL_CHECK();
+  PLVS_HIP_TRY(hipMemcpyAsync(D, h->D.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  return PLVS_OK;
+}
+
+int plvs_hip_elas_gap_interpolation(plvs_elas* h, float* D, int width, int height) {
+  PLVS_REQUIRE(h && D, "null argument");
+  PLVS_REQUIRE(width >= 2 && height >= 2, "image size");
+  hipStream_t s = h->stream;
+  const bool sub = h->prm.subsampling != 0;
+  const int W = sub ? width / 2 : width, H = sub ? height / 2 : height;
+  const size_t n = (size_t)W * H;
+  const int gap = sub ? h->prm.ipol_gap_width / 2 + 1 : h->prm.ipol_gap_width;   // elas.cpp:1172
+  PLVS_HIP_TRY(h->D.reserve(n));
+  PLVS_HIP_TRY(hipMemcpyAsync(h->D.p, D, n * sizeof(float), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(gap_rows, dim3(ceil_div((size_t)H, 64)), dim3(64), 0, s, h->D.p, W, H, gap, h->prm.add_corners);
+  hipLaunchKernelGGL(gap_cols, dim3(ceil_div((size_t)W, 64)), dim3(64), 0, s, h->D.p, W, H, gap, h->prm.add_corners);
   PLVS_KERNEL_CHECK();
   PLVS_HIP_TRY(hipMemcpyAsync(D, h->D.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
   PLVS_HIP_TRY(hipStreamSynchronize(s));

@@ -21,7 +21,9 @@ class _Params(ctypes.Structure):
     _fields_ = [("subsampling", ctypes.c_int32), ("grid_size", ctypes.c_int32), ("match_texture", ctypes.c_int32),
                 ("beta", _f), ("gamma", _f), ("sigma", _f), ("sradius", _f),
                 ("disp_min", ctypes.c_int32), ("disp_max", ctypes.c_int32), ("candidate_stepsize", ctypes.c_int32),
-                ("support_texture", ctypes.c_int32), ("lr_threshold", ctypes.c_int32), ("support_threshold", _f)]
+                ("support_texture", ctypes.c_int32), ("lr_threshold", ctypes.c_int32), ("support_threshold", _f),
+                ("speckle_sim_threshold", _f), ("speckle_size", ctypes.c_int32), ("ipol_gap_width", ctypes.c_int32),
+                ("add_corners", ctypes.c_int32)]
 
 
 L.plvs_hip_elas_create.argtypes = [ctypes.POINTER(_Params), ctypes.POINTER(_vp)]
@@ -29,6 +31,9 @@ L.plvs_hip_elas_destroy.argtypes = [_vp]
 L.plvs_hip_elas_compute_disparity.argtypes = [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]
 L.plvs_hip_elas_adaptive_mean.argtypes = [_vp, _vp, _i, _i]
 L.plvs_hip_elas_support_candidates.argtypes = [_vp, _vp, _vp, _i, _i, _vp]
+L.plvs_hip_elas_left_right_check.argtypes = [_vp, _vp, _vp, _i, _i]
+L.plvs_hip_elas_remove_small_segments.argtypes = [_vp, _vp, _i, _i]
+L.plvs_hip_elas_gap_interpolation.argtypes = [_vp, _vp, _i, _i]
 
 
 class ElasGPU:
@@ -37,18 +42,22 @@ class ElasGPU:
         PLVS starts from, `subsampling` as PLVS sets it (PointCloudMapping::skDownsampleStep even)."""
 
         def __init__(self, subsampling=False, grid_size=20, match_texture=1, beta=0.02, gamma=3.0, sigma=1.0, sradius=2.0,
-                     disp_min=0, disp_max=255, candidate_stepsize=5, support_texture=10, lr_threshold=2, support_threshold=0.85):
+                     disp_min=0, disp_max=255, candidate_stepsize=5, support_texture=10, lr_threshold=2, support_threshold=0.85,
+                     speckle_sim_threshold=1.0, speckle_size=200, ipol_gap_width=3, add_corners=False):
             self.subsampling, self.grid_size, self.match_texture = bool(subsampling), int(grid_size), int(match_texture)
             self.beta, self.gamma, self.sigma, self.sradius = float(beta), float(gamma), float(sigma), float(sradius)
             self.disp_min, self.disp_max, self.candidate_stepsize = int(disp_min), int(disp_max), int(candidate_stepsize)
             self.support_texture, self.lr_threshold = int(support_texture), int(lr_threshold)
             self.support_threshold = float(support_threshold)
+            self.speckle_sim_threshold, self.speckle_size = float(speckle_sim_threshold), int(speckle_size)
+            self.ipol_gap_width, self.add_corners = int(ipol_gap_width), bool(add_corners)
 
     def __init__(self, param=None):
         self.param = param or ElasGPU.Parameters()
         q = self.param
         p = _Params(int(q.subsampling), q.grid_size, q.match_texture, q.beta, q.gamma, q.sigma, q.sradius, q.disp_min, q.disp_max,
-                    q.candidate_stepsize, q.support_texture, q.lr_threshold, q.support_threshold)
+                    q.candidate_stepsize, q.support_texture, q.lr_threshold, q.support_threshold, q.speckle_sim_threshold,
+                    q.speckle_size, q.ipol_gap_width, int(q.add_corners))
         self._h = _vp()
         _lib.check(L.plvs_hip_elas_create(ctypes.byref(p), ctypes.byref(self._h)))
 
@@ -110,6 +119,30 @@ class ElasGPU:
         _lib.check(L.plvs_hip_elas_support_candidates(self._h, _lib.np_ptr(d1), _lib.np_ptr(d2), int(width), int(height),
                                                       _lib.np_ptr(D_can)))
         return D_can
+
+    def _map(self, D, width, height):
+        D = np.ascontiguousarray(D, dtype=np.float32).copy()
+        if D.size != int(np.prod(self._out_shape(width, height))):
+            raise ValueError("D does not have the size of the disparity map")
+        return D.reshape(self._out_shape(width, height))
+
+    def leftRightConsistencyCheck(self, D1, D2, width, height):
+        """Elas::leftRightConsistencyCheck (elas.cpp:971-1040) -> the two checked maps (invalid = -10)."""
+        D1, D2 = self._map(D1, width, height), self._map(D2, width, height)
+        _lib.check(L.plvs_hip_elas_left_right_check(self._h, _lib.np_ptr(D1), _lib.np_ptr(D2), int(width), int(height)))
+        return D1, D2
+
+    def removeSmallSegments(self, D, width, height):
+        """Elas::removeSmallSegments (elas.cpp:1043-1160) on a map whose invalid pixels are -10."""
+        D = self._map(D, width, height)
+        _lib.check(L.plvs_hip_elas_remove_small_segments(self._h, _lib.np_ptr(D), int(width), int(height)))
+        return D
+
+    def gapInterpolation(self, D, width, height):
+        """Elas::gapInterpolation (elas.cpp:1163-1347)."""
+        D = self._map(D, width, height)
+        _lib.check(L.plvs_hip_elas_gap_interpolation(self._h, _lib.np_ptr(D), int(width), int(height)))
+        return D
 
     def adaptiveMean(self, D, width, height):
         """D (the disparity map of a width x height image; half of it with subsampling) -> the filtered map."""

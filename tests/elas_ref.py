@@ -22,10 +22,13 @@ _DISP = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p
                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
 _MEAN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
 _CAND = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
+_LR = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+_MAP = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p)
 
 
 class _Hooks(ctypes.Structure):
-    _fields_ = [("compute_disparity", _DISP), ("adaptive_mean", _MEAN), ("user", ctypes.c_void_p), ("support_candidates", _CAND)]
+    _fields_ = [("compute_disparity", _DISP), ("adaptive_mean", _MEAN), ("user", ctypes.c_void_p), ("support_candidates", _CAND),
+                ("left_right_check", _LR), ("remove_small_segments", _MAP), ("gap_interpolation", _MAP)]
 
 
 def available():
@@ -47,7 +50,7 @@ def _view(ptr, dtype, count):
     return np.frombuffer(buf, dtype=dtype, count=count)
 
 
-def _run(left, right, subsampling, plvs, on_disparity, on_mean, on_candidates=None):
+def _run(left, right, subsampling, plvs, on_disparity, on_mean, on_candidates=None, post=None):
     """on_disparity(call: dict, D: float32 view to fill) / on_mean(elas handle, D view) / on_candidates(dict, D_can int16 view
     [H, W], zeroed); any of them None = the reference's own code."""
     lib = _lib()
@@ -80,8 +83,30 @@ def _run(left, right, subsampling, plvs, on_disparity, on_mean, on_candidates=No
         except Exception as e:  # noqa: BLE001
             errors.append(e)
 
+    # post: dict with any of 'left_right_check'(D1, D2), 'remove_small_segments'(D), 'gap_interpolation'(D): callables that
+    # work IN PLACE on float32 [oh, ow] views
+    post = post or {}
+
+    def guarded(f):
+        def g(*a):
+            try:
+                f(*a)
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+        return g
+
+    def lr(user, D1, D2):
+        guarded(post["left_right_check"])(_view(D1, np.float32, oh * ow).reshape(oh, ow), _view(D2, np.float32, oh * ow).reshape(oh, ow))
+
+    def seg(user, D):
+        guarded(post["remove_small_segments"])(_view(D, np.float32, oh * ow).reshape(oh, ow))
+
+    def gap(user, D):
+        guarded(post["gap_interpolation"])(_view(D, np.float32, oh * ow).reshape(oh, ow))
+
     hooks = _Hooks(_DISP(disp) if on_disparity else _DISP(), _MEAN(mean) if on_mean else _MEAN(), None,
-                   _CAND(cand) if on_candidates else _CAND())
+                   _CAND(cand) if on_candidates else _CAND(), _LR(lr) if "left_right_check" in post else _LR(),
+                   _MAP(seg) if "remove_small_segments" in post else _MAP(), _MAP(gap) if "gap_interpolation" in post else _MAP())
     left, right = np.ascontiguousarray(left), np.ascontiguousarray(right)
     lib.ref_elas_process_hooked(left.ctypes.data, right.ctypes.data, w, h, w, int(plvs), int(subsampling), d1.ctypes.data,
                                 d2.ctypes.data, ctypes.byref(hooks))
@@ -115,7 +140,7 @@ def capture(left, right, subsampling=False, plvs=True):
     return disp_calls, mean_calls, out
 
 
-def run_with(left, right, compute_disparity, adaptive_mean, subsampling=False, plvs=True, support_candidates=None):
+def run_with(left, right, compute_disparity, adaptive_mean, subsampling=False, plvs=True, support_candidates=None, post=None):
     """The reference pipeline with compute_disparity(args) -> D and adaptive_mean(D_in, width, height, subsampling) -> D
     in ElasGPU's two places (None = the reference's own) and, optionally, support_candidates(args) -> D_can [H, W] int16 as
     the candidate loop of Elas::computeSupportMatches."""
@@ -131,4 +156,4 @@ def run_with(left, right, compute_disparity, adaptive_mean, subsampling=False, p
         D_can[:] = got
 
     return _run(left, right, subsampling, plvs, on_disparity if compute_disparity else None, on_mean if adaptive_mean else None,
-                on_candidates if support_candidates else None)
+                on_candidates if support_candidates else None, post)

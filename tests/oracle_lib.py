@@ -154,6 +154,25 @@ class Oracle:
         f(ctypes.byref(p), _ptr(a["I1_desc"]), _ptr(a["I2_desc"]), w, h, _ptr(D_can))
         return D_can
 
+    # (the three below work IN PLACE on float32 [H, W] disparity maps; defaults: the ROBOTICS setting, elas.h:97-121)
+    def elas_left_right_check(self, D1, D2, subsampling, lr_threshold=2):
+        f = self.lib.oracle_elas_left_right_check
+        f.restype = None
+        f.argtypes = [_vp, _vp, _i, _i, _i, _i]
+        f(_ptr(D1), _ptr(D2), D1.shape[1], D1.shape[0], int(subsampling), lr_threshold)
+
+    def elas_remove_small_segments(self, D, subsampling, speckle_size=200, speckle_sim_threshold=1.0):
+        f = self.lib.oracle_elas_remove_small_segments
+        f.restype = None
+        f.argtypes = [_vp, _i, _i, _i, _i, _f]
+        f(_ptr(D), D.shape[1], D.shape[0], int(subsampling), speckle_size, speckle_sim_threshold)
+
+    def elas_gap_interpolation(self, D, subsampling, ipol_gap_width=3, add_corners=False):
+        f = self.lib.oracle_elas_gap_interpolation
+        f.restype = None
+        f.argtypes = [_vp, _i, _i, _i, _i, _i]
+        f(_ptr(D), D.shape[1], D.shape[0], int(subsampling), ipol_gap_width, int(add_corners))
+
     def elas_adaptive_mean(self, D, width, height, subsampling):
         D = np.ascontiguousarray(D, np.float32).copy()
         f = self.lib.oracle_elas_adaptive_mean

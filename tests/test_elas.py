@@ -97,6 +97,42 @@ def test_reference_pipeline_with_the_oracles_candidate_grid_gives_the_references
 
 
 @needs_ref
+@pytest.mark.parametrize("middlebury", [False, True])
+@pytest.mark.parametrize("subsampling", [False, True])
+def test_reference_pipeline_with_the_oracles_post_processing_equals_the_reference(oracle, subsampling, middlebury):
+    """leftRightConsistencyCheck, removeSmallSegments and gapInterpolation replaced by the oracle's, with the ROBOTICS
+    parameters PLVS starts from and with the MIDDLEBURY set (add_corners, gaps of 5000 pixels, speckle similarity 1): the
+    pipeline's maps — and every intermediate map, taken right after each stage — are the reference's."""
+    left, right = pair(900, 376)
+    mode = (2 if middlebury else 0)          # both images post-processed: exercises every method on two maps
+    prm = dict(lr=2, size=200, sim=1.0, gap=5000 if middlebury else 3, corners=middlebury)     # elas.h:97-155
+    stages_ref, stages_got = [], []
+    want = elas_ref._run(left, right, subsampling, mode, None, None, post=None)
+
+    def post(record, use_oracle):
+        def lr(D1, D2):
+            if use_oracle:
+                oracle.elas_left_right_check(D1, D2, subsampling, prm["lr"])
+            record.append(("lr", D1.copy(), D2.copy()))
+
+        def seg(D):
+            if use_oracle:
+                oracle.elas_remove_small_segments(D, subsampling, prm["size"], prm["sim"])
+            record.append(("seg", D.copy()))
+
+        def gap(D):
+            if use_oracle:
+                oracle.elas_gap_interpolation(D, subsampling, prm["gap"], prm["corners"])
+            record.append(("gap", D.copy()))
+        return dict(left_right_check=lr, remove_small_segments=seg, gap_interpolation=gap)
+    got = elas_ref._run(left, right, subsampling, mode, None, None, post=post(stages_got, True))
+    for g, w in zip(got, want):
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
+    assert [s[0] for s in stages_got] == ["lr", "seg", "seg", "gap", "gap"]
+    assert (want[0] >= 0).mean() > 0.3
+
+
+@needs_ref
 def test_adaptive_mean_alone_on_synthetic_maps_equals_the_reference_source(oracle):
     """Ramps, steps of 2 / 4 / 8 / 16 levels (the exponent classes of the subsampling branch's mask), invalid islands,
     borders: Elas::adaptiveMean alone.  (Maps of at least 32 KB: the reference reads its scratch image where it never
@@ -248,3 +284,50 @@ def test_hip_candidate_grid_equals_oracle_and_feeds_the_reference_pipeline(oracl
     assert len(grids) == 1 and (grids[0] >= 0).sum() > 50
     for g, w in zip(got, want):
         assert np.array_equal(g.view(np.uint32), w.view(np.uint32))
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("middlebury", [False, True])
+@pytest.mark.parametrize("subsampling", [False, True])
+def test_reference_pipeline_with_every_device_stage_equals_the_reference(oracle, subsampling, middlebury):
+    """Elas::process with its candidate loop, computeDisparity, leftRightConsistencyCheck, removeSmallSegments,
+    gapInterpolation and adaptiveMean on the device (ROBOTICS parameters as PLVS sets them, and the MIDDLEBURY set with
+    add_corners and gaps of any width); every post-processing stage also against the oracle on the map it was given."""
+    from plvs_amd.elas import ElasGPU
+    left, right = pair()
+    mode = 2 if middlebury else 0
+    prm = dict(lr=2, size=200, sim=1.0, gap=5000 if middlebury else 3, corners=middlebury)
+    P = ElasGPU.Parameters(subsampling=subsampling, ipol_gap_width=prm["gap"], add_corners=prm["corners"],
+                           **(dict(support_threshold=0.95, gamma=5.0, sradius=3.0, match_texture=0) if middlebury else {}))
+    e = ElasGPU(P)
+    h, w = left.shape
+    want = elas_ref._run(left, right, subsampling, mode, None, None)
+
+    def lr(D1, D2):
+        o1, o2 = D1.copy(), D2.copy()
+        oracle.elas_left_right_check(o1, o2, subsampling, prm["lr"])
+        D1[:], D2[:] = e.leftRightConsistencyCheck(D1, D2, w, h)
+        assert np.array_equal(D1.view(np.uint32), o1.view(np.uint32)) and np.array_equal(D2.view(np.uint32), o2.view(np.uint32))
+
+    def seg(D):
+        o = D.copy()
+        oracle.elas_remove_small_segments(o, subsampling, prm["size"], prm["sim"])
+        D[:] = e.removeSmallSegments(D, w, h)
+        assert np.array_equal(D.view(np.uint32), o.view(np.uint32)), f"{int((D != o).sum())} pixels differ"
+
+    def gap(D):
+        o = D.copy()
+        oracle.elas_gap_interpolation(o, subsampling, prm["gap"], prm["corners"])
+        D[:] = e.gapInterpolation(D, w, h)
+        assert np.array_equal(D.view(np.uint32), o.view(np.uint32))
+
+    def disparity(a):
+        return e.computeDisparity(a["support"], a["tri"], a["grid"], a["grid_dims"], None, None, a["right_image"], a["width"],
+                                  a["height"])
+    got = elas_ref.run_with(left, right, disparity, lambda D, ww, hh, sub: e.adaptiveMean(D, ww, hh), subsampling=subsampling,
+                            plvs=mode, support_candidates=lambda a: e.supportCandidates(a["I1_desc"], a["I2_desc"], a["width"], a["height"]),
+                            post=dict(left_right_check=lr, remove_small_segments=seg, gap_interpolation=gap))
+    for g, wv in zip(got, want):
+        assert np.array_equal(g.view(np.uint32), wv.view(np.uint32))
+    assert (want[0] >= 0).mean() > 0.3

@@ -5,8 +5,10 @@ unmodified (oracle/ref/Makefile -> oracle/_ref/libelas_ref.so); this test runs t
 compares with the stored files as main_cpu.cpp wrote them (disparities scaled to 255 / max).  The stored files come from
 another build of the library: validity masks are reproduced exactly, disparities to within one grey level for >= 98.5 %
 of the pixels.  Dev-container test: it reads the inputs where they lie under /root/reference (they are not committed:
-four 1-MB images per pair) and is skipped where the tree or the library is absent.  There is no HIP ELAS yet
-(DESIGN.md §6): nothing on the GPU is checked here."""
+four 1-MB images per pair) and is skipped where the tree or the library is absent.  The stages of libelas that run on
+the device are checked in tests/test_elas.py; nothing on the GPU is checked here.  (The library is built with
+oracle/ref/elas_zero_malloc.h in front of the sources: memory they read without having written it is zero, as in a fresh
+process.)"""
 import ctypes
 import os
 
