@@ -784,21 +784,20 @@ def main():
             _rl.ref_elas_stage_seconds.argtypes = [_ct.c_void_p] * 2 + [_ct.c_int] * 5 + [_ct.c_void_p]
             leg = {}
             for sub in (False, True):
-                dcalls, mcalls, _ = elas_ref.capture(el, er, subsampling=sub, plvs=True)
+                dcalls, mcalls, ref_out = elas_ref.capture(el, er, subsampling=sub, plvs=True)
                 eg = ElasGPU(ElasGPU.Parameters(subsampling=sub))
                 d0 = dcalls[0]       # (the descriptor pair of the run: the same images go to computeSupportMatches)
 
                 def hip_pair():
                     eg.supportCandidates(d0["I1_desc"], d0["I2_desc"], d0["width"], d0["height"])
-                    out = []
-                    for a in dcalls:     # the pair is staged by supportCandidates
-                        out.append(eg.computeDisparity(a["support"], a["tri"], a["grid"], a["grid_dims"], None, None,
-                                                       a["right_image"], a["width"], a["height"]))
-                    out.append(eg.adaptiveMean(mcalls[0]["D_in"], mcalls[0]["width"], mcalls[0]["height"]))
-                    return out
+                    Ds = [eg.computeDisparity(a["support"], a["tri"], a["grid"], a["grid_dims"], None, None, a["right_image"],
+                                              a["width"], a["height"]) for a in dcalls]     # the pair is staged by supportCandidates
+                    D1, D2 = eg.leftRightConsistencyCheck(Ds[0], Ds[1], d0["width"], d0["height"])
+                    D1 = eg.removeSmallSegments(D1, d0["width"], d0["height"])               # PLVS: postprocess_only_left
+                    D1 = eg.gapInterpolation(D1, d0["width"], d0["height"])
+                    return eg.adaptiveMean(D1, d0["width"], d0["height"]), D2
                 got = hip_pair()
-                same = all(np.array_equal(g.reshape(-1).view(np.uint32), w.reshape(-1).view(np.uint32))
-                           for g, w in zip(got, [c["D"] for c in dcalls] + [mcalls[0]["D_out"]]))
+                same = all(np.array_equal(g.reshape(-1).view(np.uint32), w.reshape(-1).view(np.uint32)) for g, w in zip(got, ref_out))
                 t0 = time.perf_counter()
                 for _ in range(10):
                     hip_pair()
@@ -810,18 +809,22 @@ def main():
                     _rl.ref_elas_stage_seconds(el.ctypes.data, er.ctypes.data, el.shape[1], el.shape[0], el.shape[1], 1, int(sub),
                                                st.ctypes.data)
                     best = st if best is None or st[10] < best[10] else best
-                moved = best[0] + best[4] + best[9]
+                moved = best[0] + best[4] + best[5] + best[6] + best[7] + best[9]
                 leg["subsampling" if sub else "full_resolution"] = {
                     "hip_ms_per_pair": round(hip_ms, 3), "cpu_ms_per_pair": round(moved * 1e3, 3),
                     "cpu_support_matches_ms": round(best[0] * 1e3, 3), "cpu_compute_disparity_ms": round(best[4] * 1e3, 3),
+                    "cpu_lr_check_speckles_gaps_ms": round((best[5] + best[6] + best[7]) * 1e3, 3),
                     "cpu_adaptive_mean_ms": round(best[9] * 1e3, 3), "bit_identical": bool(same),
                     "reference_pipeline_ms": round(best[10] * 1e3, 1),
                     "reference_pipeline_rest_ms": round((best[10] - moved) * 1e3, 1)}
-            leg["what"] = ("the candidate loop of Elas::computeSupportMatches + Elas::computeDisparity (left + right image) + "
-                           "Elas::adaptiveMean (left) of the 1241x376 pair: what ElasGPU moves to the device and one stage more; host "
-                           "flavours (descriptor images uploaded once per pair, triangles and grids per call, maps read back); cpu = "
-                           "the same stages inside the reference's compiled Elas::process, 1 thread (support matches include its "
-                           "host filters); reference_pipeline_rest_ms = what stays on the host")
+            leg["what"] = ("the candidate loop of Elas::computeSupportMatches, Elas::computeDisparity (left + right image), "
+                           "leftRightConsistencyCheck, removeSmallSegments, gapInterpolation and adaptiveMean (left map, as PLVS sets "
+                           "postprocess_only_left) of the 1241x376 pair: what ElasGPU moves to the device and four stages more, each "
+                           "through its host-pointer entry point (descriptor images uploaded once per pair, triangles and grids per "
+                           "call, every map read back and uploaded again between stages); bit_identical = the final maps against "
+                           "the reference pipeline's; cpu = the same stages inside the reference's compiled Elas::process, 1 thread "
+                           "(support matches include its host filters); reference_pipeline_rest_ms = what stays on the host: "
+                           "descriptors, support filters, triangulation, planes, grid")
             result["frontend"]["dense_stereo_elas"] = leg
         except Exception as e:
             result["frontend"]["dense_stereo_elas"] = {"skipped": repr(e)}

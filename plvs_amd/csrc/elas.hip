@@ -342,34 +342,66 @@ __device__ __forceinline__ void seg_union(uint32_t* parent, uint32_t a, uint32_t
     a = old;                                         // (somebody moved it meanwhile: go on from there)
   }
 }
-__global__ void seg_init(uint32_t* __restrict__ parent, uint32_t* __restrict__ size, size_t n) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    parent[i] = (uint32_t)i;
-    size[i] = 0u;
+// The horizontal part of the relation needs no atomics: a workgroup per row finds the start of every pixel's run of
+// mutually similar valid neighbours (a max-scan of the break positions) and makes it the pixel's parent.  Only the
+// vertical edges are left for the union-find, and of those only the first of each stretch in which the pair above and
+// the pair below both continue their runs (the others would join the same two runs again).
+__device__ __forceinline__ bool seg_similar(float a, float b, float sim) { return a >= 0 && b >= 0 && fabsf(a - b) <= sim; }
+
+__global__ __launch_bounds__(256) void seg_rows(const float* __restrict__ D, uint32_t* __restrict__ parent, uint32_t* __restrict__ size,
+                                                uint32_t* __restrict__ run_len, int W, float sim) {
+  __shared__ int s_part[256];
+  const int v = blockIdx.x, tid = threadIdx.x;
+  const float* row = D + (size_t)v * W;
+  const int per = (W + 255) / 256, begin = tid * per, end = min(begin + per, W);
+  // the last break (a pixel that does not continue its left neighbour's run) at or before each pixel
+  int last = -1;
+  for (int u = begin; u < end; ++u)
+    if (u == 0 || !seg_similar(row[u - 1], row[u], sim)) last = u;
+  s_part[tid] = last;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {      // inclusive max-scan of the segments' last breaks
+    const int mine = s_part[tid], other = tid >= off ? s_part[tid - off] : -1;
+    __syncthreads();
+    s_part[tid] = max(mine, other);
+    __syncthreads();
+  }
+  int start = tid > 0 ? s_part[tid - 1] : -1;
+  for (int u = begin; u < end; ++u) {
+    if (u == 0 || !seg_similar(row[u - 1], row[u], sim)) start = u;
+    parent[(size_t)v * W + u] = (uint32_t)((size_t)v * W + start);
+    size[(size_t)v * W + u] = 0u;
+    if (row[u] >= 0) atomicAdd(&run_len[(size_t)v * W + start], 1u);   // (run_len arrives zeroed; non-zero at run starts only)
   }
 }
+
 __global__ __launch_bounds__(256) void seg_link(const float* __restrict__ D, uint32_t* __restrict__ parent, int W, int H, float sim) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
-  if (u >= W || v >= H) return;
+  if (u >= W || v + 1 >= H) return;
   const size_t at = (size_t)v * W + u;
-  const float d = D[at];
-  if (!(d >= 0)) return;
-  if (u + 1 < W) {
-    const float r = D[at + 1];
-    if (r >= 0 && fabsf(d - r) <= sim) seg_union(parent, (uint32_t)at, (uint32_t)at + 1u);
+  const float d = D[at], b = D[at + W];
+  if (!seg_similar(d, b, sim)) return;
+  if (u > 0) {   // the pair to the left joins the same two runs: leave it to that one
+    const float dl = D[at - 1], bl = D[at + W - 1];
+    if (seg_similar(dl, bl, sim) && seg_similar(dl, d, sim) && seg_similar(bl, b, sim)) return;
   }
-  if (v + 1 < H) {
-    const float b = D[at + W];
-    if (b >= 0 && fabsf(d - b) <= sim) seg_union(parent, (uint32_t)at, (uint32_t)(at + W));
-  }
+  seg_union(parent, (uint32_t)at, (uint32_t)(at + W));
 }
-__global__ void seg_count(const float* __restrict__ D, uint32_t* __restrict__ parent, uint32_t* __restrict__ size, size_t n) {
+// the unions leave chains as long as a segment is tall (a run's root hangs under the root of a run above it): pointer
+// jumping halves them per round
+__global__ void seg_jump(uint32_t* __restrict__ parent, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !(D[i] >= 0)) return;
+  if (i < n) parent[i] = parent[parent[i]];
+}
+// a segment's size: one addition per RUN onto its root (a pixel each would be hundreds of thousands of atomics on the
+// one word of a large segment: 4 ms)
+__global__ void seg_count(uint32_t* __restrict__ parent, const uint32_t* __restrict__ run_len, uint32_t* __restrict__ size, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
   const uint32_t root = seg_find(parent, (uint32_t)i);
   parent[i] = root;   // (only shortens this pixel's own path: the roots are final after seg_link)
-  atomicAdd(&size[root], 1u);
+  const uint32_t len = run_len[i];
+  if (len) atomicAdd(&size[root], len);
 }
 __global__ void seg_apply(float* __restrict__ D, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ size, size_t n,
                           uint32_t speckle) {
@@ -421,6 +453,32 @@ __global__ void gap_cols(float* __restrict__ D, int W, int H, int gap_width, int
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u < W) gap_line(D + u, H, (size_t)W, gap_width, add_corners != 0);
 }
+// Narrow gaps without add_corners (PLVS's setting: three pixels, two with subsampling): a pixel per thread.  An invalid
+// pixel is filled exactly when valid pixels lie within gap_width steps on both sides of it along the line and the run of
+// invalid pixels between them is no longer than gap_width — the line walk above reaches the same decision and the same
+// two end values.  Out of place (the pass reads validity next to the pixels it fills).
+template <bool kCols>
+__global__ __launch_bounds__(256) void gap_pass(const float* __restrict__ src, float* __restrict__ dst, int W, int H, int gap_width) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+  if (u >= W || v >= H) return;
+  const size_t at = (size_t)v * W + u;
+  const int i = kCols ? v : u, len = kCols ? H : W;
+  const size_t stride = kCols ? (size_t)W : 1;
+  const float* line = src + (kCols ? (size_t)u : (size_t)v * W);
+  float out = src[at];
+  if (!(out >= 0)) {
+    int a = 0, b = 0;   // steps to the nearest valid pixel before / after (0: none within gap_width)
+    for (int k = 1; k <= gap_width && i - k >= 0; ++k)
+      if (line[(size_t)(i - k) * stride] >= 0) { a = k; break; }
+    for (int k = 1; k <= gap_width && i + k < len; ++k)
+      if (line[(size_t)(i + k) * stride] >= 0) { b = k; break; }
+    if (a > 0 && b > 0 && a + b - 1 <= gap_width) {
+      const float d1 = line[(size_t)(i - a) * stride], d2 = line[(size_t)(i + b) * stride];
+      out = (fabsf(d1 - d2) < 3.0f) ? (d1 + d2) / 2 : ((d2 < d1) ? d2 : d1);
+    }
+  }
+  dst[at] = out;
+}
 
 }  // namespace
 
@@ -434,7 +492,7 @@ struct plvs_elas {
   plvs::DevBuf<uint32_t> owner;
   plvs::DevBuf<float> D, D_copy, D_tmp;
   plvs::DevBuf<int16_t> D_can;
-  plvs::DevBuf<uint32_t> seg_parent, seg_size;
+  plvs::DevBuf<uint32_t> seg_parent, seg_size, seg_run;
   int desc_width = 0, desc_height = 0;   // the staged descriptor images' size (0: none)
 };
 
@@ -459,7 +517,7 @@ int plvs_hip_elas_destroy(plvs_elas* h) {
   if (!h) return PLVS_OK;
   if (h->stream) (void)hipStreamDestroy(h->stream);
   h->desc1.release(); h->desc2.release(); h->support.release(); h->tri.release(); h->grid.release(); h->prior.release();
-  h->owner.release(); h->D.release(); h->D_copy.release(); h->D_tmp.release(); h->D_can.release(); h->seg_parent.release(); h->seg_size.release();
+  h->owner.release(); h->D.release(); h->D_copy.release(); h->D_tmp.release(); h->D_can.release(); h->seg_parent.release(); h->seg_size.release(); h->seg_run.release();
   delete h;
   return PLVS_OK;
 }
@@ -630,11 +688,16 @@ int plvs_hip_elas_remove_small_segments(plvs_elas* h, float* D, int width, int h
   PLVS_HIP_TRY(h->D.reserve(n));
   PLVS_HIP_TRY(h->seg_parent.reserve(n));
   PLVS_HIP_TRY(h->seg_size.reserve(n));
+  PLVS_HIP_TRY(h->seg_run.reserve(n));
+  PLVS_HIP_TRY(hipMemsetAsync(h->seg_run.p, 0, n * sizeof(uint32_t), s));
   PLVS_HIP_TRY(hipMemcpyAsync(h->D.p, D, n * sizeof(float), hipMemcpyHostToDevice, s));
   const dim3 grid2(ceil_div((size_t)W, 256), (unsigned)H), block(256);
-  hipLaunchKernelGGL(seg_init, dim3(ceil_div(n, 256)), block, 0, s, h->seg_parent.p, h->seg_size.p, n);
+  hipLaunchKernelGGL(seg_rows, dim3((unsigned)H), block, 0, s, h->D.p, h->seg_parent.p, h->seg_size.p, h->seg_run.p, W,
+                     h->prm.speckle_sim_threshold);
   hipLaunchKernelGGL(seg_link, grid2, block, 0, s, h->D.p, h->seg_parent.p, W, H, h->prm.speckle_sim_threshold);
-  hipLaunchKernelGGL(seg_count, dim3(ceil_div(n, 256)), block, 0, s, h->D.p, h->seg_parent.p, h->seg_size.p, n);
+  for (int span = 1; span < H; span *= 2)
+    hipLaunchKernelGGL(seg_jump, dim3(ceil_div(n, 256)), block, 0, s, h->seg_parent.p, n);
+  hipLaunchKernelGGL(seg_count, dim3(ceil_div(n, 256)), block, 0, s, h->seg_parent.p, h->seg_run.p, h->seg_size.p, n);
   hipLaunchKernelGGL(seg_apply, dim3(ceil_div(n, 256)), block, 0, s, h->D.p, h->seg_parent.p, h->seg_size.p, n,
                      (uint32_t)std::max(speckle, 0));
   PLVS_KERNEL_CHECK();
@@ -653,8 +716,15 @@ int plvs_hip_elas_gap_interpolation(plvs_elas* h, float* D, int width, int heigh
   const int gap = sub ? h->prm.ipol_gap_width / 2 + 1 : h->prm.ipol_gap_width;   // elas.cpp:1172
   PLVS_HIP_TRY(h->D.reserve(n));
   PLVS_HIP_TRY(hipMemcpyAsync(h->D.p, D, n * sizeof(float), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(gap_rows, dim3(ceil_div((size_t)H, 64)), dim3(64), 0, s, h->D.p, W, H, gap, h->prm.add_corners);
-  hipLaunchKernelGGL(gap_cols, dim3(ceil_div((size_t)W, 64)), dim3(64), 0, s, h->D.p, W, H, gap, h->prm.add_corners);
+  if (!h->prm.add_corners && gap <= 64) {
+    PLVS_HIP_TRY(h->D_tmp.reserve(n));
+    const dim3 grid(ceil_div((size_t)W, 256), (unsigned)H), block(256);
+    hipLaunchKernelGGL((gap_pass<false>), grid, block, 0, s, h->D.p, h->D_tmp.p, W, H, gap);
+    hipLaunchKernelGGL((gap_pass<true>), grid, block, 0, s, h->D_tmp.p, h->D.p, W, H, gap);
+  } else {   // (MIDDLEBURY: gaps of any width, the corner fill — the reference's walk, a line per thread)
+    hipLaunchKernelGGL(gap_rows, dim3(ceil_div((size_t)H, 64)), dim3(64), 0, s, h->D.p, W, H, gap, h->prm.add_corners);
+    hipLaunchKernelGGL(gap_cols, dim3(ceil_div((size_t)W, 64)), dim3(64), 0, s, h->D.p, W, H, gap, h->prm.add_corners);
+  }
   PLVS_KERNEL_CHECK();
   PLVS_HIP_TRY(hipMemcpyAsync(D, h->D.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
   PLVS_HIP_TRY(hipStreamSynchronize(s));
