@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kExpandThreads) void vb_expand(
 //    (mul, add, round).  A trip of eight visits takes ≈ 1.3 us; nothing in it waits for global memory (the next
 //    trip's records are fetched before the chains start, the voxels of all long runs are staged in LDS up front).
 //    The groups take the chunk's long runs longest first, each the next one as soon as its own ends.
-// Measured (MI355X, 25 key frames per call, 11.2 M visits): 0.36 -> 0.25-0.27 ms, the call 1.10 -> 0.97 ms.  The
+// Measured (MI355X, 25 key frames per call, 11.2 M visits): 0.36 -> 0.20 ms, the call 1.07 -> 0.92 ms.  The
 // kernel is now bound by each chunk's longest run (a workgroup lives as long as it: ≈ 25 us on average, two to three
 // times the 8 trips a group averages) at the four workgroups per CU its 40.8 KB of LDS allow (three at 45 KB: + 5 %).  Did not help: four
 // lanes per run (slower: twice the trips on the critical run), 128- and 64-thread workgroups, a quarter fewer
