@@ -1,8 +1,12 @@
-// libelas on the device: the two methods the reference's own accelerated build overrides —
+// libelas on the device.  First the two methods the reference's own accelerated build overrides —
 //   ElasGPU::computeDisparity, ElasGPU::adaptiveMean   (Thirdparty/libelas-gpu/GPU/elas_gpu.h:41-45),
-// i.e. Elas::computeDisparity (CPU/elas.cpp:840-968 with findMatch :739-837) and Elas::adaptiveMean (:1349-1572),
-// reached from PointCloudKeyFrame::ProcessStereoLibelas (src/PointCloudKeyFrame.cc:335-432) through
-// libelas::ElasInterface::process.  Everything else of Elas::process stays the caller's host code, as in that build.
+// i.e. Elas::computeDisparity (CPU/elas.cpp:840-968 with findMatch :739-837) and Elas::adaptiveMean (:1349-1572) — then
+// the other virtual stages between the descriptors and the result: the candidate loop of computeSupportMatches (:434-456
+// with computeMatchingDisparity :296-410), leftRightConsistencyCheck (:971-1040), removeSmallSegments (:1043-1160),
+// gapInterpolation (:1163-1347).  All reached from PointCloudKeyFrame::ProcessStereoLibelas (src/PointCloudKeyFrame.cc:335-432)
+// through libelas::ElasInterface::process -> Elas::process (elas.cpp:36-159).  Descriptors, the support filters, the Delaunay
+// triangulation, planes and grid stay the caller's host code.  Every entry point takes the host pointers of the method it
+// replaces and returns results bit-identical to it.
 //
 // computeDisparity rasterises the triangles one after the other and lets later ones overwrite earlier ones on shared
 // pixels; whether a pixel is written at all depends on the pixel alone (its column and texture), the value on the plane
@@ -11,7 +15,7 @@
 // pixel; (2) elas_match — a thread per pixel runs findMatch against its owner's plane: the grid candidates, then the
 // plane's disparity range with the prior, 16-byte descriptor SADs (v_sad_u8).  adaptiveMean's two filter passes have
 // a fixed window per output pixel: a thread per pixel, the window's values summed in the order the reference's
-// four-lane registers impose (slot = pixel index mod 4 / 8).
+// four-lane registers impose (slot = pixel index mod 4 / 8).  The other stages are described at their kernels.
 #include <cmath>
 #include <vector>
 
