@@ -767,6 +767,14 @@ int plvs_hip_elas_adaptive_mean(plvs_elas* e, float* D, int width, int height);
  * images stay staged: the compute_disparity calls of the same pair pass NULL. */
 int plvs_hip_elas_support_candidates(plvs_elas* e, const uint8_t* I1_desc, const uint8_t* I2_desc, int width, int height,
                                      int16_t* D_can);
+/* The descriptor images on the device: libelas::Descriptor (descriptor.cpp:30-131 — filter::sobel3x3 over the zero-padded
+ * buffer of Elas::process, elas.cpp:39-57, and 16 samples per pixel) of both images, `stride` bytes per line.  They stay
+ * staged: support_candidates and compute_disparity then take NULL descriptor pointers.  Elas::process builds its
+ * Descriptor objects itself (no virtual method reaches them), so this serves a caller that drives the stages on its own —
+ * a replacement of ElasInterface::process — and saves the CPU descriptors and the 15 MB upload.
+ * download_descriptors: the staged images (16 * width * height bytes each), for parity checks. */
+int plvs_hip_elas_set_images(plvs_elas* e, const uint8_t* I1, const uint8_t* I2, int width, int height, int stride);
+int plvs_hip_elas_download_descriptors(plvs_elas* e, uint8_t* I1_desc, uint8_t* I2_desc);
 /* The post-processing between computeDisparity and adaptiveMean, also virtual in Elas: leftRightConsistencyCheck
  * (elas.cpp:971-1040; both maps in place), removeSmallSegments (:1043-1160), gapInterpolation (:1163-1347).  width x height
  * is the IMAGE size (the maps are half of it with subsampling).  remove_small_segments expects what the left/right check

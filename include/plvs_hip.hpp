@@ -404,6 +404,14 @@ class ElasGPU {
   void leftRightConsistencyCheck(float* D1, float* D2) { check(plvs_hip_elas_left_right_check(h_, D1, D2, width, height)); }
   void removeSmallSegments(float* D) { check(plvs_hip_elas_remove_small_segments(h_, D, width, height)); }
   void gapInterpolation(float* D) { check(plvs_hip_elas_gap_interpolation(h_, D, width, height)); }
+  // libelas::Descriptor of both images on the device; supportCandidates / computeDisparity then take nullptr descriptors
+  void setImages(const uint8_t* I1, const uint8_t* I2, int32_t stride) {
+    check(plvs_hip_elas_set_images(h_, I1, I2, width, height, stride));
+    staged_1_ = staged_2_ = nullptr;
+    staged_w_ = width;
+    staged_h_ = height;
+    staged_by_support_ = true;
+  }
   // The candidate loop of Elas::computeSupportMatches (elas.cpp:434-456): D_can as that function allocates it
   // (D_can_width x D_can_height int16); the reference's filters follow on the host.  Stages the descriptor pair.
   void supportCandidates(const uint8_t* I1_desc, const uint8_t* I2_desc, int16_t* D_can) {

@@ -406,3 +406,51 @@ void oracle_elas_gap_interpolation(float* D, int32_t W, int32_t H, int32_t subsa
   for (int32_t v = 0; v < H; ++v) gap_line(D + (size_t)v * W, W, 1, gap, add_corners);
   for (int32_t u = 0; u < W; ++u) gap_line(D + u, H, (size_t)W, gap, add_corners);
 }
+
+/* ------------------------------------------------------------------ Descriptor (descriptor.cpp:30-131) on an image as
+ * Elas::process hands it over (elas.cpp:39-57: rows copied into a zeroed buffer whose line length bpl is the width rounded
+ * up to 16): filter::sobel3x3 (filter.cpp:410-418) and the 16 samples per pixel.
+ *
+ * sobel3x3 works on the buffer as ONE flat array: a column pass over whole lines (rows 1 .. h-2), then row filters that
+ * run across the line ends and store at an offset of one — convolve_101_row_3x3_16bit (:229-271) with a scalar tail that
+ * does not saturate, convolve_121_row_3x3_16bit (:178-224) without a tail.  What they never write (first element, the last
+ * few, rows 0 and h-1 of the temporaries) is read as zero, the content of fresh pages (oracle/ref/elas_zero_malloc.h pins
+ * the compiled reference to the same).  desc: 16 * width * height bytes, zero where the reference writes nothing
+ * (a border of three pixels, rows 0-3 and every odd row at half resolution). */
+static uint8_t satu8(int32_t x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+
+void oracle_elas_descriptor(const uint8_t* img, int32_t width, int32_t height, int32_t stride, int32_t half_resolution,
+                            uint8_t* desc) {
+  const int32_t w = width + 15 - (width - 1) % 16, h = height;   /* bpl, elas.cpp:41 */
+  const size_t n = (size_t)w * h;
+  uint8_t* I = (uint8_t*)calloc(n, 1);
+  int16_t* tv = (int16_t*)calloc(n, sizeof(int16_t));
+  int16_t* th = (int16_t*)calloc(n, sizeof(int16_t));
+  uint8_t* du = (uint8_t*)calloc(n, 1);
+  uint8_t* dv = (uint8_t*)calloc(n, 1);
+  for (int32_t v = 0; v < h; ++v) memcpy(I + (size_t)v * w, img + (size_t)v * stride, (size_t)width);
+  /* convolve_cols_3x3 (filter.cpp:374-407): out_v = (1, 2, 1) down the column, out_h = (1, 0, -1) */
+  for (int32_t r = 1; r + 1 < h; ++r)
+    for (int32_t c = 0; c < w; ++c) {
+      const int32_t a = I[(size_t)(r - 1) * w + c], b = I[(size_t)r * w + c], d = I[(size_t)(r + 1) * w + c];
+      tv[(size_t)r * w + c] = (int16_t)(a + 2 * b + d);
+      th[(size_t)r * w + c] = (int16_t)(a - d);
+    }
+  const size_t blocked = (n - 2) / 16 * 16;   /* elements the vector loops of the row filters cover */
+  for (size_t j = 0; j < blocked; ++j) {
+    du[j + 1] = satu8((((int16_t)(tv[j] - tv[j + 2])) >> 2) + 128);
+    dv[j + 1] = satu8((((int16_t)(th[j] + 2 * th[j + 1] + th[j + 2])) >> 2) + 128);
+  }
+  for (size_t j = blocked; j + 2 < n; ++j) du[j + 1] = (uint8_t)(((tv[j] - tv[j + 2]) >> 2) + 128);   /* the scalar tail of the 101 filter */
+  memset(desc, 0, (size_t)16 * width * height);
+  for (int32_t v = half_resolution ? 4 : 3; v < height - 3; v += half_resolution ? 2 : 1)
+    for (int32_t u = 3; u < width - 3; ++u) {
+      uint8_t* o = desc + ((size_t)v * width + u) * 16;
+      const uint8_t *u0 = du + (size_t)(v - 2) * w + u, *u1 = du + (size_t)(v - 1) * w + u, *u2 = du + (size_t)v * w + u,
+                    *u3 = du + (size_t)(v + 1) * w + u, *u4 = du + (size_t)(v + 2) * w + u;
+      const uint8_t *v1 = dv + (size_t)(v - 1) * w + u, *v2 = dv + (size_t)v * w + u, *v3 = dv + (size_t)(v + 1) * w + u;
+      o[0] = u0[0]; o[1] = u1[-2]; o[2] = u1[0]; o[3] = u1[2]; o[4] = u2[-1]; o[5] = u2[0]; o[6] = u2[0]; o[7] = u2[1];
+      o[8] = u3[-2]; o[9] = u3[0]; o[10] = u3[2]; o[11] = u4[0]; o[12] = v1[0]; o[13] = v2[-1]; o[14] = v2[1]; o[15] = v3[0];
+    }
+  free(I); free(tv); free(th); free(du); free(dv);
+}

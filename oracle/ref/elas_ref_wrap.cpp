@@ -11,6 +11,7 @@
 #include <cstring>
 
 #include "elas.h"
+#include "descriptor.h"
 
 // The two methods the reference's own accelerated build overrides (Thirdparty/libelas-gpu/GPU/elas_gpu.h:41-45,
 // class ElasGPU : public Elas): computeDisparity and adaptiveMean.  HookedElas lets a test stand in the same place:
@@ -186,6 +187,20 @@ void ref_elas_adaptive_mean(float* D, int width, int height, int subsampling) {
     Sized(Parameters p, int w, int h) : libelas::Elas(p) { width = w; height = h; }
   } e(param, width, height);
   e.adaptiveMean(D);
+}
+
+// libelas::Descriptor on an image as Elas::process hands it over (elas.cpp:39-57: rows copied into a zeroed buffer of line
+// length bpl): desc = 16 * width * height bytes.
+void ref_elas_descriptor(const uint8_t* img, int width, int height, int stride, int half_resolution, uint8_t* desc) {
+  const int32_t bpl = width + 15 - (width - 1) % 16;
+  uint8_t* I = (uint8_t*)_mm_malloc(bpl * height * sizeof(uint8_t), 16);
+  memset(I, 0, bpl * height * sizeof(uint8_t));
+  for (int32_t v = 0; v < height; v++) memcpy(I + v * bpl, img + v * stride, width * sizeof(uint8_t));
+  {
+    libelas::Descriptor d(I, width, height, bpl, half_resolution != 0);
+    memcpy(desc, d.I_desc, (size_t)16 * width * height);
+  }
+  _mm_free(I);
 }
 
 }  // extern "C"

@@ -160,6 +160,63 @@ __global__ __launch_bounds__(256) void elas_match(MatchParams P, const Triangle*
   D[at] = out;
 }
 
+// ------------------------------------------------------------------ the descriptor images
+// libelas::Descriptor (descriptor.cpp:30-131) on the zero-padded image buffer Elas::process builds (line length bpl = the
+// width rounded up to 16, elas.cpp:41-57).  filter::sobel3x3 (filter.cpp:410-418) treats that buffer as ONE flat array: a
+// (1,2,1) / (1,0,-1) pass down the columns of rows 1 .. h-2 into 16-bit temporaries, then (1,0,-1) / (1,2,1) across the
+// flat array — over the line ends — stored one element further on, saturated to a byte after >> 2 and + 128; the last
+// elements go through the 101 filter's unsaturated scalar tail, the 121 filter has none.  What the reference never writes
+// reads as zero (fresh pages).
+__device__ __forceinline__ int32_t sobel_tv(const uint8_t* __restrict__ I, size_t q, int w, int h) {
+  const size_t r = q / (size_t)w;
+  return (r >= 1 && r + 1 < (size_t)h) ? (int32_t)I[q - w] + 2 * (int32_t)I[q] + (int32_t)I[q + w] : 0;
+}
+__device__ __forceinline__ int32_t sobel_th(const uint8_t* __restrict__ I, size_t q, int w, int h) {
+  const size_t r = q / (size_t)w;
+  return (r >= 1 && r + 1 < (size_t)h) ? (int32_t)I[q - w] - (int32_t)I[q + w] : 0;
+}
+__device__ __forceinline__ uint8_t satu8(int32_t x) { return (uint8_t)min(max(x, 0), 255); }
+
+__global__ __launch_bounds__(256) void elas_sobel(const uint8_t* __restrict__ I, int w, int h, uint8_t* __restrict__ du,
+                                                  uint8_t* __restrict__ dv) {
+  const size_t n = (size_t)w * h, p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const size_t blocked = (n - 2) / 16 * 16;   // the elements the row filters' vector loops cover
+  uint8_t u = 0, v = 0;
+  if (p >= 1) {
+    const size_t j = p - 1;
+    if (j < blocked) {
+      u = satu8(((int32_t)(int16_t)(sobel_tv(I, j, w, h) - sobel_tv(I, j + 2, w, h)) >> 2) + 128);
+      v = satu8(((int32_t)(int16_t)(sobel_th(I, j, w, h) + 2 * sobel_th(I, j + 1, w, h) + sobel_th(I, j + 2, w, h)) >> 2) + 128);
+    } else if (j + 2 < n) {
+      u = (uint8_t)(((sobel_tv(I, j, w, h) - sobel_tv(I, j + 2, w, h)) >> 2) + 128);
+    }
+  }
+  du[p] = u;
+  dv[p] = v;
+}
+
+// the 16 samples of a pixel (descriptor.cpp:75-92 / :112-129): twelve of du on a rhombus, four of dv on a cross
+__global__ __launch_bounds__(256) void elas_describe(const uint8_t* __restrict__ du, const uint8_t* __restrict__ dv, int w, int width,
+                                                     int height, int half_resolution, uint4* __restrict__ desc) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+  if (u >= width || v >= height) return;
+  uint4 out = make_uint4(0u, 0u, 0u, 0u);
+  const bool row_ok = half_resolution ? (v >= 4 && v < height - 3 && (v % 2) == 0) : (v >= 3 && v < height - 3);
+  if (row_ok && u >= 3 && u < width - 3) {
+    const uint8_t *u0 = du + (size_t)(v - 2) * w + u, *u1 = du + (size_t)(v - 1) * w + u, *u2 = du + (size_t)v * w + u,
+                  *u3 = du + (size_t)(v + 1) * w + u, *u4 = du + (size_t)(v + 2) * w + u;
+    const uint8_t *v1 = dv + (size_t)(v - 1) * w + u, *v2 = dv + (size_t)v * w + u, *v3 = dv + (size_t)(v + 1) * w + u;
+#define B4(a, b, c, d) ((uint32_t)(a) | ((uint32_t)(b) << 8) | ((uint32_t)(c) << 16) | ((uint32_t)(d) << 24))
+    out.x = B4(u0[0], u1[-2], u1[0], u1[2]);
+    out.y = B4(u2[-1], u2[0], u2[0], u2[1]);
+    out.z = B4(u3[-2], u3[0], u3[2], u4[0]);
+    out.w = B4(v1[0], v2[-1], v2[1], v3[0]);
+#undef B4
+  }
+  desc[(size_t)v * width + u] = out;
+}
+
 // ------------------------------------------------------------------ the candidate grid of computeSupportMatches
 // Elas::computeMatchingDisparity (elas.cpp:296-410) for one grid point: the energy of a disparity is the SAD of four
 // descriptors around the point (two columns / two rows away); the best disparity must beat the second smallest energy by
@@ -497,6 +554,7 @@ struct plvs_elas {
   plvs::DevBuf<float> D, D_copy, D_tmp;
   plvs::DevBuf<int16_t> D_can;
   plvs::DevBuf<uint32_t> seg_parent, seg_size, seg_run;
+  plvs::DevBuf<uint8_t> img, sob_u, sob_v;
   int desc_width = 0, desc_height = 0;   // the staged descriptor images' size (0: none)
 };
 
@@ -521,15 +579,57 @@ int plvs_hip_elas_destroy(plvs_elas* h) {
   if (!h) return PLVS_OK;
   if (h->stream) (void)hipStreamDestroy(h->stream);
   h->desc1.release(); h->desc2.release(); h->support.release(); h->tri.release(); h->grid.release(); h->prior.release();
-  h->owner.release(); h->D.release(); h->D_copy.release(); h->D_tmp.release(); h->D_can.release(); h->seg_parent.release(); h->seg_size.release(); h->seg_run.release();
+  h->owner.release(); h->D.release(); h->D_copy.release(); h->D_tmp.release(); h->D_can.release(); h->seg_parent.release(); h->seg_size.release(); h->seg_run.release(); h->img.release(); h->sob_u.release(); h->sob_v.release();
   delete h;
+  return PLVS_OK;
+}
+
+int plvs_hip_elas_set_images(plvs_elas* h, const uint8_t* I1, const uint8_t* I2, int width, int height, int stride) {
+  PLVS_REQUIRE(h && I1 && I2, "null argument");
+  PLVS_REQUIRE(width >= 16 && height >= 16 && stride >= width, "image size");
+  hipStream_t s = h->stream;
+  const int bpl = width + 15 - (width - 1) % 16;   // elas.cpp:41
+  const size_t n = (size_t)bpl * height, desc_bytes = (size_t)16 * width * height;
+  PLVS_HIP_TRY(h->img.reserve(n));
+  PLVS_HIP_TRY(h->sob_u.reserve(n));
+  PLVS_HIP_TRY(h->sob_v.reserve(n));
+  PLVS_HIP_TRY(h->desc1.reserve(desc_bytes));
+  PLVS_HIP_TRY(h->desc2.reserve(desc_bytes));
+  h->desc_width = h->desc_height = 0;
+  const uint8_t* images[2] = {I1, I2};
+  uint8_t* descs[2] = {h->desc1.p, h->desc2.p};
+  for (int k = 0; k < 2; ++k) {
+    PLVS_HIP_TRY(hipMemsetAsync(h->img.p, 0, n, s));
+    PLVS_HIP_TRY(hipMemcpy2DAsync(h->img.p, (size_t)bpl, images[k], (size_t)stride, (size_t)width, (size_t)height,
+                                  hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(elas_sobel, dim3(ceil_div(n, 256)), dim3(256), 0, s, h->img.p, bpl, height, h->sob_u.p, h->sob_v.p);
+    hipLaunchKernelGGL(elas_describe, dim3(ceil_div((size_t)width, 256), (unsigned)height), dim3(256), 0, s, h->sob_u.p,
+                       h->sob_v.p, bpl, width, height, h->prm.subsampling ? 1 : 0, reinterpret_cast<uint4*>(descs[k]));
+    PLVS_KERNEL_CHECK();
+  }
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  h->desc_width = width;
+  h->desc_height = height;
+  return PLVS_OK;
+}
+
+int plvs_hip_elas_download_descriptors(plvs_elas* h, uint8_t* I1_desc, uint8_t* I2_desc) {
+  PLVS_REQUIRE(h && I1_desc && I2_desc, "null argument");
+  PLVS_REQUIRE(h->desc_width > 0, "no descriptor images staged");
+  const size_t desc_bytes = (size_t)16 * h->desc_width * h->desc_height;
+  PLVS_HIP_TRY(hipMemcpyAsync(I1_desc, h->desc1.p, desc_bytes, hipMemcpyDeviceToHost, h->stream));
+  PLVS_HIP_TRY(hipMemcpyAsync(I2_desc, h->desc2.p, desc_bytes, hipMemcpyDeviceToHost, h->stream));
+  PLVS_HIP_TRY(hipStreamSynchronize(h->stream));
   return PLVS_OK;
 }
 
 int plvs_hip_elas_support_candidates(plvs_elas* h, const uint8_t* I1_desc, const uint8_t* I2_desc, int width, int height,
                                      int16_t* D_can) {
-  PLVS_REQUIRE(h && I1_desc && I2_desc && D_can, "null argument");
+  PLVS_REQUIRE(h && D_can, "null argument");
   PLVS_REQUIRE(width >= 16 && height >= 16, "image size");
+  PLVS_REQUIRE((I1_desc == nullptr) == (I2_desc == nullptr), "both descriptor images or neither");
+  PLVS_REQUIRE(I1_desc != nullptr || (h->desc_width == width && h->desc_height == height),
+               "no descriptor images staged for this size (plvs_hip_elas_set_images, or pass them)");
   PLVS_REQUIRE(h->prm.candidate_stepsize > 0 && h->prm.disp_max >= h->prm.disp_min && h->prm.disp_max < 32767, "support parameters");
   hipStream_t s = h->stream;
   SupportParams sp;
@@ -540,12 +640,14 @@ int plvs_hip_elas_support_candidates(plvs_elas* h, const uint8_t* I1_desc, const
   sp.disp_min = h->prm.disp_min; sp.disp_max = h->prm.disp_max; sp.support_texture = h->prm.support_texture;
   sp.lr_threshold = h->prm.lr_threshold; sp.support_threshold = h->prm.support_threshold;
   const size_t desc_bytes = (size_t)16 * width * height, ncan = (size_t)sp.can_w * sp.can_h;
-  PLVS_HIP_TRY(h->desc1.reserve(desc_bytes));
-  PLVS_HIP_TRY(h->desc2.reserve(desc_bytes));
   PLVS_HIP_TRY(h->D_can.reserve(ncan));
-  h->desc_width = h->desc_height = 0;
-  PLVS_HIP_TRY(hipMemcpyAsync(h->desc1.p, I1_desc, desc_bytes, hipMemcpyHostToDevice, s));
-  PLVS_HIP_TRY(hipMemcpyAsync(h->desc2.p, I2_desc, desc_bytes, hipMemcpyHostToDevice, s));
+  if (I1_desc != nullptr) {
+    PLVS_HIP_TRY(h->desc1.reserve(desc_bytes));
+    PLVS_HIP_TRY(h->desc2.reserve(desc_bytes));
+    h->desc_width = h->desc_height = 0;
+    PLVS_HIP_TRY(hipMemcpyAsync(h->desc1.p, I1_desc, desc_bytes, hipMemcpyHostToDevice, s));
+    PLVS_HIP_TRY(hipMemcpyAsync(h->desc2.p, I2_desc, desc_bytes, hipMemcpyHostToDevice, s));
+  }
   PLVS_HIP_TRY(hipMemsetAsync(h->D_can.p, 0, ncan * sizeof(int16_t), s));   // (row 0 / column 0: calloc's zeros, elas.cpp:429)
   if (sp.can_w > 1 && sp.can_h > 1) {
     hipLaunchKernelGGL(elas_support_candidates, dim3((unsigned)(sp.can_w - 1), (unsigned)(sp.can_h - 1)), dim3(64), 0, s, sp,

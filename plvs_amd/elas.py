@@ -32,6 +32,8 @@ L.plvs_hip_elas_compute_disparity.argtypes = [_vp, _vp, _i, _vp, _i, _vp, _vp, _
 L.plvs_hip_elas_adaptive_mean.argtypes = [_vp, _vp, _i, _i]
 L.plvs_hip_elas_support_candidates.argtypes = [_vp, _vp, _vp, _i, _i, _vp]
 L.plvs_hip_elas_left_right_check.argtypes = [_vp, _vp, _vp, _i, _i]
+L.plvs_hip_elas_set_images.argtypes = [_vp, _vp, _vp, _i, _i, _i]
+L.plvs_hip_elas_download_descriptors.argtypes = [_vp, _vp, _vp]
 L.plvs_hip_elas_remove_small_segments.argtypes = [_vp, _vp, _i, _i]
 L.plvs_hip_elas_gap_interpolation.argtypes = [_vp, _vp, _i, _i]
 
@@ -100,6 +102,22 @@ class ElasGPU:
                                                      int(bool(right_image)), _lib.np_ptr(D)))
         return D
 
+    def setImages(self, I1, I2):
+        """libelas::Descriptor of both images on the device (descriptor.cpp:30-131); they stay staged: supportCandidates and
+        computeDisparity then take None for the descriptor images."""
+        I1, I2 = np.ascontiguousarray(I1, dtype=np.uint8), np.ascontiguousarray(I2, dtype=np.uint8)
+        if I1.ndim != 2 or I1.shape != I2.shape:
+            raise ValueError("two u8 images of one size")
+        self._img_shape = I1.shape
+        _lib.check(L.plvs_hip_elas_set_images(self._h, _lib.np_ptr(I1), _lib.np_ptr(I2), I1.shape[1], I1.shape[0], I1.shape[1]))
+
+    def descriptors(self):
+        """The staged descriptor images (parity accessor) -> (I1_desc, I2_desc) uint8 [height * width * 16]."""
+        h, w = self._img_shape
+        d1, d2 = np.empty(16 * w * h, np.uint8), np.empty(16 * w * h, np.uint8)
+        _lib.check(L.plvs_hip_elas_download_descriptors(self._h, _lib.np_ptr(d1), _lib.np_ptr(d2)))
+        return d1, d2
+
     def candidateGrid(self, width, height):
         """(D_can_width, D_can_height, step) of Elas::computeSupportMatches (elas.cpp:420-428)."""
         step = self.param.candidate_stepsize + (self.param.candidate_stepsize % 2 if self.param.subsampling else 0)
@@ -110,13 +128,18 @@ class ElasGPU:
         the confirmed disparity of every grid point or -1 (row / column 0: 0).  The reference's filters
         (removeInconsistentSupportPoints, removeRedundantSupportPoints, addCornerSupportPoints) follow on the host.  The
         descriptor images stay staged for the computeDisparity calls of the pair (pass None there)."""
-        d1 = np.ascontiguousarray(I1_desc, dtype=np.uint8)
-        d2 = np.ascontiguousarray(I2_desc, dtype=np.uint8)
-        if d1.size != 16 * width * height or d2.size != d1.size:
-            raise ValueError("a descriptor image has 16 * width * height bytes")
+        d1 = d2 = None
+        if (I1_desc is None) != (I2_desc is None):
+            raise ValueError("both descriptor images or neither (None: the pair setImages staged)")
+        if I1_desc is not None:
+            d1 = np.ascontiguousarray(I1_desc, dtype=np.uint8)
+            d2 = np.ascontiguousarray(I2_desc, dtype=np.uint8)
+            if d1.size != 16 * width * height or d2.size != d1.size:
+                raise ValueError("a descriptor image has 16 * width * height bytes")
         cw, ch, _ = self.candidateGrid(width, height)
         D_can = np.empty((ch, cw), np.int16)
-        _lib.check(L.plvs_hip_elas_support_candidates(self._h, _lib.np_ptr(d1), _lib.np_ptr(d2), int(width), int(height),
+        _lib.check(L.plvs_hip_elas_support_candidates(self._h, None if d1 is None else _lib.np_ptr(d1),
+                                                      None if d2 is None else _lib.np_ptr(d2), int(width), int(height),
                                                       _lib.np_ptr(D_can)))
         return D_can
 

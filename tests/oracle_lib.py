@@ -154,6 +154,17 @@ class Oracle:
         f(ctypes.byref(p), _ptr(a["I1_desc"]), _ptr(a["I2_desc"]), w, h, _ptr(D_can))
         return D_can
 
+    def elas_descriptor(self, img, half_resolution):
+        """libelas::Descriptor of a u8 image -> I_desc uint8 [height * width * 16]."""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        desc = np.zeros(16 * w * h, np.uint8)
+        f = self.lib.oracle_elas_descriptor
+        f.restype = None
+        f.argtypes = [_vp, _i, _i, _i, _i, _vp]
+        f(_ptr(img), w, h, w, int(half_resolution), _ptr(desc))
+        return desc
+
     # (the three below work IN PLACE on float32 [H, W] disparity maps; defaults: the ROBOTICS setting, elas.h:97-121)
     def elas_left_right_check(self, D1, D2, subsampling, lr_threshold=2):
         f = self.lib.oracle_elas_left_right_check

@@ -133,6 +133,29 @@ def test_reference_pipeline_with_the_oracles_post_processing_equals_the_referenc
 
 
 @needs_ref
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("size", [(1241, 376), (640, 300), (333, 201), (64, 48)])
+def test_oracle_descriptor_equals_the_reference_source(oracle, half, size):
+    """libelas::Descriptor (Sobel over the flat buffer + the 16 samples) on both images of the pair: widths that are and are
+    not multiples of 16, full and half resolution; and the descriptors the pipeline itself hands to computeDisparity."""
+    import ctypes
+    lib = ctypes.CDLL(elas_ref.REF)
+    lib.ref_elas_descriptor.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+    for img in pair(*size):
+        h, w = img.shape
+        want = np.zeros(16 * w * h, np.uint8)
+        lib.ref_elas_descriptor(img.ctypes.data, w, h, w, int(half), want.ctypes.data)
+        got = oracle.elas_descriptor(img, half)
+        assert np.array_equal(got, want), f"{int((got != want).sum())} bytes differ"
+        assert len(np.unique(got)) > 50
+    if size == (640, 300):
+        left, right = pair(*size)
+        calls, _, _ = elas_ref.capture(left, right, subsampling=half, plvs=True)
+        assert np.array_equal(oracle.elas_descriptor(left, half), calls[0]["I1_desc"])
+        assert np.array_equal(oracle.elas_descriptor(right, half), calls[0]["I2_desc"])
+
+
+@needs_ref
 def test_adaptive_mean_alone_on_synthetic_maps_equals_the_reference_source(oracle):
     """Ramps, steps of 2 / 4 / 8 / 16 levels (the exponent classes of the subsampling branch's mask), invalid islands,
     borders: Elas::adaptiveMean alone.  (Maps of at least 32 KB: the reference reads its scratch image where it never
@@ -331,3 +354,38 @@ def test_reference_pipeline_with_every_device_stage_equals_the_reference(oracle,
     for g, wv in zip(got, want):
         assert np.array_equal(g.view(np.uint32), wv.view(np.uint32))
     assert (want[0] >= 0).mean() > 0.3
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("subsampling", [False, True])
+@pytest.mark.parametrize("size", [(1241, 376), (640, 300), (333, 201)])
+def test_hip_descriptors_from_the_images_and_the_whole_chain_on_them(oracle, subsampling, size):
+    """libelas::Descriptor on the device from the two images: the staged descriptor images equal the oracle's (= the
+    reference's) byte for byte; and the reference pipeline run with every device stage reading THOSE (the host descriptors
+    the pipeline passes are ignored) gives the reference's maps."""
+    from plvs_amd.elas import ElasGPU
+    left, right = pair(*size)
+    h, w = left.shape
+    e = ElasGPU(ElasGPU.Parameters(subsampling=subsampling))
+    e.setImages(left, right)
+    d1, d2 = e.descriptors()
+    assert np.array_equal(d1, oracle.elas_descriptor(left, subsampling)) and np.array_equal(d2, oracle.elas_descriptor(right, subsampling))
+    want = elas_ref.reference(left, right, subsampling=subsampling, plvs=True)
+
+    def disparity(a):
+        return e.computeDisparity(a["support"], a["tri"], a["grid"], a["grid_dims"], None, None, a["right_image"], w, h)
+
+    def lr(D1, D2):
+        D1[:], D2[:] = e.leftRightConsistencyCheck(D1, D2, w, h)
+
+    def seg(D):
+        D[:] = e.removeSmallSegments(D, w, h)
+
+    def gap(D):
+        D[:] = e.gapInterpolation(D, w, h)
+    got = elas_ref.run_with(left, right, disparity, lambda D, ww, hh, sub: e.adaptiveMean(D, ww, hh), subsampling=subsampling, plvs=True,
+                            support_candidates=lambda a: e.supportCandidates(None, None, w, h),
+                            post=dict(left_right_check=lr, remove_small_segments=seg, gap_interpolation=gap))
+    for g, wv in zip(got, want):
+        assert np.array_equal(g.view(np.uint32), wv.view(np.uint32))
