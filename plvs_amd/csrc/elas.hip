@@ -167,29 +167,34 @@ __global__ __launch_bounds__(256) void elas_match(MatchParams P, const Triangle*
 // flat array — over the line ends — stored one element further on, saturated to a byte after >> 2 and + 128; the last
 // elements go through the 101 filter's unsaturated scalar tail, the 121 filter has none.  What the reference never writes
 // reads as zero (fresh pages).
-__device__ __forceinline__ int32_t sobel_tv(const uint8_t* __restrict__ I, size_t q, int w, int h) {
-  const size_t r = q / (size_t)w;
-  return (r >= 1 && r + 1 < (size_t)h) ? (int32_t)I[q - w] + 2 * (int32_t)I[q] + (int32_t)I[q + w] : 0;
+// (the padded buffer is not materialised: the image is read as the caller laid it out, columns beyond the width are 0)
+struct PaddedImage {
+  const uint8_t* raw;
+  int width, stride, w, h;   // w = bpl
+  __device__ __forceinline__ int32_t at(int r, int c) const { return c < width ? (int32_t)raw[(size_t)r * stride + c] : 0; }
+};
+__device__ __forceinline__ int32_t sobel_tv(const PaddedImage& I, uint32_t q) {
+  const int r = (int)(q / (uint32_t)I.w), c = (int)(q - (uint32_t)r * (uint32_t)I.w);
+  return (r >= 1 && r + 1 < I.h) ? I.at(r - 1, c) + 2 * I.at(r, c) + I.at(r + 1, c) : 0;
 }
-__device__ __forceinline__ int32_t sobel_th(const uint8_t* __restrict__ I, size_t q, int w, int h) {
-  const size_t r = q / (size_t)w;
-  return (r >= 1 && r + 1 < (size_t)h) ? (int32_t)I[q - w] - (int32_t)I[q + w] : 0;
+__device__ __forceinline__ int32_t sobel_th(const PaddedImage& I, uint32_t q) {
+  const int r = (int)(q / (uint32_t)I.w), c = (int)(q - (uint32_t)r * (uint32_t)I.w);
+  return (r >= 1 && r + 1 < I.h) ? I.at(r - 1, c) - I.at(r + 1, c) : 0;
 }
 __device__ __forceinline__ uint8_t satu8(int32_t x) { return (uint8_t)min(max(x, 0), 255); }
 
-__global__ __launch_bounds__(256) void elas_sobel(const uint8_t* __restrict__ I, int w, int h, uint8_t* __restrict__ du,
-                                                  uint8_t* __restrict__ dv) {
-  const size_t n = (size_t)w * h, p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void elas_sobel(PaddedImage I, uint8_t* __restrict__ du, uint8_t* __restrict__ dv) {
+  const uint32_t n = (uint32_t)I.w * (uint32_t)I.h, p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
-  const size_t blocked = (n - 2) / 16 * 16;   // the elements the row filters' vector loops cover
+  const uint32_t blocked = (n - 2u) / 16u * 16u;   // the elements the row filters' vector loops cover
   uint8_t u = 0, v = 0;
-  if (p >= 1) {
-    const size_t j = p - 1;
+  if (p >= 1u) {
+    const uint32_t j = p - 1u;
     if (j < blocked) {
-      u = satu8(((int32_t)(int16_t)(sobel_tv(I, j, w, h) - sobel_tv(I, j + 2, w, h)) >> 2) + 128);
-      v = satu8(((int32_t)(int16_t)(sobel_th(I, j, w, h) + 2 * sobel_th(I, j + 1, w, h) + sobel_th(I, j + 2, w, h)) >> 2) + 128);
-    } else if (j + 2 < n) {
-      u = (uint8_t)(((sobel_tv(I, j, w, h) - sobel_tv(I, j + 2, w, h)) >> 2) + 128);
+      u = satu8(((int32_t)(int16_t)(sobel_tv(I, j) - sobel_tv(I, j + 2u)) >> 2) + 128);
+      v = satu8(((int32_t)(int16_t)(sobel_th(I, j) + 2 * sobel_th(I, j + 1u) + sobel_th(I, j + 2u)) >> 2) + 128);
+    } else if (j + 2u < n) {
+      u = (uint8_t)(((sobel_tv(I, j) - sobel_tv(I, j + 2u)) >> 2) + 128);
     }
   }
   du[p] = u;
@@ -589,20 +594,22 @@ int plvs_hip_elas_set_images(plvs_elas* h, const uint8_t* I1, const uint8_t* I2,
   PLVS_REQUIRE(width >= 16 && height >= 16 && stride >= width, "image size");
   hipStream_t s = h->stream;
   const int bpl = width + 15 - (width - 1) % 16;   // elas.cpp:41
-  const size_t n = (size_t)bpl * height, desc_bytes = (size_t)16 * width * height;
-  PLVS_HIP_TRY(h->img.reserve(n));
+  const size_t n = (size_t)bpl * height, desc_bytes = (size_t)16 * width * height, raw = (size_t)stride * height;
+  PLVS_REQUIRE(n < 0x7FFFFFFFull, "image size");
+  PLVS_HIP_TRY(h->img.reserve(2 * raw));
   PLVS_HIP_TRY(h->sob_u.reserve(n));
   PLVS_HIP_TRY(h->sob_v.reserve(n));
   PLVS_HIP_TRY(h->desc1.reserve(desc_bytes));
   PLVS_HIP_TRY(h->desc2.reserve(desc_bytes));
   h->desc_width = h->desc_height = 0;
-  const uint8_t* images[2] = {I1, I2};
+  // (one flat copy per image, lines as the caller laid them out: a pitched copy from pageable memory goes line by line)
+  const size_t used = (size_t)stride * (height - 1) + (size_t)width;   // (the last line may end with its last pixel)
+  PLVS_HIP_TRY(hipMemcpyAsync(h->img.p, I1, used, hipMemcpyHostToDevice, s));
+  PLVS_HIP_TRY(hipMemcpyAsync(h->img.p + raw, I2, used, hipMemcpyHostToDevice, s));
   uint8_t* descs[2] = {h->desc1.p, h->desc2.p};
   for (int k = 0; k < 2; ++k) {
-    PLVS_HIP_TRY(hipMemsetAsync(h->img.p, 0, n, s));
-    PLVS_HIP_TRY(hipMemcpy2DAsync(h->img.p, (size_t)bpl, images[k], (size_t)stride, (size_t)width, (size_t)height,
-                                  hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(elas_sobel, dim3(ceil_div(n, 256)), dim3(256), 0, s, h->img.p, bpl, height, h->sob_u.p, h->sob_v.p);
+    const PaddedImage img{h->img.p + (size_t)k * raw, width, stride, bpl, height};
+    hipLaunchKernelGGL(elas_sobel, dim3(ceil_div(n, 256)), dim3(256), 0, s, img, h->sob_u.p, h->sob_v.p);
     hipLaunchKernelGGL(elas_describe, dim3(ceil_div((size_t)width, 256), (unsigned)height), dim3(256), 0, s, h->sob_u.p,
                        h->sob_v.p, bpl, width, height, h->prm.subsampling ? 1 : 0, reinterpret_cast<uint4*>(descs[k]));
     PLVS_KERNEL_CHECK();
