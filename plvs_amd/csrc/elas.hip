@@ -463,11 +463,25 @@ __global__ void seg_jump(uint32_t* __restrict__ parent, size_t n) {
 // one word of a large segment: 4 ms)
 __global__ void seg_count(uint32_t* __restrict__ parent, const uint32_t* __restrict__ run_len, uint32_t* __restrict__ size, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t root = seg_find(parent, (uint32_t)i);
-  parent[i] = root;   // (only shortens this pixel's own path: the roots are final after seg_link)
-  const uint32_t len = run_len[i];
-  if (len) atomicAdd(&size[root], len);
+  uint32_t root = 0u;
+  if (i < n) {
+    root = seg_find(parent, (uint32_t)i);
+    parent[i] = root;   // (only shortens this pixel's own path: the roots are final after seg_link)
+  }
+  // the runs of a wave mostly hang under a few roots: lanes with the same root add up first, one of them goes to memory
+  uint32_t len = (i < n) ? run_len[i] : 0u;
+  while (__any(len != 0u)) {
+    const bool active = len != 0u;
+    const unsigned long long act = __ballot(active);
+    const int leader = __ffsll((long long)act) - 1;
+    const uint32_t lead_root = (uint32_t)__shfl((int)root, leader);
+    const bool same = active && root == lead_root;
+    uint32_t sum = same ? len : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += (uint32_t)__shfl_xor((int)sum, off);
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&size[lead_root], sum);
+    if (same) len = 0u;
+  }
 }
 __global__ void seg_apply(float* __restrict__ D, const uint32_t* __restrict__ parent, const uint32_t* __restrict__ size, size_t n,
                           uint32_t speckle) {

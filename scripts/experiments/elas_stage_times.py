@@ -25,7 +25,10 @@ for sub in (False, True):
             out = f(*a)
         t[name] = (time.perf_counter() - t0) / 10 * 1e3
         return out
-    timed("candidates", e.supportCandidates, d0["I1_desc"], d0["I2_desc"], w, h)
+    timed("descriptors", e.setImages, el, er)
+    d1, d2 = e.descriptors()
+    assert np.array_equal(d1, d0["I1_desc"]) and np.array_equal(d2, d0["I2_desc"])
+    timed("candidates", e.supportCandidates, None, None, w, h)
     Ds = [timed(f"disparity{i}", e.computeDisparity, a["support"], a["tri"], a["grid"], a["grid_dims"], None, None, a["right_image"], w, h)
           for i, a in enumerate(dcalls)]
     D1, D2 = timed("lr", e.leftRightConsistencyCheck, Ds[0], Ds[1], w, h)
