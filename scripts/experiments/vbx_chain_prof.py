@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Where the waves of vb_chain_chunks spend their time (a PLVS_VB_PROF=1 developer build named by PLVS_HIP_LIB):
-per call, the wave-time sums of  head list / short runs / long runs  in us, the waves, the longest workgroup."""
+"""Where the waves of vb_chain_chunks spend their time (a developer build named by PLVS_HIP_LIB:
+`make -C plvs_amd/csrc variant NAME=prof UNIT=tsdf_voxblox DEFS=-DPLVS_VB_PROF=1`): per call, the kernel's span, the mean time
+a wave spends on the head list / the short runs / the long runs, the longest wave and when it started.  (The finer probes
+of round 3 — per-trip phases, group-trips per wave — were taken out of the kernel again; DESIGN §4.1 has what they showed.)"""
 import ctypes
 import sys
 
@@ -29,12 +31,10 @@ for lap in range(3):
     for xyz, rgba, offsets, Twc in batches:
         b.integrate_batch_dev(xyz, rgba, offsets, Twc)
         nw = min(-(-b.last_stats()["visits"] // 2048) * WPB, 1 << 16)
-        buf = np.zeros((nw, 12), np.uint64)
+        buf = np.zeros((nw, 4), np.uint64)       # per wave: the times it started, finished the head list, the short runs, the kernel
         lib.plvs_hip_debug_chain_prof(buf.ctypes.data_as(ctypes.c_void_p), nw)
         if lap:
-            ph = buf[:, 4:8].astype(np.float64)
-            ex = buf[:, 8:].astype(np.int64)
-            t = buf[:, :4].astype(np.int64)
+            t = buf.astype(np.int64)
             t0 = t[:, 0].min()
             d = np.diff(t, axis=1) / 100.0                      # 100 MHz ticks -> us
             tot = (t[:, 3] - t[:, 0]) / 100.0
@@ -42,7 +42,4 @@ for lap in range(3):
             print(f"waves {nw}  kernel span {(t[:, 3].max() - t0) / 100.0:.1f} us;  mean per wave: heads {d[:, 0].mean():.2f} short {d[:, 1].mean():.2f} "
                   f"long {d[:, 2].mean():.2f} us;  longest wave {tot[i]:.1f} us (heads {d[i, 0]:.1f} short {d[i, 1]:.1f} long {d[i, 2]:.1f}), "
                   f"started at {(t[i, 0] - t0) / 100.0:.1f} us;  last wave start {(t[:, 0].max() - t0) / 100.0:.1f} us;  "
-                  f"waves longer than 50 us: {(tot > 50).sum()}, 100 us: {(tot > 100).sum()};  group 0 of a wave: {ph[:, 3].mean():.1f} trips, per trip: "
-                  f"between trips {ph[:, 0].sum() / ph[:, 3].sum() * 10:.0f} ns, operands {ph[:, 1].sum() / ph[:, 3].sum() * 10:.0f} ns, chains {ph[:, 2].sum() / ph[:, 3].sum() * 10:.0f} ns;  loop: starts {((ex[:, 0] - t[:, 2]) / 100.0).mean():.2f} us after the short runs, "
-                  f"lasts {((ex[:, 1] - ex[:, 0]) / 100.0).mean():.2f} us, {ex[:, 2].mean():.1f} group-trips per wave, {ex[:, 3].mean():.1f} long runs per workgroup;  "
-                  f"end of loop to end of wave {((t[:, 3] - ex[:, 1]) / 100.0).mean():.2f} us", flush=True)
+                  f"waves longer than 50 us: {(tot > 50).sum()}, 100 us: {(tot > 100).sum()}", flush=True)
