@@ -155,6 +155,55 @@ def test_oracle_descriptor_equals_the_reference_source(oracle, half, size):
         assert np.array_equal(oracle.elas_descriptor(right, half), calls[0]["I2_desc"])
 
 
+TREE_INPUT = "/root/reference/Thirdparty/libelas-gpu/input"
+
+
+@needs_ref
+@pytest.mark.skipif(not os.path.isdir(TREE_INPUT), reason="the reference tree's other stereo pairs are not committed (1 MB images)")
+@pytest.mark.parametrize("name,subsampling", [("cones", False), ("cones", True), ("aloe", True), ("urban3", False)])
+def test_every_oracle_stage_on_the_trees_other_pairs(oracle, name, subsampling):
+    """Dev-container test: the reference tree's own input pairs beyond urban1 (cones 900 x 750, aloe 1282 x 1110,
+    urban3 1344 x 391 — other textures, disparity ranges up to the 255 limit, widths that are not multiples of 16).  The
+    descriptors against libelas::Descriptor; then the pipeline with the oracle's candidate grid, computeDisparity,
+    left/right check, speckle removal, gap interpolation and adaptive mean in place of the reference's methods: the very
+    maps of the pure reference run."""
+    import ctypes
+
+    def pgm(path):       # (binary P5 with comment lines, which GIMP writes into some of the tree's files)
+        data = open(path, "rb").read()
+        tokens, pos = [], 0
+        while len(tokens) < 4:
+            while data[pos:pos + 1].isspace():
+                pos += 1
+            if data[pos:pos + 1] == b"#":
+                pos = data.index(b"\n", pos) + 1
+                continue
+            end = pos
+            while not data[end:end + 1].isspace():
+                end += 1
+            tokens.append(data[pos:end])
+            pos = end
+        assert tokens[0] == b"P5" and int(tokens[3]) == 255
+        w_, h_ = int(tokens[1]), int(tokens[2])
+        return np.frombuffer(data, np.uint8, w_ * h_, pos + 1).reshape(h_, w_).copy()
+    left, right = pgm(f"{TREE_INPUT}/{name}_left.pgm"), pgm(f"{TREE_INPUT}/{name}_right.pgm")
+    lib = ctypes.CDLL(elas_ref.REF)
+    lib.ref_elas_descriptor.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+    h, w = left.shape
+    want_desc = np.zeros(16 * w * h, np.uint8)
+    lib.ref_elas_descriptor(left.ctypes.data, w, h, w, int(subsampling), want_desc.ctypes.data)
+    assert np.array_equal(oracle.elas_descriptor(left, subsampling), want_desc)
+    want = elas_ref.reference(left, right, subsampling=subsampling, plvs=True)
+    post = dict(left_right_check=lambda D1, D2: oracle.elas_left_right_check(D1, D2, subsampling),
+                remove_small_segments=lambda D: oracle.elas_remove_small_segments(D, subsampling),
+                gap_interpolation=lambda D: oracle.elas_gap_interpolation(D, subsampling))
+    got = elas_ref.run_with(left, right, oracle.elas_compute_disparity, oracle.elas_adaptive_mean, subsampling=subsampling,
+                            plvs=True, support_candidates=oracle.elas_support_candidates, post=post)
+    for g, wv in zip(got, want):
+        assert np.array_equal(g.view(np.uint32), wv.view(np.uint32))
+    assert (want[0] >= 0).mean() > 0.3
+
+
 @needs_ref
 def test_adaptive_mean_alone_on_synthetic_maps_equals_the_reference_source(oracle):
     """Ramps, steps of 2 / 4 / 8 / 16 levels (the exponent classes of the subsampling branch's mask), invalid islands,
