@@ -69,7 +69,11 @@ def parse():
     ap.add_argument("--no-parity-check", action="store_true",
                     help="skip the oracle run over the same sequence (parity check + CPU baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-realistic-legs", action="store_true", help="skip the first-lap and 5-key-frame-call legs")
+    ap.add_argument("--no-realistic-legs", action="store_true", help="skip the first-lap and 5- / 1-key-frame-call legs")
+    ap.add_argument("--steady-state", action="store_true",
+                    help="chisel: make the saturated-map workload of rounds 1-3 the headline (every step re-integrates the same "
+                         "100 key frames of the small room); default: the long trajectory of distinct key frames")
+    ap.add_argument("--no-steady-state-leg", action="store_true", help="skip the saturated-map leg beside the headline")
     ap.add_argument("--no-frontend", action="store_true")
     return ap.parse_args()
 
@@ -90,7 +94,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
 
     from plvs_amd import _lib
-    from plvs_amd.synth_scene import make_keyframes
+    from plvs_amd.synth_scene import LOOP, make_keyframes, make_stream_keyframes
     from plvs_amd.shard import BlockDirectory, allgather_block_lists, sharded_integrate
     from plvs_amd.tsdf import TsdfChisel, TsdfVoxblox
 
@@ -106,7 +110,7 @@ def main():
         kfs = make_keyframes(n_poses, room_size=(16.0, 12.0, 3.0), max_depth=args.max_depth, seed=0)
         for k in kfs:
             k["rgba"] = np.concatenate([k["rgb"], np.full((k["rgb"].shape[0], 1), 255, np.uint8)], axis=1)
-    else:
+    elif args.steady_state:
         kfs = make_keyframes(n_poses, max_depth=args.max_depth, seed=0)
     # N > 1 (chisel, order-free): the ray-sharded integrate — rank r walks every N-th tile of the step's point
     # stream and sends what it collected to the chunk owners.  Weak scaling by default: a step carries --batch
@@ -114,6 +118,12 @@ def main():
     # stays what one GPU walks at N = 1.
     ray_sharded = multi and not vbx and not args.ordered
     step_kfs = args.batch * (world if (ray_sharded and not args.strong) else 1)
+    if not vbx and not args.steady_state:
+        # configs[2] stand-in, streaming: step s integrates key frames [s * step_kfs, (s + 1) * step_kfs) of the long
+        # trajectory (plvs_amd/synth_scene.py: one loop of LOOP = 2500 DISTINCT key frames around a desk island in a
+        # 9.5 x 7.5 x 3 m office; a job longer than the loop walks it again)
+        n_poses = min(total_steps * step_kfs, LOOP)
+        kfs = make_stream_keyframes(n_poses, max_depth=args.max_depth, seed=0, threads=min(32, os.cpu_count() or 8))
     batches = []
     built = {}     # steps that carry the same key frames share one copy in HBM (at N x 100 key frames per step all do)
     for s in range(total_steps):
@@ -257,7 +267,7 @@ def main():
         # runs of this same command; scripts/pmc_traffic.py) committed under profiles/
         mode_tag = "" if vbx else ("_ordered" if args.ordered else "_order_free")
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                           f"r03_pmc_traffic_{args.backend}{mode_tag}.json")
+                           f"r04_pmc_traffic_{args.backend}{mode_tag}{'_steady_state' if args.steady_state else ''}.json")
         if world == 1 and not multi and args.batch == 100 and os.path.exists(pmc):
             with open(pmc) as f:
                 t = json.load(f)
@@ -275,8 +285,15 @@ def main():
             "data": "synthetic",
             "config": {"workload": ("configs[3] stand-in: synthetic room 16x12x3 m, camera circle r=1 m, Voxblox "
                                     "simple TSDF 2 cm, max ray 5 m (wrapper constant), 76800-point keyframes" if vbx else
-                                    "configs[2] stand-in: synthetic room 6x4x3 m, camera circle r=1 m, "
-                                    "Chisel TSDF 5 cm / 5 m, 76800-point keyframes"),
+                                    ("configs[2] stand-in, STEADY STATE: synthetic room 6x4x3 m, camera circle r=1 m, every step "
+                                     "re-integrates the same 100 key frames into a saturated map, Chisel TSDF 5 cm / 5 m, "
+                                     "76800-point keyframes" if args.steady_state else
+                                     "configs[2] stand-in, STREAMING: every step integrates the NEXT keyframes_per_step DISTINCT key "
+                                     "frames of one 2500-key-frame loop around a desk island in a 9.5x7.5x3 m office (the shape of "
+                                     "TUM fr3/long_office: 6 mm and 0.144 deg per key frame, new ground and revisits in every step, "
+                                     "chunk allocation and colour folds inside the timed region), Chisel TSDF 5 cm / 5 m, 76800-pixel "
+                                     "grid of which 36-73 k points per key frame have a depth below 5 m; the saturated-map figure of "
+                                     "rounds 1-3 is the `steady_state` leg")),
                        "mode": None if vbx else mode_name,
                        "resolution": args.resolution, "max_depth": args.max_depth,
                        "keyframes_per_step": step_kfs, "points_per_step": int(points // args.steps),
@@ -344,8 +361,65 @@ def main():
                 legs.setdefault("updatemap_5", {"what": "20 calls of 5 key frames each (PointCloudMapping::UpdateMap's batch)"})[lap_name] = {
                     "ms_per_call_median": round(float(np.median(ts)) * 1e3, 4), "ms_per_call_max": round(max(ts) * 1e3, 4),
                     "value": round(vs / sum(ts) / 1e6, 2), "unit": "Mvoxels/s"}
+        # updatemap_1: ONE key frame per call — PLVS's real call shape: PointCloudMapChisel::InsertCloud per key frame
+        # (src/PointCloudMapping.cc:540, src/PointCloudMapChisel.cc:76)
+        one = []
+        for k in sel[:40]:
+            one.append((torch.from_numpy(k["xyz"]).cuda(), torch.from_numpy(k["rgb"]).cuda(),
+                        torch.from_numpy(k["kfid"].astype(np.int32)).cuda(),
+                        np.array([0, k["xyz"].shape[0]], np.int32), torch.from_numpy(k["Twc"][None]).cuda()))
+        for lap_name in ("warm-up", "first_lap", "second_lap"):
+            if lap_name != "second_lap":
+                tl.clear()
+            ts, vs = [], 0
+            for b in one:
+                dtc, stc = timed_call(tl, b)
+                ts.append(dtc)
+                vs += stc["visits"]
+            if lap_name != "warm-up":
+                legs.setdefault("updatemap_1", {"what": "40 calls of ONE key frame each (PointCloudMapChisel::InsertCloud per key frame)"})[lap_name] = {
+                    "ms_per_call_median": round(float(np.median(ts)) * 1e3, 4), "ms_per_call_max": round(max(ts) * 1e3, 4),
+                    "value": round(vs / sum(ts) / 1e6, 2), "unit": "Mvoxels/s",
+                    "roofline_frac": round((32.0 * vs + 28.0 * sum(int(b[3][1]) for b in one)) / sum(ts) / 8e12, 5)}
         tl.close()
         result["realistic_legs"] = legs
+
+    # ------------------------------------------------- the saturated-map workload of rounds 1-3, beside the headline
+    if rank == 0 and world == 1 and not vbx and not multi and not args.steady_state and not args.no_steady_state_leg:
+        sk = make_keyframes(100, max_depth=args.max_depth, seed=0)
+        sb = (torch.from_numpy(np.concatenate([k["xyz"] for k in sk])).cuda(),
+              torch.from_numpy(np.concatenate([k["rgb"] for k in sk])).cuda(),
+              torch.from_numpy(np.concatenate([k["kfid"] for k in sk]).astype(np.int32)).cuda(),
+              np.cumsum([0] + [k["xyz"].shape[0] for k in sk]).astype(np.int32),
+              torch.from_numpy(np.stack([k["Twc"] for k in sk])).cuda())
+        ts_ = TsdfChisel(args.resolution, max_chunks=16384, order_free=not args.ordered)
+        for _ in range(10):
+            ts_.integrate_batch_dev(*sb)
+        torch.cuda.synchronize()
+        ts_.set_profiling(True)
+        t0 = time.perf_counter()
+        sv = sp = 0
+        for _ in range(10):
+            ts_.integrate_batch_dev(*sb)
+            st_ = ts_.last_stats()
+            sv += st_["visits"]
+            sp += st_["points"]
+        torch.cuda.synchronize()
+        sel_ = time.perf_counter() - t0
+        ssm, sc = ts_.stage_ms()
+        ts_.set_profiling(False)
+        ts_.close()
+        sms = sum(ssm.values())
+        result["steady_state"] = {
+            "what": "rounds 1-3's headline workload: the same 100 key frames (room 6x4x3 m, camera circle r=1 m, 76800 points "
+                    "each) re-integrated into a map that has seen them 10 times — no chunk allocation, colours saturated, "
+                    "inputs and map resident in the Infinity Cache (10 warm-up + 10 timed steps)",
+            "value": round(sv / sel_ / 1e6, 2), "unit": "Mvoxels/s", "ms_per_step": round(sel_ / 10 * 1e3, 3),
+            "visits_per_step": int(sv // 10),
+            "stage_ms_per_launch": {n: round(v / max(sc, 1), 4) for n, v in ssm.items()},
+            "roofline": {"bound": "hbm", "achieved": round((32.0 * sv + 28.0 * sp) / (sms * 1e-3) / 1e9, 2), "peak": 8000.0,
+                         "unit": "GB/s", "frac": round((32.0 * sv + 28.0 * sp) / (sms * 1e-3) / 1e9 / 8000.0, 5),
+                         "ms_per_launch": round(sms / max(sc, 1), 4)}}
 
     # ------------------------------------------------- the other chisel mode, same stream (N = 1 only)
     t2 = None

@@ -938,7 +938,7 @@ static int read_counters(plvs_tsdf_chisel* h, hipStream_t s) {
 
 // ------------------------------------------------------------------ single-walk pipeline (tsdf_walk.hpp)
 constexpr int kWalkStages = 4;
-constexpr unsigned kDeferGrid = 240;   // workgroups of the general walk over the deferred tiles (it loops over the list)
+constexpr unsigned kDeferGrid = 1024;   // workgroups of the general walk over the deferred tiles (it loops over the list)
 const char* const kWalkStageNames[kWalkStages] = {"walk_tiles", "sort_segments", "apply_chunks", "fold_colours"};
 
 static int read_walk_counters(plvs_tsdf_chisel* h, hipStream_t s) {
@@ -1141,6 +1141,14 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
   }
   const WalkCounters& c = *h->h_wctr;
   h->num_chunks = h->h_ctr->num_chunks;
+  {   // developer trace of the call's counters (PLVS_HIP_TSDF_TRACE=1)
+    static const bool trace = plvs::env_int("PLVS_HIP_TSDF_TRACE", 0, 0, 1) != 0;
+    if (trace)
+      fprintf(stderr, "[tsdf_chisel] tiles %u deferred %u split %u visits %llu runs %u updated %u parts %u multi %u "
+              "rec_top %u seg_top %u voxels %u max_run %u chunks %d\n", ntiles, c.ndeferred, c.split_tiles,
+              (unsigned long long)c.total_visits, h->h_wctr[1].num_desc, c.num_updated, c.num_parts, c.num_multi, c.rec_top,
+              c.seg_top, c.num_heads, c.max_run, h->num_chunks);
+  }
   h->stats.visits = (int64_t)c.total_visits;
   h->stats.new_chunks = h->num_chunks - chunks_before;
   h->stats.updated_chunks = (int32_t)c.num_updated;

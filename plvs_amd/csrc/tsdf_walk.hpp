@@ -49,7 +49,14 @@ using plvs::tsdf::kErrPoolFull;
 
 constexpr int kWalkRays = 512;                  // rays (= threads) per tile
 constexpr int kMaskWords = kWalkRays / 32;      // a run's ray mask
-constexpr int kWalkEntries = 1024;              // LDS hash table entries
+// LDS hash table entries of a tile.  2048 since round 4: at 5 cm the 512 rays of a tile whose points lie 3 - 5 m away
+// touch 800 - 2000 distinct voxels (the rays of neighbouring pixels stop sharing voxels once the pixel footprint nears
+// the voxel size); with 1024 entries half the tiles of a real office scene overflowed and took the slow general path
+// (rounds 1-3 only ever measured a 6 x 4 m room, depths below 3 m: 300 - 600 voxels per tile).
+#ifndef PLVS_WALK_ENTRIES
+#define PLVS_WALK_ENTRIES 2048
+#endif
+constexpr int kWalkEntries = PLVS_WALK_ENTRIES;
 constexpr int kWalkLimit = kWalkEntries * 3 / 4;   // entries a (sub-)tile may use
 constexpr int kWalkWindow = kWalkLimit / 2;     // visits per window of a single over-long ray
 constexpr int kWalkChunks = 64;                 // per-tile chunk cache
@@ -178,8 +185,8 @@ constexpr uint32_t kKeyMul = 2654435761u, kKeyMulInv = 0x0E8B2F51u;
 static_assert((uint32_t)(kKeyMul * kKeyMulInv) == 1u, "inverse of the table-key multiplier");
 __device__ __forceinline__ uint32_t table_key(uint32_t key) { return key * kKeyMul; }
 __device__ __forceinline__ uint32_t voxel_key(uint32_t tkey) { return tkey * kKeyMulInv; }
-__device__ __forceinline__ uint32_t key_bucket(uint32_t tkey) { return tkey >> 24; }
-static_assert(kBuckets == 256, "key_bucket yields 8 bits");
+__device__ __forceinline__ uint32_t key_bucket(uint32_t tkey) { return tkey >> (kBuckets == 256 ? 24 : 23); }
+static_assert(kBuckets == 256 || kBuckets == 512, "key_bucket yields 8 or 9 bits");
 
 // Inclusive prefix sum over the 64 lanes of a wave by DPP (row shifts inside the rows of 16, then the row broadcasts):
 // six VALU instructions, no LDS traffic (a __shfl_up is a ds_bpermute_b32 through the LDS crossbar).
@@ -210,10 +217,14 @@ __device__ __forceinline__ int bucket_match(const uint4 k4, uint32_t want) {
 // a first touch (the bucket, the compare-and-swap): every wave step of the walk has a few lanes on this path and
 // the step is as slow as its slowest lane.  Entries are not counted here — the flush counts them (entries beyond
 // kWalkLimit: the (sub-)tile is cut, as when the table is full).
+constexpr int kProbeCap = 24;
 template <class SH>
 __device__ __forceinline__ int table_find_or_insert(SH& S, uint32_t key /* a table key */) {
   uint32_t b = key_bucket(key);
-  for (int probe = 0; probe < 4 * kBuckets; ++probe) {
+  // (kProbeCap: a tile within its limit — three quarters of the table — never chains that far; a table on its way to
+  // full does, and every probe is an LDS round trip: without the cap the rays of an overflowing tile spent hundreds of
+  // probes each before they gave up, ~1 ms per tile on the office stream of bench.py)
+  for (int probe = 0; probe < kProbeCap; ++probe) {
     const uint4 k4 = *reinterpret_cast<const uint4*>(&S.ekey[4 * b]);
     const int j = bucket_match(k4, key);
     if (j >= 0) return (int)(4 * b) + j;
@@ -563,7 +574,7 @@ struct RunOut {
   uint32_t r1_log2;
 };
 
-constexpr int kMaskCap = 256;   // ray masks built per round (LDS)
+constexpr int kMaskCap = kWalkEntries / 4;   // ray masks built per round (LDS: the area of the accumulators)
 
 __device__ __forceinline__ uint4 pack_suboffsets(const uint32_t* o) {
   return make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
@@ -582,7 +593,7 @@ struct TileMap {
 // of the rays in the ray-sharded integrate: dir = the rank's directory of every chunk it has walked through,
 // sat = its bitmap of the voxels their owners have reported saturated (4096 bits per directory slot).
 template <bool kAcc, bool kRuns>
-__global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
+__global__ __launch_bounds__(kWalkRays, kWalkEntries > 1024 ? 4 : 6) void walk_tiles(
     Params P, float scale_u, float scale_w, const float* __restrict__ xyz, int npoints,
     const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
     int32_t* __restrict__ num_chunks, WalkCounters* __restrict__ ctr, const uint32_t* __restrict__ rgbw,
@@ -1065,7 +1076,7 @@ __global__ __launch_bounds__(kWalkRays, 6) void walk_tiles(
 // or runs; its index goes to a list and walk_tiles (the general kernel) walks the list behind this kernel.  Same
 // outputs, same regions, bit for bit the same records either way.
 #ifndef PLVS_WALK_FAST_WAVES
-#define PLVS_WALK_FAST_WAVES 6
+#define PLVS_WALK_FAST_WAVES (PLVS_WALK_ENTRIES > 1024 ? 4 : 6)   // (waves per SIMD the tile's LDS allows: 2 x 62 KiB / 4 x 40 KiB per CU)
 #endif
 __global__ __launch_bounds__(kWalkRays, PLVS_WALK_FAST_WAVES) void walk_fast(
     Params P, float scale_u, float scale_w, const float* __restrict__ xyz, int npoints,
@@ -1076,9 +1087,11 @@ __global__ __launch_bounds__(kWalkRays, PLVS_WALK_FAST_WAVES) void walk_fast(
   __shared__ FastShared S;
   __shared__ uint32_t raw[kMaskCap * kMaskWords];              // accumulators during the walk, ray masks afterwards
   __shared__ uint16_t vlog[kLogLen * kWalkRays];        // entry of visit k of ray r at [k * kWalkRays + r]
-  // mask index of the entry (0xFFFF: none) — in the words of the (chunk, slab) counters, dead once the records are out
-  uint16_t* const e_midx = reinterpret_cast<uint16_t*>(S.ccnt);
-  static_assert(sizeof(S.ccnt) >= kWalkEntries * sizeof(uint16_t), "e_midx overlays ccnt");
+  // mask index of the entry (0xFFFF: none) — in the words of the (chunk, slab) counters, dead once the records are out,
+  // where they hold it
+  constexpr bool kMidxOverlay = sizeof(S.ccnt) >= kWalkEntries * sizeof(uint16_t);
+  __shared__ uint16_t e_midx_own[kMidxOverlay ? 1 : kWalkEntries];
+  uint16_t* const e_midx = kMidxOverlay ? reinterpret_cast<uint16_t*>(S.ccnt) : e_midx_own;
   int32_t* const e_wuu = reinterpret_cast<int32_t*>(raw);                                 // sum of w_u * u, fixed point
   unsigned long long* const e_wc = reinterpret_cast<unsigned long long*>(raw + kWalkEntries);   // visits << 32 | sum of w_u
   uint32_t* const e_last = raw + 3 * kWalkEntries;                                        // last visiting ray
@@ -1144,8 +1157,9 @@ __global__ __launch_bounds__(kWalkRays, PLVS_WALK_FAST_WAVES) void walk_fast(
       ekey[k] = S.ekey[tid + k * kWalkRays];
       if (ekey[k] != kKeyEmpty) ekey[k] = voxel_key(ekey[k]);   // (the table holds table keys)
     }
-    static_assert(kPer == 2, "two entries per thread");
-    const uint32_t wave_n = (uint32_t)__popcll(__ballot(ekey[0] != kKeyEmpty)) + (uint32_t)__popcll(__ballot(ekey[1] != kKeyEmpty));
+    uint32_t wave_n = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) wave_n += (uint32_t)__popcll(__ballot(ekey[k] != kKeyEmpty));
     if (lane == 0 && wave_n) atomicAdd(&S.nent, wave_n);
   } else {
 #pragma unroll
