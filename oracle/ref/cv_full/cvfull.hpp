@@ -148,10 +148,19 @@ struct DMatch {
 };
 struct FileNode {   // (parameters are never read from a file on this path)
   FileNode operator[](const char*) const { return FileNode(); }
+  bool empty() const { return true; }
+  bool isReal() const { return false; }
+  bool isInt() const { return false; }
+  bool isString() const { return false; }
+  operator double() const { return 0.0; }
+  operator std::string() const { return std::string(); }
   operator int() const { return 0; }
   operator float() const { return 0.f; }
 };
-struct FileStorage {};
+struct FileStorage {
+  FileNode operator[](const std::string&) const { return FileNode(); }
+  FileNode operator[](const char*) const { return FileNode(); }
+};
 template <class T> inline FileStorage& operator<<(FileStorage& fs, const T&) { return fs; }
 enum { NORM_L1 = 2, NORM_L2 = 4, NORM_HAMMING = 6 };
 
@@ -191,6 +200,7 @@ class Mat {
   Mat() {}
   Mat(int r, int c, int t) { create(r, c, t); }
   Mat(Size s, int t) { create(s.height, s.width, t); }
+  Mat(int r, int c, int t, const Scalar&) { std::abort(); }   // (drawing code only: never on a compared path)
   Mat(int r, int c, int t, void* ext, size_t st = 0) : rows(r), cols(c), type_(t), data(static_cast<uchar*>(ext)) {
     step.p = st ? st : (size_t)c * elem_size_of(t);   // (no copy, no ownership)
   }
@@ -229,6 +239,11 @@ class Mat {
     m.data = data + (size_t)r.y * step.p + (size_t)r.x * elemSize();
     return m;
   }
+  // (Frame.cc reshapes an N x 2 CV_32F matrix to N x 1 two-channel and back around cv::undistortPoints: the stand-in
+  // keeps the N x 2 layout, its undistortPoints reads that)
+  Mat reshape(int) const { return *this; }
+  void reserve(size_t) {}
+  static Mat eye(int, int, int) { std::abort(); }
   Mat rowRange(int a, int b) const { return (*this)(Rect(0, a, cols, b - a)); }
   Mat colRange(int a, int b) const { return (*this)(Rect(a, 0, b - a, rows)); }
   Mat row(int r) const { return rowRange(r, r + 1); }
@@ -238,6 +253,7 @@ class Mat {
   template <class T> const T* ptr(int r = 0) const { return reinterpret_cast<const T*>(data + (size_t)r * step.p); }
   template <class T> T& at(int r, int c) { return ptr<T>(r)[c]; }
   template <class T> const T& at(int r, int c) const { return ptr<T>(r)[c]; }
+  template <class T> const T& at(const Point_<int>& p) const { return ptr<T>(p.y)[p.x]; }
   template <class T> T& at(int i) { return rows == 1 ? ptr<T>(0)[i] : ptr<T>(i / cols)[i % cols]; }
   template <class T> const T& at(int i) const { return rows == 1 ? ptr<T>(0)[i] : ptr<T>(i / cols)[i % cols]; }
   void push_back(const Mat& o) {   // append rows

@@ -57,7 +57,7 @@ constexpr int kMaskWords = kWalkRays / 32;      // a run's ray mask
 #define PLVS_WALK_ENTRIES 2048
 #endif
 constexpr int kWalkEntries = PLVS_WALK_ENTRIES;
-constexpr int kWalkLimit = kWalkEntries * 3 / 4;   // entries a (sub-)tile may use
+constexpr int kWalkLimit = kWalkEntries * 7 / 8;   // entries a (sub-)tile may use (buckets of four: probes stay short)
 constexpr int kWalkWindow = kWalkLimit / 2;     // visits per window of a single over-long ray
 constexpr int kWalkChunks = 64;                 // per-tile chunk cache
 constexpr uint32_t kErrScratch = 8u;            // record / segment / run buffers too small: the host grows them and retries
@@ -612,7 +612,9 @@ __global__ __launch_bounds__(kWalkRays, kWalkEntries > 1024 ? 4 : 6) void walk_t
   // the tiles walk_fast deferred (tile_list) — or every tile of the call (tile_list = nullptr: blockIdx is the tile)
   const uint32_t nlist = tile_list ? min(*ntile_list, ntiles) : ntiles;
   for (uint32_t lb = blockIdx.x; lb < nlist; lb += gridDim.x) {
-  const uint32_t tile = tile_list ? tile_list[lb] : lb;   // the local tile: output regions
+  // (bit 31 of a list entry: walk_fast saw the tile overflow its table — it is cut in two at once)
+  const uint32_t tile = tile_list ? (tile_list[lb] & 0x7FFFFFFFu) : lb;   // the local tile: output regions
+  const bool cut_at_once = tile_list && (tile_list[lb] >> 31) != 0u;
   const uint32_t gtile = tmap.tile_of(tile);             // its place in the point stream
   const uint32_t first = gtile * kWalkRays;
   __syncthreads();   // (the previous tile of this workgroup is done with the shared state)
@@ -622,17 +624,23 @@ __global__ __launch_bounds__(kWalkRays, kWalkEntries > 1024 ? 4 : 6) void walk_t
   // more per sub-tile.
   const uint32_t nrays = min((uint32_t)kWalkRays, (uint32_t)npoints - first);
   const int cloud0 = cloud_of(offsets, nclouds, (int)first);
-  const bool single = (uint32_t)(offsets[cloud0 + 1] - (int32_t)first) >= nrays;
+  const bool one_cloud = (uint32_t)(offsets[cloud0 + 1] - (int32_t)first) >= nrays;
+  const bool single = one_cloud && !(cut_at_once && nrays > 1u);
   if (tid == 0) {
     S.sp = 0;
-    S.next = single ? nrays : 0u;
+    S.next = one_cloud ? nrays : 0u;
+    if (one_cloud && !single) {   // the two halves, the lower one on top (sub-tiles stay in point order)
+      const uint16_t mid = (uint16_t)(nrays / 2);
+      S.stack[S.sp++] = SubTile{mid, (uint16_t)nrays, 0u, 0xFFFFFFFFu, cloud0};
+      S.stack[S.sp++] = SubTile{(uint16_t)0, mid, 0u, 0xFFFFFFFFu, cloud0};
+    }
     S.nrays = nrays;
     S.run_total = 0;
     S.vis_total = 0;
   }
   const uint32_t i = first + (uint32_t)tid;
   uint32_t my_visits = 0;
-  bool was_split = false;
+  bool was_split = one_cloud && !single;
   int flushes = 0;
   bool first_pass = true;
   WALK_PROF_BEGIN();
@@ -1220,13 +1228,14 @@ __global__ __launch_bounds__(kWalkRays, PLVS_WALK_FAST_WAVES) void walk_fast(
   // (one barrier: the ranks are complete, the tile's entries are counted — and does any voxel that needs a run have
   // more than one visiting ray?)
   const bool any_multi = __syncthreads_or(multi ? 1 : 0) != 0;                              // ---- barrier 3
-  if (!defer) defer = S.overflow != 0 || S.nent > (uint32_t)kWalkLimit;
+  const bool too_many = !defer && S.nent > (uint32_t)kWalkLimit;   // (the voxels do not fit: walk_tiles cuts the tile at once)
+  if (!defer) defer = S.overflow != 0 || too_many;
   if (defer) {
     if (tid == 0) {
       out.seg_cnt[tile] = 0;
       runs.run_cnt[tile] = 0;
       out.tile_visits[tile] = 0;
-      deferred[atomicAdd(&ctr->ndeferred, 1u)] = tile;
+      deferred[atomicAdd(&ctr->ndeferred, 1u)] = tile | (too_many ? 0x80000000u : 0u);
     }
     return;
   }
@@ -1602,7 +1611,18 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
     atomicMax(&a_last[v], q.a.y);
     atomicAdd(&a_cnt[v], q.a.x >> 12);
   };
+#ifdef PLVS_WALK_PROF
+  long long ap_t = (long long)clock64();
+  unsigned long long ap_acc[5] = {0, 0, 0, 0, 0}, ap_items = 0, ap_max = 0;
+#define APPLY_PROF(k) do { const long long now = (long long)clock64(); ap_acc[k] += (unsigned long long)(now - ap_t); ap_t = now; } while (0)
+#else
+#define APPLY_PROF(k) do {} while (0)
+#endif
   for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+#ifdef PLVS_WALK_PROF
+    const long long ap_item0 = (long long)clock64();
+    ap_t = ap_item0;
+#endif
     const uint32_t pi = item / kSlabs, slab = item % kSlabs;
     uint32_t lo = 0, hi = nchunks - 1;   // the chunk of part pi: the last a with part_off[a] <= pi
     while (lo < hi) {
@@ -1617,6 +1637,7 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
       a_cnt[v] = 0;
     }
     __syncthreads();
+    APPLY_PROF(0);   // item set-up
     const uint32_t s0 = active_off[a] + (pi - part_off[a]) * part_segs;
     const uint32_t s1 = nparts > 1 ? min(active_off[a + 1], s0 + part_segs) : active_off[a + 1];
     // (the descriptors of the NEXT round are asked for before this round's records: a round is two dependent global
@@ -1651,12 +1672,38 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
         if (lo_r[j] + gl < hi_r[j]) q[j] = load(lo_r[j] + gl);
       fetch_desc(sb + kGroups * kFly);
 #pragma unroll
-      for (int j = 0; j < kFly; ++j) {
+      for (int j = 0; j < kFly; ++j)
         if (lo_r[j] + gl < hi_r[j]) add(q[j]);
-        for (uint32_t r = lo_r[j] + 16u + gl; r < hi_r[j]; r += 16) add(load(r));
+      // the rest of long slab ranges (a tile of far points puts hundreds of voxels into one slab of one chunk): the
+      // four segments side by side, two rounds of sixteen records each — eight independent loads per lane in flight
+      // (one segment after the other, one load at a time, this loop was most of the stage on the office stream)
+      uint32_t nr[kFly];
+      bool more = false;
+#pragma unroll
+      for (int j = 0; j < kFly; ++j) {
+        nr[j] = lo_r[j] + 16u + gl;
+        more = more || nr[j] < hi_r[j];
+      }
+      while (more) {
+        Rec qa[kFly], qb[kFly];
+#pragma unroll
+        for (int j = 0; j < kFly; ++j) {
+          if (nr[j] < hi_r[j]) qa[j] = load(nr[j]);
+          if (nr[j] + 16u < hi_r[j]) qb[j] = load(nr[j] + 16u);
+        }
+        more = false;
+#pragma unroll
+        for (int j = 0; j < kFly; ++j) {
+          if (nr[j] < hi_r[j]) add(qa[j]);
+          if (nr[j] + 16u < hi_r[j]) add(qb[j]);
+          nr[j] += 32u;
+          more = more || nr[j] < hi_r[j];
+        }
       }
     }
+    APPLY_PROF(1);   // thread 0's share of the segments
     __syncthreads();
+    APPLY_PROF(2);   // ... and the wait for the slowest wave
     const size_t pool0 = (size_t)active[a] * kChunkVox + (size_t)slab * kSlabVox;
     bool apply = true;
     if (nparts > 1) {
@@ -1689,6 +1736,7 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
         if (tid == 0) atomicExch(&acc.done[(size_t)multi_idx[a] * kSlabs + slab], 0u);
       }
     }
+    APPLY_PROF(3);   // parts: the sums join the chunk's accumulators
     if (apply && kEmit) {
       // ---- the slab's sums leave for the chunk's owner: one wide record per touched voxel, one descriptor
       static_assert(kSlabVox == kApplyThreads, "a thread per voxel of the slab");
@@ -1743,7 +1791,19 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
       }
     }
     __syncthreads();
+    APPLY_PROF(4);   // the voxel updates
+#ifdef PLVS_WALK_PROF
+    ++ap_items;
+    ap_max = max(ap_max, (unsigned long long)((long long)clock64() - ap_item0));
+#endif
   }
+#ifdef PLVS_WALK_PROF
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < 5; ++k) atomicAdd(&g_walk_prof[9 + k], ap_acc[k]);
+    atomicAdd(&g_walk_prof[14], ap_items);
+    atomicMax(&g_walk_prof[15], ap_max);
+  }
+#endif
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     voxels += (uint32_t)__shfl_xor((int)voxels, off);
