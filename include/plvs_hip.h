@@ -458,6 +458,17 @@ int plvs_hip_tsdf_chisel_clear(plvs_tsdf_chisel* h);
 int plvs_hip_tsdf_chisel_integrate(plvs_tsdf_chisel* h, const float* xyz, const uint8_t* rgb,
                                    const uint32_t* kfid, int n, const float* Twc);
 
+/* Queued integration — the drop-in shape of PointCloudMapChisel.  PLVS hands over ONE key frame per InsertCloud and reads
+ * the map only in UpdateMap, after at most five of them (src/PointCloudMapping.cc:540-552, 594-598).  _queue uploads the
+ * cloud (host pointers, as _integrate) and returns without integrating; _flush integrates everything queued in ONE call of
+ * the batch pipeline: the same map as integrating the clouds one by one — bit for bit in the ordered mode (the batch applies
+ * every update in point order across the clouds), within the stated tolerance in the order-free mode — at a fraction of the
+ * per-call launch chain.  Every entry point that reads or changes the map (integrate, carve, mesh, download, chunk lists,
+ * deform, last_stats, ...) flushes first; _clear drops the queue with the map.  _queued: clouds waiting. */
+int plvs_hip_tsdf_chisel_queue(plvs_tsdf_chisel* h, const float* xyz, const uint8_t* rgb, const uint32_t* kfid, int n,
+                               const float* Twc);
+int plvs_hip_tsdf_chisel_flush(plvs_tsdf_chisel* h);
+int plvs_hip_tsdf_chisel_queued(plvs_tsdf_chisel* h, int* nclouds);
 /* Batched, device-resident form: `nclouds` clouds integrated in order, cloud c
  * being points [offsets[c], offsets[c+1]) of the concatenated device arrays,
  * with pose d_Twc[12*c .. 12*c+11].  `offsets` is a host array of nclouds+1

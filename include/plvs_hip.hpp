@@ -480,9 +480,15 @@ class PointCloudMapChisel {
   // OnMapChange can deform it as Chisel::Deform does (plvs_hip_tsdf_chisel_enable_deform)
   explicit PointCloudMapChisel(float resolution, bool useCarving = false, float carvingDist = 0.05f,
                                float nearPlaneDist = 0.05f, float farPlaneDist = 5.0f, bool bResetOnSparseMapChange = true,
-                               bool bCloudDeformationOnSparseMapChange = false)
+                               bool bCloudDeformationOnSparseMapChange = false, bool queueInsertions = true)
       : useCarving_(useCarving), carvingDist_(carvingDist), near_(nearPlaneDist), far_(farPlaneDist),
-        resetOnChange_(bResetOnSparseMapChange), deformOnChange_(bCloudDeformationOnSparseMapChange) {
+        resetOnChange_(bResetOnSparseMapChange), deformOnChange_(bCloudDeformationOnSparseMapChange),
+        // queueInsertions: InsertCloud uploads the key frame's cloud, UpdateMap (or whatever reads or changes the map
+        // first) integrates the ones waiting — at most five between two UpdateMap calls of PointCloudMapping
+        // (src/PointCloudMapping.cc:540-552) — in one batch: the reference only reads the map in UpdateMap, and the batch
+        // gives the same map bit for bit in the (default) ordered mode (plvs_hip_tsdf_chisel_queue).  Off with the
+        // deformation bookkeeping, which follows the map call by call.
+        queue_(queueInsertions && !bCloudDeformationOnSparseMapChange) {
     plvs_tsdf_chisel_params p;
     check(plvs_hip_tsdf_chisel_default_params(resolution, &p));
     check(plvs_hip_tsdf_chisel_create(&p, &h_));
@@ -504,13 +510,27 @@ class PointCloudMapChisel {
       rgb_[3 * i] = p.r; rgb_[3 * i + 1] = p.g; rgb_[3 * i + 2] = p.b;
       kfid_[i] = p.kfid;
     }
+    if (queue_) {
+      check(plvs_hip_tsdf_chisel_queue(h_, xyz_.data(), rgb_.data(), kfid_.data(), (int)n, Twc.m));
+      return;
+    }
     check(plvs_hip_tsdf_chisel_integrate(h_, xyz_.data(), rgb_.data(), kfid_.data(), (int)n, Twc.m));
     MarkUpdated();
+  }
+  // Integrates the queued key frames (one batch) and notes the meshes they invalidate.
+  void Flush() {
+    int waiting = 0;
+    check(plvs_hip_tsdf_chisel_queued(h_, &waiting));
+    if (waiting > 0) {
+      check(plvs_hip_tsdf_chisel_flush(h_));
+      MarkUpdated();
+    }
   }
   // InsertCloudWithDepth: carving of the depth image's frustum first when useCarving (Chisel.cpp:394-438)
   void InsertCloudWithDepth(const std::vector<PointSurfelSegment>& cloud_camera, const SE3f& Twc, const Image32F& depthImage,
                             float fx, float fy, float cx, float cy, double max_range = 0) {
     if (useCarving_) {
+      Flush();   // (carving reads and changes the map: what is waiting goes in first)
       if (depthImage.step != (size_t)depthImage.cols * sizeof(float))
         throw std::invalid_argument("InsertCloudWithDepth: the depth image must be continuous");
       int carved = 0;
@@ -528,6 +548,7 @@ class PointCloudMapChisel {
   // UpdateMap: UpdateMesh (meshes of the 27-neighbourhood of every chunk updated since the last call,
   // Chisel.cpp:553-568) + GetPointCloud (ChiselServer.cpp:971-1068).  Returns the cloud size.
   int UpdateMap() {
+    Flush();
     std::vector<int32_t> ids;
     for (const ChunkID& c : meshesToUpdate_) { ids.push_back(std::get<0>(c)); ids.push_back(std::get<1>(c)); ids.push_back(std::get<2>(c)); }
     const int nch = (int)meshesToUpdate_.size();
@@ -593,6 +614,7 @@ class PointCloudMapChisel {
       kfid_[i] = p.kfid;
     }
     const float identity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    Flush();
     check(plvs_hip_tsdf_chisel_integrate_world_normals(h_, xyz_.data(), rgb_.data(), kfid_.data(), nrm.data(), (int)n, identity));
     MarkUpdated();
     return UpdateMap();
@@ -644,7 +666,7 @@ class PointCloudMapChisel {
   plvs_tsdf_chisel* h_ = nullptr;
   bool useCarving_;
   float carvingDist_, near_, far_;
-  bool resetOnChange_ = true, deformOnChange_ = false;
+  bool resetOnChange_ = true, deformOnChange_ = false, queue_ = true;
   std::vector<float> xyz_;
   std::vector<uint8_t> rgb_;
   std::vector<uint32_t> kfid_;

@@ -1,0 +1,194 @@
+// C entry points over the reference's OWN matchers and Frame methods — src/ORBmatcher.cc, src/LineMatcher.cc, src/Frame.cc
+// compiled unmodified against oracle/ref/slam_shim (see slam_shim.h) — for tests/test_oracle_pinned_matchers.py, which
+// holds the restatements in oracle/orb_search.c, line_search.c, line_proj_search.c, stereo.c to them.  TEST
+// INFRASTRUCTURE ONLY.  The wrapper builds Frame / KeyFrame / MapPoint / MapLine objects from the same flat views the
+// C ABI of the product takes (include/plvs_hip.h: plvs_frame_view, ...) and calls the reference's functions; where the
+// product takes a quantity "handed over by the caller" (the projection of a map point into the frame), the wrapper
+// takes the poses and points the reference derives it from, and the TEST repeats those two lines of arithmetic.
+#define private public      // Frame::AssignFeaturesToGrid / UndistortKeyPoints / UndistortKeyLines / ComputeImageBounds
+#define protected public    // ORBmatcher / LineMatcher helpers
+#include "Frame.h"
+#include "ORBmatcher.h"
+#include "LineMatcher.h"
+#include "ORBextractor.h"
+#undef private
+#undef protected
+
+#include <cstring>
+
+#include "plvs_hip.h"
+
+using namespace PLVS2;
+
+// ---- statics the three sources expect from translation units that are not compiled
+float PLVS2::Tracking::skLineStereoMaxDist = 20.f;          // src/Tracking.cc:151
+float PLVS2::Tracking::skMaxDistFovCenters = 0.5f;          // src/Tracking.cc
+bool PLVS2::Tracking::skUsePyramidPrecomputation = false;   // src/Tracking.cc
+float PLVS2::KeyFrame::skFovCenterDistance = 1.5f;          // src/KeyFrame.cc
+std::mutex PLVS2::MapPoint::mGlobalMutex;
+std::mutex PLVS2::MapLine::mGlobalMutex;
+
+namespace {
+
+cv::Mat rows32(const uint8_t* p, int n) { return cv::Mat(n, 32, CV_8U, const_cast<uint8_t*>(p)); }
+
+// What SearchByProjection / SearchByBoW / GetFeaturesInArea read of a single-camera frame.
+void fill_frame(Frame& F, const plvs_frame_view* v, const float* angle) {
+  F.N = v->n;
+  F.Nleft = -1;
+  F.mvKeysUn.resize(v->n);
+  for (int i = 0; i < v->n; ++i) {
+    cv::KeyPoint& k = F.mvKeysUn[i];
+    k.pt.x = v->x[i];
+    k.pt.y = v->y[i];
+    k.octave = v->octave[i];
+    k.angle = angle ? angle[i] : 0.f;
+  }
+  F.mvKeys = F.mvKeysUn;
+  F.mvuRight.assign(v->u_right, v->u_right + v->n);
+  F.mvDepth.assign(v->n, -1.f);
+  F.mDescriptors = rows32(v->desc, v->n);
+  F.mvScaleFactors.assign(v->scale_factors, v->scale_factors + 8);
+  F.mvpMapPoints.assign(v->n, static_cast<MapPointPtr>(nullptr));
+  F.mvbOutlier.assign(v->n, false);
+  Frame::mnMinX = v->min_x;
+  Frame::mnMinY = v->min_y;
+  Frame::mfGridElementWidthInv = v->grid_w_inv;
+  Frame::mfGridElementHeightInv = v->grid_h_inv;
+  F.AssignFeaturesToGrid();   // (the reference's: Frame.cc:716)
+}
+
+}  // namespace
+
+extern "C" {
+
+// ORBmatcher::SearchByProjection(Frame&, const vector<MapPointPtr>&, th, bFarPoints, thFarPoints)  src/ORBmatcher.cc:71
+int ref_orb_search_by_projection(const plvs_frame_view* fv, const plvs_mappoint_view* mv, float th, int far_points,
+                                 float th_far, float nn_ratio, const uint8_t* occupied, int32_t* assigned) {
+  Frame F;
+  fill_frame(F, fv, nullptr);
+  MapPoint taken;   // what an occupied keypoint holds: a map point with observations
+  taken.mnObs = 1;
+  if (occupied)
+    for (int i = 0; i < fv->n; ++i)
+      if (occupied[i]) F.mvpMapPoints[i] = &taken;
+  std::vector<MapPoint> store(mv->m);
+  std::vector<MapPointPtr> vp(mv->m);
+  for (int k = 0; k < mv->m; ++k) {
+    MapPoint& p = store[k];
+    p.mbTrackInView = mv->track_in_view[k] != 0;
+    p.mbTrackInViewR = false;
+    p.mbBad = mv->bad[k] != 0;
+    p.mTrackProjX = mv->proj_x[k];
+    p.mTrackProjY = mv->proj_y[k];
+    p.mTrackProjXR = mv->proj_xr[k];
+    p.mTrackViewCos = mv->view_cos[k];
+    p.mTrackDepth = mv->track_depth[k];
+    p.mnTrackScaleLevel = mv->level[k];
+    p.mDescriptor = rows32(mv->desc + 32 * (size_t)k, 1);
+    p.mnObs = (!mv->has_obs || mv->has_obs[k]) ? 1 : 0;
+    vp[k] = &p;
+  }
+  ORBmatcher matcher(nn_ratio, true);
+  const int n = matcher.SearchByProjection(F, vp, th, far_points != 0, th_far);
+  for (int i = 0; i < fv->n; ++i) {
+    MapPointPtr p = F.mvpMapPoints[i];
+    assigned[i] = (p && p != &taken) ? (int32_t)(p - store.data()) : -1;
+  }
+  return n;
+}
+
+// ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono)  src/ORBmatcher.cc:1774.
+// Tcw / Tlw: 3 x 4 row-major poses of the two frames; cam = fx, fy, cx, cy of CurrentFrame.mpCamera; xyz_w = world
+// position of the map point of last-frame keypoint i (n_last x 3); valid[i] = mvpMapPoints[i] && !mvbOutlier[i].
+int ref_orb_search_by_projection_ff(const plvs_frame_view* fv, const float* cur_angle, float max_x, float max_y, float mbf,
+                                    float mb, const float* Tcw, const float* Tlw, const float* cam, int n_last,
+                                    const uint8_t* valid, const float* xyz_w, const int32_t* octave, const float* angle,
+                                    const uint8_t* desc, const uint8_t* has_obs, float th, int mono, float nn_ratio,
+                                    int check_orientation, const uint8_t* occupied, int32_t* assigned) {
+  Frame C, L;
+  fill_frame(C, fv, cur_angle);
+  Frame::mnMaxX = max_x;
+  Frame::mnMaxY = max_y;
+  C.mbf = mbf;
+  C.mb = mb;
+  Pinhole camera(std::vector<float>(cam, cam + 4));
+  C.mpCamera = &camera;
+  auto pose_of = [](const float* T) {
+    Eigen::Matrix3f R;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) R(r, c) = T[4 * r + c];
+    return Sophus::SE3f(R, Eigen::Vector3f(T[3], T[7], T[11]));
+  };
+  C.SetPose(pose_of(Tcw));
+  L.SetPose(pose_of(Tlw));
+  MapPoint taken;
+  taken.mnObs = 1;
+  if (occupied)
+    for (int i = 0; i < fv->n; ++i)
+      if (occupied[i]) C.mvpMapPoints[i] = &taken;
+  L.N = n_last;
+  L.Nleft = -1;
+  L.mvKeys.resize(n_last);
+  for (int i = 0; i < n_last; ++i) {
+    L.mvKeys[i].octave = octave[i];
+    L.mvKeys[i].angle = angle[i];
+  }
+  L.mvKeysUn = L.mvKeys;
+  L.mvbOutlier.assign(n_last, false);
+  std::vector<MapPoint> store(n_last);
+  L.mvpMapPoints.assign(n_last, static_cast<MapPointPtr>(nullptr));
+  for (int i = 0; i < n_last; ++i) {
+    if (!valid[i]) continue;
+    MapPoint& p = store[i];
+    p.mWorldPos = Eigen::Vector3f(xyz_w[3 * i], xyz_w[3 * i + 1], xyz_w[3 * i + 2]);
+    p.mDescriptor = rows32(desc + 32 * (size_t)i, 1);
+    p.mnObs = (!has_obs || has_obs[i]) ? 1 : 0;
+    L.mvpMapPoints[i] = &p;
+  }
+  ORBmatcher matcher(nn_ratio, check_orientation != 0);
+  const int n = matcher.SearchByProjection(C, L, th, mono != 0);
+  for (int i = 0; i < fv->n; ++i) {
+    MapPointPtr p = C.mvpMapPoints[i];
+    assigned[i] = (p && p != &taken) ? (int32_t)(p - store.data()) : -1;
+  }
+  return n;
+}
+
+// ORBmatcher::SearchByBoW(KeyFramePtr& pKF, Frame& F, vector<MapPointPtr>&)  src/ORBmatcher.cc:300
+int ref_orb_search_by_bow(const plvs_featvec_view* kf_vec, const uint8_t* kf_desc, int kf_n, const uint8_t* kf_valid,
+                          const float* kf_angle, const plvs_featvec_view* f_vec, const uint8_t* f_desc, int f_n,
+                          const float* f_angle, float nn_ratio, int check_orientation, int32_t* assigned) {
+  auto fill_vec = [](DBoW2::FeatureVector& fvv, const plvs_featvec_view* v) {
+    for (int a = 0; a < v->nnodes; ++a)
+      for (int j = v->offset[a]; j < v->offset[a + 1]; ++j) fvv.addFeature(v->node_id[a], v->index[j]);
+  };
+  KeyFrame K;
+  K.N = kf_n;
+  K.NLeft = -1;
+  K.mDescriptors = rows32(kf_desc, kf_n);
+  K.mvKeysUn.resize(kf_n);
+  for (int i = 0; i < kf_n; ++i) K.mvKeysUn[i].angle = kf_angle[i];
+  K.mvKeys = K.mvKeysUn;
+  fill_vec(K.mFeatVec, kf_vec);
+  std::vector<MapPoint> store(kf_n);
+  K.mvpMapPoints.assign(kf_n, static_cast<MapPointPtr>(nullptr));
+  for (int i = 0; i < kf_n; ++i)
+    if (kf_valid[i]) K.mvpMapPoints[i] = &store[i];
+  Frame F;
+  F.N = f_n;
+  F.Nleft = -1;
+  F.mDescriptors = rows32(f_desc, f_n);
+  F.mvKeys.resize(f_n);
+  for (int i = 0; i < f_n; ++i) F.mvKeys[i].angle = f_angle[i];
+  F.mvKeysUn = F.mvKeys;
+  fill_vec(F.mFeatVec, f_vec);
+  std::vector<MapPointPtr> matches;
+  KeyFramePtr pKF = &K;
+  ORBmatcher matcher(nn_ratio, check_orientation != 0);
+  const int n = matcher.SearchByBoW(pKF, F, matches);
+  for (int i = 0; i < f_n; ++i) assigned[i] = matches[i] ? (int32_t)(matches[i] - store.data()) : -1;
+  return n;
+}
+
+}  // extern "C"

@@ -879,6 +879,13 @@ struct plvs_tsdf_chisel {
   DevBuf<uint32_t> st_kfid;
   plvs_tsdf_stats stats{};
   uint32_t last_updated = 0;
+  // queued key-frame clouds (plvs_hip_tsdf_chisel_queue / _flush): uploaded, not yet integrated
+  DevBuf<float> q_xyz;
+  DevBuf<uint8_t> q_rgb;
+  DevBuf<uint32_t> q_kfid;
+  std::vector<int32_t> q_offsets;   // [clouds + 1] once anything is queued
+  std::vector<float> q_Twc;         // 12 per cloud
+  bool q_kfid_given = false;
   // single-walk pipeline (tsdf_walk.hpp)
   WalkCounters* d_wctr = nullptr;   // [2]: the call's counters, the colour pass's voxel list
   WalkCounters* h_wctr = nullptr;   // pinned
@@ -920,6 +927,28 @@ struct plvs_tsdf_chisel {
   int64_t prof_calls = 0;
 };
 
+template <typename T>
+static hipError_t grow_keep(DevBuf<T>& b, size_t used, size_t want) {   // reserve() that keeps the first `used` elements
+  if (want <= b.cap) return hipSuccess;
+  DevBuf<T> nb;
+  hipError_t e = nb.reserve(std::max(want, 2 * b.cap));
+  if (e != hipSuccess) return e;
+  if (used) e = hipMemcpy(nb.p, b.p, used * sizeof(T), hipMemcpyDeviceToDevice);
+  if (e != hipSuccess) { nb.release(); return e; }
+  b.release();
+  b = nb;
+  return hipSuccess;
+}
+
+extern "C" int plvs_hip_tsdf_chisel_flush(plvs_tsdf_chisel* h);
+#define PLVS_FLUSH_QUEUE(h)                                        \
+  do {                                                             \
+    if ((h) && !(h)->q_offsets.empty()) {                          \
+      const int rc_flush_ = plvs_hip_tsdf_chisel_flush(h);         \
+      if (rc_flush_ != PLVS_OK) return rc_flush_;                  \
+    }                                                              \
+  } while (0)
+
 // Chisel::Deform support (tsdf_chisel_deform.hpp)
 static void deform_state_clear(plvs_tsdf_chisel* h);
 static void deform_state_free(plvs_tsdf_chisel* h);
@@ -939,6 +968,16 @@ static int read_counters(plvs_tsdf_chisel* h, hipStream_t s) {
 // ------------------------------------------------------------------ single-walk pipeline (tsdf_walk.hpp)
 constexpr int kWalkStages = 4;
 constexpr unsigned kDeferGrid = 1024;   // workgroups of the general walk over the deferred tiles (it loops over the list)
+// The lean walk comes with two table sizes (tsdf_walk.hpp, FastShared): 2048 entries at two tiles per CU for a call that
+// fills the device, 4096 entries at one tile per CU for the tiles that overflowed 2048 — a dozen in a hundred on an office
+// scene with points up to 5 m away — and for every tile of a call of at most kSmallCallTiles tiles (a few key frames: one
+// tile per CU is all there is to run, and a deferral costs such a call a second walk's latency).  A tile owns
+// kRecStride records (the larger table's limit) in the record buffer.
+constexpr int kFastEntries = 2048, kFastEntriesBig = 4096;
+constexpr uint32_t kRecStride = kFastEntriesBig * 7 / 8;
+constexpr uint32_t kSmallCallTiles = 320;
+constexpr unsigned kListGrid = 512;      // workgroups of the large-table pass over the first list (it loops)
+static_assert(kFastEntries == kWalkEntries, "the shard path sizes its regions by the general kernel's limit");
 const char* const kWalkStageNames[kWalkStages] = {"walk_tiles", "sort_segments", "apply_chunks", "fold_colours"};
 
 static int read_walk_counters(plvs_tsdf_chisel* h, hipStream_t s) {
@@ -1021,9 +1060,9 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
   PLVS_HIP_TRY(h->updated.reserve((size_t)max_chunks + 1));
   PLVS_HIP_TRY(h->w_seg_cnt.reserve(ntiles));
   PLVS_HIP_TRY(h->w_tile_visits.reserve(ntiles));
-  PLVS_HIP_TRY(h->w_deferred.reserve(ntiles));
-  // every tile owns kWalkLimit records / kWalkChunks segments; the spill area behind them grows on demand
-  const size_t rec_own = (size_t)ntiles * kWalkLimit, seg_own = (size_t)ntiles * kWalkChunks;
+  PLVS_HIP_TRY(h->w_deferred.reserve(2 * (size_t)ntiles));   // (two lists: after the 2048-entry pass, after the 4096-entry pass)
+  // every tile owns kRecStride records / kWalkChunks segments; the spill area behind them grows on demand
+  const size_t rec_own = (size_t)ntiles * kRecStride, seg_own = (size_t)ntiles * kWalkChunks;
   if (rec_own + (1 << 16) >= 0xFFFFFFFFull) {
     plvs::set_error("tsdf_chisel integrate: %d points in one call exceed the record index range (split the batch)", n);
     return PLVS_ERR_CAPACITY;
@@ -1061,13 +1100,31 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     RunOut runs{h->w_runkey.p, h->w_masks.p, h->w_run_cnt.p, h->run_r1_log2};
     // the common case of a tile alone in a lean kernel; what it defers (tiles over several clouds, table overflows,
     // the owner-filtered walk of a sharded handle) is walked by the general kernel from the list
-    hipLaunchKernelGGL(walk_fast, dim3(ntiles), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
-                       h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
-                       (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u}, h->w_deferred.p);
+    uint32_t* const list_a = h->w_deferred.p;
+    uint32_t* const list_b = h->w_deferred.p + ntiles;
+    const uint32_t* last_list = list_a;
+    const uint32_t* last_count = &h->d_wctr->ndeferred;
+    if (ntiles <= kSmallCallTiles) {
+      hipLaunchKernelGGL(walk_fast<kFastEntriesBig>, dim3(ntiles), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz,
+                         n, h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
+                         (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u}, kRecStride, (const uint32_t*)nullptr,
+                         (const uint32_t*)nullptr, list_a, &h->d_wctr->ndeferred);
+    } else {
+      hipLaunchKernelGGL(walk_fast<kFastEntries>, dim3(ntiles), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
+                         h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
+                         (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u}, kRecStride, (const uint32_t*)nullptr,
+                         (const uint32_t*)nullptr, list_a, &h->d_wctr->ndeferred);
+      hipLaunchKernelGGL(walk_fast<kFastEntriesBig>, dim3(std::min<unsigned>(ntiles, kListGrid)), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz,
+                         n, h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
+                         (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u}, kRecStride, (const uint32_t*)list_a,
+                         (const uint32_t*)&h->d_wctr->ndeferred, list_b, &h->d_wctr->ndeferred2);
+      last_list = list_b;
+      last_count = &h->d_wctr->ndeferred2;
+    }
     hipLaunchKernelGGL((walk_tiles<true, true>), dim3(kDeferGrid), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
                        h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
-                       (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u}, (uint32_t)ntiles,
-                       (const uint32_t*)h->w_deferred.p, (const uint32_t*)&h->d_wctr->ndeferred);
+                       (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u}, (uint32_t)ntiles, last_list, last_count,
+                       kRecStride);
     PLVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
     STAGE_MARK(1);
     const unsigned seg_blocks = ceil_div(seg_own + seg_spill, kSegSpan);
@@ -1145,7 +1202,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     static const bool trace = plvs::env_int("PLVS_HIP_TSDF_TRACE", 0, 0, 1) != 0;
     if (trace)
       fprintf(stderr, "[tsdf_chisel] tiles %u deferred %u split %u visits %llu runs %u updated %u parts %u multi %u "
-              "rec_top %u seg_top %u voxels %u max_run %u chunks %d\n", ntiles, c.ndeferred, c.split_tiles,
+              "rec_top %u seg_top %u voxels %u max_run %u chunks %d\n", ntiles, c.ndeferred * 1000u + c.ndeferred2, c.split_tiles,
               (unsigned long long)c.total_visits, h->h_wctr[1].num_desc, c.num_updated, c.num_parts, c.num_multi, c.rec_top,
               c.seg_top, c.num_heads, c.max_run, h->num_chunks);
   }
@@ -1350,6 +1407,7 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   if (h->h_sh_counts) (void)hipHostFree(h->h_sh_counts);
   if (h->h_sh_ctl) (void)hipHostFree(h->h_sh_ctl);
   if (h->h_sh_off) (void)hipHostFree(h->h_sh_off);
+  h->q_xyz.release(); h->q_rgb.release(); h->q_kfid.release();
   h->w_rec.release(); h->w_seg.release(); h->w_sorted_seg.release(); h->w_chunk_nseg.release();
   h->w_chunk_off.release(); h->w_chunk_fill.release(); h->w_active_off.release(); h->w_masks.release();
   h->w_dummy.release(); h->w_runkey.release(); h->w_run_cnt.release(); h->w_run_off.release(); h->w_val0.release();
@@ -1378,6 +1436,10 @@ static int shard_state_clear(plvs_tsdf_chisel* h);
 static int halo_drop(plvs_tsdf_chisel* h, hipStream_t s);
 
 int plvs_hip_tsdf_chisel_clear(plvs_tsdf_chisel* h) {
+  if (h) {   // (queued clouds belong to the map that is dropped)
+    h->q_offsets.clear();
+    h->q_Twc.clear();
+  }
   PLVS_REQUIRE(h, "null handle");
   {
     int rc = halo_drop(h, nullptr);
@@ -1644,12 +1706,14 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
                                              const uint8_t* d_rgb, const uint32_t* d_kfid,
                                              const int32_t* offsets, int nclouds,
                                              const float* d_Twc, void* stream) {
+  PLVS_FLUSH_QUEUE(h);
   return integrate_batch_impl(h, d_xyz, d_rgb, d_kfid, offsets, nclouds, d_Twc, stream, nullptr);
 }
 
 int plvs_hip_tsdf_chisel_integrate_world_normals_dev(plvs_tsdf_chisel* h, const float* d_xyz, const uint8_t* d_rgb,
                                                      const uint32_t* d_kfid, const float* d_normals, int n,
                                                      const float* d_Twc, void* stream) {
+  PLVS_FLUSH_QUEUE(h);
   PLVS_REQUIRE(h && n >= 0, "bad arguments");
   PLVS_REQUIRE(n == 0 || d_normals, "null normals");
   PLVS_REQUIRE(std::max(1, h->prm.shard_count) == 1 || h->prm.order_free == 0,
@@ -1660,6 +1724,7 @@ int plvs_hip_tsdf_chisel_integrate_world_normals_dev(plvs_tsdf_chisel* h, const 
 
 int plvs_hip_tsdf_chisel_integrate_world_normals(plvs_tsdf_chisel* h, const float* xyz, const uint8_t* rgb,
                                                  const uint32_t* kfid, const float* normals, int n, const float* Twc) {
+  PLVS_FLUSH_QUEUE(h);
   PLVS_REQUIRE(h, "null handle");
   PLVS_REQUIRE(n >= 0 && Twc, "bad arguments");
   h->stats = plvs_tsdf_stats{};
@@ -1682,10 +1747,64 @@ int plvs_hip_tsdf_chisel_integrate_world_normals(plvs_tsdf_chisel* h, const floa
   return rc;
 }
 
+// ---- queued integration.  PLVS hands a key frame's cloud over with InsertCloud and reads the map only in UpdateMap, after
+// at most five of them (src/PointCloudMapping.cc:540-552, 594-598).  _queue uploads the cloud and returns; _flush
+// integrates everything queued in ONE call of the batch pipeline — the same result as integrating the clouds one by one
+// (bit for bit in the ordered mode: the batch pipeline applies every update in point order across the clouds; within the
+// stated tolerance in the order-free mode, where a voxel takes one update per CALL) at a fraction of the per-call
+// launch chain.  Every entry point that reads or changes the map flushes first.
+int plvs_hip_tsdf_chisel_queue(plvs_tsdf_chisel* h, const float* xyz, const uint8_t* rgb, const uint32_t* kfid, int n,
+                               const float* Twc) {
+  PLVS_REQUIRE(h, "null handle");
+  PLVS_REQUIRE(n >= 0 && Twc, "bad arguments");
+  if (n == 0) return PLVS_OK;
+  PLVS_REQUIRE(xyz && rgb, "null cloud pointer");
+  const bool first = h->q_offsets.empty();
+  PLVS_REQUIRE(first || h->q_kfid_given == (kfid != nullptr), "queued clouds must all carry key-frame ids, or none");
+  const size_t at = first ? 0 : (size_t)h->q_offsets.back();
+  PLVS_REQUIRE(at + (size_t)n < 0x7FFFFFFFull, "too many queued points");
+  PLVS_HIP_TRY(grow_keep(h->q_xyz, 3 * at, 3 * (at + (size_t)n)));
+  PLVS_HIP_TRY(grow_keep(h->q_rgb, 3 * at, 3 * (at + (size_t)n)));
+  PLVS_HIP_TRY(hipMemcpy(h->q_xyz.p + 3 * at, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(h->q_rgb.p + 3 * at, rgb, (size_t)n * 3, hipMemcpyHostToDevice));
+  if (kfid) {
+    PLVS_HIP_TRY(grow_keep(h->q_kfid, at, at + (size_t)n));
+    PLVS_HIP_TRY(hipMemcpy(h->q_kfid.p + at, kfid, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  if (first) h->q_offsets.push_back(0);
+  h->q_kfid_given = kfid != nullptr;
+  h->q_offsets.push_back((int32_t)(at + (size_t)n));
+  h->q_Twc.insert(h->q_Twc.end(), Twc, Twc + 12);
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_chisel_queued(plvs_tsdf_chisel* h, int* nclouds) {
+  PLVS_REQUIRE(h && nclouds, "null argument");
+  *nclouds = h->q_offsets.empty() ? 0 : (int)h->q_offsets.size() - 1;
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_chisel_flush(plvs_tsdf_chisel* h) {
+  PLVS_REQUIRE(h, "null handle");
+  if (h->q_offsets.empty()) return PLVS_OK;
+  const int nclouds = (int)h->q_offsets.size() - 1;
+  std::vector<int32_t> offsets;
+  std::vector<float> Twc;
+  offsets.swap(h->q_offsets);   // (the queue is empty from here on: the integrate below flushes nothing)
+  Twc.swap(h->q_Twc);
+  PLVS_HIP_TRY(h->st_Twc.reserve((size_t)12 * nclouds));
+  PLVS_HIP_TRY(hipMemcpy(h->st_Twc.p, Twc.data(), (size_t)12 * nclouds * sizeof(float), hipMemcpyHostToDevice));
+  int rc = plvs_hip_tsdf_chisel_integrate_batch_dev(h, h->q_xyz.p, h->q_rgb.p, h->q_kfid_given ? h->q_kfid.p : nullptr,
+                                                    offsets.data(), nclouds, h->st_Twc.p, nullptr);
+  if (rc != PLVS_OK) return rc;
+  PLVS_HIP_TRY(hipDeviceSynchronize());
+  return PLVS_OK;
+}
 int plvs_hip_tsdf_chisel_integrate(plvs_tsdf_chisel* h, const float* xyz, const uint8_t* rgb,
                                    const uint32_t* kfid, int n, const float* Twc) {
   PLVS_REQUIRE(h, "null handle");
   PLVS_REQUIRE(n >= 0 && Twc, "bad arguments");
+  PLVS_FLUSH_QUEUE(h);
   if (n == 0) {
     h->stats = plvs_tsdf_stats{};
     h->last_updated = 0;
@@ -1761,6 +1880,7 @@ __global__ void gather_slot_ids(const uint32_t* __restrict__ slots, int n,
 
 int plvs_hip_tsdf_chisel_updated_chunk_ids_dev(plvs_tsdf_chisel* h, int32_t* d_ids_xyz, int cap,
                                                int* n, void* stream) {
+  PLVS_FLUSH_QUEUE(h);
   PLVS_REQUIRE(h && n, "null argument");
   *n = (int)h->last_updated;
   const int m = (int)h->last_updated < cap ? (int)h->last_updated : cap;
@@ -1773,18 +1893,21 @@ int plvs_hip_tsdf_chisel_updated_chunk_ids_dev(plvs_tsdf_chisel* h, int32_t* d_i
 }
 
 int plvs_hip_tsdf_chisel_last_stats(plvs_tsdf_chisel* h, plvs_tsdf_stats* s) {
+  PLVS_FLUSH_QUEUE(h);
   PLVS_REQUIRE(h && s, "null argument");
   *s = h->stats;
   return PLVS_OK;
 }
 
 int plvs_hip_tsdf_chisel_num_chunks(plvs_tsdf_chisel* h, int* n) {
+  PLVS_FLUSH_QUEUE(h);
   PLVS_REQUIRE(h && n, "null argument");
   *n = h->num_chunks;
   return PLVS_OK;
 }
 
 int plvs_hip_tsdf_chisel_chunk_ids(plvs_tsdf_chisel* h, int32_t* ids_xyz, int cap, int* n) {
+  PLVS_FLUSH_QUEUE(h);
   PLVS_REQUIRE(h && n, "null argument");
   *n = h->num_chunks;
   const int m = h->num_chunks < cap ? h->num_chunks : cap;
@@ -1797,6 +1920,7 @@ int plvs_hip_tsdf_chisel_chunk_ids(plvs_tsdf_chisel* h, int32_t* ids_xyz, int ca
 }
 
 int plvs_hip_tsdf_chisel_updated_chunk_ids(plvs_tsdf_chisel* h, int32_t* ids_xyz, int cap, int* n) {
+  PLVS_FLUSH_QUEUE(h);
   PLVS_REQUIRE(h && n, "null argument");
   *n = (int)h->last_updated;
   const int m = (int)h->last_updated < cap ? (int)h->last_updated : cap;
@@ -1820,6 +1944,7 @@ int plvs_hip_tsdf_chisel_updated_chunk_ids(plvs_tsdf_chisel* h, int32_t* ids_xyz
 
 int plvs_hip_tsdf_chisel_download_chunk(plvs_tsdf_chisel* h, int cx, int cy, int cz, float* sdf,
                                         float* weight, uint32_t* kfid, uint32_t* rgbw) {
+  PLVS_FLUSH_QUEUE(h);
   PLVS_REQUIRE(h && sdf && weight && kfid && rgbw, "null argument");
   // linear search of the (host-copied) slot table; a download is a debug /
   // meshing hand-off, not part of the integrate path.
@@ -1915,6 +2040,7 @@ extern "C" int plvs_hip_tsdf_chisel_carve_dev(plvs_tsdf_chisel* h, const float* 
                                               float fx, float fy, float cx, float cy, float near_dist,
                                               float far_dist, const float* Twc, float carving_dist, void* stream,
                                               int* carved_chunks) {
+  PLVS_FLUSH_QUEUE(h);
   PLVS_REQUIRE(h && Twc && carved_chunks, "null argument");
   PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
   PLVS_REQUIRE(width > 0 && height > 0, "empty depth image");
@@ -2157,6 +2283,7 @@ extern "C" {
 // volume saved with download_chunk comes back, and what lets tests put analytic distance fields on the device.
 int plvs_hip_tsdf_chisel_upload_chunk(plvs_tsdf_chisel* h, int cx, int cy, int cz, const float* sdf, const float* weight,
                                       const uint32_t* kfid, const uint32_t* rgbw) {
+  PLVS_FLUSH_QUEUE(h);
   PLVS_REQUIRE(h && sdf && weight && kfid && rgbw, "null argument");
   PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
   if (std::max(1, h->prm.shard_count) > 1)
@@ -2414,13 +2541,14 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
                (uint32_t)std::min<size_t>(seg_own + seg_spill, 0xFFFFFFFFu), h->w_seg_cnt.p, h->w_tile_visits.p};
     RunOut runs{h->w_runkey.p, h->w_masks.p, h->w_run_cnt.p, h->run_r1_log2};
     // (a chunk entered by an attempt that has to be repeated stays in the walk directory: harmless)
-    hipLaunchKernelGGL(walk_fast, dim3(nt), dim3(kWalkRays), 0, s, Pw, h->scale_u, h->scale_w, d_xyz, n,
+    hipLaunchKernelGGL(walk_fast<kFastEntries>, dim3(nt), dim3(kWalkRays), 0, s, Pw, h->scale_u, h->scale_w, d_xyz, n,
                        h->offsets.p, nclouds, h->poses.p, h->xdir, h->d_xcount, h->d_wctr, (const uint32_t*)nullptr,
-                       (const uint32_t*)h->x_sat, out, runs, tmap, h->w_deferred.p);
+                       (const uint32_t*)h->x_sat, out, runs, tmap, (uint32_t)kWalkLimit, (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, h->w_deferred.p, &h->d_wctr->ndeferred);
     hipLaunchKernelGGL((walk_tiles<true, true>), dim3(kDeferGrid), dim3(kWalkRays), 0, s, Pw, h->scale_u, h->scale_w, d_xyz, n,
                        h->offsets.p, nclouds, h->poses.p, h->xdir, h->d_xcount, h->d_wctr, (const uint32_t*)nullptr,
                        (const uint32_t*)h->x_sat, out, runs, tmap, (uint32_t)nt, (const uint32_t*)h->w_deferred.p,
-                       (const uint32_t*)&h->d_wctr->ndeferred);
+                       (const uint32_t*)&h->d_wctr->ndeferred, (uint32_t)kWalkLimit);
     const unsigned seg_blocks = ceil_div(seg_own + seg_spill, kSegSpan);
     hipLaunchKernelGGL(seg_pass<false>, dim3(seg_blocks), dim3(256), 0, s, h->w_seg.p, out.seg_cap, nt, h->w_seg_cnt.p,
                        h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p, h->d_wctr);

@@ -424,6 +424,7 @@ int plvs_hip_tsdf_chisel_enable_deform(plvs_tsdf_chisel* h) {
 
 int plvs_hip_tsdf_chisel_chunk_order(plvs_tsdf_chisel* h, int32_t* ids_xyz, int cap, int* n) {
   PLVS_REQUIRE(h && n, "null argument");
+  PLVS_FLUSH_QUEUE(h);
   PLVS_REQUIRE(h->dfm, "deform is not enabled on this map");
   *n = (int)h->dfm->chunks.size();
   PLVS_REQUIRE(cap >= *n && (ids_xyz || *n == 0), "id buffer too small");
@@ -438,6 +439,7 @@ int plvs_hip_tsdf_chisel_chunk_order(plvs_tsdf_chisel* h, int32_t* ids_xyz, int 
 int plvs_hip_tsdf_chisel_deform(plvs_tsdf_chisel* h, const uint32_t* kfids, const float* Rt, int n_map,
                                 plvs_tsdf_deform_stats* out) {
   PLVS_REQUIRE(h, "null handle");
+  PLVS_FLUSH_QUEUE(h);
   PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
   PLVS_REQUIRE(h->dfm, "deform is not enabled on this map (plvs_hip_tsdf_chisel_enable_deform on the empty map)");
   PLVS_REQUIRE(n_map >= 0 && (n_map == 0 || (kfids && Rt)), "bad deformation map");

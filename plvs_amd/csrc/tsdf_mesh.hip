@@ -515,6 +515,10 @@ static int mesh_run(plvs_tsdf_chisel* h, const int32_t* chunk_ids_xyz, int nchun
 extern "C" int plvs_hip_tsdf_chisel_mesh_chunks(plvs_tsdf_chisel* h, const int32_t* chunk_ids_xyz, int nchunks,
                                                 float* vertices, float* normals, float* colors, uint32_t* kfids,
                                                 int capacity, int32_t* chunk_first, int* nvertices) {
+  if (h) {   // (queued clouds are part of the map that is meshed)
+    const int rc = plvs_hip_tsdf_chisel_flush(h);
+    if (rc != PLVS_OK) return rc;
+  }
   return mesh_run(h, chunk_ids_xyz, nchunks, vertices, normals, colors, kfids, capacity, chunk_first, nvertices, false,
                   nullptr);
 }
@@ -522,6 +526,10 @@ extern "C" int plvs_hip_tsdf_chisel_mesh_chunks(plvs_tsdf_chisel* h, const int32
 extern "C" int plvs_hip_tsdf_chisel_mesh_probe(plvs_tsdf_chisel* h, const int32_t* chunk_ids_xyz, int nchunks,
                                                int* nmissing) {
   PLVS_REQUIRE(nmissing != nullptr, "null nmissing");
+  if (h) {
+    const int rc = plvs_hip_tsdf_chisel_flush(h);
+    if (rc != PLVS_OK) return rc;
+  }
   *nmissing = 0;
   std::vector<int32_t> first((size_t)(nchunks > 0 ? nchunks : 0) + 1);
   int nv = 0;

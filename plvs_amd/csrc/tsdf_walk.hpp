@@ -102,7 +102,8 @@ struct WalkCounters {           // device-side, read back once per call
   uint32_t split_tiles;         // tiles that had to be cut (table overflow)
   uint32_t num_parts;           // apply stage: sum over the updated chunks of their parts
   uint32_t num_multi;           //   chunks applied in more than one part
-  uint32_t ndeferred;           // tiles walk_fast left to walk_tiles (several clouds in the tile, table overflow)
+  uint32_t ndeferred;           // tiles walk_fast left to the next kernel (several clouds in the tile, table overflow)
+  uint32_t ndeferred2;          //   and what the larger-table pass over that list left to walk_tiles
 };
 
 // ------------------------------------------------------------------ the walk of one (sub-)tile
@@ -124,7 +125,9 @@ constexpr uint32_t kKeyEmpty = 0xFFFFFFFFu;
 constexpr int kBuckets = kWalkEntries / 4;
 constexpr int kOriginBias = 512;
 
+constexpr int log2_of(int v) { return v <= 1 ? 0 : 1 + log2_of(v / 2); }
 struct WalkShared {       // LDS state of walk_tiles
+  static constexpr int kEntries = kWalkEntries, kBucketCount = kWalkEntries / 4, kBucketShift = 32 - log2_of(kWalkEntries / 4);
   alignas(16) uint32_t ekey[kWalkEntries];
   int32_t org[3];                              // origin of the keys
   uint32_t cand[kWalkRays / 64];               // does the wave have a walking ray ...
@@ -142,8 +145,14 @@ struct WalkShared {       // LDS state of walk_tiles
   uint32_t wsum[kWalkRays / 64];
   uint32_t next, nrays;   // rays of the tile not yet handed out as sub-tiles / rays of the tile
 };
-struct FastShared {       // LDS state of walk_fast: WalkShared without the sub-tile stack (four tiles per CU: 40 KiB each)
-  alignas(16) uint32_t ekey[kWalkEntries];
+// LDS state of walk_fast<E>: WalkShared without the sub-tile stack, the table size a template parameter (E = 2048: two
+// tiles per CU, the kernel of a long call; E = 4096: one tile per CU — the tiles that overflowed 2048 entries, and
+// every tile of a call too short to fill the device, where the occupancy is immaterial and a deferral is not)
+template <int E>
+struct FastShared {
+  static constexpr int kEntries = E, kBucketCount = E / 4, kBucketShift = 32 - log2_of(E / 4);
+  static_assert((E & (E - 1)) == 0 && E >= 1024, "power-of-two table");
+  alignas(16) uint32_t ekey[E];
   uint32_t cand[kWalkRays / 64];
   int32_t worg[kWalkRays / 64][3];
   uint32_t run_total, vis_total;
@@ -185,8 +194,8 @@ constexpr uint32_t kKeyMul = 2654435761u, kKeyMulInv = 0x0E8B2F51u;
 static_assert((uint32_t)(kKeyMul * kKeyMulInv) == 1u, "inverse of the table-key multiplier");
 __device__ __forceinline__ uint32_t table_key(uint32_t key) { return key * kKeyMul; }
 __device__ __forceinline__ uint32_t voxel_key(uint32_t tkey) { return tkey * kKeyMulInv; }
-__device__ __forceinline__ uint32_t key_bucket(uint32_t tkey) { return tkey >> (kBuckets == 256 ? 24 : 23); }
-static_assert(kBuckets == 256 || kBuckets == 512, "key_bucket yields 8 or 9 bits");
+template <class SH>
+__device__ __forceinline__ uint32_t key_bucket(uint32_t tkey) { return tkey >> SH::kBucketShift; }
 
 // Inclusive prefix sum over the 64 lanes of a wave by DPP (row shifts inside the rows of 16, then the row broadcasts):
 // six VALU instructions, no LDS traffic (a __shfl_up is a ds_bpermute_b32 through the LDS crossbar).
@@ -220,7 +229,7 @@ __device__ __forceinline__ int bucket_match(const uint4 k4, uint32_t want) {
 constexpr int kProbeCap = 24;
 template <class SH>
 __device__ __forceinline__ int table_find_or_insert(SH& S, uint32_t key /* a table key */) {
-  uint32_t b = key_bucket(key);
+  uint32_t b = key_bucket<SH>(key);
   // (kProbeCap: a tile within its limit — three quarters of the table — never chains that far; a table on its way to
   // full does, and every probe is an LDS round trip: without the cap the rays of an overflowing tile spent hundreds of
   // probes each before they gave up, ~1 ms per tile on the office stream of bench.py)
@@ -234,7 +243,7 @@ __device__ __forceinline__ int table_find_or_insert(SH& S, uint32_t key /* a tab
       if (old == kKeyEmpty || old == key) return (int)(4 * b) + je;
       continue;   // another voxel took the slot: look at this bucket again
     }
-    b = (b + 1) & (kBuckets - 1);
+    b = (b + 1) & (SH::kBucketCount - 1);
   }
   S.overflow = 1u;
   return -1;
@@ -242,11 +251,11 @@ __device__ __forceinline__ int table_find_or_insert(SH& S, uint32_t key /* a tab
 // Entry of a (table) key that is known to be in the table.
 template <class SH>
 __device__ __forceinline__ int table_find(const SH& S, uint32_t key) {
-  uint32_t b = key_bucket(key);
-  for (int probe = 0; probe < kBuckets; ++probe) {
+  uint32_t b = key_bucket<SH>(key);
+  for (int probe = 0; probe < SH::kBucketCount; ++probe) {
     const int j = bucket_match(*reinterpret_cast<const uint4*>(&S.ekey[4 * b]), key);
     if (j >= 0) return (int)(4 * b) + j;
-    b = (b + 1) & (kBuckets - 1);
+    b = (b + 1) & (SH::kBucketCount - 1);
   }
   return -1;
 }
@@ -418,7 +427,7 @@ __device__ __forceinline__ uint32_t walk_lean(const Params& P, const Pose& pose,
       // general search's business
       int e;
       {
-        const uint32_t b = key_bucket(key);
+        const uint32_t b = key_bucket<SH>(key);
         const uint4 k4 = *reinterpret_cast<const uint4*>(&S.ekey[4 * b]);
         const int j = bucket_match(k4, key);
         if (j >= 0) {
@@ -471,7 +480,7 @@ __device__ __forceinline__ bool tile_ray(const Params& P, const float* __restric
 template <class SH>
 __device__ __forceinline__ void subtile_reset(SH& S, int tid) {
 #pragma unroll
-  for (int k = 0; k < kWalkEntries / kWalkRays; ++k) S.ekey[tid + k * kWalkRays] = kKeyEmpty;
+  for (int k = 0; k < SH::kEntries / kWalkRays; ++k) S.ekey[tid + k * kWalkRays] = kKeyEmpty;
   if (tid < kWalkChunks) {
     S.ccode[tid] = kKeyEmpty;
     S.cslot[tid] = -1;
@@ -598,7 +607,7 @@ __global__ __launch_bounds__(kWalkRays, kWalkEntries > 1024 ? 4 : 6) void walk_t
     const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
     int32_t* __restrict__ num_chunks, WalkCounters* __restrict__ ctr, const uint32_t* __restrict__ rgbw,
     const uint32_t* __restrict__ sat, AccOut out, RunOut runs, TileMap tmap, uint32_t ntiles,
-    const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ ntile_list) {
+    const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ ntile_list, uint32_t rec_stride) {
   constexpr int kPer = kWalkEntries / kWalkRays;
   __shared__ WalkShared S;
   __shared__ uint32_t raw[kMaskCap * kMaskWords];              // accumulators during the walk, ray masks afterwards
@@ -877,7 +886,7 @@ __global__ __launch_bounds__(kWalkRays, kWalkEntries > 1024 ? 4 : 6) void walk_t
       // behind a barrier; wave 0 alone writes the segment descriptors.  Later flushes (a tile that was cut) take their
       // regions from the spill counters: wave 0 scans, the others wait.
       const bool own_region = flushes == 0;
-      uint32_t rbase = tile * (uint32_t)kWalkLimit;
+      uint32_t rbase = tile * rec_stride;
       if (own_region || tid < 64) {
         const int cl = lane;   // the chunk of this lane
         uint32_t sub[kSlabs], c = 0;
@@ -896,7 +905,7 @@ __global__ __launch_bounds__(kWalkRays, kWalkEntries > 1024 ? 4 : 6) void walk_t
         uint32_t sbase = tile * (uint32_t)kWalkChunks;
         if (!own_region) {
           if (tid == 0 && tot) {
-            rbase = ntiles * (uint32_t)kWalkLimit + atomicAdd(&ctr->rec_top, tot);
+            rbase = ntiles * rec_stride + atomicAdd(&ctr->rec_top, tot);
             sbase = ntiles * (uint32_t)kWalkChunks + atomicAdd(&ctr->seg_top, stot);
             if (rbase + tot > out.rec_cap || sbase + stot > out.seg_cap) atomicOr(&ctr->err, kErrScratch);
           }
@@ -931,7 +940,7 @@ __global__ __launch_bounds__(kWalkRays, kWalkEntries > 1024 ? 4 : 6) void walk_t
         if (ci[k] >= 0) {
           at = rbase + S.cbase[ci[k] * kSlabs + (int)(vid / kSlabVox)] + rank[k];
         } else {   // beyond the chunk cache (scattered clouds): a segment of its own in the spill area
-          at = ntiles * (uint32_t)kWalkLimit + atomicAdd(&ctr->rec_top, 1u);
+          at = ntiles * rec_stride + atomicAdd(&ctr->rec_top, 1u);
           const uint32_t sg = ntiles * (uint32_t)kWalkChunks + atomicAdd(&ctr->seg_top, 1u);
           if (at >= out.rec_cap || sg >= out.seg_cap) {
             atomicOr(&ctr->err, kErrScratch);
@@ -1083,33 +1092,39 @@ __global__ __launch_bounds__(kWalkRays, kWalkEntries > 1024 ? 4 : 6) void walk_t
 // (every entry resolves its own chunk with dir_find_or_insert — no directory phase, no prefetch), no records, segments
 // or runs; its index goes to a list and walk_tiles (the general kernel) walks the list behind this kernel.  Same
 // outputs, same regions, bit for bit the same records either way.
-#ifndef PLVS_WALK_FAST_WAVES
-#define PLVS_WALK_FAST_WAVES (PLVS_WALK_ENTRIES > 1024 ? 4 : 6)   // (waves per SIMD the tile's LDS allows: 2 x 62 KiB / 4 x 40 KiB per CU)
-#endif
-__global__ __launch_bounds__(kWalkRays, PLVS_WALK_FAST_WAVES) void walk_fast(
-    Params P, float scale_u, float scale_w, const float* __restrict__ xyz, int npoints,
-    const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
+// E = table entries (see FastShared).  tile_list = nullptr: workgroup b walks tile b; otherwise the tiles of a list an
+// earlier launch left (entries with bit 31: tiles that overflowed ITS table — the others are not this kernel's case
+// either and go straight on to `deferred`), *ntile_list of them.  rec_stride = records a tile owns in out.rec (the
+// host sizes the regions for the largest table it launches).
+constexpr int walk_fast_waves(int E) { return E > 2048 ? 2 : (E > 1024 ? 4 : 6); }   // waves per SIMD the tile's LDS allows
+template <int E>
+__device__ __forceinline__ void walk_fast_tile(
+    const Params& P, float scale_u, float scale_w, const float* __restrict__ xyz, int npoints,
+    const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, const Directory& dir,
     int32_t* __restrict__ num_chunks, WalkCounters* __restrict__ ctr, const uint32_t* __restrict__ rgbw,
-    const uint32_t* __restrict__ sat, AccOut out, RunOut runs, TileMap tmap, uint32_t* __restrict__ deferred) {
-  constexpr int kPer = kWalkEntries / kWalkRays;
-  __shared__ FastShared S;
-  __shared__ uint32_t raw[kMaskCap * kMaskWords];              // accumulators during the walk, ray masks afterwards
+    const uint32_t* __restrict__ sat, const AccOut& out, const RunOut& runs, const TileMap& tmap, uint32_t rec_stride,
+    uint32_t* __restrict__ deferred, uint32_t* __restrict__ ndeferred, const uint32_t tile, const bool listed_other) {
+  constexpr int kPer = E / kWalkRays;
+  constexpr int kLimit = E * 7 / 8;          // entries a tile may use (kWalkLimit of the general kernel's table)
+  constexpr int kMaskCapE = E / 4;           // ray masks built per round: the area of the accumulators
+  __shared__ FastShared<E> S;
+  __shared__ uint32_t raw[4 * E];                              // accumulators during the walk, ray masks afterwards
   __shared__ uint16_t vlog[kLogLen * kWalkRays];        // entry of visit k of ray r at [k * kWalkRays + r]
   // mask index of the entry (0xFFFF: none) — in the words of the (chunk, slab) counters, dead once the records are out,
   // where they hold it
-  constexpr bool kMidxOverlay = sizeof(S.ccnt) >= kWalkEntries * sizeof(uint16_t);
-  __shared__ uint16_t e_midx_own[kMidxOverlay ? 1 : kWalkEntries];
+  constexpr bool kMidxOverlay = sizeof(S.ccnt) >= E * sizeof(uint16_t);
+  __shared__ uint16_t e_midx_own[kMidxOverlay ? 1 : E];
   uint16_t* const e_midx = kMidxOverlay ? reinterpret_cast<uint16_t*>(S.ccnt) : e_midx_own;
   int32_t* const e_wuu = reinterpret_cast<int32_t*>(raw);                                 // sum of w_u * u, fixed point
-  unsigned long long* const e_wc = reinterpret_cast<unsigned long long*>(raw + kWalkEntries);   // visits << 32 | sum of w_u
-  uint32_t* const e_last = raw + 3 * kWalkEntries;                                        // last visiting ray
+  unsigned long long* const e_wc = reinterpret_cast<unsigned long long*>(raw + E);   // visits << 32 | sum of w_u
+  uint32_t* const e_last = raw + 3 * E;                                             // last visiting ray
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const uint32_t tile = blockIdx.x;                       // the local tile: output regions
+  // (tile = the local tile: output regions; listed_other = a listed tile that is not an overflow: passed on)
   const uint32_t gtile = tmap.tile_of(tile);             // its place in the point stream
   const uint32_t first = gtile * kWalkRays;
   const uint32_t nrays = min((uint32_t)kWalkRays, (uint32_t)npoints - first);
   const int cloud = cloud_of(offsets, nclouds, (int)first);
-  bool defer = (uint32_t)(offsets[cloud + 1] - (int32_t)first) < nrays || P.shard_count > 1;   // (uniform)
+  bool defer = (uint32_t)(offsets[cloud + 1] - (int32_t)first) < nrays || P.shard_count > 1 || listed_other;   // (uniform)
   uint32_t nv = 0;
   bool walks = false;
   int ox = 0, oy = 0, oz = 0;
@@ -1228,14 +1243,14 @@ __global__ __launch_bounds__(kWalkRays, PLVS_WALK_FAST_WAVES) void walk_fast(
   // (one barrier: the ranks are complete, the tile's entries are counted — and does any voxel that needs a run have
   // more than one visiting ray?)
   const bool any_multi = __syncthreads_or(multi ? 1 : 0) != 0;                              // ---- barrier 3
-  const bool too_many = !defer && S.nent > (uint32_t)kWalkLimit;   // (the voxels do not fit: walk_tiles cuts the tile at once)
+  const bool too_many = !defer && S.nent > (uint32_t)kLimit;   // (the voxels do not fit: the next kernel's table is larger / walk_tiles cuts the tile at once)
   if (!defer) defer = S.overflow != 0 || too_many;
   if (defer) {
     if (tid == 0) {
       out.seg_cnt[tile] = 0;
       runs.run_cnt[tile] = 0;
       out.tile_visits[tile] = 0;
-      deferred[atomicAdd(&ctr->ndeferred, 1u)] = tile | (too_many ? 0x80000000u : 0u);
+      deferred[atomicAdd(ndeferred, 1u)] = tile | (too_many ? 0x80000000u : 0u);
     }
     return;
   }
@@ -1246,7 +1261,7 @@ __global__ __launch_bounds__(kWalkRays, PLVS_WALK_FAST_WAVES) void walk_fast(
   // ---- records: the (chunk, slab) groups are placed by a scan over the cache's 64 chunks, one lane per chunk.  EVERY
   // wave runs the scan and writes the same table of group bases — a wave reads back its own LDS writes in order, so
   // nobody waits for wave 0 behind a barrier; wave 0 alone writes the segment descriptors.
-  const uint32_t rbase = tile * (uint32_t)kWalkLimit;
+  const uint32_t rbase = tile * rec_stride;
   {
     uint32_t sub[kSlabs], c = 0;
 #pragma unroll
@@ -1329,16 +1344,16 @@ __global__ __launch_bounds__(kWalkRays, PLVS_WALK_FAST_WAVES) void walk_fast(
 #pragma unroll
       for (int k = 0; k < kPer; ++k) e_midx[tid + k * kWalkRays] = (need & (1u << k)) ? (uint16_t)m++ : (uint16_t)0xFFFFu;
     }
-    for (uint32_t r0 = 0; fits_runs && r0 < nruns; r0 += kMaskCap) {
+    for (uint32_t r0 = 0; fits_runs && r0 < nruns; r0 += kMaskCapE) {
       __syncthreads();   // e_midx complete / the previous round's masks are out
 #pragma unroll
-      for (int k = 0; k < kMaskCap * kMaskWords / kWalkRays; ++k) raw[tid + k * kWalkRays] = 0u;
+      for (int k = 0; k < kMaskCapE * kMaskWords / kWalkRays; ++k) raw[tid + k * kWalkRays] = 0u;
       __syncthreads();
       if (nv) {
         const uint32_t logged = min(nv, (uint32_t)kLogLen);
         for (uint32_t k = 0; k < logged; ++k) {
           const uint32_t m = (uint32_t)e_midx[vlog[k * kWalkRays + tid]] - r0;   // 0xFFFF - r0 stays out of range
-          if (m < (uint32_t)kMaskCap) atomicOr(&raw[m * kMaskWords + (tid >> 5)], 1u << (tid & 31));
+          if (m < (uint32_t)kMaskCapE) atomicOr(&raw[m * kMaskWords + (tid >> 5)], 1u << (tid & 31));
         }
         if (nv > (uint32_t)kLogLen) {   // the log is full: the rest of the ray is walked again
           const Pose& pose = poses[cloud];
@@ -1349,7 +1364,7 @@ __global__ __launch_bounds__(kWalkRays, PLVS_WALK_FAST_WAVES) void walk_fast(
                 uint32_t key;
                 const int e = rel_key(vx, vy, vz, ox, oy, oz, &key) ? table_find(S, table_key(key)) : -1;
                 const uint32_t m = e >= 0 ? (uint32_t)e_midx[e] - r0 : 0xFFFFFFFFu;
-                if (m < (uint32_t)kMaskCap) atomicOr(&raw[m * kMaskWords + (tid >> 5)], 1u << (tid & 31));
+                if (m < (uint32_t)kMaskCapE) atomicOr(&raw[m * kMaskWords + (tid >> 5)], 1u << (tid & 31));
               }
               return true;
             });
@@ -1359,7 +1374,7 @@ __global__ __launch_bounds__(kWalkRays, PLVS_WALK_FAST_WAVES) void walk_fast(
 #pragma unroll
       for (int k = 0; k < kPer; ++k) {
         const uint32_t m = (uint32_t)e_midx[tid + k * kWalkRays];
-        if (m == 0xFFFFu || m < r0 || m >= r0 + (uint32_t)kMaskCap) continue;
+        if (m == 0xFFFFu || m < r0 || m >= r0 + (uint32_t)kMaskCapE) continue;
         const size_t d = ((size_t)tile << runs.r1_log2) + m;
         runs.dkey[d] = vkey[k];
         const uint32_t* mk = raw + (m - r0) * kMaskWords;
@@ -1375,6 +1390,30 @@ __global__ __launch_bounds__(kWalkRays, PLVS_WALK_FAST_WAVES) void walk_fast(
   if (tid == 0) {
     runs.run_cnt[tile] = min(S.run_total, 1u << runs.r1_log2);
     out.tile_visits[tile] = S.vis_total;
+  }
+}
+
+template <int E>
+__global__ __launch_bounds__(kWalkRays, walk_fast_waves(E)) void walk_fast(
+    Params P, float scale_u, float scale_w, const float* __restrict__ xyz, int npoints,
+    const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
+    int32_t* __restrict__ num_chunks, WalkCounters* __restrict__ ctr, const uint32_t* __restrict__ rgbw,
+    const uint32_t* __restrict__ sat, AccOut out, RunOut runs, TileMap tmap, uint32_t rec_stride,
+    const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ ntile_list, uint32_t* __restrict__ deferred,
+    uint32_t* __restrict__ ndeferred) {
+  if (!tile_list) {
+    walk_fast_tile<E>(P, scale_u, scale_w, xyz, npoints, offsets, nclouds, poses, dir, num_chunks, ctr, rgbw, sat, out, runs,
+                      tmap, rec_stride, deferred, ndeferred, blockIdx.x, false);
+    return;
+  }
+  // a list: the workgroups of a small grid take its entries in turn (a grid of one workgroup per POSSIBLE entry would
+  // queue thousands of empty workgroups behind the one-per-CU limit of the large table's LDS)
+  const uint32_t nlist = *ntile_list;
+  for (uint32_t lb = blockIdx.x; lb < nlist; lb += gridDim.x) {
+    const uint32_t e = tile_list[lb];
+    walk_fast_tile<E>(P, scale_u, scale_w, xyz, npoints, offsets, nclouds, poses, dir, num_chunks, ctr, rgbw, sat, out, runs,
+                      tmap, rec_stride, deferred, ndeferred, e & 0x7FFFFFFFu, (e >> 31) == 0u);
+    __syncthreads();   // (the next tile reuses the shared state)
   }
 }
 

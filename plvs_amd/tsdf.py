@@ -58,6 +58,29 @@ class TsdfChisel:
         _lib.check(_lib.lib.plvs_hip_tsdf_chisel_integrate(
             self._h, _lib.np_ptr(xyz), _lib.np_ptr(rgb), _lib.np_ptr(kfid), xyz.shape[0], _lib.np_ptr(Twc)))
 
+    def queue(self, xyz, rgb, kfid, Twc):
+        """Host flavour, deferred: the cloud is uploaded and integrated by the next flush() — or by whatever reads or
+        changes the map first — together with everything else queued, in ONE call of the batch pipeline."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8).reshape(-1, 3)
+        kfid = None if kfid is None else np.ascontiguousarray(kfid, dtype=np.uint32)
+        Twc = np.ascontiguousarray(Twc, dtype=np.float32).reshape(3, 4)
+        f = _lib.lib.plvs_hip_tsdf_chisel_queue
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        _lib.check(f(self._h, _lib.np_ptr(xyz), _lib.np_ptr(rgb), _lib.np_ptr(kfid), xyz.shape[0], _lib.np_ptr(Twc)))
+
+    def flush(self):
+        f = _lib.lib.plvs_hip_tsdf_chisel_flush
+        f.argtypes = [ctypes.c_void_p]
+        _lib.check(f(self._h))
+
+    def queued(self):
+        n = ctypes.c_int()
+        f = _lib.lib.plvs_hip_tsdf_chisel_queued
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        _lib.check(f(self._h, ctypes.byref(n)))
+        return n.value
+
     def carve(self, depth, fx, fy, cx, cy, Twc, near=0.05, far=5.0, carving_dist=0.05):
         """Depth-image carving (Chisel.cpp:394-438 / ProjectionIntegrator::CarveWithDepth); depth is a
         float32 image (NaN = no measurement).  Returns the number of carved chunks."""
@@ -645,7 +668,13 @@ class PointCloudMapChisel:
 
     def __init__(self, resolution, min_depth=0.1, max_depth=5.0, use_carving=False, max_chunks=None,
                  carving_dist=0.05, near_plane_dist=0.05, far_plane_dist=5.0, bResetOnSparseMapChange=True,
-                 bCloudDeformationOnSparseMapChange=False):
+                 bCloudDeformationOnSparseMapChange=False, queue_insertions=True):
+        # queue_insertions: InsertCloud uploads the key frame's cloud and UpdateMap (or whatever reads or changes the map
+        # first) integrates the ones waiting — at most five between two UpdateMap calls of PointCloudMapping — in one
+        # batch: the reference only reads the map in UpdateMap (src/PointCloudMapping.cc:540-552, 594-598), and the batch
+        # gives the same map bit for bit in the (default) ordered mode.  Off with the deformation bookkeeping, which
+        # follows the map call by call.
+        self.queue_insertions = queue_insertions and not bCloudDeformationOnSparseMapChange
         self.resolution = resolution
         self.min_depth, self.max_depth = min_depth, max_depth
         self.use_carving, self.carving_dist = use_carving, carving_dist
@@ -663,18 +692,31 @@ class PointCloudMapChisel:
         the pcl point), kfid [n] u32.  Twc: 3x4 (or 4x4) camera pose."""
         print("PointCloudMapChisel<PointT>::InsertCloud()")
         Twc = np.asarray(Twc, dtype=np.float32)[:3, :4]
+        if self.queue_insertions:
+            self._tsdf.queue(cloud_camera["xyz"], cloud_camera["rgb"], cloud_camera.get("kfid"), Twc)
+            return
         self._tsdf.integrate(cloud_camera["xyz"], cloud_camera["rgb"], cloud_camera.get("kfid"), Twc)
+        self._mark_updated()
+
+    def _mark_updated(self):
         for c in self._tsdf.updated_chunk_ids():          # Chisel.cpp:553-568
             for dx in (-1, 0, 1):
                 for dy in (-1, 0, 1):
                     for dz in (-1, 0, 1):
                         self._meshes_to_update.add((int(c[0]) + dx, int(c[1]) + dy, int(c[2]) + dz))
 
+    def _flush(self):
+        """Integrates the queued key frames (one batch) and notes the meshes they invalidate."""
+        if self._tsdf.queued():
+            self._tsdf.flush()
+            self._mark_updated()
+
     def InsertCloudWithDepth(self, cloud_camera, Twc, depthImage, fx, fy, cx, cy, max_range=None):
         """src/PointCloudMapChisel.cc:100-133: with useCarving the depth image's frustum is carved first
         (Chisel.cpp:394-438), then the cloud is integrated."""
         Twc = np.asarray(Twc, dtype=np.float32)[:3, :4]
         if self.use_carving:
+            self._flush()      # (carving reads and changes the map: what is waiting goes in first)
             n = self._tsdf.carve(depthImage, fx, fy, cx, cy, Twc, near=self.near_plane_dist, far=self.far_plane_dist,
                                  carving_dist=self.carving_dist)
             if n:      # meshesToUpdate[chunkID] = true for every carved chunk, the chunk alone (Chisel.cpp:432)
@@ -685,6 +727,7 @@ class PointCloudMapChisel:
     def UpdateMap(self):
         """UpdateMesh + GetPointCloud (src/PointCloudMapChisel.cc:228-246): -> the output cloud as a structured
         array (x, y, z, normal, r, g, b, kfid), meshes walked in chunk-id order."""
+        self._flush()
         todo = sorted(self._meshes_to_update)
         if todo:
             m = self._tsdf.mesh_chunks(np.array(todo, np.int32))
@@ -727,6 +770,7 @@ class PointCloudMapChisel:
             xyz = np.stack([cloud["x"], cloud["y"], cloud["z"]], -1)
             rgb = np.stack([cloud["r"], cloud["g"], cloud["b"]], -1)
             kfid, nrm = cloud["kfid"], cloud["normal"]
+        self._flush()
         self._tsdf.integrate_world_normals(xyz, rgb, kfid, nrm)
         for c in self._tsdf.updated_chunk_ids():          # Chisel.cpp:349-365
             for dx in (-1, 0, 1):

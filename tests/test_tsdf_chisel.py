@@ -172,6 +172,104 @@ def test_hip_batch_equals_sequential_and_oracle(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("order_free", [False, True])
+def test_hip_queued_clouds_equal_one_by_one(oracle, order_free):
+    """plvs_hip_tsdf_chisel_queue + _flush (what the PointCloudMapChisel mirrors do between two UpdateMap calls) against
+    one integrate call per key frame: the same map bit for bit in the ordered mode, both within the stated tolerance of
+    the oracle in the order-free mode; whatever reads the map flushes the queue."""
+    from plvs_amd.tsdf import TsdfChisel
+    kfs = make_keyframes(5, cam=small_cam(2), seed=29)
+    ora = oracle.chisel(0.05)
+    one = TsdfChisel(0.05, max_chunks=4096, order_free=order_free)
+    que = TsdfChisel(0.05, max_chunks=4096, order_free=order_free)
+    for kf in kfs[:2]:
+        for m in (ora, one):
+            m.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+        que.queue(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+    assert que.queued() == 2
+    que.flush()
+    assert que.queued() == 0 and que.last_stats()["points"] == sum(k["xyz"].shape[0] for k in kfs[:2])
+    for kf in kfs[2:]:
+        for m in (ora, one):
+            m.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+        que.queue(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+    assert que.queued() == 3
+    n = que.num_chunks()                 # a reader: flushes
+    assert que.queued() == 0 and n == one.num_chunks()
+    if order_free:
+        for dev in (one, que):
+            for cid in map(tuple, ora.chunk_ids()):
+                a, b = ora.get_chunk(*cid), dev.get_chunk(*cid)
+                known = a[1] > 0
+                assert np.array_equal(known, b[1] > 0) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+                assert np.abs(a[0][known] - b[0][known]).max(initial=0) <= 2e-5
+                assert (np.abs(a[1][known] - b[1][known]) / a[1][known]).max(initial=0) <= 5e-5
+    else:
+        compare_maps(ora, one)
+        compare_maps(one, que)
+    que.queue(kfs[0]["xyz"], kfs[0]["rgb"], kfs[0]["kfid"], kfs[0]["Twc"])
+    que.clear()                          # the queue goes with the map
+    assert que.queued() == 0 and que.num_chunks() == 0
+    one.close()
+    que.close()
+
+
+@pytest.mark.gpu
+def test_mirror_queues_insertions_until_update_map():
+    """PointCloudMapChisel(queue_insertions=True) — InsertCloud uploads, UpdateMap integrates what waits in one batch —
+    gives the output cloud of the call-by-call mirror byte for byte (ordered mode)."""
+    from plvs_amd.tsdf import PointCloudMapChisel
+    kfs = make_keyframes(6, cam=small_cam(2), seed=31)
+    outs = []
+    for q in (False, True):
+        m = PointCloudMapChisel(0.05, max_chunks=4096, queue_insertions=q)
+        clouds = []
+        for i, kf in enumerate(kfs):
+            m.InsertCloud(kf, kf["Twc"])
+            if i in (2, 5):
+                clouds.append(m.UpdateMap())
+        outs.append(clouds)
+        m.Clear()
+    for a, b in zip(*outs):
+        assert len(a) == len(b) > 1000 and a.tobytes() == b.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order_free", [True, False])
+def test_hip_far_points_fill_the_tile_tables(oracle, order_free):
+    """Key frames of the office stream of bench.py — points up to 5 m away: a tile of 512 rays touches 800 - 2000 voxels —
+    at full resolution: tiles that fit the 2048-entry table, tiles that take the 4096-entry pass, tiles the general
+    kernel cuts, in a call long enough for the two-pass walk and in single-key-frame calls (the one-pass walk)."""
+    import torch
+    from plvs_amd.synth_scene import make_stream_keyframes
+    from plvs_amd.tsdf import TsdfChisel
+    kfs = make_stream_keyframes(4, first=1795, threads=4) + make_stream_keyframes(3, first=1000, threads=4)
+    ora = oracle.chisel(0.05)
+    for kf in kfs:
+        ora.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+    dev = TsdfChisel(0.05, max_chunks=8192, order_free=order_free)
+    big = kfs[:5]
+    dev.integrate_batch_dev(torch.from_numpy(np.concatenate([k["xyz"] for k in big])).cuda(),
+                            torch.from_numpy(np.concatenate([k["rgb"] for k in big])).cuda(),
+                            torch.from_numpy(np.concatenate([k["kfid"] for k in big]).astype(np.int32)).cuda(),
+                            np.cumsum([0] + [k["xyz"].shape[0] for k in big]).astype(np.int32),
+                            torch.from_numpy(np.stack([k["Twc"] for k in big])).cuda())
+    for kf in kfs[5:]:
+        dev.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+    assert {tuple(c) for c in ora.chunk_ids()} == {tuple(c) for c in dev.chunk_ids()}
+    if not order_free:
+        compare_maps(ora, dev)
+    else:
+        for cid in map(tuple, ora.chunk_ids()):
+            a, b = ora.get_chunk(*cid), dev.get_chunk(*cid)
+            known = a[1] > 0
+            assert np.array_equal(known, b[1] > 0) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+            assert np.abs(a[0][known] - b[0][known]).max(initial=0) <= 2e-5
+            assert (np.abs(a[1][known] - b[1][known]) / a[1][known]).max(initial=0) <= 5e-5
+    dev.close()
+
+
+@pytest.mark.gpu
 def test_hip_edge_cases(oracle):
     from plvs_amd import _lib
     from plvs_amd.tsdf import TsdfChisel
