@@ -20,6 +20,15 @@
 
 using namespace PLVS2;
 
+// (the LSD detector is not compiled — see lines_ref_wrap.cpp: its entry points named by LineExtractor.cc abort)
+namespace cv {
+namespace line_descriptor_c {
+Ptr<LSDDetectorC> LSDDetectorC::createLSDDetectorC(const LSDOptions&) { std::abort(); }
+void LSDDetectorC::detect(const Mat&, std::vector<KeyLine>&, float, int, const LSDOptions&, const Mat&) { std::abort(); }
+void LSDDetectorC::setGaussianPyramid(const std::vector<cv::Mat>&, int, float, int, int) { std::abort(); }
+}  // namespace line_descriptor_c
+}  // namespace cv
+
 // ---- statics the three sources expect from translation units that are not compiled
 float PLVS2::Tracking::skLineStereoMaxDist = 20.f;          // src/Tracking.cc:151
 float PLVS2::Tracking::skMaxDistFovCenters = 0.5f;          // src/Tracking.cc
