@@ -200,4 +200,89 @@ int ref_orb_search_by_bow(const plvs_featvec_view* kf_vec, const uint8_t* kf_des
   return n;
 }
 
+// ---- LineMatcher::SearchByKnn (three flavours): descriptors, angles (radians), octaves as flat arrays
+static void fill_keylines(std::vector<cv::line_descriptor_c::KeyLine>& v, int n, const float* angle, const int32_t* octave) {
+  v.resize(n);
+  for (int i = 0; i < n; ++i) {
+    std::memset(&v[i], 0, sizeof v[i]);
+    v[i].angle = angle ? angle[i] : 0.f;
+    v[i].octave = octave ? octave[i] : 0;
+    v[i].class_id = i;
+  }
+}
+
+// LineMatcher::SearchByKnn(Frame& CurrentFrame, const Frame& LastFrame)  src/LineMatcher.cc:303
+int ref_lines_search_by_knn(const uint8_t* last_desc, int n_last, const uint8_t* valid, const float* ang_last,
+                            const uint8_t* cur_desc, int n_cur, const float* ang_cur, float nn_ratio, int check_orientation,
+                            int32_t* assigned) {
+  Frame C, L;
+  L.Nlines = n_last;
+  L.mLineDescriptors = rows32(last_desc, n_last);
+  fill_keylines(L.mvKeyLinesUn, n_last, ang_last, nullptr);
+  L.mvbLineOutlier.assign(n_last, false);
+  std::vector<MapLine> store(n_last);
+  L.mvpMapLines.assign(n_last, static_cast<MapLinePtr>(nullptr));
+  for (int i = 0; i < n_last; ++i)
+    if (valid[i]) L.mvpMapLines[i] = &store[i];
+  C.Nlines = n_cur;
+  C.mLineDescriptors = rows32(cur_desc, n_cur);
+  fill_keylines(C.mvKeyLinesUn, n_cur, ang_cur, nullptr);
+  C.mvpMapLines.assign(n_cur, static_cast<MapLinePtr>(nullptr));
+  LineMatcher matcher(nn_ratio, false, check_orientation != 0);
+  const int n = matcher.SearchByKnn(C, L);
+  for (int i = 0; i < n_cur; ++i) assigned[i] = C.mvpMapLines[i] ? (int32_t)(C.mvpMapLines[i] - store.data()) : -1;
+  return n;
+}
+
+// LineMatcher::SearchByKnn(KeyFramePtr& pKF, const Frame& F, vector<MapLinePtr>&)  src/LineMatcher.cc:156
+int ref_lines_search_by_knn_kf(const uint8_t* kf_desc, int n_kf, const uint8_t* valid, const float* ang_kf,
+                               const uint8_t* f_desc, int n_f, const float* ang_f, float nn_ratio, int check_orientation,
+                               int32_t* assigned) {
+  KeyFrame K;
+  K.Nlines = n_kf;
+  K.mLineDescriptors = rows32(kf_desc, n_kf);
+  fill_keylines(K.mvKeyLinesUn, n_kf, ang_kf, nullptr);
+  std::vector<MapLine> store(n_kf);
+  K.mvpMapLines.assign(n_kf, static_cast<MapLinePtr>(nullptr));
+  for (int i = 0; i < n_kf; ++i)
+    if (valid[i]) K.mvpMapLines[i] = &store[i];
+  Frame F;
+  F.Nlines = n_f;
+  F.mLineDescriptors = rows32(f_desc, n_f);
+  fill_keylines(F.mvKeyLinesUn, n_f, ang_f, nullptr);
+  std::vector<MapLinePtr> matches;
+  KeyFramePtr pKF = &K;
+  LineMatcher matcher(nn_ratio, false, check_orientation != 0);
+  const int n = matcher.SearchByKnn(pKF, F, matches);
+  for (int i = 0; i < n_f; ++i) assigned[i] = ((int)matches.size() > i && matches[i]) ? (int32_t)(matches[i] - store.data()) : -1;
+  return n;
+}
+
+// LineMatcher::SearchStereoMatchesByKnn(Frame&, vector<DMatch>&, vector<bool>&, descriptorDist)  src/LineMatcher.cc:454
+int ref_lines_search_stereo_by_knn(const uint8_t* left_desc, int n_left, const float* ang_left, const int32_t* oct_left,
+                                   const uint8_t* right_desc, int n_right, const float* ang_right, const int32_t* oct_right,
+                                   float nn_ratio, int check_orientation, int descriptor_dist, int32_t* match_query,
+                                   int32_t* match_train, float* match_distance, uint8_t* match_valid, int* n_out) {
+  Frame F;
+  F.Nlines = n_left;
+  F.mLineDescriptors = rows32(left_desc, n_left);
+  F.mLineDescriptorsRight = rows32(right_desc, n_right);
+  fill_keylines(F.mvKeyLinesUn, n_left, ang_left, oct_left);
+  F.mvKeyLines = F.mvKeyLinesUn;
+  fill_keylines(F.mvKeyLinesRightUn, n_right, ang_right, oct_right);
+  F.mvKeyLinesRight = F.mvKeyLinesRightUn;
+  std::vector<cv::DMatch> m;
+  std::vector<bool> v;
+  LineMatcher matcher(nn_ratio, false, check_orientation != 0);
+  const int n = matcher.SearchStereoMatchesByKnn(F, m, v, descriptor_dist);
+  *n_out = (int)m.size();
+  for (size_t i = 0; i < m.size(); ++i) {
+    match_query[i] = m[i].queryIdx;
+    match_train[i] = m[i].trainIdx;
+    match_distance[i] = m[i].distance;
+    match_valid[i] = v[i] ? 1 : 0;
+  }
+  return n;
+}
+
 }  // extern "C"

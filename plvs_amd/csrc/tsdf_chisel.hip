@@ -98,7 +98,7 @@ __global__ void walk_prologue(const float* __restrict__ Twc, int nclouds, Pose* 
                               int nseg) {
   const int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
   for (int c = i0; c < nclouds; c += stride) make_pose(Twc + 12 * c, &poses[c]);
-  for (int c = i0; c <= nclouds; c += stride) offsets[c] = host_offsets[c];
+  for (int c = i0; c < 2 * (nclouds + 1); c += stride) offsets[c] = host_offsets[c];   // (offsets + tile table)
   for (int k = i0; k < nseg; k += stride) chunk_nseg[k] = 0u;
   uint32_t* w = reinterpret_cast<uint32_t*>(wctr);
   for (int k = i0; k < (int)(2 * sizeof(WalkCounters) / sizeof(uint32_t)); k += stride) w[k] = 0u;
@@ -916,6 +916,7 @@ struct plvs_tsdf_chisel {
   long long* h_sh_counts = nullptr;  // pinned
   int sh_n = 0, sh_nclouds = 0;      // the call in flight (shard_walk -> shard_pack -> shard_apply)
   uint32_t sh_ntiles = 0;            // tiles of the whole point stream
+  std::vector<int32_t> sh_tiletab;   // the call's offsets + tile table (host copy)
   int sh_phase = 0;
   plvs_tsdf_stats sh_stats{};
   hipStream_t side = nullptr;   // second stream for the colour chain
@@ -1042,16 +1043,17 @@ static int ensure_part_acc(plvs_tsdf_chisel* h, uint32_t chunks) {
 // whose colour weight is below 254).
 static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uint8_t* d_rgb, const uint32_t* d_kfid,
                               int n, int nclouds, const int32_t* offsets, const float* d_Twc, hipStream_t s) {
-  const uint32_t ntiles = ceil_div((size_t)n, kWalkRays);
   const int max_chunks = h->prm.max_chunks;
-  if (h->h_offsets_cap < (size_t)nclouds + 1) {   // pinned copy of the offsets: the prologue kernel reads it
+  if (h->h_offsets_cap < 2 * ((size_t)nclouds + 1)) {   // pinned copy of the offsets + tile table: the prologue kernel reads it
     if (h->h_offsets) (void)hipHostFree(h->h_offsets);
     h->h_offsets = nullptr;
     h->h_offsets_cap = 0;
-    PLVS_HIP_TRY(hipHostMalloc((void**)&h->h_offsets, ((size_t)nclouds + 1 + 64) * sizeof(int32_t)));
-    h->h_offsets_cap = (size_t)nclouds + 1 + 64;
+    PLVS_HIP_TRY(hipHostMalloc((void**)&h->h_offsets, (2 * ((size_t)nclouds + 1) + 64) * sizeof(int32_t)));
+    h->h_offsets_cap = 2 * ((size_t)nclouds + 1) + 64;
   }
-  memcpy(h->h_offsets, offsets, ((size_t)nclouds + 1) * sizeof(int32_t));
+  // tiles: 512 consecutive points of one cloud (tsdf_directory.hpp)
+  const uint32_t ntiles = plvs::tsdf::fill_tile_table(offsets, nclouds, h->h_offsets, kWalkRays);
+  PLVS_HIP_TRY(h->offsets.reserve(2 * ((size_t)nclouds + 1)));
   PLVS_HIP_TRY(h->tile_state.reserve((size_t)ntiles + 1));
   PLVS_HIP_TRY(h->w_chunk_nseg.reserve((size_t)max_chunks));
   PLVS_HIP_TRY(h->w_chunk_off.reserve((size_t)max_chunks + 1));
@@ -1124,7 +1126,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     hipLaunchKernelGGL((walk_tiles<true, true>), dim3(kDeferGrid), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
                        h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
                        (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u}, (uint32_t)ntiles, last_list, last_count,
-                       kRecStride);
+                       kRecStride, 4u);   // (what is flagged overflowed the 4096-entry table: four pieces at once)
     PLVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
     STAGE_MARK(1);
     const unsigned seg_blocks = ceil_div(seg_own + seg_spill, kSegSpan);
@@ -1173,7 +1175,8 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
           }
           hipLaunchKernelGGL(fold_colours_masks, dim3(std::min<size_t>(ceil_div(D, kFoldWaves), 8192)),
                              dim3(64 * kFoldWaves), 0, h->side, skeys, sval, side_ctr,
-                             RunSrc{h->w_masks.p, (uint32_t)kMaskWords, h->run_r1_log2, TileMap{1u, 0u}}, h->heads.p, d_rgb,
+                             RunSrc{h->w_masks.p, (uint32_t)kMaskWords, h->run_r1_log2, TileMap{1u, 0u}, h->offsets.p, nclouds},
+                             h->heads.p, d_rgb,
                              h->rgbw, &h->d_wctr[1].num_heads, (uint32_t*)nullptr, (uint32_t*)nullptr);
           PLVS_KERNEL_CHECK();
         }
@@ -1514,7 +1517,7 @@ static int integrate_batch_core(plvs_tsdf_chisel* h, const float* d_xyz, const u
     if (rc != PLVS_OK) return rc;
   }
 
-  PLVS_HIP_TRY(h->offsets.reserve((size_t)nclouds + 1));
+  PLVS_HIP_TRY(h->offsets.reserve(2 * ((size_t)nclouds + 1)));
   PLVS_HIP_TRY(h->poses.reserve((size_t)nclouds));
   if (h->prm.order_free != 0 && d_normals == nullptr) return integrate_walk_acc(h, d_xyz, d_rgb, d_kfid, n, nclouds, offsets, d_Twc, s);
   PLVS_HIP_TRY(h->counts.reserve((size_t)n + 1));
@@ -2478,14 +2481,19 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
   for (int p = 0; p < 3 * N; ++p) h->h_sh_counts[p] = 0;
   h->sh_n = n;
   h->sh_nclouds = nclouds;
-  h->sh_ntiles = (uint32_t)ceil_div((size_t)n, kWalkRays);
+  h->sh_tiletab.resize(2 * ((size_t)nclouds + 1));
+  h->sh_ntiles = plvs::tsdf::fill_tile_table(offsets, nclouds, h->sh_tiletab.data(), kWalkRays);   // (tiles never straddle clouds)
   h->sh_nt = 0;
   h->sh_runs = 0;
   h->sh_phase = 1;
   {   // the points of this rank's tiles
     int64_t own = 0;
-    for (uint32_t t = (uint32_t)rank; t < h->sh_ntiles; t += (uint32_t)N)
-      own += std::min<int64_t>(kWalkRays, (int64_t)n - (int64_t)t * kWalkRays);
+    for (int c = 0; c < nclouds; ++c) {
+      const uint32_t t0 = (uint32_t)h->sh_tiletab[(size_t)nclouds + 1 + c], t1 = (uint32_t)h->sh_tiletab[(size_t)nclouds + 2 + c];
+      for (uint32_t t = t0; t < t1; ++t)
+        if (t % (uint32_t)N == (uint32_t)rank)
+          own += std::min<int64_t>(kWalkRays, (int64_t)(offsets[c + 1] - offsets[c]) - (int64_t)(t - t0) * kWalkRays);
+    }
     h->sh_stats.points = own;
   }
   const uint32_t nt = h->sh_ntiles > (uint32_t)rank ? (h->sh_ntiles - (uint32_t)rank + (uint32_t)N - 1u) / (uint32_t)N : 0u;
@@ -2493,9 +2501,10 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
   PLVS_REQUIRE(d_xyz && d_Twc, "null device pointer");
   h->sh_nt = nt;
   const size_t xmax = (size_t)h->xdir.max_blocks;
-  PLVS_HIP_TRY(h->offsets.reserve((size_t)nclouds + 1));
+  PLVS_HIP_TRY(h->offsets.reserve(2 * ((size_t)nclouds + 1)));
   PLVS_HIP_TRY(h->poses.reserve((size_t)nclouds));
-  PLVS_HIP_TRY(hipMemcpyAsync(h->offsets.p, offsets, ((size_t)nclouds + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  PLVS_HIP_TRY(hipMemcpyAsync(h->offsets.p, h->sh_tiletab.data(), 2 * ((size_t)nclouds + 1) * sizeof(int32_t),
+                              hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(pose_prep, dim3(ceil_div((size_t)nclouds, 64)), dim3(64), 0, s, d_Twc, nclouds, h->poses.p);
   PLVS_HIP_TRY(h->w_chunk_nseg.reserve(xmax));
   PLVS_HIP_TRY(h->w_chunk_off.reserve(xmax + 1));
@@ -2548,7 +2557,7 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
     hipLaunchKernelGGL((walk_tiles<true, true>), dim3(kDeferGrid), dim3(kWalkRays), 0, s, Pw, h->scale_u, h->scale_w, d_xyz, n,
                        h->offsets.p, nclouds, h->poses.p, h->xdir, h->d_xcount, h->d_wctr, (const uint32_t*)nullptr,
                        (const uint32_t*)h->x_sat, out, runs, tmap, (uint32_t)nt, (const uint32_t*)h->w_deferred.p,
-                       (const uint32_t*)&h->d_wctr->ndeferred, (uint32_t)kWalkLimit);
+                       (const uint32_t*)&h->d_wctr->ndeferred, (uint32_t)kWalkLimit, 2u);
     const unsigned seg_blocks = ceil_div(seg_own + seg_spill, kSegSpan);
     hipLaunchKernelGGL(seg_pass<false>, dim3(seg_blocks), dim3(256), 0, s, h->w_seg.p, out.seg_cap, nt, h->w_seg_cnt.p,
                        h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p, h->d_wctr);
@@ -2770,7 +2779,8 @@ int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src,
     hipLaunchKernelGGL(voxel_heads, dim3(ceil_div(R, 256 * kHeadTiles)), dim3(256), 0, s, skeys, R, h->heads.p,
                        h->w_dummy.p, h->d_wctr + 1);
     hipLaunchKernelGGL(fold_colours_masks, dim3(std::min<size_t>(ceil_div(R, kFoldWaves), 8192)), dim3(64 * kFoldWaves), 0, s,
-                       skeys, sval, &h->d_wctr[1].num_desc, RunSrc{runs, kWireRun, 0u, TileMap{1u, 0u}}, h->heads.p, d_rgb,
+                       skeys, sval, &h->d_wctr[1].num_desc,
+                       RunSrc{runs, kWireRun, 0u, TileMap{1u, 0u}, h->offsets.p, h->sh_nclouds}, h->heads.p, d_rgb,
                        h->rgbw, &h->d_wctr[1].num_heads, h->sh_sat.p, reinterpret_cast<uint32_t*>(h->d_xcount + 2));
     PLVS_KERNEL_CHECK();
   }

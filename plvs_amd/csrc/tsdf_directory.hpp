@@ -168,5 +168,35 @@ __device__ __forceinline__ int cloud_of(const int32_t* __restrict__ offsets, int
   return lo;
 }
 
+// The tiles of the single-walk integrate: `rays` consecutive points of ONE cloud — a cloud's last tile is shorter, so no
+// tile straddles two clouds (two poses): until round 4 tiles were cut from the concatenated stream and the one tile per
+// cloud boundary took the general kernel, ~100 us of latency behind every batch.  The device copy of a call's offsets
+// carries the table right behind them: offsets[0 .. nclouds], then tile_base[0 .. nclouds] (first tile of cloud c;
+// tile_base[nclouds] = the tiles of the call).
+struct TileSpan {
+  int cloud;
+  uint32_t first, nrays;   // first point (index into the call's stream), rays of the tile
+};
+__device__ __forceinline__ TileSpan tile_span(const int32_t* __restrict__ offsets, int nclouds, uint32_t gtile, uint32_t rays) {
+  const int32_t* tb = offsets + nclouds + 1;
+  TileSpan t;
+  t.cloud = cloud_of(tb, nclouds, (int)gtile);   // (the LAST cloud whose base is <= gtile: empty clouds share a base with their successor)
+  t.first = (uint32_t)offsets[t.cloud] + (gtile - (uint32_t)tb[t.cloud]) * rays;
+  const uint32_t left = (uint32_t)offsets[t.cloud + 1] - t.first;
+  t.nrays = left < rays ? left : rays;
+  return t;
+}
+// host: both[0 .. nclouds] = offsets, both[nclouds + 1 .. 2 nclouds + 1] = tile_base; returns the tiles of the call
+static inline uint32_t fill_tile_table(const int32_t* offsets, int nclouds, int32_t* both, uint32_t rays) {
+  uint32_t t = 0;
+  for (int c = 0; c <= nclouds; ++c) both[c] = offsets[c];
+  for (int c = 0; c < nclouds; ++c) {
+    both[nclouds + 1 + c] = (int32_t)t;
+    t += ((uint32_t)(offsets[c + 1] - offsets[c]) + rays - 1u) / rays;
+  }
+  both[2 * nclouds + 1] = (int32_t)t;
+  return t;
+}
+
 }  // namespace tsdf
 }  // namespace plvs

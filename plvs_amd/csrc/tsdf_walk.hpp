@@ -42,6 +42,8 @@ namespace {
 
 using namespace plvs::chisel;
 using plvs::tsdf::cloud_of;
+using plvs::tsdf::tile_span;
+using plvs::tsdf::TileSpan;
 using plvs::tsdf::kCoordBias;
 using plvs::tsdf::kErrCoordRange;
 using plvs::tsdf::kErrDirectoryMiss;
@@ -138,7 +140,7 @@ struct WalkShared {       // LDS state of walk_tiles
   uint32_t ccnt[kWalkChunks * kSlabs];         //   entries of the (sub-)tile per (chunk, slab),
   uint16_t cbase[kWalkChunks * kSlabs];        //   first record of the group, relative to the flush's first record
   uint32_t rbase;                              // first record of the flush
-  SubTile stack[12];   // depth: 8 halvings of the ray range + the windows of one ray
+  SubTile stack[16];   // depth: up to four pieces at once, 8 halvings of the ray range, the windows of one ray
   int sp;
   uint32_t nent;          // entries in use
   uint32_t overflow;      // the table is full: the (sub-)tile is cut
@@ -607,7 +609,8 @@ __global__ __launch_bounds__(kWalkRays, kWalkEntries > 1024 ? 4 : 6) void walk_t
     const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
     int32_t* __restrict__ num_chunks, WalkCounters* __restrict__ ctr, const uint32_t* __restrict__ rgbw,
     const uint32_t* __restrict__ sat, AccOut out, RunOut runs, TileMap tmap, uint32_t ntiles,
-    const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ ntile_list, uint32_t rec_stride) {
+    const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ ntile_list, uint32_t rec_stride,
+    uint32_t cut_pieces) {
   constexpr int kPer = kWalkEntries / kWalkRays;
   __shared__ WalkShared S;
   __shared__ uint32_t raw[kMaskCap * kMaskWords];              // accumulators during the walk, ray masks afterwards
@@ -625,23 +628,26 @@ __global__ __launch_bounds__(kWalkRays, kWalkEntries > 1024 ? 4 : 6) void walk_t
   const uint32_t tile = tile_list ? (tile_list[lb] & 0x7FFFFFFFu) : lb;   // the local tile: output regions
   const bool cut_at_once = tile_list && (tile_list[lb] >> 31) != 0u;
   const uint32_t gtile = tmap.tile_of(tile);             // its place in the point stream
-  const uint32_t first = gtile * kWalkRays;
+  const TileSpan span = tile_span(offsets, nclouds, gtile, kWalkRays);   // (512 points of one cloud: tsdf_directory.hpp)
+  const uint32_t first = span.first;
   __syncthreads();   // (the previous tile of this workgroup is done with the shared state)
   // Nearly every tile lies inside one cloud and fits its table: ONE sub-tile, known without a word of shared memory.
   // A barrier costs a tile about a microsecond (the slowest of eight waves, their memory operations drained) — the
   // common path below has five of them; the sub-tile stack (several clouds in the tile, a table overflow) costs three
   // more per sub-tile.
-  const uint32_t nrays = min((uint32_t)kWalkRays, (uint32_t)npoints - first);
-  const int cloud0 = cloud_of(offsets, nclouds, (int)first);
-  const bool one_cloud = (uint32_t)(offsets[cloud0 + 1] - (int32_t)first) >= nrays;
+  const uint32_t nrays = span.nrays;
+  const int cloud0 = span.cloud;
+  const bool one_cloud = true;   // (by construction of the tiles; the cloud-by-cloud hand-out below stays for a caller-defined tiling)
   const bool single = one_cloud && !(cut_at_once && nrays > 1u);
   if (tid == 0) {
     S.sp = 0;
     S.next = one_cloud ? nrays : 0u;
-    if (one_cloud && !single) {   // the two halves, the lower one on top (sub-tiles stay in point order)
-      const uint16_t mid = (uint16_t)(nrays / 2);
-      S.stack[S.sp++] = SubTile{mid, (uint16_t)nrays, 0u, 0xFFFFFFFFu, cloud0};
-      S.stack[S.sp++] = SubTile{(uint16_t)0, mid, 0u, 0xFFFFFFFFu, cloud0};
+    if (one_cloud && !single) {
+      // cut_pieces (2 or 4: how far the table that overflowed exceeds this kernel's) equal ray ranges, the lowest on top
+      // (sub-tiles stay in point order); a piece that still does not fit is halved as usual
+      const uint32_t np = min(cut_pieces, nrays);
+      for (uint32_t q = np; q-- > 0;)
+        S.stack[S.sp++] = SubTile{(uint16_t)(nrays * q / np), (uint16_t)(nrays * (q + 1) / np), 0u, 0xFFFFFFFFu, cloud0};
     }
     S.nrays = nrays;
     S.run_total = 0;
@@ -934,7 +940,7 @@ __global__ __launch_bounds__(kWalkRays, kWalkEntries > 1024 ? 4 : 6) void walk_t
         if (slot_of[k] < 0) continue;
         const int e = tid + k * kWalkRays;
         const uint32_t vid = vkey[k] % (uint32_t)kChunkVox;
-        const uint4 r = make_uint4(vid | ((uint32_t)(ewc[k] >> 32) << 12), gtile * kWalkRays + elast[k], (uint32_t)e_wuu[e],
+        const uint4 r = make_uint4(vid | ((uint32_t)(ewc[k] >> 32) << 12), first + elast[k], (uint32_t)e_wuu[e],
                                    (uint32_t)ewc[k]);
         uint32_t at;
         if (ci[k] >= 0) {
@@ -1121,10 +1127,10 @@ __device__ __forceinline__ void walk_fast_tile(
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   // (tile = the local tile: output regions; listed_other = a listed tile that is not an overflow: passed on)
   const uint32_t gtile = tmap.tile_of(tile);             // its place in the point stream
-  const uint32_t first = gtile * kWalkRays;
-  const uint32_t nrays = min((uint32_t)kWalkRays, (uint32_t)npoints - first);
-  const int cloud = cloud_of(offsets, nclouds, (int)first);
-  bool defer = (uint32_t)(offsets[cloud + 1] - (int32_t)first) < nrays || P.shard_count > 1 || listed_other;   // (uniform)
+  const TileSpan span = tile_span(offsets, nclouds, gtile, kWalkRays);   // (512 points of one cloud: tsdf_directory.hpp)
+  const uint32_t first = span.first, nrays = span.nrays;
+  const int cloud = span.cloud;
+  bool defer = P.shard_count > 1 || listed_other;   // (uniform)
   uint32_t nv = 0;
   bool walks = false;
   int ox = 0, oy = 0, oz = 0;
@@ -1288,7 +1294,7 @@ __device__ __forceinline__ void walk_fast_tile(
   for (int k = 0; k < kPer; ++k) {
     if (vkey[k] == 0xFFFFFFFFu) continue;
     const uint32_t vid = vkey[k] % (uint32_t)kChunkVox;
-    const uint4 r = make_uint4(vid | ((uint32_t)(ewc[k] >> 32) << 12), gtile * kWalkRays + elast[k],
+    const uint4 r = make_uint4(vid | ((uint32_t)(ewc[k] >> 32) << 12), first + elast[k],
                                (uint32_t)e_wuu[tid + k * kWalkRays], (uint32_t)ewc[k]);
     out.rec[rbase + S.cbase[ci[k] * kSlabs + (int)(vid / kSlabVox)] + rank[k]] = r;
   }
@@ -2000,6 +2006,8 @@ struct RunSrc {
   const uint32_t* base;
   uint32_t words, r1_log2;
   TileMap tmap;
+  const int32_t* offsets;   // the call's offsets + tile table (tile -> first point: tile_span)
+  int nclouds;
 };
 constexpr int kFoldGroup = 8;     // voxels a wave folds together (staging: 8 lanes each; fold: 4 lanes each: r, g, b, idle)
 constexpr int kFoldSteps = 256;   // >= 254: the visits that can still count for a voxel
@@ -2060,7 +2068,8 @@ __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
             const uint4 a = m4[q];
             m[4 * q] = a.x; m[4 * q + 1] = a.y; m[4 * q + 2] = a.z; m[4 * q + 3] = a.w;
           }
-          p0 = (size_t)(src.words == kWireRun ? run[3] : src.tmap.tile_of(val >> src.r1_log2)) * (size_t)kWalkRays;
+          p0 = (size_t)tile_span(src.offsets, src.nclouds,
+                                 src.words == kWireRun ? run[3] : src.tmap.tile_of(val >> src.r1_log2), kWalkRays).first;
 #pragma unroll
           for (int w = 0; w < kMaskWords; ++w) cnt += (uint32_t)__popc(m[w]);
         }

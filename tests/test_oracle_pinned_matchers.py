@@ -149,3 +149,58 @@ def test_search_by_bow(oracle, ref, seed, ratio, check):
                check, _p(got))
     assert got_n == want_n > 100
     assert np.array_equal(got, want)
+
+
+# ---------------------------------------------------------------- LineMatcher::SearchByKnn (F-F, KF-F), SearchStereoMatchesByKnn
+from tests import test_line_search as tls  # noqa: E402
+
+
+def _knn_fn(ref, name):
+    fn = getattr(ref, name)
+    fn.restype = _i
+    fn.argtypes = [_vp, _i, _vp, _vp, _vp, _i, _vp, _f, _i, _vp]
+    return fn
+
+
+@pytest.mark.parametrize("seed,ratio,check", [(1, 0.8, True), (2, 0.7, True), (3, 0.9, False), (4, 0.8, True), (7, 0.6, True)])
+def test_lines_search_by_knn_last_frame(oracle, ref, seed, ratio, check):
+    case = tls.make_case(seed, n_last=90 + 7 * seed, n_cur=100 + 3 * seed, rot=0.3 * seed)
+    want_n, want = tls.run(tls.oracle_fn(oracle), case, ratio, check)
+    got_n, got = tls.run(_knn_fn(ref, "ref_lines_search_by_knn"), case, ratio, check)
+    assert got_n == want_n > 10
+    assert np.array_equal(got, want)
+    # a single current line: the k-NN has no second neighbour
+    last, valid, ang_last, cur, ang_cur = case
+    one = (last, valid, ang_last, cur[:1].copy(), ang_cur[:1].copy())
+    w = tls.run(tls.oracle_fn(oracle), one, ratio, check)
+    g = tls.run(_knn_fn(ref, "ref_lines_search_by_knn"), one, ratio, check)
+    assert g[0] == w[0] and np.array_equal(g[1], w[1])
+
+
+@pytest.mark.parametrize("seed,ratio,check", [(1, 0.8, True), (2, 0.7, True), (3, 0.9, False), (5, 0.8, True)])
+def test_lines_search_by_knn_key_frame(oracle, ref, seed, ratio, check):
+    case = tls.make_case(10 + seed, n_last=120 + 7 * seed, n_cur=100 + 3 * seed, rot=0.4 * seed)
+    want_n, want = tls.run(tls.oracle_kf_fn(oracle), case, ratio, check)
+    got_n, got = tls.run(_knn_fn(ref, "ref_lines_search_by_knn_kf"), case, ratio, check)
+    assert got_n == want_n > 10
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("seed,ratio,check,dd", [(1, 0.8, True, 50), (2, 0.7, True, 60), (3, 0.9, False, 50), (4, 0.8, True, 256)])
+def test_lines_search_stereo_by_knn(oracle, ref, seed, ratio, check, dd):
+    case = tls.make_stereo_case(seed, n_left=100 + 9 * seed, n_right=90 + 5 * seed)
+    want_n, wq, wt, wd, wv = tls.oracle_stereo(oracle, case, ratio, check, dd)
+    left, ang_l, oct_l, right, ang_r, oct_r = case
+    cap = max(right.shape[0], 1)
+    mq, mt = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    md, mv = np.zeros(cap, np.float32), np.zeros(cap, np.uint8)
+    n_out = ctypes.c_int()
+    fn = ref.ref_lines_search_stereo_by_knn
+    fn.restype = _i
+    fn.argtypes = [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp, _vp]
+    got_n = fn(_p(left), left.shape[0], _p(ang_l), _p(oct_l), _p(right), right.shape[0], _p(ang_r), _p(oct_r), ratio, int(check),
+               dd, _p(mq), _p(mt), _p(md), _p(mv), ctypes.byref(n_out))
+    k = n_out.value
+    assert got_n == want_n > 5 and k == len(wq)
+    assert np.array_equal(mq[:k], wq) and np.array_equal(mt[:k], wt)
+    assert np.array_equal(md[:k], wd) and np.array_equal(mv[:k].astype(bool), wv)
