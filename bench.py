@@ -737,7 +737,7 @@ def main():
                                                                               occupied=pc["occupied"], has_obs=pc["has_obs"])),
                 "cpu_us": per_call_us(lambda: tlp.oracle_ff(ora, pc, False, 0, 0.8, True), 10)}
             mt["lines_search_by_projection_maplines"] = {
-                "hip_us": per_call_us(lambda: lm.SearchByProjection(view, pc["valid"], pc["proj"], pc["octave"], pc["ldesc"],
+                "hip_us": per_call_us(lambda: lm.SearchByProjection(view, pc["valid"], pc["proj_map"], pc["octave"], pc["ldesc"],
                                                                     occupied=pc["occupied"], has_obs=pc["has_obs"])),
                 "cpu_us": per_call_us(lambda: tlp.oracle_map(ora, pc, False, 0.8), 10)}
             # ---- the tracking step on REAL extractor output: frame upload, ORB + lines of aloe_shift, and

@@ -366,7 +366,8 @@ int plvs_hip_lines_search_by_projection_ff(const plvs_line_frame_view* F, const 
 /* LineMatcher::SearchByProjection(Frame& F, const std::vector<MapLinePtr>&, bLargerSearch)
  * (src/LineMatcher.cc:1286-1560, left image), called by Tracking::SearchLocalLines (:4576).  Per map
  * line m: in_view[m] = mbTrackInView && !isBad(); proj[6 m ..] = mTrackProjStartX, StartY, EndX, EndY,
- * 1 / mTrackStartDepth, 1 / mTrackEndDepth; level[m] = mnTrackScaleLevel. */
+ * mTrackStartDepth, mTrackEndDepth (the depths themselves: the stereo gate shifts the end points by mbf / depth as
+ * :1419-1423 does — not by mbf * (1 / depth), which rounds differently); level[m] = mnTrackScaleLevel. */
 int plvs_hip_lines_search_by_projection(const plvs_line_frame_view* F, const uint8_t* occupied, int n_map,
                                         const uint8_t* in_view, const float* proj, const int32_t* level,
                                         const uint8_t* desc, const uint8_t* has_obs, int larger_search,

@@ -140,14 +140,14 @@ static int features_in_area(const LFrame* F, const LineRep* r, float dtheta, flo
 
 /* the two point-line tests of a candidate (LineMatcher.cc:990-1046 / 1372-1428): 0 = rejected */
 static int candidate_ok(const LFrame* F, int i2, const LineRep* pr, float inv_s2, float th, float uS, float vS, float uE,
-                        float vE, float invSz, float invEz) {
+                        float vE, float shiftS, float shiftE) {   /* shift = mbf * invSz (:1011) or mbf / mTrackStartDepth (:1419) */
   const KeyLine* k = &F->kl[i2];
   const float distS = pr->nx * k->startPointX + pr->ny * k->startPointY - pr->d;
   const float distE = pr->nx * k->endPointX + pr->ny * k->endPointY - pr->d;
   if (distS * distS * inv_s2 > th || distE * distE * inv_s2 > th) return 0;
   if (F->ur_start != NULL && F->ur_start[i2] >= 0 && F->ur_end[i2] >= 0) {
     LineRep rr;
-    line_rep(uS - F->bf * invSz, vS, uE - F->bf * invEz, vE, &rr);
+    line_rep(uS - shiftS, vS, uE - shiftE, vE, &rr);
     const float dSr = rr.nx * F->ur_start[i2] + rr.ny * k->startPointY - rr.d;
     const float dEr = rr.nx * F->ur_end[i2] + rr.ny * k->endPointY - rr.d;
     if (dSr * dSr * inv_s2 > th || dEr * dEr * inv_s2 > th) return 0;
@@ -220,7 +220,7 @@ int oracle_lines_search_by_projection_ff(int n_cur, const KeyLine* cur_kl, const
     for (int c = 0; c < nc; ++c) {
       const int i2 = cand[c];
       if (occ[i2]) continue;
-      if (!candidate_ok(&F, i2, &pr, F.inv_sigma2[lo], th, p[0], p[1], p[2], p[3], p[4], p[5])) continue;
+      if (!candidate_ok(&F, i2, &pr, F.inv_sigma2[lo], th, p[0], p[1], p[2], p[3], F.bf * p[4], F.bf * p[5])) continue;
       const int dist = popcount256(desc + 32 * (size_t)i, F.desc + 32 * (size_t)i2);
       if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx = i2; }
       else if (dist < bestDist2) { bestDist2 = dist; }
@@ -256,8 +256,8 @@ int oracle_lines_search_by_projection_ff(int n_cur, const KeyLine* cur_kl, const
 }
 
 /* LineMatcher::SearchByProjection(F, vpMapLines, bLargerSearch), left image only.  Per map line: in_view =
- * mbTrackInView && !isBad(); proj[6 m ..] = mTrackProjStartX, StartY, EndX, EndY, 1 / mTrackStartDepth,
- * 1 / mTrackEndDepth; level = mnTrackScaleLevel. */
+ * mbTrackInView && !isBad(); proj[6 m ..] = mTrackProjStartX, StartY, EndX, EndY, mTrackStartDepth, mTrackEndDepth (the
+ * stereo gate divides mbf by them, src/LineMatcher.cc:1419-1423); level = mnTrackScaleLevel. */
 int oracle_lines_search_by_projection_map(int n_cur, const KeyLine* cur_kl, const uint8_t* cur_desc, const float* ur_start,
                                           const float* ur_end, float bf, const float* scale, const float* inv_sigma2,
                                           float max_diag, const uint8_t* occupied, int n_map, const uint8_t* in_view,
@@ -285,7 +285,7 @@ int oracle_lines_search_by_projection_map(int n_cur, const KeyLine* cur_kl, cons
     for (int c = 0; c < nc; ++c) {
       const int idx = cand[c];
       if (occ[idx]) continue;
-      if (!candidate_ok(&F, idx, &pr, F.inv_sigma2[lv], th, p[0], p[1], p[2], p[3], p[4], p[5])) continue;
+      if (!candidate_ok(&F, idx, &pr, F.inv_sigma2[lv], th, p[0], p[1], p[2], p[3], F.bf / p[4], F.bf / p[5])) continue;
       const int dist = popcount256(desc + 32 * (size_t)m, F.desc + 32 * (size_t)idx);
       if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = F.kl[idx].octave; bestIdx = idx; }
       else if (dist < bestDist2) { bestLevel2 = F.kl[idx].octave; bestDist2 = dist; }

@@ -285,4 +285,125 @@ int ref_lines_search_stereo_by_knn(const uint8_t* left_desc, int n_left, const f
   return n;
 }
 
+// ---- LineMatcher::SearchByProjection (two flavours).  What they read of a single-camera frame: the undistorted key
+// lines, their descriptors, the right-image abscissae of the end points, mbf, the line scale tables and the (theta, d)
+// grid — filled by the reference's own Frame::AssignFeaturesToGrid.
+static void fill_line_frame(Frame& F, const plvs_line_frame_view* v) {
+  F.N = 0;
+  F.Nleft = -1;
+  F.Nlines = v->n;
+  F.NlinesLeft = -1;
+  F.mvKeyLinesUn.resize(v->n);
+  static_assert(sizeof(plvs_keyline) == sizeof(cv::line_descriptor_c::KeyLine), "plvs_keyline is KeyLine field for field");
+  if (v->n) std::memcpy(F.mvKeyLinesUn.data(), v->keylines_un, sizeof(plvs_keyline) * (size_t)v->n);
+  F.mvKeyLines = F.mvKeyLinesUn;
+  F.mLineDescriptors = rows32(v->descriptors, v->n);
+  if (v->u_right_start) {
+    F.mvuRightLineStart.assign(v->u_right_start, v->u_right_start + v->n);
+    F.mvuRightLineEnd.assign(v->u_right_end, v->u_right_end + v->n);
+  }
+  F.mbf = v->bf;
+  F.mvLineScaleFactors.assign(v->line_scale_factors, v->line_scale_factors + v->n_levels);
+  F.mvLineInvLevelSigma2.assign(v->line_inv_level_sigma2, v->line_inv_level_sigma2 + v->n_levels);
+  F.mvpMapLines.assign(v->n, static_cast<MapLinePtr>(nullptr));
+  F.mvbLineOutlier.assign(v->n, false);
+  // the line grid's geometry as Frame::Frame sets it on the first frame (src/Frame.cc:446-452 with LINE_THETA_SPAN etc.)
+  Frame::mnMaxDiag = v->max_diag;
+  Frame::mfLineGridElementThetaInv = static_cast<float>(LINE_THETA_GRID_ROWS) / static_cast<float>(LINE_THETA_SPAN);
+  Frame::mfLineGridElementDInv = static_cast<float>(LINE_D_GRID_COLS) / (2.0f * Frame::mnMaxDiag);
+  // (AssignFeaturesToGrid fills the line grid only for a frame with a line extractor: a non-null pointer it never follows)
+  F.mpLineExtractorLeft = std::shared_ptr<LineExtractor>(std::shared_ptr<int>(), reinterpret_cast<LineExtractor*>(16));
+  F.AssignFeaturesToGrid();
+  F.mpLineExtractorLeft.reset();
+}
+
+// LineMatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, bLargerSearch, bMono)  src/LineMatcher.cc:837.
+// xyz_w = world end points of the map line of last-frame line i (n_last x 6: start, end); bounds = mnMinX, mnMaxX, mnMinY,
+// mnMaxY of the current frame; the other arguments as ref_orb_search_by_projection_ff.
+int ref_lines_search_by_projection_ff(const plvs_line_frame_view* fv, const uint8_t* occupied, const float* bounds, float mb,
+                                      const float* Tcw, const float* Tlw, const float* cam, int n_last, const uint8_t* valid,
+                                      const float* xyz_w, const int32_t* octave, const float* angle, const uint8_t* desc,
+                                      const uint8_t* has_obs, int larger_search, int mono, float nn_ratio,
+                                      int check_orientation, int32_t* assigned) {
+  Frame C, L;
+  fill_line_frame(C, fv);
+  Frame::mnMinX = bounds[0]; Frame::mnMaxX = bounds[1]; Frame::mnMinY = bounds[2]; Frame::mnMaxY = bounds[3];
+  C.mb = mb;
+  Pinhole camera(std::vector<float>(cam, cam + 4));
+  C.mpCamera = &camera;
+  auto pose_of = [](const float* T) {
+    Eigen::Matrix3f R;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) R(r, c) = T[4 * r + c];
+    return Sophus::SE3f(R, Eigen::Vector3f(T[3], T[7], T[11]));
+  };
+  C.SetPose(pose_of(Tcw));
+  L.SetPose(pose_of(Tlw));
+  MapLine taken;
+  taken.mnObs = 1;
+  if (occupied)
+    for (int i = 0; i < fv->n; ++i)
+      if (occupied[i]) C.mvpMapLines[i] = &taken;
+  L.Nlines = n_last;
+  L.NlinesLeft = -1;
+  fill_keylines(L.mvKeyLinesUn, n_last, angle, octave);
+  L.mvbLineOutlier.assign(n_last, false);
+  std::vector<MapLine> store(n_last);
+  L.mvpMapLines.assign(n_last, static_cast<MapLinePtr>(nullptr));
+  for (int i = 0; i < n_last; ++i) {
+    if (!valid[i]) continue;
+    MapLine& m = store[i];
+    m.mWorldPosStart = Eigen::Vector3f(xyz_w[6 * i], xyz_w[6 * i + 1], xyz_w[6 * i + 2]);
+    m.mWorldPosEnd = Eigen::Vector3f(xyz_w[6 * i + 3], xyz_w[6 * i + 4], xyz_w[6 * i + 5]);
+    m.mDescriptor = rows32(desc + 32 * (size_t)i, 1);
+    m.mnObs = (!has_obs || has_obs[i]) ? 1 : 0;
+    L.mvpMapLines[i] = &m;
+  }
+  LineMatcher matcher(nn_ratio, false, check_orientation != 0);
+  const int n = matcher.SearchByProjection(C, L, larger_search != 0, mono != 0);
+  for (int i = 0; i < fv->n; ++i) {
+    MapLinePtr p = C.mvpMapLines[i];
+    assigned[i] = (p && p != &taken) ? (int32_t)(p - store.data()) : -1;
+  }
+  return n;
+}
+
+// LineMatcher::SearchByProjection(Frame& F, const vector<MapLinePtr>&, bLargerSearch)  src/LineMatcher.cc:1286.
+// proj[6 m ..] = mTrackProjStartX, StartY, EndX, EndY, mTrackStartDepth, mTrackEndDepth.
+int ref_lines_search_by_projection(const plvs_line_frame_view* fv, const uint8_t* occupied, int n_map, const uint8_t* in_view,
+                                   const float* proj, const int32_t* level, const uint8_t* desc, const uint8_t* has_obs,
+                                   int larger_search, float nn_ratio, int32_t* assigned) {
+  Frame F;
+  fill_line_frame(F, fv);
+  MapLine taken;
+  taken.mnObs = 1;
+  if (occupied)
+    for (int i = 0; i < fv->n; ++i)
+      if (occupied[i]) F.mvpMapLines[i] = &taken;
+  std::vector<MapLine> store(n_map);
+  std::vector<MapLinePtr> vp(n_map);
+  for (int m = 0; m < n_map; ++m) {
+    MapLine& l = store[m];
+    l.mbTrackInView = in_view[m] != 0;
+    l.mbTrackInViewR = false;
+    l.mTrackProjStartX = proj[6 * m];
+    l.mTrackProjStartY = proj[6 * m + 1];
+    l.mTrackProjEndX = proj[6 * m + 2];
+    l.mTrackProjEndY = proj[6 * m + 3];
+    l.mTrackStartDepth = proj[6 * m + 4];
+    l.mTrackEndDepth = proj[6 * m + 5];
+    l.mnTrackScaleLevel = level[m];
+    l.mDescriptor = rows32(desc + 32 * (size_t)m, 1);
+    l.mnObs = (!has_obs || has_obs[m]) ? 1 : 0;
+    vp[m] = &l;
+  }
+  LineMatcher matcher(nn_ratio, false, true);
+  const int n = matcher.SearchByProjection(F, vp, larger_search != 0);
+  for (int i = 0; i < fv->n; ++i) {
+    MapLinePtr p = F.mvpMapLines[i];
+    assigned[i] = (p && p != &taken) ? (int32_t)(p - store.data()) : -1;
+  }
+  return n;
+}
+
 }  // extern "C"

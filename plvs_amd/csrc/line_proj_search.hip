@@ -109,13 +109,16 @@ struct LineGrid {   // Frame::mLineGrid as one CSR table, cells in (column, row)
 
 // the point-to-line gates of a candidate (:990-1046, 1372-1428): both end points of the frame line within the
 // chi-square bound of the projected line, and the same on the right image when the line has a stereo match
-bool passes_gates(const plvs_line_frame_view* F, int i2, const Rep& pr, float inv_sigma2, float th, const float* p) {
+// shift_s / shift_e: the disparity of the projected end points — mbf * invSz (frame to frame, :1011-1013: the
+// projection's own inverse depths) or mbf / mTrackStartDepth (map lines, :1419-1423: a division by the stored depth)
+bool passes_gates(const plvs_line_frame_view* F, int i2, const Rep& pr, float inv_sigma2, float th, const float* p,
+                  float shift_s, float shift_e) {
   const plvs_keyline& k = F->keylines_un[i2];
   const float ds = pr.nx * k.startPointX + pr.ny * k.startPointY - pr.d;
   const float de = pr.nx * k.endPointX + pr.ny * k.endPointY - pr.d;
   if (ds * ds * inv_sigma2 > th || de * de * inv_sigma2 > th) return false;
   if (F->u_right_start != nullptr && F->u_right_start[i2] >= 0 && F->u_right_end[i2] >= 0) {
-    const Rep rr = representation(p[0] - F->bf * p[4], p[1], p[2] - F->bf * p[5], p[3]);
+    const Rep rr = representation(p[0] - shift_s, p[1], p[2] - shift_e, p[3]);
     const float dsr = rr.nx * F->u_right_start[i2] + rr.ny * k.startPointY - rr.d;
     const float der = rr.nx * F->u_right_end[i2] + rr.ny * k.endPointY - rr.d;
     if (dsr * dsr * inv_sigma2 > th || der * der * inv_sigma2 > th) return false;
@@ -178,7 +181,7 @@ int plvs_hip_lines_search_by_projection_ff(const plvs_line_frame_view* F, const 
       return PLVS_ERR_INVALID_ARG;
     }
     for (int i2 : win)
-      if (passes_gates(F, i2, pr, F->line_inv_level_sigma2[lo], th, p)) {
+      if (passes_gates(F, i2, pr, F->line_inv_level_sigma2[lo], th, p, F->bf * p[4], F->bf * p[5])) {
         C.q.push_back(i);
         C.t.push_back(i2);
       }
@@ -268,7 +271,7 @@ int plvs_hip_lines_search_by_projection(const plvs_line_frame_view* F, const uin
       return PLVS_ERR_INVALID_ARG;
     }
     for (int idx : win)
-      if (passes_gates(F, idx, pr, F->line_inv_level_sigma2[lv], th, p)) {
+      if (passes_gates(F, idx, pr, F->line_inv_level_sigma2[lv], th, p, F->bf / p[4], F->bf / p[5])) {
         C.q.push_back(m);
         C.t.push_back(idx);
       }

@@ -2497,14 +2497,15 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
     h->sh_stats.points = own;
   }
   const uint32_t nt = h->sh_ntiles > (uint32_t)rank ? (h->sh_ntiles - (uint32_t)rank + (uint32_t)N - 1u) / (uint32_t)N : 0u;
+  // (the tile table goes to the device even on a rank without tiles: the runs other ranks send it name tiles of the stream)
+  PLVS_HIP_TRY(h->offsets.reserve(2 * ((size_t)nclouds + 1)));
+  PLVS_HIP_TRY(hipMemcpyAsync(h->offsets.p, h->sh_tiletab.data(), 2 * ((size_t)nclouds + 1) * sizeof(int32_t),
+                              hipMemcpyHostToDevice, s));
   if (nt == 0) return PLVS_OK;
   PLVS_REQUIRE(d_xyz && d_Twc, "null device pointer");
   h->sh_nt = nt;
   const size_t xmax = (size_t)h->xdir.max_blocks;
-  PLVS_HIP_TRY(h->offsets.reserve(2 * ((size_t)nclouds + 1)));
   PLVS_HIP_TRY(h->poses.reserve((size_t)nclouds));
-  PLVS_HIP_TRY(hipMemcpyAsync(h->offsets.p, h->sh_tiletab.data(), 2 * ((size_t)nclouds + 1) * sizeof(int32_t),
-                              hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(pose_prep, dim3(ceil_div((size_t)nclouds, 64)), dim3(64), 0, s, d_Twc, nclouds, h->poses.p);
   PLVS_HIP_TRY(h->w_chunk_nseg.reserve(xmax));
   PLVS_HIP_TRY(h->w_chunk_off.reserve(xmax + 1));

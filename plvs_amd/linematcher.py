@@ -64,7 +64,8 @@ class LineMatcher:
 
     def SearchByProjection(self, view, in_view, proj, level, desc, occupied=None, has_obs=None, bLargerSearch=False):
         """SearchByProjection(Frame& F, const std::vector<MapLinePtr>&, bLargerSearch), src/LineMatcher.cc:1286.
-        -> (nmatches, assigned [Nlines]: map-line index or -1)."""
+        proj [n_map, 6] = mTrackProjStartX, StartY, EndX, EndY, mTrackStartDepth, mTrackEndDepth (the DEPTHS: the stereo
+        gate divides mbf by them, :1419-1423).  -> (nmatches, assigned [Nlines]: map-line index or -1)."""
         F, keep = view
         iv, pr = _u8(in_view), _f32(proj).reshape(-1, 6)
         lv, de = np.ascontiguousarray(level, np.int32), _u8(desc).reshape(-1, 32)

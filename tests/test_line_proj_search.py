@@ -67,8 +67,12 @@ def make_case(seed, n_cur=120, n_last=100, stereo=False, theta_edge=False):
             j = src[i]
             urs[j] = kl["startPointX"][j] - bf * proj[i, 4]
             ure[j] = kl["endPointX"][j] - bf * proj[i, 5]
-    return dict(kl=kl, desc=desc, urs=urs, ure=ure, bf=bf, occupied=occupied, valid=valid, proj=proj, octave=octave,
-                angle=angle, ldesc=ldesc, has_obs=has_obs, src=src)
+    # the map-line search takes the DEPTHS of the end points (mTrackStartDepth / EndDepth: it divides mbf by them,
+    # src/LineMatcher.cc:1419-1423), the frame-to-frame search the projection's inverse depths (:1011-1013)
+    proj_map = proj.copy()
+    proj_map[:, 4:6] = depth
+    return dict(kl=kl, desc=desc, urs=urs, ure=ure, bf=bf, occupied=occupied, valid=valid, proj=proj, proj_map=proj_map,
+                octave=octave, angle=angle, ldesc=ldesc, has_obs=has_obs, src=src)
 
 
 def _p(a):
@@ -94,7 +98,7 @@ def oracle_map(oracle, c, larger, ratio):
     f.argtypes = [i, vp, vp, vp, vp, fl, vp, vp, fl, vp, i, vp, vp, vp, vp, vp, i, fl, vp]
     assigned = np.full(len(c["kl"]), -7, np.int32)
     n = f(len(c["kl"]), _p(c["kl"]), _p(c["desc"]), _p(c["urs"]), _p(c["ure"]), c["bf"], _p(SCALE), _p(INV_SIGMA2), MAX_DIAG,
-          _p(c["occupied"]), len(c["valid"]), _p(c["valid"]), _p(c["proj"]), _p(c["octave"]), _p(c["ldesc"]), _p(c["has_obs"]),
+          _p(c["occupied"]), len(c["valid"]), _p(c["valid"]), _p(c["proj_map"]), _p(c["octave"]), _p(c["ldesc"]), _p(c["has_obs"]),
           int(larger), ratio, _p(assigned))
     return n, assigned
 
@@ -159,7 +163,7 @@ def test_hip_projection_search_matches_oracle(oracle, seed, stereo, edge, larger
                                                direction=direction)
     assert want_n >= 0 and got_n == want_n and np.array_equal(got, want)
     want_n, want = oracle_map(oracle, c, larger, ratio)
-    got_n, got = m.SearchByProjection(view, c["valid"], c["proj"], c["octave"], c["ldesc"], occupied=c["occupied"],
+    got_n, got = m.SearchByProjection(view, c["valid"], c["proj_map"], c["octave"], c["ldesc"], occupied=c["occupied"],
                                       has_obs=c["has_obs"], bLargerSearch=larger)
     assert want_n > 5 and got_n == want_n and np.array_equal(got, want)
 

@@ -204,3 +204,90 @@ def test_lines_search_stereo_by_knn(oracle, ref, seed, ratio, check, dd):
     assert got_n == want_n > 5 and k == len(wq)
     assert np.array_equal(mq[:k], wq) and np.array_equal(mt[:k], wt)
     assert np.array_equal(md[:k], wd) and np.array_equal(mv[:k].astype(bool), wv)
+
+
+# ---------------------------------------------------------------- LineMatcher::SearchByProjection (F, MapLines) and (F, LastF)
+from tests import test_line_proj_search as tlp  # noqa: E402
+
+
+def _line_view(c):
+    from plvs_amd.linematcher import line_frame_view
+    return line_frame_view(c["kl"], c["desc"], tlp.SCALE, tlp.INV_SIGMA2, tlp.MAX_DIAG, u_right_start=c["urs"],
+                           u_right_end=c["ure"], bf=c["bf"])
+
+
+@pytest.mark.parametrize("seed,stereo,edge,larger,ratio", [(1, False, False, False, 0.8), (2, True, False, False, 0.8),
+                                                          (3, False, True, True, 0.9), (4, True, True, False, 0.7),
+                                                          (5, True, False, True, 0.8)])
+def test_lines_search_by_projection_maplines(oracle, ref, seed, stereo, edge, larger, ratio):
+    c = tlp.make_case(seed, n_cur=150, n_last=130, stereo=stereo, theta_edge=edge)
+    want_n, want = tlp.oracle_map(oracle, c, larger, ratio)
+    F, keep = _line_view(c)
+    got = np.full(len(c["kl"]), -7, np.int32)
+    fn = ref.ref_lines_search_by_projection
+    fn.restype = _i
+    fn.argtypes = [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp]
+    got_n = fn(ctypes.byref(F), tlp._p(c["occupied"]), len(c["valid"]), tlp._p(c["valid"]), tlp._p(c["proj_map"]),
+               tlp._p(c["octave"]), tlp._p(c["ldesc"]), tlp._p(c["has_obs"]), int(larger), ratio, _p(got))
+    assert got_n == want_n > 20
+    assert np.array_equal(got, want)
+
+
+def _f32(a):
+    return np.asarray(a, np.float32)
+
+
+def _project_lines(Tcw, xyz_w, bounds):
+    """LineProjection::ProjectLineWithCheck (include/LineProjection.h:145-262) for a pinhole camera, in the reference's
+    float arithmetic: middle point in front and inside, end points in front and inside; invSz = 1.0f / z; the distance
+    test passes (the stand-in map lines accept every distance).  -> ok [n], proj [n, 6]."""
+    S, E = xyz_w[:, :3], xyz_w[:, 3:]
+    M = (np.float32(0.5) * (S + E)).astype(np.float32)
+    ok = np.ones(len(S), bool)
+    out = np.zeros((len(S), 6), np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for P, col in ((M, None), (S, 0), (E, 2)):
+            c = _transform(Tcw, P)
+            u = (CAM[0] * c[:, 0] / c[:, 2] + CAM[2]).astype(np.float32)
+            v = (CAM[1] * c[:, 1] / c[:, 2] + CAM[3]).astype(np.float32)
+            ok &= ~(c[:, 2] < 0) & ~((u < bounds[0]) | (u > bounds[1])) & ~((v < bounds[2]) | (v > bounds[3]))
+            if col is not None:
+                out[:, col], out[:, col + 1] = u, v
+                out[:, 4 + col // 2] = (np.float32(1.0) / c[:, 2]).astype(np.float32)
+    return ok, out
+
+
+@pytest.mark.parametrize("seed,stereo,edge,larger,direction,check", [(1, False, False, False, 0, True), (2, True, False, False, 0, True),
+                                                                    (3, False, True, True, 1, True), (4, True, True, False, 2, False),
+                                                                    (6, True, False, True, 0, True)])
+def test_lines_search_by_projection_last_frame(oracle, ref, seed, stereo, edge, larger, direction, check):
+    c = tlp.make_case(seed, n_cur=150, n_last=130, stereo=stereo, theta_edge=edge)
+    rng = np.random.default_rng(seed + 900)
+    Tcw = _pose(rng, 6.0, rng.uniform(-0.2, 0.2, 3))
+    # world end points whose projections are about the case's (depth = 1 / proj[:, 4:6])
+    p = c["proj"].astype(np.float64)
+    Rcw, tcw = Tcw[:, :3].astype(np.float64), Tcw[:, 3].astype(np.float64)
+    ends = []
+    for k, iz in ((0, 4), (2, 5)):
+        z = 1.0 / p[:, iz]
+        cam_pt = np.stack([(p[:, k] - CAM[2]) / CAM[0] * z, (p[:, k + 1] - CAM[3]) / CAM[1] * z, z], 1)
+        ends.append((cam_pt - tcw) @ Rcw)
+    xyz_w = np.concatenate(ends, 1).astype(np.float32)
+    bounds = _f32([0.0, tlp.W, 0.0, tlp.H])
+    ok, proj = _project_lines(Tcw, xyz_w, bounds)
+    c2 = dict(c, proj=proj, valid=(c["valid"].astype(bool) & ok).astype(np.uint8))
+    want_n, want = tlp.oracle_ff(oracle, c2, larger, direction, 0.8, check)
+    mb = 0.08
+    twc = -(Rcw.T @ tcw)
+    dz = (0.0, 1.0, -1.0)[direction]
+    Tlw = np.concatenate([np.eye(3), (-twc + np.array([0, 0, dz]))[:, None]], axis=1).astype(np.float32)
+    F, keep = _line_view(c)
+    got = np.full(len(c["kl"]), -7, np.int32)
+    fn = ref.ref_lines_search_by_projection_ff
+    fn.restype = _i
+    fn.argtypes = [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]
+    got_n = fn(ctypes.byref(F), tlp._p(c["occupied"]), _p(bounds), mb, _p(Tcw), _p(Tlw), _p(CAM), len(c["valid"]),
+               tlp._p(c["valid"]), _p(xyz_w), tlp._p(c["octave"]), tlp._p(c["angle"]), tlp._p(c["ldesc"]), tlp._p(c["has_obs"]),
+               int(larger), 0, 0.8, int(check), _p(got))
+    assert got_n == want_n > 15
+    assert np.array_equal(got, want)
