@@ -406,4 +406,36 @@ int ref_lines_search_by_projection(const plvs_line_frame_view* fv, const uint8_t
   return n;
 }
 
+// Frame::ComputeStereoMatches  src/Frame.cc:1780-1990 (CPU branch) on a rectified pair: the reference's own
+// ORBextractor runs on both images (Frame::ExtractORB, :806-813) — its pyramids are what the function reads — and the
+// frame takes its key points and descriptors as Frame::Frame does (:331-343).  mb = mbf / fx.  Outputs: mvuRight, mvDepth
+// (n_left entries, n_left returned); *n_right = right key points.
+int ref_frame_compute_stereo_matches(const uint8_t* left, const uint8_t* right, int w, int h, int stride, int nfeatures,
+                                     float scale_factor, int nlevels, int ini_th, int min_th, float mb, float mbf,
+                                     float* u_right, float* depth, int cap, int* n_right) {
+  ORBextractor exl(nfeatures, scale_factor, nlevels, ini_th, min_th), exr(nfeatures, scale_factor, nlevels, ini_th, min_th);
+  Frame F;
+  F.mpORBextractorLeft = &exl;
+  F.mpORBextractorRight = &exr;
+  std::vector<int> lap = {0, 0};
+  cv::Mat il(h, w, CV_8UC1, const_cast<uint8_t*>(left), (size_t)stride), ir(h, w, CV_8UC1, const_cast<uint8_t*>(right), (size_t)stride);
+  F.monoLeft = exl(il, cv::Mat(), F.mvKeys, F.mDescriptors, lap);
+  F.monoRight = exr(ir, cv::Mat(), F.mvKeysRight, F.mDescriptorsRight, lap);
+  F.N = (int)F.mvKeys.size();
+  F.mvKeysUn = F.mvKeys;   // (rectified: no distortion)
+  F.mnScaleLevels = exl.GetLevels();
+  F.mvScaleFactors = exl.GetScaleFactors();
+  F.mvInvScaleFactors = exl.GetInverseScaleFactors();
+  F.mb = mb;
+  F.mbf = mbf;
+  *n_right = (int)F.mvKeysRight.size();
+  if (F.N > cap) return -F.N;
+  F.ComputeStereoMatches();
+  for (int i = 0; i < F.N; ++i) {
+    u_right[i] = F.mvuRight[i];
+    depth[i] = F.mvDepth[i];
+  }
+  return F.N;
+}
+
 }  // extern "C"

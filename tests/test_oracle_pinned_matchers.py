@@ -291,3 +291,31 @@ def test_lines_search_by_projection_last_frame(oracle, ref, seed, stereo, edge, 
                int(larger), 0, 0.8, int(check), _p(got))
     assert got_n == want_n > 15
     assert np.array_equal(got, want)
+
+
+# ---------------------------------------------------------------- Frame::ComputeStereoMatches
+from tests import test_stereo as tst  # noqa: E402
+
+
+@pytest.mark.parametrize("name,nfeatures", [("urban1", 2000), ("shift17", 1000), ("swapped", 1000)])
+def test_frame_compute_stereo_matches(oracle, ref, name, nfeatures):
+    """The reference's own extractor and Frame::ComputeStereoMatches on the pair against the oracle's extractor +
+    oracle/stereo.c: the same mvuRight / mvDepth, bit for bit."""
+    left, right = tst.pair(name)
+    (kl, dl, pl), (kr, dr, pr) = tst.oracle_side(oracle, left, right, nfeatures)
+    s, inv = tst.scale_tables()
+    want_u, want_z, _, kept = oracle.stereo_matches(kl, dl, kr, dr, pl, pr, s, inv, tst.MB, np.float32(tst.KITTI_BF))
+    left, right = np.ascontiguousarray(left), np.ascontiguousarray(right)
+    cap = kl.shape[0] + 16
+    u, z = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+    nr = ctypes.c_int()
+    fn = ref.ref_frame_compute_stereo_matches
+    fn.restype = _i
+    fn.argtypes = [_vp, _vp, _i, _i, _i, _i, _f, _i, _i, _i, _f, _f, _vp, _vp, _i, _vp]
+    n = fn(_p(left), _p(right), left.shape[1], left.shape[0], left.strides[0], nfeatures, tst.SCALE, tst.NLEVELS, 20, 7,
+           float(tst.MB), float(np.float32(tst.KITTI_BF)), _p(u), _p(z), cap, ctypes.byref(nr))
+    assert n == kl.shape[0] and nr.value == kr.shape[0]
+    assert u[:n].tobytes() == want_u.tobytes()
+    assert z[:n].tobytes() == want_z.tobytes()
+    if name != "swapped":
+        assert kept > 0.25 * n
