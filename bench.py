@@ -561,22 +561,28 @@ def main():
     if t2 is not None:
         t2.close()
 
-    # ------------------------------------------------- configs[3]: voxblox 2 cm in the 16x12x3 m room (every N)
+    # ------------------------------------------------- configs[3]: voxblox 2 cm, a stream of distinct key frames (every N)
+    # 25 key frames per step, every step the NEXT 25 of the office loop (depths to 8 m; rays beyond the wrapper's 5 m limit
+    # become clearing rays): 2 warm-up + 4 timed steps = 150 distinct key frames.
     if not vbx and not args.no_voxblox_leg:
-        vk = make_keyframes(25, room_size=(16.0, 12.0, 3.0), max_depth=8.0, seed=0)
-        vxyz = torch.from_numpy(np.concatenate([k["xyz"] for k in vk])).cuda()
-        vrgba = torch.from_numpy(np.concatenate([np.concatenate([k["rgb"], np.full((k["rgb"].shape[0], 1), 255, np.uint8)],
-                                                                axis=1) for k in vk])).cuda()
-        vTwc = torch.from_numpy(np.stack([k["Twc"] for k in vk])).cuda()
-        voff = np.cumsum([0] + [k["xyz"].shape[0] for k in vk]).astype(np.int32)
+        vk = make_stream_keyframes(150, first=400, max_depth=8.0, seed=0, threads=min(32, os.cpu_count() or 8))
+        for k in vk:
+            k["rgba"] = np.concatenate([k["rgb"], np.full((k["rgb"].shape[0], 1), 255, np.uint8)], axis=1)
+        vsteps = []
+        for j0 in range(0, 150, 25):
+            grp = vk[j0:j0 + 25]
+            vsteps.append((torch.from_numpy(np.concatenate([k["xyz"] for k in grp])).cuda(),
+                           torch.from_numpy(np.concatenate([k["rgba"] for k in grp])).cuda(),
+                           np.cumsum([0] + [k["xyz"].shape[0] for k in grp]).astype(np.int32),
+                           torch.from_numpy(np.stack([k["Twc"] for k in grp])).cuda()))
         vb = TsdfVoxblox(0.02, max_blocks=65536, shard_rank=rank, shard_count=world)
-        for _ in range(2):
-            vb.integrate_batch_dev(vxyz, vrgba, voff, vTwc)
+        for b in vsteps[:2]:
+            vb.integrate_batch_dev(*b)
         barrier()
         t0 = time.perf_counter()
         vv = vp = 0
-        for _ in range(4):
-            vb.integrate_batch_dev(vxyz, vrgba, voff, vTwc)
+        for b in vsteps[2:]:
+            vb.integrate_batch_dev(*b)
             stv = vb.last_stats()
             vv += stv["visits"]
             vp += stv["points"]
@@ -593,14 +599,63 @@ def main():
             vv_total = vv
         if rank == 0:
             ach = (24.0 * vv + 16.0 * vp) / vel / 1e9
-            result["voxblox_configs3"] = {
-                "metric": "Mvoxels/sec TSDF integrate (voxblox simple 2 cm, 16x12x3 m room, depths to 8 m, max ray 5 m)",
+            leg = {
+                "metric": "Mvoxels/sec TSDF integrate (voxblox simple 2 cm, office stream, depths to 8 m, max ray 5 m)",
                 "value": round(vv_total / vel / 1e6, 2), "unit": "Mvoxels/s", "n_gpus": world, "keyframes_per_step": 25,
+                "workload": "configs[3] stand-in, STREAMING: 4 timed steps of 25 DISTINCT key frames each (key frames 450-549 of "
+                            "the office loop of plvs_amd/synth_scene.py after 2 warm-up steps), Voxblox simple TSDF 2 cm",
                 "ms_per_step": round(vel / 4 * 1e3, 3), "visits_per_step": int(vv_total // 4),
                 "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
-                             "frac": round(ach / 8000.0, 5),
+                             "frac": round(ach / 8000.0, 5), "traffic": None,
                              "note": "24 B per visit + 16 B per point over the wall time of the call (this rank's share)"},
             }
+            pmc_v = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_pmc_traffic_voxblox.json")
+            if world == 1 and os.path.exists(pmc_v):
+                with open(pmc_v) as f:
+                    leg["roofline"]["traffic"] = json.load(f)["traffic"]
+                leg["roofline"]["traffic_source"] = "profiles/r04_pmc_traffic_voxblox.json (FETCH_SIZE x2 + WRITE_SIZE per call)"
+            # the reference's own SimpleTsdfIntegrator on the host cores (oracle/_ref/libvoxblox_ref_o3.so: tsdf_integrator.cc
+            # compiled unmodified, -O3 -march=x86-64-v3), integrator_threads = 1 and = hardware_concurrency (its default)
+            vref = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "_ref", "libvoxblox_ref_o3.so")
+            if world == 1 and not args.no_cpu_baseline and os.path.exists(vref):
+                import ctypes as _ct
+                from tests import oracle_lib
+                _o = oracle_lib.load()
+                _o.lib.oracle_voxblox_pose_quat.argtypes = [_ct.c_void_p, _ct.c_void_p]
+                _r = _ct.CDLL(vref)
+                _r.ref_voxblox_create_threads.restype = _ct.c_void_p
+                _r.ref_voxblox_create_threads.argtypes = [_ct.c_float] * 5 + [_ct.c_int, _ct.c_char_p, _ct.c_int]
+                _r.ref_voxblox_integrate.argtypes = [_ct.c_void_p] * 5 + [_ct.c_int]
+                _r.ref_voxblox_destroy.argtypes = [_ct.c_void_p]
+                sample = vk[50:58]                      # the first 8 key frames of the timed steps
+                probe = _o.voxblox(0.02)
+                rvis = 0
+                for k in sample:
+                    probe.integrate(k["xyz"], k["rgba"], k["Twc"])
+                    rvis += probe.last_visits()         # (the reference exposes no visit counter: the port's count)
+                probe.close()
+                base = {}
+                for name, nthreads in (("1", 1), ("hardware_concurrency", 0)):
+                    hh = _ct.c_void_p(_r.ref_voxblox_create_threads(0.02, 0.1, 10000.0, 0.1, 5.0, 0, b"simple", nthreads))
+                    t0 = time.perf_counter()
+                    for k in sample:
+                        q = np.zeros(4, np.float32)
+                        Twc_ = np.ascontiguousarray(k["Twc"], np.float32)
+                        _o.lib.oracle_voxblox_pose_quat(Twc_.ctypes.data, q.ctypes.data)
+                        tpos = np.ascontiguousarray(Twc_[:, 3])
+                        _r.ref_voxblox_integrate(hh, q.ctypes.data, tpos.ctypes.data, k["xyz"].ctypes.data, k["rgba"].ctypes.data,
+                                                 k["xyz"].shape[0])
+                    base[name] = time.perf_counter() - t0
+                    _r.ref_voxblox_destroy(hh)
+                leg["cpu_baseline"] = {
+                    "value": round(rvis / base["1"] / 1e6, 3), "unit": "Mvoxels/s", "cores": 1, "kind": "reference",
+                    "all_cores": {"value": round(rvis / base["hardware_concurrency"] / 1e6, 3), "unit": "Mvoxels/s",
+                                  "cores": os.cpu_count(), "integrator_threads": "hardware_concurrency (voxblox's default)"},
+                    "sample": f"voxblox::SimpleTsdfIntegrator::integratePointCloud of the reference's own tsdf_integrator.cc (g++ -O3 "
+                              f"-march=x86-64-v3, oracle/_ref/libvoxblox_ref_o3.so) over 8 key frames of the timed stream into a "
+                              f"fresh 2 cm layer, {base['1']:.1f} s at integrator_threads = 1, {base['hardware_concurrency']:.1f} s at "
+                              f"hardware_concurrency; host has {os.cpu_count()} cores"}
+            result["voxblox_configs3"] = leg
         vb.close()
 
     # ------------------------------------------------- front end (N = 1 only)
@@ -767,13 +822,13 @@ def main():
 
             def track_once():
                 img = pinned[1].cuda(non_blocking=True)
-                _, k1, d1, l1, ld1 = extract_frame(ext3, lext3, img, after_points=match_points)
+                _, k1, d1, l1, ld1, hooked = extract_frame(ext3, lext3, img, after_points=match_points)
                 lview = line_frame_view(l1, ld1, tlp.SCALE, tlp.INV_SIGMA2, tlp.MAX_DIAG)
                 nl_, _ = lm4.SearchByProjectionLastFrame(lview, lvalid, lproj, l0["octave"], l0["angle"], ld0)
                 track_once.line_matches = nl_
                 cur = FrameView(k1["x"], k1["y"], k1["octave"], no_uright[:len(k1)], d1, 0.0, 0.0,
                                 64.0 / 640.0, 48.0 / 480.0, scale)
-                return extract_frame.hook_result, cur, k1
+                return hooked, cur, k1
 
             (nm, _), cur, k1 = track_once()
             real_us = per_call_us(lambda: track_once(), 30)

@@ -729,10 +729,15 @@ int plvs_hip_tsdf_chisel_halo_clear(plvs_tsdf_chisel* h);
  *   computeDisparity   Elas::computeDisparity, Thirdparty/libelas-gpu/CPU/elas.cpp:840-968 (findMatch :739-837)
  *   adaptiveMean       Elas::adaptiveMean,     Thirdparty/libelas-gpu/CPU/elas.cpp:1349-1572
  * as PointCloudKeyFrame::ProcessStereoLibelas reaches them (src/PointCloudKeyFrame.cc:335-432 ->
- * libelas::ElasInterface::process -> Elas::process, elas.cpp:36-159).  Descriptors, support matches, the Delaunay
- * triangulation, planes, grid, left/right check, speckle removal and gap interpolation stay the caller's host code, as in
- * that build.  All pointers are HOST pointers (the reference's call sites hand over host memory); results are bit-identical
- * to the CPU methods.
+ * libelas::ElasInterface::process -> Elas::process, elas.cpp:36-159) — and, beyond that build, the other stages a pair
+ * goes through (entry points further down): the descriptor images (plvs_hip_elas_set_images), the candidate loop of
+ * computeSupportMatches (_support_candidates), leftRightConsistencyCheck (_left_right_check), removeSmallSegments
+ * (_remove_small_segments) and gapInterpolation (_gap_interpolation).  The support filters, the Delaunay triangulation,
+ * the planes and the grid stay the caller's host code.  All pointers are HOST pointers (the reference's call sites hand
+ * over host memory); results are bit-identical to the CPU methods — of a reference whose uninitialised reads see zeros
+ * (oracle/ref/elas_zero_malloc.h: its sources read allocated memory they never wrote; parity is pinned through that
+ * hook).  Preconditions the post-processing stages share with the reference: invalid pixels hold -10;
+ * speckle_sim_threshold < 10.
  *   params            the fields of Elas::Parameters (elas.h:62-90) the two methods read
  *   compute_disparity support: n_support x {u, v, d} (Elas::support_pt); tri: n_tri x 36-byte Elas::triangle records
  *                     {c1, c2, c3, t1a, t1b, t1c, t2a, t2b, t2c}; disparity_grid / grid_dims as Elas::createGrid leaves

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 
 #include "voxblox/core/layer.h"
 #include "voxblox/core/voxel.h"
@@ -50,6 +51,20 @@ void* ref_voxblox_create(float voxel_size, float truncation, float max_weight, f
   c.start_voxel_subsampling_factor = 2.0f;   // (fast integrator: src/PointCloudMapVoxblox.cc:67-69)
   c.max_consecutive_ray_collisions = 2;
   c.clear_checks_every_n_frames = 1;
+  if (std::string(method) == "fast") m->integrator.reset(new voxblox::FastTsdfIntegrator(c, m->layer.get()));
+  else if (std::string(method) == "merged") m->integrator.reset(new voxblox::MergedTsdfIntegrator(c, m->layer.get()));
+  else m->integrator.reset(new voxblox::SimpleTsdfIntegrator(c, m->layer.get()));
+  return m;
+}
+
+// The same with integrator_threads given (0 = std::thread::hardware_concurrency(), voxblox's own default,
+// include/voxblox/integrator/tsdf_integrator.h:49): for TIMING the reference (bench.py's cpu_baseline of the voxblox leg) —
+// with more than one thread the voxel updates of different rays interleave and the map is no longer a function of the input.
+void* ref_voxblox_create_threads(float voxel_size, float truncation, float max_weight, float min_ray, float max_ray, int carving,
+                                 const char* method, int threads) {
+  RefMap* m = static_cast<RefMap*>(ref_voxblox_create(voxel_size, truncation, max_weight, min_ray, max_ray, carving, method));
+  voxblox::TsdfIntegratorBase::Config c = m->integrator->getConfig();
+  c.integrator_threads = threads > 0 ? (size_t)threads : (size_t)std::max(1u, std::thread::hardware_concurrency());
   if (std::string(method) == "fast") m->integrator.reset(new voxblox::FastTsdfIntegrator(c, m->layer.get()));
   else if (std::string(method) == "merged") m->integrator.reset(new voxblox::MergedTsdfIntegrator(c, m->layer.get()));
   else m->integrator.reset(new voxblox::SimpleTsdfIntegrator(c, m->layer.get()));

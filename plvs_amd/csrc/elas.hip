@@ -92,7 +92,8 @@ __global__ __launch_bounds__(64) void elas_owner(MatchParams P, const Triangle* 
       const int32_t v_1 = trunc_u32_as_i32(s.AC_a * (float)u + s.AC_b);
       const int32_t v_2 = trunc_u32_as_i32(e_a * (float)u + e_b);
       // (rows outside the image would be writes outside D in the reference: its triangles never produce them)
-      const int v_begin = max(min(v_1, v_2), 0), v_end = min(max(v_1, v_2), P.height);
+      // (with subsampling the owner map has height / 2 rows: an odd height's last row has none)
+      const int v_begin = max(min(v_1, v_2), 0), v_end = min(max(v_1, v_2), P.subsampling ? 2 * (P.height / 2) : P.height);
       for (int v = v_begin; v < v_end; ++v)
         if (!P.subsampling || (v % 2) == 0) {
           const size_t at = P.subsampling ? (size_t)(v / 2) * ow + u / 2 : (size_t)v * ow + u;
@@ -696,6 +697,11 @@ int plvs_hip_elas_compute_disparity(plvs_elas* h, const int32_t* support, int n_
                "the disparity grid does not cover the image");
   const Support* hs = reinterpret_cast<const Support*>(support);
   const Triangle* ht = static_cast<const Triangle*>(tri);
+  // (u, v, d per support point: inside the image as computeSupportMatches leaves them, or ON its far edges — the corner
+  // points addCornerSupportPoints adds sit at u = width, v = height, elas.cpp:1594-1601; elas_owner clamps its rows)
+  for (int i = 0; i < n_support; ++i)
+    PLVS_REQUIRE(support[3 * i] >= 0 && support[3 * i] <= width && support[3 * i + 1] >= 0 && support[3 * i + 1] <= height,
+                 "support point outside the image");
   for (int i = 0; i < n_tri; ++i)
     PLVS_REQUIRE(ht[i].c1 >= 0 && ht[i].c1 < n_support && ht[i].c2 >= 0 && ht[i].c2 < n_support && ht[i].c3 >= 0 &&
                      ht[i].c3 < n_support, "triangle corner outside the support points");

@@ -237,9 +237,12 @@ int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm,
   static thread_local Scratch B;
   constexpr size_t kWords[3] = {8, 8, 20};   // uint32 words of a descriptor, a voxel sum, a run
   int64_t sc[3 * 64], rcv[3 * 64];
-  // A rank whose own stage fails must not leave its peers blocked inside a collective: it goes through the
-  // exchanges with nothing to send and says so in its counts (-1), the peers finish the step with what arrived and
-  // every rank returns an error — the failing one its own, the others PLVS_ERR_HALO.
+  // A rank whose walk fails must not leave its peers blocked inside a collective: it goes through the exchanges with
+  // nothing to send and says so in its counts (-1).  Every rank learns of it in the counts exchange and NOBODY applies
+  // anything: the step is void on every rank (the maps stay as they were, the step can be repeated); the failing rank
+  // returns its own error, the others PLVS_ERR_HALO.  A failure AFTER the counts exchange (packing, applying, a HIP or
+  // RCCL error inside this function) cannot be taken back on the ranks that have applied: the error message says that
+  // the sharded map is inconsistent and must be cleared / rebuilt.
   int failed = plvs_hip_tsdf_chisel_shard_walk(h, d_xyz, offsets, nclouds, d_Twc, sc, stream);
   if (failed != PLVS_OK)
     for (int p = 0; p < world; ++p) sc[3 * p] = -1, sc[3 * p + 1] = 0, sc[3 * p + 2] = 0;
@@ -282,10 +285,12 @@ int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm,
     PLVS_HIP_TRY(B.send[k].reserve(stot[k] * kWords[k] + 4));
     PLVS_HIP_TRY(B.recv[k].reserve(rtot[k] * kWords[k] + 4));
   }
+  bool late_failure = false;   // a failure after the counts exchange: peers may apply what this rank could not
   if (failed == PLVS_OK) {
     failed = plvs_hip_tsdf_chisel_shard_pack(h, B.send[0].p, B.send[1].p, B.send[2].p, stream);
     // (the peers already expect this rank's counts: what goes out after a failed pack is unspecified data of the
-    // announced size; this rank's error return tells the caller the step is void)
+    // announced size)
+    late_failure = failed != PLVS_OK;
   }
   RCCL_TRY(r->group_start());
   {
@@ -300,10 +305,14 @@ int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm,
       }
   }
   RCCL_TRY(r->group_end());
-  if (failed == PLVS_OK) failed = plvs_hip_tsdf_chisel_shard_apply(h, B.recv[0].p, B.recv[1].p, B.recv[2].p, rcv, d_rgb, d_kfid, stream);
+  // (a peer announced a failed walk: the step is void — nothing is applied here either, no saturation is reported)
+  if (failed == PLVS_OK && !peer_failed) {
+    failed = plvs_hip_tsdf_chisel_shard_apply(h, B.recv[0].p, B.recv[1].p, B.recv[2].p, rcv, d_rgb, d_kfid, stream);
+    late_failure = failed != PLVS_OK;
+  }
   // ---- voxels whose colour saturated: every rank notes every list
   int nsat = 0;
-  if (failed == PLVS_OK) {
+  if (failed == PLVS_OK && !peer_failed) {
     rc = plvs_hip_tsdf_chisel_shard_saturated(h, nullptr, 0, &nsat, stream);
     if (rc != PLVS_OK && rc != PLVS_ERR_CAPACITY) { failed = rc; nsat = 0; }
   }
@@ -318,15 +327,29 @@ int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm,
   if (cap > 0) {
     PLVS_HIP_TRY(B.sat.reserve((size_t)cap * 4));
     PLVS_HIP_TRY(B.all_sat.reserve((size_t)cap * 4 * world));
-    if (nsat > 0 && failed == PLVS_OK) failed = plvs_hip_tsdf_chisel_shard_saturated(h, B.sat.p, cap, &nsat, stream);
+    if (nsat > 0 && failed == PLVS_OK && !peer_failed) {
+      failed = plvs_hip_tsdf_chisel_shard_saturated(h, B.sat.p, cap, &nsat, stream);
+      late_failure = late_failure || failed != PLVS_OK;
+    }
     RCCL_TRY(r->all_gather(B.sat.p, B.all_sat.p, (size_t)cap * 4, /*ncclInt32*/ 2, rccl_comm, s));
-    for (int p = 0; p < world && failed == PLVS_OK; ++p)
+    for (int p = 0; p < world && failed == PLVS_OK && !peer_failed; ++p) {
       failed = plvs_hip_tsdf_chisel_shard_note_saturated(h, B.all_sat.p + (size_t)p * cap * 4, all_n[p], stream);
+      late_failure = late_failure || failed != PLVS_OK;
+    }
   }
 #undef RCCL_TRY
-  if (failed != PLVS_OK) return failed;
+  if (failed != PLVS_OK) {
+    if (late_failure) {   // (keep this rank's own message, add what it means for the job)
+      char own[400];
+      snprintf(own, sizeof own, "%s", plvs::last_error_buf());
+      plvs::set_error("%s — after the exchange had begun: other ranks may have applied this step, the sharded map is "
+                      "inconsistent (clear or rebuild it on every rank)", own);
+    }
+    return failed;
+  }
   if (peer_failed) {
-    plvs::set_error("a peer rank failed in its share of the sharded integrate: the step is void on every rank");
+    plvs::set_error("a peer rank failed in its walk of the sharded integrate: nothing was applied on any rank that reports "
+                    "this (the step is void and can be repeated once the peer recovers)");
     return PLVS_ERR_HALO;
   }
   return PLVS_OK;

@@ -978,7 +978,7 @@ constexpr int kFastEntries = 2048, kFastEntriesBig = 4096;
 constexpr uint32_t kRecStride = kFastEntriesBig * 7 / 8;
 constexpr uint32_t kSmallCallTiles = 320;
 constexpr unsigned kListGrid = 512;      // workgroups of the large-table pass over the first list (it loops)
-static_assert(kFastEntries == kWalkEntries, "the shard path sizes its regions by the general kernel's limit");
+static_assert(kRecStride == (uint32_t)kWalkLimit, "a tile's record region holds a flush of the largest table");
 const char* const kWalkStageNames[kWalkStages] = {"walk_tiles", "sort_segments", "apply_chunks", "fold_colours"};
 
 static int read_walk_counters(plvs_tsdf_chisel* h, hipStream_t s) {
@@ -1126,7 +1126,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     hipLaunchKernelGGL((walk_tiles<true, true>), dim3(kDeferGrid), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
                        h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
                        (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u}, (uint32_t)ntiles, last_list, last_count,
-                       kRecStride, 4u);   // (what is flagged overflowed the 4096-entry table: four pieces at once)
+                       kRecStride, 2u);   // (what is flagged overflowed a 4096-entry table: two pieces at once)
     PLVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
     STAGE_MARK(1);
     const unsigned seg_blocks = ceil_div(seg_own + seg_spill, kSegSpan);
@@ -2558,7 +2558,8 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
     hipLaunchKernelGGL((walk_tiles<true, true>), dim3(kDeferGrid), dim3(kWalkRays), 0, s, Pw, h->scale_u, h->scale_w, d_xyz, n,
                        h->offsets.p, nclouds, h->poses.p, h->xdir, h->d_xcount, h->d_wctr, (const uint32_t*)nullptr,
                        (const uint32_t*)h->x_sat, out, runs, tmap, (uint32_t)nt, (const uint32_t*)h->w_deferred.p,
-                       (const uint32_t*)&h->d_wctr->ndeferred, (uint32_t)kWalkLimit, 2u);
+                       (const uint32_t*)&h->d_wctr->ndeferred, (uint32_t)kWalkLimit,
+                       1u);   // (flagged = overflowed 2048 entries: this kernel's table takes 3584, the tile goes whole)
     const unsigned seg_blocks = ceil_div(seg_own + seg_spill, kSegSpan);
     hipLaunchKernelGGL(seg_pass<false>, dim3(seg_blocks), dim3(256), 0, s, h->w_seg.p, out.seg_cap, nt, h->w_seg_cnt.p,
                        h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p, h->d_wctr);

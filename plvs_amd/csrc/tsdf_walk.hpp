@@ -55,8 +55,11 @@ constexpr int kMaskWords = kWalkRays / 32;      // a run's ray mask
 // touch 800 - 2000 distinct voxels (the rays of neighbouring pixels stop sharing voxels once the pixel footprint nears
 // the voxel size); with 1024 entries half the tiles of a real office scene overflowed and took the slow general path
 // (rounds 1-3 only ever measured a 6 x 4 m room, depths below 3 m: 300 - 600 voxels per tile).
+// (this constant: the table of the GENERAL kernel, walk_tiles — one tile per CU; the lean kernel walk_fast<E> takes its
+// table size as a template parameter: 2048 entries at two tiles per CU for the bulk of a long call, 4096 for the tiles
+// that overflow that)
 #ifndef PLVS_WALK_ENTRIES
-#define PLVS_WALK_ENTRIES 2048
+#define PLVS_WALK_ENTRIES 4096
 #endif
 constexpr int kWalkEntries = PLVS_WALK_ENTRIES;
 constexpr int kWalkLimit = kWalkEntries * 7 / 8;   // entries a (sub-)tile may use (buckets of four: probes stay short)
@@ -604,7 +607,7 @@ struct TileMap {
 // of the rays in the ray-sharded integrate: dir = the rank's directory of every chunk it has walked through,
 // sat = its bitmap of the voxels their owners have reported saturated (4096 bits per directory slot).
 template <bool kAcc, bool kRuns>
-__global__ __launch_bounds__(kWalkRays, kWalkEntries > 1024 ? 4 : 6) void walk_tiles(
+__global__ __launch_bounds__(kWalkRays, kWalkEntries > 2048 ? 2 : (kWalkEntries > 1024 ? 4 : 6)) void walk_tiles(
     Params P, float scale_u, float scale_w, const float* __restrict__ xyz, int npoints,
     const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
     int32_t* __restrict__ num_chunks, WalkCounters* __restrict__ ctr, const uint32_t* __restrict__ rgbw,

@@ -1,8 +1,11 @@
 """Host-side mirror of libelas::ElasGPU (Thirdparty/libelas-gpu/GPU/elas_gpu.h:29-47): the two methods of libelas::Elas the
 reference's accelerated build overrides — computeDisparity and adaptiveMean — as PointCloudKeyFrame::ProcessStereoLibelas
-reaches them (src/PointCloudKeyFrame.cc:335-432).  Same argument meaning as the reference's methods; the rest of
-Elas::process (descriptors, support matches, triangulation, planes, grid, left/right check, speckles, gaps) is the
-caller's.  The arithmetic runs in libplvs_hip.so; there is no CPU fallback."""
+reaches them (src/PointCloudKeyFrame.cc:335-432) — and the other device stages of a pair: setImages (the descriptor
+images), supportCandidates (the candidate loop of computeSupportMatches), leftRightConsistencyCheck, removeSmallSegments,
+gapInterpolation.  Same argument meaning as the reference's methods; the support filters, the triangulation, the planes
+and the grid of Elas::process are the caller's.  Preconditions shared with the reference: invalid pixels hold -10,
+speckle_sim_threshold < 10; parity is against a reference whose uninitialised reads see zeros (oracle/ref/
+elas_zero_malloc.h).  The arithmetic runs in libplvs_hip.so; there is no CPU fallback."""
 import ctypes
 
 import numpy as np
@@ -40,7 +43,7 @@ L.plvs_hip_elas_gap_interpolation.argtypes = [_vp, _vp, _i, _i]
 
 class ElasGPU:
     class Parameters:
-        """The fields of Elas::Parameters (elas.h:62-90) the two methods read; defaults: the ROBOTICS setting (:97-121)
+        """The fields of Elas::Parameters (elas.h:62-90) the device stages read; defaults: the ROBOTICS setting (:97-121)
         PLVS starts from, `subsampling` as PLVS sets it (PointCloudMapping::skDownsampleStep even)."""
 
         def __init__(self, subsampling=False, grid_size=20, match_texture=1, beta=0.02, gamma=3.0, sigma=1.0, sradius=2.0,

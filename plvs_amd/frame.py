@@ -20,10 +20,11 @@ L.plvs_hip_frame_extract_dev_hook.argtypes = L.plvs_hip_frame_extract_dev.argtyp
 
 def extract_frame(orb: ORBextractor, lines: LineExtractor, image: torch.Tensor, vLappingArea=(0, 0), after_points=None):
     """image: 2-D uint8 CUDA tensor.  -> (monoIndex, keypoints, descriptors, keylines, line descriptors)
+    — and, with after_points, a sixth element: what the hook returned (None when it did not run).
 
     after_points(keypoints, descriptors): called on this thread as soon as the points are out, while the line thread
     is still extracting (what the caller does with the points alone: the ORB SearchByProjection of the tracking
-    step); its return value is kept in extract_frame.hook_result."""
+    step)."""
     assert image.is_cuda and image.dtype == torch.uint8 and image.dim() == 2
     torch.cuda.current_stream().synchronize()
     h, w = image.shape
@@ -34,13 +35,13 @@ def extract_frame(orb: ORBextractor, lines: LineExtractor, image: torch.Tensor, 
     if after_points is None:
         _lib.check(L.plvs_hip_frame_extract_dev(*args))
     else:
-        failure = []
+        failure, hooked = [], [None]
 
         def hook(_user, status):
             if status != 0 or nk.value > orb._cap:
                 return
             try:
-                extract_frame.hook_result = after_points(orb._kps[:nk.value], orb._desc[:nk.value])
+                hooked[0] = after_points(orb._kps[:nk.value], orb._desc[:nk.value])
             except BaseException as e:      # (an exception must not unwind through the C frame)
                 failure.append(e)
 
@@ -49,5 +50,6 @@ def extract_frame(orb: ORBextractor, lines: LineExtractor, image: torch.Tensor, 
             raise failure[0]
     if nk.value > orb._cap or nl.value > lines._cap:
         raise RuntimeError("extract_frame: output capacity exceeded")
-    return (mono.value, orb._kps[:nk.value].copy(), orb._desc[:nk.value].copy(),
-            lines._kl[:nl.value].copy(), lines._desc[:nl.value].copy())
+    out = (mono.value, orb._kps[:nk.value].copy(), orb._desc[:nk.value].copy(),
+           lines._kl[:nl.value].copy(), lines._desc[:nl.value].copy())
+    return out if after_points is None else out + (hooked[0],)

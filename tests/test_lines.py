@@ -188,8 +188,8 @@ def test_hip_frame_extract_hook_sees_the_points_before_the_lines_are_out(oracle)
         return len(kps)
 
     for _ in range(3):
-        mono, kps, desc, kl, ldesc = extract_frame(orb, lines, torch.from_numpy(img).cuda(), after_points=hook)
-        assert extract_frame.hook_result == len(okps)
+        mono, kps, desc, kl, ldesc, hooked = extract_frame(orb, lines, torch.from_numpy(img).cuda(), after_points=hook)
+        assert hooked == len(okps)
         assert mono == omono and kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
         assert kl.tobytes() == okl.tobytes() and np.array_equal(ldesc, oldesc)
     assert len(seen) == 3
