@@ -697,11 +697,12 @@ int plvs_hip_elas_compute_disparity(plvs_elas* h, const int32_t* support, int n_
                "the disparity grid does not cover the image");
   const Support* hs = reinterpret_cast<const Support*>(support);
   const Triangle* ht = static_cast<const Triangle*>(tri);
-  // (u, v, d per support point: inside the image as computeSupportMatches leaves them, or ON its far edges — the corner
-  // points addCornerSupportPoints adds sit at u = width, v = height, elas.cpp:1594-1601; elas_owner clamps its rows)
+  // (u, v, d per support point: inside the image as computeSupportMatches leaves them and addCornerSupportPoints its four
+  // corners — plus the two points that function adds for the right image at u = width - 1 + d, beyond the right edge,
+  // elas.cpp:262-293; elas_owner clamps columns and rows to the maps)
   for (int i = 0; i < n_support; ++i)
-    PLVS_REQUIRE(support[3 * i] >= 0 && support[3 * i] <= width && support[3 * i + 1] >= 0 && support[3 * i + 1] <= height,
-                 "support point outside the image");
+    PLVS_REQUIRE(support[3 * i] >= 0 && support[3 * i] <= width + h->prm.disp_max + 1 && support[3 * i + 1] >= 0 &&
+                     support[3 * i + 1] <= height, "support point outside the image");
   for (int i = 0; i < n_tri; ++i)
     PLVS_REQUIRE(ht[i].c1 >= 0 && ht[i].c1 < n_support && ht[i].c2 >= 0 && ht[i].c2 < n_support && ht[i].c3 >= 0 &&
                      ht[i].c3 < n_support, "triangle corner outside the support points");
