@@ -179,8 +179,11 @@ def main():
     points = 0
     max_run = 0
     voxels = 0
+    step_wall = []
     for s in range(args.warmup, total_steps):
+        ts0 = time.perf_counter()
         st = step(batches[s])
+        step_wall.append(time.perf_counter() - ts0)   # (last_stats() has waited for the step: a per-step host clock)
         visits += st["visits"]
         points += st["points"]
         max_run = max(max_run, st["max_run"])
@@ -297,6 +300,7 @@ def main():
                        "mode": None if vbx else mode_name,
                        "resolution": args.resolution, "max_depth": args.max_depth,
                        "keyframes_per_step": step_kfs, "points_per_step": int(points // args.steps),
+                       "ms_per_step_median_max": [round(float(np.median(step_wall)) * 1e3, 3), round(max(step_wall) * 1e3, 3)],
                        "visits_per_step": int(visits_total // args.steps),
                        "voxels_per_step": int(voxels // args.steps), "longest_voxel_run": int(max_run),
                        "parallelism": (f"ray-sharded x{world}: rank r walks tiles t = r (mod {world}), partial sums and "
@@ -980,6 +984,107 @@ def main():
             result["frontend"]["dense_stereo_elas"] = leg
         except Exception as e:
             result["frontend"]["dense_stereo_elas"] = {"skipped": repr(e)}
+
+        # ---- configs[4] as the shipped YAML runs it (KITTI00-02.yaml: 1241x376 stereo, libelas, chisel 10 cm), one key frame:
+        # ORB 2000 || EDLines/LBD on the left image, the libelas pair with every device stage (the two disparity maps stay in
+        # HBM, the post-processing is one call), disparity -> depth -> cloud with normals on the device, one 10 cm integrate
+        try:
+            from tests import elas_ref
+            from plvs_amd import cloudgen
+            from plvs_amd.elas import ElasGPU
+            if not elas_ref.available():
+                raise RuntimeError("oracle/_ref/libelas_ref.so is not built here")
+            kl_, kr_ = golden("urban1_1241x376.pgm"), golden("urban1_right_1241x376.pgm")
+            kh, kw = kl_.shape
+            kfx, kcx, kcy, kbf = 718.856, 607.1928, 185.2157, 386.1448
+            ext_k, lext_k = ORBextractor(2000, 1.2, 8, 20, 7), LineExtractor(100)
+            d_left = torch.from_numpy(kl_).cuda()
+            eg = ElasGPU(ElasGPU.Parameters(subsampling=True))
+            kgrid = cloudgen.InitCamGridPoints(kw, kh, 2, kfx, kfx, kcx, kcy)
+            kgen = cloudgen.PointCloudGenerator(kw, kh, kgrid, step=2, min_depth=0.5, max_depth=20.0)
+            d_bgr = torch.from_numpy(np.repeat(kl_[:, :, None], 3, axis=2)).cuda()
+            d_depth = torch.empty((kh, kw), dtype=torch.float32, device="cuda")
+            d_xyz = torch.empty((kgen.ngrid, 3), dtype=torch.float32, device="cuda")
+            d_rgb = torch.empty((kgen.ngrid, 3), dtype=torch.uint8, device="cuda")
+            d_kf = torch.empty(kgen.ngrid, dtype=torch.int32, device="cuda")
+            kTwc = torch.from_numpy(np.eye(4, dtype=np.float32)[None, :3]).cuda()
+            kmap = TsdfChisel(0.10, max_chunks=16384, order_free=True)
+            stage = {}
+
+            def clock(name, fn):
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                out = fn()
+                torch.cuda.synchronize()
+                stage[name] = stage.get(name, 0.0) + (time.perf_counter() - t0_)
+                return out
+
+            def elas_pair():
+                eg.setImages(kl_, kr_)
+
+                def chain(D1, D2):
+                    D1[:], D2[:] = eg.postProcess(kw, kh, postprocess_only_left=True, filter_adaptive_mean=True)
+                return elas_ref.run_with(
+                    kl_, kr_, lambda a: eg.computeDisparity(a["support"], a["tri"], a["grid"], a["grid_dims"], None, None,
+                                                            a["right_image"], kw, kh),
+                    lambda D, ww, hh, sub: D, subsampling=True, plvs=True,
+                    support_candidates=lambda a: eg.supportCandidates(None, None, kw, kh),
+                    post=dict(left_right_check=chain, remove_small_segments=lambda D: None, gap_interpolation=lambda D: None))
+
+            def cloud_and_map():
+                eg.depthDev(kbf, 2, d_depth)
+                npts = kgen.generate_dev(d_bgr, d_depth, 7, d_xyz, d_rgb=d_rgb, d_kfid=d_kf)
+                kmap.integrate_batch_dev(d_xyz, d_rgb, d_kf, np.array([0, npts], np.int32), kTwc)
+                return npts
+
+            for _ in range(3):
+                extract_frame(ext_k, lext_k, d_left)
+                elas_pair()
+                cloud_and_map()
+            stage.clear()
+            nrep_k = 10
+            for _ in range(nrep_k):
+                clock("orb_and_lines", lambda: extract_frame(ext_k, lext_k, d_left))
+                maps = clock("libelas_pair_incl_reference_host_stages", elas_pair)
+                npts = clock("depth_cloud_integrate_10cm", cloud_and_map)
+            want_maps = elas_ref.reference(kl_, kr_, subsampling=True, plvs=True)
+            # CPU beside: the reference pipeline itself, the oracles' extraction on two threads, cloud + integrate by the ports
+            t0 = time.perf_counter()
+            elas_ref.reference(kl_, kr_, subsampling=True, plvs=True)
+            cpu_elas = time.perf_counter() - t0
+            o_orb_k, o_lines_k = ora.orb(2000, 1.2, 8, 20, 7), ora.lines()
+            t0 = time.perf_counter()
+            th_ = [threading.Thread(target=o_orb_k.extract, args=(kl_,)), threading.Thread(target=o_lines_k.extract, args=(kl_,))]
+            for t_ in th_:
+                t_.start()
+            for t_ in th_:
+                t_.join()
+            cpu_fe = time.perf_counter() - t0
+            depth_h = d_depth.cpu().numpy()
+            t0 = time.perf_counter()
+            rec_k, _ = ora.cloudgen(depth_h, np.repeat(kl_[:, :, None], 3, axis=2), kgrid, 2, 0.5, 20.0, 7)
+            o_map = ora.chisel(0.10)
+            o_map.integrate(np.stack([rec_k["x"], rec_k["y"], rec_k["z"]], -1), np.stack([rec_k["r"], rec_k["g"], rec_k["b"]], -1),
+                            rec_k["kfid"], np.eye(4, dtype=np.float32)[:3])
+            cpu_cloud = time.perf_counter() - t0
+            result["kitti_shaped"] = {
+                "what": "configs[4] as shipped (Examples_old/Stereo/KITTI00-02.yaml: 1241x376 stereo, libelas with subsampling, chisel "
+                        "10 cm), one key frame: ORB 2000 || EDLines/LBD 100x3 on the left image; the libelas pair with every device "
+                        "stage (descriptors, support candidates, computeDisparity x2 left in HBM, the post-processing chain as one "
+                        "call) inside the reference's own Elas::process, whose host stages (support filters, triangulation, planes, "
+                        "grid) run on one core; disparity -> depth -> cloud with normals on the device and one order-free integrate",
+                "ms_per_keyframe": round(sum(stage.values()) / nrep_k * 1e3, 3),
+                "stage_ms": {k: round(v / nrep_k * 1e3, 3) for k, v in stage.items()},
+                "points": int(npts), "disparity_maps_bit_identical_to_reference": bool(
+                    all(np.array_equal(g.view(np.uint32), w_.view(np.uint32)) for g, w_ in zip(maps, want_maps))),
+                "cpu_ms": {"orb_and_lines_two_threads_port": round(cpu_fe * 1e3, 2), "libelas_reference_pipeline": round(cpu_elas * 1e3, 2),
+                           "cloud_and_integrate_port": round(cpu_cloud * 1e3, 2), "cores": 2}}
+            kmap.close()
+            eg.close()
+            ext_k.close()
+            lext_k.close()
+        except Exception as e:
+            result["kitti_shaped"] = {"skipped": repr(e)}
 
     # -------------------------------------------------- CPU baseline when the parity leg did not run (rank 0)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and "cpu_baseline" not in result:

@@ -394,6 +394,30 @@ int plvs_hip_frame_extract_dev_hook(plvs_orb* orb, plvs_lines* lines, const uint
                                     plvs_keyline* keylines, uint8_t* line_desc, int line_cap,
                                     int* n_lines, void (*after_points)(void* user, int orb_status), void* user);
 
+/* ------------------------------------------------------------ Frame glue
+ * What Frame::Frame runs between ExtractORB / ExtractLSD and the first search (src/Frame.cc:541-580): host flavours — the
+ * reference's Frame holds host vectors — with the arithmetic on the device.  K4 = fx, fy, cx, cy (mpCamera->toK(), which
+ * for a pinhole camera is also toLinearK()); dist = mDistCoef: ndist = 4, 5 or 8 coefficients k1 k2 p1 p2 [k3 [k4 k5 k6]]
+ * (ndist = 0 or dist[0] == 0: no distortion, as :1510 / :1560 / :1752 test it).
+ *   _undistort_keypoints   Frame::UndistortKeyPoints :1507-1552 (cv::undistortPoints, five iterations in double)
+ *   _compute_image_bounds  Frame::ComputeImageBounds :1749-1778 -> bounds5 = mnMinX, mnMaxX, mnMinY, mnMaxY, mnMaxDiag
+ *   _undistort_keylines    Frame::UndistortKeyLines :1555-1700 (single pinhole camera): end points undistorted, the angle
+ *                          from them (cv::fastAtan2 * DEG2RAD), lines outside bounds4 = mnMinX, mnMaxX, mnMinY, mnMaxY
+ *                          dropped; kept_index[j] = the input line behind output j (the caller compacts mvKeyLines and
+ *                          mLineDescriptors with it, :1649-1655)
+ *   _assign_features_to_grid  Frame::AssignFeaturesToGrid :716-746, the 64 x 48 key-point grid as a CSR: cell = column * 48
+ *                          + row (mGrid[ix][iy]), cell_start[3073], members in key-point order (push_back); the (theta, d)
+ *                          line grid stays inside the line searches.
+ *   _undistort_points      cv::undistortPoints(src, dst, K, dist, noArray(), K) on n points (x, y interleaved). */
+int plvs_hip_frame_undistort_points(const float* xy, int n, const float* K4, const float* dist, int ndist, float* xy_out);
+int plvs_hip_frame_undistort_keypoints(const plvs_keypoint* kps, int n, const float* K4, const float* dist, int ndist,
+                                       plvs_keypoint* kps_un);
+int plvs_hip_frame_compute_image_bounds(int width, int height, const float* K4, const float* dist, int ndist, float* bounds5);
+int plvs_hip_frame_undistort_keylines(const plvs_keyline* keylines, int n, const float* K4, const float* dist, int ndist,
+                                      const float* bounds4, plvs_keyline* keylines_un, int32_t* kept_index, int* n_kept);
+int plvs_hip_frame_assign_features_to_grid(const plvs_keypoint* kps_un, int n, float min_x, float min_y, float grid_w_inv,
+                                           float grid_h_inv, int32_t* cell_start, int32_t* cell_items, int* n_items);
+
 /* Device self-test backing the TSDF chain kernel: counts the binary32 significands b =
  * 1.m * 2^exponent for which the kernel's reciprocal (v_rcp_f32 + one Newton step) differs
  * from the correctly rounded 1/b.  Expected: 0 for every exponent the kernel admits. */
@@ -800,6 +824,17 @@ int plvs_hip_elas_download_descriptors(plvs_elas* e, uint8_t* I1_desc, uint8_t* 
 int plvs_hip_elas_left_right_check(plvs_elas* e, float* D1, float* D2, int width, int height);
 int plvs_hip_elas_remove_small_segments(plvs_elas* e, float* D, int width, int height);
 int plvs_hip_elas_gap_interpolation(plvs_elas* e, float* D, int width, int height);
+/* The post-processing of Elas::process (elas.cpp:100-135) in ONE call on the maps the two plvs_hip_elas_compute_disparity
+ * calls of the pair left in HBM (they always do; pass D = NULL there to skip the download): leftRightConsistencyCheck
+ * (lr_threshold >= 0), removeSmallSegments (speckle_size > 0), gapInterpolation (ipol_gap_width > 0), adaptiveMean
+ * (filter_adaptive_mean) — the right map only unless postprocess_only_left (PLVS sets it, src/PointCloudKeyFrame.cc:349).
+ * D1 / D2: host destinations of the finished maps, may be NULL; the maps stay in HBM. */
+int plvs_hip_elas_postprocess(plvs_elas* e, int width, int height, int postprocess_only_left, int filter_adaptive_mean,
+                              float* D1, float* D2);
+/* PointCloudKeyFrame::ProcessStereoLibelas' disparity -> depth (src/PointCloudKeyFrame.cc:399-420) from the left map in HBM
+ * into d_depth (DEVICE, width x height floats: what plvs_hip_cloudgen_generate_dev reads): bf / d, with subsampling only
+ * at rows step * m1 and pixels step * n1, step * n1 + 1 (zero elsewhere); step = PointCloudMapping::skDownsampleStep. */
+int plvs_hip_elas_depth_dev(plvs_elas* e, float bf, int step, float* d_depth, int width, int height, void* stream);
 
 /* ------------------------------------------------- dense stereo (semi-global matching)
  * Replaces sgm::StereoSGM as PointCloudKeyFrame::ProcessStereoLibsgm uses it

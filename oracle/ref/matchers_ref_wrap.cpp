@@ -438,4 +438,83 @@ int ref_frame_compute_stereo_matches(const uint8_t* left, const uint8_t* right, 
   return F.N;
 }
 
+// ---- the glue between extraction and the searches: Frame::UndistortKeyPoints (:1507), ComputeImageBounds (:1749),
+// UndistortKeyLines (:1555), AssignFeaturesToGrid (:716) — the reference's own, on a frame filled from flat arrays.
+// K4 = fx, fy, cx, cy; dist = mDistCoef (4, 5 or 8 coefficients; ndist = 0: a zero 4-vector).
+static void set_calib(Frame& F, Pinhole& cam, const float* dist, int ndist) {
+  F.mpCamera = &cam;
+  F.mDistCoef = cv::Mat(ndist > 0 ? ndist : 4, 1, CV_32F);
+  for (int i = 0; i < F.mDistCoef.rows; ++i) F.mDistCoef.at<float>(i) = i < ndist ? dist[i] : 0.0f;
+}
+
+void ref_frame_undistort_keypoints(const plvs_keypoint* kps, int n, const float* K4, const float* dist, int ndist,
+                                   plvs_keypoint* un) {
+  Frame F;
+  Pinhole cam(std::vector<float>(K4, K4 + 4));
+  set_calib(F, cam, dist, ndist);
+  F.N = n;
+  F.mvKeys.resize(n);
+  for (int i = 0; i < n; ++i)
+    F.mvKeys[i] = cv::KeyPoint(kps[i].x, kps[i].y, kps[i].size, kps[i].angle, kps[i].response, kps[i].octave, kps[i].class_id);
+  F.UndistortKeyPoints();
+  for (int i = 0; i < n; ++i) {
+    const cv::KeyPoint& k = F.mvKeysUn[i];
+    un[i] = plvs_keypoint{k.pt.x, k.pt.y, k.size, k.angle, k.response, k.octave, k.class_id};
+  }
+}
+
+void ref_frame_compute_image_bounds(int width, int height, const float* K4, const float* dist, int ndist, float* bounds5) {
+  Frame F;
+  Pinhole cam(std::vector<float>(K4, K4 + 4));
+  set_calib(F, cam, dist, ndist);
+  cv::Mat im(height, width, CV_8UC1);
+  F.ComputeImageBounds(im);
+  bounds5[0] = Frame::mnMinX; bounds5[1] = Frame::mnMaxX; bounds5[2] = Frame::mnMinY; bounds5[3] = Frame::mnMaxY;
+  bounds5[4] = Frame::mnMaxDiag;
+}
+
+int ref_frame_undistort_keylines(const plvs_keyline* kl, int n, const float* K4, const float* dist, int ndist, const float* bounds4,
+                                 plvs_keyline* un, int32_t* kept_index) {
+  Frame F;
+  Pinhole cam(std::vector<float>(K4, K4 + 4));
+  set_calib(F, cam, dist, ndist);
+  Frame::mnMinX = bounds4[0]; Frame::mnMaxX = bounds4[1]; Frame::mnMinY = bounds4[2]; Frame::mnMaxY = bounds4[3];
+  F.Nlines = n;
+  F.NlinesLeft = -1;
+  F.NlinesRight = -1;
+  F.mvKeyLines.resize(n);
+  if (n) std::memcpy(F.mvKeyLines.data(), kl, sizeof(plvs_keyline) * (size_t)n);
+  for (int i = 0; i < n; ++i) F.mvKeyLines[i].class_id = i;   // (to report which lines stayed)
+  std::vector<uint8_t> d(32 * (size_t)std::max(n, 1), 0);
+  F.mLineDescriptors = rows32(d.data(), n);
+  F.UndistortKeyLines();
+  const int m = (int)F.mvKeyLinesUn.size();
+  for (int i = 0; i < m; ++i) {
+    kept_index[i] = F.mvKeyLinesUn[i].class_id;
+    std::memcpy(&un[i], &F.mvKeyLinesUn[i], sizeof(plvs_keyline));
+    un[i].class_id = kl[kept_index[i]].class_id;
+  }
+  return m;
+}
+
+int ref_frame_assign_features_to_grid(const plvs_keypoint* un, int n, float min_x, float min_y, float inv_w, float inv_h,
+                                      int32_t* cell_start, int32_t* cell_items) {
+  Frame F;
+  F.N = n;
+  F.Nleft = -1;
+  F.mvKeysUn.resize(n);
+  for (int i = 0; i < n; ++i) F.mvKeysUn[i].pt = cv::Point2f(un[i].x, un[i].y);
+  Frame::mnMinX = min_x; Frame::mnMinY = min_y;
+  Frame::mfGridElementWidthInv = inv_w; Frame::mfGridElementHeightInv = inv_h;
+  F.AssignFeaturesToGrid();
+  int at = 0;
+  for (int ix = 0; ix < FRAME_GRID_COLS; ++ix)
+    for (int iy = 0; iy < FRAME_GRID_ROWS; ++iy) {
+      cell_start[ix * FRAME_GRID_ROWS + iy] = at;
+      for (size_t v : F.mGrid[ix][iy]) cell_items[at++] = (int32_t)v;
+    }
+  cell_start[FRAME_GRID_COLS * FRAME_GRID_ROWS] = at;
+  return at;
+}
+
 }  // extern "C"

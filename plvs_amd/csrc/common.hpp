@@ -1,5 +1,6 @@
 // Shared host-side plumbing for the HIP translation units of libplvs_hip.so.
 #pragma once
+#include <algorithm>
 #include <vector>
 #include <thread>
 #include <mutex>
@@ -58,7 +59,9 @@ struct DevBuf {
   size_t cap = 0;
   hipError_t reserve(size_t n) {
     if (n <= cap) return hipSuccess;
-    size_t want = n + n / 4 + 64;
+    // (geometric growth: a buffer sized by a call's input would otherwise be re-allocated by every call a little larger
+    // than any before — a hipFree + hipMalloc of hundreds of MB costs milliseconds, on a fresh process far more)
+    size_t want = std::max(n + n / 4 + 64, 2 * cap);
     if (p) {
       hipError_t e = hipFree(p);
       p = nullptr;

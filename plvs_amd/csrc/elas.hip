@@ -576,7 +576,101 @@ struct plvs_elas {
   plvs::DevBuf<uint32_t> seg_parent, seg_size, seg_run;
   plvs::DevBuf<uint8_t> img, sob_u, sob_v;
   int desc_width = 0, desc_height = 0;   // the staged descriptor images' size (0: none)
+  // the maps of the last computeDisparity calls, kept in HBM for plvs_hip_elas_postprocess ([0] left, [1] right)
+  plvs::DevBuf<float> res[2];
+  int res_w[2] = {0, 0}, res_h[2] = {0, 0};
 };
+
+namespace {
+// ---- the post-processing stages on a map in HBM (in place), asynchronous on the handle's stream
+int mean_core(plvs_elas* h, float* d, int W, int H) {
+  hipStream_t s = h->stream;
+  const bool sub = h->prm.subsampling != 0;
+  const size_t n = (size_t)W * H;
+  PLVS_HIP_TRY(h->D_copy.reserve(n));
+  PLVS_HIP_TRY(h->D_tmp.reserve(n));
+  hipLaunchKernelGGL(mean_prepare, dim3(ceil_div(n, 256)), dim3(256), 0, s, d, n, h->D_copy.p, h->D_tmp.p);
+  const dim3 grid(ceil_div((size_t)W, 256), (unsigned)H), block(256);
+  if (sub) {
+    hipLaunchKernelGGL((mean_pass<4, false>), grid, block, 0, s, h->D_copy.p, h->D_tmp.p, W, H);
+    hipLaunchKernelGGL((mean_pass<4, true>), grid, block, 0, s, h->D_tmp.p, d, W, H);
+  } else {
+    hipLaunchKernelGGL((mean_pass<8, false>), grid, block, 0, s, h->D_copy.p, h->D_tmp.p, W, H);
+    hipLaunchKernelGGL((mean_pass<8, true>), grid, block, 0, s, h->D_tmp.p, d, W, H);
+  }
+  PLVS_KERNEL_CHECK();
+  return PLVS_OK;
+}
+int lr_core(plvs_elas* h, float* d1, float* d2, int W, int H) {
+  hipStream_t s = h->stream;
+  const size_t n = (size_t)W * H;
+  PLVS_HIP_TRY(h->D_tmp.reserve(2 * n));
+  hipLaunchKernelGGL(lr_check, dim3(ceil_div((size_t)W, 256), (unsigned)H), dim3(256), 0, s, d1, d2, h->D_tmp.p, h->D_tmp.p + n,
+                     W, H, h->prm.subsampling != 0 ? 1 : 0, h->prm.lr_threshold);
+  PLVS_KERNEL_CHECK();
+  PLVS_HIP_TRY(hipMemcpyAsync(d1, h->D_tmp.p, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  PLVS_HIP_TRY(hipMemcpyAsync(d2, h->D_tmp.p + n, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return PLVS_OK;
+}
+int seg_core(plvs_elas* h, float* d, int W, int H) {
+  PLVS_REQUIRE(h->prm.speckle_sim_threshold >= 0.0f && h->prm.speckle_sim_threshold < 10.0f,
+               "speckle_sim_threshold must stay below the distance of the invalid marker (-10) to a valid disparity");
+  hipStream_t s = h->stream;
+  const size_t n = (size_t)W * H;
+  PLVS_REQUIRE(n < 0xFFFFFFFFull, "image size");
+  int32_t speckle = h->prm.speckle_size;
+  if (h->prm.subsampling != 0) speckle = (int32_t)(std::sqrt((float)h->prm.speckle_size) * 2);   // elas.cpp:1051
+  PLVS_HIP_TRY(h->seg_parent.reserve(n));
+  PLVS_HIP_TRY(h->seg_size.reserve(n));
+  PLVS_HIP_TRY(h->seg_run.reserve(n));
+  PLVS_HIP_TRY(hipMemsetAsync(h->seg_run.p, 0, n * sizeof(uint32_t), s));
+  const dim3 grid2(ceil_div((size_t)W, 256), (unsigned)H), block(256);
+  hipLaunchKernelGGL(seg_rows, dim3((unsigned)H), block, 0, s, d, h->seg_parent.p, h->seg_size.p, h->seg_run.p, W,
+                     h->prm.speckle_sim_threshold);
+  hipLaunchKernelGGL(seg_link, grid2, block, 0, s, d, h->seg_parent.p, W, H, h->prm.speckle_sim_threshold);
+  for (int span = 1; span < H; span *= 2)
+    hipLaunchKernelGGL(seg_jump, dim3(ceil_div(n, 256)), block, 0, s, h->seg_parent.p, n);
+  hipLaunchKernelGGL(seg_count, dim3(ceil_div(n, 256)), block, 0, s, h->seg_parent.p, h->seg_run.p, h->seg_size.p, n);
+  hipLaunchKernelGGL(seg_apply, dim3(ceil_div(n, 256)), block, 0, s, d, h->seg_parent.p, h->seg_size.p, n,
+                     (uint32_t)std::max(speckle, 0));
+  PLVS_KERNEL_CHECK();
+  return PLVS_OK;
+}
+int gap_core(plvs_elas* h, float* d, int W, int H) {
+  hipStream_t s = h->stream;
+  const size_t n = (size_t)W * H;
+  const int gap = h->prm.subsampling != 0 ? h->prm.ipol_gap_width / 2 + 1 : h->prm.ipol_gap_width;   // elas.cpp:1172
+  if (!h->prm.add_corners && gap <= 64) {
+    PLVS_HIP_TRY(h->D_tmp.reserve(n));
+    const dim3 grid(ceil_div((size_t)W, 256), (unsigned)H), block(256);
+    hipLaunchKernelGGL((gap_pass<false>), grid, block, 0, s, d, h->D_tmp.p, W, H, gap);
+    hipLaunchKernelGGL((gap_pass<true>), grid, block, 0, s, h->D_tmp.p, d, W, H, gap);
+  } else {   // (MIDDLEBURY: gaps of any width, the corner fill — the reference's walk, a line per thread)
+    hipLaunchKernelGGL(gap_rows, dim3(ceil_div((size_t)H, 64)), dim3(64), 0, s, d, W, H, gap, h->prm.add_corners);
+    hipLaunchKernelGGL(gap_cols, dim3(ceil_div((size_t)W, 64)), dim3(64), 0, s, d, W, H, gap, h->prm.add_corners);
+  }
+  PLVS_KERNEL_CHECK();
+  return PLVS_OK;
+}
+// ProcessStereoLibelas' disparity -> depth (src/PointCloudKeyFrame.cc:399-420): with subsampling the depth image is zero
+// but for rows m = step * m1, where pixels n = step * n1 and n + 1 take bf / d1; without, depth = bf / d everywhere
+__global__ __launch_bounds__(256) void depth_from_disparity(const float* __restrict__ d1, int W1, int H1, float bf, int subsampling,
+                                                            int step, float* __restrict__ depth, int W, int H) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y;
+  if (u >= W || v >= H) return;
+  float out = 0.0f;
+  if (!subsampling) {
+    out = bf / d1[(size_t)v * W1 + u];
+  } else if (v % step == 0 && v / step < H1) {
+    // pixel u = n or n + 1 of some n = step * n1 (n1 < W1); with step = 2 every pixel of the row is written once, a larger
+    // step leaves the pixels in between at zero and lets a later pair overwrite nothing
+    const int n1a = u / step, n1b = (u - 1) / step;
+    if (u % step == 0 && n1a < W1) out = bf / d1[(size_t)(v / step) * W1 + n1a];
+    else if (u >= 1 && (u - 1) % step == 0 && n1b < W1) out = bf / d1[(size_t)(v / step) * W1 + n1b];
+  }
+  depth[(size_t)v * W + u] = out;
+}
+}  // namespace
 
 extern "C" {
 
@@ -600,6 +694,7 @@ int plvs_hip_elas_destroy(plvs_elas* h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   h->desc1.release(); h->desc2.release(); h->support.release(); h->tri.release(); h->grid.release(); h->prior.release();
   h->owner.release(); h->D.release(); h->D_copy.release(); h->D_tmp.release(); h->D_can.release(); h->seg_parent.release(); h->seg_size.release(); h->seg_run.release(); h->img.release(); h->sob_u.release(); h->sob_v.release();
+  h->res[0].release(); h->res[1].release();
   delete h;
   return PLVS_OK;
 }
@@ -686,7 +781,7 @@ int plvs_hip_elas_support_candidates(plvs_elas* h, const uint8_t* I1_desc, const
 int plvs_hip_elas_compute_disparity(plvs_elas* h, const int32_t* support, int n_support, const void* tri, int n_tri,
                                     const int32_t* disparity_grid, const int32_t* grid_dims, const uint8_t* I1_desc,
                                     const uint8_t* I2_desc, int width, int height, int right_image, float* D) {
-  PLVS_REQUIRE(h && grid_dims && D, "null argument");
+  PLVS_REQUIRE(h && grid_dims, "null argument");   // (D = NULL: the map stays in HBM for plvs_hip_elas_postprocess)
   PLVS_REQUIRE(width >= 8 && height >= 8, "image size");
   PLVS_REQUIRE(n_support >= 0 && n_tri >= 0 && (n_tri == 0 || (support && tri)), "support points / triangles");
   PLVS_REQUIRE(grid_dims[0] >= 2 && grid_dims[1] > 0 && grid_dims[2] > 0 && disparity_grid, "disparity grid");
@@ -751,7 +846,14 @@ int plvs_hip_elas_compute_disparity(plvs_elas* h, const int32_t* support, int n_
                      h->owner.p, h->grid.p, h->prior.p, reinterpret_cast<const uint4*>(h->desc1.p),
                      reinterpret_cast<const uint4*>(h->desc2.p), h->D.p);
   PLVS_KERNEL_CHECK();
-  PLVS_HIP_TRY(hipMemcpyAsync(D, h->D.p, npix * sizeof(float), hipMemcpyDeviceToHost, s));
+  {   // the map stays in HBM as well (the post-processing chain reads it there)
+    const int side = right_image ? 1 : 0;
+    PLVS_HIP_TRY(h->res[side].reserve(npix));
+    PLVS_HIP_TRY(hipMemcpyAsync(h->res[side].p, h->D.p, npix * sizeof(float), hipMemcpyDeviceToDevice, s));
+    h->res_w[side] = ow;
+    h->res_h[side] = oh;
+  }
+  if (D) PLVS_HIP_TRY(hipMemcpyAsync(D, h->D.p, npix * sizeof(float), hipMemcpyDeviceToHost, s));
   PLVS_HIP_TRY(hipStreamSynchronize(s));
   if (I1_desc != nullptr) {
     h->desc_width = width;
@@ -760,27 +862,20 @@ int plvs_hip_elas_compute_disparity(plvs_elas* h, const int32_t* support, int n_
   return PLVS_OK;
 }
 
+// (host flavours of the post-processing stages: one upload, the stage, one download)
+#define ELAS_STAGE_SIZES()                                                          \
+  hipStream_t s = h->stream;                                                        \
+  const bool sub = h->prm.subsampling != 0;                                         \
+  const int W = sub ? width / 2 : width, H = sub ? height / 2 : height;             \
+  const size_t n = (size_t)W * H
 int plvs_hip_elas_adaptive_mean(plvs_elas* h, float* D, int width, int height) {
   PLVS_REQUIRE(h && D, "null argument");
   PLVS_REQUIRE(width >= 2 && height >= 2, "image size");
-  hipStream_t s = h->stream;
-  const bool sub = h->prm.subsampling != 0;
-  const int W = sub ? width / 2 : width, H = sub ? height / 2 : height;
-  const size_t n = (size_t)W * H;
+  ELAS_STAGE_SIZES();
   PLVS_HIP_TRY(h->D.reserve(n));
-  PLVS_HIP_TRY(h->D_copy.reserve(n));
-  PLVS_HIP_TRY(h->D_tmp.reserve(n));
   PLVS_HIP_TRY(hipMemcpyAsync(h->D.p, D, n * sizeof(float), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(mean_prepare, dim3(ceil_div(n, 256)), dim3(256), 0, s, h->D.p, n, h->D_copy.p, h->D_tmp.p);
-  const dim3 grid(ceil_div((size_t)W, 256), (unsigned)H), block(256);
-  if (sub) {
-    hipLaunchKernelGGL((mean_pass<4, false>), grid, block, 0, s, h->D_copy.p, h->D_tmp.p, W, H);
-    hipLaunchKernelGGL((mean_pass<4, true>), grid, block, 0, s, h->D_tmp.p, h->D.p, W, H);
-  } else {
-    hipLaunchKernelGGL((mean_pass<8, false>), grid, block, 0, s, h->D_copy.p, h->D_tmp.p, W, H);
-    hipLaunchKernelGGL((mean_pass<8, true>), grid, block, 0, s, h->D_tmp.p, h->D.p, W, H);
-  }
-  PLVS_KERNEL_CHECK();
+  const int rc = mean_core(h, h->D.p, W, H);
+  if (rc != PLVS_OK) return rc;
   PLVS_HIP_TRY(hipMemcpyAsync(D, h->D.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
   PLVS_HIP_TRY(hipStreamSynchronize(s));
   return PLVS_OK;
@@ -789,20 +884,15 @@ int plvs_hip_elas_adaptive_mean(plvs_elas* h, float* D, int width, int height) {
 int plvs_hip_elas_left_right_check(plvs_elas* h, float* D1, float* D2, int width, int height) {
   PLVS_REQUIRE(h && D1 && D2, "null argument");
   PLVS_REQUIRE(width >= 2 && height >= 2, "image size");
-  hipStream_t s = h->stream;
-  const bool sub = h->prm.subsampling != 0;
-  const int W = sub ? width / 2 : width, H = sub ? height / 2 : height;
-  const size_t n = (size_t)W * H;
+  ELAS_STAGE_SIZES();
   PLVS_HIP_TRY(h->D.reserve(n));
   PLVS_HIP_TRY(h->D_copy.reserve(n));
-  PLVS_HIP_TRY(h->D_tmp.reserve(2 * n));
   PLVS_HIP_TRY(hipMemcpyAsync(h->D.p, D1, n * sizeof(float), hipMemcpyHostToDevice, s));
   PLVS_HIP_TRY(hipMemcpyAsync(h->D_copy.p, D2, n * sizeof(float), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(lr_check, dim3(ceil_div((size_t)W, 256), (unsigned)H), dim3(256), 0, s, h->D.p, h->D_copy.p, h->D_tmp.p,
-                     h->D_tmp.p + n, W, H, sub ? 1 : 0, h->prm.lr_threshold);
-  PLVS_KERNEL_CHECK();
-  PLVS_HIP_TRY(hipMemcpyAsync(D1, h->D_tmp.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
-  PLVS_HIP_TRY(hipMemcpyAsync(D2, h->D_tmp.p + n, n * sizeof(float), hipMemcpyDeviceToHost, s));
+  const int rc = lr_core(h, h->D.p, h->D_copy.p, W, H);
+  if (rc != PLVS_OK) return rc;
+  PLVS_HIP_TRY(hipMemcpyAsync(D1, h->D.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipMemcpyAsync(D2, h->D_copy.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
   PLVS_HIP_TRY(hipStreamSynchronize(s));
   return PLVS_OK;
 }
@@ -810,31 +900,11 @@ int plvs_hip_elas_left_right_check(plvs_elas* h, float* D1, float* D2, int width
 int plvs_hip_elas_remove_small_segments(plvs_elas* h, float* D, int width, int height) {
   PLVS_REQUIRE(h && D, "null argument");
   PLVS_REQUIRE(width >= 2 && height >= 2, "image size");
-  PLVS_REQUIRE(h->prm.speckle_sim_threshold >= 0.0f && h->prm.speckle_sim_threshold < 10.0f,
-               "speckle_sim_threshold must stay below the distance of the invalid marker (-10) to a valid disparity");
-  hipStream_t s = h->stream;
-  const bool sub = h->prm.subsampling != 0;
-  const int W = sub ? width / 2 : width, H = sub ? height / 2 : height;
-  const size_t n = (size_t)W * H;
-  PLVS_REQUIRE(n < 0xFFFFFFFFull, "image size");
-  int32_t speckle = h->prm.speckle_size;
-  if (sub) speckle = (int32_t)(std::sqrt((float)h->prm.speckle_size) * 2);   // elas.cpp:1051
+  ELAS_STAGE_SIZES();
   PLVS_HIP_TRY(h->D.reserve(n));
-  PLVS_HIP_TRY(h->seg_parent.reserve(n));
-  PLVS_HIP_TRY(h->seg_size.reserve(n));
-  PLVS_HIP_TRY(h->seg_run.reserve(n));
-  PLVS_HIP_TRY(hipMemsetAsync(h->seg_run.p, 0, n * sizeof(uint32_t), s));
   PLVS_HIP_TRY(hipMemcpyAsync(h->D.p, D, n * sizeof(float), hipMemcpyHostToDevice, s));
-  const dim3 grid2(ceil_div((size_t)W, 256), (unsigned)H), block(256);
-  hipLaunchKernelGGL(seg_rows, dim3((unsigned)H), block, 0, s, h->D.p, h->seg_parent.p, h->seg_size.p, h->seg_run.p, W,
-                     h->prm.speckle_sim_threshold);
-  hipLaunchKernelGGL(seg_link, grid2, block, 0, s, h->D.p, h->seg_parent.p, W, H, h->prm.speckle_sim_threshold);
-  for (int span = 1; span < H; span *= 2)
-    hipLaunchKernelGGL(seg_jump, dim3(ceil_div(n, 256)), block, 0, s, h->seg_parent.p, n);
-  hipLaunchKernelGGL(seg_count, dim3(ceil_div(n, 256)), block, 0, s, h->seg_parent.p, h->seg_run.p, h->seg_size.p, n);
-  hipLaunchKernelGGL(seg_apply, dim3(ceil_div(n, 256)), block, 0, s, h->D.p, h->seg_parent.p, h->seg_size.p, n,
-                     (uint32_t)std::max(speckle, 0));
-  PLVS_KERNEL_CHECK();
+  const int rc = seg_core(h, h->D.p, W, H);
+  if (rc != PLVS_OK) return rc;
   PLVS_HIP_TRY(hipMemcpyAsync(D, h->D.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
   PLVS_HIP_TRY(hipStreamSynchronize(s));
   return PLVS_OK;
@@ -843,26 +913,66 @@ int plvs_hip_elas_remove_small_segments(plvs_elas* h, float* D, int width, int h
 int plvs_hip_elas_gap_interpolation(plvs_elas* h, float* D, int width, int height) {
   PLVS_REQUIRE(h && D, "null argument");
   PLVS_REQUIRE(width >= 2 && height >= 2, "image size");
-  hipStream_t s = h->stream;
-  const bool sub = h->prm.subsampling != 0;
-  const int W = sub ? width / 2 : width, H = sub ? height / 2 : height;
-  const size_t n = (size_t)W * H;
-  const int gap = sub ? h->prm.ipol_gap_width / 2 + 1 : h->prm.ipol_gap_width;   // elas.cpp:1172
+  ELAS_STAGE_SIZES();
   PLVS_HIP_TRY(h->D.reserve(n));
   PLVS_HIP_TRY(hipMemcpyAsync(h->D.p, D, n * sizeof(float), hipMemcpyHostToDevice, s));
-  if (!h->prm.add_corners && gap <= 64) {
-    PLVS_HIP_TRY(h->D_tmp.reserve(n));
-    const dim3 grid(ceil_div((size_t)W, 256), (unsigned)H), block(256);
-    hipLaunchKernelGGL((gap_pass<false>), grid, block, 0, s, h->D.p, h->D_tmp.p, W, H, gap);
-    hipLaunchKernelGGL((gap_pass<true>), grid, block, 0, s, h->D_tmp.p, h->D.p, W, H, gap);
-  } else {   // (MIDDLEBURY: gaps of any width, the corner fill — the reference's walk, a line per thread)
-    hipLaunchKernelGGL(gap_rows, dim3(ceil_div((size_t)H, 64)), dim3(64), 0, s, h->D.p, W, H, gap, h->prm.add_corners);
-    hipLaunchKernelGGL(gap_cols, dim3(ceil_div((size_t)W, 64)), dim3(64), 0, s, h->D.p, W, H, gap, h->prm.add_corners);
-  }
-  PLVS_KERNEL_CHECK();
+  const int rc = gap_core(h, h->D.p, W, H);
+  if (rc != PLVS_OK) return rc;
   PLVS_HIP_TRY(hipMemcpyAsync(D, h->D.p, n * sizeof(float), hipMemcpyDeviceToHost, s));
   PLVS_HIP_TRY(hipStreamSynchronize(s));
   return PLVS_OK;
 }
+
+// Elas::process behind its two computeDisparity calls (elas.cpp:100-135) in ONE call, on the maps those calls left in HBM:
+// leftRightConsistencyCheck (lr_threshold >= 0), removeSmallSegments (speckle_size > 0), gapInterpolation
+// (ipol_gap_width > 0), adaptiveMean (filter_adaptive_mean) — the right map only unless postprocess_only_left.  D1 / D2
+// (host, may be NULL): where the finished maps go; they also stay in HBM for plvs_hip_elas_depth_dev.
+int plvs_hip_elas_postprocess(plvs_elas* h, int width, int height, int postprocess_only_left, int filter_adaptive_mean, float* D1,
+                              float* D2) {
+  PLVS_REQUIRE(h, "null argument");
+  PLVS_REQUIRE(width >= 2 && height >= 2, "image size");
+  ELAS_STAGE_SIZES();
+  PLVS_REQUIRE(h->res_w[0] == W && h->res_h[0] == H && h->res_w[1] == W && h->res_h[1] == H,
+               "no disparity maps of this size in HBM (plvs_hip_elas_compute_disparity for the left and the right image first)");
+  float* d1 = h->res[0].p;
+  float* d2 = h->res[1].p;
+  int rc = PLVS_OK;
+  if (h->prm.lr_threshold >= 0) rc = lr_core(h, d1, d2, W, H);
+  if (rc == PLVS_OK && h->prm.speckle_size > 0) {
+    rc = seg_core(h, d1, W, H);
+    if (rc == PLVS_OK && !postprocess_only_left) rc = seg_core(h, d2, W, H);
+  }
+  if (rc == PLVS_OK && h->prm.ipol_gap_width > 0) {
+    rc = gap_core(h, d1, W, H);
+    if (rc == PLVS_OK && !postprocess_only_left) rc = gap_core(h, d2, W, H);
+  }
+  if (rc == PLVS_OK && filter_adaptive_mean) {
+    rc = mean_core(h, d1, W, H);
+    if (rc == PLVS_OK && !postprocess_only_left) rc = mean_core(h, d2, W, H);
+  }
+  if (rc != PLVS_OK) return rc;
+  if (D1) PLVS_HIP_TRY(hipMemcpyAsync(D1, d1, n * sizeof(float), hipMemcpyDeviceToHost, s));
+  if (D2) PLVS_HIP_TRY(hipMemcpyAsync(D2, d2, n * sizeof(float), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  return PLVS_OK;
+}
+
+// The depth image PointCloudKeyFrame::ProcessStereoLibelas makes of the left map (src/PointCloudKeyFrame.cc:399-420):
+// d_depth (device, width x height floats) = bf / d — with subsampling only at rows step * m1, pixels step * n1 and
+// step * n1 + 1, zero elsewhere (step = PointCloudMapping::skDownsampleStep).  Reads the left map in HBM; asynchronous on
+// `stream` after the handle's own work.
+int plvs_hip_elas_depth_dev(plvs_elas* h, float bf, int step, float* d_depth, int width, int height, void* stream) {
+  PLVS_REQUIRE(h && d_depth, "null argument");
+  PLVS_REQUIRE(width >= 2 && height >= 2 && step >= 1, "image size / step");
+  const bool sub = h->prm.subsampling != 0;
+  const int W1 = sub ? width / 2 : width, H1 = sub ? height / 2 : height;
+  PLVS_REQUIRE(h->res_w[0] == W1 && h->res_h[0] == H1, "no left disparity map of this size in HBM");
+  PLVS_HIP_TRY(hipStreamSynchronize(h->stream));
+  hipLaunchKernelGGL(depth_from_disparity, dim3(ceil_div((size_t)width, 256), (unsigned)height), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), h->res[0].p, W1, H1, bf, sub ? 1 : 0, step, d_depth, width, height);
+  PLVS_KERNEL_CHECK();
+  return PLVS_OK;
+}
+#undef ELAS_STAGE_SIZES
 
 }  // extern "C"

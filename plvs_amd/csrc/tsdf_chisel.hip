@@ -900,7 +900,10 @@ struct plvs_tsdf_chisel {
   DevBuf<uint32_t> w_runkey, w_run_cnt, w_run_off, w_val0, w_val1;   // runs: per-tile regions of 2^run_r1_log2 slots
   int32_t* h_offsets = nullptr;      // pinned copy of the call's cloud offsets
   size_t h_offsets_cap = 0;
-  uint32_t run_r1_log2 = 6;
+  // run slots per tile (log2): 2048 from the start — a tile of the 2048-entry walk can need 1792, and growing the regions
+  // later means repeating a call and re-allocating its largest buffers (ntiles << r1_log2 masks of 64 B) in the middle of
+  // a job; a tile of the 4096-entry walk that needs more still grows them once
+  uint32_t run_r1_log2 = 11;
   float scale_u = 1.f, scale_w = 1.f;   // fixed-point scales of the order-free accumulators (powers of two)
   int stage_set = 0;                    // which pipeline the stage times belong to
   // ray-sharded multi-GPU integrate (tsdf_shard.hpp)
@@ -1088,10 +1091,16 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
 #define STAGE_MARK(i) \
   do { if (h->profiling) PLVS_HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
   for (int attempt = 0;; ++attempt) {
-    PLVS_HIP_TRY(h->w_rec.reserve(rec_own + rec_spill));
-    PLVS_HIP_TRY(h->w_seg.reserve(2 * (seg_own + seg_spill)));
+    // (the per-tile regions are sized by the call's tiles: a stream of calls of varying length would otherwise re-allocate
+    // these — the largest buffers of the handle, hundreds of MB: a hipFree + hipMalloc of that size costs milliseconds —
+    // every time a call is a little longer than any before; they grow to TWICE what a call needs instead)
+    if (h->w_rec.cap < rec_own + rec_spill) PLVS_HIP_TRY(h->w_rec.reserve(2 * rec_own + rec_spill));
+    if (h->w_seg.cap < 2 * (seg_own + seg_spill)) PLVS_HIP_TRY(h->w_seg.reserve(2 * (2 * seg_own + seg_spill)));
     PLVS_HIP_TRY(h->w_sorted_seg.reserve(h->w_seg.cap));
-    PLVS_HIP_TRY(h->w_runkey.reserve((size_t)ntiles << h->run_r1_log2));
+    if (h->w_runkey.cap < ((size_t)ntiles << h->run_r1_log2)) {
+      PLVS_HIP_TRY(h->w_runkey.reserve((size_t)2 * ntiles << h->run_r1_log2));
+      PLVS_HIP_TRY(h->w_masks.reserve(((size_t)2 * ntiles << h->run_r1_log2) * kMaskWords));
+    }
     PLVS_HIP_TRY(h->w_masks.reserve(((size_t)ntiles << h->run_r1_log2) * kMaskWords));
     hipLaunchKernelGGL(walk_prologue, dim3(ceil_div((size_t)std::max(max_chunks, nclouds + 1), 256)), dim3(256), 0, s, d_Twc,
                        nclouds, h->poses.p, (const int32_t*)h->h_offsets, h->offsets.p, h->d_wctr, h->d_ctr, h->w_chunk_nseg.p,

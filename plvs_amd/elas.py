@@ -80,10 +80,12 @@ class ElasGPU:
     def _out_shape(self, width, height):
         return (height // 2, width // 2) if self.param.subsampling else (height, width)
 
-    def computeDisparity(self, p_support, tri, disparity_grid, grid_dims, I1_desc, I2_desc, right_image, width, height):
+    def computeDisparity(self, p_support, tri, disparity_grid, grid_dims, I1_desc, I2_desc, right_image, width, height,
+                         download=True):
         """p_support: SUPPORT_PT records, tri: TRIANGLE records, disparity_grid / grid_dims as Elas::createGrid leaves them,
         I*_desc: Descriptor::I_desc (16 * width * height bytes; both None = the pair staged by the previous call)
-        -> D float32 (-10: no triangle, -1: no match)."""
+        -> D float32 (-10: no triangle, -1: no match); download=False: the map only stays in HBM (postProcess reads it
+        there), None is returned."""
         sup = np.ascontiguousarray(p_support, dtype=SUPPORT_PT)
         tri = np.ascontiguousarray(tri, dtype=TRIANGLE)
         grid = np.ascontiguousarray(disparity_grid, dtype=np.int32)
@@ -98,12 +100,33 @@ class ElasGPU:
             d2 = np.ascontiguousarray(I2_desc, dtype=np.uint8)
             if d1.size != 16 * width * height or d2.size != d1.size:
                 raise ValueError("a descriptor image has 16 * width * height bytes")
-        D = np.empty(self._out_shape(width, height), np.float32)
+        D = np.empty(self._out_shape(width, height), np.float32) if download else None
         _lib.check(L.plvs_hip_elas_compute_disparity(self._h, _lib.np_ptr(sup), len(sup), _lib.np_ptr(tri), len(tri),
                                                      _lib.np_ptr(grid), _lib.np_ptr(gd), None if d1 is None else _lib.np_ptr(d1),
                                                      None if d2 is None else _lib.np_ptr(d2), int(width), int(height),
                                                      int(bool(right_image)), _lib.np_ptr(D)))
         return D
+
+    def postProcess(self, width, height, postprocess_only_left=True, filter_adaptive_mean=True, download=True):
+        """The rest of Elas::process behind its two computeDisparity calls (elas.cpp:100-135) in one call on the maps they
+        left in HBM: leftRightConsistencyCheck, removeSmallSegments, gapInterpolation, adaptiveMean — the right map only
+        unless postprocess_only_left (PLVS sets it).  -> (D1, D2) float32, or None with download=False (depthDev next)."""
+        f = L.plvs_hip_elas_postprocess
+        f.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp]
+        D1 = np.empty(self._out_shape(width, height), np.float32) if download else None
+        D2 = np.empty(self._out_shape(width, height), np.float32) if download else None
+        _lib.check(f(self._h, int(width), int(height), int(bool(postprocess_only_left)), int(bool(filter_adaptive_mean)),
+                     _lib.np_ptr(D1), _lib.np_ptr(D2)))
+        return (D1, D2) if download else None
+
+    def depthDev(self, bf, step, d_depth):
+        """PointCloudKeyFrame::ProcessStereoLibelas' disparity -> depth (src/PointCloudKeyFrame.cc:399-420) from the left map
+        in HBM into the torch float32 CUDA tensor d_depth [height, width] (what PointCloudGenerator.generate_dev reads)."""
+        f = L.plvs_hip_elas_depth_dev
+        f.argtypes = [_vp, _f, _i, _vp, _i, _i, _vp]
+        assert d_depth.is_cuda and d_depth.is_contiguous() and d_depth.dim() == 2
+        _lib.check(f(self._h, float(bf), int(step), _lib.t_ptr(d_depth), d_depth.shape[1], d_depth.shape[0],
+                     _lib.current_stream_ptr()))
 
     def setImages(self, I1, I2):
         """libelas::Descriptor of both images on the device (descriptor.cpp:30-131); they stay staged: supportCandidates and

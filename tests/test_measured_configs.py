@@ -182,3 +182,74 @@ def test_kitti_chain_sgm_depth_cloud_chisel_10cm(oracle):
     assert hip.last_stats()["visits"] == ref.last_visits()
     assert compare_maps(ref, hip) > 10
     hip.close()
+
+
+@pytest.mark.gpu
+def test_kitti_chain_as_shipped_libelas_depth_cloud_chisel_10cm(oracle):
+    """configs[4] as the shipped YAML runs it (Examples_old/Stereo/KITTI00-02.yaml: libelas, skDownsampleStep 2 ->
+    subsampling): 1241x376 pair -> libelas::Elas::process with EVERY device stage — descriptors, support candidates, the
+    two computeDisparity calls leaving their maps in HBM, then leftRightConsistencyCheck / removeSmallSegments /
+    gapInterpolation / adaptiveMean as ONE call on those maps (plvs_hip_elas_postprocess) — -> ProcessStereoLibelas'
+    disparity -> depth on the device (src/PointCloudKeyFrame.cc:399-420, bf = 386.1448) -> cloud with normals -> chisel
+    TSDF 10 cm.  Against: the compiled reference pipeline's maps (bit for bit), then the same conversion in numpy and the
+    chained oracles (cloud records byte for byte, map bit for bit)."""
+    import torch
+    from tests import elas_ref
+    from tests.test_elas import pair
+    if not elas_ref.available():
+        pytest.skip("needs oracle/_ref/libelas_ref.so (built where /root/reference is)")
+    from plvs_amd import cloudgen
+    from plvs_amd.elas import ElasGPU
+    from plvs_amd.tsdf import TsdfChisel
+    left, right = pair()
+    h, w = left.shape
+    fx, fy, cx, cy, bf = 718.856, 718.856, 607.1928, 185.2157, 386.1448      # KITTI00-02.yaml
+    want1, want2 = elas_ref.reference(left, right, subsampling=True, plvs=True)
+    e = ElasGPU(ElasGPU.Parameters(subsampling=True))
+    e.setImages(left, right)
+    done = {}
+
+    def disparity(a):      # (the pipeline wants the map back: the copy in HBM is what the chain below reads)
+        return e.computeDisparity(a["support"], a["tri"], a["grid"], a["grid_dims"], None, None, a["right_image"], w, h)
+
+    def lr(D1, D2):        # the first post-processing hook: the whole chain in one call, the later hooks have nothing left to do
+        done["maps"] = e.postProcess(w, h, postprocess_only_left=True, filter_adaptive_mean=True)
+        D1[:], D2[:] = done["maps"]
+
+    got1, got2 = elas_ref.run_with(left, right, disparity, lambda D, ww, hh, sub: D, subsampling=True, plvs=True,
+                                   support_candidates=lambda a: e.supportCandidates(None, None, w, h),
+                                   post=dict(left_right_check=lr, remove_small_segments=lambda D: None,
+                                             gap_interpolation=lambda D: None))
+    assert np.array_equal(got1.view(np.uint32), want1.view(np.uint32)) and np.array_equal(got2.view(np.uint32), want2.view(np.uint32))
+    assert (want1 >= 0).mean() > 0.3
+    # --- depth as ProcessStereoLibelas makes it
+    depth_ref = np.zeros((h, w), np.float32)
+    with np.errstate(divide="ignore"):
+        q = (np.float32(bf) / want1).astype(np.float32)
+    depth_ref[0:2 * want1.shape[0]:2, 0:2 * want1.shape[1]:2] = q
+    depth_ref[0:2 * want1.shape[0]:2, 1:2 * want1.shape[1]:2] = q
+    d_depth = torch.empty((h, w), dtype=torch.float32, device="cuda")
+    e.depthDev(bf, 2, d_depth)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_depth.cpu().numpy().view(np.uint32), depth_ref.view(np.uint32))
+    # --- cloud + TSDF
+    bgr = np.repeat(left[:, :, None], 3, axis=2)
+    grid = cloudgen.InitCamGridPoints(w, h, 2, fx, fy, cx, cy)
+    gen = cloudgen.PointCloudGenerator(w, h, grid, step=2, min_depth=0.5, max_depth=20.0)
+    Twc = np.eye(4, dtype=np.float32)[:3]
+    rec, _ = oracle.cloudgen(depth_ref, bgr, grid, 2, 0.5, 20.0, 7)
+    ref = oracle.chisel(0.10)
+    ref.integrate(np.stack([rec["x"], rec["y"], rec["z"]], -1), np.stack([rec["r"], rec["g"], rec["b"]], -1), rec["kfid"], Twc)
+    ng = gen.ngrid
+    d_xyz = torch.empty((ng, 3), dtype=torch.float32, device="cuda")
+    d_rgb = torch.empty((ng, 3), dtype=torch.uint8, device="cuda")
+    d_kfid = torch.empty(ng, dtype=torch.int32, device="cuda")
+    n = gen.generate_dev(torch.from_numpy(bgr).cuda(), d_depth, 7, d_xyz, d_rgb=d_rgb, d_kfid=d_kfid)
+    assert n == rec.shape[0] > 10000
+    hip = TsdfChisel(0.10, max_chunks=16384)
+    hip.integrate_batch_dev(d_xyz, d_rgb, d_kfid, np.array([0, n], np.int32), torch.from_numpy(Twc[None]).cuda())
+    torch.cuda.synchronize()
+    assert hip.last_stats()["visits"] == ref.last_visits()
+    assert compare_maps(ref, hip) > 10
+    hip.close()
+    e.close()
