@@ -107,7 +107,11 @@ def main():
             args.resolution = 0.02
         if args.max_depth == 5.0:
             args.max_depth = 8.0
-        kfs = make_keyframes(n_poses, room_size=(16.0, 12.0, 3.0), max_depth=args.max_depth, seed=0)
+        if args.steady_state:
+            kfs = make_keyframes(n_poses, room_size=(16.0, 12.0, 3.0), max_depth=args.max_depth, seed=0)
+        else:      # the office stream from key frame 400 on, as the voxblox_configs3 leg of the default run
+            n_poses = min(total_steps * args.batch, LOOP)
+            kfs = make_stream_keyframes(n_poses, first=400, max_depth=args.max_depth, seed=0, threads=min(32, os.cpu_count() or 8))
         for k in kfs:
             k["rgba"] = np.concatenate([k["rgb"], np.full((k["rgb"].shape[0], 1), 255, np.uint8)], axis=1)
     elif args.steady_state:

@@ -3,7 +3,7 @@
 (FETCH_SIZE, WRITE_SIZE; separate runs, kernel-trace only), written as a small JSON that
 bench.py quotes in `roofline.traffic`.
 
-    pmc_traffic.py <FETCH counter_collection.csv> <WRITE counter_collection.csv> <out.json>
+    pmc_traffic.py <FETCH counter_collection.csv> <WRITE counter_collection.csv> <out.json> [voxblox]
 
 Corrections (MI355X_MICROARCH.md, HBM / rocprofv3 section): both counters are in KiB-sized
 units as rocprofv3 reports them (value x 1024 B); FETCH_SIZE on gfx950 counts 128-B requests
@@ -36,10 +36,19 @@ def load(path):
     return acc
 
 
+VOXBLOX = ("vb_pose_prep", "vb_ray_pass", "vb_expand", "vb_chain_chunks", "vb_publish_counters", "vb_merge_keys", "vb_merge_bundles",
+           "scan_single", "scan_tile_sums", "scan_sums", "scan_tile_apply", "radix_hist", "radix_scatter", "radix_scatter_lds")
+
+
 def main(argv):
     fetch, write = load(argv[1]), load(argv[2])
-    # one ray_tiles (ordered mode) / walk_tiles (order-free mode) dispatch per integrate call
-    calls = fetch["ray_tiles"][1] or fetch["walk_tiles"][1] or 1
+    global PIPELINE
+    if len(argv) > 4 and argv[4] == "voxblox":      # the voxblox leg alone (bench.py --backend voxblox): one fold per call
+        PIPELINE = VOXBLOX
+        calls = fetch["vb_chain_chunks"][1] or 1
+    else:
+        # one ray_tiles (ordered mode) / walk_tiles (order-free mode) dispatch per integrate call
+        calls = fetch["ray_tiles"][1] or fetch["walk_tiles"][1] or 1
     out = {"unit": "bytes per integrate call (one launch of the pipeline)", "integrate_calls": calls, "kernels": {}}
     tot_r = tot_w = 0.0
     for k in PIPELINE:
