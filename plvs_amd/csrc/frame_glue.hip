@@ -149,19 +149,17 @@ __global__ __launch_bounds__(1024) void assign_grid_kernel(const float2* __restr
     const int c = i < n ? cell_of(i) : -1;
     chunk_cell[tid] = c;
     __syncthreads();
+    int before = 0, total = 0;
     if (c >= 0) {
-      int before = 0, total = 0;
       for (int j = 0; j < 1024 && i0 + j < n; ++j) {
         const bool same = chunk_cell[j] == c;
         before += (same && j < tid) ? 1 : 0;
         total += same ? 1 : 0;
       }
       items[cnt[c] + before] = i;
-      __syncthreads();   // (every lane of the chunk has read cnt before anybody moves it — see the uniform barrier below)
-      if (before == 0) cnt[c] += total;
-    } else {
-      __syncthreads();
     }
+    __syncthreads();   // every lane of the chunk has read cnt before anybody moves it (barriers outside the branch: uniform)
+    if (c >= 0 && before == 0) cnt[c] += total;
     __syncthreads();
   }
 }

@@ -4,8 +4,8 @@ reaches them (src/PointCloudKeyFrame.cc:335-432) — and the other device stages
 images), supportCandidates (the candidate loop of computeSupportMatches), leftRightConsistencyCheck, removeSmallSegments,
 gapInterpolation.  Same argument meaning as the reference's methods; the support filters, the triangulation, the planes
 and the grid of Elas::process are the caller's.  Preconditions shared with the reference: invalid pixels hold -10,
-speckle_sim_threshold < 10; parity is against a reference whose uninitialised reads see zeros (oracle/ref/
-elas_zero_malloc.h).  The arithmetic runs in libplvs_hip.so; there is no CPU fallback."""
+speckle_sim_threshold < 10; parity is against a reference whose uninitialised reads see zeros (DESIGN §3:
+the zero-filling malloc the test build of the reference is compiled with).  The arithmetic runs in libplvs_hip.so; there is no CPU fallback."""
 import ctypes
 
 import numpy as np
