@@ -1134,6 +1134,7 @@ __device__ __forceinline__ void walk_fast_tile(
   const uint32_t first = span.first, nrays = span.nrays;
   const int cloud = span.cloud;
   bool defer = P.shard_count > 1 || listed_other;   // (uniform)
+  WALK_PROF_BEGIN();
   uint32_t nv = 0;
   bool walks = false;
   int ox = 0, oy = 0, oz = 0;
@@ -1155,7 +1156,9 @@ __device__ __forceinline__ void walk_fast_tile(
       if (wm && lane == __ffsll((long long)wm) - 1)
         for (int k = 0; k < 3; ++k) S.worg[wid][k] = origin_of((int)floorf(ray.start[k]));
     }
+    WALK_PROF(0);   // set-up: the ray, the origin vote
     __syncthreads();                                                                        // ---- barrier 1
+    WALK_PROF(1);   // (wait)
     {
       int w0 = 0;
 #pragma unroll
@@ -1182,8 +1185,10 @@ __device__ __forceinline__ void walk_fast_tile(
   return;
 #endif
   uint32_t ekey[kPer];
+  WALK_PROF(2);     // the voxel loop of this wave
   if (!defer) {   // entries in use (nobody counts them during the walk)
     __syncthreads();                                                                        // ---- barrier 2
+    WALK_PROF(3);   // (wait for the slowest wave)
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
       ekey[k] = S.ekey[tid + k * kWalkRays];
@@ -1251,7 +1256,9 @@ __device__ __forceinline__ void walk_fast_tile(
   }
   // (one barrier: the ranks are complete, the tile's entries are counted — and does any voxel that needs a run have
   // more than one visiting ray?)
+  WALK_PROF(4);     // entries -> chunks, ranks, colour weights
   const bool any_multi = __syncthreads_or(multi ? 1 : 0) != 0;                              // ---- barrier 3
+  WALK_PROF(5);     // (wait)
   const bool too_many = !defer && S.nent > (uint32_t)kLimit;   // (the voxels do not fit: the next kernel's table is larger / walk_tiles cuts the tile at once)
   if (!defer) defer = S.overflow != 0 || too_many;
   if (defer) {
@@ -1301,6 +1308,7 @@ __device__ __forceinline__ void walk_fast_tile(
                                (uint32_t)e_wuu[tid + k * kWalkRays], (uint32_t)ewc[k]);
     out.rec[rbase + S.cbase[ci[k] * kSlabs + (int)(vid / kSlabVox)] + rank[k]] = r;
   }
+  WALK_PROF(6);     // records
   // ---- runs: number the entries that need one (wave by wave)
   const uint32_t inc = wave_scan_incl(nneed);
   const uint32_t wave_runs = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
@@ -1394,8 +1402,11 @@ __device__ __forceinline__ void walk_fast_tile(
     }
     if (tid == 0) S.run_total = nruns;
   }
+  WALK_PROF(7);     // runs
   // ---- tile epilogue: run and visit counts
   __syncthreads();                                                                          // ---- barrier 4
+  WALK_PROF(8);
+  WALK_PROF_END();
   if (tid == 0) {
     runs.run_cnt[tile] = min(S.run_total, 1u << runs.r1_log2);
     out.tile_visits[tile] = S.vis_total;
