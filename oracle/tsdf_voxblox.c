@@ -26,9 +26,11 @@
  * The pose goes through kindr's quaternion as in the reference (quat_from_matrix / quat_transform below, restated
  * from minkindr — present in the tree — and Eigen 3.3's Quaternion.h, which is not).  The multi-threaded reference is itself
  * order-nondeterministic (per-voxel mutexes, ThreadSafeIndex); the oracle is the
- * integrator_threads = 1 schedule.  The "fast" integrator (PLVS's YAML default)
- * is racy by design (tsdf_integrator.cc:505-569) and has no deterministic
- * reference; "simple" is the parity target.
+ * integrator_threads = 1 schedule.  The "fast" integrator (PLVS's YAML default,
+ * tsdf_integrator.cc:505-605) is racy at integrator_threads > 1 and lossy by design (two approximate hash sets); its
+ * ONE-thread schedule is deterministic and restated here (oracle_voxblox_integrate_fast) twice over: with the reference's
+ * own approximate sets (pinned bit for bit by the compiled FastTsdfIntegrator, tests/test_oracle_pinned.py) and with
+ * collision-free sets — the same algorithm without the sets' losses, which is what the device builds.
  *
  * Follows (paths relative to the PLVS tree):
  *   src/PointCloudMapVoxblox.cc:48-99                      config + InsertCloud
@@ -70,6 +72,9 @@ typedef struct oracle_voxblox {
   int shard_rank, shard_count;
   int64_t last_visits;
   int defer_world_blocks, in_world_call;
+  /* FastTsdfIntegrator's two ApproxHashSet<20, 10000> (allocated by the first fast call that asks for them) */
+  uint64_t *approx_start, *approx_seen;
+  size_t approx_offset;
 } oracle_voxblox;
 
 static size_t vb_hash(const int32_t id[3]) {
@@ -159,6 +164,7 @@ void oracle_voxblox_clear(oracle_voxblox* o) {
 }
 
 void oracle_voxblox_destroy(oracle_voxblox* o) {
+  if (o) { free(o->approx_start); free(o->approx_seen); o->approx_start = o->approx_seen = NULL; }
   if (!o) return;
   oracle_voxblox_clear(o);
   free(o->tab);
@@ -389,6 +395,305 @@ void oracle_voxblox_integrate(oracle_voxblox* o, const float* xyz, const uint8_t
   }
   free(keep);
   o->last_visits = visits;
+}
+
+/* ---- FastTsdfIntegrator (tsdf_integrator.cc:505-605), integrator_threads = 1, max_integration_time_s = its default
+ * (no limit), start_voxel_subsampling_factor 2, max_consecutive_ray_collisions 2, clear_checks_every_n_frames 1 as
+ * PointCloudMapVoxblox.cc:70-72 sets them.  Per point in the mixed order: a ray starts only where no earlier ray of THIS
+ * scan started (a set of voxels of half the voxel size); it is cast from the surface end towards the sensor
+ * (cast_from_origin = false: setupRayCaster(end_scaled, start_scaled), integrator_utils.cc:164-168) and stops at the
+ * third voxel in a row that an earlier ray of the scan has gone through; every voxel before that takes updateTsdfVoxel.
+ * The two sets:
+ *   approx_sets = 1  ApproxHashSet<20, 10000> (utils/approx_hash_array.h:66-160) as one thread sees it: slot
+ *                    (hash & 0xFFFFF) + offset holds the full hash of whatever index came last; "reset" = offset + 1
+ *                    (a stale entry can never match: its slot moved), everything zeroed every 10 000 scans;
+ *   approx_sets = 0  collision-free sets: the algorithm without the sets' false negatives / positives. */
+typedef struct { int32_t* key; uint8_t* used; size_t cap, n; } vb_idxset;
+static void idxset_init(vb_idxset* s, size_t cap) {
+  s->cap = cap; s->n = 0;
+  s->key = (int32_t*)malloc(sizeof(int32_t) * 3 * cap);
+  s->used = (uint8_t*)calloc(cap, 1);
+}
+static int idxset_insert_raw(vb_idxset* s, const int32_t g[3]) {   /* 1 = new */
+  size_t h = (vb_hash(g) * 0x9E3779B97F4A7C15ull >> 20) & (s->cap - 1);
+  for (;;) {
+    if (!s->used[h]) {
+      s->used[h] = 1;
+      memcpy(s->key + 3 * h, g, 3 * sizeof(int32_t));
+      s->n++;
+      return 1;
+    }
+    if (s->key[3 * h] == g[0] && s->key[3 * h + 1] == g[1] && s->key[3 * h + 2] == g[2]) return 0;
+    h = (h + 1) & (s->cap - 1);
+  }
+}
+static int idxset_insert(vb_idxset* s, const int32_t g[3]) {
+  if ((s->n + 1) * 2 > s->cap) {
+    vb_idxset t;
+    idxset_init(&t, s->cap * 2);
+    for (size_t i = 0; i < s->cap; i++)
+      if (s->used[i]) idxset_insert_raw(&t, s->key + 3 * i);
+    free(s->key); free(s->used);
+    *s = t;
+  }
+  return idxset_insert_raw(s, g);
+}
+#define VB_APPROX_BITS 20
+#define VB_APPROX_RESET 10000
+static void approx_clear(uint64_t* a) {
+  memset(a, 0, sizeof(uint64_t) * (((size_t)1 << VB_APPROX_BITS) + VB_APPROX_RESET));
+  a[0] = UINT64_MAX;   /* pseudo_set_[offset_ = 0] = max (approx_hash_array.h:78, 148) */
+}
+static int approx_replace(uint64_t* a, size_t offset, const int32_t g[3]) {   /* replaceHash (:105-114): 1 = new */
+  const uint64_t hash = (uint64_t)vb_hash(g);
+  uint64_t* slot = a + (hash & (((uint64_t)1 << VB_APPROX_BITS) - 1)) + offset;
+  if (*slot == hash) return 0;
+  *slot = hash;
+  return 1;
+}
+
+static int32_t* g_fast_updates_out = NULL;   /* (test hook: updates per mixed position of the next fast call) */
+void oracle_voxblox_fast_record_updates(int32_t* out) { g_fast_updates_out = out; }
+void oracle_voxblox_integrate_fast(oracle_voxblox* o, const float* xyz, const uint8_t* rgba, int n, const float* Twc,
+                                   int approx_sets) {
+  float R[9], t[3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) R[3 * i + j] = Twc[4 * i + j];
+    t[i] = Twc[4 * i + 3];
+  }
+  float q[4];
+  quat_from_matrix(R, q);
+  vb_publish_pending(o);   /* (as oracle_voxblox_integrate) */
+  /* integratePointCloud (:575-605): the sets are "reset" at the start of every scan */
+  vb_idxset start_set, seen_set;
+  if (approx_sets) {
+    const size_t words = ((size_t)1 << VB_APPROX_BITS) + VB_APPROX_RESET;
+    if (!o->approx_start) {
+      o->approx_start = (uint64_t*)malloc(sizeof(uint64_t) * words);
+      o->approx_seen = (uint64_t*)malloc(sizeof(uint64_t) * words);
+      approx_clear(o->approx_start);
+      approx_clear(o->approx_seen);
+      o->approx_offset = 0;
+    }
+    if (++o->approx_offset >= VB_APPROX_RESET) {   /* resetApproxSet (:141-150), both sets in step */
+      approx_clear(o->approx_start);
+      approx_clear(o->approx_seen);
+      o->approx_offset = 0;
+    }
+  } else {
+    idxset_init(&start_set, 1 << 12);
+    idxset_init(&seen_set, 1 << 14);
+  }
+  int* keep = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  size_t m = 0;
+  for (int i = 0; i < n; i++)   /* tsdf_server.cc:509-527 */
+    if (isfinite(xyz[3 * i]) && isfinite(xyz[3 * i + 1]) && isfinite(xyz[3 * i + 2])) keep[m++] = i;
+  int64_t visits = 0;
+  const float start_inv = 2.0f * o->voxel_size_inv;   /* config_.start_voxel_subsampling_factor * voxel_size_inv_ (:540) */
+  vblock_t* last_block = NULL;
+  int32_t last_bid[3] = {0, 0, 0};
+  for (size_t seq = 0; seq < m; seq++) {
+    const int pi = keep[mixed_index(seq, m)];
+    const float* pC = xyz + 3 * (size_t)pi;
+    uint32_t color;
+    memcpy(&color, rgba + 4 * (size_t)pi, 4);
+    const float ray_distance = norm3(pC);
+    int is_clearing;
+    if (ray_distance < o->min_ray) continue;
+    else if (ray_distance > o->max_ray) {
+      if (o->allow_clear) is_clearing = 1;
+      else continue;
+    } else
+      is_clearing = 0;
+    const float* origin = t;
+    float pG[3];
+    quat_transform(q, t, pC, pG);
+    int32_t sv[3];
+    for (int k = 0; k < 3; k++) sv[k] = (int32_t)floorf(pG[k] * start_inv + 1e-6f);   /* getGridIndexFromPoint(p, inv) */
+    if (!(approx_sets ? approx_replace(o->approx_start, o->approx_offset, sv) : idxset_insert(&start_set, sv))) continue;
+    /* RayCaster(..., cast_from_origin = false): the same two end points, cast the other way round */
+    vb_ray ray;
+    {
+      const float d[3] = {pG[0] - origin[0], pG[1] - origin[1], pG[2] - origin[2]};
+      const float dn = norm3(d);
+      float unit[3] = {d[0], d[1], d[2]};
+      if (sum3(d[0] * d[0], d[1] * d[1], d[2] * d[2]) > 0.0f) { unit[0] = d[0] / dn; unit[1] = d[1] / dn; unit[2] = d[2] / dn; }
+      float rs[3], re[3], ss[3], es[3];
+      if (is_clearing) {
+        float tmp = dn - o->truncation;
+        tmp = (tmp < 0.0f) ? 0.0f : tmp;
+        const float len = (o->max_ray < tmp) ? o->max_ray : tmp;
+        for (int k = 0; k < 3; k++) { re[k] = origin[k] + unit[k] * len; rs[k] = o->carving ? origin[k] : re[k]; }
+      } else {
+        for (int k = 0; k < 3; k++) {
+          re[k] = pG[k] + unit[k] * o->truncation;
+          rs[k] = o->carving ? origin[k] : (pG[k] - unit[k] * o->truncation);
+        }
+      }
+      for (int k = 0; k < 3; k++) { ss[k] = rs[k] * o->voxel_size_inv; es[k] = re[k] * o->voxel_size_inv; }
+      vb_ray_setup_scaled(es, ss, &ray);
+    }
+    const float weight = o->use_const_weight ? 1.0f : (fabsf(pC[2]) > 1e-6f ? 1.0f / (pC[2] * pC[2]) : 0.0f);
+    int64_t collisions = 0;
+    const int64_t visits_before = visits;
+    for (int step = 0; step <= ray.steps; step++) {
+      int32_t g[3];
+      vb_ray_next(&ray, g);
+      if (!(approx_sets ? approx_replace(o->approx_seen, o->approx_offset, g) : idxset_insert(&seen_set, g))) ++collisions;
+      else collisions = 0;
+      if (collisions > 2) break;   /* max_consecutive_ray_collisions */
+      int32_t bid[3];
+      block_index(g, o->voxels_per_side_inv, bid);
+      if (o->shard_count > 1 && (int)(owner_hash(bid) % (size_t)o->shard_count) != o->shard_rank) continue;
+      if (!last_block || last_bid[0] != bid[0] || last_bid[1] != bid[1] || last_bid[2] != bid[2]) {
+        last_block = vblock_get(o, bid);
+        memcpy(last_bid, bid, sizeof(last_bid));
+      }
+      int32_t l[3];
+      local_index(g, l);
+      const int vid = l[0] + VPS * (l[1] + l[2] * VPS);
+      update_voxel(o, origin, pG, g, color, weight, &last_block->distance[vid], &last_block->weight[vid],
+                   &last_block->rgba[vid]);
+      visits++;
+    }
+    if (g_fast_updates_out) g_fast_updates_out[seq] = (int32_t)(visits - visits_before);
+  }
+  g_fast_updates_out = NULL;
+  free(keep);
+  if (!approx_sets) { free(start_set.key); free(start_set.used); free(seen_set.key); free(seen_set.used); }
+  vb_publish_pending(o);   /* updateLayerWithStoredBlocks (:601) */
+  o->last_visits = visits;
+}
+
+/* ---- A model of how the device reaches the one-thread schedule of the fast integrator without running it ray after ray
+ * (test infrastructure like the rest of this file; tests/test_tsdf_voxblox_fast.py checks it against the loop above).
+ * A ray's fate depends on the set queries of the rays before it; the set is a table of slots that remember the LAST
+ * index asked for, so "was index x seen?" = "does the previous query of x's slot, in (ray, step) order, carry x's
+ * hash?".  Given how many queries every ray makes (Q), all answers follow from one stable sort of the queries by slot;
+ * from the answers every ray finds its own stopping point; repeat until no Q changes.  Ray r's answers depend only on
+ * rays < r and its own earlier steps, so the first ray is right after one round, the fixed point is unique and it is the
+ * sequential schedule.  Returns the number of rounds; Q_out[seq] = queries of the ray at mixed position seq (0: no ray),
+ * L_out[seq] = voxels it updates. */
+typedef struct { uint32_t slot; uint32_t q; } vb_query_key;
+static int vb_query_cmp(const void* a, const void* b) {
+  const vb_query_key *x = (const vb_query_key*)a, *y = (const vb_query_key*)b;
+  if (x->slot != y->slot) return x->slot < y->slot ? -1 : 1;
+  return x->q < y->q ? -1 : (x->q > y->q ? 1 : 0);   /* (q grows with (ray, step): the stable order) */
+}
+int oracle_voxblox_fast_model(const oracle_voxblox* o, const float* xyz, int n, const float* Twc, int first_window,
+                              int32_t* Q_out, int32_t* L_out) {
+  float R[9], t[3], q[4];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) R[3 * i + j] = Twc[4 * i + j];
+    t[i] = Twc[4 * i + 3];
+  }
+  quat_from_matrix(R, q);
+  const uint64_t mask = ((uint64_t)1 << VB_APPROX_BITS) - 1;
+  const float start_inv = 2.0f * o->voxel_size_inv;
+  /* the start set: every valid point asks once, in the mixed order */
+  vb_ray* rays = (vb_ray*)malloc(sizeof(vb_ray) * (size_t)(n > 0 ? n : 1));
+  uint64_t* sh = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(n > 0 ? n : 1));
+  vb_query_key* sk = (vb_query_key*)malloc(sizeof(vb_query_key) * (size_t)(n > 0 ? n : 1));
+  int ns = 0;
+  for (int seq = 0; seq < n; seq++) {
+    Q_out[seq] = 0;
+    L_out[seq] = 0;
+    const int pi = (int)mixed_index((size_t)seq, (size_t)n);
+    const float* pC = xyz + 3 * (size_t)pi;
+    const float ray_distance = norm3(pC);
+    int is_clearing;
+    if (ray_distance < o->min_ray) continue;
+    else if (ray_distance > o->max_ray) {
+      if (o->allow_clear) is_clearing = 1;
+      else continue;
+    } else
+      is_clearing = 0;
+    float pG[3];
+    quat_transform(q, t, pC, pG);
+    int32_t sv[3];
+    for (int k = 0; k < 3; k++) sv[k] = (int32_t)floorf(pG[k] * start_inv + 1e-6f);
+    sh[seq] = (uint64_t)vb_hash(sv);
+    sk[ns].slot = (uint32_t)(sh[seq] & mask);
+    sk[ns].q = (uint32_t)seq;
+    ns++;
+    {
+      const float d[3] = {pG[0] - t[0], pG[1] - t[1], pG[2] - t[2]};
+      const float dn = norm3(d);
+      float unit[3] = {d[0], d[1], d[2]};
+      if (sum3(d[0] * d[0], d[1] * d[1], d[2] * d[2]) > 0.0f) { unit[0] = d[0] / dn; unit[1] = d[1] / dn; unit[2] = d[2] / dn; }
+      float rs[3], re[3], ss[3], es[3];
+      if (is_clearing) {
+        float tmp = dn - o->truncation;
+        tmp = (tmp < 0.0f) ? 0.0f : tmp;
+        const float len = (o->max_ray < tmp) ? o->max_ray : tmp;
+        for (int k = 0; k < 3; k++) { re[k] = t[k] + unit[k] * len; rs[k] = o->carving ? t[k] : re[k]; }
+      } else {
+        for (int k = 0; k < 3; k++) {
+          re[k] = pG[k] + unit[k] * o->truncation;
+          rs[k] = o->carving ? t[k] : (pG[k] - unit[k] * o->truncation);
+        }
+      }
+      for (int k = 0; k < 3; k++) { ss[k] = rs[k] * o->voxel_size_inv; es[k] = re[k] * o->voxel_size_inv; }
+      vb_ray_setup_scaled(es, ss, &rays[seq]);
+    }
+    Q_out[seq] = -1;   /* valid; alive or not is decided below */
+  }
+  qsort(sk, (size_t)ns, sizeof(vb_query_key), vb_query_cmp);
+  for (int p = 0; p < ns; p++) {
+    const int seq = (int)sk[p].q;
+    const int dup = p > 0 && sk[p - 1].slot == sk[p].slot && sh[sk[p - 1].q] == sh[seq];
+    Q_out[seq] = dup ? 0 : (rays[seq].steps + 1 < first_window ? rays[seq].steps + 1 : first_window);
+  }
+  /* the observed set: rounds */
+  int rounds = 0;
+  size_t cap = 0;
+  vb_query_key* qk = NULL;
+  uint64_t* qh = NULL;
+  uint8_t* seen = NULL;
+  for (;;) {
+    rounds++;
+    size_t M = 0;
+    for (int seq = 0; seq < n; seq++) M += (size_t)Q_out[seq];
+    if (M > cap) {
+      cap = M + M / 2 + 16;
+      qk = (vb_query_key*)realloc(qk, sizeof(vb_query_key) * cap);
+      qh = (uint64_t*)realloc(qh, sizeof(uint64_t) * cap);
+      seen = (uint8_t*)realloc(seen, cap);
+    }
+    size_t at = 0;
+    for (int seq = 0; seq < n; seq++) {
+      vb_ray r = rays[seq];
+      for (int s = 0; s < Q_out[seq]; s++) {
+        int32_t g[3];
+        vb_ray_next(&r, g);
+        qh[at] = (uint64_t)vb_hash(g);
+        qk[at].slot = (uint32_t)(qh[at] & mask);
+        qk[at].q = (uint32_t)at;
+        at++;
+      }
+    }
+    qsort(qk, M, sizeof(vb_query_key), vb_query_cmp);
+    for (size_t p = 0; p < M; p++)
+      seen[qk[p].q] = (uint8_t)(p > 0 && qk[p - 1].slot == qk[p].slot && qh[qk[p - 1].q] == qh[qk[p].q]);
+    int changed = 0;
+    at = 0;
+    for (int seq = 0; seq < n; seq++) {
+      const int Q = Q_out[seq], full = Q ? rays[seq].steps + 1 : 0;
+      int collisions = 0, newQ = Q, L = Q;
+      for (int s = 0; s < Q; s++) {
+        collisions = seen[at + (size_t)s] ? collisions + 1 : 0;
+        if (collisions > 2) { newQ = s + 1; L = s; break; }
+      }
+      if (newQ == Q && L == Q && Q < full) newQ = full;   /* no stop inside the window: look at the whole ray next round */
+      at += (size_t)Q;
+      if (newQ != Q) changed = 1;
+      Q_out[seq] = newQ;
+      L_out[seq] = L;
+    }
+    if (!changed) break;
+  }
+  free(rays); free(sh); free(sk); free(qk); free(qh); free(seen);
+  return rounds;
 }
 
 /* ---- MergedTsdfIntegrator (tsdf_integrator.cc:329-492), integrator_threads = 1.  The bundling — points grouped by

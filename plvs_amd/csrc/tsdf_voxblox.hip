@@ -81,7 +81,9 @@ __device__ __forceinline__ int point_of_seq(const int32_t* __restrict__ offsets,
 // world-cloud-with-normals flavour (make_ray_world): cloud order, no validity test; `aux` = normals, n x 3.  kMerged:
 // MergedTsdfIntegrator's bundles in their integration order (make_ray_merged): xyz = merged points, `aux` = merged
 // weights (n), `clr` = the bundles' clearing flags.
-enum VbMode { kSimple = 0, kWorld = 1, kMerged = 2 };
+// kFast: FastTsdfIntegrator's rays (tsdf_voxblox_fast.hpp has decided which rays live and how many voxels each updates):
+// the mixed order of kSimple, cast from the surface end, `aux` = the rays' update counts (uint32, 0 = no ray).
+enum VbMode { kSimple = 0, kWorld = 1, kMerged = 2, kFast = 3 };
 
 // The fill pass stages a wave's records in LDS: the 64 rays of a wave own ONE contiguous range of the record arrays
 // (their counts were scanned in ray order), so the wave writes it with consecutive lanes on consecutive words instead of
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void vb_ray_pass(
   const uint32_t wbase = kFill ? (uint32_t)__builtin_amdgcn_readfirstlane((int)out) : 0u;
   if (valid) {
     int cloud = 0;
-    const int p = kMode != kSimple ? i : point_of_seq(offsets, nclouds, i, &cloud);
+    const int p = (kMode == kWorld || kMode == kMerged) ? i : point_of_seq(offsets, nclouds, i, &cloud);
     const float px = xyz[3 * (size_t)p], py = xyz[3 * (size_t)p + 1], pz = xyz[3 * (size_t)p + 2];
     if (!(isfinite(px) && isfinite(py) && isfinite(pz))) {
       // the reference filters such points out BEFORE the mixed order is formed;
@@ -120,12 +122,18 @@ __global__ __launch_bounds__(256) void vb_ray_pass(
       } else if (kMode == kMerged) {
         make_ray_merged(P, pose, px, py, pz, clr[p] != 0, &ray);
       } else {
-        walk = make_ray(P, pose, px, py, pz, &ray);
+        walk = make_ray(P, pose, px, py, pz, &ray, kMode == kFast);
+      }
+      uint32_t limit = 0xFFFFFFFFu;   // voxels the ray may update
+      if (kMode == kFast) {
+        limit = reinterpret_cast<const uint32_t*>(aux)[i];
+        walk = walk && limit > 0u;
       }
       if (walk) {
         int lb[3] = {0, 0, 0}, lslot = -1;
         bool have_last = false;
-        const int steps = ray.steps < kMaxRaySteps ? ray.steps : kMaxRaySteps;
+        int steps = ray.steps < kMaxRaySteps ? ray.steps : kMaxRaySteps;
+        if (kMode == kFast && (uint32_t)steps >= limit) steps = (int)limit - 1;
         for (int s = 0; s <= steps; ++s) {
           int g[3], b[3], vid;
           ray_step(&ray, g);
@@ -174,6 +182,8 @@ __global__ __launch_bounds__(256) void vb_ray_pass(
     rec_seq[wbase + j] = s_seq[wid][j];
   }
 }
+
+#include "tsdf_voxblox_fast.hpp"
 
 // MergedTsdfIntegrator::bundleRays, the per-point part (tsdf_integrator.cc:361-386): isPointValid -> kind (0 skipped,
 // 1 normal, 2 clearing) and the voxel T_G_C * point_C ends in.  The grouping itself needs the reference's hash map and
@@ -797,6 +807,15 @@ struct plvs_tsdf_voxblox {
   DevBuf<int32_t> mg_g;
   DevBuf<uint32_t> mg_first, mg_pts, mg_col;
   DevBuf<float> mg_xyz, mg_w;
+  // fast integrator (tsdf_voxblox_fast.hpp): the two approximate sets as the reference keeps them, the offset of the next
+  // scan, and the scratch of the rounds
+  DevBuf<unsigned long long> ap_start, ap_seen, ff_shash, ff_qhash;
+  DevBuf<uint32_t> ff_skey0, ff_skey1, ff_sval0, ff_sval1, ff_full, ff_Q, ff_L, ff_qoff, ff_qkey0, ff_qkey1, ff_qval0, ff_qval1, ff_flags;
+  DevBuf<uint8_t> ff_seen;
+  uint32_t* h_ff = nullptr;            // pinned: {queries of the next round, did a ray change}
+  uint32_t ap_next = 1;                // (the reference's sets start at offset 0 and every scan begins with offset + 1)
+  bool ap_ready = false;
+  int fast_rounds = 0;                 // rounds of the last fast call (diagnostic)
   plvs_tsdf_stats stats{};
   uint32_t last_updated = 0;
   void* ext = nullptr;                 // meshing scratch (tsdf_voxblox_mesh.hip), freed with the map
@@ -864,6 +883,10 @@ int plvs_hip_tsdf_voxblox_destroy(plvs_tsdf_voxblox* h) {
   (void)hipFree(h->dir.keys); (void)hipFree(h->dir.slots); (void)hipFree(h->dir.slot_ids);
   (void)hipFree(h->dist); (void)hipFree(h->weight); (void)hipFree(h->rgba); (void)hipFree(h->d_ctr);
   if (h->h_ctr) (void)hipHostFree(h->h_ctr);
+  if (h->h_ff) (void)hipHostFree(h->h_ff);
+  h->ap_start.release(); h->ap_seen.release(); h->ff_shash.release(); h->ff_qhash.release(); h->ff_skey0.release(); h->ff_skey1.release();
+  h->ff_sval0.release(); h->ff_sval1.release(); h->ff_full.release(); h->ff_Q.release(); h->ff_L.release(); h->ff_qoff.release();
+  h->ff_qkey0.release(); h->ff_qkey1.release(); h->ff_qval0.release(); h->ff_qval1.release(); h->ff_flags.release(); h->ff_seen.release();
   h->counts.release(); h->keys0.release(); h->keys1.release(); h->seq0.release(); h->seq1.release();
   h->heads.release(); h->updated.release(); h->scratch.release(); h->rec_c.release(); h->rec.release(); h->upd_merge.release();
   h->offsets.release(); h->st_xyz.release(); h->st_Twc.release(); h->st_nrm.release(); h->st_rgba.release();
@@ -891,6 +914,8 @@ int plvs_hip_tsdf_voxblox_clear(plvs_tsdf_voxblox* h) {
   h->poisoned = false;
   h->stats = plvs_tsdf_stats{};
   h->last_updated = 0;
+  h->ap_ready = false;   // (a new map = a new integrator: fresh sets, offset 0)
+  h->ap_next = 1;
   return PLVS_OK;
 }
 
@@ -1203,9 +1228,88 @@ static int vb_publish_waiting(plvs_tsdf_voxblox* h, hipStream_t s, int published
 
 // mode kWorld: the world-cloud-with-normals flavour (integrateWorlPointCloud), d_aux = normals; mode kMerged:
 // MergedTsdfIntegrator's bundles, d_aux = merged weights, d_clr = clearing flags.  Both: one cloud.
+static int vb_fast_tables(plvs_tsdf_voxblox* h, hipStream_t s, bool reset) {
+  if (h->ap_ready && !reset) return PLVS_OK;
+  PLVS_HIP_TRY(h->ap_start.reserve(kApproxWords));
+  PLVS_HIP_TRY(h->ap_seen.reserve(kApproxWords));
+  if (!h->h_ff) PLVS_HIP_TRY(hipHostMalloc((void**)&h->h_ff, 2 * sizeof(uint32_t)));
+  hipLaunchKernelGGL(vbf_init_table, dim3(ceil_div(kApproxWords, 256)), dim3(256), 0, s, h->ap_start.p, kApproxWords);
+  hipLaunchKernelGGL(vbf_init_table, dim3(ceil_div(kApproxWords, 256)), dim3(256), 0, s, h->ap_seen.p, kApproxWords);
+  PLVS_KERNEL_CHECK();
+  h->ap_ready = true;
+  return PLVS_OK;
+}
+
+// Which rays of the batch's scans are cast and how many voxels each updates (h->ff_L, per sequence position): the
+// rounds described in tsdf_voxblox_fast.hpp.  The offsets and poses of the call are on the device already.
+static int vb_fast_plan(plvs_tsdf_voxblox* h, const float* d_xyz, int n, int nclouds, const PoseRt* d_poses, uint32_t first_offset,
+                        hipStream_t s) {
+  const unsigned nb = ceil_div((size_t)n, 256);
+  PLVS_HIP_TRY(h->ff_skey0.reserve((size_t)n)); PLVS_HIP_TRY(h->ff_skey1.reserve((size_t)n));
+  PLVS_HIP_TRY(h->ff_sval0.reserve((size_t)n)); PLVS_HIP_TRY(h->ff_sval1.reserve((size_t)n));
+  PLVS_HIP_TRY(h->ff_shash.reserve((size_t)n)); PLVS_HIP_TRY(h->ff_full.reserve((size_t)n));
+  PLVS_HIP_TRY(h->ff_Q.reserve((size_t)n)); PLVS_HIP_TRY(h->ff_L.reserve((size_t)n));
+  PLVS_HIP_TRY(h->ff_qoff.reserve((size_t)n)); PLVS_HIP_TRY(h->ff_flags.reserve(2));
+  PLVS_HIP_TRY(h->scratch.reserve(std::max(radix_scratch_words((size_t)n), scan_scratch_words((size_t)n))));
+  hipLaunchKernelGGL(vbf_start, dim3(nb), dim3(256), 0, s, h->P, d_xyz, n, h->offsets.p, nclouds, d_poses, first_offset,
+                     h->ff_skey0.p, h->ff_sval0.p, h->ff_shash.p, h->ff_full.p, h->d_ctr);
+  PLVS_KERNEL_CHECK();
+  bool second = false;
+  PLVS_HIP_TRY(radix_sort_pairs(h->ff_skey0.p, h->ff_sval0.p, h->ff_skey1.p, h->ff_sval1.p, (size_t)n, 0, kApproxKeyBits,
+                                h->scratch.p, s, &second));
+  const uint32_t* sk = second ? h->ff_skey1.p : h->ff_skey0.p;
+  const uint32_t* sv = second ? h->ff_sval1.p : h->ff_sval0.p;
+  hipLaunchKernelGGL(vbf_alive, dim3(nb), dim3(256), 0, s, sk, sv, (uint32_t)n, h->ff_shash.p, h->ap_start.p, h->ff_full.p, h->ff_Q.p);
+  hipLaunchKernelGGL(vbf_write_back, dim3(nb), dim3(256), 0, s, sk, sv, (uint32_t)n, h->ff_shash.p, h->ap_start.p);
+  PLVS_KERNEL_CHECK();
+  h->fast_rounds = 0;
+  PLVS_HIP_TRY(hipMemsetAsync(h->ff_flags.p, 0, 2 * sizeof(uint32_t), s));
+  const uint32_t *qk = nullptr, *qv = nullptr;
+  uint32_t M = 0;
+  for (;;) {
+    // queries of the round; did the round before change anything?
+    PLVS_HIP_TRY(exclusive_scan_u32(h->ff_Q.p, h->ff_qoff.p, (size_t)n, h->ff_flags.p, h->scratch.p, s));
+    hipLaunchKernelGGL(vbf_publish, dim3(1), dim3(1), 0, s, h->ff_flags.p, h->ff_flags.p + 1, h->h_ff);
+    PLVS_KERNEL_CHECK();
+    PLVS_HIP_TRY(hipStreamSynchronize(s));
+    if (h->fast_rounds > 0 && h->h_ff[1] == 0) break;   // (the sorted queries of the last round are the scans' queries)
+    PLVS_REQUIRE(h->fast_rounds < 100000, "fast integrator: the rounds do not settle");
+    M = h->h_ff[0];
+    ++h->fast_rounds;
+    PLVS_HIP_TRY(hipMemsetAsync(h->ff_flags.p + 1, 0, sizeof(uint32_t), s));
+    if (M == 0) {   // no ray at all: nothing to ask
+      hipLaunchKernelGGL(vbf_trim, dim3(nb), dim3(256), 0, s, n, h->ff_qoff.p, h->ff_full.p, (const uint8_t*)nullptr, h->ff_Q.p,
+                         h->ff_L.p, h->ff_flags.p + 1);
+      PLVS_KERNEL_CHECK();
+      continue;
+    }
+    PLVS_HIP_TRY(h->ff_qkey0.reserve(M)); PLVS_HIP_TRY(h->ff_qkey1.reserve(M));
+    PLVS_HIP_TRY(h->ff_qval0.reserve(M)); PLVS_HIP_TRY(h->ff_qval1.reserve(M));
+    PLVS_HIP_TRY(h->ff_qhash.reserve(M)); PLVS_HIP_TRY(h->ff_seen.reserve(M));
+    PLVS_HIP_TRY(h->scratch.reserve(std::max(radix_scratch_words((size_t)M), scan_scratch_words((size_t)n))));
+    hipLaunchKernelGGL(vbf_emit, dim3(nb), dim3(256), 0, s, h->P, d_xyz, n, h->offsets.p, nclouds, d_poses, first_offset, h->ff_Q.p,
+                       h->ff_qoff.p, h->ff_qkey0.p, h->ff_qval0.p, h->ff_qhash.p);
+    PLVS_KERNEL_CHECK();
+    bool sec = false;
+    PLVS_HIP_TRY(radix_sort_pairs(h->ff_qkey0.p, h->ff_qval0.p, h->ff_qkey1.p, h->ff_qval1.p, (size_t)M, 0, kApproxKeyBits,
+                                  h->scratch.p, s, &sec));
+    qk = sec ? h->ff_qkey1.p : h->ff_qkey0.p;
+    qv = sec ? h->ff_qval1.p : h->ff_qval0.p;
+    hipLaunchKernelGGL(vbf_seen, dim3(ceil_div((size_t)M, 256)), dim3(256), 0, s, qk, qv, M, h->ff_qhash.p, h->ap_seen.p, h->ff_seen.p);
+    hipLaunchKernelGGL(vbf_trim, dim3(nb), dim3(256), 0, s, n, h->ff_qoff.p, h->ff_full.p, h->ff_seen.p, h->ff_Q.p, h->ff_L.p,
+                       h->ff_flags.p + 1);
+    PLVS_KERNEL_CHECK();
+  }
+  if (M > 0 && qk) {
+    hipLaunchKernelGGL(vbf_write_back, dim3(ceil_div((size_t)M, 256)), dim3(256), 0, s, qk, qv, M, h->ff_qhash.p, h->ap_seen.p);
+    PLVS_KERNEL_CHECK();
+  }
+  return PLVS_OK;
+}
+
 static int vb_integrate_impl(plvs_tsdf_voxblox* h, const float* d_xyz, const uint8_t* d_rgba, const int32_t* offsets,
                              int nclouds, const float* d_Twc, void* stream, int mode, const float* d_aux,
-                             const uint8_t* d_clr) {
+                             const uint8_t* d_clr, uint32_t fast_offset = 0) {
   PLVS_REQUIRE(h, "null handle");
   PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
   PLVS_REQUIRE(offsets && nclouds >= 0, "bad offsets");
@@ -1244,11 +1348,17 @@ static int vb_integrate_impl(plvs_tsdf_voxblox* h, const float* d_xyz, const uin
   hipLaunchKernelGGL(vb_pose_prep, dim3(ceil_div((size_t)nclouds, 64)), dim3(64), 0, s, d_Twc, nclouds, h->poses.p);
   const PoseRt* const d_poses = h->poses.p;
   const dim3 rgrid(ceil_div((size_t)n, 256)), rblock(256);
+  if (mode == kFast) {   // which rays are cast, and how far: the update counts take aux's place
+    int rcf = vb_fast_plan(h, d_xyz, n, nclouds, d_poses, fast_offset, s);
+    if (rcf != PLVS_OK) return rcf;
+    d_aux = reinterpret_cast<const float*>(h->ff_L.p);
+  }
 #define VB_RAY_PASS(FILL, MODE, K, Q)                                                                                    \
   hipLaunchKernelGGL((vb_ray_pass<FILL, MODE>), rgrid, rblock, 0, s, h->P, d_xyz, d_aux, d_clr, n, h->offsets.p, nclouds, \
                      d_poses, h->dir, h->d_ctr, h->counts.p, K, Q)
   if (mode == kWorld) VB_RAY_PASS(false, kWorld, (uint32_t*)nullptr, (uint32_t*)nullptr);
   else if (mode == kMerged) VB_RAY_PASS(false, kMerged, (uint32_t*)nullptr, (uint32_t*)nullptr);
+  else if (mode == kFast) VB_RAY_PASS(false, kFast, (uint32_t*)nullptr, (uint32_t*)nullptr);
   else VB_RAY_PASS(false, kSimple, (uint32_t*)nullptr, (uint32_t*)nullptr);
   PLVS_KERNEL_CHECK();
   PLVS_HIP_TRY(exclusive_scan_u32(h->counts.p, h->counts.p, (size_t)n, &h->d_ctr->total_visits,
@@ -1284,6 +1394,7 @@ static int vb_integrate_impl(plvs_tsdf_voxblox* h, const float* d_xyz, const uin
   PLVS_HIP_TRY(h->scratch.reserve(radix_scratch_words(V)));
   if (mode == kWorld) VB_RAY_PASS(true, kWorld, h->keys0.p, h->seq0.p);
   else if (mode == kMerged) VB_RAY_PASS(true, kMerged, h->keys0.p, h->seq0.p);
+  else if (mode == kFast) VB_RAY_PASS(true, kFast, h->keys0.p, h->seq0.p);
   else VB_RAY_PASS(true, kSimple, h->keys0.p, h->seq0.p);
 #undef VB_RAY_PASS
   PLVS_KERNEL_CHECK();
@@ -1341,6 +1452,68 @@ int plvs_hip_tsdf_voxblox_integrate_batch_dev(plvs_tsdf_voxblox* h, const float*
                                               const uint8_t* d_rgba, const int32_t* offsets,
                                               int nclouds, const float* d_Twc, void* stream) {
   return vb_integrate_impl(h, d_xyz, d_rgba, offsets, nclouds, d_Twc, stream, kSimple, nullptr, nullptr);
+}
+
+int plvs_hip_tsdf_voxblox_integrate_fast_batch_dev(plvs_tsdf_voxblox* h, const float* d_xyz, const uint8_t* d_rgba,
+                                                   const int32_t* offsets, int nclouds, const float* d_Twc, void* stream) {
+  PLVS_REQUIRE(h, "null handle");
+  PLVS_REQUIRE(offsets && nclouds >= 0, "bad offsets");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // Every cloud is a scan, every scan begins with the sets' "reset": offset + 1, and the 10 000th zeroes them
+  // (approx_hash_array.h:141-150).  A batch is cut where that happens.
+  std::vector<int32_t> sub;
+  int c0 = 0;
+  int rounds = 0;
+  plvs_tsdf_stats total{};
+  while (c0 < nclouds) {
+    const bool zero = h->ap_next >= kApproxReset;
+    int rc = vb_fast_tables(h, s, zero);
+    if (rc != PLVS_OK) return rc;
+    if (zero) h->ap_next = 0;
+    const int count = std::min<int>(nclouds - c0, (int)(kApproxReset - h->ap_next));
+    sub.assign((size_t)count + 1, 0);
+    for (int c = 0; c <= count; ++c) sub[(size_t)c] = offsets[c0 + c] - offsets[c0];
+    const size_t p0 = (size_t)offsets[c0];
+    rc = vb_integrate_impl(h, d_xyz ? d_xyz + 3 * p0 : nullptr, d_rgba ? d_rgba + 4 * p0 : nullptr, sub.data(), count,
+                           d_Twc ? d_Twc + 12 * (size_t)c0 : nullptr, stream, kFast, nullptr, nullptr, h->ap_next);
+    if (rc != PLVS_OK) return rc;
+    h->ap_next += (uint32_t)count;
+    c0 += count;
+    rounds = std::max(rounds, h->fast_rounds);
+    total.points += h->stats.points; total.visits += h->stats.visits; total.new_chunks += h->stats.new_chunks;
+    total.updated_chunks = h->stats.updated_chunks; total.voxels = h->stats.voxels; total.max_run = h->stats.max_run;
+  }
+  if (nclouds > 0) h->stats = total;
+  h->fast_rounds = rounds;
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_voxblox_integrate_fast(plvs_tsdf_voxblox* h, const float* xyz, const uint8_t* rgba, int n, const float* Twc) {
+  PLVS_REQUIRE(h, "null handle");
+  PLVS_REQUIRE(n >= 0 && Twc, "bad arguments");
+  if (n == 0) {   // (an empty scan still moves the sets on)
+    const int32_t none[2] = {0, 0};
+    return plvs_hip_tsdf_voxblox_integrate_fast_batch_dev(h, nullptr, nullptr, none, 1, nullptr, nullptr);
+  }
+  PLVS_REQUIRE(xyz && rgba, "null cloud pointer");
+  PLVS_HIP_TRY(h->st_xyz.reserve((size_t)n * 3));
+  PLVS_HIP_TRY(h->st_rgba.reserve((size_t)n));
+  PLVS_HIP_TRY(h->st_Twc.reserve(12));
+  PLVS_HIP_TRY(hipMemcpy(h->st_xyz.p, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(h->st_rgba.p, rgba, (size_t)n * 4, hipMemcpyHostToDevice));
+  PLVS_HIP_TRY(hipMemcpy(h->st_Twc.p, Twc, 12 * sizeof(float), hipMemcpyHostToDevice));
+  const int32_t offsets[2] = {0, n};
+  int rc = plvs_hip_tsdf_voxblox_integrate_fast_batch_dev(h, h->st_xyz.p, reinterpret_cast<const uint8_t*>(h->st_rgba.p), offsets, 1,
+                                                        h->st_Twc.p, nullptr);
+  if (rc != PLVS_OK) return rc;
+  PLVS_HIP_TRY(hipDeviceSynchronize());
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_voxblox_fast_rounds(plvs_tsdf_voxblox* h, int* rounds) {
+  PLVS_REQUIRE(h && rounds, "null argument");
+  *rounds = h->fast_rounds;
+  return PLVS_OK;
 }
 
 int plvs_hip_tsdf_voxblox_integrate_world_normals(plvs_tsdf_voxblox* h, const float* xyz, const uint8_t* rgba,

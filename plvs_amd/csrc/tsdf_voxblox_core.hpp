@@ -90,10 +90,12 @@ struct Ray {
   float weight;               // getVoxelWeight(point_C)
 };
 
-PLVS_HD void ray_setup(const Params& P, const PoseRt& pose, bool clearing, Ray* r);
+PLVS_HD void ray_setup(const Params& P, const PoseRt& pose, bool clearing, Ray* r, bool from_end = false);
 
 // isPointValid + RayCaster set-up.  Returns false when the point is skipped.
-PLVS_HD bool make_ray(const Params& P, const PoseRt& pose, float px, float py, float pz, Ray* r) {
+// from_end: the same two end points cast the other way round (RayCaster(..., cast_from_origin = false),
+// integrator_utils.cc:164-168: what FastTsdfIntegrator asks for).
+PLVS_HD bool make_ray(const Params& P, const PoseRt& pose, float px, float py, float pz, Ray* r, bool from_end = false) {
   const float ray_distance = sqrtf(vsum3(px * px, py * py, pz * pz));
   bool clearing;
   if (ray_distance < P.min_ray) return false;
@@ -103,7 +105,7 @@ PLVS_HD bool make_ray(const Params& P, const PoseRt& pose, float px, float py, f
   } else
     clearing = false;
   quat_transform(pose, px, py, pz, r->pG);
-  ray_setup(P, pose, clearing, r);
+  ray_setup(P, pose, clearing, r, from_end);
   r->weight = fabsf(pz) > 1e-6f ? 1.0f / (pz * pz) : 0.0f;  // use_const_weight = false
   return true;
 }
@@ -117,7 +119,7 @@ PLVS_HD void make_ray_merged(const Params& P, const PoseRt& pose, float px, floa
 }
 
 // RayCaster's constructor from origin and r->pG (integrator_utils.cc:137-167) + setupRayCaster (:196-235).
-PLVS_HD void ray_setup(const Params& P, const PoseRt& pose, bool clearing, Ray* r) {
+PLVS_HD void ray_setup(const Params& P, const PoseRt& pose, bool clearing, Ray* r, bool from_end) {
   const float* o = pose.t;
   const float d0 = r->pG[0] - o[0], d1 = r->pG[1] - o[1], d2 = r->pG[2] - o[2];
   const float z2 = vsum3(d0 * d0, d1 * d1, d2 * d2);
@@ -141,7 +143,8 @@ PLVS_HD void ray_setup(const Params& P, const PoseRt& pose, bool clearing, Ray* 
   }
   r->steps = 0;
   for (int k = 0; k < 3; ++k) {
-    const float ss = rs[k] * P.voxel_size_inv, es = re[k] * P.voxel_size_inv;
+    // (cast_from_origin = false: setupRayCaster(end_scaled, start_scaled))
+    const float ss = (from_end ? re[k] : rs[k]) * P.voxel_size_inv, es = (from_end ? rs[k] : re[k]) * P.voxel_size_inv;
     r->cur[k] = (int)floorf(ss + 1e-6f);
     const int endk = (int)floorf(es + 1e-6f);
     const int dk = endk - r->cur[k];

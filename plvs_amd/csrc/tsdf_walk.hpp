@@ -1853,7 +1853,8 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
     APPLY_PROF(4);   // the voxel updates
 #ifdef PLVS_WALK_PROF
     ++ap_items;
-    ap_max = max(ap_max, (unsigned long long)((long long)clock64() - ap_item0));
+    ap_max = max(ap_max, ((unsigned long long)((long long)clock64() - ap_item0) << 24) | ((unsigned long long)min(s1 - s0, 0xFFFFFu) << 4) |
+                             (unsigned long long)min(nparts, 15u));   // cycles | segments of the item | parts of its chunk
 #endif
   }
 #ifdef PLVS_WALK_PROF

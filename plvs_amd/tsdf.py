@@ -433,6 +433,31 @@ class TsdfVoxblox:
         _lib.check(_L.plvs_hip_tsdf_voxblox_integrate(self._h, _lib.np_ptr(xyz), _lib.np_ptr(rgba), xyz.shape[0],
                                                       _lib.np_ptr(Twc)))
 
+    def integrate_fast(self, xyz, rgba, Twc):
+        """FastTsdfIntegrator::integratePointCloud (integration method "fast", one thread; the reference's approximate sets
+        word for word, kept from scan to scan)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8).reshape(-1, 4)
+        Twc = np.ascontiguousarray(Twc, dtype=np.float32).reshape(3, 4)
+        f = _L.plvs_hip_tsdf_voxblox_integrate_fast
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        _lib.check(f(self._h, _lib.np_ptr(xyz), _lib.np_ptr(rgba), xyz.shape[0], _lib.np_ptr(Twc)))
+
+    def integrate_fast_batch_dev(self, d_xyz, d_rgba, offsets, d_Twc):
+        """The same for several clouds in HBM: every cloud is one scan."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        f = _L.plvs_hip_tsdf_voxblox_integrate_fast_batch_dev
+        f.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        _lib.check(f(self._h, _lib.t_ptr(d_xyz), _lib.t_ptr(d_rgba), _lib.np_ptr(offsets), offsets.shape[0] - 1,
+                     _lib.t_ptr(d_Twc), _lib.current_stream_ptr()))
+
+    def fast_rounds(self):
+        n = ctypes.c_int()
+        f = _L.plvs_hip_tsdf_voxblox_fast_rounds
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        _lib.check(f(self._h, ctypes.byref(n)))
+        return n.value
+
     def integrate_merged(self, xyz, rgba, Twc):
         """MergedTsdfIntegrator::integratePointCloud (integration method "merged", one thread)."""
         xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
@@ -567,8 +592,10 @@ class TsdfVoxblox:
 class PointCloudMapVoxblox:
     """Same surface as PLVS2::PointCloudMapVoxblox for the integrate path
     (src/PointCloudMapVoxblox.cc:48-99)."""
-    # "simple" and "merged" reproduce the reference's one-thread schedules bit for bit; "fast" (the reference's YAML
-    # default: a lossy, order-dependent, racy speed-up of "simple") is substituted by "simple" (INTEGRATION.md §4)
+    # "simple", "merged" and "fast" (the reference's YAML default) reproduce the reference's one-thread schedules bit for
+    # bit (INTEGRATION.md §4).  "fast" is no speed-up on the device — it skips nine tenths of the updates at the price of
+    # several rounds over the scan — so the class default stays "simple"; a port that wants maps equal to a PLVS run with
+    # its YAML's method sets it.
     skIntegrationMethod = "simple"
 
     def __init__(self, resolution, use_carving=False, max_blocks=None):
@@ -583,6 +610,8 @@ class PointCloudMapVoxblox:
         Twc = np.asarray(Twc, dtype=np.float32)[:3, :4]
         if self.skIntegrationMethod == "merged":
             self._tsdf.integrate_merged(cloud_camera["xyz"], cloud_camera["rgba"], Twc)
+        elif self.skIntegrationMethod == "fast":
+            self._tsdf.integrate_fast(cloud_camera["xyz"], cloud_camera["rgba"], Twc)
         else:
             self._tsdf.integrate(cloud_camera["xyz"], cloud_camera["rgba"], Twc)
         for b in self._tsdf.updated_chunk_ids():          # tsdf_integrator.cc:151

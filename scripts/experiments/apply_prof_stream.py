@@ -29,8 +29,11 @@ skf = make_stream_keyframes(NS * 100, threads=32)
 steps = [pack(skf[i * 100:(i + 1) * 100]) for i in range(NS)]
 room = [pack(make_keyframes(100, max_depth=5.0, seed=0))] * 10
 NAMES = ["set-up", "segments(thread 0)", "wait slowest wave", "part merge", "voxel updates"]
-for name, seq in (("stream", steps), ("room", room)):
+PARTS = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]] or [(256, 2048)]
+for name, seq, (ps, pm) in [(n, q, p) for p in PARTS for n, q in (("stream", steps), ("room", room))]:
     t = TsdfChisel(0.05, max_chunks=16384, order_free=True)
+    t.set_apply_parts(ps, pm)
+    print((ps, pm), end=" ")
     for b in seq[:4]:
         t.integrate_batch_dev(*b)
     _lib.lib.plvs_hip_debug_walk_prof(None, 1)
@@ -43,5 +46,6 @@ for name, seq in (("stream", steps), ("room", room)):
     tot = float(sum(buf[9:14])) or 1.0
     print(name, {k: round(v / c, 4) for k, v in sm.items()},
           {NAMES[i]: round(buf[9 + i] / tot, 3) for i in range(5)},
-          "items/call", buf[14] // c, "cycles/item", int(tot / max(buf[14], 1)), "longest item cycles", buf[15], flush=True)
+          "items/call", buf[14] // c, "cycles/item", int(tot / max(buf[14], 1)), "longest item: cycles", buf[15] >> 24, "segments", (buf[15] >> 4) & 0xFFFFF,
+          "parts of its chunk", buf[15] & 15, flush=True)
     t.close()

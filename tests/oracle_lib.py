@@ -611,6 +611,17 @@ class _VoxbloxLike:
         Twc = np.ascontiguousarray(Twc, dtype=np.float32).reshape(3, 4)
         getattr(self.lib, self.p + "_integrate")(self.h, _ptr(xyz), _ptr(rgba), xyz.shape[0], _ptr(Twc))
 
+    def integrate_fast(self, xyz, rgba, Twc, approx_sets=False):
+        """FastTsdfIntegrator::integratePointCloud, one thread (oracle only): with the reference's approximate hash sets
+        (approx_sets) or with collision-free sets (what the device builds)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        Twc = np.ascontiguousarray(Twc, dtype=np.float32).reshape(3, 4)
+        f = getattr(self.lib, self.p + "_integrate_fast")
+        f.restype = None
+        f.argtypes = [_vp, _vp, _vp, _i, _vp, _i]
+        f(self.h, _ptr(xyz), _ptr(rgba), xyz.shape[0], _ptr(Twc), int(bool(approx_sets)))
+
     def integrate_merged(self, xyz, rgba, Twc):
         """MergedTsdfIntegrator::integratePointCloud (oracle only) -> (number of bundles, first point of each)."""
         xyz = np.ascontiguousarray(xyz, dtype=np.float32)

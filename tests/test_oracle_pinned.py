@@ -378,6 +378,55 @@ def test_voxblox_integrators_equal_the_reference_sources(method, vs, carving, fa
 
 
 @needs_vref
+@pytest.mark.parametrize("vs,carving,far,stride", [(0.05, False, False, 2), (0.10, True, True, 2), (0.05, True, False, 3),
+                                                   (0.02, False, False, 1)])
+def test_voxblox_fast_integrator_equals_the_reference_source(vs, carving, far, stride):
+    """FastTsdfIntegrator (tsdf_integrator.cc:505-605) — PLVS's YAML default — compiled unmodified, integrator_threads = 1,
+    against the restatement with the reference's own approximate sets: the start-voxel test at half the voxel size, the
+    cast from the surface end, the stop at the third already-seen voxel in a row, ApproxHashSet's slot / offset rules
+    over several scans — every voxel of every block bit for bit.  And the class statement the device's integrator rests
+    on: the same algorithm with collision-free sets differs from it only where two indices shared a slot."""
+    from tests import oracle_lib
+    from tests.plvs_amd_synth import make_keyframes
+    ref = ctypes.CDLL(VREF)
+    oracle = oracle_lib.load()
+    ref.ref_voxblox_integrate.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int]
+    ref.ref_voxblox_destroy.argtypes = [ctypes.c_void_p]
+    oracle.lib.oracle_voxblox_pose_quat.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    h = _ref_map(ref, vs, carving, "fast")
+    ora, exact, simple = oracle.voxblox(vs, carving=carving), oracle.voxblox(vs, carving=carving), oracle.voxblox(vs, carving=carving)
+    kfs = make_keyframes(4, max_depth=8.0, room_size=(16.0, 12.0, 3.0), seed=11) if far else make_keyframes(4, seed=11)
+    for k in kfs:
+        xyz = np.ascontiguousarray(k["xyz"][::stride], np.float32)
+        rgba = np.ascontiguousarray(np.concatenate([k["rgb"][::stride], np.full((len(xyz), 1), 255, np.uint8)], 1))
+        Twc = np.ascontiguousarray(k["Twc"], np.float32).reshape(3, 4)
+        q = np.zeros(4, np.float32)
+        oracle.lib.oracle_voxblox_pose_quat(Twc.ctypes.data, q.ctypes.data)
+        t = np.ascontiguousarray(Twc[:, 3])
+        ref.ref_voxblox_integrate(h, q.ctypes.data, t.ctypes.data, xyz.ctypes.data, rgba.ctypes.data, len(xyz))
+        ora.integrate_fast(xyz, rgba, Twc, approx_sets=True)
+        exact.integrate_fast(xyz, rgba, Twc, approx_sets=False)
+        simple.integrate(xyz, rgba, Twc)
+    want = _ref_blocks(ref, h)
+    got = {tuple(int(v) for v in b): ora.get_chunk(*b) for b in ora.chunk_ids()}
+    assert set(got) == set(want) and len(want) > 20
+    for bid, planes in want.items():
+        for name, x, y in zip(("distance", "weight", "colour"), planes, got[bid]):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (name, bid)
+    # fast really is another integrator: fewer updates than simple ...
+    assert ora.last_visits() < 0.8 * simple.last_visits()
+    # ... and the collision-free sets change only a small part of it
+    ex = {tuple(int(v) for v in b): exact.get_chunk(*b) for b in exact.chunk_ids()}
+    nvox = ndiff = 0
+    for bid, (d, w, c) in got.items():
+        e = ex.get(bid)
+        nvox += int((w > 0).sum())
+        ndiff += int((w > 0).sum()) if e is None else int(((w != e[1]) | (d != e[0]))[(w > 0) | (e[1] > 0)].sum())
+    assert ndiff < 0.05 * nvox, (ndiff, nvox)
+    ref.ref_voxblox_destroy(h)
+
+
+@needs_vref
 def test_voxblox_world_cloud_integrate_equals_the_reference_source():
     """TsdfIntegratorBase::integrateWorlPointCloud (the LoadMap path) of the reference against the restatement: posed
     clouds with un-normalised and zero normals, onto a map that already holds camera-ray integrations."""

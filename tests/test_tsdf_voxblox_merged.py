@@ -97,11 +97,11 @@ def test_mirror_runs_the_merged_method(oracle):
 
     with pytest.raises(ValueError):
         Unknown(0.05)
-    # "fast" (the reference's YAML default) is accepted and runs the integrator it approximates: "simple" 
+    # "fast" (the reference's YAML default): FastTsdfIntegrator's one-thread schedule with its approximate sets
     pf, refs = Fast(0.05), oracle.voxblox(0.05)
     for k in make_keyframes(2, seed=8):
         pf.InsertCloud(dict(xyz=k["xyz"], rgba=rgba_of(k)), k["Twc"])
-        refs.integrate(k["xyz"], rgba_of(k), k["Twc"])
+        refs.integrate_fast(k["xyz"], rgba_of(k), k["Twc"], approx_sets=True)
     maps_equal(refs, pf.tsdf)
     pm, ref = Merged(0.05), oracle.voxblox(0.05)
     for k in make_keyframes(2, seed=8):
