@@ -677,6 +677,66 @@ def main():
                               f"-march=x86-64-v3, oracle/_ref/libvoxblox_ref_o3.so) over 8 key frames of the timed stream into a "
                               f"fresh 2 cm layer, {base['1']:.1f} s at integrator_threads = 1, {base['hardware_concurrency']:.1f} s at "
                               f"hardware_concurrency; host has {os.cpu_count()} cores"}
+                # ---- the "fast" method (PLVS's YAML default): the device's one-thread schedule against the reference's
+                # own FastTsdfIntegrator on the same 8 key frames, one scan per call as PLVS issues them
+                try:
+                    vf = TsdfVoxblox(0.02, max_blocks=65536)
+                    hh = _ct.c_void_p(_r.ref_voxblox_create_threads(0.02, 0.1, 10000.0, 0.1, 5.0, 0, b"fast", 1))
+                    t_ref = t_hip = 0.0
+                    fvis = rounds = 0
+                    for k in sample:
+                        q = np.zeros(4, np.float32)
+                        Twc_ = np.ascontiguousarray(k["Twc"], np.float32)
+                        _o.lib.oracle_voxblox_pose_quat(Twc_.ctypes.data, q.ctypes.data)
+                        tpos = np.ascontiguousarray(Twc_[:, 3])
+                        t0 = time.perf_counter()
+                        _r.ref_voxblox_integrate(hh, q.ctypes.data, tpos.ctypes.data, k["xyz"].ctypes.data, k["rgba"].ctypes.data,
+                                                 k["xyz"].shape[0])
+                        t_ref += time.perf_counter() - t0
+                        t0 = time.perf_counter()
+                        vf.integrate_fast(k["xyz"], k["rgba"], k["Twc"])
+                        t_hip += time.perf_counter() - t0
+                        fvis += vf.last_stats()["visits"]
+                        rounds = max(rounds, vf.fast_rounds())
+                    _r.ref_voxblox_destroy(hh)
+                    # bit identity: against the reference built WITHOUT floating-point contraction (libvoxblox_ref.so, the build
+                    # the oracle is pinned by; the -O3 -march build above fuses multiply-adds: DESIGN §3)
+                    _p = _ct.CDLL(vref.replace("libvoxblox_ref_o3.so", "libvoxblox_ref.so"))
+                    _p.ref_voxblox_create.restype = _ct.c_void_p
+                    _p.ref_voxblox_create.argtypes = [_ct.c_float] * 5 + [_ct.c_int, _ct.c_char_p]
+                    _p.ref_voxblox_integrate.argtypes = [_ct.c_void_p] * 5 + [_ct.c_int]
+                    _p.ref_voxblox_num_blocks.argtypes = [_ct.c_void_p]
+                    _p.ref_voxblox_block_ids.argtypes = [_ct.c_void_p, _ct.c_void_p]
+                    _p.ref_voxblox_get_block.argtypes = [_ct.c_void_p] + [_ct.c_int] * 3 + [_ct.c_void_p] * 3
+                    _p.ref_voxblox_destroy.argtypes = [_ct.c_void_p]
+                    hh = _ct.c_void_p(_p.ref_voxblox_create(0.02, 0.1, 10000.0, 0.1, 5.0, 0, b"fast"))
+                    for k in sample:
+                        q = np.zeros(4, np.float32)
+                        Twc_ = np.ascontiguousarray(k["Twc"], np.float32)
+                        _o.lib.oracle_voxblox_pose_quat(Twc_.ctypes.data, q.ctypes.data)
+                        tpos = np.ascontiguousarray(Twc_[:, 3])
+                        _p.ref_voxblox_integrate(hh, q.ctypes.data, tpos.ctypes.data, k["xyz"].ctypes.data, k["rgba"].ctypes.data,
+                                                 k["xyz"].shape[0])
+                    nbk = _p.ref_voxblox_num_blocks(hh)
+                    bids = np.zeros((max(nbk, 1), 3), np.int32)
+                    _p.ref_voxblox_block_ids(hh, bids.ctypes.data)
+                    same = nbk == vf.num_chunks()
+                    for bid in bids[:nbk]:
+                        d_, w_, c_ = np.zeros(4096, np.float32), np.zeros(4096, np.float32), np.zeros(4096, np.uint32)
+                        _p.ref_voxblox_get_block(hh, int(bid[0]), int(bid[1]), int(bid[2]), d_.ctypes.data, w_.ctypes.data, c_.ctypes.data)
+                        g_ = vf.get_chunk(*bid)
+                        same = same and all(np.array_equal(x.view(np.uint32), y.view(np.uint32)) for x, y in zip((d_, w_, c_), g_))
+                    _p.ref_voxblox_destroy(hh)
+                    vf.close()
+                    leg["fast_method"] = {
+                        "what": "FastTsdfIntegrator (PointCloudMapping.voxbloxIntegrationMethod: fast), one key frame per call, host "
+                                "flavour, 8 key frames into a fresh 2 cm layer: the device's one-thread schedule against the reference's "
+                                "own integrator at integrator_threads = 1",
+                        "hip_ms_per_keyframe": round(t_hip / len(sample) * 1e3, 3), "reference_cpu_ms_per_keyframe": round(t_ref / len(sample) * 1e3, 2),
+                        "voxel_updates": int(fvis), "simple_voxel_updates": int(rvis), "rounds_max": int(rounds),
+                        "bit_identical_to_the_reference_layer": bool(same), "blocks": int(nbk)}
+                except Exception as e:   # (a reported leg, never the headline)
+                    leg["fast_method"] = {"error": repr(e)}
             result["voxblox_configs3"] = leg
         vb.close()
 
@@ -902,6 +962,35 @@ def main():
                 "value": round(1e3 / cpu_ms, 2), "unit": "frames/s", "ms_per_frame": round(cpu_ms, 2), "cores": 2,
                 "kind": "port", "sample": f"oracle/orb.cpp || oracle/lines.cpp on two threads, {ncpu} frames after 10 warm-up "
                                           f"frames (extraction only), host has {os.cpu_count()} cores"}
+            # the reference's own extractors where they have been built (oracle/_ref/libfrontend_ref_o3.so: src/ORBextractor.cc,
+            # src/LineExtractor.cc, binary_descriptor_custom.cpp compiled unmodified, -O3 -march=x86-64-v3, against the OpenCV
+            # stand-in whose image primitives are this repository's restatements): the same two threads
+            fref = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "_ref", "libfrontend_ref_o3.so")
+            if os.path.exists(fref):
+                import ctypes as _ct
+                from tests.oracle_lib import OracleLines
+                from tests.test_oracle_pinned_frontend import _RefNames, _RefOrb
+                names = _RefNames(_ct.CDLL(fref))
+                r_orb, r_lines = _RefOrb(names, 2000), OracleLines(names)
+                for i in range(10):
+                    r_orb.extract(host_frames[i % 3])
+                    r_lines.extract(host_frames[i % 3])
+                t0 = time.perf_counter()
+                for i in range(ncpu):
+                    img = host_frames[i % 3]
+                    th_ = [threading.Thread(target=r_orb.extract, args=(img,)), threading.Thread(target=r_lines.extract, args=(img,))]
+                    for t_ in th_:
+                        t_.start()
+                    for t_ in th_:
+                        t_.join()
+                ref_ms = (time.perf_counter() - t0) / ncpu * 1e3
+                result["frontend"]["cpu_baseline"] = {
+                    "value": round(1e3 / ref_ms, 2), "unit": "frames/s", "ms_per_frame": round(ref_ms, 2), "cores": 2,
+                    "kind": "reference", "port_ms_per_frame": round(cpu_ms, 2),
+                    "sample": f"PLVS2::ORBextractor::operator() || PLVS2::LineExtractor::operator() of the reference's own sources "
+                              f"(oracle/_ref/libfrontend_ref_o3.so, g++ -O3 -march=x86-64-v3; OpenCV's image primitives are the "
+                              f"repository's restatements) on two threads as src/Frame.cc:503-508 runs them, {ncpu} frames after 10 "
+                              f"warm-up frames (extraction only), host has {os.cpu_count()} cores"}
         except Exception as e:      # the timing harness must not take the benchmark line down
             result["frontend"]["search_functions"] = {"error": repr(e)}
         # configs[4] (KITTI stereo): dense disparity by semi-global matching on a 1240x376 pair resident in HBM

@@ -684,14 +684,12 @@ struct VoxbloxMesh {   // voxblox::Mesh after updateMeshForBlock (three consecut
 class PointCloudMapVoxblox {
  public:
   using BlockID = std::tuple<int, int, int>;
-  // integrationMethod: PointCloudMapping.voxbloxIntegrationMethod (src/PointCloudMapVoxblox.cc:44, :74) — "simple" and
-  // "merged" are on the accelerated path (one-thread schedules of the reference, bit for bit).  "fast" (the YAML default)
-  // is voxblox's lossy speed-up of "simple" — points whose start voxel was seen are dropped, rays stop after two voxels
-  // some ray of the scan already updated — sequential through two approximate hash sets and racy across its threads:
-  // there is no single result to reproduce.  It is SUBSTITUTED by "simple", the integrator it approximates (every ray
-  // cast in full: the map observes a superset of fast's voxels; INTEGRATION.md §4 has the measured difference).
+  // integrationMethod: PointCloudMapping.voxbloxIntegrationMethod (src/PointCloudMapVoxblox.cc:44, :74) — "simple",
+  // "merged" and "fast" (the YAML default) are all on the accelerated path, each the one-thread schedule of the
+  // reference's integrator bit for bit ("fast": with its two approximate hash sets word for word, kept from scan to scan;
+  // plvs_hip.h has the details — on the device it is the slowest of the three: INTEGRATION.md §4).
   explicit PointCloudMapVoxblox(float voxelSize, bool useCarving = false, const std::string& integrationMethod = "simple")
-      : merged_(integrationMethod == "merged"), fast_substituted_(integrationMethod == "fast") {
+      : merged_(integrationMethod == "merged"), fast_(integrationMethod == "fast") {
     if (integrationMethod != "simple" && integrationMethod != "merged" && integrationMethod != "fast")
       throw std::runtime_error("plvs_hip: unknown voxblox integration method '" + integrationMethod + "'");
     plvs_tsdf_voxblox_params p;
@@ -714,6 +712,7 @@ class PointCloudMapVoxblox {
       rgba_[4 * i] = p.r; rgba_[4 * i + 1] = p.g; rgba_[4 * i + 2] = p.b; rgba_[4 * i + 3] = p.a;
     }
     if (merged_) check(plvs_hip_tsdf_voxblox_integrate_merged(h_, xyz_.data(), rgba_.data(), (int)n, Twc.m));
+    else if (fast_) check(plvs_hip_tsdf_voxblox_integrate_fast(h_, xyz_.data(), rgba_.data(), (int)n, Twc.m));
     else check(plvs_hip_tsdf_voxblox_integrate(h_, xyz_.data(), rgba_.data(), (int)n, Twc.m));
     MarkUpdated();
   }
@@ -840,7 +839,7 @@ class PointCloudMapVoxblox {
   }
   plvs_tsdf_voxblox* h_ = nullptr;
   bool merged_ = false;
-  bool fast_substituted_ = false;   // "fast" was asked for: "simple" runs (see the constructor)
+  bool fast_ = false;
   std::vector<float> xyz_;
   std::vector<uint8_t> rgba_;
   std::set<BlockID> updated_;

@@ -191,6 +191,16 @@ int main(int argc, char** argv) {
   const int vpts = vmap.UpdateMap();
   dump("vmap_cloud", vmap.GetPointCloud().data(), vmap.GetPointCloud().size() * sizeof(PointSurfelSegment));
   std::printf("voxblox %d %d %d\n", vmap.NumBlocks(), vpts, (int)vmap.GetMeshLayer().size());
+  {   // PLVS's YAML default method
+    PointCloudMapVoxblox vfast(0.05f, false, "fast");
+    SE3f Tf = Twc;
+    vfast.InsertCloud(cloud, Tf);
+    Tf.m[3] += 0.03f;
+    vfast.InsertCloud(cloud, Tf);
+    const int fpts = vfast.UpdateMap();
+    dump("vfast_cloud", vfast.GetPointCloud().data(), vfast.GetPointCloud().size() * sizeof(PointSurfelSegment));
+    std::printf("voxblox_fast %d %d\n", vfast.NumBlocks(), fpts);
+  }
   {   // saveMap / loadMap of the layer: into an empty map, meshed there
     PointCloudMapVoxblox vcopy(0.05f);
     vcopy.LoadLayer(vmap.SaveLayer());

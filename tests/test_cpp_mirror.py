@@ -128,6 +128,17 @@ def test_cpp_mirror_matches_python_mirror(tmp_path):
     assert int(lines_out["voxblox"][0]) == v.tsdf.num_chunks()
     assert int(lines_out["voxblox"][1]) == len(vcloud) > 1000 and int(lines_out["voxblox"][2]) == len(v.mesh_layer)
     assert load("vmap_cloud", np.uint8).tobytes() == vcloud.tobytes()
+    class Fast(PointCloudMapVoxblox):
+        skIntegrationMethod = "fast"
+    vf = Fast(0.05)
+    vf.InsertCloud(vc, Twc3)
+    Twc4 = Twc3.copy()
+    Twc4[0, 3] += np.float32(0.03)
+    vf.InsertCloud(vc, Twc4)
+    fcloud = vf.UpdateMap()
+    assert int(lines_out["voxblox_fast"][0]) == vf.tsdf.num_chunks() and int(lines_out["voxblox_fast"][1]) == len(fcloud) > 500
+    assert load("vfast_cloud", np.uint8).tobytes() == fcloud.tobytes()
+    assert len(fcloud) != len(vcloud)
     # the layer saved and loaded into an empty map meshes to the same cloud
     assert lines_out["voxblox_layer"] == [lines_out["voxblox"][0], lines_out["voxblox"][1], "1"]
     # OnMapChange with cloud deformation, C++ mirror against the python mirror (both over the C ABI)

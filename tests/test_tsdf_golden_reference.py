@@ -129,10 +129,16 @@ def vgolden():
 class VoxbloxOracleAdapter:
     def __init__(self, case):
         self.m = oracle_lib.load().voxblox(case["vs"], carving=case["carving"])
-        self.merged = case["method"] == "merged"
+        self.method = case["method"]
 
     def integrate(self, xyz, rgba, Twc):
-        (self.m.integrate_merged if self.merged else self.m.integrate)(xyz, rgba, Twc)
+        if self.method == "fast":
+            self._fast(xyz, rgba, Twc)
+        else:
+            (self.m.integrate_merged if self.method == "merged" else self.m.integrate)(xyz, rgba, Twc)
+
+    def _fast(self, xyz, rgba, Twc):   # the reference's approximate sets (the oracle also has collision-free ones)
+        self.m.integrate_fast(xyz, rgba, Twc, approx_sets=True)
 
     def world(self, xyz, rgba, nrm, Twc):
         self.m.integrate_world_normals(xyz, rgba, nrm, Twc)
@@ -152,8 +158,11 @@ class VoxbloxDeviceAdapter(VoxbloxOracleAdapter):
     def __init__(self, case):
         from plvs_amd.tsdf import TsdfVoxblox
         self.m = TsdfVoxblox(case["vs"], use_carving=case["carving"], max_blocks=8192)
-        self.merged = case["method"] == "merged"
+        self.method = case["method"]
         self._mesh = None
+
+    def _fast(self, xyz, rgba, Twc):
+        self.m.integrate_fast(xyz, rgba, Twc)
 
     def mesh_block(self, bx, by, bz):
         if self._mesh is None:

@@ -12,7 +12,9 @@ from tests.test_tsdf_loadmap import surface_cloud
 CASES = [dict(name="simple 5 cm + world cloud", method="simple", vs=0.05, carving=False, far=False, world=True),
          dict(name="merged 5 cm", method="merged", vs=0.05, carving=False, far=False, world=False),
          dict(name="simple 10 cm, carving, depths to 8 m", method="simple", vs=0.10, carving=True, far=True, world=False),
-         dict(name="merged 10 cm, carving, depths to 8 m", method="merged", vs=0.10, carving=True, far=True, world=False)]
+         dict(name="merged 10 cm, carving, depths to 8 m", method="merged", vs=0.10, carving=True, far=True, world=False),
+         dict(name="fast 5 cm", method="fast", vs=0.05, carving=False, far=False, world=False),
+         dict(name="fast 10 cm, carving, depths to 8 m", method="fast", vs=0.10, carving=True, far=True, world=False)]
 
 
 def case_inputs(case):
