@@ -897,6 +897,7 @@ struct plvs_tsdf_chisel {
   DevBuf<uint32_t> pa_last, pa_cnt, pa_done;
   uint32_t multi_cap = 0;
   uint32_t part_segs = kPartSegs, part_min = kPartMin;   // (plvs_hip_tsdf_chisel_set_apply_parts)
+  bool walk_small = false, walk_small_used = false;      // first-pass table of the order-free walk: 1024 entries instead of 2048
   DevBuf<uint32_t> w_runkey, w_run_cnt, w_run_off, w_val0, w_val1;   // runs: per-tile regions of 2^run_r1_log2 slots
   int32_t* h_offsets = nullptr;      // pinned copy of the call's cloud offsets
   size_t h_offsets_cap = 0;
@@ -977,7 +978,7 @@ constexpr unsigned kDeferGrid = 1024;   // workgroups of the general walk over t
 // scene with points up to 5 m away — and for every tile of a call of at most kSmallCallTiles tiles (a few key frames: one
 // tile per CU is all there is to run, and a deferral costs such a call a second walk's latency).  A tile owns
 // kRecStride records (the larger table's limit) in the record buffer.
-constexpr int kFastEntries = 2048, kFastEntriesBig = 4096;
+constexpr int kFastEntriesSmall = 1024, kFastEntries = 2048, kFastEntriesBig = 4096;
 constexpr uint32_t kRecStride = kFastEntriesBig * 7 / 8;
 constexpr uint32_t kSmallCallTiles = 320;
 constexpr unsigned kListGrid = 512;      // workgroups of the large-table pass over the first list (it loops)
@@ -1121,6 +1122,18 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
                          (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u}, kRecStride, (const uint32_t*)nullptr,
                          (const uint32_t*)nullptr, list_a, &h->d_wctr->ndeferred);
     } else {
+      // The table of the first pass follows the scene: tiles of near surfaces (a small room, a desk) hold 300-600 voxels
+      // and a 1024-entry table lets THREE of them share a CU (6 waves per SIMD: 0.49 against 0.65 ms for the 100 key
+      // frames of the saturated room); tiles of walls 3-5 m away hold 800-2000 and would nearly all overflow it.  The
+      // counters of the call before decide (walk_small): the 2048-entry kernel counts the tiles a 1024-entry table would
+      // not have held, the 1024-entry kernel's deferred list says when it stops paying.
+      h->walk_small_used = h->walk_small;
+      if (h->walk_small)
+        hipLaunchKernelGGL(walk_fast<kFastEntriesSmall>, dim3(ntiles), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
+                           h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
+                           (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u}, kRecStride, (const uint32_t*)nullptr,
+                           (const uint32_t*)nullptr, list_a, &h->d_wctr->ndeferred);
+      else
       hipLaunchKernelGGL(walk_fast<kFastEntries>, dim3(ntiles), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
                          h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
                          (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u}, kRecStride, (const uint32_t*)nullptr,
@@ -1210,6 +1223,13 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
   }
   const WalkCounters& c = *h->h_wctr;
   h->num_chunks = h->h_ctr->num_chunks;
+  if (ntiles > kSmallCallTiles) {   // the first pass's table for the next call of this size class
+    if (h->walk_small_used) {
+      if ((size_t)c.ndeferred * 16 > ntiles) h->walk_small = false;   // more than 6 % of the tiles overflowed the small table
+    } else if ((size_t)c.over_small * 50 <= ntiles) {
+      h->walk_small = true;                                             // at most 2 % would
+    }
+  }
   {   // developer trace of the call's counters (PLVS_HIP_TSDF_TRACE=1)
     static const bool trace = plvs::env_int("PLVS_HIP_TSDF_TRACE", 0, 0, 1) != 0;
     if (trace)

@@ -109,6 +109,7 @@ struct WalkCounters {           // device-side, read back once per call
   uint32_t num_multi;           //   chunks applied in more than one part
   uint32_t ndeferred;           // tiles walk_fast left to the next kernel (several clouds in the tile, table overflow)
   uint32_t ndeferred2;          //   and what the larger-table pass over that list left to walk_tiles
+  uint32_t over_small;          // tiles of a 2048-entry first pass that a 1024-entry table would not have held
 };
 
 // ------------------------------------------------------------------ the walk of one (sub-)tile
@@ -1260,6 +1261,7 @@ __device__ __forceinline__ void walk_fast_tile(
   const bool any_multi = __syncthreads_or(multi ? 1 : 0) != 0;                              // ---- barrier 3
   WALK_PROF(5);     // (wait)
   const bool too_many = !defer && S.nent > (uint32_t)kLimit;   // (the voxels do not fit: the next kernel's table is larger / walk_tiles cuts the tile at once)
+  if (E == 2048 && tid == 0 && !defer && S.nent > 1024u * 7u / 8u) atomicAdd(&ctr->over_small, 1u);   // (the host's choice of the next call's table)
   if (!defer) defer = S.overflow != 0 || too_many;
   if (defer) {
     if (tid == 0) {
