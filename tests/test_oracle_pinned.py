@@ -415,14 +415,21 @@ def test_voxblox_fast_integrator_equals_the_reference_source(vs, carving, far, s
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (name, bid)
     # fast really is another integrator: fewer updates than simple ...
     assert ora.last_visits() < 0.8 * simple.last_visits()
-    # ... and the collision-free sets change only a small part of it
+    # ... and what the sets' collisions cost: with collision-free sets (same algorithm) the map observes nearly the same
+    # voxels, at distances millimetres away (the device reproduces the approximate sets, not these)
     ex = {tuple(int(v) for v in b): exact.get_chunk(*b) for b in exact.chunk_ids()}
-    nvox = ndiff = 0
+    both = only = 0
+    dd = []
     for bid, (d, w, c) in got.items():
         e = ex.get(bid)
-        nvox += int((w > 0).sum())
-        ndiff += int((w > 0).sum()) if e is None else int(((w != e[1]) | (d != e[0]))[(w > 0) | (e[1] > 0)].sum())
-    assert ndiff < 0.05 * nvox, (ndiff, nvox)
+        we = e[1] if e is not None else np.zeros(4096, np.float32)
+        m = (w > 0) & (we > 0)
+        both += int(m.sum())
+        only += int(((w > 0) ^ (we > 0)).sum())
+        if e is not None:
+            dd.append(np.abs(d[m] - e[0][m]))
+    dd = np.concatenate(dd)
+    assert only < 0.05 * both and np.percentile(dd, 90) < 0.004 and ((dd > 0).any() or only > 0), (both, only, np.percentile(dd, 90))
     ref.ref_voxblox_destroy(h)
 
 
