@@ -69,6 +69,12 @@ constexpr uint32_t kErrScratch = 8u;            // record / segment / run buffer
 
 // Phase clocks of walk_tiles (a developer build: make PROF=1 -> libplvs_hip_prof.so; thread 0 of a tile adds the shader
 // cycles between the tile's barriers to g_walk_prof[phase]).  Compiled out of the product library.
+#ifndef PLVS_WALK_SORT
+#define PLVS_WALK_SORT 0    // walk_fast: 1 = the rays of a tile dealt to the waves by depth — parity holds, measured SLOWER
+                            // (walk 0.857 -> 0.880 ms on the stream, 0.512 -> 0.550 in the room: three barriers, scattered point
+                            // loads and neighbouring lanes no longer sharing table buckets cost more than the 14-19 % of loop
+                            // iterations the homogeneous waves save); kept as a switch
+#endif
 #ifndef PLVS_WALK_EXP
 #define PLVS_WALK_EXP 0     // timing experiments (developer builds; results are wrong with any bit set)
 #endif
@@ -405,7 +411,7 @@ __device__ __forceinline__ int lean_reach(const Ray& ray) {   // how far (in vox
 template <bool kAcc, bool kRuns, class SH>
 __device__ __forceinline__ uint32_t walk_lean(const Params& P, const Pose& pose, const Ray& ray, SH& S, int ox, int oy,
                                               int oz, int tid, float wu_scaled, uint32_t q_w, int32_t* e_wuu,
-                                              unsigned long long* e_wc, uint32_t* e_last, uint16_t* vlog) {
+                                              unsigned long long* e_wc, uint32_t* e_last, uint16_t* vlog, uint32_t rid) {
   RayCursor cur;
   ray_begin(ray, &cur);
   if (cur.done) return 0u;   // start voxel == end voxel: Raycast.cpp emits nothing
@@ -450,7 +456,7 @@ __device__ __forceinline__ uint32_t walk_lean(const Params& P, const Pose& pose,
       if (kAcc) {
         atomicAdd(&e_wuu[e], __float2int_rn(wu_scaled * u));
         atomicAdd(&e_wc[e], (1ull << 32) | (unsigned long long)q_w);
-        atomicMax(&e_last[e], (uint32_t)tid);
+        atomicMax(&e_last[e], rid);   // (the ray's index in the tile: = tid unless the tile's rays were re-dealt)
       }
       ++nv;
     }
@@ -758,7 +764,7 @@ __global__ __launch_bounds__(kWalkRays, kWalkEntries > 2048 ? 2 : (kWalkEntries 
         ray_begin(ray, &cur);   // (walk_lean's own ray_begin is this one: common subexpression)
         if (won_s && dir_peek_slot(peek_s) >= 0) S.cslot[ci_s] = dir_peek_slot(peek_s);
         if (won_e && dir_peek_slot(peek_e) >= 0) S.cslot[ci_e] = dir_peek_slot(peek_e);
-        nv = walk_lean<kAcc, kRuns>(P, pose, ray, S, ox, oy, oz, tid, wu_scaled, q_w, e_wuu, e_wc, e_last, vlog);
+        nv = walk_lean<kAcc, kRuns>(P, pose, ray, S, ox, oy, oz, tid, wu_scaled, q_w, e_wuu, e_wc, e_last, vlog, (uint32_t)tid);
       }
     } else if (walks && !(PLVS_WALK_EXP & 32)) {   // (bit 32, timing experiment: set-up and flush only)
       WALK_PROF(0);
@@ -1137,6 +1143,7 @@ __device__ __forceinline__ void walk_fast_tile(
   bool defer = P.shard_count > 1 || listed_other;   // (uniform)
   WALK_PROF_BEGIN();
   uint32_t nv = 0;
+  uint32_t rid = (uint32_t)threadIdx.x;   // the ray of the tile this thread walks
   bool walks = false;
   int ox = 0, oy = 0, oz = 0;
   if (!defer) {
@@ -1147,9 +1154,35 @@ __device__ __forceinline__ void walk_fast_tile(
       S.run_total = 0;
       S.vis_total = 0;
     }
+#if PLVS_WALK_SORT
+    {
+      // Rays of like length into the same wave: a wave runs its voxel loop as long as its longest ray, and the rays of a
+      // tile (a strip of the image) differ by the depths they end at — the truncation band grows with the square of it.
+      // Counting sort of the tile's rays by depth bucket (12.5 cm), in the visit log's memory (free until the walk); a
+      // thread then walks ray `rid`, and everything that names a ray — the last visitor of an entry, the bits of the
+      // ray masks, the point it reads — names it by rid, so the tile's outputs do not depend on the assignment.
+      uint32_t* const bins = reinterpret_cast<uint32_t*>(vlog) + 256;   // 64 words behind the 512 u16 of the permutation
+      if (tid < 64) bins[tid] = 0u;
+      __syncthreads();
+      int b = 63;
+      uint32_t r = 0;
+      if ((uint32_t)tid < nrays) {
+        const float z = xyz[3 * (size_t)(first + (uint32_t)tid) + 2];
+        b = z < 0.01f ? 63 : min(62, (int)(z * 8.0f));
+        r = atomicAdd(&bins[b], 1u);
+      }
+      __syncthreads();
+      const uint32_t c = bins[lane];
+      const uint32_t excl = wave_scan_incl(c) - c;   // (every wave scans the 64 bins for itself)
+      const uint32_t start = (uint32_t)__shfl((int)excl, b);
+      if ((uint32_t)tid < nrays) vlog[start + r] = (uint16_t)tid;   // (the permutation lies in front of the bins)
+      __syncthreads();
+      if ((uint32_t)tid < nrays) rid = (uint32_t)vlog[tid];          // (a thread's first log entry is this very slot)
+    }
+#endif
     const Pose& pose = poses[cloud];   // (uniform address: scalar loads where it is used)
     Ray ray;
-    walks = (uint32_t)tid < nrays && tile_ray(P, xyz, pose, first + (uint32_t)tid, &ray, &ctr->err);
+    walks = (uint32_t)tid < nrays && tile_ray(P, xyz, pose, first + rid, &ray, &ctr->err);
     const float wu = walks ? P.weight / (2.0f * ray.truncation) : 0.0f;
     {   // origin of the voxel keys: below the start voxel of the first walking ray, on a chunk boundary
       const unsigned long long wm = __ballot(walks);
@@ -1177,7 +1210,7 @@ __device__ __forceinline__ void walk_fast_tile(
     if (fits) {
 #if !(PLVS_WALK_EXP & 32)   // (bit 32, timing experiment: no voxel loop)
       nv = walk_lean<true, true>(P, pose, ray, S, ox, oy, oz, tid, wu * scale_u, (uint32_t)__float2int_rn(wu * scale_w), e_wuu,
-                                 e_wc, e_last, vlog);
+                                 e_wc, e_last, vlog, rid);
 #endif
     }
   }
@@ -1388,18 +1421,18 @@ __device__ __forceinline__ void walk_fast_tile(
         const uint32_t logged = min(nv, (uint32_t)kLogLen);
         for (uint32_t k = 0; k < logged; ++k) {
           const uint32_t m = (uint32_t)e_midx[vlog[k * kWalkRays + tid]] - r0;   // 0xFFFF - r0 stays out of range
-          if (m < (uint32_t)kMaskCapE) atomicOr(&raw[m * kMaskWords + (tid >> 5)], 1u << (tid & 31));
+          if (m < (uint32_t)kMaskCapE) atomicOr(&raw[m * kMaskWords + (rid >> 5)], 1u << (rid & 31));
         }
         if (nv > (uint32_t)kLogLen) {   // the log is full: the rest of the ray is walked again
           const Pose& pose = poses[cloud];
           Ray ray;
-          if (tile_ray(P, xyz, pose, first + (uint32_t)tid, &ray, &ctr->err))
+          if (tile_ray(P, xyz, pose, first + rid, &ray, &ctr->err))
             walk_one(P, pose, ray, 0u, 0xFFFFFFFFu, [&](uint32_t k, int vx, int vy, int vz, float) {
               if (k >= (uint32_t)kLogLen) {
                 uint32_t key;
                 const int e = rel_key(vx, vy, vz, ox, oy, oz, &key) ? table_find(S, table_key(key)) : -1;
                 const uint32_t m = e >= 0 ? (uint32_t)e_midx[e] - r0 : 0xFFFFFFFFu;
-                if (m < (uint32_t)kMaskCapE) atomicOr(&raw[m * kMaskWords + (tid >> 5)], 1u << (tid & 31));
+                if (m < (uint32_t)kMaskCapE) atomicOr(&raw[m * kMaskWords + (rid >> 5)], 1u << (rid & 31));
               }
               return true;
             });
