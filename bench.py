@@ -305,6 +305,7 @@ def main():
                        "resolution": args.resolution, "max_depth": args.max_depth,
                        "keyframes_per_step": step_kfs, "points_per_step": int(points // args.steps),
                        "ms_per_step_median_max": [round(float(np.median(step_wall)) * 1e3, 3), round(max(step_wall) * 1e3, 3)],
+                       **({"ms_per_step_each": [round(x * 1e3, 2) for x in step_wall]} if multi else {}),
                        "visits_per_step": int(visits_total // args.steps),
                        "voxels_per_step": int(voxels // args.steps), "longest_voxel_run": int(max_run),
                        "parallelism": (f"ray-sharded x{world}: rank r walks tiles t = r (mod {world}), partial sums and "
@@ -1203,7 +1204,12 @@ def main():
         }
 
     if rank == 0:
-        print(json.dumps(result))
+        try:      # (whatever the runtime's C libraries — RCCL's banner — still hold in stdio comes out BEFORE the line)
+            import ctypes as _c
+            _c.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(result), flush=True)
     tsdf.close()
     if multi:
         dist.destroy_process_group()
