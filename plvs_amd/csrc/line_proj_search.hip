@@ -22,6 +22,54 @@ constexpr int kThHigh = 110;    // LineMatcher::TH_HIGH
 constexpr int kHisto = 12;      // HISTO_LENGTH
 constexpr float kEps = 1.1920929e-07f;   // std::numeric_limits<float>::epsilon()
 
+// All query x train distances of two small descriptor sets (a few hundred lines each), started BEFORE the host evaluates
+// its windows and gates and collected after: the launch-and-wait round trip of the device (~40 us, more than the 75 000
+// popcounts take) runs beside the ~20 us of host work instead of behind it.  The u16 matrix is written straight into the
+// pinned block.
+__global__ __launch_bounds__(256) void hamming_matrix_kernel(const uint4* __restrict__ query, int nq, const uint4* __restrict__ train,
+                                                             int nt, uint16_t* __restrict__ out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nq * nt) return;
+  const int q = p / nt, t = p - q * nt;
+  const uint4 a0 = query[2 * q], a1 = query[2 * q + 1], b0 = train[2 * t], b1 = train[2 * t + 1];
+  out[p] = (uint16_t)(__popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+                      __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w));
+}
+constexpr int kMatrixMaxPairs = 1 << 18;   // (512 x 512 lines; beyond that the candidate pairs go through plvs_hip_hamming_pairs)
+struct MatrixJob {
+  const uint16_t* dist = nullptr;   // nq x nt, valid after matrix_wait
+  int nt = 0;
+  bool started = false;
+};
+int matrix_begin(MatrixJob& J, const uint8_t* query, int nq, const uint8_t* train, int nt) {
+  J.started = false;
+  if (nq <= 0 || nt <= 0 || (long long)nq * nt > kMatrixMaxPairs) return PLVS_OK;
+  auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t o_q = 0, o_t = o_q + up16((size_t)nq * 32), o_d = o_t + up16((size_t)nt * 32), total = o_d + up16(sizeof(uint16_t) * (size_t)nq * nt);
+  plvs::HostStage& st = plvs::thread_stage();
+  PLVS_HIP_TRY(st.reserve(total));
+  memcpy(st.pinned + o_q, query, (size_t)nq * 32);
+  memcpy(st.pinned + o_t, train, (size_t)nt * 32);
+  // (the descriptors are copied: every one is read by hundreds of threads, and a read of pinned host memory is not cached)
+  PLVS_HIP_TRY(hipMemcpyAsync(st.dev, st.pinned, o_d, hipMemcpyHostToDevice, st.stream));
+  hipLaunchKernelGGL(hamming_matrix_kernel, dim3(plvs::ceil_div((size_t)nq * nt, 256)), dim3(256), 0, st.stream,
+                     reinterpret_cast<const uint4*>(st.dev + o_q), nq, reinterpret_cast<const uint4*>(st.dev + o_t), nt,
+                     reinterpret_cast<uint16_t*>(st.pinned + o_d));
+  PLVS_KERNEL_CHECK();
+  J.dist = reinterpret_cast<const uint16_t*>(st.pinned + o_d);
+  J.nt = nt;
+  J.started = true;
+  return PLVS_OK;
+}
+int matrix_wait(MatrixJob& J) {
+  if (J.started) PLVS_HIP_TRY(hipStreamSynchronize(plvs::thread_stage().stream));
+  return PLVS_OK;
+}
+struct MatrixGuard {   // no call leaves with its kernel still writing into the thread's staging block (error returns)
+  MatrixJob& j;
+  ~MatrixGuard() { if (j.started) (void)hipStreamSynchronize(plvs::thread_stage().stream); }
+};
+
 struct Rep { float theta, d, nx, ny; };
 
 // Geom2DUtils::GetLine2dRepresentation (include/Geom2DUtils.h:135-159): unit normal with nx >= 0
@@ -85,15 +133,16 @@ struct LineGrid {   // Frame::mLineGrid as one CSR table, cells in (column, row)
     if (c0 >= kCols) return;
     const int c1 = std::min(kCols - 1, (int)std::floor((dmax + F->max_diag) * d_inv));
     if (c1 < 0) return;
-    for (int ix = c0; ix <= c1; ++ix)
-      for (int iy = r0; iy <= r1; ++iy) {
-        const size_t c = (size_t)ix * kRows + (size_t)iy;
-        for (int k = first[c]; k < first[c + 1]; ++k) {
-          const int j = items[(size_t)k];
-          if (check && (F->keylines_un[j].octave < lo || F->keylines_un[j].octave > hi)) continue;
-          out.push_back(j);
-        }
+    // (the cells of a column are consecutive in the table: rows r0 .. r1 of column ix are ONE range of items, in the
+    // reference's order — a fifth of the loop trips of a cell-by-cell walk)
+    for (int ix = c0; ix <= c1; ++ix) {
+      const size_t ca = (size_t)ix * kRows + (size_t)r0, cb = (size_t)ix * kRows + (size_t)r1 + 1;
+      for (int k = first[ca]; k < first[cb]; ++k) {
+        const int j = items[(size_t)k];
+        if (check && (F->keylines_un[j].octave < lo || F->keylines_un[j].octave > hi)) continue;
+        out.push_back(j);
       }
+    }
   }
 
   // false: the interval is wider than pi (the reference prints an error and leaves the process)
@@ -111,14 +160,29 @@ struct LineGrid {   // Frame::mLineGrid as one CSR table, cells in (column, row)
 // chi-square bound of the projected line, and the same on the right image when the line has a stereo match
 // shift_s / shift_e: the disparity of the projected end points — mbf * invSz (frame to frame, :1011-1013: the
 // projection's own inverse depths) or mbf / mTrackStartDepth (map lines, :1419-1423: a division by the stored depth)
+// (the right-image representation of the projected line depends on the projection alone: the reference forms it for every
+// candidate, here it is formed once per projected line, and without the angle it never uses)
+struct RightRep {
+  bool have = false;
+  float nx = 0, ny = 0, d = 0;
+};
 bool passes_gates(const plvs_line_frame_view* F, int i2, const Rep& pr, float inv_sigma2, float th, const float* p,
-                  float shift_s, float shift_e) {
+                  float shift_s, float shift_e, RightRep& rr) {
   const plvs_keyline& k = F->keylines_un[i2];
   const float ds = pr.nx * k.startPointX + pr.ny * k.startPointY - pr.d;
   const float de = pr.nx * k.endPointX + pr.ny * k.endPointY - pr.d;
   if (ds * ds * inv_sigma2 > th || de * de * inv_sigma2 > th) return false;
   if (F->u_right_start != nullptr && F->u_right_start[i2] >= 0 && F->u_right_end[i2] >= 0) {
-    const Rep rr = representation(p[0] - shift_s, p[1], p[2] - shift_e, p[3]);
+    if (!rr.have) {   // Geom2DUtils::GetLine2dRepresentation of the shifted end points (representation() above, less theta)
+      const float xs = p[0] - shift_s, ys = p[1], xe = p[2] - shift_e, ye = p[3];
+      float nx = ye - ys, ny = xs - xe;
+      if (nx < 0) { nx *= -1.0f; ny *= -1.0f; }
+      const float inv = 1.0f / std::sqrt(nx * nx + ny * ny);
+      nx *= inv;
+      ny *= inv;
+      rr.nx = nx; rr.ny = ny; rr.d = nx * xe + ny * ye;
+      rr.have = true;
+    }
     const float dsr = rr.nx * F->u_right_start[i2] + rr.ny * k.startPointY - rr.d;
     const float der = rr.nx * F->u_right_end[i2] + rr.ny * k.endPointY - rr.d;
     if (dsr * dsr * inv_sigma2 > th || der * der * inv_sigma2 > th) return false;
@@ -131,8 +195,14 @@ struct Candidates {   // per projected line: its gated candidates, and one dista
   std::vector<int32_t> q, t, dist;
 };
 
-int candidate_distances(const plvs_line_frame_view* F, const uint8_t* qdesc, int nq, Candidates& C) {
+int candidate_distances(const plvs_line_frame_view* F, const uint8_t* qdesc, int nq, Candidates& C, MatrixJob& J) {
   C.dist.assign(C.q.size(), 0);
+  if (J.started) {   // (the matrix has been on its way since the call began)
+    const int rc = matrix_wait(J);
+    if (rc != PLVS_OK) return rc;
+    for (size_t c = 0; c < C.q.size(); ++c) C.dist[c] = (int)J.dist[(size_t)C.q[c] * (size_t)J.nt + (size_t)C.t[c]];
+    return PLVS_OK;
+  }
   if (C.q.empty()) return PLVS_OK;
   return plvs_hip_hamming_pairs(qdesc, nq, F->descriptors, F->n, C.q.data(), C.t.data(), (int)C.q.size(), C.dist.data());
 }
@@ -158,6 +228,12 @@ int plvs_hip_lines_search_by_projection_ff(const plvs_line_frame_view* F, const 
   for (int i = 0; i < F->n; ++i) assigned[i] = -1;
   if (F->n == 0 || n_last == 0) return PLVS_OK;
   const float th = larger_search ? 5.024f : 3.84f;   // kChiSquareLinePointProj(Larger), :98-99
+  MatrixJob job;
+  MatrixGuard guard{job};
+  {
+    const int rcj = matrix_begin(job, desc, n_last, F->descriptors, F->n);
+    if (rcj != PLVS_OK) return rcj;
+  }
   const LineGrid grid(F);
   // ---- pass 1: windows and gates for every projected line
   Candidates C;
@@ -180,15 +256,16 @@ int plvs_hip_lines_search_by_projection_ff(const plvs_line_frame_view* F, const 
       plvs::set_error("GetLineFeaturesInArea: search over the full theta interval (the reference terminates here)");
       return PLVS_ERR_INVALID_ARG;
     }
+    RightRep rr;
     for (int i2 : win)
-      if (passes_gates(F, i2, pr, F->line_inv_level_sigma2[lo], th, p, F->bf * p[4], F->bf * p[5])) {
+      if (passes_gates(F, i2, pr, F->line_inv_level_sigma2[lo], th, p, F->bf * p[4], F->bf * p[5], rr)) {
         C.q.push_back(i);
         C.t.push_back(i2);
       }
   }
   C.first[(size_t)n_last] = (int)C.q.size();
   // ---- all candidate distances in one launch
-  const int rc = candidate_distances(F, desc, n_last, C);
+  const int rc = candidate_distances(F, desc, n_last, C, job);
   if (rc != PLVS_OK) return rc;
   // ---- pass 2: the reference's loop
   std::vector<uint8_t> occ((size_t)F->n, 0);
@@ -254,6 +331,12 @@ int plvs_hip_lines_search_by_projection(const plvs_line_frame_view* F, const uin
   for (int i = 0; i < F->n; ++i) assigned[i] = -1;
   if (F->n == 0 || n_map == 0) return PLVS_OK;
   const float th = larger_search ? 5.024f : 3.84f;
+  MatrixJob job;
+  MatrixGuard guard{job};
+  {
+    const int rcj = matrix_begin(job, desc, n_map, F->descriptors, F->n);
+    if (rcj != PLVS_OK) return rcj;
+  }
   const LineGrid grid(F);
   Candidates C;
   C.first.assign((size_t)n_map + 1, 0);
@@ -270,14 +353,15 @@ int plvs_hip_lines_search_by_projection(const plvs_line_frame_view* F, const uin
       plvs::set_error("GetLineFeaturesInArea: search over the full theta interval (the reference terminates here)");
       return PLVS_ERR_INVALID_ARG;
     }
+    RightRep rr;
     for (int idx : win)
-      if (passes_gates(F, idx, pr, F->line_inv_level_sigma2[lv], th, p, F->bf / p[4], F->bf / p[5])) {
+      if (passes_gates(F, idx, pr, F->line_inv_level_sigma2[lv], th, p, F->bf / p[4], F->bf / p[5], rr)) {
         C.q.push_back(m);
         C.t.push_back(idx);
       }
   }
   C.first[(size_t)n_map] = (int)C.q.size();
-  const int rc = candidate_distances(F, desc, n_map, C);
+  const int rc = candidate_distances(F, desc, n_map, C, job);
   if (rc != PLVS_OK) return rc;
   std::vector<uint8_t> occ((size_t)F->n, 0);
   if (occupied)
