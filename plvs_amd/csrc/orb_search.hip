@@ -252,6 +252,57 @@ void three_maxima(const int* count, int L, int& ind1, int& ind2, int& ind3) {
 
 constexpr size_t kDirectReadBytes = 96 * 1024;   // inputs up to this size are read in place from pinned host memory
 
+// The pair distances of plvs_hip_hamming_pairs in two steps, for a caller that knows the descriptor sets before it knows
+// the pairs (SearchByBoW enumerates them node by node): begin() stages the descriptors and starts their copy, the host
+// enumerates, finish() sends the pair lists behind them, launches and waits.  max_pairs bounds the pairs of finish().
+struct PairsJob {
+  size_t o_pq = 0, o_pt = 0, o_d = 0;
+  int nq = 0, nt = 0, max_pairs = 0;
+};
+int pairs_begin(PairsJob& J, const uint8_t* query, int nq, const uint8_t* train, int nt, int max_pairs) {
+  auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t o_q = 0, o_t = o_q + up16((size_t)nq * 32);
+  J.o_pq = o_t + up16((size_t)nt * 32);
+  J.o_pt = J.o_pq + up16(sizeof(int32_t) * (size_t)max_pairs);
+  J.o_d = J.o_pt + up16(sizeof(int32_t) * (size_t)max_pairs);
+  J.nq = nq; J.nt = nt; J.max_pairs = max_pairs;
+  plvs::HostStage& st = plvs::thread_stage();
+  PLVS_HIP_TRY(st.reserve(J.o_d + up16(sizeof(int32_t) * (size_t)max_pairs)));
+  memcpy(st.pinned + o_q, query, (size_t)nq * 32);
+  memcpy(st.pinned + o_t, train, (size_t)nt * 32);
+  PLVS_HIP_TRY(hipMemcpyAsync(st.dev, st.pinned, J.o_pq, hipMemcpyHostToDevice, st.stream));
+  return PLVS_OK;
+}
+int pairs_finish(PairsJob& J, const int32_t* pair_q, const int32_t* pair_t, int npairs, int32_t* dist) {
+  plvs::HostStage& st = plvs::thread_stage();
+  if (npairs == 0) {
+    PLVS_HIP_TRY(hipStreamSynchronize(st.stream));
+    return PLVS_OK;
+  }
+  PLVS_REQUIRE(npairs <= J.max_pairs, "more pairs than announced");
+  memcpy(st.pinned + J.o_pq, pair_q, sizeof(int32_t) * (size_t)npairs);
+  memcpy(st.pinned + J.o_pt, pair_t, sizeof(int32_t) * (size_t)npairs);
+  // (the two lists lie apart — max_pairs each —: one copy over both when they are nearly full, two otherwise)
+  if ((size_t)npairs * 2 >= (size_t)J.max_pairs) {
+    PLVS_HIP_TRY(hipMemcpyAsync(st.dev + J.o_pq, st.pinned + J.o_pq, (J.o_pt - J.o_pq) + sizeof(int32_t) * (size_t)npairs, hipMemcpyHostToDevice, st.stream));
+  } else {
+    PLVS_HIP_TRY(hipMemcpyAsync(st.dev + J.o_pq, st.pinned + J.o_pq, sizeof(int32_t) * (size_t)npairs, hipMemcpyHostToDevice, st.stream));
+    PLVS_HIP_TRY(hipMemcpyAsync(st.dev + J.o_pt, st.pinned + J.o_pt, sizeof(int32_t) * (size_t)npairs, hipMemcpyHostToDevice, st.stream));
+  }
+  hipLaunchKernelGGL(hamming_pairs_kernel, dim3(plvs::ceil_div(npairs, 256)), dim3(256), 0, st.stream,
+                     reinterpret_cast<const uint4*>(st.dev), reinterpret_cast<const uint4*>(st.dev + ((size_t)J.nq * 32 + 15) / 16 * 16),
+                     reinterpret_cast<const int32_t*>(st.dev + J.o_pq), reinterpret_cast<const int32_t*>(st.dev + J.o_pt), npairs,
+                     reinterpret_cast<int32_t*>(st.pinned + J.o_d));
+  PLVS_KERNEL_CHECK();
+  PLVS_HIP_TRY(hipStreamSynchronize(st.stream));
+  memcpy(dist, st.pinned + J.o_d, sizeof(int32_t) * (size_t)npairs);
+  return PLVS_OK;
+}
+struct PairsGuard {   // (an error return between begin and finish must not leave the copy in flight on the staging block)
+  bool armed = false;
+  ~PairsGuard() { if (armed) (void)hipStreamSynchronize(plvs::thread_stage().stream); }
+};
+
 extern "C" {
 
 int plvs_hip_hamming_pairs(const uint8_t* query, int nq, const uint8_t* train, int nt, const int32_t* pair_q,
@@ -469,6 +520,27 @@ int plvs_hip_orb_search_by_bow(const plvs_featvec_view* KV, const uint8_t* kf_de
   struct Query { int kf; int first, count; };
   std::vector<Query> queries;
   std::vector<int32_t> pair_q, pair_t;
+  // the descriptors are on their way to the device while the pairs are enumerated (a walk over the nodes alone bounds them)
+  PairsJob job;
+  PairsGuard guard;
+  {
+    long long bound = 0;
+    int a0 = 0, b0 = 0;
+    while (a0 < KV->nnodes && b0 < FV->nnodes) {
+      if (KV->node_id[a0] == FV->node_id[b0]) {
+        bound += (long long)(KV->offset[a0 + 1] - KV->offset[a0]) * (FV->offset[b0 + 1] - FV->offset[b0]);
+        ++a0; ++b0;
+      } else if (KV->node_id[a0] < FV->node_id[b0]) ++a0;
+      else ++b0;
+    }
+    PLVS_REQUIRE(bound < (1ll << 30), "too many candidate pairs");
+    if (bound == 0) return PLVS_OK;
+    const int rcb = pairs_begin(job, kf_desc, kf_n, f_desc, f_n, (int)bound);
+    if (rcb != PLVS_OK) return rcb;
+    guard.armed = true;
+    pair_q.reserve((size_t)bound);
+    pair_t.reserve((size_t)bound);
+  }
   int a = 0, b = 0;
   while (a < KV->nnodes && b < FV->nnodes) {   // the lower_bound walk of :327-489
     if (KV->node_id[a] == FV->node_id[b]) {
@@ -491,8 +563,8 @@ int plvs_hip_orb_search_by_bow(const plvs_featvec_view* KV, const uint8_t* kf_de
     }
   }
   std::vector<int32_t> dist(pair_q.size());
-  int rc = plvs_hip_hamming_pairs(kf_desc, kf_n, f_desc, f_n, pair_q.data(), pair_t.data(), (int)pair_q.size(),
-                                  dist.data());
+  int rc = pairs_finish(job, pair_q.data(), pair_t.data(), (int)pair_q.size(), dist.data());
+  guard.armed = false;
   if (rc != PLVS_OK) return rc;
   std::vector<int> hist_item, hist_bin;
   const float factor = kHistoLength / 360.0f;   // USE_NEW_HISTOGRAM_FACTOR, :52, :313
