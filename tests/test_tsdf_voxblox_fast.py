@@ -143,3 +143,31 @@ def test_hip_fast_batches_scans_history_and_other_methods(oracle):
     hip.integrate_fast(kfs[0]["xyz"], rgba_of(kfs[0]), kfs[0]["Twc"])
     maps_equal(ref2, hip)
     hip.close()
+
+
+@pytest.mark.gpu
+def test_hip_fast_on_a_sharded_map_is_the_union_of_its_shards(oracle):
+    """Block-hash shards (the multi-GPU layout): every rank settles the same rays (the sets do not know about owners) and
+    keeps the voxels of its own blocks — the shards' blocks are disjoint and together they are the one-GPU map."""
+    from plvs_amd.tsdf import TsdfVoxblox
+    vs = 0.05
+    kfs = make_keyframes(3, seed=44)
+    whole = TsdfVoxblox(vs, max_blocks=8192)
+    shards = [TsdfVoxblox(vs, max_blocks=8192, shard_rank=r, shard_count=3) for r in range(3)]
+    for k in kfs:
+        whole.integrate_fast(k["xyz"], rgba_of(k), k["Twc"])
+        for sh in shards:
+            sh.integrate_fast(k["xyz"], rgba_of(k), k["Twc"])
+    ids = sorted(tuple(int(v) for v in b) for b in whole.chunk_ids())
+    seen = {}
+    for r, sh in enumerate(shards):
+        for b in sh.chunk_ids():
+            bid = tuple(int(v) for v in b)
+            assert bid not in seen
+            seen[bid] = r
+    assert sorted(seen) == ids and len(set(seen.values())) == 3
+    for bid in ids:
+        for x, y in zip(whole.get_chunk(*bid), shards[seen[bid]].get_chunk(*bid)):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), bid
+    for t in shards + [whole]:
+        t.close()
