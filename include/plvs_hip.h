@@ -958,6 +958,16 @@ int plvs_hip_tsdf_voxblox_integrate(plvs_tsdf_voxblox* h, const float* xyz, cons
 int plvs_hip_tsdf_voxblox_integrate_batch_dev(plvs_tsdf_voxblox* h, const float* d_xyz,
                                               const uint8_t* d_rgba, const int32_t* offsets,
                                               int nclouds, const float* d_Twc, void* stream);
+/* Queued insertion, as plvs_hip_tsdf_chisel_queue / _flush for the chisel map: PointCloudMapVoxblox::InsertCloud
+ * (src/PointCloudMapVoxblox.cc:81) is called once per key frame, the layer is read only by UpdateMap (:160) after at most
+ * kMaxNumKeyFramesToInsertInMapInOneStep of them (src/PointCloudMapping.cc:537-556, 594-598).  _queue uploads the cloud
+ * and returns; _flush integrates everything queued as ONE batch of the simple integrator, every cloud a scan of its own,
+ * in order — the layer of the call-by-call sequence bit for bit, at the per-key-frame cost of a batch.  Every entry point
+ * that reads or changes the map (the integrates, block lists, download / upload, the meshers, the halo calls) flushes
+ * first; plvs_hip_tsdf_voxblox_clear drops the queue.  Host pointers; arguments as plvs_hip_tsdf_voxblox_integrate. */
+int plvs_hip_tsdf_voxblox_queue(plvs_tsdf_voxblox* h, const float* xyz, const uint8_t* rgba, int n, const float* Twc);
+int plvs_hip_tsdf_voxblox_flush(plvs_tsdf_voxblox* h);
+int plvs_hip_tsdf_voxblox_queued(plvs_tsdf_voxblox* h, int* nclouds);
 /* The "fast" integration method (PointCloudMapping.voxbloxIntegrationMethod: "fast" — the default of PLVS's YAML files):
  * FastTsdfIntegrator::integratePointCloud (Thirdparty/voxblox/src/integrator/tsdf_integrator.cc:505-605) in its
  * integrator_threads = 1 schedule, with start_voxel_subsampling_factor 2, max_consecutive_ray_collisions 2 and

@@ -688,8 +688,12 @@ class PointCloudMapVoxblox {
   // "merged" and "fast" (the YAML default) are all on the accelerated path, each the one-thread schedule of the
   // reference's integrator bit for bit ("fast": with its two approximate hash sets word for word, kept from scan to scan;
   // plvs_hip.h has the details — on the device it is the slowest of the three: INTEGRATION.md §4).
-  explicit PointCloudMapVoxblox(float voxelSize, bool useCarving = false, const std::string& integrationMethod = "simple")
-      : merged_(integrationMethod == "merged"), fast_(integrationMethod == "fast") {
+  // queueInsertions ("simple" only): InsertCloud uploads, UpdateMap — the one reader of the layer — integrates what waits as
+  // one batch (plvs_hip_tsdf_voxblox_queue / _flush): the same layer bit for bit, at a quarter of the per-key-frame cost.
+  explicit PointCloudMapVoxblox(float voxelSize, bool useCarving = false, const std::string& integrationMethod = "simple",
+                                bool queueInsertions = true)
+      : merged_(integrationMethod == "merged"), fast_(integrationMethod == "fast"),
+        queue_(queueInsertions && integrationMethod == "simple") {
     if (integrationMethod != "simple" && integrationMethod != "merged" && integrationMethod != "fast")
       throw std::runtime_error("plvs_hip: unknown voxblox integration method '" + integrationMethod + "'");
     plvs_tsdf_voxblox_params p;
@@ -713,16 +717,28 @@ class PointCloudMapVoxblox {
     }
     if (merged_) check(plvs_hip_tsdf_voxblox_integrate_merged(h_, xyz_.data(), rgba_.data(), (int)n, Twc.m));
     else if (fast_) check(plvs_hip_tsdf_voxblox_integrate_fast(h_, xyz_.data(), rgba_.data(), (int)n, Twc.m));
-    else check(plvs_hip_tsdf_voxblox_integrate(h_, xyz_.data(), rgba_.data(), (int)n, Twc.m));
+    else if (queue_) {
+      check(plvs_hip_tsdf_voxblox_queue(h_, xyz_.data(), rgba_.data(), (int)n, Twc.m));
+      pending_ = true;
+      return;
+    } else check(plvs_hip_tsdf_voxblox_integrate(h_, xyz_.data(), rgba_.data(), (int)n, Twc.m));
+    MarkUpdated();
+  }
+  // Integrates what InsertCloud has queued (UpdateMap and every other reader of the layer call it).
+  void Flush() {
+    if (!pending_) return;
+    check(plvs_hip_tsdf_voxblox_flush(h_));
+    pending_ = false;
     MarkUpdated();
   }
   // The reference's LoadMap leaves the blocks of the loaded cloud outside the layer until the next InsertCloud
   // (integrateWorlPointCloud never publishes them: plvs_hip_tsdf_voxblox_set_deferred_world_blocks) — its UpdateMap
   // meshes none of them.  Off by default (the loaded map shows at once); on = what a PLVS build does today.
-  void SetReferenceLoadMapVisibility(bool on) { check(plvs_hip_tsdf_voxblox_set_deferred_world_blocks(h_, on ? 1 : 0)); }
+  void SetReferenceLoadMapVisibility(bool on) { Flush(); check(plvs_hip_tsdf_voxblox_set_deferred_world_blocks(h_, on ? 1 : 0)); }
   // LoadMap of a saved cloud once PointCloudMap::LoadMap has read it (src/PointCloudMapVoxblox.cc:233-258):
   // TsdfServer::insertWorldPointCloud(cloud, identity) — every point along its normal — then UpdateMap.
   int LoadMap(const std::vector<PointSurfelSegment>& cloud) {
+    Flush();
     const size_t n = cloud.size();
     xyz_.resize(3 * n);
     rgba_.resize(4 * n);
@@ -742,6 +758,7 @@ class PointCloudMapVoxblox {
   // + getMeshAsPointcloud (voxblox_ros/mesh_vis.h:272-318, ColorMode::kColor)  (src/PointCloudMapVoxblox.cc:160-179).
   // Returns the cloud size.
   int UpdateMap() {
+    Flush();
     const int nb = (int)updated_.size();
     if (nb > 0) {
       std::vector<int32_t> ids;
@@ -782,12 +799,13 @@ class PointCloudMapVoxblox {
     return (int)pointCloud_.size();
   }
   void Clear() {
-    check(plvs_hip_tsdf_voxblox_clear(h_));
+    check(plvs_hip_tsdf_voxblox_clear(h_));   // (drops what was queued)
+    pending_ = false;
     updated_.clear();
     meshLayer_.clear();
     pointCloud_.clear();
   }
-  int NumBlocks() { int n = 0; check(plvs_hip_tsdf_voxblox_num_blocks(h_, &n)); return n; }
+  int NumBlocks() { Flush(); int n = 0; check(plvs_hip_tsdf_voxblox_num_blocks(h_, &n)); return n; }
   // The device side of TsdfServer::saveMap / loadMap (tsdf_server.cc:859-872): every block's voxel planes out of /
   // into HBM; the `.proto` serialisation of a StoredBlock stays with the reference's protobuf code.  A loaded block
   // replaces / creates its block and is marked updated (BlockMergingStrategy::kReplace, core/layer_inl.h:195-197, :215).
@@ -812,6 +830,7 @@ class PointCloudMapVoxblox {
     return out;
   }
   bool LoadLayer(const std::vector<StoredBlock>& blocks) {
+    Flush();
     for (const StoredBlock& b : blocks) {
       check(plvs_hip_tsdf_voxblox_upload_block(h_, std::get<0>(b.id), std::get<1>(b.id), std::get<2>(b.id), b.distance.data(),
                                                b.weight.data(), b.rgba.data()));
@@ -840,6 +859,7 @@ class PointCloudMapVoxblox {
   plvs_tsdf_voxblox* h_ = nullptr;
   bool merged_ = false;
   bool fast_ = false;
+  bool queue_ = false, pending_ = false;
   std::vector<float> xyz_;
   std::vector<uint8_t> rgba_;
   std::set<BlockID> updated_;

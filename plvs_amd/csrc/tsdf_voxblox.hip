@@ -816,6 +816,12 @@ struct plvs_tsdf_voxblox {
   uint32_t ap_next = 1;                // (the reference's sets start at offset 0 and every scan begins with offset + 1)
   bool ap_ready = false;
   int fast_rounds = 0;                 // rounds of the last fast call (diagnostic)
+  // queued key-frame clouds (plvs_hip_tsdf_voxblox_queue / _flush): uploaded, not yet integrated
+  DevBuf<float> q_xyz, q_Twc_dev;   // (the poses get a buffer of their own: a host-flavour integrate that finds a queue has
+                                    //  staged ITS pose in st_Twc already)
+  DevBuf<uint32_t> q_rgba;
+  std::vector<int32_t> q_offsets;   // [clouds + 1] once anything is queued
+  std::vector<float> q_Twc;         // 12 per cloud
   plvs_tsdf_stats stats{};
   uint32_t last_updated = 0;
   void* ext = nullptr;                 // meshing scratch (tsdf_voxblox_mesh.hip), freed with the map
@@ -826,11 +832,33 @@ struct plvs_tsdf_voxblox {
   DevBuf<uint32_t> halo_row;
 };
 
+template <typename T>
+static hipError_t vb_grow_keep(DevBuf<T>& b, size_t used, size_t want) {   // reserve() that keeps the first `used` elements
+  if (want <= b.cap) return hipSuccess;
+  DevBuf<T> nb;
+  hipError_t e = nb.reserve(std::max(want, 2 * b.cap));
+  if (e != hipSuccess) return e;
+  if (used) e = hipMemcpy(nb.p, b.p, used * sizeof(T), hipMemcpyDeviceToDevice);
+  if (e != hipSuccess) { nb.release(); return e; }
+  b.release();
+  b = nb;
+  return hipSuccess;
+}
+extern "C" int plvs_hip_tsdf_voxblox_flush(plvs_tsdf_voxblox* h);
+#define VB_FLUSH_QUEUE(h)                                          \
+  do {                                                             \
+    if ((h) && !(h)->q_offsets.empty()) {                          \
+      const int rc_flush_ = plvs_hip_tsdf_voxblox_flush(h);        \
+      if (rc_flush_ != PLVS_OK) return rc_flush_;                  \
+    }                                                              \
+  } while (0)
+
 namespace plvs {
 namespace vbx {
 
 bool voxblox_map_view(plvs_tsdf_voxblox* h, VoxbloxMapView* v) {
   if (h == nullptr || v == nullptr || h->poisoned) return false;
+  if (!h->q_offsets.empty() && plvs_hip_tsdf_voxblox_flush(h) != PLVS_OK) return false;   // (the meshers read the map)
   v->voxel_size = h->P.voxel_size;
   v->voxel_size_inv = h->P.voxel_size_inv;
   v->dir = h->dir;
@@ -884,6 +912,7 @@ int plvs_hip_tsdf_voxblox_destroy(plvs_tsdf_voxblox* h) {
   (void)hipFree(h->dist); (void)hipFree(h->weight); (void)hipFree(h->rgba); (void)hipFree(h->d_ctr);
   if (h->h_ctr) (void)hipHostFree(h->h_ctr);
   if (h->h_ff) (void)hipHostFree(h->h_ff);
+  h->q_xyz.release(); h->q_rgba.release(); h->q_Twc_dev.release();
   h->ap_start.release(); h->ap_seen.release(); h->ff_shash.release(); h->ff_qhash.release(); h->ff_skey0.release(); h->ff_skey1.release();
   h->ff_sval0.release(); h->ff_sval1.release(); h->ff_full.release(); h->ff_Q.release(); h->ff_L.release(); h->ff_qoff.release();
   h->ff_qkey0.release(); h->ff_qkey1.release(); h->ff_qval0.release(); h->ff_qval1.release(); h->ff_flags.release(); h->ff_seen.release();
@@ -916,6 +945,8 @@ int plvs_hip_tsdf_voxblox_clear(plvs_tsdf_voxblox* h) {
   h->last_updated = 0;
   h->ap_ready = false;   // (a new map = a new integrator: fresh sets, offset 0)
   h->ap_next = 1;
+  h->q_offsets.clear();  // (queued clouds belong to the map that is gone)
+  h->q_Twc.clear();
   return PLVS_OK;
 }
 
@@ -1106,6 +1137,7 @@ extern "C" {
 int plvs_hip_tsdf_voxblox_upload_block(plvs_tsdf_voxblox* h, int bx, int by, int bz, const float* distance, const float* weight,
                                        const uint32_t* rgba) {
   PLVS_REQUIRE(h && distance && weight && rgba, "null argument");
+  VB_FLUSH_QUEUE(h);
   PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
   if (h->P.shard_count > 1)
     PLVS_REQUIRE(shard_of(owner_hash(bx, by, bz), h->P.shard_count) == h->P.shard_rank, "the block belongs to another rank");
@@ -1135,6 +1167,7 @@ int plvs_hip_tsdf_voxblox_upload_block(plvs_tsdf_voxblox* h, int bx, int by, int
 
 int plvs_hip_tsdf_voxblox_halo_lookup(plvs_tsdf_voxblox* h, const int32_t* d_ids_xyz, int n, uint32_t* d_found, void* stream) {
   PLVS_REQUIRE(h && !h->poisoned, "unusable handle");
+  VB_FLUSH_QUEUE(h);
   PLVS_REQUIRE(n >= 0, "negative size");
   if (n == 0) return PLVS_OK;
   PLVS_REQUIRE(d_ids_xyz && d_found, "null argument");
@@ -1147,6 +1180,7 @@ int plvs_hip_tsdf_voxblox_halo_lookup(plvs_tsdf_voxblox* h, const int32_t* d_ids
 int plvs_hip_tsdf_voxblox_halo_export(plvs_tsdf_voxblox* h, const int32_t* d_ids_xyz, const uint32_t* d_found, int n,
                                       uint32_t* d_payload, void* stream) {
   PLVS_REQUIRE(h && !h->poisoned, "unusable handle");
+  VB_FLUSH_QUEUE(h);
   PLVS_REQUIRE(n >= 0, "negative size");
   if (n == 0 || d_payload == nullptr) return PLVS_OK;   // (no payload buffer: the caller saw no flag set)
   PLVS_REQUIRE(d_ids_xyz && d_found, "null argument");
@@ -1162,6 +1196,7 @@ int plvs_hip_tsdf_voxblox_halo_export(plvs_tsdf_voxblox* h, const int32_t* d_ids
 int plvs_hip_tsdf_voxblox_halo_import(plvs_tsdf_voxblox* h, const int32_t* d_ids_xyz, const uint32_t* d_found,
                                       const uint32_t* d_payload, int n, int nfound, void* stream) {
   PLVS_REQUIRE(h && !h->poisoned, "unusable handle");
+  VB_FLUSH_QUEUE(h);
   PLVS_REQUIRE(n >= 0 && nfound >= 0 && nfound <= n, "bad sizes");
   if (n == 0 || nfound == 0) return PLVS_OK;
   PLVS_REQUIRE(d_ids_xyz && d_found && d_payload, "null argument");
@@ -1195,6 +1230,7 @@ int plvs_hip_tsdf_voxblox_halo_import(plvs_tsdf_voxblox* h, const int32_t* d_ids
 
 int plvs_hip_tsdf_voxblox_halo_clear(plvs_tsdf_voxblox* h) {
   PLVS_REQUIRE(h, "null handle");
+  VB_FLUSH_QUEUE(h);
   int rc = vb_halo_drop(h, nullptr);
   if (rc != PLVS_OK) return rc;
   PLVS_HIP_TRY(hipStreamSynchronize(nullptr));
@@ -1451,12 +1487,14 @@ extern "C" {
 int plvs_hip_tsdf_voxblox_integrate_batch_dev(plvs_tsdf_voxblox* h, const float* d_xyz,
                                               const uint8_t* d_rgba, const int32_t* offsets,
                                               int nclouds, const float* d_Twc, void* stream) {
+  VB_FLUSH_QUEUE(h);
   return vb_integrate_impl(h, d_xyz, d_rgba, offsets, nclouds, d_Twc, stream, kSimple, nullptr, nullptr);
 }
 
 int plvs_hip_tsdf_voxblox_integrate_fast_batch_dev(plvs_tsdf_voxblox* h, const float* d_xyz, const uint8_t* d_rgba,
                                                    const int32_t* offsets, int nclouds, const float* d_Twc, void* stream) {
   PLVS_REQUIRE(h, "null handle");
+  VB_FLUSH_QUEUE(h);
   PLVS_REQUIRE(offsets && nclouds >= 0, "bad offsets");
   hipStream_t s = static_cast<hipStream_t>(stream);
   // Every cloud is a scan, every scan begins with the sets' "reset": offset + 1, and the 10 000th zeroes them
@@ -1490,6 +1528,7 @@ int plvs_hip_tsdf_voxblox_integrate_fast_batch_dev(plvs_tsdf_voxblox* h, const f
 
 int plvs_hip_tsdf_voxblox_integrate_fast(plvs_tsdf_voxblox* h, const float* xyz, const uint8_t* rgba, int n, const float* Twc) {
   PLVS_REQUIRE(h, "null handle");
+  VB_FLUSH_QUEUE(h);
   PLVS_REQUIRE(n >= 0 && Twc, "bad arguments");
   if (n == 0) {   // (an empty scan still moves the sets on)
     const int32_t none[2] = {0, 0};
@@ -1519,6 +1558,7 @@ int plvs_hip_tsdf_voxblox_fast_rounds(plvs_tsdf_voxblox* h, int* rounds) {
 int plvs_hip_tsdf_voxblox_integrate_world_normals(plvs_tsdf_voxblox* h, const float* xyz, const uint8_t* rgba,
                                                   const float* normals, int n, const float* Twc) {
   PLVS_REQUIRE(h, "null handle");
+  VB_FLUSH_QUEUE(h);
   PLVS_REQUIRE(n >= 0 && Twc, "bad arguments");
   if (n == 0) {
     h->stats = plvs_tsdf_stats{};
@@ -1544,6 +1584,7 @@ int plvs_hip_tsdf_voxblox_integrate_world_normals(plvs_tsdf_voxblox* h, const fl
 int plvs_hip_tsdf_voxblox_integrate_merged(plvs_tsdf_voxblox* h, const float* xyz, const uint8_t* rgba, int n,
                                            const float* Twc) {
   PLVS_REQUIRE(h, "null handle");
+  VB_FLUSH_QUEUE(h);
   PLVS_REQUIRE(n >= 0 && Twc, "bad arguments");
   PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
   h->stats = plvs_tsdf_stats{};
@@ -1640,9 +1681,57 @@ int plvs_hip_tsdf_voxblox_integrate_merged(plvs_tsdf_voxblox* h, const float* xy
   return rc;
 }
 
+// Queued insertion, as for the chisel map (plvs_hip_tsdf_chisel_queue): PLVS inserts one key frame per InsertCloud and reads
+// the layer only in UpdateMap (src/PointCloudMapping.cc:537-556, 594-598; PointCloudMapVoxblox::UpdateMap :160-179).  _queue
+// uploads and returns, _flush integrates what waits as ONE batch of the simple integrator — every cloud a scan of its own,
+// in order: the layer of the call-by-call sequence, bit for bit.  Every entry point that reads or changes the map flushes
+// first; clear drops the queue.
+int plvs_hip_tsdf_voxblox_queue(plvs_tsdf_voxblox* h, const float* xyz, const uint8_t* rgba, int n, const float* Twc) {
+  PLVS_REQUIRE(h, "null handle");
+  PLVS_REQUIRE(n >= 0 && Twc, "bad arguments");
+  PLVS_REQUIRE(n == 0 || (xyz && rgba), "null cloud pointer");
+  const bool first = h->q_offsets.empty();
+  const size_t at = first ? 0 : (size_t)h->q_offsets.back();
+  PLVS_REQUIRE(at + (size_t)n < 0x7FFFFFFFull, "too many queued points");
+  if (n) {
+    PLVS_HIP_TRY(vb_grow_keep(h->q_xyz, 3 * at, 3 * (at + (size_t)n)));
+    PLVS_HIP_TRY(vb_grow_keep(h->q_rgba, at, at + (size_t)n));
+    PLVS_HIP_TRY(hipMemcpy(h->q_xyz.p + 3 * at, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    PLVS_HIP_TRY(hipMemcpy(h->q_rgba.p + at, rgba, (size_t)n * 4, hipMemcpyHostToDevice));
+  }
+  if (first) h->q_offsets.push_back(0);
+  h->q_offsets.push_back((int32_t)(at + (size_t)n));   // (an empty cloud is a scan too: it publishes waiting blocks)
+  h->q_Twc.insert(h->q_Twc.end(), Twc, Twc + 12);
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_voxblox_queued(plvs_tsdf_voxblox* h, int* nclouds) {
+  PLVS_REQUIRE(h && nclouds, "null argument");
+  *nclouds = h->q_offsets.empty() ? 0 : (int)h->q_offsets.size() - 1;
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_voxblox_flush(plvs_tsdf_voxblox* h) {
+  PLVS_REQUIRE(h, "null handle");
+  if (h->q_offsets.empty()) return PLVS_OK;
+  const int nclouds = (int)h->q_offsets.size() - 1;
+  std::vector<int32_t> offsets;
+  std::vector<float> Twc;
+  offsets.swap(h->q_offsets);   // (the queue is empty from here on: the integrate below flushes nothing)
+  Twc.swap(h->q_Twc);
+  PLVS_HIP_TRY(h->q_Twc_dev.reserve((size_t)12 * nclouds));
+  PLVS_HIP_TRY(hipMemcpy(h->q_Twc_dev.p, Twc.data(), (size_t)12 * nclouds * sizeof(float), hipMemcpyHostToDevice));
+  int rc = plvs_hip_tsdf_voxblox_integrate_batch_dev(h, h->q_xyz.p, reinterpret_cast<const uint8_t*>(h->q_rgba.p), offsets.data(), nclouds,
+                                                     h->q_Twc_dev.p, nullptr);
+  if (rc != PLVS_OK) return rc;
+  PLVS_HIP_TRY(hipDeviceSynchronize());
+  return PLVS_OK;
+}
+
 int plvs_hip_tsdf_voxblox_integrate(plvs_tsdf_voxblox* h, const float* xyz, const uint8_t* rgba,
                                     int n, const float* Twc) {
   PLVS_REQUIRE(h, "null handle");
+  VB_FLUSH_QUEUE(h);
   PLVS_REQUIRE(n >= 0 && Twc, "bad arguments");
   if (n == 0) {   // (an empty cloud still publishes what a world cloud left waiting)
     const int32_t none[2] = {0, 0};
@@ -1665,6 +1754,7 @@ int plvs_hip_tsdf_voxblox_integrate(plvs_tsdf_voxblox* h, const float* xyz, cons
 
 int plvs_hip_tsdf_voxblox_set_deferred_world_blocks(plvs_tsdf_voxblox* h, int enable) {
   PLVS_REQUIRE(h, "null handle");
+  VB_FLUSH_QUEUE(h);
   h->defer_world_blocks = enable != 0;
   if (!h->defer_world_blocks) h->visible_blocks = h->num_blocks;
   return PLVS_OK;
@@ -1672,18 +1762,21 @@ int plvs_hip_tsdf_voxblox_set_deferred_world_blocks(plvs_tsdf_voxblox* h, int en
 
 int plvs_hip_tsdf_voxblox_last_stats(plvs_tsdf_voxblox* h, plvs_tsdf_stats* s) {
   PLVS_REQUIRE(h && s, "null argument");
+  VB_FLUSH_QUEUE(h);
   *s = h->stats;
   return PLVS_OK;
 }
 
 int plvs_hip_tsdf_voxblox_num_blocks(plvs_tsdf_voxblox* h, int* n) {
   PLVS_REQUIRE(h && n, "null argument");
+  VB_FLUSH_QUEUE(h);
   *n = h->visible_blocks;
   return PLVS_OK;
 }
 
 int plvs_hip_tsdf_voxblox_block_ids(plvs_tsdf_voxblox* h, int32_t* ids_xyz, int cap, int* n) {
   PLVS_REQUIRE(h && n, "null argument");
+  VB_FLUSH_QUEUE(h);
   *n = h->visible_blocks;
   const int m = h->visible_blocks < cap ? h->visible_blocks : cap;
   if (m > 0) {
@@ -1696,6 +1789,7 @@ int plvs_hip_tsdf_voxblox_block_ids(plvs_tsdf_voxblox* h, int32_t* ids_xyz, int 
 int plvs_hip_tsdf_voxblox_updated_block_ids_dev(plvs_tsdf_voxblox* h, int32_t* d_ids_xyz, int cap,
                                                 int* n, void* stream) {
   PLVS_REQUIRE(h && n, "null argument");
+  VB_FLUSH_QUEUE(h);
   *n = (int)h->last_updated;
   const int m = (int)h->last_updated < cap ? (int)h->last_updated : cap;
   if (m <= 0) return PLVS_OK;
@@ -1708,6 +1802,7 @@ int plvs_hip_tsdf_voxblox_updated_block_ids_dev(plvs_tsdf_voxblox* h, int32_t* d
 
 int plvs_hip_tsdf_voxblox_updated_block_ids(plvs_tsdf_voxblox* h, int32_t* ids_xyz, int cap, int* n) {
   PLVS_REQUIRE(h && n, "null argument");
+  VB_FLUSH_QUEUE(h);
   *n = (int)h->last_updated;
   const int m = (int)h->last_updated < cap ? (int)h->last_updated : cap;
   if (m <= 0) return PLVS_OK;
@@ -1724,6 +1819,7 @@ int plvs_hip_tsdf_voxblox_updated_block_ids(plvs_tsdf_voxblox* h, int32_t* ids_x
 int plvs_hip_tsdf_voxblox_download_block(plvs_tsdf_voxblox* h, int bx, int by, int bz,
                                          float* distance, float* weight, uint32_t* rgba) {
   PLVS_REQUIRE(h && distance && weight && rgba, "null argument");
+  VB_FLUSH_QUEUE(h);
   int32_t* all = new int32_t[(size_t)(h->num_blocks > 0 ? h->num_blocks : 1) * 3];
   hipError_t e = hipSuccess;
   if (h->num_blocks > 0)

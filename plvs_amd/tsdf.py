@@ -433,6 +433,28 @@ class TsdfVoxblox:
         _lib.check(_L.plvs_hip_tsdf_voxblox_integrate(self._h, _lib.np_ptr(xyz), _lib.np_ptr(rgba), xyz.shape[0],
                                                       _lib.np_ptr(Twc)))
 
+    def queue(self, xyz, rgba, Twc):
+        """Upload a key frame's cloud without integrating it (plvs_hip_tsdf_voxblox_queue); flush() — or any call that reads
+        the map — integrates what waits as one batch of the simple integrator."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8).reshape(-1, 4)
+        Twc = np.ascontiguousarray(Twc, dtype=np.float32).reshape(3, 4)
+        f = _L.plvs_hip_tsdf_voxblox_queue
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        _lib.check(f(self._h, _lib.np_ptr(xyz), _lib.np_ptr(rgba), xyz.shape[0], _lib.np_ptr(Twc)))
+
+    def flush(self):
+        f = _L.plvs_hip_tsdf_voxblox_flush
+        f.argtypes = [ctypes.c_void_p]
+        _lib.check(f(self._h))
+
+    def queued(self):
+        n = ctypes.c_int()
+        f = _L.plvs_hip_tsdf_voxblox_queued
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        _lib.check(f(self._h, ctypes.byref(n)))
+        return n.value
+
     def integrate_fast(self, xyz, rgba, Twc):
         """FastTsdfIntegrator::integratePointCloud (integration method "fast", one thread; the reference's approximate sets
         word for word, kept from scan to scan)."""
@@ -598,10 +620,13 @@ class PointCloudMapVoxblox:
     # its YAML's method sets it.
     skIntegrationMethod = "simple"
 
-    def __init__(self, resolution, use_carving=False, max_blocks=None):
+    def __init__(self, resolution, use_carving=False, max_blocks=None, queue_insertions=True):
         if self.skIntegrationMethod not in ("simple", "merged", "fast"):
             raise ValueError(f"unknown voxblox integration method {self.skIntegrationMethod!r}")
         self._tsdf = TsdfVoxblox(resolution, use_carving, max_blocks)
+        # "simple": InsertCloud uploads, UpdateMap (the one reader of the layer) integrates what waits as one batch
+        self._queue = bool(queue_insertions) and self.skIntegrationMethod == "simple"
+        self._pending = False
         self._updated = set()        # the blocks whose updated() flag is set
         self.mesh_layer = {}         # block id -> dict(vertices, normals, colors): voxblox::MeshLayer
 
@@ -612,20 +637,35 @@ class PointCloudMapVoxblox:
             self._tsdf.integrate_merged(cloud_camera["xyz"], cloud_camera["rgba"], Twc)
         elif self.skIntegrationMethod == "fast":
             self._tsdf.integrate_fast(cloud_camera["xyz"], cloud_camera["rgba"], Twc)
+        elif self._queue:
+            self._tsdf.queue(cloud_camera["xyz"], cloud_camera["rgba"], Twc)
+            self._pending = True
+            return
         else:
             self._tsdf.integrate(cloud_camera["xyz"], cloud_camera["rgba"], Twc)
+        self._mark_updated()
+
+    def _mark_updated(self):
         for b in self._tsdf.updated_chunk_ids():          # tsdf_integrator.cc:151
             self._updated.add((int(b[0]), int(b[1]), int(b[2])))
+
+    def _flush(self):
+        if self._pending:
+            self._tsdf.flush()
+            self._pending = False
+            self._mark_updated()
 
     def SetReferenceLoadMapVisibility(self, on):
         """The reference's LoadMap leaves the loaded cloud's blocks outside the layer until the next InsertCloud
         (integrateWorlPointCloud never publishes them); on = reproduce that, off (default) = the map shows at once."""
+        self._flush()
         self._tsdf.set_deferred_world_blocks(on)
 
     def LoadMap(self, cloud):
         """LoadMap of a saved cloud once PointCloudMap::LoadMap has read it (src/PointCloudMapVoxblox.cc:233-258):
         TsdfServer::insertWorldPointCloud(cloud, identity) — every point along its normal — then UpdateMap.  (The
         `.proto` volume file of TsdfServer::loadMap is protobuf I/O on the host: not mirrored.)"""
+        self._flush()
         xyz = np.stack([cloud["x"], cloud["y"], cloud["z"]], -1)
         rgba = np.stack([cloud["r"], cloud["g"], cloud["b"], cloud["a"]], -1)
         self._tsdf.integrate_world_normals(xyz, rgba, cloud["normal"])
@@ -636,12 +676,14 @@ class PointCloudMapVoxblox:
     def SaveLayer(self):
         """TsdfServer::saveMap's device side (tsdf_server.cc:859-863, io::SaveLayer): every block's voxel planes, as
         {block id: (distance, weight, rgba)} — the `.proto` serialisation itself stays with the reference's protobuf code."""
+        self._flush()
         return {tuple(int(v) for v in b): self._tsdf.get_chunk(*b) for b in self._tsdf.chunk_ids()}
 
     def LoadLayer(self, blocks):
         """TsdfServer::loadMap's device side (tsdf_server.cc:865-872: LoadBlocksFromFile with kReplace): every stored block
         replaces / creates its block and is marked updated (core/layer_inl.h:195-197, :215).  No UpdateMap: the reference's
         `.proto` branch of LoadMap does not call it either (src/PointCloudMapVoxblox.cc:237-241)."""
+        self._flush()
         for bid, (d, w, c) in blocks.items():
             self._tsdf.set_chunk(bid[0], bid[1], bid[2], d, w, c)
             self._updated.add((int(bid[0]), int(bid[1]), int(bid[2])))
@@ -655,6 +697,7 @@ class PointCloudMapVoxblox:
         getMeshAsPointcloud (voxblox_ros/mesh_vis.h:272-318, ColorMode::kColor)  (src/PointCloudMapVoxblox.cc:160-179).
         -> the output cloud as a structured array (x, y, z, normal, r, g, b), meshes walked in block-id order (the
         reference walks its hash map)."""
+        self._flush()
         todo = sorted(self._updated)
         if todo:
             m = self._tsdf.mesh_blocks(np.array(todo, np.int32))
@@ -683,12 +726,14 @@ class PointCloudMapVoxblox:
         return cloud
 
     def Clear(self):
-        self._tsdf.clear()
+        self._tsdf.clear()      # (drops what was queued)
+        self._pending = False
         self._updated.clear()
         self.mesh_layer.clear()
 
     @property
     def tsdf(self):
+        self._flush()
         return self._tsdf
 
 

@@ -206,3 +206,47 @@ def test_oracle_pose_goes_through_the_kindr_quaternion():
             want = Twc[:, :3].astype(np.float64) @ p.astype(np.float64) + Twc[:, 3]
             assert np.abs(out - want).max() < 2e-5, (R, p, out, want)
     assert seen == {"w", "x", "y", "z"}
+
+
+@pytest.mark.gpu
+def test_hip_queued_clouds_equal_one_by_one(oracle):
+    """plvs_hip_tsdf_voxblox_queue / _flush: InsertCloud may upload and UpdateMap integrate — the layer is that of the
+    call-by-call sequence bit for bit; an empty cloud in the queue is a scan too; every reader flushes; clear drops the queue."""
+    from plvs_amd.tsdf import TsdfVoxblox
+    vs = 0.05
+    kfs = make_keyframes(5, seed=61)
+    ref = oracle.voxblox(vs)
+    hip = TsdfVoxblox(vs, max_blocks=8192)
+    for k in kfs[:3]:
+        ref.integrate(k["xyz"], rgba_of(k), k["Twc"])
+        hip.queue(k["xyz"], rgba_of(k), k["Twc"])
+    hip.queue(np.zeros((0, 3), np.float32), np.zeros((0, 4), np.uint8), kfs[0]["Twc"])
+    assert hip.queued() == 4
+    hip.flush()
+    assert hip.queued() == 0 and hip.last_stats()["points"] == sum(len(k["xyz"]) for k in kfs[:3])
+    compare(ref, hip)
+    # a reader flushes by itself; a direct integrate takes its place behind the queue
+    hip.queue(kfs[3]["xyz"], rgba_of(kfs[3]), kfs[3]["Twc"])
+    hip.integrate(kfs[4]["xyz"], rgba_of(kfs[4]), kfs[4]["Twc"])
+    ref.integrate(kfs[3]["xyz"], rgba_of(kfs[3]), kfs[3]["Twc"])
+    ref.integrate(kfs[4]["xyz"], rgba_of(kfs[4]), kfs[4]["Twc"])
+    compare(ref, hip)
+    hip.queue(kfs[0]["xyz"], rgba_of(kfs[0]), kfs[0]["Twc"])
+    hip.clear()
+    assert hip.queued() == 0 and hip.num_chunks() == 0
+    hip.close()
+
+
+@pytest.mark.gpu
+def test_mirror_queues_insertions_until_update_map(oracle):
+    from plvs_amd.tsdf import PointCloudMapVoxblox
+    vs = 0.05
+    kfs = make_keyframes(3, seed=62)
+    a, b = PointCloudMapVoxblox(vs), PointCloudMapVoxblox(vs, queue_insertions=False)
+    for k in kfs:
+        a.InsertCloud(dict(xyz=k["xyz"], rgba=rgba_of(k)), k["Twc"])
+        b.InsertCloud(dict(xyz=k["xyz"], rgba=rgba_of(k)), k["Twc"])
+    assert a._tsdf.queued() == 3 and b._tsdf.queued() == 0
+    ca, cb = a.UpdateMap(), b.UpdateMap()
+    assert a._tsdf.queued() == 0 and len(ca) > 1000 and ca.tobytes() == cb.tobytes()
+    assert sorted(a.mesh_layer) == sorted(b.mesh_layer)

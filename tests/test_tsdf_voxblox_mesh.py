@@ -205,6 +205,7 @@ def test_update_map_mirror_accumulates_updated_blocks(oracle):
     k = kfs[2]
     ref.integrate(k["xyz"], rgba_of(k), k["Twc"])
     pm.InsertCloud(dict(xyz=k["xyz"], rgba=rgba_of(k)), k["Twc"])
+    pm._flush()                # (the mirror queues insertions: the updated set exists once they are integrated)
     touched = set(pm._updated)
     cloud = pm.UpdateMap()
     n = 0
