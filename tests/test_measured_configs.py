@@ -4,6 +4,8 @@ reduced image sizes so that the oracle finishes in seconds):
   configs[2]  the exact bench step — 100 full-resolution keyframes in ONE integrate_batch_dev on the
               6x4x3 m room, chisel 5 cm / 5 m — in the bit-exact and in the order-free mode, first on an
               empty map and again on the populated one; carving after integrate at 640x480.
+              The STREAMING headline of round 4 — the first two 100-key-frame steps of the office loop, as bench.py runs
+              them — in both modes (order-free: the stated tolerance against the exact mean AND against the reference).
   configs[3]  voxblox 2 cm in the 16x12x3 m room at full resolution, points beyond the wrapper's 5 m
               ray limit, carving off and on.
   configs[4]  KITTI-sized stereo pair -> SGM disparity -> depth (bf 386.1448) -> cloud -> chisel 10 cm,
@@ -76,6 +78,77 @@ def test_chisel_bench_step_matches_oracle(bench_stream, order_free):
         if order_free:
             print(f"step {step}: order-free deviations sdf {worst_s:.3g} m, weight {worst_w:.3g} rel")
             assert worst_s <= ORDER_FREE_SDF_ATOL and worst_w <= ORDER_FREE_WEIGHT_RTOL
+    dev.close()
+
+
+@pytest.fixture(scope="module")
+def headline_stream(oracle):
+    """The first two steps of bench.py's STREAMING headline (key frames 0-99 into an empty map, 100-199 into that map) on the
+    oracle: voxel planes after each, and the exact (f64) mean of every voxel's visits beside the reference's f32 running mean."""
+    from plvs_amd.synth_scene import make_stream_keyframes
+    kfs = make_stream_keyframes(200, max_depth=5.0, seed=0, threads=16)
+    ora = oracle.chisel(0.05)
+    ora.track_exact()
+    visits, snaps, exact = [], [], []
+    for step in range(2):
+        v = 0
+        for kf in kfs[100 * step:100 * step + 100]:
+            ora.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+            v += ora.last_visits()
+        visits.append(v)
+        snaps.append(_snapshot(ora))
+        exact.append({tuple(c): tuple(np.array(x, copy=True) for x in ora.get_chunk_exact(*c)) for c in ora.chunk_ids()})
+    return kfs, visits, snaps, exact
+
+
+@pytest.mark.parametrize("order_free", [False, True])
+def test_chisel_streaming_headline_steps_match_oracle(headline_stream, order_free):
+    """The headline as the bench runs it since round 4: tiles of walls 3-5 m away (800-2 000 voxels each: the 2048-entry
+    first pass, the 4096-entry pass over what overflowed, the general kernel behind it), chunk allocation and colour folds
+    inside the step.  Ordered mode: bit for bit.  Order-free mode: kfid and colour exact; sdf / weight within 2e-5 m / 5e-5
+    of the EXACT mean of the reference's own visits, and within the stated bound of the reference's f32 map — a voxel with n
+    visits: 2e-5 m + n 2^-24 tau, 5e-5 + n 2^-24 (tau = the truncation distance at 5 m; bench.py asserts the same)."""
+    import torch
+    from plvs_amd.tsdf import TsdfChisel
+    kfs, visits, snaps, exact = headline_stream
+    tau = max((0.0019 * 25.0 - 0.00152 * 5.0 + 0.001504) * 6.0, 2.0 * np.sqrt(3.0) * 0.05)
+    w_min = 1.0 / (2.0 * tau)
+    dev = TsdfChisel(0.05, max_chunks=16384, order_free=order_free)
+    for step in range(2):
+        g = kfs[100 * step:100 * step + 100]
+        xyz = torch.from_numpy(np.concatenate([k["xyz"] for k in g])).cuda()
+        rgb = torch.from_numpy(np.concatenate([k["rgb"] for k in g])).cuda()
+        kfid = torch.from_numpy(np.concatenate([k["kfid"] for k in g]).astype(np.int32)).cuda()
+        Twc = torch.from_numpy(np.stack([k["Twc"] for k in g])).cuda()
+        offsets = np.cumsum([0] + [k["xyz"].shape[0] for k in g]).astype(np.int32)
+        dev.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
+        torch.cuda.synchronize()
+        st = dev.last_stats()
+        assert st["visits"] == visits[step] and st["points"] == xyz.shape[0]
+        want = snaps[step]
+        assert {tuple(c) for c in dev.chunk_ids()} == set(want)
+        assert len(want) > 80
+        ws = ww = bound_s = bound_w = 0.0
+        for cid, a in want.items():
+            b = dev.get_chunk(*cid)
+            assert np.array_equal(a[2], b[2]), f"kfid differs in chunk {cid}"
+            assert np.array_equal(a[3], b[3]), f"colour differs in chunk {cid}"
+            if order_free:
+                known = a[1] > 0
+                assert np.array_equal(known, b[1] > 0)
+                if known.any():
+                    xs, xw = exact[step][cid]
+                    ws = max(ws, float(np.abs(b[0][known] - xs[known]).max()))
+                    ww = max(ww, float((np.abs(b[1][known] - xw[known]) / xw[known]).max()))
+                    n_up = np.ceil(xw[known] / w_min) + 1.0
+                    bound_s = max(bound_s, float((np.abs(a[0][known] - b[0][known]) / (2e-5 + n_up * 2.0 ** -24 * tau)).max()))
+                    bound_w = max(bound_w, float((np.abs(a[1][known] - b[1][known]) / a[1][known] / (5e-5 + n_up * 2.0 ** -24)).max()))
+            else:
+                assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), f"sdf differs in chunk {cid}"
+                assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), f"weight differs in chunk {cid}"
+        if order_free:
+            assert ws <= ORDER_FREE_SDF_ATOL and ww <= ORDER_FREE_WEIGHT_RTOL, (ws, ww)
+            assert bound_s <= 1.0 and bound_w <= 1.0, (bound_s, bound_w)
     dev.close()
 
 
