@@ -24,7 +24,8 @@ CASES = ([("M3 SearchByProjection(F, MapPoints)", s, th, far) for s, th, far in 
          [("M7 SearchByKnn(pKF, F)", s, r, c) for s, r, c in ((1, 0.8, True), (2, 0.7, True), (3, 0.9, False))] +
          [("M7 SearchStereoMatchesByKnn", s, r, c, dd) for s, r, c, dd in ((1, 0.8, True, 50), (2, 0.7, True, 60), (3, 0.9, False, 50), (4, 0.8, True, 256))] +
          [("M9 SearchByProjection(F, MapLines)", s, st, e, lg, r) for s, st, e, lg, r in ((1, False, False, False, 0.8), (2, True, False, False, 0.8),
-                                                                                      (3, False, True, True, 0.9), (4, True, True, False, 0.7))])
+                                                                                      (3, False, True, True, 0.9), (4, True, True, False, 0.7))] +
+         [("M5 Frame::ComputeStereoMatches", name, nf) for name, nf in (("urban1", 2000), ("shift17", 1000))])
 
 
 def _digest(n, *arrays):
@@ -134,6 +135,33 @@ def run_case(case, backend, oracle=None, ref=None):
                 n = fn(ctypes.byref(F), tlp._p(c["occupied"]), len(c["valid"]), tlp._p(c["valid"]), tlp._p(c["proj_map"]),
                        tlp._p(c["octave"]), tlp._p(c["ldesc"]), tlp._p(c["has_obs"]), int(larger), ratio, _p(a))
         return _digest(n, np.asarray(a, np.int32))
+    if kind.startswith("M5"):   # the reference runs its OWN extractor on the pair, then Frame::ComputeStereoMatches
+        from tests import test_stereo as tst
+        _, name, nf = case
+        left, right = tst.pair(name)
+        left, right = np.ascontiguousarray(left), np.ascontiguousarray(right)
+        if backend == "ref":
+            cap = 2 * nf + 64
+            u, z = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+            nr = ctypes.c_int()
+            fn = ref.ref_frame_compute_stereo_matches
+            fn.restype = _i
+            fn.argtypes = [_vp, _vp, _i, _i, _i, _i, _f, _i, _i, _i, _f, _f, _vp, _vp, _i, _vp]
+            n = fn(_p(left), _p(right), left.shape[1], left.shape[0], left.strides[0], nf, tst.SCALE, tst.NLEVELS, 20, 7,
+                   float(tst.MB), float(np.float32(tst.KITTI_BF)), _p(u), _p(z), cap, ctypes.byref(nr))
+            u, z = u[:n], z[:n]
+        elif backend == "oracle":
+            (kl, dl, pl), (kr, dr, pr) = tst.oracle_side(oracle, left, right, nf)
+            sc, inv = tst.scale_tables()
+            u, z, _, _ = oracle.stereo_matches(kl, dl, kr, dr, pl, pr, sc, inv, tst.MB, np.float32(tst.KITTI_BF))
+        else:
+            from plvs_amd.orb import ORBextractor
+            from plvs_amd.stereo import StereoMatcher
+            exl, exr = ORBextractor(nf, tst.SCALE, tst.NLEVELS, 20, 7), ORBextractor(nf, tst.SCALE, tst.NLEVELS, 20, 7)
+            _, hkl, hdl = exl(left)
+            _, hkr, hdr = exr(right)
+            u, z = StereoMatcher(exl, exr).ComputeStereoMatches(hkl, hdl, hkr, hdr, tst.MB, np.float32(tst.KITTI_BF))
+        return _digest(int((np.asarray(u) >= 0).sum()), np.asarray(u, np.float32), np.asarray(z, np.float32))
     raise ValueError(kind)
 
 
