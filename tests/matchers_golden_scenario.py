@@ -25,7 +25,8 @@ CASES = ([("M3 SearchByProjection(F, MapPoints)", s, th, far) for s, th, far in 
          [("M7 SearchStereoMatchesByKnn", s, r, c, dd) for s, r, c, dd in ((1, 0.8, True, 50), (2, 0.7, True, 60), (3, 0.9, False, 50), (4, 0.8, True, 256))] +
          [("M9 SearchByProjection(F, MapLines)", s, st, e, lg, r) for s, st, e, lg, r in ((1, False, False, False, 0.8), (2, True, False, False, 0.8),
                                                                                       (3, False, True, True, 0.9), (4, True, True, False, 0.7))] +
-         [("M5 Frame::ComputeStereoMatches", name, nf) for name, nf in (("urban1", 2000), ("shift17", 1000))])
+         [("M5 Frame::ComputeStereoMatches", name, nf) for name, nf in (("urban1", 2000), ("shift17", 1000))] +
+         [("G Frame::UndistortKeyPoints / ComputeImageBounds / AssignFeaturesToGrid / UndistortKeyLines", ci) for ci in range(5)])
 
 
 def _digest(n, *arrays):
@@ -162,6 +163,21 @@ def run_case(case, backend, oracle=None, ref=None):
             _, hkr, hdr = exr(right)
             u, z = StereoMatcher(exl, exr).ComputeStereoMatches(hkl, hdl, hkr, hdr, tst.MB, np.float32(tst.KITTI_BF))
         return _digest(int((np.asarray(u) >= 0).sum()), np.asarray(u, np.float32), np.asarray(z, np.float32))
+    if kind.startswith("G "):   # the glue of Frame::Frame between extraction and search, per calibration of tests/test_frame_glue.py
+        from tests import test_frame_glue as tfg
+        _, ci = case
+        side = (tfg._Side(ref, "ref_frame_") if backend == "ref" else
+                tfg._Side(oracle.lib, "oracle_frame_") if backend == "oracle" else tfg._Hip())
+        K, D = tfg.CALIBS[ci]
+        k = tfg._keypoints(70 + ci, 2100 if ci == 0 else 300)
+        un = side.undistort_keypoints(k, K, D)
+        b = np.asarray(side.bounds(640, 480, K, D), np.float32)
+        iw, ih = np.float32(64.0) / np.float32(b[1] - b[0]), np.float32(48.0) / np.float32(b[3] - b[2])
+        start, items = side.grid(un, float(b[0]), float(b[2]), float(iw), float(ih))
+        kl = tfg._keylines(120 + ci, 160)
+        lu, kept = side.undistort_keylines(kl, K, D, b)
+        return _digest(len(items), un, b, np.asarray(start, np.int32), np.asarray(items, np.int32), np.ascontiguousarray(lu),
+                       np.asarray(kept, np.int32))
     raise ValueError(kind)
 
 
