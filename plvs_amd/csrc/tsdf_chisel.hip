@@ -95,10 +95,11 @@ __global__ void pose_prep(const float* __restrict__ Twc, int nclouds, Pose* __re
 __global__ void walk_prologue(const float* __restrict__ Twc, int nclouds, Pose* __restrict__ poses,
                               const int32_t* __restrict__ host_offsets, int32_t* __restrict__ offsets,
                               WalkCounters* __restrict__ wctr, Counters* __restrict__ ctr, uint32_t* __restrict__ chunk_nseg,
-                              int nseg) {
+                              int nseg, int ntile_first = 0) {
   const int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
   for (int c = i0; c < nclouds; c += stride) make_pose(Twc + 12 * c, &poses[c]);
-  for (int c = i0; c < 2 * (nclouds + 1); c += stride) offsets[c] = host_offsets[c];   // (offsets + tile table)
+  // (offsets + tile table, and behind them the first point of every tile: what the colour fold reads per run)
+  for (int c = i0; c < 2 * (nclouds + 1) + ntile_first; c += stride) offsets[c] = host_offsets[c];
   for (int k = i0; k < nseg; k += stride) chunk_nseg[k] = 0u;
   uint32_t* w = reinterpret_cast<uint32_t*>(wctr);
   for (int k = i0; k < (int)(2 * sizeof(WalkCounters) / sizeof(uint32_t)); k += stride) w[k] = 0u;
@@ -1048,16 +1049,25 @@ static int ensure_part_acc(plvs_tsdf_chisel* h, uint32_t chunks) {
 static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uint8_t* d_rgb, const uint32_t* d_kfid,
                               int n, int nclouds, const int32_t* offsets, const float* d_Twc, hipStream_t s) {
   const int max_chunks = h->prm.max_chunks;
-  if (h->h_offsets_cap < 2 * ((size_t)nclouds + 1)) {   // pinned copy of the offsets + tile table: the prologue kernel reads it
+  // tiles: 512 consecutive points of one cloud (tsdf_directory.hpp)
+  size_t tiles_of_call = 0;
+  for (int c = 0; c < nclouds; ++c) tiles_of_call += ((size_t)(offsets[c + 1] - offsets[c]) + kWalkRays - 1) / kWalkRays;
+  const size_t table_words = 2 * ((size_t)nclouds + 1) + tiles_of_call;
+  if (h->h_offsets_cap < table_words) {   // pinned copy of the offsets + tile table + tile starts: the prologue kernel reads it
     if (h->h_offsets) (void)hipHostFree(h->h_offsets);
     h->h_offsets = nullptr;
     h->h_offsets_cap = 0;
-    PLVS_HIP_TRY(hipHostMalloc((void**)&h->h_offsets, (2 * ((size_t)nclouds + 1) + 64) * sizeof(int32_t)));
-    h->h_offsets_cap = 2 * ((size_t)nclouds + 1) + 64;
+    PLVS_HIP_TRY(hipHostMalloc((void**)&h->h_offsets, (2 * table_words + 64) * sizeof(int32_t)));
+    h->h_offsets_cap = 2 * table_words + 64;
   }
-  // tiles: 512 consecutive points of one cloud (tsdf_directory.hpp)
   const uint32_t ntiles = plvs::tsdf::fill_tile_table(offsets, nclouds, h->h_offsets, kWalkRays);
-  PLVS_HIP_TRY(h->offsets.reserve(2 * ((size_t)nclouds + 1)));
+  {   // the first point of every tile (the colour fold would otherwise search the cloud table once per RUN)
+    int32_t* tf = h->h_offsets + 2 * ((size_t)nclouds + 1);
+    size_t t = 0;
+    for (int c = 0; c < nclouds; ++c)
+      for (int32_t p = offsets[c]; p < offsets[c + 1]; p += kWalkRays) tf[t++] = p;
+  }
+  PLVS_HIP_TRY(h->offsets.reserve(table_words));
   PLVS_HIP_TRY(h->tile_state.reserve((size_t)ntiles + 1));
   PLVS_HIP_TRY(h->w_chunk_nseg.reserve((size_t)max_chunks));
   PLVS_HIP_TRY(h->w_chunk_off.reserve((size_t)max_chunks + 1));
@@ -1105,7 +1115,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     PLVS_HIP_TRY(h->w_masks.reserve(((size_t)ntiles << h->run_r1_log2) * kMaskWords));
     hipLaunchKernelGGL(walk_prologue, dim3(ceil_div((size_t)std::max(max_chunks, nclouds + 1), 256)), dim3(256), 0, s, d_Twc,
                        nclouds, h->poses.p, (const int32_t*)h->h_offsets, h->offsets.p, h->d_wctr, h->d_ctr, h->w_chunk_nseg.p,
-                       max_chunks);
+                       max_chunks, (int)ntiles);
     STAGE_MARK(0);
     AccOut out{h->w_rec.p, (uint32_t)std::min<size_t>(rec_own + rec_spill, 0xFFFFFFFFu), h->w_seg.p,
                (uint32_t)std::min<size_t>(seg_own + seg_spill, 0xFFFFFFFFu), h->w_seg_cnt.p, h->w_tile_visits.p};
@@ -1197,7 +1207,8 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
           }
           hipLaunchKernelGGL(fold_colours_masks, dim3(std::min<size_t>(ceil_div(D, kFoldWaves), 8192)),
                              dim3(64 * kFoldWaves), 0, h->side, skeys, sval, side_ctr,
-                             RunSrc{h->w_masks.p, (uint32_t)kMaskWords, h->run_r1_log2, TileMap{1u, 0u}, h->offsets.p, nclouds},
+                             RunSrc{h->w_masks.p, (uint32_t)kMaskWords, h->run_r1_log2, TileMap{1u, 0u}, h->offsets.p, nclouds,
+                                    reinterpret_cast<const uint32_t*>(h->offsets.p) + 2 * ((size_t)nclouds + 1)},
                              h->heads.p, d_rgb,
                              h->rgbw, &h->d_wctr[1].num_heads, (uint32_t*)nullptr, (uint32_t*)nullptr);
           PLVS_KERNEL_CHECK();
@@ -2817,7 +2828,7 @@ int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src,
                        h->w_dummy.p, h->d_wctr + 1);
     hipLaunchKernelGGL(fold_colours_masks, dim3(std::min<size_t>(ceil_div(R, kFoldWaves), 8192)), dim3(64 * kFoldWaves), 0, s,
                        skeys, sval, &h->d_wctr[1].num_desc,
-                       RunSrc{runs, kWireRun, 0u, TileMap{1u, 0u}, h->offsets.p, h->sh_nclouds}, h->heads.p, d_rgb,
+                       RunSrc{runs, kWireRun, 0u, TileMap{1u, 0u}, h->offsets.p, h->sh_nclouds, nullptr}, h->heads.p, d_rgb,
                        h->rgbw, &h->d_wctr[1].num_heads, h->sh_sat.p, reinterpret_cast<uint32_t*>(h->d_xcount + 2));
     PLVS_KERNEL_CHECK();
   }

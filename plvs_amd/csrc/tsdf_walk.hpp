@@ -2074,6 +2074,7 @@ struct RunSrc {
   TileMap tmap;
   const int32_t* offsets;   // the call's offsets + tile table (tile -> first point: tile_span)
   int nclouds;
+  const uint32_t* tile_first;   // first point of every tile of the call (nullptr: searched in the table above)
 };
 constexpr int kFoldGroup = 8;     // voxels a wave folds together (staging: 8 lanes each; fold: 4 lanes each: r, g, b, idle)
 constexpr int kFoldSteps = 256;   // >= 254: the visits that can still count for a voxel
@@ -2134,8 +2135,8 @@ __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
             const uint4 a = m4[q];
             m[4 * q] = a.x; m[4 * q + 1] = a.y; m[4 * q + 2] = a.z; m[4 * q + 3] = a.w;
           }
-          p0 = (size_t)tile_span(src.offsets, src.nclouds,
-                                 src.words == kWireRun ? run[3] : src.tmap.tile_of(val >> src.r1_log2), kWalkRays).first;
+          const uint32_t gt = src.words == kWireRun ? run[3] : src.tmap.tile_of(val >> src.r1_log2);
+          p0 = src.tile_first ? (size_t)src.tile_first[gt] : (size_t)tile_span(src.offsets, src.nclouds, gt, kWalkRays).first;
 #pragma unroll
           for (int w = 0; w < kMaskWords; ++w) cnt += (uint32_t)__popc(m[w]);
         }
