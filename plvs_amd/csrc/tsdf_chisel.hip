@@ -1052,7 +1052,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
   // tiles: 512 consecutive points of one cloud (tsdf_directory.hpp)
   size_t tiles_of_call = 0;
   for (int c = 0; c < nclouds; ++c) tiles_of_call += ((size_t)(offsets[c + 1] - offsets[c]) + kWalkRays - 1) / kWalkRays;
-  const size_t table_words = 2 * ((size_t)nclouds + 1) + tiles_of_call;
+  const size_t table_words = 2 * ((size_t)nclouds + 1) + 2 * tiles_of_call;
   if (h->h_offsets_cap < table_words) {   // pinned copy of the offsets + tile table + tile starts: the prologue kernel reads it
     if (h->h_offsets) (void)hipHostFree(h->h_offsets);
     h->h_offsets = nullptr;
@@ -1065,7 +1065,10 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     int32_t* tf = h->h_offsets + 2 * ((size_t)nclouds + 1);
     size_t t = 0;
     for (int c = 0; c < nclouds; ++c)
-      for (int32_t p = offsets[c]; p < offsets[c + 1]; p += kWalkRays) tf[t++] = p;
+      for (int32_t p = offsets[c]; p < offsets[c + 1]; p += kWalkRays) {
+        tf[ntiles + t] = c;   // (and its cloud: the walk's tiles read both instead of searching: tile_span_tables)
+        tf[t++] = p;
+      }
   }
   PLVS_HIP_TRY(h->offsets.reserve(table_words));
   PLVS_HIP_TRY(h->tile_state.reserve((size_t)ntiles + 1));
@@ -1115,7 +1118,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     PLVS_HIP_TRY(h->w_masks.reserve(((size_t)ntiles << h->run_r1_log2) * kMaskWords));
     hipLaunchKernelGGL(walk_prologue, dim3(ceil_div((size_t)std::max(max_chunks, nclouds + 1), 256)), dim3(256), 0, s, d_Twc,
                        nclouds, h->poses.p, (const int32_t*)h->h_offsets, h->offsets.p, h->d_wctr, h->d_ctr, h->w_chunk_nseg.p,
-                       max_chunks, (int)ntiles);
+                       max_chunks, (int)(2 * ntiles));
     STAGE_MARK(0);
     AccOut out{h->w_rec.p, (uint32_t)std::min<size_t>(rec_own + rec_spill, 0xFFFFFFFFu), h->w_seg.p,
                (uint32_t)std::min<size_t>(seg_own + seg_spill, 0xFFFFFFFFu), h->w_seg_cnt.p, h->w_tile_visits.p};
@@ -1129,7 +1132,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     if (ntiles <= kSmallCallTiles) {
       hipLaunchKernelGGL(walk_fast<kFastEntriesBig>, dim3(ntiles), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz,
                          n, h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
-                         (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u}, kRecStride, (const uint32_t*)nullptr,
+                         (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u, 1u}, kRecStride, (const uint32_t*)nullptr,
                          (const uint32_t*)nullptr, list_a, &h->d_wctr->ndeferred);
     } else {
       // The table of the first pass follows the scene: tiles of near surfaces (a small room, a desk) hold 300-600 voxels
@@ -1141,23 +1144,23 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
       if (h->walk_small)
         hipLaunchKernelGGL(walk_fast<kFastEntriesSmall>, dim3(ntiles), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
                            h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
-                           (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u}, kRecStride, (const uint32_t*)nullptr,
+                           (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u, 1u}, kRecStride, (const uint32_t*)nullptr,
                            (const uint32_t*)nullptr, list_a, &h->d_wctr->ndeferred);
       else
       hipLaunchKernelGGL(walk_fast<kFastEntries>, dim3(ntiles), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
                          h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
-                         (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u}, kRecStride, (const uint32_t*)nullptr,
+                         (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u, 1u}, kRecStride, (const uint32_t*)nullptr,
                          (const uint32_t*)nullptr, list_a, &h->d_wctr->ndeferred);
       hipLaunchKernelGGL(walk_fast<kFastEntriesBig>, dim3(std::min<unsigned>(ntiles, kListGrid)), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz,
                          n, h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
-                         (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u}, kRecStride, (const uint32_t*)list_a,
+                         (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u, 1u}, kRecStride, (const uint32_t*)list_a,
                          (const uint32_t*)&h->d_wctr->ndeferred, list_b, &h->d_wctr->ndeferred2);
       last_list = list_b;
       last_count = &h->d_wctr->ndeferred2;
     }
     hipLaunchKernelGGL((walk_tiles<true, true>), dim3(kDeferGrid), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
                        h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
-                       (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u}, (uint32_t)ntiles, last_list, last_count,
+                       (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u, 1u}, (uint32_t)ntiles, last_list, last_count,
                        kRecStride, 2u);   // (what is flagged overflowed a 4096-entry table: two pieces at once)
     PLVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
     STAGE_MARK(1);

@@ -186,6 +186,19 @@ __device__ __forceinline__ TileSpan tile_span(const int32_t* __restrict__ offset
   t.nrays = left < rays ? left : rays;
   return t;
 }
+// The same from the two per-tile tables a caller may put behind the tile table (tile_first[0 .. ntiles), tile_cloud[0 ..
+// ntiles)): three dependent loads instead of the eight of the search.
+__device__ __forceinline__ TileSpan tile_span_tables(const int32_t* __restrict__ offsets, int nclouds, uint32_t gtile, uint32_t rays) {
+  const int32_t* tb = offsets + nclouds + 1;
+  const int32_t* tf = tb + nclouds + 1;
+  const uint32_t nt = (uint32_t)tb[nclouds];
+  TileSpan t;
+  t.first = (uint32_t)tf[gtile];
+  t.cloud = tf[nt + gtile];
+  const uint32_t left = (uint32_t)offsets[t.cloud + 1] - t.first;
+  t.nrays = left < rays ? left : rays;
+  return t;
+}
 // host: both[0 .. nclouds] = offsets, both[nclouds + 1 .. 2 nclouds + 1] = tile_base; returns the tiles of the call
 static inline uint32_t fill_tile_table(const int32_t* offsets, int nclouds, int32_t* both, uint32_t rays) {
   uint32_t t = 0;

@@ -43,6 +43,7 @@ namespace {
 using namespace plvs::chisel;
 using plvs::tsdf::cloud_of;
 using plvs::tsdf::tile_span;
+using plvs::tsdf::tile_span_tables;
 using plvs::tsdf::TileSpan;
 using plvs::tsdf::kCoordBias;
 using plvs::tsdf::kErrCoordRange;
@@ -606,6 +607,7 @@ __device__ __forceinline__ uint4 pack_suboffsets(const uint32_t* o) {
 // block ("local tile").
 struct TileMap {
   uint32_t stride, first;
+  uint32_t tables;   // 1: the call's offsets carry tile_first / tile_cloud behind the tile table (tile_span_tables)
   __device__ __host__ uint32_t tile_of(uint32_t local) const { return local * stride + first; }
 };
 
@@ -638,7 +640,8 @@ __global__ __launch_bounds__(kWalkRays, kWalkEntries > 2048 ? 2 : (kWalkEntries 
   const uint32_t tile = tile_list ? (tile_list[lb] & 0x7FFFFFFFu) : lb;   // the local tile: output regions
   const bool cut_at_once = tile_list && (tile_list[lb] >> 31) != 0u;
   const uint32_t gtile = tmap.tile_of(tile);             // its place in the point stream
-  const TileSpan span = tile_span(offsets, nclouds, gtile, kWalkRays);   // (512 points of one cloud: tsdf_directory.hpp)
+  const TileSpan span = tmap.tables ? tile_span_tables(offsets, nclouds, gtile, kWalkRays)   // (512 points of one cloud:
+                                    : tile_span(offsets, nclouds, gtile, kWalkRays);          //  tsdf_directory.hpp)
   const uint32_t first = span.first;
   __syncthreads();   // (the previous tile of this workgroup is done with the shared state)
   // Nearly every tile lies inside one cloud and fits its table: ONE sub-tile, known without a word of shared memory.
@@ -1137,7 +1140,8 @@ __device__ __forceinline__ void walk_fast_tile(
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   // (tile = the local tile: output regions; listed_other = a listed tile that is not an overflow: passed on)
   const uint32_t gtile = tmap.tile_of(tile);             // its place in the point stream
-  const TileSpan span = tile_span(offsets, nclouds, gtile, kWalkRays);   // (512 points of one cloud: tsdf_directory.hpp)
+  const TileSpan span = tmap.tables ? tile_span_tables(offsets, nclouds, gtile, kWalkRays)   // (512 points of one cloud:
+                                    : tile_span(offsets, nclouds, gtile, kWalkRays);          //  tsdf_directory.hpp)
   const uint32_t first = span.first, nrays = span.nrays;
   const int cloud = span.cloud;
   bool defer = P.shard_count > 1 || listed_other;   // (uniform)
@@ -1734,10 +1738,15 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
     ap_t = ap_item0;
 #endif
     const uint32_t pi = item / kSlabs, slab = item % kSlabs;
-    uint32_t lo = 0, hi = nchunks - 1;   // the chunk of part pi: the last a with part_off[a] <= pi
-    while (lo < hi) {
-      const uint32_t mid = (lo + hi + 1) >> 1;
-      if (part_off[mid] <= pi) lo = mid; else hi = mid - 1;
+    // the chunk of part pi: the last a with part_off[a] <= pi — a 64-way search by every wave (two dependent loads for
+    // up to 4096 updated chunks; a binary search is a dozen, and an item is short)
+    uint32_t lo = 0, span = nchunks;
+    while (span > 1) {
+      const uint32_t step = (span + 63u) >> 6, at = lo + (uint32_t)lane * step;
+      const unsigned long long le = __ballot(at < lo + span && part_off[at] <= pi);   // (lane 0 always: part_off[lo] <= pi)
+      const uint32_t k = 63u - (uint32_t)__clzll((long long)le), end = lo + span;
+      lo += k * step;
+      span = min(step, end - lo);
     }
     const uint32_t a = lo, nparts = part_off[a + 1] - part_off[a];
     for (int v = tid; v < kSlabVox; v += kApplyThreads) {
