@@ -588,12 +588,15 @@ int plvs_hip_tsdf_chisel_carve_dev(plvs_tsdf_chisel* h, const float* d_depth, in
  * t = r (mod N) of 512 consecutive points of every call, through whatever chunks their rays cross, and sends
  * what it collected to the chunk owners.  Every rank is given the same clouds.  One call =
  *   shard_walk    this rank's tiles, then its own aggregation: one sum per touched voxel;
- *                 send_counts[3 * N] = {descriptors, voxel sums, colour runs} per destination
+ *                 send_counts[3 * N] = {descriptors, voxel sums, colour-run records} per destination
  *   shard_pack    the three send buffers, each grouped by destination in rank order:
- *                 descriptors 32 B (one per chunk and slab of 512 voxels), sums 32 B, runs 80 B per item
+ *                 descriptors 32 B (one per chunk and slab of 512 voxels), sums 32 B, colour-run records 24 B:
+ *                 {chunk key 8 B, voxel | tile << 12, six 16-bit spans (first ray | (length - 1) << 9, 0xFFFF =
+ *                 none) of the tile's rays that saw the voxel}; a run with more than six spans takes further
+ *                 records (round 4: 80 B with the 512-bit ray mask before; at most 2^20 tiles per call)
  *   all-to-all    counts, then the three buffers (the caller's transport; ..._integrate_sharded does it over RCCL)
  *   shard_apply   the three receive buffers grouped by source in rank order, recv_counts[3 * N]
- *   shard_saturated / all-gather / shard_note_saturated
+ *   shard_saturated / all-gather / shard_note_saturated  (or _saturated_message / all-gather / _note_gathered)
  *                 the voxels whose colour weight reached 254 in the call: walkers stop sending their runs
  *                 (late knowledge only costs surplus runs).
  * The partial sums are integers: the union of the shards is bit-identical to the single-device order_free map
@@ -611,6 +614,14 @@ int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src,
  * quadruples when cap >= *n (PLVS_ERR_CAPACITY otherwise: call once with cap 0 for the count). */
 int plvs_hip_tsdf_chisel_shard_saturated(plvs_tsdf_chisel* h, int32_t* d_voxels, int cap, int* n, void* stream);
 int plvs_hip_tsdf_chisel_shard_note_saturated(plvs_tsdf_chisel* h, const int32_t* d_voxels, int n, void* stream);
+/* The same feedback without a host read (round 4): _saturated_message moves the last shard_apply's voxels to a waiting
+ * list kept with the handle and writes this rank's fixed-size message — d_msg[0 .. k) = the first k <= rows waiting
+ * voxels, d_msg[rows] = {k, 0, 0, 0} (int32 quadruples, rows + 1 of them); what does not fit waits for the next step.
+ * _note_gathered notes the all-gathered messages of nranks ranks (nranks x (rows + 1) quadruples), every length read
+ * on the device. */
+int plvs_hip_tsdf_chisel_shard_saturated_message(plvs_tsdf_chisel* h, int32_t* d_msg, int rows, void* stream);
+int plvs_hip_tsdf_chisel_shard_note_gathered(plvs_tsdf_chisel* h, const int32_t* d_gathered, int nranks, int rows,
+                                             void* stream);
 /* All of the above with the exchanges over RCCL (grouped ncclSend / ncclRecv, ncclAllGather); rccl_comm is the
  * caller's ncclComm_t, one process per GPU, its size and rank those of the map's shard_count / shard_rank. */
 int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm, const float* d_xyz,

@@ -108,39 +108,72 @@ constexpr size_t kSingleMax = 6 * (size_t)kSingleSpan;      // 49152 elements
 
 __global__ __launch_bounds__(kSingleThreads) void scan_single(const uint32_t* in, uint32_t* out,   // (in == out is allowed)
                                                               size_t n, uint32_t* __restrict__ total) {
-  __shared__ uint32_t wsum[kSingleThreads / 64];
+  // Every span's loads are issued before anything is summed, and one barrier serves all spans: span after span — load,
+  // scan, barrier, store — a six-span scan took 11-17 us, the latency of six dependent global loads and twelve barriers.
+  constexpr int kSpans = (int)(kSingleMax / kSingleSpan);
+  __shared__ uint32_t wsum[kSpans][kSingleThreads / 64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  uint32_t carry = 0;
-  for (size_t start = 0; start < n; start += kSingleSpan) {
-    const size_t base = start + (size_t)threadIdx.x * kScanItems;
-    uint32_t v[kScanItems];
-    uint32_t s = 0;
+  const int spans = (int)((n + kSingleSpan - 1) / kSingleSpan);
+  uint32_t v[kSpans][kScanItems], x[kSpans], s[kSpans];
+  // (a thread's eight words as two 16-byte loads where they are whole and aligned: eight 4-byte loads at a 32-byte stride
+  // across the lanes were what the kernel spent its time on)
+  static_assert(kScanItems == 8, "two uint4 per thread and span");
+  const bool vec = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
 #pragma unroll
-    for (int i = 0; i < kScanItems; ++i) {
-      v[i] = (base + i < n) ? in[base + i] : 0u;
-      s += v[i];
+  for (int k = 0; k < kSpans; ++k) {
+    const size_t base = (size_t)k * kSingleSpan + (size_t)threadIdx.x * kScanItems;
+    if (vec && k < spans && base + kScanItems <= n) {
+      const uint4 a = reinterpret_cast<const uint4*>(in + base)[0], c = reinterpret_cast<const uint4*>(in + base)[1];
+      v[k][0] = a.x; v[k][1] = a.y; v[k][2] = a.z; v[k][3] = a.w;
+      v[k][4] = c.x; v[k][5] = c.y; v[k][6] = c.z; v[k][7] = c.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < kScanItems; ++i) v[k][i] = (k < spans && base + i < n) ? in[base + i] : 0u;
     }
-    uint32_t x = s;
+  }
+#pragma unroll
+  for (int k = 0; k < kSpans; ++k) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) t += v[k][i];
+    s[k] = t;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t y = __shfl_up(x, d, 64);
-      if (lane >= d) x += y;
+      const uint32_t y = __shfl_up(t, d, 64);
+      if (lane >= d) t += y;
     }
-    if (lane == 63) wsum[wid] = x;
-    __syncthreads();
+    x[k] = t;
+    if (lane == 63) wsum[k][wid] = t;
+  }
+  __syncthreads();
+  uint32_t carry = 0;
+#pragma unroll
+  for (int k = 0; k < kSpans; ++k) {
+    if (k >= spans) break;
     uint32_t wbase = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < kSingleThreads / 64; ++w) {
-      const uint32_t t = wsum[w];
+      const uint32_t t = wsum[k][w];
       if (w < wid) wbase += t;
       tot += t;
     }
-    __syncthreads();   // wsum is rewritten by the next span
-    uint32_t ex = carry + wbase + x - s;
+    const size_t base = (size_t)k * kSingleSpan + (size_t)threadIdx.x * kScanItems;
+    uint32_t ex = carry + wbase + x[k] - s[k];
+    if (vec && base + kScanItems <= n) {
+      uint32_t e[kScanItems];
 #pragma unroll
-    for (int i = 0; i < kScanItems; ++i) {
-      if (base + i < n) out[base + i] = ex;
-      ex += v[i];
+      for (int i = 0; i < kScanItems; ++i) {
+        e[i] = ex;
+        ex += v[k][i];
+      }
+      reinterpret_cast<uint4*>(out + base)[0] = make_uint4(e[0], e[1], e[2], e[3]);
+      reinterpret_cast<uint4*>(out + base)[1] = make_uint4(e[4], e[5], e[6], e[7]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < kScanItems; ++i) {
+        if (base + i < n) out[base + i] = ex;
+        ex += v[k][i];
+      }
     }
     carry += tot;
   }

@@ -232,10 +232,10 @@ int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm,
   struct Scratch {   // grow-only device buffers of this thread
     plvs::DevBuf<long long> cnt;
     plvs::DevBuf<uint32_t> send[3], recv[3];
-    plvs::DevBuf<int32_t> sat, all_sat, nsat;
+    plvs::DevBuf<int32_t> sat, all_sat;
   };
   static thread_local Scratch B;
-  constexpr size_t kWords[3] = {8, 8, 20};   // uint32 words of a descriptor, a voxel sum, a run
+  constexpr size_t kWords[3] = {8, 8, 6};   // uint32 words of a descriptor, a voxel sum, a run record (kWireRun)
   int64_t sc[3 * 64], rcv[3 * 64];
   // A rank whose walk fails must not leave its peers blocked inside a collective: it goes through the exchanges with
   // nothing to send and says so in its counts (-1).  Every rank learns of it in the counts exchange and NOBODY applies
@@ -310,33 +310,24 @@ int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm,
     failed = plvs_hip_tsdf_chisel_shard_apply(h, B.recv[0].p, B.recv[1].p, B.recv[2].p, rcv, d_rgb, d_kfid, stream);
     late_failure = failed != PLVS_OK;
   }
-  // ---- voxels whose colour saturated: every rank notes every list
-  int nsat = 0;
+  // ---- voxels whose colour saturated: every rank notes every list.  ONE fixed-size all-gather (up to kSatRows voxels + their
+  // number in a last row; a longer list waits in the handle for the next step — the list is advisory: a run sent for a
+  // saturated voxel is a no-op at its owner), the lengths read on the device: no host read in the feedback.
+  constexpr int kSatRows = 16384;
+  const size_t msg_words = 4 * ((size_t)kSatRows + 1);
+  PLVS_HIP_TRY(B.sat.reserve(msg_words));
+  PLVS_HIP_TRY(B.all_sat.reserve(msg_words * world));
+  PLVS_HIP_TRY(hipMemsetAsync(B.sat.p + 4 * (size_t)kSatRows, 0, 4 * sizeof(int32_t), s));   // (a failed rank announces none)
   if (failed == PLVS_OK && !peer_failed) {
-    rc = plvs_hip_tsdf_chisel_shard_saturated(h, nullptr, 0, &nsat, stream);
-    if (rc != PLVS_OK && rc != PLVS_ERR_CAPACITY) { failed = rc; nsat = 0; }
+    failed = plvs_hip_tsdf_chisel_shard_saturated_message(h, B.sat.p, kSatRows, stream);
+    late_failure = failed != PLVS_OK;
   }
-  PLVS_HIP_TRY(B.nsat.reserve((size_t)world + 1));
-  PLVS_HIP_TRY(hipMemcpyAsync(B.nsat.p + rank, &nsat, sizeof(int32_t), hipMemcpyHostToDevice, s));
-  RCCL_TRY(r->all_gather(B.nsat.p + rank, B.nsat.p, 1, /*ncclInt32*/ 2, rccl_comm, s));
-  int32_t all_n[64];
-  PLVS_HIP_TRY(hipMemcpyAsync(all_n, B.nsat.p, (size_t)world * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  PLVS_HIP_TRY(hipStreamSynchronize(s));
-  int cap = 0;
-  for (int p = 0; p < world; ++p) cap = all_n[p] > cap ? all_n[p] : cap;
-  if (cap > 0) {
-    PLVS_HIP_TRY(B.sat.reserve((size_t)cap * 4));
-    PLVS_HIP_TRY(B.all_sat.reserve((size_t)cap * 4 * world));
-    if (nsat > 0 && failed == PLVS_OK && !peer_failed) {
-      failed = plvs_hip_tsdf_chisel_shard_saturated(h, B.sat.p, cap, &nsat, stream);
-      late_failure = late_failure || failed != PLVS_OK;
-    }
-    RCCL_TRY(r->all_gather(B.sat.p, B.all_sat.p, (size_t)cap * 4, /*ncclInt32*/ 2, rccl_comm, s));
-    for (int p = 0; p < world && failed == PLVS_OK && !peer_failed; ++p) {
-      failed = plvs_hip_tsdf_chisel_shard_note_saturated(h, B.all_sat.p + (size_t)p * cap * 4, all_n[p], stream);
-      late_failure = late_failure || failed != PLVS_OK;
-    }
+  RCCL_TRY(r->all_gather(B.sat.p, B.all_sat.p, msg_words, /*ncclInt32*/ 2, rccl_comm, s));
+  if (failed == PLVS_OK && !peer_failed) {
+    failed = plvs_hip_tsdf_chisel_shard_note_gathered(h, B.all_sat.p, world, kSatRows, stream);
+    late_failure = failed != PLVS_OK;
   }
+  (void)rc;
 #undef RCCL_TRY
   if (failed != PLVS_OK) {
     if (late_failure) {   // (keep this rank's own message, add what it means for the job)

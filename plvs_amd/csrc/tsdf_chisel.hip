@@ -917,7 +917,10 @@ struct plvs_tsdf_chisel {
   uint32_t* h_sh_off = nullptr;      // pinned [128 + 132]: region offsets on their way to the device (pack | apply)
   DevBuf<uint4> sh_seg_reg, sh_rec_reg;
   DevBuf<uint32_t> sh_nrec, sh_owner, sh_slot_owner, sh_src_off, sh_run_ctr, sh_vkey, sh_sat;
+  DevBuf<uint4> sh_run_first;   // per run of a sharded walk: the first wire record's spans + its number of records
   uint32_t sh_nt = 0, sh_runs = 0, sh_nsat = 0;
+  DevBuf<int32_t> sh_wait;   // saturated voxels not yet announced ({chunk x, y, z, voxel}): [sh_wait_first, + sh_wait_count)
+  uint32_t sh_wait_first = 0, sh_wait_count = 0;
   long long* h_sh_counts = nullptr;  // pinned
   int sh_n = 0, sh_nclouds = 0;      // the call in flight (shard_walk -> shard_pack -> shard_apply)
   uint32_t sh_ntiles = 0;            // tiles of the whole point stream
@@ -1466,7 +1469,7 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   h->w_val1.release(); h->w_seg_cnt.release(); h->w_tile_visits.release(); h->w_deferred.release(); h->w_part_off.release(); h->w_multi_idx.release();
   h->pa_wuu.release(); h->pa_w.release(); h->pa_last.release(); h->pa_cnt.release(); h->pa_done.release();
   h->sh_nrec.release(); h->sh_owner.release(); h->halo_row.release();
-  h->sh_ctl.release(); h->sh_seg_reg.release(); h->sh_rec_reg.release(); h->sh_src_off.release(); h->sh_slot_owner.release(); h->sh_run_ctr.release(); h->sh_vkey.release(); h->sh_sat.release();
+  h->sh_ctl.release(); h->sh_seg_reg.release(); h->sh_rec_reg.release(); h->sh_src_off.release(); h->sh_slot_owner.release(); h->sh_run_ctr.release(); h->sh_vkey.release(); h->sh_sat.release(); h->sh_wait.release(); h->sh_run_first.release();
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->side) (void)hipStreamDestroy(h->side);
@@ -2505,6 +2508,7 @@ static int shard_state_clear(plvs_tsdf_chisel* h) {
   PLVS_HIP_TRY(hipMemset(h->d_xcount, 0, 4 * sizeof(int32_t)));
   h->sh_phase = 0;
   h->sh_nsat = 0;
+  h->sh_wait_first = h->sh_wait_count = 0;
   return PLVS_OK;
 }
 
@@ -2532,6 +2536,10 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
   h->sh_nclouds = nclouds;
   h->sh_tiletab.resize(2 * ((size_t)nclouds + 1));
   h->sh_ntiles = plvs::tsdf::fill_tile_table(offsets, nclouds, h->sh_tiletab.data(), kWalkRays);   // (tiles never straddle clouds)
+  if (h->sh_ntiles >= (1u << kWireTileBits)) {
+    plvs::set_error("tsdf_chisel shard_walk: %u tiles in one call exceed the wire format's tile index (split the batch)", h->sh_ntiles);
+    return PLVS_ERR_CAPACITY;
+  }
   h->sh_nt = 0;
   h->sh_runs = 0;
   h->sh_phase = 1;
@@ -2585,13 +2593,18 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
   Pw.shard_rank = 0;
   const TileMap tmap{(uint32_t)N, (uint32_t)rank};
   for (int attempt = 0;; ++attempt) {
-    PLVS_HIP_TRY(h->w_rec.reserve(rec_own + rec_spill));
-    PLVS_HIP_TRY(h->w_seg.reserve(2 * (seg_own + seg_spill)));
+    // (sized by the call's tiles, and the largest buffers of the handle — 64 B of masks per run slot, gigabytes: a stream of
+    // calls of varying length would re-allocate them whenever a call is a little longer than any before, so they grow to
+    // TWICE what a call needs, as in integrate_walk_acc)
+    if (h->w_rec.cap < rec_own + rec_spill) PLVS_HIP_TRY(h->w_rec.reserve(2 * rec_own + rec_spill));
+    if (h->w_seg.cap < 2 * (seg_own + seg_spill)) PLVS_HIP_TRY(h->w_seg.reserve(2 * (2 * seg_own + seg_spill)));
     PLVS_HIP_TRY(h->w_sorted_seg.reserve(h->w_seg.cap));
-    PLVS_HIP_TRY(h->w_runkey.reserve((size_t)nt << h->run_r1_log2));
-    PLVS_HIP_TRY(h->w_masks.reserve(((size_t)nt << h->run_r1_log2) * kMaskWords));
-    PLVS_HIP_TRY(h->dkey0.reserve((size_t)nt << h->run_r1_log2));   // (all a call's runs, whatever their number)
-    PLVS_HIP_TRY(h->w_val0.reserve((size_t)nt << h->run_r1_log2));
+    const size_t run_slots = (size_t)nt << h->run_r1_log2;
+    if (h->w_runkey.cap < run_slots) PLVS_HIP_TRY(h->w_runkey.reserve(2 * run_slots));
+    if (h->w_masks.cap < run_slots * kMaskWords) PLVS_HIP_TRY(h->w_masks.reserve(2 * run_slots * kMaskWords));
+    if (h->dkey0.cap < run_slots) PLVS_HIP_TRY(h->dkey0.reserve(2 * run_slots));   // (all a call's runs, whatever their number)
+    if (h->sh_run_first.cap < run_slots) PLVS_HIP_TRY(h->sh_run_first.reserve(2 * run_slots));   // (first wire record per run)
+    if (h->w_val0.cap < run_slots) PLVS_HIP_TRY(h->w_val0.reserve(2 * run_slots));
     PLVS_HIP_TRY(h->scratch.reserve(scan_scratch_words(nt)));
     PLVS_HIP_TRY(hipMemsetAsync(h->d_wctr, 0, 2 * sizeof(WalkCounters), s));
     PLVS_HIP_TRY(hipMemsetAsync(h->w_chunk_nseg.p, 0, xmax * sizeof(uint32_t), s));
@@ -2625,8 +2638,8 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
     PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, nt, nullptr, h->scratch.p, s));
     hipLaunchKernelGGL(compact_runs, dim3(ceil_div(nt, 4)), dim3(256), 0, s, h->w_runkey.p, h->w_run_cnt.p,
                        h->w_run_off.p, nt, h->run_r1_log2, h->dkey0.p, h->w_val0.p);
-    hipLaunchKernelGGL(shard_run_count, dim3(256), dim3(256), 0, s, h->dkey0.p, &h->d_wctr[0].num_desc,
-                       h->sh_slot_owner.p, N, h->sh_run_ctr.p, h->d_wctr);
+    hipLaunchKernelGGL(shard_run_count, dim3(2048), dim3(256), 0, s, h->dkey0.p, h->w_val0.p, &h->d_wctr[0].num_desc,
+                       h->w_masks.p, h->sh_slot_owner.p, N, h->sh_run_ctr.p, h->sh_run_first.p, h->d_wctr);
     hipLaunchKernelGGL(shard_run_plan, dim3(1), dim3(64), 0, s, h->sh_run_ctr.p, N, h->d_wctr);
     PLVS_KERNEL_CHECK();
     // sizes of the send regions (and whether the walk has to be repeated)
@@ -2707,7 +2720,7 @@ int plvs_hip_tsdf_chisel_shard_pack(plvs_tsdf_chisel* h, void* d_seg_dst, void* 
                      h->sh_src_off.p, N, static_cast<uint4*>(d_seg_dst), static_cast<uint4*>(d_rec_dst));
   if (h->sh_runs > 0)
     hipLaunchKernelGGL(shard_run_pack, dim3(std::min<size_t>(ceil_div((size_t)h->sh_runs, kRunSpan), 4096)), dim3(256), 0, s,
-                       h->dkey0.p, h->w_val0.p, &h->d_wctr[0].num_desc, h->w_masks.p, h->run_r1_log2,
+                       h->dkey0.p, h->w_val0.p, &h->d_wctr[0].num_desc, h->w_masks.p, h->sh_run_first.p, h->run_r1_log2,
                        TileMap{(uint32_t)std::max(1, h->prm.shard_count), h->prm.shard_count > 1 ? (uint32_t)h->prm.shard_rank : 0u},
                        h->xdir.slot_ids,
                        h->sh_slot_owner.p, h->sh_run_ctr.p + 64, h->sh_run_ctr.p + 128, static_cast<uint32_t*>(d_run_dst));
@@ -2873,6 +2886,49 @@ int plvs_hip_tsdf_chisel_shard_saturated(plvs_tsdf_chisel* h, int32_t* d_voxels,
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(shard_saturated_ids, dim3(ceil_div((size_t)h->sh_nsat, 256)), dim3(256), 0, s, h->sh_sat.p, h->sh_nsat,
                      h->dir.slot_ids, d_voxels);
+  PLVS_KERNEL_CHECK();
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_chisel_shard_saturated_message(plvs_tsdf_chisel* h, int32_t* d_msg, int rows, void* stream) {
+  PLVS_REQUIRE(h && d_msg && rows > 0, "bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (h->sh_nsat > 0) {   // the last shard_apply's voxels join the waiting list
+    const size_t need = 4 * ((size_t)h->sh_wait_first + h->sh_wait_count + h->sh_nsat);
+    if (need > h->sh_wait.cap) {
+      DevBuf<int32_t> grown;
+      PLVS_HIP_TRY(grown.reserve(need));
+      if (h->sh_wait_count)
+        PLVS_HIP_TRY(hipMemcpyAsync(grown.p, h->sh_wait.p + 4 * (size_t)h->sh_wait_first, 16 * (size_t)h->sh_wait_count,
+                                    hipMemcpyDeviceToDevice, s));
+      PLVS_HIP_TRY(hipStreamSynchronize(s));
+      h->sh_wait.release();
+      h->sh_wait = grown;
+      h->sh_wait_first = 0;
+    }
+    hipLaunchKernelGGL(shard_saturated_ids, dim3(ceil_div((size_t)h->sh_nsat, 256)), dim3(256), 0, s, h->sh_sat.p, h->sh_nsat,
+                       h->dir.slot_ids, h->sh_wait.p + 4 * ((size_t)h->sh_wait_first + h->sh_wait_count));
+    h->sh_wait_count += h->sh_nsat;
+    h->sh_nsat = 0;
+  }
+  const uint32_t k = std::min<uint32_t>(h->sh_wait_count, (uint32_t)rows);
+  hipLaunchKernelGGL(shard_sat_message, dim3(std::max<unsigned>(1u, ceil_div((size_t)k, 256))), dim3(256), 0, s,
+                     h->sh_wait.p ? h->sh_wait.p + 4 * (size_t)h->sh_wait_first : (const int32_t*)nullptr, k, (uint32_t)rows, d_msg);
+  PLVS_KERNEL_CHECK();
+  h->sh_wait_first += k;
+  h->sh_wait_count -= k;
+  if (h->sh_wait_count == 0) h->sh_wait_first = 0;
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_chisel_shard_note_gathered(plvs_tsdf_chisel* h, const int32_t* d_gathered, int nranks, int rows, void* stream) {
+  PLVS_REQUIRE(h && d_gathered && nranks >= 1 && rows > 0, "bad argument");
+  PLVS_REQUIRE(h->prm.order_free != 0 && h->prm.shard_count >= 1, "not a ray-sharded map");
+  int rc = shard_state_init(h);
+  if (rc != PLVS_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(shard_note_gathered, dim3(ceil_div((size_t)rows, 256), (unsigned)nranks), dim3(256), 0, s, d_gathered,
+                     (uint32_t)rows, h->xdir, h->d_xcount, reinterpret_cast<uint32_t*>(h->d_xcount + 1), h->x_sat);
   PLVS_KERNEL_CHECK();
   return PLVS_OK;
 }

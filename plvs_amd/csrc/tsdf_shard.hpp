@@ -20,7 +20,8 @@
 //                 sums (N per voxel at most).  The sums are integers: the result is bit-identical to the single-device order-free
 //                 integrate whatever N is.
 //                 Colours (the truncating u8 mean is order dependent below weight 254): the received runs
-//                 (voxel, tile, ray mask) are sorted by (voxel, tile) and folded as on a single device.  A walker
+//                 (voxel, tile, the tile's rays as spans: kWireRun, tsdf_walk.hpp) are sorted by (voxel, tile) and
+//                 folded as on a single device.  A walker
 //                 sends a run for every voxel it does not KNOW to be saturated; owners list the voxels that
 //                 reach 254 in a call (shard_saturated), the lists are all-gathered and every rank notes them in
 //                 its walk directory (shard_note_saturated).  Late knowledge only costs surplus runs (the fold
@@ -137,17 +138,41 @@ __global__ __launch_bounds__(256) void shard_translate(const uint4* __restrict__
 }
 
 // ---- colour runs
-// Runs per destination (dkey = dense run keys in local tile order, slot * 4096 + voxel of the walk directory).
-__global__ __launch_bounds__(256) void shard_run_count(const uint32_t* __restrict__ dkey, const uint32_t* __restrict__ nd_dev,
+// Wire records per destination (dkey = dense run keys in local tile order, slot * 4096 + voxel of the walk directory; dval
+// = the run's place in the per-tile regions): a run takes one record per six spans of its mask (kWireRun, tsdf_walk.hpp).
+__global__ __launch_bounds__(256) void shard_run_count(const uint32_t* __restrict__ dkey, const uint32_t* __restrict__ dval,
+                                                       const uint32_t* __restrict__ nd_dev, const uint32_t* __restrict__ masks,
                                                        const uint32_t* __restrict__ slot_owner, int nranks,
-                                                       uint32_t* __restrict__ run_counts, const WalkCounters* __restrict__ ctr) {
+                                                       uint32_t* __restrict__ run_counts, uint4* __restrict__ run_first,
+                                                       const WalkCounters* __restrict__ ctr) {
+  // run_first[j] = {the spans of the run's first record (three words), its number of records}: shard_run_pack reads the
+  // 64-byte mask again only for the few runs with more than six spans.
   __shared__ uint32_t hist[64];
   if (ctr->err) return;   // (a walk that ran out of room leaves unwritten run slots behind: the host repeats the call)
   if (threadIdx.x < 64) hist[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t nd = *nd_dev;
-  for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < nd; j += gridDim.x * 256u)
-    atomicAdd(&hist[slot_owner[dkey[j] >> 12]], 1u);
+  for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < nd; j += gridDim.x * 256u) {
+    uint32_t m[kMaskWords];
+    const uint4* m4 = reinterpret_cast<const uint4*>(masks + (size_t)dval[j] * kMaskWords);
+#pragma unroll
+    for (int q = 0; q < kMaskWords / 4; ++q) {
+      const uint4 a = m4[q];
+      m[4 * q] = a.x; m[4 * q + 1] = a.y; m[4 * q + 2] = a.z; m[4 * q + 3] = a.w;
+    }
+    uint32_t acc[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, have = 0;
+    const uint32_t spans = mask_spans(m, [&](uint32_t first, uint32_t len) {
+      if (have < kWireSpans) {
+        const uint32_t code = first | ((len - 1u) << 9), sh = (have & 1u) * 16u;
+        uint32_t& word = acc[have >> 1];
+        word = (word & ~(0xFFFFu << sh)) | (code << sh);
+      }
+      ++have;
+    });
+    const uint32_t nrec = max(1u, (spans + kWireSpans - 1u) / kWireSpans);   // (<= 43)
+    run_first[j] = make_uint4(acc[0], acc[1], acc[2], nrec);
+    atomicAdd(&hist[slot_owner[dkey[j] >> 12]], nrec);
+  }
   __syncthreads();
   if ((int)threadIdx.x < nranks && hist[threadIdx.x]) atomicAdd(&run_counts[threadIdx.x], hist[threadIdx.x]);
 }
@@ -164,12 +189,12 @@ __global__ void shard_run_plan(uint32_t* __restrict__ rc, int nranks, const Walk
   }
 }
 
-// Wire form of a run, kWireRun words: {chunk key low, chunk key high, voxel, tile, ray mask}.  The runs of a
-// destination keep no particular order (the owner sorts by voxel and tile); a workgroup reserves its places
-// with one atomic per destination.
+// The records of a destination keep no particular order between runs (the owner sorts by voxel and tile; the records of
+// ONE run are consecutive and in span order); a workgroup reserves its places with one atomic per destination.
 constexpr int kRunSpan = 1024;
 __global__ __launch_bounds__(256) void shard_run_pack(const uint32_t* __restrict__ dkey, const uint32_t* __restrict__ dval,
                                                       const uint32_t* __restrict__ nd_dev, const uint32_t* __restrict__ masks,
+                                                      const uint4* __restrict__ run_first,
                                                       uint32_t r1_log2, TileMap tmap, const int32_t* __restrict__ slot_ids,
                                                       const uint32_t* __restrict__ slot_owner, const uint32_t* __restrict__ run_base,
                                                       uint32_t* __restrict__ run_fill, uint32_t* __restrict__ out) {
@@ -185,7 +210,7 @@ __global__ __launch_bounds__(256) void shard_run_pack(const uint32_t* __restrict
       own[q] = 0xFFFFFFFFu;
       if (j < nd) {
         own[q] = slot_owner[dkey[j] >> 12];
-        rnk[q] = atomicAdd(&hist[own[q]], 1u);
+        rnk[q] = atomicAdd(&hist[own[q]], run_first[j].w);
       }
     }
     __syncthreads();
@@ -199,11 +224,40 @@ __global__ __launch_bounds__(256) void shard_run_pack(const uint32_t* __restrict
       const int32_t* id = slot_ids + 3 * (size_t)(key >> 12);
       unsigned long long ck = 0;
       pack_block(id[0], id[1], id[2], &ck);
-      uint4* dst = reinterpret_cast<uint4*>(out + (size_t)(base[own[q]] + rnk[q]) * kWireRun);
+      const uint2 head = make_uint2((uint32_t)ck, (uint32_t)(ck >> 32));
+      const uint32_t vt = (key & 0xFFFu) | (tmap.tile_of(val >> r1_log2) << 12);
+      uint2* dst = reinterpret_cast<uint2*>(out + (size_t)(base[own[q]] + rnk[q]) * kWireRun);
+      const uint4 first = run_first[j];
+      if (first.w == 1u) {   // (nearly every run)
+        dst[0] = head;
+        dst[1] = make_uint2(vt, first.x);
+        dst[2] = make_uint2(first.y, first.z);
+        continue;
+      }
+      uint32_t m[kMaskWords];
       const uint4* m4 = reinterpret_cast<const uint4*>(masks + (size_t)val * kMaskWords);
-      dst[0] = make_uint4((uint32_t)ck, (uint32_t)(ck >> 32), key & 0xFFFu, tmap.tile_of(val >> r1_log2));
 #pragma unroll
-      for (int w = 0; w < kMaskWords / 4; ++w) dst[1 + w] = m4[w];
+      for (int w = 0; w < kMaskWords / 4; ++w) {
+        const uint4 a = m4[w];
+        m[4 * w] = a.x; m[4 * w + 1] = a.y; m[4 * w + 2] = a.z; m[4 * w + 3] = a.w;
+      }
+      uint32_t acc[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, have = 0;
+      auto flush = [&]() {
+        dst[0] = head;
+        dst[1] = make_uint2(vt, acc[0]);
+        dst[2] = make_uint2(acc[1], acc[2]);
+        dst += 3;
+        acc[0] = acc[1] = acc[2] = 0xFFFFFFFFu;
+        have = 0;
+      };
+      const uint32_t spans = mask_spans(m, [&](uint32_t first, uint32_t len) {
+        if (have == kWireSpans) flush();
+        const uint32_t code = first | ((len - 1u) << 9), sh = (have & 1u) * 16u;
+        uint32_t& word = acc[have >> 1];
+        word = (word & ~(0xFFFFu << sh)) | (code << sh);
+        ++have;
+      });
+      if (have || spans == 0u) flush();
     }
     __syncthreads();
   }
@@ -216,7 +270,9 @@ __global__ __launch_bounds__(256) void shard_run_translate(const uint32_t* __res
                                                            uint32_t* __restrict__ tile, uint32_t* __restrict__ val) {
   const uint32_t j = blockIdx.x * 256u + threadIdx.x;
   if (j >= total) return;
-  const uint4 hd = *reinterpret_cast<const uint4*>(runs + (size_t)j * kWireRun);
+  const uint2 ck = reinterpret_cast<const uint2*>(runs + (size_t)j * kWireRun)[0];
+  const uint32_t vt = runs[(size_t)j * kWireRun + 2];
+  const uint4 hd = make_uint4(ck.x, ck.y, vt & 0xFFFu, vt >> 12);
   const unsigned long long key = (unsigned long long)hd.x | ((unsigned long long)hd.y << 32);
   const int slot = dir_find(dir, (int)((key >> 42) & 0x1FFFFFu) - kCoordBias, (int)((key >> 21) & 0x1FFFFFu) - kCoordBias,
                             (int)(key & 0x1FFFFFu) - kCoordBias);
@@ -250,6 +306,29 @@ __global__ void shard_note_saturated(const int32_t* __restrict__ list, uint32_t 
                                      uint32_t* __restrict__ err, uint32_t* __restrict__ sat) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const int32_t* e = list + 4 * (size_t)i;
+  const int slot = dir_find_or_insert(xdir, e[0], e[1], e[2], xcount, err);
+  if (slot < 0) return;
+  const uint32_t v = (uint32_t)slot * (uint32_t)kChunkVox + ((uint32_t)e[3] & 0xFFFu);
+  atomicOr(&sat[v >> 5], 1u << (v & 31u));
+}
+
+
+// The rank's message for the saturation all-gather: rows [0, k) = waiting voxels, row `rows` = {k, 0, 0, 0}.
+__global__ void shard_sat_message(const int32_t* __restrict__ wait, uint32_t k, uint32_t rows, int32_t* __restrict__ msg) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < k) reinterpret_cast<int4*>(msg)[i] = reinterpret_cast<const int4*>(wait)[i];
+  if (i == 0) reinterpret_cast<int4*>(msg)[rows] = make_int4((int)k, 0, 0, 0);
+}
+
+// The gathered messages of all ranks (nranks x (rows + 1) entries of {chunk x, y, z, voxel}) noted in one launch: every
+// message's length is read from its last row on the device — no host read between the all-gather and this.
+__global__ void shard_note_gathered(const int32_t* __restrict__ gathered, uint32_t rows, Directory xdir, int32_t* __restrict__ xcount,
+                                    uint32_t* __restrict__ err, uint32_t* __restrict__ sat) {
+  const int32_t* list = gathered + 4 * (size_t)blockIdx.y * (rows + 1);
+  const uint32_t k = min((uint32_t)list[4 * (size_t)rows], rows);
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
   const int32_t* e = list + 4 * (size_t)i;
   const int slot = dir_find_or_insert(xdir, e[0], e[1], e[2], xcount, err);
   if (slot < 0) return;

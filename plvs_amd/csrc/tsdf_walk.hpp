@@ -2075,8 +2075,50 @@ __global__ __launch_bounds__(1024) void sort_runs_small(const uint32_t* __restri
 constexpr int kFoldWaves = 4;
 // Where the fold finds run `val`: the per-tile regions of the walk (words = kMaskWords: the mask at
 // base + val * words, the tile from the slot number) or the runs an owner received in the ray-sharded integrate
-// (words = kWireRun: {chunk key, voxel, tile, mask}).
-constexpr uint32_t kWireRun = 4 + kMaskWords;
+// (words = kWireRun: {chunk key (2 words), voxel | tile << 12, six ray spans}).
+//
+// Wire form of a run (round 4; it was the 512-bit mask behind a 16-byte header, 80 bytes): the rays of a tile that see
+// one voxel are a few stretches of consecutive points (neighbouring pixels of one or two image rows), so the mask
+// travels as SPANS, 16 bits each: first ray (9 bits) | length - 1 (7 bits) << 9, 0xFFFF = none.  Six spans per
+// 24-byte record; a run with more spans (or one longer than 128 rays) continues in further records of the same
+// (voxel, tile), which the stable sorts keep in order.
+constexpr uint32_t kWireRun = 6;
+constexpr uint32_t kWireSpans = 6;
+constexpr uint32_t kSpanNone = 0xFFFFu;
+constexpr uint32_t kWireTileBits = 20;   // tile index of the call in the upper bits of word 2
+// Spans of a ray mask, in ascending order: calls emit(start, length) for each (length <= 128); returns their number.
+template <typename Emit>
+__device__ __forceinline__ uint32_t mask_spans(const uint32_t* m, Emit emit) {
+  uint32_t n = 0;
+  int start = -1;   // first ray of the open stretch
+  auto close = [&](uint32_t end) {
+    uint32_t first = (uint32_t)start, len = end - first;
+    for (; len > 128u; first += 128u, len -= 128u, ++n) emit(first, 128u);
+    emit(first, len);
+    ++n;
+    start = -1;
+  };
+#pragma unroll
+  for (int w = 0; w < kMaskWords; ++w) {
+    const uint32_t bits = m[w];
+    uint32_t pos = 0;
+    while (pos < 32u) {
+      if (start < 0) {   // the next one at or after pos
+        const uint32_t rest = bits >> pos;
+        if (rest == 0u) break;
+        pos += (uint32_t)__ffs((int)rest) - 1u;
+        start = w * 32 + (int)pos;
+      } else {           // the next zero
+        const uint32_t rest = ~bits >> pos;
+        if (rest == 0u) break;   // ones to the end of the word: the stretch goes on
+        pos += (uint32_t)__ffs((int)rest) - 1u;
+        close((uint32_t)w * 32u + pos);
+      }
+    }
+  }
+  if (start >= 0) close((uint32_t)kMaskWords * 32u);
+  return n;
+}
 struct RunSrc {
   const uint32_t* base;
   uint32_t words, r1_log2;
@@ -2135,19 +2177,32 @@ __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
         for (int w = 0; w < kMaskWords; ++w) m[w] = 0;
         size_t p0 = 0;
         uint32_t cnt = 0;
+        uint32_t sp[kWireSpans];   // (received runs: the spans of the record)
+#pragma unroll
+        for (int q = 0; q < (int)kWireSpans; ++q) sp[q] = kSpanNone;
+        const bool wire = src.words == kWireRun;
         if (mine) {
           const uint32_t val = sorted_val[j];
           const uint32_t* run = src.base + (size_t)val * src.words;
-          const uint4* m4 = reinterpret_cast<const uint4*>(run + (src.words - kMaskWords));
+          uint32_t gt;
+          if (wire) {
+            const uint2 a = reinterpret_cast<const uint2*>(run)[1], c = reinterpret_cast<const uint2*>(run)[2];
+            gt = a.x >> 12;
+            sp[0] = a.y & 0xFFFFu; sp[1] = a.y >> 16; sp[2] = c.x & 0xFFFFu; sp[3] = c.x >> 16; sp[4] = c.y & 0xFFFFu; sp[5] = c.y >> 16;
 #pragma unroll
-          for (int q = 0; q < kMaskWords / 4; ++q) {
-            const uint4 a = m4[q];
-            m[4 * q] = a.x; m[4 * q + 1] = a.y; m[4 * q + 2] = a.z; m[4 * q + 3] = a.w;
+            for (int q = 0; q < (int)kWireSpans; ++q) cnt += sp[q] == kSpanNone ? 0u : (sp[q] >> 9) + 1u;
+          } else {
+            const uint4* m4 = reinterpret_cast<const uint4*>(run);
+#pragma unroll
+            for (int q = 0; q < kMaskWords / 4; ++q) {
+              const uint4 a = m4[q];
+              m[4 * q] = a.x; m[4 * q + 1] = a.y; m[4 * q + 2] = a.z; m[4 * q + 3] = a.w;
+            }
+            gt = src.tmap.tile_of(val >> src.r1_log2);
+#pragma unroll
+            for (int w = 0; w < kMaskWords; ++w) cnt += (uint32_t)__popc(m[w]);
           }
-          const uint32_t gt = src.words == kWireRun ? run[3] : src.tmap.tile_of(val >> src.r1_log2);
           p0 = src.tile_first ? (size_t)src.tile_first[gt] : (size_t)tile_span(src.offsets, src.nclouds, gt, kWalkRays).first;
-#pragma unroll
-          for (int w = 0; w < kMaskWords; ++w) cnt += (uint32_t)__popc(m[w]);
         }
         uint32_t inc = cnt;   // prefix over the voxel's eight lanes
 #pragma unroll
@@ -2156,13 +2211,22 @@ __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
           if (sub >= d) inc += up;
         }
         uint32_t at = havev + inc - cnt;
+        if (wire) {
 #pragma unroll
-        for (int w = 0; w < kMaskWords; ++w) {
-          uint32_t bits = m[w];
-          while (bits && at < needv) {
-            const int bpos = __ffs((int)bits) - 1;
-            bits &= bits - 1u;
-            stage[wid][vl][at++] = (uint32_t)(p0 + (size_t)(w * 32 + bpos));   // the visit's point; its colour below
+          for (int q = 0; q < (int)kWireSpans; ++q) {
+            if (sp[q] == kSpanNone) continue;
+            const uint32_t first = sp[q] & 0x1FFu, len = (sp[q] >> 9) + 1u;
+            for (uint32_t k = 0; k < len && at < needv; ++k) stage[wid][vl][at++] = (uint32_t)(p0 + (size_t)(first + k));
+          }
+        } else {
+#pragma unroll
+          for (int w = 0; w < kMaskWords; ++w) {
+            uint32_t bits = m[w];
+            while (bits && at < needv) {
+              const int bpos = __ffs((int)bits) - 1;
+              bits &= bits - 1u;
+              stage[wid][vl][at++] = (uint32_t)(p0 + (size_t)(w * 32 + bpos));   // the visit's point; its colour below
+            }
           }
         }
         havev += (uint32_t)__shfl((int)inc, 7, 8);

@@ -59,21 +59,23 @@ def allgather_block_lists(local_ids, count, cap, group=None, padded=False):
 def exchange_segments(send_seg, send_rec, send_run, send_counts, group=None):
     """The all-to-all of the ray-sharded integrate (TsdfChisel.shard_walk / shard_pack / shard_apply).
 
-    send_seg [S, 8], send_rec [R, 8], send_run [U, 20] int32 tensors grouped by destination rank in rank order,
+    send_seg [S, 8], send_rec [R, 8], send_run [U, 6] int32 tensors grouped by destination rank in rank order,
     send_counts [world, 3] (descriptors, voxel sums, runs per destination).  Returns (recv_seg, recv_rec, recv_run,
     recv_counts) grouped by source rank.  Two collectives: the counts, then ONE group of point-to-point
     operations carrying the three payloads of every pair of ranks (RCCL: a single grouped launch of ncclSend /
     ncclRecv pairs over xGMI — what an all-to-all is made of; gloo in the CPU tests); a rank's messages to itself
-    are copies."""
+    are copies (at world size 1 the send buffers are handed back as they are)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = send_seg.device
     send_counts = np.ascontiguousarray(send_counts, dtype=np.int64).reshape(world, 3)
+    if world == 1:      # everything stays here: the send buffers ARE the receive buffers (no copy, no count exchange)
+        return send_seg.reshape(-1, 8), send_rec.reshape(-1, 8), send_run.reshape(-1, RUN_WORDS), send_counts.copy()
     sc = torch.from_numpy(send_counts.copy()).to(dev)
     rc = torch.zeros_like(sc)
     dist.all_to_all_single(rc, sc, group=group)
     recv_counts = rc.cpu().numpy()
-    send = [send_seg.reshape(-1, 8), send_rec.reshape(-1, 8), send_run.reshape(-1, 20)]
-    recv = [torch.empty((int(recv_counts[:, k].sum()), w), dtype=send[k].dtype, device=dev) for k, w in enumerate((8, 8, 20))]
+    send = [send_seg.reshape(-1, 8), send_rec.reshape(-1, 8), send_run.reshape(-1, RUN_WORDS)]
+    recv = [torch.empty((int(recv_counts[:, k].sum()), w), dtype=send[k].dtype, device=dev) for k, w in enumerate((8, 8, RUN_WORDS))]
     so, ro, ops = [0, 0, 0], [0, 0, 0], []
     for p in range(world):
         for k in range(3):
@@ -96,6 +98,7 @@ def exchange_segments(send_seg, send_rec, send_run, send_counts, group=None):
     return recv[0], recv[1], recv[2], recv_counts
 
 
+RUN_WORDS = 6         # int32 words of a colour-run record on the wire (kWireRun, plvs_amd/csrc/tsdf_walk.hpp)
 SAT_ROWS = 16384      # newly saturated voxels a rank reports per step (16 B each: a 256 KiB message); a longer list waits for the next step
 
 
@@ -124,7 +127,7 @@ def sharded_integrate(tsdf, d_xyz, d_rgb, d_kfid, offsets, d_Twc, group=None, ti
     lap("walk")
     seg = torch.empty((int(counts[:, 0].sum()), 8), dtype=torch.int32, device=dev)    # (shard_pack fills every row)
     rec = torch.empty((int(counts[:, 1].sum()), 8), dtype=torch.int32, device=dev)
-    run = torch.empty((int(counts[:, 2].sum()), 20), dtype=torch.int32, device=dev)
+    run = torch.empty((int(counts[:, 2].sum()), RUN_WORDS), dtype=torch.int32, device=dev)
     tsdf.shard_pack(seg, rec, run)
     lap("pack")
     rseg, rrec, rrun, rcounts = exchange_segments(seg, rec, run, counts, group)
@@ -133,24 +136,13 @@ def sharded_integrate(tsdf, d_xyz, d_rgb, d_kfid, offsets, d_Twc, group=None, ti
     lap("apply")
     # voxels whose colour saturated in this call: every rank stops sending their runs.  One fixed-size all-gather
     # (list + its length in a last row); the list is advisory — a run sent for a saturated voxel is a no-op at its
-    # owner — so what does not fit waits for the next step.
-    sat = tsdf.shard_saturated()
-    backlog = getattr(tsdf, "_sat_backlog", None)
-    if backlog is not None and backlog.shape[0]:
-        sat = torch.cat([backlog, sat])
-    k = min(int(sat.shape[0]), SAT_ROWS)
-    tsdf._sat_backlog = sat[k:].clone() if sat.shape[0] > k else None
-    mine = torch.empty((SAT_ROWS + 1, 4), dtype=torch.int32, device=dev)       # (rows past k are never read)
-    if k:
-        mine[:k] = sat[:k]
-    mine[SAT_ROWS] = torch.tensor([k, 0, 0, 0], dtype=torch.int32)
+    # owner — so what does not fit waits (with the handle) for the next step.  No host read: the lengths are read on
+    # the device.
+    mine = torch.empty((SAT_ROWS + 1, 4), dtype=torch.int32, device=dev)       # (rows past the length are never read)
+    tsdf.shard_saturated_message(mine, SAT_ROWS)
     flat = torch.empty((world * (SAT_ROWS + 1), 4), dtype=torch.int32, device=dev)
     dist.all_gather_into_tensor(flat, mine, group=group)
-    gathered = flat.view(world, SAT_ROWS + 1, 4)
-    ks = gathered[:, SAT_ROWS, 0].cpu()
-    for r in range(world):
-        if int(ks[r]):
-            tsdf.shard_note_saturated(gathered[r, : int(ks[r])])
+    tsdf.shard_note_gathered(flat, world, SAT_ROWS)
     lap("feedback")
     return counts
 

@@ -259,7 +259,7 @@ class TsdfChisel:
     # ---- ray-sharded multi-GPU integrate (order_free, shard_count > 1): walk -> pack -> exchange -> apply
     def shard_walk(self, d_xyz, offsets, d_Twc):
         """Phase 1: this rank walks its tiles of the point stream (tile t belongs to rank t % shard_count).
-        Returns the int64 array [shard_count, 3] of (descriptors, voxel sums, colour runs) bound for every rank."""
+        Returns the int64 array [shard_count, 3] of (descriptors, voxel sums, colour-run records) bound for every rank."""
         offsets = np.ascontiguousarray(offsets, dtype=np.int32)
         counts = np.zeros((self.params.shard_count, 3), np.int64)
         f = _lib.lib.plvs_hip_tsdf_chisel_shard_walk
@@ -269,7 +269,7 @@ class TsdfChisel:
         return counts
 
     def shard_pack(self, d_seg, d_rec, d_run):
-        """Phase 2: fills the send buffers (torch int32 tensors [descriptors, 8], [sums, 8] and [runs, 20]),
+        """Phase 2: fills the send buffers (torch int32 tensors [descriptors, 8], [sums, 8] and [run records, 6]),
         each grouped by destination rank in rank order."""
         f = _lib.lib.plvs_hip_tsdf_chisel_shard_pack
         f.argtypes = [ctypes.c_void_p] * 5
@@ -302,6 +302,19 @@ class TsdfChisel:
         f = _lib.lib.plvs_hip_tsdf_chisel_shard_note_saturated
         f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         _lib.check(f(self._h, _lib.t_ptr(d_voxels), int(d_voxels.shape[0]), _lib.current_stream_ptr()))
+
+    def shard_saturated_message(self, d_msg, rows):
+        """This rank's message for the saturation all-gather (int32 tensor [rows + 1, 4]): up to `rows` waiting
+        voxels, their number in the last row; the rest waits with the handle for the next step."""
+        f = _lib.lib.plvs_hip_tsdf_chisel_shard_saturated_message
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        _lib.check(f(self._h, _lib.t_ptr(d_msg), int(rows), _lib.current_stream_ptr()))
+
+    def shard_note_gathered(self, d_gathered, nranks, rows):
+        """Notes the all-gathered messages of `nranks` ranks ([nranks * (rows + 1), 4]); no host read."""
+        f = _lib.lib.plvs_hip_tsdf_chisel_shard_note_gathered
+        f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        _lib.check(f(self._h, _lib.t_ptr(d_gathered), int(nranks), int(rows), _lib.current_stream_ptr()))
 
     def last_stats(self):
         s = _lib.TsdfStats()

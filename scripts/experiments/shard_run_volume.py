@@ -17,4 +17,4 @@ for lap in range(10):
     t.shard_apply(bufs[0], bufs[1], bufs[2], c.reshape(1,3), rgb, kfid)
     sat = t.shard_saturated()
     if sat.shape[0]: t.shard_note_saturated(sat)
-    print("lap %d: descriptors %d, voxel sums %d, colour runs %d (%.1f MB), newly saturated %d" % (lap, c[0,0], c[0,1], c[0,2], c[0,2]*80/1e6, sat.shape[0]))
+    print("lap %d: descriptors %d, voxel sums %d, colour-run records %d (%.1f MB), newly saturated %d" % (lap, c[0,0], c[0,1], c[0,2], c[0,2]*24/1e6, sat.shape[0]))

@@ -36,9 +36,10 @@ for i, b in enumerate(steps):
     tim = {}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    sharded_integrate(t, *b, timings=tim)
+    c = sharded_integrate(t, *b, timings=tim)
     torch.cuda.synchronize()
-    print(i, round((time.perf_counter() - t0) * 1e3, 2), {k: round(v, 2) for k, v in tim.items()}, flush=True)
+    print(i, round((time.perf_counter() - t0) * 1e3, 2), {k: round(v, 2) for k, v in tim.items()},
+          "descriptors / voxel sums / runs sent:", c.sum(axis=0).tolist(), flush=True)
 for i, b in enumerate(steps[:6]):
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -45,7 +45,7 @@ for s in range(STEPS + 2):
     counts = lap("walk", lambda: t.shard_walk(xyz, offsets, Twc))
     seg = torch.empty((int(counts[:, 0].sum()), 8), dtype=torch.int32, device="cuda")
     rec = torch.empty((int(counts[:, 1].sum()), 8), dtype=torch.int32, device="cuda")
-    run = torch.empty((int(counts[:, 2].sum()), 20), dtype=torch.int32, device="cuda")
+    run = torch.empty((int(counts[:, 2].sum()), 6), dtype=torch.int32, device="cuda")
     lap("pack", lambda: t.shard_pack(seg, rec, run))
     rs, rr, ru, rc = lap("exchange", lambda: shard.exchange_segments(seg, rec, run, counts))
     lap("apply", lambda: t.shard_apply(rs, rr, ru, rc, rgb, kfid))

@@ -113,7 +113,7 @@ def _worker_segments(rank, world, port, q):
     # stamped with (src, dst, index) so that the receiver can tell where each row comes from
     counts = np.array([[rank + 2 * d, 3 * rank + d, rank * d] for d in range(world)], np.int64)
     bufs = []
-    for k, width in enumerate((8, 8, 20)):
+    for k, width in enumerate((8, 8, 6)):
         rows = []
         for d in range(world):
             for i in range(counts[d, k]):
@@ -121,7 +121,7 @@ def _worker_segments(rank, world, port, q):
         bufs.append(torch.tensor(rows, dtype=torch.int32).reshape(-1, width))
     seg, rec, run, rc = shard_mod.exchange_segments(bufs[0], bufs[1], bufs[2], counts)
     ok = True
-    for k, (got, width) in enumerate(((seg, 8), (rec, 8), (run, 20))):
+    for k, (got, width) in enumerate(((seg, 8), (rec, 8), (run, 6))):
         want = []
         for src in range(world):
             n = [src + 2 * rank, 3 * src + rank, src * rank][k]
@@ -180,11 +180,15 @@ class _FakeIntegrate:
         assert self.packed
         self.applied = (seg.clone(), rec.clone(), run.clone(), np.array(counts))
 
-    def shard_saturated(self):
-        return torch.tensor([[self.rank, 0, 0, v] for v in range(self.rank + 1)], dtype=torch.int32).reshape(-1, 4)
+    def shard_saturated_message(self, msg, rows):
+        mine = torch.tensor([[self.rank, 0, 0, v] for v in range(self.rank + 1)], dtype=torch.int32).reshape(-1, 4)
+        msg[: mine.shape[0]] = mine
+        msg[rows] = torch.tensor([mine.shape[0], 0, 0, 0], dtype=torch.int32)
 
-    def shard_note_saturated(self, voxels):
-        self.noted.append(voxels.clone())
+    def shard_note_gathered(self, gathered, nranks, rows):
+        g = gathered.view(nranks, rows + 1, 4)
+        for r in range(nranks):
+            self.noted.append(g[r, : int(g[r, rows, 0])].clone())
 
 
 def _worker_sharded_integrate(rank, world, port, q):
@@ -205,7 +209,7 @@ def _worker_sharded_integrate(rank, world, port, q):
         counts = shard_mod.sharded_integrate(t, xyz, None, None, np.array([0, 4], np.int32), None, timings=timings)
         ok &= np.array_equal(counts, t._counts())
         seg, rec, run, rc = t.applied
-        for k, (got, width) in enumerate(((seg, 8), (rec, 8), (run, 20))):
+        for k, (got, width) in enumerate(((seg, 8), (rec, 8), (run, 6))):
             want = []
             for src in range(world):
                 n = [src + 2 * rank, 3 * src + rank + 1, src * rank][k]

@@ -19,7 +19,7 @@ def _batch(kfs):
     return xyz, rgb, kfid, offsets, Twc
 
 
-WIDTHS = (8, 8, 20)   # int32 words of a descriptor, a voxel sum, a colour run
+WIDTHS = (8, 8, 6)   # int32 words of a descriptor, a voxel sum, a colour-run record
 
 
 def virtual_all_to_all(counts, bufs):
@@ -93,6 +93,108 @@ def test_hip_ray_sharded_integrate_equals_the_single_device_map(world):
     saturated = sum(int(((single.get_chunk(*cid)[3] >> 24) >= 254).sum()) for cid in ids)
     assert saturated > 0, "the scene must drive some colours to saturation for the test to cover the feedback"
     assert runs_sent[1] < runs_sent[0], "walkers stop sending the runs of voxels reported saturated"
+    for t in ranks + [single]:
+        t.close()
+
+
+def sharded_step_messages(ranks, xyz, rgb, kfid, offsets, Twc, rows):
+    """sharded_step with the feedback in its message form (what plvs_amd.shard.sharded_integrate does): fixed-size
+    messages of `rows` voxels + a length row, gathered, noted without a host read.  Returns the voxels announced."""
+    world = len(ranks)
+    counts = [t.shard_walk(xyz, offsets, Twc) for t in ranks]
+    bufs = [send_buffers(t, c) for t, c in zip(ranks, counts)]
+    torch.cuda.synchronize()
+    for t, (seg, rec, run, rc) in zip(ranks, virtual_all_to_all(counts, bufs)):
+        t.shard_apply(seg, rec, run, rc, rgb, kfid)
+    gathered = torch.full((world * (rows + 1), 4), -7, dtype=torch.int32, device="cuda")
+    for r, t in enumerate(ranks):
+        t.shard_saturated_message(gathered[r * (rows + 1):(r + 1) * (rows + 1)], rows)
+    for t in ranks:
+        t.shard_note_gathered(gathered, world, rows)
+    torch.cuda.synchronize()
+    g = gathered.cpu().numpy().reshape(world, rows + 1, 4)
+    assert all(0 <= g[r, rows, 0] <= rows and not g[r, rows, 1:].any() for r in range(world))
+    return [tuple(v) for r in range(world) for v in g[r, : g[r, rows, 0]].tolist()]
+
+
+@pytest.mark.gpu
+def test_hip_saturation_feedback_as_fixed_size_messages_with_a_waiting_list():
+    """The feedback without host reads: with messages of 40 voxels most of a call's saturated voxels wait in the handle
+    and go out over the following steps — every voxel is announced exactly once, the same set the list form
+    (shard_saturated) reports, and the maps stay bit-identical to the single-device one."""
+    from plvs_amd.tsdf import TsdfChisel
+    world, rows = 3, 40
+    kfs = make_keyframes(12, max_depth=5.0, seed=3)
+    single = TsdfChisel(0.05, max_chunks=4096, order_free=True)
+    ranks = [TsdfChisel(0.05, max_chunks=4096, shard_rank=r, shard_count=world, order_free=True) for r in range(world)]
+    lists = [TsdfChisel(0.05, max_chunks=4096, shard_rank=r, shard_count=world, order_free=True) for r in range(world)]
+    announced, listed = [], []
+    for b0 in range(0, len(kfs), 4):
+        xyz, rgb, kfid, offsets, Twc = _batch(kfs[b0:b0 + 4])
+        single.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
+        announced += sharded_step_messages(ranks, xyz, rgb, kfid, offsets, Twc, rows)
+        counts = [t.shard_walk(xyz, offsets, Twc) for t in lists]
+        bufs = [send_buffers(t, c) for t, c in zip(lists, counts)]
+        for t, (seg, rec, run, rc) in zip(lists, virtual_all_to_all(counts, bufs)):
+            t.shard_apply(seg, rec, run, rc, rgb, kfid)
+        for t in lists:
+            listed += [tuple(v) for v in t.shard_saturated().cpu().numpy().tolist()]
+    assert len(listed) > 4 * world * rows, "the scene must saturate more voxels than the messages carry"
+    assert len(announced) < len(listed), "so some are still waiting"
+    e = np.zeros(1, np.int32)
+    for _ in range(len(listed) // rows + 2):   # empty steps drain the waiting lists
+        xyz, rgb, kfid, offsets, Twc = _batch(kfs[:1])
+        announced += sharded_step_messages(ranks, xyz[:0], rgb[:0], kfid[:0], e, Twc[:0], rows)
+    assert len(announced) == len(set(announced)), "a voxel is announced once"
+    assert set(announced) == set(listed)
+    got = {}
+    for t in ranks:
+        for cid in (tuple(x) for x in t.chunk_ids()):
+            got[cid] = t.get_chunk(*cid)
+    assert set(got) == {tuple(x) for x in single.chunk_ids()}
+    for cid, b in got.items():
+        a = single.get_chunk(*cid)
+        assert all(np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x,
+                                  y.view(np.uint32) if y.dtype == np.float32 else y) for x, y in zip(a, b))
+    for t in ranks + lists + [single]:
+        t.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2])
+def test_hip_ray_sharded_colour_runs_with_many_and_with_long_spans(world):
+    """The wire form of a colour run is a list of ray spans, six per record, 128 rays per span at most: clouds whose
+    neighbouring points alternate between two distant surfaces (a voxel's rays are every second point of a tile: dozens
+    of one-ray spans, several records per run) and a point repeated 700 times (every voxel on its ray is seen by all 512
+    rays of a tile: one stretch cut into four spans) must still give the single-device colours bit for bit."""
+    from plvs_amd.tsdf import TsdfChisel
+    kf = make_keyframes(1, max_depth=5.0, seed=11)[0]
+    n = kf["xyz"].shape[0]
+    a, b = np.arange(0, 1500), np.arange(n // 2, n // 2 + 1500)
+    mixed = np.empty(3000, np.int64)
+    mixed[0::2], mixed[1::2] = a, b
+    idx = np.concatenate([mixed, np.full(700, n // 3), np.arange(2000, 2600)])
+    rng = np.random.default_rng(5)
+    sub = dict(kf, xyz=kf["xyz"][idx], rgb=rng.integers(0, 256, (idx.shape[0], 3)).astype(np.uint8), kfid=kf["kfid"][idx])
+    single = TsdfChisel(0.05, max_chunks=1024, order_free=True)
+    ranks = [TsdfChisel(0.05, max_chunks=1024, shard_rank=r, shard_count=world, order_free=True) for r in range(world)]
+    xyz, rgb, kfid, offsets, Twc = _batch([sub])
+    records = 0
+    for _ in range(2):   # (the second call folds onto half-filled colour weights)
+        single.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
+        counts = sharded_step(ranks, xyz, rgb, kfid, offsets, Twc)
+        records += int(sum(c[:, 2].sum() for c in counts))
+    got = {}
+    for t in ranks:
+        for cid in (tuple(x) for x in t.chunk_ids()):
+            got[cid] = t.get_chunk(*cid)
+    assert set(got) == {tuple(x) for x in single.chunk_ids()}
+    for cid, y in got.items():
+        x = single.get_chunk(*cid)
+        assert all(np.array_equal(p.view(np.uint32) if p.dtype == np.float32 else p,
+                                  q.view(np.uint32) if q.dtype == np.float32 else q) for p, q in zip(x, y)), cid
+    voxels = sum(int((single.get_chunk(*cid)[1] > 0).sum()) for cid in got)
+    assert records > 3 * voxels, "the alternating points must have produced runs of several records"
     for t in ranks + [single]:
         t.close()
 
