@@ -2658,6 +2658,9 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
     if (err & ~kErrScratch) return walk_fail(h, err);
     if (err & kErrScratch) {
       if (attempt >= 8) return walk_fail(h, err);
+      if (getenv("PLVS_DEBUG_SHARD"))   // (a repeated walk doubles the step: which scratch region was short)
+        fprintf(stderr, "shard_walk repeats: %u tiles, records %u of %zu spill, segments %u of %zu spill, runs per tile %u of %u\n",
+                nt, h->h_wctr->rec_top, rec_spill, h->h_wctr->seg_top, seg_spill, h->h_wctr->run_need, 1u << h->run_r1_log2);
       rec_spill = std::max<size_t>(rec_spill, (size_t)h->h_wctr->rec_top * 2);
       seg_spill = std::max<size_t>(seg_spill, (size_t)h->h_wctr->seg_top * 2);
       while ((1u << h->run_r1_log2) < h->h_wctr->run_need) ++h->run_r1_log2;
@@ -2833,10 +2836,10 @@ int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src,
     uint32_t* k_in = second ? h->dkey0.p : h->dkey1.p;   // the key buffer the tile sort has left free
     uint32_t* k_out = second ? h->dkey1.p : h->dkey0.p;
     hipLaunchKernelGGL(shard_gather_keys, dim3(ceil_div((size_t)R, 256)), dim3(256), 0, s, h->sh_vkey.p, order, R, k_in);
-    // the chunk count after this call's insertions bounds the voxel keys; it is read below with the counters, so
-    // take the pool capacity as the bound here
+    // (a received descriptor can add one chunk at most: the chunks before the call + the descriptors bound the slots)
+    const long long slot_bound = std::min<long long>(max_chunks, (long long)chunks_before + (long long)tseg);
     int key_bits = 12;
-    while ((1ll << (key_bits - 12)) < (long long)max_chunks) ++key_bits;
+    while ((1ll << (key_bits - 12)) < slot_bound) ++key_bits;
     PLVS_HIP_TRY(radix_sort_pairs(k_in, order, k_out, other, R, 0, key_bits, h->scratch.p, s, &second));
     const uint32_t* skeys = second ? k_out : k_in;
     const uint32_t* sval = second ? other : order;

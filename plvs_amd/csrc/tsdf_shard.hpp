@@ -151,6 +151,9 @@ __global__ __launch_bounds__(256) void shard_run_count(const uint32_t* __restric
   if (ctr->err) return;   // (a walk that ran out of room leaves unwritten run slots behind: the host repeats the call)
   if (threadIdx.x < 64) hist[threadIdx.x] = 0;
   __syncthreads();
+  // (the masks read through LDS — four neighbouring lanes per mask, sixteen whole masks per load instruction, then a lane
+  // its own 64 bytes from LDS — made it slower, 211 -> 265 us: the kernel is bound by the 350 MB of masks and the
+  // divergent span loop, not by how the lanes address them)
   const uint32_t nd = *nd_dev;
   for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < nd; j += gridDim.x * 256u) {
     uint32_t m[kMaskWords];
