@@ -929,6 +929,8 @@ struct plvs_tsdf_chisel {
   plvs_tsdf_stats sh_stats{};
   hipStream_t side = nullptr;   // second stream for the colour chain
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool small_runs_known = false;   // the runs of the last small call (integrate_walk_acc launches the next one's colour chain on them)
+  uint32_t small_runs_last = 0;
   // optional per-stage timing (HIP events on the caller's stream)
   bool profiling = false;
   hipEvent_t ev[kNumStages + 1] = {};
@@ -985,6 +987,7 @@ constexpr unsigned kDeferGrid = 1024;   // workgroups of the general walk over t
 constexpr int kFastEntriesSmall = 1024, kFastEntries = 2048, kFastEntriesBig = 4096;
 constexpr uint32_t kRecStride = kFastEntriesBig * 7 / 8;
 constexpr uint32_t kSmallCallTiles = 320;
+constexpr uint32_t kPredictTiles = 4096;   // calls up to this size (~25 key frames) launch their colour chain on the previous call's sizes
 constexpr unsigned kListGrid = 512;      // workgroups of the large-table pass over the first list (it loops)
 static_assert(kRecStride == (uint32_t)kWalkLimit, "a tile's record region holds a flush of the largest table");
 const char* const kWalkStageNames[kWalkStages] = {"walk_tiles", "sort_segments", "apply_chunks", "fold_colours"};
@@ -1007,7 +1010,9 @@ static int walk_fail(plvs_tsdf_chisel* h, uint32_t err) {
 // Stable sort of the D runs walk_tiles left in the per-tile regions by voxel key: per voxel its runs
 // in tile (= point) order; the value carried is the run's slot (tile = slot >> r1_log2, mask at slot * 8).
 static int sort_runs(plvs_tsdf_chisel* h, uint32_t D, uint32_t ntiles, int num_chunks, hipStream_t s,
-                     const uint32_t** skeys, const uint32_t** sval) {
+                     const uint32_t** skeys, const uint32_t** sval, const RunGuard* guard = nullptr) {
+  // guard (a chain launched before the host knows the call's runs): D and num_chunks are BOUNDS, compact_runs pads the pairs
+  // up to D and leaves the verdict in *guard->skip
   PLVS_HIP_TRY(h->dkey0.reserve(D));
   PLVS_HIP_TRY(h->dkey1.reserve(D));
   PLVS_HIP_TRY(h->w_val0.reserve(D));
@@ -1015,10 +1020,12 @@ static int sort_runs(plvs_tsdf_chisel* h, uint32_t D, uint32_t ntiles, int num_c
   PLVS_HIP_TRY(h->w_run_off.reserve((size_t)ntiles + 1));
   PLVS_HIP_TRY(h->scratch.reserve(std::max(radix_scratch_words(D), scan_scratch_words(ntiles))));
   // (the caller has scanned run_cnt into w_run_off)
-  hipLaunchKernelGGL(compact_runs, dim3(ceil_div(ntiles, 4)), dim3(256), 0, s, h->w_runkey.p, h->w_run_cnt.p,
-                     h->w_run_off.p, ntiles, h->run_r1_log2, h->dkey0.p, h->w_val0.p);
+  hipLaunchKernelGGL(compact_runs, dim3(ceil_div(ntiles, 4) + (guard ? std::min<unsigned>(64u, ceil_div((size_t)D, 1024)) : 0u)),
+                     dim3(256), 0, s, h->w_runkey.p, h->w_run_cnt.p, h->w_run_off.p, ntiles, h->run_r1_log2, h->dkey0.p,
+                     h->w_val0.p, guard ? *guard : RunGuard{0xFFFFFFFFu, nullptr, nullptr, 0, nullptr, nullptr});
   int key_bits = 12;
-  while ((1ll << (key_bits - 12)) < (long long)num_chunks) ++key_bits;   // (the count after this call's insertions)
+  // (the count after this call's insertions; + 1 under a guard: its padding keys, all ones, must not be a voxel's)
+  while ((1ll << (key_bits - 12)) < (long long)num_chunks + (guard ? 1 : 0)) ++key_bits;
   bool second = false;
   PLVS_HIP_TRY(radix_sort_pairs(h->dkey0.p, h->w_val0.p, h->dkey1.p, h->w_val1.p, D, 0, key_bits, h->scratch.p, s,
                                 &second));
@@ -1167,57 +1174,87 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
                        kRecStride, 2u);   // (what is flagged overflowed a 4096-entry table: two pieces at once)
     PLVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
     STAGE_MARK(1);
+    // A small call (a few key frames: PointCloudMapping::UpdateMap's batches) launches its colour chain on the sizes of
+    // the small call before it instead of waiting for its own (below), and keeps the chain — a dozen dependent launches,
+    // the longer of the two branches — on the caller's stream: the segment sort and the apply stage go to the side stream
+    // and are long over when the chain ends.  (A branch on another stream starts ~20 us after the event it waits for and is
+    // joined ~20 us after it ends.)
+    const bool predicted = ntiles <= kPredictTiles && h->small_runs_known && attempt == 0;
+    const hipStream_t q_apply = predicted ? h->side : s, q_colour = predicted ? s : h->side;
+    if (predicted) PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+#define STAGE_MARK_ON(i, q) \
+  do { if (h->profiling) PLVS_HIP_TRY(hipEventRecord(h->ev[i], q)); } while (0)
     const unsigned seg_blocks = ceil_div(seg_own + seg_spill, kSegSpan);
-    hipLaunchKernelGGL(seg_pass<false>, dim3(seg_blocks), dim3(256), 0, s, h->w_seg.p, out.seg_cap, ntiles,
+    hipLaunchKernelGGL(seg_pass<false>, dim3(seg_blocks), dim3(256), 0, q_apply, h->w_seg.p, out.seg_cap, ntiles,
                        h->w_seg_cnt.p, h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p,
                        h->d_wctr);
-    hipLaunchKernelGGL(seg_scan, dim3(1), dim3(1024), 0, s, h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p,
+    hipLaunchKernelGGL(seg_scan, dim3(1), dim3(1024), 0, q_apply, h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p,
                        h->updated.p, h->w_active_off.p, h->d_wctr, &h->d_ctr->num_chunks, max_chunks,
                        h->w_tile_visits.p, h->w_run_cnt.p, ntiles, h->w_part_off.p, h->w_multi_idx.p, h->multi_cap,
                        h->part_segs, h->part_min);
-    hipLaunchKernelGGL(seg_pass<true>, dim3(seg_blocks), dim3(256), 0, s, h->w_seg.p, out.seg_cap, ntiles,
+    hipLaunchKernelGGL(seg_pass<true>, dim3(seg_blocks), dim3(256), 0, q_apply, h->w_seg.p, out.seg_cap, ntiles,
                        h->w_seg_cnt.p, h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p,
                        h->d_wctr);
-    STAGE_MARK(2);
-    hipLaunchKernelGGL((apply_chunks<false, false>), dim3(4096), dim3(kApplyThreads), 0, s, h->w_sorted_seg.p, h->updated.p,
+    STAGE_MARK_ON(2, q_apply);
+    hipLaunchKernelGGL((apply_chunks<false, false>), dim3(4096), dim3(kApplyThreads), 0, q_apply, h->w_sorted_seg.p, h->updated.p,
                        h->w_active_off.p, h->w_part_off.p, h->w_multi_idx.p, h->part_segs,
                        PartAcc{h->pa_wuu.p, h->pa_w.p, h->pa_last.p, h->pa_cnt.p, h->pa_done.p}, h->w_rec.p,
                        1.0 / (double)h->scale_u, 1.0 / (double)h->scale_w, d_kfid, h->sdf, h->weight, h->kfid, h->d_wctr,
                        EmitOut{});
     PLVS_KERNEL_CHECK();
-    STAGE_MARK(3);
+    STAGE_MARK_ON(3, q_apply);
+#undef STAGE_MARK_ON
     // ---- colour fold: the truncating u8 mean is order dependent -> through the sorted runs of the voxels
-    // whose colour weight is below 254.  It only needs the runs the walk left, so it runs on the side stream
-    // beside the segment sort and the apply stage (both short, latency-bound kernels).
+    // whose colour weight is below 254.  It only needs the runs the walk left, so it runs on another stream than
+    // the segment sort and the apply stage (both short, latency-bound kernels).
+    uint32_t* const side_ctr = &h->d_wctr[1].num_desc;   // the run count, for the side stream's kernels
+    // the chain behind the scan of the run counts, for D runs (or a bound on them: guard) on stream q
+    auto colour_chain = [&](uint32_t D, int chunks, hipStream_t q, const RunGuard* guard) -> int {
+      const uint32_t* skeys = h->dkey0.p;
+      const uint32_t* sval = h->w_val0.p;
+      if (D <= kSmallRuns) {
+        hipLaunchKernelGGL(sort_runs_small, dim3(1), dim3(1024), 0, q, h->w_runkey.p, h->w_run_cnt.p, ntiles,
+                           h->run_r1_log2, h->d_wctr + 1, h->dkey0.p, h->w_val0.p, h->heads.p, guard ? guard->skip : (uint32_t*)nullptr);
+      } else {
+        int rc = sort_runs(h, D, ntiles, chunks, q, &skeys, &sval, guard);
+        if (rc != PLVS_OK) return rc;
+        PLVS_HIP_TRY(h->heads.reserve(D));
+        PLVS_HIP_TRY(h->w_dummy.reserve((size_t)max_chunks + 1));
+        hipLaunchKernelGGL(voxel_heads, dim3(ceil_div(D, 256 * kHeadTiles)), dim3(256), 0, q, skeys, D,
+                           h->heads.p, h->w_dummy.p, h->d_wctr + 1, guard ? (const uint32_t*)side_ctr : (const uint32_t*)nullptr);
+      }
+      hipLaunchKernelGGL(fold_colours_masks, dim3(std::min<size_t>(ceil_div(D, kFoldWaves), 8192)),
+                         dim3(64 * kFoldWaves), 0, q, skeys, sval, side_ctr,
+                         RunSrc{h->w_masks.p, (uint32_t)kMaskWords, h->run_r1_log2, TileMap{1u, 0u}, h->offsets.p, nclouds,
+                                reinterpret_cast<const uint32_t*>(h->offsets.p) + 2 * ((size_t)nclouds + 1)},
+                         h->heads.p, d_rgb,
+                         h->rgbw, &h->d_wctr[1].num_heads, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                         guard ? (const uint32_t*)guard->skip : (const uint32_t*)nullptr);
+      PLVS_KERNEL_CHECK();
+      return PLVS_OK;
+    };
+    // (predicted: a bound that does not hold costs the chain a second time — the fold of the first skips itself: compact_runs)
+    uint32_t run_bound = 0;
+    int chunk_bound = 0;
     {
-      uint32_t* const side_ctr = &h->d_wctr[1].num_desc;   // the run count, for the side stream's kernels
-      PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-      {
-        PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, ntiles, side_ctr, h->scratch.p, h->side));
+      if (!predicted) PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+      PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, ntiles, side_ctr, h->scratch.p, q_colour));
+      if (predicted) {
+        const size_t slots = (size_t)ntiles << h->run_r1_log2;
+        run_bound = h->small_runs_last <= kSmallRuns / 2
+                        ? kSmallRuns
+                        : (uint32_t)std::min<size_t>(slots, ((size_t)h->small_runs_last * 5 / 4 + 8191) / 4096 * 4096);
+        chunk_bound = std::min(max_chunks, std::max(2 * chunks_before, chunks_before + 256));
+        const RunGuard guard{run_bound, side_ctr, &h->d_ctr->num_chunks, chunk_bound, &h->d_wctr[0].err, &h->d_wctr[1].skip};
+        int rc = colour_chain(run_bound, chunk_bound, q_colour, &guard);
+        if (rc != PLVS_OK) return rc;
+      } else {
         hipLaunchKernelGGL(publish_counters, dim3(1), dim3(64), 0, h->side, h->d_wctr, h->d_ctr, h->h_wctr, h->h_ctr);
         PLVS_HIP_TRY(hipStreamSynchronize(h->side));   // the walk is over; segment sort and apply are queued behind it
         const uint32_t D = h->h_wctr[1].num_desc;
         if (h->h_wctr[0].err == 0 && D > 0) {
-          const uint32_t* skeys = h->dkey0.p;
-          const uint32_t* sval = h->w_val0.p;
-          if (D <= kSmallRuns) {
-            hipLaunchKernelGGL(sort_runs_small, dim3(1), dim3(1024), 0, h->side, h->w_runkey.p, h->w_run_cnt.p, ntiles,
-                               h->run_r1_log2, h->d_wctr + 1, h->dkey0.p, h->w_val0.p, h->heads.p);
-          } else {
-            int rc = sort_runs(h, D, ntiles, h->h_ctr->num_chunks, h->side, &skeys, &sval);
-            if (rc != PLVS_OK) return rc;
-            PLVS_HIP_TRY(h->heads.reserve(D));
-            PLVS_HIP_TRY(h->w_dummy.reserve((size_t)max_chunks + 1));
-            hipLaunchKernelGGL(voxel_heads, dim3(ceil_div(D, 256 * kHeadTiles)), dim3(256), 0, h->side, skeys, D,
-                               h->heads.p, h->w_dummy.p, h->d_wctr + 1);
-          }
-          hipLaunchKernelGGL(fold_colours_masks, dim3(std::min<size_t>(ceil_div(D, kFoldWaves), 8192)),
-                             dim3(64 * kFoldWaves), 0, h->side, skeys, sval, side_ctr,
-                             RunSrc{h->w_masks.p, (uint32_t)kMaskWords, h->run_r1_log2, TileMap{1u, 0u}, h->offsets.p, nclouds,
-                                    reinterpret_cast<const uint32_t*>(h->offsets.p) + 2 * ((size_t)nclouds + 1)},
-                             h->heads.p, d_rgb,
-                             h->rgbw, &h->d_wctr[1].num_heads, (uint32_t*)nullptr, (uint32_t*)nullptr);
-          PLVS_KERNEL_CHECK();
+          int rc = colour_chain(D, h->h_ctr->num_chunks, h->side, nullptr);
+          if (rc != PLVS_OK) return rc;
         }
       }
       PLVS_HIP_TRY(hipEventRecord(h->ev_join, h->side));
@@ -1235,6 +1272,19 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
       while ((1u << h->run_r1_log2) < h->h_wctr->run_need) ++h->run_r1_log2;
       if (((size_t)ntiles << h->run_r1_log2) >= 0xFFFFFFFFull) return walk_fail(h, err);
       continue;
+    }
+    if (predicted && h->h_wctr[1].skip != 0u) {   // the bounds did not hold: the chain once more, with the call's numbers
+      const uint32_t D = h->h_wctr[1].num_desc;
+      PLVS_HIP_TRY(hipMemsetAsync(&h->d_wctr[1].num_heads, 0, sizeof(uint32_t), s));
+      PLVS_HIP_TRY(hipMemsetAsync(&h->d_wctr[1].num_updated, 0, sizeof(uint32_t), s));
+      int rc2 = colour_chain(D, h->h_ctr->num_chunks, s, nullptr);
+      if (rc2 != PLVS_OK) return rc2;
+      rc2 = read_walk_counters(h, s);
+      if (rc2 != PLVS_OK) return rc2;
+    }
+    if (ntiles <= kPredictTiles) {
+      h->small_runs_known = true;
+      h->small_runs_last = h->h_wctr[1].num_desc;
     }
     break;
   }
@@ -2637,7 +2687,8 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
     // the runs, densely, in tile order (seg_scan has left their number in num_desc), counted per destination
     PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, nt, nullptr, h->scratch.p, s));
     hipLaunchKernelGGL(compact_runs, dim3(ceil_div(nt, 4)), dim3(256), 0, s, h->w_runkey.p, h->w_run_cnt.p,
-                       h->w_run_off.p, nt, h->run_r1_log2, h->dkey0.p, h->w_val0.p);
+                       h->w_run_off.p, nt, h->run_r1_log2, h->dkey0.p, h->w_val0.p,
+                       RunGuard{0xFFFFFFFFu, nullptr, nullptr, 0, nullptr, nullptr});
     hipLaunchKernelGGL(shard_run_count, dim3(2048), dim3(256), 0, s, h->dkey0.p, h->w_val0.p, &h->d_wctr[0].num_desc,
                        h->w_masks.p, h->sh_slot_owner.p, N, h->sh_run_ctr.p, h->sh_run_first.p, h->d_wctr);
     hipLaunchKernelGGL(shard_run_plan, dim3(1), dim3(64), 0, s, h->sh_run_ctr.p, N, h->d_wctr);
@@ -2848,7 +2899,8 @@ int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src,
     hipLaunchKernelGGL(fold_colours_masks, dim3(std::min<size_t>(ceil_div(R, kFoldWaves), 8192)), dim3(64 * kFoldWaves), 0, s,
                        skeys, sval, &h->d_wctr[1].num_desc,
                        RunSrc{runs, kWireRun, 0u, TileMap{1u, 0u}, h->offsets.p, h->sh_nclouds, nullptr}, h->heads.p, d_rgb,
-                       h->rgbw, &h->d_wctr[1].num_heads, h->sh_sat.p, reinterpret_cast<uint32_t*>(h->d_xcount + 2));
+                       h->rgbw, &h->d_wctr[1].num_heads, h->sh_sat.p, reinterpret_cast<uint32_t*>(h->d_xcount + 2),
+                       (const uint32_t*)nullptr);
     PLVS_KERNEL_CHECK();
   }
   STAGE_MARK(4);

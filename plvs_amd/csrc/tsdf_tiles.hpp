@@ -347,7 +347,9 @@ constexpr int kHeadTiles = 16;   // 4096 runs per block: few same-address atomic
 template <typename CountersT>
 __global__ __launch_bounds__(256) void voxel_heads(
     const uint32_t* __restrict__ skeys, uint32_t nd, uint32_t* __restrict__ vj0,
-    uint32_t* __restrict__ updated_slots, CountersT* __restrict__ ctr) {
+    uint32_t* __restrict__ updated_slots, CountersT* __restrict__ ctr, const uint32_t* __restrict__ nd_dev = nullptr) {
+  // (nd_dev: the array holds min(nd, *nd_dev) runs — a launch sized by a bound on their number)
+  if (nd_dev != nullptr) nd = min(nd, *nd_dev);
   __shared__ uint32_t wtot[4];
   __shared__ uint32_t block_base[2];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;

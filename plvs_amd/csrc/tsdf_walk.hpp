@@ -117,6 +117,7 @@ struct WalkCounters {           // device-side, read back once per call
   uint32_t ndeferred;           // tiles walk_fast left to the next kernel (several clouds in the tile, table overflow)
   uint32_t ndeferred2;          //   and what the larger-table pass over that list left to walk_tiles
   uint32_t over_small;          // tiles of a 2048-entry first pass that a 1024-entry table would not have held
+  uint32_t skip;                // colour side: a chain launched on predicted sizes found them too small (compact_runs)
 };
 
 // ------------------------------------------------------------------ the walk of one (sub-)tile
@@ -1968,14 +1969,38 @@ __global__ void selftest_walk_math_kernel(uint32_t seed, uint32_t* __restrict__ 
 
 // Runs of the per-tile regions -> dense (key, slot) pairs in tile order (the input of the stable sort
 // by voxel key).  One wave per tile.
+// A call that launches its colour chain BEFORE the host knows the number of runs (small calls: the host read in the middle
+// of the chain was a fifth of their time) sorts `limit` pairs, a bound taken from the call before: the workgroups beyond
+// the tiles' fill dkey[total .. limit) with keys that sort last, and say in *skip whether the bounds held — the runs fit
+// `limit`, the map's chunks `chunk_limit` (the key bits of the sort).  If not, the fold does nothing and the host
+// repeats the chain with the real numbers.  Other calls: limit = 0xFFFFFFFF, no extra workgroups.
+struct RunGuard {
+  uint32_t limit;
+  const uint32_t* total;        // runs of the call (the scan of run_cnt left it)
+  const int32_t* num_chunks;    // chunks of the map after the walk
+  int chunk_limit;
+  const uint32_t* err;          // the walk's error word: a walk that has to be repeated leaves nothing to fold
+  uint32_t* skip;
+};
 __global__ __launch_bounds__(256) void compact_runs(const uint32_t* __restrict__ runkey, const uint32_t* __restrict__ run_cnt,
                                                     const uint32_t* __restrict__ run_off, uint32_t ntiles,
                                                     uint32_t r1_log2, uint32_t* __restrict__ dkey,
-                                                    uint32_t* __restrict__ dval) {
+                                                    uint32_t* __restrict__ dval, RunGuard guard) {
+  const uint32_t tile_blocks = (ntiles + 3u) / 4u;
+  if (blockIdx.x >= tile_blocks) {
+    const uint32_t total = *guard.total, b = blockIdx.x - tile_blocks, nb = gridDim.x - tile_blocks;
+    if (b == 0 && threadIdx.x == 0)
+      *guard.skip = (total > guard.limit || *guard.num_chunks > guard.chunk_limit || *guard.err != 0u) ? 1u : 0u;
+    for (uint32_t i = total + b * 256u + threadIdx.x; i < guard.limit; i += nb * 256u) {
+      dkey[i] = 0xFFFFFFFFu;
+      dval[i] = 0u;
+    }
+    return;
+  }
   const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (t >= ntiles) return;
+  if (t >= ntiles || (guard.err != nullptr && *guard.err != 0u)) return;
   const uint32_t n = run_cnt[t], o = run_off[t], base = t << r1_log2;
-  for (uint32_t k = threadIdx.x & 63; k < n; k += 64) {
+  for (uint32_t k = threadIdx.x & 63; k < n && o + k < guard.limit; k += 64) {
     dkey[o + k] = runkey[base + k];
     dval[o + k] = base + k;
   }
@@ -1990,12 +2015,17 @@ constexpr uint32_t kSmallRuns = 4096;
 __global__ __launch_bounds__(1024) void sort_runs_small(const uint32_t* __restrict__ runkey, const uint32_t* __restrict__ run_cnt,
                                                         uint32_t ntiles, uint32_t r1_log2, WalkCounters* __restrict__ ctr,
                                                         uint32_t* __restrict__ skeys, uint32_t* __restrict__ sval,
-                                                        uint32_t* __restrict__ heads) {
+                                                        uint32_t* __restrict__ heads, uint32_t* __restrict__ skip) {
   __shared__ unsigned long long item[kSmallRuns];
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t carry;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const uint32_t D = ctr->num_desc;   // 0 < D <= kSmallRuns (the host chose this path)
+  const uint32_t D = ctr->num_desc;   // <= kSmallRuns: the host chose this path knowing D, or (skip != nullptr) expecting it
+  if (skip != nullptr) {
+    const bool bad = D > kSmallRuns || (ctr - 1)->err != 0u;   // (ctr = the colour side's counters, behind the walk's)
+    if (tid == 0) *skip = bad ? 1u : 0u;
+    if (bad) return;
+  }
   uint32_t P = 64;
   while (P < D) P <<= 1;
   for (uint32_t k = tid; k < P; k += 1024) item[k] = ~0ull;
@@ -2132,8 +2162,11 @@ constexpr int kFoldSteps = 256;   // >= 254: the visits that can still count for
 __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
     const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ sorted_val, const uint32_t* __restrict__ nd_dev,
     RunSrc src, const uint32_t* __restrict__ vj0, const uint8_t* __restrict__ rgb, uint32_t* __restrict__ rgbw,
-    const uint32_t* __restrict__ num_heads, uint32_t* __restrict__ sat_list, uint32_t* __restrict__ sat_count) {
+    const uint32_t* __restrict__ num_heads, uint32_t* __restrict__ sat_list, uint32_t* __restrict__ sat_count,
+    const uint32_t* __restrict__ skip) {
   // sat_list (ray-sharded integrate): the voxels whose colour weight reaches 254 in this call
+  // skip (a chain launched on predicted sizes, compact_runs): non-zero = the prediction failed, nothing here is valid
+  if (skip != nullptr && *skip != 0u) return;
   // A wave takes kFoldGroup voxels of the head list at a time.
   //  staging  eight lanes per voxel, one lane per RUN, eight runs of every voxel at a time: the lane reads its run's ray
   //           mask and writes the colours of its rays — bits ascending = point order — into the stage of its voxel, at

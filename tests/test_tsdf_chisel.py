@@ -435,6 +435,49 @@ def test_hip_order_free_mode_is_within_the_stated_tolerance(oracle, batch):
     dev.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("resolution", [0.05, 0.01])
+def test_hip_small_calls_launch_their_colour_chain_on_predicted_sizes(oracle, resolution):
+    """A call of up to ~25 key frames launches its colour chain on the run count and chunk count of the call before it
+    (integrate_walk_acc: no host read in the middle of the call); when the bounds do not hold the fold skips itself
+    and the chain is repeated with the call's own numbers.  Sequences that break the bounds both ways — a few points,
+    then whole key frames (the runs exceed the bound; at 1 cm a key frame also adds more chunks than the chunk bound
+    allows), then a few points again, then several key frames — must give the oracle's colours exactly."""
+    import torch
+    from plvs_amd.tsdf import TsdfChisel
+    kfs = make_keyframes(7, cam=small_cam(2), seed=33)
+    few = lambda kf, n: dict(kf, xyz=kf["xyz"][:n], rgb=kf["rgb"][:n], kfid=kf["kfid"][:n])
+    calls = [[few(kfs[0], 60)], [kfs[0]], [kfs[1]], [few(kfs[2], 30)], [kfs[2], kfs[3], kfs[4]], [kfs[5]], [few(kfs[6], 900)], [kfs[6]]]
+    ora = oracle.chisel(resolution)
+    dev = TsdfChisel(resolution, max_chunks=16384, order_free=True)
+    runs_seen, new_chunks = [], []
+    for part in calls:
+        for kf in part:
+            ora.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
+        xyz = torch.from_numpy(np.concatenate([k["xyz"] for k in part])).cuda()
+        rgb = torch.from_numpy(np.concatenate([k["rgb"] for k in part])).cuda()
+        kfid = torch.from_numpy(np.concatenate([k["kfid"] for k in part]).astype(np.int32)).cuda()
+        Twc = torch.from_numpy(np.stack([k["Twc"] for k in part])).cuda()
+        offsets = np.cumsum([0] + [k["xyz"].shape[0] for k in part]).astype(np.int32)
+        dev.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
+        runs_seen.append(dev.last_stats()["voxels"])
+        new_chunks.append(dev.last_stats()["new_chunks"])
+    assert max(runs_seen) > 20 * min(runs_seen), "the calls must differ in size by more than the bound's margin"
+    ia = {tuple(x) for x in ora.chunk_ids()}
+    assert ia == {tuple(x) for x in dev.chunk_ids()}
+    if resolution == 0.01:   # (bound: twice the chunks before the call, or 256 more)
+        assert new_chunks[0] < 20 and new_chunks[1] > 2 * new_chunks[0] + 256, "a key frame must add more chunks than the bound allows"
+    for cid in sorted(ia):
+        a, b = ora.get_chunk(*cid), dev.get_chunk(*cid)
+        known = a[1] > 0
+        assert np.array_equal(known, b[1] > 0)
+        assert np.array_equal(a[2], b[2]), "kfid must be exact"
+        if known.any():
+            assert float(np.abs(a[0][known] - b[0][known]).max()) <= ORDER_FREE_SDF_ATOL
+            assert np.array_equal(a[3][known], b[3][known]), f"colours of chunk {cid} differ"
+    dev.close()
+
+
 def _scattered_cloud(n, seed, spread=4.0, zmax=6.0):
     """Points with no spatial coherence at all: consecutive points land in far-apart chunks (a
     tile meets hundreds of chunks: the per-tile chunk cache overflows and falls back)."""
