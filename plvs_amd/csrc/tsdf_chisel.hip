@@ -930,7 +930,7 @@ struct plvs_tsdf_chisel {
   hipStream_t side = nullptr;   // second stream for the colour chain
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool small_runs_known = false;   // the runs of the last small call (integrate_walk_acc launches the next one's colour chain on them)
-  uint32_t small_runs_last = 0;
+  uint32_t small_runs_last = 0, small_tiles_last = 1;
   // optional per-stage timing (HIP events on the caller's stream)
   bool profiling = false;
   hipEvent_t ev[kNumStages + 1] = {};
@@ -1181,9 +1181,9 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     // joined ~20 us after it ends.)
     const bool predicted = ntiles <= kPredictTiles && h->small_runs_known && attempt == 0;
     const hipStream_t q_apply = predicted ? h->side : s, q_colour = predicted ? s : h->side;
-    if (predicted) PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
 #define STAGE_MARK_ON(i, q) \
   do { if (h->profiling) PLVS_HIP_TRY(hipEventRecord(h->ev[i], q)); } while (0)
+    auto segments_and_apply = [&]() -> int {
     const unsigned seg_blocks = ceil_div(seg_own + seg_spill, kSegSpan);
     hipLaunchKernelGGL(seg_pass<false>, dim3(seg_blocks), dim3(256), 0, q_apply, h->w_seg.p, out.seg_cap, ntiles,
                        h->w_seg_cnt.p, h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p,
@@ -1203,7 +1203,13 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
                        EmitOut{});
     PLVS_KERNEL_CHECK();
     STAGE_MARK_ON(3, q_apply);
-#undef STAGE_MARK_ON
+    return PLVS_OK;
+    };
+    // (the host issues the critical branch first: a one-key-frame walk is over before a dozen launches have been made)
+    if (!predicted) {
+      int rc = segments_and_apply();
+      if (rc != PLVS_OK) return rc;
+    }
     // ---- colour fold: the truncating u8 mean is order dependent -> through the sorted runs of the voxels
     // whose colour weight is below 254.  It only needs the runs the walk left, so it runs on another stream than
     // the segment sort and the apply stage (both short, latency-bound kernels).
@@ -1241,12 +1247,15 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
       PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, ntiles, side_ctr, h->scratch.p, q_colour));
       if (predicted) {
         const size_t slots = (size_t)ntiles << h->run_r1_log2;
-        run_bound = h->small_runs_last <= kSmallRuns / 2
-                        ? kSmallRuns
-                        : (uint32_t)std::min<size_t>(slots, ((size_t)h->small_runs_last * 5 / 4 + 8191) / 4096 * 4096);
+        // (the call before scaled to this call's tiles — calls of one and of five key frames may alternate —, a quarter more)
+        const size_t expect = (size_t)((double)h->small_runs_last * (double)ntiles / (double)std::max(1u, h->small_tiles_last));
+        run_bound = expect <= kSmallRuns / 2 ? kSmallRuns : (uint32_t)std::min<size_t>(slots, (expect * 5 / 4 + 8191) / 4096 * 4096);
         chunk_bound = std::min(max_chunks, std::max(2 * chunks_before, chunks_before + 256));
         const RunGuard guard{run_bound, side_ctr, &h->d_ctr->num_chunks, chunk_bound, &h->d_wctr[0].err, &h->d_wctr[1].skip};
         int rc = colour_chain(run_bound, chunk_bound, q_colour, &guard);
+        if (rc != PLVS_OK) return rc;
+        PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        rc = segments_and_apply();
         if (rc != PLVS_OK) return rc;
       } else {
         hipLaunchKernelGGL(publish_counters, dim3(1), dim3(64), 0, h->side, h->d_wctr, h->d_ctr, h->h_wctr, h->h_ctr);
@@ -1260,6 +1269,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
       PLVS_HIP_TRY(hipEventRecord(h->ev_join, h->side));
       PLVS_HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
     }
+#undef STAGE_MARK_ON
     STAGE_MARK(4);
     int rc = read_walk_counters(h, s);
     if (rc != PLVS_OK) return rc;
@@ -1285,6 +1295,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     if (ntiles <= kPredictTiles) {
       h->small_runs_known = true;
       h->small_runs_last = h->h_wctr[1].num_desc;
+      h->small_tiles_last = ntiles;
     }
     break;
   }
@@ -1566,6 +1577,7 @@ int plvs_hip_tsdf_chisel_clear(plvs_tsdf_chisel* h) {
   PLVS_KERNEL_CHECK();
   PLVS_HIP_TRY(hipDeviceSynchronize());
   h->num_chunks = 0;
+  h->small_runs_known = false;   // (the first small call on the empty map reads its own run count)
   h->poisoned = false;
   h->stats = plvs_tsdf_stats{};
   h->last_updated = 0;
