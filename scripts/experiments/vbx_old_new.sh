@@ -1,0 +1,7 @@
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+for V in old new old new; do
+  if [ "$V" = "old" ]; then export PLVS_HIP_LIB="$PWD/plvs_amd/lib/libplvs_hip_old.so"; else unset PLVS_HIP_LIB; fi
+  timeout 300 python bench.py --backend voxblox --resolution 0.02 --batch 25 --steps 8 --warmup 4 --max-depth 8 --no-frontend --no-cpu-baseline --no-realistic-legs --no-steady-state-leg --no-other-mode-leg --no-voxblox-leg --no-parity-check 2>&1 | grep "^{" | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('$V', d['value'], d['ms_per_step'])"
+done
