@@ -979,6 +979,29 @@ int plvs_hip_tsdf_voxblox_integrate_batch_dev(plvs_tsdf_voxblox* h, const float*
 int plvs_hip_tsdf_voxblox_queue(plvs_tsdf_voxblox* h, const float* xyz, const uint8_t* rgba, int n, const float* Twc);
 int plvs_hip_tsdf_voxblox_flush(plvs_tsdf_voxblox* h);
 int plvs_hip_tsdf_voxblox_queued(plvs_tsdf_voxblox* h, int* nclouds);
+/* ------------------------------------------- multi-GPU: the ray-sharded integrate (voxblox, "simple"; round 4)
+ * New design (the reference is one process): the MAP is sharded by block (shard_rank / shard_count, owner =
+ * AnyIndexHash(block id) mod N, block_hash.h:21-24), the WORK by key frame — rank r casts the rays of the clouds
+ * c = r (mod N) of every call, through whatever blocks they cross, and every voxel visit travels to the block's owner as
+ * a 16-byte record {block id packed in 8 B, voxel | cloud << 12, sequence number of the ray}.  Every rank is given the
+ * same clouds.  updateTsdfVoxel is order dependent: the owner applies a voxel's visits in the reference's order (cloud
+ * after cloud, the mixed point order inside), so the union of the shards is the single-device layer bit for bit for
+ * every N (tests/test_tsdf_voxblox_shard.py).  One call =
+ *   shard_walk    this rank's rays; send_counts[N] = records per destination
+ *   shard_pack    the records grouped by destination in rank order, 16 B each (d_send: sum of send_counts records)
+ *   all-to-all    counts, then the records (the caller's transport: plvs_amd/shard.py does it over torch.distributed)
+ *   shard_apply   the records grouped by source in rank order, recv_counts[N]; the clouds again (the operands of a visit
+ *                 are recomputed at the owner)
+ * shard_count = 1 is allowed (the rank sends to itself).  Before round 4 a sharded voxblox map had every rank cast every
+ * ray and keep its own blocks' visits (plvs_hip_tsdf_voxblox_integrate_batch_dev on a handle with shard_count > 1 still
+ * does that). */
+int plvs_hip_tsdf_voxblox_shard_walk(plvs_tsdf_voxblox* h, const float* d_xyz, const int32_t* offsets, int nclouds,
+                                     const float* d_Twc, int64_t* send_counts, void* stream);
+int plvs_hip_tsdf_voxblox_shard_pack(plvs_tsdf_voxblox* h, void* d_send, void* stream);
+int plvs_hip_tsdf_voxblox_shard_apply(plvs_tsdf_voxblox* h, const void* d_recv, const int64_t* recv_counts,
+                                      const float* d_xyz, const uint8_t* d_rgba, const int32_t* offsets, int nclouds,
+                                      const float* d_Twc, void* stream);
+
 /* The "fast" integration method (PointCloudMapping.voxbloxIntegrationMethod: "fast" — the default of PLVS's YAML files):
  * FastTsdfIntegrator::integratePointCloud (Thirdparty/voxblox/src/integrator/tsdf_integrator.cc:505-605) in its
  * integrator_threads = 1 schedule, with start_voxel_subsampling_factor 2, max_consecutive_ray_collisions 2 and

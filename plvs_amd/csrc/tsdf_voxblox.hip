@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256) void vb_ray_pass(
 }
 
 #include "tsdf_voxblox_fast.hpp"
+#include "tsdf_voxblox_shard.hpp"
 
 // MergedTsdfIntegrator::bundleRays, the per-point part (tsdf_integrator.cc:361-386): isPointValid -> kind (0 skipped,
 // 1 normal, 2 clearing) and the voxel T_G_C * point_C ends in.  The grouping itself needs the reference's hash map and
@@ -830,6 +831,14 @@ struct plvs_tsdf_voxblox {
   Directory gdir{};
   int ghost_count = 0;
   DevBuf<uint32_t> halo_row;
+  // ray-sharded integrate (tsdf_voxblox_shard.hpp): this rank's visit records in sequence order, their destinations and the
+  // stable partition by destination; the owner's translated keys
+  DevBuf<uint4> sv_rec;
+  DevBuf<uint32_t> sv_dest, sv_dest1, sv_idx, sv_idx1, sv_cnt, sv_vkey, sv_seq;
+  uint32_t* h_sv_cnt = nullptr;        // pinned: records per destination
+  uint32_t sv_V = 0;
+  int sv_phase = 0;                    // 0 idle, 1 walked, 2 packed
+  bool sv_partitioned = false;
 };
 
 template <typename T>
@@ -912,6 +921,9 @@ int plvs_hip_tsdf_voxblox_destroy(plvs_tsdf_voxblox* h) {
   (void)hipFree(h->dist); (void)hipFree(h->weight); (void)hipFree(h->rgba); (void)hipFree(h->d_ctr);
   if (h->h_ctr) (void)hipHostFree(h->h_ctr);
   if (h->h_ff) (void)hipHostFree(h->h_ff);
+  if (h->h_sv_cnt) (void)hipHostFree(h->h_sv_cnt);
+  h->sv_rec.release(); h->sv_dest.release(); h->sv_dest1.release(); h->sv_idx.release(); h->sv_idx1.release(); h->sv_cnt.release();
+  h->sv_vkey.release(); h->sv_seq.release();
   h->q_xyz.release(); h->q_rgba.release(); h->q_Twc_dev.release();
   h->ap_start.release(); h->ap_seen.release(); h->ff_shash.release(); h->ff_qhash.release(); h->ff_skey0.release(); h->ff_skey1.release();
   h->ff_sval0.release(); h->ff_sval1.release(); h->ff_full.release(); h->ff_Q.release(); h->ff_L.release(); h->ff_qoff.release();
@@ -1489,6 +1501,212 @@ int plvs_hip_tsdf_voxblox_integrate_batch_dev(plvs_tsdf_voxblox* h, const float*
                                               int nclouds, const float* d_Twc, void* stream) {
   VB_FLUSH_QUEUE(h);
   return vb_integrate_impl(h, d_xyz, d_rgba, offsets, nclouds, d_Twc, stream, kSimple, nullptr, nullptr);
+}
+
+// ---- the ray-sharded integrate (tsdf_voxblox_shard.hpp)
+int plvs_hip_tsdf_voxblox_shard_walk(plvs_tsdf_voxblox* h, const float* d_xyz, const int32_t* offsets, int nclouds,
+                                     const float* d_Twc, int64_t* send_counts, void* stream) {
+  PLVS_REQUIRE(h && offsets && send_counts && nclouds >= 0, "bad argument");
+  PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
+  VB_FLUSH_QUEUE(h);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int N = std::max(1, h->P.shard_count), rank = N > 1 ? h->P.shard_rank : 0;
+  PLVS_REQUIRE(N <= 64, "at most 64 ranks");
+  for (int p = 0; p < N; ++p) send_counts[p] = 0;
+  h->sv_V = 0;
+  h->sv_phase = 1;
+  h->sv_partitioned = false;
+  if (nclouds == 0) return PLVS_OK;
+  const int n = offsets[nclouds] - offsets[0];
+  PLVS_REQUIRE(offsets[0] == 0 && n >= 0, "offsets must start at 0 and be non-decreasing");
+  for (int c = 0; c < nclouds; ++c) PLVS_REQUIRE(offsets[c + 1] >= offsets[c], "offsets must be non-decreasing");
+  PLVS_REQUIRE((size_t)nclouds < ((size_t)1 << 20), "at most 2^20 clouds per call");
+  if (n == 0) return PLVS_OK;
+  PLVS_REQUIRE(d_xyz && d_Twc, "null device pointer");
+  if (!h->h_sv_cnt) PLVS_HIP_TRY(hipHostMalloc((void**)&h->h_sv_cnt, 64 * sizeof(uint32_t)));
+  PLVS_HIP_TRY(h->offsets.reserve((size_t)nclouds + 1));
+  PLVS_HIP_TRY(h->counts.reserve((size_t)n));
+  PLVS_HIP_TRY(h->scratch.reserve(scan_scratch_words((size_t)n)));
+  PLVS_HIP_TRY(h->sv_cnt.reserve(64));
+  PLVS_HIP_TRY(hipMemcpyAsync(h->offsets.p, offsets, ((size_t)nclouds + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->total_visits, 0, sizeof(uint32_t), s));
+  PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->err, 0, 4 * sizeof(uint32_t), s));
+  PLVS_HIP_TRY(h->poses.reserve((size_t)nclouds));
+  hipLaunchKernelGGL(vb_pose_prep, dim3(ceil_div((size_t)nclouds, 64)), dim3(64), 0, s, d_Twc, nclouds, h->poses.p);
+  Params Pw = h->P;   // this rank's rays go through every block they cross
+  Pw.shard_count = 1;
+  Pw.shard_rank = 0;
+  const dim3 rgrid(ceil_div((size_t)n, 256)), rblock(256);
+  hipLaunchKernelGGL(vb_shard_ray_pass<false>, rgrid, rblock, 0, s, Pw, d_xyz, n, h->offsets.p, nclouds, h->poses.p, rank, N,
+                     h->d_ctr, h->counts.p, (uint4*)nullptr, (uint32_t*)nullptr);
+  PLVS_KERNEL_CHECK();
+  PLVS_HIP_TRY(exclusive_scan_u32(h->counts.p, h->counts.p, (size_t)n, &h->d_ctr->total_visits, h->scratch.p, s));
+  int rc = vb_read_counters(h, s);
+  if (rc != PLVS_OK) return rc;
+  if (h->h_ctr->err) {
+    plvs::set_error("tsdf_voxblox shard_walk: %s%s", (h->h_ctr->err & kErrCoordRange) ? "block id outside +-2^20 " : "",
+                    (h->h_ctr->err & kErrNonFinite) ? "non-finite point in the cloud " : "");
+    return (h->h_ctr->err & kErrNonFinite) ? PLVS_ERR_INVALID_ARG : PLVS_ERR_CAPACITY;
+  }
+  const uint32_t V = h->h_ctr->total_visits;
+  h->sv_V = V;
+  if (V == 0) return PLVS_OK;
+  PLVS_HIP_TRY(h->sv_rec.reserve(V));
+  PLVS_HIP_TRY(h->sv_dest.reserve(V));
+  hipLaunchKernelGGL(vb_shard_ray_pass<true>, rgrid, rblock, 0, s, Pw, d_xyz, n, h->offsets.p, nclouds, h->poses.p, rank, N,
+                     h->d_ctr, h->counts.p, h->sv_rec.p, h->sv_dest.p);
+  PLVS_KERNEL_CHECK();
+  if (N == 1) {
+    send_counts[0] = (int64_t)V;
+    return PLVS_OK;
+  }
+  // stable partition by destination: one radix pass over (destination, record index)
+  PLVS_HIP_TRY(h->sv_dest1.reserve(V));
+  PLVS_HIP_TRY(h->sv_idx.reserve(V));
+  PLVS_HIP_TRY(h->sv_idx1.reserve(V));
+  PLVS_HIP_TRY(h->scratch.reserve(radix_scratch_words(V)));
+  hipLaunchKernelGGL(vb_iota, dim3(ceil_div((size_t)V, 256)), dim3(256), 0, s, h->sv_idx.p, V);
+  int bits = 1;
+  while ((1 << bits) < N) ++bits;
+  bool second = false;
+  PLVS_HIP_TRY(radix_sort_pairs(h->sv_dest.p, h->sv_idx.p, h->sv_dest1.p, h->sv_idx1.p, V, 0, bits, h->scratch.p, s, &second));
+  if (second) {   // (the gather of shard_pack reads sv_idx, the counts below sv_dest)
+    std::swap(h->sv_dest, h->sv_dest1);
+    std::swap(h->sv_idx, h->sv_idx1);
+  }
+  h->sv_partitioned = true;
+  hipLaunchKernelGGL(vb_shard_dest_counts, dim3(1), dim3(64), 0, s, h->sv_dest.p, V, N, h->sv_cnt.p);
+  PLVS_KERNEL_CHECK();
+  PLVS_HIP_TRY(hipMemcpyAsync(h->h_sv_cnt, h->sv_cnt.p, (size_t)N * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  for (int p = 0; p < N; ++p) send_counts[p] = (int64_t)h->h_sv_cnt[p];
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_voxblox_shard_pack(plvs_tsdf_voxblox* h, void* d_send, void* stream) {
+  PLVS_REQUIRE(h, "null handle");
+  PLVS_REQUIRE(h->sv_phase == 1, "shard_pack follows shard_walk");
+  h->sv_phase = 2;
+  if (h->sv_V == 0) return PLVS_OK;
+  PLVS_REQUIRE(d_send, "null send buffer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(vb_shard_gather, dim3(ceil_div((size_t)h->sv_V, 256)), dim3(256), 0, s, h->sv_rec.p,
+                     h->sv_partitioned ? (const uint32_t*)h->sv_idx.p : (const uint32_t*)nullptr, h->sv_V, static_cast<uint4*>(d_send));
+  PLVS_KERNEL_CHECK();
+  return PLVS_OK;
+}
+
+int plvs_hip_tsdf_voxblox_shard_apply(plvs_tsdf_voxblox* h, const void* d_recv, const int64_t* recv_counts, const float* d_xyz,
+                                      const uint8_t* d_rgba, const int32_t* offsets, int nclouds, const float* d_Twc, void* stream) {
+  PLVS_REQUIRE(h && recv_counts && offsets && nclouds >= 0, "bad argument");
+  PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
+  PLVS_REQUIRE(h->sv_phase == 2, "shard_apply follows shard_pack");
+  h->sv_phase = 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int N = std::max(1, h->P.shard_count), rank = N > 1 ? h->P.shard_rank : 0;
+  h->stats = plvs_tsdf_stats{};
+  h->last_updated = 0;
+  size_t total = 0;
+  for (int p = 0; p < N; ++p) {
+    PLVS_REQUIRE(recv_counts[p] >= 0, "negative receive count");
+    total += (size_t)recv_counts[p];
+  }
+  PLVS_REQUIRE(total < 0xFFFFFFFFull, "receive buffer beyond the index range (split the batch)");
+  // a camera cloud, even an empty one, starts with updateLayerWithStoredBlocks (tsdf_integrator.cc:306 / :343)
+  const int n = nclouds > 0 ? offsets[nclouds] - offsets[0] : 0;
+  h->stats.points = n;
+  if (total == 0) {
+    const int lo = h->visible_blocks, hi = h->num_blocks;
+    h->visible_blocks = h->num_blocks;
+    return vb_publish_waiting(h, s, lo, hi);
+  }
+  PLVS_REQUIRE(d_recv && d_xyz && d_rgba && d_Twc, "null device pointer");
+  PLVS_REQUIRE((reinterpret_cast<uintptr_t>(d_rgba) & 3) == 0, "rgba must be 4-byte aligned");
+  {
+    int rc = vb_halo_drop(h, s);   // new blocks go into the pool slots a meshing halo may still occupy
+    if (rc != PLVS_OK) return rc;
+  }
+  const uint32_t V = (uint32_t)total;
+  const uint32_t* d_col = reinterpret_cast<const uint32_t*>(d_rgba);
+  PLVS_HIP_TRY(h->offsets.reserve((size_t)nclouds + 1));
+  PLVS_HIP_TRY(hipMemcpyAsync(h->offsets.p, offsets, ((size_t)nclouds + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  PLVS_HIP_TRY(h->poses.reserve((size_t)nclouds));
+  hipLaunchKernelGGL(vb_pose_prep, dim3(ceil_div((size_t)nclouds, 64)), dim3(64), 0, s, d_Twc, nclouds, h->poses.p);
+  PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->total_visits, 0, sizeof(uint32_t), s));
+  PLVS_HIP_TRY(hipMemsetAsync(&h->d_ctr->err, 0, 4 * sizeof(uint32_t), s));
+  PLVS_HIP_TRY(h->keys0.reserve(V));
+  PLVS_HIP_TRY(h->keys1.reserve(V));
+  PLVS_HIP_TRY(h->seq0.reserve(V));
+  PLVS_HIP_TRY(h->seq1.reserve(V));
+  PLVS_HIP_TRY(h->heads.reserve(V));
+  PLVS_HIP_TRY(h->rec.reserve(V));
+  PLVS_HIP_TRY(h->rec_c.reserve(V));
+  PLVS_HIP_TRY(h->scratch.reserve(radix_scratch_words(V)));
+  const bool by_cloud = N > 1;   // (one source: the records are in sequence order already)
+  if (by_cloud) {
+    PLVS_HIP_TRY(h->sv_vkey.reserve(V));
+    PLVS_HIP_TRY(h->sv_seq.reserve(V));
+  }
+  hipLaunchKernelGGL(vb_shard_translate, dim3(ceil_div((size_t)V, 256)), dim3(256), 0, s, static_cast<const uint4*>(d_recv), V,
+                     h->dir, rank, N, h->d_ctr, by_cloud ? h->sv_vkey.p : h->keys0.p, by_cloud ? h->sv_seq.p : h->seq0.p,
+                     by_cloud ? h->keys0.p : (uint32_t*)nullptr, by_cloud ? h->seq0.p : (uint32_t*)nullptr);
+  PLVS_KERNEL_CHECK();
+  int rc = vb_read_counters(h, s);
+  if (rc != PLVS_OK) return rc;
+  if (h->h_ctr->err) {
+    h->poisoned = true;
+    plvs::set_error("tsdf_voxblox shard_apply: %s%s%s", (h->h_ctr->err & kErrPoolFull) ? "block pool full (raise max_blocks) " : "",
+                    (h->h_ctr->err & kErrCoordRange) ? "block id outside +-2^20 " : "",
+                    (h->h_ctr->err & kErrDirectoryMiss) ? "a record for a block of another rank " : "");
+    return PLVS_ERR_CAPACITY;
+  }
+  const int before = h->num_blocks;
+  h->num_blocks = h->h_ctr->num_blocks;
+  const int published_lo = h->visible_blocks, published_hi = before;
+  h->visible_blocks = h->num_blocks;
+  h->stats.visits = V;
+  h->stats.new_chunks = h->num_blocks - before;
+  PLVS_HIP_TRY(h->updated.reserve((size_t)h->num_blocks + 1));
+  bool second = false;
+  if (by_cloud) {   // (cloud, record index) -> the records in cloud order, each cloud's in its sender's (sequence) order
+    int cbits = 1;
+    while ((1ll << cbits) < (long long)nclouds) ++cbits;
+    PLVS_HIP_TRY(radix_sort_pairs(h->keys0.p, h->seq0.p, h->keys1.p, h->seq1.p, V, 0, cbits, h->scratch.p, s, &second));
+    const uint32_t* order = second ? h->seq1.p : h->seq0.p;
+    uint32_t* k_out = second ? h->keys0.p : h->keys1.p;   // (the pair of buffers the sort has left free)
+    uint32_t* q_out = second ? h->seq0.p : h->seq1.p;
+    hipLaunchKernelGGL(vb_shard_permute, dim3(ceil_div((size_t)V, 256)), dim3(256), 0, s, h->sv_vkey.p, h->sv_seq.p, order, V, k_out, q_out);
+    PLVS_KERNEL_CHECK();
+    if (!second) {   // the permuted records sit in keys1 / seq1: make them the sort's input pair
+      std::swap(h->keys0, h->keys1);
+      std::swap(h->seq0, h->seq1);
+    }
+  }
+  int key_bits = 12;
+  while ((1ll << (key_bits - 12)) < (long long)h->num_blocks) ++key_bits;
+  second = false;
+  PLVS_HIP_TRY(radix_sort_pairs(h->keys0.p, h->seq0.p, h->keys1.p, h->seq1.p, V, 0, key_bits, h->scratch.p, s, &second));
+  const uint32_t* keys = second ? h->keys1.p : h->keys0.p;
+  const uint32_t* seqs = second ? h->seq1.p : h->seq0.p;
+  hipLaunchKernelGGL(vb_expand<kSimple>, dim3(ceil_div(V, kExpandThreads)), dim3(kExpandThreads), 0, s, h->P, keys, seqs, V, d_xyz,
+                     (const float*)nullptr, d_col, h->offsets.p, nclouds, h->poses.p, h->dir.slot_ids, h->rec.p, h->rec_c.p,
+                     h->heads.p, h->updated.p, h->d_ctr);
+  PLVS_KERNEL_CHECK();
+  hipLaunchKernelGGL(vb_chain_chunks, dim3(ceil_div(V, kChainChunk)), dim3(kChainThreads), 0, s, h->P, keys, V, h->rec.p,
+                     h->rec_c.p, h->d_ctr, h->dist, h->weight, h->rgba);
+  PLVS_KERNEL_CHECK();
+  rc = vb_read_counters(h, s);
+  if (rc != PLVS_OK) return rc;
+  if (h->h_ctr->err) {
+    h->poisoned = true;
+    plvs::set_error("tsdf_voxblox shard_apply: internal directory miss (err=%u)", h->h_ctr->err);
+    return PLVS_ERR_CAPACITY;
+  }
+  h->stats.updated_chunks = (int32_t)h->h_ctr->num_updated;
+  h->stats.voxels = (int32_t)h->h_ctr->num_heads;
+  h->stats.max_run = (int32_t)h->h_ctr->max_run;
+  h->last_updated = h->h_ctr->num_updated;
+  return vb_publish_waiting(h, s, published_lo, published_hi);
 }
 
 int plvs_hip_tsdf_voxblox_integrate_fast_batch_dev(plvs_tsdf_voxblox* h, const float* d_xyz, const uint8_t* d_rgba,

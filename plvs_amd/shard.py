@@ -147,6 +147,41 @@ def sharded_integrate(tsdf, d_xyz, d_rgb, d_kfid, offsets, d_Twc, group=None, ti
     return counts
 
 
+def sharded_integrate_voxblox(tsdf, d_xyz, d_rgba, offsets, d_Twc, group=None, timings=None):
+    """One ray-sharded integrate call of this rank's TsdfVoxblox ("simple"; every rank calls it with the same clouds):
+    the rank casts the rays of its clouds (cloud c -> rank c % world), every voxel visit travels to the block's owner as
+    a 16-byte record, the owner applies them in the reference's order (plvs_amd/csrc/tsdf_voxblox_shard.hpp).  Two
+    collectives: the counts, the records.  timings: as in sharded_integrate ('walk', 'pack', 'exchange', 'apply')."""
+    world = dist.get_world_size(group)
+    dev = d_xyz.device
+    t_last = [0.0]
+
+    def lap(name):
+        if timings is None:
+            return
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        now = time.perf_counter()
+        if name is not None:
+            timings[name] = timings.get(name, 0.0) + (now - t_last[0]) * 1e3
+        t_last[0] = now
+
+    lap(None)
+    counts = tsdf.shard_walk(d_xyz, offsets, d_Twc)
+    lap("walk")
+    send = torch.empty((int(counts.sum()), 4), dtype=torch.int32, device=dev)    # (shard_pack fills every row)
+    tsdf.shard_pack(send)
+    lap("pack")
+    if world == 1:
+        recv, rcounts = send, [int(counts[0])]
+    else:
+        recv, rcounts = _all_to_all_rows(send, counts, group)
+    lap("exchange")
+    tsdf.shard_apply(recv, rcounts, d_xyz, d_rgba, offsets, d_Twc)
+    lap("apply")
+    return counts
+
+
 def _all_to_all_rows(send, send_counts, group):
     """send [sum, w] grouped by destination rank, send_counts [world] -> (recv grouped by source, recv_counts)."""
     world = dist.get_world_size(group)

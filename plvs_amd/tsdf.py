@@ -414,6 +414,7 @@ class TsdfVoxblox:
         if max_weight is not None:          # TsdfIntegratorBase::Config::max_weight (10000 unless the caller says otherwise)
             p.max_weight = float(max_weight)
         p.shard_rank, p.shard_count = int(shard_rank), int(shard_count)
+        self.shard_rank, self.shard_count = int(shard_rank), int(shard_count)
         self.params = p
         self._h = _vp()
         _lib.check(_L.plvs_hip_tsdf_voxblox_create(ctypes.byref(p), ctypes.byref(self._h)))
@@ -517,6 +518,34 @@ class TsdfVoxblox:
         _lib.check(_L.plvs_hip_tsdf_voxblox_integrate_batch_dev(
             self._h, _lib.t_ptr(d_xyz), _lib.t_ptr(d_rgba), _lib.np_ptr(offsets), offsets.shape[0] - 1,
             _lib.t_ptr(d_Twc), _lib.current_stream_ptr()))
+
+    # ---- ray-sharded multi-GPU integrate ("simple", shard_count >= 1): walk -> pack -> exchange -> apply
+    def shard_walk(self, d_xyz, offsets, d_Twc):
+        """Phase 1: this rank casts the rays of its clouds (cloud c belongs to rank c % shard_count).  Returns the
+        int64 array [shard_count] of visit records bound for every rank."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        counts = np.zeros(max(1, self.shard_count), np.int64)
+        f = _L.plvs_hip_tsdf_voxblox_shard_walk
+        f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 3
+        _lib.check(f(self._h, _lib.t_ptr(d_xyz), _lib.np_ptr(offsets), offsets.shape[0] - 1, _lib.t_ptr(d_Twc),
+                     _lib.np_ptr(counts), _lib.current_stream_ptr()))
+        return counts
+
+    def shard_pack(self, d_send):
+        """Phase 2: fills the send buffer (torch int32 tensor [records, 4]), grouped by destination rank in rank order."""
+        f = _L.plvs_hip_tsdf_voxblox_shard_pack
+        f.argtypes = [ctypes.c_void_p] * 3
+        _lib.check(f(self._h, _lib.t_ptr(d_send), _lib.current_stream_ptr()))
+
+    def shard_apply(self, d_recv, recv_counts, d_xyz, d_rgba, offsets, d_Twc):
+        """Phase 3: the received records (grouped by source rank in rank order; recv_counts [shard_count]) are applied
+        to this rank's blocks in the reference's order; the clouds again: the owner recomputes a visit's operands."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        recv_counts = np.ascontiguousarray(recv_counts, dtype=np.int64)
+        f = _L.plvs_hip_tsdf_voxblox_shard_apply
+        f.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] + [ctypes.c_void_p] * 2
+        _lib.check(f(self._h, _lib.t_ptr(d_recv), _lib.np_ptr(recv_counts), _lib.t_ptr(d_xyz), _lib.t_ptr(d_rgba),
+                     _lib.np_ptr(offsets), offsets.shape[0] - 1, _lib.t_ptr(d_Twc), _lib.current_stream_ptr()))
 
     def last_stats(self):
         s = _lib.TsdfStats()

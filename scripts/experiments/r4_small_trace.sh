@@ -3,7 +3,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/${1:-r04s}; mkdir -p $O
 export TMPDIR=/tmp
 R=$PWD
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $R/$O/prof -o r -- python $R/scripts/experiments/small_calls.py ${2:-5} 2 2>&1 | grep "K=" ) > $O/calls.log 2>&1
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $R/$O/prof -o r -- python $R/scripts/experiments/small_calls.py ${2:-5} 2 ${4:-} 2>&1 | grep "K=" ) > $O/calls.log 2>&1
 cat $O/calls.log
 python scripts/experiments/trace_gaps.py $(find $O/prof -name "*kernel_trace.csv" | head -1) ${3:-50} > $O/gaps.txt
 cat $O/gaps.txt

@@ -1,6 +1,6 @@
 """The order-free integrate in calls of K key frames (default 5: PointCloudMapping::UpdateMap's batch) on a fresh map
 (first lap) and on the map that lap left (second lap): wall time per call and the library's stage times.
-usage: small_calls.py [K] [laps]"""
+usage: small_calls.py [K] [laps] [--ordered]"""
 import os
 import sys
 import time
@@ -12,8 +12,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from plvs_amd.synth_scene import make_keyframes  # noqa: E402
 from plvs_amd.tsdf import TsdfChisel  # noqa: E402
 
-K = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-LAPS = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+ORDERED = "--ordered" in sys.argv
+ARGS = [a for a in sys.argv[1:] if not a.startswith("-")]
+K = int(ARGS[0]) if len(ARGS) > 0 else 5
+LAPS = int(ARGS[1]) if len(ARGS) > 1 else 2
 kfs = make_keyframes(100, max_depth=5.0, seed=0)
 calls = []
 for j0 in range(0, 100, K):
@@ -23,7 +25,7 @@ for j0 in range(0, 100, K):
                   torch.from_numpy(np.concatenate([k["kfid"] for k in g]).astype(np.int32)).cuda(),
                   np.cumsum([0] + [k["xyz"].shape[0] for k in g]).astype(np.int32),
                   torch.from_numpy(np.stack([k["Twc"] for k in g])).cuda()))
-t = TsdfChisel(0.05, max_chunks=16384, order_free=True)
+t = TsdfChisel(0.05, max_chunks=16384, order_free=not ORDERED)
 for c in calls:           # warm-up lap: sizes the scratch buffers
     t.integrate_batch_dev(*c)
 t.clear()
