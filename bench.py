@@ -95,13 +95,18 @@ def main():
 
     from plvs_amd import _lib
     from plvs_amd.synth_scene import LOOP, make_keyframes, make_stream_keyframes
-    from plvs_amd.shard import BlockDirectory, allgather_block_lists, sharded_integrate
+    from plvs_amd.shard import BlockDirectory, allgather_block_lists, sharded_integrate, sharded_integrate_voxblox
     from plvs_amd.tsdf import TsdfChisel, TsdfVoxblox
 
     # ---------------------------------------------------------------- inputs
     n_poses = 100                                    # 100 poses, 3.6 deg yaw step
     total_steps = args.warmup + args.steps
     vbx = args.backend == "voxblox"
+    # N > 1 (voxblox, "simple"): the ray-sharded integrate of tsdf_voxblox_shard.hpp — rank r casts the rays of every N-th key
+    # frame of the step and sends the voxel visits to the block owners.  STRONG scaling (the step stays --batch key frames):
+    # the update is an ordered fold per voxel, and a step of N x 25 consecutive key frames of one camera makes every voxel's
+    # run N times longer instead of giving the ranks more voxels (one device: 1.07 ms for 25 key frames, 21 ms for 200).
+    vbx_sharded = multi and vbx
     if vbx:                      # 2 cm voxels, 16x12x3 m room, depths to 8 m
         if args.resolution == 0.05:
             args.resolution = 0.02
@@ -154,7 +159,9 @@ def main():
 
     def step(b):
         xyz, rgb, kfid, offsets, Twc = b
-        if vbx:
+        if vbx_sharded:
+            sharded_integrate_voxblox(tsdf, xyz, rgb, offsets, Twc)
+        elif vbx:
             tsdf.integrate_batch_dev(xyz, rgb, offsets, Twc)
         elif ray_sharded:
             sharded_integrate(tsdf, xyz, rgb, kfid, offsets, Twc)
@@ -208,6 +215,14 @@ def main():
     # other_leg: the same job under the OTHER scaling rule (weak: --batch key frames per GPU per step; strong: --batch
     # key frames per step whatever N), so one run of `bench.py --gpus N` gives both curves.
     phases_ms, other_leg = None, None
+    if vbx_sharded:
+        tim = {}
+        for s in range(3):
+            sharded_integrate_voxblox(tsdf, *[batches[s % len(batches)][i] for i in (0, 1, 3, 4)], timings=tim)
+        names = ["walk", "pack", "exchange", "apply"]
+        t = torch.tensor([tim.get(k, 0.0) / 3.0 for k in names], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        phases_ms = {k: round(float(v), 4) for k, v in zip(names, t.tolist())}
     if ray_sharded:
         tim = {}
         for s in range(3):
@@ -310,7 +325,11 @@ def main():
                        "voxels_per_step": int(voxels // args.steps), "longest_voxel_run": int(max_run),
                        "parallelism": (f"ray-sharded x{world}: rank r walks tiles t = r (mod {world}), partial sums and "
                                        f"colour runs go to the chunk owners (three-prime hash mod {world}) in one "
-                                       "all-to-all per step" if ray_sharded else f"chunk-hash shard x{world}"),
+                                       "all-to-all per step" if ray_sharded else
+                                       (f"ray-sharded x{world}: rank r casts the rays of the key frames c = r (mod {world}), every voxel "
+                                        f"visit goes to the block's owner (three-prime hash mod {world}) as a 16-byte record in one "
+                                        "all-to-all per step, the owner applies them in the reference's order" if vbx_sharded else
+                                        f"chunk-hash shard x{world}")),
                        "global_directory_blocks": (gdir.count() if gdir is not None else None)},
             "roofline": roofline,
         }

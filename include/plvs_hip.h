@@ -1001,6 +1001,10 @@ int plvs_hip_tsdf_voxblox_shard_pack(plvs_tsdf_voxblox* h, void* d_send, void* s
 int plvs_hip_tsdf_voxblox_shard_apply(plvs_tsdf_voxblox* h, const void* d_recv, const int64_t* recv_counts,
                                       const float* d_xyz, const uint8_t* d_rgba, const int32_t* offsets, int nclouds,
                                       const float* d_Twc, void* stream);
+/* The three phases with the exchanges over RCCL (grouped ncclSend / ncclRecv); rccl_comm is the caller's ncclComm_t, one
+ * process per GPU, its size and rank those of the map's shard_count / shard_rank. */
+int plvs_hip_tsdf_voxblox_integrate_sharded(plvs_tsdf_voxblox* h, void* rccl_comm, const float* d_xyz, const uint8_t* d_rgba,
+                                            const int32_t* offsets, int nclouds, const float* d_Twc, void* stream);
 
 /* The "fast" integration method (PointCloudMapping.voxbloxIntegrationMethod: "fast" — the default of PLVS's YAML files):
  * FastTsdfIntegrator::integratePointCloud (Thirdparty/voxblox/src/integrator/tsdf_integrator.cc:505-605) in its

@@ -346,6 +346,104 @@ int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm,
   return PLVS_OK;
 }
 
+// The ray-sharded voxblox integrate with its exchange over RCCL (tsdf_voxblox_shard.hpp): shard_walk, the all-to-all of the
+// counts, shard_pack, the all-to-all of the 16-byte visit records (grouped ncclSend / ncclRecv, uint32 words), shard_apply.
+// A rank whose walk fails goes through both exchanges with nothing to send and says so in its counts (-1): nobody applies
+// anything, the step is void on every rank (the failing rank returns its own error, the others PLVS_ERR_HALO).
+int plvs_hip_tsdf_voxblox_integrate_sharded(plvs_tsdf_voxblox* h, void* rccl_comm, const float* d_xyz, const uint8_t* d_rgba,
+                                            const int32_t* offsets, int nclouds, const float* d_Twc, void* stream) {
+  PLVS_REQUIRE(h && rccl_comm, "null argument");
+  const Rccl* r = rccl();
+  if (r == nullptr || !r->send || !r->recv || !r->group_start || !r->group_end) {
+    plvs::set_error("RCCL is not available in this process (ncclSend / ncclRecv / librccl.so.1 not found)");
+    return PLVS_ERR_NO_DEVICE;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int world = 0, rank = 0;
+  if (r->comm_count(rccl_comm, &world) != 0 || r->comm_rank(rccl_comm, &rank) != 0 || world < 1 || world > 64) {
+    plvs::set_error("bad RCCL communicator (1..64 ranks)");
+    return PLVS_ERR_INVALID_ARG;
+  }
+  struct Scratch {   // grow-only device buffers of this thread
+    plvs::DevBuf<long long> cnt;
+    plvs::DevBuf<uint32_t> send, recv;
+  };
+  static thread_local Scratch B;
+  constexpr size_t kWords = 4;   // uint32 words of a visit record (kVbWire)
+  int64_t sc[64], rcv[64];
+  int failed = plvs_hip_tsdf_voxblox_shard_walk(h, d_xyz, offsets, nclouds, d_Twc, sc, stream);
+  if (failed != PLVS_OK)
+    for (int p = 0; p < world; ++p) sc[p] = -1;
+  bool peer_failed = false;
+#define RCCL_TRY(call)                                                      \
+  do {                                                                      \
+    const int e_ = (call);                                                  \
+    if (e_ != 0) {                                                          \
+      plvs::set_error("%s failed: %s", #call, r->err ? r->err(e_) : "?");   \
+      return PLVS_ERR_HIP;                                                  \
+    }                                                                       \
+  } while (0)
+  PLVS_HIP_TRY(B.cnt.reserve((size_t)2 * world));
+  PLVS_HIP_TRY(hipMemcpyAsync(B.cnt.p, sc, (size_t)world * sizeof(long long), hipMemcpyHostToDevice, s));
+  RCCL_TRY(r->group_start());
+  for (int p = 0; p < world; ++p) {
+    RCCL_TRY(r->send(B.cnt.p + p, 1, /*ncclInt64*/ 4, p, rccl_comm, s));
+    RCCL_TRY(r->recv(B.cnt.p + world + p, 1, /*ncclInt64*/ 4, p, rccl_comm, s));
+  }
+  RCCL_TRY(r->group_end());
+  PLVS_HIP_TRY(hipMemcpyAsync(rcv, B.cnt.p + world, (size_t)world * sizeof(long long), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  size_t stot = 0, rtot = 0;
+  for (int p = 0; p < world; ++p) {
+    if (rcv[p] < 0) {
+      peer_failed = peer_failed || p != rank;
+      rcv[p] = 0;
+    }
+    if (sc[p] < 0) sc[p] = 0;
+    stot += (size_t)sc[p];
+    rtot += (size_t)rcv[p];
+  }
+  PLVS_HIP_TRY(B.send.reserve(stot * kWords + 4));
+  PLVS_HIP_TRY(B.recv.reserve(rtot * kWords + 4));
+  bool late_failure = false;   // a failure after the counts exchange: peers may apply what this rank could not
+  if (failed == PLVS_OK) {
+    failed = plvs_hip_tsdf_voxblox_shard_pack(h, B.send.p, stream);
+    late_failure = failed != PLVS_OK;
+  }
+  RCCL_TRY(r->group_start());
+  {
+    size_t so = 0, ro = 0;
+    for (int p = 0; p < world; ++p) {
+      const size_t ns = (size_t)sc[p] * kWords, nr = (size_t)rcv[p] * kWords;
+      if (ns) RCCL_TRY(r->send(B.send.p + so, ns, /*ncclUint32*/ 3, p, rccl_comm, s));
+      if (nr) RCCL_TRY(r->recv(B.recv.p + ro, nr, /*ncclUint32*/ 3, p, rccl_comm, s));
+      so += ns;
+      ro += nr;
+    }
+  }
+  RCCL_TRY(r->group_end());
+#undef RCCL_TRY
+  if (failed == PLVS_OK && !peer_failed) {
+    failed = plvs_hip_tsdf_voxblox_shard_apply(h, B.recv.p, rcv, d_xyz, d_rgba, offsets, nclouds, d_Twc, stream);
+    late_failure = failed != PLVS_OK;
+  }
+  if (failed != PLVS_OK) {
+    if (late_failure) {
+      char own[400];
+      snprintf(own, sizeof own, "%s", plvs::last_error_buf());
+      plvs::set_error("%s — after the exchange had begun: other ranks may have applied this step, the sharded map is "
+                      "inconsistent and must be cleared / rebuilt", own);
+    }
+    return failed;
+  }
+  if (peer_failed) {
+    plvs::set_error("a peer rank failed in its walk of the sharded integrate: nothing was applied on any rank that reports "
+                    "this (the step is void and can be repeated once the peer recovers)");
+    return PLVS_ERR_HALO;
+  }
+  return PLVS_OK;
+}
+
 }  // extern "C"
 
 namespace {

@@ -306,6 +306,30 @@ def test_hip_ray_sharded_integrate_through_torch_distributed_and_rccl_at_world_o
         assert fetched == 0 and all(a[n].tobytes() == b[n].tobytes() for n in ("vertices", "normals", "colors", "block_first"))
         assert vb.halo_gather(comm, bids) == 0          # the same exchange behind the C ABI over the ncclComm_t
         vb.close()
+        # the ray-sharded voxblox integrate through the same two transports
+        from plvs_amd.shard import sharded_integrate_voxblox
+        vs, vt, vr = TsdfVoxblox(0.05), TsdfVoxblox(0.05), TsdfVoxblox(0.05)
+        fv = _lib.lib.plvs_hip_tsdf_voxblox_integrate_sharded
+        fv.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] + [ctypes.c_void_p] * 2
+        for b0 in range(0, len(kfs), 3):
+            part = kfs[b0:b0 + 3]
+            xyz, rgb, kfid, offsets, Twc = _batch(part)
+            rgba = torch.cat([rgb, torch.full((rgb.shape[0], 1), 255, dtype=torch.uint8, device="cuda")], dim=1).contiguous()
+            vs.integrate_batch_dev(xyz, rgba, offsets, Twc)
+            sharded_integrate_voxblox(vt, xyz, rgba, offsets, Twc)
+            _lib.check(fv(vr._h, comm, _lib.t_ptr(xyz), _lib.t_ptr(rgba), _lib.np_ptr(offsets), offsets.shape[0] - 1,
+                          _lib.t_ptr(Twc), _lib.current_stream_ptr()))
+            torch.cuda.synchronize()
+            assert vs.last_stats()["visits"] == vt.last_stats()["visits"] == vr.last_stats()["visits"] > 0
+        bids = sorted(tuple(x) for x in vs.chunk_ids())
+        for other in (vt, vr):
+            assert sorted(tuple(x) for x in other.chunk_ids()) == bids
+            for bid in bids:
+                for x, y in zip(vs.get_chunk(*bid), other.get_chunk(*bid)):
+                    assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x,
+                                          y.view(np.uint32) if y.dtype == np.float32 else y)
+        for t in (vs, vt, vr):
+            t.close()
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)
