@@ -1647,8 +1647,10 @@ int plvs_hip_tsdf_voxblox_shard_apply(plvs_tsdf_voxblox* h, const void* d_recv, 
     PLVS_HIP_TRY(h->sv_vkey.reserve(V));
     PLVS_HIP_TRY(h->sv_seq.reserve(V));
   }
+  hipLaunchKernelGGL(vb_shard_insert, dim3(ceil_div((size_t)V, 256)), dim3(256), 0, s, static_cast<const uint4*>(d_recv), V, h->dir,
+                     rank, N, h->d_ctr);
   hipLaunchKernelGGL(vb_shard_translate, dim3(ceil_div((size_t)V, 256)), dim3(256), 0, s, static_cast<const uint4*>(d_recv), V,
-                     h->dir, rank, N, h->d_ctr, by_cloud ? h->sv_vkey.p : h->keys0.p, by_cloud ? h->sv_seq.p : h->seq0.p,
+                     h->dir, h->d_ctr, by_cloud ? h->sv_vkey.p : h->keys0.p, by_cloud ? h->sv_seq.p : h->seq0.p,
                      by_cloud ? h->keys0.p : (uint32_t*)nullptr, by_cloud ? h->seq0.p : (uint32_t*)nullptr);
   PLVS_KERNEL_CHECK();
   int rc = vb_read_counters(h, s);

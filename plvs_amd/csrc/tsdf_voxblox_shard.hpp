@@ -90,8 +90,27 @@ __global__ void vb_shard_gather(const uint4* __restrict__ rec, const uint32_t* _
   if (j < n) out[j] = rec[order ? order[j] : j];
 }
 
-// Received records -> voxel key in the owner's pool (first-touch blocks are inserted), sequence number, cloud.
-__global__ __launch_bounds__(256) void vb_shard_translate(const uint4* __restrict__ rec, uint32_t n, Directory dir, int rank, int nranks,
+// Received records: first-touch blocks enter the owner's directory (dir_insert never waits: the slot of a block inserted here
+// is looked up by the NEXT kernel, as the count pass and the fill pass of the single-device call do — a find-or-insert that
+// waits for another lane's slot met a circular wait between waves here, 64 records of a wave naming the same new block).
+__global__ __launch_bounds__(256) void vb_shard_insert(const uint4* __restrict__ rec, uint32_t n, Directory dir, int rank, int nranks,
+                                                       VCounters* __restrict__ ctr) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const uint4 r = rec[j];
+  if (j > 0) {   // (consecutive records mostly name the same block: one insertion attempt per change)
+    const uint4 q = rec[j - 1];
+    if (q.x == r.x && q.y == r.y && (j & 63u) != 0u) return;
+  }
+  const unsigned long long key = (unsigned long long)r.x | ((unsigned long long)r.y << 32);
+  const int x = (int)((key >> 42) & 0x1FFFFFu) - kCoordBias, y = (int)((key >> 21) & 0x1FFFFFu) - kCoordBias,
+            z = (int)(key & 0x1FFFFFu) - kCoordBias;
+  if (shard_of(owner_hash(x, y, z), nranks) != rank) atomicOr(&ctr->err, kErrDirectoryMiss);   // (a record sent to the wrong rank)
+  else dir_insert(dir, x, y, z, &ctr->num_blocks, &ctr->err);
+}
+
+// ... -> voxel key in the owner's pool, sequence number, cloud.
+__global__ __launch_bounds__(256) void vb_shard_translate(const uint4* __restrict__ rec, uint32_t n, Directory dir,
                                                           VCounters* __restrict__ ctr, uint32_t* __restrict__ vkey,
                                                           uint32_t* __restrict__ seq, uint32_t* __restrict__ cloud,
                                                           uint32_t* __restrict__ index) {
@@ -101,9 +120,8 @@ __global__ __launch_bounds__(256) void vb_shard_translate(const uint4* __restric
   const unsigned long long key = (unsigned long long)r.x | ((unsigned long long)r.y << 32);
   const int x = (int)((key >> 42) & 0x1FFFFFu) - kCoordBias, y = (int)((key >> 21) & 0x1FFFFFu) - kCoordBias,
             z = (int)(key & 0x1FFFFFu) - kCoordBias;
-  int slot = -1;
-  if (shard_of(owner_hash(x, y, z), nranks) != rank) atomicOr(&ctr->err, kErrDirectoryMiss);   // (a record sent to the wrong rank)
-  else slot = dir_find_or_insert(dir, x, y, z, &ctr->num_blocks, &ctr->err);
+  const int slot = dir_find(dir, x, y, z);
+  if (slot < 0) atomicOr(&ctr->err, kErrDirectoryMiss);
   vkey[j] = (slot < 0 ? 0u : (uint32_t)slot) * (uint32_t)kBlockVox + (r.z & 0xFFFu);
   seq[j] = r.w;
   if (cloud) {

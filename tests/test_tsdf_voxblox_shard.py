@@ -86,6 +86,28 @@ def test_hip_ray_sharded_voxblox_integrate_equals_the_oracle_shard_by_shard(orac
         t.close()
 
 
+@pytest.mark.gpu
+def test_hip_ray_sharded_voxblox_at_configs3_size_equals_the_single_device_layer():
+    """2 cm voxels, full-resolution key frames with depths to 8 m (configs[3]): millions of visit records per call — the
+    partition, the cloud sort and the voxel sort take the large-array radix passes — on three ranks; the union of the
+    shards is the single-device layer bit for bit."""
+    from plvs_amd.tsdf import TsdfVoxblox
+    kfs = make_keyframes(5, room_size=(16.0, 12.0, 3.0), max_depth=8.0, seed=41)
+    world = 3
+    ranks = [TsdfVoxblox(0.02, max_blocks=65536, shard_rank=r, shard_count=world) for r in range(world)]
+    single = TsdfVoxblox(0.02, max_blocks=65536)
+    for part in (kfs[:4], kfs[4:]):
+        xyz, rgba, offsets, Twc = _batch(part)
+        single.integrate_batch_dev(xyz, rgba, offsets, Twc)
+        counts = sharded_step(ranks, xyz, rgba, offsets, Twc)
+        assert int(sum(c.sum() for c in counts)) == single.last_stats()["visits"]
+        largest = max(locals().get("largest", 0), single.last_stats()["visits"])
+    assert largest > (1 << 20), "the first call must take the large-array radix passes"
+    assert compare_union(single, ranks) > 200
+    for t in ranks + [single]:
+        t.close()
+
+
 def compare_union(single, ranks):
     """The shards together are the single-device layer: every block on exactly one rank, bit for bit."""
     ids = {tuple(x) for x in single.chunk_ids()}
