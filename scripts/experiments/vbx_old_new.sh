@@ -1,3 +1,5 @@
+# A/B of the voxblox streaming leg under two builds of the library: put the build to compare with at plvs_amd/lib/libplvs_hip_old.so
+# (e.g. git archive <commit> plvs_amd/csrc include | tar -x -C /tmp/old && make -C /tmp/old/plvs_amd/csrc), then run on the GPU box.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 for V in old new old new; do
   if [ "$V" = "old" ]; then export PLVS_HIP_LIB="$PWD/plvs_amd/lib/libplvs_hip_old.so"; else unset PLVS_HIP_LIB; fi
