@@ -685,12 +685,13 @@ class PointCloudMapVoxblox {
  public:
   using BlockID = std::tuple<int, int, int>;
   // integrationMethod: PointCloudMapping.voxbloxIntegrationMethod (src/PointCloudMapVoxblox.cc:44, :74) — "simple",
-  // "merged" and "fast" (the YAML default) are all on the accelerated path, each the one-thread schedule of the
-  // reference's integrator bit for bit ("fast": with its two approximate hash sets word for word, kept from scan to scan;
-  // plvs_hip.h has the details — on the device it is the slowest of the three: INTEGRATION.md §4).
+  // "merged" and "fast" are all on the accelerated path, each the one-thread schedule of the reference's integrator bit
+  // for bit ("fast": with its two approximate hash sets word for word, kept from scan to scan; plvs_hip.h has the
+  // details — on the device it is the slowest of the three: INTEGRATION.md §4).  The default is the reference's own
+  // (skIntegrationMethod = "fast", :44); "simple" is the opt-in for speed.
   // queueInsertions ("simple" only): InsertCloud uploads, UpdateMap — the one reader of the layer — integrates what waits as
   // one batch (plvs_hip_tsdf_voxblox_queue / _flush): the same layer bit for bit, at a quarter of the per-key-frame cost.
-  explicit PointCloudMapVoxblox(float voxelSize, bool useCarving = false, const std::string& integrationMethod = "simple",
+  explicit PointCloudMapVoxblox(float voxelSize, bool useCarving = false, const std::string& integrationMethod = "fast",
                                 bool queueInsertions = true)
       : merged_(integrationMethod == "merged"), fast_(integrationMethod == "fast"),
         queue_(queueInsertions && integrationMethod == "simple") {

@@ -61,7 +61,10 @@ struct DevBuf {
     if (n <= cap) return hipSuccess;
     // (geometric growth: a buffer sized by a call's input would otherwise be re-allocated by every call a little larger
     // than any before — a hipFree + hipMalloc of hundreds of MB costs milliseconds, on a fresh process far more)
-    size_t want = std::max(n + n / 4 + 64, 2 * cap);
+    // Doubling only while the buffer is small: beyond 256 MB (the masks / records of a long batch run to gigabytes) the
+    // next size is a quarter above the need or the old capacity — callers that know better size their request themselves.
+    const bool large = cap * sizeof(T) > ((size_t)256 << 20);
+    size_t want = std::max(n + n / 4 + 64, large ? cap + cap / 4 : 2 * cap);
     if (p) {
       hipError_t e = hipFree(p);
       p = nullptr;

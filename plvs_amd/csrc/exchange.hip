@@ -27,6 +27,7 @@ using SendFn = int (*)(const void*, size_t, int, int, void*, hipStream_t);
 using RecvFn = int (*)(void*, size_t, int, int, void*, hipStream_t);
 using GroupFn = int (*)();
 using CommCountFn = int (*)(void*, int*);
+using CommAbortFn = int (*)(void*);
 using ErrStrFn = const char* (*)(int);
 struct Rccl {
   AllGatherFn all_gather = nullptr;
@@ -34,8 +35,49 @@ struct Rccl {
   RecvFn recv = nullptr;
   GroupFn group_start = nullptr, group_end = nullptr;
   CommCountFn comm_count = nullptr, comm_rank = nullptr;
+  CommAbortFn comm_abort = nullptr;
   ErrStrFn err = nullptr;
 };
+
+// Once the counts of a sharded step have been exchanged every peer is committed to the collectives that follow with
+// the sizes this rank announced.  From there on a local error must not return past a collective the peers will enter:
+//   soft errors (a HIP call, packing, applying) are NOTED and the rank keeps going through every collective with the
+//     announced sizes (the data it sends is then unspecified; its return value and message say the map is inconsistent);
+//   hard errors (the exchange buffers cannot be allocated, RCCL itself returned an error) leave no way to honour the
+//     announced sizes: the communicator is ABORTED (ncclCommAbort), which fails the peers' pending collectives instead
+//     of leaving them blocked.
+struct LateErrors {
+  int rc = PLVS_OK;          // the first error noted
+  bool hard = false;
+  char msg[400] = {0};
+  void note(int e, bool is_hard) {
+    if (e == PLVS_OK) return;
+    if (rc == PLVS_OK) {
+      rc = e;
+      snprintf(msg, sizeof msg, "%s", plvs::last_error_buf());
+    }
+    hard = hard || is_hard;
+  }
+  void note_hip(hipError_t e, const char* what, bool is_hard) {
+    if (e == hipSuccess) return;
+    plvs::set_error("%s failed: %s", what, hipGetErrorString(e));
+    note(PLVS_ERR_HIP, is_hard);
+  }
+  void note_rccl(const Rccl* r, int e, const char* what) {
+    if (e == 0) return;
+    plvs::set_error("%s failed: %s", what, r->err ? r->err(e) : "?");
+    note(PLVS_ERR_HIP, true);
+  }
+};
+
+int abort_exchange(const Rccl* r, void* comm, const LateErrors& L) {
+  const bool aborted = r->comm_abort != nullptr && r->comm_abort(comm) == 0;
+  plvs::set_error("%s — after the counts of the sharded step had been exchanged and with no way to go through its "
+                  "collectives: %s; other ranks may have applied this step, the sharded map is inconsistent (clear or "
+                  "rebuild it on every rank with a new communicator)", L.msg,
+                  aborted ? "the communicator was aborted so that no peer stays blocked" : "ncclCommAbort is not available: peers may be blocked");
+  return L.rc;
+}
 
 const Rccl* rccl() {
   static Rccl r;
@@ -54,6 +96,7 @@ const Rccl* rccl() {
       r.recv = reinterpret_cast<RecvFn>(dlsym(h, "ncclRecv"));
       r.group_start = reinterpret_cast<GroupFn>(dlsym(h, "ncclGroupStart"));
       r.group_end = reinterpret_cast<GroupFn>(dlsym(h, "ncclGroupEnd"));
+      r.comm_abort = reinterpret_cast<CommAbortFn>(dlsym(h, "ncclCommAbort"));
     }
   }
   return (r.all_gather && r.comm_count && r.comm_rank) ? &r : nullptr;
@@ -274,69 +317,58 @@ int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm,
     }
     if (sc[3 * p] < 0) sc[3 * p] = 0;
   }
-  // ---- payloads
+  // ---- payloads.  From here on no error returns before the last collective (LateErrors, above).
+#undef RCCL_TRY
+  LateErrors L;
   size_t stot[3] = {0, 0, 0}, rtot[3] = {0, 0, 0};
   for (int p = 0; p < world; ++p)
     for (int k = 0; k < 3; ++k) {
       stot[k] += (size_t)sc[3 * p + k];
       rtot[k] += (size_t)rcv[3 * p + k];
     }
+  constexpr int kSatRows = 16384;
+  const size_t msg_words = 4 * ((size_t)kSatRows + 1);
   for (int k = 0; k < 3; ++k) {
-    PLVS_HIP_TRY(B.send[k].reserve(stot[k] * kWords[k] + 4));
-    PLVS_HIP_TRY(B.recv[k].reserve(rtot[k] * kWords[k] + 4));
+    L.note_hip(B.send[k].reserve(stot[k] * kWords[k] + 4), "reserving the send buffer", true);
+    L.note_hip(B.recv[k].reserve(rtot[k] * kWords[k] + 4), "reserving the receive buffer", true);
   }
-  bool late_failure = false;   // a failure after the counts exchange: peers may apply what this rank could not
-  if (failed == PLVS_OK) {
-    failed = plvs_hip_tsdf_chisel_shard_pack(h, B.send[0].p, B.send[1].p, B.send[2].p, stream);
-    // (the peers already expect this rank's counts: what goes out after a failed pack is unspecified data of the
-    // announced size)
-    late_failure = failed != PLVS_OK;
-  }
-  RCCL_TRY(r->group_start());
+  L.note_hip(B.sat.reserve(msg_words), "reserving the saturation message", true);
+  L.note_hip(B.all_sat.reserve(msg_words * world), "reserving the gathered saturation messages", true);
+  if (L.hard) return abort_exchange(r, rccl_comm, L);
+  const bool walked = failed == PLVS_OK;   // (a failed walk was announced: the step is void everywhere, not a late failure)
+  if (walked) L.note(plvs_hip_tsdf_chisel_shard_pack(h, B.send[0].p, B.send[1].p, B.send[2].p, stream), false);
+  // (the peers already expect this rank's counts: what goes out after a failed pack is unspecified data of the announced size)
+  L.note_rccl(r, r->group_start(), "ncclGroupStart");
   {
     size_t so[3] = {0, 0, 0}, ro[3] = {0, 0, 0};
     for (int p = 0; p < world; ++p)
       for (int k = 0; k < 3; ++k) {
         const size_t ns = (size_t)sc[3 * p + k] * kWords[k], nr = (size_t)rcv[3 * p + k] * kWords[k];
-        if (ns) RCCL_TRY(r->send(B.send[k].p + so[k], ns, /*ncclUint32*/ 3, p, rccl_comm, s));
-        if (nr) RCCL_TRY(r->recv(B.recv[k].p + ro[k], nr, /*ncclUint32*/ 3, p, rccl_comm, s));
+        if (ns) L.note_rccl(r, r->send(B.send[k].p + so[k], ns, /*ncclUint32*/ 3, p, rccl_comm, s), "ncclSend");
+        if (nr) L.note_rccl(r, r->recv(B.recv[k].p + ro[k], nr, /*ncclUint32*/ 3, p, rccl_comm, s), "ncclRecv");
         so[k] += ns;
         ro[k] += nr;
       }
   }
-  RCCL_TRY(r->group_end());
+  L.note_rccl(r, r->group_end(), "ncclGroupEnd");
+  if (L.hard) return abort_exchange(r, rccl_comm, L);
   // (a peer announced a failed walk: the step is void — nothing is applied here either, no saturation is reported)
-  if (failed == PLVS_OK && !peer_failed) {
-    failed = plvs_hip_tsdf_chisel_shard_apply(h, B.recv[0].p, B.recv[1].p, B.recv[2].p, rcv, d_rgb, d_kfid, stream);
-    late_failure = failed != PLVS_OK;
-  }
+  const auto live = [&]() { return walked && !peer_failed && L.rc == PLVS_OK; };
+  if (live()) L.note(plvs_hip_tsdf_chisel_shard_apply(h, B.recv[0].p, B.recv[1].p, B.recv[2].p, rcv, d_rgb, d_kfid, stream), false);
   // ---- voxels whose colour saturated: every rank notes every list.  ONE fixed-size all-gather (up to kSatRows voxels + their
   // number in a last row; a longer list waits in the handle for the next step — the list is advisory: a run sent for a
   // saturated voxel is a no-op at its owner), the lengths read on the device: no host read in the feedback.
-  constexpr int kSatRows = 16384;
-  const size_t msg_words = 4 * ((size_t)kSatRows + 1);
-  PLVS_HIP_TRY(B.sat.reserve(msg_words));
-  PLVS_HIP_TRY(B.all_sat.reserve(msg_words * world));
-  PLVS_HIP_TRY(hipMemsetAsync(B.sat.p + 4 * (size_t)kSatRows, 0, 4 * sizeof(int32_t), s));   // (a failed rank announces none)
-  if (failed == PLVS_OK && !peer_failed) {
-    failed = plvs_hip_tsdf_chisel_shard_saturated_message(h, B.sat.p, kSatRows, stream);
-    late_failure = failed != PLVS_OK;
-  }
-  RCCL_TRY(r->all_gather(B.sat.p, B.all_sat.p, msg_words, /*ncclInt32*/ 2, rccl_comm, s));
-  if (failed == PLVS_OK && !peer_failed) {
-    failed = plvs_hip_tsdf_chisel_shard_note_gathered(h, B.all_sat.p, world, kSatRows, stream);
-    late_failure = failed != PLVS_OK;
-  }
+  L.note_hip(hipMemsetAsync(B.sat.p + 4 * (size_t)kSatRows, 0, 4 * sizeof(int32_t), s), "hipMemsetAsync", false);   // (a failed rank announces none)
+  if (live()) L.note(plvs_hip_tsdf_chisel_shard_saturated_message(h, B.sat.p, kSatRows, stream), false);
+  L.note_rccl(r, r->all_gather(B.sat.p, B.all_sat.p, msg_words, /*ncclInt32*/ 2, rccl_comm, s), "ncclAllGather");
+  if (L.hard) return abort_exchange(r, rccl_comm, L);
+  if (live()) L.note(plvs_hip_tsdf_chisel_shard_note_gathered(h, B.all_sat.p, world, kSatRows, stream), false);
   (void)rc;
-#undef RCCL_TRY
-  if (failed != PLVS_OK) {
-    if (late_failure) {   // (keep this rank's own message, add what it means for the job)
-      char own[400];
-      snprintf(own, sizeof own, "%s", plvs::last_error_buf());
-      plvs::set_error("%s — after the exchange had begun: other ranks may have applied this step, the sharded map is "
-                      "inconsistent (clear or rebuild it on every rank)", own);
-    }
-    return failed;
+  if (!walked) return failed;   // its own walk's error; announced, nothing was applied anywhere
+  if (L.rc != PLVS_OK) {   // (keep this rank's own message, add what it means for the job)
+    plvs::set_error("%s — after the exchange had begun: other ranks may have applied this step, the sharded map is "
+                    "inconsistent (clear or rebuild it on every rank)", L.msg);
+    return L.rc;
   }
   if (peer_failed) {
     plvs::set_error("a peer rank failed in its walk of the sharded integrate: nothing was applied on any rank that reports "
@@ -403,38 +435,34 @@ int plvs_hip_tsdf_voxblox_integrate_sharded(plvs_tsdf_voxblox* h, void* rccl_com
     stot += (size_t)sc[p];
     rtot += (size_t)rcv[p];
   }
-  PLVS_HIP_TRY(B.send.reserve(stot * kWords + 4));
-  PLVS_HIP_TRY(B.recv.reserve(rtot * kWords + 4));
-  bool late_failure = false;   // a failure after the counts exchange: peers may apply what this rank could not
-  if (failed == PLVS_OK) {
-    failed = plvs_hip_tsdf_voxblox_shard_pack(h, B.send.p, stream);
-    late_failure = failed != PLVS_OK;
-  }
-  RCCL_TRY(r->group_start());
+  // From here on no error returns before the last collective (LateErrors, above).
+#undef RCCL_TRY
+  LateErrors L;
+  L.note_hip(B.send.reserve(stot * kWords + 4), "reserving the send buffer", true);
+  L.note_hip(B.recv.reserve(rtot * kWords + 4), "reserving the receive buffer", true);
+  if (L.hard) return abort_exchange(r, rccl_comm, L);
+  const bool walked = failed == PLVS_OK;   // (a failed walk was announced: the step is void everywhere, not a late failure)
+  if (walked) L.note(plvs_hip_tsdf_voxblox_shard_pack(h, B.send.p, stream), false);
+  L.note_rccl(r, r->group_start(), "ncclGroupStart");
   {
     size_t so = 0, ro = 0;
     for (int p = 0; p < world; ++p) {
       const size_t ns = (size_t)sc[p] * kWords, nr = (size_t)rcv[p] * kWords;
-      if (ns) RCCL_TRY(r->send(B.send.p + so, ns, /*ncclUint32*/ 3, p, rccl_comm, s));
-      if (nr) RCCL_TRY(r->recv(B.recv.p + ro, nr, /*ncclUint32*/ 3, p, rccl_comm, s));
+      if (ns) L.note_rccl(r, r->send(B.send.p + so, ns, /*ncclUint32*/ 3, p, rccl_comm, s), "ncclSend");
+      if (nr) L.note_rccl(r, r->recv(B.recv.p + ro, nr, /*ncclUint32*/ 3, p, rccl_comm, s), "ncclRecv");
       so += ns;
       ro += nr;
     }
   }
-  RCCL_TRY(r->group_end());
-#undef RCCL_TRY
-  if (failed == PLVS_OK && !peer_failed) {
-    failed = plvs_hip_tsdf_voxblox_shard_apply(h, B.recv.p, rcv, d_xyz, d_rgba, offsets, nclouds, d_Twc, stream);
-    late_failure = failed != PLVS_OK;
-  }
-  if (failed != PLVS_OK) {
-    if (late_failure) {
-      char own[400];
-      snprintf(own, sizeof own, "%s", plvs::last_error_buf());
-      plvs::set_error("%s — after the exchange had begun: other ranks may have applied this step, the sharded map is "
-                      "inconsistent and must be cleared / rebuilt", own);
-    }
-    return failed;
+  L.note_rccl(r, r->group_end(), "ncclGroupEnd");
+  if (L.hard) return abort_exchange(r, rccl_comm, L);
+  if (walked && !peer_failed && L.rc == PLVS_OK)
+    L.note(plvs_hip_tsdf_voxblox_shard_apply(h, B.recv.p, rcv, d_xyz, d_rgba, offsets, nclouds, d_Twc, stream), false);
+  if (!walked) return failed;   // its own walk's error; announced, nothing was applied anywhere
+  if (L.rc != PLVS_OK) {
+    plvs::set_error("%s — after the exchange had begun: other ranks may have applied this step, the sharded map is "
+                    "inconsistent and must be cleared / rebuilt", L.msg);
+    return L.rc;
   }
   if (peer_failed) {
     plvs::set_error("a peer rank failed in its walk of the sharded integrate: nothing was applied on any rank that reports "

@@ -656,13 +656,16 @@ class TsdfVoxblox:
 class PointCloudMapVoxblox:
     """Same surface as PLVS2::PointCloudMapVoxblox for the integrate path
     (src/PointCloudMapVoxblox.cc:48-99)."""
-    # "simple", "merged" and "fast" (the reference's YAML default) reproduce the reference's one-thread schedules bit for
-    # bit (INTEGRATION.md §4).  "fast" is no speed-up on the device — it skips nine tenths of the updates at the price of
-    # several rounds over the scan — so the class default stays "simple"; a port that wants maps equal to a PLVS run with
-    # its YAML's method sets it.
-    skIntegrationMethod = "simple"
+    # "simple", "merged" and "fast" reproduce the reference's one-thread schedules bit for bit (INTEGRATION.md §4).
+    # The default is the reference's own static default, "fast" (src/PointCloudMapVoxblox.cc:44; its YAMLs set it too):
+    # a drop-in gives the maps a PLVS run gives.  "fast" is no speed-up on the device — it skips nine tenths of the
+    # updates at the price of several rounds over the scan — so "simple" (the integrator of the measured configs[3]
+    # leg and of the sharded path) is the documented opt-in: integration_method="simple", or a subclass attribute.
+    skIntegrationMethod = "fast"
 
-    def __init__(self, resolution, use_carving=False, max_blocks=None, queue_insertions=True):
+    def __init__(self, resolution, use_carving=False, max_blocks=None, queue_insertions=True, integration_method=None):
+        if integration_method is not None:
+            self.skIntegrationMethod = integration_method
         if self.skIntegrationMethod not in ("simple", "merged", "fast"):
             raise ValueError(f"unknown voxblox integration method {self.skIntegrationMethod!r}")
         self._tsdf = TsdfVoxblox(resolution, use_carving, max_blocks)
@@ -802,6 +805,7 @@ class PointCloudMapChisel:
             self._tsdf.enable_deform()       # the map keeps the reference's chunk order from its first cloud on
         self._meshes_to_update = set()       # Chisel::meshesToUpdate
         self.all_meshes = {}                 # chunk id -> dict(vertices, normals, colors, kfids)
+        self._pending = False                # clouds queued since the last _flush (their chunks are not yet marked)
 
     def InsertCloud(self, cloud_camera, Twc, max_range=None):
         """cloud_camera: dict/obj with xyz [n,3] f32, rgb [n,3] u8 (r,g,b members of
@@ -810,6 +814,7 @@ class PointCloudMapChisel:
         Twc = np.asarray(Twc, dtype=np.float32)[:3, :4]
         if self.queue_insertions:
             self._tsdf.queue(cloud_camera["xyz"], cloud_camera["rgb"], cloud_camera.get("kfid"), Twc)
+            self._pending = True
             return
         self._tsdf.integrate(cloud_camera["xyz"], cloud_camera["rgb"], cloud_camera.get("kfid"), Twc)
         self._mark_updated()
@@ -822,9 +827,13 @@ class PointCloudMapChisel:
                         self._meshes_to_update.add((int(c[0]) + dx, int(c[1]) + dy, int(c[2]) + dz))
 
     def _flush(self):
-        """Integrates the queued key frames (one batch) and notes the meshes they invalidate."""
-        if self._tsdf.queued():
-            self._tsdf.flush()
+        """Integrates the queued key frames (one batch) and notes the meshes they invalidate.  `_pending`, not the
+        handle's queue length, decides: a C reader reached in between flushes the queue itself (PLVS_FLUSH_QUEUE), and
+        the batch's chunks must still be marked — the handle's updated list stays that batch's until the next integrate."""
+        if self._pending:
+            if self._tsdf.queued():
+                self._tsdf.flush()
+            self._pending = False
             self._mark_updated()
 
     def InsertCloudWithDepth(self, cloud_camera, Twc, depthImage, fx, fy, cx, cy, max_range=None):
@@ -910,6 +919,7 @@ class PointCloudMapChisel:
         key frames as :420-478 does.  -> the output cloud after the change."""
         if self.bResetOnSparseMapChange:
             self._tsdf.clear()                               # Chisel::Reset: chunks, meshes, meshesToUpdate
+            self._pending = False                            # (what was queued went with the map)
             self._meshes_to_update.clear()
             self.all_meshes.clear()
         if self.bCloudDeformationOnSparseMapChange:
@@ -928,9 +938,11 @@ class PointCloudMapChisel:
 
     def Clear(self):
         self._tsdf.clear()
+        self._pending = False
         self._meshes_to_update.clear()
         self.all_meshes.clear()
 
     @property
     def tsdf(self):
+        self._flush()
         return self._tsdf

@@ -184,7 +184,7 @@ int main(int argc, char** argv) {
   }
   dump("map_cloud", map.GetPointCloud().data(), map.GetPointCloud().size() * sizeof(PointSurfelSegment));
   std::printf("chisel %d %d %016llx\n", npts, (int)map.GetAllMeshes().size(), (unsigned long long)hv);
-  PointCloudMapVoxblox vmap(0.05f);
+  PointCloudMapVoxblox vmap(0.05f, false, "simple");
   vmap.InsertCloud(cloud, Twc);
   Twc.m[3] -= 0.03f;
   vmap.InsertCloud(cloud, Twc);
@@ -192,7 +192,7 @@ int main(int argc, char** argv) {
   dump("vmap_cloud", vmap.GetPointCloud().data(), vmap.GetPointCloud().size() * sizeof(PointSurfelSegment));
   std::printf("voxblox %d %d %d\n", vmap.NumBlocks(), vpts, (int)vmap.GetMeshLayer().size());
   {   // PLVS's YAML default method
-    PointCloudMapVoxblox vfast(0.05f, false, "fast");
+    PointCloudMapVoxblox vfast(0.05f);   // (the constructor's default, as the reference's: src/PointCloudMapVoxblox.cc:44)
     SE3f Tf = Twc;
     vfast.InsertCloud(cloud, Tf);
     Tf.m[3] += 0.03f;
@@ -202,7 +202,7 @@ int main(int argc, char** argv) {
     std::printf("voxblox_fast %d %d\n", vfast.NumBlocks(), fpts);
   }
   {   // saveMap / loadMap of the layer: into an empty map, meshed there
-    PointCloudMapVoxblox vcopy(0.05f);
+    PointCloudMapVoxblox vcopy(0.05f, false, "simple");
     vcopy.LoadLayer(vmap.SaveLayer());
     const int cpts = vcopy.UpdateMap();
     std::printf("voxblox_layer %d %d %d\n", vcopy.NumBlocks(), cpts,

@@ -118,7 +118,7 @@ def test_cpp_mirror_matches_python_mirror(tmp_path):
     assert int(lines_out["loadmap"][0]) == len(lc) > 500 and int(lines_out["loadmap"][1]) == len(again.all_meshes)
     assert load("loaded_cloud", np.uint8).tobytes() == lc.tobytes()
     from plvs_amd.tsdf import PointCloudMapVoxblox
-    v = PointCloudMapVoxblox(0.05)
+    v = PointCloudMapVoxblox(0.05, integration_method="simple")
     vc = dict(xyz=pc["xyz"], rgba=np.stack([cloud["r"], cloud["g"], cloud["b"], cloud["a"]], -1))
     v.InsertCloud(vc, Twc2)
     Twc3 = Twc2.copy()
@@ -128,9 +128,8 @@ def test_cpp_mirror_matches_python_mirror(tmp_path):
     assert int(lines_out["voxblox"][0]) == v.tsdf.num_chunks()
     assert int(lines_out["voxblox"][1]) == len(vcloud) > 1000 and int(lines_out["voxblox"][2]) == len(v.mesh_layer)
     assert load("vmap_cloud", np.uint8).tobytes() == vcloud.tobytes()
-    class Fast(PointCloudMapVoxblox):
-        skIntegrationMethod = "fast"
-    vf = Fast(0.05)
+    assert PointCloudMapVoxblox.skIntegrationMethod == "fast"     # src/PointCloudMapVoxblox.cc:44
+    vf = PointCloudMapVoxblox(0.05)                                # the default IS the reference's default
     vf.InsertCloud(vc, Twc3)
     Twc4 = Twc3.copy()
     Twc4[0, 3] += np.float32(0.03)

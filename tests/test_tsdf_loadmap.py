@@ -181,13 +181,13 @@ def test_hip_voxblox_world_normals_matches_oracle(oracle, vs, n):
 @pytest.mark.gpu
 def test_voxblox_save_load_round_trip_through_the_mirror(oracle):
     from plvs_amd.tsdf import PointCloudMapVoxblox
-    pm = PointCloudMapVoxblox(0.05)
+    pm = PointCloudMapVoxblox(0.05, integration_method="simple")
     for k in make_keyframes(3, seed=6):
         rgba = np.concatenate([k["rgb"], np.full((len(k["rgb"]), 1), 255, np.uint8)], 1)
         pm.InsertCloud(dict(xyz=k["xyz"], rgba=rgba), k["Twc"])
     saved = pm.UpdateMap()
     assert len(saved) > 8000
-    fresh = PointCloudMapVoxblox(0.05)
+    fresh = PointCloudMapVoxblox(0.05, integration_method="simple")
     reloaded = fresh.LoadMap(saved)
     ref = oracle.voxblox(0.05)
     ref.integrate_world_normals(np.stack([saved["x"], saved["y"], saved["z"]], -1),

@@ -242,7 +242,8 @@ def test_mirror_queues_insertions_until_update_map(oracle):
     from plvs_amd.tsdf import PointCloudMapVoxblox
     vs = 0.05
     kfs = make_keyframes(3, seed=62)
-    a, b = PointCloudMapVoxblox(vs), PointCloudMapVoxblox(vs, queue_insertions=False)
+    a, b = (PointCloudMapVoxblox(vs, integration_method="simple"),
+            PointCloudMapVoxblox(vs, queue_insertions=False, integration_method="simple"))
     for k in kfs:
         a.InsertCloud(dict(xyz=k["xyz"], rgba=rgba_of(k)), k["Twc"])
         b.InsertCloud(dict(xyz=k["xyz"], rgba=rgba_of(k)), k["Twc"])

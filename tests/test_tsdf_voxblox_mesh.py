@@ -193,7 +193,7 @@ def test_update_map_mirror_accumulates_updated_blocks(oracle):
     """PointCloudMapVoxblox.UpdateMap: the blocks of every integrate call since the last UpdateMap are re-meshed,
     the others keep their mesh; the cloud is every block's vertices with the colour round trip."""
     from plvs_amd.tsdf import PointCloudMapVoxblox
-    ref, pm = oracle.voxblox(0.05), PointCloudMapVoxblox(0.05)
+    ref, pm = oracle.voxblox(0.05), PointCloudMapVoxblox(0.05, integration_method="simple")
     kfs = make_keyframes(3, seed=2)
     for k in kfs[:2]:
         ref.integrate(k["xyz"], rgba_of(k), k["Twc"])
@@ -331,11 +331,11 @@ def test_hip_mesh_of_an_analytic_sphere_through_upload_block(oracle):
         total += len(v)
     assert total > 3000
     # save -> load through the mirror
-    src = PointCloudMapVoxblox(vs, max_blocks=64)
+    src = PointCloudMapVoxblox(vs, max_blocks=64, integration_method="simple")
     for bid in ids:
         src.tsdf.set_chunk(*bid, *hip.get_chunk(*bid))
     layer = src.SaveLayer()
-    dst = PointCloudMapVoxblox(vs, max_blocks=64)
+    dst = PointCloudMapVoxblox(vs, max_blocks=64, integration_method="simple")
     assert dst.LoadLayer(layer) and dst.tsdf.num_chunks() == 8
     cloud = dst.UpdateMap()                                                   # every loaded block is marked updated
     assert len(cloud) == total
