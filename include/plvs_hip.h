@@ -505,6 +505,33 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
                                              const int32_t* offsets, int nclouds,
                                              const float* d_Twc, void* stream);
 
+/* Depth images straight into the map: PointCloudMapping::GeneratePointCloudInCameraFrameBGRA's cloud
+ * (src/PointCloudMapping.cc:957-996: p = (gx d, gy d, d) for every pixel (m, n) of the stride-`step` grid with
+ * min_depth < d < max_depth, in raster order, coloured r, g, b = bytes 0, 1, 2 of the pixel) integrated as
+ * PointCloudMapChisel::InsertCloud would (src/PointCloudMapChisel.cc:100-133 -> Chisel.cpp:442-585) — for `nclouds`
+ * images with poses d_Twc[12 c ..], in order — WITHOUT the cloud ever being written to memory.  The map is, bit for bit,
+ * the map of plvs_hip_cloudgen_generate_dev + plvs_hip_tsdf_chisel_integrate_batch_dev on the same images, in both modes
+ * (tests/test_tsdf_chisel_depth.py).  On an order-free handle the walk's tiles are 32 x 16 blocks of grid pixels instead of
+ * 512 consecutive points (neighbouring rays share their voxels: fewer table entries, records and segments per tile),
+ * the point order the colours and key-frame ids need is recovered from (image, pixel).  Everything is DEVICE memory:
+ *   d_depth        image c at d_depth + c * depth_image_stride (floats), rows depth_pitch floats apart
+ *   d_bgr          image c at d_bgr + c * bgr_image_stride (bytes), rows bgr_pitch bytes apart, 3 bytes per pixel
+ *   d_grid_points  matCamGridPoints_ (plvs_hip_cloudgen_grid_points), ceil(height / step) x ceil(width / step) x 2 floats
+ *   d_kfid         one key-frame id per image (may be NULL: 0)
+ * Asynchronous on `stream` except for the call's one read of its counters. */
+typedef struct plvs_depth_batch {
+  const float* d_depth;
+  const uint8_t* d_bgr;
+  size_t depth_image_stride, bgr_image_stride;
+  int depth_pitch, bgr_pitch;
+  int width, height, step;
+  const float* d_grid_points;
+  double min_depth, max_depth;
+  const uint32_t* d_kfid;
+} plvs_depth_batch;
+int plvs_hip_tsdf_chisel_integrate_depth_batch_dev(plvs_tsdf_chisel* h, const plvs_depth_batch* in, int nclouds,
+                                                   const float* d_Twc, void* stream);
+
 /* A cloud WITH NORMALS, as PointCloudMapChisel::LoadMap feeds the saved map through
  * (src/PointCloudMapChisel.cc:527-546 -> ChiselServer::IntegrateWorldPointCloud, ChiselServer.cpp:587-615, Twc =
  * identity there -> Chisel::IntegrateWorldPointCloudWithNormals, Chisel.cpp:238-376): every point casts the

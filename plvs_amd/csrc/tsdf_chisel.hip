@@ -968,6 +968,37 @@ static int deform_track_begin(plvs_tsdf_chisel* h, const float* d_xyz, const flo
                               const float* d_Twc, hipStream_t s);
 static int deform_track_end(plvs_tsdf_chisel* h, hipStream_t s);
 
+// The reference's cloud of every depth image of a call, for the handles that take point streams (ordered / sharded /
+// deform-tracking): cell = (image, grid pixel) in raster order; mark -> exclusive scan -> emit.
+__global__ __launch_bounds__(256) void grid_cloud_mark(GridSrc g, int nclouds, uint32_t* __restrict__ flag) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, ngrid = (size_t)g.gw * g.gh;
+  if (i >= ngrid * (size_t)nclouds) return;
+  const uint32_t c = (uint32_t)(i / ngrid), r = (uint32_t)(i - (size_t)c * ngrid), m = r / g.gw, n = r - m * g.gw;
+  const float d = g.depth[(size_t)c * g.image_stride + (size_t)(m * g.step) * g.pitch + n * g.step];
+  flag[i] = (((double)d > g.min_depth) && ((double)d < g.max_depth)) ? 1u : 0u;   // src/PointCloudMapping.cc:967
+}
+__global__ __launch_bounds__(256) void grid_cloud_emit(GridSrc g, int nclouds, const uint32_t* __restrict__ pos /* cells + 1 */,
+                                                       const uint8_t* __restrict__ bgr, const uint32_t* __restrict__ kfid_of_image,
+                                                       float* __restrict__ xyz, uint8_t* __restrict__ rgb,
+                                                       uint32_t* __restrict__ kfid, uint32_t* __restrict__ offsets) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, ngrid = (size_t)g.gw * g.gh, cells = ngrid * (size_t)nclouds;
+  if (i > cells) return;
+  if (i == cells || i % ngrid == 0) offsets[i / ngrid] = pos[i];
+  if (i == cells || pos[i + 1] == pos[i]) return;
+  const uint32_t c = (uint32_t)(i / ngrid), r = (uint32_t)(i - (size_t)c * ngrid), m = r / g.gw, n = r - m * g.gw;
+  const float d = g.depth[(size_t)c * g.image_stride + (size_t)(m * g.step) * g.pitch + n * g.step];
+  const float2 cam = reinterpret_cast<const float2*>(g.cam)[r];
+  const size_t o = pos[i];
+  xyz[3 * o] = cam.x * d;        // :973-975
+  xyz[3 * o + 1] = cam.y * d;
+  xyz[3 * o + 2] = d;
+  const uint8_t* px = bgr + (size_t)c * g.bgr_image_stride + (size_t)(m * g.step) * g.bgr_pitch + (size_t)(n * g.step) * 3u;
+  rgb[3 * o] = px[0];            // :978-980: the point's r, g, b members take bytes 0, 1, 2 of the pixel
+  rgb[3 * o + 1] = px[1];
+  rgb[3 * o + 2] = px[2];
+  kfid[o] = kfid_of_image ? kfid_of_image[c] : 0u;
+}
+
 static int read_counters(plvs_tsdf_chisel* h, hipStream_t s) {
   hipLaunchKernelGGL(publish_counters, dim3(1), dim3(64), 0, s, (const WalkCounters*)nullptr, h->d_ctr, (WalkCounters*)nullptr,
                      h->h_ctr);
@@ -1056,13 +1087,22 @@ static int ensure_part_acc(plvs_tsdf_chisel* h, uint32_t chunks) {
 
 // Order-free mode: walk_tiles -> segment sort -> apply_chunks (+ the colour fold when the call met voxels
 // whose colour weight is below 254).
+// gsrc (plvs_hip_tsdf_chisel_integrate_depth_batch_dev): the clouds are depth images — tiles are 32 x 16 blocks of grid
+// pixels (GridSrc, tsdf_walk.hpp), d_xyz is null, d_rgb = the colour images, d_kfid = one id per image, offsets =
+// nclouds + 1 zeros (nothing reads them).
 static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uint8_t* d_rgb, const uint32_t* d_kfid,
-                              int n, int nclouds, const int32_t* offsets, const float* d_Twc, hipStream_t s) {
+                              int n, int nclouds, const int32_t* offsets, const float* d_Twc, hipStream_t s,
+                              const GridSrc* gsrc = nullptr) {
   const int max_chunks = h->prm.max_chunks;
+  const GridSrc grid = gsrc ? *gsrc : GridSrc{};
   // tiles: 512 consecutive points of one cloud (tsdf_directory.hpp)
   size_t tiles_of_call = 0;
   for (int c = 0; c < nclouds; ++c) tiles_of_call += ((size_t)(offsets[c + 1] - offsets[c]) + kWalkRays - 1) / kWalkRays;
-  const size_t table_words = 2 * ((size_t)nclouds + 1) + 2 * tiles_of_call;
+  const size_t grid_tiles = gsrc ? (size_t)nclouds * grid.ntx * grid.nty : 0;
+  if (gsrc) PLVS_REQUIRE(grid_tiles < 0x7FFFFFFFull, "too many images in one call");
+  constexpr size_t kGridWords = (sizeof(GridSrc) + 3) / 4;
+  static_assert(sizeof(GridSrc) % 4 == 0 && alignof(GridSrc) <= 8, "GridSrc travels as words behind the offsets");
+  const size_t table_words = 2 * ((size_t)nclouds + 1) + 2 * tiles_of_call + (gsrc ? kGridWords : 0);
   if (h->h_offsets_cap < table_words) {   // pinned copy of the offsets + tile table + tile starts: the prologue kernel reads it
     if (h->h_offsets) (void)hipHostFree(h->h_offsets);
     h->h_offsets = nullptr;
@@ -1070,7 +1110,11 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     PLVS_HIP_TRY(hipHostMalloc((void**)&h->h_offsets, (2 * table_words + 64) * sizeof(int32_t)));
     h->h_offsets_cap = 2 * table_words + 64;
   }
-  const uint32_t ntiles = plvs::tsdf::fill_tile_table(offsets, nclouds, h->h_offsets, kWalkRays);
+  const uint32_t ntiles = gsrc ? (uint32_t)grid_tiles : plvs::tsdf::fill_tile_table(offsets, nclouds, h->h_offsets, kWalkRays);
+  if (gsrc) {   // (zeros: the table is unused; the walk's copy of the grid description travels behind it)
+    plvs::tsdf::fill_tile_table(offsets, nclouds, h->h_offsets, kWalkRays);
+    memcpy(h->h_offsets + 2 * ((size_t)nclouds + 1), &grid, sizeof(GridSrc));
+  }
   {   // the first point of every tile (the colour fold would otherwise search the cloud table once per RUN)
     int32_t* tf = h->h_offsets + 2 * ((size_t)nclouds + 1);
     size_t t = 0;
@@ -1128,8 +1172,9 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     PLVS_HIP_TRY(h->w_masks.reserve(((size_t)ntiles << h->run_r1_log2) * kMaskWords));
     hipLaunchKernelGGL(walk_prologue, dim3(ceil_div((size_t)std::max(max_chunks, nclouds + 1), 256)), dim3(256), 0, s, d_Twc,
                        nclouds, h->poses.p, (const int32_t*)h->h_offsets, h->offsets.p, h->d_wctr, h->d_ctr, h->w_chunk_nseg.p,
-                       max_chunks, (int)(2 * ntiles));
+                       max_chunks, gsrc ? (int)kGridWords : (int)(2 * ntiles));
     STAGE_MARK(0);
+    const GridSrc* const d_grid = gsrc ? reinterpret_cast<const GridSrc*>(h->offsets.p + 2 * ((size_t)nclouds + 1)) : nullptr;
     AccOut out{h->w_rec.p, (uint32_t)std::min<size_t>(rec_own + rec_spill, 0xFFFFFFFFu), h->w_seg.p,
                (uint32_t)std::min<size_t>(seg_own + seg_spill, 0xFFFFFFFFu), h->w_seg_cnt.p, h->w_tile_visits.p};
     RunOut runs{h->w_runkey.p, h->w_masks.p, h->w_run_cnt.p, h->run_r1_log2};
@@ -1139,11 +1184,18 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     uint32_t* const list_b = h->w_deferred.p + ntiles;
     const uint32_t* last_list = list_a;
     const uint32_t* last_count = &h->d_wctr->ndeferred;
+#define PLVS_LAUNCH_WALK_FAST(E, GRID, TILES, LIST, NLIST, DEFERRED, NDEFERRED)                                              \
+  hipLaunchKernelGGL((walk_fast<E, GRID>), dim3(TILES), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,          \
+                     h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,                     \
+                     (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u, 1u}, kRecStride, (const uint32_t*)(LIST),            \
+                     (const uint32_t*)(NLIST), DEFERRED, NDEFERRED, d_grid)
+#define PLVS_WALK_FAST(E, TILES, LIST, NLIST, DEFERRED, NDEFERRED)                                  \
+  do {                                                                                              \
+    if (gsrc) PLVS_LAUNCH_WALK_FAST(E, true, TILES, LIST, NLIST, DEFERRED, NDEFERRED);              \
+    else PLVS_LAUNCH_WALK_FAST(E, false, TILES, LIST, NLIST, DEFERRED, NDEFERRED);                  \
+  } while (0)
     if (ntiles <= kSmallCallTiles) {
-      hipLaunchKernelGGL(walk_fast<kFastEntriesBig>, dim3(ntiles), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz,
-                         n, h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
-                         (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u, 1u}, kRecStride, (const uint32_t*)nullptr,
-                         (const uint32_t*)nullptr, list_a, &h->d_wctr->ndeferred);
+      PLVS_WALK_FAST(kFastEntriesBig, ntiles, nullptr, nullptr, list_a, &h->d_wctr->ndeferred);
     } else {
       // The table of the first pass follows the scene: tiles of near surfaces (a small room, a desk) hold 300-600 voxels
       // and a 1024-entry table lets THREE of them share a CU (6 waves per SIMD: 0.49 against 0.65 ms for the 100 key
@@ -1151,27 +1203,19 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
       // counters of the call before decide (walk_small): the 2048-entry kernel counts the tiles a 1024-entry table would
       // not have held, the 1024-entry kernel's deferred list says when it stops paying.
       h->walk_small_used = h->walk_small;
-      if (h->walk_small)
-        hipLaunchKernelGGL(walk_fast<kFastEntriesSmall>, dim3(ntiles), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
-                           h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
-                           (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u, 1u}, kRecStride, (const uint32_t*)nullptr,
-                           (const uint32_t*)nullptr, list_a, &h->d_wctr->ndeferred);
-      else
-      hipLaunchKernelGGL(walk_fast<kFastEntries>, dim3(ntiles), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
-                         h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
-                         (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u, 1u}, kRecStride, (const uint32_t*)nullptr,
-                         (const uint32_t*)nullptr, list_a, &h->d_wctr->ndeferred);
-      hipLaunchKernelGGL(walk_fast<kFastEntriesBig>, dim3(std::min<unsigned>(ntiles, kListGrid)), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz,
-                         n, h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
-                         (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u, 1u}, kRecStride, (const uint32_t*)list_a,
-                         (const uint32_t*)&h->d_wctr->ndeferred, list_b, &h->d_wctr->ndeferred2);
+      if (h->walk_small) PLVS_WALK_FAST(kFastEntriesSmall, ntiles, nullptr, nullptr, list_a, &h->d_wctr->ndeferred);
+      else PLVS_WALK_FAST(kFastEntries, ntiles, nullptr, nullptr, list_a, &h->d_wctr->ndeferred);
+      PLVS_WALK_FAST(kFastEntriesBig, std::min<unsigned>(ntiles, kListGrid), list_a, &h->d_wctr->ndeferred, list_b,
+                     &h->d_wctr->ndeferred2);
+#undef PLVS_WALK_FAST
+#undef PLVS_LAUNCH_WALK_FAST
       last_list = list_b;
       last_count = &h->d_wctr->ndeferred2;
     }
     hipLaunchKernelGGL((walk_tiles<true, true>), dim3(kDeferGrid), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
                        h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
                        (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u, 1u}, (uint32_t)ntiles, last_list, last_count,
-                       kRecStride, 2u);   // (what is flagged overflowed a 4096-entry table: two pieces at once)
+                       kRecStride, 2u, d_grid);   // (what is flagged overflowed a 4096-entry table: two pieces at once)
     PLVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
     STAGE_MARK(1);
     // A small call (a few key frames: PointCloudMapping::UpdateMap's batches) launches its colour chain on the sizes of
@@ -1200,7 +1244,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
                        h->w_active_off.p, h->w_part_off.p, h->w_multi_idx.p, h->part_segs,
                        PartAcc{h->pa_wuu.p, h->pa_w.p, h->pa_last.p, h->pa_cnt.p, h->pa_done.p}, h->w_rec.p,
                        1.0 / (double)h->scale_u, 1.0 / (double)h->scale_w, d_kfid, h->sdf, h->weight, h->kfid, h->d_wctr,
-                       EmitOut{});
+                       EmitOut{}, gsrc ? grid.key_bits : 0u);
     PLVS_KERNEL_CHECK();
     STAGE_MARK_ON(3, q_apply);
     return PLVS_OK;
@@ -1229,13 +1273,18 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
         hipLaunchKernelGGL(voxel_heads, dim3(ceil_div(D, 256 * kHeadTiles)), dim3(256), 0, q, skeys, D,
                            h->heads.p, h->w_dummy.p, h->d_wctr + 1, guard ? (const uint32_t*)side_ctr : (const uint32_t*)nullptr);
       }
-      hipLaunchKernelGGL(fold_colours_masks, dim3(std::min<size_t>(ceil_div(D, kFoldWaves), 8192)),
-                         dim3(64 * kFoldWaves), 0, q, skeys, sval, side_ctr,
-                         RunSrc{h->w_masks.p, (uint32_t)kMaskWords, h->run_r1_log2, TileMap{1u, 0u}, h->offsets.p, nclouds,
-                                reinterpret_cast<const uint32_t*>(h->offsets.p) + 2 * ((size_t)nclouds + 1)},
-                         h->heads.p, d_rgb,
-                         h->rgbw, &h->d_wctr[1].num_heads, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                         guard ? (const uint32_t*)guard->skip : (const uint32_t*)nullptr);
+      const RunSrc rsrc{h->w_masks.p, (uint32_t)kMaskWords, h->run_r1_log2, TileMap{1u, 0u}, h->offsets.p, nclouds,
+                        reinterpret_cast<const uint32_t*>(h->offsets.p) + 2 * ((size_t)nclouds + 1)};
+      if (gsrc)
+        hipLaunchKernelGGL(fold_colours_masks<true>, dim3(std::min<size_t>(ceil_div(D, kFoldWaves), 8192)),
+                           dim3(64 * kFoldWaves), 0, q, skeys, sval, side_ctr, rsrc, h->heads.p, d_rgb,
+                           h->rgbw, &h->d_wctr[1].num_heads, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                           guard ? (const uint32_t*)guard->skip : (const uint32_t*)nullptr, grid);
+      else
+        hipLaunchKernelGGL(fold_colours_masks<false>, dim3(std::min<size_t>(ceil_div(D, kFoldWaves), 8192)),
+                           dim3(64 * kFoldWaves), 0, q, skeys, sval, side_ctr, rsrc, h->heads.p, d_rgb,
+                           h->rgbw, &h->d_wctr[1].num_heads, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                           guard ? (const uint32_t*)guard->skip : (const uint32_t*)nullptr, grid);
       PLVS_KERNEL_CHECK();
       return PLVS_OK;
     };
@@ -1825,6 +1874,79 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
                                              const float* d_Twc, void* stream) {
   PLVS_FLUSH_QUEUE(h);
   return integrate_batch_impl(h, d_xyz, d_rgb, d_kfid, offsets, nclouds, d_Twc, stream, nullptr);
+}
+
+// ---- depth images straight into the map (round 5): GeneratePointCloudInCameraFrameBGRA + InsertCloud in one call.
+// Order-free handles walk 32 x 16 blocks of grid pixels (GridSrc, tsdf_walk.hpp): the cloud is never written.  Ordered
+// handles (and sharded ones) build the reference's clouds in scratch memory — raster-order compaction of the valid grid
+// pixels — and take the ordinary batch path: bit for bit plvs_hip_cloudgen_generate_dev + integrate_batch_dev.
+int plvs_hip_tsdf_chisel_integrate_depth_batch_dev(plvs_tsdf_chisel* h, const plvs_depth_batch* in, int nclouds,
+                                                   const float* d_Twc, void* stream) {
+  PLVS_FLUSH_QUEUE(h);
+  PLVS_REQUIRE(h && in, "null argument");
+  PLVS_REQUIRE(!h->poisoned, "handle is in a failed state (clear it)");
+  PLVS_REQUIRE(nclouds >= 0, "bad image count");
+  h->stats = plvs_tsdf_stats{};
+  h->last_updated = 0;
+  if (nclouds == 0) return PLVS_OK;
+  PLVS_REQUIRE(in->d_depth && in->d_bgr && in->d_grid_points && d_Twc, "null device pointer");
+  PLVS_REQUIRE(in->width > 0 && in->height > 0 && in->step > 0, "image size / step");
+  PLVS_REQUIRE(in->depth_pitch >= in->width && in->bgr_pitch >= 3 * in->width, "row pitch smaller than a row");
+  PLVS_REQUIRE(in->depth_image_stride >= (size_t)in->depth_pitch * (size_t)(in->height - 1) + (size_t)in->width &&
+               in->bgr_image_stride >= (size_t)in->bgr_pitch * (size_t)(in->height - 1) + 3 * (size_t)in->width,
+               "image stride smaller than an image");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  GridSrc g{};
+  g.depth = in->d_depth;
+  g.cam = in->d_grid_points;
+  g.image_stride = in->depth_image_stride;
+  g.pitch = (uint32_t)in->depth_pitch;
+  g.step = (uint32_t)in->step;
+  g.gw = (uint32_t)((in->width + in->step - 1) / in->step);
+  g.gh = (uint32_t)((in->height + in->step - 1) / in->step);
+  g.ntx = (g.gw + kGridTileW - 1) / kGridTileW;
+  g.nty = (g.gh + kGridTileH - 1) / kGridTileH;
+  g.key_bits = 1;
+  while ((1ull << g.key_bits) < (unsigned long long)g.gw * g.gh) ++g.key_bits;
+  g.min_depth = in->min_depth;
+  g.max_depth = in->max_depth;
+  g.bgr_image_stride = in->bgr_image_stride;
+  g.bgr_pitch = (uint32_t)in->bgr_pitch;
+  PLVS_REQUIRE(g.key_bits < 31 && (unsigned long long)nclouds <= (1ull << (32 - g.key_bits)),
+               "too many images in one call for the order keys (split the batch)");
+  const size_t ngrid = (size_t)g.gw * g.gh;
+  h->stats.points = 0;
+  {
+    int rc = halo_drop(h, s);   // new chunks go into the pool slots a meshing halo may still occupy
+    if (rc != PLVS_OK) return rc;
+  }
+  const bool walk2d = h->prm.order_free != 0 && std::max(1, h->prm.shard_count) == 1 && h->dfm == nullptr;
+  if (walk2d) {
+    std::vector<int32_t> zeros((size_t)nclouds + 1, 0);
+    PLVS_HIP_TRY(h->offsets.reserve(2 * ((size_t)nclouds + 1)));
+    PLVS_HIP_TRY(h->poses.reserve((size_t)nclouds));
+    return integrate_walk_acc(h, nullptr, in->d_bgr, in->d_kfid, 0, nclouds, zeros.data(), d_Twc, s, &g);
+  }
+  // ---- the reference's clouds, in scratch memory
+  const size_t cells = ngrid * (size_t)nclouds;
+  PLVS_REQUIRE(cells < 0x7FFFFFFFull, "too many grid pixels in one call (split the batch)");
+  static thread_local plvs::DevBuf<uint32_t> pos, scan_scratch, d_off;
+  PLVS_HIP_TRY(pos.reserve(cells + 1));
+  PLVS_HIP_TRY(scan_scratch.reserve(scan_scratch_words(cells)));
+  PLVS_HIP_TRY(d_off.reserve((size_t)nclouds + 1));
+  PLVS_HIP_TRY(h->st_xyz.reserve(cells * 3));
+  PLVS_HIP_TRY(h->st_rgb.reserve(cells * 3));
+  PLVS_HIP_TRY(h->st_kfid.reserve(cells));
+  hipLaunchKernelGGL(grid_cloud_mark, dim3(ceil_div(cells, 256)), dim3(256), 0, s, g, nclouds, pos.p);
+  PLVS_HIP_TRY(exclusive_scan_u32(pos.p, pos.p, cells, pos.p + cells, scan_scratch.p, s));
+  hipLaunchKernelGGL(grid_cloud_emit, dim3(ceil_div(cells + 1, 256)), dim3(256), 0, s, g, nclouds, (const uint32_t*)pos.p, in->d_bgr,
+                     in->d_kfid, h->st_xyz.p, h->st_rgb.p, h->st_kfid.p, d_off.p);
+  PLVS_KERNEL_CHECK();
+  std::vector<int32_t> offsets((size_t)nclouds + 1);
+  PLVS_HIP_TRY(hipMemcpyAsync(offsets.data(), d_off.p, ((size_t)nclouds + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  PLVS_HIP_TRY(hipStreamSynchronize(s));
+  return integrate_batch_impl(h, h->st_xyz.p, h->st_rgb.p, in->d_kfid ? h->st_kfid.p : nullptr, offsets.data(), nclouds, d_Twc,
+                              stream, nullptr);
 }
 
 int plvs_hip_tsdf_chisel_integrate_world_normals_dev(plvs_tsdf_chisel* h, const float* d_xyz, const uint8_t* d_rgb,
@@ -2678,12 +2800,12 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
     hipLaunchKernelGGL(walk_fast<kFastEntries>, dim3(nt), dim3(kWalkRays), 0, s, Pw, h->scale_u, h->scale_w, d_xyz, n,
                        h->offsets.p, nclouds, h->poses.p, h->xdir, h->d_xcount, h->d_wctr, (const uint32_t*)nullptr,
                        (const uint32_t*)h->x_sat, out, runs, tmap, (uint32_t)kWalkLimit, (const uint32_t*)nullptr,
-                       (const uint32_t*)nullptr, h->w_deferred.p, &h->d_wctr->ndeferred);
+                       (const uint32_t*)nullptr, h->w_deferred.p, &h->d_wctr->ndeferred, (const GridSrc*)nullptr);
     hipLaunchKernelGGL((walk_tiles<true, true>), dim3(kDeferGrid), dim3(kWalkRays), 0, s, Pw, h->scale_u, h->scale_w, d_xyz, n,
                        h->offsets.p, nclouds, h->poses.p, h->xdir, h->d_xcount, h->d_wctr, (const uint32_t*)nullptr,
                        (const uint32_t*)h->x_sat, out, runs, tmap, (uint32_t)nt, (const uint32_t*)h->w_deferred.p,
                        (const uint32_t*)&h->d_wctr->ndeferred, (uint32_t)kWalkLimit,
-                       1u);   // (flagged = overflowed 2048 entries: this kernel's table takes 3584, the tile goes whole)
+                       1u, (const GridSrc*)nullptr);   // (flagged = overflowed 2048 entries: this kernel's table takes 3584, the tile goes whole)
     const unsigned seg_blocks = ceil_div(seg_own + seg_spill, kSegSpan);
     hipLaunchKernelGGL(seg_pass<false>, dim3(seg_blocks), dim3(256), 0, s, h->w_seg.p, out.seg_cap, nt, h->w_seg_cnt.p,
                        h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p, h->d_wctr);
@@ -2739,7 +2861,7 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
                        PartAcc{h->pa_wuu.p, h->pa_w.p, h->pa_last.p, h->pa_cnt.p, h->pa_done.p}, h->w_rec.p, 0.0, 0.0,
                        (const uint32_t*)nullptr, (float*)nullptr, (float*)nullptr, (uint32_t*)nullptr, h->d_wctr,
                        EmitOut{h->xdir.slot_ids, h->sh_owner.p, ctl, ctl + 64, ctl + 128, ctl + 192, h->sh_seg_reg.p,
-                               h->sh_rec_reg.p});
+                               h->sh_rec_reg.p}, 0u);
     PLVS_KERNEL_CHECK();
     hipLaunchKernelGGL(publish_words, dim3(1), dim3(256), 0, s, (const uint32_t*)h->sh_ctl.p, h->h_sh_ctl, 256,
                        (const uint32_t*)h->sh_run_ctr.p, h->h_sh_ctl + 256, 64, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0);
@@ -2871,7 +2993,7 @@ int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src,
                      h->w_active_off.p, h->w_part_off.p, h->w_multi_idx.p, h->part_segs,
                      PartAcc{h->pa_wuu.p, h->pa_w.p, h->pa_last.p, h->pa_cnt.p, h->pa_done.p},
                      static_cast<const uint4*>(d_rec_src), 1.0 / (double)h->scale_u, 1.0 / (double)h->scale_w, d_kfid,
-                     h->sdf, h->weight, h->kfid, h->d_wctr, EmitOut{});
+                     h->sdf, h->weight, h->kfid, h->d_wctr, EmitOut{}, 0u);
   PLVS_KERNEL_CHECK();
   STAGE_MARK(3);
   // ---- colours: the received runs, by (voxel, tile)
@@ -2908,11 +3030,11 @@ int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src,
     const uint32_t* sval = second ? other : order;
     hipLaunchKernelGGL(voxel_heads, dim3(ceil_div(R, 256 * kHeadTiles)), dim3(256), 0, s, skeys, R, h->heads.p,
                        h->w_dummy.p, h->d_wctr + 1);
-    hipLaunchKernelGGL(fold_colours_masks, dim3(std::min<size_t>(ceil_div(R, kFoldWaves), 8192)), dim3(64 * kFoldWaves), 0, s,
+    hipLaunchKernelGGL(fold_colours_masks<false>, dim3(std::min<size_t>(ceil_div(R, kFoldWaves), 8192)), dim3(64 * kFoldWaves), 0, s,
                        skeys, sval, &h->d_wctr[1].num_desc,
                        RunSrc{runs, kWireRun, 0u, TileMap{1u, 0u}, h->offsets.p, h->sh_nclouds, nullptr}, h->heads.p, d_rgb,
                        h->rgbw, &h->d_wctr[1].num_heads, h->sh_sat.p, reinterpret_cast<uint32_t*>(h->d_xcount + 2),
-                       (const uint32_t*)nullptr);
+                       (const uint32_t*)nullptr, GridSrc{});
     PLVS_KERNEL_CHECK();
   }
   STAGE_MARK(4);

@@ -478,8 +478,85 @@ __device__ __forceinline__ uint32_t walk_lean(const Params& P, const Pose& pose,
   return nv;
 }
 
+// ------------------------------------------------------------------ rays straight from depth images (round 5)
+// plvs_hip_tsdf_chisel_integrate_depth_batch_dev: the call's "clouds" are depth images and the points are what
+// PointCloudMapping::GeneratePointCloudInCameraFrameBGRA (src/PointCloudMapping.cc:957-996) would have pushed into the
+// cloud — p = (gx d, gy d, d) for every pixel of the stride-`step` grid with min < d < max, in raster order — but they are
+// never written: a tile is a 32 x 16 block of GRID PIXELS (kGridTileW x kGridTileH), thread r = pixel (r / 32, r % 32) of
+// the block.  Rays of a 2-D block share their voxels: 2-3 x fewer table entries and records per tile than 512
+// CONSECUTIVE points (a strip 1.6 rows high), and a chunk meets a quarter of the tiles.
+// What needs the reference's point order still has it:
+//   * the order of two visits of one voxel = (image, raster index of the grid pixel) — inside a tile that is the ray
+//     number (bit order of a run's mask), between tiles of one band of 16 grid rows it interleaves row by row: the fold
+//     (fold_colours_masks<true>) merges the runs of a band by mask word, one word = one grid row of a tile;
+//   * a record's last visitor is the ORDER KEY image << key_bits | raster index (maxima compare like point indices);
+//     apply_chunks takes the key-frame id from kfid[key >> key_bits].
+// Tile t of the call: image t / (ntx nty), band (t / ntx) % nty, column block t % ntx.
+constexpr int kGridTileW = 32, kGridTileH = kWalkRays / kGridTileW;
+static_assert(kGridTileW == 32 && kGridTileH == kMaskWords, "one mask word per grid row of a tile");
+struct GridSrc {
+  const float* depth;        // nullptr: the call's points come from its point stream (xyz)
+  const float* cam;          // matCamGridPoints_: (gx, gy) per grid pixel, gh x gw x 2
+  unsigned long long image_stride;   // floats between two images
+  uint32_t pitch;            // floats per image row
+  uint32_t step, gw, gh;     // grid: pixel (m, n) of the grid is pixel (m step, n step) of the image
+  uint32_t ntx, nty;         // tiles per band, bands per image
+  uint32_t key_bits;         // bits of the raster index gh x gw in an order key
+  double min_depth, max_depth;
+  // the colour images (the fold reads a visit's colour where the reference's cloud would carry it: bytes 0, 1, 2 of the
+  // pixel -> the point's r, g, b members, :978-980)
+  unsigned long long bgr_image_stride;   // bytes between two images
+  uint32_t bgr_pitch;                    // bytes per image row
+};
+struct GridTile {
+  uint32_t cloud, row0, col0;   // image, first grid row / column of the tile
+};
+__device__ __forceinline__ GridTile grid_tile(const GridSrc& g, uint32_t gtile) {
+  const uint32_t per = g.ntx * g.nty, c = gtile / per, t = gtile - c * per, br = t / g.ntx;
+  return GridTile{c, br * (uint32_t)kGridTileH, (t - br * g.ntx) * (uint32_t)kGridTileW};
+}
+// The point ray `rid` of the tile would be in the reference's cloud; false: the grid pixel does not exist or its depth
+// is not inside (min, max) (compared in double, :967).
+__device__ __forceinline__ bool grid_point(const GridSrc& g, const GridTile& t, uint32_t rid, float* x, float* y, float* z) {
+  const uint32_t m = t.row0 + rid / (uint32_t)kGridTileW, n = t.col0 + rid % (uint32_t)kGridTileW;
+  if (m >= g.gh || n >= g.gw) return false;
+  const float d = g.depth[(size_t)t.cloud * g.image_stride + (size_t)(m * g.step) * g.pitch + n * g.step];
+  if (!(((double)d > g.min_depth) && ((double)d < g.max_depth))) return false;
+  const float2 c = reinterpret_cast<const float2*>(g.cam)[m * g.gw + n];
+  *x = c.x * d;   // :973-975 (two float products)
+  *y = c.y * d;
+  *z = d;
+  return true;
+}
+__device__ __forceinline__ uint32_t grid_order_key(const GridSrc& g, const GridTile& t, uint32_t rid) {
+  return (t.cloud << g.key_bits) | ((t.row0 + rid / (uint32_t)kGridTileW) * g.gw + t.col0 + rid % (uint32_t)kGridTileW);
+}
+
 // Ray of point i under the pose of its cloud; false if the point casts no ray (or lies outside the
 // supported extent).
+__device__ __forceinline__ bool ray_of_point(const Params& P, const Pose& pose, float x, float y, float z, Ray* ray,
+                                             uint32_t* err) {
+  if (!make_ray(P, pose, x, y, z, ray)) return false;
+  if (!ray_in_coord_range(*ray)) {
+    atomicOr(err, kErrCoordRange);
+    return false;
+  }
+  if (P.shard_count > 2 && !walk_may_touch_owned(P, *ray)) return false;
+  return true;
+}
+// ... of ray `rid` of a tile: point first + rid of the stream, or the grid pixel of a depth-image tile
+__device__ __forceinline__ bool tile_ray_src(const Params& P, const float* __restrict__ xyz, const GridSrc* __restrict__ g,
+                                             const GridTile& gt, const Pose& pose, uint32_t first, uint32_t rid, Ray* ray,
+                                             uint32_t* err) {
+  float x, y, z;
+  if (g) {   // (a pointer, not a kernel argument by value: its twenty words would live in scalar registers through the voxel loop)
+    if (!grid_point(*g, gt, rid, &x, &y, &z)) return false;
+  } else {
+    const size_t i = (size_t)first + rid;
+    x = xyz[3 * i]; y = xyz[3 * i + 1]; z = xyz[3 * i + 2];
+  }
+  return ray_of_point(P, pose, x, y, z, ray, err);
+}
 __device__ __forceinline__ bool tile_ray(const Params& P, const float* __restrict__ xyz, const Pose& pose, uint32_t i,
                                          Ray* ray, uint32_t* err) {
   if (!make_ray(P, pose, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], ray)) return false;
@@ -623,7 +700,7 @@ __global__ __launch_bounds__(kWalkRays, kWalkEntries > 2048 ? 2 : (kWalkEntries 
     int32_t* __restrict__ num_chunks, WalkCounters* __restrict__ ctr, const uint32_t* __restrict__ rgbw,
     const uint32_t* __restrict__ sat, AccOut out, RunOut runs, TileMap tmap, uint32_t ntiles,
     const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ ntile_list, uint32_t rec_stride,
-    uint32_t cut_pieces) {
+    uint32_t cut_pieces, const GridSrc* __restrict__ grid) {
   constexpr int kPer = kWalkEntries / kWalkRays;
   __shared__ WalkShared S;
   __shared__ uint32_t raw[kMaskCap * kMaskWords];              // accumulators during the walk, ray masks afterwards
@@ -641,7 +718,9 @@ __global__ __launch_bounds__(kWalkRays, kWalkEntries > 2048 ? 2 : (kWalkEntries 
   const uint32_t tile = tile_list ? (tile_list[lb] & 0x7FFFFFFFu) : lb;   // the local tile: output regions
   const bool cut_at_once = tile_list && (tile_list[lb] >> 31) != 0u;
   const uint32_t gtile = tmap.tile_of(tile);             // its place in the point stream
-  const TileSpan span = tmap.tables ? tile_span_tables(offsets, nclouds, gtile, kWalkRays)   // (512 points of one cloud:
+  const GridTile gt = grid ? grid_tile(*grid, gtile) : GridTile{0u, 0u, 0u};
+  const TileSpan span = grid ? TileSpan{(int)gt.cloud, 0u, (uint32_t)kWalkRays}   // (a block of grid pixels of one image)
+                      : tmap.tables ? tile_span_tables(offsets, nclouds, gtile, kWalkRays)   // (512 points of one cloud:
                                     : tile_span(offsets, nclouds, gtile, kWalkRays);          //  tsdf_directory.hpp)
   const uint32_t first = span.first;
   __syncthreads();   // (the previous tile of this workgroup is done with the shared state)
@@ -667,7 +746,6 @@ __global__ __launch_bounds__(kWalkRays, kWalkEntries > 2048 ? 2 : (kWalkEntries 
     S.run_total = 0;
     S.vis_total = 0;
   }
-  const uint32_t i = first + (uint32_t)tid;
   uint32_t my_visits = 0;
   bool was_split = one_cloud && !single;
   int flushes = 0;
@@ -700,7 +778,7 @@ __global__ __launch_bounds__(kWalkRays, kWalkEntries > 2048 ? 2 : (kWalkEntries 
     for (int k = 0; k < 4 * kPer; ++k) raw[tid + k * kWalkRays] = 0u;
     const Pose& pose = poses[__builtin_amdgcn_readfirstlane(st.cloud)];   // (scalar loads where it is used)
     Ray ray;
-    const bool walks = tid >= st.lo && tid < st.hi && tile_ray(P, xyz, pose, i, &ray, &ctr->err);
+    const bool walks = tid >= st.lo && tid < st.hi && tile_ray_src(P, xyz, grid, gt, pose, first, (uint32_t)tid, &ray, &ctr->err);
     const float wu = walks ? P.weight / (2.0f * ray.truncation) : 0.0f;
     const float wu_scaled = wu * scale_u;
     const uint32_t q_w = (uint32_t)__float2int_rn(wu * scale_w);
@@ -954,7 +1032,8 @@ __global__ __launch_bounds__(kWalkRays, kWalkEntries > 2048 ? 2 : (kWalkEntries 
         if (slot_of[k] < 0) continue;
         const int e = tid + k * kWalkRays;
         const uint32_t vid = vkey[k] % (uint32_t)kChunkVox;
-        const uint4 r = make_uint4(vid | ((uint32_t)(ewc[k] >> 32) << 12), first + elast[k], (uint32_t)e_wuu[e],
+        const uint4 r = make_uint4(vid | ((uint32_t)(ewc[k] >> 32) << 12),
+                                   grid ? grid_order_key(*grid, gt, elast[k]) : first + elast[k], (uint32_t)e_wuu[e],
                                    (uint32_t)ewc[k]);
         uint32_t at;
         if (ci[k] >= 0) {
@@ -1117,13 +1196,16 @@ __global__ __launch_bounds__(kWalkRays, kWalkEntries > 2048 ? 2 : (kWalkEntries 
 // either and go straight on to `deferred`), *ntile_list of them.  rec_stride = records a tile owns in out.rec (the
 // host sizes the regions for the largest table it launches).
 constexpr int walk_fast_waves(int E) { return E > 2048 ? 2 : (E > 1024 ? 4 : 6); }   // waves per SIMD the tile's LDS allows
-template <int E>
+template <int E, bool kGrid>
 __device__ __forceinline__ void walk_fast_tile(
     const Params& P, float scale_u, float scale_w, const float* __restrict__ xyz, int npoints,
     const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, const Directory& dir,
     int32_t* __restrict__ num_chunks, WalkCounters* __restrict__ ctr, const uint32_t* __restrict__ rgbw,
     const uint32_t* __restrict__ sat, const AccOut& out, const RunOut& runs, const TileMap& tmap, uint32_t rec_stride,
-    uint32_t* __restrict__ deferred, uint32_t* __restrict__ ndeferred, const uint32_t tile, const bool listed_other) {
+    uint32_t* __restrict__ deferred, uint32_t* __restrict__ ndeferred, const uint32_t tile, const bool listed_other,
+    const GridSrc* __restrict__ grid_arg) {
+  // (kGrid a template parameter: the point-stream instances keep the registers they had before round 5)
+  const GridSrc* __restrict__ const grid = kGrid ? grid_arg : nullptr;
   constexpr int kPer = E / kWalkRays;
   constexpr int kLimit = E * 7 / 8;          // entries a tile may use (kWalkLimit of the general kernel's table)
   constexpr int kMaskCapE = E / 4;           // ray masks built per round: the area of the accumulators
@@ -1141,7 +1223,9 @@ __device__ __forceinline__ void walk_fast_tile(
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   // (tile = the local tile: output regions; listed_other = a listed tile that is not an overflow: passed on)
   const uint32_t gtile = tmap.tile_of(tile);             // its place in the point stream
-  const TileSpan span = tmap.tables ? tile_span_tables(offsets, nclouds, gtile, kWalkRays)   // (512 points of one cloud:
+  const GridTile gt = grid ? grid_tile(*grid, gtile) : GridTile{0u, 0u, 0u};
+  const TileSpan span = grid ? TileSpan{(int)gt.cloud, 0u, (uint32_t)kWalkRays}   // (a block of grid pixels of one image)
+                      : tmap.tables ? tile_span_tables(offsets, nclouds, gtile, kWalkRays)   // (512 points of one cloud:
                                     : tile_span(offsets, nclouds, gtile, kWalkRays);          //  tsdf_directory.hpp)
   const uint32_t first = span.first, nrays = span.nrays;
   const int cloud = span.cloud;
@@ -1172,7 +1256,7 @@ __device__ __forceinline__ void walk_fast_tile(
       int b = 63;
       uint32_t r = 0;
       if ((uint32_t)tid < nrays) {
-        const float z = xyz[3 * (size_t)(first + (uint32_t)tid) + 2];
+        const float z = grid ? 0.0f : xyz[3 * (size_t)(first + (uint32_t)tid) + 2];   // (the switch is a cloud-mode experiment)
         b = z < 0.01f ? 63 : min(62, (int)(z * 8.0f));
         r = atomicAdd(&bins[b], 1u);
       }
@@ -1187,7 +1271,7 @@ __device__ __forceinline__ void walk_fast_tile(
 #endif
     const Pose& pose = poses[cloud];   // (uniform address: scalar loads where it is used)
     Ray ray;
-    walks = (uint32_t)tid < nrays && tile_ray(P, xyz, pose, first + rid, &ray, &ctr->err);
+    walks = (uint32_t)tid < nrays && tile_ray_src(P, xyz, grid, gt, pose, first, rid, &ray, &ctr->err);
     const float wu = walks ? P.weight / (2.0f * ray.truncation) : 0.0f;
     {   // origin of the voxel keys: below the start voxel of the first walking ray, on a chunk boundary
       const unsigned long long wm = __ballot(walks);
@@ -1360,7 +1444,8 @@ __device__ __forceinline__ void walk_fast_tile(
   for (int k = 0; k < kPer; ++k) {
     if (vkey[k] == 0xFFFFFFFFu) continue;
     const uint32_t vid = vkey[k] % (uint32_t)kChunkVox;
-    const uint4 r = make_uint4(vid | ((uint32_t)(ewc[k] >> 32) << 12), first + elast[k],
+    const uint4 r = make_uint4(vid | ((uint32_t)(ewc[k] >> 32) << 12),
+                               grid ? grid_order_key(*grid, gt, elast[k]) : first + elast[k],
                                (uint32_t)e_wuu[tid + k * kWalkRays], (uint32_t)ewc[k]);
     out.rec[rbase + S.cbase[ci[k] * kSlabs + (int)(vid / kSlabVox)] + rank[k]] = r;
   }
@@ -1431,7 +1516,7 @@ __device__ __forceinline__ void walk_fast_tile(
         if (nv > (uint32_t)kLogLen) {   // the log is full: the rest of the ray is walked again
           const Pose& pose = poses[cloud];
           Ray ray;
-          if (tile_ray(P, xyz, pose, first + rid, &ray, &ctr->err))
+          if (tile_ray_src(P, xyz, grid, gt, pose, first, rid, &ray, &ctr->err))
             walk_one(P, pose, ray, 0u, 0xFFFFFFFFu, [&](uint32_t k, int vx, int vy, int vz, float) {
               if (k >= (uint32_t)kLogLen) {
                 uint32_t key;
@@ -1469,17 +1554,17 @@ __device__ __forceinline__ void walk_fast_tile(
   }
 }
 
-template <int E>
+template <int E, bool kGrid = false>
 __global__ __launch_bounds__(kWalkRays, walk_fast_waves(E)) void walk_fast(
     Params P, float scale_u, float scale_w, const float* __restrict__ xyz, int npoints,
     const int32_t* __restrict__ offsets, int nclouds, const Pose* __restrict__ poses, Directory dir,
     int32_t* __restrict__ num_chunks, WalkCounters* __restrict__ ctr, const uint32_t* __restrict__ rgbw,
     const uint32_t* __restrict__ sat, AccOut out, RunOut runs, TileMap tmap, uint32_t rec_stride,
     const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ ntile_list, uint32_t* __restrict__ deferred,
-    uint32_t* __restrict__ ndeferred) {
+    uint32_t* __restrict__ ndeferred, const GridSrc* __restrict__ grid) {
   if (!tile_list) {
-    walk_fast_tile<E>(P, scale_u, scale_w, xyz, npoints, offsets, nclouds, poses, dir, num_chunks, ctr, rgbw, sat, out, runs,
-                      tmap, rec_stride, deferred, ndeferred, blockIdx.x, false);
+    walk_fast_tile<E, kGrid>(P, scale_u, scale_w, xyz, npoints, offsets, nclouds, poses, dir, num_chunks, ctr, rgbw, sat, out, runs,
+                      tmap, rec_stride, deferred, ndeferred, blockIdx.x, false, grid);
     return;
   }
   // a list: the workgroups of a small grid take its entries in turn (a grid of one workgroup per POSSIBLE entry would
@@ -1487,8 +1572,8 @@ __global__ __launch_bounds__(kWalkRays, walk_fast_waves(E)) void walk_fast(
   const uint32_t nlist = *ntile_list;
   for (uint32_t lb = blockIdx.x; lb < nlist; lb += gridDim.x) {
     const uint32_t e = tile_list[lb];
-    walk_fast_tile<E>(P, scale_u, scale_w, xyz, npoints, offsets, nclouds, poses, dir, num_chunks, ctr, rgbw, sat, out, runs,
-                      tmap, rec_stride, deferred, ndeferred, e & 0x7FFFFFFFu, (e >> 31) == 0u);
+    walk_fast_tile<E, kGrid>(P, scale_u, scale_w, xyz, npoints, offsets, nclouds, poses, dir, num_chunks, ctr, rgbw, sat, out, runs,
+                      tmap, rec_stride, deferred, ndeferred, e & 0x7FFFFFFFu, (e >> 31) == 0u, grid);
     __syncthreads();   // (the next tile reuses the shared state)
   }
 }
@@ -1692,7 +1777,9 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
     const uint32_t* __restrict__ part_off, const uint32_t* __restrict__ multi_idx, uint32_t part_segs, PartAcc acc,
     const uint4* __restrict__ rec, double inv_scale_u, double inv_scale_w, const uint32_t* __restrict__ kfid_of_point,
     float* __restrict__ sdf, float* __restrict__ weight, uint32_t* __restrict__ vkfid, WalkCounters* __restrict__ ctr,
-    EmitOut emit) {
+    EmitOut emit, uint32_t last_shift) {
+  // last_shift: 0 = a record's last visitor is a point of the stream (kfid_of_point per point); otherwise it is the order
+  // key of a depth-image call (GridSrc::key_bits) and kfid_of_point holds one id per image
   __shared__ long long a_wuu[kSlabVox];
   __shared__ unsigned long long a_w[kSlabVox];
   __shared__ uint32_t a_last[kSlabVox], a_cnt[kSlabVox];
@@ -1904,7 +1991,7 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
           const float wn = W + ws;
           sdf[pool0 + v] = (W * Sd + m) / wn;
           weight[pool0 + v] = wn;
-          vkfid[pool0 + v] = kfid_of_point ? kfid_of_point[a_last[v]] : 0u;
+          vkfid[pool0 + v] = kfid_of_point ? kfid_of_point[a_last[v] >> last_shift] : 0u;
           ++voxels;
           longest = max(longest, c);
         }
@@ -2159,11 +2246,16 @@ struct RunSrc {
 };
 constexpr int kFoldGroup = 8;     // voxels a wave folds together (staging: 8 lanes each; fold: 4 lanes each: r, g, b, idle)
 constexpr int kFoldSteps = 256;   // >= 254: the visits that can still count for a voxel
+// kGrid: the runs of a depth-image call (GridSrc): tiles are 32 x 16 blocks of grid pixels, `rgb` = the colour images.  The
+// runs of a voxel arrive in tile order = (image, band of 16 grid rows, column block); the reference's point order inside a
+// band goes row by row ACROSS its tiles, so the runs of one band are staged together, mask word by mask word (a word = one
+// grid row of a tile).  A staged visit is its order key (image << key_bits | raster index), its colour is read at that pixel.
+template <bool kGrid>
 __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
     const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ sorted_val, const uint32_t* __restrict__ nd_dev,
     RunSrc src, const uint32_t* __restrict__ vj0, const uint8_t* __restrict__ rgb, uint32_t* __restrict__ rgbw,
     const uint32_t* __restrict__ num_heads, uint32_t* __restrict__ sat_list, uint32_t* __restrict__ sat_count,
-    const uint32_t* __restrict__ skip) {
+    const uint32_t* __restrict__ skip, const GridSrc grid) {
   // sat_list (ray-sharded integrate): the voxels whose colour weight reaches 254 in this call
   // skip (a chain launched on predicted sizes, compact_runs): non-zero = the prediction failed, nothing here is valid
   if (skip != nullptr && *skip != 0u) return;
@@ -2195,7 +2287,139 @@ __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
       my_col = rgbw[my_key];
     }
     // ---- staging: lanes 8 v .. 8 v + 7 work on voxel v
-    {
+    if constexpr (kGrid) {
+      // A lane per BAND of the voxel (a band's runs = its column blocks, consecutive in the sorted order; nearly always
+      // one, two where the voxel's pixels straddle a block boundary): the lane merges its band's masks word by word — row
+      // w of block A, then row w of block B ... — which is the reference's raster order inside the band; bands follow
+      // each other in point order, so the lanes' counts chain by a prefix sum as the runs of the point-stream form do.
+      // The eight lanes look at eight runs at a time and take the complete bands among them; a band of more than three
+      // runs (a voxel a hand's breadth from the camera) takes the general form below, alone.
+      const int vl = lane >> 3, sub = lane & 7;
+      const uint32_t j0v = (uint32_t)__shfl((int)my_j0, vl), keyv = (uint32_t)__shfl((int)my_key, vl);
+      const uint32_t cwv = (uint32_t)__shfl((int)my_col, vl) >> 24;
+      const uint32_t needv = cwv >= 254u ? 0u : 254u - cwv;
+      uint32_t havev = 0, jn = j0v;
+      bool open = (uint32_t)vl < nv && needv > 0u;
+      const uint32_t gshift = 8u * (uint32_t)vl;
+      auto run_tile = [&](uint32_t j) { return src.tmap.tile_of(sorted_val[j] >> src.r1_log2); };
+      // (general form) one mask word of every run of a chunk of up to eight runs of one band: grid row w, tile after tile
+      auto stage_row = [&](uint32_t bits, const GridTile& t, uint32_t w) {
+        const uint32_t cnt = (uint32_t)__popc(bits);
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) {
+          const uint32_t up = (uint32_t)__shfl_up((int)inc, d, 8);
+          if (sub >= d) inc += up;
+        }
+        uint32_t at = havev + inc - cnt;
+        const uint32_t key0 = (t.cloud << grid.key_bits) | ((t.row0 + w) * grid.gw + t.col0);
+        while (bits && at < needv) {
+          const int bpos = __ffs((int)bits) - 1;
+          bits &= bits - 1u;
+          stage[wid][vl][at++] = key0 + (uint32_t)bpos;
+        }
+        havev += (uint32_t)__shfl((int)inc, 7, 8);
+      };
+      while (__any(open)) {
+        const uint32_t j = jn + (uint32_t)sub;
+        const bool mine = open && j < nd && skeys[j] == keyv;
+        const uint32_t val = mine ? sorted_val[j] : 0u;
+        const uint32_t gtile = mine ? src.tmap.tile_of(val >> src.r1_log2) : 0u;
+        const uint32_t band = mine ? gtile / grid.ntx : 0xFFFFFFFFu;   // (image and band in one number: tiles are numbered band by band)
+        uint32_t band8 = 0xFFFFFFFEu;   // the band of the run behind these eight: is the last band here complete?
+        if (open && jn + 8u < nd && skeys[jn + 8u] == keyv) band8 = run_tile(jn + 8u) / grid.ntx;
+        const uint32_t bprev = (uint32_t)__shfl_up((int)band, 1, 8);
+        const bool start = mine && (sub == 0 || band != bprev);
+        const uint32_t minem = (uint32_t)(__ballot(mine) >> gshift) & 0xFFu, startm = (uint32_t)(__ballot(start) >> gshift) & 0xFFu;
+        const uint32_t nvalid = (uint32_t)__popc(minem);
+        const bool tail_open = nvalid == 8u && band8 == (uint32_t)__shfl((int)band, 7, 8);
+        uint32_t take = tail_open ? 31u - (uint32_t)__clz((int)startm) : nvalid;   // runs of complete bands
+        const uint32_t above = startm & ~((2u << sub) - 1u);
+        const uint32_t nb = (above ? (uint32_t)__ffs((int)above) - 1u : nvalid) - (uint32_t)sub;   // (a band leader's runs)
+        const uint32_t bigm = (uint32_t)(__ballot(start && (uint32_t)sub < take && nb > 3u) >> gshift) & 0xFFu;
+        if (bigm) take = min(take, (uint32_t)__ffs((int)bigm) - 1u);
+        if (!open) {
+          // (the voxel is done: its lanes idle through the other voxels' rounds)
+        } else if (minem == 0u) {
+          open = false;   // the voxel has no further run
+        } else if (take > 0u) {
+          const bool lead = start && (uint32_t)sub < take;
+          const uint32_t val1 = (uint32_t)__shfl_down((int)val, 1, 8), val2 = (uint32_t)__shfl_down((int)val, 2, 8);
+          const uint32_t gt1 = (uint32_t)__shfl_down((int)gtile, 1, 8), gt2 = (uint32_t)__shfl_down((int)gtile, 2, 8);
+          uint32_t mA[kMaskWords], mB[kMaskWords], mC[kMaskWords];
+#pragma unroll
+          for (int w = 0; w < kMaskWords; ++w) mA[w] = mB[w] = mC[w] = 0u;
+          auto load_mask = [&](uint32_t v, uint32_t* m) {
+            const uint4* m4 = reinterpret_cast<const uint4*>(src.base + (size_t)v * src.words);
+#pragma unroll
+            for (int q = 0; q < kMaskWords / 4; ++q) {
+              const uint4 a = m4[q];
+              m[4 * q] = a.x; m[4 * q + 1] = a.y; m[4 * q + 2] = a.z; m[4 * q + 3] = a.w;
+            }
+          };
+          if (lead) load_mask(val, mA);
+          if (lead && nb > 1u) load_mask(val1, mB);
+          if (lead && nb > 2u) load_mask(val2, mC);
+          uint32_t cnt = 0;
+#pragma unroll
+          for (int w = 0; w < kMaskWords; ++w) cnt += (uint32_t)(__popc(mA[w]) + __popc(mB[w]) + __popc(mC[w]));
+          uint32_t inc = cnt;
+#pragma unroll
+          for (int d = 1; d < 8; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)inc, d, 8);
+            if (sub >= d) inc += up;
+          }
+          uint32_t at = havev + inc - cnt;
+          const GridTile tA = grid_tile(grid, gtile);
+          const uint32_t colB = grid_tile(grid, gt1).col0, colC = grid_tile(grid, gt2).col0;
+          uint32_t rowkey = (tA.cloud << grid.key_bits) | (tA.row0 * grid.gw);
+          auto put = [&](uint32_t bits, uint32_t key0) {
+            while (bits && at < needv) {
+              const int bpos = __ffs((int)bits) - 1;
+              bits &= bits - 1u;
+              stage[wid][vl][at++] = key0 + (uint32_t)bpos;
+            }
+          };
+#pragma unroll
+          for (int w = 0; w < kMaskWords; ++w) {
+            put(mA[w], rowkey + tA.col0);
+            put(mB[w], rowkey + colB);
+            put(mC[w], rowkey + colC);
+            rowkey += grid.gw;
+          }
+          havev += (uint32_t)__shfl((int)inc, 7, 8);
+          jn += take;
+          open = havev < needv && !(take == nvalid && nvalid < 8u);
+        } else {
+          // ---- the general form, for the band that starts at run jn: its runs [jn, jn + nbt), eight at a time per grid row
+          const uint32_t band0 = (uint32_t)__shfl((int)band, 0, 8);
+          uint32_t nbt = 0u;
+          for (;; nbt += 8u) {
+            const uint32_t jc = jn + nbt + (uint32_t)sub;
+            const bool in = jc < nd && skeys[jc] == keyv && run_tile(jc) / grid.ntx == band0;
+            const uint32_t cm = (uint32_t)(__ballot(in) >> gshift) & 0xFFu;
+            if (cm != 0xFFu) {
+              nbt += (uint32_t)__popc(cm);
+              break;
+            }
+          }
+          for (uint32_t w = 0; w < (uint32_t)kMaskWords && havev < needv; ++w)
+            for (uint32_t c0 = 0; c0 < nbt; c0 += 8u) {
+              const uint32_t jc = jn + c0 + (uint32_t)sub;
+              GridTile t{0u, 0u, 0u};
+              uint32_t bits = 0u;
+              if (c0 + (uint32_t)sub < nbt) {
+                t = grid_tile(grid, run_tile(jc));
+                bits = src.base[(size_t)sorted_val[jc] * src.words + w];
+              }
+              stage_row(bits, t, w);
+            }
+          jn += nbt;
+          open = havev < needv;
+        }
+      }
+      if (sub == 0 && vl < kFoldGroup) have[wid][vl] = min(havev, needv);
+    } else {
       const int vl = lane >> 3, sub = lane & 7;
       const uint32_t j0v = (uint32_t)__shfl((int)my_j0, vl), keyv = (uint32_t)__shfl((int)my_key, vl);
       const uint32_t cwv = (uint32_t)__shfl((int)my_col, vl) >> 24;
@@ -2286,7 +2510,14 @@ __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
       for (int u = 0; u < 8; ++u) {
         colr[u] = 0;
         if (ok[u]) {
-          const uint8_t* px = rgb + 3 * (size_t)idx[u];
+          const uint8_t* px;
+          if constexpr (kGrid) {   // (a staged visit is its order key: image, grid pixel)
+            const uint32_t r = idx[u] & ((1u << grid.key_bits) - 1u), m = r / grid.gw, n = r - m * grid.gw;
+            px = rgb + (size_t)(idx[u] >> grid.key_bits) * grid.bgr_image_stride + (size_t)(m * grid.step) * grid.bgr_pitch +
+                 (size_t)(n * grid.step) * 3u;
+          } else {
+            px = rgb + 3 * (size_t)idx[u];
+          }
           colr[u] = colour_roundtrip(px[0]) | (colour_roundtrip(px[1]) << 8) | (colour_roundtrip(px[2]) << 16);
         }
       }

@@ -183,7 +183,7 @@ def _stream_depth(T, cam, step):
     return GX, GY, depth.astype(np.float32)
 
 
-def stream_keyframe(k, cam=None, step=2, min_depth=0.1, max_depth=5.0, seed=0):
+def stream_keyframe(k, cam=None, step=2, min_depth=0.1, max_depth=5.0, seed=0, images=False):
     """Key frame k of the long trajectory: {xyz f32[n,3], rgb u8[n,3], kfid u32[n], Twc f32[3,4]} (deterministic in k)."""
     cam = cam or TUM1
     T = stream_pose(k)
@@ -196,8 +196,19 @@ def stream_keyframe(k, cam=None, step=2, min_depth=0.1, max_depth=5.0, seed=0):
     xyz = np.stack([GX * d32, GY * d32, d32], axis=-1)[keep]
     vv, uu = np.nonzero(keep)
     rgb = np.stack([(uu * 3 + k) & 255, (vv * 5 + 2 * k) & 255, (uu + vv + (k >> 3)) & 255], axis=-1)
-    return dict(xyz=np.ascontiguousarray(xyz, dtype=np.float32), rgb=np.ascontiguousarray(rgb, dtype=np.uint8),
-                kfid=np.full(xyz.shape[0], k, dtype=np.uint32), Twc=np.ascontiguousarray(T.astype(np.float32)))
+    out = dict(xyz=np.ascontiguousarray(xyz, dtype=np.float32), rgb=np.ascontiguousarray(rgb, dtype=np.uint8),
+               kfid=np.full(xyz.shape[0], k, dtype=np.uint32), Twc=np.ascontiguousarray(T.astype(np.float32)))
+    if images:
+        # the same key frame as the IMAGES PointCloudMapping starts from (the depth-image entry point of the TSDF,
+        # plvs_hip_tsdf_chisel_integrate_depth_batch_dev): depth and colour on the stride-`step` grid (the pixels in between
+        # are never read: GeneratePointCloudInCameraFrameBGRA visits m, n = 0, step, 2 step, ...) and the grid table the
+        # points above were made with (matCamGridPoints_ of this synthetic camera)
+        vv, uu = np.mgrid[0:d32.shape[0], 0:d32.shape[1]]
+        out["depth_grid"] = np.ascontiguousarray(d32)
+        out["rgb_grid"] = np.ascontiguousarray(np.stack([(uu * 3 + k) & 255, (vv * 5 + 2 * k) & 255, (uu + vv + (k >> 3)) & 255],
+                                                        axis=-1).astype(np.uint8))
+        out["cam_grid"] = np.ascontiguousarray(np.stack([GX, GY], axis=-1).reshape(-1, 2).astype(np.float32))
+    return out
 
 
 def make_stream_keyframes(n_keyframes, first=0, threads=16, **kw):

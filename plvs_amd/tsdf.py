@@ -18,6 +18,16 @@ import torch
 from . import _lib
 
 
+class DepthBatch(ctypes.Structure):
+    """plvs_depth_batch (include/plvs_hip.h)."""
+    _fields_ = [("d_depth", ctypes.c_void_p), ("d_bgr", ctypes.c_void_p),
+                ("depth_image_stride", ctypes.c_size_t), ("bgr_image_stride", ctypes.c_size_t),
+                ("depth_pitch", ctypes.c_int), ("bgr_pitch", ctypes.c_int),
+                ("width", ctypes.c_int), ("height", ctypes.c_int), ("step", ctypes.c_int),
+                ("d_grid_points", ctypes.c_void_p), ("min_depth", ctypes.c_double), ("max_depth", ctypes.c_double),
+                ("d_kfid", ctypes.c_void_p)]
+
+
 class TsdfChisel:
     """Thin RAII wrapper of the plvs_hip_tsdf_chisel_* C ABI."""
 
@@ -255,6 +265,28 @@ class TsdfChisel:
         _lib.check(_lib.lib.plvs_hip_tsdf_chisel_integrate_batch_dev(
             self._h, _lib.t_ptr(d_xyz), _lib.t_ptr(d_rgb), _lib.t_ptr(d_kfid), _lib.np_ptr(offsets),
             offsets.shape[0] - 1, _lib.t_ptr(d_Twc), _lib.current_stream_ptr()))
+
+    def integrate_depth_batch_dev(self, d_depth, d_bgr, d_grid, step, min_depth, max_depth, d_kfid, d_Twc):
+        """GeneratePointCloudInCameraFrameBGRA + InsertCloud in one call (plvs_hip_tsdf_chisel_integrate_depth_batch_dev):
+        d_depth [n, h, w] f32, d_bgr [n, h, w, 3] u8, d_grid [ceil(h / step) * ceil(w / step), 2] f32 (InitCamGridPoints),
+        d_kfid [n] int32 / uint32 (or None), d_Twc [n, 3, 4] f32 — torch tensors in HBM.  Image rows may be strided."""
+        n, hgt, wid = d_depth.shape
+        assert d_depth.dtype == torch.float32 and d_depth.stride(2) == 1
+        assert d_bgr.dtype == torch.uint8 and tuple(d_bgr.shape) == (n, hgt, wid, 3) and d_bgr.stride(3) == 1 and d_bgr.stride(2) == 3
+        assert d_grid.dtype == torch.float32 and d_grid.is_contiguous()
+        assert d_kfid is None or (d_kfid.dtype in (torch.int32, torch.uint32) and d_kfid.is_contiguous())
+        b = DepthBatch()
+        b.d_depth, b.d_bgr = d_depth.data_ptr(), d_bgr.data_ptr()
+        b.depth_image_stride = d_depth.stride(0) if n > 1 else hgt * d_depth.stride(1)
+        b.bgr_image_stride = d_bgr.stride(0) if n > 1 else hgt * d_bgr.stride(1)
+        b.depth_pitch, b.bgr_pitch = d_depth.stride(1), d_bgr.stride(1)
+        b.width, b.height, b.step = wid, hgt, int(step)
+        b.d_grid_points = d_grid.data_ptr()
+        b.min_depth, b.max_depth = float(min_depth), float(max_depth)
+        b.d_kfid = d_kfid.data_ptr() if d_kfid is not None else None
+        f = _lib.lib.plvs_hip_tsdf_chisel_integrate_depth_batch_dev
+        f.argtypes = [ctypes.c_void_p, ctypes.POINTER(DepthBatch), ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        _lib.check(f(self._h, ctypes.byref(b), n, _lib.t_ptr(d_Twc), _lib.current_stream_ptr()))
 
     # ---- ray-sharded multi-GPU integrate (order_free, shard_count > 1): walk -> pack -> exchange -> apply
     def shard_walk(self, d_xyz, offsets, d_Twc):
