@@ -75,7 +75,92 @@ def parse():
                          "100 key frames of the small room); default: the long trajectory of distinct key frames")
     ap.add_argument("--no-steady-state-leg", action="store_true", help="skip the saturated-map leg beside the headline")
     ap.add_argument("--no-frontend", action="store_true")
+    ap.add_argument("--cloud-input", action="store_true",
+                    help="chisel, N = 1, order-free: feed the steps as point streams (plvs_hip_tsdf_chisel_integrate_batch_dev, the "
+                         "headline of rounds 1-4) instead of as the depth images the clouds are made from "
+                         "(plvs_hip_tsdf_chisel_integrate_depth_batch_dev: GeneratePointCloudInCameraFrameBGRA + InsertCloud in one "
+                         "call, the default since round 5)")
+    ap.add_argument("--verbose-line", action="store_true",
+                    help="print the full result (every leg with its prose) instead of the compact line; the full result is "
+                         "always written to gpurun_out/bench_full.json")
     return ap.parse_args()
+
+
+def compact_line(r):
+    """The one JSON line of the driver's contract, numbers only (round 5).  The full result — every leg with the prose that
+    says what it is — goes to gpurun_out/bench_full.json and is described in DESIGN.md §4.6; the driver keeps the contract
+    keys, the scalar members of `config`, `roofline` and `cpu_baseline`, and the last 2 KB of the line, so the key figures of
+    every leg are lifted into those three objects as flat scalars and repeated in `summary`, the LAST key of the line."""
+    def g(d, *path, default=None):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return default
+            d = d[k]
+        return d
+
+    def short(x, n=110):
+        return x if not isinstance(x, str) or len(x) <= n else x[:n - 1] + "~"
+    out = {k: r[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                             "vs_baseline", "dtype", "data") if k in r}
+    cfg = dict(r.get("config", {}))
+    wl = cfg.get("workload", "")
+    cfg["workload"] = (wl.split(":")[0] + ": see DESIGN.md 4.1 / 4.6") if len(wl) > 110 else wl
+    cfg = {k: short(v) for k, v in cfg.items() if not isinstance(v, (dict, list)) or k == "ms_per_step_median_max"}
+    roof = {k: short(v) for k, v in r.get("roofline", {}).items() if not isinstance(v, dict)}
+    for k, v in (g(r, "roofline", "stage_ms_per_launch", default={}) or {}).items():
+        roof["ms_" + k] = v
+    cpu = {k: short(v, 160) for k, v in r.get("cpu_baseline", {}).items() if not isinstance(v, dict)}
+    summary = {
+        "frac": g(r, "roofline", "frac"), "ms_gpu": g(r, "roofline", "ms_per_launch"),
+        "steady_state_value": g(r, "steady_state", "value"), "steady_state_frac": g(r, "steady_state", "roofline", "frac"),
+        "steady_state_ms": g(r, "steady_state", "roofline", "ms_per_launch"),
+        "bit_exact_value": g(r, "bit_exact_mode", "value"), "bit_exact_frac": g(r, "bit_exact_mode", "roofline", "frac"),
+        "bit_exact_ms": g(r, "bit_exact_mode", "roofline", "ms_per_launch"),
+        "first_lap_ms": g(r, "realistic_legs", "first_lap", "ms_per_call"),
+        "updatemap_5_ms": g(r, "realistic_legs", "updatemap_5", "second_lap", "ms_per_call_median"),
+        "updatemap_1_ms": g(r, "realistic_legs", "updatemap_1", "second_lap", "ms_per_call_median"),
+        "updatemap_1_frac": g(r, "realistic_legs", "updatemap_1", "second_lap", "roofline_frac"),
+        "voxblox_value": g(r, "voxblox_configs3", "value"), "voxblox_ms": g(r, "voxblox_configs3", "ms_per_step"),
+        "voxblox_frac": g(r, "voxblox_configs3", "roofline", "frac"), "voxblox_traffic": g(r, "voxblox_configs3", "roofline", "traffic"),
+        "voxblox_cpu_value": g(r, "voxblox_configs3", "cpu_baseline", "value"),
+        "voxblox_cpu_kind": g(r, "voxblox_configs3", "cpu_baseline", "kind"),
+        "voxblox_fast_ms_per_kf": g(r, "voxblox_configs3", "fast_method", "hip_ms_per_keyframe"),
+        "voxblox_fast_bit_identical": g(r, "voxblox_configs3", "fast_method", "bit_identical_to_the_reference_layer"),
+        "frontend_ms_per_frame": g(r, "frontend", "ms_per_frame"), "frontend_fps": g(r, "frontend", "frames_per_s"),
+        "frontend_orb_ms": g(r, "frontend", "orb_extract_ms"), "frontend_lines_ms": g(r, "frontend", "lines_extract_ms"),
+        "frontend_cpu_ms_per_frame": g(r, "frontend", "cpu_baseline", "ms_per_frame"),
+        "frontend_cpu_kind": g(r, "frontend", "cpu_baseline", "kind"),
+        "sgm_ms_per_pair": g(r, "frontend", "dense_stereo_sgm", "ms_per_pair"),
+        "kitti_ms_per_keyframe": g(r, "kitti_shaped", "ms_per_keyframe"),
+        "kitti_maps_bit_identical": g(r, "kitti_shaped", "disparity_maps_bit_identical_to_reference"),
+        "parity_ok": r.get("parity_checked"),
+        "parity_bit_exact_mode": g(r, "parity", "bit_exact_mode", "sdf_weight"),
+        "parity_order_free_worst_fraction_of_bound_sdf": g(r, "parity", "order_free_mode",
+                                                           "order_free_vs_reference_f32_worst_fraction_of_bound", "sdf"),
+        "parity_order_free_worst_fraction_of_bound_weight": g(r, "parity", "order_free_mode",
+                                                              "order_free_vs_reference_f32_worst_fraction_of_bound", "weight"),
+        "parity_order_free_vs_exact_mean_sdf_m": g(r, "parity", "order_free_mode", "order_free_vs_exact_mean", "max_abs_sdf_m"),
+        "parity_chunks": g(r, "parity", "order_free_mode", "chunks"),
+    }
+    summary = {k: v for k, v in summary.items() if v is not None}
+    # the lifted copies (the driver's record keeps scalars of these three objects)
+    for k in ("steady_state_frac", "steady_state_value", "bit_exact_frac", "bit_exact_value", "voxblox_frac", "voxblox_value",
+              "voxblox_traffic"):
+        if k in summary:
+            roof[k] = summary[k]
+    for k in ("first_lap_ms", "updatemap_5_ms", "updatemap_1_ms", "frontend_ms_per_frame", "kitti_ms_per_keyframe", "parity_ok"):
+        if k in summary:
+            cfg[k] = summary[k]
+    for k in ("voxblox_cpu_value", "frontend_cpu_ms_per_frame"):
+        if k in summary:
+            cpu[k] = summary[k]
+    out["config"], out["roofline"], out["cpu_baseline"] = cfg, roof, cpu
+    for k in ("phases_ms", "other_scaling_leg"):
+        if k in r:
+            out[k] = r[k]
+    out["full_result"] = "gpurun_out/bench_full.json (legs: DESIGN.md 4.6)"
+    out["summary"] = summary
+    return out
 
 
 def main():
@@ -127,13 +212,34 @@ def main():
     # stays what one GPU walks at N = 1.
     ray_sharded = multi and not vbx and not args.ordered
     step_kfs = args.batch * (world if (ray_sharded and not args.strong) else 1)
+    # N = 1, order-free chisel: the steps go in as the DEPTH IMAGES of the key frames (PLVS's real pipeline: depth image ->
+    # GeneratePointCloudInCameraFrameBGRA -> InsertCloud); the same key frames as point streams stay in HBM for the other
+    # legs (bit-exact mode, parity) and behind --cloud-input
+    depth_input = not vbx and not multi and not args.ordered and not args.cloud_input
     if not vbx and not args.steady_state:
         # configs[2] stand-in, streaming: step s integrates key frames [s * step_kfs, (s + 1) * step_kfs) of the long
         # trajectory (plvs_amd/synth_scene.py: one loop of LOOP = 2500 DISTINCT key frames around a desk island in a
         # 9.5 x 7.5 x 3 m office; a job longer than the loop walks it again)
         n_poses = min(total_steps * step_kfs, LOOP)
-        kfs = make_stream_keyframes(n_poses, max_depth=args.max_depth, seed=0, threads=min(32, os.cpu_count() or 8))
+        kfs = make_stream_keyframes(n_poses, max_depth=args.max_depth, seed=0, threads=min(32, os.cpu_count() or 8),
+                                    images=depth_input)
+    elif depth_input:
+        kfs = make_keyframes(n_poses, max_depth=args.max_depth, seed=0, images=True)
+
+    def pack_depth(sel, step=2):
+        """The key frames as 640 x 480 images in HBM: depth and colour at the pixels of the stride-2 grid (the others are
+        never read: src/PointCloudMapping.cc:957-996 visits m, n = 0, step, 2 step, ...), the grid table, one id per image."""
+        gh, gw = sel[0]["depth_grid"].shape
+        d = torch.zeros((len(sel), gh * step, gw * step), dtype=torch.float32, device="cuda")
+        c = torch.zeros((len(sel), gh * step, gw * step, 3), dtype=torch.uint8, device="cuda")
+        d[:, ::step, ::step] = torch.from_numpy(np.stack([k["depth_grid"] for k in sel])).cuda()
+        c[:, ::step, ::step] = torch.from_numpy(np.stack([k["rgb_grid"] for k in sel])).cuda()
+        return (d, c, torch.from_numpy(sel[0]["cam_grid"]).cuda(), step, 0.1, args.max_depth,
+                torch.from_numpy(np.array([int(k["kfid"][0]) if len(k["kfid"]) else 0 for k in sel], np.int32)).cuda(),
+                torch.from_numpy(np.stack([k["Twc"] for k in sel])).cuda())
     batches = []
+    depth_batches = []
+    built_depth = {}
     built = {}     # steps that carry the same key frames share one copy in HBM (at N x 100 key frames per step all do)
     for s in range(total_steps):
         first = (s * step_kfs) % n_poses
@@ -145,7 +251,11 @@ def main():
             Twc = torch.from_numpy(np.stack([k["Twc"] for k in sel])).cuda()
             offsets = np.cumsum([0] + [k["xyz"].shape[0] for k in sel]).astype(np.int32)
             built[first] = (xyz, rgb, kfid, offsets, Twc)
+            if depth_input:
+                built_depth[first] = pack_depth(sel)
         batches.append(built[first])
+        if depth_input:
+            depth_batches.append(built_depth[first])
 
     if vbx:
         tsdf = TsdfVoxblox(args.resolution, max_blocks=65536, shard_rank=rank, shard_count=world)
@@ -158,6 +268,11 @@ def main():
     gdir = BlockDirectory(16384) if multi else None      # every rank's copy of the global block -> owner table
 
     def step(b):
+        if depth_input:      # b = (depth images, colour images, grid table, step, min, max, ids, poses), points of the step
+            tsdf.integrate_depth_batch_dev(*b[0])
+            st = tsdf.last_stats()
+            st["points"] = b[1]          # (the library never forms the cloud: the points of the step from the generator)
+            return st
         xyz, rgb, kfid, offsets, Twc = b
         if vbx_sharded:
             sharded_integrate_voxblox(tsdf, xyz, rgb, offsets, Twc)
@@ -180,8 +295,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    timed = [(depth_batches[s], int(batches[s][3][-1])) for s in range(total_steps)] if depth_input else batches
     for s in range(args.warmup):
-        step(batches[s])
+        step(timed[s])
     if not vbx:
         tsdf.set_profiling(True)
     barrier()
@@ -193,7 +309,7 @@ def main():
     step_wall = []
     for s in range(args.warmup, total_steps):
         ts0 = time.perf_counter()
-        st = step(batches[s])
+        st = step(timed[s])
         step_wall.append(time.perf_counter() - ts0)   # (last_stats() has waited for the step: a per-step host clock)
         visits += st["visits"]
         points += st["points"]
@@ -288,8 +404,10 @@ def main():
         # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
         # runs of this same command; scripts/pmc_traffic.py) committed under profiles/
         mode_tag = "" if vbx else ("_ordered" if args.ordered else "_order_free")
+        # (round 5: the depth-image input has its own passes; a point-stream run cites round 4's)
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                           f"r04_pmc_traffic_{args.backend}{mode_tag}{'_steady_state' if args.steady_state else ''}.json")
+                           f"{'r05' if depth_input else 'r04'}_pmc_traffic_{args.backend}{mode_tag}"
+                           f"{'_steady_state' if args.steady_state else ''}.json")
         if world == 1 and not multi and args.batch == 100 and os.path.exists(pmc):
             with open(pmc) as f:
                 t = json.load(f)
@@ -316,6 +434,9 @@ def main():
                                      "chunk allocation and colour folds inside the timed region), Chisel TSDF 5 cm / 5 m, 76800-pixel "
                                      "grid of which 36-73 k points per key frame have a depth below 5 m; the saturated-map figure of "
                                      "rounds 1-3 is the `steady_state` leg")),
+                       "input": ("depth images (640x480, stride-2 grid): GeneratePointCloudInCameraFrameBGRA + InsertCloud fused, "
+                                 "plvs_hip_tsdf_chisel_integrate_depth_batch_dev" if depth_input else
+                                 "camera-frame point streams resident in HBM (integrate_batch_dev)"),
                        "mode": None if vbx else mode_name,
                        "resolution": args.resolution, "max_depth": args.max_depth,
                        "keyframes_per_step": step_kfs, "points_per_step": int(points // args.steps),
@@ -414,24 +535,31 @@ def main():
 
     # ------------------------------------------------- the saturated-map workload of rounds 1-3, beside the headline
     if rank == 0 and world == 1 and not vbx and not multi and not args.steady_state and not args.no_steady_state_leg:
-        sk = make_keyframes(100, max_depth=args.max_depth, seed=0)
-        sb = (torch.from_numpy(np.concatenate([k["xyz"] for k in sk])).cuda(),
-              torch.from_numpy(np.concatenate([k["rgb"] for k in sk])).cuda(),
-              torch.from_numpy(np.concatenate([k["kfid"] for k in sk]).astype(np.int32)).cuda(),
-              np.cumsum([0] + [k["xyz"].shape[0] for k in sk]).astype(np.int32),
-              torch.from_numpy(np.stack([k["Twc"] for k in sk])).cuda())
+        sk = make_keyframes(100, max_depth=args.max_depth, seed=0, images=depth_input)
+        if depth_input:
+            sb = pack_depth(sk)
+            spts = sum(k["xyz"].shape[0] for k in sk)
+            s_call = lambda: ts_.integrate_depth_batch_dev(*sb)   # noqa: E731
+        else:
+            sb = (torch.from_numpy(np.concatenate([k["xyz"] for k in sk])).cuda(),
+                  torch.from_numpy(np.concatenate([k["rgb"] for k in sk])).cuda(),
+                  torch.from_numpy(np.concatenate([k["kfid"] for k in sk]).astype(np.int32)).cuda(),
+                  np.cumsum([0] + [k["xyz"].shape[0] for k in sk]).astype(np.int32),
+                  torch.from_numpy(np.stack([k["Twc"] for k in sk])).cuda())
+            spts = int(sb[3][-1])
+            s_call = lambda: ts_.integrate_batch_dev(*sb)         # noqa: E731
         ts_ = TsdfChisel(args.resolution, max_chunks=16384, order_free=not args.ordered)
         for _ in range(10):
-            ts_.integrate_batch_dev(*sb)
+            s_call()
         torch.cuda.synchronize()
         ts_.set_profiling(True)
         t0 = time.perf_counter()
         sv = sp = 0
         for _ in range(10):
-            ts_.integrate_batch_dev(*sb)
+            s_call()
             st_ = ts_.last_stats()
             sv += st_["visits"]
-            sp += st_["points"]
+            sp += spts
         torch.cuda.synchronize()
         sel_ = time.perf_counter() - t0
         ssm, sc = ts_.stage_ms()
@@ -1228,7 +1356,14 @@ def main():
             _c.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(result), flush=True)
+        full = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpurun_out")
+        try:      # every leg with its prose (what each leg is: DESIGN.md §4.6)
+            os.makedirs(full, exist_ok=True)
+            with open(os.path.join(full, "bench_full.json"), "w") as f:
+                json.dump(result, f, indent=1)
+        except OSError:
+            pass
+        print(json.dumps(result if args.verbose_line else compact_line(result)), flush=True)
     tsdf.close()
     if multi:
         dist.destroy_process_group()

@@ -43,8 +43,9 @@ def _render_depth(R, t, cam, room, spheres, step):
 
 
 def make_keyframes(n_keyframes=100, cam=None, room_size=(6.0, 4.0, 3.0), step=2, min_depth=0.1,
-                   max_depth=5.0, seed=0, noise=True, first=0):
-    """Returns a list of dicts {xyz f32[n,3], rgb u8[n,3], kfid u32[n], Twc f32[3,4]}."""
+                   max_depth=5.0, seed=0, noise=True, first=0, images=False):
+    """Returns a list of dicts {xyz f32[n,3], rgb u8[n,3], kfid u32[n], Twc f32[3,4]}; images=True adds the key frame as
+    the images the cloud was made from (depth_grid, rgb_grid on the stride-`step` grid, cam_grid: see stream_keyframe)."""
     cam = cam or TUM1
     rng = np.random.default_rng(seed)
     half = np.array(room_size, dtype=np.float64) / 2.0
@@ -78,6 +79,12 @@ def make_keyframes(n_keyframes=100, cam=None, room_size=(6.0, 4.0, 3.0), step=2,
                         rgb=np.ascontiguousarray(rgb, dtype=np.uint8),
                         kfid=np.full(xyz.shape[0], k, dtype=np.uint32),
                         Twc=np.ascontiguousarray(Twc)))
+        if images:
+            va, ua = np.mgrid[0:d32.shape[0], 0:d32.shape[1]]
+            out[-1]["depth_grid"] = np.ascontiguousarray(d32)
+            out[-1]["rgb_grid"] = np.ascontiguousarray(np.stack([(ua * 3 + k) & 255, (va * 5 + 2 * k) & 255, (ua + va) & 255],
+                                                                axis=-1).astype(np.uint8))
+            out[-1]["cam_grid"] = np.ascontiguousarray(np.stack([gx32, gy32], axis=-1).reshape(-1, 2))
     return out
 
 

@@ -47,6 +47,10 @@ maps = {}
 MODES = sys.argv[3].split(",") if len(sys.argv) > 3 else ["cloud", "depth", "cloud", "depth"]
 for name in MODES:
     t = TsdfChisel(0.05, max_chunks=16384, order_free=True)
+    if ":" in name:      # "depth:64,64" = apply parts of 64 segments for chunks of more than 64
+        name, parts = name.split(":")
+        t.set_apply_parts(*[int(x) for x in parts.split(".")])
+        print("parts", parts, end=" ")
     warm = min(3, NS - 1)
     for i in range(warm):
         (t.integrate_batch_dev(*clouds[i]) if name == "cloud" else t.integrate_depth_batch_dev(*depths[i]))
