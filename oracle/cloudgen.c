@@ -11,10 +11,15 @@
  * Segmentation.on 0, filterDepth.on 0 (Examples_old/RGB-D/TUM1.yaml:186,203), so the
  * COMPUTE_SEGMENTS block (:1033-1216) and FilterDepthimage (:939-942) do not run.
  *
- * Parity unpinned: the reference holds no test or stored output for this function, and it
- * cannot be built here (OpenCV, Eigen, PCL absent).  Eigen 3.3 semantics assumed where they
- * matter: a reduction of three terms is a0 + (a1 + a2); normalize() leaves a zero vector
- * untouched.  No FMA contraction (oracle/Makefile).
+ * PINNED (round 5): the two functions are cut verbatim out of the reference's src/PointCloudMapping.cc at build time and
+ * compiled against stand-ins for OpenCV / Eigen / PCL (oracle/ref/Makefile, oracle/ref/cloudgen_ref_wrap.cpp ->
+ * oracle/_ref/libcloudgen_ref.so); tests/test_oracle_pinned_cloudgen.py compares the grid table, every byte of every point
+ * record and pixelToPointIndex on images with holes at steps 1 - 4, odd sizes, padded rows and cutting limits, and
+ * reference-made digests are committed (scripts/make_cloudgen_golden.py -> tests/golden/cloudgen_reference_digests.json).
+ * What stays a reading is of Eigen 3.3, encoded in the stand-in (oracle/ref/eigen_full): a reduction of three terms is
+ * a0 + (a1 + a2); normalize() leaves a zero vector untouched.  No FMA contraction (oracle/Makefile).
+ * One thing the pin showed about the CALLER: the reference's fx, fy, cx, cy are doubles holding the FLOAT entries of K
+ * (src/PointCloudMapping.cc:177-180) — oracle_cam_grid_points takes doubles: pass (double)(float)fx for the reference's table.
  */
 #include <math.h>
 #include <stdint.h>

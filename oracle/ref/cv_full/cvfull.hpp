@@ -316,6 +316,10 @@ template <class T>
 struct Mat_ : Mat {
   Mat_() { type_ = DataType<T>::type; }
   Mat_(int r, int c) : Mat(r, c, DataType<T>::type) {}
+  Mat_(int r, int c, const T& v) : Mat(r, c, DataType<T>::type) {   // (rows x cols, every element v)
+    for (int i = 0; i < r; ++i)
+      for (int k = 0; k < c; ++k) this->template at<T>(i, k) = v;
+  }
   Mat_(const Mat& m) { *this = m; }
   Mat_& operator=(const Mat& m) {   // shares a matrix of the same type, converts one of another
     if (m.type() == DataType<T>::type || m.empty()) {
