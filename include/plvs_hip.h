@@ -924,7 +924,8 @@ int plvs_hip_cloudgen_num_grid_points(int width, int height, int step);
 /* InitCamGridPoints (src/PointCloudMapping.cc:796-905) for an undistorted,
  * unrectified camera (mDistCoef[0] == 0): grid[2*ii] = (n - cx)/fx,
  * grid[2*ii+1] = (m - cy)/fy.  Host function, no GPU.  A PLVS build with
- * distortion hands over its own matCamGridPoints_ instead.  * NOTE (pinned by the reference's own source, tests/test_oracle_pinned_cloudgen.py): PLVS fills fx, fy, cx, cy from the
+ * distortion hands over its own matCamGridPoints_ instead.
+ * NOTE (pinned by the reference's own source, tests/test_oracle_pinned_cloudgen.py): PLVS fills fx, fy, cx, cy from the
  * FLOAT entries of K (src/PointCloudMapping.cc:177-180: `pCameraParams_->fx = mK.at<float>(0,0)`), so the doubles it divides
  * by are float values: pass (double)(float)fx ... for a table identical to the reference's. */
 int plvs_hip_cloudgen_grid_points(int width, int height, int step, double fx, double fy, double cx,
