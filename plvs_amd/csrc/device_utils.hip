@@ -6,6 +6,8 @@
 // which is what keeps the sort stable without any per-item atomics.
 #include "device_utils.hpp"
 
+#include "common.hpp"
+
 namespace plvs {
 namespace {
 
@@ -437,7 +439,10 @@ static hipError_t radix_sort_impl(uint32_t* keys0, TV* vals0, uint32_t* keys1, T
   const int total = bit_hi - bit_lo;
   uint32_t *ki = keys0, *ko = keys1;
   TV *vi = vals0, *vo = vals1;
-  if (n >= kLdsScatterMin) {   // long arrays: passes over 8-bit digits, the tiles reordered in LDS
+  // (developer switch, round 5: PLVS_SORT_WIDE_MAX = n up to which 2 passes of <= 11 bits are taken instead of 3 of 8)
+  static const size_t wide_max = (size_t)env_int("PLVS_SORT_WIDE_MAX", 0, 0, 1 << 30);
+  const bool wide = n < wide_max && total > 16 && total <= 2 * kMaxRadixBits;
+  if (n >= kLdsScatterMin && !wide) {   // long arrays: passes over 8-bit digits, the tiles reordered in LDS
     for (int shift = bit_lo; shift < bit_hi; shift += 8) {
       hipError_t e = radix_pass_lds<TV>(ki, vi, ko, vo, n, shift, nb, hist, scan_scratch, stream);
       if (e != hipSuccess) return e;

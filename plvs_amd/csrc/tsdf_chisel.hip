@@ -1175,8 +1175,10 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
                        max_chunks, gsrc ? (int)kGridWords : (int)(2 * ntiles));
     STAGE_MARK(0);
     const GridSrc* const d_grid = gsrc ? reinterpret_cast<const GridSrc*>(h->offsets.p + 2 * ((size_t)nclouds + 1)) : nullptr;
+    static const bool count_in_walk = plvs::env_int("PLVS_SEG_COUNT_IN_WALK", 1, 0, 1) != 0;   // (developer switch)
     AccOut out{h->w_rec.p, (uint32_t)std::min<size_t>(rec_own + rec_spill, 0xFFFFFFFFu), h->w_seg.p,
-               (uint32_t)std::min<size_t>(seg_own + seg_spill, 0xFFFFFFFFu), h->w_seg_cnt.p, h->w_tile_visits.p};
+               (uint32_t)std::min<size_t>(seg_own + seg_spill, 0xFFFFFFFFu), h->w_seg_cnt.p, h->w_tile_visits.p,
+               count_in_walk ? h->w_chunk_nseg.p : nullptr};
     RunOut runs{h->w_runkey.p, h->w_masks.p, h->w_run_cnt.p, h->run_r1_log2};
     // the common case of a tile alone in a lean kernel; what it defers (tiles over several clouds, table overflows,
     // the owner-filtered walk of a sharded handle) is walked by the general kernel from the list
@@ -1223,15 +1225,29 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     // the longer of the two branches — on the caller's stream: the segment sort and the apply stage go to the side stream
     // and are long over when the chain ends.  (A branch on another stream starts ~20 us after the event it waits for and is
     // joined ~20 us after it ends.)
-    const bool predicted = ntiles <= kPredictTiles && h->small_runs_known && attempt == 0;
-    const hipStream_t q_apply = predicted ? h->side : s, q_colour = predicted ? s : h->side;
+    // (round 5) ... and so does a LONG call once the map has saturated: the call before left at most a few hundred runs (what
+    // few rays reach at the rim of the map), the chain is then three short launches on a bound of kSmallRuns, and the host's
+    // read of the run count — scan, publish, a wake-up: 0.06 ms behind a 0.09 ms segment sort + apply — was what a steady-state
+    // step ended with.  A long call over new ground (millions of runs, twice or half the call before) keeps its own count.
+    const size_t expect_runs = h->small_runs_known
+        ? (size_t)((double)h->small_runs_last * (double)ntiles / (double)std::max(1u, h->small_tiles_last)) : ~(size_t)0;
+    // (a moderate number — a saturated map's rim: tens of thousands — is sorted on a bound a quarter above the expectation)
+    constexpr size_t kPredictRuns = 200000;
+    const bool predicted = h->small_runs_known && attempt == 0 && (ntiles <= kPredictTiles || expect_runs <= kPredictRuns);
+    // When that bound is the small one (<= kSmallRuns: ONE sorting launch), nothing is worth a second stream: a branch on
+    // another stream starts ~20 us after the event it waits for and is joined ~20 us after it ends — more than the chain
+    // itself.  Segment sort, apply, sort_runs_small, fold follow each other on the caller's stream; seg_scan, which sums the
+    // tiles' run counts anyway, leaves the total where the colour side reads it (no scan of the counts either).
+    const bool serial_small = predicted && expect_runs <= kSmallRuns / 2;
+    const hipStream_t q_apply = (predicted && !serial_small) ? h->side : s, q_colour = predicted ? s : h->side;
 #define STAGE_MARK_ON(i, q) \
   do { if (h->profiling) PLVS_HIP_TRY(hipEventRecord(h->ev[i], q)); } while (0)
     auto segments_and_apply = [&]() -> int {
     const unsigned seg_blocks = ceil_div(seg_own + seg_spill, kSegSpan);
-    hipLaunchKernelGGL(seg_pass<false>, dim3(seg_blocks), dim3(256), 0, q_apply, h->w_seg.p, out.seg_cap, ntiles,
-                       h->w_seg_cnt.p, h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p,
-                       h->d_wctr);
+    if (!count_in_walk)
+      hipLaunchKernelGGL(seg_pass<false>, dim3(seg_blocks), dim3(256), 0, q_apply, h->w_seg.p, out.seg_cap, ntiles,
+                         h->w_seg_cnt.p, h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p,
+                         h->d_wctr);
     hipLaunchKernelGGL(seg_scan, dim3(1), dim3(1024), 0, q_apply, h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p,
                        h->updated.p, h->w_active_off.p, h->d_wctr, &h->d_ctr->num_chunks, max_chunks,
                        h->w_tile_visits.p, h->w_run_cnt.p, ntiles, h->w_part_off.p, h->w_multi_idx.p, h->multi_cap,
@@ -1291,7 +1307,15 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     // (predicted: a bound that does not hold costs the chain a second time — the fold of the first skips itself: compact_runs)
     uint32_t run_bound = 0;
     int chunk_bound = 0;
-    {
+    if (serial_small) {
+      int rc = segments_and_apply();
+      if (rc != PLVS_OK) return rc;
+      run_bound = kSmallRuns;
+      chunk_bound = std::min(max_chunks, std::max(2 * chunks_before, chunks_before + 256));
+      const RunGuard guard{run_bound, side_ctr, &h->d_ctr->num_chunks, chunk_bound, &h->d_wctr[0].err, &h->d_wctr[1].skip};
+      rc = colour_chain(run_bound, chunk_bound, s, &guard);
+      if (rc != PLVS_OK) return rc;
+    } else {
       if (!predicted) PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
       PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, ntiles, side_ctr, h->scratch.p, q_colour));
       if (predicted) {
@@ -1334,6 +1358,8 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     }
     if (predicted && h->h_wctr[1].skip != 0u) {   // the bounds did not hold: the chain once more, with the call's numbers
       const uint32_t D = h->h_wctr[1].num_desc;
+      if (serial_small)   // (its chain had no use for the offsets of the tiles' runs: the compaction of the long form has)
+        PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, ntiles, side_ctr, h->scratch.p, s));
       PLVS_HIP_TRY(hipMemsetAsync(&h->d_wctr[1].num_heads, 0, sizeof(uint32_t), s));
       PLVS_HIP_TRY(hipMemsetAsync(&h->d_wctr[1].num_updated, 0, sizeof(uint32_t), s));
       int rc2 = colour_chain(D, h->h_ctr->num_chunks, s, nullptr);
@@ -1341,11 +1367,9 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
       rc2 = read_walk_counters(h, s);
       if (rc2 != PLVS_OK) return rc2;
     }
-    if (ntiles <= kPredictTiles) {
-      h->small_runs_known = true;
-      h->small_runs_last = h->h_wctr[1].num_desc;
-      h->small_tiles_last = ntiles;
-    }
+    h->small_runs_known = true;      // (the runs of the last call, whatever its length)
+    h->small_runs_last = h->h_wctr[1].num_desc;
+    h->small_tiles_last = ntiles;
     break;
   }
   const WalkCounters& c = *h->h_wctr;
@@ -2794,7 +2818,7 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
     PLVS_HIP_TRY(hipMemsetAsync(h->w_chunk_nseg.p, 0, xmax * sizeof(uint32_t), s));
     PLVS_HIP_TRY(hipMemsetAsync(h->sh_run_ctr.p, 0, 3 * 64 * sizeof(uint32_t), s));
     AccOut out{h->w_rec.p, (uint32_t)std::min<size_t>(rec_own + rec_spill, 0xFFFFFFFFu), h->w_seg.p,
-               (uint32_t)std::min<size_t>(seg_own + seg_spill, 0xFFFFFFFFu), h->w_seg_cnt.p, h->w_tile_visits.p};
+               (uint32_t)std::min<size_t>(seg_own + seg_spill, 0xFFFFFFFFu), h->w_seg_cnt.p, h->w_tile_visits.p, nullptr};
     RunOut runs{h->w_runkey.p, h->w_masks.p, h->w_run_cnt.p, h->run_r1_log2};
     // (a chunk entered by an attempt that has to be repeated stays in the walk directory: harmless)
     hipLaunchKernelGGL(walk_fast<kFastEntries>, dim3(nt), dim3(kWalkRays), 0, s, Pw, h->scale_u, h->scale_w, d_xyz, n,

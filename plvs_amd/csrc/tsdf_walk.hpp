@@ -660,6 +660,10 @@ struct AccOut {
   uint32_t seg_cap;          // ntiles * kWalkChunks + spill (in segments)
   uint32_t* seg_cnt;         // [ntiles] segments in the tile's own region
   uint32_t* tile_visits;     // [ntiles]
+  // (round 5) per pool slot: segments of the call, counted where they are written — one fire-and-forget atomic per
+  // (tile, chunk), spread over the walk — instead of by a pass over every descriptor slot behind it (seg_pass<false>:
+  // 46 us for the 960 000 slots of a 100-key-frame call, nine tenths of them empty).  nullptr: seg_pass<false> counts.
+  uint32_t* chunk_nseg;
 };
 // Runs: one descriptor + 256-bit ray mask per (tile, voxel) that needs its visits in order.
 // Tile t owns run slots [t << r1_log2, (t + 1) << r1_log2) and fills them from the front, in the order
@@ -1020,6 +1024,7 @@ __global__ __launch_bounds__(kWalkRays, kWalkEntries > 2048 ? 2 : (kWalkEntries 
           if (sg < out.seg_cap) {
             out.seg[2 * (size_t)sg] = make_uint4((uint32_t)S.cslot[cl], rbase + inc - c, c, gtile);
             out.seg[2 * (size_t)sg + 1] = pack_suboffsets(sub);
+            if (out.chunk_nseg) atomicAdd(&out.chunk_nseg[S.cslot[cl]], 1u);
           }
         }
       }
@@ -1049,6 +1054,7 @@ __global__ __launch_bounds__(kWalkRays, kWalkEntries > 2048 ? 2 : (kWalkEntries 
             for (int s = 0; s < kSlabs; ++s) sub[s] = (uint32_t)s > vid / kSlabVox ? 1u : 0u;
             out.seg[2 * (size_t)sg] = make_uint4((uint32_t)slot_of[k], at, 1u, gtile);
             out.seg[2 * (size_t)sg + 1] = pack_suboffsets(sub);
+            if (out.chunk_nseg) atomicAdd(&out.chunk_nseg[slot_of[k]], 1u);
           }
         }
         if (at < out.rec_cap) out.rec[at] = r;
@@ -1437,6 +1443,7 @@ __device__ __forceinline__ void walk_fast_tile(
         const uint32_t sg = tile * (uint32_t)kWalkChunks + sinc - 1u;
         out.seg[2 * (size_t)sg] = make_uint4((uint32_t)S.cslot[lane], rbase + inc - c, c, gtile);
         out.seg[2 * (size_t)sg + 1] = pack_suboffsets(sub);
+        if (out.chunk_nseg) atomicAdd(&out.chunk_nseg[S.cslot[lane]], 1u);
       }
     }
   }
@@ -1736,6 +1743,7 @@ __global__ __launch_bounds__(1024) void seg_scan(const uint32_t* __restrict__ ch
     for (int w = 0; w < 16; ++w) { tot += vsum[w]; rtot += rsum[w]; }
     ctr->total_visits = tot;
     ctr->num_desc = (uint32_t)rtot;
+    if (run_cnt) ctr[1].num_desc = (uint32_t)rtot;   // (the colour side's counters: what a scan of the run counts leaves there too)
     ctr->num_updated = acarry;
     active_off[acarry] = carry;
     part_off[acarry] = pcarry;

@@ -12,7 +12,7 @@ import torch
 
 ROOT = __file__.rsplit("/", 3)[0]
 sys.path.insert(0, ROOT)
-from plvs_amd.synth_scene import make_stream_keyframes  # noqa: E402
+from plvs_amd.synth_scene import make_keyframes, make_stream_keyframes  # noqa: E402
 from plvs_amd.tsdf import TsdfChisel  # noqa: E402
 
 NS = int(sys.argv[1]) if len(sys.argv) > 1 else 8
@@ -41,6 +41,7 @@ def pack_depth(kfs, step=2):
 
 clouds = [pack_cloud(skf[i * KF:(i + 1) * KF]) for i in range(NS)]
 depths = [pack_depth(skf[i * KF:(i + 1) * KF]) for i in range(NS)]
+room = None      # "room" / "room:parts": the saturated small room of the steady-state leg, depth input
 os.environ.setdefault("PLVS_HIP_TSDF_TRACE", "0")
 res = {}
 maps = {}
@@ -51,6 +52,25 @@ for name in MODES:
         name, parts = name.split(":")
         t.set_apply_parts(*[int(x) for x in parts.split(".")])
         print("parts", parts, end=" ")
+    if name == "room":
+        if room is None:
+            room = pack_depth(make_keyframes(100, images=True))
+        for _ in range(10):
+            t.integrate_depth_batch_dev(*room)
+        t.set_profiling(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        v = 0
+        for _ in range(10):
+            t.integrate_depth_batch_dev(*room)
+            v += t.last_stats()["visits"]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        sm, c = t.stage_ms()
+        print("room ms/step", round(dt * 1e3, 3), "visits/step", v // 10, {k: round(x / c, 4) for k, x in sm.items()},
+              "sum", round(sum(sm.values()) / c, 4), flush=True)
+        t.close()
+        continue
     warm = min(3, NS - 1)
     for i in range(warm):
         (t.integrate_batch_dev(*clouds[i]) if name == "cloud" else t.integrate_depth_batch_dev(*depths[i]))
