@@ -1186,6 +1186,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     uint32_t* const list_b = h->w_deferred.p + ntiles;
     const uint32_t* last_list = list_a;
     const uint32_t* last_count = &h->d_wctr->ndeferred;
+    bool second_small = false;
 #define PLVS_LAUNCH_WALK_FAST(E, GRID, TILES, LIST, NLIST, DEFERRED, NDEFERRED)                                              \
   hipLaunchKernelGGL((walk_fast<E, GRID>), dim3(TILES), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,          \
                      h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,                     \
@@ -1207,8 +1208,15 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
       h->walk_small_used = h->walk_small;
       if (h->walk_small) PLVS_WALK_FAST(kFastEntriesSmall, ntiles, nullptr, nullptr, list_a, &h->d_wctr->ndeferred);
       else PLVS_WALK_FAST(kFastEntries, ntiles, nullptr, nullptr, list_a, &h->d_wctr->ndeferred);
-      PLVS_WALK_FAST(kFastEntriesBig, std::min<unsigned>(ntiles, kListGrid), list_a, &h->d_wctr->ndeferred, list_b,
-                     &h->d_wctr->ndeferred2);
+      // the tiles that overflowed the first pass: a 1024-entry first pass hands them to the 2048-entry kernel (two tiles per CU
+      // instead of one: nearly all of them fit it), a 2048-entry first pass to the 4096-entry one
+      if (h->walk_small)
+        PLVS_WALK_FAST(kFastEntries, std::min<unsigned>(ntiles, 2 * kListGrid), list_a, &h->d_wctr->ndeferred, list_b,
+                       &h->d_wctr->ndeferred2);
+      else
+        PLVS_WALK_FAST(kFastEntriesBig, std::min<unsigned>(ntiles, kListGrid), list_a, &h->d_wctr->ndeferred, list_b,
+                       &h->d_wctr->ndeferred2);
+      second_small = h->walk_small;
 #undef PLVS_WALK_FAST
 #undef PLVS_LAUNCH_WALK_FAST
       last_list = list_b;
@@ -1217,7 +1225,8 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     hipLaunchKernelGGL((walk_tiles<true, true>), dim3(kDeferGrid), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
                        h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
                        (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u, 1u}, (uint32_t)ntiles, last_list, last_count,
-                       kRecStride, 2u, d_grid);   // (what is flagged overflowed a 4096-entry table: two pieces at once)
+                       kRecStride, second_small ? 1u : 2u,
+                       d_grid);   // (what is flagged overflowed a 4096-entry table: two pieces at once; a 2048-entry one: it goes whole)
     PLVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
     STAGE_MARK(1);
     // A small call (a few key frames: PointCloudMapping::UpdateMap's batches) launches its colour chain on the sizes of

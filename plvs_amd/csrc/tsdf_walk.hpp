@@ -1293,6 +1293,19 @@ __device__ __forceinline__ void walk_fast_tile(
 #pragma unroll
       for (int w = kWalkRays / 64 - 1; w >= 0; --w) w0 = S.cand[w] ? w : w0;
       ox = S.worg[w0][0]; oy = S.worg[w0][1]; oz = S.worg[w0][2];
+      // no ray at all (a block of grid pixels without a valid depth: sky, a wall beyond max_depth, a hole — a sixth of the
+      // tiles of an office stream): the tile is over, three barriers and a flush of nothing earlier
+      uint32_t anyc = 0;
+#pragma unroll
+      for (int w = 0; w < kWalkRays / 64; ++w) anyc |= S.cand[w];
+      if (anyc == 0u) {   // (uniform: every thread reads the same words)
+        if (tid == 0) {
+          out.seg_cnt[tile] = 0;
+          runs.run_cnt[tile] = 0;
+          out.tile_visits[tile] = 0;
+        }
+        return;
+      }
     }
     // ---- does the ray's whole box (start voxel +- its reach) lie inside the key box?
     bool fits = false;
