@@ -1384,10 +1384,13 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
   const WalkCounters& c = *h->h_wctr;
   h->num_chunks = h->h_ctr->num_chunks;
   if (ntiles > kSmallCallTiles) {   // the first pass's table for the next call of this size class
+    // (round 5: what overflows the small table goes to the 2048-entry kernel at two tiles per CU — a fifth of the tiles there
+    // still costs less than a 2048-entry first pass for all of them: 0.51 + 0.1 against 0.8 ms on the office stream, where
+    // the 6 % / 2 % thresholds of round 4 had every other step fall back to the large table)
     if (h->walk_small_used) {
-      if ((size_t)c.ndeferred * 16 > ntiles) h->walk_small = false;   // more than 6 % of the tiles overflowed the small table
-    } else if ((size_t)c.over_small * 50 <= ntiles) {
-      h->walk_small = true;                                             // at most 2 % would
+      if ((size_t)c.ndeferred * 4 > ntiles) h->walk_small = false;    // more than a quarter of the tiles overflowed the small table
+    } else if ((size_t)c.over_small * 6 <= ntiles) {
+      h->walk_small = true;                                             // at most a sixth would
     }
   }
   {   // developer trace of the call's counters (PLVS_HIP_TSDF_TRACE=1)

@@ -19,6 +19,7 @@ from tests.plvs_amd_synth import make_keyframes, TUM1
 from tests.test_tsdf_chisel import (ORDER_FREE_SDF_ATOL, ORDER_FREE_WEIGHT_RTOL, _depth_image, compare_maps)
 
 pytestmark = pytest.mark.gpu
+HEADLINE_STEPS = 5
 
 
 def _snapshot(m):
@@ -83,14 +84,16 @@ def test_chisel_bench_step_matches_oracle(bench_stream, order_free):
 
 @pytest.fixture(scope="module")
 def headline_stream(oracle):
-    """The first two steps of bench.py's STREAMING headline (key frames 0-99 into an empty map, 100-199 into that map) on the
-    oracle: voxel planes after each, and the exact (f64) mean of every voxel's visits beside the reference's f32 running mean."""
+    """The first HEADLINE_STEPS steps of bench.py's STREAMING headline (key frames 0-99 into an empty map, 100-199 into that
+    map, ...) on the oracle: voxel planes after each, and the exact (f64) mean of every voxel's visits beside the reference's
+    f32 running mean.  Five steps: the first call on an empty map, the calls in which the walk's first-pass table follows the
+    scene (2048 -> 1024 entries for the 2-D tiles of the depth entry point), revisits of the desk island."""
     from plvs_amd.synth_scene import make_stream_keyframes
-    kfs = make_stream_keyframes(200, max_depth=5.0, seed=0, threads=16)
+    kfs = make_stream_keyframes(100 * HEADLINE_STEPS, max_depth=5.0, seed=0, threads=16, images=True)
     ora = oracle.chisel(0.05)
     ora.track_exact()
     visits, snaps, exact = [], [], []
-    for step in range(2):
+    for step in range(HEADLINE_STEPS):
         v = 0
         for kf in kfs[100 * step:100 * step + 100]:
             ora.integrate(kf["xyz"], kf["rgb"], kf["kfid"], kf["Twc"])
@@ -101,8 +104,22 @@ def headline_stream(oracle):
     return kfs, visits, snaps, exact
 
 
-@pytest.mark.parametrize("order_free", [False, True])
-def test_chisel_streaming_headline_steps_match_oracle(headline_stream, order_free):
+def _depth_batch(g, max_depth=5.0, step=2):
+    """The key frames as bench.py hands them to the depth entry point: 640 x 480 images, depth and colour at the pixels of
+    the stride-2 grid."""
+    import torch
+    gh, gw = g[0]["depth_grid"].shape
+    d = torch.zeros((len(g), gh * step, gw * step), dtype=torch.float32, device="cuda")
+    c = torch.zeros((len(g), gh * step, gw * step, 3), dtype=torch.uint8, device="cuda")
+    d[:, ::step, ::step] = torch.from_numpy(np.stack([k["depth_grid"] for k in g])).cuda()
+    c[:, ::step, ::step] = torch.from_numpy(np.stack([k["rgb_grid"] for k in g])).cuda()
+    return (d, c, torch.from_numpy(g[0]["cam_grid"]).cuda(), step, 0.1, max_depth,
+            torch.from_numpy(np.array([int(k["kfid"][0]) for k in g], np.int32)).cuda(),
+            torch.from_numpy(np.stack([k["Twc"] for k in g])).cuda())
+
+
+@pytest.mark.parametrize("order_free,entry", [(False, "cloud"), (True, "cloud"), (True, "depth")])
+def test_chisel_streaming_headline_steps_match_oracle(headline_stream, order_free, entry):
     """The headline as the bench runs it since round 4: tiles of walls 3-5 m away (800-2 000 voxels each: the 2048-entry
     first pass, the 4096-entry pass over what overflowed, the general kernel behind it), chunk allocation and colour folds
     inside the step.  Ordered mode: bit for bit.  Order-free mode: kfid and colour exact; sdf / weight within 2e-5 m / 5e-5
@@ -114,17 +131,22 @@ def test_chisel_streaming_headline_steps_match_oracle(headline_stream, order_fre
     tau = max((0.0019 * 25.0 - 0.00152 * 5.0 + 0.001504) * 6.0, 2.0 * np.sqrt(3.0) * 0.05)
     w_min = 1.0 / (2.0 * tau)
     dev = TsdfChisel(0.05, max_chunks=16384, order_free=order_free)
-    for step in range(2):
+    for step in range(HEADLINE_STEPS if order_free else 2):      # (the ordered mode: two steps, as in round 4)
         g = kfs[100 * step:100 * step + 100]
-        xyz = torch.from_numpy(np.concatenate([k["xyz"] for k in g])).cuda()
-        rgb = torch.from_numpy(np.concatenate([k["rgb"] for k in g])).cuda()
-        kfid = torch.from_numpy(np.concatenate([k["kfid"] for k in g]).astype(np.int32)).cuda()
-        Twc = torch.from_numpy(np.stack([k["Twc"] for k in g])).cuda()
-        offsets = np.cumsum([0] + [k["xyz"].shape[0] for k in g]).astype(np.int32)
-        dev.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
-        torch.cuda.synchronize()
-        st = dev.last_stats()
-        assert st["visits"] == visits[step] and st["points"] == xyz.shape[0]
+        if entry == "depth":      # the headline of round 5: GeneratePointCloudInCameraFrameBGRA + InsertCloud in one call
+            dev.integrate_depth_batch_dev(*_depth_batch(g))
+            torch.cuda.synchronize()
+            assert dev.last_stats()["visits"] == visits[step]
+        else:
+            xyz = torch.from_numpy(np.concatenate([k["xyz"] for k in g])).cuda()
+            rgb = torch.from_numpy(np.concatenate([k["rgb"] for k in g])).cuda()
+            kfid = torch.from_numpy(np.concatenate([k["kfid"] for k in g]).astype(np.int32)).cuda()
+            Twc = torch.from_numpy(np.stack([k["Twc"] for k in g])).cuda()
+            offsets = np.cumsum([0] + [k["xyz"].shape[0] for k in g]).astype(np.int32)
+            dev.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
+            torch.cuda.synchronize()
+            st = dev.last_stats()
+            assert st["visits"] == visits[step] and st["points"] == xyz.shape[0]
         want = snaps[step]
         assert {tuple(c) for c in dev.chunk_ids()} == set(want)
         assert len(want) > 80
@@ -150,6 +172,31 @@ def test_chisel_streaming_headline_steps_match_oracle(headline_stream, order_fre
             assert ws <= ORDER_FREE_SDF_ATOL and ww <= ORDER_FREE_WEIGHT_RTOL, (ws, ww)
             assert bound_s <= 1.0 and bound_w <= 1.0, (bound_s, bound_w)
     dev.close()
+
+
+def test_chisel_streaming_headline_later_steps_depth_entry_equals_point_streams():
+    """Steps 1-13 of the headline (1 300 key frames: the map grows to ~450 chunks, the walk's first-pass table has settled,
+    the colour chain runs on predicted sizes where the run count allows): the map of the depth entry point against the map
+    of the point-stream entry point, both order-free, bit for bit after steps 5, 9 and 13.  (The point-stream map of ALL 25
+    steps is compared with the oracle inside bench.py, `parity`; the first five steps against the oracle above.)"""
+    import torch
+    from plvs_amd.synth_scene import make_stream_keyframes
+    from plvs_amd.tsdf import TsdfChisel
+    a = TsdfChisel(0.05, max_chunks=16384, order_free=True)
+    b = TsdfChisel(0.05, max_chunks=16384, order_free=True)
+    for step in range(13):
+        g = make_stream_keyframes(100, first=100 * step, max_depth=5.0, seed=0, threads=16, images=True)
+        a.integrate_depth_batch_dev(*_depth_batch(g))
+        b.integrate_batch_dev(torch.from_numpy(np.concatenate([k["xyz"] for k in g])).cuda(),
+                              torch.from_numpy(np.concatenate([k["rgb"] for k in g])).cuda(),
+                              torch.from_numpy(np.concatenate([k["kfid"] for k in g]).astype(np.int32)).cuda(),
+                              np.cumsum([0] + [k["xyz"].shape[0] for k in g]).astype(np.int32),
+                              torch.from_numpy(np.stack([k["Twc"] for k in g])).cuda())
+        assert a.last_stats()["visits"] == b.last_stats()["visits"] > 10_000_000
+        if step in (4, 8, 12):
+            assert compare_maps(a, b) > 150
+    a.close()
+    b.close()
 
 
 @pytest.mark.parametrize("kind", ["far", "mixed"])
