@@ -518,7 +518,8 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
  *   d_bgr          image c at d_bgr + c * bgr_image_stride (bytes), rows bgr_pitch bytes apart, 3 bytes per pixel
  *   d_grid_points  matCamGridPoints_ (plvs_hip_cloudgen_grid_points), ceil(height / step) x ceil(width / step) x 2 floats
  *   d_kfid         one key-frame id per image (may be NULL: 0)
- * Asynchronous on `stream` except for the call's one read of its counters. */
+ * Asynchronous on `stream` except for the call's one read of its counters.  plvs_tsdf_stats.points is 0 after a call on
+ * an order-free handle (the cloud is never formed); ordered handles report the points of the clouds they built. */
 typedef struct plvs_depth_batch {
   const float* d_depth;
   const uint8_t* d_bgr;
