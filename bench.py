@@ -131,6 +131,8 @@ def compact_line(r):
         "frontend_cpu_ms_per_frame": g(r, "frontend", "cpu_baseline", "ms_per_frame"),
         "frontend_cpu_kind": g(r, "frontend", "cpu_baseline", "kind"),
         "sgm_ms_per_pair": g(r, "frontend", "dense_stereo_sgm", "ms_per_pair"),
+        "sgm_parity": "unpinned (libsgm is CUDA-only: oracle/sgm.c is a restatement)" if g(r, "frontend", "dense_stereo_sgm") else None,
+        "elas_parity_note": "bit-identical on zero-initialised heaps (oracle/ref/elas_zero_malloc.h)" if g(r, "kitti_shaped", "ms_per_keyframe") else None,
         "kitti_ms_per_keyframe": g(r, "kitti_shaped", "ms_per_keyframe"),
         "kitti_maps_bit_identical": g(r, "kitti_shaped", "disparity_maps_bit_identical_to_reference"),
         "parity_ok": r.get("parity_checked"),

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): GPU parity tests, smoke, bench, rocprof stats + PMC.
 # Every stage has its own timeout and log under gpurun_out/.  Usage:
-#   bash scripts/gpu_check.sh [tag] [stages]     stages: subset of "test smoke bench prof pmc"
+#   bash scripts/gpu_check.sh [tag] [stages]     stages: subset of "test smoke bench prof pmc multi"
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 TAG="${1:-run}"
 STAGES="${2:-test smoke bench prof pmc}"
@@ -31,6 +31,20 @@ if [[ "$STAGES" == *sweep* ]]; then
     ( timeout 200 python bench.py --batch $B --no-cpu-baseline --no-frontend 2>&1 | tail -1 ) >> "$O/sweep.log" 2>&1
   done
   echo "sweep done $(date +%T)" >> "$O/stages.log"
+fi
+# the first multi-GPU box: the N = 2 bench over RCCL exactly as the driver launches it (one rank per GPU), chisel ray-sharded and
+# the voxblox leg; skipped where the box has one device
+if [[ "$STAGES" == *multi* ]]; then
+  NDEV=$(python -c "import torch; print(torch.cuda.device_count())" 2>/dev/null || echo 0)
+  if [ "${NDEV:-0}" -ge 2 ]; then
+    ( HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+        --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 3 --no-cpu-baseline --no-frontend 2>&1 | tail -3 ) > "$O/bench_2gpu.log" 2>&1
+    ( HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+        --master-port 29534 bench.py --gpus 2 --steps 5 --warmup 3 --backend voxblox --no-cpu-baseline --no-frontend 2>&1 | tail -3 ) > "$O/bench_2gpu_voxblox.log" 2>&1
+  else
+    echo "one device: the 2-GPU RCCL rehearsal is skipped" > "$O/bench_2gpu.log"
+  fi
+  echo "multi done $(date +%T)" >> "$O/stages.log"
 fi
 if [[ "$STAGES" == *prof* ]]; then
   ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof" -o r -- python "$R/bench.py" --no-cpu-baseline --no-frontend --no-realistic-legs $BENCH_ARGS 2>&1 | tail -5 ) > "$O/rocprof.log" 2>&1
