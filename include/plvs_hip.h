@@ -489,7 +489,9 @@ int plvs_hip_tsdf_chisel_integrate(plvs_tsdf_chisel* h, const float* xyz, const 
  * the batch pipeline: the same map as integrating the clouds one by one — bit for bit in the ordered mode (the batch applies
  * every update in point order across the clouds), within the stated tolerance in the order-free mode — at a fraction of the
  * per-call launch chain.  Every entry point that reads or changes the map (integrate, carve, mesh, download, chunk lists,
- * deform, last_stats, ...) flushes first; _clear drops the queue with the map.  _queued: clouds waiting. */
+ * deform, last_stats, ...) flushes first — so a READER can return an integrate error (capacity, a non-finite point): the
+ * message then names the flush and the number of queued clouds, none of which was integrated; they are dropped (queue them
+ * again after clearing / enlarging the map).  _clear drops the queue with the map.  _queued: clouds waiting. */
 int plvs_hip_tsdf_chisel_queue(plvs_tsdf_chisel* h, const float* xyz, const uint8_t* rgb, const uint32_t* kfid, int n,
                                const float* Twc);
 int plvs_hip_tsdf_chisel_flush(plvs_tsdf_chisel* h);

@@ -1943,7 +1943,16 @@ int plvs_hip_tsdf_voxblox_flush(plvs_tsdf_voxblox* h) {
   PLVS_HIP_TRY(hipMemcpy(h->q_Twc_dev.p, Twc.data(), (size_t)12 * nclouds * sizeof(float), hipMemcpyHostToDevice));
   int rc = plvs_hip_tsdf_voxblox_integrate_batch_dev(h, h->q_xyz.p, reinterpret_cast<const uint8_t*>(h->q_rgba.p), offsets.data(), nclouds,
                                                      h->q_Twc_dev.p, nullptr);
-  if (rc != PLVS_OK) return rc;
+  if (rc != PLVS_OK) {
+    // The queue was taken before the batch ran (a reader that flushes must not flush again from inside it): its clouds are
+    // gone.  Say so, and how many — the error surfaces from whichever call triggered the flush, possibly a reader.
+    char own[400];
+    snprintf(own, sizeof own, "%s", plvs::last_error_buf());
+    plvs::set_error("%s — raised by the flush of %d queued key-frame cloud%s (plvs_hip_tsdf_voxblox_queue): NONE of them was "
+                    "integrated and they are dropped; queue them again after clearing / enlarging the map", own, nclouds,
+                    nclouds == 1 ? "" : "s");
+    return rc;
+  }
   PLVS_HIP_TRY(hipDeviceSynchronize());
   return PLVS_OK;
 }
