@@ -1942,6 +1942,8 @@ int plvs_hip_tsdf_chisel_integrate_depth_batch_dev(plvs_tsdf_chisel* h, const pl
   g.gh = (uint32_t)((in->height + in->step - 1) / in->step);
   g.ntx = (g.gw + kGridTileW - 1) / kGridTileW;
   g.nty = (g.gh + kGridTileH - 1) / kGridTileH;
+  g.inv_ntx = 1.0f / (float)g.ntx;
+  g.inv_nty = 1.0f / (float)g.nty;
   g.key_bits = 1;
   while ((1ull << g.key_bits) < (unsigned long long)g.gw * g.gh) ++g.key_bits;
   g.min_depth = in->min_depth;

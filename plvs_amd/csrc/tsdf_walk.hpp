@@ -507,13 +507,28 @@ struct GridSrc {
   // pixel -> the point's r, g, b members, :978-980)
   unsigned long long bgr_image_stride;   // bytes between two images
   uint32_t bgr_pitch;                    // bytes per image row
+  float inv_ntx, inv_nty;                // 1 / ntx, 1 / nty (fast_div: a tile index is split once per run in the fold)
 };
 struct GridTile {
   uint32_t cloud, row0, col0;   // image, first grid row / column of the tile
 };
+// x / d for x below 2^24 by the float reciprocal (one multiply and a fix-up instead of the ~40 instructions of a 32-bit
+// division: the colour fold splits a tile index for every run it reads); the plain quotient beyond.
+__device__ __forceinline__ uint32_t fast_div(uint32_t x, uint32_t d, float inv) {
+  if (x >= (1u << 24)) return x / d;
+  uint32_t q = (uint32_t)((float)x * inv);
+  const int32_t r = (int32_t)(x - q * d);
+  q = r < 0 ? q - 1u : ((uint32_t)r >= d ? q + 1u : q);
+  return q;
+}
+// tile -> band (image and band of grid rows in one number: tiles are numbered band by band)
+__device__ __forceinline__ uint32_t grid_band(const GridSrc& g, uint32_t gtile) { return fast_div(gtile, g.ntx, g.inv_ntx); }
+__device__ __forceinline__ GridTile grid_tile_of_band(const GridSrc& g, uint32_t gtile, uint32_t band) {
+  const uint32_t c = fast_div(band, g.nty, g.inv_nty);
+  return GridTile{c, (band - c * g.nty) * (uint32_t)kGridTileH, (gtile - band * g.ntx) * (uint32_t)kGridTileW};
+}
 __device__ __forceinline__ GridTile grid_tile(const GridSrc& g, uint32_t gtile) {
-  const uint32_t per = g.ntx * g.nty, c = gtile / per, t = gtile - c * per, br = t / g.ntx;
-  return GridTile{c, br * (uint32_t)kGridTileH, (t - br * g.ntx) * (uint32_t)kGridTileW};
+  return grid_tile_of_band(g, gtile, grid_band(g, gtile));
 }
 // The point ray `rid` of the tile would be in the reference's cloud; false: the grid pixel does not exist or its depth
 // is not inside (min, max) (compared in double, :967).
@@ -2343,12 +2358,17 @@ __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
       };
       while (__any(open)) {
         const uint32_t j = jn + (uint32_t)sub;
-        const bool mine = open && j < nd && skeys[j] == keyv;
-        const uint32_t val = mine ? sorted_val[j] : 0u;
+        // (key and slot of a run are fetched TOGETHER, the slot whether or not the key turns out to be the voxel's: a round
+        // is then two dependent memory latencies — keys and slots, masks — instead of three; a voxel 4 m away needs ~150
+        // runs = 19 rounds for its 254 visits, and the slowest voxel of its eight is the wave's time)
+        const uint32_t jc = min(j, nd - 1u), j8 = min(jn + 8u, nd - 1u);
+        const uint32_t key_j = skeys[jc], val_j = sorted_val[jc], key_8 = skeys[j8], val_8 = sorted_val[j8];
+        const bool mine = open && j < nd && key_j == keyv;
+        const uint32_t val = mine ? val_j : 0u;
         const uint32_t gtile = mine ? src.tmap.tile_of(val >> src.r1_log2) : 0u;
-        const uint32_t band = mine ? gtile / grid.ntx : 0xFFFFFFFFu;   // (image and band in one number: tiles are numbered band by band)
+        const uint32_t band = mine ? grid_band(grid, gtile) : 0xFFFFFFFFu;   // (image and band in one number: tiles are numbered band by band)
         uint32_t band8 = 0xFFFFFFFEu;   // the band of the run behind these eight: is the last band here complete?
-        if (open && jn + 8u < nd && skeys[jn + 8u] == keyv) band8 = run_tile(jn + 8u) / grid.ntx;
+        if (open && jn + 8u < nd && key_8 == keyv) band8 = grid_band(grid, src.tmap.tile_of(val_8 >> src.r1_log2));
         const uint32_t bprev = (uint32_t)__shfl_up((int)band, 1, 8);
         const bool start = mine && (sub == 0 || band != bprev);
         const uint32_t minem = (uint32_t)(__ballot(mine) >> gshift) & 0xFFu, startm = (uint32_t)(__ballot(start) >> gshift) & 0xFFu;
@@ -2379,11 +2399,20 @@ __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
             }
           };
           if (lead) load_mask(val, mA);
-          if (lead && nb > 1u) load_mask(val1, mB);
-          if (lead && nb > 2u) load_mask(val2, mC);
+          // (three bands in four have ONE run: a wave whose bands all do skips the second and third run's registers, loads
+          // and empty bit loops altogether)
+          const bool wide = __any(lead && nb > 1u);
+          if (wide) {
+            if (lead && nb > 1u) load_mask(val1, mB);
+            if (lead && nb > 2u) load_mask(val2, mC);
+          }
           uint32_t cnt = 0;
 #pragma unroll
-          for (int w = 0; w < kMaskWords; ++w) cnt += (uint32_t)(__popc(mA[w]) + __popc(mB[w]) + __popc(mC[w]));
+          for (int w = 0; w < kMaskWords; ++w) cnt += (uint32_t)__popc(mA[w]);
+          if (wide) {
+#pragma unroll
+            for (int w = 0; w < kMaskWords; ++w) cnt += (uint32_t)(__popc(mB[w]) + __popc(mC[w]));
+          }
           uint32_t inc = cnt;
 #pragma unroll
           for (int d = 1; d < 8; d <<= 1) {
@@ -2391,8 +2420,9 @@ __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
             if (sub >= d) inc += up;
           }
           uint32_t at = havev + inc - cnt;
-          const GridTile tA = grid_tile(grid, gtile);
-          const uint32_t colB = grid_tile(grid, gt1).col0, colC = grid_tile(grid, gt2).col0;
+          const GridTile tA = grid_tile_of_band(grid, gtile, band);
+          // (the other runs of the band: its column blocks)
+          const uint32_t colB = (gt1 - band * grid.ntx) * (uint32_t)kGridTileW, colC = (gt2 - band * grid.ntx) * (uint32_t)kGridTileW;
           uint32_t rowkey = (tA.cloud << grid.key_bits) | (tA.row0 * grid.gw);
           auto put = [&](uint32_t bits, uint32_t key0) {
             while (bits && at < needv) {
@@ -2401,12 +2431,20 @@ __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
               stage[wid][vl][at++] = key0 + (uint32_t)bpos;
             }
           };
+          if (wide) {
 #pragma unroll
-          for (int w = 0; w < kMaskWords; ++w) {
-            put(mA[w], rowkey + tA.col0);
-            put(mB[w], rowkey + colB);
-            put(mC[w], rowkey + colC);
-            rowkey += grid.gw;
+            for (int w = 0; w < kMaskWords; ++w) {
+              put(mA[w], rowkey + tA.col0);
+              put(mB[w], rowkey + colB);
+              put(mC[w], rowkey + colC);
+              rowkey += grid.gw;
+            }
+          } else {
+#pragma unroll
+            for (int w = 0; w < kMaskWords; ++w) {
+              put(mA[w], rowkey + tA.col0);
+              rowkey += grid.gw;
+            }
           }
           havev += (uint32_t)__shfl((int)inc, 7, 8);
           jn += take;
@@ -2417,7 +2455,7 @@ __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
           uint32_t nbt = 0u;
           for (;; nbt += 8u) {
             const uint32_t jc = jn + nbt + (uint32_t)sub;
-            const bool in = jc < nd && skeys[jc] == keyv && run_tile(jc) / grid.ntx == band0;
+            const bool in = jc < nd && skeys[jc] == keyv && grid_band(grid, run_tile(jc)) == band0;
             const uint32_t cm = (uint32_t)(__ballot(in) >> gshift) & 0xFFu;
             if (cm != 0xFFu) {
               nbt += (uint32_t)__popc(cm);
@@ -2449,7 +2487,9 @@ __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
       bool open = (uint32_t)vl < nv && needv > 0u;
       for (uint32_t jb = 0; __any(open); jb += 8) {
         const uint32_t j = j0v + jb + (uint32_t)sub;
-        const bool mine = open && j < nd && skeys[j] == keyv;
+        const uint32_t jc = min(j, nd - 1u);
+        const uint32_t key_j = skeys[jc], val_j = sorted_val[jc];   // (together: see the depth-image form above)
+        const bool mine = open && j < nd && key_j == keyv;
         uint32_t m[kMaskWords];
 #pragma unroll
         for (int w = 0; w < kMaskWords; ++w) m[w] = 0;
@@ -2460,7 +2500,7 @@ __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
         for (int q = 0; q < (int)kWireSpans; ++q) sp[q] = kSpanNone;
         const bool wire = src.words == kWireRun;
         if (mine) {
-          const uint32_t val = sorted_val[j];
+          const uint32_t val = val_j;
           const uint32_t* run = src.base + (size_t)val * src.words;
           uint32_t gt;
           if (wire) {
