@@ -299,6 +299,45 @@ int plvs_hip_lines_octave_size(plvs_lines* h, int octave, int* w, int* hh);
 int plvs_hip_lines_download_map(plvs_lines* h, int octave, int which, void* out);
 int plvs_hip_lines_num_in_octave(plvs_lines* h, int octave);
 
+/* ---------------------------------------------------------------------------
+ * The LSD detector (Line.LSD.on: 1 -> LineExtractor::skUseLsdExtractor, src/LineExtractor.cc:203-206, 275-279;
+ * src/Tracking.cc reads the flag from the settings file).  Replaces
+ *   cv::lsd::LineSegmentDetectorImpl::detect   Thirdparty/line_descriptor/src/lsd_custom.cpp:433-1081
+ *   LSDDetectorC::detect / detectImpl           Thirdparty/line_descriptor/src/LSDDetector_custom.cpp:50-298
+ * and, for plvs_hip_lsd_extract, LineExtractor::operator() with that detector in front of the LBD descriptor.
+ * Device: the Gaussian + INTER_LINEAR_EXACT rescaling in front of the detector, the level-line field (gradient norm in
+ * double, angle by cv::fastAtan2), the pyramid, Sobel and LBD.  Host threads inside the library: the pseudo-ordering
+ * (the reference's unstable std::sort, reproduced by running it) and the sequential region growing / rectangle
+ * refinement / NFA loop.  Results are those of the reference's sources bit for bit (tests/test_lsd.py).
+ */
+typedef struct plvs_lsd plvs_lsd;
+typedef struct plvs_lsd_options {   /* LSDDetectorC::LSDOptions (descriptor_custom.hpp:928-957) */
+  int refine;                       /* cv::LSD_REFINE_NONE / STD / ADV = 0 / 1 / 2; default 2      */
+  double scale, sigma_scale, quant, ang_th, log_eps, density_th;   /* 0.8, 0.6, 2.0, 22.5, 0, 0.7 */
+  int n_bins;                       /* 1024                                                      */
+} plvs_lsd_options;
+int plvs_hip_lsd_default_options(plvs_lsd_options* out);
+int plvs_hip_lsd_create(plvs_lsd** out);
+int plvs_hip_lsd_destroy(plvs_lsd* h);
+/* LineSegmentDetector::detect(image, lines): segments = cap x 4 floats (x1, y1, x2, y2 — cv::Vec4f), in the
+ * reference's order; *n = their number (nothing is written if n > cap).  options = NULL: the defaults. */
+int plvs_hip_lsd_segments(plvs_lsd* h, const uint8_t* image, int w, int hh, int stride, const plvs_lsd_options* options,
+                          float* segments, int cap, int* n);
+/* LSDDetectorC::detect(image, keylines, numOctaves, scale, opts): the detector's own Gaussian pyramid
+ * (5 x 5, sigma 1, then INTER_LINEAR by 1 / scale), LSD on every level, KeyLines of the segments longer than
+ * min_length x the image diagonal (opts.min_length). */
+int plvs_hip_lsd_detect(plvs_lsd* h, const uint8_t* image, int w, int hh, int stride, int num_octaves, float scale,
+                        const plvs_lsd_options* options, double min_length, plvs_keyline* keylines, int cap, int* n);
+/* LineExtractor::operator() with the LSD detector, options as Tracking fills them (src/Tracking.cc:1458-1485): num_octaves =
+ * Line.nLevels; options->scale = Line.scaleFactor — the pyramid scale (narrowed to float, as detectLineFeatures passes it) AND
+ * the detector's own rescaling; the other members = the Line.LSD.* keys.  Detection, detectLineFeatures' selection of the
+ * nfeatures strongest, LBD descriptors on BinaryDescriptor's own (unblurred) pyramid.  Outputs as plvs_hip_lines_extract. */
+int plvs_hip_lsd_extract(plvs_lsd* h, const uint8_t* image, int w, int hh, int stride, int nfeatures, int num_octaves,
+                         const plvs_lsd_options* options, double min_length, plvs_keyline* keylines, uint8_t* desc, int cap,
+                         int* n);
+/* ms of the last call: [0] device maps + copies, [1] host ordering + region loop (summed over levels), [2] selection + LBD */
+int plvs_hip_lsd_last_stage_ms(plvs_lsd* h, double* ms, int cap);
+
 /* LineMatcher::SearchByKnn(Frame& CurrentFrame, const Frame& LastFrame)
  * (src/LineMatcher.cc:303-447), single-camera frames.  Last frame = query side:
  * LBD descriptors (n_last x 32), valid_last[i] = LastFrame.mvpMapLines[i] &&

@@ -105,6 +105,68 @@ inline void resize_linear_u8_factor(const Image& src, Image& dst, double fx, dou
   resize_linear_u8_impl(src, dst, fx, fy);
 }
 
+/* cv::resize(src, dst, Size(), fx, fy, INTER_LINEAR_EXACT) for CV_8UC1 (OpenCV 4.x resize.cpp: resize_bitExact<uint8_t,
+ * interpolationLinear<uint8_t>>, the "bit-exact" path the LSD detector rescales with, lsd_custom.cpp:493):
+ *   dsize = (cvRound(w fx), cvRound(h fy));  per destination index v: f = (1 / inv_scale) (v + 0.5) - 0.5 in IEEE double
+ *   (softdouble), i = floor(f); inside the source: offset i, coefficients c1 = cvRound((f - i) 256), c0 = 256 - c1
+ *   (ufixedpoint16, 8 fraction bits); before the first / behind the last sample the edge value.  Horizontal pass into
+ *   16-bit fixed point (c0 p0 + c1 p1), vertical pass in 32-bit fixed point, rounded once: (v + 2^15) >> 16.
+ * Restated from the published source; like the other primitives here it could not be run against an OpenCV. */
+inline void resize_linear_exact_u8_factor(const Image& src, Image& dst, double fx, double fy) {
+  const int sw = src.w, sh = src.h;
+  const int dw = cv_round(sw * fx), dh = cv_round(sh * fy);
+  dst = Image(dw, dh);
+  struct Axis { std::vector<int> ofs; std::vector<unsigned> c0, c1; int lo, hi; };
+  auto coeffs = [](double inv_scale, int srcsize, int dstsize) {
+    Axis a;
+    a.ofs.assign(dstsize, 0); a.c0.assign(dstsize, 256u); a.c1.assign(dstsize, 0u);
+    a.lo = 0; a.hi = dstsize;
+    const double scale = 1.0 / inv_scale;
+    for (int v = 0; v < dstsize; ++v) {
+      const double f = scale * ((double)v + 0.5) - 0.5;
+      const int i = cv_floor(f);
+      if (i >= 0 && srcsize > 1) {
+        if (i < srcsize - 1) {
+          a.ofs[v] = i;
+          a.c1[v] = (unsigned)cv_round((f - (double)i) * 256.0);
+          a.c0[v] = 256u > a.c1[v] ? 256u - a.c1[v] : 0u;
+        } else {
+          a.ofs[v] = srcsize - 1;
+          a.hi = a.hi < v ? a.hi : v;
+        }
+      } else {
+        a.lo = a.lo > v + 1 ? a.lo : v + 1;
+      }
+    }
+    return a;
+  };
+  const Axis X = coeffs(fx, sw, dw), Y = coeffs(fy, sh, dh);
+  auto hline = [&](int sy, std::vector<unsigned>& D) {   // ufixedpoint16 values
+    const uint8_t* S = src.row(sy);
+    int i = 0;
+    for (; i < X.lo && i < dw; ++i) D[i] = (unsigned)S[0] << 8;
+    for (; i < X.hi; ++i) D[i] = X.c0[i] * S[X.ofs[i]] + X.c1[i] * S[X.ofs[i] + 1];
+    const unsigned last = (unsigned)S[X.ofs[dw - 1]] << 8;
+    for (; i < dw; ++i) D[i] = last;
+  };
+  std::vector<unsigned> r0(dw), r1(dw);
+  for (int dy = 0; dy < dh; ++dy) {
+    uint8_t* D = dst.row(dy);
+    if (dy < Y.lo || dy >= Y.hi) {   // the first / last source row alone
+      hline(dy < Y.lo ? 0 : Y.ofs[dh - 1], r0);
+      for (int x = 0; x < dw; ++x) D[x] = (uint8_t)((r0[x] + 128u) >> 8);
+      continue;
+    }
+    hline(Y.ofs[dy], r0);
+    hline(Y.ofs[dy] + 1, r1);
+    for (int x = 0; x < dw; ++x) {
+      const unsigned long long v = (unsigned long long)Y.c0[dy] * r0[x] + (unsigned long long)Y.c1[dy] * r1[x];
+      const unsigned long long q = (v + 32768ull) >> 16;
+      D[x] = (uint8_t)(q > 255ull ? 255ull : q);
+    }
+  }
+}
+
 /* cv::Sobel(src, dst, CV_16S, dx, dy, 3) with the default BORDER_REFLECT_101: exact integers. */
 inline void sobel3_s16(const Image& src, std::vector<short>& dxo, std::vector<short>& dyo) {
   const int w = src.w, h = src.h;

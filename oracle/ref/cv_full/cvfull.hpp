@@ -38,6 +38,12 @@
 #define CV_IN_OUT
 #define CV_PROP_RW
 #define CV_PROP
+#ifndef CV_OVERRIDE
+#define CV_OVERRIDE override
+#endif
+#ifndef CV_FINAL
+#define CV_FINAL final
+#endif
 #define CV_8U 0
 #define CV_8S 1
 #define CV_16U 2
@@ -122,6 +128,7 @@ struct Size {
   Size(int w, int h) : width(w), height(h) {}
   bool operator==(const Size& o) const { return width == o.width && height == o.height; }
   bool operator!=(const Size& o) const { return !(*this == o); }
+  bool empty() const { return width <= 0 || height <= 0; }
 };
 struct Rect {
   int x = 0, y = 0, width = 0, height = 0;
@@ -164,7 +171,7 @@ struct FileStorage {
 template <class T> inline FileStorage& operator<<(FileStorage& fs, const T&) { return fs; }
 enum { NORM_L1 = 2, NORM_L2 = 4, NORM_HAMMING = 6 };
 
-enum { INTER_NEAREST = 0, INTER_LINEAR = 1 };
+enum { INTER_NEAREST = 0, INTER_LINEAR = 1, INTER_LINEAR_EXACT = 5 };
 enum { BORDER_CONSTANT = 0, BORDER_REPLICATE = 1, BORDER_REFLECT = 2, BORDER_WRAP = 3, BORDER_REFLECT_101 = 4,
        BORDER_DEFAULT = 4, BORDER_ISOLATED = 16 };
 enum { THRESH_BINARY = 0, THRESH_TOZERO = 3 };
@@ -189,6 +196,10 @@ struct MatStep {
   size_t operator[](int i) const { return i == 0 ? p : 0; }
 };
 
+#ifdef PLVS_CVFULL_LSD
+template <class T, int N> struct Vec;
+struct _OutputArray;
+#endif
 class Mat {
  public:
   int rows = 0, cols = 0;
@@ -254,6 +265,16 @@ class Mat {
   template <class T> T& at(int r, int c) { return ptr<T>(r)[c]; }
   template <class T> const T& at(int r, int c) const { return ptr<T>(r)[c]; }
   template <class T> const T& at(const Point_<int>& p) const { return ptr<T>(p.y)[p.x]; }
+  template <class T> T& at(const Point_<int>& p) { return ptr<T>(p.y)[p.x]; }
+  Mat col(int c) const { return colRange(c, c + 1); }
+#ifdef PLVS_CVFULL_LSD
+  // (lsd_custom.cpp:452-455: Mat(lines).copyTo(_lines) — a matrix over a vector's elements, copied into the caller's vector)
+  explicit Mat(const std::vector<Vec<float, 4> >& v);
+  explicit Mat(const std::vector<double>& v);
+  void copyTo(const _OutputArray& o) const;
+  int checkVector(int) const { std::abort(); }                 // (drawSegments / compareSegments: never on a compared path)
+  void convertTo(Mat&, int) const { std::abort(); }
+#endif
   template <class T> T& at(int i) { return rows == 1 ? ptr<T>(0)[i] : ptr<T>(i / cols)[i % cols]; }
   template <class T> const T& at(int i) const { return rows == 1 ? ptr<T>(0)[i] : ptr<T>(i / cols)[i % cols]; }
   void push_back(const Mat& o) {   // append rows
@@ -306,16 +327,56 @@ class Mat {
   static Mat ones(int r, int c, int t) { Mat m(r, c, t); m = Scalar(1); return m; }
 };
 typedef const Mat& InputArray;
+#ifndef PLVS_CVFULL_LSD
 typedef Mat& OutputArray;
 typedef Mat& InputOutputArray;
-typedef const std::vector<Mat>& InputArrayOfArrays;
 inline Mat& noArray() { static Mat none; return none; }
+#else
+// The LSD sources (lsd_custom.cpp, LSDDetector_custom.cpp: oracle/_ref/liblsd_ref.so) hand a std::vector<Vec4f> to an
+// OutputArray and ask an optional one whether it is needed(): for that build the output face is a small proxy — a matrix, a
+// vector of segments or of doubles, or nothing — that still converts to the Mat& the image primitives below take.
+template <class T, int N>
+struct Vec {
+  T val[N];
+  Vec() { for (int i = 0; i < N; ++i) val[i] = T(0); }
+  Vec(T a, T b) { static_assert(N == 2, ""); val[0] = a; val[1] = b; }
+  Vec(T a, T b, T c, T d) { static_assert(N == 4, ""); val[0] = a; val[1] = b; val[2] = c; val[3] = d; }
+  T& operator[](int i) { return val[i]; }
+  const T& operator[](int i) const { return val[i]; }
+};
+typedef Vec<float, 4> Vec4f;
+typedef Vec<int, 4> Vec4i;
+struct _OutputArray {
+  Mat* m = nullptr;
+  std::vector<Vec4f>* v4 = nullptr;
+  std::vector<double>* vd = nullptr;
+  _OutputArray() {}
+  _OutputArray(Mat& x) : m(&x) {}
+  _OutputArray(std::vector<Vec4f>& x) : v4(&x) {}
+  _OutputArray(std::vector<double>& x) : vd(&x) {}
+  bool needed() const { return m != nullptr || v4 != nullptr || vd != nullptr; }
+  bool empty() const { return m == nullptr || m->empty(); }
+  operator Mat&() const { if (!m) std::abort(); return *m; }
+  Mat& getMatRef() const { if (!m) std::abort(); return *m; }
+  Mat getMat() const { return m ? *m : Mat(); }
+  int channels() const { return 1; }
+  Size size() const { return m ? m->size() : Size(); }
+  void create(int r, int c, int t) const { if (!m) std::abort(); m->create(r, c, t); }
+  void release() const { if (m) m->release(); }
+};
+typedef const _OutputArray& OutputArray;
+typedef const _OutputArray& InputOutputArray;
+inline const _OutputArray& noArray() { static _OutputArray none; return none; }
+#endif
+typedef const std::vector<Mat>& InputArrayOfArrays;
 
 template <class T> struct MatCommaInitializer_;
 template <class T>
 struct Mat_ : Mat {
   Mat_() { type_ = DataType<T>::type; }
   Mat_(int r, int c) : Mat(r, c, DataType<T>::type) {}
+  explicit Mat_(Size s) : Mat(s.height, s.width, DataType<T>::type) {}
+  static Mat_ zeros(Size s) { Mat_ m(s); for (int i = 0; i < s.height; ++i) std::memset(m.ptr(i), 0, m.step.p); return m; }
   Mat_(int r, int c, const T& v) : Mat(r, c, DataType<T>::type) {   // (rows x cols, every element v)
     for (int i = 0; i < r; ++i)
       for (int k = 0; k < c; ++k) this->template at<T>(i, k) = v;
@@ -395,6 +456,47 @@ class Algorithm {
   virtual void write(FileStorage&) const {}
 };
 
+#ifdef PLVS_CVFULL_LSD
+inline Mat::Mat(const std::vector<Vec<float, 4> >& v) {
+  create((int)v.size(), 4, CV_32F);
+  for (size_t i = 0; i < v.size(); ++i) std::memcpy(ptr((int)i), v[i].val, 4 * sizeof(float));
+}
+inline Mat::Mat(const std::vector<double>& v) {
+  create((int)v.size(), 1, CV_64F);
+  for (size_t i = 0; i < v.size(); ++i) at<double>((int)i, 0) = v[i];
+}
+inline void Mat::copyTo(const _OutputArray& o) const {
+  if (o.v4) {
+    o.v4->resize((size_t)rows);
+    for (int i = 0; i < rows; ++i) std::memcpy((*o.v4)[(size_t)i].val, ptr(i), 4 * sizeof(float));
+  } else if (o.vd) {
+    o.vd->resize((size_t)rows);
+    for (int i = 0; i < rows; ++i) (*o.vd)[(size_t)i] = at<double>(i, 0);
+  } else if (o.m) {
+    copyTo(*o.m);
+  }
+}
+// cv::LineIterator as LSDDetectorC uses it (LSDDetector_custom.cpp:256-257): only `count`, for end points inside the image
+// (checkLineExtremes has clamped them).  imgproc/drawing.cpp: the Point2f end points convert to Point by saturate_cast<int>
+// (cvRound); 8-connected: count = max(|dx|, |dy|) + 1.
+struct LineIterator {
+  int count;
+  LineIterator(const Mat& img, Point2f p1, Point2f p2) {
+    const int x1 = cvRound(p1.x), y1 = cvRound(p1.y), x2 = cvRound(p2.x), y2 = cvRound(p2.y);
+    if ((unsigned)x1 >= (unsigned)img.cols || (unsigned)x2 >= (unsigned)img.cols || (unsigned)y1 >= (unsigned)img.rows ||
+        (unsigned)y2 >= (unsigned)img.rows)
+      std::abort();   // (would need clipLine: cannot happen behind checkLineExtremes)
+    const int dx = x2 > x1 ? x2 - x1 : x1 - x2, dy = y2 > y1 ? y2 - y1 : y1 - y2;
+    count = (dx > dy ? dx : dy) + 1;
+  }
+};
+enum { COLOR_GRAY2BGR = 8 };
+inline void cvtColor(const _OutputArray&, const _OutputArray&, int) { std::abort(); }
+template <class P> inline void line(const _OutputArray&, P, P, const Scalar&, int = 1) { std::abort(); }
+inline void bitwise_xor(const Mat&, const Mat&, Mat&) { std::abort(); }
+inline int countNonZero(const Mat&) { std::abort(); }
+#endif
+
 // ---------------------------------------------------------------- image primitives (forwarded to oracle/cv_primitives.hpp)
 inline ocv::Image to_image(const Mat& m) {
   assert(m.depth() == CV_8U);
@@ -413,10 +515,16 @@ inline void FAST(InputArray image, std::vector<KeyPoint>& kps, int threshold, bo
   kps.clear();
   for (const ocv::FastKp& k : out) kps.push_back(KeyPoint(k.x, k.y, 7.f, -1, k.response));
 }
-inline void resize(InputArray src, OutputArray dst, Size dsize, double fx = 0, double fy = 0, int interpolation = INTER_LINEAR) {
-  assert(interpolation == INTER_LINEAR);
+inline void resize(InputArray src, Mat& dst, Size dsize, double fx = 0, double fy = 0, int interpolation = INTER_LINEAR) {
   const ocv::Image s = to_image(src);
   ocv::Image d;
+  if (interpolation == INTER_LINEAR_EXACT) {   // (the LSD detector's rescaling, lsd_custom.cpp:493)
+    assert(dsize.width == 0 && dsize.height == 0);
+    ocv::resize_linear_exact_u8_factor(s, d, fx, fy);
+    from_image(d, dst);
+    return;
+  }
+  assert(interpolation == INTER_LINEAR);
   if (dsize.width > 0 && dsize.height > 0) {
     d = ocv::Image(dsize.width, dsize.height);
     ocv::resize_linear_u8(s, d);
@@ -425,7 +533,7 @@ inline void resize(InputArray src, OutputArray dst, Size dsize, double fx = 0, d
   }
   from_image(d, dst);
 }
-inline void copyMakeBorder(InputArray src, OutputArray dst, int top, int bottom, int left, int right, int borderType) {
+inline void copyMakeBorder(InputArray src, Mat& dst, int top, int bottom, int left, int right, int borderType) {
   assert((borderType & ~BORDER_ISOLATED) == BORDER_REFLECT_101);   // (src may be a region of dst: work from a copy)
   const ocv::Image s = to_image(src);
   ocv::Image d(s.w + left + right, s.h + top + bottom);
@@ -436,14 +544,14 @@ inline void copyMakeBorder(InputArray src, OutputArray dst, int top, int bottom,
   }
   from_image(d, dst);
 }
-inline void GaussianBlur(InputArray src, OutputArray dst, Size ksize, double sigmaX, double sigmaY = 0, int borderType = BORDER_DEFAULT) {
+inline void GaussianBlur(InputArray src, Mat& dst, Size ksize, double sigmaX, double sigmaY = 0, int borderType = BORDER_DEFAULT) {
   assert(ksize.width == ksize.height && (sigmaY == 0 || sigmaY == sigmaX) && borderType == BORDER_REFLECT_101);
   const ocv::Image s = to_image(src);
   ocv::Image d;
   ocv::gaussian_blur_u8(s, d, ksize.width, sigmaX);
   from_image(d, dst);
 }
-inline void Sobel(InputArray src, OutputArray dst, int ddepth, int dx, int dy, int ksize = 3) {
+inline void Sobel(InputArray src, Mat& dst, int ddepth, int dx, int dy, int ksize = 3) {
   assert(ddepth == CV_16S && ksize == 3 && dx + dy == 1);
   std::vector<short> gx, gy;
   ocv::sobel3_s16(to_image(src), gx, gy);
@@ -458,14 +566,14 @@ inline Mat abs(const Mat& a) {
     for (int c = 0; c < a.cols; ++c) { const int v = a.at<short>(r, c); m.at<short>(r, c) = saturate_cast<short>(v < 0 ? -v : v); }
   return m;
 }
-inline void add(InputArray a, InputArray b, OutputArray dst) {
+inline void add(InputArray a, InputArray b, Mat& dst) {
   assert(a.type() == CV_16S && b.type() == CV_16S);
   Mat m(a.rows, a.cols, CV_16S);
   for (int r = 0; r < a.rows; ++r)
     for (int c = 0; c < a.cols; ++c) m.at<short>(r, c) = saturate_cast<short>((int)a.at<short>(r, c) + (int)b.at<short>(r, c));
   dst = m;
 }
-inline double threshold(InputArray src, OutputArray dst, double thresh, double /*maxval*/, int type) {
+inline double threshold(InputArray src, Mat& dst, double thresh, double /*maxval*/, int type) {
   assert(src.type() == CV_16S && type == THRESH_TOZERO);
   const int ith = cvFloor(thresh);
   Mat m(src.rows, src.cols, CV_16S);
@@ -474,7 +582,7 @@ inline double threshold(InputArray src, OutputArray dst, double thresh, double /
   dst = m;
   return thresh;
 }
-inline void compare(InputArray a, InputArray b, OutputArray dst, int op) {
+inline void compare(InputArray a, InputArray b, Mat& dst, int op) {
   assert(a.type() == CV_16S && b.type() == CV_16S && op == CMP_LT);
   Mat m(a.rows, a.cols, CV_8U);
   for (int r = 0; r < a.rows; ++r)
@@ -482,9 +590,9 @@ inline void compare(InputArray a, InputArray b, OutputArray dst, int op) {
   dst = m;
 }
 // named by paths the hot path never takes (colour input, the pyrDown pyramid, the sharpener)
-inline void cvtColor(InputArray, OutputArray, int) { std::abort(); }
-inline void pyrDown(InputArray, OutputArray, Size = Size()) { std::abort(); }
-inline void filter2D(InputArray, OutputArray, int, InputArray) { std::abort(); }
+inline void cvtColor(InputArray, Mat&, int) { std::abort(); }
+inline void pyrDown(InputArray, Mat&, Size = Size()) { std::abort(); }
+inline void filter2D(InputArray, Mat&, int, InputArray) { std::abort(); }
 
 struct KeyPointsFilter {   // features2d: keep the n strongest (and every tie with the n-th)
   static void retainBest(std::vector<KeyPoint>& kps, int n) {

@@ -28,6 +28,7 @@
 
 #include "common.hpp"
 #include "lines_host.hpp"
+#include "lsd_host.hpp"
 #include "orb_internal.hpp"
 
 using namespace plvs;
@@ -841,3 +842,5 @@ int plvs_hip_lines_num_in_octave(plvs_lines* o, int octave) {
 namespace plvs {
 plvs_orb* lines_shared_orb(const plvs_lines* o) { return o ? o->shared : nullptr; }
 }  // namespace plvs
+
+#include "lsd_lines.inc"
