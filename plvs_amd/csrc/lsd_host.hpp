@@ -18,13 +18,17 @@
 //           loop over the seeds, as in the reference (this file).
 // Every arithmetic step keeps the reference's operand types and order (float / double, which libm function): the parity
 // tests compare segments, KeyLines and descriptors bit for bit with the reference's own sources compiled here
-// (oracle/_ref/liblsd_ref.so) and with digests they made.
+// (tests/test_lsd.py) and with digests they made.
 #pragma once
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <cstdlib>
+#include <ctime>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace plvs {
@@ -136,6 +140,61 @@ inline ExactAxis exact_resize_axis(double inv_scale, int srcsize, int dstsize) {
 // ---------------------------------------------------------------- the detector on one level-line field
 struct Segment4 { float x1, y1, x2, y2; };
 
+// std::sort's result — libstdc++'s introsort — with the halves of its partitions on several threads.  The reference's
+// ordering is an UNSTABLE sort whose comparator sees part of the element only: the order of equal keys is whatever this
+// implementation of std::sort does, and the only way to have it is to run its steps.  They are run here through libstdc++'s
+// own building blocks: __introsort_loop is, per range, { partition around the median of three; recurse into the right part;
+// continue with the left }, the recursion touches nothing outside its range, so the right part can go to another thread —
+// same comparisons, same moves, same array afterwards; __final_insertion_sort then runs over the whole array as std::sort does.
+// (tests/test_lsd.py compares with the reference's own std::sort call, compiled by g++ from its sources.)
+#if defined(__GLIBCXX__)
+template <typename It, typename Comp>
+void introsort_loop_mt(It first, It last, long depth, Comp comp, int level, std::vector<std::thread>& pool, std::mutex& mu) {
+  while (last - first > int(std::_S_threshold)) {
+    if (depth == 0) {
+      std::__partial_sort(first, last, last, comp);
+      return;
+    }
+    --depth;
+    It cut = std::__unguarded_partition_pivot(first, last, comp);
+    if (level < 3 && last - cut > 8192) {
+      ++level;
+      std::lock_guard<std::mutex> g(mu);
+      pool.emplace_back([=, &pool, &mu] { introsort_loop_mt(cut, last, depth, comp, level, pool, mu); });
+    } else {
+      std::__introsort_loop(cut, last, depth, comp);
+    }
+    last = cut;
+  }
+}
+template <typename It, typename Cmp>
+void sort_as_std(It first, It last, Cmp cmp, bool threads) {
+  if (!threads || last - first < 65536) {
+    std::sort(first, last, cmp);
+    return;
+  }
+  auto comp = __gnu_cxx::__ops::__iter_comp_iter(cmp);
+  std::vector<std::thread> pool;
+  std::mutex mu;
+  pool.reserve(16);   // (at most 7 are made; no reallocation while a worker holds a reference)
+  introsort_loop_mt(first, last, std::__lg(last - first) * 2, comp, 0, pool, mu);
+  for (size_t i = 0;; ++i) {
+    std::thread t;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      if (i >= pool.size()) break;
+      t = std::move(pool[i]);
+    }
+    t.join();
+  }
+  std::__final_insertion_sort(first, last, comp);
+}
+#else
+template <typename It, typename Cmp>
+void sort_as_std(It first, It last, Cmp cmp, bool) { std::sort(first, last, cmp); }
+#endif
+
+
 class Level {
  public:
   // angles / modgrad: w x h doubles as lsd_ll_angle leaves them (angles = kNotDef where undefined; the last row and column
@@ -147,15 +206,36 @@ class Level {
     w_ = w;
     h_ = h;
     out.clear();
-    // ---- pseudo-ordering (lsd_custom.cpp:600-611): every pixel of the field but the last row / column, by bin, descending
+    // ---- pseudo-ordering (lsd_custom.cpp:600-611): every pixel of the field but the last row / column, by bin, descending.
+    // The reference sorts {x, y, bin} records with std::sort and a comparator that reads the bin only: UNSTABLE, the order of
+    // equal bins is whatever libstdc++'s introsort does on this input.  Which elements it compares and moves depends on the
+    // comparisons' outcomes alone, not on what else an element carries — so the same call on 4-byte keys (bin above the pixel
+    // index) yields the same permutation with a third of the memory traffic.
+    // Beside it, on helper threads: cosf / sinf of every defined pixel's angle, which region growing adds up point by point
+    // (the same libm calls on the same arguments, made ahead of the loop instead of inside it).
+    const double t_a = now_ms_();
+    const size_t npx = (size_t)w * h;
+    cs_.resize(2 * npx);
+    const int helpers = std::thread::hardware_concurrency() >= 4 ? 2 : 0;
+    std::thread th[2];
+    auto fill_cs = [this, angles, w](int y0, int y1) {
+      for (size_t at = (size_t)y0 * w, end = (size_t)y1 * w; at < end; ++at)
+        if (angles[at] != kNotDef) {
+          cs_[2 * at] = cosf(float(angles[at]));
+          cs_[2 * at + 1] = sinf(float(angles[at]));
+        }
+    };
+    for (int i = 0; i < helpers; ++i) th[i] = std::thread(fill_cs, (h * i) / helpers, (h * (i + 1)) / helpers);
     const double bin_coef = (max_grad > 0) ? double(o.n_bins - 1) / max_grad : 0;
-    order_.clear();
-    order_.reserve((size_t)(w - 1) * (size_t)(h - 1));
-    for (int y = 0; y < h - 1; ++y) {
-      const double* row = modgrad + (size_t)y * w;
-      for (int x = 0; x < w - 1; ++x) order_.push_back(Seed{x, y, int(row[x] * bin_coef)});
-    }
-    std::sort(order_.begin(), order_.end(), [](const Seed& a, const Seed& b) { return a.bin > b.bin; });   // (the reference's call: unstable)
+    const bool narrow = npx <= (size_t(1) << 22) && o.n_bins <= 1024;
+    const char* force = getenv("PLVS_LSD_SORT_THREADS");   // 0 / 1: never / always (tests); default: where there are cores to spare
+    const bool mt = force ? force[0] == '1' : std::thread::hardware_concurrency() >= 16;
+    if (narrow) order_seeds<uint32_t, 22>(modgrad, w, h, bin_coef, keys32_, mt);
+    else order_seeds<uint64_t, 32>(modgrad, w, h, bin_coef, keys64_, mt);
+    const size_t nseeds = narrow ? keys32_.size() : keys64_.size();
+    if (helpers == 0) fill_cs(0, h);
+    for (int i = 0; i < helpers; ++i) th[i].join();
+    ms_order = now_ms_() - t_a;
 
     const double prec = kPi * o.ang_th / 180;
     const double p = o.ang_th / 180;
@@ -163,12 +243,11 @@ class Level {
     const size_t min_reg_size = size_t(-log_nt_ / std::log10(p));
     used_.assign((size_t)w * h, 0);
     std::vector<Pt> reg;
-    for (size_t i = 0; i < order_.size(); ++i) {
-      const Seed& sd = order_[i];
-      const size_t at = (size_t)sd.y * w + sd.x;
+    for (size_t i = 0; i < nseeds; ++i) {
+      const size_t at = narrow ? size_t(keys32_[i] & ((1u << 22) - 1)) : size_t(keys64_[i] & 0xffffffffull);
       if (used_[at] != 0 || angles[at] == kNotDef) continue;
       double reg_angle;
-      grow(sd.x, sd.y, reg, reg_angle, prec);
+      grow(int(at % (size_t)w), int(at / (size_t)w), reg, reg_angle, prec);
       if (reg.size() < min_reg_size) continue;
       Rect rec;
       to_rect(reg, reg_angle, prec, p, rec);
@@ -190,10 +269,22 @@ class Level {
       }
       out.push_back(Segment4{float(rec.x1), float(rec.y1), float(rec.x2), float(rec.y2)});
     }
+    ms_regions = now_ms_() - t_a - ms_order;
   }
+  double ms_order = 0, ms_regions = 0;   // of the last detect: the ordering; the seed loop
 
  private:
-  struct Seed { int x, y, bin; };           // normPoint
+  // normPoint {p, norm} as a key: the bin above the pixel index y w + x
+  template <typename K, int kShift>
+  static void order_seeds(const double* modgrad, int w, int h, double bin_coef, std::vector<K>& keys, bool threads) {
+    keys.clear();
+    keys.reserve((size_t)(w - 1) * (size_t)(h - 1));
+    for (int y = 0; y < h - 1; ++y) {
+      const double* row = modgrad + (size_t)y * w;
+      for (int x = 0; x < w - 1; ++x) keys.push_back((K(int(row[x] * bin_coef)) << kShift) | K((size_t)y * w + x));
+    }
+    sort_as_std(keys.begin(), keys.end(), [](const K& a, const K& b) { return (a >> kShift) > (b >> kShift); }, threads);
+  }
   struct Pt { int x, y; double angle, modgrad; };   // RegionPoint (its `used` pointer is the index y w + x)
   struct Rect {
     double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p;
@@ -202,9 +293,16 @@ class Level {
   const double* mod_ = nullptr;
   int w_ = 0, h_ = 0;
   double log_nt_ = 0;
-  std::vector<Seed> order_;
+  std::vector<uint32_t> keys32_;
+  std::vector<uint64_t> keys64_;
+  std::vector<float> cs_;          // cosf, sinf of the angle of every defined pixel
   std::vector<uint8_t> used_;
 
+  static double now_ms_() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+  }
   static double dist2(double x1, double y1, double x2, double y2) { return (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1); }
   static double dist(double x1, double y1, double x2, double y2) { return std::sqrt(dist2(x1, y1, x2, y2)); }
   static double diff_signed(double a, double b) {
@@ -257,8 +355,8 @@ class Level {
             const double angle = ang_[at];
             used_[at] = 1;
             reg.push_back(Pt{xx, yy, angle, mod_[at]});
-            sumdx += cosf(float(angle));
-            sumdy += sinf(float(angle));
+            sumdx += cs_[2 * at];        // cosf(float(angle))
+            sumdy += cs_[2 * at + 1];    // sinf(float(angle))
             reg_angle = fast_atan2_deg(sumdy, sumdx) * kDegToRad;
           }
         }

@@ -4,6 +4,8 @@
 // reference's compiled LSD.  Test infrastructure only.
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -88,6 +90,7 @@ extern "C" int hostlsd_segments(const uint8_t* img, int w, int h, int stride, in
   Level level;
   std::vector<Segment4> segs;
   level.detect(ang.data(), mod.data(), fw, fh, max_grad, o, segs);
+  if (getenv("PLVS_LSD_PROFILE")) fprintf(stderr, "%d x %d: ordering %.2f ms, seed loop %.2f ms, %zu segments\n", fw, fh, level.ms_order, level.ms_regions, segs.size());
   if ((int)segs.size() <= cap && !segs.empty()) memcpy(out, segs.data(), segs.size() * sizeof(Segment4));
   return (int)segs.size();
 }

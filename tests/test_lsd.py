@@ -155,7 +155,11 @@ def test_host_stages_equal_the_compiled_reference_on_degenerate_images():
     assert len(ref.segments(flat, **S.DEFAULTS)) == 0 and len(ref.segments(step, **S.DEFAULTS)) >= 1
 
 
-def test_host_stages_reproduce_the_reference_made_digests():
+@pytest.mark.parametrize("sort_threads", ["0", "1"], ids=["one_thread_sort", "partitions_on_threads"])
+def test_host_stages_reproduce_the_reference_made_digests(sort_threads, monkeypatch):
+    """The ordering is std::sort's on one thread, or libstdc++'s own partition steps with the right halves on other threads
+    (lsd_host.hpp, sort_as_std): the same permutation either way, i.e. the same segments in the same order."""
+    monkeypatch.setenv("PLVS_LSD_SORT_THREADS", sort_threads)
     assert S.run(HostBackend(), parts=("segments",))["segments"] == _golden()["segments"]
 
 
