@@ -36,8 +36,10 @@ the library's own stream, HBM traffic from the committed PMC passes) and under
 "frontend" the per-frame front end — N = 1 only.
 """
 import argparse
+import ctypes
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -130,6 +132,9 @@ def compact_line(r):
         "frontend_orb_ms": g(r, "frontend", "orb_extract_ms"), "frontend_lines_ms": g(r, "frontend", "lines_extract_ms"),
         "frontend_cpu_ms_per_frame": g(r, "frontend", "cpu_baseline", "ms_per_frame"),
         "frontend_cpu_kind": g(r, "frontend", "cpu_baseline", "kind"),
+        "lsd_ms_per_frame": g(r, "frontend", "lsd_extract", "ms_per_frame"),
+        "lsd_cpu_ms_per_frame": g(r, "frontend", "lsd_extract", "cpu_baseline", "ms_per_frame"),
+        "lsd_parity_ok": g(r, "frontend", "lsd_extract", "parity_ok"),
         "sgm_ms_per_pair": g(r, "frontend", "dense_stereo_sgm", "ms_per_pair"),
         "sgm_parity": "unpinned (libsgm is CUDA-only: oracle/sgm.c is a restatement)" if g(r, "frontend", "dense_stereo_sgm") else None,
         "elas_parity_note": "bit-identical on zero-initialised heaps (oracle/ref/elas_zero_malloc.h)" if g(r, "kitti_shaped", "ms_per_keyframe") else None,
@@ -150,10 +155,11 @@ def compact_line(r):
               "voxblox_traffic"):
         if k in summary:
             roof[k] = summary[k]
-    for k in ("first_lap_ms", "updatemap_5_ms", "updatemap_1_ms", "frontend_ms_per_frame", "kitti_ms_per_keyframe", "parity_ok"):
+    for k in ("first_lap_ms", "updatemap_5_ms", "updatemap_1_ms", "frontend_ms_per_frame", "lsd_ms_per_frame", "kitti_ms_per_keyframe",
+              "parity_ok"):
         if k in summary:
             cfg[k] = summary[k]
-    for k in ("voxblox_cpu_value", "frontend_cpu_ms_per_frame"):
+    for k in ("voxblox_cpu_value", "frontend_cpu_ms_per_frame", "lsd_cpu_ms_per_frame"):
         if k in summary:
             cpu[k] = summary[k]
     out["config"], out["roofline"], out["cpu_baseline"] = cfg, roof, cpu
@@ -1161,6 +1167,52 @@ def main():
         result["frontend"]["dense_stereo_sgm"] = {
             "ms_per_pair": round(e0.elapsed_time(e1) / 20, 3), "size": "1240x376, 64 disparities, 8 paths",
             "valid_fraction": round(float((sd > 0).float().mean()), 3)}
+
+        # the line extractor with Line.LSD.on: 1 (row L9): plvs_hip_lsd_extract, 100 lines, three octaves, the options Tracking
+        # passes; beside it the reference's own sources (oracle/_ref/liblsd_ref.so) on one core where they have been built
+        try:
+            from plvs_amd.lines import LineExtractor as _LX, LSDOptions as _LO
+
+            class _Lsd(_LX):
+                skUseLsdExtractor = True
+            lsd_img = np.ascontiguousarray(golden("aloe_640x480.pgm"))
+            lsd_opts = dict(refine=1, scale=float(np.float32(1.2)), sigma_scale=0.6, quant=2.0, ang_th=22.5, log_eps=1.0,
+                            density_th=0.6, n_bins=1024)
+            lx_ = _Lsd(100, _LO(numOctaves=3, min_length=0.025, **lsd_opts))
+            lx_(lsd_img)
+            ts_ = []
+            for _ in range(10):
+                t0 = time.perf_counter()
+                lkl, ldesc = lx_(lsd_img)
+                ts_.append((time.perf_counter() - t0) * 1e3)
+            leg = {"what": "LineExtractor::operator() with skUseLsdExtractor on a 640x480 frame, host image in, KeyLines + LBD out",
+                   "ms_per_frame": round(sorted(ts_)[len(ts_) // 2], 2), "ms_min": round(min(ts_), 2), "lines": int(len(lkl)),
+                   "stage_ms": {k: round(v, 2) for k, v in lx_.stage_ms().items()}}
+            lx_.close()
+            lref = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "_ref", "liblsd_ref.so")
+            if os.path.exists(lref):
+                from tests.test_lsd import RefBackend as _LsdRef
+                rb_ = _LsdRef()
+                sys.stdout.flush()
+                with open(os.devnull, "w") as dn_:
+                    fd_ = os.dup(1)
+                    os.dup2(dn_.fileno(), 1)      # (the reference prints a line per call — the bench prints ONE line)
+                    try:
+                        t0 = time.perf_counter()
+                        for _ in range(3):
+                            rkl, rdesc = rb_.extract(lsd_img, 100, 3, lsd_opts, 0.025)
+                        ref_ms = (time.perf_counter() - t0) / 3 * 1e3
+                    finally:
+                        ctypes.CDLL(None).fflush(None)
+                        os.dup2(fd_, 1)
+                        os.close(fd_)
+                leg["cpu_baseline"] = {"ms_per_frame": round(ref_ms, 1), "cores": 1, "kind": "reference",
+                                       "sample": "the reference's lsd_custom.cpp / LSDDetector_custom.cpp / LineExtractor.cc "
+                                                 "(oracle/_ref/liblsd_ref.so, g++ -O2; image primitives are the stand-in's), 3 calls"}
+                leg["parity_ok"] = bool(len(rkl) == len(lkl) and rkl.tobytes() == lkl.tobytes() and rdesc.tobytes() == ldesc.tobytes())
+            result["frontend"]["lsd_extract"] = leg
+        except Exception as e:
+            result["frontend"]["lsd_extract"] = {"error": repr(e)}
 
         # dense disparity by libelas: the stages on the device — the candidate loop of computeSupportMatches and the two
         # methods the reference's GPU build overrides — on the arguments the reference's own pipeline produces for that pair

@@ -323,9 +323,11 @@ int plvs_hip_lsd_destroy(plvs_lsd* h);
  * reference's order; *n = their number (nothing is written if n > cap).  options = NULL: the defaults. */
 int plvs_hip_lsd_segments(plvs_lsd* h, const uint8_t* image, int w, int hh, int stride, const plvs_lsd_options* options,
                           float* segments, int cap, int* n);
-/* LSDDetectorC::detect(image, keylines, numOctaves, scale, opts): the detector's own Gaussian pyramid
- * (5 x 5, sigma 1, then INTER_LINEAR by 1 / scale), LSD on every level, KeyLines of the segments longer than
- * min_length x the image diagonal (opts.min_length). */
+/* LSDDetectorC::detect(image, keylines, scale, numOctaves, opts): the detector's own pyramid, LSD on every level, KeyLines
+ * of the segments longer than min_length x the image diagonal (opts.min_length).  The pyramid as the reference's loop
+ * leaves it (LSDDetector_custom.cpp:56-83: it blurs in place an image it has already stored): every level but the last
+ * is detected on its 5 x 5, sigma 1 blurred image, level k + 1 = INTER_LINEAR resize by 1.f / scale of that blurred
+ * level, the last level is not blurred. */
 int plvs_hip_lsd_detect(plvs_lsd* h, const uint8_t* image, int w, int hh, int stride, int num_octaves, float scale,
                         const plvs_lsd_options* options, double min_length, plvs_keyline* keylines, int cap, int* n);
 /* LineExtractor::operator() with the LSD detector, options as Tracking fills them (src/Tracking.cc:1458-1485): num_octaves =

@@ -115,19 +115,26 @@ class ORBextractor {
 };
 
 // ------------------------------------------------------------------------------------ lines
-struct LSDOptions {   // the fields of LSDDetectorC::LSDOptions the EDLines path reads (LineExtractor.cc:104-145)
+struct LSDOptions {   // LSDDetectorC::LSDOptions (descriptor_custom.hpp:928-957); the EDLines path reads the first four
   int numOctaves = 3;
   float scale = 1.2f;
   double min_length = 0.02;
   double lineFitErrThreshold = 1.6;
+  int refine = 2;       // cv::LSD_REFINE_ADV — Tracking passes Line.LSD.refine (1), .logEps (1.0), .densityTh (0.6), Tracking.cc:1476-1482
+  double sigma_scale = 0.6, quant = 2.0, ang_th = 22.5, log_eps = 0.0, density_th = 0.7;
+  int n_bins = 1024;
+  plvs_lsd_options c() const { return plvs_lsd_options{refine, (double)scale, sigma_scale, quant, ang_th, log_eps, density_th, n_bins}; }
 };
 
 class LineExtractor {
  public:
-  LineExtractor(int numLinefeatures, const LSDOptions& opts = LSDOptions()) {
+  // LineExtractor::skUseLsdExtractor (Line.LSD.on): read when an extractor is constructed, as the reference's mLsd is made
+  static bool& UseLsdExtractor() { static bool on = false; return on; }
+  LineExtractor(int numLinefeatures, const LSDOptions& opts = LSDOptions()) : n_(numLinefeatures), opts_(opts) {
     check(plvs_hip_lines_create(numLinefeatures, opts.numOctaves, opts.scale, opts.min_length, opts.lineFitErrThreshold, &h_));
+    if (UseLsdExtractor()) check(plvs_hip_lsd_create(&lsd_));
   }
-  ~LineExtractor() { plvs_hip_lines_destroy(h_); }
+  ~LineExtractor() { plvs_hip_lines_destroy(h_); plvs_hip_lsd_destroy(lsd_); }
   LineExtractor(const LineExtractor&) = delete;
   LineExtractor& operator=(const LineExtractor&) = delete;
 
@@ -135,20 +142,36 @@ class LineExtractor {
   // (after "no lines!") when nothing is found, LineExtractor.cc:269-273.
   void operator()(const Image8U& image, std::vector<KeyLine>& keylines, std::vector<uint8_t>& descriptors) {
     int cap = 4096, n = 0;
-    keylines.resize((size_t)cap);
-    descriptors.resize((size_t)cap * 32);
-    check(plvs_hip_lines_extract(h_, image.data, image.cols, image.rows, (int)image.step, keylines.data(),
-                                 descriptors.data(), cap, &n));
+    for (;;) {
+      keylines.resize((size_t)cap);
+      descriptors.resize((size_t)cap * 32);
+      if (lsd_) {
+        const plvs_lsd_options o = opts_.c();
+        check(plvs_hip_lsd_extract(lsd_, image.data, image.cols, image.rows, (int)image.step, n_, opts_.numOctaves, &o,
+                                   opts_.min_length, keylines.data(), descriptors.data(), cap, &n));
+      } else {
+        check(plvs_hip_lines_extract(h_, image.data, image.cols, image.rows, (int)image.step, keylines.data(),
+                                     descriptors.data(), cap, &n));
+      }
+      if (n <= cap) break;
+      cap = n;   // (nfeatures = 0 keeps every line)
+    }
     keylines.resize((size_t)n);
     descriptors.resize((size_t)n * 32);
   }
   // SetGaussianPyramid(mpORBextractor->mvImagePyramid, levels, scale) of Frame::PrecomputeGaussianPyramid: the
   // pyramid stays on the device, so the extractor itself is handed over (nullptr = own pyramid again).
-  void SetGaussianPyramid(ORBextractor* orb) { check(plvs_hip_lines_set_gaussian_pyramid(h_, orb ? orb->handle() : nullptr)); }
+  void SetGaussianPyramid(ORBextractor* orb) {
+    if (lsd_) throw std::invalid_argument("LineExtractor: Line.pyramidPrecomputation with Line.LSD.on is not on the accelerated path");
+    check(plvs_hip_lines_set_gaussian_pyramid(h_, orb ? orb->handle() : nullptr));
+  }
   plvs_lines* handle() { return h_; }
 
  private:
   plvs_lines* h_ = nullptr;
+  plvs_lsd* lsd_ = nullptr;
+  int n_;
+  LSDOptions opts_;
 };
 
 // ------------------------------------------------------------------------------------ matching

@@ -74,6 +74,19 @@ int main(int argc, char** argv) {
               (unsigned long long)fnv(ldl.data(), ldl.size()));
   dump("lines_keys", ll.data(), ll.size() * sizeof(KeyLine));
   dump("lines_desc", ldl.data(), ldl.size());
+  {   // the same extractor with Line.LSD.on: 1, options as Tracking fills them
+    LineExtractor::UseLsdExtractor() = true;
+    LSDOptions lo;
+    lo.refine = 1; lo.log_eps = 1.0; lo.density_th = 0.6; lo.min_length = 0.025;
+    LineExtractor lsd(100, lo);
+    LineExtractor::UseLsdExtractor() = false;
+    std::vector<KeyLine> kl;
+    std::vector<uint8_t> kd;
+    lsd(il, kl, kd);
+    std::printf("lsd_lines %d\n", (int)kl.size());
+    dump("lsd_keys", kl.data(), kl.size() * sizeof(KeyLine));
+    dump("lsd_desc", kd.data(), kd.size());
+  }
   BinaryDescriptorMatcher bdm;
   std::vector<std::vector<DMatch>> matches;
   bdm.knnMatch(ldl.data(), (int)ll.size(), ldr.data(), (int)lr.size(), matches);

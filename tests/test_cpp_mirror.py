@@ -60,6 +60,14 @@ def test_cpp_mirror_matches_python_mirror(tmp_path):
     lr, ldr = lx2(right)
     assert int(lines_out["lines"][0]) == len(ll)
     assert load("lines_keys", np.uint8).tobytes() == ll.tobytes() and load("lines_desc", np.uint8).tobytes() == ldl.tobytes()
+    from plvs_amd.lines import LSDOptions
+
+    class LsdExtractor(LineExtractor):
+        skUseLsdExtractor = True
+    lsd_kl, lsd_kd = LsdExtractor(100, LSDOptions(numOctaves=3, scale=float(np.float32(1.2)), min_length=0.025, refine=1, log_eps=1.0,
+                                          density_th=0.6))(left)
+    assert int(lines_out["lsd_lines"][0]) == len(lsd_kl) > 50
+    assert load("lsd_keys", np.uint8).tobytes() == lsd_kl.tobytes() and load("lsd_desc", np.uint8).tobytes() == lsd_kd.tobytes()
     matches = []
     BinaryDescriptorMatcher().knnMatch(ldl, ldr, matches, k=2)
     flat = np.array([[m.queryIdx, m.trainIdx, int(m.distance)] for row in matches for m in row], np.int32).reshape(-1)
