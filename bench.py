@@ -173,6 +173,11 @@ def compact_line(r):
 
 def main():
     args = parse()
+    # ONE line on stdout: the compiled reference sources behind the cpu_baseline legs print (open_chisel a line per garbage
+    # collection, line_descriptor a line per pyramid) — everything written to file descriptor 1 before the result goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1193,19 +1198,10 @@ def main():
             if os.path.exists(lref):
                 from tests.test_lsd import RefBackend as _LsdRef
                 rb_ = _LsdRef()
-                sys.stdout.flush()
-                with open(os.devnull, "w") as dn_:
-                    fd_ = os.dup(1)
-                    os.dup2(dn_.fileno(), 1)      # (the reference prints a line per call — the bench prints ONE line)
-                    try:
-                        t0 = time.perf_counter()
-                        for _ in range(3):
-                            rkl, rdesc = rb_.extract(lsd_img, 100, 3, lsd_opts, 0.025)
-                        ref_ms = (time.perf_counter() - t0) / 3 * 1e3
-                    finally:
-                        ctypes.CDLL(None).fflush(None)
-                        os.dup2(fd_, 1)
-                        os.close(fd_)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    rkl, rdesc = rb_.extract(lsd_img, 100, 3, lsd_opts, 0.025)
+                ref_ms = (time.perf_counter() - t0) / 3 * 1e3
                 leg["cpu_baseline"] = {"ms_per_frame": round(ref_ms, 1), "cores": 1, "kind": "reference",
                                        "sample": "the reference's lsd_custom.cpp / LSDDetector_custom.cpp / LineExtractor.cc "
                                                  "(oracle/_ref/liblsd_ref.so, g++ -O2; image primitives are the stand-in's), 3 calls"}
@@ -1417,6 +1413,9 @@ def main():
                 json.dump(result, f, indent=1)
         except OSError:
             pass
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(real_stdout, 1)
         print(json.dumps(result if args.verbose_line else compact_line(result)), flush=True)
     tsdf.close()
     if multi:

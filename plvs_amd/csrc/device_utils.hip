@@ -396,6 +396,141 @@ hipError_t radix_pass_lds(const uint32_t* ki, const TV* vi, uint32_t* ko, TV* vo
   return hipGetLastError();
 }
 
+// ---- one launch per pass (round 5, late): the chained scan inside the scatter
+// A pass of radix_pass_lds is five launches — tile histograms, a three-kernel scan of 256 x tiles counters, the scatter — and on
+// the arrays the TSDF pipelines sort (1-20 M pairs) the first four cost as much as the scatter itself (13 + 17 of 58 us per pass
+// at 2.5 M pairs, plus four launch gaps on a chain of dependent kernels).  Here the digit totals of EVERY pass come from one
+// read of the keys up front (radix_digit_totals: a permutation does not change them), and a pass is one kernel: a tile takes
+// a ticket, ranks its keys as radix_scatter_lds does, publishes its 256 digit counts as "aggregate" words, looks back over
+// the tiles before it — thread d for digit d, adding aggregates until it meets a tile that has published its inclusive
+// prefix — publishes its own prefix, and scatters.  A status word carries its flag and its count together (2 + 30 bits:
+// one atomic word, no fence between a flag and a payload); tickets are taken in launch order, so every tile a block waits for
+// is already running.  Same stable order as the three-kernel pass (tests: plvs_hip_selftest_radix_sort against a host sort).
+constexpr int kOsMaxPasses = 4;
+constexpr uint32_t kOsAggregate = 1u << 30, kOsPrefix = 2u << 30, kOsCount = (1u << 30) - 1u;
+
+__global__ __launch_bounds__(kThreads) void radix_digit_totals(const uint32_t* __restrict__ keys, size_t n, int bit_lo, int passes,
+                                                               size_t nb, uint32_t* __restrict__ totals /* [passes][256], zeroed */) {
+  __shared__ uint32_t h[kOsMaxPasses][256];
+  for (int p = 0; p < passes; ++p) h[p][threadIdx.x] = 0;
+  __syncthreads();
+  for (size_t b = blockIdx.x; b < nb; b += gridDim.x) {
+    const size_t tile = b * kSortTile;
+#pragma unroll 4
+    for (int it = 0; it < kSortItems; ++it) {
+      const size_t i = tile + (size_t)it * kThreads + threadIdx.x;
+      if (i < n) {
+        const uint32_t k = keys[i] >> bit_lo;
+        for (int p = 0; p < passes; ++p) atomicAdd(&h[p][(k >> (8 * p)) & 255u], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int p = 0; p < passes; ++p) {
+    const uint32_t c = h[p][threadIdx.x];
+    if (c) atomicAdd(&totals[p * 256 + threadIdx.x], c);
+  }
+}
+
+template <typename TV>
+__global__ __launch_bounds__(kThreads) void radix_onesweep(
+    const uint32_t* __restrict__ keys_in, const TV* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+    TV* __restrict__ vals_out, size_t n, int shift, const uint32_t* __restrict__ totals /* [256] of this pass */,
+    uint32_t* __restrict__ status /* [tiles][256], zeroed */, uint32_t* __restrict__ ticket /* zeroed */) {
+  constexpr int kRadix = 256;
+  __shared__ uint32_t wave_hist[kWaves][kRadix];
+  __shared__ uint32_t gbase[kRadix], lbase[kRadix];
+  __shared__ uint32_t s_key[kSortTile];
+  __shared__ TV s_val[kSortTile];
+  __shared__ uint32_t s_tile;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int d = threadIdx.x;   // kThreads == kRadix
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) wave_hist[w][d] = 0;
+  __syncthreads();
+  const uint32_t b = s_tile;
+  const size_t tile0 = (size_t)b * kSortTile;
+  const size_t span = tile0 + (size_t)wid * kWaveSpan;
+  const uint32_t ntile = (uint32_t)(n - tile0 < (size_t)kSortTile ? n - tile0 : (size_t)kSortTile);
+  uint32_t k[kSortItems], rank[kSortItems];
+  TV v[kSortItems];
+  volatile uint32_t* my_hist = wave_hist[wid];
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int it = 0; it < kSortItems; ++it) {
+    const size_t i = span + (size_t)it * 64 + lane;
+    const bool valid = i < n;
+    k[it] = valid ? keys_in[i] : 0u;
+    v[it] = valid ? vals_in[i] : TV(0);
+    const uint32_t dg = (k[it] >> shift) & 255u;
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const unsigned long long bal = __ballot((dg >> bit) & 1u);
+      peers &= ((dg >> bit) & 1u) ? bal : ~bal;
+    }
+    const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
+    const uint32_t cnt = (uint32_t)__popcll(peers);
+    uint32_t base = 0;
+    if (valid) base = my_hist[dg];
+    rank[it] = base + before;
+    if (valid && before == 0) my_hist[dg] = base + cnt;
+  }
+  __syncthreads();
+  {   // digit d: the tile's count -> aggregate out, look back, prefix out; the digits' places inside the tile
+    uint32_t run = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+      const uint32_t c = wave_hist[w][d];
+      wave_hist[w][d] = run;
+      run += c;
+    }
+    uint32_t* const mine = status + (size_t)b * kRadix + d;
+    __hip_atomic_store(mine, kOsAggregate | run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t* scratch = s_key;   // (not yet in use)
+    uint32_t tot, all;
+    const uint32_t ex = block_exclusive_scan(run, &tot, scratch);
+    lbase[d] = ex;
+    const uint32_t dbase = block_exclusive_scan(totals[d], &all, scratch);   // keys with a smaller digit, whole array
+    uint32_t sum = 0;
+    for (uint32_t p = b; p-- > 0;) {
+      const uint32_t* at = status + (size_t)p * kRadix + d;
+      uint32_t st;
+      do {
+        st = __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } while ((st >> 30) == 0u);
+      sum += st & kOsCount;
+      if (st & kOsPrefix) break;
+    }
+    __hip_atomic_store(mine, kOsPrefix | (sum + run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    gbase[d] = dbase + sum;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < kSortItems; ++it) {
+    const size_t i = span + (size_t)it * 64 + lane;
+    if (i < n) {
+      const uint32_t dg = (k[it] >> shift) & 255u;
+      const uint32_t p = lbase[dg] + wave_hist[wid][dg] + rank[it];
+      s_key[p] = k[it];
+      s_val[p] = v[it];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < kSortItems; ++it) {
+    const uint32_t i = (uint32_t)(it * kThreads + threadIdx.x);
+    if (i < ntile) {
+      const uint32_t key = s_key[i];
+      const uint32_t dg = (key >> shift) & 255u;
+      const size_t pos = (size_t)gbase[dg] + (i - lbase[dg]);
+      keys_out[pos] = key;
+      vals_out[pos] = s_val[i];
+    }
+  }
+}
+
 }  // namespace
 
 size_t scan_scratch_words(size_t n) { return (n + kScanTile - 1) / kScanTile + 1; }
@@ -421,7 +556,8 @@ hipError_t exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, uint3
 size_t radix_scratch_words(size_t n) {
   const size_t nb = (n + kSortTile - 1) / kSortTile;
   const size_t radix = (size_t)1 << kMaxRadixBits;
-  return radix * nb + scan_scratch_words(radix * nb);
+  // (the one-launch passes: at most 4 x (256 totals + 256 x tiles status words) + tickets — less than this)
+  return radix * nb + scan_scratch_words(radix * nb) + 2048;
 }
 
 template <typename TV>
@@ -442,6 +578,32 @@ static hipError_t radix_sort_impl(uint32_t* keys0, TV* vals0, uint32_t* keys1, T
   // (developer switch, round 5: PLVS_SORT_WIDE_MAX = n up to which 2 passes of <= 11 bits are taken instead of 3 of 8)
   static const size_t wide_max = (size_t)env_int("PLVS_SORT_WIDE_MAX", 0, 0, 1 << 30);
   const bool wide = n < wide_max && total > 16 && total <= 2 * kMaxRadixBits;
+  // (developer switch: PLVS_SORT_ONESWEEP_MIN = n from which a pass is ONE launch, the scan chained inside the scatter; 0 = never)
+  // Measured (MI355X): 2.5 M pairs, three passes: 144 us against 175 us + twelve launch gaps (the chisel colour chain: the step
+  // 1.05 -> 1.04 ms); 18 M pairs (voxblox's visits): the look-back costs what the scan kernels did and the totals come on top
+  // (1.67 -> 1.70 ms per step) — hence the upper bound.
+  static const size_t onesweep_min = (size_t)env_int("PLVS_SORT_ONESWEEP_MIN", 1 << 18, 0, 1 << 30);
+  static const size_t onesweep_max = (size_t)env_int("PLVS_SORT_ONESWEEP_MAX", 1 << 23, 0, 1 << 30);
+  const int os_passes = (total + 7) / 8;
+  if (onesweep_min != 0 && n >= onesweep_min && n < onesweep_max && os_passes <= kOsMaxPasses && !wide) {
+    // scratch: [passes][256] digit totals | [passes] tickets | [passes][tiles][256] status words, zeroed together
+    uint32_t* totals = scratch;
+    uint32_t* tickets = totals + (size_t)os_passes * 256;
+    uint32_t* status = tickets + kOsMaxPasses;
+    const size_t words = (size_t)os_passes * 256 + kOsMaxPasses + (size_t)os_passes * nb * 256;
+    hipError_t e = hipMemsetAsync(scratch, 0, words * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(radix_digit_totals, dim3((unsigned)std::min<size_t>(nb, 1024)), dim3(kThreads), 0, stream, ki, n, bit_lo,
+                       os_passes, nb, totals);
+    for (int p = 0; p < os_passes; ++p) {
+      hipLaunchKernelGGL((radix_onesweep<TV>), dim3((unsigned)nb), dim3(kThreads), 0, stream, ki, vi, ko, vo, n, bit_lo + 8 * p,
+                         totals + (size_t)p * 256, status + (size_t)p * nb * 256, tickets + p);
+      uint32_t* t = ki; ki = ko; ko = t;
+      TV* tv = vi; vi = vo; vo = tv;
+      *result_in_second = !*result_in_second;
+    }
+    return hipGetLastError();
+  }
   if (n >= kLdsScatterMin && !wide) {   // long arrays: passes over 8-bit digits, the tiles reordered in LDS
     for (int shift = bit_lo; shift < bit_hi; shift += 8) {
       hipError_t e = radix_pass_lds<TV>(ki, vi, ko, vo, n, shift, nb, hist, scan_scratch, stream);

@@ -1205,6 +1205,10 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
       // frames of the saturated room); tiles of walls 3-5 m away hold 800-2000 and would nearly all overflow it.  The
       // counters of the call before decide (walk_small): the 2048-entry kernel counts the tiles a 1024-entry table would
       // not have held, the 1024-entry kernel's deferred list says when it stops paying.
+      {   // developer switch: PLVS_WALK_SMALL = 0 / 1 forces the first pass's table
+        static const int force = plvs::env_int("PLVS_WALK_SMALL", -1, -1, 1);
+        if (force >= 0) h->walk_small = force != 0;
+      }
       h->walk_small_used = h->walk_small;
       if (h->walk_small) PLVS_WALK_FAST(kFastEntriesSmall, ntiles, nullptr, nullptr, list_a, &h->d_wctr->ndeferred);
       else PLVS_WALK_FAST(kFastEntries, ntiles, nullptr, nullptr, list_a, &h->d_wctr->ndeferred);

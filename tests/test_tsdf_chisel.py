@@ -373,13 +373,15 @@ def test_hip_radix_sort_is_a_stable_sort_on_both_scatter_paths(wide):
     """device_utils.hip's sort orders the visit records, the runs and the deform records of both back ends: stable (a
     voxel's items keep their order), pairs intact, on either side of the 2^20-pair switch between the wide-digit
     scatter and the 8-bit LDS-reordering one, for sizes that are not multiples of the tile, few and many distinct
-    keys, a bit range that does not start at 0, 32- and 64-bit values."""
+    keys, a bit range that does not start at 0, 32- and 64-bit values; from 2^18 pairs on a pass is one launch with the scan
+    chained inside the scatter (radix_onesweep)."""
     import ctypes
     from plvs_amd import _lib
     f = _lib.lib.plvs_hip_selftest_radix_sort
     f.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p]
     cases = [(1, 0, 8), (4097, 0, 12), (100003, 0, 20), ((1 << 20) - 5, 0, 22), (1 << 20, 0, 22), ((1 << 20) + 4097, 0, 26),
-             (3333333, 0, 22), (2500000, 0, 5), (1300001, 3, 19), (5000011, 0, 32), (777777, 5, 26)]
+             (3333333, 0, 22), (2500000, 0, 5), (1300001, 3, 19), (5000011, 0, 32), (777777, 5, 26),
+             (1 << 18, 0, 22), ((1 << 18) - 1, 0, 22), ((1 << 18) + 1, 0, 24), (300000, 2, 18), (20000003, 0, 24)]
     for n, lo, hi in cases:
         bad = (ctypes.c_uint32 * 2)(9, 9)
         _lib.check(f(n, lo, hi, wide, 12345 + n, bad))
