@@ -817,6 +817,7 @@ struct plvs_tsdf_voxblox {
   uint32_t ap_next = 1;                // (the reference's sets start at offset 0 and every scan begins with offset + 1)
   bool ap_ready = false;
   int fast_rounds = 0;                 // rounds of the last fast call (diagnostic)
+  bool fast_sequential = false;        //   ... and whether it was finished on one thread (vbf_sequential)
   // queued key-frame clouds (plvs_hip_tsdf_voxblox_queue / _flush): uploaded, not yet integrated
   DevBuf<float> q_xyz, q_Twc_dev;   // (the poses get a buffer of their own: a host-flavour integrate that finds a queue has
                                     //  staged ITS pose in st_Twc already)
@@ -1311,6 +1312,7 @@ static int vb_fast_plan(plvs_tsdf_voxblox* h, const float* d_xyz, int n, int ncl
   hipLaunchKernelGGL(vbf_write_back, dim3(nb), dim3(256), 0, s, sk, sv, (uint32_t)n, h->ff_shash.p, h->ap_start.p);
   PLVS_KERNEL_CHECK();
   h->fast_rounds = 0;
+  h->fast_sequential = false;
   PLVS_HIP_TRY(hipMemsetAsync(h->ff_flags.p, 0, 2 * sizeof(uint32_t), s));
   const uint32_t *qk = nullptr, *qv = nullptr;
   uint32_t M = 0;
@@ -1321,7 +1323,16 @@ static int vb_fast_plan(plvs_tsdf_voxblox* h, const float* d_xyz, int n, int ncl
     PLVS_KERNEL_CHECK();
     PLVS_HIP_TRY(hipStreamSynchronize(s));
     if (h->fast_rounds > 0 && h->h_ff[1] == 0) break;   // (the sorted queries of the last round are the scans' queries)
-    PLVS_REQUIRE(h->fast_rounds < 100000, "fast integrator: the rounds do not settle");
+    {   // a cloud whose rounds do not settle (one round per ray at worst): finish on one thread, in the reference's own order
+      static const int max_rounds = plvs::env_int("PLVS_VB_FAST_MAX_ROUNDS", 512, 0, 100000);
+      if (h->fast_rounds >= max_rounds) {
+        hipLaunchKernelGGL(vbf_sequential, dim3(1), dim3(1), 0, s, h->P, d_xyz, n, h->offsets.p, nclouds, d_poses, first_offset,
+                           h->ff_Q.p, h->ff_full.p, h->ap_seen.p, h->ff_L.p);
+        PLVS_KERNEL_CHECK();
+        h->fast_sequential = true;
+        return PLVS_OK;   // (the observed set already holds what the queries leave)
+      }
+    }
     M = h->h_ff[0];
     ++h->fast_rounds;
     PLVS_HIP_TRY(hipMemsetAsync(h->ff_flags.p + 1, 0, sizeof(uint32_t), s));

@@ -171,6 +171,44 @@ __global__ __launch_bounds__(256) void vbf_trim(int npoints, const uint32_t* __r
   L[i] = upd;
 }
 
+// The rounds above need as many iterations as the longest chain of rays that decide each other's stops: 4-40 on depth-camera
+// clouds, but up to one per ray on an adversarial one.  Past a bound the plan is finished the way the reference makes it: ONE
+// thread walks the rays that start (Q > 0: the start set was settled before the rounds, in one sort) in sequence order and asks
+// the observed set voxel by voxel, leaving each answer's hash in the array at once.  Slow (two dependent memory round trips per
+// query) but finite, and by construction the reference's schedule.
+__global__ void vbf_sequential(Params P, const float* __restrict__ xyz, int npoints, const int32_t* __restrict__ offsets,
+                               int nclouds, const PoseRt* __restrict__ Twc, uint32_t first_offset, const uint32_t* __restrict__ Q,
+                               const uint32_t* __restrict__ full, unsigned long long* __restrict__ table, uint32_t* __restrict__ L) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  for (int i = 0; i < npoints; ++i) {
+    if (Q[i] == 0u) {
+      L[i] = 0u;
+      continue;
+    }
+    int cloud = 0;
+    const int p = point_of_seq(offsets, nclouds, i, &cloud);
+    const PoseRt pose = load_pose(Twc, cloud);
+    Ray ray;
+    make_ray(P, pose, xyz[3 * (size_t)p], xyz[3 * (size_t)p + 1], xyz[3 * (size_t)p + 2], &ray, true);
+    const uint32_t len = full[i];
+    uint32_t run = 0, upd = len;
+    for (uint32_t s = 0; s < len; ++s) {
+      int g[3];
+      ray_step(&ray, g);
+      const unsigned long long h = any_index_hash(g[0], g[1], g[2]);
+      const uint32_t word = ((uint32_t)h & kApproxMask) + first_offset + (uint32_t)cloud;
+      const unsigned long long before = table[word];
+      table[word] = h;
+      run = before == h ? run + 1u : 0u;
+      if (run > 2u) {
+        upd = s;
+        break;
+      }
+    }
+    L[i] = upd;
+  }
+}
+
 __global__ void vbf_publish(const uint32_t* __restrict__ total, const uint32_t* __restrict__ changed, uint32_t* __restrict__ host2) {
   host2[0] = *total;
   host2[1] = *changed;

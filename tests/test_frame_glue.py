@@ -142,3 +142,45 @@ def test_oracle_glue_equals_the_reference_source(oracle):
 @pytest.mark.gpu
 def test_hip_glue_equals_the_oracle(oracle):
     _check(_Side(oracle.lib, "oracle_frame_"), _Hip(), 7)
+
+
+def _distort(xy_un, K, D):
+    """The forward Brown model in float64 (OpenCV's projectPoints with R = I, t = 0): undistorted pixels -> distorted pixels."""
+    fx, fy, cx, cy = [float(v) for v in K]
+    k1, k2, p1, p2 = [float(v) for v in D[:4]]
+    k3 = float(D[4]) if len(D) > 4 else 0.0
+    x, y = (xy_un[:, 0] - cx) / fx, (xy_un[:, 1] - cy) / fy
+    r2 = x * x + y * y
+    rad = 1 + k1 * r2 + k2 * r2 * r2 + k3 * r2 ** 3
+    xd = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    return np.stack([xd * fx + cx, yd * fy + cy], -1)
+
+
+def _round_trip(side):
+    """An analytic check that rests on nothing restated: distort known pixels with the forward model, undistort
+    them — the fixed-point iteration of cv::undistortPoints (five rounds) must come back to where they started.  How close
+    depends on the distortion at the pixel (five rounds are OpenCV's count, not enough to converge in the corners of a
+    strongly distorted image): TUM1 under 0.05 px everywhere, EuRoC (k1 = -0.28) under 0.05 px for 9 pixels in 10 and
+    0.23 px in the corners, exact without distortion."""
+    rng = np.random.default_rng(4)
+    for K, D, tol, tol90 in ((TUM1_K, TUM1_D, 0.05, 0.05), (CALIBS[2][0], CALIBS[2][1], 0.3, 0.05),
+                             (TUM1_K, np.zeros(5, np.float32), 2e-4, 2e-4)):
+        un = np.stack([rng.uniform(20, 620, 500), rng.uniform(20, 460, 500)], -1)
+        d = _distort(un, K, D)
+        k = np.zeros(len(d), KP_DTYPE)
+        k["x"], k["y"] = d[:, 0], d[:, 1]
+        got = side.undistort_keypoints(k, K, D)
+        # (the input itself is rounded to float32 pixels: 3e-5 px at 640)
+        err = np.hypot(got["x"].astype(np.float64) - un[:, 0], got["y"].astype(np.float64) - un[:, 1])
+        assert err.max() < tol and np.quantile(err, 0.9) < tol90, (float(err.max()), float(np.quantile(err, 0.9)), K, D)
+        assert np.array_equal(got["octave"], k["octave"]) and np.array_equal(got["angle"], k["angle"])
+
+
+def test_oracle_undistort_inverts_the_forward_model(oracle):
+    _round_trip(_Side(oracle.lib, "oracle_frame_"))
+
+
+@pytest.mark.gpu
+def test_hip_undistort_inverts_the_forward_model():
+    _round_trip(_Hip())

@@ -171,3 +171,42 @@ def test_hip_fast_on_a_sharded_map_is_the_union_of_its_shards(oracle):
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), bid
     for t in shards + [whole]:
         t.close()
+
+
+_SEQUENTIAL_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from tests import oracle_lib
+from tests.plvs_amd_synth import make_keyframes
+from tests.test_tsdf_voxblox_fast import maps_equal, rgba_of
+from plvs_amd.tsdf import TsdfVoxblox
+oracle = oracle_lib.load()
+kfs = make_keyframes(3, seed=5)
+ref, hip = oracle.voxblox(0.05, carving=True), TsdfVoxblox(0.05, use_carving=True, max_blocks=8192)
+for k in kfs:
+    xyz, col = np.ascontiguousarray(k["xyz"][::6]), np.ascontiguousarray(rgba_of(k)[::6])
+    ref.integrate_fast(xyz, col, k["Twc"], approx_sets=True)
+    hip.integrate_fast(xyz, col, k["Twc"])
+    assert hip.last_stats()["visits"] == ref.last_visits() > 1000
+    assert hip.fast_rounds() <= int(sys.argv[2])
+print("blocks", len(maps_equal(ref, hip)))
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_rounds", [0, 2], ids=["one_thread_from_the_start", "after_two_rounds"])
+def test_hip_fast_finishes_on_one_thread_when_the_rounds_do_not_settle(max_rounds, tmp_path):
+    """the rounds of vb_fast_plan can take one iteration per ray on an adversarial cloud; past
+    PLVS_VB_FAST_MAX_ROUNDS (512) the plan is finished by vbf_sequential — one device thread, the reference's own order.
+    Forced here to 0 and 2 rounds (the switch is read once per process: a child process): the maps equal the oracle's."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "seq.py"
+    script.write_text(_SEQUENTIAL_SCRIPT)
+    env = dict(os.environ, PLVS_VB_FAST_MAX_ROUNDS=str(max_rounds))
+    r = subprocess.run([sys.executable, str(script), root, str(max_rounds)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert int(r.stdout.strip().split()[-1]) > 10
