@@ -157,13 +157,17 @@ void introsort_loop_mt(It first, It last, long depth, Comp comp, int level, std:
     }
     --depth;
     It cut = std::__unguarded_partition_pivot(first, last, comp);
+    bool handed_over = false;
     if (level < 3 && last - cut > 8192) {
       ++level;
       std::lock_guard<std::mutex> g(mu);
-      pool.emplace_back([=, &pool, &mu] { introsort_loop_mt(cut, last, depth, comp, level, pool, mu); });
-    } else {
-      std::__introsort_loop(cut, last, depth, comp);
+      try {
+        pool.emplace_back([=, &pool, &mu] { introsort_loop_mt(cut, last, depth, comp, level, pool, mu); });
+        handed_over = true;
+      } catch (...) {   // (no thread to be had: the right part is sorted here, as std::sort would)
+      }
     }
+    if (!handed_over) std::__introsort_loop(cut, last, depth, comp);
     last = cut;
   }
 }
@@ -225,7 +229,14 @@ class Level {
           cs_[2 * at + 1] = sinf(float(angles[at]));
         }
     };
-    for (int i = 0; i < helpers; ++i) th[i] = std::thread(fill_cs, (h * i) / helpers, (h * (i + 1)) / helpers);
+    bool inline_part[2] = {false, false};
+    for (int i = 0; i < helpers; ++i) {
+      try {
+        th[i] = std::thread(fill_cs, (h * i) / helpers, (h * (i + 1)) / helpers);
+      } catch (...) {   // (no thread to be had: this part after the ordering, on this one)
+        inline_part[i] = true;
+      }
+    }
     const double bin_coef = (max_grad > 0) ? double(o.n_bins - 1) / max_grad : 0;
     const bool narrow = npx <= (size_t(1) << 22) && o.n_bins <= 1024;
     const char* force = getenv("PLVS_LSD_SORT_THREADS");   // 0 / 1: never / always (tests); default: where there are cores to spare
@@ -234,7 +245,10 @@ class Level {
     else order_seeds<uint64_t, 32>(modgrad, w, h, bin_coef, keys64_, mt);
     const size_t nseeds = narrow ? keys32_.size() : keys64_.size();
     if (helpers == 0) fill_cs(0, h);
-    for (int i = 0; i < helpers; ++i) th[i].join();
+    for (int i = 0; i < helpers; ++i) {
+      if (inline_part[i]) fill_cs((h * i) / helpers, (h * (i + 1)) / helpers);
+      else th[i].join();
+    }
     ms_order = now_ms_() - t_a;
 
     const double prec = kPi * o.ang_th / 180;
