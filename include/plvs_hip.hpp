@@ -162,7 +162,7 @@ class LineExtractor {
   // SetGaussianPyramid(mpORBextractor->mvImagePyramid, levels, scale) of Frame::PrecomputeGaussianPyramid: the
   // pyramid stays on the device, so the extractor itself is handed over (nullptr = own pyramid again).
   void SetGaussianPyramid(ORBextractor* orb) {
-    if (lsd_) throw std::invalid_argument("LineExtractor: Line.pyramidPrecomputation with Line.LSD.on is not on the accelerated path");
+    if (lsd_) throw std::invalid_argument("LineExtractor: Line.pyramidPrecomputation with Line.LSD.on is undefined behaviour in the reference (DESIGN.md 6), not reproduced");
     check(plvs_hip_lines_set_gaussian_pyramid(h_, orb ? orb->handle() : nullptr));
   }
   plvs_lines* handle() { return h_; }

@@ -224,7 +224,11 @@ class LineExtractor:
         """LineExtractor::SetGaussianPyramid as Frame::PrecomputeGaussianPyramid uses it (src/Frame.cc:848):
         the octaves become the levels of `orb_extractor`'s device pyramid; None restores the own chain."""
         if self._lsd is not None:
-            raise NotImplementedError("Line.pyramidPrecomputation together with Line.LSD.on is not on the accelerated path")
+            # (the reference has no defined result to reproduce here: with the LSD detector BinaryDescriptor::compute takes
+            # its sizes from `images_sizes`, which setGaussianPyramid only appends to behind the constructor's zero entries
+            # — computeLBD then reads pdxImg[-1]; DESIGN.md §6 "The LSD detector")
+            raise NotImplementedError("Line.pyramidPrecomputation together with Line.LSD.on: undefined behaviour in the "
+                                      "reference, not reproduced")
         self._shared = orb_extractor                       # keep the handle alive
         L.plvs_hip_lines_set_gaussian_pyramid.argtypes = [_vp, _vp]
         _lib.check(L.plvs_hip_lines_set_gaussian_pyramid(self._h, orb_extractor._h if orb_extractor else None))
