@@ -17,8 +17,8 @@ from collections import defaultdict
 
 PIPELINE = ("pose_prep", "walk_prologue", "walk_fast", "walk_tiles", "seg_pass", "seg_scan", "apply_chunks", "compact_runs", "sort_runs_small", "fold_colours_masks",
             "ray_count", "scan_tile_sums", "scan_sums", "scan_tile_apply", "mark_tiles", "ray_tiles",
-            "radix_hist", "radix_scatter", "radix_scatter_lds", "voxel_heads", "fold_colours", "reduce_sums", "run_counts", "mark_blocks",
-            "gather_runs", "chain_runs")
+            "radix_hist", "radix_scatter", "radix_scatter_lds", "radix_onesweep", "radix_digit_totals", "scan_single", "voxel_heads",
+            "fold_colours", "reduce_sums", "run_counts", "mark_blocks", "gather_runs", "chain_runs")
 
 
 def short(n):
@@ -37,7 +37,8 @@ def load(path):
 
 
 VOXBLOX = ("vb_pose_prep", "vb_ray_pass", "vb_expand", "vb_chain_chunks", "vb_publish_counters", "vb_merge_keys", "vb_merge_bundles",
-           "scan_single", "scan_tile_sums", "scan_sums", "scan_tile_apply", "radix_hist", "radix_scatter", "radix_scatter_lds")
+           "scan_single", "scan_tile_sums", "scan_sums", "scan_tile_apply", "radix_hist", "radix_scatter", "radix_scatter_lds",
+           "radix_onesweep", "radix_digit_totals")
 
 
 def main(argv):
