@@ -183,13 +183,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
+    # PLVS_BENCH_REHEARSAL=1 (scripts/gpu_check.sh, stage `multi` on a one-GPU box): every rank on device 0, the exchanges over
+    # gloo (RCCL refuses two ranks on one device) — the N > 1 code path end to end with two real processes; never a measurement
+    rehearsal = os.environ.get("PLVS_BENCH_REHEARSAL", "0") == "1"
+    device_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(device_index)
     multi = world > 1 or args.sharded_at_one
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+        if rehearsal:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
 
     from plvs_amd import _lib
     from plvs_amd.synth_scene import LOOP, make_keyframes, make_stream_keyframes

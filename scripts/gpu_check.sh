@@ -42,7 +42,13 @@ if [[ "$STAGES" == *multi* ]]; then
     ( HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
         --master-port 29534 bench.py --gpus 2 --steps 5 --warmup 3 --backend voxblox --no-cpu-baseline --no-frontend 2>&1 | tail -3 ) > "$O/bench_2gpu_voxblox.log" 2>&1
   else
-    echo "one device: the 2-GPU RCCL rehearsal is skipped" > "$O/bench_2gpu.log"
+    # one device: the same two-rank launch with both ranks on device 0 and the exchanges over gloo (bench.py, PLVS_BENCH_REHEARSAL:
+    # RCCL refuses two ranks on one device) — the N = 2 code path end to end with two real processes; the times mean nothing
+    for B in chisel voxblox; do
+      ( PLVS_BENCH_REHEARSAL=1 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+          --master-addr 127.0.0.1 --master-port 29535 bench.py --gpus 2 --steps 4 --warmup 2 --backend $B --no-cpu-baseline --no-frontend \
+          2>/dev/null | tail -1 ) > "$O/bench_2ranks_one_device_$B.log" 2>&1
+    done
   fi
   echo "multi done $(date +%T)" >> "$O/stages.log"
 fi
