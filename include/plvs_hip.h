@@ -337,6 +337,10 @@ int plvs_hip_lsd_detect(plvs_lsd* h, const uint8_t* image, int w, int hh, int st
 int plvs_hip_lsd_extract(plvs_lsd* h, const uint8_t* image, int w, int hh, int stride, int nfeatures, int num_octaves,
                          const plvs_lsd_options* options, double min_length, plvs_keyline* keylines, uint8_t* desc, int cap,
                          int* n);
+/* ... with the image in device memory (stride in bytes; the work that produced it must be complete), as plvs_hip_lines_extract_dev */
+int plvs_hip_lsd_extract_dev(plvs_lsd* h, const uint8_t* d_image, int w, int hh, int stride, int nfeatures, int num_octaves,
+                             const plvs_lsd_options* options, double min_length, plvs_keyline* keylines, uint8_t* desc, int cap,
+                             int* n);
 /* ms of the last call: [0] device maps + copies, [1] host ordering + region loop (summed over levels), [2] selection + LBD */
 int plvs_hip_lsd_last_stage_ms(plvs_lsd* h, double* ms, int cap);
 

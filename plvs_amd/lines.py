@@ -44,6 +44,7 @@ L.plvs_hip_lsd_default_options.argtypes = [_vp]
 L.plvs_hip_lsd_segments.argtypes = [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]
 L.plvs_hip_lsd_detect.argtypes = [_vp, _vp, _i, _i, _i, _i, _f, _vp, _d, _vp, _i, _vp]
 L.plvs_hip_lsd_extract.argtypes = [_vp, _vp, _i, _i, _i, _i, _i, _vp, _d, _vp, _vp, _i, _vp]
+L.plvs_hip_lsd_extract_dev.argtypes = [_vp, _vp, _i, _i, _i, _i, _i, _vp, _d, _vp, _vp, _i, _vp]
 L.plvs_hip_lsd_last_stage_ms.argtypes = [_vp, _vp, _i]
 
 LSD_REFINE_NONE, LSD_REFINE_STD, LSD_REFINE_ADV = 0, 1, 2
@@ -181,15 +182,19 @@ class LineExtractor:
             pass
 
     def _call_lsd(self, image):
-        if isinstance(image, torch.Tensor):
-            image = image.cpu().numpy()
-        image = _gray(image)
+        on_device = isinstance(image, torch.Tensor)
+        if on_device:
+            assert image.is_cuda and image.dtype == torch.uint8 and image.dim() == 2 and image.stride(1) == 1
+            torch.cuda.current_stream().synchronize()
+            f, ptr, stride = L.plvs_hip_lsd_extract_dev, _vp(image.data_ptr()), image.stride(0)
+        else:
+            image = _gray(image)
+            f, ptr, stride = L.plvs_hip_lsd_extract, _lib.np_ptr(image), image.shape[1]
         h, w = image.shape
         n, c = _i(), self.opts._c()
         while True:
-            _lib.check(L.plvs_hip_lsd_extract(self._lsd._h, _lib.np_ptr(image), w, h, w, self._n, self.opts.numOctaves,
-                                              ctypes.byref(c), float(self.opts.min_length), _lib.np_ptr(self._kl),
-                                              _lib.np_ptr(self._desc), self._cap, ctypes.byref(n)))
+            _lib.check(f(self._lsd._h, ptr, w, h, stride, self._n, self.opts.numOctaves, ctypes.byref(c),
+                         float(self.opts.min_length), _lib.np_ptr(self._kl), _lib.np_ptr(self._desc), self._cap, ctypes.byref(n)))
             if n.value <= self._cap:
                 break
             self._cap = n.value

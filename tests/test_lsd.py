@@ -218,6 +218,20 @@ def test_hip_lsd_edge_cases():
     b = det.detect(S.image_of(S.SEGMENT_CASES[1]))
     assert a.tobytes() == b.tobytes() and len(a) > 100
     det.close()
+    # the image in device memory, rows further apart than they need to be: the same lines
+    import torch
+
+    class LsdDev(LineExtractor):
+        skUseLsdExtractor = True
+    c0 = S.EXTRACT_CASES[0]
+    exd = LsdDev(c0["nfeatures"], LSDOptions(numOctaves=c0["num_octaves"], min_length=c0["min_length"], **S.options(c0)))
+    img = S.image_of(c0)
+    wide = torch.zeros((img.shape[0], img.shape[1] + 64), dtype=torch.uint8, device="cuda")
+    wide[:, :img.shape[1]] = torch.from_numpy(img).cuda()
+    kh, dh = exd(img)
+    kd, dd = exd(wide[:, :img.shape[1]])
+    assert len(kh) == 100 and kh.tobytes() == kd.tobytes() and dh.tobytes() == dd.tobytes()
+    exd.close()
     # the extractor with LSD on a flat image: no lines, empty outputs
     class Lsd(LineExtractor):
         skUseLsdExtractor = True
