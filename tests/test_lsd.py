@@ -245,3 +245,23 @@ def test_hip_lsd_edge_cases():
     with pytest.raises(_lib.PlvsHipError):
         d2.detect(S.image_of(S.SEGMENT_CASES[0]), 1.2, 9, LSDOptions(numOctaves=9))     # more octaves than the library holds
     d2.close()
+
+
+@pytest.mark.gpu
+@needs_ref
+def test_hip_equals_the_compiled_reference_on_degenerate_images():
+    """The images of the CPU test of the host stages, through the device: flat, noise, one edge, a diagonal, 9 x 11, and an
+    odd size under three option sets."""
+    rng = np.random.default_rng(3)
+    ref, hip = RefBackend(), HipBackend()
+    flat = np.full((120, 160), 90, np.uint8)
+    noise = rng.integers(0, 256, (97, 131), dtype=np.uint8)
+    step = np.zeros((64, 200), np.uint8)
+    step[:, 100:] = 255
+    diag = (np.add.outer(np.arange(150), np.arange(150)) > 150).astype(np.uint8) * 200
+    small = rng.integers(0, 256, (9, 11), dtype=np.uint8)
+    odd = np.ascontiguousarray(rng.integers(0, 256, (333, 517), dtype=np.uint8))
+    for img in (flat, noise, step, diag, small, odd):
+        for o in (S.DEFAULTS, dict(S.DEFAULTS, **S.TRACKING), dict(S.DEFAULTS, scale=1.0, refine=0)):
+            want, got = ref.segments(img, **o), hip.segments(img, **o)
+            assert len(want) == len(got) and want.tobytes() == got.tobytes(), (img.shape, o)
