@@ -81,6 +81,7 @@ constexpr uint32_t kErrScratch = 8u;            // record / segment / run buffer
 #endif
 #ifdef PLVS_WALK_PROF
 __device__ unsigned long long g_walk_prof[16];
+__device__ unsigned long long g_apply_items[8192][4];   // per item of the LAST apply launch: cycles, segments << 32 | records of thread 0's group
 #define WALK_PROF_BEGIN()                                         \
   long long prof_t = (long long)clock64();                        \
   unsigned long long prof_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}
@@ -1820,9 +1821,9 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
   __shared__ unsigned long long a_w[kSlabVox];
   __shared__ uint32_t a_last[kSlabVox], a_cnt[kSlabVox];
   __shared__ uint32_t is_last;
+  constexpr int kPieceBatch = 2 * kApplyThreads;      // segments listed at a time
+  __shared__ uint32_t p_lo[kPieceBatch], p_pre[kPieceBatch], p_wave[kApplyThreads / 64];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int grp = tid >> 4, gl = tid & 15;
-  constexpr int kGroups = kApplyThreads / 16, kFly = 4;
   if (ctr->err) return;   // the walk ran out of scratch: the host grows it and repeats the call, the map stays as it was
   const uint32_t nchunks = ctr->num_updated, nitems = ctr->num_parts * kSlabs;
   uint32_t voxels = 0, longest = 0;
@@ -1860,6 +1861,8 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
 #ifdef PLVS_WALK_PROF
     const long long ap_item0 = (long long)clock64();
     ap_t = ap_item0;
+    uint32_t ap_recs = 0, ap_rounds = 0;
+    unsigned long long ap_load = 0, ap_add = 0;
 #endif
     const uint32_t pi = item / kSlabs, slab = item % kSlabs;
     // the chunk of part pi: the last a with part_off[a] <= pi — a 64-way search by every wave (two dependent loads for
@@ -1883,66 +1886,77 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
     APPLY_PROF(0);   // item set-up
     const uint32_t s0 = active_off[a] + (pi - part_off[a]) * part_segs;
     const uint32_t s1 = nparts > 1 ? min(active_off[a + 1], s0 + part_segs) : active_off[a + 1];
-    // (the descriptors of the NEXT round are asked for before this round's records: a round is two dependent global
-    // loads — descriptor, then records — and a slab's item runs a dozen rounds)
-    uint4 nd0[kFly], nd1[kFly];
-    auto fetch_desc = [&](uint32_t sb) {
+    // The slab's records of every segment form one PIECE (contiguous; 0 to 512 records — a tile on a wall puts hundreds of
+    // voxels into one slab of one chunk, a tile that grazes the chunk a handful).  Round 5, late: the pieces are listed in LDS
+    // (first record, running total) and the workgroup then runs over ALL their records as one flat range, four loads per
+    // thread in flight, every lane busy whatever the sizes of the pieces.  (Before: sixteen lanes per segment, four segments
+    // per group in flight; a wave iterated as long as the LONGEST of its sixteen pieces, two dependent loads per trip — the
+    // item of a hot chunk, 1 000-2 000 segments, took 0.3 ms, 95 % of it in that loop: the whole length of the kernel.)
+    for (uint32_t sb0 = s0; sb0 < s1; sb0 += (uint32_t)kPieceBatch) {
+      const uint32_t nb = min((uint32_t)kPieceBatch, s1 - sb0);
+      uint32_t len[kPieceBatch / kApplyThreads], lo_p[kPieceBatch / kApplyThreads], mine = 0;
 #pragma unroll
-      for (int j = 0; j < kFly; ++j)
-        if (sb + j < s1) {
-          nd0[j] = sorted_seg[2 * (size_t)(sb + j)];
-          nd1[j] = sorted_seg[2 * (size_t)(sb + j) + 1];
+      for (int k = 0; k < kPieceBatch / kApplyThreads; ++k) {
+        const uint32_t i = (uint32_t)tid * (kPieceBatch / kApplyThreads) + k;   // (consecutive pieces per thread: one scan)
+        len[k] = lo_p[k] = 0;
+        if (i < nb) {
+          const uint4 d0 = sorted_seg[2 * (size_t)(sb0 + i)], d1 = sorted_seg[2 * (size_t)(sb0 + i) + 1];
+          const uint32_t w0 = slab < 2 ? d1.x : slab < 4 ? d1.y : slab < 6 ? d1.z : d1.w;
+          const uint32_t w1 = slab + 1 < 2 ? d1.x : slab + 1 < 4 ? d1.y : slab + 1 < 6 ? d1.z : d1.w;
+          const uint32_t o = (w0 >> ((slab & 1) * 16)) & 0xFFFFu;
+          const uint32_t e = slab + 1 < kSlabs ? (w1 >> (((slab + 1) & 1) * 16)) & 0xFFFFu : d0.z;
+          lo_p[k] = d0.y + o;
+          len[k] = e - o;
         }
-    };
-    fetch_desc(s0 + (uint32_t)grp * kFly);
-    for (uint32_t sb = s0 + (uint32_t)grp * kFly; sb < s1; sb += kGroups * kFly) {
-      uint32_t lo_r[kFly], hi_r[kFly];
-#pragma unroll
-      for (int j = 0; j < kFly; ++j) {
-        lo_r[j] = hi_r[j] = 0;
-        if (sb + j < s1) {
-          const uint4 d0 = nd0[j], d1 = nd1[j];
-          const uint32_t w[4] = {d1.x, d1.y, d1.z, d1.w};
-          const uint32_t o = (w[slab >> 1] >> ((slab & 1) * 16)) & 0xFFFFu;
-          const uint32_t e = slab + 1 < kSlabs ? (w[(slab + 1) >> 1] >> (((slab + 1) & 1) * 16)) & 0xFFFFu : d0.z;
-          lo_r[j] = d0.y + o;
-          hi_r[j] = d0.y + e;
-        }
+        mine += len[k];
       }
-      Rec q[kFly];
+      // exclusive prefix of the pieces' lengths over the workgroup
+      uint32_t inc = mine;
 #pragma unroll
-      for (int j = 0; j < kFly; ++j)
-        if (lo_r[j] + gl < hi_r[j]) q[j] = load(lo_r[j] + gl);
-      fetch_desc(sb + kGroups * kFly);
-#pragma unroll
-      for (int j = 0; j < kFly; ++j)
-        if (lo_r[j] + gl < hi_r[j]) add(q[j]);
-      // the rest of long slab ranges (a tile of far points puts hundreds of voxels into one slab of one chunk): the
-      // four segments side by side, two rounds of sixteen records each — eight independent loads per lane in flight
-      // (one segment after the other, one load at a time, this loop was most of the stage on the office stream)
-      uint32_t nr[kFly];
-      bool more = false;
-#pragma unroll
-      for (int j = 0; j < kFly; ++j) {
-        nr[j] = lo_r[j] + 16u + gl;
-        more = more || nr[j] < hi_r[j];
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)inc, off);
+        if (lane >= off) inc += up;
       }
-      while (more) {
-        Rec qa[kFly], qb[kFly];
+      if (lane == 63) p_wave[tid >> 6] = inc;
+      __syncthreads();
+      uint32_t wbase = 0, total = 0;
 #pragma unroll
-        for (int j = 0; j < kFly; ++j) {
-          if (nr[j] < hi_r[j]) qa[j] = load(nr[j]);
-          if (nr[j] + 16u < hi_r[j]) qb[j] = load(nr[j] + 16u);
-        }
-        more = false;
-#pragma unroll
-        for (int j = 0; j < kFly; ++j) {
-          if (nr[j] < hi_r[j]) add(qa[j]);
-          if (nr[j] + 16u < hi_r[j]) add(qb[j]);
-          nr[j] += 32u;
-          more = more || nr[j] < hi_r[j];
-        }
+      for (int w = 0; w < kApplyThreads / 64; ++w) {
+        if (w < (tid >> 6)) wbase += p_wave[w];
+        total += p_wave[w];
       }
+      uint32_t run = wbase + inc - mine;
+#pragma unroll
+      for (int k = 0; k < kPieceBatch / kApplyThreads; ++k) {
+        const uint32_t i = (uint32_t)tid * (kPieceBatch / kApplyThreads) + k;
+        p_lo[i] = lo_p[k];
+        p_pre[i] = run;       // (pieces behind nb: length 0, prefix = total)
+        run += len[k];
+      }
+      __syncthreads();
+      auto record_of = [&](uint32_t f) -> uint32_t {   // flat index -> record: the last piece with p_pre <= f
+        uint32_t lo = 0, hi = nb;                       // (empty pieces share a prefix with their successor: the LAST one wins,
+        while (hi - lo > 1) {                           //  and it is the non-empty one or followed only by empty ones... see below)
+          const uint32_t mid = (lo + hi) >> 1;
+          if (p_pre[mid] <= f) lo = mid; else hi = mid;
+        }
+        return p_lo[lo] + (f - p_pre[lo]);
+      };
+      // (the search returns the LAST piece whose prefix is <= f: of a run of pieces with the same prefix — all but the last
+      // empty — that is the non-empty one, the only one f can lie in)
+      constexpr int kFlat = 4;
+      for (uint32_t f0 = (uint32_t)tid; f0 < total; f0 += (uint32_t)(kFlat * kApplyThreads)) {
+        Rec q[kFlat];
+#pragma unroll
+        for (int j = 0; j < kFlat; ++j) {
+          const uint32_t f = f0 + (uint32_t)(j * kApplyThreads);
+          if (f < total) q[j] = load(record_of(f));
+        }
+#pragma unroll
+        for (int j = 0; j < kFlat; ++j)
+          if (f0 + (uint32_t)(j * kApplyThreads) < total) add(q[j]);
+      }
+      __syncthreads();   // (p_lo / p_pre are rewritten by the next batch)
     }
     APPLY_PROF(1);   // thread 0's share of the segments
     __syncthreads();
@@ -2036,6 +2050,12 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
     __syncthreads();
     APPLY_PROF(4);   // the voxel updates
 #ifdef PLVS_WALK_PROF
+    if (threadIdx.x == 0 && item < 8192u) {
+      g_apply_items[item][0] = (unsigned long long)((long long)clock64() - ap_item0);
+      g_apply_items[item][1] = ((unsigned long long)(s1 - s0) << 32) | (unsigned long long)ap_recs;
+      g_apply_items[item][2] = ap_load;
+      g_apply_items[item][3] = (ap_add << 8) | (unsigned long long)min(ap_rounds, 255u);
+    }
     ++ap_items;
     ap_max = max(ap_max, ((unsigned long long)((long long)clock64() - ap_item0) << 24) | ((unsigned long long)min(s1 - s0, 0xFFFFFu) << 4) |
                              (unsigned long long)min(nparts, 15u));   // cycles | segments of the item | parts of its chunk
