@@ -409,8 +409,15 @@ hipError_t radix_pass_lds(const uint32_t* ki, const TV* vi, uint32_t* ko, TV* vo
 constexpr int kOsMaxPasses = 4;
 constexpr uint32_t kOsAggregate = 1u << 30, kOsPrefix = 2u << 30, kOsCount = (1u << 30) - 1u;
 
+// (n_dev, here and in radix_onesweep: the array holds min(n, *n_dev) pairs — a sort launched on a BOUND of their number, before
+// the host knows it; the tiles behind them leave at once)
 __global__ __launch_bounds__(kThreads) void radix_digit_totals(const uint32_t* __restrict__ keys, size_t n, int bit_lo, int passes,
-                                                               size_t nb, uint32_t* __restrict__ totals /* [passes][256], zeroed */) {
+                                                               size_t nb, uint32_t* __restrict__ totals /* [passes][256], zeroed */,
+                                                               const uint32_t* __restrict__ n_dev) {
+  if (n_dev != nullptr) {
+    n = n < (size_t)*n_dev ? n : (size_t)*n_dev;
+    nb = (n + kSortTile - 1) / kSortTile;
+  }
   __shared__ uint32_t h[kOsMaxPasses][256];
   for (int p = 0; p < passes; ++p) h[p][threadIdx.x] = 0;
   __syncthreads();
@@ -436,8 +443,10 @@ template <typename TV>
 __global__ __launch_bounds__(kThreads) void radix_onesweep(
     const uint32_t* __restrict__ keys_in, const TV* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     TV* __restrict__ vals_out, size_t n, int shift, const uint32_t* __restrict__ totals /* [256] of this pass */,
-    uint32_t* __restrict__ status /* [tiles][256], zeroed */, uint32_t* __restrict__ ticket /* zeroed */) {
+    uint32_t* __restrict__ status /* [tiles][256], zeroed */, uint32_t* __restrict__ ticket /* zeroed */,
+    const uint32_t* __restrict__ n_dev) {
   constexpr int kRadix = 256;
+  if (n_dev != nullptr) n = n < (size_t)*n_dev ? n : (size_t)*n_dev;
   __shared__ uint32_t wave_hist[kWaves][kRadix];
   __shared__ uint32_t gbase[kRadix], lbase[kRadix];
   __shared__ uint32_t s_key[kSortTile];
@@ -451,6 +460,7 @@ __global__ __launch_bounds__(kThreads) void radix_onesweep(
   __syncthreads();
   const uint32_t b = s_tile;
   const size_t tile0 = (size_t)b * kSortTile;
+  if (tile0 >= n) return;   // (a launch on a bound: tickets are taken in order, so every tile that holds pairs has a smaller one)
   const size_t span = tile0 + (size_t)wid * kWaveSpan;
   const uint32_t ntile = (uint32_t)(n - tile0 < (size_t)kSortTile ? n - tile0 : (size_t)kSortTile);
   uint32_t k[kSortItems], rank[kSortItems];
@@ -563,7 +573,7 @@ size_t radix_scratch_words(size_t n) {
 template <typename TV>
 static hipError_t radix_sort_impl(uint32_t* keys0, TV* vals0, uint32_t* keys1, TV* vals1,
                             size_t n, int bit_lo, int bit_hi, uint32_t* scratch,
-                            hipStream_t stream, bool* result_in_second) {
+                            hipStream_t stream, bool* result_in_second, const uint32_t* n_dev = nullptr) {
   *result_in_second = false;
   if (n == 0 || bit_hi <= bit_lo) return hipSuccess;
   const size_t nb = (n + kSortTile - 1) / kSortTile;
@@ -585,7 +595,8 @@ static hipError_t radix_sort_impl(uint32_t* keys0, TV* vals0, uint32_t* keys1, T
   static const size_t onesweep_min = (size_t)env_int("PLVS_SORT_ONESWEEP_MIN", 1 << 18, 0, 1 << 30);
   static const size_t onesweep_max = (size_t)env_int("PLVS_SORT_ONESWEEP_MAX", 1 << 23, 0, 1 << 30);
   const int os_passes = (total + 7) / 8;
-  if (onesweep_min != 0 && n >= onesweep_min && n < onesweep_max && os_passes <= kOsMaxPasses && !wide) {
+  if (n_dev != nullptr && os_passes > kOsMaxPasses) return hipErrorInvalidValue;
+  if (n_dev != nullptr || (onesweep_min != 0 && n >= onesweep_min && n < onesweep_max && os_passes <= kOsMaxPasses && !wide)) {
     // scratch: [passes][256] digit totals | [passes] tickets | [passes][tiles][256] status words, zeroed together
     uint32_t* totals = scratch;
     uint32_t* tickets = totals + (size_t)os_passes * 256;
@@ -594,10 +605,10 @@ static hipError_t radix_sort_impl(uint32_t* keys0, TV* vals0, uint32_t* keys1, T
     hipError_t e = hipMemsetAsync(scratch, 0, words * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(radix_digit_totals, dim3((unsigned)std::min<size_t>(nb, 1024)), dim3(kThreads), 0, stream, ki, n, bit_lo,
-                       os_passes, nb, totals);
+                       os_passes, nb, totals, n_dev);
     for (int p = 0; p < os_passes; ++p) {
       hipLaunchKernelGGL((radix_onesweep<TV>), dim3((unsigned)nb), dim3(kThreads), 0, stream, ki, vi, ko, vo, n, bit_lo + 8 * p,
-                         totals + (size_t)p * 256, status + (size_t)p * nb * 256, tickets + p);
+                         totals + (size_t)p * 256, status + (size_t)p * nb * 256, tickets + p, n_dev);
       uint32_t* t = ki; ki = ko; ko = t;
       TV* tv = vi; vi = vo; vo = tv;
       *result_in_second = !*result_in_second;
@@ -638,6 +649,12 @@ hipError_t radix_sort_pairs(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, u
                             hipStream_t stream, bool* result_in_second) {
   return radix_sort_impl<uint32_t>(keys0, vals0, keys1, vals1, n, bit_lo, bit_hi, scratch, stream,
                                    result_in_second);
+}
+
+hipError_t radix_sort_pairs_bound(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1, size_t n_bound,
+                                  const uint32_t* n_dev, int bit_lo, int bit_hi, uint32_t* scratch, hipStream_t stream,
+                                  bool* result_in_second) {
+  return radix_sort_impl<uint32_t>(keys0, vals0, keys1, vals1, n_bound, bit_lo, bit_hi, scratch, stream, result_in_second, n_dev);
 }
 
 hipError_t radix_sort_pairs_u64(uint32_t* keys0, unsigned long long* vals0, uint32_t* keys1,

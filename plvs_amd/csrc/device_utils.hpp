@@ -24,6 +24,13 @@ hipError_t radix_sort_pairs(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, u
                             size_t n, int bit_lo, int bit_hi, uint32_t* scratch,
                             hipStream_t stream, bool* result_in_second);
 
+// The same launched on a BOUND: the arrays hold min(n_bound, *n_dev) pairs, n_dev a device word written before the sort runs
+// (the host does not know it yet); every pass is one launch sized by the bound whose surplus tiles leave at once.
+// Scratch: radix_scratch_words(n_bound).  At most 32 key bits.
+hipError_t radix_sort_pairs_bound(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1, size_t n_bound,
+                                  const uint32_t* n_dev, int bit_lo, int bit_hi, uint32_t* scratch, hipStream_t stream,
+                                  bool* result_in_second);
+
 // Same with 64-bit values.
 hipError_t radix_sort_pairs_u64(uint32_t* keys0, unsigned long long* vals0, uint32_t* keys1,
                                 unsigned long long* vals1, size_t n, int bit_lo, int bit_hi,

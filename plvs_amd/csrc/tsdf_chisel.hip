@@ -1051,15 +1051,19 @@ static int sort_runs(plvs_tsdf_chisel* h, uint32_t D, uint32_t ntiles, int num_c
   PLVS_HIP_TRY(h->w_run_off.reserve((size_t)ntiles + 1));
   PLVS_HIP_TRY(h->scratch.reserve(std::max(radix_scratch_words(D), scan_scratch_words(ntiles))));
   // (the caller has scanned run_cnt into w_run_off)
-  hipLaunchKernelGGL(compact_runs, dim3(ceil_div(ntiles, 4) + (guard ? std::min<unsigned>(64u, ceil_div((size_t)D, 1024)) : 0u)),
+  hipLaunchKernelGGL(compact_runs, dim3(ceil_div(ntiles, 4) + (guard ? (guard->pad ? std::min<unsigned>(64u, ceil_div((size_t)D, 1024)) : 1u) : 0u)),
                      dim3(256), 0, s, h->w_runkey.p, h->w_run_cnt.p, h->w_run_off.p, ntiles, h->run_r1_log2, h->dkey0.p,
-                     h->w_val0.p, guard ? *guard : RunGuard{0xFFFFFFFFu, nullptr, nullptr, 0, nullptr, nullptr});
+                     h->w_val0.p, guard ? *guard : RunGuard{0xFFFFFFFFu, nullptr, nullptr, 0, nullptr, nullptr, 0u});
   int key_bits = 12;
   // (the count after this call's insertions; + 1 under a guard: its padding keys, all ones, must not be a voxel's)
   while ((1ll << (key_bits - 12)) < (long long)num_chunks + (guard ? 1 : 0)) ++key_bits;
   bool second = false;
-  PLVS_HIP_TRY(radix_sort_pairs(h->dkey0.p, h->w_val0.p, h->dkey1.p, h->w_val1.p, D, 0, key_bits, h->scratch.p, s,
-                                &second));
+  if (guard && !guard->pad)   // the bound is loose: the sort takes the number of pairs from the device
+    PLVS_HIP_TRY(radix_sort_pairs_bound(h->dkey0.p, h->w_val0.p, h->dkey1.p, h->w_val1.p, D, guard->total, 0, key_bits,
+                                        h->scratch.p, s, &second));
+  else
+    PLVS_HIP_TRY(radix_sort_pairs(h->dkey0.p, h->w_val0.p, h->dkey1.p, h->w_val1.p, D, 0, key_bits, h->scratch.p, s,
+                                  &second));
   *skeys = second ? h->dkey1.p : h->dkey0.p;
   *sval = second ? h->w_val1.p : h->w_val0.p;
   return PLVS_OK;
@@ -1245,8 +1249,17 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     const size_t expect_runs = h->small_runs_known
         ? (size_t)((double)h->small_runs_last * (double)ntiles / (double)std::max(1u, h->small_tiles_last)) : ~(size_t)0;
     // (a moderate number — a saturated map's rim: tens of thousands — is sorted on a bound a quarter above the expectation)
+    // (end of round 5, measured and left OFF: PLVS_TSDF_PREDICT_LONG=1) every call whose predecessor left a count could do so:
+    // beyond a moderate number with a LOOSE bound — three times the expectation, a million at least: the stream's counts go
+    // 4.5 M, 1.4 M, 1.6 M, 1.1 M, 2.6 M ... — and a sort that takes the number of pairs from the device
+    // (radix_sort_pairs_bound: launches sized by the bound, surplus tiles leave at once), so that a loose bound costs empty
+    // workgroups, not sorted padding, and the chain is queued behind the walk without a host read.  On the stream: GPU time
+    // per step 0.969 -> 0.965 ms, wall time 1.05 -> 1.07 (a bound that fails costs the chain twice): the chain's length is its
+    // kernels' (fold 0.13, three passes 0.15, compaction, heads), not the host's read.
     constexpr size_t kPredictRuns = 200000;
-    const bool predicted = h->small_runs_known && attempt == 0 && (ntiles <= kPredictTiles || expect_runs <= kPredictRuns);
+    static const bool predict_long = plvs::env_int("PLVS_TSDF_PREDICT_LONG", 0, 0, 1) != 0;   // (developer switch)
+    const bool predicted = h->small_runs_known && attempt == 0 &&
+                           (predict_long || ntiles <= kPredictTiles || expect_runs <= kPredictRuns);
     // When that bound is the small one (<= kSmallRuns: ONE sorting launch), nothing is worth a second stream: a branch on
     // another stream starts ~20 us after the event it waits for and is joined ~20 us after it ends — more than the chain
     // itself.  Segment sort, apply, sort_runs_small, fold follow each other on the caller's stream; seg_scan, which sums the
@@ -1325,7 +1338,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
       if (rc != PLVS_OK) return rc;
       run_bound = kSmallRuns;
       chunk_bound = std::min(max_chunks, std::max(2 * chunks_before, chunks_before + 256));
-      const RunGuard guard{run_bound, side_ctr, &h->d_ctr->num_chunks, chunk_bound, &h->d_wctr[0].err, &h->d_wctr[1].skip};
+      const RunGuard guard{run_bound, side_ctr, &h->d_ctr->num_chunks, chunk_bound, &h->d_wctr[0].err, &h->d_wctr[1].skip, 1u};
       rc = colour_chain(run_bound, chunk_bound, s, &guard);
       if (rc != PLVS_OK) return rc;
     } else {
@@ -1335,9 +1348,14 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
         const size_t slots = (size_t)ntiles << h->run_r1_log2;
         // (the call before scaled to this call's tiles — calls of one and of five key frames may alternate —, a quarter more)
         const size_t expect = (size_t)((double)h->small_runs_last * (double)ntiles / (double)std::max(1u, h->small_tiles_last));
-        run_bound = expect <= kSmallRuns / 2 ? kSmallRuns : (uint32_t)std::min<size_t>(slots, (expect * 5 / 4 + 8191) / 4096 * 4096);
+        // (up to kPredictRuns: a tight bound, padded — two or three short launches of the plain sort; beyond: the loose one)
+        const bool loose = predict_long && expect > kPredictRuns;
+        run_bound = expect <= kSmallRuns / 2 ? kSmallRuns
+                    : loose ? (uint32_t)std::min<size_t>(slots, (std::max<size_t>(3 * expect, (size_t)1 << 20) + 4095) / 4096 * 4096)
+                            : (uint32_t)std::min<size_t>(slots, (expect * 5 / 4 + 8191) / 4096 * 4096);
         chunk_bound = std::min(max_chunks, std::max(2 * chunks_before, chunks_before + 256));
-        const RunGuard guard{run_bound, side_ctr, &h->d_ctr->num_chunks, chunk_bound, &h->d_wctr[0].err, &h->d_wctr[1].skip};
+        const RunGuard guard{run_bound, side_ctr, &h->d_ctr->num_chunks, chunk_bound, &h->d_wctr[0].err, &h->d_wctr[1].skip,
+                             loose ? 0u : 1u};
         int rc = colour_chain(run_bound, chunk_bound, q_colour, &guard);
         if (rc != PLVS_OK) return rc;
         PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
@@ -1450,24 +1468,35 @@ int plvs_hip_selftest_radix_sort(uint32_t n, int bit_lo, int bit_hi, int wide_va
   PLVS_REQUIRE(mismatches2 && n > 0 && bit_lo >= 0 && bit_hi > bit_lo && bit_hi <= 32, "bad argument");
   plvs::DevBuf<uint32_t> k_in, k0, k1, v0, v1, scratch, bad;
   plvs::DevBuf<unsigned long long> w0, w1;
-  PLVS_HIP_TRY(k_in.reserve(n));
-  PLVS_HIP_TRY(k0.reserve(n));
-  PLVS_HIP_TRY(k1.reserve(n));
+  // wide_values = 2: the sort launched on a BOUND of the number of pairs (radix_sort_pairs_bound): the arrays are sized for
+  // n + n / 2 + 4097 pairs, the first n are filled, the count sits in a device word
+  const bool bound_mode = wide_values == 2;
+  if (bound_mode) wide_values = 0;
+  const uint32_t n_alloc = bound_mode ? n + n / 2 + 4097u : n;
+  PLVS_HIP_TRY(k_in.reserve(n_alloc));
+  PLVS_HIP_TRY(k0.reserve(n_alloc));
+  PLVS_HIP_TRY(k1.reserve(n_alloc));
   if (wide_values) {
     PLVS_HIP_TRY(w0.reserve(n));
     PLVS_HIP_TRY(w1.reserve(n));
   } else {
-    PLVS_HIP_TRY(v0.reserve(n));
-    PLVS_HIP_TRY(v1.reserve(n));
+    PLVS_HIP_TRY(v0.reserve(n_alloc));
+    PLVS_HIP_TRY(v1.reserve(n_alloc));
   }
-  PLVS_HIP_TRY(scratch.reserve(radix_scratch_words(n)));
+  PLVS_HIP_TRY(scratch.reserve(radix_scratch_words(n_alloc) + 1));
   PLVS_HIP_TRY(bad.reserve(2));
   PLVS_HIP_TRY(hipMemset(bad.p, 0, 2 * sizeof(uint32_t)));
   const dim3 grid(ceil_div((size_t)n, 256)), block(256);
   hipLaunchKernelGGL(selftest_sort_fill, grid, block, 0, nullptr, k0.p, v0.p, w0.p, n, bit_hi, seed);
   PLVS_HIP_TRY(hipMemcpyAsync(k_in.p, k0.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, nullptr));
   bool second = false;
-  if (wide_values) PLVS_HIP_TRY(radix_sort_pairs_u64(k0.p, w0.p, k1.p, w1.p, n, bit_lo, bit_hi, scratch.p, nullptr, &second));
+  if (bound_mode) {
+    PLVS_HIP_TRY(hipMemsetAsync(k0.p + n, 0x5A, (size_t)(n_alloc - n) * sizeof(uint32_t), nullptr));   // (what lies behind the pairs is not sorted in)
+    uint32_t* d_n = scratch.p + radix_scratch_words(n_alloc);
+    PLVS_HIP_TRY(hipMemcpyAsync(d_n, &n, sizeof(uint32_t), hipMemcpyHostToDevice, nullptr));
+    PLVS_HIP_TRY(hipStreamSynchronize(nullptr));
+    PLVS_HIP_TRY(radix_sort_pairs_bound(k0.p, v0.p, k1.p, v1.p, n_alloc, d_n, bit_lo, bit_hi, scratch.p, nullptr, &second));
+  } else if (wide_values) PLVS_HIP_TRY(radix_sort_pairs_u64(k0.p, w0.p, k1.p, w1.p, n, bit_lo, bit_hi, scratch.p, nullptr, &second));
   else PLVS_HIP_TRY(radix_sort_pairs(k0.p, v0.p, k1.p, v1.p, n, bit_lo, bit_hi, scratch.p, nullptr, &second));
   hipLaunchKernelGGL(selftest_sort_check, grid, block, 0, nullptr, k_in.p, second ? k1.p : k0.p,
                      wide_values ? (const uint32_t*)nullptr : (second ? v1.p : v0.p),
@@ -2873,7 +2902,7 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
     PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, nt, nullptr, h->scratch.p, s));
     hipLaunchKernelGGL(compact_runs, dim3(ceil_div(nt, 4)), dim3(256), 0, s, h->w_runkey.p, h->w_run_cnt.p,
                        h->w_run_off.p, nt, h->run_r1_log2, h->dkey0.p, h->w_val0.p,
-                       RunGuard{0xFFFFFFFFu, nullptr, nullptr, 0, nullptr, nullptr});
+                       RunGuard{0xFFFFFFFFu, nullptr, nullptr, 0, nullptr, nullptr, 0u});
     hipLaunchKernelGGL(shard_run_count, dim3(2048), dim3(256), 0, s, h->dkey0.p, h->w_val0.p, &h->d_wctr[0].num_desc,
                        h->w_masks.p, h->sh_slot_owner.p, N, h->sh_run_ctr.p, h->sh_run_first.p, h->d_wctr);
     hipLaunchKernelGGL(shard_run_plan, dim3(1), dim3(64), 0, s, h->sh_run_ctr.p, N, h->d_wctr);

@@ -2113,10 +2113,12 @@ __global__ void selftest_walk_math_kernel(uint32_t seed, uint32_t* __restrict__ 
 // Runs of the per-tile regions -> dense (key, slot) pairs in tile order (the input of the stable sort
 // by voxel key).  One wave per tile.
 // A call that launches its colour chain BEFORE the host knows the number of runs (small calls: the host read in the middle
-// of the chain was a fifth of their time) sorts `limit` pairs, a bound taken from the call before: the workgroups beyond
-// the tiles' fill dkey[total .. limit) with keys that sort last, and say in *skip whether the bounds held — the runs fit
-// `limit`, the map's chunks `chunk_limit` (the key bits of the sort).  If not, the fold does nothing and the host
-// repeats the chain with the real numbers.  Other calls: limit = 0xFFFFFFFF, no extra workgroups.
+// of the chain was a fifth of their time; since the end of round 5 every call whose predecessor left a count) sorts at most
+// `limit` pairs, a bound taken from the call before: the sort and the kernels behind it read the real number from the device
+// (radix_sort_pairs_bound; `pad`: the one-launch sort of a small bound takes exactly `limit` pairs instead, the surplus filled
+// with keys that sort last), and one extra workgroup says in *skip whether the bounds held — the runs fit `limit`, the map's
+// chunks `chunk_limit` (the key bits of the sort).  If not, the fold does nothing and the host repeats the chain with the real
+// numbers.  Other calls: limit = 0xFFFFFFFF, no extra workgroups.
 struct RunGuard {
   uint32_t limit;
   const uint32_t* total;        // runs of the call (the scan of run_cnt left it)
@@ -2124,6 +2126,7 @@ struct RunGuard {
   int chunk_limit;
   const uint32_t* err;          // the walk's error word: a walk that has to be repeated leaves nothing to fold
   uint32_t* skip;
+  uint32_t pad;                 // fill dkey[total .. limit) (a sort that takes `limit` pairs whatever their number)
 };
 __global__ __launch_bounds__(256) void compact_runs(const uint32_t* __restrict__ runkey, const uint32_t* __restrict__ run_cnt,
                                                     const uint32_t* __restrict__ run_off, uint32_t ntiles,
@@ -2134,10 +2137,11 @@ __global__ __launch_bounds__(256) void compact_runs(const uint32_t* __restrict__
     const uint32_t total = *guard.total, b = blockIdx.x - tile_blocks, nb = gridDim.x - tile_blocks;
     if (b == 0 && threadIdx.x == 0)
       *guard.skip = (total > guard.limit || *guard.num_chunks > guard.chunk_limit || *guard.err != 0u) ? 1u : 0u;
-    for (uint32_t i = total + b * 256u + threadIdx.x; i < guard.limit; i += nb * 256u) {
-      dkey[i] = 0xFFFFFFFFu;
-      dval[i] = 0u;
-    }
+    if (guard.pad)
+      for (uint32_t i = total + b * 256u + threadIdx.x; i < guard.limit; i += nb * 256u) {
+        dkey[i] = 0xFFFFFFFFu;
+        dval[i] = 0u;
+      }
     return;
   }
   const uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
