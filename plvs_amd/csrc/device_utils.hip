@@ -421,8 +421,23 @@ __global__ __launch_bounds__(kThreads) void radix_digit_totals(const uint32_t* _
   __shared__ uint32_t h[kOsMaxPasses][256];
   for (int p = 0; p < passes; ++p) h[p][threadIdx.x] = 0;
   __syncthreads();
+  const bool vec = (reinterpret_cast<uintptr_t>(keys) & 15u) == 0;
   for (size_t b = blockIdx.x; b < nb; b += gridDim.x) {
     const size_t tile = b * kSortTile;
+    if (vec && tile + kSortTile <= n) {   // (a whole tile: four 16-byte loads per thread, all in flight before the first atomic)
+      uint4 q[kSortItems / 4];
+#pragma unroll
+      for (int it = 0; it < kSortItems / 4; ++it)
+        q[it] = reinterpret_cast<const uint4*>(keys + tile)[it * kThreads + threadIdx.x];
+#pragma unroll
+      for (int it = 0; it < kSortItems / 4; ++it) {
+        const uint32_t k4[4] = {q[it].x >> bit_lo, q[it].y >> bit_lo, q[it].z >> bit_lo, q[it].w >> bit_lo};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          for (int p = 0; p < passes; ++p) atomicAdd(&h[p][(k4[c] >> (8 * p)) & 255u], 1u);
+      }
+      continue;
+    }
 #pragma unroll 4
     for (int it = 0; it < kSortItems; ++it) {
       const size_t i = tile + (size_t)it * kThreads + threadIdx.x;
@@ -573,7 +588,8 @@ size_t radix_scratch_words(size_t n) {
 template <typename TV>
 static hipError_t radix_sort_impl(uint32_t* keys0, TV* vals0, uint32_t* keys1, TV* vals1,
                             size_t n, int bit_lo, int bit_hi, uint32_t* scratch,
-                            hipStream_t stream, bool* result_in_second, const uint32_t* n_dev = nullptr) {
+                            hipStream_t stream, bool* result_in_second, const uint32_t* n_dev = nullptr,
+                            bool scratch_zeroed = false) {
   *result_in_second = false;
   if (n == 0 || bit_hi <= bit_lo) return hipSuccess;
   const size_t nb = (n + kSortTile - 1) / kSortTile;
@@ -602,8 +618,10 @@ static hipError_t radix_sort_impl(uint32_t* keys0, TV* vals0, uint32_t* keys1, T
     uint32_t* tickets = totals + (size_t)os_passes * 256;
     uint32_t* status = tickets + kOsMaxPasses;
     const size_t words = (size_t)os_passes * 256 + kOsMaxPasses + (size_t)os_passes * nb * 256;
-    hipError_t e = hipMemsetAsync(scratch, 0, words * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
+    if (!scratch_zeroed) {
+      hipError_t e = hipMemsetAsync(scratch, 0, words * sizeof(uint32_t), stream);
+      if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(radix_digit_totals, dim3((unsigned)std::min<size_t>(nb, 1024)), dim3(kThreads), 0, stream, ki, n, bit_lo,
                        os_passes, nb, totals, n_dev);
     for (int p = 0; p < os_passes; ++p) {
@@ -649,6 +667,23 @@ hipError_t radix_sort_pairs(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, u
                             hipStream_t stream, bool* result_in_second) {
   return radix_sort_impl<uint32_t>(keys0, vals0, keys1, vals1, n, bit_lo, bit_hi, scratch, stream,
                                    result_in_second);
+}
+
+size_t radix_sort_zero_words(size_t n, int bit_lo, int bit_hi) {
+  static const size_t onesweep_min = (size_t)env_int("PLVS_SORT_ONESWEEP_MIN", 1 << 18, 0, 1 << 30);
+  static const size_t onesweep_max = (size_t)env_int("PLVS_SORT_ONESWEEP_MAX", 1 << 23, 0, 1 << 30);
+  static const size_t wide_max = (size_t)env_int("PLVS_SORT_WIDE_MAX", 0, 0, 1 << 30);
+  const int total = bit_hi - bit_lo, os_passes = (total + 7) / 8;
+  const bool wide = n < wide_max && total > 16 && total <= 2 * kMaxRadixBits;
+  if (n == 0 || total <= 0 || onesweep_min == 0 || n < onesweep_min || n >= onesweep_max || os_passes > kOsMaxPasses || wide) return 0;
+  const size_t nb = (n + kSortTile - 1) / kSortTile;
+  return (size_t)os_passes * 256 + kOsMaxPasses + (size_t)os_passes * nb * 256;
+}
+
+hipError_t radix_sort_pairs_zeroed(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1, size_t n, int bit_lo,
+                                   int bit_hi, uint32_t* scratch, hipStream_t stream, bool* result_in_second) {
+  return radix_sort_impl<uint32_t>(keys0, vals0, keys1, vals1, n, bit_lo, bit_hi, scratch, stream, result_in_second, nullptr,
+                                   radix_sort_zero_words(n, bit_lo, bit_hi) != 0);
 }
 
 hipError_t radix_sort_pairs_bound(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1, size_t n_bound,

@@ -24,6 +24,13 @@ hipError_t radix_sort_pairs(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, u
                             size_t n, int bit_lo, int bit_hi, uint32_t* scratch,
                             hipStream_t stream, bool* result_in_second);
 
+// A sort of 2^18..2^23 pairs starts by zeroing part of its scratch (a launch of its own, 25 us in front of a chain of dependent
+// kernels).  A caller whose previous kernel can do that on the side asks how many words (0: this sort zeroes nothing), has them
+// zeroed, and calls the _zeroed form.
+size_t radix_sort_zero_words(size_t n, int bit_lo, int bit_hi);
+hipError_t radix_sort_pairs_zeroed(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1, size_t n, int bit_lo,
+                                   int bit_hi, uint32_t* scratch, hipStream_t stream, bool* result_in_second);
+
 // The same launched on a BOUND: the arrays hold min(n_bound, *n_dev) pairs, n_dev a device word written before the sort runs
 // (the host does not know it yet); every pass is one launch sized by the bound whose surplus tiles leave at once.
 // Scratch: radix_scratch_words(n_bound).  At most 32 key bits.

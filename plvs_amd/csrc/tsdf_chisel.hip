@@ -1051,16 +1051,25 @@ static int sort_runs(plvs_tsdf_chisel* h, uint32_t D, uint32_t ntiles, int num_c
   PLVS_HIP_TRY(h->w_run_off.reserve((size_t)ntiles + 1));
   PLVS_HIP_TRY(h->scratch.reserve(std::max(radix_scratch_words(D), scan_scratch_words(ntiles))));
   // (the caller has scanned run_cnt into w_run_off)
-  hipLaunchKernelGGL(compact_runs, dim3(ceil_div(ntiles, 4) + (guard ? (guard->pad ? std::min<unsigned>(64u, ceil_div((size_t)D, 1024)) : 1u) : 0u)),
-                     dim3(256), 0, s, h->w_runkey.p, h->w_run_cnt.p, h->w_run_off.p, ntiles, h->run_r1_log2, h->dkey0.p,
-                     h->w_val0.p, guard ? *guard : RunGuard{0xFFFFFFFFu, nullptr, nullptr, 0, nullptr, nullptr, 0u});
   int key_bits = 12;
   // (the count after this call's insertions; + 1 under a guard: its padding keys, all ones, must not be a voxel's)
   while ((1ll << (key_bits - 12)) < (long long)num_chunks + (guard ? 1 : 0)) ++key_bits;
+  // (the plain sort of a known number of pairs: its status words are zeroed by the compaction, on the side — a launch of its
+  // own otherwise, 25 us in front of the chain)
+  const size_t zero_words = guard ? 0 : radix_sort_zero_words(D, 0, key_bits);
+  RunGuard g = guard ? *guard : RunGuard{0xFFFFFFFFu, nullptr, nullptr, 0, nullptr, nullptr, 0u, nullptr, 0u};
+  g.zero = zero_words ? h->scratch.p : nullptr;
+  g.zero_words = (uint32_t)zero_words;
+  hipLaunchKernelGGL(compact_runs, dim3(ceil_div(ntiles, 4) + (guard ? (guard->pad ? std::min<unsigned>(64u, ceil_div((size_t)D, 1024)) : 1u) : 0u)),
+                     dim3(256), 0, s, h->w_runkey.p, h->w_run_cnt.p, h->w_run_off.p, ntiles, h->run_r1_log2, h->dkey0.p,
+                     h->w_val0.p, g);
   bool second = false;
   if (guard && !guard->pad)   // the bound is loose: the sort takes the number of pairs from the device
     PLVS_HIP_TRY(radix_sort_pairs_bound(h->dkey0.p, h->w_val0.p, h->dkey1.p, h->w_val1.p, D, guard->total, 0, key_bits,
                                         h->scratch.p, s, &second));
+  else if (zero_words)
+    PLVS_HIP_TRY(radix_sort_pairs_zeroed(h->dkey0.p, h->w_val0.p, h->dkey1.p, h->w_val1.p, D, 0, key_bits, h->scratch.p, s,
+                                         &second));
   else
     PLVS_HIP_TRY(radix_sort_pairs(h->dkey0.p, h->w_val0.p, h->dkey1.p, h->w_val1.p, D, 0, key_bits, h->scratch.p, s,
                                   &second));
@@ -1338,7 +1347,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
       if (rc != PLVS_OK) return rc;
       run_bound = kSmallRuns;
       chunk_bound = std::min(max_chunks, std::max(2 * chunks_before, chunks_before + 256));
-      const RunGuard guard{run_bound, side_ctr, &h->d_ctr->num_chunks, chunk_bound, &h->d_wctr[0].err, &h->d_wctr[1].skip, 1u};
+      const RunGuard guard{run_bound, side_ctr, &h->d_ctr->num_chunks, chunk_bound, &h->d_wctr[0].err, &h->d_wctr[1].skip, 1u, nullptr, 0u};
       rc = colour_chain(run_bound, chunk_bound, s, &guard);
       if (rc != PLVS_OK) return rc;
     } else {
@@ -1355,7 +1364,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
                             : (uint32_t)std::min<size_t>(slots, (expect * 5 / 4 + 8191) / 4096 * 4096);
         chunk_bound = std::min(max_chunks, std::max(2 * chunks_before, chunks_before + 256));
         const RunGuard guard{run_bound, side_ctr, &h->d_ctr->num_chunks, chunk_bound, &h->d_wctr[0].err, &h->d_wctr[1].skip,
-                             loose ? 0u : 1u};
+                             loose ? 0u : 1u, nullptr, 0u};
         int rc = colour_chain(run_bound, chunk_bound, q_colour, &guard);
         if (rc != PLVS_OK) return rc;
         PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
@@ -2902,7 +2911,7 @@ int plvs_hip_tsdf_chisel_shard_walk(plvs_tsdf_chisel* h, const float* d_xyz, con
     PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, nt, nullptr, h->scratch.p, s));
     hipLaunchKernelGGL(compact_runs, dim3(ceil_div(nt, 4)), dim3(256), 0, s, h->w_runkey.p, h->w_run_cnt.p,
                        h->w_run_off.p, nt, h->run_r1_log2, h->dkey0.p, h->w_val0.p,
-                       RunGuard{0xFFFFFFFFu, nullptr, nullptr, 0, nullptr, nullptr, 0u});
+                       RunGuard{0xFFFFFFFFu, nullptr, nullptr, 0, nullptr, nullptr, 0u, nullptr, 0u});
     hipLaunchKernelGGL(shard_run_count, dim3(2048), dim3(256), 0, s, h->dkey0.p, h->w_val0.p, &h->d_wctr[0].num_desc,
                        h->w_masks.p, h->sh_slot_owner.p, N, h->sh_run_ctr.p, h->sh_run_first.p, h->d_wctr);
     hipLaunchKernelGGL(shard_run_plan, dim3(1), dim3(64), 0, s, h->sh_run_ctr.p, N, h->d_wctr);

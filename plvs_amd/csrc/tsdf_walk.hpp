@@ -2127,12 +2127,17 @@ struct RunGuard {
   const uint32_t* err;          // the walk's error word: a walk that has to be repeated leaves nothing to fold
   uint32_t* skip;
   uint32_t pad;                 // fill dkey[total .. limit) (a sort that takes `limit` pairs whatever their number)
+  uint32_t* zero;               // words the sort behind the compaction wants zeroed (radix_sort_zero_words), or null
+  uint32_t zero_words;
 };
 __global__ __launch_bounds__(256) void compact_runs(const uint32_t* __restrict__ runkey, const uint32_t* __restrict__ run_cnt,
                                                     const uint32_t* __restrict__ run_off, uint32_t ntiles,
                                                     uint32_t r1_log2, uint32_t* __restrict__ dkey,
                                                     uint32_t* __restrict__ dval, RunGuard guard) {
   const uint32_t tile_blocks = (ntiles + 3u) / 4u;
+  // (on the side: the status words of the sort that follows — a launch of its own otherwise, 25 us in front of the chain)
+  if (guard.zero != nullptr)
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < guard.zero_words; i += gridDim.x * 256u) guard.zero[i] = 0u;
   if (blockIdx.x >= tile_blocks) {
     const uint32_t total = *guard.total, b = blockIdx.x - tile_blocks, nb = gridDim.x - tile_blocks;
     if (b == 0 && threadIdx.x == 0)
