@@ -115,8 +115,12 @@ __global__ void walk_prologue(const float* __restrict__ Twc, int nclouds, Pose* 
 
 // Counters -> their pinned host copies by a kernel's stores: a small device-to-host copy command costs tens of
 // microseconds of queueing, a store through the host-mapped pointer a few.
+// host_seq (the order-free pipeline's reads): after the counters a sequence number, stored with system scope — the host polls that
+// word in pinned memory instead of sleeping on the stream (wait_published: a wake-up is 20-30 us, on the critical path of a
+// long call's colour chain and a fifth of a one-key-frame call)
 __global__ void publish_counters(const WalkCounters* __restrict__ wctr, const Counters* __restrict__ ctr,
-                                 WalkCounters* __restrict__ host_wctr, Counters* __restrict__ host_ctr) {
+                                 WalkCounters* __restrict__ host_wctr, Counters* __restrict__ host_ctr,
+                                 uint32_t* __restrict__ host_seq = nullptr, uint32_t seq = 0u) {
   if (wctr) {
     const uint32_t* a = reinterpret_cast<const uint32_t*>(wctr);
     uint32_t* b = reinterpret_cast<uint32_t*>(host_wctr);
@@ -128,6 +132,10 @@ __global__ void publish_counters(const WalkCounters* __restrict__ wctr, const Co
     for (int k = threadIdx.x; k < (int)(sizeof(Counters) / sizeof(uint32_t)); k += blockDim.x) d[k] = c[k];
   }
   __threadfence_system();
+  if (host_seq != nullptr) {
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // The start of shard_apply in one launch: counters of the call cleared, the received totals in place (what a
@@ -890,6 +898,8 @@ struct plvs_tsdf_chisel {
   // single-walk pipeline (tsdf_walk.hpp)
   WalkCounters* d_wctr = nullptr;   // [2]: the call's counters, the colour pass's voxel list
   WalkCounters* h_wctr = nullptr;   // pinned
+  uint32_t* h_seq = nullptr;        // pinned, coherent: the sequence number of the last publish_counters that has landed
+  uint32_t seq_next = 0;
   DevBuf<uint4> w_rec, w_seg, w_sorted_seg;
   DevBuf<uint32_t> w_chunk_nseg, w_chunk_off, w_chunk_fill, w_active_off, w_masks, w_dummy, w_seg_cnt, w_tile_visits, w_deferred;
   DevBuf<uint32_t> w_part_off, w_multi_idx;          // apply stage: parts of the updated chunks
@@ -1023,11 +1033,38 @@ constexpr unsigned kListGrid = 512;      // workgroups of the large-table pass o
 static_assert(kRecStride == (uint32_t)kWalkLimit, "a tile's record region holds a flush of the largest table");
 const char* const kWalkStageNames[kWalkStages] = {"walk_tiles", "sort_segments", "apply_chunks", "fold_colours"};
 
-static int read_walk_counters(plvs_tsdf_chisel* h, hipStream_t s) {
-  hipLaunchKernelGGL(publish_counters, dim3(1), dim3(64), 0, s, h->d_wctr, h->d_ctr, h->h_wctr, h->h_ctr);
-  PLVS_KERNEL_CHECK();
-  PLVS_HIP_TRY(hipStreamSynchronize(s));
+// The host's wait for a publish_counters launch that carried sequence number `seq` on stream q: it polls the word for up to
+// PLVS_TSDF_SPIN_US microseconds (default 3000; 0 = never), then sleeps on the stream.  Everything enqueued on q before that
+// launch has completed when the word arrives (stream order), so this stands for hipStreamSynchronize(q) as far as the
+// pipeline's own buffers and the caller's inputs are concerned.
+static int wait_published(plvs_tsdf_chisel* h, uint32_t seq, hipStream_t q) {
+  static const int spin_us = plvs::env_int("PLVS_TSDF_SPIN_US", 3000, 0, 10000000);
+  if (spin_us > 0 && h->h_seq != nullptr) {
+    const volatile uint32_t* const word = h->h_seq;
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint32_t spins = 0;; ++spins) {
+      if (*word == seq) {
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        return PLVS_OK;
+      }
+      __builtin_ia32_pause();
+      if ((spins & 255u) == 255u) {
+        timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((t1.tv_sec - t0.tv_sec) * 1000000ll + (t1.tv_nsec - t0.tv_nsec) / 1000 > spin_us) break;
+      }
+    }
+  }
+  PLVS_HIP_TRY(hipStreamSynchronize(q));
   return PLVS_OK;
+}
+
+static int read_walk_counters(plvs_tsdf_chisel* h, hipStream_t s) {
+  const uint32_t seq = ++h->seq_next;
+  hipLaunchKernelGGL(publish_counters, dim3(1), dim3(64), 0, s, h->d_wctr, h->d_ctr, h->h_wctr, h->h_ctr, h->h_seq, seq);
+  PLVS_KERNEL_CHECK();
+  return wait_published(h, seq, s);
 }
 
 static int walk_fail(plvs_tsdf_chisel* h, uint32_t err) {
@@ -1371,8 +1408,12 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
         rc = segments_and_apply();
         if (rc != PLVS_OK) return rc;
       } else {
-        hipLaunchKernelGGL(publish_counters, dim3(1), dim3(64), 0, h->side, h->d_wctr, h->d_ctr, h->h_wctr, h->h_ctr);
-        PLVS_HIP_TRY(hipStreamSynchronize(h->side));   // the walk is over; segment sort and apply are queued behind it
+        const uint32_t seq = ++h->seq_next;
+        hipLaunchKernelGGL(publish_counters, dim3(1), dim3(64), 0, h->side, h->d_wctr, h->d_ctr, h->h_wctr, h->h_ctr, h->h_seq, seq);
+        {   // the walk is over; segment sort and apply are queued behind it
+          int rcw = wait_published(h, seq, h->side);
+          if (rcw != PLVS_OK) return rcw;
+        }
         const uint32_t D = h->h_wctr[1].num_desc;
         if (h->h_wctr[0].err == 0 && D > 0) {
           int rc = colour_chain(D, h->h_ctr->num_chunks, h->side, nullptr);
@@ -1597,9 +1638,11 @@ int plvs_hip_tsdf_chisel_create(const plvs_tsdf_chisel_params* p, plvs_tsdf_chis
   CREATE_TRY(hipMalloc((void**)&h->kfid, nvox * sizeof(uint32_t)));
   CREATE_TRY(hipMalloc((void**)&h->rgbw, nvox * sizeof(uint32_t)));
   CREATE_TRY(hipMalloc((void**)&h->d_ctr, sizeof(Counters)));
-  CREATE_TRY(hipHostMalloc((void**)&h->h_ctr, sizeof(Counters)));
+  CREATE_TRY(hipHostMalloc((void**)&h->h_ctr, sizeof(Counters), hipHostMallocCoherent));   // (read behind a polled word: wait_published)
   CREATE_TRY(hipMalloc((void**)&h->d_wctr, 2 * sizeof(WalkCounters)));
-  CREATE_TRY(hipHostMalloc((void**)&h->h_wctr, 2 * sizeof(WalkCounters)));
+  CREATE_TRY(hipHostMalloc((void**)&h->h_wctr, 2 * sizeof(WalkCounters), hipHostMallocCoherent));
+  CREATE_TRY(hipHostMalloc((void**)&h->h_seq, 64, hipHostMallocCoherent));
+  h->h_seq[0] = 0u;
   {
     // Fixed-point scales of the order-free accumulators: a tile adds at most kWalkRays terms per voxel,
     // |w_u u| < weight / 2 and w_u <= weight / (2 diag); the largest powers of two that keep a tile's
@@ -1636,6 +1679,7 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   if (h->h_ctr) (void)hipHostFree(h->h_ctr);
   (void)hipFree(h->d_wctr);
   if (h->h_wctr) (void)hipHostFree(h->h_wctr);
+  if (h->h_seq) (void)hipHostFree(h->h_seq);
   if (h->h_offsets) (void)hipHostFree(h->h_offsets);
   (void)hipFree(h->gdir.keys);
   (void)hipFree(h->gdir.slots);
