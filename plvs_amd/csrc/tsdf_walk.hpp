@@ -1861,8 +1861,6 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
 #ifdef PLVS_WALK_PROF
     const long long ap_item0 = (long long)clock64();
     ap_t = ap_item0;
-    uint32_t ap_recs = 0, ap_rounds = 0;
-    unsigned long long ap_load = 0, ap_add = 0;
 #endif
     const uint32_t pi = item / kSlabs, slab = item % kSlabs;
     // the chunk of part pi: the last a with part_off[a] <= pi — a 64-way search by every wave (two dependent loads for
@@ -2052,9 +2050,9 @@ __global__ __launch_bounds__(kApplyThreads) void apply_chunks(
 #ifdef PLVS_WALK_PROF
     if (threadIdx.x == 0 && item < 8192u) {
       g_apply_items[item][0] = (unsigned long long)((long long)clock64() - ap_item0);
-      g_apply_items[item][1] = ((unsigned long long)(s1 - s0) << 32) | (unsigned long long)ap_recs;
-      g_apply_items[item][2] = ap_load;
-      g_apply_items[item][3] = (ap_add << 8) | (unsigned long long)min(ap_rounds, 255u);
+      g_apply_items[item][1] = (unsigned long long)(s1 - s0) << 32;
+      g_apply_items[item][2] = 0;
+      g_apply_items[item][3] = 0;
     }
     ++ap_items;
     ap_max = max(ap_max, ((unsigned long long)((long long)clock64() - ap_item0) << 24) | ((unsigned long long)min(s1 - s0, 0xFFFFFu) << 4) |
