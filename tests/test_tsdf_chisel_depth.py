@@ -150,3 +150,44 @@ def test_hip_depth_entry_empty_and_invalid_images(oracle):
         assert compare_maps(a, b) >= 1 and a.last_stats()["visits"] == b.last_stats()["visits"] > 0
         a.close()
         b.close()
+
+
+_SPIN_SCRIPT = r"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1])
+from tests import oracle_lib
+from tests.plvs_amd_synth import TUM1, make_rgbd_frames
+from tests.test_tsdf_chisel import compare_maps
+from tests.test_tsdf_chisel_depth import _clouds, _integrate_clouds, _integrate_depth
+from plvs_amd.tsdf import TsdfChisel
+oracle = oracle_lib.load()
+grid = oracle.cam_grid_points(640, 480, 2, TUM1["fx"], TUM1["fy"], TUM1["cx"], TUM1["cy"])
+frames = make_rgbd_frames(4, seed=9, holes=True)
+a, b = TsdfChisel(0.05, max_chunks=8192, order_free=True), TsdfChisel(0.05, max_chunks=8192, order_free=True)
+for k0 in (0, 2):
+    fr, kf = frames[k0:k0 + 2], [k0, k0 + 1]
+    _integrate_depth(a, fr, grid, 2, 0.1, 5.0, kf)
+    _integrate_clouds(b, _clouds(oracle, fr, grid, 2, 0.1, 5.0, kf))
+    assert a.last_stats()["visits"] == b.last_stats()["visits"] > 0
+    print("chunks", compare_maps(a, b))
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spin_us", ["0", "1"], ids=["sleeps_on_the_stream", "gives_up_polling_after_a_microsecond"])
+def test_hip_counter_read_without_polling(spin_us, tmp_path):
+    """The host normally POLLS a word in pinned memory for the call's counters (wait_published, PLVS_TSDF_SPIN_US = 3000); with
+    0 it sleeps on the stream as it did before, with 1 it starts polling and falls back to the stream at once — the two
+    maps of the depth / point-stream entry points stay bit-identical either way (the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "spin.py"
+    script.write_text(_SPIN_SCRIPT)
+    r = subprocess.run([sys.executable, str(script), root], env=dict(os.environ, PLVS_TSDF_SPIN_US=spin_us), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert r.stdout.count("chunks") == 2
