@@ -20,6 +20,7 @@ import pytest
 
 from tests import lsd_golden_scenario as S
 from tests import oracle_lib
+from tests.oracle_lib import golden
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref", "liblsd_ref.so")
@@ -265,3 +266,24 @@ def test_hip_equals_the_compiled_reference_on_degenerate_images():
         for o in (S.DEFAULTS, dict(S.DEFAULTS, **S.TRACKING), dict(S.DEFAULTS, scale=1.0, refine=0)):
             want, got = ref.segments(img, **o), hip.segments(img, **o)
             assert len(want) == len(got) and want.tobytes() == got.tobytes(), (img.shape, o)
+    # more than 2^22 pixels: 64-bit ordering keys on the host, a 4.3-megapixel field on the device
+    tiles = [golden(n) for n in ("aloe_640x480.pgm", "cones_640x480.pgm", "aloe_640x480_shift.pgm")]
+    row = np.concatenate([tiles[0], tiles[1], tiles[2], tiles[1][:, :480]], 1)
+    big = np.ascontiguousarray(np.concatenate([row, row[::-1], row[:, ::-1], row[::-1, ::-1][:360]], 0))
+    o = dict(S.DEFAULTS, scale=1.0, refine=1)
+    want, got = ref.segments(big, **o), hip.segments(big, **o)
+    assert len(want) == len(got) > 10000 and want.tobytes() == got.tobytes()
+
+
+@needs_ref
+def test_host_stages_equal_the_compiled_reference_on_an_image_of_more_than_four_megapixels():
+    """Beyond 2^22 pixels the ordering's keys are 64 bits wide (bin above a 32-bit pixel index) instead of 32: the same
+    permutation, the same segments.  A 2 400 x 1 800 mosaic of the golden images at scale 1."""
+    tiles = [golden(n) for n in ("aloe_640x480.pgm", "cones_640x480.pgm", "aloe_640x480_shift.pgm")]
+    row = np.concatenate([tiles[0], tiles[1], tiles[2], tiles[1][:, :480]], 1)          # 480 x 2400
+    img = np.ascontiguousarray(np.concatenate([row, row[::-1], row[:, ::-1], row[::-1, ::-1][:360]], 0))   # 1800 x 2400
+    assert img.shape[0] * img.shape[1] > (1 << 22)
+    o = dict(S.DEFAULTS, scale=1.0, refine=1)
+    want, got = RefBackend().segments(img, **o), HostBackend().segments(img, **o)
+    assert len(want) == len(got) > 10000
+    assert want.tobytes() == got.tobytes()
