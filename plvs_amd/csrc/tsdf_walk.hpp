@@ -242,8 +242,17 @@ __device__ __forceinline__ int bucket_match(const uint4 k4, uint32_t want) {
 // the step is as slow as its slowest lane.  Entries are not counted here — the flush counts them (entries beyond
 // kWalkLimit: the (sub-)tile is cut, as when the table is full).
 constexpr int kProbeCap = 24;
+#ifndef PLVS_PROBE_NOINLINE
+#define PLVS_PROBE_NOINLINE 0   // 1: the general search as a CALL — measured slower (round 6: a wave step has a lane on this path every
+                                // other step, and a call saves and restores the caller's registers around it)
+#endif
+#if PLVS_PROBE_NOINLINE
+#define PLVS_PROBE_ATTR __attribute__((noinline))
+#else
+#define PLVS_PROBE_ATTR __forceinline__
+#endif
 template <class SH>
-__device__ __forceinline__ int table_find_or_insert(SH& S, uint32_t key /* a table key */) {
+__device__ PLVS_PROBE_ATTR int table_find_or_insert(SH& S, uint32_t key /* a table key */) {
   uint32_t b = key_bucket<SH>(key);
   // (kProbeCap: a tile within its limit — three quarters of the table — never chains that far; a table on its way to
   // full does, and every probe is an LDS round trip: without the cap the rays of an overflowing tile spent hundreds of
@@ -430,7 +439,11 @@ __device__ __forceinline__ uint32_t walk_lean(const Params& P, const Pose& pose,
   // an axis that never steps has tDelta = 0 / 0; it is never added in the reference (its tMax is +inf), here it is
   // multiplied by a zero mask: keep it finite
   const float tdx = cur.stepX ? cur.tDeltaX : 0.0f, tdy = cur.stepY ? cur.tDeltaY : 0.0f, tdz = cur.stepZ ? cur.tDeltaZ : 0.0f;
-  uint32_t nv = 0;
+  // the visits so far, carried as the BYTE OFFSET of the ray's next slot in the visit log (visit j of ray r at
+  // [j * kWalkRays + r], 16-bit entries): one register for the count and the address — a separate log pointer was the value
+  // the allocator spilled inside this loop (a scratch reload per visit in walk_multi)
+  static_assert(kWalkRays * sizeof(uint16_t) == 1024, "the count is the offset >> 10");
+  uint32_t vp = (uint32_t)tid * (uint32_t)sizeof(uint16_t);
   for (int guard = 0; guard < kRayStepGuard; ++guard) {   // (the reference loop is unbounded)
     // ---- Raycast.cpp:115-129 at the current voxel
     const float d = sqnorm3(fx - cur.sx, fy - cur.sy, fz - cur.sz);
@@ -455,13 +468,14 @@ __device__ __forceinline__ uint32_t walk_lean(const Params& P, const Pose& pose,
         }
       }
       if (__builtin_expect(e < 0, 0)) break;   // the table is full: the (sub-)tile is cut
-      if (kRuns && nv < (uint32_t)kLogLen) vlog[nv * kWalkRays + tid] = (uint16_t)e;
+      if (kRuns && vp < (uint32_t)(kLogLen * kWalkRays * sizeof(uint16_t)))
+        *reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(vlog) + vp) = (uint16_t)e;
       if (kAcc) {
         atomicAdd(&e_wuu[e], __float2int_rn(wu_scaled * u));
         atomicAdd(&e_wc[e], (1ull << 32) | (unsigned long long)q_w);
         atomicMax(&e_last[e], rid);   // (the ray's index in the tile: = tid unless the tile's rays were re-dealt)
       }
-      ++nv;
+      vp += (uint32_t)(kWalkRays * sizeof(uint16_t));
     }
     if (stop) break;
     // ---- Raycast.cpp:131-180: the axis with the smallest tMax steps (the reference's comparisons and tie rules)
@@ -476,7 +490,7 @@ __device__ __forceinline__ uint32_t walk_lean(const Params& P, const Pose& pose,
     tmz = fmaf(mz, tdz, tmz);
     key += go_x ? kx : (go_y ? ky : kz);
   }
-  return nv;
+  return vp >> 10;
 }
 
 // ------------------------------------------------------------------ rays straight from depth images (round 5)
@@ -2318,7 +2332,9 @@ __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
     const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ sorted_val, const uint32_t* __restrict__ nd_dev,
     RunSrc src, const uint32_t* __restrict__ vj0, const uint8_t* __restrict__ rgb, uint32_t* __restrict__ rgbw,
     const uint32_t* __restrict__ num_heads, uint32_t* __restrict__ sat_list, uint32_t* __restrict__ sat_count,
-    const uint32_t* __restrict__ skip, const GridSrc grid) {
+    const uint32_t* __restrict__ skip, const GridSrc grid, uint32_t* __restrict__ cnt_reset = nullptr) {
+  // cnt_reset (walk_multi, tsdf_walk_multi.hpp): the per-voxel visit counts of the call's first part — every voxel that
+  // was counted has a run, so the fold leaves the plane zero for the next call
   // sat_list (ray-sharded integrate): the voxels whose colour weight reaches 254 in this call
   // skip (a chain launched on predicted sizes, compact_runs): non-zero = the prediction failed, nothing here is valid
   if (skip != nullptr && *skip != 0u) return;
@@ -2637,6 +2653,7 @@ __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
         rgbw[key] = ch | (g << 8) | (bl << 16) | ((cw0 + steps) << 24);
         if (sat_list && cw0 + steps >= 254u) sat_list[atomicAdd(sat_count, 1u)] = key;
       }
+      if (cnt_reset != nullptr && active && fc == 0) cnt_reset[key] = 0u;
     }
     __builtin_amdgcn_wave_barrier();
   }
