@@ -611,15 +611,6 @@ int plvs_hip_tsdf_chisel_last_stats(plvs_tsdf_chisel* h, plvs_tsdf_stats* s);
  * a call is applied in parts of `part_segments` segments (defaults 2048 / 256); results do not depend on it. */
 int plvs_hip_tsdf_chisel_set_apply_parts(plvs_tsdf_chisel* h, int part_segments, int min_segments);
 
-/* Tuning knob of the order_free walk of depth-image calls (plvs_hip_tsdf_chisel_integrate_depth_batch_dev) of eight images
- * or more: a workgroup walks the same block of grid pixels of up to `images_per_task` consecutive images into one voxel
- * table before it writes its records (0 = the library's choice, 1 = one image per workgroup; at most 7), and the first
- * 1 / `first_part_divisor` of a call's images tell the rest which voxels' colours have saturated (0 = default 4, 1 = off).
- * Results do not depend on either: the maps are bit-identical (PointCloudMapping::UpdateMap hands its key frames over in
- * order, src/PointCloudMapping.cc:537-556; what is grouped here is the bookkeeping behind Chisel.cpp:505-540, not its
- * arithmetic). */
-int plvs_hip_tsdf_chisel_set_walk_windows(plvs_tsdf_chisel* h, int images_per_task, int first_part_divisor);
-
 /* Optional per-stage timing with HIP events recorded on the caller's stream
  * (what bench.py uses for the live roofline figure).  Enabling resets the
  * accumulators.  stage_ms returns the milliseconds accumulated per pipeline

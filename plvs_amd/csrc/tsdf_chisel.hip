@@ -41,7 +41,6 @@
 #include "tsdf_chisel_view.hpp"
 #include "tsdf_tiles.hpp"
 #include "tsdf_walk.hpp"
-#include "tsdf_walk_multi.hpp"
 #include "tsdf_shard.hpp"
 
 using namespace plvs;
@@ -910,14 +909,6 @@ struct plvs_tsdf_chisel {
   uint32_t multi_cap = 0;
   uint32_t part_segs = kPartSegs, part_min = kPartMin;   // (plvs_hip_tsdf_chisel_set_apply_parts)
   bool walk_small = false, walk_small_used = false;      // first-pass table of the order-free walk: 1024 entries instead of 2048
-  // walk_multi (tsdf_walk_multi.hpp): long depth-image calls walk a block of grid pixels of several consecutive key frames
-  // into one table.  multi_k = images per task the next call takes (halved when a call defers too many windows to the
-  // one-tile kernels, 1 = off; raised again after a stretch of calls that deferred nearly nothing)
-  uint32_t multi_k = 4, multi_calm = 0;
-  bool multi_used = false, cnt_dirty = true;
-  int multi_forced = 0;              // plvs_hip_tsdf_chisel_set_walk_windows: images per task (0: multi_k; 1: walk_fast only)
-  uint32_t multi_part = 4;           //   the first part of a call = 1 / multi_part of its images (1: no second part)
-  DevBuf<uint32_t> w_cnt;            // per voxel: visits the first part of the call in flight has counted (zero between calls)
   DevBuf<uint32_t> w_runkey, w_run_cnt, w_run_off, w_val0, w_val1;   // runs: per-tile regions of 2^run_r1_log2 slots
   int32_t* h_offsets = nullptr;      // pinned copy of the call's cloud offsets
   size_t h_offsets_cap = 0;
@@ -1256,7 +1247,6 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     if (gsrc) PLVS_LAUNCH_WALK_FAST(E, true, TILES, LIST, NLIST, DEFERRED, NDEFERRED);              \
     else PLVS_LAUNCH_WALK_FAST(E, false, TILES, LIST, NLIST, DEFERRED, NDEFERRED);                  \
   } while (0)
-    h->multi_used = false;
     if (ntiles <= kSmallCallTiles) {
       PLVS_WALK_FAST(kFastEntriesBig, ntiles, nullptr, nullptr, list_a, &h->d_wctr->ndeferred);
     } else {
@@ -1270,46 +1260,17 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
         if (force >= 0) h->walk_small = force != 0;
       }
       h->walk_small_used = h->walk_small;
-      // (round 6) a long depth-image call walks the same block of grid pixels of several consecutive key frames into one
-      // 1024-entry table (walk_multi, tsdf_walk_multi.hpp); what does not fit there is handed to the 2048-entry kernel tile by tile
-      static const int multi_env = plvs::env_int("PLVS_WALK_MULTI", -1, -1, 7);      // developer switch: images per task (0, 1: off)
-      static const int part_env = plvs::env_int("PLVS_WALK_MULTI_PART", 0, 0, 64);     //   the first part of a call = 1 / this of its images
-      const uint32_t multi_part = part_env > 0 ? (uint32_t)part_env : h->multi_part;
-      const uint32_t mk = h->multi_forced > 0 ? (uint32_t)h->multi_forced : multi_env >= 0 ? (uint32_t)multi_env : h->multi_k;
-      static const int multi_one = plvs::env_int("PLVS_WALK_MULTI_ONE", 0, 0, 1);   // (developer: one image per task THROUGH walk_multi)
-      h->multi_used = gsrc != nullptr && (mk >= 2u || (multi_one && mk == 1u)) && nclouds >= 8 && h->P.shard_count <= 1;
-      if (h->multi_used) {
-        const size_t nvox = (size_t)max_chunks * kChunkVox;
-        if (h->w_cnt.cap < nvox) {
-          PLVS_HIP_TRY(h->w_cnt.reserve(nvox));
-          h->cnt_dirty = true;
-        }
-        if (h->cnt_dirty) PLVS_HIP_TRY(hipMemsetAsync(h->w_cnt.p, 0, h->w_cnt.cap * sizeof(uint32_t), s));
-        h->cnt_dirty = true;   // (until the call has ended well: its fold leaves the plane zero)
-        MultiPlan plan;
-        plan.nimg = (uint32_t)nclouds;
-        plan.n1 = multi_part > 1 ? std::max<uint32_t>(1u, (uint32_t)nclouds / (uint32_t)multi_part) : (uint32_t)nclouds;
-        plan.k1 = plan.k2 = mk;
-        plan.g1 = (plan.n1 + plan.k1 - 1u) / plan.k1;
-        plan.tpi = grid.ntx * grid.nty;
-        static const int fill_env = plvs::env_int("PLVS_WALK_MULTI_FILL", kFastEntriesSmall * 7 / 8, 64, kFastEntriesSmall * 7 / 8);
-        plan.fill = (uint32_t)fill_env;
-        const uint32_t g2 = (plan.nimg - plan.n1 + plan.k2 - 1u) / plan.k2;
-        hipLaunchKernelGGL((walk_multi<kFastEntriesSmall>), dim3((plan.g1 + g2) * plan.tpi), dim3(kWalkRays), 0, s, h->P, h->scale_u,
-                           h->scale_w, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
-                           multi_part > 1 ? h->w_cnt.p : (uint32_t*)nullptr, out, runs, kRecStride, list_a, &h->d_wctr->ndeferred,
-                           d_grid, plan);
-      } else if (h->walk_small) PLVS_WALK_FAST(kFastEntriesSmall, ntiles, nullptr, nullptr, list_a, &h->d_wctr->ndeferred);
+      if (h->walk_small) PLVS_WALK_FAST(kFastEntriesSmall, ntiles, nullptr, nullptr, list_a, &h->d_wctr->ndeferred);
       else PLVS_WALK_FAST(kFastEntries, ntiles, nullptr, nullptr, list_a, &h->d_wctr->ndeferred);
       // the tiles that overflowed the first pass: a 1024-entry first pass hands them to the 2048-entry kernel (two tiles per CU
       // instead of one: nearly all of them fit it), a 2048-entry first pass to the 4096-entry one
-      if (h->walk_small || h->multi_used)
+      if (h->walk_small)
         PLVS_WALK_FAST(kFastEntries, std::min<unsigned>(ntiles, 2 * kListGrid), list_a, &h->d_wctr->ndeferred, list_b,
                        &h->d_wctr->ndeferred2);
       else
         PLVS_WALK_FAST(kFastEntriesBig, std::min<unsigned>(ntiles, kListGrid), list_a, &h->d_wctr->ndeferred, list_b,
                        &h->d_wctr->ndeferred2);
-      second_small = h->walk_small || h->multi_used;
+      second_small = h->walk_small;
 #undef PLVS_WALK_FAST
 #undef PLVS_LAUNCH_WALK_FAST
       last_list = list_b;
@@ -1406,8 +1367,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
         hipLaunchKernelGGL(fold_colours_masks<true>, dim3(std::min<size_t>(ceil_div(D, kFoldWaves), 8192)),
                            dim3(64 * kFoldWaves), 0, q, skeys, sval, side_ctr, rsrc, h->heads.p, d_rgb,
                            h->rgbw, &h->d_wctr[1].num_heads, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                           guard ? (const uint32_t*)guard->skip : (const uint32_t*)nullptr, grid,
-                           h->multi_used ? h->w_cnt.p : (uint32_t*)nullptr);
+                           guard ? (const uint32_t*)guard->skip : (const uint32_t*)nullptr, grid);
       else
         hipLaunchKernelGGL(fold_colours_masks<false>, dim3(std::min<size_t>(ceil_div(D, kFoldWaves), 8192)),
                            dim3(64 * kFoldWaves), 0, q, skeys, sval, side_ctr, rsrc, h->heads.p, d_rgb,
@@ -1488,7 +1448,6 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
       rc2 = read_walk_counters(h, s);
       if (rc2 != PLVS_OK) return rc2;
     }
-    if (h->multi_used) h->cnt_dirty = false;
     h->small_runs_known = true;      // (the runs of the last call, whatever its length)
     h->small_runs_last = h->h_wctr[1].num_desc;
     h->small_tiles_last = ntiles;
@@ -1496,19 +1455,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
   }
   const WalkCounters& c = *h->h_wctr;
   h->num_chunks = h->h_ctr->num_chunks;
-  if (h->multi_used) {
-    // walk_multi's windows: a call that handed more than a quarter of its tiles on to the one-tile kernels (a camera that
-    // turns quickly, walls whose tiles fill a 1024-entry table alone) takes half the images per task next time; after a
-    // stretch of calls without it the next call tries the longer task again
-    if ((size_t)c.ndeferred * 4 > ntiles) {
-      h->multi_k = std::max(1u, h->multi_k / 2u);
-      h->multi_calm = 0;
-    }
-  } else if (h->multi_k < 4u && ntiles > kSmallCallTiles && gsrc != nullptr && ++h->multi_calm >= 32u) {
-    h->multi_k *= 2u;
-    h->multi_calm = 0;
-  }
-  if (ntiles > kSmallCallTiles && !h->multi_used) {   // the first pass's table for the next call of this size class
+  if (ntiles > kSmallCallTiles) {   // the first pass's table for the next call of this size class
     // (round 5: what overflows the small table goes to the 2048-entry kernel at two tiles per CU — a fifth of the tiles there
     // still costs less than a 2048-entry first pass for all of them: 0.51 + 0.1 against 0.8 ms on the office stream, where
     // the 6 % / 2 % thresholds of round 4 had every other step fall back to the large table)
@@ -1522,9 +1469,9 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     static const bool trace = plvs::env_int("PLVS_HIP_TSDF_TRACE", 0, 0, 1) != 0;
     if (trace)
       fprintf(stderr, "[tsdf_chisel] tiles %u deferred %u split %u visits %llu runs %u updated %u parts %u multi %u "
-              "rec_top %u seg_top %u voxels %u max_run %u chunks %d [multi %d: early big %u table %u]\n", ntiles, c.ndeferred * 1000u + c.ndeferred2, c.split_tiles,
+              "rec_top %u seg_top %u voxels %u max_run %u chunks %d\n", ntiles, c.ndeferred * 1000u + c.ndeferred2, c.split_tiles,
               (unsigned long long)c.total_visits, h->h_wctr[1].num_desc, c.num_updated, c.num_parts, c.num_multi, c.rec_top,
-              c.seg_top, c.num_heads, c.max_run, h->num_chunks, (int)h->multi_used, c.ncold, c.over_small);
+              c.seg_top, c.num_heads, c.max_run, h->num_chunks);
   }
   h->stats.visits = (int64_t)c.total_visits;
   h->stats.new_chunks = h->num_chunks - chunks_before;
@@ -2260,13 +2207,6 @@ int plvs_hip_tsdf_chisel_set_apply_parts(plvs_tsdf_chisel* h, int part_segments,
   PLVS_REQUIRE(h && part_segments >= 1 && min_segments >= 1, "bad argument");
   h->part_segs = (uint32_t)part_segments;
   h->part_min = (uint32_t)min_segments;
-  return PLVS_OK;
-}
-
-int plvs_hip_tsdf_chisel_set_walk_windows(plvs_tsdf_chisel* h, int images_per_task, int first_part_divisor) {
-  PLVS_REQUIRE(h && images_per_task >= 0 && images_per_task <= 7 && first_part_divisor >= 0 && first_part_divisor <= 64, "bad argument");
-  h->multi_forced = images_per_task;       // 0 = the library's own choice
-  h->multi_part = first_part_divisor == 0 ? 4u : (uint32_t)first_part_divisor;
   return PLVS_OK;
 }
 

@@ -242,17 +242,8 @@ __device__ __forceinline__ int bucket_match(const uint4 k4, uint32_t want) {
 // the step is as slow as its slowest lane.  Entries are not counted here — the flush counts them (entries beyond
 // kWalkLimit: the (sub-)tile is cut, as when the table is full).
 constexpr int kProbeCap = 24;
-#ifndef PLVS_PROBE_NOINLINE
-#define PLVS_PROBE_NOINLINE 0   // 1: the general search as a CALL — measured slower (round 6: a wave step has a lane on this path every
-                                // other step, and a call saves and restores the caller's registers around it)
-#endif
-#if PLVS_PROBE_NOINLINE
-#define PLVS_PROBE_ATTR __attribute__((noinline))
-#else
-#define PLVS_PROBE_ATTR __forceinline__
-#endif
 template <class SH>
-__device__ PLVS_PROBE_ATTR int table_find_or_insert(SH& S, uint32_t key /* a table key */) {
+__device__ __forceinline__ int table_find_or_insert(SH& S, uint32_t key /* a table key */) {
   uint32_t b = key_bucket<SH>(key);
   // (kProbeCap: a tile within its limit — three quarters of the table — never chains that far; a table on its way to
   // full does, and every probe is an LDS round trip: without the cap the rays of an overflowing tile spent hundreds of
@@ -440,8 +431,7 @@ __device__ __forceinline__ uint32_t walk_lean(const Params& P, const Pose& pose,
   // multiplied by a zero mask: keep it finite
   const float tdx = cur.stepX ? cur.tDeltaX : 0.0f, tdy = cur.stepY ? cur.tDeltaY : 0.0f, tdz = cur.stepZ ? cur.tDeltaZ : 0.0f;
   // the visits so far, carried as the BYTE OFFSET of the ray's next slot in the visit log (visit j of ray r at
-  // [j * kWalkRays + r], 16-bit entries): one register for the count and the address — a separate log pointer was the value
-  // the allocator spilled inside this loop (a scratch reload per visit in walk_multi)
+  // [j * kWalkRays + r], 16-bit entries): one register for the count and the address instead of two
   static_assert(kWalkRays * sizeof(uint16_t) == 1024, "the count is the offset >> 10");
   uint32_t vp = (uint32_t)tid * (uint32_t)sizeof(uint16_t);
   for (int guard = 0; guard < kRayStepGuard; ++guard) {   // (the reference loop is unbounded)
@@ -2332,9 +2322,7 @@ __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
     const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ sorted_val, const uint32_t* __restrict__ nd_dev,
     RunSrc src, const uint32_t* __restrict__ vj0, const uint8_t* __restrict__ rgb, uint32_t* __restrict__ rgbw,
     const uint32_t* __restrict__ num_heads, uint32_t* __restrict__ sat_list, uint32_t* __restrict__ sat_count,
-    const uint32_t* __restrict__ skip, const GridSrc grid, uint32_t* __restrict__ cnt_reset = nullptr) {
-  // cnt_reset (walk_multi, tsdf_walk_multi.hpp): the per-voxel visit counts of the call's first part — every voxel that
-  // was counted has a run, so the fold leaves the plane zero for the next call
+    const uint32_t* __restrict__ skip, const GridSrc grid) {
   // sat_list (ray-sharded integrate): the voxels whose colour weight reaches 254 in this call
   // skip (a chain launched on predicted sizes, compact_runs): non-zero = the prediction failed, nothing here is valid
   if (skip != nullptr && *skip != 0u) return;
@@ -2653,7 +2641,6 @@ __global__ __launch_bounds__(64 * kFoldWaves) void fold_colours_masks(
         rgbw[key] = ch | (g << 8) | (bl << 16) | ((cw0 + steps) << 24);
         if (sat_list && cw0 + steps >= 254u) sat_list[atomicAdd(sat_count, 1u)] = key;
       }
-      if (cnt_reset != nullptr && active && fc == 0) cnt_reset[key] = 0u;
     }
     __builtin_amdgcn_wave_barrier();
   }

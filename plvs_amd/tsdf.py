@@ -361,14 +361,6 @@ class TsdfChisel:
         f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         _lib.check(f(self._h, int(part_segments), int(min_segments)))
 
-    def set_walk_windows(self, images_per_task=0, first_part_divisor=0):
-        """Tuning knob of the order-free walk of long depth-image calls (results do not depend on it): images of one block of
-        grid pixels a workgroup walks into one table (0 = the library's choice, 1 = one), and the part of a call whose visit
-        counts spare the rest its surplus colour runs (0 = default a quarter, 1 = off)."""
-        f = _lib.lib.plvs_hip_tsdf_chisel_set_walk_windows
-        f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
-        _lib.check(f(self._h, int(images_per_task), int(first_part_divisor)))
-
     def set_profiling(self, enable=True):
         _lib.check(_lib.lib.plvs_hip_tsdf_chisel_set_profiling(self._h, int(bool(enable))))
 
