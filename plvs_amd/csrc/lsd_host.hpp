@@ -140,16 +140,39 @@ inline ExactAxis exact_resize_axis(double inv_scale, int srcsize, int dstsize) {
 // ---------------------------------------------------------------- the detector on one level-line field
 struct Segment4 { float x1, y1, x2, y2; };
 
+// A helper thread that is joined when its owner goes out of scope, whatever way it leaves (an exception between the start
+// of a helper and its join would otherwise destroy a joinable std::thread: std::terminate inside the C ABI).
+struct JoinedThread {
+  std::thread t;
+  JoinedThread() = default;
+  explicit JoinedThread(std::thread&& th) : t(std::move(th)) {}
+  JoinedThread(JoinedThread&&) = default;
+  JoinedThread& operator=(JoinedThread&& o) {
+    if (t.joinable()) t.join();
+    t = std::move(o.t);
+    return *this;
+  }
+  ~JoinedThread() {
+    if (t.joinable()) t.join();
+  }
+};
+
 // std::sort's result — libstdc++'s introsort — with the halves of its partitions on several threads.  The reference's
 // ordering is an UNSTABLE sort whose comparator sees part of the element only: the order of equal keys is whatever this
 // implementation of std::sort does, and the only way to have it is to run its steps.  They are run here through libstdc++'s
 // own building blocks: __introsort_loop is, per range, { partition around the median of three; recurse into the right part;
 // continue with the left }, the recursion touches nothing outside its range, so the right part can go to another thread —
 // same comparisons, same moves, same array afterwards; __final_insertion_sort then runs over the whole array as std::sort does.
+// Those building blocks are private to libstdc++: the first use compares the threaded form with std::sort itself on a probe
+// (sort_threads_ok) and a library whose internals have moved on simply keeps the one-thread std::sort.
 // (tests/test_lsd.py compares with the reference's own std::sort call, compiled by g++ from its sources.)
 #if defined(__GLIBCXX__)
+struct SortPool {
+  std::vector<JoinedThread> threads;   // (joined by its destructor at the latest)
+  std::mutex mu;
+};
 template <typename It, typename Comp>
-void introsort_loop_mt(It first, It last, long depth, Comp comp, int level, std::vector<std::thread>& pool, std::mutex& mu) {
+void introsort_loop_mt(It first, It last, long depth, Comp comp, int level, SortPool& pool) {
   while (last - first > int(std::_S_threshold)) {
     if (depth == 0) {
       std::__partial_sort(first, last, last, comp);
@@ -160,9 +183,9 @@ void introsort_loop_mt(It first, It last, long depth, Comp comp, int level, std:
     bool handed_over = false;
     if (level < 3 && last - cut > 8192) {
       ++level;
-      std::lock_guard<std::mutex> g(mu);
+      std::lock_guard<std::mutex> g(pool.mu);
       try {
-        pool.emplace_back([=, &pool, &mu] { introsort_loop_mt(cut, last, depth, comp, level, pool, mu); });
+        pool.threads.emplace_back(std::thread([=, &pool] { introsort_loop_mt(cut, last, depth, comp, level, pool); }));
         handed_over = true;
       } catch (...) {   // (no thread to be had: the right part is sorted here, as std::sort would)
       }
@@ -172,33 +195,67 @@ void introsort_loop_mt(It first, It last, long depth, Comp comp, int level, std:
   }
 }
 template <typename It, typename Cmp>
-void sort_as_std(It first, It last, Cmp cmp, bool threads) {
-  if (!threads || last - first < 65536) {
-    std::sort(first, last, cmp);
-    return;
-  }
+void sort_threaded(It first, It last, Cmp cmp) {
   auto comp = __gnu_cxx::__ops::__iter_comp_iter(cmp);
-  std::vector<std::thread> pool;
-  std::mutex mu;
-  pool.reserve(16);   // (at most 7 are made; no reallocation while a worker holds a reference)
-  introsort_loop_mt(first, last, std::__lg(last - first) * 2, comp, 0, pool, mu);
+  SortPool pool;
+  pool.threads.reserve(16);   // (at most 7 are made; no reallocation while a worker holds a reference)
+  introsort_loop_mt(first, last, std::__lg(last - first) * 2, comp, 0, pool);
   for (size_t i = 0;; ++i) {
     std::thread t;
     {
-      std::lock_guard<std::mutex> g(mu);
-      if (i >= pool.size()) break;
-      t = std::move(pool[i]);
+      std::lock_guard<std::mutex> g(pool.mu);
+      if (i >= pool.threads.size()) break;
+      t = std::move(pool.threads[i].t);
     }
     t.join();
   }
   std::__final_insertion_sort(first, last, comp);
+}
+// Does the threaded form give std::sort's permutation with THIS libstdc++?  Checked once per process on 2^17 keys of 64
+// distinct bins (long runs of equal keys: the case that decides the order of LSD's seeds).
+inline bool sort_threads_ok() {
+  static const bool ok = [] {
+    std::vector<uint32_t> a((size_t)1 << 17), b;
+    uint32_t x = 2463534242u;
+    for (size_t i = 0; i < a.size(); ++i) {
+      x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+      a[i] = ((x & 63u) << 22) | (uint32_t)i;
+    }
+    b = a;
+    auto by_bin = [](const uint32_t& p, const uint32_t& q) { return (p >> 22) > (q >> 22); };
+    try {
+      sort_threaded(a.begin(), a.end(), by_bin);
+    } catch (...) {
+      return false;
+    }
+    std::sort(b.begin(), b.end(), by_bin);
+    return a == b;
+  }();
+  return ok;
+}
+template <typename It, typename Cmp>
+void sort_as_std(It first, It last, Cmp cmp, bool threads) {
+  if (!threads || last - first < 65536 || !sort_threads_ok()) {
+    std::sort(first, last, cmp);
+    return;
+  }
+  sort_threaded(first, last, cmp);
 }
 #else
 template <typename It, typename Cmp>
 void sort_as_std(It first, It last, Cmp cmp, bool) { std::sort(first, last, cmp); }
 #endif
 
-
+// One level of the detector.  What the reference does per seed (lsd_custom.cpp:461-547: grow a region of aligned pixels,
+// fit a rectangle, tighten it until it is dense, improve its NFA, keep it if meaningful) on this file's own data:
+//   * a region is a list of pixel INDICES with their coordinates (angle and gradient norm stay in the field arrays);
+//   * the rectangle's pixels are enumerated as one [first, last] column SPAN per image row (built once per rectangle,
+//     clipped to the image once per row) and counted over the row of the field — the reference tests every pixel's
+//     coordinates against the image inside its double loop;
+//   * the NFA search is ONE loop over a table of moves (halve the tolerance, narrow, shift one side in, the other, halve
+//     again) instead of five copies of the loop; log-gamma of the integer arguments the binomial tail needs is memoised.
+// The arithmetic — operand types, order of the sums (region order), which libm function — is the reference's: the segments
+// are compared bit for bit with those of its compiled sources (tests/test_lsd.py).
 class Level {
  public:
   // angles / modgrad: w x h doubles as lsd_ll_angle leaves them (angles = kNotDef where undefined; the last row and column
@@ -220,8 +277,6 @@ class Level {
     const double t_a = now_ms_();
     const size_t npx = (size_t)w * h;
     cs_.resize(2 * npx);
-    const int helpers = std::thread::hardware_concurrency() >= 4 ? 2 : 0;
-    std::thread th[2];
     auto fill_cs = [this, angles, w](int y0, int y1) {
       for (size_t at = (size_t)y0 * w, end = (size_t)y1 * w; at < end; ++at)
         if (angles[at] != kNotDef) {
@@ -229,59 +284,52 @@ class Level {
           cs_[2 * at + 1] = sinf(float(angles[at]));
         }
     };
-    bool inline_part[2] = {false, false};
-    for (int i = 0; i < helpers; ++i) {
-      try {
-        th[i] = std::thread(fill_cs, (h * i) / helpers, (h * (i + 1)) / helpers);
-      } catch (...) {   // (no thread to be had: this part after the ordering, on this one)
-        inline_part[i] = true;
+    const int helpers = std::thread::hardware_concurrency() >= 4 ? 2 : 0;
+    bool inline_part[2] = {helpers < 1, helpers < 2};
+    {
+      JoinedThread th[2];   // (joined when this block ends — also when the ordering throws)
+      for (int i = 0; i < helpers; ++i) {
+        try {
+          th[i] = JoinedThread(std::thread(fill_cs, (h * i) / helpers, (h * (i + 1)) / helpers));
+        } catch (...) {   // (no thread to be had: this part after the ordering, on this one)
+          inline_part[i] = true;
+        }
       }
+      const double bin_coef = (max_grad > 0) ? double(o.n_bins - 1) / max_grad : 0;
+      narrow_ = npx <= (size_t(1) << 22) && o.n_bins <= 1024;
+      const char* force = getenv("PLVS_LSD_SORT_THREADS");   // 0 / 1: never / always (tests); default: where there are cores to spare
+      const bool mt = force ? force[0] == '1' : std::thread::hardware_concurrency() >= 16;
+      if (narrow_) order_seeds<uint32_t, 22>(modgrad, w, h, bin_coef, keys32_, mt);
+      else order_seeds<uint64_t, 32>(modgrad, w, h, bin_coef, keys64_, mt);
     }
-    const double bin_coef = (max_grad > 0) ? double(o.n_bins - 1) / max_grad : 0;
-    const bool narrow = npx <= (size_t(1) << 22) && o.n_bins <= 1024;
-    const char* force = getenv("PLVS_LSD_SORT_THREADS");   // 0 / 1: never / always (tests); default: where there are cores to spare
-    const bool mt = force ? force[0] == '1' : std::thread::hardware_concurrency() >= 16;
-    if (narrow) order_seeds<uint32_t, 22>(modgrad, w, h, bin_coef, keys32_, mt);
-    else order_seeds<uint64_t, 32>(modgrad, w, h, bin_coef, keys64_, mt);
-    const size_t nseeds = narrow ? keys32_.size() : keys64_.size();
     if (helpers == 0) fill_cs(0, h);
-    for (int i = 0; i < helpers; ++i) {
-      if (inline_part[i]) fill_cs((h * i) / helpers, (h * (i + 1)) / helpers);
-      else th[i].join();
-    }
+    else
+      for (int i = 0; i < helpers; ++i)
+        if (inline_part[i]) fill_cs((h * i) / helpers, (h * (i + 1)) / helpers);
+    const size_t nseeds = narrow_ ? keys32_.size() : keys64_.size();
     ms_order = now_ms_() - t_a;
 
     const double prec = kPi * o.ang_th / 180;
     const double p = o.ang_th / 180;
     log_nt_ = 5 * (std::log10(double(w)) + std::log10(double(h))) / 2 + std::log10(11.0);
     const size_t min_reg_size = size_t(-log_nt_ / std::log10(p));
-    used_.assign((size_t)w * h, 0);
-    std::vector<Pt> reg;
+    used_.assign(npx, 0);
     for (size_t i = 0; i < nseeds; ++i) {
-      const size_t at = narrow ? size_t(keys32_[i] & ((1u << 22) - 1)) : size_t(keys64_[i] & 0xffffffffull);
+      const size_t at = narrow_ ? size_t(keys32_[i] & ((1u << 22) - 1)) : size_t(keys64_[i] & 0xffffffffull);
       if (used_[at] != 0 || angles[at] == kNotDef) continue;
-      double reg_angle;
-      grow(int(at % (size_t)w), int(at / (size_t)w), reg, reg_angle, prec);
-      if (reg.size() < min_reg_size) continue;
-      Rect rec;
-      to_rect(reg, reg_angle, prec, p, rec);
-      double log_nfa = -1;
+      double run_angle = collect(at, prec);
+      if (px_.size() < min_reg_size) continue;
+      Box box;
+      fit_box(run_angle, prec, p, box);
       if (o.refine > 0) {
-        if (!refine(reg, reg_angle, prec, p, rec, o.density_th)) continue;
-        if (o.refine >= 2) {
-          log_nfa = improve(rec, o.log_eps);
-          if (log_nfa <= o.log_eps) continue;
-        }
+        if (!make_dense(run_angle, prec, p, box, o.density_th)) continue;
+        if (o.refine >= 2 && best_nfa(box, o.log_eps) <= o.log_eps) continue;
       }
-      (void)log_nfa;
-      rec.x1 += 0.5; rec.y1 += 0.5;
-      rec.x2 += 0.5; rec.y2 += 0.5;
-      if (o.scale != 1) {
-        rec.x1 /= o.scale; rec.y1 /= o.scale;
-        rec.x2 /= o.scale; rec.y2 /= o.scale;
-        rec.width /= o.scale;
-      }
-      out.push_back(Segment4{float(rec.x1), float(rec.y1), float(rec.x2), float(rec.y2)});
+      // (:523-537) half a pixel, then back to the scale of the input
+      double e[4] = {box.ax + 0.5, box.ay + 0.5, box.bx + 0.5, box.by + 0.5};
+      if (o.scale != 1)
+        for (double& v : e) v /= o.scale;
+      out.push_back(Segment4{float(e[0]), float(e[1]), float(e[2]), float(e[3])});
     }
     ms_regions = now_ms_() - t_a - ms_order;
   }
@@ -299,306 +347,250 @@ class Level {
     }
     sort_as_std(keys.begin(), keys.end(), [](const K& a, const K& b) { return (a >> kShift) > (b >> kShift); }, threads);
   }
-  struct Pt { int x, y; double angle, modgrad; };   // RegionPoint (its `used` pointer is the index y w + x)
-  struct Rect {
-    double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p;
+
+  struct Px { uint32_t at; int32_t x, y; };   // a pixel of the region in hand: index in the field, coordinates
+  struct Box {                                // a region's rectangle, in the numbers the reference's NFA moves act on
+    double ax, ay, bx, by;                    //   ends of the axis (rect::x1, y1, x2, y2)
+    double width, theta, ux, uy;              //   width, direction and its unit vector (dx, dy)
+    double prec, p;                           //   angle tolerance and the probability that goes with it
   };
   const double* ang_ = nullptr;
   const double* mod_ = nullptr;
   int w_ = 0, h_ = 0;
+  bool narrow_ = true;
   double log_nt_ = 0;
   std::vector<uint32_t> keys32_;
   std::vector<uint64_t> keys64_;
   std::vector<float> cs_;          // cosf, sinf of the angle of every defined pixel
   std::vector<uint8_t> used_;
+  std::vector<Px> px_;             // the region in hand, in the order its pixels joined
+  std::vector<double> lgam_;       // log_gamma(m) for integer m, as far as asked for (NaN: not yet)
+  struct Span { int y, x0, x1; };
+  mutable std::vector<Span> spans_;
 
   static double now_ms_() {
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
   }
-  static double dist2(double x1, double y1, double x2, double y2) { return (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1); }
-  static double dist(double x1, double y1, double x2, double y2) { return std::sqrt(dist2(x1, y1, x2, y2)); }
-  static double diff_signed(double a, double b) {
-    double d = a - b;
+  static double sq_dist(double x1, double y1, double x2, double y2) { return (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1); }
+  static double wrap_pi(double d) {   // angle_diff_signed's result for the difference d (:1090-1097)
     while (d <= -kPi) d += (2 * kPi);
     while (d > kPi) d -= (2 * kPi);
     return d;
   }
-  static double diff_abs(double a, double b) { return std::fabs(diff_signed(a, b)); }
-  static bool rel_equal(double a, double b) {
-    if (a == b) return true;
-    const double abs_diff = std::fabs(a - b), aa = std::fabs(a), bb = std::fabs(b);
-    double abs_max = (aa > bb) ? aa : bb;
-    if (abs_max < DBL_MIN) abs_max = DBL_MIN;
-    return (abs_diff / abs_max) <= (100.0 * DBL_EPSILON);
-  }
-
-  bool aligned(int x, int y, double theta, double prec) const {   // isAligned :1121-1137
-    if (x < 0 || y < 0 || x >= w_ || y >= h_) return false;
-    const double a = ang_[(size_t)y * w_ + x];
+  // isAligned (:1121-1137) for a pixel inside the field
+  static bool within(double a, double theta, double tol) {
     if (a == kNotDef) return false;
-    double n_theta = theta - a;
-    if (n_theta < 0) n_theta = -n_theta;
-    if (n_theta > (3 * kPi) / 2) {
-      n_theta -= (2 * kPi);
-      if (n_theta < 0) n_theta = -n_theta;
-    }
-    return n_theta <= prec;
+    double d = std::fabs(theta - a);
+    if (d > (3 * kPi) / 2) d = std::fabs(d - (2 * kPi));
+    return d <= tol;
   }
 
-  // region_grow :613-668.  The running direction is summed in float; each new point contributes the FLOAT cosine / sine of
-  // its angle rounded to float (`cos(float(angle))`: with the reference's includes the unqualified name resolves to the
-  // float overload, i.e. libm's cosf / sinf — checked on the object code of the compiled reference).
-  void grow(int sx, int sy, std::vector<Pt>& reg, double& reg_angle, double prec) {
-    reg.clear();
-    const size_t s_at = (size_t)sy * w_ + sx;
-    reg_angle = ang_[s_at];
-    reg.push_back(Pt{sx, sy, reg_angle, mod_[s_at]});
-    float sumdx = float(std::cos(reg_angle));
-    float sumdy = float(std::sin(reg_angle));
-    used_[s_at] = 1;
-    for (size_t i = 0; i < reg.size(); ++i) {
-      const int px = reg[i].x, py = reg[i].y;
-      const int xx_min = std::max(px - 1, 0), xx_max = std::min(px + 1, w_ - 1);
-      const int yy_min = std::max(py - 1, 0), yy_max = std::min(py + 1, h_ - 1);
-      for (int yy = yy_min; yy <= yy_max; ++yy) {
-        for (int xx = xx_min; xx <= xx_max; ++xx) {
-          const size_t at = (size_t)yy * w_ + xx;
-          if (used_[at] != 1 && aligned(xx, yy, reg_angle, prec)) {
-            const double angle = ang_[at];
-            used_[at] = 1;
-            reg.push_back(Pt{xx, yy, angle, mod_[at]});
-            sumdx += cs_[2 * at];        // cosf(float(angle))
-            sumdy += cs_[2 * at + 1];    // sinf(float(angle))
-            reg_angle = fast_atan2_deg(sumdy, sumdx) * kDegToRad;
+  // region_grow (:613-668) from the pixel `seed` with tolerance `tol`: px_ = the region, the return value its direction.
+  // A pixel joins when it is free and within `tol` of the direction the region has at that moment; the direction is the
+  // angle of the FLOAT sum of the members' (cosf, sinf) — `cos(float(angle))` resolves to the float overload in the
+  // reference (checked on its object code) — so the order of the 3 x 3 scan (rows, then columns) is part of the result.
+  double collect(size_t seed, double tol) {
+    px_.clear();
+    double dir = ang_[seed];
+    px_.push_back(Px{(uint32_t)seed, int32_t(seed % (size_t)w_), int32_t(seed / (size_t)w_)});
+    float sx = float(std::cos(dir)), sy = float(std::sin(dir));   // (the seed's own terms: double functions, rounded)
+    used_[seed] = 1;
+    for (size_t i = 0; i < px_.size(); ++i) {
+      const Px c = px_[i];
+      const int x_lo = c.x > 0 ? c.x - 1 : 0, x_hi = c.x + 1 < w_ ? c.x + 1 : w_ - 1;
+      const int y_lo = c.y > 0 ? c.y - 1 : 0, y_hi = c.y + 1 < h_ ? c.y + 1 : h_ - 1;
+      for (int y = y_lo; y <= y_hi; ++y) {
+        const size_t row = (size_t)y * w_;
+        for (int x = x_lo; x <= x_hi; ++x) {
+          const size_t at = row + x;
+          if (used_[at] == 1 || !within(ang_[at], dir, tol)) continue;
+          used_[at] = 1;
+          px_.push_back(Px{(uint32_t)at, x, y});
+          sx += cs_[2 * at];
+          sy += cs_[2 * at + 1];
+          dir = fast_atan2_deg(sy, sx) * kDegToRad;
+        }
+      }
+    }
+    return dir;
+  }
+
+  // region2rect + get_theta (:670-757): gradient-weighted centroid, direction of the smallest inertia, extent along and
+  // across it.  Three passes in region order (the sums are doubles: their order is the result).
+  void fit_box(double dir, double prec, double p, Box& b) const {
+    double mx = 0, my = 0, mass = 0;
+    for (const Px& q : px_) {
+      const double m = mod_[q.at];
+      mx += double(q.x) * m;
+      my += double(q.y) * m;
+      mass += m;
+    }
+    mx /= mass;
+    my /= mass;
+    double ixx = 0.0, iyy = 0.0, ixy = 0.0;
+    for (const Px& q : px_) {
+      const double m = mod_[q.at], rx = double(q.x) - mx, ry = double(q.y) - my;
+      ixx += ry * ry * m;
+      iyy += rx * rx * m;
+      ixy -= rx * ry * m;
+    }
+    const double small = 0.5 * (ixx + iyy - std::sqrt((ixx - iyy) * (ixx - iyy) + 4.0 * ixy * ixy));   // smallest eigenvalue
+    double th = (std::fabs(ixx) > std::fabs(iyy)) ? double(fast_atan2_deg(float(small - ixx), float(ixy)))
+                                                  : double(fast_atan2_deg(float(ixy), float(small - iyy)));
+    th *= kDegToRad;
+    if (std::fabs(wrap_pi(th - dir)) > prec) th += kPi;
+    const double ux = std::cos(th), uy = std::sin(th);
+    double along_lo = 0, along_hi = 0, across_lo = 0, across_hi = 0;
+    for (const Px& q : px_) {
+      const double rx = double(q.x) - mx, ry = double(q.y) - my;
+      const double along = rx * ux + ry * uy, across = -rx * uy + ry * ux;
+      if (along > along_hi) along_hi = along;
+      else if (along < along_lo) along_lo = along;
+      if (across > across_hi) across_hi = across;
+      else if (across < across_lo) across_lo = across;
+    }
+    b.ax = mx + along_lo * ux;
+    b.ay = my + along_lo * uy;
+    b.bx = mx + along_hi * ux;
+    b.by = my + along_hi * uy;
+    b.width = across_hi - across_lo;
+    if (b.width < 1.0) b.width = 1.0;
+    b.theta = th;
+    b.ux = ux;
+    b.uy = uy;
+    b.prec = prec;
+    b.p = p;
+  }
+  double density(const Box& b) const { return double(px_.size()) / (std::sqrt(sq_dist(b.ax, b.ay, b.bx, b.by)) * b.width); }
+
+  // refine + reduce_region_radius (:759-852): a region too sparse for its rectangle is grown again from its first pixel
+  // with the tolerance its pixels near that one suggest (twice their standard deviation), and if that is not enough it
+  // loses the pixels beyond a radius that shrinks by a quarter per round.  false: nothing worth a rectangle is left.
+  bool make_dense(double dir, double prec, double p, Box& b, double want) {
+    if (density(b) >= want) return true;
+    const Px first = px_[0];
+    const double fx = double(first.x), fy = double(first.y), fa = ang_[first.at];
+    double s1 = 0, s2 = 0;
+    int near = 0;
+    for (const Px& q : px_) {
+      used_[q.at] = 0;
+      if (std::sqrt(sq_dist(fx, fy, q.x, q.y)) < b.width) {
+        const double d = wrap_pi(ang_[q.at] - fa);
+        s1 += d;
+        s2 += d * d;
+        ++near;
+      }
+    }
+    const double mean = s1 / double(near);
+    const double tol = 2.0 * std::sqrt((s2 - 2.0 * mean * s1) / double(near) + mean * mean);
+    dir = collect(first.at, tol);
+    if (px_.size() < 2) return false;
+    fit_box(dir, prec, p, b);
+    double have = density(b);
+    if (have >= want) return true;
+    const double ra = sq_dist(fx, fy, b.ax, b.ay), rb = sq_dist(fx, fy, b.bx, b.by);
+    double r2 = ra > rb ? ra : rb;
+    while (have < want) {
+      r2 *= 0.75 * 0.75;
+      for (size_t i = 0; i < px_.size();) {   // (a pixel that goes is replaced by the last one, which is looked at next)
+        if (sq_dist(fx, fy, double(px_[i].x), double(px_[i].y)) > r2) {
+          used_[px_[i].at] = 0;
+          px_[i] = px_.back();
+          px_.pop_back();
+        } else {
+          ++i;
+        }
+      }
+      if (px_.size() < 2) return false;
+      fit_box(dir, prec, p, b);
+      have = density(b);
+    }
+    return true;
+  }
+
+  // rect_improve (:854-956): five kinds of move, each tried up to five times on the rectangle the previous tries left; a
+  // try that raises the NFA replaces the best rectangle; a kind is skipped once the best is meaningful.
+  //   0 halve the tolerance      1 narrow by half a pixel      2 / 3 move one long side in by a quarter pixel (and narrow)
+  //   4 halve the tolerance, only while the rectangle could still be narrowed
+  double best_nfa(Box& best, double log_eps) {
+    const double step = 0.5, half_step = step / 2.0;
+    double top = box_nfa(best);
+    for (int kind = 0; kind < 5 && top <= log_eps; ++kind) {
+      Box t = best;
+      for (int n = 0; n < 5; ++n) {
+        if (kind != 0 && !((t.width - step) >= 0.5)) continue;
+        if (kind == 0 || kind == 4) {
+          t.p /= 2;
+          t.prec = t.p * kPi;
+        } else {
+          if (kind == 2) {
+            t.ax += -t.uy * half_step; t.ay += t.ux * half_step;
+            t.bx += -t.uy * half_step; t.by += t.ux * half_step;
+          } else if (kind == 3) {
+            t.ax -= -t.uy * half_step; t.ay -= t.ux * half_step;
+            t.bx -= -t.uy * half_step; t.by -= t.ux * half_step;
           }
+          t.width -= step;
+        }
+        const double v = box_nfa(t);
+        if (v > top) {
+          top = v;
+          best = t;
         }
       }
     }
+    return top;
   }
 
-  double theta_of(const std::vector<Pt>& reg, double x, double y, double reg_angle, double prec) const {   // get_theta :723-757
-    double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
-    for (size_t i = 0; i < reg.size(); ++i) {
-      const double regx = reg[i].x, regy = reg[i].y, weight = reg[i].modgrad;
-      const double dx = regx - x, dy = regy - y;
-      Ixx += dy * dy * weight;
-      Iyy += dx * dx * weight;
-      Ixy -= dx * dy * weight;
+  // rect_nfa (:958-1081): pixels of the rectangle and how many of them are aligned with it.  The reference walks the rows
+  // between the lowest and the highest corner with two edges that start at the lowest corner and advance by INTEGER
+  // quotients of corner differences (it divides ints), switching to a second slope at the rows of the left and the right
+  // corner; the second slopes compare a row with the fourth corner's COLUMN (`tailp->p.x`): as written there.  Rows outside
+  // the image advance nothing.
+  double box_nfa(const Box& b) const {
+    const double hw = b.width / 2.0, ox = b.uy * hw, oy = b.ux * hw;
+    struct Corner { int x, y; };
+    Corner c[4] = {{int(b.ax - ox), int(b.ay + oy)}, {int(b.bx - ox), int(b.by + oy)},
+                   {int(b.bx + ox), int(b.by - oy)}, {int(b.ax + ox), int(b.ay - oy)}};
+    for (int i = 1; i < 4; ++i)   // by column, then row (four elements: insertion)
+      for (int j = i; j > 0 && (c[j].x < c[j - 1].x || (c[j].x == c[j - 1].x && c[j].y < c[j - 1].y)); --j) std::swap(c[j], c[j - 1]);
+    int low = 0, high = 0;        // first of the lowest / highest rows
+    for (int i = 1; i < 4; ++i) {
+      if (c[low].y > c[i].y) low = i;
+      if (c[high].y < c[i].y) high = i;
     }
-    const double lambda = 0.5 * (Ixx + Iyy - std::sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
-    double theta = (std::fabs(Ixx) > std::fabs(Iyy)) ? double(fast_atan2_deg(float(lambda - Ixx), float(Ixy)))
-                                                     : double(fast_atan2_deg(float(Ixy), float(lambda - Iyy)));
-    theta *= kDegToRad;
-    if (diff_abs(theta, reg_angle) > prec) theta += kPi;
-    return theta;
-  }
-
-  void to_rect(const std::vector<Pt>& reg, double reg_angle, double prec, double p, Rect& rec) const {   // region2rect :670-721
-    double x = 0, y = 0, sum = 0;
-    for (size_t i = 0; i < reg.size(); ++i) {
-      const double weight = reg[i].modgrad;
-      x += double(reg[i].x) * weight;
-      y += double(reg[i].y) * weight;
-      sum += weight;
-    }
-    x /= sum;
-    y /= sum;
-    const double theta = theta_of(reg, x, y, reg_angle, prec);
-    const double dx = std::cos(theta), dy = std::sin(theta);
-    double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
-    for (size_t i = 0; i < reg.size(); ++i) {
-      const double regdx = double(reg[i].x) - x, regdy = double(reg[i].y) - y;
-      const double l = regdx * dx + regdy * dy;
-      const double w = -regdx * dy + regdy * dx;
-      if (l > l_max) l_max = l;
-      else if (l < l_min) l_min = l;
-      if (w > w_max) w_max = w;
-      else if (w < w_min) w_min = w;
-    }
-    rec.x1 = x + l_min * dx;
-    rec.y1 = y + l_min * dy;
-    rec.x2 = x + l_max * dx;
-    rec.y2 = y + l_max * dy;
-    rec.width = w_max - w_min;
-    rec.x = x;
-    rec.y = y;
-    rec.theta = theta;
-    rec.dx = dx;
-    rec.dy = dy;
-    rec.prec = prec;
-    rec.p = p;
-    if (rec.width < 1.0) rec.width = 1.0;
-  }
-
-  bool refine(std::vector<Pt>& reg, double reg_angle, double prec, double p, Rect& rec, double density_th) {   // :759-813
-    double density = double(reg.size()) / (dist(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
-    if (density >= density_th) return true;
-    const double xc = double(reg[0].x), yc = double(reg[0].y), ang_c = reg[0].angle;
-    double sum = 0, s_sum = 0;
-    int n = 0;
-    for (size_t i = 0; i < reg.size(); ++i) {
-      used_[(size_t)reg[i].y * w_ + reg[i].x] = 0;
-      if (dist(xc, yc, reg[i].x, reg[i].y) < rec.width) {
-        const double ang_d = diff_signed(reg[i].angle, ang_c);
-        sum += ang_d;
-        s_sum += ang_d * ang_d;
-        ++n;
-      }
-    }
-    const double mean_angle = sum / double(n);
-    const double tau = 2.0 * std::sqrt((s_sum - 2.0 * mean_angle * sum) / double(n) + mean_angle * mean_angle);
-    const int rx = reg[0].x, ry = reg[0].y;
-    grow(rx, ry, reg, reg_angle, tau);
-    if (reg.size() < 2) return false;
-    to_rect(reg, reg_angle, prec, p, rec);
-    density = double(reg.size()) / (dist(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
-    if (density < density_th) return shrink(reg, reg_angle, prec, p, rec, density, density_th);
-    return true;
-  }
-
-  bool shrink(std::vector<Pt>& reg, double reg_angle, double prec, double p, Rect& rec, double density, double density_th) {   // :815-852
-    const double xc = double(reg[0].x), yc = double(reg[0].y);
-    const double r1 = dist2(xc, yc, rec.x1, rec.y1), r2 = dist2(xc, yc, rec.x2, rec.y2);
-    double rad2 = r1 > r2 ? r1 : r2;
-    while (density < density_th) {
-      rad2 *= 0.75 * 0.75;
-      for (size_t i = 0; i < reg.size(); ++i) {
-        if (dist2(xc, yc, double(reg[i].x), double(reg[i].y)) > rad2) {
-          used_[(size_t)reg[i].y * w_ + reg[i].x] = 0;
-          std::swap(reg[i], reg[reg.size() - 1]);
-          reg.pop_back();
-          --i;
-        }
-      }
-      if (reg.size() < 2) return false;
-      to_rect(reg, reg_angle, prec, p, rec);
-      density = double(reg.size()) / (dist(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
-    }
-    return true;
-  }
-
-  double improve(Rect& rec, double log_eps) const {   // rect_improve :854-956
-    const double delta = 0.5, delta_2 = delta / 2.0;
-    double log_nfa = rect_nfa(rec);
-    if (log_nfa > log_eps) return log_nfa;
-    Rect r = rec;
-    for (int n = 0; n < 5; ++n) {
-      r.p /= 2;
-      r.prec = r.p * kPi;
-      const double v = rect_nfa(r);
-      if (v > log_nfa) { log_nfa = v; rec = r; }
-    }
-    if (log_nfa > log_eps) return log_nfa;
-    r = rec;
-    for (unsigned n = 0; n < 5; ++n) {
-      if ((r.width - delta) >= 0.5) {
-        r.width -= delta;
-        const double v = rect_nfa(r);
-        if (v > log_nfa) { rec = r; log_nfa = v; }
-      }
-    }
-    if (log_nfa > log_eps) return log_nfa;
-    r = rec;
-    for (unsigned n = 0; n < 5; ++n) {
-      if ((r.width - delta) >= 0.5) {
-        r.x1 += -r.dy * delta_2;
-        r.y1 += r.dx * delta_2;
-        r.x2 += -r.dy * delta_2;
-        r.y2 += r.dx * delta_2;
-        r.width -= delta;
-        const double v = rect_nfa(r);
-        if (v > log_nfa) { rec = r; log_nfa = v; }
-      }
-    }
-    if (log_nfa > log_eps) return log_nfa;
-    r = rec;
-    for (unsigned n = 0; n < 5; ++n) {
-      if ((r.width - delta) >= 0.5) {
-        r.x1 -= -r.dy * delta_2;
-        r.y1 -= r.dx * delta_2;
-        r.x2 -= -r.dy * delta_2;
-        r.y2 -= r.dx * delta_2;
-        r.width -= delta;
-        const double v = rect_nfa(r);
-        if (v > log_nfa) { rec = r; log_nfa = v; }
-      }
-    }
-    if (log_nfa > log_eps) return log_nfa;
-    r = rec;
-    for (unsigned n = 0; n < 5; ++n) {
-      if ((r.width - delta) >= 0.5) {
-        r.p /= 2;
-        r.prec = r.p * kPi;
-        const double v = rect_nfa(r);
-        if (v > log_nfa) { rec = r; log_nfa = v; }
-      }
-    }
-    return log_nfa;
-  }
-
-  // rect_nfa :958-1081: the rectangle's pixels are walked between two edges that advance by INTEGER-quotient steps (the
-  // reference divides ints) and whose second slopes compare a y with an x (`tailp->p.x`): reproduced as written.
-  double rect_nfa(const Rect& rec) const {
-    int total_pts = 0, alg_pts = 0;
-    const double half_width = rec.width / 2.0;
-    const double dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
-    struct Corner { int x, y; bool taken; };
-    Corner c[4];
-    c[0] = Corner{int(rec.x1 - dyhw), int(rec.y1 + dxhw), false};
-    c[1] = Corner{int(rec.x2 - dyhw), int(rec.y2 + dxhw), false};
-    c[2] = Corner{int(rec.x2 + dyhw), int(rec.y2 - dxhw), false};
-    c[3] = Corner{int(rec.x1 + dyhw), int(rec.y1 - dxhw), false};
-    std::sort(c, c + 4, [](const Corner& a, const Corner& b) { return a.x == b.x ? a.y < b.y : a.x < b.x; });
-    Corner* min_y = &c[0];
-    Corner* max_y = &c[0];
-    for (unsigned i = 1; i < 4; ++i) {
-      if (min_y->y > c[i].y) min_y = &c[i];
-      if (max_y->y < c[i].y) max_y = &c[i];
-    }
-    min_y->taken = true;
-    Corner* leftmost = nullptr;
-    for (unsigned i = 0; i < 4; ++i)
-      if (!c[i].taken) {
-        if (!leftmost) leftmost = &c[i];
-        else if (leftmost->x > c[i].x) leftmost = &c[i];
-      }
-    leftmost->taken = true;
-    Corner* rightmost = nullptr;
-    for (unsigned i = 0; i < 4; ++i)
-      if (!c[i].taken) {
-        if (!rightmost) rightmost = &c[i];
-        else if (rightmost->x < c[i].x) rightmost = &c[i];
-      }
-    rightmost->taken = true;
-    Corner* tailp = nullptr;
-    for (unsigned i = 0; i < 4; ++i)
-      if (!c[i].taken) {
-        if (!tailp) tailp = &c[i];
-        else if (tailp->x > c[i].x) tailp = &c[i];
-      }
-    tailp->taken = true;
-    const double flstep = (min_y->y != leftmost->y) ? (min_y->x - leftmost->x) / (min_y->y - leftmost->y) : 0;
-    const double slstep = (leftmost->y != tailp->x) ? (leftmost->x - tailp->x) / (leftmost->y - tailp->x) : 0;
-    const double frstep = (min_y->y != rightmost->y) ? (min_y->x - rightmost->x) / (min_y->y - rightmost->y) : 0;
-    const double srstep = (rightmost->y != tailp->x) ? (rightmost->x - tailp->x) / (rightmost->y - tailp->x) : 0;
-    double lstep = flstep, rstep = frstep;
-    double left_x = min_y->x, right_x = min_y->x;
-    const int min_iter = min_y->y, max_iter = max_y->y;
-    for (int y = min_iter; y <= max_iter; ++y) {
+    // of the other three (still in column order): the first is the left corner, the first of the largest column among the
+    // remaining two the right one, the last the fourth
+    int rest[3], nr = 0;
+    for (int i = 0; i < 4; ++i)
+      if (i != low) rest[nr++] = i;
+    const int left = rest[0];
+    const int right = c[rest[1]].x < c[rest[2]].x ? rest[2] : rest[1];
+    const int fourth = right == rest[1] ? rest[2] : rest[1];
+    auto slope = [](int dx, int dy) { return dy != 0 ? double(dx / dy) : 0.0; };
+    const double l1 = slope(c[low].x - c[left].x, c[low].y - c[left].y), l2 = slope(c[left].x - c[fourth].x, c[left].y - c[fourth].x);
+    const double r1 = slope(c[low].x - c[right].x, c[low].y - c[right].y), r2 = slope(c[right].x - c[fourth].x, c[right].y - c[fourth].x);
+    spans_.clear();
+    double lx = c[low].x, rx = c[low].x, ls = l1, rs = r1;
+    for (int y = c[low].y; y <= c[high].y; ++y) {
       if (y < 0 || y >= h_) continue;
-      for (int x = int(left_x); x <= int(right_x); ++x) {
-        if (x < 0 || x >= w_) continue;
-        ++total_pts;
-        if (aligned(x, y, rec.theta, rec.prec)) ++alg_pts;
-      }
-      if (y >= leftmost->y) lstep = slstep;
-      if (y >= rightmost->y) rstep = srstep;
-      left_x += lstep;
-      right_x += rstep;
+      spans_.push_back(Span{y, int(lx), int(rx)});
+      if (y >= c[left].y) ls = l2;
+      if (y >= c[right].y) rs = r2;
+      lx += ls;
+      rx += rs;
     }
-    return nfa(total_pts, alg_pts, rec.p);
+    int total = 0, good = 0;
+    for (const Span& sp : spans_) {
+      const int x0 = sp.x0 > 0 ? sp.x0 : 0, x1 = sp.x1 < w_ - 1 ? sp.x1 : w_ - 1;
+      if (x1 < x0) continue;
+      total += x1 - x0 + 1;
+      const double* row = ang_ + (size_t)sp.y * w_;
+      for (int x = x0; x <= x1; ++x) good += within(row[x], b.theta, b.prec) ? 1 : 0;
+    }
+    return tail_nfa(total, good, b.p);
   }
 
   static double lgamma_w(double x) {   // log_gamma_windschitl
@@ -614,32 +606,39 @@ class Level {
     }
     return a + std::log(b);
   }
-  static double lgamma_(double x) { return x > 15.0 ? lgamma_w(x) : lgamma_l(x); }
+  double lgamma_int(int m) const {   // log_gamma(double(m)), memoised (the same call on the same argument)
+    std::vector<double>& t = const_cast<std::vector<double>&>(lgam_);
+    if ((size_t)m >= t.size()) t.resize((size_t)m + 1024, std::nan(""));
+    if (t[(size_t)m] != t[(size_t)m]) t[(size_t)m] = double(m) > 15.0 ? lgamma_w(double(m)) : lgamma_l(double(m));
+    return t[(size_t)m];
+  }
 
-  double nfa(int n, int k, double p) const {   // :1083-1119
+  // nfa (:1083-1119): -log10 of the number of false alarms of k aligned pixels among n at probability p — the binomial
+  // tail, summed until the rest is provably below a tenth of the result.  (Its first term carries `n + 1` where the formula
+  // has log_gamma(n + 1): as in the reference.)
+  double tail_nfa(int n, int k, double p) const {
     if (n == 0 || k == 0) return -log_nt_;
     if (n == k) return -log_nt_ - double(n) * std::log10(p);
-    const double p_term = p / (1 - p);
-    const double log1term = (double(n) + 1) - lgamma_(double(k) + 1) - lgamma_(double(n - k) + 1) + double(k) * std::log(p) +
-                            double(n - k) * std::log(1.0 - p);
-    double term = std::exp(log1term);
-    if (rel_equal(term, 0)) {
-      if (k > n * p) return -log1term / 2.30258509299404568402 - log_nt_;
-      return -log_nt_;
+    const double odds = p / (1 - p);
+    const double log_first = (double(n) + 1) - lgamma_int(k + 1) - lgamma_int(n - k + 1) + double(k) * std::log(p) +
+                             double(n - k) * std::log(1.0 - p);
+    double term = std::exp(log_first);
+    {   // double_equal(term, 0): relative difference within 100 epsilon
+      const double mag = std::fabs(term) < DBL_MIN ? DBL_MIN : std::fabs(term);
+      if (term == 0.0 || (std::fabs(term) / mag) <= (100.0 * DBL_EPSILON))
+        return (k > n * p) ? -log_first / 2.30258509299404568402 - log_nt_ : -log_nt_;
     }
-    double bin_tail = term;
-    const double tolerance = 0.1;
+    double tail = term;
     for (int i = k + 1; i <= n; ++i) {
-      const double bin_term = double(n - i + 1) / double(i);
-      const double mult_term = bin_term * p_term;
-      term *= mult_term;
-      bin_tail += term;
-      if (bin_term < 1) {
-        const double err = term * ((1 - std::pow(mult_term, double(n - i + 1))) / (1 - mult_term) - 1);
-        if (err < tolerance * std::fabs(-std::log10(bin_tail) - log_nt_) * bin_tail) break;
+      const double ratio = double(n - i + 1) / double(i), mult = ratio * odds;
+      term *= mult;
+      tail += term;
+      if (ratio < 1) {
+        const double rest = term * ((1 - std::pow(mult, double(n - i + 1))) / (1 - mult) - 1);
+        if (rest < 0.1 * std::fabs(-std::log10(tail) - log_nt_) * tail) break;
       }
     }
-    return -std::log10(bin_tail) - log_nt_;
+    return -std::log10(tail) - log_nt_;
   }
 };
 
