@@ -33,6 +33,8 @@ extern "C" {
 #define PLVS_ERR_CAPACITY (-4)    /* a fixed-capacity device structure overflowed */
 #define PLVS_ERR_EMPTY (-5)       /* empty input where the reference bails out */
 #define PLVS_ERR_HALO (-6)        /* sharded map: chunks of other ranks are needed first (plvs_hip_tsdf_chisel_halo_*) */
+#define PLVS_ERR_COMM_FATAL (-7)  /* a sharded step failed past its counts exchange with no way through its collectives:  */
+                                  /* abort / destroy the communicator on every rank, rebuild the sharded map           */
 
 /* Human-readable description of the last error on the calling thread. */
 const char* plvs_hip_last_error(void);
@@ -565,7 +567,8 @@ int plvs_hip_tsdf_chisel_integrate_batch_dev(plvs_tsdf_chisel* h, const float* d
  *   d_bgr          image c at d_bgr + c * bgr_image_stride (bytes), rows bgr_pitch bytes apart, 3 bytes per pixel
  *   d_grid_points  matCamGridPoints_ (plvs_hip_cloudgen_grid_points), ceil(height / step) x ceil(width / step) x 2 floats
  *   d_kfid         one key-frame id per image (may be NULL: 0)
- * Asynchronous on `stream` except for the call's one read of its counters.  plvs_tsdf_stats.points is 0 after a call on
+ * Asynchronous on `stream` except for the call's one read of its counters (an ordered, sharded or deforming handle builds
+ * the reference's clouds in scratch memory first and waits once more, for their sizes).  plvs_tsdf_stats.points is 0 after a call on
  * an order-free handle (the cloud is never formed); ordered handles report the points of the clouds they built. */
 typedef struct plvs_depth_batch {
   const float* d_depth;
@@ -702,6 +705,15 @@ int plvs_hip_tsdf_chisel_shard_note_gathered(plvs_tsdf_chisel* h, const int32_t*
 int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm, const float* d_xyz,
                                            const uint8_t* d_rgb, const uint32_t* d_kfid, const int32_t* offsets,
                                            int nclouds, const float* d_Twc, void* stream);
+/* Errors of the *_integrate_sharded calls.  Before a step's counts exchange a failing rank announces it (-1 counts): no rank
+ * applies anything, the failing rank returns its error, the others PLVS_ERR_HALO, the maps are as before.  After it a rank
+ * that cannot go through the step's collectives (exchange buffers cannot be allocated, RCCL itself fails) returns
+ * PLVS_ERR_COMM_FATAL and LEAVES THE COMMUNICATOR ALONE — it is the caller's (e.g. torch's ProcessGroup): the caller must
+ * abort or destroy it on every rank (the peers are inside collectives this rank will not enter; they leave them through
+ * their own abort or RCCL's watchdog) and clear or rebuild the sharded map.  plvs_hip_exchange_abort_on_fatal(1) opts in to
+ * ncclCommAbort on the failing rank's communicator before the call returns (process-wide; for callers that own the
+ * communicator outright and never touch it again). */
+int plvs_hip_exchange_abort_on_fatal(int enable);
 
 /* ------------------------------------------- multi-GPU: the block-list exchange
  * The sharded TSDF path (shard_rank / shard_count of either back end; owner(block) =

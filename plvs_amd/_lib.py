@@ -22,6 +22,7 @@ PLVS_ERR_NO_DEVICE = -3
 PLVS_ERR_CAPACITY = -4
 PLVS_ERR_EMPTY = -5
 PLVS_ERR_HALO = -6
+PLVS_ERR_COMM_FATAL = -7   # a sharded step failed past its counts exchange: abort the communicator on every rank, rebuild the map
 
 TIE_LOWEST_INDEX = 0
 TIE_MIH = 1

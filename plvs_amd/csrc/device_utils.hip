@@ -585,6 +585,29 @@ size_t radix_scratch_words(size_t n) {
   return radix * nb + scan_scratch_words(radix * nb) + 2048;
 }
 
+// The developer switches of the sort, read once (PLVS_SORT_WIDE_MAX = n up to which 2 passes of <= 11 bits are taken instead of
+// 3 of 8; PLVS_SORT_ONESWEEP_MIN / _MAX = the lengths for which a pass is ONE launch, the scan chained inside the scatter).
+struct SortSwitches {
+  size_t wide_max, onesweep_min, onesweep_max;
+};
+static const SortSwitches& sort_switches() {
+  static const SortSwitches sw{(size_t)env_int("PLVS_SORT_WIDE_MAX", 0, 0, 1 << 30),
+                               (size_t)env_int("PLVS_SORT_ONESWEEP_MIN", 1 << 18, 0, 1 << 30),
+                               (size_t)env_int("PLVS_SORT_ONESWEEP_MAX", 1 << 23, 0, 1 << 30)};
+  return sw;
+}
+static bool sort_is_wide(size_t n, int total) { return n < sort_switches().wide_max && total > 16 && total <= 2 * kMaxRadixBits; }
+// Does a sort of n pairs over `total` key bits take the one-launch passes?  (`bound` = the caller gives the number of pairs on
+// the device, radix_sort_pairs_bound: that form exists as one-launch passes only.)  ONE predicate for radix_sort_impl and for
+// radix_sort_zero_words, whose callers zero the status words on the side.
+static bool sort_takes_onesweep(size_t n, int total, bool bound) {
+  const SortSwitches& sw = sort_switches();
+  const int os_passes = (total + 7) / 8;
+  if (n == 0 || total <= 0 || os_passes > kOsMaxPasses) return false;
+  if (bound) return true;
+  return sw.onesweep_min != 0 && n >= sw.onesweep_min && n < sw.onesweep_max && !sort_is_wide(n, total);
+}
+
 template <typename TV>
 static hipError_t radix_sort_impl(uint32_t* keys0, TV* vals0, uint32_t* keys1, TV* vals1,
                             size_t n, int bit_lo, int bit_hi, uint32_t* scratch,
@@ -601,18 +624,15 @@ static hipError_t radix_sort_impl(uint32_t* keys0, TV* vals0, uint32_t* keys1, T
   const int total = bit_hi - bit_lo;
   uint32_t *ki = keys0, *ko = keys1;
   TV *vi = vals0, *vo = vals1;
-  // (developer switch, round 5: PLVS_SORT_WIDE_MAX = n up to which 2 passes of <= 11 bits are taken instead of 3 of 8)
-  static const size_t wide_max = (size_t)env_int("PLVS_SORT_WIDE_MAX", 0, 0, 1 << 30);
-  const bool wide = n < wide_max && total > 16 && total <= 2 * kMaxRadixBits;
-  // (developer switch: PLVS_SORT_ONESWEEP_MIN = n from which a pass is ONE launch, the scan chained inside the scatter; 0 = never)
+  const bool wide = sort_is_wide(n, total);
   // Measured (MI355X): 2.5 M pairs, three passes: 144 us against 175 us + twelve launch gaps (the chisel colour chain: the step
   // 1.05 -> 1.04 ms); 18 M pairs (voxblox's visits): the look-back costs what the scan kernels did and the totals come on top
   // (1.67 -> 1.70 ms per step) — hence the upper bound.
-  static const size_t onesweep_min = (size_t)env_int("PLVS_SORT_ONESWEEP_MIN", 1 << 18, 0, 1 << 30);
-  static const size_t onesweep_max = (size_t)env_int("PLVS_SORT_ONESWEEP_MAX", 1 << 23, 0, 1 << 30);
   const int os_passes = (total + 7) / 8;
   if (n_dev != nullptr && os_passes > kOsMaxPasses) return hipErrorInvalidValue;
-  if (n_dev != nullptr || (onesweep_min != 0 && n >= onesweep_min && n < onesweep_max && os_passes <= kOsMaxPasses && !wide)) {
+  if (sort_takes_onesweep(n, total, n_dev != nullptr)) {
+    // (a status word carries a flag in its top two bits and a count below: kOsCount — a tile's inclusive prefix must fit)
+    if (n > (size_t)kOsCount) return hipErrorInvalidValue;
     // scratch: [passes][256] digit totals | [passes] tickets | [passes][tiles][256] status words, zeroed together
     uint32_t* totals = scratch;
     uint32_t* tickets = totals + (size_t)os_passes * 256;
@@ -670,12 +690,8 @@ hipError_t radix_sort_pairs(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, u
 }
 
 size_t radix_sort_zero_words(size_t n, int bit_lo, int bit_hi) {
-  static const size_t onesweep_min = (size_t)env_int("PLVS_SORT_ONESWEEP_MIN", 1 << 18, 0, 1 << 30);
-  static const size_t onesweep_max = (size_t)env_int("PLVS_SORT_ONESWEEP_MAX", 1 << 23, 0, 1 << 30);
-  static const size_t wide_max = (size_t)env_int("PLVS_SORT_WIDE_MAX", 0, 0, 1 << 30);
   const int total = bit_hi - bit_lo, os_passes = (total + 7) / 8;
-  const bool wide = n < wide_max && total > 16 && total <= 2 * kMaxRadixBits;
-  if (n == 0 || total <= 0 || onesweep_min == 0 || n < onesweep_min || n >= onesweep_max || os_passes > kOsMaxPasses || wide) return 0;
+  if (!sort_takes_onesweep(n, total, false)) return 0;
   const size_t nb = (n + kSortTile - 1) / kSortTile;
   return (size_t)os_passes * 256 + kOsMaxPasses + (size_t)os_passes * nb * 256;
 }

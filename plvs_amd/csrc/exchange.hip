@@ -6,6 +6,7 @@
 //
 // RCCL is resolved at run time (the symbols of the process if RCCL is already loaded — e.g. by torch —,
 // librccl.so.1 otherwise): the library carries no link-time dependency on it.
+#include <atomic>
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -44,8 +45,13 @@ struct Rccl {
 //   soft errors (a HIP call, packing, applying) are NOTED and the rank keeps going through every collective with the
 //     announced sizes (the data it sends is then unspecified; its return value and message say the map is inconsistent);
 //   hard errors (the exchange buffers cannot be allocated, RCCL itself returned an error) leave no way to honour the
-//     announced sizes: the communicator is ABORTED (ncclCommAbort), which fails the peers' pending collectives instead
-//     of leaving them blocked.
+//     announced sizes.  The communicator is the CALLER's (torch's ProcessGroup owns it in plvs_amd/shard.py and bench.py): the
+//     library does not touch it — an aborted communicator that its owner later uses or destroys is undefined behaviour, and
+//     a local ncclCommAbort does not reliably release remote ranks that are already inside the group call either.  The rank
+//     returns PLVS_ERR_COMM_FATAL: the caller must abort (or destroy) the communicator on EVERY rank — the peers of this
+//     step are inside collectives this rank will not enter and leave them through their own abort or RCCL's watchdog —
+//     and clear or rebuild the sharded map.  A caller that owns its communicator outright can opt in to the old behaviour
+//     (plvs_hip_exchange_abort_on_fatal(1): ncclCommAbort before returning, which fails this rank's side at once).
 struct LateErrors {
   int rc = PLVS_OK;          // the first error noted
   bool hard = false;
@@ -70,13 +76,17 @@ struct LateErrors {
   }
 };
 
+std::atomic<int> g_abort_on_fatal{0};
+
 int abort_exchange(const Rccl* r, void* comm, const LateErrors& L) {
-  const bool aborted = r->comm_abort != nullptr && r->comm_abort(comm) == 0;
+  const bool opted = g_abort_on_fatal.load() != 0;
+  const bool aborted = opted && r->comm_abort != nullptr && r->comm_abort(comm) == 0;
   plvs::set_error("%s — after the counts of the sharded step had been exchanged and with no way to go through its "
-                  "collectives: %s; other ranks may have applied this step, the sharded map is inconsistent (clear or "
-                  "rebuild it on every rank with a new communicator)", L.msg,
-                  aborted ? "the communicator was aborted so that no peer stays blocked" : "ncclCommAbort is not available: peers may be blocked");
-  return L.rc;
+                  "collectives: %s; other ranks may have applied this step and may still be inside its collectives: abort or "
+                  "destroy the communicator on every rank, then clear or rebuild the sharded map with a new one", L.msg,
+                  aborted ? "this rank's communicator was aborted (plvs_hip_exchange_abort_on_fatal)"
+                          : "the communicator was left as it is (it is the caller's)");
+  return PLVS_ERR_COMM_FATAL;
 }
 
 const Rccl* rccl() {
@@ -157,6 +167,12 @@ __global__ void store_word(int32_t* p, int32_t v) { *p = v; }
 }  // namespace
 
 extern "C" {
+
+int plvs_hip_exchange_abort_on_fatal(int enable) {
+  g_abort_on_fatal.store(enable ? 1 : 0);
+  return PLVS_OK;
+}
+
 
 int plvs_hip_block_directory_create(int max_blocks, plvs_block_directory** out) {
   PLVS_REQUIRE(out && max_blocks > 0 && max_blocks <= (1 << 24), "bad arguments");

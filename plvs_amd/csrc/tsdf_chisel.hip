@@ -886,6 +886,7 @@ struct plvs_tsdf_chisel {
   DevBuf<float> st_xyz, st_Twc, st_nrm;
   DevBuf<uint8_t> st_rgb;
   DevBuf<uint32_t> st_kfid;
+  DevBuf<uint32_t> st_pos, st_scan, st_off;   // depth-image entry of an ordered / sharded / deforming handle: the clouds' scan
   plvs_tsdf_stats stats{};
   uint32_t last_updated = 0;
   // queued key-frame clouds (plvs_hip_tsdf_chisel_queue / _flush): uploaded, not yet integrated
@@ -900,6 +901,7 @@ struct plvs_tsdf_chisel {
   WalkCounters* h_wctr = nullptr;   // pinned
   uint32_t* h_seq = nullptr;        // pinned, coherent: the sequence number of the last publish_counters that has landed
   uint32_t seq_next = 0;
+  double wait_ema_us[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};       // how long the host's last waits for the published counters took (wait_published)
   DevBuf<uint4> w_rec, w_seg, w_sorted_seg;
   DevBuf<uint32_t> w_chunk_nseg, w_chunk_off, w_chunk_fill, w_active_off, w_masks, w_dummy, w_seg_cnt, w_tile_visits, w_deferred;
   DevBuf<uint32_t> w_part_off, w_multi_idx;          // apply stage: parts of the updated chunks
@@ -1037,34 +1039,64 @@ const char* const kWalkStageNames[kWalkStages] = {"walk_tiles", "sort_segments",
 // PLVS_TSDF_SPIN_US microseconds (default 3000; 0 = never), then sleeps on the stream.  Everything enqueued on q before that
 // launch has completed when the word arrives (stream order), so this stands for hipStreamSynchronize(q) as far as the
 // pipeline's own buffers and the caller's inputs are concerned.
-static int wait_published(plvs_tsdf_chisel* h, uint32_t seq, hipStream_t q) {
-  static const int spin_us = plvs::env_int("PLVS_TSDF_SPIN_US", 3000, 0, 10000000);
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__) || defined(__arm__)
+  __asm__ __volatile__("yield");
+#endif
+}
+// The host's cost: the calling thread SLEEPS through most of the wait it expects (the handle remembers how long its last waits
+// of this kind took: a 100-key-frame step's last wait is ~0.9 ms, a one-key-frame call's ~0.1 ms) and polls only for the
+// rest — at most PLVS_TSDF_SPIN_US microseconds (default 400; 0: never poll) before it falls back to hipStreamSynchronize —
+// so a SLAM thread next to it loses a core for a few hundred microseconds per call at worst, not for the length of the call.
+// kind: 0 the end of a call, 1 the read in front of its colour chain; size_class: calls of a few key frames, of tens, of a hundred
+// (their waits differ by an order of magnitude, and a SLAM system alternates them)
+static int wait_published(plvs_tsdf_chisel* h, uint32_t seq, hipStream_t q, int kind = 0, int size_class = 0) {
+  double& ema = h->wait_ema_us[kind][size_class];
+  static const int spin_us = plvs::env_int("PLVS_TSDF_SPIN_US", 400, 0, 10000000);
   if (spin_us > 0 && h->h_seq != nullptr) {
     const volatile uint32_t* const word = h->h_seq;
-    timespec t0;
+    timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (uint32_t spins = 0;; ++spins) {
-      if (*word == seq) {
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        return PLVS_OK;
-      }
-      __builtin_ia32_pause();
-      if ((spins & 255u) == 255u) {
-        timespec t1;
-        clock_gettime(CLOCK_MONOTONIC, &t1);
-        if ((t1.tv_sec - t0.tv_sec) * 1000000ll + (t1.tv_nsec - t0.tv_nsec) / 1000 > spin_us) break;
-      }
+    auto elapsed_us = [&]() {
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      return (double)(t1.tv_sec - t0.tv_sec) * 1e6 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-3;
+    };
+    bool done = *word == seq;
+    if (!done && ema > 200.0) {   // most of an expected long wait is slept, not polled (timer slack: ~60 us)
+      timespec nap;
+      const double us = std::min(ema - 120.0, 5000.0);
+      nap.tv_sec = 0;
+      nap.tv_nsec = (long)(us * 1e3);
+      nanosleep(&nap, nullptr);
+      done = *word == seq;
     }
+    const double spin_from = done ? 0.0 : elapsed_us();
+    for (uint32_t spins = 0; !done; ++spins) {
+      done = *word == seq;
+      if (done) break;
+      cpu_relax();
+      if ((spins & 255u) == 255u && elapsed_us() - spin_from > (double)spin_us) break;
+    }
+    if (done) {
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      ema = 0.75 * ema + 0.25 * elapsed_us();
+      return PLVS_OK;
+    }
+    ema = 0.75 * ema + 0.25 * (elapsed_us() + 200.0);   // (longer than expected: sleep longer next time)
   }
+  // (the runtime has not observed the stream's completion after a polled read; nothing below relies on it: buffers are
+  // re-used in stream order, and hipFree — DevBuf::reserve — synchronises the device itself)
   PLVS_HIP_TRY(hipStreamSynchronize(q));
   return PLVS_OK;
 }
 
-static int read_walk_counters(plvs_tsdf_chisel* h, hipStream_t s) {
+static int read_walk_counters(plvs_tsdf_chisel* h, hipStream_t s, int size_class = 0) {
   const uint32_t seq = ++h->seq_next;
   hipLaunchKernelGGL(publish_counters, dim3(1), dim3(64), 0, s, h->d_wctr, h->d_ctr, h->h_wctr, h->h_ctr, h->h_seq, seq);
   PLVS_KERNEL_CHECK();
-  return wait_published(h, seq, s);
+  return wait_published(h, seq, s, 0, size_class);
 }
 
 static int walk_fail(plvs_tsdf_chisel* h, uint32_t err) {
@@ -1205,6 +1237,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
   PLVS_HIP_TRY(h->w_run_off.reserve((size_t)ntiles + 1));
   PLVS_HIP_TRY(h->scratch.reserve(scan_scratch_words(ntiles)));
   h->stage_set = 1;
+  const int size_class = ntiles <= kSmallCallTiles ? 0 : (ntiles <= kPredictTiles ? 1 : 2);
   const int chunks_before = h->num_chunks;
 #define STAGE_MARK(i) \
   do { if (h->profiling) PLVS_HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
@@ -1411,7 +1444,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
         const uint32_t seq = ++h->seq_next;
         hipLaunchKernelGGL(publish_counters, dim3(1), dim3(64), 0, h->side, h->d_wctr, h->d_ctr, h->h_wctr, h->h_ctr, h->h_seq, seq);
         {   // the walk is over; segment sort and apply are queued behind it
-          int rcw = wait_published(h, seq, h->side);
+          int rcw = wait_published(h, seq, h->side, 1, size_class);
           if (rcw != PLVS_OK) return rcw;
         }
         const uint32_t D = h->h_wctr[1].num_desc;
@@ -1425,7 +1458,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     }
 #undef STAGE_MARK_ON
     STAGE_MARK(4);
-    int rc = read_walk_counters(h, s);
+    int rc = read_walk_counters(h, s, size_class);
     if (rc != PLVS_OK) return rc;
     const uint32_t err = h->h_wctr->err;
     if (err & ~kErrScratch) return walk_fail(h, err);
@@ -1445,7 +1478,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
       PLVS_HIP_TRY(hipMemsetAsync(&h->d_wctr[1].num_updated, 0, sizeof(uint32_t), s));
       int rc2 = colour_chain(D, h->h_ctr->num_chunks, s, nullptr);
       if (rc2 != PLVS_OK) return rc2;
-      rc2 = read_walk_counters(h, s);
+      rc2 = read_walk_counters(h, s, size_class);
       if (rc2 != PLVS_OK) return rc2;
     }
     h->small_runs_known = true;      // (the runs of the last call, whatever its length)
@@ -1715,6 +1748,7 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   h->heads.release(); h->updated.release(); h->scratch.release(); h->poses.release();
   h->offsets.release(); h->st_xyz.release(); h->st_Twc.release(); h->st_nrm.release(); h->st_rgb.release();
   h->st_kfid.release();
+  h->st_pos.release(); h->st_scan.release(); h->st_off.release();
   delete h;
   return PLVS_OK;
 }
@@ -2054,7 +2088,8 @@ int plvs_hip_tsdf_chisel_integrate_depth_batch_dev(plvs_tsdf_chisel* h, const pl
   // ---- the reference's clouds, in scratch memory
   const size_t cells = ngrid * (size_t)nclouds;
   PLVS_REQUIRE(cells < 0x7FFFFFFFull, "too many grid pixels in one call (split the batch)");
-  static thread_local plvs::DevBuf<uint32_t> pos, scan_scratch, d_off;
+  // (the scratch of this path lives with the handle: allocated on the handle's device, released by destroy)
+  plvs::DevBuf<uint32_t>&pos = h->st_pos, &scan_scratch = h->st_scan, &d_off = h->st_off;
   PLVS_HIP_TRY(pos.reserve(cells + 1));
   PLVS_HIP_TRY(scan_scratch.reserve(scan_scratch_words(cells)));
   PLVS_HIP_TRY(d_off.reserve((size_t)nclouds + 1));
