@@ -135,10 +135,13 @@ def compact_line(r):
         "lsd_ms_per_frame": g(r, "frontend", "lsd_extract", "ms_per_frame"),
         "lsd_cpu_ms_per_frame": g(r, "frontend", "lsd_extract", "cpu_baseline", "ms_per_frame"),
         "lsd_parity_ok": g(r, "frontend", "lsd_extract", "parity_ok"),
-        "sgm_ms_per_pair": g(r, "frontend", "dense_stereo_sgm", "ms_per_pair"),
-        "sgm_parity": "unpinned (libsgm is CUDA-only: oracle/sgm.c is a restatement)" if g(r, "frontend", "dense_stereo_sgm") else None,
+        "sgm_ms_per_pair_parity_unpinned": g(r, "frontend", "dense_stereo_sgm", "ms_per_pair"),
+        "sgm_parity": "unpinned (libsgm is CUDA-only, not compilable here: oracle/sgm.c is a restatement nothing checks)" if g(r, "frontend", "dense_stereo_sgm") else None,
         "elas_parity_note": "bit-identical on zero-initialised heaps (oracle/ref/elas_zero_malloc.h)" if g(r, "kitti_shaped", "ms_per_keyframe") else None,
-        "kitti_ms_per_keyframe": g(r, "kitti_shaped", "ms_per_keyframe"),
+        "kitti_ms_per_keyframe_incl_reference_host_stages": g(r, "kitti_shaped", "ms_per_keyframe"),
+        "kitti_note": ("NOT a product number: libelas' host stages (support filters, Delaunay, planes, grid) run inside the "
+                       "reference's compiled Elas::process (oracle/_ref/libelas_ref.so); the device stages are the product's")
+        if g(r, "kitti_shaped", "ms_per_keyframe") else None,
         "kitti_maps_bit_identical": g(r, "kitti_shaped", "disparity_maps_bit_identical_to_reference"),
         "parity_ok": r.get("parity_checked"),
         "parity_bit_exact_mode": g(r, "parity", "bit_exact_mode", "sdf_weight"),
@@ -155,8 +158,8 @@ def compact_line(r):
               "voxblox_traffic"):
         if k in summary:
             roof[k] = summary[k]
-    for k in ("first_lap_ms", "updatemap_5_ms", "updatemap_1_ms", "frontend_ms_per_frame", "lsd_ms_per_frame", "kitti_ms_per_keyframe",
-              "parity_ok"):
+    for k in ("first_lap_ms", "updatemap_5_ms", "updatemap_1_ms", "frontend_ms_per_frame", "lsd_ms_per_frame",
+              "kitti_ms_per_keyframe_incl_reference_host_stages", "parity_ok"):
         if k in summary:
             cfg[k] = summary[k]
     for k in ("voxblox_cpu_value", "frontend_cpu_ms_per_frame", "lsd_cpu_ms_per_frame"):
@@ -166,7 +169,7 @@ def compact_line(r):
     for k in ("phases_ms", "other_scaling_leg"):
         if k in r:
             out[k] = r[k]
-    out["full_result"] = "gpurun_out/bench_full.json (legs: DESIGN.md 4.6)"
+    out["full_result"] = "gpurun_out/bench_full.json (every leg of a default run; a run with legs switched off: bench_partial.json)"
     out["summary"] = summary
     return out
 
@@ -1416,7 +1419,13 @@ def main():
         full = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpurun_out")
         try:      # every leg with its prose (what each leg is: DESIGN.md §4.6)
             os.makedirs(full, exist_ok=True)
-            with open(os.path.join(full, "bench_full.json"), "w") as f:
+            # (bench_full.json is the DEFAULT run's record — every leg; a run with legs switched off, another backend or
+            # other sizes — the profiling passes of scripts/ — writes bench_partial.json and leaves it alone)
+            whole = not (args.no_other_mode_leg or args.no_voxblox_leg or args.no_realistic_legs or args.no_steady_state_leg or
+                         args.no_frontend or args.no_cpu_baseline or args.no_parity_check or args.steady_state or args.ordered or
+                         args.cloud_input or args.sharded_at_one or args.backend != "chisel" or world != 1 or args.batch != 100)
+            result["legs_present"] = sorted(k for k in result if isinstance(result[k], dict) and k not in ("config", "roofline"))
+            with open(os.path.join(full, "bench_full.json" if whole else "bench_partial.json"), "w") as f:
                 json.dump(result, f, indent=1)
         except OSError:
             pass

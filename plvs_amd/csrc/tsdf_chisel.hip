@@ -1380,12 +1380,37 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     // the segment sort and the apply stage (both short, latency-bound kernels).
     uint32_t* const side_ctr = &h->d_wctr[1].num_desc;   // the run count, for the side stream's kernels
     // the chain behind the scan of the run counts, for D runs (or a bound on them: guard) on stream q
+    // (developer switch: the most runs the one-launch sort takes, 0 = never; one workgroup sorts ~1 000 pairs per microsecond
+    // and pass, the general chain costs ~60 us of launches before it does anything)
+    static const uint32_t medium_max = (uint32_t)plvs::env_int("PLVS_TSDF_MEDIUM_SORT", 16384, 0, (int)kMediumRuns);
+    const bool medium_sort = medium_max != 0;
     auto colour_chain = [&](uint32_t D, int chunks, hipStream_t q, const RunGuard* guard) -> int {
       const uint32_t* skeys = h->dkey0.p;
       const uint32_t* sval = h->w_val0.p;
       if (D <= kSmallRuns) {
         hipLaunchKernelGGL(sort_runs_small, dim3(1), dim3(1024), 0, q, h->w_runkey.p, h->w_run_cnt.p, ntiles,
                            h->run_r1_log2, h->d_wctr + 1, h->dkey0.p, h->w_val0.p, h->heads.p, guard ? guard->skip : (uint32_t*)nullptr);
+      } else if (D <= medium_max) {
+        // one workgroup, one launch: the runs listed, sorted and their voxels' first runs found (sort_runs_medium)
+        PLVS_HIP_TRY(h->dkey0.reserve(D));
+        PLVS_HIP_TRY(h->dkey1.reserve(D));
+        PLVS_HIP_TRY(h->w_val0.reserve(D));
+        PLVS_HIP_TRY(h->w_val1.reserve(D));
+        PLVS_HIP_TRY(h->heads.reserve(D));
+        int key_bits = 12;
+        while ((1ll << (key_bits - 12)) < (long long)chunks) ++key_bits;
+        const bool ten = key_bits <= 20;   // (two passes of ten bits instead of three of eight)
+        const int passes = ten ? 2 : (key_bits + 7) / 8;
+#define PLVS_SORT_MEDIUM(BITS)                                                                                                    \
+  hipLaunchKernelGGL(sort_runs_medium<BITS>, dim3(1), dim3(1024), 0, q, h->w_runkey.p, h->w_run_cnt.p, ntiles, h->run_r1_log2,   \
+                     h->d_wctr + 1, h->dkey0.p, h->w_val0.p, h->dkey1.p, h->w_val1.p, h->w_run_off.p, h->heads.p, passes,         \
+                     guard ? guard->limit : 0xFFFFFFFFu, &h->d_ctr->num_chunks, guard ? guard->chunk_limit : 0,                   \
+                     guard ? guard->skip : (uint32_t*)nullptr)
+        if (ten) PLVS_SORT_MEDIUM(10);
+        else PLVS_SORT_MEDIUM(8);
+#undef PLVS_SORT_MEDIUM
+        skeys = (passes & 1) ? h->dkey1.p : h->dkey0.p;
+        sval = (passes & 1) ? h->w_val1.p : h->w_val0.p;
       } else {
         int rc = sort_runs(h, D, ntiles, chunks, q, &skeys, &sval, guard);
         if (rc != PLVS_OK) return rc;
@@ -1422,7 +1447,6 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
       if (rc != PLVS_OK) return rc;
     } else {
       if (!predicted) PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-      PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, ntiles, side_ctr, h->scratch.p, q_colour));
       if (predicted) {
         const size_t slots = (size_t)ntiles << h->run_r1_log2;
         // (the call before scaled to this call's tiles — calls of one and of five key frames may alternate —, a quarter more)
@@ -1432,6 +1456,11 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
         run_bound = expect <= kSmallRuns / 2 ? kSmallRuns
                     : loose ? (uint32_t)std::min<size_t>(slots, (std::max<size_t>(3 * expect, (size_t)1 << 20) + 4095) / 4096 * 4096)
                             : (uint32_t)std::min<size_t>(slots, (expect * 5 / 4 + 8191) / 4096 * 4096);
+        // (a moderate expectation: the one-launch sort on its full capacity — a bound that costs nothing; it sums the tiles'
+        // run counts itself, the general chain wants them scanned)
+        if (medium_sort && run_bound > kSmallRuns && expect * 5 / 4 + 1024 <= medium_max) run_bound = medium_max;
+        if (run_bound > medium_max)
+          PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, ntiles, side_ctr, h->scratch.p, q_colour));
         chunk_bound = std::min(max_chunks, std::max(2 * chunks_before, chunks_before + 256));
         const RunGuard guard{run_bound, side_ctr, &h->d_ctr->num_chunks, chunk_bound, &h->d_wctr[0].err, &h->d_wctr[1].skip,
                              loose ? 0u : 1u, nullptr, 0u};
@@ -1441,6 +1470,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
         rc = segments_and_apply();
         if (rc != PLVS_OK) return rc;
       } else {
+        PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, ntiles, side_ctr, h->scratch.p, q_colour));
         const uint32_t seq = ++h->seq_next;
         hipLaunchKernelGGL(publish_counters, dim3(1), dim3(64), 0, h->side, h->d_wctr, h->d_ctr, h->h_wctr, h->h_ctr, h->h_seq, seq);
         {   // the walk is over; segment sort and apply are queued behind it

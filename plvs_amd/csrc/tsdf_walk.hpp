@@ -2251,6 +2251,144 @@ __global__ __launch_bounds__(1024) void sort_runs_small(const uint32_t* __restri
   if (tid == 0) ctr->num_heads = carry;
 }
 
+// ... and for a call with a MODERATE number of runs (a single key frame over new ground: 150 tiles of a few hundred cold
+// voxels; the rim of a saturated map in a long call): the same three steps — the runs of the tiles listed densely in tile
+// order, a stable sort by voxel key, the first run of every voxel — by ONE workgroup in one launch, where the general form
+// takes eight (scan, compaction, two or three passes of histogram / scan / scatter, heads: 60 us of launches for 25 000
+// runs, a third of a one-key-frame call).  LSD radix over 8-bit digits through two global buffers: a wave owns a contiguous
+// slice, counts its digits into its own LDS histogram, and places its pairs batch by batch (64 at a time; a pair's rank
+// among the batch's equal digits from eight ballots) behind everything smaller and behind the earlier waves' equals —
+// stable, no atomics on shared counters.  passes = ceil(key bits / 8): the result is in (k0, v0) after an even number.
+// limit / chunk_limit / skip: as compact_runs' guard (a chain launched on predicted sizes).
+constexpr uint32_t kMediumRuns = 65536;
+template <int kDigitBits>   // 8, or 10 where two passes of 10 bits cover the key (a map of up to 256 chunks: a third less work)
+__global__ __launch_bounds__(1024) void sort_runs_medium(const uint32_t* __restrict__ runkey, const uint32_t* __restrict__ run_cnt,
+                                                         uint32_t ntiles, uint32_t r1_log2, WalkCounters* __restrict__ ctr,
+                                                         uint32_t* __restrict__ k0, uint32_t* __restrict__ v0,
+                                                         uint32_t* __restrict__ k1, uint32_t* __restrict__ v1,
+                                                         uint32_t* __restrict__ tile_off, uint32_t* __restrict__ heads, int passes,
+                                                         uint32_t limit, const int32_t* __restrict__ num_chunks, int chunk_limit,
+                                                         uint32_t* __restrict__ skip) {
+  constexpr int kWaves = 16, kBins = 1 << kDigitBits;
+  __shared__ uint32_t hist[kWaves][kBins];
+  __shared__ uint32_t wsum[kWaves];
+  __shared__ uint32_t carry;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  auto block_scan = [&](uint32_t c, uint32_t* total) {   // exclusive prefix of c over the workgroup, after `carry`
+    const uint32_t inc = wave_scan_incl(c);
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    uint32_t wb = carry, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+      if (w < wid) wb += wsum[w];
+      tot += wsum[w];
+    }
+    *total = tot;
+    return wb + inc - c;
+  };
+  // ---- where every tile's runs go
+  for (uint32_t base = 0; base < ntiles; base += 1024) {
+    const uint32_t t = base + (uint32_t)tid;
+    const uint32_t n = t < ntiles ? run_cnt[t] : 0u;
+    uint32_t tot;
+    const uint32_t o = block_scan(n, &tot);
+    if (t < ntiles) tile_off[t] = o;
+    __syncthreads();
+    if (tid == 0) carry += tot;
+    __syncthreads();
+  }
+  const uint32_t D = carry;
+  if (tid == 0) ctr->num_desc = D;   // (the colour side's counters: what the fold reads as the number of runs)
+  const bool bad = D > limit || D > kMediumRuns || (skip != nullptr && (*num_chunks > chunk_limit || (ctr - 1)->err != 0u));
+  if (skip != nullptr && tid == 0) *skip = bad ? 1u : 0u;
+  if (bad || D == 0u) {
+    if (tid == 0 && !bad) ctr->num_heads = 0;
+    return;
+  }
+  __syncthreads();   // (tile_off: written by other threads of this workgroup)
+  for (uint32_t t = (uint32_t)wid; t < ntiles; t += kWaves) {   // a wave per tile: (key, slot) in tile order
+    const uint32_t n = run_cnt[t], o = tile_off[t], slot0 = t << r1_log2;
+    for (uint32_t j = (uint32_t)lane; j < n; j += 64) {
+      k0[o + j] = runkey[slot0 + j];
+      v0[o + j] = slot0 + j;
+    }
+  }
+  __syncthreads();
+  // ---- the passes
+  const uint32_t per_wave = ((D + kWaves - 1) / kWaves + 63u) & ~63u;   // a slice of whole batches
+  const uint32_t lo = min(D, (uint32_t)wid * per_wave), hi = min(D, lo + per_wave);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  uint32_t *ki = k0, *vi = v0, *ko = k1, *vo = v1;
+  for (int p = 0; p < passes; ++p) {
+    const int shift = kDigitBits * p;
+    for (int d = lane; d < kBins; d += 64) hist[wid][d] = 0u;
+    for (uint32_t j = lo + (uint32_t)lane; j < hi; j += 64) atomicAdd(&hist[wid][(ki[j] >> shift) & (uint32_t)(kBins - 1)], 1u);
+    __syncthreads();
+    {   // hist[w][d] -> where wave w's first pair of digit d goes: digits ascending, waves ascending inside a digit
+      constexpr int kOwn = kBins * kWaves / 1024;   // (digit, wave) pairs a thread owns, consecutive in digit-major order
+      uint32_t c[kOwn], sum = 0;
+#pragma unroll
+      for (int q = 0; q < kOwn; ++q) {
+        const int i = kOwn * tid + q;
+        c[q] = hist[i & (kWaves - 1)][i >> 4];
+        sum += c[q];
+      }
+      if (tid == 0) carry = 0;
+      uint32_t tot;
+      const uint32_t o = block_scan(sum, &tot);   // (its barrier orders the reads above before the writes below)
+      __syncthreads();
+      uint32_t run = o;
+#pragma unroll
+      for (int q = 0; q < kOwn; ++q) {
+        const int i = kOwn * tid + q;
+        hist[i & (kWaves - 1)][i >> 4] = run;
+        run += c[q];
+      }
+    }
+    __syncthreads();
+    for (uint32_t j0 = lo; j0 < hi; j0 += 64) {
+      const uint32_t j = j0 + (uint32_t)lane;
+      const bool live = j < hi;
+      const uint32_t key = live ? ki[j] : 0u, val = live ? vi[j] : 0u;
+      const uint32_t dg = (key >> shift) & (uint32_t)(kBins - 1);
+      unsigned long long same = __ballot(live);
+#pragma unroll
+      for (int b = 0; b < kDigitBits; ++b) {
+        const unsigned long long m = __ballot((dg >> b) & 1u);
+        same &= ((dg >> b) & 1u) ? m : ~m;
+      }
+      if (live) {
+        const uint32_t at = hist[wid][dg] + (uint32_t)__popcll(same & below);
+        ko[at] = key;
+        vo[at] = val;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (live && (same >> lane) <= 1ull) hist[wid][dg] += (uint32_t)__popcll(same);   // (the digit's last lane of the batch)
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    uint32_t* t = ki; ki = ko; ko = t;
+    t = vi; vi = vo; vo = t;
+  }
+  // ---- the first run of every voxel
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < D; base += 1024) {
+    const uint32_t j = base + (uint32_t)tid;
+    const uint32_t head = (j < D && (j == 0 || ki[j - 1] != ki[j])) ? 1u : 0u;
+    uint32_t tot;
+    const uint32_t o = block_scan(head, &tot);
+    if (head) heads[o] = j;
+    __syncthreads();
+    if (tid == 0) carry += tot;
+    __syncthreads();
+  }
+  if (tid == 0) ctr->num_heads = carry;
+}
+
 // ColorVoxel::IntegrateSimple visit by visit, for the voxels whose colour weight is below 254.  One
 // wave per voxel: the lanes take its runs (sorted: tile order = point order) 64 at a time, place the
 // colours of their visits — the rays of a mask in ascending order — in LDS at the visit's rank, and three
