@@ -202,7 +202,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
 
     from plvs_amd import _lib
-    from plvs_amd.synth_scene import LOOP, make_keyframes, make_stream_keyframes
+    from tests.synth_scene import LOOP, make_keyframes, make_stream_keyframes
     from plvs_amd.shard import BlockDirectory, allgather_block_lists, sharded_integrate, sharded_integrate_voxblox
     from plvs_amd.tsdf import TsdfChisel, TsdfVoxblox
 
@@ -241,7 +241,7 @@ def main():
     depth_input = not vbx and not multi and not args.ordered and not args.cloud_input
     if not vbx and not args.steady_state:
         # configs[2] stand-in, streaming: step s integrates key frames [s * step_kfs, (s + 1) * step_kfs) of the long
-        # trajectory (plvs_amd/synth_scene.py: one loop of LOOP = 2500 DISTINCT key frames around a desk island in a
+        # trajectory (tests/synth_scene.py: one loop of LOOP = 2500 DISTINCT key frames around a desk island in a
         # 9.5 x 7.5 x 3 m office; a job longer than the loop walks it again)
         n_poses = min(total_steps * step_kfs, LOOP)
         kfs = make_stream_keyframes(n_poses, max_depth=args.max_depth, seed=0, threads=min(32, os.cpu_count() or 8),
@@ -664,7 +664,7 @@ def main():
         if os.path.exists(ref_so):
             import tests.test_oracle_pinned_chisel_map as pinned
             pinned.REF = ref_so
-            from plvs_amd.synth_scene import TUM1
+            from tests.synth_scene import TUM1
             refmap = pinned.RefChisel(args.resolution, dict(TUM1))
             nref = min(total_steps * args.batch, 120)
             for j in range(5):
@@ -796,7 +796,7 @@ def main():
                 "metric": "Mvoxels/sec TSDF integrate (voxblox simple 2 cm, office stream, depths to 8 m, max ray 5 m)",
                 "value": round(vv_total / vel / 1e6, 2), "unit": "Mvoxels/s", "n_gpus": world, "keyframes_per_step": 25,
                 "workload": "configs[3] stand-in, STREAMING: 4 timed steps of 25 DISTINCT key frames each (key frames 450-549 of "
-                            "the office loop of plvs_amd/synth_scene.py after 2 warm-up steps), Voxblox simple TSDF 2 cm",
+                            "the office loop of tests/synth_scene.py after 2 warm-up steps), Voxblox simple TSDF 2 cm",
                 "ms_per_step": round(vel / 4 * 1e3, 3), "visits_per_step": int(vv_total // 4),
                 "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
                              "frac": round(ach / 8000.0, 5), "traffic": None,
@@ -931,7 +931,7 @@ def main():
             fe[name + "_us"] = round(e0.elapsed_time(e1) / 50 * 1e3, 2)
         # ORB(2000) extraction on a 640x480 frame resident in HBM (configs[1] front end)
         from plvs_amd.orb import ORBextractor
-        from plvs_amd.pgm import golden_frame as golden
+        from tests.pgm import golden_frame as golden
         frames = [torch.from_numpy(golden(n)).cuda() for n in ("aloe_640x480.pgm", "aloe_640x480_shift.pgm",
                                                                 "cones_640x480.pgm")]
         ext = ORBextractor(2000, 1.2, 8, 20, 7)

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, __file__.rsplit("/", 3)[0])
-from plvs_amd.synth_scene import make_keyframes  # noqa: E402
+from tests.synth_scene import make_keyframes  # noqa: E402
 from plvs_amd.tsdf import TsdfChisel  # noqa: E402
 
 kfs = make_keyframes(100, max_depth=5.0, seed=0)

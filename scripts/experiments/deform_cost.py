@@ -4,7 +4,7 @@
 import sys, time
 import numpy as np
 sys.path.insert(0, '/root/repo')
-from plvs_amd.synth_scene import make_keyframes
+from tests.synth_scene import make_keyframes
 from plvs_amd.tsdf import TsdfChisel
 
 N = 40

@@ -7,7 +7,7 @@ import numpy as np
 
 sys.path.insert(0, __file__.rsplit("/", 3)[0])
 from plvs_amd.elas import ElasGPU  # noqa: E402
-from plvs_amd.pgm import golden_frame as golden  # noqa: E402
+from tests.pgm import golden_frame as golden  # noqa: E402
 from tests import elas_ref  # noqa: E402
 
 el, er = golden("urban1_1241x376.pgm"), golden("urban1_right_1241x376.pgm")

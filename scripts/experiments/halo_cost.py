@@ -12,7 +12,7 @@ import torch
 
 sys.path.insert(0, __file__.rsplit("/", 3)[0])
 from plvs_amd.shard import owner_of  # noqa: E402
-from plvs_amd.synth_scene import make_keyframes  # noqa: E402
+from tests.synth_scene import make_keyframes  # noqa: E402
 from plvs_amd.tsdf import TsdfChisel  # noqa: E402
 from tests.test_shard_rays import _batch, _nbhd27, sharded_step, virtual_halo_round  # noqa: E402
 

@@ -2,7 +2,7 @@
 sorted by step count inside their 512-ray tile (VERDICT r3's suggestion).  CPU only."""
 import sys, numpy as np
 sys.path.insert(0, "/root/repo")
-from plvs_amd.synth_scene import make_keyframes, make_stream_keyframes
+from tests.synth_scene import make_keyframes, make_stream_keyframes
 # chisel truncation as PLVS sets it (quadratic 0.0019, 0.00152, 0.001504, scale 8): read from the params default
 import ctypes
 from plvs_amd import _lib

@@ -8,7 +8,7 @@ import torch
 
 sys.path.insert(0, __file__.rsplit("/", 3)[0])
 from plvs_amd.lines import LineExtractor  # noqa: E402
-from plvs_amd.pgm import golden_frame as golden  # noqa: E402
+from tests.pgm import golden_frame as golden  # noqa: E402
 
 frames = [torch.from_numpy(golden(n)).cuda() for n in ("aloe_640x480.pgm", "aloe_640x480_shift.pgm", "cones_640x480.pgm")]
 lext = LineExtractor(100)

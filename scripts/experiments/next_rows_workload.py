@@ -10,10 +10,10 @@ import torch
 
 from plvs_amd import cloudgen
 from plvs_amd.orb import ORBextractor
-from plvs_amd.pgm import golden_frame as golden
+from tests.pgm import golden_frame as golden
 from plvs_amd.sgm import StereoSGM
 from plvs_amd.stereo import StereoMatcher
-from plvs_amd.synth_scene import TUM1, make_keyframes, make_rgbd_frames
+from tests.synth_scene import TUM1, make_keyframes, make_rgbd_frames
 from plvs_amd.tsdf import TsdfChisel
 
 

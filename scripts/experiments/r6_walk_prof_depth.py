@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 if os.path.exists(os.path.join(ROOT, "plvs_amd", "lib", "libplvs_hip_prof.so")) and "PLVS_HIP_LIB" not in os.environ:
     os.environ["PLVS_HIP_LIB"] = os.path.join(ROOT, "plvs_amd", "lib", "libplvs_hip_prof.so")
 from plvs_amd import _lib  # noqa: E402
-from plvs_amd.synth_scene import make_stream_keyframes  # noqa: E402
+from tests.synth_scene import make_stream_keyframes  # noqa: E402
 from plvs_amd.tsdf import TsdfChisel  # noqa: E402
 
 

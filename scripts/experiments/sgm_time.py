@@ -3,7 +3,7 @@
 import numpy as np
 import torch
 
-from plvs_amd.pgm import golden_frame as golden
+from tests.pgm import golden_frame as golden
 from plvs_amd.sgm import StereoSGM
 
 left = np.ascontiguousarray(golden("urban1_1241x376.pgm")[:, :1240])

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, __file__.rsplit("/", 3)[0])
-from plvs_amd.synth_scene import make_keyframes  # noqa: E402
+from tests.synth_scene import make_keyframes  # noqa: E402
 from plvs_amd.tsdf import TsdfChisel  # noqa: E402
 from tests.test_shard_rays import WIDTHS, send_buffers, virtual_all_to_all  # noqa: E402
 

@@ -1,6 +1,6 @@
 import sys, numpy as np, torch
 sys.path.insert(0,'/root/repo')
-from plvs_amd.synth_scene import make_keyframes
+from tests.synth_scene import make_keyframes
 from plvs_amd.tsdf import TsdfChisel
 from tests.test_shard_rays import WIDTHS, send_buffers, virtual_all_to_all
 kfs = make_keyframes(100, max_depth=5.0, seed=0)

@@ -11,7 +11,7 @@ import torch.distributed as dist
 
 sys.path.insert(0, __file__.rsplit("/", 3)[0])
 from plvs_amd import shard  # noqa: E402
-from plvs_amd.synth_scene import make_keyframes  # noqa: E402
+from tests.synth_scene import make_keyframes  # noqa: E402
 from plvs_amd.tsdf import TsdfChisel  # noqa: E402
 
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from plvs_amd.synth_scene import make_keyframes  # noqa: E402
+from tests.synth_scene import make_keyframes  # noqa: E402
 from plvs_amd.tsdf import TsdfChisel  # noqa: E402
 
 ORDERED = "--ordered" in sys.argv

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, __file__.rsplit("/", 3)[0])
-from plvs_amd.synth_scene import make_keyframes, make_stream_keyframes  # noqa: E402
+from tests.synth_scene import make_keyframes, make_stream_keyframes  # noqa: E402
 from plvs_amd.tsdf import TsdfChisel  # noqa: E402
 
 NS = int(sys.argv[1]) if len(sys.argv) > 1 else 10

@@ -11,7 +11,7 @@ import torch
 
 sys.path.insert(0, __file__.rsplit("/", 3)[0])
 from plvs_amd import _lib  # noqa: E402
-from plvs_amd.synth_scene import make_keyframes  # noqa: E402
+from tests.synth_scene import make_keyframes  # noqa: E402
 from plvs_amd.tsdf import TsdfVoxblox  # noqa: E402
 
 lib = ctypes.CDLL(_lib.LIB_PATH)

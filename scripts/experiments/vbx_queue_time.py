@@ -9,7 +9,7 @@ import numpy as np
 ROOT = __file__.rsplit("/", 3)[0]
 sys.path.insert(0, ROOT)
 import torch  # noqa: F401,E402
-from plvs_amd.synth_scene import make_stream_keyframes  # noqa: E402
+from tests.synth_scene import make_stream_keyframes  # noqa: E402
 from plvs_amd.tsdf import TsdfVoxblox  # noqa: E402
 
 kfs = make_stream_keyframes(60, first=400, max_depth=8.0, threads=16)

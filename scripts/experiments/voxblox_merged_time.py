@@ -1,6 +1,6 @@
 import sys, time, numpy as np
 sys.path.insert(0,'/root/repo')
-from plvs_amd.synth_scene import make_keyframes
+from tests.synth_scene import make_keyframes
 from plvs_amd.tsdf import TsdfVoxblox
 kfs = make_keyframes(20, max_depth=5.0, seed=0)
 for meth in ("simple", "merged"):

@@ -12,7 +12,7 @@ ROOT = __file__.rsplit("/", 3)[0]
 sys.path.insert(0, ROOT)
 os.environ.setdefault("PLVS_HIP_LIB", os.path.join(ROOT, "plvs_amd", "lib", "libplvs_hip_prof.so"))
 from plvs_amd import _lib  # noqa: E402
-from plvs_amd.synth_scene import make_keyframes, make_stream_keyframes  # noqa: E402
+from tests.synth_scene import make_keyframes, make_stream_keyframes  # noqa: E402
 from plvs_amd.tsdf import TsdfChisel  # noqa: E402
 
 

@@ -18,7 +18,7 @@ def child():
     import torch
     sys.path.insert(0, ROOT)
     from plvs_amd import _lib
-    from plvs_amd.synth_scene import make_keyframes
+    from tests.synth_scene import make_keyframes
     from plvs_amd.tsdf import TsdfChisel
     kfs = make_keyframes(100, max_depth=5.0, seed=0)
     xyz = torch.from_numpy(np.concatenate([k["xyz"] for k in kfs])).cuda()

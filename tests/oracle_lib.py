@@ -397,7 +397,7 @@ class OracleLines:
         return self.lib.oracle_lines_num_in_octave(self.h, octave)
 
 
-from plvs_amd.pgm import read_pgm  # noqa: E402
+from tests.pgm import read_pgm  # noqa: E402
 
 
 def golden(name):

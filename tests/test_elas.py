@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from tests import elas_ref
-from plvs_amd.pgm import read_pgm
+from tests.pgm import read_pgm
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")

@@ -88,7 +88,7 @@ def headline_stream(oracle):
     map, ...) on the oracle: voxel planes after each, and the exact (f64) mean of every voxel's visits beside the reference's
     f32 running mean.  Five steps: the first call on an empty map, the calls in which the walk's first-pass table follows the
     scene (2048 -> 1024 entries for the 2-D tiles of the depth entry point), revisits of the desk island."""
-    from plvs_amd.synth_scene import make_stream_keyframes
+    from tests.synth_scene import make_stream_keyframes
     kfs = make_stream_keyframes(100 * HEADLINE_STEPS, max_depth=5.0, seed=0, threads=16, images=True)
     ora = oracle.chisel(0.05)
     ora.track_exact()
@@ -180,7 +180,7 @@ def test_chisel_streaming_headline_later_steps_depth_entry_equals_point_streams(
     of the point-stream entry point, both order-free, bit for bit after steps 5, 9 and 13.  (The point-stream map of ALL 25
     steps is compared with the oracle inside bench.py, `parity`; the first five steps against the oracle above.)"""
     import torch
-    from plvs_amd.synth_scene import make_stream_keyframes
+    from tests.synth_scene import make_stream_keyframes
     from plvs_amd.tsdf import TsdfChisel
     a = TsdfChisel(0.05, max_chunks=16384, order_free=True)
     b = TsdfChisel(0.05, max_chunks=16384, order_free=True)
@@ -257,7 +257,7 @@ def test_kitti_chain_sgm_depth_cloud_chisel_10cm(oracle):
     device path, compared with the oracles chained the same way."""
     import torch
     from plvs_amd import cloudgen
-    from plvs_amd.pgm import golden_frame
+    from tests.pgm import golden_frame
     from plvs_amd.sgm import StereoSGM
     from plvs_amd.tsdf import TsdfChisel
     left = np.ascontiguousarray(golden_frame("urban1_1241x376.pgm")[:, :1240])

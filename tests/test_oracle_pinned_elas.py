@@ -15,7 +15,7 @@ import os
 import numpy as np
 import pytest
 
-from plvs_amd.pgm import read_pgm
+from tests.pgm import read_pgm
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref", "libelas_ref.so")

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from plvs_amd.shard import owner_of
-from plvs_amd.synth_scene import make_keyframes
+from tests.synth_scene import make_keyframes
 
 
 def _batch(kfs):

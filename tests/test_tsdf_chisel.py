@@ -241,7 +241,7 @@ def test_hip_far_points_fill_the_tile_tables(oracle, order_free):
     at full resolution: tiles that fit the 2048-entry table, tiles that take the 4096-entry pass, tiles the general
     kernel cuts, in a call long enough for the two-pass walk and in single-key-frame calls (the one-pass walk)."""
     import torch
-    from plvs_amd.synth_scene import make_stream_keyframes
+    from tests.synth_scene import make_stream_keyframes
     from plvs_amd.tsdf import TsdfChisel
     kfs = make_stream_keyframes(4, first=1795, threads=4) + make_stream_keyframes(3, first=1000, threads=4)
     ora = oracle.chisel(0.05)
