@@ -1383,14 +1383,16 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     // (developer switch: the most runs the one-launch sort takes, 0 = never; one workgroup sorts ~1 000 pairs per microsecond
     // and pass, the general chain costs ~60 us of launches before it does anything)
     static const uint32_t medium_max = (uint32_t)plvs::env_int("PLVS_TSDF_MEDIUM_SORT", 16384, 0, (int)kMediumRuns);
-    const bool medium_sort = medium_max != 0;
+    // (... and of few tiles: its listing of the runs is one workgroup's loop over the tiles — 15 000 tiles with a run each, the rim
+    // of a saturated map in a 100-key-frame call, take it longer than the general chain's launches: steady state 0.62 -> 0.67 ms)
+    const bool medium_sort = medium_max != 0 && ntiles <= 2048u;
     auto colour_chain = [&](uint32_t D, int chunks, hipStream_t q, const RunGuard* guard) -> int {
       const uint32_t* skeys = h->dkey0.p;
       const uint32_t* sval = h->w_val0.p;
       if (D <= kSmallRuns) {
         hipLaunchKernelGGL(sort_runs_small, dim3(1), dim3(1024), 0, q, h->w_runkey.p, h->w_run_cnt.p, ntiles,
                            h->run_r1_log2, h->d_wctr + 1, h->dkey0.p, h->w_val0.p, h->heads.p, guard ? guard->skip : (uint32_t*)nullptr);
-      } else if (D <= medium_max) {
+      } else if (medium_sort && D <= medium_max) {
         // one workgroup, one launch: the runs listed, sorted and their voxels' first runs found (sort_runs_medium)
         PLVS_HIP_TRY(h->dkey0.reserve(D));
         PLVS_HIP_TRY(h->dkey1.reserve(D));

@@ -2309,11 +2309,21 @@ __global__ __launch_bounds__(1024) void sort_runs_medium(const uint32_t* __restr
     return;
   }
   __syncthreads();   // (tile_off: written by other threads of this workgroup)
-  for (uint32_t t = (uint32_t)wid; t < ntiles; t += kWaves) {   // a wave per tile: (key, slot) in tile order
-    const uint32_t n = run_cnt[t], o = tile_off[t], slot0 = t << r1_log2;
-    for (uint32_t j = (uint32_t)lane; j < n; j += 64) {
-      k0[o + j] = runkey[slot0 + j];
-      v0[o + j] = slot0 + j;
+  if (D >= 8u * ntiles) {
+    for (uint32_t t = (uint32_t)wid; t < ntiles; t += kWaves) {   // a wave per tile: (key, slot) in tile order
+      const uint32_t n = run_cnt[t], o = tile_off[t], slot0 = t << r1_log2;
+      for (uint32_t j = (uint32_t)lane; j < n; j += 64) {
+        k0[o + j] = runkey[slot0 + j];
+        v0[o + j] = slot0 + j;
+      }
+    }
+  } else {   // many tiles with a run or two each (the rim of a saturated map in a long call): a thread per tile
+    for (uint32_t t = (uint32_t)tid; t < ntiles; t += 1024) {
+      const uint32_t n = run_cnt[t], o = tile_off[t], slot0 = t << r1_log2;
+      for (uint32_t j = 0; j < n; ++j) {
+        k0[o + j] = runkey[slot0 + j];
+        v0[o + j] = slot0 + j;
+      }
     }
   }
   __syncthreads();
