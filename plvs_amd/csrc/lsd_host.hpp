@@ -313,10 +313,13 @@ class Level {
     const double p = o.ang_th / 180;
     log_nt_ = 5 * (std::log10(double(w)) + std::log10(double(h))) / 2 + std::log10(11.0);
     const size_t min_reg_size = size_t(-log_nt_ / std::log10(p));
-    used_.assign(npx, 0);
+    // (a pixel without a level-line angle can neither seed a region nor join one: it starts out as taken, and the growth loop
+    // never loads its angle — two pixels in five of a camera image)
+    used_.resize(npx);
+    for (size_t at = 0; at < npx; ++at) used_[at] = angles[at] == kNotDef ? 1 : 0;
     for (size_t i = 0; i < nseeds; ++i) {
       const size_t at = narrow_ ? size_t(keys32_[i] & ((1u << 22) - 1)) : size_t(keys64_[i] & 0xffffffffull);
-      if (used_[at] != 0 || angles[at] == kNotDef) continue;
+      if (used_[at] != 0) continue;
       double run_angle = collect(at, prec);
       if (px_.size() < min_reg_size) continue;
       Box box;
@@ -403,6 +406,8 @@ class Level {
       const int y_lo = c.y > 0 ? c.y - 1 : 0, y_hi = c.y + 1 < h_ ? c.y + 1 : h_ - 1;
       for (int y = y_lo; y <= y_hi; ++y) {
         const size_t row = (size_t)y * w_;
+        // (inside a grown region the three neighbours of a row are all taken: one look at the row)
+        if (x_hi - x_lo == 2 && (used_[row + x_lo] & used_[row + x_lo + 1] & used_[row + x_hi]) == 1) continue;
         for (int x = x_lo; x <= x_hi; ++x) {
           const size_t at = row + x;
           if (used_[at] == 1 || !within(ang_[at], dir, tol)) continue;
