@@ -427,10 +427,15 @@ def main():
         # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
         # runs of this same command; scripts/pmc_traffic.py) committed under profiles/
         mode_tag = "" if vbx else ("_ordered" if args.ordered else "_order_free")
-        # (round 5: the depth-image input has its own passes; a point-stream run cites round 4's)
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                           f"{'r05' if depth_input else 'r04'}_pmc_traffic_{args.backend}{mode_tag}"
-                           f"{'_steady_state' if args.steady_state else ''}.json")
+        # (the newest committed passes of this command: round 6's for the depth-image headline and the voxblox leg, round 5's /
+        # round 4's where a later round made none)
+        pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        rounds = ("r06", "r05") if depth_input else ("r06", "r04")
+        pmc = ""
+        for rr in rounds:
+            pmc = os.path.join(pdir, f"{rr}_pmc_traffic_{args.backend}{mode_tag}{'_steady_state' if args.steady_state else ''}.json")
+            if os.path.exists(pmc):
+                break
         if world == 1 and not multi and args.batch == 100 and os.path.exists(pmc):
             with open(pmc) as f:
                 t = json.load(f)
@@ -802,11 +807,12 @@ def main():
                              "frac": round(ach / 8000.0, 5), "traffic": None,
                              "note": "24 B per visit + 16 B per point over the wall time of the call (this rank's share)"},
             }
-            pmc_v = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_pmc_traffic_voxblox.json")
-            if world == 1 and os.path.exists(pmc_v):
+            pmc_v = next((q for q in (os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"{rr}_pmc_traffic_voxblox.json")
+                                      for rr in ("r06", "r04")) if os.path.exists(q)), "")
+            if world == 1 and pmc_v:
                 with open(pmc_v) as f:
                     leg["roofline"]["traffic"] = json.load(f)["traffic"]
-                leg["roofline"]["traffic_source"] = "profiles/r04_pmc_traffic_voxblox.json (FETCH_SIZE x2 + WRITE_SIZE per call)"
+                leg["roofline"]["traffic_source"] = f"profiles/{os.path.basename(pmc_v)} (FETCH_SIZE x2 + WRITE_SIZE per call)"
             # the reference's own SimpleTsdfIntegrator on the host cores (oracle/_ref/libvoxblox_ref_o3.so: tsdf_integrator.cc
             # compiled unmodified, -O3 -march=x86-64-v3), integrator_threads = 1 and = hardware_concurrency (its default)
             vref = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "_ref", "libvoxblox_ref_o3.so")
