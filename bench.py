@@ -174,320 +174,24 @@ def compact_line(r):
     return out
 
 
-def main():
-    args = parse()
-    # ONE line on stdout: the compiled reference sources behind the cpu_baseline legs print (open_chisel a line per garbage
-    # collection, line_descriptor a line per pyramid) — everything written to file descriptor 1 before the result goes to stderr
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    # PLVS_BENCH_REHEARSAL=1 (scripts/gpu_check.sh, stage `multi` on a one-GPU box): every rank on device 0, the exchanges over
-    # gloo (RCCL refuses two ranks on one device) — the N > 1 code path end to end with two real processes; never a measurement
-    rehearsal = os.environ.get("PLVS_BENCH_REHEARSAL", "0") == "1"
-    device_index = 0 if rehearsal else local_rank
-    torch.cuda.set_device(device_index)
-    multi = world > 1 or args.sharded_at_one
-    if multi:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if rehearsal:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
-
-    from plvs_amd import _lib
-    from tests.synth_scene import LOOP, make_keyframes, make_stream_keyframes
-    from plvs_amd.shard import BlockDirectory, allgather_block_lists, sharded_integrate, sharded_integrate_voxblox
-    from plvs_amd.tsdf import TsdfChisel, TsdfVoxblox
-
-    # ---------------------------------------------------------------- inputs
-    n_poses = 100                                    # SURVEY §8d: 100 poses, 3.6 deg yaw step
-    total_steps = args.warmup + args.steps
-    vbx = args.backend == "voxblox"
-    # N > 1 (voxblox, "simple"): the ray-sharded integrate of tsdf_voxblox_shard.hpp — rank r casts the rays of every N-th key
-    # frame of the step and sends the voxel visits to the block owners.  STRONG scaling (the step stays --batch key frames):
-    # the update is an ordered fold per voxel, and a step of N x 25 consecutive key frames of one camera makes every voxel's
-    # run N times longer instead of giving the ranks more voxels (one device: 1.07 ms for 25 key frames, 21 ms for 200).
-    vbx_sharded = multi and vbx
-    if vbx:                      # SURVEY §8d config 4: 2 cm voxels, 16x12x3 m room, depths to 8 m
-        if args.resolution == 0.05:
-            args.resolution = 0.02
-        if args.max_depth == 5.0:
-            args.max_depth = 8.0
-        if args.steady_state:
-            kfs = make_keyframes(n_poses, room_size=(16.0, 12.0, 3.0), max_depth=args.max_depth, seed=0)
-        else:      # the office stream from key frame 400 on, as the voxblox_configs3 leg of the default run
-            n_poses = min(total_steps * args.batch, LOOP)
-            kfs = make_stream_keyframes(n_poses, first=400, max_depth=args.max_depth, seed=0, threads=min(32, os.cpu_count() or 8))
-        for k in kfs:
-            k["rgba"] = np.concatenate([k["rgb"], np.full((k["rgb"].shape[0], 1), 255, np.uint8)], axis=1)
-    elif args.steady_state:
-        kfs = make_keyframes(n_poses, max_depth=args.max_depth, seed=0)
-    # N > 1 (chisel, order-free): the ray-sharded integrate — rank r walks every N-th tile of the step's point
-    # stream and sends what it collected to the chunk owners.  Weak scaling by default: a step carries --batch
-    # keyframes PER GPU (a longer stretch of the stream, e.g. a map rebuild), so every rank's share of the rays
-    # stays what one GPU walks at N = 1.
-    ray_sharded = multi and not vbx and not args.ordered
-    step_kfs = args.batch * (world if (ray_sharded and not args.strong) else 1)
-    # N = 1, order-free chisel: the steps go in as the DEPTH IMAGES of the key frames (PLVS's real pipeline: depth image ->
-    # GeneratePointCloudInCameraFrameBGRA -> InsertCloud); the same key frames as point streams stay in HBM for the other
-    # legs (bit-exact mode, parity) and behind --cloud-input
-    depth_input = not vbx and not multi and not args.ordered and not args.cloud_input
-    if not vbx and not args.steady_state:
-        # configs[2] stand-in, streaming: step s integrates key frames [s * step_kfs, (s + 1) * step_kfs) of the long
-        # trajectory (tests/synth_scene.py: one loop of LOOP = 2500 DISTINCT key frames around a desk island in a
-        # 9.5 x 7.5 x 3 m office; a job longer than the loop walks it again)
-        n_poses = min(total_steps * step_kfs, LOOP)
-        kfs = make_stream_keyframes(n_poses, max_depth=args.max_depth, seed=0, threads=min(32, os.cpu_count() or 8),
-                                    images=depth_input)
-    elif depth_input:
-        kfs = make_keyframes(n_poses, max_depth=args.max_depth, seed=0, images=True)
-
-    def pack_depth(sel, step=2):
-        """The key frames as 640 x 480 images in HBM: depth and colour at the pixels of the stride-2 grid (the others are
-        never read: src/PointCloudMapping.cc:957-996 visits m, n = 0, step, 2 step, ...), the grid table, one id per image."""
-        gh, gw = sel[0]["depth_grid"].shape
-        d = torch.zeros((len(sel), gh * step, gw * step), dtype=torch.float32, device="cuda")
-        c = torch.zeros((len(sel), gh * step, gw * step, 3), dtype=torch.uint8, device="cuda")
-        d[:, ::step, ::step] = torch.from_numpy(np.stack([k["depth_grid"] for k in sel])).cuda()
-        c[:, ::step, ::step] = torch.from_numpy(np.stack([k["rgb_grid"] for k in sel])).cuda()
-        return (d, c, torch.from_numpy(sel[0]["cam_grid"]).cuda(), step, 0.1, args.max_depth,
-                torch.from_numpy(np.array([int(k["kfid"][0]) if len(k["kfid"]) else 0 for k in sel], np.int32)).cuda(),
-                torch.from_numpy(np.stack([k["Twc"] for k in sel])).cuda())
-    batches = []
-    depth_batches = []
-    built_depth = {}
-    built = {}     # steps that carry the same key frames share one copy in HBM (at N x 100 key frames per step all do)
-    for s in range(total_steps):
-        first = (s * step_kfs) % n_poses
-        if first not in built:
-            sel = [kfs[(first + j) % n_poses] for j in range(step_kfs)]
-            xyz = torch.from_numpy(np.concatenate([k["xyz"] for k in sel])).cuda()
-            rgb = torch.from_numpy(np.concatenate([k["rgba" if vbx else "rgb"] for k in sel])).cuda()
-            kfid = torch.from_numpy(np.concatenate([k["kfid"] for k in sel]).astype(np.int32)).cuda()
-            Twc = torch.from_numpy(np.stack([k["Twc"] for k in sel])).cuda()
-            offsets = np.cumsum([0] + [k["xyz"].shape[0] for k in sel]).astype(np.int32)
-            built[first] = (xyz, rgb, kfid, offsets, Twc)
-            if depth_input:
-                built_depth[first] = pack_depth(sel)
-        batches.append(built[first])
-        if depth_input:
-            depth_batches.append(built_depth[first])
-
-    if vbx:
-        tsdf = TsdfVoxblox(args.resolution, max_blocks=65536, shard_rank=rank, shard_count=world)
-    else:
-        tsdf = TsdfChisel(args.resolution, max_chunks=16384, shard_rank=rank, shard_count=world,
-                          order_free=not args.ordered)
-    upd_cap = 16384          # = max_chunks: an updated-chunk list always fits
-    d_upd = torch.zeros((upd_cap, 3), dtype=torch.int32, device="cuda")
-    gathered_blocks = [0]
-    gdir = BlockDirectory(16384) if multi else None      # every rank's copy of the global block -> owner table
-
-    def step(b):
-        if depth_input:      # b = (depth images, colour images, grid table, step, min, max, ids, poses), points of the step
-            tsdf.integrate_depth_batch_dev(*b[0])
-            st = tsdf.last_stats()
-            st["points"] = b[1]          # (the library never forms the cloud: the points of the step from the generator)
-            return st
-        xyz, rgb, kfid, offsets, Twc = b
-        if vbx_sharded:
-            sharded_integrate_voxblox(tsdf, xyz, rgb, offsets, Twc)
-        elif vbx:
-            tsdf.integrate_batch_dev(xyz, rgb, offsets, Twc)
-        elif ray_sharded:
-            sharded_integrate(tsdf, xyz, rgb, kfid, offsets, Twc)
-        else:
-            tsdf.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
-        st = tsdf.last_stats()
-        if multi:      # the updated block lists, over RCCL
-            n = tsdf.updated_chunk_ids_dev(d_upd)
-            all_ids, counts = allgather_block_lists(d_upd, n, upd_cap, padded=True)
-            gdir.merge(all_ids, counts)
-            gathered_blocks[0] += 1
-        return st
-
-    def barrier():
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    timed = [(depth_batches[s], int(batches[s][3][-1])) for s in range(total_steps)] if depth_input else batches
-    for s in range(args.warmup):
-        step(timed[s])
-    if not vbx:
-        tsdf.set_profiling(True)
-    barrier()
-    t0 = time.perf_counter()
-    visits = 0
-    points = 0
-    max_run = 0
-    voxels = 0
-    step_wall = []
-    for s in range(args.warmup, total_steps):
-        ts0 = time.perf_counter()
-        st = step(timed[s])
-        step_wall.append(time.perf_counter() - ts0)   # (last_stats() has waited for the step: a per-step host clock)
-        visits += st["visits"]
-        points += st["points"]
-        max_run = max(max_run, st["max_run"])
-        voxels += st["voxels"]
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if vbx or ray_sharded:   # (the sharded step is three library calls around the exchanges: the wall clock is its time)
-        stage_ms, calls = {}, args.steps
-        if not vbx:
-            tsdf.set_profiling(False)
-    else:
-        stage_ms, calls = tsdf.stage_ms()
-        tsdf.set_profiling(False)
-
-    # ---- N > 1 (ray-sharded): where a step's time goes, and the other scaling leg
-    # phases_ms: three more steps run with a device synchronisation after each phase (walk / pack / exchange / apply /
-    # feedback; max over ranks) — their sum exceeds ms_per_step by the overlap the synchronisations remove.
-    # other_leg: the same job under the OTHER scaling rule (weak: --batch key frames per GPU per step; strong: --batch
-    # key frames per step whatever N), so one run of `bench.py --gpus N` gives both curves.
-    phases_ms, other_leg = None, None
-    if vbx_sharded:
-        tim = {}
-        for s in range(3):
-            sharded_integrate_voxblox(tsdf, *[batches[s % len(batches)][i] for i in (0, 1, 3, 4)], timings=tim)
-        names = ["walk", "pack", "exchange", "apply"]
-        t = torch.tensor([tim.get(k, 0.0) / 3.0 for k in names], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        phases_ms = {k: round(float(v), 4) for k, v in zip(names, t.tolist())}
-    if ray_sharded:
-        tim = {}
-        for s in range(3):
-            sharded_integrate(tsdf, *[batches[s % len(batches)][i] for i in (0, 1, 2, 3, 4)], timings=tim)
-        names = ["walk", "pack", "exchange", "apply", "feedback"]
-        t = torch.tensor([tim.get(k, 0.0) / 3.0 for k in names], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        phases_ms = {k: round(float(v), 4) for k, v in zip(names, t.tolist())}
-        if world > 1 or os.environ.get("PLVS_BENCH_FORCE_OTHER_LEG"):   # (the variable: a one-GPU rehearsal of this branch)
-            other_kfs = args.batch * (1 if not args.strong else world)
-            sel = [kfs[j % n_poses] for j in range(other_kfs)]
-            ob = (torch.from_numpy(np.concatenate([k["xyz"] for k in sel])).cuda(),
-                  torch.from_numpy(np.concatenate([k["rgb"] for k in sel])).cuda(),
-                  torch.from_numpy(np.concatenate([k["kfid"] for k in sel]).astype(np.int32)).cuda(),
-                  np.cumsum([0] + [k["xyz"].shape[0] for k in sel]).astype(np.int32),
-                  torch.from_numpy(np.stack([k["Twc"] for k in sel])).cuda())
-            for s in range(max(args.warmup, 1)):
-                step(ob)
-            barrier()
-            t1 = time.perf_counter()
-            ov = 0
-            for s in range(args.steps):
-                ov += step(ob)["visits"]
-            barrier()
-            t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            v = torch.tensor([ov], dtype=torch.int64, device="cuda")
-            dist.all_reduce(v, op=dist.ReduceOp.SUM)
-            other_leg = {"scaling": "strong" if not args.strong else "weak", "keyframes_per_step": other_kfs,
-                         "value": round(int(v.item()) / float(t.item()) / 1e6, 2), "unit": "Mvoxels/s",
-                         "ms_per_step": round(float(t.item()) / args.steps * 1e3, 3), "steps": args.steps}
-
-    # max over ranks of the elapsed time, sum over ranks of the visits
-    if multi:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        v = torch.tensor([visits], dtype=torch.int64, device="cuda")
-        dist.all_reduce(v, op=dist.ReduceOp.SUM)
-        visits_total = int(v.item())
-    else:
-        visits_total = visits
-
-    result = None
-    if rank == 0:
-        mvox = visits_total / elapsed / 1e6
-        # ------------------------------------------------------------ roofline
-        # Algorithmic bytes (SURVEY §8d): 32 B per voxel visit (16 B read + 16 B
-        # written of logical payload) + 28 B per point, for what THIS rank applied.
-        alg_bytes = (24.0 * visits + 16.0 * points) if vbx else (32.0 * visits + 28.0 * points)
-        gpu_ms = sum(stage_ms.values()) if stage_ms else elapsed * 1e3
-        dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None
-        achieved = alg_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else 0.0
-        roofline = {
-            "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-            "frac": round(achieved / 8000.0, 5), "traffic": None,
-            "kernel": f"tsdf_{args.backend} integrate pipeline (" + (", ".join(stage_ms) or "wall clock of the call") + ")",
-            "ms_per_launch": round(gpu_ms / max(calls, 1), 4),
-            "stage_ms_per_launch": {k: round(v / max(calls, 1), 4) for k, v in stage_ms.items()},
-            "dominant_stage": dominant,
-            "algorithmic_bytes_per_launch": alg_bytes / max(calls, 1),
-        }
-        # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
-        # runs of this same command; scripts/pmc_traffic.py) committed under profiles/
-        mode_tag = "" if vbx else ("_ordered" if args.ordered else "_order_free")
-        # (the newest committed passes of this command: round 6's for the depth-image headline and the voxblox leg, round 5's /
-        # round 4's where a later round made none)
-        pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        rounds = ("r06", "r05") if depth_input else ("r06", "r04")
-        pmc = ""
-        for rr in rounds:
-            pmc = os.path.join(pdir, f"{rr}_pmc_traffic_{args.backend}{mode_tag}{'_steady_state' if args.steady_state else ''}.json")
-            if os.path.exists(pmc):
-                break
-        if world == 1 and not multi and args.batch == 100 and os.path.exists(pmc):
-            with open(pmc) as f:
-                t = json.load(f)
-            roofline["traffic"] = t["traffic"]
-            roofline["traffic_source"] = ("profiles/" + os.path.basename(pmc) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                          "passes of this command, FETCH_SIZE x2 (gfx950) + WRITE_SIZE, per launch")
-        mode_name = "ordered (bit-exact)" if args.ordered else "order-free (fixed-point sums; sdf / weight within tolerance)"
-        result = {
-            "metric": ("Mvoxels/sec TSDF integrate (voxblox simple 2 cm / 8 m, 640x480 RGB-D)" if vbx else
-                       "Mvoxels/sec TSDF integrate (chisel 5 cm / 5 m, 640x480 RGB-D)"),
-            "value": round(mvox, 2), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak" if (ray_sharded and not args.strong) else "strong",
-            "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": ("configs[3] stand-in: synthetic room 16x12x3 m, camera circle r=1 m, Voxblox "
-                                    "simple TSDF 2 cm, max ray 5 m (wrapper constant), 76800-point keyframes" if vbx else
-                                    ("configs[2] stand-in, STEADY STATE: synthetic room 6x4x3 m, camera circle r=1 m, every step "
-                                     "re-integrates the same 100 key frames into a saturated map, Chisel TSDF 5 cm / 5 m, "
-                                     "76800-point keyframes" if args.steady_state else
-                                     "configs[2] stand-in, STREAMING: every step integrates the NEXT keyframes_per_step DISTINCT key "
-                                     "frames of one 2500-key-frame loop around a desk island in a 9.5x7.5x3 m office (the shape of "
-                                     "TUM fr3/long_office: 6 mm and 0.144 deg per key frame, new ground and revisits in every step, "
-                                     "chunk allocation and colour folds inside the timed region), Chisel TSDF 5 cm / 5 m, 76800-pixel "
-                                     "grid of which 36-73 k points per key frame have a depth below 5 m; the saturated-map figure of "
-                                     "rounds 1-3 is the `steady_state` leg")),
-                       "input": ("depth images (640x480, stride-2 grid): GeneratePointCloudInCameraFrameBGRA + InsertCloud fused, "
-                                 "plvs_hip_tsdf_chisel_integrate_depth_batch_dev" if depth_input else
-                                 "camera-frame point streams resident in HBM (integrate_batch_dev)"),
-                       "mode": None if vbx else mode_name,
-                       "resolution": args.resolution, "max_depth": args.max_depth,
-                       "keyframes_per_step": step_kfs, "points_per_step": int(points // args.steps),
-                       "ms_per_step_median_max": [round(float(np.median(step_wall)) * 1e3, 3), round(max(step_wall) * 1e3, 3)],
-                       **({"ms_per_step_each": [round(x * 1e3, 2) for x in step_wall]} if multi else {}),
-                       "visits_per_step": int(visits_total // args.steps),
-                       "voxels_per_step": int(voxels // args.steps), "longest_voxel_run": int(max_run),
-                       "parallelism": (f"ray-sharded x{world}: rank r walks tiles t = r (mod {world}), partial sums and "
-                                       f"colour runs go to the chunk owners (three-prime hash mod {world}) in one "
-                                       "all-to-all per step" if ray_sharded else
-                                       (f"ray-sharded x{world}: rank r casts the rays of the key frames c = r (mod {world}), every voxel "
-                                        f"visit goes to the block's owner (three-prime hash mod {world}) as a 16-byte record in one "
-                                        "all-to-all per step, the owner applies them in the reference's order" if vbx_sharded else
-                                        f"chunk-hash shard x{world}")),
-                       "global_directory_blocks": (gdir.count() if gdir is not None else None)},
-            "roofline": roofline,
-        }
-        if phases_ms is not None:
-            result["phases_ms"] = phases_ms
-        if other_leg is not None:
-            result["other_scaling_leg"] = other_leg
-
+def leg_realistic_calls(C):
     # ------------------------------------------------- what PLVS runs, not only the steady state (N = 1 only)
+    # (main's locals this leg reads)
+    TsdfChisel = getattr(C, 'TsdfChisel', None)
+    args = getattr(C, 'args', None)
+    batches = getattr(C, 'batches', None)
+    k = getattr(C, 'k', None)
+    kfs = getattr(C, 'kfs', None)
+    multi = getattr(C, 'multi', None)
+    n_poses = getattr(C, 'n_poses', None)
+    rank = getattr(C, 'rank', None)
+    result = getattr(C, 'result', None)
+    sel = getattr(C, 'sel', None)
+    st = getattr(C, 'st', None)
+    t = getattr(C, 't', None)
+    t0 = getattr(C, 't0', None)
+    vbx = getattr(C, 'vbx', None)
+    world = getattr(C, 'world', None)
     # The headline step re-integrates the same 100 key frames into a map that has seen them: no chunk is allocated,
     # nearly every colour has saturated.  Two legs with the rest inside the timed region:
     #  first_lap    a FRESH map takes the 100 key frames in one call: chunk allocation, directory inserts, a run and a
@@ -561,7 +265,23 @@ def main():
         tl.close()
         result["realistic_legs"] = legs
 
+
+def leg_steady_state(C):
     # ------------------------------------------------- the saturated-map workload of rounds 1-3, beside the headline
+    # (main's locals this leg reads)
+    TsdfChisel = getattr(C, 'TsdfChisel', None)
+    args = getattr(C, 'args', None)
+    depth_input = getattr(C, 'depth_input', None)
+    k = getattr(C, 'k', None)
+    make_keyframes = getattr(C, 'make_keyframes', None)
+    multi = getattr(C, 'multi', None)
+    pack_depth = getattr(C, 'pack_depth', None)
+    rank = getattr(C, 'rank', None)
+    result = getattr(C, 'result', None)
+    t0 = getattr(C, 't0', None)
+    v = getattr(C, 'v', None)
+    vbx = getattr(C, 'vbx', None)
+    world = getattr(C, 'world', None)
     if rank == 0 and world == 1 and not vbx and not multi and not args.steady_state and not args.no_steady_state_leg:
         sk = make_keyframes(100, max_depth=args.max_depth, seed=0, images=depth_input)
         if depth_input:
@@ -605,7 +325,21 @@ def main():
                          "unit": "GB/s", "frac": round((32.0 * sv + 28.0 * sp) / (sms * 1e-3) / 1e9 / 8000.0, 5),
                          "ms_per_launch": round(sms / max(sc, 1), 4)}}
 
+
+def leg_other_chisel_mode(C):
     # ------------------------------------------------- the other chisel mode, same stream (N = 1 only)
+    # (main's locals this leg reads)
+    TsdfChisel = getattr(C, 'TsdfChisel', None)
+    args = getattr(C, 'args', None)
+    batches = getattr(C, 'batches', None)
+    rank = getattr(C, 'rank', None)
+    result = getattr(C, 'result', None)
+    s = getattr(C, 's', None)
+    t0 = getattr(C, 't0', None)
+    total_steps = getattr(C, 'total_steps', None)
+    v = getattr(C, 'v', None)
+    vbx = getattr(C, 'vbx', None)
+    world = getattr(C, 'world', None)
     t2 = None
     if rank == 0 and world == 1 and not vbx and not args.no_other_mode_leg:
         t2 = TsdfChisel(args.resolution, max_chunks=16384, order_free=args.ordered)
@@ -640,8 +374,29 @@ def main():
             leg["what"] = ("plvs_tsdf_chisel_params.order_free = 0: every voxel update applied in the reference's order "
                            "(count, scan, tile sort, run sort, gather, sequential chain); sdf / weight bit-identical")
             result["bit_exact_mode"] = leg
+    # (what the rest of main reads again)
+    _l = locals()
+    if 't2' in _l:
+        C.t2 = _l['t2']
 
+
+def leg_parity_and_cpu_baseline(C):
     # ------------------------------------------------- parity of the timed maps + CPU baseline (rank 0, N = 1)
+    # (main's locals this leg reads)
+    args = getattr(C, 'args', None)
+    b = getattr(C, 'b', None)
+    k = getattr(C, 'k', None)
+    kfs = getattr(C, 'kfs', None)
+    n_poses = getattr(C, 'n_poses', None)
+    rank = getattr(C, 'rank', None)
+    result = getattr(C, 'result', None)
+    s = getattr(C, 's', None)
+    t0 = getattr(C, 't0', None)
+    t2 = getattr(C, 't2', None)
+    total_steps = getattr(C, 'total_steps', None)
+    tsdf = getattr(C, 'tsdf', None)
+    vbx = getattr(C, 'vbx', None)
+    world = getattr(C, 'world', None)
     if rank == 0 and world == 1 and not vbx and not args.no_parity_check and not args.no_cpu_baseline:
         from tests import oracle_lib
         oracle = oracle_lib.load()
@@ -759,7 +514,30 @@ def main():
     if t2 is not None:
         t2.close()
 
+
+def leg_voxblox_configs3(C):
     # ------------------------------------------------- configs[3]: voxblox 2 cm, a stream of distinct key frames (every N)
+    # (main's locals this leg reads)
+    TsdfVoxblox = getattr(C, 'TsdfVoxblox', None)
+    args = getattr(C, 'args', None)
+    b = getattr(C, 'b', None)
+    barrier = getattr(C, 'barrier', None)
+    f = getattr(C, 'f', None)
+    grp = getattr(C, 'grp', None)
+    j0 = getattr(C, 'j0', None)
+    k = getattr(C, 'k', None)
+    leg = getattr(C, 'leg', None)
+    make_stream_keyframes = getattr(C, 'make_stream_keyframes', None)
+    multi = getattr(C, 'multi', None)
+    oracle_lib = getattr(C, 'oracle_lib', None)
+    probe = getattr(C, 'probe', None)
+    rank = getattr(C, 'rank', None)
+    result = getattr(C, 'result', None)
+    rounds = getattr(C, 'rounds', None)
+    rr = getattr(C, 'rr', None)
+    t0 = getattr(C, 't0', None)
+    vbx = getattr(C, 'vbx', None)
+    world = getattr(C, 'world', None)
     # 25 key frames per step, every step the NEXT 25 of the office loop (depths to 8 m; rays beyond the wrapper's 5 m limit
     # become clearing rays): 2 warm-up + 4 timed steps = 150 distinct key frames.
     if not vbx and not args.no_voxblox_leg:
@@ -917,7 +695,35 @@ def main():
             result["voxblox_configs3"] = leg
         vb.close()
 
+
+def leg_frontend(C):
     # ------------------------------------------------- front end (N = 1 only)
+    # (main's locals this leg reads)
+    TsdfChisel = getattr(C, 'TsdfChisel', None)
+    _ct = getattr(C, '_ct', None)
+    _lib = getattr(C, '_lib', None)
+    args = getattr(C, 'args', None)
+    e = getattr(C, 'e', None)
+    f = getattr(C, 'f', None)
+    k = getattr(C, 'k', None)
+    leg = getattr(C, 'leg', None)
+    name = getattr(C, 'name', None)
+    names = getattr(C, 'names', None)
+    ora = getattr(C, 'ora', None)
+    oracle_lib = getattr(C, 'oracle_lib', None)
+    pinned = getattr(C, 'pinned', None)
+    q = getattr(C, 'q', None)
+    rank = getattr(C, 'rank', None)
+    result = getattr(C, 'result', None)
+    same = getattr(C, 'same', None)
+    st = getattr(C, 'st', None)
+    t = getattr(C, 't', None)
+    t0 = getattr(C, 't0', None)
+    ts = getattr(C, 'ts', None)
+    ts_ = getattr(C, 'ts_', None)
+    v = getattr(C, 'v', None)
+    w_ = getattr(C, 'w_', None)
+    world = getattr(C, 'world', None)
     if rank == 0 and world == 1 and not args.no_frontend:
         from plvs_amd.matcher import knn2_raw
         rng = np.random.default_rng(1)
@@ -1395,7 +1201,25 @@ def main():
         except Exception as e:
             result["kitti_shaped"] = {"skipped": repr(e)}
 
+
+def leg_cpu_baseline_alone(C):
     # -------------------------------------------------- CPU baseline when the parity leg did not run (rank 0)
+    # (main's locals this leg reads)
+    args = getattr(C, 'args', None)
+    ct = getattr(C, 'ct', None)
+    cv = getattr(C, 'cv', None)
+    i = getattr(C, 'i', None)
+    k = getattr(C, 'k', None)
+    kfs = getattr(C, 'kfs', None)
+    n_poses = getattr(C, 'n_poses', None)
+    ora = getattr(C, 'ora', None)
+    oracle = getattr(C, 'oracle', None)
+    oracle_lib = getattr(C, 'oracle_lib', None)
+    rank = getattr(C, 'rank', None)
+    result = getattr(C, 'result', None)
+    t0 = getattr(C, 't0', None)
+    vbx = getattr(C, 'vbx', None)
+    world = getattr(C, 'world', None)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and "cpu_baseline" not in result:
         from tests import oracle_lib
         oracle = oracle_lib.load()
@@ -1415,6 +1239,345 @@ def main():
             "sample": f"oracle/tsdf_{args.backend}.c (sequential / integrator_threads=1) on the first {nb} "
                       f"keyframes of the same stream, {ct:.1f} s, host has {os.cpu_count()} cores",
         }
+
+
+def main():
+    import types
+    C = types.SimpleNamespace()
+    args = parse()
+    # ONE line on stdout: the compiled reference sources behind the cpu_baseline legs print (open_chisel a line per garbage
+    # collection, line_descriptor a line per pyramid) — everything written to file descriptor 1 before the result goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    # PLVS_BENCH_REHEARSAL=1 (scripts/gpu_check.sh, stage `multi` on a one-GPU box): every rank on device 0, the exchanges over
+    # gloo (RCCL refuses two ranks on one device) — the N > 1 code path end to end with two real processes; never a measurement
+    rehearsal = os.environ.get("PLVS_BENCH_REHEARSAL", "0") == "1"
+    device_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(device_index)
+    multi = world > 1 or args.sharded_at_one
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if rehearsal:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+
+    from plvs_amd import _lib
+    from tests.synth_scene import LOOP, make_keyframes, make_stream_keyframes
+    from plvs_amd.shard import BlockDirectory, allgather_block_lists, sharded_integrate, sharded_integrate_voxblox
+    from plvs_amd.tsdf import TsdfChisel, TsdfVoxblox
+
+    # ---------------------------------------------------------------- inputs
+    n_poses = 100                                    # SURVEY §8d: 100 poses, 3.6 deg yaw step
+    total_steps = args.warmup + args.steps
+    vbx = args.backend == "voxblox"
+    # N > 1 (voxblox, "simple"): the ray-sharded integrate of tsdf_voxblox_shard.hpp — rank r casts the rays of every N-th key
+    # frame of the step and sends the voxel visits to the block owners.  STRONG scaling (the step stays --batch key frames):
+    # the update is an ordered fold per voxel, and a step of N x 25 consecutive key frames of one camera makes every voxel's
+    # run N times longer instead of giving the ranks more voxels (one device: 1.07 ms for 25 key frames, 21 ms for 200).
+    vbx_sharded = multi and vbx
+    if vbx:                      # SURVEY §8d config 4: 2 cm voxels, 16x12x3 m room, depths to 8 m
+        if args.resolution == 0.05:
+            args.resolution = 0.02
+        if args.max_depth == 5.0:
+            args.max_depth = 8.0
+        if args.steady_state:
+            kfs = make_keyframes(n_poses, room_size=(16.0, 12.0, 3.0), max_depth=args.max_depth, seed=0)
+        else:      # the office stream from key frame 400 on, as the voxblox_configs3 leg of the default run
+            n_poses = min(total_steps * args.batch, LOOP)
+            kfs = make_stream_keyframes(n_poses, first=400, max_depth=args.max_depth, seed=0, threads=min(32, os.cpu_count() or 8))
+        for k in kfs:
+            k["rgba"] = np.concatenate([k["rgb"], np.full((k["rgb"].shape[0], 1), 255, np.uint8)], axis=1)
+    elif args.steady_state:
+        kfs = make_keyframes(n_poses, max_depth=args.max_depth, seed=0)
+    # N > 1 (chisel, order-free): the ray-sharded integrate — rank r walks every N-th tile of the step's point
+    # stream and sends what it collected to the chunk owners.  Weak scaling by default: a step carries --batch
+    # keyframes PER GPU (a longer stretch of the stream, e.g. a map rebuild), so every rank's share of the rays
+    # stays what one GPU walks at N = 1.
+    ray_sharded = multi and not vbx and not args.ordered
+    step_kfs = args.batch * (world if (ray_sharded and not args.strong) else 1)
+    # N = 1, order-free chisel: the steps go in as the DEPTH IMAGES of the key frames (PLVS's real pipeline: depth image ->
+    # GeneratePointCloudInCameraFrameBGRA -> InsertCloud); the same key frames as point streams stay in HBM for the other
+    # legs (bit-exact mode, parity) and behind --cloud-input
+    depth_input = not vbx and not multi and not args.ordered and not args.cloud_input
+    if not vbx and not args.steady_state:
+        # configs[2] stand-in, streaming: step s integrates key frames [s * step_kfs, (s + 1) * step_kfs) of the long
+        # trajectory (tests/synth_scene.py: one loop of LOOP = 2500 DISTINCT key frames around a desk island in a
+        # 9.5 x 7.5 x 3 m office; a job longer than the loop walks it again)
+        n_poses = min(total_steps * step_kfs, LOOP)
+        kfs = make_stream_keyframes(n_poses, max_depth=args.max_depth, seed=0, threads=min(32, os.cpu_count() or 8),
+                                    images=depth_input)
+    elif depth_input:
+        kfs = make_keyframes(n_poses, max_depth=args.max_depth, seed=0, images=True)
+
+    def pack_depth(sel, step=2):
+        """The key frames as 640 x 480 images in HBM: depth and colour at the pixels of the stride-2 grid (the others are
+        never read: src/PointCloudMapping.cc:957-996 visits m, n = 0, step, 2 step, ...), the grid table, one id per image."""
+        gh, gw = sel[0]["depth_grid"].shape
+        d = torch.zeros((len(sel), gh * step, gw * step), dtype=torch.float32, device="cuda")
+        c = torch.zeros((len(sel), gh * step, gw * step, 3), dtype=torch.uint8, device="cuda")
+        d[:, ::step, ::step] = torch.from_numpy(np.stack([k["depth_grid"] for k in sel])).cuda()
+        c[:, ::step, ::step] = torch.from_numpy(np.stack([k["rgb_grid"] for k in sel])).cuda()
+        return (d, c, torch.from_numpy(sel[0]["cam_grid"]).cuda(), step, 0.1, args.max_depth,
+                torch.from_numpy(np.array([int(k["kfid"][0]) if len(k["kfid"]) else 0 for k in sel], np.int32)).cuda(),
+                torch.from_numpy(np.stack([k["Twc"] for k in sel])).cuda())
+    batches = []
+    depth_batches = []
+    built_depth = {}
+    built = {}     # steps that carry the same key frames share one copy in HBM (at N x 100 key frames per step all do)
+    for s in range(total_steps):
+        first = (s * step_kfs) % n_poses
+        if first not in built:
+            sel = [kfs[(first + j) % n_poses] for j in range(step_kfs)]
+            xyz = torch.from_numpy(np.concatenate([k["xyz"] for k in sel])).cuda()
+            rgb = torch.from_numpy(np.concatenate([k["rgba" if vbx else "rgb"] for k in sel])).cuda()
+            kfid = torch.from_numpy(np.concatenate([k["kfid"] for k in sel]).astype(np.int32)).cuda()
+            Twc = torch.from_numpy(np.stack([k["Twc"] for k in sel])).cuda()
+            offsets = np.cumsum([0] + [k["xyz"].shape[0] for k in sel]).astype(np.int32)
+            built[first] = (xyz, rgb, kfid, offsets, Twc)
+            if depth_input:
+                built_depth[first] = pack_depth(sel)
+        batches.append(built[first])
+        if depth_input:
+            depth_batches.append(built_depth[first])
+
+    if vbx:
+        tsdf = TsdfVoxblox(args.resolution, max_blocks=65536, shard_rank=rank, shard_count=world)
+    else:
+        tsdf = TsdfChisel(args.resolution, max_chunks=16384, shard_rank=rank, shard_count=world,
+                          order_free=not args.ordered)
+    upd_cap = 16384          # = max_chunks: an updated-chunk list always fits
+    d_upd = torch.zeros((upd_cap, 3), dtype=torch.int32, device="cuda")
+    gathered_blocks = [0]
+    gdir = BlockDirectory(16384) if multi else None      # every rank's copy of the global block -> owner table
+
+    def step(b):
+        if depth_input:      # b = (depth images, colour images, grid table, step, min, max, ids, poses), points of the step
+            tsdf.integrate_depth_batch_dev(*b[0])
+            st = tsdf.last_stats()
+            st["points"] = b[1]          # (the library never forms the cloud: the points of the step from the generator)
+            return st
+        xyz, rgb, kfid, offsets, Twc = b
+        if vbx_sharded:
+            sharded_integrate_voxblox(tsdf, xyz, rgb, offsets, Twc)
+        elif vbx:
+            tsdf.integrate_batch_dev(xyz, rgb, offsets, Twc)
+        elif ray_sharded:
+            sharded_integrate(tsdf, xyz, rgb, kfid, offsets, Twc)
+        else:
+            tsdf.integrate_batch_dev(xyz, rgb, kfid, offsets, Twc)
+        st = tsdf.last_stats()
+        if multi:      # the updated block lists, over RCCL
+            n = tsdf.updated_chunk_ids_dev(d_upd)
+            all_ids, counts = allgather_block_lists(d_upd, n, upd_cap, padded=True)
+            gdir.merge(all_ids, counts)
+            gathered_blocks[0] += 1
+        return st
+
+    def barrier():
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    timed = [(depth_batches[s], int(batches[s][3][-1])) for s in range(total_steps)] if depth_input else batches
+    for s in range(args.warmup):
+        step(timed[s])
+    if not vbx:
+        tsdf.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    visits = 0
+    points = 0
+    max_run = 0
+    voxels = 0
+    step_wall = []
+    for s in range(args.warmup, total_steps):
+        ts0 = time.perf_counter()
+        st = step(timed[s])
+        step_wall.append(time.perf_counter() - ts0)   # (last_stats() has waited for the step: a per-step host clock)
+        visits += st["visits"]
+        points += st["points"]
+        max_run = max(max_run, st["max_run"])
+        voxels += st["voxels"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if vbx or ray_sharded:   # (the sharded step is three library calls around the exchanges: the wall clock is its time)
+        stage_ms, calls = {}, args.steps
+        if not vbx:
+            tsdf.set_profiling(False)
+    else:
+        stage_ms, calls = tsdf.stage_ms()
+        tsdf.set_profiling(False)
+
+    # ---- N > 1 (ray-sharded): where a step's time goes, and the other scaling leg
+    # phases_ms: three more steps run with a device synchronisation after each phase (walk / pack / exchange / apply /
+    # feedback; max over ranks) — their sum exceeds ms_per_step by the overlap the synchronisations remove.
+    # other_leg: the same job under the OTHER scaling rule (weak: --batch key frames per GPU per step; strong: --batch
+    # key frames per step whatever N), so one run of `bench.py --gpus N` gives both curves.
+    phases_ms, other_leg = None, None
+    if vbx_sharded:
+        tim = {}
+        for s in range(3):
+            sharded_integrate_voxblox(tsdf, *[batches[s % len(batches)][i] for i in (0, 1, 3, 4)], timings=tim)
+        names = ["walk", "pack", "exchange", "apply"]
+        t = torch.tensor([tim.get(k, 0.0) / 3.0 for k in names], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        phases_ms = {k: round(float(v), 4) for k, v in zip(names, t.tolist())}
+    if ray_sharded:
+        tim = {}
+        for s in range(3):
+            sharded_integrate(tsdf, *[batches[s % len(batches)][i] for i in (0, 1, 2, 3, 4)], timings=tim)
+        names = ["walk", "pack", "exchange", "apply", "feedback"]
+        t = torch.tensor([tim.get(k, 0.0) / 3.0 for k in names], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        phases_ms = {k: round(float(v), 4) for k, v in zip(names, t.tolist())}
+        if world > 1 or os.environ.get("PLVS_BENCH_FORCE_OTHER_LEG"):   # (the variable: a one-GPU rehearsal of this branch)
+            other_kfs = args.batch * (1 if not args.strong else world)
+            sel = [kfs[j % n_poses] for j in range(other_kfs)]
+            ob = (torch.from_numpy(np.concatenate([k["xyz"] for k in sel])).cuda(),
+                  torch.from_numpy(np.concatenate([k["rgb"] for k in sel])).cuda(),
+                  torch.from_numpy(np.concatenate([k["kfid"] for k in sel]).astype(np.int32)).cuda(),
+                  np.cumsum([0] + [k["xyz"].shape[0] for k in sel]).astype(np.int32),
+                  torch.from_numpy(np.stack([k["Twc"] for k in sel])).cuda())
+            for s in range(max(args.warmup, 1)):
+                step(ob)
+            barrier()
+            t1 = time.perf_counter()
+            ov = 0
+            for s in range(args.steps):
+                ov += step(ob)["visits"]
+            barrier()
+            t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            v = torch.tensor([ov], dtype=torch.int64, device="cuda")
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            other_leg = {"scaling": "strong" if not args.strong else "weak", "keyframes_per_step": other_kfs,
+                         "value": round(int(v.item()) / float(t.item()) / 1e6, 2), "unit": "Mvoxels/s",
+                         "ms_per_step": round(float(t.item()) / args.steps * 1e3, 3), "steps": args.steps}
+
+    # max over ranks of the elapsed time, sum over ranks of the visits
+    if multi:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        v = torch.tensor([visits], dtype=torch.int64, device="cuda")
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        visits_total = int(v.item())
+    else:
+        visits_total = visits
+
+    result = None
+    if rank == 0:
+        mvox = visits_total / elapsed / 1e6
+        # ------------------------------------------------------------ roofline
+        # Algorithmic bytes (SURVEY §8d): 32 B per voxel visit (16 B read + 16 B
+        # written of logical payload) + 28 B per point, for what THIS rank applied.
+        alg_bytes = (24.0 * visits + 16.0 * points) if vbx else (32.0 * visits + 28.0 * points)
+        gpu_ms = sum(stage_ms.values()) if stage_ms else elapsed * 1e3
+        dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None
+        achieved = alg_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else 0.0
+        roofline = {
+            "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(achieved / 8000.0, 5), "traffic": None,
+            "kernel": f"tsdf_{args.backend} integrate pipeline (" + (", ".join(stage_ms) or "wall clock of the call") + ")",
+            "ms_per_launch": round(gpu_ms / max(calls, 1), 4),
+            "stage_ms_per_launch": {k: round(v / max(calls, 1), 4) for k, v in stage_ms.items()},
+            "dominant_stage": dominant,
+            "algorithmic_bytes_per_launch": alg_bytes / max(calls, 1),
+        }
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
+        # runs of this same command; scripts/pmc_traffic.py) committed under profiles/
+        mode_tag = "" if vbx else ("_ordered" if args.ordered else "_order_free")
+        # (the newest committed passes of this command: round 6's for the depth-image headline and the voxblox leg, round 5's /
+        # round 4's where a later round made none)
+        pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        rounds = ("r06", "r05") if depth_input else ("r06", "r04")
+        pmc = ""
+        for rr in rounds:
+            pmc = os.path.join(pdir, f"{rr}_pmc_traffic_{args.backend}{mode_tag}{'_steady_state' if args.steady_state else ''}.json")
+            if os.path.exists(pmc):
+                break
+        if world == 1 and not multi and args.batch == 100 and os.path.exists(pmc):
+            with open(pmc) as f:
+                t = json.load(f)
+            roofline["traffic"] = t["traffic"]
+            roofline["traffic_source"] = ("profiles/" + os.path.basename(pmc) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                          "passes of this command, FETCH_SIZE x2 (gfx950) + WRITE_SIZE, per launch")
+        mode_name = "ordered (bit-exact)" if args.ordered else "order-free (fixed-point sums; sdf / weight within tolerance)"
+        result = {
+            "metric": ("Mvoxels/sec TSDF integrate (voxblox simple 2 cm / 8 m, 640x480 RGB-D)" if vbx else
+                       "Mvoxels/sec TSDF integrate (chisel 5 cm / 5 m, 640x480 RGB-D)"),
+            "value": round(mvox, 2), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak" if (ray_sharded and not args.strong) else "strong",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": ("configs[3] stand-in: synthetic room 16x12x3 m, camera circle r=1 m, Voxblox "
+                                    "simple TSDF 2 cm, max ray 5 m (wrapper constant), 76800-point keyframes" if vbx else
+                                    ("configs[2] stand-in, STEADY STATE: synthetic room 6x4x3 m, camera circle r=1 m, every step "
+                                     "re-integrates the same 100 key frames into a saturated map, Chisel TSDF 5 cm / 5 m, "
+                                     "76800-point keyframes" if args.steady_state else
+                                     "configs[2] stand-in, STREAMING: every step integrates the NEXT keyframes_per_step DISTINCT key "
+                                     "frames of one 2500-key-frame loop around a desk island in a 9.5x7.5x3 m office (the shape of "
+                                     "TUM fr3/long_office: 6 mm and 0.144 deg per key frame, new ground and revisits in every step, "
+                                     "chunk allocation and colour folds inside the timed region), Chisel TSDF 5 cm / 5 m, 76800-pixel "
+                                     "grid of which 36-73 k points per key frame have a depth below 5 m; the saturated-map figure of "
+                                     "rounds 1-3 is the `steady_state` leg")),
+                       "input": ("depth images (640x480, stride-2 grid): GeneratePointCloudInCameraFrameBGRA + InsertCloud fused, "
+                                 "plvs_hip_tsdf_chisel_integrate_depth_batch_dev" if depth_input else
+                                 "camera-frame point streams resident in HBM (integrate_batch_dev)"),
+                       "mode": None if vbx else mode_name,
+                       "resolution": args.resolution, "max_depth": args.max_depth,
+                       "keyframes_per_step": step_kfs, "points_per_step": int(points // args.steps),
+                       "ms_per_step_median_max": [round(float(np.median(step_wall)) * 1e3, 3), round(max(step_wall) * 1e3, 3)],
+                       **({"ms_per_step_each": [round(x * 1e3, 2) for x in step_wall]} if multi else {}),
+                       "visits_per_step": int(visits_total // args.steps),
+                       "voxels_per_step": int(voxels // args.steps), "longest_voxel_run": int(max_run),
+                       "parallelism": (f"ray-sharded x{world}: rank r walks tiles t = r (mod {world}), partial sums and "
+                                       f"colour runs go to the chunk owners (three-prime hash mod {world}) in one "
+                                       "all-to-all per step" if ray_sharded else
+                                       (f"ray-sharded x{world}: rank r casts the rays of the key frames c = r (mod {world}), every voxel "
+                                        f"visit goes to the block's owner (three-prime hash mod {world}) as a 16-byte record in one "
+                                        "all-to-all per step, the owner applies them in the reference's order" if vbx_sharded else
+                                        f"chunk-hash shard x{world}")),
+                       "global_directory_blocks": (gdir.count() if gdir is not None else None)},
+            "roofline": roofline,
+        }
+        if phases_ms is not None:
+            result["phases_ms"] = phases_ms
+        if other_leg is not None:
+            result["other_scaling_leg"] = other_leg
+
+    C.__dict__.update(locals())   # (the leg reads main's locals through C)
+    leg_realistic_calls(C)
+
+    C.__dict__.update(locals())   # (the leg reads main's locals through C)
+    leg_steady_state(C)
+
+    C.__dict__.update(locals())   # (the leg reads main's locals through C)
+    leg_other_chisel_mode(C)
+    if hasattr(C, 't2'):
+        t2 = C.t2
+
+    C.__dict__.update(locals())   # (the leg reads main's locals through C)
+    leg_parity_and_cpu_baseline(C)
+
+    C.__dict__.update(locals())   # (the leg reads main's locals through C)
+    leg_voxblox_configs3(C)
+
+    C.__dict__.update(locals())   # (the leg reads main's locals through C)
+    leg_frontend(C)
+
+    C.__dict__.update(locals())   # (the leg reads main's locals through C)
+    leg_cpu_baseline_alone(C)
 
     if rank == 0:
         try:      # (whatever the runtime's C libraries — RCCL's banner — still hold in stdio comes out BEFORE the line)
