@@ -303,6 +303,26 @@ int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm,
   // RCCL error inside this function) cannot be taken back on the ranks that have applied: the error message says that
   // the sharded map is inconsistent and must be cleared / rebuilt.
   int failed = plvs_hip_tsdf_chisel_shard_walk(h, d_xyz, offsets, nclouds, d_Twc, sc, stream);
+  constexpr int kSatRows = 16384;
+  const size_t msg_words = 4 * ((size_t)kSatRows + 1);
+  if (failed == PLVS_OK) {
+    // Every buffer whose size this rank knows BEFORE the counts exchange is reserved before it: running out of
+    // memory for them is then an announced failure — the step is void on every rank — and not a rank that cannot go through
+    // collectives its peers are committed to.  Only the receive buffers wait for the peers' counts.
+    size_t own[3] = {0, 0, 0};
+    for (int p = 0; p < world; ++p)
+      for (int k = 0; k < 3; ++k) own[k] += (size_t)sc[3 * p + k];
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < 3 && e == hipSuccess; ++k) e = B.send[k].reserve(own[k] * kWords[k] + 4);
+    if (e == hipSuccess) e = B.sat.reserve(msg_words);
+    if (e == hipSuccess) e = B.all_sat.reserve(msg_words * world);
+    if (e == hipSuccess) e = B.cnt.reserve((size_t)6 * world);
+    if (e != hipSuccess) {
+      plvs::set_error("sharded integrate: reserving the send buffers failed: %s (announced: the step is void on every rank)",
+                      hipGetErrorString(e));
+      failed = PLVS_ERR_HIP;
+    }
+  }
   if (failed != PLVS_OK)
     for (int p = 0; p < world; ++p) sc[3 * p] = -1, sc[3 * p + 1] = 0, sc[3 * p + 2] = 0;
   int rc = PLVS_OK;
@@ -342,8 +362,6 @@ int plvs_hip_tsdf_chisel_integrate_sharded(plvs_tsdf_chisel* h, void* rccl_comm,
       stot[k] += (size_t)sc[3 * p + k];
       rtot[k] += (size_t)rcv[3 * p + k];
     }
-  constexpr int kSatRows = 16384;
-  const size_t msg_words = 4 * ((size_t)kSatRows + 1);
   for (int k = 0; k < 3; ++k) {
     L.note_hip(B.send[k].reserve(stot[k] * kWords[k] + 4), "reserving the send buffer", true);
     L.note_hip(B.recv[k].reserve(rtot[k] * kWords[k] + 4), "reserving the receive buffer", true);
@@ -420,6 +438,17 @@ int plvs_hip_tsdf_voxblox_integrate_sharded(plvs_tsdf_voxblox* h, void* rccl_com
   constexpr size_t kWords = 4;   // uint32 words of a visit record (kVbWire)
   int64_t sc[64], rcv[64];
   int failed = plvs_hip_tsdf_voxblox_shard_walk(h, d_xyz, offsets, nclouds, d_Twc, sc, stream);
+  if (failed == PLVS_OK) {   // (the send buffer's size is known before the counts exchange: out of memory for it is an announced failure)
+    size_t own = 0;
+    for (int p = 0; p < world; ++p) own += (size_t)sc[p];
+    hipError_t e = B.send.reserve(own * kWords + 4);
+    if (e == hipSuccess) e = B.cnt.reserve((size_t)2 * world);
+    if (e != hipSuccess) {
+      plvs::set_error("sharded integrate: reserving the send buffer failed: %s (announced: the step is void on every rank)",
+                      hipGetErrorString(e));
+      failed = PLVS_ERR_HIP;
+    }
+  }
   if (failed != PLVS_OK)
     for (int p = 0; p < world; ++p) sc[p] = -1;
   bool peer_failed = false;
