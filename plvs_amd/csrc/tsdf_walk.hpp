@@ -2335,7 +2335,17 @@ __global__ __launch_bounds__(1024) void sort_runs_medium(const uint32_t* __restr
   for (int p = 0; p < passes; ++p) {
     const int shift = kDigitBits * p;
     for (int d = lane; d < kBins; d += 64) hist[wid][d] = 0u;
-    for (uint32_t j = lo + (uint32_t)lane; j < hi; j += 64) atomicAdd(&hist[wid][(ki[j] >> shift) & (uint32_t)(kBins - 1)], 1u);
+    for (uint32_t j0 = lo; j0 < hi; j0 += 4 * 64) {   // (four independent loads in flight per lane: one CU's global latency is the pass)
+      uint32_t kk[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t j = j0 + (uint32_t)(u * 64 + lane);
+        kk[u] = j < hi ? ki[j] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j0 + (uint32_t)(u * 64 + lane) < hi) atomicAdd(&hist[wid][(kk[u] >> shift) & (uint32_t)(kBins - 1)], 1u);
+    }
     __syncthreads();
     {   // hist[w][d] -> where wave w's first pair of digit d goes: digits ascending, waves ascending inside a digit
       constexpr int kOwn = kBins * kWaves / 1024;   // (digit, wave) pairs a thread owns, consecutive in digit-major order
@@ -2359,10 +2369,21 @@ __global__ __launch_bounds__(1024) void sort_runs_medium(const uint32_t* __restr
       }
     }
     __syncthreads();
-    for (uint32_t j0 = lo; j0 < hi; j0 += 64) {
+    for (uint32_t jq = lo; jq < hi; jq += 4 * 64) {
+      uint32_t kq[4], vq[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {   // (the loads of four batches in flight, then the batches in order)
+        const uint32_t j = jq + (uint32_t)(u * 64 + lane);
+        kq[u] = j < hi ? ki[j] : 0u;
+        vq[u] = j < hi ? vi[j] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+      const uint32_t j0 = jq + (uint32_t)(u * 64);
+      if (j0 >= hi) break;   // (uniform over the wave)
       const uint32_t j = j0 + (uint32_t)lane;
       const bool live = j < hi;
-      const uint32_t key = live ? ki[j] : 0u, val = live ? vi[j] : 0u;
+      const uint32_t key = kq[u], val = vq[u];
       const uint32_t dg = (key >> shift) & (uint32_t)(kBins - 1);
       unsigned long long same = __ballot(live);
 #pragma unroll
@@ -2378,6 +2399,7 @@ __global__ __launch_bounds__(1024) void sort_runs_medium(const uint32_t* __restr
       __builtin_amdgcn_wave_barrier();
       if (live && (same >> lane) <= 1ull) hist[wid][dg] += (uint32_t)__popcll(same);   // (the digit's last lane of the batch)
       __builtin_amdgcn_wave_barrier();
+      }
     }
     __syncthreads();
     uint32_t* t = ki; ki = ko; ko = t;
