@@ -901,8 +901,16 @@ struct plvs_tsdf_chisel {
   WalkCounters* h_wctr = nullptr;   // pinned
   uint32_t* h_seq = nullptr;        // pinned, coherent: the sequence number of the last publish_counters that has landed
   uint32_t seq_next = 0;
-  double wait_ema_us[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};       // how long the host's last waits for the published counters took (wait_published)
+  double wait_ema_us[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};       // how long the host's last waits for the published counters took (wait_published)
   DevBuf<uint4> w_rec, w_seg, w_sorted_seg;
+  // a long call's runs chunk by chunk (runs_count ... parts_place): the segments' run descriptors and the runs of the
+  // same row in the block's earlier tiles; runs per (row, block); chunk slot -> place among the updated; region, runs and
+  // first part of every row; the parts' rows and histograms
+  DevBuf<uint4> w_rseg, w_rpre;
+  DevBuf<uint32_t> w_run_matrix, w_active_idx, w_item_base, w_item_cnt, w_item_part0, w_part_item, w_phist, w_row_heads;
+  hipEvent_t ev_seg = nullptr;   // the updated chunks are listed (seg_scan; caller's stream -> side stream)
+  int last_chain = 0;            // (developer trace) the last call's colour chain: 0 on its own counts, 1 predicted, 2 collected
+  bool last_chain_skipped = false;   //   ... and whether it had to be repeated
   DevBuf<uint32_t> w_chunk_nseg, w_chunk_off, w_chunk_fill, w_active_off, w_masks, w_dummy, w_seg_cnt, w_tile_visits, w_deferred;
   DevBuf<uint32_t> w_part_off, w_multi_idx;          // apply stage: parts of the updated chunks
   DevBuf<long long> pa_wuu;                          //   accumulators of the chunks applied in parts (zero between calls)
@@ -1066,7 +1074,9 @@ static int wait_published(plvs_tsdf_chisel* h, uint32_t seq, hipStream_t q, int 
     bool done = *word == seq;
     if (!done && ema > 200.0) {   // most of an expected long wait is slept, not polled (timer slack: ~60 us)
       timespec nap;
-      const double us = std::min(ema - 120.0, 5000.0);
+      // (... of a wait of a whole long call — a chain queued without a read of the walk's counters — 70 %: its length follows
+      // the view, +-20 % from call to call, and a nap that overshoots is paid in full)
+      const double us = std::min(std::min(ema - 120.0, 0.7 * ema), 5000.0);
       nap.tv_sec = 0;
       nap.tv_nsec = (long)(us * 1e3);
       nanosleep(&nap, nullptr);
@@ -1215,7 +1225,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
   PLVS_HIP_TRY(h->updated.reserve((size_t)max_chunks + 1));
   PLVS_HIP_TRY(h->w_seg_cnt.reserve(ntiles));
   PLVS_HIP_TRY(h->w_tile_visits.reserve(ntiles));
-  PLVS_HIP_TRY(h->w_deferred.reserve(2 * (size_t)ntiles));   // (two lists: after the 2048-entry pass, after the 4096-entry pass)
+  PLVS_HIP_TRY(h->w_deferred.reserve(3 * (size_t)ntiles));   // (three lists: one behind each lean pass)
   // every tile owns kRecStride records / kWalkChunks segments; the spill area behind them grows on demand
   const size_t rec_own = (size_t)ntiles * kRecStride, seg_own = (size_t)ntiles * kWalkChunks;
   if (rec_own + (1 << 16) >= 0xFFFFFFFFull) {
@@ -1239,6 +1249,8 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
   h->stage_set = 1;
   const int size_class = ntiles <= kSmallCallTiles ? 0 : (ntiles <= kPredictTiles ? 1 : 2);
   const int chunks_before = h->num_chunks;
+  timespec trace_t0;   // (developer trace: the call's time on the host's clock)
+  clock_gettime(CLOCK_MONOTONIC, &trace_t0);
 #define STAGE_MARK(i) \
   do { if (h->profiling) PLVS_HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
   for (int attempt = 0;; ++attempt) {
@@ -1248,6 +1260,41 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     if (h->w_rec.cap < rec_own + rec_spill) PLVS_HIP_TRY(h->w_rec.reserve(2 * rec_own + rec_spill));
     if (h->w_seg.cap < 2 * (seg_own + seg_spill)) PLVS_HIP_TRY(h->w_seg.reserve(2 * (2 * seg_own + seg_spill)));
     PLVS_HIP_TRY(h->w_sorted_seg.reserve(h->w_seg.cap));
+    // (a long call: its runs may be collected chunk by chunk — decided once the walk's counters are read, below)
+    static const int collect_mode = plvs::env_int("PLVS_TSDF_COLLECT", 1, 0, 2);   // (developer switch: 0 never, 2 every call — tests)
+    const bool collect_ready = collect_mode != 0 && (ntiles > kPredictTiles || collect_mode == 2);
+    // (rows of the run matrix: twice the chunks the call before updated — more than that and the general chain takes over)
+    // (a power of two: the matrix is re-allocated when a stream's calls update twice the chunks, not a few more each time)
+    size_t collect_row_chunks = 256;
+    while (collect_row_chunks < 2 * (size_t)h->last_updated + 64) collect_row_chunks *= 2;
+    const uint32_t collect_rows = (uint32_t)std::min<size_t>((size_t)max_chunks, collect_row_chunks) * kSlabs;
+    const uint32_t collect_blocks = (uint32_t)ceil_div(seg_own, kSegSpan);
+    // (the most runs its buffers hold: four times the call before scaled to this call's tiles — the stream's counts go 4.5 M,
+    // 1.4 M, 1.6 M, 1.1 M, 2.6 M —, 8 M at least, never more than the tiles' run slots)
+    const uint32_t collect_bound = (uint32_t)std::min<size_t>(
+        (size_t)ntiles << h->run_r1_log2,
+        std::max<size_t>((size_t)8 << 20, h->small_runs_known ? (size_t)(4.0 * (double)h->small_runs_last * (double)ntiles /
+                                                                         (double)std::max(1u, h->small_tiles_last)) : 0));
+    if (collect_ready) {
+      PLVS_HIP_TRY(h->w_rseg.reserve(h->w_seg.cap));
+      PLVS_HIP_TRY(h->w_rpre.reserve(seg_own));
+      PLVS_HIP_TRY(h->w_active_idx.reserve((size_t)max_chunks));
+      PLVS_HIP_TRY(h->w_run_matrix.reserve((size_t)collect_rows * collect_blocks));
+      PLVS_HIP_TRY(h->w_item_base.reserve(collect_rows));
+      PLVS_HIP_TRY(h->w_item_cnt.reserve(collect_rows));
+      PLVS_HIP_TRY(h->w_item_part0.reserve(collect_rows));
+      PLVS_HIP_TRY(h->w_row_heads.reserve(collect_rows));
+      const size_t parts_cap = (size_t)collect_bound / kCollectPart + collect_rows + 1;
+      PLVS_HIP_TRY(h->dkey0.reserve(collect_bound));
+      PLVS_HIP_TRY(h->dkey1.reserve(collect_bound));
+      PLVS_HIP_TRY(h->w_val0.reserve(collect_bound));
+      PLVS_HIP_TRY(h->w_val1.reserve(collect_bound));
+      PLVS_HIP_TRY(h->heads.reserve(collect_bound));
+      PLVS_HIP_TRY(h->w_part_item.reserve(parts_cap));
+      PLVS_HIP_TRY(h->w_phist.reserve(parts_cap * kSlabVox));
+      // (zero while the walk runs: runs_count writes the cells that hold runs)
+      PLVS_HIP_TRY(hipMemsetAsync(h->w_run_matrix.p, 0, (size_t)collect_rows * collect_blocks * sizeof(uint32_t), h->side));
+    }
     if (h->w_runkey.cap < ((size_t)ntiles << h->run_r1_log2)) {
       PLVS_HIP_TRY(h->w_runkey.reserve((size_t)2 * ntiles << h->run_r1_log2));
       PLVS_HIP_TRY(h->w_masks.reserve(((size_t)2 * ntiles << h->run_r1_log2) * kMaskWords));
@@ -1262,11 +1309,12 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     AccOut out{h->w_rec.p, (uint32_t)std::min<size_t>(rec_own + rec_spill, 0xFFFFFFFFu), h->w_seg.p,
                (uint32_t)std::min<size_t>(seg_own + seg_spill, 0xFFFFFFFFu), h->w_seg_cnt.p, h->w_tile_visits.p,
                count_in_walk ? h->w_chunk_nseg.p : nullptr};
-    RunOut runs{h->w_runkey.p, h->w_masks.p, h->w_run_cnt.p, h->run_r1_log2};
+    RunOut runs{h->w_runkey.p, h->w_masks.p, h->w_run_cnt.p, h->run_r1_log2, collect_ready ? h->w_rseg.p : nullptr};
     // the common case of a tile alone in a lean kernel; what it defers (tiles over several clouds, table overflows,
     // the owner-filtered walk of a sharded handle) is walked by the general kernel from the list
     uint32_t* const list_a = h->w_deferred.p;
     uint32_t* const list_b = h->w_deferred.p + ntiles;
+    uint32_t* const list_c = h->w_deferred.p + 2 * (size_t)ntiles;
     const uint32_t* last_list = list_a;
     const uint32_t* last_count = &h->d_wctr->ndeferred;
     bool second_small = false;
@@ -1297,17 +1345,22 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
       else PLVS_WALK_FAST(kFastEntries, ntiles, nullptr, nullptr, list_a, &h->d_wctr->ndeferred);
       // the tiles that overflowed the first pass: a 1024-entry first pass hands them to the 2048-entry kernel (two tiles per CU
       // instead of one: nearly all of them fit it), a 2048-entry first pass to the 4096-entry one
-      if (h->walk_small)
+      if (h->walk_small) {
         PLVS_WALK_FAST(kFastEntries, std::min<unsigned>(ntiles, 2 * kListGrid), list_a, &h->d_wctr->ndeferred, list_b,
                        &h->d_wctr->ndeferred2);
-      else
+        // ... and what overflows that one too (a tile or two of a call, a wall 5 m away seen at a slant) to the 4096-entry
+        // kernel rather than to walk_tiles: a launch that finds an empty list nearly always — and a call none of whose tiles
+        // reaches walk_tiles can have its runs collected chunk by chunk (below) instead of sorted
+        PLVS_WALK_FAST(kFastEntriesBig, std::min<unsigned>(ntiles, kListGrid), list_b, &h->d_wctr->ndeferred2, list_c,
+                       &h->d_wctr->ndeferred3);
+      } else
         PLVS_WALK_FAST(kFastEntriesBig, std::min<unsigned>(ntiles, kListGrid), list_a, &h->d_wctr->ndeferred, list_b,
                        &h->d_wctr->ndeferred2);
-      second_small = h->walk_small;
+      second_small = false;   // (the last lean pass had 4096 entries either way)
 #undef PLVS_WALK_FAST
 #undef PLVS_LAUNCH_WALK_FAST
-      last_list = list_b;
-      last_count = &h->d_wctr->ndeferred2;
+      last_list = h->walk_small ? list_c : list_b;
+      last_count = h->walk_small ? &h->d_wctr->ndeferred3 : &h->d_wctr->ndeferred2;
     }
     hipLaunchKernelGGL((walk_tiles<true, true>), dim3(kDeferGrid), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
                        h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
@@ -1336,8 +1389,9 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     // per step 0.969 -> 0.965 ms, wall time 1.05 -> 1.07 (a bound that fails costs the chain twice): the chain's length is its
     // kernels' (fold 0.13, three passes 0.15, compaction, heads), not the host's read.
     constexpr size_t kPredictRuns = 200000;
+    constexpr uint32_t kCollectMinRuns = 65536;
     static const bool predict_long = plvs::env_int("PLVS_TSDF_PREDICT_LONG", 0, 0, 1) != 0;   // (developer switch)
-    const bool predicted = h->small_runs_known && attempt == 0 &&
+    const bool predicted = h->small_runs_known && attempt == 0 && collect_mode != 2 &&
                            (predict_long || ntiles <= kPredictTiles || expect_runs <= kPredictRuns);
     // When that bound is the small one (<= kSmallRuns: ONE sorting launch), nothing is worth a second stream: a branch on
     // another stream starts ~20 us after the event it waits for and is joined ~20 us after it ends — more than the chain
@@ -1356,7 +1410,19 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     hipLaunchKernelGGL(seg_scan, dim3(1), dim3(1024), 0, q_apply, h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p,
                        h->updated.p, h->w_active_off.p, h->d_wctr, &h->d_ctr->num_chunks, max_chunks,
                        h->w_tile_visits.p, h->w_run_cnt.p, ntiles, h->w_part_off.p, h->w_multi_idx.p, h->multi_cap,
-                       h->part_segs, h->part_min);
+                       h->part_segs, h->part_min, collect_ready ? h->w_active_idx.p : (uint32_t*)nullptr);
+    if (collect_ready) {
+      // the colour side's counting stages here, in front of the segment sort: short kernels that would otherwise start
+      // beside the apply stage's first thousand workgroups and wait for their slots (40 us each, measured)
+      hipLaunchKernelGGL(runs_count, dim3(collect_blocks), dim3(kSegSpan), 0, q_apply, h->w_seg.p, h->w_rseg.p, ntiles, h->w_seg_cnt.p,
+                         h->w_active_idx.p, collect_rows, collect_blocks, h->w_run_matrix.p, h->w_rpre.p, h->d_wctr, last_count);
+      hipLaunchKernelGGL(runs_rowscan, dim3(std::min<uint32_t>(ceil_div(collect_rows, 4), 1024u)), dim3(256), 0, q_apply,
+                         h->w_run_matrix.p, collect_rows, collect_blocks, h->d_wctr, h->w_item_cnt.p);
+      hipLaunchKernelGGL(rows_place, dim3(1), dim3(1024), 0, q_apply, h->w_item_cnt.p, collect_rows, collect_bound,
+                         (uint32_t)std::min<size_t>((size_t)collect_bound / kCollectPart + collect_rows + 1, 0xFFFFFFFFu), h->d_wctr,
+                         h->w_item_base.p, h->w_item_part0.p, h->w_part_item.p);
+      PLVS_HIP_TRY(hipEventRecord(h->ev_seg, q_apply));
+    }
     hipLaunchKernelGGL(seg_pass<true>, dim3(seg_blocks), dim3(256), 0, q_apply, h->w_seg.p, out.seg_cap, ntiles,
                        h->w_seg_cnt.p, h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p, h->w_sorted_seg.p,
                        h->d_wctr);
@@ -1386,6 +1452,20 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     // (... and of few tiles: its listing of the runs is one workgroup's loop over the tiles — 15 000 tiles with a run each, the rim
     // of a saturated map in a 100-key-frame call, take it longer than the general chain's launches: steady state 0.62 -> 0.67 ms)
     const bool medium_sort = medium_max != 0 && ntiles <= 2048u;
+    auto launch_fold = [&](uint32_t D, const uint32_t* skeys, const uint32_t* sval, hipStream_t q, const uint32_t* skip) -> int {
+      const RunSrc rsrc{h->w_masks.p, (uint32_t)kMaskWords, h->run_r1_log2, TileMap{1u, 0u}, h->offsets.p, nclouds,
+                        reinterpret_cast<const uint32_t*>(h->offsets.p) + 2 * ((size_t)nclouds + 1)};
+      if (gsrc)
+        hipLaunchKernelGGL(fold_colours_masks<true>, dim3(std::min<size_t>(ceil_div(D, kFoldWaves), 8192)),
+                           dim3(64 * kFoldWaves), 0, q, skeys, sval, side_ctr, rsrc, h->heads.p, d_rgb,
+                           h->rgbw, &h->d_wctr[1].num_heads, (uint32_t*)nullptr, (uint32_t*)nullptr, skip, grid);
+      else
+        hipLaunchKernelGGL(fold_colours_masks<false>, dim3(std::min<size_t>(ceil_div(D, kFoldWaves), 8192)),
+                           dim3(64 * kFoldWaves), 0, q, skeys, sval, side_ctr, rsrc, h->heads.p, d_rgb,
+                           h->rgbw, &h->d_wctr[1].num_heads, (uint32_t*)nullptr, (uint32_t*)nullptr, skip, grid);
+      PLVS_KERNEL_CHECK();
+      return PLVS_OK;
+    };
     auto colour_chain = [&](uint32_t D, int chunks, hipStream_t q, const RunGuard* guard) -> int {
       const uint32_t* skeys = h->dkey0.p;
       const uint32_t* sval = h->w_val0.p;
@@ -1421,24 +1501,32 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
         hipLaunchKernelGGL(voxel_heads, dim3(ceil_div(D, 256 * kHeadTiles)), dim3(256), 0, q, skeys, D,
                            h->heads.p, h->w_dummy.p, h->d_wctr + 1, guard ? (const uint32_t*)side_ctr : (const uint32_t*)nullptr);
       }
-      const RunSrc rsrc{h->w_masks.p, (uint32_t)kMaskWords, h->run_r1_log2, TileMap{1u, 0u}, h->offsets.p, nclouds,
-                        reinterpret_cast<const uint32_t*>(h->offsets.p) + 2 * ((size_t)nclouds + 1)};
-      if (gsrc)
-        hipLaunchKernelGGL(fold_colours_masks<true>, dim3(std::min<size_t>(ceil_div(D, kFoldWaves), 8192)),
-                           dim3(64 * kFoldWaves), 0, q, skeys, sval, side_ctr, rsrc, h->heads.p, d_rgb,
-                           h->rgbw, &h->d_wctr[1].num_heads, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                           guard ? (const uint32_t*)guard->skip : (const uint32_t*)nullptr, grid);
-      else
-        hipLaunchKernelGGL(fold_colours_masks<false>, dim3(std::min<size_t>(ceil_div(D, kFoldWaves), 8192)),
-                           dim3(64 * kFoldWaves), 0, q, skeys, sval, side_ctr, rsrc, h->heads.p, d_rgb,
-                           h->rgbw, &h->d_wctr[1].num_heads, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                           guard ? (const uint32_t*)guard->skip : (const uint32_t*)nullptr, grid);
-      PLVS_KERNEL_CHECK();
-      return PLVS_OK;
+      return launch_fold(D, skeys, sval, q, guard ? (const uint32_t*)guard->skip : (const uint32_t*)nullptr);
+    };
+    // the runs of a long call whose tiles all went through walk_fast, chunk by chunk (runs_count ... parts_place): behind the
+    // list of the updated chunks (ev_seg), no pass that sorts all runs.  What it cannot take sets `skip` — the fold then
+    // leaves at once and the general chain runs once the call's counters are read (as for a predicted chain whose bounds
+    // did not hold).
+    auto collect_chain = [&](uint32_t D, hipStream_t q) -> int {
+      const size_t parts_cap = (size_t)collect_bound / kCollectPart + collect_rows + 1;
+      PLVS_HIP_TRY(hipStreamWaitEvent(q, h->ev_seg, 0));
+      hipLaunchKernelGGL(runs_scatter, dim3(collect_blocks * (kSegSpan / 256)), dim3(256), 0, q, h->w_seg.p, h->w_rseg.p, ntiles, h->w_seg_cnt.p,
+                         h->w_active_idx.p, collect_rows, collect_blocks, h->w_run_matrix.p, h->w_rpre.p, h->w_item_base.p,
+                         h->d_wctr, h->w_val0.p);
+      const unsigned part_grid = (unsigned)std::min<size_t>(parts_cap, 4096);
+      hipLaunchKernelGGL(parts_count, dim3(part_grid), dim3(256), 0, q, h->w_part_item.p, h->w_item_part0.p, h->w_item_base.p,
+                         h->w_item_cnt.p, h->w_runkey.p, h->d_wctr, h->w_val0.p, h->dkey0.p, h->w_phist.p);
+      hipLaunchKernelGGL(rows_heads, dim3(std::min<uint32_t>(ceil_div(collect_rows, 4), 1024u)), dim3(256), 0, q, h->w_item_part0.p,
+                         h->w_item_cnt.p, h->w_phist.p, h->d_wctr, collect_rows, h->w_row_heads.p);
+      hipLaunchKernelGGL(parts_place, dim3(part_grid), dim3(512), 0, q, h->w_part_item.p, h->w_item_part0.p, h->w_item_base.p,
+                         h->w_item_cnt.p, h->w_phist.p, h->d_wctr, h->dkey0.p, h->w_val0.p, h->dkey1.p, h->w_val1.p, h->heads.p,
+                         h->w_row_heads.p, collect_rows);
+      return launch_fold(D, h->dkey1.p, h->w_val1.p, q, &h->d_wctr[1].skip);
     };
     // (predicted: a bound that does not hold costs the chain a second time — the fold of the first skips itself: compact_runs)
     uint32_t run_bound = 0;
     int chunk_bound = 0;
+    bool collected = false, scanned = false;
     if (serial_small) {
       int rc = segments_and_apply();
       if (rc != PLVS_OK) return rc;
@@ -1461,8 +1549,10 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
         // (a moderate expectation: the one-launch sort on its full capacity — a bound that costs nothing; it sums the tiles'
         // run counts itself, the general chain wants them scanned)
         if (medium_sort && run_bound > kSmallRuns && expect * 5 / 4 + 1024 <= medium_max) run_bound = medium_max;
-        if (run_bound > medium_max)
+        if (run_bound > medium_max) {
+          scanned = true;
           PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, ntiles, side_ctr, h->scratch.p, q_colour));
+        }
         chunk_bound = std::min(max_chunks, std::max(2 * chunks_before, chunks_before + 256));
         const RunGuard guard{run_bound, side_ctr, &h->d_ctr->num_chunks, chunk_bound, &h->d_wctr[0].err, &h->d_wctr[1].skip,
                              loose ? 0u : 1u, nullptr, 0u};
@@ -1471,7 +1561,42 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
         PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
         rc = segments_and_apply();
         if (rc != PLVS_OK) return rc;
+      } else if (collect_ready && h->small_runs_known && attempt == 0) {
+        // a long call over new ground, not the handle's first: the runs chunk by chunk, queued behind the walk without a
+        // read of its counters — the buffers hold four times the call before, the kernels decide themselves whether the
+        // call is theirs (runs_count, rows_place: `skip`)
+        // The walk's counters are published all the same — in front of the chain on the side stream, which waits for the
+        // counting stages anyway — and read while the chain is queued: a tile or two of one call in twenty reach walk_tiles (a
+        // wall seen at a slant: more chunks than a tile's cache holds), the chain's kernels then leave at once (runs_count:
+        // `skip`) and the general chain is queued behind them now, not after the call's last kernel.
+        const uint32_t seq = ++h->seq_next;
+        hipLaunchKernelGGL(publish_counters, dim3(1), dim3(64), 0, h->side, h->d_wctr, h->d_ctr, h->h_wctr, h->h_ctr, h->h_seq, seq);
+        collected = true;
+        int rc = collect_chain(collect_bound, h->side);
+        if (rc != PLVS_OK) return rc;
+        {
+          int rcw = wait_published(h, seq, h->side, 1, size_class);
+          if (rcw != PLVS_OK) return rcw;
+        }
+        const uint32_t left_to_walk_tiles =
+            reinterpret_cast<const uint32_t*>(h->h_wctr)[last_count - reinterpret_cast<const uint32_t*>(h->d_wctr)];
+        if (h->h_wctr[0].err == 0 && (left_to_walk_tiles != 0u || h->h_wctr[0].seg_top != 0u)) {
+          collected = false;
+          scanned = true;
+          PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, ntiles, side_ctr, h->scratch.p, h->side));
+          // (the run count: what seg_scan leaves is not there yet — the tiles' counts are: summed here)
+          const uint32_t seq2 = ++h->seq_next;
+          hipLaunchKernelGGL(publish_counters, dim3(1), dim3(64), 0, h->side, h->d_wctr, h->d_ctr, h->h_wctr, h->h_ctr, h->h_seq, seq2);
+          int rcw = wait_published(h, seq2, h->side, 2, size_class);   // (kind 2: a short wait of its own expectation)
+          if (rcw != PLVS_OK) return rcw;
+          const uint32_t D = h->h_wctr[1].num_desc;
+          if (D > 0) {
+            rc = colour_chain(D, h->h_ctr->num_chunks, h->side, nullptr);
+            if (rc != PLVS_OK) return rc;
+          }
+        }
       } else {
+        scanned = true;
         PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, ntiles, side_ctr, h->scratch.p, q_colour));
         const uint32_t seq = ++h->seq_next;
         hipLaunchKernelGGL(publish_counters, dim3(1), dim3(64), 0, h->side, h->d_wctr, h->d_ctr, h->h_wctr, h->h_ctr, h->h_seq, seq);
@@ -1480,8 +1605,13 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
           if (rcw != PLVS_OK) return rcw;
         }
         const uint32_t D = h->h_wctr[1].num_desc;
+        // (collected: no tile was left to walk_tiles — its runs are not grouped by chunk — and enough runs to pay two launches)
+        const uint32_t left_to_walk_tiles =
+            reinterpret_cast<const uint32_t*>(h->h_wctr)[last_count - reinterpret_cast<const uint32_t*>(h->d_wctr)];
+        collected = collect_ready && left_to_walk_tiles == 0u && h->h_wctr[0].seg_top == 0u &&
+                    (D > kCollectMinRuns || collect_mode == 2);
         if (h->h_wctr[0].err == 0 && D > 0) {
-          int rc = colour_chain(D, h->h_ctr->num_chunks, h->side, nullptr);
+          int rc = collected ? collect_chain(D, h->side) : colour_chain(D, h->h_ctr->num_chunks, h->side, nullptr);
           if (rc != PLVS_OK) return rc;
         }
       }
@@ -1502,9 +1632,11 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
       if (((size_t)ntiles << h->run_r1_log2) >= 0xFFFFFFFFull) return walk_fail(h, err);
       continue;
     }
-    if (predicted && h->h_wctr[1].skip != 0u) {   // the bounds did not hold: the chain once more, with the call's numbers
+    h->last_chain = collected ? 2 : (predicted ? 1 : 0);
+    h->last_chain_skipped = (predicted || collected) && h->h_wctr[1].skip != 0u;
+    if ((predicted || collected) && h->h_wctr[1].skip != 0u) {   // the bounds did not hold: the chain once more, with the call's numbers
       const uint32_t D = h->h_wctr[1].num_desc;
-      if (serial_small)   // (its chain had no use for the offsets of the tiles' runs: the compaction of the long form has)
+      if (!scanned)   // (its chain had no use for the offsets of the tiles' runs: the compaction of the long form has)
         PLVS_HIP_TRY(exclusive_scan_u32(h->w_run_cnt.p, h->w_run_off.p, ntiles, side_ctr, h->scratch.p, s));
       PLVS_HIP_TRY(hipMemsetAsync(&h->d_wctr[1].num_heads, 0, sizeof(uint32_t), s));
       PLVS_HIP_TRY(hipMemsetAsync(&h->d_wctr[1].num_updated, 0, sizeof(uint32_t), s));
@@ -1532,11 +1664,16 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
   }
   {   // developer trace of the call's counters (PLVS_HIP_TSDF_TRACE=1)
     static const bool trace = plvs::env_int("PLVS_HIP_TSDF_TRACE", 0, 0, 1) != 0;
+    if (trace) {
+      timespec t1;
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      fprintf(stderr, "[tsdf_chisel] %.0f us ", (double)(t1.tv_sec - trace_t0.tv_sec) * 1e6 + (double)(t1.tv_nsec - trace_t0.tv_nsec) * 1e-3);
+    }
     if (trace)
       fprintf(stderr, "[tsdf_chisel] tiles %u deferred %u split %u visits %llu runs %u updated %u parts %u multi %u "
-              "rec_top %u seg_top %u voxels %u max_run %u chunks %d\n", ntiles, c.ndeferred * 1000u + c.ndeferred2, c.split_tiles,
+              "rec_top %u seg_top %u voxels %u max_run %u chunks %d chain %d%s\n", ntiles, c.ndeferred * 1000u + c.ndeferred2 + c.ndeferred3 * 1000000u, c.split_tiles,
               (unsigned long long)c.total_visits, h->h_wctr[1].num_desc, c.num_updated, c.num_parts, c.num_multi, c.rec_top,
-              c.seg_top, c.num_heads, c.max_run, h->num_chunks);
+              c.seg_top, c.num_heads, c.max_run, h->num_chunks, h->last_chain, h->last_chain_skipped ? " REPEATED" : "");
   }
   h->stats.visits = (int64_t)c.total_visits;
   h->stats.new_chunks = h->num_chunks - chunks_before;
@@ -1716,9 +1853,18 @@ int plvs_hip_tsdf_chisel_create(const plvs_tsdf_chisel_params* p, plvs_tsdf_chis
     h->scale_u = (float)std::exp2(std::floor(std::log2(1073741824.0 / (kWalkRays * wuu_max))));
     h->scale_w = (float)std::exp2(std::floor(std::log2(1073741824.0 / (kWalkRays * wu_max))));
   }
-  CREATE_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  {
+    // The side stream carries a long call's colour chain — the longer of the two branches behind the walk, a row of short
+    // kernels — beside the apply stage's thousands of workgroups on the caller's stream: at the highest priority its
+    // workgroups are dispatched ahead of the apply stage's queue instead of behind it.  (developer switch)
+    int least = 0, greatest = 0;
+    CREATE_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const bool prio = plvs::env_int("PLVS_TSDF_SIDE_PRIORITY", 1, 0, 1) != 0;
+    CREATE_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio ? greatest : least));
+  }
   CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   CREATE_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  CREATE_TRY(hipEventCreateWithFlags(&h->ev_seg, hipEventDisableTiming));
 #undef CREATE_TRY
   *out = h;
   int rc = plvs_hip_tsdf_chisel_clear(h);
@@ -1769,6 +1915,10 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   h->sh_ctl.release(); h->sh_seg_reg.release(); h->sh_rec_reg.release(); h->sh_src_off.release(); h->sh_slot_owner.release(); h->sh_run_ctr.release(); h->sh_vkey.release(); h->sh_sat.release(); h->sh_wait.release(); h->sh_run_first.release();
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->ev_seg) (void)hipEventDestroy(h->ev_seg);
+  h->w_rseg.release(); h->w_rpre.release(); h->w_run_matrix.release(); h->w_active_idx.release(); h->w_item_base.release();
+  h->w_item_cnt.release(); h->w_item_part0.release(); h->w_part_item.release(); h->w_phist.release();
+  h->w_row_heads.release();
   if (h->side) (void)hipStreamDestroy(h->side);
   for (int i = 0; i <= kNumStages; ++i)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);

@@ -119,6 +119,9 @@ struct WalkCounters {           // device-side, read back once per call
   uint32_t ndeferred2;          //   and what the larger-table pass over that list left to walk_tiles
   uint32_t over_small;          // tiles of a 2048-entry first pass that a 1024-entry table would not have held
   uint32_t skip;                // colour side: a chain launched on predicted sizes found them too small (compact_runs)
+  uint32_t collect_top;         // colour side: runs given a place by runs_rowscan (the regions of the (chunk, slab) rows)
+  uint32_t collect_parts;       //   and the parts of kCollectPart runs these regions are sorted in
+  uint32_t ndeferred3;          // what a third pass (4096 entries, behind a 1024- and a 2048-entry one) left to walk_tiles
 };
 
 // ------------------------------------------------------------------ the walk of one (sub-)tile
@@ -175,8 +178,9 @@ struct FastShared {
   int32_t cslot[kWalkChunks];
   uint32_t ccnt[kWalkChunks * kSlabs];
   uint16_t cbase[kWalkChunks * kSlabs];
+  uint32_t rcnt[kWalkChunks * kSlabs];    // runs of the (chunk, slab) group
+  uint16_t rcbase[kWalkChunks * kSlabs];  // the group's first run among the tile's (every wave writes the same table)
   uint32_t nent, overflow;
-  uint32_t wsum[kWalkRays / 64];
 };
 
 
@@ -696,6 +700,10 @@ struct RunOut {
   uint32_t* masks;                // [(ntiles << r1_log2) * kMaskWords] rays of the tile that visit the voxel, bit r = ray r
   uint32_t* run_cnt;              // [ntiles]
   uint32_t r1_log2;
+  // walk_fast only, may be null: the runs of a tile lie grouped by (chunk, slab), and beside segment descriptor sg
+  // (AccOut::seg) stands where its chunk's runs are: [2 sg] = {first run slot, runs, 0, 0}, [2 sg + 1] = the first run of
+  // each slab inside them (pack_suboffsets) — what runs_count / runs_scatter place a chunk's runs by without a sort of all runs
+  uint4* rseg;
 };
 
 constexpr int kMaskCap = kWalkEntries / 4;   // ray masks built per round (LDS: the area of the accumulators)
@@ -1264,6 +1272,8 @@ __device__ __forceinline__ void walk_fast_tile(
   if (!defer) {
     subtile_reset(S, tid);
 #pragma unroll
+    for (int k = 0; k < kWalkChunks * kSlabs / kWalkRays; ++k) S.rcnt[tid + k * kWalkRays] = 0u;
+#pragma unroll
     for (int k = 0; k < 4 * kPer; ++k) raw[tid + k * kWalkRays] = 0u;
     if (tid == 0) {
       S.run_total = 0;
@@ -1373,14 +1383,15 @@ __device__ __forceinline__ void walk_fast_tile(
   // at the next barrier: a tile that does not is deferred there — all it has done to global memory by then is to
   // enter chunks its voxels need anyway.
   int ci[kPer];
-  uint32_t rank[kPer], vkey[kPer], elast[kPer];
+  uint32_t rank[kPer], rrank[kPer], vkey[kPer], elast[kPer];
   unsigned long long ewc[kPer];
-  uint32_t need = 0, nneed = 0;   // entries of this thread that leave the tile as runs
+  uint32_t need = 0;              // entries of this thread that leave the tile as runs
   bool multi = false;             // ... one of them visited by more than one ray
 #pragma unroll
   for (int k = 0; k < kPer; ++k) {
     ci[k] = -2;
     rank[k] = 0;
+    rrank[k] = 0;
     vkey[k] = 0xFFFFFFFFu;        // (no entry / no pool slot: the directory is full)
     elast[k] = 0;
     ewc[k] = 0;
@@ -1427,8 +1438,9 @@ __device__ __forceinline__ void walk_fast_tile(
       const bool cold = sat ? ((cw[k] >> (vkey[k] & 31u)) & 1u) == 0u : (cw[k] >> 24) < 254u;
       if (cold) {   // its colour still depends on the order of the visits
         need |= 1u << k;
-        ++nneed;
         multi = multi || (uint32_t)(ewc[k] >> 32) > 1u;
+        // (its place among the runs of its (chunk, slab) group — the runs of a tile leave it grouped like its records)
+        rrank[k] = atomicAdd(&S.rcnt[ci[k] * kSlabs + (int)((vkey[k] % (uint32_t)kChunkVox) / kSlabVox)], 1u);
       }
     }
   }
@@ -1457,13 +1469,20 @@ __device__ __forceinline__ void walk_fast_tile(
   // wave runs the scan and writes the same table of group bases — a wave reads back its own LDS writes in order, so
   // nobody waits for wave 0 behind a barrier; wave 0 alone writes the segment descriptors.
   const uint32_t rbase = tile * rec_stride;
+  uint32_t nruns;   // runs of the tile (every wave computes it)
   {
-    uint32_t sub[kSlabs], c = 0;
+    uint32_t sub[kSlabs], c = 0, rsub[kSlabs], rc = 0;
 #pragma unroll
     for (int s = 0; s < kSlabs; ++s) {
       sub[s] = c;
       c += S.ccnt[lane * kSlabs + s];
+      rsub[s] = rc;
+      rc += S.rcnt[lane * kSlabs + s];
     }
+    const uint32_t rinc = wave_scan_incl(rc);
+    nruns = (uint32_t)__builtin_amdgcn_readlane((int)rinc, 63);
+#pragma unroll
+    for (int s = 0; s < kSlabs; ++s) S.rcbase[lane * kSlabs + s] = (uint16_t)(rinc - rc + rsub[s]);
     // (records and segments in one scan: a chunk holds at most 1024 entries of the tile)
     const uint32_t both = wave_scan_incl(c | (c ? 1u << 16 : 0u));
     const uint32_t inc = both & 0xFFFFu, sinc = both >> 16;
@@ -1476,6 +1495,10 @@ __device__ __forceinline__ void walk_fast_tile(
         const uint32_t sg = tile * (uint32_t)kWalkChunks + sinc - 1u;
         out.seg[2 * (size_t)sg] = make_uint4((uint32_t)S.cslot[lane], rbase + inc - c, c, gtile);
         out.seg[2 * (size_t)sg + 1] = pack_suboffsets(sub);
+        if (runs.rseg) {
+          runs.rseg[2 * (size_t)sg] = make_uint4((tile << runs.r1_log2) + rinc - rc, rc, 0u, 0u);
+          runs.rseg[2 * (size_t)sg + 1] = pack_suboffsets(rsub);
+        }
         if (out.chunk_nseg) atomicAdd(&out.chunk_nseg[S.cslot[lane]], 1u);
       }
     }
@@ -1490,58 +1513,37 @@ __device__ __forceinline__ void walk_fast_tile(
     out.rec[rbase + S.cbase[ci[k] * kSlabs + (int)(vid / kSlabVox)] + rank[k]] = r;
   }
   WALK_PROF(6);     // records
-  // ---- runs: number the entries that need one (wave by wave)
-  const uint32_t inc = wave_scan_incl(nneed);
-  const uint32_t wave_runs = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+  // ---- runs: an entry that needs one has its place: the first run of its (chunk, slab) group + its rank in it
+  const bool fits_runs = nruns <= (1u << runs.r1_log2);
+  if (!fits_runs && tid == 0) {
+    atomicOr(&ctr->err, kErrScratch);
+    atomicMax(&ctr->run_need, nruns);
+  }
+  uint32_t mrun[kPer];
+#pragma unroll
+  for (int k = 0; k < kPer; ++k)
+    mrun[k] = (need & (1u << k)) ? (uint32_t)S.rcbase[ci[k] * kSlabs + (int)((vkey[k] % (uint32_t)kChunkVox) / kSlabVox)] + rrank[k] : 0xFFFFu;
   if (!any_multi) {
     // every voxel that needs a run has ONE visiting ray — the steady state of a map whose colours have mostly
     // saturated: what is still below 254 is what few rays reach — and the accumulator named it (e_last): the mask is
-    // that one bit, no pass over the visit logs.  The tile's run slots are handed out wave by wave (the order of a
-    // tile's runs among themselves is immaterial: they are runs of different voxels), no barrier.
-    if (wave_runs) {   // (uniform over the wave)
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&S.run_total, wave_runs);
-      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      const bool fits_runs = base + wave_runs <= (1u << runs.r1_log2);
-      if (!fits_runs && lane == 0) {
-        atomicOr(&ctr->err, kErrScratch);
-        atomicMax(&ctr->run_need, base + wave_runs);   // (the largest of these is the tile's total)
-      }
-      uint32_t m = base + inc - nneed;
+    // that one bit, no pass over the visit logs, no barrier.
 #pragma unroll
-      for (int k = 0; k < kPer; ++k) {
-        if (!(need & (1u << k)) || !fits_runs) continue;
-        const size_t d = ((size_t)tile << runs.r1_log2) + m++;
-        runs.dkey[d] = vkey[k];
-        uint4* dst = reinterpret_cast<uint4*>(runs.masks + d * kMaskWords);
-        const uint32_t word = elast[k] >> 5, bit = 1u << (elast[k] & 31u);
+    for (int k = 0; k < kPer; ++k) {
+      if (!(need & (1u << k)) || !fits_runs) continue;
+      const size_t d = ((size_t)tile << runs.r1_log2) + mrun[k];
+      runs.dkey[d] = vkey[k];
+      uint4* dst = reinterpret_cast<uint4*>(runs.masks + d * kMaskWords);
+      const uint32_t word = elast[k] >> 5, bit = 1u << (elast[k] & 31u);
 #pragma unroll
-        for (int q = 0; q < kMaskWords / 4; ++q)
-          dst[q] = make_uint4(word == 4u * q ? bit : 0u, word == 4u * q + 1u ? bit : 0u, word == 4u * q + 2u ? bit : 0u,
-                              word == 4u * q + 3u ? bit : 0u);
-      }
+      for (int q = 0; q < kMaskWords / 4; ++q)
+        dst[q] = make_uint4(word == 4u * q ? bit : 0u, word == 4u * q + 1u ? bit : 0u, word == 4u * q + 2u ? bit : 0u,
+                            word == 4u * q + 3u ? bit : 0u);
     }
   } else {
     // the masks come from the visit logs: bit r of a voxel's mask = ray r of the tile visits it
-    if (lane == 63) S.wsum[wid] = inc;
-    __syncthreads();   // (also: the records are out, the accumulator area is free)
-    uint32_t wbase = 0, nruns = 0;
+    __syncthreads();   // (the records are out: the accumulator area and the words of the (chunk, slab) counters are free)
 #pragma unroll
-    for (int w = 0; w < kWalkRays / 64; ++w) {
-      const uint32_t v = S.wsum[w];
-      if (w < wid) wbase += v;
-      nruns += v;
-    }
-    const bool fits_runs = nruns <= (1u << runs.r1_log2);
-    if (!fits_runs && tid == 0) {
-      atomicOr(&ctr->err, kErrScratch);
-      atomicMax(&ctr->run_need, nruns);
-    }
-    {
-      uint32_t m = wbase + inc - nneed;
-#pragma unroll
-      for (int k = 0; k < kPer; ++k) e_midx[tid + k * kWalkRays] = (need & (1u << k)) ? (uint16_t)m++ : (uint16_t)0xFFFFu;
-    }
+    for (int k = 0; k < kPer; ++k) e_midx[tid + k * kWalkRays] = (uint16_t)mrun[k];
     for (uint32_t r0 = 0; fits_runs && r0 < nruns; r0 += kMaskCapE) {
       __syncthreads();   // e_midx complete / the previous round's masks are out
 #pragma unroll
@@ -1581,8 +1583,8 @@ __device__ __forceinline__ void walk_fast_tile(
         for (int q = 0; q < kMaskWords / 4; ++q) dst[q] = make_uint4(mk[4 * q], mk[4 * q + 1], mk[4 * q + 2], mk[4 * q + 3]);
       }
     }
-    if (tid == 0) S.run_total = nruns;
   }
+  if (tid == 0) S.run_total = nruns;
   WALK_PROF(7);     // runs
   // ---- tile epilogue: run and visit counts
   __syncthreads();                                                                          // ---- barrier 4
@@ -1691,7 +1693,9 @@ __global__ __launch_bounds__(1024) void seg_scan(const uint32_t* __restrict__ ch
                                                  const uint32_t* __restrict__ tile_visits,
                                                  const uint32_t* __restrict__ run_cnt, uint32_t ntiles,
                                                  uint32_t* __restrict__ part_off, uint32_t* __restrict__ multi_idx,
-                                                 uint32_t multi_cap, uint32_t part_segs, uint32_t part_min) {
+                                                 uint32_t multi_cap, uint32_t part_segs, uint32_t part_min,
+                                                 uint32_t* __restrict__ active_idx = nullptr) {
+  // (active_idx, may be null: slot of an updated chunk -> its place in `active`)
   // part_off / multi_idx (per updated chunk, in `active` order): the chunk's first part in the apply stage's
   // item list (a part = part_segs segments of a chunk with more than part_min of them) and its index among the
   // chunks applied in parts
@@ -1749,6 +1753,7 @@ __global__ __launch_bounds__(1024) void seg_scan(const uint32_t* __restrict__ ch
       if (c) {
         const uint32_t at = ab + ainc - 1u;
         active[at] = (uint32_t)s;
+        if (active_idx) active_idx[s] = at;
         active_off[at] = wb + inc - c;
         part_off[at] = pb + pinc - np;
         multi_idx[at] = multi ? midx : 0xFFFFFFFFu;
@@ -2441,6 +2446,412 @@ constexpr uint32_t kWireSpans = 6;
 constexpr uint32_t kSpanNone = 0xFFFFu;
 constexpr uint32_t kWireTileBits = 20;   // tile index of the call in the upper bits of word 2
 // Spans of a ray mask, in ascending order: calls emit(start, length) for each (length <= 128); returns their number.
+// ------------------------------------------------------------------ a long call's runs, chunk by chunk
+// The stable sort of ALL runs by voxel (compaction, digit totals, three radix passes, heads: 0.2 ms for the 2.5 million runs of
+// 100 key frames over new ground, the tail of the step) without sorting them all: walk_fast leaves a tile's runs grouped by
+// (chunk, slab) and says beside every segment descriptor where they are (RunOut::rseg).  A ROW = (updated chunk, slab); the
+// descriptor slots are cut into blocks of kSegSpan (16 tiles):
+//   runs_count     a workgroup per block: the runs of every row in the block -> matrix [row][block]; per descriptor, the runs
+//                  of its rows in the block's earlier tiles (rpre)
+//   runs_rowscan   a wave per row: exclusive scan along the blocks; the row's total gives it a region of the output and its
+//                  parts of kCollectPart runs
+//   runs_scatter   a workgroup per block: the slots of its runs to region + matrix + rpre — the row's runs in TILE order,
+//                  no atomics, nothing sorted
+//   parts_count    a workgroup per part: the keys of its runs fetched, a histogram over the slab's 512 voxels
+//   parts_place    a workgroup per part: stable counting sort by voxel — the row's parts before this one, per-wave
+//                  histograms, ranks by ballots; the first part of a row lists the voxels' first runs (heads)
+// and the fold reads keys, slots and heads as the general chain leaves them.  Only calls whose tiles all went through
+// walk_fast (no tile left to walk_tiles, whose runs are not grouped).  More updated chunks than the matrix has rows for, or
+// more chunks in a block than runs_count's table holds, set `skip`: the fold leaves at once and the host runs the general chain.
+constexpr uint32_t kCollectPart = 4096;
+constexpr int kRunTable = 256;            // chunks of one block (16 tiles) runs_count has room for
+constexpr int kSpanTiles = kSegSpan / kWalkChunks;
+__device__ __forceinline__ uint32_t suboffset_of(const uint4& p, int s) {   // (pack_suboffsets)
+  const uint32_t w = s < 2 ? p.x : (s < 4 ? p.y : (s < 6 ? p.z : p.w));
+  return (s & 1) ? w >> 16 : w & 0xFFFFu;
+}
+// runs of slab s of the segment whose run descriptor is (r0, r1): first slot, count
+__device__ __forceinline__ void slab_runs(const uint4& r0, const uint4& r1, int s, uint32_t* first, uint32_t* cnt) {
+  const uint32_t lo = suboffset_of(r1, s), hi = s + 1 < kSlabs ? suboffset_of(r1, s + 1) : r0.y;
+  *first = r0.x + lo;
+  *cnt = hi - lo;
+}
+
+__global__ __launch_bounds__(kSegSpan) void runs_count(const uint4* __restrict__ seg, const uint4* __restrict__ rseg, uint32_t ntiles,
+                                                       const uint32_t* __restrict__ seg_cnt, const uint32_t* __restrict__ active_idx,
+                                                       uint32_t rows_cap, uint32_t nblocks, uint32_t* __restrict__ M,
+                                                       uint4* __restrict__ rpre, WalkCounters* __restrict__ ctr,
+                                                       const uint32_t* __restrict__ left_to_walk_tiles) {
+  // (a thread per descriptor slot: one chain of dependent loads per thread, all of the block's in flight together)
+  __shared__ uint32_t hkey[kRunTable];
+  __shared__ alignas(16) uint16_t tbl[kRunTable][kSpanTiles][kSlabs];
+  static_assert(kSpanTiles == 16 && kSegSpan == 1024, "16 tiles per block");
+  const int tid = threadIdx.x;
+  // (a tile left to walk_tiles: its runs are not grouped by chunk, its segments may lie in the spill area — not this chain's call)
+  // (... nor a call that has to be repeated with more room: err); the run descriptors of such tiles are not valid
+  if (*left_to_walk_tiles != 0u || ctr->seg_top != 0u || ctr->err != 0u) {   // (uniform)
+    if (blockIdx.x == 0 && tid == 0) ctr[1].skip = 1u;
+    return;
+  }
+  static_assert(kRunTable <= kSegSpan && (kRunTable & (kRunTable - 1)) == 0, "a thread per table entry");
+  if (tid < kRunTable) hkey[tid] = 0xFFFFFFFFu;
+  for (int k = tid; k < kRunTable * kSpanTiles * kSlabs / 2; k += kSegSpan) reinterpret_cast<uint32_t*>(&tbl[0][0][0])[k] = 0u;
+  __syncthreads();
+  const uint32_t j = blockIdx.x * (uint32_t)kSegSpan + (uint32_t)tid;
+  const uint32_t tile = j / kWalkChunks;
+  const int tl = tid / kWalkChunks;
+  int ent = -1;
+  if (tile < ntiles && (j % kWalkChunks) < seg_cnt[tile]) {
+    const uint4 r0 = rseg[2 * (size_t)j], r1 = rseg[2 * (size_t)j + 1];
+    const uint32_t slot = seg[2 * (size_t)j].x;
+    if (r0.y != 0u) {   // (runs in this chunk)
+      uint32_t h = (slot * 2654435761u) >> (32 - log2_of(kRunTable));
+      for (int probe = 0; probe < kRunTable; ++probe) {
+        uint32_t cur = hkey[h];
+        if (cur == 0xFFFFFFFFu) cur = atomicCAS(&hkey[h], 0xFFFFFFFFu, slot);
+        if (cur == 0xFFFFFFFFu || cur == slot) {
+          ent = (int)h;
+          break;
+        }
+        h = (h + 1) & (kRunTable - 1);
+      }
+      if (ent < 0) {
+        ctr[1].skip = 1u;   // more chunks in the block than the table holds
+      } else {
+        uint32_t c[kSlabs];
+#pragma unroll
+        for (int s = 0; s < kSlabs; ++s) {
+          uint32_t f;
+          slab_runs(r0, r1, s, &f, &c[s]);
+        }
+        *reinterpret_cast<uint4*>(&tbl[ent][tl][0]) = pack_suboffsets(c);
+      }
+    }
+  }
+  __syncthreads();
+  if (ent >= 0) {
+    uint32_t pre[kSlabs];
+#pragma unroll
+    for (int s = 0; s < kSlabs; ++s) pre[s] = 0;
+    for (int t = 0; t < tl; ++t) {
+      const uint4 row = *reinterpret_cast<const uint4*>(&tbl[ent][t][0]);
+      pre[0] += row.x & 0xFFFFu; pre[1] += row.x >> 16;
+      pre[2] += row.y & 0xFFFFu; pre[3] += row.y >> 16;
+      pre[4] += row.z & 0xFFFFu; pre[5] += row.z >> 16;
+      pre[6] += row.w & 0xFFFFu; pre[7] += row.w >> 16;
+    }
+    rpre[j] = pack_suboffsets(pre);   // (at most 15 tiles x 512 runs each)
+  }
+  for (int cell = tid; cell < kRunTable * kSlabs; cell += kSegSpan) {   // the (chunk, slab) cells of the table
+    const int e = cell / kSlabs, s = cell % kSlabs;
+    if (hkey[e] != 0xFFFFFFFFu) {
+      uint32_t tot = 0;
+#pragma unroll
+      for (int t = 0; t < kSpanTiles; ++t) tot += tbl[e][t][s];
+      if (tot != 0u) {
+        const uint32_t row = active_idx[hkey[e]] * (uint32_t)kSlabs + (uint32_t)s;
+        if (row < rows_cap) M[(size_t)row * nblocks + blockIdx.x] = tot;
+        else ctr[1].skip = 1u;   // more updated chunks than the matrix has rows for
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void runs_rowscan(uint32_t* __restrict__ M, uint32_t rows_cap, uint32_t nblocks,
+                                                    const WalkCounters* __restrict__ ctr, uint32_t* __restrict__ item_cnt) {
+  if (ctr[1].skip != 0u) return;
+  const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const uint32_t nrows = min(rows_cap, ctr->num_updated * (uint32_t)kSlabs);
+  for (uint32_t row = blockIdx.x * 4u + wid; row < nrows; row += gridDim.x * 4u) {
+    uint32_t* const m = M + (size_t)row * nblocks;
+    uint32_t running = 0;
+    // (a lane takes 16 consecutive blocks: the loads of a round of 1024 blocks are in flight together, one scan per round)
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += 1024) {
+      uint32_t v[16], sum = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const uint32_t b = b0 + lane * 16u + (uint32_t)k;
+        v[k] = b < nblocks ? m[b] : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sum += v[k];
+      const uint32_t inc = wave_scan_incl(sum);
+      uint32_t at = running + inc - sum;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const uint32_t b = b0 + lane * 16u + (uint32_t)k;
+        if (b < nblocks && v[k] != 0u) m[b] = at;   // (only the cells that hold runs are read again)
+        at += v[k];
+      }
+      running += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+    if (lane == 0) item_cnt[row] = running;
+  }
+}
+
+// The rows' regions and parts: one workgroup scans the rows' totals (a counter bumped by every row instead serialises a
+// thousand same-address atomics).
+__global__ __launch_bounds__(1024) void rows_place(const uint32_t* __restrict__ item_cnt, uint32_t rows_cap, uint32_t run_bound,
+                                                   uint32_t parts_cap, WalkCounters* __restrict__ ctr,
+                                                   uint32_t* __restrict__ item_base, uint32_t* __restrict__ item_part0,
+                                                   uint32_t* __restrict__ part_item) {
+  __shared__ uint32_t wt[16], wp[16];
+  __shared__ uint32_t ct, cp;
+  if (ctr[1].skip != 0u) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t nrows = min(rows_cap, ctr->num_updated * (uint32_t)kSlabs);
+  if (tid == 0) { ct = 0; cp = 0; }
+  __syncthreads();
+  for (uint32_t r0 = 0; r0 < nrows; r0 += 1024) {
+    const uint32_t r = r0 + tid;
+    const uint32_t T = r < nrows ? item_cnt[r] : 0u, np = (T + kCollectPart - 1u) / kCollectPart;
+    const uint32_t ti = wave_scan_incl(T), pi = wave_scan_incl(np);
+    if (lane == 63) { wt[wid] = ti; wp[wid] = pi; }
+    __syncthreads();
+    uint32_t tb = ct, pb = cp, tt = 0, pt = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; ++w) {
+      if (w < wid) { tb += wt[w]; pb += wp[w]; }
+      tt += wt[w];
+      pt += wp[w];
+    }
+    if (r < nrows) {
+      const uint32_t p0 = pb + pi - np;
+      item_base[r] = tb + ti - T;
+      item_part0[r] = p0;
+      for (uint32_t i = 0; i < np && p0 + i < parts_cap; ++i) part_item[p0 + i] = r;
+    }
+    __syncthreads();
+    if (tid == 0) { ct += tt; cp += pt; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    ctr[1].collect_top = ct;
+    ctr[1].collect_parts = cp;
+    if (ct > run_bound || cp > parts_cap) ctr[1].skip = 1u;   // (buffers sized on the call before: the host runs the general chain)
+  }
+}
+
+__global__ __launch_bounds__(256) void runs_scatter(const uint4* __restrict__ seg, const uint4* __restrict__ rseg, uint32_t ntiles,
+                                                    const uint32_t* __restrict__ seg_cnt, const uint32_t* __restrict__ active_idx,
+                                                    uint32_t rows_cap, uint32_t nblocks, const uint32_t* __restrict__ M,
+                                                    const uint4* __restrict__ rpre, const uint32_t* __restrict__ item_base,
+                                                    const WalkCounters* __restrict__ ctr, uint32_t* __restrict__ tv) {
+  // (a thread per descriptor slot, 256 slots = four tiles per workgroup; the loads of the eight slabs' places go out together;
+  // a group of 32 runs or more is written by the whole wave)
+  if (ctr[1].skip != 0u) return;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t tile = j / kWalkChunks, block = j / (uint32_t)kSegSpan;
+  uint32_t f[kSlabs], c[kSlabs], at[kSlabs];
+#pragma unroll
+  for (int s = 0; s < kSlabs; ++s) f[s] = c[s] = at[s] = 0u;
+  uint4 r0 = make_uint4(0u, 0u, 0u, 0u);
+  if (tile < ntiles && (j % kWalkChunks) < seg_cnt[tile]) r0 = rseg[2 * (size_t)j];
+  if (r0.y != 0u) {
+    const uint4 r1 = rseg[2 * (size_t)j + 1], pre = rpre[j];
+    const uint32_t row0 = active_idx[seg[2 * (size_t)j].x] * (uint32_t)kSlabs;
+#pragma unroll
+    for (int s = 0; s < kSlabs; ++s) slab_runs(r0, r1, s, &f[s], &c[s]);
+    const uint4 ib0 = *reinterpret_cast<const uint4*>(item_base + row0), ib1 = *reinterpret_cast<const uint4*>(item_base + row0 + 4);
+    const uint32_t ib[kSlabs] = {ib0.x, ib0.y, ib0.z, ib0.w, ib1.x, ib1.y, ib1.z, ib1.w};
+    uint32_t m[kSlabs];
+#pragma unroll
+    for (int s = 0; s < kSlabs; ++s) m[s] = c[s] ? M[(size_t)(row0 + (uint32_t)s) * nblocks + block] : 0u;
+#pragma unroll
+    for (int s = 0; s < kSlabs; ++s) at[s] = ib[s] + m[s] + suboffset_of(pre, s);
+  }
+#pragma unroll
+  for (int s = 0; s < kSlabs; ++s) {
+    const bool big = c[s] >= 32u;
+    if (!big)
+      for (uint32_t k = 0; k < c[s]; ++k) tv[at[s] + k] = f[s] + k;
+    unsigned long long todo = __ballot(big);
+    while (todo) {
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1ull;
+      const uint32_t bp = (uint32_t)__shfl((int)at[s], src), bf = (uint32_t)__shfl((int)f[s], src);
+      const uint32_t bc = (uint32_t)__shfl((int)c[s], src);
+      for (uint32_t k = lane; k < bc; k += 64) tv[bp + k] = bf + k;
+    }
+  }
+}
+
+constexpr int kCollectFlight = 4;   // loads of 64 a wave has in flight
+__global__ __launch_bounds__(256) void parts_count(const uint32_t* __restrict__ part_item, const uint32_t* __restrict__ item_part0,
+                                                   const uint32_t* __restrict__ item_base, const uint32_t* __restrict__ item_cnt,
+                                                   const uint32_t* __restrict__ runkey, const WalkCounters* __restrict__ ctr,
+                                                   const uint32_t* __restrict__ tv, uint32_t* __restrict__ tk,
+                                                   uint32_t* __restrict__ phist) {
+  __shared__ uint32_t hist[kSlabVox];
+  if (ctr[1].skip != 0u) return;
+  const uint32_t tid = threadIdx.x, nparts = ctr[1].collect_parts;
+  for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
+    const uint32_t row = part_item[p], lo = (p - item_part0[row]) * kCollectPart, hi = min(item_cnt[row], lo + kCollectPart);
+    const uint32_t base = item_base[row];
+    for (uint32_t k = tid; k < (uint32_t)kSlabVox; k += 256) hist[k] = 0u;
+    __syncthreads();
+    for (uint32_t e0 = lo; e0 < hi; e0 += 256 * kCollectFlight) {
+      uint32_t slot[kCollectFlight], k[kCollectFlight];
+#pragma unroll
+      for (int b = 0; b < kCollectFlight; ++b) {
+        const uint32_t e = e0 + 256u * (uint32_t)b + tid;
+        slot[b] = e < hi ? tv[base + e] : 0xFFFFFFFFu;
+      }
+#pragma unroll
+      for (int b = 0; b < kCollectFlight; ++b) k[b] = slot[b] != 0xFFFFFFFFu ? runkey[slot[b]] : 0u;
+#pragma unroll
+      for (int b = 0; b < kCollectFlight; ++b) {
+        if (slot[b] == 0xFFFFFFFFu) continue;
+        tk[base + e0 + 256u * (uint32_t)b + tid] = k[b];
+        atomicAdd(&hist[k[b] % (uint32_t)kSlabVox], 1u);
+      }
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < (uint32_t)kSlabVox; k += 256) phist[(size_t)p * kSlabVox + k] = hist[k];
+    __syncthreads();
+  }
+}
+
+// Voxels of a row that have runs = the entries it adds to the head list (a wave per row sums its parts' histograms), so that
+// parts_place finds a row's place in the list by a sum over the rows before it instead of a same-address atomic per row.
+// (A kernel of its own: the last part of a row to finish could do it behind a device-scope fence — which on this device
+// writes the L2 back, 150 us for the six hundred workgroups of parts_count.)
+__global__ __launch_bounds__(256) void rows_heads(const uint32_t* __restrict__ item_part0, const uint32_t* __restrict__ item_cnt,
+                                                  const uint32_t* __restrict__ phist, const WalkCounters* __restrict__ ctr,
+                                                  uint32_t rows_cap, uint32_t* __restrict__ row_heads) {
+  if (ctr[1].skip != 0u) return;
+  const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const uint32_t nrows = min(rows_cap, ctr->num_updated * (uint32_t)kSlabs);
+  for (uint32_t row = blockIdx.x * 4u + wid; row < nrows; row += gridDim.x * 4u) {
+    const uint32_t T = item_cnt[row], P = (T + kCollectPart - 1u) / kCollectPart, p0 = item_part0[row];
+    uint32_t nz = 0;
+    if (P) {
+      uint32_t h[kSlabVox / 64];
+#pragma unroll
+      for (int k = 0; k < kSlabVox / 64; ++k) h[k] = 0;
+      for (uint32_t q = 0; q < P; ++q)
+#pragma unroll
+        for (int k = 0; k < kSlabVox / 64; ++k) h[k] += phist[(size_t)(p0 + q) * kSlabVox + (uint32_t)k * 64u + lane];
+#pragma unroll
+      for (int k = 0; k < kSlabVox / 64; ++k) nz += (uint32_t)__popcll(__ballot(h[k] != 0u));
+    }
+    if (lane == 0) row_heads[row] = nz;
+  }
+}
+
+__global__ __launch_bounds__(512) void parts_place(const uint32_t* __restrict__ part_item, const uint32_t* __restrict__ item_part0,
+                                                   const uint32_t* __restrict__ item_base, const uint32_t* __restrict__ item_cnt,
+                                                   const uint32_t* __restrict__ phist, WalkCounters* __restrict__ ctr,
+                                                   const uint32_t* __restrict__ tk, const uint32_t* __restrict__ tv,
+                                                   uint32_t* __restrict__ ok, uint32_t* __restrict__ ov,
+                                                   uint32_t* __restrict__ heads, const uint32_t* __restrict__ row_heads,
+                                                   uint32_t rows_cap) {
+  constexpr int kWaves = 8, kBatches = kCollectPart / (64 * kWaves);   // a wave: 512 consecutive runs of the part
+  __shared__ uint32_t hist[kWaves][kSlabVox];
+  __shared__ uint32_t wtot[kWaves], wflag[kWaves], wsum[kWaves];
+  static_assert(kSlabVox == 512, "a thread per voxel of the slab");
+  if (ctr[1].skip != 0u) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t nparts = ctr[1].collect_parts;
+  const uint32_t nrows = min(rows_cap, ctr->num_updated * (uint32_t)kSlabs);
+  for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
+    const uint32_t row = part_item[p], p0 = item_part0[row], pi = p - p0, T = item_cnt[row];
+    const uint32_t base = item_base[row], lo = pi * kCollectPart, hi = min(T, lo + kCollectPart);
+    const uint32_t P = (T + kCollectPart - 1u) / kCollectPart;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) hist[w][tid] = 0u;
+    __syncthreads();
+    const uint32_t wlo = lo + wid * (kCollectPart / kWaves);
+    uint32_t k[kBatches], v[kBatches];
+#pragma unroll
+    for (int b = 0; b < kBatches; ++b) {
+      const uint32_t e = wlo + 64u * (uint32_t)b + lane;
+      k[b] = e < hi ? tk[base + e] : 0u;
+      v[b] = e < hi ? tv[base + e] : 0u;
+    }
+#pragma unroll
+    for (int b = 0; b < kBatches; ++b)
+      if (wlo + 64u * (uint32_t)b + lane < hi) atomicAdd(&hist[wid][k[b] % (uint32_t)kSlabVox], 1u);
+    __syncthreads();
+    {   // thread x: voxel x of the slab
+      uint32_t tot = 0;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) {
+        const uint32_t c = hist[w][tid];
+        hist[w][tid] = tot;
+        tot += c;
+      }
+      uint32_t all = 0, before = 0;   // the voxel's runs in the whole row / in the row's parts before this one
+      for (uint32_t q0 = 0; q0 < P; q0 += 8) {   // (eight parts' rows in flight)
+        uint32_t c[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) c[u] = q0 + u < P ? phist[(size_t)(p0 + q0 + u) * kSlabVox + tid] : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+          all += c[u];
+          before += q0 + u < pi ? c[u] : 0u;
+        }
+      }
+      const uint32_t flag = (pi == 0u && all) ? 1u : 0u;
+      const uint32_t inc = wave_scan_incl(all), finc = wave_scan_incl(flag);
+      // (the row's place in the head list: the head counts of the rows before it — parts_count left them; the first part of
+      // all also leaves the list's length)
+      uint32_t hsum = 0;
+      if (pi == 0u) {   // (uniform)
+        for (uint32_t r = tid; r < row; r += 512) hsum += row_heads[r];
+        uint32_t all_rows = 0;
+        if (p == 0u) {
+          for (uint32_t r = tid; r < nrows; r += 512) all_rows += row_heads[r];
+          all_rows = wave_sum(all_rows);
+        }
+        hsum = wave_sum(hsum);
+        if (lane == 0) wsum[wid] = hsum;
+        if (p == 0u && lane == 0 && all_rows) atomicAdd(&ctr[1].num_heads, all_rows);
+      }
+      if (lane == 63) {
+        wtot[wid] = inc;
+        wflag[wid] = finc;
+      }
+      __syncthreads();
+      uint32_t wb = 0, fb = 0, hbase = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < (uint32_t)kWaves; ++w) {
+        if (w < wid) {
+          wb += wtot[w];
+          fb += wflag[w];
+        }
+        hbase += pi == 0u ? wsum[w] : 0u;
+      }
+      const uint32_t start = wb + inc - all;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) hist[w][tid] += start + before;
+      __syncthreads();
+      if (flag) heads[hbase + fb + finc - 1u] = base + start;
+    }
+    // ---- placement: the lanes of a batch that name the same voxel keep their order (ballots)
+#pragma unroll
+    for (int b = 0; b < kBatches; ++b) {
+      const bool valid = wlo + 64u * (uint32_t)b + lane < hi;
+      const uint32_t d = k[b] % (uint32_t)kSlabVox;
+      unsigned long long same = __ballot(valid);
+#pragma unroll
+      for (int bit = 0; bit < 9; ++bit) {
+        const unsigned long long bb = __ballot((d >> bit) & 1u);
+        same &= ((d >> bit) & 1u) ? bb : ~bb;
+      }
+      if (valid) {
+        const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        const uint32_t pos = hist[wid][d] + rank;
+        ok[base + pos] = k[b];
+        ov[base + pos] = v[b];
+        if ((same >> lane) == 1ull) hist[wid][d] = pos + 1u;   // (the group's last lane: the next batch goes on behind it)
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <typename Emit>
 __device__ __forceinline__ uint32_t mask_spans(const uint32_t* m, Emit emit) {
   uint32_t n = 0;
