@@ -1367,8 +1367,6 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
                        (const uint32_t*)nullptr, out, runs, TileMap{1u, 0u, 1u}, (uint32_t)ntiles, last_list, last_count,
                        kRecStride, second_small ? 1u : 2u,
                        d_grid);   // (what is flagged overflowed a 4096-entry table: two pieces at once; a 2048-entry one: it goes whole)
-    PLVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
-    STAGE_MARK(1);
     // A small call (a few key frames: PointCloudMapping::UpdateMap's batches) launches its colour chain on the sizes of
     // the small call before it instead of waiting for its own (below), and keeps the chain — a dozen dependent launches,
     // the longer of the two branches — on the caller's stream: the segment sort and the apply stage go to the side stream
@@ -1393,6 +1391,12 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     static const bool predict_long = plvs::env_int("PLVS_TSDF_PREDICT_LONG", 0, 0, 1) != 0;   // (developer switch)
     const bool predicted = h->small_runs_known && attempt == 0 && collect_mode != 2 &&
                            (predict_long || ntiles <= kPredictTiles || expect_runs <= kPredictRuns);
+    // (a long call over new ground, not the handle's first: its runs are collected chunk by chunk, below; it has nothing for
+    // the side stream before its counting stages are over — ev_seg — and goes without the event behind the walk: an event
+    // between two kernels of a stream costs ~8 us)
+    const bool collect_fast = collect_ready && h->small_runs_known && attempt == 0 && !predicted;
+    if (!collect_fast) PLVS_HIP_TRY(hipEventRecord(h->ev_fork, s));
+    STAGE_MARK(1);
     // When that bound is the small one (<= kSmallRuns: ONE sorting launch), nothing is worth a second stream: a branch on
     // another stream starts ~20 us after the event it waits for and is joined ~20 us after it ends — more than the chain
     // itself.  Segment sort, apply, sort_runs_small, fold follow each other on the caller's stream; seg_scan, which sums the
@@ -1401,6 +1405,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     const hipStream_t q_apply = (predicted && !serial_small) ? h->side : s, q_colour = predicted ? s : h->side;
 #define STAGE_MARK_ON(i, q) \
   do { if (h->profiling) PLVS_HIP_TRY(hipEventRecord(h->ev[i], q)); } while (0)
+    uint32_t collect_seq = 0;   // (the sequence number rows_place publishes the walk's counters under)
     auto segments_and_apply = [&]() -> int {
     const unsigned seg_blocks = ceil_div(seg_own + seg_spill, kSegSpan);
     if (!count_in_walk)
@@ -1420,7 +1425,10 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
                          h->w_run_matrix.p, collect_rows, collect_blocks, h->d_wctr, h->w_item_cnt.p);
       hipLaunchKernelGGL(rows_place, dim3(1), dim3(1024), 0, q_apply, h->w_item_cnt.p, collect_rows, collect_bound,
                          (uint32_t)std::min<size_t>((size_t)collect_bound / kCollectPart + collect_rows + 1, 0xFFFFFFFFu), h->d_wctr,
-                         h->w_item_base.p, h->w_item_part0.p, h->w_part_item.p);
+                         h->w_item_base.p, h->w_item_part0.p, h->w_part_item.p, reinterpret_cast<const uint32_t*>(h->d_ctr),
+                         reinterpret_cast<uint32_t*>(h->h_wctr), reinterpret_cast<uint32_t*>(h->h_ctr),
+                         (uint32_t)(sizeof(Counters) / sizeof(uint32_t)), collect_fast ? h->h_seq : (uint32_t*)nullptr,
+                         collect_fast ? (collect_seq = ++h->seq_next) : 0u);
       PLVS_HIP_TRY(hipEventRecord(h->ev_seg, q_apply));
     }
     hipLaunchKernelGGL(seg_pass<true>, dim3(seg_blocks), dim3(256), 0, q_apply, h->w_seg.p, out.seg_cap, ntiles,
@@ -1536,7 +1544,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
       rc = colour_chain(run_bound, chunk_bound, s, &guard);
       if (rc != PLVS_OK) return rc;
     } else {
-      if (!predicted) PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+      if (!predicted && !collect_fast) PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
       if (predicted) {
         const size_t slots = (size_t)ntiles << h->run_r1_log2;
         // (the call before scaled to this call's tiles — calls of one and of five key frames may alternate —, a quarter more)
@@ -1561,7 +1569,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
         PLVS_HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
         rc = segments_and_apply();
         if (rc != PLVS_OK) return rc;
-      } else if (collect_ready && h->small_runs_known && attempt == 0) {
+      } else if (collect_fast) {
         // a long call over new ground, not the handle's first: the runs chunk by chunk, queued behind the walk without a
         // read of its counters — the buffers hold four times the call before, the kernels decide themselves whether the
         // call is theirs (runs_count, rows_place: `skip`)
@@ -1569,8 +1577,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
         // counting stages anyway — and read while the chain is queued: a tile or two of one call in twenty reach walk_tiles (a
         // wall seen at a slant: more chunks than a tile's cache holds), the chain's kernels then leave at once (runs_count:
         // `skip`) and the general chain is queued behind them now, not after the call's last kernel.
-        const uint32_t seq = ++h->seq_next;
-        hipLaunchKernelGGL(publish_counters, dim3(1), dim3(64), 0, h->side, h->d_wctr, h->d_ctr, h->h_wctr, h->h_ctr, h->h_seq, seq);
+        const uint32_t seq = collect_seq;   // (published by rows_place)
         collected = true;
         int rc = collect_chain(collect_bound, h->side);
         if (rc != PLVS_OK) return rc;

@@ -2594,12 +2594,17 @@ __global__ __launch_bounds__(256) void runs_rowscan(uint32_t* __restrict__ M, ui
 __global__ __launch_bounds__(1024) void rows_place(const uint32_t* __restrict__ item_cnt, uint32_t rows_cap, uint32_t run_bound,
                                                    uint32_t parts_cap, WalkCounters* __restrict__ ctr,
                                                    uint32_t* __restrict__ item_base, uint32_t* __restrict__ item_part0,
-                                                   uint32_t* __restrict__ part_item) {
+                                                   uint32_t* __restrict__ part_item, const uint32_t* __restrict__ pub_b,
+                                                   uint32_t* __restrict__ host_a, uint32_t* __restrict__ host_b,
+                                                   uint32_t nb, uint32_t* __restrict__ host_seq, uint32_t seq) {
+  // (host_seq, may be null: the kernel ends by publishing the counters — both WalkCounters to host_a, nb words of pub_b to
+  // host_b, then the sequence number — as tsdf_chisel.hip's publish_counters does: the last single-workgroup kernel behind
+  // the walk on the caller's stream saves the call a launch of that one)
   __shared__ uint32_t wt[16], wp[16];
   __shared__ uint32_t ct, cp;
-  if (ctr[1].skip != 0u) return;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const uint32_t nrows = min(rows_cap, ctr->num_updated * (uint32_t)kSlabs);
+  const bool go = ctr[1].skip == 0u;   // (uniform)
+  const uint32_t nrows = go ? min(rows_cap, ctr->num_updated * (uint32_t)kSlabs) : 0u;
   if (tid == 0) { ct = 0; cp = 0; }
   __syncthreads();
   for (uint32_t r0 = 0; r0 < nrows; r0 += 1024) {
@@ -2625,10 +2630,19 @@ __global__ __launch_bounds__(1024) void rows_place(const uint32_t* __restrict__ 
     if (tid == 0) { ct += tt; cp += pt; }
     __syncthreads();
   }
-  if (tid == 0) {
+  if (tid == 0 && go) {
     ctr[1].collect_top = ct;
     ctr[1].collect_parts = cp;
     if (ct > run_bound || cp > parts_cap) ctr[1].skip = 1u;   // (buffers sized on the call before: the host runs the general chain)
+  }
+  if (host_seq != nullptr) {
+    __syncthreads();
+    const uint32_t* a = reinterpret_cast<const uint32_t*>(ctr);
+    for (uint32_t k = tid; k < (uint32_t)(2 * sizeof(WalkCounters) / sizeof(uint32_t)); k += 1024) host_a[k] = a[k];
+    for (uint32_t k = tid; k < nb; k += 1024) host_b[k] = pub_b[k];
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

@@ -18,7 +18,11 @@ from collections import defaultdict
 PIPELINE = ("pose_prep", "walk_prologue", "walk_fast", "walk_tiles", "seg_pass", "seg_scan", "apply_chunks", "compact_runs", "sort_runs_small", "fold_colours_masks",
             "ray_count", "scan_tile_sums", "scan_sums", "scan_tile_apply", "mark_tiles", "ray_tiles",
             "radix_hist", "radix_scatter", "radix_scatter_lds", "radix_onesweep", "radix_digit_totals", "scan_single", "voxel_heads",
-            "fold_colours", "reduce_sums", "run_counts", "mark_blocks", "gather_runs", "chain_runs")
+            "fold_colours", "reduce_sums", "run_counts", "mark_blocks", "gather_runs", "chain_runs",
+            # (round 6: a long call's runs collected chunk by chunk.  NOT in the sum: the hipMemsetAsync that zeroes its run matrix,
+            # 8 - 16 MB written per call — the runtime's fill kernel has one name for the bench's own fills too)
+            "runs_count", "runs_rowscan", "rows_place", "runs_scatter", "parts_count", "rows_heads", "parts_place",
+            "sort_runs_medium", "publish_counters")
 
 
 def short(n):
