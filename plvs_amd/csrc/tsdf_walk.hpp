@@ -1629,7 +1629,7 @@ constexpr int kSegSpan = 1024;     // descriptor slots per workgroup (16 tiles)
 constexpr uint32_t kPartSegs = 256;   // segments of a busy chunk one work item of the apply stage takes (default)
 constexpr uint32_t kPartMin = 2048;   // a chunk with more segments than this is applied in parts (default)
 constexpr int kSegTable = 512;
-template <bool kScatter>
+template <bool kScatter, int kSpan = kSegSpan>
 __global__ __launch_bounds__(256) void seg_pass(const uint4* __restrict__ seg, uint32_t seg_cap, uint32_t ntiles,
                                                 const uint32_t* __restrict__ seg_cnt, uint32_t* __restrict__ chunk_nseg,
                                                 const uint32_t* __restrict__ chunk_off, uint32_t* __restrict__ chunk_fill,
@@ -1643,12 +1643,12 @@ __global__ __launch_bounds__(256) void seg_pass(const uint4* __restrict__ seg, u
     hcnt[k] = 0;
   }
   __syncthreads();
-  constexpr int kPer = kSegSpan / 256;
+  constexpr int kPer = kSpan / 256;
   int ent[kPer];
   uint32_t rnk[kPer], slot[kPer];
 #pragma unroll
   for (int q = 0; q < kPer; ++q) {
-    const uint32_t j = blockIdx.x * (uint32_t)kSegSpan + (uint32_t)(q * 256 + tid);
+    const uint32_t j = blockIdx.x * (uint32_t)kSpan + (uint32_t)(q * 256 + tid);
     ent[q] = -2;   // no segment here
     if (j >= n || (j < own && (j % kWalkChunks) >= seg_cnt[j / kWalkChunks])) continue;
     slot[q] = seg[2 * (size_t)j].x;
@@ -1675,7 +1675,7 @@ __global__ __launch_bounds__(256) void seg_pass(const uint4* __restrict__ seg, u
 #pragma unroll
   for (int q = 0; q < kPer; ++q) {
     if (ent[q] == -2) continue;
-    const uint32_t j = blockIdx.x * (uint32_t)kSegSpan + (uint32_t)(q * 256 + tid);
+    const uint32_t j = blockIdx.x * (uint32_t)kSpan + (uint32_t)(q * 256 + tid);
     if (kScatter) {
       const uint32_t at = ent[q] >= 0 ? hbase[ent[q]] + rnk[q] : chunk_off[slot[q]] + atomicAdd(&chunk_fill[slot[q]], 1u);
       sorted[2 * (size_t)at] = seg[2 * (size_t)j];
