@@ -1262,7 +1262,16 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     PLVS_HIP_TRY(h->w_sorted_seg.reserve(h->w_seg.cap));
     // (a long call: its runs may be collected chunk by chunk — decided once the walk's counters are read, below)
     static const int collect_mode = plvs::env_int("PLVS_TSDF_COLLECT", 1, 0, 2);   // (developer switch: 0 never, 2 every call — tests)
-    const bool collect_ready = collect_mode != 0 && (ntiles > kPredictTiles || collect_mode == 2);
+    // (the colour chain of this attempt — the reasons are where the chains are queued, below: `predicted` = on the sizes of
+    // the call before, general chain; a long call over new ground: collected)
+    const size_t expect_runs = h->small_runs_known
+        ? (size_t)((double)h->small_runs_last * (double)ntiles / (double)std::max(1u, h->small_tiles_last)) : ~(size_t)0;
+    constexpr size_t kPredictRuns = 200000;
+    constexpr uint32_t kCollectMinRuns = 65536;
+    static const bool predict_long = plvs::env_int("PLVS_TSDF_PREDICT_LONG", 0, 0, 1) != 0;   // (developer switch)
+    const bool predicted = h->small_runs_known && attempt == 0 && collect_mode != 2 &&
+                           (predict_long || ntiles <= kPredictTiles || expect_runs <= kPredictRuns);
+    const bool collect_ready = collect_mode != 0 && (ntiles > kPredictTiles || collect_mode == 2) && !predicted;
     // (rows of the run matrix: twice the chunks the call before updated — more than that and the general chain takes over)
     // (a power of two: the matrix is re-allocated when a stream's calls update twice the chunks, not a few more each time)
     size_t collect_row_chunks = 256;
@@ -1376,8 +1385,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     // few rays reach at the rim of the map), the chain is then three short launches on a bound of kSmallRuns, and the host's
     // read of the run count — scan, publish, a wake-up: 0.06 ms behind a 0.09 ms segment sort + apply — was what a steady-state
     // step ended with.  A long call over new ground (millions of runs, twice or half the call before) keeps its own count.
-    const size_t expect_runs = h->small_runs_known
-        ? (size_t)((double)h->small_runs_last * (double)ntiles / (double)std::max(1u, h->small_tiles_last)) : ~(size_t)0;
+    // (expect_runs, predicted: computed at the top of the attempt — what the call reserves depends on them)
     // (a moderate number — a saturated map's rim: tens of thousands — is sorted on a bound a quarter above the expectation)
     // (end of round 5, measured and left OFF: PLVS_TSDF_PREDICT_LONG=1) every call whose predecessor left a count could do so:
     // beyond a moderate number with a LOOSE bound — three times the expectation, a million at least: the stream's counts go
@@ -1386,11 +1394,6 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     // workgroups, not sorted padding, and the chain is queued behind the walk without a host read.  On the stream: GPU time
     // per step 0.969 -> 0.965 ms, wall time 1.05 -> 1.07 (a bound that fails costs the chain twice): the chain's length is its
     // kernels' (fold 0.13, three passes 0.15, compaction, heads), not the host's read.
-    constexpr size_t kPredictRuns = 200000;
-    constexpr uint32_t kCollectMinRuns = 65536;
-    static const bool predict_long = plvs::env_int("PLVS_TSDF_PREDICT_LONG", 0, 0, 1) != 0;   // (developer switch)
-    const bool predicted = h->small_runs_known && attempt == 0 && collect_mode != 2 &&
-                           (predict_long || ntiles <= kPredictTiles || expect_runs <= kPredictRuns);
     // (a long call over new ground, not the handle's first: its runs are collected chunk by chunk, below; it has nothing for
     // the side stream before its counting stages are over — ev_seg — and goes without the event behind the walk: an event
     // between two kernels of a stream costs ~8 us)
