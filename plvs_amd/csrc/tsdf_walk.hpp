@@ -180,6 +180,7 @@ struct FastShared {
   uint16_t cbase[kWalkChunks * kSlabs];
   uint32_t rcnt[kWalkChunks * kSlabs];    // runs of the (chunk, slab) group
   uint16_t rcbase[kWalkChunks * kSlabs];  // the group's first run among the tile's (every wave writes the same table)
+  uint32_t any_cold;                      // a voxel of the tile needs a run
   uint32_t nent, overflow;
 };
 
@@ -1278,6 +1279,7 @@ __device__ __forceinline__ void walk_fast_tile(
     if (tid == 0) {
       S.run_total = 0;
       S.vis_total = 0;
+      S.any_cold = 0;
     }
 #if PLVS_WALK_SORT
     {
@@ -1447,7 +1449,11 @@ __device__ __forceinline__ void walk_fast_tile(
   // (one barrier: the ranks are complete, the tile's entries are counted — and does any voxel that needs a run have
   // more than one visiting ray?)
   WALK_PROF(4);     // entries -> chunks, ranks, colour weights
+  // (... and does any voxel need a run at all?  A tile of a saturated map has none: no scan of the run groups.  A flag in
+  // LDS: __syncthreads_or returns a truth value, not the OR of its arguments)
+  if (need) S.any_cold = 1u;
   const bool any_multi = __syncthreads_or(multi ? 1 : 0) != 0;                              // ---- barrier 3
+  const bool any_cold = S.any_cold != 0u;
   WALK_PROF(5);     // (wait)
   const bool too_many = !defer && S.nent > (uint32_t)kLimit;   // (the voxels do not fit: the next kernel's table is larger / walk_tiles cuts the tile at once)
   if (E == 2048 && tid == 0 && !defer && S.nent > 1024u * 7u / 8u) atomicAdd(&ctr->over_small, 1u);   // (the host's choice of the next call's table)
@@ -1476,13 +1482,21 @@ __device__ __forceinline__ void walk_fast_tile(
     for (int s = 0; s < kSlabs; ++s) {
       sub[s] = c;
       c += S.ccnt[lane * kSlabs + s];
-      rsub[s] = rc;
-      rc += S.rcnt[lane * kSlabs + s];
+      rsub[s] = 0;
     }
-    const uint32_t rinc = wave_scan_incl(rc);
-    nruns = (uint32_t)__builtin_amdgcn_readlane((int)rinc, 63);
+    uint32_t rinc = 0;
+    nruns = 0;
+    if (any_cold) {   // (uniform)
 #pragma unroll
-    for (int s = 0; s < kSlabs; ++s) S.rcbase[lane * kSlabs + s] = (uint16_t)(rinc - rc + rsub[s]);
+      for (int s = 0; s < kSlabs; ++s) {
+        rsub[s] = rc;
+        rc += S.rcnt[lane * kSlabs + s];
+      }
+      rinc = wave_scan_incl(rc);
+      nruns = (uint32_t)__builtin_amdgcn_readlane((int)rinc, 63);
+#pragma unroll
+      for (int s = 0; s < kSlabs; ++s) S.rcbase[lane * kSlabs + s] = (uint16_t)(rinc - rc + rsub[s]);
+    }
     // (records and segments in one scan: a chunk holds at most 1024 entries of the tile)
     const uint32_t both = wave_scan_incl(c | (c ? 1u << 16 : 0u));
     const uint32_t inc = both & 0xFFFFu, sinc = both >> 16;
