@@ -1279,6 +1279,9 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     // (a power of two: the matrix is re-allocated when a stream's calls update twice the chunks, not a few more each time)
     size_t collect_row_chunks = 256;
     while (collect_row_chunks < 2 * (size_t)h->last_updated + 64) collect_row_chunks *= 2;
+    // (developer switch, tests: at most this many chunks' rows — calls that update more repeat their chain, the general one)
+    static const int max_row_chunks = plvs::env_int("PLVS_TSDF_COLLECT_MAX_ROWS", 0, 0, 1 << 20);
+    if (max_row_chunks > 0) collect_row_chunks = std::min<size_t>(collect_row_chunks, (size_t)max_row_chunks);
     const uint32_t collect_rows = (uint32_t)std::min<size_t>((size_t)max_chunks, collect_row_chunks) * kSlabs;
     const uint32_t collect_blocks = (uint32_t)ceil_div(seg_own, kSegSpan);
     // (the most runs its buffers hold: four times the call before scaled to this call's tiles — the stream's counts go 4.5 M,

@@ -14,8 +14,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(mode):
-    env = dict(os.environ, PLVS_TSDF_COLLECT=str(mode), PLVS_HIP_TSDF_TRACE="1")
+def _run(mode, **extra):
+    env = dict(os.environ, PLVS_TSDF_COLLECT=str(mode), PLVS_HIP_TSDF_TRACE="1", **extra)
     p = subprocess.run([sys.executable, "-m", "tests.collect_scenario"], cwd=ROOT, env=env, capture_output=True, text=True,
                        timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -37,3 +37,13 @@ def test_hip_collected_chain_leaves_the_map_of_the_sorted_chain():
     assert kinds.count("2") >= 3, forced_chains
     assert kinds.count("0") >= 1, forced_chains   # (a call with tiles left to walk_tiles: handed over)
     assert all(c[0] != "2" for c in plain_chains), plain_chains
+
+
+@pytest.mark.gpu
+def test_hip_collected_chain_repeats_as_the_general_one_when_its_matrix_is_too_small():
+    """Rows for eight chunks only (PLVS_TSDF_COLLECT_MAX_ROWS): every call that updates more sets `skip` on the device, its
+    fold leaves at once, and the host runs the general chain once the call's counters are read — the same maps."""
+    small, small_chains = _run(2, PLVS_TSDF_COLLECT_MAX_ROWS="8")
+    plain, _ = _run(0)
+    assert small == plain and len(small) == 9
+    assert any(len(c) > 1 and c[1] == "REPEATED" for c in small_chains), small_chains
