@@ -1260,7 +1260,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     if (h->w_rec.cap < rec_own + rec_spill) PLVS_HIP_TRY(h->w_rec.reserve(2 * rec_own + rec_spill));
     if (h->w_seg.cap < 2 * (seg_own + seg_spill)) PLVS_HIP_TRY(h->w_seg.reserve(2 * (2 * seg_own + seg_spill)));
     PLVS_HIP_TRY(h->w_sorted_seg.reserve(h->w_seg.cap));
-    // (a long call: its runs may be collected chunk by chunk — decided once the walk's counters are read, below)
+    // (a long call's runs may be collected chunk by chunk instead of sorted: collect_chain, below)
     static const int collect_mode = plvs::env_int("PLVS_TSDF_COLLECT", 1, 0, 2);   // (developer switch: 0 never, 2 every call — tests)
     // (the colour chain of this attempt — the reasons are where the chains are queued, below: `predicted` = on the sizes of
     // the call before, general chain; a long call over new ground: collected)
@@ -1273,7 +1273,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
                            (predict_long || ntiles <= kPredictTiles || (expect_runs <= kPredictRuns && collect_mode == 0));
     // (with the collected chain a long call is never `predicted`: that chain is queued without the call's counts just as
     // well, and the few runs of a saturated map's rim cost it seven short kernels instead of the sort's ten — steady state
-    // 0.631 -> 0.623 ms)
+    // 0.631 -> 0.618 ms)
     const bool collect_ready = collect_mode != 0 && (ntiles > kPredictTiles || collect_mode == 2) && !predicted;
     // (rows of the run matrix: twice the chunks the call before updated — more than that and the general chain takes over)
     // (a power of two: the matrix is re-allocated when a stream's calls update twice the chunks, not a few more each time)
