@@ -1885,6 +1885,9 @@ int plvs_hip_tsdf_chisel_create(const plvs_tsdf_chisel_params* p, plvs_tsdf_chis
     CREATE_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
     const bool prio = plvs::env_int("PLVS_TSDF_SIDE_PRIORITY", 1, 0, 1) != 0;
     CREATE_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio ? greatest : least));
+    // (developer switches: the apply stage's parts, as plvs_hip_tsdf_chisel_set_apply_parts sets them)
+    h->part_segs = (uint32_t)plvs::env_int("PLVS_APPLY_PART_SEGS", (int)kPartSegs, 1, 1 << 20);
+    h->part_min = (uint32_t)plvs::env_int("PLVS_APPLY_PART_MIN", (int)kPartMin, 1, 1 << 20);
   }
   CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   CREATE_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));

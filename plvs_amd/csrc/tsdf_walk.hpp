@@ -1641,7 +1641,7 @@ __global__ __launch_bounds__(kWalkRays, walk_fast_waves(E)) void walk_fast(
 // seg_scan scans (and lists the updated chunks, sums the per-tile visit counts), seg_pass<true> places.
 constexpr int kSegSpan = 1024;     // descriptor slots per workgroup (16 tiles)
 constexpr uint32_t kPartSegs = 256;   // segments of a busy chunk one work item of the apply stage takes (default)
-constexpr uint32_t kPartMin = 2048;   // a chunk with more segments than this is applied in parts (default)
+constexpr uint32_t kPartMin = 512;    // a chunk with more segments than this is applied in parts (default; round 6: 2048 -> 512, apply 0.18 -> 0.14 ms on the stream)
 constexpr int kSegTable = 512;
 template <bool kScatter, int kSpan = kSegSpan>
 __global__ __launch_bounds__(256) void seg_pass(const uint4* __restrict__ seg, uint32_t seg_cap, uint32_t ntiles,
