@@ -907,7 +907,7 @@ struct plvs_tsdf_chisel {
   // same row in the block's earlier tiles; runs per (row, block); chunk slot -> place among the updated; region, runs and
   // first part of every row; the parts' rows and histograms
   DevBuf<uint4> w_rseg, w_rpre;
-  DevBuf<uint32_t> w_run_matrix, w_active_idx, w_item_base, w_item_cnt, w_item_part0, w_part_item, w_phist, w_row_heads;
+  DevBuf<uint32_t> w_run_matrix, w_active_idx, w_item_base, w_item_cnt, w_item_part0, w_part_item, w_phist, w_row_heads, w_row_tot;
   hipEvent_t ev_seg = nullptr;   // the updated chunks are listed (seg_scan; caller's stream -> side stream)
   int last_chain = 0;            // (developer trace) the last call's colour chain: 0 on its own counts, 1 predicted, 2 collected
   bool last_chain_skipped = false;   //   ... and whether it had to be repeated
@@ -1299,6 +1299,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
       PLVS_HIP_TRY(h->w_item_cnt.reserve(collect_rows));
       PLVS_HIP_TRY(h->w_item_part0.reserve(collect_rows));
       PLVS_HIP_TRY(h->w_row_heads.reserve(collect_rows));
+      PLVS_HIP_TRY(h->w_row_tot.reserve((size_t)collect_rows * kSlabVox));
       const size_t parts_cap = (size_t)collect_bound / kCollectPart + collect_rows + 1;
       PLVS_HIP_TRY(h->dkey0.reserve(collect_bound));
       PLVS_HIP_TRY(h->dkey1.reserve(collect_bound));
@@ -1542,10 +1543,10 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
       hipLaunchKernelGGL(parts_count, dim3(part_grid), dim3(256), 0, q, h->w_part_item.p, h->w_item_part0.p, h->w_item_base.p,
                          h->w_item_cnt.p, h->w_runkey.p, h->d_wctr, h->w_val0.p, h->dkey0.p, h->w_phist.p);
       hipLaunchKernelGGL(rows_heads, dim3(std::min<uint32_t>(ceil_div(collect_rows, 4), 1024u)), dim3(256), 0, q, h->w_item_part0.p,
-                         h->w_item_cnt.p, h->w_phist.p, h->d_wctr, collect_rows, h->w_row_heads.p);
+                         h->w_item_cnt.p, h->w_phist.p, h->d_wctr, collect_rows, h->w_row_heads.p, h->w_row_tot.p);
       hipLaunchKernelGGL(parts_place, dim3(part_grid), dim3(512), 0, q, h->w_part_item.p, h->w_item_part0.p, h->w_item_base.p,
                          h->w_item_cnt.p, h->w_phist.p, h->d_wctr, h->dkey0.p, h->w_val0.p, h->dkey1.p, h->w_val1.p, h->heads.p,
-                         h->w_row_heads.p, collect_rows);
+                         h->w_row_heads.p, collect_rows, h->w_row_tot.p);
       return launch_fold(D, h->dkey1.p, h->w_val1.p, q, &h->d_wctr[1].skip);
     };
     // (predicted: a bound that does not hold costs the chain a second time — the fold of the first skips itself: compact_runs)
@@ -1945,7 +1946,7 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   if (h->ev_seg) (void)hipEventDestroy(h->ev_seg);
   h->w_rseg.release(); h->w_rpre.release(); h->w_run_matrix.release(); h->w_active_idx.release(); h->w_item_base.release();
   h->w_item_cnt.release(); h->w_item_part0.release(); h->w_part_item.release(); h->w_phist.release();
-  h->w_row_heads.release();
+  h->w_row_heads.release(); h->w_row_tot.release();
   if (h->side) (void)hipStreamDestroy(h->side);
   for (int i = 0; i <= kNumStages; ++i)
     if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);

@@ -2746,8 +2746,12 @@ __global__ __launch_bounds__(256) void parts_count(const uint32_t* __restrict__ 
 // (A kernel of its own: the last part of a row to finish could do it behind a device-scope fence — which on this device
 // writes the L2 back, 150 us for the six hundred workgroups of parts_count.)
 __global__ __launch_bounds__(256) void rows_heads(const uint32_t* __restrict__ item_part0, const uint32_t* __restrict__ item_cnt,
-                                                  const uint32_t* __restrict__ phist, const WalkCounters* __restrict__ ctr,
-                                                  uint32_t rows_cap, uint32_t* __restrict__ row_heads) {
+                                                  uint32_t* __restrict__ phist, const WalkCounters* __restrict__ ctr,
+                                                  uint32_t rows_cap, uint32_t* __restrict__ row_heads,
+                                                  uint32_t* __restrict__ row_tot) {
+  // (... and turns the histograms of a row's parts into their exclusive prefix along the parts, the row's totals beside them
+  // (row_tot): a part of parts_place then reads two rows of 512 counts, not one per part of its row — a voxel slab seen by a
+  // thousand key frames has hundreds of parts)
   if (ctr[1].skip != 0u) return;
   const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const uint32_t nrows = min(rows_cap, ctr->num_updated * (uint32_t)kSlabs);
@@ -2760,9 +2764,17 @@ __global__ __launch_bounds__(256) void rows_heads(const uint32_t* __restrict__ i
       for (int k = 0; k < kSlabVox / 64; ++k) h[k] = 0;
       for (uint32_t q = 0; q < P; ++q)
 #pragma unroll
-        for (int k = 0; k < kSlabVox / 64; ++k) h[k] += phist[(size_t)(p0 + q) * kSlabVox + (uint32_t)k * 64u + lane];
+        for (int k = 0; k < kSlabVox / 64; ++k) {
+          uint32_t* const cell = &phist[(size_t)(p0 + q) * kSlabVox + (uint32_t)k * 64u + lane];
+          const uint32_t c = *cell;
+          *cell = h[k];
+          h[k] += c;
+        }
 #pragma unroll
-      for (int k = 0; k < kSlabVox / 64; ++k) nz += (uint32_t)__popcll(__ballot(h[k] != 0u));
+      for (int k = 0; k < kSlabVox / 64; ++k) {
+        row_tot[(size_t)row * kSlabVox + (uint32_t)k * 64u + lane] = h[k];
+        nz += (uint32_t)__popcll(__ballot(h[k] != 0u));
+      }
     }
     if (lane == 0) row_heads[row] = nz;
   }
@@ -2774,7 +2786,7 @@ __global__ __launch_bounds__(512) void parts_place(const uint32_t* __restrict__ 
                                                    const uint32_t* __restrict__ tk, const uint32_t* __restrict__ tv,
                                                    uint32_t* __restrict__ ok, uint32_t* __restrict__ ov,
                                                    uint32_t* __restrict__ heads, const uint32_t* __restrict__ row_heads,
-                                                   uint32_t rows_cap) {
+                                                   uint32_t rows_cap, const uint32_t* __restrict__ row_tot) {
   constexpr int kWaves = 8, kBatches = kCollectPart / (64 * kWaves);   // a wave: 512 consecutive runs of the part
   __shared__ uint32_t hist[kWaves][kSlabVox];
   __shared__ uint32_t wtot[kWaves], wflag[kWaves], wsum[kWaves];
@@ -2786,7 +2798,6 @@ __global__ __launch_bounds__(512) void parts_place(const uint32_t* __restrict__ 
   for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
     const uint32_t row = part_item[p], p0 = item_part0[row], pi = p - p0, T = item_cnt[row];
     const uint32_t base = item_base[row], lo = pi * kCollectPart, hi = min(T, lo + kCollectPart);
-    const uint32_t P = (T + kCollectPart - 1u) / kCollectPart;
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) hist[w][tid] = 0u;
     __syncthreads();
@@ -2810,17 +2821,8 @@ __global__ __launch_bounds__(512) void parts_place(const uint32_t* __restrict__ 
         hist[w][tid] = tot;
         tot += c;
       }
-      uint32_t all = 0, before = 0;   // the voxel's runs in the whole row / in the row's parts before this one
-      for (uint32_t q0 = 0; q0 < P; q0 += 8) {   // (eight parts' rows in flight)
-        uint32_t c[8];
-#pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) c[u] = q0 + u < P ? phist[(size_t)(p0 + q0 + u) * kSlabVox + tid] : 0u;
-#pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) {
-          all += c[u];
-          before += q0 + u < pi ? c[u] : 0u;
-        }
-      }
+      // the voxel's runs in the whole row / in the row's parts before this one (rows_heads)
+      const uint32_t all = row_tot[(size_t)row * kSlabVox + tid], before = phist[(size_t)p * kSlabVox + tid];
       const uint32_t flag = (pi == 0u && all) ? 1u : 0u;
       const uint32_t inc = wave_scan_incl(all), finc = wave_scan_incl(flag);
       // (the row's place in the head list: the head counts of the rows before it — parts_count left them; the first part of
