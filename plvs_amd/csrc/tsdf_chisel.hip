@@ -918,6 +918,7 @@ struct plvs_tsdf_chisel {
   DevBuf<uint32_t> pa_last, pa_cnt, pa_done;
   uint32_t multi_cap = 0;
   uint32_t part_segs = kPartSegs, part_min = kPartMin;   // (plvs_hip_tsdf_chisel_set_apply_parts)
+  bool third_pass = false;                                // a 4096-entry pass behind the 1024- and the 2048-entry one (the call before needed it)
   bool walk_small = false, walk_small_used = false;      // first-pass table of the order-free walk: 1024 entries instead of 2048
   DevBuf<uint32_t> w_runkey, w_run_cnt, w_run_off, w_val0, w_val1;   // runs: per-tile regions of 2^run_r1_log2 slots
   int32_t* h_offsets = nullptr;      // pinned copy of the call's cloud offsets
@@ -1333,7 +1334,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     uint32_t* const list_c = h->w_deferred.p + 2 * (size_t)ntiles;
     const uint32_t* last_list = list_a;
     const uint32_t* last_count = &h->d_wctr->ndeferred;
-    bool second_small = false;
+    bool second_small = false, third_pass = false;
 #define PLVS_LAUNCH_WALK_FAST(E, GRID, TILES, LIST, NLIST, DEFERRED, NDEFERRED)                                              \
   hipLaunchKernelGGL((walk_fast<E, GRID>), dim3(TILES), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,          \
                      h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,                     \
@@ -1364,19 +1365,21 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
       if (h->walk_small) {
         PLVS_WALK_FAST(kFastEntries, std::min<unsigned>(ntiles, 2 * kListGrid), list_a, &h->d_wctr->ndeferred, list_b,
                        &h->d_wctr->ndeferred2);
-        // ... and what overflows that one too (a tile or two of a call, a wall 5 m away seen at a slant) to the 4096-entry
-        // kernel rather than to walk_tiles: a launch that finds an empty list nearly always — and a call none of whose tiles
-        // reaches walk_tiles can have its runs collected chunk by chunk (below) instead of sorted
-        PLVS_WALK_FAST(kFastEntriesBig, std::min<unsigned>(ntiles, kListGrid), list_b, &h->d_wctr->ndeferred2, list_c,
-                       &h->d_wctr->ndeferred3);
+        // ... and what overflows that one too (a wall 5 m away seen at a slant) to the 4096-entry kernel rather than to
+        // walk_tiles — a call none of whose tiles reaches walk_tiles can have its runs collected chunk by chunk (below) instead
+        // of sorted — when the call before had such tiles: a launch that finds an empty list costs the stream 8 us
+        third_pass = h->third_pass;
+        if (third_pass)
+          PLVS_WALK_FAST(kFastEntriesBig, std::min<unsigned>(ntiles, kListGrid), list_b, &h->d_wctr->ndeferred2, list_c,
+                         &h->d_wctr->ndeferred3);
       } else
         PLVS_WALK_FAST(kFastEntriesBig, std::min<unsigned>(ntiles, kListGrid), list_a, &h->d_wctr->ndeferred, list_b,
                        &h->d_wctr->ndeferred2);
-      second_small = false;   // (the last lean pass had 4096 entries either way)
+      second_small = h->walk_small && !third_pass;   // (the last lean pass had 2048 entries)
 #undef PLVS_WALK_FAST
 #undef PLVS_LAUNCH_WALK_FAST
-      last_list = h->walk_small ? list_c : list_b;
-      last_count = h->walk_small ? &h->d_wctr->ndeferred3 : &h->d_wctr->ndeferred2;
+      last_list = third_pass ? list_c : list_b;
+      last_count = third_pass ? &h->d_wctr->ndeferred3 : &h->d_wctr->ndeferred2;
     }
     hipLaunchKernelGGL((walk_tiles<true, true>), dim3(kDeferGrid), dim3(kWalkRays), 0, s, h->P, h->scale_u, h->scale_w, d_xyz, n,
                        h->offsets.p, nclouds, h->poses.p, h->dir, &h->d_ctr->num_chunks, h->d_wctr, h->rgbw,
@@ -1682,6 +1685,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     // still costs less than a 2048-entry first pass for all of them: 0.51 + 0.1 against 0.8 ms on the office stream, where
     // the 6 % / 2 % thresholds of round 4 had every other step fall back to the large table)
     if (h->walk_small_used) {
+      h->third_pass = c.ndeferred2 != 0u;   // (tiles overflowed the 2048-entry table too: the next call has a 4096-entry pass)
       if ((size_t)c.ndeferred * 4 > ntiles) h->walk_small = false;    // more than a quarter of the tiles overflowed the small table
     } else if ((size_t)c.over_small * 6 <= ntiles) {
       h->walk_small = true;                                             // at most a sixth would
