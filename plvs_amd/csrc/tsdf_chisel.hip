@@ -908,6 +908,7 @@ struct plvs_tsdf_chisel {
   // first part of every row; the parts' rows and histograms
   DevBuf<uint4> w_rseg, w_rpre;
   DevBuf<uint32_t> w_run_matrix, w_active_idx, w_item_base, w_item_cnt, w_item_part0, w_part_item, w_phist, w_row_heads, w_row_tot;
+  hipEvent_t ev_zero = nullptr;  // the run matrix is zero (side stream -> caller's stream)
   hipEvent_t ev_seg = nullptr;   // the updated chunks are listed (seg_scan; caller's stream -> side stream)
   int last_chain = 0;            // (developer trace) the last call's colour chain: 0 on its own counts, 1 predicted, 2 collected
   bool last_chain_skipped = false;   //   ... and whether it had to be repeated
@@ -1311,6 +1312,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
       PLVS_HIP_TRY(h->w_phist.reserve(parts_cap * kSlabVox));
       // (zero while the walk runs: runs_count writes the cells that hold runs)
       PLVS_HIP_TRY(hipMemsetAsync(h->w_run_matrix.p, 0, (size_t)collect_rows * collect_blocks * sizeof(uint32_t), h->side));
+      PLVS_HIP_TRY(hipEventRecord(h->ev_zero, h->side));   // (runs_count, on the caller's stream, waits for it: long over by then)
     }
     if (h->w_runkey.cap < ((size_t)ntiles << h->run_r1_log2)) {
       PLVS_HIP_TRY(h->w_runkey.reserve((size_t)2 * ntiles << h->run_r1_log2));
@@ -1432,6 +1434,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     if (collect_ready) {
       // the colour side's counting stages here, in front of the segment sort: short kernels that would otherwise start
       // beside the apply stage's first thousand workgroups and wait for their slots (40 us each, measured)
+      PLVS_HIP_TRY(hipStreamWaitEvent(q_apply, h->ev_zero, 0));
       hipLaunchKernelGGL(runs_count, dim3(collect_blocks), dim3(kSegSpan), 0, q_apply, h->w_seg.p, h->w_rseg.p, ntiles, h->w_seg_cnt.p,
                          h->w_active_idx.p, collect_rows, collect_blocks, h->w_run_matrix.p, h->w_rpre.p, h->d_wctr, last_count);
       hipLaunchKernelGGL(runs_rowscan, dim3(std::min<uint32_t>(ceil_div(collect_rows, 4), 1024u)), dim3(256), 0, q_apply,
@@ -1897,6 +1900,7 @@ int plvs_hip_tsdf_chisel_create(const plvs_tsdf_chisel_params* p, plvs_tsdf_chis
   CREATE_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   CREATE_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   CREATE_TRY(hipEventCreateWithFlags(&h->ev_seg, hipEventDisableTiming));
+  CREATE_TRY(hipEventCreateWithFlags(&h->ev_zero, hipEventDisableTiming));
 #undef CREATE_TRY
   *out = h;
   int rc = plvs_hip_tsdf_chisel_clear(h);
@@ -1948,6 +1952,7 @@ int plvs_hip_tsdf_chisel_destroy(plvs_tsdf_chisel* h) {
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->ev_seg) (void)hipEventDestroy(h->ev_seg);
+  if (h->ev_zero) (void)hipEventDestroy(h->ev_zero);
   h->w_rseg.release(); h->w_rpre.release(); h->w_run_matrix.release(); h->w_active_idx.release(); h->w_item_base.release();
   h->w_item_cnt.release(); h->w_item_part0.release(); h->w_part_item.release(); h->w_phist.release();
   h->w_row_heads.release(); h->w_row_tot.release();
