@@ -1451,7 +1451,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
     // the kernel waits for is their atomics on the counters of a hundred-odd chunks)
     static const bool wide_span = plvs::env_int("PLVS_SEG_SPAN_WIDE", 1, 0, 1) != 0;   // (developer switch)
     if (wide_span && ntiles > kPredictTiles)
-      hipLaunchKernelGGL((seg_pass<true, 4096>), dim3(ceil_div(seg_own + seg_spill, 4096)), dim3(256), 0, q_apply, h->w_seg.p,
+      hipLaunchKernelGGL((seg_pass<true, kSegSpanLong>), dim3(ceil_div(seg_own + seg_spill, kSegSpanLong)), dim3(256), 0, q_apply, h->w_seg.p,
                          out.seg_cap, ntiles, h->w_seg_cnt.p, h->w_chunk_nseg.p, h->w_chunk_off.p, h->w_chunk_fill.p,
                          h->w_sorted_seg.p, h->d_wctr);
     else

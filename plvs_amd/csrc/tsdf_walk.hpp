@@ -1640,6 +1640,7 @@ __global__ __launch_bounds__(kWalkRays, walk_fast_waves(E)) void walk_fast(
 // goes to the global per-chunk counters once per (workgroup, chunk): seg_pass<false> counts,
 // seg_scan scans (and lists the updated chunks, sums the per-tile visit counts), seg_pass<true> places.
 constexpr int kSegSpan = 1024;     // descriptor slots per workgroup (16 tiles)
+constexpr int kSegSpanLong = 4096; // ... of seg_pass<true> in a long call (64 tiles: a quarter of the atomics on the chunks' counters)
 constexpr uint32_t kPartSegs = 256;   // segments of a busy chunk one work item of the apply stage takes (default)
 constexpr uint32_t kPartMin = 512;    // a chunk with more segments than this is applied in parts (default; round 6: 2048 -> 512, apply 0.18 -> 0.14 ms on the stream)
 constexpr int kSegTable = 512;
