@@ -1062,6 +1062,21 @@ static inline void cpu_relax() {
 // so a SLAM thread next to it loses a core for a few hundred microseconds per call at worst, not for the length of the call.
 // kind: 0 the end of a call, 1 the read in front of its colour chain; size_class: calls of a few key frames, of tens, of a hundred
 // (their waits differ by an order of magnitude, and a SLAM system alternates them)
+// Time between two stage events of a call the host has read the counters of.  The read polls a word the call's last kernel
+// stores to pinned memory (wait_published) and can be ahead of the runtime's own book-keeping of the events recorded in
+// front of that kernel: hipEventElapsedTime then says "not ready" (once in two thousand calls, measured) — the events are
+// waited for and asked again.
+static hipError_t stage_elapsed(float* ms, hipEvent_t a, hipEvent_t b) {
+  hipError_t e = hipEventElapsedTime(ms, a, b);
+  if (e == hipErrorNotReady) {
+    (void)hipGetLastError();
+    e = hipEventSynchronize(a);
+    if (e == hipSuccess) e = hipEventSynchronize(b);
+    if (e == hipSuccess) e = hipEventElapsedTime(ms, a, b);
+  }
+  return e;
+}
+
 static int wait_published(plvs_tsdf_chisel* h, uint32_t seq, hipStream_t q, int kind = 0, int size_class = 0) {
   double& ema = h->wait_ema_us[kind][size_class];
   static const int spin_us = plvs::env_int("PLVS_TSDF_SPIN_US", 400, 0, 10000000);
@@ -1725,7 +1740,7 @@ static int integrate_walk_acc(plvs_tsdf_chisel* h, const float* d_xyz, const uin
   }
   float ms[4] = {0.f, 0.f, 0.f, 0.f};   // the last one: what the colour fold adds behind the apply stage
   if (h->profiling)
-    for (int i = 0; i < 4; ++i) PLVS_HIP_TRY(hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+    for (int i = 0; i < 4; ++i) PLVS_HIP_TRY(stage_elapsed(&ms[i], h->ev[i], h->ev[i + 1]));
 #undef STAGE_MARK
   if (h->profiling) {
     for (int i = 0; i < 4; ++i) h->stage_ms[i] += ms[i];
@@ -2120,8 +2135,8 @@ static int integrate_batch_core(plvs_tsdf_chisel* h, const float* d_xyz, const u
   PLVS_HIP_TRY(h->block_first.reserve(ceil_div(V, kGatherSpan)));
   float ms_a[2] = {0.f, 0.f};
   if (h->profiling) {  // stages 0,1 are complete (the counter read synchronised)
-    PLVS_HIP_TRY(hipEventElapsedTime(&ms_a[0], h->ev[0], h->ev[1]));
-    PLVS_HIP_TRY(hipEventElapsedTime(&ms_a[1], h->ev[1], h->ev[2]));
+    PLVS_HIP_TRY(stage_elapsed(&ms_a[0], h->ev[0], h->ev[1]));
+    PLVS_HIP_TRY(stage_elapsed(&ms_a[1], h->ev[1], h->ev[2]));
   }
   STAGE_MARK(2);
   PLVS_HIP_TRY(hipMemsetAsync(h->tile_state.p, 0, ((size_t)ntiles + 1) * sizeof(unsigned long long), s));
@@ -2150,7 +2165,7 @@ static int integrate_batch_core(plvs_tsdf_chisel* h, const float* d_xyz, const u
   }
   const uint32_t D = h->h_ctr->num_desc;
   float ms_b = 0.f;
-  if (h->profiling) PLVS_HIP_TRY(hipEventElapsedTime(&ms_b, h->ev[2], h->ev[3]));
+  if (h->profiling) PLVS_HIP_TRY(stage_elapsed(&ms_b, h->ev[2], h->ev[3]));
   PLVS_HIP_TRY(h->dkey1.reserve(D));
   PLVS_HIP_TRY(h->scratch.reserve(radix_scratch_words(D)));
   int key_bits = 12;
@@ -2207,7 +2222,7 @@ static int integrate_batch_core(plvs_tsdf_chisel* h, const float* d_xyz, const u
     h->stage_ms[2] += ms_b;
     for (int i = 3; i < kNumStages; ++i) {
       float ms = 0.f;
-      PLVS_HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+      PLVS_HIP_TRY(stage_elapsed(&ms, h->ev[i], h->ev[i + 1]));
       h->stage_ms[i] += ms;
     }
     h->prof_calls++;
@@ -3441,7 +3456,7 @@ int plvs_hip_tsdf_chisel_shard_apply(plvs_tsdf_chisel* h, const void* d_seg_src,
   if (h->profiling) {
     for (int i = 0; i < 4; ++i) {
       float ms = 0.f;
-      PLVS_HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+      PLVS_HIP_TRY(stage_elapsed(&ms, h->ev[i], h->ev[i + 1]));
       h->stage_ms[i] += ms;
     }
     h->prof_calls++;
